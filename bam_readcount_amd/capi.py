@@ -1,0 +1,305 @@
+"""ctypes binding of the C-ABI declared in include/brc.h.
+
+Plumbing only: the product is the shared library `bam_readcount_amd/csrc/libbrc_hip.so` (hand-written HIP
+for gfx950 behind the C-ABI).  The same binding class can be pointed at any library exporting the ABI;
+tests/ use that to drive the CPU oracle (oracle/libbrc_oracle.so) through identical calls.  This module
+never falls back to another implementation: if the product library is missing, `load_product()` raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PRODUCT_LIB = os.path.join(HERE, "csrc", "libbrc_hip.so")
+
+NBUCKET, NI, NF, NWARN, NKERNEL = 6, 9, 4, 4, 8
+I_NAMES = ["n", "smq", "sse", "plus", "minus", "nq2", "smmq", "sclip", "sbq"]
+F_NAMES = ["sev", "sq2", "snm", "s3p"]
+
+EXPORTS = [
+    "brc_strerror", "brc_last_error", "brc_kernel_name", "brc_engine_kind", "brc_create", "brc_destroy",
+    "brc_begin_region", "brc_push_reads", "brc_upload", "brc_compute", "brc_fetch_result", "brc_end_region",
+    "brc_clear_indel_queue", "brc_region_counts", "brc_format_region",
+]
+
+
+class Stat(C.Structure):
+    _fields_ = [("i", C.c_uint32 * NI), ("f", C.c_float * NF)]
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("min_mapq", C.c_int32), ("min_bq", C.c_int32), ("max_cnt", C.c_int32),
+                ("per_lib", C.c_int32), ("insertion_centric", C.c_int32), ("n_libs", C.c_int32),
+                ("lib_names", C.POINTER(C.c_char_p)), ("device", C.c_int32), ("ref_len_check", C.c_int32)]
+
+
+class ReadBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("pos", C.c_void_p), ("flag", C.c_void_p), ("mapq", C.c_void_p), ("lib", C.c_void_p),
+                ("l_qseq", C.c_void_p), ("n_cigar", C.c_void_p), ("cigar_off", C.c_void_p), ("seq_off", C.c_void_p),
+                ("qual_off", C.c_void_p), ("nm", C.c_void_p), ("sm", C.c_void_p), ("tags", C.c_void_p), ("cigar", C.c_void_p),
+                ("seq4", C.c_void_p), ("qual", C.c_void_p), ("n_cigar_total", C.c_uint64), ("seq_bytes", C.c_uint64),
+                ("qual_bytes", C.c_uint64), ("qname", C.c_void_p)]
+
+
+class Indel(C.Structure):
+    _fields_ = [("pos", C.c_int32), ("lib", C.c_int32), ("len", C.c_int32), ("rep_read", C.c_uint32), ("rep_qpos", C.c_int32),
+                ("allele_off", C.c_uint32), ("allele_len", C.c_uint32), ("stat", Stat)]
+
+
+class Result(C.Structure):
+    _fields_ = [("tid", C.c_int32), ("beg0", C.c_int32), ("end", C.c_int32), ("pos0", C.c_int32), ("n_pos", C.c_int64),
+                ("n_lib", C.c_int32), ("ncol", C.POINTER(C.c_uint32)), ("depth", C.POINTER(C.c_uint32)),
+                ("istat", C.POINTER(C.c_uint32)), ("fstat", C.POINTER(C.c_float)), ("unavail", C.POINTER(C.c_uint32)),
+                ("refbase", C.POINTER(C.c_char)), ("n_indel", C.c_int64), ("indel", C.POINTER(Indel)),
+                ("alleles", C.POINTER(C.c_char)), ("alleles_len", C.c_uint64), ("n_events", C.c_uint64),
+                ("warn", C.c_uint64 * NWARN)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("ms", C.c_float * NKERNEL), ("total_ms", C.c_float)]
+
+
+BATCH_DTYPES = dict(pos=np.int32, flag=np.uint16, mapq=np.uint8, lib=np.int16, l_qseq=np.int32, n_cigar=np.uint32,
+                    cigar_off=np.uint64, seq_off=np.uint64, qual_off=np.uint64, nm=np.int32, sm=np.int32, tags=np.uint8,
+                    cigar=np.uint32, seq4=np.uint8, qual=np.uint8)
+
+
+class BrcError(RuntimeError):
+    pass
+
+
+class Library:
+    """One loaded shared library exporting the brc C-ABI."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise BrcError("brc library not found: %s (run `python __graft_entry__.py` / build() first)" % path)
+        self.path = path
+        self.lib = L = C.CDLL(path)
+        L.brc_strerror.restype = C.c_char_p; L.brc_strerror.argtypes = [C.c_int]
+        L.brc_last_error.restype = C.c_char_p; L.brc_last_error.argtypes = [C.c_void_p]
+        L.brc_kernel_name.restype = C.c_char_p; L.brc_kernel_name.argtypes = [C.c_int]
+        L.brc_engine_kind.restype = C.c_char_p
+        L.brc_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+        L.brc_destroy.argtypes = [C.c_void_p]; L.brc_destroy.restype = None
+        L.brc_begin_region.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]
+        L.brc_push_reads.argtypes = [C.c_void_p, C.POINTER(ReadBatch)]
+        L.brc_upload.argtypes = [C.c_void_p]
+        L.brc_compute.argtypes = [C.c_void_p, C.POINTER(Timing)]
+        L.brc_fetch_result.argtypes = [C.c_void_p, C.POINTER(Result)]
+        L.brc_end_region.argtypes = [C.c_void_p, C.POINTER(Result)]
+        L.brc_clear_indel_queue.argtypes = [C.c_void_p]
+        L.brc_region_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.brc_format_region.argtypes = [C.c_void_p, C.POINTER(Result), C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
+
+    def kind(self):
+        return self.lib.brc_engine_kind().decode()
+
+    def kernel_names(self):
+        out = []
+        for k in range(NKERNEL):
+            s = self.lib.brc_kernel_name(k)
+            out.append(s.decode() if s else None)
+        return out
+
+
+def load_product():
+    """The HIP engine.  Raises (never substitutes) when the library has not been built."""
+    return Library(PRODUCT_LIB)
+
+
+def make_batch(arrs):
+    """numpy arrays (names of brc_read_batch) -> (ReadBatch, keepalive list)."""
+    keep = {}
+    b = ReadBatch()
+    n = len(arrs["pos"])
+    b.n_reads = n
+    for k, dt in BATCH_DTYPES.items():
+        if k == "lib" and arrs.get("lib") is None:
+            setattr(b, k, None)
+            continue
+        a = np.ascontiguousarray(arrs[k], dtype=dt)
+        if a.size == 0:
+            a = np.zeros(1, dt)
+        keep[k] = a
+        setattr(b, k, a.ctypes.data)
+    b.n_cigar_total = int(np.asarray(arrs["cigar"]).size)
+    b.seq_bytes = int(np.asarray(arrs["seq4"]).size)
+    b.qual_bytes = int(np.asarray(arrs["qual"]).size)
+    b.qname = None
+    return b, keep
+
+
+def select_reads(arrs, idx):
+    """Sub-batch with the reads `idx` (ascending), arenas compacted."""
+    idx = np.asarray(idx, np.int64)
+    out = {}
+    for k in ("pos", "flag", "mapq", "lib", "l_qseq", "n_cigar", "nm", "sm", "tags"):
+        if arrs.get(k) is not None:
+            out[k] = np.asarray(arrs[k])[idx]
+        else:
+            out[k] = None
+    ncig = np.asarray(arrs["n_cigar"])[idx].astype(np.int64)
+    lq = np.asarray(arrs["l_qseq"])[idx].astype(np.int64)
+    sb = (lq + 1) // 2
+
+    def gather(src, offs, lens):
+        tot = int(lens.sum())
+        if tot == 0:
+            return np.zeros(0, src.dtype), np.zeros(len(lens), np.uint64)
+        starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+        ii = np.repeat(offs.astype(np.int64) - starts, lens) + np.arange(tot)
+        return src[ii], starts.astype(np.uint64)
+
+    out["cigar"], out["cigar_off"] = gather(np.asarray(arrs["cigar"]), np.asarray(arrs["cigar_off"])[idx], ncig)
+    out["seq4"], out["seq_off"] = gather(np.asarray(arrs["seq4"]), np.asarray(arrs["seq_off"])[idx], sb)
+    out["qual"], out["qual_off"] = gather(np.asarray(arrs["qual"]), np.asarray(arrs["qual_off"])[idx], lq)
+    return out
+
+
+class RegionResult:
+    """Host copy of a brc_result as numpy arrays."""
+
+    def __init__(self, r):
+        P, L = int(r.n_pos), int(r.n_lib)
+        self.tid, self.beg0, self.end, self.pos0, self.n_pos, self.n_lib = r.tid, r.beg0, r.end, r.pos0, P, L
+
+        def arr(ptr, shape, dt):
+            n = int(np.prod(shape))
+            if n == 0 or not ptr:
+                return np.zeros(shape, dt)
+            return np.ctypeslib.as_array(ptr, shape=(n,)).view(dt).reshape(shape).copy()
+
+        self.ncol = arr(r.ncol, (L, P), np.uint32)
+        self.depth = arr(r.depth, (L, P), np.uint32)
+        self.istat = arr(r.istat, (L, NBUCKET, NI, P), np.uint32)
+        self.fstat = arr(r.fstat, (L, NBUCKET, NF, P), np.float32)
+        self.unavail = arr(r.unavail, (P,), np.uint32) if r.unavail else None
+        self.refbase = C.string_at(r.refbase, P) if P and r.refbase else b""
+        alle = C.string_at(r.alleles, r.alleles_len) if r.alleles_len else b""
+        self.indels = []
+        for k in range(int(r.n_indel)):
+            d = r.indel[k]
+            self.indels.append(dict(pos=d.pos, lib=d.lib, len=d.len, rep_read=d.rep_read, rep_qpos=d.rep_qpos,
+                                    allele=alle[d.allele_off:d.allele_off + d.allele_len].decode("latin1"),
+                                    i=np.array(d.stat.i[:], np.uint32), f=np.array(d.stat.f[:], np.float32)))
+        self.n_events = int(r.n_events)
+        self.warn = [int(x) for x in r.warn]
+
+
+class Engine:
+    """Mirror of the reference's per-region pileup lifecycle (bam_plbuf_init .. destroy, bamreadcount.cpp:591-605)."""
+
+    def __init__(self, lib, min_mapq=0, min_bq=0, max_cnt=0, per_lib=False, insertion_centric=False, lib_names=(),
+                 device=0, ref_len_check=False):
+        self.L = lib
+        self._names = [s.encode() if isinstance(s, str) else bytes(s) for s in lib_names]
+        self._name_arr = (C.c_char_p * max(1, len(self._names)))(*self._names) if self._names else None
+        cfg = Config(1, min_mapq, min_bq, max_cnt, int(per_lib), int(insertion_centric), len(self._names),
+                     self._name_arr if self._names else None, device, int(ref_len_check))
+        self.h = C.c_void_p()
+        self._check(lib.lib.brc_create(C.byref(cfg), C.byref(self.h)), create=True)
+        self._ref = None
+        self._res = Result()
+
+    def _check(self, rc, create=False):
+        if rc != 0:
+            msg = self.L.lib.brc_strerror(rc).decode()
+            if not create and self.h:
+                msg += ": " + self.L.lib.brc_last_error(self.h).decode()
+            raise BrcError("brc error %d (%s)" % (rc, msg))
+
+    def close(self):
+        if self.h:
+            self.L.lib.brc_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def begin_region(self, tid, beg0, end, ref):
+        """ref: None or contiguous uint8 numpy array / bytes holding the whole contig."""
+        if ref is None:
+            self._ref = None
+            self._check(self.L.lib.brc_begin_region(self.h, tid, beg0, end, None, 0))
+        else:
+            self._ref = np.ascontiguousarray(np.frombuffer(ref, np.uint8) if isinstance(ref, (bytes, bytearray)) else ref, np.uint8)
+            self._check(self.L.lib.brc_begin_region(self.h, tid, beg0, end, self._ref.ctypes.data, self._ref.size))
+
+    def push_reads(self, arrs):
+        b, keep = make_batch(arrs)
+        self._check(self.L.lib.brc_push_reads(self.h, C.byref(b)))
+        del keep
+
+    def upload(self):
+        self._check(self.L.lib.brc_upload(self.h))
+
+    def compute(self):
+        t = Timing()
+        self._check(self.L.lib.brc_compute(self.h, C.byref(t)))
+        return [float(x) for x in t.ms], float(t.total_ms)
+
+    def fetch_result(self):
+        self._check(self.L.lib.brc_fetch_result(self.h, C.byref(self._res)))
+        return RegionResult(self._res)
+
+    def end_region(self):
+        self._check(self.L.lib.brc_end_region(self.h, C.byref(self._res)))
+        return RegionResult(self._res)
+
+    def counts(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self.L.lib.brc_region_counts(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def clear_indel_queue(self):
+        self._check(self.L.lib.brc_clear_indel_queue(self.h))
+
+    def format_region(self, chrom):
+        """Text of the last fetched region (bytes), exactly as the reference prints it."""
+        p = C.c_char_p(); n = C.c_size_t()
+        self._check(self.L.lib.brc_format_region(self.h, C.byref(self._res), chrom.encode(), C.byref(p), C.byref(n)))
+        return C.string_at(p, n.value)
+
+
+def fetch_overlapping(arrs, ends, lo, hi):
+    """Indices of reads overlapping [lo,hi) — what samfetch(in, idx, tid, lo, hi, ..) hands to fetch_func
+    (bamreadcount.cpp:602; hts iterator: beg clamped at 0, overlap = pos < hi && end > lo)."""
+    lo = max(lo, 0)
+    pos = np.asarray(arrs["pos"]).astype(np.int64)
+    return np.nonzero((pos < hi) & (np.asarray(ends) > lo))[0]
+
+
+def read_ends(arrs):
+    """bam_endpos per read: pos + reference length of the CIGAR (M,D,N,=,X); pos+1 for unmapped / no CIGAR."""
+    cig = np.asarray(arrs["cigar"]).astype(np.int64)
+    ncig = np.asarray(arrs["n_cigar"]).astype(np.int64)
+    off = np.asarray(arrs["cigar_off"]).astype(np.int64)
+    op = cig & 15
+    ln = np.where((op == 0) | (op == 2) | (op == 3) | (op == 7) | (op == 8), cig >> 4, 0)
+    cs = np.concatenate([[0], np.cumsum(ln)])
+    rlen = cs[off + ncig] - cs[off]
+    flag = np.asarray(arrs["flag"]).astype(np.int64)
+    rlen = np.where(((flag & 4) != 0) | (ncig == 0), 1, rlen)
+    return np.asarray(arrs["pos"]).astype(np.int64) + rlen
+
+
+def run_regions(engine, arrs, regions, tid, chrom, ref, clear_queue=True):
+    """Drive the engine the way the reference's site-list loop does (bamreadcount.cpp:574-607):
+    per region fetch [beg0-1, end), begin/push/end, format; returns (text, [RegionResult])."""
+    ends = read_ends(arrs)
+    text = b""
+    results = []
+    for (beg0, end) in regions:
+        idx = fetch_overlapping(arrs, ends, beg0 - 1, end)
+        engine.begin_region(tid, beg0, end, ref)
+        engine.push_reads(select_reads(arrs, idx))
+        results.append(engine.end_region())
+        text += engine.format_region(chrom)
+        if clear_queue:
+            engine.clear_indel_queue()
+    return text, results

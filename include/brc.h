@@ -1,0 +1,212 @@
+/*
+ * brc.h — C-ABI drop-in boundary of the MI355X pileup/readcount engine.
+ *
+ * The reference (genome/bam-readcount) has no plugin API: its per-position accumulation sits behind two
+ * htslib callbacks and one C++ method.  Each entry point below names the reference seam it replaces
+ * (paths relative to the reference tree):
+ *
+ *   brc_create / brc_destroy   <- pileup_data_t setup + WARN.reset      src/exe/bam-readcount/bamreadcount.cpp:430-432,499,508-511
+ *   brc_begin_region           <- d.beg/d.end + load_reference + bam_plbuf_init + bam_plp_set_maxcnt   bamreadcount.cpp:588-592, 644-651
+ *   brc_push_reads             <- fetch_func (per-read "Zm" annotation) + bam_plbuf_push               bamreadcount.cpp:114-261
+ *   brc_end_region             <- bam_plbuf_push(0,buf) flush + every pileup_func callback             bamreadcount.cpp:265-419, 603-605, 655-656
+ *                                 (BasicStat::process_read, src/lib/bamrc/BasicStat.cpp:28-107)
+ *   brc_format_region          <- record assembly, IndelQueue::process, operator<<(BasicStat)          bamreadcount.cpp:351-416,
+ *                                 src/lib/bamrc/IndelQueue.cpp:3-15, BasicStat.cpp:110-159
+ *
+ * Conventions: extern "C", opaque handle, plain pointers + sizes, 0 = ok / negative = error
+ * (brc_strerror).  No exceptions cross the boundary.  One engine per GPU / rank; one producer thread
+ * per engine.  All caller arrays are borrowed only for the duration of the call unless stated.
+ */
+#ifndef BRC_H
+#define BRC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BRC_ABI_VERSION 1
+
+/* error codes */
+#define BRC_OK            0
+#define BRC_E_ARG        -1   /* bad argument / call order */
+#define BRC_E_NODEVICE   -2   /* no HIP device / kernels unavailable: the engine never falls back to CPU */
+#define BRC_E_HIP        -3   /* HIP runtime error (see brc_last_error) */
+#define BRC_E_NOMEM      -4
+#define BRC_E_LIMIT      -5   /* region / batch exceeds an engine limit (see brc_limits) */
+
+/* number of base buckets per (position, library): "=ACGTN"  (bamreadcount.cpp:34-39) */
+#define BRC_NBUCKET 6
+/* integer and float accumulator planes per bucket (BasicStat.hpp:12-24) */
+#define BRC_NI 9
+#define BRC_NF 4
+
+/* integer plane order */
+enum {
+    BRC_I_N = 0,      /* read_count */
+    BRC_I_SMQ,        /* sum_map_qualities */
+    BRC_I_SSE,        /* sum_single_ended_map_qualities */
+    BRC_I_PLUS,       /* num_plus_strand */
+    BRC_I_MINUS,      /* num_minus_strand */
+    BRC_I_NQ2,        /* num_q2_reads */
+    BRC_I_SMMQ,       /* sum_of_mismatch_qualities */
+    BRC_I_SCLIP,      /* sum_of_clipped_lengths */
+    BRC_I_SBQ         /* sum_base_qualities */
+};
+/* float plane order (fp32 running sums in pileup-column order) */
+enum {
+    BRC_F_SEV = 0,    /* sum_event_location */
+    BRC_F_SQ2,        /* sum_q2_distance */
+    BRC_F_SNM,        /* sum_number_of_mismatches */
+    BRC_F_S3P         /* sum_3p_distance */
+};
+
+/* One accumulated bucket, 52 bytes: the 13 BasicStat accumulators (BasicStat.hpp:12-24). */
+typedef struct brc_stat {
+    uint32_t i[BRC_NI];
+    float    f[BRC_NF];
+} brc_stat;
+
+/* tag presence bits in brc_read_batch.tags */
+#define BRC_TAG_NM 1u
+#define BRC_TAG_SM 2u
+
+typedef struct brc_config {
+    int32_t abi_version;        /* BRC_ABI_VERSION */
+    int32_t min_mapq;           /* -q  (bamreadcount.cpp:438) */
+    int32_t min_bq;             /* -b  (:439) */
+    int32_t max_cnt;            /* -d  (:440); 0 => default 10000000 */
+    int32_t per_lib;            /* -p  (:444) */
+    int32_t insertion_centric;  /* -i  (:446) */
+    int32_t n_libs;             /* number of library names (per_lib only) */
+    const char* const* lib_names; /* bytewise-sorted library names (std::map order, :273,360); copied */
+    int32_t device;             /* HIP device ordinal */
+    int32_t ref_len_check;      /* 1 in site-list mode: fetch_data_t.ref_len != 0 (:594-600,144-148) */
+} brc_config;
+
+/*
+ * A batch of decoded alignment records, structure-of-arrays, coordinate-sorted (file order).
+ * Field meanings are BAM's (SAMv1 4.2): pos 0-based leftmost; cigar = len<<4|op; seq4 = two bases
+ * per byte, high nibble first, each read starting on a byte boundary; qual = phred bytes.
+ * Reads with flag UNMAP/SECONDARY/QCFAIL/DUP may be present; the engine drops them exactly where
+ * bam_plp_push would (after annotation).
+ */
+typedef struct brc_read_batch {
+    int64_t n_reads;
+    const int32_t*  pos;        /* [n] */
+    const uint16_t* flag;       /* [n] */
+    const uint8_t*  mapq;       /* [n] */
+    const int16_t*  lib;        /* [n] index into brc_config.lib_names, -1 = library unavailable; may be NULL when !per_lib */
+    const int32_t*  l_qseq;     /* [n] */
+    const uint32_t* n_cigar;    /* [n] */
+    const uint64_t* cigar_off;  /* [n] index of the read's first op in cigar[] */
+    const uint64_t* seq_off;    /* [n] byte offset of the read's first base pair in seq4[] */
+    const uint64_t* qual_off;   /* [n] byte offset of the read's first quality in qual[] */
+    const int32_t*  nm;         /* [n] NM:i value (valid when tags & BRC_TAG_NM) */
+    const int32_t*  sm;         /* [n] SM:i value (valid when tags & BRC_TAG_SM) */
+    const uint8_t*  tags;       /* [n] BRC_TAG_* presence bits */
+    const uint32_t* cigar;      /* [n_cigar_total] */
+    const uint8_t*  seq4;       /* [seq_bytes] */
+    const uint8_t*  qual;       /* [qual_bytes] */
+    uint64_t n_cigar_total, seq_bytes, qual_bytes;
+    const char* const* qname;   /* [n] optional (warning text only); may be NULL */
+} brc_read_batch;
+
+/* One indel bucket (LibraryCounts::indel_stats entry, bamreadcount.cpp:47,315-342). */
+typedef struct brc_indel {
+    int32_t  pos;        /* 0-based reference position of the base BEFORE the indel (the pileup position) */
+    int32_t  lib;        /* library index (0 in all-lib mode) */
+    int32_t  len;        /* >0 insertion length, <0 deletion length */
+    uint32_t rep_read;   /* region-wide index (push order) of the first read carrying this allele */
+    int32_t  rep_qpos;   /* qpos of that read at pos; inserted bases are rep_qpos+1 .. rep_qpos+len */
+    uint32_t allele_off; /* offset into brc_result.alleles of the allele text ("+ACG" / "-TT"), not NUL-terminated */
+    uint32_t allele_len; /* bytes, including the leading sign */
+    brc_stat stat;
+} brc_indel;
+
+/* warning counters, same order as ReadWarnings::WarningType (ReadWarnings.hpp:13-19) */
+enum { BRC_W_SM_MISSING = 0, BRC_W_NM_MISSING, BRC_W_ZM_MISSING, BRC_W_LIB_UNAVAILABLE, BRC_N_WARN };
+
+/*
+ * Result of one region, position-major planes ("SoA"): element [plane][k] is position pos0 + k.
+ * Position index 0 is the lead position beg0-1 (processed only so that deletions starting there
+ * can be reported at beg0, bamreadcount.cpp:269 vs :414); when beg0 == 0 there is no lead position
+ * and pos0 == 0.  All arrays are engine-owned host memory, valid until the next begin_region/destroy.
+ */
+typedef struct brc_result {
+    int32_t tid, beg0, end;     /* reporting window [beg0,end) */
+    int32_t pos0;               /* reference position of index 0 */
+    int64_t n_pos;              /* P */
+    int32_t n_lib;              /* Lp: 1 in all-lib mode, n_libs in per-lib mode */
+    const uint32_t* ncol;       /* [Lp][P] pileup column entries of that library (pre-filter, incl. deletions/ref-skips): lib_counts[] creation, :286 */
+    const uint32_t* depth;      /* [Lp][P] mapq_n contribution (:312) */
+    const uint32_t* istat;      /* [Lp][BRC_NBUCKET][BRC_NI][P] */
+    const float*    fstat;      /* [Lp][BRC_NBUCKET][BRC_NF][P] */
+    const uint32_t* unavail;    /* [P] per-lib mode: region-wide index of the first library-unavailable read in the column, 0xFFFFFFFF if none (:281-284); NULL in all-lib mode */
+    const char* refbase;        /* [P] raw reference character printed in column 3 ('N' when no reference / past its end, :353) */
+    int64_t n_indel;
+    const brc_indel* indel;     /* sorted by (pos, lib, allele text bytewise) = std::map iteration order (:389-401) */
+    const char* alleles;        /* allele text arena */
+    uint64_t alleles_len;
+    uint64_t n_events;          /* pileup base-events inside [beg0,end) (SURVEY 8d unit of work) */
+    uint64_t warn[BRC_N_WARN];  /* process_read-level warning counts (BasicStat.cpp:74,85,100) + positions abandoned (:282) */
+} brc_result;
+
+/* per-kernel timing of the last brc_compute (HIP events on the engine's stream) */
+#define BRC_NKERNEL 8
+typedef struct brc_timing {
+    float ms[BRC_NKERNEL];          /* see brc_kernel_name() */
+    float total_ms;                 /* first launch -> last completion */
+} brc_timing;
+
+typedef struct brc_engine brc_engine;
+
+const char* brc_strerror(int code);
+const char* brc_last_error(const brc_engine*);
+const char* brc_kernel_name(int k);     /* name of timing slot k, NULL if unused */
+const char* brc_engine_kind(void);      /* "hip-gfx950" for the product library, "oracle-c" for oracle/ */
+
+int  brc_create(const brc_config* cfg, brc_engine** out);
+void brc_destroy(brc_engine*);
+
+/* Open the reporting window [beg0,end) on contig tid.  ref = raw FASTA characters of the whole contig
+ * (ref[i] = base at 0-based i), borrowed until brc_end_region/brc_fetch_result returns.  ref may be NULL
+ * (no -f): then indel alleles are not collected and the reference base prints as 'N' (:315,353). */
+int  brc_begin_region(brc_engine*, int32_t tid, int32_t beg0, int32_t end, const char* ref, int64_t ref_len);
+
+/* Append coordinate-sorted reads (may be called repeatedly; batches must be in file order).
+ * The engine copies what it needs into pinned staging before returning. */
+int  brc_push_reads(brc_engine*, const brc_read_batch*);
+
+/* Split form of brc_end_region, used by the benchmark to keep inputs/outputs resident in HBM:
+ *   brc_upload   : staging -> HBM (async on the engine stream, then waits)
+ *   brc_compute  : launch the whole device pipeline on the engine stream and wait; repeatable
+ *   brc_fetch_result : HBM -> host planes + host-side allele ordering                                  */
+int  brc_upload(brc_engine*);
+int  brc_compute(brc_engine*, brc_timing* timing /* may be NULL */);
+int  brc_fetch_result(brc_engine*, brc_result* out);
+
+/* Forget deletions queued for pos+1 (d.indel_queue_map.clear(), bamreadcount.cpp:605: after every -l line,
+ * NOT between command-line regions).  The queue lives in the host-side assembler (brc_format_region). */
+int  brc_clear_indel_queue(brc_engine*);
+
+/* upload + compute + fetch_result */
+int  brc_end_region(brc_engine*, brc_result* out);
+
+/* Number of pileup base-events / emitted positions of the last compute without downloading planes. */
+int  brc_region_counts(brc_engine*, uint64_t* n_events, uint64_t* n_positions);
+
+/*
+ * Host-side record assembly for the last fetched region: produces the reference's exact stdout text
+ * ("chr\tpos\tref\tdepth\t..." lines, one per emitted position) in an engine-owned buffer that stays
+ * valid until the next call on this engine.  chrom = target name; library names come from the config.
+ */
+int  brc_format_region(brc_engine*, const brc_result*, const char* chrom,
+                       const char** text, size_t* text_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BRC_H */

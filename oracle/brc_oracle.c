@@ -1,0 +1,729 @@
+/*
+ * brc_oracle.c — CPU restatement of bam-readcount's per-position accumulation path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle: only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may build, load or call it, and only as the checker / the reported CPU
+ * baseline.  Nothing under bam_readcount_amd/ links or calls it; the product path is the HIP engine.
+ *
+ * It exports the same C ABI as the product library (include/brc.h) so the tests can run identical
+ * calls against both and compare planes and text.  Single-threaded, like the reference.
+ *
+ * Parity pinning: tests/test_oracle_golden.py checks this file against the reference's own four golden
+ * files (test-data/expected_*) byte-for-byte, with the recovered pseudo-reference (tools/make_fixtures.py).
+ * Behaviour NOT covered by any reference test ("parity unpinned"): deletions and the
+ * pos+1 queue, N/=/X/P/H operators, flag drops, -q/-b thresholds, max-count, SM-tagged reads.
+ *
+ * Each function cites the reference lines it follows (paths relative to the reference tree).  The
+ * pileup iterator lives in samtools/htslib 1.10 (cmake/BuildSamtools.cmake:3), which is NOT in the
+ * reference tree; its published algorithm (htslib sam.c: bam_plp_push / bam_plp_next / resolve_cigar2,
+ * bam_endpos) is restated here and anchored on the reference's call sites bamreadcount.cpp:259,591-603.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include "brc.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---------------------------------------------------------------- small helpers */
+
+typedef struct { char* p; size_t n, cap; } sbuf;
+
+static void sb_reserve(sbuf* b, size_t extra) {
+    if (b->n + extra + 1 > b->cap) {
+        size_t c = b->cap ? b->cap * 2 : 4096;
+        while (c < b->n + extra + 1) c *= 2;
+        b->p = (char*)realloc(b->p, c);
+        b->cap = c;
+    }
+}
+static void sb_put(sbuf* b, const char* s, size_t n) { sb_reserve(b, n); memcpy(b->p + b->n, s, n); b->n += n; b->p[b->n] = 0; }
+static void sb_puts(sbuf* b, const char* s) { sb_put(b, s, strlen(s)); }
+static void sb_putc(sbuf* b, char c) { sb_put(b, &c, 1); }
+
+/* BAM constants (SAMv1 4.2) */
+enum { CMATCH = 0, CINS, CDEL, CREF_SKIP, CSOFT_CLIP, CHARD_CLIP, CPAD, CEQUAL, CDIFF };
+#define FPROPER_PAIR 2
+#define FUNMAP 4
+#define FREVERSE 16
+#define FSECONDARY 256
+#define FQCFAIL 512
+#define FDUP 1024
+
+/* seq_nt16_table of htslib (IUPAC char -> 4-bit code, case-insensitive, everything else 15),
+ * used by bamreadcount.cpp:149 as bam_nt16_table */
+static unsigned char nt16_of_char(unsigned char c) {
+    switch (c) {
+        case '=': return 0;
+        case 'A': case 'a': return 1;  case 'C': case 'c': return 2;  case 'M': case 'm': return 3;
+        case 'G': case 'g': return 4;  case 'R': case 'r': return 5;  case 'S': case 's': return 6;
+        case 'V': case 'v': return 7;  case 'T': case 't': return 8;  case 'W': case 'w': return 9;
+        case 'Y': case 'y': return 10; case 'H': case 'h': return 11; case 'K': case 'k': return 12;
+        case 'D': case 'd': return 13; case 'B': case 'b': return 14;
+        case '0': return 1; case '1': return 2; case '2': return 4; case '3': return 8;
+        default: return 15;
+    }
+}
+/* bamreadcount.cpp:34-39 */
+static const char canonical_nt[] = "=ACGTN";
+static const unsigned char nt16_canonical[16] = {0, 1, 2, 5, 3, 5, 5, 5, 4, 5, 5, 5, 5, 5, 5, 5};
+
+/* ---------------------------------------------------------------- BasicStat */
+
+/* BasicStat.hpp:12-24 */
+typedef struct {
+    unsigned read_count, sum_map_qualities, sum_single_ended_map_qualities, num_plus_strand, num_minus_strand;
+    float sum_event_location, sum_q2_distance;
+    unsigned num_q2_reads;
+    float sum_number_of_mismatches;
+    unsigned sum_of_mismatch_qualities, sum_of_clipped_lengths;
+    float sum_3p_distance;
+    unsigned sum_base_qualities;
+    int is_indel;
+} ostat;
+
+/* auxfields.hpp:6-11 */
+typedef struct { int sum_of_mismatch_qualities, clipped_length, left_clip, three_prime_index, q2_pos; } zm_t;
+
+typedef struct {
+    int32_t pos; uint16_t flag; uint8_t mapq; int16_t lib; int32_t l_qseq; uint32_t n_cigar;
+    const uint32_t* cigar; const uint8_t* seq4; const uint8_t* qual;
+    int32_t nm, sm; uint8_t tags;
+    zm_t zm; int has_zm;
+} oread;
+
+static inline int seqi(const uint8_t* s, int i) { return (s[i >> 1] >> ((~i & 1) << 2)) & 0xf; }
+
+struct brc_engine {
+    brc_config cfg;
+    char** lib_names;
+    char errbuf[256];
+    /* region */
+    int in_region; int32_t tid, beg0, end; const char* ref; int64_t ref_len;
+    /* read store (arenas are chunked so pointers stay valid) */
+    oread* reads; size_t n_reads, cap_reads;
+    void** chunks; size_t n_chunks;
+    /* result planes */
+    int32_t pos0; int64_t P; int Lp;
+    uint32_t *ncol, *depth, *istat, *unavail; float* fstat; char* refbase;
+    brc_indel* indel; size_t n_indel, cap_indel;
+    sbuf alleles;
+    uint64_t n_events; uint64_t warn[BRC_N_WARN];
+    /* text of the region as the reference would print it */
+    sbuf text, fmt_text;
+    /* indel queues (bamreadcount.cpp:52,69): one FIFO per library name */
+    struct qent { uint32_t tid, pos; ostat st; char* allele; } **queue; size_t *qn, *qhead, *qcap;
+    int n_queues;
+};
+
+/* BasicStat.cpp:28-107 */
+static void process_read(brc_engine* e, ostat* s, const oread* r, int qpos) {
+    s->read_count++;
+    s->sum_map_qualities += r->mapq;
+    if (r->flag & FREVERSE) s->num_minus_strand++; else s->num_plus_strand++;
+
+    int32_t left_clip = 0, clipped_length = r->l_qseq, mismatch_sum = 0, q2_val = 0, three_prime_index = 0;
+    if (r->has_zm) {
+        mismatch_sum = r->zm.sum_of_mismatch_qualities;
+        clipped_length = r->zm.clipped_length;
+        left_clip = r->zm.left_clip;
+        three_prime_index = r->zm.three_prime_index;
+        q2_val = r->zm.q2_pos;
+        s->sum_of_mismatch_qualities += mismatch_sum;
+        if (q2_val > -1) {
+            s->sum_q2_distance += (float)abs(qpos - q2_val) / (float)r->l_qseq;
+            s->num_q2_reads++;
+        }
+        s->sum_3p_distance += (float)abs(qpos - three_prime_index) / (float)r->l_qseq;
+        s->sum_of_clipped_lengths += clipped_length;
+        float read_center = (float)clipped_length / 2.0;
+        /* :70 — float += double expression: promoted add, then rounded back to float */
+        s->sum_event_location = (float)((double)s->sum_event_location +
+                                        (1.0 - fabsf((float)(qpos - left_clip) - read_center) / read_center));
+    } else {
+        e->warn[BRC_W_ZM_MISSING]++;
+    }
+    if (r->flag & FPROPER_PAIR) {
+        if (r->tags & BRC_TAG_SM) s->sum_single_ended_map_qualities += r->sm;
+        else e->warn[BRC_W_SM_MISSING]++;
+    } else {
+        s->sum_single_ended_map_qualities += r->mapq;
+    }
+    if (r->tags & BRC_TAG_NM) {
+        s->sum_number_of_mismatches += r->nm / (float)clipped_length;
+    } else {
+        e->warn[BRC_W_NM_MISSING]++;
+    }
+    if (!s->is_indel) s->sum_base_qualities += r->qual[qpos];
+}
+
+/* BasicStat.cpp:110-159; iostream fixed/setprecision(2) on a float == printf("%.2f", (double)f) in glibc */
+static void format_stat(sbuf* b, const ostat* s) {
+    char t[512];
+    int n;
+    if (s->read_count > 0) {
+        float c = (float)s->read_count;
+        n = snprintf(t, sizeof t, "%u:%.2f:%.2f:%.2f:%u:%u:%.2f:%.2f:%.2f:%u:%.2f:%.2f:%.2f",
+                     s->read_count,
+                     (double)((float)s->sum_map_qualities / c),
+                     s->is_indel ? 0.0 : (double)((float)s->sum_base_qualities / c),
+                     (double)((float)s->sum_single_ended_map_qualities / c),
+                     s->num_plus_strand, s->num_minus_strand,
+                     (double)(s->sum_event_location / c),
+                     (double)(s->sum_number_of_mismatches / c),
+                     (double)((float)s->sum_of_mismatch_qualities / c),
+                     s->num_q2_reads,
+                     s->num_q2_reads > 0 ? (double)(s->sum_q2_distance / (float)s->num_q2_reads) : 0.0,
+                     (double)((float)s->sum_of_clipped_lengths / c),
+                     (double)(s->sum_3p_distance / c));
+    } else {
+        n = snprintf(t, sizeof t, "0:0.00:0.00:0.00:0:0:0.00:0.00:0.00:0:0.00:0.00:0.00");
+    }
+    sb_put(b, t, (size_t)n);
+}
+
+static void stat_to_abi(const ostat* s, brc_stat* o) {
+    o->i[BRC_I_N] = s->read_count; o->i[BRC_I_SMQ] = s->sum_map_qualities; o->i[BRC_I_SSE] = s->sum_single_ended_map_qualities;
+    o->i[BRC_I_PLUS] = s->num_plus_strand; o->i[BRC_I_MINUS] = s->num_minus_strand; o->i[BRC_I_NQ2] = s->num_q2_reads;
+    o->i[BRC_I_SMMQ] = s->sum_of_mismatch_qualities; o->i[BRC_I_SCLIP] = s->sum_of_clipped_lengths; o->i[BRC_I_SBQ] = s->sum_base_qualities;
+    o->f[BRC_F_SEV] = s->sum_event_location; o->f[BRC_F_SQ2] = s->sum_q2_distance;
+    o->f[BRC_F_SNM] = s->sum_number_of_mismatches; o->f[BRC_F_S3P] = s->sum_3p_distance;
+}
+
+/* ---------------------------------------------------------------- fetch_func: per-read annotation */
+
+/* bamreadcount.cpp:114-256.  ref[i] is defined for i < ref_len; ref[ref_len] is the NUL terminator of
+ * fai_fetch's string; anything beyond is undefined in the reference and treated as NUL here. */
+static void annotate(const brc_engine* e, oread* r) {
+    const char* ref = e->ref; int64_t ref_len = e->ref_len;
+    int i, reference_position, read_position;
+    uint32_t sum_of_mismatch_qualities = 0;
+    int left_clip = 0, clipped_length = r->l_qseq, right_clip = r->l_qseq;
+    int last_mismatch_position = -1, last_mismatch_qual = 0;
+
+    for (i = read_position = 0, reference_position = r->pos; i < (int)r->n_cigar; ++i) {
+        int j, op_length = r->cigar[i] >> 4, op = r->cigar[i] & 0xf;
+        if (op == CMATCH) {
+            for (j = 0; j < op_length; j++) {
+                int current_base_position = read_position + j;
+                int read_base = seqi(r->seq4, current_base_position);
+                int64_t refpos = (int64_t)reference_position + j;
+                if (e->cfg.ref_len_check && ref_len && refpos > ref_len) continue;          /* :144-148 (warning text not kept) */
+                unsigned char rc = (refpos >= 0 && refpos < ref_len) ? (unsigned char)ref[refpos] : 0;
+                int ref_base = nt16_of_char(rc);
+                if (rc == 0) break;                                                          /* :151 */
+                if (read_base != ref_base && ref_base != 15 && read_base != 0) {             /* :152 */
+                    int qual = r->qual[current_base_position];
+                    if (last_mismatch_position != -1) {
+                        if (last_mismatch_position + 1 != current_base_position) {
+                            sum_of_mismatch_qualities += last_mismatch_qual;
+                            last_mismatch_qual = qual;
+                            last_mismatch_position = current_base_position;
+                        } else {
+                            if (last_mismatch_qual < qual) last_mismatch_qual = qual;
+                            last_mismatch_position = current_base_position;
+                        }
+                    } else {
+                        last_mismatch_position = current_base_position;
+                        last_mismatch_qual = qual;
+                    }
+                }
+            }
+            if (j < op_length) break;                                                        /* :175 */
+            reference_position += op_length;
+            read_position += op_length;
+        } else if (op == CDEL || op == CREF_SKIP) {
+            reference_position += op_length;
+        } else if (op == CINS) {
+            read_position += op_length;
+        } else if (op == CSOFT_CLIP) {
+            read_position += op_length;
+            clipped_length -= op_length;
+            if (i == 0) left_clip += op_length; else right_clip -= op_length;
+        }
+        /* H, P, =, X: no branch in the reference (:138-196) */
+    }
+    sum_of_mismatch_qualities += last_mismatch_qual;                                         /* :199 */
+
+    /* :201-238 */
+    int three_prime_index = -1, q2_pos = -1, k, increment;
+    if (r->flag & FREVERSE) {
+        k = three_prime_index = 0; increment = 1;
+        if (three_prime_index < left_clip) three_prime_index = left_clip;
+    } else {
+        k = three_prime_index = r->l_qseq - 1; increment = -1;
+        if (three_prime_index > right_clip) three_prime_index = right_clip;
+    }
+    while (q2_pos < 0 && k >= 0 && k < r->l_qseq) {
+        if (r->qual[k] != 2) { q2_pos = k - 1; break; }
+        k += increment;
+    }
+    if (r->flag & FREVERSE) {
+        if (three_prime_index < q2_pos) three_prime_index = q2_pos;
+    } else {
+        if (three_prime_index > q2_pos && q2_pos != -1) three_prime_index = q2_pos;
+    }
+    r->zm.sum_of_mismatch_qualities = (int)sum_of_mismatch_qualities;
+    r->zm.clipped_length = clipped_length;
+    r->zm.left_clip = left_clip;
+    r->zm.three_prime_index = three_prime_index;
+    r->zm.q2_pos = q2_pos;
+    r->has_zm = 1;
+}
+
+/* ---------------------------------------------------------------- pileup iterator (htslib 1.10 sam.c, restated) */
+
+typedef struct { int k, x, y, end; } cstate;
+typedef struct { size_t ridx; int beg, end; cstate s; } lnode;
+typedef struct { size_t ridx; int qpos, indel, is_del, is_refskip; } pileup1;
+
+typedef struct {
+    lnode* list; size_t n, cap;
+    pileup1* plp; size_t max_plp;
+    int tid, pos, max_tid, max_pos, is_eof, maxcnt;
+    int any_pushed;
+} plp_iter;
+
+static int is_refop(int op) { return op == CMATCH || op == CDEL || op == CREF_SKIP || op == CEQUAL || op == CDIFF; }
+static int is_mop(int op) { return op == CMATCH || op == CEQUAL || op == CDIFF; }
+
+/* bam_endpos / bam_cigar2rlen */
+static int read_endpos(const oread* r) {
+    if (!(r->flag & FUNMAP) && r->n_cigar > 0) {
+        int l = 0;
+        for (uint32_t k = 0; k < r->n_cigar; ++k) if (is_refop(r->cigar[k] & 0xf)) l += r->cigar[k] >> 4;
+        return r->pos + l;
+    }
+    return r->pos + 1;
+}
+
+/* resolve_cigar2: stateful CIGAR cursor; called for every position pos >= read start in ascending order */
+static int resolve_cigar2(const oread* r, pileup1* p, int pos, cstate* s) {
+    const uint32_t* cigar = r->cigar; int n_cigar = (int)r->n_cigar; int k;
+    if (s->k == -1) {
+        p->qpos = 0;
+        if (n_cigar == 1) {
+            if (is_mop(cigar[0] & 0xf)) s->k = 0, s->x = r->pos, s->y = 0;
+        } else {
+            for (k = 0, s->x = r->pos, s->y = 0; k < n_cigar; ++k) {
+                int op = cigar[k] & 0xf, l = cigar[k] >> 4;
+                if (is_refop(op)) break;
+                else if (op == CINS || op == CSOFT_CLIP) s->y += l;
+            }
+            s->k = k;
+        }
+        if (s->k < 0 || s->k >= n_cigar) return 0; /* reference build would assert/UB; treated as "not in column" */
+    } else {
+        int op, l = cigar[s->k] >> 4;
+        if (pos - s->x >= l) {
+            if (s->k + 1 >= n_cigar) return 0;
+            op = cigar[s->k + 1] & 0xf;
+            if (is_refop(op)) {
+                if (is_mop(cigar[s->k] & 0xf)) s->y += l;
+                s->x += l;
+                ++s->k;
+            } else {
+                if (is_mop(cigar[s->k] & 0xf)) s->y += l;
+                s->x += l;
+                for (k = s->k + 1; k < n_cigar; ++k) {
+                    op = cigar[k] & 0xf; l = cigar[k] >> 4;
+                    if (is_refop(op)) break;
+                    else if (op == CINS || op == CSOFT_CLIP) s->y += l;
+                }
+                s->k = k;
+            }
+            if (s->k >= n_cigar) return 0;
+        }
+    }
+    {
+        int op = cigar[s->k] & 0xf, l = cigar[s->k] >> 4;
+        p->is_del = p->indel = p->is_refskip = 0;
+        if (s->x + l - 1 == pos && s->k + 1 < n_cigar) {
+            int op2 = cigar[s->k + 1] & 0xf, l2 = cigar[s->k + 1] >> 4;
+            if (op2 == CDEL) p->indel = -(int)l2;
+            else if (op2 == CINS) p->indel = l2;
+            else if (op2 == CPAD && s->k + 2 < n_cigar) {
+                int l3 = 0;
+                for (k = s->k + 2; k < n_cigar; ++k) {
+                    op2 = cigar[k] & 0xf; l2 = cigar[k] >> 4;
+                    if (op2 == CINS) l3 += l2;
+                    else if (op2 == CDEL || op2 == CMATCH || op2 == CREF_SKIP || op2 == CEQUAL || op2 == CDIFF) break;
+                }
+                if (l3 > 0) p->indel = l3;
+            }
+        }
+        if (is_mop(op)) {
+            p->qpos = s->y + (pos - s->x);
+        } else if (op == CDEL || op == CREF_SKIP) {
+            p->is_del = 1; p->qpos = s->y;
+            p->is_refskip = (op == CREF_SKIP);
+        }
+    }
+    return 1;
+}
+
+/* ---------------------------------------------------------------- pileup_func */
+
+typedef struct { char* allele; ostat st; size_t rep_read; int rep_qpos; } oindel;
+typedef struct { int present; ostat base[BRC_NBUCKET]; oindel* ind; size_t n_ind, cap_ind; } libcounts;
+
+static void queue_push(brc_engine* e, int lib, uint32_t tid, uint32_t pos, const ostat* st, const char* allele) {
+    if (e->qn[lib] == e->qcap[lib]) {
+        e->qcap[lib] = e->qcap[lib] ? e->qcap[lib] * 2 : 16;
+        e->queue[lib] = (struct qent*)realloc(e->queue[lib], e->qcap[lib] * sizeof(struct qent));
+    }
+    struct qent* q = &e->queue[lib][e->qn[lib]++];
+    q->tid = tid; q->pos = pos; q->st = *st; q->allele = strdup(allele);
+}
+/* IndelQueue.cpp:3-15 */
+static int queue_process(brc_engine* e, int lib, uint32_t tid, uint32_t pos, sbuf* rec) {
+    int extra_depth = 0;
+    size_t* h = &e->qhead[lib];
+    struct qent* q = e->queue[lib];
+    while (*h < e->qn[lib] && ((q[*h].tid == tid && q[*h].pos < pos) || q[*h].tid != tid)) { free(q[*h].allele); ++*h; }
+    while (*h < e->qn[lib] && q[*h].tid == tid && q[*h].pos == pos) {
+        sb_putc(rec, '\t'); sb_puts(rec, q[*h].allele); sb_putc(rec, ':'); format_stat(rec, &q[*h].st);
+        extra_depth += (int)q[*h].st.read_count;
+        free(q[*h].allele); ++*h;
+    }
+    if (*h == e->qn[lib]) { *h = 0; e->qn[lib] = 0; }
+    return extra_depth;
+}
+
+static void result_add_indel(brc_engine* e, int pos, int lib, const oindel* a, size_t rep_read, int rep_qpos, int len) {
+    if (e->n_indel == e->cap_indel) {
+        e->cap_indel = e->cap_indel ? e->cap_indel * 2 : 64;
+        e->indel = (brc_indel*)realloc(e->indel, e->cap_indel * sizeof(brc_indel));
+    }
+    brc_indel* o = &e->indel[e->n_indel++];
+    memset(o, 0, sizeof *o);
+    o->pos = pos; o->lib = lib; o->len = len; o->rep_read = (uint32_t)rep_read; o->rep_qpos = rep_qpos;
+    o->allele_off = (uint32_t)e->alleles.n; o->allele_len = (uint32_t)strlen(a->allele);
+    sb_puts(&e->alleles, a->allele);
+    stat_to_abi(&a->st, &o->stat);
+}
+
+/* bamreadcount.cpp:265-419 */
+static void pileup_func(brc_engine* e, uint32_t tid, uint32_t pos, int n, const pileup1* pl, libcounts* lc, const char* chrom_unused) {
+    (void)chrom_unused;
+    const brc_config* c = &e->cfg;
+    if (!((int)pos >= e->beg0 - 1 && (int)pos < e->end)) return;                             /* :269 */
+    int Lp = e->Lp;
+    int64_t k = (int64_t)pos - e->pos0;
+    int in_planes = (k >= 0 && k < e->P);
+    int mapq_n = 0;
+    for (int l = 0; l < Lp; ++l) { lc[l].present = 0; memset(lc[l].base, 0, sizeof lc[l].base); lc[l].n_ind = 0; }
+
+    for (int i = 0; i < n; ++i) {
+        const pileup1* base = pl + i;
+        const oread* r = &e->reads[base->ridx];
+        int lib = 0;
+        if (c->per_lib) {
+            lib = r->lib;
+            if (lib < 0) {                                                                    /* :281-284 */
+                e->warn[BRC_W_LIB_UNAVAILABLE]++;
+                if (in_planes) {
+                    e->unavail[k] = (uint32_t)base->ridx;
+                    /* the reference abandons the position: nothing of it is reported */
+                    for (int l = 0; l < Lp; ++l) { e->ncol[(int64_t)l * e->P + k] = 0; e->depth[(int64_t)l * e->P + k] = 0; }
+                }
+                for (int l = 0; l < Lp; ++l) { for (size_t a = 0; a < lc[l].n_ind; ++a) free(lc[l].ind[a].allele); lc[l].n_ind = 0; }
+                return;
+            }
+        }
+        libcounts* cur = &lc[lib];
+        cur->present = 1;                                                                     /* :286 */
+        if (in_planes) e->ncol[(int64_t)lib * e->P + k]++;
+        if ((int)pos >= e->beg0) e->n_events++;
+        if (!base->is_del && r->mapq >= c->min_mapq && r->qual[base->qpos] >= c->min_bq) {    /* :288 */
+            if (r->flag & (FUNMAP | FSECONDARY | FQCFAIL | FDUP)) continue;                   /* :295-310 */
+            mapq_n++;                                                                         /* :312 */
+            if (in_planes) e->depth[(int64_t)lib * e->P + k]++;
+            if (base->indel != 0 && e->ref) {                                                 /* :315 */
+                char* allele; int alen = abs(base->indel);
+                allele = (char*)malloc((size_t)alen + 2);
+                if (base->indel > 0) {
+                    allele[0] = '+';
+                    for (int ib = 0; ib < base->indel; ib++) {
+                        int qi = base->qpos + 1 + ib;
+                        allele[1 + ib] = (qi < r->l_qseq) ? canonical_nt[nt16_canonical[seqi(r->seq4, qi)]] : 'N';
+                    }
+                } else {
+                    allele[0] = '-';
+                    for (int ib = 0; ib < alen; ib++) {
+                        int64_t rp = (int64_t)pos + ib + 1;
+                        allele[1 + ib] = (rp < e->ref_len) ? e->ref[rp] : 'N'; /* reference reads past the string here (UB); 'N' substituted */
+                    }
+                }
+                allele[alen + 1] = 0;
+                /* std::map<std::string,BasicStat>::operator[] — keep sorted bytewise */
+                size_t a = 0; int found = 0;
+                for (; a < cur->n_ind; ++a) { int cmp = strcmp(cur->ind[a].allele, allele); if (cmp == 0) { found = 1; break; } if (cmp > 0) break; }
+                if (!found) {
+                    if (cur->n_ind == cur->cap_ind) { cur->cap_ind = cur->cap_ind ? cur->cap_ind * 2 : 8; cur->ind = (oindel*)realloc(cur->ind, cur->cap_ind * sizeof(oindel)); }
+                    memmove(cur->ind + a + 1, cur->ind + a, (cur->n_ind - a) * sizeof(oindel));
+                    cur->n_ind++;
+                    cur->ind[a].allele = allele; memset(&cur->ind[a].st, 0, sizeof(ostat));
+                    cur->ind[a].rep_read = base->ridx; cur->ind[a].rep_qpos = base->qpos;   /* ABI bookkeeping, not in the reference */
+                } else free(allele);
+                cur->ind[a].st.is_indel = 1;                                                  /* :340 */
+                process_read(e, &cur->ind[a].st, r, base->qpos);                              /* :341 */
+            }
+            if (base->indel < 1 || !c->insertion_centric) {                                   /* :343 */
+                unsigned char cb = nt16_canonical[seqi(r->seq4, base->qpos)];
+                process_read(e, &cur->base[cb], r, base->qpos);
+            }
+        }
+    }
+
+    /* planes */
+    if (in_planes) {
+        for (int l = 0; l < Lp; ++l) for (int b = 0; b < BRC_NBUCKET; ++b) {
+            brc_stat t; stat_to_abi(&lc[l].base[b], &t);
+            for (int f = 0; f < BRC_NI; ++f) e->istat[(((int64_t)l * BRC_NBUCKET + b) * BRC_NI + f) * e->P + k] = t.i[f];
+            for (int f = 0; f < BRC_NF; ++f) e->fstat[(((int64_t)l * BRC_NBUCKET + b) * BRC_NF + f) * e->P + k] = t.f[f];
+        }
+    }
+
+    /* :351-416 */
+    char ref_base = (e->ref && (int64_t)pos < e->ref_len) ? e->ref[pos] : 'N';
+    sbuf rec = {0, 0, 0};
+    sb_reserve(&rec, 16);
+    int extra_depth = 0;
+    for (int l = 0; l < Lp; ++l) {
+        if (!lc[l].present) continue;
+        if (c->per_lib) { sb_putc(&rec, '\t'); sb_puts(&rec, e->lib_names[l]); sb_puts(&rec, "\t{"); }
+        for (int j = 0; j < BRC_NBUCKET; ++j) { sb_putc(&rec, '\t'); sb_putc(&rec, canonical_nt[j]); sb_putc(&rec, ':'); format_stat(&rec, &lc[l].base[j]); }
+        for (size_t a = 0; a < lc[l].n_ind; ++a) {
+            oindel* it = &lc[l].ind[a];
+            int len = (int)strlen(it->allele) - 1;
+            result_add_indel(e, (int)pos, l, it, it->rep_read, it->rep_qpos, it->allele[0] == '-' ? -len : len);
+            if (it->allele[0] == '-') queue_push(e, l, tid, pos + 1, &it->st, it->allele);      /* :391-396 */
+            else { sb_putc(&rec, '\t'); sb_puts(&rec, it->allele); sb_putc(&rec, ':'); format_stat(&rec, &it->st); }
+            free(it->allele);
+        }
+        lc[l].n_ind = 0;
+        extra_depth += queue_process(e, l, tid, pos, &rec);                                   /* :403-409 */
+        if (c->per_lib) sb_puts(&rec, "\t}");
+    }
+    if ((int)pos >= e->beg0 && (int)pos < e->end) {                                           /* :414-416 */
+        char t[64];
+        int m = snprintf(t, sizeof t, "\t%u\t%c\t%d", pos + 1, ref_base, mapq_n + extra_depth);
+        sb_puts(&e->text, "\x01");   /* chrom placeholder, substituted by brc_format_region */
+        sb_put(&e->text, t, (size_t)m);
+        if (rec.n) sb_put(&e->text, rec.p, rec.n);
+        sb_putc(&e->text, '\n');
+    }
+    free(rec.p);
+}
+
+/* ---------------------------------------------------------------- ABI */
+
+const char* brc_strerror(int code) {
+    switch (code) {
+        case BRC_OK: return "ok"; case BRC_E_ARG: return "bad argument or call order";
+        case BRC_E_NODEVICE: return "no device"; case BRC_E_HIP: return "HIP error";
+        case BRC_E_NOMEM: return "out of memory"; case BRC_E_LIMIT: return "engine limit exceeded";
+        default: return "unknown";
+    }
+}
+const char* brc_last_error(const brc_engine* e) { return e ? e->errbuf : ""; }
+const char* brc_kernel_name(int k) { (void)k; return NULL; }
+const char* brc_engine_kind(void) { return "oracle-c"; }
+
+int brc_create(const brc_config* cfg, brc_engine** out) {
+    if (!cfg || !out || cfg->abi_version != BRC_ABI_VERSION) return BRC_E_ARG;
+    brc_engine* e = (brc_engine*)calloc(1, sizeof *e);
+    e->cfg = *cfg;
+    if (e->cfg.max_cnt <= 0) e->cfg.max_cnt = 10000000;
+    e->Lp = cfg->per_lib ? cfg->n_libs : 1;
+    if (e->Lp < 1) e->Lp = 1;
+    e->lib_names = (char**)calloc((size_t)e->Lp, sizeof(char*));
+    for (int l = 0; l < e->Lp; ++l) e->lib_names[l] = strdup(cfg->per_lib && cfg->lib_names ? cfg->lib_names[l] : "all");
+    e->n_queues = e->Lp;
+    e->queue = (struct qent**)calloc((size_t)e->Lp, sizeof(void*));
+    e->qn = (size_t*)calloc((size_t)e->Lp, sizeof(size_t)); e->qhead = (size_t*)calloc((size_t)e->Lp, sizeof(size_t)); e->qcap = (size_t*)calloc((size_t)e->Lp, sizeof(size_t));
+    *out = e;
+    return BRC_OK;
+}
+
+static void free_region(brc_engine* e) {
+    for (size_t i = 0; i < e->n_chunks; ++i) free(e->chunks[i]);
+    free(e->chunks); e->chunks = 0; e->n_chunks = 0;
+    free(e->reads); e->reads = 0; e->n_reads = e->cap_reads = 0;
+    free(e->ncol); free(e->depth); free(e->istat); free(e->fstat); free(e->unavail); free(e->refbase);
+    e->ncol = e->depth = e->istat = e->unavail = 0; e->fstat = 0; e->refbase = 0;
+    free(e->indel); e->indel = 0; e->n_indel = e->cap_indel = 0;
+    e->alleles.n = 0; e->text.n = 0;
+}
+
+int brc_clear_indel_queue(brc_engine* e) {
+    if (!e) return BRC_E_ARG;
+    for (int l = 0; l < e->n_queues; ++l) {
+        for (size_t i = e->qhead[l]; i < e->qn[l]; ++i) free(e->queue[l][i].allele);
+        e->qn[l] = e->qhead[l] = 0;
+    }
+    return BRC_OK;
+}
+
+void brc_destroy(brc_engine* e) {
+    if (!e) return;
+    free_region(e);
+    brc_clear_indel_queue(e);
+    for (int l = 0; l < e->Lp; ++l) { free(e->lib_names[l]); free(e->queue[l]); }
+    free(e->lib_names); free(e->queue); free(e->qn); free(e->qhead); free(e->qcap);
+    free(e->alleles.p); free(e->text.p); free(e->fmt_text.p);
+    free(e);
+}
+
+int brc_begin_region(brc_engine* e, int32_t tid, int32_t beg0, int32_t end, const char* ref, int64_t ref_len) {
+    if (!e || beg0 < 0 || end < beg0) return BRC_E_ARG;
+    free_region(e);
+    e->tid = tid; e->beg0 = beg0; e->end = end; e->ref = ref; e->ref_len = ref ? ref_len : 0;
+    e->in_region = 1; e->n_events = 0; memset(e->warn, 0, sizeof e->warn);
+    return BRC_OK;
+}
+
+int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
+    if (!e || !e->in_region || !b) return BRC_E_ARG;
+    /* private copies of the three arenas */
+    uint32_t* cig = (uint32_t*)malloc((b->n_cigar_total + 1) * 4); memcpy(cig, b->cigar, b->n_cigar_total * 4);
+    uint8_t* seq = (uint8_t*)malloc(b->seq_bytes + 1); memcpy(seq, b->seq4, b->seq_bytes);
+    uint8_t* qual = (uint8_t*)malloc(b->qual_bytes + 1); memcpy(qual, b->qual, b->qual_bytes);
+    e->chunks = (void**)realloc(e->chunks, (e->n_chunks + 3) * sizeof(void*));
+    e->chunks[e->n_chunks++] = cig; e->chunks[e->n_chunks++] = seq; e->chunks[e->n_chunks++] = qual;
+    if (e->n_reads + (size_t)b->n_reads > e->cap_reads) {
+        e->cap_reads = (e->n_reads + (size_t)b->n_reads) * 2 + 16;
+        e->reads = (oread*)realloc(e->reads, e->cap_reads * sizeof(oread));
+    }
+    for (int64_t i = 0; i < b->n_reads; ++i) {
+        oread* r = &e->reads[e->n_reads++];
+        memset(r, 0, sizeof *r);
+        r->pos = b->pos[i]; r->flag = b->flag[i]; r->mapq = b->mapq[i];
+        r->lib = (e->cfg.per_lib && b->lib) ? b->lib[i] : 0;
+        r->l_qseq = b->l_qseq[i]; r->n_cigar = b->n_cigar[i];
+        r->cigar = cig + b->cigar_off[i]; r->seq4 = seq + b->seq_off[i]; r->qual = qual + b->qual_off[i];
+        r->nm = b->nm ? b->nm[i] : 0; r->sm = b->sm ? b->sm[i] : 0; r->tags = b->tags ? b->tags[i] : 0;
+    }
+    return BRC_OK;
+}
+
+int brc_upload(brc_engine* e) { return e ? BRC_OK : BRC_E_ARG; }
+
+/* bam_plp_next, restated (see file header) */
+static const pileup1* plp_next(brc_engine* e, plp_iter* it, int* tid, int* pos, int* n_plp_out) {
+    if (it->is_eof && it->n == 0) { *n_plp_out = 0; return 0; }
+    while (it->is_eof || it->max_tid > it->tid || (it->max_tid == it->tid && it->max_pos > it->pos)) {
+        int n_plp = 0; size_t w = 0;
+        for (size_t i = 0; i < it->n; ++i) {
+            lnode* p = &it->list[i];
+            if (e->tid < it->tid || (e->tid == it->tid && p->end <= it->pos)) continue; /* removed */
+            if (e->tid == it->tid && p->beg <= it->pos) {
+                if ((size_t)n_plp == it->max_plp) { it->max_plp = it->max_plp ? it->max_plp << 1 : 256; it->plp = (pileup1*)realloc(it->plp, it->max_plp * sizeof(pileup1)); }
+                it->plp[n_plp].ridx = p->ridx;
+                if (resolve_cigar2(&e->reads[p->ridx], &it->plp[n_plp], it->pos, &p->s)) ++n_plp;
+            }
+            if (w != i) it->list[w] = *p;
+            ++w;
+        }
+        it->n = w;
+        *tid = it->tid; *pos = it->pos;
+        if (it->n > 0) {
+            if (it->tid < e->tid) { it->tid = e->tid; it->pos = it->list[0].beg; }
+            else if (it->pos < it->list[0].beg) it->pos = it->list[0].beg;
+            else ++it->pos;
+        } else ++it->pos;
+        if (n_plp) { *n_plp_out = n_plp; return it->plp; }
+        if (it->is_eof && it->n == 0) break;
+    }
+    *n_plp_out = 0;
+    return 0;
+}
+
+int brc_compute(brc_engine* e, brc_timing* timing) {
+    if (!e || !e->in_region) return BRC_E_ARG;
+    if (timing) memset(timing, 0, sizeof *timing);
+    /* window of the planes: [max(beg0-1,0), end) clipped to the extent of the pushed reads */
+    int64_t lo = e->beg0 > 0 ? e->beg0 - 1 : 0, hi = e->end;
+    int64_t rmin = INT64_MAX, rmax = -1;
+    for (size_t i = 0; i < e->n_reads; ++i) {
+        int en = read_endpos(&e->reads[i]);
+        if (e->reads[i].pos < rmin) rmin = e->reads[i].pos;
+        if (en > rmax) rmax = en;
+    }
+    if (rmin > lo) lo = rmin;
+    if (rmax < hi) hi = rmax;
+    if (e->n_reads == 0 || hi < lo) hi = lo;
+    e->pos0 = (int32_t)lo; e->P = hi - lo;
+    size_t P = (size_t)e->P, Lp = (size_t)e->Lp;
+    free(e->ncol); free(e->depth); free(e->istat); free(e->fstat); free(e->unavail); free(e->refbase);
+    e->ncol = (uint32_t*)calloc(Lp * P + 1, 4); e->depth = (uint32_t*)calloc(Lp * P + 1, 4);
+    e->istat = (uint32_t*)calloc(Lp * BRC_NBUCKET * BRC_NI * P + 1, 4); e->fstat = (float*)calloc(Lp * BRC_NBUCKET * BRC_NF * P + 1, 4);
+    e->unavail = (uint32_t*)malloc((P + 1) * 4); memset(e->unavail, 0xff, (P + 1) * 4);
+    e->refbase = (char*)malloc(P + 1);
+    for (size_t k = 0; k < P; ++k) { int64_t p = lo + (int64_t)k; e->refbase[k] = (e->ref && p < e->ref_len) ? e->ref[p] : 'N'; }
+    e->n_indel = 0; e->alleles.n = 0; e->text.n = 0; e->n_events = 0; memset(e->warn, 0, sizeof e->warn);
+
+    libcounts* lc = (libcounts*)calloc(Lp, sizeof(libcounts));
+    plp_iter it; memset(&it, 0, sizeof it);
+    it.maxcnt = e->cfg.max_cnt;
+    /* the iterator starts at tid 0 / pos 0 (bam_plp_init); regions live on one contig, e->tid */
+    for (size_t i = 0; i <= e->n_reads; ++i) {
+        if (i < e->n_reads) {
+            oread* r = &e->reads[i];
+            annotate(e, r);                                                               /* fetch_func :114-256 */
+            /* bam_plp_push */
+            if (r->flag & (FUNMAP | FSECONDARY | FQCFAIL | FDUP)) continue;
+            if (it.tid == e->tid && it.pos == r->pos && (int)(it.n + 1) > it.maxcnt) continue;
+            if (it.n == it.cap) { it.cap = it.cap ? it.cap * 2 : 1024; it.list = (lnode*)realloc(it.list, it.cap * sizeof(lnode)); }
+            lnode* nd = &it.list[it.n++];
+            nd->ridx = i; nd->beg = r->pos; nd->end = read_endpos(r);
+            nd->s.k = -1; nd->s.x = 0; nd->s.y = 0; nd->s.end = nd->end - 1;
+            it.max_tid = e->tid; it.max_pos = r->pos;
+        } else {
+            it.is_eof = 1;                                                                /* bam_plbuf_push(0, buf), :603 */
+        }
+        int tid, pos, n; const pileup1* pl;
+        while ((pl = plp_next(e, &it, &tid, &pos, &n)) != 0) pileup_func(e, (uint32_t)tid, (uint32_t)pos, n, pl, lc, 0);
+    }
+    for (size_t l = 0; l < Lp; ++l) free(lc[l].ind);
+    free(lc); free(it.list); free(it.plp);
+    return BRC_OK;
+}
+
+int brc_fetch_result(brc_engine* e, brc_result* out) {
+    if (!e || !out) return BRC_E_ARG;
+    memset(out, 0, sizeof *out);
+    out->tid = e->tid; out->beg0 = e->beg0; out->end = e->end; out->pos0 = e->pos0; out->n_pos = e->P; out->n_lib = e->Lp;
+    out->ncol = e->ncol; out->depth = e->depth; out->istat = e->istat; out->fstat = e->fstat;
+    out->unavail = e->cfg.per_lib ? e->unavail : NULL; out->refbase = e->refbase;
+    out->n_indel = (int64_t)e->n_indel; out->indel = e->indel; out->alleles = e->alleles.p; out->alleles_len = e->alleles.n;
+    out->n_events = e->n_events; memcpy(out->warn, e->warn, sizeof e->warn);
+    return BRC_OK;
+}
+
+int brc_end_region(brc_engine* e, brc_result* out) {
+    int rc = brc_compute(e, NULL);
+    if (rc) return rc;
+    return brc_fetch_result(e, out);
+}
+
+int brc_region_counts(brc_engine* e, uint64_t* n_events, uint64_t* n_positions) {
+    if (!e) return BRC_E_ARG;
+    if (n_events) *n_events = e->n_events;
+    if (n_positions) { uint64_t n = 0; for (size_t i = 0; i < e->text.n; ++i) n += e->text.p[i] == '\n'; *n_positions = n; }
+    return BRC_OK;
+}
+
+int brc_format_region(brc_engine* e, const brc_result* res, const char* chrom, const char** text, size_t* text_len) {
+    (void)res;
+    if (!e || !chrom || !text) return BRC_E_ARG;
+    e->fmt_text.n = 0; sb_reserve(&e->fmt_text, e->text.n + 16);
+    for (size_t i = 0; i < e->text.n; ++i) {
+        if (e->text.p[i] == '\x01') sb_puts(&e->fmt_text, chrom); else sb_putc(&e->fmt_text, e->text.p[i]);
+    }
+    *text = e->fmt_text.p ? e->fmt_text.p : "";
+    if (text_len) *text_len = e->fmt_text.n;
+    return BRC_OK;
+}

@@ -1,0 +1,49 @@
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    """CPU oracle (test infrastructure only), built on demand with gcc."""
+    from bam_readcount_amd import capi
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    return capi.Library(os.path.join(ROOT, "oracle", "libbrc_oracle.so"))
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """The product library; fails loudly when it was not built (no fallback)."""
+    from bam_readcount_amd import capi
+    return capi.load_product()
+
+
+def load_fixture(name):
+    z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    arrs = {k: z[k] for k in z.files}
+    ref = np.full(int(arrs["ref_len"]), ord("N"), np.uint8)
+    s = int(arrs["ref_start"])
+    ref[s:s + arrs["ref_slice"].size] = arrs["ref_slice"]
+    arrs["ref"] = ref
+    return arrs
+
+
+@pytest.fixture(scope="session")
+def test_bam():
+    return load_fixture("test_bam.npz")
+
+
+@pytest.fixture(scope="session")
+def twolib():
+    return load_fixture("twolib.npz")
