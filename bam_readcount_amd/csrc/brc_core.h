@@ -1,0 +1,479 @@
+// brc_core.h — per-lane algorithms of the MI355X pileup/readcount pipeline.
+//
+// Everything here is written once as __host__ __device__ code: the HIP kernels in brc_engine.hip are thin
+// wave/grid wrappers around these functions, and tests/sim/ runs the very same functions lane-by-lane on the
+// CPU so the device algorithm can be debugged without a GPU.  (The simulator is test infrastructure; the
+// product library contains only the HIP kernels.)
+//
+// Work decomposition:
+//   K1  annotate_read     one lane per read      : fetch_func's five "Zm" integers + per-read constants
+//                                                   (reference bamreadcount.cpp:114-256)
+//   K1' enumerate_indels  one lane per read      : the (position, qpos, length) of every indel event the
+//                                                   pileup would see for this read (htslib resolve_cigar2 peek)
+//   KB  pileup_lane       one lane per position  : wave-uniform walk over the reads covering the lane's
+//                                                   64-position tile, in file order = pileup column order;
+//                                                   BasicStat::process_read per event into 6 register-resident
+//                                                   buckets (BasicStat.cpp:28-107, bamreadcount.cpp:276-348)
+//   KI  reduce_indel_key  one lane per (pos,lib) : ordered reduction of that key's indel events into
+//                                                   per-allele BasicStats (bamreadcount.cpp:315-342)
+#ifndef BRC_CORE_H
+#define BRC_CORE_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define BRC_HD __host__ __device__ __forceinline__
+#else
+#define BRC_HD static inline __attribute__((always_inline))
+#endif
+
+namespace brc {
+
+// BAM constants (SAMv1 4.2)
+enum { CMATCH = 0, CINS, CDEL, CREF_SKIP, CSOFT_CLIP, CHARD_CLIP, CPAD, CEQUAL, CDIFF };
+enum { FPROPER_PAIR = 2, FUNMAP = 4, FREVERSE = 16, FSECONDARY = 256, FQCFAIL = 512, FDUP = 1024 };
+// engine-private flag bit set on the host for reads bam_plp_push would drop because of -d/max-count
+enum { FHOSTDROP = 0x8000 };
+#define BRC_PUSH_MASK (brc::FUNMAP | brc::FSECONDARY | brc::FQCFAIL | brc::FDUP | brc::FHOSTDROP)
+
+enum { NBUCKET = 6, NI = 9, NF = 4 };
+// integer plane order == brc.h BRC_I_*; float plane order == BRC_F_*
+enum { I_N = 0, I_SMQ, I_SSE, I_PLUS, I_MINUS, I_NQ2, I_SMMQ, I_SCLIP, I_SBQ };
+enum { F_SEV = 0, F_SQ2, F_SNM, F_S3P };
+// register accumulators per bucket: the 8 stored integers (read_count = plus + minus) + 4 floats
+enum { A_SMQ = 0, A_SSE, A_PLUS, A_MINUS, A_NQ2, A_SMMQ, A_SCLIP, A_SBQ, NACC_I };
+
+static const uint32_t NONE32 = 0xFFFFFFFFu;
+static const int TILE = 64;   // positions per wave = lanes per wavefront on gfx950
+
+struct DevCfg {
+    int32_t min_mapq, min_bq, per_lib, insertion_centric, Lp, ref_len_check, has_ref;
+    int32_t beg0, end;      // reporting window [beg0,end)
+    int32_t pos0;           // reference position of plane index 0
+    int64_t P;              // plane length
+    int64_t ref_lo, ref_hi; // the device reference slice holds contig positions [ref_lo, ref_hi)
+    int64_t ref_len;        // contig length (positions >= ref_len read as NUL)
+    int64_t n_reads;
+};
+
+// Region inputs exactly as brc_read_batch lays them out (uploaded as-is; offsets rebased per region).
+struct DevIn {
+    const int32_t* pos; const uint16_t* flag; const uint8_t* mapq; const int16_t* lib; const int32_t* l_qseq;
+    const uint32_t* n_cigar; const uint64_t* cig_off; const uint64_t* seq_off; const uint64_t* qual_off;
+    const int32_t* nm; const int32_t* sm; const uint8_t* tags;
+    const uint32_t* cigar; const uint8_t* seq4; const uint8_t* qual; const char* ref;
+};
+
+// Packed per-read record written by K1 and read with scalar loads by KB (80 bytes).
+enum { M_REV = 1, M_Q2OK = 2, M_SMW = 4, M_NMW = 8, M_SIMPLE = 16 };
+struct DRead {
+    int32_t pos, end;          // [pos,end) on the reference; end == pos when the read never enters a column
+    uint32_t cig_off, n_cigar;
+    uint64_t qual_off, seq_off;
+    uint32_t misc;             // M_* | mapq << 8 | (lib + 1) << 16   (lib + 1 == 0: library unavailable)
+    int32_t l_qseq;
+    int32_t q2, tp, left, clipped;   // Zm: q2_pos, three_prime_index, left_clip, clipped_length
+    uint32_t zm_sum, sse_add;        // Zm sum_of_mismatch_qualities; per-event addend of sum_single_ended_map_qualities
+    float snm_add;                   // per-event addend of sum_number_of_mismatches: NM / (float)clipped_length
+    uint32_t pad0, pad1, pad2;
+};
+
+// One indel event, produced by the per-read enumeration, consumed by the per-key reduction (16 bytes).
+struct IndelEv { uint32_t read; int32_t qpos; int32_t len; uint32_t key_lo; };
+// One reduced indel bucket.
+struct IndelOut { int32_t pos, lib, len; uint32_t rep_read; int32_t rep_qpos; uint32_t i[NI]; float f[NF]; };
+
+struct Planes {
+    uint32_t* ncol;    // [Lp][P]
+    uint32_t* depth;   // [Lp][P]
+    uint32_t* istat;   // [Lp][6][9][P]
+    float* fstat;      // [Lp][6][4][P]
+    uint32_t* unavail; // [P]
+};
+
+// ---------------------------------------------------------------- small tables as packed constants
+
+// htslib seq_nt16_table (IUPAC char -> 4-bit code; '=' 0; '0'..'3' 1,2,4,8; everything else 15), bamreadcount.cpp:149
+BRC_HD uint32_t nt16_of_char(uint32_t c) {
+    uint32_t l = (c | 0x20u) - 'a';
+    if (l < 26u) {
+        // a b c d e f g h i j k l m n o p | q r s t u v w x y z
+        const uint64_t lo = 0xFFF3FCFFB4FFD2E1ull;  // nibbles a..p (a in the lowest nibble)
+        const uint64_t hi = 0x000000FAF97F865Full;  // nibbles q..z
+        return (uint32_t)(((l < 16u) ? (lo >> (l * 4)) : (hi >> ((l - 16u) * 4))) & 15u);
+    }
+    if (c == '=') return 0;
+    if (c - '0' < 4u) return 1u << (c - '0');
+    return 15;
+}
+// bam_nt16_canonical_table (bamreadcount.cpp:36-39): 4-bit base code -> bucket index in "=ACGTN"
+BRC_HD uint32_t canon_bucket(uint32_t b4) { return (uint32_t)((0x5555555455535210ull >> (b4 * 4)) & 15u); }
+
+BRC_HD uint32_t seqi(const uint8_t* s, int64_t i) { return (s[i >> 1] >> ((~i & 1) << 2)) & 0xfu; }
+BRC_HD bool is_refop(uint32_t op) { return op == CMATCH || op == CDEL || op == CREF_SKIP || op == CEQUAL || op == CDIFF; }
+BRC_HD bool is_mop(uint32_t op) { return op == CMATCH || op == CEQUAL || op == CDIFF; }
+BRC_HD int iabs(int x) { return x < 0 ? -x : x; }
+
+BRC_HD uint32_t ref_at(const DevCfg& c, const char* ref, int64_t p) {
+    return (p >= 0 && p < c.ref_len && p >= c.ref_lo && p < c.ref_hi) ? (uint32_t)(uint8_t)ref[p - c.ref_lo] : 0u;
+}
+
+// ---------------------------------------------------------------- K1: per-read annotation (fetch_func)
+
+// Restates bamreadcount.cpp:114-256 for read i and packs everything KB needs into a DRead.
+BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i) {
+    DRead r;
+    const int32_t pos = in.pos[i];
+    const uint32_t flag = in.flag[i];
+    const int32_t L = in.l_qseq[i];
+    const uint32_t nc = in.n_cigar[i];
+    const uint32_t* cig = in.cigar + in.cig_off[i];
+    const uint8_t* seq = in.seq4 + in.seq_off[i];
+    const uint8_t* qual = in.qual + in.qual_off[i];
+    const uint32_t mapq = in.mapq[i];
+    const uint32_t tags = in.tags[i];
+
+    uint32_t sum = 0;
+    int left_clip = 0, clipped = L, right_clip = L;
+    int last_mm_pos = -1, last_mm_qual = 0;
+    int read_position = 0;
+    int64_t reference_position = pos;
+    int32_t rlen = 0;           // reference length: bam_cigar2rlen
+    bool stop = false;          // ':151/:175' out-of-reference break: ends ALL CIGAR processing of the annotator
+    for (uint32_t k = 0; k < nc; ++k) {
+        const uint32_t op = cig[k] & 0xfu;
+        const int len = (int)(cig[k] >> 4);
+        if (is_refop(op)) rlen += len;
+        if (stop) continue;     // rlen (the pileup's view of the read) still needs the remaining ops
+        if (op == CMATCH) {
+            int j = 0;
+            for (; j < len; ++j) {
+                const int cur = read_position + j;
+                const int64_t refpos = reference_position + j;
+                if (c.ref_len_check && c.ref_len && refpos > c.ref_len) continue;          // :144-148
+                const uint32_t rc = ref_at(c, in.ref, refpos);
+                if (rc == 0) break;                                                          // :151
+                const uint32_t refb = nt16_of_char(rc);
+                const uint32_t rb = seqi(seq, cur);
+                if (rb != refb && refb != 15u && rb != 0u) {                                 // :152
+                    const int q = qual[cur];
+                    if (last_mm_pos != -1) {
+                        if (last_mm_pos + 1 != cur) { sum += (uint32_t)last_mm_qual; last_mm_qual = q; }
+                        else if (last_mm_qual < q) last_mm_qual = q;
+                    } else last_mm_qual = q;
+                    last_mm_pos = cur;
+                }
+            }
+            if (j < len) { stop = true; continue; }                                          // :175
+            reference_position += len; read_position += len;
+        } else if (op == CDEL || op == CREF_SKIP) {
+            reference_position += len;
+        } else if (op == CINS) {
+            read_position += len;
+        } else if (op == CSOFT_CLIP) {
+            read_position += len; clipped -= len;
+            if (k == 0) left_clip += len; else right_clip -= len;
+        }
+    }
+    sum += (uint32_t)last_mm_qual;                                                           // :199
+
+    int tp, q2 = -1, kq, inc;                                                                // :201-238
+    const bool rev = (flag & FREVERSE) != 0;
+    if (rev) { kq = tp = 0; inc = 1; if (tp < left_clip) tp = left_clip; }
+    else { kq = tp = L - 1; inc = -1; if (tp > right_clip) tp = right_clip; }
+    while (kq >= 0 && kq < L) {
+        if (qual[kq] != 2) { q2 = kq - 1; break; }
+        kq += inc;
+    }
+    if (rev) { if (tp < q2) tp = q2; }
+    else { if (tp > q2 && q2 != -1) tp = q2; }
+
+    // bam_plp_push drop rules + bam_endpos; a lone non-M operator never resolves (htslib resolve_cigar2 k == -1)
+    bool dropped = (flag & BRC_PUSH_MASK) != 0;
+    if (nc == 0) dropped = true;   // bam_endpos = pos + 1, but resolve_cigar2 has no operator to stand on
+    if (nc == 1 && !is_mop(cig[0] & 0xfu)) dropped = true;
+    r.pos = pos;
+    r.end = dropped ? pos : pos + rlen;
+    r.cig_off = (uint32_t)in.cig_off[i];
+    r.n_cigar = nc;
+    r.qual_off = in.qual_off[i];
+    r.seq_off = in.seq_off[i];
+    const int lib = c.per_lib ? (int)in.lib[i] : 0;
+    uint32_t misc = (mapq << 8) | ((uint32_t)((lib + 1) & 0xffff) << 16);
+    if (rev) misc |= M_REV;
+    if (q2 > -1) misc |= M_Q2OK;
+    if (nc == 1 && (cig[0] & 0xfu) == CMATCH) misc |= M_SIMPLE;
+    uint32_t sse;
+    if (flag & FPROPER_PAIR) {                                                               // BasicStat.cpp:78-91
+        if (tags & 2u) sse = (uint32_t)in.sm[i]; else { sse = 0; misc |= M_SMW; }
+    } else sse = mapq;
+    float snm = 0.0f;
+    if (tags & 1u) snm = (float)in.nm[i] / (float)clipped;                                   // BasicStat.cpp:94-97
+    else misc |= M_NMW;
+    r.misc = misc; r.l_qseq = L; r.q2 = q2; r.tp = tp; r.left = left_clip; r.clipped = clipped;
+    r.zm_sum = sum; r.sse_add = sse; r.snm_add = snm; r.pad0 = r.pad1 = r.pad2 = 0;
+    return r;
+}
+
+// ---------------------------------------------------------------- BasicStat::process_read for one event
+
+// BasicStat.cpp:28-107 with the Zm string round trip removed.  ai = NACC_I integers, af = NF floats of ONE bucket.
+// All float arithmetic is fp32 round-to-nearest exactly where the reference's is, and the event-location sum goes
+// through double exactly like `float += 1.0 - float_expr` (BasicStat.cpp:69-70).  Build with -ffp-contract=off.
+BRC_HD void acc_event(uint32_t* ai, float* af, const DRead& r, int qpos, uint32_t q, bool is_indel) {
+    const uint32_t m = r.misc;
+    ai[A_SMQ] += (m >> 8) & 0xffu;
+    if (m & M_REV) ai[A_MINUS]++; else ai[A_PLUS]++;
+    ai[A_SMMQ] += r.zm_sum;
+    const float Lf = (float)r.l_qseq;
+    if (m & M_Q2OK) { af[F_SQ2] += (float)iabs(qpos - r.q2) / Lf; ai[A_NQ2]++; }
+    af[F_S3P] += (float)iabs(qpos - r.tp) / Lf;
+    ai[A_SCLIP] += (uint32_t)r.clipped;
+    const float center = (float)r.clipped * 0.5f;                       // (float)clipped_length/2.0, exact
+    float d = (float)(qpos - r.left) - center;
+    d = d < 0.0f ? -d : d;
+    const float t = d / center;
+    af[F_SEV] = (float)((double)af[F_SEV] + (1.0 - (double)t));
+    ai[A_SSE] += r.sse_add;
+    if (!(m & M_NMW)) af[F_SNM] += r.snm_add;
+    if (!is_indel) ai[A_SBQ] += q;
+}
+
+// ---------------------------------------------------------------- htslib resolve_cigar2 as a pure function of (read, position)
+
+struct Ev { int qpos; int indel; bool in_col; bool is_del; };
+
+// Position p (absolute) against a general CIGAR.  Equivalent to the stateful cursor of htslib 1.10 sam.c
+// resolve_cigar2 for every position pos <= p < end visited in ascending order.
+BRC_HD Ev resolve_cigar(const uint32_t* cig, uint32_t nc, int32_t pos, int32_t p) {
+    Ev e; e.qpos = 0; e.indel = 0; e.in_col = false; e.is_del = false;
+    int32_t x = pos; int y = 0;
+    for (uint32_t k = 0; k < nc; ++k) {
+        const uint32_t op = cig[k] & 0xfu; const int len = (int)(cig[k] >> 4);
+        if (is_refop(op)) {
+            if (p >= x && p < x + len) {
+                e.in_col = true;
+                if (is_mop(op)) e.qpos = y + (p - x); else { e.is_del = true; e.qpos = y; }
+                if (p == x + len - 1 && k + 1 < nc) {          // peek the next operation
+                    const uint32_t op2 = cig[k + 1] & 0xfu; const int l2 = (int)(cig[k + 1] >> 4);
+                    if (op2 == CDEL) e.indel = -l2;
+                    else if (op2 == CINS) e.indel = l2;
+                    else if (op2 == CPAD && k + 2 < nc) {
+                        int l3 = 0;
+                        for (uint32_t kk = k + 2; kk < nc; ++kk) {
+                            const uint32_t o = cig[kk] & 0xfu;
+                            if (o == CINS) l3 += (int)(cig[kk] >> 4);
+                            else if (o == CDEL || o == CMATCH || o == CREF_SKIP || o == CEQUAL || o == CDIFF) break;
+                        }
+                        if (l3 > 0) e.indel = l3;
+                    }
+                }
+                return e;
+            }
+            x += len;
+            if (is_mop(op)) y += len;
+        } else if (op == CINS || op == CSOFT_CLIP) y += len;
+    }
+    return e;
+}
+
+// ---------------------------------------------------------------- KB: one lane = one reference position
+
+struct LaneAcc {
+    uint32_t ai[NBUCKET][NACC_I];
+    float af[NBUCKET][NF];
+    uint32_t ncol, depth, unavail;
+    uint32_t w_sm, w_nm;      // process_read-level warning counts of this lane
+};
+
+BRC_HD void lane_init(LaneAcc& a) {
+    for (int b = 0; b < NBUCKET; ++b) {
+        for (int f = 0; f < NACC_I; ++f) a.ai[b][f] = 0;
+        for (int f = 0; f < NF; ++f) a.af[b][f] = 0.0f;
+    }
+    a.ncol = a.depth = 0; a.unavail = NONE32; a.w_sm = a.w_nm = 0;
+}
+
+// One read against one lane.  `rd` and everything derived only from it is wave-uniform on the device
+// (scalar registers); p / qpos / q / base are per lane.  lib_sel = lib index + 1 handled by this wave.
+BRC_HD void lane_visit_read(const DevCfg& c, const DevIn& in, const DRead& rd, uint32_t ridx, uint32_t lib_sel,
+                            int32_t p, bool lane_valid, LaneAcc& a) {
+    if (rd.end <= rd.pos) return;                                       // dropped at push (uniform)
+    const uint32_t rlib = rd.misc >> 16;
+    bool covered = lane_valid && p >= rd.pos && p < rd.end;
+    if (c.per_lib) {
+        if (rlib == 0) {                                                // library unavailable (:281-284)
+            if (covered && a.unavail == NONE32) a.unavail = ridx;
+            return;
+        }
+        if (rlib != lib_sel) return;                                    // another library's wave handles it (uniform)
+    }
+    if (!covered) return;
+    int qpos; bool is_del = false; int indel = 0;
+    if (rd.misc & M_SIMPLE) qpos = p - rd.pos;
+    else {
+        const Ev e = resolve_cigar(in.cigar + rd.cig_off, rd.n_cigar, rd.pos, p);
+        if (!e.in_col) return;
+        qpos = e.qpos; is_del = e.is_del; indel = e.indel;
+    }
+    a.ncol++;                                                           // lib_counts[library] created (:286)
+    if (is_del) return;
+    if ((int)((rd.misc >> 8) & 0xffu) < c.min_mapq) return;             // :288 (uniform)
+    const uint32_t q = in.qual[rd.qual_off + (uint64_t)qpos];
+    if ((int)q < c.min_bq) return;
+    a.depth++;                                                          // mapq_n (:312)
+    if (indel < 1 || !c.insertion_centric) {                            // :343
+        const uint32_t b = canon_bucket(seqi(in.seq4 + rd.seq_off, qpos));
+        if (rd.misc & M_SMW) a.w_sm++;
+        if (rd.misc & M_NMW) a.w_nm++;
+        switch (b) {                                                    // static indices keep the 6 buckets in registers
+            case 0: acc_event(a.ai[0], a.af[0], rd, qpos, q, false); break;
+            case 1: acc_event(a.ai[1], a.af[1], rd, qpos, q, false); break;
+            case 2: acc_event(a.ai[2], a.af[2], rd, qpos, q, false); break;
+            case 3: acc_event(a.ai[3], a.af[3], rd, qpos, q, false); break;
+            case 4: acc_event(a.ai[4], a.af[4], rd, qpos, q, false); break;
+            default: acc_event(a.ai[5], a.af[5], rd, qpos, q, false); break;
+        }
+    }
+}
+
+// Write one lane's accumulators to the position-major planes (coalesced across the wave: lane == position).
+BRC_HD void lane_store(const DevCfg& c, const Planes& pl, int lib, int64_t k, const LaneAcc& a) {
+    const int64_t P = c.P;
+    const bool dead = c.per_lib && a.unavail != NONE32;                 // position abandoned: report nothing
+    pl.ncol[(int64_t)lib * P + k] = dead ? 0u : a.ncol;
+    pl.depth[(int64_t)lib * P + k] = dead ? 0u : a.depth;
+    if (c.per_lib && lib == 0) pl.unavail[k] = a.unavail;
+    for (int b = 0; b < NBUCKET; ++b) {
+        uint32_t* ip = pl.istat + (((int64_t)lib * NBUCKET + b) * NI) * P + k;
+        float* fp = pl.fstat + (((int64_t)lib * NBUCKET + b) * NF) * P + k;
+        const uint32_t* s = a.ai[b];
+        ip[I_N * P] = dead ? 0u : s[A_PLUS] + s[A_MINUS];
+        ip[I_SMQ * P] = dead ? 0u : s[A_SMQ];
+        ip[I_SSE * P] = dead ? 0u : s[A_SSE];
+        ip[I_PLUS * P] = dead ? 0u : s[A_PLUS];
+        ip[I_MINUS * P] = dead ? 0u : s[A_MINUS];
+        ip[I_NQ2 * P] = dead ? 0u : s[A_NQ2];
+        ip[I_SMMQ * P] = dead ? 0u : s[A_SMMQ];
+        ip[I_SCLIP * P] = dead ? 0u : s[A_SCLIP];
+        ip[I_SBQ * P] = dead ? 0u : s[A_SBQ];
+        for (int f = 0; f < NF; ++f) fp[f * P] = dead ? 0.0f : a.af[b][f];
+    }
+}
+
+// ---------------------------------------------------------------- K1': per-read indel event enumeration
+
+// Calls emit(p, qpos, len) for every event of read `rd` that pileup_func would bucket as an indel allele
+// (bamreadcount.cpp:288-342): last base of an M/=/X operator followed by I, D or P..I, inside the processing
+// window [beg0-1,end), passing the MAPQ / base-quality filters.
+template <class F>
+BRC_HD void enumerate_indels(const DevCfg& c, const DevIn& in, const DRead& rd, F emit) {
+    if (rd.end <= rd.pos || (rd.misc & M_SIMPLE) || !c.has_ref) return;
+    if ((rd.misc >> 16) == 0) return;                                   // library unavailable: position is abandoned
+    if ((int)((rd.misc >> 8) & 0xffu) < c.min_mapq) return;
+    const uint32_t* cig = in.cigar + rd.cig_off; const uint32_t nc = rd.n_cigar;
+    int32_t x = rd.pos; int y = 0;
+    for (uint32_t k = 0; k < nc; ++k) {
+        const uint32_t op = cig[k] & 0xfu; const int len = (int)(cig[k] >> 4);
+        if (is_refop(op)) {
+            if (is_mop(op) && len > 0 && k + 1 < nc) {
+                const uint32_t op2 = cig[k + 1] & 0xfu; const int l2 = (int)(cig[k + 1] >> 4);
+                int indel = 0;
+                if (op2 == CDEL) indel = -l2;
+                else if (op2 == CINS) indel = l2;
+                else if (op2 == CPAD && k + 2 < nc) {
+                    int l3 = 0;
+                    for (uint32_t kk = k + 2; kk < nc; ++kk) {
+                        const uint32_t o = cig[kk] & 0xfu;
+                        if (o == CINS) l3 += (int)(cig[kk] >> 4);
+                        else if (o == CDEL || o == CMATCH || o == CREF_SKIP || o == CEQUAL || o == CDIFF) break;
+                    }
+                    if (l3 > 0) indel = l3;
+                }
+                if (indel != 0) {
+                    const int32_t p = x + len - 1; const int qpos = y + len - 1;
+                    if (p >= c.beg0 - 1 && p < c.end && p >= c.pos0 && (int64_t)p < (int64_t)c.pos0 + c.P) {
+                        const uint32_t q = in.qual[rd.qual_off + (uint64_t)qpos];
+                        if ((int)q >= c.min_bq) emit(p, qpos, indel);
+                    }
+                }
+            }
+            x += len;
+            if (is_mop(op)) y += len;
+        } else if (op == CINS || op == CSOFT_CLIP) y += len;
+    }
+}
+
+// Same allele?  Deletions: same length (the allele text is the reference, identical for equal length);
+// insertions: same canonical ("=ACGTN") inserted bases (bamreadcount.cpp:324-338).
+BRC_HD bool same_allele(const DevIn& in, const DRead* reads, const IndelEv& a, const IndelEv& b) {
+    if (a.len != b.len) return false;
+    if (a.len < 0) return true;
+    const DRead& ra = reads[a.read]; const DRead& rb = reads[b.read];
+    for (int j = 0; j < a.len; ++j) {
+        const int qa = a.qpos + 1 + j, qb = b.qpos + 1 + j;
+        const uint32_t ca = qa < ra.l_qseq ? canon_bucket(seqi(in.seq4 + ra.seq_off, qa)) : 5u;
+        const uint32_t cb = qb < rb.l_qseq ? canon_bucket(seqi(in.seq4 + rb.seq_off, qb)) : 5u;
+        if (ca != cb) return false;
+    }
+    return true;
+}
+
+// KI: ordered reduction of the n events of one (position, library) key.  ev[0..n) hold the key's events in
+// arbitrary order; they are first sorted by read index (= pileup column order), then folded into out[0..na)
+// (one IndelOut per distinct allele, first-seen order).  Returns na.  w_sm/w_nm: warning counts.
+BRC_HD int reduce_indel_key(const DevCfg& c, const DevIn& in, const DRead* reads, IndelEv* ev, int n, int32_t pos, int lib,
+                            IndelOut* out, uint32_t& w_sm, uint32_t& w_nm) {
+    (void)c;
+    for (int i = 1; i < n; ++i) {                                       // insertion sort by read index; n is tiny
+        const IndelEv t = ev[i]; int j = i - 1;
+        while (j >= 0 && ev[j].read > t.read) { ev[j + 1] = ev[j]; --j; }
+        ev[j + 1] = t;
+    }
+    int na = 0;
+    for (int i = 0; i < n; ++i) {
+        const IndelEv e = ev[i];
+        int g = 0;
+        for (; g < na; ++g) {
+            IndelEv rep; rep.read = out[g].rep_read; rep.qpos = out[g].rep_qpos; rep.len = out[g].len; rep.key_lo = 0;
+            if (same_allele(in, reads, rep, e)) break;
+        }
+        if (g == na) {
+            IndelOut o; o.pos = pos; o.lib = lib; o.len = e.len; o.rep_read = e.read; o.rep_qpos = e.qpos;
+            for (int f = 0; f < NI; ++f) o.i[f] = 0;
+            for (int f = 0; f < NF; ++f) o.f[f] = 0.0f;
+            out[na++] = o;
+        }
+        const DRead& rd = reads[e.read];
+        uint32_t ai[NACC_I]; float af[NF];
+        ai[A_SMQ] = out[g].i[I_SMQ]; ai[A_SSE] = out[g].i[I_SSE]; ai[A_PLUS] = out[g].i[I_PLUS]; ai[A_MINUS] = out[g].i[I_MINUS];
+        ai[A_NQ2] = out[g].i[I_NQ2]; ai[A_SMMQ] = out[g].i[I_SMMQ]; ai[A_SCLIP] = out[g].i[I_SCLIP]; ai[A_SBQ] = 0;
+        for (int f = 0; f < NF; ++f) af[f] = out[g].f[f];
+        acc_event(ai, af, rd, e.qpos, 0, true);
+        if (rd.misc & M_SMW) w_sm++;
+        if (rd.misc & M_NMW) w_nm++;
+        out[g].i[I_N] = ai[A_PLUS] + ai[A_MINUS]; out[g].i[I_SMQ] = ai[A_SMQ]; out[g].i[I_SSE] = ai[A_SSE];
+        out[g].i[I_PLUS] = ai[A_PLUS]; out[g].i[I_MINUS] = ai[A_MINUS]; out[g].i[I_NQ2] = ai[A_NQ2];
+        out[g].i[I_SMMQ] = ai[A_SMMQ]; out[g].i[I_SCLIP] = ai[A_SCLIP]; out[g].i[I_SBQ] = 0;
+        for (int f = 0; f < NF; ++f) out[g].f[f] = af[f];
+    }
+    return na;
+}
+
+// ---------------------------------------------------------------- tile -> read range
+
+// Tile t covers plane indices [t*TILE, t*TILE+TILE).  lo = first read whose running-max end exceeds the tile's
+// first position (no earlier read can cover any of its positions); hi = first read starting after its last one.
+BRC_HD void tile_range(const DevCfg& c, const int32_t* prefmax_end, const DRead* reads, int64_t t, uint32_t& lo, uint32_t& hi) {
+    const int64_t p0 = (int64_t)c.pos0 + t * TILE;
+    const int64_t p1 = p0 + TILE - 1;
+    int64_t a = 0, b = c.n_reads;
+    while (a < b) { const int64_t m = (a + b) >> 1; if ((int64_t)prefmax_end[m] > p0) b = m; else a = m + 1; }
+    lo = (uint32_t)a;
+    a = lo; b = c.n_reads;
+    while (a < b) { const int64_t m = (a + b) >> 1; if ((int64_t)reads[m].pos > p1) b = m; else a = m + 1; }
+    hi = (uint32_t)a;
+}
+
+}  // namespace brc
+#endif

@@ -1,0 +1,419 @@
+// brc_host.cpp — C-ABI glue (include/brc.h) and the host-side halves of the path:
+//   * brc_push_reads : staging with rebased offsets, bam_plp_push's max-count drop rule, region extent
+//   * brc_fetch_result : allele text + std::map ordering of indel buckets
+//   * brc_format_region : pileup_func's record assembly (bamreadcount.cpp:351-416), IndelQueue::process
+//                         (IndelQueue.cpp:3-15) and operator<<(BasicStat) (BasicStat.cpp:110-159)
+// No accumulation happens here: every number printed comes out of the device planes.
+#include "brc_host.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <deque>
+#include <functional>
+#include <queue>
+
+namespace brc {
+
+void Staged::init(const HostAlloc* A) {
+    pos.A = A; flag.A = A; mapq.A = A; lib.A = A; l_qseq.A = A; n_cigar.A = A; cig_off.A = A; seq_off.A = A; qual_off.A = A;
+    nm.A = A; sm.A = A; tags.A = A; cigar.A = A; seq4.A = A; qual.A = A;
+}
+void Staged::clear() {
+    pos.clear(); flag.clear(); mapq.clear(); lib.clear(); l_qseq.clear(); n_cigar.clear(); cig_off.clear(); seq_off.clear();
+    qual_off.clear(); nm.clear(); sm.clear(); tags.clear(); cigar.clear(); seq4.clear(); qual.clear();
+    n = 0; min_pos = 0; max_end = 0; n_indel_ops = 0;
+}
+void Staged::destroy() {
+    pos.destroy(); flag.destroy(); mapq.destroy(); lib.destroy(); l_qseq.destroy(); n_cigar.destroy(); cig_off.destroy();
+    seq_off.destroy(); qual_off.destroy(); nm.destroy(); sm.destroy(); tags.destroy(); cigar.destroy(); seq4.destroy(); qual.destroy();
+}
+
+int fmt_u32(char* out, uint32_t v) {
+    char t[12]; int n = 0;
+    do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    for (int i = 0; i < n; ++i) out[i] = t[n - 1 - i];
+    return n;
+}
+
+// "%.2f" of the exact binary value, round-half-even: v*100 is exact in double (24+7 significant bits), so
+// nearbyint() of it is the correctly rounded count of hundredths glibc's printf would print.
+int fmt_f2(char* out, float v) {
+    if (!(fabsf(v) < 4.0e13f)) return snprintf(out, 64, "%.2f", (double)v);   // inf / nan / huge: libc path
+    const double s = fabs((double)v * 100.0);
+    uint64_t u = (uint64_t)nearbyint(s);
+    int n = 0;
+    if (signbit(v)) out[n++] = '-';
+    uint64_t ip = u / 100; uint32_t fr = (uint32_t)(u % 100);
+    char t[24]; int m = 0;
+    do { t[m++] = (char)('0' + ip % 10); ip /= 10; } while (ip);
+    while (m) out[n++] = t[--m];
+    out[n++] = '.'; out[n++] = (char)('0' + fr / 10); out[n++] = (char)('0' + fr % 10);
+    return n;
+}
+
+static const char kZeroStat[] = "0:0.00:0.00:0.00:0:0:0.00:0.00:0.00:0:0.00:0.00:0.00";
+
+// operator<<(ostream&, BasicStat) (BasicStat.cpp:110-159)
+static void fmt_stat(std::string& o, const uint32_t* si, const float* sf, bool is_indel) {
+    const uint32_t n = si[I_N];
+    if (n == 0) { o.append(kZeroStat, sizeof(kZeroStat) - 1); return; }
+    char b[512]; int k = 0;
+    const float c = (float)n;
+    k += fmt_u32(b + k, n); b[k++] = ':';
+    k += fmt_f2(b + k, (float)si[I_SMQ] / c); b[k++] = ':';
+    if (is_indel) { memcpy(b + k, "0.00", 4); k += 4; } else k += fmt_f2(b + k, (float)si[I_SBQ] / c);
+    b[k++] = ':';
+    k += fmt_f2(b + k, (float)si[I_SSE] / c); b[k++] = ':';
+    k += fmt_u32(b + k, si[I_PLUS]); b[k++] = ':';
+    k += fmt_u32(b + k, si[I_MINUS]); b[k++] = ':';
+    k += fmt_f2(b + k, sf[F_SEV] / c); b[k++] = ':';
+    k += fmt_f2(b + k, sf[F_SNM] / c); b[k++] = ':';
+    k += fmt_f2(b + k, (float)si[I_SMMQ] / c); b[k++] = ':';
+    k += fmt_u32(b + k, si[I_NQ2]); b[k++] = ':';
+    if (si[I_NQ2] > 0) k += fmt_f2(b + k, sf[F_SQ2] / (float)si[I_NQ2]); else { memcpy(b + k, "0.00", 4); k += 4; }
+    b[k++] = ':';
+    k += fmt_f2(b + k, (float)si[I_SCLIP] / c); b[k++] = ':';
+    k += fmt_f2(b + k, sf[F_S3P] / c);
+    o.append(b, (size_t)k);
+}
+
+}  // namespace brc
+
+using namespace brc;
+
+struct QEnt { uint32_t tid, pos; brc_stat st; std::string allele; };
+
+struct brc_engine {
+    brc_config cfg;
+    std::vector<std::string> libs;
+    Backend* be = nullptr;
+    Staged st;
+    Geometry g;
+    int state = 0;   // 0 idle, 1 region open, 2 uploaded, 3 computed, 4 fetched
+    std::string err;
+    // bam_plp_push max-count emulation
+    int64_t accepted = 0, n_ext = 0; int32_t last_acc_pos = 0; int32_t last_pos = 0;
+    bool heap_built = false;
+    std::priority_queue<int32_t, std::vector<int32_t>, std::greater<int32_t> > live_ends;
+    // fetched result
+    HostPlanes hp;
+    std::vector<brc_indel> indels;
+    std::string alleles;
+    std::vector<char> refbase;
+    // formatter state
+    std::string text;
+    std::vector<std::deque<QEnt> > queue;
+};
+
+static int fail(brc_engine* e, int code, const char* msg) { e->err = msg; return code; }
+
+extern "C" {
+
+const char* brc_strerror(int code) {
+    switch (code) {
+        case BRC_OK: return "ok";
+        case BRC_E_ARG: return "bad argument or call order";
+        case BRC_E_NODEVICE: return "no HIP device / kernels unavailable (the engine has no CPU fallback)";
+        case BRC_E_HIP: return "HIP runtime error";
+        case BRC_E_NOMEM: return "out of memory";
+        case BRC_E_LIMIT: return "engine limit exceeded";
+        default: return "unknown error";
+    }
+}
+const char* brc_last_error(const brc_engine* e) { return e ? e->err.c_str() : ""; }
+const char* brc_kernel_name(int k) { return (k >= 0 && k < BRC_NKERNEL) ? backend_kernel_name(k) : NULL; }
+const char* brc_engine_kind(void) { return backend_kind(); }
+
+int brc_create(const brc_config* cfg, brc_engine** out) {
+    if (!cfg || !out || cfg->abi_version != BRC_ABI_VERSION) return BRC_E_ARG;
+    if (cfg->per_lib && (cfg->n_libs < 0 || (cfg->n_libs > 0 && !cfg->lib_names) || cfg->n_libs > 65000)) return BRC_E_ARG;
+    brc_engine* e = new (std::nothrow) brc_engine();
+    if (!e) return BRC_E_NOMEM;
+    e->cfg = *cfg;
+    if (e->cfg.max_cnt <= 0) e->cfg.max_cnt = 10000000;
+    if (cfg->per_lib) for (int i = 0; i < cfg->n_libs; ++i) e->libs.push_back(cfg->lib_names[i]);
+    e->cfg.lib_names = NULL;
+    e->g.Lp = cfg->per_lib ? (cfg->n_libs > 0 ? cfg->n_libs : 1) : 1;
+    int err = BRC_OK;
+    e->be = make_backend(e->cfg, &err);
+    if (!e->be) { delete e; return err ? err : BRC_E_NODEVICE; }
+    e->st.init(e->be->host_alloc());
+    e->queue.resize((size_t)e->g.Lp);
+    *out = e;
+    return BRC_OK;
+}
+
+void brc_destroy(brc_engine* e) {
+    if (!e) return;
+    e->st.destroy();
+    delete e->be;
+    delete e;
+}
+
+int brc_begin_region(brc_engine* e, int32_t tid, int32_t beg0, int32_t end, const char* ref, int64_t ref_len) {
+    if (!e) return BRC_E_ARG;
+    if (beg0 < 0 || end < beg0 || (ref && ref_len < 0)) return fail(e, BRC_E_ARG, "bad region");
+    e->st.clear();
+    e->g.tid = tid; e->g.beg0 = beg0; e->g.end = end; e->g.ref = ref; e->g.ref_len = ref ? ref_len : 0;
+    e->g.P = 0; e->g.pos0 = 0;
+    e->accepted = 0; e->n_ext = 0; e->last_acc_pos = 0; e->last_pos = INT32_MIN; e->heap_built = false;
+    while (!e->live_ends.empty()) e->live_ends.pop();
+    e->state = 1;
+    return BRC_OK;
+}
+
+static inline int32_t cigar_rlen(const uint32_t* cig, uint32_t nc, uint64_t* n_indel_ops) {
+    int32_t l = 0;
+    for (uint32_t k = 0; k < nc; ++k) {
+        const uint32_t op = cig[k] & 0xfu;
+        if (is_refop(op)) l += (int32_t)(cig[k] >> 4);
+        if (op == CINS || op == CDEL || op == CPAD) ++*n_indel_ops;
+    }
+    return l;
+}
+
+int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
+    if (!e || !b) return BRC_E_ARG;
+    if (e->state != 1) return fail(e, BRC_E_ARG, "brc_push_reads outside an open region");
+    if (b->n_reads < 0) return fail(e, BRC_E_ARG, "negative n_reads");
+    if (e->cfg.per_lib && !b->lib && b->n_reads) return fail(e, BRC_E_ARG, "per-library mode needs brc_read_batch.lib");
+    Staged& s = e->st;
+    const size_t n = (size_t)b->n_reads, n0 = (size_t)s.n;
+    if ((uint64_t)s.n + n >= 0xFFFFFFF0ull || s.cigar.n + b->n_cigar_total >= 0xFFFFFFF0ull)
+        return fail(e, BRC_E_LIMIT, "more than 2^32 reads or CIGAR operators in one region: split the region");
+    const uint64_t cb = s.cigar.n, sb = s.seq4.n, qb = s.qual.n;
+    bool ok = s.pos.append(b->pos, n) && s.flag.append(b->flag, n) && s.mapq.append(b->mapq, n) && s.l_qseq.append(b->l_qseq, n) &&
+              s.n_cigar.append(b->n_cigar, n) && s.cig_off.append(b->cigar_off, n) && s.seq_off.append(b->seq_off, n) &&
+              s.qual_off.append(b->qual_off, n) && s.cigar.append(b->cigar, b->n_cigar_total) &&
+              s.seq4.append(b->seq4, b->seq_bytes) && s.qual.append(b->qual, b->qual_bytes) &&
+              s.lib.reserve(n0 + n + 16) && s.nm.reserve(n0 + n + 16) && s.sm.reserve(n0 + n + 16) && s.tags.reserve(n0 + n + 16);
+    if (!ok) return fail(e, BRC_E_NOMEM, "host staging allocation failed");
+    for (size_t i = 0; i < n; ++i) {
+        s.lib.p[n0 + i] = (e->cfg.per_lib && b->lib) ? b->lib[i] : 0;
+        s.nm.p[n0 + i] = b->nm ? b->nm[i] : 0;
+        s.sm.p[n0 + i] = b->sm ? b->sm[i] : 0;
+        s.tags.p[n0 + i] = b->tags ? b->tags[i] : 0;
+    }
+    s.lib.n = s.nm.n = s.sm.n = s.tags.n = n0 + n;
+    const int32_t maxcnt = e->cfg.max_cnt;
+    for (size_t i = 0; i < n; ++i) {
+        const size_t r = n0 + i;
+        const uint32_t nc = s.n_cigar.p[r];
+        if (b->cigar_off[i] + nc > b->n_cigar_total || b->qual_off[i] + (uint64_t)(s.l_qseq.p[r] > 0 ? s.l_qseq.p[r] : 0) > b->qual_bytes ||
+            b->seq_off[i] + (uint64_t)((s.l_qseq.p[r] + 1) / 2) > b->seq_bytes || s.l_qseq.p[r] < 0)
+            return fail(e, BRC_E_ARG, "read offsets outside the batch arenas");
+        if (e->cfg.per_lib && s.lib.p[r] >= e->g.Lp) return fail(e, BRC_E_ARG, "library index out of range");
+        s.cig_off.p[r] += cb; s.seq_off.p[r] += sb; s.qual_off.p[r] += qb;
+        const int32_t pos = s.pos.p[r];
+        if (pos < e->last_pos) return fail(e, BRC_E_ARG, "reads are not coordinate-sorted");
+        e->last_pos = pos;
+        uint16_t fl = (uint16_t)(s.flag.p[r] & 0x7fffu);
+        const int32_t rlen = cigar_rlen(s.cigar.p + s.cig_off.p[r], nc, &s.n_indel_ops);
+        const int32_t end = (!(fl & FUNMAP) && nc > 0) ? pos + rlen : pos + 1;           // bam_endpos
+        bool accept = !(fl & (FUNMAP | FSECONDARY | FQCFAIL | FDUP)) && pos >= 0;
+        if (accept) {   // region extent: every read that passes the flag mask (max-count drops included)
+            if (e->n_ext == 0) { s.min_pos = pos; s.max_end = end; }
+            else { if (pos < s.min_pos) s.min_pos = pos; if (end > s.max_end) s.max_end = end; }
+            e->n_ext++;
+        }
+        if (accept && e->accepted >= maxcnt) {
+            // bam_plp_push: drop when iter->pos == b->core.pos && mempool count > maxcnt.  iter->pos equals the
+            // start of the last accepted read; live nodes are accepted reads with end >= pos (lazy removal).
+            if (!e->heap_built) {
+                uint64_t dummy = 0;
+                for (size_t j = 0; j < r; ++j) {
+                    const uint16_t f2 = s.flag.p[j];
+                    if (f2 & BRC_PUSH_MASK) continue;
+                    const int32_t rl = cigar_rlen(s.cigar.p + s.cig_off.p[j], s.n_cigar.p[j], &dummy);
+                    e->live_ends.push(s.n_cigar.p[j] > 0 ? s.pos.p[j] + rl : s.pos.p[j] + 1);
+                }
+                e->heap_built = true;
+            }
+            while (!e->live_ends.empty() && e->live_ends.top() < pos) e->live_ends.pop();
+            if (pos == e->last_acc_pos && (int64_t)e->live_ends.size() + 1 > (int64_t)maxcnt) { accept = false; fl |= FHOSTDROP; }
+        }
+        s.flag.p[r] = fl;
+        if (accept) {
+            e->accepted++; e->last_acc_pos = pos;
+            if (e->heap_built) e->live_ends.push(end);
+        }
+    }
+    s.n += (int64_t)n;
+    return BRC_OK;
+}
+
+int brc_upload(brc_engine* e) {
+    if (!e) return BRC_E_ARG;
+    if (e->state != 1) return fail(e, BRC_E_ARG, "brc_upload needs an open region");
+    Geometry& g = e->g; const Staged& s = e->st;
+    int64_t lo = g.beg0 > 0 ? g.beg0 - 1 : 0, hi = g.end;
+    if (e->n_ext == 0) { hi = lo; }
+    else { if (s.min_pos > lo) lo = s.min_pos; if (s.max_end < hi) hi = s.max_end; if (hi < lo) hi = lo; }
+    g.pos0 = (int32_t)lo; g.P = hi - lo;
+    g.ref_lo = g.ref_hi = 0;
+    if (g.ref && e->n_ext) {
+        g.ref_lo = std::min<int64_t>(std::max<int64_t>(s.min_pos, 0), g.ref_len);
+        g.ref_hi = std::min<int64_t>(std::max<int64_t>(s.max_end, g.ref_lo), g.ref_len);
+    }
+    int rc = e->be->upload(e->cfg, s, g);
+    if (rc) return fail(e, rc, e->be->last_error());
+    e->state = 2;
+    return BRC_OK;
+}
+
+int brc_compute(brc_engine* e, brc_timing* t) {
+    if (!e) return BRC_E_ARG;
+    if (e->state < 2) return fail(e, BRC_E_ARG, "brc_compute before brc_upload");
+    int rc = e->be->compute(t);
+    if (rc) return fail(e, rc, e->be->last_error());
+    e->state = 3;
+    return BRC_OK;
+}
+
+int brc_fetch_result(brc_engine* e, brc_result* out) {
+    if (!e || !out) return BRC_E_ARG;
+    if (e->state < 3) return fail(e, BRC_E_ARG, "brc_fetch_result before brc_compute");
+    int rc = e->be->fetch(&e->hp);
+    if (rc) return fail(e, rc, e->be->last_error());
+    const Geometry& g = e->g; const Staged& s = e->st; const HostPlanes& hp = e->hp;
+    // column 3: raw reference character (bamreadcount.cpp:353)
+    e->refbase.resize((size_t)g.P + 1);
+    for (int64_t k = 0; k < g.P; ++k) { const int64_t p = g.pos0 + k; e->refbase[(size_t)k] = (g.ref && p < g.ref_len) ? g.ref[p] : 'N'; }
+    // allele text + std::map<std::string,BasicStat> iteration order (bamreadcount.cpp:323-342, 389-401)
+    std::vector<std::string> txt((size_t)hp.n_indel);
+    for (int64_t i = 0; i < hp.n_indel; ++i) {
+        const IndelOut& o = hp.indel[i];
+        std::string& a = txt[(size_t)i];
+        if (o.len > 0) {
+            a.push_back('+');
+            const uint8_t* seq = s.seq4.p + s.seq_off.p[o.rep_read];
+            const int32_t L = s.l_qseq.p[o.rep_read];
+            for (int j = 0; j < o.len; ++j) { const int q = o.rep_qpos + 1 + j; a.push_back(q < L ? "=ACGTN"[canon_bucket(seqi(seq, q))] : 'N'); }
+        } else {
+            a.push_back('-');
+            for (int j = 0; j < -o.len; ++j) { const int64_t p = (int64_t)o.pos + 1 + j; a.push_back((g.ref && p < g.ref_len) ? g.ref[p] : 'N'); }
+        }
+    }
+    std::vector<uint32_t> ord((size_t)hp.n_indel);
+    for (size_t i = 0; i < ord.size(); ++i) ord[i] = (uint32_t)i;
+    std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) {
+        const IndelOut& a = hp.indel[x]; const IndelOut& b = hp.indel[y];
+        if (a.pos != b.pos) return a.pos < b.pos;
+        if (a.lib != b.lib) return a.lib < b.lib;
+        return txt[x] < txt[y];
+    });
+    e->indels.resize(ord.size()); e->alleles.clear();
+    for (size_t i = 0; i < ord.size(); ++i) {
+        const IndelOut& o = hp.indel[ord[i]]; brc_indel& d = e->indels[i];
+        d.pos = o.pos; d.lib = o.lib; d.len = o.len; d.rep_read = o.rep_read; d.rep_qpos = o.rep_qpos;
+        d.allele_off = (uint32_t)e->alleles.size(); d.allele_len = (uint32_t)txt[ord[i]].size();
+        e->alleles += txt[ord[i]];
+        for (int f = 0; f < BRC_NI; ++f) d.stat.i[f] = o.i[f];
+        for (int f = 0; f < BRC_NF; ++f) d.stat.f[f] = o.f[f];
+    }
+    memset(out, 0, sizeof *out);
+    out->tid = g.tid; out->beg0 = g.beg0; out->end = g.end; out->pos0 = g.pos0; out->n_pos = g.P; out->n_lib = g.Lp;
+    out->ncol = hp.ncol; out->depth = hp.depth; out->istat = hp.istat; out->fstat = hp.fstat;
+    out->unavail = e->cfg.per_lib ? hp.unavail : NULL;
+    out->refbase = e->refbase.data();
+    out->n_indel = (int64_t)e->indels.size(); out->indel = e->indels.data();
+    out->alleles = e->alleles.data(); out->alleles_len = e->alleles.size();
+    out->n_events = hp.n_events;
+    for (int w = 0; w < BRC_N_WARN; ++w) out->warn[w] = hp.warn[w];
+    e->state = 4;
+    return BRC_OK;
+}
+
+int brc_end_region(brc_engine* e, brc_result* out) {
+    int rc = brc_upload(e);
+    if (rc) return rc;
+    rc = brc_compute(e, NULL);
+    if (rc) return rc;
+    return brc_fetch_result(e, out);
+}
+
+int brc_region_counts(brc_engine* e, uint64_t* n_events, uint64_t* n_positions) {
+    if (!e) return BRC_E_ARG;
+    if (e->state < 3) return fail(e, BRC_E_ARG, "brc_region_counts before brc_compute");
+    int rc = e->be->counts(n_events, n_positions);
+    if (rc) return fail(e, rc, e->be->last_error());
+    return BRC_OK;
+}
+
+int brc_clear_indel_queue(brc_engine* e) {
+    if (!e) return BRC_E_ARG;
+    for (size_t l = 0; l < e->queue.size(); ++l) e->queue[l].clear();
+    return BRC_OK;
+}
+
+int brc_format_region(brc_engine* e, const brc_result* r, const char* chrom, const char** text, size_t* text_len) {
+    if (!e || !r || !chrom || !text) return BRC_E_ARG;
+    const int Lp = r->n_lib; const int64_t P = r->n_pos;
+    if ((size_t)Lp != e->queue.size()) return fail(e, BRC_E_ARG, "result does not belong to this engine");
+    std::string& out = e->text; out.clear();
+    std::string rec;
+    const bool per_lib = e->cfg.per_lib != 0;
+    int64_t ii = 0;                         // cursor into the (pos, lib, allele)-sorted indel list
+    const size_t chrom_len = strlen(chrom);
+    char nb[32];
+    uint32_t si[BRC_NI]; float sf[BRC_NF];
+    for (int64_t k = 0; k < P; ++k) {
+        const int32_t pos = r->pos0 + (int32_t)k;
+        while (ii < r->n_indel && r->indel[ii].pos < pos) ++ii;
+        if (per_lib && r->unavail && r->unavail[k] != 0xFFFFFFFFu) continue;            // :281-284: position abandoned
+        uint32_t tot = 0, depth = 0;
+        for (int l = 0; l < Lp; ++l) { tot += r->ncol[(int64_t)l * P + k]; depth += r->depth[(int64_t)l * P + k]; }
+        if (tot == 0) continue;                                                           // no reads: no pileup callback
+        rec.clear();
+        int extra_depth = 0;
+        for (int l = 0; l < Lp; ++l) {
+            if (r->ncol[(int64_t)l * P + k] == 0) continue;                               // lib_counts has no entry (:286,360)
+            if (per_lib) { rec += '\t'; rec += e->libs[(size_t)l]; rec += "\t{"; }
+            for (int b = 0; b < BRC_NBUCKET; ++b) {
+                for (int f = 0; f < BRC_NI; ++f) si[f] = r->istat[(((int64_t)l * BRC_NBUCKET + b) * BRC_NI + f) * P + k];
+                rec += '\t'; rec += "=ACGTN"[b]; rec += ':';
+                if (si[I_N] == 0) { fmt_stat(rec, si, sf, false); continue; }
+                for (int f = 0; f < BRC_NF; ++f) sf[f] = r->fstat[(((int64_t)l * BRC_NBUCKET + b) * BRC_NF + f) * P + k];
+                fmt_stat(rec, si, sf, false);
+            }
+            while (ii < r->n_indel && r->indel[ii].pos == pos && r->indel[ii].lib < l) ++ii;
+            for (; ii < r->n_indel && r->indel[ii].pos == pos && r->indel[ii].lib == l; ++ii) {
+                const brc_indel& d = r->indel[ii];
+                if (d.len < 0) {                                                          // :391-396
+                    QEnt q; q.tid = (uint32_t)r->tid; q.pos = (uint32_t)pos + 1; q.st = d.stat;
+                    q.allele.assign(r->alleles + d.allele_off, d.allele_len);
+                    e->queue[(size_t)l].push_back(q);
+                } else {                                                                  // :399
+                    rec += '\t'; rec.append(r->alleles + d.allele_off, d.allele_len); rec += ':';
+                    fmt_stat(rec, d.stat.i, d.stat.f, true);
+                }
+            }
+            // IndelQueue::process (IndelQueue.cpp:3-15)
+            std::deque<QEnt>& q = e->queue[(size_t)l];
+            while (!q.empty() && ((q.front().tid == (uint32_t)r->tid && q.front().pos < (uint32_t)pos) || q.front().tid != (uint32_t)r->tid)) q.pop_front();
+            while (!q.empty() && q.front().tid == (uint32_t)r->tid && q.front().pos == (uint32_t)pos) {
+                rec += '\t'; rec += q.front().allele; rec += ':';
+                fmt_stat(rec, q.front().st.i, q.front().st.f, true);
+                extra_depth += (int)q.front().st.i[I_N];
+                q.pop_front();
+            }
+            if (per_lib) rec += "\t}";
+        }
+        if (pos >= r->beg0 && pos < r->end) {                                             // :414-416
+            out.append(chrom, chrom_len); out += '\t';
+            out.append(nb, (size_t)fmt_u32(nb, (uint32_t)pos + 1)); out += '\t';
+            out += r->refbase[k]; out += '\t';
+            const int d = (int)depth + extra_depth;
+            out.append(nb, (size_t)snprintf(nb, sizeof nb, "%d", d));
+            out += rec; out += '\n';
+        }
+    }
+    *text = out.c_str();
+    if (text_len) *text_len = out.size();
+    return BRC_OK;
+}
+
+}  // extern "C"

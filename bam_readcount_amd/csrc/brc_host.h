@@ -1,0 +1,103 @@
+// brc_host.h — host side of the engine above the device pipeline (pure C++, no HIP).
+//
+//   Staged        region inputs accumulated by brc_push_reads in (pinned) host memory, offsets rebased
+//   Backend       what the C-ABI glue needs from a device pipeline; the product implements it with HIP
+//                 (brc_engine.hip).  tests/sim/ implements it with the CPU lane simulator — never shipped.
+//   assemble / format   brc_fetch_result's allele ordering and brc_format_region's record assembly
+#ifndef BRC_HOST_H
+#define BRC_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/brc.h"
+#include "brc_core.h"
+
+namespace brc {
+
+struct HostAlloc {
+    void* (*alloc)(size_t bytes);
+    void (*release)(void* p);
+};
+
+// Grow-only host array living in backend-provided (pinned) memory.
+template <class T>
+struct HBuf {
+    T* p = nullptr;
+    size_t n = 0, cap = 0;
+    const HostAlloc* A = nullptr;
+    bool reserve(size_t want) {
+        if (want <= cap) return true;
+        size_t c = cap ? cap : 1024;
+        while (c < want) c += c / 2 + 1024;
+        T* q = (T*)A->alloc(c * sizeof(T));
+        if (!q) return false;
+        if (n) memcpy(q, p, n * sizeof(T));
+        if (p) A->release(p);
+        p = q; cap = c;
+        return true;
+    }
+    bool append(const T* src, size_t k) {
+        if (!reserve(n + k + 16)) return false;
+        if (k) memcpy(p + n, src, k * sizeof(T));
+        n += k;
+        return true;
+    }
+    void clear() { n = 0; }
+    void destroy() { if (p) A->release(p); p = nullptr; n = cap = 0; }
+};
+
+struct Staged {
+    HBuf<int32_t> pos; HBuf<uint16_t> flag; HBuf<uint8_t> mapq; HBuf<int16_t> lib; HBuf<int32_t> l_qseq;
+    HBuf<uint32_t> n_cigar; HBuf<uint64_t> cig_off, seq_off, qual_off; HBuf<int32_t> nm, sm; HBuf<uint8_t> tags;
+    HBuf<uint32_t> cigar; HBuf<uint8_t> seq4, qual;
+    int64_t n = 0;
+    int64_t min_pos = 0, max_end = 0;   // extent of reads that enter the pileup
+    uint64_t n_indel_ops = 0;           // upper bound on indel events (I/D/P operators)
+    void init(const HostAlloc* A);
+    void clear();
+    void destroy();
+};
+
+struct Geometry {
+    int32_t tid = 0, beg0 = 0, end = 0;
+    int32_t pos0 = 0; int64_t P = 0; int Lp = 1;
+    const char* ref = nullptr; int64_t ref_len = 0;
+    int64_t ref_lo = 0, ref_hi = 0;     // slice of the contig the device needs
+};
+
+// Host view of the device results after fetch.
+struct HostPlanes {
+    uint32_t *ncol = nullptr, *depth = nullptr, *istat = nullptr, *unavail = nullptr;
+    float* fstat = nullptr;
+    const IndelOut* indel = nullptr; int64_t n_indel = 0;
+    uint64_t n_events = 0, n_positions = 0;
+    uint64_t warn[BRC_N_WARN] = {0, 0, 0, 0};
+};
+
+class Backend {
+  public:
+    virtual ~Backend() {}
+    virtual const HostAlloc* host_alloc() = 0;
+    virtual int upload(const brc_config& cfg, const Staged& s, const Geometry& g) = 0;   // staging -> device
+    virtual int compute(brc_timing* t) = 0;                                              // whole pipeline, waits
+    virtual int fetch(HostPlanes* out) = 0;                                              // device -> host planes
+    virtual int counts(uint64_t* n_events, uint64_t* n_positions) = 0;
+    virtual const char* last_error() const = 0;
+};
+
+// Provided by exactly one translation unit per library: brc_engine.hip (product) or tests/sim/brc_sim.cpp.
+Backend* make_backend(const brc_config& cfg, int* err);
+const char* backend_kind();
+const char* backend_kernel_name(int k);
+
+// exact "%.2f" of a float (== iostream fixed/setprecision(2), BasicStat.cpp:116); returns bytes written
+int fmt_f2(char* out, float v);
+int fmt_u32(char* out, uint32_t v);
+
+}  // namespace brc
+#endif

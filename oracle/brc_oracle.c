@@ -435,7 +435,6 @@ static void pileup_func(brc_engine* e, uint32_t tid, uint32_t pos, int n, const 
         libcounts* cur = &lc[lib];
         cur->present = 1;                                                                     /* :286 */
         if (in_planes) e->ncol[(int64_t)lib * e->P + k]++;
-        if ((int)pos >= e->beg0) e->n_events++;
         if (!base->is_del && r->mapq >= c->min_mapq && r->qual[base->qpos] >= c->min_bq) {    /* :288 */
             if (r->flag & (FUNMAP | FSECONDARY | FQCFAIL | FDUP)) continue;                   /* :295-310 */
             mapq_n++;                                                                         /* :312 */
@@ -648,13 +647,13 @@ int brc_compute(brc_engine* e, brc_timing* timing) {
     int64_t lo = e->beg0 > 0 ? e->beg0 - 1 : 0, hi = e->end;
     int64_t rmin = INT64_MAX, rmax = -1;
     for (size_t i = 0; i < e->n_reads; ++i) {
+        if (e->reads[i].flag & (FUNMAP | FSECONDARY | FQCFAIL | FDUP)) continue;   /* never enters the pileup */
         int en = read_endpos(&e->reads[i]);
         if (e->reads[i].pos < rmin) rmin = e->reads[i].pos;
         if (en > rmax) rmax = en;
     }
-    if (rmin > lo) lo = rmin;
-    if (rmax < hi) hi = rmax;
-    if (e->n_reads == 0 || hi < lo) hi = lo;
+    if (rmax < 0) { hi = lo; }
+    else { if (rmin > lo) lo = rmin; if (rmax < hi) hi = rmax; if (hi < lo) hi = lo; }
     e->pos0 = (int32_t)lo; e->P = hi - lo;
     size_t P = (size_t)e->P, Lp = (size_t)e->Lp;
     free(e->ncol); free(e->depth); free(e->istat); free(e->fstat); free(e->unavail); free(e->refbase);
@@ -689,6 +688,8 @@ int brc_compute(brc_engine* e, brc_timing* timing) {
     }
     for (size_t l = 0; l < Lp; ++l) free(lc[l].ind);
     free(lc); free(it.list); free(it.plp);
+    /* unit of work: column entries of reported positions */
+    for (size_t l = 0; l < Lp; ++l) for (size_t k = 0; k < P; ++k) if (lo + (int64_t)k >= e->beg0) e->n_events += e->ncol[l * P + k];
     return BRC_OK;
 }
 

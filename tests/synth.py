@@ -1,0 +1,152 @@
+"""Seeded synthetic read batches for parity tests (numpy; small sizes).  Produces brc_read_batch arrays."""
+import numpy as np
+
+NT16 = "=ACMGRSVTWYHKDBN"
+CODE = {c: i for i, c in enumerate(NT16)}
+
+
+def make_ref(rng, length, weird=0.0):
+    ref = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=length)
+    if weird > 0:
+        m = rng.random(length) < weird
+        ref[m] = rng.choice(np.frombuffer(b"acgtNnRYMKswBDHV", np.uint8), size=int(m.sum()))
+    return ref
+
+
+def random_cigar(rng, L, style):
+    """Return list of (op,len) consuming exactly L query bases.  style: 'simple' | 'indel' | 'wild'."""
+    if style == "simple" or L < 8:
+        return [(0, L)]
+    ops = []
+    rem = L
+    if style == "wild" and rng.random() < 0.15:
+        ops.append((5, int(rng.integers(1, 10))))             # H
+    if rng.random() < (0.3 if style == "wild" else 0.08):
+        s = int(rng.integers(1, min(20, rem - 4))); ops.append((4, s)); rem -= s
+    tail_s = 0
+    if rng.random() < (0.3 if style == "wild" else 0.08) and rem > 8:
+        tail_s = int(rng.integers(1, min(20, rem - 4))); rem -= tail_s
+    nseg = int(rng.integers(1, 5 if style == "wild" else 3))
+    first = True
+    while rem > 0:
+        if nseg <= 1 or rem < 4:
+            ops.append((int(rng.choice([0, 0, 0, 7, 8])) if style == "wild" else 0, rem)); rem = 0
+            break
+        m = int(rng.integers(1, rem - 1))
+        ops.append((int(rng.choice([0, 0, 0, 7, 8])) if style == "wild" else 0, m)); rem -= m
+        kind = rng.random()
+        if kind < 0.4:
+            k = int(rng.integers(1, min(6, rem))); ops.append((1, k)); rem -= k            # I
+        elif kind < 0.8:
+            ops.append((2, int(rng.integers(1, 6))))                                        # D
+        elif style == "wild":
+            r = rng.random()
+            if r < 0.4:
+                ops.append((3, int(rng.integers(1, 30))))                                   # N
+            elif r < 0.7 and rem > 2:
+                ops.append((6, int(rng.integers(1, 3))))                                    # P then I
+                k = int(rng.integers(1, min(4, rem))); ops.append((1, k)); rem -= k
+            else:
+                ops.append((2, int(rng.integers(1, 4))))
+                if rem > 2 and rng.random() < 0.5:
+                    k = int(rng.integers(1, min(3, rem))); ops.append((1, k)); rem -= k     # D then I
+        else:
+            ops.append((2, int(rng.integers(1, 4))))
+        nseg -= 1
+        first = False
+    if ops[-1][0] not in (0, 7, 8):      # must end on a match segment before the optional clip
+        ops.append((0, 1)); # steal one base from a previous M if possible
+        for i, (o, l) in enumerate(ops[:-1]):
+            if o in (0, 7, 8) and l > 1:
+                ops[i] = (o, l - 1); break
+        else:
+            ops.pop()
+    if tail_s:
+        ops.append((4, tail_s))
+    if style == "wild" and rng.random() < 0.1:
+        ops.append((5, int(rng.integers(1, 10))))
+    # merge adjacent identical ops
+    out = []
+    for o, l in ops:
+        if out and out[-1][0] == o:
+            out[-1] = (o, out[-1][1] + l)
+        else:
+            out.append((o, l))
+    q = sum(l for o, l in out if o in (0, 1, 4, 7, 8))
+    assert q == L, (out, q, L)
+    return out
+
+
+def make_batch(seed, ref, n_reads, read_len=(30, 120), style="indel", n_libs=1, p_nolib=0.0, p_flagdrop=0.02,
+               p_nonm=0.1, p_sm=0.5, p_q2tail=0.3, mismatch=0.02, region=None, p_iupac_read=0.005):
+    """Coordinate-sorted batch over `ref` (uint8 array).  Returns dict of arrays (see capi.BATCH_DTYPES)."""
+    rng = np.random.default_rng(seed)
+    RL = len(ref)
+    lo, hi = region if region else (0, RL)
+    starts = np.sort(rng.integers(max(lo - 60, 0), max(hi - 1, lo + 1), size=n_reads))
+    pos, flag, mapq, lib, lq, ncig, nm, sm, tags = [], [], [], [], [], [], [], [], []
+    cig_all, seq_all, qual_all, cig_off, seq_off, qual_off = [], [], [], [], [], []
+    co = so = qo = 0
+    for s in starts:
+        L = int(rng.integers(read_len[0], read_len[1] + 1))
+        st = style if style != "mixed" else str(rng.choice(["simple", "simple", "indel", "wild"]))
+        cg = random_cigar(rng, L, st)
+        span = sum(l for o, l in cg if o in (0, 2, 3, 7, 8))
+        # build the read sequence from the reference with mismatches
+        seq = np.empty(L, np.uint8)
+        qp = 0; rp = int(s); nmv = 0
+        for o, l in cg:
+            if o in (0, 7, 8):
+                for j in range(l):
+                    rc = chr(ref[rp + j]).upper() if rp + j < RL else "N"
+                    b = CODE.get(rc, 15)
+                    if rng.random() < mismatch:
+                        b = int(rng.choice([1, 2, 4, 8])); nmv += int(NT16[b] != rc)
+                    seq[qp + j] = b
+                qp += l; rp += l
+            elif o in (1, 4):
+                seq[qp:qp + l] = rng.choice([1, 2, 4, 8], size=l); qp += l
+                if o == 1:
+                    nmv += l
+            elif o in (2, 3):
+                rp += l
+                if o == 2:
+                    nmv += l
+        iu = rng.random(L) < p_iupac_read
+        seq[iu] = rng.choice([0, 3, 5, 15, 15], size=int(iu.sum()))
+        q = np.clip(np.rint(rng.normal(30, 8, L)), 3, 41).astype(np.uint8)
+        if rng.random() < p_q2tail:
+            k = int(rng.integers(1, max(2, L // 3)))
+            if rng.random() < 0.5:
+                q[-k:] = 2
+            else:
+                q[:k] = 2
+        if rng.random() < 0.02:
+            q[:] = 2
+        f = int(rng.choice([99, 147, 83, 163, 65, 129, 121, 0, 16, 97, 145]))
+        if rng.random() < p_flagdrop:
+            f |= int(rng.choice([4, 256, 512, 1024]))
+        if rng.random() < 0.01:
+            f |= 2048
+        pos.append(int(s)); flag.append(f)
+        mapq.append(int(rng.choice([60, 60, 60, 47, 29, 13, 0, 255, int(rng.integers(0, 60))])))
+        lib.append(-1 if rng.random() < p_nolib else int(rng.integers(0, max(1, n_libs))))
+        lq.append(L); ncig.append(len(cg))
+        t = 0
+        if rng.random() >= p_nonm:
+            t |= 1
+        if rng.random() < p_sm:
+            t |= 2
+        tags.append(t); nm.append(nmv if (t & 1) else 0); sm.append(int(rng.integers(0, 61)) if (t & 2) else 0)
+        cig_off.append(co); seq_off.append(so); qual_off.append(qo)
+        cig_all.extend([(l << 4) | o for o, l in cg]); co += len(cg)
+        if L & 1:
+            seq = np.append(seq, 0)
+        seq_all.append(((seq[0::2] << 4) | seq[1::2]).astype(np.uint8)); so += (L + 1) // 2
+        qual_all.append(q); qo += L
+    return dict(pos=np.array(pos, np.int32), flag=np.array(flag, np.uint16), mapq=np.array(mapq, np.uint8),
+                lib=np.array(lib, np.int16), l_qseq=np.array(lq, np.int32), n_cigar=np.array(ncig, np.uint32),
+                cigar_off=np.array(cig_off, np.uint64), seq_off=np.array(seq_off, np.uint64), qual_off=np.array(qual_off, np.uint64),
+                nm=np.array(nm, np.int32), sm=np.array(sm, np.int32), tags=np.array(tags, np.uint8),
+                cigar=np.array(cig_all, np.uint32), seq4=np.concatenate(seq_all) if seq_all else np.zeros(0, np.uint8),
+                qual=np.concatenate(qual_all) if qual_all else np.zeros(0, np.uint8))

@@ -1,0 +1,109 @@
+"""CPU-only checks of the DEVICE algorithm (bam_readcount_amd/csrc/brc_core.h run lane-by-lane by tests/sim)
+and the host formatter against the oracle and the reference goldens.  The GPU parity tests (test_gpu_parity.py)
+repeat these through the HIP library."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from bam_readcount_amd import capi
+from conftest import ROOT
+import parity
+import synth
+from test_oracle_golden import CASES, golden, run_case
+
+
+@pytest.fixture(scope="session")
+def sim_lib():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    return capi.Library(os.path.join(ROOT, "tests", "sim", "libbrc_sim.so"))
+
+
+@pytest.mark.parametrize("name,opts,bad_rg", CASES)
+def test_sim_matches_reference_goldens(sim_lib, test_bam, name, opts, bad_rg):
+    text, _ = run_case(sim_lib, test_bam, opts, bad_rg)
+    assert text == golden(name)
+
+
+def test_sim_full_window_of_test_bam_equals_oracle(sim_lib, oracle_lib, test_bam):
+    # 21:10402737-10405248 -> 796 emitted lines, sum of depths 96243
+    names = [str(s) for s in test_bam["lib_names"]]
+    for per_lib in (False, True):
+        for ic in (False, True):
+            text, res = parity.compare_libs(sim_lib, oracle_lib, test_bam, [(10402736, 10405248)], tid=20, chrom="21",
+                                            ref=test_bam["ref"], lib_names=names if per_lib else (), per_lib=per_lib,
+                                            insertion_centric=ic)
+            lines = text.decode().splitlines()
+            assert len(lines) == 796
+            assert sum(int(l.split("\t")[3]) for l in lines) == 96243
+
+
+FUZZ = [
+    dict(seed=1, style="simple", n=300, opts=dict()),
+    dict(seed=2, style="indel", n=400, opts=dict()),
+    dict(seed=3, style="wild", n=400, opts=dict()),
+    dict(seed=4, style="wild", n=400, opts=dict(min_mapq=20, min_bq=13)),
+    dict(seed=5, style="mixed", n=500, opts=dict(insertion_centric=True)),
+    dict(seed=6, style="wild", n=400, opts=dict(per_lib=True), n_libs=3),
+    dict(seed=7, style="wild", n=400, opts=dict(per_lib=True, insertion_centric=True, min_mapq=10, min_bq=5), n_libs=4, p_nolib=0.01),
+    dict(seed=8, style="mixed", n=600, opts=dict(per_lib=True), n_libs=2, p_nolib=0.2),
+    dict(seed=9, style="wild", n=300, opts=dict(min_bq=30), weird=0.1),
+    dict(seed=10, style="indel", n=50, opts=dict()),
+]
+
+
+@pytest.mark.parametrize("case", FUZZ, ids=lambda c: "seed%d-%s" % (c["seed"], c["style"]))
+def test_sim_fuzz_equals_oracle(sim_lib, oracle_lib, case):
+    rng = np.random.default_rng(case["seed"])
+    ref = synth.make_ref(rng, 3000, weird=case.get("weird", 0.0))
+    n_libs = case.get("n_libs", 1)
+    arrs = synth.make_batch(case["seed"] + 100, ref, case["n"], style=case["style"], n_libs=n_libs,
+                            p_nolib=case.get("p_nolib", 0.0))
+    names = ["lib%c" % (65 + i) for i in range(n_libs)] if case["opts"].get("per_lib") else ()
+    regions = [(0, 3000), (100, 101), (700, 1500), (2990, 3200), (1500, 1500)]
+    nolib = case.get("p_nolib", 0.0) > 0
+    parity.compare_libs(sim_lib, oracle_lib, arrs, regions, ref=ref, lib_names=names, check_warn=not nolib, **case["opts"])
+
+
+def test_sim_without_reference(sim_lib, oracle_lib):
+    rng = np.random.default_rng(77)
+    ref = synth.make_ref(rng, 1000)
+    arrs = synth.make_batch(78, ref, 150, style="indel")
+    parity.compare_libs(sim_lib, oracle_lib, arrs, [(0, 1000)], ref=None)
+
+
+def test_sim_empty_and_ragged(sim_lib, oracle_lib):
+    rng = np.random.default_rng(5)
+    ref = synth.make_ref(rng, 500)
+    arrs = synth.make_batch(6, ref, 40, style="indel", region=(200, 300))
+    # empty region (no reads overlap), region before/after all reads, single base, zero reads pushed
+    text, res = parity.compare_libs(sim_lib, oracle_lib, arrs, [(0, 50), (480, 500), (250, 251), (0, 500)], ref=ref)
+    assert res[0].n_pos == 0
+    empty = capi.select_reads(arrs, [])
+    parity.compare_libs(sim_lib, oracle_lib, empty, [(0, 100)], ref=ref)
+
+
+def test_sim_max_count(sim_lib, oracle_lib):
+    rng = np.random.default_rng(11)
+    ref = synth.make_ref(rng, 400)
+    arrs = synth.make_batch(12, ref, 300, style="simple", region=(100, 110), read_len=(50, 60))
+    arrs["pos"] = np.sort(np.where(np.arange(300) % 3 == 0, 100, arrs["pos"])).astype(np.int32)
+    for d in (1, 5, 40):
+        parity.compare_libs(sim_lib, oracle_lib, arrs, [(90, 200)], ref=ref, max_cnt=d)
+
+
+def test_fmt_f2_matches_printf(sim_lib):
+    import ctypes as C
+    lib = C.CDLL(sim_lib.path)
+    f = getattr(lib, "_ZN3brc6fmt_f2EPcf")
+    f.argtypes = [C.c_char_p, C.c_float]; f.restype = C.c_int
+    rng = np.random.default_rng(3)
+    vals = np.concatenate([rng.random(20000).astype(np.float32) * np.float32(10.0) ** rng.integers(-4, 6, 20000),
+                           np.array([0.0, -0.0, 0.005, 0.015, 0.025, 0.125, 0.375, 2.675, 1e9, 237.765, -0.001, -1.005, 0.994999,
+                                     np.inf, -np.inf, np.nan, 3.4e38, 1e-30, 52.805, 0.495, 0.505], np.float32),
+                           (np.arange(0, 4000, dtype=np.float32) * np.float32(0.005))]).astype(np.float32)
+    buf = C.create_string_buffer(128)
+    for v in vals:
+        n = f(buf, C.c_float(float(v)))
+        assert buf.raw[:n].decode() == "%.2f" % float(np.float32(v)), float(v)
