@@ -217,26 +217,42 @@ BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i) {
 
 // ---------------------------------------------------------------- BasicStat::process_read for one event
 
-// BasicStat.cpp:28-107 with the Zm string round trip removed.  ai = NACC_I integers, af = NF floats of ONE bucket.
+// BasicStat.cpp:28-107 with the Zm string round trip removed, split in two so that the divisions are evaluated once
+// per event (event_terms) and only the adds sit under the bucket dispatch (acc_apply).
 // All float arithmetic is fp32 round-to-nearest exactly where the reference's is, and the event-location sum goes
 // through double exactly like `float += 1.0 - float_expr` (BasicStat.cpp:69-70).  Build with -ffp-contract=off.
-BRC_HD void acc_event(uint32_t* ai, float* af, const DRead& r, int qpos, uint32_t q, bool is_indel) {
+struct EvTerms { float q2, s3p; double sev; };
+
+BRC_HD EvTerms event_terms(const DRead& r, int qpos) {
+    EvTerms t;
+    const float Lf = (float)r.l_qseq;
+    t.q2 = (float)iabs(qpos - r.q2) / Lf;                               // BasicStat.cpp:62
+    t.s3p = (float)iabs(qpos - r.tp) / Lf;                              // :66
+    const float center = (float)r.clipped * 0.5f;                       // :69  (float)clipped_length/2.0, exact
+    float d = (float)(qpos - r.left) - center;
+    d = d < 0.0f ? -d : d;
+    t.sev = 1.0 - (double)(d / center);                                 // :70  double expression
+    return t;
+}
+
+// ai = NACC_I integers, af = NF floats of ONE bucket.
+BRC_HD void acc_apply(uint32_t* ai, float* af, const DRead& r, const EvTerms& t, uint32_t q, bool is_indel) {
     const uint32_t m = r.misc;
     ai[A_SMQ] += (m >> 8) & 0xffu;
     if (m & M_REV) ai[A_MINUS]++; else ai[A_PLUS]++;
     ai[A_SMMQ] += r.zm_sum;
-    const float Lf = (float)r.l_qseq;
-    if (m & M_Q2OK) { af[F_SQ2] += (float)iabs(qpos - r.q2) / Lf; ai[A_NQ2]++; }
-    af[F_S3P] += (float)iabs(qpos - r.tp) / Lf;
+    if (m & M_Q2OK) { af[F_SQ2] += t.q2; ai[A_NQ2]++; }
+    af[F_S3P] += t.s3p;
     ai[A_SCLIP] += (uint32_t)r.clipped;
-    const float center = (float)r.clipped * 0.5f;                       // (float)clipped_length/2.0, exact
-    float d = (float)(qpos - r.left) - center;
-    d = d < 0.0f ? -d : d;
-    const float t = d / center;
-    af[F_SEV] = (float)((double)af[F_SEV] + (1.0 - (double)t));
+    af[F_SEV] = (float)((double)af[F_SEV] + t.sev);
     ai[A_SSE] += r.sse_add;
     if (!(m & M_NMW)) af[F_SNM] += r.snm_add;
     if (!is_indel) ai[A_SBQ] += q;
+}
+
+BRC_HD void acc_event(uint32_t* ai, float* af, const DRead& r, int qpos, uint32_t q, bool is_indel) {
+    const EvTerms t = event_terms(r, qpos);
+    acc_apply(ai, af, r, t, q, is_indel);
 }
 
 // ---------------------------------------------------------------- htslib resolve_cigar2 as a pure function of (read, position)
@@ -326,13 +342,14 @@ BRC_HD void lane_visit_read(const DevCfg& c, const DevIn& in, const DRead& rd, u
         const uint32_t b = canon_bucket(seqi(in.seq4 + rd.seq_off, qpos));
         if (rd.misc & M_SMW) a.w_sm++;
         if (rd.misc & M_NMW) a.w_nm++;
+        const EvTerms t = event_terms(rd, qpos);
         switch (b) {                                                    // static indices keep the 6 buckets in registers
-            case 0: acc_event(a.ai[0], a.af[0], rd, qpos, q, false); break;
-            case 1: acc_event(a.ai[1], a.af[1], rd, qpos, q, false); break;
-            case 2: acc_event(a.ai[2], a.af[2], rd, qpos, q, false); break;
-            case 3: acc_event(a.ai[3], a.af[3], rd, qpos, q, false); break;
-            case 4: acc_event(a.ai[4], a.af[4], rd, qpos, q, false); break;
-            default: acc_event(a.ai[5], a.af[5], rd, qpos, q, false); break;
+            case 0: acc_apply(a.ai[0], a.af[0], rd, t, q, false); break;
+            case 1: acc_apply(a.ai[1], a.af[1], rd, t, q, false); break;
+            case 2: acc_apply(a.ai[2], a.af[2], rd, t, q, false); break;
+            case 3: acc_apply(a.ai[3], a.af[3], rd, t, q, false); break;
+            case 4: acc_apply(a.ai[4], a.af[4], rd, t, q, false); break;
+            default: acc_apply(a.ai[5], a.af[5], rd, t, q, false); break;
         }
     }
 }

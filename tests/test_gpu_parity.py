@@ -1,0 +1,113 @@
+"""Parity tests proper: the HIP engine (through the C-ABI) against the reference goldens and the CPU oracle.
+Integer planes bit-exact, fp32 planes bit-exact (order-preserving sums; the north_star tolerance is 1e-6 relative),
+text byte-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from bam_readcount_amd import capi
+import parity
+import synth
+from test_oracle_golden import CASES, golden, run_case
+from test_sim_parity import FUZZ
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,opts,bad_rg", CASES)
+def test_hip_matches_reference_goldens(hip_lib, test_bam, name, opts, bad_rg):
+    text, _ = run_case(hip_lib, test_bam, opts, bad_rg)
+    assert text == golden(name)
+
+
+def test_hip_regions_on_cmdline(hip_lib, test_bam):
+    text, _ = run_case(hip_lib, test_bam, dict(per_lib=False, insertion_centric=False), False, site_mode=False)
+    assert text == golden("expected_all_lib")
+
+
+def test_hip_full_window_of_test_bam_equals_oracle(hip_lib, oracle_lib, test_bam):
+    names = [str(s) for s in test_bam["lib_names"]]
+    for per_lib in (False, True):
+        for ic in (False, True):
+            text, _ = parity.compare_libs(hip_lib, oracle_lib, test_bam, [(10402736, 10405248)], tid=20, chrom="21",
+                                          ref=test_bam["ref"], lib_names=names if per_lib else (), per_lib=per_lib,
+                                          insertion_centric=ic)
+            assert text.count(b"\n") == 796
+
+
+def test_hip_twolib_cram_fixture(hip_lib, oracle_lib, twolib):
+    # BASELINE config 2(ii): twolib.sorted.cram -p -i, site list "rand1k 50 60" -> 11 lines, GPU vs oracle (no reference golden exists)
+    names = [str(s) for s in twolib["lib_names"]]
+    text, res = parity.compare_libs(hip_lib, oracle_lib, twolib, [(49, 60)], tid=0, chrom="rand1k", ref=twolib["ref"],
+                                    lib_names=names, per_lib=True, insertion_centric=True, ref_len_check=True)
+    lines = text.decode().splitlines()
+    assert len(lines) == 11
+    assert lines[0].startswith("rand1k\t50\tA\t1\treads1_lb\t{") and lines[0].endswith("\t}")
+    assert "A:1:60.00:255.00:60.00:1:0:0.37:0.00:0.00:1:0.15:60.00:0.15" in lines[0]
+    assert res[0].warn[capi.NWARN - 3] == 11                                                # 11 NM-missing warnings
+
+
+@pytest.mark.parametrize("case", FUZZ, ids=lambda c: "seed%d-%s" % (c["seed"], c["style"]))
+def test_hip_fuzz_equals_oracle(hip_lib, oracle_lib, case):
+    rng = np.random.default_rng(case["seed"])
+    ref = synth.make_ref(rng, 3000, weird=case.get("weird", 0.0))
+    n_libs = case.get("n_libs", 1)
+    arrs = synth.make_batch(case["seed"] + 100, ref, case["n"], style=case["style"], n_libs=n_libs, p_nolib=case.get("p_nolib", 0.0))
+    names = ["lib%c" % (65 + i) for i in range(n_libs)] if case["opts"].get("per_lib") else ()
+    regions = [(0, 3000), (100, 101), (700, 1500), (2990, 3200), (1500, 1500)]
+    nolib = case.get("p_nolib", 0.0) > 0
+    parity.compare_libs(hip_lib, oracle_lib, arrs, regions, ref=ref, lib_names=names, check_warn=not nolib, **case["opts"])
+
+
+def test_hip_edge_cases(hip_lib, oracle_lib):
+    rng = np.random.default_rng(5)
+    ref = synth.make_ref(rng, 500)
+    arrs = synth.make_batch(6, ref, 40, style="indel", region=(200, 300))
+    parity.compare_libs(hip_lib, oracle_lib, arrs, [(0, 50), (480, 500), (250, 251), (0, 500)], ref=ref)
+    parity.compare_libs(hip_lib, oracle_lib, capi.select_reads(arrs, []), [(0, 100)], ref=ref)
+    parity.compare_libs(hip_lib, oracle_lib, arrs, [(0, 500)], ref=None)
+    a2 = synth.make_batch(12, ref, 300, style="simple", region=(100, 110), read_len=(50, 60))
+    a2["pos"] = np.sort(np.where(np.arange(300) % 3 == 0, 100, a2["pos"])).astype(np.int32)
+    for d in (1, 5, 40):
+        parity.compare_libs(hip_lib, oracle_lib, a2, [(90, 200)], ref=ref, max_cnt=d)
+
+
+def test_hip_is_deterministic_and_repeatable(hip_lib):
+    rng = np.random.default_rng(99)
+    ref = synth.make_ref(rng, 20000)
+    arrs = synth.make_batch(100, ref, 6000, style="mixed", n_libs=3)
+    eng = capi.Engine(hip_lib, per_lib=True, lib_names=["a", "b", "c"])
+    eng.begin_region(0, 0, 20000, ref); eng.push_reads(arrs); eng.upload()
+    eng.compute(); r1 = eng.fetch_result(); t1 = eng.format_region("x")
+    eng.compute(); r2 = eng.fetch_result(); t2 = eng.format_region("x")
+    parity.assert_results_equal(r1, r2, "repeat")
+    assert t1 == t2
+    eng.close()
+
+
+def test_hip_wgs_sample_equals_oracle_and_full_size_properties(hip_lib, oracle_lib):
+    """BASELINE config 3 data model at reduced contig length vs the oracle, then size-independent properties on a larger
+    contig: (i) tiling invariance — the same contig computed as one region and as abutting sub-regions gives the
+    same planes; (ii) conservation — sum of ncol over positions == sum over reads of in-window reference span."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import synthgen as gen
+    ref, arrs = gen.generate(300_000, "wgs30x", seed=3, n_chunks=16)
+    parity.compare_libs(hip_lib, oracle_lib, arrs, [(0, 300_000)], ref=ref, min_mapq=20, min_bq=13)
+    ref, arrs = gen.generate(8_000_000, "wgs30x", seed=5, n_chunks=64)
+    eng = capi.Engine(hip_lib, min_mapq=20, min_bq=13)
+    eng.begin_region(0, 0, 8_000_000, ref); eng.push_reads(arrs); whole = eng.end_region()
+    ends = capi.read_ends(arrs)
+    span = (np.minimum(ends, 8_000_000) - np.maximum(arrs["pos"].astype(np.int64), 0)).clip(min=0).sum()
+    assert int(whole.ncol.sum(dtype=np.uint64)) == int(span) == whole.n_events
+    cuts = [0, 1_000_001, 1_000_002, 4_194_304, 8_000_000]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        idx = capi.fetch_overlapping(arrs, ends, a - 1, b)
+        eng.begin_region(0, a, b, ref); eng.push_reads(capi.select_reads(arrs, idx)); part = eng.end_region()
+        lo = a - whole.pos0; off = a - part.pos0
+        n = b - a
+        np.testing.assert_array_equal(part.istat[..., off:off + n], whole.istat[..., lo:lo + n])
+        np.testing.assert_array_equal(part.fstat[..., off:off + n].view(np.uint32), whole.fstat[..., lo:lo + n].view(np.uint32))
+        np.testing.assert_array_equal(part.depth[:, off:off + n], whole.depth[:, lo:lo + n])
+    eng.close()

@@ -1,0 +1,70 @@
+"""ctypes wrapper of tools/synth_gen.c (bench / full-size test infrastructure)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libsynth.so")
+
+
+class Params(C.Structure):
+    _fields_ = [("contig_len", C.c_int64), ("n_reads", C.c_int64), ("read_len", C.c_int32), ("n_libs", C.c_int32),
+                ("seed", C.c_uint64), ("p_sub", C.c_double), ("p_clip", C.c_double), ("p_ins", C.c_double), ("p_del", C.c_double),
+                ("indel_max", C.c_int32), ("n_chunks", C.c_int32)]
+
+
+def build():
+    src = os.path.join(HERE, "synth_gen.c")
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-std=c99", "-fopenmp", "-fPIC", "-shared", src, "-o", LIB, "-lm"])
+    return LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+    return _lib
+
+
+# the BASELINE.json configurations
+CONFIGS = {
+    # config 3: 30x, 150 bp, one contig
+    "wgs30x": dict(depth=30.0, read_len=150, n_libs=1, p_sub=0.005, p_clip=0.05, p_ins=0.01, p_del=0.01, indel_max=3),
+    # config 5: 200x tumour, 4 libraries, 10 % of reads carry one I or D of length U[1,10]
+    "tumor200x": dict(depth=200.0, read_len=150, n_libs=4, p_sub=0.005, p_clip=0.05, p_ins=0.05, p_del=0.05, indel_max=10),
+}
+
+
+def generate(contig_len, config="wgs30x", seed=1, n_chunks=64):
+    """Returns (ref uint8[contig_len], arrays dict in brc_read_batch layout)."""
+    cfg = CONFIGS[config]
+    L = cfg["read_len"]
+    n = int(round(contig_len * cfg["depth"] / L))
+    ref = np.empty(contig_len, np.uint8)
+    lib().synth_ref(ref.ctypes.data_as(C.c_void_p), C.c_int64(contig_len), C.c_uint64(seed))
+    a = dict(pos=np.empty(n, np.int32), flag=np.empty(n, np.uint16), mapq=np.empty(n, np.uint8), lib=np.empty(n, np.int16),
+             l_qseq=np.empty(n, np.int32), n_cigar=np.empty(n, np.uint32), cigar_off=np.empty(n, np.uint64),
+             seq_off=np.empty(n, np.uint64), qual_off=np.empty(n, np.uint64), nm=np.empty(n, np.int32), sm=np.empty(n, np.int32),
+             tags=np.empty(n, np.uint8), cigar=np.empty(3 * n, np.uint32), seq4=np.empty(n * ((L + 1) // 2), np.uint8),
+             qual=np.empty(n * L, np.uint8))
+    p = Params(contig_len, n, L, cfg["n_libs"], seed + 1, cfg["p_sub"], cfg["p_clip"], cfg["p_ins"], cfg["p_del"], cfg["indel_max"], n_chunks)
+    order = ["pos", "flag", "mapq", "lib", "l_qseq", "n_cigar", "cigar_off", "seq_off", "qual_off", "nm", "sm", "tags", "cigar", "seq4", "qual"]
+    rc = lib().synth_reads(C.byref(p), ref.ctypes.data_as(C.c_void_p), *[a[k].ctypes.data_as(C.c_void_p) for k in order])
+    if rc != 0:
+        raise RuntimeError("synth_reads failed: %d" % rc)
+    return ref, a
+
+
+def algorithmic_bytes(arrs, n_positions, n_libs_printed, n_indel_buckets=0, ref_positions=None):
+    """B_in + B_ref + B_out (compulsory HBM traffic of the path, implementation independent)."""
+    L = arrs["l_qseq"].astype(np.int64)
+    b_in = int((32 + 4 * arrs["n_cigar"].astype(np.int64) + (L + 1) // 2 + L).sum())
+    b_ref = int(ref_positions if ref_positions is not None else n_positions)
+    b_out = 312 * int(n_positions) * int(n_libs_printed) + 52 * int(n_indel_buckets)
+    return b_in, b_ref, b_out
