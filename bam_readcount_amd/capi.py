@@ -49,7 +49,7 @@ class Indel(C.Structure):
 
 class Result(C.Structure):
     _fields_ = [("tid", C.c_int32), ("beg0", C.c_int32), ("end", C.c_int32), ("pos0", C.c_int32), ("n_pos", C.c_int64),
-                ("n_lib", C.c_int32), ("ncol", C.POINTER(C.c_uint32)), ("depth", C.POINTER(C.c_uint32)),
+                ("stride", C.c_int64), ("n_lib", C.c_int32), ("ncol", C.POINTER(C.c_uint32)), ("depth", C.POINTER(C.c_uint32)),
                 ("istat", C.POINTER(C.c_uint32)), ("fstat", C.POINTER(C.c_float)), ("unavail", C.POINTER(C.c_uint32)),
                 ("refbase", C.POINTER(C.c_char)), ("n_indel", C.c_int64), ("indel", C.POINTER(Indel)),
                 ("alleles", C.POINTER(C.c_char)), ("alleles_len", C.c_uint64), ("n_events", C.c_uint64),
@@ -165,11 +165,15 @@ class RegionResult:
         P, L = int(r.n_pos), int(r.n_lib)
         self.tid, self.beg0, self.end, self.pos0, self.n_pos, self.n_lib = r.tid, r.beg0, r.end, r.pos0, P, L
 
+        S = int(r.stride)
+
         def arr(ptr, shape, dt):
-            n = int(np.prod(shape))
-            if n == 0 or not ptr:
+            """planes are `stride` elements apart; keep the P valid ones"""
+            if int(np.prod(shape)) == 0 or not ptr:
                 return np.zeros(shape, dt)
-            return np.ctypeslib.as_array(ptr, shape=(n,)).view(dt).reshape(shape).copy()
+            full = shape[:-1] + (S,)
+            a = np.ctypeslib.as_array(ptr, shape=(int(np.prod(full)),)).view(dt).reshape(full)
+            return a[..., :shape[-1]].copy()
 
         self.ncol = arr(r.ncol, (L, P), np.uint32)
         self.depth = arr(r.depth, (L, P), np.uint32)

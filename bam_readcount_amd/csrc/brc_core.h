@@ -50,7 +50,8 @@ struct DevCfg {
     int32_t min_mapq, min_bq, per_lib, insertion_centric, Lp, ref_len_check, has_ref;
     int32_t beg0, end;      // reporting window [beg0,end)
     int32_t pos0;           // reference position of plane index 0
-    int64_t P;              // plane length
+    int64_t P;              // plane length (positions)
+    int64_t PS;             // plane stride in elements: P rounded up to 64 so every wave's plane store is one aligned 256-B segment
     int64_t ref_lo, ref_hi; // the device reference slice holds contig positions [ref_lo, ref_hi)
     int64_t ref_len;        // contig length (positions >= ref_len read as NUL)
     int64_t n_reads;
@@ -62,20 +63,22 @@ struct DevIn {
     const uint32_t* n_cigar; const uint64_t* cig_off; const uint64_t* seq_off; const uint64_t* qual_off;
     const int32_t* nm; const int32_t* sm; const uint8_t* tags;
     const uint32_t* cigar; const uint8_t* seq4; const uint8_t* qual; const char* ref;
+    // device-produced by K1, indexed like qual[]: per base  quality | bucket("=ACGTN") << 8
+    const uint16_t* bq;
 };
 
-// Packed per-read record written by K1 and read with scalar loads by KB (80 bytes).
+// Packed per-read record written by K1 and read with ONE scalar load (s_load_dwordx16) by KB: 64 bytes.
 enum { M_REV = 1, M_Q2OK = 2, M_SMW = 4, M_NMW = 8, M_SIMPLE = 16 };
-struct DRead {
+struct alignas(64) DRead {
     int32_t pos, end;          // [pos,end) on the reference; end == pos when the read never enters a column
     uint32_t cig_off, n_cigar;
-    uint64_t qual_off, seq_off;
+    uint64_t bq_off;           // index of the read's first base in bq[] (== its qual_off)
     uint32_t misc;             // M_* | mapq << 8 | (lib + 1) << 16   (lib + 1 == 0: library unavailable)
     int32_t l_qseq;
     int32_t q2, tp, left, clipped;   // Zm: q2_pos, three_prime_index, left_clip, clipped_length
     uint32_t zm_sum, sse_add;        // Zm sum_of_mismatch_qualities; per-event addend of sum_single_ended_map_qualities
     float snm_add;                   // per-event addend of sum_number_of_mismatches: NM / (float)clipped_length
-    uint32_t pad0, pad1, pad2;
+    uint32_t pad0;
 };
 
 // One indel event, produced by the per-read enumeration, consumed by the per-key reduction (16 bytes).
@@ -84,11 +87,11 @@ struct IndelEv { uint32_t read; int32_t qpos; int32_t len; uint32_t key_lo; };
 struct IndelOut { int32_t pos, lib, len; uint32_t rep_read; int32_t rep_qpos; uint32_t i[NI]; float f[NF]; };
 
 struct Planes {
-    uint32_t* ncol;    // [Lp][P]
-    uint32_t* depth;   // [Lp][P]
-    uint32_t* istat;   // [Lp][6][9][P]
-    float* fstat;      // [Lp][6][4][P]
-    uint32_t* unavail; // [P]
+    uint32_t* ncol;    // [Lp][PS]
+    uint32_t* depth;   // [Lp][PS]
+    uint32_t* istat;   // [Lp][6][9][PS]
+    float* fstat;      // [Lp][6][4][PS]
+    uint32_t* unavail; // [PS]
 };
 
 // ---------------------------------------------------------------- small tables as packed constants
@@ -121,7 +124,7 @@ BRC_HD uint32_t ref_at(const DevCfg& c, const char* ref, int64_t p) {
 // ---------------------------------------------------------------- K1: per-read annotation (fetch_func)
 
 // Restates bamreadcount.cpp:114-256 for read i and packs everything KB needs into a DRead.
-BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i) {
+BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i, uint16_t* bq_out) {
     DRead r;
     const int32_t pos = in.pos[i];
     const uint32_t flag = in.flag[i];
@@ -196,8 +199,9 @@ BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i) {
     r.end = dropped ? pos : pos + rlen;
     r.cig_off = (uint32_t)in.cig_off[i];
     r.n_cigar = nc;
-    r.qual_off = in.qual_off[i];
-    r.seq_off = in.seq_off[i];
+    r.bq_off = in.qual_off[i];
+    // per-base stream for KB: quality | bucket << 8
+    for (int j = 0; j < L; ++j) bq_out[in.qual_off[i] + (uint64_t)j] = (uint16_t)(qual[j] | (canon_bucket(seqi(seq, j)) << 8));
     const int lib = c.per_lib ? (int)in.lib[i] : 0;
     uint32_t misc = (mapq << 8) | ((uint32_t)((lib + 1) & 0xffff) << 16);
     if (rev) misc |= M_REV;
@@ -211,7 +215,7 @@ BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i) {
     if (tags & 1u) snm = (float)in.nm[i] / (float)clipped;                                   // BasicStat.cpp:94-97
     else misc |= M_NMW;
     r.misc = misc; r.l_qseq = L; r.q2 = q2; r.tp = tp; r.left = left_clip; r.clipped = clipped;
-    r.zm_sum = sum; r.sse_add = sse; r.snm_add = snm; r.pad0 = r.pad1 = r.pad2 = 0;
+    r.zm_sum = sum; r.sse_add = sse; r.snm_add = snm; r.pad0 = 0;
     return r;
 }
 
@@ -239,7 +243,10 @@ BRC_HD EvTerms event_terms(const DRead& r, int qpos) {
 BRC_HD void acc_apply(uint32_t* ai, float* af, const DRead& r, const EvTerms& t, uint32_t q, bool is_indel) {
     const uint32_t m = r.misc;
     ai[A_SMQ] += (m >> 8) & 0xffu;
-    if (m & M_REV) ai[A_MINUS]++; else ai[A_PLUS]++;
+    // branch-free on purpose: an if/else over two different accumulators becomes a select-of-pointers in LLVM, which
+    // blocks scalar replacement of the accumulator struct and sends all 78 accumulators to scratch memory
+    const uint32_t rev = m & M_REV;
+    ai[A_MINUS] += rev; ai[A_PLUS] += 1u - rev;
     ai[A_SMMQ] += r.zm_sum;
     if (m & M_Q2OK) { af[F_SQ2] += t.q2; ai[A_NQ2]++; }
     af[F_S3P] += t.s3p;
@@ -302,65 +309,91 @@ struct LaneAcc {
     uint32_t w_sm, w_nm;      // process_read-level warning counts of this lane
 };
 
+#if defined(__clang__)
+#define BRC_UNROLL _Pragma("unroll")
+#else
+#define BRC_UNROLL _Pragma("GCC unroll 16")
+#endif
+
 BRC_HD void lane_init(LaneAcc& a) {
+    BRC_UNROLL
     for (int b = 0; b < NBUCKET; ++b) {
+        BRC_UNROLL
         for (int f = 0; f < NACC_I; ++f) a.ai[b][f] = 0;
+        BRC_UNROLL
         for (int f = 0; f < NF; ++f) a.af[b][f] = 0.0f;
     }
     a.ncol = a.depth = 0; a.unavail = NONE32; a.w_sm = a.w_nm = 0;
 }
 
-// One read against one lane.  `rd` and everything derived only from it is wave-uniform on the device
-// (scalar registers); p / qpos / q / base are per lane.  lib_sel = lib index + 1 handled by this wave.
-BRC_HD void lane_visit_read(const DevCfg& c, const DevIn& in, const DRead& rd, uint32_t ridx, uint32_t lib_sel,
-                            int32_t p, bool lane_valid, LaneAcc& a) {
-    if (rd.end <= rd.pos) return;                                       // dropped at push (uniform)
+// One read against one lane, in two stages so the device loop can software-pipeline them (probe + issue the event
+// load for read r+1 while read r is being accumulated).  `rd` and everything derived only from it is wave-uniform on
+// the device (scalar registers); p / qpos / the event word are per lane.  lib_sel = library index + 1 of this wave.
+struct Probe { int qpos; int indel; bool want; };   // want: the lane needs bq[rd.bq_off + qpos]
+
+BRC_HD Probe lane_probe(const DevCfg& c, const DevIn& in, const DRead& rd, uint32_t ridx, uint32_t lib_sel,
+                        int32_t p, bool lane_valid, LaneAcc& a) {
+    Probe pr; pr.qpos = 0; pr.indel = 0; pr.want = false;
+    if (rd.end <= rd.pos) return pr;                                    // dropped at push (uniform)
     const uint32_t rlib = rd.misc >> 16;
-    bool covered = lane_valid && p >= rd.pos && p < rd.end;
+    const bool covered = lane_valid && p >= rd.pos && p < rd.end;
     if (c.per_lib) {
         if (rlib == 0) {                                                // library unavailable (:281-284)
             if (covered && a.unavail == NONE32) a.unavail = ridx;
-            return;
+            return pr;
         }
-        if (rlib != lib_sel) return;                                    // another library's wave handles it (uniform)
+        if (rlib != lib_sel) return pr;                                 // another library's wave handles it (uniform)
     }
-    if (!covered) return;
-    int qpos; bool is_del = false; int indel = 0;
-    if (rd.misc & M_SIMPLE) qpos = p - rd.pos;
+    if (!covered) return pr;
+    bool is_del = false;
+    if (rd.misc & M_SIMPLE) pr.qpos = p - rd.pos;
     else {
         const Ev e = resolve_cigar(in.cigar + rd.cig_off, rd.n_cigar, rd.pos, p);
-        if (!e.in_col) return;
-        qpos = e.qpos; is_del = e.is_del; indel = e.indel;
+        if (!e.in_col) return pr;
+        pr.qpos = e.qpos; is_del = e.is_del; pr.indel = e.indel;
     }
     a.ncol++;                                                           // lib_counts[library] created (:286)
-    if (is_del) return;
-    if ((int)((rd.misc >> 8) & 0xffu) < c.min_mapq) return;             // :288 (uniform)
-    const uint32_t q = in.qual[rd.qual_off + (uint64_t)qpos];
-    if ((int)q < c.min_bq) return;
+    if (is_del) return pr;
+    if ((int)((rd.misc >> 8) & 0xffu) < c.min_mapq) return pr;          // :288 (uniform)
+    pr.want = true;
+    return pr;
+}
+
+BRC_HD void lane_accumulate(const DevCfg& c, const DRead& rd, const Probe& pr, uint32_t bqv, LaneAcc& a) {
+    if (!pr.want) return;
+    const uint32_t q = bqv & 0xffu;
+    if ((int)q < c.min_bq) return;                                      // :288
     a.depth++;                                                          // mapq_n (:312)
-    if (indel < 1 || !c.insertion_centric) {                            // :343
-        const uint32_t b = canon_bucket(seqi(in.seq4 + rd.seq_off, qpos));
+    if (pr.indel < 1 || !c.insertion_centric) {                         // :343
+        const uint32_t b = bqv >> 8;
         if (rd.misc & M_SMW) a.w_sm++;
         if (rd.misc & M_NMW) a.w_nm++;
-        const EvTerms t = event_terms(rd, qpos);
-        switch (b) {                                                    // static indices keep the 6 buckets in registers
-            case 0: acc_apply(a.ai[0], a.af[0], rd, t, q, false); break;
-            case 1: acc_apply(a.ai[1], a.af[1], rd, t, q, false); break;
-            case 2: acc_apply(a.ai[2], a.af[2], rd, t, q, false); break;
-            case 3: acc_apply(a.ai[3], a.af[3], rd, t, q, false); break;
-            case 4: acc_apply(a.ai[4], a.af[4], rd, t, q, false); break;
-            default: acc_apply(a.ai[5], a.af[5], rd, t, q, false); break;
-        }
+        const EvTerms t = event_terms(rd, pr.qpos);
+        // Six independent, fully unrolled `if (b == k)` blocks with static indices keep the 6 buckets in registers.
+        // (A `switch` lets LLVM sink the arms' common tail into one block addressed through a phi of pointers, which
+        // defeats scalar replacement and spills every accumulator to scratch.)
+        BRC_UNROLL
+        for (uint32_t k = 0; k < (uint32_t)NBUCKET; ++k)
+            if (b == k) acc_apply(a.ai[k], a.af[k], rd, t, q, false);
     }
+}
+
+// unpipelined form (simulator, reference for the pipelined device loop)
+BRC_HD void lane_visit_read(const DevCfg& c, const DevIn& in, const DRead& rd, uint32_t ridx, uint32_t lib_sel,
+                            int32_t p, bool lane_valid, LaneAcc& a) {
+    const Probe pr = lane_probe(c, in, rd, ridx, lib_sel, p, lane_valid, a);
+    const uint32_t bqv = pr.want ? in.bq[rd.bq_off + (uint64_t)pr.qpos] : 0u;
+    lane_accumulate(c, rd, pr, bqv, a);
 }
 
 // Write one lane's accumulators to the position-major planes (coalesced across the wave: lane == position).
 BRC_HD void lane_store(const DevCfg& c, const Planes& pl, int lib, int64_t k, const LaneAcc& a) {
-    const int64_t P = c.P;
+    const int64_t P = c.PS;                                              // plane stride
     const bool dead = c.per_lib && a.unavail != NONE32;                 // position abandoned: report nothing
     pl.ncol[(int64_t)lib * P + k] = dead ? 0u : a.ncol;
     pl.depth[(int64_t)lib * P + k] = dead ? 0u : a.depth;
     if (c.per_lib && lib == 0) pl.unavail[k] = a.unavail;
+    BRC_UNROLL
     for (int b = 0; b < NBUCKET; ++b) {
         uint32_t* ip = pl.istat + (((int64_t)lib * NBUCKET + b) * NI) * P + k;
         float* fp = pl.fstat + (((int64_t)lib * NBUCKET + b) * NF) * P + k;
@@ -374,6 +407,7 @@ BRC_HD void lane_store(const DevCfg& c, const Planes& pl, int lib, int64_t k, co
         ip[I_SMMQ * P] = dead ? 0u : s[A_SMMQ];
         ip[I_SCLIP * P] = dead ? 0u : s[A_SCLIP];
         ip[I_SBQ * P] = dead ? 0u : s[A_SBQ];
+        BRC_UNROLL
         for (int f = 0; f < NF; ++f) fp[f * P] = dead ? 0.0f : a.af[b][f];
     }
 }
@@ -410,7 +444,7 @@ BRC_HD void enumerate_indels(const DevCfg& c, const DevIn& in, const DRead& rd, 
                 if (indel != 0) {
                     const int32_t p = x + len - 1; const int qpos = y + len - 1;
                     if (p >= c.beg0 - 1 && p < c.end && p >= c.pos0 && (int64_t)p < (int64_t)c.pos0 + c.P) {
-                        const uint32_t q = in.qual[rd.qual_off + (uint64_t)qpos];
+                        const uint32_t q = in.bq[rd.bq_off + (uint64_t)qpos] & 0xffu;
                         if ((int)q >= c.min_bq) emit(p, qpos, indel);
                     }
                 }
@@ -429,8 +463,8 @@ BRC_HD bool same_allele(const DevIn& in, const DRead* reads, const IndelEv& a, c
     const DRead& ra = reads[a.read]; const DRead& rb = reads[b.read];
     for (int j = 0; j < a.len; ++j) {
         const int qa = a.qpos + 1 + j, qb = b.qpos + 1 + j;
-        const uint32_t ca = qa < ra.l_qseq ? canon_bucket(seqi(in.seq4 + ra.seq_off, qa)) : 5u;
-        const uint32_t cb = qb < rb.l_qseq ? canon_bucket(seqi(in.seq4 + rb.seq_off, qb)) : 5u;
+        const uint32_t ca = qa < ra.l_qseq ? (uint32_t)(in.bq[ra.bq_off + (uint64_t)qa] >> 8) : 5u;
+        const uint32_t cb = qb < rb.l_qseq ? (uint32_t)(in.bq[rb.bq_off + (uint64_t)qb] >> 8) : 5u;
         if (ca != cb) return false;
     }
     return true;

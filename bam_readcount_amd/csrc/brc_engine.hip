@@ -19,6 +19,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -42,10 +43,10 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 // ---------------------------------------------------------------- K1
 
 __global__ __launch_bounds__(256) void k_annotate(DevCfg c, DevIn in, DRead* __restrict__ reads, int32_t* __restrict__ ends,
-                                                  uint32_t* __restrict__ indel_cnt) {
+                                                  uint16_t* __restrict__ bq, uint32_t* __restrict__ indel_cnt) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c.n_reads) return;
-    const DRead r = annotate_read(c, in, i);
+    const DRead r = annotate_read(c, in, i, bq);
     reads[i] = r;
     ends[i] = r.end;
     if (indel_cnt) {
@@ -169,7 +170,7 @@ enum { PILEUP_WAVES = 4 };   // 256 threads: 4 consecutive tiles (256 positions)
 
 __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in, const DRead* __restrict__ reads,
                                                               const uint2* __restrict__ rng, int64_t ntiles, Planes pl,
-                                                              Counters* __restrict__ ctr) {
+                                                              uint4* __restrict__ tile_ctr) {
     // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch order); give every XCD one contiguous
     // run of tiles so neighbouring tiles, which share most of their reads, hit the same 4-MiB L2.
     const uint32_t nb = gridDim.x;            // multiple of 8
@@ -187,9 +188,25 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
 
     LaneAcc a;
     lane_init(a);
-    for (uint32_t r = lo; r < hi; ++r) {
-        const DRead rd = reads[r];            // uniform address: scalar loads
-        lane_visit_read(c, in, rd, r, (uint32_t)lib + 1u, p, valid, a);
+    // Software pipeline over the tile's reads (file order): while read r is accumulated, the event word of read r+1
+    // is in flight (vector load) and the record of read r+2 is in flight (scalar load).
+    if (lo < hi) {
+        const uint32_t libsel = (uint32_t)lib + 1u;
+        DRead r0 = reads[lo];
+        DRead r1 = reads[lo + 1 < hi ? lo + 1 : lo];
+        Probe p0 = lane_probe(c, in, r0, lo, libsel, p, valid, a);
+        uint32_t v0 = p0.want ? (uint32_t)in.bq[r0.bq_off + (uint64_t)p0.qpos] : 0u;
+        for (uint32_t r = lo; r < hi; ++r) {
+            const DRead r2 = reads[r + 2 < hi ? r + 2 : hi - 1];                    // stage A: record r+2 (uniform address)
+            Probe p1; p1.qpos = 0; p1.indel = 0; p1.want = false;
+            uint32_t v1 = 0u;
+            if (r + 1 < hi) {                                                        // stage B: probe + event load of r+1
+                p1 = lane_probe(c, in, r1, r + 1, libsel, p, valid, a);
+                v1 = p1.want ? (uint32_t)in.bq[r1.bq_off + (uint64_t)p1.qpos] : 0u;
+            }
+            lane_accumulate(c, r0, p0, v0, a);                                       // stage C: accumulate r
+            r0 = r1; r1 = r2; p0 = p1; v0 = v1;
+        }
     }
     if (valid) lane_store(c, pl, lib, k, a);
 
@@ -198,24 +215,44 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
     unsigned long long ev = (live && p >= c.beg0) ? a.ncol : 0u;
     unsigned long long wsm = live ? a.w_sm : 0u, wnm = live ? a.w_nm : 0u, wl = (valid && dead && lib == 0) ? 1u : 0u;
     ev = wave_sum_u64(ev); wsm = wave_sum_u64(wsm); wnm = wave_sum_u64(wnm); wl = wave_sum_u64(wl);
-    if (lane == 0) {
-        if (ev) atomicAdd(&ctr->n_events, ev);
-        if (wsm) atomicAdd(&ctr->w_sm, wsm);
-        if (wnm) atomicAdd(&ctr->w_nm, wnm);
-        if (wl) atomicAdd(&ctr->w_lib, wl);
-    }
+    // per-(tile, library) partials; k_finalize sums them (a single-address atomic per wave costs ~12 ns x 780 k waves)
+    if (lane == 0) tile_ctr[(int64_t)lib * ntiles + tile] = make_uint4((uint32_t)ev, (uint32_t)wsm, (uint32_t)wnm, (uint32_t)wl);
 }
 
-__global__ __launch_bounds__(256) void k_count_pos(DevCfg c, const uint32_t* __restrict__ ncol, Counters* __restrict__ ctr) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long one = 0;
-    if (k < c.P && c.pos0 + k >= c.beg0) {
+template <int NV>
+__device__ __forceinline__ void block_sum_u64(unsigned long long (&v)[NV], unsigned long long* sh /* [4*NV] */) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum_u64(v[i]);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) for (int i = 0; i < NV; ++i) sh[w * NV + i] = v[i];
+    __syncthreads();
+    if (threadIdx.x == 0) for (int i = 0; i < NV; ++i) { unsigned long long t = 0; for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += sh[k * NV + i]; v[i] = t; }
+}
+
+// emitted-position count + sum of the per-tile partials; grid-stride, one set of atomics per work-group
+__global__ __launch_bounds__(256) void k_finalize(DevCfg c, const uint32_t* __restrict__ ncol, const uint4* __restrict__ tile_ctr,
+                                                  int64_t n_tile_ctr, Counters* __restrict__ ctr) {
+    __shared__ unsigned long long sh[4 * 5];
+    unsigned long long v[5] = {0, 0, 0, 0, 0};   // positions, events, w_sm, w_nm, w_lib
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < c.P; k += stride) {
+        if (c.pos0 + k < c.beg0) continue;
         uint32_t tot = 0;
-        for (int l = 0; l < c.Lp; ++l) tot += ncol[(int64_t)l * c.P + k];
-        one = tot ? 1u : 0u;
+        for (int l = 0; l < c.Lp; ++l) tot += ncol[(int64_t)l * c.PS + k];
+        v[0] += tot ? 1u : 0u;
     }
-    one = wave_sum_u64(one);
-    if ((threadIdx.x & 63) == 0 && one) atomicAdd(&ctr->n_positions, one);
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_tile_ctr; t += stride) {
+        const uint4 x = tile_ctr[t];
+        v[1] += x.x; v[2] += x.y; v[3] += x.z; v[4] += x.w;
+    }
+    block_sum_u64<5>(v, sh);
+    if (threadIdx.x == 0) {
+        if (v[0]) atomicAdd(&ctr->n_positions, v[0]);
+        if (v[1]) atomicAdd(&ctr->n_events, v[1]);
+        if (v[2]) atomicAdd(&ctr->w_sm, v[2]);
+        if (v[3]) atomicAdd(&ctr->w_nm, v[3]);
+        if (v[4]) atomicAdd(&ctr->w_lib, v[4]);
+    }
 }
 
 // ---------------------------------------------------------------- indel side path
@@ -233,24 +270,35 @@ __global__ __launch_bounds__(256) void k_indel_fill(DevCfg c, DevIn in, const DR
     });
 }
 
-// cursor[key] has been advanced by k_indel_fill to the END of the key's events
+// cursor[key] has been advanced by k_indel_fill to the END of the key's events.  A key's reduced alleles are written to
+// out[start .. start+na) where [start, start+n) is the key's own event range (no slot atomics); unused slots get len = 0.
 __global__ __launch_bounds__(256) void k_indel_reduce(DevCfg c, DevIn in, const DRead* __restrict__ reads, const uint32_t* __restrict__ cnt,
                                                       const uint32_t* __restrict__ cursor, IndelEv* __restrict__ ev,
                                                       const uint32_t* __restrict__ unavail, IndelOut* __restrict__ out,
                                                       Counters* __restrict__ ctr) {
-    const int64_t key = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (key >= c.P * c.Lp) return;
-    const int n = (int)cnt[key];
-    if (n == 0) return;
-    const int64_t k = key / c.Lp; const int lib = (int)(key % c.Lp);
-    if (c.per_lib && unavail[k] != NONE32) return;                  // position abandoned (bamreadcount.cpp:281-284)
-    const uint32_t start = cursor[key] - (uint32_t)n;
-    const uint32_t o = atomicAdd(&ctr->n_indel_slots, (uint32_t)n); // n slots claimed, na <= n used, rest marked len = 0
-    uint32_t wsm = 0, wnm = 0;
-    const int na = reduce_indel_key(c, in, reads, ev + start, n, (int32_t)(c.pos0 + k), lib, out + o, wsm, wnm);
-    for (int j = na; j < n; ++j) out[o + j].len = 0;
-    if (wsm) atomicAdd(&ctr->w_sm, (unsigned long long)wsm);
-    if (wnm) atomicAdd(&ctr->w_nm, (unsigned long long)wnm);
+    __shared__ unsigned long long sh[4 * 2];
+    unsigned long long w[2] = {0, 0};
+    const int64_t nkeys = c.P * c.Lp;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t key = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; key < nkeys; key += stride) {
+        const int n = (int)cnt[key];
+        if (key == nkeys - 1) ctr->n_indel_slots = cursor[key];        // total number of event slots
+        if (n == 0) continue;
+        const int64_t k = key / c.Lp; const int lib = (int)(key % c.Lp);
+        const uint32_t start = cursor[key] - (uint32_t)n;
+        int na = 0;
+        if (!(c.per_lib && unavail[k] != NONE32)) {                     // else: position abandoned (bamreadcount.cpp:281-284)
+            uint32_t wsm = 0, wnm = 0;
+            na = reduce_indel_key(c, in, reads, ev + start, n, (int32_t)(c.pos0 + k), lib, out + start, wsm, wnm);
+            w[0] += wsm; w[1] += wnm;
+        }
+        for (int j = na; j < n; ++j) out[start + j].len = 0;
+    }
+    block_sum_u64<2>(w, sh);
+    if (threadIdx.x == 0) {
+        if (w[0]) atomicAdd(&ctr->w_sm, w[0]);
+        if (w[1]) atomicAdd(&ctr->w_nm, w[1]);
+    }
 }
 
 // ---------------------------------------------------------------- host side of the backend
@@ -278,7 +326,7 @@ struct DBuf {
 };
 
 enum { T_ANNOTATE = 0, T_SCAN_ENDS, T_TILES, T_PILEUP, T_COUNT, T_INDEL_SCAN, T_INDEL_FILL, T_INDEL_REDUCE, T_N };
-static const char* kKernelNames[BRC_NKERNEL] = {"k_annotate", "k_scan_ends", "k_tiles", "k_pileup", "k_count_pos",
+static const char* kKernelNames[BRC_NKERNEL] = {"k_annotate", "k_scan_ends", "k_tiles", "k_pileup", "k_finalize",
                                                 "k_scan_indel", "k_indel_fill", "k_indel_reduce"};
 
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { return hip_fail(_e, #x); } } while (0)
@@ -293,7 +341,7 @@ class HipBackend : public Backend {
     int64_t ntiles = 0; uint64_t n_indel_cap = 0;
     // device buffers
     DBuf d_pos, d_flag, d_mapq, d_lib, d_lq, d_nc, d_co, d_so, d_qo, d_nm, d_sm, d_tags, d_cigar, d_seq, d_qual, d_ref;
-    DBuf d_reads, d_ends, d_prefmax, d_agg, d_rng, d_ncol, d_depth, d_istat, d_fstat, d_unavail, d_cnt, d_cursor, d_ev, d_iout, d_ctr;
+    DBuf d_bq, d_reads, d_ends, d_prefmax, d_agg, d_rng, d_ncol, d_depth, d_istat, d_fstat, d_unavail, d_cnt, d_cursor, d_ev, d_iout, d_ctr, d_tilectr;
     // host result buffers (pinned)
     HBuf<uint32_t> h_ncol, h_depth, h_istat, h_unavail; HBuf<float> h_fstat; HBuf<IndelOut> h_iout;
     std::vector<IndelOut> iout_compact;
@@ -323,8 +371,8 @@ class HipBackend : public Backend {
     ~HipBackend() override {
         (void)hipSetDevice(device);
         DBuf* all[] = {&d_pos, &d_flag, &d_mapq, &d_lib, &d_lq, &d_nc, &d_co, &d_so, &d_qo, &d_nm, &d_sm, &d_tags, &d_cigar, &d_seq, &d_qual,
-                       &d_ref, &d_reads, &d_ends, &d_prefmax, &d_agg, &d_rng, &d_ncol, &d_depth, &d_istat, &d_fstat, &d_unavail, &d_cnt,
-                       &d_cursor, &d_ev, &d_iout, &d_ctr};
+                       &d_ref, &d_bq, &d_reads, &d_ends, &d_prefmax, &d_agg, &d_rng, &d_ncol, &d_depth, &d_istat, &d_fstat, &d_unavail, &d_cnt,
+                       &d_cursor, &d_ev, &d_iout, &d_ctr, &d_tilectr};
         for (DBuf* b : all) b->release();
         h_ncol.destroy(); h_depth.destroy(); h_istat.destroy(); h_unavail.destroy(); h_fstat.destroy(); h_iout.destroy();
         if (have_events) for (int i = 0; i <= T_N; ++i) (void)hipEventDestroy(evt[i]);
@@ -340,13 +388,14 @@ class HipBackend : public Backend {
         return BRC_OK;
     }
 
-    int upload(const brc_config& cfg, const Staged& s, const Geometry& g) override {
+    int upload(const brc_config& cfg, const Staged& s, Geometry& g) override {
         HIPCHK(hipSetDevice(device));
         computed = false;
         memset(&c, 0, sizeof c);
         c.min_mapq = cfg.min_mapq; c.min_bq = cfg.min_bq; c.per_lib = cfg.per_lib; c.insertion_centric = cfg.insertion_centric;
         c.Lp = g.Lp; c.ref_len_check = cfg.ref_len_check; c.has_ref = g.ref != nullptr;
-        c.beg0 = g.beg0; c.end = g.end; c.pos0 = g.pos0; c.P = g.P; c.ref_lo = g.ref_lo; c.ref_hi = g.ref_hi; c.ref_len = g.ref_len;
+        g.PS = (g.P + 63) & ~(int64_t)63;
+        c.beg0 = g.beg0; c.end = g.end; c.pos0 = g.pos0; c.P = g.P; c.PS = g.PS; c.ref_lo = g.ref_lo; c.ref_hi = g.ref_hi; c.ref_len = g.ref_len;
         c.n_reads = s.n;
         const size_t n = (size_t)s.n;
         int rc;
@@ -363,8 +412,10 @@ class HipBackend : public Backend {
         in.seq_off = (const uint64_t*)d_so.p; in.qual_off = (const uint64_t*)d_qo.p; in.nm = (const int32_t*)d_nm.p; in.sm = (const int32_t*)d_sm.p;
         in.tags = (const uint8_t*)d_tags.p; in.cigar = (const uint32_t*)d_cigar.p; in.seq4 = (const uint8_t*)d_seq.p; in.qual = (const uint8_t*)d_qual.p;
         in.ref = (const char*)d_ref.p;
+        HIPCHK(d_bq.ensure((s.qual.n + 16) * sizeof(uint16_t)));
+        in.bq = (const uint16_t*)d_bq.p;
         // outputs / scratch
-        const size_t P = (size_t)c.P, Lp = (size_t)c.Lp;
+        const size_t P = (size_t)c.PS, Lp = (size_t)c.Lp;   // allocation sizes use the padded stride
         ntiles = (c.P + TILE - 1) / TILE;
         n_indel_cap = c.has_ref ? s.n_indel_ops : 0;
         const size_t nagg = std::max<size_t>((std::max<size_t>(n, P * Lp) + SCAN_CHUNK - 1) / SCAN_CHUNK, 1);
@@ -372,7 +423,7 @@ class HipBackend : public Backend {
         HIPCHK(d_agg.ensure(nagg * 4 + 16)); HIPCHK(d_rng.ensure(((size_t)ntiles + 1) * sizeof(uint2)));
         HIPCHK(d_ncol.ensure(Lp * P * 4 + 16)); HIPCHK(d_depth.ensure(Lp * P * 4 + 16)); HIPCHK(d_unavail.ensure(P * 4 + 16));
         HIPCHK(d_istat.ensure(Lp * NBUCKET * NI * P * 4 + 16)); HIPCHK(d_fstat.ensure(Lp * NBUCKET * NF * P * 4 + 16));
-        HIPCHK(d_ctr.ensure(sizeof(Counters)));
+        HIPCHK(d_ctr.ensure(sizeof(Counters))); HIPCHK(d_tilectr.ensure(((size_t)ntiles * Lp + 1) * sizeof(uint4)));
         if (n_indel_cap) {
             HIPCHK(d_cnt.ensure(Lp * P * 4 + 16)); HIPCHK(d_cursor.ensure(Lp * P * 4 + 16));
             HIPCHK(d_ev.ensure((n_indel_cap + 1) * sizeof(IndelEv))); HIPCHK(d_iout.ensure((n_indel_cap + 1) * sizeof(IndelOut)));
@@ -406,7 +457,7 @@ class HipBackend : public Backend {
         HIPCHK(hipEventRecord(evt[T_ANNOTATE], stream));
         if (n > 0)
             hipLaunchKernelGGL(k_annotate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (int32_t*)d_ends.p,
-                               indels ? (uint32_t*)d_cnt.p : (uint32_t*)nullptr);
+                               (uint16_t*)d_bq.p, indels ? (uint32_t*)d_cnt.p : (uint32_t*)nullptr);
         HIPCHK(hipEventRecord(evt[T_SCAN_ENDS], stream));
         if ((rc = scan<OpMaxI32, true>((const int32_t*)d_ends.p, (int32_t*)d_prefmax.p, n))) return rc;
         HIPCHK(hipEventRecord(evt[T_TILES], stream));
@@ -417,10 +468,13 @@ class HipBackend : public Backend {
         if (ntiles > 0) {
             unsigned nwg = (unsigned)((ntiles + PILEUP_WAVES - 1) / PILEUP_WAVES);
             nwg = (nwg + 7u) & ~7u;
-            hipLaunchKernelGGL(k_pileup, dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), 0, stream, c, in, reads, (const uint2*)d_rng.p, ntiles, pl, ctr);
+            hipLaunchKernelGGL(k_pileup, dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), 0, stream, c, in, reads, (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p);
         }
         HIPCHK(hipEventRecord(evt[T_COUNT], stream));
-        if (P > 0) hipLaunchKernelGGL(k_count_pos, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, c, (const uint32_t*)d_ncol.p, ctr);
+        if (P > 0) {
+            const unsigned nb = (unsigned)std::min<int64_t>((P + 255) / 256, 2048);
+            hipLaunchKernelGGL(k_finalize, dim3(nb), dim3(256), 0, stream, c, (const uint32_t*)d_ncol.p, (const uint4*)d_tilectr.p, (int64_t)ntiles * Lp, ctr);
+        }
         HIPCHK(hipEventRecord(evt[T_INDEL_SCAN], stream));
         if (indels && (rc = scan<OpSumU32, false>((const uint32_t*)d_cnt.p, (uint32_t*)d_cursor.p, (int64_t)Lp * P))) return rc;
         HIPCHK(hipEventRecord(evt[T_INDEL_FILL], stream));
@@ -428,7 +482,7 @@ class HipBackend : public Backend {
             hipLaunchKernelGGL(k_indel_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, reads, (uint32_t*)d_cursor.p, (IndelEv*)d_ev.p);
         HIPCHK(hipEventRecord(evt[T_INDEL_REDUCE], stream));
         if (indels)
-            hipLaunchKernelGGL(k_indel_reduce, dim3((unsigned)(((int64_t)Lp * P + 255) / 256)), dim3(256), 0, stream, c, in, reads,
+            hipLaunchKernelGGL(k_indel_reduce, dim3((unsigned)std::min<int64_t>(((int64_t)Lp * P + 255) / 256, 4096)), dim3(256), 0, stream, c, in, reads,
                                (const uint32_t*)d_cnt.p, (const uint32_t*)d_cursor.p, (IndelEv*)d_ev.p, (const uint32_t*)d_unavail.p,
                                (IndelOut*)d_iout.p, ctr);
         HIPCHK(hipEventRecord(evt[T_N], stream));
@@ -454,7 +508,7 @@ class HipBackend : public Backend {
     int fetch(HostPlanes* out) override {
         HIPCHK(hipSetDevice(device));
         if (!computed) { err = "not computed"; return BRC_E_ARG; }
-        const size_t P = (size_t)c.P, Lp = (size_t)c.Lp;
+        const size_t P = (size_t)c.PS, Lp = (size_t)c.Lp;   // planes are copied with their padded stride
         if (!h_ncol.reserve(Lp * P + 4) || !h_depth.reserve(Lp * P + 4) || !h_unavail.reserve(P + 4) ||
             !h_istat.reserve(Lp * NBUCKET * NI * P + 4) || !h_fstat.reserve(Lp * NBUCKET * NF * P + 4)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }
         if (P) {

@@ -315,7 +315,7 @@ int brc_fetch_result(brc_engine* e, brc_result* out) {
         for (int f = 0; f < BRC_NF; ++f) d.stat.f[f] = o.f[f];
     }
     memset(out, 0, sizeof *out);
-    out->tid = g.tid; out->beg0 = g.beg0; out->end = g.end; out->pos0 = g.pos0; out->n_pos = g.P; out->n_lib = g.Lp;
+    out->tid = g.tid; out->beg0 = g.beg0; out->end = g.end; out->pos0 = g.pos0; out->n_pos = g.P; out->stride = g.PS; out->n_lib = g.Lp;
     out->ncol = hp.ncol; out->depth = hp.depth; out->istat = hp.istat; out->fstat = hp.fstat;
     out->unavail = e->cfg.per_lib ? hp.unavail : NULL;
     out->refbase = e->refbase.data();
@@ -351,7 +351,7 @@ int brc_clear_indel_queue(brc_engine* e) {
 
 int brc_format_region(brc_engine* e, const brc_result* r, const char* chrom, const char** text, size_t* text_len) {
     if (!e || !r || !chrom || !text) return BRC_E_ARG;
-    const int Lp = r->n_lib; const int64_t P = r->n_pos;
+    const int Lp = r->n_lib; const int64_t P = r->n_pos; const int64_t S = r->stride;
     if ((size_t)Lp != e->queue.size()) return fail(e, BRC_E_ARG, "result does not belong to this engine");
     std::string& out = e->text; out.clear();
     std::string rec;
@@ -365,18 +365,18 @@ int brc_format_region(brc_engine* e, const brc_result* r, const char* chrom, con
         while (ii < r->n_indel && r->indel[ii].pos < pos) ++ii;
         if (per_lib && r->unavail && r->unavail[k] != 0xFFFFFFFFu) continue;            // :281-284: position abandoned
         uint32_t tot = 0, depth = 0;
-        for (int l = 0; l < Lp; ++l) { tot += r->ncol[(int64_t)l * P + k]; depth += r->depth[(int64_t)l * P + k]; }
+        for (int l = 0; l < Lp; ++l) { tot += r->ncol[(int64_t)l * S + k]; depth += r->depth[(int64_t)l * S + k]; }
         if (tot == 0) continue;                                                           // no reads: no pileup callback
         rec.clear();
         int extra_depth = 0;
         for (int l = 0; l < Lp; ++l) {
-            if (r->ncol[(int64_t)l * P + k] == 0) continue;                               // lib_counts has no entry (:286,360)
+            if (r->ncol[(int64_t)l * S + k] == 0) continue;                               // lib_counts has no entry (:286,360)
             if (per_lib) { rec += '\t'; rec += e->libs[(size_t)l]; rec += "\t{"; }
             for (int b = 0; b < BRC_NBUCKET; ++b) {
-                for (int f = 0; f < BRC_NI; ++f) si[f] = r->istat[(((int64_t)l * BRC_NBUCKET + b) * BRC_NI + f) * P + k];
+                for (int f = 0; f < BRC_NI; ++f) si[f] = r->istat[(((int64_t)l * BRC_NBUCKET + b) * BRC_NI + f) * S + k];
                 rec += '\t'; rec += "=ACGTN"[b]; rec += ':';
                 if (si[I_N] == 0) { fmt_stat(rec, si, sf, false); continue; }
-                for (int f = 0; f < BRC_NF; ++f) sf[f] = r->fstat[(((int64_t)l * BRC_NBUCKET + b) * BRC_NF + f) * P + k];
+                for (int f = 0; f < BRC_NF; ++f) sf[f] = r->fstat[(((int64_t)l * BRC_NBUCKET + b) * BRC_NF + f) * S + k];
                 fmt_stat(rec, si, sf, false);
             }
             while (ii < r->n_indel && r->indel[ii].pos == pos && r->indel[ii].lib < l) ++ii;

@@ -66,6 +66,7 @@ struct Staged {
 struct Geometry {
     int32_t tid = 0, beg0 = 0, end = 0;
     int32_t pos0 = 0; int64_t P = 0; int Lp = 1;
+    int64_t PS = 0;                     // plane stride chosen by the backend at upload (>= P)
     const char* ref = nullptr; int64_t ref_len = 0;
     int64_t ref_lo = 0, ref_hi = 0;     // slice of the contig the device needs
 };
@@ -83,7 +84,7 @@ class Backend {
   public:
     virtual ~Backend() {}
     virtual const HostAlloc* host_alloc() = 0;
-    virtual int upload(const brc_config& cfg, const Staged& s, const Geometry& g) = 0;   // staging -> device
+    virtual int upload(const brc_config& cfg, const Staged& s, Geometry& g) = 0;         // staging -> device; sets g.PS
     virtual int compute(brc_timing* t) = 0;                                              // whole pipeline, waits
     virtual int fetch(HostPlanes* out) = 0;                                              // device -> host planes
     virtual int counts(uint64_t* n_events, uint64_t* n_positions) = 0;

@@ -130,7 +130,9 @@ typedef struct brc_indel {
 enum { BRC_W_SM_MISSING = 0, BRC_W_NM_MISSING, BRC_W_ZM_MISSING, BRC_W_LIB_UNAVAILABLE, BRC_N_WARN };
 
 /*
- * Result of one region, position-major planes ("SoA"): element [plane][k] is position pos0 + k.
+ * Result of one region, position-major planes ("SoA"): element plane*stride + k is position pos0 + k ("[..][P]" below
+ * means P valid elements per plane, planes `stride` elements apart).  The plane window [pos0, pos0+P) is the processing
+ * window [max(beg0-1,0), end) intersected with the extent of the pushed reads that pass the flag mask.
  * Position index 0 is the lead position beg0-1 (processed only so that deletions starting there
  * can be reported at beg0, bamreadcount.cpp:269 vs :414); when beg0 == 0 there is no lead position
  * and pos0 == 0.  All arrays are engine-owned host memory, valid until the next begin_region/destroy.
@@ -139,6 +141,7 @@ typedef struct brc_result {
     int32_t tid, beg0, end;     /* reporting window [beg0,end) */
     int32_t pos0;               /* reference position of index 0 */
     int64_t n_pos;              /* P */
+    int64_t stride;             /* elements between consecutive planes (>= P; the HIP engine pads P to a multiple of 64) */
     int32_t n_lib;              /* Lp: 1 in all-lib mode, n_libs in per-lib mode */
     const uint32_t* ncol;       /* [Lp][P] pileup column entries of that library (pre-filter, incl. deletions/ref-skips): lib_counts[] creation, :286 */
     const uint32_t* depth;      /* [Lp][P] mapq_n contribution (:312) */

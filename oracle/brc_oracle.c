@@ -696,7 +696,7 @@ int brc_compute(brc_engine* e, brc_timing* timing) {
 int brc_fetch_result(brc_engine* e, brc_result* out) {
     if (!e || !out) return BRC_E_ARG;
     memset(out, 0, sizeof *out);
-    out->tid = e->tid; out->beg0 = e->beg0; out->end = e->end; out->pos0 = e->pos0; out->n_pos = e->P; out->n_lib = e->Lp;
+    out->tid = e->tid; out->beg0 = e->beg0; out->end = e->end; out->pos0 = e->pos0; out->n_pos = e->P; out->stride = e->P; out->n_lib = e->Lp;
     out->ncol = e->ncol; out->depth = e->depth; out->istat = e->istat; out->fstat = e->fstat;
     out->unavail = e->cfg.per_lib ? e->unavail : NULL; out->refbase = e->refbase;
     out->n_indel = (int64_t)e->n_indel; out->indel = e->indel; out->alleles = e->alleles.p; out->alleles_len = e->alleles.n;

@@ -20,7 +20,7 @@ static const HostAlloc kAlloc = {sim_alloc, sim_release};
 
 class SimBackend : public Backend {
     DevCfg c; DevIn in; std::string err;
-    std::vector<DRead> reads; std::vector<int32_t> prefmax;
+    std::vector<DRead> reads; std::vector<int32_t> prefmax; std::vector<uint16_t> bq; size_t bq_n = 0;
     std::vector<uint32_t> ncol, depth, istat, unavail; std::vector<float> fstat;
     std::vector<IndelOut> iout;
     uint64_t n_events = 0, n_positions = 0, warn[BRC_N_WARN] = {0, 0, 0, 0};
@@ -28,26 +28,28 @@ class SimBackend : public Backend {
   public:
     const HostAlloc* host_alloc() override { return &kAlloc; }
     const char* last_error() const override { return err.c_str(); }
-    int upload(const brc_config& cfg, const Staged& s, const Geometry& g) override {
+    int upload(const brc_config& cfg, const Staged& s, Geometry& g) override {
+        g.PS = g.P + 3;   // deliberately odd stride: exercises the stride handling of the host side
         memset(&c, 0, sizeof c);
         c.min_mapq = cfg.min_mapq; c.min_bq = cfg.min_bq; c.per_lib = cfg.per_lib; c.insertion_centric = cfg.insertion_centric;
         c.Lp = g.Lp; c.ref_len_check = cfg.ref_len_check; c.has_ref = g.ref != nullptr;
-        c.beg0 = g.beg0; c.end = g.end; c.pos0 = g.pos0; c.P = g.P; c.ref_lo = g.ref_lo; c.ref_hi = g.ref_hi; c.ref_len = g.ref_len;
+        c.beg0 = g.beg0; c.end = g.end; c.pos0 = g.pos0; c.P = g.P; c.PS = g.PS; c.ref_lo = g.ref_lo; c.ref_hi = g.ref_hi; c.ref_len = g.ref_len;
         c.n_reads = s.n;
         in.pos = s.pos.p; in.flag = s.flag.p; in.mapq = s.mapq.p; in.lib = s.lib.p; in.l_qseq = s.l_qseq.p; in.n_cigar = s.n_cigar.p;
         in.cig_off = s.cig_off.p; in.seq_off = s.seq_off.p; in.qual_off = s.qual_off.p; in.nm = s.nm.p; in.sm = s.sm.p; in.tags = s.tags.p;
         in.cigar = s.cigar.p; in.seq4 = s.seq4.p; in.qual = s.qual.p; in.ref = g.ref ? g.ref + g.ref_lo : nullptr;
+        bq_n = s.qual.n; in.bq = nullptr;
         return BRC_OK;
     }
     int compute(brc_timing* t) override {
         if (t) memset(t, 0, sizeof *t);
-        const int64_t n = c.n_reads, P = c.P; const int Lp = c.Lp;
-        reads.resize((size_t)n); prefmax.resize((size_t)n);
-        for (int64_t i = 0; i < n; ++i) reads[(size_t)i] = annotate_read(c, in, i);                    // K1
+        const int64_t n = c.n_reads, P = c.P, PS = c.PS; const int Lp = c.Lp;
+        reads.resize((size_t)n); prefmax.resize((size_t)n); bq.assign(bq_n + 1, 0); in.bq = bq.data();
+        for (int64_t i = 0; i < n; ++i) reads[(size_t)i] = annotate_read(c, in, i, bq.data());         // K1
         int32_t m = INT32_MIN;
         for (int64_t i = 0; i < n; ++i) { if (reads[(size_t)i].end > m) m = reads[(size_t)i].end; prefmax[(size_t)i] = m; }
-        ncol.assign((size_t)(Lp * P), 0); depth.assign((size_t)(Lp * P), 0); unavail.assign((size_t)P, NONE32);
-        istat.assign((size_t)(Lp * NBUCKET * NI * P), 0); fstat.assign((size_t)(Lp * NBUCKET * NF * P), 0.0f);
+        ncol.assign((size_t)(Lp * PS), 0); depth.assign((size_t)(Lp * PS), 0); unavail.assign((size_t)PS, NONE32);
+        istat.assign((size_t)(Lp * NBUCKET * NI * PS), 0); fstat.assign((size_t)(Lp * NBUCKET * NF * PS), 0.0f);
         Planes pl = {ncol.data(), depth.data(), istat.data(), fstat.data(), unavail.data()};
         n_events = n_positions = 0; memset(warn, 0, sizeof warn);
         const int64_t ntiles = (P + TILE - 1) / TILE;
@@ -66,7 +68,7 @@ class SimBackend : public Backend {
         }
         for (int64_t k = 0; k < P; ++k) {
             if (c.pos0 + k < c.beg0) continue;
-            uint32_t tot = 0; for (int l = 0; l < Lp; ++l) tot += ncol[(size_t)(l * P + k)];
+            uint32_t tot = 0; for (int l = 0; l < Lp; ++l) tot += ncol[(size_t)(l * PS + k)];
             if (tot) n_positions++;
         }
         // indel events: count -> scan -> fill -> reduce
