@@ -19,6 +19,7 @@
 #ifndef BRC_CORE_H
 #define BRC_CORE_H
 
+#include <math.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__)
@@ -55,6 +56,7 @@ struct DevCfg {
     int64_t ref_lo, ref_hi; // the device reference slice holds contig positions [ref_lo, ref_hi)
     int64_t ref_len;        // contig length (positions >= ref_len read as NUL)
     int64_t n_reads;
+    int32_t variant;        // 0 in production; >0 = profiling ablations selected by BRC_PILEUP_VARIANT (see brc_engine.hip)
 };
 
 // Region inputs exactly as brc_read_batch lays them out (uploaded as-is; offsets rebased per region).
@@ -63,16 +65,23 @@ struct DevIn {
     const uint32_t* n_cigar; const uint64_t* cig_off; const uint64_t* seq_off; const uint64_t* qual_off;
     const int32_t* nm; const int32_t* sm; const uint8_t* tags;
     const uint32_t* cigar; const uint8_t* seq4; const uint8_t* qual; const char* ref;
-    // device-produced by K1, indexed like qual[]: per base  quality | bucket("=ACGTN") << 8
+    // device-produced by K1: per base  quality | bucket("=ACGTN") << 8; read i's row starts at element bq_row[i]
+    // (rows are padded to multiples of 8 elements so every row is 16-byte aligned: KB bulk-loads row windows as uint4)
     const uint16_t* bq;
+    const uint64_t* bq_row;  // [n_reads] host-computed prefix sums of roundup8(l_qseq)
+    const struct RcpPair* rcp;   // [n_reads], device-produced by K1
 };
 
+// correctly rounded reciprocals written by K1 next to each DRead: 1/(float)l_qseq and 1/((float)clipped_length/2)
+struct RcpPair { float rcpL, rcpC; };
+
 // Packed per-read record written by K1 and read with ONE scalar load (s_load_dwordx16) by KB: 64 bytes.
-enum { M_REV = 1, M_Q2OK = 2, M_SMW = 4, M_NMW = 8, M_SIMPLE = 16 };
+enum { M_REV = 1, M_Q2OK = 2, M_SMW = 4, M_NMW = 8, M_SIMPLE = 16,
+       M_FAST = 32 };   // per-read constants fit the branch-free accumulate (acc_fast): L, clipped >= 1 and all addends < 2^24
 struct alignas(64) DRead {
     int32_t pos, end;          // [pos,end) on the reference; end == pos when the read never enters a column
     uint32_t cig_off, n_cigar;
-    uint64_t bq_off;           // index of the read's first base in bq[] (== its qual_off)
+    uint64_t bq_off;           // index of the read's first base in bq[] (multiple of 8: 16-byte aligned row)
     uint32_t misc;             // M_* | mapq << 8 | (lib + 1) << 16   (lib + 1 == 0: library unavailable)
     int32_t l_qseq;
     int32_t q2, tp, left, clipped;   // Zm: q2_pos, three_prime_index, left_clip, clipped_length
@@ -124,7 +133,7 @@ BRC_HD uint32_t ref_at(const DevCfg& c, const char* ref, int64_t p) {
 // ---------------------------------------------------------------- K1: per-read annotation (fetch_func)
 
 // Restates bamreadcount.cpp:114-256 for read i and packs everything KB needs into a DRead.
-BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i, uint16_t* bq_out) {
+BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i, uint16_t* bq_out, RcpPair* rcp_out) {
     DRead r;
     const int32_t pos = in.pos[i];
     const uint32_t flag = in.flag[i];
@@ -199,9 +208,9 @@ BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i, uint16_t
     r.end = dropped ? pos : pos + rlen;
     r.cig_off = (uint32_t)in.cig_off[i];
     r.n_cigar = nc;
-    r.bq_off = in.qual_off[i];
+    r.bq_off = in.bq_row[i];
     // per-base stream for KB: quality | bucket << 8
-    for (int j = 0; j < L; ++j) bq_out[in.qual_off[i] + (uint64_t)j] = (uint16_t)(qual[j] | (canon_bucket(seqi(seq, j)) << 8));
+    for (int j = 0; j < L; ++j) bq_out[in.bq_row[i] + (uint64_t)j] = (uint16_t)(qual[j] | (canon_bucket(seqi(seq, j)) << 8));
     const int lib = c.per_lib ? (int)in.lib[i] : 0;
     uint32_t misc = (mapq << 8) | ((uint32_t)((lib + 1) & 0xffff) << 16);
     if (rev) misc |= M_REV;
@@ -214,6 +223,9 @@ BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i, uint16_t
     float snm = 0.0f;
     if (tags & 1u) snm = (float)in.nm[i] / (float)clipped;                                   // BasicStat.cpp:94-97
     else misc |= M_NMW;
+    if (L >= 1 && clipped >= 1 && L < (1 << 24) && sum < (1u << 24) && sse < (1u << 24)) misc |= M_FAST;
+    RcpPair rc; rc.rcpL = 1.0f / (float)L; rc.rcpC = 1.0f / ((float)clipped * 0.5f);
+    rcp_out[i] = rc;
     r.misc = misc; r.l_qseq = L; r.q2 = q2; r.tp = tp; r.left = left_clip; r.clipped = clipped;
     r.zm_sum = sum; r.sse_add = sse; r.snm_add = snm; r.pad0 = 0;
     return r;
@@ -261,6 +273,33 @@ BRC_HD void acc_event(uint32_t* ai, float* af, const DRead& r, int qpos, uint32_
     const EvTerms t = event_terms(r, qpos);
     acc_apply(ai, af, r, t, q, is_indel);
 }
+
+// a / b with one multiply and two FMAs, given y = RN(1/b): q = RN(a*y); r = a - q*b (exact in one FMA);
+// result = RN(q + r*y).  With a correctly rounded reciprocal this IS the correctly rounded quotient (Markstein);
+// tests/test_exact_division.py checks it bit-for-bit against `/` over every (numerator, denominator) the path can form.
+BRC_HD float div_rcp(float a, float b, float y) {
+    const float q = a * y;
+    const float r = fmaf(-q, b, a);
+    return fmaf(r, y, q);
+}
+
+BRC_HD EvTerms event_terms_fast(const DRead& r, const RcpPair& rc, int qpos) {
+    EvTerms t;
+    const float Lf = (float)r.l_qseq;
+    t.q2 = div_rcp((float)iabs(qpos - r.q2), Lf, rc.rcpL);
+    t.s3p = div_rcp((float)iabs(qpos - r.tp), Lf, rc.rcpL);
+    const float center = (float)r.clipped * 0.5f;
+    float d = (float)(qpos - r.left) - center;
+    d = d < 0.0f ? -d : d;
+    t.sev = 1.0 - (double)div_rcp(d, center, rc.rcpC);
+    return t;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BRC_MAD24(e, v, acc) ((e) * (v) + (acc))                /* e is 0/1: the compiler emits select + add */
+#else
+#define BRC_MAD24(e, v, acc) ((e) * (v) + (acc))
+#endif
 
 // ---------------------------------------------------------------- htslib resolve_cigar2 as a pure function of (read, position)
 
@@ -333,33 +372,31 @@ struct Probe { int qpos; int indel; bool want; };   // want: the lane needs bq[r
 
 BRC_HD Probe lane_probe(const DevCfg& c, const DevIn& in, const DRead& rd, uint32_t ridx, uint32_t lib_sel,
                         int32_t p, bool lane_valid, LaneAcc& a) {
-    Probe pr; pr.qpos = 0; pr.indel = 0; pr.want = false;
-    if (rd.end <= rd.pos) return pr;                                    // dropped at push (uniform)
+    Probe pr; pr.qpos = p - rd.pos; pr.indel = 0; pr.want = false;
     const uint32_t rlib = rd.misc >> 16;
-    const bool covered = lane_valid && p >= rd.pos && p < rd.end;
-    if (c.per_lib) {
+    // one subtract + one unsigned compare; false for reads dropped at push (end == pos)
+    const bool covered = lane_valid && (uint32_t)(p - rd.pos) < (uint32_t)(rd.end - rd.pos);
+    if (c.per_lib) {                                                    // (uniform)
         if (rlib == 0) {                                                // library unavailable (:281-284)
             if (covered && a.unavail == NONE32) a.unavail = ridx;
             return pr;
         }
-        if (rlib != lib_sel) return pr;                                 // another library's wave handles it (uniform)
+        if (rlib != lib_sel) return pr;                                 // another library's wave handles it
     }
-    if (!covered) return pr;
-    bool is_del = false;
-    if (rd.misc & M_SIMPLE) pr.qpos = p - rd.pos;
-    else {
-        const Ev e = resolve_cigar(in.cigar + rd.cig_off, rd.n_cigar, rd.pos, p);
-        if (!e.in_col) return pr;
-        pr.qpos = e.qpos; is_del = e.is_del; pr.indel = e.indel;
+    bool in_col = covered, is_del = false;
+    if (!(rd.misc & M_SIMPLE)) {                                        // general CIGAR (uniform, uncommon)
+        in_col = false;
+        if (covered) {
+            const Ev e = resolve_cigar(in.cigar + rd.cig_off, rd.n_cigar, rd.pos, p);
+            in_col = e.in_col; pr.qpos = e.qpos; is_del = e.is_del; pr.indel = e.indel;
+        }
     }
-    a.ncol++;                                                           // lib_counts[library] created (:286)
-    if (is_del) return pr;
-    if ((int)((rd.misc >> 8) & 0xffu) < c.min_mapq) return pr;          // :288 (uniform)
-    pr.want = true;
+    a.ncol += in_col ? 1u : 0u;                                         // lib_counts[library] created (:286)
+    pr.want = in_col && !is_del && (int)((rd.misc >> 8) & 0xffu) >= c.min_mapq;   // :288
     return pr;
 }
 
-BRC_HD void lane_accumulate(const DevCfg& c, const DRead& rd, const Probe& pr, uint32_t bqv, LaneAcc& a) {
+BRC_HD void lane_accumulate(const DevCfg& c, const DRead& rd, const RcpPair& rc, const Probe& pr, uint32_t bqv, LaneAcc& a) {
     if (!pr.want) return;
     const uint32_t q = bqv & 0xffu;
     if ((int)q < c.min_bq) return;                                      // :288
@@ -368,8 +405,10 @@ BRC_HD void lane_accumulate(const DevCfg& c, const DRead& rd, const Probe& pr, u
         const uint32_t b = bqv >> 8;
         if (rd.misc & M_SMW) a.w_sm++;
         if (rd.misc & M_NMW) a.w_nm++;
-        const EvTerms t = event_terms(rd, pr.qpos);
-        // Six independent, fully unrolled `if (b == k)` blocks with static indices keep the 6 buckets in registers.
+        // whenever a lane has an event the read has l_qseq >= 1 and clipped_length >= 1: reciprocals are finite
+        const EvTerms t = event_terms_fast(rd, rc, pr.qpos);
+        // Six independent, fully unrolled `if (b == k)` blocks with static indices keep the 6 buckets in registers; the
+        // lane masks are SALU work, only the 12-13 adds of the buckets actually present in the wave cost VALU issue.
         // (A `switch` lets LLVM sink the arms' common tail into one block addressed through a phi of pointers, which
         // defeats scalar replacement and spills every accumulator to scratch.)
         BRC_UNROLL
@@ -378,12 +417,56 @@ BRC_HD void lane_accumulate(const DevCfg& c, const DRead& rd, const Probe& pr, u
     }
 }
 
+// Branch-free form of lane_accumulate (the one the pileup kernel uses; whenever a lane has an event the read has
+// l_qseq >= 1 and clipped_length >= 1, so the reciprocal-based divisions are well defined): the lane predicate e = pass && (base == bucket k) is folded
+// into the arithmetic (integer sums: acc += e * addend as one mad24; float sums: acc += e ? term : +0.0f, which is the
+// identity on these non-negative-zero sums; event location: select between the old and the double-promoted new sum),
+// so a wave with mixed bases executes one straight-line block instead of four exec-masked regions.  Buckets '=' and
+// 'N' are rare and handled by an ordinary branch.
+BRC_HD void acc_fast(const DevCfg& c, const DRead& rd, const RcpPair& rc, const Probe& pr, uint32_t bqv, LaneAcc& a) {
+    const uint32_t q = bqv & 0xffu, b = bqv >> 8;
+    const bool pass = pr.want && (int)q >= c.min_bq && (pr.indel < 1 || !c.insertion_centric);
+    const bool dep = pr.want && (int)q >= c.min_bq;
+    a.depth += dep ? 1u : 0u;
+    const uint32_t m = rd.misc;
+    const uint32_t mapq = (m >> 8) & 0xffu, rev = m & M_REV, q2ok = (m & M_Q2OK) ? 1u : 0u;
+    a.w_sm += (pass && (m & M_SMW)) ? 1u : 0u;
+    a.w_nm += (pass && (m & M_NMW)) ? 1u : 0u;
+    const EvTerms t = event_terms_fast(rd, rc, pr.qpos);
+    const float tq2 = q2ok ? t.q2 : 0.0f;
+    const float tnm = (m & M_NMW) ? 0.0f : rd.snm_add;
+    BRC_UNROLL
+    for (uint32_t k = 1; k <= 4; ++k) {
+        const bool e = pass && b == k;
+        const uint32_t ei = e ? 1u : 0u;
+        uint32_t* ai = a.ai[k]; float* af = a.af[k];
+        ai[A_SMQ] = BRC_MAD24(ei, mapq, ai[A_SMQ]);
+        ai[A_SSE] = BRC_MAD24(ei, rd.sse_add, ai[A_SSE]);
+        ai[A_MINUS] = BRC_MAD24(ei, rev, ai[A_MINUS]);
+        ai[A_PLUS] = BRC_MAD24(ei, 1u - rev, ai[A_PLUS]);
+        ai[A_NQ2] = BRC_MAD24(ei, q2ok, ai[A_NQ2]);
+        ai[A_SMMQ] = BRC_MAD24(ei, rd.zm_sum, ai[A_SMMQ]);
+        ai[A_SCLIP] = BRC_MAD24(ei, (uint32_t)rd.clipped, ai[A_SCLIP]);
+        ai[A_SBQ] = BRC_MAD24(ei, q, ai[A_SBQ]);
+        af[F_SQ2] += e ? tq2 : 0.0f;
+        af[F_S3P] += e ? t.s3p : 0.0f;
+        af[F_SNM] += e ? tnm : 0.0f;
+        const float nsev = (float)((double)af[F_SEV] + t.sev);
+        af[F_SEV] = e ? nsev : af[F_SEV];
+    }
+    if (pass && (b == 0u || b >= 5u)) {
+        if (b == 0u) acc_apply(a.ai[0], a.af[0], rd, t, q, false);
+        if (b >= 5u) acc_apply(a.ai[5], a.af[5], rd, t, q, false);
+    }
+}
+
 // unpipelined form (simulator, reference for the pipelined device loop)
 BRC_HD void lane_visit_read(const DevCfg& c, const DevIn& in, const DRead& rd, uint32_t ridx, uint32_t lib_sel,
                             int32_t p, bool lane_valid, LaneAcc& a) {
     const Probe pr = lane_probe(c, in, rd, ridx, lib_sel, p, lane_valid, a);
     const uint32_t bqv = pr.want ? in.bq[rd.bq_off + (uint64_t)pr.qpos] : 0u;
-    lane_accumulate(c, rd, pr, bqv, a);
+    if (c.variant == 7) acc_fast(c, rd, in.rcp[ridx], pr, bqv, a);      // alternative formulation kept for A/B runs
+    else lane_accumulate(c, rd, in.rcp[ridx], pr, bqv, a);
 }
 
 // Write one lane's accumulators to the position-major planes (coalesced across the wave: lane == position).
@@ -417,8 +500,9 @@ BRC_HD void lane_store(const DevCfg& c, const Planes& pl, int lib, int64_t k, co
 // Calls emit(p, qpos, len) for every event of read `rd` that pileup_func would bucket as an indel allele
 // (bamreadcount.cpp:288-342): last base of an M/=/X operator followed by I, D or P..I, inside the processing
 // window [beg0-1,end), passing the MAPQ / base-quality filters.
+// qual_row = the read's QUAL bytes (in.qual + qual_off[read])
 template <class F>
-BRC_HD void enumerate_indels(const DevCfg& c, const DevIn& in, const DRead& rd, F emit) {
+BRC_HD void enumerate_indels(const DevCfg& c, const DevIn& in, const DRead& rd, const uint8_t* qual_row, F emit) {
     if (rd.end <= rd.pos || (rd.misc & M_SIMPLE) || !c.has_ref) return;
     if ((rd.misc >> 16) == 0) return;                                   // library unavailable: position is abandoned
     if ((int)((rd.misc >> 8) & 0xffu) < c.min_mapq) return;
@@ -444,7 +528,7 @@ BRC_HD void enumerate_indels(const DevCfg& c, const DevIn& in, const DRead& rd, 
                 if (indel != 0) {
                     const int32_t p = x + len - 1; const int qpos = y + len - 1;
                     if (p >= c.beg0 - 1 && p < c.end && p >= c.pos0 && (int64_t)p < (int64_t)c.pos0 + c.P) {
-                        const uint32_t q = in.bq[rd.bq_off + (uint64_t)qpos] & 0xffu;
+                        const uint32_t q = qual_row[qpos];
                         if ((int)q >= c.min_bq) emit(p, qpos, indel);
                     }
                 }

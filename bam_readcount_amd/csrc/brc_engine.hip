@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -43,17 +44,131 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 // ---------------------------------------------------------------- K1
 
 __global__ __launch_bounds__(256) void k_annotate(DevCfg c, DevIn in, DRead* __restrict__ reads, int32_t* __restrict__ ends,
-                                                  uint16_t* __restrict__ bq, uint32_t* __restrict__ indel_cnt) {
+                                                  uint16_t* __restrict__ bq, RcpPair* __restrict__ rcp, uint32_t* __restrict__ indel_cnt) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c.n_reads) return;
-    const DRead r = annotate_read(c, in, i, bq);
+    const DRead r = annotate_read(c, in, i, bq, rcp);
     reads[i] = r;
     ends[i] = r.end;
     if (indel_cnt) {
         const int lib = (int)(r.misc >> 16) - 1;
-        enumerate_indels(c, in, r, [&](int32_t p, int, int) {
+        enumerate_indels(c, in, r, in.qual + in.qual_off[i], [&](int32_t p, int, int) {
             atomicAdd(&indel_cnt[(int64_t)(p - c.pos0) * c.Lp + lib], 1u);
         });
+    }
+}
+
+// K1, wave-per-read form (the one normally launched): the 64 lanes walk the read's bases, so QUAL / SEQ / reference
+// loads and the bq stores are contiguous across the wave.  Restates bamreadcount.cpp:114-256 exactly like annotate_read():
+//   * mismatch qualities: runs of read-adjacent mismatching M-op bases contribute their maximum quality (:152-172,199).
+//     Per 64-base chunk: ballot of the mismatch flags, run length ending at each lane from the ballot, segmented max by
+//     doubling (shfl_up), run ends summed; a run crossing a chunk boundary is carried in (carry_open, carry_max).
+//   * Q2 scan (:201-238) from ballots of (qual != 2): highest such index (forward reads) / lowest (reverse reads).
+// Reads that overhang the end of the reference take the reference's break/continue quirks (:144-151,175); those, and
+// everything when no reference was given, go through the serial annotate_read() on lane 0 instead.
+__global__ __launch_bounds__(256) void k_annotate_wave(DevCfg c, DevIn in, DRead* __restrict__ reads, int32_t* __restrict__ ends,
+                                                       uint16_t* __restrict__ bq, RcpPair* __restrict__ rcp, uint32_t* __restrict__ indel_cnt) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = __builtin_amdgcn_readfirstlane((uint32_t)(blockIdx.x * 4u + (threadIdx.x >> 6)));
+    if ((int64_t)w >= c.n_reads) return;
+    const int64_t i = w;
+    const int32_t pos = in.pos[i];
+    const uint32_t flag = in.flag[i];
+    const int32_t L = in.l_qseq[i];
+    const uint32_t nc = in.n_cigar[i];
+    const uint64_t qoff = in.qual_off[i];
+    const uint64_t brow = in.bq_row[i];
+    const uint32_t* __restrict__ cig = in.cigar + in.cig_off[i];
+    const uint8_t* __restrict__ seq = in.seq4 + in.seq_off[i];
+    const uint8_t* __restrict__ qual = in.qual + qoff;
+
+    int32_t rlen = 0; int clipped = L, left_clip = 0, right_clip = L;
+    for (uint32_t k = 0; k < nc; ++k) {
+        const uint32_t op = cig[k] & 0xfu; const int len = (int)(cig[k] >> 4);
+        if (is_refop(op)) rlen += len;
+        if (op == CSOFT_CLIP) { clipped -= len; if (k == 0) left_clip += len; else right_clip -= len; }
+    }
+    const bool simple = nc == 1 && (cig[0] & 0xfu) == CMATCH;
+    DRead r;
+    if (!c.has_ref || pos < 0 || (int64_t)pos + rlen > c.ref_len) {
+        if (lane == 0) { r = annotate_read(c, in, i, bq, rcp); reads[i] = r; ends[i] = r.end; }
+    } else {
+        uint32_t sum = 0; bool carry_open = false; int carry_max = 0;
+        int hi_nq2 = -1, lo_nq2 = -1;
+        for (int b0 = 0; b0 < L; b0 += 64) {
+            const int j = b0 + lane; const bool inr = j < L;
+            const uint32_t q = inr ? qual[j] : 2u;
+            const uint32_t nib = inr ? seqi(seq, j) : 0u;
+            if (inr) bq[brow + (uint64_t)j] = (uint16_t)(q | (canon_bucket(nib) << 8));
+            bool inM = false; int64_t refpos = 0;
+            if (simple) { inM = inr; refpos = (int64_t)pos + j; }
+            else {
+                int rs = 0; int64_t x = pos;
+                for (uint32_t k = 0; k < nc; ++k) {
+                    const uint32_t op = cig[k] & 0xfu; const int len = (int)(cig[k] >> 4);
+                    if (op == CMATCH) { if (inr && j >= rs && j < rs + len) { inM = true; refpos = x + (j - rs); } rs += len; x += len; }
+                    else if (op == CDEL || op == CREF_SKIP) x += len;
+                    else if (op == CINS || op == CSOFT_CLIP) rs += len;
+                    // '=' / 'X' / H / P: the reference annotator advances neither cursor (:138-196)
+                }
+            }
+            bool m = false;
+            if (inM) {
+                const uint32_t refb = nt16_of_char(ref_at(c, in.ref, refpos));
+                m = nib != refb && refb != 15u && nib != 0u;
+            }
+            const unsigned long long mask = __ballot(m);
+            const unsigned long long nz = __ballot(inr && q != 2u);
+            if (nz) { hi_nq2 = b0 + 63 - __builtin_clzll(nz); if (lo_nq2 < 0) lo_nq2 = b0 + __builtin_ctzll(nz); }
+            if (carry_open && !(mask & 1ull)) { sum += (uint32_t)carry_max; carry_open = false; }
+            if (mask) {
+                const unsigned long long below = lane ? (~mask & ((1ull << lane) - 1ull)) : 0ull;
+                const int h = below ? 63 - __builtin_clzll(below) : -1;
+                const int runlen = m ? lane - h : 0;
+                int v = m ? (int)q : 0;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d, 64); if (runlen > d) v = v > o ? v : o; }
+                if (carry_open && m && runlen == lane + 1) v = v > carry_max ? v : carry_max;
+                const bool is_end = m && (lane < 63 ? !((mask >> (lane + 1)) & 1ull) : (j + 1 >= L));
+                sum += (uint32_t)wave_sum_u64(is_end ? (unsigned long long)v : 0ull);
+                const bool open_out = ((mask >> 63) & 1ull) && (b0 + 64 < L);
+                carry_max = __builtin_amdgcn_readlane(v, 63);
+                carry_open = open_out;
+            }
+        }
+        if (carry_open) sum += (uint32_t)carry_max;
+        const bool rev = (flag & FREVERSE) != 0;
+        int tp, q2;
+        if (rev) { tp = 0; if (tp < left_clip) tp = left_clip; q2 = lo_nq2 >= 0 ? lo_nq2 - 1 : -1; if (tp < q2) tp = q2; }
+        else { tp = L - 1; if (tp > right_clip) tp = right_clip; q2 = hi_nq2 >= 0 ? hi_nq2 - 1 : -1; if (tp > q2 && q2 != -1) tp = q2; }
+        bool dropped = (flag & BRC_PUSH_MASK) != 0;
+        if (nc == 0) dropped = true;
+        if (nc == 1 && !is_mop(cig[0] & 0xfu)) dropped = true;
+        const uint32_t mapq = in.mapq[i]; const uint32_t tags = in.tags[i];
+        r.pos = pos; r.end = dropped ? pos : pos + rlen;
+        r.cig_off = (uint32_t)in.cig_off[i]; r.n_cigar = nc; r.bq_off = brow;
+        const int lib = c.per_lib ? (int)in.lib[i] : 0;
+        uint32_t misc = (mapq << 8) | ((uint32_t)((lib + 1) & 0xffff) << 16);
+        if (rev) misc |= M_REV;
+        if (q2 > -1) misc |= M_Q2OK;
+        if (simple) misc |= M_SIMPLE;
+        uint32_t sse;
+        if (flag & FPROPER_PAIR) { if (tags & 2u) sse = (uint32_t)in.sm[i]; else { sse = 0; misc |= M_SMW; } } else sse = mapq;
+        float snm = 0.0f;
+        if (tags & 1u) snm = (float)in.nm[i] / (float)clipped; else misc |= M_NMW;
+        if (L >= 1 && clipped >= 1 && L < (1 << 24) && sum < (1u << 24) && sse < (1u << 24)) misc |= M_FAST;
+        r.misc = misc; r.l_qseq = L; r.q2 = q2; r.tp = tp; r.left = left_clip; r.clipped = clipped;
+        r.zm_sum = sum; r.sse_add = sse; r.snm_add = snm; r.pad0 = 0;
+        if (lane == 0) {
+            reads[i] = r; ends[i] = r.end;
+            RcpPair rc; rc.rcpL = 1.0f / (float)L; rc.rcpC = 1.0f / ((float)clipped * 0.5f);
+            rcp[i] = rc;
+        }
+    }
+    if (indel_cnt && lane == 0 && !simple) {
+        const DRead rr = reads[i];   // lane 0 wrote it above (same lane: program order)
+        const int lib = (int)(rr.misc >> 16) - 1;
+        enumerate_indels(c, in, rr, qual, [&](int32_t p, int, int) { atomicAdd(&indel_cnt[(int64_t)(p - c.pos0) * c.Lp + lib], 1u); });
     }
 }
 
@@ -167,7 +282,10 @@ __global__ __launch_bounds__(256) void k_tiles(DevCfg c, const int32_t* __restri
 // ---------------------------------------------------------------- KB: pileup + BasicStat accumulation (the hot kernel)
 
 enum { PILEUP_WAVES = 4 };   // 256 threads: 4 consecutive tiles (256 positions) per workgroup
+enum { ROW_U4 = 9 };         // LDS row per staged read: 9 x 16 B = 72 bq elements (64 tile positions + up to 7 of alignment slack)
 
+// V: 0 = production; 1/2/3 = profiling ablations (no plane stores / probe+loads only / stores only), BRC_PILEUP_VARIANT
+template <int V>
 __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in, const DRead* __restrict__ reads,
                                                               const uint2* __restrict__ rng, int64_t ntiles, Planes pl,
                                                               uint4* __restrict__ tile_ctr) {
@@ -188,27 +306,126 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
 
     LaneAcc a;
     lane_init(a);
-    // Software pipeline over the tile's reads (file order): while read r is accumulated, the event word of read r+1
-    // is in flight (vector load) and the record of read r+2 is in flight (scalar load).
-    if (lo < hi) {
+    // The tile's reads are visited in file order, in batches of 64:
+    //  1. batch table: lane l loads the 32-byte probe half of read base+l into its own registers (coalesced);
+    //  2. staging: lane l copies the 72-element window of its read's bq row that this tile can touch into a wave-private
+    //     LDS row (nine independent 16-byte loads per lane, all in flight together: the memory latency of the whole
+    //     batch is paid once, not once per read);
+    //  3. the read loop: read j's pos/end/misc are broadcast with v_readlane, its event word comes from LDS row j
+    //     (ds_read_u16, issued one read ahead), its accumulate half (Zm integers, addends, reciprocals) through scalar
+    //     loads one read ahead (two register sets alternating by name).  Reads with a general CIGAR are not staged; their
+    //     event words are fetched from global memory (uncommon).
+    __shared__ uint4 lds_rows[PILEUP_WAVES][64][ROW_U4];
+    if (lo < hi && V != 3) {
         const uint32_t libsel = (uint32_t)lib + 1u;
-        DRead r0 = reads[lo];
-        DRead r1 = reads[lo + 1 < hi ? lo + 1 : lo];
-        Probe p0 = lane_probe(c, in, r0, lo, libsel, p, valid, a);
-        uint32_t v0 = p0.want ? (uint32_t)in.bq[r0.bq_off + (uint64_t)p0.qpos] : 0u;
-        for (uint32_t r = lo; r < hi; ++r) {
-            const DRead r2 = reads[r + 2 < hi ? r + 2 : hi - 1];                    // stage A: record r+2 (uniform address)
-            Probe p1; p1.qpos = 0; p1.indel = 0; p1.want = false;
-            uint32_t v1 = 0u;
-            if (r + 1 < hi) {                                                        // stage B: probe + event load of r+1
-                p1 = lane_probe(c, in, r1, r + 1, libsel, p, valid, a);
-                v1 = p1.want ? (uint32_t)in.bq[r1.bq_off + (uint64_t)p1.qpos] : 0u;
+        struct ProbeHalf { int32_t pos, end; uint32_t cig_off, n_cigar; uint64_t bq_off; uint32_t misc; int32_t l_qseq; };
+        struct AccHalf { int32_t q2, tp, left, clipped; uint32_t zm_sum, sse_add; float snm_add; uint32_t pad0; };
+        static_assert(sizeof(ProbeHalf) == 32 && sizeof(AccHalf) == 32 && sizeof(DRead) == 64, "DRead halves");
+        const char* __restrict__ rbase = reinterpret_cast<const char*>(reads);
+        const RcpPair* __restrict__ rcp = in.rcp;
+        uint4(*rows)[ROW_U4] = lds_rows[threadIdx.x >> 6];
+        const int32_t p0 = (int32_t)(c.pos0 + tile * TILE);                 // first position of the tile (uniform)
+#define BRC_LD_ACC(i) (*reinterpret_cast<const AccHalf*>(rbase + (size_t)(i) * 64u + 32u))
+#define BRC_RL(x, j) __builtin_amdgcn_readlane((int)(x), (int)(j))
+        for (uint32_t base = lo; base < hi; base += 64u) {
+            const uint32_t nb = (hi - base) < 64u ? (hi - base) : 64u;
+            const uint32_t last = base + nb - 1u;
+            // 1. batch table
+            const ProbeHalf T = *reinterpret_cast<const ProbeHalf*>(rbase + (size_t)(base + ((uint32_t)lane < nb ? (uint32_t)lane : 0u)) * 64u);
+            // 2. staging (window start rounded down to 8 elements = 16 bytes; qpos - ws is in [0, 71] for covered lanes)
+            {
+                const int32_t d0 = p0 - T.pos;
+                const uint32_t ws = d0 > 0 ? ((uint32_t)d0 & ~7u) : 0u;
+                const bool row_ok = (uint32_t)lane < nb && (T.misc & M_SIMPLE) && T.end > T.pos && (int32_t)ws < T.l_qseq + 8;
+                if (row_ok) {
+                    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(in.bq + T.bq_off + ws);
+                    uint4 w[ROW_U4];
+#pragma unroll
+                    for (int q = 0; q < ROW_U4; ++q) w[q] = src[q];
+#pragma unroll
+                    for (int q = 0; q < ROW_U4; ++q) rows[lane][q] = w[q];
+                }
             }
-            lane_accumulate(c, r0, p0, v0, a);                                       // stage C: accumulate r
-            r0 = r1; r1 = r2; p0 = p1; v0 = v1;
+            // 3. read loop
+            // probe of read j (inline form of lane_probe; see brc_core.h for the commented reference version)
+#define BRC_PROBE(j, PO, VO)                                                                                            \
+            {                                                                                                             \
+                const int32_t pos_j = BRC_RL(T.pos, j), end_j = BRC_RL(T.end, j);                                         \
+                const uint32_t misc_j = (uint32_t)BRC_RL(T.misc, j);                                                      \
+                PO.qpos = p - pos_j; PO.indel = 0; PO.want = false; VO = 0u;                                              \
+                const bool covered = valid && (uint32_t)(p - pos_j) < (uint32_t)(end_j - pos_j);                          \
+                const uint32_t rlib = misc_j >> 16;                                                                       \
+                bool mine = true;                                                                                         \
+                if (c.per_lib) {                                                                                          \
+                    if (rlib == 0) { if (covered && a.unavail == NONE32) a.unavail = base + (j); mine = false; }          \
+                    else if (rlib != libsel) mine = false;                                                                \
+                }                                                                                                         \
+                if (mine) {                                                                                               \
+                    const bool mapq_ok = (int)((misc_j >> 8) & 0xffu) >= c.min_mapq;                                      \
+                    if (misc_j & M_SIMPLE) {                                                                              \
+                        a.ncol += covered ? 1u : 0u;                                                                      \
+                        PO.want = covered && mapq_ok;                                                                     \
+                        const int32_t d0 = p0 - pos_j;                                                                    \
+                        const uint32_t ws = d0 > 0 ? ((uint32_t)d0 & ~7u) : 0u;                                           \
+                        if (PO.want) VO = (uint32_t)reinterpret_cast<const uint16_t*>(rows[(j)])[(uint32_t)PO.qpos - ws]; \
+                    } else if (covered) {                                                                                 \
+                        const uint32_t cig_off = (uint32_t)BRC_RL(T.cig_off, j), n_cig = (uint32_t)BRC_RL(T.n_cigar, j);  \
+                        const uint64_t bqo = (uint64_t)(uint32_t)BRC_RL((uint32_t)T.bq_off, j) |                          \
+                                             ((uint64_t)(uint32_t)BRC_RL((uint32_t)(T.bq_off >> 32), j) << 32);           \
+                        const Ev e = resolve_cigar(in.cigar + cig_off, n_cig, pos_j, p);                                  \
+                        if (e.in_col) {                                                                                   \
+                            a.ncol++;                                                                                     \
+                            PO.qpos = e.qpos; PO.indel = e.indel; PO.want = !e.is_del && mapq_ok;                         \
+                            if (PO.want) VO = (uint32_t)in.bq[bqo + (uint64_t)(uint32_t)e.qpos];                          \
+                        }                                                                                                 \
+                    }                                                                                                     \
+                }                                                                                                         \
+            }
+            // NOTE: readlane inside the divergent `else if (covered)` branch would read with a partial exec mask; v_readlane
+            // ignores exec for the source lane, so the broadcast is still well defined.
+            AccHalf GA = BRC_LD_ACC(base), GB = GA;
+            RcpPair CA = rcp[base], CB = CA;
+            Probe P0, P1; uint32_t V0, V1 = 0u;
+            BRC_PROBE(0u, P0, V0)
+            P1 = P0;
+            DRead RQ; RQ.pad0 = 0; RQ.pos = RQ.end = 0; RQ.cig_off = RQ.n_cigar = 0; RQ.bq_off = 0;
+            // STEP(j): accumulate read j with acc half G0/C0; probe read j+1; issue scalar loads of the acc half of j+1 -> G1/C1
+#define BRC_STEP(j, G0, C0, G1, C1)                                                                                     \
+            {                                                                                                             \
+                const uint32_t j1 = (j) + 1u < nb ? (j) + 1u : (j);                                                       \
+                G1 = BRC_LD_ACC(base + j1); C1 = rcp[base + j1];                                                          \
+                if ((j) + 1u < nb) BRC_PROBE((j) + 1u, P1, V1)                                                            \
+                RQ.misc = (uint32_t)BRC_RL(T.misc, j); RQ.l_qseq = BRC_RL(T.l_qseq, j);                                   \
+                RQ.q2 = G0.q2; RQ.tp = G0.tp; RQ.left = G0.left; RQ.clipped = G0.clipped;                                 \
+                RQ.zm_sum = G0.zm_sum; RQ.sse_add = G0.sse_add; RQ.snm_add = G0.snm_add;                                  \
+                if (V == 2) a.depth += V0;                                                                                \
+                else if (V == 7) acc_fast(c, RQ, C0, P0, V0, a);                                                          \
+                else lane_accumulate(c, RQ, C0, P0, V0, a);                                                               \
+                P0 = P1; V0 = V1;                                                                                         \
+            }
+            for (uint32_t j = 0; j < nb; j += 2u) {
+                BRC_STEP(j, GA, CA, GB, CB)
+                if (j + 1u < nb) BRC_STEP(j + 1u, GB, CB, GA, CA)
+            }
+            (void)last;
+#undef BRC_STEP
+#undef BRC_PROBE
         }
+#undef BRC_LD_ACC
+#undef BRC_RL
     }
-    if (valid) lane_store(c, pl, lib, k, a);
+    if (V != 1) { if (valid) lane_store(c, pl, lib, k, a); }
+    else if (valid) {
+        uint32_t x = a.ncol ^ a.depth;
+#pragma unroll
+        for (int b = 0; b < NBUCKET; ++b) {
+#pragma unroll
+            for (int f = 0; f < NACC_I; ++f) x ^= a.ai[b][f];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) x ^= __float_as_uint(a.af[b][f]);
+        }
+        pl.ncol[(int64_t)lib * c.PS + k] = x;
+    }
 
     const bool dead = c.per_lib && a.unavail != NONE32;
     const bool live = valid && !dead;
@@ -263,7 +480,7 @@ __global__ __launch_bounds__(256) void k_indel_fill(DevCfg c, DevIn in, const DR
     if (i >= c.n_reads) return;
     const DRead r = reads[i];
     const int lib = (int)(r.misc >> 16) - 1;
-    enumerate_indels(c, in, r, [&](int32_t p, int qpos, int len) {
+    enumerate_indels(c, in, r, in.qual + in.qual_off[i], [&](int32_t p, int qpos, int len) {
         const uint32_t slot = atomicAdd(&cursor[(int64_t)(p - c.pos0) * c.Lp + lib], 1u);
         IndelEv e; e.read = (uint32_t)i; e.qpos = qpos; e.len = len; e.key_lo = 0;
         ev[slot] = e;
@@ -341,7 +558,7 @@ class HipBackend : public Backend {
     int64_t ntiles = 0; uint64_t n_indel_cap = 0;
     // device buffers
     DBuf d_pos, d_flag, d_mapq, d_lib, d_lq, d_nc, d_co, d_so, d_qo, d_nm, d_sm, d_tags, d_cigar, d_seq, d_qual, d_ref;
-    DBuf d_bq, d_reads, d_ends, d_prefmax, d_agg, d_rng, d_ncol, d_depth, d_istat, d_fstat, d_unavail, d_cnt, d_cursor, d_ev, d_iout, d_ctr, d_tilectr;
+    DBuf d_bq, d_bqrow, d_rcp, d_reads, d_ends, d_prefmax, d_agg, d_rng, d_ncol, d_depth, d_istat, d_fstat, d_unavail, d_cnt, d_cursor, d_ev, d_iout, d_ctr, d_tilectr;
     // host result buffers (pinned)
     HBuf<uint32_t> h_ncol, h_depth, h_istat, h_unavail; HBuf<float> h_fstat; HBuf<IndelOut> h_iout;
     std::vector<IndelOut> iout_compact;
@@ -371,7 +588,7 @@ class HipBackend : public Backend {
     ~HipBackend() override {
         (void)hipSetDevice(device);
         DBuf* all[] = {&d_pos, &d_flag, &d_mapq, &d_lib, &d_lq, &d_nc, &d_co, &d_so, &d_qo, &d_nm, &d_sm, &d_tags, &d_cigar, &d_seq, &d_qual,
-                       &d_ref, &d_bq, &d_reads, &d_ends, &d_prefmax, &d_agg, &d_rng, &d_ncol, &d_depth, &d_istat, &d_fstat, &d_unavail, &d_cnt,
+                       &d_ref, &d_bq, &d_bqrow, &d_rcp, &d_reads, &d_ends, &d_prefmax, &d_agg, &d_rng, &d_ncol, &d_depth, &d_istat, &d_fstat, &d_unavail, &d_cnt,
                        &d_cursor, &d_ev, &d_iout, &d_ctr, &d_tilectr};
         for (DBuf* b : all) b->release();
         h_ncol.destroy(); h_depth.destroy(); h_istat.destroy(); h_unavail.destroy(); h_fstat.destroy(); h_iout.destroy();
@@ -397,6 +614,7 @@ class HipBackend : public Backend {
         g.PS = (g.P + 63) & ~(int64_t)63;
         c.beg0 = g.beg0; c.end = g.end; c.pos0 = g.pos0; c.P = g.P; c.PS = g.PS; c.ref_lo = g.ref_lo; c.ref_hi = g.ref_hi; c.ref_len = g.ref_len;
         c.n_reads = s.n;
+        { const char* v = getenv("BRC_PILEUP_VARIANT"); c.variant = v ? atoi(v) : 0; }
         const size_t n = (size_t)s.n;
         int rc;
         if ((rc = up(d_pos, s.pos, n)) || (rc = up(d_flag, s.flag, n)) || (rc = up(d_mapq, s.mapq, n)) || (rc = up(d_lib, s.lib, n)) ||
@@ -412,8 +630,12 @@ class HipBackend : public Backend {
         in.seq_off = (const uint64_t*)d_so.p; in.qual_off = (const uint64_t*)d_qo.p; in.nm = (const int32_t*)d_nm.p; in.sm = (const int32_t*)d_sm.p;
         in.tags = (const uint8_t*)d_tags.p; in.cigar = (const uint32_t*)d_cigar.p; in.seq4 = (const uint8_t*)d_seq.p; in.qual = (const uint8_t*)d_qual.p;
         in.ref = (const char*)d_ref.p;
-        HIPCHK(d_bq.ensure((s.qual.n + 16) * sizeof(uint16_t)));
+        HIPCHK(d_bq.ensure((s.bq_elems + 256) * sizeof(uint16_t)));   // + slack: staged windows may read past the last row
         in.bq = (const uint16_t*)d_bq.p;
+        if ((rc = up(d_bqrow, s.bq_row, n))) return rc;
+        in.bq_row = (const uint64_t*)d_bqrow.p;
+        HIPCHK(d_rcp.ensure((n + 1) * sizeof(RcpPair)));
+        in.rcp = (const RcpPair*)d_rcp.p;
         // outputs / scratch
         const size_t P = (size_t)c.PS, Lp = (size_t)c.Lp;   // allocation sizes use the padded stride
         ntiles = (c.P + TILE - 1) / TILE;
@@ -455,9 +677,15 @@ class HipBackend : public Backend {
         Planes pl = {(uint32_t*)d_ncol.p, (uint32_t*)d_depth.p, (uint32_t*)d_istat.p, (float*)d_fstat.p, (uint32_t*)d_unavail.p};
         const DRead* reads = (const DRead*)d_reads.p;
         HIPCHK(hipEventRecord(evt[T_ANNOTATE], stream));
-        if (n > 0)
-            hipLaunchKernelGGL(k_annotate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (int32_t*)d_ends.p,
-                               (uint16_t*)d_bq.p, indels ? (uint32_t*)d_cnt.p : (uint32_t*)nullptr);
+        if (n > 0) {
+            static const bool serial = getenv("BRC_ANNOTATE_SERIAL") != nullptr;   // A/B knob: the per-lane form of K1
+            if (serial)
+                hipLaunchKernelGGL(k_annotate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (int32_t*)d_ends.p,
+                                   (uint16_t*)d_bq.p, (RcpPair*)d_rcp.p, indels ? (uint32_t*)d_cnt.p : (uint32_t*)nullptr);
+            else
+                hipLaunchKernelGGL(k_annotate_wave, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (int32_t*)d_ends.p,
+                                   (uint16_t*)d_bq.p, (RcpPair*)d_rcp.p, indels ? (uint32_t*)d_cnt.p : (uint32_t*)nullptr);
+        }
         HIPCHK(hipEventRecord(evt[T_SCAN_ENDS], stream));
         if ((rc = scan<OpMaxI32, true>((const int32_t*)d_ends.p, (int32_t*)d_prefmax.p, n))) return rc;
         HIPCHK(hipEventRecord(evt[T_TILES], stream));
@@ -468,7 +696,8 @@ class HipBackend : public Backend {
         if (ntiles > 0) {
             unsigned nwg = (unsigned)((ntiles + PILEUP_WAVES - 1) / PILEUP_WAVES);
             nwg = (nwg + 7u) & ~7u;
-            hipLaunchKernelGGL(k_pileup, dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), 0, stream, c, in, reads, (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p);
+#define BRC_LAUNCH_PILEUP(V) hipLaunchKernelGGL((k_pileup<V>), dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), 0, stream, c, in, reads, (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p)
+            switch (c.variant) { case 1: BRC_LAUNCH_PILEUP(1); break; case 2: BRC_LAUNCH_PILEUP(2); break; case 3: BRC_LAUNCH_PILEUP(3); break; case 7: BRC_LAUNCH_PILEUP(7); break; default: BRC_LAUNCH_PILEUP(0); }
         }
         HIPCHK(hipEventRecord(evt[T_COUNT], stream));
         if (P > 0) {

@@ -19,16 +19,16 @@ namespace brc {
 
 void Staged::init(const HostAlloc* A) {
     pos.A = A; flag.A = A; mapq.A = A; lib.A = A; l_qseq.A = A; n_cigar.A = A; cig_off.A = A; seq_off.A = A; qual_off.A = A;
-    nm.A = A; sm.A = A; tags.A = A; cigar.A = A; seq4.A = A; qual.A = A;
+    nm.A = A; sm.A = A; tags.A = A; cigar.A = A; seq4.A = A; qual.A = A; bq_row.A = A;
 }
 void Staged::clear() {
     pos.clear(); flag.clear(); mapq.clear(); lib.clear(); l_qseq.clear(); n_cigar.clear(); cig_off.clear(); seq_off.clear();
-    qual_off.clear(); nm.clear(); sm.clear(); tags.clear(); cigar.clear(); seq4.clear(); qual.clear();
-    n = 0; min_pos = 0; max_end = 0; n_indel_ops = 0;
+    qual_off.clear(); nm.clear(); sm.clear(); tags.clear(); cigar.clear(); seq4.clear(); qual.clear(); bq_row.clear();
+    bq_elems = 0; n = 0; min_pos = 0; max_end = 0; n_indel_ops = 0;
 }
 void Staged::destroy() {
     pos.destroy(); flag.destroy(); mapq.destroy(); lib.destroy(); l_qseq.destroy(); n_cigar.destroy(); cig_off.destroy();
-    seq_off.destroy(); qual_off.destroy(); nm.destroy(); sm.destroy(); tags.destroy(); cigar.destroy(); seq4.destroy(); qual.destroy();
+    seq_off.destroy(); qual_off.destroy(); nm.destroy(); sm.destroy(); tags.destroy(); cigar.destroy(); seq4.destroy(); qual.destroy(); bq_row.destroy();
 }
 
 int fmt_u32(char* out, uint32_t v) {
@@ -189,7 +189,7 @@ int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
               s.n_cigar.append(b->n_cigar, n) && s.cig_off.append(b->cigar_off, n) && s.seq_off.append(b->seq_off, n) &&
               s.qual_off.append(b->qual_off, n) && s.cigar.append(b->cigar, b->n_cigar_total) &&
               s.seq4.append(b->seq4, b->seq_bytes) && s.qual.append(b->qual, b->qual_bytes) &&
-              s.lib.reserve(n0 + n + 16) && s.nm.reserve(n0 + n + 16) && s.sm.reserve(n0 + n + 16) && s.tags.reserve(n0 + n + 16);
+              s.bq_row.reserve(n0 + n + 16) && s.lib.reserve(n0 + n + 16) && s.nm.reserve(n0 + n + 16) && s.sm.reserve(n0 + n + 16) && s.tags.reserve(n0 + n + 16);
     if (!ok) return fail(e, BRC_E_NOMEM, "host staging allocation failed");
     for (size_t i = 0; i < n; ++i) {
         s.lib.p[n0 + i] = (e->cfg.per_lib && b->lib) ? b->lib[i] : 0;
@@ -197,7 +197,7 @@ int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
         s.sm.p[n0 + i] = b->sm ? b->sm[i] : 0;
         s.tags.p[n0 + i] = b->tags ? b->tags[i] : 0;
     }
-    s.lib.n = s.nm.n = s.sm.n = s.tags.n = n0 + n;
+    s.lib.n = s.nm.n = s.sm.n = s.tags.n = s.bq_row.n = n0 + n;
     const int32_t maxcnt = e->cfg.max_cnt;
     for (size_t i = 0; i < n; ++i) {
         const size_t r = n0 + i;
@@ -207,6 +207,7 @@ int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
             return fail(e, BRC_E_ARG, "read offsets outside the batch arenas");
         if (e->cfg.per_lib && s.lib.p[r] >= e->g.Lp) return fail(e, BRC_E_ARG, "library index out of range");
         s.cig_off.p[r] += cb; s.seq_off.p[r] += sb; s.qual_off.p[r] += qb;
+        s.bq_row.p[r] = s.bq_elems; s.bq_elems += ((uint64_t)s.l_qseq.p[r] + 7u) & ~(uint64_t)7u;
         const int32_t pos = s.pos.p[r];
         if (pos < e->last_pos) return fail(e, BRC_E_ARG, "reads are not coordinate-sorted");
         e->last_pos = pos;

@@ -55,6 +55,8 @@ struct Staged {
     HBuf<int32_t> pos; HBuf<uint16_t> flag; HBuf<uint8_t> mapq; HBuf<int16_t> lib; HBuf<int32_t> l_qseq;
     HBuf<uint32_t> n_cigar; HBuf<uint64_t> cig_off, seq_off, qual_off; HBuf<int32_t> nm, sm; HBuf<uint8_t> tags;
     HBuf<uint32_t> cigar; HBuf<uint8_t> seq4, qual;
+    HBuf<uint64_t> bq_row;              // per read: first element of its 16-byte-aligned row in the device bq stream
+    uint64_t bq_elems = 0;              // total elements of the bq stream (sum of roundup8(l_qseq))
     int64_t n = 0;
     int64_t min_pos = 0, max_end = 0;   // extent of reads that enter the pileup
     uint64_t n_indel_ops = 0;           // upper bound on indel events (I/D/P operators)

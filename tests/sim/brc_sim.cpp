@@ -20,7 +20,7 @@ static const HostAlloc kAlloc = {sim_alloc, sim_release};
 
 class SimBackend : public Backend {
     DevCfg c; DevIn in; std::string err;
-    std::vector<DRead> reads; std::vector<int32_t> prefmax; std::vector<uint16_t> bq; size_t bq_n = 0;
+    std::vector<DRead> reads; std::vector<int32_t> prefmax; std::vector<uint16_t> bq; size_t bq_n = 0; std::vector<RcpPair> rcp;
     std::vector<uint32_t> ncol, depth, istat, unavail; std::vector<float> fstat;
     std::vector<IndelOut> iout;
     uint64_t n_events = 0, n_positions = 0, warn[BRC_N_WARN] = {0, 0, 0, 0};
@@ -38,14 +38,14 @@ class SimBackend : public Backend {
         in.pos = s.pos.p; in.flag = s.flag.p; in.mapq = s.mapq.p; in.lib = s.lib.p; in.l_qseq = s.l_qseq.p; in.n_cigar = s.n_cigar.p;
         in.cig_off = s.cig_off.p; in.seq_off = s.seq_off.p; in.qual_off = s.qual_off.p; in.nm = s.nm.p; in.sm = s.sm.p; in.tags = s.tags.p;
         in.cigar = s.cigar.p; in.seq4 = s.seq4.p; in.qual = s.qual.p; in.ref = g.ref ? g.ref + g.ref_lo : nullptr;
-        bq_n = s.qual.n; in.bq = nullptr;
+        bq_n = s.bq_elems; in.bq = nullptr; in.bq_row = s.bq_row.p;
         return BRC_OK;
     }
     int compute(brc_timing* t) override {
         if (t) memset(t, 0, sizeof *t);
         const int64_t n = c.n_reads, P = c.P, PS = c.PS; const int Lp = c.Lp;
-        reads.resize((size_t)n); prefmax.resize((size_t)n); bq.assign(bq_n + 1, 0); in.bq = bq.data();
-        for (int64_t i = 0; i < n; ++i) reads[(size_t)i] = annotate_read(c, in, i, bq.data());         // K1
+        reads.resize((size_t)n); prefmax.resize((size_t)n); bq.assign(bq_n + 1, 0); in.bq = bq.data(); rcp.resize((size_t)n + 1); in.rcp = rcp.data();
+        for (int64_t i = 0; i < n; ++i) reads[(size_t)i] = annotate_read(c, in, i, bq.data(), rcp.data());   // K1
         int32_t m = INT32_MIN;
         for (int64_t i = 0; i < n; ++i) { if (reads[(size_t)i].end > m) m = reads[(size_t)i].end; prefmax[(size_t)i] = m; }
         ncol.assign((size_t)(Lp * PS), 0); depth.assign((size_t)(Lp * PS), 0); unavail.assign((size_t)PS, NONE32);
@@ -75,14 +75,14 @@ class SimBackend : public Backend {
         std::vector<uint32_t> cnt((size_t)(P * Lp) + 1, 0), off((size_t)(P * Lp) + 1, 0);
         for (int64_t i = 0; i < n; ++i) {
             const DRead& rd = reads[(size_t)i]; const int lib = (int)(rd.misc >> 16) - 1;
-            enumerate_indels(c, in, rd, [&](int32_t p, int, int) { cnt[(size_t)((int64_t)(p - c.pos0) * Lp + lib)]++; });
+            enumerate_indels(c, in, rd, in.qual + in.qual_off[i], [&](int32_t p, int, int) { cnt[(size_t)((int64_t)(p - c.pos0) * Lp + lib)]++; });
         }
         uint32_t run = 0;
         for (size_t k = 0; k < cnt.size(); ++k) { off[k] = run; run += cnt[k]; }
         std::vector<IndelEv> ev(run + 1); std::vector<uint32_t> cur(off);
         for (int64_t i = n - 1; i >= 0; --i) {   // reversed on purpose: the reduction must not depend on fill order
             const DRead& rd = reads[(size_t)i]; const int lib = (int)(rd.misc >> 16) - 1;
-            enumerate_indels(c, in, rd, [&](int32_t p, int qpos, int len) {
+            enumerate_indels(c, in, rd, in.qual + in.qual_off[i], [&](int32_t p, int qpos, int len) {
                 IndelEv e; e.read = (uint32_t)i; e.qpos = qpos; e.len = len; e.key_lo = 0;
                 ev[cur[(size_t)((int64_t)(p - c.pos0) * Lp + lib)]++] = e;
             });
