@@ -72,8 +72,9 @@ struct DevIn {
     const struct RcpPair* rcp;   // [n_reads], device-produced by K1
 };
 
-// correctly rounded reciprocals written by K1 next to each DRead: 1/(float)l_qseq and 1/((float)clipped_length/2)
-struct RcpPair { float rcpL, rcpC; };
+// per-read float constants written by K1 next to each DRead (one 16-byte scalar load in KB): correctly rounded
+// reciprocals 1/(float)l_qseq and 1/((float)clipped_length/2), and the two denominators themselves
+struct RcpPair { float rcpL, rcpC, Lf, center; };
 
 // Packed per-read record written by K1 and read with ONE scalar load (s_load_dwordx16) by KB: 64 bytes.
 enum { M_REV = 1, M_Q2OK = 2, M_SMW = 4, M_NMW = 8, M_SIMPLE = 16,
@@ -224,7 +225,7 @@ BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i, uint16_t
     if (tags & 1u) snm = (float)in.nm[i] / (float)clipped;                                   // BasicStat.cpp:94-97
     else misc |= M_NMW;
     if (L >= 1 && clipped >= 1 && L < (1 << 24) && sum < (1u << 24) && sse < (1u << 24)) misc |= M_FAST;
-    RcpPair rc; rc.rcpL = 1.0f / (float)L; rc.rcpC = 1.0f / ((float)clipped * 0.5f);
+    RcpPair rc; rc.Lf = (float)L; rc.center = (float)clipped * 0.5f; rc.rcpL = 1.0f / rc.Lf; rc.rcpC = 1.0f / rc.center;
     rcp_out[i] = rc;
     r.misc = misc; r.l_qseq = L; r.q2 = q2; r.tp = tp; r.left = left_clip; r.clipped = clipped;
     r.zm_sum = sum; r.sse_add = sse; r.snm_add = snm; r.pad0 = 0;
@@ -237,12 +238,12 @@ BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i, uint16_t
 // per event (event_terms) and only the adds sit under the bucket dispatch (acc_apply).
 // All float arithmetic is fp32 round-to-nearest exactly where the reference's is, and the event-location sum goes
 // through double exactly like `float += 1.0 - float_expr` (BasicStat.cpp:69-70).  Build with -ffp-contract=off.
-struct EvTerms { float q2, s3p; double sev; };
+struct EvTerms { float q2, s3p; double sev; };   // q2: 0.0f when the read has no Q2 position; see acc_apply
 
 BRC_HD EvTerms event_terms(const DRead& r, int qpos) {
     EvTerms t;
     const float Lf = (float)r.l_qseq;
-    t.q2 = (float)iabs(qpos - r.q2) / Lf;                               // BasicStat.cpp:62
+    t.q2 = (r.misc & M_Q2OK) ? (float)iabs(qpos - r.q2) / Lf : 0.0f;   // BasicStat.cpp:60-62
     t.s3p = (float)iabs(qpos - r.tp) / Lf;                              // :66
     const float center = (float)r.clipped * 0.5f;                       // :69  (float)clipped_length/2.0, exact
     float d = (float)(qpos - r.left) - center;
@@ -260,12 +261,14 @@ BRC_HD void acc_apply(uint32_t* ai, float* af, const DRead& r, const EvTerms& t,
     const uint32_t rev = m & M_REV;
     ai[A_MINUS] += rev; ai[A_PLUS] += 1u - rev;
     ai[A_SMMQ] += r.zm_sum;
-    if (m & M_Q2OK) { af[F_SQ2] += t.q2; ai[A_NQ2]++; }
+    // adding +0.0f is the identity on these sums (they are never -0.0), so the two uniform conditions are folded into
+    // the addends once per event (event_addends) instead of once per bucket arm
+    af[F_SQ2] += t.q2; ai[A_NQ2] += (m & M_Q2OK) ? 1u : 0u;
     af[F_S3P] += t.s3p;
     ai[A_SCLIP] += (uint32_t)r.clipped;
     af[F_SEV] = (float)((double)af[F_SEV] + t.sev);
     ai[A_SSE] += r.sse_add;
-    if (!(m & M_NMW)) af[F_SNM] += r.snm_add;
+    af[F_SNM] += r.snm_add;                                             // 0.0f when NM is missing (annotate_read)
     if (!is_indel) ai[A_SBQ] += q;
 }
 
@@ -283,23 +286,21 @@ BRC_HD float div_rcp(float a, float b, float y) {
     return fmaf(r, y, q);
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BRC_ABSDIFF(a, b) ((int)__usad((unsigned)(a), (unsigned)(b), 0u))   /* v_sad_u32: both operands are >= 0 where the result is used */
+#else
+#define BRC_ABSDIFF(a, b) iabs((a) - (b))
+#endif
+
 BRC_HD EvTerms event_terms_fast(const DRead& r, const RcpPair& rc, int qpos) {
     EvTerms t;
-    const float Lf = (float)r.l_qseq;
-    t.q2 = div_rcp((float)iabs(qpos - r.q2), Lf, rc.rcpL);
-    t.s3p = div_rcp((float)iabs(qpos - r.tp), Lf, rc.rcpL);
-    const float center = (float)r.clipped * 0.5f;
-    float d = (float)(qpos - r.left) - center;
+    t.q2 = (r.misc & M_Q2OK) ? div_rcp((float)BRC_ABSDIFF(qpos, r.q2), rc.Lf, rc.rcpL) : 0.0f;
+    t.s3p = div_rcp((float)BRC_ABSDIFF(qpos, r.tp), rc.Lf, rc.rcpL);     // tp >= 0 whenever the read has a base
+    float d = (float)(qpos - r.left) - rc.center;
     d = d < 0.0f ? -d : d;
-    t.sev = 1.0 - (double)div_rcp(d, center, rc.rcpC);
+    t.sev = 1.0 - (double)div_rcp(d, rc.center, rc.rcpC);
     return t;
 }
-
-#if defined(__HIP_DEVICE_COMPILE__)
-#define BRC_MAD24(e, v, acc) ((e) * (v) + (acc))                /* e is 0/1: the compiler emits select + add */
-#else
-#define BRC_MAD24(e, v, acc) ((e) * (v) + (acc))
-#endif
 
 // ---------------------------------------------------------------- htslib resolve_cigar2 as a pure function of (read, position)
 
@@ -307,33 +308,41 @@ struct Ev { int qpos; int indel; bool in_col; bool is_del; };
 
 // Position p (absolute) against a general CIGAR.  Equivalent to the stateful cursor of htslib 1.10 sam.c
 // resolve_cigar2 for every position pos <= p < end visited in ascending order.
+// Written in uniform-control form: the loop, its trip count and every CIGAR load are the same for all lanes of a wave
+// (the read is wave-uniform), only the selects depend on the lane's p.  On the device this keeps the CIGAR reads on
+// the scalar unit (no per-lane early exit, no loads under divergent control flow).
 BRC_HD Ev resolve_cigar(const uint32_t* cig, uint32_t nc, int32_t pos, int32_t p) {
     Ev e; e.qpos = 0; e.indel = 0; e.in_col = false; e.is_del = false;
     int32_t x = pos; int y = 0;
     for (uint32_t k = 0; k < nc; ++k) {
         const uint32_t op = cig[k] & 0xfu; const int len = (int)(cig[k] >> 4);
         if (is_refop(op)) {
-            if (p >= x && p < x + len) {
-                e.in_col = true;
-                if (is_mop(op)) e.qpos = y + (p - x); else { e.is_del = true; e.qpos = y; }
-                if (p == x + len - 1 && k + 1 < nc) {          // peek the next operation
-                    const uint32_t op2 = cig[k + 1] & 0xfu; const int l2 = (int)(cig[k + 1] >> 4);
-                    if (op2 == CDEL) e.indel = -l2;
-                    else if (op2 == CINS) e.indel = l2;
-                    else if (op2 == CPAD && k + 2 < nc) {
-                        int l3 = 0;
-                        for (uint32_t kk = k + 2; kk < nc; ++kk) {
-                            const uint32_t o = cig[kk] & 0xfu;
-                            if (o == CINS) l3 += (int)(cig[kk] >> 4);
-                            else if (o == CDEL || o == CMATCH || o == CREF_SKIP || o == CEQUAL || o == CDIFF) break;
-                        }
-                        if (l3 > 0) e.indel = l3;
+            // what a lane standing on the LAST base of this operator would peek (uniform)
+            int peek = 0;
+            if (k + 1 < nc) {
+                const uint32_t op2 = cig[k + 1] & 0xfu; const int l2 = (int)(cig[k + 1] >> 4);
+                if (op2 == CDEL) peek = -l2;
+                else if (op2 == CINS) peek = l2;
+                else if (op2 == CPAD && k + 2 < nc) {
+                    int l3 = 0;
+                    for (uint32_t kk = k + 2; kk < nc; ++kk) {
+                        const uint32_t o = cig[kk] & 0xfu;
+                        if (o == CINS) l3 += (int)(cig[kk] >> 4);
+                        else if (o == CDEL || o == CMATCH || o == CREF_SKIP || o == CEQUAL || o == CDIFF) break;
                     }
+                    if (l3 > 0) peek = l3;
                 }
-                return e;
+            }
+            const bool here = !e.in_col && p >= x && p < x + len;       // per lane
+            const bool m = is_mop(op);
+            if (here) {
+                e.in_col = true;
+                e.is_del = !m;
+                e.qpos = m ? y + (p - x) : y;
+                e.indel = (p == x + len - 1) ? peek : 0;
             }
             x += len;
-            if (is_mop(op)) y += len;
+            if (m) y += len;
         } else if (op == CINS || op == CSOFT_CLIP) y += len;
     }
     return e;
@@ -341,12 +350,23 @@ BRC_HD Ev resolve_cigar(const uint32_t* cig, uint32_t nc, int32_t pos, int32_t p
 
 // ---------------------------------------------------------------- KB: one lane = one reference position
 
+// Per-lane (= per reference position) accumulator state.  Only the hot set lives in registers:
+//   dom  bucket dom_b = the reference base of the position: ~99 % of a position's events
+//   alt  bucket alt_b = the first other base seen at the position (SNP allele / first sequencing error)
+// A third, fourth, ... distinct base at one position is rare; those events read-modify-write the output planes of
+// this position directly (overflow_event) and `mem` remembers which buckets already live there.  Every bucket lives
+// in exactly one place for the whole tile, so its events are still summed in pileup-column order: exactness does not
+// depend on how dom_b / alt_b happen to be chosen.  (6 x 12 register accumulators would cap the kernel at 3-4 waves
+// per SIMD; this layout needs 24.)
 struct LaneAcc {
-    uint32_t ai[NBUCKET][NACC_I];
-    float af[NBUCKET][NF];
+    uint32_t di[NACC_I]; float df[NF];      // dominant bucket
+    uint32_t xi[NACC_I]; float xf[NF];      // alternate bucket
+    uint32_t dom_b, alt_b;                  // bucket ids; alt_b == NB_NONE until assigned
+    uint32_t mem;                           // bit k: bucket k has been written to the planes by overflow_event
     uint32_t ncol, depth, unavail;
-    uint32_t w_sm, w_nm;      // process_read-level warning counts of this lane
+    uint32_t w_sm, w_nm;                    // process_read-level warning counts of this lane
 };
+enum { NB_NONE = 7 };
 
 #if defined(__clang__)
 #define BRC_UNROLL _Pragma("unroll")
@@ -356,13 +376,17 @@ struct LaneAcc {
 
 BRC_HD void lane_init(LaneAcc& a) {
     BRC_UNROLL
-    for (int b = 0; b < NBUCKET; ++b) {
-        BRC_UNROLL
-        for (int f = 0; f < NACC_I; ++f) a.ai[b][f] = 0;
-        BRC_UNROLL
-        for (int f = 0; f < NF; ++f) a.af[b][f] = 0.0f;
-    }
+    for (int f = 0; f < NACC_I; ++f) { a.di[f] = 0; a.xi[f] = 0; }
+    BRC_UNROLL
+    for (int f = 0; f < NF; ++f) { a.df[f] = 0.0f; a.xf[f] = 0.0f; }
+    a.dom_b = 1; a.alt_b = NB_NONE; a.mem = 0;
     a.ncol = a.depth = 0; a.unavail = NONE32; a.w_sm = a.w_nm = 0;
+}
+
+// dominant bucket of position p: the bucket of its reference base ('A' when there is no reference)
+BRC_HD uint32_t dominant_bucket(const DevCfg& c, const DevIn& in, int64_t p) {
+    if (!c.has_ref) return 1u;
+    return canon_bucket(nt16_of_char(ref_at(c, in.ref, p)));
 }
 
 // One read against one lane, in two stages so the device loop can software-pipeline them (probe + issue the event
@@ -385,18 +409,40 @@ BRC_HD Probe lane_probe(const DevCfg& c, const DevIn& in, const DRead& rd, uint3
     }
     bool in_col = covered, is_del = false;
     if (!(rd.misc & M_SIMPLE)) {                                        // general CIGAR (uniform, uncommon)
-        in_col = false;
-        if (covered) {
-            const Ev e = resolve_cigar(in.cigar + rd.cig_off, rd.n_cigar, rd.pos, p);
-            in_col = e.in_col; pr.qpos = e.qpos; is_del = e.is_del; pr.indel = e.indel;
-        }
+        const Ev e = resolve_cigar(in.cigar + rd.cig_off, rd.n_cigar, rd.pos, p);   // uniform control: all lanes
+        in_col = covered && e.in_col; pr.qpos = e.qpos; is_del = e.is_del; pr.indel = e.indel;
     }
     a.ncol += in_col ? 1u : 0u;                                         // lib_counts[library] created (:286)
     pr.want = in_col && !is_del && (int)((rd.misc >> 8) & 0xffu) >= c.min_mapq;   // :288
     return pr;
 }
 
-BRC_HD void lane_accumulate(const DevCfg& c, const DRead& rd, const RcpPair& rc, const Probe& pr, uint32_t bqv, LaneAcc& a) {
+// where a lane's planes live (wave-uniform except k)
+struct LaneOut { Planes pl; int lib; int64_t k; };
+
+// Third-or-later distinct base at this position: accumulate straight into the output planes (read-modify-write; the
+// lane owns its position, so no atomics).  First touch of a bucket starts from zero instead of reading the planes.
+BRC_HD void overflow_event(const DevCfg& c, const LaneOut& o, LaneAcc& a, uint32_t b, const DRead& rd, const EvTerms& t, uint32_t q) {
+    const int64_t P = c.PS;
+    uint32_t* ip = o.pl.istat + (((int64_t)o.lib * NBUCKET + b) * NI) * P + o.k;
+    float* fp = o.pl.fstat + (((int64_t)o.lib * NBUCKET + b) * NF) * P + o.k;
+    uint32_t ai[NACC_I]; float af[NF];
+    const bool fresh = !((a.mem >> b) & 1u);
+    ai[A_SMQ] = fresh ? 0u : ip[I_SMQ * P]; ai[A_SSE] = fresh ? 0u : ip[I_SSE * P]; ai[A_PLUS] = fresh ? 0u : ip[I_PLUS * P];
+    ai[A_MINUS] = fresh ? 0u : ip[I_MINUS * P]; ai[A_NQ2] = fresh ? 0u : ip[I_NQ2 * P]; ai[A_SMMQ] = fresh ? 0u : ip[I_SMMQ * P];
+    ai[A_SCLIP] = fresh ? 0u : ip[I_SCLIP * P]; ai[A_SBQ] = fresh ? 0u : ip[I_SBQ * P];
+    BRC_UNROLL
+    for (int f = 0; f < NF; ++f) af[f] = fresh ? 0.0f : fp[f * P];
+    acc_apply(ai, af, rd, t, q, false);
+    ip[I_N * P] = ai[A_PLUS] + ai[A_MINUS]; ip[I_SMQ * P] = ai[A_SMQ]; ip[I_SSE * P] = ai[A_SSE]; ip[I_PLUS * P] = ai[A_PLUS];
+    ip[I_MINUS * P] = ai[A_MINUS]; ip[I_NQ2 * P] = ai[A_NQ2]; ip[I_SMMQ * P] = ai[A_SMMQ]; ip[I_SCLIP * P] = ai[A_SCLIP];
+    ip[I_SBQ * P] = ai[A_SBQ];
+    BRC_UNROLL
+    for (int f = 0; f < NF; ++f) fp[f * P] = af[f];
+    a.mem |= 1u << b;
+}
+
+BRC_HD void lane_accumulate(const DevCfg& c, const DRead& rd, const RcpPair& rc, const Probe& pr, uint32_t bqv, const LaneOut& o, LaneAcc& a) {
     if (!pr.want) return;
     const uint32_t q = bqv & 0xffu;
     if ((int)q < c.min_bq) return;                                      // :288
@@ -407,71 +453,30 @@ BRC_HD void lane_accumulate(const DevCfg& c, const DRead& rd, const RcpPair& rc,
         if (rd.misc & M_NMW) a.w_nm++;
         // whenever a lane has an event the read has l_qseq >= 1 and clipped_length >= 1: reciprocals are finite
         const EvTerms t = event_terms_fast(rd, rc, pr.qpos);
-        // Six independent, fully unrolled `if (b == k)` blocks with static indices keep the 6 buckets in registers; the
-        // lane masks are SALU work, only the 12-13 adds of the buckets actually present in the wave cost VALU issue.
-        // (A `switch` lets LLVM sink the arms' common tail into one block addressed through a phi of pointers, which
-        // defeats scalar replacement and spills every accumulator to scratch.)
-        BRC_UNROLL
-        for (uint32_t k = 0; k < (uint32_t)NBUCKET; ++k)
-            if (b == k) acc_apply(a.ai[k], a.af[k], rd, t, q, false);
-    }
-}
-
-// Branch-free form of lane_accumulate (the one the pileup kernel uses; whenever a lane has an event the read has
-// l_qseq >= 1 and clipped_length >= 1, so the reciprocal-based divisions are well defined): the lane predicate e = pass && (base == bucket k) is folded
-// into the arithmetic (integer sums: acc += e * addend as one mad24; float sums: acc += e ? term : +0.0f, which is the
-// identity on these non-negative-zero sums; event location: select between the old and the double-promoted new sum),
-// so a wave with mixed bases executes one straight-line block instead of four exec-masked regions.  Buckets '=' and
-// 'N' are rare and handled by an ordinary branch.
-BRC_HD void acc_fast(const DevCfg& c, const DRead& rd, const RcpPair& rc, const Probe& pr, uint32_t bqv, LaneAcc& a) {
-    const uint32_t q = bqv & 0xffu, b = bqv >> 8;
-    const bool pass = pr.want && (int)q >= c.min_bq && (pr.indel < 1 || !c.insertion_centric);
-    const bool dep = pr.want && (int)q >= c.min_bq;
-    a.depth += dep ? 1u : 0u;
-    const uint32_t m = rd.misc;
-    const uint32_t mapq = (m >> 8) & 0xffu, rev = m & M_REV, q2ok = (m & M_Q2OK) ? 1u : 0u;
-    a.w_sm += (pass && (m & M_SMW)) ? 1u : 0u;
-    a.w_nm += (pass && (m & M_NMW)) ? 1u : 0u;
-    const EvTerms t = event_terms_fast(rd, rc, pr.qpos);
-    const float tq2 = q2ok ? t.q2 : 0.0f;
-    const float tnm = (m & M_NMW) ? 0.0f : rd.snm_add;
-    BRC_UNROLL
-    for (uint32_t k = 1; k <= 4; ++k) {
-        const bool e = pass && b == k;
-        const uint32_t ei = e ? 1u : 0u;
-        uint32_t* ai = a.ai[k]; float* af = a.af[k];
-        ai[A_SMQ] = BRC_MAD24(ei, mapq, ai[A_SMQ]);
-        ai[A_SSE] = BRC_MAD24(ei, rd.sse_add, ai[A_SSE]);
-        ai[A_MINUS] = BRC_MAD24(ei, rev, ai[A_MINUS]);
-        ai[A_PLUS] = BRC_MAD24(ei, 1u - rev, ai[A_PLUS]);
-        ai[A_NQ2] = BRC_MAD24(ei, q2ok, ai[A_NQ2]);
-        ai[A_SMMQ] = BRC_MAD24(ei, rd.zm_sum, ai[A_SMMQ]);
-        ai[A_SCLIP] = BRC_MAD24(ei, (uint32_t)rd.clipped, ai[A_SCLIP]);
-        ai[A_SBQ] = BRC_MAD24(ei, q, ai[A_SBQ]);
-        af[F_SQ2] += e ? tq2 : 0.0f;
-        af[F_S3P] += e ? t.s3p : 0.0f;
-        af[F_SNM] += e ? tnm : 0.0f;
-        const float nsev = (float)((double)af[F_SEV] + t.sev);
-        af[F_SEV] = e ? nsev : af[F_SEV];
-    }
-    if (pass && (b == 0u || b >= 5u)) {
-        if (b == 0u) acc_apply(a.ai[0], a.af[0], rd, t, q, false);
-        if (b >= 5u) acc_apply(a.ai[5], a.af[5], rd, t, q, false);
+        // Independent single-predecessor blocks only (no if/else chain, no switch): LLVM would otherwise sink the arms'
+        // common tail into one block addressed through a phi of pointers, which defeats scalar replacement of the
+        // accumulators and sends them to scratch memory.
+        const bool isd = b == a.dom_b;
+        if (isd) acc_apply(a.di, a.df, rd, t, q, false);
+        const bool take_alt = !isd && (a.alt_b == NB_NONE || a.alt_b == b);
+        if (take_alt) { a.alt_b = b; acc_apply(a.xi, a.xf, rd, t, q, false); }
+        if (!isd && !take_alt) overflow_event(c, o, a, b, rd, t, q);
     }
 }
 
 // unpipelined form (simulator, reference for the pipelined device loop)
 BRC_HD void lane_visit_read(const DevCfg& c, const DevIn& in, const DRead& rd, uint32_t ridx, uint32_t lib_sel,
-                            int32_t p, bool lane_valid, LaneAcc& a) {
+                            int32_t p, bool lane_valid, const LaneOut& o, LaneAcc& a) {
     const Probe pr = lane_probe(c, in, rd, ridx, lib_sel, p, lane_valid, a);
     const uint32_t bqv = pr.want ? in.bq[rd.bq_off + (uint64_t)pr.qpos] : 0u;
-    if (c.variant == 7) acc_fast(c, rd, in.rcp[ridx], pr, bqv, a);      // alternative formulation kept for A/B runs
-    else lane_accumulate(c, rd, in.rcp[ridx], pr, bqv, a);
+    lane_accumulate(c, rd, in.rcp[ridx], pr, bqv, o, a);
 }
 
-// Write one lane's accumulators to the position-major planes (coalesced across the wave: lane == position).
-BRC_HD void lane_store(const DevCfg& c, const Planes& pl, int lib, int64_t k, const LaneAcc& a) {
+// Write one lane's accumulators to the position-major planes (coalesced across the wave: lane == position).  Buckets
+// that overflow_event already wrote stay as they are; the rest are the dominant / alternate registers or zero.
+BRC_HD void lane_store(const DevCfg& c, const LaneOut& o, const LaneAcc& a) {
     const int64_t P = c.PS;                                              // plane stride
+    const Planes& pl = o.pl; const int lib = o.lib; const int64_t k = o.k;
     const bool dead = c.per_lib && a.unavail != NONE32;                 // position abandoned: report nothing
     pl.ncol[(int64_t)lib * P + k] = dead ? 0u : a.ncol;
     pl.depth[(int64_t)lib * P + k] = dead ? 0u : a.depth;
@@ -480,18 +485,18 @@ BRC_HD void lane_store(const DevCfg& c, const Planes& pl, int lib, int64_t k, co
     for (int b = 0; b < NBUCKET; ++b) {
         uint32_t* ip = pl.istat + (((int64_t)lib * NBUCKET + b) * NI) * P + k;
         float* fp = pl.fstat + (((int64_t)lib * NBUCKET + b) * NF) * P + k;
-        const uint32_t* s = a.ai[b];
-        ip[I_N * P] = dead ? 0u : s[A_PLUS] + s[A_MINUS];
-        ip[I_SMQ * P] = dead ? 0u : s[A_SMQ];
-        ip[I_SSE * P] = dead ? 0u : s[A_SSE];
-        ip[I_PLUS * P] = dead ? 0u : s[A_PLUS];
-        ip[I_MINUS * P] = dead ? 0u : s[A_MINUS];
-        ip[I_NQ2 * P] = dead ? 0u : s[A_NQ2];
-        ip[I_SMMQ * P] = dead ? 0u : s[A_SMMQ];
-        ip[I_SCLIP * P] = dead ? 0u : s[A_SCLIP];
-        ip[I_SBQ * P] = dead ? 0u : s[A_SBQ];
+        const bool isdom = !dead && a.dom_b == (uint32_t)b, isalt = !dead && a.alt_b == (uint32_t)b;
+        if (!dead && !isdom && !isalt && ((a.mem >> b) & 1u)) continue;  // lives in the planes already
+        uint32_t s[NACC_I]; float g[NF];
         BRC_UNROLL
-        for (int f = 0; f < NF; ++f) fp[f * P] = dead ? 0.0f : a.af[b][f];
+        for (int f = 0; f < NACC_I; ++f) s[f] = isdom ? a.di[f] : (isalt ? a.xi[f] : 0u);
+        BRC_UNROLL
+        for (int f = 0; f < NF; ++f) g[f] = isdom ? a.df[f] : (isalt ? a.xf[f] : 0.0f);
+        ip[I_N * P] = s[A_PLUS] + s[A_MINUS];
+        ip[I_SMQ * P] = s[A_SMQ]; ip[I_SSE * P] = s[A_SSE]; ip[I_PLUS * P] = s[A_PLUS]; ip[I_MINUS * P] = s[A_MINUS];
+        ip[I_NQ2 * P] = s[A_NQ2]; ip[I_SMMQ * P] = s[A_SMMQ]; ip[I_SCLIP * P] = s[A_SCLIP]; ip[I_SBQ * P] = s[A_SBQ];
+        BRC_UNROLL
+        for (int f = 0; f < NF; ++f) fp[f * P] = g[f];
     }
 }
 

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_annotate_wave(DevCfg c, DevIn in, DRead
         r.zm_sum = sum; r.sse_add = sse; r.snm_add = snm; r.pad0 = 0;
         if (lane == 0) {
             reads[i] = r; ends[i] = r.end;
-            RcpPair rc; rc.rcpL = 1.0f / (float)L; rc.rcpC = 1.0f / ((float)clipped * 0.5f);
+            RcpPair rc; rc.Lf = (float)L; rc.center = (float)clipped * 0.5f; rc.rcpL = 1.0f / rc.Lf; rc.rcpC = 1.0f / rc.center;
             rcp[i] = rc;
         }
     }
@@ -282,13 +282,19 @@ __global__ __launch_bounds__(256) void k_tiles(DevCfg c, const int32_t* __restri
 // ---------------------------------------------------------------- KB: pileup + BasicStat accumulation (the hot kernel)
 
 enum { PILEUP_WAVES = 4 };   // 256 threads: 4 consecutive tiles (256 positions) per workgroup
-enum { ROW_U4 = 9 };         // LDS row per staged read: 9 x 16 B = 72 bq elements (64 tile positions + up to 7 of alignment slack)
+enum { WIN_U4 = 12 };        // bq window per staged read: 12 x 16 B = 96 elements (>= 64 tile positions + 7 of alignment slack)
+enum { ROW_U4 = 15 };        // LDS row = window + the read's accumulate half (2 x 16 B) + its float constants (16 B)
+enum { BATCH = 16 };         // reads staged per batch (LDS rows per wave): 16 x 240 B = 3.75 KB per wave
 
 // V: 0 = production; 1/2/3 = profiling ablations (no plane stores / probe+loads only / stores only), BRC_PILEUP_VARIANT
 template <int V>
 __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in, const DRead* __restrict__ reads,
                                                               const uint2* __restrict__ rng, int64_t ntiles, Planes pl,
-                                                              uint4* __restrict__ tile_ctr) {
+                                                              uint4* __restrict__ tile_ctr,
+                                                              // read-only inputs again as restrict-qualified kernel arguments:
+                                                              // only then may wave-uniform reads of them use scalar loads
+                                                              const uint32_t* __restrict__ cigar_ro, const RcpPair* __restrict__ rcp,
+                                                              const uint16_t* __restrict__ bq_ro) {
     // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch order); give every XCD one contiguous
     // run of tiles so neighbouring tiles, which share most of their reads, hit the same 4-MiB L2.
     const uint32_t nb = gridDim.x;            // multiple of 8
@@ -306,47 +312,72 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
 
     LaneAcc a;
     lane_init(a);
-    // The tile's reads are visited in file order, in batches of 64:
-    //  1. batch table: lane l loads the 32-byte probe half of read base+l into its own registers (coalesced);
-    //  2. staging: lane l copies the 72-element window of its read's bq row that this tile can touch into a wave-private
-    //     LDS row (nine independent 16-byte loads per lane, all in flight together: the memory latency of the whole
-    //     batch is paid once, not once per read);
-    //  3. the read loop: read j's pos/end/misc are broadcast with v_readlane, its event word comes from LDS row j
-    //     (ds_read_u16, issued one read ahead), its accumulate half (Zm integers, addends, reciprocals) through scalar
-    //     loads one read ahead (two register sets alternating by name).  Reads with a general CIGAR are not staged; their
-    //     event words are fetched from global memory (uncommon).
-    __shared__ uint4 lds_rows[PILEUP_WAVES][64][ROW_U4];
+    a.dom_b = valid ? dominant_bucket(c, in, p) : 1u;
+    LaneOut o; o.pl = pl; o.lib = lib; o.k = valid ? k : 0;
+    // The tile's reads are visited in file order, in batches of BATCH = 16, software-pipelined at batch level:
+    //  * lane table: lanes r, r+16, r+32, r+48 hold the probe half (pos, end, bq row, misc, l_qseq) of read base+r;
+    //  * staging: those four lanes copy the 96-element window of that read's bq row that this tile can touch into a
+    //    wave-private LDS row (3 x 16-byte loads per lane); the loads of batch b+1 are issued into registers at the START
+    //    of batch b's read loop and written to LDS at its END, and the lane table of batch b+2 is prefetched, so the
+    //    memory latency of staging hides behind the loop (only the first batch of a tile pays it);
+    //  * read loop: read j's pos/end/misc are broadcast with v_readlane, its event word comes from LDS row j
+    //    (ds_read_u16, issued one read ahead), its accumulate half (Zm integers, addends, float constants) from the
+    //    same row with three broadcast ds_read_b128 — no scalar/vector memory latency inside the loop.  Reads with a general CIGAR are not staged; their event words come from global
+    //    memory (uncommon).
+    __shared__ uint4 lds_rows[PILEUP_WAVES][BATCH][ROW_U4];
     if (lo < hi && V != 3) {
         const uint32_t libsel = (uint32_t)lib + 1u;
         struct ProbeHalf { int32_t pos, end; uint32_t cig_off, n_cigar; uint64_t bq_off; uint32_t misc; int32_t l_qseq; };
         struct AccHalf { int32_t q2, tp, left, clipped; uint32_t zm_sum, sse_add; float snm_add; uint32_t pad0; };
+        struct Tab { int32_t pos, end; uint64_t bq_off; uint32_t misc; int32_t l_qseq; };
         static_assert(sizeof(ProbeHalf) == 32 && sizeof(AccHalf) == 32 && sizeof(DRead) == 64, "DRead halves");
         const char* __restrict__ rbase = reinterpret_cast<const char*>(reads);
-        const RcpPair* __restrict__ rcp = in.rcp;
         uint4(*rows)[ROW_U4] = lds_rows[threadIdx.x >> 6];
         const int32_t p0 = (int32_t)(c.pos0 + tile * TILE);                 // first position of the tile (uniform)
+        const uint32_t row = (uint32_t)lane & (uint32_t)(BATCH - 1), slot = (uint32_t)lane >> 4;   // slot 0..3
 #define BRC_LD_ACC(i) (*reinterpret_cast<const AccHalf*>(rbase + (size_t)(i) * 64u + 32u))
 #define BRC_RL(x, j) __builtin_amdgcn_readlane((int)(x), (int)(j))
-        for (uint32_t base = lo; base < hi; base += 64u) {
-            const uint32_t nb = (hi - base) < 64u ? (hi - base) : 64u;
-            const uint32_t last = base + nb - 1u;
-            // 1. batch table
-            const ProbeHalf T = *reinterpret_cast<const ProbeHalf*>(rbase + (size_t)(base + ((uint32_t)lane < nb ? (uint32_t)lane : 0u)) * 64u);
-            // 2. staging (window start rounded down to 8 elements = 16 bytes; qpos - ws is in [0, 71] for covered lanes)
-            {
-                const int32_t d0 = p0 - T.pos;
-                const uint32_t ws = d0 > 0 ? ((uint32_t)d0 & ~7u) : 0u;
-                const bool row_ok = (uint32_t)lane < nb && (T.misc & M_SIMPLE) && T.end > T.pos && (int32_t)ws < T.l_qseq + 8;
-                if (row_ok) {
-                    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(in.bq + T.bq_off + ws);
-                    uint4 w[ROW_U4];
-#pragma unroll
-                    for (int q = 0; q < ROW_U4; ++q) w[q] = src[q];
-#pragma unroll
-                    for (int q = 0; q < ROW_U4; ++q) rows[lane][q] = w[q];
-                }
+        // lane table of the batch starting at read b0 (clamped to the tile's reads)
+#define BRC_LD_TAB(TT, b0)                                                                                              \
+        {                                                                                                                 \
+            const uint32_t ri = (b0) + row < hi ? (b0) + row : hi - 1u;                                                   \
+            const ProbeHalf* hp = reinterpret_cast<const ProbeHalf*>(rbase + (size_t)ri * 64u);                           \
+            TT.pos = hp->pos; TT.end = hp->end; TT.bq_off = hp->bq_off; TT.misc = hp->misc; TT.l_qseq = hp->l_qseq;       \
+        }
+        // window loads of a batch into registers (W0..W2 = chunks slot, slot+4, slot+8 of the lane's row) ...
+#define BRC_LD_WIN(TT, b0, W0, W1, W2, W3, OK)                                                                          \
+        {                                                                                                                 \
+            const int32_t d0 = p0 - TT.pos;                                                                               \
+            const uint32_t ws = d0 > 0 ? ((uint32_t)d0 & ~7u) : 0u;                                                       \
+            OK = (b0) + row < hi && (TT.misc & M_SIMPLE) && TT.end > TT.pos && (int32_t)ws < TT.l_qseq + 8;               \
+            if (OK) {                                                                                                     \
+                const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bq_ro + TT.bq_off + ws) + slot;           \
+                W0 = src[0]; W1 = src[4]; W2 = src[8];                                                                    \
+            }                                                                                                             \
+            /* accumulate half (slots 0,1: the two 16-byte halves at +32) and float constants (slot 2) of read b0+row */ \
+            const uint32_t ri = (b0) + row < hi ? (b0) + row : hi - 1u;                                                   \
+            if (slot < 2u) W3 = *reinterpret_cast<const uint4*>(rbase + (size_t)ri * 64u + 32u + 16u * slot);             \
+            else if (slot == 2u) W3 = *reinterpret_cast<const uint4*>(rcp + ri);                                          \
+        }
+        // ... and their write into the LDS rows
+#define BRC_ST_WIN(W0, W1, W2, W3, OK)                                                                                  \
+        {                                                                                                                 \
+            if (OK) { rows[row][slot] = W0; rows[row][slot + 4u] = W1; rows[row][slot + 8u] = W2; }                       \
+            if (slot < 3u) rows[row][(uint32_t)WIN_U4 + slot] = W3;                                                       \
+        }
+        Tab T, Tn, Tnn;
+        uint4 W0 = make_uint4(0, 0, 0, 0), W1 = W0, W2 = W0, W3 = W0; bool wok = false;
+        BRC_LD_TAB(T, lo)
+        BRC_LD_TAB(Tn, lo + (uint32_t)BATCH)
+        BRC_LD_WIN(T, lo, W0, W1, W2, W3, wok)
+        BRC_ST_WIN(W0, W1, W2, W3, wok)                                           // first batch: staged synchronously
+        for (uint32_t base = lo; base < hi; base += (uint32_t)BATCH) {
+            const uint32_t nb = (hi - base) < (uint32_t)BATCH ? (hi - base) : (uint32_t)BATCH;
+            const bool more = base + (uint32_t)BATCH < hi;
+            if (more) {                                                       // prefetch: windows of batch b+1, table of batch b+2
+                BRC_LD_WIN(Tn, base + (uint32_t)BATCH, W0, W1, W2, W3, wok)
+                BRC_LD_TAB(Tnn, base + 2u * (uint32_t)BATCH)
             }
-            // 3. read loop
             // probe of read j (inline form of lane_probe; see brc_core.h for the commented reference version)
 #define BRC_PROBE(j, PO, VO)                                                                                            \
             {                                                                                                             \
@@ -368,62 +399,53 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
                         const int32_t d0 = p0 - pos_j;                                                                    \
                         const uint32_t ws = d0 > 0 ? ((uint32_t)d0 & ~7u) : 0u;                                           \
                         if (PO.want) VO = (uint32_t)reinterpret_cast<const uint16_t*>(rows[(j)])[(uint32_t)PO.qpos - ws]; \
-                    } else if (covered) {                                                                                 \
-                        const uint32_t cig_off = (uint32_t)BRC_RL(T.cig_off, j), n_cig = (uint32_t)BRC_RL(T.n_cigar, j);  \
-                        const uint64_t bqo = (uint64_t)(uint32_t)BRC_RL((uint32_t)T.bq_off, j) |                          \
-                                             ((uint64_t)(uint32_t)BRC_RL((uint32_t)(T.bq_off >> 32), j) << 32);           \
-                        const Ev e = resolve_cigar(in.cigar + cig_off, n_cig, pos_j, p);                                  \
-                        if (e.in_col) {                                                                                   \
-                            a.ncol++;                                                                                     \
-                            PO.qpos = e.qpos; PO.indel = e.indel; PO.want = !e.is_del && mapq_ok;                         \
-                            if (PO.want) VO = (uint32_t)in.bq[bqo + (uint64_t)(uint32_t)e.qpos];                          \
-                        }                                                                                                 \
+                    } else {   /* general CIGAR: everything up to the final event load stays wave-uniform (scalar loads) */ \
+                        const ProbeHalf* hj = reinterpret_cast<const ProbeHalf*>(rbase + (size_t)(base + (j)) * 64u);     \
+                        const uint32_t cig_off = hj->cig_off, n_cig = hj->n_cigar;                                        \
+                        const uint64_t bqo = hj->bq_off;                                                                  \
+                        const Ev e = resolve_cigar(cigar_ro + cig_off, n_cig, pos_j, p);                                  \
+                        const bool in_col = covered && e.in_col;                                                          \
+                        a.ncol += in_col ? 1u : 0u;                                                                       \
+                        PO.qpos = e.qpos; PO.indel = e.indel; PO.want = in_col && !e.is_del && mapq_ok;                   \
+                        if (PO.want) VO = (uint32_t)bq_ro[bqo + (uint64_t)(uint32_t)e.qpos];                              \
                     }                                                                                                     \
                 }                                                                                                         \
             }
-            // NOTE: readlane inside the divergent `else if (covered)` branch would read with a partial exec mask; v_readlane
-            // ignores exec for the source lane, so the broadcast is still well defined.
-            AccHalf GA = BRC_LD_ACC(base), GB = GA;
-            RcpPair CA = rcp[base], CB = CA;
             Probe P0, P1; uint32_t V0, V1 = 0u;
             BRC_PROBE(0u, P0, V0)
             P1 = P0;
-            DRead RQ; RQ.pad0 = 0; RQ.pos = RQ.end = 0; RQ.cig_off = RQ.n_cigar = 0; RQ.bq_off = 0;
-            // STEP(j): accumulate read j with acc half G0/C0; probe read j+1; issue scalar loads of the acc half of j+1 -> G1/C1
-#define BRC_STEP(j, G0, C0, G1, C1)                                                                                     \
-            {                                                                                                             \
-                const uint32_t j1 = (j) + 1u < nb ? (j) + 1u : (j);                                                       \
-                G1 = BRC_LD_ACC(base + j1); C1 = rcp[base + j1];                                                          \
-                if ((j) + 1u < nb) BRC_PROBE((j) + 1u, P1, V1)                                                            \
-                RQ.misc = (uint32_t)BRC_RL(T.misc, j); RQ.l_qseq = BRC_RL(T.l_qseq, j);                                   \
-                RQ.q2 = G0.q2; RQ.tp = G0.tp; RQ.left = G0.left; RQ.clipped = G0.clipped;                                 \
-                RQ.zm_sum = G0.zm_sum; RQ.sse_add = G0.sse_add; RQ.snm_add = G0.snm_add;                                  \
-                if (V == 2) a.depth += V0;                                                                                \
-                else if (V == 7) acc_fast(c, RQ, C0, P0, V0, a);                                                          \
-                else lane_accumulate(c, RQ, C0, P0, V0, a);                                                               \
-                P0 = P1; V0 = V1;                                                                                         \
+            DRead RQ; RQ.pad0 = 0; RQ.pos = RQ.end = 0; RQ.cig_off = RQ.n_cigar = 0; RQ.bq_off = 0; RQ.l_qseq = 0;
+            for (uint32_t j = 0; j < nb; ++j) {
+                // read j's accumulate half + float constants: three broadcast LDS reads (same address in every lane)
+                const uint4 g0 = rows[j][WIN_U4], g1 = rows[j][WIN_U4 + 1], g2 = rows[j][WIN_U4 + 2];
+                if (j + 1u < nb) BRC_PROBE(j + 1u, P1, V1)                       // probe read j+1 (its LDS read in flight)
+                RQ.misc = (uint32_t)BRC_RL(T.misc, j);
+                RQ.q2 = (int32_t)g0.x; RQ.tp = (int32_t)g0.y; RQ.left = (int32_t)g0.z; RQ.clipped = (int32_t)g0.w;
+                RQ.zm_sum = g1.x; RQ.sse_add = g1.y; RQ.snm_add = __uint_as_float(g1.z);
+                RcpPair C; C.rcpL = __uint_as_float(g2.x); C.rcpC = __uint_as_float(g2.y); C.Lf = __uint_as_float(g2.z); C.center = __uint_as_float(g2.w);
+                if (V == 2) a.depth += V0;
+                else lane_accumulate(c, RQ, C, P0, V0, o, a);                    // accumulate read j
+                P0 = P1; V0 = V1;
             }
-            for (uint32_t j = 0; j < nb; j += 2u) {
-                BRC_STEP(j, GA, CA, GB, CB)
-                if (j + 1u < nb) BRC_STEP(j + 1u, GB, CB, GA, CA)
-            }
-            (void)last;
-#undef BRC_STEP
 #undef BRC_PROBE
+            if (more) {                                                       // all reads of this batch are done with the rows
+                BRC_ST_WIN(W0, W1, W2, W3, wok)
+                T = Tn; Tn = Tnn;
+            }
         }
 #undef BRC_LD_ACC
 #undef BRC_RL
+#undef BRC_LD_TAB
+#undef BRC_LD_WIN
+#undef BRC_ST_WIN
     }
-    if (V != 1) { if (valid) lane_store(c, pl, lib, k, a); }
+    if (V != 1) { if (valid) lane_store(c, o, a); }
     else if (valid) {
         uint32_t x = a.ncol ^ a.depth;
 #pragma unroll
-        for (int b = 0; b < NBUCKET; ++b) {
+        for (int f = 0; f < NACC_I; ++f) x ^= a.di[f] ^ a.xi[f];
 #pragma unroll
-            for (int f = 0; f < NACC_I; ++f) x ^= a.ai[b][f];
-#pragma unroll
-            for (int f = 0; f < NF; ++f) x ^= __float_as_uint(a.af[b][f]);
-        }
+        for (int f = 0; f < NF; ++f) x ^= __float_as_uint(a.df[f]) ^ __float_as_uint(a.xf[f]);
         pl.ncol[(int64_t)lib * c.PS + k] = x;
     }
 
@@ -630,7 +652,7 @@ class HipBackend : public Backend {
         in.seq_off = (const uint64_t*)d_so.p; in.qual_off = (const uint64_t*)d_qo.p; in.nm = (const int32_t*)d_nm.p; in.sm = (const int32_t*)d_sm.p;
         in.tags = (const uint8_t*)d_tags.p; in.cigar = (const uint32_t*)d_cigar.p; in.seq4 = (const uint8_t*)d_seq.p; in.qual = (const uint8_t*)d_qual.p;
         in.ref = (const char*)d_ref.p;
-        HIPCHK(d_bq.ensure((s.bq_elems + 256) * sizeof(uint16_t)));   // + slack: staged windows may read past the last row
+        HIPCHK(d_bq.ensure((s.bq_elems + 512) * sizeof(uint16_t)));   // + slack: staged windows may read past the last row
         in.bq = (const uint16_t*)d_bq.p;
         if ((rc = up(d_bqrow, s.bq_row, n))) return rc;
         in.bq_row = (const uint64_t*)d_bqrow.p;
@@ -696,8 +718,8 @@ class HipBackend : public Backend {
         if (ntiles > 0) {
             unsigned nwg = (unsigned)((ntiles + PILEUP_WAVES - 1) / PILEUP_WAVES);
             nwg = (nwg + 7u) & ~7u;
-#define BRC_LAUNCH_PILEUP(V) hipLaunchKernelGGL((k_pileup<V>), dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), 0, stream, c, in, reads, (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p)
-            switch (c.variant) { case 1: BRC_LAUNCH_PILEUP(1); break; case 2: BRC_LAUNCH_PILEUP(2); break; case 3: BRC_LAUNCH_PILEUP(3); break; case 7: BRC_LAUNCH_PILEUP(7); break; default: BRC_LAUNCH_PILEUP(0); }
+#define BRC_LAUNCH_PILEUP(V) hipLaunchKernelGGL((k_pileup<V>), dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), 0, stream, c, in, reads, (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.cigar, in.rcp, in.bq)
+            switch (c.variant) { case 1: BRC_LAUNCH_PILEUP(1); break; case 2: BRC_LAUNCH_PILEUP(2); break; case 3: BRC_LAUNCH_PILEUP(3); break; default: BRC_LAUNCH_PILEUP(0); }
         }
         HIPCHK(hipEventRecord(evt[T_COUNT], stream));
         if (P > 0) {

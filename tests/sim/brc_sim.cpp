@@ -57,10 +57,12 @@ class SimBackend : public Backend {
             uint32_t lo, hi; tile_range(c, prefmax.data(), reads.data(), tl, lo, hi);
             for (int lane = 0; lane < TILE; ++lane) {
                 const int64_t k = tl * TILE + lane; const bool valid = k < P;
-                LaneAcc a; lane_init(a);
-                for (uint32_t r = lo; r < hi; ++r) lane_visit_read(c, in, reads[r], r, (uint32_t)l + 1, (int32_t)(c.pos0 + k), valid, a);
+                LaneAcc a; lane_init(a); a.dom_b = dominant_bucket(c, in, c.pos0 + k);
+                if (getenv("BRC_SIM_DOM")) a.dom_b = (uint32_t)atoi(getenv("BRC_SIM_DOM"));   // stress the alternate/overflow paths
+                LaneOut o; o.pl = pl; o.lib = l; o.k = valid ? k : 0;
+                for (uint32_t r = lo; r < hi; ++r) lane_visit_read(c, in, reads[r], r, (uint32_t)l + 1, (int32_t)(c.pos0 + k), valid, o, a);
                 if (!valid) continue;
-                lane_store(c, pl, l, k, a);
+                lane_store(c, o, a);
                 const bool dead = c.per_lib && a.unavail != NONE32;
                 if (!dead) { warn[BRC_W_SM_MISSING] += a.w_sm; warn[BRC_W_NM_MISSING] += a.w_nm; if (c.pos0 + k >= c.beg0) n_events += a.ncol; }
                 if (dead && l == 0) warn[BRC_W_LIB_UNAVAILABLE]++;
