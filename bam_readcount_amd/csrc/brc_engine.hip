@@ -172,6 +172,190 @@ __global__ __launch_bounds__(256) void k_annotate_wave(DevCfg c, DevIn in, DRead
     }
 }
 
+// K1, batch form (the one normally launched): one wave owns 64 consecutive reads.
+//   phase A (lane = read): metadata + a walk over the read's own CIGAR (reference length, clips, "simple nM" flag);
+//   phase B (wave-cooperative, reads visited one after the other, lanes = 64 consecutive bases): bq packing, mismatch
+//            flags against the reference, run-max sum of mismatch qualities and the Q2 scan, exactly as in
+//            k_annotate_wave; the QUAL/SEQ/REF loads of the NEXT 64-base chunk (possibly of the next read) are issued
+//            before the current chunk is processed, so one memory round trip is in flight per chunk instead of being
+//            waited for; per-read parameters come from the lane table with v_readlane, results go back to lane j;
+//   phase C (lane = read): three-prime / Q2 logic, DRead + float constants, indel-event counting.
+// Reads that overhang the reference end (the annotator's break/continue quirks) or everything when there is no
+// reference are done by the serial annotate_read() in phase C.
+struct AnnItem { int32_t L, pos; uint64_t qoff, soff, brow; uint32_t coff, nc; bool simple; };
+
+__global__ __launch_bounds__(256) void k_annotate_batch(DevCfg c, DevIn in, DRead* __restrict__ reads, int32_t* __restrict__ ends,
+                                                        uint16_t* __restrict__ bq, RcpPair* __restrict__ rcp, uint32_t* __restrict__ indel_cnt,
+                                                        const uint32_t* __restrict__ cigar_ro, const uint8_t* __restrict__ qual_ro,
+                                                        const uint8_t* __restrict__ seq_ro, const char* __restrict__ ref_ro) {
+    // per-workgroup lookup tables: reference character -> 4-bit base code (htslib seq_nt16_table), base code -> "=ACGTN" bucket
+    __shared__ uint8_t lut_nt16[256];
+    __shared__ uint8_t lut_bucket[16];
+    lut_nt16[threadIdx.x] = (uint8_t)nt16_of_char(threadIdx.x);
+    if (threadIdx.x < 16) lut_bucket[threadIdx.x] = (uint8_t)canon_bucket(threadIdx.x);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t rb = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (rb >= c.n_reads) return;
+    const int nrd = (int)((c.n_reads - rb) < 64 ? (c.n_reads - rb) : 64);
+    const int64_t my = rb + (lane < nrd ? lane : nrd - 1);
+    const bool have = lane < nrd;
+    // ---- phase A
+    const int32_t pos = in.pos[my];
+    const uint32_t flag = in.flag[my];
+    const int32_t L = in.l_qseq[my];
+    const uint32_t nc = in.n_cigar[my];
+    const uint64_t qoff = in.qual_off[my], soff = in.seq_off[my], brow = in.bq_row[my];
+    const uint32_t coff = (uint32_t)in.cig_off[my];
+    int32_t rlen = 0; int clipped = L, left_clip = 0, right_clip = L;
+    uint32_t cig0 = 0;
+    for (uint32_t k = 0; k < nc; ++k) {
+        const uint32_t cg = cigar_ro[coff + k];
+        if (k == 0) cig0 = cg;
+        const uint32_t op = cg & 0xfu; const int len = (int)(cg >> 4);
+        if (is_refop(op)) rlen += len;
+        if (op == CSOFT_CLIP) { clipped -= len; if (k == 0) left_clip += len; else right_clip -= len; }
+    }
+    const bool simple = nc == 1 && (cig0 & 0xfu) == CMATCH;
+    bool dropped = (flag & BRC_PUSH_MASK) != 0;
+    if (nc == 0) dropped = true;
+    if (nc == 1 && !is_mop(cig0 & 0xfu)) dropped = true;
+    const bool fallback = !c.has_ref || pos < 0 || (int64_t)pos + rlen > c.ref_len;
+    // reads whose per-base pass is needed: in the pileup, annotated by the wave path
+    const unsigned long long work = __ballot(have && !dropped && !fallback && L > 0);
+    uint32_t my_sum = 0; int my_hi = -1, my_lo = -1;
+
+    // ---- phase B
+#define BRC_RL(x, j) __builtin_amdgcn_readlane((int)(x), (int)(j))
+#define BRC_RL64(x, j) ((uint64_t)(uint32_t)BRC_RL((uint32_t)(x), j) | ((uint64_t)(uint32_t)BRC_RL((uint32_t)((x) >> 32), j) << 32))
+#define BRC_ITEM(IT, j) { IT.L = BRC_RL(L, j); IT.pos = BRC_RL(pos, j); IT.qoff = BRC_RL64(qoff, j); IT.soff = BRC_RL64(soff, j); IT.brow = BRC_RL64(brow, j); \
+                          IT.coff = (uint32_t)BRC_RL(coff, j); IT.nc = (uint32_t)BRC_RL(nc, j); IT.simple = BRC_RL(simple ? 1 : 0, j) != 0; }
+    // loads of one 64-base chunk (b0) of item IT into (q, nib, rch, inM); lanes past the read's end get q = 2, nib = 0
+#define BRC_CHUNK_LOAD(IT, b0, Q, NIB, RCH, INM)                                                                        \
+    {                                                                                                                     \
+        const int jj = (b0) + lane; const bool inr = jj < IT.L;                                                           \
+        Q = inr ? (uint32_t)(qual_ro + IT.qoff)[(uint32_t)jj] : 2u;                                                       \
+        NIB = inr ? (((uint32_t)(seq_ro + IT.soff)[(uint32_t)jj >> 1] >> ((~jj & 1) << 2)) & 0xfu) : 0u;                  \
+        INM = false; int64_t refpos = 0;                                                                                  \
+        if (IT.simple) { INM = inr; refpos = (int64_t)IT.pos + jj; }                                                      \
+        else {                                                                                                            \
+            int rs = 0; int64_t x = IT.pos;                                                                               \
+            for (uint32_t k = 0; k < IT.nc; ++k) {                                                                        \
+                const uint32_t cg = cigar_ro[IT.coff + k]; const uint32_t op = cg & 0xfu; const int len = (int)(cg >> 4); \
+                if (op == CMATCH) { if (inr && jj >= rs && jj < rs + len) { INM = true; refpos = x + (jj - rs); } rs += len; x += len; } \
+                else if (op == CDEL || op == CREF_SKIP) x += len;                                                         \
+                else if (op == CINS || op == CSOFT_CLIP) rs += len;                                                       \
+            }                                                                                                             \
+        }                                                                                                                 \
+        RCH = 0u;                                                                                                         \
+        if (INM) RCH = (uint32_t)(uint8_t)ref_ro[refpos - c.ref_lo];   /* inside the slice: pos >= 0, pos + rlen <= ref_len */ \
+    }
+    if (work) {
+        // item iterator: (read j, chunk b0) in order; a ring of 4 chunk slots keeps four chunks' loads in flight
+        unsigned long long todo = work;
+        int it_j = -1, it_b0 = 0, it_L = 0; bool it_ok = true;
+        AnnItem itx; itx.L = 0; itx.pos = 0; itx.qoff = itx.soff = itx.brow = 0; itx.coff = itx.nc = 0; itx.simple = true;
+#define BRC_NEXT_ITEM()                                                                                                 \
+        {                                                                                                                 \
+            if (it_j >= 0 && it_b0 + 64 < it_L) it_b0 += 64;                                                              \
+            else if (todo) { it_j = __builtin_ctzll(todo); todo &= todo - 1; it_b0 = 0; it_L = BRC_RL(L, it_j); BRC_ITEM(itx, it_j) } \
+            else it_ok = false;                                                                                           \
+        }
+#define BRC_FILL(K)                                                                                                     \
+        {                                                                                                                 \
+            BRC_NEXT_ITEM()                                                                                               \
+            ok##K = it_ok; sj##K = it_j; sb##K = it_b0;                                                                     \
+            if (it_ok) { BRC_CHUNK_LOAD(itx, it_b0, q##K, nib##K, rch##K, inM##K) }                                       \
+        }
+        uint32_t sum = 0; bool carry_open = false; int carry_max = 0; int hi_nq2 = -1, lo_nq2 = -1;
+#define BRC_PROCESS(K)                                                                                                  \
+        {                                                                                                                 \
+            const int jr = sj##K, b0 = sb##K;                                                                               \
+            const int Lr = BRC_RL(L, jr); const uint64_t browr = BRC_RL64(brow, jr);                                      \
+            const int jj = b0 + lane; const bool inr = jj < Lr;                                                           \
+            const uint32_t q = q##K, nib = nib##K;                                                                        \
+            if (inr) (bq + browr)[(uint32_t)jj] = (uint16_t)(q | ((uint32_t)lut_bucket[nib] << 8));                       \
+            bool m = false;                                                                                               \
+            if (inM##K) { const uint32_t refb = lut_nt16[rch##K]; m = nib != refb && refb != 15u && nib != 0u; }          \
+            const unsigned long long mask = __ballot(m);                                                                  \
+            const unsigned long long nz = __ballot(inr && q != 2u);                                                       \
+            if (nz) { hi_nq2 = b0 + 63 - __builtin_clzll(nz); if (lo_nq2 < 0) lo_nq2 = b0 + __builtin_ctzll(nz); }        \
+            if (carry_open && !(mask & 1ull)) { sum += (uint32_t)carry_max; carry_open = false; }                         \
+            if (mask) {                                                                                                   \
+                const unsigned long long below = lane ? (~mask & ((1ull << lane) - 1ull)) : 0ull;                         \
+                const int h = below ? 63 - __builtin_clzll(below) : -1;                                                   \
+                const int runlen = m ? lane - h : 0;                                                                      \
+                int v = m ? (int)q : 0;                                                                                   \
+                _Pragma("unroll") for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d, 64); if (runlen > d) v = v > o ? v : o; } \
+                if (carry_open && m && runlen == lane + 1) v = v > carry_max ? v : carry_max;                             \
+                const bool is_end = m && (lane < 63 ? !((mask >> (lane + 1)) & 1ull) : (jj + 1 >= Lr));                   \
+                sum += (uint32_t)wave_sum_u64(is_end ? (unsigned long long)v : 0ull);                                     \
+                carry_max = __builtin_amdgcn_readlane(v, 63);                                                             \
+                carry_open = ((mask >> 63) & 1ull) && (b0 + 64 < Lr);                                                     \
+            }                                                                                                             \
+            if (b0 + 64 >= Lr) {                                  /* last chunk of the read: deposit into its lane */   \
+                if (carry_open) sum += (uint32_t)carry_max;                                                               \
+                if (lane == jr) { my_sum = sum; my_hi = hi_nq2; my_lo = lo_nq2; }                                         \
+                sum = 0; carry_open = false; carry_max = 0; hi_nq2 = -1; lo_nq2 = -1;                                     \
+            }                                                                                                             \
+        }
+        uint32_t q0 = 2, nib0 = 0, rch0 = 0, q1 = 2, nib1 = 0, rch1 = 0, q2s = 2, nib2 = 0, rch2 = 0, q3 = 2, nib3 = 0, rch3 = 0;
+        bool inM0 = false, inM1 = false, inM2 = false, inM3 = false, ok0, ok1, ok2, ok3;
+        int sj0, sj1, sj2, sj3, sb0, sb1, sb2, sb3;
+#define q2 q2s
+        BRC_FILL(0) BRC_FILL(1) BRC_FILL(2) BRC_FILL(3)
+        while (ok0) {
+            BRC_PROCESS(0) BRC_FILL(0)
+            if (!ok1) break;
+            BRC_PROCESS(1) BRC_FILL(1)
+            if (!ok2) break;
+            BRC_PROCESS(2) BRC_FILL(2)
+            if (!ok3) break;
+            BRC_PROCESS(3) BRC_FILL(3)
+        }
+#undef q2
+#undef BRC_PROCESS
+#undef BRC_FILL
+#undef BRC_NEXT_ITEM
+    }
+#undef BRC_CHUNK_LOAD
+#undef BRC_ITEM
+#undef BRC_RL64
+#undef BRC_RL
+    // ---- phase C
+    if (!have) return;
+    DRead r;
+    if (fallback) {
+        r = annotate_read(c, in, my, bq, rcp);
+    } else {
+        const bool rev = (flag & FREVERSE) != 0;
+        int tp, q2;
+        if (rev) { tp = 0; if (tp < left_clip) tp = left_clip; q2 = my_lo >= 0 ? my_lo - 1 : -1; if (tp < q2) tp = q2; }
+        else { tp = L - 1; if (tp > right_clip) tp = right_clip; q2 = my_hi >= 0 ? my_hi - 1 : -1; if (tp > q2 && q2 != -1) tp = q2; }
+        const uint32_t mapq = in.mapq[my]; const uint32_t tags = in.tags[my];
+        r.pos = pos; r.end = dropped ? pos : pos + rlen;
+        r.cig_off = coff; r.n_cigar = nc; r.bq_off = brow;
+        const int lib = c.per_lib ? (int)in.lib[my] : 0;
+        uint32_t misc = (mapq << 8) | ((uint32_t)((lib + 1) & 0xffff) << 16);
+        if (rev) misc |= M_REV;
+        if (q2 > -1) misc |= M_Q2OK;
+        if (simple) misc |= M_SIMPLE;
+        uint32_t sse;
+        if (flag & FPROPER_PAIR) { if (tags & 2u) sse = (uint32_t)in.sm[my]; else { sse = 0; misc |= M_SMW; } } else sse = mapq;
+        float snm = 0.0f;
+        if (tags & 1u) snm = (float)in.nm[my] / (float)clipped; else misc |= M_NMW;
+        r.misc = misc; r.l_qseq = L; r.q2 = q2; r.tp = tp; r.left = left_clip; r.clipped = clipped;
+        r.zm_sum = my_sum; r.sse_add = sse; r.snm_add = snm; r.pad0 = 0;
+        RcpPair rc; rc.Lf = (float)L; rc.center = (float)clipped * 0.5f; rc.rcpL = 1.0f / rc.Lf; rc.rcpC = 1.0f / rc.center;
+        rcp[my] = rc;
+    }
+    reads[my] = r; ends[my] = r.end;
+    if (indel_cnt && !simple) {
+        const int lib = (int)(r.misc >> 16) - 1;
+        enumerate_indels(c, in, r, qual_ro + qoff, [&](int32_t p, int, int) { atomicAdd(&indel_cnt[(int64_t)(p - c.pos0) * c.Lp + lib], 1u); });
+    }
+}
+
 // ---------------------------------------------------------------- scans (3-phase: block aggregates, scan of aggregates, apply)
 
 enum { SCAN_T = 256, SCAN_ITEMS = 16, SCAN_CHUNK = SCAN_T * SCAN_ITEMS };
@@ -700,8 +884,13 @@ class HipBackend : public Backend {
         const DRead* reads = (const DRead*)d_reads.p;
         HIPCHK(hipEventRecord(evt[T_ANNOTATE], stream));
         if (n > 0) {
-            static const bool serial = getenv("BRC_ANNOTATE_SERIAL") != nullptr;   // A/B knob: the per-lane form of K1
-            if (serial)
+            static const char* mode = getenv("BRC_ANNOTATE");   // A/B knob: "serial" | "wave" | default batch form
+            const bool serial = mode && !strcmp(mode, "serial"), wavef = mode && !strcmp(mode, "wave");
+            if (!serial && !wavef)
+                hipLaunchKernelGGL(k_annotate_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (int32_t*)d_ends.p,
+                                   (uint16_t*)d_bq.p, (RcpPair*)d_rcp.p, indels ? (uint32_t*)d_cnt.p : (uint32_t*)nullptr,
+                                   in.cigar, in.qual, in.seq4, in.ref);
+            else if (serial)
                 hipLaunchKernelGGL(k_annotate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (int32_t*)d_ends.p,
                                    (uint16_t*)d_bq.p, (RcpPair*)d_rcp.p, indels ? (uint32_t*)d_cnt.p : (uint32_t*)nullptr);
             else
