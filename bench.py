@@ -34,8 +34,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--contig-mbp", type=float, default=50.0, help="contig length per GPU (BASELINE config 3: 50)")
     ap.add_argument("--config", default="wgs30x", choices=["wgs30x", "tumor200x"])
-    ap.add_argument("--cpu-sample-mbp", type=float, default=1.5, help="prefix timed with the CPU oracle (0 = skip)")
-    ap.add_argument("--traffic-json", default=None, help="optional JSON with PMC-derived HBM bytes per k_pileup launch")
+    ap.add_argument("--cpu-sample-mbp", type=float, default=8.0, help="prefix timed with the CPU oracle (0 = skip); 8 Mbp ~ 240 M events ~ 10-20 s")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_traffic.json"),
+                    help="JSON with the PMC-derived HBM bytes per k_pileup launch (separate rocprofv3 --pmc passes of this command)")
     args = ap.parse_args()
 
     import numpy as np
@@ -115,8 +116,8 @@ def main():
         alg = b_in + b_ref + b_out
         achieved = alg / (kms[k_pile] * 1e-3) / 1e9 if kms[k_pile] > 0 else 0.0
         traffic = None
-        if args.traffic_json and os.path.exists(args.traffic_json):
-            traffic = json.load(open(args.traffic_json)).get("k_pileup_hbm_bytes_per_launch")
+        if args.traffic_json and os.path.exists(args.traffic_json) and args.config == "wgs30x" and abs(args.contig_mbp - 50.0) < 1e-9:
+            traffic = json.load(open(args.traffic_json)).get("k_pileup_hbm_bytes_per_launch")   # measured on this exact workload
         roof = {"bound": "hbm", "kernel": "k_pileup", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg, "bytes_per_event": round(alg / max(n_events, 1), 3),
