@@ -56,6 +56,7 @@ struct DevCfg {
     int64_t ref_lo, ref_hi; // the device reference slice holds contig positions [ref_lo, ref_hi)
     int64_t ref_len;        // contig length (positions >= ref_len read as NUL)
     int64_t n_reads;
+    int32_t table_len;      // L0: modal read length of the region (host); reads with l_qseq == clipped == L0 take their terms from tables
     int32_t variant;        // 0 in production; >0 = profiling ablations selected by BRC_PILEUP_VARIANT (see brc_engine.hip)
 };
 
@@ -78,7 +79,7 @@ struct RcpPair { float rcpL, rcpC, Lf, center; };
 
 // Packed per-read record written by K1 and read with ONE scalar load (s_load_dwordx16) by KB: 64 bytes.
 enum { M_REV = 1, M_Q2OK = 2, M_SMW = 4, M_NMW = 8, M_SIMPLE = 16,
-       M_FAST = 32 };   // per-read constants fit the branch-free accumulate (acc_fast): L, clipped >= 1 and all addends < 2^24
+       M_TABLE = 32 };  // l_qseq == clipped_length == DevCfg.table_len: event terms come from the quotient tables
 struct alignas(64) DRead {
     int32_t pos, end;          // [pos,end) on the reference; end == pos when the read never enters a column
     uint32_t cig_off, n_cigar;
@@ -224,7 +225,7 @@ BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i, uint16_t
     float snm = 0.0f;
     if (tags & 1u) snm = (float)in.nm[i] / (float)clipped;                                   // BasicStat.cpp:94-97
     else misc |= M_NMW;
-    if (L >= 1 && clipped >= 1 && L < (1 << 24) && sum < (1u << 24) && sse < (1u << 24)) misc |= M_FAST;
+    if (c.table_len > 0 && L == c.table_len && clipped == L) misc |= M_TABLE;
     RcpPair rc; rc.Lf = (float)L; rc.center = (float)clipped * 0.5f; rc.rcpL = 1.0f / rc.Lf; rc.rcpC = 1.0f / rc.center;
     rcp_out[i] = rc;
     r.misc = misc; r.l_qseq = L; r.q2 = q2; r.tp = tp; r.left = left_clip; r.clipped = clipped;
@@ -286,11 +287,25 @@ BRC_HD float div_rcp(float a, float b, float y) {
     return fmaf(r, y, q);
 }
 
-#if defined(__HIP_DEVICE_COMPILE__)
-#define BRC_ABSDIFF(a, b) ((int)__usad((unsigned)(a), (unsigned)(b), 0u))   /* v_sad_u32: both operands are >= 0 where the result is used */
-#else
-#define BRC_ABSDIFF(a, b) iabs((a) - (b))
-#endif
+// |a - b| for two non-negative ints
+BRC_HD uint32_t absdiff_u(uint32_t a, uint32_t b) { return (a > b ? a : b) - (a < b ? a : b); }
+#define BRC_ABSDIFF(a, b) ((int)absdiff_u((uint32_t)(a), (uint32_t)(b)))
+
+// Quotient tables for reads with l_qseq == clipped_length == L0 (DevCfg.table_len): every division of the event terms is
+// then n / L0 with an integer 0 <= n <= L0:  |qpos-q2| / L,  |qpos-tp| / L  and  |(qpos-left) - cl/2| / (cl/2) = |2(qpos-left) - cl| / cl.
+//   q[n] = (float)n / (float)L0   (fp32 division, correctly rounded: identical to what the reference computes)
+//   e[n] = 1.0 - (double)q[n]     (the double-precision event-location term, BasicStat.cpp:70)
+// Built once per workgroup in LDS (k_pileup) / once per region in the simulator.
+enum { TABLE_MAX = 512 };
+struct TermTab { const float* q; const double* e; };
+
+BRC_HD EvTerms event_terms_tab(const DRead& r, const TermTab& tt, int qpos) {
+    EvTerms t;
+    t.q2 = (r.misc & M_Q2OK) ? tt.q[absdiff_u((uint32_t)qpos, (uint32_t)r.q2)] : 0.0f;
+    t.s3p = tt.q[absdiff_u((uint32_t)qpos, (uint32_t)r.tp)];
+    t.sev = tt.e[absdiff_u(2u * (uint32_t)(qpos - r.left), (uint32_t)r.clipped)];
+    return t;
+}
 
 BRC_HD EvTerms event_terms_fast(const DRead& r, const RcpPair& rc, int qpos) {
     EvTerms t;
@@ -442,34 +457,38 @@ BRC_HD void overflow_event(const DevCfg& c, const LaneOut& o, LaneAcc& a, uint32
     a.mem |= 1u << b;
 }
 
-BRC_HD void lane_accumulate(const DevCfg& c, const DRead& rd, const RcpPair& rc, const Probe& pr, uint32_t bqv, const LaneOut& o, LaneAcc& a) {
-    if (!pr.want) return;
-    const uint32_t q = bqv & 0xffu;
-    if ((int)q < c.min_bq) return;                                      // :288
-    a.depth++;                                                          // mapq_n (:312)
-    if (pr.indel < 1 || !c.insertion_centric) {                         // :343
-        const uint32_t b = bqv >> 8;
-        if (rd.misc & M_SMW) a.w_sm++;
-        if (rd.misc & M_NMW) a.w_nm++;
-        // whenever a lane has an event the read has l_qseq >= 1 and clipped_length >= 1: reciprocals are finite
-        const EvTerms t = event_terms_fast(rd, rc, pr.qpos);
-        // Independent single-predecessor blocks only (no if/else chain, no switch): LLVM would otherwise sink the arms'
-        // common tail into one block addressed through a phi of pointers, which defeats scalar replacement of the
-        // accumulators and sends them to scratch memory.
-        const bool isd = b == a.dom_b;
-        if (isd) acc_apply(a.di, a.df, rd, t, q, false);
-        const bool take_alt = !isd && (a.alt_b == NB_NONE || a.alt_b == b);
+// Flat control flow on purpose: the lane conditions are combined into one predicate, the event terms are computed for
+// every lane, and there is a single predicated region for the dominant-bucket adds plus one (usually skipped) region
+// for everything else.  Each extra divergent `if` costs three scalar instructions (save / branch / restore exec) and a
+// dependency stall per wave-iteration, and this kernel runs at the issue-slot limit.
+BRC_HD void lane_accumulate(const DevCfg& c, const DRead& rd, const RcpPair& rc, const TermTab& tt, const Probe& pr, uint32_t bqv, const LaneOut& o, LaneAcc& a) {
+    const uint32_t q = bqv & 0xffu, b = bqv >> 8;
+    const bool dep = pr.want && (int)q >= c.min_bq;                     // :288
+    a.depth += dep ? 1u : 0u;                                           // mapq_n (:312)
+    const bool pass = dep && (pr.indel < 1 || !c.insertion_centric);    // :343
+    if (rd.misc & M_SMW) a.w_sm += pass ? 1u : 0u;                      // (uniform conditions)
+    if (rd.misc & M_NMW) a.w_nm += pass ? 1u : 0u;
+    // whenever a lane has an event the read has l_qseq >= 1 and clipped_length >= 1: reciprocals are finite; lanes
+    // without an event compute garbage that is never added
+    const EvTerms t = (rd.misc & M_TABLE) ? event_terms_tab(rd, tt, pass ? pr.qpos : 0) : event_terms_fast(rd, rc, pr.qpos);   // (uniform)
+    // Independent single-predecessor blocks only (no if/else chain, no switch): LLVM would otherwise sink the arms'
+    // common tail into one block addressed through a phi of pointers, which defeats scalar replacement of the
+    // accumulators and sends them to scratch memory.
+    const bool isd = pass && b == a.dom_b;
+    if (isd) acc_apply(a.di, a.df, rd, t, q, false);
+    if (pass && !isd) {
+        const bool take_alt = a.alt_b == NB_NONE || a.alt_b == b;
         if (take_alt) { a.alt_b = b; acc_apply(a.xi, a.xf, rd, t, q, false); }
-        if (!isd && !take_alt) overflow_event(c, o, a, b, rd, t, q);
+        if (!take_alt) overflow_event(c, o, a, b, rd, t, q);
     }
 }
 
 // unpipelined form (simulator, reference for the pipelined device loop)
 BRC_HD void lane_visit_read(const DevCfg& c, const DevIn& in, const DRead& rd, uint32_t ridx, uint32_t lib_sel,
-                            int32_t p, bool lane_valid, const LaneOut& o, LaneAcc& a) {
+                            int32_t p, bool lane_valid, const TermTab& tt, const LaneOut& o, LaneAcc& a) {
     const Probe pr = lane_probe(c, in, rd, ridx, lib_sel, p, lane_valid, a);
     const uint32_t bqv = pr.want ? in.bq[rd.bq_off + (uint64_t)pr.qpos] : 0u;
-    lane_accumulate(c, rd, in.rcp[ridx], pr, bqv, o, a);
+    lane_accumulate(c, rd, in.rcp[ridx], tt, pr, bqv, o, a);
 }
 
 // Write one lane's accumulators to the position-major planes (coalesced across the wave: lane == position).  Buckets

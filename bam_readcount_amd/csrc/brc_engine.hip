@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void k_annotate_wave(DevCfg c, DevIn in, DRead
         if (flag & FPROPER_PAIR) { if (tags & 2u) sse = (uint32_t)in.sm[i]; else { sse = 0; misc |= M_SMW; } } else sse = mapq;
         float snm = 0.0f;
         if (tags & 1u) snm = (float)in.nm[i] / (float)clipped; else misc |= M_NMW;
-        if (L >= 1 && clipped >= 1 && L < (1 << 24) && sum < (1u << 24) && sse < (1u << 24)) misc |= M_FAST;
+        if (c.table_len > 0 && L == c.table_len && clipped == L) misc |= M_TABLE;
         r.misc = misc; r.l_qseq = L; r.q2 = q2; r.tp = tp; r.left = left_clip; r.clipped = clipped;
         r.zm_sum = sum; r.sse_add = sse; r.snm_add = snm; r.pad0 = 0;
         if (lane == 0) {
@@ -340,6 +340,7 @@ __global__ __launch_bounds__(256) void k_annotate_batch(DevCfg c, DevIn in, DRea
         if (rev) misc |= M_REV;
         if (q2 > -1) misc |= M_Q2OK;
         if (simple) misc |= M_SIMPLE;
+        if (c.table_len > 0 && L == c.table_len && clipped == L) misc |= M_TABLE;
         uint32_t sse;
         if (flag & FPROPER_PAIR) { if (tags & 2u) sse = (uint32_t)in.sm[my]; else { sse = 0; misc |= M_SMW; } } else sse = mapq;
         float snm = 0.0f;
@@ -484,6 +485,14 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
     const uint32_t nb = gridDim.x;            // multiple of 8
     const uint32_t per = nb >> 3;
     const uint32_t wg = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    // quotient tables of the region's modal read length (see event_terms_tab): built once per workgroup
+    __shared__ float tab_q[TABLE_MAX + 1];
+    __shared__ double tab_e[TABLE_MAX + 1];
+    if (V != 3) {
+        const float l0 = (float)c.table_len;
+        for (int n = threadIdx.x; n <= c.table_len; n += PILEUP_WAVES * 64) { const float qv = (float)n / l0; tab_q[n] = qv; tab_e[n] = 1.0 - (double)qv; }
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)wg * PILEUP_WAVES + (threadIdx.x >> 6);
     if (tile >= ntiles) return;
@@ -509,6 +518,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
     //    same row with three broadcast ds_read_b128 — no scalar/vector memory latency inside the loop.  Reads with a general CIGAR are not staged; their event words come from global
     //    memory (uncommon).
     __shared__ uint4 lds_rows[PILEUP_WAVES][BATCH][ROW_U4];
+    TermTab tt; tt.q = tab_q; tt.e = tab_e;
     if (lo < hi && V != 3) {
         const uint32_t libsel = (uint32_t)lib + 1u;
         struct ProbeHalf { int32_t pos, end; uint32_t cig_off, n_cigar; uint64_t bq_off; uint32_t misc; int32_t l_qseq; };
@@ -567,32 +577,32 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
             {                                                                                                             \
                 const int32_t pos_j = BRC_RL(T.pos, j), end_j = BRC_RL(T.end, j);                                         \
                 const uint32_t misc_j = (uint32_t)BRC_RL(T.misc, j);                                                      \
-                PO.qpos = p - pos_j; PO.indel = 0; PO.want = false; VO = 0u;                                              \
                 const bool covered = valid && (uint32_t)(p - pos_j) < (uint32_t)(end_j - pos_j);                          \
                 const uint32_t rlib = misc_j >> 16;                                                                       \
-                bool mine = true;                                                                                         \
+                bool mine = true;                                                     /* (uniform) */                     \
                 if (c.per_lib) {                                                                                          \
                     if (rlib == 0) { if (covered && a.unavail == NONE32) a.unavail = base + (j); mine = false; }          \
                     else if (rlib != libsel) mine = false;                                                                \
                 }                                                                                                         \
-                if (mine) {                                                                                               \
-                    const bool mapq_ok = (int)((misc_j >> 8) & 0xffu) >= c.min_mapq;                                      \
-                    if (misc_j & M_SIMPLE) {                                                                              \
-                        a.ncol += covered ? 1u : 0u;                                                                      \
-                        PO.want = covered && mapq_ok;                                                                     \
-                        const int32_t d0 = p0 - pos_j;                                                                    \
-                        const uint32_t ws = d0 > 0 ? ((uint32_t)d0 & ~7u) : 0u;                                           \
-                        if (PO.want) VO = (uint32_t)reinterpret_cast<const uint16_t*>(rows[(j)])[(uint32_t)PO.qpos - ws]; \
-                    } else {   /* general CIGAR: everything up to the final event load stays wave-uniform (scalar loads) */ \
-                        const ProbeHalf* hj = reinterpret_cast<const ProbeHalf*>(rbase + (size_t)(base + (j)) * 64u);     \
-                        const uint32_t cig_off = hj->cig_off, n_cig = hj->n_cigar;                                        \
-                        const uint64_t bqo = hj->bq_off;                                                                  \
-                        const Ev e = resolve_cigar(cigar_ro + cig_off, n_cig, pos_j, p);                                  \
-                        const bool in_col = covered && e.in_col;                                                          \
-                        a.ncol += in_col ? 1u : 0u;                                                                       \
-                        PO.qpos = e.qpos; PO.indel = e.indel; PO.want = in_col && !e.is_del && mapq_ok;                   \
-                        if (PO.want) VO = (uint32_t)bq_ro[bqo + (uint64_t)(uint32_t)e.qpos];                              \
-                    }                                                                                                     \
+                const bool mapq_ok = (int)((misc_j >> 8) & 0xffu) >= c.min_mapq;      /* (uniform) */                     \
+                PO.qpos = p - pos_j; PO.indel = 0; PO.want = false; VO = 0u;                                              \
+                if (mine && (misc_j & M_SIMPLE)) {                                    /* (uniform) flat fast path */      \
+                    a.ncol += covered ? 1u : 0u;                                                                          \
+                    PO.want = covered && mapq_ok;                                                                         \
+                    const int32_t d0 = p0 - pos_j;                                                                        \
+                    const uint32_t ws = d0 > 0 ? ((uint32_t)d0 & ~7u) : 0u;                                               \
+                    /* unconditional LDS read; lanes without an event read a clamped (in-row) element that is never used */ \
+                    const uint32_t e = ((uint32_t)PO.qpos - ws) & 127u;                                                   \
+                    VO = (uint32_t)reinterpret_cast<const uint16_t*>(rows[(j)])[e < (uint32_t)(WIN_U4 * 8) ? e : 0u];      \
+                } else if (mine) {   /* general CIGAR: everything up to the final event load stays wave-uniform */       \
+                    const ProbeHalf* hj = reinterpret_cast<const ProbeHalf*>(rbase + (size_t)(base + (j)) * 64u);         \
+                    const uint32_t cig_off = hj->cig_off, n_cig = hj->n_cigar;                                            \
+                    const uint64_t bqo = hj->bq_off;                                                                      \
+                    const Ev e = resolve_cigar(cigar_ro + cig_off, n_cig, pos_j, p);                                      \
+                    const bool in_col = covered && e.in_col;                                                              \
+                    a.ncol += in_col ? 1u : 0u;                                                                           \
+                    PO.qpos = e.qpos; PO.indel = e.indel; PO.want = in_col && !e.is_del && mapq_ok;                       \
+                    if (PO.want) VO = (uint32_t)bq_ro[bqo + (uint64_t)(uint32_t)e.qpos];                                  \
                 }                                                                                                         \
             }
             Probe P0, P1; uint32_t V0, V1 = 0u;
@@ -608,7 +618,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
                 RQ.zm_sum = g1.x; RQ.sse_add = g1.y; RQ.snm_add = __uint_as_float(g1.z);
                 RcpPair C; C.rcpL = __uint_as_float(g2.x); C.rcpC = __uint_as_float(g2.y); C.Lf = __uint_as_float(g2.z); C.center = __uint_as_float(g2.w);
                 if (V == 2) a.depth += V0;
-                else lane_accumulate(c, RQ, C, P0, V0, o, a);                    // accumulate read j
+                else lane_accumulate(c, RQ, C, tt, P0, V0, o, a);                // accumulate read j
                 P0 = P1; V0 = V1;
             }
 #undef BRC_PROBE
@@ -819,7 +829,7 @@ class HipBackend : public Backend {
         c.Lp = g.Lp; c.ref_len_check = cfg.ref_len_check; c.has_ref = g.ref != nullptr;
         g.PS = (g.P + 63) & ~(int64_t)63;
         c.beg0 = g.beg0; c.end = g.end; c.pos0 = g.pos0; c.P = g.P; c.PS = g.PS; c.ref_lo = g.ref_lo; c.ref_hi = g.ref_hi; c.ref_len = g.ref_len;
-        c.n_reads = s.n;
+        c.n_reads = s.n; c.table_len = getenv("BRC_NO_TABLE") ? 0 : s.modal_len();
         { const char* v = getenv("BRC_PILEUP_VARIANT"); c.variant = v ? atoi(v) : 0; }
         const size_t n = (size_t)s.n;
         int rc;

@@ -24,7 +24,7 @@ void Staged::init(const HostAlloc* A) {
 void Staged::clear() {
     pos.clear(); flag.clear(); mapq.clear(); lib.clear(); l_qseq.clear(); n_cigar.clear(); cig_off.clear(); seq_off.clear();
     qual_off.clear(); nm.clear(); sm.clear(); tags.clear(); cigar.clear(); seq4.clear(); qual.clear(); bq_row.clear();
-    bq_elems = 0; n = 0; min_pos = 0; max_end = 0; n_indel_ops = 0;
+    bq_elems = 0; memset(len_hist, 0, sizeof len_hist); n = 0; min_pos = 0; max_end = 0; n_indel_ops = 0;
 }
 void Staged::destroy() {
     pos.destroy(); flag.destroy(); mapq.destroy(); lib.destroy(); l_qseq.destroy(); n_cigar.destroy(); cig_off.destroy();
@@ -208,6 +208,7 @@ int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
         if (e->cfg.per_lib && s.lib.p[r] >= e->g.Lp) return fail(e, BRC_E_ARG, "library index out of range");
         s.cig_off.p[r] += cb; s.seq_off.p[r] += sb; s.qual_off.p[r] += qb;
         s.bq_row.p[r] = s.bq_elems; s.bq_elems += ((uint64_t)s.l_qseq.p[r] + 7u) & ~(uint64_t)7u;
+        if (s.l_qseq.p[r] <= TABLE_MAX) s.len_hist[s.l_qseq.p[r]]++;
         const int32_t pos = s.pos.p[r];
         if (pos < e->last_pos) return fail(e, BRC_E_ARG, "reads are not coordinate-sorted");
         e->last_pos = pos;

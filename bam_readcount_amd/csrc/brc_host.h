@@ -57,6 +57,8 @@ struct Staged {
     HBuf<uint32_t> cigar; HBuf<uint8_t> seq4, qual;
     HBuf<uint64_t> bq_row;              // per read: first element of its 16-byte-aligned row in the device bq stream
     uint64_t bq_elems = 0;              // total elements of the bq stream (sum of roundup8(l_qseq))
+    uint32_t len_hist[TABLE_MAX + 1] = {0};   // histogram of l_qseq <= TABLE_MAX (modal length -> DevCfg.table_len)
+    int32_t modal_len() const { uint32_t best = 0; int32_t arg = 0; for (int l = 1; l <= TABLE_MAX; ++l) if (len_hist[l] > best) { best = len_hist[l]; arg = l; } return arg; }
     int64_t n = 0;
     int64_t min_pos = 0, max_end = 0;   // extent of reads that enter the pileup
     uint64_t n_indel_ops = 0;           // upper bound on indel events (I/D/P operators)

@@ -20,7 +20,7 @@ static const HostAlloc kAlloc = {sim_alloc, sim_release};
 
 class SimBackend : public Backend {
     DevCfg c; DevIn in; std::string err;
-    std::vector<DRead> reads; std::vector<int32_t> prefmax; std::vector<uint16_t> bq; size_t bq_n = 0; std::vector<RcpPair> rcp;
+    std::vector<DRead> reads; std::vector<int32_t> prefmax; std::vector<uint16_t> bq; size_t bq_n = 0; std::vector<RcpPair> rcp; std::vector<float> tq; std::vector<double> te;
     std::vector<uint32_t> ncol, depth, istat, unavail; std::vector<float> fstat;
     std::vector<IndelOut> iout;
     uint64_t n_events = 0, n_positions = 0, warn[BRC_N_WARN] = {0, 0, 0, 0};
@@ -34,7 +34,9 @@ class SimBackend : public Backend {
         c.min_mapq = cfg.min_mapq; c.min_bq = cfg.min_bq; c.per_lib = cfg.per_lib; c.insertion_centric = cfg.insertion_centric;
         c.Lp = g.Lp; c.ref_len_check = cfg.ref_len_check; c.has_ref = g.ref != nullptr;
         c.beg0 = g.beg0; c.end = g.end; c.pos0 = g.pos0; c.P = g.P; c.PS = g.PS; c.ref_lo = g.ref_lo; c.ref_hi = g.ref_hi; c.ref_len = g.ref_len;
-        c.n_reads = s.n;
+        c.n_reads = s.n; c.table_len = s.modal_len();
+        tq.assign((size_t)TABLE_MAX + 2, 0.0f); te.assign((size_t)TABLE_MAX + 2, 0.0);
+        for (int k = 0; k <= c.table_len; ++k) { tq[(size_t)k] = (float)k / (float)c.table_len; te[(size_t)k] = 1.0 - (double)tq[(size_t)k]; }
         in.pos = s.pos.p; in.flag = s.flag.p; in.mapq = s.mapq.p; in.lib = s.lib.p; in.l_qseq = s.l_qseq.p; in.n_cigar = s.n_cigar.p;
         in.cig_off = s.cig_off.p; in.seq_off = s.seq_off.p; in.qual_off = s.qual_off.p; in.nm = s.nm.p; in.sm = s.sm.p; in.tags = s.tags.p;
         in.cigar = s.cigar.p; in.seq4 = s.seq4.p; in.qual = s.qual.p; in.ref = g.ref ? g.ref + g.ref_lo : nullptr;
@@ -60,7 +62,8 @@ class SimBackend : public Backend {
                 LaneAcc a; lane_init(a); a.dom_b = dominant_bucket(c, in, c.pos0 + k);
                 if (getenv("BRC_SIM_DOM")) a.dom_b = (uint32_t)atoi(getenv("BRC_SIM_DOM"));   // stress the alternate/overflow paths
                 LaneOut o; o.pl = pl; o.lib = l; o.k = valid ? k : 0;
-                for (uint32_t r = lo; r < hi; ++r) lane_visit_read(c, in, reads[r], r, (uint32_t)l + 1, (int32_t)(c.pos0 + k), valid, o, a);
+                TermTab tt; tt.q = tq.data(); tt.e = te.data();
+                for (uint32_t r = lo; r < hi; ++r) lane_visit_read(c, in, reads[r], r, (uint32_t)l + 1, (int32_t)(c.pos0 + k), valid, tt, o, a);
                 if (!valid) continue;
                 lane_store(c, o, a);
                 const bool dead = c.per_lib && a.unavail != NONE32;

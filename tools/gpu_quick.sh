@@ -9,3 +9,6 @@ done
 for m in ${ANNOTATE_MODES:-}; do
   BRC_ANNOTATE=$m timeout 300 python bench.py --steps 5 --warmup 1 --cpu-sample-mbp 0 ${BENCH_ARGS:-} 2>&1 | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('annotate $m', d['value'], d['roofline']['kernel_ms'])" | tee -a gpurun_out/quick.log
 done
+for g in ${WG_PER_CU:-}; do
+  BRC_PILEUP_WG_PER_CU=$g timeout 300 python bench.py --steps 5 --warmup 1 --cpu-sample-mbp 0 ${BENCH_ARGS:-} 2>&1 | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('wg_per_cu $g', d['value'], d['roofline']['frac'], d['roofline']['kernel_ms']['k_pileup'])" | tee -a gpurun_out/quick.log
+done
