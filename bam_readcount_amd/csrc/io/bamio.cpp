@@ -1,0 +1,310 @@
+// bamio.cpp — see bamio.h.  Wire formats per the public SAMv1 specification; no htslib code involved.
+#include "bamio.h"
+
+#include <string.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <set>
+
+namespace brcio {
+
+static inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+static inline uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+static inline uint64_t rd64(const uint8_t* p) { return (uint64_t)rd32(p) | ((uint64_t)rd32(p + 4) << 32); }
+
+// ---------------------------------------------------------------- BGZF
+
+bool Bgzf::open(const std::string& path) {
+    close();
+    f_ = fopen(path.c_str(), "rb");
+    if (!f_) { err_ = "cannot open " + path; return false; }
+    cbuf_.resize(1 << 16); ubuf_.resize(1 << 16);
+    block_coff_ = next_coff_ = 0; pos_ = len_ = 0; eof_ = false;
+    return true;
+}
+void Bgzf::close() { if (f_) fclose(f_); f_ = nullptr; }
+
+// One BGZF member: gzip header with the BC extra subfield (total block size - 1), raw deflate payload, CRC32, ISIZE.
+bool Bgzf::load_block(uint64_t coff) {
+    if (fseeko(f_, (off_t)coff, SEEK_SET) != 0) { err_ = "seek failed"; return false; }
+    uint8_t h[18];
+    const size_t got = fread(h, 1, 18, f_);
+    if (got == 0) { eof_ = true; len_ = pos_ = 0; block_coff_ = coff; next_coff_ = coff; return false; }
+    if (got < 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { err_ = "not a BGZF block"; return false; }
+    const uint16_t xlen = rd16(h + 10);
+    // locate the BC subfield (normally first)
+    std::vector<uint8_t> extra(xlen);
+    memcpy(extra.data(), h + 12, std::min<size_t>(6, xlen));
+    if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, f_) != (size_t)(xlen - 6)) { err_ = "truncated BGZF header"; return false; }
+    int bsize = -1;
+    for (size_t o = 0; o + 4 <= extra.size();) {
+        const uint16_t slen = rd16(extra.data() + o + 2);
+        if (extra[o] == 66 && extra[o + 1] == 67 && slen == 2) bsize = rd16(extra.data() + o + 4);
+        o += 4 + slen;
+    }
+    if (bsize < 0) { err_ = "BGZF block without BC subfield"; return false; }
+    const size_t clen = (size_t)bsize + 1 - 12 - xlen - 8;
+    if (clen > cbuf_.size()) cbuf_.resize(clen);
+    uint8_t tail[8];
+    if (fread(cbuf_.data(), 1, clen, f_) != clen || fread(tail, 1, 8, f_) != 8) { err_ = "truncated BGZF block"; return false; }
+    const uint32_t isize = rd32(tail + 4);
+    if (isize > ubuf_.size()) ubuf_.resize(isize);
+    z_stream zs; memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) { err_ = "zlib init failed"; return false; }
+    zs.next_in = cbuf_.data(); zs.avail_in = (uInt)clen; zs.next_out = ubuf_.data(); zs.avail_out = (uInt)ubuf_.size();
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    if (rc != Z_STREAM_END || zs.total_out != isize) { err_ = "inflate failed"; return false; }
+    block_coff_ = coff; next_coff_ = coff + (uint64_t)bsize + 1; len_ = isize; pos_ = 0;
+    return true;
+}
+
+bool Bgzf::seek(uint64_t voffset) {
+    const uint64_t coff = voffset >> 16; const size_t uoff = (size_t)(voffset & 0xffff);
+    eof_ = false;
+    if (!(len_ > 0 && coff == block_coff_)) { if (!load_block(coff)) return eof_ ? (uoff == 0) : false; }
+    if (uoff > len_) { err_ = "virtual offset beyond block"; return false; }
+    pos_ = uoff;
+    return true;
+}
+
+bool Bgzf::read(void* dst, size_t n) {
+    uint8_t* d = (uint8_t*)dst;
+    while (n > 0) {
+        if (pos_ == len_) {
+            // blocks with ISIZE 0 (EOF marker) are skipped
+            do { if (!load_block(next_coff_)) return false; } while (len_ == 0);
+        }
+        const size_t k = std::min(n, len_ - pos_);
+        memcpy(d, ubuf_.data() + pos_, k);
+        pos_ += k; d += k; n -= k;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------- BAM records
+
+int32_t BamRecord::endpos() const {
+    if (!(flag & 4) && n_cigar > 0) {
+        int32_t l = 0;
+        const uint8_t* c = data.data() + l_qname;
+        for (unsigned k = 0; k < n_cigar; ++k) {
+            const uint32_t v = rd32(c + 4 * k); const uint32_t op = v & 15;
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) l += (int32_t)(v >> 4);
+        }
+        return pos + l;
+    }
+    return pos + 1;
+}
+
+static const uint8_t* aux_find(const uint8_t* p, const uint8_t* e, const char tag[2]) {
+    while (p + 3 <= e) {
+        const bool hit = p[0] == (uint8_t)tag[0] && p[1] == (uint8_t)tag[1];
+        const uint8_t ty = p[2];
+        const uint8_t* v = p + 3;
+        size_t sz;
+        switch (ty) {
+            case 'A': case 'c': case 'C': sz = 1; break;
+            case 's': case 'S': sz = 2; break;
+            case 'i': case 'I': case 'f': sz = 4; break;
+            case 'd': sz = 8; break;
+            case 'Z': case 'H': { const uint8_t* q = v; while (q < e && *q) ++q; sz = (size_t)(q - v) + 1; break; }
+            case 'B': {
+                if (v + 5 > e) return nullptr;
+                const uint8_t st = v[0]; const uint32_t n = rd32(v + 1);
+                const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+                sz = 5 + (size_t)n * es; break;
+            }
+            default: return nullptr;
+        }
+        if (hit) return p + 2;   // points at the type byte
+        p = v + sz;
+    }
+    return nullptr;
+}
+
+bool BamRecord::aux_int(const char tag[2], int32_t* out) const {
+    const uint8_t* t = aux_find(aux(), data.data() + data.size(), tag);
+    if (!t) return false;
+    const uint8_t* v = t + 1;
+    switch (*t) {   // bam_aux2i
+        case 'c': *out = (int8_t)v[0]; return true;
+        case 'C': *out = v[0]; return true;
+        case 's': *out = (int16_t)rd16(v); return true;
+        case 'S': *out = rd16(v); return true;
+        case 'i': case 'I': *out = (int32_t)rd32(v); return true;
+        default: *out = 0; return true;   // bam_aux2i returns 0 for non-integer types; the tag is still "present"
+    }
+}
+
+const char* BamRecord::aux_str(const char tag[2]) const {
+    const uint8_t* t = aux_find(aux(), data.data() + data.size(), tag);
+    if (!t || (*t != 'Z' && *t != 'H')) return nullptr;
+    return (const char*)(t + 1);
+}
+
+std::vector<std::string> BamHeader::libraries() const {
+    std::set<std::string> s;
+    for (const auto& kv : rg2lb) s.insert(kv.second);
+    return std::vector<std::string>(s.begin(), s.end());
+}
+
+bool BamReader::open(const std::string& path) {
+    if (!bg_.open(path)) { err_ = bg_.error(); return false; }
+    uint8_t m[8];
+    if (!bg_.read(m, 8) || memcmp(m, "BAM\1", 4) != 0) { err_ = "not a BAM file"; return false; }
+    const uint32_t l_text = rd32(m + 4);
+    hdr_.text.resize(l_text);
+    if (l_text && !bg_.read(&hdr_.text[0], l_text)) { err_ = "truncated BAM header"; return false; }
+    hdr_.text.resize(strlen(hdr_.text.c_str()));
+    uint8_t b4[4];
+    if (!bg_.read(b4, 4)) { err_ = "truncated BAM header"; return false; }
+    const uint32_t n_ref = rd32(b4);
+    for (uint32_t i = 0; i < n_ref; ++i) {
+        if (!bg_.read(b4, 4)) return false;
+        const uint32_t ln = rd32(b4);
+        std::string name(ln, '\0');
+        if (!bg_.read(&name[0], ln) || !bg_.read(b4, 4)) return false;
+        name.resize(strlen(name.c_str()));
+        hdr_.name2tid[name] = (int)hdr_.names.size();
+        hdr_.names.push_back(name); hdr_.lengths.push_back((int32_t)rd32(b4));
+    }
+    // @RG lines: ID -> LB
+    size_t p = 0;
+    while (p < hdr_.text.size()) {
+        size_t e = hdr_.text.find('\n', p); if (e == std::string::npos) e = hdr_.text.size();
+        const std::string line = hdr_.text.substr(p, e - p);
+        if (line.compare(0, 3, "@RG") == 0) {
+            std::string id, lb; bool has_lb = false;
+            size_t q = 3;
+            while (q < line.size()) {
+                size_t t = line.find('\t', q + 1); if (t == std::string::npos) t = line.size();
+                const std::string f = line.substr(q + 1, t - q - 1);
+                if (f.compare(0, 3, "ID:") == 0) id = f.substr(3);
+                if (f.compare(0, 3, "LB:") == 0) { lb = f.substr(3); has_lb = true; }
+                q = t;
+            }
+            if (!id.empty() && has_lb) hdr_.rg2lb[id] = lb;
+        }
+        p = e + 1;
+    }
+    return true;
+}
+
+bool BamReader::next(BamRecord* r) {
+    uint8_t h[36];
+    if (!bg_.read(h, 4)) return false;
+    const uint32_t bs = rd32(h);
+    if (bs < 32 || !bg_.read(h + 4, 32)) { err_ = "truncated BAM record"; return false; }
+    r->tid = (int32_t)rd32(h + 4); r->pos = (int32_t)rd32(h + 8);
+    r->l_qname = h[12]; r->mapq = h[13]; r->bin = rd16(h + 14);
+    r->n_cigar = rd16(h + 16); r->flag = rd16(h + 18); r->l_seq = (int32_t)rd32(h + 20);
+    r->mtid = (int32_t)rd32(h + 24); r->mpos = (int32_t)rd32(h + 28); r->tlen = (int32_t)rd32(h + 32);
+    r->data.resize(bs - 32);
+    if (bs > 32 && !bg_.read(r->data.data(), bs - 32)) { err_ = "truncated BAM record"; return false; }
+    return true;
+}
+
+// ---------------------------------------------------------------- BAI
+
+bool BamIndex::load(const std::string& bam_path) {
+    std::vector<std::string> cand;
+    cand.push_back(bam_path + ".bai");
+    if (bam_path.size() > 4) cand.push_back(bam_path.substr(0, bam_path.size() - 4) + ".bai");
+    FILE* f = nullptr;
+    for (const std::string& c : cand) if ((f = fopen(c.c_str(), "rb"))) break;
+    if (!f) { err_ = "index not found"; return false; }
+    std::vector<uint8_t> d;
+    uint8_t buf[1 << 16]; size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) d.insert(d.end(), buf, buf + n);
+    fclose(f);
+    if (d.size() < 8 || memcmp(d.data(), "BAI\1", 4) != 0) { err_ = "not a BAI file"; return false; }
+    size_t o = 4;
+    const uint32_t n_ref = rd32(d.data() + o); o += 4;
+    refs_.assign(n_ref, Ref());
+    for (uint32_t i = 0; i < n_ref; ++i) {
+        if (o + 4 > d.size()) { err_ = "truncated BAI"; return false; }
+        const uint32_t n_bin = rd32(d.data() + o); o += 4;
+        for (uint32_t b = 0; b < n_bin; ++b) {
+            if (o + 8 > d.size()) { err_ = "truncated BAI"; return false; }
+            const uint32_t bin = rd32(d.data() + o); const uint32_t n_chunk = rd32(d.data() + o + 4); o += 8;
+            if (o + 16ull * n_chunk > d.size()) { err_ = "truncated BAI"; return false; }
+            std::vector<Chunk>& v = refs_[i].bins[bin];
+            for (uint32_t c = 0; c < n_chunk; ++c) { Chunk ch; ch.beg = rd64(d.data() + o); ch.end = rd64(d.data() + o + 8); o += 16; v.push_back(ch); }
+        }
+        if (o + 4 > d.size()) { err_ = "truncated BAI"; return false; }
+        const uint32_t n_intv = rd32(d.data() + o); o += 4;
+        if (o + 8ull * n_intv > d.size()) { err_ = "truncated BAI"; return false; }
+        for (uint32_t k = 0; k < n_intv; ++k) { refs_[i].linear.push_back(rd64(d.data() + o)); o += 8; }
+    }
+    return true;
+}
+
+std::vector<Chunk> BamIndex::query(int tid, int64_t beg, int64_t end) const {
+    std::vector<Chunk> out;
+    if (tid < 0 || (size_t)tid >= refs_.size() || end <= beg) return out;
+    if (end > (1ll << 29)) end = 1ll << 29;
+    const Ref& r = refs_[(size_t)tid];
+    // reg2bins (SAMv1 5.3)
+    std::vector<uint32_t> bins;
+    const int64_t e = end - 1;
+    bins.push_back(0);
+    for (int64_t k = 1 + (beg >> 26); k <= 1 + (e >> 26); ++k) bins.push_back((uint32_t)k);
+    for (int64_t k = 9 + (beg >> 23); k <= 9 + (e >> 23); ++k) bins.push_back((uint32_t)k);
+    for (int64_t k = 73 + (beg >> 20); k <= 73 + (e >> 20); ++k) bins.push_back((uint32_t)k);
+    for (int64_t k = 585 + (beg >> 17); k <= 585 + (e >> 17); ++k) bins.push_back((uint32_t)k);
+    for (int64_t k = 4681 + (beg >> 14); k <= 4681 + (e >> 14); ++k) bins.push_back((uint32_t)k);
+    uint64_t min_off = 0;
+    const size_t li = (size_t)(beg >> 14);
+    if (!r.linear.empty()) min_off = li < r.linear.size() ? r.linear[li] : r.linear.back();
+    for (uint32_t b : bins) {
+        auto it = r.bins.find(b);
+        if (it == r.bins.end()) continue;
+        for (const Chunk& c : it->second) if (c.end > min_off) out.push_back(c);
+    }
+    std::sort(out.begin(), out.end(), [](const Chunk& a, const Chunk& b) { return a.beg < b.beg; });
+    std::vector<Chunk> merged;
+    for (const Chunk& c : out) {
+        if (!merged.empty() && c.beg <= merged.back().end) { if (c.end > merged.back().end) merged.back().end = c.end; }
+        else merged.push_back(c);
+    }
+    return merged;
+}
+
+// ---------------------------------------------------------------- FASTA
+
+bool Fasta::open(const std::string& path) {
+    path_ = path;
+    FILE* f = fopen((path + ".fai").c_str(), "r");
+    if (!f) { err_ = "cannot open " + path + ".fai"; return false; }
+    char name[4096]; long long len, off; int lb, lw;
+    char line[8192];
+    while (fgets(line, sizeof line, f)) {
+        if (sscanf(line, "%4095s %lld %lld %d %d", name, &len, &off, &lb, &lw) == 5) { Ent e; e.len = len; e.off = off; e.linebases = lb; e.linewidth = lw; idx_[name] = e; }
+    }
+    fclose(f);
+    FILE* g = fopen(path.c_str(), "rb");
+    if (!g) { err_ = "cannot open " + path; return false; }
+    fclose(g);
+    return true;
+}
+
+bool Fasta::fetch(const std::string& name, std::string* seq) {
+    auto it = idx_.find(name);
+    if (it == idx_.end()) { err_ = "sequence " + name + " not in FASTA index"; return false; }
+    const Ent& e = it->second;
+    FILE* f = fopen(path_.c_str(), "rb");
+    if (!f) { err_ = "cannot open " + path_; return false; }
+    seq->clear(); seq->reserve((size_t)e.len);
+    if (fseeko(f, (off_t)e.off, SEEK_SET) != 0) { fclose(f); err_ = "seek failed"; return false; }
+    const int64_t nlines = (e.len + e.linebases - 1) / e.linebases;
+    const size_t raw = (size_t)(nlines * e.linewidth);
+    std::vector<char> buf(raw + 1);
+    const size_t got = fread(buf.data(), 1, raw, f);
+    fclose(f);
+    for (size_t i = 0; i < got && (int64_t)seq->size() < e.len; ++i) { const char ch = buf[i]; if (ch != '\n' && ch != '\r') seq->push_back(ch); }
+    return true;
+}
+
+}  // namespace brcio

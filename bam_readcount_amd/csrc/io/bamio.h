@@ -1,0 +1,132 @@
+// bamio.h — host-side input layer of the drop-in CLI: BGZF, BAM records, BAI region queries, FASTA + .fai.
+//
+// The reference delegates all of this to samtools-1.10/htslib-1.10 (bamreadcount.cpp:16-19: samopen, samfetch,
+// sam_index_load3, fai_load/fai_fetch, bam_get_library).  htslib is not available in this environment, so this is a
+// from-scratch reader of the public wire formats (SAMv1 spec sections 4.1 BGZF, 4.2 BAM, 5.2 BAI; faidx format).  It
+// only implements what the readcount path needs: sequential inflate of BGZF blocks, seeking by virtual offset, the
+// overlap query of an indexed region, whole-contig FASTA fetch, and the @SQ/@RG header fields.
+#ifndef BRC_BAMIO_H
+#define BRC_BAMIO_H
+
+#include <stdint.h>
+#include <stdio.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+namespace brcio {
+
+// ---------------------------------------------------------------- BGZF
+class Bgzf {
+  public:
+    bool open(const std::string& path);
+    void close();
+    ~Bgzf() { close(); }
+    // virtual offset = compressed block offset << 16 | offset inside the uncompressed block
+    bool seek(uint64_t voffset);
+    uint64_t tell() const { return (block_coff_ << 16) | (uint64_t)pos_; }
+    // read exactly n bytes (crossing blocks); returns false at EOF / error
+    bool read(void* dst, size_t n);
+    bool eof_clean() const { return eof_; }
+    const std::string& error() const { return err_; }
+
+  private:
+    bool load_block(uint64_t coff);
+    FILE* f_ = nullptr;
+    std::vector<uint8_t> cbuf_, ubuf_;
+    uint64_t block_coff_ = 0, next_coff_ = 0;
+    size_t pos_ = 0, len_ = 0;
+    bool eof_ = false;
+    std::string err_;
+};
+
+// ---------------------------------------------------------------- BAM
+struct BamRecord {
+    int32_t tid = -1, pos = -1, l_seq = 0, mtid = -1, mpos = -1, tlen = 0;
+    uint16_t flag = 0, n_cigar = 0, bin = 0;
+    uint8_t mapq = 0;
+    std::vector<uint8_t> data;       // the variable part: qname\0, cigar, seq, qual, aux
+    uint32_t l_qname = 0;
+    const char* qname() const { return (const char*)data.data(); }
+    const uint32_t* cigar() const { return (const uint32_t*)(data.data() + l_qname); }
+    const uint8_t* seq() const { return data.data() + l_qname + 4u * n_cigar; }
+    const uint8_t* qual() const { return seq() + (l_seq + 1) / 2; }
+    const uint8_t* aux() const { return qual() + l_seq; }
+    size_t aux_len() const { return data.size() - (size_t)(aux() - data.data()); }
+    int32_t endpos() const;          // bam_endpos
+    // integer aux tag (types c C s S i I); returns false when absent or not an integer
+    bool aux_int(const char tag[2], int32_t* out) const;
+    // Z aux tag
+    const char* aux_str(const char tag[2]) const;
+};
+
+struct BamHeader {
+    std::string text;
+    std::vector<std::string> names;
+    std::vector<int32_t> lengths;
+    std::map<std::string, int> name2tid;
+    std::map<std::string, std::string> rg2lb;      // @RG ID -> LB (only RG lines that carry an LB)
+    std::vector<std::string> libraries() const;    // sorted unique LB values (find_library_names, bamreadcount.cpp:92-111)
+};
+
+struct Chunk { uint64_t beg, end; };
+
+class BamIndex {
+  public:
+    bool load(const std::string& bam_path);        // <bam>.bai, then <bam minus .bam>.bai
+    // chunks (virtual offset ranges) that may hold records overlapping [beg,end) on tid, merged and sorted
+    std::vector<Chunk> query(int tid, int64_t beg, int64_t end) const;
+    const std::string& error() const { return err_; }
+
+  private:
+    struct Ref { std::map<uint32_t, std::vector<Chunk> > bins; std::vector<uint64_t> linear; };
+    std::vector<Ref> refs_;
+    std::string err_;
+};
+
+class BamReader {
+  public:
+    bool open(const std::string& path);
+    const BamHeader& header() const { return hdr_; }
+    bool next(BamRecord* r);                        // sequential; false at EOF
+    // samfetch: every record with tid == tid, pos < end, endpos > beg (beg clamped at 0), in file order
+    template <class F>
+    bool fetch(const BamIndex& idx, int tid, int64_t beg, int64_t end, F cb) {
+        if (beg < 0) beg = 0;
+        if (end <= beg) return true;
+        BamRecord r;
+        for (const Chunk& c : idx.query(tid, beg, end)) {
+            if (!bg_.seek(c.beg)) return false;
+            while (bg_.tell() < c.end) {
+                if (!next(&r)) break;
+                if (r.tid != tid || r.pos >= end) { if (r.tid > tid || (r.tid == tid && r.pos >= end)) return true; continue; }
+                if (r.endpos() > beg) cb(r);
+            }
+        }
+        return true;
+    }
+    const std::string& error() const { return err_; }
+
+  private:
+    Bgzf bg_;
+    BamHeader hdr_;
+    std::string err_;
+};
+
+// ---------------------------------------------------------------- FASTA + .fai
+class Fasta {
+  public:
+    bool open(const std::string& path);            // needs <path>.fai
+    // whole contig, raw characters (case preserved), like fai_fetch(fai, name, &len)
+    bool fetch(const std::string& name, std::string* seq);
+    const std::string& error() const { return err_; }
+
+  private:
+    struct Ent { int64_t len, off; int linebases, linewidth; };
+    std::map<std::string, Ent> idx_;
+    std::string path_, err_;
+};
+
+}  // namespace brcio
+#endif

@@ -1,0 +1,285 @@
+// cli.cpp — `bam-readcount`-compatible command line over the C-ABI engine (include/brc.h).
+//
+// Mirrors main() of the reference (src/exe/bam-readcount/bamreadcount.cpp:421-670): same options and spellings
+// (boost::program_options unix style: -q20, -q 20, --min-mapping-quality=20, --min-mapping-quality 20, sticky short
+// switches -pi, unambiguous long prefixes), same positional arguments (BAM then regions), same stdout records, the same
+// informational stderr lines, same -l site-list and region semantics including the "fetch one base early" rule (:602).
+// What differs is below the callbacks: reads are batched and handed to the MI355X engine instead of bam_plbuf.
+//
+// Not reproduced (documented in DESIGN.md): per-read WARNING lines on stderr are summarised as counts; whole-file mode
+// without region or site list (the reference marks it FIXME and produces degraded output) is refused; CRAM input.
+#include <errno.h>
+#include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../../include/brc.h"
+#include "bamio.h"
+
+using namespace brcio;
+
+struct Options {
+    bool help = false, version = false, per_lib = false, insertion_centric = false, distribution = false;
+    int min_mapq = 0, min_bq = 0, max_cnt = 10000000;
+    long long max_warnings = -1;
+    std::string site_list, fasta, bam;
+    std::vector<std::string> regions;
+    long long chunk_bp = 8000000;   // engine-side tiling of long regions (not a reference option): --brc-chunk
+};
+
+static const char* kUsage =
+    "Usage: bam-readcount [OPTIONS] bam_file|cram_file [region]\n"
+    "Generate metrics for bam_file at single nucleotide positions.\n"
+    "Example: bam-readcount -f ref.fa some.bam|some.cram\n\n"
+    "Available options:\n"
+    "  -h [ --help ]                         produce this message\n"
+    "  -v [ --version ]                      output the version number\n"
+    "  -q [ --min-mapping-quality ] arg (=0) minimum mapping quality of reads used \n"
+    "                                        for counting.\n"
+    "  -b [ --min-base-quality ] arg (=0)    minimum base quality at a position to \n"
+    "                                        use the read for counting.\n"
+    "  -d [ --max-count ] arg (=10000000)    max depth to avoid excessive memory \n"
+    "                                        usage.\n"
+    "  -l [ --site-list ] arg                file containing a list of regions to \n"
+    "                                        report readcounts within.\n"
+    "  -f [ --reference-fasta ] arg          reference sequence in the fasta format.\n"
+    "  -D [ --print-individual-mapq ] arg    report the mapping qualities as a comma \n"
+    "                                        separated list.\n"
+    "  -p [ --per-library ]                  report results by library.\n"
+    "  -w [ --max-warnings ] arg             maximum number of warnings of each type \n"
+    "                                        to emit. -1 gives an unlimited number.\n"
+    "  -i [ --insertion-centric ]            generate indel centric readcounts. Reads \n"
+    "                                        containing insertions will not be \n"
+    "                                        included in per-base counts\n\n";
+
+struct OptSpec { char s; const char* l; bool takes_value; };
+static const OptSpec kSpecs[] = {
+    {'h', "help", false}, {'v', "version", false}, {'q', "min-mapping-quality", true}, {'b', "min-base-quality", true},
+    {'d', "max-count", true}, {'l', "site-list", true}, {'f', "reference-fasta", true}, {'D', "print-individual-mapq", true},
+    {'p', "per-library", false}, {'w', "max-warnings", true}, {'i', "insertion-centric", false}, {0, "brc-chunk", true},
+};
+
+static bool apply(Options& o, const OptSpec& sp, const std::string& v, std::string* err) {
+    auto to_ll = [&](long long* out) {
+        char* e = nullptr; errno = 0; const long long x = strtoll(v.c_str(), &e, 10);
+        if (errno || e == v.c_str() || *e) { *err = "the argument ('" + v + "') for option '--" + sp.l + "' is invalid"; return false; }
+        *out = x; return true;
+    };
+    long long x = 0;
+    switch (sp.s) {
+        case 'h': o.help = true; return true;
+        case 'v': o.version = true; return true;
+        case 'p': o.per_lib = true; return true;
+        case 'i': o.insertion_centric = true; return true;
+        case 'q': if (!to_ll(&x)) return false; o.min_mapq = (int)x; return true;
+        case 'b': if (!to_ll(&x)) return false; o.min_bq = (int)x; return true;
+        case 'd': if (!to_ll(&x)) return false; o.max_cnt = (int)x; return true;
+        case 'w': if (!to_ll(&x)) return false; o.max_warnings = x; return true;
+        case 'l': o.site_list = v; return true;
+        case 'f': o.fasta = v; return true;
+        case 'D': o.distribution = (v == "1" || v == "true" || v == "yes" || v == "on"); return true;
+        default: if (!to_ll(&x)) return false; o.chunk_bp = x; return true;
+    }
+}
+
+static bool parse_args(int argc, char** argv, Options& o, std::string* err) {
+    std::vector<std::string> pos;
+    bool only_pos = false;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (only_pos || a.size() < 2 || a[0] != '-') { pos.push_back(a); continue; }
+        if (a == "--") { only_pos = true; continue; }
+        if (a[1] == '-') {                                   // long option, optional =value, unambiguous prefix
+            const size_t eq = a.find('=');
+            const std::string name = a.substr(2, eq == std::string::npos ? std::string::npos : eq - 2);
+            const OptSpec* hit = nullptr; int nhit = 0;
+            for (const OptSpec& sp : kSpecs) {
+                if (name == sp.l) { hit = &sp; nhit = 1; break; }
+                if (strncmp(sp.l, name.c_str(), name.size()) == 0) { hit = &sp; ++nhit; }
+            }
+            if (nhit == 0) { *err = "unrecognised option '" + a + "'"; return false; }
+            if (nhit > 1) { *err = "option '" + a + "' is ambiguous"; return false; }
+            std::string v;
+            if (hit->takes_value) {
+                if (eq != std::string::npos) v = a.substr(eq + 1);
+                else if (i + 1 < argc) v = argv[++i];
+                else { *err = std::string("the required argument for option '--") + hit->l + "' is missing"; return false; }
+            } else if (eq != std::string::npos) { *err = "option '--" + name + "' does not take any arguments"; return false; }
+            if (!apply(o, *hit, v, err)) return false;
+            continue;
+        }
+        for (size_t k = 1; k < a.size(); ++k) {              // short options, sticky
+            const OptSpec* hit = nullptr;
+            for (const OptSpec& sp : kSpecs) if (sp.s && sp.s == a[k]) hit = &sp;
+            if (!hit) { *err = std::string("unrecognised option '-") + a[k] + "'"; return false; }
+            if (hit->takes_value) {
+                std::string v = a.substr(k + 1);
+                if (v.empty()) { if (i + 1 < argc) v = argv[++i]; else { *err = std::string("the required argument for option '--") + hit->l + "' is missing"; return false; } }
+                if (!apply(o, *hit, v, err)) return false;
+                break;
+            }
+            if (!apply(o, *hit, "", err)) return false;
+        }
+    }
+    if (!pos.empty()) { o.bam = pos[0]; o.regions.assign(pos.begin() + 1, pos.end()); }
+    return true;
+}
+
+// SoA batch in the brc_read_batch layout
+struct Batcher {
+    std::vector<int32_t> pos, l_qseq, nm, sm; std::vector<uint16_t> flag; std::vector<uint8_t> mapq, tags;
+    std::vector<int16_t> lib; std::vector<uint32_t> n_cigar, cigar; std::vector<uint64_t> cig_off, seq_off, qual_off;
+    std::vector<uint8_t> seq4, qual;
+    void clear() { pos.clear(); l_qseq.clear(); nm.clear(); sm.clear(); flag.clear(); mapq.clear(); tags.clear(); lib.clear(); n_cigar.clear(); cigar.clear(); cig_off.clear(); seq_off.clear(); qual_off.clear(); seq4.clear(); qual.clear(); }
+    void add(const BamRecord& r, int lib_index) {
+        pos.push_back(r.pos); flag.push_back(r.flag); mapq.push_back(r.mapq); l_qseq.push_back(r.l_seq); n_cigar.push_back(r.n_cigar);
+        lib.push_back((int16_t)lib_index);
+        cig_off.push_back(cigar.size()); seq_off.push_back(seq4.size()); qual_off.push_back(qual.size());
+        const uint32_t* c = r.cigar(); cigar.insert(cigar.end(), c, c + r.n_cigar);
+        seq4.insert(seq4.end(), r.seq(), r.seq() + (r.l_seq + 1) / 2);
+        qual.insert(qual.end(), r.qual(), r.qual() + r.l_seq);
+        uint8_t t = 0; int32_t vnm = 0, vsm = 0;
+        if (r.aux_int("NM", &vnm)) t |= BRC_TAG_NM;      // bam_aux_get + bam_aux2i (BasicStat.cpp:94-96)
+        if (r.aux_int("SM", &vsm)) t |= BRC_TAG_SM;      // (BasicStat.cpp:79-81)
+        nm.push_back(vnm); sm.push_back(vsm); tags.push_back(t);
+    }
+    brc_read_batch view() const {
+        brc_read_batch v; memset(&v, 0, sizeof v);
+        v.n_reads = (int64_t)pos.size(); v.pos = pos.data(); v.flag = flag.data(); v.mapq = mapq.data(); v.lib = lib.data();
+        v.l_qseq = l_qseq.data(); v.n_cigar = n_cigar.data(); v.cigar_off = cig_off.data(); v.seq_off = seq_off.data(); v.qual_off = qual_off.data();
+        v.nm = nm.data(); v.sm = sm.data(); v.tags = tags.data(); v.cigar = cigar.data(); v.seq4 = seq4.data(); v.qual = qual.data();
+        v.n_cigar_total = cigar.size(); v.seq_bytes = seq4.size(); v.qual_bytes = qual.size();
+        return v;
+    }
+};
+
+struct Ctx {
+    Options opt; BamReader bam; BamIndex idx; Fasta fa; bool have_fa = false;
+    brc_engine* eng = nullptr;
+    std::vector<std::string> libs;
+    int ref_tid = -1; std::string ref;      // currently loaded contig (load_reference, :83-90)
+    Batcher batch;
+    uint64_t warn[BRC_N_WARN] = {0, 0, 0, 0};
+};
+
+static int lib_index(const Ctx& c, const BamRecord& r) {      // bam_get_library: RG tag -> @RG ID -> LB
+    const char* rg = r.aux_str("RG");
+    if (!rg) return -1;
+    auto it = c.bam.header().rg2lb.find(rg);
+    if (it == c.bam.header().rg2lb.end()) return -1;
+    for (size_t i = 0; i < c.libs.size(); ++i) if (c.libs[i] == it->second) return (int)i;
+    return -1;
+}
+
+// one reporting window [beg0,end) on tid: the body of the site-list / region loops (:588-605, :649-656)
+static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode) {
+    const BamHeader& h = c.bam.header();
+    if (c.have_fa && tid != c.ref_tid) {
+        if (!c.fa.fetch(h.names[(size_t)tid], &c.ref)) c.ref.clear();
+        c.ref_tid = tid;
+    }
+    const char* ref = c.have_fa && !c.ref.empty() ? c.ref.data() : nullptr;
+    if (end > (int64_t)h.lengths[(size_t)tid] + 1000) end = (int64_t)h.lengths[(size_t)tid] + 1000;   // nothing aligns past the contig
+    if (end < beg0) end = beg0;
+    // long regions are cut into abutting pieces; each piece fetches one base early exactly like the reference (:602)
+    int64_t a = beg0;
+    do {
+        const int64_t b = std::min<int64_t>(a + c.opt.chunk_bp, end);
+        c.batch.clear();
+        if (!c.bam.fetch(c.idx, tid, a - 1, b, [&](const BamRecord& r) { c.batch.add(r, c.opt.per_lib ? lib_index(c, r) : 0); })) {
+            fprintf(stderr, "bam-readcount: read error: %s\n", c.bam.error().c_str()); return 1;
+        }
+        int rc = brc_begin_region(c.eng, tid, (int32_t)a, (int32_t)b, ref, (int64_t)c.ref.size());
+        const brc_read_batch v = c.batch.view();
+        if (!rc) rc = brc_push_reads(c.eng, &v);
+        brc_result res; const char* text = ""; size_t len = 0;
+        if (!rc) rc = brc_end_region(c.eng, &res);
+        if (!rc) rc = brc_format_region(c.eng, &res, h.names[(size_t)tid].c_str(), &text, &len);
+        if (rc) { fprintf(stderr, "bam-readcount: engine error %d: %s (%s)\n", rc, brc_strerror(rc), brc_last_error(c.eng)); return 1; }
+        if (len) fwrite(text, 1, len, stdout);
+        for (int w = 0; w < BRC_N_WARN; ++w) c.warn[w] += res.warn[w];
+        a = b;
+    } while (a < end);
+    if (site_mode) brc_clear_indel_queue(c.eng);                                      // :605
+    return 0;
+}
+
+// "chr", "chr:beg", "chr:beg-end" (1-based, commas allowed) -> tid, 0-based beg, end      (bam_parse_region, :644)
+static bool parse_region(const BamHeader& h, const std::string& s, int* tid, int64_t* beg, int64_t* end) {
+    std::string t; for (char ch : s) if (ch != ',') t.push_back(ch);
+    auto it = h.name2tid.find(t);
+    size_t colon = t.rfind(':');
+    if (it != h.name2tid.end()) { *tid = it->second; *beg = 0; *end = INT_MAX; return true; }
+    if (colon == std::string::npos) return false;
+    it = h.name2tid.find(t.substr(0, colon));
+    if (it == h.name2tid.end()) return false;
+    *tid = it->second;
+    const std::string r = t.substr(colon + 1);
+    char* e = nullptr;
+    const long long b = strtoll(r.c_str(), &e, 10);
+    *beg = b > 0 ? b - 1 : 0; *end = INT_MAX;
+    if (*e == '-') { const long long x = strtoll(e + 1, &e, 10); *end = x; }
+    return *beg < *end;
+}
+
+int main(int argc, char** argv) {
+    Ctx c; std::string err;
+    if (!parse_args(argc, argv, c.opt, &err)) { fprintf(stderr, "bam-readcount: %s\n", err.c_str()); return 1; }
+    const Options& o = c.opt;
+    if (o.version) { printf("bam-readcount version: 1.0.1-mi355x (engine %s, abi %d)\n", brc_engine_kind(), BRC_ABI_VERSION); return 1; }   // :467-470
+    if (o.help || o.bam.empty()) { fputs(kUsage, stdout); fputs("\n", stdout); return 1; }                                                   // :472-475
+    fprintf(stderr, "Minimum mapping quality is set to %d\n", o.min_mapq);                                                                 // :477
+    if (!o.fasta.empty()) {
+        if (!c.fa.open(o.fasta)) { fprintf(stderr, "Fail to open reference file %s\n", o.fasta.c_str()); return 1; }
+        c.have_fa = true;
+    }
+    if (!c.bam.open(o.bam)) { fprintf(stderr, "Fail to open BAM file %s\n", o.bam.c_str()); return 1; }                                   // :513-516
+    c.libs = c.bam.header().libraries();
+    for (const std::string& l : c.libs) fprintf(stderr, "Expect library: %s in BAM\n", l.c_str());                                         // :526-529
+    if (o.distribution) { fprintf(stderr, "Not currently supporting distributions\n"); return 1; }                                          // :367 (the reference throws)
+    std::vector<const char*> names; for (const std::string& l : c.libs) names.push_back(l.c_str());
+    brc_config cfg; memset(&cfg, 0, sizeof cfg);
+    cfg.abi_version = BRC_ABI_VERSION; cfg.min_mapq = o.min_mapq; cfg.min_bq = o.min_bq; cfg.max_cnt = o.max_cnt;
+    cfg.per_lib = o.per_lib; cfg.insertion_centric = o.insertion_centric; cfg.n_libs = (int32_t)names.size();
+    cfg.lib_names = names.empty() ? nullptr : names.data(); cfg.device = getenv("BRC_DEVICE") ? atoi(getenv("BRC_DEVICE")) : 0;
+    cfg.ref_len_check = (!o.site_list.empty() && c.have_fa) ? 1 : 0;                                                                        // :594-600
+    int rc = brc_create(&cfg, &c.eng);
+    if (rc) { fprintf(stderr, "bam-readcount: cannot create the MI355X engine: %s\n", brc_strerror(rc)); return 1; }
+    int ret = 0;
+    if (!o.site_list.empty()) {
+        FILE* fp = fopen(o.site_list.c_str(), "r");
+        if (!fp) { fprintf(stderr, "Failed to open region list file: %s\n", o.site_list.c_str()); brc_destroy(c.eng); return 1; }            // :535-538
+        if (!c.idx.load(o.bam)) { fprintf(stderr, "BAM indexing file is not available.\n"); brc_destroy(c.eng); return 1; }                  // :548-551
+        char line[65536];
+        while (fgets(line, sizeof line, fp)) {                                       // ss >> ref_name >> beg >> end (:574-577)
+            char name[4096]; int beg, end;
+            if (sscanf(line, "%4095s %d %d", name, &beg, &end) != 3) continue;
+            auto it = c.bam.header().name2tid.find(name);
+            if (it == c.bam.header().name2tid.end()) { fprintf(stderr, "%s not found in bam file. Region %s %i %i skipped.\n", name, name, beg, end); continue; }   // :580-582
+            if (beg < 1) beg = 1;
+            if ((ret = run_region(c, it->second, (int64_t)beg - 1, end, true))) break;
+        }
+        fclose(fp);
+    } else if (!o.regions.empty()) {
+        if (!c.idx.load(o.bam)) { fprintf(stderr, "BAM indexing file is not available.\n"); brc_destroy(c.eng); return 1; }                  // :637-640
+        for (const std::string& r : o.regions) {
+            int tid; int64_t beg, end;
+            if (!parse_region(c.bam.header(), r, &tid, &beg, &end)) { fprintf(stderr, "Invalid region %s\n", r.c_str()); ret = 1; break; }   // :645-648
+            if ((ret = run_region(c, tid, beg, end, false))) break;
+        }
+    } else {
+        fprintf(stderr, "bam-readcount: give a region or a site list (-l); the reference's whole-file mode skips its per-read "
+                        "pre-processing (bamreadcount.cpp:624 FIXME) and is not reproduced\n");
+        ret = 1;
+    }
+    static const char* wn[BRC_N_WARN] = {"SM tag missing", "NM tag missing", "generated tag missing", "library unavailable"};
+    for (int w = 0; w < BRC_N_WARN; ++w)
+        if (c.warn[w] && o.max_warnings != 0) fprintf(stderr, "WARNING: %llu events: %s\n", (unsigned long long)c.warn[w], wn[w]);
+    brc_destroy(c.eng);
+    return ret;
+}

@@ -128,8 +128,10 @@ def main():
     np.savez_compressed(os.path.join(OUT, "test_bam.npz"), ref_start=np.int64(lo), ref_slice=ref,
                         ref_len=np.int64(int(fai[1])), contig=np.array(fai[0]), tid=np.int32(recs[0]["tid"]),
                         lib_names=np.array(lib_names), **a)
+    # the four goldens, the site lists, and the reference's BAM inputs themselves (data, needed by the CLI tests)
     for f in ("expected_all_lib", "expected_per_lib", "expected_insertion_centric_all_lib",
-              "expected_insertion_centric_per_lib", "site_list", "twolib_site_list.txt"):
+              "expected_insertion_centric_per_lib", "site_list", "twolib_site_list.txt",
+              "test.bam", "test.bam.bai", "test_bad_rg.bam", "test_bad_rg.bam.bai"):
         shutil.copyfile(os.path.join(REF, f), os.path.join(OUT, f))
 
     # twolib.sorted.cram: 4 reads 60M, flag 0, MAPQ 60, starts 0/60/120/180, perfect match, QUAL 0xFF, no NM/SM
