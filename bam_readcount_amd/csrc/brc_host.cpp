@@ -11,7 +11,9 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <deque>
+#include <thread>
 #include <functional>
 #include <queue>
 
@@ -351,18 +353,25 @@ int brc_clear_indel_queue(brc_engine* e) {
     return BRC_OK;
 }
 
-int brc_format_region(brc_engine* e, const brc_result* r, const char* chrom, const char** text, size_t* text_len) {
-    if (!e || !r || !chrom || !text) return BRC_E_ARG;
+// Record assembly for plane indices [k0,k1) into `out`, with deletion queues `queue` (one FIFO per library).
+static void format_range(const brc_engine* e, const brc_result* r, const char* chrom, int64_t k0, int64_t k1,
+                         std::vector<std::deque<QEnt> >& queue, std::string& out) {
     const int Lp = r->n_lib; const int64_t P = r->n_pos; const int64_t S = r->stride;
-    if ((size_t)Lp != e->queue.size()) return fail(e, BRC_E_ARG, "result does not belong to this engine");
-    std::string& out = e->text; out.clear();
+    (void)P;
     std::string rec;
     const bool per_lib = e->cfg.per_lib != 0;
-    int64_t ii = 0;                         // cursor into the (pos, lib, allele)-sorted indel list
     const size_t chrom_len = strlen(chrom);
     char nb[32];
     uint32_t si[BRC_NI]; float sf[BRC_NF];
-    for (int64_t k = 0; k < P; ++k) {
+    // cursor into the (pos, lib, allele)-sorted indel list: first entry with pos >= pos0 + k0
+    int64_t ii;
+    {
+        const int32_t p0 = r->pos0 + (int32_t)k0;
+        int64_t lo = 0, hi = r->n_indel;
+        while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (r->indel[m].pos < p0) lo = m + 1; else hi = m; }
+        ii = lo;
+    }
+    for (int64_t k = k0; k < k1; ++k) {
         const int32_t pos = r->pos0 + (int32_t)k;
         while (ii < r->n_indel && r->indel[ii].pos < pos) ++ii;
         if (per_lib && r->unavail && r->unavail[k] != 0xFFFFFFFFu) continue;            // :281-284: position abandoned
@@ -387,14 +396,14 @@ int brc_format_region(brc_engine* e, const brc_result* r, const char* chrom, con
                 if (d.len < 0) {                                                          // :391-396
                     QEnt q; q.tid = (uint32_t)r->tid; q.pos = (uint32_t)pos + 1; q.st = d.stat;
                     q.allele.assign(r->alleles + d.allele_off, d.allele_len);
-                    e->queue[(size_t)l].push_back(q);
+                    queue[(size_t)l].push_back(q);
                 } else {                                                                  // :399
                     rec += '\t'; rec.append(r->alleles + d.allele_off, d.allele_len); rec += ':';
                     fmt_stat(rec, d.stat.i, d.stat.f, true);
                 }
             }
             // IndelQueue::process (IndelQueue.cpp:3-15)
-            std::deque<QEnt>& q = e->queue[(size_t)l];
+            std::deque<QEnt>& q = queue[(size_t)l];
             while (!q.empty() && ((q.front().tid == (uint32_t)r->tid && q.front().pos < (uint32_t)pos) || q.front().tid != (uint32_t)r->tid)) q.pop_front();
             while (!q.empty() && q.front().tid == (uint32_t)r->tid && q.front().pos == (uint32_t)pos) {
                 rec += '\t'; rec += q.front().allele; rec += ':';
@@ -412,6 +421,49 @@ int brc_format_region(brc_engine* e, const brc_result* r, const char* chrom, con
             out.append(nb, (size_t)snprintf(nb, sizeof nb, "%d", d));
             out += rec; out += '\n';
         }
+    }
+}
+
+// Chunks of positions are formatted by a pool of threads.  A queued deletion lives for exactly one position (pushed at
+// p for p+1, emitted or dropped there), so a chunk starting at k0 > 0 reproduces the queue state it would inherit by
+// replaying position k0-1 into a scratch buffer; chunk 0 continues the engine's persistent queues and the last chunk's
+// final queues become the engine's (regions given on the command line are not separated by a clear, :641-657).
+int brc_format_region(brc_engine* e, const brc_result* r, const char* chrom, const char** text, size_t* text_len) {
+    if (!e || !r || !chrom || !text) return BRC_E_ARG;
+    const int Lp = r->n_lib; const int64_t P = r->n_pos;
+    if ((size_t)Lp != e->queue.size()) return fail(e, BRC_E_ARG, "result does not belong to this engine");
+    std::string& out = e->text; out.clear();
+    int64_t CH = 1 << 16;
+    if (const char* t = getenv("BRC_FORMAT_CHUNK")) { const long long v = atoll(t); if (v > 0) CH = v; }   // test knob
+    const int64_t nch = (P + CH - 1) / CH;
+    unsigned nthr = std::thread::hardware_concurrency(); if (nthr == 0) nthr = 1; if (nthr > 64) nthr = 64;
+    if (const char* t = getenv("BRC_FORMAT_THREADS")) { const int v = atoi(t); if (v > 0) nthr = (unsigned)v; }
+    if (nch <= 1 || nthr == 1) {
+        format_range(e, r, chrom, 0, P, e->queue, out);
+    } else {
+        std::vector<std::string> parts((size_t)nch);
+        std::vector<std::vector<std::deque<QEnt> > > qs((size_t)nch);
+        std::atomic<int64_t> next(0);
+        auto work = [&]() {
+            for (;;) {
+                const int64_t c = next.fetch_add(1);
+                if (c >= nch) break;
+                const int64_t k0 = c * CH, k1 = std::min<int64_t>(P, k0 + CH);
+                if (c == 0) qs[0] = e->queue;
+                else { qs[(size_t)c].assign((size_t)Lp, std::deque<QEnt>()); std::string scratch; format_range(e, r, chrom, k0 - 1, k0, qs[(size_t)c], scratch); }
+                parts[(size_t)c].reserve((size_t)(k1 - k0) * 96);
+                format_range(e, r, chrom, k0, k1, qs[(size_t)c], parts[(size_t)c]);
+            }
+        };
+        std::vector<std::thread> th;
+        const unsigned nt = (unsigned)std::min<int64_t>(nthr, nch);
+        for (unsigned i = 1; i < nt; ++i) th.emplace_back(work);
+        work();
+        for (std::thread& t : th) t.join();
+        size_t total = 0; for (const std::string& s : parts) total += s.size();
+        out.reserve(total + 1);
+        for (const std::string& s : parts) out += s;
+        e->queue = qs[(size_t)nch - 1];
     }
     *text = out.c_str();
     if (text_len) *text_len = out.size();

@@ -107,3 +107,19 @@ def test_fmt_f2_matches_printf(sim_lib):
     for v in vals:
         n = f(buf, C.c_float(float(v)))
         assert buf.raw[:n].decode() == "%.2f" % float(np.float32(v)), float(v)
+
+
+def test_threaded_formatter_chunk_boundaries(sim_lib, oracle_lib, monkeypatch):
+    """brc_format_region formats chunks of positions in parallel and seeds each chunk's deletion queue from the
+    position before it; tiny chunks put a boundary next to every deletion."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synthgen
+    ref, arrs = synthgen.generate(40_000, "tumor200x", seed=11, n_chunks=8)
+    names = ["libA", "libB", "libC", "libD"]
+    want, _ = parity.run_engine(oracle_lib, arrs, [(0, 40_000), (5000, 5001), (77, 30000)], ref=ref, lib_names=names, per_lib=True, clear_queue=False)
+    assert want.count(b"\t-") > 1000          # plenty of deletions in the text
+    for chunk, threads in (("7", "8"), ("1", "3"), ("1000", "1")):
+        monkeypatch.setenv("BRC_FORMAT_CHUNK", chunk); monkeypatch.setenv("BRC_FORMAT_THREADS", threads)
+        got, _ = parity.run_engine(sim_lib, arrs, [(0, 40_000), (5000, 5001), (77, 30000)], ref=ref, lib_names=names, per_lib=True, clear_queue=False)
+        assert got == want, (chunk, threads)
