@@ -20,7 +20,7 @@ F_NAMES = ["sev", "sq2", "snm", "s3p"]
 EXPORTS = [
     "brc_strerror", "brc_last_error", "brc_kernel_name", "brc_engine_kind", "brc_create", "brc_destroy",
     "brc_begin_region", "brc_push_reads", "brc_upload", "brc_compute", "brc_fetch_result", "brc_end_region",
-    "brc_clear_indel_queue", "brc_region_counts", "brc_format_region",
+    "brc_clear_indel_queue", "brc_region_counts", "brc_format_region", "brc_format_window",
 ]
 
 
@@ -92,6 +92,7 @@ class Library:
         L.brc_clear_indel_queue.argtypes = [C.c_void_p]
         L.brc_region_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.brc_format_region.argtypes = [C.c_void_p, C.POINTER(Result), C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
+        L.brc_format_window.argtypes = [C.c_void_p, C.POINTER(Result), C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
 
     def kind(self):
         return self.lib.brc_engine_kind().decode()
@@ -268,6 +269,16 @@ class Engine:
         p = C.c_char_p(); n = C.c_size_t()
         self._check(self.L.lib.brc_format_region(self.h, C.byref(self._res), chrom.encode(), C.byref(p), C.byref(n)))
         return C.string_at(p, n.value)
+
+
+def _format_window(self, chrom, vbeg0, vend, delta):
+    """Text of the sub-window [vbeg0,vend) of the last fetched region, coordinates shifted by -delta (site-list planner)."""
+    p = C.c_char_p(); n = C.c_size_t()
+    self._check(self.L.lib.brc_format_window(self.h, C.byref(self._res), chrom.encode(), vbeg0, vend, delta, C.byref(p), C.byref(n)))
+    return C.string_at(p, n.value)
+
+
+Engine.format_window = _format_window
 
 
 def fetch_overlapping(arrs, ends, lo, hi):

@@ -285,7 +285,7 @@ int brc_fetch_result(brc_engine* e, brc_result* out) {
     const Geometry& g = e->g; const Staged& s = e->st; const HostPlanes& hp = e->hp;
     // column 3: raw reference character (bamreadcount.cpp:353)
     e->refbase.resize((size_t)g.P + 1);
-    for (int64_t k = 0; k < g.P; ++k) { const int64_t p = g.pos0 + k; e->refbase[(size_t)k] = (g.ref && p < g.ref_len) ? g.ref[p] : 'N'; }
+    for (int64_t k = 0; k < g.P; ++k) { const int64_t p = g.pos0 + k; e->refbase[(size_t)k] = (g.ref && p < g.ref_len && g.ref[p]) ? g.ref[p] : 'N'; }
     // allele text + std::map<std::string,BasicStat> iteration order (bamreadcount.cpp:323-342, 389-401)
     std::vector<std::string> txt((size_t)hp.n_indel);
     for (int64_t i = 0; i < hp.n_indel; ++i) {
@@ -298,7 +298,7 @@ int brc_fetch_result(brc_engine* e, brc_result* out) {
             for (int j = 0; j < o.len; ++j) { const int q = o.rep_qpos + 1 + j; a.push_back(q < L ? "=ACGTN"[canon_bucket(seqi(seq, q))] : 'N'); }
         } else {
             a.push_back('-');
-            for (int j = 0; j < -o.len; ++j) { const int64_t p = (int64_t)o.pos + 1 + j; a.push_back((g.ref && p < g.ref_len) ? g.ref[p] : 'N'); }
+            for (int j = 0; j < -o.len; ++j) { const int64_t p = (int64_t)o.pos + 1 + j; a.push_back((g.ref && p < g.ref_len && g.ref[p]) ? g.ref[p] : 'N'); }
         }
     }
     std::vector<uint32_t> ord((size_t)hp.n_indel);
@@ -354,8 +354,9 @@ int brc_clear_indel_queue(brc_engine* e) {
 }
 
 // Record assembly for plane indices [k0,k1) into `out`, with deletion queues `queue` (one FIFO per library).
+// Lines are printed for positions inside [wbeg0, wend) with coordinate pos + 1 - delta.
 static void format_range(const brc_engine* e, const brc_result* r, const char* chrom, int64_t k0, int64_t k1,
-                         std::vector<std::deque<QEnt> >& queue, std::string& out) {
+                         std::vector<std::deque<QEnt> >& queue, std::string& out, int32_t wbeg0, int32_t wend, int32_t delta) {
     const int Lp = r->n_lib; const int64_t P = r->n_pos; const int64_t S = r->stride;
     (void)P;
     std::string rec;
@@ -413,9 +414,9 @@ static void format_range(const brc_engine* e, const brc_result* r, const char* c
             }
             if (per_lib) rec += "\t}";
         }
-        if (pos >= r->beg0 && pos < r->end) {                                             // :414-416
+        if (pos >= wbeg0 && pos < wend) {                                                 // :414-416
             out.append(chrom, chrom_len); out += '\t';
-            out.append(nb, (size_t)fmt_u32(nb, (uint32_t)pos + 1)); out += '\t';
+            out.append(nb, (size_t)fmt_u32(nb, (uint32_t)(pos + 1 - delta))); out += '\t';
             out += r->refbase[k]; out += '\t';
             const int d = (int)depth + extra_depth;
             out.append(nb, (size_t)snprintf(nb, sizeof nb, "%d", d));
@@ -439,7 +440,7 @@ int brc_format_region(brc_engine* e, const brc_result* r, const char* chrom, con
     unsigned nthr = std::thread::hardware_concurrency(); if (nthr == 0) nthr = 1; if (nthr > 64) nthr = 64;
     if (const char* t = getenv("BRC_FORMAT_THREADS")) { const int v = atoi(t); if (v > 0) nthr = (unsigned)v; }
     if (nch <= 1 || nthr == 1) {
-        format_range(e, r, chrom, 0, P, e->queue, out);
+        format_range(e, r, chrom, 0, P, e->queue, out, r->beg0, r->end, 0);
     } else {
         std::vector<std::string> parts((size_t)nch);
         std::vector<std::vector<std::deque<QEnt> > > qs((size_t)nch);
@@ -450,9 +451,9 @@ int brc_format_region(brc_engine* e, const brc_result* r, const char* chrom, con
                 if (c >= nch) break;
                 const int64_t k0 = c * CH, k1 = std::min<int64_t>(P, k0 + CH);
                 if (c == 0) qs[0] = e->queue;
-                else { qs[(size_t)c].assign((size_t)Lp, std::deque<QEnt>()); std::string scratch; format_range(e, r, chrom, k0 - 1, k0, qs[(size_t)c], scratch); }
+                else { qs[(size_t)c].assign((size_t)Lp, std::deque<QEnt>()); std::string scratch; format_range(e, r, chrom, k0 - 1, k0, qs[(size_t)c], scratch, r->beg0, r->end, 0); }
                 parts[(size_t)c].reserve((size_t)(k1 - k0) * 96);
-                format_range(e, r, chrom, k0, k1, qs[(size_t)c], parts[(size_t)c]);
+                format_range(e, r, chrom, k0, k1, qs[(size_t)c], parts[(size_t)c], r->beg0, r->end, 0);
             }
         };
         std::vector<std::thread> th;
@@ -464,6 +465,24 @@ int brc_format_region(brc_engine* e, const brc_result* r, const char* chrom, con
         out.reserve(total + 1);
         for (const std::string& s : parts) out += s;
         e->queue = qs[(size_t)nch - 1];
+    }
+    *text = out.c_str();
+    if (text_len) *text_len = out.size();
+    return BRC_OK;
+}
+
+int brc_format_window(brc_engine* e, const brc_result* r, const char* chrom, int32_t vbeg0, int32_t vend, int32_t delta,
+                      const char** text, size_t* text_len) {
+    if (!e || !r || !chrom || !text || vend < vbeg0) return BRC_E_ARG;
+    if ((size_t)r->n_lib != e->queue.size()) return fail(e, BRC_E_ARG, "result does not belong to this engine");
+    std::string& out = e->text; out.clear();
+    // plane indices of [vbeg0 - 1, vend) clipped to the planes; the lead position only feeds the deletion queue (:269 vs :414)
+    int64_t k0 = (int64_t)vbeg0 - 1 - r->pos0, k1 = (int64_t)vend - r->pos0;
+    if (k0 < 0) k0 = 0;
+    if (k1 > r->n_pos) k1 = r->n_pos;
+    if (k1 > k0) {
+        std::vector<std::deque<QEnt> > q((size_t)r->n_lib);
+        format_range(e, r, chrom, k0, k1, q, out, vbeg0, vend, delta);
     }
     *text = out.c_str();
     if (text_len) *text_len = out.size();

@@ -30,6 +30,7 @@ struct Options {
     std::string site_list, fasta, bam;
     std::vector<std::string> regions;
     long long chunk_bp = 8000000;   // engine-side tiling of long regions (not a reference option): --brc-chunk
+    long long plan_sites = 4096;    // site-list planner: -l lines batched per engine pass (0 = one pass per line): --brc-plan
 };
 
 static const char* kUsage =
@@ -61,7 +62,7 @@ struct OptSpec { char s; const char* l; bool takes_value; };
 static const OptSpec kSpecs[] = {
     {'h', "help", false}, {'v', "version", false}, {'q', "min-mapping-quality", true}, {'b', "min-base-quality", true},
     {'d', "max-count", true}, {'l', "site-list", true}, {'f', "reference-fasta", true}, {'D', "print-individual-mapq", true},
-    {'p', "per-library", false}, {'w', "max-warnings", true}, {'i', "insertion-centric", false}, {0, "brc-chunk", true},
+    {'p', "per-library", false}, {'w', "max-warnings", true}, {'i', "insertion-centric", false}, {0, "brc-chunk", true}, {1, "brc-plan", true},
 };
 
 static bool apply(Options& o, const OptSpec& sp, const std::string& v, std::string* err) {
@@ -83,6 +84,7 @@ static bool apply(Options& o, const OptSpec& sp, const std::string& v, std::stri
         case 'l': o.site_list = v; return true;
         case 'f': o.fasta = v; return true;
         case 'D': o.distribution = (v == "1" || v == "true" || v == "yes" || v == "on"); return true;
+        case 1: if (!to_ll(&x)) return false; o.plan_sites = x; return true;
         default: if (!to_ll(&x)) return false; o.chunk_bp = x; return true;
     }
 }
@@ -115,7 +117,7 @@ static bool parse_args(int argc, char** argv, Options& o, std::string* err) {
         }
         for (size_t k = 1; k < a.size(); ++k) {              // short options, sticky
             const OptSpec* hit = nullptr;
-            for (const OptSpec& sp : kSpecs) if (sp.s && sp.s == a[k]) hit = &sp;
+            for (const OptSpec& sp : kSpecs) if (sp.s > 1 && sp.s == a[k]) hit = &sp;
             if (!hit) { *err = std::string("unrecognised option '-") + a[k] + "'"; return false; }
             if (hit->takes_value) {
                 std::string v = a.substr(k + 1);
@@ -209,6 +211,92 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
     return 0;
 }
 
+// ---------------------------------------------------------------- site-list planner
+// The reference runs every -l line as an independent fetch + pileup (bamreadcount.cpp:574-607).  Here a batch of lines is
+// laid out side by side on one virtual coordinate axis: window i keeps its own reads (fetched exactly like the
+// reference would, [beg0-1, end)), translated by delta_i, and its own slice of the reference; the engine runs ONE region
+// over the whole axis, and each line's text is cut out of the shared planes with brc_format_window (fresh deletion
+// queues, coordinates translated back).  Duplicate and overlapping lines stay exact because every window carries its own
+// copy of its reads.  The indexed fetches of a batch run on a pool of threads, each with its own BAM handle.
+#include <atomic>
+#include <thread>
+
+struct Site { int tid; int64_t beg0, end; };
+
+static int run_site_batch(Ctx& c, const std::vector<Site>& sites) {
+    const size_t n = sites.size();
+    const BamHeader& h = c.bam.header();
+    std::vector<Batcher> parts(n);
+    std::vector<int64_t> lo(n), hi(n);
+    std::atomic<size_t> next(0); std::atomic<int> failed(0);
+    auto work = [&]() {
+        BamReader rd;
+        if (!rd.open(c.opt.bam)) { failed = 1; return; }
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= n) break;
+            const Site& st = sites[i];
+            int64_t l = st.beg0 > 0 ? st.beg0 - 1 : 0, r = st.end;
+            if (!rd.fetch(c.idx, st.tid, st.beg0 - 1, st.end, [&](const BamRecord& rec) {
+                    parts[i].add(rec, c.opt.per_lib ? lib_index(c, rec) : 0);
+                    if (rec.pos < l) l = rec.pos;
+                    const int64_t e = rec.endpos(); if (e > r) r = e;
+                })) failed = 1;
+            lo[i] = l; hi[i] = r + 64;      // room for deletion alleles read from the reference past the last read
+        }
+    };
+    unsigned nthr = std::thread::hardware_concurrency(); if (nthr == 0) nthr = 1; if (nthr > 64) nthr = 64;
+    if (const char* t = getenv("BRC_FETCH_THREADS")) { const int v = atoi(t); if (v > 0) nthr = (unsigned)v; }
+    std::vector<std::thread> th;
+    for (unsigned k = 1; k < nthr && k < n; ++k) th.emplace_back(work);
+    work();
+    for (std::thread& t : th) t.join();
+    if (failed) { fprintf(stderr, "bam-readcount: read error while fetching sites\n"); return 1; }
+    // virtual layout
+    std::vector<int64_t> delta(n);
+    int64_t V = 1;
+    for (size_t i = 0; i < n; ++i) { delta[i] = V - lo[i]; V += (hi[i] - lo[i]) + 1; }
+    std::string vref;
+    if (c.have_fa) vref.assign((size_t)V + 1, '\0');
+    Batcher all;
+    for (size_t i = 0; i < n; ++i) {
+        const Site& st = sites[i];
+        if (c.have_fa) {
+            if (st.tid != c.ref_tid) { if (!c.fa.fetch(h.names[(size_t)st.tid], &c.ref)) c.ref.clear(); c.ref_tid = st.tid; }
+            // past the contig: the annotator stops at the terminating NUL (x == len, :151) but merely skips positions
+            // x > len (site-list mode, :144-148); 'N' reproduces the skip (it never counts as a mismatch, :152)
+            const int64_t clen = (int64_t)c.ref.size();
+            for (int64_t x = lo[i]; x < hi[i]; ++x)
+                if (x >= 0) vref[(size_t)(x + delta[i])] = x < clen ? c.ref[(size_t)x] : (x == clen ? '\0' : 'N');
+        }
+        const Batcher& b = parts[i];
+        const uint64_t cb = all.cigar.size(), sb = all.seq4.size(), qb = all.qual.size();
+        for (size_t k = 0; k < b.pos.size(); ++k) {
+            all.pos.push_back((int32_t)(b.pos[k] + delta[i])); all.flag.push_back(b.flag[k]); all.mapq.push_back(b.mapq[k]); all.lib.push_back(b.lib[k]);
+            all.l_qseq.push_back(b.l_qseq[k]); all.n_cigar.push_back(b.n_cigar[k]); all.nm.push_back(b.nm[k]); all.sm.push_back(b.sm[k]); all.tags.push_back(b.tags[k]);
+            all.cig_off.push_back(b.cig_off[k] + cb); all.seq_off.push_back(b.seq_off[k] + sb); all.qual_off.push_back(b.qual_off[k] + qb);
+        }
+        all.cigar.insert(all.cigar.end(), b.cigar.begin(), b.cigar.end());
+        all.seq4.insert(all.seq4.end(), b.seq4.begin(), b.seq4.end());
+        all.qual.insert(all.qual.end(), b.qual.begin(), b.qual.end());
+    }
+    int rc = brc_begin_region(c.eng, 0, 1, (int32_t)V, c.have_fa ? vref.data() : nullptr, V);
+    const brc_read_batch v = all.view();
+    if (!rc) rc = brc_push_reads(c.eng, &v);
+    brc_result res;
+    if (!rc) rc = brc_end_region(c.eng, &res);
+    if (rc) { fprintf(stderr, "bam-readcount: engine error %d: %s (%s)\n", rc, brc_strerror(rc), brc_last_error(c.eng)); return 1; }
+    for (size_t i = 0; i < n; ++i) {
+        const Site& st = sites[i];
+        const char* text = ""; size_t len = 0;
+        rc = brc_format_window(c.eng, &res, h.names[(size_t)st.tid].c_str(), (int32_t)(st.beg0 + delta[i]), (int32_t)(st.end + delta[i]), (int32_t)delta[i], &text, &len);
+        if (rc) { fprintf(stderr, "bam-readcount: engine error %d: %s\n", rc, brc_strerror(rc)); return 1; }
+        if (len) fwrite(text, 1, len, stdout);
+    }
+    for (int w = 0; w < BRC_N_WARN; ++w) c.warn[w] += res.warn[w];
+    return 0;
+}
+
 // "chr", "chr:beg", "chr:beg-end" (1-based, commas allowed) -> tid, 0-based beg, end      (bam_parse_region, :644)
 static bool parse_region(const BamHeader& h, const std::string& s, int* tid, int64_t* beg, int64_t* end) {
     std::string t; for (char ch : s) if (ch != ',') t.push_back(ch);
@@ -255,6 +343,10 @@ int main(int argc, char** argv) {
         FILE* fp = fopen(o.site_list.c_str(), "r");
         if (!fp) { fprintf(stderr, "Failed to open region list file: %s\n", o.site_list.c_str()); brc_destroy(c.eng); return 1; }            // :535-538
         if (!c.idx.load(o.bam)) { fprintf(stderr, "BAM indexing file is not available.\n"); brc_destroy(c.eng); return 1; }                  // :548-551
+        // the planner needs -d to be out of play (its drop rule depends on what else is buffered) and short windows
+        const bool plan = o.plan_sites > 0 && o.max_cnt >= 1000000;
+        std::vector<Site> pending; int64_t pending_bp = 0;
+        auto flush = [&]() { int r = 0; if (!pending.empty()) { r = run_site_batch(c, pending); pending.clear(); pending_bp = 0; } return r; };
         char line[65536];
         while (fgets(line, sizeof line, fp)) {                                       // ss >> ref_name >> beg >> end (:574-577)
             char name[4096]; int beg, end;
@@ -262,8 +354,16 @@ int main(int argc, char** argv) {
             auto it = c.bam.header().name2tid.find(name);
             if (it == c.bam.header().name2tid.end()) { fprintf(stderr, "%s not found in bam file. Region %s %i %i skipped.\n", name, name, beg, end); continue; }   // :580-582
             if (beg < 1) beg = 1;
+            if (plan && (int64_t)end - beg < 100000) {
+                Site st; st.tid = it->second; st.beg0 = (int64_t)beg - 1; st.end = end < beg - 1 ? beg - 1 : end;
+                pending.push_back(st); pending_bp += (st.end - st.beg0) + 2000;
+                if ((long long)pending.size() >= o.plan_sites || pending_bp > 200000000) { if ((ret = flush())) break; }
+                continue;
+            }
+            if ((ret = flush())) break;
             if ((ret = run_region(c, it->second, (int64_t)beg - 1, end, true))) break;
         }
+        if (!ret) ret = flush();
         fclose(fp);
     } else if (!o.regions.empty()) {
         if (!c.idx.load(o.bam)) { fprintf(stderr, "BAM indexing file is not available.\n"); brc_destroy(c.eng); return 1; }                  // :637-640

@@ -209,6 +209,16 @@ int  brc_region_counts(brc_engine*, uint64_t* n_events, uint64_t* n_positions);
 int  brc_format_region(brc_engine*, const brc_result*, const char* chrom,
                        const char** text, size_t* text_len);
 
+/*
+ * Site-list planner support: format only the sub-window [vbeg0, vend) of a fetched region (plus its lead position
+ * vbeg0-1 for deletions), starting from EMPTY deletion queues (the reference clears them after every -l line,
+ * bamreadcount.cpp:605) and printing coordinate pos + 1 - delta.  Lets a caller lay many independent -l windows side
+ * by side on one virtual coordinate axis (reads and reference translated by delta), run the device pipeline once, and
+ * emit each line's text in file order.  Does not touch the engine's persistent queues.
+ */
+int  brc_format_window(brc_engine*, const brc_result*, const char* chrom, int32_t vbeg0, int32_t vend, int32_t delta,
+                       const char** text, size_t* text_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -728,3 +728,10 @@ int brc_format_region(brc_engine* e, const brc_result* res, const char* chrom, c
     if (text_len) *text_len = e->fmt_text.n;
     return BRC_OK;
 }
+
+/* planner support exists only in the product's host assembler; the oracle prints while it piles up (like the reference) */
+int brc_format_window(brc_engine* e, const brc_result* res, const char* chrom, int32_t vbeg0, int32_t vend, int32_t delta,
+                      const char** text, size_t* text_len) {
+    (void)e; (void)res; (void)chrom; (void)vbeg0; (void)vend; (void)delta; (void)text; (void)text_len;
+    return BRC_E_ARG;
+}

@@ -91,3 +91,95 @@ def test_cli_option_spellings_and_errors_cpu(workdir):
 def test_cli_reference_integration_tests_gpu(workdir):
     assert os.path.exists(HIP_CLI), "build the product first (python __graft_entry__.py)"
     check(HIP_CLI, workdir)
+
+
+def _write_fasta(path, name_seq):
+    with open(path, "wb") as f, open(str(path) + ".fai", "w") as fai:
+        off = 0
+        for name, seq in name_seq:
+            hdr = b">" + name.encode() + b"\n"; f.write(hdr); off += len(hdr)
+            fai.write("%s\t%d\t%d\t60\t61\n" % (name, len(seq), off))
+            for i in range(0, len(seq), 60):
+                f.write(bytes(seq[i:i + 60]) + b"\n")
+            off += len(seq) + (len(seq) + 59) // 60
+
+
+@pytest.fixture(scope="session")
+def synthetic_bam(tmp_path_factory):
+    """Two contigs of synthetic reads with every CIGAR operator, two libraries (one RG without LB), written as a real
+    multi-block BAM + BAI (tools/bamio.write_bam) and FASTA + .fai."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bamio
+    import synth
+    d = tmp_path_factory.mktemp("synbam")
+    rng = np.random.default_rng(5)
+    refs = [synth.make_ref(rng, 5000, weird=0.01), synth.make_ref(rng, 3000)]
+    parts = [synth.make_batch(31, refs[0], 1500, style="mixed", n_libs=2), synth.make_batch(32, refs[1], 600, style="wild", n_libs=2)]
+    from bam_readcount_amd import capi
+    arrs = {}
+    for k in ("pos", "flag", "mapq", "lib", "l_qseq", "n_cigar", "nm", "sm", "tags"):
+        arrs[k] = np.concatenate([p[k] for p in parts])
+    for arena, off, unit in (("cigar", "cigar_off", None), ("seq4", "seq_off", None), ("qual", "qual_off", None)):
+        arrs[arena] = np.concatenate([p[arena] for p in parts])
+        arrs[off] = np.concatenate([parts[0][off], parts[1][off] + np.uint64(parts[0][arena].size)])
+    tids = np.concatenate([np.zeros(len(parts[0]["pos"]), int), np.ones(len(parts[1]["pos"]), int)])
+    rgs = [["rgA1", "rgB1"][int(l)] if l >= 0 else None for l in arrs["lib"]]
+    bamio.write_bam(str(d / "syn.bam"), [("chrA", 5000), ("chrB", 3000)], arrs, tids, rg_of_read=rgs,
+                    rg_lines=["@RG\tID:rgA1\tLB:libA\tSM:s", "@RG\tID:rgB1\tLB:libB\tSM:s"], block_bytes=6000)
+    _write_fasta(d / "syn.fa", [("chrA", refs[0]), ("chrB", refs[1])])
+    return d
+
+
+def _sites_file(d, name, sites):
+    open(d / name, "w").write("".join("%s\t%d\t%d\n" % s for s in sites))
+    return name
+
+
+def _planner_check(cli, synthetic_bam):
+    """n3: the batched virtual-axis planner must print exactly what one engine pass per -l line prints — including
+    duplicate lines, overlapping ranges, unsorted order, both contigs, per-library and insertion-centric modes."""
+    d = synthetic_bam
+    rng = np.random.default_rng(9)
+    sites = [("chrA", int(p), int(p)) for p in rng.integers(1, 5000, 120)] + [("chrB", int(p), int(p) + int(w)) for p, w in zip(rng.integers(1, 2900, 40), rng.integers(0, 60, 40))]
+    sites += [("chrA", 100, 100), ("chrA", 100, 100), ("chrA", 90, 130), ("chrB", 1, 1), ("chrA", 1, 3), ("chrA", 4990, 5000), ("chrA", 2000, 2700)]
+    order = rng.permutation(len(sites)); sites = [sites[i] for i in order]
+    sl = _sites_file(d, "sites.txt", sites)
+    for extra in ([], ["-p"], ["-i", "-q", "10", "-b", "8"], ["-p", "-i"]):
+        base = [cli, "-w", "0", "-f", "syn.fa", "-l", sl] + extra
+        a = subprocess.run(base + ["--brc-plan", "0", "syn.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        b = subprocess.run(base + ["--brc-plan", "64", "syn.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        c = subprocess.run(base + ["syn.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert a.returncode == 0 and b.returncode == 0 and c.returncode == 0, (a.stderr, b.stderr)
+        assert a.stdout.count(b"\n") > 400
+        assert a.stdout == b.stdout == c.stdout, extra
+    return a.stdout
+
+
+def test_site_list_planner_equals_line_by_line_cpu(synthetic_bam):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    _planner_check(SIM_CLI, synthetic_bam)
+
+
+@pytest.mark.gpu
+def test_site_list_planner_equals_line_by_line_gpu(synthetic_bam):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    got = _planner_check(HIP_CLI, synthetic_bam)
+    assert got == _planner_check(SIM_CLI, synthetic_bam)      # and the GPU binary prints what the CPU simulator prints
+
+
+def test_cli_bam_reader_region_equals_oracle_cpu(synthetic_bam, oracle_lib):
+    """The host BGZF/BAM/BAI reader + CLI on a synthetic multi-block, two-contig BAM against the oracle fed with the
+    original arrays (checks index queries, aux parsing, RG->LB mapping with a library-less read group)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bamio
+    from bam_readcount_amd import capi
+    import parity
+    d = synthetic_bam
+    text, refs, recs = bamio.read_bam(str(d / "syn.bam"))
+    got = subprocess.run([SIM_CLI, "-p", "-f", "syn.fa", "syn.bam", "chrA:1000-1800", "chrB", "chrA:1-40"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert got.returncode == 0, got.stderr
+    assert b"Expect library: libA in BAM" in got.stderr and b"Expect library: libB in BAM" in got.stderr
+    assert got.stdout.count(b"\n") > 3000 and got.stdout.startswith(b"chrA\t1000\t")
+    assert b"\tlibA\t{" in got.stdout and b"chrB\t" in got.stdout

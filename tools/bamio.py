@@ -99,3 +99,85 @@ def rg_to_lib(header_text):
             f = dict(x.split(":", 1) for x in line.split("\t")[1:] if ":" in x)
             m[f.get("ID")] = f.get("LB")
     return m
+
+
+# ---------------------------------------------------------------- writer (tests only): BAM + BAI from brc_read_batch arrays
+
+def _reg2bin(beg, end):
+    end -= 1
+    if beg >> 14 == end >> 14: return ((1 << 15) - 1) // 7 + (beg >> 14)
+    if beg >> 17 == end >> 17: return ((1 << 12) - 1) // 7 + (beg >> 17)
+    if beg >> 20 == end >> 20: return ((1 << 9) - 1) // 7 + (beg >> 20)
+    if beg >> 23 == end >> 23: return ((1 << 6) - 1) // 7 + (beg >> 23)
+    if beg >> 26 == end >> 26: return ((1 << 3) - 1) // 7 + (beg >> 26)
+    return 0
+
+
+def _bgzf_block(payload):
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    c = co.compress(payload) + co.flush()
+    bsize = len(c) + 25
+    hdr = struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, bsize)
+    return hdr + c + struct.pack("<II", zlib.crc32(payload) & 0xffffffff, len(payload))
+
+
+def write_bam(path, contigs, arrs, tids, rg_of_read=None, rg_lines=(), qnames=None, block_bytes=20000):
+    """contigs: [(name, length)]; arrs: brc_read_batch arrays (coordinate-sorted per contig); tids: contig index per
+    read (non-decreasing).  Writes path and path + '.bai'.  Aux: NM:i / SM:i when the tags bits say so, RG:Z."""
+    text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % c for c in contigs) + "".join(l + "\n" for l in rg_lines)
+    head = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(contigs))
+    for name, ln in contigs:
+        head += struct.pack("<i", len(name) + 1) + name.encode() + b"\0" + struct.pack("<i", ln)
+    out = bytearray(); cur = bytearray(head)
+    coff = 0
+    bins = [dict() for _ in contigs]; linear = [dict() for _ in contigs]
+    n = len(arrs["pos"])
+
+    def flush():
+        nonlocal coff, cur
+        if cur:
+            blk = _bgzf_block(bytes(cur)); out.extend(blk); coff += len(blk); cur = bytearray()
+
+    flush()
+    for i in range(n):
+        if len(cur) > block_bytes:
+            flush()
+        v0 = (coff << 16) | len(cur)
+        L = int(arrs["l_qseq"][i]); nc = int(arrs["n_cigar"][i]); pos = int(arrs["pos"][i]); tid = int(tids[i])
+        cig = arrs["cigar"][int(arrs["cigar_off"][i]):int(arrs["cigar_off"][i]) + nc]
+        rl = sum(int(c) >> 4 for c in cig if (int(c) & 15) in (0, 2, 3, 7, 8))
+        flag = int(arrs["flag"][i])
+        end = pos + (rl if (nc and not flag & 4) else 1)
+        qn = (qnames[i] if qnames is not None else "r%d" % i).encode() + b"\0"
+        aux = b""
+        if int(arrs["tags"][i]) & 1: aux += b"NMi" + struct.pack("<i", int(arrs["nm"][i]))
+        if int(arrs["tags"][i]) & 2: aux += b"SMi" + struct.pack("<i", int(arrs["sm"][i]))
+        if rg_of_read is not None and rg_of_read[i] is not None: aux += b"RGZ" + rg_of_read[i].encode() + b"\0"
+        seq = bytes(arrs["seq4"][int(arrs["seq_off"][i]):int(arrs["seq_off"][i]) + (L + 1) // 2])
+        qual = bytes(arrs["qual"][int(arrs["qual_off"][i]):int(arrs["qual_off"][i]) + L])
+        b = _reg2bin(pos, end)
+        body = struct.pack("<iiBBHHHiiii", tid, pos, len(qn), int(arrs["mapq"][i]), b, nc, flag, L, -1, -1, 0) + qn + \
+            b"".join(struct.pack("<I", int(c)) for c in cig) + seq + qual + aux
+        cur.extend(struct.pack("<i", len(body)) + body)
+        v1 = (coff << 16) | len(cur)
+        ch = bins[tid].setdefault(b, [])
+        if ch and ch[-1][1] == v0: ch[-1][1] = v1
+        else: ch.append([v0, v1])
+        for w in range(pos >> 14, ((end - 1) >> 14) + 1):
+            linear[tid].setdefault(w, v0)
+    flush()
+    out.extend(_bgzf_block(b""))
+    open(path, "wb").write(bytes(out))
+    bai = bytearray(b"BAI\1" + struct.pack("<i", len(contigs)))
+    for t in range(len(contigs)):
+        bai += struct.pack("<i", len(bins[t]))
+        for b, chunks in sorted(bins[t].items()):
+            bai += struct.pack("<Ii", b, len(chunks))
+            for a, e in chunks: bai += struct.pack("<QQ", a, e)
+        nl = (max(linear[t]) + 1) if linear[t] else 0
+        bai += struct.pack("<i", nl)
+        last = 0
+        for w in range(nl):
+            last = linear[t].get(w, last)
+            bai += struct.pack("<Q", last)
+    open(path + ".bai", "wb").write(bytes(bai))
