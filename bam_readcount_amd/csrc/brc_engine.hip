@@ -230,25 +230,30 @@ __global__ __launch_bounds__(256) void k_annotate_batch(DevCfg c, DevIn in, DRea
 #define BRC_RL64(x, j) ((uint64_t)(uint32_t)BRC_RL((uint32_t)(x), j) | ((uint64_t)(uint32_t)BRC_RL((uint32_t)((x) >> 32), j) << 32))
 #define BRC_ITEM(IT, j) { IT.L = BRC_RL(L, j); IT.pos = BRC_RL(pos, j); IT.qoff = BRC_RL64(qoff, j); IT.soff = BRC_RL64(soff, j); IT.brow = BRC_RL64(brow, j); \
                           IT.coff = (uint32_t)BRC_RL(coff, j); IT.nc = (uint32_t)BRC_RL(nc, j); IT.simple = BRC_RL(simple ? 1 : 0, j) != 0; }
-    // loads of one 64-base chunk (b0) of item IT into (q, nib, rch, inM); lanes past the read's end get q = 2, nib = 0
-#define BRC_CHUNK_LOAD(IT, b0, Q, NIB, RCH, INM)                                                                        \
+    // loads of one 64-base chunk (b0) of item IT into (q, seq byte, ref char) + flag bits (1 = inside the read, 2 = M-op base).
+    // Straight-line on purpose: the three vector loads are issued unconditionally with clamped addresses and validity is
+    // carried in FL, because loads inside conditional blocks make the compiler's wait-count analysis fall back to
+    // s_waitcnt vmcnt(0) at every merge, which serialises the prefetch ring.
+#define BRC_CHUNK_LOAD(IT, b0, Q, SB, RCH, FL)                                                                          \
     {                                                                                                                     \
         const int jj = (b0) + lane; const bool inr = jj < IT.L;                                                           \
-        Q = inr ? (uint32_t)(qual_ro + IT.qoff)[(uint32_t)jj] : 2u;                                                       \
-        NIB = inr ? (((uint32_t)(seq_ro + IT.soff)[(uint32_t)jj >> 1] >> ((~jj & 1) << 2)) & 0xfu) : 0u;                  \
-        INM = false; int64_t refpos = 0;                                                                                  \
-        if (IT.simple) { INM = inr; refpos = (int64_t)IT.pos + jj; }                                                      \
+        const uint32_t jc = inr ? (uint32_t)jj : 0u;                                                                      \
+        bool inm = false; int64_t refpos = IT.pos;                                                                        \
+        if (IT.simple) { inm = inr; refpos = (int64_t)IT.pos + jc; }                                                      \
         else {                                                                                                            \
             int rs = 0; int64_t x = IT.pos;                                                                               \
             for (uint32_t k = 0; k < IT.nc; ++k) {                                                                        \
                 const uint32_t cg = cigar_ro[IT.coff + k]; const uint32_t op = cg & 0xfu; const int len = (int)(cg >> 4); \
-                if (op == CMATCH) { if (inr && jj >= rs && jj < rs + len) { INM = true; refpos = x + (jj - rs); } rs += len; x += len; } \
+                if (op == CMATCH) { if (inr && jj >= rs && jj < rs + len) { inm = true; refpos = x + (jj - rs); } rs += len; x += len; } \
                 else if (op == CDEL || op == CREF_SKIP) x += len;                                                         \
                 else if (op == CINS || op == CSOFT_CLIP) rs += len;                                                       \
             }                                                                                                             \
         }                                                                                                                 \
-        RCH = 0u;                                                                                                         \
-        if (INM) RCH = (uint32_t)(uint8_t)ref_ro[refpos - c.ref_lo];   /* inside the slice: pos >= 0, pos + rlen <= ref_len */ \
+        const int64_t ro = inm ? refpos - c.ref_lo : (int64_t)IT.pos - c.ref_lo;   /* inside the slice: pos >= 0, pos + rlen <= ref_len */ \
+        Q = (uint32_t)(qual_ro + IT.qoff)[jc];                                                                            \
+        SB = (uint32_t)(seq_ro + IT.soff)[jc >> 1];                                                                       \
+        RCH = (uint32_t)(uint8_t)ref_ro[ro];                                                                              \
+        FL = (inr ? 1u : 0u) | (inm ? 2u : 0u);                                                                           \
     }
     if (work) {
         // item iterator: (read j, chunk b0) in order; a ring of 4 chunk slots keeps four chunks' loads in flight
@@ -265,18 +270,19 @@ __global__ __launch_bounds__(256) void k_annotate_batch(DevCfg c, DevIn in, DRea
         {                                                                                                                 \
             BRC_NEXT_ITEM()                                                                                               \
             ok##K = it_ok; sj##K = it_j; sb##K = it_b0;                                                                     \
-            if (it_ok) { BRC_CHUNK_LOAD(itx, it_b0, q##K, nib##K, rch##K, inM##K) }                                       \
+            BRC_CHUNK_LOAD(itx, it_ok ? it_b0 : 0, q##K, nib##K, rch##K, inM##K)   /* unconditional: see BRC_CHUNK_LOAD */ \
         }
         uint32_t sum = 0; bool carry_open = false; int carry_max = 0; int hi_nq2 = -1, lo_nq2 = -1;
 #define BRC_PROCESS(K)                                                                                                  \
         {                                                                                                                 \
             const int jr = sj##K, b0 = sb##K;                                                                               \
             const int Lr = BRC_RL(L, jr); const uint64_t browr = BRC_RL64(brow, jr);                                      \
-            const int jj = b0 + lane; const bool inr = jj < Lr;                                                           \
-            const uint32_t q = q##K, nib = nib##K;                                                                        \
+            const int jj = b0 + lane; const bool inr = (inM##K & 1u) != 0;                                                \
+            const uint32_t q = inr ? q##K : 2u;                                                                           \
+            const uint32_t nib = inr ? ((nib##K >> ((~jj & 1) << 2)) & 0xfu) : 0u;                                        \
             if (inr) (bq + browr)[(uint32_t)jj] = (uint16_t)(q | ((uint32_t)lut_bucket[nib] << 8));                       \
             bool m = false;                                                                                               \
-            if (inM##K) { const uint32_t refb = lut_nt16[rch##K]; m = nib != refb && refb != 15u && nib != 0u; }          \
+            if (inM##K & 2u) { const uint32_t refb = lut_nt16[rch##K]; m = nib != refb && refb != 15u && nib != 0u; }     \
             const unsigned long long mask = __ballot(m);                                                                  \
             const unsigned long long nz = __ballot(inr && q != 2u);                                                       \
             if (nz) { hi_nq2 = b0 + 63 - __builtin_clzll(nz); if (lo_nq2 < 0) lo_nq2 = b0 + __builtin_ctzll(nz); }        \
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(256) void k_annotate_batch(DevCfg c, DevIn in, DRea
             }                                                                                                             \
         }
         uint32_t q0 = 2, nib0 = 0, rch0 = 0, q1 = 2, nib1 = 0, rch1 = 0, q2s = 2, nib2 = 0, rch2 = 0, q3 = 2, nib3 = 0, rch3 = 0;
-        bool inM0 = false, inM1 = false, inM2 = false, inM3 = false, ok0, ok1, ok2, ok3;
+        uint32_t inM0 = 0, inM1 = 0, inM2 = 0, inM3 = 0; bool ok0, ok1, ok2, ok3;
         int sj0, sj1, sj2, sj3, sb0, sb1, sb2, sb3;
 #define q2 q2s
         BRC_FILL(0) BRC_FILL(1) BRC_FILL(2) BRC_FILL(3)
