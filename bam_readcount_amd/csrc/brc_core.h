@@ -79,12 +79,15 @@ struct RcpPair { float rcpL, rcpC, Lf, center; };
 
 // Packed per-read record written by K1 and read with ONE scalar load (s_load_dwordx16) by KB: 64 bytes.
 enum { M_REV = 1, M_Q2OK = 2, M_SMW = 4, M_NMW = 8, M_SIMPLE = 16,
-       M_TABLE = 32 };  // l_qseq == clipped_length == DevCfg.table_len: event terms come from the quotient tables
+       M_TABLE = 32,    // l_qseq == clipped_length == DevCfg.table_len: event terms come from the quotient tables
+       M_STAGED = 64 }; // KB can stage this read's bq window in LDS: simple CIGAR, or deleted + inserted + clipped bases <= 24
+// misc layout: bits 0-6 flags | 8-15 mapq | 16-23 library index + 1 (0 = unavailable) | 24-31 total D/N bases (staged reads)
+enum { STAGE_SLACK = 24 };
 struct alignas(64) DRead {
     int32_t pos, end;          // [pos,end) on the reference; end == pos when the read never enters a column
     uint32_t cig_off, n_cigar;
     uint64_t bq_off;           // index of the read's first base in bq[] (multiple of 8: 16-byte aligned row)
-    uint32_t misc;             // M_* | mapq << 8 | (lib + 1) << 16   (lib + 1 == 0: library unavailable)
+    uint32_t misc;             // see the misc layout above
     int32_t l_qseq;
     int32_t q2, tp, left, clipped;   // Zm: q2_pos, three_prime_index, left_clip, clipped_length
     uint32_t zm_sum, sse_add;        // Zm sum_of_mismatch_qualities; per-event addend of sum_single_ended_map_qualities
@@ -153,11 +156,14 @@ BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i, uint16_t
     int read_position = 0;
     int64_t reference_position = pos;
     int32_t rlen = 0;           // reference length: bam_cigar2rlen
+    int64_t tot_d = 0, tot_is = 0;   // deleted/skipped reference bases, inserted + soft-clipped query bases
     bool stop = false;          // ':151/:175' out-of-reference break: ends ALL CIGAR processing of the annotator
     for (uint32_t k = 0; k < nc; ++k) {
         const uint32_t op = cig[k] & 0xfu;
         const int len = (int)(cig[k] >> 4);
         if (is_refop(op)) rlen += len;
+        if (op == CDEL || op == CREF_SKIP) tot_d += len;
+        if (op == CINS || op == CSOFT_CLIP) tot_is += len;
         if (stop) continue;     // rlen (the pileup's view of the read) still needs the remaining ops
         if (op == CMATCH) {
             int j = 0;
@@ -214,10 +220,11 @@ BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i, uint16_t
     // per-base stream for KB: quality | bucket << 8
     for (int j = 0; j < L; ++j) bq_out[in.bq_row[i] + (uint64_t)j] = (uint16_t)(qual[j] | (canon_bucket(seqi(seq, j)) << 8));
     const int lib = c.per_lib ? (int)in.lib[i] : 0;
-    uint32_t misc = (mapq << 8) | ((uint32_t)((lib + 1) & 0xffff) << 16);
+    uint32_t misc = (mapq << 8) | ((uint32_t)((lib + 1) & 0xff) << 16);
     if (rev) misc |= M_REV;
     if (q2 > -1) misc |= M_Q2OK;
     if (nc == 1 && (cig[0] & 0xfu) == CMATCH) misc |= M_SIMPLE;
+    if (tot_d + tot_is <= STAGE_SLACK) misc |= M_STAGED | ((uint32_t)tot_d << 24);
     uint32_t sse;
     if (flag & FPROPER_PAIR) {                                                               // BasicStat.cpp:78-91
         if (tags & 2u) sse = (uint32_t)in.sm[i]; else { sse = 0; misc |= M_SMW; }
@@ -412,7 +419,7 @@ struct Probe { int qpos; int indel; bool want; };   // want: the lane needs bq[r
 BRC_HD Probe lane_probe(const DevCfg& c, const DevIn& in, const DRead& rd, uint32_t ridx, uint32_t lib_sel,
                         int32_t p, bool lane_valid, LaneAcc& a) {
     Probe pr; pr.qpos = p - rd.pos; pr.indel = 0; pr.want = false;
-    const uint32_t rlib = rd.misc >> 16;
+    const uint32_t rlib = (rd.misc >> 16) & 0xffu;
     // one subtract + one unsigned compare; false for reads dropped at push (end == pos)
     const bool covered = lane_valid && (uint32_t)(p - rd.pos) < (uint32_t)(rd.end - rd.pos);
     if (c.per_lib) {                                                    // (uniform)
@@ -528,7 +535,7 @@ BRC_HD void lane_store(const DevCfg& c, const LaneOut& o, const LaneAcc& a) {
 template <class F>
 BRC_HD void enumerate_indels(const DevCfg& c, const DevIn& in, const DRead& rd, const uint8_t* qual_row, F emit) {
     if (rd.end <= rd.pos || (rd.misc & M_SIMPLE) || !c.has_ref) return;
-    if ((rd.misc >> 16) == 0) return;                                   // library unavailable: position is abandoned
+    if (((rd.misc >> 16) & 0xffu) == 0) return;                         // library unavailable: position is abandoned
     if ((int)((rd.misc >> 8) & 0xffu) < c.min_mapq) return;
     const uint32_t* cig = in.cigar + rd.cig_off; const uint32_t nc = rd.n_cigar;
     int32_t x = rd.pos; int y = 0;

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_annotate(DevCfg c, DevIn in, DRead* __r
     reads[i] = r;
     ends[i] = r.end;
     if (indel_cnt) {
-        const int lib = (int)(r.misc >> 16) - 1;
+        const int lib = (int)((r.misc >> 16) & 0xffu) - 1;
         enumerate_indels(c, in, r, in.qual + in.qual_off[i], [&](int32_t p, int, int) {
             atomicAdd(&indel_cnt[(int64_t)(p - c.pos0) * c.Lp + lib], 1u);
         });
@@ -82,10 +82,12 @@ __global__ __launch_bounds__(256) void k_annotate_wave(DevCfg c, DevIn in, DRead
     const uint8_t* __restrict__ seq = in.seq4 + in.seq_off[i];
     const uint8_t* __restrict__ qual = in.qual + qoff;
 
-    int32_t rlen = 0; int clipped = L, left_clip = 0, right_clip = L;
+    int32_t rlen = 0; int clipped = L, left_clip = 0, right_clip = L; int64_t tot_d = 0, tot_is = 0;
     for (uint32_t k = 0; k < nc; ++k) {
         const uint32_t op = cig[k] & 0xfu; const int len = (int)(cig[k] >> 4);
         if (is_refop(op)) rlen += len;
+        if (op == CDEL || op == CREF_SKIP) tot_d += len;
+        if (op == CINS || op == CSOFT_CLIP) tot_is += len;
         if (op == CSOFT_CLIP) { clipped -= len; if (k == 0) left_clip += len; else right_clip -= len; }
     }
     const bool simple = nc == 1 && (cig[0] & 0xfu) == CMATCH;
@@ -148,10 +150,11 @@ __global__ __launch_bounds__(256) void k_annotate_wave(DevCfg c, DevIn in, DRead
         r.pos = pos; r.end = dropped ? pos : pos + rlen;
         r.cig_off = (uint32_t)in.cig_off[i]; r.n_cigar = nc; r.bq_off = brow;
         const int lib = c.per_lib ? (int)in.lib[i] : 0;
-        uint32_t misc = (mapq << 8) | ((uint32_t)((lib + 1) & 0xffff) << 16);
+        uint32_t misc = (mapq << 8) | ((uint32_t)((lib + 1) & 0xff) << 16);
         if (rev) misc |= M_REV;
         if (q2 > -1) misc |= M_Q2OK;
         if (simple) misc |= M_SIMPLE;
+        if (tot_d + tot_is <= STAGE_SLACK) misc |= M_STAGED | ((uint32_t)tot_d << 24);
         uint32_t sse;
         if (flag & FPROPER_PAIR) { if (tags & 2u) sse = (uint32_t)in.sm[i]; else { sse = 0; misc |= M_SMW; } } else sse = mapq;
         float snm = 0.0f;
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256) void k_annotate_wave(DevCfg c, DevIn in, DRead
     }
     if (indel_cnt && lane == 0 && !simple) {
         const DRead rr = reads[i];   // lane 0 wrote it above (same lane: program order)
-        const int lib = (int)(rr.misc >> 16) - 1;
+        const int lib = (int)((rr.misc >> 16) & 0xffu) - 1;
         enumerate_indels(c, in, rr, qual, [&](int32_t p, int, int) { atomicAdd(&indel_cnt[(int64_t)(p - c.pos0) * c.Lp + lib], 1u); });
     }
 }
@@ -207,13 +210,15 @@ __global__ __launch_bounds__(256) void k_annotate_batch(DevCfg c, DevIn in, DRea
     const uint32_t nc = in.n_cigar[my];
     const uint64_t qoff = in.qual_off[my], soff = in.seq_off[my], brow = in.bq_row[my];
     const uint32_t coff = (uint32_t)in.cig_off[my];
-    int32_t rlen = 0; int clipped = L, left_clip = 0, right_clip = L;
+    int32_t rlen = 0; int clipped = L, left_clip = 0, right_clip = L; int64_t tot_d = 0, tot_is = 0;
     uint32_t cig0 = 0;
     for (uint32_t k = 0; k < nc; ++k) {
         const uint32_t cg = cigar_ro[coff + k];
         if (k == 0) cig0 = cg;
         const uint32_t op = cg & 0xfu; const int len = (int)(cg >> 4);
         if (is_refop(op)) rlen += len;
+        if (op == CDEL || op == CREF_SKIP) tot_d += len;
+        if (op == CINS || op == CSOFT_CLIP) tot_is += len;
         if (op == CSOFT_CLIP) { clipped -= len; if (k == 0) left_clip += len; else right_clip -= len; }
     }
     const bool simple = nc == 1 && (cig0 & 0xfu) == CMATCH;
@@ -342,10 +347,11 @@ __global__ __launch_bounds__(256) void k_annotate_batch(DevCfg c, DevIn in, DRea
         r.pos = pos; r.end = dropped ? pos : pos + rlen;
         r.cig_off = coff; r.n_cigar = nc; r.bq_off = brow;
         const int lib = c.per_lib ? (int)in.lib[my] : 0;
-        uint32_t misc = (mapq << 8) | ((uint32_t)((lib + 1) & 0xffff) << 16);
+        uint32_t misc = (mapq << 8) | ((uint32_t)((lib + 1) & 0xff) << 16);
         if (rev) misc |= M_REV;
         if (q2 > -1) misc |= M_Q2OK;
         if (simple) misc |= M_SIMPLE;
+        if (tot_d + tot_is <= STAGE_SLACK) misc |= M_STAGED | ((uint32_t)tot_d << 24);
         if (c.table_len > 0 && L == c.table_len && clipped == L) misc |= M_TABLE;
         uint32_t sse;
         if (flag & FPROPER_PAIR) { if (tags & 2u) sse = (uint32_t)in.sm[my]; else { sse = 0; misc |= M_SMW; } } else sse = mapq;
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(256) void k_annotate_batch(DevCfg c, DevIn in, DRea
     }
     reads[my] = r; ends[my] = r.end;
     if (indel_cnt && !simple) {
-        const int lib = (int)(r.misc >> 16) - 1;
+        const int lib = (int)((r.misc >> 16) & 0xffu) - 1;
         enumerate_indels(c, in, r, qual_ro + qoff, [&](int32_t p, int, int) { atomicAdd(&indel_cnt[(int64_t)(p - c.pos0) * c.Lp + lib], 1u); });
     }
 }
@@ -547,9 +553,9 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
         // window loads of a batch into registers (W0..W2 = chunks slot, slot+4, slot+8 of the lane's row) ...
 #define BRC_LD_WIN(TT, b0, W0, W1, W2, W3, OK)                                                                          \
         {                                                                                                                 \
-            const int32_t d0 = p0 - TT.pos;                                                                               \
+            const int32_t d0 = p0 - TT.pos - (int32_t)(TT.misc >> 24);       /* query offset of the tile start, lower bound */ \
             const uint32_t ws = d0 > 0 ? ((uint32_t)d0 & ~7u) : 0u;                                                       \
-            OK = (b0) + row < hi && (TT.misc & M_SIMPLE) && TT.end > TT.pos && (int32_t)ws < TT.l_qseq + 8;               \
+            OK = (b0) + row < hi && (TT.misc & M_STAGED) && TT.end > TT.pos && (int32_t)ws < TT.l_qseq + 8;               \
             if (OK) {                                                                                                     \
                 const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bq_ro + TT.bq_off + ws) + slot;           \
                 W0 = src[0]; W1 = src[4]; W2 = src[8];                                                                    \
@@ -584,7 +590,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
                 const int32_t pos_j = BRC_RL(T.pos, j), end_j = BRC_RL(T.end, j);                                         \
                 const uint32_t misc_j = (uint32_t)BRC_RL(T.misc, j);                                                      \
                 const bool covered = valid && (uint32_t)(p - pos_j) < (uint32_t)(end_j - pos_j);                          \
-                const uint32_t rlib = misc_j >> 16;                                                                       \
+                const uint32_t rlib = (misc_j >> 16) & 0xffu;                                                             \
                 bool mine = true;                                                     /* (uniform) */                     \
                 if (c.per_lib) {                                                                                          \
                     if (rlib == 0) { if (covered && a.unavail == NONE32) a.unavail = base + (j); mine = false; }          \
@@ -592,23 +598,28 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
                 }                                                                                                         \
                 const bool mapq_ok = (int)((misc_j >> 8) & 0xffu) >= c.min_mapq;      /* (uniform) */                     \
                 PO.qpos = p - pos_j; PO.indel = 0; PO.want = false; VO = 0u;                                              \
-                if (mine && (misc_j & M_SIMPLE)) {                                    /* (uniform) flat fast path */      \
-                    a.ncol += covered ? 1u : 0u;                                                                          \
-                    PO.want = covered && mapq_ok;                                                                         \
-                    const int32_t d0 = p0 - pos_j;                                                                        \
-                    const uint32_t ws = d0 > 0 ? ((uint32_t)d0 & ~7u) : 0u;                                               \
-                    /* unconditional LDS read; lanes without an event read a clamped (in-row) element that is never used */ \
-                    const uint32_t e = ((uint32_t)PO.qpos - ws) & 127u;                                                   \
-                    VO = (uint32_t)reinterpret_cast<const uint16_t*>(rows[(j)])[e < (uint32_t)(WIN_U4 * 8) ? e : 0u];      \
-                } else if (mine) {   /* general CIGAR: everything up to the final event load stays wave-uniform */       \
-                    const ProbeHalf* hj = reinterpret_cast<const ProbeHalf*>(rbase + (size_t)(base + (j)) * 64u);         \
-                    const uint32_t cig_off = hj->cig_off, n_cig = hj->n_cigar;                                            \
-                    const uint64_t bqo = hj->bq_off;                                                                      \
-                    const Ev e = resolve_cigar(cigar_ro + cig_off, n_cig, pos_j, p);                                      \
-                    const bool in_col = covered && e.in_col;                                                              \
+                if (mine) {                                                                                               \
+                    bool in_col = covered, is_del = false;                                                                \
+                    if (!(misc_j & M_SIMPLE)) {   /* general CIGAR (uniform): wave-uniform walk on the scalar unit */      \
+                        const ProbeHalf* hj = reinterpret_cast<const ProbeHalf*>(rbase + (size_t)(base + (j)) * 64u);     \
+                        const Ev e = resolve_cigar(cigar_ro + hj->cig_off, hj->n_cigar, pos_j, p);                        \
+                        in_col = covered && e.in_col; is_del = e.is_del; PO.qpos = e.qpos; PO.indel = e.indel;            \
+                    }                                                                                                     \
                     a.ncol += in_col ? 1u : 0u;                                                                           \
-                    PO.qpos = e.qpos; PO.indel = e.indel; PO.want = in_col && !e.is_del && mapq_ok;                       \
-                    if (PO.want) VO = (uint32_t)bq_ro[bqo + (uint64_t)(uint32_t)e.qpos];                                  \
+                    PO.want = in_col && !is_del && mapq_ok;                                                               \
+                    if (misc_j & M_STAGED) {      /* (uniform) event word from the LDS row */                             \
+                        const int32_t d0 = p0 - pos_j - (int32_t)(misc_j >> 24);                                          \
+                        const uint32_t ws = d0 > 0 ? ((uint32_t)d0 & ~7u) : 0u;                                           \
+                        /* unconditional LDS read; lanes without an event read a clamped (in-row) element, never used */  \
+                        const uint32_t e = ((uint32_t)PO.qpos - ws) & 127u;                                               \
+                        VO = (uint32_t)reinterpret_cast<const uint16_t*>(rows[(j)])[e < (uint32_t)(WIN_U4 * 8) ? e : 0u];  \
+                    } else {                      /* > 24 inserted/deleted/clipped bases: fetch from global memory and      \
+                                                     consume it here, so no vector load is pending at the merge point   */  \
+                        const ProbeHalf* hj = reinterpret_cast<const ProbeHalf*>(rbase + (size_t)(base + (j)) * 64u);     \
+                        uint32_t t = PO.want ? (uint32_t)bq_ro[hj->bq_off + (uint64_t)(uint32_t)PO.qpos] : 0u;            \
+                        asm volatile("" : "+v"(t));                                                                       \
+                        VO = t;                                                                                           \
+                    }                                                                                                     \
                 }                                                                                                         \
             }
             Probe P0, P1; uint32_t V0, V1 = 0u;
@@ -701,7 +712,7 @@ __global__ __launch_bounds__(256) void k_indel_fill(DevCfg c, DevIn in, const DR
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c.n_reads) return;
     const DRead r = reads[i];
-    const int lib = (int)(r.misc >> 16) - 1;
+    const int lib = (int)((r.misc >> 16) & 0xffu) - 1;
     enumerate_indels(c, in, r, in.qual + in.qual_off[i], [&](int32_t p, int qpos, int len) {
         const uint32_t slot = atomicAdd(&cursor[(int64_t)(p - c.pos0) * c.Lp + lib], 1u);
         IndelEv e; e.read = (uint32_t)i; e.qpos = qpos; e.len = len; e.key_lo = 0;

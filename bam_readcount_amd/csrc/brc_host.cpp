@@ -131,7 +131,7 @@ const char* brc_engine_kind(void) { return backend_kind(); }
 
 int brc_create(const brc_config* cfg, brc_engine** out) {
     if (!cfg || !out || cfg->abi_version != BRC_ABI_VERSION) return BRC_E_ARG;
-    if (cfg->per_lib && (cfg->n_libs < 0 || (cfg->n_libs > 0 && !cfg->lib_names) || cfg->n_libs > 65000)) return BRC_E_ARG;
+    if (cfg->per_lib && (cfg->n_libs < 0 || (cfg->n_libs > 0 && !cfg->lib_names) || cfg->n_libs > 254)) return BRC_E_ARG;   // library index + 1 travels in 8 bits of the device read record
     brc_engine* e = new (std::nothrow) brc_engine();
     if (!e) return BRC_E_NOMEM;
     e->cfg = *cfg;

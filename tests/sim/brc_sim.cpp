@@ -79,14 +79,14 @@ class SimBackend : public Backend {
         // indel events: count -> scan -> fill -> reduce
         std::vector<uint32_t> cnt((size_t)(P * Lp) + 1, 0), off((size_t)(P * Lp) + 1, 0);
         for (int64_t i = 0; i < n; ++i) {
-            const DRead& rd = reads[(size_t)i]; const int lib = (int)(rd.misc >> 16) - 1;
+            const DRead& rd = reads[(size_t)i]; const int lib = (int)((rd.misc >> 16) & 0xffu) - 1;
             enumerate_indels(c, in, rd, in.qual + in.qual_off[i], [&](int32_t p, int, int) { cnt[(size_t)((int64_t)(p - c.pos0) * Lp + lib)]++; });
         }
         uint32_t run = 0;
         for (size_t k = 0; k < cnt.size(); ++k) { off[k] = run; run += cnt[k]; }
         std::vector<IndelEv> ev(run + 1); std::vector<uint32_t> cur(off);
         for (int64_t i = n - 1; i >= 0; --i) {   // reversed on purpose: the reduction must not depend on fill order
-            const DRead& rd = reads[(size_t)i]; const int lib = (int)(rd.misc >> 16) - 1;
+            const DRead& rd = reads[(size_t)i]; const int lib = (int)((rd.misc >> 16) & 0xffu) - 1;
             enumerate_indels(c, in, rd, in.qual + in.qual_off[i], [&](int32_t p, int qpos, int len) {
                 IndelEv e; e.read = (uint32_t)i; e.qpos = qpos; e.len = len; e.key_lo = 0;
                 ev[cur[(size_t)((int64_t)(p - c.pos0) * Lp + lib)]++] = e;
