@@ -128,5 +128,31 @@ class Fasta {
     std::string path_, err_;
 };
 
+// ---------------------------------------------------------------- CRAM 3.0 (minimal, cram.cpp)
+// The reference reads CRAM through htslib's samopen (bamreadcount.cpp:411, test-data/twolib.sorted.cram); this reader
+// covers reference-based CRAM 3.x with raw/gzip blocks.  Records come out in BAM layout.
+class CramReader {
+  public:
+    CramReader();
+    ~CramReader();
+    CramReader(const CramReader&) = delete;
+    CramReader& operator=(const CramReader&) = delete;
+    static bool is_cram(const std::string& path);
+    bool open(const std::string& path, Fasta* fasta);   // fasta: needed to reconstruct mapped reads
+    const BamHeader& header() const;
+    template <class F>
+    bool fetch(int tid, int64_t beg, int64_t end, F cb) {
+        if (beg < 0) beg = 0;
+        if (end <= beg) return true;
+        return fetch_impl(tid, beg, end, [](void* c, const BamRecord& r) { (*(F*)c)(r); }, &cb);
+    }
+    const std::string& error() const;
+
+  private:
+    struct Impl;
+    bool fetch_impl(int tid, int64_t beg, int64_t end, void (*thunk)(void*, const BamRecord&), void* ctx);
+    Impl* d_;
+};
+
 }  // namespace brcio
 #endif

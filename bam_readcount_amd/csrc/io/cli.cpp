@@ -162,6 +162,8 @@ struct Batcher {
 
 struct Ctx {
     Options opt; BamReader bam; BamIndex idx; Fasta fa; bool have_fa = false;
+    CramReader cram; bool is_cram = false;          // minimal CRAM 3.0 input (cram.cpp); region queries scan container headers
+    const BamHeader& header() const { return is_cram ? cram.header() : bam.header(); }
     brc_engine* eng = nullptr;
     std::vector<std::string> libs;
     int ref_tid = -1; std::string ref;      // currently loaded contig (load_reference, :83-90)
@@ -172,15 +174,15 @@ struct Ctx {
 static int lib_index(const Ctx& c, const BamRecord& r) {      // bam_get_library: RG tag -> @RG ID -> LB
     const char* rg = r.aux_str("RG");
     if (!rg) return -1;
-    auto it = c.bam.header().rg2lb.find(rg);
-    if (it == c.bam.header().rg2lb.end()) return -1;
+    auto it = c.header().rg2lb.find(rg);
+    if (it == c.header().rg2lb.end()) return -1;
     for (size_t i = 0; i < c.libs.size(); ++i) if (c.libs[i] == it->second) return (int)i;
     return -1;
 }
 
 // one reporting window [beg0,end) on tid: the body of the site-list / region loops (:588-605, :649-656)
 static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode) {
-    const BamHeader& h = c.bam.header();
+    const BamHeader& h = c.header();
     if (c.have_fa && tid != c.ref_tid) {
         if (!c.fa.fetch(h.names[(size_t)tid], &c.ref)) c.ref.clear();
         c.ref_tid = tid;
@@ -193,8 +195,9 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
     do {
         const int64_t b = std::min<int64_t>(a + c.opt.chunk_bp, end);
         c.batch.clear();
-        if (!c.bam.fetch(c.idx, tid, a - 1, b, [&](const BamRecord& r) { c.batch.add(r, c.opt.per_lib ? lib_index(c, r) : 0); })) {
-            fprintf(stderr, "bam-readcount: read error: %s\n", c.bam.error().c_str()); return 1;
+        auto add = [&](const BamRecord& r) { c.batch.add(r, c.opt.per_lib ? lib_index(c, r) : 0); };
+        if (!(c.is_cram ? c.cram.fetch(tid, a - 1, b, add) : c.bam.fetch(c.idx, tid, a - 1, b, add))) {
+            fprintf(stderr, "bam-readcount: read error: %s\n", (c.is_cram ? c.cram.error() : c.bam.error()).c_str()); return 1;
         }
         int rc = brc_begin_region(c.eng, tid, (int32_t)a, (int32_t)b, ref, (int64_t)c.ref.size());
         const brc_read_batch v = c.batch.view();
@@ -225,7 +228,7 @@ struct Site { int tid; int64_t beg0, end; };
 
 static int run_site_batch(Ctx& c, const std::vector<Site>& sites) {
     const size_t n = sites.size();
-    const BamHeader& h = c.bam.header();
+    const BamHeader& h = c.header();
     std::vector<Batcher> parts(n);
     std::vector<int64_t> lo(n), hi(n);
     std::atomic<size_t> next(0); std::atomic<int> failed(0);
@@ -326,8 +329,13 @@ int main(int argc, char** argv) {
         if (!c.fa.open(o.fasta)) { fprintf(stderr, "Fail to open reference file %s\n", o.fasta.c_str()); return 1; }
         c.have_fa = true;
     }
-    if (!c.bam.open(o.bam)) { fprintf(stderr, "Fail to open BAM file %s\n", o.bam.c_str()); return 1; }                                   // :513-516
-    c.libs = c.bam.header().libraries();
+    c.is_cram = CramReader::is_cram(o.bam);
+    if (c.is_cram ? !c.cram.open(o.bam, c.have_fa ? &c.fa : nullptr) : !c.bam.open(o.bam)) {                                               // :513-516
+        fprintf(stderr, "Fail to open BAM file %s\n", o.bam.c_str());
+        if (c.is_cram) fprintf(stderr, "bam-readcount: %s\n", c.cram.error().c_str());
+        return 1;
+    }
+    c.libs = c.header().libraries();
     for (const std::string& l : c.libs) fprintf(stderr, "Expect library: %s in BAM\n", l.c_str());                                         // :526-529
     if (o.distribution) { fprintf(stderr, "Not currently supporting distributions\n"); return 1; }                                          // :367 (the reference throws)
     std::vector<const char*> names; for (const std::string& l : c.libs) names.push_back(l.c_str());
@@ -342,17 +350,17 @@ int main(int argc, char** argv) {
     if (!o.site_list.empty()) {
         FILE* fp = fopen(o.site_list.c_str(), "r");
         if (!fp) { fprintf(stderr, "Failed to open region list file: %s\n", o.site_list.c_str()); brc_destroy(c.eng); return 1; }            // :535-538
-        if (!c.idx.load(o.bam)) { fprintf(stderr, "BAM indexing file is not available.\n"); brc_destroy(c.eng); return 1; }                  // :548-551
+        if (!c.is_cram && !c.idx.load(o.bam)) { fprintf(stderr, "BAM indexing file is not available.\n"); brc_destroy(c.eng); return 1; }                  // :548-551
         // the planner needs -d to be out of play (its drop rule depends on what else is buffered) and short windows
-        const bool plan = o.plan_sites > 0 && o.max_cnt >= 1000000;
+        const bool plan = o.plan_sites > 0 && o.max_cnt >= 1000000 && !c.is_cram;
         std::vector<Site> pending; int64_t pending_bp = 0;
         auto flush = [&]() { int r = 0; if (!pending.empty()) { r = run_site_batch(c, pending); pending.clear(); pending_bp = 0; } return r; };
         char line[65536];
         while (fgets(line, sizeof line, fp)) {                                       // ss >> ref_name >> beg >> end (:574-577)
             char name[4096]; int beg, end;
             if (sscanf(line, "%4095s %d %d", name, &beg, &end) != 3) continue;
-            auto it = c.bam.header().name2tid.find(name);
-            if (it == c.bam.header().name2tid.end()) { fprintf(stderr, "%s not found in bam file. Region %s %i %i skipped.\n", name, name, beg, end); continue; }   // :580-582
+            auto it = c.header().name2tid.find(name);
+            if (it == c.header().name2tid.end()) { fprintf(stderr, "%s not found in bam file. Region %s %i %i skipped.\n", name, name, beg, end); continue; }   // :580-582
             if (beg < 1) beg = 1;
             if (plan && (int64_t)end - beg < 100000) {
                 Site st; st.tid = it->second; st.beg0 = (int64_t)beg - 1; st.end = end < beg - 1 ? beg - 1 : end;
@@ -366,10 +374,10 @@ int main(int argc, char** argv) {
         if (!ret) ret = flush();
         fclose(fp);
     } else if (!o.regions.empty()) {
-        if (!c.idx.load(o.bam)) { fprintf(stderr, "BAM indexing file is not available.\n"); brc_destroy(c.eng); return 1; }                  // :637-640
+        if (!c.is_cram && !c.idx.load(o.bam)) { fprintf(stderr, "BAM indexing file is not available.\n"); brc_destroy(c.eng); return 1; }                  // :637-640
         for (const std::string& r : o.regions) {
             int tid; int64_t beg, end;
-            if (!parse_region(c.bam.header(), r, &tid, &beg, &end)) { fprintf(stderr, "Invalid region %s\n", r.c_str()); ret = 1; break; }   // :645-648
+            if (!parse_region(c.header(), r, &tid, &beg, &end)) { fprintf(stderr, "Invalid region %s\n", r.c_str()); ret = 1; break; }   // :645-648
             if ((ret = run_region(c, tid, beg, end, false))) break;
         }
     } else {

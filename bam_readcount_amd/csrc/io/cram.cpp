@@ -1,0 +1,361 @@
+// cram.cpp — minimal CRAM 3.0 reader, written from the public CRAM 3.0 specification; no htslib code.
+//
+// Scope: what reference-based CRAMs written by `samtools view -C` with gzip (or raw) blocks need — ITF8/LTF8, container
+// / block / slice structure, the compression header (preservation map incl. substitution matrix and tag dictionary,
+// data-series and tag encodings), the codecs EXTERNAL, HUFFMAN (canonical codes from the core bit stream, incl. the
+// zero-length single-symbol form), BYTE_ARRAY_LEN, BYTE_ARRAY_STOP and BETA, and read reconstruction from the reference
+// plus the standard feature codes (X I i D N S H P B b Q q).  Blocks compressed with rANS / bzip2 / lzma and the codecs
+// GAMMA / SUBEXP / GOLOMB are reported as unsupported.  Records come out as BAM-layout BamRecords (bamio.h) so the CLI's
+// batcher is unchanged.  Region queries scan the container headers (ref id, start, span); the .crai is not needed.
+#include <string.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <map>
+
+#include "bamio.h"
+
+namespace brcio {
+
+namespace {
+
+struct Cur { const uint8_t* p; const uint8_t* e; bool bad = false;
+    uint8_t u8() { if (p >= e) { bad = true; return 0; } return *p++; }
+    int32_t itf8() {
+        const uint8_t v = u8();
+        if (v < 0x80) return v;
+        if (v < 0xc0) return ((v & 0x3f) << 8) | u8();
+        if (v < 0xe0) { const int a = u8(), b = u8(); return ((v & 0x1f) << 16) | (a << 8) | b; }
+        if (v < 0xf0) { const int a = u8(), b = u8(), c = u8(); return ((v & 0x0f) << 24) | (a << 16) | (b << 8) | c; }
+        const int a = u8(), b = u8(), c = u8(), d = u8();
+        return (int32_t)(((uint32_t)(v & 0x0f) << 28) | ((uint32_t)a << 20) | ((uint32_t)b << 12) | ((uint32_t)c << 4) | (uint32_t)(d & 0x0f));
+    }
+    int64_t ltf8() {
+        const uint8_t v = u8();
+        int n = 0; for (uint8_t m = v; m & 0x80; m = (uint8_t)(m << 1)) ++n;
+        if (n == 0) return v;
+        int64_t val = n < 8 ? (v & (0xff >> (n + 1))) : 0;
+        for (int k = 0; k < n; ++k) val = (val << 8) | u8();
+        return val;
+    }
+    int32_t i32() { uint32_t v = 0; for (int k = 0; k < 4; ++k) v |= (uint32_t)u8() << (8 * k); return (int32_t)v; }
+};
+
+struct Block { int method = 0, type = 0, id = 0; std::vector<uint8_t> data; size_t pos = 0; };
+
+struct Enc {            // one data-series / tag encoding
+    int codec = 0;      // 0 NULL 1 EXTERNAL 3 HUFFMAN 4 BYTE_ARRAY_LEN 5 BYTE_ARRAY_STOP 6 BETA
+    int ext_id = -1;    // EXTERNAL / BYTE_ARRAY_STOP
+    uint8_t stop = 0;
+    std::vector<int32_t> sym, len;   // HUFFMAN
+    std::vector<uint32_t> code;      // canonical codes matching sym/len (sorted)
+    int beta_off = 0, beta_bits = 0;
+    std::vector<Enc> sub;            // BYTE_ARRAY_LEN: [0] lengths, [1] values
+};
+
+struct BitReader { const uint8_t* p = nullptr; size_t n = 0, bit = 0;
+    int get() { if ((bit >> 3) >= n) return 0; const int b = (p[bit >> 3] >> (7 - (bit & 7))) & 1; ++bit; return b; }
+    uint32_t bits(int k) { uint32_t v = 0; for (int i = 0; i < k; ++i) v = (v << 1) | (uint32_t)get(); return v; }
+};
+
+bool parse_enc(Cur& c, Enc* e, std::string* err) {
+    e->codec = c.itf8();
+    const int32_t plen = c.itf8();
+    Cur q; q.p = c.p; q.e = c.p + plen; c.p += plen;
+    if (c.p > c.e) { *err = "truncated CRAM encoding"; return false; }
+    switch (e->codec) {
+        case 0: return true;
+        case 1: e->ext_id = q.itf8(); return true;
+        case 3: {
+            const int na = q.itf8(); for (int i = 0; i < na; ++i) e->sym.push_back(q.itf8());
+            const int nl = q.itf8(); for (int i = 0; i < nl; ++i) e->len.push_back(q.itf8());
+            if (na != nl) { *err = "bad HUFFMAN encoding"; return false; }
+            // canonical code assignment: sort by (length, symbol)
+            std::vector<int> ord((size_t)na); for (int i = 0; i < na; ++i) ord[(size_t)i] = i;
+            std::sort(ord.begin(), ord.end(), [&](int a, int b) { return e->len[(size_t)a] != e->len[(size_t)b] ? e->len[(size_t)a] < e->len[(size_t)b] : e->sym[(size_t)a] < e->sym[(size_t)b]; });
+            std::vector<int32_t> s2, l2; for (int i : ord) { s2.push_back(e->sym[(size_t)i]); l2.push_back(e->len[(size_t)i]); }
+            e->sym = s2; e->len = l2; e->code.assign((size_t)na, 0);
+            uint32_t code = 0; int prev = na ? e->len[0] : 0;
+            for (int i = 0; i < na; ++i) { code <<= (e->len[(size_t)i] - prev); prev = e->len[(size_t)i]; e->code[(size_t)i] = code++; }
+            return true;
+        }
+        case 4: { e->sub.resize(2); return parse_enc(q, &e->sub[0], err) && parse_enc(q, &e->sub[1], err); }
+        case 5: e->stop = q.u8(); e->ext_id = q.itf8(); return true;
+        case 6: e->beta_off = q.itf8(); e->beta_bits = q.itf8(); return true;
+        default: *err = "CRAM codec " + std::to_string(e->codec) + " not supported by the minimal reader"; return false;
+    }
+}
+
+}  // namespace
+
+struct CramReader::Impl {
+    FILE* f = nullptr;
+    BamHeader hdr;
+    std::vector<std::string> rg_ids;            // @RG IDs in header order (RG data series indexes this)
+    Fasta* fa = nullptr;
+    std::string err;
+    int ref_tid = -1; std::string ref;
+    off_t data_start = 0;
+    // per-slice decode state
+    std::map<int, Block> ext; Block core; BitReader br;
+    std::map<std::string, Enc> ds; std::map<int32_t, Enc> tagenc;
+    bool rn_preserved = true, ap_delta = true; uint8_t sm[5] = {0, 0, 0, 0, 0};
+    std::vector<std::vector<int32_t> > td;      // tag dictionary: per line the tag keys (tag0<<16|tag1<<8|type)
+
+    bool read_block(Cur& c, Block* b) {
+        b->method = c.u8(); b->type = c.u8(); b->id = c.itf8();
+        const int32_t cs = c.itf8(), us = c.itf8();
+        if (c.bad || c.p + cs + 4 > c.e) { err = "truncated CRAM block"; return false; }
+        if (b->method == 0) b->data.assign(c.p, c.p + cs);
+        else if (b->method == 1) {
+            b->data.assign((size_t)us, 0);
+            z_stream zs; memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, 15 + 32) != Z_OK) { err = "zlib init failed"; return false; }
+            zs.next_in = (Bytef*)c.p; zs.avail_in = (uInt)cs; zs.next_out = b->data.data(); zs.avail_out = (uInt)us;
+            const int rc = inflate(&zs, Z_FINISH); inflateEnd(&zs);
+            if (rc != Z_STREAM_END) { err = "CRAM gzip block inflate failed"; return false; }
+        } else { err = "CRAM block compression method " + std::to_string(b->method) + " (bzip2/lzma/rANS) not supported by the minimal reader"; return false; }
+        b->pos = 0; c.p += cs + 4;
+        return true;
+    }
+
+    // ---- decoders
+    bool dec_int(const Enc& e, int32_t* out) {
+        switch (e.codec) {
+            case 1: { auto it = ext.find(e.ext_id); if (it == ext.end()) { err = "missing CRAM external block"; return false; }
+                      Cur c; c.p = it->second.data.data() + it->second.pos; c.e = it->second.data.data() + it->second.data.size();
+                      *out = c.itf8(); it->second.pos = (size_t)(c.p - it->second.data.data()); return !c.bad; }
+            case 3: { if (e.sym.size() == 1 && e.len[0] == 0) { *out = e.sym[0]; return true; }
+                      uint32_t code = 0; int l = 0; size_t i = 0;
+                      while (i < e.sym.size()) { while (l < e.len[i]) { code = (code << 1) | (uint32_t)br.get(); ++l; }
+                          for (; i < e.sym.size() && e.len[i] == l; ++i) if (e.code[i] == code) { *out = e.sym[i]; return true; } }
+                      err = "bad CRAM Huffman code"; return false; }
+            case 6: *out = (int32_t)br.bits(e.beta_bits) - e.beta_off; return true;
+            default: err = "CRAM integer codec " + std::to_string(e.codec) + " not supported"; return false;
+        }
+    }
+    bool dec_byte(const Enc& e, uint8_t* out) {
+        if (e.codec == 1) { auto it = ext.find(e.ext_id); if (it == ext.end() || it->second.pos >= it->second.data.size()) { err = "CRAM external block exhausted"; return false; }
+            *out = it->second.data[it->second.pos++]; return true; }
+        int32_t v; if (!dec_int(e, &v)) return false; *out = (uint8_t)v; return true;
+    }
+    bool dec_bytes(const Enc& e, std::vector<uint8_t>* out) {
+        out->clear();
+        if (e.codec == 5) { auto it = ext.find(e.ext_id); if (it == ext.end()) { err = "missing CRAM external block"; return false; }
+            Block& b = it->second; while (b.pos < b.data.size() && b.data[b.pos] != e.stop) out->push_back(b.data[b.pos++]); if (b.pos < b.data.size()) ++b.pos; return true; }
+        if (e.codec == 4) { int32_t n; if (!dec_int(e.sub[0], &n)) return false; for (int i = 0; i < n; ++i) { uint8_t v; if (!dec_byte(e.sub[1], &v)) return false; out->push_back(v); } return true; }
+        err = "CRAM byte-array codec " + std::to_string(e.codec) + " not supported"; return false;
+    }
+    const Enc* series(const char* k) { auto it = ds.find(k); return it == ds.end() ? nullptr : &it->second; }
+    bool geti(const char* k, int32_t* v) { const Enc* e = series(k); if (!e) { err = std::string("CRAM data series ") + k + " missing"; return false; } return dec_int(*e, v); }
+    bool getb(const char* k, uint8_t* v) { const Enc* e = series(k); if (!e) { err = std::string("CRAM data series ") + k + " missing"; return false; } return dec_byte(*e, v); }
+    bool geta(const char* k, std::vector<uint8_t>* v) { const Enc* e = series(k); if (!e) { err = std::string("CRAM data series ") + k + " missing"; return false; } return dec_bytes(*e, v); }
+
+    bool parse_comp_header(const Block& b) {
+        ds.clear(); tagenc.clear(); td.clear(); rn_preserved = true; ap_delta = true;
+        Cur c; c.p = b.data.data(); c.e = c.p + b.data.size();
+        { const int32_t sz = c.itf8(); Cur m; m.p = c.p; m.e = c.p + sz; c.p += sz;
+          const int n = m.itf8();
+          for (int i = 0; i < n; ++i) {
+              const char k0 = (char)m.u8(), k1 = (char)m.u8();
+              if (k0 == 'R' && k1 == 'N') rn_preserved = m.u8() != 0;
+              else if (k0 == 'A' && k1 == 'P') ap_delta = m.u8() != 0;
+              else if (k0 == 'R' && k1 == 'R') (void)m.u8();
+              else if (k0 == 'S' && k1 == 'M') for (int j = 0; j < 5; ++j) sm[j] = m.u8();
+              else if (k0 == 'T' && k1 == 'D') { const int32_t l = m.itf8(); const uint8_t* t = m.p; m.p += l;
+                  std::vector<int32_t> line; for (int32_t o = 0; o < l;) { if (t[o] == 0) { td.push_back(line); line.clear(); ++o; } else { line.push_back((t[o] << 16) | (t[o + 1] << 8) | t[o + 2]); o += 3; } } }
+              else { err = "unknown CRAM preservation key"; return false; } } }
+        { const int32_t sz = c.itf8(); Cur m; m.p = c.p; m.e = c.p + sz; c.p += sz;
+          const int n = m.itf8();
+          for (int i = 0; i < n; ++i) { std::string k; k.push_back((char)m.u8()); k.push_back((char)m.u8()); Enc e; if (!parse_enc(m, &e, &err)) return false; ds[k] = e; } }
+        { const int32_t sz = c.itf8(); Cur m; m.p = c.p; m.e = c.p + sz; c.p += sz;
+          const int n = m.itf8();
+          for (int i = 0; i < n; ++i) { const int32_t key = m.itf8(); Enc e; if (!parse_enc(m, &e, &err)) return false; tagenc[key] = e; } }
+        return !c.bad;
+    }
+
+    static int base_index(char b) { switch (b) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; } }
+    char substitute(char refb, int code) const {
+        static const char B[5] = {'A', 'C', 'G', 'T', 'N'};
+        const int r = base_index(refb); int k = 0;
+        for (int a = 0; a < 5; ++a) { if (a == r) continue; if (((sm[r] >> (6 - 2 * k)) & 3) == code) return B[a]; ++k; }
+        return 'N';
+    }
+
+    static void push_cigar(std::vector<uint32_t>& cg, uint32_t op, uint32_t len) {
+        if (!len) return;
+        if (!cg.empty() && (cg.back() & 15u) == op) cg.back() += len << 4; else cg.push_back((len << 4) | op);
+    }
+
+    // decode the records of one slice; cb(record) for those overlapping [beg,end) on tid
+    template <class F>
+    bool decode_slice(int slice_ref, int slice_start, int nrec, int tid, int64_t beg, int64_t end, F& cb) {
+        br.p = core.data.data(); br.n = core.data.size(); br.bit = 0;
+        int32_t last_ap = slice_start;
+        static const uint8_t nt16[256] = {0};
+        (void)nt16;
+        for (int r = 0; r < nrec; ++r) {
+            int32_t bf, cf, ri = slice_ref, rl, ap, rg;
+            if (!geti("BF", &bf) || !geti("CF", &cf)) return false;
+            if (slice_ref == -2 && !geti("RI", &ri)) return false;
+            if (!geti("RL", &rl) || !geti("AP", &ap) || !geti("RG", &rg)) return false;
+            if (ap_delta) { ap += last_ap; last_ap = ap; }
+            std::vector<uint8_t> name, tmp;
+            if (rn_preserved && !geta("RN", &name)) return false;
+            if (cf & 2) { int32_t mf, ns, np, ts; if (!geti("MF", &mf)) return false; if (!rn_preserved && !geta("RN", &name)) return false;
+                          if (!geti("NS", &ns) || !geti("NP", &np) || !geti("TS", &ts)) return false; }
+            else if (cf & 4) { int32_t nf; if (!geti("NF", &nf)) return false; }
+            int32_t tl; if (!geti("TL", &tl)) return false;
+            std::vector<uint8_t> aux;
+            if (tl >= 0 && (size_t)tl < td.size()) for (int32_t key : td[(size_t)tl]) {
+                auto it = tagenc.find(key); if (it == tagenc.end()) { err = "CRAM tag encoding missing"; return false; }
+                if (!dec_bytes(it->second, &tmp)) return false;
+                aux.push_back((uint8_t)(key >> 16)); aux.push_back((uint8_t)(key >> 8)); aux.push_back((uint8_t)key);
+                aux.insert(aux.end(), tmp.begin(), tmp.end());
+            }
+            if (rg >= 0 && (size_t)rg < rg_ids.size()) { aux.push_back('R'); aux.push_back('G'); aux.push_back('Z'); aux.insert(aux.end(), rg_ids[(size_t)rg].begin(), rg_ids[(size_t)rg].end()); aux.push_back(0); }
+            std::string seq((size_t)std::max(rl, 0), 'N'); std::vector<uint8_t> qual((size_t)std::max(rl, 0), 0xff); std::vector<uint32_t> cg;
+            int32_t mq = 0;
+            if (!(bf & 4)) {
+                if (ri != ref_tid) { if (!fa || !fa->fetch(hdr.names[(size_t)ri], &ref)) { err = "CRAM needs the reference FASTA (-f) to reconstruct reads"; return false; } ref_tid = ri; }
+                int32_t fn; if (!geti("FN", &fn)) return false;
+                int64_t refp = (int64_t)ap - 1; int sp = 1, prev = 0;
+                auto copy_ref = [&](int len) { for (int i = 0; i < len; ++i) { const int64_t x = refp + i; seq[(size_t)(sp - 1 + i)] = (x >= 0 && x < (int64_t)ref.size()) ? (char)toupper((unsigned char)ref[(size_t)x]) : 'N'; } };
+                for (int fi = 0; fi < fn; ++fi) {
+                    uint8_t fc; int32_t fp; if (!getb("FC", &fc) || !geti("FP", &fp)) return false;
+                    const int pos = prev + fp; prev = pos;
+                    if (pos > sp) { const int l = pos - sp; copy_ref(l); push_cigar(cg, 0, (uint32_t)l); refp += l; sp = pos; }
+                    uint8_t b1; int32_t iv;
+                    switch (fc) {
+                        case 'X': if (!getb("BS", &b1)) return false; seq[(size_t)(sp - 1)] = substitute((refp >= 0 && refp < (int64_t)ref.size()) ? ref[(size_t)refp] : 'N', b1); push_cigar(cg, 0, 1); ++refp; ++sp; break;
+                        case 'I': if (!geta("IN", &tmp)) return false; for (size_t i = 0; i < tmp.size(); ++i) seq[(size_t)(sp - 1) + i] = (char)tmp[i]; push_cigar(cg, 1, (uint32_t)tmp.size()); sp += (int)tmp.size(); break;
+                        case 'i': if (!getb("BA", &b1)) return false; seq[(size_t)(sp - 1)] = (char)b1; push_cigar(cg, 1, 1); ++sp; break;
+                        case 'S': if (!geta("SC", &tmp)) return false; for (size_t i = 0; i < tmp.size(); ++i) seq[(size_t)(sp - 1) + i] = (char)tmp[i]; push_cigar(cg, 4, (uint32_t)tmp.size()); sp += (int)tmp.size(); break;
+                        case 'D': if (!geti("DL", &iv)) return false; push_cigar(cg, 2, (uint32_t)iv); refp += iv; break;
+                        case 'N': if (!geti("RS", &iv)) return false; push_cigar(cg, 3, (uint32_t)iv); refp += iv; break;
+                        case 'H': if (!geti("HC", &iv)) return false; push_cigar(cg, 5, (uint32_t)iv); break;
+                        case 'P': if (!geti("PD", &iv)) return false; push_cigar(cg, 6, (uint32_t)iv); break;
+                        case 'B': { uint8_t q; if (!getb("BA", &b1) || !getb("QS", &q)) return false; seq[(size_t)(sp - 1)] = (char)b1; qual[(size_t)(sp - 1)] = q; push_cigar(cg, 0, 1); ++refp; ++sp; break; }
+                        case 'b': if (!geta("BB", &tmp)) return false; for (size_t i = 0; i < tmp.size(); ++i) seq[(size_t)(sp - 1) + i] = (char)tmp[i]; push_cigar(cg, 0, (uint32_t)tmp.size()); refp += (int64_t)tmp.size(); sp += (int)tmp.size(); break;
+                        case 'Q': { uint8_t q; if (!getb("QS", &q)) return false; qual[(size_t)(pos - 1)] = q; break; }
+                        case 'q': if (!geta("QQ", &tmp)) return false; for (size_t i = 0; i < tmp.size(); ++i) qual[(size_t)(pos - 1) + i] = tmp[i]; break;
+                        default: err = "unknown CRAM feature code"; return false;
+                    }
+                }
+                if (sp <= rl) { const int l = rl - sp + 1; copy_ref(l); push_cigar(cg, 0, (uint32_t)l); }
+                if (!geti("MQ", &mq)) return false;
+                if (cf & 1) for (int i = 0; i < rl; ++i) if (!getb("QS", &qual[(size_t)i])) return false;
+            } else {
+                for (int i = 0; i < rl; ++i) { uint8_t b; if (!getb("BA", &b)) return false; seq[(size_t)i] = (char)b; }
+                if (cf & 1) for (int i = 0; i < rl; ++i) if (!getb("QS", &qual[(size_t)i])) return false;
+            }
+            // ---- BAM-layout record
+            BamRecord rec;
+            rec.tid = ri; rec.pos = ap - 1; rec.mapq = (uint8_t)mq; rec.flag = (uint16_t)bf; rec.l_seq = rl; rec.n_cigar = (uint16_t)cg.size();
+            if (name.empty()) { const std::string gen = "cram" + std::to_string(r); name.assign(gen.begin(), gen.end()); }
+            rec.l_qname = (uint32_t)name.size() + 1;
+            rec.data.assign(name.begin(), name.end()); rec.data.push_back(0);
+            for (uint32_t v : cg) for (int k = 0; k < 4; ++k) rec.data.push_back((uint8_t)(v >> (8 * k)));
+            static const char* codes = "=ACMGRSVTWYHKDBN";
+            for (int i = 0; i < rl; i += 2) {
+                auto code_of = [&](char ch) { const char* q = strchr(codes, toupper((unsigned char)ch)); return (uint8_t)(q ? q - codes : 15); };
+                const uint8_t hi = code_of(seq[(size_t)i]), lo = i + 1 < rl ? code_of(seq[(size_t)i + 1]) : 0;
+                rec.data.push_back((uint8_t)((hi << 4) | lo));
+            }
+            rec.data.insert(rec.data.end(), qual.begin(), qual.end());
+            rec.data.insert(rec.data.end(), aux.begin(), aux.end());
+            if (rec.tid == tid && rec.pos < end && rec.endpos() > beg) cb(rec);
+        }
+        return true;
+    }
+};
+
+CramReader::CramReader() : d_(new Impl) {}
+CramReader::~CramReader() { if (d_->f) fclose(d_->f); delete d_; }
+const BamHeader& CramReader::header() const { return d_->hdr; }
+const std::string& CramReader::error() const { return d_->err; }
+
+bool CramReader::is_cram(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb"); if (!f) return false;
+    char m[4] = {0, 0, 0, 0}; const size_t n = fread(m, 1, 4, f); fclose(f);
+    return n == 4 && memcmp(m, "CRAM", 4) == 0;
+}
+
+static bool read_container_header(FILE* f, int32_t* length, int32_t* ref, int32_t* start, int32_t* span, int32_t* nrec, int32_t* nblocks, std::vector<int32_t>* land) {
+    uint8_t buf[1024];
+    const off_t at = ftello(f);
+    const size_t got = fread(buf, 1, sizeof buf, f);
+    if (got < 8) return false;
+    Cur c; c.p = buf; c.e = buf + got;
+    *length = c.i32(); *ref = c.itf8(); *start = c.itf8(); *span = c.itf8(); *nrec = c.itf8();
+    (void)c.ltf8(); (void)c.ltf8(); *nblocks = c.itf8();
+    const int nl = c.itf8(); land->clear(); for (int i = 0; i < nl; ++i) land->push_back(c.itf8());
+    c.p += 4;                                   // crc32
+    if (c.bad) return false;
+    fseeko(f, at + (off_t)(c.p - buf), SEEK_SET);
+    return true;
+}
+
+bool CramReader::open(const std::string& path, Fasta* fasta) {
+    Impl& d = *d_;
+    d.fa = fasta;
+    d.f = fopen(path.c_str(), "rb");
+    if (!d.f) { d.err = "cannot open " + path; return false; }
+    uint8_t def[26];
+    if (fread(def, 1, 26, d.f) != 26 || memcmp(def, "CRAM", 4) != 0) { d.err = "not a CRAM file"; return false; }
+    if (def[4] != 3) { d.err = "only CRAM 3.x is supported by the minimal reader"; return false; }
+    int32_t len, ref, start, span, nrec, nblocks; std::vector<int32_t> land;
+    if (!read_container_header(d.f, &len, &ref, &start, &span, &nrec, &nblocks, &land)) { d.err = "bad CRAM header container"; return false; }
+    std::vector<uint8_t> body((size_t)len);
+    if (fread(body.data(), 1, body.size(), d.f) != body.size()) { d.err = "truncated CRAM header container"; return false; }
+    d.data_start = ftello(d.f);
+    Cur c; c.p = body.data(); c.e = c.p + body.size();
+    Block b; if (!d.read_block(c, &b)) return false;
+    if (b.data.size() < 4) { d.err = "bad CRAM SAM header block"; return false; }
+    uint32_t tl = 0; for (int k = 0; k < 4; ++k) tl |= (uint32_t)b.data[(size_t)k] << (8 * k);
+    d.hdr.text.assign((const char*)b.data.data() + 4, std::min<size_t>(tl, b.data.size() - 4));
+    // @SQ / @RG
+    size_t p = 0;
+    while (p < d.hdr.text.size()) {
+        size_t e = d.hdr.text.find('\n', p); if (e == std::string::npos) e = d.hdr.text.size();
+        const std::string line = d.hdr.text.substr(p, e - p);
+        auto field = [&](const char* key) { const std::string k = std::string("\t") + key + ":"; const size_t q = line.find(k); if (q == std::string::npos) return std::string(); size_t t = line.find('\t', q + 1); return line.substr(q + k.size(), (t == std::string::npos ? line.size() : t) - q - k.size()); };
+        if (line.compare(0, 3, "@SQ") == 0) { const std::string n = field("SN"); d.hdr.name2tid[n] = (int)d.hdr.names.size(); d.hdr.names.push_back(n); d.hdr.lengths.push_back(atoi(field("LN").c_str())); }
+        if (line.compare(0, 3, "@RG") == 0) { const std::string id = field("ID"); d.rg_ids.push_back(id); if (line.find("\tLB:") != std::string::npos) d.hdr.rg2lb[id] = field("LB"); }
+        p = e + 1;
+    }
+    return true;
+}
+
+bool CramReader::fetch_impl(int tid, int64_t beg, int64_t end, void (*thunk)(void*, const BamRecord&), void* ctx) {
+    Impl& d = *d_;
+    if (beg < 0) beg = 0;
+    fseeko(d.f, d.data_start, SEEK_SET);
+    for (;;) {
+        int32_t len, ref, start, span, nrec, nblocks; std::vector<int32_t> land;
+        if (!read_container_header(d.f, &len, &ref, &start, &span, &nrec, &nblocks, &land)) break;
+        const off_t body_at = ftello(d.f);
+        const bool eof_marker = ref == -1 && nrec == 0;
+        const bool may = !eof_marker && nrec > 0 && (ref == -2 || (ref == tid && (int64_t)start - 1 < end && (int64_t)start - 1 + span > beg));
+        if (may) {
+            std::vector<uint8_t> body((size_t)len);
+            if (fread(body.data(), 1, body.size(), d.f) != body.size()) { d.err = "truncated CRAM container"; return false; }
+            Cur c; c.p = body.data(); c.e = c.p + body.size();
+            Block ch; if (!d.read_block(c, &ch) || ch.type != 1 || !d.parse_comp_header(ch)) { if (d.err.empty()) d.err = "bad CRAM compression header"; return false; }
+            while (c.p < c.e) {
+                Block sh; if (!d.read_block(c, &sh)) return false;
+                if (sh.type != 2) { d.err = "expected a CRAM slice header"; return false; }
+                Cur s; s.p = sh.data.data(); s.e = s.p + sh.data.size();
+                const int32_t sref = s.itf8(), sstart = s.itf8(); (void)s.itf8(); const int32_t snrec = s.itf8(); (void)s.ltf8(); const int32_t snb = s.itf8();
+                d.ext.clear();
+                for (int i = 0; i < snb; ++i) { Block b; if (!d.read_block(c, &b)) return false; if (b.type == 5) d.core = b; else d.ext[b.id] = b; }
+                auto cb = [&](const BamRecord& r) { thunk(ctx, r); };
+                if (!d.decode_slice(sref, sstart, snrec, tid, beg, end, cb)) return false;
+            }
+        }
+        if (fseeko(d.f, body_at + len, SEEK_SET) != 0) break;
+    }
+    return true;
+}
+
+}  // namespace brcio

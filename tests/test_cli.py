@@ -128,6 +128,25 @@ def synthetic_bam(tmp_path_factory):
     bamio.write_bam(str(d / "syn.bam"), [("chrA", 5000), ("chrB", 3000)], arrs, tids, rg_of_read=rgs,
                     rg_lines=["@RG\tID:rgA1\tLB:libA\tSM:s", "@RG\tID:rgB1\tLB:libB\tSM:s"], block_bytes=6000)
     _write_fasta(d / "syn.fa", [("chrA", refs[0]), ("chrB", refs[1])])
+    # CRAM does not keep '=' / 'X' operators (they come back as 'M', adjacent runs merged) and the reference's annotator
+    # treats them differently from 'M' (bamreadcount.cpp:133-200 only walks BAM_CMATCH), so the BAM twin of the CRAM is
+    # written from the normalised CIGARs
+    norm = dict(arrs); cig = []; ncs = []
+    for i in range(len(arrs["pos"])):
+        ops = []
+        for c in arrs["cigar"][int(arrs["cigar_off"][i]):int(arrs["cigar_off"][i]) + int(arrs["n_cigar"][i])]:
+            op, ln = int(c) & 15, int(c) >> 4
+            if op in (7, 8): op = 0
+            if ops and ops[-1][0] == op: ops[-1][1] += ln
+            else: ops.append([op, ln])
+        cig += [(ln << 4) | op for op, ln in ops]; ncs.append(len(ops))
+    norm["cigar"] = np.array(cig, np.uint32); norm["n_cigar"] = np.array(ncs, np.uint32)
+    norm["cigar_off"] = np.concatenate([[0], np.cumsum(ncs)[:-1]]).astype(np.uint64)
+    bamio.write_bam(str(d / "syn_m.bam"), [("chrA", 5000), ("chrB", 3000)], norm, tids, rg_of_read=rgs,
+                    rg_lines=["@RG\tID:rgA1\tLB:libA\tSM:s", "@RG\tID:rgB1\tLB:libB\tSM:s"], block_bytes=6000)
+    import cramio
+    cramio.write_cram(str(d / "syn.cram"), [("chrA", 5000), ("chrB", 3000)], arrs, tids, refs, rg_of_read=rgs,
+                      rg_lines=["@RG\tID:rgA1\tLB:libA\tSM:s", "@RG\tID:rgB1\tLB:libB\tSM:s"], per_container=280)
     return d
 
 
@@ -183,3 +202,54 @@ def test_cli_bam_reader_region_equals_oracle_cpu(synthetic_bam, oracle_lib):
     assert b"Expect library: libA in BAM" in got.stderr and b"Expect library: libB in BAM" in got.stderr
     assert got.stdout.count(b"\n") > 3000 and got.stdout.startswith(b"chrA\t1000\t")
     assert b"\tlibA\t{" in got.stdout and b"chrB\t" in got.stdout
+
+
+def _cram_check(cli, oracle_lib, twolib):
+    """n4: the reference's CRAM smoke run (test-data/cram_site_test.sh:1 — it has no expected file) through the minimal
+    CRAM 3.0 reader: the CLI's text must equal the oracle fed with the same 4 reads re-created from rand1k.fa."""
+    import parity
+    names = [str(s) for s in twolib["lib_names"]]
+    for extra, kw in (([], dict()), (["-p", "-i"], dict(per_lib=True, insertion_centric=True, lib_names=names)),
+                      (["-p"], dict(per_lib=True, lib_names=names))):
+        want, _ = parity.run_engine(oracle_lib, twolib, [(49, 60)], tid=0, chrom="rand1k", ref=twolib["ref"], ref_len_check=True, **kw)
+        p = subprocess.run([cli, "-w", "0"] + extra + ["-l", "twolib_site_list.txt", "-f", "rand1k.fa", "twolib.sorted.cram"],
+                           cwd=GOLDEN, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr
+        assert p.stdout == want and p.stdout.count(b"\n") == 11, extra
+        assert b"Expect library: reads1_lb in BAM" in p.stderr and b"Expect library: reads2_lb in BAM" in p.stderr
+    # region mode over all four reads (both libraries), and a query that starts inside the second read
+    want, _ = parity.run_engine(oracle_lib, twolib, [(0, 1000), (100, 130)], tid=0, chrom="rand1k", ref=twolib["ref"], per_lib=True, lib_names=names, clear_queue=False)
+    p = subprocess.run([cli, "-w", "0", "-p", "-f", "rand1k.fa", "twolib.sorted.cram", "rand1k", "rand1k:101-130"], cwd=GOLDEN, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0 and p.stdout == want and p.stdout.count(b"\n") == 240 + 30
+    # mapped CRAM records cannot be rebuilt without the reference
+    p = subprocess.run([cli, "twolib.sorted.cram", "rand1k:1-10"], cwd=GOLDEN, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 1 and b"reference FASTA" in p.stderr
+
+
+def test_cli_cram_input_equals_oracle_cpu(oracle_lib, twolib):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    _cram_check(SIM_CLI, oracle_lib, twolib)
+
+
+@pytest.mark.gpu
+def test_cli_cram_input_equals_oracle_gpu(oracle_lib, twolib):
+    _cram_check(HIP_CLI, oracle_lib, twolib)
+
+
+def test_cli_cram_reader_equals_bam_reader_cpu(synthetic_bam):
+    """The same synthetic reads written as BAM and (tools/cramio.py) as a multi-container reference-based CRAM with every
+    feature code, a multi-reference slice, Huffman/BETA core-stream series: the CLI must print identical text for both."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    d = synthetic_bam
+    for extra in ([], ["-p", "-i"], ["-q", "15", "-b", "10"]):
+        regs = ["chrA:1-5000", "chrB", "chrA:2400-2450", "chrB:1-20"]
+        a = subprocess.run([SIM_CLI, "-w", "0", "-f", "syn.fa"] + extra + ["syn_m.bam"] + regs, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        b = subprocess.run([SIM_CLI, "-w", "0", "-f", "syn.fa"] + extra + ["syn.cram"] + regs, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
+        assert a.stdout.count(b"\n") > 7000
+        assert a.stdout == b.stdout, extra
+        assert a.stderr == b.stderr
+    sl = _sites_file(d, "csites.txt", [("chrA", 1200, 1260), ("chrB", 5, 9), ("chrA", 1200, 1200), ("chrB", 2990, 3005)])
+    a = subprocess.run([SIM_CLI, "-w", "0", "-f", "syn.fa", "-p", "-l", sl, "--brc-plan", "0", "syn_m.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    b = subprocess.run([SIM_CLI, "-w", "0", "-f", "syn.fa", "-p", "-l", sl, "syn.cram"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and a.stdout.count(b"\n") > 60

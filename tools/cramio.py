@@ -1,0 +1,218 @@
+"""Test-side CRAM 3.0 writer (no htslib here): turns brc_read_batch arrays into a reference-based CRAM so the minimal
+CRAM reader of the drop-in CLI (bam_readcount_amd/csrc/io/cram.cpp) can be exercised on more than the reference's one
+4-read fixture.  Written from the public CRAM 3.0 specification.  It deliberately uses every codec the reader supports:
+
+  BF           HUFFMAN with real multi-symbol canonical codes (core bit stream)
+  MQ           BETA (core bit stream)
+  CF, TL       HUFFMAN single symbol, zero-length code
+  RN, SC       BYTE_ARRAY_STOP            IN, BB      BYTE_ARRAY_LEN(EXTERNAL, EXTERNAL)
+  tags         BYTE_ARRAY_LEN(HUFFMAN single symbol, EXTERNAL)
+  the rest     EXTERNAL (ITF8 / bytes), blocks alternately raw and gzip
+
+Reads become features against the reference: X (substitution matrix), B (base+quality, for IUPAC read bases), I / i, D, N,
+S, H, P.  A chunk of reads that spans two contigs is written as a multi-reference slice (ref id -2, RI series, absolute
+AP); single-reference slices use delta AP.  '=' / 'X' CIGAR operators come back as 'M' (CRAM does not keep them)."""
+import heapq
+import struct
+import zlib
+
+NT16 = "=ACMGRSVTWYHKDBN"
+
+
+def itf8(v):
+    v &= 0xFFFFFFFF
+    if v < 0x80: return bytes([v])
+    if v < 0x4000: return bytes([0x80 | (v >> 8), v & 0xFF])
+    if v < 0x200000: return bytes([0xC0 | (v >> 16), (v >> 8) & 0xFF, v & 0xFF])
+    if v < 0x10000000: return bytes([0xE0 | (v >> 24), (v >> 16) & 0xFF, (v >> 8) & 0xFF, v & 0xFF])
+    return bytes([0xF0 | (v >> 28), (v >> 20) & 0xFF, (v >> 12) & 0xFF, (v >> 4) & 0xFF, v & 0x0F])
+
+
+def ltf8(v):
+    assert 0 <= v < (1 << 28)
+    return itf8(v)          # identical to ITF8 below 2^28
+
+
+def block(method, ctype, cid, data):
+    comp = data
+    if method == 1:
+        co = zlib.compressobj(6, zlib.DEFLATED, 31); comp = co.compress(data) + co.flush()
+    b = bytes([method, ctype]) + itf8(cid) + itf8(len(comp)) + itf8(len(data)) + comp
+    return b + struct.pack("<I", zlib.crc32(b))
+
+
+def enc(codec, params):
+    return itf8(codec) + itf8(len(params)) + params
+
+
+def e_ext(cid): return enc(1, itf8(cid))
+def e_huff1(sym): return enc(3, itf8(1) + itf8(sym) + itf8(1) + itf8(0))
+def e_stop(stop, cid): return enc(5, bytes([stop]) + itf8(cid))
+def e_len(le, ve): return enc(4, le + ve)
+def e_beta(off, bits): return enc(6, itf8(off) + itf8(bits))
+
+
+def huffman_lengths(freq):
+    if len(freq) == 1: return {next(iter(freq)): 0}
+    heap = [(f, i, [s]) for i, (s, f) in enumerate(sorted(freq.items()))]
+    heapq.heapify(heap); lens = {s: 0 for s in freq}; k = len(heap)
+    while len(heap) > 1:
+        fa, _, sa = heapq.heappop(heap); fb, _, sb = heapq.heappop(heap)
+        for s in sa + sb: lens[s] += 1
+        heapq.heappush(heap, (fa + fb, k, sa + sb)); k += 1
+    return lens
+
+
+def canonical(lens):
+    order = sorted(lens, key=lambda s: (lens[s], s))
+    codes = {}; code = 0; prev = lens[order[0]]
+    for s in order:
+        code <<= (lens[s] - prev); prev = lens[s]; codes[s] = code; code += 1
+    return order, codes
+
+
+class Bits:
+    def __init__(self): self.out = bytearray(); self.n = 0
+    def put(self, v, k):
+        for i in range(k - 1, -1, -1):
+            if self.n % 8 == 0: self.out.append(0)
+            if (v >> i) & 1: self.out[-1] |= 1 << (7 - self.n % 8)
+            self.n += 1
+
+
+SM_ORDER = {"A": "CGTN", "C": "AGTN", "G": "ACTN", "T": "ACGN", "N": "ACGT"}   # alternatives in ACGTN order minus self
+# substitution codes: a permutation per reference base (deliberately not the identity)
+SM_CODES = {"A": [1, 0, 3, 2], "C": [0, 2, 1, 3], "G": [3, 2, 1, 0], "T": [2, 3, 0, 1], "N": [0, 1, 2, 3]}
+
+
+def sm_bytes():
+    return bytes(sum(c << (6 - 2 * k) for k, c in enumerate(SM_CODES[r])) for r in "ACGTN")
+
+
+def refclass(ch):
+    ch = ch.upper()
+    return ch if ch in "ACGT" else "N"
+
+
+# data-series content ids
+IDS = dict(RI=1, RL=2, AP=3, RG=4, RN=5, MF=6, NS=7, NP=8, TS=9, NF=10, FN=11, FC=12, FP=13, BS=14, IN=15, INL=16, SC=17, DL=18, RS=19,
+           HC=20, PD=21, BA=22, QS=23, BB=24, BBL=25, QQ=26)
+
+
+def write_cram(path, contigs, arrs, tids, refs, rg_of_read=None, rg_lines=(), qnames=None, per_container=300):
+    """contigs [(name, len)], arrs = brc_read_batch arrays, tids = contig per read, refs = list of uint8 reference arrays."""
+    text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % c for c in contigs) + "".join(l + "\n" for l in rg_lines)
+    rg_ids = [dict(f.split(":", 1) for f in l.split("\t")[1:])["ID"] for l in rg_lines]
+    out = bytearray(b"CRAM" + bytes([3, 0]) + b"brc-test-cram".ljust(20, b"\0"))
+
+    def container(ref, start, span, nrec, blocks, landmarks):
+        body = b"".join(blocks)
+        h = struct.pack("<i", len(body)) + itf8(ref) + itf8(start) + itf8(span) + itf8(nrec) + ltf8(0) + ltf8(0) + itf8(len(blocks)) + \
+            itf8(len(landmarks)) + b"".join(itf8(x) for x in landmarks)
+        return h + struct.pack("<I", zlib.crc32(h)) + body
+
+    out += container(0, 0, 0, 0, [block(0, 0, 0, struct.pack("<i", len(text)) + text.encode())], [0])
+    n = len(arrs["pos"])
+    for c0 in range(0, n, per_container):
+        idx = range(c0, min(n, c0 + per_container))
+        ctids = sorted(set(int(tids[i]) for i in idx))
+        multi = len(ctids) > 1
+        ext = {k: bytearray() for k in IDS}
+        tag_blocks = {}; td_lines = []; core = Bits()
+        flags = {}
+        for i in idx: flags[int(arrs["flag"][i])] = flags.get(int(arrs["flag"][i]), 0) + 1
+        blens = huffman_lengths(flags); border, bcodes = canonical(blens)
+        first_pos = int(arrs["pos"][c0]) + 1
+        last_ap = first_pos; max_end = first_pos
+        for i in idx:
+            L = int(arrs["l_qseq"][i]); nc = int(arrs["n_cigar"][i]); pos = int(arrs["pos"][i]); tid = int(tids[i]); flag = int(arrs["flag"][i])
+            cig = [int(x) for x in arrs["cigar"][int(arrs["cigar_off"][i]):int(arrs["cigar_off"][i]) + nc]]
+            s4 = arrs["seq4"][int(arrs["seq_off"][i]):int(arrs["seq_off"][i]) + (L + 1) // 2]
+            seq = "".join(NT16[(int(s4[j >> 1]) >> (4 if j % 2 == 0 else 0)) & 15] for j in range(L))
+            qual = bytes(arrs["qual"][int(arrs["qual_off"][i]):int(arrs["qual_off"][i]) + L])
+            core.put(bcodes[flag], blens[flag])                                  # BF
+            if multi: ext["RI"] += itf8(tid)
+            ext["RL"] += itf8(L)
+            ext["AP"] += itf8(pos + 1) if multi else itf8(pos + 1 - last_ap)
+            last_ap = pos + 1
+            rg = rg_of_read[i] if rg_of_read is not None else None
+            ext["RG"] += itf8(rg_ids.index(rg) if rg in rg_ids else -1)
+            ext["RN"] += (qnames[i] if qnames is not None else "r%d" % i).encode() + b"\0"
+            # tags
+            tl = []
+            if int(arrs["tags"][i]) & 1: tl.append((b"NMC" if 0 <= int(arrs["nm"][i]) < 256 else b"NMi", int(arrs["nm"][i])))
+            if int(arrs["tags"][i]) & 2: tl.append((b"SMC" if 0 <= int(arrs["sm"][i]) < 256 else b"SMi", int(arrs["sm"][i])))
+            line = b"".join(k for k, _ in tl)
+            if line not in td_lines: td_lines.append(line)
+            ext.setdefault("TL", bytearray()); ext["TL"] += itf8(td_lines.index(line))
+            for k, v in tl:
+                key = (k[0] << 16) | (k[1] << 8) | k[2]
+                tag_blocks.setdefault(key, bytearray()); tag_blocks[key] += bytes([v]) if k[2:] == b"C" else struct.pack("<i", v)
+            if not flag & 4:
+                ref = refs[tid]; feats = []; rp = pos; sp = 1
+                for c in cig:
+                    op, ln = c & 15, c >> 4
+                    if op in (0, 7, 8):
+                        for j in range(ln):
+                            rb = chr(ref[rp + j]).upper() if 0 <= rp + j < len(ref) else "N"
+                            b = seq[sp - 1 + j]
+                            if b == rb: continue
+                            if b in "ACGTN" and refclass(rb) != b: feats.append((sp + j, "X", SM_CODES[refclass(rb)][SM_ORDER[refclass(rb)].index(b)]))
+                            else: feats.append((sp + j, "B", (b, qual[sp - 1 + j])))
+                        rp += ln; sp += ln
+                    elif op == 1:
+                        feats.append((sp, "i", seq[sp - 1]) if ln == 1 and (sp % 2) else (sp, "I", seq[sp - 1:sp - 1 + ln])); sp += ln
+                    elif op == 4: feats.append((sp, "S", seq[sp - 1:sp - 1 + ln])); sp += ln
+                    elif op == 2: feats.append((sp, "D", ln)); rp += ln
+                    elif op == 3: feats.append((sp, "N", ln)); rp += ln
+                    elif op == 5: feats.append((sp, "H", ln))
+                    elif op == 6: feats.append((sp, "P", ln))
+                max_end = max(max_end, rp)
+                ext["FN"] += itf8(len(feats)); prev = 0
+                for fp, fc, v in feats:
+                    ext["FC"] += fc.encode(); ext["FP"] += itf8(fp - prev); prev = fp
+                    if fc == "X": ext["BS"].append(v)
+                    elif fc == "B": ext["BA"] += v[0].encode(); ext["QS"].append(v[1])
+                    elif fc == "i": ext["BA"] += v.encode()
+                    elif fc == "I": ext["INL"] += itf8(len(v)); ext["IN"] += v.encode()
+                    elif fc == "S": ext["SC"] += v.encode() + b"\0"
+                    elif fc == "D": ext["DL"] += itf8(v)
+                    elif fc == "N": ext["RS"] += itf8(v)
+                    elif fc == "H": ext["HC"] += itf8(v)
+                    elif fc == "P": ext["PD"] += itf8(v)
+                core.put(int(arrs["mapq"][i]) + 3, 9)                            # MQ: BETA offset 3, 9 bits
+                ext["QS"] += qual
+            else:
+                ext["BA"] += seq.encode(); ext["QS"] += qual
+                max_end = max(max_end, pos + 1)
+        # ---- compression header
+        td = b"".join(l + b"\0" for l in td_lines)
+        pres = [b"RN" + b"\1", b"AP" + (b"\0" if multi else b"\1"), b"RR" + b"\1", b"SM" + sm_bytes(), b"TD" + itf8(len(td)) + td]
+        pm = itf8(len(pres)) + b"".join(pres)
+        dse = {"BF": enc(3, itf8(len(border)) + b"".join(itf8(s) for s in border) + itf8(len(border)) + b"".join(itf8(blens[s]) for s in border)),
+               "CF": e_huff1(1), "MQ": e_beta(3, 9), "RN": e_stop(0, IDS["RN"]), "SC": e_stop(0, IDS["SC"]),
+               "IN": e_len(e_ext(IDS["INL"]), e_ext(IDS["IN"])), "BB": e_len(e_ext(IDS["BBL"]), e_ext(IDS["BB"])),
+               "QQ": e_len(e_ext(IDS["BBL"]), e_ext(IDS["QQ"]))}
+        tl_ids = 27
+        dse["TL"] = e_huff1(0) if len(td_lines) == 1 else e_ext(tl_ids)
+        for k in ("RI", "RL", "AP", "RG", "MF", "NS", "NP", "TS", "NF", "FN", "FC", "FP", "BS", "DL", "RS", "HC", "PD", "BA", "QS"):
+            dse[k] = e_ext(IDS[k])
+        dm = itf8(len(dse)) + b"".join(k.encode() + v for k, v in dse.items())
+        te = {key: e_len(e_huff1(1 if (key & 0xFF) == ord("C") else 4), e_ext(key)) for key in tag_blocks}
+        tm = itf8(len(te)) + b"".join(itf8(k) + v for k, v in te.items())
+        ch = block(0, 1, 0, itf8(len(pm)) + pm + itf8(len(dm)) + dm + itf8(len(tm)) + tm)
+        # ---- slice
+        eblocks = []
+        for j, (k, cid) in enumerate(sorted(IDS.items(), key=lambda kv: kv[1])):
+            if ext[k]: eblocks.append(block(j % 2, 4, cid, bytes(ext[k])))
+        if len(td_lines) > 1: eblocks.append(block(1, 4, tl_ids, bytes(ext["TL"])))
+        for key, data in tag_blocks.items(): eblocks.append(block(1, 4, key, bytes(data)))
+        sref = -2 if multi else ctids[0]
+        sstart = 0 if multi else first_pos; sspan = 0 if multi else max_end - first_pos + 1
+        ids = [IDS[k] for k in sorted(IDS, key=lambda kk: IDS[kk]) if ext[k]] + ([tl_ids] if len(td_lines) > 1 else []) + list(tag_blocks)
+        sh = itf8(sref) + itf8(sstart) + itf8(sspan) + itf8(len(idx)) + ltf8(c0) + itf8(1 + len(eblocks)) + itf8(len(ids)) + \
+            b"".join(itf8(x) for x in ids) + itf8(-1) + bytes(16)
+        blocks = [ch, block(0, 2, 0, sh), block(0, 5, 0, bytes(core.out))] + eblocks
+        out += container(sref, sstart, sspan, len(idx), blocks, [len(ch)])
+    out += bytes.fromhex("0f000000ffffffff0fe0454f460000000001000 5bdd94f0001000606010001000100ee63014b".replace(" ", ""))
+    open(path, "wb").write(bytes(out))

@@ -131,7 +131,8 @@ def main():
     # the four goldens, the site lists, and the reference's BAM inputs themselves (data, needed by the CLI tests)
     for f in ("expected_all_lib", "expected_per_lib", "expected_insertion_centric_all_lib",
               "expected_insertion_centric_per_lib", "site_list", "twolib_site_list.txt",
-              "test.bam", "test.bam.bai", "test_bad_rg.bam", "test_bad_rg.bam.bai"):
+              "test.bam", "test.bam.bai", "test_bad_rg.bam", "test_bad_rg.bam.bai",
+              "twolib.sorted.cram", "twolib.sorted.cram.crai", "rand1k.fa", "rand1k.fa.fai"):
         shutil.copyfile(os.path.join(REF, f), os.path.join(OUT, f))
 
     # twolib.sorted.cram: 4 reads 60M, flag 0, MAPQ 60, starts 0/60/120/180, perfect match, QUAL 0xFF, no NM/SM
