@@ -79,9 +79,11 @@ struct RcpPair { float rcpL, rcpC, Lf, center; };
 
 // Packed per-read record written by K1 and read with ONE scalar load (s_load_dwordx16) by KB: 64 bytes.
 enum { M_REV = 1, M_Q2OK = 2, M_SMW = 4, M_NMW = 8, M_SIMPLE = 16,
-       M_TABLE = 32,    // l_qseq == clipped_length == DevCfg.table_len: event terms come from the quotient tables
-       M_STAGED = 64 }; // KB can stage this read's bq window in LDS: simple CIGAR, or deleted + inserted + clipped bases <= 24
-// misc layout: bits 0-6 flags | 8-15 mapq | 16-23 library index + 1 (0 = unavailable) | 24-31 total D/N bases (staged reads)
+       M_CLIPM = 32,    // CIGAR is one M with soft clips around it ([S] M [S]): qpos = p - pos + left, no CIGAR walk in KB
+       M_STAGED = 64,   // KB can stage this read's bq window in LDS: simple CIGAR, or deleted + inserted + clipped bases <= 24
+       M_FAST = 128 };  // SIMPLE && STAGED && library known && l_qseq == clipped_length == DevCfg.table_len: KB's branch-free
+                        // probe applies and the event terms come from the quotient tables (finish_misc)
+// misc layout: bits 0-7 flags | 8-15 mapq | 16-23 library index + 1 (0 = unavailable) | 24-31 total D/N bases (staged reads)
 enum { STAGE_SLACK = 24 };
 struct alignas(64) DRead {
     int32_t pos, end;          // [pos,end) on the reference; end == pos when the read never enters a column
@@ -92,8 +94,24 @@ struct alignas(64) DRead {
     int32_t q2, tp, left, clipped;   // Zm: q2_pos, three_prime_index, left_clip, clipped_length
     uint32_t zm_sum, sse_add;        // Zm sum_of_mismatch_qualities; per-event addend of sum_single_ended_map_qualities
     float snm_add;                   // per-event addend of sum_number_of_mismatches: NM / (float)clipped_length
-    uint32_t pad0;
+    int32_t clipped_dup;             // == clipped: the accumulate stage reads {zm_sum, sse_add, snm_add, clipped} as ONE 16-byte word
 };
+
+// table: l_qseq == clipped_length == DevCfg.table_len;  clipm: the CIGAR is [S] M [S] and left_clip is the leading clip
+BRC_HD uint32_t finish_misc(uint32_t misc, bool table, bool clipm) {
+    const uint32_t need = M_SIMPLE | M_STAGED;
+    if (clipm && (misc & M_STAGED)) misc |= M_CLIPM;
+    if (table && (misc & need) == need && ((misc >> 16) & 0xffu) != 0u) misc |= M_FAST;
+    return misc;
+}
+// shape of a CIGAR for M_CLIPM, fed operator by operator
+struct CigShape { int n_m = 0, n_other = 0, lead_s = 0; };
+BRC_HD void shape_add(CigShape& s, uint32_t op, int len) {
+    if (op == 0u /* CMATCH */) ++s.n_m;
+    else if (op == 4u /* CSOFT_CLIP */) { if (!s.n_m) s.lead_s += len; }
+    else ++s.n_other;
+}
+BRC_HD bool shape_clipm(const CigShape& s, uint32_t nc, int left_clip) { return nc >= 2u && s.n_m == 1 && s.n_other == 0 && s.lead_s == left_clip; }
 
 // One indel event, produced by the per-read enumeration, consumed by the per-key reduction (16 bytes).
 struct IndelEv { uint32_t read; int32_t qpos; int32_t len; uint32_t key_lo; };
@@ -157,11 +175,13 @@ BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i, uint16_t
     int64_t reference_position = pos;
     int32_t rlen = 0;           // reference length: bam_cigar2rlen
     int64_t tot_d = 0, tot_is = 0;   // deleted/skipped reference bases, inserted + soft-clipped query bases
+    CigShape shape;
     bool stop = false;          // ':151/:175' out-of-reference break: ends ALL CIGAR processing of the annotator
     for (uint32_t k = 0; k < nc; ++k) {
         const uint32_t op = cig[k] & 0xfu;
         const int len = (int)(cig[k] >> 4);
         if (is_refop(op)) rlen += len;
+        shape_add(shape, op, len);
         if (op == CDEL || op == CREF_SKIP) tot_d += len;
         if (op == CINS || op == CSOFT_CLIP) tot_is += len;
         if (stop) continue;     // rlen (the pileup's view of the read) still needs the remaining ops
@@ -232,11 +252,11 @@ BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i, uint16_t
     float snm = 0.0f;
     if (tags & 1u) snm = (float)in.nm[i] / (float)clipped;                                   // BasicStat.cpp:94-97
     else misc |= M_NMW;
-    if (c.table_len > 0 && L == c.table_len && clipped == L) misc |= M_TABLE;
+    const bool table = c.table_len > 0 && L == c.table_len && clipped == L;
     RcpPair rc; rc.Lf = (float)L; rc.center = (float)clipped * 0.5f; rc.rcpL = 1.0f / rc.Lf; rc.rcpC = 1.0f / rc.center;
     rcp_out[i] = rc;
-    r.misc = misc; r.l_qseq = L; r.q2 = q2; r.tp = tp; r.left = left_clip; r.clipped = clipped;
-    r.zm_sum = sum; r.sse_add = sse; r.snm_add = snm; r.pad0 = 0;
+    r.misc = finish_misc(misc, table, shape_clipm(shape, nc, left_clip)); r.l_qseq = L; r.q2 = q2; r.tp = tp; r.left = left_clip; r.clipped = clipped;
+    r.zm_sum = sum; r.sse_add = sse; r.snm_add = snm; r.clipped_dup = clipped;
     return r;
 }
 
@@ -430,7 +450,8 @@ BRC_HD Probe lane_probe(const DevCfg& c, const DevIn& in, const DRead& rd, uint3
         if (rlib != lib_sel) return pr;                                 // another library's wave handles it
     }
     bool in_col = covered, is_del = false;
-    if (!(rd.misc & M_SIMPLE)) {                                        // general CIGAR (uniform, uncommon)
+    if (rd.misc & M_CLIPM) pr.qpos += rd.left;                          // [S] M [S]: the query offset of the leading clip
+    else if (!(rd.misc & M_SIMPLE)) {                                   // general CIGAR (uniform, uncommon)
         const Ev e = resolve_cigar(in.cigar + rd.cig_off, rd.n_cigar, rd.pos, p);   // uniform control: all lanes
         in_col = covered && e.in_col; pr.qpos = e.qpos; is_del = e.is_del; pr.indel = e.indel;
     }
@@ -477,7 +498,7 @@ BRC_HD void lane_accumulate(const DevCfg& c, const DRead& rd, const RcpPair& rc,
     if (rd.misc & M_NMW) a.w_nm += pass ? 1u : 0u;
     // whenever a lane has an event the read has l_qseq >= 1 and clipped_length >= 1: reciprocals are finite; lanes
     // without an event compute garbage that is never added
-    const EvTerms t = (rd.misc & M_TABLE) ? event_terms_tab(rd, tt, pass ? pr.qpos : 0) : event_terms_fast(rd, rc, pr.qpos);   // (uniform)
+    const EvTerms t = (rd.misc & M_FAST) ? event_terms_tab(rd, tt, pass ? pr.qpos : 0) : event_terms_fast(rd, rc, pr.qpos);   // (uniform)
     // Independent single-predecessor blocks only (no if/else chain, no switch): LLVM would otherwise sink the arms'
     // common tail into one block addressed through a phi of pointers, which defeats scalar replacement of the
     // accumulators and sends them to scratch memory.

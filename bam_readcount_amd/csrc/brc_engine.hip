@@ -83,8 +83,10 @@ __global__ __launch_bounds__(256) void k_annotate_wave(DevCfg c, DevIn in, DRead
     const uint8_t* __restrict__ qual = in.qual + qoff;
 
     int32_t rlen = 0; int clipped = L, left_clip = 0, right_clip = L; int64_t tot_d = 0, tot_is = 0;
+    CigShape shape;
     for (uint32_t k = 0; k < nc; ++k) {
         const uint32_t op = cig[k] & 0xfu; const int len = (int)(cig[k] >> 4);
+        shape_add(shape, op, len);
         if (is_refop(op)) rlen += len;
         if (op == CDEL || op == CREF_SKIP) tot_d += len;
         if (op == CINS || op == CSOFT_CLIP) tot_is += len;
@@ -159,9 +161,8 @@ __global__ __launch_bounds__(256) void k_annotate_wave(DevCfg c, DevIn in, DRead
         if (flag & FPROPER_PAIR) { if (tags & 2u) sse = (uint32_t)in.sm[i]; else { sse = 0; misc |= M_SMW; } } else sse = mapq;
         float snm = 0.0f;
         if (tags & 1u) snm = (float)in.nm[i] / (float)clipped; else misc |= M_NMW;
-        if (c.table_len > 0 && L == c.table_len && clipped == L) misc |= M_TABLE;
-        r.misc = misc; r.l_qseq = L; r.q2 = q2; r.tp = tp; r.left = left_clip; r.clipped = clipped;
-        r.zm_sum = sum; r.sse_add = sse; r.snm_add = snm; r.pad0 = 0;
+        r.misc = finish_misc(misc, c.table_len > 0 && L == c.table_len && clipped == L, shape_clipm(shape, nc, left_clip)); r.l_qseq = L; r.q2 = q2; r.tp = tp; r.left = left_clip; r.clipped = clipped;
+        r.zm_sum = sum; r.sse_add = sse; r.snm_add = snm; r.clipped_dup = clipped;
         if (lane == 0) {
             reads[i] = r; ends[i] = r.end;
             RcpPair rc; rc.Lf = (float)L; rc.center = (float)clipped * 0.5f; rc.rcpL = 1.0f / rc.Lf; rc.rcpC = 1.0f / rc.center;
@@ -212,10 +213,12 @@ __global__ __launch_bounds__(256) void k_annotate_batch(DevCfg c, DevIn in, DRea
     const uint32_t coff = (uint32_t)in.cig_off[my];
     int32_t rlen = 0; int clipped = L, left_clip = 0, right_clip = L; int64_t tot_d = 0, tot_is = 0;
     uint32_t cig0 = 0;
+    CigShape shape;
     for (uint32_t k = 0; k < nc; ++k) {
         const uint32_t cg = cigar_ro[coff + k];
         if (k == 0) cig0 = cg;
         const uint32_t op = cg & 0xfu; const int len = (int)(cg >> 4);
+        shape_add(shape, op, len);
         if (is_refop(op)) rlen += len;
         if (op == CDEL || op == CREF_SKIP) tot_d += len;
         if (op == CINS || op == CSOFT_CLIP) tot_is += len;
@@ -352,13 +355,12 @@ __global__ __launch_bounds__(256) void k_annotate_batch(DevCfg c, DevIn in, DRea
         if (q2 > -1) misc |= M_Q2OK;
         if (simple) misc |= M_SIMPLE;
         if (tot_d + tot_is <= STAGE_SLACK) misc |= M_STAGED | ((uint32_t)tot_d << 24);
-        if (c.table_len > 0 && L == c.table_len && clipped == L) misc |= M_TABLE;
         uint32_t sse;
         if (flag & FPROPER_PAIR) { if (tags & 2u) sse = (uint32_t)in.sm[my]; else { sse = 0; misc |= M_SMW; } } else sse = mapq;
         float snm = 0.0f;
         if (tags & 1u) snm = (float)in.nm[my] / (float)clipped; else misc |= M_NMW;
-        r.misc = misc; r.l_qseq = L; r.q2 = q2; r.tp = tp; r.left = left_clip; r.clipped = clipped;
-        r.zm_sum = my_sum; r.sse_add = sse; r.snm_add = snm; r.pad0 = 0;
+        r.misc = finish_misc(misc, c.table_len > 0 && L == c.table_len && clipped == L, shape_clipm(shape, nc, left_clip)); r.l_qseq = L; r.q2 = q2; r.tp = tp; r.left = left_clip; r.clipped = clipped;
+        r.zm_sum = my_sum; r.sse_add = sse; r.snm_add = snm; r.clipped_dup = clipped;
         RcpPair rc; rc.Lf = (float)L; rc.center = (float)clipped * 0.5f; rc.rcpL = 1.0f / rc.Lf; rc.rcpC = 1.0f / rc.center;
         rcp[my] = rc;
     }
@@ -478,6 +480,17 @@ __global__ __launch_bounds__(256) void k_tiles(DevCfg c, const int32_t* __restri
 
 // ---------------------------------------------------------------- KB: pileup + BasicStat accumulation (the hot kernel)
 
+// |a - b| of two unsigned values in one instruction (LLVM does not form v_sad_u32 from max - min)
+__device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "s"(b));
+    return d;
+}
+// x += 1 in the lanes of a wave mask held in scalar registers: one add-with-carry instead of select + add
+__device__ __forceinline__ void count_if(uint32_t& x, uint64_t mask) {
+    asm("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(x) : "s"(mask) : "vcc");
+}
+
 enum { PILEUP_WAVES = 4 };   // 256 threads: 4 consecutive tiles (256 positions) per workgroup
 enum { WIN_U4 = 12 };        // bq window per staged read: 12 x 16 B = 96 elements (>= 64 tile positions + 7 of alignment slack)
 enum { ROW_U4 = 15 };        // LDS row = window + the read's accumulate half (2 x 16 B) + its float constants (16 B)
@@ -497,16 +510,28 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
     const uint32_t nb = gridDim.x;            // multiple of 8
     const uint32_t per = nb >> 3;
     const uint32_t wg = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-    // quotient tables of the region's modal read length (see event_terms_tab): built once per workgroup
-    __shared__ float tab_q[TABLE_MAX + 1];
-    __shared__ double tab_e[TABLE_MAX + 1];
+    // One LDS object so the order is fixed: the quotient tables first, the staging rows last (a lane that is outside a
+    // read fetches an unused element a little before its row: that must stay inside the allocation).
+    //   q[n] = (float)n / (float)L0 for 0 <= n <= L0 (see event_terms_tab), 0.0f for L0 < n <= 2 L0 + 1: a read without
+    //          a Q2 position looks up |qpos - (2 L0 + 1)|, which lands in the zero part;   e[n] = 1.0 - (double)q[n]
+    struct Lds {
+        float q[2 * TABLE_MAX + 4];
+        double e[TABLE_MAX + 1];
+        alignas(16) uint4 rows[PILEUP_WAVES][BATCH][ROW_U4];
+    };
+    __shared__ Lds lds;
     if (V != 3) {
         const float l0 = (float)c.table_len;
-        for (int n = threadIdx.x; n <= c.table_len; n += PILEUP_WAVES * 64) { const float qv = (float)n / l0; tab_q[n] = qv; tab_e[n] = 1.0 - (double)qv; }
+        for (int n = threadIdx.x; n <= 2 * c.table_len + 1; n += PILEUP_WAVES * 64) {
+            const float qv = n <= c.table_len ? (float)n / l0 : 0.0f;
+            lds.q[n] = qv;
+            if (n <= c.table_len) lds.e[n] = 1.0 - (double)qv;
+        }
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
-    const int64_t tile = (int64_t)wg * PILEUP_WAVES + (threadIdx.x >> 6);
+    const uint32_t wv = __builtin_amdgcn_readfirstlane((uint32_t)threadIdx.x >> 6);   // wave of the workgroup (scalar)
+    const int64_t tile = (int64_t)wg * PILEUP_WAVES + wv;
     if (tile >= ntiles) return;
     const int lib = blockIdx.y;
     const uint2 r2 = rng[tile];
@@ -529,26 +554,29 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
     //    (ds_read_u16, issued one read ahead), its accumulate half (Zm integers, addends, float constants) from the
     //    same row with three broadcast ds_read_b128 — no scalar/vector memory latency inside the loop.  Reads with a general CIGAR are not staged; their event words come from global
     //    memory (uncommon).
-    __shared__ uint4 lds_rows[PILEUP_WAVES][BATCH][ROW_U4];
-    TermTab tt; tt.q = tab_q; tt.e = tab_e;
     if (lo < hi && V != 3) {
         const uint32_t libsel = (uint32_t)lib + 1u;
-        struct ProbeHalf { int32_t pos, end; uint32_t cig_off, n_cigar; uint64_t bq_off; uint32_t misc; int32_t l_qseq; };
-        struct AccHalf { int32_t q2, tp, left, clipped; uint32_t zm_sum, sse_add; float snm_add; uint32_t pad0; };
-        struct Tab { int32_t pos, end; uint64_t bq_off; uint32_t misc; int32_t l_qseq; };
-        static_assert(sizeof(ProbeHalf) == 32 && sizeof(AccHalf) == 32 && sizeof(DRead) == 64, "DRead halves");
+        struct ProbeHalf { int32_t pos, end; uint32_t cig_off, n_cigar; uint64_t bq_off; uint32_t misc; int32_t l_qseq; int32_t q2, tp; };
+        struct Tab { int32_t pos, end; uint64_t bq_off; uint32_t misc; int32_t l_qseq; int32_t q2, tp; };
+        static_assert(sizeof(ProbeHalf) == 40 && sizeof(DRead) == 64, "DRead layout");
         const char* __restrict__ rbase = reinterpret_cast<const char*>(reads);
-        uint4(*rows)[ROW_U4] = lds_rows[threadIdx.x >> 6];
-        const int32_t p0 = (int32_t)(c.pos0 + tile * TILE);                 // first position of the tile (uniform)
+        uint4(*rows)[ROW_U4] = lds.rows[wv];
+        const int32_t p0 = (int32_t)(c.pos0 + tile * TILE);                 // first position of the tile (scalar)
         const uint32_t row = (uint32_t)lane & (uint32_t)(BATCH - 1), slot = (uint32_t)lane >> 4;   // slot 0..3
-#define BRC_LD_ACC(i) (*reinterpret_cast<const AccHalf*>(rbase + (size_t)(i) * 64u + 32u))
+        // lanes past the region's last position stand on INT32_MIN: (uint32)(INT32_MIN - pos) = 2^31 - pos >= end - pos for
+        // every read (end <= 2^31 - 1), so no coverage test is ever true for them
+        const int32_t pe = valid ? p : INT32_MIN;
+        const uint32_t L0 = (uint32_t)c.table_len;
 #define BRC_RL(x, j) __builtin_amdgcn_readlane((int)(x), (int)(j))
+#define BRC_ALL(cond) ((cond) ? ~0ull : 0ull)
         // lane table of the batch starting at read b0 (clamped to the tile's reads)
 #define BRC_LD_TAB(TT, b0)                                                                                              \
         {                                                                                                                 \
             const uint32_t ri = (b0) + row < hi ? (b0) + row : hi - 1u;                                                   \
             const ProbeHalf* hp = reinterpret_cast<const ProbeHalf*>(rbase + (size_t)ri * 64u);                           \
             TT.pos = hp->pos; TT.end = hp->end; TT.bq_off = hp->bq_off; TT.misc = hp->misc; TT.l_qseq = hp->l_qseq;       \
+            /* byte offsets for the quotient-table look-ups of M_FAST reads; no Q2 position -> the zero part of q[] */    \
+            TT.q2 = (TT.misc & M_Q2OK) ? hp->q2 * 4 : (int32_t)(2u * L0 + 1u) * 4; TT.tp = hp->tp * 4;                     \
         }
         // window loads of a batch into registers (W0..W2 = chunks slot, slot+4, slot+8 of the lane's row) ...
 #define BRC_LD_WIN(TT, b0, W0, W1, W2, W3, OK)                                                                          \
@@ -565,89 +593,176 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
             if (slot < 2u) W3 = *reinterpret_cast<const uint4*>(rbase + (size_t)ri * 64u + 32u + 16u * slot);             \
             else if (slot == 2u) W3 = *reinterpret_cast<const uint4*>(rcp + ri);                                          \
         }
+        // the staging predicate of BRC_LD_WIN again (recomputed at store time so it is not carried through the read loop)
+#define BRC_LD_WIN_OK(TT, b0, OK)                                                                                       \
+        {                                                                                                                 \
+            const int32_t d0 = p0 - TT.pos - (int32_t)(TT.misc >> 24);                                                    \
+            const uint32_t ws = d0 > 0 ? ((uint32_t)d0 & ~7u) : 0u;                                                       \
+            OK = (b0) + row < hi && (TT.misc & M_STAGED) && TT.end > TT.pos && (int32_t)ws < TT.l_qseq + 8;               \
+        }
         // ... and their write into the LDS rows
 #define BRC_ST_WIN(W0, W1, W2, W3, OK)                                                                                  \
         {                                                                                                                 \
             if (OK) { rows[row][slot] = W0; rows[row][slot + 4u] = W1; rows[row][slot + 8u] = W2; }                       \
             if (slot < 3u) rows[row][(uint32_t)WIN_U4 + slot] = W3;                                                       \
         }
-        Tab T, Tn, Tnn;
-        uint4 W0 = make_uint4(0, 0, 0, 0), W1 = W0, W2 = W0, W3 = W0; bool wok = false;
-        BRC_LD_TAB(T, lo)
-        BRC_LD_TAB(Tn, lo + (uint32_t)BATCH)
-        BRC_LD_WIN(T, lo, W0, W1, W2, W3, wok)
-        BRC_ST_WIN(W0, W1, W2, W3, wok)                                           // first batch: staged synchronously
-        for (uint32_t base = lo; base < hi; base += (uint32_t)BATCH) {
-            const uint32_t nb = (hi - base) < (uint32_t)BATCH ? (hi - base) : (uint32_t)BATCH;
-            const bool more = base + (uint32_t)BATCH < hi;
-            if (more) {                                                       // prefetch: windows of batch b+1, table of batch b+2
-                BRC_LD_WIN(Tn, base + (uint32_t)BATCH, W0, W1, W2, W3, wok)
-                BRC_LD_TAB(Tnn, base + 2u * (uint32_t)BATCH)
-            }
-            // probe of read j (inline form of lane_probe; see brc_core.h for the commented reference version)
-#define BRC_PROBE(j, PO, VO)                                                                                            \
-            {                                                                                                             \
-                const int32_t pos_j = BRC_RL(T.pos, j), end_j = BRC_RL(T.end, j);                                         \
-                const uint32_t misc_j = (uint32_t)BRC_RL(T.misc, j);                                                      \
-                const bool covered = valid && (uint32_t)(p - pos_j) < (uint32_t)(end_j - pos_j);                          \
-                const uint32_t rlib = (misc_j >> 16) & 0xffu;                                                             \
-                bool mine = true;                                                     /* (uniform) */                     \
+        // One read against the wave goes through two stages, software-pipelined one read apart:
+        //   PROBE  coverage test, column count, the lane's event word (quality | bucket << 8) from the read's LDS row and
+        //          the three event terms (table look-ups for M_FAST reads: everything in flight is an LDS read);
+        //   ACC    base-quality filter, depth, warning counts and the BasicStat adds of the dominant / alternate bucket.
+        // Lane conditions are kept as 64-bit wave masks in scalar registers (ballot of ONE compare each, combined with
+        // scalar and/andn2) so counting is one v_addc per counter and the two predicated regions of ACC are the only
+        // exec changes.  Per-read constants come from the lane table with v_readlane (pos, end, misc, q2, tp) or as one
+        // broadcast 16-byte LDS read (zm_sum, sse_add, snm_add, clipped).  A read that is not M_FAST (general CIGAR,
+        // clipped, odd length, unavailable library: a few percent) takes the one uniform branch into the general probe.
+        struct Stage { uint32_t v; float tq2, ts3p; double tsev; uint64_t m_want, m_pass; uint32_t misc; int32_t thr; };
+#define BRC_PROBE(j, S)                                                                                                 \
+        {                                                                                                                 \
+            const int32_t pos_j = BRC_RL(T.pos, j), end_j = BRC_RL(T.end, j);                                             \
+            const uint32_t misc_j = (uint32_t)BRC_RL(T.misc, j);                                                          \
+            const uint32_t rlib = (misc_j >> 16) & 0xffu;                                                                 \
+            /* a read below the mapping-quality cut can never pass the base-quality test (:288) */                        \
+            S.thr = (int)((misc_j >> 8) & 0xffu) >= c.min_mapq ? c.min_bq : 256;                                          \
+            S.misc = misc_j;                                                                                              \
+            int32_t qpos = pe - pos_j;                                                                                    \
+            uint64_t m_in;                                                            /* lanes whose column holds the read */ \
+            if (__builtin_expect((misc_j & M_FAST) != 0u, 1)) {                                                           \
+                /* another library's read has length 0 here (without -p every read carries library 1 == libsel) */       \
+                uint32_t len = rlib == libsel ? (uint32_t)(end_j - pos_j) : 0u;                                           \
+                asm("" : "+s"(len));      /* keep it ONE scalar select (else: a branch or a lane-mask round trip) */     \
+                m_in = __builtin_amdgcn_ballot_w64((uint32_t)qpos < len);                                                 \
+                S.m_want = m_in; S.m_pass = m_in;                                                                         \
+                const int32_t d0 = p0 - pos_j;                                                                            \
+                const uint32_t ws = d0 > 0 ? ((uint32_t)d0 & ~7u) : 0u;                                                   \
+                /* lanes outside the read use query position 0: some element of LDS at or a little before the row */     \
+                const uint32_t qp = __builtin_amdgcn_inverse_ballot_w64(m_in) ? (uint32_t)qpos : 0u;                      \
+                S.v = (uint32_t)*reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(rows[(j)]) - 2u * ws + 2u * qp); \
+                /* event_terms_tab as byte offsets: 4|qp - q2|, 4|qp - tp|, 8|2 qp - L0| */                               \
+                const uint32_t qp4 = qp << 2;                                                                             \
+                S.tq2 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds.q) + sad_u32(qp4, (uint32_t)BRC_RL(T.q2, j)));  \
+                S.ts3p = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds.q) + sad_u32(qp4, (uint32_t)BRC_RL(T.tp, j))); \
+                S.tsev = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds.e) + sad_u32(qp4 << 2, L0 << 3)); \
+            } else {                                                                                                      \
+                const uint64_t m_cov = __builtin_amdgcn_ballot_w64((uint32_t)qpos < (uint32_t)(end_j - pos_j));                 \
+                bool mine = true;                                                                                         \
                 if (c.per_lib) {                                                                                          \
-                    if (rlib == 0) { if (covered && a.unavail == NONE32) a.unavail = base + (j); mine = false; }          \
+                    if (rlib == 0) { if (__builtin_amdgcn_inverse_ballot_w64(m_cov) && a.unavail == NONE32) a.unavail = base + (j); mine = false; } \
                     else if (rlib != libsel) mine = false;                                                                \
                 }                                                                                                         \
-                const bool mapq_ok = (int)((misc_j >> 8) & 0xffu) >= c.min_mapq;      /* (uniform) */                     \
-                PO.qpos = p - pos_j; PO.indel = 0; PO.want = false; VO = 0u;                                              \
+                m_in = 0; S.m_want = 0; S.m_pass = 0; S.v = 0u; S.tq2 = 0.0f; S.ts3p = 0.0f; S.tsev = 0.0;                \
                 if (mine) {                                                                                               \
-                    bool in_col = covered, is_del = false;                                                                \
-                    if (!(misc_j & M_SIMPLE)) {   /* general CIGAR (uniform): wave-uniform walk on the scalar unit */      \
+                    /* the read's constants from its LDS row */                                                           \
+                    const uint4 h0 = rows[(j)][WIN_U4], h2 = rows[(j)][WIN_U4 + 2];                                       \
+                    uint64_t m_del = 0, m_ins = 0;                                                                        \
+                    m_in = m_cov;                                                                                         \
+                    if (misc_j & M_CLIPM) qpos += (int32_t)h0.z;  /* [S] M [S]: offset of the leading clip */              \
+                    else if (!(misc_j & M_SIMPLE)) {   /* general CIGAR: wave-uniform walk on the scalar unit */          \
                         const ProbeHalf* hj = reinterpret_cast<const ProbeHalf*>(rbase + (size_t)(base + (j)) * 64u);     \
                         const Ev e = resolve_cigar(cigar_ro + hj->cig_off, hj->n_cigar, pos_j, p);                        \
-                        in_col = covered && e.in_col; is_del = e.is_del; PO.qpos = e.qpos; PO.indel = e.indel;            \
+                        m_in &= __builtin_amdgcn_ballot_w64(e.in_col); m_del = __builtin_amdgcn_ballot_w64(e.is_del);     \
+                        m_ins = __builtin_amdgcn_ballot_w64(e.indel >= 1); qpos = e.qpos;                                 \
                     }                                                                                                     \
-                    a.ncol += in_col ? 1u : 0u;                                                                           \
-                    PO.want = in_col && !is_del && mapq_ok;                                                               \
-                    if (misc_j & M_STAGED) {      /* (uniform) event word from the LDS row */                             \
+                    S.m_want = m_in & ~m_del;                                                                             \
+                    S.m_pass = c.insertion_centric ? S.m_want & ~m_ins : S.m_want;                                        \
+                    const bool want = __builtin_amdgcn_inverse_ballot_w64(S.m_want);                                      \
+                    if (misc_j & M_STAGED) {      /* event word from the LDS row */                                       \
                         const int32_t d0 = p0 - pos_j - (int32_t)(misc_j >> 24);                                          \
                         const uint32_t ws = d0 > 0 ? ((uint32_t)d0 & ~7u) : 0u;                                           \
-                        /* unconditional LDS read; lanes without an event read a clamped (in-row) element, never used */  \
-                        const uint32_t e = ((uint32_t)PO.qpos - ws) & 127u;                                               \
-                        VO = (uint32_t)reinterpret_cast<const uint16_t*>(rows[(j)])[e < (uint32_t)(WIN_U4 * 8) ? e : 0u];  \
+                        const uint32_t e = ((uint32_t)qpos - ws) & 127u;                                                  \
+                        S.v = (uint32_t)reinterpret_cast<const uint16_t*>(rows[(j)])[e < (uint32_t)(WIN_U4 * 8) ? e : 0u];  \
                     } else {                      /* > 24 inserted/deleted/clipped bases: fetch from global memory and      \
                                                      consume it here, so no vector load is pending at the merge point   */  \
                         const ProbeHalf* hj = reinterpret_cast<const ProbeHalf*>(rbase + (size_t)(base + (j)) * 64u);     \
-                        uint32_t t = PO.want ? (uint32_t)bq_ro[hj->bq_off + (uint64_t)(uint32_t)PO.qpos] : 0u;            \
+                        uint32_t t = want ? (uint32_t)bq_ro[hj->bq_off + (uint64_t)(uint32_t)qpos] : 0u;                  \
                         asm volatile("" : "+v"(t));                                                                       \
-                        VO = t;                                                                                           \
+                        S.v = t;                                                                                          \
                     }                                                                                                     \
+                    /* event terms by exact reciprocal division (event_terms_fast) */                                     \
+                    DRead RX; RX.misc = misc_j; RX.q2 = (int32_t)h0.x; RX.tp = (int32_t)h0.y; RX.left = (int32_t)h0.z; RX.clipped = (int32_t)h0.w; \
+                    RcpPair C; C.rcpL = __uint_as_float(h2.x); C.rcpC = __uint_as_float(h2.y); C.Lf = __uint_as_float(h2.z); C.center = __uint_as_float(h2.w); \
+                    const EvTerms t = event_terms_fast(RX, C, want ? qpos : 0);                                           \
+                    S.tq2 = t.q2; S.ts3p = t.s3p; S.tsev = t.sev;                                                         \
                 }                                                                                                         \
+            }                                                                                                             \
+            count_if(a.ncol, m_in);                                                   /* lib_counts[library] (:286) */    \
+        }
+        // accumulate stage of read j (S = its probe results)
+#define BRC_ACC(j, S)                                                                                                   \
+        {                                                                                                                 \
+            if (V == 2) a.depth += S.v + (uint32_t)S.tsev;                                                                \
+            else {                                                                                                        \
+                const uint32_t q = S.v & 0xffu, b = S.v >> 8;                                                             \
+                const uint64_t m_bq = __builtin_amdgcn_ballot_w64((int)q >= S.thr);       /* :288 */                      \
+                count_if(a.depth, S.m_want & m_bq);                                       /* mapq_n (:312) */             \
+                const uint64_t m_p = S.m_pass & m_bq;                                     /* :343 */                      \
+                RQ.misc = S.misc; RQ.zm_sum = g1.x; RQ.sse_add = g1.y; RQ.snm_add = __uint_as_float(g1.z); RQ.clipped = (int32_t)g1.w; \
+                EvTerms t; t.q2 = S.tq2; t.s3p = S.ts3p; t.sev = S.tsev;                                                  \
+                const uint32_t smw = (S.misc / M_SMW) & 1u, nmw = (S.misc / M_NMW) & 1u;  /* process_read warnings */     \
+                const uint64_t m_dom = m_p & __builtin_amdgcn_ballot_w64(b == a.dom_b);                                   \
+                /* independent single-predecessor regions (see lane_accumulate in brc_core.h) */                         \
+                if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(m_dom), 1)) {                                    \
+                    acc_apply(a.di, a.df, RQ, t, q, false); a.w_sm += smw; a.w_nm += nmw;                                 \
+                }                                                                                                         \
+                if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(m_p & ~m_dom), 0)) {                             \
+                    const bool take_alt = a.alt_b == NB_NONE || a.alt_b == b;                                             \
+                    a.w_sm += smw; a.w_nm += nmw;                                                                         \
+                    if (take_alt) { a.alt_b = b; acc_apply(a.xi, a.xf, RQ, t, q, false); }                                \
+                    if (!take_alt) overflow_event(c, o, a, b, RQ, t, q);                                                  \
+                }                                                                                                         \
+            }                                                                                                             \
+        }
+        // one pipeline step: constants and probe of read j+1 into (GN, SN), then accumulate read j from (GC, SC).  Nothing
+        // inside a step consumes an LDS result issued in the same step, so the only LDS wait is at the top of a step.
+#define BRC_STEP(j, SC, SN, GC, GN)                                                                                     \
+        {                                                                                                                 \
+            /* every LDS read of the previous step has had a whole accumulate stage to land: wait for them HERE, on    \
+               every path, so that the compiler does not put a full lgkmcnt(0) wait (covering this step's own reads)   \
+               in front of the first use inside the accumulate stage */                                                \
+            __builtin_amdgcn_s_waitcnt(0xC07F);                               /* lgkmcnt(0) */                             \
+            if ((j) + 1u < nb) {                                                                                          \
+                GN = rows[(j) + 1u][WIN_U4 + 1];                              /* zm_sum, sse_add, snm_add, clipped */      \
+                BRC_PROBE((j) + 1u, SN)                                                                                   \
+            }                                                                                                             \
+            { const uint4 g1 = GC; BRC_ACC(j, SC) }                                                                       \
+        }
+        Tab T, Tn;
+        uint4 W0 = make_uint4(0, 0, 0, 0), W1 = W0, W2 = W0, W3 = W0; bool wok = false;
+        BRC_LD_TAB(T, lo)
+        Tn = T;
+        BRC_LD_WIN(T, lo, W0, W1, W2, W3, wok)
+        BRC_ST_WIN(W0, W1, W2, W3, wok)                                           // first batch: staged synchronously
+        DRead RQ; RQ.pos = RQ.end = 0; RQ.cig_off = RQ.n_cigar = 0; RQ.bq_off = 0; RQ.l_qseq = 0; RQ.q2 = RQ.tp = RQ.left = 0;
+        for (uint32_t base = lo; base < hi; base += (uint32_t)BATCH) {
+            const uint32_t nb = (hi - base) < (uint32_t)BATCH ? (hi - base) : (uint32_t)BATCH;
+            const bool more = base + (uint32_t)BATCH < hi;                    // then nb == BATCH
+            if (more) BRC_LD_TAB(Tn, base + (uint32_t)BATCH)                  // lane table of the next batch
+            Stage S0, S1;
+            uint4 G0 = rows[0][WIN_U4 + 1], G1;
+            BRC_PROBE(0u, S0)
+            S1 = S0; G1 = G0;
+            // two reads per trip so the two stage buffers swap roles instead of being copied
+            for (uint32_t j = 0; j < nb; j += 2u) {
+                // half way through, the next batch's windows are requested (its lane table has arrived by now); they
+                // land in registers while the remaining reads are processed and are written to LDS after the loop
+                if (j == (uint32_t)(BATCH / 2) && more) { bool ok2; BRC_LD_WIN(Tn, base + (uint32_t)BATCH, W0, W1, W2, W3, ok2) (void)ok2; }
+                BRC_STEP(j, S0, S1, G0, G1)
+                if (j + 1u >= nb) break;
+                BRC_STEP(j + 1u, S1, S0, G1, G0)
             }
-            Probe P0, P1; uint32_t V0, V1 = 0u;
-            BRC_PROBE(0u, P0, V0)
-            P1 = P0;
-            DRead RQ; RQ.pad0 = 0; RQ.pos = RQ.end = 0; RQ.cig_off = RQ.n_cigar = 0; RQ.bq_off = 0; RQ.l_qseq = 0;
-            for (uint32_t j = 0; j < nb; ++j) {
-                // read j's accumulate half + float constants: three broadcast LDS reads (same address in every lane)
-                const uint4 g0 = rows[j][WIN_U4], g1 = rows[j][WIN_U4 + 1], g2 = rows[j][WIN_U4 + 2];
-                if (j + 1u < nb) BRC_PROBE(j + 1u, P1, V1)                       // probe read j+1 (its LDS read in flight)
-                RQ.misc = (uint32_t)BRC_RL(T.misc, j);
-                RQ.q2 = (int32_t)g0.x; RQ.tp = (int32_t)g0.y; RQ.left = (int32_t)g0.z; RQ.clipped = (int32_t)g0.w;
-                RQ.zm_sum = g1.x; RQ.sse_add = g1.y; RQ.snm_add = __uint_as_float(g1.z);
-                RcpPair C; C.rcpL = __uint_as_float(g2.x); C.rcpC = __uint_as_float(g2.y); C.Lf = __uint_as_float(g2.z); C.center = __uint_as_float(g2.w);
-                if (V == 2) a.depth += V0;
-                else lane_accumulate(c, RQ, C, tt, P0, V0, o, a);                // accumulate read j
-                P0 = P1; V0 = V1;
-            }
-#undef BRC_PROBE
             if (more) {                                                       // all reads of this batch are done with the rows
+                BRC_LD_WIN_OK(Tn, base + (uint32_t)BATCH, wok)
                 BRC_ST_WIN(W0, W1, W2, W3, wok)
-                T = Tn; Tn = Tnn;
+                T = Tn;
             }
         }
-#undef BRC_LD_ACC
+#undef BRC_STEP
+#undef BRC_ACC
+#undef BRC_PROBE
 #undef BRC_RL
+#undef BRC_ALL
 #undef BRC_LD_TAB
 #undef BRC_LD_WIN
+#undef BRC_LD_WIN_OK
 #undef BRC_ST_WIN
     }
     if (V != 1) { if (valid) lane_store(c, o, a); }
@@ -934,7 +1049,9 @@ class HipBackend : public Backend {
         if (ntiles > 0) {
             unsigned nwg = (unsigned)((ntiles + PILEUP_WAVES - 1) / PILEUP_WAVES);
             nwg = (nwg + 7u) & ~7u;
-#define BRC_LAUNCH_PILEUP(V) hipLaunchKernelGGL((k_pileup<V>), dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), 0, stream, c, in, reads, (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.cigar, in.rcp, in.bq)
+            // profiling knob: unused dynamic LDS lowers the number of resident waves (occupancy sweeps)
+            static const unsigned dyn_lds = getenv("BRC_PILEUP_LDS_PAD") ? (unsigned)atoi(getenv("BRC_PILEUP_LDS_PAD")) : 0u;
+#define BRC_LAUNCH_PILEUP(V) hipLaunchKernelGGL((k_pileup<V>), dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), dyn_lds, stream, c, in, reads, (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.cigar, in.rcp, in.bq)
             switch (c.variant) { case 1: BRC_LAUNCH_PILEUP(1); break; case 2: BRC_LAUNCH_PILEUP(2); break; case 3: BRC_LAUNCH_PILEUP(3); break; default: BRC_LAUNCH_PILEUP(0); }
         }
         HIPCHK(hipEventRecord(evt[T_COUNT], stream));
