@@ -371,6 +371,317 @@ __global__ __launch_bounds__(256) void k_annotate_batch(DevCfg c, DevIn in, DRea
     }
 }
 
+// Reference characters -> 4-bit base codes, once per region (the annotator compares codes, bamreadcount.cpp:149-152).
+// A NUL character keeps bit 7 set: the annotator stops at it (:151), which only the serial path reproduces.
+// REFCODE_PAD bytes of padding (code 15) on both sides: an 8-byte window may start before / end after the slice.
+enum { REFCODE_PAD = 16 };
+__global__ __launch_bounds__(256) void k_refcode(const char* __restrict__ ref, uint8_t* __restrict__ code, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // index into the padded buffer
+    if (i >= n + 2 * REFCODE_PAD) return;
+    const int64_t j = i - REFCODE_PAD;
+    uint32_t v = 0x0fu;
+    if (j >= 0 && j < n) { const uint32_t ch = (uint8_t)ref[j]; v = ch ? nt16_of_char(ch) : 0x8fu; }
+    code[i] = (uint8_t)v;
+}
+
+// K1, group form (the one normally launched): one wave owns 64 consecutive reads; a lane of the per-base pass owns one
+// GROUP of 8 consecutive bases of one read, groups of consecutive reads packed back to back over the lanes, so the
+// QUAL / SEQ / reference-code loads (8 / 4 / 8 bytes per lane) and the 16-byte bq stores are contiguous across the wave
+// and every per-base step works on 4 bases per instruction (bytes of a dword):
+//   phase A (lane = read)  metadata + CIGAR walk: reference length, clips, and the (at most two) M operators as query
+//                          ranges with their reference offsets; reads needing the per-base pass are compacted ("dense")
+//                          and their parameters go to LDS; reads with more than two M operators, reads overhanging the
+//                          reference (the annotator's break/continue quirks) and runs without a reference are left to
+//                          the serial annotate_read() in phase C;
+//   phase B (lane = group) 64 groups per pass.  lane -> read through a per-pass marker row in LDS (ballot + mbcnt);
+//                          base codes vs reference codes, "=ACGTN" buckets and the quality != 2 test are byte-parallel;
+//                          mismatch qualities: runs of read-adjacent mismatches contribute their maximum (:152-172,199) —
+//                          a lone mismatch inside its group is added directly, anything else (two mismatches in a group,
+//                          a run crossing a group or pass boundary) goes through a lane-serial walk + neighbour links;
+//                          results are accumulated per read in LDS (sum, first/last quality != 2);
+//   phase C (lane = read)  three-prime / Q2 logic, DRead + float constants, indel-event counting.
+struct AnnPar { uint4 a, b, c; };    // a = {L, qrel, srel, browrel}  b = {S, m1lo, m1hi, d1}  c = {m2lo, m2hi, d2, unused}
+
+__device__ __forceinline__ uint32_t nzb7(uint32_t x) { return x + 0x7f7f7f7fu; }   // bytes <= 0x7f: bit 7 of a byte <=> byte != 0
+
+__global__ __launch_bounds__(256) void k_annotate_groups(DevCfg c, DevIn in, DRead* __restrict__ reads, int32_t* __restrict__ ends,
+                                                         uint16_t* __restrict__ bq, RcpPair* __restrict__ rcp, uint32_t* __restrict__ indel_cnt,
+                                                         const uint32_t* __restrict__ cigar_ro, const uint8_t* __restrict__ qual_ro,
+                                                         const uint8_t* __restrict__ seq_ro, const uint8_t* __restrict__ refcode) {
+    struct WaveLds { AnnPar par[64]; int32_t lo[64], hi[64]; uint32_t sum[64]; uint32_t redo[64]; uint32_t G[64]; uint8_t mark[64]; };
+    __shared__ WaveLds lds_all[4];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane((uint32_t)threadIdx.x >> 6);
+    WaveLds& W = lds_all[wv];
+    const int64_t rb = ((int64_t)blockIdx.x * 4 + wv) * 64;
+    if (rb >= c.n_reads) return;
+    const int nrd = (int)((c.n_reads - rb) < 64 ? (c.n_reads - rb) : 64);
+    const int64_t my = rb + (lane < nrd ? lane : nrd - 1);
+    const bool have = lane < nrd;
+    // ---- phase A
+    const int32_t pos = in.pos[my];
+    const uint32_t flag = in.flag[my];
+    const int32_t L = in.l_qseq[my];
+    const uint32_t nc = in.n_cigar[my];
+    const uint64_t qoff = in.qual_off[my], soff = in.seq_off[my], brow = in.bq_row[my];
+    const uint32_t coff = (uint32_t)in.cig_off[my];
+    int32_t rlen = 0; int clipped = L, left_clip = 0, right_clip = L; int64_t tot_d = 0, tot_is = 0;
+    uint32_t cig0 = 0;
+    CigShape shape;
+    int n_m = 0; int32_t m1lo = 0, m1hi = 0, m2lo = 0, m2hi = 0; int64_t d1 = 0, d2 = 0;
+    {
+        int rs = 0; int64_t x = pos;                     // the annotator's read / reference cursors (bamreadcount.cpp:133-198)
+        for (uint32_t k = 0; k < nc; ++k) {
+            const uint32_t cg = cigar_ro[coff + k];
+            if (k == 0) cig0 = cg;
+            const uint32_t op = cg & 0xfu; const int len = (int)(cg >> 4);
+            shape_add(shape, op, len);
+            if (is_refop(op)) rlen += len;
+            if (op == CDEL || op == CREF_SKIP) tot_d += len;
+            if (op == CINS || op == CSOFT_CLIP) tot_is += len;
+            if (op == CSOFT_CLIP) { clipped -= len; if (k == 0) left_clip += len; else right_clip -= len; }
+            if (op == CMATCH) {
+                if (n_m == 0) { m1lo = rs; m1hi = rs + len; d1 = x - rs - c.ref_lo; }
+                else if (n_m == 1) { m2lo = rs; m2hi = rs + len; d2 = x - rs - c.ref_lo; }
+                ++n_m; rs += len; x += len;
+            } else if (op == CDEL || op == CREF_SKIP) x += len;
+            else if (op == CINS || op == CSOFT_CLIP) rs += len;
+        }
+    }
+    const bool simple = nc == 1 && (cig0 & 0xfu) == CMATCH;
+    bool dropped = (flag & BRC_PUSH_MASK) != 0;
+    if (nc == 0) dropped = true;
+    if (nc == 1 && !is_mop(cig0 & 0xfu)) dropped = true;
+    // query ranges are clamped to the read (malformed CIGARs), reference offsets must fit the 32-bit slice index
+    if (m1hi > L) m1hi = L; if (m2hi > L) m2hi = L; if (m1lo > m1hi) m1lo = m1hi; if (m2lo > m2hi) m2lo = m2hi;
+    const bool fallback = !c.has_ref || pos < 0 || (int64_t)pos + rlen > c.ref_len || n_m > 2 ||
+                          d1 < -(int64_t)L || d2 < -(int64_t)L || d1 > 0x7fff0000ll || d2 > 0x7fff0000ll;
+    const bool work_me = have && !dropped && !fallback && L > 0;
+    const unsigned long long work = __ballot(work_me);
+    const int nd = __builtin_popcountll(work);                               // dense reads of this wave
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(work >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)work, 0u));
+    const uint64_t qbase = __builtin_amdgcn_readfirstlane((uint32_t)qoff) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(qoff >> 32)) << 32);
+    const uint64_t sbase = __builtin_amdgcn_readfirstlane((uint32_t)soff) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(soff >> 32)) << 32);
+    const uint64_t bbase = __builtin_amdgcn_readfirstlane((uint32_t)brow) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(brow >> 32)) << 32);
+    uint32_t T = 0;
+    if (nd) {
+        if (work_me) {
+            AnnPar p;
+            p.a = make_uint4((uint32_t)L, (uint32_t)(qoff - qbase), (uint32_t)(soff - sbase), (uint32_t)(brow - bbase));
+            p.b = make_uint4(0u, (uint32_t)m1lo, (uint32_t)m1hi, (uint32_t)(int32_t)d1);
+            p.c = make_uint4((uint32_t)m2lo, (uint32_t)m2hi, (uint32_t)(int32_t)d2, 0u);
+            W.par[rank] = p;
+            W.G[rank] = ((uint32_t)L + 7u) >> 3;
+        }
+        W.lo[lane] = INT32_MAX; W.hi[lane] = -1; W.sum[lane] = 0u; W.redo[lane] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");               // lanes read each other's LDS records below
+        // exclusive prefix sum of the group counts over the dense reads
+        const uint32_t g_me = lane < nd ? W.G[lane] : 0u;
+        uint32_t incl = g_me;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+        T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t S_me = incl - g_me;                                   // first group of dense read `lane`
+        if (lane < nd) W.par[lane].b.x = S_me;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+
+        // ---- phase B
+        int jbefore = -1;                          // last dense read that starts before the pass
+        bool carry_open = false; uint32_t carry_t = 0; int carry_jr = -1;    // mismatch run open at the end of the previous pass
+        bool carry_nz = false;                                              // previous pass's last lane saw a quality != 2 (same read)
+        const int64_t ref_n = c.ref_hi - c.ref_lo;
+        for (uint32_t base = 0; base < T; base += 64u) {
+            // lane -> dense read: reads starting inside the pass mark their first lane
+            // (volatile: the lanes talk to each other through this row; without it the compiler forwards a lane's own store)
+            volatile uint8_t* mark = W.mark;
+            mark[lane] = 0;
+            { const uint32_t d = S_me - base; if (lane < nd && g_me && d < 64u) mark[d] = 1; }
+            const unsigned long long M = __ballot(mark[lane] != 0);
+            const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0u));
+            const int jr = jbefore + below + (int)((M >> lane) & 1ull);
+            jbefore += __builtin_popcountll(M);
+            const uint32_t G = base + (uint32_t)lane;
+            const bool act = G < T;
+            const AnnPar P = W.par[jr];
+            const uint32_t gi = G - P.b.x;
+            const int32_t b = act ? (int32_t)(gi << 3) : 0;          // idle lanes of the last pass stay inside their read
+            const int32_t Lr = (int32_t)P.a.x;
+            const int nv = act ? (Lr - b < 8 ? Lr - b : 8) : 0;              // valid bases of the group (1..8)
+            // ---- loads (unaligned 8 / 4 / 8 bytes)
+            uint2 Q; uint32_t S; uint2 R1;
+            __builtin_memcpy(&Q, qual_ro + qbase + P.a.y + (uint32_t)b, 8);
+            __builtin_memcpy(&S, seq_ro + sbase + P.a.z + ((uint32_t)b >> 1), 4);
+            // flags of the bases inside the first / second M operator, as bit 7 of each byte
+            const unsigned long long vflags = (nv >= 8 ? ~0ull : ((1ull << (8 * nv)) - 1ull)) & 0x8080808080808080ull;
+            unsigned long long f1 = vflags, f2 = 0ull;
+            int64_t r1off = (int64_t)b + (int32_t)P.b.w;
+            const bool plain = (int32_t)P.b.y == 0 && (int32_t)P.b.z == Lr;       // one M operator over the whole read
+            if (__ballot(act && !plain)) {
+                const int lo1 = (int32_t)P.b.y - b, hi1 = (int32_t)P.b.z - b;     // first M operator, group-relative
+                const int a1 = lo1 < 0 ? 0 : (lo1 > 8 ? 8 : lo1), e1 = hi1 < 0 ? 0 : (hi1 > 8 ? 8 : hi1);
+                const unsigned long long below_e1 = e1 >= 8 ? ~0ull : ((1ull << (8 * e1)) - 1ull), below_a1 = a1 >= 8 ? ~0ull : ((1ull << (8 * a1)) - 1ull);
+                f1 = vflags & below_e1 & ~below_a1;
+                const int lo2 = (int32_t)P.c.x - b, hi2 = (int32_t)P.c.y - b;
+                const int a2 = lo2 < 0 ? 0 : (lo2 > 8 ? 8 : lo2), e2 = hi2 < 0 ? 0 : (hi2 > 8 ? 8 : hi2);
+                const unsigned long long below_e2 = e2 >= 8 ? ~0ull : ((1ull << (8 * e2)) - 1ull), below_a2 = a2 >= 8 ? ~0ull : ((1ull << (8 * a2)) - 1ull);
+                f2 = vflags & below_e2 & ~below_a2;
+            }
+            if (!f1 || r1off < -8 || r1off > ref_n) r1off = 0;                // nothing to compare: any in-bounds window
+            __builtin_memcpy(&R1, refcode + r1off, 8);
+            // ---- base codes of the 8 bases in read order: N.x = bases 0..3, N.y = bases 4..7 (one per byte)
+            const uint32_t Ev = (S >> 4) & 0x0f0f0f0fu, Od = S & 0x0f0f0f0fu;
+            uint2 N;
+            N.x = __builtin_amdgcn_perm(Od, Ev, 0x05010400u);
+            N.y = __builtin_amdgcn_perm(Od, Ev, 0x07030602u);
+            // ---- mismatch flags (:152): base != reference code, reference code != 15, base != 0 — on M-operator bases
+            uint2 mm; uint32_t nul;
+            {
+                const uint32_t rx = R1.x & 0x0f0f0f0fu, ry = R1.y & 0x0f0f0f0fu;
+                mm.x = nzb7(N.x ^ rx) & nzb7(rx ^ 0x0f0f0f0fu) & nzb7(N.x) & (uint32_t)f1;
+                mm.y = nzb7(N.y ^ ry) & nzb7(ry ^ 0x0f0f0f0fu) & nzb7(N.y) & (uint32_t)(f1 >> 32);
+                nul = (R1.x & (uint32_t)f1) | (R1.y & (uint32_t)(f1 >> 32));
+            }
+            if (__ballot(f2 != 0ull)) {                                       // bases of a second M operator (after an indel)
+                int64_t r2off = (int64_t)b + (int32_t)P.c.z;
+                if (!f2 || r2off < -8 || r2off > ref_n) r2off = 0;
+                uint2 R2; __builtin_memcpy(&R2, refcode + r2off, 8);
+                const uint32_t rx = R2.x & 0x0f0f0f0fu, ry = R2.y & 0x0f0f0f0fu;
+                mm.x |= nzb7(N.x ^ rx) & nzb7(rx ^ 0x0f0f0f0fu) & nzb7(N.x) & (uint32_t)f2;
+                mm.y |= nzb7(N.y ^ ry) & nzb7(ry ^ 0x0f0f0f0fu) & nzb7(N.y) & (uint32_t)(f2 >> 32);
+                nul |= (R2.x & (uint32_t)f2) | (R2.y & (uint32_t)(f2 >> 32));
+            }
+#ifdef BRC_DEBUG_ANN
+            if (rb == 0 && base == 0 && (lane == 0 || lane == 1 || lane == 31 || lane == 32))
+                printf("DBG lane %d jr %d gi %u b %d nv %d L %d qrel %u srel %u brow %u S %u Q %08x %08x Sq %08x N %08x %08x R %08x %08x mm %08x %08x d1 %d M %llx nd %d T %u\n", lane, jr, gi, b, nv, Lr, P.a.y, P.a.z, P.a.w, P.b.x, Q.x, Q.y, S, N.x, N.y, R1.x, R1.y, mm.x, mm.y, (int)P.b.w, M, nd, T);
+#endif
+            // ---- "=ACGTN" buckets (canon_bucket) per byte: codes 0..7 and 8..15 through two byte tables
+            uint2 Bk;
+            {
+                const uint32_t sx = N.x & 0x07070707u, sy = N.y & 0x07070707u;
+                const uint32_t lx = __builtin_amdgcn_perm(0x05050503u, 0x05020100u, sx), ly = __builtin_amdgcn_perm(0x05050503u, 0x05020100u, sy);
+                const uint32_t hx = __builtin_amdgcn_perm(0x05050505u, 0x05050504u, sx), hy = __builtin_amdgcn_perm(0x05050505u, 0x05050504u, sy);
+                const uint32_t gx = (N.x + 0x78787878u) & 0x80808080u, gy = (N.y + 0x78787878u) & 0x80808080u;   // code >= 8
+                const uint32_t mx = (gx - (gx >> 7)) | gx, my2 = (gy - (gy >> 7)) | gy;                             // 0xff per such byte
+                Bk.x = (hx & mx) | (lx & ~mx); Bk.y = (hy & my2) | (ly & ~my2);
+            }
+            // ---- the packed stream for KB: quality | bucket << 8 per base; the row is padded to 8 elements
+            if (act) {
+                uint4 out;
+                out.x = __builtin_amdgcn_perm(Bk.x, Q.x, 0x05010400u); out.y = __builtin_amdgcn_perm(Bk.x, Q.x, 0x07030602u);
+                out.z = __builtin_amdgcn_perm(Bk.y, Q.y, 0x05010400u); out.w = __builtin_amdgcn_perm(Bk.y, Q.y, 0x07030602u);
+                __builtin_memcpy(bq + bbase + P.a.w + (uint32_t)b, &out, 16);
+            }
+            // ---- first / last base with quality != 2 (:201-238)
+            uint2 nz;
+            { const uint32_t x = Q.x ^ 0x02020202u, y = Q.y ^ 0x02020202u;
+              nz.x = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & (uint32_t)vflags; nz.y = (((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y) & (uint32_t)(vflags >> 32); }
+            const bool has_nz = (nz.x | nz.y) != 0u;
+            {
+                // only the ends of lane runs with such a base touch the per-read slots (no same-address pile-ups)
+                const int pj = __shfl_up(jr, 1, 64), nj = __shfl_down(jr, 1, 64);
+                const int pn = __shfl_up(has_nz ? 1 : 0, 1, 64), nn = __shfl_down(has_nz ? 1 : 0, 1, 64);
+                const bool prev_same_nz = lane ? (pj == jr && pn != 0) : (carry_nz && carry_jr == jr);
+                const bool next_same_nz = lane < 63 && nj == jr && nn != 0;
+                if (has_nz && !prev_same_nz) atomicMin(&W.lo[jr], b + (nz.x ? (__builtin_ctz(nz.x) >> 3) : 4 + (__builtin_ctz(nz.y) >> 3)));
+                if (has_nz && !next_same_nz) atomicMax(&W.hi[jr], b + (nz.y ? 4 + ((31 - __builtin_clz(nz.y)) >> 3) : ((31 - __builtin_clz(nz.x)) >> 3)));
+            }
+            if (nul & 0x80808080u) atomicOr(&W.redo[jr], 1u);                           // a NUL reference character under an M base
+            // ---- mismatch qualities
+            const bool has_mm = (mm.x | mm.y) != 0u;
+            const int nbits = __builtin_popcount(mm.x) + __builtin_popcount(mm.y);
+            const bool bit0 = (mm.x & 0x80u) != 0u, bit7 = (mm.y & 0x80000000u) != 0u;
+            const int pjr = __shfl_up(jr, 1, 64); const int pb7 = __shfl_up(bit7 ? 1 : 0, 1, 64);
+            const bool link = bit0 && (lane ? (pjr == jr && pb7 != 0) : (carry_open && carry_jr == jr));
+            // a run left open by the previous pass that does not continue into lane 0 ended there
+            if (carry_open && lane == 0 && !link) atomicAdd(&W.sum[carry_jr], carry_t);
+            const unsigned long long any_mm = __ballot(has_mm);
+            uint32_t t_out = 0u;                                              // maximum of the run still open at the lane's last base
+            if (any_mm) {
+                const unsigned long long hard = __ballot(has_mm && (nbits > 1 || link || bit7));
+                if (!hard) {
+                    // every mismatch stands alone inside its group: its quality is the run maximum
+                    if (has_mm) {
+                        const int k = mm.x ? (__builtin_ctz(mm.x) >> 3) : 4 + (__builtin_ctz(mm.y) >> 3);
+                        const uint32_t qv = ((k < 4 ? Q.x : Q.y) >> ((k & 3) << 3)) & 0xffu;
+                        atomicAdd(&W.sum[jr], qv);
+                    }
+                } else {
+                    // lane-serial walk over the 8 bases (:152-172); runs entering from / leaving to a neighbour lane are linked
+                    const unsigned long long m64 = (unsigned long long)mm.x | ((unsigned long long)mm.y << 32);
+                    const unsigned long long q64 = (unsigned long long)Q.x | ((unsigned long long)Q.y << 32);
+                    const bool full = nbits == 8;
+                    // own tail-run maximum, ignoring what enters from the left (exact unless the whole lane is one run)
+                    uint32_t t_own = 0u; { bool open = false; uint32_t cur = 0u;
+                        _Pragma("unroll") for (int k = 0; k < 8; ++k) { const bool m = (m64 >> (8 * k + 7)) & 1ull; const uint32_t qv = (uint32_t)(q64 >> (8 * k)) & 0xffu;
+                            if (m) { cur = open ? (cur > qv ? cur : qv) : qv; open = true; } else open = false; }
+                        t_own = open ? cur : 0u; }
+                    // propagate through lanes that are one run from end to end
+                    uint32_t t = t_own;
+                    for (;;) {
+                        uint32_t pt = (uint32_t)__shfl_up((int)t, 1, 64);
+                        if (lane == 0) pt = carry_t;
+                        const uint32_t nt = (full && link) ? (t_own > pt ? t_own : pt) : t_own;
+                        const bool ch = nt != t; t = nt;
+                        if (!__ballot(ch)) break;
+                    }
+                    uint32_t pt = (uint32_t)__shfl_up((int)t, 1, 64);
+                    if (lane == 0) pt = carry_t;
+                    const int nlink = __shfl_down(link ? 1 : 0, 1, 64);       // does the next lane continue my tail run?
+                    uint32_t add = 0u; { bool open = link; uint32_t cur = link ? pt : 0u;
+                        _Pragma("unroll") for (int k = 0; k < 8; ++k) { const bool m = (m64 >> (8 * k + 7)) & 1ull; const uint32_t qv = (uint32_t)(q64 >> (8 * k)) & 0xffu;
+                            if (m) { cur = open ? (cur > qv ? cur : qv) : qv; open = true; } else { if (open) add += cur; open = false; } }
+                        if (open) { if (lane < 63 && !nlink) add += cur; else t_out = cur; } }   // lane 63: decided by the next pass
+                    if (has_mm || link) { if (add) atomicAdd(&W.sum[jr], add); }
+                    if (lane < 63) t_out = 0u;
+                }
+            }
+            // carries into the next pass (from lane 63)
+            carry_open = __builtin_amdgcn_readlane((bit7 && act) ? 1 : 0, 63) != 0;
+            carry_t = (uint32_t)__builtin_amdgcn_readlane((int)t_out, 63);
+            carry_nz = __builtin_amdgcn_readlane(has_nz ? 1 : 0, 63) != 0;
+            carry_jr = __builtin_amdgcn_readlane(jr, 63);
+        }
+        if (carry_open && lane == 0) atomicAdd(&W.sum[carry_jr], carry_t);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    // ---- phase C
+    if (!have) return;
+    DRead r;
+    bool serial = fallback;
+    uint32_t my_sum = 0; int my_hi = -1, my_lo = -1;
+    if (work_me) { my_sum = W.sum[rank]; my_hi = W.hi[rank]; my_lo = W.lo[rank]; if (my_lo == INT32_MAX) my_lo = -1; if (W.redo[rank]) serial = true; }
+    if (serial) {
+        r = annotate_read(c, in, my, bq, rcp);
+    } else {
+        const bool rev = (flag & FREVERSE) != 0;
+        int tp, q2;
+        if (rev) { tp = 0; if (tp < left_clip) tp = left_clip; q2 = my_lo >= 0 ? my_lo - 1 : -1; if (tp < q2) tp = q2; }
+        else { tp = L - 1; if (tp > right_clip) tp = right_clip; q2 = my_hi >= 0 ? my_hi - 1 : -1; if (tp > q2 && q2 != -1) tp = q2; }
+        const uint32_t mapq = in.mapq[my]; const uint32_t tags = in.tags[my];
+        r.pos = pos; r.end = dropped ? pos : pos + rlen;
+        r.cig_off = coff; r.n_cigar = nc; r.bq_off = brow;
+        const int lib = c.per_lib ? (int)in.lib[my] : 0;
+        uint32_t misc = (mapq << 8) | ((uint32_t)((lib + 1) & 0xff) << 16);
+        if (rev) misc |= M_REV;
+        if (q2 > -1) misc |= M_Q2OK;
+        if (simple) misc |= M_SIMPLE;
+        if (tot_d + tot_is <= STAGE_SLACK) misc |= M_STAGED | ((uint32_t)tot_d << 24);
+        uint32_t sse;
+        if (flag & FPROPER_PAIR) { if (tags & 2u) sse = (uint32_t)in.sm[my]; else { sse = 0; misc |= M_SMW; } } else sse = mapq;
+        float snm = 0.0f;
+        if (tags & 1u) snm = (float)in.nm[my] / (float)clipped; else misc |= M_NMW;
+        r.misc = finish_misc(misc, c.table_len > 0 && L == c.table_len && clipped == L, shape_clipm(shape, nc, left_clip)); r.l_qseq = L; r.q2 = q2; r.tp = tp; r.left = left_clip; r.clipped = clipped;
+        r.zm_sum = my_sum; r.sse_add = sse; r.snm_add = snm; r.clipped_dup = clipped;
+        RcpPair rc; rc.Lf = (float)L; rc.center = (float)clipped * 0.5f; rc.rcpL = 1.0f / rc.Lf; rc.rcpC = 1.0f / rc.center;
+        rcp[my] = rc;
+    }
+    reads[my] = r; ends[my] = r.end;
+    if (indel_cnt && !simple) {
+        const int lib = (int)((r.misc >> 16) & 0xffu) - 1;
+        enumerate_indels(c, in, r, qual_ro + qoff, [&](int32_t p, int, int) { atomicAdd(&indel_cnt[(int64_t)(p - c.pos0) * c.Lp + lib], 1u); });
+    }
+}
+
 // ---------------------------------------------------------------- scans (3-phase: block aggregates, scan of aggregates, apply)
 
 enum { SCAN_T = 256, SCAN_ITEMS = 16, SCAN_CHUNK = SCAN_T * SCAN_ITEMS };
@@ -905,7 +1216,7 @@ class HipBackend : public Backend {
     DevCfg c; DevIn in;
     int64_t ntiles = 0; uint64_t n_indel_cap = 0;
     // device buffers
-    DBuf d_pos, d_flag, d_mapq, d_lib, d_lq, d_nc, d_co, d_so, d_qo, d_nm, d_sm, d_tags, d_cigar, d_seq, d_qual, d_ref;
+    DBuf d_pos, d_flag, d_mapq, d_lib, d_lq, d_nc, d_co, d_so, d_qo, d_nm, d_sm, d_tags, d_cigar, d_seq, d_qual, d_ref, d_refcode;
     DBuf d_bq, d_bqrow, d_rcp, d_reads, d_ends, d_prefmax, d_agg, d_rng, d_ncol, d_depth, d_istat, d_fstat, d_unavail, d_cnt, d_cursor, d_ev, d_iout, d_ctr, d_tilectr;
     // host result buffers (pinned)
     HBuf<uint32_t> h_ncol, h_depth, h_istat, h_unavail; HBuf<float> h_fstat; HBuf<IndelOut> h_iout;
@@ -936,7 +1247,7 @@ class HipBackend : public Backend {
     ~HipBackend() override {
         (void)hipSetDevice(device);
         DBuf* all[] = {&d_pos, &d_flag, &d_mapq, &d_lib, &d_lq, &d_nc, &d_co, &d_so, &d_qo, &d_nm, &d_sm, &d_tags, &d_cigar, &d_seq, &d_qual,
-                       &d_ref, &d_bq, &d_bqrow, &d_rcp, &d_reads, &d_ends, &d_prefmax, &d_agg, &d_rng, &d_ncol, &d_depth, &d_istat, &d_fstat, &d_unavail, &d_cnt,
+                       &d_ref, &d_refcode, &d_bq, &d_bqrow, &d_rcp, &d_reads, &d_ends, &d_prefmax, &d_agg, &d_rng, &d_ncol, &d_depth, &d_istat, &d_fstat, &d_unavail, &d_cnt,
                        &d_cursor, &d_ev, &d_iout, &d_ctr, &d_tilectr};
         for (DBuf* b : all) b->release();
         h_ncol.destroy(); h_depth.destroy(); h_istat.destroy(); h_unavail.destroy(); h_fstat.destroy(); h_iout.destroy();
@@ -972,6 +1283,7 @@ class HipBackend : public Backend {
             return rc;
         const size_t rl = (size_t)(g.ref_hi - g.ref_lo);
         HIPCHK(d_ref.ensure(rl + 16));
+        HIPCHK(d_refcode.ensure(rl + 2 * REFCODE_PAD + 16));
         if (rl) HIPCHK(hipMemcpyAsync(d_ref.p, g.ref + g.ref_lo, rl, hipMemcpyHostToDevice, stream));
         in.pos = (const int32_t*)d_pos.p; in.flag = (const uint16_t*)d_flag.p; in.mapq = (const uint8_t*)d_mapq.p; in.lib = (const int16_t*)d_lib.p;
         in.l_qseq = (const int32_t*)d_lq.p; in.n_cigar = (const uint32_t*)d_nc.p; in.cig_off = (const uint64_t*)d_co.p;
@@ -1026,9 +1338,16 @@ class HipBackend : public Backend {
         const DRead* reads = (const DRead*)d_reads.p;
         HIPCHK(hipEventRecord(evt[T_ANNOTATE], stream));
         if (n > 0) {
-            static const char* mode = getenv("BRC_ANNOTATE");   // A/B knob: "serial" | "wave" | default batch form
-            const bool serial = mode && !strcmp(mode, "serial"), wavef = mode && !strcmp(mode, "wave");
-            if (!serial && !wavef)
+            static const char* mode = getenv("BRC_ANNOTATE");   // A/B knob: "serial" | "wave" | "batch" | default group form
+            const bool serial = mode && !strcmp(mode, "serial"), wavef = mode && !strcmp(mode, "wave"), batchf = mode && !strcmp(mode, "batch");
+            if (!serial && !wavef && !batchf) {
+                const int64_t rl = c.ref_hi - c.ref_lo;
+                if (c.has_ref)
+                    hipLaunchKernelGGL(k_refcode, dim3((unsigned)((rl + 2 * REFCODE_PAD + 255) / 256)), dim3(256), 0, stream, in.ref, (uint8_t*)d_refcode.p, rl);
+                hipLaunchKernelGGL(k_annotate_groups, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (int32_t*)d_ends.p,
+                                   (uint16_t*)d_bq.p, (RcpPair*)d_rcp.p, indels ? (uint32_t*)d_cnt.p : (uint32_t*)nullptr,
+                                   in.cigar, in.qual, in.seq4, (const uint8_t*)d_refcode.p + REFCODE_PAD);
+            } else if (batchf)
                 hipLaunchKernelGGL(k_annotate_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (int32_t*)d_ends.p,
                                    (uint16_t*)d_bq.p, (RcpPair*)d_rcp.p, indels ? (uint32_t*)d_cnt.p : (uint32_t*)nullptr,
                                    in.cigar, in.qual, in.seq4, in.ref);
