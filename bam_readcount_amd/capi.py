@@ -106,7 +106,16 @@ class Library:
 
 
 def load_product():
-    """The HIP engine.  Raises (never substitutes) when the library has not been built."""
+    """The HIP engine.  Raises (never substitutes) when the library has not been built.
+    BRC_HIP_LIB=<path of another build of libbrc_hip.so> is an A/B profiling knob (tools/gpu_ab.sh)."""
+    alt = os.environ.get("BRC_HIP_LIB")
+    if alt:
+        if not os.path.basename(alt).startswith("libbrc_hip"):
+            raise BrcError("BRC_HIP_LIB must name another build of libbrc_hip*.so, got %s" % alt)
+        lib = Library(alt)
+        if lib.kind() != Library(PRODUCT_LIB).kind():
+            raise BrcError("BRC_HIP_LIB is not a HIP engine build: %s" % lib.kind())
+        return lib
     return Library(PRODUCT_LIB)
 
 

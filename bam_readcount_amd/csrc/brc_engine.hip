@@ -807,7 +807,8 @@ enum { WIN_U4 = 12 };        // bq window per staged read: 12 x 16 B = 96 elemen
 enum { ROW_U4 = 15 };        // LDS row = window + the read's accumulate half (2 x 16 B) + its float constants (16 B)
 enum { BATCH = 16 };         // reads staged per batch (LDS rows per wave): 16 x 240 B = 3.75 KB per wave
 
-// V: 0 = production; 1/2/3 = profiling ablations (no plane stores / probe+loads only / stores only), BRC_PILEUP_VARIANT
+// V: 0 = production; 1/2/3/4 = profiling ablations (no plane stores / probe+loads only / stores only / tile prologue +
+// first-batch staging + stores, no read loop), BRC_PILEUP_VARIANT
 template <int V>
 __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in, const DRead* __restrict__ reads,
                                                               const uint2* __restrict__ rng, int64_t ntiles, Planes pl,
@@ -1043,7 +1044,8 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
         BRC_LD_WIN(T, lo, W0, W1, W2, W3, wok)
         BRC_ST_WIN(W0, W1, W2, W3, wok)                                           // first batch: staged synchronously
         DRead RQ; RQ.pos = RQ.end = 0; RQ.cig_off = RQ.n_cigar = 0; RQ.bq_off = 0; RQ.l_qseq = 0; RQ.q2 = RQ.tp = RQ.left = 0;
-        for (uint32_t base = lo; base < hi; base += (uint32_t)BATCH) {
+        if (V == 4) a.depth += rows[row][slot].x;                                  // ablation: tile prologue + epilogue only
+        for (uint32_t base = lo; base < hi && V != 4; base += (uint32_t)BATCH) {
             const uint32_t nb = (hi - base) < (uint32_t)BATCH ? (hi - base) : (uint32_t)BATCH;
             const bool more = base + (uint32_t)BATCH < hi;                    // then nb == BATCH
             if (more) BRC_LD_TAB(Tn, base + (uint32_t)BATCH)                  // lane table of the next batch
@@ -1371,7 +1373,7 @@ class HipBackend : public Backend {
             // profiling knob: unused dynamic LDS lowers the number of resident waves (occupancy sweeps)
             static const unsigned dyn_lds = getenv("BRC_PILEUP_LDS_PAD") ? (unsigned)atoi(getenv("BRC_PILEUP_LDS_PAD")) : 0u;
 #define BRC_LAUNCH_PILEUP(V) hipLaunchKernelGGL((k_pileup<V>), dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), dyn_lds, stream, c, in, reads, (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.cigar, in.rcp, in.bq)
-            switch (c.variant) { case 1: BRC_LAUNCH_PILEUP(1); break; case 2: BRC_LAUNCH_PILEUP(2); break; case 3: BRC_LAUNCH_PILEUP(3); break; default: BRC_LAUNCH_PILEUP(0); }
+            switch (c.variant) { case 1: BRC_LAUNCH_PILEUP(1); break; case 2: BRC_LAUNCH_PILEUP(2); break; case 3: BRC_LAUNCH_PILEUP(3); break; case 4: BRC_LAUNCH_PILEUP(4); break; default: BRC_LAUNCH_PILEUP(0); }
         }
         HIPCHK(hipEventRecord(evt[T_COUNT], stream));
         if (P > 0) {
