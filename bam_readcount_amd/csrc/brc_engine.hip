@@ -5,7 +5,7 @@
 //                   also counts each read's indel events per (position, library) key
 //   k_scan_*        3-phase scans: inclusive running max of read ends (tile lower bounds), exclusive sum of
 //                   indel-event counts (per-key offsets)
-//   k_tiles         one lane per 64-position tile: [lo,hi) read range by binary search
+//   k_tiles         [lo,hi) read range of every 64-position tile, one coalesced pass over the reads
 //   k_pileup        THE hot kernel: one wave per (tile, library), lane == reference position, wave-uniform walk
 //                   over the tile's reads in file order (read records in SGPRs, coalesced byte loads of QUAL/SEQ
 //                   along the lanes), 6 buckets x 12 accumulators in VGPRs, order-preserving fp32 sums, coalesced
@@ -755,10 +755,22 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_apply(const typename Op::T* __r
     typedef typename Op::T T;
     __shared__ T sh[SCAN_T];
     const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    static_assert(sizeof(T) == 4 && SCAN_ITEMS % 4 == 0, "16-byte accesses");
     T v[SCAN_ITEMS];
     T tot = Op::id();
+    const bool whole = base + SCAN_ITEMS <= n;       // the thread's 16 elements (64 contiguous, 64-byte aligned bytes) are all inside
+    if (whole) {
 #pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; ++j) { v[j] = (base + j < n) ? in[base + j] : Op::id(); tot = Op::op(tot, v[j]); }
+        for (int q = 0; q < SCAN_ITEMS / 4; ++q) {
+            const uint4 x = reinterpret_cast<const uint4*>(in + base)[q];
+            v[4 * q] = (T)x.x; v[4 * q + 1] = (T)x.y; v[4 * q + 2] = (T)x.z; v[4 * q + 3] = (T)x.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; ++j) v[j] = (base + j < n) ? in[base + j] : Op::id();
+    }
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) tot = Op::op(tot, v[j]);
     sh[threadIdx.x] = tot;
     __syncthreads();
     for (int o = 1; o < SCAN_T; o <<= 1) {
@@ -769,24 +781,53 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_apply(const typename Op::T* __r
         __syncthreads();
     }
     T run = Op::op(agg[blockIdx.x], threadIdx.x ? sh[threadIdx.x - 1] : Op::id());
+    T w[SCAN_ITEMS];
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; ++j) {
-        if (base + j < n) {
-            if (INCLUSIVE) { run = Op::op(run, v[j]); out[base + j] = run; }
-            else { out[base + j] = run; run = Op::op(run, v[j]); }
-        }
+        if (INCLUSIVE) { run = Op::op(run, v[j]); w[j] = run; }
+        else { w[j] = run; run = Op::op(run, v[j]); }
+    }
+    if (whole) {
+#pragma unroll
+        for (int q = 0; q < SCAN_ITEMS / 4; ++q)
+            reinterpret_cast<uint4*>(out + base)[q] = make_uint4((uint32_t)w[4 * q], (uint32_t)w[4 * q + 1], (uint32_t)w[4 * q + 2], (uint32_t)w[4 * q + 3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; ++j) if (base + j < n) out[base + j] = w[j];
     }
 }
 
 // ---------------------------------------------------------------- tiles
 
-__global__ __launch_bounds__(256) void k_tiles(DevCfg c, const int32_t* __restrict__ prefmax, const DRead* __restrict__ reads,
+// Read range [lo, hi) of every 64-position tile (tile_range in brc_core.h states it as two binary searches):
+//   lo(t) = first read m with prefmax_end[m] > p0(t)      (prefmax_end = running maximum of the reads' ends, non-decreasing)
+//   hi(t) = first read m with pos[m] > p1(t) = p0(t) + 63 (reads are sorted by pos)
+// Inverted here so that the work is one coalesced pass over the reads instead of two dependent-load searches per tile:
+// read r owns the tiles whose lo is r (prefmax_end[r-1] <= p0 < prefmax_end[r]) and the tiles whose hi is r + 1
+// (pos[r] <= p1 < pos[r+1]) — usually none or one of each; the last read also covers the tiles past the data.
+__device__ __forceinline__ int64_t tiles_ceil_div64(int64_t x) { return x <= 0 ? 0 : (x + (TILE - 1)) / TILE; }
+
+__global__ __launch_bounds__(256) void k_tiles(DevCfg c, const int32_t* __restrict__ prefmax, const int32_t* __restrict__ pos,
                                                int64_t ntiles, uint2* __restrict__ rng) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ntiles) return;
-    uint32_t lo, hi;
-    tile_range(c, prefmax, reads, t, lo, hi);
-    rng[t] = make_uint2(lo, hi);
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= c.n_reads) return;
+    uint32_t* out = reinterpret_cast<uint32_t*>(rng);
+    // lo: tiles t with prefmax[r-1] <= p0(t) < prefmax[r]
+    {
+        int64_t t0 = r ? tiles_ceil_div64((int64_t)prefmax[r - 1] - c.pos0) : 0;
+        int64_t t1 = tiles_ceil_div64((int64_t)prefmax[r] - c.pos0);
+        if (t1 > ntiles) t1 = ntiles;
+        for (int64_t t = t0; t < t1; ++t) out[2 * t] = (uint32_t)r;
+        if (r == c.n_reads - 1) for (int64_t t = t1 > t0 ? t1 : t0; t < ntiles; ++t) out[2 * t] = (uint32_t)c.n_reads;
+    }
+    // hi: tiles t with pos[r] <= p1(t) < pos[r+1]      (p1(t) >= x  <=>  t >= ceil((x - pos0 - 63) / 64))
+    {
+        int64_t t0 = tiles_ceil_div64((int64_t)pos[r] - c.pos0 - (TILE - 1));
+        int64_t t1 = r + 1 < c.n_reads ? tiles_ceil_div64((int64_t)pos[r + 1] - c.pos0 - (TILE - 1)) : ntiles;
+        if (t1 > ntiles) t1 = ntiles;
+        if (r == 0) for (int64_t t = 0; t < t0 && t < ntiles; ++t) out[2 * t + 1] = 0u;
+        for (int64_t t = t0; t < t1; ++t) out[2 * t + 1] = (uint32_t)(r + 1);
+    }
 }
 
 // ---------------------------------------------------------------- KB: pileup + BasicStat accumulation (the hot kernel)
@@ -1109,28 +1150,34 @@ __device__ __forceinline__ void block_sum_u64(unsigned long long (&v)[NV], unsig
 
 // emitted-position count + sum of the per-tile partials; grid-stride, one set of atomics per work-group
 __global__ __launch_bounds__(256) void k_finalize(DevCfg c, const uint32_t* __restrict__ ncol, const uint4* __restrict__ tile_ctr,
-                                                  int64_t n_tile_ctr, Counters* __restrict__ ctr) {
+                                                  int64_t n_tile_ctr, unsigned long long* __restrict__ part) {
     __shared__ unsigned long long sh[4 * 5];
     unsigned long long v[5] = {0, 0, 0, 0, 0};   // positions, events, w_sm, w_nm, w_lib
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < c.P; k += stride) {
-        if (c.pos0 + k < c.beg0) continue;
-        uint32_t tot = 0;
-        for (int l = 0; l < c.Lp; ++l) tot += ncol[(int64_t)l * c.PS + k];
-        v[0] += tot ? 1u : 0u;
+    // four positions per thread and load (the plane stride PS is a multiple of 64, the planes are 16-byte aligned)
+    for (int64_t k4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; k4 < c.P; k4 += stride * 4) {
+        uint4 tot = make_uint4(0u, 0u, 0u, 0u);
+        for (int l = 0; l < c.Lp; ++l) { const uint4 x = *reinterpret_cast<const uint4*>(ncol + (int64_t)l * c.PS + k4); tot.x |= x.x; tot.y |= x.y; tot.z |= x.z; tot.w |= x.w; }
+        const int64_t pk = c.pos0 + k4;
+        v[0] += (tot.x && pk >= c.beg0 ? 1u : 0u) + (tot.y && pk + 1 >= c.beg0 && k4 + 1 < c.P ? 1u : 0u) +
+                (tot.z && pk + 2 >= c.beg0 && k4 + 2 < c.P ? 1u : 0u) + (tot.w && pk + 3 >= c.beg0 && k4 + 3 < c.P ? 1u : 0u);
     }
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_tile_ctr; t += stride) {
         const uint4 x = tile_ctr[t];
         v[1] += x.x; v[2] += x.y; v[3] += x.z; v[4] += x.w;
     }
     block_sum_u64<5>(v, sh);
-    if (threadIdx.x == 0) {
-        if (v[0]) atomicAdd(&ctr->n_positions, v[0]);
-        if (v[1]) atomicAdd(&ctr->n_events, v[1]);
-        if (v[2]) atomicAdd(&ctr->w_sm, v[2]);
-        if (v[3]) atomicAdd(&ctr->w_nm, v[3]);
-        if (v[4]) atomicAdd(&ctr->w_lib, v[4]);
-    }
+    // per-block partials, summed by k_finalize_sum: thousands of atomics on one cache line cost ~12 ns each
+    if (threadIdx.x == 0) for (int i = 0; i < 5; ++i) part[(int64_t)blockIdx.x * 5 + i] = v[i];
+}
+
+__global__ __launch_bounds__(256) void k_finalize_sum(const unsigned long long* __restrict__ part, int nblocks, Counters* __restrict__ ctr) {
+    __shared__ unsigned long long sh[4 * 5];
+    unsigned long long v[5] = {0, 0, 0, 0, 0};
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
+        for (int i = 0; i < 5; ++i) v[i] += part[(int64_t)b * 5 + i];
+    block_sum_u64<5>(v, sh);
+    if (threadIdx.x == 0) { ctr->n_positions += v[0]; ctr->n_events += v[1]; ctr->w_sm += v[2]; ctr->w_nm += v[3]; ctr->w_lib += v[4]; }
 }
 
 // ---------------------------------------------------------------- indel side path
@@ -1219,7 +1266,7 @@ class HipBackend : public Backend {
     int64_t ntiles = 0; uint64_t n_indel_cap = 0;
     // device buffers
     DBuf d_pos, d_flag, d_mapq, d_lib, d_lq, d_nc, d_co, d_so, d_qo, d_nm, d_sm, d_tags, d_cigar, d_seq, d_qual, d_ref, d_refcode;
-    DBuf d_bq, d_bqrow, d_rcp, d_reads, d_ends, d_prefmax, d_agg, d_rng, d_ncol, d_depth, d_istat, d_fstat, d_unavail, d_cnt, d_cursor, d_ev, d_iout, d_ctr, d_tilectr;
+    DBuf d_bq, d_bqrow, d_rcp, d_reads, d_ends, d_prefmax, d_agg, d_rng, d_ncol, d_depth, d_istat, d_fstat, d_unavail, d_cnt, d_cursor, d_ev, d_iout, d_ctr, d_tilectr, d_part;
     // host result buffers (pinned)
     HBuf<uint32_t> h_ncol, h_depth, h_istat, h_unavail; HBuf<float> h_fstat; HBuf<IndelOut> h_iout;
     std::vector<IndelOut> iout_compact;
@@ -1250,7 +1297,7 @@ class HipBackend : public Backend {
         (void)hipSetDevice(device);
         DBuf* all[] = {&d_pos, &d_flag, &d_mapq, &d_lib, &d_lq, &d_nc, &d_co, &d_so, &d_qo, &d_nm, &d_sm, &d_tags, &d_cigar, &d_seq, &d_qual,
                        &d_ref, &d_refcode, &d_bq, &d_bqrow, &d_rcp, &d_reads, &d_ends, &d_prefmax, &d_agg, &d_rng, &d_ncol, &d_depth, &d_istat, &d_fstat, &d_unavail, &d_cnt,
-                       &d_cursor, &d_ev, &d_iout, &d_ctr, &d_tilectr};
+                       &d_cursor, &d_ev, &d_iout, &d_ctr, &d_tilectr, &d_part};
         for (DBuf* b : all) b->release();
         h_ncol.destroy(); h_depth.destroy(); h_istat.destroy(); h_unavail.destroy(); h_fstat.destroy(); h_iout.destroy();
         if (have_events) for (int i = 0; i <= T_N; ++i) (void)hipEventDestroy(evt[i]);
@@ -1307,6 +1354,7 @@ class HipBackend : public Backend {
         HIPCHK(d_agg.ensure(nagg * 4 + 16)); HIPCHK(d_rng.ensure(((size_t)ntiles + 1) * sizeof(uint2)));
         HIPCHK(d_ncol.ensure(Lp * P * 4 + 16)); HIPCHK(d_depth.ensure(Lp * P * 4 + 16)); HIPCHK(d_unavail.ensure(P * 4 + 16));
         HIPCHK(d_istat.ensure(Lp * NBUCKET * NI * P * 4 + 16)); HIPCHK(d_fstat.ensure(Lp * NBUCKET * NF * P * 4 + 16));
+        HIPCHK(d_part.ensure(4096 * 5 * sizeof(unsigned long long)));
         HIPCHK(d_ctr.ensure(sizeof(Counters))); HIPCHK(d_tilectr.ensure(((size_t)ntiles * Lp + 1) * sizeof(uint4)));
         if (n_indel_cap) {
             HIPCHK(d_cnt.ensure(Lp * P * 4 + 16)); HIPCHK(d_cursor.ensure(Lp * P * 4 + 16));
@@ -1363,8 +1411,9 @@ class HipBackend : public Backend {
         HIPCHK(hipEventRecord(evt[T_SCAN_ENDS], stream));
         if ((rc = scan<OpMaxI32, true>((const int32_t*)d_ends.p, (int32_t*)d_prefmax.p, n))) return rc;
         HIPCHK(hipEventRecord(evt[T_TILES], stream));
-        if (ntiles > 0)
-            hipLaunchKernelGGL(k_tiles, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, c, (const int32_t*)d_prefmax.p, reads, ntiles,
+        if (ntiles > 0 && n == 0) HIPCHK(hipMemsetAsync(d_rng.p, 0, (size_t)ntiles * sizeof(uint2), stream));
+        if (ntiles > 0 && n > 0)
+            hipLaunchKernelGGL(k_tiles, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, (const int32_t*)d_prefmax.p, in.pos, ntiles,
                                (uint2*)d_rng.p);
         HIPCHK(hipEventRecord(evt[T_PILEUP], stream));
         if (ntiles > 0) {
@@ -1377,8 +1426,10 @@ class HipBackend : public Backend {
         }
         HIPCHK(hipEventRecord(evt[T_COUNT], stream));
         if (P > 0) {
-            const unsigned nb = (unsigned)std::min<int64_t>((P + 255) / 256, 2048);
-            hipLaunchKernelGGL(k_finalize, dim3(nb), dim3(256), 0, stream, c, (const uint32_t*)d_ncol.p, (const uint4*)d_tilectr.p, (int64_t)ntiles * Lp, ctr);
+            const unsigned nb = (unsigned)std::min<int64_t>((P / 4 + 255) / 256 + 1, 4096);
+            hipLaunchKernelGGL(k_finalize, dim3(nb), dim3(256), 0, stream, c, (const uint32_t*)d_ncol.p, (const uint4*)d_tilectr.p, (int64_t)ntiles * Lp,
+                               (unsigned long long*)d_part.p);
+            hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(256), 0, stream, (const unsigned long long*)d_part.p, (int)nb, ctr);
         }
         HIPCHK(hipEventRecord(evt[T_INDEL_SCAN], stream));
         if (indels && (rc = scan<OpSumU32, false>((const uint32_t*)d_cnt.p, (uint32_t*)d_cursor.p, (int64_t)Lp * P))) return rc;
