@@ -1186,6 +1186,7 @@ __global__ __launch_bounds__(256) void k_indel_fill(DevCfg c, DevIn in, const DR
                                                     IndelEv* __restrict__ ev) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c.n_reads) return;
+    if (in.n_cigar[i] < 2u) return;                   // an indel needs an M operator next to an I / D: skip without touching the record
     const DRead r = reads[i];
     const int lib = (int)((r.misc >> 16) & 0xffu) - 1;
     enumerate_indels(c, in, r, in.qual + in.qual_off[i], [&](int32_t p, int qpos, int len) {
