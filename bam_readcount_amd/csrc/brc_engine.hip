@@ -376,12 +376,28 @@ __global__ __launch_bounds__(256) void k_annotate_batch(DevCfg c, DevIn in, DRea
 // REFCODE_PAD bytes of padding (code 15) on both sides: an 8-byte window may start before / end after the slice.
 enum { REFCODE_PAD = 16 };
 __global__ __launch_bounds__(256) void k_refcode(const char* __restrict__ ref, uint8_t* __restrict__ code, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // index into the padded buffer
-    if (i >= n + 2 * REFCODE_PAD) return;
-    const int64_t j = i - REFCODE_PAD;
-    uint32_t v = 0x0fu;
-    if (j >= 0 && j < n) { const uint32_t ch = (uint8_t)ref[j]; v = ch ? nt16_of_char(ch) : 0x8fu; }
-    code[i] = (uint8_t)v;
+    // 16 codes per thread; `code` (padded buffer) is 16-byte aligned and REFCODE_PAD == 16, so chunk i of the output
+    // holds the codes of ref[16 i - 16 .. 16 i)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t j0 = i * 16 - REFCODE_PAD;
+    if (j0 >= n + REFCODE_PAD) return;
+    uint32_t w[4];
+    uint8_t src[16];
+    if (j0 >= 0 && j0 + 16 <= n) __builtin_memcpy(src, ref + j0, 16);
+    else for (int k = 0; k < 16; ++k) { const int64_t j = j0 + k; src[k] = (j >= 0 && j < n) ? (uint8_t)ref[j] : (uint8_t)'N'; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t j = j0 + 4 * q + k;
+            const uint32_t ch = src[4 * q + k];
+            const uint32_t cd = (j >= 0 && j < n) ? (ch ? nt16_of_char(ch) : 0x8fu) : 0x0fu;
+            v |= cd << (8 * k);
+        }
+        w[q] = v;
+    }
+    *reinterpret_cast<uint4*>(code + i * 16) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 // K1, group form (the one normally launched): one wave owns 64 consecutive reads; a lane of the per-base pass owns one
@@ -550,10 +566,6 @@ __global__ __launch_bounds__(256) void k_annotate_groups(DevCfg c, DevIn in, DRe
                 mm.y |= nzb7(N.y ^ ry) & nzb7(ry ^ 0x0f0f0f0fu) & nzb7(N.y) & (uint32_t)(f2 >> 32);
                 nul |= (R2.x & (uint32_t)f2) | (R2.y & (uint32_t)(f2 >> 32));
             }
-#ifdef BRC_DEBUG_ANN
-            if (rb == 0 && base == 0 && (lane == 0 || lane == 1 || lane == 31 || lane == 32))
-                printf("DBG lane %d jr %d gi %u b %d nv %d L %d qrel %u srel %u brow %u S %u Q %08x %08x Sq %08x N %08x %08x R %08x %08x mm %08x %08x d1 %d M %llx nd %d T %u\n", lane, jr, gi, b, nv, Lr, P.a.y, P.a.z, P.a.w, P.b.x, Q.x, Q.y, S, N.x, N.y, R1.x, R1.y, mm.x, mm.y, (int)P.b.w, M, nd, T);
-#endif
             // ---- "=ACGTN" buckets (canon_bucket) per byte: codes 0..7 and 8..15 through two byte tables
             uint2 Bk;
             {
@@ -1394,7 +1406,7 @@ class HipBackend : public Backend {
             if (!serial && !wavef && !batchf) {
                 const int64_t rl = c.ref_hi - c.ref_lo;
                 if (c.has_ref)
-                    hipLaunchKernelGGL(k_refcode, dim3((unsigned)((rl + 2 * REFCODE_PAD + 255) / 256)), dim3(256), 0, stream, in.ref, (uint8_t*)d_refcode.p, rl);
+                    hipLaunchKernelGGL(k_refcode, dim3((unsigned)(((rl + 2 * REFCODE_PAD + 15) / 16 + 255) / 256)), dim3(256), 0, stream, in.ref, (uint8_t*)d_refcode.p, rl);
                 hipLaunchKernelGGL(k_annotate_groups, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (int32_t*)d_ends.p,
                                    (uint16_t*)d_bq.p, (RcpPair*)d_rcp.p, indels ? (uint32_t*)d_cnt.p : (uint32_t*)nullptr,
                                    in.cigar, in.qual, in.seq4, (const uint8_t*)d_refcode.p + REFCODE_PAD);
