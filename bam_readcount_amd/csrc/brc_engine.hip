@@ -858,6 +858,9 @@ __device__ __forceinline__ void count_if(uint32_t& x, uint64_t mask) {
 enum { PILEUP_WAVES = 4 };   // 256 threads: 4 consecutive tiles (256 positions) per workgroup
 enum { WIN_U4 = 12 };        // bq window per staged read: 12 x 16 B = 96 elements (>= 64 tile positions + 7 of alignment slack)
 enum { ROW_U4 = 15 };        // LDS row = window + the read's accumulate half (2 x 16 B) + its float constants (16 B)
+#ifndef BRC_TRIGGER
+#define BRC_TRIGGER 4      // step of a batch at which the next batch's windows are requested (even)
+#endif
 enum { BATCH = 16 };         // reads staged per batch (LDS rows per wave): 16 x 240 B = 3.75 KB per wave
 
 // V: 0 = production; 1/2/3/4 = profiling ablations (no plane stores / probe+loads only / stores only / tile prologue +
@@ -1110,7 +1113,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
             for (uint32_t j = 0; j < nb; j += 2u) {
                 // half way through, the next batch's windows are requested (its lane table has arrived by now); they
                 // land in registers while the remaining reads are processed and are written to LDS after the loop
-                if (j == (uint32_t)(BATCH / 2) && more) { bool ok2; BRC_LD_WIN(Tn, base + (uint32_t)BATCH, W0, W1, W2, W3, ok2) (void)ok2; }
+                if (j == (uint32_t)(BRC_TRIGGER) && more) { bool ok2; BRC_LD_WIN(Tn, base + (uint32_t)BATCH, W0, W1, W2, W3, ok2) (void)ok2; }
                 BRC_STEP(j, S0, S1, G0, G1)
                 if (j + 1u >= nb) break;
                 BRC_STEP(j + 1u, S1, S0, G1, G0)
