@@ -63,13 +63,15 @@ def test_hip_fuzz_equals_oracle(hip_lib, oracle_lib, case):
 
 
 @pytest.mark.parametrize("mismatch,read_len,style", [(0.3, (1, 700), "mixed"), (0.95, (200, 600), "simple"), (0.6, (1, 40), "indel"),
-                                                      (1.0, (64, 64), "simple"), (0.5, (500, 900), "wild")])
+                                                      (1.0, (64, 64), "simple"), (0.5, (500, 900), "wild"), (0.05, (3000, 6000), "indel")])
 def test_hip_annotate_mismatch_runs_stress(hip_lib, oracle_lib, mismatch, read_len, style):
     """K1's group form: mismatch runs that cross 8-base groups, 64-group passes and whole groups, Q2 tails, reads shorter
     than a group, reads with more than two M operators (serial path) — Zm sums / Q2 / three-prime must stay exact."""
     rng = np.random.default_rng(int(mismatch * 100) + read_len[1])
     ref = synth.make_ref(rng, 8000, weird=0.01)
-    arrs = synth.make_batch(77 + read_len[0], ref, 400, read_len=read_len, style=style, mismatch=mismatch, p_q2tail=0.5, region=(0, 7000))
+    long_reads = read_len[0] >= 3000          # long reads: few of them, all inside the reference
+    arrs = synth.make_batch(77 + read_len[0], ref, 60 if long_reads else 400, read_len=read_len, style=style, mismatch=mismatch, p_q2tail=0.5,
+                            region=(0, 1900) if long_reads else (0, 7000))
     parity.compare_libs(hip_lib, oracle_lib, arrs, [(0, 8000), (3000, 3100)], ref=ref)
     parity.compare_libs(hip_lib, oracle_lib, arrs, [(0, 8000)], ref=ref, min_mapq=10, min_bq=15, insertion_centric=True)
 
