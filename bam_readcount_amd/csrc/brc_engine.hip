@@ -863,9 +863,10 @@ enum { ROW_U4 = 15 };        // LDS row = window + the read's accumulate half (2
 #endif
 enum { BATCH = 16 };         // reads staged per batch (LDS rows per wave): 16 x 240 B = 3.75 KB per wave
 
+// PL: per-library form (-p): a wave visits only the reads of its own library (and library-less ones), see the read loop.
 // V: 0 = production; 1/2/3/4 = profiling ablations (no plane stores / probe+loads only / stores only / tile prologue +
 // first-batch staging + stores, no read loop), BRC_PILEUP_VARIANT
-template <int V>
+template <int V, bool PL>
 __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in, const DRead* __restrict__ reads,
                                                               const uint2* __restrict__ rng, int64_t ntiles, Planes pl,
                                                               uint4* __restrict__ tile_ctr,
@@ -937,6 +938,8 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
         const uint32_t L0 = (uint32_t)c.table_len;
 #define BRC_RL(x, j) __builtin_amdgcn_readlane((int)(x), (int)(j))
 #define BRC_ALL(cond) ((cond) ? ~0ull : 0ull)
+        // per-library form: does this wave visit the read at all?  (its own library, or none: LIBRARY_UNAVAILABLE, :281-284)
+#define BRC_MINE(misc_) (!PL || (((misc_) >> 16) & 0xffu) == libsel || (((misc_) >> 16) & 0xffu) == 0u)
         // lane table of the batch starting at read b0 (clamped to the tile's reads)
 #define BRC_LD_TAB(TT, b0)                                                                                              \
         {                                                                                                                 \
@@ -951,7 +954,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
         {                                                                                                                 \
             const int32_t d0 = p0 - TT.pos - (int32_t)(TT.misc >> 24);       /* query offset of the tile start, lower bound */ \
             const uint32_t ws = d0 > 0 ? ((uint32_t)d0 & ~7u) : 0u;                                                       \
-            OK = (b0) + row < hi && (TT.misc & M_STAGED) && TT.end > TT.pos && (int32_t)ws < TT.l_qseq + 8;               \
+            OK = (b0) + row < hi && (TT.misc & M_STAGED) && TT.end > TT.pos && (int32_t)ws < TT.l_qseq + 8 && BRC_MINE(TT.misc); \
             if (OK) {                                                                                                     \
                 const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bq_ro + TT.bq_off + ws) + slot;           \
                 W0 = src[0]; W1 = src[4]; W2 = src[8];                                                                    \
@@ -966,7 +969,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
         {                                                                                                                 \
             const int32_t d0 = p0 - TT.pos - (int32_t)(TT.misc >> 24);                                                    \
             const uint32_t ws = d0 > 0 ? ((uint32_t)d0 & ~7u) : 0u;                                                       \
-            OK = (b0) + row < hi && (TT.misc & M_STAGED) && TT.end > TT.pos && (int32_t)ws < TT.l_qseq + 8;               \
+            OK = (b0) + row < hi && (TT.misc & M_STAGED) && TT.end > TT.pos && (int32_t)ws < TT.l_qseq + 8 && BRC_MINE(TT.misc); \
         }
         // ... and their write into the LDS rows
 #define BRC_ST_WIN(W0, W1, W2, W3, OK)                                                                                  \
@@ -1081,17 +1084,17 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
         }
         // one pipeline step: constants and probe of read j+1 into (GN, SN), then accumulate read j from (GC, SC).  Nothing
         // inside a step consumes an LDS result issued in the same step, so the only LDS wait is at the top of a step.
-#define BRC_STEP(j, SC, SN, GC, GN)                                                                                     \
+#define BRC_STEP(jc, jn, HASN, SC, SN, GC, GN)                                                                          \
         {                                                                                                                 \
             /* every LDS read of the previous step has had a whole accumulate stage to land: wait for them HERE, on    \
                every path, so that the compiler does not put a full lgkmcnt(0) wait (covering this step's own reads)   \
                in front of the first use inside the accumulate stage */                                                \
             __builtin_amdgcn_s_waitcnt(0xC07F);                               /* lgkmcnt(0) */                             \
-            if ((j) + 1u < nb) {                                                                                          \
-                GN = rows[(j) + 1u][WIN_U4 + 1];                              /* zm_sum, sse_add, snm_add, clipped */      \
-                BRC_PROBE((j) + 1u, SN)                                                                                   \
+            if (HASN) {                                                                                                   \
+                GN = rows[(jn)][WIN_U4 + 1];                                  /* zm_sum, sse_add, snm_add, clipped */      \
+                BRC_PROBE((jn), SN)                                                                                       \
             }                                                                                                             \
-            { const uint4 g1 = GC; BRC_ACC(j, SC) }                                                                       \
+            { const uint4 g1 = GC; BRC_ACC(jc, SC) }                                                                      \
         }
         Tab T, Tn;
         uint4 W0 = make_uint4(0, 0, 0, 0), W1 = W0, W2 = W0, W3 = W0; bool wok = false;
@@ -1106,17 +1109,39 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
             const bool more = base + (uint32_t)BATCH < hi;                    // then nb == BATCH
             if (more) BRC_LD_TAB(Tn, base + (uint32_t)BATCH)                  // lane table of the next batch
             Stage S0, S1;
-            uint4 G0 = rows[0][WIN_U4 + 1], G1;
-            BRC_PROBE(0u, S0)
-            S1 = S0; G1 = G0;
-            // two reads per trip so the two stage buffers swap roles instead of being copied
-            for (uint32_t j = 0; j < nb; j += 2u) {
-                // half way through, the next batch's windows are requested (its lane table has arrived by now); they
-                // land in registers while the remaining reads are processed and are written to LDS after the loop
-                if (j == (uint32_t)(BRC_TRIGGER) && more) { bool ok2; BRC_LD_WIN(Tn, base + (uint32_t)BATCH, W0, W1, W2, W3, ok2) (void)ok2; }
-                BRC_STEP(j, S0, S1, G0, G1)
-                if (j + 1u >= nb) break;
-                BRC_STEP(j + 1u, S1, S0, G1, G0)
+            if (!PL) {
+                uint4 G0 = rows[0][WIN_U4 + 1], G1;
+                BRC_PROBE(0u, S0)
+                S1 = S0; G1 = G0;
+                // two reads per trip so the two stage buffers swap roles instead of being copied
+                for (uint32_t j = 0; j < nb; j += 2u) {
+                    // a quarter into the batch the next batch's windows are requested (its lane table has arrived by now);
+                    // they land in registers while the remaining reads are processed and are written to LDS after the loop
+                    if (j == (uint32_t)(BRC_TRIGGER) && more) { bool ok2; BRC_LD_WIN(Tn, base + (uint32_t)BATCH, W0, W1, W2, W3, ok2) (void)ok2; }
+                    BRC_STEP(j, j + 1u, j + 1u < nb, S0, S1, G0, G1)
+                    if (j + 1u >= nb) break;
+                    BRC_STEP(j + 1u, j + 2u, j + 2u < nb, S1, S0, G1, G0)
+                }
+            } else {
+                // per-library form: only the reads of this wave's library (and library-less reads) are visited — the
+                // other libraries' waves of the same tile take the rest — so a wave's steps shrink by the library count
+                uint32_t todo = (uint32_t)__builtin_amdgcn_ballot_w64(BRC_MINE(T.misc)) & ((1u << nb) - 1u) & 0xffffu;
+                if (more) { bool ok2; BRC_LD_WIN(Tn, base + (uint32_t)BATCH, W0, W1, W2, W3, ok2) (void)ok2; }   // few steps: request at once
+                if (todo) {
+                    uint32_t jc = (uint32_t)__builtin_ctz(todo); todo &= todo - 1u;
+                    uint4 G0 = rows[jc][WIN_U4 + 1], G1;
+                    BRC_PROBE(jc, S0)
+                    S1 = S0; G1 = G0;
+                    for (;;) {
+                        const bool h1 = todo != 0u; const uint32_t j1 = h1 ? (uint32_t)__builtin_ctz(todo) : 0u; todo &= todo - 1u;
+                        BRC_STEP(jc, j1, h1, S0, S1, G0, G1)
+                        if (!h1) break;
+                        const bool h2 = todo != 0u; const uint32_t j2 = h2 ? (uint32_t)__builtin_ctz(todo) : 0u; todo &= todo - 1u;
+                        BRC_STEP(j1, j2, h2, S1, S0, G1, G0)
+                        if (!h2) break;
+                        jc = j2;
+                    }
+                }
             }
             if (more) {                                                       // all reads of this batch are done with the rows
                 BRC_LD_WIN_OK(Tn, base + (uint32_t)BATCH, wok)
@@ -1129,6 +1154,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
 #undef BRC_PROBE
 #undef BRC_RL
 #undef BRC_ALL
+#undef BRC_MINE
 #undef BRC_LD_TAB
 #undef BRC_LD_WIN
 #undef BRC_LD_WIN_OK
@@ -1437,8 +1463,10 @@ class HipBackend : public Backend {
             nwg = (nwg + 7u) & ~7u;
             // profiling knob: unused dynamic LDS lowers the number of resident waves (occupancy sweeps)
             static const unsigned dyn_lds = getenv("BRC_PILEUP_LDS_PAD") ? (unsigned)atoi(getenv("BRC_PILEUP_LDS_PAD")) : 0u;
-#define BRC_LAUNCH_PILEUP(V) hipLaunchKernelGGL((k_pileup<V>), dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), dyn_lds, stream, c, in, reads, (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.cigar, in.rcp, in.bq)
-            switch (c.variant) { case 1: BRC_LAUNCH_PILEUP(1); break; case 2: BRC_LAUNCH_PILEUP(2); break; case 3: BRC_LAUNCH_PILEUP(3); break; case 4: BRC_LAUNCH_PILEUP(4); break; default: BRC_LAUNCH_PILEUP(0); }
+#define BRC_LAUNCH_PILEUP(V) hipLaunchKernelGGL((k_pileup<V, false>), dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), dyn_lds, stream, c, in, reads, (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.cigar, in.rcp, in.bq)
+            if (c.per_lib && !getenv("BRC_NO_PL"))
+                hipLaunchKernelGGL((k_pileup<0, true>), dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), dyn_lds, stream, c, in, reads, (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.cigar, in.rcp, in.bq);
+            else switch (c.variant) { case 1: BRC_LAUNCH_PILEUP(1); break; case 2: BRC_LAUNCH_PILEUP(2); break; case 3: BRC_LAUNCH_PILEUP(3); break; case 4: BRC_LAUNCH_PILEUP(4); break; default: BRC_LAUNCH_PILEUP(0); }
         }
         HIPCHK(hipEventRecord(evt[T_COUNT], stream));
         if (P > 0) {
