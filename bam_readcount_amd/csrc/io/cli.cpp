@@ -29,7 +29,7 @@ struct Options {
     long long max_warnings = -1;
     std::string site_list, fasta, bam;
     std::vector<std::string> regions;
-    long long chunk_bp = 8000000;   // engine-side tiling of long regions (not a reference option): --brc-chunk
+    long long chunk_bp = 1000000;   // engine-side tiling of long regions (not a reference option): --brc-chunk
     long long plan_sites = 4096;    // site-list planner: -l lines batched per engine pass (0 = one pass per line): --brc-plan
 };
 
@@ -160,8 +160,16 @@ struct Batcher {
     }
 };
 
+#include <atomic>
+#include <chrono>
+#include <memory>
+#include <thread>
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 struct Ctx {
+    double t_fetch = 0, t_engine = 0, t_format = 0, t_write = 0;   // BRC_CLI_TIMING=1 prints them on stderr
     Options opt; BamReader bam; BamIndex idx; Fasta fa; bool have_fa = false;
+    std::vector<std::unique_ptr<BamReader> > pool;   // extra BAM handles of the striped parallel fetch
     CramReader cram; bool is_cram = false;          // minimal CRAM 3.0 input (cram.cpp); region queries scan container headers
     const BamHeader& header() const { return is_cram ? cram.header() : bam.header(); }
     brc_engine* eng = nullptr;
@@ -180,6 +188,44 @@ static int lib_index(const Ctx& c, const BamRecord& r) {      // bam_get_library
     return -1;
 }
 
+// Reads of one chunk [a-1, b) (the reference's own fetch rule, :602), decoded by a pool of BAM handles: the chunk is cut
+// by read START position into K stripes; stripe i keeps the records whose pos lies in its stripe (stripe 0 also the reads
+// that start before the chunk), so the stripes concatenated are exactly the single-handle fetch, in file order.
+struct Fetched { std::vector<Batcher> parts; bool ok = true; std::string err; };
+
+static void fetch_chunk(Ctx& c, int tid, int64_t a, int64_t b, Fetched& out) {
+    out.ok = true; out.err.clear();
+    const int64_t q0 = a - 1 < 0 ? 0 : a - 1;
+    unsigned K = 1;
+    static const long long stripe_min = getenv("BRC_FETCH_STRIPE_MIN") ? atoll(getenv("BRC_FETCH_STRIPE_MIN")) : 65536;   // (tests force small chunks into stripes)
+    if (!c.is_cram && b - q0 >= stripe_min) {
+        K = std::thread::hardware_concurrency(); if (K == 0) K = 1; if (K > 16) K = 16;
+        if (const char* t = getenv("BRC_FETCH_THREADS")) { const int v = atoi(t); if (v > 0) K = (unsigned)v; }
+        if ((int64_t)K > b - q0) K = (unsigned)(b - q0);          // every stripe at least one position wide (stripe 0 must contain q0)
+    }
+    if (out.parts.size() < K) out.parts.resize(K);
+    for (Batcher& p : out.parts) p.clear();
+    if (K == 1) {
+        auto add = [&](const BamRecord& r) { out.parts[0].add(r, c.opt.per_lib ? lib_index(c, r) : 0); };
+        if (!(c.is_cram ? c.cram.fetch(tid, a - 1, b, add) : c.bam.fetch(c.idx, tid, a - 1, b, add))) { out.ok = false; out.err = c.is_cram ? c.cram.error() : c.bam.error(); }
+        return;
+    }
+    while (c.pool.size() < K) { c.pool.emplace_back(new BamReader()); if (!c.pool.back()->open(c.opt.bam)) { out.ok = false; out.err = "cannot reopen " + c.opt.bam; return; } }
+    std::atomic<int> failed(0);
+    auto work = [&](unsigned i) {
+        const int64_t s0 = q0 + (b - q0) * (int64_t)i / (int64_t)K, s1 = q0 + (b - q0) * (int64_t)(i + 1) / (int64_t)K;
+        if (!c.pool[i]->fetch(c.idx, tid, i == 0 ? a - 1 : s0, s1, [&](const BamRecord& r) {
+                if (r.pos >= s1 || (i > 0 && r.pos < s0)) return;
+                out.parts[i].add(r, c.opt.per_lib ? lib_index(c, r) : 0);
+            })) failed = 1;
+    };
+    std::vector<std::thread> th;
+    for (unsigned i = 1; i < K; ++i) th.emplace_back(work, i);
+    work(0);
+    for (std::thread& t : th) t.join();
+    if (failed) { out.ok = false; out.err = "read error while fetching a region stripe"; }
+}
+
 // one reporting window [beg0,end) on tid: the body of the site-list / region loops (:588-605, :649-656)
 static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode) {
     const BamHeader& h = c.header();
@@ -190,25 +236,44 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
     const char* ref = c.have_fa && !c.ref.empty() ? c.ref.data() : nullptr;
     if (end > (int64_t)h.lengths[(size_t)tid] + 1000) end = (int64_t)h.lengths[(size_t)tid] + 1000;   // nothing aligns past the contig
     if (end < beg0) end = beg0;
-    // long regions are cut into abutting pieces; each piece fetches one base early exactly like the reference (:602)
+    // long regions are cut into abutting pieces; each piece fetches one base early exactly like the reference (:602).
+    // The next piece is fetched and decoded in the background while the current one is on the GPU / being formatted.
+    Fetched bufs[2];
+    int cur = 0;
     int64_t a = beg0;
+    double t0 = now_s();
+    fetch_chunk(c, tid, a, std::min<int64_t>(a + c.opt.chunk_bp, end), bufs[cur]);
+    c.t_fetch += now_s() - t0;
     do {
         const int64_t b = std::min<int64_t>(a + c.opt.chunk_bp, end);
-        c.batch.clear();
-        auto add = [&](const BamRecord& r) { c.batch.add(r, c.opt.per_lib ? lib_index(c, r) : 0); };
-        if (!(c.is_cram ? c.cram.fetch(tid, a - 1, b, add) : c.bam.fetch(c.idx, tid, a - 1, b, add))) {
-            fprintf(stderr, "bam-readcount: read error: %s\n", (c.is_cram ? c.cram.error() : c.bam.error()).c_str()); return 1;
-        }
+        Fetched& F = bufs[cur];
+        if (!F.ok) { fprintf(stderr, "bam-readcount: read error: %s\n", F.err.c_str()); return 1; }
+        std::thread pre;
+        const bool more = b < end;
+        if (more) pre = std::thread([&c, tid, b, end, &bufs, cur]() { fetch_chunk(c, tid, b, std::min<int64_t>(b + c.opt.chunk_bp, end), bufs[cur ^ 1]); });
+        double t1 = now_s();
+        // an internal piece boundary is not a region boundary: the deletions left pending by the previous piece start at its
+        // last position, which is this piece's lead position and queues them again — drop the leftovers (the FIRST piece
+        // keeps whatever the previous command-line region left, like the reference, :641-657)
+        if (a > beg0) brc_clear_indel_queue(c.eng);
         int rc = brc_begin_region(c.eng, tid, (int32_t)a, (int32_t)b, ref, (int64_t)c.ref.size());
-        const brc_read_batch v = c.batch.view();
-        if (!rc) rc = brc_push_reads(c.eng, &v);
+        for (const Batcher& part : F.parts) {
+            if (rc || part.pos.empty()) continue;
+            const brc_read_batch v = part.view();
+            rc = brc_push_reads(c.eng, &v);
+        }
         brc_result res; const char* text = ""; size_t len = 0;
         if (!rc) rc = brc_end_region(c.eng, &res);
+        double t2 = now_s(); c.t_engine += t2 - t1;
         if (!rc) rc = brc_format_region(c.eng, &res, h.names[(size_t)tid].c_str(), &text, &len);
+        double t3 = now_s(); c.t_format += t3 - t2;
+        if (!rc && len) fwrite(text, 1, len, stdout);
+        double t4 = now_s(); c.t_write += t4 - t3;
+        if (pre.joinable()) pre.join();
+        c.t_fetch += now_s() - t4;                  // only the part of the background fetch that was not hidden
         if (rc) { fprintf(stderr, "bam-readcount: engine error %d: %s (%s)\n", rc, brc_strerror(rc), brc_last_error(c.eng)); return 1; }
-        if (len) fwrite(text, 1, len, stdout);
         for (int w = 0; w < BRC_N_WARN; ++w) c.warn[w] += res.warn[w];
-        a = b;
+        a = b; cur ^= 1;
     } while (a < end);
     if (site_mode) brc_clear_indel_queue(c.eng);                                      // :605
     return 0;
@@ -388,6 +453,7 @@ int main(int argc, char** argv) {
     static const char* wn[BRC_N_WARN] = {"SM tag missing", "NM tag missing", "generated tag missing", "library unavailable"};
     for (int w = 0; w < BRC_N_WARN; ++w)
         if (c.warn[w] && o.max_warnings != 0) fprintf(stderr, "WARNING: %llu events: %s\n", (unsigned long long)c.warn[w], wn[w]);
+    if (getenv("BRC_CLI_TIMING")) fprintf(stderr, "timing: fetch+decode %.3f s, engine (push, upload, kernels, download) %.3f s, format %.3f s, write %.3f s\n", c.t_fetch, c.t_engine, c.t_format, c.t_write);
     brc_destroy(c.eng);
     return ret;
 }

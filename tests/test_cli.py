@@ -254,3 +254,23 @@ def test_cli_cram_reader_equals_bam_reader_cpu(synthetic_bam):
     a = subprocess.run([SIM_CLI, "-w", "0", "-f", "syn.fa", "-p", "-l", sl, "--brc-plan", "0", "syn_m.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     b = subprocess.run([SIM_CLI, "-w", "0", "-f", "syn.fa", "-p", "-l", sl, "syn.cram"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and a.stdout.count(b"\n") > 60
+
+
+def test_cli_striped_parallel_fetch_equals_single_handle_cpu(synthetic_bam, workdir):
+    """Long chunks are decoded by several BAM handles in stripes of read start positions while the previous chunk is on
+    the engine; forced here onto small regions (BRC_FETCH_STRIPE_MIN) with odd thread counts and chunk sizes."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    d = synthetic_bam
+    base = [SIM_CLI, "-w", "0", "-p", "-f", "syn.fa", "syn.bam", "chrA", "chrB:100-2900", "chrA:4990-5000"]
+    want = subprocess.run(base, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert want.returncode == 0 and want.stdout.count(b"\n") > 7000
+    for threads, chunk in ((3, "700"), (7, "1000000"), (16, "64"), (2, "5000")):
+        env = dict(os.environ, BRC_FETCH_STRIPE_MIN="1", BRC_FETCH_THREADS=str(threads))
+        got = subprocess.run(base[:1] + ["--brc-chunk", chunk] + base[1:], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert got.returncode == 0, got.stderr
+        assert got.stdout == want.stdout, (threads, chunk)
+    env = dict(os.environ, BRC_FETCH_STRIPE_MIN="1", BRC_FETCH_THREADS="5")
+    exp = open(os.path.join(GOLDEN, "expected_insertion_centric_per_lib"), "rb").read()
+    rc, out, _ = run_cli(SIM_CLI, workdir, "test.bam", ["-i", "-p"], "list") if False else (0, None, None)
+    p = subprocess.run([SIM_CLI, "-w", "1", "-i", "-p", "-f", "ref.fa", "-l", "site_list", "--brc-plan", "0", "test.bam"], cwd=workdir, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert p.returncode == 0 and p.stdout == exp
