@@ -385,9 +385,11 @@ static void format_range(const brc_engine* e, const brc_result* r, const char* c
             if (r->ncol[(int64_t)l * S + k] == 0) continue;                               // lib_counts has no entry (:286,360)
             if (per_lib) { rec += '\t'; rec += e->libs[(size_t)l]; rec += "\t{"; }
             for (int b = 0; b < BRC_NBUCKET; ++b) {
-                for (int f = 0; f < BRC_NI; ++f) si[f] = r->istat[(((int64_t)l * BRC_NBUCKET + b) * BRC_NI + f) * S + k];
+                // (the planes are position-major: look at the count plane first, the other 12 only for occupied buckets)
+                si[I_N] = r->istat[(((int64_t)l * BRC_NBUCKET + b) * BRC_NI + I_N) * S + k];
                 rec += '\t'; rec += "=ACGTN"[b]; rec += ':';
                 if (si[I_N] == 0) { fmt_stat(rec, si, sf, false); continue; }
+                for (int f = 0; f < BRC_NI; ++f) si[f] = r->istat[(((int64_t)l * BRC_NBUCKET + b) * BRC_NI + f) * S + k];
                 for (int f = 0; f < BRC_NF; ++f) sf[f] = r->fstat[(((int64_t)l * BRC_NBUCKET + b) * BRC_NF + f) * S + k];
                 fmt_stat(rec, si, sf, false);
             }
@@ -434,11 +436,13 @@ int brc_format_region(brc_engine* e, const brc_result* r, const char* chrom, con
     const int Lp = r->n_lib; const int64_t P = r->n_pos;
     if ((size_t)Lp != e->queue.size()) return fail(e, BRC_E_ARG, "result does not belong to this engine");
     std::string& out = e->text; out.clear();
-    int64_t CH = 1 << 16;
-    if (const char* t = getenv("BRC_FORMAT_CHUNK")) { const long long v = atoll(t); if (v > 0) CH = v; }   // test knob
-    const int64_t nch = (P + CH - 1) / CH;
     unsigned nthr = std::thread::hardware_concurrency(); if (nthr == 0) nthr = 1; if (nthr > 64) nthr = 64;
     if (const char* t = getenv("BRC_FORMAT_THREADS")) { const int v = atoi(t); if (v > 0) nthr = (unsigned)v; }
+    // about four chunks per thread, 2048 .. 65536 positions each (a 1-Mbp piece in 64-Ki chunks keeps only 15 threads busy)
+    int64_t CH = P / (4 * (int64_t)nthr);
+    if (CH < 2048) CH = 2048; if (CH > (1 << 16)) CH = 1 << 16;
+    if (const char* t = getenv("BRC_FORMAT_CHUNK")) { const long long v = atoll(t); if (v > 0) CH = v; }   // test knob
+    const int64_t nch = (P + CH - 1) / CH;
     if (nch <= 1 || nthr == 1) {
         format_range(e, r, chrom, 0, P, e->queue, out, r->beg0, r->end, 0);
     } else {

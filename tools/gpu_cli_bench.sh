@@ -43,3 +43,4 @@ import subprocess
 PY
 for ch in 250000 1000000 4000000; do echo "cli region --brc-chunk $ch -> /dev/null:"; time bam_readcount_amd/csrc/bam-readcount -w 1 -q 20 -b 13 --brc-chunk $ch -f /tmp/syn.fa /tmp/syn.bam chrS > /dev/null 2>/dev/null; done
 echo "cli region default chunk, timing:"; time BRC_CLI_TIMING=1 bam_readcount_amd/csrc/bam-readcount -w 1 -q 20 -b 13 -f /tmp/syn.fa /tmp/syn.bam chrS 2>&1 > /dev/null | tail -1
+for fc in 4096 16384; do echo "cli region BRC_FORMAT_CHUNK=$fc:"; time BRC_FORMAT_CHUNK=$fc BRC_CLI_TIMING=1 bam_readcount_amd/csrc/bam-readcount -w 1 -q 20 -b 13 -f /tmp/syn.fa /tmp/syn.bam chrS 2>&1 > /dev/null | tail -1; done
