@@ -1231,14 +1231,16 @@ __global__ __launch_bounds__(256) void k_indel_fill(DevCfg c, DevIn in, const DR
     const DRead r = reads[i];
     const int lib = (int)((r.misc >> 16) & 0xffu) - 1;
     enumerate_indels(c, in, r, in.qual + in.qual_off[i], [&](int32_t p, int qpos, int len) {
-        const uint32_t slot = atomicAdd(&cursor[(int64_t)(p - c.pos0) * c.Lp + lib], 1u);
-        IndelEv e; e.read = (uint32_t)i; e.qpos = qpos; e.len = len; e.key_lo = 0;
+        const int64_t key = (int64_t)(p - c.pos0) * c.Lp + lib;
+        const uint32_t slot = atomicAdd(&cursor[key], 1u);
+        IndelEv e; e.read = (uint32_t)i; e.qpos = qpos; e.len = len; e.key_lo = (uint32_t)key;   // (keys fit 32 bits: checked at upload)
         ev[slot] = e;
     });
 }
 
-// cursor[key] has been advanced by k_indel_fill to the END of the key's events.  A key's reduced alleles are written to
-// out[start .. start+na) where [start, start+n) is the key's own event range (no slot atomics); unused slots get len = 0.
+// cursor[key] has been advanced by k_indel_fill to the END of the key's events, which sit in consecutive slots.  One lane
+// per SLOT: the lane of a key's first slot reduces the key (the count plane is never scanned: keys with events are a few
+// in ten thousand).  A key's reduced alleles are written to out[start .. start+na); unused slots get len = 0.
 __global__ __launch_bounds__(256) void k_indel_reduce(DevCfg c, DevIn in, const DRead* __restrict__ reads, const uint32_t* __restrict__ cnt,
                                                       const uint32_t* __restrict__ cursor, IndelEv* __restrict__ ev,
                                                       const uint32_t* __restrict__ unavail, IndelOut* __restrict__ out,
@@ -1246,13 +1248,15 @@ __global__ __launch_bounds__(256) void k_indel_reduce(DevCfg c, DevIn in, const 
     __shared__ unsigned long long sh[4 * 2];
     unsigned long long w[2] = {0, 0};
     const int64_t nkeys = c.P * c.Lp;
+    const uint32_t nslots = nkeys > 0 ? cursor[nkeys - 1] : 0u;          // total number of event slots
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctr->n_indel_slots = nslots;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t key = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; key < nkeys; key += stride) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)nslots; i += stride) {
+        const uint32_t key = ev[i].key_lo;
+        if (i > 0 && ev[i - 1].key_lo == key) continue;                 // not the first slot of its key
         const int n = (int)cnt[key];
-        if (key == nkeys - 1) ctr->n_indel_slots = cursor[key];        // total number of event slots
-        if (n == 0) continue;
-        const int64_t k = key / c.Lp; const int lib = (int)(key % c.Lp);
-        const uint32_t start = cursor[key] - (uint32_t)n;
+        const int64_t k = (int64_t)key / c.Lp; const int lib = (int)((int64_t)key % c.Lp);
+        const uint32_t start = (uint32_t)i;
         int na = 0;
         if (!(c.per_lib && unavail[k] != NONE32)) {                     // else: position abandoned (bamreadcount.cpp:281-284)
             uint32_t wsm = 0, wnm = 0;
@@ -1391,6 +1395,7 @@ class HipBackend : public Backend {
         const size_t P = (size_t)c.PS, Lp = (size_t)c.Lp;   // allocation sizes use the padded stride
         ntiles = (c.P + TILE - 1) / TILE;
         n_indel_cap = c.has_ref ? s.n_indel_ops : 0;
+        if (n_indel_cap && (uint64_t)c.P * (uint64_t)c.Lp >= 0xffffffffull) { err = "region too large: (positions x libraries) must stay below 2^32"; return BRC_E_ARG; }
         const size_t nagg = std::max<size_t>((std::max<size_t>(n, P * Lp) + SCAN_CHUNK - 1) / SCAN_CHUNK, 1);
         HIPCHK(d_reads.ensure((n + 1) * sizeof(DRead))); HIPCHK(d_ends.ensure((n + 1) * 4)); HIPCHK(d_prefmax.ensure((n + 1) * 4));
         HIPCHK(d_agg.ensure(nagg * 4 + 16)); HIPCHK(d_rng.ensure(((size_t)ntiles + 1) * sizeof(uint2)));
@@ -1482,7 +1487,7 @@ class HipBackend : public Backend {
             hipLaunchKernelGGL(k_indel_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, reads, (uint32_t*)d_cursor.p, (IndelEv*)d_ev.p);
         HIPCHK(hipEventRecord(evt[T_INDEL_REDUCE], stream));
         if (indels)
-            hipLaunchKernelGGL(k_indel_reduce, dim3((unsigned)std::min<int64_t>(((int64_t)Lp * P + 255) / 256, 4096)), dim3(256), 0, stream, c, in, reads,
+            hipLaunchKernelGGL(k_indel_reduce, dim3((unsigned)std::min<int64_t>(((int64_t)n_indel_cap + 255) / 256 + 1, 4096)), dim3(256), 0, stream, c, in, reads,
                                (const uint32_t*)d_cnt.p, (const uint32_t*)d_cursor.p, (IndelEv*)d_ev.p, (const uint32_t*)d_unavail.p,
                                (IndelOut*)d_iout.p, ctr);
         HIPCHK(hipEventRecord(evt[T_N], stream));
