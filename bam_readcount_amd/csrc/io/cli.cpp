@@ -409,6 +409,9 @@ int main(int argc, char** argv) {
     cfg.per_lib = o.per_lib; cfg.insertion_centric = o.insertion_centric; cfg.n_libs = (int32_t)names.size();
     cfg.lib_names = names.empty() ? nullptr : names.data(); cfg.device = getenv("BRC_DEVICE") ? atoi(getenv("BRC_DEVICE")) : 0;
     cfg.ref_len_check = (!o.site_list.empty() && c.have_fa) ? 1 : 0;                                                                        // :594-600
+    // -d below any real depth changes which reads bam_plp_push keeps, and that depends on everything buffered before:
+    // no internal pieces then (the planner is off for the same reason)
+    if (o.max_cnt < 1000000) c.opt.chunk_bp = (long long)INT_MAX;
     int rc = brc_create(&cfg, &c.eng);
     if (rc) { fprintf(stderr, "bam-readcount: cannot create the MI355X engine: %s\n", brc_strerror(rc)); return 1; }
     int ret = 0;
