@@ -76,6 +76,20 @@ def test_hip_annotate_mismatch_runs_stress(hip_lib, oracle_lib, mismatch, read_l
     parity.compare_libs(hip_lib, oracle_lib, arrs, [(0, 8000)], ref=ref, min_mapq=10, min_bq=15, insertion_centric=True)
 
 
+@pytest.mark.parametrize("env", ["BRC_NO_TABLE", "BRC_NO_PL"])
+def test_hip_alternative_device_paths(hip_lib, oracle_lib, monkeypatch, env):
+    """Paths that the default configuration uses only for a few percent of the reads (every read through the general
+    probe with exact reciprocal division: BRC_NO_TABLE) or not at all (per-library launch without the own-library read
+    mask: BRC_NO_PL) must give the same bits."""
+    monkeypatch.setenv(env, "1")
+    rng = np.random.default_rng(99)
+    ref = synth.make_ref(rng, 3000, weird=0.01)
+    arrs = synth.make_batch(199, ref, 700, style="mixed", n_libs=3, p_nolib=0.02)
+    names = ["libA", "libB", "libC"]
+    parity.compare_libs(hip_lib, oracle_lib, arrs, [(0, 3000), (1200, 1300)], ref=ref, lib_names=names, per_lib=True, check_warn=False)
+    parity.compare_libs(hip_lib, oracle_lib, arrs, [(0, 3000)], ref=ref, min_mapq=5, min_bq=10, insertion_centric=True)
+
+
 def test_hip_edge_cases(hip_lib, oracle_lib):
     rng = np.random.default_rng(5)
     ref = synth.make_ref(rng, 500)
