@@ -30,8 +30,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICR
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--contig-mbp", type=float, default=50.0, help="contig length per GPU (BASELINE config 3: 50)")
     ap.add_argument("--config", default="wgs30x", choices=["wgs30x", "tumor200x"])
     ap.add_argument("--cpu-sample-mbp", type=float, default=8.0, help="prefix timed with the CPU oracle (0 = skip); 8 Mbp ~ 240 M events ~ 10-20 s")
