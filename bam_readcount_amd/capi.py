@@ -308,7 +308,7 @@ def read_ends(arrs):
     cs = np.concatenate([[0], np.cumsum(ln)])
     rlen = cs[off + ncig] - cs[off]
     flag = np.asarray(arrs["flag"]).astype(np.int64)
-    rlen = np.where(((flag & 4) != 0) | (ncig == 0), 1, rlen)
+    rlen = np.where(((flag & 4) != 0) | (ncig == 0) | (rlen == 0), 1, rlen)   # bam_endpos: rlen 0 counts as 1
     return np.asarray(arrs["pos"]).astype(np.int64) + rlen
 
 

@@ -35,7 +35,12 @@ enum { CMATCH = 0, CINS, CDEL, CREF_SKIP, CSOFT_CLIP, CHARD_CLIP, CPAD, CEQUAL, 
 enum { FPROPER_PAIR = 2, FUNMAP = 4, FREVERSE = 16, FSECONDARY = 256, FQCFAIL = 512, FDUP = 1024 };
 // engine-private flag bit set on the host for reads bam_plp_push would drop because of -d/max-count
 enum { FHOSTDROP = 0x8000 };
-#define BRC_PUSH_MASK (brc::FUNMAP | brc::FSECONDARY | brc::FQCFAIL | brc::FDUP | brc::FHOSTDROP)
+// Reads that never enter a pileup column: htslib 1.10's bam_plp_push skips UNMAPPED reads only ("any additional filtering
+// must be done in iter->func") + the host's max-count drops.
+#define BRC_PUSH_MASK (brc::FUNMAP | brc::FHOSTDROP)
+// Reads that sit in the column (they create their library's entry, can abandon a -p position and make a position print,
+// bamreadcount.cpp:276-286) but that pileup_func never counts (:295-310).
+#define BRC_NOCOUNT_MASK (brc::FSECONDARY | brc::FQCFAIL | brc::FDUP)
 
 enum { NBUCKET = 6, NI = 9, NF = 4 };
 // integer plane order == brc.h BRC_I_*; float plane order == BRC_F_*
@@ -83,7 +88,8 @@ enum { M_REV = 1, M_Q2OK = 2, M_SMW = 4, M_NMW = 8, M_SIMPLE = 16,
        M_STAGED = 64,   // KB can stage this read's bq window in LDS: simple CIGAR, or deleted + inserted + clipped bases <= 24
        M_FAST = 128 };  // SIMPLE && STAGED && library known && l_qseq == clipped_length == DevCfg.table_len: KB's branch-free
                         // probe applies and the event terms come from the quotient tables (finish_misc)
-// misc layout: bits 0-7 flags | 8-15 mapq | 16-23 library index + 1 (0 = unavailable) | 24-31 total D/N bases (staged reads)
+static const uint32_t M_NOCOUNT = 0x80000000u;   // SECONDARY / QCFAIL / DUP: in the column, never counted (BRC_NOCOUNT_MASK)
+// misc layout: bits 0-7 flags | 8-15 mapq | 16-23 library index + 1 (0 = unavailable) | 24-30 total D/N bases (staged reads) | 31 M_NOCOUNT
 enum { STAGE_SLACK = 24 };
 struct alignas(64) DRead {
     int32_t pos, end;          // [pos,end) on the reference; end == pos when the read never enters a column
@@ -242,6 +248,7 @@ BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i, uint16_t
     const int lib = c.per_lib ? (int)in.lib[i] : 0;
     uint32_t misc = (mapq << 8) | ((uint32_t)((lib + 1) & 0xff) << 16);
     if (rev) misc |= M_REV;
+    if (flag & BRC_NOCOUNT_MASK) misc |= M_NOCOUNT;
     if (q2 > -1) misc |= M_Q2OK;
     if (nc == 1 && (cig[0] & 0xfu) == CMATCH) misc |= M_SIMPLE;
     if (tot_d + tot_is <= STAGE_SLACK) misc |= M_STAGED | ((uint32_t)tot_d << 24);
@@ -456,7 +463,7 @@ BRC_HD Probe lane_probe(const DevCfg& c, const DevIn& in, const DRead& rd, uint3
         in_col = covered && e.in_col; pr.qpos = e.qpos; is_del = e.is_del; pr.indel = e.indel;
     }
     a.ncol += in_col ? 1u : 0u;                                         // lib_counts[library] created (:286)
-    pr.want = in_col && !is_del && (int)((rd.misc >> 8) & 0xffu) >= c.min_mapq;   // :288
+    pr.want = in_col && !is_del && (int)((rd.misc >> 8) & 0xffu) >= c.min_mapq && !(rd.misc & M_NOCOUNT);   // :288, :295-310
     return pr;
 }
 
@@ -557,7 +564,7 @@ template <class F>
 BRC_HD void enumerate_indels(const DevCfg& c, const DevIn& in, const DRead& rd, const uint8_t* qual_row, F emit) {
     if (rd.end <= rd.pos || (rd.misc & M_SIMPLE) || !c.has_ref) return;
     if (((rd.misc >> 16) & 0xffu) == 0) return;                         // library unavailable: position is abandoned
-    if ((int)((rd.misc >> 8) & 0xffu) < c.min_mapq) return;
+    if ((int)((rd.misc >> 8) & 0xffu) < c.min_mapq || (rd.misc & M_NOCOUNT)) return;
     const uint32_t* cig = in.cigar + rd.cig_off; const uint32_t nc = rd.n_cigar;
     int32_t x = rd.pos; int y = 0;
     for (uint32_t k = 0; k < nc; ++k) {

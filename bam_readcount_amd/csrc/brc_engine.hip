@@ -43,334 +43,6 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 
 // ---------------------------------------------------------------- K1
 
-__global__ __launch_bounds__(256) void k_annotate(DevCfg c, DevIn in, DRead* __restrict__ reads, int32_t* __restrict__ ends,
-                                                  uint16_t* __restrict__ bq, RcpPair* __restrict__ rcp, uint32_t* __restrict__ indel_cnt) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= c.n_reads) return;
-    const DRead r = annotate_read(c, in, i, bq, rcp);
-    reads[i] = r;
-    ends[i] = r.end;
-    if (indel_cnt) {
-        const int lib = (int)((r.misc >> 16) & 0xffu) - 1;
-        enumerate_indels(c, in, r, in.qual + in.qual_off[i], [&](int32_t p, int, int) {
-            atomicAdd(&indel_cnt[(int64_t)(p - c.pos0) * c.Lp + lib], 1u);
-        });
-    }
-}
-
-// K1, wave-per-read form (the one normally launched): the 64 lanes walk the read's bases, so QUAL / SEQ / reference
-// loads and the bq stores are contiguous across the wave.  Restates bamreadcount.cpp:114-256 exactly like annotate_read():
-//   * mismatch qualities: runs of read-adjacent mismatching M-op bases contribute their maximum quality (:152-172,199).
-//     Per 64-base chunk: ballot of the mismatch flags, run length ending at each lane from the ballot, segmented max by
-//     doubling (shfl_up), run ends summed; a run crossing a chunk boundary is carried in (carry_open, carry_max).
-//   * Q2 scan (:201-238) from ballots of (qual != 2): highest such index (forward reads) / lowest (reverse reads).
-// Reads that overhang the end of the reference take the reference's break/continue quirks (:144-151,175); those, and
-// everything when no reference was given, go through the serial annotate_read() on lane 0 instead.
-__global__ __launch_bounds__(256) void k_annotate_wave(DevCfg c, DevIn in, DRead* __restrict__ reads, int32_t* __restrict__ ends,
-                                                       uint16_t* __restrict__ bq, RcpPair* __restrict__ rcp, uint32_t* __restrict__ indel_cnt) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t w = __builtin_amdgcn_readfirstlane((uint32_t)(blockIdx.x * 4u + (threadIdx.x >> 6)));
-    if ((int64_t)w >= c.n_reads) return;
-    const int64_t i = w;
-    const int32_t pos = in.pos[i];
-    const uint32_t flag = in.flag[i];
-    const int32_t L = in.l_qseq[i];
-    const uint32_t nc = in.n_cigar[i];
-    const uint64_t qoff = in.qual_off[i];
-    const uint64_t brow = in.bq_row[i];
-    const uint32_t* __restrict__ cig = in.cigar + in.cig_off[i];
-    const uint8_t* __restrict__ seq = in.seq4 + in.seq_off[i];
-    const uint8_t* __restrict__ qual = in.qual + qoff;
-
-    int32_t rlen = 0; int clipped = L, left_clip = 0, right_clip = L; int64_t tot_d = 0, tot_is = 0;
-    CigShape shape;
-    for (uint32_t k = 0; k < nc; ++k) {
-        const uint32_t op = cig[k] & 0xfu; const int len = (int)(cig[k] >> 4);
-        shape_add(shape, op, len);
-        if (is_refop(op)) rlen += len;
-        if (op == CDEL || op == CREF_SKIP) tot_d += len;
-        if (op == CINS || op == CSOFT_CLIP) tot_is += len;
-        if (op == CSOFT_CLIP) { clipped -= len; if (k == 0) left_clip += len; else right_clip -= len; }
-    }
-    const bool simple = nc == 1 && (cig[0] & 0xfu) == CMATCH;
-    DRead r;
-    if (!c.has_ref || pos < 0 || (int64_t)pos + rlen > c.ref_len) {
-        if (lane == 0) { r = annotate_read(c, in, i, bq, rcp); reads[i] = r; ends[i] = r.end; }
-    } else {
-        uint32_t sum = 0; bool carry_open = false; int carry_max = 0;
-        int hi_nq2 = -1, lo_nq2 = -1;
-        for (int b0 = 0; b0 < L; b0 += 64) {
-            const int j = b0 + lane; const bool inr = j < L;
-            const uint32_t q = inr ? qual[j] : 2u;
-            const uint32_t nib = inr ? seqi(seq, j) : 0u;
-            if (inr) bq[brow + (uint64_t)j] = (uint16_t)(q | (canon_bucket(nib) << 8));
-            bool inM = false; int64_t refpos = 0;
-            if (simple) { inM = inr; refpos = (int64_t)pos + j; }
-            else {
-                int rs = 0; int64_t x = pos;
-                for (uint32_t k = 0; k < nc; ++k) {
-                    const uint32_t op = cig[k] & 0xfu; const int len = (int)(cig[k] >> 4);
-                    if (op == CMATCH) { if (inr && j >= rs && j < rs + len) { inM = true; refpos = x + (j - rs); } rs += len; x += len; }
-                    else if (op == CDEL || op == CREF_SKIP) x += len;
-                    else if (op == CINS || op == CSOFT_CLIP) rs += len;
-                    // '=' / 'X' / H / P: the reference annotator advances neither cursor (:138-196)
-                }
-            }
-            bool m = false;
-            if (inM) {
-                const uint32_t refb = nt16_of_char(ref_at(c, in.ref, refpos));
-                m = nib != refb && refb != 15u && nib != 0u;
-            }
-            const unsigned long long mask = __ballot(m);
-            const unsigned long long nz = __ballot(inr && q != 2u);
-            if (nz) { hi_nq2 = b0 + 63 - __builtin_clzll(nz); if (lo_nq2 < 0) lo_nq2 = b0 + __builtin_ctzll(nz); }
-            if (carry_open && !(mask & 1ull)) { sum += (uint32_t)carry_max; carry_open = false; }
-            if (mask) {
-                const unsigned long long below = lane ? (~mask & ((1ull << lane) - 1ull)) : 0ull;
-                const int h = below ? 63 - __builtin_clzll(below) : -1;
-                const int runlen = m ? lane - h : 0;
-                int v = m ? (int)q : 0;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d, 64); if (runlen > d) v = v > o ? v : o; }
-                if (carry_open && m && runlen == lane + 1) v = v > carry_max ? v : carry_max;
-                const bool is_end = m && (lane < 63 ? !((mask >> (lane + 1)) & 1ull) : (j + 1 >= L));
-                sum += (uint32_t)wave_sum_u64(is_end ? (unsigned long long)v : 0ull);
-                const bool open_out = ((mask >> 63) & 1ull) && (b0 + 64 < L);
-                carry_max = __builtin_amdgcn_readlane(v, 63);
-                carry_open = open_out;
-            }
-        }
-        if (carry_open) sum += (uint32_t)carry_max;
-        const bool rev = (flag & FREVERSE) != 0;
-        int tp, q2;
-        if (rev) { tp = 0; if (tp < left_clip) tp = left_clip; q2 = lo_nq2 >= 0 ? lo_nq2 - 1 : -1; if (tp < q2) tp = q2; }
-        else { tp = L - 1; if (tp > right_clip) tp = right_clip; q2 = hi_nq2 >= 0 ? hi_nq2 - 1 : -1; if (tp > q2 && q2 != -1) tp = q2; }
-        bool dropped = (flag & BRC_PUSH_MASK) != 0;
-        if (nc == 0) dropped = true;
-        if (nc == 1 && !is_mop(cig[0] & 0xfu)) dropped = true;
-        const uint32_t mapq = in.mapq[i]; const uint32_t tags = in.tags[i];
-        r.pos = pos; r.end = dropped ? pos : pos + rlen;
-        r.cig_off = (uint32_t)in.cig_off[i]; r.n_cigar = nc; r.bq_off = brow;
-        const int lib = c.per_lib ? (int)in.lib[i] : 0;
-        uint32_t misc = (mapq << 8) | ((uint32_t)((lib + 1) & 0xff) << 16);
-        if (rev) misc |= M_REV;
-        if (q2 > -1) misc |= M_Q2OK;
-        if (simple) misc |= M_SIMPLE;
-        if (tot_d + tot_is <= STAGE_SLACK) misc |= M_STAGED | ((uint32_t)tot_d << 24);
-        uint32_t sse;
-        if (flag & FPROPER_PAIR) { if (tags & 2u) sse = (uint32_t)in.sm[i]; else { sse = 0; misc |= M_SMW; } } else sse = mapq;
-        float snm = 0.0f;
-        if (tags & 1u) snm = (float)in.nm[i] / (float)clipped; else misc |= M_NMW;
-        r.misc = finish_misc(misc, c.table_len > 0 && L == c.table_len && clipped == L, shape_clipm(shape, nc, left_clip)); r.l_qseq = L; r.q2 = q2; r.tp = tp; r.left = left_clip; r.clipped = clipped;
-        r.zm_sum = sum; r.sse_add = sse; r.snm_add = snm; r.clipped_dup = clipped;
-        if (lane == 0) {
-            reads[i] = r; ends[i] = r.end;
-            RcpPair rc; rc.Lf = (float)L; rc.center = (float)clipped * 0.5f; rc.rcpL = 1.0f / rc.Lf; rc.rcpC = 1.0f / rc.center;
-            rcp[i] = rc;
-        }
-    }
-    if (indel_cnt && lane == 0 && !simple) {
-        const DRead rr = reads[i];   // lane 0 wrote it above (same lane: program order)
-        const int lib = (int)((rr.misc >> 16) & 0xffu) - 1;
-        enumerate_indels(c, in, rr, qual, [&](int32_t p, int, int) { atomicAdd(&indel_cnt[(int64_t)(p - c.pos0) * c.Lp + lib], 1u); });
-    }
-}
-
-// K1, batch form (the one normally launched): one wave owns 64 consecutive reads.
-//   phase A (lane = read): metadata + a walk over the read's own CIGAR (reference length, clips, "simple nM" flag);
-//   phase B (wave-cooperative, reads visited one after the other, lanes = 64 consecutive bases): bq packing, mismatch
-//            flags against the reference, run-max sum of mismatch qualities and the Q2 scan, exactly as in
-//            k_annotate_wave; the QUAL/SEQ/REF loads of the NEXT 64-base chunk (possibly of the next read) are issued
-//            before the current chunk is processed, so one memory round trip is in flight per chunk instead of being
-//            waited for; per-read parameters come from the lane table with v_readlane, results go back to lane j;
-//   phase C (lane = read): three-prime / Q2 logic, DRead + float constants, indel-event counting.
-// Reads that overhang the reference end (the annotator's break/continue quirks) or everything when there is no
-// reference are done by the serial annotate_read() in phase C.
-struct AnnItem { int32_t L, pos; uint64_t qoff, soff, brow; uint32_t coff, nc; bool simple; };
-
-__global__ __launch_bounds__(256) void k_annotate_batch(DevCfg c, DevIn in, DRead* __restrict__ reads, int32_t* __restrict__ ends,
-                                                        uint16_t* __restrict__ bq, RcpPair* __restrict__ rcp, uint32_t* __restrict__ indel_cnt,
-                                                        const uint32_t* __restrict__ cigar_ro, const uint8_t* __restrict__ qual_ro,
-                                                        const uint8_t* __restrict__ seq_ro, const char* __restrict__ ref_ro) {
-    // per-workgroup lookup tables: reference character -> 4-bit base code (htslib seq_nt16_table), base code -> "=ACGTN" bucket
-    __shared__ uint8_t lut_nt16[256];
-    __shared__ uint8_t lut_bucket[16];
-    lut_nt16[threadIdx.x] = (uint8_t)nt16_of_char(threadIdx.x);
-    if (threadIdx.x < 16) lut_bucket[threadIdx.x] = (uint8_t)canon_bucket(threadIdx.x);
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int64_t rb = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
-    if (rb >= c.n_reads) return;
-    const int nrd = (int)((c.n_reads - rb) < 64 ? (c.n_reads - rb) : 64);
-    const int64_t my = rb + (lane < nrd ? lane : nrd - 1);
-    const bool have = lane < nrd;
-    // ---- phase A
-    const int32_t pos = in.pos[my];
-    const uint32_t flag = in.flag[my];
-    const int32_t L = in.l_qseq[my];
-    const uint32_t nc = in.n_cigar[my];
-    const uint64_t qoff = in.qual_off[my], soff = in.seq_off[my], brow = in.bq_row[my];
-    const uint32_t coff = (uint32_t)in.cig_off[my];
-    int32_t rlen = 0; int clipped = L, left_clip = 0, right_clip = L; int64_t tot_d = 0, tot_is = 0;
-    uint32_t cig0 = 0;
-    CigShape shape;
-    for (uint32_t k = 0; k < nc; ++k) {
-        const uint32_t cg = cigar_ro[coff + k];
-        if (k == 0) cig0 = cg;
-        const uint32_t op = cg & 0xfu; const int len = (int)(cg >> 4);
-        shape_add(shape, op, len);
-        if (is_refop(op)) rlen += len;
-        if (op == CDEL || op == CREF_SKIP) tot_d += len;
-        if (op == CINS || op == CSOFT_CLIP) tot_is += len;
-        if (op == CSOFT_CLIP) { clipped -= len; if (k == 0) left_clip += len; else right_clip -= len; }
-    }
-    const bool simple = nc == 1 && (cig0 & 0xfu) == CMATCH;
-    bool dropped = (flag & BRC_PUSH_MASK) != 0;
-    if (nc == 0) dropped = true;
-    if (nc == 1 && !is_mop(cig0 & 0xfu)) dropped = true;
-    const bool fallback = !c.has_ref || pos < 0 || (int64_t)pos + rlen > c.ref_len;
-    // reads whose per-base pass is needed: in the pileup, annotated by the wave path
-    const unsigned long long work = __ballot(have && !dropped && !fallback && L > 0);
-    uint32_t my_sum = 0; int my_hi = -1, my_lo = -1;
-
-    // ---- phase B
-#define BRC_RL(x, j) __builtin_amdgcn_readlane((int)(x), (int)(j))
-#define BRC_RL64(x, j) ((uint64_t)(uint32_t)BRC_RL((uint32_t)(x), j) | ((uint64_t)(uint32_t)BRC_RL((uint32_t)((x) >> 32), j) << 32))
-#define BRC_ITEM(IT, j) { IT.L = BRC_RL(L, j); IT.pos = BRC_RL(pos, j); IT.qoff = BRC_RL64(qoff, j); IT.soff = BRC_RL64(soff, j); IT.brow = BRC_RL64(brow, j); \
-                          IT.coff = (uint32_t)BRC_RL(coff, j); IT.nc = (uint32_t)BRC_RL(nc, j); IT.simple = BRC_RL(simple ? 1 : 0, j) != 0; }
-    // loads of one 64-base chunk (b0) of item IT into (q, seq byte, ref char) + flag bits (1 = inside the read, 2 = M-op base).
-    // Straight-line on purpose: the three vector loads are issued unconditionally with clamped addresses and validity is
-    // carried in FL, because loads inside conditional blocks make the compiler's wait-count analysis fall back to
-    // s_waitcnt vmcnt(0) at every merge, which serialises the prefetch ring.
-#define BRC_CHUNK_LOAD(IT, b0, Q, SB, RCH, FL)                                                                          \
-    {                                                                                                                     \
-        const int jj = (b0) + lane; const bool inr = jj < IT.L;                                                           \
-        const uint32_t jc = inr ? (uint32_t)jj : 0u;                                                                      \
-        bool inm = false; int64_t refpos = IT.pos;                                                                        \
-        if (IT.simple) { inm = inr; refpos = (int64_t)IT.pos + jc; }                                                      \
-        else {                                                                                                            \
-            int rs = 0; int64_t x = IT.pos;                                                                               \
-            for (uint32_t k = 0; k < IT.nc; ++k) {                                                                        \
-                const uint32_t cg = cigar_ro[IT.coff + k]; const uint32_t op = cg & 0xfu; const int len = (int)(cg >> 4); \
-                if (op == CMATCH) { if (inr && jj >= rs && jj < rs + len) { inm = true; refpos = x + (jj - rs); } rs += len; x += len; } \
-                else if (op == CDEL || op == CREF_SKIP) x += len;                                                         \
-                else if (op == CINS || op == CSOFT_CLIP) rs += len;                                                       \
-            }                                                                                                             \
-        }                                                                                                                 \
-        const int64_t ro = inm ? refpos - c.ref_lo : (int64_t)IT.pos - c.ref_lo;   /* inside the slice: pos >= 0, pos + rlen <= ref_len */ \
-        Q = (uint32_t)(qual_ro + IT.qoff)[jc];                                                                            \
-        SB = (uint32_t)(seq_ro + IT.soff)[jc >> 1];                                                                       \
-        RCH = (uint32_t)(uint8_t)ref_ro[ro];                                                                              \
-        FL = (inr ? 1u : 0u) | (inm ? 2u : 0u);                                                                           \
-    }
-    if (work) {
-        // item iterator: (read j, chunk b0) in order; a ring of 4 chunk slots keeps four chunks' loads in flight
-        unsigned long long todo = work;
-        int it_j = -1, it_b0 = 0, it_L = 0; bool it_ok = true;
-        AnnItem itx; itx.L = 0; itx.pos = 0; itx.qoff = itx.soff = itx.brow = 0; itx.coff = itx.nc = 0; itx.simple = true;
-#define BRC_NEXT_ITEM()                                                                                                 \
-        {                                                                                                                 \
-            if (it_j >= 0 && it_b0 + 64 < it_L) it_b0 += 64;                                                              \
-            else if (todo) { it_j = __builtin_ctzll(todo); todo &= todo - 1; it_b0 = 0; it_L = BRC_RL(L, it_j); BRC_ITEM(itx, it_j) } \
-            else it_ok = false;                                                                                           \
-        }
-#define BRC_FILL(K)                                                                                                     \
-        {                                                                                                                 \
-            BRC_NEXT_ITEM()                                                                                               \
-            ok##K = it_ok; sj##K = it_j; sb##K = it_b0;                                                                     \
-            BRC_CHUNK_LOAD(itx, it_ok ? it_b0 : 0, q##K, nib##K, rch##K, inM##K)   /* unconditional: see BRC_CHUNK_LOAD */ \
-        }
-        uint32_t sum = 0; bool carry_open = false; int carry_max = 0; int hi_nq2 = -1, lo_nq2 = -1;
-#define BRC_PROCESS(K)                                                                                                  \
-        {                                                                                                                 \
-            const int jr = sj##K, b0 = sb##K;                                                                               \
-            const int Lr = BRC_RL(L, jr); const uint64_t browr = BRC_RL64(brow, jr);                                      \
-            const int jj = b0 + lane; const bool inr = (inM##K & 1u) != 0;                                                \
-            const uint32_t q = inr ? q##K : 2u;                                                                           \
-            const uint32_t nib = inr ? ((nib##K >> ((~jj & 1) << 2)) & 0xfu) : 0u;                                        \
-            if (inr) (bq + browr)[(uint32_t)jj] = (uint16_t)(q | ((uint32_t)lut_bucket[nib] << 8));                       \
-            bool m = false;                                                                                               \
-            if (inM##K & 2u) { const uint32_t refb = lut_nt16[rch##K]; m = nib != refb && refb != 15u && nib != 0u; }     \
-            const unsigned long long mask = __ballot(m);                                                                  \
-            const unsigned long long nz = __ballot(inr && q != 2u);                                                       \
-            if (nz) { hi_nq2 = b0 + 63 - __builtin_clzll(nz); if (lo_nq2 < 0) lo_nq2 = b0 + __builtin_ctzll(nz); }        \
-            if (carry_open && !(mask & 1ull)) { sum += (uint32_t)carry_max; carry_open = false; }                         \
-            if (mask) {                                                                                                   \
-                const unsigned long long below = lane ? (~mask & ((1ull << lane) - 1ull)) : 0ull;                         \
-                const int h = below ? 63 - __builtin_clzll(below) : -1;                                                   \
-                const int runlen = m ? lane - h : 0;                                                                      \
-                int v = m ? (int)q : 0;                                                                                   \
-                _Pragma("unroll") for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d, 64); if (runlen > d) v = v > o ? v : o; } \
-                if (carry_open && m && runlen == lane + 1) v = v > carry_max ? v : carry_max;                             \
-                const bool is_end = m && (lane < 63 ? !((mask >> (lane + 1)) & 1ull) : (jj + 1 >= Lr));                   \
-                sum += (uint32_t)wave_sum_u64(is_end ? (unsigned long long)v : 0ull);                                     \
-                carry_max = __builtin_amdgcn_readlane(v, 63);                                                             \
-                carry_open = ((mask >> 63) & 1ull) && (b0 + 64 < Lr);                                                     \
-            }                                                                                                             \
-            if (b0 + 64 >= Lr) {                                  /* last chunk of the read: deposit into its lane */   \
-                if (carry_open) sum += (uint32_t)carry_max;                                                               \
-                if (lane == jr) { my_sum = sum; my_hi = hi_nq2; my_lo = lo_nq2; }                                         \
-                sum = 0; carry_open = false; carry_max = 0; hi_nq2 = -1; lo_nq2 = -1;                                     \
-            }                                                                                                             \
-        }
-        uint32_t q0 = 2, nib0 = 0, rch0 = 0, q1 = 2, nib1 = 0, rch1 = 0, q2s = 2, nib2 = 0, rch2 = 0, q3 = 2, nib3 = 0, rch3 = 0;
-        uint32_t inM0 = 0, inM1 = 0, inM2 = 0, inM3 = 0; bool ok0, ok1, ok2, ok3;
-        int sj0, sj1, sj2, sj3, sb0, sb1, sb2, sb3;
-#define q2 q2s
-        BRC_FILL(0) BRC_FILL(1) BRC_FILL(2) BRC_FILL(3)
-        while (ok0) {
-            BRC_PROCESS(0) BRC_FILL(0)
-            if (!ok1) break;
-            BRC_PROCESS(1) BRC_FILL(1)
-            if (!ok2) break;
-            BRC_PROCESS(2) BRC_FILL(2)
-            if (!ok3) break;
-            BRC_PROCESS(3) BRC_FILL(3)
-        }
-#undef q2
-#undef BRC_PROCESS
-#undef BRC_FILL
-#undef BRC_NEXT_ITEM
-    }
-#undef BRC_CHUNK_LOAD
-#undef BRC_ITEM
-#undef BRC_RL64
-#undef BRC_RL
-    // ---- phase C
-    if (!have) return;
-    DRead r;
-    if (fallback) {
-        r = annotate_read(c, in, my, bq, rcp);
-    } else {
-        const bool rev = (flag & FREVERSE) != 0;
-        int tp, q2;
-        if (rev) { tp = 0; if (tp < left_clip) tp = left_clip; q2 = my_lo >= 0 ? my_lo - 1 : -1; if (tp < q2) tp = q2; }
-        else { tp = L - 1; if (tp > right_clip) tp = right_clip; q2 = my_hi >= 0 ? my_hi - 1 : -1; if (tp > q2 && q2 != -1) tp = q2; }
-        const uint32_t mapq = in.mapq[my]; const uint32_t tags = in.tags[my];
-        r.pos = pos; r.end = dropped ? pos : pos + rlen;
-        r.cig_off = coff; r.n_cigar = nc; r.bq_off = brow;
-        const int lib = c.per_lib ? (int)in.lib[my] : 0;
-        uint32_t misc = (mapq << 8) | ((uint32_t)((lib + 1) & 0xff) << 16);
-        if (rev) misc |= M_REV;
-        if (q2 > -1) misc |= M_Q2OK;
-        if (simple) misc |= M_SIMPLE;
-        if (tot_d + tot_is <= STAGE_SLACK) misc |= M_STAGED | ((uint32_t)tot_d << 24);
-        uint32_t sse;
-        if (flag & FPROPER_PAIR) { if (tags & 2u) sse = (uint32_t)in.sm[my]; else { sse = 0; misc |= M_SMW; } } else sse = mapq;
-        float snm = 0.0f;
-        if (tags & 1u) snm = (float)in.nm[my] / (float)clipped; else misc |= M_NMW;
-        r.misc = finish_misc(misc, c.table_len > 0 && L == c.table_len && clipped == L, shape_clipm(shape, nc, left_clip)); r.l_qseq = L; r.q2 = q2; r.tp = tp; r.left = left_clip; r.clipped = clipped;
-        r.zm_sum = my_sum; r.sse_add = sse; r.snm_add = snm; r.clipped_dup = clipped;
-        RcpPair rc; rc.Lf = (float)L; rc.center = (float)clipped * 0.5f; rc.rcpL = 1.0f / rc.Lf; rc.rcpC = 1.0f / rc.center;
-        rcp[my] = rc;
-    }
-    reads[my] = r; ends[my] = r.end;
-    if (indel_cnt && !simple) {
-        const int lib = (int)((r.misc >> 16) & 0xffu) - 1;
-        enumerate_indels(c, in, r, qual_ro + qoff, [&](int32_t p, int, int) { atomicAdd(&indel_cnt[(int64_t)(p - c.pos0) * c.Lp + lib], 1u); });
-    }
-}
-
 // Reference characters -> 4-bit base codes, once per region (the annotator compares codes, bamreadcount.cpp:149-152).
 // A NUL character keeps bit 7 set: the annotator stops at it (:151), which only the serial path reproduces.
 // REFCODE_PAD bytes of padding (code 15) on both sides: an 8-byte window may start before / end after the slice.
@@ -675,6 +347,7 @@ __global__ __launch_bounds__(256) void k_annotate_groups(DevCfg c, DevIn in, DRe
         const int lib = c.per_lib ? (int)in.lib[my] : 0;
         uint32_t misc = (mapq << 8) | ((uint32_t)((lib + 1) & 0xff) << 16);
         if (rev) misc |= M_REV;
+        if (flag & BRC_NOCOUNT_MASK) misc |= M_NOCOUNT;
         if (q2 > -1) misc |= M_Q2OK;
         if (simple) misc |= M_SIMPLE;
         if (tot_d + tot_is <= STAGE_SLACK) misc |= M_STAGED | ((uint32_t)tot_d << 24);
@@ -952,7 +625,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
         // window loads of a batch into registers (W0..W2 = chunks slot, slot+4, slot+8 of the lane's row) ...
 #define BRC_LD_WIN(TT, b0, W0, W1, W2, W3, OK)                                                                          \
         {                                                                                                                 \
-            const int32_t d0 = p0 - TT.pos - (int32_t)(TT.misc >> 24);       /* query offset of the tile start, lower bound */ \
+            const int32_t d0 = p0 - TT.pos - (int32_t)((TT.misc >> 24) & 0x7fu);       /* query offset of the tile start, lower bound */ \
             const uint32_t ws = d0 > 0 ? ((uint32_t)d0 & ~7u) : 0u;                                                       \
             OK = (b0) + row < hi && (TT.misc & M_STAGED) && TT.end > TT.pos && (int32_t)ws < TT.l_qseq + 8 && BRC_MINE(TT.misc); \
             if (OK) {                                                                                                     \
@@ -967,7 +640,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
         // the staging predicate of BRC_LD_WIN again (recomputed at store time so it is not carried through the read loop)
 #define BRC_LD_WIN_OK(TT, b0, OK)                                                                                       \
         {                                                                                                                 \
-            const int32_t d0 = p0 - TT.pos - (int32_t)(TT.misc >> 24);                                                    \
+            const int32_t d0 = p0 - TT.pos - (int32_t)((TT.misc >> 24) & 0x7fu);                                                    \
             const uint32_t ws = d0 > 0 ? ((uint32_t)d0 & ~7u) : 0u;                                                       \
             OK = (b0) + row < hi && (TT.misc & M_STAGED) && TT.end > TT.pos && (int32_t)ws < TT.l_qseq + 8 && BRC_MINE(TT.misc); \
         }
@@ -992,8 +665,8 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
             const int32_t pos_j = BRC_RL(T.pos, j), end_j = BRC_RL(T.end, j);                                             \
             const uint32_t misc_j = (uint32_t)BRC_RL(T.misc, j);                                                          \
             const uint32_t rlib = (misc_j >> 16) & 0xffu;                                                                 \
-            /* a read below the mapping-quality cut can never pass the base-quality test (:288) */                        \
-            S.thr = (int)((misc_j >> 8) & 0xffu) >= c.min_mapq ? c.min_bq : 256;                                          \
+            /* a read below the mapping-quality cut (:288) or carrying SECONDARY/QCFAIL/DUP (:295-310) never passes */                        \
+            S.thr = ((int)((misc_j >> 8) & 0xffu) >= c.min_mapq && !(misc_j & M_NOCOUNT)) ? c.min_bq : 256;                                          \
             S.misc = misc_j;                                                                                              \
             int32_t qpos = pe - pos_j;                                                                                    \
             uint64_t m_in;                                                            /* lanes whose column holds the read */ \
@@ -1037,7 +710,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
                     S.m_pass = c.insertion_centric ? S.m_want & ~m_ins : S.m_want;                                        \
                     const bool want = __builtin_amdgcn_inverse_ballot_w64(S.m_want);                                      \
                     if (misc_j & M_STAGED) {      /* event word from the LDS row */                                       \
-                        const int32_t d0 = p0 - pos_j - (int32_t)(misc_j >> 24);                                          \
+                        const int32_t d0 = p0 - pos_j - (int32_t)((misc_j >> 24) & 0x7fu);                                          \
                         const uint32_t ws = d0 > 0 ? ((uint32_t)d0 & ~7u) : 0u;                                           \
                         const uint32_t e = ((uint32_t)qpos - ws) & 127u;                                                  \
                         S.v = (uint32_t)reinterpret_cast<const uint16_t*>(rows[(j)])[e < (uint32_t)(WIN_U4 * 8) ? e : 0u];  \
@@ -1435,25 +1108,12 @@ class HipBackend : public Backend {
         const DRead* reads = (const DRead*)d_reads.p;
         HIPCHK(hipEventRecord(evt[T_ANNOTATE], stream));
         if (n > 0) {
-            static const char* mode = getenv("BRC_ANNOTATE");   // A/B knob: "serial" | "wave" | "batch" | default group form
-            const bool serial = mode && !strcmp(mode, "serial"), wavef = mode && !strcmp(mode, "wave"), batchf = mode && !strcmp(mode, "batch");
-            if (!serial && !wavef && !batchf) {
-                const int64_t rl = c.ref_hi - c.ref_lo;
-                if (c.has_ref)
-                    hipLaunchKernelGGL(k_refcode, dim3((unsigned)(((rl + 2 * REFCODE_PAD + 15) / 16 + 255) / 256)), dim3(256), 0, stream, in.ref, (uint8_t*)d_refcode.p, rl);
-                hipLaunchKernelGGL(k_annotate_groups, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (int32_t*)d_ends.p,
-                                   (uint16_t*)d_bq.p, (RcpPair*)d_rcp.p, indels ? (uint32_t*)d_cnt.p : (uint32_t*)nullptr,
-                                   in.cigar, in.qual, in.seq4, (const uint8_t*)d_refcode.p + REFCODE_PAD);
-            } else if (batchf)
-                hipLaunchKernelGGL(k_annotate_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (int32_t*)d_ends.p,
-                                   (uint16_t*)d_bq.p, (RcpPair*)d_rcp.p, indels ? (uint32_t*)d_cnt.p : (uint32_t*)nullptr,
-                                   in.cigar, in.qual, in.seq4, in.ref);
-            else if (serial)
-                hipLaunchKernelGGL(k_annotate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (int32_t*)d_ends.p,
-                                   (uint16_t*)d_bq.p, (RcpPair*)d_rcp.p, indels ? (uint32_t*)d_cnt.p : (uint32_t*)nullptr);
-            else
-                hipLaunchKernelGGL(k_annotate_wave, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (int32_t*)d_ends.p,
-                                   (uint16_t*)d_bq.p, (RcpPair*)d_rcp.p, indels ? (uint32_t*)d_cnt.p : (uint32_t*)nullptr);
+            const int64_t rl = c.ref_hi - c.ref_lo;
+            if (c.has_ref)
+                hipLaunchKernelGGL(k_refcode, dim3((unsigned)(((rl + 2 * REFCODE_PAD + 15) / 16 + 255) / 256)), dim3(256), 0, stream, in.ref, (uint8_t*)d_refcode.p, rl);
+            hipLaunchKernelGGL(k_annotate_groups, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (int32_t*)d_ends.p,
+                               (uint16_t*)d_bq.p, (RcpPair*)d_rcp.p, indels ? (uint32_t*)d_cnt.p : (uint32_t*)nullptr,
+                               in.cigar, in.qual, in.seq4, (const uint8_t*)d_refcode.p + REFCODE_PAD);
         }
         HIPCHK(hipEventRecord(evt[T_SCAN_ENDS], stream));
         if ((rc = scan<OpMaxI32, true>((const int32_t*)d_ends.p, (int32_t*)d_prefmax.p, n))) return rc;

@@ -217,8 +217,8 @@ int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
         uint16_t fl = (uint16_t)(s.flag.p[r] & 0x7fffu);
         const int32_t rlen = cigar_rlen(s.cigar.p + s.cig_off.p[r], nc, &s.n_indel_ops);
         const int32_t end = (!(fl & FUNMAP) && nc > 0) ? pos + rlen : pos + 1;           // bam_endpos
-        bool accept = !(fl & (FUNMAP | FSECONDARY | FQCFAIL | FDUP)) && pos >= 0;
-        if (accept) {   // region extent: every read that passes the flag mask (max-count drops included)
+        bool accept = !(fl & FUNMAP) && pos >= 0;      // bam_plp_push (htslib 1.10) skips unmapped reads only
+        if (accept) {   // region extent: every read bam_plp_push takes (max-count drops included)
             if (e->n_ext == 0) { s.min_pos = pos; s.max_end = end; }
             else { if (pos < s.min_pos) s.min_pos = pos; if (end > s.max_end) s.max_end = end; }
             e->n_ext++;

@@ -10,8 +10,11 @@
  *
  * Parity pinning: tests/test_oracle_golden.py checks this file against the reference's own four golden
  * files (test-data/expected_*) byte-for-byte, with the recovered pseudo-reference (tools/make_fixtures.py).
- * Behaviour NOT covered by any reference test ("parity unpinned"): deletions and the
- * pos+1 queue, N/=/X/P/H operators, flag drops, -q/-b thresholds, max-count, SM-tagged reads.
+ * tests/test_ref_compiled.py additionally pins it against the reference's OWN fetch_func / pileup_func / BasicStat /
+ * IndelQueue compiled unmodified into oracle/_ref/ (oracle/ref_shim): text byte-exact over the fuzz families
+ * (all CIGAR operators, flags, -q/-b/-d/-p/-i, SM/NM present or missing, IUPAC / lower-case reference), the five Zm
+ * integers and the 13 raw BasicStat accumulators bit-exact.  What stays restated-only ("parity unpinned") is the
+ * htslib-1.10 pileup iterator underneath (bam_plp_push / bam_plp_next / resolve_cigar2): the shim restates it too.
  *
  * Each function cites the reference lines it follows (paths relative to the reference tree).  The
  * pileup iterator lives in samtools/htslib 1.10 (cmake/BuildSamtools.cmake:3), which is NOT in the
@@ -647,7 +650,7 @@ int brc_compute(brc_engine* e, brc_timing* timing) {
     int64_t lo = e->beg0 > 0 ? e->beg0 - 1 : 0, hi = e->end;
     int64_t rmin = INT64_MAX, rmax = -1;
     for (size_t i = 0; i < e->n_reads; ++i) {
-        if (e->reads[i].flag & (FUNMAP | FSECONDARY | FQCFAIL | FDUP)) continue;   /* never enters the pileup */
+        if (e->reads[i].flag & FUNMAP) continue;   /* never enters the pileup (bam_plp_push, see below) */
         int en = read_endpos(&e->reads[i]);
         if (e->reads[i].pos < rmin) rmin = e->reads[i].pos;
         if (en > rmax) rmax = en;
@@ -672,8 +675,12 @@ int brc_compute(brc_engine* e, brc_timing* timing) {
         if (i < e->n_reads) {
             oread* r = &e->reads[i];
             annotate(e, r);                                                               /* fetch_func :114-256 */
-            /* bam_plp_push */
-            if (r->flag & (FUNMAP | FSECONDARY | FQCFAIL | FDUP)) continue;
+            /* bam_plp_push of htslib 1.10 drops unmapped reads only ("Skip only unmapped reads here, any additional
+             * filtering must be done in iter->func"): SECONDARY / QCFAIL / DUP reads DO enter the column — they create
+             * their library's entry (:286), can abandon a -p position (:281-284) and make a position print — and are
+             * skipped by pileup_func's own flag tests (:295-310).  Pinned by oracle/_ref (reference pileup_func compiled
+             * against the shim iterator); the samtools-0.1.19-era default mask in push is what bam-readcount 0.x had. */
+            if (r->flag & FUNMAP) continue;
             if (it.tid == e->tid && it.pos == r->pos && (int)(it.n + 1) > it.maxcnt) continue;
             if (it.n == it.cap) { it.cap = it.cap ? it.cap * 2 : 1024; it.list = (lnode*)realloc(it.list, it.cap * sizeof(lnode)); }
             lnode* nd = &it.list[it.n++];

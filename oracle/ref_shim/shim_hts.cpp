@@ -1,0 +1,432 @@
+/*
+ * shim_hts.cpp — implementation of the samtools-1.10 / htslib-1.10 API slice declared in sam.h, header.h and
+ * htslib/faidx.h of this directory.  TEST INFRASTRUCTURE ONLY: it exists so that the reference's own sources
+ * (bamreadcount.cpp, BasicStat.cpp, IndelQueue*.cpp) can be compiled unmodified into oracle/_ref/ and used to pin the
+ * C oracle (oracle/brc_oracle.c).  htslib itself is absent here (vendor/samtools-1.10.tar.bz2 is a missing blob of the
+ * reference checkout), so:
+ *   - bam_aux_get / bam_aux2i / bam_aux_append follow the BAM aux wire format (SAMv1 4.2.4);
+ *   - the pileup iterator restates htslib 1.10 sam.c (bam_plp_push, bam_plp_next, resolve_cigar2, bam_endpos) —
+ *     control flow as published (lazy node removal, max_pos gating, max-count rule on mp->cnt), while the per-entry
+ *     CIGAR resolution is written STATELESSLY (a pure function of (cigar, pos)) as a second formulation next to
+ *     the stateful cursor of oracle/brc_oracle.c;
+ *   - samopen / samfetch / sam_index_load3 / fai_* sit on this repository's own BGZF/BAM/BAI/CRAM/FASTA readers
+ *     (bam_readcount_amd/csrc/io/bamio.*), used here purely as a file-format library.
+ */
+#include <limits.h>
+#include <stdio.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../bam_readcount_amd/csrc/io/bamio.h"
+#include "header.h"
+#include "htslib/faidx.h"
+#include "sam.h"
+
+/* ---------------------------------------------------------------- tables */
+
+/* IUPAC character -> 4-bit base code ('=' 0, A 1, C 2, G 4, T 8, N and anything else 15, '0'..'3' -> 1,2,4,8) */
+extern "C" const unsigned char seq_nt16_table[256] = {
+    15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15,
+    15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15,
+    15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15,
+     1,  2,  4,  8, 15, 15, 15, 15, 15, 15, 15, 15, 15,  0, 15, 15,
+    15,  1, 14,  2, 13, 15, 15,  4, 11, 15, 15, 12, 15,  3, 15, 15,
+    15, 15,  5,  6,  8, 15,  7,  9, 15, 10, 15, 15, 15, 15, 15, 15,
+    15,  1, 14,  2, 13, 15, 15,  4, 11, 15, 15, 12, 15,  3, 15, 15,
+    15, 15,  5,  6,  8, 15,  7,  9, 15, 10, 15, 15, 15, 15, 15, 15,
+    15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15,
+    15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15,
+    15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15,
+    15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15,
+    15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15,
+    15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15,
+    15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15,
+    15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15};
+
+/* ---------------------------------------------------------------- aux fields */
+
+static int aux_type_size(int t) {
+    switch (t) { case 'A': case 'c': case 'C': return 1; case 's': case 'S': return 2; case 'i': case 'I': case 'f': return 4; case 'd': return 8; default: return 0; }
+}
+static const uint8_t* aux_skip(const uint8_t* s, const uint8_t* end) {
+    if (s >= end) return end;
+    const int t = *s++;
+    if (t == 'Z' || t == 'H') { while (s < end && *s) ++s; return s < end ? s + 1 : end; }
+    if (t == 'B') {
+        if (s + 5 > end) return end;
+        const int sz = aux_type_size(*s); uint32_t n; memcpy(&n, s + 1, 4);
+        s += 5 + (size_t)sz * n;
+        return s > end ? end : s;
+    }
+    const int sz = aux_type_size(t);
+    if (!sz) return end;
+    return s + sz > end ? end : s + sz;
+}
+extern "C" uint8_t* bam_aux_get(const bam1_t* b, const char tag[2]) {
+    const uint8_t* s = bam1_aux(b);
+    const uint8_t* end = b->data + b->l_data;
+    while (s + 3 <= end) {
+        if (s[0] == (uint8_t)tag[0] && s[1] == (uint8_t)tag[1]) return (uint8_t*)s + 2;   // points at the type byte
+        s = aux_skip(s + 2, end);
+    }
+    return 0;
+}
+extern "C" int64_t bam_aux2i(const uint8_t* s) {
+    const int t = *s++;
+    switch (t) {
+        case 'c': return (int8_t)*s;
+        case 'C': return *s;
+        case 's': { int16_t v; memcpy(&v, s, 2); return v; }
+        case 'S': { uint16_t v; memcpy(&v, s, 2); return v; }
+        case 'i': { int32_t v; memcpy(&v, s, 4); return v; }
+        case 'I': { uint32_t v; memcpy(&v, s, 4); return v; }
+        default: return 0;
+    }
+}
+extern "C" int bam_aux_append(bam1_t* b, const char tag[2], char type, int len, const uint8_t* data) {
+    const uint32_t need = (uint32_t)b->l_data + 3u + (uint32_t)len;
+    if (need > b->m_data) {
+        uint32_t m = b->m_data ? b->m_data : 64; while (m < need) m <<= 1;
+        b->data = (uint8_t*)realloc(b->data, m); b->m_data = m;
+    }
+    b->data[b->l_data] = (uint8_t)tag[0]; b->data[b->l_data + 1] = (uint8_t)tag[1]; b->data[b->l_data + 2] = (uint8_t)type;
+    memcpy(b->data + b->l_data + 3, data, (size_t)len);
+    b->l_data += 3 + len;
+    return 0;
+}
+
+/* ---------------------------------------------------------------- pileup iterator */
+
+static inline bool refop(int op) { return op == BAM_CMATCH || op == BAM_CDEL || op == BAM_CREF_SKIP || op == BAM_CEQUAL || op == BAM_CDIFF; }
+static inline bool mop(int op) { return op == BAM_CMATCH || op == BAM_CEQUAL || op == BAM_CDIFF; }
+
+static hts_pos_t shim_endpos(const bam1_t* b) {   // bam_endpos: rlen 0 (or unmapped) counts as 1
+    hts_pos_t l = 0;
+    if (!(b->core.flag & BAM_FUNMAP) && b->core.n_cigar > 0) {
+        const uint32_t* c = bam1_cigar(b);
+        for (uint32_t k = 0; k < b->core.n_cigar; ++k) if (refop(c[k] & 0xf)) l += c[k] >> 4;
+    }
+    return b->core.pos + (l ? l : 1);
+}
+
+/* resolve_cigar2 as a pure function of the position: which operator holds `pos`, the query offset there, and what the
+ * last reference base of an operator sees ahead (D -> -len, I -> +len, P...I -> +sum of I).  Returns false when no
+ * reference-consuming operator covers pos. */
+static bool resolve_stateless(const bam1_t* b, hts_pos_t pos, bam_pileup1_t* p) {
+    const uint32_t* c = bam1_cigar(b); const int n = (int)b->core.n_cigar;
+    hts_pos_t x = b->core.pos; int y = 0;
+    if (n == 1 && !mop(c[0] & 0xf)) return false;    // htslib asserts here; nothing to stand on
+    for (int k = 0; k < n; ++k) {
+        const int op = c[k] & 0xf, l = c[k] >> 4;
+        if (refop(op)) {
+            if (pos >= x && pos < x + l) {
+                p->is_del = p->is_refskip = 0; p->indel = 0;
+                if (mop(op)) p->qpos = y + (int)(pos - x);
+                else { p->is_del = 1; p->qpos = y; p->is_refskip = (op == BAM_CREF_SKIP); }
+                if (pos == x + l - 1 && k + 1 < n) {
+                    const int op2 = c[k + 1] & 0xf, l2 = c[k + 1] >> 4;
+                    if (op2 == BAM_CDEL) p->indel = -l2;
+                    else if (op2 == BAM_CINS) p->indel = l2;
+                    else if (op2 == BAM_CPAD && k + 2 < n) {
+                        int l3 = 0;
+                        for (int j = k + 2; j < n; ++j) {
+                            const int o = c[j] & 0xf;
+                            if (o == BAM_CINS) l3 += c[j] >> 4;
+                            else if (o == BAM_CDEL || o == BAM_CMATCH || o == BAM_CREF_SKIP || o == BAM_CEQUAL || o == BAM_CDIFF) break;
+                        }
+                        if (l3 > 0) p->indel = l3;
+                    }
+                }
+                return true;
+            }
+            x += l;
+            if (mop(op)) y += l;
+        } else if (op == BAM_CINS || op == BAM_CSOFT_CLIP) y += l;
+    }
+    return false;
+}
+
+struct PlpNode { bam1_t b; hts_pos_t beg, end; };
+struct __bam_plp_t {
+    std::vector<PlpNode*> list;          // head..tail (without htslib's spare tail node)
+    std::vector<bam_pileup1_t> plp;
+    int tid = 0, max_tid = -1; hts_pos_t pos = 0, max_pos = -1;
+    int is_eof = 0, maxcnt = 8000;
+};
+static void node_free(PlpNode* n) { free(n->b.data); delete n; }
+
+extern "C" void bam_plp_set_maxcnt(bam_plp_t iter, int maxcnt) { iter->maxcnt = maxcnt; }
+
+static int plp_push(bam_plp_t it, const bam1_t* b) {
+    if (b) {
+        if (b->core.tid < 0) return 0;
+        if (b->core.flag & BAM_FUNMAP) return 0;   // htslib 1.10: "Skip only unmapped reads here, any additional filtering must be done in iter->func"
+        // mp->cnt counts live nodes plus the spare tail node: cnt > maxcnt  <=>  live >= maxcnt
+        if (it->tid == b->core.tid && it->pos == b->core.pos && (int)it->list.size() + 1 > it->maxcnt) return 0;
+        PlpNode* n = new PlpNode();
+        n->b = *b;
+        n->b.data = (uint8_t*)malloc((size_t)(b->l_data > 0 ? b->l_data : 1));
+        memcpy(n->b.data, b->data, (size_t)b->l_data);
+        n->b.m_data = (uint32_t)b->l_data;
+        n->beg = b->core.pos; n->end = shim_endpos(b);
+        it->max_tid = b->core.tid; it->max_pos = n->beg;
+        it->list.push_back(n);
+    } else it->is_eof = 1;
+    return 0;
+}
+
+static const bam_pileup1_t* plp_next(bam_plp_t it, int* tid, int* pos, int* n_out) {
+    *n_out = 0;
+    if (it->is_eof && it->list.empty()) return 0;
+    while (it->is_eof || it->max_tid > it->tid || (it->max_tid == it->tid && it->max_pos > it->pos)) {
+        int n_plp = 0; size_t w = 0;
+        it->plp.clear();
+        for (size_t i = 0; i < it->list.size(); ++i) {
+            PlpNode* p = it->list[i];
+            if (p->b.core.tid < it->tid || (p->b.core.tid == it->tid && p->end <= it->pos)) { node_free(p); continue; }
+            if (p->b.core.tid == it->tid && p->beg <= it->pos) {
+                bam_pileup1_t e; memset(&e, 0, sizeof e);
+                e.b = &p->b;
+                if (resolve_stateless(&p->b, it->pos, &e)) {
+                    e.is_head = (it->pos == p->beg); e.is_tail = (it->pos == p->end - 1);
+                    it->plp.push_back(e); ++n_plp;
+                }
+            }
+            it->list[w++] = p;
+        }
+        it->list.resize(w);
+        *n_out = n_plp; *tid = it->tid; *pos = (int)it->pos;
+        if (!it->list.empty()) {
+            PlpNode* h = it->list[0];
+            if (it->tid < h->b.core.tid) { it->tid = h->b.core.tid; it->pos = h->beg; }
+            else if (it->pos < h->beg) it->pos = h->beg;
+            else ++it->pos;
+        } else ++it->pos;
+        if (n_plp) return it->plp.data();
+        if (it->is_eof && it->list.empty()) break;
+    }
+    *n_out = 0;
+    return 0;
+}
+
+extern "C" bam_plbuf_t* bam_plbuf_init(bam_pileup_f func, void* data) {
+    bam_plbuf_t* buf = (bam_plbuf_t*)calloc(1, sizeof(bam_plbuf_t));
+    buf->iter = new __bam_plp_t();
+    buf->func = func; buf->data = data;
+    return buf;
+}
+extern "C" void bam_plbuf_destroy(bam_plbuf_t* buf) {
+    if (!buf) return;
+    for (size_t i = 0; i < buf->iter->list.size(); ++i) node_free(buf->iter->list[i]);
+    delete buf->iter;
+    free(buf);
+}
+extern "C" int bam_plbuf_push(const bam1_t* b, bam_plbuf_t* buf) {
+    int ret, n_plp, tid, pos;
+    const bam_pileup1_t* plp;
+    ret = plp_push(buf->iter, b);
+    if (ret < 0) return ret;
+    while ((plp = plp_next(buf->iter, &tid, &pos, &n_plp)) != 0) buf->func((uint32_t)tid, (uint32_t)pos, n_plp, plp, buf->data);
+    return 0;
+}
+
+/* ---------------------------------------------------------------- header, files, index (on bamio) */
+
+struct htsFile {
+    std::string path, fai_path;
+    bool is_cram = false, opened = false;
+    brcio::BamReader bam;
+    brcio::CramReader* cram = 0;
+    brcio::Fasta fasta;
+};
+struct hts_idx_t { brcio::BamIndex idx; bool none = false; };
+struct faidx_shim_t { brcio::Fasta fa; };
+
+static bam_hdr_t* make_header(const brcio::BamHeader& h) {
+    bam_hdr_t* o = (bam_hdr_t*)calloc(1, sizeof(bam_hdr_t));
+    o->n_targets = (int32_t)h.names.size();
+    o->target_len = (uint32_t*)calloc(h.names.size() + 1, 4);
+    o->target_name = (char**)calloc(h.names.size() + 1, sizeof(char*));
+    for (size_t i = 0; i < h.names.size(); ++i) { o->target_len[i] = (uint32_t)h.lengths[i]; o->target_name[i] = strdup(h.names[i].c_str()); }
+    o->l_text = h.text.size(); o->text = strdup(h.text.c_str());
+    o->shim = new brcio::BamHeader(h);
+    return o;
+}
+static void free_header(bam_hdr_t* o) {
+    if (!o) return;
+    for (int i = 0; i < o->n_targets; ++i) free(o->target_name[i]);
+    free(o->target_name); free(o->target_len); free(o->text);
+    delete (brcio::BamHeader*)o->shim;
+    free(o);
+}
+
+static bool ensure_open(samfile_t* fp) {
+    htsFile* f = fp->file;
+    if (f->opened) return true;
+    if (f->is_cram) {
+        if (f->fai_path.empty()) { fprintf(stderr, "[shim] CRAM input needs a reference\n"); return false; }
+        std::string fa = f->fai_path; if (fa.size() > 4 && fa.compare(fa.size() - 4, 4, ".fai") == 0) fa.resize(fa.size() - 4);
+        if (!f->fasta.open(fa)) return false;
+        f->cram = new brcio::CramReader();
+        if (!f->cram->open(f->path, &f->fasta)) return false;
+    }
+    f->opened = true;
+    return true;
+}
+
+extern "C" samfile_t* samopen(const char* fn, const char* mode, const void*) {
+    if (!fn || !mode || mode[0] != 'r') return 0;
+    samfile_t* fp = (samfile_t*)calloc(1, sizeof(samfile_t));
+    fp->file = new htsFile();
+    fp->file->path = fn;
+    fp->file->is_cram = brcio::CramReader::is_cram(fn);
+    if (!fp->file->is_cram) {
+        if (!fp->file->bam.open(fn)) { delete fp->file; free(fp); return 0; }
+        fp->file->opened = true;
+        fp->header = make_header(fp->file->bam.header());
+    } else {
+        // the header of a CRAM needs no reference: open a header-only view with a throw-away reader
+        brcio::CramReader probe;
+        if (!probe.open(fn, 0)) { delete fp->file; free(fp); return 0; }
+        fp->header = make_header(probe.header());
+    }
+    return fp;
+}
+extern "C" void samclose(samfile_t* fp) {
+    if (!fp) return;
+    free_header(fp->header);
+    delete fp->file->cram;
+    delete fp->file;
+    free(fp);
+}
+extern "C" int hts_set_fai_filename(htsFile* fp, const char* fn_aux) { fp->fai_path = fn_aux ? fn_aux : ""; return 0; }
+extern "C" char* samfaipath(const char* fn_ref) {
+    if (!fn_ref) return 0;
+    std::string p = std::string(fn_ref) + ".fai";
+    FILE* f = fopen(p.c_str(), "rb");
+    if (!f) { fprintf(stderr, "[shim samfaipath] %s not found (the shim does not build indexes)\n", p.c_str()); return 0; }
+    fclose(f);
+    return strdup(p.c_str());
+}
+extern "C" hts_idx_t* sam_index_load3(htsFile* fp, const char* fn, const char*, int) {
+    hts_idx_t* x = new hts_idx_t();
+    if (fp->is_cram) { x->none = true; return x; }      // the CRAM reader scans its own container index
+    if (!x->idx.load(fn)) { delete x; return 0; }
+    return x;
+}
+extern "C" void hts_idx_destroy(hts_idx_t* idx) { delete idx; }
+
+static void to_bam1(const brcio::BamRecord& r, bam1_t* b) {
+    memset(&b->core, 0, sizeof b->core);
+    b->core.pos = r.pos; b->core.tid = r.tid; b->core.bin = r.bin; b->core.qual = r.mapq; b->core.flag = r.flag;
+    b->core.l_qname = (uint16_t)r.l_qname; b->core.n_cigar = r.n_cigar; b->core.l_qseq = r.l_seq;
+    b->core.mtid = r.mtid; b->core.mpos = r.mpos; b->core.isize = r.tlen;
+    if (b->m_data < r.data.size() + 64) { b->m_data = (uint32_t)r.data.size() + 64; b->data = (uint8_t*)realloc(b->data, b->m_data); }
+    memcpy(b->data, r.data.data(), r.data.size());
+    b->l_data = (int)r.data.size();
+}
+
+extern "C" int samfetch(samfile_t* fp, const hts_idx_t* idx, int tid, int beg, int end, void* data, bam_fetch_f func) {
+    if (!ensure_open(fp)) return -1;
+    bam1_t b; memset(&b, 0, sizeof b);
+    auto cb = [&](const brcio::BamRecord& r) { to_bam1(r, &b); func(&b, data); };
+    bool ok;
+    if (fp->file->is_cram) ok = fp->file->cram->fetch(tid, beg, end, cb);
+    else ok = fp->file->bam.fetch(idx->idx, tid, beg, end, cb);
+    free(b.data);
+    return ok ? 0 : -1;
+}
+extern "C" int sampileup(samfile_t*, int, bam_pileup_f, void*) {
+    fprintf(stderr, "[shim] whole-file mode (sampileup) is not provided: the reference itself marks it broken (bamreadcount.cpp:624)\n");
+    return -1;
+}
+
+/* samtools legacy bam_parse_region -> hts_parse_reg: "chr", "chr:beg", "chr:beg-end"; commas ignored; 1-based inclusive
+ * begin becomes 0-based; a bare name covers [0, INT_MAX) */
+extern "C" int bam_parse_region(bam_header_t* header, const char* str, int* ref_id, int* begin, int* end) {
+    std::string s;
+    for (const char* p = str; *p; ++p) if (*p != ',' && !isspace((unsigned char)*p)) s += *p;
+    const brcio::BamHeader* h = (const brcio::BamHeader*)header->shim;
+    *ref_id = -1; *begin = 0; *end = INT_MAX;
+    std::string name = s; long long b = 0, e = INT_MAX;
+    const size_t colon = s.rfind(':');
+    std::map<std::string, int>::const_iterator it = h->name2tid.find(s);
+    if (it == h->name2tid.end() && colon != std::string::npos) {
+        name = s.substr(0, colon);
+        const std::string rng = s.substr(colon + 1);
+        char* q = 0;
+        b = strtoll(rng.c_str(), &q, 10);
+        if (b > 0) --b; else b = 0;
+        if (*q == '-') { e = strtoll(q + 1, &q, 10); if (e <= 0) e = INT_MAX; }
+        else if (q != rng.c_str()) e = INT_MAX;
+        it = h->name2tid.find(name);
+    }
+    if (it == h->name2tid.end()) return -1;
+    if (b > e) return -1;
+    *ref_id = it->second; *begin = (int)b; *end = (int)(e > INT_MAX ? INT_MAX : e);
+    return 0;
+}
+
+/* samtools legacy bam_get_library: LB of the @RG line named by the read's RG:Z tag; NULL when either is missing */
+extern "C" const char* bam_get_library(bam_header_t* header, const bam1_t* b) {
+    static std::string buf;      // the legacy API returns a static buffer too
+    const uint8_t* rg = bam_aux_get(b, "RG");
+    if (!rg || *rg != 'Z') return 0;
+    const brcio::BamHeader* h = (const brcio::BamHeader*)header->shim;
+    std::map<std::string, std::string>::const_iterator it = h->rg2lb.find((const char*)(rg + 1));
+    if (it == h->rg2lb.end()) return 0;
+    buf = it->second;
+    return buf.c_str();
+}
+
+/* sam_hdr_parse, reduced to what find_library_names walks: every @RG line as a linked list of its tags in file order */
+extern "C" sam_hdr_t* sam_hdr_parse(size_t l_text, const char* text) {
+    sam_hdr_t* hd = (sam_hdr_t*)calloc(1, sizeof(sam_hdr_t));
+    hd->hrecs = (sam_hrecs_t*)calloc(1, sizeof(sam_hrecs_t));
+    std::vector<sam_hrec_rg_t> rgs;
+    std::string all(text ? text : "", text ? l_text : 0);
+    size_t p = 0;
+    while (p < all.size()) {
+        size_t e = all.find('\n', p); if (e == std::string::npos) e = all.size();
+        std::string line = all.substr(p, e - p); p = e + 1;
+        if (!line.empty() && line[line.size() - 1] == '\r') line.resize(line.size() - 1);
+        if (line.compare(0, 3, "@RG") != 0) continue;
+        sam_hrec_type_t* ty = (sam_hrec_type_t*)calloc(1, sizeof(sam_hrec_type_t));
+        sam_hrec_tag_t* last = 0;
+        size_t q = 3;
+        while (q < line.size()) {
+            if (line[q] == '\t') { ++q; continue; }
+            size_t t = line.find('\t', q); if (t == std::string::npos) t = line.size();
+            sam_hrec_tag_t* tag = (sam_hrec_tag_t*)calloc(1, sizeof(sam_hrec_tag_t));
+            char* s = strdup(line.substr(q, t - q).c_str());
+            tag->str = s; tag->len = (int)(t - q);
+            if (last) last->next = tag; else ty->tag = tag;
+            last = tag; q = t;
+        }
+        if (!ty->tag) { free(ty); continue; }
+        sam_hrec_rg_t rg; memset(&rg, 0, sizeof rg); rg.ty = ty; rg.id = (int)rgs.size();
+        rgs.push_back(rg);
+    }
+    hd->hrecs->nrg = (int)rgs.size();
+    hd->hrecs->rg = (sam_hrec_rg_t*)calloc(rgs.size() + 1, sizeof(sam_hrec_rg_t));
+    for (size_t i = 0; i < rgs.size(); ++i) hd->hrecs->rg[i] = rgs[i];
+    return hd;   // the reference never frees it (bamreadcount.cpp:94)
+}
+
+/* ---------------------------------------------------------------- faidx */
+extern "C" faidx_t* fai_load(const char* fn) {
+    faidx_shim_t* f = new faidx_shim_t();
+    if (!f->fa.open(fn)) { delete f; return 0; }
+    return f;
+}
+extern "C" void fai_destroy(faidx_t* fai) { delete fai; }
+extern "C" char* fai_fetch(const faidx_t* fai, const char* reg, int* len) {
+    std::string seq;
+    if (!const_cast<faidx_shim_t*>(fai)->fa.fetch(reg, &seq)) { *len = -2; return 0; }
+    char* s = (char*)malloc(seq.size() + 1);
+    memcpy(s, seq.data(), seq.size()); s[seq.size()] = 0;
+    *len = (int)seq.size();
+    return s;
+}

@@ -47,3 +47,18 @@ def test_bam():
 @pytest.fixture(scope="session")
 def twolib():
     return load_fixture("twolib.npz")
+
+
+@pytest.fixture(scope="session")
+def workdir(tmp_path_factory, test_bam):
+    d = tmp_path_factory.mktemp("cli")
+    ref = test_bam["ref"]
+    n = ref.size; L = 60; rows = (n + L - 1) // L
+    pad = np.full(rows * L, ord("\n"), np.uint8); pad[:n] = ref
+    body = np.concatenate([pad.reshape(rows, L), np.full((rows, 1), 10, np.uint8)], axis=1).tobytes()
+    with open(d / "ref.fa", "wb") as f:
+        f.write(b">21\n"); f.write(body)
+    open(d / "ref.fa.fai", "w").write("21\t%d\t4\t60\t61\n" % n)      # same index line as test-data/ref.fa.fai
+    for f in ("test.bam", "test.bam.bai", "test_bad_rg.bam", "test_bad_rg.bam.bai", "site_list"):
+        os.symlink(os.path.join(GOLDEN, f), d / f)
+    return d

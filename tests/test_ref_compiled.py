@@ -1,0 +1,336 @@
+"""Pins the C oracle (and through it everything else) against the REFERENCE'S OWN SOURCES compiled here.
+
+oracle/ref_shim/ compiles /root/reference/src/exe/bam-readcount/bamreadcount.cpp (fetch_func, pileup_func, main) and
+src/lib/bamrc/{BasicStat,IndelQueue,IndelQueueEntry}.cpp UNMODIFIED into oracle/_ref/ against a shim of the
+samtools-1.10 / htslib-1.10 API (the only part that is not the reference's own code: htslib is a missing blob).
+
+  * the reference's main() reproduces its own four golden files on the six integration commands;
+  * oracle text == reference-compiled text, byte for byte, over the fuzz families (every CIGAR operator, flagged reads,
+    -q/-b/-d/-p/-i, SM/NM present or missing, IUPAC / lower-case reference, queue kept or cleared);
+  * the five Zm integers of fetch_func: SURVEY Appendix-B known answers;
+  * the 13 raw BasicStat accumulators (IEEE bits) and operator<< text: oracle planes vs BasicStat::process_read;
+  * the reference's unit KATs re-expressed: test/lib/bamrc/TestIndelQueue.cpp:21-88, TestIndelQueueEntry.cpp:24-34,
+    TestAuxFields.cpp:9-48, TestReadWarnings.cpp:36-71.
+
+The prebuilt oracle/_ref files travel to boxes without /root/reference; where neither exists the tests skip."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from bam_readcount_amd import capi
+from conftest import GOLDEN, ROOT
+import parity
+import synth
+
+REF_TREE = "/root/reference"
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+REF_LIB = os.path.join(REF_DIR, "libbamrc_ref.so")
+REF_CLI = os.path.join(REF_DIR, "bam-readcount-ref")
+
+
+@pytest.fixture(scope="session")
+def ref_lib():
+    if os.path.isdir(REF_TREE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle", "ref_shim")])
+    if not os.path.exists(REF_LIB):
+        pytest.skip("oracle/_ref not built and no reference checkout here")
+    lib = capi.Library(REF_LIB)
+    assert lib.kind() == "reference-compiled"
+    L = lib.lib
+    L.bamrc_ref_annotate.argtypes = [C.POINTER(capi.ReadBatch), C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+    L.bamrc_ref_basicstat.argtypes = [C.POINTER(capi.ReadBatch), C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_void_p,
+                                      C.c_void_p, C.POINTER(capi.Stat), C.c_char_p, C.c_size_t, C.c_void_p]
+    L.bamrc_ref_queue_new.restype = C.c_void_p
+    L.bamrc_ref_queue_free.argtypes = [C.c_void_p]
+    L.bamrc_ref_queue_push.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_char_p]
+    L.bamrc_ref_queue_size.argtypes = [C.c_void_p]; L.bamrc_ref_queue_size.restype = C.c_size_t
+    L.bamrc_ref_queue_process.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t]
+    L.bamrc_ref_zm_roundtrip.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p]
+    L.bamrc_ref_readwarnings.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.c_char_p, C.c_size_t]
+    L.bamrc_ref_set_max_warnings.argtypes = [C.c_void_p, C.c_int64]
+    L.bamrc_ref_warnings.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
+    return lib
+
+
+# ---------------------------------------------------------------- the reference's main() on its own integration tests
+
+def test_reference_main_reproduces_its_goldens(ref_lib, workdir):
+    from test_cli import RUNS, run_cli
+    for exp, bam, extra, how in RUNS:
+        rc, out, err = run_cli(REF_CLI, workdir, bam, extra, how)
+        assert rc == 0, err
+        assert out == open(os.path.join(GOLDEN, exp), "rb").read(), (exp, bam, extra, how)
+        assert "Minimum mapping quality is set to 0" in err
+
+
+# ---------------------------------------------------------------- oracle text == reference-compiled text
+
+FUZZ = [
+    dict(seed=1, style="simple", n=300, opts=dict()),
+    dict(seed=2, style="indel", n=400, opts=dict()),
+    dict(seed=3, style="wild", n=400, opts=dict()),
+    dict(seed=4, style="wild", n=400, opts=dict(min_mapq=20, min_bq=13)),
+    dict(seed=5, style="mixed", n=500, opts=dict(insertion_centric=True)),
+    dict(seed=6, style="wild", n=400, opts=dict(per_lib=True), n_libs=3),
+    dict(seed=7, style="wild", n=400, opts=dict(per_lib=True, insertion_centric=True, min_mapq=10, min_bq=5), n_libs=4, p_nolib=0.01),
+    dict(seed=8, style="mixed", n=600, opts=dict(per_lib=True), n_libs=2, p_nolib=0.2),
+    dict(seed=9, style="wild", n=300, opts=dict(min_bq=30), weird=0.1),
+    dict(seed=10, style="indel", n=50, opts=dict()),
+    # flagged reads (SECONDARY / QCFAIL / DUP stay in the column, UNMAP does not), heavy
+    dict(seed=11, style="mixed", n=400, opts=dict(), p_flagdrop=0.4),
+    dict(seed=12, style="wild", n=400, opts=dict(per_lib=True, insertion_centric=True), n_libs=3, p_flagdrop=0.4, p_nolib=0.02),
+    # max-count
+    dict(seed=13, style="indel", n=500, opts=dict(max_cnt=1)),
+    dict(seed=14, style="mixed", n=500, opts=dict(max_cnt=5)),
+    dict(seed=15, style="wild", n=500, opts=dict(max_cnt=40, min_mapq=1)),
+    # tags: nothing / everything
+    dict(seed=16, style="indel", n=300, opts=dict(), p_nonm=1.0, p_sm=0.0),
+    dict(seed=17, style="indel", n=300, opts=dict(min_bq=20), p_nonm=0.0, p_sm=1.0),
+]
+
+
+def fuzz_inputs(case, ref_len=3000, tail=400):
+    """Reads start inside [0, ref_len); the reference is `tail` bases longer so that no read and no deletion allele
+    reaches its end: past the end the reference reads unowned memory (bamreadcount.cpp:149,337 — undefined behaviour,
+    where the oracle substitutes NUL / 'N')."""
+    rng = np.random.default_rng(case["seed"])
+    ref = synth.make_ref(rng, ref_len + tail, weird=case.get("weird", 0.0))
+    n_libs = case.get("n_libs", 1)
+    kw = {k: case[k] for k in ("p_flagdrop", "p_nonm", "p_sm") if k in case}
+    arrs = synth.make_batch(case["seed"] + 100, ref, case["n"], style=case["style"], n_libs=n_libs, p_nolib=case.get("p_nolib", 0.0),
+                            region=(0, ref_len), **kw)
+    names = ["lib%c" % (65 + i) for i in range(n_libs)] if case["opts"].get("per_lib") else ()
+    return ref, arrs, names
+
+
+@pytest.mark.parametrize("case", FUZZ, ids=lambda c: "seed%d-%s" % (c["seed"], c["style"]))
+def test_oracle_text_equals_reference_compiled(oracle_lib, ref_lib, case):
+    ref, arrs, names = fuzz_inputs(case)
+    regions = [(0, 3000), (100, 101), (700, 1500), (1490, 1700), (2990, 3200), (1500, 1500)]
+    for clear_queue, site_mode in ((True, True), (False, False)):
+        ta, _ = parity.run_engine(oracle_lib, arrs, regions, ref=ref, lib_names=names, clear_queue=clear_queue, ref_len_check=site_mode, **case["opts"])
+        tb, _ = parity.run_engine(ref_lib, arrs, regions, ref=ref, lib_names=names, clear_queue=clear_queue, ref_len_check=site_mode, **case["opts"])
+        assert len(ta) > 1000
+        assert ta == tb, "oracle and reference-compiled text differ (clear_queue=%r)" % clear_queue
+
+
+# (no-reference runs cannot be pinned: without -f the reference dereferences a NULL `ref` in fetch_func,
+# bamreadcount.cpp:117,149 — it crashes on the first M operator.  The engines define that case: no mismatch qualities, no alleles, 'N'.)
+
+
+def test_oracle_equals_reference_compiled_on_test_bam_full_window(oracle_lib, ref_lib, test_bam):
+    names = [str(s) for s in test_bam["lib_names"]]
+    for per_lib in (False, True):
+        for ic in (False, True):
+            kw = dict(tid=20, chrom="21", ref=test_bam["ref"], lib_names=names if per_lib else (), per_lib=per_lib, insertion_centric=ic)
+            ta, _ = parity.run_engine(oracle_lib, test_bam, [(10402736, 10405248)], **kw)
+            tb, _ = parity.run_engine(ref_lib, test_bam, [(10402736, 10405248)], **kw)
+            assert ta == tb and ta.count(b"\n") == 796
+
+
+# ---------------------------------------------------------------- fetch_func: the five Zm integers
+
+APPENDIX_B = {0: (0, 250, 0, 248, 248), 1: (8, 250, 0, 234, 234), 2: (2, 250, 0, 17, 17), 4: (29, 250, 0, 83, 83),
+              9: (9, 247, 0, 245, 245), 10: (38, 242, 8, 8, -1), 17: (12, 237, 13, 63, 63), 41: (6, 230, 0, 173, 173)}
+
+
+def ref_annotate(ref_lib, arrs, ref, check=0):
+    b, keep = capi.make_batch(arrs)
+    zm = np.zeros(5 * len(arrs["pos"]), np.int32)
+    r = np.ascontiguousarray(ref, np.uint8)
+    assert ref_lib.lib.bamrc_ref_annotate(C.byref(b), r.ctypes.data, r.size, check, zm.ctypes.data) == 0
+    return zm.reshape(-1, 5)
+
+
+def test_reference_fetch_func_known_answers(ref_lib, test_bam):
+    zm = ref_annotate(ref_lib, test_bam, test_bam["ref"])
+    for rec, want in APPENDIX_B.items():
+        assert tuple(int(x) for x in zm[rec]) == want, rec
+
+
+# ---------------------------------------------------------------- BasicStat::process_read + operator<<, raw accumulators
+
+def column_events(arrs, p, min_mapq=0, min_bq=0):
+    """(read, qpos, bucket) of every counted event at position p for M-only reads, in column (= file) order."""
+    canon = [0, 1, 2, 5, 3, 5, 5, 5, 4, 5, 5, 5, 5, 5, 5, 5]
+    ev = []
+    for i in range(len(arrs["pos"])):
+        pos, L, fl = int(arrs["pos"][i]), int(arrs["l_qseq"][i]), int(arrs["flag"][i])
+        if not (pos <= p < pos + L) or (fl & 4):
+            continue
+        q = p - pos
+        if int(arrs["mapq"][i]) < min_mapq or int(arrs["qual"][int(arrs["qual_off"][i]) + q]) < min_bq or (fl & (256 | 512 | 1024)):
+            continue
+        b4 = (int(arrs["seq4"][int(arrs["seq_off"][i]) + (q >> 1)]) >> ((~q & 1) << 2)) & 15
+        ev.append((i, q, canon[b4]))
+    return ev
+
+
+def ref_basicstat(ref_lib, arrs, ref, events, with_zm=1, is_indel=0):
+    b, keep = capi.make_batch(arrs)
+    r = np.ascontiguousarray(ref, np.uint8)
+    er = np.array([e[0] for e in events], np.int32); eq = np.array([e[1] for e in events], np.int32)
+    st = capi.Stat(); text = C.create_string_buffer(512); warn = np.zeros(3, np.uint64)
+    assert ref_lib.lib.bamrc_ref_basicstat(C.byref(b), r.ctypes.data, r.size, with_zm, is_indel, len(events), er.ctypes.data, eq.ctypes.data,
+                                           C.byref(st), text, 512, warn.ctypes.data) == 0
+    return np.array(st.i[:], np.uint32), np.array(st.f[:], np.float32), text.value, [int(x) for x in warn]
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(min_mapq=20, min_bq=13)], ids=["q0b0", "q20b13"])
+def test_oracle_raw_sums_equal_reference_basicstat(oracle_lib, ref_lib, opts):
+    ref, arrs, _ = fuzz_inputs(dict(seed=31, style="simple", n=500, opts={}, p_flagdrop=0.1))
+    text, res = parity.run_engine(oracle_lib, arrs, [(0, 3000)], ref=ref, **opts)
+    r = res[0]
+    lines = {int(l.split(b"\t")[1]): l for l in text.split(b"\n") if l}
+    checked = 0
+    for p in range(40, 2960, 37):
+        ev = column_events(arrs, p, **opts)
+        k = p - r.pos0
+        for b in range(6):
+            sub = [(i, q) for (i, q, bb) in ev if bb == b]
+            ii, ff, txt, _ = ref_basicstat(ref_lib, arrs, ref, sub)
+            np.testing.assert_array_equal(ii, r.istat[0, b, :, k], err_msg="pos %d bucket %d" % (p, b))
+            np.testing.assert_array_equal(ff.view(np.uint32), r.fstat[0, b, :, k].view(np.uint32), err_msg="pos %d bucket %d floats" % (p, b))
+            assert (b"\t" + b"=ACGTN"[b:b + 1] + b":" + txt) in lines[p + 1]                  # operator<< (BasicStat.cpp:110-159)
+            checked += len(sub)
+    assert checked > 400
+
+
+def test_reference_basicstat_missing_tags_and_indel_flag(oracle_lib, ref_lib):
+    ref, arrs, _ = fuzz_inputs(dict(seed=32, style="simple", n=60, opts={}, p_nonm=0.5, p_sm=0.3))
+    ev = [(i, int(arrs["l_qseq"][i]) // 2) for i in range(60)]
+    ii, ff, txt, warn = ref_basicstat(ref_lib, arrs, ref, ev, with_zm=0)
+    assert warn[2] == 60 and ii[capi.I_NAMES.index("smmq")] == 0 and ii[capi.I_NAMES.index("sclip")] == 0     # Zm missing: BasicStat.cpp:73-75
+    assert warn[1] == int(((arrs["tags"] & 1) == 0).sum())
+    assert warn[0] == int((((arrs["tags"] & 2) == 0) & ((arrs["flag"] & 2) != 0)).sum())
+    ii2, _, txt2, _ = ref_basicstat(ref_lib, arrs, ref, ev, is_indel=1)
+    assert ii2[capi.I_NAMES.index("sbq")] == 0 and txt2.split(b":")[2] == b"0.00"                               # :101-103, :120-122
+    _, _, txt0, _ = ref_basicstat(ref_lib, arrs, ref, [])
+    assert txt0 == b"0:0.00:0.00:0.00:0:0:0.00:0.00:0.00:0:0.00:0.00:0.00"                                      # :142-155
+
+
+# ---------------------------------------------------------------- the reference's unit tests, re-expressed
+
+def test_kat_indel_queue(ref_lib):
+    """test/lib/bamrc/TestIndelQueue.cpp:21-88 on the reference-compiled IndelQueue."""
+    L = ref_lib.lib
+    buf = C.create_string_buffer(1024)
+    q = L.bamrc_ref_queue_new()                                   # push
+    assert L.bamrc_ref_queue_size(q) == 0
+    L.bamrc_ref_queue_push(q, 0, 0, 0, 0, b"")
+    assert L.bamrc_ref_queue_size(q) == 1
+    L.bamrc_ref_queue_free(q)
+    q = L.bamrc_ref_queue_new()                                   # process_irrelevant
+    L.bamrc_ref_queue_push(q, 1, 1, 0, 0, b""); L.bamrc_ref_queue_push(q, 1, 5, 0, 0, b"")
+    L.bamrc_ref_queue_process(q, 1, 2, buf, 1024)
+    assert L.bamrc_ref_queue_size(q) == 1
+    L.bamrc_ref_queue_free(q)
+    q = L.bamrc_ref_queue_new()                                   # process_new_chromosome
+    L.bamrc_ref_queue_push(q, 1, 1, 0, 0, b""); L.bamrc_ref_queue_push(q, 1, 5, 0, 0, b"")
+    L.bamrc_ref_queue_process(q, 10, 2, buf, 1024)
+    assert L.bamrc_ref_queue_size(q) == 0
+    L.bamrc_ref_queue_free(q)
+    q = L.bamrc_ref_queue_new()                                   # process_relevant
+    L.bamrc_ref_queue_push(q, 1, 1, 0, 0, b""); L.bamrc_ref_queue_push(q, 1, 5, 10, 0, b"")
+    depth = L.bamrc_ref_queue_process(q, 1, 5, buf, 1024)
+    assert L.bamrc_ref_queue_size(q) == 0 and depth == 10 and len(buf.value) != 0
+    L.bamrc_ref_queue_free(q)
+    # TestIndelQueueEntry.cpp:24-34: entry text = allele ':' stat
+    q = L.bamrc_ref_queue_new()
+    L.bamrc_ref_queue_push(q, 1, 20, 0, 1, b"-AA")
+    L.bamrc_ref_queue_process(q, 1, 20, buf, 1024)
+    assert buf.value == b"\t-AA:0:0.00:0.00:0.00:0:0:0.00:0.00:0.00:0:0.00:0.00:0.00"
+    L.bamrc_ref_queue_free(q)
+
+
+def deletion_reads():
+    """two reads 40M3D40M at 60 and 70 over an ACGT reference: deletion of ref[100:103] / ref[110:113]"""
+    rng = np.random.default_rng(3)
+    ref = synth.make_ref(rng, 400)
+    n = 2; L = 80
+    cig = np.array([(40 << 4) | 0, (3 << 4) | 2, (40 << 4) | 0] * n, np.uint32)
+    pos = np.array([60, 70], np.int32)
+    seqs, quals = [], []
+    for s in pos:
+        bases = np.concatenate([ref[s:s + 40], ref[s + 43:s + 83]])
+        codes = np.array([synth.CODE[chr(c)] for c in bases], np.uint8)
+        seqs.append(((codes[0::2] << 4) | codes[1::2]).astype(np.uint8)); quals.append(np.full(L, 30, np.uint8))
+    arrs = dict(pos=pos, flag=np.array([0, 16], np.uint16), mapq=np.array([60, 50], np.uint8), lib=np.zeros(n, np.int16),
+                l_qseq=np.full(n, L, np.int32), n_cigar=np.full(n, 3, np.uint32), cigar_off=np.array([0, 3], np.uint64),
+                seq_off=np.array([0, 40], np.uint64), qual_off=np.array([0, 80], np.uint64), nm=np.full(n, 3, np.int32), sm=np.zeros(n, np.int32),
+                tags=np.full(n, 1, np.uint8), cigar=cig, seq4=np.concatenate(seqs), qual=np.concatenate(quals))
+    return ref, arrs
+
+
+def test_kat_indel_queue_through_the_engines(oracle_lib, ref_lib):
+    """The same three behaviours through the C-ABI (IndelQueue.cpp:3-15 inside pileup_func :391-409): a deletion found at
+    position 99 (0-based) is queued for position 100; whether it prints depends on what is processed next."""
+    ref, arrs = deletion_reads()
+    dele = b"\t-" + bytes(ref[100:103])
+
+    def run(lib, steps):
+        eng = capi.Engine(lib)
+        out = []
+        ends = capi.read_ends(arrs)
+        for tid, beg0, end, clear in steps:
+            idx = capi.fetch_overlapping(arrs, ends, beg0 - 1, end)       # the same reads exist on every contig
+            eng.begin_region(tid, beg0, end, ref)
+            eng.push_reads(capi.select_reads(arrs, idx))
+            eng.end_region()
+            out.append(eng.format_region("c%d" % tid))
+            if clear:
+                eng.clear_indel_queue()
+        eng.close()
+        return out
+
+    def depth(t):
+        return int(t.split(b"\t")[3])
+
+    for lib in (oracle_lib, ref_lib):
+        # At 0-based position 100 the column holds read 2's base (mapq_n = 1) and read 1's deletion (not counted).  Every
+        # region recomputes its lead position 99, so it queues the deletion (0,100) itself: one print, depth 1 + 1.
+        b = run(lib, [(0, 90, 100, True), (0, 100, 101, False)])
+        assert dele not in b[0] and b[1].count(dele) == 1 and depth(b[1]) == 2
+        # relevant (process_relevant): without the clear of :605 the entry queued by the first region is still there and
+        # prints too — abutting command-line regions report the deletion twice and count it twice
+        a = run(lib, [(0, 90, 100, False), (0, 100, 101, False)])
+        assert dele not in a[0] and a[1].count(dele) == 2 and depth(a[1]) == 3
+        # irrelevant (process_irrelevant): a region further right passes the stale entry by (entry.pos < pos): dropped silently
+        c = run(lib, [(0, 90, 100, False), (0, 105, 106, False), (0, 100, 101, False)])
+        assert dele not in c[1] and c[2].count(dele) == 1 and depth(c[2]) == 2
+        # new chromosome (process_new_chromosome): the stale entry of contig 0 is dropped when contig 1 is processed
+        d = run(lib, [(0, 90, 100, False), (1, 100, 101, False)])
+        assert d[1].count(dele) == 1 and depth(d[1]) == 2
+    for steps in ([(0, 90, 100, False), (0, 100, 101, False)], [(0, 90, 100, False), (1, 100, 101, False), (0, 95, 120, False)]):
+        assert run(oracle_lib, steps) == run(ref_lib, steps)
+
+
+def test_kat_aux_fields(ref_lib):
+    """test/lib/bamrc/TestAuxFields.cpp:9-48"""
+    for vals, text in (((1, 2, 3, 4, 5), b"1 2 3 4 5"), ((-1, -2, -3, -4, -5), b"-1 -2 -3 -4 -5")):
+        a = np.array(vals, np.int32); out = np.zeros(5, np.int32); buf = C.create_string_buffer(128)
+        ref_lib.lib.bamrc_ref_zm_roundtrip(a.ctypes.data, buf, 128, out.ctypes.data)
+        assert buf.value == text and tuple(out) == vals
+
+
+def run_readwarnings(ref_lib, max_per_type, rounds):
+    types = np.array([0, 1, 2], np.int32)
+    names = (C.c_char_p * 3)(b"x", b"y", b"z")
+    buf = C.create_string_buffer(1 << 16)
+    ref_lib.lib.bamrc_ref_readwarnings(max_per_type, rounds, types.ctypes.data, names, 3, buf, 1 << 16)
+    return buf.value.decode().splitlines()
+
+
+def test_kat_read_warnings(ref_lib):
+    """test/lib/bamrc/TestReadWarnings.cpp:36-71"""
+    lines = run_readwarnings(ref_lib, -1, 100)
+    assert len(lines) == 300
+    assert sum("SM tag" in l for l in lines) == 100 and sum("NM tag" in l for l in lines) == 100 and sum("generated tag" in l for l in lines) == 100
+    lines = run_readwarnings(ref_lib, 5, 100)
+    assert len(lines) == 15 + 3
+    assert sum("SM tag" in l for l in lines) == 5 and sum("NM tag" in l for l in lines) == 5 and sum("generated tag" in l for l in lines) == 5
+    assert lines[0] == "WARNING: In read x: Couldn't find single-end mapping quality. Check to see if the SM tag is in BAM."
+    assert "The previous warning has been emitted 5 times and will be disabled." in lines
