@@ -63,6 +63,10 @@ struct DevCfg {
     int64_t n_reads;
     int32_t table_len;      // L0: modal read length of the region (host); reads with l_qseq == clipped == L0 take their terms from tables
     int32_t variant;        // 0 in production; >0 = profiling ablations selected by BRC_PILEUP_VARIANT (see brc_engine.hip)
+    int32_t force_dom;      // test knob (BRC_FORCE_DOM): -1, or the bucket every lane treats as dominant (stresses the alternate / third-allele paths)
+    int64_t n_pieces;       // pieces of all libraries (KB v2)
+    int32_t flush_k;        // K: pieces a lane may accumulate in its packed integer registers between two flushes (1..63)
+    uint32_t pack_lim;      // 65535 / K: largest per-read value a 16-bit packed field can take (PF_HUGE above it)
 };
 
 // Region inputs exactly as brc_read_batch lays them out (uploaded as-is; offsets rebased per region).
@@ -71,7 +75,8 @@ struct DevIn {
     const uint32_t* n_cigar; const uint64_t* cig_off; const uint64_t* seq_off; const uint64_t* qual_off;
     const int32_t* nm; const int32_t* sm; const uint8_t* tags;
     const uint32_t* cigar; const uint8_t* seq4; const uint8_t* qual; const char* ref;
-    // device-produced by K1: per base  quality | bucket("=ACGTN") << 8; read i's row starts at element bq_row[i]
+    // device-produced by K1: per base  quality << 8 | bucket("=ACGTN") (the "event word": `word >= min_bq << 8` is the
+    // base-quality test of bamreadcount.cpp:288 without unpacking); read i's row starts at element bq_row[i]
     // (rows are padded to multiples of 8 elements so every row is 16-byte aligned: KB bulk-loads row windows as uint4)
     const uint16_t* bq;
     const uint64_t* bq_row;  // [n_reads] host-computed prefix sums of roundup8(l_qseq)
@@ -162,7 +167,7 @@ BRC_HD uint32_t ref_at(const DevCfg& c, const char* ref, int64_t p) {
 // ---------------------------------------------------------------- K1: per-read annotation (fetch_func)
 
 // Restates bamreadcount.cpp:114-256 for read i and packs everything KB needs into a DRead.
-BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i, uint16_t* bq_out, RcpPair* rcp_out) {
+BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i, uint16_t* bq_out) {
     DRead r;
     const int32_t pos = in.pos[i];
     const uint32_t flag = in.flag[i];
@@ -244,7 +249,7 @@ BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i, uint16_t
     r.n_cigar = nc;
     r.bq_off = in.bq_row[i];
     // per-base stream for KB: quality | bucket << 8
-    for (int j = 0; j < L; ++j) bq_out[in.bq_row[i] + (uint64_t)j] = (uint16_t)(qual[j] | (canon_bucket(seqi(seq, j)) << 8));
+    for (int j = 0; j < L; ++j) bq_out[in.bq_row[i] + (uint64_t)j] = (uint16_t)((qual[j] << 8) | canon_bucket(seqi(seq, j)));
     const int lib = c.per_lib ? (int)in.lib[i] : 0;
     uint32_t misc = (mapq << 8) | ((uint32_t)((lib + 1) & 0xff) << 16);
     if (rev) misc |= M_REV;
@@ -260,8 +265,6 @@ BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i, uint16_t
     if (tags & 1u) snm = (float)in.nm[i] / (float)clipped;                                   // BasicStat.cpp:94-97
     else misc |= M_NMW;
     const bool table = c.table_len > 0 && L == c.table_len && clipped == L;
-    RcpPair rc; rc.Lf = (float)L; rc.center = (float)clipped * 0.5f; rc.rcpL = 1.0f / rc.Lf; rc.rcpC = 1.0f / rc.center;
-    rcp_out[i] = rc;
     r.misc = finish_misc(misc, table, shape_clipm(shape, nc, left_clip)); r.l_qseq = L; r.q2 = q2; r.tp = tp; r.left = left_clip; r.clipped = clipped;
     r.zm_sum = sum; r.sse_add = sse; r.snm_add = snm; r.clipped_dup = clipped;
     return r;
@@ -497,7 +500,7 @@ BRC_HD void overflow_event(const DevCfg& c, const LaneOut& o, LaneAcc& a, uint32
 // for everything else.  Each extra divergent `if` costs three scalar instructions (save / branch / restore exec) and a
 // dependency stall per wave-iteration, and this kernel runs at the issue-slot limit.
 BRC_HD void lane_accumulate(const DevCfg& c, const DRead& rd, const RcpPair& rc, const TermTab& tt, const Probe& pr, uint32_t bqv, const LaneOut& o, LaneAcc& a) {
-    const uint32_t q = bqv & 0xffu, b = bqv >> 8;
+    const uint32_t q = bqv >> 8, b = bqv & 0xffu;
     const bool dep = pr.want && (int)q >= c.min_bq;                     // :288
     a.depth += dep ? 1u : 0u;                                           // mapq_n (:312)
     const bool pass = dep && (pr.indel < 1 || !c.insertion_centric);    // :343
@@ -554,6 +557,281 @@ BRC_HD void lane_store(const DevCfg& c, const LaneOut& o, const LaneAcc& a) {
     }
 }
 
+// ================================================================ KB v2: pieces
+//
+// The pileup kernel does not walk reads, it walks PIECES: one piece = one M/=/X segment of one read, i.e. a run of
+// events qpos = p - a over the reference interval [rs, rs + len).  Every CIGAR is cut into pieces once, in K1 (the host
+// counts them at push time so that each read knows its slots), which leaves exactly one kind of work item in the hot
+// loop — htslib's resolve_cigar2 is not evaluated per (read, position) any more:
+//   * deletions / reference skips produce no events; they only keep the read in the column, so the piece in front of
+//     them carries an extended column length `ext` (pieces of one read tile [pos, end) without gaps);
+//   * with -i the last base before an insertion is counted in the depth but not in a base bucket (bamreadcount.cpp:312
+//     vs :343): it becomes a one-base piece flagged PF_NB;
+//   * a read that can never be counted (MAPQ below -q, SECONDARY/QCFAIL/DUP) is ONE event-less piece over [pos, end).
+// Pieces of a read are adjacent and reads keep their file order, so every bucket still sees its events in pileup-column
+// order.  In per-library mode (-p) the pieces are laid out library-major (all pieces of library 0 in file order, then
+// library 1, ...): a (tile, library) wave walks only its own library's stream.
+enum { PF_TABLE = 1,    // event terms come from the quotient tables (l_qseq == clipped == table_len, left_clip == 0, q2 in {tp, none})
+       PF_Q2OK = 2, PF_NB = 4,
+       PF_HUGE = 8,     // a per-read integer does not fit its packed field: w2/w3 carry only the mapping quality, the rest is added by drain_int()
+       PF_SMW = 16, PF_NMW = 32, PF_REV = 64 };
+static const uint32_t THR_NEVER = 0x10000u;   // no 16-bit event word reaches it
+
+// hot half: everything the read loop needs, ONE 64-byte scalar load (s_load_dwordx16) per piece
+struct alignas(64) PieceHot {
+    int32_t rs;            // reference position of the first base
+    int32_t a;             // rs - query offset: the lane on position p sees query base p - a
+    int32_t len;           // events: positions [rs, rs + len)
+    int32_t ext;           // column: positions [rs, rs + ext), ext >= len
+    uint32_t thr;          // an event word w counts iff w >= thr  (min_bq << 8, or THR_NEVER)
+    uint32_t tp_flags;     // bits 0-23: three_prime_index * 4 (byte offset into the float quotient table); 24-31: PF_*
+    uint32_t w1, w2, w3;   // packed integer addends: 1 | rev << 10 | q2ok << 20;  mapq | sse << 16;  zm_sum | clipped << 16
+    float snm;             // NM / (float)clipped_length, 0 when NM is missing
+    float rcpL, Lf, rcpC, center;   // exact-division constants (RcpPair)
+    int32_t left, q2;
+};
+// cold half: staging, the drain paths and the indel reduction
+struct alignas(32) PieceCold {
+    uint64_t bq_off;       // first element of the read's row in the event-word stream
+    int32_t a;             // copy of PieceHot::a (staging reads {bq_off, a} with one 16-byte load)
+    uint32_t read;         // region-wide read index (push order)
+    uint32_t zm_raw, sse_raw, mapq;
+    int32_t clipped;
+};
+BRC_HD uint32_t piece_flags(const PieceHot& h) { return h.tp_flags >> 24; }
+BRC_HD int piece_tp(const PieceHot& h) { return (int)((h.tp_flags & 0xffffffu) >> 2); }
+
+// what K1 knows about a read once it is annotated
+struct ReadConst {
+    int32_t pos, l_qseq, clipped, left, tp, q2;
+    uint32_t flags;        // PF_REV | PF_Q2OK | PF_SMW | PF_NMW
+    uint32_t mapq, zm, sse;
+    float snm;
+    uint64_t bq_off; uint32_t read;
+    bool counts;           // MAPQ >= -q and no SECONDARY/QCFAIL/DUP flag
+};
+
+BRC_HD ReadConst read_const(const DevCfg& c, const DRead& rd, uint32_t read_index) {
+    ReadConst rc;
+    rc.pos = rd.pos; rc.l_qseq = rd.l_qseq; rc.clipped = rd.clipped; rc.left = rd.left; rc.tp = rd.tp; rc.q2 = rd.q2;
+    rc.flags = ((rd.misc & M_REV) ? PF_REV : 0u) | ((rd.misc & M_Q2OK) ? PF_Q2OK : 0u) | ((rd.misc & M_SMW) ? PF_SMW : 0u) | ((rd.misc & M_NMW) ? PF_NMW : 0u);
+    rc.mapq = (rd.misc >> 8) & 0xffu; rc.zm = rd.zm_sum; rc.sse = rd.sse_add; rc.snm = rd.snm_add; rc.bq_off = rd.bq_off; rc.read = read_index;
+    rc.counts = (int)rc.mapq >= c.min_mapq && !(rd.misc & M_NOCOUNT);
+    return rc;
+}
+
+// does the base in front of CIGAR operator k+1.. see an insertion (resolve_cigar2's peek: I, or P ... I)?
+BRC_HD bool peek_insertion(const uint32_t* cig, uint32_t nc, uint32_t k) {
+    if (k + 1 >= nc) return false;
+    const uint32_t op2 = cig[k + 1] & 0xfu;
+    if (op2 == CINS) return (cig[k + 1] >> 4) > 0;
+    if (op2 == CPAD && k + 2 < nc) {
+        int l3 = 0;
+        for (uint32_t kk = k + 2; kk < nc; ++kk) {
+            const uint32_t o = cig[kk] & 0xfu;
+            if (o == CINS) l3 += (int)(cig[kk] >> 4);
+            else if (o == CDEL || o == CMATCH || o == CREF_SKIP || o == CEQUAL || o == CDIFF) break;
+        }
+        return l3 > 0;
+    }
+    return false;
+}
+
+// THE piece decomposition (host: counting at push time; K1: emission; the two must agree, so both call this).
+// f(rs, len, ext, qoff, nb).  `entered`: the read enters pileup columns at all (not dropped at push, has a usable CIGAR).
+template <class F>
+BRC_HD void walk_pieces(bool insertion_centric, bool entered, bool counts, int32_t pos, const uint32_t* cig, uint32_t nc, F f) {
+    if (!entered) return;
+    int32_t x = pos; int y = 0;
+    if (!counts) {
+        int32_t rlen = 0;
+        for (uint32_t k = 0; k < nc; ++k) if (is_refop(cig[k] & 0xfu)) rlen += (int32_t)(cig[k] >> 4);
+        if (rlen > 0) f(pos, 0, rlen, 0, false);
+        return;
+    }
+    bool have = false; int32_t crs = 0, clen = 0; int cq = 0; bool cnb = false;
+    for (uint32_t k = 0; k < nc; ++k) {
+        const uint32_t op = cig[k] & 0xfu; const int32_t len = (int32_t)(cig[k] >> 4);
+        if (is_mop(op)) {
+            if (len > 0) {
+                if (have) f(crs, clen, x - crs, cq, cnb);
+                else if (x > pos) f(pos, 0, x - pos, 0, false);              // leading deletion / skip: column only
+                have = true;
+                if (insertion_centric && peek_insertion(cig, nc, k)) {
+                    if (len > 1) f(x, len - 1, len - 1, y, false);
+                    crs = x + len - 1; clen = 1; cq = y + len - 1; cnb = true;
+                } else { crs = x; clen = len; cq = y; cnb = false; }
+            }
+            x += len; y += len;
+        } else if (op == CDEL || op == CREF_SKIP) x += len;
+        else if (op == CINS || op == CSOFT_CLIP) y += len;
+    }
+    if (have) f(crs, clen, x - crs, cq, cnb);
+    else if (x > pos) f(pos, 0, x - pos, 0, false);
+}
+
+// does a read enter pileup columns?  (bam_plp_push drop rules + a CIGAR resolve_cigar2 can stand on)
+BRC_HD bool read_enters(uint32_t flag, const uint32_t* cig, uint32_t nc) {
+    if (flag & BRC_PUSH_MASK) return false;
+    if (nc == 0) return false;
+    if (nc == 1 && !is_mop(cig[0] & 0xfu)) return false;
+    return true;
+}
+
+BRC_HD void make_piece(const DevCfg& c, const ReadConst& r, int32_t rs, int32_t len, int32_t ext, int qoff, bool nb, PieceHot& h, PieceCold& cold) {
+    h.rs = rs; h.a = rs - qoff; h.len = len; h.ext = ext;
+    h.thr = r.counts ? ((uint32_t)(c.min_bq < 0 ? 0 : (c.min_bq > 256 ? 256 : c.min_bq)) << 8) : THR_NEVER;
+    uint32_t fl = r.flags;
+    const bool q2ok = (fl & PF_Q2OK) != 0;
+    if (c.table_len > 0 && r.l_qseq == c.table_len && r.clipped == c.table_len && r.left == 0 && r.tp >= 0 && r.tp <= c.table_len &&
+        (!q2ok || r.q2 == r.tp)) fl |= PF_TABLE;
+    if (nb) fl |= PF_NB;
+    const bool huge = r.zm > c.pack_lim || r.sse > c.pack_lim || (uint32_t)r.clipped > c.pack_lim;
+    if (huge) fl |= PF_HUGE;
+    h.tp_flags = (((uint32_t)r.tp << 2) & 0xffffffu) | (fl << 24);      // l_qseq < 2^22 is checked at push
+    h.w1 = 1u | ((fl & PF_REV) ? (1u << 10) : 0u) | (q2ok ? (1u << 20) : 0u);
+    h.w2 = r.mapq | (huge ? 0u : (r.sse << 16));
+    h.w3 = huge ? 0u : (r.zm | ((uint32_t)r.clipped << 16));
+    h.snm = r.snm;
+    h.Lf = (float)r.l_qseq; h.center = (float)r.clipped * 0.5f; h.rcpL = 1.0f / h.Lf; h.rcpC = 1.0f / h.center;
+    h.left = r.left; h.q2 = r.q2;
+    cold.bq_off = r.bq_off; cold.a = h.a; cold.read = r.read; cold.zm_raw = r.zm; cold.sse_raw = r.sse; cold.mapq = r.mapq;
+    cold.clipped = r.clipped;
+}
+
+// event terms of a piece at query position qpos by exact division (any read) ...
+BRC_HD EvTerms piece_terms_div(const PieceHot& h, int qpos) {
+    EvTerms t; const int tp = piece_tp(h);
+    t.q2 = (piece_flags(h) & PF_Q2OK) ? div_rcp((float)BRC_ABSDIFF(qpos, h.q2), h.Lf, h.rcpL) : 0.0f;
+    t.s3p = div_rcp((float)BRC_ABSDIFF(qpos, tp), h.Lf, h.rcpL);
+    float d = (float)(qpos - h.left) - h.center;
+    d = d < 0.0f ? -d : d;
+    t.sev = 1.0 - (double)div_rcp(d, h.center, h.rcpC);
+    return t;
+}
+// ... and from the quotient tables (PF_TABLE): one float look-up serves both distances (q2 == tp or no q2)
+BRC_HD EvTerms piece_terms_tab(const PieceHot& h, const TermTab& tt, int table_len, int qpos) {
+    EvTerms t;
+    t.s3p = tt.q[absdiff_u((uint32_t)qpos, (uint32_t)piece_tp(h))];
+    t.q2 = (piece_flags(h) & PF_Q2OK) ? t.s3p : 0.0f;
+    t.sev = tt.e[absdiff_u(2u * (uint32_t)qpos, (uint32_t)table_len)];
+    return t;
+}
+
+// One bucket of a lane between two flushes: three packed integer registers, the base-quality sum and the four
+// order-sensitive float sums.
+struct PackAcc { uint32_t w1, w2, w3, sbq; float f[NF]; };
+BRC_HD void pack_init(PackAcc& a) { a.w1 = a.w2 = a.w3 = a.sbq = 0; for (int f = 0; f < NF; ++f) a.f[f] = 0.0f; }
+BRC_HD void pack_event(PackAcc& a, const PieceHot& h, const EvTerms& t, uint32_t q) {
+    a.w1 += h.w1; a.w2 += h.w2; a.w3 += h.w3; a.sbq += q;
+    a.f[F_SQ2] += t.q2; a.f[F_S3P] += t.s3p;
+    a.f[F_SEV] = (float)((double)a.f[F_SEV] + t.sev);
+    a.f[F_SNM] += h.snm;
+}
+// the nine integer plane values held by a PackAcc (I_* order)
+BRC_HD void pack_unpack(const PackAcc& a, uint32_t* v) {
+    const uint32_t n = a.w1 & 0x3ffu, minus = (a.w1 >> 10) & 0x3ffu;
+    v[I_N] = n; v[I_SMQ] = a.w2 & 0xffffu; v[I_SSE] = a.w2 >> 16; v[I_PLUS] = n - minus; v[I_MINUS] = minus;
+    v[I_NQ2] = a.w1 >> 20; v[I_SMMQ] = a.w3 & 0xffffu; v[I_SCLIP] = a.w3 >> 16; v[I_SBQ] = a.sbq;
+}
+
+// K (pieces between two flushes of a lane's packed integers) and the per-read limit of a 16-bit field: clipped_length of
+// every read must fit, so long reads get a small K
+// (the overrides are test knobs: a small K exercises the flushes, a small limit the PF_HUGE path)
+BRC_HD void choose_pack(int32_t max_lqseq, int32_t k_override, int32_t lim_override, int32_t& K, uint32_t& lim) {
+    int32_t m = max_lqseq < 255 ? 255 : max_lqseq;
+    K = 65535 / m; if (K > 63) K = 63; if (K < 1) K = 1;
+    if (k_override > 0 && k_override < K) K = k_override;
+    lim = 65535u / (uint32_t)K;
+    if (lim_override >= 255 && (uint32_t)lim_override < lim) lim = (uint32_t)lim_override;    // >= 255: a mapping quality always fits
+}
+
+// Per-lane state of KB v2.  `mem` bit b: the planes of bucket b already hold partial sums of this position (an earlier
+// flush of the dominant / alternate registers, or drained events of a third allele) and must be added to, not overwritten.
+enum { HALF = 6 };          // pieces per staging half-batch (6 rows x 9 chunks = 54 lanes of one direct-to-LDS instruction; a multiple of 3,
+                            // the rotation period of the piece-record registers); queue drains and flushes happen between half-batches
+struct LaneAcc2 {
+    PackAcc dom, alt;
+    uint32_t dom_b, alt_b, mem, ncol, depth, w_sm, w_nm;
+};
+BRC_HD void lane2_init(LaneAcc2& a, uint32_t dom_b) {
+    pack_init(a.dom); pack_init(a.alt); a.dom_b = dom_b; a.alt_b = NB_NONE; a.mem = 0; a.ncol = a.depth = a.w_sm = a.w_nm = 0;
+}
+BRC_HD uint32_t* plane_i(const DevCfg& c, const Planes& pl, int lib, uint32_t b, int64_t k) { return pl.istat + (((int64_t)lib * NBUCKET + b) * NI) * c.PS + k; }
+BRC_HD float* plane_f(const DevCfg& c, const Planes& pl, int lib, uint32_t b, int64_t k) { return pl.fstat + (((int64_t)lib * NBUCKET + b) * NF) * c.PS + k; }
+
+// registers -> integer planes of one bucket (adds when the planes are live), registers reset
+BRC_HD void flush_bucket(const DevCfg& c, const Planes& pl, int lib, int64_t k, PackAcc& a, uint32_t b, uint32_t& mem) {
+    uint32_t v[NI]; pack_unpack(a, v);
+    uint32_t* ip = plane_i(c, pl, lib, b, k);
+    const bool live = (mem >> b) & 1u;
+    for (int f = 0; f < NI; ++f) ip[(int64_t)f * c.PS] = v[f] + (live ? ip[(int64_t)f * c.PS] : 0u);
+    mem |= 1u << b;
+    a.w1 = a.w2 = a.w3 = a.sbq = 0;
+}
+BRC_HD void lane2_flush(const DevCfg& c, const Planes& pl, int lib, int64_t k, LaneAcc2& a) {
+    flush_bucket(c, pl, lib, k, a.dom, a.dom_b, a.mem);
+    if (a.alt_b != NB_NONE) flush_bucket(c, pl, lib, k, a.alt, a.alt_b, a.mem);
+}
+// one event of a third (fourth, ...) base at this position, straight into the planes; events of one bucket arrive in
+// column order because the queue is drained in piece order
+BRC_HD void drain_full(const DevCfg& c, const Planes& pl, int lib, int64_t k, uint32_t& mem, const PieceHot& h, const PieceCold& cold, int qpos, uint32_t word) {
+    const uint32_t b = word & 0xffu, q = word >> 8;
+    uint32_t* ip = plane_i(c, pl, lib, b, k); float* fp = plane_f(c, pl, lib, b, k);
+    const bool live = (mem >> b) & 1u;
+    const int64_t P = c.PS;
+    const EvTerms t = piece_terms_div(h, qpos);
+    const uint32_t fl = piece_flags(h);
+    const uint32_t rev = (fl & PF_REV) ? 1u : 0u;
+    ip[I_N * P] = (live ? ip[I_N * P] : 0u) + 1u; ip[I_SMQ * P] = (live ? ip[I_SMQ * P] : 0u) + cold.mapq;
+    ip[I_SSE * P] = (live ? ip[I_SSE * P] : 0u) + cold.sse_raw; ip[I_PLUS * P] = (live ? ip[I_PLUS * P] : 0u) + (1u - rev);
+    ip[I_MINUS * P] = (live ? ip[I_MINUS * P] : 0u) + rev; ip[I_NQ2 * P] = (live ? ip[I_NQ2 * P] : 0u) + ((fl & PF_Q2OK) ? 1u : 0u);
+    ip[I_SMMQ * P] = (live ? ip[I_SMMQ * P] : 0u) + cold.zm_raw; ip[I_SCLIP * P] = (live ? ip[I_SCLIP * P] : 0u) + (uint32_t)cold.clipped;
+    ip[I_SBQ * P] = (live ? ip[I_SBQ * P] : 0u) + q;
+    fp[F_SQ2 * P] = (live ? fp[F_SQ2 * P] : 0.0f) + t.q2; fp[F_S3P * P] = (live ? fp[F_S3P * P] : 0.0f) + t.s3p;
+    fp[F_SEV * P] = (float)((double)(live ? fp[F_SEV * P] : 0.0f) + t.sev); fp[F_SNM * P] = (live ? fp[F_SNM * P] : 0.0f) + h.snm;
+    mem |= 1u << b;
+}
+// the integers of a PF_HUGE piece that its packed addends left out, for a lane whose event went to bucket b (dominant or alternate)
+BRC_HD void drain_int(const DevCfg& c, const Planes& pl, int lib, int64_t k, uint32_t& mem, const PieceCold& cold, uint32_t b) {
+    uint32_t* ip = plane_i(c, pl, lib, b, k);
+    const bool live = (mem >> b) & 1u;
+    const int64_t P = c.PS;
+    if (!live) for (int f = 0; f < NI; ++f) ip[(int64_t)f * P] = 0u;
+    ip[I_SSE * P] += cold.sse_raw; ip[I_SMMQ * P] += cold.zm_raw; ip[I_SCLIP * P] += (uint32_t)cold.clipped;
+    mem |= 1u << b;
+}
+// end of the tile: whatever is still in registers, and zeros for the untouched buckets
+BRC_HD void lane2_store(const DevCfg& c, const Planes& pl, int lib, int64_t k, LaneAcc2& a, bool dead) {
+    const int64_t P = c.PS;
+    pl.ncol[(int64_t)lib * P + k] = dead ? 0u : a.ncol;
+    pl.depth[(int64_t)lib * P + k] = dead ? 0u : a.depth;
+    for (uint32_t b = 0; b < NBUCKET; ++b) {
+        uint32_t* ip = plane_i(c, pl, lib, b, k); float* fp = plane_f(c, pl, lib, b, k);
+        const bool isdom = !dead && a.dom_b == b, isalt = !dead && a.alt_b == b;
+        if (isdom || isalt) {
+            PackAcc& r = isdom ? a.dom : a.alt;
+            for (int f = 0; f < NF; ++f) fp[(int64_t)f * P] = r.f[f];
+            flush_bucket(c, pl, lib, k, r, b, a.mem);
+        } else if (dead || !((a.mem >> b) & 1u)) {
+            for (int f = 0; f < NI; ++f) ip[(int64_t)f * P] = 0u;
+            for (int f = 0; f < NF; ++f) fp[(int64_t)f * P] = 0.0f;
+        }
+    }
+}
+
+// tile -> piece range inside one library's stream [seg_lo, seg_hi): lo = first piece whose running-max reach exceeds the
+// tile's first position, hi = first piece whose read starts after its last one (key = start of the parent read)
+BRC_HD void tile_range2(const DevCfg& c, const int32_t* prefmax_reach, const int32_t* key, int64_t seg_lo, int64_t seg_hi, int64_t t, uint32_t& lo, uint32_t& hi) {
+    const int64_t p0 = (int64_t)c.pos0 + t * TILE, p1 = p0 + TILE - 1;
+    int64_t a = seg_lo, b = seg_hi;
+    while (a < b) { const int64_t m = (a + b) >> 1; if ((int64_t)prefmax_reach[m] > p0) b = m; else a = m + 1; }
+    lo = (uint32_t)a;
+    b = seg_hi;
+    while (a < b) { const int64_t m = (a + b) >> 1; if ((int64_t)key[m] > p1) b = m; else a = m + 1; }
+    hi = (uint32_t)a;
+}
+
 // ---------------------------------------------------------------- K1': per-read indel event enumeration
 
 // Calls emit(p, qpos, len) for every event of read `rd` that pileup_func would bucket as an indel allele
@@ -606,8 +884,8 @@ BRC_HD bool same_allele(const DevIn& in, const DRead* reads, const IndelEv& a, c
     const DRead& ra = reads[a.read]; const DRead& rb = reads[b.read];
     for (int j = 0; j < a.len; ++j) {
         const int qa = a.qpos + 1 + j, qb = b.qpos + 1 + j;
-        const uint32_t ca = qa < ra.l_qseq ? (uint32_t)(in.bq[ra.bq_off + (uint64_t)qa] >> 8) : 5u;
-        const uint32_t cb = qb < rb.l_qseq ? (uint32_t)(in.bq[rb.bq_off + (uint64_t)qb] >> 8) : 5u;
+        const uint32_t ca = qa < ra.l_qseq ? (uint32_t)(in.bq[ra.bq_off + (uint64_t)qa] & 0xffu) : 5u;
+        const uint32_t cb = qb < rb.l_qseq ? (uint32_t)(in.bq[rb.bq_off + (uint64_t)qb] & 0xffu) : 5u;
         if (ca != cb) return false;
     }
     return true;

@@ -1,16 +1,19 @@
 // brc_engine.hip — the HIP/CDNA4 (gfx950) device pipeline behind the C-ABI of include/brc.h.
 //
 // Kernels (per region, all on one engine-owned stream; see DESIGN.md for layouts and rooflines):
-//   k_annotate      one lane per read: fetch_func's Zm integers + per-read constants -> 80-B DRead records;
-//                   also counts each read's indel events per (position, library) key
-//   k_scan_*        3-phase scans: inclusive running max of read ends (tile lower bounds), exclusive sum of
+//   k_refcode       reference characters -> 4-bit codes
+//   k_annotate_groups  K1: fetch_func's Zm integers per read (8 bases per lane, byte-parallel), the event-word stream
+//                   (quality << 8 | bucket per base) and the read's PIECES (walk_pieces): 64-B hot + 32-B cold records in
+//                   library-major slots; also counts each read's indel events per (position, library) key
+//   k_unavail       -p only: first library-less read of every column (those positions are abandoned, :281-284)
+//   k_scan_*        3-phase scans: running max of piece reaches per library (tile lower bounds), exclusive sum of
 //                   indel-event counts (per-key offsets)
-//   k_tiles         [lo,hi) read range of every 64-position tile, one coalesced pass over the reads
-//   k_pileup        THE hot kernel: one wave per (tile, library), lane == reference position, wave-uniform walk
-//                   over the tile's reads in file order (read records in SGPRs, coalesced byte loads of QUAL/SEQ
-//                   along the lanes), 6 buckets x 12 accumulators in VGPRs, order-preserving fp32 sums, coalesced
-//                   256-B plane stores.  Integer/byte work, HBM-bound: no MFMA by design.
-//   k_count_pos     emitted-position count
+//   k_tiles         [lo,hi) piece range of every 64-position tile of a library, one coalesced pass over its pieces
+//   k_pileup2       THE hot kernel: one wave per (tile, library), lane == reference position, wave-uniform walk over the
+//                   tile's pieces in column order: piece records by scalar loads, event-word windows staged into LDS by
+//                   direct-to-LDS loads, three packed integer accumulators + 4 order-preserving fp32 sums per bucket,
+//                   coalesced 256-B plane stores.  Integer/byte work, HBM-bound: no MFMA by design.
+//   k_finalize      emitted-position count + per-tile partial counters
 //   k_indel_fill / k_indel_reduce   indel side path (<1 % of events): keyed fill, ordered per-key reduction
 //
 // There is no CPU fallback here: without a HIP device make_backend() fails with BRC_E_NODEVICE.
@@ -92,8 +95,9 @@ struct AnnPar { uint4 a, b, c; };    // a = {L, qrel, srel, browrel}  b = {S, m1
 
 __device__ __forceinline__ uint32_t nzb7(uint32_t x) { return x + 0x7f7f7f7fu; }   // bytes <= 0x7f: bit 7 of a byte <=> byte != 0
 
-__global__ __launch_bounds__(256) void k_annotate_groups(DevCfg c, DevIn in, DRead* __restrict__ reads, int32_t* __restrict__ ends,
-                                                         uint16_t* __restrict__ bq, RcpPair* __restrict__ rcp, uint32_t* __restrict__ indel_cnt,
+__global__ __launch_bounds__(256) void k_annotate_groups(DevCfg c, DevIn in, DRead* __restrict__ reads, const uint32_t* __restrict__ piece_off,
+                                                         PieceHot* __restrict__ hot, PieceCold* __restrict__ cold, int32_t* __restrict__ key, int32_t* __restrict__ reach,
+                                                         uint16_t* __restrict__ bq, uint32_t* __restrict__ indel_cnt,
                                                          const uint32_t* __restrict__ cigar_ro, const uint8_t* __restrict__ qual_ro,
                                                          const uint8_t* __restrict__ seq_ro, const uint8_t* __restrict__ refcode) {
     struct WaveLds { AnnPar par[64]; int32_t lo[64], hi[64]; uint32_t sum[64]; uint32_t redo[64]; uint32_t G[64]; uint8_t mark[64]; };
@@ -248,11 +252,11 @@ __global__ __launch_bounds__(256) void k_annotate_groups(DevCfg c, DevIn in, DRe
                 const uint32_t mx = (gx - (gx >> 7)) | gx, my2 = (gy - (gy >> 7)) | gy;                             // 0xff per such byte
                 Bk.x = (hx & mx) | (lx & ~mx); Bk.y = (hy & my2) | (ly & ~my2);
             }
-            // ---- the packed stream for KB: quality | bucket << 8 per base; the row is padded to 8 elements
+            // ---- the event words for KB: quality << 8 | bucket per base; the row is padded to 8 elements
             if (act) {
                 uint4 out;
-                out.x = __builtin_amdgcn_perm(Bk.x, Q.x, 0x05010400u); out.y = __builtin_amdgcn_perm(Bk.x, Q.x, 0x07030602u);
-                out.z = __builtin_amdgcn_perm(Bk.y, Q.y, 0x05010400u); out.w = __builtin_amdgcn_perm(Bk.y, Q.y, 0x07030602u);
+                out.x = __builtin_amdgcn_perm(Bk.x, Q.x, 0x01050004u); out.y = __builtin_amdgcn_perm(Bk.x, Q.x, 0x03070206u);
+                out.z = __builtin_amdgcn_perm(Bk.y, Q.y, 0x01050004u); out.w = __builtin_amdgcn_perm(Bk.y, Q.y, 0x03070206u);
                 __builtin_memcpy(bq + bbase + P.a.w + (uint32_t)b, &out, 16);
             }
             // ---- first / last base with quality != 2 (:201-238)
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(256) void k_annotate_groups(DevCfg c, DevIn in, DRe
     uint32_t my_sum = 0; int my_hi = -1, my_lo = -1;
     if (work_me) { my_sum = W.sum[rank]; my_hi = W.hi[rank]; my_lo = W.lo[rank]; if (my_lo == INT32_MAX) my_lo = -1; if (W.redo[rank]) serial = true; }
     if (serial) {
-        r = annotate_read(c, in, my, bq, rcp);
+        r = annotate_read(c, in, my, bq);
     } else {
         const bool rev = (flag & FREVERSE) != 0;
         int tp, q2;
@@ -357,10 +361,19 @@ __global__ __launch_bounds__(256) void k_annotate_groups(DevCfg c, DevIn in, DRe
         if (tags & 1u) snm = (float)in.nm[my] / (float)clipped; else misc |= M_NMW;
         r.misc = finish_misc(misc, c.table_len > 0 && L == c.table_len && clipped == L, shape_clipm(shape, nc, left_clip)); r.l_qseq = L; r.q2 = q2; r.tp = tp; r.left = left_clip; r.clipped = clipped;
         r.zm_sum = my_sum; r.sse_add = sse; r.snm_add = snm; r.clipped_dup = clipped;
-        RcpPair rc; rc.Lf = (float)L; rc.center = (float)clipped * 0.5f; rc.rcpL = 1.0f / rc.Lf; rc.rcpC = 1.0f / rc.center;
-        rcp[my] = rc;
     }
-    reads[my] = r; ends[my] = r.end;
+    if (nc >= 2u) reads[my] = r;          // only the indel side path reads these records, and only for reads with an indel operator
+    {   // the read's pieces (the host counted them with the same walk_pieces: piece_off[] are their slots)
+        const bool nolib = c.per_lib && in.lib[my] < 0;
+        const bool enters = r.end > r.pos && pos >= 0;
+        const ReadConst rc = read_const(c, r, (uint32_t)my);
+        uint32_t slot = piece_off[my];
+        walk_pieces(c.insertion_centric != 0, enters && !nolib, rc.counts, pos, cigar_ro + coff, nc, [&](int32_t rs, int32_t len, int32_t ext, int qoff, bool nb) {
+            PieceHot h; PieceCold cd;
+            make_piece(c, rc, rs, len, ext, qoff, nb, h, cd);
+            hot[slot] = h; cold[slot] = cd; key[slot] = pos; reach[slot] = rs + ext; ++slot;
+        });
+    }
     if (indel_cnt && !simple) {
         const int lib = (int)((r.misc >> 16) & 0xffu) - 1;
         enumerate_indels(c, in, r, qual_ro + qoff, [&](int32_t p, int, int) { atomicAdd(&indel_cnt[(int64_t)(p - c.pos0) * c.Lp + lib], 1u); });
@@ -484,34 +497,37 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_apply(const typename Op::T* __r
 
 // ---------------------------------------------------------------- tiles
 
-// Read range [lo, hi) of every 64-position tile (tile_range in brc_core.h states it as two binary searches):
-//   lo(t) = first read m with prefmax_end[m] > p0(t)      (prefmax_end = running maximum of the reads' ends, non-decreasing)
-//   hi(t) = first read m with pos[m] > p1(t) = p0(t) + 63 (reads are sorted by pos)
-// Inverted here so that the work is one coalesced pass over the reads instead of two dependent-load searches per tile:
-// read r owns the tiles whose lo is r (prefmax_end[r-1] <= p0 < prefmax_end[r]) and the tiles whose hi is r + 1
-// (pos[r] <= p1 < pos[r+1]) — usually none or one of each; the last read also covers the tiles past the data.
+// Piece range [lo, hi) of every 64-position tile (tile_range2 in brc_core.h states it as two binary searches):
+//   lo(t) = first piece m with prefmax[m] > p0(t)          (prefmax = running maximum of the pieces' reaches, non-decreasing)
+//   hi(t) = first piece m with key[m] > p1(t) = p0(t) + 63 (key = start of the piece's read; reads are sorted by pos)
+// Inverted here so that the work is one coalesced pass over the pieces instead of two dependent-load searches per tile:
+// piece r owns the tiles whose lo is r (prefmax[r-1] <= p0 < prefmax[r]) and the tiles whose hi is r + 1
+// (key[r] <= p1 < key[r+1]) — usually none or one of each; the last piece also covers the tiles past the data.
 __device__ __forceinline__ int64_t tiles_ceil_div64(int64_t x) { return x <= 0 ? 0 : (x + (TILE - 1)) / TILE; }
 
-__global__ __launch_bounds__(256) void k_tiles(DevCfg c, const int32_t* __restrict__ prefmax, const int32_t* __restrict__ pos,
-                                               int64_t ntiles, uint2* __restrict__ rng) {
+__global__ __launch_bounds__(256) void k_tiles(DevCfg c, const int32_t* __restrict__ prefmax, const int32_t* __restrict__ key,
+                                               int64_t s0, int64_t n, int64_t ntiles, uint2* __restrict__ rng) {
+    // piece stream [s0, s0 + n) of one library; prefmax = running max of the pieces' reaches inside the stream, key = start
+    // of each piece's read (non-decreasing); rng = this library's row of tile ranges (absolute piece indices)
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= c.n_reads) return;
+    if (r >= n) return;
+    prefmax += s0; key += s0;
     uint32_t* out = reinterpret_cast<uint32_t*>(rng);
     // lo: tiles t with prefmax[r-1] <= p0(t) < prefmax[r]
     {
         int64_t t0 = r ? tiles_ceil_div64((int64_t)prefmax[r - 1] - c.pos0) : 0;
         int64_t t1 = tiles_ceil_div64((int64_t)prefmax[r] - c.pos0);
         if (t1 > ntiles) t1 = ntiles;
-        for (int64_t t = t0; t < t1; ++t) out[2 * t] = (uint32_t)r;
-        if (r == c.n_reads - 1) for (int64_t t = t1 > t0 ? t1 : t0; t < ntiles; ++t) out[2 * t] = (uint32_t)c.n_reads;
+        for (int64_t t = t0; t < t1; ++t) out[2 * t] = (uint32_t)(s0 + r);
+        if (r == n - 1) for (int64_t t = t1 > t0 ? t1 : t0; t < ntiles; ++t) out[2 * t] = (uint32_t)(s0 + n);
     }
-    // hi: tiles t with pos[r] <= p1(t) < pos[r+1]      (p1(t) >= x  <=>  t >= ceil((x - pos0 - 63) / 64))
+    // hi: tiles t with key[r] <= p1(t) < key[r+1]      (p1(t) >= x  <=>  t >= ceil((x - pos0 - 63) / 64))
     {
-        int64_t t0 = tiles_ceil_div64((int64_t)pos[r] - c.pos0 - (TILE - 1));
-        int64_t t1 = r + 1 < c.n_reads ? tiles_ceil_div64((int64_t)pos[r + 1] - c.pos0 - (TILE - 1)) : ntiles;
+        int64_t t0 = tiles_ceil_div64((int64_t)key[r] - c.pos0 - (TILE - 1));
+        int64_t t1 = r + 1 < n ? tiles_ceil_div64((int64_t)key[r + 1] - c.pos0 - (TILE - 1)) : ntiles;
         if (t1 > ntiles) t1 = ntiles;
-        if (r == 0) for (int64_t t = 0; t < t0 && t < ntiles; ++t) out[2 * t + 1] = 0u;
-        for (int64_t t = t0; t < t1; ++t) out[2 * t + 1] = (uint32_t)(r + 1);
+        if (r == 0) for (int64_t t = 0; t < t0 && t < ntiles; ++t) out[2 * t + 1] = (uint32_t)s0;
+        for (int64_t t = t0; t < t1; ++t) out[2 * t + 1] = (uint32_t)(s0 + r + 1);
     }
 }
 
@@ -529,45 +545,60 @@ __device__ __forceinline__ void count_if(uint32_t& x, uint64_t mask) {
 }
 
 enum { PILEUP_WAVES = 4 };   // 256 threads: 4 consecutive tiles (256 positions) per workgroup
-enum { WIN_U4 = 12 };        // bq window per staged read: 12 x 16 B = 96 elements (>= 64 tile positions + 7 of alignment slack)
-enum { ROW_U4 = 15 };        // LDS row = window + the read's accumulate half (2 x 16 B) + its float constants (16 B)
-#ifndef BRC_TRIGGER
-#define BRC_TRIGGER 4      // step of a batch at which the next batch's windows are requested (even)
-#endif
-enum { BATCH = 16 };         // reads staged per batch (LDS rows per wave): 16 x 240 B = 3.75 KB per wave
+enum { WIN_U4 = 9 };         // event-word window of a staged piece: 9 x 16 B = 72 elements >= 64 tile positions + 7 of alignment
+enum { ROW_BYTES = WIN_U4 * 16 };
+enum { QCAP = 2 * HALF + 2 };   // deferred entries of one half-batch: at most a third-allele and a huge-integer entry per piece
+static_assert(HALF * WIN_U4 <= 64, "one direct-to-LDS instruction stages a half-batch");
+static_assert(HALF % 3 == 0, "the piece-record registers rotate with period 3");
 
-// PL: per-library form (-p): a wave visits only the reads of its own library (and library-less ones), see the read loop.
-// V: 0 = production; 1/2/3/4 = profiling ablations (no plane stores / probe+loads only / stores only / tile prologue +
-// first-batch staging + stores, no read loop), BRC_PILEUP_VARIANT
-template <int V, bool PL>
-__global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in, const DRead* __restrict__ reads,
-                                                              const uint2* __restrict__ rng, int64_t ntiles, Planes pl,
-                                                              uint4* __restrict__ tile_ctr,
-                                                              // read-only inputs again as restrict-qualified kernel arguments:
-                                                              // only then may wave-uniform reads of them use scalar loads
-                                                              const uint32_t* __restrict__ cigar_ro, const RcpPair* __restrict__ rcp,
-                                                              const uint16_t* __restrict__ bq_ro) {
+struct PRec { uint4 h0, h1, h2, h3; };     // PieceHot as four scalar 16-byte words
+__device__ __forceinline__ PieceHot prec_hot(const PRec& r) {
+    PieceHot h;
+    h.rs = (int32_t)r.h0.x; h.a = (int32_t)r.h0.y; h.len = (int32_t)r.h0.z; h.ext = (int32_t)r.h0.w;
+    h.thr = r.h1.x; h.tp_flags = r.h1.y; h.w1 = r.h1.z; h.w2 = r.h1.w;
+    h.w3 = r.h2.x; h.snm = __uint_as_float(r.h2.y); h.rcpL = __uint_as_float(r.h2.z); h.Lf = __uint_as_float(r.h2.w);
+    h.rcpC = __uint_as_float(r.h3.x); h.center = __uint_as_float(r.h3.y); h.left = (int32_t)r.h3.z; h.q2 = (int32_t)r.h3.w;
+    return h;
+}
+
+// One wave = one (64-position tile, library); lane == position.  The wave walks the tile's pieces [lo, hi) of its library
+// in stream (= pileup column) order, in half-batches of HALF = 6:
+//  * piece records: one 64-byte scalar load per piece, two pieces ahead, rotating through three scalar register sets —
+//    everything wave-uniform (positions, lengths, thresholds, packed addends, division constants) lives in SGPRs;
+//  * event words: the 72-element window of each piece's row that this tile can touch is copied by ONE direct-to-LDS
+//    instruction per half-batch (global_load_lds_dwordx4: lane = row * 9 + chunk, no VGPR round trip) into a two-half
+//    ring; the copy of half-batch h + 2 is issued when h is done, its addresses come from a 16-byte cold-record load
+//    issued one half-batch earlier;
+//  * one pipeline step = probe of piece j + 1 (coverage ballots, event word and table look-ups: LDS reads only) and
+//    accumulate of piece j (quality / bucket ballots, one exec region with the 10 adds of the dominant bucket, a usually
+//    skipped one for everything else); lane conditions are 64-bit masks in scalar registers;
+//  * per bucket a lane holds three PACKED integer registers (counters 10 bits each; mapq | sse; zm | clipped), the
+//    base-quality sum and the four fp32 sums; the packed ones are flushed to the planes every K pieces (rare: K = 63
+//    for short reads) and at the end of the tile;
+//  * third alleles (a lane keeps its reference base and the first other base in registers) and PF_HUGE integers are
+//    queued and drained into the planes between half-batches, in piece order.
+__global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn in, const uint4* __restrict__ hot4, const PieceCold* __restrict__ cold,
+                                                               const uint2* __restrict__ rng, int64_t ntiles, Planes pl, uint4* __restrict__ tile_ctr,
+                                                               const uint16_t* __restrict__ bq_ro, const uint32_t* __restrict__ unavail_ro) {
     // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch order); give every XCD one contiguous
-    // run of tiles so neighbouring tiles, which share most of their reads, hit the same 4-MiB L2.
-    const uint32_t nb = gridDim.x;            // multiple of 8
-    const uint32_t per = nb >> 3;
+    // run of tiles so neighbouring tiles, which share most of their pieces, hit the same 4-MiB L2.
+    const uint32_t nbk = gridDim.x;           // multiple of 8
+    const uint32_t per = nbk >> 3;
     const uint32_t wg = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-    // One LDS object so the order is fixed: the quotient tables first, the staging rows last (a lane that is outside a
-    // read fetches an unused element a little before its row: that must stay inside the allocation).
-    //   q[n] = (float)n / (float)L0 for 0 <= n <= L0 (see event_terms_tab), 0.0f for L0 < n <= 2 L0 + 1: a read without
-    //          a Q2 position looks up |qpos - (2 L0 + 1)|, which lands in the zero part;   e[n] = 1.0 - (double)q[n]
+    //   q[n] = (float)n / (float)L0 for 0 <= n <= L0 (see piece_terms_tab);   e[n] = 1.0 - (double)q[n]
+    struct QEnt { uint32_t piece, kind, mlo, mhi; };
     struct Lds {
-        float q[2 * TABLE_MAX + 4];
-        double e[TABLE_MAX + 1];
-        alignas(16) uint4 rows[PILEUP_WAVES][BATCH][ROW_U4];
+        float q[TABLE_MAX + 4];
+        double e[TABLE_MAX + 2];
+        alignas(16) uint4 rows[PILEUP_WAVES][2 * HALF][WIN_U4];
+        QEnt queue[PILEUP_WAVES][QCAP];
     };
     __shared__ Lds lds;
-    if (V != 3) {
+    {
         const float l0 = (float)c.table_len;
-        for (int n = threadIdx.x; n <= 2 * c.table_len + 1; n += PILEUP_WAVES * 64) {
-            const float qv = n <= c.table_len ? (float)n / l0 : 0.0f;
-            lds.q[n] = qv;
-            if (n <= c.table_len) lds.e[n] = 1.0 - (double)qv;
+        for (int n = threadIdx.x; n <= c.table_len; n += PILEUP_WAVES * 64) {
+            const float qv = (float)n / l0;
+            lds.q[n] = qv; lds.e[n] = 1.0 - (double)qv;
         }
         __syncthreads();
     }
@@ -576,274 +607,217 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup(DevCfg c, DevIn in
     const int64_t tile = (int64_t)wg * PILEUP_WAVES + wv;
     if (tile >= ntiles) return;
     const int lib = blockIdx.y;
-    const uint2 r2 = rng[tile];
+    const uint2 r2 = rng[(int64_t)lib * ntiles + tile];
     const uint32_t lo = __builtin_amdgcn_readfirstlane(r2.x), hi = __builtin_amdgcn_readfirstlane(r2.y);
     const int64_t k = tile * TILE + lane;
     const bool valid = k < c.P;
     const int32_t p = (int32_t)(c.pos0 + k);
+    const int32_t p0 = (int32_t)(c.pos0 + tile * TILE);                     // first position of the tile (scalar)
 
-    LaneAcc a;
-    lane_init(a);
-    a.dom_b = valid ? dominant_bucket(c, in, p) : 1u;
-    LaneOut o; o.pl = pl; o.lib = lib; o.k = valid ? k : 0;
-    // The tile's reads are visited in file order, in batches of BATCH = 16, software-pipelined at batch level:
-    //  * lane table: lanes r, r+16, r+32, r+48 hold the probe half (pos, end, bq row, misc, l_qseq) of read base+r;
-    //  * staging: those four lanes copy the 96-element window of that read's bq row that this tile can touch into a
-    //    wave-private LDS row (3 x 16-byte loads per lane); the loads of batch b+1 are issued into registers at the START
-    //    of batch b's read loop and written to LDS at its END, and the lane table of batch b+2 is prefetched, so the
-    //    memory latency of staging hides behind the loop (only the first batch of a tile pays it);
-    //  * read loop: read j's pos/end/misc are broadcast with v_readlane, its event word comes from LDS row j
-    //    (ds_read_u16, issued one read ahead), its accumulate half (Zm integers, addends, float constants) from the
-    //    same row with three broadcast ds_read_b128 — no scalar/vector memory latency inside the loop.  Reads with a general CIGAR are not staged; their event words come from global
-    //    memory (uncommon).
-    if (lo < hi && V != 3) {
-        const uint32_t libsel = (uint32_t)lib + 1u;
-        struct ProbeHalf { int32_t pos, end; uint32_t cig_off, n_cigar; uint64_t bq_off; uint32_t misc; int32_t l_qseq; int32_t q2, tp; };
-        struct Tab { int32_t pos, end; uint64_t bq_off; uint32_t misc; int32_t l_qseq; int32_t q2, tp; };
-        static_assert(sizeof(ProbeHalf) == 40 && sizeof(DRead) == 64, "DRead layout");
-        const char* __restrict__ rbase = reinterpret_cast<const char*>(reads);
-        uint4(*rows)[ROW_U4] = lds.rows[wv];
-        const int32_t p0 = (int32_t)(c.pos0 + tile * TILE);                 // first position of the tile (scalar)
-        const uint32_t row = (uint32_t)lane & (uint32_t)(BATCH - 1), slot = (uint32_t)lane >> 4;   // slot 0..3
-        // lanes past the region's last position stand on INT32_MIN: (uint32)(INT32_MIN - pos) = 2^31 - pos >= end - pos for
-        // every read (end <= 2^31 - 1), so no coverage test is ever true for them
-        const int32_t pe = valid ? p : INT32_MIN;
+    LaneAcc2 a;
+    lane2_init(a, c.force_dom >= 0 ? (uint32_t)c.force_dom : (valid ? dominant_bucket(c, in, p) : 1u));
+    const int64_t kk = valid ? k : 0;
+
+    if (lo < hi) {
+        // lanes past the region's last position stand far left of every piece: no coverage test is ever true for them
+        // (d = 2^31 + lane + p0 - rs >= 2^31 - (rs - p0) >= ext for every piece, because rs + ext <= 2^31 - 1 and p0 >= 0)
+        const uint32_t lanev = valid ? (uint32_t)lane : (0x80000000u | (uint32_t)lane);
         const uint32_t L0 = (uint32_t)c.table_len;
-#define BRC_RL(x, j) __builtin_amdgcn_readlane((int)(x), (int)(j))
-#define BRC_ALL(cond) ((cond) ? ~0ull : 0ull)
-        // per-library form: does this wave visit the read at all?  (its own library, or none: LIBRARY_UNAVAILABLE, :281-284)
-#define BRC_MINE(misc_) (!PL || (((misc_) >> 16) & 0xffu) == libsel || (((misc_) >> 16) & 0xffu) == 0u)
-        // lane table of the batch starting at read b0 (clamped to the tile's reads)
-#define BRC_LD_TAB(TT, b0)                                                                                              \
+        char* const rows_base = reinterpret_cast<char*>(&lds.rows[wv][0][0]);
+        QEnt* const queue = lds.queue[wv];
+        uint32_t qn = 0;                                                       // queued entries (scalar)
+        int32_t since_flush = 0;
+        // ---- staging: lane -> (row, chunk) of a half-batch
+        const uint32_t srow = (uint32_t)lane / (uint32_t)WIN_U4, schunk = (uint32_t)lane % (uint32_t)WIN_U4;
+        const bool slane = lane < HALF * WIN_U4;
+        // {bq_off, a} of piece b0 + srow (clamped): what the window copy of that row needs
+#define BRC_LD_TAB(T, b0) { const uint32_t mi = (b0) + srow < hi ? (b0) + srow : hi - 1u; T = *reinterpret_cast<const uint4*>(cold + mi); }
+        // window copy of the half-batch starting at piece b0 into ring half `hf`: element window [ws, ws + 72) of the row,
+        // ws = floor8(p0 - a) (may start before the row: the event-word stream is padded)
+#define BRC_STAGE(T, b0, hf)                                                                                             \
         {                                                                                                                 \
-            const uint32_t ri = (b0) + row < hi ? (b0) + row : hi - 1u;                                                   \
-            const ProbeHalf* hp = reinterpret_cast<const ProbeHalf*>(rbase + (size_t)ri * 64u);                           \
-            TT.pos = hp->pos; TT.end = hp->end; TT.bq_off = hp->bq_off; TT.misc = hp->misc; TT.l_qseq = hp->l_qseq;       \
-            /* byte offsets for the quotient-table look-ups of M_FAST reads; no Q2 position -> the zero part of q[] */    \
-            TT.q2 = (TT.misc & M_Q2OK) ? hp->q2 * 4 : (int32_t)(2u * L0 + 1u) * 4; TT.tp = hp->tp * 4;                     \
-        }
-        // window loads of a batch into registers (W0..W2 = chunks slot, slot+4, slot+8 of the lane's row) ...
-#define BRC_LD_WIN(TT, b0, W0, W1, W2, W3, OK)                                                                          \
-        {                                                                                                                 \
-            const int32_t d0 = p0 - TT.pos - (int32_t)((TT.misc >> 24) & 0x7fu);       /* query offset of the tile start, lower bound */ \
-            const uint32_t ws = d0 > 0 ? ((uint32_t)d0 & ~7u) : 0u;                                                       \
-            OK = (b0) + row < hi && (TT.misc & M_STAGED) && TT.end > TT.pos && (int32_t)ws < TT.l_qseq + 8 && BRC_MINE(TT.misc); \
-            if (OK) {                                                                                                     \
-                const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bq_ro + TT.bq_off + ws) + slot;           \
-                W0 = src[0]; W1 = src[4]; W2 = src[8];                                                                    \
+            if (slane && (b0) + srow < hi) {                                                                              \
+                const int64_t boff = (int64_t)(((uint64_t)T.y << 32) | T.x);                                              \
+                const int32_t ws = (p0 - (int32_t)T.z) & ~7;                                                              \
+                const uint16_t* src = bq_ro + (boff + ws) + 8u * schunk;                                                  \
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,                      \
+                    (void __attribute__((address_space(3)))*)(rows_base + (hf) * (HALF * ROW_BYTES)), 16, 0, 0);          \
             }                                                                                                             \
-            /* accumulate half (slots 0,1: the two 16-byte halves at +32) and float constants (slot 2) of read b0+row */ \
-            const uint32_t ri = (b0) + row < hi ? (b0) + row : hi - 1u;                                                   \
-            if (slot < 2u) W3 = *reinterpret_cast<const uint4*>(rbase + (size_t)ri * 64u + 32u + 16u * slot);             \
-            else if (slot == 2u) W3 = *reinterpret_cast<const uint4*>(rcp + ri);                                          \
         }
-        // the staging predicate of BRC_LD_WIN again (recomputed at store time so it is not carried through the read loop)
-#define BRC_LD_WIN_OK(TT, b0, OK)                                                                                       \
+        // piece record m (clamped) by scalar loads
+#define BRC_LD_REC(R, m) { const uint32_t mm = (m) < hi ? (m) : hi - 1u; const uint4* hp = hot4 + (size_t)mm * 4u; R.h0 = hp[0]; R.h1 = hp[1]; R.h2 = hp[2]; R.h3 = hp[3]; }
+        struct Stage { uint32_t w; float t, tq2; double sev; uint64_t m_in; };
+        // PROBE of the piece in R, staged in ring row `rw`
+#define BRC_PROBE(R, rw, S)                                                                                             \
         {                                                                                                                 \
-            const int32_t d0 = p0 - TT.pos - (int32_t)((TT.misc >> 24) & 0x7fu);                                                    \
-            const uint32_t ws = d0 > 0 ? ((uint32_t)d0 & ~7u) : 0u;                                                       \
-            OK = (b0) + row < hi && (TT.misc & M_STAGED) && TT.end > TT.pos && (int32_t)ws < TT.l_qseq + 8 && BRC_MINE(TT.misc); \
-        }
-        // ... and their write into the LDS rows
-#define BRC_ST_WIN(W0, W1, W2, W3, OK)                                                                                  \
-        {                                                                                                                 \
-            if (OK) { rows[row][slot] = W0; rows[row][slot + 4u] = W1; rows[row][slot + 8u] = W2; }                       \
-            if (slot < 3u) rows[row][(uint32_t)WIN_U4 + slot] = W3;                                                       \
-        }
-        // One read against the wave goes through two stages, software-pipelined one read apart:
-        //   PROBE  coverage test, column count, the lane's event word (quality | bucket << 8) from the read's LDS row and
-        //          the three event terms (table look-ups for M_FAST reads: everything in flight is an LDS read);
-        //   ACC    base-quality filter, depth, warning counts and the BasicStat adds of the dominant / alternate bucket.
-        // Lane conditions are kept as 64-bit wave masks in scalar registers (ballot of ONE compare each, combined with
-        // scalar and/andn2) so counting is one v_addc per counter and the two predicated regions of ACC are the only
-        // exec changes.  Per-read constants come from the lane table with v_readlane (pos, end, misc, q2, tp) or as one
-        // broadcast 16-byte LDS read (zm_sum, sse_add, snm_add, clipped).  A read that is not M_FAST (general CIGAR,
-        // clipped, odd length, unavailable library: a few percent) takes the one uniform branch into the general probe.
-        struct Stage { uint32_t v; float tq2, ts3p; double tsev; uint64_t m_want, m_pass; uint32_t misc; int32_t thr; };
-#define BRC_PROBE(j, S)                                                                                                 \
-        {                                                                                                                 \
-            const int32_t pos_j = BRC_RL(T.pos, j), end_j = BRC_RL(T.end, j);                                             \
-            const uint32_t misc_j = (uint32_t)BRC_RL(T.misc, j);                                                          \
-            const uint32_t rlib = (misc_j >> 16) & 0xffu;                                                                 \
-            /* a read below the mapping-quality cut (:288) or carrying SECONDARY/QCFAIL/DUP (:295-310) never passes */                        \
-            S.thr = ((int)((misc_j >> 8) & 0xffu) >= c.min_mapq && !(misc_j & M_NOCOUNT)) ? c.min_bq : 256;                                          \
-            S.misc = misc_j;                                                                                              \
-            int32_t qpos = pe - pos_j;                                                                                    \
-            uint64_t m_in;                                                            /* lanes whose column holds the read */ \
-            if (__builtin_expect((misc_j & M_FAST) != 0u, 1)) {                                                           \
-                /* another library's read has length 0 here (without -p every read carries library 1 == libsel) */       \
-                uint32_t len = rlib == libsel ? (uint32_t)(end_j - pos_j) : 0u;                                           \
-                asm("" : "+s"(len));      /* keep it ONE scalar select (else: a branch or a lane-mask round trip) */     \
-                m_in = __builtin_amdgcn_ballot_w64((uint32_t)qpos < len);                                                 \
-                S.m_want = m_in; S.m_pass = m_in;                                                                         \
-                const int32_t d0 = p0 - pos_j;                                                                            \
-                const uint32_t ws = d0 > 0 ? ((uint32_t)d0 & ~7u) : 0u;                                                   \
-                /* lanes outside the read use query position 0: some element of LDS at or a little before the row */     \
-                const uint32_t qp = __builtin_amdgcn_inverse_ballot_w64(m_in) ? (uint32_t)qpos : 0u;                      \
-                S.v = (uint32_t)*reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(rows[(j)]) - 2u * ws + 2u * qp); \
-                /* event_terms_tab as byte offsets: 4|qp - q2|, 4|qp - tp|, 8|2 qp - L0| */                               \
-                const uint32_t qp4 = qp << 2;                                                                             \
-                S.tq2 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds.q) + sad_u32(qp4, (uint32_t)BRC_RL(T.q2, j)));  \
-                S.ts3p = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds.q) + sad_u32(qp4, (uint32_t)BRC_RL(T.tp, j))); \
-                S.tsev = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds.e) + sad_u32(qp4 << 2, L0 << 3)); \
+            const int32_t s_d = p0 - (int32_t)R.h0.x, s_c = p0 - (int32_t)R.h0.y;                                         \
+            const uint32_t d = lanev + (uint32_t)s_d;                                                                     \
+            const uint64_t m_cov = __builtin_amdgcn_ballot_w64(d < R.h0.w);                                               \
+            count_if(a.ncol, m_cov);                                          /* lib_counts[library] (:286) */            \
+            S.m_in = __builtin_amdgcn_ballot_w64(d < R.h0.z);                                                             \
+            const uint32_t off = (uint32_t)(rw) * (uint32_t)ROW_BYTES + 2u * ((uint32_t)s_c & 7u);                        \
+            S.w = (uint32_t)*reinterpret_cast<const uint16_t*>(rows_base + off + 2u * (uint32_t)lane);                    \
+            const uint32_t fl = R.h1.y >> 24;                                                                             \
+            if (__builtin_expect((fl & PF_TABLE) != 0u, 1)) {                                                             \
+                const uint32_t qp4 = 4u * (uint32_t)lane + 4u * (uint32_t)s_c;                                            \
+                S.t = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds.q) + sad_u32(qp4, R.h1.y & 0xffffffu)); \
+                S.sev = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds.e) + sad_u32(qp4 << 2, L0 << 3)); \
+                S.tq2 = S.t;                                  /* q2 == tp or no q2 at all: masked in the accumulate stage */ \
             } else {                                                                                                      \
-                const uint64_t m_cov = __builtin_amdgcn_ballot_w64((uint32_t)qpos < (uint32_t)(end_j - pos_j));                 \
-                bool mine = true;                                                                                         \
-                if (c.per_lib) {                                                                                          \
-                    if (rlib == 0) { if (__builtin_amdgcn_inverse_ballot_w64(m_cov) && a.unavail == NONE32) a.unavail = base + (j); mine = false; } \
-                    else if (rlib != libsel) mine = false;                                                                \
-                }                                                                                                         \
-                m_in = 0; S.m_want = 0; S.m_pass = 0; S.v = 0u; S.tq2 = 0.0f; S.ts3p = 0.0f; S.tsev = 0.0;                \
-                if (mine) {                                                                                               \
-                    /* the read's constants from its LDS row */                                                           \
-                    const uint4 h0 = rows[(j)][WIN_U4], h2 = rows[(j)][WIN_U4 + 2];                                       \
-                    uint64_t m_del = 0, m_ins = 0;                                                                        \
-                    m_in = m_cov;                                                                                         \
-                    if (misc_j & M_CLIPM) qpos += (int32_t)h0.z;  /* [S] M [S]: offset of the leading clip */              \
-                    else if (!(misc_j & M_SIMPLE)) {   /* general CIGAR: wave-uniform walk on the scalar unit */          \
-                        const ProbeHalf* hj = reinterpret_cast<const ProbeHalf*>(rbase + (size_t)(base + (j)) * 64u);     \
-                        const Ev e = resolve_cigar(cigar_ro + hj->cig_off, hj->n_cigar, pos_j, p);                        \
-                        m_in &= __builtin_amdgcn_ballot_w64(e.in_col); m_del = __builtin_amdgcn_ballot_w64(e.is_del);     \
-                        m_ins = __builtin_amdgcn_ballot_w64(e.indel >= 1); qpos = e.qpos;                                 \
-                    }                                                                                                     \
-                    S.m_want = m_in & ~m_del;                                                                             \
-                    S.m_pass = c.insertion_centric ? S.m_want & ~m_ins : S.m_want;                                        \
-                    const bool want = __builtin_amdgcn_inverse_ballot_w64(S.m_want);                                      \
-                    if (misc_j & M_STAGED) {      /* event word from the LDS row */                                       \
-                        const int32_t d0 = p0 - pos_j - (int32_t)((misc_j >> 24) & 0x7fu);                                          \
-                        const uint32_t ws = d0 > 0 ? ((uint32_t)d0 & ~7u) : 0u;                                           \
-                        const uint32_t e = ((uint32_t)qpos - ws) & 127u;                                                  \
-                        S.v = (uint32_t)reinterpret_cast<const uint16_t*>(rows[(j)])[e < (uint32_t)(WIN_U4 * 8) ? e : 0u];  \
-                    } else {                      /* > 24 inserted/deleted/clipped bases: fetch from global memory and      \
-                                                     consume it here, so no vector load is pending at the merge point   */  \
-                        const ProbeHalf* hj = reinterpret_cast<const ProbeHalf*>(rbase + (size_t)(base + (j)) * 64u);     \
-                        uint32_t t = want ? (uint32_t)bq_ro[hj->bq_off + (uint64_t)(uint32_t)qpos] : 0u;                  \
-                        asm volatile("" : "+v"(t));                                                                       \
-                        S.v = t;                                                                                          \
-                    }                                                                                                     \
-                    /* event terms by exact reciprocal division (event_terms_fast) */                                     \
-                    DRead RX; RX.misc = misc_j; RX.q2 = (int32_t)h0.x; RX.tp = (int32_t)h0.y; RX.left = (int32_t)h0.z; RX.clipped = (int32_t)h0.w; \
-                    RcpPair C; C.rcpL = __uint_as_float(h2.x); C.rcpC = __uint_as_float(h2.y); C.Lf = __uint_as_float(h2.z); C.center = __uint_as_float(h2.w); \
-                    const EvTerms t = event_terms_fast(RX, C, want ? qpos : 0);                                           \
-                    S.tq2 = t.q2; S.ts3p = t.s3p; S.tsev = t.sev;                                                         \
-                }                                                                                                         \
+                const PieceHot H = prec_hot(R);                                                                           \
+                const EvTerms t = piece_terms_div(H, (int)((uint32_t)lane + (uint32_t)s_c));                              \
+                S.t = t.s3p; S.tq2 = t.q2; S.sev = t.sev;                                                                 \
             }                                                                                                             \
-            count_if(a.ncol, m_in);                                                   /* lib_counts[library] (:286) */    \
         }
-        // accumulate stage of read j (S = its probe results)
-#define BRC_ACC(j, S)                                                                                                   \
+        // ACC of the piece in R (S = its probe results), piece index m
+#define BRC_ACC(R, S, m)                                                                                                \
         {                                                                                                                 \
-            if (V == 2) a.depth += S.v + (uint32_t)S.tsev;                                                                \
-            else {                                                                                                        \
-                const uint32_t q = S.v & 0xffu, b = S.v >> 8;                                                             \
-                const uint64_t m_bq = __builtin_amdgcn_ballot_w64((int)q >= S.thr);       /* :288 */                      \
-                count_if(a.depth, S.m_want & m_bq);                                       /* mapq_n (:312) */             \
-                const uint64_t m_p = S.m_pass & m_bq;                                     /* :343 */                      \
-                RQ.misc = S.misc; RQ.zm_sum = g1.x; RQ.sse_add = g1.y; RQ.snm_add = __uint_as_float(g1.z); RQ.clipped = (int32_t)g1.w; \
-                EvTerms t; t.q2 = S.tq2; t.s3p = S.ts3p; t.sev = S.tsev;                                                  \
-                const uint32_t smw = (S.misc / M_SMW) & 1u, nmw = (S.misc / M_NMW) & 1u;  /* process_read warnings */     \
+            const uint32_t fl = R.h1.y >> 24;                                                                             \
+            const uint64_t m_p = S.m_in & __builtin_amdgcn_ballot_w64(S.w >= R.h1.x);         /* :288 */                  \
+            count_if(a.depth, m_p);                                                            /* mapq_n (:312) */         \
+            if (!(fl & PF_NB)) {                                                               /* :343 with -i */          \
+                count_if(a.w_sm, (fl & PF_SMW) ? m_p : 0ull); count_if(a.w_nm, (fl & PF_NMW) ? m_p : 0ull);               \
+                const uint32_t b = S.w & 0xffu, q = S.w >> 8;                                                             \
+                /* a table piece without a Q2 position adds +0.0f (the identity on these sums) */                        \
+                const float tq2 = __uint_as_float(__float_as_uint(S.tq2) & (((fl & (PF_TABLE | PF_Q2OK)) == PF_TABLE) ? 0u : 0xffffffffu)); \
                 const uint64_t m_dom = m_p & __builtin_amdgcn_ballot_w64(b == a.dom_b);                                   \
-                /* independent single-predecessor regions (see lane_accumulate in brc_core.h) */                         \
                 if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(m_dom), 1)) {                                    \
-                    acc_apply(a.di, a.df, RQ, t, q, false); a.w_sm += smw; a.w_nm += nmw;                                 \
+                    a.dom.w1 += R.h1.z; a.dom.w2 += R.h1.w; a.dom.w3 += R.h2.x; a.dom.sbq += q;                           \
+                    a.dom.f[F_SQ2] += tq2; a.dom.f[F_S3P] += S.t;                                                         \
+                    a.dom.f[F_SEV] = (float)((double)a.dom.f[F_SEV] + S.sev);                                             \
+                    a.dom.f[F_SNM] += __uint_as_float(R.h2.y);                                                            \
                 }                                                                                                         \
-                if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(m_p & ~m_dom), 0)) {                             \
-                    const bool take_alt = a.alt_b == NB_NONE || a.alt_b == b;                                             \
-                    a.w_sm += smw; a.w_nm += nmw;                                                                         \
-                    if (take_alt) { a.alt_b = b; acc_apply(a.xi, a.xf, RQ, t, q, false); }                                \
-                    if (!take_alt) overflow_event(c, o, a, b, RQ, t, q);                                                  \
+                const uint64_t m_rest = m_p & ~m_dom;                                                                     \
+                uint64_t m_ovf = 0;                                                                                       \
+                if (__builtin_expect(m_rest != 0ull, 0)) {                                                                \
+                    bool ovf = false;                                                                                     \
+                    if (__builtin_amdgcn_inverse_ballot_w64(m_rest)) {                                                    \
+                        const bool take_alt = a.alt_b == NB_NONE || a.alt_b == b;                                         \
+                        if (take_alt) {                                                                                   \
+                            a.alt_b = b;                                                                                  \
+                            a.alt.w1 += R.h1.z; a.alt.w2 += R.h1.w; a.alt.w3 += R.h2.x; a.alt.sbq += q;                   \
+                            a.alt.f[F_SQ2] += tq2; a.alt.f[F_S3P] += S.t;                                                 \
+                            a.alt.f[F_SEV] = (float)((double)a.alt.f[F_SEV] + S.sev);                                     \
+                            a.alt.f[F_SNM] += __uint_as_float(R.h2.y);                                                    \
+                        }                                                                                                 \
+                        ovf = !take_alt;                                                                                  \
+                    }                                                                                                     \
+                    m_ovf = __builtin_amdgcn_ballot_w64(ovf);                                                             \
+                    if (m_ovf) { if (lane == 0) { QEnt e; e.piece = (m); e.kind = 0u; e.mlo = (uint32_t)m_ovf; e.mhi = (uint32_t)(m_ovf >> 32); queue[qn] = e; } ++qn; } \
+                }                                                                                                         \
+                if (__builtin_expect((fl & PF_HUGE) != 0u, 0)) {                                                          \
+                    const uint64_t m_int = m_p & ~m_ovf;                                                                  \
+                    if (m_int) { if (lane == 0) { QEnt e; e.piece = (m); e.kind = 1u; e.mlo = (uint32_t)m_int; e.mhi = (uint32_t)(m_int >> 32); queue[qn] = e; } ++qn; } \
                 }                                                                                                         \
             }                                                                                                             \
         }
-        // one pipeline step: constants and probe of read j+1 into (GN, SN), then accumulate read j from (GC, SC).  Nothing
-        // inside a step consumes an LDS result issued in the same step, so the only LDS wait is at the top of a step.
-#define BRC_STEP(jc, jn, HASN, SC, SN, GC, GN)                                                                          \
-        {                                                                                                                 \
-            /* every LDS read of the previous step has had a whole accumulate stage to land: wait for them HERE, on    \
-               every path, so that the compiler does not put a full lgkmcnt(0) wait (covering this step's own reads)   \
-               in front of the first use inside the accumulate stage */                                                \
+        // one pipeline step inside a half-batch: J = step (compile time), piece base + J is accumulated, base + J + 1 probed,
+        // the record of base + J + 2 requested.  RC / RN / RL = the three record sets in their roles of this step.
+#define BRC_STEP(J, RC, RN, RL, SC, SN)                                                                                 \
+        if ((J) < nb) {                                                                                                   \
+            /* all LDS and scalar-memory results of the previous step (incl. the record RN) have had a whole accumulate  \
+               stage to land: wait for them here, once.  The last step probes the first row of the OTHER ring half: its   \
+               copy (and the cold-record load behind it) was issued at the previous half-batch boundary.               */ \
+            if ((J) == HALF - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
             __builtin_amdgcn_s_waitcnt(0xC07F);                               /* lgkmcnt(0) */                             \
-            if (HASN) {                                                                                                   \
-                GN = rows[(jn)][WIN_U4 + 1];                                  /* zm_sum, sse_add, snm_add, clipped */      \
-                BRC_PROBE((jn), SN)                                                                                       \
+            BRC_LD_REC(RL, base + (J) + 2u)                                                                               \
+            if (base + (J) + 1u < hi) {                                                                                   \
+                const uint32_t rw = ((J) + 1 < HALF) ? hf * HALF + (J) + 1 : (hf ^ 1u) * HALF;                            \
+                BRC_PROBE(RN, rw, SN)                                                                                     \
             }                                                                                                             \
-            { const uint4 g1 = GC; BRC_ACC(jc, SC) }                                                                      \
+            BRC_ACC(RC, SC, base + (J))                                                                                   \
         }
-        Tab T, Tn;
-        uint4 W0 = make_uint4(0, 0, 0, 0), W1 = W0, W2 = W0, W3 = W0; bool wok = false;
+        uint4 T;
         BRC_LD_TAB(T, lo)
-        Tn = T;
-        BRC_LD_WIN(T, lo, W0, W1, W2, W3, wok)
-        BRC_ST_WIN(W0, W1, W2, W3, wok)                                           // first batch: staged synchronously
-        DRead RQ; RQ.pos = RQ.end = 0; RQ.cig_off = RQ.n_cigar = 0; RQ.bq_off = 0; RQ.l_qseq = 0; RQ.q2 = RQ.tp = RQ.left = 0;
-        if (V == 4) a.depth += rows[row][slot].x;                                  // ablation: tile prologue + epilogue only
-        for (uint32_t base = lo; base < hi && V != 4; base += (uint32_t)BATCH) {
-            const uint32_t nb = (hi - base) < (uint32_t)BATCH ? (hi - base) : (uint32_t)BATCH;
-            const bool more = base + (uint32_t)BATCH < hi;                    // then nb == BATCH
-            if (more) BRC_LD_TAB(Tn, base + (uint32_t)BATCH)                  // lane table of the next batch
-            Stage S0, S1;
-            if (!PL) {
-                uint4 G0 = rows[0][WIN_U4 + 1], G1;
-                BRC_PROBE(0u, S0)
-                S1 = S0; G1 = G0;
-                // two reads per trip so the two stage buffers swap roles instead of being copied
-                for (uint32_t j = 0; j < nb; j += 2u) {
-                    // a quarter into the batch the next batch's windows are requested (its lane table has arrived by now);
-                    // they land in registers while the remaining reads are processed and are written to LDS after the loop
-                    if (j == (uint32_t)(BRC_TRIGGER) && more) { bool ok2; BRC_LD_WIN(Tn, base + (uint32_t)BATCH, W0, W1, W2, W3, ok2) (void)ok2; }
-                    BRC_STEP(j, j + 1u, j + 1u < nb, S0, S1, G0, G1)
-                    if (j + 1u >= nb) break;
-                    BRC_STEP(j + 1u, j + 2u, j + 2u < nb, S1, S0, G1, G0)
-                }
-            } else {
-                // per-library form: only the reads of this wave's library (and library-less reads) are visited — the
-                // other libraries' waves of the same tile take the rest — so a wave's steps shrink by the library count
-                uint32_t todo = (uint32_t)__builtin_amdgcn_ballot_w64(BRC_MINE(T.misc)) & ((1u << nb) - 1u) & 0xffffu;
-                if (more) { bool ok2; BRC_LD_WIN(Tn, base + (uint32_t)BATCH, W0, W1, W2, W3, ok2) (void)ok2; }   // few steps: request at once
-                if (todo) {
-                    uint32_t jc = (uint32_t)__builtin_ctz(todo); todo &= todo - 1u;
-                    uint4 G0 = rows[jc][WIN_U4 + 1], G1;
-                    BRC_PROBE(jc, S0)
-                    S1 = S0; G1 = G0;
-                    for (;;) {
-                        const bool h1 = todo != 0u; const uint32_t j1 = h1 ? (uint32_t)__builtin_ctz(todo) : 0u; todo &= todo - 1u;
-                        BRC_STEP(jc, j1, h1, S0, S1, G0, G1)
-                        if (!h1) break;
-                        const bool h2 = todo != 0u; const uint32_t j2 = h2 ? (uint32_t)__builtin_ctz(todo) : 0u; todo &= todo - 1u;
-                        BRC_STEP(j1, j2, h2, S1, S0, G1, G0)
-                        if (!h2) break;
-                        jc = j2;
+        BRC_STAGE(T, lo, 0u)
+        BRC_LD_TAB(T, lo + (uint32_t)HALF)
+        BRC_STAGE(T, lo + (uint32_t)HALF, 1u)
+        BRC_LD_TAB(T, lo + 2u * (uint32_t)HALF)
+        PRec R0, R1, R2;
+        BRC_LD_REC(R0, lo)
+        BRC_LD_REC(R1, lo + 1u)
+        R2 = R1;
+        Stage S0, S1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // first two half-batches staged (tile prologue)
+        BRC_PROBE(R0, 0u, S0)
+        S1 = S0;
+        uint32_t hf = 0;
+        for (uint32_t base = lo; base < hi; base += (uint32_t)HALF, hf ^= 1u) {
+            const uint32_t nb = (hi - base) < (uint32_t)HALF ? (hi - base) : (uint32_t)HALF;
+            BRC_STEP(0, R0, R1, R2, S0, S1)
+            BRC_STEP(1, R1, R2, R0, S1, S0)
+            BRC_STEP(2, R2, R0, R1, S0, S1)
+            BRC_STEP(3, R0, R1, R2, S1, S0)
+            BRC_STEP(4, R1, R2, R0, S0, S1)
+            BRC_STEP(5, R2, R0, R1, S1, S0)
+            // ---- between half-batches
+            since_flush += (int32_t)nb;
+            if (__builtin_expect(qn != 0u, 0)) {
+                // drain in piece order; the event words of this half-batch are still staged in ring half hf
+                for (uint32_t e = 0; e < qn; ++e) {
+                    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane(queue[e].piece), kind = (uint32_t)__builtin_amdgcn_readfirstlane(queue[e].kind);
+                    // (readfirstlane returns int: without the casts a set bit 31 of the low half would sign-extend into the high half)
+                    const uint64_t mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(queue[e].mhi) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(queue[e].mlo);
+                    const PieceHot H = *reinterpret_cast<const PieceHot*>(hot4 + (size_t)m * 4u);
+                    const PieceCold CD = cold[m];
+                    if ((mask >> lane) & 1ull) {
+                        const int32_t s_c = p0 - H.a;
+                        const uint32_t off = (hf * (uint32_t)HALF + (m - base)) * (uint32_t)ROW_BYTES + 2u * ((uint32_t)s_c & 7u);
+                        const uint32_t w = (uint32_t)*reinterpret_cast<const uint16_t*>(rows_base + off + 2u * (uint32_t)lane);
+                        if (kind == 0u) drain_full(c, pl, lib, kk, a.mem, H, CD, lane + s_c, w);
+                        else drain_int(c, pl, lib, kk, a.mem, CD, w & 0xffu);
                     }
                 }
+                qn = 0;
             }
-            if (more) {                                                       // all reads of this batch are done with the rows
-                BRC_LD_WIN_OK(Tn, base + (uint32_t)BATCH, wok)
-                BRC_ST_WIN(W0, W1, W2, W3, wok)
-                T = Tn;
+            if (__builtin_expect(since_flush + HALF > c.flush_k, 0)) {
+                if (valid) lane2_flush(c, pl, lib, kk, a);
+                since_flush = 0;
+            }
+            // the ring half just processed is free (every LDS read of it has returned after the lgkmcnt wait): copy
+            // half-batch base + 2 HALF into it and request the addresses of the one after
+            if (base + 2u * (uint32_t)HALF < hi) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                BRC_STAGE(T, base + 2u * (uint32_t)HALF, hf)
+                BRC_LD_TAB(T, base + 3u * (uint32_t)HALF)
             }
         }
 #undef BRC_STEP
 #undef BRC_ACC
 #undef BRC_PROBE
-#undef BRC_RL
-#undef BRC_ALL
-#undef BRC_MINE
+#undef BRC_LD_REC
+#undef BRC_STAGE
 #undef BRC_LD_TAB
-#undef BRC_LD_WIN
-#undef BRC_LD_WIN_OK
-#undef BRC_ST_WIN
     }
-    if (V != 1) { if (valid) lane_store(c, o, a); }
-    else if (valid) {
-        uint32_t x = a.ncol ^ a.depth;
+    // ---- end of the tile: registers -> planes (coalesced: lane == position), zeros for the untouched buckets
+    const bool dead = c.per_lib && valid && unavail_ro[kk] != NONE32;
+    if (valid) {
+        const int64_t P = c.PS;
+        pl.ncol[(int64_t)lib * P + k] = dead ? 0u : a.ncol;
+        pl.depth[(int64_t)lib * P + k] = dead ? 0u : a.depth;
+        uint32_t dv[NI], av[NI];
+        pack_unpack(a.dom, dv); pack_unpack(a.alt, av);
+        const bool any_mem = __builtin_amdgcn_ballot_w64(a.mem != 0u) != 0ull;   // (uniform) some lane has live planes
 #pragma unroll
-        for (int f = 0; f < NACC_I; ++f) x ^= a.di[f] ^ a.xi[f];
+        for (uint32_t b = 0; b < (uint32_t)NBUCKET; ++b) {
+            uint32_t* ip = plane_i(c, pl, lib, b, k); float* fp = plane_f(c, pl, lib, b, k);
+            const bool isd = !dead && a.dom_b == b, isa = !dead && a.alt_b == b;
+            const bool live = any_mem && !dead && ((a.mem >> b) & 1u);
+            const bool keep = live && !isd && !isa;                            // a drained third allele: the planes are final
 #pragma unroll
-        for (int f = 0; f < NF; ++f) x ^= __float_as_uint(a.df[f]) ^ __float_as_uint(a.xf[f]);
-        pl.ncol[(int64_t)lib * c.PS + k] = x;
+            for (int f = 0; f < NI; ++f) {
+                uint32_t v = isd ? dv[f] : (isa ? av[f] : 0u);
+                if (any_mem) { if (live && !keep) v += ip[(int64_t)f * P]; if (keep) continue; }
+                ip[(int64_t)f * P] = v;
+            }
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const float v = isd ? a.dom.f[f] : (isa ? a.alt.f[f] : 0.0f);
+                if (any_mem && keep) continue;
+                fp[(int64_t)f * P] = v;
+            }
+        }
     }
-
-    const bool dead = c.per_lib && a.unavail != NONE32;
     const bool live = valid && !dead;
     unsigned long long ev = (live && p >= c.beg0) ? a.ncol : 0u;
     unsigned long long wsm = live ? a.w_sm : 0u, wnm = live ? a.w_nm : 0u, wl = (valid && dead && lib == 0) ? 1u : 0u;
@@ -909,6 +883,21 @@ __global__ __launch_bounds__(256) void k_indel_fill(DevCfg c, DevIn in, const DR
         IndelEv e; e.read = (uint32_t)i; e.qpos = qpos; e.len = len; e.key_lo = (uint32_t)key;   // (keys fit 32 bits: checked at upload)
         ev[slot] = e;
     });
+}
+
+// -p: reads without a library abandon every position they cover (bamreadcount.cpp:281-284).  unavail[k] = index of the
+// first such read in the column (NONE32 when there is none); those reads have no pieces.
+__global__ __launch_bounds__(256) void k_unavail(DevCfg c, DevIn in, uint32_t* __restrict__ unavail) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c.n_reads || in.lib[i] >= 0) return;
+    const uint32_t nc = in.n_cigar[i]; const uint32_t* cg = in.cigar + in.cig_off[i];
+    if (!read_enters(in.flag[i], cg, nc) || in.pos[i] < 0) return;
+    int64_t rlen = 0;
+    for (uint32_t k = 0; k < nc; ++k) if (is_refop(cg[k] & 0xfu)) rlen += (int64_t)(cg[k] >> 4);
+    int64_t k0 = (int64_t)in.pos[i] - c.pos0, k1 = k0 + rlen;
+    if (k0 < 0) k0 = 0;
+    if (k1 > c.P) k1 = c.P;
+    for (int64_t k = k0; k < k1; ++k) atomicMin(&unavail[k], (uint32_t)i);
 }
 
 // cursor[key] has been advanced by k_indel_fill to the END of the key's events, which sit in consecutive slots.  One lane
@@ -983,9 +972,10 @@ class HipBackend : public Backend {
     bool have_events = false;
     DevCfg c; DevIn in;
     int64_t ntiles = 0; uint64_t n_indel_cap = 0;
+    std::vector<int64_t> lib_base;      // first piece of every library's stream (Lp + 1 entries)
     // device buffers
     DBuf d_pos, d_flag, d_mapq, d_lib, d_lq, d_nc, d_co, d_so, d_qo, d_nm, d_sm, d_tags, d_cigar, d_seq, d_qual, d_ref, d_refcode;
-    DBuf d_bq, d_bqrow, d_rcp, d_reads, d_ends, d_prefmax, d_agg, d_rng, d_ncol, d_depth, d_istat, d_fstat, d_unavail, d_cnt, d_cursor, d_ev, d_iout, d_ctr, d_tilectr, d_part;
+    DBuf d_bq, d_bqrow, d_pieceoff, d_hot, d_cold, d_key, d_reach, d_reads, d_prefmax, d_agg, d_rng, d_ncol, d_depth, d_istat, d_fstat, d_unavail, d_cnt, d_cursor, d_ev, d_iout, d_ctr, d_tilectr, d_part;
     // host result buffers (pinned)
     HBuf<uint32_t> h_ncol, h_depth, h_istat, h_unavail; HBuf<float> h_fstat; HBuf<IndelOut> h_iout;
     std::vector<IndelOut> iout_compact;
@@ -1015,7 +1005,7 @@ class HipBackend : public Backend {
     ~HipBackend() override {
         (void)hipSetDevice(device);
         DBuf* all[] = {&d_pos, &d_flag, &d_mapq, &d_lib, &d_lq, &d_nc, &d_co, &d_so, &d_qo, &d_nm, &d_sm, &d_tags, &d_cigar, &d_seq, &d_qual,
-                       &d_ref, &d_refcode, &d_bq, &d_bqrow, &d_rcp, &d_reads, &d_ends, &d_prefmax, &d_agg, &d_rng, &d_ncol, &d_depth, &d_istat, &d_fstat, &d_unavail, &d_cnt,
+                       &d_ref, &d_refcode, &d_bq, &d_bqrow, &d_pieceoff, &d_hot, &d_cold, &d_key, &d_reach, &d_reads, &d_prefmax, &d_agg, &d_rng, &d_ncol, &d_depth, &d_istat, &d_fstat, &d_unavail, &d_cnt,
                        &d_cursor, &d_ev, &d_iout, &d_ctr, &d_tilectr, &d_part};
         for (DBuf* b : all) b->release();
         h_ncol.destroy(); h_depth.destroy(); h_istat.destroy(); h_unavail.destroy(); h_fstat.destroy(); h_iout.destroy();
@@ -1041,7 +1031,10 @@ class HipBackend : public Backend {
         g.PS = (g.P + 63) & ~(int64_t)63;
         c.beg0 = g.beg0; c.end = g.end; c.pos0 = g.pos0; c.P = g.P; c.PS = g.PS; c.ref_lo = g.ref_lo; c.ref_hi = g.ref_hi; c.ref_len = g.ref_len;
         c.n_reads = s.n; c.table_len = getenv("BRC_NO_TABLE") ? 0 : s.modal_len();
-        { const char* v = getenv("BRC_PILEUP_VARIANT"); c.variant = v ? atoi(v) : 0; }
+        c.n_pieces = s.n_pieces; lib_base = s.lib_base;
+        // test knobs (tests/test_gpu_parity.py): small K -> flushes, small limit -> PF_HUGE, forced dominant bucket -> third alleles
+        choose_pack(s.max_lqseq, getenv("BRC_FLUSH_K") ? atoi(getenv("BRC_FLUSH_K")) : 0, getenv("BRC_PACK_LIM") ? atoi(getenv("BRC_PACK_LIM")) : 0, c.flush_k, c.pack_lim);
+        c.force_dom = getenv("BRC_FORCE_DOM") ? atoi(getenv("BRC_FORCE_DOM")) : -1;
         const size_t n = (size_t)s.n;
         int rc;
         if ((rc = up(d_pos, s.pos, n)) || (rc = up(d_flag, s.flag, n)) || (rc = up(d_mapq, s.mapq, n)) || (rc = up(d_lib, s.lib, n)) ||
@@ -1058,20 +1051,24 @@ class HipBackend : public Backend {
         in.seq_off = (const uint64_t*)d_so.p; in.qual_off = (const uint64_t*)d_qo.p; in.nm = (const int32_t*)d_nm.p; in.sm = (const int32_t*)d_sm.p;
         in.tags = (const uint8_t*)d_tags.p; in.cigar = (const uint32_t*)d_cigar.p; in.seq4 = (const uint8_t*)d_seq.p; in.qual = (const uint8_t*)d_qual.p;
         in.ref = (const char*)d_ref.p;
-        HIPCHK(d_bq.ensure((s.bq_elems + 512) * sizeof(uint16_t)));   // + slack: staged windows may read past the last row
-        in.bq = (const uint16_t*)d_bq.p;
-        if ((rc = up(d_bqrow, s.bq_row, n))) return rc;
+        // event-word stream, padded on both sides: a staged window starts up to 71 elements before / ends after a row
+        enum { BQ_PAD = 128 };
+        HIPCHK(d_bq.ensure((s.bq_elems + BQ_PAD + 512) * sizeof(uint16_t)));
+        in.bq = (const uint16_t*)d_bq.p + BQ_PAD;
+        if ((rc = up(d_bqrow, s.bq_row, n)) || (rc = up(d_pieceoff, s.piece_off, n))) return rc;
         in.bq_row = (const uint64_t*)d_bqrow.p;
-        HIPCHK(d_rcp.ensure((n + 1) * sizeof(RcpPair)));
-        in.rcp = (const RcpPair*)d_rcp.p;
+        in.rcp = nullptr;
+        const size_t np = (size_t)c.n_pieces;
+        HIPCHK(d_hot.ensure((np + 2) * sizeof(PieceHot))); HIPCHK(d_cold.ensure((np + 2) * sizeof(PieceCold)));
+        HIPCHK(d_key.ensure((np + 16) * 4)); HIPCHK(d_reach.ensure((np + 16) * 4));
         // outputs / scratch
         const size_t P = (size_t)c.PS, Lp = (size_t)c.Lp;   // allocation sizes use the padded stride
         ntiles = (c.P + TILE - 1) / TILE;
         n_indel_cap = c.has_ref ? s.n_indel_ops : 0;
         if (n_indel_cap && (uint64_t)c.P * (uint64_t)c.Lp >= 0xffffffffull) { err = "region too large: (positions x libraries) must stay below 2^32"; return BRC_E_ARG; }
-        const size_t nagg = std::max<size_t>((std::max<size_t>(n, P * Lp) + SCAN_CHUNK - 1) / SCAN_CHUNK, 1);
-        HIPCHK(d_reads.ensure((n + 1) * sizeof(DRead))); HIPCHK(d_ends.ensure((n + 1) * 4)); HIPCHK(d_prefmax.ensure((n + 1) * 4));
-        HIPCHK(d_agg.ensure(nagg * 4 + 16)); HIPCHK(d_rng.ensure(((size_t)ntiles + 1) * sizeof(uint2)));
+        const size_t nagg = std::max<size_t>((std::max<size_t>(np, P * Lp) + SCAN_CHUNK - 1) / SCAN_CHUNK, 1);
+        HIPCHK(d_reads.ensure((n + 1) * sizeof(DRead))); HIPCHK(d_prefmax.ensure((np + 16) * 4));
+        HIPCHK(d_agg.ensure(nagg * 4 + 16)); HIPCHK(d_rng.ensure(((size_t)ntiles * Lp + 1) * sizeof(uint2)));
         HIPCHK(d_ncol.ensure(Lp * P * 4 + 16)); HIPCHK(d_depth.ensure(Lp * P * 4 + 16)); HIPCHK(d_unavail.ensure(P * 4 + 16));
         HIPCHK(d_istat.ensure(Lp * NBUCKET * NI * P * 4 + 16)); HIPCHK(d_fstat.ensure(Lp * NBUCKET * NF * P * 4 + 16));
         HIPCHK(d_part.ensure(4096 * 5 * sizeof(unsigned long long)));
@@ -1111,27 +1108,36 @@ class HipBackend : public Backend {
             const int64_t rl = c.ref_hi - c.ref_lo;
             if (c.has_ref)
                 hipLaunchKernelGGL(k_refcode, dim3((unsigned)(((rl + 2 * REFCODE_PAD + 15) / 16 + 255) / 256)), dim3(256), 0, stream, in.ref, (uint8_t*)d_refcode.p, rl);
-            hipLaunchKernelGGL(k_annotate_groups, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (int32_t*)d_ends.p,
-                               (uint16_t*)d_bq.p, (RcpPair*)d_rcp.p, indels ? (uint32_t*)d_cnt.p : (uint32_t*)nullptr,
+            hipLaunchKernelGGL(k_annotate_groups, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (const uint32_t*)d_pieceoff.p,
+                               (PieceHot*)d_hot.p, (PieceCold*)d_cold.p, (int32_t*)d_key.p, (int32_t*)d_reach.p,
+                               (uint16_t*)in.bq, indels ? (uint32_t*)d_cnt.p : (uint32_t*)nullptr,
                                in.cigar, in.qual, in.seq4, (const uint8_t*)d_refcode.p + REFCODE_PAD);
-        }
+            if (c.per_lib) {
+                HIPCHK(hipMemsetAsync(d_unavail.p, 0xff, (size_t)c.PS * 4, stream));
+                hipLaunchKernelGGL(k_unavail, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (uint32_t*)d_unavail.p);
+            }
+        } else if (c.per_lib && P > 0) HIPCHK(hipMemsetAsync(d_unavail.p, 0xff, (size_t)c.PS * 4, stream));
         HIPCHK(hipEventRecord(evt[T_SCAN_ENDS], stream));
-        if ((rc = scan<OpMaxI32, true>((const int32_t*)d_ends.p, (int32_t*)d_prefmax.p, n))) return rc;
+        // per library: running max of the piece reaches of its stream, then the piece range of every tile
+        for (int l = 0; l < Lp; ++l) {
+            const int64_t s0 = lib_base[(size_t)l], ns = lib_base[(size_t)l + 1] - s0;
+            if ((rc = scan<OpMaxI32, true>((const int32_t*)d_reach.p + s0, (int32_t*)d_prefmax.p + s0, ns))) return rc;
+        }
         HIPCHK(hipEventRecord(evt[T_TILES], stream));
-        if (ntiles > 0 && n == 0) HIPCHK(hipMemsetAsync(d_rng.p, 0, (size_t)ntiles * sizeof(uint2), stream));
-        if (ntiles > 0 && n > 0)
-            hipLaunchKernelGGL(k_tiles, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, (const int32_t*)d_prefmax.p, in.pos, ntiles,
-                               (uint2*)d_rng.p);
+        for (int l = 0; l < Lp && ntiles > 0; ++l) {
+            const int64_t s0 = lib_base[(size_t)l], ns = lib_base[(size_t)l + 1] - s0;
+            uint2* row = (uint2*)d_rng.p + (int64_t)l * ntiles;
+            if (ns == 0) HIPCHK(hipMemsetAsync(row, 0, (size_t)ntiles * sizeof(uint2), stream));
+            else hipLaunchKernelGGL(k_tiles, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, c, (const int32_t*)d_prefmax.p, (const int32_t*)d_key.p, s0, ns, ntiles, row);
+        }
         HIPCHK(hipEventRecord(evt[T_PILEUP], stream));
         if (ntiles > 0) {
             unsigned nwg = (unsigned)((ntiles + PILEUP_WAVES - 1) / PILEUP_WAVES);
             nwg = (nwg + 7u) & ~7u;
             // profiling knob: unused dynamic LDS lowers the number of resident waves (occupancy sweeps)
             static const unsigned dyn_lds = getenv("BRC_PILEUP_LDS_PAD") ? (unsigned)atoi(getenv("BRC_PILEUP_LDS_PAD")) : 0u;
-#define BRC_LAUNCH_PILEUP(V) hipLaunchKernelGGL((k_pileup<V, false>), dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), dyn_lds, stream, c, in, reads, (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.cigar, in.rcp, in.bq)
-            if (c.per_lib && !getenv("BRC_NO_PL"))
-                hipLaunchKernelGGL((k_pileup<0, true>), dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), dyn_lds, stream, c, in, reads, (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.cigar, in.rcp, in.bq);
-            else switch (c.variant) { case 1: BRC_LAUNCH_PILEUP(1); break; case 2: BRC_LAUNCH_PILEUP(2); break; case 3: BRC_LAUNCH_PILEUP(3); break; case 4: BRC_LAUNCH_PILEUP(4); break; default: BRC_LAUNCH_PILEUP(0); }
+            hipLaunchKernelGGL(k_pileup2, dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), dyn_lds, stream, c, in, (const uint4*)d_hot.p, (const PieceCold*)d_cold.p,
+                               (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.bq, (const uint32_t*)d_unavail.p);
         }
         HIPCHK(hipEventRecord(evt[T_COUNT], stream));
         if (P > 0) {

@@ -21,16 +21,32 @@ namespace brc {
 
 void Staged::init(const HostAlloc* A) {
     pos.A = A; flag.A = A; mapq.A = A; lib.A = A; l_qseq.A = A; n_cigar.A = A; cig_off.A = A; seq_off.A = A; qual_off.A = A;
-    nm.A = A; sm.A = A; tags.A = A; cigar.A = A; seq4.A = A; qual.A = A; bq_row.A = A;
+    nm.A = A; sm.A = A; tags.A = A; cigar.A = A; seq4.A = A; qual.A = A; bq_row.A = A; piece_cnt.A = A; piece_off.A = A;
 }
 void Staged::clear() {
     pos.clear(); flag.clear(); mapq.clear(); lib.clear(); l_qseq.clear(); n_cigar.clear(); cig_off.clear(); seq_off.clear();
     qual_off.clear(); nm.clear(); sm.clear(); tags.clear(); cigar.clear(); seq4.clear(); qual.clear(); bq_row.clear();
     bq_elems = 0; memset(len_hist, 0, sizeof len_hist); n = 0; min_pos = 0; max_end = 0; n_indel_ops = 0;
+    piece_cnt.clear(); piece_off.clear(); lib_base.clear(); n_pieces = 0; max_lqseq = 0;
 }
 void Staged::destroy() {
     pos.destroy(); flag.destroy(); mapq.destroy(); lib.destroy(); l_qseq.destroy(); n_cigar.destroy(); cig_off.destroy();
     seq_off.destroy(); qual_off.destroy(); nm.destroy(); sm.destroy(); tags.destroy(); cigar.destroy(); seq4.destroy(); qual.destroy(); bq_row.destroy();
+    piece_cnt.destroy(); piece_off.destroy();
+}
+// library-major slots: all pieces of library 0 in file order, then library 1, ... (one stream without -p)
+void Staged::layout_pieces(int Lp, bool per_lib) {
+    lib_base.assign((size_t)Lp + 1, 0);
+    for (int64_t i = 0; i < n; ++i) if (piece_cnt.p[i]) lib_base[(size_t)(per_lib ? lib.p[i] : 0) + 1] += piece_cnt.p[i];
+    for (int l = 0; l < Lp; ++l) lib_base[(size_t)l + 1] += lib_base[(size_t)l];
+    n_pieces = lib_base[(size_t)Lp];
+    std::vector<int64_t> cur(lib_base.begin(), lib_base.end() - 1);
+    piece_off.n = (size_t)n;
+    for (int64_t i = 0; i < n; ++i) {
+        const int l = per_lib ? (int)lib.p[i] : 0;
+        if (!piece_cnt.p[i]) { piece_off.p[i] = 0; continue; }
+        piece_off.p[i] = (uint32_t)cur[(size_t)l]; cur[(size_t)l] += piece_cnt.p[i];
+    }
 }
 
 int fmt_u32(char* out, uint32_t v) {
@@ -191,7 +207,7 @@ int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
               s.n_cigar.append(b->n_cigar, n) && s.cig_off.append(b->cigar_off, n) && s.seq_off.append(b->seq_off, n) &&
               s.qual_off.append(b->qual_off, n) && s.cigar.append(b->cigar, b->n_cigar_total) &&
               s.seq4.append(b->seq4, b->seq_bytes) && s.qual.append(b->qual, b->qual_bytes) &&
-              s.bq_row.reserve(n0 + n + 16) && s.lib.reserve(n0 + n + 16) && s.nm.reserve(n0 + n + 16) && s.sm.reserve(n0 + n + 16) && s.tags.reserve(n0 + n + 16);
+              s.bq_row.reserve(n0 + n + 16) && s.piece_cnt.reserve(n0 + n + 16) && s.piece_off.reserve(n0 + n + 16) && s.lib.reserve(n0 + n + 16) && s.nm.reserve(n0 + n + 16) && s.sm.reserve(n0 + n + 16) && s.tags.reserve(n0 + n + 16);
     if (!ok) return fail(e, BRC_E_NOMEM, "host staging allocation failed");
     for (size_t i = 0; i < n; ++i) {
         s.lib.p[n0 + i] = (e->cfg.per_lib && b->lib) ? b->lib[i] : 0;
@@ -199,7 +215,7 @@ int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
         s.sm.p[n0 + i] = b->sm ? b->sm[i] : 0;
         s.tags.p[n0 + i] = b->tags ? b->tags[i] : 0;
     }
-    s.lib.n = s.nm.n = s.sm.n = s.tags.n = s.bq_row.n = n0 + n;
+    s.lib.n = s.nm.n = s.sm.n = s.tags.n = s.bq_row.n = s.piece_cnt.n = n0 + n;
     const int32_t maxcnt = e->cfg.max_cnt;
     for (size_t i = 0; i < n; ++i) {
         const size_t r = n0 + i;
@@ -211,6 +227,8 @@ int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
         s.cig_off.p[r] += cb; s.seq_off.p[r] += sb; s.qual_off.p[r] += qb;
         s.bq_row.p[r] = s.bq_elems; s.bq_elems += ((uint64_t)s.l_qseq.p[r] + 7u) & ~(uint64_t)7u;
         if (s.l_qseq.p[r] <= TABLE_MAX) s.len_hist[s.l_qseq.p[r]]++;
+        if (s.l_qseq.p[r] >= (1 << 22)) return fail(e, BRC_E_LIMIT, "reads of 4 Mbases and more are not supported");
+        if (s.l_qseq.p[r] > s.max_lqseq) s.max_lqseq = s.l_qseq.p[r];
         const int32_t pos = s.pos.p[r];
         if (pos < e->last_pos) return fail(e, BRC_E_ARG, "reads are not coordinate-sorted");
         e->last_pos = pos;
@@ -244,6 +262,15 @@ int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
             e->accepted++; e->last_acc_pos = pos;
             if (e->heap_built) e->live_ends.push(end);
         }
+        {   // pieces of this read (KB v2): none for a read outside the columns or without a library (-p: it abandons positions instead)
+            const uint32_t* cg = s.cigar.p + s.cig_off.p[r];
+            const bool entered = read_enters(fl, cg, nc) && pos >= 0 && !(e->cfg.per_lib && s.lib.p[r] < 0);
+            const bool counts = (int)s.mapq.p[r] >= e->cfg.min_mapq && !(fl & BRC_NOCOUNT_MASK);
+            uint32_t np = 0;
+            walk_pieces(e->cfg.insertion_centric != 0, entered, counts, pos, cg, nc, [&](int32_t, int32_t, int32_t, int, bool) { ++np; });
+            s.piece_cnt.p[r] = np;
+            if ((uint64_t)(s.n_pieces += np) >= 0xFFFFFFF0ull) return fail(e, BRC_E_LIMIT, "more than 2^32 read segments in one region: split the region");
+        }
     }
     s.n += (int64_t)n;
     return BRC_OK;
@@ -262,6 +289,7 @@ int brc_upload(brc_engine* e) {
         g.ref_lo = std::min<int64_t>(std::max<int64_t>(s.min_pos, 0), g.ref_len);
         g.ref_hi = std::min<int64_t>(std::max<int64_t>(s.max_end, g.ref_lo), g.ref_len);
     }
+    e->st.layout_pieces(g.Lp, e->cfg.per_lib != 0);
     int rc = e->be->upload(e->cfg, s, g);
     if (rc) return fail(e, rc, e->be->last_error());
     e->state = 2;

@@ -1,9 +1,10 @@
-// brc_sim.cpp — CPU lane-by-lane simulator of the device pipeline.  TEST INFRASTRUCTURE ONLY.
+// brc_sim.cpp — CPU simulator of the device pipeline.  TEST INFRASTRUCTURE ONLY.
 //
-// Runs the __host__ __device__ functions of bam_readcount_amd/csrc/brc_core.h — the same code the HIP kernels
-// wrap — one lane at a time, in the kernels' launch structure (K1 annotate, prefix-max, tile ranges, KB pileup
-// tiles of 64 lanes, indel count/scan/fill/reduce).  It lets `-m "not gpu"` tests check the device algorithm
-// against the oracle without a GPU.  It is never linked into the product library and the product never loads it.
+// Runs the __host__ __device__ functions of bam_readcount_amd/csrc/brc_core.h — the same code the HIP kernels wrap — in
+// the kernels' launch structure: K1 (annotate + piece emission), per-library running max + tile ranges, KB (64-lane
+// tiles walking pieces in half-batches of HALF, packed integer registers with flushes every K pieces, queued third-allele
+// / huge-integer events drained between half-batches), indel count / scan / fill / reduce.  It lets `-m "not gpu"` tests
+// check the device ALGORITHM against the oracle without a GPU.  Never linked into the product, never loaded by it.
 #include <stdlib.h>
 #include <string.h>
 
@@ -20,7 +21,9 @@ static const HostAlloc kAlloc = {sim_alloc, sim_release};
 
 class SimBackend : public Backend {
     DevCfg c; DevIn in; std::string err;
-    std::vector<DRead> reads; std::vector<int32_t> prefmax; std::vector<uint16_t> bq; size_t bq_n = 0; std::vector<RcpPair> rcp; std::vector<float> tq; std::vector<double> te;
+    const Staged* st = nullptr;
+    std::vector<DRead> reads; std::vector<uint16_t> bq; size_t bq_n = 0; std::vector<float> tq; std::vector<double> te;
+    std::vector<PieceHot> hot; std::vector<PieceCold> cold; std::vector<int32_t> key, reach, prefmax;
     std::vector<uint32_t> ncol, depth, istat, unavail; std::vector<float> fstat;
     std::vector<IndelOut> iout;
     uint64_t n_events = 0, n_positions = 0, warn[BRC_N_WARN] = {0, 0, 0, 0};
@@ -34,41 +37,121 @@ class SimBackend : public Backend {
         c.min_mapq = cfg.min_mapq; c.min_bq = cfg.min_bq; c.per_lib = cfg.per_lib; c.insertion_centric = cfg.insertion_centric;
         c.Lp = g.Lp; c.ref_len_check = cfg.ref_len_check; c.has_ref = g.ref != nullptr;
         c.beg0 = g.beg0; c.end = g.end; c.pos0 = g.pos0; c.P = g.P; c.PS = g.PS; c.ref_lo = g.ref_lo; c.ref_hi = g.ref_hi; c.ref_len = g.ref_len;
-        c.n_reads = s.n; c.table_len = s.modal_len();
+        c.n_reads = s.n; c.table_len = getenv("BRC_NO_TABLE") ? 0 : s.modal_len(); c.n_pieces = s.n_pieces;
+        c.force_dom = getenv("BRC_FORCE_DOM") ? atoi(getenv("BRC_FORCE_DOM")) : -1;
+        choose_pack(s.max_lqseq, getenv("BRC_FLUSH_K") ? atoi(getenv("BRC_FLUSH_K")) : 0, getenv("BRC_PACK_LIM") ? atoi(getenv("BRC_PACK_LIM")) : 0, c.flush_k, c.pack_lim);
         tq.assign((size_t)TABLE_MAX + 2, 0.0f); te.assign((size_t)TABLE_MAX + 2, 0.0);
         for (int k = 0; k <= c.table_len; ++k) { tq[(size_t)k] = (float)k / (float)c.table_len; te[(size_t)k] = 1.0 - (double)tq[(size_t)k]; }
         in.pos = s.pos.p; in.flag = s.flag.p; in.mapq = s.mapq.p; in.lib = s.lib.p; in.l_qseq = s.l_qseq.p; in.n_cigar = s.n_cigar.p;
         in.cig_off = s.cig_off.p; in.seq_off = s.seq_off.p; in.qual_off = s.qual_off.p; in.nm = s.nm.p; in.sm = s.sm.p; in.tags = s.tags.p;
         in.cigar = s.cigar.p; in.seq4 = s.seq4.p; in.qual = s.qual.p; in.ref = g.ref ? g.ref + g.ref_lo : nullptr;
         bq_n = s.bq_elems; in.bq = nullptr; in.bq_row = s.bq_row.p;
+        st = &s;
         return BRC_OK;
     }
+
+    // one (tile, library) wave of KB
+    void pileup_tile(const Planes& pl, int lib, int64_t tl, uint32_t lo, uint32_t hi) {
+        LaneAcc2 a[TILE]; bool valid[TILE]; int32_t p[TILE]; int64_t kk[TILE];
+        for (int l = 0; l < TILE; ++l) {
+            kk[l] = tl * TILE + l; valid[l] = kk[l] < c.P; p[l] = (int32_t)(c.pos0 + kk[l]);
+            uint32_t dom = valid[l] ? dominant_bucket(c, in, p[l]) : 1u;
+            if (c.force_dom >= 0) dom = (uint32_t)c.force_dom;
+            lane2_init(a[l], dom);
+        }
+        TermTab tt; tt.q = tq.data(); tt.e = te.data();
+        struct QEnt { uint32_t piece; int kind; bool lane[TILE]; };    // kind 0: third-allele events, 1: integers of a huge piece
+        std::vector<QEnt> queue;
+        int since_flush = 0;
+        for (uint32_t base = lo; base < hi; base += HALF) {
+            const uint32_t nb = hi - base < (uint32_t)HALF ? hi - base : (uint32_t)HALF;
+            for (uint32_t m = base; m < base + nb; ++m) {
+                const PieceHot& h = hot[m]; const PieceCold& cd = cold[m];
+                const uint32_t fl = piece_flags(h);
+                QEnt full, ints; full.piece = ints.piece = m; full.kind = 0; ints.kind = 1; bool any_full = false, any_int = false;
+                for (int l = 0; l < TILE; ++l) {
+                    full.lane[l] = ints.lane[l] = false;
+                    if (!valid[l]) continue;
+                    const uint32_t d = (uint32_t)(p[l] - h.rs);
+                    if (d < (uint32_t)h.ext) a[l].ncol++;                                             // lib_counts[library] (:286)
+                    if (!(d < (uint32_t)h.len)) continue;
+                    const int qpos = p[l] - h.a;
+                    const uint32_t w = bq[cd.bq_off + (uint64_t)qpos];
+                    if (w < h.thr) continue;                                                          // :288
+                    a[l].depth++;                                                                     // mapq_n (:312)
+                    if (fl & PF_NB) continue;                                                         // :343 with -i
+                    a[l].w_sm += (fl & PF_SMW) ? 1u : 0u; a[l].w_nm += (fl & PF_NMW) ? 1u : 0u;
+                    const EvTerms t = (fl & PF_TABLE) ? piece_terms_tab(h, tt, c.table_len, qpos) : piece_terms_div(h, qpos);
+                    const uint32_t b = w & 0xffu, q = w >> 8;
+                    if (b == a[l].dom_b) { pack_event(a[l].dom, h, t, q); if (fl & PF_HUGE) { ints.lane[l] = true; any_int = true; } }
+                    else if (a[l].alt_b == NB_NONE || a[l].alt_b == b) { a[l].alt_b = b; pack_event(a[l].alt, h, t, q); if (fl & PF_HUGE) { ints.lane[l] = true; any_int = true; } }
+                    else { full.lane[l] = true; any_full = true; }
+                }
+                if (any_full) queue.push_back(full);
+                if (any_int) queue.push_back(ints);
+            }
+            since_flush += (int)nb;
+            // between half-batches: drain the queue (the event words of this half-batch are still staged), flush when the
+            // packed fields could overflow during the next half-batch
+            for (const QEnt& e : queue) {
+                const PieceHot& h = hot[e.piece]; const PieceCold& cd = cold[e.piece];
+                for (int l = 0; l < TILE; ++l) {
+                    if (!e.lane[l]) continue;
+                    const int qpos = p[l] - h.a;
+                    const uint32_t w = bq[cd.bq_off + (uint64_t)qpos];
+                    if (e.kind == 0) drain_full(c, pl, lib, kk[l], a[l].mem, h, cd, qpos, w);
+                    else drain_int(c, pl, lib, kk[l], a[l].mem, cd, w & 0xffu);
+                }
+            }
+            queue.clear();
+            if (since_flush + HALF > c.flush_k) {
+                for (int l = 0; l < TILE; ++l) if (valid[l]) lane2_flush(c, pl, lib, kk[l], a[l]);
+                since_flush = 0;
+            }
+        }
+        for (int l = 0; l < TILE; ++l) {
+            if (!valid[l]) continue;
+            const bool dead = c.per_lib && unavail[(size_t)kk[l]] != NONE32;
+            lane2_store(c, pl, lib, kk[l], a[l], dead);
+            if (!dead) { warn[BRC_W_SM_MISSING] += a[l].w_sm; warn[BRC_W_NM_MISSING] += a[l].w_nm; if (p[l] >= c.beg0) n_events += a[l].ncol; }
+            if (dead && lib == 0) warn[BRC_W_LIB_UNAVAILABLE]++;
+        }
+    }
+
     int compute(brc_timing* t) override {
         if (t) memset(t, 0, sizeof *t);
         const int64_t n = c.n_reads, P = c.P, PS = c.PS; const int Lp = c.Lp;
-        reads.resize((size_t)n); prefmax.resize((size_t)n); bq.assign(bq_n + 1, 0); in.bq = bq.data(); rcp.resize((size_t)n + 1); in.rcp = rcp.data();
-        for (int64_t i = 0; i < n; ++i) reads[(size_t)i] = annotate_read(c, in, i, bq.data(), rcp.data());   // K1
-        int32_t m = INT32_MIN;
-        for (int64_t i = 0; i < n; ++i) { if (reads[(size_t)i].end > m) m = reads[(size_t)i].end; prefmax[(size_t)i] = m; }
-        ncol.assign((size_t)(Lp * PS), 0); depth.assign((size_t)(Lp * PS), 0); unavail.assign((size_t)PS, NONE32);
-        istat.assign((size_t)(Lp * NBUCKET * NI * PS), 0); fstat.assign((size_t)(Lp * NBUCKET * NF * PS), 0.0f);
+        const int64_t np = c.n_pieces;
+        reads.resize((size_t)n); bq.assign(bq_n + 1, 0); in.bq = bq.data();
+        hot.assign((size_t)np + 1, PieceHot()); cold.assign((size_t)np + 1, PieceCold()); key.assign((size_t)np + 1, 0); reach.assign((size_t)np + 1, 0); prefmax.assign((size_t)np + 1, 0);
+        unavail.assign((size_t)PS, NONE32);
+        for (int64_t i = 0; i < n; ++i) {                                                             // K1
+            const DRead rd = reads[(size_t)i] = annotate_read(c, in, i, bq.data());
+            const uint32_t* cg = in.cigar + in.cig_off[i];
+            const bool nolib = c.per_lib && in.lib[i] < 0;
+            const bool enters = read_enters(in.flag[i], cg, in.n_cigar[i]) && in.pos[i] >= 0;
+            if (enters && nolib)                                                                       // k_unavail: first library-less read of every column (:281-284)
+                for (int64_t q = rd.pos; q < rd.end; ++q) { const int64_t k = q - c.pos0; if (k >= 0 && k < P && unavail[(size_t)k] > (uint32_t)i) unavail[(size_t)k] = (uint32_t)i; }
+            const ReadConst rc = read_const(c, rd, (uint32_t)i);
+            uint32_t slot = st->piece_off.p[i], cnt = 0;
+            walk_pieces(c.insertion_centric != 0, enters && !nolib, rc.counts, rd.pos, cg, in.n_cigar[i], [&](int32_t rs, int32_t len, int32_t ext, int qoff, bool nb) {
+                make_piece(c, rc, rs, len, ext, qoff, nb, hot[slot], cold[slot]);
+                key[slot] = rd.pos; reach[slot] = rs + ext; ++slot; ++cnt;
+            });
+            if (cnt != st->piece_cnt.p[i]) { err = "piece count of the host and of K1 differ"; return BRC_E_ARG; }
+        }
+        ncol.assign((size_t)(Lp * PS), 0); depth.assign((size_t)(Lp * PS), 0);
+        istat.assign((size_t)(Lp * NBUCKET * NI * PS), 0xdeadbeefu); fstat.assign((size_t)(Lp * NBUCKET * NF * PS), -1.0f);   // KB must write every plane element
         Planes pl = {ncol.data(), depth.data(), istat.data(), fstat.data(), unavail.data()};
         n_events = n_positions = 0; memset(warn, 0, sizeof warn);
         const int64_t ntiles = (P + TILE - 1) / TILE;
-        for (int l = 0; l < Lp; ++l) for (int64_t tl = 0; tl < ntiles; ++tl) {                         // KB
-            uint32_t lo, hi; tile_range(c, prefmax.data(), reads.data(), tl, lo, hi);
-            for (int lane = 0; lane < TILE; ++lane) {
-                const int64_t k = tl * TILE + lane; const bool valid = k < P;
-                LaneAcc a; lane_init(a); a.dom_b = dominant_bucket(c, in, c.pos0 + k);
-                if (getenv("BRC_SIM_DOM")) a.dom_b = (uint32_t)atoi(getenv("BRC_SIM_DOM"));   // stress the alternate/overflow paths
-                LaneOut o; o.pl = pl; o.lib = l; o.k = valid ? k : 0;
-                TermTab tt; tt.q = tq.data(); tt.e = te.data();
-                for (uint32_t r = lo; r < hi; ++r) lane_visit_read(c, in, reads[r], r, (uint32_t)l + 1, (int32_t)(c.pos0 + k), valid, tt, o, a);
-                if (!valid) continue;
-                lane_store(c, o, a);
-                const bool dead = c.per_lib && a.unavail != NONE32;
-                if (!dead) { warn[BRC_W_SM_MISSING] += a.w_sm; warn[BRC_W_NM_MISSING] += a.w_nm; if (c.pos0 + k >= c.beg0) n_events += a.ncol; }
-                if (dead && l == 0) warn[BRC_W_LIB_UNAVAILABLE]++;
+        for (int l = 0; l < Lp; ++l) {
+            const int64_t s0 = st->lib_base[(size_t)l], s1 = st->lib_base[(size_t)l + 1];
+            int32_t m = INT32_MIN;
+            for (int64_t i = s0; i < s1; ++i) { if (reach[(size_t)i] > m) m = reach[(size_t)i]; prefmax[(size_t)i] = m; }
+            for (int64_t tl = 0; tl < ntiles; ++tl) {                                                 // KB
+                uint32_t lo, hi; tile_range2(c, prefmax.data(), key.data(), s0, s1, tl, lo, hi);
+                pileup_tile(pl, l, tl, lo, hi);
             }
         }
         for (int64_t k = 0; k < P; ++k) {
@@ -94,13 +177,13 @@ class SimBackend : public Backend {
         }
         iout.clear();
         std::vector<IndelOut> tmp;
-        for (int64_t key = 0; key < P * Lp; ++key) {
-            const int nk = (int)cnt[(size_t)key]; if (!nk) continue;
-            const int64_t k = key / Lp; const int lib = (int)(key % Lp);
+        for (int64_t key2 = 0; key2 < P * Lp; ++key2) {
+            const int nk = (int)cnt[(size_t)key2]; if (!nk) continue;
+            const int64_t k = key2 / Lp; const int lib = (int)(key2 % Lp);
             if (c.per_lib && unavail[(size_t)k] != NONE32) continue;                                  // position abandoned
             tmp.resize((size_t)nk);
             uint32_t wsm = 0, wnm = 0;
-            const int na = reduce_indel_key(c, in, reads.data(), ev.data() + off[(size_t)key], nk, (int32_t)(c.pos0 + k), lib, tmp.data(), wsm, wnm);
+            const int na = reduce_indel_key(c, in, reads.data(), ev.data() + off[(size_t)key2], nk, (int32_t)(c.pos0 + k), lib, tmp.data(), wsm, wnm);
             warn[BRC_W_SM_MISSING] += wsm; warn[BRC_W_NM_MISSING] += wnm;
             for (int a = 0; a < na; ++a) iout.push_back(tmp[(size_t)a]);
         }

@@ -76,18 +76,26 @@ def test_hip_annotate_mismatch_runs_stress(hip_lib, oracle_lib, mismatch, read_l
     parity.compare_libs(hip_lib, oracle_lib, arrs, [(0, 8000)], ref=ref, min_mapq=10, min_bq=15, insertion_centric=True)
 
 
-@pytest.mark.parametrize("env", ["BRC_NO_TABLE", "BRC_NO_PL"])
-def test_hip_alternative_device_paths(hip_lib, oracle_lib, monkeypatch, env):
-    """Paths that the default configuration uses only for a few percent of the reads (every read through the general
-    probe with exact reciprocal division: BRC_NO_TABLE) or not at all (per-library launch without the own-library read
-    mask: BRC_NO_PL) must give the same bits."""
-    monkeypatch.setenv(env, "1")
+KNOBS = [{"BRC_NO_TABLE": "1"}, {"BRC_FLUSH_K": "3"}, {"BRC_PACK_LIM": "255", "BRC_FLUSH_K": "9"}, {"BRC_FORCE_DOM": "0"},
+         {"BRC_FORCE_DOM": "3", "BRC_FLUSH_K": "1"}, {"BRC_FORCE_DOM": "5", "BRC_PACK_LIM": "255"}]
+
+
+@pytest.mark.parametrize("env", KNOBS, ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()))
+def test_hip_rare_device_paths(hip_lib, oracle_lib, monkeypatch, env):
+    """Paths of k_pileup2 that ordinary data takes for a few events only, forced for all of them by test knobs: event terms by
+    exact reciprocal division (BRC_NO_TABLE), flushes of the packed integer registers every K pieces (BRC_FLUSH_K), PF_HUGE
+    pieces whose integers are drained (BRC_PACK_LIM), third-allele queue + live planes at the final store (BRC_FORCE_DOM
+    makes every lane treat one bucket as dominant).  Same bits as the oracle in every case."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     rng = np.random.default_rng(99)
     ref = synth.make_ref(rng, 3000, weird=0.01)
     arrs = synth.make_batch(199, ref, 700, style="mixed", n_libs=3, p_nolib=0.02)
     names = ["libA", "libB", "libC"]
     parity.compare_libs(hip_lib, oracle_lib, arrs, [(0, 3000), (1200, 1300)], ref=ref, lib_names=names, per_lib=True, check_warn=False)
     parity.compare_libs(hip_lib, oracle_lib, arrs, [(0, 3000)], ref=ref, min_mapq=5, min_bq=10, insertion_centric=True)
+    deep = synth.make_batch(299, ref, 2500, style="mixed", region=(900, 1400), read_len=(100, 150))       # ~600x: many half-batches per tile
+    parity.compare_libs(hip_lib, oracle_lib, deep, [(800, 1600)], ref=ref)
 
 
 def test_hip_edge_cases(hip_lib, oracle_lib):

@@ -123,3 +123,22 @@ def test_threaded_formatter_chunk_boundaries(sim_lib, oracle_lib, monkeypatch):
         monkeypatch.setenv("BRC_FORMAT_CHUNK", chunk); monkeypatch.setenv("BRC_FORMAT_THREADS", threads)
         got, _ = parity.run_engine(sim_lib, arrs, [(0, 40_000), (5000, 5001), (77, 30000)], ref=ref, lib_names=names, per_lib=True, clear_queue=False)
         assert got == want, (chunk, threads)
+
+
+KNOBS = [{"BRC_NO_TABLE": "1"}, {"BRC_FLUSH_K": "3"}, {"BRC_PACK_LIM": "255", "BRC_FLUSH_K": "9"}, {"BRC_FORCE_DOM": "0"},
+         {"BRC_FORCE_DOM": "3", "BRC_FLUSH_K": "1"}, {"BRC_FORCE_DOM": "5", "BRC_PACK_LIM": "255"}]
+
+
+@pytest.mark.parametrize("env", KNOBS, ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()))
+def test_sim_rare_device_paths(sim_lib, oracle_lib, monkeypatch, env):
+    """The rarely taken paths of the piece walk, forced by test knobs (see tests/test_gpu_parity.py::test_hip_rare_device_paths)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(99)
+    ref = synth.make_ref(rng, 3000, weird=0.01)
+    arrs = synth.make_batch(199, ref, 700, style="mixed", n_libs=3, p_nolib=0.02)
+    names = ["libA", "libB", "libC"]
+    parity.compare_libs(sim_lib, oracle_lib, arrs, [(0, 3000), (1200, 1300)], ref=ref, lib_names=names, per_lib=True, check_warn=False)
+    parity.compare_libs(sim_lib, oracle_lib, arrs, [(0, 3000)], ref=ref, min_mapq=5, min_bq=10, insertion_centric=True)
+    deep = synth.make_batch(299, ref, 2500, style="mixed", region=(900, 1400), read_len=(100, 150))
+    parity.compare_libs(sim_lib, oracle_lib, deep, [(800, 1600)], ref=ref)
