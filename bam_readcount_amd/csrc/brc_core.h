@@ -65,7 +65,7 @@ struct DevCfg {
     int32_t variant;        // 0 in production; >0 = profiling ablations selected by BRC_PILEUP_VARIANT (see brc_engine.hip)
     int32_t force_dom;      // test knob (BRC_FORCE_DOM): -1, or the bucket every lane treats as dominant (stresses the alternate / third-allele paths)
     int64_t n_pieces;       // pieces of all libraries (KB v2)
-    int32_t flush_k;        // K: pieces a lane may accumulate in its packed integer registers between two flushes (1..63)
+    int32_t flush_k;        // K: pieces a lane may accumulate in its packed integer registers between two flushes (1..63: 6-bit warning counters)
     uint32_t pack_lim;      // 65535 / K: largest per-read value a 16-bit packed field can take (PF_HUGE above it)
 };
 
@@ -575,19 +575,21 @@ enum { PF_TABLE = 1,    // event terms come from the quotient tables (l_qseq == 
        PF_Q2OK = 2, PF_NB = 4,
        PF_HUGE = 8,     // a per-read integer does not fit its packed field: w2/w3 carry only the mapping quality, the rest is added by drain_int()
        PF_SMW = 16, PF_NMW = 32, PF_REV = 64 };
-static const uint32_t THR_NEVER = 0x10000u;   // no 16-bit event word reaches it
+// an event word w passes the base-quality test (:288) iff w >= piece_thr(c)  (0x10000: no 16-bit word reaches it)
+BRC_HD uint32_t piece_thr(const DevCfg& c) { return (uint32_t)(c.min_bq < 0 ? 0 : (c.min_bq > 256 ? 256 : c.min_bq)) << 8; }
 
-// hot half: everything the read loop needs, ONE 64-byte scalar load (s_load_dwordx16) per piece
+// hot half (64 bytes): dwords 0-9 are what the read loop needs of every piece (scalar loads x8 + x2, two pieces ahead);
+// dwords 10-15 only pieces whose event terms are divided out (no PF_TABLE)
 struct alignas(64) PieceHot {
     int32_t rs;            // reference position of the first base
     int32_t a;             // rs - query offset: the lane on position p sees query base p - a
-    int32_t len;           // events: positions [rs, rs + len)
+    int32_t len;           // events: positions [rs, rs + len); every piece with len > 0 belongs to a read that counts
     int32_t ext;           // column: positions [rs, rs + ext), ext >= len
-    uint32_t thr;          // an event word w counts iff w >= thr  (min_bq << 8, or THR_NEVER)
     uint32_t tp_flags;     // bits 0-23: three_prime_index * 4 (byte offset into the float quotient table); 24-31: PF_*
     uint32_t w1, w2, w3;   // packed integer addends: 1 | rev << 10 | q2ok << 20;  mapq | sse << 16;  zm_sum | clipped << 16
     float snm;             // NM / (float)clipped_length, 0 when NM is missing
-    float rcpL, Lf, rcpC, center;   // exact-division constants (RcpPair)
+    uint32_t ws;           // rides on the base-quality sum: SM-missing << 14 | NM-missing << 20 (process_read warnings, BasicStat.cpp:85,100)
+    float rcpL, Lf, rcpC, center;   // exact-division constants
     int32_t left, q2;
 };
 // cold half: staging, the drain paths and the indel reduction
@@ -680,7 +682,6 @@ BRC_HD bool read_enters(uint32_t flag, const uint32_t* cig, uint32_t nc) {
 
 BRC_HD void make_piece(const DevCfg& c, const ReadConst& r, int32_t rs, int32_t len, int32_t ext, int qoff, bool nb, PieceHot& h, PieceCold& cold) {
     h.rs = rs; h.a = rs - qoff; h.len = len; h.ext = ext;
-    h.thr = r.counts ? ((uint32_t)(c.min_bq < 0 ? 0 : (c.min_bq > 256 ? 256 : c.min_bq)) << 8) : THR_NEVER;
     uint32_t fl = r.flags;
     const bool q2ok = (fl & PF_Q2OK) != 0;
     if (c.table_len > 0 && r.l_qseq == c.table_len && r.clipped == c.table_len && r.left == 0 && r.tp >= 0 && r.tp <= c.table_len &&
@@ -693,6 +694,7 @@ BRC_HD void make_piece(const DevCfg& c, const ReadConst& r, int32_t rs, int32_t 
     h.w2 = r.mapq | (huge ? 0u : (r.sse << 16));
     h.w3 = huge ? 0u : (r.zm | ((uint32_t)r.clipped << 16));
     h.snm = r.snm;
+    h.ws = ((fl & PF_SMW) ? (1u << 14) : 0u) | ((fl & PF_NMW) ? (1u << 20) : 0u);
     h.Lf = (float)r.l_qseq; h.center = (float)r.clipped * 0.5f; h.rcpL = 1.0f / h.Lf; h.rcpC = 1.0f / h.center;
     h.left = r.left; h.q2 = r.q2;
     cold.bq_off = r.bq_off; cold.a = h.a; cold.read = r.read; cold.zm_raw = r.zm; cold.sse_raw = r.sse; cold.mapq = r.mapq;
@@ -718,12 +720,12 @@ BRC_HD EvTerms piece_terms_tab(const PieceHot& h, const TermTab& tt, int table_l
     return t;
 }
 
-// One bucket of a lane between two flushes: three packed integer registers, the base-quality sum and the four
-// order-sensitive float sums.
+// One bucket of a lane between two flushes: three packed integer registers, the base-quality sum (bits 0-13, with the two
+// warning counters above it: bits 14-19 and 20-25; K <= 63 keeps every field inside its bits) and the four order-sensitive float sums.
 struct PackAcc { uint32_t w1, w2, w3, sbq; float f[NF]; };
 BRC_HD void pack_init(PackAcc& a) { a.w1 = a.w2 = a.w3 = a.sbq = 0; for (int f = 0; f < NF; ++f) a.f[f] = 0.0f; }
 BRC_HD void pack_event(PackAcc& a, const PieceHot& h, const EvTerms& t, uint32_t q) {
-    a.w1 += h.w1; a.w2 += h.w2; a.w3 += h.w3; a.sbq += q;
+    a.w1 += h.w1; a.w2 += h.w2; a.w3 += h.w3; a.sbq += q + h.ws;
     a.f[F_SQ2] += t.q2; a.f[F_S3P] += t.s3p;
     a.f[F_SEV] = (float)((double)a.f[F_SEV] + t.sev);
     a.f[F_SNM] += h.snm;
@@ -732,7 +734,7 @@ BRC_HD void pack_event(PackAcc& a, const PieceHot& h, const EvTerms& t, uint32_t
 BRC_HD void pack_unpack(const PackAcc& a, uint32_t* v) {
     const uint32_t n = a.w1 & 0x3ffu, minus = (a.w1 >> 10) & 0x3ffu;
     v[I_N] = n; v[I_SMQ] = a.w2 & 0xffffu; v[I_SSE] = a.w2 >> 16; v[I_PLUS] = n - minus; v[I_MINUS] = minus;
-    v[I_NQ2] = a.w1 >> 20; v[I_SMMQ] = a.w3 & 0xffffu; v[I_SCLIP] = a.w3 >> 16; v[I_SBQ] = a.sbq;
+    v[I_NQ2] = a.w1 >> 20; v[I_SMMQ] = a.w3 & 0xffffu; v[I_SCLIP] = a.w3 >> 16; v[I_SBQ] = a.sbq & 0x3fffu;
 }
 
 // K (pieces between two flushes of a lane's packed integers) and the per-read limit of a 16-bit field: clipped_length of
@@ -760,18 +762,35 @@ BRC_HD void lane2_init(LaneAcc2& a, uint32_t dom_b) {
 BRC_HD uint32_t* plane_i(const DevCfg& c, const Planes& pl, int lib, uint32_t b, int64_t k) { return pl.istat + (((int64_t)lib * NBUCKET + b) * NI) * c.PS + k; }
 BRC_HD float* plane_f(const DevCfg& c, const Planes& pl, int lib, uint32_t b, int64_t k) { return pl.fstat + (((int64_t)lib * NBUCKET + b) * NF) * c.PS + k; }
 
+// The three functions below are the RARE paths of KB (a flush every K pieces, a drained event per few tiles).  They are
+// written as rolled loops over the plane index with the value picked by a select chain: slow, but a handful of live
+// registers — inlined into the read loop they must not raise its register peak (61 VGPRs = 8 waves / SIMD without them,
+// 100 with their unrolled forms).
+#if defined(__clang__)
+#define BRC_NOUNROLL _Pragma("unroll 1")
+#else
+#define BRC_NOUNROLL _Pragma("GCC unroll 1")
+#endif
+BRC_HD uint32_t pack_field(const PackAcc& a, int f) {
+    const uint32_t n = a.w1 & 0x3ffu, minus = (a.w1 >> 10) & 0x3ffu;
+    uint32_t v = n;                                            // I_N
+    v = f == I_SMQ ? (a.w2 & 0xffffu) : v; v = f == I_SSE ? (a.w2 >> 16) : v; v = f == I_PLUS ? n - minus : v; v = f == I_MINUS ? minus : v;
+    v = f == I_NQ2 ? (a.w1 >> 20) : v; v = f == I_SMMQ ? (a.w3 & 0xffffu) : v; v = f == I_SCLIP ? (a.w3 >> 16) : v; v = f == I_SBQ ? (a.sbq & 0x3fffu) : v;
+    return v;
+}
 // registers -> integer planes of one bucket (adds when the planes are live), registers reset
-BRC_HD void flush_bucket(const DevCfg& c, const Planes& pl, int lib, int64_t k, PackAcc& a, uint32_t b, uint32_t& mem) {
-    uint32_t v[NI]; pack_unpack(a, v);
+BRC_HD void flush_bucket(const DevCfg& c, const Planes& pl, int lib, int64_t k, PackAcc& a, uint32_t b, uint32_t& mem, uint32_t& w_sm, uint32_t& w_nm) {
     uint32_t* ip = plane_i(c, pl, lib, b, k);
+    w_sm += (a.sbq >> 14) & 63u; w_nm += (a.sbq >> 20) & 63u;
     const bool live = (mem >> b) & 1u;
-    for (int f = 0; f < NI; ++f) ip[(int64_t)f * c.PS] = v[f] + (live ? ip[(int64_t)f * c.PS] : 0u);
+    BRC_NOUNROLL
+    for (int f = 0; f < NI; ++f) { const uint32_t v = pack_field(a, f); ip[(int64_t)f * c.PS] = v + (live ? ip[(int64_t)f * c.PS] : 0u); }
     mem |= 1u << b;
     a.w1 = a.w2 = a.w3 = a.sbq = 0;
 }
 BRC_HD void lane2_flush(const DevCfg& c, const Planes& pl, int lib, int64_t k, LaneAcc2& a) {
-    flush_bucket(c, pl, lib, k, a.dom, a.dom_b, a.mem);
-    if (a.alt_b != NB_NONE) flush_bucket(c, pl, lib, k, a.alt, a.alt_b, a.mem);
+    flush_bucket(c, pl, lib, k, a.dom, a.dom_b, a.mem, a.w_sm, a.w_nm);
+    if (a.alt_b != NB_NONE) flush_bucket(c, pl, lib, k, a.alt, a.alt_b, a.mem, a.w_sm, a.w_nm);
 }
 // one event of a third (fourth, ...) base at this position, straight into the planes; events of one bucket arrive in
 // column order because the queue is drained in piece order
@@ -779,26 +798,35 @@ BRC_HD void drain_full(const DevCfg& c, const Planes& pl, int lib, int64_t k, ui
     const uint32_t b = word & 0xffu, q = word >> 8;
     uint32_t* ip = plane_i(c, pl, lib, b, k); float* fp = plane_f(c, pl, lib, b, k);
     const bool live = (mem >> b) & 1u;
-    const int64_t P = c.PS;
-    const EvTerms t = piece_terms_div(h, qpos);
     const uint32_t fl = piece_flags(h);
     const uint32_t rev = (fl & PF_REV) ? 1u : 0u;
-    ip[I_N * P] = (live ? ip[I_N * P] : 0u) + 1u; ip[I_SMQ * P] = (live ? ip[I_SMQ * P] : 0u) + cold.mapq;
-    ip[I_SSE * P] = (live ? ip[I_SSE * P] : 0u) + cold.sse_raw; ip[I_PLUS * P] = (live ? ip[I_PLUS * P] : 0u) + (1u - rev);
-    ip[I_MINUS * P] = (live ? ip[I_MINUS * P] : 0u) + rev; ip[I_NQ2 * P] = (live ? ip[I_NQ2 * P] : 0u) + ((fl & PF_Q2OK) ? 1u : 0u);
-    ip[I_SMMQ * P] = (live ? ip[I_SMMQ * P] : 0u) + cold.zm_raw; ip[I_SCLIP * P] = (live ? ip[I_SCLIP * P] : 0u) + (uint32_t)cold.clipped;
-    ip[I_SBQ * P] = (live ? ip[I_SBQ * P] : 0u) + q;
-    fp[F_SQ2 * P] = (live ? fp[F_SQ2 * P] : 0.0f) + t.q2; fp[F_S3P * P] = (live ? fp[F_S3P * P] : 0.0f) + t.s3p;
-    fp[F_SEV * P] = (float)((double)(live ? fp[F_SEV * P] : 0.0f) + t.sev); fp[F_SNM * P] = (live ? fp[F_SNM * P] : 0.0f) + h.snm;
+    BRC_NOUNROLL
+    for (int f = 0; f < NI; ++f) {
+        uint32_t v = 1u;                                       // I_N
+        v = f == I_SMQ ? cold.mapq : v; v = f == I_SSE ? cold.sse_raw : v; v = f == I_PLUS ? 1u - rev : v; v = f == I_MINUS ? rev : v;
+        v = f == I_NQ2 ? ((fl & PF_Q2OK) ? 1u : 0u) : v; v = f == I_SMMQ ? cold.zm_raw : v; v = f == I_SCLIP ? (uint32_t)cold.clipped : v; v = f == I_SBQ ? q : v;
+        ip[(int64_t)f * c.PS] = v + (live ? ip[(int64_t)f * c.PS] : 0u);
+    }
+    const EvTerms t = piece_terms_div(h, qpos);
+    BRC_NOUNROLL
+    for (int f = 0; f < NF; ++f) {
+        const float old = live ? fp[(int64_t)f * c.PS] : 0.0f;
+        float v = f == F_SQ2 ? t.q2 : (f == F_S3P ? t.s3p : h.snm);
+        float r = old + v;
+        if (f == F_SEV) r = (float)((double)old + t.sev);
+        fp[(int64_t)f * c.PS] = r;
+    }
     mem |= 1u << b;
 }
 // the integers of a PF_HUGE piece that its packed addends left out, for a lane whose event went to bucket b (dominant or alternate)
 BRC_HD void drain_int(const DevCfg& c, const Planes& pl, int lib, int64_t k, uint32_t& mem, const PieceCold& cold, uint32_t b) {
     uint32_t* ip = plane_i(c, pl, lib, b, k);
     const bool live = (mem >> b) & 1u;
-    const int64_t P = c.PS;
-    if (!live) for (int f = 0; f < NI; ++f) ip[(int64_t)f * P] = 0u;
-    ip[I_SSE * P] += cold.sse_raw; ip[I_SMMQ * P] += cold.zm_raw; ip[I_SCLIP * P] += (uint32_t)cold.clipped;
+    BRC_NOUNROLL
+    for (int f = 0; f < NI; ++f) {
+        const uint32_t v = f == I_SSE ? cold.sse_raw : (f == I_SMMQ ? cold.zm_raw : (f == I_SCLIP ? (uint32_t)cold.clipped : 0u));
+        ip[(int64_t)f * c.PS] = v + (live ? ip[(int64_t)f * c.PS] : 0u);
+    }
     mem |= 1u << b;
 }
 // end of the tile: whatever is still in registers, and zeros for the untouched buckets
@@ -812,7 +840,7 @@ BRC_HD void lane2_store(const DevCfg& c, const Planes& pl, int lib, int64_t k, L
         if (isdom || isalt) {
             PackAcc& r = isdom ? a.dom : a.alt;
             for (int f = 0; f < NF; ++f) fp[(int64_t)f * P] = r.f[f];
-            flush_bucket(c, pl, lib, k, r, b, a.mem);
+            flush_bucket(c, pl, lib, k, r, b, a.mem, a.w_sm, a.w_nm);
         } else if (dead || !((a.mem >> b) & 1u)) {
             for (int f = 0; f < NI; ++f) ip[(int64_t)f * P] = 0u;
             for (int f = 0; f < NF; ++f) fp[(int64_t)f * P] = 0.0f;

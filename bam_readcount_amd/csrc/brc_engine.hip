@@ -551,20 +551,17 @@ enum { QCAP = 2 * HALF + 2 };   // deferred entries of one half-batch: at most a
 static_assert(HALF * WIN_U4 <= 64, "one direct-to-LDS instruction stages a half-batch");
 static_assert(HALF % 3 == 0, "the piece-record registers rotate with period 3");
 
-struct PRec { uint4 h0, h1, h2, h3; };     // PieceHot as four scalar 16-byte words
-__device__ __forceinline__ PieceHot prec_hot(const PRec& r) {
-    PieceHot h;
-    h.rs = (int32_t)r.h0.x; h.a = (int32_t)r.h0.y; h.len = (int32_t)r.h0.z; h.ext = (int32_t)r.h0.w;
-    h.thr = r.h1.x; h.tp_flags = r.h1.y; h.w1 = r.h1.z; h.w2 = r.h1.w;
-    h.w3 = r.h2.x; h.snm = __uint_as_float(r.h2.y); h.rcpL = __uint_as_float(r.h2.z); h.Lf = __uint_as_float(r.h2.w);
-    h.rcpC = __uint_as_float(r.h3.x); h.center = __uint_as_float(r.h3.y); h.left = (int32_t)r.h3.z; h.q2 = (int32_t)r.h3.w;
-    return h;
-}
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+// dwords 0-9 of a PieceHot in scalar registers: f = {rs, a, len, ext, tp_flags, w1, w2, w3}, g = {snm, ws}
+struct PRec { u32x8 f; u32x2 g; };
 
 // One wave = one (64-position tile, library); lane == position.  The wave walks the tile's pieces [lo, hi) of its library
 // in stream (= pileup column) order, in half-batches of HALF = 6:
-//  * piece records: one 64-byte scalar load per piece, two pieces ahead, rotating through three scalar register sets —
-//    everything wave-uniform (positions, lengths, thresholds, packed addends, division constants) lives in SGPRs;
+//  * piece records: the 40 bytes every piece needs arrive by two scalar loads, two pieces ahead, rotating through three
+//    scalar register sets — everything wave-uniform (positions, lengths, packed addends) lives in SGPRs.  The loads are
+//    inline assembly so that they are issued exactly there (the scheduler sinks compiler-visible loads to their first use);
+//    the matching s_waitcnt names the registers, which orders every use behind it;
 //  * event words: the 72-element window of each piece's row that this tile can touch is copied by ONE direct-to-LDS
 //    instruction per half-batch (global_load_lds_dwordx4: lane = row * 9 + chunk, no VGPR round trip) into a two-half
 //    ring; the copy of half-batch h + 2 is issued when h is done, its addresses come from a 16-byte cold-record load
@@ -573,8 +570,8 @@ __device__ __forceinline__ PieceHot prec_hot(const PRec& r) {
 //    accumulate of piece j (quality / bucket ballots, one exec region with the 10 adds of the dominant bucket, a usually
 //    skipped one for everything else); lane conditions are 64-bit masks in scalar registers;
 //  * per bucket a lane holds three PACKED integer registers (counters 10 bits each; mapq | sse; zm | clipped), the
-//    base-quality sum and the four fp32 sums; the packed ones are flushed to the planes every K pieces (rare: K = 63
-//    for short reads) and at the end of the tile;
+//    base-quality sum with the two warning counters on top, and the four fp32 sums; the integers are flushed to the
+//    planes every K pieces (K = 63 for short reads) and at the end of the tile;
 //  * third alleles (a lane keeps its reference base and the first other base in registers) and PF_HUGE integers are
 //    queued and drained into the planes between half-batches, in piece order.
 __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn in, const uint4* __restrict__ hot4, const PieceCold* __restrict__ cold,
@@ -618,11 +615,12 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn i
     lane2_init(a, c.force_dom >= 0 ? (uint32_t)c.force_dom : (valid ? dominant_bucket(c, in, p) : 1u));
     const int64_t kk = valid ? k : 0;
 
-    if (lo < hi) {
+    if (lo < hi && c.variant != 4) {            // (variant: profiling ablations, BRC_PILEUP_VARIANT — 4: no piece loop, 1: no plane stores, 5: one half-batch only)
         // lanes past the region's last position stand far left of every piece: no coverage test is ever true for them
         // (d = 2^31 + lane + p0 - rs >= 2^31 - (rs - p0) >= ext for every piece, because rs + ext <= 2^31 - 1 and p0 >= 0)
         const uint32_t lanev = valid ? (uint32_t)lane : (0x80000000u | (uint32_t)lane);
         const uint32_t L0 = (uint32_t)c.table_len;
+        const uint32_t thr0 = piece_thr(c);
         char* const rows_base = reinterpret_cast<char*>(&lds.rows[wv][0][0]);
         QEnt* const queue = lds.queue[wv];
         uint32_t qn = 0;                                                       // queued entries (scalar)
@@ -631,61 +629,75 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn i
         const uint32_t srow = (uint32_t)lane / (uint32_t)WIN_U4, schunk = (uint32_t)lane % (uint32_t)WIN_U4;
         const bool slane = lane < HALF * WIN_U4;
         // {bq_off, a} of piece b0 + srow (clamped): what the window copy of that row needs
-#define BRC_LD_TAB(T, b0) { const uint32_t mi = (b0) + srow < hi ? (b0) + srow : hi - 1u; T = *reinterpret_cast<const uint4*>(cold + mi); }
-        // window copy of the half-batch starting at piece b0 into ring half `hf`: element window [ws, ws + 72) of the row,
-        // ws = floor8(p0 - a) (may start before the row: the event-word stream is padded)
-#define BRC_STAGE(T, b0, hf)                                                                                             \
+        // ... and, by the first lane of every row, one dword of its hot record: nothing uses the value — the load pulls the
+        // record's cache line into L2 a half-batch before the scalar loads of the read loop ask for it (their own look-ahead
+        // of two pieces covers an L2 hit, not an HBM miss)
+#define BRC_LD_TAB(T, b0) { const uint32_t mi = (b0) + srow < hi ? (b0) + srow : hi - 1u; T = *reinterpret_cast<const uint4*>(cold + mi); \
+                            asm volatile("" :: "v"(pf)); if (schunk == 0u) pf = hot4[(size_t)mi * 4u].x; }
+        // window copy of the half-batch starting at piece b0 into the ring half at byte offset hoff: element window
+        // [ws, ws + 72) of the row, ws = floor8(p0 - a) (may start before the row: the event-word stream is padded)
+#define BRC_STAGE(T, b0, hoff)                                                                                           \
         {                                                                                                                 \
             if (slane && (b0) + srow < hi) {                                                                              \
                 const int64_t boff = (int64_t)(((uint64_t)T.y << 32) | T.x);                                              \
                 const int32_t ws = (p0 - (int32_t)T.z) & ~7;                                                              \
                 const uint16_t* src = bq_ro + (boff + ws) + 8u * schunk;                                                  \
                 __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,                      \
-                    (void __attribute__((address_space(3)))*)(rows_base + (hf) * (HALF * ROW_BYTES)), 16, 0, 0);          \
+                    (void __attribute__((address_space(3)))*)(rows_base + (hoff)), 16, 0, 0);                             \
             }                                                                                                             \
         }
-        // piece record m (clamped) by scalar loads
-#define BRC_LD_REC(R, m) { const uint32_t mm = (m) < hi ? (m) : hi - 1u; const uint4* hp = hot4 + (size_t)mm * 4u; R.h0 = hp[0]; R.h1 = hp[1]; R.h2 = hp[2]; R.h3 = hp[3]; }
-        struct Stage { uint32_t w; float t, tq2; double sev; uint64_t m_in; };
-        // PROBE of the piece in R, staged in ring row `rw`
-#define BRC_PROBE(R, rw, S)                                                                                             \
+        // scalar loads of the record at rp (issued HERE), and the wait that makes them usable
+#define BRC_LD_REC(R, rp) asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x20" : "=&s"(R.f), "=&s"(R.g) : "s"(rp));
+#define BRC_WAIT_REC(R) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R.f), "+s"(R.g));
+        // the division constants of piece m (dwords 10-15 of its record) by scalar loads, on demand: only pieces without PF_TABLE
+#define BRC_LD_DIV(H, R, m)                                                                                             \
         {                                                                                                                 \
-            const int32_t s_d = p0 - (int32_t)R.h0.x, s_c = p0 - (int32_t)R.h0.y;                                         \
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));                                                   \
+            u32x4 dA; u32x2 dB; const char* dp = reinterpret_cast<const char*>(hot4) + (size_t)(m) * 64u;                 \
+            asm volatile("s_load_dwordx4 %0, %2, 0x28\n\ts_load_dwordx2 %1, %2, 0x38\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dA), "=&s"(dB) : "s"(dp)); \
+            H.tp_flags = R.f[4]; H.rcpL = __uint_as_float(dA[0]); H.Lf = __uint_as_float(dA[1]); H.rcpC = __uint_as_float(dA[2]);  \
+            H.center = __uint_as_float(dA[3]); H.left = (int32_t)dB[0]; H.q2 = (int32_t)dB[1];                            \
+        }
+        struct Stage { uint32_t w; float t; double sev; uint64_t m_in, m_cov; int32_t s_c; };
+        // PROBE of the piece in R, staged in the ring row at byte offset roff: coverage ballots and three LDS reads whose
+        // results nothing in this stage touches (a copy or a select here would stall the wave on its own reads).  The table
+        // look-ups are issued for every piece; a piece without PF_TABLE ignores them and divides in its accumulate stage.
+#define BRC_PROBE(R, roff, S)                                                                                           \
+        {                                                                                                                 \
+            const int32_t s_d = p0 - (int32_t)R.f[0]; S.s_c = p0 - (int32_t)R.f[1];                                       \
             const uint32_t d = lanev + (uint32_t)s_d;                                                                     \
-            const uint64_t m_cov = __builtin_amdgcn_ballot_w64(d < R.h0.w);                                               \
-            count_if(a.ncol, m_cov);                                          /* lib_counts[library] (:286) */            \
-            S.m_in = __builtin_amdgcn_ballot_w64(d < R.h0.z);                                                             \
-            const uint32_t off = (uint32_t)(rw) * (uint32_t)ROW_BYTES + 2u * ((uint32_t)s_c & 7u);                        \
+            S.m_cov = __builtin_amdgcn_ballot_w64(d < R.f[3]);   /* counted in the accumulate stage: a probe may run past the tile's last piece */ \
+            S.m_in = __builtin_amdgcn_ballot_w64(d < R.f[2]);                                                             \
+            const uint32_t off = (uint32_t)(roff) + 2u * ((uint32_t)S.s_c & 7u);                                          \
             S.w = (uint32_t)*reinterpret_cast<const uint16_t*>(rows_base + off + 2u * (uint32_t)lane);                    \
-            const uint32_t fl = R.h1.y >> 24;                                                                             \
-            if (__builtin_expect((fl & PF_TABLE) != 0u, 1)) {                                                             \
-                const uint32_t qp4 = 4u * (uint32_t)lane + 4u * (uint32_t)s_c;                                            \
-                S.t = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds.q) + sad_u32(qp4, R.h1.y & 0xffffffu)); \
-                S.sev = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds.e) + sad_u32(qp4 << 2, L0 << 3)); \
-                S.tq2 = S.t;                                  /* q2 == tp or no q2 at all: masked in the accumulate stage */ \
-            } else {                                                                                                      \
-                const PieceHot H = prec_hot(R);                                                                           \
-                const EvTerms t = piece_terms_div(H, (int)((uint32_t)lane + (uint32_t)s_c));                              \
-                S.t = t.s3p; S.tq2 = t.q2; S.sev = t.sev;                                                                 \
-            }                                                                                                             \
+            const uint32_t qp4 = 4u * (uint32_t)lane + 4u * (uint32_t)S.s_c;                                              \
+            S.t = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds.q) + sad_u32(qp4, R.f[4] & 0xffffffu)); \
+            S.sev = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds.e) + sad_u32(qp4 << 2, L0 << 3));  \
         }
         // ACC of the piece in R (S = its probe results), piece index m
 #define BRC_ACC(R, S, m)                                                                                                \
         {                                                                                                                 \
-            const uint32_t fl = R.h1.y >> 24;                                                                             \
-            const uint64_t m_p = S.m_in & __builtin_amdgcn_ballot_w64(S.w >= R.h1.x);         /* :288 */                  \
+            const uint32_t fl = R.f[4] >> 24;                                                                             \
+            count_if(a.ncol, S.m_cov);                                                         /* lib_counts[library] (:286) */ \
+            const uint64_t m_p = S.m_in & __builtin_amdgcn_ballot_w64(S.w >= thr0);           /* :288 */                  \
             count_if(a.depth, m_p);                                                            /* mapq_n (:312) */         \
             if (!(fl & PF_NB)) {                                                               /* :343 with -i */          \
-                count_if(a.w_sm, (fl & PF_SMW) ? m_p : 0ull); count_if(a.w_nm, (fl & PF_NMW) ? m_p : 0ull);               \
-                const uint32_t b = S.w & 0xffu, q = S.w >> 8;                                                             \
-                /* a table piece without a Q2 position adds +0.0f (the identity on these sums) */                        \
-                const float tq2 = __uint_as_float(__float_as_uint(S.tq2) & (((fl & (PF_TABLE | PF_Q2OK)) == PF_TABLE) ? 0u : 0xffffffffu)); \
+                const uint32_t b = S.w & 0xffu, qw = (S.w >> 8) + R.g[1];     /* base quality + the warning bits */       \
+                float ts3p, tq2; double tsev;                                                                             \
+                if (__builtin_expect((fl & PF_TABLE) != 0u, 1)) {                                                         \
+                    /* q2 == tp, or no Q2 position: then +0.0f, the identity on these sums */                            \
+                    ts3p = S.t; tsev = S.sev; tq2 = __uint_as_float(__float_as_uint(S.t) & ((fl & PF_Q2OK) ? 0xffffffffu : 0u)); \
+                } else {                                                                                                  \
+                    PieceHot H; BRC_LD_DIV(H, R, m)                                                                       \
+                    const EvTerms t = piece_terms_div(H, (int)((uint32_t)lane + (uint32_t)S.s_c));                        \
+                    ts3p = t.s3p; tq2 = t.q2; tsev = t.sev;                                                               \
+                }                                                                                                         \
                 const uint64_t m_dom = m_p & __builtin_amdgcn_ballot_w64(b == a.dom_b);                                   \
                 if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(m_dom), 1)) {                                    \
-                    a.dom.w1 += R.h1.z; a.dom.w2 += R.h1.w; a.dom.w3 += R.h2.x; a.dom.sbq += q;                           \
-                    a.dom.f[F_SQ2] += tq2; a.dom.f[F_S3P] += S.t;                                                         \
-                    a.dom.f[F_SEV] = (float)((double)a.dom.f[F_SEV] + S.sev);                                             \
-                    a.dom.f[F_SNM] += __uint_as_float(R.h2.y);                                                            \
+                    a.dom.w1 += R.f[5]; a.dom.w2 += R.f[6]; a.dom.w3 += R.f[7]; a.dom.sbq += qw;                          \
+                    a.dom.f[F_SQ2] += tq2; a.dom.f[F_S3P] += ts3p;                                                        \
+                    a.dom.f[F_SEV] = (float)((double)a.dom.f[F_SEV] + tsev);                                              \
+                    a.dom.f[F_SNM] += __uint_as_float(R.g[0]);                                                            \
                 }                                                                                                         \
                 const uint64_t m_rest = m_p & ~m_dom;                                                                     \
                 uint64_t m_ovf = 0;                                                                                       \
@@ -695,10 +707,12 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn i
                         const bool take_alt = a.alt_b == NB_NONE || a.alt_b == b;                                         \
                         if (take_alt) {                                                                                   \
                             a.alt_b = b;                                                                                  \
-                            a.alt.w1 += R.h1.z; a.alt.w2 += R.h1.w; a.alt.w3 += R.h2.x; a.alt.sbq += q;                   \
-                            a.alt.f[F_SQ2] += tq2; a.alt.f[F_S3P] += S.t;                                                 \
-                            a.alt.f[F_SEV] = (float)((double)a.alt.f[F_SEV] + S.sev);                                     \
-                            a.alt.f[F_SNM] += __uint_as_float(R.h2.y);                                                    \
+                            a.alt.w1 += R.f[5]; a.alt.w2 += R.f[6]; a.alt.w3 += R.f[7]; a.alt.sbq += qw;                  \
+                            a.alt.f[F_SQ2] += tq2; a.alt.f[F_S3P] += ts3p;                                                \
+                            a.alt.f[F_SEV] = (float)((double)a.alt.f[F_SEV] + tsev);                                      \
+                            a.alt.f[F_SNM] += __uint_as_float(R.g[0]);                                                    \
+                        } else {                                                                                          \
+                            a.w_sm += (fl & PF_SMW) ? 1u : 0u; a.w_nm += (fl & PF_NMW) ? 1u : 0u;                         \
                         }                                                                                                 \
                         ovf = !take_alt;                                                                                  \
                     }                                                                                                     \
@@ -711,95 +725,127 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn i
                 }                                                                                                         \
             }                                                                                                             \
         }
-        // one pipeline step inside a half-batch: J = step (compile time), piece base + J is accumulated, base + J + 1 probed,
-        // the record of base + J + 2 requested.  RC / RN / RL = the three record sets in their roles of this step.
-#define BRC_STEP(J, RC, RN, RL, SC, SN)                                                                                 \
-        if ((J) < nb) {                                                                                                   \
-            /* all LDS and scalar-memory results of the previous step (incl. the record RN) have had a whole accumulate  \
-               stage to land: wait for them here, once.  The last step probes the first row of the OTHER ring half: its   \
-               copy (and the cold-record load behind it) was issued at the previous half-batch boundary.               */ \
+        // one pipeline step inside a half-batch: J = step (compile time); piece base + J is accumulated, base + J + 1 probed,
+        // the record of base + J + 2 requested.  RC / RN / RL = the three record sets in their roles of this step.  A probe
+        // past the tile's last piece reads a stale row and a record of the slack behind the stream; its result is never
+        // accumulated.
+#define BRC_STEP(J, RC, RN, RL, SC, SN, G)                                                                              \
+        if ((J) == 0 || (J) < nb) {                                                                                       \
+            /* the last step probes the first row of the OTHER ring half: its copy (and the cold-record load behind it)  \
+               was issued at the previous half-batch boundary */                                                         \
             if ((J) == HALF - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
-            __builtin_amdgcn_s_waitcnt(0xC07F);                               /* lgkmcnt(0) */                             \
-            BRC_LD_REC(RL, base + (J) + 2u)                                                                               \
-            if (base + (J) + 1u < hi) {                                                                                   \
-                const uint32_t rw = ((J) + 1 < HALF) ? hf * HALF + (J) + 1 : (hf ^ 1u) * HALF;                            \
-                BRC_PROBE(RN, rw, SN)                                                                                     \
+            /* record RN was requested a whole step ago, the LDS results of the previous probe likewise */               \
+            BRC_WAIT_REC(RN)                                                                                              \
+            BRC_LD_REC(RL, recp) recp += recstep;                                                                         \
+            {                                                                                                             \
+                BRC_PROBE(RN, ((J) + 1 < HALF ? hoff + ((J) + 1) * ROW_BYTES : (hoff ^ HOFF_X)), SN)                      \
             }                                                                                                             \
             BRC_ACC(RC, SC, base + (J))                                                                                   \
         }
-        uint4 T;
+        // between half-batches: drain the queue (the event words of this half-batch are still staged in ring half hoff),
+        // flush when the packed fields could overflow during the next half-batch, then reuse the ring half just processed
+        // (every LDS read of it has returned after the lgkmcnt wait): copy half-batch base + 2 HALF into it and request
+        // the addresses of the one after
+#define BRC_BOUNDARY(nbv)                                                                                               \
+        {                                                                                                                 \
+            since_flush += (int32_t)(nbv);                                                                                \
+            if (__builtin_expect(qn != 0u, 0)) {                                                                          \
+                for (uint32_t e = 0; e < qn; ++e) {                                                                       \
+                    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane(queue[e].piece), kind = (uint32_t)__builtin_amdgcn_readfirstlane(queue[e].kind); \
+                    /* (readfirstlane returns int: without the casts a set bit 31 of the low half would sign-extend) */  \
+                    const uint64_t mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(queue[e].mhi) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(queue[e].mlo); \
+                    PieceHot H; PieceCold CD;                                                                             \
+                    {   /* both records into scalar registers */                                                         \
+                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));                                       \
+                        u32x8 hf; u32x2 hg; u32x4 dA; u32x2 dB; u32x4 cd;                                                 \
+                        const char* hp = reinterpret_cast<const char*>(hot4) + (size_t)m * 64u;                           \
+                        const char* cp = reinterpret_cast<const char*>(cold) + (size_t)m * 32u;                           \
+                        asm volatile("s_load_dwordx8 %0, %5, 0x0\n\ts_load_dwordx2 %1, %5, 0x20\n\ts_load_dwordx4 %2, %5, 0x28\n\t" \
+                                     "s_load_dwordx2 %3, %5, 0x38\n\ts_load_dwordx4 %4, %6, 0x10\n\ts_waitcnt lgkmcnt(0)"   \
+                                     : "=&s"(hf), "=&s"(hg), "=&s"(dA), "=&s"(dB), "=&s"(cd) : "s"(hp), "s"(cp));         \
+                        H.rs = (int32_t)hf[0]; H.a = (int32_t)hf[1]; H.len = (int32_t)hf[2]; H.ext = (int32_t)hf[3]; H.tp_flags = hf[4]; \
+                        H.w1 = hf[5]; H.w2 = hf[6]; H.w3 = hf[7]; H.snm = __uint_as_float(hg[0]); H.ws = hg[1];          \
+                        H.rcpL = __uint_as_float(dA[0]); H.Lf = __uint_as_float(dA[1]); H.rcpC = __uint_as_float(dA[2]); H.center = __uint_as_float(dA[3]); \
+                        H.left = (int32_t)dB[0]; H.q2 = (int32_t)dB[1];                                                   \
+                        CD.bq_off = 0; CD.a = H.a; CD.read = 0; CD.zm_raw = cd[0]; CD.sse_raw = cd[1]; CD.mapq = cd[2]; CD.clipped = (int32_t)cd[3]; \
+                    }                                                                                                     \
+                    if ((mask >> lane) & 1ull) {                                                                          \
+                        const int32_t s_c = p0 - H.a;                                                                     \
+                        const uint32_t off = hoff + (m - base) * (uint32_t)ROW_BYTES + 2u * ((uint32_t)s_c & 7u);         \
+                        const uint32_t w = (uint32_t)*reinterpret_cast<const uint16_t*>(rows_base + off + 2u * (uint32_t)lane); \
+                        if (kind == 0u) drain_full(c, pl, lib, kk, a.mem, H, CD, lane + s_c, w);                          \
+                        else drain_int(c, pl, lib, kk, a.mem, CD, w & 0xffu);                                             \
+                    }                                                                                                     \
+                }                                                                                                         \
+                qn = 0;                                                                                                   \
+            }                                                                                                             \
+            if (__builtin_expect(since_flush + HALF > c.flush_k, 0)) {                                                    \
+                if (valid) lane2_flush(c, pl, lib, kk, a);                                                                \
+                since_flush = 0;                                                                                          \
+            }                                                                                                             \
+            if (base + 2u * (uint32_t)HALF < hi) {                                                                        \
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                               \
+                BRC_STAGE(T, base + 2u * (uint32_t)HALF, hoff)                                                            \
+                BRC_LD_TAB(T, base + 3u * (uint32_t)HALF)                                                                 \
+            }                                                                                                             \
+        }
+        enum { HOFF_X = HALF * ROW_BYTES };                                    // byte offset of the second ring half
+        uint4 T; uint32_t pf = 0;
         BRC_LD_TAB(T, lo)
-        BRC_STAGE(T, lo, 0u)
+        if (c.variant != 7) BRC_STAGE(T, lo, 0u)
         BRC_LD_TAB(T, lo + (uint32_t)HALF)
-        BRC_STAGE(T, lo + (uint32_t)HALF, 1u)
+        if (c.variant != 7) BRC_STAGE(T, lo + (uint32_t)HALF, (uint32_t)HOFF_X)
         BRC_LD_TAB(T, lo + 2u * (uint32_t)HALF)
         PRec R0, R1, R2;
-        BRC_LD_REC(R0, lo)
-        BRC_LD_REC(R1, lo + 1u)
+        const char* recp = reinterpret_cast<const char*>(hot4) + (size_t)lo * 64u;   // (scalar) next record to request
+        const uint32_t recstep = c.variant == 10 ? 0u : 64u;                   // (profiling: 10 = every scalar load hits the same line)
+        BRC_LD_REC(R0, recp) recp += 64;
+        BRC_LD_REC(R1, recp) recp += 64;
         R2 = R1;
         Stage S0, S1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // first two half-batches staged (tile prologue)
+        BRC_WAIT_REC(R0)
         BRC_PROBE(R0, 0u, S0)
         S1 = S0;
-        uint32_t hf = 0;
-        for (uint32_t base = lo; base < hi; base += (uint32_t)HALF, hf ^= 1u) {
+        uint32_t hoff = 0;                                                     // byte offset of the current ring half
+        uint32_t base = (c.variant == 6 || c.variant == 7) ? hi : lo;
+        for (; base < hi; base += (uint32_t)HALF, hoff ^= (uint32_t)HOFF_X) {
             const uint32_t nb = (hi - base) < (uint32_t)HALF ? (hi - base) : (uint32_t)HALF;
-            BRC_STEP(0, R0, R1, R2, S0, S1)
-            BRC_STEP(1, R1, R2, R0, S1, S0)
-            BRC_STEP(2, R2, R0, R1, S0, S1)
-            BRC_STEP(3, R0, R1, R2, S1, S0)
-            BRC_STEP(4, R1, R2, R0, S0, S1)
-            BRC_STEP(5, R2, R0, R1, S1, S0)
-            // ---- between half-batches
-            since_flush += (int32_t)nb;
-            if (__builtin_expect(qn != 0u, 0)) {
-                // drain in piece order; the event words of this half-batch are still staged in ring half hf
-                for (uint32_t e = 0; e < qn; ++e) {
-                    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane(queue[e].piece), kind = (uint32_t)__builtin_amdgcn_readfirstlane(queue[e].kind);
-                    // (readfirstlane returns int: without the casts a set bit 31 of the low half would sign-extend into the high half)
-                    const uint64_t mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(queue[e].mhi) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(queue[e].mlo);
-                    const PieceHot H = *reinterpret_cast<const PieceHot*>(hot4 + (size_t)m * 4u);
-                    const PieceCold CD = cold[m];
-                    if ((mask >> lane) & 1ull) {
-                        const int32_t s_c = p0 - H.a;
-                        const uint32_t off = (hf * (uint32_t)HALF + (m - base)) * (uint32_t)ROW_BYTES + 2u * ((uint32_t)s_c & 7u);
-                        const uint32_t w = (uint32_t)*reinterpret_cast<const uint16_t*>(rows_base + off + 2u * (uint32_t)lane);
-                        if (kind == 0u) drain_full(c, pl, lib, kk, a.mem, H, CD, lane + s_c, w);
-                        else drain_int(c, pl, lib, kk, a.mem, CD, w & 0xffu);
-                    }
-                }
-                qn = 0;
-            }
-            if (__builtin_expect(since_flush + HALF > c.flush_k, 0)) {
-                if (valid) lane2_flush(c, pl, lib, kk, a);
-                since_flush = 0;
-            }
-            // the ring half just processed is free (every LDS read of it has returned after the lgkmcnt wait): copy
-            // half-batch base + 2 HALF into it and request the addresses of the one after
-            if (base + 2u * (uint32_t)HALF < hi) {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                BRC_STAGE(T, base + 2u * (uint32_t)HALF, hf)
-                BRC_LD_TAB(T, base + 3u * (uint32_t)HALF)
-            }
+            if (c.variant == 5 && base != lo) continue;
+            BRC_STEP(0, R0, R1, R2, S0, S1, true)
+            BRC_STEP(1, R1, R2, R0, S1, S0, true)
+            BRC_STEP(2, R2, R0, R1, S0, S1, true)
+            BRC_STEP(3, R0, R1, R2, S1, S0, true)
+            BRC_STEP(4, R1, R2, R0, S0, S1, true)
+            BRC_STEP(5, R2, R0, R1, S1, S0, true)
+            BRC_BOUNDARY(nb)
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R0.f), "+s"(R0.g), "+s"(R1.f), "+s"(R1.g), "+s"(R2.f), "+s"(R2.g));   // no scalar load may outlive its registers
+        asm volatile("" :: "v"(pf));
+#undef BRC_BOUNDARY
 #undef BRC_STEP
 #undef BRC_ACC
 #undef BRC_PROBE
+#undef BRC_WAIT_REC
+#undef BRC_LD_DIV
 #undef BRC_LD_REC
 #undef BRC_STAGE
 #undef BRC_LD_TAB
     }
     // ---- end of the tile: registers -> planes (coalesced: lane == position), zeros for the untouched buckets
     const bool dead = c.per_lib && valid && unavail_ro[kk] != NONE32;
-    if (valid) {
+    if (valid && c.variant != 1) {
         const int64_t P = c.PS;
         pl.ncol[(int64_t)lib * P + k] = dead ? 0u : a.ncol;
         pl.depth[(int64_t)lib * P + k] = dead ? 0u : a.depth;
         uint32_t dv[NI], av[NI];
         pack_unpack(a.dom, dv); pack_unpack(a.alt, av);
+        a.w_sm += ((a.dom.sbq >> 14) & 63u) + ((a.alt.sbq >> 14) & 63u); a.w_nm += ((a.dom.sbq >> 20) & 63u) + ((a.alt.sbq >> 20) & 63u);
         const bool any_mem = __builtin_amdgcn_ballot_w64(a.mem != 0u) != 0ull;   // (uniform) some lane has live planes
+        const bool nt = c.variant == 9;
 #pragma unroll
         for (uint32_t b = 0; b < (uint32_t)NBUCKET; ++b) {
+            if (c.variant == 11 && b >= 3u) continue;                          // (profiling: half of the plane stores)
             uint32_t* ip = plane_i(c, pl, lib, b, k); float* fp = plane_f(c, pl, lib, b, k);
             const bool isd = !dead && a.dom_b == b, isa = !dead && a.alt_b == b;
             const bool live = any_mem && !dead && ((a.mem >> b) & 1u);
@@ -808,13 +854,13 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn i
             for (int f = 0; f < NI; ++f) {
                 uint32_t v = isd ? dv[f] : (isa ? av[f] : 0u);
                 if (any_mem) { if (live && !keep) v += ip[(int64_t)f * P]; if (keep) continue; }
-                ip[(int64_t)f * P] = v;
+                if (nt) __builtin_nontemporal_store(v, &ip[(int64_t)f * P]); else ip[(int64_t)f * P] = v;
             }
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 const float v = isd ? a.dom.f[f] : (isa ? a.alt.f[f] : 0.0f);
                 if (any_mem && keep) continue;
-                fp[(int64_t)f * P] = v;
+                if (nt) __builtin_nontemporal_store(v, &fp[(int64_t)f * P]); else fp[(int64_t)f * P] = v;
             }
         }
     }
@@ -1035,6 +1081,7 @@ class HipBackend : public Backend {
         // test knobs (tests/test_gpu_parity.py): small K -> flushes, small limit -> PF_HUGE, forced dominant bucket -> third alleles
         choose_pack(s.max_lqseq, getenv("BRC_FLUSH_K") ? atoi(getenv("BRC_FLUSH_K")) : 0, getenv("BRC_PACK_LIM") ? atoi(getenv("BRC_PACK_LIM")) : 0, c.flush_k, c.pack_lim);
         c.force_dom = getenv("BRC_FORCE_DOM") ? atoi(getenv("BRC_FORCE_DOM")) : -1;
+        c.variant = getenv("BRC_PILEUP_VARIANT") ? atoi(getenv("BRC_PILEUP_VARIANT")) : 0;
         const size_t n = (size_t)s.n;
         int rc;
         if ((rc = up(d_pos, s.pos, n)) || (rc = up(d_flag, s.flag, n)) || (rc = up(d_mapq, s.mapq, n)) || (rc = up(d_lib, s.lib, n)) ||

@@ -60,6 +60,7 @@ class SimBackend : public Backend {
             lane2_init(a[l], dom);
         }
         TermTab tt; tt.q = tq.data(); tt.e = te.data();
+        const uint32_t thr = piece_thr(c);
         struct QEnt { uint32_t piece; int kind; bool lane[TILE]; };    // kind 0: third-allele events, 1: integers of a huge piece
         std::vector<QEnt> queue;
         int since_flush = 0;
@@ -77,15 +78,14 @@ class SimBackend : public Backend {
                     if (!(d < (uint32_t)h.len)) continue;
                     const int qpos = p[l] - h.a;
                     const uint32_t w = bq[cd.bq_off + (uint64_t)qpos];
-                    if (w < h.thr) continue;                                                          // :288
+                    if (w < thr) continue;                                                            // :288
                     a[l].depth++;                                                                     // mapq_n (:312)
                     if (fl & PF_NB) continue;                                                         // :343 with -i
-                    a[l].w_sm += (fl & PF_SMW) ? 1u : 0u; a[l].w_nm += (fl & PF_NMW) ? 1u : 0u;
                     const EvTerms t = (fl & PF_TABLE) ? piece_terms_tab(h, tt, c.table_len, qpos) : piece_terms_div(h, qpos);
                     const uint32_t b = w & 0xffu, q = w >> 8;
                     if (b == a[l].dom_b) { pack_event(a[l].dom, h, t, q); if (fl & PF_HUGE) { ints.lane[l] = true; any_int = true; } }
                     else if (a[l].alt_b == NB_NONE || a[l].alt_b == b) { a[l].alt_b = b; pack_event(a[l].alt, h, t, q); if (fl & PF_HUGE) { ints.lane[l] = true; any_int = true; } }
-                    else { full.lane[l] = true; any_full = true; }
+                    else { full.lane[l] = true; any_full = true; a[l].w_sm += (fl & PF_SMW) ? 1u : 0u; a[l].w_nm += (fl & PF_NMW) ? 1u : 0u; }
                 }
                 if (any_full) queue.push_back(full);
                 if (any_int) queue.push_back(ints);

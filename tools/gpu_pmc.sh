@@ -24,6 +24,8 @@ for set in ${PMC_SETS:-sq1 sq2}; do
     sq1) run_pmc sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_LDS";;
     sq2) run_pmc sq2 "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM";;
     sq3) run_pmc sq3 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_BRANCH SQ_WAVES_EQ_64 SQ_INSTS_VSKIPPED SQ_INST_LEVEL_LDS";;
+    sqc) run_pmc sqc "SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_DCACHE_HITS SQC_DCACHE_MISSES SQ_IFETCH SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAVE_CYCLES";;
+    lvl) run_pmc lvl "SQ_INST_LEVEL_SMEM SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_SMEM SQ_BUSY_CYCLES";;
     fetch) run_pmc fetch "FETCH_SIZE";;
     write) run_pmc write "WRITE_SIZE";;
   esac
