@@ -7,13 +7,14 @@
 //
 // Work decomposition:
 //   K1  annotate_read     one lane per read      : fetch_func's five "Zm" integers + per-read constants
-//                                                   (reference bamreadcount.cpp:114-256)
+//                                                   (reference bamreadcount.cpp:114-256), then the read's PIECES
+//                                                   (walk_pieces: one per M/=/X segment)
 //   K1' enumerate_indels  one lane per read      : the (position, qpos, length) of every indel event the
 //                                                   pileup would see for this read (htslib resolve_cigar2 peek)
-//   KB  pileup_lane       one lane per position  : wave-uniform walk over the reads covering the lane's
-//                                                   64-position tile, in file order = pileup column order;
-//                                                   BasicStat::process_read per event into 6 register-resident
-//                                                   buckets (BasicStat.cpp:28-107, bamreadcount.cpp:276-348)
+//   KB  k_pileup2         one lane per position  : wave-uniform walk over the pieces covering the lane's 64-position
+//                                                   tile, in stream order = pileup column order; BasicStat::process_read
+//                                                   per event into two register-resident buckets with packed integers
+//                                                   (BasicStat.cpp:28-107, bamreadcount.cpp:276-348)
 //   KI  reduce_indel_key  one lane per (pos,lib) : ordered reduction of that key's indel events into
 //                                                   per-allele BasicStats (bamreadcount.cpp:315-342)
 #ifndef BRC_CORE_H
@@ -65,7 +66,7 @@ struct DevCfg {
     int32_t variant;        // 0 in production; >0 = profiling ablations selected by BRC_PILEUP_VARIANT (see brc_engine.hip)
     int32_t force_dom;      // test knob (BRC_FORCE_DOM): -1, or the bucket every lane treats as dominant (stresses the alternate / third-allele paths)
     int64_t n_pieces;       // pieces of all libraries (KB v2)
-    int32_t flush_k;        // K: pieces a lane may accumulate in its packed integer registers between two flushes (1..63: 6-bit warning counters)
+    int32_t flush_k;        // K: pieces a lane may accumulate in its packed integer registers between two flushes (1..127: 7-bit warning counters, 15-bit base-quality sum)
     uint32_t pack_lim;      // 65535 / K: largest per-read value a 16-bit packed field can take (PF_HUGE above it)
 };
 
@@ -129,12 +130,30 @@ struct IndelEv { uint32_t read; int32_t qpos; int32_t len; uint32_t key_lo; };
 // One reduced indel bucket.
 struct IndelOut { int32_t pos, lib, len; uint32_t rep_read; int32_t rep_qpos; uint32_t i[NI]; float f[NF]; };
 
+// Device result of KB, compact: a position keeps the BasicStats of TWO buckets per library — slot 0 = the bucket of its
+// reference base ("dominant"), slot 1 = the first other base seen ("alternate") — instead of all six (four of the six
+// are all-zero at practically every position: 116 instead of 320 bytes per position and library leave the GPU).  Events
+// of a third, fourth, ... base (sequencing errors: well under 1 % of the positions) are appended to a list as raw
+// addends and folded in by the host when it expands the slots to the ABI's dense planes (expand_slots, brc_host.cpp),
+// in list order = pileup-column order, so the fp32 sums stay bit-exact.
+struct XEv {                // one third-allele event (48 bytes)
+    uint32_t k;             // plane index of the position
+    uint32_t lib_b;         // library << 8 | bucket
+    uint32_t mapq, sse, zm, clip;
+    uint32_t qf;            // base quality | reverse << 8 | q2ok << 9
+    float fq2, fs3p, fsnm;
+    double sev;             // the event-location term, added through double (BasicStat.cpp:70)
+};
 struct Planes {
-    uint32_t* ncol;    // [Lp][PS]
-    uint32_t* depth;   // [Lp][PS]
-    uint32_t* istat;   // [Lp][6][9][PS]
-    float* fstat;      // [Lp][6][4][PS]
-    uint32_t* unavail; // [PS]
+    uint32_t* ncol;     // [Lp][PS]
+    uint32_t* depth;    // [Lp][PS]
+    uint32_t* slotid;   // [Lp][PS]  dominant bucket | alternate bucket << 8 (NB_NONE: slot 1 unused)
+    uint32_t* si;       // [Lp][2][9][PS]
+    float* sf;          // [Lp][2][4][PS]
+    uint32_t* unavail;  // [PS]
+    XEv* xev;           // third-allele events, appended with atomic cursor *xev_n; entries past xev_cap are dropped
+    uint32_t* xev_n;    // (the host sees *xev_n > xev_cap, grows the list and computes again)
+    uint32_t xev_cap;
 };
 
 // ---------------------------------------------------------------- small tables as packed constants
@@ -336,225 +355,19 @@ BRC_HD uint32_t absdiff_u(uint32_t a, uint32_t b) { return (a > b ? a : b) - (a 
 enum { TABLE_MAX = 512 };
 struct TermTab { const float* q; const double* e; };
 
-BRC_HD EvTerms event_terms_tab(const DRead& r, const TermTab& tt, int qpos) {
-    EvTerms t;
-    t.q2 = (r.misc & M_Q2OK) ? tt.q[absdiff_u((uint32_t)qpos, (uint32_t)r.q2)] : 0.0f;
-    t.s3p = tt.q[absdiff_u((uint32_t)qpos, (uint32_t)r.tp)];
-    t.sev = tt.e[absdiff_u(2u * (uint32_t)(qpos - r.left), (uint32_t)r.clipped)];
-    return t;
-}
+// ---------------------------------------------------------------- KB helpers
 
-BRC_HD EvTerms event_terms_fast(const DRead& r, const RcpPair& rc, int qpos) {
-    EvTerms t;
-    t.q2 = (r.misc & M_Q2OK) ? div_rcp((float)BRC_ABSDIFF(qpos, r.q2), rc.Lf, rc.rcpL) : 0.0f;
-    t.s3p = div_rcp((float)BRC_ABSDIFF(qpos, r.tp), rc.Lf, rc.rcpL);     // tp >= 0 whenever the read has a base
-    float d = (float)(qpos - r.left) - rc.center;
-    d = d < 0.0f ? -d : d;
-    t.sev = 1.0 - (double)div_rcp(d, rc.center, rc.rcpC);
-    return t;
-}
-
-// ---------------------------------------------------------------- htslib resolve_cigar2 as a pure function of (read, position)
-
-struct Ev { int qpos; int indel; bool in_col; bool is_del; };
-
-// Position p (absolute) against a general CIGAR.  Equivalent to the stateful cursor of htslib 1.10 sam.c
-// resolve_cigar2 for every position pos <= p < end visited in ascending order.
-// Written in uniform-control form: the loop, its trip count and every CIGAR load are the same for all lanes of a wave
-// (the read is wave-uniform), only the selects depend on the lane's p.  On the device this keeps the CIGAR reads on
-// the scalar unit (no per-lane early exit, no loads under divergent control flow).
-BRC_HD Ev resolve_cigar(const uint32_t* cig, uint32_t nc, int32_t pos, int32_t p) {
-    Ev e; e.qpos = 0; e.indel = 0; e.in_col = false; e.is_del = false;
-    int32_t x = pos; int y = 0;
-    for (uint32_t k = 0; k < nc; ++k) {
-        const uint32_t op = cig[k] & 0xfu; const int len = (int)(cig[k] >> 4);
-        if (is_refop(op)) {
-            // what a lane standing on the LAST base of this operator would peek (uniform)
-            int peek = 0;
-            if (k + 1 < nc) {
-                const uint32_t op2 = cig[k + 1] & 0xfu; const int l2 = (int)(cig[k + 1] >> 4);
-                if (op2 == CDEL) peek = -l2;
-                else if (op2 == CINS) peek = l2;
-                else if (op2 == CPAD && k + 2 < nc) {
-                    int l3 = 0;
-                    for (uint32_t kk = k + 2; kk < nc; ++kk) {
-                        const uint32_t o = cig[kk] & 0xfu;
-                        if (o == CINS) l3 += (int)(cig[kk] >> 4);
-                        else if (o == CDEL || o == CMATCH || o == CREF_SKIP || o == CEQUAL || o == CDIFF) break;
-                    }
-                    if (l3 > 0) peek = l3;
-                }
-            }
-            const bool here = !e.in_col && p >= x && p < x + len;       // per lane
-            const bool m = is_mop(op);
-            if (here) {
-                e.in_col = true;
-                e.is_del = !m;
-                e.qpos = m ? y + (p - x) : y;
-                e.indel = (p == x + len - 1) ? peek : 0;
-            }
-            x += len;
-            if (m) y += len;
-        } else if (op == CINS || op == CSOFT_CLIP) y += len;
-    }
-    return e;
-}
-
-// ---------------------------------------------------------------- KB: one lane = one reference position
-
-// Per-lane (= per reference position) accumulator state.  Only the hot set lives in registers:
-//   dom  bucket dom_b = the reference base of the position: ~99 % of a position's events
-//   alt  bucket alt_b = the first other base seen at the position (SNP allele / first sequencing error)
-// A third, fourth, ... distinct base at one position is rare; those events read-modify-write the output planes of
-// this position directly (overflow_event) and `mem` remembers which buckets already live there.  Every bucket lives
-// in exactly one place for the whole tile, so its events are still summed in pileup-column order: exactness does not
-// depend on how dom_b / alt_b happen to be chosen.  (6 x 12 register accumulators would cap the kernel at 3-4 waves
-// per SIMD; this layout needs 24.)
-struct LaneAcc {
-    uint32_t di[NACC_I]; float df[NF];      // dominant bucket
-    uint32_t xi[NACC_I]; float xf[NF];      // alternate bucket
-    uint32_t dom_b, alt_b;                  // bucket ids; alt_b == NB_NONE until assigned
-    uint32_t mem;                           // bit k: bucket k has been written to the planes by overflow_event
-    uint32_t ncol, depth, unavail;
-    uint32_t w_sm, w_nm;                    // process_read-level warning counts of this lane
-};
-enum { NB_NONE = 7 };
-
+enum { NB_NONE = 7 };      // "no alternate bucket yet"
 #if defined(__clang__)
 #define BRC_UNROLL _Pragma("unroll")
 #else
 #define BRC_UNROLL _Pragma("GCC unroll 16")
 #endif
 
-BRC_HD void lane_init(LaneAcc& a) {
-    BRC_UNROLL
-    for (int f = 0; f < NACC_I; ++f) { a.di[f] = 0; a.xi[f] = 0; }
-    BRC_UNROLL
-    for (int f = 0; f < NF; ++f) { a.df[f] = 0.0f; a.xf[f] = 0.0f; }
-    a.dom_b = 1; a.alt_b = NB_NONE; a.mem = 0;
-    a.ncol = a.depth = 0; a.unavail = NONE32; a.w_sm = a.w_nm = 0;
-}
-
 // dominant bucket of position p: the bucket of its reference base ('A' when there is no reference)
 BRC_HD uint32_t dominant_bucket(const DevCfg& c, const DevIn& in, int64_t p) {
     if (!c.has_ref) return 1u;
     return canon_bucket(nt16_of_char(ref_at(c, in.ref, p)));
-}
-
-// One read against one lane, in two stages so the device loop can software-pipeline them (probe + issue the event
-// load for read r+1 while read r is being accumulated).  `rd` and everything derived only from it is wave-uniform on
-// the device (scalar registers); p / qpos / the event word are per lane.  lib_sel = library index + 1 of this wave.
-struct Probe { int qpos; int indel; bool want; };   // want: the lane needs bq[rd.bq_off + qpos]
-
-BRC_HD Probe lane_probe(const DevCfg& c, const DevIn& in, const DRead& rd, uint32_t ridx, uint32_t lib_sel,
-                        int32_t p, bool lane_valid, LaneAcc& a) {
-    Probe pr; pr.qpos = p - rd.pos; pr.indel = 0; pr.want = false;
-    const uint32_t rlib = (rd.misc >> 16) & 0xffu;
-    // one subtract + one unsigned compare; false for reads dropped at push (end == pos)
-    const bool covered = lane_valid && (uint32_t)(p - rd.pos) < (uint32_t)(rd.end - rd.pos);
-    if (c.per_lib) {                                                    // (uniform)
-        if (rlib == 0) {                                                // library unavailable (:281-284)
-            if (covered && a.unavail == NONE32) a.unavail = ridx;
-            return pr;
-        }
-        if (rlib != lib_sel) return pr;                                 // another library's wave handles it
-    }
-    bool in_col = covered, is_del = false;
-    if (rd.misc & M_CLIPM) pr.qpos += rd.left;                          // [S] M [S]: the query offset of the leading clip
-    else if (!(rd.misc & M_SIMPLE)) {                                   // general CIGAR (uniform, uncommon)
-        const Ev e = resolve_cigar(in.cigar + rd.cig_off, rd.n_cigar, rd.pos, p);   // uniform control: all lanes
-        in_col = covered && e.in_col; pr.qpos = e.qpos; is_del = e.is_del; pr.indel = e.indel;
-    }
-    a.ncol += in_col ? 1u : 0u;                                         // lib_counts[library] created (:286)
-    pr.want = in_col && !is_del && (int)((rd.misc >> 8) & 0xffu) >= c.min_mapq && !(rd.misc & M_NOCOUNT);   // :288, :295-310
-    return pr;
-}
-
-// where a lane's planes live (wave-uniform except k)
-struct LaneOut { Planes pl; int lib; int64_t k; };
-
-// Third-or-later distinct base at this position: accumulate straight into the output planes (read-modify-write; the
-// lane owns its position, so no atomics).  First touch of a bucket starts from zero instead of reading the planes.
-BRC_HD void overflow_event(const DevCfg& c, const LaneOut& o, LaneAcc& a, uint32_t b, const DRead& rd, const EvTerms& t, uint32_t q) {
-    const int64_t P = c.PS;
-    uint32_t* ip = o.pl.istat + (((int64_t)o.lib * NBUCKET + b) * NI) * P + o.k;
-    float* fp = o.pl.fstat + (((int64_t)o.lib * NBUCKET + b) * NF) * P + o.k;
-    uint32_t ai[NACC_I]; float af[NF];
-    const bool fresh = !((a.mem >> b) & 1u);
-    ai[A_SMQ] = fresh ? 0u : ip[I_SMQ * P]; ai[A_SSE] = fresh ? 0u : ip[I_SSE * P]; ai[A_PLUS] = fresh ? 0u : ip[I_PLUS * P];
-    ai[A_MINUS] = fresh ? 0u : ip[I_MINUS * P]; ai[A_NQ2] = fresh ? 0u : ip[I_NQ2 * P]; ai[A_SMMQ] = fresh ? 0u : ip[I_SMMQ * P];
-    ai[A_SCLIP] = fresh ? 0u : ip[I_SCLIP * P]; ai[A_SBQ] = fresh ? 0u : ip[I_SBQ * P];
-    BRC_UNROLL
-    for (int f = 0; f < NF; ++f) af[f] = fresh ? 0.0f : fp[f * P];
-    acc_apply(ai, af, rd, t, q, false);
-    ip[I_N * P] = ai[A_PLUS] + ai[A_MINUS]; ip[I_SMQ * P] = ai[A_SMQ]; ip[I_SSE * P] = ai[A_SSE]; ip[I_PLUS * P] = ai[A_PLUS];
-    ip[I_MINUS * P] = ai[A_MINUS]; ip[I_NQ2 * P] = ai[A_NQ2]; ip[I_SMMQ * P] = ai[A_SMMQ]; ip[I_SCLIP * P] = ai[A_SCLIP];
-    ip[I_SBQ * P] = ai[A_SBQ];
-    BRC_UNROLL
-    for (int f = 0; f < NF; ++f) fp[f * P] = af[f];
-    a.mem |= 1u << b;
-}
-
-// Flat control flow on purpose: the lane conditions are combined into one predicate, the event terms are computed for
-// every lane, and there is a single predicated region for the dominant-bucket adds plus one (usually skipped) region
-// for everything else.  Each extra divergent `if` costs three scalar instructions (save / branch / restore exec) and a
-// dependency stall per wave-iteration, and this kernel runs at the issue-slot limit.
-BRC_HD void lane_accumulate(const DevCfg& c, const DRead& rd, const RcpPair& rc, const TermTab& tt, const Probe& pr, uint32_t bqv, const LaneOut& o, LaneAcc& a) {
-    const uint32_t q = bqv >> 8, b = bqv & 0xffu;
-    const bool dep = pr.want && (int)q >= c.min_bq;                     // :288
-    a.depth += dep ? 1u : 0u;                                           // mapq_n (:312)
-    const bool pass = dep && (pr.indel < 1 || !c.insertion_centric);    // :343
-    if (rd.misc & M_SMW) a.w_sm += pass ? 1u : 0u;                      // (uniform conditions)
-    if (rd.misc & M_NMW) a.w_nm += pass ? 1u : 0u;
-    // whenever a lane has an event the read has l_qseq >= 1 and clipped_length >= 1: reciprocals are finite; lanes
-    // without an event compute garbage that is never added
-    const EvTerms t = (rd.misc & M_FAST) ? event_terms_tab(rd, tt, pass ? pr.qpos : 0) : event_terms_fast(rd, rc, pr.qpos);   // (uniform)
-    // Independent single-predecessor blocks only (no if/else chain, no switch): LLVM would otherwise sink the arms'
-    // common tail into one block addressed through a phi of pointers, which defeats scalar replacement of the
-    // accumulators and sends them to scratch memory.
-    const bool isd = pass && b == a.dom_b;
-    if (isd) acc_apply(a.di, a.df, rd, t, q, false);
-    if (pass && !isd) {
-        const bool take_alt = a.alt_b == NB_NONE || a.alt_b == b;
-        if (take_alt) { a.alt_b = b; acc_apply(a.xi, a.xf, rd, t, q, false); }
-        if (!take_alt) overflow_event(c, o, a, b, rd, t, q);
-    }
-}
-
-// unpipelined form (simulator, reference for the pipelined device loop)
-BRC_HD void lane_visit_read(const DevCfg& c, const DevIn& in, const DRead& rd, uint32_t ridx, uint32_t lib_sel,
-                            int32_t p, bool lane_valid, const TermTab& tt, const LaneOut& o, LaneAcc& a) {
-    const Probe pr = lane_probe(c, in, rd, ridx, lib_sel, p, lane_valid, a);
-    const uint32_t bqv = pr.want ? in.bq[rd.bq_off + (uint64_t)pr.qpos] : 0u;
-    lane_accumulate(c, rd, in.rcp[ridx], tt, pr, bqv, o, a);
-}
-
-// Write one lane's accumulators to the position-major planes (coalesced across the wave: lane == position).  Buckets
-// that overflow_event already wrote stay as they are; the rest are the dominant / alternate registers or zero.
-BRC_HD void lane_store(const DevCfg& c, const LaneOut& o, const LaneAcc& a) {
-    const int64_t P = c.PS;                                              // plane stride
-    const Planes& pl = o.pl; const int lib = o.lib; const int64_t k = o.k;
-    const bool dead = c.per_lib && a.unavail != NONE32;                 // position abandoned: report nothing
-    pl.ncol[(int64_t)lib * P + k] = dead ? 0u : a.ncol;
-    pl.depth[(int64_t)lib * P + k] = dead ? 0u : a.depth;
-    if (c.per_lib && lib == 0) pl.unavail[k] = a.unavail;
-    BRC_UNROLL
-    for (int b = 0; b < NBUCKET; ++b) {
-        uint32_t* ip = pl.istat + (((int64_t)lib * NBUCKET + b) * NI) * P + k;
-        float* fp = pl.fstat + (((int64_t)lib * NBUCKET + b) * NF) * P + k;
-        const bool isdom = !dead && a.dom_b == (uint32_t)b, isalt = !dead && a.alt_b == (uint32_t)b;
-        if (!dead && !isdom && !isalt && ((a.mem >> b) & 1u)) continue;  // lives in the planes already
-        uint32_t s[NACC_I]; float g[NF];
-        BRC_UNROLL
-        for (int f = 0; f < NACC_I; ++f) s[f] = isdom ? a.di[f] : (isalt ? a.xi[f] : 0u);
-        BRC_UNROLL
-        for (int f = 0; f < NF; ++f) g[f] = isdom ? a.df[f] : (isalt ? a.xf[f] : 0.0f);
-        ip[I_N * P] = s[A_PLUS] + s[A_MINUS];
-        ip[I_SMQ * P] = s[A_SMQ]; ip[I_SSE * P] = s[A_SSE]; ip[I_PLUS * P] = s[A_PLUS]; ip[I_MINUS * P] = s[A_MINUS];
-        ip[I_NQ2 * P] = s[A_NQ2]; ip[I_SMMQ * P] = s[A_SMMQ]; ip[I_SCLIP * P] = s[A_SCLIP]; ip[I_SBQ * P] = s[A_SBQ];
-        BRC_UNROLL
-        for (int f = 0; f < NF; ++f) fp[f * P] = g[f];
-    }
 }
 
 // ================================================================ KB v2: pieces
@@ -588,7 +401,7 @@ struct alignas(64) PieceHot {
     uint32_t tp_flags;     // bits 0-23: three_prime_index * 4 (byte offset into the float quotient table); 24-31: PF_*
     uint32_t w1, w2, w3;   // packed integer addends: 1 | rev << 10 | q2ok << 20;  mapq | sse << 16;  zm_sum | clipped << 16
     float snm;             // NM / (float)clipped_length, 0 when NM is missing
-    uint32_t ws;           // rides on the base-quality sum: SM-missing << 14 | NM-missing << 20 (process_read warnings, BasicStat.cpp:85,100)
+    uint32_t ws;           // rides on the base-quality sum: SM-missing << 15 | NM-missing << 22 (process_read warnings, BasicStat.cpp:85,100)
     float rcpL, Lf, rcpC, center;   // exact-division constants
     int32_t left, q2;
 };
@@ -694,7 +507,7 @@ BRC_HD void make_piece(const DevCfg& c, const ReadConst& r, int32_t rs, int32_t 
     h.w2 = r.mapq | (huge ? 0u : (r.sse << 16));
     h.w3 = huge ? 0u : (r.zm | ((uint32_t)r.clipped << 16));
     h.snm = r.snm;
-    h.ws = ((fl & PF_SMW) ? (1u << 14) : 0u) | ((fl & PF_NMW) ? (1u << 20) : 0u);
+    h.ws = ((fl & PF_SMW) ? (1u << 15) : 0u) | ((fl & PF_NMW) ? (1u << 22) : 0u);
     h.Lf = (float)r.l_qseq; h.center = (float)r.clipped * 0.5f; h.rcpL = 1.0f / h.Lf; h.rcpC = 1.0f / h.center;
     h.left = r.left; h.q2 = r.q2;
     cold.bq_off = r.bq_off; cold.a = h.a; cold.read = r.read; cold.zm_raw = r.zm; cold.sse_raw = r.sse; cold.mapq = r.mapq;
@@ -720,8 +533,8 @@ BRC_HD EvTerms piece_terms_tab(const PieceHot& h, const TermTab& tt, int table_l
     return t;
 }
 
-// One bucket of a lane between two flushes: three packed integer registers, the base-quality sum (bits 0-13, with the two
-// warning counters above it: bits 14-19 and 20-25; K <= 63 keeps every field inside its bits) and the four order-sensitive float sums.
+// One bucket of a lane between two flushes: three packed integer registers, the base-quality sum (bits 0-14, with the two
+// warning counters above it: bits 15-21 and 22-28; K <= 127 keeps every field inside its bits) and the four order-sensitive float sums.
 struct PackAcc { uint32_t w1, w2, w3, sbq; float f[NF]; };
 BRC_HD void pack_init(PackAcc& a) { a.w1 = a.w2 = a.w3 = a.sbq = 0; for (int f = 0; f < NF; ++f) a.f[f] = 0.0f; }
 BRC_HD void pack_event(PackAcc& a, const PieceHot& h, const EvTerms& t, uint32_t q) {
@@ -734,7 +547,7 @@ BRC_HD void pack_event(PackAcc& a, const PieceHot& h, const EvTerms& t, uint32_t
 BRC_HD void pack_unpack(const PackAcc& a, uint32_t* v) {
     const uint32_t n = a.w1 & 0x3ffu, minus = (a.w1 >> 10) & 0x3ffu;
     v[I_N] = n; v[I_SMQ] = a.w2 & 0xffffu; v[I_SSE] = a.w2 >> 16; v[I_PLUS] = n - minus; v[I_MINUS] = minus;
-    v[I_NQ2] = a.w1 >> 20; v[I_SMMQ] = a.w3 & 0xffffu; v[I_SCLIP] = a.w3 >> 16; v[I_SBQ] = a.sbq & 0x3fffu;
+    v[I_NQ2] = a.w1 >> 20; v[I_SMMQ] = a.w3 & 0xffffu; v[I_SCLIP] = a.w3 >> 16; v[I_SBQ] = a.sbq & 0x7fffu;
 }
 
 // K (pieces between two flushes of a lane's packed integers) and the per-read limit of a 16-bit field: clipped_length of
@@ -742,30 +555,28 @@ BRC_HD void pack_unpack(const PackAcc& a, uint32_t* v) {
 // (the overrides are test knobs: a small K exercises the flushes, a small limit the PF_HUGE path)
 BRC_HD void choose_pack(int32_t max_lqseq, int32_t k_override, int32_t lim_override, int32_t& K, uint32_t& lim) {
     int32_t m = max_lqseq < 255 ? 255 : max_lqseq;
-    K = 65535 / m; if (K > 63) K = 63; if (K < 1) K = 1;
+    K = 65535 / m; if (K > 127) K = 127; if (K < 1) K = 1;
     if (k_override > 0 && k_override < K) K = k_override;
     lim = 65535u / (uint32_t)K;
     if (lim_override >= 255 && (uint32_t)lim_override < lim) lim = (uint32_t)lim_override;    // >= 255: a mapping quality always fits
 }
 
-// Per-lane state of KB v2.  `mem` bit b: the planes of bucket b already hold partial sums of this position (an earlier
-// flush of the dominant / alternate registers, or drained events of a third allele) and must be added to, not overwritten.
+// Per-lane state of KB v2.
 enum { HALF = 6 };          // pieces per staging half-batch (6 rows x 9 chunks = 54 lanes of one direct-to-LDS instruction; a multiple of 3,
                             // the rotation period of the piece-record registers); queue drains and flushes happen between half-batches
 struct LaneAcc2 {
     PackAcc dom, alt;
-    uint32_t dom_b, alt_b, mem, ncol, depth, w_sm, w_nm;
+    uint32_t dom_b, alt_b, ncol, depth, w_sm, w_nm;
 };
 BRC_HD void lane2_init(LaneAcc2& a, uint32_t dom_b) {
-    pack_init(a.dom); pack_init(a.alt); a.dom_b = dom_b; a.alt_b = NB_NONE; a.mem = 0; a.ncol = a.depth = a.w_sm = a.w_nm = 0;
+    pack_init(a.dom); pack_init(a.alt); a.dom_b = dom_b; a.alt_b = NB_NONE; a.ncol = a.depth = a.w_sm = a.w_nm = 0;
 }
-BRC_HD uint32_t* plane_i(const DevCfg& c, const Planes& pl, int lib, uint32_t b, int64_t k) { return pl.istat + (((int64_t)lib * NBUCKET + b) * NI) * c.PS + k; }
-BRC_HD float* plane_f(const DevCfg& c, const Planes& pl, int lib, uint32_t b, int64_t k) { return pl.fstat + (((int64_t)lib * NBUCKET + b) * NF) * c.PS + k; }
+BRC_HD uint32_t* slot_i(const DevCfg& c, const Planes& pl, int lib, uint32_t slot, int64_t k) { return pl.si + (((int64_t)lib * 2 + slot) * NI) * c.PS + k; }
+BRC_HD float* slot_f(const DevCfg& c, const Planes& pl, int lib, uint32_t slot, int64_t k) { return pl.sf + (((int64_t)lib * 2 + slot) * NF) * c.PS + k; }
 
-// The three functions below are the RARE paths of KB (a flush every K pieces, a drained event per few tiles).  They are
-// written as rolled loops over the plane index with the value picked by a select chain: slow, but a handful of live
-// registers — inlined into the read loop they must not raise its register peak (61 VGPRs = 8 waves / SIMD without them,
-// 100 with their unrolled forms).
+// The functions below are the RARE paths of KB (a flush every K pieces, a drained event per few tiles).  They are written
+// as rolled loops over the plane index with the value picked by a select chain: slow, but a handful of live registers —
+// inlined into the read loop they must not raise its register peak.
 #if defined(__clang__)
 #define BRC_NOUNROLL _Pragma("unroll 1")
 #else
@@ -775,76 +586,51 @@ BRC_HD uint32_t pack_field(const PackAcc& a, int f) {
     const uint32_t n = a.w1 & 0x3ffu, minus = (a.w1 >> 10) & 0x3ffu;
     uint32_t v = n;                                            // I_N
     v = f == I_SMQ ? (a.w2 & 0xffffu) : v; v = f == I_SSE ? (a.w2 >> 16) : v; v = f == I_PLUS ? n - minus : v; v = f == I_MINUS ? minus : v;
-    v = f == I_NQ2 ? (a.w1 >> 20) : v; v = f == I_SMMQ ? (a.w3 & 0xffffu) : v; v = f == I_SCLIP ? (a.w3 >> 16) : v; v = f == I_SBQ ? (a.sbq & 0x3fffu) : v;
+    v = f == I_NQ2 ? (a.w1 >> 20) : v; v = f == I_SMMQ ? (a.w3 & 0xffffu) : v; v = f == I_SCLIP ? (a.w3 >> 16) : v; v = f == I_SBQ ? (a.sbq & 0x7fffu) : v;
     return v;
 }
-// registers -> integer planes of one bucket (adds when the planes are live), registers reset
-BRC_HD void flush_bucket(const DevCfg& c, const Planes& pl, int lib, int64_t k, PackAcc& a, uint32_t b, uint32_t& mem, uint32_t& w_sm, uint32_t& w_nm) {
-    uint32_t* ip = plane_i(c, pl, lib, b, k);
-    w_sm += (a.sbq >> 14) & 63u; w_nm += (a.sbq >> 20) & 63u;
-    const bool live = (mem >> b) & 1u;
+// packed registers -> the integer planes of one slot (adds when the tile has flushed before), registers reset
+BRC_HD void flush_slot(const DevCfg& c, const Planes& pl, int lib, int64_t k, PackAcc& a, uint32_t slot, bool live, uint32_t& w_sm, uint32_t& w_nm) {
+    uint32_t* ip = slot_i(c, pl, lib, slot, k);
+    w_sm += (a.sbq >> 15) & 127u; w_nm += (a.sbq >> 22) & 127u;
     BRC_NOUNROLL
     for (int f = 0; f < NI; ++f) { const uint32_t v = pack_field(a, f); ip[(int64_t)f * c.PS] = v + (live ? ip[(int64_t)f * c.PS] : 0u); }
-    mem |= 1u << b;
     a.w1 = a.w2 = a.w3 = a.sbq = 0;
 }
-BRC_HD void lane2_flush(const DevCfg& c, const Planes& pl, int lib, int64_t k, LaneAcc2& a) {
-    flush_bucket(c, pl, lib, k, a.dom, a.dom_b, a.mem, a.w_sm, a.w_nm);
-    if (a.alt_b != NB_NONE) flush_bucket(c, pl, lib, k, a.alt, a.alt_b, a.mem, a.w_sm, a.w_nm);
+// `live`: the tile has flushed before (wave-uniform)
+BRC_HD void lane2_flush(const DevCfg& c, const Planes& pl, int lib, int64_t k, LaneAcc2& a, bool live) {
+    flush_slot(c, pl, lib, k, a.dom, 0u, live, a.w_sm, a.w_nm);
+    flush_slot(c, pl, lib, k, a.alt, 1u, live, a.w_sm, a.w_nm);
 }
-// one event of a third (fourth, ...) base at this position, straight into the planes; events of one bucket arrive in
-// column order because the queue is drained in piece order
-BRC_HD void drain_full(const DevCfg& c, const Planes& pl, int lib, int64_t k, uint32_t& mem, const PieceHot& h, const PieceCold& cold, int qpos, uint32_t word) {
-    const uint32_t b = word & 0xffu, q = word >> 8;
-    uint32_t* ip = plane_i(c, pl, lib, b, k); float* fp = plane_f(c, pl, lib, b, k);
-    const bool live = (mem >> b) & 1u;
+// one event of a third (fourth, ...) base at this position: its raw addends, for the list
+BRC_HD XEv make_xev(int lib, int64_t k, const PieceHot& h, const PieceCold& cold, int qpos, uint32_t word) {
+    XEv e;
     const uint32_t fl = piece_flags(h);
-    const uint32_t rev = (fl & PF_REV) ? 1u : 0u;
-    BRC_NOUNROLL
-    for (int f = 0; f < NI; ++f) {
-        uint32_t v = 1u;                                       // I_N
-        v = f == I_SMQ ? cold.mapq : v; v = f == I_SSE ? cold.sse_raw : v; v = f == I_PLUS ? 1u - rev : v; v = f == I_MINUS ? rev : v;
-        v = f == I_NQ2 ? ((fl & PF_Q2OK) ? 1u : 0u) : v; v = f == I_SMMQ ? cold.zm_raw : v; v = f == I_SCLIP ? (uint32_t)cold.clipped : v; v = f == I_SBQ ? q : v;
-        ip[(int64_t)f * c.PS] = v + (live ? ip[(int64_t)f * c.PS] : 0u);
-    }
     const EvTerms t = piece_terms_div(h, qpos);
-    BRC_NOUNROLL
-    for (int f = 0; f < NF; ++f) {
-        const float old = live ? fp[(int64_t)f * c.PS] : 0.0f;
-        float v = f == F_SQ2 ? t.q2 : (f == F_S3P ? t.s3p : h.snm);
-        float r = old + v;
-        if (f == F_SEV) r = (float)((double)old + t.sev);
-        fp[(int64_t)f * c.PS] = r;
-    }
-    mem |= 1u << b;
+    e.k = (uint32_t)k; e.lib_b = ((uint32_t)lib << 8) | (word & 0xffu);
+    e.mapq = cold.mapq; e.sse = cold.sse_raw; e.zm = cold.zm_raw; e.clip = (uint32_t)cold.clipped;
+    e.qf = (word >> 8) | ((fl & PF_REV) ? 0x100u : 0u) | ((fl & PF_Q2OK) ? 0x200u : 0u);
+    e.fq2 = t.q2; e.fs3p = t.s3p; e.fsnm = h.snm; e.sev = t.sev;
+    return e;
 }
-// the integers of a PF_HUGE piece that its packed addends left out, for a lane whose event went to bucket b (dominant or alternate)
-BRC_HD void drain_int(const DevCfg& c, const Planes& pl, int lib, int64_t k, uint32_t& mem, const PieceCold& cold, uint32_t b) {
-    uint32_t* ip = plane_i(c, pl, lib, b, k);
-    const bool live = (mem >> b) & 1u;
-    BRC_NOUNROLL
-    for (int f = 0; f < NI; ++f) {
-        const uint32_t v = f == I_SSE ? cold.sse_raw : (f == I_SMMQ ? cold.zm_raw : (f == I_SCLIP ? (uint32_t)cold.clipped : 0u));
-        ip[(int64_t)f * c.PS] = v + (live ? ip[(int64_t)f * c.PS] : 0u);
-    }
-    mem |= 1u << b;
+// the integers of a PF_HUGE piece that its packed addends left out, for a lane whose event went to `slot` (the slot planes
+// are live: the caller flushed)
+BRC_HD void drain_int(const DevCfg& c, const Planes& pl, int lib, int64_t k, const PieceCold& cold, uint32_t slot) {
+    uint32_t* ip = slot_i(c, pl, lib, slot, k);
+    ip[(int64_t)I_SSE * c.PS] += cold.sse_raw; ip[(int64_t)I_SMMQ * c.PS] += cold.zm_raw; ip[(int64_t)I_SCLIP * c.PS] += (uint32_t)cold.clipped;
 }
-// end of the tile: whatever is still in registers, and zeros for the untouched buckets
-BRC_HD void lane2_store(const DevCfg& c, const Planes& pl, int lib, int64_t k, LaneAcc2& a, bool dead) {
+// end of the tile (reference statement; the kernel stores the same values with coalesced selects)
+BRC_HD void lane2_store(const DevCfg& c, const Planes& pl, int lib, int64_t k, LaneAcc2& a, bool dead, bool live) {
     const int64_t P = c.PS;
     pl.ncol[(int64_t)lib * P + k] = dead ? 0u : a.ncol;
     pl.depth[(int64_t)lib * P + k] = dead ? 0u : a.depth;
-    for (uint32_t b = 0; b < NBUCKET; ++b) {
-        uint32_t* ip = plane_i(c, pl, lib, b, k); float* fp = plane_f(c, pl, lib, b, k);
-        const bool isdom = !dead && a.dom_b == b, isalt = !dead && a.alt_b == b;
-        if (isdom || isalt) {
-            PackAcc& r = isdom ? a.dom : a.alt;
-            for (int f = 0; f < NF; ++f) fp[(int64_t)f * P] = r.f[f];
-            flush_bucket(c, pl, lib, k, r, b, a.mem, a.w_sm, a.w_nm);
-        } else if (dead || !((a.mem >> b) & 1u)) {
-            for (int f = 0; f < NI; ++f) ip[(int64_t)f * P] = 0u;
-            for (int f = 0; f < NF; ++f) fp[(int64_t)f * P] = 0.0f;
-        }
+    pl.slotid[(int64_t)lib * P + k] = dead ? (1u | ((uint32_t)NB_NONE << 8)) : (a.dom_b | (a.alt_b << 8));
+    for (uint32_t sl = 0; sl < 2u; ++sl) {
+        PackAcc& r = sl ? a.alt : a.dom;
+        float* fp = slot_f(c, pl, lib, sl, k);
+        for (int f = 0; f < NF; ++f) fp[(int64_t)f * P] = dead ? 0.0f : r.f[f];
+        flush_slot(c, pl, lib, k, r, sl, live, a.w_sm, a.w_nm);
+        if (dead) { uint32_t* ip = slot_i(c, pl, lib, sl, k); for (int f = 0; f < NI; ++f) ip[(int64_t)f * P] = 0u; }
     }
 }
 

@@ -33,7 +33,7 @@ namespace brc {
 
 struct Counters {
     unsigned long long n_events, n_positions, w_sm, w_nm, w_lib;
-    unsigned int n_indel_slots, pad;
+    unsigned int n_indel_slots, n_xev;   // n_xev: third-allele events KB wanted to append (may exceed the list's capacity)
 };
 
 // ---------------------------------------------------------------- wave helpers (wave64)
@@ -571,7 +571,7 @@ struct PRec { u32x8 f; u32x2 g; };
 //    skipped one for everything else); lane conditions are 64-bit masks in scalar registers;
 //  * per bucket a lane holds three PACKED integer registers (counters 10 bits each; mapq | sse; zm | clipped), the
 //    base-quality sum with the two warning counters on top, and the four fp32 sums; the integers are flushed to the
-//    planes every K pieces (K = 63 for short reads) and at the end of the tile;
+//    planes every K pieces (K = 127 for short reads) and at the end of the tile;
 //  * third alleles (a lane keeps its reference base and the first other base in registers) and PF_HUGE integers are
 //    queued and drained into the planes between half-batches, in piece order.
 __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn in, const uint4* __restrict__ hot4, const PieceCold* __restrict__ cold,
@@ -607,13 +607,17 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn i
     const uint2 r2 = rng[(int64_t)lib * ntiles + tile];
     const uint32_t lo = __builtin_amdgcn_readfirstlane(r2.x), hi = __builtin_amdgcn_readfirstlane(r2.y);
     const int64_t k = tile * TILE + lane;
-    const bool valid = k < c.P;
+    const bool inreg = k < c.P;
+    const int64_t kk = inreg ? k : 0;
+    // a position abandoned for a library-less read (:281-284) accumulates nothing: it behaves like a lane outside the region
+    const bool dead = c.per_lib && inreg && unavail_ro[kk] != NONE32;
+    const bool valid = inreg && !dead;
     const int32_t p = (int32_t)(c.pos0 + k);
     const int32_t p0 = (int32_t)(c.pos0 + tile * TILE);                     // first position of the tile (scalar)
 
     LaneAcc2 a;
     lane2_init(a, c.force_dom >= 0 ? (uint32_t)c.force_dom : (valid ? dominant_bucket(c, in, p) : 1u));
-    const int64_t kk = valid ? k : 0;
+    bool flushed = false;                                                   // (scalar) the slot planes of this tile hold partial integer sums
 
     if (lo < hi && c.variant != 4) {            // (variant: profiling ablations, BRC_PILEUP_VARIANT — 4: no piece loop, 1: no plane stores, 5: one half-batch only)
         // lanes past the region's last position stand far left of every piece: no coverage test is ever true for them
@@ -769,19 +773,28 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn i
                         H.left = (int32_t)dB[0]; H.q2 = (int32_t)dB[1];                                                   \
                         CD.bq_off = 0; CD.a = H.a; CD.read = 0; CD.zm_raw = cd[0]; CD.sse_raw = cd[1]; CD.mapq = cd[2]; CD.clipped = (int32_t)cd[3]; \
                     }                                                                                                     \
-                    if ((mask >> lane) & 1ull) {                                                                          \
-                        const int32_t s_c = p0 - H.a;                                                                     \
-                        const uint32_t off = hoff + (m - base) * (uint32_t)ROW_BYTES + 2u * ((uint32_t)s_c & 7u);         \
-                        const uint32_t w = (uint32_t)*reinterpret_cast<const uint16_t*>(rows_base + off + 2u * (uint32_t)lane); \
-                        if (kind == 0u) drain_full(c, pl, lib, kk, a.mem, H, CD, lane + s_c, w);                          \
-                        else drain_int(c, pl, lib, kk, a.mem, CD, w & 0xffu);                                             \
+                    if (kind == 1u && !flushed) {              /* huge integers go straight to the slot planes: make them live */ \
+                        if (valid) lane2_flush(c, pl, lib, kk, a, false);                                                 \
+                        flushed = true; since_flush = 0;                                                                  \
                     }                                                                                                     \
+                    const bool mine = ((mask >> lane) & 1ull) != 0ull;                                                    \
+                    const int32_t s_c = p0 - H.a;                                                                         \
+                    const uint32_t off = hoff + (m - base) * (uint32_t)ROW_BYTES + 2u * ((uint32_t)s_c & 7u);             \
+                    const uint32_t w = (uint32_t)*reinterpret_cast<const uint16_t*>(rows_base + off + 2u * (uint32_t)lane); \
+                    if (kind == 0u) {                          /* third alleles: raw addends to the list, in piece order */ \
+                        uint32_t at0 = 0;                                                                                 \
+                        if (lane == 0) at0 = atomicAdd(pl.xev_n, (uint32_t)__builtin_popcountll(mask));                   \
+                        at0 = (uint32_t)__builtin_amdgcn_readfirstlane(at0);                                              \
+                        const uint64_t below = mask & ((1ull << lane) - 1ull);                                            \
+                        const uint32_t at = at0 + (uint32_t)__builtin_popcountll(below);                                  \
+                        if (mine && at < pl.xev_cap) pl.xev[at] = make_xev(lib, kk, H, CD, lane + s_c, w);                \
+                    } else if (mine) drain_int(c, pl, lib, kk, CD, (w & 0xffu) == a.dom_b ? 0u : 1u);                     \
                 }                                                                                                         \
                 qn = 0;                                                                                                   \
             }                                                                                                             \
             if (__builtin_expect(since_flush + HALF > c.flush_k, 0)) {                                                    \
-                if (valid) lane2_flush(c, pl, lib, kk, a);                                                                \
-                since_flush = 0;                                                                                          \
+                if (valid) lane2_flush(c, pl, lib, kk, a, flushed);                                                       \
+                flushed = true; since_flush = 0;                                                                          \
             }                                                                                                             \
             if (base + 2u * (uint32_t)HALF < hi) {                                                                        \
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                               \
@@ -832,41 +845,28 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn i
 #undef BRC_STAGE
 #undef BRC_LD_TAB
     }
-    // ---- end of the tile: registers -> planes (coalesced: lane == position), zeros for the untouched buckets
-    const bool dead = c.per_lib && valid && unavail_ro[kk] != NONE32;
-    if (valid && c.variant != 1) {
+    // ---- end of the tile: registers -> the two slots of every position (coalesced: lane == position)
+    if (inreg && c.variant != 1) {
         const int64_t P = c.PS;
-        pl.ncol[(int64_t)lib * P + k] = dead ? 0u : a.ncol;
-        pl.depth[(int64_t)lib * P + k] = dead ? 0u : a.depth;
+        pl.ncol[(int64_t)lib * P + k] = a.ncol;                            // (dead lanes accumulated nothing: zeros)
+        pl.depth[(int64_t)lib * P + k] = a.depth;
+        pl.slotid[(int64_t)lib * P + k] = a.dom_b | (a.alt_b << 8);
+        a.w_sm += ((a.dom.sbq >> 15) & 127u) + ((a.alt.sbq >> 15) & 127u); a.w_nm += ((a.dom.sbq >> 22) & 127u) + ((a.alt.sbq >> 22) & 127u);
         uint32_t dv[NI], av[NI];
         pack_unpack(a.dom, dv); pack_unpack(a.alt, av);
-        a.w_sm += ((a.dom.sbq >> 14) & 63u) + ((a.alt.sbq >> 14) & 63u); a.w_nm += ((a.dom.sbq >> 20) & 63u) + ((a.alt.sbq >> 20) & 63u);
-        const bool any_mem = __builtin_amdgcn_ballot_w64(a.mem != 0u) != 0ull;   // (uniform) some lane has live planes
-        const bool nt = c.variant == 9;
+        uint32_t* i0 = slot_i(c, pl, lib, 0u, k); uint32_t* i1 = slot_i(c, pl, lib, 1u, k);
+        float* f0 = slot_f(c, pl, lib, 0u, k); float* f1 = slot_f(c, pl, lib, 1u, k);
+        const bool add = flushed && !dead;                                 // (uniform but for dead lanes) earlier flushes of this tile
 #pragma unroll
-        for (uint32_t b = 0; b < (uint32_t)NBUCKET; ++b) {
-            if (c.variant == 11 && b >= 3u) continue;                          // (profiling: half of the plane stores)
-            uint32_t* ip = plane_i(c, pl, lib, b, k); float* fp = plane_f(c, pl, lib, b, k);
-            const bool isd = !dead && a.dom_b == b, isa = !dead && a.alt_b == b;
-            const bool live = any_mem && !dead && ((a.mem >> b) & 1u);
-            const bool keep = live && !isd && !isa;                            // a drained third allele: the planes are final
-#pragma unroll
-            for (int f = 0; f < NI; ++f) {
-                uint32_t v = isd ? dv[f] : (isa ? av[f] : 0u);
-                if (any_mem) { if (live && !keep) v += ip[(int64_t)f * P]; if (keep) continue; }
-                if (nt) __builtin_nontemporal_store(v, &ip[(int64_t)f * P]); else ip[(int64_t)f * P] = v;
-            }
-#pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                const float v = isd ? a.dom.f[f] : (isa ? a.alt.f[f] : 0.0f);
-                if (any_mem && keep) continue;
-                if (nt) __builtin_nontemporal_store(v, &fp[(int64_t)f * P]); else fp[(int64_t)f * P] = v;
-            }
+        for (int f = 0; f < NI; ++f) {
+            i0[(int64_t)f * P] = dv[f] + (add ? i0[(int64_t)f * P] : 0u);
+            i1[(int64_t)f * P] = av[f] + (add ? i1[(int64_t)f * P] : 0u);
         }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) { f0[(int64_t)f * P] = a.dom.f[f]; f1[(int64_t)f * P] = a.alt.f[f]; }
     }
-    const bool live = valid && !dead;
-    unsigned long long ev = (live && p >= c.beg0) ? a.ncol : 0u;
-    unsigned long long wsm = live ? a.w_sm : 0u, wnm = live ? a.w_nm : 0u, wl = (valid && dead && lib == 0) ? 1u : 0u;
+    unsigned long long ev = (valid && p >= c.beg0) ? a.ncol : 0u;
+    unsigned long long wsm = valid ? a.w_sm : 0u, wnm = valid ? a.w_nm : 0u, wl = (dead && lib == 0) ? 1u : 0u;
     ev = wave_sum_u64(ev); wsm = wave_sum_u64(wsm); wnm = wave_sum_u64(wnm); wl = wave_sum_u64(wl);
     // per-(tile, library) partials; k_finalize sums them (a single-address atomic per wave costs ~12 ns x 780 k waves)
     if (lane == 0) tile_ctr[(int64_t)lib * ntiles + tile] = make_uint4((uint32_t)ev, (uint32_t)wsm, (uint32_t)wnm, (uint32_t)wl);
@@ -1021,9 +1021,10 @@ class HipBackend : public Backend {
     std::vector<int64_t> lib_base;      // first piece of every library's stream (Lp + 1 entries)
     // device buffers
     DBuf d_pos, d_flag, d_mapq, d_lib, d_lq, d_nc, d_co, d_so, d_qo, d_nm, d_sm, d_tags, d_cigar, d_seq, d_qual, d_ref, d_refcode;
-    DBuf d_bq, d_bqrow, d_pieceoff, d_hot, d_cold, d_key, d_reach, d_reads, d_prefmax, d_agg, d_rng, d_ncol, d_depth, d_istat, d_fstat, d_unavail, d_cnt, d_cursor, d_ev, d_iout, d_ctr, d_tilectr, d_part;
+    DBuf d_bq, d_bqrow, d_pieceoff, d_hot, d_cold, d_key, d_reach, d_reads, d_prefmax, d_agg, d_rng, d_ncol, d_depth, d_slotid, d_si, d_sf, d_xev, d_unavail, d_cnt, d_cursor, d_ev, d_iout, d_ctr, d_tilectr, d_part;
     // host result buffers (pinned)
-    HBuf<uint32_t> h_ncol, h_depth, h_istat, h_unavail; HBuf<float> h_fstat; HBuf<IndelOut> h_iout;
+    HBuf<uint32_t> h_ncol, h_depth, h_slotid, h_si, h_unavail; HBuf<float> h_sf; HBuf<IndelOut> h_iout; HBuf<XEv> h_xev;
+    size_t xev_cap = 0;
     std::vector<IndelOut> iout_compact;
     Counters h_ctr;
     bool computed = false;
@@ -1045,16 +1046,16 @@ class HipBackend : public Backend {
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         for (int i = 0; i <= T_N; ++i) HIPCHK(hipEventCreate(&evt[i]));
         have_events = true;
-        h_ncol.A = h_depth.A = h_istat.A = h_unavail.A = &kPinned; h_fstat.A = &kPinned; h_iout.A = &kPinned;
+        h_ncol.A = h_depth.A = h_slotid.A = h_si.A = h_unavail.A = &kPinned; h_sf.A = &kPinned; h_iout.A = &kPinned; h_xev.A = &kPinned;
         return BRC_OK;
     }
     ~HipBackend() override {
         (void)hipSetDevice(device);
         DBuf* all[] = {&d_pos, &d_flag, &d_mapq, &d_lib, &d_lq, &d_nc, &d_co, &d_so, &d_qo, &d_nm, &d_sm, &d_tags, &d_cigar, &d_seq, &d_qual,
-                       &d_ref, &d_refcode, &d_bq, &d_bqrow, &d_pieceoff, &d_hot, &d_cold, &d_key, &d_reach, &d_reads, &d_prefmax, &d_agg, &d_rng, &d_ncol, &d_depth, &d_istat, &d_fstat, &d_unavail, &d_cnt,
+                       &d_ref, &d_refcode, &d_bq, &d_bqrow, &d_pieceoff, &d_hot, &d_cold, &d_key, &d_reach, &d_reads, &d_prefmax, &d_agg, &d_rng, &d_ncol, &d_depth, &d_slotid, &d_si, &d_sf, &d_xev, &d_unavail, &d_cnt,
                        &d_cursor, &d_ev, &d_iout, &d_ctr, &d_tilectr, &d_part};
         for (DBuf* b : all) b->release();
-        h_ncol.destroy(); h_depth.destroy(); h_istat.destroy(); h_unavail.destroy(); h_fstat.destroy(); h_iout.destroy();
+        h_ncol.destroy(); h_depth.destroy(); h_slotid.destroy(); h_si.destroy(); h_unavail.destroy(); h_sf.destroy(); h_iout.destroy(); h_xev.destroy();
         if (have_events) for (int i = 0; i <= T_N; ++i) (void)hipEventDestroy(evt[i]);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -1117,7 +1118,10 @@ class HipBackend : public Backend {
         HIPCHK(d_reads.ensure((n + 1) * sizeof(DRead))); HIPCHK(d_prefmax.ensure((np + 16) * 4));
         HIPCHK(d_agg.ensure(nagg * 4 + 16)); HIPCHK(d_rng.ensure(((size_t)ntiles * Lp + 1) * sizeof(uint2)));
         HIPCHK(d_ncol.ensure(Lp * P * 4 + 16)); HIPCHK(d_depth.ensure(Lp * P * 4 + 16)); HIPCHK(d_unavail.ensure(P * 4 + 16));
-        HIPCHK(d_istat.ensure(Lp * NBUCKET * NI * P * 4 + 16)); HIPCHK(d_fstat.ensure(Lp * NBUCKET * NF * P * 4 + 16));
+        HIPCHK(d_slotid.ensure(Lp * P * 4 + 16)); HIPCHK(d_si.ensure(Lp * 2 * NI * P * 4 + 16)); HIPCHK(d_sf.ensure(Lp * 2 * NF * P * 4 + 16));
+        if (xev_cap == 0) { const char* xc = getenv("BRC_XEV_CAP"); xev_cap = xc ? (size_t)atoi(xc) : (size_t)1 << 20; }   // (test knob: a tiny list exercises the grow-and-recompute path)
+        xev_cap = std::max(xev_cap, getenv("BRC_XEV_CAP") ? (size_t)1 : np / 16);
+        HIPCHK(d_xev.ensure((xev_cap + 1) * sizeof(XEv)));
         HIPCHK(d_part.ensure(4096 * 5 * sizeof(unsigned long long)));
         HIPCHK(d_ctr.ensure(sizeof(Counters))); HIPCHK(d_tilectr.ensure(((size_t)ntiles * Lp + 1) * sizeof(uint4)));
         if (n_indel_cap) {
@@ -1148,7 +1152,8 @@ class HipBackend : public Backend {
         HIPCHK(hipMemsetAsync(ctr, 0, sizeof(Counters), stream));
         const bool indels = n_indel_cap > 0 && P > 0 && n > 0;
         if (indels) HIPCHK(hipMemsetAsync(d_cnt.p, 0, (size_t)(Lp * P) * 4, stream));
-        Planes pl = {(uint32_t*)d_ncol.p, (uint32_t*)d_depth.p, (uint32_t*)d_istat.p, (float*)d_fstat.p, (uint32_t*)d_unavail.p};
+        Planes pl = {(uint32_t*)d_ncol.p, (uint32_t*)d_depth.p, (uint32_t*)d_slotid.p, (uint32_t*)d_si.p, (float*)d_sf.p, (uint32_t*)d_unavail.p,
+                     (XEv*)d_xev.p, &ctr->n_xev, (uint32_t)xev_cap};
         const DRead* reads = (const DRead*)d_reads.p;
         HIPCHK(hipEventRecord(evt[T_ANNOTATE], stream));
         if (n > 0) {
@@ -1207,6 +1212,11 @@ class HipBackend : public Backend {
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(&h_ctr, ctr, sizeof(Counters), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
+        if ((size_t)h_ctr.n_xev > xev_cap) {          // the third-allele list was too short: grow it and compute again
+            xev_cap = (size_t)h_ctr.n_xev * 2;
+            HIPCHK(d_xev.ensure((xev_cap + 1) * sizeof(XEv)));
+            return compute(t);
+        }
         if (t) {
             memset(t, 0, sizeof *t);
             for (int i = 0; i < T_N; ++i) HIPCHK(hipEventElapsedTime(&t->ms[i], evt[i], evt[i + 1]));
@@ -1227,15 +1237,18 @@ class HipBackend : public Backend {
         HIPCHK(hipSetDevice(device));
         if (!computed) { err = "not computed"; return BRC_E_ARG; }
         const size_t P = (size_t)c.PS, Lp = (size_t)c.Lp;   // planes are copied with their padded stride
-        if (!h_ncol.reserve(Lp * P + 4) || !h_depth.reserve(Lp * P + 4) || !h_unavail.reserve(P + 4) ||
-            !h_istat.reserve(Lp * NBUCKET * NI * P + 4) || !h_fstat.reserve(Lp * NBUCKET * NF * P + 4)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }
+        const size_t nx = h_ctr.n_xev;
+        if (!h_ncol.reserve(Lp * P + 4) || !h_depth.reserve(Lp * P + 4) || !h_slotid.reserve(Lp * P + 4) || !h_unavail.reserve(P + 4) ||
+            !h_si.reserve(Lp * 2 * NI * P + 4) || !h_sf.reserve(Lp * 2 * NF * P + 4) || !h_xev.reserve(nx + 4)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }
         if (P) {
             HIPCHK(hipMemcpyAsync(h_ncol.p, d_ncol.p, Lp * P * 4, hipMemcpyDeviceToHost, stream));
             HIPCHK(hipMemcpyAsync(h_depth.p, d_depth.p, Lp * P * 4, hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipMemcpyAsync(h_istat.p, d_istat.p, Lp * NBUCKET * NI * P * 4, hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipMemcpyAsync(h_fstat.p, d_fstat.p, Lp * NBUCKET * NF * P * 4, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(h_slotid.p, d_slotid.p, Lp * P * 4, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(h_si.p, d_si.p, Lp * 2 * NI * P * 4, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(h_sf.p, d_sf.p, Lp * 2 * NF * P * 4, hipMemcpyDeviceToHost, stream));
             if (c.per_lib) HIPCHK(hipMemcpyAsync(h_unavail.p, d_unavail.p, P * 4, hipMemcpyDeviceToHost, stream));
         }
+        if (nx) HIPCHK(hipMemcpyAsync(h_xev.p, d_xev.p, nx * sizeof(XEv), hipMemcpyDeviceToHost, stream));
         const size_t ns = h_ctr.n_indel_slots;
         if (ns) {
             if (!h_iout.reserve(ns + 4)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }
@@ -1244,7 +1257,8 @@ class HipBackend : public Backend {
         HIPCHK(hipStreamSynchronize(stream));
         iout_compact.clear();
         for (size_t i = 0; i < ns; ++i) if (h_iout.p[i].len != 0) iout_compact.push_back(h_iout.p[i]);
-        out->ncol = h_ncol.p; out->depth = h_depth.p; out->istat = h_istat.p; out->fstat = h_fstat.p; out->unavail = h_unavail.p;
+        out->ncol = h_ncol.p; out->depth = h_depth.p; out->slotid = h_slotid.p; out->si = h_si.p; out->sf = h_sf.p; out->unavail = h_unavail.p;
+        out->xev = h_xev.p; out->n_xev = nx;
         out->indel = iout_compact.data(); out->n_indel = (int64_t)iout_compact.size();
         out->n_events = h_ctr.n_events; out->n_positions = h_ctr.n_positions;
         out->warn[BRC_W_SM_MISSING] = h_ctr.w_sm; out->warn[BRC_W_NM_MISSING] = h_ctr.w_nm; out->warn[BRC_W_ZM_MISSING] = 0;

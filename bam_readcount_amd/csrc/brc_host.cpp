@@ -72,6 +72,60 @@ int fmt_f2(char* out, float v) {
     return n;
 }
 
+void expand_slots(const HostPlanes& hp, int Lp, int64_t P, int64_t PS, uint32_t* istat, float* fstat) {
+    const int64_t CH = 1 << 16;
+    const int64_t nch = (PS + CH - 1) / CH;
+    std::atomic<int64_t> next(0);
+    auto work = [&]() {
+        for (;;) {
+            const int64_t ci = next.fetch_add(1);
+            if (ci >= nch) break;
+            const int64_t k0 = ci * CH, k1 = std::min(PS, k0 + CH);
+            for (int l = 0; l < Lp; ++l) {
+                for (int b = 0; b < NBUCKET; ++b) {
+                    for (int f = 0; f < NI; ++f) memset(istat + (((int64_t)l * NBUCKET + b) * NI + f) * PS + k0, 0, (size_t)(k1 - k0) * 4);
+                    for (int f = 0; f < NF; ++f) memset(fstat + (((int64_t)l * NBUCKET + b) * NF + f) * PS + k0, 0, (size_t)(k1 - k0) * 4);
+                }
+                const uint32_t* sid = hp.slotid + (int64_t)l * PS;
+                for (int sl = 0; sl < 2; ++sl) {
+                    for (int f = 0; f < NI; ++f) {
+                        const uint32_t* src = hp.si + (((int64_t)l * 2 + sl) * NI + f) * PS;
+                        for (int64_t k = k0; k < std::min(P, k1); ++k) {
+                            const uint32_t b = (sid[k] >> (8 * sl)) & 0xffu;
+                            if (b < (uint32_t)NBUCKET && src[k]) istat[(((int64_t)l * NBUCKET + b) * NI + f) * PS + k] = src[k];
+                        }
+                    }
+                    for (int f = 0; f < NF; ++f) {
+                        const float* src = hp.sf + (((int64_t)l * 2 + sl) * NF + f) * PS;
+                        for (int64_t k = k0; k < std::min(P, k1); ++k) {
+                            const uint32_t b = (sid[k] >> (8 * sl)) & 0xffu;
+                            if (b < (uint32_t)NBUCKET) fstat[(((int64_t)l * NBUCKET + b) * NF + f) * PS + k] = src[k];
+                        }
+                    }
+                }
+            }
+        }
+    };
+    unsigned nt = std::thread::hardware_concurrency(); if (nt > 32) nt = 32; if (nt < 1) nt = 1;
+    if (nch < (int64_t)nt) nt = (unsigned)nch;
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    // third-allele events, in list order (= pileup-column order of every bucket they touch)
+    for (uint64_t i = 0; i < hp.n_xev; ++i) {
+        const XEv& e = hp.xev[i];
+        const int64_t l = e.lib_b >> 8; const uint32_t b = e.lib_b & 0xffu; const int64_t k = e.k;
+        if (l >= Lp || b >= (uint32_t)NBUCKET || k >= P) continue;
+        uint32_t* ip = istat + ((l * NBUCKET + b) * NI) * PS + k; float* fp = fstat + ((l * NBUCKET + b) * NF) * PS + k;
+        const uint32_t rev = (e.qf >> 8) & 1u;
+        ip[I_N * PS] += 1u; ip[I_SMQ * PS] += e.mapq; ip[I_SSE * PS] += e.sse; ip[I_PLUS * PS] += 1u - rev; ip[I_MINUS * PS] += rev;
+        ip[I_NQ2 * PS] += (e.qf >> 9) & 1u; ip[I_SMMQ * PS] += e.zm; ip[I_SCLIP * PS] += e.clip; ip[I_SBQ * PS] += e.qf & 0xffu;
+        fp[F_SQ2 * PS] += e.fq2; fp[F_S3P * PS] += e.fs3p; fp[F_SNM * PS] += e.fsnm;
+        fp[F_SEV * PS] = (float)((double)fp[F_SEV * PS] + e.sev);
+    }
+}
+
 static const char kZeroStat[] = "0:0.00:0.00:0.00:0:0:0.00:0.00:0.00:0:0.00:0.00:0.00";
 
 // operator<<(ostream&, BasicStat) (BasicStat.cpp:110-159)
@@ -116,8 +170,9 @@ struct brc_engine {
     int64_t accepted = 0, n_ext = 0; int32_t last_acc_pos = 0; int32_t last_pos = 0;
     bool heap_built = false;
     std::priority_queue<int32_t, std::vector<int32_t>, std::greater<int32_t> > live_ends;
-    // fetched result
+    // fetched result: compact planes from the backend, expanded to the ABI's dense planes
     HostPlanes hp;
+    uint32_t* dense_i = nullptr; float* dense_f = nullptr; size_t dense_cap = 0;
     std::vector<brc_indel> indels;
     std::string alleles;
     std::vector<char> refbase;
@@ -168,6 +223,7 @@ void brc_destroy(brc_engine* e) {
     if (!e) return;
     e->st.destroy();
     delete e->be;
+    free(e->dense_i); free(e->dense_f);
     delete e;
 }
 
@@ -348,7 +404,16 @@ int brc_fetch_result(brc_engine* e, brc_result* out) {
     }
     memset(out, 0, sizeof *out);
     out->tid = g.tid; out->beg0 = g.beg0; out->end = g.end; out->pos0 = g.pos0; out->n_pos = g.P; out->stride = g.PS; out->n_lib = g.Lp;
-    out->ncol = hp.ncol; out->depth = hp.depth; out->istat = hp.istat; out->fstat = hp.fstat;
+    {
+        const size_t need = (size_t)g.Lp * NBUCKET * (size_t)g.PS + 16;
+        if (need > e->dense_cap) {
+            free(e->dense_i); free(e->dense_f);
+            e->dense_i = (uint32_t*)malloc(need * NI * 4); e->dense_f = (float*)malloc(need * NF * 4); e->dense_cap = need;
+            if (!e->dense_i || !e->dense_f) { e->dense_cap = 0; return fail(e, BRC_E_NOMEM, "host allocation of the dense planes failed"); }
+        }
+        expand_slots(hp, g.Lp, g.P, g.PS, e->dense_i, e->dense_f);
+    }
+    out->ncol = hp.ncol; out->depth = hp.depth; out->istat = e->dense_i; out->fstat = e->dense_f;
     out->unavail = e->cfg.per_lib ? hp.unavail : NULL;
     out->refbase = e->refbase.data();
     out->n_indel = (int64_t)e->indels.size(); out->indel = e->indels.data();

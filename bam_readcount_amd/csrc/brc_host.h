@@ -82,10 +82,12 @@ struct Geometry {
     int64_t ref_lo = 0, ref_hi = 0;     // slice of the contig the device needs
 };
 
-// Host view of the device results after fetch.
+// Host view of the device results after fetch: the compact slot planes + third-allele events (struct Planes, brc_core.h);
+// brc_fetch_result expands them to the ABI's dense planes (expand_slots).
 struct HostPlanes {
-    uint32_t *ncol = nullptr, *depth = nullptr, *istat = nullptr, *unavail = nullptr;
-    float* fstat = nullptr;
+    uint32_t *ncol = nullptr, *depth = nullptr, *slotid = nullptr, *si = nullptr, *unavail = nullptr;
+    float* sf = nullptr;
+    const XEv* xev = nullptr; uint64_t n_xev = 0;
     const IndelOut* indel = nullptr; int64_t n_indel = 0;
     uint64_t n_events = 0, n_positions = 0;
     uint64_t warn[BRC_N_WARN] = {0, 0, 0, 0};
@@ -106,6 +108,9 @@ class Backend {
 Backend* make_backend(const brc_config& cfg, int* err);
 const char* backend_kind();
 const char* backend_kernel_name(int k);
+
+// slot planes + event list -> dense planes istat[Lp][6][9][PS], fstat[Lp][6][4][PS] (every element written); multi-threaded
+void expand_slots(const HostPlanes& hp, int Lp, int64_t P, int64_t PS, uint32_t* istat, float* fstat);
 
 // exact "%.2f" of a float (== iostream fixed/setprecision(2), BasicStat.cpp:116); returns bytes written
 int fmt_f2(char* out, float v);

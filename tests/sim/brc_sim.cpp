@@ -24,7 +24,7 @@ class SimBackend : public Backend {
     const Staged* st = nullptr;
     std::vector<DRead> reads; std::vector<uint16_t> bq; size_t bq_n = 0; std::vector<float> tq; std::vector<double> te;
     std::vector<PieceHot> hot; std::vector<PieceCold> cold; std::vector<int32_t> key, reach, prefmax;
-    std::vector<uint32_t> ncol, depth, istat, unavail; std::vector<float> fstat;
+    std::vector<uint32_t> ncol, depth, slotid, si, unavail; std::vector<float> sf; std::vector<XEv> xev; uint32_t xev_n = 0;
     std::vector<IndelOut> iout;
     uint64_t n_events = 0, n_positions = 0, warn[BRC_N_WARN] = {0, 0, 0, 0};
 
@@ -52,9 +52,11 @@ class SimBackend : public Backend {
 
     // one (tile, library) wave of KB
     void pileup_tile(const Planes& pl, int lib, int64_t tl, uint32_t lo, uint32_t hi) {
-        LaneAcc2 a[TILE]; bool valid[TILE]; int32_t p[TILE]; int64_t kk[TILE];
+        LaneAcc2 a[TILE]; bool valid[TILE], inreg[TILE]; int32_t p[TILE]; int64_t kk[TILE];
         for (int l = 0; l < TILE; ++l) {
-            kk[l] = tl * TILE + l; valid[l] = kk[l] < c.P; p[l] = (int32_t)(c.pos0 + kk[l]);
+            kk[l] = tl * TILE + l; inreg[l] = kk[l] < c.P; p[l] = (int32_t)(c.pos0 + kk[l]);
+            // a position abandoned for a library-less read (:281-284) accumulates nothing: it behaves like a lane outside the region
+            valid[l] = inreg[l] && !(c.per_lib && unavail[(size_t)kk[l]] != NONE32);
             uint32_t dom = valid[l] ? dominant_bucket(c, in, p[l]) : 1u;
             if (c.force_dom >= 0) dom = (uint32_t)c.force_dom;
             lane2_init(a[l], dom);
@@ -63,7 +65,7 @@ class SimBackend : public Backend {
         const uint32_t thr = piece_thr(c);
         struct QEnt { uint32_t piece; int kind; bool lane[TILE]; };    // kind 0: third-allele events, 1: integers of a huge piece
         std::vector<QEnt> queue;
-        int since_flush = 0;
+        int since_flush = 0; bool flushed = false;
         for (uint32_t base = lo; base < hi; base += HALF) {
             const uint32_t nb = hi - base < (uint32_t)HALF ? hi - base : (uint32_t)HALF;
             for (uint32_t m = base; m < base + nb; ++m) {
@@ -95,24 +97,28 @@ class SimBackend : public Backend {
             // packed fields could overflow during the next half-batch
             for (const QEnt& e : queue) {
                 const PieceHot& h = hot[e.piece]; const PieceCold& cd = cold[e.piece];
+                if (e.kind == 1 && !flushed) {                                                        // huge integers go straight to the slot planes: make them live
+                    for (int l = 0; l < TILE; ++l) if (valid[l]) lane2_flush(c, pl, lib, kk[l], a[l], false);
+                    flushed = true; since_flush = 0;
+                }
                 for (int l = 0; l < TILE; ++l) {
                     if (!e.lane[l]) continue;
                     const int qpos = p[l] - h.a;
                     const uint32_t w = bq[cd.bq_off + (uint64_t)qpos];
-                    if (e.kind == 0) drain_full(c, pl, lib, kk[l], a[l].mem, h, cd, qpos, w);
-                    else drain_int(c, pl, lib, kk[l], a[l].mem, cd, w & 0xffu);
+                    if (e.kind == 0) { const XEv x = make_xev(lib, kk[l], h, cd, qpos, w); const uint32_t at = (*pl.xev_n)++; if (at < pl.xev_cap) pl.xev[at] = x; }
+                    else drain_int(c, pl, lib, kk[l], cd, (w & 0xffu) == a[l].dom_b ? 0u : 1u);
                 }
             }
             queue.clear();
             if (since_flush + HALF > c.flush_k) {
-                for (int l = 0; l < TILE; ++l) if (valid[l]) lane2_flush(c, pl, lib, kk[l], a[l]);
-                since_flush = 0;
+                for (int l = 0; l < TILE; ++l) if (valid[l]) lane2_flush(c, pl, lib, kk[l], a[l], flushed);
+                flushed = true; since_flush = 0;
             }
         }
         for (int l = 0; l < TILE; ++l) {
-            if (!valid[l]) continue;
-            const bool dead = c.per_lib && unavail[(size_t)kk[l]] != NONE32;
-            lane2_store(c, pl, lib, kk[l], a[l], dead);
+            if (!inreg[l]) continue;
+            const bool dead = !valid[l];
+            lane2_store(c, pl, lib, kk[l], a[l], dead, flushed && !dead);
             if (!dead) { warn[BRC_W_SM_MISSING] += a[l].w_sm; warn[BRC_W_NM_MISSING] += a[l].w_nm; if (p[l] >= c.beg0) n_events += a[l].ncol; }
             if (dead && lib == 0) warn[BRC_W_LIB_UNAVAILABLE]++;
         }
@@ -140,9 +146,13 @@ class SimBackend : public Backend {
             });
             if (cnt != st->piece_cnt.p[i]) { err = "piece count of the host and of K1 differ"; return BRC_E_ARG; }
         }
-        ncol.assign((size_t)(Lp * PS), 0); depth.assign((size_t)(Lp * PS), 0);
-        istat.assign((size_t)(Lp * NBUCKET * NI * PS), 0xdeadbeefu); fstat.assign((size_t)(Lp * NBUCKET * NF * PS), -1.0f);   // KB must write every plane element
-        Planes pl = {ncol.data(), depth.data(), istat.data(), fstat.data(), unavail.data()};
+        ncol.assign((size_t)(Lp * PS), 0); depth.assign((size_t)(Lp * PS), 0); slotid.assign((size_t)(Lp * PS), 0xdeadbeefu);
+        si.assign((size_t)(Lp * 2 * NI * PS), 0xdeadbeefu); sf.assign((size_t)(Lp * 2 * NF * PS), -1.0f);   // KB must write every plane element
+        const char* xc = getenv("BRC_XEV_CAP");                                                            // (test knob: a tiny list exercises the grow-and-recompute path)
+        if (xev.empty()) xev.resize(xc ? (size_t)atoi(xc) : 1024);
+      again:
+        xev_n = 0;
+        Planes pl = {ncol.data(), depth.data(), slotid.data(), si.data(), sf.data(), unavail.data(), xev.data(), &xev_n, (uint32_t)xev.size()};
         n_events = n_positions = 0; memset(warn, 0, sizeof warn);
         const int64_t ntiles = (P + TILE - 1) / TILE;
         for (int l = 0; l < Lp; ++l) {
@@ -154,6 +164,7 @@ class SimBackend : public Backend {
                 pileup_tile(pl, l, tl, lo, hi);
             }
         }
+        if (xev_n > xev.size()) { xev.resize((size_t)xev_n * 2); goto again; }                                 // the list was too short: grow, compute again
         for (int64_t k = 0; k < P; ++k) {
             if (c.pos0 + k < c.beg0) continue;
             uint32_t tot = 0; for (int l = 0; l < Lp; ++l) tot += ncol[(size_t)(l * PS + k)];
@@ -190,7 +201,8 @@ class SimBackend : public Backend {
         return BRC_OK;
     }
     int fetch(HostPlanes* out) override {
-        out->ncol = ncol.data(); out->depth = depth.data(); out->istat = istat.data(); out->fstat = fstat.data(); out->unavail = unavail.data();
+        out->ncol = ncol.data(); out->depth = depth.data(); out->slotid = slotid.data(); out->si = si.data(); out->sf = sf.data(); out->unavail = unavail.data();
+        out->xev = xev.data(); out->n_xev = xev_n;
         out->indel = iout.data(); out->n_indel = (int64_t)iout.size(); out->n_events = n_events; out->n_positions = n_positions;
         memcpy(out->warn, warn, sizeof warn);
         return BRC_OK;
