@@ -544,6 +544,16 @@ __device__ __forceinline__ void count_if(uint32_t& x, uint64_t mask) {
     asm("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(x) : "s"(mask) : "vcc");
 }
 
+__device__ __forceinline__ void fadd_v(float& acc, float x) { acc += x; }
+__device__ __forceinline__ void fadd_s(float& acc, float x) { acc += x; }
+// acc = (float)((double)acc + x)   (sum_event_location, BasicStat.cpp:70), in place: left to the compiler the sum is computed
+// into a temporary and copied back inside the exec region.  (The same treatment of the three plain float adds costs five
+// registers — their operands must then sit in registers of their own — and with them a wave per SIMD.)
+__device__ __forceinline__ void fadd_through_double(float& acc, double x) {
+    double t;
+    asm("v_cvt_f64_f32_e32 %1, %0\n\tv_add_f64 %1, %1, %2\n\tv_cvt_f32_f64_e32 %0, %1" : "+v"(acc), "=&v"(t) : "v"(x));
+}
+
 enum { PILEUP_WAVES = 4 };   // 256 threads: 4 consecutive tiles (256 positions) per workgroup
 enum { WIN_U4 = 9 };         // event-word window of a staged piece: 9 x 16 B = 72 elements >= 64 tile positions + 7 of alignment
 enum { ROW_BYTES = WIN_U4 * 16 };
@@ -553,8 +563,8 @@ static_assert(HALF % 3 == 0, "the piece-record registers rotate with period 3");
 
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-// dwords 0-9 of a PieceHot in scalar registers: f = {rs, a, len, ext, tp_flags, w1, w2, w3}, g = {snm, ws}
-struct PRec { u32x8 f; u32x2 g; };
+// dwords 0-8 of a PieceHot in scalar registers: f = {rs, a, len, ext, tp_flags, w1, w2, w3}, g = snm
+struct PRec { u32x8 f; uint32_t g; };
 
 // One wave = one (64-position tile, library); lane == position.  The wave walks the tile's pieces [lo, hi) of its library
 // in stream (= pileup column) order, in half-batches of HALF = 6:
@@ -569,9 +579,9 @@ struct PRec { u32x8 f; u32x2 g; };
 //  * one pipeline step = probe of piece j + 1 (coverage ballots, event word and table look-ups: LDS reads only) and
 //    accumulate of piece j (quality / bucket ballots, one exec region with the 10 adds of the dominant bucket, a usually
 //    skipped one for everything else); lane conditions are 64-bit masks in scalar registers;
-//  * per bucket a lane holds three PACKED integer registers (counters 10 bits each; mapq | sse; zm | clipped), the
-//    base-quality sum with the two warning counters on top, and the four fp32 sums; the integers are flushed to the
-//    planes every K pieces (K = 127 for short reads) and at the end of the tile;
+//  * per bucket a lane holds three PACKED integer registers (five 6-bit counters; mapq | sse; zm | clipped), the sum of
+//    its event words (= 256 x base-quality sum + count x bucket) and the four fp32 sums; the integers are flushed to the
+//    planes every K pieces (K = 63 for short reads) and at the end of the tile;
 //  * third alleles (a lane keeps its reference base and the first other base in registers) and PF_HUGE integers are
 //    queued and drained into the planes between half-batches, in piece order.
 __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn in, const uint4* __restrict__ hot4, const PieceCold* __restrict__ cold,
@@ -651,7 +661,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn i
             }                                                                                                             \
         }
         // scalar loads of the record at rp (issued HERE), and the wait that makes them usable
-#define BRC_LD_REC(R, rp) asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x20" : "=&s"(R.f), "=&s"(R.g) : "s"(rp));
+#define BRC_LD_REC(R, rp) asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x20" : "=&s"(R.f), "=&s"(R.g) : "s"(rp));
 #define BRC_WAIT_REC(R) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R.f), "+s"(R.g));
         // the division constants of piece m (dwords 10-15 of its record) by scalar loads, on demand: only pieces without PF_TABLE
 #define BRC_LD_DIV(H, R, m)                                                                                             \
@@ -673,10 +683,9 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn i
             S.m_cov = __builtin_amdgcn_ballot_w64(d < R.f[3]);   /* counted in the accumulate stage: a probe may run past the tile's last piece */ \
             S.m_in = __builtin_amdgcn_ballot_w64(d < R.f[2]);                                                             \
             const uint32_t off = (uint32_t)(roff) + 2u * ((uint32_t)S.s_c & 7u);                                          \
-            S.w = (uint32_t)*reinterpret_cast<const uint16_t*>(rows_base + off + 2u * (uint32_t)lane);                    \
-            const uint32_t qp4 = 4u * (uint32_t)lane + 4u * (uint32_t)S.s_c;                                              \
-            S.t = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds.q) + sad_u32(qp4, R.f[4] & 0xffffffu)); \
-            S.sev = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds.e) + sad_u32(qp4 << 2, L0 << 3));  \
+            S.w = (uint32_t)*reinterpret_cast<const uint16_t*>(rows_base + (((uint32_t)lane << 1) + off));                                  \
+            S.t = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds.q) + sad_u32(((uint32_t)lane << 2) + 4u * (uint32_t)S.s_c, R.f[4] & 0xffffffu)); \
+            S.sev = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds.e) + sad_u32(((uint32_t)lane << 4) + 16u * (uint32_t)S.s_c, L0 << 3)); \
         }
         // ACC of the piece in R (S = its probe results), piece index m
 #define BRC_ACC(R, S, m)                                                                                                \
@@ -686,7 +695,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn i
             const uint64_t m_p = S.m_in & __builtin_amdgcn_ballot_w64(S.w >= thr0);           /* :288 */                  \
             count_if(a.depth, m_p);                                                            /* mapq_n (:312) */         \
             if (!(fl & PF_NB)) {                                                               /* :343 with -i */          \
-                const uint32_t b = S.w & 0xffu, qw = (S.w >> 8) + R.g[1];     /* base quality + the warning bits */       \
+                const uint32_t b = S.w & 0xffu;                                                                           \
                 float ts3p, tq2; double tsev;                                                                             \
                 if (__builtin_expect((fl & PF_TABLE) != 0u, 1)) {                                                         \
                     /* q2 == tp, or no Q2 position: then +0.0f, the identity on these sums */                            \
@@ -698,10 +707,10 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn i
                 }                                                                                                         \
                 const uint64_t m_dom = m_p & __builtin_amdgcn_ballot_w64(b == a.dom_b);                                   \
                 if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(m_dom), 1)) {                                    \
-                    a.dom.w1 += R.f[5]; a.dom.w2 += R.f[6]; a.dom.w3 += R.f[7]; a.dom.sbq += qw;                          \
-                    a.dom.f[F_SQ2] += tq2; a.dom.f[F_S3P] += ts3p;                                                        \
-                    a.dom.f[F_SEV] = (float)((double)a.dom.f[F_SEV] + tsev);                                              \
-                    a.dom.f[F_SNM] += __uint_as_float(R.g[0]);                                                            \
+                    a.dom.w1 += R.f[5]; a.dom.w2 += R.f[6]; a.dom.w3 += R.f[7]; a.dom.sw += S.w;                          \
+                    fadd_v(a.dom.f[F_SQ2], tq2); fadd_v(a.dom.f[F_S3P], ts3p);                                            \
+                    fadd_through_double(a.dom.f[F_SEV], tsev);                                                            \
+                    fadd_s(a.dom.f[F_SNM], __uint_as_float(R.g));                                                         \
                 }                                                                                                         \
                 const uint64_t m_rest = m_p & ~m_dom;                                                                     \
                 uint64_t m_ovf = 0;                                                                                       \
@@ -711,10 +720,10 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn i
                         const bool take_alt = a.alt_b == NB_NONE || a.alt_b == b;                                         \
                         if (take_alt) {                                                                                   \
                             a.alt_b = b;                                                                                  \
-                            a.alt.w1 += R.f[5]; a.alt.w2 += R.f[6]; a.alt.w3 += R.f[7]; a.alt.sbq += qw;                  \
-                            a.alt.f[F_SQ2] += tq2; a.alt.f[F_S3P] += ts3p;                                                \
-                            a.alt.f[F_SEV] = (float)((double)a.alt.f[F_SEV] + tsev);                                      \
-                            a.alt.f[F_SNM] += __uint_as_float(R.g[0]);                                                    \
+                            a.alt.w1 += R.f[5]; a.alt.w2 += R.f[6]; a.alt.w3 += R.f[7]; a.alt.sw += S.w;                  \
+                            fadd_v(a.alt.f[F_SQ2], tq2); fadd_v(a.alt.f[F_S3P], ts3p);                                    \
+                            fadd_through_double(a.alt.f[F_SEV], tsev);                                                    \
+                            fadd_s(a.alt.f[F_SNM], __uint_as_float(R.g));                                                 \
                         } else {                                                                                          \
                             a.w_sm += (fl & PF_SMW) ? 1u : 0u; a.w_nm += (fl & PF_NMW) ? 1u : 0u;                         \
                         }                                                                                                 \
@@ -768,7 +777,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn i
                                      "s_load_dwordx2 %3, %5, 0x38\n\ts_load_dwordx4 %4, %6, 0x10\n\ts_waitcnt lgkmcnt(0)"   \
                                      : "=&s"(hf), "=&s"(hg), "=&s"(dA), "=&s"(dB), "=&s"(cd) : "s"(hp), "s"(cp));         \
                         H.rs = (int32_t)hf[0]; H.a = (int32_t)hf[1]; H.len = (int32_t)hf[2]; H.ext = (int32_t)hf[3]; H.tp_flags = hf[4]; \
-                        H.w1 = hf[5]; H.w2 = hf[6]; H.w3 = hf[7]; H.snm = __uint_as_float(hg[0]); H.ws = hg[1];          \
+                        H.w1 = hf[5]; H.w2 = hf[6]; H.w3 = hf[7]; H.snm = __uint_as_float(hg[0]); H.pad = 0u;           \
                         H.rcpL = __uint_as_float(dA[0]); H.Lf = __uint_as_float(dA[1]); H.rcpC = __uint_as_float(dA[2]); H.center = __uint_as_float(dA[3]); \
                         H.left = (int32_t)dB[0]; H.q2 = (int32_t)dB[1];                                                   \
                         CD.bq_off = 0; CD.a = H.a; CD.read = 0; CD.zm_raw = cd[0]; CD.sse_raw = cd[1]; CD.mapq = cd[2]; CD.clipped = (int32_t)cd[3]; \
@@ -851,9 +860,9 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn i
         pl.ncol[(int64_t)lib * P + k] = a.ncol;                            // (dead lanes accumulated nothing: zeros)
         pl.depth[(int64_t)lib * P + k] = a.depth;
         pl.slotid[(int64_t)lib * P + k] = a.dom_b | (a.alt_b << 8);
-        a.w_sm += ((a.dom.sbq >> 15) & 127u) + ((a.alt.sbq >> 15) & 127u); a.w_nm += ((a.dom.sbq >> 22) & 127u) + ((a.alt.sbq >> 22) & 127u);
+        a.w_sm += ((a.dom.w1 >> 18) & 63u) + ((a.alt.w1 >> 18) & 63u); a.w_nm += ((a.dom.w1 >> 24) & 63u) + ((a.alt.w1 >> 24) & 63u);
         uint32_t dv[NI], av[NI];
-        pack_unpack(a.dom, dv); pack_unpack(a.alt, av);
+        pack_unpack(a.dom, a.dom_b, dv); pack_unpack(a.alt, a.alt_b, av);
         uint32_t* i0 = slot_i(c, pl, lib, 0u, k); uint32_t* i1 = slot_i(c, pl, lib, 1u, k);
         float* f0 = slot_f(c, pl, lib, 0u, k); float* f1 = slot_f(c, pl, lib, 1u, k);
         const bool add = flushed && !dead;                                 // (uniform but for dead lanes) earlier flushes of this tile

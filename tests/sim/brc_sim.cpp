@@ -84,9 +84,9 @@ class SimBackend : public Backend {
                     a[l].depth++;                                                                     // mapq_n (:312)
                     if (fl & PF_NB) continue;                                                         // :343 with -i
                     const EvTerms t = (fl & PF_TABLE) ? piece_terms_tab(h, tt, c.table_len, qpos) : piece_terms_div(h, qpos);
-                    const uint32_t b = w & 0xffu, q = w >> 8;
-                    if (b == a[l].dom_b) { pack_event(a[l].dom, h, t, q); if (fl & PF_HUGE) { ints.lane[l] = true; any_int = true; } }
-                    else if (a[l].alt_b == NB_NONE || a[l].alt_b == b) { a[l].alt_b = b; pack_event(a[l].alt, h, t, q); if (fl & PF_HUGE) { ints.lane[l] = true; any_int = true; } }
+                    const uint32_t b = w & 0xffu;
+                    if (b == a[l].dom_b) { pack_event(a[l].dom, h, t, w); if (fl & PF_HUGE) { ints.lane[l] = true; any_int = true; } }
+                    else if (a[l].alt_b == NB_NONE || a[l].alt_b == b) { a[l].alt_b = b; pack_event(a[l].alt, h, t, w); if (fl & PF_HUGE) { ints.lane[l] = true; any_int = true; } }
                     else { full.lane[l] = true; any_full = true; a[l].w_sm += (fl & PF_SMW) ? 1u : 0u; a[l].w_nm += (fl & PF_NMW) ? 1u : 0u; }
                 }
                 if (any_full) queue.push_back(full);
