@@ -280,6 +280,19 @@ class Engine:
         return C.string_at(p, n.value)
 
 
+def _format_region_np(self, chrom):
+    """Text of the last fetched region as a uint8 numpy view of the engine's buffer (no copy; texts above 2 GiB are fine).
+    Valid until the next call on this engine."""
+    p = C.c_void_p(); n = C.c_size_t()
+    self._check(self.L.lib.brc_format_region(self.h, C.byref(self._res), chrom.encode(), C.cast(C.byref(p), C.POINTER(C.c_char_p)), C.byref(n)))
+    if not n.value:
+        return np.zeros(0, np.uint8)
+    return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_ubyte)), shape=(n.value,))
+
+
+Engine.format_region_np = _format_region_np
+
+
 def _format_window(self, chrom, vbeg0, vend, delta):
     """Text of the sub-window [vbeg0,vend) of the last fetched region, coordinates shifted by -delta (site-list planner)."""
     p = C.c_char_p(); n = C.c_size_t()

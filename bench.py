@@ -1,78 +1,153 @@
 #!/usr/bin/env python3
-"""bench.py — pileup base-events/s of the MI355X readcount engine on BASELINE.json's timed configuration.
+"""bench.py — pileup base-events/s of the MI355X readcount engine on BASELINE.json's timed configurations.
 
-A "step" = one pass of the whole device pipeline (k_annotate -> scans -> k_tiles -> k_pileup -> indel path) over one
-synthetic contig whose inputs are already resident in HBM (uploaded before the timed region); outputs (the
-position-major BasicStat planes) are written to HBM.  Workload = BASELINE config 3 (synthetic 30x WGS, 150 bp reads,
--q20 -b13, one contig; SURVEY.md 8d generator).  With N ranks every rank processes its own contig of the same size
-(independent genomic intervals -> no data-path collective; "weak" scaling).  value = total events of all ranks per step
-/ max-over-ranks step time.
+A "step" = one pass of the whole device pipeline (k_annotate -> scans -> k_tiles -> k_pileup2 -> indel path) over one
+synthetic region whose inputs are already resident in HBM (uploaded before the timed region); the results (compact
+slot planes + third-allele list + indel buckets) are written to HBM.  value = events of all ranks per step /
+max-over-ranks step time.
 
-Extra objects on the JSON line:
-  roofline      k_pileup (dominant kernel): algorithmic bytes per launch (B_in + B_ref + B_out) / its average
-                duration measured with HIP events on the engine's stream, against the 8 TB/s HBM peak.
-  cpu_baseline  the C oracle (CPU restatement of the reference semantics, 1 thread like the reference) timed on a bounded
-                prefix of the same contig on rank 0.
+  --mode weak    (default) BASELINE config 3 per GPU: synthetic 30x WGS, 150 bp, one 50-Mbp contig, -q20 -b13; with N ranks
+                 every rank owns a contig of the same size (independent genomic intervals, no data-path collective)
+  --mode strong  BASELINE config 5: synthetic 200x tumour, 4 libraries, -p -i, one 50-Mbp contig cut into N intervals,
+                 one per rank (fixed total work)
+  --mode sites   BASELINE config 4: a -l list of 100 000 single-base sites in file order, cut into N contiguous slices;
+                 each rank lays its sites side by side on one virtual axis (the CLI's site-list planner) and runs the
+                 pipeline once per step.  The genome is scaled: one 50-Mbp contig per rank instead of 3.1 Gbp.
+
+`--gpus N` with N > 1 re-executes itself under torch.distributed.run (one rank per GPU, RCCL) unless it already runs
+under a launcher.  Extra objects on the JSON line:
+  roofline      k_pileup2 (dominant kernel): algorithmic bytes per launch (B_in + B_ref + B_out, dense 312 B per
+                position and library) / its average duration measured with HIP events on the engine's stream, against the
+                8 TB/s HBM peak and the 6.29 TB/s measured copy rate; the bytes the kernel really writes (compact planes)
+  cpu_baseline  the C oracle (CPU restatement of the reference semantics): 1 thread like the reference, and all cores
+                (one oracle process per core, each on its own contig of the same data model, after the timed region)
+  e2e           the drop-in command line on a generated BAM + BAI -> /dev/null (BAM decode, PCIe, formatting included)
+  validated     the HIP planes / text of a prefix of the timed contig equal the oracle's, and the event count of the timed
+                full-size run equals the sum of the reads' in-window spans
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_COPY_GBS = 6290.0    # measured streaming-copy rate of the same guide's chip table
+CLI = os.path.join(ROOT, "bam_readcount_amd", "csrc", "bam-readcount")
+
+
+def cpu_worker(seed, mbp, config):
+    """One oracle process of the all-cores baseline: its own slice of the data model; prints events and seconds."""
+    import synthgen
+    from bam_readcount_amd import capi
+    n = int(mbp * 1e6)
+    ref, arrs = synthgen.generate(n, config, seed=seed, n_chunks=1)
+    oracle = capi.Library(os.path.join(ROOT, "oracle", "libbrc_oracle.so"))
+    per_lib = config == "tumor200x"
+    names = ["lib%d" % i for i in range(synthgen.CONFIGS[config]["n_libs"])] if per_lib else ()
+    opts = dict(min_mapq=20, min_bq=13) if not per_lib else dict(per_lib=True, insertion_centric=True)
+    e = capi.Engine(oracle, lib_names=names, **opts)
+    e.begin_region(0, 0, n, ref); e.push_reads(arrs)
+    t0 = time.perf_counter(); e.upload(); e.compute(); dt = time.perf_counter() - t0
+    ev, _ = e.counts(); e.close()
+    print(json.dumps({"events": ev, "seconds": dt}))
+
+
+def site_batch(np, capi, arrs, ref, sites, window=384, lead=170):
+    """The CLI planner's layout for single-base -l lines: site i's reads (those samfetch would return for [s-2, s)) and its
+    reference slice are translated to virtual positions [i * window, (i + 1) * window)."""
+    pos = arrs["pos"].astype(np.int64); ends = capi.read_ends(arrs)
+    first = np.searchsorted(pos, sites - lead, side="left"); last = np.searchsorted(pos, sites, side="left")   # pos in [s - lead, s)
+    cnt = last - first
+    ridx = np.repeat(first, cnt) + (np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt))
+    sidx = np.repeat(np.arange(len(sites)), cnt)
+    keep = ends[ridx] > sites[sidx] - 2                                 # overlaps [s - 2, s)
+    ridx, sidx = ridx[keep], sidx[keep]
+    sub = capi.select_reads(arrs, ridx)
+    delta = sidx * window + lead - sites[sidx]
+    sub["pos"] = (sub["pos"].astype(np.int64) + delta).astype(np.int32)
+    vref = np.full(len(sites) * window, ord("N"), np.uint8)
+    src = (sites[:, None] - lead + np.arange(window)[None, :]).clip(0, len(ref) - 1)
+    vref[:] = ref[src].reshape(-1)
+    events = int(np.bincount(sidx, minlength=len(sites)).sum())
+    return sub, vref, events
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--contig-mbp", type=float, default=50.0, help="contig length per GPU (BASELINE config 3: 50)")
-    ap.add_argument("--config", default="wgs30x", choices=["wgs30x", "tumor200x"])
-    ap.add_argument("--cpu-sample-mbp", type=float, default=8.0, help="prefix timed with the CPU oracle (0 = skip); 8 Mbp ~ 240 M events ~ 10-20 s")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_traffic.json"),
-                    help="JSON with the PMC-derived HBM bytes per k_pileup launch (separate rocprofv3 --pmc passes of this command)")
+    ap.add_argument("--steps", type=int, default=300, help="timed steps (300 x ~7 ms: a timed region above 2 s)")
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--mode", default="weak", choices=["weak", "strong", "sites"])
+    ap.add_argument("--config", default=None, choices=["wgs30x", "tumor200x"], help="data model (default: wgs30x; tumor200x for --mode strong)")
+    ap.add_argument("--contig-mbp", type=float, default=50.0, help="weak/sites: contig per GPU; strong: the whole contig")
+    ap.add_argument("--sites", type=int, default=100000, help="--mode sites: lines of the site list (all ranks together)")
+    ap.add_argument("--cpu-sample-mbp", type=float, default=8.0, help="prefix timed with the 1-thread CPU oracle and used for validation (0 = skip)")
+    ap.add_argument("--cpu-all-cores", type=int, default=-1, help="oracle processes of the all-cores baseline (-1: min(cores, 64); 0 = skip)")
+    ap.add_argument("--e2e-mbp", type=float, default=4.0, help="contig of the end-to-end command-line run (0 = skip)")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r02_traffic.json"))
+    ap.add_argument("--cpu-worker", nargs=3, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker:
+        return cpu_worker(int(args.cpu_worker[0]), float(args.cpu_worker[1]), args.cpu_worker[2])
+    config = args.config or ("tumor200x" if args.mode == "strong" else "wgs30x")
+
+    # ---- N > 1 without a launcher: become `python -m torch.distributed.run ... bench.py <same arguments>`
+    if args.gpus > 1 and "RANK" not in os.environ:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
 
     import numpy as np
     import torch
     import synthgen
     from bam_readcount_amd import capi
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+    torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
-    torch.cuda.set_device(local_rank)
+
+    ncpu = os.cpu_count() or 1
+    nworkers = (min(ncpu, 64) if args.cpu_all_cores < 0 else args.cpu_all_cores) if (rank == 0 and world == 1 and args.cpu_sample_mbp > 0) else 0
 
     hip = capi.load_product()
-    contig_len = int(args.contig_mbp * 1e6)
-    per_lib = args.config == "tumor200x"
-    names = ["lib%d" % i for i in range(synthgen.CONFIGS[args.config]["n_libs"])] if per_lib else ()
+    per_lib = config == "tumor200x"
+    names = ["lib%d" % i for i in range(synthgen.CONFIGS[config]["n_libs"])] if per_lib else ()
     opts = dict(min_mapq=20, min_bq=13) if not per_lib else dict(min_mapq=0, min_bq=0, per_lib=True, insertion_centric=True)
 
+    total_len = int(args.contig_mbp * 1e6)
+    contig_len = total_len // world if args.mode == "strong" else total_len
     t0 = time.time()
-    ref, arrs = synthgen.generate(contig_len, args.config, seed=1 + 1000 * rank)
+    ref, arrs = synthgen.generate(contig_len, config, seed=1 + 1000 * rank)
     t_gen = time.time() - t0
     eng = capi.Engine(hip, lib_names=names, device=local_rank, **opts)
+    site_events = 0
+    if args.mode == "sites":
+        n_mine = args.sites // world + (1 if rank < args.sites % world else 0)
+        sites = np.sort(np.random.default_rng(3 + rank).integers(200, contig_len - 200, n_mine))      # 1-based site == 0-based end
+        sub, vref, site_events = site_batch(np, capi, arrs, ref, sites)
+        region_len, region_ref, region_reads = len(vref), vref, sub
+    else:
+        region_len, region_ref, region_reads = contig_len, ref, arrs
     t0 = time.time()
-    eng.begin_region(0, 0, contig_len, ref)
-    eng.push_reads(arrs)
+    eng.begin_region(0, 0, region_len, region_ref)
+    eng.push_reads(region_reads)
     t_push = time.time() - t0
     t0 = time.time()
     eng.upload()                                  # inputs resident in HBM from here on
@@ -98,6 +173,8 @@ def main():
     dt = time.perf_counter() - t0
     kms /= max(args.steps, 1)
     n_events, n_positions = eng.counts()
+    if args.mode == "sites":
+        n_events, n_positions = site_events, len(sites)      # the unit of work counts the requested sites only
 
     tmax, ev_total, pos_total = dt, n_events, n_positions
     if dist is not None:
@@ -110,50 +187,106 @@ def main():
     if rank == 0:
         ms_per_step = tmax / args.steps * 1e3
         value = ev_total * args.steps / tmax
-        # roofline of the dominant kernel
         res_libs = len(names) if per_lib else 1
-        b_in, b_ref, b_out = synthgen.algorithmic_bytes(arrs, n_positions, res_libs, 0, ref_positions=contig_len)
+        # ---- roofline of the dominant kernel
+        eng_events, eng_positions = eng.counts()
+        b_in, b_ref, b_out = synthgen.algorithmic_bytes(region_reads, eng_positions, res_libs, 0, ref_positions=region_len)
         alg = b_in + b_ref + b_out
         achieved = alg / (kms[k_pile] * 1e-3) / 1e9 if kms[k_pile] > 0 else 0.0
-        traffic = None
-        if args.traffic_json and os.path.exists(args.traffic_json) and args.config == "wgs30x" and abs(args.contig_mbp - 50.0) < 1e-9:
-            traffic = json.load(open(args.traffic_json)).get("k_pileup_hbm_bytes_per_launch")   # measured on this exact workload
-        roof = {"bound": "hbm", "kernel": "k_pileup", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": alg, "bytes_per_event": round(alg / max(n_events, 1), 3),
+        traffic = None; traffic_src = None
+        if os.path.exists(args.traffic_json) and args.mode != "sites" and abs(args.contig_mbp - 50.0) < 1e-9 and world == 1:
+            tj = json.load(open(args.traffic_json)).get(config)
+            if tj:
+                traffic = tj.get("k_pileup_hbm_bytes_per_launch")
+                traffic_src = "%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not measured in this run" % os.path.relpath(args.traffic_json, ROOT)
+        roof = {"bound": "hbm", "kernel": "k_pileup2", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_copy_rate": round(achieved / HBM_COPY_GBS, 4),
+                "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": alg, "bytes_per_event": round(alg / max(eng_events, 1), 3),
+                "compact_result_bytes_per_launch": 116 * int(eng_positions) * res_libs,
+                "whole_step_frac": round(alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if world == 1 else None,
                 "kernel_ms": {k: round(float(v), 4) for k, v in zip(kernel_names, kms) if k}}
-        # CPU baseline: the oracle on a bounded prefix, 1 thread
-        cpu = None
+
+        # ---- validation + 1-thread CPU baseline on a prefix of the timed contig
+        cpu = None; validated = None
+        ends = capi.read_ends(arrs)
+        if args.mode != "sites":
+            span = int((np.minimum(ends, contig_len) - np.maximum(arrs["pos"].astype(np.int64), 0)).clip(min=0).sum())
+            dropped = (arrs["flag"] & 4) != 0
+            validated = {"events_equal_sum_of_spans": bool(eng_events == span and not dropped.any())}
         if args.cpu_sample_mbp > 0:
-            import subprocess
+            import parity
             subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
             oracle = capi.Library(os.path.join(ROOT, "oracle", "libbrc_oracle.so"))
-            send = int(min(args.cpu_sample_mbp * 1e6, contig_len))
-            ends = capi.read_ends(arrs)
-            idx = capi.fetch_overlapping(arrs, ends, -1, send)
-            sub = capi.select_reads(arrs, idx)
+            send = int(min(args.cpu_sample_mbp * 1e6 * (0.15 if per_lib else 1.0), contig_len))
+            sub = capi.select_reads(arrs, capi.fetch_overlapping(arrs, ends, -1, send))
             oe = capi.Engine(oracle, lib_names=names, **opts)
-            oe.begin_region(0, 0, send, ref)
-            oe.push_reads(sub)
-            t0 = time.perf_counter()
-            oe.upload(); oe.compute()
-            tc = time.perf_counter() - t0
-            oev, _ = oe.counts()
-            oe.close()
+            oe.begin_region(0, 0, send, ref); oe.push_reads(sub)
+            t0 = time.perf_counter(); oe.upload(); oe.compute(); tc = time.perf_counter() - t0
+            ores = oe.fetch_result(); otext = oe.format_region_np("chrS"); oev, _ = oe.counts()
+            he = capi.Engine(hip, lib_names=names, device=local_rank, **opts)
+            he.begin_region(0, 0, send, ref); he.push_reads(sub)
+            hres = he.end_region(); htext = he.format_region_np("chrS")
+            parity.assert_results_equal(hres, ores, "bench prefix")       # raises on the first differing plane element
+            assert len(htext) == len(otext) and np.array_equal(htext, otext), "text of the HIP engine and of the oracle differ"
+            text_bytes = int(len(htext)); he.close(); oe.close()
+            validated = dict(validated or {}, prefix_mbp=send / 1e6, planes_bit_exact=True, text_byte_exact=True, text_bytes=text_bytes)
             cpu = {"value": round(oev / tc, 1), "unit": "pileup base-events/s", "cores": 1, "kind": "port",
                    "sample": "first %.2f Mbp of the same contig (%d events, %.1f s), C oracle incl. its text formatting, 1 thread of %d host cores"
-                             % (send / 1e6, oev, tc, os.cpu_count())}
+                             % (send / 1e6, oev, tc, ncpu)}
+            if nworkers:
+                # all cores: one oracle process per core, each on its own contig of the same data model; started only now —
+                # nothing else of this benchmark runs while they do
+                per = 1.0 if config == "wgs30x" else 0.15                        # ~2 s of oracle work per process
+                cpu_procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(1000 + w), str(per), config],
+                                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for w in range(nworkers)]
+                outs = [json.loads(p.communicate()[0].decode().strip().splitlines()[-1]) for p in cpu_procs]
+                cpu["all_cores"] = {"value": round(sum(o["events"] for o in outs) / max(o["seconds"] for o in outs), 1), "cores": len(outs),
+                                    "sample": "%d oracle processes at once, each on its own %.2f-Mbp contig of the same data model (%d events in all, slowest %.1f s)"
+                                              % (len(outs), 1.0 if config == "wgs30x" else 0.15, sum(o["events"] for o in outs), max(o["seconds"] for o in outs))}
+
+        # ---- end to end through the drop-in command line (BAM decode + PCIe + text)
+        e2e = None
+        if args.e2e_mbp > 0 and world == 1 and os.path.exists(CLI):
+            import bamio
+            import tempfile
+            n = int(args.e2e_mbp * 1e6)
+            d = tempfile.mkdtemp(prefix="brc_e2e_")
+            r2, a2 = synthgen.generate(n, "wgs30x", seed=3)
+            bamio.write_bam(os.path.join(d, "syn.bam"), [("chrS", n)], a2, np.zeros(len(a2["pos"]), int), block_bytes=60000)
+            rows = (n + 59) // 60
+            pad = np.full(rows * 60, 10, np.uint8); pad[:n] = r2
+            with open(os.path.join(d, "syn.fa"), "wb") as f:
+                f.write(b">chrS\n" + np.concatenate([pad.reshape(rows, 60), np.full((rows, 1), 10, np.uint8)], axis=1).tobytes())
+            open(os.path.join(d, "syn.fa.fai"), "w").write("chrS\t%d\t6\t60\t61\n" % n)
+            e2 = capi.read_ends(a2)
+            ev2 = int((np.minimum(e2, n) - a2["pos"].astype(np.int64)).clip(min=0).sum())
+            best = None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                p = subprocess.run([CLI, "-w", "0", "-q", "20", "-b", "13", "-f", "syn.fa", "syn.bam", "chrS"], cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                t1 = time.perf_counter() - t0
+                if p.returncode == 0 and (best is None or t1 < best):
+                    best = t1
+            if best:
+                e2e = {"value": round(ev2 / best, 1), "unit": "pileup base-events/s", "seconds": round(best, 3), "events": ev2,
+                       "what": "bam-readcount (this repository's drop-in CLI) -q20 -b13 -f syn.fa syn.bam chrS > /dev/null on a %.0f-Mbp 30x synthetic BAM: process start, BGZF/BAM decode, H2D, device pipeline, D2H, text formatting" % args.e2e_mbp}
+
+        what = {"weak": "synthetic 30x WGS, 150bp reads, 1 contig %.0f Mbp per GPU, -q20 -b13" % (contig_len / 1e6),
+                "strong": "synthetic 200x tumor 4 libraries, 150bp reads, -p -i, 1 contig %.0f Mbp cut into %d intervals" % (total_len / 1e6, world),
+                "sites": "-l site list of %d single-base sites in file order over %d synthetic 30x contigs of %.0f Mbp (genome scaled from 3.1 Gbp), -q20 -b13, cut into %d slices"
+                         % (args.sites, world, contig_len / 1e6, world)}[args.mode]
+        if config == "tumor200x" and args.mode == "weak":
+            what = "synthetic 200x tumor 4 libraries, 150bp reads, -p -i, 1 contig %.2f Mbp per GPU" % (contig_len / 1e6)
         line = {
             "metric": "pileup base-events/sec", "value": round(value, 1), "unit": "events/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32+f32", "data": "synthetic",
-            "config": {"workload": "synthetic %s, 150bp reads, 1 contig %.0f Mbp per GPU, %s" % (
-                "30x WGS" if not per_lib else "200x tumor 4 libraries", contig_len / 1e6,
-                "-q20 -b13" if not per_lib else "-p -i"), "reads_per_gpu": int(len(arrs["pos"])),
-                "events_per_step": int(ev_total), "positions_per_step": int(pos_total), "parallelism": "interval-shard x%d" % world},
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak" if args.mode == "weak" else "strong", "vs_baseline": None, "dtype": "u32+f32", "data": "synthetic",
+            "config": {"workload": what, "mode": args.mode, "reads_per_gpu": int(len(region_reads["pos"])),
+                       "events_per_step": int(ev_total), "positions_per_step": int(pos_total), "parallelism": "interval-shard x%d" % world},
             "positions_per_s": round(pos_total * args.steps / tmax, 1),
-            "roofline": roof, "cpu_baseline": cpu,
-            "host": {"gen_s": round(t_gen, 2), "push_s": round(t_push, 2), "upload_s": round(t_up, 2)},
+            "roofline": roof, "cpu_baseline": cpu, "e2e": e2e, "validated": validated,
+            "host": {"gen_s": round(t_gen, 2), "push_s": round(t_push, 2), "upload_s": round(t_up, 2), "timed_s": round(tmax, 3)},
         }
         print(json.dumps(line))
     eng.close()
