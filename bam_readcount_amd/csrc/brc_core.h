@@ -66,7 +66,7 @@ struct DevCfg {
     int32_t variant;        // 0 in production; >0 = profiling ablations selected by BRC_PILEUP_VARIANT (see brc_engine.hip)
     int32_t force_dom;      // test knob (BRC_FORCE_DOM): -1, or the bucket every lane treats as dominant (stresses the alternate / third-allele paths)
     int64_t n_pieces;       // pieces of all libraries (KB v2)
-    int32_t flush_k;        // K: pieces a lane may accumulate in its packed integer registers between two flushes (1..63: 6-bit counters)
+    int32_t flush_k;        // K: pieces a lane may accumulate in its packed integer registers between two flushes (1..127)
     uint32_t pack_lim;      // 65535 / K: largest per-read value a 16-bit packed field can take (PF_HUGE above it)
 };
 
@@ -399,10 +399,9 @@ struct alignas(64) PieceHot {
     int32_t len;           // events: positions [rs, rs + len); every piece with len > 0 belongs to a read that counts
     int32_t ext;           // column: positions [rs, rs + ext), ext >= len
     uint32_t tp_flags;     // bits 0-23: three_prime_index * 4 (byte offset into the float quotient table); 24-31: PF_*
-    uint32_t w1, w2, w3;   // packed integer addends: five 6-bit counters 1 | rev << 6 | q2ok << 12 | SM-missing << 18 | NM-missing << 24
-                           // (the last two: process_read warnings, BasicStat.cpp:85,100);  mapq | sse << 16;  zm_sum | clipped << 16
+    uint32_t w1, w2, w3;   // packed integer addends: three 10-bit counters 1 | rev << 10 | q2ok << 20;  mapq | sse << 16;  zm_sum | clipped << 16
     float snm;             // NM / (float)clipped_length, 0 when NM is missing
-    uint32_t pad;
+    uint32_t ww;           // per-lane (not per-bucket) warning counters: SM-missing | NM-missing << 16 (process_read warnings, BasicStat.cpp:85,100)
     float rcpL, Lf, rcpC, center;   // exact-division constants
     int32_t left, q2;
 };
@@ -504,11 +503,11 @@ BRC_HD void make_piece(const DevCfg& c, const ReadConst& r, int32_t rs, int32_t 
     const bool huge = r.zm > c.pack_lim || r.sse > c.pack_lim || (uint32_t)r.clipped > c.pack_lim;
     if (huge) fl |= PF_HUGE;
     h.tp_flags = (((uint32_t)r.tp << 2) & 0xffffffu) | (fl << 24);      // l_qseq < 2^22 is checked at push
-    h.w1 = 1u | ((fl & PF_REV) ? (1u << 6) : 0u) | (q2ok ? (1u << 12) : 0u) | ((fl & PF_SMW) ? (1u << 18) : 0u) | ((fl & PF_NMW) ? (1u << 24) : 0u);
+    h.w1 = 1u | ((fl & PF_REV) ? (1u << 10) : 0u) | (q2ok ? (1u << 20) : 0u);
     h.w2 = r.mapq | (huge ? 0u : (r.sse << 16));
     h.w3 = huge ? 0u : (r.zm | ((uint32_t)r.clipped << 16));
     h.snm = r.snm;
-    h.pad = 0u;
+    h.ww = ((fl & PF_SMW) ? 1u : 0u) | ((fl & PF_NMW) ? (1u << 16) : 0u);
     h.Lf = (float)r.l_qseq; h.center = (float)r.clipped * 0.5f; h.rcpL = 1.0f / h.Lf; h.rcpC = 1.0f / h.center;
     h.left = r.left; h.q2 = r.q2;
     cold.bq_off = r.bq_off; cold.a = h.a; cold.read = r.read; cold.zm_raw = r.zm; cold.sse_raw = r.sse; cold.mapq = r.mapq;
@@ -534,8 +533,8 @@ BRC_HD EvTerms piece_terms_tab(const PieceHot& h, const TermTab& tt, int table_l
     return t;
 }
 
-// One bucket of a lane between two flushes: three packed integer registers (w1: five 6-bit counters, so K <= 63 pieces
-// between flushes; w2, w3: two 16-bit sums each), the sum of the EVENT WORDS (quality << 8 | bucket: every event of a slot
+// One bucket of a lane between two flushes: three packed integer registers (w1: three 10-bit counters; w2, w3: two 16-bit
+// sums each, which bound K: 255 x K and clipped_length x K must stay below 2^16), the sum of the EVENT WORDS (quality << 8 | bucket: every event of a slot
 // has the slot's bucket, so the base-quality sum is (sum - count * bucket) >> 8 — no unpacking per event) and the four
 // order-sensitive float sums.
 struct PackAcc { uint32_t w1, w2, w3, sw; float f[NF]; };
@@ -548,9 +547,9 @@ BRC_HD void pack_event(PackAcc& a, const PieceHot& h, const EvTerms& t, uint32_t
 }
 // the nine integer plane values held by a PackAcc whose events all carry bucket b (I_* order)
 BRC_HD void pack_unpack(const PackAcc& a, uint32_t b, uint32_t* v) {
-    const uint32_t n = a.w1 & 63u, minus = (a.w1 >> 6) & 63u;
+    const uint32_t n = a.w1 & 0x3ffu, minus = (a.w1 >> 10) & 0x3ffu;
     v[I_N] = n; v[I_SMQ] = a.w2 & 0xffffu; v[I_SSE] = a.w2 >> 16; v[I_PLUS] = n - minus; v[I_MINUS] = minus;
-    v[I_NQ2] = (a.w1 >> 12) & 63u; v[I_SMMQ] = a.w3 & 0xffffu; v[I_SCLIP] = a.w3 >> 16; v[I_SBQ] = (a.sw - n * b) >> 8;
+    v[I_NQ2] = a.w1 >> 20; v[I_SMMQ] = a.w3 & 0xffffu; v[I_SCLIP] = a.w3 >> 16; v[I_SBQ] = (a.sw - n * b) >> 8;
 }
 
 // K (pieces between two flushes of a lane's packed integers) and the per-read limit of a 16-bit field: clipped_length of
@@ -558,7 +557,7 @@ BRC_HD void pack_unpack(const PackAcc& a, uint32_t b, uint32_t* v) {
 // (the overrides are test knobs: a small K exercises the flushes, a small limit the PF_HUGE path)
 BRC_HD void choose_pack(int32_t max_lqseq, int32_t k_override, int32_t lim_override, int32_t& K, uint32_t& lim) {
     int32_t m = max_lqseq < 255 ? 255 : max_lqseq;
-    K = 65535 / m; if (K > 63) K = 63; if (K < 1) K = 1;
+    K = 65535 / m; if (K > 127) K = 127; if (K < 1) K = 1;
     if (k_override > 0 && k_override < K) K = k_override;
     lim = 65535u / (uint32_t)K;
     if (lim_override >= 255 && (uint32_t)lim_override < lim) lim = (uint32_t)lim_override;    // >= 255: a mapping quality always fits
@@ -569,10 +568,10 @@ enum { HALF = 6 };          // pieces per staging half-batch (6 rows x 9 chunks 
                             // the rotation period of the piece-record registers); queue drains and flushes happen between half-batches
 struct LaneAcc2 {
     PackAcc dom, alt;
-    uint32_t dom_b, alt_b, ncol, depth, w_sm, w_nm;
+    uint32_t dom_b, alt_b, ncol, depth, ww;   // ww: SM-missing | NM-missing << 16 warnings of this position
 };
 BRC_HD void lane2_init(LaneAcc2& a, uint32_t dom_b) {
-    pack_init(a.dom); pack_init(a.alt); a.dom_b = dom_b; a.alt_b = NB_NONE; a.ncol = a.depth = a.w_sm = a.w_nm = 0;
+    pack_init(a.dom); pack_init(a.alt); a.dom_b = dom_b; a.alt_b = NB_NONE; a.ncol = a.depth = a.ww = 0;
 }
 BRC_HD uint32_t* slot_i(const DevCfg& c, const Planes& pl, int lib, uint32_t slot, int64_t k) { return pl.si + (((int64_t)lib * 2 + slot) * NI) * c.PS + k; }
 BRC_HD float* slot_f(const DevCfg& c, const Planes& pl, int lib, uint32_t slot, int64_t k) { return pl.sf + (((int64_t)lib * 2 + slot) * NF) * c.PS + k; }
@@ -586,24 +585,23 @@ BRC_HD float* slot_f(const DevCfg& c, const Planes& pl, int lib, uint32_t slot, 
 #define BRC_NOUNROLL _Pragma("GCC unroll 1")
 #endif
 BRC_HD uint32_t pack_field(const PackAcc& a, uint32_t b, int f) {
-    const uint32_t n = a.w1 & 63u, minus = (a.w1 >> 6) & 63u;
+    const uint32_t n = a.w1 & 0x3ffu, minus = (a.w1 >> 10) & 0x3ffu;
     uint32_t v = n;                                            // I_N
     v = f == I_SMQ ? (a.w2 & 0xffffu) : v; v = f == I_SSE ? (a.w2 >> 16) : v; v = f == I_PLUS ? n - minus : v; v = f == I_MINUS ? minus : v;
-    v = f == I_NQ2 ? ((a.w1 >> 12) & 63u) : v; v = f == I_SMMQ ? (a.w3 & 0xffffu) : v; v = f == I_SCLIP ? (a.w3 >> 16) : v; v = f == I_SBQ ? ((a.sw - n * b) >> 8) : v;
+    v = f == I_NQ2 ? (a.w1 >> 20) : v; v = f == I_SMMQ ? (a.w3 & 0xffffu) : v; v = f == I_SCLIP ? (a.w3 >> 16) : v; v = f == I_SBQ ? ((a.sw - n * b) >> 8) : v;
     return v;
 }
 // packed registers -> the integer planes of one slot (adds when the tile has flushed before), registers reset; b = the slot's bucket
-BRC_HD void flush_slot(const DevCfg& c, const Planes& pl, int lib, int64_t k, PackAcc& a, uint32_t slot, uint32_t b, bool live, uint32_t& w_sm, uint32_t& w_nm) {
+BRC_HD void flush_slot(const DevCfg& c, const Planes& pl, int lib, int64_t k, PackAcc& a, uint32_t slot, uint32_t b, bool live) {
     uint32_t* ip = slot_i(c, pl, lib, slot, k);
-    w_sm += (a.w1 >> 18) & 63u; w_nm += (a.w1 >> 24) & 63u;
     BRC_NOUNROLL
     for (int f = 0; f < NI; ++f) { const uint32_t v = pack_field(a, b, f); ip[(int64_t)f * c.PS] = v + (live ? ip[(int64_t)f * c.PS] : 0u); }
     a.w1 = a.w2 = a.w3 = a.sw = 0;
 }
 // `live`: the tile has flushed before (wave-uniform)
 BRC_HD void lane2_flush(const DevCfg& c, const Planes& pl, int lib, int64_t k, LaneAcc2& a, bool live) {
-    flush_slot(c, pl, lib, k, a.dom, 0u, a.dom_b, live, a.w_sm, a.w_nm);
-    flush_slot(c, pl, lib, k, a.alt, 1u, a.alt_b, live, a.w_sm, a.w_nm);
+    flush_slot(c, pl, lib, k, a.dom, 0u, a.dom_b, live);
+    flush_slot(c, pl, lib, k, a.alt, 1u, a.alt_b, live);
 }
 // one event of a third (fourth, ...) base at this position: its raw addends, for the list
 BRC_HD XEv make_xev(int lib, int64_t k, const PieceHot& h, const PieceCold& cold, int qpos, uint32_t word) {
@@ -632,7 +630,7 @@ BRC_HD void lane2_store(const DevCfg& c, const Planes& pl, int lib, int64_t k, L
         PackAcc& r = sl ? a.alt : a.dom;
         float* fp = slot_f(c, pl, lib, sl, k);
         for (int f = 0; f < NF; ++f) fp[(int64_t)f * P] = dead ? 0.0f : r.f[f];
-        flush_slot(c, pl, lib, k, r, sl, sl ? a.alt_b : a.dom_b, live, a.w_sm, a.w_nm);
+        flush_slot(c, pl, lib, k, r, sl, sl ? a.alt_b : a.dom_b, live);
         if (dead) { uint32_t* ip = slot_i(c, pl, lib, sl, k); for (int f = 0; f < NI; ++f) ip[(int64_t)f * P] = 0u; }
     }
 }

@@ -563,8 +563,8 @@ static_assert(HALF % 3 == 0, "the piece-record registers rotate with period 3");
 
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-// dwords 0-8 of a PieceHot in scalar registers: f = {rs, a, len, ext, tp_flags, w1, w2, w3}, g = snm
-struct PRec { u32x8 f; uint32_t g; };
+// dwords 0-9 of a PieceHot in scalar registers: f = {rs, a, len, ext, tp_flags, w1, w2, w3}, g = {snm, ww}
+struct PRec { u32x8 f; u32x2 g; };
 
 // One wave = one (64-position tile, library); lane == position.  The wave walks the tile's pieces [lo, hi) of its library
 // in stream (= pileup column) order, in half-batches of HALF = 6:
@@ -579,12 +579,15 @@ struct PRec { u32x8 f; uint32_t g; };
 //  * one pipeline step = probe of piece j + 1 (coverage ballots, event word and table look-ups: LDS reads only) and
 //    accumulate of piece j (quality / bucket ballots, one exec region with the 10 adds of the dominant bucket, a usually
 //    skipped one for everything else); lane conditions are 64-bit masks in scalar registers;
-//  * per bucket a lane holds three PACKED integer registers (five 6-bit counters; mapq | sse; zm | clipped), the sum of
+//  * per bucket a lane holds three PACKED integer registers (three 10-bit counters; mapq | sse; zm | clipped), the sum of
 //    its event words (= 256 x base-quality sum + count x bucket) and the four fp32 sums; the integers are flushed to the
-//    planes every K pieces (K = 63 for short reads) and at the end of the tile;
+//    planes every K pieces (K = 127 for short reads) and at the end of the tile;
 //  * third alleles (a lane keeps its reference base and the first other base in registers) and PF_HUGE integers are
 //    queued and drained into the planes between half-batches, in piece order.
-__global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn in, const uint4* __restrict__ hot4, const PieceCold* __restrict__ cold,
+#ifndef BRC_WAVES_PER_EU
+#define BRC_WAVES_PER_EU 7      // 72 VGPRs: 16 values spill into the rare paths (measured: 6 waves 3.92 ms, 7 waves 3.78 ms, 8 waves 5.6 ms — spills reach the loop)
+#endif
+__global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_eu(BRC_WAVES_PER_EU, BRC_WAVES_PER_EU))) void k_pileup2(DevCfg c, DevIn in, const uint4* __restrict__ hot4, const PieceCold* __restrict__ cold,
                                                                const uint2* __restrict__ rng, int64_t ntiles, Planes pl, uint4* __restrict__ tile_ctr,
                                                                const uint16_t* __restrict__ bq_ro, const uint32_t* __restrict__ unavail_ro) {
     // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch order); give every XCD one contiguous
@@ -628,6 +631,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn i
     LaneAcc2 a;
     lane2_init(a, c.force_dom >= 0 ? (uint32_t)c.force_dom : (valid ? dominant_bucket(c, in, p) : 1u));
     bool flushed = false;                                                   // (scalar) the slot planes of this tile hold partial integer sums
+    unsigned long long wsm_tot = 0, wnm_tot = 0;                            // (scalar) warnings moved out of the lanes at flushes
 
     if (lo < hi && c.variant != 4) {            // (variant: profiling ablations, BRC_PILEUP_VARIANT — 4: no piece loop, 1: no plane stores, 5: one half-batch only)
         // lanes past the region's last position stand far left of every piece: no coverage test is ever true for them
@@ -661,7 +665,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn i
             }                                                                                                             \
         }
         // scalar loads of the record at rp (issued HERE), and the wait that makes them usable
-#define BRC_LD_REC(R, rp) asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x20" : "=&s"(R.f), "=&s"(R.g) : "s"(rp));
+#define BRC_LD_REC(R, rp) asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x20" : "=&s"(R.f), "=&s"(R.g) : "s"(rp));
 #define BRC_WAIT_REC(R) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R.f), "+s"(R.g));
         // the division constants of piece m (dwords 10-15 of its record) by scalar loads, on demand: only pieces without PF_TABLE
 #define BRC_LD_DIV(H, R, m)                                                                                             \
@@ -710,7 +714,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn i
                     a.dom.w1 += R.f[5]; a.dom.w2 += R.f[6]; a.dom.w3 += R.f[7]; a.dom.sw += S.w;                          \
                     fadd_v(a.dom.f[F_SQ2], tq2); fadd_v(a.dom.f[F_S3P], ts3p);                                            \
                     fadd_through_double(a.dom.f[F_SEV], tsev);                                                            \
-                    fadd_s(a.dom.f[F_SNM], __uint_as_float(R.g));                                                         \
+                    fadd_s(a.dom.f[F_SNM], __uint_as_float(R.g[0])); a.ww += R.g[1];                                      \
                 }                                                                                                         \
                 const uint64_t m_rest = m_p & ~m_dom;                                                                     \
                 uint64_t m_ovf = 0;                                                                                       \
@@ -723,10 +727,9 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn i
                             a.alt.w1 += R.f[5]; a.alt.w2 += R.f[6]; a.alt.w3 += R.f[7]; a.alt.sw += S.w;                  \
                             fadd_v(a.alt.f[F_SQ2], tq2); fadd_v(a.alt.f[F_S3P], ts3p);                                    \
                             fadd_through_double(a.alt.f[F_SEV], tsev);                                                    \
-                            fadd_s(a.alt.f[F_SNM], __uint_as_float(R.g));                                                 \
-                        } else {                                                                                          \
-                            a.w_sm += (fl & PF_SMW) ? 1u : 0u; a.w_nm += (fl & PF_NMW) ? 1u : 0u;                         \
+                            fadd_s(a.alt.f[F_SNM], __uint_as_float(R.g[0]));                                              \
                         }                                                                                                 \
+                        a.ww += R.g[1];                        /* alternate and third alleles alike */                    \
                         ovf = !take_alt;                                                                                  \
                     }                                                                                                     \
                     m_ovf = __builtin_amdgcn_ballot_w64(ovf);                                                             \
@@ -755,6 +758,13 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn i
             }                                                                                                             \
             BRC_ACC(RC, SC, base + (J))                                                                                   \
         }
+        // packed integers -> slot planes; the 16-bit warning counters of the lanes move to the wave's totals
+#define BRC_FLUSH()                                                                                                     \
+        {                                                                                                                 \
+            if (valid) lane2_flush(c, pl, lib, kk, a, flushed);                                                           \
+            wsm_tot += wave_sum_u64(valid ? (a.ww & 0xffffu) : 0u); wnm_tot += wave_sum_u64(valid ? (a.ww >> 16) : 0u); a.ww = 0u; \
+            flushed = true; since_flush = 0;                                                                              \
+        }
         // between half-batches: drain the queue (the event words of this half-batch are still staged in ring half hoff),
         // flush when the packed fields could overflow during the next half-batch, then reuse the ring half just processed
         // (every LDS read of it has returned after the lgkmcnt wait): copy half-batch base + 2 HALF into it and request
@@ -777,14 +787,13 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn i
                                      "s_load_dwordx2 %3, %5, 0x38\n\ts_load_dwordx4 %4, %6, 0x10\n\ts_waitcnt lgkmcnt(0)"   \
                                      : "=&s"(hf), "=&s"(hg), "=&s"(dA), "=&s"(dB), "=&s"(cd) : "s"(hp), "s"(cp));         \
                         H.rs = (int32_t)hf[0]; H.a = (int32_t)hf[1]; H.len = (int32_t)hf[2]; H.ext = (int32_t)hf[3]; H.tp_flags = hf[4]; \
-                        H.w1 = hf[5]; H.w2 = hf[6]; H.w3 = hf[7]; H.snm = __uint_as_float(hg[0]); H.pad = 0u;           \
+                        H.w1 = hf[5]; H.w2 = hf[6]; H.w3 = hf[7]; H.snm = __uint_as_float(hg[0]); H.ww = hg[1];          \
                         H.rcpL = __uint_as_float(dA[0]); H.Lf = __uint_as_float(dA[1]); H.rcpC = __uint_as_float(dA[2]); H.center = __uint_as_float(dA[3]); \
                         H.left = (int32_t)dB[0]; H.q2 = (int32_t)dB[1];                                                   \
                         CD.bq_off = 0; CD.a = H.a; CD.read = 0; CD.zm_raw = cd[0]; CD.sse_raw = cd[1]; CD.mapq = cd[2]; CD.clipped = (int32_t)cd[3]; \
                     }                                                                                                     \
                     if (kind == 1u && !flushed) {              /* huge integers go straight to the slot planes: make them live */ \
-                        if (valid) lane2_flush(c, pl, lib, kk, a, false);                                                 \
-                        flushed = true; since_flush = 0;                                                                  \
+                        BRC_FLUSH()                                                                                       \
                     }                                                                                                     \
                     const bool mine = ((mask >> lane) & 1ull) != 0ull;                                                    \
                     const int32_t s_c = p0 - H.a;                                                                         \
@@ -802,8 +811,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn i
                 qn = 0;                                                                                                   \
             }                                                                                                             \
             if (__builtin_expect(since_flush + HALF > c.flush_k, 0)) {                                                    \
-                if (valid) lane2_flush(c, pl, lib, kk, a, flushed);                                                       \
-                flushed = true; since_flush = 0;                                                                          \
+                BRC_FLUSH()                                                                                               \
             }                                                                                                             \
             if (base + 2u * (uint32_t)HALF < hi) {                                                                        \
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                               \
@@ -845,6 +853,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn i
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R0.f), "+s"(R0.g), "+s"(R1.f), "+s"(R1.g), "+s"(R2.f), "+s"(R2.g));   // no scalar load may outlive its registers
         asm volatile("" :: "v"(pf));
 #undef BRC_BOUNDARY
+#undef BRC_FLUSH
 #undef BRC_STEP
 #undef BRC_ACC
 #undef BRC_PROBE
@@ -860,7 +869,6 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn i
         pl.ncol[(int64_t)lib * P + k] = a.ncol;                            // (dead lanes accumulated nothing: zeros)
         pl.depth[(int64_t)lib * P + k] = a.depth;
         pl.slotid[(int64_t)lib * P + k] = a.dom_b | (a.alt_b << 8);
-        a.w_sm += ((a.dom.w1 >> 18) & 63u) + ((a.alt.w1 >> 18) & 63u); a.w_nm += ((a.dom.w1 >> 24) & 63u) + ((a.alt.w1 >> 24) & 63u);
         uint32_t dv[NI], av[NI];
         pack_unpack(a.dom, a.dom_b, dv); pack_unpack(a.alt, a.alt_b, av);
         uint32_t* i0 = slot_i(c, pl, lib, 0u, k); uint32_t* i1 = slot_i(c, pl, lib, 1u, k);
@@ -875,8 +883,8 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) void k_pileup2(DevCfg c, DevIn i
         for (int f = 0; f < NF; ++f) { f0[(int64_t)f * P] = a.dom.f[f]; f1[(int64_t)f * P] = a.alt.f[f]; }
     }
     unsigned long long ev = (valid && p >= c.beg0) ? a.ncol : 0u;
-    unsigned long long wsm = valid ? a.w_sm : 0u, wnm = valid ? a.w_nm : 0u, wl = (dead && lib == 0) ? 1u : 0u;
-    ev = wave_sum_u64(ev); wsm = wave_sum_u64(wsm); wnm = wave_sum_u64(wnm); wl = wave_sum_u64(wl);
+    unsigned long long wsm = valid ? (a.ww & 0xffffu) : 0u, wnm = valid ? (a.ww >> 16) : 0u, wl = (dead && lib == 0) ? 1u : 0u;
+    ev = wave_sum_u64(ev); wsm = wave_sum_u64(wsm) + wsm_tot; wnm = wave_sum_u64(wnm) + wnm_tot; wl = wave_sum_u64(wl);
     // per-(tile, library) partials; k_finalize sums them (a single-address atomic per wave costs ~12 ns x 780 k waves)
     if (lane == 0) tile_ctr[(int64_t)lib * ntiles + tile] = make_uint4((uint32_t)ev, (uint32_t)wsm, (uint32_t)wnm, (uint32_t)wl);
 }

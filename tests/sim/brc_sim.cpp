@@ -85,9 +85,10 @@ class SimBackend : public Backend {
                     if (fl & PF_NB) continue;                                                         // :343 with -i
                     const EvTerms t = (fl & PF_TABLE) ? piece_terms_tab(h, tt, c.table_len, qpos) : piece_terms_div(h, qpos);
                     const uint32_t b = w & 0xffu;
+                    a[l].ww += h.ww;
                     if (b == a[l].dom_b) { pack_event(a[l].dom, h, t, w); if (fl & PF_HUGE) { ints.lane[l] = true; any_int = true; } }
                     else if (a[l].alt_b == NB_NONE || a[l].alt_b == b) { a[l].alt_b = b; pack_event(a[l].alt, h, t, w); if (fl & PF_HUGE) { ints.lane[l] = true; any_int = true; } }
-                    else { full.lane[l] = true; any_full = true; a[l].w_sm += (fl & PF_SMW) ? 1u : 0u; a[l].w_nm += (fl & PF_NMW) ? 1u : 0u; }
+                    else { full.lane[l] = true; any_full = true; }
                 }
                 if (any_full) queue.push_back(full);
                 if (any_int) queue.push_back(ints);
@@ -119,7 +120,7 @@ class SimBackend : public Backend {
             if (!inreg[l]) continue;
             const bool dead = !valid[l];
             lane2_store(c, pl, lib, kk[l], a[l], dead, flushed && !dead);
-            if (!dead) { warn[BRC_W_SM_MISSING] += a[l].w_sm; warn[BRC_W_NM_MISSING] += a[l].w_nm; if (p[l] >= c.beg0) n_events += a[l].ncol; }
+            if (!dead) { warn[BRC_W_SM_MISSING] += a[l].ww & 0xffffu; warn[BRC_W_NM_MISSING] += a[l].ww >> 16; if (p[l] >= c.beg0) n_events += a[l].ncol; }
             if (dead && lib == 0) warn[BRC_W_LIB_UNAVAILABLE]++;
         }
     }

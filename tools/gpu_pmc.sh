@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
 rm -f gpurun_out/pmc.log
 run_pmc() {
   rm -rf gpurun_out/pmc_$1
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d "$OLDPWD/gpurun_out/pmc_$1" -o pmc -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --cpu-sample-mbp 0 ${BENCH_ARGS:-} ) > gpurun_out/pmc_$1.log 2>&1
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d "$OLDPWD/gpurun_out/pmc_$1" -o pmc -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --cpu-sample-mbp 0 --e2e-mbp 0 ${BENCH_ARGS:-} ) > gpurun_out/pmc_$1.log 2>&1
   f=$(find gpurun_out/pmc_$1 -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python - "$f" <<'PY' | tee -a gpurun_out/pmc.log
 import csv, sys, collections
