@@ -6,8 +6,12 @@
 // informational stderr lines, same -l site-list and region semantics including the "fetch one base early" rule (:602).
 // What differs is below the callbacks: reads are batched and handed to the MI355X engine instead of bam_plbuf.
 //
-// Not reproduced (documented in DESIGN.md): per-read WARNING lines on stderr are summarised as counts; whole-file mode
-// without region or site list (the reference marks it FIXME and produces degraded output) is refused; CRAM input.
+// Not reproduced (documented in DESIGN.md): whole-file mode without region or site list (the reference marks it FIXME
+// and produces degraded output) is refused.
+//
+// Engine-side options (not in the reference): --brc-chunk (tiling of long regions), --brc-plan (site-list planner),
+// --brc-gpus N / BRC_DEVICES=0,1,.. (one engine + worker thread per GPU; work items — region pieces, site-list batches —
+// are dealt out in file order and their text is written in file order).
 #include <errno.h>
 #include <limits.h>
 #include <stdio.h>
@@ -31,6 +35,7 @@ struct Options {
     std::vector<std::string> regions;
     long long chunk_bp = 1000000;   // engine-side tiling of long regions (not a reference option): --brc-chunk
     long long plan_sites = 4096;    // site-list planner: -l lines batched per engine pass (0 = one pass per line): --brc-plan
+    long long gpus = 1;             // engines (one per GPU): --brc-gpus
 };
 
 static const char* kUsage =
@@ -62,7 +67,7 @@ struct OptSpec { char s; const char* l; bool takes_value; };
 static const OptSpec kSpecs[] = {
     {'h', "help", false}, {'v', "version", false}, {'q', "min-mapping-quality", true}, {'b', "min-base-quality", true},
     {'d', "max-count", true}, {'l', "site-list", true}, {'f', "reference-fasta", true}, {'D', "print-individual-mapq", true},
-    {'p', "per-library", false}, {'w', "max-warnings", true}, {'i', "insertion-centric", false}, {0, "brc-chunk", true}, {1, "brc-plan", true},
+    {'p', "per-library", false}, {'w', "max-warnings", true}, {'i', "insertion-centric", false}, {0, "brc-chunk", true}, {1, "brc-plan", true}, {2, "brc-gpus", true},
 };
 
 static bool apply(Options& o, const OptSpec& sp, const std::string& v, std::string* err) {
@@ -85,6 +90,7 @@ static bool apply(Options& o, const OptSpec& sp, const std::string& v, std::stri
         case 'f': o.fasta = v; return true;
         case 'D': o.distribution = (v == "1" || v == "true" || v == "yes" || v == "on"); return true;
         case 1: if (!to_ll(&x)) return false; o.plan_sites = x; return true;
+        case 2: if (!to_ll(&x)) return false; o.gpus = x; return true;
         default: if (!to_ll(&x)) return false; o.chunk_bp = x; return true;
     }
 }
@@ -117,7 +123,7 @@ static bool parse_args(int argc, char** argv, Options& o, std::string* err) {
         }
         for (size_t k = 1; k < a.size(); ++k) {              // short options, sticky
             const OptSpec* hit = nullptr;
-            for (const OptSpec& sp : kSpecs) if (sp.s > 1 && sp.s == a[k]) hit = &sp;
+            for (const OptSpec& sp : kSpecs) if (sp.s > 2 && sp.s == a[k]) hit = &sp;
             if (!hit) { *err = std::string("unrecognised option '-") + a[k] + "'"; return false; }
             if (hit->takes_value) {
                 std::string v = a.substr(k + 1);
@@ -177,6 +183,11 @@ struct Ctx {
     int ref_tid = -1; std::string ref;      // currently loaded contig (load_reference, :83-90)
     Batcher batch;
     uint64_t warn[BRC_N_WARN] = {0, 0, 0, 0};
+    // where a work item's text goes: straight to stdout / stderr (one engine), or into the item's buffers (several engines:
+    // the main thread writes them in file order)
+    std::string* out_buf = nullptr; std::string* err_buf = nullptr;
+    void emit(const char* t, size_t n) { if (!n) return; if (out_buf) out_buf->append(t, n); else fwrite(t, 1, n, stdout); }
+    void complain(const std::string& m) { if (err_buf) err_buf->append(m); else fputs(m.c_str(), stderr); }
 };
 
 static int lib_index(const Ctx& c, const BamRecord& r) {      // bam_get_library: RG tag -> @RG ID -> LB
@@ -227,7 +238,8 @@ static void fetch_chunk(Ctx& c, int tid, int64_t a, int64_t b, Fetched& out) {
 }
 
 // one reporting window [beg0,end) on tid: the body of the site-list / region loops (:588-605, :649-656)
-static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode) {
+// keep_queue: the first piece keeps the deletions the previous command-line region left pending (like the reference, :641-657)
+static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode, bool keep_queue = true) {
     const BamHeader& h = c.header();
     if (c.have_fa && tid != c.ref_tid) {
         if (!c.fa.fetch(h.names[(size_t)tid], &c.ref)) c.ref.clear();
@@ -247,7 +259,7 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
     do {
         const int64_t b = std::min<int64_t>(a + c.opt.chunk_bp, end);
         Fetched& F = bufs[cur];
-        if (!F.ok) { fprintf(stderr, "bam-readcount: read error: %s\n", F.err.c_str()); return 1; }
+        if (!F.ok) { c.complain("bam-readcount: read error: " + F.err + "\n"); return 1; }
         std::thread pre;
         const bool more = b < end;
         if (more) pre = std::thread([&c, tid, b, end, &bufs, cur]() { fetch_chunk(c, tid, b, std::min<int64_t>(b + c.opt.chunk_bp, end), bufs[cur ^ 1]); });
@@ -255,7 +267,7 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
         // an internal piece boundary is not a region boundary: the deletions left pending by the previous piece start at its
         // last position, which is this piece's lead position and queues them again — drop the leftovers (the FIRST piece
         // keeps whatever the previous command-line region left, like the reference, :641-657)
-        if (a > beg0) brc_clear_indel_queue(c.eng);
+        if (a > beg0 || !keep_queue) brc_clear_indel_queue(c.eng);
         int rc = brc_begin_region(c.eng, tid, (int32_t)a, (int32_t)b, ref, (int64_t)c.ref.size());
         for (const Batcher& part : F.parts) {
             if (rc || part.pos.empty()) continue;
@@ -267,11 +279,11 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
         double t2 = now_s(); c.t_engine += t2 - t1;
         if (!rc) rc = brc_format_region(c.eng, &res, h.names[(size_t)tid].c_str(), &text, &len);
         double t3 = now_s(); c.t_format += t3 - t2;
-        if (!rc && len) fwrite(text, 1, len, stdout);
+        if (!rc) c.emit(text, len);
         double t4 = now_s(); c.t_write += t4 - t3;
         if (pre.joinable()) pre.join();
         c.t_fetch += now_s() - t4;                  // only the part of the background fetch that was not hidden
-        if (rc) { fprintf(stderr, "bam-readcount: engine error %d: %s (%s)\n", rc, brc_strerror(rc), brc_last_error(c.eng)); return 1; }
+        if (rc) { c.complain(std::string("bam-readcount: engine error: ") + brc_strerror(rc) + " (" + brc_last_error(c.eng) + ")\n"); return 1; }
         for (int w = 0; w < BRC_N_WARN; ++w) c.warn[w] += res.warn[w];
         a = b; cur ^= 1;
     } while (a < end);
@@ -319,49 +331,57 @@ static int run_site_batch(Ctx& c, const std::vector<Site>& sites) {
     for (unsigned k = 1; k < nthr && k < n; ++k) th.emplace_back(work);
     work();
     for (std::thread& t : th) t.join();
-    if (failed) { fprintf(stderr, "bam-readcount: read error while fetching sites\n"); return 1; }
-    // virtual layout
+    if (failed) { c.complain("bam-readcount: read error while fetching sites\n"); return 1; }
+    // Virtual layout, in sub-batches: the engine keeps planes for every virtual position, and a window's extent is known
+    // only now (it includes the overhang of its reads — with long reads far more than the line asked for), so the batch is
+    // cut wherever the axis would outgrow the chunk size.  A window wider than that runs alone.
+    static const long long vmax_env = getenv("BRC_PLAN_VMAX") ? atoll(getenv("BRC_PLAN_VMAX")) : 0;   // (tests force tiny sub-batches)
+    const int64_t vmax = vmax_env > 0 ? vmax_env : std::max<int64_t>(4 * c.opt.chunk_bp, 1 << 20);
     std::vector<int64_t> delta(n);
-    int64_t V = 1;
-    for (size_t i = 0; i < n; ++i) { delta[i] = V - lo[i]; V += (hi[i] - lo[i]) + 1; }
-    std::string vref;
-    if (c.have_fa) vref.assign((size_t)V + 1, '\0');
-    Batcher all;
-    for (size_t i = 0; i < n; ++i) {
-        const Site& st = sites[i];
-        if (c.have_fa) {
-            if (st.tid != c.ref_tid) { if (!c.fa.fetch(h.names[(size_t)st.tid], &c.ref)) c.ref.clear(); c.ref_tid = st.tid; }
-            // past the contig: the annotator stops at the terminating NUL (x == len, :151) but merely skips positions
-            // x > len (site-list mode, :144-148); 'N' reproduces the skip (it never counts as a mismatch, :152)
-            const int64_t clen = (int64_t)c.ref.size();
-            for (int64_t x = lo[i]; x < hi[i]; ++x)
-                if (x >= 0) vref[(size_t)(x + delta[i])] = x < clen ? c.ref[(size_t)x] : (x == clen ? '\0' : 'N');
+    for (size_t i0 = 0; i0 < n;) {
+        int64_t V = 1; size_t i1 = i0;
+        while (i1 < n && (i1 == i0 || V + (hi[i1] - lo[i1]) + 1 <= vmax)) { delta[i1] = V - lo[i1]; V += (hi[i1] - lo[i1]) + 1; ++i1; }
+        if (V >= (int64_t)INT_MAX - 64) { c.complain("bam-readcount: a site-list window is too wide for the planner; rerun with --brc-plan 0\n"); return 1; }
+        std::string vref;
+        if (c.have_fa) vref.assign((size_t)V + 1, '\0');
+        Batcher all;
+        for (size_t i = i0; i < i1; ++i) {
+            const Site& st = sites[i];
+            if (c.have_fa) {
+                if (st.tid != c.ref_tid) { if (!c.fa.fetch(h.names[(size_t)st.tid], &c.ref)) c.ref.clear(); c.ref_tid = st.tid; }
+                // past the contig: the annotator stops at the terminating NUL (x == len, :151) but merely skips positions
+                // x > len (site-list mode, :144-148); 'N' reproduces the skip (it never counts as a mismatch, :152)
+                const int64_t clen = (int64_t)c.ref.size();
+                for (int64_t x = lo[i]; x < hi[i]; ++x)
+                    if (x >= 0) vref[(size_t)(x + delta[i])] = x < clen ? c.ref[(size_t)x] : (x == clen ? '\0' : 'N');
+            }
+            const Batcher& b = parts[i];
+            const uint64_t cb = all.cigar.size(), sb = all.seq4.size(), qb = all.qual.size();
+            for (size_t k = 0; k < b.pos.size(); ++k) {
+                all.pos.push_back((int32_t)(b.pos[k] + delta[i])); all.flag.push_back(b.flag[k]); all.mapq.push_back(b.mapq[k]); all.lib.push_back(b.lib[k]);
+                all.l_qseq.push_back(b.l_qseq[k]); all.n_cigar.push_back(b.n_cigar[k]); all.nm.push_back(b.nm[k]); all.sm.push_back(b.sm[k]); all.tags.push_back(b.tags[k]);
+                all.cig_off.push_back(b.cig_off[k] + cb); all.seq_off.push_back(b.seq_off[k] + sb); all.qual_off.push_back(b.qual_off[k] + qb);
+            }
+            all.cigar.insert(all.cigar.end(), b.cigar.begin(), b.cigar.end());
+            all.seq4.insert(all.seq4.end(), b.seq4.begin(), b.seq4.end());
+            all.qual.insert(all.qual.end(), b.qual.begin(), b.qual.end());
         }
-        const Batcher& b = parts[i];
-        const uint64_t cb = all.cigar.size(), sb = all.seq4.size(), qb = all.qual.size();
-        for (size_t k = 0; k < b.pos.size(); ++k) {
-            all.pos.push_back((int32_t)(b.pos[k] + delta[i])); all.flag.push_back(b.flag[k]); all.mapq.push_back(b.mapq[k]); all.lib.push_back(b.lib[k]);
-            all.l_qseq.push_back(b.l_qseq[k]); all.n_cigar.push_back(b.n_cigar[k]); all.nm.push_back(b.nm[k]); all.sm.push_back(b.sm[k]); all.tags.push_back(b.tags[k]);
-            all.cig_off.push_back(b.cig_off[k] + cb); all.seq_off.push_back(b.seq_off[k] + sb); all.qual_off.push_back(b.qual_off[k] + qb);
+        int rc = brc_begin_region(c.eng, 0, 1, (int32_t)V, c.have_fa ? vref.data() : nullptr, V);
+        const brc_read_batch v = all.view();
+        if (!rc) rc = brc_push_reads(c.eng, &v);
+        brc_result res;
+        if (!rc) rc = brc_end_region(c.eng, &res);
+        if (rc) { c.complain(std::string("bam-readcount: engine error: ") + brc_strerror(rc) + " (" + brc_last_error(c.eng) + ")\n"); return 1; }
+        for (size_t i = i0; i < i1; ++i) {
+            const Site& st = sites[i];
+            const char* text = ""; size_t len = 0;
+            rc = brc_format_window(c.eng, &res, h.names[(size_t)st.tid].c_str(), (int32_t)(st.beg0 + delta[i]), (int32_t)(st.end + delta[i]), (int32_t)delta[i], &text, &len);
+            if (rc) { c.complain(std::string("bam-readcount: engine error: ") + brc_strerror(rc) + "\n"); return 1; }
+            c.emit(text, len);
         }
-        all.cigar.insert(all.cigar.end(), b.cigar.begin(), b.cigar.end());
-        all.seq4.insert(all.seq4.end(), b.seq4.begin(), b.seq4.end());
-        all.qual.insert(all.qual.end(), b.qual.begin(), b.qual.end());
+        for (int w = 0; w < BRC_N_WARN; ++w) c.warn[w] += res.warn[w];
+        i0 = i1;
     }
-    int rc = brc_begin_region(c.eng, 0, 1, (int32_t)V, c.have_fa ? vref.data() : nullptr, V);
-    const brc_read_batch v = all.view();
-    if (!rc) rc = brc_push_reads(c.eng, &v);
-    brc_result res;
-    if (!rc) rc = brc_end_region(c.eng, &res);
-    if (rc) { fprintf(stderr, "bam-readcount: engine error %d: %s (%s)\n", rc, brc_strerror(rc), brc_last_error(c.eng)); return 1; }
-    for (size_t i = 0; i < n; ++i) {
-        const Site& st = sites[i];
-        const char* text = ""; size_t len = 0;
-        rc = brc_format_window(c.eng, &res, h.names[(size_t)st.tid].c_str(), (int32_t)(st.beg0 + delta[i]), (int32_t)(st.end + delta[i]), (int32_t)delta[i], &text, &len);
-        if (rc) { fprintf(stderr, "bam-readcount: engine error %d: %s\n", rc, brc_strerror(rc)); return 1; }
-        if (len) fwrite(text, 1, len, stdout);
-    }
-    for (int w = 0; w < BRC_N_WARN; ++w) c.warn[w] += res.warn[w];
     return 0;
 }
 
@@ -383,6 +403,55 @@ static bool parse_region(const BamHeader& h, const std::string& s, int* tid, int
     return *beg < *end;
 }
 
+// ---------------------------------------------------------------- work items and engines
+// The command line is turned into work items in file order: a site-list batch (narrow -l lines, planner), or a piece of a
+// region / wide -l line.  One engine: the items run one after the other on it.  Several engines (--brc-gpus N, one per
+// GPU, each with a worker thread and its own file handles): item i goes to engine i mod N — except the first piece of a
+// command-line region, which follows the last piece of the previous region onto its engine, because it must see the
+// deletions that piece left pending (the reference does not clear its queue between command-line regions, :641-657) —
+// and the main thread writes the items' text in file order.
+#include <condition_variable>
+#include <mutex>
+
+struct Work {
+    int kind = 0;                     // 0: region piece, 1: site-list batch
+    int tid = 0; int64_t beg0 = 0, end = 0; bool site_mode = false, keep_queue = false;
+    std::vector<Site> sites;
+    int engine = 0;
+    std::string out, err; int rc = 0; bool done = false;
+};
+
+static int run_item(Ctx& c, Work& w) {
+    if (w.kind == 1) return run_site_batch(c, w.sites);
+    return run_region(c, w.tid, w.beg0, w.end, w.site_mode, w.keep_queue);
+}
+
+static bool open_inputs(Ctx& c, bool quiet) {
+    const Options& o = c.opt;
+    if (!o.fasta.empty()) {
+        if (!c.fa.open(o.fasta)) { if (!quiet) fprintf(stderr, "Fail to open reference file %s\n", o.fasta.c_str()); return false; }
+        c.have_fa = true;
+    }
+    c.is_cram = CramReader::is_cram(o.bam);
+    if (c.is_cram ? !c.cram.open(o.bam, c.have_fa ? &c.fa : nullptr) : !c.bam.open(o.bam)) {                                               // :513-516
+        if (!quiet) { fprintf(stderr, "Fail to open BAM file %s\n", o.bam.c_str()); if (c.is_cram) fprintf(stderr, "bam-readcount: %s\n", c.cram.error().c_str()); }
+        return false;
+    }
+    c.libs = c.header().libraries();
+    return true;
+}
+
+static int make_engine(Ctx& c, int device) {
+    const Options& o = c.opt;
+    std::vector<const char*> names; for (const std::string& l : c.libs) names.push_back(l.c_str());
+    brc_config cfg; memset(&cfg, 0, sizeof cfg);
+    cfg.abi_version = BRC_ABI_VERSION; cfg.min_mapq = o.min_mapq; cfg.min_bq = o.min_bq; cfg.max_cnt = o.max_cnt;
+    cfg.per_lib = o.per_lib; cfg.insertion_centric = o.insertion_centric; cfg.n_libs = (int32_t)names.size();
+    cfg.lib_names = names.empty() ? nullptr : names.data(); cfg.device = device;
+    cfg.ref_len_check = (!o.site_list.empty() && c.have_fa) ? 1 : 0;                                                                        // :594-600
+    return brc_create(&cfg, &c.eng);
+}
+
 int main(int argc, char** argv) {
     Ctx c; std::string err;
     if (!parse_args(argc, argv, c.opt, &err)) { fprintf(stderr, "bam-readcount: %s\n", err.c_str()); return 1; }
@@ -390,68 +459,141 @@ int main(int argc, char** argv) {
     if (o.version) { printf("bam-readcount version: 1.0.1-mi355x (engine %s, abi %d)\n", brc_engine_kind(), BRC_ABI_VERSION); return 1; }   // :467-470
     if (o.help || o.bam.empty()) { fputs(kUsage, stdout); fputs("\n", stdout); return 1; }                                                   // :472-475
     fprintf(stderr, "Minimum mapping quality is set to %d\n", o.min_mapq);                                                                 // :477
-    if (!o.fasta.empty()) {
-        if (!c.fa.open(o.fasta)) { fprintf(stderr, "Fail to open reference file %s\n", o.fasta.c_str()); return 1; }
-        c.have_fa = true;
-    }
-    c.is_cram = CramReader::is_cram(o.bam);
-    if (c.is_cram ? !c.cram.open(o.bam, c.have_fa ? &c.fa : nullptr) : !c.bam.open(o.bam)) {                                               // :513-516
-        fprintf(stderr, "Fail to open BAM file %s\n", o.bam.c_str());
-        if (c.is_cram) fprintf(stderr, "bam-readcount: %s\n", c.cram.error().c_str());
-        return 1;
-    }
-    c.libs = c.header().libraries();
+    if (!open_inputs(c, false)) return 1;
     for (const std::string& l : c.libs) fprintf(stderr, "Expect library: %s in BAM\n", l.c_str());                                         // :526-529
     if (o.distribution) { fprintf(stderr, "Not currently supporting distributions\n"); return 1; }                                          // :367 (the reference throws)
-    std::vector<const char*> names; for (const std::string& l : c.libs) names.push_back(l.c_str());
-    brc_config cfg; memset(&cfg, 0, sizeof cfg);
-    cfg.abi_version = BRC_ABI_VERSION; cfg.min_mapq = o.min_mapq; cfg.min_bq = o.min_bq; cfg.max_cnt = o.max_cnt;
-    cfg.per_lib = o.per_lib; cfg.insertion_centric = o.insertion_centric; cfg.n_libs = (int32_t)names.size();
-    cfg.lib_names = names.empty() ? nullptr : names.data(); cfg.device = getenv("BRC_DEVICE") ? atoi(getenv("BRC_DEVICE")) : 0;
-    cfg.ref_len_check = (!o.site_list.empty() && c.have_fa) ? 1 : 0;                                                                        // :594-600
     // -d below any real depth changes which reads bam_plp_push keeps, and that depends on everything buffered before:
     // no internal pieces then (the planner is off for the same reason)
     if (o.max_cnt < 1000000) c.opt.chunk_bp = (long long)INT_MAX;
-    int rc = brc_create(&cfg, &c.eng);
+    // devices: BRC_DEVICES=0,2,3 or --brc-gpus N (devices 0..N-1); BRC_DEVICE=k for a single engine
+    std::vector<int> devices;
+    if (const char* dv = getenv("BRC_DEVICES")) { for (const char* q = dv; *q;) { devices.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q) ++q; } }
+    if (devices.empty()) for (long long g = 0; g < std::max<long long>(o.gpus, 1); ++g) devices.push_back((o.gpus <= 1 && getenv("BRC_DEVICE")) ? atoi(getenv("BRC_DEVICE")) : (int)g);
+    const size_t N = devices.size();
+    int rc = make_engine(c, devices[0]);
     if (rc) { fprintf(stderr, "bam-readcount: cannot create the MI355X engine: %s\n", brc_strerror(rc)); return 1; }
+
+    // ---- the work items, in file order
+    std::vector<Work> items;
     int ret = 0;
+    auto add_region = [&](int tid, int64_t beg0, int64_t end, bool site_mode) {
+        // one engine: the region as a whole (run_region cuts it and fetches the next piece in the background); several:
+        // its pieces become items of their own so that they spread over the GPUs
+        const BamHeader& h = c.header();
+        if (end > (int64_t)h.lengths[(size_t)tid] + 1000) end = (int64_t)h.lengths[(size_t)tid] + 1000;
+        if (end < beg0) end = beg0;
+        const int64_t step = N > 1 ? (int64_t)c.opt.chunk_bp : (int64_t)INT_MAX;
+        bool first = true;
+        int64_t a = beg0;
+        do {
+            const int64_t b = std::min<int64_t>(a + step, end);
+            Work w; w.kind = 0; w.tid = tid; w.beg0 = a; w.end = b; w.site_mode = site_mode && b >= end;
+            w.keep_queue = first && !site_mode;       // a -l line starts from an empty queue (:605 cleared it after the previous line)
+            items.push_back(std::move(w));
+            first = false; a = b;
+        } while (a < end);
+    };
     if (!o.site_list.empty()) {
         FILE* fp = fopen(o.site_list.c_str(), "r");
         if (!fp) { fprintf(stderr, "Failed to open region list file: %s\n", o.site_list.c_str()); brc_destroy(c.eng); return 1; }            // :535-538
         if (!c.is_cram && !c.idx.load(o.bam)) { fprintf(stderr, "BAM indexing file is not available.\n"); brc_destroy(c.eng); return 1; }                  // :548-551
-        // the planner needs -d to be out of play (its drop rule depends on what else is buffered) and short windows
+        // the planner needs -d to be out of play (its drop rule depends on what else is buffered) and narrow lines
         const bool plan = o.plan_sites > 0 && o.max_cnt >= 1000000 && !c.is_cram;
-        std::vector<Site> pending; int64_t pending_bp = 0;
-        auto flush = [&]() { int r = 0; if (!pending.empty()) { r = run_site_batch(c, pending); pending.clear(); pending_bp = 0; } return r; };
+        Work pend; pend.kind = 1; int64_t pend_bp = 0;
+        auto flush = [&]() { if (!pend.sites.empty()) { items.push_back(std::move(pend)); pend = Work(); pend.kind = 1; pend_bp = 0; } };
         char line[65536];
         while (fgets(line, sizeof line, fp)) {                                       // ss >> ref_name >> beg >> end (:574-577)
             char name[4096]; int beg, end;
             if (sscanf(line, "%4095s %d %d", name, &beg, &end) != 3) continue;
             auto it = c.header().name2tid.find(name);
-            if (it == c.header().name2tid.end()) { fprintf(stderr, "%s not found in bam file. Region %s %i %i skipped.\n", name, name, beg, end); continue; }   // :580-582
+            if (it == c.header().name2tid.end()) {                                   // :580-582 (printed when the line is read, like the reference)
+                fprintf(stderr, "%s not found in bam file. Region %s %i %i skipped.\n", name, name, beg, end); continue;
+            }
             if (beg < 1) beg = 1;
-            if (plan && (int64_t)end - beg < 100000) {
+            if (plan && (int64_t)end - beg < 1000) {
                 Site st; st.tid = it->second; st.beg0 = (int64_t)beg - 1; st.end = end < beg - 1 ? beg - 1 : end;
-                pending.push_back(st); pending_bp += (st.end - st.beg0) + 2000;
-                if ((long long)pending.size() >= o.plan_sites || pending_bp > 200000000) { if ((ret = flush())) break; }
+                const int64_t clen = (int64_t)c.header().lengths[(size_t)st.tid];
+                if (st.end > clen + 1000) st.end = std::max<int64_t>(clen + 1000, st.beg0);
+                pend.sites.push_back(st); pend_bp += (st.end - st.beg0) + 600;
+                if ((long long)pend.sites.size() >= o.plan_sites || pend_bp > 4 * (int64_t)c.opt.chunk_bp) flush();
                 continue;
             }
-            if ((ret = flush())) break;
-            if ((ret = run_region(c, it->second, (int64_t)beg - 1, end, true))) break;
+            flush();
+            add_region(it->second, (int64_t)beg - 1, end, true);
         }
-        if (!ret) ret = flush();
+        flush();
         fclose(fp);
     } else if (!o.regions.empty()) {
         if (!c.is_cram && !c.idx.load(o.bam)) { fprintf(stderr, "BAM indexing file is not available.\n"); brc_destroy(c.eng); return 1; }                  // :637-640
         for (const std::string& r : o.regions) {
             int tid; int64_t beg, end;
-            if (!parse_region(c.header(), r, &tid, &beg, &end)) { fprintf(stderr, "Invalid region %s\n", r.c_str()); ret = 1; break; }   // :645-648
-            if ((ret = run_region(c, tid, beg, end, false))) break;
+            if (!parse_region(c.header(), r, &tid, &beg, &end)) {                    // :645-648: the regions before it have been printed
+                Work w; w.kind = 2; w.err = "Invalid region " + r + "\n"; w.rc = 1; items.push_back(std::move(w)); break;
+            }
+            add_region(tid, beg, end, false);
         }
     } else {
         fprintf(stderr, "bam-readcount: give a region or a site list (-l); the reference's whole-file mode skips its per-read "
                         "pre-processing (bamreadcount.cpp:624 FIXME) and is not reproduced\n");
-        ret = 1;
+        brc_destroy(c.eng);
+        return 1;
+    }
+
+    if (N == 1) {
+        for (Work& w : items) {
+            if (w.kind == 2) { fputs(w.err.c_str(), stderr); ret = 1; break; }
+            if ((ret = run_item(c, w))) break;
+        }
+    } else {
+        // engine of every item: round robin, the first piece of a command-line region after the region before it
+        int last_engine = -1; size_t rr = 0;
+        for (Work& w : items) {
+            if (w.kind == 0 && w.keep_queue && last_engine >= 0) w.engine = last_engine;
+            else w.engine = (int)(rr++ % N);
+            last_engine = w.engine;
+        }
+        std::vector<std::unique_ptr<Ctx> > ctxs(N);
+        std::mutex mu; std::condition_variable cv;
+        size_t printed = 0; bool abort_all = false;
+        auto worker = [&](size_t g) {
+            Ctx* wc = &c;
+            if (g > 0) {                                                             // own handles, own engine
+                ctxs[g].reset(new Ctx()); wc = ctxs[g].get(); wc->opt = c.opt;
+                bool ok = open_inputs(*wc, true) && (wc->is_cram || wc->idx.load(c.opt.bam)) && make_engine(*wc, devices[g]) == 0;
+                if (!ok) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    for (Work& w : items) if ((size_t)w.engine == g && !w.done) { w.rc = 1; w.err = "bam-readcount: cannot set up the engine of GPU " + std::to_string(devices[g]) + "\n"; w.done = true; }
+                    cv.notify_all(); return;
+                }
+            }
+            for (size_t i = 0; i < items.size(); ++i) {
+                Work& w = items[i];
+                if ((size_t)w.engine != g) continue;
+                {   // bound the text held in memory: stay within 4 N items of the one being written
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&]() { return abort_all || i < printed + 4 * N; });
+                    if (abort_all) return;
+                }
+                int r = w.rc;
+                if (w.kind != 2) { wc->out_buf = &w.out; wc->err_buf = &w.err; r = run_item(*wc, w); }
+                std::lock_guard<std::mutex> lk(mu);
+                w.rc = r; w.done = true; cv.notify_all();
+            }
+        };
+        std::vector<std::thread> th;
+        for (size_t g = 0; g < N; ++g) th.emplace_back(worker, g);
+        for (size_t i = 0; i < items.size(); ++i) {
+            Work& w = items[i];
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return w.done; }); }
+            if (!w.out.empty()) fwrite(w.out.data(), 1, w.out.size(), stdout);
+            if (!w.err.empty()) fputs(w.err.c_str(), stderr);
+            std::string().swap(w.out);
+            { std::lock_guard<std::mutex> lk(mu); printed = i + 1; if (w.rc) { abort_all = true; ret = 1; } cv.notify_all(); }
+            if (ret) break;
+        }
+        { std::lock_guard<std::mutex> lk(mu); abort_all = abort_all || ret != 0; printed = items.size(); cv.notify_all(); }
+        for (std::thread& t : th) t.join();
+        for (size_t g = 1; g < N; ++g) if (ctxs[g]) { for (int w = 0; w < BRC_N_WARN; ++w) c.warn[w] += ctxs[g]->warn[w]; if (ctxs[g]->eng) brc_destroy(ctxs[g]->eng); }
     }
     static const char* wn[BRC_N_WARN] = {"SM tag missing", "NM tag missing", "generated tag missing", "library unavailable"};
     for (int w = 0; w < BRC_N_WARN; ++w)

@@ -166,11 +166,75 @@ def test_site_list_planner_equals_line_by_line_cpu(synthetic_bam):
     _planner_check(SIM_CLI, synthetic_bam)
 
 
+def test_site_list_planner_sub_batches_cpu(synthetic_bam, monkeypatch):
+    """A batch whose windows (with the overhang of their reads) outgrow the chunk size is cut into several engine passes:
+    BRC_PLAN_VMAX forces a cut every few windows; the text must not change."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    want = _planner_check(SIM_CLI, synthetic_bam)
+    monkeypatch.setenv("BRC_PLAN_VMAX", "700")
+    assert _planner_check(SIM_CLI, synthetic_bam) == want
+
+
+def _multi_engine_check(cli, d):
+    """--brc-gpus N: region pieces and site-list batches dealt out to N engines must print, in file order, exactly what one
+    engine prints — including a deletion pending across two abutting command-line regions (the first piece of a region
+    follows the previous region onto its engine) and pieces cut inside deletions."""
+    rng = np.random.default_rng(11)
+    sites = [("chrA", int(p), int(p)) for p in rng.integers(1, 5000, 200)] + [("chrB", 10, 2500), ("chrA", 300, 2900), ("chrB", 5, 5)]
+    sl = _sites_file(d, "sites_multi.txt", sites)
+    runs = [["-f", "syn.fa", "syn.bam", "chrA:1-2000", "chrA:2001-5000", "chrB", "chrA:100-100"],
+            ["-p", "-i", "-f", "syn.fa", "syn.bam", "chrA", "chrB:1-1500", "chrB:1501-3000"],
+            ["-q", "10", "-b", "5", "-f", "syn.fa", "-l", sl, "--brc-plan", "16", "syn.bam"],
+            ["-p", "-f", "syn.fa", "-l", sl, "syn.bam"]]
+    for args in runs:
+        env1 = dict(os.environ); env1.pop("BRC_DEVICES", None)
+        one = subprocess.run([cli, "-w", "0", "--brc-chunk", "333"] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env1)
+        assert one.returncode == 0 and one.stdout.count(b"\n") > 1000, one.stderr
+        for n in ("2", "3"):
+            env = dict(os.environ); env.pop("BRC_DEVICES", None)
+            one_env = env                                            # (the single-engine runs ignore BRC_DEVICES)
+            many = subprocess.run([cli, "-w", "0", "--brc-chunk", "333", "--brc-gpus", n] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert many.returncode == 0, many.stderr
+            assert many.stdout == one.stdout, (args, n)
+        whole = subprocess.run([cli, "-w", "0"] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env1)
+        assert whole.stdout == one.stdout, args                  # and the tiling itself changes nothing
+    bad = subprocess.run([cli, "--brc-gpus", "2", "-f", "syn.fa", "syn.bam", "chrA:1-50", "nochr:1-2", "chrB:1-5"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert bad.returncode == 1 and b"Invalid region nochr:1-2" in bad.stderr and bad.stdout.startswith(b"chrA\t") and b"chrB" not in bad.stdout
+
+
+def test_cli_multi_engine_equals_single_cpu(synthetic_bam):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    _multi_engine_check(SIM_CLI, synthetic_bam)
+
+
+@pytest.mark.gpu
+def test_cli_multi_engine_equals_single_gpu(synthetic_bam, monkeypatch):
+    """The GPU box has one device: BRC_DEVICES=0,0,0 still creates one engine, stream and worker thread per entry."""
+    monkeypatch.setenv("BRC_DEVICES", "0,0,0")
+    _multi_engine_check(HIP_CLI, synthetic_bam)
+
+
 @pytest.mark.gpu
 def test_site_list_planner_equals_line_by_line_gpu(synthetic_bam):
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
     got = _planner_check(HIP_CLI, synthetic_bam)
     assert got == _planner_check(SIM_CLI, synthetic_bam)      # and the GPU binary prints what the CPU simulator prints
+
+
+def _records_to_arrays(recs, rg2lib):
+    """brc_read_batch arrays from the record dicts of tools/bamio.read_bam"""
+    a = dict(pos=np.array([r["pos"] for r in recs], np.int32), flag=np.array([r["flag"] for r in recs], np.uint16),
+             mapq=np.array([r["mapq"] for r in recs], np.uint8), l_qseq=np.array([r["l_seq"] for r in recs], np.int32),
+             lib=np.array([rg2lib.get(r["aux"].get("RG", (None, None))[1], -1) for r in recs], np.int16),
+             n_cigar=np.array([len(r["cigar"]) for r in recs], np.uint32),
+             nm=np.array([r["aux"]["NM"][1] if "NM" in r["aux"] else 0 for r in recs], np.int32),
+             sm=np.array([r["aux"]["SM"][1] if "SM" in r["aux"] else 0 for r in recs], np.int32),
+             tags=np.array([(1 if "NM" in r["aux"] else 0) | (2 if "SM" in r["aux"] else 0) for r in recs], np.uint8))
+    for arena, key, dt in (("cigar", "cigar", np.uint32), ("seq4", "seq4", np.uint8), ("qual", "qual", np.uint8)):
+        lens = np.array([len(r[key]) for r in recs], np.int64)
+        a[arena] = np.concatenate([r[key] for r in recs]).astype(dt) if recs else np.zeros(0, dt)
+        a[{"cigar": "cigar_off", "seq4": "seq_off", "qual": "qual_off"}[arena]] = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64) if recs else np.zeros(0, np.uint64)
+    return a
 
 
 def test_cli_bam_reader_region_equals_oracle_cpu(synthetic_bam, oracle_lib):
@@ -188,6 +252,17 @@ def test_cli_bam_reader_region_equals_oracle_cpu(synthetic_bam, oracle_lib):
     assert b"Expect library: libA in BAM" in got.stderr and b"Expect library: libB in BAM" in got.stderr
     assert got.stdout.count(b"\n") > 3000 and got.stdout.startswith(b"chrA\t1000\t")
     assert b"\tlibA\t{" in got.stdout and b"chrB\t" in got.stdout
+    # ... and byte for byte what the oracle prints for the records the test-side BAM decoder reads from the same file
+    # (command-line regions: the deletion queue is not cleared between them; a bare contig name runs to INT_MAX)
+    names = ["libA", "libB"]
+    want = b""
+    eng = capi.Engine(oracle_lib, per_lib=True, lib_names=names)
+    for tid, chrom, beg0, end in ((0, "chrA", 999, 1800), (1, "chrB", 0, 3000 + 1000), (0, "chrA", 0, 40)):
+        arrs = _records_to_arrays([r for r in recs if r["tid"] == tid], {"rgA1": 0, "rgB1": 1})
+        t, _ = capi.run_regions(eng, arrs, [(beg0, end)], tid, chrom, np.frombuffer(open(d / "syn.fa", "rb").read().split(b">")[tid + 1].split(b"\n", 1)[1].replace(b"\n", b""), np.uint8), clear_queue=False)
+        want += t
+    eng.close()
+    assert got.stdout == want
 
 
 def _cram_check(cli, oracle_lib, twolib):
