@@ -4,8 +4,8 @@ The path partitions by genomic interval with no exchange step: every output line
 overlap its position (plus the position before it for deletions, which the engine's lead position beg0-1 carries,
 bamreadcount.cpp:269/602).  So each rank takes a contiguous slice of the work list — the site list in FILE ORDER for
 -l, the region list for command-line regions, or equal sub-intervals of one long region — processes it independently,
-and rank 0 concatenates the per-rank text in rank order.  The only communication is the gather of the text (and the
-all-reduce of two counters for the metrics line); no collective touches pileup data.  With torch.distributed backend
+and rank 0 concatenates the per-rank text in rank order.  The only communication is the gather of the text as
+size-prefixed byte tensors (and the all-reduce of two counters for the metrics line); no collective touches pileup data.  With torch.distributed backend
 "nccl" (= RCCL on ROCm) on GPUs, "gloo" in the CPU tests.
 """
 import numpy as np
@@ -54,6 +54,26 @@ def run_sharded(lib, arrs, regions, tid, chrom, ref, dist=None, clear_queue=True
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     cnt = torch.tensor([ev, npos], dtype=torch.int64, device=dev)
     dist.all_reduce(cnt)                                    # metrics only: 16 bytes
-    gathered = [None] * world if rank == 0 else None
-    dist.gather_object(text, gathered, dst=0)               # ordered concatenation on rank 0
-    return (b"".join(gathered) if rank == 0 else None), (int(cnt[0]), int(cnt[1]))
+    return gather_text(text, dist), (int(cnt[0]), int(cnt[1]))
+
+
+def gather_text(text, dist):
+    """Ordered concatenation of the ranks' text on rank 0 as raw bytes: one all_gather of the sizes (8 bytes per rank), then
+    one padded uint8 all_gather (text of dense regions runs to gigabytes: no pickling, no per-object round trips)."""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    size = torch.tensor([len(text)], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, size)
+    sizes = [int(x.item()) for x in sizes]
+    cap = max(max(sizes), 1)
+    mine = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    if len(text):
+        mine[:len(text)] = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev)
+    if rank == 0:
+        bufs = [torch.zeros(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
+        dist.gather(mine, bufs, dst=0)
+        return b"".join(bytes(b[:n].cpu().numpy()) for b, n in zip(bufs, sizes))
+    dist.gather(mine, None, dst=0)
+    return None
