@@ -20,7 +20,7 @@ F_NAMES = ["sev", "sq2", "snm", "s3p"]
 EXPORTS = [
     "brc_strerror", "brc_last_error", "brc_kernel_name", "brc_engine_kind", "brc_create", "brc_destroy",
     "brc_begin_region", "brc_push_reads", "brc_upload", "brc_compute", "brc_fetch_result", "brc_end_region",
-    "brc_clear_indel_queue", "brc_region_counts", "brc_format_region", "brc_format_window",
+    "brc_clear_indel_queue", "brc_region_counts", "brc_format_region", "brc_format_window", "brc_region_warnings", "brc_window_warnings", "brc_warnings_text",
 ]
 
 
@@ -92,6 +92,11 @@ class Library:
         L.brc_clear_indel_queue.argtypes = [C.c_void_p]
         L.brc_region_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.brc_format_region.argtypes = [C.c_void_p, C.POINTER(Result), C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
+        if hasattr(L, "brc_region_warnings"):
+            L.brc_region_warnings.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
+            L.brc_warnings_text.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
+        if hasattr(L, "brc_window_warnings"):
+            L.brc_window_warnings.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
         L.brc_format_window.argtypes = [C.c_void_p, C.POINTER(Result), C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
 
     def kind(self):
@@ -138,6 +143,11 @@ def make_batch(arrs):
     b.seq_bytes = int(np.asarray(arrs["seq4"]).size)
     b.qual_bytes = int(np.asarray(arrs["qual"]).size)
     b.qname = None
+    if arrs.get("qname") is not None:                       # read names (warning text only)
+        names = [q if isinstance(q, bytes) else str(q).encode() for q in arrs["qname"]]
+        arr = (C.c_char_p * max(1, len(names)))(*names)
+        keep["qname"] = (names, arr)
+        b.qname = C.cast(arr, C.c_void_p)
     return b, keep
 
 
@@ -150,6 +160,8 @@ def select_reads(arrs, idx):
             out[k] = np.asarray(arrs[k])[idx]
         else:
             out[k] = None
+    if arrs.get("qname") is not None:
+        out["qname"] = [arrs["qname"][int(i)] for i in idx]
     ncig = np.asarray(arrs["n_cigar"])[idx].astype(np.int64)
     lq = np.asarray(arrs["l_qseq"])[idx].astype(np.int64)
     sb = (lq + 1) // 2
@@ -291,6 +303,34 @@ def _format_region_np(self, chrom):
 
 
 Engine.format_region_np = _format_region_np
+
+
+def _region_warnings(self, chrom, cap=-1):
+    """Tagged warning events of the last computed region (include/brc.h: brc_region_warnings), bytes."""
+    p = C.c_char_p(); n = C.c_size_t()
+    self._check(self.L.lib.brc_region_warnings(self.h, chrom.encode(), cap, C.byref(p), C.byref(n)))
+    return C.string_at(p, n.value)
+
+
+def _warnings_text(self, events, max_per_type, counts):
+    """ReadWarnings text of an event stream; `counts` (list of 4 ints) are the running per-type counters, updated in place."""
+    c = (C.c_int64 * NWARN)(*counts)
+    p = C.c_char_p(); n = C.c_size_t()
+    self._check(self.L.lib.brc_warnings_text(self.h, events, len(events), max_per_type, c, C.byref(p), C.byref(n)))
+    counts[:] = list(c)
+    return C.string_at(p, n.value)
+
+
+def _window_warnings(self, vbeg0, vend, cap=-1):
+    """Events of a stand-alone run over [vbeg0,vend) inside the last computed region (site-list planner; no bounds lines)."""
+    p = C.c_char_p(); n = C.c_size_t()
+    self._check(self.L.lib.brc_window_warnings(self.h, vbeg0, vend, cap, C.byref(p), C.byref(n)))
+    return C.string_at(p, n.value)
+
+
+Engine.region_warnings = _region_warnings
+Engine.window_warnings = _window_warnings
+Engine.warnings_text = _warnings_text
 
 
 def _format_window(self, chrom, vbeg0, vend, delta):

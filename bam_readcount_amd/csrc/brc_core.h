@@ -429,7 +429,7 @@ struct ReadConst {
 BRC_HD ReadConst read_const(const DevCfg& c, const DRead& rd, uint32_t read_index) {
     ReadConst rc;
     rc.pos = rd.pos; rc.l_qseq = rd.l_qseq; rc.clipped = rd.clipped; rc.left = rd.left; rc.tp = rd.tp; rc.q2 = rd.q2;
-    rc.flags = ((rd.misc & M_REV) ? PF_REV : 0u) | ((rd.misc & M_Q2OK) ? PF_Q2OK : 0u) | ((rd.misc & M_SMW) ? PF_SMW : 0u) | ((rd.misc & M_NMW) ? PF_NMW : 0u);
+    rc.flags = ((rd.misc & M_REV) ? (uint32_t)PF_REV : 0u) | ((rd.misc & M_Q2OK) ? (uint32_t)PF_Q2OK : 0u) | ((rd.misc & M_SMW) ? (uint32_t)PF_SMW : 0u) | ((rd.misc & M_NMW) ? (uint32_t)PF_NMW : 0u);
     rc.mapq = (rd.misc >> 8) & 0xffu; rc.zm = rd.zm_sum; rc.sse = rd.sse_add; rc.snm = rd.snm_add; rc.bq_off = rd.bq_off; rc.read = read_index;
     rc.counts = (int)rc.mapq >= c.min_mapq && !(rd.misc & M_NOCOUNT);
     return rc;

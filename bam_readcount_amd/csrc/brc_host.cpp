@@ -21,18 +21,18 @@ namespace brc {
 
 void Staged::init(const HostAlloc* A) {
     pos.A = A; flag.A = A; mapq.A = A; lib.A = A; l_qseq.A = A; n_cigar.A = A; cig_off.A = A; seq_off.A = A; qual_off.A = A;
-    nm.A = A; sm.A = A; tags.A = A; cigar.A = A; seq4.A = A; qual.A = A; bq_row.A = A; piece_cnt.A = A; piece_off.A = A;
+    nm.A = A; sm.A = A; tags.A = A; cigar.A = A; seq4.A = A; qual.A = A; bq_row.A = A; piece_cnt.A = A; piece_off.A = A; qnames.A = A; qname_off.A = A;
 }
 void Staged::clear() {
     pos.clear(); flag.clear(); mapq.clear(); lib.clear(); l_qseq.clear(); n_cigar.clear(); cig_off.clear(); seq_off.clear();
     qual_off.clear(); nm.clear(); sm.clear(); tags.clear(); cigar.clear(); seq4.clear(); qual.clear(); bq_row.clear();
     bq_elems = 0; memset(len_hist, 0, sizeof len_hist); n = 0; min_pos = 0; max_end = 0; n_indel_ops = 0;
-    piece_cnt.clear(); piece_off.clear(); lib_base.clear(); n_pieces = 0; max_lqseq = 0;
+    piece_cnt.clear(); piece_off.clear(); lib_base.clear(); n_pieces = 0; max_lqseq = 0; max_span = 0; qnames.clear(); qname_off.clear();
 }
 void Staged::destroy() {
     pos.destroy(); flag.destroy(); mapq.destroy(); lib.destroy(); l_qseq.destroy(); n_cigar.destroy(); cig_off.destroy();
     seq_off.destroy(); qual_off.destroy(); nm.destroy(); sm.destroy(); tags.destroy(); cigar.destroy(); seq4.destroy(); qual.destroy(); bq_row.destroy();
-    piece_cnt.destroy(); piece_off.destroy();
+    piece_cnt.destroy(); piece_off.destroy(); qnames.destroy(); qname_off.destroy();
 }
 // library-major slots: all pieces of library 0 in file order, then library 1, ... (one stream without -p)
 void Staged::layout_pieces(int Lp, bool per_lib) {
@@ -177,7 +177,7 @@ struct brc_engine {
     std::string alleles;
     std::vector<char> refbase;
     // formatter state
-    std::string text;
+    std::string text, wev, wtext;
     std::vector<std::deque<QEnt> > queue;
 };
 
@@ -265,6 +265,13 @@ int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
               s.seq4.append(b->seq4, b->seq_bytes) && s.qual.append(b->qual, b->qual_bytes) &&
               s.bq_row.reserve(n0 + n + 16) && s.piece_cnt.reserve(n0 + n + 16) && s.piece_off.reserve(n0 + n + 16) && s.lib.reserve(n0 + n + 16) && s.nm.reserve(n0 + n + 16) && s.sm.reserve(n0 + n + 16) && s.tags.reserve(n0 + n + 16);
     if (!ok) return fail(e, BRC_E_NOMEM, "host staging allocation failed");
+    if (!s.qname_off.reserve(n0 + n + 16)) return fail(e, BRC_E_NOMEM, "host staging allocation failed");
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t off = ~0ull;
+        if (b->qname && b->qname[i]) { off = s.qnames.n; if (!s.qnames.append(b->qname[i], strlen(b->qname[i]) + 1)) return fail(e, BRC_E_NOMEM, "host staging allocation failed"); }
+        s.qname_off.p[n0 + i] = off;
+    }
+    s.qname_off.n = n0 + n;
     for (size_t i = 0; i < n; ++i) {
         s.lib.p[n0 + i] = (e->cfg.per_lib && b->lib) ? b->lib[i] : 0;
         s.nm.p[n0 + i] = b->nm ? b->nm[i] : 0;
@@ -291,6 +298,7 @@ int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
         uint16_t fl = (uint16_t)(s.flag.p[r] & 0x7fffu);
         const int32_t rlen = cigar_rlen(s.cigar.p + s.cig_off.p[r], nc, &s.n_indel_ops);
         const int32_t end = (!(fl & FUNMAP) && nc > 0) ? pos + rlen : pos + 1;           // bam_endpos
+        if (rlen > s.max_span) s.max_span = rlen;
         bool accept = !(fl & FUNMAP) && pos >= 0;      // bam_plp_push (htslib 1.10) skips unmapped reads only
         if (accept) {   // region extent: every read bam_plp_push takes (max-count drops included)
             if (e->n_ext == 0) { s.min_pos = pos; s.max_end = end; }
@@ -580,6 +588,188 @@ int brc_format_window(brc_engine* e, const brc_result* r, const char* chrom, int
     if (k1 > k0) {
         std::vector<std::deque<QEnt> > q((size_t)r->n_lib);
         format_range(e, r, chrom, k0, k1, q, out, vbeg0, vend, delta);
+    }
+    *text = out.c_str();
+    if (text_len) *text_len = out.size();
+    return BRC_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- the stderr side (ReadWarnings)
+
+namespace {
+struct WEv { int qpos, indel; bool in_col, is_del; };
+// htslib's resolve_cigar2 as a pure function of (read, position): what the pileup entry of read r at p looks like
+WEv resolve_at(const uint32_t* cig, uint32_t nc, int32_t pos, int32_t p) {
+    WEv e; e.qpos = 0; e.indel = 0; e.in_col = false; e.is_del = false;
+    int32_t x = pos; int y = 0;
+    for (uint32_t k = 0; k < nc; ++k) {
+        const uint32_t op = cig[k] & 0xfu; const int len = (int)(cig[k] >> 4);
+        if (is_refop(op)) {
+            if (p >= x && p < x + len) {
+                const bool m = is_mop(op);
+                e.in_col = true; e.is_del = !m; e.qpos = m ? y + (p - x) : y;
+                if (p == x + len - 1 && k + 1 < nc) {
+                    const uint32_t op2 = cig[k + 1] & 0xfu; const int l2 = (int)(cig[k + 1] >> 4);
+                    if (op2 == CDEL) e.indel = -l2;
+                    else if (op2 == CINS) e.indel = l2;
+                    else if (peek_insertion(cig, nc, k)) { int l3 = 0; for (uint32_t kk = k + 2; kk < nc; ++kk) { const uint32_t o = cig[kk] & 0xfu; if (o == CINS) l3 += (int)(cig[kk] >> 4); else if (is_refop(o)) break; } e.indel = l3; }
+                }
+                return e;
+            }
+            x += len;
+            if (is_mop(op)) y += len;
+        } else if (op == CINS || op == CSOFT_CLIP) y += len;
+    }
+    return e;
+}
+}  // namespace
+
+extern "C" {
+
+// The events ReadWarnings::warn / fetch_func's fprintf would see, in the reference's order (see include/brc.h).  Only reads
+// that can warn are walked: library-less reads (-p), reads without NM, proper pairs without SM, and — with a site list — reads
+// hanging over the end of the reference.  They are swept position by position exactly like the pileup would present them
+// (file order inside a column; a library-less read ends its position, :281-284); a read's "Request for position" lines
+// come when fetch_func sees it, i.e. after the positions left of the previous pushed read.
+static int warnings_impl(brc_engine* e, const char* chrom, int64_t wbeg0, int64_t wend, bool with_bounds, int64_t cap, const char** events, size_t* events_len) {
+    if (!e || !chrom || !events) return BRC_E_ARG;
+    if (e->state < 1) return fail(e, BRC_E_ARG, "brc_region_warnings needs a region");
+    const Staged& s = e->st; const Geometry& g = e->g; const brc_config& cfg = e->cfg;
+    std::string& out = e->wev; out.clear();
+    const int64_t n = s.n;
+    auto name_of = [&](int64_t i) -> const char* { return s.qname_off.p[i] == ~0ull ? "?" : s.qnames.p + s.qname_off.p[i]; };
+    struct Rel { int64_t i; int32_t pos, end; bool lib_less, want_s, want_n, warns, bounds; int32_t barrier_q; };
+    std::vector<Rel> rel;
+    int32_t prev_enter_pos = INT32_MIN;
+    int64_t i_first = 0;
+    if (!with_bounds) i_first = std::lower_bound(s.pos.p, s.pos.p + n, (int32_t)std::max<int64_t>(wbeg0 - 1 - s.max_span, INT32_MIN)) - s.pos.p;   // window mode: reads sorted by pos
+    for (int64_t i = i_first; i < n; ++i) {
+        const uint32_t fl = s.flag.p[i]; const uint32_t nc = s.n_cigar.p[i]; const uint32_t* cg = s.cigar.p + s.cig_off.p[i];
+        const int32_t pos = s.pos.p[i];
+        const bool enters = read_enters(fl, cg, nc) && pos >= 0;
+        Rel r; r.i = i; r.pos = pos; r.end = pos; r.barrier_q = prev_enter_pos;
+        r.lib_less = cfg.per_lib && s.lib.p[i] < 0;
+        r.want_s = (fl & FPROPER_PAIR) && !(s.tags.p[i] & BRC_TAG_SM);
+        r.want_n = !(s.tags.p[i] & BRC_TAG_NM);
+        r.warns = enters && (r.lib_less || r.want_s || r.want_n);
+        if (!with_bounds && (pos >= wend)) break;                    // window mode: nothing right of the window matters
+        r.bounds = false;
+        int32_t rlen = 0, x = pos;
+        for (uint32_t k = 0; k < nc; ++k) {
+            const uint32_t op = cg[k] & 0xfu; const int32_t len = (int32_t)(cg[k] >> 4);
+            if (is_refop(op)) rlen += len;
+            if (op == CMATCH) { if (with_bounds && cfg.ref_len_check && g.ref && g.ref_len && (int64_t)x + len - 1 > g.ref_len) r.bounds = true; x += len; }
+            else if (op == CDEL || op == CREF_SKIP) x += len;
+        }
+        r.end = pos + rlen;
+        if ((r.warns && r.end > wbeg0 - 1 && r.pos < wend) || r.bounds) rel.push_back(r);
+        if (enters) prev_enter_pos = pos;
+    }
+    int64_t listed[BRC_N_WARN] = {0, 0, 0, 0};
+    auto emit = [&](int type, int64_t i) {
+        if (cap >= 0 && listed[type] >= cap) return;
+        listed[type]++;
+        out.push_back("SNZL"[type]); out.push_back('\t'); out.append(name_of(i)); out.push_back('\n');
+    };
+    auto capped = [&]() { return cap >= 0 && listed[BRC_W_SM_MISSING] >= cap && listed[BRC_W_NM_MISSING] >= cap && (!cfg.per_lib || listed[BRC_W_LIB_UNAVAILABLE] >= cap); };
+    // fetch_func's own lines of read r (:139-148): every M base whose reference position lies beyond the contig
+    auto bounds_lines = [&](const Rel& r) {
+        const uint32_t nc = s.n_cigar.p[r.i]; const uint32_t* cg = s.cigar.p + s.cig_off.p[r.i];
+        int64_t x = r.pos; char t[320];
+        for (uint32_t k = 0; k < nc; ++k) {
+            const uint32_t op = cg[k] & 0xfu; const int32_t len = (int32_t)(cg[k] >> 4);
+            if (op == CMATCH) {
+                bool stopped = false;
+                for (int32_t j = 0; j < len; ++j) {
+                    const int64_t refpos = x + j;
+                    if (refpos > g.ref_len) { const int m = snprintf(t, sizeof t, "B\tWARNING: Request for position %d in sequence %s is > length of %d!\n", (int)refpos, chrom, (int)g.ref_len); out.append(t, (size_t)m); continue; }
+                    if (refpos == g.ref_len || refpos < 0 || g.ref[refpos] == 0) { stopped = true; break; }       // :151 the terminating NUL ends the walk
+                }
+                if (stopped) return;
+                x += len;
+            } else if (op == CDEL || op == CREF_SKIP) x += len;
+        }
+    };
+    // sweep
+    std::vector<size_t> active;      // indices into rel, file order
+    size_t next_add = 0;             // next warning read to add to the active list
+    int64_t cur = INT64_MIN;         // next position to present
+    auto sweep_to = [&](int64_t limit) {    // present every position < limit
+        for (;;) {
+            if (capped()) return;
+            // next position >= cur covered by an active read or by a read not yet added
+            size_t w = 0; int64_t nextp = INT64_MAX;
+            for (size_t a : active) { if (rel[a].end > cur) { active[w++] = a; nextp = std::min<int64_t>(nextp, std::max<int64_t>(cur, rel[a].pos)); } }
+            active.resize(w);
+            size_t na = next_add; while (na < rel.size() && !rel[na].warns) ++na;
+            if (na < rel.size()) nextp = std::min<int64_t>(nextp, std::max<int64_t>(cur, rel[na].pos));
+            if (nextp == INT64_MAX || nextp >= limit) { cur = std::max(cur, std::min<int64_t>(limit, nextp == INT64_MAX ? limit : nextp)); return; }
+            const int64_t p = nextp;
+            while (next_add < rel.size() && (!rel[next_add].warns || rel[next_add].pos <= p)) { if (rel[next_add].warns) active.push_back(next_add); ++next_add; }
+            if (p >= wbeg0 - 1 && p < wend) {                                                               // :269
+                for (size_t a : active) {
+                    const Rel& r = rel[a];
+                    if (!(r.pos <= p && p < r.end)) continue;
+                    if (r.lib_less) { emit(BRC_W_LIB_UNAVAILABLE, r.i); break; }                            // :281-284
+                    const WEv ev = resolve_at(s.cigar.p + s.cig_off.p[r.i], s.n_cigar.p[r.i], r.pos, (int32_t)p);
+                    if (!ev.in_col || ev.is_del) continue;
+                    if ((int)s.mapq.p[r.i] < cfg.min_mapq || ev.qpos >= s.l_qseq.p[r.i] || (int)s.qual.p[s.qual_off.p[r.i] + (uint64_t)ev.qpos] < cfg.min_bq) continue;   // :288
+                    if (s.flag.p[r.i] & BRC_NOCOUNT_MASK) continue;                                         // :295-310
+                    const int calls = ((ev.indel != 0 && g.ref) ? 1 : 0) + ((ev.indel < 1 || !cfg.insertion_centric) ? 1 : 0);   // :315-346
+                    for (int c2 = 0; c2 < calls; ++c2) {                                                    // BasicStat::process_read
+                        if (r.want_s) emit(BRC_W_SM_MISSING, r.i);
+                        if (r.want_n) emit(BRC_W_NM_MISSING, r.i);
+                    }
+                }
+            }
+            cur = p + 1;
+        }
+    };
+    for (const Rel& r : rel) {
+        if (!r.bounds) continue;
+        if (r.barrier_q != INT32_MIN) sweep_to(r.barrier_q);          // positions left of the previous pushed read came out before fetch_func saw this one
+        bounds_lines(r);
+    }
+    cur = std::max<int64_t>(cur, wbeg0 - 1);
+    sweep_to(wend);
+    *events = out.c_str();
+    if (events_len) *events_len = out.size();
+    return BRC_OK;
+}
+
+int brc_region_warnings(brc_engine* e, const char* chrom, int64_t cap, const char** events, size_t* events_len) {
+    if (!e) return BRC_E_ARG;
+    return warnings_impl(e, chrom, e->g.beg0, e->g.end, true, cap, events, events_len);
+}
+int brc_window_warnings(brc_engine* e, int32_t vbeg0, int32_t vend, int64_t cap, const char** events, size_t* events_len) {
+    return warnings_impl(e, "", vbeg0, vend, false, cap, events, events_len);
+}
+
+// ReadWarnings::warn (ReadWarnings.hpp:39-50) applied to a tagged event stream
+int brc_warnings_text(brc_engine* e, const char* ev, size_t n, int64_t max, int64_t* counts, const char** text, size_t* text_len) {
+    if (!e || !text || !counts || (!ev && n)) return BRC_E_ARG;
+    static const char* const kMsg[BRC_N_WARN] = {
+        "Couldn't find single-end mapping quality. Check to see if the SM tag is in BAM.",
+        "Couldn't find number of mismatches. Check to see if the NM tag is in BAM.",
+        "Couldn't find the generated tag.",
+        "Library unavailable. Check to make sure the LB tag is present in the @RG entries of the header."};
+    std::string& out = e->wtext; out.clear();
+    size_t i = 0;
+    while (i < n) {
+        size_t j = i; while (j < n && ev[j] != '\n') ++j;
+        const char* tp = strchr("SNZL", ev[i]);
+        if (ev[i] == 'B') { if (j > i + 2) out.append(ev + i + 2, j - (i + 2)); out.push_back('\n'); }
+        else if (tp && *tp && j >= i + 2) {
+            const int t = (int)(tp - "SNZL");
+            ++counts[t];
+            if (!(max >= 0 && counts[t] > max)) {
+                out.append("WARNING: In read "); out.append(ev + i + 2, j - (i + 2)); out.append(": "); out.append(kMsg[t]); out.push_back('\n');
+                if (max >= 0 && counts[t] == max) { out.append("The previous warning has been emitted "); out.append(std::to_string((long long)counts[t])); out.append(" times and will be disabled.\n"); }
+            }
+        }
+        i = j + 1;
     }
     *text = out.c_str();
     if (text_len) *text_len = out.size();

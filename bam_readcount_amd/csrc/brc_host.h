@@ -59,10 +59,12 @@ struct Staged {
     uint64_t bq_elems = 0;              // total elements of the bq stream (sum of roundup8(l_qseq))
     // KB v2: pieces (walk_pieces in brc_core.h).  piece_cnt is filled at push time; piece_off (library-major slot of a
     // read's first piece) and lib_base (first slot of every library's stream, Lp + 1 entries) at upload
+    HBuf<char> qnames; HBuf<uint64_t> qname_off;   // read names when the caller gave them (warning text only); qname_off[i] = ~0 without
     HBuf<uint32_t> piece_cnt, piece_off;
     std::vector<int64_t> lib_base;
     int64_t n_pieces = 0;
     int32_t max_lqseq = 0;
+    int64_t max_span = 0;               // longest reference span of a pushed read
     void layout_pieces(int Lp, bool per_lib);
     uint32_t len_hist[TABLE_MAX + 1] = {0};   // histogram of l_qseq <= TABLE_MAX (modal length -> DevCfg.table_len)
     int32_t modal_len() const { uint32_t best = 0; int32_t arg = 0; for (int l = 1; l <= TABLE_MAX; ++l) if (len_hist[l] > best) { best = len_hist[l]; arg = l; } return arg; }

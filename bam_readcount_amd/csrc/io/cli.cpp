@@ -143,7 +143,8 @@ struct Batcher {
     std::vector<int32_t> pos, l_qseq, nm, sm; std::vector<uint16_t> flag; std::vector<uint8_t> mapq, tags;
     std::vector<int16_t> lib; std::vector<uint32_t> n_cigar, cigar; std::vector<uint64_t> cig_off, seq_off, qual_off;
     std::vector<uint8_t> seq4, qual;
-    void clear() { pos.clear(); l_qseq.clear(); nm.clear(); sm.clear(); flag.clear(); mapq.clear(); tags.clear(); lib.clear(); n_cigar.clear(); cigar.clear(); cig_off.clear(); seq_off.clear(); qual_off.clear(); seq4.clear(); qual.clear(); }
+    std::vector<char> names; std::vector<size_t> name_off; mutable std::vector<const char*> name_ptr;   // read names (warning text)
+    void clear() { names.clear(); name_off.clear(); pos.clear(); l_qseq.clear(); nm.clear(); sm.clear(); flag.clear(); mapq.clear(); tags.clear(); lib.clear(); n_cigar.clear(); cigar.clear(); cig_off.clear(); seq_off.clear(); qual_off.clear(); seq4.clear(); qual.clear(); }
     void add(const BamRecord& r, int lib_index) {
         pos.push_back(r.pos); flag.push_back(r.flag); mapq.push_back(r.mapq); l_qseq.push_back(r.l_seq); n_cigar.push_back(r.n_cigar);
         lib.push_back((int16_t)lib_index);
@@ -155,6 +156,7 @@ struct Batcher {
         if (r.aux_int("NM", &vnm)) t |= BRC_TAG_NM;      // bam_aux_get + bam_aux2i (BasicStat.cpp:94-96)
         if (r.aux_int("SM", &vsm)) t |= BRC_TAG_SM;      // (BasicStat.cpp:79-81)
         nm.push_back(vnm); sm.push_back(vsm); tags.push_back(t);
+        name_off.push_back(names.size()); const char* q = r.qname(); names.insert(names.end(), q, q + strlen(q) + 1);
     }
     brc_read_batch view() const {
         brc_read_batch v; memset(&v, 0, sizeof v);
@@ -162,6 +164,9 @@ struct Batcher {
         v.l_qseq = l_qseq.data(); v.n_cigar = n_cigar.data(); v.cigar_off = cig_off.data(); v.seq_off = seq_off.data(); v.qual_off = qual_off.data();
         v.nm = nm.data(); v.sm = sm.data(); v.tags = tags.data(); v.cigar = cigar.data(); v.seq4 = seq4.data(); v.qual = qual.data();
         v.n_cigar_total = cigar.size(); v.seq_bytes = seq4.size(); v.qual_bytes = qual.size();
+        name_ptr.resize(name_off.size());
+        for (size_t i = 0; i < name_off.size(); ++i) name_ptr[i] = names.data() + name_off[i];
+        v.qname = name_ptr.empty() ? nullptr : name_ptr.data();
         return v;
     }
 };
@@ -171,6 +176,29 @@ struct Batcher {
 #include <memory>
 #include <thread>
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ReadWarnings::warn (src/lib/bamrc/ReadWarnings.hpp:39-50) over a tagged event stream of the engine (brc_region_warnings)
+static void print_warn_events(const char* ev, size_t n, long long max, int64_t* counts, FILE* fp) {
+    static const char* const kMsg[BRC_N_WARN] = {
+        "Couldn't find single-end mapping quality. Check to see if the SM tag is in BAM.",
+        "Couldn't find number of mismatches. Check to see if the NM tag is in BAM.",
+        "Couldn't find the generated tag.",
+        "Library unavailable. Check to make sure the LB tag is present in the @RG entries of the header."};
+    for (size_t i = 0; i < n;) {
+        size_t j = i; while (j < n && ev[j] != '\n') ++j;
+        const char* tp = strchr("SNZL", ev[i]);
+        if (ev[i] == 'B') { if (j > i + 2) fwrite(ev + i + 2, 1, j - (i + 2), fp); fputc('\n', fp); }
+        else if (tp && *tp && j >= i + 2) {
+            const int t = (int)(tp - "SNZL");
+            ++counts[t];
+            if (!(max >= 0 && counts[t] > max)) {
+                fputs("WARNING: In read ", fp); fwrite(ev + i + 2, 1, j - (i + 2), fp); fputs(": ", fp); fputs(kMsg[t], fp); fputc('\n', fp);
+                if (max >= 0 && counts[t] == max) fprintf(fp, "The previous warning has been emitted %lld times and will be disabled.\n", (long long)counts[t]);
+            }
+        }
+        i = j + 1;
+    }
+}
 
 struct Ctx {
     double t_fetch = 0, t_engine = 0, t_format = 0, t_write = 0;   // BRC_CLI_TIMING=1 prints them on stderr
@@ -186,6 +214,13 @@ struct Ctx {
     // where a work item's text goes: straight to stdout / stderr (one engine), or into the item's buffers (several engines:
     // the main thread writes them in file order)
     std::string* out_buf = nullptr; std::string* err_buf = nullptr;
+    std::string* wev_buf = nullptr;       // tagged warning events of the item (several engines) — else they are printed at once
+    int64_t wcount[BRC_N_WARN] = {0, 0, 0, 0};   // ReadWarnings' counters (the main context's are the global ones)
+    void warn_events(const char* ev, size_t n) {
+        if (!n) return;
+        if (wev_buf) { wev_buf->append(ev, n); return; }
+        print_warn_events(ev, n, opt.max_warnings, wcount, stderr);
+    }
     void emit(const char* t, size_t n) { if (!n) return; if (out_buf) out_buf->append(t, n); else fwrite(t, 1, n, stdout); }
     void complain(const std::string& m) { if (err_buf) err_buf->append(m); else fputs(m.c_str(), stderr); }
 };
@@ -280,6 +315,7 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
         if (!rc) rc = brc_format_region(c.eng, &res, h.names[(size_t)tid].c_str(), &text, &len);
         double t3 = now_s(); c.t_format += t3 - t2;
         if (!rc) c.emit(text, len);
+        if (!rc && c.opt.max_warnings != 0) { const char* ev = ""; size_t evn = 0; if (brc_region_warnings(c.eng, h.names[(size_t)tid].c_str(), c.opt.max_warnings, &ev, &evn) == 0) c.warn_events(ev, evn); }
         double t4 = now_s(); c.t_write += t4 - t3;
         if (pre.joinable()) pre.join();
         c.t_fetch += now_s() - t4;                  // only the part of the background fetch that was not hidden
@@ -362,6 +398,7 @@ static int run_site_batch(Ctx& c, const std::vector<Site>& sites) {
                 all.l_qseq.push_back(b.l_qseq[k]); all.n_cigar.push_back(b.n_cigar[k]); all.nm.push_back(b.nm[k]); all.sm.push_back(b.sm[k]); all.tags.push_back(b.tags[k]);
                 all.cig_off.push_back(b.cig_off[k] + cb); all.seq_off.push_back(b.seq_off[k] + sb); all.qual_off.push_back(b.qual_off[k] + qb);
             }
+            { const size_t nb0 = all.names.size(); for (size_t k = 0; k < b.name_off.size(); ++k) all.name_off.push_back(b.name_off[k] + nb0); all.names.insert(all.names.end(), b.names.begin(), b.names.end()); }
             all.cigar.insert(all.cigar.end(), b.cigar.begin(), b.cigar.end());
             all.seq4.insert(all.seq4.end(), b.seq4.begin(), b.seq4.end());
             all.qual.insert(all.qual.end(), b.qual.begin(), b.qual.end());
@@ -378,6 +415,7 @@ static int run_site_batch(Ctx& c, const std::vector<Site>& sites) {
             rc = brc_format_window(c.eng, &res, h.names[(size_t)st.tid].c_str(), (int32_t)(st.beg0 + delta[i]), (int32_t)(st.end + delta[i]), (int32_t)delta[i], &text, &len);
             if (rc) { c.complain(std::string("bam-readcount: engine error: ") + brc_strerror(rc) + "\n"); return 1; }
             c.emit(text, len);
+            if (c.opt.max_warnings != 0) { const char* ev = ""; size_t evn = 0; if (brc_window_warnings(c.eng, (int32_t)(st.beg0 + delta[i]), (int32_t)(st.end + delta[i]), c.opt.max_warnings, &ev, &evn) == 0) c.warn_events(ev, evn); }
         }
         for (int w = 0; w < BRC_N_WARN; ++w) c.warn[w] += res.warn[w];
         i0 = i1;
@@ -418,7 +456,7 @@ struct Work {
     int tid = 0; int64_t beg0 = 0, end = 0; bool site_mode = false, keep_queue = false;
     std::vector<Site> sites;
     int engine = 0;
-    std::string out, err; int rc = 0; bool done = false;
+    std::string out, err, wev; int rc = 0; bool done = false;
 };
 
 static int run_item(Ctx& c, Work& w) {
@@ -510,7 +548,8 @@ int main(int argc, char** argv) {
                 fprintf(stderr, "%s not found in bam file. Region %s %i %i skipped.\n", name, name, beg, end); continue;
             }
             if (beg < 1) beg = 1;
-            if (plan && (int64_t)end - beg < 1000) {
+            // (windows near the end of a contig run on their own: fetch_func's "Request for position" lines carry real coordinates)
+            if (plan && (int64_t)end - beg < 1000 && (int64_t)end + 100000 < (int64_t)c.header().lengths[(size_t)it->second]) {
                 Site st; st.tid = it->second; st.beg0 = (int64_t)beg - 1; st.end = end < beg - 1 ? beg - 1 : end;
                 const int64_t clen = (int64_t)c.header().lengths[(size_t)st.tid];
                 if (st.end > clen + 1000) st.end = std::max<int64_t>(clen + 1000, st.beg0);
@@ -555,6 +594,7 @@ int main(int argc, char** argv) {
         std::vector<std::unique_ptr<Ctx> > ctxs(N);
         std::mutex mu; std::condition_variable cv;
         size_t printed = 0; bool abort_all = false;
+        int64_t gcount[BRC_N_WARN] = {0, 0, 0, 0};
         auto worker = [&](size_t g) {
             Ctx* wc = &c;
             if (g > 0) {                                                             // own handles, own engine
@@ -575,7 +615,7 @@ int main(int argc, char** argv) {
                     if (abort_all) return;
                 }
                 int r = w.rc;
-                if (w.kind != 2) { wc->out_buf = &w.out; wc->err_buf = &w.err; r = run_item(*wc, w); }
+                if (w.kind != 2) { wc->out_buf = &w.out; wc->err_buf = &w.err; wc->wev_buf = &w.wev; r = run_item(*wc, w); }
                 std::lock_guard<std::mutex> lk(mu);
                 w.rc = r; w.done = true; cv.notify_all();
             }
@@ -586,6 +626,7 @@ int main(int argc, char** argv) {
             Work& w = items[i];
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return w.done; }); }
             if (!w.out.empty()) fwrite(w.out.data(), 1, w.out.size(), stdout);
+            if (!w.wev.empty()) print_warn_events(w.wev.data(), w.wev.size(), c.opt.max_warnings, gcount, stderr);   // the global -w counters, in file order
             if (!w.err.empty()) fputs(w.err.c_str(), stderr);
             std::string().swap(w.out);
             { std::lock_guard<std::mutex> lk(mu); printed = i + 1; if (w.rc) { abort_all = true; ret = 1; } cv.notify_all(); }
@@ -595,9 +636,6 @@ int main(int argc, char** argv) {
         for (std::thread& t : th) t.join();
         for (size_t g = 1; g < N; ++g) if (ctxs[g]) { for (int w = 0; w < BRC_N_WARN; ++w) c.warn[w] += ctxs[g]->warn[w]; if (ctxs[g]->eng) brc_destroy(ctxs[g]->eng); }
     }
-    static const char* wn[BRC_N_WARN] = {"SM tag missing", "NM tag missing", "generated tag missing", "library unavailable"};
-    for (int w = 0; w < BRC_N_WARN; ++w)
-        if (c.warn[w] && o.max_warnings != 0) fprintf(stderr, "WARNING: %llu events: %s\n", (unsigned long long)c.warn[w], wn[w]);
     if (getenv("BRC_CLI_TIMING")) fprintf(stderr, "timing: fetch+decode %.3f s, engine (push, upload, kernels, download) %.3f s, format %.3f s, write %.3f s\n", c.t_fetch, c.t_engine, c.t_format, c.t_write);
     brc_destroy(c.eng);
     return ret;

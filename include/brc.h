@@ -219,6 +219,28 @@ int  brc_format_region(brc_engine*, const brc_result*, const char* chrom,
 int  brc_format_window(brc_engine*, const brc_result*, const char* chrom, int32_t vbeg0, int32_t vend, int32_t delta,
                        const char** text, size_t* text_len);
 
+/*
+ * The stderr side of the path: what ReadWarnings::warn (src/lib/bamrc/ReadWarnings.hpp:39-50) would be called with while the
+ * last computed region was piled up — LIBRARY_UNAVAILABLE from pileup_func (bamreadcount.cpp:281-284), SM / NM tag missing
+ * from BasicStat::process_read (BasicStat.cpp:85,100) — and the uncapped "Request for position ..." lines of fetch_func
+ * (bamreadcount.cpp:144-148), in the order the reference emits them (read by read, position by position, column order).
+ * One event per line, tagged so that the caller applies the -w cap ACROSS regions (the reference's counters are global):
+ *     "S\t<read name>\n"  SM_TAG_MISSING      "N\t<read name>\n"  NM_TAG_MISSING      "L\t<read name>\n"  LIBRARY_UNAVAILABLE
+ *     "B\t<the complete line fetch_func prints>\n"
+ * At most `cap` events of each capped type are listed (cap < 0: all of them — one line per pileup event of an untagged
+ * read, exactly what the reference floods stderr with).  Needs brc_read_batch.qname; reads pushed without names are
+ * listed as "?".  brc_warnings_text() turns such a stream into the reference's text given the running counters.
+ */
+int  brc_region_warnings(brc_engine*, const char* chrom /* target name, printed by the "B" lines */, int64_t cap,
+                         const char** events, size_t* events_len);
+/* The same for the sub-window [vbeg0, vend) of the region (plus its lead position), for callers that laid several windows side
+ * by side (see brc_format_window); no "B" lines: such callers keep windows that reach past a contig out of shared regions. */
+int  brc_window_warnings(brc_engine*, int32_t vbeg0, int32_t vend, int64_t cap, const char** events, size_t* events_len);
+/* counts[BRC_N_WARN]: events seen so far per type (updated); max_per_type: -w.  Appends to an engine-owned buffer that is
+ * reset by the call; returns the text ReadWarnings would have written for these events. */
+int  brc_warnings_text(brc_engine*, const char* events, size_t events_len, int64_t max_per_type, int64_t* counts,
+                       const char** text, size_t* text_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,6 +94,7 @@ typedef struct {
     const uint32_t* cigar; const uint8_t* seq4; const uint8_t* qual;
     int32_t nm, sm; uint8_t tags;
     zm_t zm; int has_zm;
+    const char* qname;
 } oread;
 
 static inline int seqi(const uint8_t* s, int i) { return (s[i >> 1] >> ((~i & 1) << 2)) & 0xf; }
@@ -115,10 +116,20 @@ struct brc_engine {
     uint64_t n_events; uint64_t warn[BRC_N_WARN];
     /* text of the region as the reference would print it */
     sbuf text, fmt_text;
+    /* warning events of the region, in the order the reference emits them (brc_region_warnings) */
+    sbuf wev, wtext, wout; int64_t wcap; int64_t wlisted[BRC_N_WARN];
     /* indel queues (bamreadcount.cpp:52,69): one FIFO per library name */
     struct qent { uint32_t tid, pos; ostat st; char* allele; } **queue; size_t *qn, *qhead, *qcap;
     int n_queues;
 };
+
+/* ReadWarnings::warn(type, read name) as a tagged event line (see brc_region_warnings in brc.h) */
+static void warn_event(brc_engine* e, int type, const oread* r) {
+    e->warn[type]++;
+    if (e->wcap >= 0 && e->wlisted[type] >= e->wcap) return;
+    e->wlisted[type]++;
+    sb_putc(&e->wev, "SNZL"[type]); sb_putc(&e->wev, '\t'); sb_puts(&e->wev, r->qname ? r->qname : "?"); sb_putc(&e->wev, '\n');
+}
 
 /* BasicStat.cpp:28-107 */
 static void process_read(brc_engine* e, ostat* s, const oread* r, int qpos) {
@@ -145,18 +156,18 @@ static void process_read(brc_engine* e, ostat* s, const oread* r, int qpos) {
         s->sum_event_location = (float)((double)s->sum_event_location +
                                         (1.0 - fabsf((float)(qpos - left_clip) - read_center) / read_center));
     } else {
-        e->warn[BRC_W_ZM_MISSING]++;
+        warn_event(e, BRC_W_ZM_MISSING, r);
     }
     if (r->flag & FPROPER_PAIR) {
         if (r->tags & BRC_TAG_SM) s->sum_single_ended_map_qualities += r->sm;
-        else e->warn[BRC_W_SM_MISSING]++;
+        else warn_event(e, BRC_W_SM_MISSING, r);
     } else {
         s->sum_single_ended_map_qualities += r->mapq;
     }
     if (r->tags & BRC_TAG_NM) {
         s->sum_number_of_mismatches += r->nm / (float)clipped_length;
     } else {
-        e->warn[BRC_W_NM_MISSING]++;
+        warn_event(e, BRC_W_NM_MISSING, r);
     }
     if (!s->is_indel) s->sum_base_qualities += r->qual[qpos];
 }
@@ -198,7 +209,7 @@ static void stat_to_abi(const ostat* s, brc_stat* o) {
 
 /* bamreadcount.cpp:114-256.  ref[i] is defined for i < ref_len; ref[ref_len] is the NUL terminator of
  * fai_fetch's string; anything beyond is undefined in the reference and treated as NUL here. */
-static void annotate(const brc_engine* e, oread* r) {
+static void annotate(brc_engine* e, oread* r) {
     const char* ref = e->ref; int64_t ref_len = e->ref_len;
     int i, reference_position, read_position;
     uint32_t sum_of_mismatch_qualities = 0;
@@ -212,7 +223,12 @@ static void annotate(const brc_engine* e, oread* r) {
                 int current_base_position = read_position + j;
                 int read_base = seqi(r->seq4, current_base_position);
                 int64_t refpos = (int64_t)reference_position + j;
-                if (e->cfg.ref_len_check && ref_len && refpos > ref_len) continue;          /* :144-148 (warning text not kept) */
+                if (e->cfg.ref_len_check && ref_len && refpos > ref_len) {                   /* :144-148 */
+                    char t[256];
+                    int m = snprintf(t, sizeof t, "B\tWARNING: Request for position %d in sequence %s is > length of %d!\n", (int)refpos, "\x01", (int)ref_len);
+                    sb_put(&e->wev, t, (size_t)m);
+                    continue;
+                }
                 unsigned char rc = (refpos >= 0 && refpos < ref_len) ? (unsigned char)ref[refpos] : 0;
                 int ref_base = nt16_of_char(rc);
                 if (rc == 0) break;                                                          /* :151 */
@@ -425,7 +441,7 @@ static void pileup_func(brc_engine* e, uint32_t tid, uint32_t pos, int n, const 
         if (c->per_lib) {
             lib = r->lib;
             if (lib < 0) {                                                                    /* :281-284 */
-                e->warn[BRC_W_LIB_UNAVAILABLE]++;
+                warn_event(e, BRC_W_LIB_UNAVAILABLE, r);
                 if (in_planes) {
                     e->unavail[k] = (uint32_t)base->ridx;
                     /* the reference abandons the position: nothing of it is reported */
@@ -575,7 +591,7 @@ void brc_destroy(brc_engine* e) {
     brc_clear_indel_queue(e);
     for (int l = 0; l < e->Lp; ++l) { free(e->lib_names[l]); free(e->queue[l]); }
     free(e->lib_names); free(e->queue); free(e->qn); free(e->qhead); free(e->qcap);
-    free(e->alleles.p); free(e->text.p); free(e->fmt_text.p);
+    free(e->alleles.p); free(e->text.p); free(e->fmt_text.p); free(e->wev.p); free(e->wtext.p); free(e->wout.p);
     free(e);
 }
 
@@ -607,6 +623,11 @@ int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
         r->l_qseq = b->l_qseq[i]; r->n_cigar = b->n_cigar[i];
         r->cigar = cig + b->cigar_off[i]; r->seq4 = seq + b->seq_off[i]; r->qual = qual + b->qual_off[i];
         r->nm = b->nm ? b->nm[i] : 0; r->sm = b->sm ? b->sm[i] : 0; r->tags = b->tags ? b->tags[i] : 0;
+        if (b->qname && b->qname[i]) {
+            char* q = strdup(b->qname[i]);
+            e->chunks = (void**)realloc(e->chunks, (e->n_chunks + 1) * sizeof(void*)); e->chunks[e->n_chunks++] = q;
+            r->qname = q;
+        }
     }
     return BRC_OK;
 }
@@ -666,6 +687,8 @@ int brc_compute(brc_engine* e, brc_timing* timing) {
     e->refbase = (char*)malloc(P + 1);
     for (size_t k = 0; k < P; ++k) { int64_t p = lo + (int64_t)k; e->refbase[k] = (e->ref && p < e->ref_len) ? e->ref[p] : 'N'; }
     e->n_indel = 0; e->alleles.n = 0; e->text.n = 0; e->n_events = 0; memset(e->warn, 0, sizeof e->warn);
+    e->wev.n = 0; memset(e->wlisted, 0, sizeof e->wlisted);
+    { const char* wc = getenv("BRC_ORACLE_WARN_CAP"); e->wcap = wc ? atoll(wc) : 64; }   /* events kept per type for brc_region_warnings */
 
     libcounts* lc = (libcounts*)calloc(Lp, sizeof(libcounts));
     plp_iter it; memset(&it, 0, sizeof it);
@@ -741,4 +764,57 @@ int brc_format_window(brc_engine* e, const brc_result* res, const char* chrom, i
                       const char** text, size_t* text_len) {
     (void)e; (void)res; (void)chrom; (void)vbeg0; (void)vend; (void)delta; (void)text; (void)text_len;
     return BRC_E_ARG;
+}
+
+/* the events recorded by the last brc_compute (the oracle records while it piles up: at most BRC_ORACLE_WARN_CAP, default 64,
+ * per type — `cap` can only shorten that); chrom replaces the placeholder of the "B" lines */
+int brc_region_warnings(brc_engine* e, const char* chrom, int64_t cap, const char** events, size_t* events_len) {
+    if (!e || !events || !chrom) return BRC_E_ARG;
+    int64_t seen[BRC_N_WARN] = {0, 0, 0, 0};
+    e->wtext.n = 0; sb_reserve(&e->wtext, e->wev.n + 16);
+    size_t i = 0;
+    while (i < e->wev.n) {
+        size_t j = i; while (j < e->wev.n && e->wev.p[j] != '\n') ++j;
+        const char* tp = strchr("SNZL", e->wev.p[i]);
+        int keep = 1;
+        if (tp && *tp) { int t = (int)(tp - "SNZL"); keep = cap < 0 || seen[t] < cap; seen[t]++; }
+        if (keep) for (size_t k = i; k <= j && k < e->wev.n; ++k) { if (e->wev.p[k] == '\x01') sb_puts(&e->wtext, chrom); else sb_putc(&e->wtext, e->wev.p[k]); }
+        i = j + 1;
+    }
+    *events = e->wtext.p ? e->wtext.p : "";
+    if (events_len) *events_len = e->wtext.n;
+    return BRC_OK;
+}
+
+/* ReadWarnings::warn (ReadWarnings.hpp:39-50) applied to a tagged event stream */
+static const char* const kWarnMsg[BRC_N_WARN] = {
+    "Couldn't find single-end mapping quality. Check to see if the SM tag is in BAM.",
+    "Couldn't find number of mismatches. Check to see if the NM tag is in BAM.",
+    "Couldn't find the generated tag.",
+    "Library unavailable. Check to make sure the LB tag is present in the @RG entries of the header."};
+int brc_warnings_text(brc_engine* e, const char* ev, size_t n, int64_t max, int64_t* counts, const char** text, size_t* text_len) {
+    if (!e || !text || !counts) return BRC_E_ARG;
+    e->wout.n = 0; sb_reserve(&e->wout, 16);
+    size_t i = 0;
+    while (i < n) {
+        size_t j = i; while (j < n && ev[j] != '\n') ++j;
+        const char* tp = strchr("SNZL", ev[i]);
+        if (ev[i] == 'B') { if (j > i + 2) sb_put(&e->wout, ev + i + 2, j - (i + 2)); sb_putc(&e->wout, '\n'); }
+        else if (tp && *tp && j >= i + 2) {
+            const int t = (int)(tp - "SNZL");
+            ++counts[t];
+            if (!(max >= 0 && counts[t] > max)) {
+                char tmp[64];
+                sb_puts(&e->wout, "WARNING: In read "); sb_put(&e->wout, ev + i + 2, j - (i + 2)); sb_puts(&e->wout, ": "); sb_puts(&e->wout, kWarnMsg[t]); sb_putc(&e->wout, '\n');
+                if (max >= 0 && counts[t] == max) {
+                    int m = snprintf(tmp, sizeof tmp, "%lld", (long long)counts[t]);
+                    sb_puts(&e->wout, "The previous warning has been emitted "); sb_put(&e->wout, tmp, (size_t)m); sb_puts(&e->wout, " times and will be disabled.\n");
+                }
+            }
+        }
+        i = j + 1;
+    }
+    *text = e->wout.p ? e->wout.p : "";
+    if (text_len) *text_len = e->wout.n;
+    return BRC_OK;
 }

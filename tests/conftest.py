@@ -23,6 +23,14 @@ def oracle_lib():
 
 
 @pytest.fixture(scope="session")
+def sim_lib():
+    """The product's host code + shared device functions executed on the CPU by tests/sim (test infrastructure only)."""
+    from bam_readcount_amd import capi
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    return capi.Library(os.path.join(ROOT, "tests", "sim", "libbrc_sim.so"))
+
+
+@pytest.fixture(scope="session")
 def hip_lib():
     """The product library; fails loudly when it was not built (no fallback)."""
     from bam_readcount_amd import capi

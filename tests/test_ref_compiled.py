@@ -334,3 +334,155 @@ def test_kat_read_warnings(ref_lib):
     assert sum("SM tag" in l for l in lines) == 5 and sum("NM tag" in l for l in lines) == 5 and sum("generated tag" in l for l in lines) == 5
     assert lines[0] == "WARNING: In read x: Couldn't find single-end mapping quality. Check to see if the SM tag is in BAM."
     assert "The previous warning has been emitted 5 times and will be disabled." in lines
+
+
+# ---------------------------------------------------------------- ReadWarnings through the engines (bamreadcount.cpp:178,192,239,108)
+
+WARN_CASES = [c for c in FUZZ if c["seed"] in (3, 7, 8, 12, 16)]
+
+
+def warnings_per_region(lib, arrs, regions, ref, names, max_w, opts, site_mode=True, window_of=None):
+    """Per region: the WARNING text a fresh ReadWarnings(max_w) would print (each compute of the reference-compiled engine
+    starts one, as main() does once per run).  `window_of`: compute that covering region once and ask for each region as a
+    sub-window instead (the site-list planner's path, brc_window_warnings)."""
+    eng = capi.Engine(lib, lib_names=names, ref_len_check=site_mode, **opts)
+    ends = capi.read_ends(arrs)
+    out = []
+    try:
+        if lib.kind() == "reference-compiled":
+            lib.lib.bamrc_ref_set_max_warnings(eng.h, max_w)
+        if window_of is not None:
+            idx = capi.fetch_overlapping(arrs, ends, window_of[0] - 1, window_of[1])
+            eng.begin_region(0, window_of[0], window_of[1], ref); eng.push_reads(capi.select_reads(arrs, idx)); eng.end_region()
+            for (b, e) in regions:
+                out.append(eng.warnings_text(eng.window_warnings(b, e, max_w), max_w, [0, 0, 0, 0]))
+            return out
+        for (b, e) in regions:
+            idx = capi.fetch_overlapping(arrs, ends, b - 1, e)
+            eng.begin_region(0, b, e, ref); eng.push_reads(capi.select_reads(arrs, idx)); eng.end_region()
+            if lib.kind() == "reference-compiled":
+                p = C.c_char_p(); n = C.c_size_t()
+                lib.lib.bamrc_ref_warnings(eng.h, C.byref(p), C.byref(n))
+                out.append(C.string_at(p, n.value))
+            else:
+                out.append(eng.warnings_text(eng.region_warnings("chrS", max_w), max_w, [0, 0, 0, 0]))
+            eng.clear_indel_queue()
+    finally:
+        eng.close()
+    return out
+
+
+def warn_inputs(case):
+    ref, arrs, names = fuzz_inputs(case)
+    arrs = dict(arrs)
+    arrs["qname"] = [b"read/%d:%d" % (case["seed"], i) for i in range(len(arrs["pos"]))]
+    return ref, arrs, names
+
+
+WARN_REGIONS = [(0, 3000), (100, 101), (700, 1500), (1490, 1700), (2990, 3200), (1500, 1500)]
+
+
+@pytest.mark.parametrize("case", WARN_CASES, ids=lambda c: "seed%d-%s" % (c["seed"], c["style"]))
+def test_warning_text_equals_reference_compiled(oracle_lib, sim_lib, ref_lib, case):
+    """The per-read WARNING lines (missing SM / NM tag, library unavailable) and their -w cap: the product's host generator
+    (csrc/brc_host.cpp warnings_impl, linked into tests/sim) and the oracle's recorder against the reference's own WARN
+    stream, byte for byte, in the order the reference's column walk emits them."""
+    ref, arrs, names = warn_inputs(case)
+    some = 0
+    for max_w in (1, 3, -1, 0):
+        want = warnings_per_region(ref_lib, arrs, WARN_REGIONS, ref, names, max_w, case["opts"])
+        got = warnings_per_region(sim_lib, arrs, WARN_REGIONS, ref, names, max_w, case["opts"])
+        assert got == want, "product warnings differ at -w %d" % max_w
+        if max_w in (1, 3):         # the oracle records at most BRC_ORACLE_WARN_CAP events per type
+            assert warnings_per_region(oracle_lib, arrs, WARN_REGIONS, ref, names, max_w, case["opts"]) == want
+        some += sum(len(t) for t in want)
+        # a planned window of a covering batch prints what its own run would have printed
+        if max_w != 0:
+            narrow = [(100, 101), (1490, 1700), (2500, 2501), (1500, 1500)]
+            w_ref = warnings_per_region(ref_lib, arrs, narrow, ref, names, max_w, case["opts"])
+            w_win = warnings_per_region(sim_lib, arrs, narrow, ref, names, max_w, case["opts"], window_of=(90, 2700))
+            assert w_win == w_ref, "window warnings differ at -w %d" % max_w
+    assert some > 0
+
+
+def test_cli_bounds_warning_equals_reference_main(ref_lib, tmp_path):
+    """fetch_func's "WARNING: Request for position .. is > length of .." line (bamreadcount.cpp:144-148, site-list mode,
+    straight to stderr, not capped by -w).  It can only fire for an M operator that starts beyond the loaded contig without
+    any earlier M base landing on the terminating NUL (:150,175 stop the walk there): here a read whose deletion spans the
+    end of a FASTA contig that is shorter than the BAM header says.  stdout, stderr (with the interleaving of WARN lines
+    and bounds lines) and exit code against the reference's main()."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bamio
+    from test_cli import SIM_CLI, _write_fasta
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    d = tmp_path
+    rng = np.random.default_rng(5)
+    ref = synth.make_ref(rng, 5000)
+    arrs = synth.make_batch(31, ref, 1500, style="mixed", n_libs=2, p_nolib=0.05)
+    cut = None
+    for i in range(len(arrs["pos"]) - 1, -1, -1):               # the last read with M..D..M: cut the contig at its deletion
+        x = int(arrs["pos"][i]); ops = arrs["cigar"][int(arrs["cigar_off"][i]):int(arrs["cigar_off"][i]) + int(arrs["n_cigar"][i])]
+        seen_m = False
+        for k, c in enumerate(ops):
+            op, ln = int(c) & 15, int(c) >> 4
+            if op == 2 and seen_m and any((int(c2) & 15) == 0 for c2 in ops[k + 1:]) and not (int(arrs["flag"][i]) & 4):
+                cut = x; break
+            seen_m |= op == 0
+            if op in (0, 2, 3, 7, 8): x += ln
+        if cut: break
+    assert cut and cut > 4000
+    rgs = [["rgA1", "rgB1"][int(l)] if l >= 0 else None for l in arrs["lib"]]
+    bamio.write_bam(str(d / "syn.bam"), [("chrA", 5000)], arrs, np.zeros(len(arrs["pos"]), int), rg_of_read=rgs,
+                    rg_lines=["@RG\tID:rgA1\tLB:libA\tSM:s", "@RG\tID:rgB1\tLB:libB\tSM:s"], block_bytes=6000)
+    _write_fasta(d / "short.fa", [("chrA", ref[:cut])])
+    sites = [("chrA", cut - 60, cut - 5), ("chrA", cut - 10, cut - 10), ("chrA", 100, 120), ("chrA", cut - 4, cut - 1)]
+    open(d / "sites.txt", "w").write("".join("%s\t%d\t%d\n" % s for s in sites))
+    for w in ("1", "-1"):
+        for extra in ([], ["-p"], ["-i", "-p"]):
+            want = subprocess.run([REF_CLI, "-w", w, "-f", "short.fa", "-l", "sites.txt"] + extra + ["syn.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert want.returncode == 0 and want.stderr.count(b"WARNING: Request for position") > 10
+            for more in ([], ["--brc-gpus", "2"], ["--brc-plan", "0"]):
+                got = subprocess.run([SIM_CLI, "-w", w, "-f", "short.fa", "-l", "sites.txt"] + extra + more + ["syn.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                assert (got.returncode, got.stdout) == (want.returncode, want.stdout)
+                assert got.stderr == want.stderr, (w, extra, more)
+
+
+def test_cli_stderr_equals_reference_main(ref_lib, workdir):
+    """The six integration commands (and the multi-engine / line-by-line variants of the drop-in): stdout, stderr and exit
+    code of the drop-in CLI == the reference's own main() compiled over the shim, for -w 1, 3, unlimited and 0."""
+    from test_cli import RUNS, SIM_CLI
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    for w in ("1", "3", "-1", "0"):
+        for _, bam, extra, how in RUNS:
+            tail = ["-l", "site_list", bam] if how == "list" else [bam, "21:10402985-10402985", "21:10405200-10405200"]
+            want = subprocess.run([REF_CLI, "-w", w] + extra + ["-f", "ref.fa"] + tail, cwd=workdir, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            for more in ([], ["--brc-gpus", "2"], ["--brc-plan", "0"]):
+                got = subprocess.run([SIM_CLI, "-w", w] + extra + ["-f", "ref.fa"] + more + tail, cwd=workdir, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                assert (got.returncode, got.stdout) == (want.returncode, want.stdout)
+                assert got.stderr == want.stderr, (w, bam, extra, how, more)
+
+
+@pytest.mark.gpu
+def test_cli_stderr_equals_reference_main_gpu(ref_lib, workdir):
+    """The product binary on the GPU: stdout + stderr + exit code of the six integration commands == the reference's main()
+    (oracle/_ref travels prebuilt), -w 1 and unlimited, one and three engines on the device."""
+    from test_cli import RUNS, HIP_CLI
+    env = dict(os.environ, BRC_DEVICES="0,0,0")
+    for w in ("1", "-1"):
+        for _, bam, extra, how in RUNS:
+            tail = ["-l", "site_list", bam] if how == "list" else [bam, "21:10402985-10402985", "21:10405200-10405200"]
+            want = subprocess.run([REF_CLI, "-w", w] + extra + ["-f", "ref.fa"] + tail, cwd=workdir, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            for more, e in (([], None), (["--brc-plan", "0"], env)):
+                got = subprocess.run([HIP_CLI, "-w", w] + extra + ["-f", "ref.fa"] + more + tail, cwd=workdir, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+                assert (got.returncode, got.stdout) == (want.returncode, want.stdout), got.stderr[-400:]
+                assert got.stderr == want.stderr, (w, bam, extra, how, more)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", WARN_CASES[:3], ids=lambda c: "seed%d-%s" % (c["seed"], c["style"]))
+def test_hip_warning_text_equals_reference_compiled(hip_lib, ref_lib, case):
+    ref, arrs, names = warn_inputs(case)
+    for max_w in (1, -1):
+        want = warnings_per_region(ref_lib, arrs, WARN_REGIONS, ref, names, max_w, case["opts"])
+        assert warnings_per_region(hip_lib, arrs, WARN_REGIONS, ref, names, max_w, case["opts"]) == want

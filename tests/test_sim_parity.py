@@ -14,12 +14,6 @@ import synth
 from test_oracle_golden import CASES, golden, run_case
 
 
-@pytest.fixture(scope="session")
-def sim_lib():
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
-    return capi.Library(os.path.join(ROOT, "tests", "sim", "libbrc_sim.so"))
-
-
 @pytest.mark.parametrize("name,opts,bad_rg", CASES)
 def test_sim_matches_reference_goldens(sim_lib, test_bam, name, opts, bad_rg):
     text, _ = run_case(sim_lib, test_bam, opts, bad_rg)
