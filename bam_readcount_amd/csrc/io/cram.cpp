@@ -4,9 +4,14 @@
 // / block / slice structure, the compression header (preservation map incl. substitution matrix and tag dictionary,
 // data-series and tag encodings), the codecs EXTERNAL, HUFFMAN (canonical codes from the core bit stream, incl. the
 // zero-length single-symbol form), BYTE_ARRAY_LEN, BYTE_ARRAY_STOP and BETA, and read reconstruction from the reference
-// plus the standard feature codes (X I i D N S H P B b Q q).  Blocks compressed with rANS / bzip2 / lzma and the codecs
-// GAMMA / SUBEXP / GOLOMB are reported as unsupported.  Records come out as BAM-layout BamRecords (bamio.h) so the CLI's
-// batcher is unchanged.  Region queries scan the container headers (ref id, start, span); the .crai is not needed.
+// plus the standard feature codes (X I i D N S H P B b Q q).  Block compression: raw, gzip, rANS 4x8 order 0 and 1 (the
+// codec samtools uses for qualities and most byte series; decoder written from the specification's description of the
+// frequency tables and the four interleaved states), bzip2 and lzma (through the system's libbz2 / liblzma, looked up at
+// run time: the image has the shared objects but no headers); every block's CRC32 is checked.  Integer codecs GAMMA and
+// SUBEXP are decoded too; GOLOMB / GOLOMB_RICE (no known writer) are reported as unsupported.  Records come out as
+// BAM-layout BamRecords (bamio.h) so the CLI's batcher is unchanged.  Region queries scan the container headers (ref id,
+// start, span); the .crai is not needed.
+#include <dlfcn.h>
 #include <string.h>
 #include <zlib.h>
 
@@ -49,7 +54,7 @@ struct Enc {            // one data-series / tag encoding
     uint8_t stop = 0;
     std::vector<int32_t> sym, len;   // HUFFMAN
     std::vector<uint32_t> code;      // canonical codes matching sym/len (sorted)
-    int beta_off = 0, beta_bits = 0;
+    int beta_off = 0, beta_bits = 0;     // BETA; GAMMA: offset; SUBEXP: offset, k
     std::vector<Enc> sub;            // BYTE_ARRAY_LEN: [0] lengths, [1] values
 };
 
@@ -82,8 +87,112 @@ bool parse_enc(Cur& c, Enc* e, std::string* err) {
         case 4: { e->sub.resize(2); return parse_enc(q, &e->sub[0], err) && parse_enc(q, &e->sub[1], err); }
         case 5: e->stop = q.u8(); e->ext_id = q.itf8(); return true;
         case 6: e->beta_off = q.itf8(); e->beta_bits = q.itf8(); return true;
+        case 7: e->beta_off = q.itf8(); e->beta_bits = q.itf8(); return true;     // SUBEXP: offset, k
+        case 9: e->beta_off = q.itf8(); return true;                              // GAMMA: offset
         default: *err = "CRAM codec " + std::to_string(e->codec) + " not supported by the minimal reader"; return false;
     }
+}
+
+// ---- rANS 4x8 (block method 4).  Stream: order u8, compressed size u32, uncompressed size u32, frequency table(s),
+// four little-endian 32-bit states, renormalisation bytes.  Frequencies are 12-bit (sum 4096 per table); a state x yields
+// the symbol whose cumulative range holds x & 4095 and continues as F * (x >> 12) + (x & 4095) - C, refilled bytewise
+// while below 2^23.
+struct RansTab { uint16_t F[256], C[256]; uint8_t R[4096]; bool used = false; };
+
+// one frequency table: symbols ascending, runs of consecutive symbols announced by (symbol, run length)
+bool rans_read_table(Cur& c, RansTab* t, bool order1) {
+    memset(t->F, 0, sizeof t->F); memset(t->C, 0, sizeof t->C); memset(t->R, 0, sizeof t->R); t->used = true;
+    int rle = 0, x = 0; int j = c.u8();
+    do {
+        int f = c.u8();
+        if (f >= 128) f = ((f & 127) << 8) | c.u8();
+        if (f == 0 && order1) f = 4096;
+        if (c.bad || x + f > 4096) return false;
+        t->F[j] = (uint16_t)f; t->C[j] = (uint16_t)x;
+        memset(t->R + x, j, (size_t)f); x += f;
+        if (!rle && c.p < c.e && j + 1 == *c.p) { j = c.u8(); rle = c.u8(); }
+        else if (rle) { --rle; ++j; if (j > 255) return false; }
+        else j = c.u8();
+    } while (j && !c.bad);
+    return !c.bad;
+}
+
+inline bool rans_step(uint32_t* x, const RansTab& t, Cur& c, uint8_t* sym) {
+    const uint32_t m = *x & 4095u; const uint8_t s = t.R[m]; *sym = s;
+    if (!t.F[s]) return false;                          // a slot no symbol owns: corrupt stream
+    *x = t.F[s] * (*x >> 12) + m - t.C[s];
+    while (*x < (1u << 23)) { if (c.p >= c.e) { *x <<= 8; c.bad = true; break; } *x = (*x << 8) | *c.p++; }
+    return true;
+}
+
+bool rans_decode(const uint8_t* in, size_t n, size_t expect, std::vector<uint8_t>* out, std::string* err) {
+    Cur c; c.p = in; c.e = in + n;
+    const int order = c.u8(); const uint32_t csz = (uint32_t)c.i32(), usz = (uint32_t)c.i32();
+    if (c.bad || order > 1 || (size_t)csz + 9 != n || usz != expect) { *err = "bad CRAM rANS block header"; return false; }
+    out->assign(usz, 0);
+    if (!usz) return true;
+    uint32_t R[4];
+    if (order == 0) {
+        RansTab t;
+        if (!rans_read_table(c, &t, false)) { *err = "bad CRAM rANS frequency table"; return false; }
+        for (int k = 0; k < 4; ++k) R[k] = (uint32_t)c.i32();
+        if (c.bad) { *err = "truncated CRAM rANS block"; return false; }
+        // symbol i comes from state i & 3; the last (usz & 3) symbols are read without advancing their states
+        const size_t full = usz & ~(size_t)3;
+        for (size_t i = 0; i < full; ++i) if (!rans_step(&R[i & 3], t, c, &(*out)[i])) { *err = "corrupt CRAM rANS stream"; return false; }
+        for (size_t i = full; i < usz; ++i) (*out)[i] = t.R[R[i & 3] & 4095u];
+        return true;
+    }
+    std::vector<RansTab> tabs(256);
+    {   // the contexts come as an outer table of the same (symbol, run) form
+        int rle = 0; int i = c.u8();
+        do {
+            if (!rans_read_table(c, &tabs[(size_t)i], true)) { *err = "bad CRAM rANS frequency table"; return false; }
+            if (!rle && c.p < c.e && i + 1 == *c.p) { i = c.u8(); rle = c.u8(); }
+            else if (rle) { --rle; ++i; if (i > 255) { *err = "bad CRAM rANS frequency table"; return false; } }
+            else i = c.u8();
+        } while (i && !c.bad);
+    }
+    for (int k = 0; k < 4; ++k) R[k] = (uint32_t)c.i32();
+    if (c.bad) { *err = "truncated CRAM rANS block"; return false; }
+    // four quarter streams, each with its own state and its own previous symbol (0 at the start); the fourth also
+    // carries what is left after 4 * (usz / 4)
+    const size_t q = usz >> 2; size_t at[4] = {0, q, 2 * q, 3 * q}; uint8_t last[4] = {0, 0, 0, 0};
+    for (size_t t = 0; t < q; ++t)
+        for (int k = 0; k < 4; ++k) {
+            const RansTab& tb = tabs[last[k]];
+            if (!tb.used || !rans_step(&R[k], tb, c, &(*out)[at[k]])) { *err = "corrupt CRAM rANS stream"; return false; }
+            last[k] = (*out)[at[k]++];
+        }
+    for (; at[3] < usz; ++at[3]) {
+        const RansTab& tb = tabs[last[3]];
+        if (!tb.used || !rans_step(&R[3], tb, c, &(*out)[at[3]])) { *err = "corrupt CRAM rANS stream"; return false; }
+        last[3] = (*out)[at[3]];
+    }
+    return true;
+}
+
+// ---- bzip2 / lzma blocks through the system libraries (no headers in this image: prototypes restated from their
+// public API, resolved with dlopen on first use)
+bool bz2_decode(const uint8_t* in, size_t n, std::vector<uint8_t>* out, std::string* err) {
+    typedef int (*Fn)(char*, unsigned*, char*, unsigned, int, int);
+    static Fn fn = nullptr; static bool tried = false;
+    if (!tried) { tried = true; void* h = dlopen("libbz2.so.1.0", RTLD_NOW); if (!h) h = dlopen("libbz2.so.1", RTLD_NOW); if (!h) h = dlopen("libbz2.so", RTLD_NOW);
+                  if (h) fn = (Fn)dlsym(h, "BZ2_bzBuffToBuffDecompress"); }
+    if (!fn) { *err = "CRAM bzip2 block: libbz2 is not available on this system"; return false; }
+    unsigned len = (unsigned)out->size();
+    if (fn((char*)out->data(), &len, (char*)in, (unsigned)n, 0, 0) != 0 || len != out->size()) { *err = "CRAM bzip2 block decompression failed"; return false; }
+    return true;
+}
+bool lzma_decode(const uint8_t* in, size_t n, std::vector<uint8_t>* out, std::string* err) {
+    typedef int (*Fn)(uint64_t*, uint32_t, const void*, const uint8_t*, size_t*, size_t, uint8_t*, size_t*, size_t);
+    static Fn fn = nullptr; static bool tried = false;
+    if (!tried) { tried = true; void* h = dlopen("liblzma.so.5", RTLD_NOW); if (!h) h = dlopen("liblzma.so", RTLD_NOW);
+                  if (h) fn = (Fn)dlsym(h, "lzma_stream_buffer_decode"); }
+    if (!fn) { *err = "CRAM lzma block: liblzma is not available on this system"; return false; }
+    uint64_t memlimit = UINT64_MAX; size_t ip = 0, op = 0;
+    if (fn(&memlimit, 0, nullptr, in, &ip, n, out->data(), &op, out->size()) != 0 || op != out->size()) { *err = "CRAM lzma block decompression failed"; return false; }
+    return true;
 }
 
 }  // namespace
@@ -103,9 +212,14 @@ struct CramReader::Impl {
     std::vector<std::vector<int32_t> > td;      // tag dictionary: per line the tag keys (tag0<<16|tag1<<8|type)
 
     bool read_block(Cur& c, Block* b) {
+        const uint8_t* const b0 = c.p;
         b->method = c.u8(); b->type = c.u8(); b->id = c.itf8();
         const int32_t cs = c.itf8(), us = c.itf8();
-        if (c.bad || c.p + cs + 4 > c.e) { err = "truncated CRAM block"; return false; }
+        if (c.bad || cs < 0 || us < 0 || c.p + cs + 4 > c.e) { err = "truncated CRAM block"; return false; }
+        {   // CRC32 over the block header and its (compressed) data
+            uint32_t want = 0; for (int k = 0; k < 4; ++k) want |= (uint32_t)c.p[cs + k] << (8 * k);
+            if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), b0, (uInt)(c.p + cs - b0)) != want) { err = "CRAM block CRC32 mismatch"; return false; }
+        }
         if (b->method == 0) b->data.assign(c.p, c.p + cs);
         else if (b->method == 1) {
             b->data.assign((size_t)us, 0);
@@ -114,7 +228,10 @@ struct CramReader::Impl {
             zs.next_in = (Bytef*)c.p; zs.avail_in = (uInt)cs; zs.next_out = b->data.data(); zs.avail_out = (uInt)us;
             const int rc = inflate(&zs, Z_FINISH); inflateEnd(&zs);
             if (rc != Z_STREAM_END) { err = "CRAM gzip block inflate failed"; return false; }
-        } else { err = "CRAM block compression method " + std::to_string(b->method) + " (bzip2/lzma/rANS) not supported by the minimal reader"; return false; }
+        } else if (b->method == 2) { b->data.assign((size_t)us, 0); if (!bz2_decode(c.p, (size_t)cs, &b->data, &err)) return false; }
+        else if (b->method == 3) { b->data.assign((size_t)us, 0); if (!lzma_decode(c.p, (size_t)cs, &b->data, &err)) return false; }
+        else if (b->method == 4) { if (!rans_decode(c.p, (size_t)cs, (size_t)us, &b->data, &err)) return false; }
+        else { err = "CRAM block compression method " + std::to_string(b->method) + " not supported by the minimal reader"; return false; }
         b->pos = 0; c.p += cs + 4;
         return true;
     }
@@ -131,6 +248,12 @@ struct CramReader::Impl {
                           for (; i < e.sym.size() && e.len[i] == l; ++i) if (e.code[i] == code) { *out = e.sym[i]; return true; } }
                       err = "bad CRAM Huffman code"; return false; }
             case 6: *out = (int32_t)br.bits(e.beta_bits) - e.beta_off; return true;
+            case 7: { int i = 0; while (br.get() == 1 && i < 32) ++i;                     // SUBEXP: i ones, a zero, then i ? i + k - 1 : k bits
+                      const int tail = i ? i + e.beta_bits - 1 : e.beta_bits;
+                      uint32_t v = br.bits(tail); if (i) v += 1u << tail;
+                      *out = (int32_t)v - e.beta_off; return true; }
+            case 9: { int nz = 0; while (br.get() == 0 && nz < 31) { ++nz; if ((br.bit >> 3) >= br.n) { err = "CRAM core block exhausted"; return false; } }   // GAMMA: nz zeros, a one, nz bits
+                      *out = (int32_t)((1u << nz) | br.bits(nz)) - e.beta_off; return true; }
             default: err = "CRAM integer codec " + std::to_string(e.codec) + " not supported"; return false;
         }
     }

@@ -133,6 +133,11 @@ def synthetic_bam(tmp_path_factory):
     import cramio
     cramio.write_cram(str(d / "syn.cram"), [("chrA", 5000), ("chrB", 3000)], arrs, tids, refs, rg_of_read=rgs,
                       rg_lines=["@RG\tID:rgA1\tLB:libA\tSM:s", "@RG\tID:rgB1\tLB:libB\tSM:s"], per_container=280)
+    # the same reads with every block compression method (raw, gzip, bzip2, lzma, rANS 4x8 order 0 and order 1; the core
+    # bit stream compressed too) and the GAMMA / SUBEXP integer codecs
+    cramio.write_cram(str(d / "syn_rans.cram"), [("chrA", 5000), ("chrB", 3000)], arrs, tids, refs, rg_of_read=rgs,
+                      rg_lines=["@RG\tID:rgA1\tLB:libA\tSM:s", "@RG\tID:rgB1\tLB:libB\tSM:s"], per_container=310,
+                      methods=(4, 5, 0, 1, 2, 3, 5), int_codecs=True)
     return d
 
 
@@ -314,6 +319,42 @@ def test_cli_cram_reader_equals_bam_reader_cpu(synthetic_bam):
     a = subprocess.run([SIM_CLI, "-w", "0", "-f", "syn.fa", "-p", "-l", sl, "--brc-plan", "0", "syn_m.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     b = subprocess.run([SIM_CLI, "-w", "0", "-f", "syn.fa", "-p", "-l", sl, "syn.cram"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and a.stdout.count(b"\n") > 60
+
+
+def test_cli_cram_rans_bzip2_lzma_blocks_equal_bam_reader_cpu(synthetic_bam):
+    """n4 "then rANS": the CRAM twin written with rANS 4x8 (order 0 and 1), bzip2, lzma, gzip and raw blocks, a compressed
+    core block and GAMMA / SUBEXP series prints what the BAM prints; a flipped payload byte is caught by the block CRC."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    d = synthetic_bam
+    raw = open(d / "syn_rans.cram", "rb").read()
+    assert raw.count(b"BZh") > 3 and raw.count(b"\xfd7zXZ\x00") > 3          # bzip2 / xz streams are really in the file
+    for extra in ([], ["-p", "-i"], ["-q", "15", "-b", "10"]):
+        regs = ["chrA:1-5000", "chrB", "chrA:2400-2450"]
+        a = subprocess.run([SIM_CLI, "-w", "0", "-f", "syn.fa"] + extra + ["syn_m.bam"] + regs, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        b = subprocess.run([SIM_CLI, "-w", "0", "-f", "syn.fa"] + extra + ["syn_rans.cram"] + regs, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
+        assert a.stdout.count(b"\n") > 7000 and a.stdout == b.stdout and a.stderr == b.stderr, extra
+    bad = bytearray(raw); bad[len(bad) // 2] ^= 0x10
+    open(d / "syn_bad.cram", "wb").write(bytes(bad))
+    c = subprocess.run([SIM_CLI, "-w", "0", "-f", "syn.fa", "syn_bad.cram", "chrA", "chrB"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert c.returncode != 0 and b"CRC32" in c.stderr, c.stderr[-300:]
+
+
+def test_rans_encoder_round_trip_sizes():
+    """tools/cramio.py's rANS encoder against an independent pure-Python decoder written from the same format description
+    (sizes 0..9 and larger, skewed and flat distributions, both orders) — guards the test-side writer itself."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import cramio
+    rng = np.random.default_rng(11)
+    for order in (0, 1):
+        for n in list(range(0, 10)) + [63, 64, 257, 4099]:
+            for kind in ("skew", "flat", "one"):
+                if kind == "skew": data = bytes(rng.choice([33, 34, 35, 40, 41, 255, 0, 2], n, p=[.5, .2, .1, .05, .05, .04, .03, .03]).astype(np.uint8))
+                elif kind == "flat": data = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+                else: data = bytes([7]) * n
+                comp = cramio.rans_encode(data, order)
+                assert cramio.rans_decode(comp) == data, (order, n, kind)
 
 
 def test_cli_striped_parallel_fetch_equals_single_handle_cpu(synthetic_bam, workdir):

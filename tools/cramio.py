@@ -7,7 +7,9 @@ CRAM reader of the drop-in CLI (bam_readcount_amd/csrc/io/cram.cpp) can be exerc
   CF, TL       HUFFMAN single symbol, zero-length code
   RN, SC       BYTE_ARRAY_STOP            IN, BB      BYTE_ARRAY_LEN(EXTERNAL, EXTERNAL)
   tags         BYTE_ARRAY_LEN(HUFFMAN single symbol, EXTERNAL)
-  the rest     EXTERNAL (ITF8 / bytes), blocks alternately raw and gzip
+  the rest     EXTERNAL (ITF8 / bytes); the blocks cycle through `methods` (default: raw, gzip; also bzip2, lzma and
+               rANS 4x8 order 0 / order 1 — the encoder below is the test-side counterpart of the reader's decoder)
+  optional     RL as GAMMA, DL as SUBEXP (core bit stream) with int_codecs=True
 
 Reads become features against the reference: X (substitution matrix), B (base+quality, for IUPAC read bases), I / i, D, N,
 S, H, P.  A chunk of reads that spans two contigs is written as a multi-reference slice (ref id -2, RI series, absolute
@@ -33,10 +35,149 @@ def ltf8(v):
     return itf8(v)          # identical to ITF8 below 2^28
 
 
+RANS_L = 1 << 23
+
+
+def rans_normalise(cnt):
+    """counts -> 12-bit frequencies summing to 4096, every present symbol >= 1"""
+    tot = sum(cnt)
+    F = [max(1, c * 4096 // tot) if c else 0 for c in cnt]
+    while sum(F) != 4096:
+        d = 4096 - sum(F)
+        j = max(range(256), key=lambda k: F[k])
+        F[j] += d if d > 0 or F[j] + d >= 1 else -(F[j] - 1)
+    return F
+
+
+def rans_table(F):
+    """one frequency table: symbols ascending; a symbol whose predecessor is present is followed by the number of further
+    consecutive symbols, which then come without their symbol byte"""
+    out = bytearray(); rle = 0
+    for j in range(256):
+        if not F[j]: continue
+        if rle: rle -= 1
+        else:
+            out.append(j)
+            if j and F[j - 1]:
+                r = j + 1
+                while r < 256 and F[r]: r += 1
+                rle = r - (j + 1); out.append(rle)
+        out += bytes([F[j]]) if F[j] < 128 else bytes([128 | (F[j] >> 8), F[j] & 0xFF])
+    out.append(0)
+    return out
+
+
+def rans_put(x, out, f, c):
+    x_max = ((RANS_L >> 12) << 8) * f
+    while x >= x_max:
+        out.append(x & 0xFF); x >>= 8
+    return ((x // f) << 12) + (x % f) + c
+
+
+def rans_encode(data, order):
+    """CRAM 3.0 rANS 4x8: order u8, compressed size u32, uncompressed size u32, tables, 4 states, bytes"""
+    n = len(data); x = [RANS_L] * 4; rev = bytearray()
+    if order == 0:
+        cnt = [0] * 256
+        for b in data: cnt[b] += 1
+        F = rans_normalise(cnt); C = [0] * 256
+        for j in range(1, 256): C[j] = C[j - 1] + F[j - 1]
+        tab = rans_table(F)
+        for i in range(n - 1, -1, -1):
+            x[i & 3] = rans_put(x[i & 3], rev, F[data[i]], C[data[i]])
+    else:
+        q = n >> 2
+        def ctx(i, k): return data[i - 1] if i > k * q else 0
+        cnt = {}
+        for k in range(4):
+            for i in range(k * q, (k + 1) * q if k < 3 else n):
+                cnt.setdefault(ctx(i, k), [0] * 256)[data[i]] += 1
+        F = {c: rans_normalise(v) for c, v in cnt.items()}; C = {}
+        for c, f in F.items():
+            C[c] = [0] * 256
+            for j in range(1, 256): C[c][j] = C[c][j - 1] + f[j - 1]
+        present = [1 if c in F else 0 for c in range(256)]
+        tab = bytearray(); rle = 0
+        for i in range(256):
+            if not present[i]: continue
+            if rle: rle -= 1
+            else:
+                tab.append(i)
+                if i and present[i - 1]:
+                    r = i + 1
+                    while r < 256 and present[r]: r += 1
+                    rle = r - (i + 1); tab.append(rle)
+            tab += rans_table(F[i])
+        tab.append(0)
+        for i in range(n - 1, 4 * q - 1, -1):
+            c = ctx(i, 3); x[3] = rans_put(x[3], rev, F[c][data[i]], C[c][data[i]])
+        for t in range(q - 1, -1, -1):
+            for k in (3, 2, 1, 0):
+                i = k * q + t; c = ctx(i, k); x[k] = rans_put(x[k], rev, F[c][data[i]], C[c][data[i]])
+    body = bytes(tab) + struct.pack("<4I", *x) + bytes(reversed(rev))
+    return bytes([order]) + struct.pack("<II", len(body), n) + body
+
+
+def rans_decode(comp):
+    """Plain decoder of rans_encode's output (test infrastructure: checks the encoder on its own)."""
+    order = comp[0]; csz, n = struct.unpack_from("<II", comp, 1); assert csz + 9 == len(comp)
+    p = [9]
+    def u8():
+        v = comp[p[0]]; p[0] += 1; return v
+    def table():
+        F = [0] * 256; C = [0] * 256; R = [0] * 4096; x = 0; rle = 0; j = u8()
+        while True:
+            f = u8()
+            if f >= 128: f = ((f & 127) << 8) | u8()
+            F[j] = f; C[j] = x
+            for t in range(x, x + f): R[t] = j
+            x += f
+            if not rle and j + 1 == comp[p[0]]: j = u8(); rle = u8()
+            elif rle: rle -= 1; j += 1
+            else: j = u8()
+            if j == 0: break
+        return F, C, R
+    out = bytearray(n)
+    if n == 0: return bytes(out)
+    def step(x, T):
+        F, C, R = T; m = x & 4095; s = R[m]; x = F[s] * (x >> 12) + m - C[s]
+        while x < RANS_L: x = (x << 8) | u8()
+        return x, s
+    if order == 0:
+        T = table(); X = list(struct.unpack_from("<4I", comp, p[0])); p[0] += 16
+        full = n & ~3
+        for i in range(full): X[i & 3], out[i] = step(X[i & 3], T)
+        for i in range(full, n): out[i] = T[2][X[i & 3] & 4095]
+        return bytes(out)
+    tabs = {}; rle = 0; i = u8()
+    while True:
+        tabs[i] = table()
+        if not rle and i + 1 == comp[p[0]]: i = u8(); rle = u8()
+        elif rle: rle -= 1; i += 1
+        else: i = u8()
+        if i == 0: break
+    X = list(struct.unpack_from("<4I", comp, p[0])); p[0] += 16
+    q = n >> 2; at = [0, q, 2 * q, 3 * q]; last = [0, 0, 0, 0]
+    for t in range(q):
+        for k in range(4):
+            X[k], s = step(X[k], tabs[last[k]]); out[at[k]] = s; at[k] += 1; last[k] = s
+    while at[3] < n:
+        X[3], s = step(X[3], tabs[last[3]]); out[at[3]] = s; at[3] += 1; last[3] = s
+    return bytes(out)
+
+
 def block(method, ctype, cid, data):
+    """method: 0 raw, 1 gzip, 2 bzip2, 3 lzma, 4 rANS order 0, 5 -> rANS order 1 (written as method 4)"""
     comp = data
+    if not data and method > 1: method = 0
     if method == 1:
         co = zlib.compressobj(6, zlib.DEFLATED, 31); comp = co.compress(data) + co.flush()
+    elif method == 2:
+        import bz2; comp = bz2.compress(data)
+    elif method == 3:
+        import lzma; comp = lzma.compress(data)
+    elif method in (4, 5):
+        comp = rans_encode(data, method - 4); method = 4
     b = bytes([method, ctype]) + itf8(cid) + itf8(len(comp)) + itf8(len(data)) + comp
     return b + struct.pack("<I", zlib.crc32(b))
 
@@ -50,6 +191,8 @@ def e_huff1(sym): return enc(3, itf8(1) + itf8(sym) + itf8(1) + itf8(0))
 def e_stop(stop, cid): return enc(5, bytes([stop]) + itf8(cid))
 def e_len(le, ve): return enc(4, le + ve)
 def e_beta(off, bits): return enc(6, itf8(off) + itf8(bits))
+def e_subexp(off, k): return enc(7, itf8(off) + itf8(k))
+def e_gamma(off): return enc(9, itf8(off))
 
 
 def huffman_lengths(freq):
@@ -78,6 +221,16 @@ class Bits:
             if self.n % 8 == 0: self.out.append(0)
             if (v >> i) & 1: self.out[-1] |= 1 << (7 - self.n % 8)
             self.n += 1
+    def gamma(self, v, off):
+        v += off; assert v >= 1
+        nb = v.bit_length() - 1
+        self.put(0, nb); self.put(v, nb + 1)
+    def subexp(self, v, off, k):
+        v += off; assert v >= 0
+        if v < (1 << k): self.put(0, 1); self.put(v, k); return
+        b = v.bit_length() - 1                      # b >= k;  i = b - k + 1 ones, a zero, then the b low bits
+        i = b - k + 1
+        self.put((1 << i) - 1, i); self.put(0, 1); self.put(v - (1 << b), b)
 
 
 SM_ORDER = {"A": "CGTN", "C": "AGTN", "G": "ACTN", "T": "ACGN", "N": "ACGT"}   # alternatives in ACGTN order minus self
@@ -99,7 +252,7 @@ IDS = dict(RI=1, RL=2, AP=3, RG=4, RN=5, MF=6, NS=7, NP=8, TS=9, NF=10, FN=11, F
            HC=20, PD=21, BA=22, QS=23, BB=24, BBL=25, QQ=26)
 
 
-def write_cram(path, contigs, arrs, tids, refs, rg_of_read=None, rg_lines=(), qnames=None, per_container=300):
+def write_cram(path, contigs, arrs, tids, refs, rg_of_read=None, rg_lines=(), qnames=None, per_container=300, methods=(0, 1), int_codecs=False):
     """contigs [(name, len)], arrs = brc_read_batch arrays, tids = contig per read, refs = list of uint8 reference arrays."""
     text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % c for c in contigs) + "".join(l + "\n" for l in rg_lines)
     rg_ids = [dict(f.split(":", 1) for f in l.split("\t")[1:])["ID"] for l in rg_lines]
@@ -132,7 +285,8 @@ def write_cram(path, contigs, arrs, tids, refs, rg_of_read=None, rg_lines=(), qn
             qual = bytes(arrs["qual"][int(arrs["qual_off"][i]):int(arrs["qual_off"][i]) + L])
             core.put(bcodes[flag], blens[flag])                                  # BF
             if multi: ext["RI"] += itf8(tid)
-            ext["RL"] += itf8(L)
+            if int_codecs: core.gamma(L, 1)
+            else: ext["RL"] += itf8(L)
             ext["AP"] += itf8(pos + 1) if multi else itf8(pos + 1 - last_ap)
             last_ap = pos + 1
             rg = rg_of_read[i] if rg_of_read is not None else None
@@ -176,7 +330,9 @@ def write_cram(path, contigs, arrs, tids, refs, rg_of_read=None, rg_lines=(), qn
                     elif fc == "i": ext["BA"] += v.encode()
                     elif fc == "I": ext["INL"] += itf8(len(v)); ext["IN"] += v.encode()
                     elif fc == "S": ext["SC"] += v.encode() + b"\0"
-                    elif fc == "D": ext["DL"] += itf8(v)
+                    elif fc == "D":
+                        if int_codecs: core.subexp(v, 0, 2)
+                        else: ext["DL"] += itf8(v)
                     elif fc == "N": ext["RS"] += itf8(v)
                     elif fc == "H": ext["HC"] += itf8(v)
                     elif fc == "P": ext["PD"] += itf8(v)
@@ -197,6 +353,7 @@ def write_cram(path, contigs, arrs, tids, refs, rg_of_read=None, rg_lines=(), qn
         dse["TL"] = e_huff1(0) if len(td_lines) == 1 else e_ext(tl_ids)
         for k in ("RI", "RL", "AP", "RG", "MF", "NS", "NP", "TS", "NF", "FN", "FC", "FP", "BS", "DL", "RS", "HC", "PD", "BA", "QS"):
             dse[k] = e_ext(IDS[k])
+        if int_codecs: dse["RL"] = e_gamma(1); dse["DL"] = e_subexp(0, 2)
         dm = itf8(len(dse)) + b"".join(k.encode() + v for k, v in dse.items())
         te = {key: e_len(e_huff1(1 if (key & 0xFF) == ord("C") else 4), e_ext(key)) for key in tag_blocks}
         tm = itf8(len(te)) + b"".join(itf8(k) + v for k, v in te.items())
@@ -204,15 +361,15 @@ def write_cram(path, contigs, arrs, tids, refs, rg_of_read=None, rg_lines=(), qn
         # ---- slice
         eblocks = []
         for j, (k, cid) in enumerate(sorted(IDS.items(), key=lambda kv: kv[1])):
-            if ext[k]: eblocks.append(block(j % 2, 4, cid, bytes(ext[k])))
+            if ext[k]: eblocks.append(block(methods[(j + c0 // per_container) % len(methods)], 4, cid, bytes(ext[k])))
         if len(td_lines) > 1: eblocks.append(block(1, 4, tl_ids, bytes(ext["TL"])))
-        for key, data in tag_blocks.items(): eblocks.append(block(1, 4, key, bytes(data)))
+        for key, data in tag_blocks.items(): eblocks.append(block(methods[-1], 4, key, bytes(data)))
         sref = -2 if multi else ctids[0]
         sstart = 0 if multi else first_pos; sspan = 0 if multi else max_end - first_pos + 1
         ids = [IDS[k] for k in sorted(IDS, key=lambda kk: IDS[kk]) if ext[k]] + ([tl_ids] if len(td_lines) > 1 else []) + list(tag_blocks)
         sh = itf8(sref) + itf8(sstart) + itf8(sspan) + itf8(len(idx)) + ltf8(c0) + itf8(1 + len(eblocks)) + itf8(len(ids)) + \
             b"".join(itf8(x) for x in ids) + itf8(-1) + bytes(16)
-        blocks = [ch, block(0, 2, 0, sh), block(0, 5, 0, bytes(core.out))] + eblocks
+        blocks = [ch, block(0, 2, 0, sh), block(methods[-1] if len(methods) > 2 else 0, 5, 0, bytes(core.out))] + eblocks
         out += container(sref, sstart, sspan, len(idx), blocks, [len(ch)])
     out += bytes.fromhex("0f000000ffffffff0fe0454f460000000001000 5bdd94f0001000606010001000100ee63014b".replace(" ", ""))
     open(path, "wb").write(bytes(out))
