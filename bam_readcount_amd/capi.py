@@ -20,7 +20,7 @@ F_NAMES = ["sev", "sq2", "snm", "s3p"]
 EXPORTS = [
     "brc_strerror", "brc_last_error", "brc_kernel_name", "brc_engine_kind", "brc_create", "brc_destroy",
     "brc_begin_region", "brc_push_reads", "brc_upload", "brc_compute", "brc_fetch_result", "brc_end_region",
-    "brc_clear_indel_queue", "brc_region_counts", "brc_format_region", "brc_format_window", "brc_region_warnings", "brc_window_warnings", "brc_warnings_text",
+    "brc_clear_indel_queue", "brc_region_counts", "brc_format_region", "brc_format_window", "brc_region_warnings", "brc_window_warnings", "brc_warnings_text", "brc_set_option",
 ]
 
 
@@ -83,6 +83,8 @@ class Library:
         L.brc_engine_kind.restype = C.c_char_p
         L.brc_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
         L.brc_destroy.argtypes = [C.c_void_p]; L.brc_destroy.restype = None
+        if hasattr(L, "brc_set_option"):       # (the reference-compiled checker library has no options)
+            L.brc_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int64]
         L.brc_begin_region.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]
         L.brc_push_reads.argtypes = [C.c_void_p, C.POINTER(ReadBatch)]
         L.brc_upload.argtypes = [C.c_void_p]
@@ -218,7 +220,9 @@ class Engine:
     """Mirror of the reference's per-region pileup lifecycle (bam_plbuf_init .. destroy, bamreadcount.cpp:591-605)."""
 
     def __init__(self, lib, min_mapq=0, min_bq=0, max_cnt=0, per_lib=False, insertion_centric=False, lib_names=(),
-                 device=0, ref_len_check=False):
+                 device=0, ref_len_check=False, text_only=False):
+        """text_only: BRC_OPT_TEXT_ONLY — results are consumed through format_region only (no dense planes; istat / fstat
+        of fetch_result() come back as zeros)."""
         self.L = lib
         self._names = [s.encode() if isinstance(s, str) else bytes(s) for s in lib_names]
         self._name_arr = (C.c_char_p * max(1, len(self._names)))(*self._names) if self._names else None
@@ -226,6 +230,8 @@ class Engine:
                      self._name_arr if self._names else None, device, int(ref_len_check))
         self.h = C.c_void_p()
         self._check(lib.lib.brc_create(C.byref(cfg), C.byref(self.h)), create=True)
+        if text_only:
+            self._check(lib.lib.brc_set_option(self.h, 1, 1))
         self._ref = None
         self._res = Result()
 

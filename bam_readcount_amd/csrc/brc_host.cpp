@@ -12,12 +12,29 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <deque>
 #include <thread>
 #include <functional>
 #include <queue>
 
 namespace brc {
+
+static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// run fn(i) for i in [0, n) on up to nthr threads (dynamic hand-out); the caller's thread works too
+template <class F>
+static void parallel_for(int64_t n, unsigned nthr, F fn) {
+    if (n <= 0) return;
+    if (nthr > (unsigned)n) nthr = (unsigned)n;
+    if (nthr <= 1) { for (int64_t i = 0; i < n; ++i) fn(i); return; }
+    std::atomic<int64_t> next(0);
+    auto work = [&]() { for (;;) { const int64_t i = next.fetch_add(1); if (i >= n) break; fn(i); } };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nthr; ++t) th.emplace_back(work);
+    work();
+    for (std::thread& t : th) t.join();
+}
 
 void Staged::init(const HostAlloc* A) {
     pos.A = A; flag.A = A; mapq.A = A; lib.A = A; l_qseq.A = A; n_cigar.A = A; cig_off.A = A; seq_off.A = A; qual_off.A = A;
@@ -157,6 +174,7 @@ static void fmt_stat(std::string& o, const uint32_t* si, const float* sf, bool i
 using namespace brc;
 
 struct QEnt { uint32_t tid, pos; brc_stat st; std::string allele; };
+struct XAgg { uint64_t key; brc_stat st; };      // key = k << 16 | library << 8 | bucket
 
 struct brc_engine {
     brc_config cfg;
@@ -176,9 +194,19 @@ struct brc_engine {
     std::vector<brc_indel> indels;
     std::string alleles;
     std::vector<char> refbase;
-    // formatter state
+    // BRC_OPT_TEXT_ONLY: the caller only formats (brc_format_region / brc_format_window): no dense planes are built, the
+    // formatter reads the compact slot planes; third-allele events are aggregated into a sparse (position, library,
+    // bucket)-sorted table instead
+    bool text_only = false;
+    std::vector<XAgg> xagg;
+    // formatter state: the text of the last call (one contiguous buffer, capacity kept across calls), the per-chunk
+    // buffers the threads format into (kept too: a fresh 300-MB buffer per piece costs more in page faults than the text)
+    char* tbuf = nullptr; size_t tcap = 0, tlen = 0;
+    std::vector<std::string> fparts;
     std::string text, wev, wtext;
     std::vector<std::deque<QEnt> > queue;
+    // host-side phase timers (BRC_ENGINE_TIMING=1: printed by brc_destroy)
+    double t_push = 0, t_upload = 0, t_compute = 0, t_d2h = 0, t_post = 0, t_format = 0; int64_t n_regions = 0;
 };
 
 static int fail(brc_engine* e, int code, const char* msg) { e->err = msg; return code; }
@@ -221,10 +249,21 @@ int brc_create(const brc_config* cfg, brc_engine** out) {
 
 void brc_destroy(brc_engine* e) {
     if (!e) return;
+    if (getenv("BRC_ENGINE_TIMING"))
+        fprintf(stderr, "engine timing (%lld regions): push %.3f s, upload %.3f s, compute %.3f s, download %.3f s, assemble %.3f s, format %.3f s\n",
+                (long long)e->n_regions, e->t_push, e->t_upload, e->t_compute, e->t_d2h, e->t_post, e->t_format);
     e->st.destroy();
     delete e->be;
-    free(e->dense_i); free(e->dense_f);
+    free(e->dense_i); free(e->dense_f); free(e->tbuf);
     delete e;
+}
+
+int brc_set_option(brc_engine* e, int option, int64_t value) {
+    if (!e) return BRC_E_ARG;
+    switch (option) {
+        case BRC_OPT_TEXT_ONLY: e->text_only = value != 0; return BRC_OK;
+        default: return fail(e, BRC_E_ARG, "unknown engine option");
+    }
 }
 
 int brc_begin_region(brc_engine* e, int32_t tid, int32_t beg0, int32_t end, const char* ref, int64_t ref_len) {
@@ -255,6 +294,8 @@ int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
     if (b->n_reads < 0) return fail(e, BRC_E_ARG, "negative n_reads");
     if (e->cfg.per_lib && !b->lib && b->n_reads) return fail(e, BRC_E_ARG, "per-library mode needs brc_read_batch.lib");
     Staged& s = e->st;
+    const double t_in = now_s();
+    struct Tm { brc_engine* e; double t0; ~Tm() { e->t_push += now_s() - t0; } } tm_{e, t_in};
     const size_t n = (size_t)b->n_reads, n0 = (size_t)s.n;
     if ((uint64_t)s.n + n >= 0xFFFFFFF0ull || s.cigar.n + b->n_cigar_total >= 0xFFFFFFF0ull)
         return fail(e, BRC_E_LIMIT, "more than 2^32 reads or CIGAR operators in one region: split the region");
@@ -343,6 +384,7 @@ int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
 int brc_upload(brc_engine* e) {
     if (!e) return BRC_E_ARG;
     if (e->state != 1) return fail(e, BRC_E_ARG, "brc_upload needs an open region");
+    const double t_in = now_s();
     Geometry& g = e->g; const Staged& s = e->st;
     int64_t lo = g.beg0 > 0 ? g.beg0 - 1 : 0, hi = g.end;
     if (e->n_ext == 0) { hi = lo; }
@@ -356,28 +398,36 @@ int brc_upload(brc_engine* e) {
     e->st.layout_pieces(g.Lp, e->cfg.per_lib != 0);
     int rc = e->be->upload(e->cfg, s, g);
     if (rc) return fail(e, rc, e->be->last_error());
-    e->state = 2;
+    e->state = 2; e->t_upload += now_s() - t_in; e->n_regions++;
     return BRC_OK;
 }
 
 int brc_compute(brc_engine* e, brc_timing* t) {
     if (!e) return BRC_E_ARG;
     if (e->state < 2) return fail(e, BRC_E_ARG, "brc_compute before brc_upload");
+    const double t_in = now_s();
     int rc = e->be->compute(t);
     if (rc) return fail(e, rc, e->be->last_error());
-    e->state = 3;
+    e->state = 3; e->t_compute += now_s() - t_in;
     return BRC_OK;
 }
 
 int brc_fetch_result(brc_engine* e, brc_result* out) {
     if (!e || !out) return BRC_E_ARG;
     if (e->state < 3) return fail(e, BRC_E_ARG, "brc_fetch_result before brc_compute");
+    const double t_in = now_s();
     int rc = e->be->fetch(&e->hp);
     if (rc) return fail(e, rc, e->be->last_error());
+    const double t_dl = now_s(); e->t_d2h += t_dl - t_in;
     const Geometry& g = e->g; const Staged& s = e->st; const HostPlanes& hp = e->hp;
     // column 3: raw reference character (bamreadcount.cpp:353)
     e->refbase.resize((size_t)g.P + 1);
-    for (int64_t k = 0; k < g.P; ++k) { const int64_t p = g.pos0 + k; e->refbase[(size_t)k] = (g.ref && p < g.ref_len && g.ref[p]) ? g.ref[p] : 'N'; }
+    {
+        const int64_t have = g.ref ? std::max<int64_t>(0, std::min<int64_t>(g.P, g.ref_len - g.pos0)) : 0;
+        if (have) memcpy(e->refbase.data(), g.ref + g.pos0, (size_t)have);
+        for (int64_t k = 0; k < have; ++k) if (!e->refbase[(size_t)k]) e->refbase[(size_t)k] = 'N';
+        if (g.P > have) memset(e->refbase.data() + have, 'N', (size_t)(g.P - have));
+    }
     // allele text + std::map<std::string,BasicStat> iteration order (bamreadcount.cpp:323-342, 389-401)
     std::vector<std::string> txt((size_t)hp.n_indel);
     for (int64_t i = 0; i < hp.n_indel; ++i) {
@@ -412,7 +462,28 @@ int brc_fetch_result(brc_engine* e, brc_result* out) {
     }
     memset(out, 0, sizeof *out);
     out->tid = g.tid; out->beg0 = g.beg0; out->end = g.end; out->pos0 = g.pos0; out->n_pos = g.P; out->stride = g.PS; out->n_lib = g.Lp;
-    {
+    if (e->text_only) {
+        // third-allele events -> one brc_stat per (position, library, bucket), accumulated in list order (= the pileup-column
+        // order of every bucket they touch); sorted by position for the formatter's merge
+        std::vector<std::pair<uint64_t, uint32_t> > ord2((size_t)hp.n_xev);
+        for (uint64_t i = 0; i < hp.n_xev; ++i) {
+            const XEv& x = hp.xev[i];
+            ord2[(size_t)i] = std::make_pair(((uint64_t)x.k << 16) | (uint64_t)(x.lib_b & 0xffffu), (uint32_t)i);
+        }
+        std::stable_sort(ord2.begin(), ord2.end(), [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& b) { return a.first < b.first; });
+        e->xagg.clear();
+        for (const auto& kv : ord2) {
+            const XEv& x = hp.xev[kv.second];
+            if ((int64_t)(x.lib_b >> 8) >= g.Lp || (x.lib_b & 0xffu) >= (uint32_t)NBUCKET || (int64_t)x.k >= g.P) continue;
+            if (e->xagg.empty() || e->xagg.back().key != kv.first) { XAgg a; a.key = kv.first; memset(&a.st, 0, sizeof a.st); e->xagg.push_back(a); }
+            brc_stat& t = e->xagg.back().st;
+            const uint32_t rev = (x.qf >> 8) & 1u;
+            t.i[I_N] += 1u; t.i[I_SMQ] += x.mapq; t.i[I_SSE] += x.sse; t.i[I_PLUS] += 1u - rev; t.i[I_MINUS] += rev;
+            t.i[I_NQ2] += (x.qf >> 9) & 1u; t.i[I_SMMQ] += x.zm; t.i[I_SCLIP] += x.clip; t.i[I_SBQ] += x.qf & 0xffu;
+            t.f[F_SQ2] += x.fq2; t.f[F_S3P] += x.fs3p; t.f[F_SNM] += x.fsnm;
+            t.f[F_SEV] = (float)((double)t.f[F_SEV] + x.sev);
+        }
+    } else {
         const size_t need = (size_t)g.Lp * NBUCKET * (size_t)g.PS + 16;
         if (need > e->dense_cap) {
             free(e->dense_i); free(e->dense_f);
@@ -421,14 +492,15 @@ int brc_fetch_result(brc_engine* e, brc_result* out) {
         }
         expand_slots(hp, g.Lp, g.P, g.PS, e->dense_i, e->dense_f);
     }
-    out->ncol = hp.ncol; out->depth = hp.depth; out->istat = e->dense_i; out->fstat = e->dense_f;
+    out->ncol = hp.ncol; out->depth = hp.depth;
+    out->istat = e->text_only ? NULL : e->dense_i; out->fstat = e->text_only ? NULL : e->dense_f;
     out->unavail = e->cfg.per_lib ? hp.unavail : NULL;
     out->refbase = e->refbase.data();
     out->n_indel = (int64_t)e->indels.size(); out->indel = e->indels.data();
     out->alleles = e->alleles.data(); out->alleles_len = e->alleles.size();
     out->n_events = hp.n_events;
     for (int w = 0; w < BRC_N_WARN; ++w) out->warn[w] = hp.warn[w];
-    e->state = 4;
+    e->state = 4; e->t_post += now_s() - t_dl;
     return BRC_OK;
 }
 
@@ -473,9 +545,15 @@ static void format_range(const brc_engine* e, const brc_result* r, const char* c
         while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (r->indel[m].pos < p0) lo = m + 1; else hi = m; }
         ii = lo;
     }
+    // text-only engines: the buckets come from the two slots of a position (+ the sparse third-allele table)
+    const bool compact = r->istat == NULL;
+    const HostPlanes& hp = e->hp;
+    size_t xi = 0;
+    if (compact) xi = (size_t)(std::lower_bound(e->xagg.begin(), e->xagg.end(), (uint64_t)k0 << 16, [](const XAgg& a, uint64_t key) { return a.key < key; }) - e->xagg.begin());
     for (int64_t k = k0; k < k1; ++k) {
         const int32_t pos = r->pos0 + (int32_t)k;
         while (ii < r->n_indel && r->indel[ii].pos < pos) ++ii;
+        if (compact) while (xi < e->xagg.size() && (int64_t)(e->xagg[xi].key >> 16) < k) ++xi;
         if (per_lib && r->unavail && r->unavail[k] != 0xFFFFFFFFu) continue;            // :281-284: position abandoned
         uint32_t tot = 0, depth = 0;
         for (int l = 0; l < Lp; ++l) { tot += r->ncol[(int64_t)l * S + k]; depth += r->depth[(int64_t)l * S + k]; }
@@ -485,10 +563,25 @@ static void format_range(const brc_engine* e, const brc_result* r, const char* c
         for (int l = 0; l < Lp; ++l) {
             if (r->ncol[(int64_t)l * S + k] == 0) continue;                               // lib_counts has no entry (:286,360)
             if (per_lib) { rec += '\t'; rec += e->libs[(size_t)l]; rec += "\t{"; }
+            const uint32_t sid = compact ? hp.slotid[(int64_t)l * S + k] : 0u;
             for (int b = 0; b < BRC_NBUCKET; ++b) {
+                rec += '\t'; rec += "=ACGTN"[b]; rec += ':';
+                if (compact) {
+                    const int sl = (uint32_t)b == (sid & 0xffu) ? 0 : ((uint32_t)b == ((sid >> 8) & 0xffu) ? 1 : -1);
+                    if (sl >= 0) {
+                        const uint32_t* ip = hp.si + (((int64_t)l * 2 + sl) * NI) * S + k; const float* fp = hp.sf + (((int64_t)l * 2 + sl) * NF) * S + k;
+                        si[I_N] = ip[(int64_t)I_N * S];
+                        if (si[I_N] != 0) { for (int f = 0; f < BRC_NI; ++f) si[f] = ip[(int64_t)f * S]; for (int f = 0; f < BRC_NF; ++f) sf[f] = fp[(int64_t)f * S]; }
+                    } else {
+                        si[I_N] = 0;
+                        for (size_t x = xi; x < e->xagg.size() && (int64_t)(e->xagg[x].key >> 16) == k; ++x)
+                            if ((e->xagg[x].key & 0xffffu) == (((uint64_t)l << 8) | (uint64_t)b)) { memcpy(si, e->xagg[x].st.i, sizeof si); memcpy(sf, e->xagg[x].st.f, sizeof sf); break; }
+                    }
+                    fmt_stat(rec, si, sf, false);
+                    continue;
+                }
                 // (the planes are position-major: look at the count plane first, the other 12 only for occupied buckets)
                 si[I_N] = r->istat[(((int64_t)l * BRC_NBUCKET + b) * BRC_NI + I_N) * S + k];
-                rec += '\t'; rec += "=ACGTN"[b]; rec += ':';
                 if (si[I_N] == 0) { fmt_stat(rec, si, sf, false); continue; }
                 for (int f = 0; f < BRC_NI; ++f) si[f] = r->istat[(((int64_t)l * BRC_NBUCKET + b) * BRC_NI + f) * S + k];
                 for (int f = 0; f < BRC_NF; ++f) sf[f] = r->fstat[(((int64_t)l * BRC_NBUCKET + b) * BRC_NF + f) * S + k];
@@ -536,43 +629,42 @@ int brc_format_region(brc_engine* e, const brc_result* r, const char* chrom, con
     if (!e || !r || !chrom || !text) return BRC_E_ARG;
     const int Lp = r->n_lib; const int64_t P = r->n_pos;
     if ((size_t)Lp != e->queue.size()) return fail(e, BRC_E_ARG, "result does not belong to this engine");
-    std::string& out = e->text; out.clear();
+    if (r->istat == NULL && (!e->text_only || e->state != 4)) return fail(e, BRC_E_ARG, "a text-only result can only be formatted right after its fetch");
+    const double t_in = now_s();
     unsigned nthr = std::thread::hardware_concurrency(); if (nthr == 0) nthr = 1; if (nthr > 64) nthr = 64;
     if (const char* t = getenv("BRC_FORMAT_THREADS")) { const int v = atoi(t); if (v > 0) nthr = (unsigned)v; }
     // about four chunks per thread, 2048 .. 65536 positions each (a 1-Mbp piece in 64-Ki chunks keeps only 15 threads busy)
     int64_t CH = P / (4 * (int64_t)nthr);
-    if (CH < 2048) CH = 2048; if (CH > (1 << 16)) CH = 1 << 16;
+    if (CH < 2048) CH = 2048;
+    if (CH > (1 << 16)) CH = 1 << 16;
     if (const char* t = getenv("BRC_FORMAT_CHUNK")) { const long long v = atoll(t); if (v > 0) CH = v; }   // test knob
-    const int64_t nch = (P + CH - 1) / CH;
-    if (nch <= 1 || nthr == 1) {
-        format_range(e, r, chrom, 0, P, e->queue, out, r->beg0, r->end, 0);
-    } else {
-        std::vector<std::string> parts((size_t)nch);
-        std::vector<std::vector<std::deque<QEnt> > > qs((size_t)nch);
-        std::atomic<int64_t> next(0);
-        auto work = [&]() {
-            for (;;) {
-                const int64_t c = next.fetch_add(1);
-                if (c >= nch) break;
-                const int64_t k0 = c * CH, k1 = std::min<int64_t>(P, k0 + CH);
-                if (c == 0) qs[0] = e->queue;
-                else { qs[(size_t)c].assign((size_t)Lp, std::deque<QEnt>()); std::string scratch; format_range(e, r, chrom, k0 - 1, k0, qs[(size_t)c], scratch, r->beg0, r->end, 0); }
-                parts[(size_t)c].reserve((size_t)(k1 - k0) * 96);
-                format_range(e, r, chrom, k0, k1, qs[(size_t)c], parts[(size_t)c], r->beg0, r->end, 0);
-            }
-        };
-        std::vector<std::thread> th;
-        const unsigned nt = (unsigned)std::min<int64_t>(nthr, nch);
-        for (unsigned i = 1; i < nt; ++i) th.emplace_back(work);
-        work();
-        for (std::thread& t : th) t.join();
-        size_t total = 0; for (const std::string& s : parts) total += s.size();
-        out.reserve(total + 1);
-        for (const std::string& s : parts) out += s;
-        e->queue = qs[(size_t)nch - 1];
+    const int64_t nch = std::max<int64_t>((P + CH - 1) / CH, 1);
+    if (e->fparts.size() < (size_t)nch) e->fparts.resize((size_t)nch);
+    std::vector<std::string>& parts = e->fparts;
+    std::vector<std::vector<std::deque<QEnt> > > qs((size_t)nch);
+    parallel_for(nch, nthr, [&](int64_t c) {
+        const int64_t k0 = c * CH, k1 = std::min<int64_t>(P, k0 + CH);
+        if (c == 0) qs[0] = e->queue;
+        else { qs[(size_t)c].assign((size_t)Lp, std::deque<QEnt>()); std::string scratch; format_range(e, r, chrom, k0 - 1, k0, qs[(size_t)c], scratch, r->beg0, r->end, 0); }
+        std::string& part = parts[(size_t)c];
+        part.clear();
+        if (part.capacity() < (size_t)(k1 - k0) * 96) part.reserve((size_t)(k1 - k0) * 96);
+        format_range(e, r, chrom, k0, k1, qs[(size_t)c], part, r->beg0, r->end, 0);
+    });
+    e->queue = qs[(size_t)nch - 1];
+    // one contiguous text: every chunk is copied to its offset by the pool (the buffer keeps its capacity across calls)
+    std::vector<size_t> off((size_t)nch + 1, 0);
+    for (int64_t c = 0; c < nch; ++c) off[(size_t)c + 1] = off[(size_t)c] + parts[(size_t)c].size();
+    const size_t total = off[(size_t)nch];
+    if (total + 1 > e->tcap) {
+        free(e->tbuf); e->tcap = total + total / 4 + 4096; e->tbuf = (char*)malloc(e->tcap);
+        if (!e->tbuf) { e->tcap = 0; return fail(e, BRC_E_NOMEM, "host allocation of the text buffer failed"); }
     }
-    *text = out.c_str();
-    if (text_len) *text_len = out.size();
+    parallel_for(nch, nthr, [&](int64_t c) { if (!parts[(size_t)c].empty()) memcpy(e->tbuf + off[(size_t)c], parts[(size_t)c].data(), parts[(size_t)c].size()); });
+    e->tbuf[total] = 0; e->tlen = total;
+    *text = e->tbuf;
+    if (text_len) *text_len = total;
+    e->t_format += now_s() - t_in;
     return BRC_OK;
 }
 
@@ -580,6 +672,7 @@ int brc_format_window(brc_engine* e, const brc_result* r, const char* chrom, int
                       const char** text, size_t* text_len) {
     if (!e || !r || !chrom || !text || vend < vbeg0) return BRC_E_ARG;
     if ((size_t)r->n_lib != e->queue.size()) return fail(e, BRC_E_ARG, "result does not belong to this engine");
+    if (r->istat == NULL && (!e->text_only || e->state != 4)) return fail(e, BRC_E_ARG, "a text-only result can only be formatted right after its fetch");
     std::string& out = e->text; out.clear();
     // plane indices of [vbeg0 - 1, vend) clipped to the planes; the lead position only feeds the deletion queue (:269 vs :414)
     int64_t k0 = (int64_t)vbeg0 - 1 - r->pos0, k1 = (int64_t)vend - r->pos0;

@@ -487,7 +487,9 @@ static int make_engine(Ctx& c, int device) {
     cfg.per_lib = o.per_lib; cfg.insertion_centric = o.insertion_centric; cfg.n_libs = (int32_t)names.size();
     cfg.lib_names = names.empty() ? nullptr : names.data(); cfg.device = device;
     cfg.ref_len_check = (!o.site_list.empty() && c.have_fa) ? 1 : 0;                                                                        // :594-600
-    return brc_create(&cfg, &c.eng);
+    const int rc = brc_create(&cfg, &c.eng);
+    if (rc == 0) brc_set_option(c.eng, BRC_OPT_TEXT_ONLY, 1);      // the command line only prints: no dense planes on the host
+    return rc;
 }
 
 int main(int argc, char** argv) {

@@ -174,6 +174,15 @@ const char* brc_engine_kind(void);      /* "hip-gfx950" for the product library,
 int  brc_create(const brc_config* cfg, brc_engine** out);
 void brc_destroy(brc_engine*);
 
+/* Engine options (set after brc_create, before the first region).
+ *   BRC_OPT_TEXT_ONLY  1: the caller consumes results only through brc_format_region / brc_format_window (the drop-in command
+ *                      line: the reference itself only prints, bamreadcount.cpp:351-416).  brc_result.istat / fstat are then
+ *                      NULL — the dense 312-byte-per-position planes are never built on the host, the formatter reads the
+ *                      engine's compact result (two bucket slots per position + the third-allele list) — and such a result
+ *                      must be formatted before the next region of this engine.  Everything else of brc_result is filled. */
+#define BRC_OPT_TEXT_ONLY 1
+int  brc_set_option(brc_engine*, int option, int64_t value);
+
 /* Open the reporting window [beg0,end) on contig tid.  ref = raw FASTA characters of the whole contig
  * (ref[i] = base at 0-based i), borrowed until brc_end_region/brc_fetch_result returns.  ref may be NULL
  * (no -f): then indel alleles are not collected and the reference base prints as 'N' (:315,353). */

@@ -550,6 +550,9 @@ const char* brc_last_error(const brc_engine* e) { return e ? e->errbuf : ""; }
 const char* brc_kernel_name(int k) { (void)k; return NULL; }
 const char* brc_engine_kind(void) { return "oracle-c"; }
 
+/* the oracle always builds the dense planes; the option only changes how the product lays its result out */
+int brc_set_option(brc_engine* e, int option, int64_t value) { (void)value; return (e && option == BRC_OPT_TEXT_ONLY) ? BRC_OK : BRC_E_ARG; }
+
 int brc_create(const brc_config* cfg, brc_engine** out) {
     if (!cfg || !out || cfg->abi_version != BRC_ABI_VERSION) return BRC_E_ARG;
     brc_engine* e = (brc_engine*)calloc(1, sizeof *e);

@@ -150,3 +150,16 @@ def test_hip_wgs_sample_equals_oracle_and_full_size_properties(hip_lib, oracle_l
         np.testing.assert_array_equal(part.fstat[..., q].view(np.uint32), whole.fstat[..., w].view(np.uint32))
         np.testing.assert_array_equal(part.depth[:, q], whole.depth[:, w])
     eng.close()
+
+
+@pytest.mark.gpu
+def test_hip_text_only_engine_prints_the_same(hip_lib, oracle_lib):
+    """BRC_OPT_TEXT_ONLY (the command line's setting): the formatter reads the compact device result directly."""
+    import synthgen
+    ref, arrs = synthgen.generate(300_000, "tumor200x", seed=11, n_chunks=4)
+    names = ["libA", "libB", "libC", "libD"]
+    for kw in (dict(min_mapq=20, min_bq=13), dict(per_lib=True, insertion_centric=True, lib_names=names)):
+        want, _ = parity.run_engine(oracle_lib, arrs, [(0, 40000), (150000, 150001)], ref=ref, **kw)
+        got, res = parity.run_engine(hip_lib, arrs, [(0, 40000), (150000, 150001)], ref=ref, text_only=True, **kw)
+        assert got == want and want.count(b"\n") > 39000
+        assert not res[0].istat.any()

@@ -136,3 +136,26 @@ def test_sim_rare_device_paths(sim_lib, oracle_lib, monkeypatch, env):
     parity.compare_libs(sim_lib, oracle_lib, arrs, [(0, 3000)], ref=ref, min_mapq=5, min_bq=10, insertion_centric=True)
     deep = synth.make_batch(299, ref, 2500, style="mixed", region=(900, 1400), read_len=(100, 150))
     parity.compare_libs(sim_lib, oracle_lib, deep, [(800, 1600)], ref=ref)
+
+
+@pytest.mark.parametrize("case", [FUZZ[2], FUZZ[4], FUZZ[6], FUZZ[7]], ids=lambda c: "seed%d-%s" % (c["seed"], c["style"]))
+def test_sim_text_only_engine_prints_the_same(sim_lib, oracle_lib, case):
+    """BRC_OPT_TEXT_ONLY (what the drop-in command line sets): the formatter reads the compact result — two bucket slots per
+    position plus the sparse third-allele table — instead of dense planes; the text must not change.  High depth so that
+    third and fourth alleles occur at many positions."""
+    rng = np.random.default_rng(case["seed"])
+    ref = synth.make_ref(rng, 1200, weird=case.get("weird", 0.0))
+    n_libs = case.get("n_libs", 1)
+    arrs = synth.make_batch(case["seed"] + 300, ref, 1500, style=case["style"], n_libs=n_libs, p_nolib=case.get("p_nolib", 0.0))
+    names = ["lib%c" % (65 + i) for i in range(n_libs)] if case["opts"].get("per_lib") else ()
+    regions = [(0, 1200), (300, 301), (700, 900)]
+    want, _ = parity.run_engine(oracle_lib, arrs, regions, ref=ref, lib_names=names, **case["opts"])
+    got, res = parity.run_engine(sim_lib, arrs, regions, ref=ref, lib_names=names, text_only=True, **case["opts"])
+    assert got == want
+    assert not res[0].istat.any()                     # no dense planes were built
+    os.environ["BRC_FORMAT_CHUNK"] = "64"; os.environ["BRC_FORMAT_THREADS"] = "5"
+    try:
+        got2, _ = parity.run_engine(sim_lib, arrs, regions, ref=ref, lib_names=names, text_only=True, **case["opts"])
+    finally:
+        del os.environ["BRC_FORMAT_CHUNK"]; del os.environ["BRC_FORMAT_THREADS"]
+    assert got2 == want
