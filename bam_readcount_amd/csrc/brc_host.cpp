@@ -66,26 +66,37 @@ void Staged::layout_pieces(int Lp, bool per_lib) {
     }
 }
 
-int fmt_u32(char* out, uint32_t v) {
-    char t[12]; int n = 0;
-    do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+// two decimal digits at a time
+static const char kD2[201] =
+    "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869"
+    "707172737475767778798081828384858687888990919293949596979899";
+
+static inline int fmt_u64(char* out, uint64_t v) {
+    char t[24]; int n = 0;
+    while (v >= 100) { const unsigned d = (unsigned)(v % 100); v /= 100; t[n++] = kD2[2 * d + 1]; t[n++] = kD2[2 * d]; }
+    if (v >= 10) { t[n++] = kD2[2 * v + 1]; t[n++] = kD2[2 * v]; } else t[n++] = (char)('0' + v);
     for (int i = 0; i < n; ++i) out[i] = t[n - 1 - i];
     return n;
 }
+int fmt_u32(char* out, uint32_t v) {
+    if (v < 10) { out[0] = (char)('0' + v); return 1; }
+    if (v < 100) { out[0] = kD2[2 * v]; out[1] = kD2[2 * v + 1]; return 2; }
+    return fmt_u64(out, v);
+}
 
-// "%.2f" of the exact binary value, round-half-even: v*100 is exact in double (24+7 significant bits), so
-// nearbyint() of it is the correctly rounded count of hundredths glibc's printf would print.
+// "%.2f" of the exact binary value, round-half-even: v*100 is exact in double (24+7 significant bits), so rounding it
+// to an integer in the current (to-nearest-even) mode gives the correctly rounded count of hundredths glibc's printf
+// would print; adding and subtracting 2^52 does that rounding without a libm call.
 int fmt_f2(char* out, float v) {
     if (!(fabsf(v) < 4.0e13f)) return snprintf(out, 64, "%.2f", (double)v);   // inf / nan / huge: libc path
     const double s = fabs((double)v * 100.0);
-    uint64_t u = (uint64_t)nearbyint(s);
+    volatile double big = s + 4503599627370496.0;       // (volatile: the sum must be rounded to double before the subtraction)
+    const uint64_t u = (uint64_t)(big - 4503599627370496.0);
     int n = 0;
     if (signbit(v)) out[n++] = '-';
-    uint64_t ip = u / 100; uint32_t fr = (uint32_t)(u % 100);
-    char t[24]; int m = 0;
-    do { t[m++] = (char)('0' + ip % 10); ip /= 10; } while (ip);
-    while (m) out[n++] = t[--m];
-    out[n++] = '.'; out[n++] = (char)('0' + fr / 10); out[n++] = (char)('0' + fr % 10);
+    const uint64_t ip = u / 100; const unsigned fr = (unsigned)(u % 100);
+    n += ip < 100 ? fmt_u32(out + n, (uint32_t)ip) : fmt_u64(out + n, ip);
+    out[n++] = '.'; out[n++] = kD2[2 * fr]; out[n++] = kD2[2 * fr + 1];
     return n;
 }
 
@@ -144,30 +155,52 @@ void expand_slots(const HostPlanes& hp, int Lp, int64_t P, int64_t PS, uint32_t*
 }
 
 static const char kZeroStat[] = "0:0.00:0.00:0.00:0:0:0.00:0.00:0.00:0:0.00:0.00:0.00";
+enum { ZERO_LEN = sizeof(kZeroStat) - 1, STAT_MAX = 13 * 48 };     // (a float field can be as long as "%.2f" of FLT_MAX)
 
-// operator<<(ostream&, BasicStat) (BasicStat.cpp:110-159)
-static void fmt_stat(std::string& o, const uint32_t* si, const float* sf, bool is_indel) {
+// operator<<(ostream&, BasicStat) (BasicStat.cpp:110-159); writes at w (room for STAT_MAX bytes), returns the new end
+static inline char* fmt_stat(char* w, const uint32_t* si, const float* sf, bool is_indel) {
     const uint32_t n = si[I_N];
-    if (n == 0) { o.append(kZeroStat, sizeof(kZeroStat) - 1); return; }
-    char b[512]; int k = 0;
+    if (n == 0) { memcpy(w, kZeroStat, ZERO_LEN); return w + ZERO_LEN; }
     const float c = (float)n;
-    k += fmt_u32(b + k, n); b[k++] = ':';
-    k += fmt_f2(b + k, (float)si[I_SMQ] / c); b[k++] = ':';
-    if (is_indel) { memcpy(b + k, "0.00", 4); k += 4; } else k += fmt_f2(b + k, (float)si[I_SBQ] / c);
-    b[k++] = ':';
-    k += fmt_f2(b + k, (float)si[I_SSE] / c); b[k++] = ':';
-    k += fmt_u32(b + k, si[I_PLUS]); b[k++] = ':';
-    k += fmt_u32(b + k, si[I_MINUS]); b[k++] = ':';
-    k += fmt_f2(b + k, sf[F_SEV] / c); b[k++] = ':';
-    k += fmt_f2(b + k, sf[F_SNM] / c); b[k++] = ':';
-    k += fmt_f2(b + k, (float)si[I_SMMQ] / c); b[k++] = ':';
-    k += fmt_u32(b + k, si[I_NQ2]); b[k++] = ':';
-    if (si[I_NQ2] > 0) k += fmt_f2(b + k, sf[F_SQ2] / (float)si[I_NQ2]); else { memcpy(b + k, "0.00", 4); k += 4; }
-    b[k++] = ':';
-    k += fmt_f2(b + k, (float)si[I_SCLIP] / c); b[k++] = ':';
-    k += fmt_f2(b + k, sf[F_S3P] / c);
-    o.append(b, (size_t)k);
+    w += fmt_u32(w, n); *w++ = ':';
+    w += fmt_f2(w, (float)si[I_SMQ] / c); *w++ = ':';
+    if (is_indel) { memcpy(w, "0.00", 4); w += 4; } else w += fmt_f2(w, (float)si[I_SBQ] / c);
+    *w++ = ':';
+    w += fmt_f2(w, (float)si[I_SSE] / c); *w++ = ':';
+    w += fmt_u32(w, si[I_PLUS]); *w++ = ':';
+    w += fmt_u32(w, si[I_MINUS]); *w++ = ':';
+    w += fmt_f2(w, sf[F_SEV] / c); *w++ = ':';
+    w += fmt_f2(w, sf[F_SNM] / c); *w++ = ':';
+    w += fmt_f2(w, (float)si[I_SMMQ] / c); *w++ = ':';
+    w += fmt_u32(w, si[I_NQ2]); *w++ = ':';
+    if (si[I_NQ2] > 0) w += fmt_f2(w, sf[F_SQ2] / (float)si[I_NQ2]); else { memcpy(w, "0.00", 4); w += 4; }
+    *w++ = ':';
+    w += fmt_f2(w, (float)si[I_SCLIP] / c); *w++ = ':';
+    w += fmt_f2(w, sf[F_S3P] / c);
+    return w;
 }
+
+// grow-only text buffer the formatter writes into through raw pointers
+struct TextBuf {
+    char* p = nullptr; size_t n = 0, cap = 0;
+    TextBuf() {}
+    TextBuf(const TextBuf&) = delete;
+    TextBuf& operator=(const TextBuf&) = delete;
+    TextBuf(TextBuf&& o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
+    ~TextBuf() { free(p); }
+    void clear() { n = 0; }
+    // pointer to the end of the text with at least k bytes of room behind it; NULL when memory runs out
+    char* room(size_t k) {
+        if (n + k > cap) {
+            size_t c = cap + cap / 2 + (1u << 16);
+            if (c < n + k) c = n + k + (n + k) / 4;
+            char* q = (char*)realloc(p, c);
+            if (!q) return nullptr;
+            p = q; cap = c;
+        }
+        return p + n;
+    }
+};
 
 }  // namespace brc
 
@@ -202,8 +235,10 @@ struct brc_engine {
     // formatter state: the text of the last call (one contiguous buffer, capacity kept across calls), the per-chunk
     // buffers the threads format into (kept too: a fresh 300-MB buffer per piece costs more in page faults than the text)
     char* tbuf = nullptr; size_t tcap = 0, tlen = 0;
-    std::vector<std::string> fparts;
-    std::string text, wev, wtext;
+    std::vector<TextBuf> fparts;
+    std::vector<const char*> part_ptr; std::vector<size_t> part_len;
+    TextBuf wbuf;                                   // brc_format_window's text
+    std::string wev, wtext;
     std::vector<std::deque<QEnt> > queue;
     // host-side phase timers (BRC_ENGINE_TIMING=1: printed by brc_destroy)
     double t_push = 0, t_upload = 0, t_compute = 0, t_d2h = 0, t_post = 0, t_format = 0; int64_t n_regions = 0;
@@ -527,16 +562,20 @@ int brc_clear_indel_queue(brc_engine* e) {
 }
 
 // Record assembly for plane indices [k0,k1) into `out`, with deletion queues `queue` (one FIFO per library).
-// Lines are printed for positions inside [wbeg0, wend) with coordinate pos + 1 - delta.
-static void format_range(const brc_engine* e, const brc_result* r, const char* chrom, int64_t k0, int64_t k1,
-                         std::vector<std::deque<QEnt> >& queue, std::string& out, int32_t wbeg0, int32_t wend, int32_t delta) {
-    const int Lp = r->n_lib; const int64_t P = r->n_pos; const int64_t S = r->stride;
-    (void)P;
-    std::string rec;
+// Lines are printed for positions inside [wbeg0, wend) with coordinate pos + 1 - delta.  Returns false when memory ran out.
+static bool format_range(const brc_engine* e, const brc_result* r, const char* chrom, int64_t k0, int64_t k1,
+                         std::vector<std::deque<QEnt> >& queue, TextBuf& out, int32_t wbeg0, int32_t wend, int32_t delta) {
+    const int Lp = r->n_lib; const int64_t S = r->stride;
     const bool per_lib = e->cfg.per_lib != 0;
     const size_t chrom_len = strlen(chrom);
-    char nb[32];
     uint32_t si[BRC_NI]; float sf[BRC_NF];
+    // room one line needs without its indel entries: chrom, coordinate, reference base, depth, and per library its name,
+    // braces and six buckets
+    size_t max_name = 0; for (const std::string& n : e->libs) max_name = std::max(max_name, n.size());
+    const size_t line0 = chrom_len + 64 + (size_t)Lp * (max_name + 16 + (size_t)BRC_NBUCKET * (STAT_MAX + 4));
+    // the six "\tX:" + all-zero buckets, precomposed
+    char zero[BRC_NBUCKET][ZERO_LEN + 3];
+    for (int b = 0; b < BRC_NBUCKET; ++b) { zero[b][0] = '\t'; zero[b][1] = "=ACGTN"[b]; zero[b][2] = ':'; memcpy(zero[b] + 3, kZeroStat, ZERO_LEN); }
     // cursor into the (pos, lib, allele)-sorted indel list: first entry with pos >= pos0 + k0
     int64_t ii;
     {
@@ -550,6 +589,7 @@ static void format_range(const brc_engine* e, const brc_result* r, const char* c
     const HostPlanes& hp = e->hp;
     size_t xi = 0;
     if (compact) xi = (size_t)(std::lower_bound(e->xagg.begin(), e->xagg.end(), (uint64_t)k0 << 16, [](const XAgg& a, uint64_t key) { return a.key < key; }) - e->xagg.begin());
+    const uint32_t tid = (uint32_t)r->tid;
     for (int64_t k = k0; k < k1; ++k) {
         const int32_t pos = r->pos0 + (int32_t)k;
         while (ii < r->n_indel && r->indel[ii].pos < pos) ++ii;
@@ -558,79 +598,97 @@ static void format_range(const brc_engine* e, const brc_result* r, const char* c
         uint32_t tot = 0, depth = 0;
         for (int l = 0; l < Lp; ++l) { tot += r->ncol[(int64_t)l * S + k]; depth += r->depth[(int64_t)l * S + k]; }
         if (tot == 0) continue;                                                           // no reads: no pileup callback
-        rec.clear();
-        int extra_depth = 0;
+        // deletions queued for this position add their read counts to the depth column (IndelQueue.cpp:11, :415); only
+        // the libraries present in the column look at their queue (:360-411)
+        for (int l = 0; l < Lp; ++l) {
+            const std::deque<QEnt>& q = queue[(size_t)l];
+            if (q.empty() || r->ncol[(int64_t)l * S + k] == 0) continue;
+            for (const QEnt& x : q) {
+                if (x.tid != tid || x.pos < (uint32_t)pos) continue;                      // (stale: dropped below)
+                if (x.pos != (uint32_t)pos) break;
+                depth += x.st.i[I_N];
+            }
+        }
+        const size_t line_start = out.n;
+        char* w = out.room(line0);
+        if (!w) return false;
+        memcpy(w, chrom, chrom_len); w += chrom_len; *w++ = '\t';                        // :414-416
+        w += fmt_u32(w, (uint32_t)(pos + 1 - delta)); *w++ = '\t';
+        *w++ = r->refbase[k]; *w++ = '\t';
+        w += fmt_u32(w, depth);
         for (int l = 0; l < Lp; ++l) {
             if (r->ncol[(int64_t)l * S + k] == 0) continue;                               // lib_counts has no entry (:286,360)
-            if (per_lib) { rec += '\t'; rec += e->libs[(size_t)l]; rec += "\t{"; }
-            const uint32_t sid = compact ? hp.slotid[(int64_t)l * S + k] : 0u;
-            for (int b = 0; b < BRC_NBUCKET; ++b) {
-                rec += '\t'; rec += "=ACGTN"[b]; rec += ':';
-                if (compact) {
-                    const int sl = (uint32_t)b == (sid & 0xffu) ? 0 : ((uint32_t)b == ((sid >> 8) & 0xffu) ? 1 : -1);
+            if (per_lib) { const std::string& nm = e->libs[(size_t)l]; *w++ = '\t'; memcpy(w, nm.data(), nm.size()); w += nm.size(); *w++ = '\t'; *w++ = '{'; }
+            if (compact) {
+                const uint32_t sid = hp.slotid[(int64_t)l * S + k];
+                const uint32_t b0 = sid & 0xffu, b1 = (sid >> 8) & 0xffu;
+                for (uint32_t b = 0; b < (uint32_t)BRC_NBUCKET; ++b) {
+                    const int sl = b == b0 ? 0 : (b == b1 ? 1 : -1);
                     if (sl >= 0) {
-                        const uint32_t* ip = hp.si + (((int64_t)l * 2 + sl) * NI) * S + k; const float* fp = hp.sf + (((int64_t)l * 2 + sl) * NF) * S + k;
-                        si[I_N] = ip[(int64_t)I_N * S];
-                        if (si[I_N] != 0) { for (int f = 0; f < BRC_NI; ++f) si[f] = ip[(int64_t)f * S]; for (int f = 0; f < BRC_NF; ++f) sf[f] = fp[(int64_t)f * S]; }
+                        const uint32_t* ip = hp.si + (((int64_t)l * 2 + sl) * NI) * S + k;
+                        if (ip[(int64_t)I_N * S] == 0) { memcpy(w, zero[b], ZERO_LEN + 3); w += ZERO_LEN + 3; continue; }
+                        const float* fp = hp.sf + (((int64_t)l * 2 + sl) * NF) * S + k;
+                        for (int f = 0; f < BRC_NI; ++f) si[f] = ip[(int64_t)f * S];
+                        for (int f = 0; f < BRC_NF; ++f) sf[f] = fp[(int64_t)f * S];
                     } else {
                         si[I_N] = 0;
                         for (size_t x = xi; x < e->xagg.size() && (int64_t)(e->xagg[x].key >> 16) == k; ++x)
                             if ((e->xagg[x].key & 0xffffu) == (((uint64_t)l << 8) | (uint64_t)b)) { memcpy(si, e->xagg[x].st.i, sizeof si); memcpy(sf, e->xagg[x].st.f, sizeof sf); break; }
+                        if (si[I_N] == 0) { memcpy(w, zero[b], ZERO_LEN + 3); w += ZERO_LEN + 3; continue; }
                     }
-                    fmt_stat(rec, si, sf, false);
-                    continue;
+                    memcpy(w, zero[b], 3); w = fmt_stat(w + 3, si, sf, false);
                 }
-                // (the planes are position-major: look at the count plane first, the other 12 only for occupied buckets)
-                si[I_N] = r->istat[(((int64_t)l * BRC_NBUCKET + b) * BRC_NI + I_N) * S + k];
-                if (si[I_N] == 0) { fmt_stat(rec, si, sf, false); continue; }
-                for (int f = 0; f < BRC_NI; ++f) si[f] = r->istat[(((int64_t)l * BRC_NBUCKET + b) * BRC_NI + f) * S + k];
-                for (int f = 0; f < BRC_NF; ++f) sf[f] = r->fstat[(((int64_t)l * BRC_NBUCKET + b) * BRC_NF + f) * S + k];
-                fmt_stat(rec, si, sf, false);
+            } else {
+                for (int b = 0; b < BRC_NBUCKET; ++b) {
+                    // (the planes are position-major: look at the count plane first, the other 12 only for occupied buckets)
+                    si[I_N] = r->istat[(((int64_t)l * BRC_NBUCKET + b) * BRC_NI + I_N) * S + k];
+                    if (si[I_N] == 0) { memcpy(w, zero[b], ZERO_LEN + 3); w += ZERO_LEN + 3; continue; }
+                    for (int f = 0; f < BRC_NI; ++f) si[f] = r->istat[(((int64_t)l * BRC_NBUCKET + b) * BRC_NI + f) * S + k];
+                    for (int f = 0; f < BRC_NF; ++f) sf[f] = r->fstat[(((int64_t)l * BRC_NBUCKET + b) * BRC_NF + f) * S + k];
+                    memcpy(w, zero[b], 3); w = fmt_stat(w + 3, si, sf, false);
+                }
             }
+            // an indel entry needs room of its own (the allele text is as long as the indel): re-anchor the write pointer
+            auto entry = [&](const char* allele, size_t alen, const uint32_t* ei, const float* ef) -> bool {
+                out.n = (size_t)(w - out.p);
+                w = out.room(alen + 8 + STAT_MAX + line0);
+                if (!w) return false;
+                *w++ = '\t'; memcpy(w, allele, alen); w += alen; *w++ = ':';
+                w = fmt_stat(w, ei, ef, true);
+                return true;
+            };
             while (ii < r->n_indel && r->indel[ii].pos == pos && r->indel[ii].lib < l) ++ii;
             for (; ii < r->n_indel && r->indel[ii].pos == pos && r->indel[ii].lib == l; ++ii) {
                 const brc_indel& d = r->indel[ii];
                 if (d.len < 0) {                                                          // :391-396
-                    QEnt q; q.tid = (uint32_t)r->tid; q.pos = (uint32_t)pos + 1; q.st = d.stat;
+                    QEnt q; q.tid = tid; q.pos = (uint32_t)pos + 1; q.st = d.stat;
                     q.allele.assign(r->alleles + d.allele_off, d.allele_len);
                     queue[(size_t)l].push_back(q);
-                } else {                                                                  // :399
-                    rec += '\t'; rec.append(r->alleles + d.allele_off, d.allele_len); rec += ':';
-                    fmt_stat(rec, d.stat.i, d.stat.f, true);
-                }
+                } else if (!entry(r->alleles + d.allele_off, d.allele_len, d.stat.i, d.stat.f)) return false;   // :399
             }
             // IndelQueue::process (IndelQueue.cpp:3-15)
             std::deque<QEnt>& q = queue[(size_t)l];
-            while (!q.empty() && ((q.front().tid == (uint32_t)r->tid && q.front().pos < (uint32_t)pos) || q.front().tid != (uint32_t)r->tid)) q.pop_front();
-            while (!q.empty() && q.front().tid == (uint32_t)r->tid && q.front().pos == (uint32_t)pos) {
-                rec += '\t'; rec += q.front().allele; rec += ':';
-                fmt_stat(rec, q.front().st.i, q.front().st.f, true);
-                extra_depth += (int)q.front().st.i[I_N];
+            while (!q.empty() && ((q.front().tid == tid && q.front().pos < (uint32_t)pos) || q.front().tid != tid)) q.pop_front();
+            while (!q.empty() && q.front().tid == tid && q.front().pos == (uint32_t)pos) {
+                if (!entry(q.front().allele.data(), q.front().allele.size(), q.front().st.i, q.front().st.f)) return false;
                 q.pop_front();
             }
-            if (per_lib) rec += "\t}";
+            if (per_lib) { *w++ = '\t'; *w++ = '}'; }
         }
-        if (pos >= wbeg0 && pos < wend) {                                                 // :414-416
-            out.append(chrom, chrom_len); out += '\t';
-            out.append(nb, (size_t)fmt_u32(nb, (uint32_t)(pos + 1 - delta))); out += '\t';
-            out += r->refbase[k]; out += '\t';
-            const int d = (int)depth + extra_depth;
-            out.append(nb, (size_t)snprintf(nb, sizeof nb, "%d", d));
-            out += rec; out += '\n';
-        }
+        *w++ = '\n';
+        out.n = (pos >= wbeg0 && pos < wend) ? (size_t)(w - out.p) : line_start;          // the lead position only feeds the queues
     }
+    return true;
 }
 
 // Chunks of positions are formatted by a pool of threads.  A queued deletion lives for exactly one position (pushed at
 // p for p+1, emitted or dropped there), so a chunk starting at k0 > 0 reproduces the queue state it would inherit by
 // replaying position k0-1 into a scratch buffer; chunk 0 continues the engine's persistent queues and the last chunk's
 // final queues become the engine's (regions given on the command line are not separated by a clear, :641-657).
-int brc_format_region(brc_engine* e, const brc_result* r, const char* chrom, const char** text, size_t* text_len) {
-    if (!e || !r || !chrom || !text) return BRC_E_ARG;
+static int format_chunks(brc_engine* e, const brc_result* r, const char* chrom, int64_t* n_chunks, unsigned* threads) {
     const int Lp = r->n_lib; const int64_t P = r->n_pos;
     if ((size_t)Lp != e->queue.size()) return fail(e, BRC_E_ARG, "result does not belong to this engine");
     if (r->istat == NULL && (!e->text_only || e->state != 4)) return fail(e, BRC_E_ARG, "a text-only result can only be formatted right after its fetch");
-    const double t_in = now_s();
     unsigned nthr = std::thread::hardware_concurrency(); if (nthr == 0) nthr = 1; if (nthr > 64) nthr = 64;
     if (const char* t = getenv("BRC_FORMAT_THREADS")) { const int v = atoi(t); if (v > 0) nthr = (unsigned)v; }
     // about four chunks per thread, 2048 .. 65536 positions each (a 1-Mbp piece in 64-Ki chunks keeps only 15 threads busy)
@@ -639,31 +697,60 @@ int brc_format_region(brc_engine* e, const brc_result* r, const char* chrom, con
     if (CH > (1 << 16)) CH = 1 << 16;
     if (const char* t = getenv("BRC_FORMAT_CHUNK")) { const long long v = atoll(t); if (v > 0) CH = v; }   // test knob
     const int64_t nch = std::max<int64_t>((P + CH - 1) / CH, 1);
-    if (e->fparts.size() < (size_t)nch) e->fparts.resize((size_t)nch);
-    std::vector<std::string>& parts = e->fparts;
+    while (e->fparts.size() < (size_t)nch) e->fparts.emplace_back();
+    std::vector<TextBuf>& parts = e->fparts;
     std::vector<std::vector<std::deque<QEnt> > > qs((size_t)nch);
+    std::atomic<int> nomem(0);
     parallel_for(nch, nthr, [&](int64_t c) {
         const int64_t k0 = c * CH, k1 = std::min<int64_t>(P, k0 + CH);
-        if (c == 0) qs[0] = e->queue;
-        else { qs[(size_t)c].assign((size_t)Lp, std::deque<QEnt>()); std::string scratch; format_range(e, r, chrom, k0 - 1, k0, qs[(size_t)c], scratch, r->beg0, r->end, 0); }
-        std::string& part = parts[(size_t)c];
-        part.clear();
-        if (part.capacity() < (size_t)(k1 - k0) * 96) part.reserve((size_t)(k1 - k0) * 96);
-        format_range(e, r, chrom, k0, k1, qs[(size_t)c], part, r->beg0, r->end, 0);
+        bool ok = true;
+        try {
+            if (c == 0) qs[0] = e->queue;
+            else { qs[(size_t)c].assign((size_t)Lp, std::deque<QEnt>()); TextBuf scratch; ok = format_range(e, r, chrom, k0 - 1, k0, qs[(size_t)c], scratch, r->beg0, r->end, 0); }
+            TextBuf& part = parts[(size_t)c];
+            part.clear();
+            ok = ok && format_range(e, r, chrom, k0, k1, qs[(size_t)c], part, r->beg0, r->end, 0);
+        } catch (...) { ok = false; }
+        if (!ok) nomem = 1;
     });
+    if (nomem) return fail(e, BRC_E_NOMEM, "host allocation of the text buffers failed");
     e->queue = qs[(size_t)nch - 1];
+    *n_chunks = nch; *threads = nthr;
+    return BRC_OK;
+}
+
+int brc_format_region(brc_engine* e, const brc_result* r, const char* chrom, const char** text, size_t* text_len) {
+    if (!e || !r || !chrom || !text) return BRC_E_ARG;
+    const double t_in = now_s();
+    int64_t nch = 0; unsigned nthr = 1;
+    const int rc = format_chunks(e, r, chrom, &nch, &nthr);
+    if (rc) return rc;
+    std::vector<TextBuf>& parts = e->fparts;
     // one contiguous text: every chunk is copied to its offset by the pool (the buffer keeps its capacity across calls)
     std::vector<size_t> off((size_t)nch + 1, 0);
-    for (int64_t c = 0; c < nch; ++c) off[(size_t)c + 1] = off[(size_t)c] + parts[(size_t)c].size();
+    for (int64_t c = 0; c < nch; ++c) off[(size_t)c + 1] = off[(size_t)c] + parts[(size_t)c].n;
     const size_t total = off[(size_t)nch];
     if (total + 1 > e->tcap) {
         free(e->tbuf); e->tcap = total + total / 4 + 4096; e->tbuf = (char*)malloc(e->tcap);
         if (!e->tbuf) { e->tcap = 0; return fail(e, BRC_E_NOMEM, "host allocation of the text buffer failed"); }
     }
-    parallel_for(nch, nthr, [&](int64_t c) { if (!parts[(size_t)c].empty()) memcpy(e->tbuf + off[(size_t)c], parts[(size_t)c].data(), parts[(size_t)c].size()); });
+    parallel_for(nch, nthr, [&](int64_t c) { if (parts[(size_t)c].n) memcpy(e->tbuf + off[(size_t)c], parts[(size_t)c].p, parts[(size_t)c].n); });
     e->tbuf[total] = 0; e->tlen = total;
     *text = e->tbuf;
     if (text_len) *text_len = total;
+    e->t_format += now_s() - t_in;
+    return BRC_OK;
+}
+
+int brc_format_region_parts(brc_engine* e, const brc_result* r, const char* chrom, const char* const** parts, const size_t** part_lens, size_t* n_parts) {
+    if (!e || !r || !chrom || !parts || !part_lens || !n_parts) return BRC_E_ARG;
+    const double t_in = now_s();
+    int64_t nch = 0; unsigned nthr = 1;
+    const int rc = format_chunks(e, r, chrom, &nch, &nthr);
+    if (rc) return rc;
+    e->part_ptr.resize((size_t)nch); e->part_len.resize((size_t)nch);
+    for (int64_t c = 0; c < nch; ++c) { e->part_ptr[(size_t)c] = e->fparts[(size_t)c].p ? e->fparts[(size_t)c].p : ""; e->part_len[(size_t)c] = e->fparts[(size_t)c].n; }
+    *parts = e->part_ptr.data(); *part_lens = e->part_len.data(); *n_parts = (size_t)nch;
     e->t_format += now_s() - t_in;
     return BRC_OK;
 }
@@ -673,17 +760,21 @@ int brc_format_window(brc_engine* e, const brc_result* r, const char* chrom, int
     if (!e || !r || !chrom || !text || vend < vbeg0) return BRC_E_ARG;
     if ((size_t)r->n_lib != e->queue.size()) return fail(e, BRC_E_ARG, "result does not belong to this engine");
     if (r->istat == NULL && (!e->text_only || e->state != 4)) return fail(e, BRC_E_ARG, "a text-only result can only be formatted right after its fetch");
-    std::string& out = e->text; out.clear();
+    TextBuf& out = e->wbuf; out.clear();
     // plane indices of [vbeg0 - 1, vend) clipped to the planes; the lead position only feeds the deletion queue (:269 vs :414)
     int64_t k0 = (int64_t)vbeg0 - 1 - r->pos0, k1 = (int64_t)vend - r->pos0;
     if (k0 < 0) k0 = 0;
     if (k1 > r->n_pos) k1 = r->n_pos;
     if (k1 > k0) {
-        std::vector<std::deque<QEnt> > q((size_t)r->n_lib);
-        format_range(e, r, chrom, k0, k1, q, out, vbeg0, vend, delta);
+        bool ok = true;
+        try { std::vector<std::deque<QEnt> > q((size_t)r->n_lib); ok = format_range(e, r, chrom, k0, k1, q, out, vbeg0, vend, delta); } catch (...) { ok = false; }
+        if (!ok) return fail(e, BRC_E_NOMEM, "host allocation of the text buffer failed");
     }
-    *text = out.c_str();
-    if (text_len) *text_len = out.size();
+    char* z = out.room(1);
+    if (!z) return fail(e, BRC_E_NOMEM, "host allocation of the text buffer failed");
+    *z = 0;
+    *text = out.p;
+    if (text_len) *text_len = out.n;
     return BRC_OK;
 }
 

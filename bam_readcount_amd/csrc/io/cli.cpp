@@ -10,8 +10,9 @@
 // and produces degraded output) is refused.
 //
 // Engine-side options (not in the reference): --brc-chunk (tiling of long regions), --brc-plan (site-list planner),
-// --brc-gpus N / BRC_DEVICES=0,1,.. (one engine + worker thread per GPU; work items — region pieces, site-list batches —
-// are dealt out in file order and their text is written in file order).
+// --brc-gpus N / BRC_DEVICES=0,1,.. and --brc-streams K (K engines per GPU, each with a worker thread: while one engine's
+// piece is being formatted the next piece is on the GPU and the one after is being decoded; work items — region pieces,
+// site-list batches — are dealt out in file order and their text is written in file order).
 #include <errno.h>
 #include <limits.h>
 #include <stdio.h>
@@ -19,6 +20,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -35,7 +37,8 @@ struct Options {
     std::vector<std::string> regions;
     long long chunk_bp = 1000000;   // engine-side tiling of long regions (not a reference option): --brc-chunk
     long long plan_sites = 4096;    // site-list planner: -l lines batched per engine pass (0 = one pass per line): --brc-plan
-    long long gpus = 1;             // engines (one per GPU): --brc-gpus
+    long long gpus = 1;             // GPUs: --brc-gpus
+    long long streams = 0;          // engines per GPU (0: 3 when there is more than one work item): --brc-streams
 };
 
 static const char* kUsage =
@@ -67,7 +70,7 @@ struct OptSpec { char s; const char* l; bool takes_value; };
 static const OptSpec kSpecs[] = {
     {'h', "help", false}, {'v', "version", false}, {'q', "min-mapping-quality", true}, {'b', "min-base-quality", true},
     {'d', "max-count", true}, {'l', "site-list", true}, {'f', "reference-fasta", true}, {'D', "print-individual-mapq", true},
-    {'p', "per-library", false}, {'w', "max-warnings", true}, {'i', "insertion-centric", false}, {0, "brc-chunk", true}, {1, "brc-plan", true}, {2, "brc-gpus", true},
+    {'p', "per-library", false}, {'w', "max-warnings", true}, {'i', "insertion-centric", false}, {0, "brc-chunk", true}, {1, "brc-plan", true}, {2, "brc-gpus", true}, {3, "brc-streams", true},
 };
 
 static bool apply(Options& o, const OptSpec& sp, const std::string& v, std::string* err) {
@@ -91,6 +94,7 @@ static bool apply(Options& o, const OptSpec& sp, const std::string& v, std::stri
         case 'D': o.distribution = (v == "1" || v == "true" || v == "yes" || v == "on"); return true;
         case 1: if (!to_ll(&x)) return false; o.plan_sites = x; return true;
         case 2: if (!to_ll(&x)) return false; o.gpus = x; return true;
+        case 3: if (!to_ll(&x)) return false; o.streams = x; return true;
         default: if (!to_ll(&x)) return false; o.chunk_bp = x; return true;
     }
 }
@@ -144,6 +148,7 @@ struct Batcher {
     std::vector<int16_t> lib; std::vector<uint32_t> n_cigar, cigar; std::vector<uint64_t> cig_off, seq_off, qual_off;
     std::vector<uint8_t> seq4, qual;
     std::vector<char> names; std::vector<size_t> name_off; mutable std::vector<const char*> name_ptr;   // read names (warning text)
+    bool keep_names = true;           // -w 0: no warning text will ever be printed
     void clear() { names.clear(); name_off.clear(); pos.clear(); l_qseq.clear(); nm.clear(); sm.clear(); flag.clear(); mapq.clear(); tags.clear(); lib.clear(); n_cigar.clear(); cigar.clear(); cig_off.clear(); seq_off.clear(); qual_off.clear(); seq4.clear(); qual.clear(); }
     void add(const BamRecord& r, int lib_index) {
         pos.push_back(r.pos); flag.push_back(r.flag); mapq.push_back(r.mapq); l_qseq.push_back(r.l_seq); n_cigar.push_back(r.n_cigar);
@@ -156,7 +161,7 @@ struct Batcher {
         if (r.aux_int("NM", &vnm)) t |= BRC_TAG_NM;      // bam_aux_get + bam_aux2i (BasicStat.cpp:94-96)
         if (r.aux_int("SM", &vsm)) t |= BRC_TAG_SM;      // (BasicStat.cpp:79-81)
         nm.push_back(vnm); sm.push_back(vsm); tags.push_back(t);
-        name_off.push_back(names.size()); const char* q = r.qname(); names.insert(names.end(), q, q + strlen(q) + 1);
+        if (keep_names) { name_off.push_back(names.size()); const char* q = r.qname(); names.insert(names.end(), q, q + strlen(q) + 1); }
     }
     brc_read_batch view() const {
         brc_read_batch v; memset(&v, 0, sizeof v);
@@ -222,6 +227,18 @@ struct Ctx {
         print_warn_events(ev, n, opt.max_warnings, wcount, stderr);
     }
     void emit(const char* t, size_t n) { if (!n) return; if (out_buf) out_buf->append(t, n); else fwrite(t, 1, n, stdout); }
+    // several engines, region pieces: the text stays in the engine's buffer (no copy of hundreds of megabytes per piece);
+    // the main thread writes it from there, and this engine's next format call waits for that (pre_format)
+    std::function<void()> pre_format;
+    std::function<void()> after_take;       // run once the piece has taken its reads (the worker starts the next fetch then)
+    const char* const** zc_parts = nullptr; const size_t** zc_lens = nullptr; size_t* zc_n = nullptr;
+    void emit_region(const char* const* parts, const size_t* lens, size_t n) {
+        if (zc_parts) { *zc_parts = parts; *zc_lens = lens; *zc_n = n; return; }
+        for (size_t i = 0; i < n; ++i) emit(parts[i], lens[i]);
+    }
+    // several engines: the reads of this engine's next piece, fetched while the current piece is on the GPU / being formatted
+    struct Prefetch { bool valid = false; int tid = 0; int64_t a = 0, b = 0; } pf;
+    std::unique_ptr<struct Fetched> pf_buf;
     void complain(const std::string& m) { if (err_buf) err_buf->append(m); else fputs(m.c_str(), stderr); }
 };
 
@@ -250,7 +267,7 @@ static void fetch_chunk(Ctx& c, int tid, int64_t a, int64_t b, Fetched& out) {
         if ((int64_t)K > b - q0) K = (unsigned)(b - q0);          // every stripe at least one position wide (stripe 0 must contain q0)
     }
     if (out.parts.size() < K) out.parts.resize(K);
-    for (Batcher& p : out.parts) p.clear();
+    for (Batcher& p : out.parts) { p.clear(); p.keep_names = c.opt.max_warnings != 0; }
     if (K == 1) {
         auto add = [&](const BamRecord& r) { out.parts[0].add(r, c.opt.per_lib ? lib_index(c, r) : 0); };
         if (!(c.is_cram ? c.cram.fetch(tid, a - 1, b, add) : c.bam.fetch(c.idx, tid, a - 1, b, add))) { out.ok = false; out.err = c.is_cram ? c.cram.error() : c.bam.error(); }
@@ -289,7 +306,10 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
     int cur = 0;
     int64_t a = beg0;
     double t0 = now_s();
-    fetch_chunk(c, tid, a, std::min<int64_t>(a + c.opt.chunk_bp, end), bufs[cur]);
+    if (c.pf.valid && c.pf.tid == tid && c.pf.a == a && c.pf.b == std::min<int64_t>(a + c.opt.chunk_bp, end)) std::swap(bufs[cur], *c.pf_buf);   // fetched ahead by the worker
+    else fetch_chunk(c, tid, a, std::min<int64_t>(a + c.opt.chunk_bp, end), bufs[cur]);
+    c.pf.valid = false;
+    if (c.after_take) { c.after_take(); c.after_take = nullptr; }
     c.t_fetch += now_s() - t0;
     do {
         const int64_t b = std::min<int64_t>(a + c.opt.chunk_bp, end);
@@ -309,12 +329,13 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
             const brc_read_batch v = part.view();
             rc = brc_push_reads(c.eng, &v);
         }
-        brc_result res; const char* text = ""; size_t len = 0;
+        brc_result res; const char* const* tparts = nullptr; const size_t* tlens = nullptr; size_t tn = 0;
         if (!rc) rc = brc_end_region(c.eng, &res);
         double t2 = now_s(); c.t_engine += t2 - t1;
-        if (!rc) rc = brc_format_region(c.eng, &res, h.names[(size_t)tid].c_str(), &text, &len);
+        if (!rc && c.pre_format) c.pre_format();
+        if (!rc) rc = brc_format_region_parts(c.eng, &res, h.names[(size_t)tid].c_str(), &tparts, &tlens, &tn);
         double t3 = now_s(); c.t_format += t3 - t2;
-        if (!rc) c.emit(text, len);
+        if (!rc) c.emit_region(tparts, tlens, tn);
         if (!rc && c.opt.max_warnings != 0) { const char* ev = ""; size_t evn = 0; if (brc_region_warnings(c.eng, h.names[(size_t)tid].c_str(), c.opt.max_warnings, &ev, &evn) == 0) c.warn_events(ev, evn); }
         double t4 = now_s(); c.t_write += t4 - t3;
         if (pre.joinable()) pre.join();
@@ -343,6 +364,7 @@ static int run_site_batch(Ctx& c, const std::vector<Site>& sites) {
     const size_t n = sites.size();
     const BamHeader& h = c.header();
     std::vector<Batcher> parts(n);
+    for (Batcher& b : parts) b.keep_names = c.opt.max_warnings != 0;
     std::vector<int64_t> lo(n), hi(n);
     std::atomic<size_t> next(0); std::atomic<int> failed(0);
     auto work = [&]() {
@@ -457,6 +479,7 @@ struct Work {
     std::vector<Site> sites;
     int engine = 0;
     std::string out, err, wev; int rc = 0; bool done = false;
+    const char* const* parts = nullptr; const size_t* lens = nullptr; size_t n_parts = 0;      // a region piece's text, still in its engine's buffers
 };
 
 static int run_item(Ctx& c, Work& w) {
@@ -509,7 +532,14 @@ int main(int argc, char** argv) {
     std::vector<int> devices;
     if (const char* dv = getenv("BRC_DEVICES")) { for (const char* q = dv; *q;) { devices.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q) ++q; } }
     if (devices.empty()) for (long long g = 0; g < std::max<long long>(o.gpus, 1); ++g) devices.push_back((o.gpus <= 1 && getenv("BRC_DEVICE")) ? atoi(getenv("BRC_DEVICE")) : (int)g);
-    const size_t N = devices.size();
+    {   // K engines per GPU, GPU-major round robin (engine i -> GPU i mod #GPUs)
+        long long K = o.streams > 0 ? o.streams : (getenv("BRC_STREAMS") ? atoll(getenv("BRC_STREAMS")) : 3);
+        if (K < 1) K = 1;
+        if (o.max_cnt < 1000000) K = 1;                  // (no internal pieces then)
+        const std::vector<int> one = devices;
+        for (long long k = 1; k < K; ++k) devices.insert(devices.end(), one.begin(), one.end());
+    }
+    size_t N = devices.size();
     int rc = make_engine(c, devices[0]);
     if (rc) { fprintf(stderr, "bam-readcount: cannot create the MI355X engine: %s\n", brc_strerror(rc)); return 1; }
 
@@ -580,6 +610,7 @@ int main(int argc, char** argv) {
         return 1;
     }
 
+    if (items.size() < N) N = std::max<size_t>(items.size(), 1);      // engines without work are never created
     if (N == 1) {
         for (Work& w : items) {
             if (w.kind == 2) { fputs(w.err.c_str(), stderr); ret = 1; break; }
@@ -608,16 +639,48 @@ int main(int argc, char** argv) {
                     cv.notify_all(); return;
                 }
             }
+            size_t held = (size_t)-1;                                               // item whose text sits in this engine's buffer
+            wc->pre_format = [&]() {
+                if (held == (size_t)-1) return;
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&]() { return abort_all || printed > held; });
+                held = (size_t)-1;
+            };
             for (size_t i = 0; i < items.size(); ++i) {
                 Work& w = items[i];
                 if ((size_t)w.engine != g) continue;
-                {   // bound the text held in memory: stay within 4 N items of the one being written
+                {   // bound the text held in memory: stay within 2 N items of the one being written
                     std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&]() { return abort_all || i < printed + 4 * N; });
+                    cv.wait(lk, [&]() { return abort_all || i < printed + 2 * N; });
                     if (abort_all) return;
                 }
                 int r = w.rc;
-                if (w.kind != 2) { wc->out_buf = &w.out; wc->err_buf = &w.err; wc->wev_buf = &w.wev; r = run_item(*wc, w); }
+                if (w.kind != 2) {
+                    wc->out_buf = &w.out; wc->err_buf = &w.err; wc->wev_buf = &w.wev;
+                    // (a piece is formatted by exactly one brc_format_region call: its text can stay where it is)
+                    const bool zc = w.kind == 0 && w.end - w.beg0 <= (int64_t)c.opt.chunk_bp;
+                    wc->zc_parts = zc ? &w.parts : nullptr; wc->zc_lens = zc ? &w.lens : nullptr; wc->zc_n = zc ? &w.n_parts : nullptr;
+                    if (!zc) wc->pre_format();
+                    // the reads of this engine's next piece are fetched meanwhile (own handles: fetch_chunk only touches the
+                    // context's reader pool, which a single-piece item does not use after its own fetch)
+                    std::thread ahead;
+                    size_t j = i + 1;
+                    while (j < items.size() && (size_t)items[j].engine != g) ++j;
+                    if (zc && j < items.size() && items[j].kind == 0 && !wc->is_cram) {
+                        if (!wc->pf_buf) wc->pf_buf.reset(new Fetched());
+                        const Work& nx = items[j];
+                        const int64_t nb = std::min<int64_t>(nx.beg0 + (int64_t)c.opt.chunk_bp, nx.end);
+                        if (!(wc->pf.valid && wc->pf.tid == nx.tid && wc->pf.a == nx.beg0 && wc->pf.b == nb)) {
+                            Ctx* pc = wc; const int ntid = nx.tid; const int64_t na = nx.beg0;
+                            // (started only after this item took its own prefetched reads: run_region swaps them out first thing)
+                            wc->after_take = [pc, ntid, na, nb, &ahead]() { ahead = std::thread([pc, ntid, na, nb]() { fetch_chunk(*pc, ntid, na, nb, *pc->pf_buf); pc->pf.tid = ntid; pc->pf.a = na; pc->pf.b = nb; }); };
+                        }
+                    }
+                    r = run_item(*wc, w);
+                    wc->after_take = nullptr;
+                    if (ahead.joinable()) { ahead.join(); wc->pf.valid = true; }
+                    if (zc && w.n_parts) held = i;
+                }
                 std::lock_guard<std::mutex> lk(mu);
                 w.rc = r; w.done = true; cv.notify_all();
             }
@@ -628,6 +691,7 @@ int main(int argc, char** argv) {
             Work& w = items[i];
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return w.done; }); }
             if (!w.out.empty()) fwrite(w.out.data(), 1, w.out.size(), stdout);
+            for (size_t k = 0; k < w.n_parts; ++k) if (w.lens[k]) fwrite(w.parts[k], 1, w.lens[k], stdout);
             if (!w.wev.empty()) print_warn_events(w.wev.data(), w.wev.size(), c.opt.max_warnings, gcount, stderr);   // the global -w counters, in file order
             if (!w.err.empty()) fputs(w.err.c_str(), stderr);
             std::string().swap(w.out);

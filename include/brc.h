@@ -218,6 +218,13 @@ int  brc_region_counts(brc_engine*, uint64_t* n_events, uint64_t* n_positions);
 int  brc_format_region(brc_engine*, const brc_result*, const char* chrom,
                        const char** text, size_t* text_len);
 
+/* The same text as brc_format_region, handed over as n_parts consecutive pieces — the buffers the formatter's threads wrote,
+ * not concatenated: saves a pass over hundreds of megabytes per region when the caller only writes the text out (the
+ * reference streams its lines to stdout one by one, bamreadcount.cpp:414-416).  Engine-owned, valid until the next
+ * format call on this engine; advances the deletion queues exactly like brc_format_region (call one of the two). */
+int  brc_format_region_parts(brc_engine*, const brc_result*, const char* chrom,
+                             const char* const** parts, const size_t** part_lens, size_t* n_parts);
+
 /*
  * Site-list planner support: format only the sub-window [vbeg0, vend) of a fetched region (plus its lead position
  * vbeg0-1 for deletions), starting from EMPTY deletion queues (the reference clears them after every -l line,

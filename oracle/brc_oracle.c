@@ -550,6 +550,16 @@ const char* brc_last_error(const brc_engine* e) { return e ? e->errbuf : ""; }
 const char* brc_kernel_name(int k) { (void)k; return NULL; }
 const char* brc_engine_kind(void) { return "oracle-c"; }
 
+/* one part: the oracle formats serially */
+static const char* g_part_ptr[1]; static size_t g_part_len[1];
+int brc_format_region_parts(brc_engine* e, const brc_result* r, const char* chrom, const char* const** parts, const size_t** part_lens, size_t* n_parts) {
+    const char* t = ""; size_t n = 0;
+    const int rc = brc_format_region(e, r, chrom, &t, &n);
+    if (rc) return rc;
+    g_part_ptr[0] = t; g_part_len[0] = n; *parts = g_part_ptr; *part_lens = g_part_len; *n_parts = 1;
+    return BRC_OK;
+}
+
 /* the oracle always builds the dense planes; the option only changes how the product lays its result out */
 int brc_set_option(brc_engine* e, int option, int64_t value) { (void)value; return (e && option == BRC_OPT_TEXT_ONLY) ? BRC_OK : BRC_E_ARG; }
 

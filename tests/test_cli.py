@@ -193,14 +193,13 @@ def _multi_engine_check(cli, d):
             ["-p", "-f", "syn.fa", "-l", sl, "syn.bam"]]
     for args in runs:
         env1 = dict(os.environ); env1.pop("BRC_DEVICES", None)
-        one = subprocess.run([cli, "-w", "0", "--brc-chunk", "333"] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env1)
+        one = subprocess.run([cli, "-w", "0", "--brc-chunk", "333", "--brc-streams", "1"] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env1)
         assert one.returncode == 0 and one.stdout.count(b"\n") > 1000, one.stderr
-        for n in ("2", "3"):
-            env = dict(os.environ); env.pop("BRC_DEVICES", None)
-            one_env = env                                            # (the single-engine runs ignore BRC_DEVICES)
-            many = subprocess.run([cli, "-w", "0", "--brc-chunk", "333", "--brc-gpus", n] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        # engines = GPUs x streams; the default is three engines per GPU (pieces pipelined: decode | GPU | format)
+        for extra in (["--brc-gpus", "2", "--brc-streams", "1"], ["--brc-gpus", "3"], [], ["--brc-streams", "5"]):
+            many = subprocess.run([cli, "-w", "0", "--brc-chunk", "333"] + extra + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             assert many.returncode == 0, many.stderr
-            assert many.stdout == one.stdout, (args, n)
+            assert many.stdout == one.stdout, (args, extra)
         whole = subprocess.run([cli, "-w", "0"] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env1)
         assert whole.stdout == one.stdout, args                  # and the tiling itself changes nothing
     bad = subprocess.run([cli, "--brc-gpus", "2", "-f", "syn.fa", "syn.bam", "chrA:1-50", "nochr:1-2", "chrB:1-5"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)

@@ -22,6 +22,28 @@ def build():
     return LIB
 
 
+BAMLIB = os.path.join(HERE, "libbamwrite.so")
+
+
+def write_bam(path, contig, contig_len, arrs, n_libs=1, block_bytes=60000, level=1):
+    """Fast single-contig BAM + BAI of a brc_read_batch (tools/bam_write.c); libraries become @RG rg<k> with LB lib<k>."""
+    src = os.path.join(HERE, "bam_write.c")
+    if not os.path.exists(BAMLIB) or os.path.getmtime(BAMLIB) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-fopenmp", "-fPIC", "-shared", src, "-o", BAMLIB, "-lz"])
+    L = C.CDLL(BAMLIB)
+    text = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:%s\tLN:%d\n" % (contig, contig_len)
+    if n_libs > 1:
+        text += "".join("@RG\tID:rg%d\tLB:lib%d\tSM:s\n" % (k, k) for k in range(n_libs))
+    order = [("pos", np.int32), ("flag", np.uint16), ("mapq", np.uint8), ("lib", np.int16), ("l_qseq", np.int32), ("n_cigar", np.uint32),
+             ("cigar_off", np.uint64), ("seq_off", np.uint64), ("qual_off", np.uint64), ("nm", np.int32), ("sm", np.int32), ("tags", np.uint8),
+             ("cigar", np.uint32), ("seq4", np.uint8), ("qual", np.uint8)]
+    keep = [np.ascontiguousarray(arrs[k], dt) for k, dt in order]
+    rc = L.brc_write_bam(path.encode(), text.encode(), contig.encode(), C.c_int32(contig_len), C.c_int64(len(arrs["pos"])), C.c_int32(n_libs),
+                         *[a.ctypes.data_as(C.c_void_p) for a in keep], C.c_int32(block_bytes), C.c_int32(level))
+    if rc != 0:
+        raise RuntimeError("brc_write_bam failed: %d" % rc)
+
+
 _lib = None
 
 
