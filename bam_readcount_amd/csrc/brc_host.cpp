@@ -232,6 +232,7 @@ struct brc_engine {
     // bucket)-sorted table instead
     bool text_only = false;
     std::vector<XAgg> xagg;
+    size_t hint_reads = 0, hint_bases = 0;          // BRC_OPT_EXPECT_*: staging is sized once instead of grown batch by batch
     // formatter state: the text of the last call (one contiguous buffer, capacity kept across calls), the per-chunk
     // buffers the threads format into (kept too: a fresh 300-MB buffer per piece costs more in page faults than the text)
     char* tbuf = nullptr; size_t tcap = 0, tlen = 0;
@@ -297,6 +298,8 @@ int brc_set_option(brc_engine* e, int option, int64_t value) {
     if (!e) return BRC_E_ARG;
     switch (option) {
         case BRC_OPT_TEXT_ONLY: e->text_only = value != 0; return BRC_OK;
+        case BRC_OPT_EXPECT_READS: e->hint_reads = value > 0 ? (size_t)value : 0; return BRC_OK;
+        case BRC_OPT_EXPECT_BASES: e->hint_bases = value > 0 ? (size_t)value : 0; return BRC_OK;
         default: return fail(e, BRC_E_ARG, "unknown engine option");
     }
 }
@@ -335,6 +338,14 @@ int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
     if ((uint64_t)s.n + n >= 0xFFFFFFF0ull || s.cigar.n + b->n_cigar_total >= 0xFFFFFFF0ull)
         return fail(e, BRC_E_LIMIT, "more than 2^32 reads or CIGAR operators in one region: split the region");
     const uint64_t cb = s.cigar.n, sb = s.seq4.n, qb = s.qual.n;
+    if (e->hint_reads > n0 + n || e->hint_bases > qb + b->qual_bytes) {
+        const size_t hr = std::max(e->hint_reads, n0 + n) + 16, hb = std::max<size_t>(e->hint_bases, qb + b->qual_bytes) + 16;
+        bool okh = s.pos.reserve(hr) && s.flag.reserve(hr) && s.mapq.reserve(hr) && s.l_qseq.reserve(hr) && s.n_cigar.reserve(hr) && s.cig_off.reserve(hr) &&
+                   s.seq_off.reserve(hr) && s.qual_off.reserve(hr) && s.bq_row.reserve(hr) && s.piece_cnt.reserve(hr) && s.piece_off.reserve(hr) && s.lib.reserve(hr) &&
+                   s.nm.reserve(hr) && s.sm.reserve(hr) && s.tags.reserve(hr) && s.qname_off.reserve(hr) && s.cigar.reserve(hr + hr / 4) &&
+                   s.qual.reserve(hb) && s.seq4.reserve(hb / 2 + hr);
+        if (!okh) return fail(e, BRC_E_NOMEM, "host staging allocation failed");
+    }
     bool ok = s.pos.append(b->pos, n) && s.flag.append(b->flag, n) && s.mapq.append(b->mapq, n) && s.l_qseq.append(b->l_qseq, n) &&
               s.n_cigar.append(b->n_cigar, n) && s.cig_off.append(b->cigar_off, n) && s.seq_off.append(b->seq_off, n) &&
               s.qual_off.append(b->qual_off, n) && s.cigar.append(b->cigar, b->n_cigar_total) &&
@@ -688,7 +699,7 @@ static bool format_range(const brc_engine* e, const brc_result* r, const char* c
 static int format_chunks(brc_engine* e, const brc_result* r, const char* chrom, int64_t* n_chunks, unsigned* threads) {
     const int Lp = r->n_lib; const int64_t P = r->n_pos;
     if ((size_t)Lp != e->queue.size()) return fail(e, BRC_E_ARG, "result does not belong to this engine");
-    if (r->istat == NULL && (!e->text_only || e->state != 4)) return fail(e, BRC_E_ARG, "a text-only result can only be formatted right after its fetch");
+    if (r->istat == NULL && (!e->text_only || r->ncol != e->hp.ncol)) return fail(e, BRC_E_ARG, "a text-only result can only be formatted before the next download");
     unsigned nthr = std::thread::hardware_concurrency(); if (nthr == 0) nthr = 1; if (nthr > 64) nthr = 64;
     if (const char* t = getenv("BRC_FORMAT_THREADS")) { const int v = atoi(t); if (v > 0) nthr = (unsigned)v; }
     // about four chunks per thread, 2048 .. 65536 positions each (a 1-Mbp piece in 64-Ki chunks keeps only 15 threads busy)
@@ -759,7 +770,7 @@ int brc_format_window(brc_engine* e, const brc_result* r, const char* chrom, int
                       const char** text, size_t* text_len) {
     if (!e || !r || !chrom || !text || vend < vbeg0) return BRC_E_ARG;
     if ((size_t)r->n_lib != e->queue.size()) return fail(e, BRC_E_ARG, "result does not belong to this engine");
-    if (r->istat == NULL && (!e->text_only || e->state != 4)) return fail(e, BRC_E_ARG, "a text-only result can only be formatted right after its fetch");
+    if (r->istat == NULL && (!e->text_only || r->ncol != e->hp.ncol)) return fail(e, BRC_E_ARG, "a text-only result can only be formatted before the next download");
     TextBuf& out = e->wbuf; out.clear();
     // plane indices of [vbeg0 - 1, vend) clipped to the planes; the lead position only feeds the deletion queue (:269 vs :414)
     int64_t k0 = (int64_t)vbeg0 - 1 - r->pos0, k1 = (int64_t)vend - r->pos0;

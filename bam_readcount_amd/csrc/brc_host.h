@@ -32,8 +32,9 @@ struct HBuf {
     const HostAlloc* A = nullptr;
     bool reserve(size_t want) {
         if (want <= cap) return true;
-        size_t c = cap ? cap : 1024;
-        while (c < want) c += c / 2 + 1024;
+        // (pinned allocations are expensive: double, and never start small)
+        size_t c = cap ? 2 * cap : (size_t)(1u << 16);
+        if (c < want) c = want + want / 8;
         T* q = (T*)A->alloc(c * sizeof(T));
         if (!q) return false;
         if (n) memcpy(q, p, n * sizeof(T));

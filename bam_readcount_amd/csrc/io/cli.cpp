@@ -10,14 +10,16 @@
 // and produces degraded output) is refused.
 //
 // Engine-side options (not in the reference): --brc-chunk (tiling of long regions), --brc-plan (site-list planner),
-// --brc-gpus N / BRC_DEVICES=0,1,.. and --brc-streams K (K engines per GPU, each with a worker thread: while one engine's
-// piece is being formatted the next piece is on the GPU and the one after is being decoded; work items — region pieces,
-// site-list batches — are dealt out in file order and their text is written in file order).
+// --brc-gpus N / BRC_DEVICES=0,1,.. and --brc-streams K (K engines per GPU, each with a worker thread; work items — region
+// pieces, site-list batches — are dealt out in file order and their text is written in file order).  Every engine
+// pipelines consecutive pieces: piece k is formatted and written while piece k+1 is staged and on the GPU and piece k+2
+// is being decoded.
 #include <errno.h>
 #include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <functional>
@@ -38,7 +40,7 @@ struct Options {
     long long chunk_bp = 1000000;   // engine-side tiling of long regions (not a reference option): --brc-chunk
     long long plan_sites = 4096;    // site-list planner: -l lines batched per engine pass (0 = one pass per line): --brc-plan
     long long gpus = 1;             // GPUs: --brc-gpus
-    long long streams = 0;          // engines per GPU (0: 3 when there is more than one work item): --brc-streams
+    long long streams = 0;          // engines per GPU (0: one; every engine already overlaps decode | GPU | format of consecutive pieces): --brc-streams
 };
 
 static const char* kUsage =
@@ -311,39 +313,67 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
     c.pf.valid = false;
     if (c.after_take) { c.after_take(); c.after_take = nullptr; }
     c.t_fetch += now_s() - t0;
+    // Two stages, one piece apart: while a helper thread formats and writes piece k (host planes of the last download),
+    // this thread stages, uploads and computes piece k + 1 (staging and device buffers only); the download of k + 1 —
+    // which overwrites the host planes — waits for the helper.  include/brc.h states this concurrency rule.
+    brc_result res[2]; int slot = 0;
+    std::thread fmt; int fmt_rc = 0; double fmt_s = 0;
+    auto join_fmt = [&]() { if (fmt.joinable()) { fmt.join(); c.t_format += fmt_s; fmt_s = 0; } return fmt_rc; };
+    int rc = 0;
     do {
         const int64_t b = std::min<int64_t>(a + c.opt.chunk_bp, end);
         Fetched& F = bufs[cur];
-        if (!F.ok) { c.complain("bam-readcount: read error: " + F.err + "\n"); return 1; }
+        if (!F.ok) { join_fmt(); c.complain("bam-readcount: read error: " + F.err + "\n"); return 1; }
         std::thread pre;
         const bool more = b < end;
         if (more) pre = std::thread([&c, tid, b, end, &bufs, cur]() { fetch_chunk(c, tid, b, std::min<int64_t>(b + c.opt.chunk_bp, end), bufs[cur ^ 1]); });
         double t1 = now_s();
-        // an internal piece boundary is not a region boundary: the deletions left pending by the previous piece start at its
-        // last position, which is this piece's lead position and queues them again — drop the leftovers (the FIRST piece
-        // keeps whatever the previous command-line region left, like the reference, :641-657)
-        if (a > beg0 || !keep_queue) brc_clear_indel_queue(c.eng);
-        int rc = brc_begin_region(c.eng, tid, (int32_t)a, (int32_t)b, ref, (int64_t)c.ref.size());
+        rc = brc_begin_region(c.eng, tid, (int32_t)a, (int32_t)b, ref, (int64_t)c.ref.size());
+        {   // the stripes of a piece arrive as separate batches: tell the engine their total so it sizes its staging once
+            size_t nr = 0, nq = 0; for (const Batcher& part : F.parts) { nr += part.pos.size(); nq += part.qual.size(); }
+            brc_set_option(c.eng, BRC_OPT_EXPECT_READS, (int64_t)(nr + nr / 8)); brc_set_option(c.eng, BRC_OPT_EXPECT_BASES, (int64_t)(nq + nq / 8));
+        }
         for (const Batcher& part : F.parts) {
             if (rc || part.pos.empty()) continue;
             const brc_read_batch v = part.view();
             rc = brc_push_reads(c.eng, &v);
         }
-        brc_result res; const char* const* tparts = nullptr; const size_t* tlens = nullptr; size_t tn = 0;
-        if (!rc) rc = brc_end_region(c.eng, &res);
+        if (!rc) rc = brc_upload(c.eng);
+        if (!rc) rc = brc_compute(c.eng, nullptr);
         double t2 = now_s(); c.t_engine += t2 - t1;
-        if (!rc && c.pre_format) c.pre_format();
-        if (!rc) rc = brc_format_region_parts(c.eng, &res, h.names[(size_t)tid].c_str(), &tparts, &tlens, &tn);
-        double t3 = now_s(); c.t_format += t3 - t2;
-        if (!rc) c.emit_region(tparts, tlens, tn);
-        if (!rc && c.opt.max_warnings != 0) { const char* ev = ""; size_t evn = 0; if (brc_region_warnings(c.eng, h.names[(size_t)tid].c_str(), c.opt.max_warnings, &ev, &evn) == 0) c.warn_events(ev, evn); }
-        double t4 = now_s(); c.t_write += t4 - t3;
+        const int prev_rc = join_fmt();                       // piece k is out: its host planes may be overwritten
+        double t3 = now_s(); c.t_write += t3 - t2;           // (time this thread waited for the formatter / writer)
+        if (!rc && prev_rc) rc = prev_rc;
+        brc_result& R = res[slot]; slot ^= 1;
+        if (!rc) rc = brc_fetch_result(c.eng, &R);
+        c.t_engine += now_s() - t3;
+        if (!rc) {
+            // an internal piece boundary is not a region boundary: the deletions left pending by the previous piece start at
+            // its last position, which is this piece's lead position and queues them again — drop the leftovers (the FIRST
+            // piece keeps whatever the previous command-line region left, like the reference, :641-657)
+            const bool clear_first = a > beg0 || !keep_queue;
+            const char* chrom = h.names[(size_t)tid].c_str();
+            fmt_rc = 0;
+            fmt = std::thread([&c, &R, chrom, clear_first, &fmt_rc, &fmt_s]() {
+                const double f0 = now_s();
+                if (clear_first) brc_clear_indel_queue(c.eng);
+                if (c.pre_format) c.pre_format();
+                const char* const* tparts = nullptr; const size_t* tlens = nullptr; size_t tn = 0;
+                fmt_rc = brc_format_region_parts(c.eng, &R, chrom, &tparts, &tlens, &tn);
+                if (!fmt_rc) c.emit_region(tparts, tlens, tn);
+                fmt_s = now_s() - f0;
+            });
+            // (the warnings read the staged reads of this piece: before the next brc_begin_region)
+            if (c.opt.max_warnings != 0) { const char* ev = ""; size_t evn = 0; if (brc_region_warnings(c.eng, chrom, c.opt.max_warnings, &ev, &evn) == 0) c.warn_events(ev, evn); }
+            for (int w = 0; w < BRC_N_WARN; ++w) c.warn[w] += R.warn[w];
+        }
+        double t4 = now_s();
         if (pre.joinable()) pre.join();
         c.t_fetch += now_s() - t4;                  // only the part of the background fetch that was not hidden
-        if (rc) { c.complain(std::string("bam-readcount: engine error: ") + brc_strerror(rc) + " (" + brc_last_error(c.eng) + ")\n"); return 1; }
-        for (int w = 0; w < BRC_N_WARN; ++w) c.warn[w] += res.warn[w];
+        if (rc) { join_fmt(); c.complain(std::string("bam-readcount: engine error: ") + brc_strerror(rc) + " (" + brc_last_error(c.eng) + ")\n"); return 1; }
         a = b; cur ^= 1;
     } while (a < end);
+    if ((rc = join_fmt())) { c.complain(std::string("bam-readcount: engine error: ") + brc_strerror(rc) + " (" + brc_last_error(c.eng) + ")\n"); return 1; }
     if (site_mode) brc_clear_indel_queue(c.eng);                                      // :605
     return 0;
 }
@@ -533,7 +563,7 @@ int main(int argc, char** argv) {
     if (const char* dv = getenv("BRC_DEVICES")) { for (const char* q = dv; *q;) { devices.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q) ++q; } }
     if (devices.empty()) for (long long g = 0; g < std::max<long long>(o.gpus, 1); ++g) devices.push_back((o.gpus <= 1 && getenv("BRC_DEVICE")) ? atoi(getenv("BRC_DEVICE")) : (int)g);
     {   // K engines per GPU, GPU-major round robin (engine i -> GPU i mod #GPUs)
-        long long K = o.streams > 0 ? o.streams : (getenv("BRC_STREAMS") ? atoll(getenv("BRC_STREAMS")) : 3);
+        long long K = o.streams > 0 ? o.streams : (getenv("BRC_STREAMS") ? atoll(getenv("BRC_STREAMS")) : 1);
         if (K < 1) K = 1;
         if (o.max_cnt < 1000000) K = 1;                  // (no internal pieces then)
         const std::vector<int> one = devices;
@@ -611,6 +641,7 @@ int main(int argc, char** argv) {
     }
 
     if (items.size() < N) N = std::max<size_t>(items.size(), 1);      // engines without work are never created
+    const bool clean_exit = getenv("BRC_CLEAN_EXIT") != nullptr || getenv("BRC_ENGINE_TIMING") != nullptr;
     if (N == 1) {
         for (Work& w : items) {
             if (w.kind == 2) { fputs(w.err.c_str(), stderr); ret = 1; break; }
@@ -700,9 +731,15 @@ int main(int argc, char** argv) {
         }
         { std::lock_guard<std::mutex> lk(mu); abort_all = abort_all || ret != 0; printed = items.size(); cv.notify_all(); }
         for (std::thread& t : th) t.join();
-        for (size_t g = 1; g < N; ++g) if (ctxs[g]) { for (int w = 0; w < BRC_N_WARN; ++w) c.warn[w] += ctxs[g]->warn[w]; if (ctxs[g]->eng) brc_destroy(ctxs[g]->eng); }
+        // (the process is about to end: see below for why the engines are only destroyed on request)
+        for (size_t g = 1; g < N; ++g) if (ctxs[g]) { for (int w = 0; w < BRC_N_WARN; ++w) c.warn[w] += ctxs[g]->warn[w]; if (ctxs[g]->eng && clean_exit) brc_destroy(ctxs[g]->eng); }
+        if (!clean_exit) for (auto& p : ctxs) (void)p.release();
     }
     if (getenv("BRC_CLI_TIMING")) fprintf(stderr, "timing: fetch+decode %.3f s, engine (push, upload, kernels, download) %.3f s, format %.3f s, write %.3f s\n", c.t_fetch, c.t_engine, c.t_format, c.t_write);
+    // Everything has been written.  Unpinning and freeing gigabytes of staging and the HIP runtime's own teardown only delay
+    // the exit of a process that is done: leave them to the operating system (BRC_CLEAN_EXIT=1 keeps the orderly path).
+    fflush(stdout); fflush(stderr);
+    if (!clean_exit) _exit(ret);
     brc_destroy(c.eng);
     return ret;
 }

@@ -16,6 +16,12 @@
  * Conventions: extern "C", opaque handle, plain pointers + sizes, 0 = ok / negative = error
  * (brc_strerror).  No exceptions cross the boundary.  One engine per GPU / rank; one producer thread
  * per engine.  All caller arrays are borrowed only for the duration of the call unless stated.
+ *
+ * Threads: calls on one engine are not re-entrant, with ONE exception that lets a caller pipeline regions: the host-side
+ * assembly of region k (brc_format_region / brc_format_region_parts / brc_format_window, brc_clear_indel_queue) may run on
+ * a second thread while the producer thread already runs brc_begin_region, brc_push_reads, brc_upload and brc_compute of
+ * region k + 1 — those touch the staging and device buffers only.  brc_fetch_result / brc_end_region of region k + 1
+ * overwrite the host result and must wait until region k has been formatted.
  */
 #ifndef BRC_H
 #define BRC_H
@@ -181,6 +187,10 @@ void brc_destroy(brc_engine*);
  *                      engine's compact result (two bucket slots per position + the third-allele list) — and such a result
  *                      must be formatted before the next region of this engine.  Everything else of brc_result is filled. */
 #define BRC_OPT_TEXT_ONLY 1
+/*   BRC_OPT_EXPECT_READS / BRC_OPT_EXPECT_BASES  sizing hints for the next regions (reads and quality bytes a region is
+ *                      expected to push): the pinned staging is allocated once instead of grown batch by batch */
+#define BRC_OPT_EXPECT_READS 2
+#define BRC_OPT_EXPECT_BASES 3
 int  brc_set_option(brc_engine*, int option, int64_t value);
 
 /* Open the reporting window [beg0,end) on contig tid.  ref = raw FASTA characters of the whole contig

@@ -201,10 +201,14 @@ class SimBackend : public Backend {
         }
         return BRC_OK;
     }
+    // "download": like the HIP backend, the host view is a copy — upload / compute of the next region may run while the
+    // previous result is still being formatted (include/brc.h, threads)
+    std::vector<uint32_t> h_ncol, h_depth, h_slotid, h_si, h_unavail; std::vector<float> h_sf; std::vector<XEv> h_xev; std::vector<IndelOut> h_iout;
     int fetch(HostPlanes* out) override {
-        out->ncol = ncol.data(); out->depth = depth.data(); out->slotid = slotid.data(); out->si = si.data(); out->sf = sf.data(); out->unavail = unavail.data();
-        out->xev = xev.data(); out->n_xev = xev_n;
-        out->indel = iout.data(); out->n_indel = (int64_t)iout.size(); out->n_events = n_events; out->n_positions = n_positions;
+        h_ncol = ncol; h_depth = depth; h_slotid = slotid; h_si = si; h_unavail = unavail; h_sf = sf; h_xev = xev; h_iout = iout;
+        out->ncol = h_ncol.data(); out->depth = h_depth.data(); out->slotid = h_slotid.data(); out->si = h_si.data(); out->sf = h_sf.data(); out->unavail = h_unavail.data();
+        out->xev = h_xev.data(); out->n_xev = xev_n;
+        out->indel = h_iout.data(); out->n_indel = (int64_t)h_iout.size(); out->n_events = n_events; out->n_positions = n_positions;
         memcpy(out->warn, warn, sizeof warn);
         return BRC_OK;
     }

@@ -195,8 +195,8 @@ def _multi_engine_check(cli, d):
         env1 = dict(os.environ); env1.pop("BRC_DEVICES", None)
         one = subprocess.run([cli, "-w", "0", "--brc-chunk", "333", "--brc-streams", "1"] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env1)
         assert one.returncode == 0 and one.stdout.count(b"\n") > 1000, one.stderr
-        # engines = GPUs x streams; the default is three engines per GPU (pieces pipelined: decode | GPU | format)
-        for extra in (["--brc-gpus", "2", "--brc-streams", "1"], ["--brc-gpus", "3"], [], ["--brc-streams", "5"]):
+        # engines = GPUs x streams
+        for extra in (["--brc-gpus", "2"], ["--brc-gpus", "3"], ["--brc-streams", "3"], ["--brc-gpus", "2", "--brc-streams", "2"]):
             many = subprocess.run([cli, "-w", "0", "--brc-chunk", "333"] + extra + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             assert many.returncode == 0, many.stderr
             assert many.stdout == one.stdout, (args, extra)
