@@ -264,7 +264,7 @@ static void fetch_chunk(Ctx& c, int tid, int64_t a, int64_t b, Fetched& out) {
     unsigned K = 1;
     static const long long stripe_min = getenv("BRC_FETCH_STRIPE_MIN") ? atoll(getenv("BRC_FETCH_STRIPE_MIN")) : 65536;   // (tests force small chunks into stripes)
     if (!c.is_cram && b - q0 >= stripe_min) {
-        K = std::thread::hardware_concurrency(); if (K == 0) K = 1; if (K > 16) K = 16;
+        K = std::thread::hardware_concurrency() / 4; if (K == 0) K = 1; if (K > 32) K = 32;
         if (const char* t = getenv("BRC_FETCH_THREADS")) { const int v = atoi(t); if (v > 0) K = (unsigned)v; }
         if ((int64_t)K > b - q0) K = (unsigned)(b - q0);          // every stripe at least one position wide (stripe 0 must contain q0)
     }
@@ -552,7 +552,9 @@ int main(int argc, char** argv) {
     if (o.version) { printf("bam-readcount version: 1.0.1-mi355x (engine %s, abi %d)\n", brc_engine_kind(), BRC_ABI_VERSION); return 1; }   // :467-470
     if (o.help || o.bam.empty()) { fputs(kUsage, stdout); fputs("\n", stdout); return 1; }                                                   // :472-475
     fprintf(stderr, "Minimum mapping quality is set to %d\n", o.min_mapq);                                                                 // :477
+    const double t_start = now_s();
     if (!open_inputs(c, false)) return 1;
+    const double t_inputs = now_s();
     for (const std::string& l : c.libs) fprintf(stderr, "Expect library: %s in BAM\n", l.c_str());                                         // :526-529
     if (o.distribution) { fprintf(stderr, "Not currently supporting distributions\n"); return 1; }                                          // :367 (the reference throws)
     // -d below any real depth changes which reads bam_plp_push keeps, and that depends on everything buffered before:
@@ -571,6 +573,7 @@ int main(int argc, char** argv) {
     }
     size_t N = devices.size();
     int rc = make_engine(c, devices[0]);
+    const double t_engine0 = now_s();
     if (rc) { fprintf(stderr, "bam-readcount: cannot create the MI355X engine: %s\n", brc_strerror(rc)); return 1; }
 
     // ---- the work items, in file order
@@ -735,6 +738,7 @@ int main(int argc, char** argv) {
         for (size_t g = 1; g < N; ++g) if (ctxs[g]) { for (int w = 0; w < BRC_N_WARN; ++w) c.warn[w] += ctxs[g]->warn[w]; if (ctxs[g]->eng && clean_exit) brc_destroy(ctxs[g]->eng); }
         if (!clean_exit) for (auto& p : ctxs) (void)p.release();
     }
+    if (getenv("BRC_CLI_TIMING")) fprintf(stderr, "startup: open inputs %.3f s, create engine %.3f s\n", t_inputs - t_start, t_engine0 - t_inputs);
     if (getenv("BRC_CLI_TIMING")) fprintf(stderr, "timing: fetch+decode %.3f s, engine (push, upload, kernels, download) %.3f s, format %.3f s, write %.3f s\n", c.t_fetch, c.t_engine, c.t_format, c.t_write);
     // Everything has been written.  Unpinning and freeing gigabytes of staging and the HIP runtime's own teardown only delay
     // the exit of a process that is done: leave them to the operating system (BRC_CLEAN_EXIT=1 keeps the orderly path).
