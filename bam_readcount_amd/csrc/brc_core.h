@@ -136,6 +136,7 @@ struct IndelOut { int32_t pos, lib, len; uint32_t rep_read; int32_t rep_qpos; ui
 // of a third, fourth, ... base (sequencing errors: well under 1 % of the positions) are appended to a list as raw
 // addends and folded in by the host when it expands the slots to the ABI's dense planes (expand_slots, brc_host.cpp),
 // in list order = pileup-column order, so the fp32 sums stay bit-exact.
+enum { XEV_CTR_STRIDE = 16 };   // words between the cursors of two sub-lists (64 bytes)
 struct XEv {                // one third-allele event (48 bytes)
     uint32_t k;             // plane index of the position
     uint32_t lib_b;         // library << 8 | bucket
@@ -151,9 +152,12 @@ struct Planes {
     uint32_t* si;       // [Lp][2][9][PS]
     float* sf;          // [Lp][2][4][PS]
     uint32_t* unavail;  // [PS]
-    XEv* xev;           // third-allele events, appended with atomic cursor *xev_n; entries past xev_cap are dropped
-    uint32_t* xev_n;    // (the host sees *xev_n > xev_cap, grows the list and computes again)
+    XEv* xev;           // third-allele events: xev_shards sub-lists of xev_cap entries each, one atomic cursor per sub-list
+    uint32_t* xev_n;    // cursors, XEV_CTR_STRIDE words apart (a single cursor serialises every wave of the launch on one
+                        // L2 atomic unit: ~12 ns per append); entries past xev_cap are dropped — the host sees a cursor
+                        // above xev_cap, grows the lists and computes again
     uint32_t xev_cap;
+    uint32_t xev_shards;   // power of two (1 in the CPU simulator)
 };
 
 // ---------------------------------------------------------------- small tables as packed constants

@@ -33,7 +33,8 @@ namespace brc {
 
 struct Counters {
     unsigned long long n_events, n_positions, w_sm, w_nm, w_lib;
-    unsigned int n_indel_slots, n_xev;   // n_xev: third-allele events KB wanted to append (may exceed the list's capacity)
+    unsigned int n_indel_slots, n_xev;   // n_xev: third-allele events in the compacted list
+    unsigned int xev_max, pad_;          // fullest sub-list's cursor (above its capacity: grow and compute again)
 };
 
 // ---------------------------------------------------------------- wave helpers (wave64)
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void k_refcode(const char* __restrict__ ref, u
 //                          a run crossing a group or pass boundary) goes through a lane-serial walk + neighbour links;
 //                          results are accumulated per read in LDS (sum, first/last quality != 2);
 //   phase C (lane = read)  three-prime / Q2 logic, DRead + float constants, indel-event counting.
-struct AnnPar { uint4 a, b, c; };    // a = {L, qrel, srel, browrel}  b = {S, m1lo, m1hi, d1}  c = {m2lo, m2hi, d2, unused}
+struct AnnPar { uint4 a, b, c; };    // a = {L, qrel, srel, brow.lo}  b = {S, m1lo, m1hi, d1}  c = {m2lo, m2hi, d2, brow.hi}
 
 __device__ __forceinline__ uint32_t nzb7(uint32_t x) { return x + 0x7f7f7f7fu; }   // bytes <= 0x7f: bit 7 of a byte <=> byte != 0
 
@@ -154,14 +155,15 @@ __global__ __launch_bounds__(256) void k_annotate_groups(DevCfg c, DevIn in, DRe
     const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(work >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)work, 0u));
     const uint64_t qbase = __builtin_amdgcn_readfirstlane((uint32_t)qoff) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(qoff >> 32)) << 32);
     const uint64_t sbase = __builtin_amdgcn_readfirstlane((uint32_t)soff) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(soff >> 32)) << 32);
-    const uint64_t bbase = __builtin_amdgcn_readfirstlane((uint32_t)brow) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(brow >> 32)) << 32);
     uint32_t T = 0;
     if (nd) {
         if (work_me) {
             AnnPar p;
-            p.a = make_uint4((uint32_t)L, (uint32_t)(qoff - qbase), (uint32_t)(soff - sbase), (uint32_t)(brow - bbase));
+            // (the rows of a wave's reads are NOT near each other in per-library mode — every library has its own run of rows —
+            // so the row start travels as a full 64-bit element index: a.w low, c.w high)
+            p.a = make_uint4((uint32_t)L, (uint32_t)(qoff - qbase), (uint32_t)(soff - sbase), (uint32_t)brow);
             p.b = make_uint4(0u, (uint32_t)m1lo, (uint32_t)m1hi, (uint32_t)(int32_t)d1);
-            p.c = make_uint4((uint32_t)m2lo, (uint32_t)m2hi, (uint32_t)(int32_t)d2, 0u);
+            p.c = make_uint4((uint32_t)m2lo, (uint32_t)m2hi, (uint32_t)(int32_t)d2, (uint32_t)(brow >> 32));
             W.par[rank] = p;
             W.G[rank] = ((uint32_t)L + 7u) >> 3;
         }
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(256) void k_annotate_groups(DevCfg c, DevIn in, DRe
                 uint4 out;
                 out.x = __builtin_amdgcn_perm(Bk.x, Q.x, 0x01050004u); out.y = __builtin_amdgcn_perm(Bk.x, Q.x, 0x03070206u);
                 out.z = __builtin_amdgcn_perm(Bk.y, Q.y, 0x01050004u); out.w = __builtin_amdgcn_perm(Bk.y, Q.y, 0x03070206u);
-                __builtin_memcpy(bq + bbase + P.a.w + (uint32_t)b, &out, 16);
+                __builtin_memcpy(bq + ((((uint64_t)P.c.w) << 32) | (uint64_t)P.a.w) + (uint32_t)b, &out, 16);
             }
             // ---- first / last base with quality != 2 (:201-238)
             uint2 nz;
@@ -641,6 +643,9 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         const uint32_t thr0 = piece_thr(c);
         char* const rows_base = reinterpret_cast<char*>(&lds.rows[wv][0][0]);
         QEnt* const queue = lds.queue[wv];
+        // sub-list of this workgroup's third-allele events: workgroups in flight on an XCD are consecutive, so their
+        // cursors are different words in different lines
+        const uint32_t xshard = (wg + (uint32_t)lib * 257u) & (pl.xev_shards - 1u);
         uint32_t qn = 0;                                                       // queued entries (scalar)
         int32_t since_flush = 0;
         // ---- staging: lane -> (row, chunk) of a half-batch
@@ -801,11 +806,11 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                     const uint32_t w = (uint32_t)*reinterpret_cast<const uint16_t*>(rows_base + off + 2u * (uint32_t)lane); \
                     if (kind == 0u) {                          /* third alleles: raw addends to the list, in piece order */ \
                         uint32_t at0 = 0;                                                                                 \
-                        if (lane == 0) at0 = atomicAdd(pl.xev_n, (uint32_t)__builtin_popcountll(mask));                   \
+                        if (lane == 0 && c.variant != 11) at0 = atomicAdd(pl.xev_n + (size_t)xshard * XEV_CTR_STRIDE, (uint32_t)__builtin_popcountll(mask)); /* (11: profiling, no list cursor) */ \
                         at0 = (uint32_t)__builtin_amdgcn_readfirstlane(at0);                                              \
                         const uint64_t below = mask & ((1ull << lane) - 1ull);                                            \
                         const uint32_t at = at0 + (uint32_t)__builtin_popcountll(below);                                  \
-                        if (mine && at < pl.xev_cap) pl.xev[at] = make_xev(lib, kk, H, CD, lane + s_c, w);                \
+                        if (mine && at < pl.xev_cap) pl.xev[(size_t)xshard * pl.xev_cap + at] = make_xev(lib, kk, H, CD, lane + s_c, w); \
                     } else if (mine) drain_int(c, pl, lib, kk, CD, (w & 0xffu) == a.dom_b ? 0u : 1u);                     \
                 }                                                                                                         \
                 qn = 0;                                                                                                   \
@@ -933,6 +938,31 @@ __global__ __launch_bounds__(256) void k_finalize_sum(const unsigned long long* 
 
 // ---------------------------------------------------------------- indel side path
 
+// Third-allele sub-lists -> one list (sub-list order; the events of one position all sit in one sub-list, in append
+// order, which is all the host needs): block s copies its entries behind those of the sub-lists before it.
+__global__ __launch_bounds__(256) void k_xev_compact(const XEv* __restrict__ lists, const uint32_t* __restrict__ cursors, uint32_t cap, uint32_t shards,
+                                                    XEv* __restrict__ out, Counters* __restrict__ ctr) {
+    __shared__ unsigned long long sh[4];
+    const uint32_t s = blockIdx.x;
+    unsigned long long before = 0; uint32_t mx = 0;
+    for (uint32_t t = threadIdx.x; t < shards; t += 256) {
+        const uint32_t n = cursors[(size_t)t * XEV_CTR_STRIDE];
+        if (t < s) before += n < cap ? n : cap;
+        mx = n > mx ? n : mx;
+    }
+    before = wave_sum_u64(before);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)mx, o, 64); mx = v > mx ? v : mx; }
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = before;
+    __syncthreads();
+    const unsigned long long off = sh[0] + sh[1] + sh[2] + sh[3];
+    const uint32_t mine = cursors[(size_t)s * XEV_CTR_STRIDE], n = mine < cap ? mine : cap;
+    const uint4* src = reinterpret_cast<const uint4*>(lists + (size_t)s * cap); uint4* dst = reinterpret_cast<uint4*>(out + off);
+    for (uint32_t i = threadIdx.x; i < n * 3u; i += 256) dst[i] = src[i];                 // 48-byte entries as 3 x 16 bytes
+    if (s == shards - 1 && threadIdx.x == 0) ctr->n_xev = (unsigned int)(off + n);
+    if (s == 0 && (threadIdx.x & 63) == 0) atomicMax(&ctr->xev_max, mx);
+}
+
 __global__ __launch_bounds__(256) void k_indel_fill(DevCfg c, DevIn in, const DRead* __restrict__ reads, uint32_t* __restrict__ cursor,
                                                     IndelEv* __restrict__ ev) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1038,10 +1068,11 @@ class HipBackend : public Backend {
     std::vector<int64_t> lib_base;      // first piece of every library's stream (Lp + 1 entries)
     // device buffers
     DBuf d_pos, d_flag, d_mapq, d_lib, d_lq, d_nc, d_co, d_so, d_qo, d_nm, d_sm, d_tags, d_cigar, d_seq, d_qual, d_ref, d_refcode;
-    DBuf d_bq, d_bqrow, d_pieceoff, d_hot, d_cold, d_key, d_reach, d_reads, d_prefmax, d_agg, d_rng, d_ncol, d_depth, d_slotid, d_si, d_sf, d_xev, d_unavail, d_cnt, d_cursor, d_ev, d_iout, d_ctr, d_tilectr, d_part;
+    DBuf d_bq, d_bqrow, d_pieceoff, d_hot, d_cold, d_key, d_reach, d_reads, d_prefmax, d_agg, d_rng, d_ncol, d_depth, d_slotid, d_si, d_sf, d_xev, d_xevc, d_xevn, d_unavail, d_cnt, d_cursor, d_ev, d_iout, d_ctr, d_tilectr, d_part;
     // host result buffers (pinned)
     HBuf<uint32_t> h_ncol, h_depth, h_slotid, h_si, h_unavail; HBuf<float> h_sf; HBuf<IndelOut> h_iout; HBuf<XEv> h_xev;
-    size_t xev_cap = 0;
+    size_t xev_cap = 0;                  // entries per sub-list
+    enum { XEV_SHARDS = 1024 };
     std::vector<IndelOut> iout_compact;
     Counters h_ctr;
     bool computed = false;
@@ -1069,7 +1100,7 @@ class HipBackend : public Backend {
     ~HipBackend() override {
         (void)hipSetDevice(device);
         DBuf* all[] = {&d_pos, &d_flag, &d_mapq, &d_lib, &d_lq, &d_nc, &d_co, &d_so, &d_qo, &d_nm, &d_sm, &d_tags, &d_cigar, &d_seq, &d_qual,
-                       &d_ref, &d_refcode, &d_bq, &d_bqrow, &d_pieceoff, &d_hot, &d_cold, &d_key, &d_reach, &d_reads, &d_prefmax, &d_agg, &d_rng, &d_ncol, &d_depth, &d_slotid, &d_si, &d_sf, &d_xev, &d_unavail, &d_cnt,
+                       &d_ref, &d_refcode, &d_bq, &d_bqrow, &d_pieceoff, &d_hot, &d_cold, &d_key, &d_reach, &d_reads, &d_prefmax, &d_agg, &d_rng, &d_ncol, &d_depth, &d_slotid, &d_si, &d_sf, &d_xev, &d_xevc, &d_xevn, &d_unavail, &d_cnt,
                        &d_cursor, &d_ev, &d_iout, &d_ctr, &d_tilectr, &d_part};
         for (DBuf* b : all) b->release();
         h_ncol.destroy(); h_depth.destroy(); h_slotid.destroy(); h_si.destroy(); h_unavail.destroy(); h_sf.destroy(); h_iout.destroy(); h_xev.destroy();
@@ -1136,9 +1167,15 @@ class HipBackend : public Backend {
         HIPCHK(d_agg.ensure(nagg * 4 + 16)); HIPCHK(d_rng.ensure(((size_t)ntiles * Lp + 1) * sizeof(uint2)));
         HIPCHK(d_ncol.ensure(Lp * P * 4 + 16)); HIPCHK(d_depth.ensure(Lp * P * 4 + 16)); HIPCHK(d_unavail.ensure(P * 4 + 16));
         HIPCHK(d_slotid.ensure(Lp * P * 4 + 16)); HIPCHK(d_si.ensure(Lp * 2 * NI * P * 4 + 16)); HIPCHK(d_sf.ensure(Lp * 2 * NF * P * 4 + 16));
-        if (xev_cap == 0) { const char* xc = getenv("BRC_XEV_CAP"); xev_cap = xc ? (size_t)atoi(xc) : (size_t)1 << 20; }   // (test knob: a tiny list exercises the grow-and-recompute path)
-        xev_cap = std::max(xev_cap, getenv("BRC_XEV_CAP") ? (size_t)1 : np / 16);
-        HIPCHK(d_xev.ensure((xev_cap + 1) * sizeof(XEv)));
+        // third-allele lists: XEV_SHARDS sub-lists; about one piece in 25 leaves an event at 30-50x, capacity for twice that,
+        // spread evenly (the grow-and-recompute path covers the rest)
+        {
+            const char* xc = getenv("BRC_XEV_CAP");           // (test knob: tiny lists exercise the grow-and-recompute path)
+            const size_t want = xc ? (size_t)std::max(atoi(xc), 1) : std::max<size_t>(256, np / 8 / XEV_SHARDS);
+            if (want > xev_cap) xev_cap = want;
+        }
+        HIPCHK(d_xev.ensure(((size_t)XEV_SHARDS * xev_cap + 1) * sizeof(XEv))); HIPCHK(d_xevc.ensure(((size_t)XEV_SHARDS * xev_cap + 1) * sizeof(XEv)));
+        HIPCHK(d_xevn.ensure((size_t)XEV_SHARDS * XEV_CTR_STRIDE * 4));
         HIPCHK(d_part.ensure(4096 * 5 * sizeof(unsigned long long)));
         HIPCHK(d_ctr.ensure(sizeof(Counters))); HIPCHK(d_tilectr.ensure(((size_t)ntiles * Lp + 1) * sizeof(uint4)));
         if (n_indel_cap) {
@@ -1167,10 +1204,11 @@ class HipBackend : public Backend {
         int rc;
         Counters* ctr = (Counters*)d_ctr.p;
         HIPCHK(hipMemsetAsync(ctr, 0, sizeof(Counters), stream));
+        HIPCHK(hipMemsetAsync(d_xevn.p, 0, (size_t)XEV_SHARDS * XEV_CTR_STRIDE * 4, stream));
         const bool indels = n_indel_cap > 0 && P > 0 && n > 0;
         if (indels) HIPCHK(hipMemsetAsync(d_cnt.p, 0, (size_t)(Lp * P) * 4, stream));
         Planes pl = {(uint32_t*)d_ncol.p, (uint32_t*)d_depth.p, (uint32_t*)d_slotid.p, (uint32_t*)d_si.p, (float*)d_sf.p, (uint32_t*)d_unavail.p,
-                     (XEv*)d_xev.p, &ctr->n_xev, (uint32_t)xev_cap};
+                     (XEv*)d_xev.p, (uint32_t*)d_xevn.p, (uint32_t)xev_cap, (uint32_t)XEV_SHARDS};
         const DRead* reads = (const DRead*)d_reads.p;
         HIPCHK(hipEventRecord(evt[T_ANNOTATE], stream));
         if (n > 0) {
@@ -1207,6 +1245,8 @@ class HipBackend : public Backend {
             static const unsigned dyn_lds = getenv("BRC_PILEUP_LDS_PAD") ? (unsigned)atoi(getenv("BRC_PILEUP_LDS_PAD")) : 0u;
             hipLaunchKernelGGL(k_pileup2, dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), dyn_lds, stream, c, in, (const uint4*)d_hot.p, (const PieceCold*)d_cold.p,
                                (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.bq, (const uint32_t*)d_unavail.p);
+            hipLaunchKernelGGL(k_xev_compact, dim3((unsigned)XEV_SHARDS), dim3(256), 0, stream, (const XEv*)d_xev.p, (const uint32_t*)d_xevn.p, (uint32_t)xev_cap,
+                               (uint32_t)XEV_SHARDS, (XEv*)d_xevc.p, ctr);
         }
         HIPCHK(hipEventRecord(evt[T_COUNT], stream));
         if (P > 0) {
@@ -1229,9 +1269,9 @@ class HipBackend : public Backend {
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(&h_ctr, ctr, sizeof(Counters), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
-        if ((size_t)h_ctr.n_xev > xev_cap) {          // the third-allele list was too short: grow it and compute again
-            xev_cap = (size_t)h_ctr.n_xev * 2;
-            HIPCHK(d_xev.ensure((xev_cap + 1) * sizeof(XEv)));
+        if ((size_t)h_ctr.xev_max > xev_cap) {        // a third-allele sub-list was too short: grow them and compute again
+            xev_cap = (size_t)h_ctr.xev_max * 2;
+            HIPCHK(d_xev.ensure(((size_t)XEV_SHARDS * xev_cap + 1) * sizeof(XEv))); HIPCHK(d_xevc.ensure(((size_t)XEV_SHARDS * xev_cap + 1) * sizeof(XEv)));
             return compute(t);
         }
         if (t) {
@@ -1265,7 +1305,7 @@ class HipBackend : public Backend {
             HIPCHK(hipMemcpyAsync(h_sf.p, d_sf.p, Lp * 2 * NF * P * 4, hipMemcpyDeviceToHost, stream));
             if (c.per_lib) HIPCHK(hipMemcpyAsync(h_unavail.p, d_unavail.p, P * 4, hipMemcpyDeviceToHost, stream));
         }
-        if (nx) HIPCHK(hipMemcpyAsync(h_xev.p, d_xev.p, nx * sizeof(XEv), hipMemcpyDeviceToHost, stream));
+        if (nx) HIPCHK(hipMemcpyAsync(h_xev.p, d_xevc.p, nx * sizeof(XEv), hipMemcpyDeviceToHost, stream));
         const size_t ns = h_ctr.n_indel_slots;
         if (ns) {
             if (!h_iout.reserve(ns + 4)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }

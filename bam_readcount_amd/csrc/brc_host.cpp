@@ -64,6 +64,16 @@ void Staged::layout_pieces(int Lp, bool per_lib) {
         if (!piece_cnt.p[i]) { piece_off.p[i] = 0; continue; }
         piece_off.p[i] = (uint32_t)cur[(size_t)l]; cur[(size_t)l] += piece_cnt.p[i];
     }
+    // event-word rows, library-major as well: the pieces a (tile, library) wave stages one after the other then lie one
+    // after the other in the stream (reads without a library, which have no pieces, go last).  Without -p this is the
+    // file order brc_push_reads already assigned.
+    if (per_lib && Lp > 1) {
+        std::vector<uint64_t> rows((size_t)Lp + 2, 0);
+        auto slot = [&](int64_t i) { const int l = (int)lib.p[i]; return (size_t)((l >= 0 && l < Lp) ? l : Lp); };
+        for (int64_t i = 0; i < n; ++i) rows[slot(i) + 1] += ((uint64_t)l_qseq.p[i] + 7u) & ~(uint64_t)7u;
+        for (int l = 0; l <= Lp; ++l) rows[(size_t)l + 1] += rows[(size_t)l];
+        for (int64_t i = 0; i < n; ++i) { const size_t k = slot(i); bq_row.p[i] = rows[k]; rows[k] += ((uint64_t)l_qseq.p[i] + 7u) & ~(uint64_t)7u; }
+    }
 }
 
 // two decimal digits at a time
@@ -243,6 +253,7 @@ struct brc_engine {
     std::vector<std::deque<QEnt> > queue;
     // host-side phase timers (BRC_ENGINE_TIMING=1: printed by brc_destroy)
     double t_push = 0, t_upload = 0, t_compute = 0, t_d2h = 0, t_post = 0, t_format = 0; int64_t n_regions = 0;
+    uint64_t n_xev_total = 0, n_indel_total = 0;
 };
 
 static int fail(brc_engine* e, int code, const char* msg) { e->err = msg; return code; }
@@ -286,8 +297,8 @@ int brc_create(const brc_config* cfg, brc_engine** out) {
 void brc_destroy(brc_engine* e) {
     if (!e) return;
     if (getenv("BRC_ENGINE_TIMING"))
-        fprintf(stderr, "engine timing (%lld regions): push %.3f s, upload %.3f s, compute %.3f s, download %.3f s, assemble %.3f s, format %.3f s\n",
-                (long long)e->n_regions, e->t_push, e->t_upload, e->t_compute, e->t_d2h, e->t_post, e->t_format);
+        fprintf(stderr, "engine timing (%lld regions): push %.3f s, upload %.3f s, compute %.3f s, download %.3f s, assemble %.3f s, format %.3f s; third-allele events %llu, indel buckets %llu\n",
+                (long long)e->n_regions, e->t_push, e->t_upload, e->t_compute, e->t_d2h, e->t_post, e->t_format, (unsigned long long)e->n_xev_total, (unsigned long long)e->n_indel_total);
     e->st.destroy();
     delete e->be;
     free(e->dense_i); free(e->dense_f); free(e->tbuf);
@@ -465,6 +476,7 @@ int brc_fetch_result(brc_engine* e, brc_result* out) {
     int rc = e->be->fetch(&e->hp);
     if (rc) return fail(e, rc, e->be->last_error());
     const double t_dl = now_s(); e->t_d2h += t_dl - t_in;
+    e->n_xev_total += e->hp.n_xev; e->n_indel_total += (uint64_t)e->hp.n_indel;
     const Geometry& g = e->g; const Staged& s = e->st; const HostPlanes& hp = e->hp;
     // column 3: raw reference character (bamreadcount.cpp:353)
     e->refbase.resize((size_t)g.P + 1);

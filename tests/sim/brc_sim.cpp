@@ -153,7 +153,7 @@ class SimBackend : public Backend {
         if (xev.empty()) xev.resize(xc ? (size_t)atoi(xc) : 1024);
       again:
         xev_n = 0;
-        Planes pl = {ncol.data(), depth.data(), slotid.data(), si.data(), sf.data(), unavail.data(), xev.data(), &xev_n, (uint32_t)xev.size()};
+        Planes pl = {ncol.data(), depth.data(), slotid.data(), si.data(), sf.data(), unavail.data(), xev.data(), &xev_n, (uint32_t)xev.size(), 1u};
         n_events = n_positions = 0; memset(warn, 0, sizeof warn);
         const int64_t ntiles = (P + TILE - 1) / TILE;
         for (int l = 0; l < Lp; ++l) {

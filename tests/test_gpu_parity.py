@@ -77,7 +77,8 @@ def test_hip_annotate_mismatch_runs_stress(hip_lib, oracle_lib, mismatch, read_l
 
 
 KNOBS = [{"BRC_NO_TABLE": "1"}, {"BRC_FLUSH_K": "3"}, {"BRC_PACK_LIM": "255", "BRC_FLUSH_K": "9"}, {"BRC_FORCE_DOM": "0"},
-         {"BRC_FORCE_DOM": "3", "BRC_FLUSH_K": "1"}, {"BRC_FORCE_DOM": "5", "BRC_PACK_LIM": "255"}]
+         {"BRC_FORCE_DOM": "3", "BRC_FLUSH_K": "1"}, {"BRC_FORCE_DOM": "5", "BRC_PACK_LIM": "255"},
+         {"BRC_FORCE_DOM": "3", "BRC_XEV_CAP": "1"}]          # one entry per third-allele sub-list: grow and compute again
 
 
 @pytest.mark.parametrize("env", KNOBS, ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()))
