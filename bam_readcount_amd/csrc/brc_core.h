@@ -716,10 +716,28 @@ BRC_HD bool same_allele(const DevIn& in, const DRead* reads, const IndelEv& a, c
 BRC_HD int reduce_indel_key(const DevCfg& c, const DevIn& in, const DRead* reads, IndelEv* ev, int n, int32_t pos, int lib,
                             IndelOut* out, uint32_t& w_sm, uint32_t& w_nm) {
     (void)c;
-    for (int i = 1; i < n; ++i) {                                       // insertion sort by read index; n is tiny
-        const IndelEv t = ev[i]; int j = i - 1;
-        while (j >= 0 && ev[j].read > t.read) { ev[j + 1] = ev[j]; --j; }
-        ev[j + 1] = t;
+    if (n <= 48) {
+        for (int i = 1; i < n; ++i) {                                   // insertion sort by read index: n is tiny as a rule
+            const IndelEv t = ev[i]; int j = i - 1;
+            while (j >= 0 && ev[j].read > t.read) { ev[j + 1] = ev[j]; --j; }
+            ev[j + 1] = t;
+        }
+    } else {
+        // deep targeted data can put thousands of reads on one indel: heapsort (in place, n log n moves; a read has one
+        // event per key, so no ties)
+        auto sift = [&](int root, int end) {
+            const IndelEv t = ev[root];
+            for (;;) {
+                int ch = 2 * root + 1;
+                if (ch >= end) break;
+                if (ch + 1 < end && ev[ch + 1].read > ev[ch].read) ++ch;
+                if (ev[ch].read <= t.read) break;
+                ev[root] = ev[ch]; root = ch;
+            }
+            ev[root] = t;
+        };
+        for (int i = n / 2 - 1; i >= 0; --i) sift(i, n);
+        for (int e2 = n - 1; e2 > 0; --e2) { const IndelEv t = ev[0]; ev[0] = ev[e2]; ev[e2] = t; sift(0, e2); }
     }
     int na = 0;
     for (int i = 0; i < n; ++i) {

@@ -194,7 +194,7 @@ bool BamReader::open(const std::string& path) {
 
 bool BamReader::next(BamRecord* r) {
     uint8_t h[36];
-    if (!bg_.read(h, 4)) return false;
+    if (!bg_.read(h, 4)) { if (!bg_.eof_clean()) err_ = bg_.error().empty() ? "truncated BAM file" : bg_.error(); return false; }
     const uint32_t bs = rd32(h);
     if (bs < 32 || !bg_.read(h + 4, 32)) { err_ = "truncated BAM record"; return false; }
     r->tid = (int32_t)rd32(h + 4); r->pos = (int32_t)rd32(h + 8);
@@ -203,6 +203,28 @@ bool BamReader::next(BamRecord* r) {
     r->mtid = (int32_t)rd32(h + 24); r->mpos = (int32_t)rd32(h + 28); r->tlen = (int32_t)rd32(h + 32);
     r->data.resize(bs - 32);
     if (bs > 32 && !bg_.read(r->data.data(), bs - 32)) { err_ = "truncated BAM record"; return false; }
+    if ((size_t)r->l_qname + 4u * r->n_cigar + (size_t)((r->l_seq + 1) / 2) + (size_t)r->l_seq > r->data.size() || r->l_seq < 0) { err_ = "corrupt BAM record"; return false; }
+    // Long CIGARs (SAMv1 4.2.2): more than 65535 operators are stored in the CG:B,I tag behind the placeholder <l_seq>S<span>N;
+    // put the real operators in place (htslib's bam_tag2cigar does the same when it reads the record)
+    if (r->n_cigar == 2) {
+        const uint32_t c0 = rd32(r->data.data() + r->l_qname), c1 = rd32(r->data.data() + r->l_qname + 4);
+        if ((c0 & 15u) == 4u && (int32_t)(c0 >> 4) == r->l_seq && (c1 & 15u) == 3u) {
+            const uint8_t* t = aux_find(r->aux(), r->data.data() + r->data.size(), "CG");
+            if (t && t[0] == 'B' && (t[1] == 'I' || t[1] == 'i')) {
+                const uint32_t n = rd32(t + 2);
+                const uint8_t* ops = t + 6;
+                if (n > 0 && ops + 4ull * n <= r->data.data() + r->data.size()) {
+                    std::vector<uint8_t> d2;
+                    d2.reserve(r->data.size() + 4ull * n);
+                    d2.insert(d2.end(), r->data.begin(), r->data.begin() + r->l_qname);
+                    d2.insert(d2.end(), ops, ops + 4ull * n);
+                    d2.insert(d2.end(), r->seq(), t - 2);                  // seq, qual and the aux fields before CG
+                    d2.insert(d2.end(), ops + 4ull * n, (const uint8_t*)(r->data.data() + r->data.size()));
+                    r->data.swap(d2); r->n_cigar = n;
+                }
+            }
+        }
+    }
     return true;
 }
 

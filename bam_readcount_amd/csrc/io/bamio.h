@@ -44,7 +44,8 @@ class Bgzf {
 // ---------------------------------------------------------------- BAM
 struct BamRecord {
     int32_t tid = -1, pos = -1, l_seq = 0, mtid = -1, mpos = -1, tlen = 0;
-    uint16_t flag = 0, n_cigar = 0, bin = 0;
+    uint16_t flag = 0, bin = 0;
+    uint32_t n_cigar = 0;            // (32 bits: a CIGAR of more than 65535 operators arrives in the CG tag, SAMv1 4.2.2)
     uint8_t mapq = 0;
     std::vector<uint8_t> data;       // the variable part: qname\0, cigar, seq, qual, aux
     uint32_t l_qname = 0;
@@ -95,11 +96,18 @@ class BamReader {
     bool fetch(const BamIndex& idx, int tid, int64_t beg, int64_t end, F cb) {
         if (beg < 0) beg = 0;
         if (end <= beg) return true;
+        err_.clear();
         BamRecord r;
         for (const Chunk& c : idx.query(tid, beg, end)) {
             if (!bg_.seek(c.beg)) return false;
             while (bg_.tell() < c.end) {
-                if (!next(&r)) break;
+                if (!next(&r)) {
+                    // the end of the file inside a chunk is not an error (the index may point past the last record); a
+                    // truncated record, a failed inflate or a bad block is — the caller must not print a partial result
+                    if (bg_.eof_clean() && err_.empty()) break;
+                    if (err_.empty()) err_ = bg_.error().empty() ? "read error" : bg_.error();
+                    return false;
+                }
                 if (r.tid != tid || r.pos >= end) { if (r.tid > tid || (r.tid == tid && r.pos >= end)) return true; continue; }
                 if (r.endpos() > beg) cb(r);
             }

@@ -374,7 +374,7 @@ struct CramReader::Impl {
             }
             // ---- BAM-layout record
             BamRecord rec;
-            rec.tid = ri; rec.pos = ap - 1; rec.mapq = (uint8_t)mq; rec.flag = (uint16_t)bf; rec.l_seq = rl; rec.n_cigar = (uint16_t)cg.size();
+            rec.tid = ri; rec.pos = ap - 1; rec.mapq = (uint8_t)mq; rec.flag = (uint16_t)bf; rec.l_seq = rl; rec.n_cigar = (uint32_t)cg.size();
             if (name.empty()) { const std::string gen = "cram" + std::to_string(r); name.assign(gen.begin(), gen.end()); }
             rec.l_qname = (uint32_t)name.size() + 1;
             rec.data.assign(name.begin(), name.end()); rec.data.push_back(0);

@@ -150,3 +150,20 @@ def make_batch(seed, ref, n_reads, read_len=(30, 120), style="indel", n_libs=1, 
                 nm=np.array(nm, np.int32), sm=np.array(sm, np.int32), tags=np.array(tags, np.uint8),
                 cigar=np.array(cig_all, np.uint32), seq4=np.concatenate(seq_all) if seq_all else np.zeros(0, np.uint8),
                 qual=np.concatenate(qual_all) if qual_all else np.zeros(0, np.uint8))
+
+
+def pile_indels(arrs, x, seed=0, frac=0.9):
+    """Rewrite the CIGAR of (most of) the single-operator reads that span reference position x so that they carry the SAME
+    deletion (3 bases) or an insertion (2 bases) right after x: one (position, library) indel key with hundreds of events."""
+    rng = np.random.default_rng(seed)
+    cig, off, ncs = [], [], []
+    for i in range(len(arrs["pos"])):
+        c = [int(v) for v in arrs["cigar"][int(arrs["cigar_off"][i]):int(arrs["cigar_off"][i]) + int(arrs["n_cigar"][i])]]
+        p, L = int(arrs["pos"][i]), int(arrs["l_qseq"][i])
+        a = x - p + 1                                                # bases up to and including x
+        if len(c) == 1 and (c[0] & 15) == 0 and 4 <= a <= L - 6 and rng.random() < frac:
+            c = [(a << 4) | 0, (3 << 4) | 2, ((L - a) << 4) | 0] if rng.random() < 0.6 else [(a << 4) | 0, (2 << 4) | 1, ((L - a - 2) << 4) | 0]
+        off.append(len(cig)); ncs.append(len(c)); cig += c
+    out = dict(arrs)
+    out["cigar"] = np.array(cig, np.uint32); out["n_cigar"] = np.array(ncs, np.uint32); out["cigar_off"] = np.array(off, np.uint64)
+    return out

@@ -339,6 +339,33 @@ def test_cli_cram_rans_bzip2_lzma_blocks_equal_bam_reader_cpu(synthetic_bam):
     assert c.returncode != 0 and b"CRC32" in c.stderr, c.stderr[-300:]
 
 
+def test_cli_long_cigar_in_cg_tag_and_truncated_bam_cpu(tmp_path):
+    """A record whose CIGAR sits in the CG:B,I tag behind the <l_seq>S<span>N placeholder (SAMv1 4.2.2) is read with its real
+    operators; a BAM cut in the middle of a block is an error (exit code 1, message), not a silently shorter output."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bamio
+    import synth
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    rng = np.random.default_rng(3)
+    ref = synth.make_ref(rng, 4000)
+    arrs = synth.make_batch(77, ref, 900, style="indel")
+    tids = np.zeros(len(arrs["pos"]), int)
+    multi = [i for i in range(len(arrs["pos"])) if int(arrs["n_cigar"][i]) >= 3][:40]
+    assert len(multi) == 40
+    bamio.write_bam(str(tmp_path / "plain.bam"), [("chrA", 4000)], arrs, tids, block_bytes=3000)
+    bamio.write_bam(str(tmp_path / "cg.bam"), [("chrA", 4000)], arrs, tids, block_bytes=3000, long_cigar=set(multi))
+    _write_fasta(tmp_path / "r.fa", [("chrA", ref)])
+    a = subprocess.run([SIM_CLI, "-w", "0", "-f", "r.fa", "plain.bam", "chrA"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    b = subprocess.run([SIM_CLI, "-w", "0", "-f", "r.fa", "cg.bam", "chrA"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert a.returncode == 0 and b.returncode == 0 and a.stdout.count(b"\n") > 3500 and a.stdout == b.stdout
+    raw = open(tmp_path / "plain.bam", "rb").read()
+    open(tmp_path / "cut.bam", "wb").write(raw[:len(raw) * 2 // 3])
+    os.link(tmp_path / "plain.bam.bai", tmp_path / "cut.bam.bai")
+    c = subprocess.run([SIM_CLI, "-w", "0", "-f", "r.fa", "cut.bam", "chrA"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert c.returncode == 1 and b"read error" in c.stderr, (c.returncode, c.stderr[-200:])
+
+
 def test_rans_encoder_round_trip_sizes():
     """tools/cramio.py's rANS encoder against an independent pure-Python decoder written from the same format description
     (sizes 0..9 and larger, skewed and flat distributions, both orders) — guards the test-side writer itself."""

@@ -164,3 +164,15 @@ def test_hip_text_only_engine_prints_the_same(hip_lib, oracle_lib):
         got, res = parity.run_engine(hip_lib, arrs, [(0, 40000), (150000, 150001)], ref=ref, text_only=True, **kw)
         assert got == want and want.count(b"\n") > 39000
         assert not res[0].istat.any()
+
+
+@pytest.mark.gpu
+def test_hip_deep_indel_key_equals_oracle(hip_lib, oracle_lib):
+    """k_indel_reduce with hundreds (and, at 6000 reads, thousands) of events on one (position, library) key."""
+    rng = np.random.default_rng(41)
+    ref = synth.make_ref(rng, 600)
+    for n in (700, 6000):
+        arrs = synth.pile_indels(synth.make_batch(141, ref, n, style="simple", region=(215, 262), read_len=(80, 100), n_libs=2), 270, seed=3)
+        for kw in (dict(), dict(per_lib=True, insertion_centric=True, lib_names=["libA", "libB"])):
+            text, res = parity.compare_libs(hip_lib, oracle_lib, arrs, [(0, 600)], ref=ref, **kw)
+            assert max(int(d["i"][0]) for d in res[0].indels) > n // 8

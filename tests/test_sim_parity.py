@@ -159,3 +159,15 @@ def test_sim_text_only_engine_prints_the_same(sim_lib, oracle_lib, case):
     finally:
         del os.environ["BRC_FORMAT_CHUNK"]; del os.environ["BRC_FORMAT_THREADS"]
     assert got2 == want
+
+
+def test_sim_deep_indel_key_equals_oracle(sim_lib, oracle_lib):
+    """Amplicon-like pile: ~500 reads share one deletion / insertion position — the keyed indel reduction sorts the events of a
+    key by read index (heapsort above 48 events) before folding them in pileup-column order."""
+    rng = np.random.default_rng(41)
+    ref = synth.make_ref(rng, 600)
+    arrs = synth.pile_indels(synth.make_batch(141, ref, 700, style="simple", region=(215, 262), read_len=(80, 100), n_libs=2), 270, seed=3)
+    assert int((arrs["n_cigar"] == 3).sum()) > 400
+    for kw in (dict(), dict(per_lib=True, insertion_centric=True, lib_names=["libA", "libB"])):
+        text, res = parity.compare_libs(sim_lib, oracle_lib, arrs, [(0, 600), (271, 272)], ref=ref, **kw)
+        assert max(int(d["i"][0]) for d in res[0].indels) > 100

@@ -121,7 +121,7 @@ def _bgzf_block(payload):
     return hdr + c + struct.pack("<II", zlib.crc32(payload) & 0xffffffff, len(payload))
 
 
-def write_bam(path, contigs, arrs, tids, rg_of_read=None, rg_lines=(), qnames=None, block_bytes=20000):
+def write_bam(path, contigs, arrs, tids, rg_of_read=None, rg_lines=(), qnames=None, block_bytes=20000, long_cigar=()):
     """contigs: [(name, length)]; arrs: brc_read_batch arrays (coordinate-sorted per contig); tids: contig index per
     read (non-decreasing).  Writes path and path + '.bai'.  Aux: NM:i / SM:i when the tags bits say so, RG:Z."""
     text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % c for c in contigs) + "".join(l + "\n" for l in rg_lines)
@@ -153,6 +153,9 @@ def write_bam(path, contigs, arrs, tids, rg_of_read=None, rg_lines=(), qnames=No
         if int(arrs["tags"][i]) & 1: aux += b"NMi" + struct.pack("<i", int(arrs["nm"][i]))
         if int(arrs["tags"][i]) & 2: aux += b"SMi" + struct.pack("<i", int(arrs["sm"][i]))
         if rg_of_read is not None and rg_of_read[i] is not None: aux += b"RGZ" + rg_of_read[i].encode() + b"\0"
+        if i in long_cigar:      # SAMv1 4.2.2: the real operators travel in CG:B,I behind the placeholder <l_seq>S<span>N
+            aux += b"CGBI" + struct.pack("<I", nc) + b"".join(struct.pack("<I", int(c)) for c in cig)
+            cig = [(L << 4) | 4, (rl << 4) | 3]; nc = 2
         seq = bytes(arrs["seq4"][int(arrs["seq_off"][i]):int(arrs["seq_off"][i]) + (L + 1) // 2])
         qual = bytes(arrs["qual"][int(arrs["qual_off"][i]):int(arrs["qual_off"][i]) + L])
         b = _reg2bin(pos, end)
