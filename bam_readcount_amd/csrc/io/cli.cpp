@@ -210,7 +210,6 @@ static void print_warn_events(const char* ev, size_t n, long long max, int64_t* 
 struct Ctx {
     double t_fetch = 0, t_engine = 0, t_format = 0, t_write = 0;   // BRC_CLI_TIMING=1 prints them on stderr
     Options opt; BamReader bam; BamIndex idx; Fasta fa; bool have_fa = false;
-    std::vector<std::unique_ptr<BamReader> > pool;   // extra BAM handles of the striped parallel fetch
     CramReader cram; bool is_cram = false;          // minimal CRAM 3.0 input (cram.cpp); region queries scan container headers
     const BamHeader& header() const { return is_cram ? cram.header() : bam.header(); }
     brc_engine* eng = nullptr;
@@ -256,7 +255,8 @@ static int lib_index(const Ctx& c, const BamRecord& r) {      // bam_get_library
 // Reads of one chunk [a-1, b) (the reference's own fetch rule, :602), decoded by a pool of BAM handles: the chunk is cut
 // by read START position into K stripes; stripe i keeps the records whose pos lies in its stripe (stripe 0 also the reads
 // that start before the chunk), so the stripes concatenated are exactly the single-handle fetch, in file order.
-struct Fetched { std::vector<Batcher> parts; bool ok = true; std::string err; };
+struct Fetched { std::vector<Batcher> parts; bool ok = true; std::string err;
+                 std::vector<std::unique_ptr<BamReader> > pool; };   // the BAM handles of this buffer's stripes (fetches of different buffers run side by side)
 
 static void fetch_chunk(Ctx& c, int tid, int64_t a, int64_t b, Fetched& out) {
     out.ok = true; out.err.clear();
@@ -270,25 +270,25 @@ static void fetch_chunk(Ctx& c, int tid, int64_t a, int64_t b, Fetched& out) {
     }
     if (out.parts.size() < K) out.parts.resize(K);
     for (Batcher& p : out.parts) { p.clear(); p.keep_names = c.opt.max_warnings != 0; }
-    if (K == 1) {
+    if (c.is_cram) {
         auto add = [&](const BamRecord& r) { out.parts[0].add(r, c.opt.per_lib ? lib_index(c, r) : 0); };
-        if (!(c.is_cram ? c.cram.fetch(tid, a - 1, b, add) : c.bam.fetch(c.idx, tid, a - 1, b, add))) { out.ok = false; out.err = c.is_cram ? c.cram.error() : c.bam.error(); }
+        if (!c.cram.fetch(tid, a - 1, b, add)) { out.ok = false; out.err = c.cram.error(); }
         return;
     }
-    while (c.pool.size() < K) { c.pool.emplace_back(new BamReader()); if (!c.pool.back()->open(c.opt.bam)) { out.ok = false; out.err = "cannot reopen " + c.opt.bam; return; } }
+    while (out.pool.size() < K) { out.pool.emplace_back(new BamReader()); if (!out.pool.back()->open(c.opt.bam)) { out.ok = false; out.err = "cannot reopen " + c.opt.bam; return; } }
     std::atomic<int> failed(0);
     auto work = [&](unsigned i) {
         const int64_t s0 = q0 + (b - q0) * (int64_t)i / (int64_t)K, s1 = q0 + (b - q0) * (int64_t)(i + 1) / (int64_t)K;
-        if (!c.pool[i]->fetch(c.idx, tid, i == 0 ? a - 1 : s0, s1, [&](const BamRecord& r) {
+        if (!out.pool[i]->fetch(c.idx, tid, i == 0 ? a - 1 : s0, s1, [&](const BamRecord& r) {
                 if (r.pos >= s1 || (i > 0 && r.pos < s0)) return;
                 out.parts[i].add(r, c.opt.per_lib ? lib_index(c, r) : 0);
-            })) failed = 1;
+            })) { failed = 1; if (out.err.empty()) out.err = out.pool[i]->error(); }
     };
     std::vector<std::thread> th;
     for (unsigned i = 1; i < K; ++i) th.emplace_back(work, i);
     work(0);
     for (std::thread& t : th) t.join();
-    if (failed) { out.ok = false; out.err = "read error while fetching a region stripe"; }
+    if (failed) { out.ok = false; out.err = "read error while fetching a region stripe" + (out.err.empty() ? std::string() : ": " + out.err); }
 }
 
 // one reporting window [beg0,end) on tid: the body of the site-list / region loops (:588-605, :649-656)
@@ -303,15 +303,27 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
     if (end > (int64_t)h.lengths[(size_t)tid] + 1000) end = (int64_t)h.lengths[(size_t)tid] + 1000;   // nothing aligns past the contig
     if (end < beg0) end = beg0;
     // long regions are cut into abutting pieces; each piece fetches one base early exactly like the reference (:602).
-    // The next piece is fetched and decoded in the background while the current one is on the GPU / being formatted.
-    Fetched bufs[2];
-    int cur = 0;
+    // The next `ahead` pieces are fetched and decoded in the background (each by its own pool of striped BAM handles)
+    // while the current one is on the GPU / being formatted: decoding is the slowest of the three stages.
+    const int64_t chunk = (int64_t)c.opt.chunk_bp;
+    const int64_t npieces = std::max<int64_t>(1, (end - beg0 + chunk - 1) / chunk);
+    static const int ahead_env = getenv("BRC_FETCH_AHEAD") ? atoi(getenv("BRC_FETCH_AHEAD")) : 0;
+    const int ahead = c.is_cram ? 1 : (ahead_env > 0 ? ahead_env : 2);        // (the CRAM reader is one handle: one fetch at a time)
+    std::vector<Fetched> bufs((size_t)ahead + 1); std::vector<std::thread> fth((size_t)ahead + 1);
+    auto start_fetch = [&](int64_t j) {
+        if (j >= npieces) return;
+        const size_t slot = (size_t)(j % (ahead + 1));
+        const int64_t fa = beg0 + j * chunk, fb = std::min<int64_t>(fa + chunk, end);
+        fth[slot] = std::thread([&c, tid, fa, fb, &bufs, slot]() { fetch_chunk(c, tid, fa, fb, bufs[slot]); });
+    };
+    struct JoinAll { std::vector<std::thread>& t; ~JoinAll() { for (std::thread& x : t) if (x.joinable()) x.join(); } } join_all{fth};
     int64_t a = beg0;
     double t0 = now_s();
-    if (c.pf.valid && c.pf.tid == tid && c.pf.a == a && c.pf.b == std::min<int64_t>(a + c.opt.chunk_bp, end)) std::swap(bufs[cur], *c.pf_buf);   // fetched ahead by the worker
-    else fetch_chunk(c, tid, a, std::min<int64_t>(a + c.opt.chunk_bp, end), bufs[cur]);
+    if (c.pf.valid && c.pf.tid == tid && c.pf.a == a && c.pf.b == std::min<int64_t>(a + chunk, end)) std::swap(bufs[0], *c.pf_buf);   // fetched ahead by the worker
+    else start_fetch(0);
     c.pf.valid = false;
-    if (c.after_take) { c.after_take(); c.after_take = nullptr; }
+    if (c.after_take) { if (fth[0].joinable()) fth[0].join(); c.after_take(); c.after_take = nullptr; }
+    for (int64_t j = 1; j < ahead; ++j) start_fetch(j);
     c.t_fetch += now_s() - t0;
     // Two stages, one piece apart: while a helper thread formats and writes piece k (host planes of the last download),
     // this thread stages, uploads and computes piece k + 1 (staging and device buffers only); the download of k + 1 —
@@ -320,13 +332,13 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
     std::thread fmt; int fmt_rc = 0; double fmt_s = 0;
     auto join_fmt = [&]() { if (fmt.joinable()) { fmt.join(); c.t_format += fmt_s; fmt_s = 0; } return fmt_rc; };
     int rc = 0;
-    do {
-        const int64_t b = std::min<int64_t>(a + c.opt.chunk_bp, end);
+    for (int64_t j = 0; j < npieces; ++j) {
+        const int64_t b = std::min<int64_t>(a + chunk, end);
+        const size_t cur = (size_t)(j % (ahead + 1));
+        { const double w0 = now_s(); if (fth[cur].joinable()) fth[cur].join(); c.t_fetch += now_s() - w0; }   // only what the background fetch did not hide
+        start_fetch(j + ahead);                          // into the buffer piece j - 1 has left
         Fetched& F = bufs[cur];
         if (!F.ok) { join_fmt(); c.complain("bam-readcount: read error: " + F.err + "\n"); return 1; }
-        std::thread pre;
-        const bool more = b < end;
-        if (more) pre = std::thread([&c, tid, b, end, &bufs, cur]() { fetch_chunk(c, tid, b, std::min<int64_t>(b + c.opt.chunk_bp, end), bufs[cur ^ 1]); });
         double t1 = now_s();
         rc = brc_begin_region(c.eng, tid, (int32_t)a, (int32_t)b, ref, (int64_t)c.ref.size());
         {   // the stripes of a piece arrive as separate batches: tell the engine their total so it sizes its staging once
@@ -367,12 +379,9 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
             if (c.opt.max_warnings != 0) { const char* ev = ""; size_t evn = 0; if (brc_region_warnings(c.eng, chrom, c.opt.max_warnings, &ev, &evn) == 0) c.warn_events(ev, evn); }
             for (int w = 0; w < BRC_N_WARN; ++w) c.warn[w] += R.warn[w];
         }
-        double t4 = now_s();
-        if (pre.joinable()) pre.join();
-        c.t_fetch += now_s() - t4;                  // only the part of the background fetch that was not hidden
         if (rc) { join_fmt(); c.complain(std::string("bam-readcount: engine error: ") + brc_strerror(rc) + " (" + brc_last_error(c.eng) + ")\n"); return 1; }
-        a = b; cur ^= 1;
-    } while (a < end);
+        a = b;
+    }
     if ((rc = join_fmt())) { c.complain(std::string("bam-readcount: engine error: ") + brc_strerror(rc) + " (" + brc_last_error(c.eng) + ")\n"); return 1; }
     if (site_mode) brc_clear_indel_queue(c.eng);                                      // :605
     return 0;
