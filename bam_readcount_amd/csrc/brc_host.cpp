@@ -20,6 +20,29 @@
 
 namespace brc {
 
+// CPUs this process may really use at once: the affinity mask, capped by a cgroup CPU quota (cpu.max / cfs_quota_us).
+// Pools sized by hardware_concurrency() on a 256-thread host inside a 16-CPU container burn the quota in a fraction of
+// every scheduling period and are throttled for the rest of it.
+unsigned effective_cpus() {
+    static unsigned cached = 0;
+    if (cached) return cached;
+    unsigned n = std::thread::hardware_concurrency(); if (n == 0) n = 1;
+    double quota = 0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                        // cgroup v2: "<quota|max> <period>"
+        char q[64]; long long per = 0;
+        if (fscanf(f, "%63s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) quota = atof(q) / (double)per;
+        fclose(f);
+    } else {
+        long long q = -1, per = 0;
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &q) != 1) q = -1; fclose(g); }
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &per) != 1) per = 0; fclose(g); }
+        if (q > 0 && per > 0) quota = (double)q / (double)per;
+    }
+    if (quota > 0 && quota < (double)n) n = (unsigned)(quota + 0.999);
+    if (n < 1) n = 1;
+    return cached = n;
+}
+
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // run fn(i) for i in [0, n) on up to nthr threads (dynamic hand-out); the caller's thread works too
@@ -144,7 +167,7 @@ void expand_slots(const HostPlanes& hp, int Lp, int64_t P, int64_t PS, uint32_t*
             }
         }
     };
-    unsigned nt = std::thread::hardware_concurrency(); if (nt > 32) nt = 32; if (nt < 1) nt = 1;
+    unsigned nt = effective_cpus(); if (nt > 32) nt = 32; if (nt < 1) nt = 1;
     if (nch < (int64_t)nt) nt = (unsigned)nch;
     std::vector<std::thread> th;
     for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
@@ -712,7 +735,7 @@ static int format_chunks(brc_engine* e, const brc_result* r, const char* chrom, 
     const int Lp = r->n_lib; const int64_t P = r->n_pos;
     if ((size_t)Lp != e->queue.size()) return fail(e, BRC_E_ARG, "result does not belong to this engine");
     if (r->istat == NULL && (!e->text_only || r->ncol != e->hp.ncol)) return fail(e, BRC_E_ARG, "a text-only result can only be formatted before the next download");
-    unsigned nthr = std::thread::hardware_concurrency(); if (nthr == 0) nthr = 1; if (nthr > 64) nthr = 64;
+    unsigned nthr = effective_cpus(); if (nthr > 64) nthr = 64;
     if (const char* t = getenv("BRC_FORMAT_THREADS")) { const int v = atoi(t); if (v > 0) nthr = (unsigned)v; }
     // about four chunks per thread, 2048 .. 65536 positions each (a 1-Mbp piece in 64-Ki chunks keeps only 15 threads busy)
     int64_t CH = P / (4 * (int64_t)nthr);

@@ -115,6 +115,9 @@ const char* backend_kernel_name(int k);
 // slot planes + event list -> dense planes istat[Lp][6][9][PS], fstat[Lp][6][4][PS] (every element written); multi-threaded
 void expand_slots(const HostPlanes& hp, int Lp, int64_t P, int64_t PS, uint32_t* istat, float* fstat);
 
+// CPUs the process may use at once (affinity, cgroup quota): sizes the host-side thread pools
+unsigned effective_cpus();
+
 // exact "%.2f" of a float (== iostream fixed/setprecision(2), BasicStat.cpp:116); returns bytes written
 int fmt_f2(char* out, float v);
 int fmt_u32(char* out, uint32_t v);

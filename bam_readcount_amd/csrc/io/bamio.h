@@ -38,6 +38,7 @@ class Bgzf {
     uint64_t block_coff_ = 0, next_coff_ = 0;
     size_t pos_ = 0, len_ = 0;
     bool eof_ = false;
+    void* ld_ = nullptr;             // libdeflate decompressor of this handle (when the library is present)
     std::string err_;
 };
 

@@ -184,6 +184,27 @@ struct Batcher {
 #include <thread>
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// CPUs this process may really use at once: hardware threads capped by a cgroup CPU quota (a container with 16 CPUs of
+// quota on a 256-thread host is throttled for most of every period if its pools are sized by the hardware)
+static unsigned effective_cpus() {
+    static unsigned cached = 0;
+    if (cached) return cached;
+    unsigned n = std::thread::hardware_concurrency(); if (n == 0) n = 1;
+    double quota = 0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64]; long long per = 0;
+        if (fscanf(f, "%63s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) quota = atof(q) / (double)per;
+        fclose(f);
+    } else {
+        long long q = -1, per = 0;
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &q) != 1) q = -1; fclose(g); }
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &per) != 1) per = 0; fclose(g); }
+        if (q > 0 && per > 0) quota = (double)q / (double)per;
+    }
+    if (quota > 0 && quota < (double)n) n = (unsigned)(quota + 0.999);
+    return cached = (n < 1 ? 1 : n);
+}
+
 // ReadWarnings::warn (src/lib/bamrc/ReadWarnings.hpp:39-50) over a tagged event stream of the engine (brc_region_warnings)
 static void print_warn_events(const char* ev, size_t n, long long max, int64_t* counts, FILE* fp) {
     static const char* const kMsg[BRC_N_WARN] = {
@@ -264,7 +285,7 @@ static void fetch_chunk(Ctx& c, int tid, int64_t a, int64_t b, Fetched& out) {
     unsigned K = 1;
     static const long long stripe_min = getenv("BRC_FETCH_STRIPE_MIN") ? atoll(getenv("BRC_FETCH_STRIPE_MIN")) : 65536;   // (tests force small chunks into stripes)
     if (!c.is_cram && b - q0 >= stripe_min) {
-        K = std::thread::hardware_concurrency() / 4; if (K == 0) K = 1; if (K > 32) K = 32;
+        K = effective_cpus() / 2; if (K == 0) K = 1; if (K > 32) K = 32;
         if (const char* t = getenv("BRC_FETCH_THREADS")) { const int v = atoi(t); if (v > 0) K = (unsigned)v; }
         if ((int64_t)K > b - q0) K = (unsigned)(b - q0);          // every stripe at least one position wide (stripe 0 must contain q0)
     }
@@ -308,7 +329,8 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
     const int64_t chunk = (int64_t)c.opt.chunk_bp;
     const int64_t npieces = std::max<int64_t>(1, (end - beg0 + chunk - 1) / chunk);
     static const int ahead_env = getenv("BRC_FETCH_AHEAD") ? atoi(getenv("BRC_FETCH_AHEAD")) : 0;
-    const int ahead = c.is_cram ? 1 : (ahead_env > 0 ? ahead_env : 2);        // (the CRAM reader is one handle: one fetch at a time)
+    // (the CRAM reader is one handle: one fetch at a time; with few CPUs a second fetch only takes them from the formatter)
+    const int ahead = c.is_cram ? 1 : (ahead_env > 0 ? ahead_env : (effective_cpus() >= 64 ? 2 : 1));
     std::vector<Fetched> bufs((size_t)ahead + 1); std::vector<std::thread> fth((size_t)ahead + 1);
     auto start_fetch = [&](int64_t j) {
         if (j >= npieces) return;
@@ -422,7 +444,7 @@ static int run_site_batch(Ctx& c, const std::vector<Site>& sites) {
             lo[i] = l; hi[i] = r + 64;      // room for deletion alleles read from the reference past the last read
         }
     };
-    unsigned nthr = std::thread::hardware_concurrency(); if (nthr == 0) nthr = 1; if (nthr > 64) nthr = 64;
+    unsigned nthr = effective_cpus(); if (nthr > 64) nthr = 64;
     if (const char* t = getenv("BRC_FETCH_THREADS")) { const int v = atoi(t); if (v > 0) nthr = (unsigned)v; }
     std::vector<std::thread> th;
     for (unsigned k = 1; k < nthr && k < n; ++k) th.emplace_back(work);

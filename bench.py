@@ -43,6 +43,23 @@ HBM_COPY_GBS = 6290.0    # measured streaming-copy rate of the same guide's chip
 CLI = os.path.join(ROOT, "bam_readcount_amd", "csrc", "bam-readcount")
 
 
+def effective_cpus():
+    """CPUs this process may really use at once: the affinity mask capped by a cgroup CPU quota (cpu.max / cfs_quota_us)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(-(-int(q) // int(per)))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, -(-q // per)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_worker(seed, mbp, config):
     """One oracle process of the all-cores baseline: its own slice of the data model; prints events and seconds."""
     import synthgen
@@ -90,7 +107,7 @@ def main():
     ap.add_argument("--contig-mbp", type=float, default=50.0, help="weak/sites: contig per GPU; strong: the whole contig")
     ap.add_argument("--sites", type=int, default=100000, help="--mode sites: lines of the site list (all ranks together)")
     ap.add_argument("--cpu-sample-mbp", type=float, default=8.0, help="prefix timed with the 1-thread CPU oracle and used for validation (0 = skip)")
-    ap.add_argument("--cpu-all-cores", type=int, default=-1, help="oracle processes of the all-cores baseline (-1: min(cores, 64); 0 = skip)")
+    ap.add_argument("--cpu-all-cores", type=int, default=-1, help="oracle processes of the all-cores baseline (-1: min(usable CPUs, 64); 0 = skip)")
     ap.add_argument("--e2e-mbp", type=float, default=30.0, help="contig of the end-to-end command-line run (0 = skip)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r02_traffic.json"))
     ap.add_argument("--cpu-worker", nargs=3, default=None, help=argparse.SUPPRESS)
@@ -124,7 +141,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
 
     ncpu = os.cpu_count() or 1
-    nworkers = (min(ncpu, 64) if args.cpu_all_cores < 0 else args.cpu_all_cores) if (rank == 0 and world == 1 and args.cpu_sample_mbp > 0) else 0
+    ncpu_eff = effective_cpus()
+    nworkers = (min(ncpu_eff, 64) if args.cpu_all_cores < 0 else args.cpu_all_cores) if (rank == 0 and world == 1 and args.cpu_sample_mbp > 0) else 0
 
     hip = capi.load_product()
     per_lib = config == "tumor200x"
@@ -194,14 +212,16 @@ def main():
         alg = b_in + b_ref + b_out
         achieved = alg / (kms[k_pile] * 1e-3) / 1e9 if kms[k_pile] > 0 else 0.0
         traffic = None; traffic_src = None
-        if os.path.exists(args.traffic_json) and args.mode != "sites" and abs(args.contig_mbp - 50.0) < 1e-9 and world == 1:
+        if os.path.exists(args.traffic_json) and args.mode != "sites" and world == 1:
             tj = json.load(open(args.traffic_json)).get(config)
-            if tj:
+            if tj and abs(float(tj.get("contig_mbp", 50.0)) - contig_len / 1e6) < 1e-6:       # the passes measured exactly this workload
                 traffic = tj.get("k_pileup_hbm_bytes_per_launch")
                 traffic_src = "%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not measured in this run" % os.path.relpath(args.traffic_json, ROOT)
         roof = {"bound": "hbm", "kernel": "k_pileup2", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_copy_rate": round(achieved / HBM_COPY_GBS, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_GBs": round(traffic / (kms[k_pile] * 1e-3) / 1e9, 1) if (traffic and kms[k_pile] > 0) else None,
+                "frac_of_peak_by_traffic": round(traffic / (kms[k_pile] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (traffic and kms[k_pile] > 0) else None,
                 "algorithmic_bytes_per_launch": alg, "bytes_per_event": round(alg / max(eng_events, 1), 3),
                 "compact_result_bytes_per_launch": 116 * int(eng_positions) * res_libs,
                 "whole_step_frac": round(alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if world == 1 else None,
@@ -242,8 +262,8 @@ def main():
                                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for w in range(nworkers)]
                 outs = [json.loads(p.communicate()[0].decode().strip().splitlines()[-1]) for p in cpu_procs]
                 cpu["all_cores"] = {"value": round(sum(o["events"] for o in outs) / max(o["seconds"] for o in outs), 1), "cores": len(outs),
-                                    "sample": "%d oracle processes at once, each on its own %.2f-Mbp contig of the same data model (%d events in all, slowest %.1f s)"
-                                              % (len(outs), 1.0 if config == "wgs30x" else 0.15, sum(o["events"] for o in outs), max(o["seconds"] for o in outs))}
+                                    "sample": "%d oracle processes at once (the CPUs this container may use: %d hardware threads, cgroup quota %d), each on its own %.2f-Mbp contig of the same data model (%d events in all, slowest %.1f s)"
+                                              % (len(outs), ncpu, ncpu_eff, 1.0 if config == "wgs30x" else 0.15, sum(o["events"] for o in outs), max(o["seconds"] for o in outs))}
 
         # ---- end to end through the drop-in command line (BAM decode + PCIe + text)
         e2e = None
