@@ -20,7 +20,7 @@ F_NAMES = ["sev", "sq2", "snm", "s3p"]
 EXPORTS = [
     "brc_strerror", "brc_last_error", "brc_kernel_name", "brc_engine_kind", "brc_create", "brc_destroy",
     "brc_begin_region", "brc_push_reads", "brc_upload", "brc_compute", "brc_fetch_result", "brc_end_region",
-    "brc_clear_indel_queue", "brc_region_counts", "brc_format_region", "brc_format_window", "brc_region_warnings", "brc_window_warnings", "brc_warnings_text", "brc_set_option", "brc_format_region_parts",
+    "brc_clear_indel_queue", "brc_region_counts", "brc_format_region", "brc_format_window", "brc_region_warnings", "brc_window_warnings", "brc_warnings_text", "brc_set_option", "brc_format_region_parts", "brc_set_chrom",
 ]
 
 
@@ -85,6 +85,7 @@ class Library:
         L.brc_destroy.argtypes = [C.c_void_p]; L.brc_destroy.restype = None
         if hasattr(L, "brc_set_option"):       # (the reference-compiled checker library has no options)
             L.brc_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int64]
+            L.brc_set_chrom.argtypes = [C.c_void_p, C.c_char_p]
         L.brc_begin_region.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]
         L.brc_push_reads.argtypes = [C.c_void_p, C.POINTER(ReadBatch)]
         L.brc_upload.argtypes = [C.c_void_p]
@@ -220,7 +221,7 @@ class Engine:
     """Mirror of the reference's per-region pileup lifecycle (bam_plbuf_init .. destroy, bamreadcount.cpp:591-605)."""
 
     def __init__(self, lib, min_mapq=0, min_bq=0, max_cnt=0, per_lib=False, insertion_centric=False, lib_names=(),
-                 device=0, ref_len_check=False, text_only=False):
+                 device=0, ref_len_check=False, text_only=False, device_text=None):
         """text_only: BRC_OPT_TEXT_ONLY — results are consumed through format_region only (no dense planes; istat / fstat
         of fetch_result() come back as zeros)."""
         self.L = lib
@@ -230,8 +231,11 @@ class Engine:
                      self._name_arr if self._names else None, device, int(ref_len_check))
         self.h = C.c_void_p()
         self._check(lib.lib.brc_create(C.byref(cfg), C.byref(self.h)), create=True)
-        if text_only:
+        if text_only or device_text:
             self._check(lib.lib.brc_set_option(self.h, 1, 1))
+        if device_text:                                   # BRC_OPT_DEVICE_TEXT: device_text = the target name of column 1
+            self._check(lib.lib.brc_set_option(self.h, 4, 1))
+            self._check(lib.lib.brc_set_chrom(self.h, device_text.encode()))
         self._ref = None
         self._res = Result()
 

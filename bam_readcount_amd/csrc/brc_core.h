@@ -784,5 +784,100 @@ BRC_HD void tile_range(const DevCfg& c, const int32_t* prefmax_end, const DRead*
     hi = (uint32_t)a;
 }
 
+// ================================================================ device-side text (the "on device" option)
+//
+// The line pileup_func prints for one position (bamreadcount.cpp:351-416 with operator<<(BasicStat), BasicStat.cpp:110-159),
+// written straight from the compact result: chrom, 1-based position, reference character, depth, and per library present in
+// the column its six base buckets.  What a lane cannot know stays with the host, which rewrites those few lines
+// (brc_host.cpp: patch_lines): indel buckets (their alleles are ordered as strings on the host), the deletions queued for
+// pos + 1 with their depth increment (IndelQueue.cpp:3-15), and buckets of a third base (they live in the event list).
+// Two passes over the same code: lengths (w == nullptr), an exclusive scan, then the bytes.
+struct TextCtx {
+    const char* chrom; int32_t chrom_len;
+    const char* lib_names; const int32_t* lib_off;      // library l's name: lib_names[lib_off[l] .. lib_off[l + 1])
+};
+struct TextSink { char* w; uint32_t n; };
+BRC_HD void ts_put(TextSink& s, char ch) { if (s.w) s.w[s.n] = ch; ++s.n; }
+BRC_HD void ts_bytes(TextSink& s, const char* p, int len) { if (s.w) for (int i = 0; i < len; ++i) s.w[s.n + i] = p[i]; s.n += (uint32_t)len; }
+BRC_HD void ts_u64(TextSink& s, uint64_t v) {
+    int nd = 1; for (uint64_t t = v; t >= 10; t /= 10) ++nd;
+    if (s.w) for (int i = nd - 1; i >= 0; --i) { s.w[s.n + i] = (char)('0' + (int)(v % 10)); v /= 10; }
+    s.n += (uint32_t)nd;
+}
+BRC_HD void ts_u32(TextSink& s, uint32_t v) {
+    int nd = 1; for (uint32_t t = v; t >= 10; t /= 10) ++nd;
+    if (s.w) for (int i = nd - 1; i >= 0; --i) { s.w[s.n + i] = (char)('0' + (int)(v % 10)); v /= 10; }
+    s.n += (uint32_t)nd;
+}
+// "%.2f" of the exact binary value (see fmt_f2 in brc_host.cpp): v * 100 is exact in double, rint() rounds it half-even
+BRC_HD void ts_f2(TextSink& s, float v) {
+    const double h = (double)v * 100.0;
+    const uint64_t u = (uint64_t)__builtin_rint(h < 0 ? -h : h);
+    if (__builtin_signbit(v)) ts_put(s, '-');
+    ts_u64(s, u / 100);
+    const int fr = (int)(u % 100);
+    ts_put(s, '.'); ts_put(s, (char)('0' + fr / 10)); ts_put(s, (char)('0' + fr % 10));
+}
+// operator<<(ostream&, BasicStat) for a base bucket with at least one read (BasicStat.cpp:110-140)
+BRC_HD void ts_stat(TextSink& s, const uint32_t* si, const float* sf) {
+    const float c = (float)si[I_N];
+    ts_u32(s, si[I_N]); ts_put(s, ':');
+    ts_f2(s, (float)si[I_SMQ] / c); ts_put(s, ':');
+    ts_f2(s, (float)si[I_SBQ] / c); ts_put(s, ':');
+    ts_f2(s, (float)si[I_SSE] / c); ts_put(s, ':');
+    ts_u32(s, si[I_PLUS]); ts_put(s, ':');
+    ts_u32(s, si[I_MINUS]); ts_put(s, ':');
+    ts_f2(s, sf[F_SEV] / c); ts_put(s, ':');
+    ts_f2(s, sf[F_SNM] / c); ts_put(s, ':');
+    ts_f2(s, (float)si[I_SMMQ] / c); ts_put(s, ':');
+    ts_u32(s, si[I_NQ2]); ts_put(s, ':');
+    if (si[I_NQ2] > 0) ts_f2(s, sf[F_SQ2] / (float)si[I_NQ2]); else { ts_put(s, '0'); ts_put(s, '.'); ts_put(s, '0'); ts_put(s, '0'); }
+    ts_put(s, ':');
+    ts_f2(s, (float)si[I_SCLIP] / c); ts_put(s, ':');
+    ts_f2(s, sf[F_S3P] / c);
+}
+// The line of plane index k, or nothing (returns 0) when no read covers the position / the position was abandoned (:281-284).
+// Lines are produced for every index, the lead position included (the host needs its shape; it does not print it).
+BRC_HD uint32_t text_line(const DevCfg& c, const DevIn& in, const Planes& pl, const TextCtx& t, int64_t k, char* w) {
+    if (c.per_lib && pl.unavail[k] != NONE32) return 0u;
+    uint32_t tot = 0, depth = 0;
+    for (int l = 0; l < c.Lp; ++l) { tot += pl.ncol[(int64_t)l * c.PS + k]; depth += pl.depth[(int64_t)l * c.PS + k]; }
+    if (tot == 0) return 0u;
+    TextSink s; s.w = w; s.n = 0;
+    const int64_t p = (int64_t)c.pos0 + k;
+    ts_bytes(s, t.chrom, t.chrom_len); ts_put(s, '\t');
+    ts_u32(s, (uint32_t)(p + 1)); ts_put(s, '\t');
+    { const uint32_t rc = c.has_ref ? ref_at(c, in.ref, p) : 0u; ts_put(s, rc ? (char)rc : 'N'); }                 // :353
+    ts_put(s, '\t');
+    ts_u32(s, depth);
+    const char zero[] = "0:0.00:0.00:0.00:0:0:0.00:0.00:0.00:0:0.00:0.00:0.00";
+    const char bases[] = "=ACGTN";
+    for (int l = 0; l < c.Lp; ++l) {
+        if (pl.ncol[(int64_t)l * c.PS + k] == 0) continue;                                                             // :286,360
+        if (c.per_lib) { ts_put(s, '\t'); ts_bytes(s, t.lib_names + t.lib_off[l], t.lib_off[l + 1] - t.lib_off[l]); ts_put(s, '\t'); ts_put(s, '{'); }
+        const uint32_t sid = pl.slotid[(int64_t)l * c.PS + k];
+        const uint32_t b0 = sid & 0xffu, b1 = (sid >> 8) & 0xffu;
+        for (uint32_t b = 0; b < (uint32_t)NBUCKET; ++b) {
+            ts_put(s, '\t'); ts_put(s, bases[b]); ts_put(s, ':');
+            const int sl = b == b0 ? 0 : (b == b1 ? 1 : -1);
+            uint32_t si[NI]; float sf[NF];
+            si[I_N] = 0;
+            if (sl >= 0) {
+                const uint32_t* ip = pl.si + (((int64_t)l * 2 + sl) * NI) * c.PS + k;
+                si[I_N] = ip[(int64_t)I_N * c.PS];
+                if (si[I_N]) {
+                    const float* fp = pl.sf + (((int64_t)l * 2 + sl) * NF) * c.PS + k;
+                    for (int f = 0; f < NI; ++f) si[f] = ip[(int64_t)f * c.PS];
+                    for (int f = 0; f < NF; ++f) sf[f] = fp[(int64_t)f * c.PS];
+                }
+            }
+            if (si[I_N]) ts_stat(s, si, sf); else ts_bytes(s, zero, (int)sizeof(zero) - 1);
+        }
+        if (c.per_lib) { ts_put(s, '\t'); ts_put(s, '}'); }
+    }
+    ts_put(s, '\n');
+    return s.n;
+}
+
 }  // namespace brc
 #endif

@@ -963,6 +963,19 @@ __global__ __launch_bounds__(256) void k_xev_compact(const XEv* __restrict__ lis
     if (s == 0 && (threadIdx.x & 63) == 0) atomicMax(&ctr->xev_max, mx);
 }
 
+// Device-side text (brc_core.h: text_line): byte length of every position's line, then — after an exclusive scan — the bytes.
+// One lane per position; a lane's stores walk its own line, neighbouring lanes write neighbouring lines.
+__global__ __launch_bounds__(256) void k_text_len(DevCfg c, DevIn in, Planes pl, TextCtx t, uint32_t* __restrict__ len) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > c.P) return;
+    len[k] = k < c.P ? text_line(c, in, pl, t, k, nullptr) : 0u;        // (entry P: the scan turns it into the total)
+}
+__global__ __launch_bounds__(256) void k_text_write(DevCfg c, DevIn in, Planes pl, TextCtx t, const uint32_t* __restrict__ off, char* __restrict__ text) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= c.P || off[k + 1] == off[k]) return;
+    (void)text_line(c, in, pl, t, k, text + off[k]);
+}
+
 __global__ __launch_bounds__(256) void k_indel_fill(DevCfg c, DevIn in, const DRead* __restrict__ reads, uint32_t* __restrict__ cursor,
                                                     IndelEv* __restrict__ ev) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1069,6 +1082,10 @@ class HipBackend : public Backend {
     // device buffers
     DBuf d_pos, d_flag, d_mapq, d_lib, d_lq, d_nc, d_co, d_so, d_qo, d_nm, d_sm, d_tags, d_cigar, d_seq, d_qual, d_ref, d_refcode;
     DBuf d_bq, d_bqrow, d_pieceoff, d_hot, d_cold, d_key, d_reach, d_reads, d_prefmax, d_agg, d_rng, d_ncol, d_depth, d_slotid, d_si, d_sf, d_xev, d_xevc, d_xevn, d_unavail, d_cnt, d_cursor, d_ev, d_iout, d_ctr, d_tilectr, d_part;
+    DBuf d_tlen, d_toff, d_text, d_tctx;
+    HBuf<char> h_text; HBuf<uint32_t> h_toff; HBuf<uint32_t> h_total;      // device-side text, downloaded (pinned)
+    hipEvent_t ev_text = nullptr; bool text_pending = false; uint64_t text_total = 0;
+    Planes pl_last;                      // the planes of the last compute
     // host result buffers (pinned)
     HBuf<uint32_t> h_ncol, h_depth, h_slotid, h_si, h_unavail; HBuf<float> h_sf; HBuf<IndelOut> h_iout; HBuf<XEv> h_xev;
     size_t xev_cap = 0;                  // entries per sub-list
@@ -1094,6 +1111,8 @@ class HipBackend : public Backend {
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         for (int i = 0; i <= T_N; ++i) HIPCHK(hipEventCreate(&evt[i]));
         have_events = true;
+        HIPCHK(hipEventCreateWithFlags(&ev_text, hipEventDisableTiming));
+        h_text.A = &kPinned; h_toff.A = &kPinned; h_total.A = &kPinned;
         h_ncol.A = h_depth.A = h_slotid.A = h_si.A = h_unavail.A = &kPinned; h_sf.A = &kPinned; h_iout.A = &kPinned; h_xev.A = &kPinned;
         return BRC_OK;
     }
@@ -1101,8 +1120,10 @@ class HipBackend : public Backend {
         (void)hipSetDevice(device);
         DBuf* all[] = {&d_pos, &d_flag, &d_mapq, &d_lib, &d_lq, &d_nc, &d_co, &d_so, &d_qo, &d_nm, &d_sm, &d_tags, &d_cigar, &d_seq, &d_qual,
                        &d_ref, &d_refcode, &d_bq, &d_bqrow, &d_pieceoff, &d_hot, &d_cold, &d_key, &d_reach, &d_reads, &d_prefmax, &d_agg, &d_rng, &d_ncol, &d_depth, &d_slotid, &d_si, &d_sf, &d_xev, &d_xevc, &d_xevn, &d_unavail, &d_cnt,
-                       &d_cursor, &d_ev, &d_iout, &d_ctr, &d_tilectr, &d_part};
+                       &d_cursor, &d_ev, &d_iout, &d_ctr, &d_tilectr, &d_part, &d_tlen, &d_toff, &d_text, &d_tctx};
         for (DBuf* b : all) b->release();
+        h_text.destroy(); h_toff.destroy(); h_total.destroy();
+        if (ev_text) (void)hipEventDestroy(ev_text);
         h_ncol.destroy(); h_depth.destroy(); h_slotid.destroy(); h_si.destroy(); h_unavail.destroy(); h_sf.destroy(); h_iout.destroy(); h_xev.destroy();
         if (have_events) for (int i = 0; i <= T_N; ++i) (void)hipEventDestroy(evt[i]);
         if (stream) (void)hipStreamDestroy(stream);
@@ -1209,6 +1230,7 @@ class HipBackend : public Backend {
         if (indels) HIPCHK(hipMemsetAsync(d_cnt.p, 0, (size_t)(Lp * P) * 4, stream));
         Planes pl = {(uint32_t*)d_ncol.p, (uint32_t*)d_depth.p, (uint32_t*)d_slotid.p, (uint32_t*)d_si.p, (float*)d_sf.p, (uint32_t*)d_unavail.p,
                      (XEv*)d_xev.p, (uint32_t*)d_xevn.p, (uint32_t)xev_cap, (uint32_t)XEV_SHARDS};
+        pl_last = pl;
         const DRead* reads = (const DRead*)d_reads.p;
         HIPCHK(hipEventRecord(evt[T_ANNOTATE], stream));
         if (n > 0) {
@@ -1283,6 +1305,47 @@ class HipBackend : public Backend {
         return BRC_OK;
     }
 
+    int text_begin(const std::string& chrom, const std::vector<std::string>& libs) override {
+        HIPCHK(hipSetDevice(device));
+        if (!computed) { err = "not computed"; return BRC_E_ARG; }
+        const int64_t P = c.P;
+        text_pending = true; text_total = 0;
+        if (!h_toff.reserve((size_t)P + 4) || !h_total.reserve(4)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }
+        if (P == 0) { h_toff.p[0] = 0; HIPCHK(hipEventRecord(ev_text, stream)); return BRC_OK; }
+        // column 1 and the library names, behind the offsets of the names
+        std::vector<int32_t> loff((size_t)c.Lp + 1, 0); std::string bytes = chrom;
+        if (c.per_lib) for (int l = 0; l < c.Lp; ++l) { loff[(size_t)l] = (int32_t)bytes.size(); if ((size_t)l < libs.size()) bytes += libs[(size_t)l]; loff[(size_t)l + 1] = (int32_t)bytes.size(); }
+        const size_t ob = loff.size() * 4;
+        std::vector<char> ctx(ob + bytes.size() + 1);
+        memcpy(ctx.data(), loff.data(), ob); memcpy(ctx.data() + ob, bytes.data(), bytes.size());
+        HIPCHK(d_tctx.ensure(ctx.size() + 16)); HIPCHK(d_tlen.ensure(((size_t)P + 8) * 4)); HIPCHK(d_toff.ensure(((size_t)P + 8) * 4));
+        HIPCHK(hipMemcpyAsync(d_tctx.p, ctx.data(), ctx.size(), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));                                  // (ctx is a local)
+        TextCtx t; t.lib_off = (const int32_t*)d_tctx.p; t.chrom = (const char*)d_tctx.p + ob; t.chrom_len = (int32_t)chrom.size(); t.lib_names = t.chrom;
+        const unsigned nb = (unsigned)((P + 1 + 255) / 256);
+        hipLaunchKernelGGL(k_text_len, dim3(nb), dim3(256), 0, stream, c, in, pl_last, t, (uint32_t*)d_tlen.p);
+        int rc;
+        if ((rc = scan<OpSumU32, false>((const uint32_t*)d_tlen.p, (uint32_t*)d_toff.p, P + 1))) return rc;
+        HIPCHK(hipMemcpyAsync(h_total.p, (const uint32_t*)d_toff.p + P, 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        text_total = h_total.p[0];
+        HIPCHK(d_text.ensure((size_t)text_total + 64));
+        if (!h_text.reserve((size_t)text_total + 64)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }
+        hipLaunchKernelGGL(k_text_write, dim3(nb), dim3(256), 0, stream, c, in, pl_last, t, (const uint32_t*)d_toff.p, (char*)d_text.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h_toff.p, d_toff.p, ((size_t)P + 1) * 4, hipMemcpyDeviceToHost, stream));
+        if (text_total) HIPCHK(hipMemcpyAsync(h_text.p, d_text.p, (size_t)text_total, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipEventRecord(ev_text, stream));
+        return BRC_OK;
+    }
+    int text_wait(HostText* out) override {
+        HIPCHK(hipSetDevice(device));
+        if (!text_pending) { err = "no device text was started"; return BRC_E_ARG; }
+        HIPCHK(hipEventSynchronize(ev_text));
+        out->text = h_text.p; out->off = h_toff.p; out->total = text_total; out->n = c.P;
+        return BRC_OK;
+    }
+
     int counts(uint64_t* e, uint64_t* p) override {
         if (!computed) { err = "not computed"; return BRC_E_ARG; }
         if (e) *e = h_ctr.n_events;
@@ -1290,10 +1353,10 @@ class HipBackend : public Backend {
         return BRC_OK;
     }
 
-    int fetch(HostPlanes* out) override {
+    int fetch(HostPlanes* out, bool planes) override {
         HIPCHK(hipSetDevice(device));
         if (!computed) { err = "not computed"; return BRC_E_ARG; }
-        const size_t P = (size_t)c.PS, Lp = (size_t)c.Lp;   // planes are copied with their padded stride
+        const size_t P = planes ? (size_t)c.PS : 0, Lp = (size_t)c.Lp;   // planes are copied with their padded stride
         const size_t nx = h_ctr.n_xev;
         if (!h_ncol.reserve(Lp * P + 4) || !h_depth.reserve(Lp * P + 4) || !h_slotid.reserve(Lp * P + 4) || !h_unavail.reserve(P + 4) ||
             !h_si.reserve(Lp * 2 * NI * P + 4) || !h_sf.reserve(Lp * 2 * NF * P + 4) || !h_xev.reserve(nx + 4)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }

@@ -264,6 +264,11 @@ struct brc_engine {
     // formatter reads the compact slot planes; third-allele events are aggregated into a sparse (position, library,
     // bucket)-sorted table instead
     bool text_only = false;
+    bool device_text = false; std::string chrom;   // BRC_OPT_DEVICE_TEXT / brc_set_chrom
+    bool text_result = false;                       // the last fetched result is device text (no planes on the host)
+    TextBuf pbuf;                                   // the lines the host rewrote
+    struct Patch { int64_t k; size_t off, len; };
+    std::vector<Patch> patches;
     std::vector<XAgg> xagg;
     size_t hint_reads = 0, hint_bases = 0;          // BRC_OPT_EXPECT_*: staging is sized once instead of grown batch by batch
     // formatter state: the text of the last call (one contiguous buffer, capacity kept across calls), the per-chunk
@@ -328,12 +333,19 @@ void brc_destroy(brc_engine* e) {
     delete e;
 }
 
+int brc_set_chrom(brc_engine* e, const char* chrom) {
+    if (!e || !chrom) return BRC_E_ARG;
+    e->chrom = chrom;
+    return BRC_OK;
+}
+
 int brc_set_option(brc_engine* e, int option, int64_t value) {
     if (!e) return BRC_E_ARG;
     switch (option) {
         case BRC_OPT_TEXT_ONLY: e->text_only = value != 0; return BRC_OK;
         case BRC_OPT_EXPECT_READS: e->hint_reads = value > 0 ? (size_t)value : 0; return BRC_OK;
         case BRC_OPT_EXPECT_BASES: e->hint_bases = value > 0 ? (size_t)value : 0; return BRC_OK;
+        case BRC_OPT_DEVICE_TEXT: e->device_text = value != 0; return BRC_OK;
         default: return fail(e, BRC_E_ARG, "unknown engine option");
     }
 }
@@ -496,14 +508,17 @@ int brc_fetch_result(brc_engine* e, brc_result* out) {
     if (!e || !out) return BRC_E_ARG;
     if (e->state < 3) return fail(e, BRC_E_ARG, "brc_fetch_result before brc_compute");
     const double t_in = now_s();
-    int rc = e->be->fetch(&e->hp);
+    // device-side text: no planes come to the host (lines above 4 GiB per region would overflow the 32-bit offsets)
+    e->text_result = e->text_only && e->device_text && !e->chrom.empty() &&
+                     (double)e->g.P * (double)e->g.Lp * 700.0 + 64.0 * (double)e->g.P < 4.0e9;
+    int rc = e->be->fetch(&e->hp, !e->text_result);
     if (rc) return fail(e, rc, e->be->last_error());
     const double t_dl = now_s(); e->t_d2h += t_dl - t_in;
     e->n_xev_total += e->hp.n_xev; e->n_indel_total += (uint64_t)e->hp.n_indel;
     const Geometry& g = e->g; const Staged& s = e->st; const HostPlanes& hp = e->hp;
     // column 3: raw reference character (bamreadcount.cpp:353)
     e->refbase.resize((size_t)g.P + 1);
-    {
+    if (!e->text_result) {
         const int64_t have = g.ref ? std::max<int64_t>(0, std::min<int64_t>(g.P, g.ref_len - g.pos0)) : 0;
         if (have) memcpy(e->refbase.data(), g.ref + g.pos0, (size_t)have);
         for (int64_t k = 0; k < have; ++k) if (!e->refbase[(size_t)k]) e->refbase[(size_t)k] = 'N';
@@ -577,6 +592,11 @@ int brc_fetch_result(brc_engine* e, brc_result* out) {
     out->istat = e->text_only ? NULL : e->dense_i; out->fstat = e->text_only ? NULL : e->dense_f;
     out->unavail = e->cfg.per_lib ? hp.unavail : NULL;
     out->refbase = e->refbase.data();
+    if (e->text_result) {
+        out->ncol = out->depth = out->unavail = NULL; out->refbase = NULL;
+        rc = e->be->text_begin(e->chrom, e->libs);              // line kernels + the download, behind the lists on the stream
+        if (rc) return fail(e, rc, e->be->last_error());
+    }
     out->n_indel = (int64_t)e->indels.size(); out->indel = e->indels.data();
     out->alleles = e->alleles.data(); out->alleles_len = e->alleles.size();
     out->n_events = hp.n_events;
@@ -731,9 +751,127 @@ static bool format_range(const brc_engine* e, const brc_result* r, const char* c
 // p for p+1, emitted or dropped there), so a chunk starting at k0 > 0 reproduces the queue state it would inherit by
 // replaying position k0-1 into a scratch buffer; chunk 0 continues the engine's persistent queues and the last chunk's
 // final queues become the engine's (regions given on the command line are not separated by a clear, :641-657).
+// BRC_OPT_DEVICE_TEXT: the lines came from the GPU (Backend::text_begin).  What a lane cannot know is finished here, for the
+// few lines it concerns — the same record assembly as format_range, applied to the device's line instead of the planes:
+//   * indel buckets of the position (:389-401): insertions are appended to their library's block, deletions are queued for pos+1;
+//   * IndelQueue::process (IndelQueue.cpp:3-15) for the libraries present in the line: queued deletions due at this position
+//     are appended and their read counts added to the depth column;
+//   * buckets of a third base: the device printed them as empty, their sums are in the third-allele table.
+// Every line of the region is a candidate while a queue is not empty (process() runs at every printed position), so the
+// deque semantics — including entries stuck behind a later-due front entry — are the reference's.
+// Output: e->part_ptr / e->part_len, pieces of the downloaded text interleaved with the rewritten lines.
+static int format_device_text(brc_engine* e, const brc_result* r) {
+    HostText ht;
+    int rc = e->be->text_wait(&ht);
+    if (rc) return fail(e, rc, e->be->last_error());
+    const int Lp = r->n_lib; const int64_t P = r->n_pos;
+    const bool per_lib = e->cfg.per_lib != 0;
+    const uint32_t tid = (uint32_t)r->tid;
+    e->pbuf.clear(); e->patches.clear();
+    std::vector<std::deque<QEnt> >& queue = e->queue;
+    int64_t ii = 0; size_t xi = 0;
+    auto queues_busy = [&]() { for (const std::deque<QEnt>& q : queue) if (!q.empty()) return true; return false; };
+    std::string body; char nb[STAT_MAX + 64];
+    int64_t k = -1;
+    for (;;) {
+        while (ii < r->n_indel && (int64_t)r->indel[ii].pos - r->pos0 <= k) ++ii;       // behind the last line looked at
+        while (xi < e->xagg.size() && (int64_t)(e->xagg[xi].key >> 16) <= k) ++xi;
+        int64_t kc = INT64_MAX;
+        if (ii < r->n_indel) kc = std::min<int64_t>(kc, (int64_t)r->indel[ii].pos - r->pos0);
+        if (xi < e->xagg.size()) kc = std::min<int64_t>(kc, (int64_t)(e->xagg[xi].key >> 16));
+        if (queues_busy()) { int64_t j = k + 1; while (j < P && ht.off[j + 1] == ht.off[j]) ++j; if (j < P) kc = std::min(kc, j); }
+        if (kc == INT64_MAX || kc >= P) break;
+        if (kc <= k) kc = k + 1;                                   // (defensive: cursors always move forward)
+        k = kc;
+        const int32_t pos = r->pos0 + (int32_t)k;
+        while (ii < r->n_indel && r->indel[ii].pos < pos) ++ii;
+        while (xi < e->xagg.size() && (int64_t)(e->xagg[xi].key >> 16) < k) ++xi;
+        if (ht.off[k + 1] == ht.off[k]) {                          // no line: no pileup callback here, nothing is queued or processed
+            while (ii < r->n_indel && r->indel[ii].pos == pos) ++ii;
+            continue;
+        }
+        const char* L0 = ht.text + ht.off[k]; const char* const L1 = ht.text + ht.off[k + 1] - 1;    // [L0, L1): the line without its newline
+        // prefix: chrom \t pos \t ref \t depth
+        const char* p = L0; int tabs = 0;
+        while (p < L1 && tabs < 3) { if (*p == '\t') ++tabs; ++p; }
+        const char* const dep0 = p; uint32_t depth = 0;
+        while (p < L1 && *p != '\t') { depth = depth * 10u + (uint32_t)(*p - '0'); ++p; }
+        // the blocks
+        body.clear(); bool changed = false; uint32_t extra = 0;
+        auto bucket_tokens = [&](int l) {
+            for (int b = 0; b < BRC_NBUCKET; ++b) {                // p at '\t' of "\tX:stat"
+                const char* t0 = p; ++p; while (p < L1 && *p != '\t') ++p;
+                const XAgg* xa = nullptr;
+                for (size_t x = xi; x < e->xagg.size() && (int64_t)(e->xagg[x].key >> 16) == k; ++x)
+                    if ((e->xagg[x].key & 0xffffu) == (((uint64_t)l << 8) | (uint64_t)b)) { xa = &e->xagg[x]; break; }
+                if (!xa) { body.append(t0, (size_t)(p - t0)); continue; }
+                body.append(t0, 3);                                // "\tX:"
+                char* w = fmt_stat(nb, xa->st.i, xa->st.f, false); body.append(nb, (size_t)(w - nb)); changed = true;
+            }
+        };
+        auto lib_tail = [&](int l) {
+            auto entry = [&](const char* allele, size_t alen, const uint32_t* ei, const float* ef) {
+                body += '\t'; body.append(allele, alen); body += ':';
+                char* w = fmt_stat(nb, ei, ef, true); body.append(nb, (size_t)(w - nb)); changed = true;
+            };
+            while (ii < r->n_indel && r->indel[ii].pos == pos && r->indel[ii].lib < l) ++ii;
+            for (; ii < r->n_indel && r->indel[ii].pos == pos && r->indel[ii].lib == l; ++ii) {
+                const brc_indel& d = r->indel[ii];
+                if (d.len < 0) {                                                          // :391-396
+                    QEnt q; q.tid = tid; q.pos = (uint32_t)pos + 1; q.st = d.stat;
+                    q.allele.assign(r->alleles + d.allele_off, d.allele_len);
+                    queue[(size_t)l].push_back(q);
+                } else entry(r->alleles + d.allele_off, d.allele_len, d.stat.i, d.stat.f);   // :399
+            }
+            std::deque<QEnt>& q = queue[(size_t)l];                                       // IndelQueue::process
+            while (!q.empty() && ((q.front().tid == tid && q.front().pos < (uint32_t)pos) || q.front().tid != tid)) q.pop_front();
+            while (!q.empty() && q.front().tid == tid && q.front().pos == (uint32_t)pos) {
+                entry(q.front().allele.data(), q.front().allele.size(), q.front().st.i, q.front().st.f);
+                extra += q.front().st.i[I_N];
+                q.pop_front();
+            }
+        };
+        if (!per_lib) { bucket_tokens(0); lib_tail(0); }
+        else {
+            while (p < L1) {                                       // "\tname\t{" six buckets "\t}"
+                const char* t0 = p; ++p; const char* n0 = p; while (p < L1 && *p != '\t') ++p;
+                int l = -1; for (int x = 0; x < Lp; ++x) if (e->libs[(size_t)x].size() == (size_t)(p - n0) && memcmp(e->libs[(size_t)x].data(), n0, (size_t)(p - n0)) == 0) { l = x; break; }
+                p += 2;                                            // "\t{"
+                body.append(t0, (size_t)(p - t0));
+                if (l < 0) return fail(e, BRC_E_ARG, "device text: unknown library block");
+                bucket_tokens(l); lib_tail(l);
+                body.append(p, 2); p += 2;                         // "\t}"
+            }
+        }
+        while (ii < r->n_indel && r->indel[ii].pos == pos) ++ii;   // (indel entries of libraries without a block cannot exist)
+        if (!changed) continue;
+        const size_t need = (size_t)(dep0 - L0) + 16 + body.size() + 2;
+        char* w = e->pbuf.room(need);
+        if (!w) return fail(e, BRC_E_NOMEM, "host allocation of the text buffers failed");
+        brc_engine::Patch pt; pt.k = k; pt.off = e->pbuf.n;
+        memcpy(w, L0, (size_t)(dep0 - L0)); w += dep0 - L0;
+        w += fmt_u32(w, depth + extra);
+        memcpy(w, body.data(), body.size()); w += body.size(); *w++ = '\n';
+        pt.len = (size_t)(w - (e->pbuf.p + pt.off)); e->pbuf.n += pt.len;
+        e->patches.push_back(pt);
+    }
+    // parts: device text between the rewritten lines; the lead position (index 0 when pos0 < beg0) is never printed
+    e->part_ptr.clear(); e->part_len.clear();
+    uint64_t cur = (P > 0 && r->pos0 < r->beg0) ? ht.off[1] : 0;
+    for (const brc_engine::Patch& pt : e->patches) {
+        if (pt.k == 0 && r->pos0 < r->beg0) continue;
+        if (ht.off[pt.k] > cur) { e->part_ptr.push_back(ht.text + cur); e->part_len.push_back((size_t)(ht.off[pt.k] - cur)); }
+        e->part_ptr.push_back(e->pbuf.p + pt.off); e->part_len.push_back(pt.len);
+        cur = ht.off[pt.k + 1];
+    }
+    if (P > 0 && ht.total > cur) { e->part_ptr.push_back(ht.text + cur); e->part_len.push_back((size_t)(ht.total - cur)); }
+    return BRC_OK;
+}
+
 static int format_chunks(brc_engine* e, const brc_result* r, const char* chrom, int64_t* n_chunks, unsigned* threads) {
     const int Lp = r->n_lib; const int64_t P = r->n_pos;
     if ((size_t)Lp != e->queue.size()) return fail(e, BRC_E_ARG, "result does not belong to this engine");
+    if (r->ncol == NULL) return fail(e, BRC_E_ARG, "this result carries device text only");
     if (r->istat == NULL && (!e->text_only || r->ncol != e->hp.ncol)) return fail(e, BRC_E_ARG, "a text-only result can only be formatted before the next download");
     unsigned nthr = effective_cpus(); if (nthr > 64) nthr = 64;
     if (const char* t = getenv("BRC_FORMAT_THREADS")) { const int v = atoi(t); if (v > 0) nthr = (unsigned)v; }
@@ -768,6 +906,19 @@ static int format_chunks(brc_engine* e, const brc_result* r, const char* chrom, 
 int brc_format_region(brc_engine* e, const brc_result* r, const char* chrom, const char** text, size_t* text_len) {
     if (!e || !r || !chrom || !text) return BRC_E_ARG;
     const double t_in = now_s();
+    if (r->ncol == NULL && e->text_result) {                       // device text: concatenate the pieces
+        const int rc0 = format_device_text(e, r);
+        if (rc0) return rc0;
+        size_t total = 0; for (size_t v : e->part_len) total += v;
+        if (total + 1 > e->tcap) {
+            free(e->tbuf); e->tcap = total + total / 4 + 4096; e->tbuf = (char*)malloc(e->tcap);
+            if (!e->tbuf) { e->tcap = 0; return fail(e, BRC_E_NOMEM, "host allocation of the text buffer failed"); }
+        }
+        size_t at = 0; for (size_t i = 0; i < e->part_len.size(); ++i) { memcpy(e->tbuf + at, e->part_ptr[i], e->part_len[i]); at += e->part_len[i]; }
+        e->tbuf[total] = 0; e->tlen = total; *text = e->tbuf; if (text_len) *text_len = total;
+        e->t_format += now_s() - t_in;
+        return BRC_OK;
+    }
     int64_t nch = 0; unsigned nthr = 1;
     const int rc = format_chunks(e, r, chrom, &nch, &nthr);
     if (rc) return rc;
@@ -791,6 +942,13 @@ int brc_format_region(brc_engine* e, const brc_result* r, const char* chrom, con
 int brc_format_region_parts(brc_engine* e, const brc_result* r, const char* chrom, const char* const** parts, const size_t** part_lens, size_t* n_parts) {
     if (!e || !r || !chrom || !parts || !part_lens || !n_parts) return BRC_E_ARG;
     const double t_in = now_s();
+    if (r->ncol == NULL && e->text_result) {
+        const int rc0 = format_device_text(e, r);
+        if (rc0) return rc0;
+        *parts = e->part_ptr.data(); *part_lens = e->part_len.data(); *n_parts = e->part_ptr.size();
+        e->t_format += now_s() - t_in;
+        return BRC_OK;
+    }
     int64_t nch = 0; unsigned nthr = 1;
     const int rc = format_chunks(e, r, chrom, &nch, &nthr);
     if (rc) return rc;
@@ -805,6 +963,7 @@ int brc_format_window(brc_engine* e, const brc_result* r, const char* chrom, int
                       const char** text, size_t* text_len) {
     if (!e || !r || !chrom || !text || vend < vbeg0) return BRC_E_ARG;
     if ((size_t)r->n_lib != e->queue.size()) return fail(e, BRC_E_ARG, "result does not belong to this engine");
+    if (r->ncol == NULL) return fail(e, BRC_E_ARG, "brc_format_window needs planes: switch BRC_OPT_DEVICE_TEXT off for regions cut into windows");
     if (r->istat == NULL && (!e->text_only || r->ncol != e->hp.ncol)) return fail(e, BRC_E_ARG, "a text-only result can only be formatted before the next download");
     TextBuf& out = e->wbuf; out.clear();
     // plane indices of [vbeg0 - 1, vend) clipped to the planes; the lead position only feeds the deletion queue (:269 vs :414)

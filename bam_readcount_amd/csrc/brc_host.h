@@ -96,13 +96,21 @@ struct HostPlanes {
     uint64_t warn[BRC_N_WARN] = {0, 0, 0, 0};
 };
 
+// The region's text as the device wrote it (BRC_OPT_DEVICE_TEXT): line of plane index k = text[off[k] .. off[k + 1]), empty
+// for positions that print nothing; n + 1 offsets.
+struct HostText { const char* text = nullptr; const uint32_t* off = nullptr; uint64_t total = 0; int64_t n = 0; };
+
 class Backend {
   public:
     virtual ~Backend() {}
     virtual const HostAlloc* host_alloc() = 0;
     virtual int upload(const brc_config& cfg, const Staged& s, Geometry& g) = 0;         // staging -> device; sets g.PS
     virtual int compute(brc_timing* t) = 0;                                              // whole pipeline, waits
-    virtual int fetch(HostPlanes* out) = 0;                                              // device -> host planes
+    virtual int fetch(HostPlanes* out, bool planes) = 0;                                 // device -> host: counters, third-allele and indel lists, and (planes) the slot planes
+    // device-side text of the computed region: text_begin launches the line kernels and starts the download (the device
+    // buffers of the region stay untouched until it is done: same stream), text_wait waits for it
+    virtual int text_begin(const std::string& chrom, const std::vector<std::string>& libs) = 0;
+    virtual int text_wait(HostText* out) = 0;
     virtual int counts(uint64_t* n_events, uint64_t* n_positions) = 0;
     virtual const char* last_error() const = 0;
 };

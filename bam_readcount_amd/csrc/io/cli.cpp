@@ -363,6 +363,10 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
         if (!F.ok) { join_fmt(); c.complain("bam-readcount: read error: " + F.err + "\n"); return 1; }
         double t1 = now_s();
         rc = brc_begin_region(c.eng, tid, (int32_t)a, (int32_t)b, ref, (int64_t)c.ref.size());
+        // the lines of a region piece are written on the GPU and come back as text (BRC_DEVICE_TEXT=0: host formatter)
+        static const bool dev_text = !(getenv("BRC_DEVICE_TEXT") && atoi(getenv("BRC_DEVICE_TEXT")) == 0);
+        brc_set_option(c.eng, BRC_OPT_DEVICE_TEXT, dev_text ? 1 : 0);
+        if (dev_text) brc_set_chrom(c.eng, h.names[(size_t)tid].c_str());
         {   // the stripes of a piece arrive as separate batches: tell the engine their total so it sizes its staging once
             size_t nr = 0, nq = 0; for (const Batcher& part : F.parts) { nr += part.pos.size(); nq += part.qual.size(); }
             brc_set_option(c.eng, BRC_OPT_EXPECT_READS, (int64_t)(nr + nr / 8)); brc_set_option(c.eng, BRC_OPT_EXPECT_BASES, (int64_t)(nq + nq / 8));
@@ -379,6 +383,7 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
         double t3 = now_s(); c.t_write += t3 - t2;           // (time this thread waited for the formatter / writer)
         if (!rc && prev_rc) rc = prev_rc;
         brc_result& R = res[slot]; slot ^= 1;
+        if (!rc && c.pre_format) c.pre_format();             // several engines: the writer is done with this engine's previous text
         if (!rc) rc = brc_fetch_result(c.eng, &R);
         c.t_engine += now_s() - t3;
         if (!rc) {
@@ -391,7 +396,6 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
             fmt = std::thread([&c, &R, chrom, clear_first, &fmt_rc, &fmt_s]() {
                 const double f0 = now_s();
                 if (clear_first) brc_clear_indel_queue(c.eng);
-                if (c.pre_format) c.pre_format();
                 const char* const* tparts = nullptr; const size_t* tlens = nullptr; size_t tn = 0;
                 fmt_rc = brc_format_region_parts(c.eng, &R, chrom, &tparts, &tlens, &tn);
                 if (!fmt_rc) c.emit_region(tparts, tlens, tn);
@@ -486,6 +490,7 @@ static int run_site_batch(Ctx& c, const std::vector<Site>& sites) {
             all.seq4.insert(all.seq4.end(), b.seq4.begin(), b.seq4.end());
             all.qual.insert(all.qual.end(), b.qual.begin(), b.qual.end());
         }
+        brc_set_option(c.eng, BRC_OPT_DEVICE_TEXT, 0);           // windows are cut out of shared planes on the host
         int rc = brc_begin_region(c.eng, 0, 1, (int32_t)V, c.have_fa ? vref.data() : nullptr, V);
         const brc_read_batch v = all.view();
         if (!rc) rc = brc_push_reads(c.eng, &v);

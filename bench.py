@@ -249,8 +249,13 @@ def main():
             hres = he.end_region(); htext = he.format_region_np("chrS")
             parity.assert_results_equal(hres, ores, "bench prefix")       # raises on the first differing plane element
             assert len(htext) == len(otext) and np.array_equal(htext, otext), "text of the HIP engine and of the oracle differ"
-            text_bytes = int(len(htext)); he.close(); oe.close()
-            validated = dict(validated or {}, prefix_mbp=send / 1e6, planes_bit_exact=True, text_byte_exact=True, text_bytes=text_bytes)
+            text_bytes = int(len(htext)); he.close()
+            # the same prefix through the device-side text path (what the command line uses): lines written by k_text_write
+            hd = capi.Engine(hip, lib_names=names, device=local_rank, device_text="chrS", **opts)
+            hd.begin_region(0, 0, send, ref); hd.push_reads(sub); hd.end_region(); dtext = hd.format_region_np("chrS")
+            assert len(dtext) == len(otext) and np.array_equal(dtext, otext), "device-side text and the oracle's text differ"
+            hd.close(); oe.close()
+            validated = dict(validated or {}, prefix_mbp=send / 1e6, planes_bit_exact=True, text_byte_exact=True, device_text_byte_exact=True, text_bytes=text_bytes)
             cpu = {"value": round(oev / tc, 1), "unit": "pileup base-events/s", "cores": 1, "kind": "port",
                    "sample": "first %.2f Mbp of the same contig (%d events, %.1f s), C oracle incl. its text formatting, 1 thread of %d host cores"
                              % (send / 1e6, oev, tc, ncpu)}

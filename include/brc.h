@@ -191,7 +191,18 @@ void brc_destroy(brc_engine*);
  *                      expected to push): the pinned staging is allocated once instead of grown batch by batch */
 #define BRC_OPT_EXPECT_READS 2
 #define BRC_OPT_EXPECT_BASES 3
+/*   BRC_OPT_DEVICE_TEXT  1 (with BRC_OPT_TEXT_ONLY and a column-1 name set by brc_set_chrom): the lines of the following regions
+ *                      are written on the GPU from the compact result and downloaded as text; brc_fetch_result downloads
+ *                      no planes at all (brc_result.ncol / depth / istat / fstat / refbase are NULL), brc_format_region[_parts]
+ *                      only rewrites the few lines the device cannot finish (indel buckets, deletions queued for pos+1,
+ *                      buckets of a third base).  Such a result must be formatted, and the returned text consumed, before
+ *                      the next brc_fetch_result of this engine; brc_format_window needs planes and refuses it.  Regions
+ *                      whose text could exceed 4 GiB fall back to the host formatter by themselves. */
+#define BRC_OPT_DEVICE_TEXT 4
 int  brc_set_option(brc_engine*, int option, int64_t value);
+/* Target name printed in column 1 of the following regions' lines (BRC_OPT_DEVICE_TEXT: the text is written at
+ * brc_fetch_result time, before brc_format_region names the contig); copied. */
+int  brc_set_chrom(brc_engine*, const char* chrom);
 
 /* Open the reporting window [beg0,end) on contig tid.  ref = raw FASTA characters of the whole contig
  * (ref[i] = base at 0-based i), borrowed until brc_end_region/brc_fetch_result returns.  ref may be NULL

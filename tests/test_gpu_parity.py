@@ -164,6 +164,24 @@ def test_hip_text_only_engine_prints_the_same(hip_lib, oracle_lib):
         got, res = parity.run_engine(hip_lib, arrs, [(0, 40000), (150000, 150001)], ref=ref, text_only=True, **kw)
         assert got == want and want.count(b"\n") > 39000
         assert not res[0].istat.any()
+        got2, res2 = parity.run_engine(hip_lib, arrs, [(0, 40000), (150000, 150001)], ref=ref, device_text="chrS", **kw)   # BRC_OPT_DEVICE_TEXT
+        assert got2 == want and not res2[0].ncol.any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", FUZZ, ids=lambda c: "seed%d-%s" % (c["seed"], c["style"]))
+def test_hip_device_text_equals_oracle_on_every_fuzz_family(hip_lib, oracle_lib, case):
+    """k_text_len / k_text_write + the host's line patcher against the oracle's text (see the simulator twin)."""
+    rng = np.random.default_rng(case["seed"])
+    ref = synth.make_ref(rng, 3000, weird=case.get("weird", 0.0))
+    n_libs = case.get("n_libs", 1)
+    arrs = synth.make_batch(case["seed"] + 100, ref, case["n"], style=case["style"], n_libs=n_libs, p_nolib=case.get("p_nolib", 0.0))
+    names = ["lib%c" % (65 + i) for i in range(n_libs)] if case["opts"].get("per_lib") else ()
+    regions = [(0, 3000), (100, 101), (700, 1500), (1500, 1501), (1501, 2200), (2990, 3200), (1500, 1500), (5, 900)]
+    for clear in (True, False):
+        want, _ = parity.run_engine(oracle_lib, arrs, regions, ref=ref, lib_names=names, clear_queue=clear, **case["opts"])
+        got, _ = parity.run_engine(hip_lib, arrs, regions, ref=ref, lib_names=names, clear_queue=clear, device_text="chrS", **case["opts"])
+        assert got == want, clear
 
 
 @pytest.mark.gpu

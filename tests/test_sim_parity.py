@@ -138,6 +138,22 @@ def test_sim_rare_device_paths(sim_lib, oracle_lib, monkeypatch, env):
     parity.compare_libs(sim_lib, oracle_lib, deep, [(800, 1600)], ref=ref)
 
 
+@pytest.mark.parametrize("case", FUZZ, ids=lambda c: "seed%d-%s" % (c["seed"], c["style"]))
+def test_sim_device_text_equals_oracle_on_every_fuzz_family(sim_lib, oracle_lib, case):
+    """Device-side text through the same regions as test_sim_fuzz_equals_oracle, deletion queues carried across regions
+    (no clear between them, like regions given on the command line) and cleared (site-list mode)."""
+    rng = np.random.default_rng(case["seed"])
+    ref = synth.make_ref(rng, 3000, weird=case.get("weird", 0.0))
+    n_libs = case.get("n_libs", 1)
+    arrs = synth.make_batch(case["seed"] + 100, ref, case["n"], style=case["style"], n_libs=n_libs, p_nolib=case.get("p_nolib", 0.0))
+    names = ["lib%c" % (65 + i) for i in range(n_libs)] if case["opts"].get("per_lib") else ()
+    regions = [(0, 3000), (100, 101), (700, 1500), (1500, 1501), (1501, 2200), (2990, 3200), (1500, 1500), (5, 900)]
+    for clear in (True, False):
+        want, _ = parity.run_engine(oracle_lib, arrs, regions, ref=ref, lib_names=names, clear_queue=clear, **case["opts"])
+        got, _ = parity.run_engine(sim_lib, arrs, regions, ref=ref, lib_names=names, clear_queue=clear, device_text="chrS", **case["opts"])
+        assert got == want, clear
+
+
 @pytest.mark.parametrize("case", [FUZZ[2], FUZZ[4], FUZZ[6], FUZZ[7]], ids=lambda c: "seed%d-%s" % (c["seed"], c["style"]))
 def test_sim_text_only_engine_prints_the_same(sim_lib, oracle_lib, case):
     """BRC_OPT_TEXT_ONLY (what the drop-in command line sets): the formatter reads the compact result — two bucket slots per
@@ -159,6 +175,11 @@ def test_sim_text_only_engine_prints_the_same(sim_lib, oracle_lib, case):
     finally:
         del os.environ["BRC_FORMAT_CHUNK"]; del os.environ["BRC_FORMAT_THREADS"]
     assert got2 == want
+    # BRC_OPT_DEVICE_TEXT: the lines are written by the device code (text_line) and the host only rewrites the lines with
+    # indel buckets, queued deletions or a third base
+    got3, res3 = parity.run_engine(sim_lib, arrs, regions, ref=ref, lib_names=names, device_text="chrS", **case["opts"])
+    assert got3 == want
+    assert not res3[0].ncol.any()                     # no planes at all came to the host
 
 
 def test_sim_deep_indel_key_equals_oracle(sim_lib, oracle_lib):
