@@ -1083,8 +1083,10 @@ class HipBackend : public Backend {
     DBuf d_pos, d_flag, d_mapq, d_lib, d_lq, d_nc, d_co, d_so, d_qo, d_nm, d_sm, d_tags, d_cigar, d_seq, d_qual, d_ref, d_refcode;
     DBuf d_bq, d_bqrow, d_pieceoff, d_hot, d_cold, d_key, d_reach, d_reads, d_prefmax, d_agg, d_rng, d_ncol, d_depth, d_slotid, d_si, d_sf, d_xev, d_xevc, d_xevn, d_unavail, d_cnt, d_cursor, d_ev, d_iout, d_ctr, d_tilectr, d_part;
     DBuf d_tlen, d_toff, d_text, d_tctx;
-    HBuf<char> h_text; HBuf<uint32_t> h_toff; HBuf<uint32_t> h_total;      // device-side text, downloaded (pinned)
-    hipEvent_t ev_text = nullptr; bool text_pending = false; uint64_t text_total = 0;
+    // device-side text, downloaded (pinned) on its own stream into one of two host buffers
+    HBuf<char> h_text[2]; HBuf<uint32_t> h_toff[2]; HBuf<uint32_t> h_total;
+    hipStream_t stream2 = nullptr; hipEvent_t ev_text[2] = {nullptr, nullptr}, ev_lines = nullptr;
+    bool text_started[2] = {false, false}; uint64_t text_total[2] = {0, 0}; int64_t text_n[2] = {0, 0}; int text_slot = 0;
     Planes pl_last;                      // the planes of the last compute
     // host result buffers (pinned)
     HBuf<uint32_t> h_ncol, h_depth, h_slotid, h_si, h_unavail; HBuf<float> h_sf; HBuf<IndelOut> h_iout; HBuf<XEv> h_xev;
@@ -1111,8 +1113,10 @@ class HipBackend : public Backend {
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         for (int i = 0; i <= T_N; ++i) HIPCHK(hipEventCreate(&evt[i]));
         have_events = true;
-        HIPCHK(hipEventCreateWithFlags(&ev_text, hipEventDisableTiming));
-        h_text.A = &kPinned; h_toff.A = &kPinned; h_total.A = &kPinned;
+        HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) { HIPCHK(hipEventCreateWithFlags(&ev_text[i], hipEventDisableTiming)); h_text[i].A = &kPinned; h_toff[i].A = &kPinned; }
+        HIPCHK(hipEventCreateWithFlags(&ev_lines, hipEventDisableTiming));
+        h_total.A = &kPinned;
         h_ncol.A = h_depth.A = h_slotid.A = h_si.A = h_unavail.A = &kPinned; h_sf.A = &kPinned; h_iout.A = &kPinned; h_xev.A = &kPinned;
         return BRC_OK;
     }
@@ -1122,8 +1126,10 @@ class HipBackend : public Backend {
                        &d_ref, &d_refcode, &d_bq, &d_bqrow, &d_pieceoff, &d_hot, &d_cold, &d_key, &d_reach, &d_reads, &d_prefmax, &d_agg, &d_rng, &d_ncol, &d_depth, &d_slotid, &d_si, &d_sf, &d_xev, &d_xevc, &d_xevn, &d_unavail, &d_cnt,
                        &d_cursor, &d_ev, &d_iout, &d_ctr, &d_tilectr, &d_part, &d_tlen, &d_toff, &d_text, &d_tctx};
         for (DBuf* b : all) b->release();
-        h_text.destroy(); h_toff.destroy(); h_total.destroy();
-        if (ev_text) (void)hipEventDestroy(ev_text);
+        for (int i = 0; i < 2; ++i) { h_text[i].destroy(); h_toff[i].destroy(); if (ev_text[i]) (void)hipEventDestroy(ev_text[i]); }
+        h_total.destroy();
+        if (ev_lines) (void)hipEventDestroy(ev_lines);
+        if (stream2) (void)hipStreamDestroy(stream2);
         h_ncol.destroy(); h_depth.destroy(); h_slotid.destroy(); h_si.destroy(); h_unavail.destroy(); h_sf.destroy(); h_iout.destroy(); h_xev.destroy();
         if (have_events) for (int i = 0; i <= T_N; ++i) (void)hipEventDestroy(evt[i]);
         if (stream) (void)hipStreamDestroy(stream);
@@ -1305,13 +1311,14 @@ class HipBackend : public Backend {
         return BRC_OK;
     }
 
-    int text_begin(const std::string& chrom, const std::vector<std::string>& libs) override {
+    int text_begin(const std::string& chrom, const std::vector<std::string>& libs, int* slot_out) override {
         HIPCHK(hipSetDevice(device));
         if (!computed) { err = "not computed"; return BRC_E_ARG; }
         const int64_t P = c.P;
-        text_pending = true; text_total = 0;
-        if (!h_toff.reserve((size_t)P + 4) || !h_total.reserve(4)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }
-        if (P == 0) { h_toff.p[0] = 0; HIPCHK(hipEventRecord(ev_text, stream)); return BRC_OK; }
+        const int slot = (text_slot ^= 1); *slot_out = slot;
+        text_started[slot] = true; text_total[slot] = 0; text_n[slot] = P;
+        if (!h_toff[slot].reserve((size_t)P + 4) || !h_total.reserve(4)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }
+        if (P == 0) { h_toff[slot].p[0] = 0; HIPCHK(hipEventRecord(ev_text[slot], stream)); return BRC_OK; }
         // column 1 and the library names, behind the offsets of the names
         std::vector<int32_t> loff((size_t)c.Lp + 1, 0); std::string bytes = chrom;
         if (c.per_lib) for (int l = 0; l < c.Lp; ++l) { loff[(size_t)l] = (int32_t)bytes.size(); if ((size_t)l < libs.size()) bytes += libs[(size_t)l]; loff[(size_t)l + 1] = (int32_t)bytes.size(); }
@@ -1319,30 +1326,38 @@ class HipBackend : public Backend {
         std::vector<char> ctx(ob + bytes.size() + 1);
         memcpy(ctx.data(), loff.data(), ob); memcpy(ctx.data() + ob, bytes.data(), bytes.size());
         HIPCHK(d_tctx.ensure(ctx.size() + 16)); HIPCHK(d_tlen.ensure(((size_t)P + 8) * 4)); HIPCHK(d_toff.ensure(((size_t)P + 8) * 4));
+        // the download before this one read d_toff / d_text on the copy stream: it is long done, but say so to the device
+        HIPCHK(hipStreamWaitEvent(stream, ev_text[slot ^ 1], 0));
         HIPCHK(hipMemcpyAsync(d_tctx.p, ctx.data(), ctx.size(), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipStreamSynchronize(stream));                                  // (ctx is a local)
         TextCtx t; t.lib_off = (const int32_t*)d_tctx.p; t.chrom = (const char*)d_tctx.p + ob; t.chrom_len = (int32_t)chrom.size(); t.lib_names = t.chrom;
         const unsigned nb = (unsigned)((P + 1 + 255) / 256);
         hipLaunchKernelGGL(k_text_len, dim3(nb), dim3(256), 0, stream, c, in, pl_last, t, (uint32_t*)d_tlen.p);
         int rc;
         if ((rc = scan<OpSumU32, false>((const uint32_t*)d_tlen.p, (uint32_t*)d_toff.p, P + 1))) return rc;
         HIPCHK(hipMemcpyAsync(h_total.p, (const uint32_t*)d_toff.p + P, 4, hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
-        text_total = h_total.p[0];
-        HIPCHK(d_text.ensure((size_t)text_total + 64));
-        if (!h_text.reserve((size_t)text_total + 64)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }
+        HIPCHK(hipStreamSynchronize(stream));                                  // (also covers the local `ctx`)
+        const uint64_t total = h_total.p[0];
+        text_total[slot] = total;
+        HIPCHK(d_text.ensure((size_t)total + 64));
+        if (!h_text[slot].reserve((size_t)total + 64)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }
         hipLaunchKernelGGL(k_text_write, dim3(nb), dim3(256), 0, stream, c, in, pl_last, t, (const uint32_t*)d_toff.p, (char*)d_text.p);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(h_toff.p, d_toff.p, ((size_t)P + 1) * 4, hipMemcpyDeviceToHost, stream));
-        if (text_total) HIPCHK(hipMemcpyAsync(h_text.p, d_text.p, (size_t)text_total, hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipEventRecord(ev_text, stream));
+        HIPCHK(hipEventRecord(ev_lines, stream));
+        // the copies run on their own stream: uploads and kernels of the next region do not queue behind 300 MB of text
+        HIPCHK(hipStreamWaitEvent(stream2, ev_lines, 0));
+        HIPCHK(hipMemcpyAsync(h_toff[slot].p, d_toff.p, ((size_t)P + 1) * 4, hipMemcpyDeviceToHost, stream2));
+        if (total) HIPCHK(hipMemcpyAsync(h_text[slot].p, d_text.p, (size_t)total, hipMemcpyDeviceToHost, stream2));
+        HIPCHK(hipEventRecord(ev_text[slot], stream2));
+        // ... but the next region's kernels overwrite d_toff / d_text / the planes only after the copies (d_text is rewritten
+        // by the next text_begin, which waits above; d_tlen / d_toff likewise)
         return BRC_OK;
     }
-    int text_wait(HostText* out) override {
+    int text_wait(int slot, HostText* out) override {
         HIPCHK(hipSetDevice(device));
-        if (!text_pending) { err = "no device text was started"; return BRC_E_ARG; }
-        HIPCHK(hipEventSynchronize(ev_text));
-        out->text = h_text.p; out->off = h_toff.p; out->total = text_total; out->n = c.P;
+        slot &= 1;
+        if (!text_started[slot]) { err = "no device text was started"; return BRC_E_ARG; }
+        HIPCHK(hipEventSynchronize(ev_text[slot]));
+        out->text = h_text[slot].p; out->off = h_toff[slot].p; out->total = text_total[slot]; out->n = text_n[slot];
         return BRC_OK;
     }
 

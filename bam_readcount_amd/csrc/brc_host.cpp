@@ -266,6 +266,7 @@ struct brc_engine {
     bool text_only = false;
     bool device_text = false; std::string chrom;   // BRC_OPT_DEVICE_TEXT / brc_set_chrom
     bool text_result = false;                       // the last fetched result is device text (no planes on the host)
+    bool text_computed = false; int text_slot_computed = 0, text_slot = 0;   // device text started by the last brc_compute / fetched
     TextBuf pbuf;                                   // the lines the host rewrote
     struct Patch { int64_t k; size_t off, len; };
     std::vector<Patch> patches;
@@ -281,7 +282,7 @@ struct brc_engine {
     std::vector<std::deque<QEnt> > queue;
     // host-side phase timers (BRC_ENGINE_TIMING=1: printed by brc_destroy)
     double t_push = 0, t_upload = 0, t_compute = 0, t_d2h = 0, t_post = 0, t_format = 0; int64_t n_regions = 0;
-    uint64_t n_xev_total = 0, n_indel_total = 0;
+    uint64_t n_xev_total = 0, n_indel_total = 0; double t_textwait = 0;
 };
 
 static int fail(brc_engine* e, int code, const char* msg) { e->err = msg; return code; }
@@ -325,8 +326,8 @@ int brc_create(const brc_config* cfg, brc_engine** out) {
 void brc_destroy(brc_engine* e) {
     if (!e) return;
     if (getenv("BRC_ENGINE_TIMING"))
-        fprintf(stderr, "engine timing (%lld regions): push %.3f s, upload %.3f s, compute %.3f s, download %.3f s, assemble %.3f s, format %.3f s; third-allele events %llu, indel buckets %llu\n",
-                (long long)e->n_regions, e->t_push, e->t_upload, e->t_compute, e->t_d2h, e->t_post, e->t_format, (unsigned long long)e->n_xev_total, (unsigned long long)e->n_indel_total);
+        fprintf(stderr, "engine timing (%lld regions): push %.3f s, upload %.3f s, compute %.3f s, download %.3f s, assemble %.3f s, format %.3f s (of which waiting for the device text %.3f s); third-allele events %llu, indel buckets %llu\n",
+                (long long)e->n_regions, e->t_push, e->t_upload, e->t_compute, e->t_d2h, e->t_post, e->t_format, e->t_textwait, (unsigned long long)e->n_xev_total, (unsigned long long)e->n_indel_total);
     e->st.destroy();
     delete e->be;
     free(e->dense_i); free(e->dense_f); free(e->tbuf);
@@ -500,6 +501,14 @@ int brc_compute(brc_engine* e, brc_timing* t) {
     const double t_in = now_s();
     int rc = e->be->compute(t);
     if (rc) return fail(e, rc, e->be->last_error());
+    // device-side text: the line kernels and the download start as soon as the region is computed (lines above 4 GiB per
+    // region would overflow the 32-bit offsets: such regions are formatted on the host)
+    e->text_computed = e->text_only && e->device_text && !e->chrom.empty() &&
+                       (double)e->g.P * (double)e->g.Lp * 700.0 + 64.0 * (double)e->g.P < 4.0e9;
+    if (e->text_computed) {
+        rc = e->be->text_begin(e->chrom, e->libs, &e->text_slot_computed);
+        if (rc) return fail(e, rc, e->be->last_error());
+    }
     e->state = 3; e->t_compute += now_s() - t_in;
     return BRC_OK;
 }
@@ -509,8 +518,7 @@ int brc_fetch_result(brc_engine* e, brc_result* out) {
     if (e->state < 3) return fail(e, BRC_E_ARG, "brc_fetch_result before brc_compute");
     const double t_in = now_s();
     // device-side text: no planes come to the host (lines above 4 GiB per region would overflow the 32-bit offsets)
-    e->text_result = e->text_only && e->device_text && !e->chrom.empty() &&
-                     (double)e->g.P * (double)e->g.Lp * 700.0 + 64.0 * (double)e->g.P < 4.0e9;
+    e->text_result = e->text_computed; e->text_slot = e->text_slot_computed;
     int rc = e->be->fetch(&e->hp, !e->text_result);
     if (rc) return fail(e, rc, e->be->last_error());
     const double t_dl = now_s(); e->t_d2h += t_dl - t_in;
@@ -594,8 +602,6 @@ int brc_fetch_result(brc_engine* e, brc_result* out) {
     out->refbase = e->refbase.data();
     if (e->text_result) {
         out->ncol = out->depth = out->unavail = NULL; out->refbase = NULL;
-        rc = e->be->text_begin(e->chrom, e->libs);              // line kernels + the download, behind the lists on the stream
-        if (rc) return fail(e, rc, e->be->last_error());
     }
     out->n_indel = (int64_t)e->indels.size(); out->indel = e->indels.data();
     out->alleles = e->alleles.data(); out->alleles_len = e->alleles.size();
@@ -762,8 +768,10 @@ static bool format_range(const brc_engine* e, const brc_result* r, const char* c
 // Output: e->part_ptr / e->part_len, pieces of the downloaded text interleaved with the rewritten lines.
 static int format_device_text(brc_engine* e, const brc_result* r) {
     HostText ht;
-    int rc = e->be->text_wait(&ht);
+    const double t_w = now_s();
+    int rc = e->be->text_wait(e->text_slot, &ht);
     if (rc) return fail(e, rc, e->be->last_error());
+    e->t_textwait += now_s() - t_w;
     const int Lp = r->n_lib; const int64_t P = r->n_pos;
     const bool per_lib = e->cfg.per_lib != 0;
     const uint32_t tid = (uint32_t)r->tid;
@@ -771,7 +779,7 @@ static int format_device_text(brc_engine* e, const brc_result* r) {
     std::vector<std::deque<QEnt> >& queue = e->queue;
     int64_t ii = 0; size_t xi = 0;
     auto queues_busy = [&]() { for (const std::deque<QEnt>& q : queue) if (!q.empty()) return true; return false; };
-    std::string body; char nb[STAT_MAX + 64];
+    char nb[STAT_MAX + 64];
     int64_t k = -1;
     for (;;) {
         while (ii < r->n_indel && (int64_t)r->indel[ii].pos - r->pos0 <= k) ++ii;       // behind the last line looked at
@@ -796,23 +804,44 @@ static int format_device_text(brc_engine* e, const brc_result* r) {
         while (p < L1 && tabs < 3) { if (*p == '\t') ++tabs; ++p; }
         const char* const dep0 = p; uint32_t depth = 0;
         while (p < L1 && *p != '\t') { depth = depth * 10u + (uint32_t)(*p - '0'); ++p; }
-        // the blocks
-        body.clear(); bool changed = false; uint32_t extra = 0;
-        auto bucket_tokens = [&](int l) {
-            for (int b = 0; b < BRC_NBUCKET; ++b) {                // p at '\t' of "\tX:stat"
-                const char* t0 = p; ++p; while (p < L1 && *p != '\t') ++p;
-                const XAgg* xa = nullptr;
-                for (size_t x = xi; x < e->xagg.size() && (int64_t)(e->xagg[x].key >> 16) == k; ++x)
-                    if ((e->xagg[x].key & 0xffffu) == (((uint64_t)l << 8) | (uint64_t)b)) { xa = &e->xagg[x]; break; }
-                if (!xa) { body.append(t0, (size_t)(p - t0)); continue; }
-                body.append(t0, 3);                                // "\tX:"
-                char* w = fmt_stat(nb, xa->st.i, xa->st.f, false); body.append(nb, (size_t)(w - nb)); changed = true;
+        // the blocks, rebuilt behind room for the prefix and a depth of up to ten digits (the depth is known last)
+        const size_t pre = (size_t)(dep0 - L0);
+        const size_t base = e->pbuf.n;
+        size_t cap_need = pre + 16 + (size_t)(L1 - L0) + 64;
+        char* w0 = e->pbuf.room(cap_need);
+        if (!w0) return fail(e, BRC_E_NOMEM, "host allocation of the text buffers failed");
+        size_t wn = pre + 10;                                      // bytes used behind w0 (body starts here)
+        bool changed = false; uint32_t extra = 0;
+        auto put = [&](const char* src, size_t len) -> bool {
+            if (wn + len + 64 > cap_need) {                        // indel entries make a line longer than the device's
+                cap_need = wn + len + 4096;
+                if (!e->pbuf.room(cap_need)) return false;
+                w0 = e->pbuf.p + base;
             }
+            memcpy(w0 + wn, src, len); wn += len;
+            return true;
         };
-        auto lib_tail = [&](int l) {
-            auto entry = [&](const char* allele, size_t alen, const uint32_t* ei, const float* ef) {
-                body += '\t'; body.append(allele, alen); body += ':';
-                char* w = fmt_stat(nb, ei, ef, true); body.append(nb, (size_t)(w - nb)); changed = true;
+        auto bucket_tokens = [&](int l) -> bool {
+            const bool any = xi < e->xagg.size() && (int64_t)(e->xagg[xi].key >> 16) == k;
+            for (int b = 0; b < BRC_NBUCKET; ++b) {                // p at '\t' of "\tX:stat"
+                const char* t0 = p;
+                const char* t1 = (const char*)memchr(p + 1, '\t', (size_t)(L1 - p - 1));
+                p = t1 ? t1 : L1;
+                const XAgg* xa = nullptr;
+                if (any) for (size_t x = xi; x < e->xagg.size() && (int64_t)(e->xagg[x].key >> 16) == k; ++x)
+                    if ((e->xagg[x].key & 0xffffu) == (((uint64_t)l << 8) | (uint64_t)b)) { xa = &e->xagg[x]; break; }
+                if (!xa) { if (!put(t0, (size_t)(p - t0))) return false; continue; }
+                char* w = fmt_stat(nb, xa->st.i, xa->st.f, false);
+                if (!put(t0, 3) || !put(nb, (size_t)(w - nb))) return false;       // "\tX:" + the bucket's text
+                changed = true;
+            }
+            return true;
+        };
+        auto lib_tail = [&](int l) -> bool {
+            auto entry = [&](const char* allele, size_t alen, const uint32_t* ei, const float* ef) -> bool {
+                char* w = fmt_stat(nb, ei, ef, true);
+                changed = true;
+                return put("\t", 1) && put(allele, alen) && put(":", 1) && put(nb, (size_t)(w - nb));
             };
             while (ii < r->n_indel && r->indel[ii].pos == pos && r->indel[ii].lib < l) ++ii;
             for (; ii < r->n_indel && r->indel[ii].pos == pos && r->indel[ii].lib == l; ++ii) {
@@ -821,38 +850,38 @@ static int format_device_text(brc_engine* e, const brc_result* r) {
                     QEnt q; q.tid = tid; q.pos = (uint32_t)pos + 1; q.st = d.stat;
                     q.allele.assign(r->alleles + d.allele_off, d.allele_len);
                     queue[(size_t)l].push_back(q);
-                } else entry(r->alleles + d.allele_off, d.allele_len, d.stat.i, d.stat.f);   // :399
+                } else if (!entry(r->alleles + d.allele_off, d.allele_len, d.stat.i, d.stat.f)) return false;   // :399
             }
             std::deque<QEnt>& q = queue[(size_t)l];                                       // IndelQueue::process
             while (!q.empty() && ((q.front().tid == tid && q.front().pos < (uint32_t)pos) || q.front().tid != tid)) q.pop_front();
             while (!q.empty() && q.front().tid == tid && q.front().pos == (uint32_t)pos) {
-                entry(q.front().allele.data(), q.front().allele.size(), q.front().st.i, q.front().st.f);
+                if (!entry(q.front().allele.data(), q.front().allele.size(), q.front().st.i, q.front().st.f)) return false;
                 extra += q.front().st.i[I_N];
                 q.pop_front();
             }
+            return true;
         };
-        if (!per_lib) { bucket_tokens(0); lib_tail(0); }
+        bool ok = true;
+        if (!per_lib) ok = bucket_tokens(0) && lib_tail(0);
         else {
-            while (p < L1) {                                       // "\tname\t{" six buckets "\t}"
+            while (ok && p < L1) {                                 // "\tname\t{" six buckets "\t}"
                 const char* t0 = p; ++p; const char* n0 = p; while (p < L1 && *p != '\t') ++p;
                 int l = -1; for (int x = 0; x < Lp; ++x) if (e->libs[(size_t)x].size() == (size_t)(p - n0) && memcmp(e->libs[(size_t)x].data(), n0, (size_t)(p - n0)) == 0) { l = x; break; }
                 p += 2;                                            // "\t{"
-                body.append(t0, (size_t)(p - t0));
-                if (l < 0) return fail(e, BRC_E_ARG, "device text: unknown library block");
-                bucket_tokens(l); lib_tail(l);
-                body.append(p, 2); p += 2;                         // "\t}"
+                if (l < 0 || p > L1) return fail(e, BRC_E_ARG, "device text: unknown library block");
+                ok = put(t0, (size_t)(p - t0)) && bucket_tokens(l) && lib_tail(l) && put(p, 2);
+                p += 2;                                            // "\t}"
             }
         }
+        if (!ok) return fail(e, BRC_E_NOMEM, "host allocation of the text buffers failed");
         while (ii < r->n_indel && r->indel[ii].pos == pos) ++ii;   // (indel entries of libraries without a block cannot exist)
-        if (!changed) continue;
-        const size_t need = (size_t)(dep0 - L0) + 16 + body.size() + 2;
-        char* w = e->pbuf.room(need);
-        if (!w) return fail(e, BRC_E_NOMEM, "host allocation of the text buffers failed");
-        brc_engine::Patch pt; pt.k = k; pt.off = e->pbuf.n;
-        memcpy(w, L0, (size_t)(dep0 - L0)); w += dep0 - L0;
-        w += fmt_u32(w, depth + extra);
-        memcpy(w, body.data(), body.size()); w += body.size(); *w++ = '\n';
-        pt.len = (size_t)(w - (e->pbuf.p + pt.off)); e->pbuf.n += pt.len;
+        if (!changed) continue;                                    // (nothing was committed: pbuf.n is unchanged)
+        w0[wn++] = '\n';
+        char dg[16]; const int nd = fmt_u32(dg, depth + extra);
+        char* line = w0 + 10 - nd;                                 // prefix + depth right in front of the body
+        memmove(line, L0, pre); memcpy(line + pre, dg, (size_t)nd);
+        brc_engine::Patch pt; pt.k = k; pt.off = base + (size_t)(10 - nd); pt.len = wn - (size_t)(10 - nd);
+        e->pbuf.n = base + wn;
         e->patches.push_back(pt);
     }
     // parts: device text between the rewritten lines; the lead position (index 0 when pos0 < beg0) is never printed

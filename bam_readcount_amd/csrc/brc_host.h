@@ -109,8 +109,10 @@ class Backend {
     virtual int fetch(HostPlanes* out, bool planes) = 0;                                 // device -> host: counters, third-allele and indel lists, and (planes) the slot planes
     // device-side text of the computed region: text_begin launches the line kernels and starts the download (the device
     // buffers of the region stay untouched until it is done: same stream), text_wait waits for it
-    virtual int text_begin(const std::string& chrom, const std::vector<std::string>& libs) = 0;
-    virtual int text_wait(HostText* out) = 0;
+    // (two host buffers: `slot` names the one this region's text goes to — the text of the region before may still be
+    // in the writer's hands while the next region's download is already running)
+    virtual int text_begin(const std::string& chrom, const std::vector<std::string>& libs, int* slot) = 0;
+    virtual int text_wait(int slot, HostText* out) = 0;
     virtual int counts(uint64_t* n_events, uint64_t* n_positions) = 0;
     virtual const char* last_error() const = 0;
 };

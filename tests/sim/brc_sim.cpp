@@ -205,9 +205,11 @@ class SimBackend : public Backend {
     // "download": like the HIP backend, the host view is a copy — upload / compute of the next region may run while the
     // previous result is still being formatted (include/brc.h, threads)
     std::vector<uint32_t> h_ncol, h_depth, h_slotid, h_si, h_unavail; std::vector<float> h_sf; std::vector<XEv> h_xev; std::vector<IndelOut> h_iout;
-    std::vector<char> t_text; std::vector<uint32_t> t_off; Planes pl_last; bool have_pl = false;
-    int text_begin(const std::string& chrom, const std::vector<std::string>& libs) override {
+    std::vector<char> t_text2[2]; std::vector<uint32_t> t_off2[2]; int t_slot = 0; Planes pl_last; bool have_pl = false;
+    int text_begin(const std::string& chrom, const std::vector<std::string>& libs, int* slot) override {
         if (!have_pl) return BRC_E_ARG;
+        t_slot ^= 1; *slot = t_slot;
+        std::vector<char>& t_text = t_text2[t_slot]; std::vector<uint32_t>& t_off = t_off2[t_slot];
         std::vector<int32_t> loff((size_t)c.Lp + 1, 0); std::string names;
         if (c.per_lib) for (int l = 0; l < c.Lp; ++l) { loff[(size_t)l] = (int32_t)names.size(); if ((size_t)l < libs.size()) names += libs[(size_t)l]; loff[(size_t)l + 1] = (int32_t)names.size(); }
         TextCtx t; t.chrom = chrom.data(); t.chrom_len = (int32_t)chrom.size(); t.lib_names = names.data(); t.lib_off = loff.data();
@@ -217,7 +219,10 @@ class SimBackend : public Backend {
         for (int64_t k = 0; k < c.P; ++k) if (t_off[(size_t)k + 1] > t_off[(size_t)k]) (void)text_line(c, in, pl_last, t, k, t_text.data() + t_off[(size_t)k]);
         return BRC_OK;
     }
-    int text_wait(HostText* out) override { out->text = t_text.data(); out->off = t_off.data(); out->total = t_off.empty() ? 0 : t_off.back(); out->n = c.P; return BRC_OK; }
+    int text_wait(int slot, HostText* out) override {
+        const std::vector<char>& t_text = t_text2[slot & 1]; const std::vector<uint32_t>& t_off = t_off2[slot & 1];
+        out->text = t_text.data(); out->off = t_off.data(); out->total = t_off.empty() ? 0 : t_off.back(); out->n = (int64_t)t_off.size() - 1; return BRC_OK;
+    }
     int fetch(HostPlanes* out, bool) override {
         h_ncol = ncol; h_depth = depth; h_slotid = slotid; h_si = si; h_unavail = unavail; h_sf = sf; h_xev = xev; h_iout = iout;
         out->ncol = h_ncol.data(); out->depth = h_depth.data(); out->slotid = h_slotid.data(); out->si = h_si.data(); out->sf = h_sf.data(); out->unavail = h_unavail.data();
