@@ -781,7 +781,12 @@ static int format_device_text(brc_engine* e, const brc_result* r) {
     auto queues_busy = [&]() { for (const std::deque<QEnt>& q : queue) if (!q.empty()) return true; return false; };
     char nb[STAT_MAX + 64];
     int64_t k = -1;
+    // the lines to rewrite are scattered over text that just arrived by DMA (not in any cache): pull the next few in early
+    int64_t la_i = 0; size_t la_x = 0;
+    auto prefetch_line = [&](int64_t kk) { if (kk >= 0 && kk < P) { const char* q = ht.text + ht.off[kk]; for (int o = 0; o < 448; o += 64) __builtin_prefetch(q + o); } };
     for (;;) {
+        for (la_i = std::max(la_i, ii); la_i < r->n_indel && la_i < ii + 12; ++la_i) { const int64_t kk = (int64_t)r->indel[la_i].pos - r->pos0; prefetch_line(kk); prefetch_line(kk + 1); }
+        for (la_x = std::max(la_x, xi); la_x < e->xagg.size() && la_x < xi + 12; ++la_x) prefetch_line((int64_t)(e->xagg[la_x].key >> 16));
         while (ii < r->n_indel && (int64_t)r->indel[ii].pos - r->pos0 <= k) ++ii;       // behind the last line looked at
         while (xi < e->xagg.size() && (int64_t)(e->xagg[xi].key >> 16) <= k) ++xi;
         int64_t kc = INT64_MAX;

@@ -228,6 +228,28 @@ static void print_warn_events(const char* ev, size_t n, long long max, int64_t* 
     }
 }
 
+// Many pieces of text -> stdout with few system calls: a region's text arrives as thousands of pieces (the device's text
+// between the lines the host rewrote); one write() each would cost more than producing them.
+#include <sys/uio.h>
+static void write_parts(const char* const* parts, const size_t* lens, size_t n) {
+    fflush(stdout);
+    const int fd = fileno(stdout);
+    std::vector<struct iovec> iov; iov.reserve(1024);
+    size_t i = 0;
+    while (i < n) {
+        iov.clear();
+        for (; i < n && iov.size() < 1024; ++i) if (lens[i]) { struct iovec v; v.iov_base = (void*)parts[i]; v.iov_len = lens[i]; iov.push_back(v); }
+        size_t k = 0;
+        while (k < iov.size()) {
+            const ssize_t w = writev(fd, iov.data() + k, (int)(iov.size() - k));
+            if (w < 0) { if (errno == EINTR || errno == EAGAIN) continue; return; }     // (a closed pipe: like the reference, carry on silently)
+            size_t left = (size_t)w;
+            while (k < iov.size() && left >= iov[k].iov_len) { left -= iov[k].iov_len; ++k; }
+            if (k < iov.size() && left) { iov[k].iov_base = (char*)iov[k].iov_base + left; iov[k].iov_len -= left; }
+        }
+    }
+}
+
 struct Ctx {
     double t_fetch = 0, t_engine = 0, t_format = 0, t_write = 0;   // BRC_CLI_TIMING=1 prints them on stderr
     Options opt; BamReader bam; BamIndex idx; Fasta fa; bool have_fa = false;
@@ -256,7 +278,8 @@ struct Ctx {
     const char* const** zc_parts = nullptr; const size_t** zc_lens = nullptr; size_t* zc_n = nullptr;
     void emit_region(const char* const* parts, const size_t* lens, size_t n) {
         if (zc_parts) { *zc_parts = parts; *zc_lens = lens; *zc_n = n; return; }
-        for (size_t i = 0; i < n; ++i) emit(parts[i], lens[i]);
+        if (out_buf) { for (size_t i = 0; i < n; ++i) emit(parts[i], lens[i]); return; }
+        write_parts(parts, lens, n);
     }
     // several engines: the reads of this engine's next piece, fetched while the current piece is on the GPU / being formatted
     struct Prefetch { bool valid = false; int tid = 0; int64_t a = 0, b = 0; } pf;
@@ -761,7 +784,7 @@ int main(int argc, char** argv) {
             Work& w = items[i];
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return w.done; }); }
             if (!w.out.empty()) fwrite(w.out.data(), 1, w.out.size(), stdout);
-            for (size_t k = 0; k < w.n_parts; ++k) if (w.lens[k]) fwrite(w.parts[k], 1, w.lens[k], stdout);
+            if (w.n_parts) write_parts(w.parts, w.lens, w.n_parts);
             if (!w.wev.empty()) print_warn_events(w.wev.data(), w.wev.size(), c.opt.max_warnings, gcount, stderr);   // the global -w counters, in file order
             if (!w.err.empty()) fputs(w.err.c_str(), stderr);
             std::string().swap(w.out);
