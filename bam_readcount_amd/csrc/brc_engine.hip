@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "brc_host.h"
@@ -1317,6 +1318,7 @@ class HipBackend : public Backend {
         const int64_t P = c.P;
         const int slot = (text_slot ^= 1); *slot_out = slot;
         text_started[slot] = true; text_total[slot] = 0; text_n[slot] = P;
+        { const int rc0 = enqueue_lists(); if (rc0) return rc0; }
         if (!h_toff[slot].reserve((size_t)P + 4) || !h_total.reserve(4)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }
         if (P == 0) { h_toff[slot].p[0] = 0; HIPCHK(hipEventRecord(ev_text[slot], stream)); return BRC_OK; }
         // column 1 and the library names, behind the offsets of the names
@@ -1338,6 +1340,7 @@ class HipBackend : public Backend {
         HIPCHK(hipStreamSynchronize(stream));                                  // (also covers the local `ctx`)
         const uint64_t total = h_total.p[0];
         text_total[slot] = total;
+        std::lock_guard<std::mutex> lk(text_mu);
         HIPCHK(d_text.ensure((size_t)total + 64));
         if (!h_text[slot].reserve((size_t)total + 64)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }
         hipLaunchKernelGGL(k_text_write, dim3(nb), dim3(256), 0, stream, c, in, pl_last, t, (const uint32_t*)d_toff.p, (char*)d_text.p);
@@ -1368,6 +1371,26 @@ class HipBackend : public Backend {
         return BRC_OK;
     }
 
+    // the two small lists (third-allele events, indel buckets) -> pinned host memory.  With device-side text they are
+    // requested BEFORE the text: the DMA engine serves copies in order, and the caller needs the lists first.
+    bool lists_enqueued = false;
+    int enqueue_lists() {
+        const size_t nx = h_ctr.n_xev, ns = h_ctr.n_indel_slots;
+        if (!h_xev.reserve(nx + 4) || !h_iout.reserve(ns + 4)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }
+        if (nx) HIPCHK(hipMemcpyAsync(h_xev.p, d_xevc.p, nx * sizeof(XEv), hipMemcpyDeviceToHost, stream));
+        if (ns) HIPCHK(hipMemcpyAsync(h_iout.p, d_iout.p, ns * sizeof(IndelOut), hipMemcpyDeviceToHost, stream));
+        lists_enqueued = true;
+        return BRC_OK;
+    }
+    // pinned / device room for the text of regions of about `bytes` (called early, from any thread, before the first region)
+    std::mutex text_mu;                  // reserve_text may run on another thread while the first region is staged
+    int reserve_text(size_t bytes) override {
+        std::lock_guard<std::mutex> lk(text_mu);
+        HIPCHK(hipSetDevice(device));
+        for (int i = 0; i < 2; ++i) if (!h_text[i].reserve(bytes)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }
+        HIPCHK(d_text.ensure(bytes));
+        return BRC_OK;
+    }
     int fetch(HostPlanes* out, bool planes) override {
         HIPCHK(hipSetDevice(device));
         if (!computed) { err = "not computed"; return BRC_E_ARG; }
@@ -1383,12 +1406,9 @@ class HipBackend : public Backend {
             HIPCHK(hipMemcpyAsync(h_sf.p, d_sf.p, Lp * 2 * NF * P * 4, hipMemcpyDeviceToHost, stream));
             if (c.per_lib) HIPCHK(hipMemcpyAsync(h_unavail.p, d_unavail.p, P * 4, hipMemcpyDeviceToHost, stream));
         }
-        if (nx) HIPCHK(hipMemcpyAsync(h_xev.p, d_xevc.p, nx * sizeof(XEv), hipMemcpyDeviceToHost, stream));
         const size_t ns = h_ctr.n_indel_slots;
-        if (ns) {
-            if (!h_iout.reserve(ns + 4)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }
-            HIPCHK(hipMemcpyAsync(h_iout.p, d_iout.p, ns * sizeof(IndelOut), hipMemcpyDeviceToHost, stream));
-        }
+        if (!lists_enqueued) { const int rc = enqueue_lists(); if (rc) return rc; }
+        lists_enqueued = false;
         HIPCHK(hipStreamSynchronize(stream));
         iout_compact.clear();
         for (size_t i = 0; i < ns; ++i) if (h_iout.p[i].len != 0) iout_compact.push_back(h_iout.p[i]);

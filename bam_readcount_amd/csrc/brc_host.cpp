@@ -347,6 +347,7 @@ int brc_set_option(brc_engine* e, int option, int64_t value) {
         case BRC_OPT_EXPECT_READS: e->hint_reads = value > 0 ? (size_t)value : 0; return BRC_OK;
         case BRC_OPT_EXPECT_BASES: e->hint_bases = value > 0 ? (size_t)value : 0; return BRC_OK;
         case BRC_OPT_DEVICE_TEXT: e->device_text = value != 0; return BRC_OK;
+        case BRC_OPT_EXPECT_TEXT: { if (value <= 0) return BRC_OK; const int rc = e->be->reserve_text((size_t)value); return rc ? fail(e, rc, e->be->last_error()) : BRC_OK; }
         default: return fail(e, BRC_E_ARG, "unknown engine option");
     }
 }

@@ -703,6 +703,18 @@ int main(int argc, char** argv) {
     }
 
     if (items.size() < N) N = std::max<size_t>(items.size(), 1);      // engines without work are never created
+    // pin the text buffers of a long region's pieces while the first reads are being decoded
+    std::thread pin_ahead;
+    {
+        int64_t widest = 0; for (const Work& w : items) if (w.kind == 0) widest = std::max<int64_t>(widest, std::min<int64_t>(w.end - w.beg0, (int64_t)c.opt.chunk_bp));
+        const bool dev_text = !(getenv("BRC_DEVICE_TEXT") && atoi(getenv("BRC_DEVICE_TEXT")) == 0);
+        if (dev_text && widest >= 100000) {
+            const int64_t bytes = widest * (int64_t)(o.per_lib ? std::max<size_t>(c.libs.size(), 1) : 1) * 400;
+            brc_engine* eng0 = c.eng;
+            pin_ahead = std::thread([eng0, bytes]() { brc_set_option(eng0, BRC_OPT_EXPECT_TEXT, bytes); });
+        }
+    }
+    struct JoinPin { std::thread& t; ~JoinPin() { if (t.joinable()) t.join(); } } join_pin{pin_ahead};
     const bool clean_exit = getenv("BRC_CLEAN_EXIT") != nullptr || getenv("BRC_ENGINE_TIMING") != nullptr;
     if (N == 1) {
         for (Work& w : items) {

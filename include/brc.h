@@ -199,6 +199,10 @@ void brc_destroy(brc_engine*);
  *                      the next brc_fetch_result of this engine; brc_format_window needs planes and refuses it.  Regions
  *                      whose text could exceed 4 GiB fall back to the host formatter by themselves. */
 #define BRC_OPT_DEVICE_TEXT 4
+/*   BRC_OPT_EXPECT_TEXT  bytes of text a coming region will print: the two pinned text buffers are allocated now (this one
+ *                      option may be set from another thread while the first region is being staged — pinning hundreds of
+ *                      megabytes takes as long as decoding the first reads) */
+#define BRC_OPT_EXPECT_TEXT 5
 int  brc_set_option(brc_engine*, int option, int64_t value);
 /* Target name printed in column 1 of the following regions' lines (BRC_OPT_DEVICE_TEXT: the text is written at
  * brc_fetch_result time, before brc_format_region names the contig); copied. */
