@@ -359,7 +359,17 @@ bool Fasta::fetch(const std::string& name, std::string* seq) {
     std::vector<char> buf(raw + 1);
     const size_t got = fread(buf.data(), 1, raw, f);
     fclose(f);
-    for (size_t i = 0; i < got && (int64_t)seq->size() < e.len; ++i) { const char ch = buf[i]; if (ch != '\n' && ch != '\r') seq->push_back(ch); }
+    // the index promises uniform lines (linebases of linewidth bytes): copy line by line
+    seq->resize((size_t)e.len);
+    int64_t done = 0;
+    for (int64_t l = 0; l < nlines && done < e.len; ++l) {
+        const size_t o = (size_t)(l * e.linewidth);
+        if (o >= got) break;
+        const size_t n = (size_t)std::min<int64_t>(std::min<int64_t>(e.linebases, e.len - done), (int64_t)(got - o));
+        memcpy(&(*seq)[(size_t)done], buf.data() + o, n);
+        done += (int64_t)n;
+    }
+    seq->resize((size_t)done);
     return true;
 }
 

@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <functional>
+#include <future>
 #include <string>
 #include <vector>
 
@@ -273,6 +274,7 @@ struct Ctx {
     void emit(const char* t, size_t n) { if (!n) return; if (out_buf) out_buf->append(t, n); else fwrite(t, 1, n, stdout); }
     // several engines, region pieces: the text stays in the engine's buffer (no copy of hundreds of megabytes per piece);
     // the main thread writes it from there, and this engine's next format call waits for that (pre_format)
+    std::function<bool()> need_engine;      // the first context's engine is created in the background: wait for it (false: it failed)
     std::function<void()> pre_format;
     std::function<void()> after_take;       // run once the piece has taken its reads (the worker starts the next fetch then)
     const char* const** zc_parts = nullptr; const size_t** zc_lens = nullptr; size_t* zc_n = nullptr;
@@ -308,7 +310,7 @@ static void fetch_chunk(Ctx& c, int tid, int64_t a, int64_t b, Fetched& out) {
     unsigned K = 1;
     static const long long stripe_min = getenv("BRC_FETCH_STRIPE_MIN") ? atoll(getenv("BRC_FETCH_STRIPE_MIN")) : 65536;   // (tests force small chunks into stripes)
     if (!c.is_cram && b - q0 >= stripe_min) {
-        K = effective_cpus() / 2; if (K == 0) K = 1; if (K > 32) K = 32;
+        K = effective_cpus() * 3 / 4; if (K == 0) K = 1; if (K > 32) K = 32;
         if (const char* t = getenv("BRC_FETCH_THREADS")) { const int v = atoi(t); if (v > 0) K = (unsigned)v; }
         if ((int64_t)K > b - q0) K = (unsigned)(b - q0);          // every stripe at least one position wide (stripe 0 must contain q0)
     }
@@ -352,8 +354,8 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
     const int64_t chunk = (int64_t)c.opt.chunk_bp;
     const int64_t npieces = std::max<int64_t>(1, (end - beg0 + chunk - 1) / chunk);
     static const int ahead_env = getenv("BRC_FETCH_AHEAD") ? atoi(getenv("BRC_FETCH_AHEAD")) : 0;
-    // (the CRAM reader is one handle: one fetch at a time; with few CPUs a second fetch only takes them from the formatter)
-    const int ahead = c.is_cram ? 1 : (ahead_env > 0 ? ahead_env : (effective_cpus() >= 64 ? 2 : 1));
+    // (the CRAM reader is one handle: one fetch at a time)
+    const int ahead = c.is_cram ? 1 : (ahead_env > 0 ? ahead_env : 2);
     std::vector<Fetched> bufs((size_t)ahead + 1); std::vector<std::thread> fth((size_t)ahead + 1);
     auto start_fetch = [&](int64_t j) {
         if (j >= npieces) return;
@@ -385,6 +387,7 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
         Fetched& F = bufs[cur];
         if (!F.ok) { join_fmt(); c.complain("bam-readcount: read error: " + F.err + "\n"); return 1; }
         double t1 = now_s();
+        if (c.need_engine && !c.need_engine()) { join_fmt(); return 1; }
         rc = brc_begin_region(c.eng, tid, (int32_t)a, (int32_t)b, ref, (int64_t)c.ref.size());
         // the lines of a region piece are written on the GPU and come back as text (BRC_DEVICE_TEXT=0: host formatter)
         static const bool dev_text = !(getenv("BRC_DEVICE_TEXT") && atoi(getenv("BRC_DEVICE_TEXT")) == 0);
@@ -513,6 +516,7 @@ static int run_site_batch(Ctx& c, const std::vector<Site>& sites) {
             all.seq4.insert(all.seq4.end(), b.seq4.begin(), b.seq4.end());
             all.qual.insert(all.qual.end(), b.qual.begin(), b.qual.end());
         }
+        if (c.need_engine && !c.need_engine()) return 1;
         brc_set_option(c.eng, BRC_OPT_DEVICE_TEXT, 0);           // windows are cut out of shared planes on the host
         int rc = brc_begin_region(c.eng, 0, 1, (int32_t)V, c.have_fa ? vref.data() : nullptr, V);
         const brc_read_batch v = all.view();
@@ -631,9 +635,19 @@ int main(int argc, char** argv) {
         for (long long k = 1; k < K; ++k) devices.insert(devices.end(), one.begin(), one.end());
     }
     size_t N = devices.size();
-    int rc = make_engine(c, devices[0]);
-    const double t_engine0 = now_s();
-    if (rc) { fprintf(stderr, "bam-readcount: cannot create the MI355X engine: %s\n", brc_strerror(rc)); return 1; }
+    // The engine (HIP runtime start, streams) is created on a thread of its own while this one reads the index and the site
+    // list and — inside the first work item — the reference and the first reads; whoever needs the engine waits for it.
+    double t_engine0 = 0;
+    std::promise<int> eng_promise; std::shared_future<int> eng_ready = eng_promise.get_future().share();
+    std::thread eng_thread([&]() { const int r = make_engine(c, devices[0]); t_engine0 = now_s(); eng_promise.set_value(r); });
+    bool eng_reported = false;
+    auto wait_engine = [&]() -> bool {
+        const int r = eng_ready.get();
+        if (r && !eng_reported) { eng_reported = true; fprintf(stderr, "bam-readcount: cannot create the MI355X engine: %s\n", brc_strerror(r)); }
+        return r == 0;
+    };
+    c.need_engine = wait_engine;
+    struct JoinEng { std::thread& t; ~JoinEng() { if (t.joinable()) t.join(); } } join_eng{eng_thread};
 
     // ---- the work items, in file order
     std::vector<Work> items;
@@ -657,8 +671,8 @@ int main(int argc, char** argv) {
     };
     if (!o.site_list.empty()) {
         FILE* fp = fopen(o.site_list.c_str(), "r");
-        if (!fp) { fprintf(stderr, "Failed to open region list file: %s\n", o.site_list.c_str()); brc_destroy(c.eng); return 1; }            // :535-538
-        if (!c.is_cram && !c.idx.load(o.bam)) { fprintf(stderr, "BAM indexing file is not available.\n"); brc_destroy(c.eng); return 1; }                  // :548-551
+        if (!fp) { fprintf(stderr, "Failed to open region list file: %s\n", o.site_list.c_str()); return 1; }            // :535-538
+        if (!c.is_cram && !c.idx.load(o.bam)) { fprintf(stderr, "BAM indexing file is not available.\n"); return 1; }                  // :548-551
         // the planner needs -d to be out of play (its drop rule depends on what else is buffered) and narrow lines
         const bool plan = o.plan_sites > 0 && o.max_cnt >= 1000000 && !c.is_cram;
         Work pend; pend.kind = 1; int64_t pend_bp = 0;
@@ -687,7 +701,7 @@ int main(int argc, char** argv) {
         flush();
         fclose(fp);
     } else if (!o.regions.empty()) {
-        if (!c.is_cram && !c.idx.load(o.bam)) { fprintf(stderr, "BAM indexing file is not available.\n"); brc_destroy(c.eng); return 1; }                  // :637-640
+        if (!c.is_cram && !c.idx.load(o.bam)) { fprintf(stderr, "BAM indexing file is not available.\n"); return 1; }                  // :637-640
         for (const std::string& r : o.regions) {
             int tid; int64_t beg, end;
             if (!parse_region(c.header(), r, &tid, &beg, &end)) {                    // :645-648: the regions before it have been printed
@@ -698,7 +712,6 @@ int main(int argc, char** argv) {
     } else {
         fprintf(stderr, "bam-readcount: give a region or a site list (-l); the reference's whole-file mode skips its per-read "
                         "pre-processing (bamreadcount.cpp:624 FIXME) and is not reproduced\n");
-        brc_destroy(c.eng);
         return 1;
     }
 
@@ -710,8 +723,7 @@ int main(int argc, char** argv) {
         const bool dev_text = !(getenv("BRC_DEVICE_TEXT") && atoi(getenv("BRC_DEVICE_TEXT")) == 0);
         if (dev_text && widest >= 100000) {
             const int64_t bytes = widest * (int64_t)(o.per_lib ? std::max<size_t>(c.libs.size(), 1) : 1) * 400;
-            brc_engine* eng0 = c.eng;
-            pin_ahead = std::thread([eng0, bytes]() { brc_set_option(eng0, BRC_OPT_EXPECT_TEXT, bytes); });
+            pin_ahead = std::thread([&c, eng_ready, bytes]() { if (eng_ready.get() == 0) brc_set_option(c.eng, BRC_OPT_EXPECT_TEXT, bytes); });
         }
     }
     struct JoinPin { std::thread& t; ~JoinPin() { if (t.joinable()) t.join(); } } join_pin{pin_ahead};
@@ -815,6 +827,6 @@ int main(int argc, char** argv) {
     // the exit of a process that is done: leave them to the operating system (BRC_CLEAN_EXIT=1 keeps the orderly path).
     fflush(stdout); fflush(stderr);
     if (!clean_exit) _exit(ret);
-    brc_destroy(c.eng);
+    if (wait_engine()) brc_destroy(c.eng);
     return ret;
 }
