@@ -1383,6 +1383,7 @@ class HipBackend : public Backend {
         return BRC_OK;
     }
     // pinned / device room for the text of regions of about `bytes` (called early, from any thread, before the first region)
+    void list_sizes(uint64_t* n_xev, uint64_t* n_indel_slots) override { *n_xev = h_ctr.n_xev; *n_indel_slots = h_ctr.n_indel_slots; }
     std::mutex text_mu;                  // reserve_text may run on another thread while the first region is staged
     int reserve_text(size_t bytes) override {
         std::lock_guard<std::mutex> lk(text_mu);

@@ -507,6 +507,13 @@ int brc_compute(brc_engine* e, brc_timing* t) {
     e->text_computed = e->text_only && e->device_text && !e->chrom.empty() &&
                        (double)e->g.P * (double)e->g.Lp * 700.0 + 64.0 * (double)e->g.P < 4.0e9;
     if (e->text_computed) {
+        // the host rewrites the lines with indel buckets (and the line after a deletion) or a third base one by one: where
+        // those are a large share of the region (deep, indel-rich data) the pooled host formatter is the faster route
+        uint64_t nx = 0, ni = 0; e->be->list_sizes(&nx, &ni);
+        static const double max_share = getenv("BRC_DEVICE_TEXT_MAX_SHARE") ? atof(getenv("BRC_DEVICE_TEXT_MAX_SHARE")) : 0.06;
+        if ((double)nx + 2.0 * (double)ni > max_share * (double)std::max<int64_t>(e->g.P, 1)) e->text_computed = false;
+    }
+    if (e->text_computed) {
         rc = e->be->text_begin(e->chrom, e->libs, &e->text_slot_computed);
         if (rc) return fail(e, rc, e->be->last_error());
     }

@@ -113,7 +113,8 @@ class Backend {
     // in the writer's hands while the next region's download is already running)
     virtual int text_begin(const std::string& chrom, const std::vector<std::string>& libs, int* slot) = 0;
     virtual int text_wait(int slot, HostText* out) = 0;
-    virtual int reserve_text(size_t) { return BRC_OK; }                                  // room for the text of coming regions (optional)
+    virtual int reserve_text(size_t) { return BRC_OK; }
+    virtual void list_sizes(uint64_t* n_xev, uint64_t* n_indel_slots) { *n_xev = 0; *n_indel_slots = 0; }   // of the last compute                                  // room for the text of coming regions (optional)
     virtual int counts(uint64_t* n_events, uint64_t* n_positions) = 0;
     virtual const char* last_error() const = 0;
 };

@@ -5,6 +5,11 @@ import sys
 import numpy as np
 import pytest
 
+# Device-side text is chosen per region by the share of lines the host would have to rewrite (deep indel-rich fuzz data is
+# above the production threshold): the tests force it so that the rewriting is what they exercise; test_cli covers the
+# default threshold too.
+os.environ.setdefault("BRC_DEVICE_TEXT_MAX_SHARE", "100")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")

@@ -219,6 +219,7 @@ class SimBackend : public Backend {
         for (int64_t k = 0; k < c.P; ++k) if (t_off[(size_t)k + 1] > t_off[(size_t)k]) (void)text_line(c, in, pl_last, t, k, t_text.data() + t_off[(size_t)k]);
         return BRC_OK;
     }
+    void list_sizes(uint64_t* nx, uint64_t* ni) override { *nx = xev_n; *ni = iout.size(); }
     int text_wait(int slot, HostText* out) override {
         const std::vector<char>& t_text = t_text2[slot & 1]; const std::vector<uint32_t>& t_off = t_off2[slot & 1];
         out->text = t_text.data(); out->off = t_off.data(); out->total = t_off.empty() ? 0 : t_off.back(); out->n = (int64_t)t_off.size() - 1; return BRC_OK;

@@ -202,6 +202,11 @@ def _multi_engine_check(cli, d):
             assert many.stdout == one.stdout, (args, extra)
         whole = subprocess.run([cli, "-w", "0"] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env1)
         assert whole.stdout == one.stdout, args                  # and the tiling itself changes nothing
+        # the three text routes: production threshold (this indel-rich data goes to the host's compact-plane formatter),
+        # device-side text forced (the suite's default), host formatter forced
+        for k, v in (("BRC_DEVICE_TEXT_MAX_SHARE", "0.06"), ("BRC_DEVICE_TEXT_MAX_SHARE", "100"), ("BRC_DEVICE_TEXT", "0")):
+            alt = subprocess.run([cli, "-w", "0", "--brc-chunk", "333"] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(env1, **{k: v}))
+            assert alt.returncode == 0 and alt.stdout == one.stdout, (args, k, v)
     bad = subprocess.run([cli, "--brc-gpus", "2", "-f", "syn.fa", "syn.bam", "chrA:1-50", "nochr:1-2", "chrB:1-5"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert bad.returncode == 1 and b"Invalid region nochr:1-2" in bad.stderr and bad.stdout.startswith(b"chrA\t") and b"chrB" not in bad.stdout
 
