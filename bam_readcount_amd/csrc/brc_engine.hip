@@ -52,6 +52,8 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 // A NUL character keeps bit 7 set: the annotator stops at it (:151), which only the serial path reproduces.
 // REFCODE_PAD bytes of padding (code 15) on both sides: an 8-byte window may start before / end after the slice.
 enum { REFCODE_PAD = 16 };
+// (launched once when an engine is created: the code object is loaded then, not inside the first region)
+__global__ void k_warm() {}
 __global__ __launch_bounds__(256) void k_refcode(const char* __restrict__ ref, uint8_t* __restrict__ code, int64_t n) {
     // 16 codes per thread; `code` (padded buffer) is 16-byte aligned and REFCODE_PAD == 16, so chunk i of the output
     // holds the codes of ref[16 i - 16 .. 16 i)
@@ -934,7 +936,8 @@ __global__ __launch_bounds__(256) void k_finalize_sum(const unsigned long long* 
     for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
         for (int i = 0; i < 5; ++i) v[i] += part[(int64_t)b * 5 + i];
     block_sum_u64<5>(v, sh);
-    if (threadIdx.x == 0) { ctr->n_positions += v[0]; ctr->n_events += v[1]; ctr->w_sm += v[2]; ctr->w_nm += v[3]; ctr->w_lib += v[4]; }
+    // (w_sm / w_nm: k_indel_reduce adds to them from another stream)
+    if (threadIdx.x == 0) { ctr->n_positions += v[0]; ctr->n_events += v[1]; atomicAdd(&ctr->w_sm, v[2]); atomicAdd(&ctr->w_nm, v[3]); ctr->w_lib += v[4]; }
 }
 
 // ---------------------------------------------------------------- indel side path
@@ -1087,6 +1090,7 @@ class HipBackend : public Backend {
     // device-side text, downloaded (pinned) on its own stream into one of two host buffers
     HBuf<char> h_text[2]; HBuf<uint32_t> h_toff[2]; HBuf<uint32_t> h_total;
     hipStream_t stream2 = nullptr; hipEvent_t ev_text[2] = {nullptr, nullptr}, ev_lines = nullptr;
+    hipStream_t stream3 = nullptr; hipEvent_t ev_indel[4] = {nullptr, nullptr, nullptr, nullptr}; DBuf d_agg2;   // the indel side path's stream
     bool text_started[2] = {false, false}; uint64_t text_total[2] = {0, 0}; int64_t text_n[2] = {0, 0}; int text_slot = 0;
     Planes pl_last;                      // the planes of the last compute
     // host result buffers (pinned)
@@ -1115,6 +1119,10 @@ class HipBackend : public Backend {
         for (int i = 0; i <= T_N; ++i) HIPCHK(hipEventCreate(&evt[i]));
         have_events = true;
         HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&stream3, hipStreamNonBlocking));
+        for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&ev_indel[i]));
+        hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, stream);
+        HIPCHK(hipStreamSynchronize(stream));
         for (int i = 0; i < 2; ++i) { HIPCHK(hipEventCreateWithFlags(&ev_text[i], hipEventDisableTiming)); h_text[i].A = &kPinned; h_toff[i].A = &kPinned; }
         HIPCHK(hipEventCreateWithFlags(&ev_lines, hipEventDisableTiming));
         h_total.A = &kPinned;
@@ -1131,6 +1139,9 @@ class HipBackend : public Backend {
         h_total.destroy();
         if (ev_lines) (void)hipEventDestroy(ev_lines);
         if (stream2) (void)hipStreamDestroy(stream2);
+        for (int i = 0; i < 4; ++i) if (ev_indel[i]) (void)hipEventDestroy(ev_indel[i]);
+        if (stream3) (void)hipStreamDestroy(stream3);
+        d_agg2.release();
         h_ncol.destroy(); h_depth.destroy(); h_slotid.destroy(); h_si.destroy(); h_unavail.destroy(); h_sf.destroy(); h_iout.destroy(); h_xev.destroy();
         if (have_events) for (int i = 0; i <= T_N; ++i) (void)hipEventDestroy(evt[i]);
         if (stream) (void)hipStreamDestroy(stream);
@@ -1192,7 +1203,7 @@ class HipBackend : public Backend {
         if (n_indel_cap && (uint64_t)c.P * (uint64_t)c.Lp >= 0xffffffffull) { err = "region too large: (positions x libraries) must stay below 2^32"; return BRC_E_ARG; }
         const size_t nagg = std::max<size_t>((std::max<size_t>(np, P * Lp) + SCAN_CHUNK - 1) / SCAN_CHUNK, 1);
         HIPCHK(d_reads.ensure((n + 1) * sizeof(DRead))); HIPCHK(d_prefmax.ensure((np + 16) * 4));
-        HIPCHK(d_agg.ensure(nagg * 4 + 16)); HIPCHK(d_rng.ensure(((size_t)ntiles * Lp + 1) * sizeof(uint2)));
+        HIPCHK(d_agg.ensure(nagg * 4 + 16)); HIPCHK(d_agg2.ensure(nagg * 4 + 16)); HIPCHK(d_rng.ensure(((size_t)ntiles * Lp + 1) * sizeof(uint2)));
         HIPCHK(d_ncol.ensure(Lp * P * 4 + 16)); HIPCHK(d_depth.ensure(Lp * P * 4 + 16)); HIPCHK(d_unavail.ensure(P * 4 + 16));
         HIPCHK(d_slotid.ensure(Lp * P * 4 + 16)); HIPCHK(d_si.ensure(Lp * 2 * NI * P * 4 + 16)); HIPCHK(d_sf.ensure(Lp * 2 * NF * P * 4 + 16));
         // third-allele lists: XEV_SHARDS sub-lists; about one piece in 25 leaves an event at 30-50x, capacity for twice that,
@@ -1215,13 +1226,16 @@ class HipBackend : public Backend {
     }
 
     template <class Op, bool INCL>
-    int scan(const typename Op::T* src, typename Op::T* dst, int64_t n) {
+    int scan(const typename Op::T* src, typename Op::T* dst, int64_t n) { return scan_on<Op, INCL>(src, dst, n, stream, d_agg); }
+    // (the indel side path scans on its own stream with its own block-aggregate scratch)
+    template <class Op, bool INCL>
+    int scan_on(const typename Op::T* src, typename Op::T* dst, int64_t n, hipStream_t st, DBuf& scratch) {
         if (n <= 0) return BRC_OK;
         const int64_t nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
-        typename Op::T* agg = (typename Op::T*)d_agg.p;
-        hipLaunchKernelGGL((k_scan_reduce<Op>), dim3((unsigned)nb), dim3(SCAN_T), 0, stream, src, n, agg);
-        hipLaunchKernelGGL((k_scan_aggregates<Op>), dim3(1), dim3(1024), 0, stream, agg, nb);
-        hipLaunchKernelGGL((k_scan_apply<Op, INCL>), dim3((unsigned)nb), dim3(SCAN_T), 0, stream, src, dst, n, (const typename Op::T*)agg);
+        typename Op::T* agg = (typename Op::T*)scratch.p;
+        hipLaunchKernelGGL((k_scan_reduce<Op>), dim3((unsigned)nb), dim3(SCAN_T), 0, st, src, n, agg);
+        hipLaunchKernelGGL((k_scan_aggregates<Op>), dim3(1), dim3(1024), 0, st, agg, nb);
+        hipLaunchKernelGGL((k_scan_apply<Op, INCL>), dim3((unsigned)nb), dim3(SCAN_T), 0, st, src, dst, n, (const typename Op::T*)agg);
         HIPCHK(hipGetLastError());
         return BRC_OK;
     }
@@ -1254,6 +1268,20 @@ class HipBackend : public Backend {
             }
         } else if (c.per_lib && P > 0) HIPCHK(hipMemsetAsync(d_unavail.p, 0xff, (size_t)c.PS * 4, stream));
         HIPCHK(hipEventRecord(evt[T_SCAN_ENDS], stream));
+        // The indel side path (<1 % of the events: keyed count -> scan -> fill -> ordered reduce) depends on K1 only: it runs on
+        // a stream of its own under the pileup kernel instead of after it.
+        if (indels) {
+            HIPCHK(hipStreamWaitEvent(stream3, evt[T_SCAN_ENDS], 0));
+            HIPCHK(hipEventRecord(ev_indel[0], stream3));
+            if ((rc = scan_on<OpSumU32, false>((const uint32_t*)d_cnt.p, (uint32_t*)d_cursor.p, (int64_t)Lp * P, stream3, d_agg2))) return rc;
+            HIPCHK(hipEventRecord(ev_indel[1], stream3));
+            hipLaunchKernelGGL(k_indel_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream3, c, in, reads, (uint32_t*)d_cursor.p, (IndelEv*)d_ev.p);
+            HIPCHK(hipEventRecord(ev_indel[2], stream3));
+            hipLaunchKernelGGL(k_indel_reduce, dim3((unsigned)std::min<int64_t>(((int64_t)n_indel_cap + 255) / 256 + 1, 4096)), dim3(256), 0, stream3, c, in, reads,
+                               (const uint32_t*)d_cnt.p, (const uint32_t*)d_cursor.p, (IndelEv*)d_ev.p, (const uint32_t*)d_unavail.p,
+                               (IndelOut*)d_iout.p, ctr);
+            HIPCHK(hipEventRecord(ev_indel[3], stream3));
+        }
         // per library: running max of the piece reaches of its stream, then the piece range of every tile
         for (int l = 0; l < Lp; ++l) {
             const int64_t s0 = lib_base[(size_t)l], ns = lib_base[(size_t)l + 1] - s0;
@@ -1285,15 +1313,9 @@ class HipBackend : public Backend {
             hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(256), 0, stream, (const unsigned long long*)d_part.p, (int)nb, ctr);
         }
         HIPCHK(hipEventRecord(evt[T_INDEL_SCAN], stream));
-        if (indels && (rc = scan<OpSumU32, false>((const uint32_t*)d_cnt.p, (uint32_t*)d_cursor.p, (int64_t)Lp * P))) return rc;
-        HIPCHK(hipEventRecord(evt[T_INDEL_FILL], stream));
-        if (indels)
-            hipLaunchKernelGGL(k_indel_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, reads, (uint32_t*)d_cursor.p, (IndelEv*)d_ev.p);
-        HIPCHK(hipEventRecord(evt[T_INDEL_REDUCE], stream));
-        if (indels)
-            hipLaunchKernelGGL(k_indel_reduce, dim3((unsigned)std::min<int64_t>(((int64_t)n_indel_cap + 255) / 256 + 1, 4096)), dim3(256), 0, stream, c, in, reads,
-                               (const uint32_t*)d_cnt.p, (const uint32_t*)d_cursor.p, (IndelEv*)d_ev.p, (const uint32_t*)d_unavail.p,
-                               (IndelOut*)d_iout.p, ctr);
+        // (the indel side path ran meanwhile on its own stream, see above; the timing slots of its three stages are
+        // filled from that stream's events)
+        if (indels) HIPCHK(hipStreamWaitEvent(stream, ev_indel[3], 0));
         HIPCHK(hipEventRecord(evt[T_N], stream));
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(&h_ctr, ctr, sizeof(Counters), hipMemcpyDeviceToHost, stream));
@@ -1305,7 +1327,8 @@ class HipBackend : public Backend {
         }
         if (t) {
             memset(t, 0, sizeof *t);
-            for (int i = 0; i < T_N; ++i) HIPCHK(hipEventElapsedTime(&t->ms[i], evt[i], evt[i + 1]));
+            for (int i = 0; i < T_INDEL_SCAN; ++i) HIPCHK(hipEventElapsedTime(&t->ms[i], evt[i], evt[i + 1]));
+            if (indels) for (int i = 0; i < 3; ++i) HIPCHK(hipEventElapsedTime(&t->ms[T_INDEL_SCAN + i], ev_indel[i], ev_indel[i + 1]));
             HIPCHK(hipEventElapsedTime(&t->total_ms, evt[0], evt[T_N]));
         }
         computed = true;
