@@ -117,6 +117,17 @@ bool Bgzf::read(void* dst, size_t n) {
     return true;
 }
 
+size_t Bgzf::read_some(void* dst, size_t n) {
+    uint8_t* d = (uint8_t*)dst; size_t got = 0;
+    while (got < n) {
+        if (pos_ == len_) { bool ok = true; do { ok = load_block(next_coff_); } while (ok && len_ == 0); if (!ok) break; }
+        const size_t k = std::min(n - got, len_ - pos_);
+        memcpy(d + got, ubuf_.data() + pos_, k);
+        pos_ += k; got += k;
+    }
+    return got;
+}
+
 // ---------------------------------------------------------------- BAM records
 
 int32_t BamRecord::endpos() const {
@@ -270,7 +281,11 @@ bool BamIndex::load(const std::string& bam_path) {
     if (bam_path.size() > 4) cand.push_back(bam_path.substr(0, bam_path.size() - 4) + ".bai");
     FILE* f = nullptr;
     for (const std::string& c : cand) if ((f = fopen(c.c_str(), "rb"))) break;
-    if (!f) { err_ = "index not found"; return false; }
+    if (!f) {
+        for (const std::string& c : {bam_path + ".csi", bam_path.size() > 4 ? bam_path.substr(0, bam_path.size() - 4) + ".csi" : std::string()})
+            if (!c.empty()) { FILE* g = fopen(c.c_str(), "rb"); if (g) { fclose(g); return load_csi(c); } }
+        err_ = "index not found"; return false;
+    }
     std::vector<uint8_t> d;
     uint8_t buf[1 << 16]; size_t n;
     while ((n = fread(buf, 1, sizeof buf, f)) > 0) d.insert(d.end(), buf, buf + n);
@@ -297,23 +312,67 @@ bool BamIndex::load(const std::string& bam_path) {
     return true;
 }
 
+// CSI (coordinate-sorted index, CSIv1): BGZF-compressed; like BAI with a configurable finest bin width (2^min_shift) and
+// number of levels, a left offset per bin instead of the 16-kb linear index
+bool BamIndex::load_csi(const std::string& path) {
+    Bgzf z;
+    if (!z.open(path)) { err_ = z.error(); return false; }
+    std::vector<uint8_t> d; uint8_t buf[1 << 16]; size_t n;
+    while ((n = z.read_some(buf, sizeof buf)) > 0) d.insert(d.end(), buf, buf + n);
+    if (!z.error().empty() && !z.eof_clean()) { err_ = "cannot read the CSI index: " + z.error(); return false; }
+    if (d.size() < 16 || memcmp(d.data(), "CSI\1", 4) != 0) { err_ = "not a CSI file"; return false; }
+    size_t o = 4;
+    min_shift_ = (int)rd32(d.data() + o); depth_ = (int)rd32(d.data() + o + 4); const uint32_t l_aux = rd32(d.data() + o + 8); o += 12;
+    if (min_shift_ < 1 || min_shift_ > 30 || depth_ < 1 || depth_ > 9 || o + l_aux + 4 > d.size()) { err_ = "bad CSI header"; return false; }
+    o += l_aux;
+    const uint32_t n_ref = rd32(d.data() + o); o += 4;
+    refs_.assign(n_ref, Ref());
+    for (uint32_t i = 0; i < n_ref; ++i) {
+        if (o + 4 > d.size()) { err_ = "truncated CSI"; return false; }
+        const uint32_t n_bin = rd32(d.data() + o); o += 4;
+        for (uint32_t b = 0; b < n_bin; ++b) {
+            if (o + 16 > d.size()) { err_ = "truncated CSI"; return false; }
+            const uint32_t bin = rd32(d.data() + o); const uint64_t loff = rd64(d.data() + o + 4); const uint32_t n_chunk = rd32(d.data() + o + 12); o += 16;
+            if (o + 16ull * n_chunk > d.size()) { err_ = "truncated CSI"; return false; }
+            refs_[i].loffset[bin] = loff;
+            std::vector<Chunk>& v = refs_[i].bins[bin];
+            for (uint32_t c = 0; c < n_chunk; ++c) { Chunk ch; ch.beg = rd64(d.data() + o); ch.end = rd64(d.data() + o + 8); o += 16; v.push_back(ch); }
+        }
+    }
+    csi_ = true;
+    return true;
+}
+
 std::vector<Chunk> BamIndex::query(int tid, int64_t beg, int64_t end) const {
     std::vector<Chunk> out;
     if (tid < 0 || (size_t)tid >= refs_.size() || end <= beg) return out;
-    if (end > (1ll << 29)) end = 1ll << 29;
+    const int64_t maxpos = 1ll << (min_shift_ + 3 * depth_);
+    if (end > maxpos) end = maxpos;
+    if (beg >= end) return out;
     const Ref& r = refs_[(size_t)tid];
-    // reg2bins (SAMv1 5.3)
+    // reg2bins (SAMv1 5.3, generalised to min_shift / depth): level l starts at bin ((1 << 3l) - 1) / 7
     std::vector<uint32_t> bins;
     const int64_t e = end - 1;
-    bins.push_back(0);
-    for (int64_t k = 1 + (beg >> 26); k <= 1 + (e >> 26); ++k) bins.push_back((uint32_t)k);
-    for (int64_t k = 9 + (beg >> 23); k <= 9 + (e >> 23); ++k) bins.push_back((uint32_t)k);
-    for (int64_t k = 73 + (beg >> 20); k <= 73 + (e >> 20); ++k) bins.push_back((uint32_t)k);
-    for (int64_t k = 585 + (beg >> 17); k <= 585 + (e >> 17); ++k) bins.push_back((uint32_t)k);
-    for (int64_t k = 4681 + (beg >> 14); k <= 4681 + (e >> 14); ++k) bins.push_back((uint32_t)k);
+    {
+        int64_t t = 0; int s = min_shift_ + 3 * depth_;
+        for (int l = 0; l <= depth_; ++l) {
+            for (int64_t k = t + (beg >> s); k <= t + (e >> s); ++k) bins.push_back((uint32_t)k);
+            t += 1ll << (3 * l); s -= 3;
+        }
+    }
     uint64_t min_off = 0;
-    const size_t li = (size_t)(beg >> 14);
-    if (!r.linear.empty()) min_off = li < r.linear.size() ? r.linear[li] : r.linear.back();
+    if (!csi_) {
+        const size_t li = (size_t)(beg >> 14);
+        if (!r.linear.empty()) min_off = li < r.linear.size() ? r.linear[li] : r.linear.back();
+    } else {
+        // the left offset of the finest existing bin that contains beg (walk up from the last level)
+        int64_t bin = ((1ll << (3 * depth_)) - 1) / 7 + (beg >> min_shift_);
+        for (int l = depth_; l >= 0; --l) {
+            auto it = r.loffset.find((uint32_t)bin);
+            if (it != r.loffset.end()) { min_off = it->second; break; }
+            bin = (bin - 1) >> 3;                                    // parent
+        }
+    }
     for (uint32_t b : bins) {
         auto it = r.bins.find(b);
         if (it == r.bins.end()) continue;

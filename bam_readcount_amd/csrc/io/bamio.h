@@ -28,6 +28,7 @@ class Bgzf {
     uint64_t tell() const { return (block_coff_ << 16) | (uint64_t)pos_; }
     // read exactly n bytes (crossing blocks); returns false at EOF / error
     bool read(void* dst, size_t n);
+    size_t read_some(void* dst, size_t n);         // up to n bytes; fewer only at EOF / error
     bool eof_clean() const { return eof_; }
     const std::string& error() const { return err_; }
 
@@ -76,14 +77,17 @@ struct Chunk { uint64_t beg, end; };
 
 class BamIndex {
   public:
-    bool load(const std::string& bam_path);        // <bam>.bai, then <bam minus .bam>.bai
+    bool load(const std::string& bam_path);        // <bam>.bai, <bam minus .bam>.bai, then <bam>.csi (SAMv1 5.2 / CSIv1)
     // chunks (virtual offset ranges) that may hold records overlapping [beg,end) on tid, merged and sorted
     std::vector<Chunk> query(int tid, int64_t beg, int64_t end) const;
     const std::string& error() const { return err_; }
 
   private:
-    struct Ref { std::map<uint32_t, std::vector<Chunk> > bins; std::vector<uint64_t> linear; };
+    struct Ref { std::map<uint32_t, std::vector<Chunk> > bins; std::vector<uint64_t> linear; std::map<uint32_t, uint64_t> loffset; };
+    bool load_csi(const std::string& path);
     std::vector<Ref> refs_;
+    int min_shift_ = 14, depth_ = 5;               // BAI's fixed binning; a CSI file carries its own
+    bool csi_ = false;
     std::string err_;
 };
 

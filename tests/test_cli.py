@@ -371,6 +371,42 @@ def test_cli_long_cigar_in_cg_tag_and_truncated_bam_cpu(tmp_path):
     assert c.returncode == 1 and b"read error" in c.stderr, (c.returncode, c.stderr[-200:])
 
 
+def test_cli_csi_index_equals_bai_cpu(tmp_path):
+    """The same BAM with a .bai and — in another directory, so that only one index can be found — with .csi indexes of two
+    geometries (the default 14 / 5 and a finer, deeper one): identical output for whole contigs, narrow regions and a site list."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bamio
+    import synth
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    rng = np.random.default_rng(5)
+    refs = [synth.make_ref(rng, 40000), synth.make_ref(rng, 9000)]
+    parts = [synth.make_batch(71, refs[0], 2500, style="indel"), synth.make_batch(72, refs[1], 700, style="mixed")]
+    arrs = {}
+    for k in ("pos", "flag", "mapq", "lib", "l_qseq", "n_cigar", "nm", "sm", "tags"):
+        arrs[k] = np.concatenate([p[k] for p in parts])
+    for arena, off in (("cigar", "cigar_off"), ("seq4", "seq_off"), ("qual", "qual_off")):
+        arrs[arena] = np.concatenate([p[arena] for p in parts])
+        arrs[off] = np.concatenate([parts[0][off], parts[1][off] + np.uint64(parts[0][arena].size)])
+    tids = np.concatenate([np.zeros(len(parts[0]["pos"]), int), np.ones(len(parts[1]["pos"]), int)])
+    outs = []
+    site_lines = [("chrA", int(p), int(p) + 3) for p in rng.integers(1, 39000, 60)] + [("chrB", 17, 17), ("chrB", 8000, 9000)]
+    for name, csi in (("bai", None), ("csi145", (14, 5)), ("csi106", (10, 6))):
+        d = tmp_path / name; d.mkdir()
+        bamio.write_bam(str(d / "x.bam"), [("chrA", 40000), ("chrB", 9000)], arrs, tids, block_bytes=4000, csi=csi)
+        assert os.path.exists(d / ("x.bam.csi" if csi else "x.bam.bai")) and not os.path.exists(d / ("x.bam.bai" if csi else "x.bam.csi"))
+        _write_fasta(d / "r.fa", [("chrA", refs[0]), ("chrB", refs[1])])
+        sl = _sites_file(d, "s.txt", site_lines)
+        got = []
+        for args in (["x.bam", "chrA", "chrB"], ["x.bam", "chrA:16380-16390", "chrA:1024-1024", "chrB:8999-9000"], ["-l", sl, "x.bam"], ["-l", sl, "--brc-plan", "0", "x.bam"]):
+            p = subprocess.run([SIM_CLI, "-w", "0", "-f", "r.fa"] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert p.returncode == 0, (name, args, p.stderr[-300:])
+            got.append(p.stdout)
+        outs.append(got)
+    assert outs[0][0].count(b"\n") > 40000
+    assert outs[1] == outs[0] and outs[2] == outs[0]
+
+
 def test_rans_encoder_round_trip_sizes():
     """tools/cramio.py's rANS encoder against an independent pure-Python decoder written from the same format description
     (sizes 0..9 and larger, skewed and flat distributions, both orders) — guards the test-side writer itself."""

@@ -121,9 +121,11 @@ def _bgzf_block(payload):
     return hdr + c + struct.pack("<II", zlib.crc32(payload) & 0xffffffff, len(payload))
 
 
-def write_bam(path, contigs, arrs, tids, rg_of_read=None, rg_lines=(), qnames=None, block_bytes=20000, long_cigar=()):
+def write_bam(path, contigs, arrs, tids, rg_of_read=None, rg_lines=(), qnames=None, block_bytes=20000, long_cigar=(), csi=None):
     """contigs: [(name, length)]; arrs: brc_read_batch arrays (coordinate-sorted per contig); tids: contig index per
-    read (non-decreasing).  Writes path and path + '.bai'.  Aux: NM:i / SM:i when the tags bits say so, RG:Z."""
+    read (non-decreasing).  Writes path and path + '.bai' — or, with csi=(min_shift, depth), path + '.csi' (CSIv1: BGZF-
+    compressed, bins of that geometry with a left offset each, no linear index).  Aux: NM:i / SM:i when the tags bits say so, RG:Z."""
+    csi_bins = [dict() for _ in contigs]; csi_loff = [dict() for _ in contigs]
     text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % c for c in contigs) + "".join(l + "\n" for l in rg_lines)
     head = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(contigs))
     for name, ln in contigs:
@@ -168,9 +170,36 @@ def write_bam(path, contigs, arrs, tids, rg_of_read=None, rg_lines=(), qnames=No
         else: ch.append([v0, v1])
         for w in range(pos >> 14, ((end - 1) >> 14) + 1):
             linear[tid].setdefault(w, v0)
+        if csi:
+            ms, dp = csi
+            # the record's bin: the finest level at which it fits one bin
+            l, sh, t = dp, ms, ((1 << (3 * dp)) - 1) // 7
+            while l > 0 and (pos >> sh) != ((end - 1) >> sh):
+                l -= 1; sh += 3; t -= 1 << (3 * l)
+            cb = t + (pos >> sh)
+            chc = csi_bins[tid].setdefault(cb, [])
+            if chc and chc[-1][1] == v0: chc[-1][1] = v1
+            else: chc.append([v0, v1])
+            # left offsets: every bin (at every level) the record overlaps
+            t2, sh2 = 0, ms + 3 * dp
+            for l2 in range(dp + 1):
+                for bb in range(t2 + (pos >> sh2), t2 + ((end - 1) >> sh2) + 1):
+                    if bb not in csi_loff[tid] or v0 < csi_loff[tid][bb]: csi_loff[tid][bb] = v0
+                t2 += 1 << (3 * l2); sh2 -= 3
     flush()
     out.extend(_bgzf_block(b""))
     open(path, "wb").write(bytes(out))
+    if csi:
+        ms, dp = csi
+        raw = bytearray(b"CSI\1" + struct.pack("<iii", ms, dp, 0) + struct.pack("<i", len(contigs)))
+        for t in range(len(contigs)):
+            raw += struct.pack("<i", len(csi_bins[t]))
+            for b, chunks in sorted(csi_bins[t].items()):
+                raw += struct.pack("<IQi", b, csi_loff[t].get(b, chunks[0][0]), len(chunks))
+                for a, e in chunks: raw += struct.pack("<QQ", a, e)
+        comp = b"".join(_bgzf_block(bytes(raw[o:o + 60000])) for o in range(0, len(raw), 60000)) + _bgzf_block(b"")
+        open(path + ".csi", "wb").write(comp)
+        return
     bai = bytearray(b"BAI\1" + struct.pack("<i", len(contigs)))
     for t in range(len(contigs)):
         bai += struct.pack("<i", len(bins[t]))
