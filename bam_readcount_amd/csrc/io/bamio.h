@@ -2,7 +2,7 @@
 //
 // The reference delegates all of this to samtools-1.10/htslib-1.10 (bamreadcount.cpp:16-19: samopen, samfetch,
 // sam_index_load3, fai_load/fai_fetch, bam_get_library).  htslib is not available in this environment, so this is a
-// from-scratch reader of the public wire formats (SAMv1 spec sections 4.1 BGZF, 4.2 BAM, 5.2 BAI; faidx format).  It
+// from-scratch reader of the public wire formats (SAMv1 spec sections 4.1 BGZF, 4.2 BAM, 5.2 BAI, CSIv1; faidx format).  It
 // only implements what the readcount path needs: sequential inflate of BGZF blocks, seeking by virtual offset, the
 // overlap query of an indexed region, whole-contig FASTA fetch, and the @SQ/@RG header fields.
 #ifndef BRC_BAMIO_H
@@ -143,7 +143,7 @@ class Fasta {
 
 // ---------------------------------------------------------------- CRAM 3.0 (minimal, cram.cpp)
 // The reference reads CRAM through htslib's samopen (bamreadcount.cpp:411, test-data/twolib.sorted.cram); this reader
-// covers reference-based CRAM 3.x with raw/gzip blocks.  Records come out in BAM layout.
+// covers reference-based CRAM 3.0 (raw / gzip / rANS 4x8 / bzip2 / lzma blocks).  Records come out in BAM layout.
 class CramReader {
   public:
     CramReader();
