@@ -99,7 +99,12 @@ struct AnnPar { uint4 a, b, c; };    // a = {L, qrel, srel, brow.lo}  b = {S, m1
 
 __device__ __forceinline__ uint32_t nzb7(uint32_t x) { return x + 0x7f7f7f7fu; }   // bytes <= 0x7f: bit 7 of a byte <=> byte != 0
 
-__global__ __launch_bounds__(256) void k_annotate_groups(DevCfg c, DevIn in, DRead* __restrict__ reads, const uint32_t* __restrict__ piece_off,
+#ifdef BRC_ANN_WAVES_PER_EU
+#define BRC_ANN_OCC __attribute__((amdgpu_waves_per_eu(BRC_ANN_WAVES_PER_EU, BRC_ANN_WAVES_PER_EU)))
+#else
+#define BRC_ANN_OCC
+#endif
+__global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, DevIn in, DRead* __restrict__ reads, const uint32_t* __restrict__ piece_off,
                                                          PieceHot* __restrict__ hot, PieceCold* __restrict__ cold, int32_t* __restrict__ key, int32_t* __restrict__ reach,
                                                          uint16_t* __restrict__ bq, uint32_t* __restrict__ indel_cnt,
                                                          const uint32_t* __restrict__ cigar_ro, const uint8_t* __restrict__ qual_ro,

@@ -167,3 +167,15 @@ def pile_indels(arrs, x, seed=0, frac=0.9):
     out = dict(arrs)
     out["cigar"] = np.array(cig, np.uint32); out["n_cigar"] = np.array(ncs, np.uint32); out["cigar_off"] = np.array(off, np.uint64)
     return out
+
+
+def add_sequenceless_secondary(arrs, pos, span=50):
+    """Insert a SECONDARY read with SEQ '*' (l_qseq 0) and CIGAR <span>M at `pos`: it sits in the pileup columns (it makes its
+    library and positions print) but is never counted (bamreadcount.cpp:295-310)."""
+    a = dict(arrs)
+    i = int(np.searchsorted(a["pos"], pos))
+    for k, v in (("pos", pos), ("flag", 256 | 16), ("mapq", 60), ("lib", 0), ("l_qseq", 0), ("n_cigar", 1), ("nm", 0), ("sm", 0), ("tags", 0),
+                 ("cigar_off", len(a["cigar"])), ("seq_off", 0), ("qual_off", 0)):
+        a[k] = np.insert(a[k], i, v).astype(a[k].dtype)
+    a["cigar"] = np.append(a["cigar"], np.uint32((span << 4) | 0)).astype(np.uint32)
+    return a

@@ -194,3 +194,16 @@ def test_hip_deep_indel_key_equals_oracle(hip_lib, oracle_lib):
         for kw in (dict(), dict(per_lib=True, insertion_centric=True, lib_names=["libA", "libB"])):
             text, res = parity.compare_libs(hip_lib, oracle_lib, arrs, [(0, 600)], ref=ref, **kw)
             assert max(int(d["i"][0]) for d in res[0].indels) > n // 8
+
+
+@pytest.mark.gpu
+def test_hip_sequenceless_secondary_read(hip_lib, oracle_lib):
+    """A secondary alignment stored without its sequence (SEQ '*', l_qseq 0) but with a CIGAR: in the columns, never counted."""
+    rng = np.random.default_rng(1)
+    ref = synth.make_ref(rng, 600)
+    arrs = synth.add_sequenceless_secondary(synth.make_batch(5, ref, 60, style="simple", region=(100, 300)), 200)
+    arrs = synth.add_sequenceless_secondary(arrs, 420, span=30)            # beyond every other read: positions that print only because of it
+    for kw in (dict(), dict(min_mapq=10, min_bq=5), dict(per_lib=True, lib_names=["libA"])):
+        text, _ = parity.compare_libs(hip_lib, oracle_lib, arrs, [(0, 600)], ref=ref, **kw)
+        got, _ = parity.run_engine(hip_lib, arrs, [(0, 600)], ref=ref, device_text="chrS", **kw)
+        assert got == text and b"\t421\t" in text
