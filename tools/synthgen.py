@@ -19,18 +19,23 @@ def build():
     src = os.path.join(HERE, "synth_gen.c")
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
         subprocess.check_call(["gcc", "-O2", "-std=c99", "-fopenmp", "-fPIC", "-shared", src, "-o", LIB, "-lm"])
+    build_bamwrite()
     return LIB
 
 
 BAMLIB = os.path.join(HERE, "libbamwrite.so")
 
 
-def write_bam(path, contig, contig_len, arrs, n_libs=1, block_bytes=60000, level=1):
-    """Fast single-contig BAM + BAI of a brc_read_batch (tools/bam_write.c); libraries become @RG rg<k> with LB lib<k>."""
+def build_bamwrite():
     src = os.path.join(HERE, "bam_write.c")
     if not os.path.exists(BAMLIB) or os.path.getmtime(BAMLIB) < os.path.getmtime(src):
         subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-fopenmp", "-fPIC", "-shared", src, "-o", BAMLIB, "-lz"])
-    L = C.CDLL(BAMLIB)
+    return BAMLIB
+
+
+def write_bam(path, contig, contig_len, arrs, n_libs=1, block_bytes=60000, level=1):
+    """Fast single-contig BAM + BAI of a brc_read_batch (tools/bam_write.c); libraries become @RG rg<k> with LB lib<k>."""
+    L = C.CDLL(build_bamwrite())
     text = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:%s\tLN:%d\n" % (contig, contig_len)
     if n_libs > 1:
         text += "".join("@RG\tID:rg%d\tLB:lib%d\tSM:s\n" % (k, k) for k in range(n_libs))
