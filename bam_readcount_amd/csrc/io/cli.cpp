@@ -187,6 +187,7 @@ static double now_s() { return std::chrono::duration<double>(std::chrono::steady
 
 // CPUs this process may really use at once: hardware threads capped by a cgroup CPU quota (a container with 16 CPUs of
 // quota on a 256-thread host is throttled for most of every period if its pools are sized by the hardware)
+static unsigned g_engines = 1;            // engines of this process (they share the CPUs)
 static unsigned effective_cpus() {
     static unsigned cached = 0;
     if (cached) return cached;
@@ -310,7 +311,7 @@ static void fetch_chunk(Ctx& c, int tid, int64_t a, int64_t b, Fetched& out) {
     unsigned K = 1;
     static const long long stripe_min = getenv("BRC_FETCH_STRIPE_MIN") ? atoll(getenv("BRC_FETCH_STRIPE_MIN")) : 65536;   // (tests force small chunks into stripes)
     if (!c.is_cram && b - q0 >= stripe_min) {
-        K = effective_cpus() * 3 / 4; if (K == 0) K = 1; if (K > 32) K = 32;
+        K = effective_cpus() * 3 / 4 / g_engines; if (K < 2) K = 2; if (K > 32) K = 32;
         if (const char* t = getenv("BRC_FETCH_THREADS")) { const int v = atoi(t); if (v > 0) K = (unsigned)v; }
         if ((int64_t)K > b - q0) K = (unsigned)(b - q0);          // every stripe at least one position wide (stripe 0 must contain q0)
     }
@@ -716,6 +717,10 @@ int main(int argc, char** argv) {
     }
 
     if (items.size() < N) N = std::max<size_t>(items.size(), 1);      // engines without work are never created
+    if (N > 1) {    // the engines share this process's CPUs: each gets its part of the decode and formatter pools
+        g_engines = (unsigned)N;
+        if (!getenv("BRC_FORMAT_THREADS")) { const unsigned ft = std::max(2u, effective_cpus() / (unsigned)N); setenv("BRC_FORMAT_THREADS", std::to_string(ft).c_str(), 1); }
+    }
     // pin the text buffers of a long region's pieces while the first reads are being decoded
     std::thread pin_ahead;
     {
