@@ -1,6 +1,7 @@
 // brc_engine.hip — the HIP/CDNA4 (gfx950) device pipeline behind the C-ABI of include/brc.h.
 //
-// Kernels (per region, all on one engine-owned stream; see DESIGN.md for layouts and rooflines):
+// Kernels (per region; the main pipeline on one engine-owned stream, the indel side path on a second one, the download of
+// device-written text on a third; see DESIGN.md for layouts and rooflines):
 //   k_refcode       reference characters -> 4-bit codes
 //   k_annotate_groups  K1: fetch_func's Zm integers per read (8 bases per lane, byte-parallel), the event-word stream
 //                   (quality << 8 | bucket per base) and the read's PIECES (walk_pieces): 64-B hot + 32-B cold records in
@@ -13,8 +14,11 @@
 //                   tile's pieces in column order: piece records by scalar loads, event-word windows staged into LDS by
 //                   direct-to-LDS loads, three packed integer accumulators + 4 order-preserving fp32 sums per bucket,
 //                   coalesced 256-B plane stores.  Integer/byte work, HBM-bound: no MFMA by design.
+//   k_xev_compact   the 1024 third-allele sub-lists (one atomic cursor each) -> one list
 //   k_finalize      emitted-position count + per-tile partial counters
 //   k_indel_fill / k_indel_reduce   indel side path (<1 % of events): keyed fill, ordered per-key reduction
+//   k_text_len / k_text_write   BRC_OPT_DEVICE_TEXT: the lines pileup_func prints, written from the compact result
+//                   (brc_core.h: text_line): byte lengths -> exclusive scan -> bytes
 //
 // There is no CPU fallback here: without a HIP device make_backend() fails with BRC_E_NODEVICE.
 #include <hip/hip_runtime.h>

@@ -2,7 +2,10 @@
 //   * brc_push_reads : staging with rebased offsets, bam_plp_push's max-count drop rule, region extent
 //   * brc_fetch_result : allele text + std::map ordering of indel buckets
 //   * brc_format_region : pileup_func's record assembly (bamreadcount.cpp:351-416), IndelQueue::process
-//                         (IndelQueue.cpp:3-15) and operator<<(BasicStat) (BasicStat.cpp:110-159)
+//                         (IndelQueue.cpp:3-15) and operator<<(BasicStat) (BasicStat.cpp:110-159) — from dense planes, from
+//                         the compact result (BRC_OPT_TEXT_ONLY), or as the finishing pass over device-written text
+//                         (BRC_OPT_DEVICE_TEXT: format_device_text)
+//   * brc_region_warnings : the stderr side (ReadWarnings)
 // No accumulation happens here: every number printed comes out of the device planes.
 #include "brc_host.h"
 
