@@ -93,7 +93,9 @@ def site_batch(np, capi, arrs, ref, sites, window=384, lead=170):
     vref = np.full(len(sites) * window, ord("N"), np.uint8)
     src = (sites[:, None] - lead + np.arange(window)[None, :]).clip(0, len(ref) - 1)
     vref[:] = ref[src].reshape(-1)
-    events = int(np.bincount(sidx, minlength=len(sites)).sum())
+    # unit of work: reads covering the reported position s - 1 itself (the fetch also returns reads that only
+    # cover the lead position s - 2)
+    events = int(((pos[ridx] <= sites[sidx] - 1) & (ends[ridx] > sites[sidx] - 1)).sum())
     return sub, vref, events
 
 
@@ -154,7 +156,8 @@ def main():
     t0 = time.time()
     ref, arrs = synthgen.generate(contig_len, config, seed=1 + 1000 * rank)
     t_gen = time.time() - t0
-    eng = capi.Engine(hip, lib_names=names, device=local_rank, **opts)
+    # (sites mode: the result is only ever cut into lines — no dense planes on the host)
+    eng = capi.Engine(hip, lib_names=names, device=local_rank, text_only=(args.mode == "sites"), **opts)
     site_events = 0
     if args.mode == "sites":
         n_mine = args.sites // world + (1 if rank < args.sites % world else 0)
@@ -234,7 +237,26 @@ def main():
             span = int((np.minimum(ends, contig_len) - np.maximum(arrs["pos"].astype(np.int64), 0)).clip(min=0).sum())
             dropped = (arrs["flag"] & 4) != 0
             validated = {"events_equal_sum_of_spans": bool(eng_events == span and not dropped.any())}
-        if args.cpu_sample_mbp > 0:
+        if args.mode == "sites" and args.cpu_sample_mbp > 0:
+            # a sample of the site list against the oracle, site by site: the reference's own -l loop (one fetch + pileup per line,
+            # bamreadcount.cpp:574-607) vs the line cut out of the shared virtual axis
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+            oracle = capi.Library(os.path.join(ROOT, "oracle", "libbrc_oracle.so"))
+            eng.fetch_result()
+            oe = capi.Engine(oracle, lib_names=names, **opts)
+            pick = np.unique(np.linspace(0, len(sites) - 1, 400).astype(np.int64)); t0c = time.perf_counter(); oev = 0
+            for i in pick:
+                sp = int(sites[i])
+                oe.begin_region(0, sp - 1, sp, ref); oe.push_reads(capi.select_reads(arrs, capi.fetch_overlapping(arrs, ends, sp - 2, sp)))
+                oe.end_region(); want = oe.format_region("chrS"); oe.clear_indel_queue(); oev += oe.counts()[0]
+                d = int(i) * 384 + 170 - sp
+                got = eng.format_window("chrS", sp - 1 + d, sp + d, d)
+                assert got == want, "site %d (position %d): the planner's line differs from the oracle's" % (i, sp)
+            oe.close()
+            validated = {"sites_checked": int(len(pick)), "site_lines_byte_exact": True}
+            cpu = {"value": round(oev / (time.perf_counter() - t0c), 1), "unit": "pileup base-events/s", "cores": 1, "kind": "port",
+                   "sample": "%d of the %d sites, one oracle region per site (fetch of the overlapping reads included)" % (len(pick), len(sites))}
+        elif args.cpu_sample_mbp > 0:
             import parity
             subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
             oracle = capi.Library(os.path.join(ROOT, "oracle", "libbrc_oracle.so"))
