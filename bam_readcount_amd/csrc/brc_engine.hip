@@ -1277,19 +1277,27 @@ class HipBackend : public Backend {
             }
         } else if (c.per_lib && P > 0) HIPCHK(hipMemsetAsync(d_unavail.p, 0xff, (size_t)c.PS * 4, stream));
         HIPCHK(hipEventRecord(evt[T_SCAN_ENDS], stream));
-        // The indel side path (<1 % of the events: keyed count -> scan -> fill -> ordered reduce) depends on K1 only: it runs on
-        // a stream of its own under the pileup kernel instead of after it.
-        if (indels) {
-            HIPCHK(hipStreamWaitEvent(stream3, evt[T_SCAN_ENDS], 0));
-            HIPCHK(hipEventRecord(ev_indel[0], stream3));
-            if ((rc = scan_on<OpSumU32, false>((const uint32_t*)d_cnt.p, (uint32_t*)d_cursor.p, (int64_t)Lp * P, stream3, d_agg2))) return rc;
-            HIPCHK(hipEventRecord(ev_indel[1], stream3));
-            hipLaunchKernelGGL(k_indel_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream3, c, in, reads, (uint32_t*)d_cursor.p, (IndelEv*)d_ev.p);
-            HIPCHK(hipEventRecord(ev_indel[2], stream3));
-            hipLaunchKernelGGL(k_indel_reduce, dim3((unsigned)std::min<int64_t>(((int64_t)n_indel_cap + 255) / 256 + 1, 4096)), dim3(256), 0, stream3, c, in, reads,
+        // The indel side path (<1 % of the events: keyed count -> scan -> fill -> ordered reduce) depends on K1 only.  It can run
+        // on a stream of its own under the pileup kernel (BRC_INDEL_OVERLAP=1) — measured: the step does not get shorter, the
+        // two only share the machine (k_pileup2 3.75 -> 3.95 ms, step 6.2 ms either way) — so by default it follows the
+        // pileup on the main stream.
+        static const bool indel_overlap = getenv("BRC_INDEL_OVERLAP") && atoi(getenv("BRC_INDEL_OVERLAP")) != 0;
+        auto launch_indel = [&](hipStream_t si, DBuf& scratch) -> int {
+            HIPCHK(hipEventRecord(ev_indel[0], si));
+            int r2;
+            if ((r2 = scan_on<OpSumU32, false>((const uint32_t*)d_cnt.p, (uint32_t*)d_cursor.p, (int64_t)Lp * P, si, scratch))) return r2;
+            HIPCHK(hipEventRecord(ev_indel[1], si));
+            hipLaunchKernelGGL(k_indel_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, si, c, in, reads, (uint32_t*)d_cursor.p, (IndelEv*)d_ev.p);
+            HIPCHK(hipEventRecord(ev_indel[2], si));
+            hipLaunchKernelGGL(k_indel_reduce, dim3((unsigned)std::min<int64_t>(((int64_t)n_indel_cap + 255) / 256 + 1, 4096)), dim3(256), 0, si, c, in, reads,
                                (const uint32_t*)d_cnt.p, (const uint32_t*)d_cursor.p, (IndelEv*)d_ev.p, (const uint32_t*)d_unavail.p,
                                (IndelOut*)d_iout.p, ctr);
-            HIPCHK(hipEventRecord(ev_indel[3], stream3));
+            HIPCHK(hipEventRecord(ev_indel[3], si));
+            return BRC_OK;
+        };
+        if (indels && indel_overlap) {
+            HIPCHK(hipStreamWaitEvent(stream3, evt[T_SCAN_ENDS], 0));
+            if ((rc = launch_indel(stream3, d_agg2))) return rc;
         }
         // per library: running max of the piece reaches of its stream, then the piece range of every tile
         for (int l = 0; l < Lp; ++l) {
@@ -1322,9 +1330,9 @@ class HipBackend : public Backend {
             hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(256), 0, stream, (const unsigned long long*)d_part.p, (int)nb, ctr);
         }
         HIPCHK(hipEventRecord(evt[T_INDEL_SCAN], stream));
-        // (the indel side path ran meanwhile on its own stream, see above; the timing slots of its three stages are
-        // filled from that stream's events)
-        if (indels) HIPCHK(hipStreamWaitEvent(stream, ev_indel[3], 0));
+        // (the timing slots of the indel path's three stages are filled from its own events)
+        if (indels && !indel_overlap) { if ((rc = launch_indel(stream, d_agg))) return rc; }
+        if (indels && indel_overlap) HIPCHK(hipStreamWaitEvent(stream, ev_indel[3], 0));
         HIPCHK(hipEventRecord(evt[T_N], stream));
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(&h_ctr, ctr, sizeof(Counters), hipMemcpyDeviceToHost, stream));
