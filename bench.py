@@ -244,18 +244,23 @@ def main():
             oracle = capi.Library(os.path.join(ROOT, "oracle", "libbrc_oracle.so"))
             eng.fetch_result()
             oe = capi.Engine(oracle, lib_names=names, **opts)
-            pick = np.unique(np.linspace(0, len(sites) - 1, 400).astype(np.int64)); t0c = time.perf_counter(); oev = 0
+            pick = np.unique(np.linspace(0, len(sites) - 1, 400).astype(np.int64)); tcpu = 0.0; oev = 0
+            pos64 = arrs["pos"].astype(np.int64)
             for i in pick:
                 sp = int(sites[i])
-                oe.begin_region(0, sp - 1, sp, ref); oe.push_reads(capi.select_reads(arrs, capi.fetch_overlapping(arrs, ends, sp - 2, sp)))
-                oe.end_region(); want = oe.format_region("chrS"); oe.clear_indel_queue(); oev += oe.counts()[0]
+                lo_i = int(np.searchsorted(pos64, sp - 2 - 1000, side="left")); hi_i = int(np.searchsorted(pos64, sp, side="left"))     # (reads are at most 1 kb long here)
+                idx = lo_i + np.nonzero(ends[lo_i:hi_i] > max(sp - 2, 0))[0]
+                sel = capi.select_reads(arrs, idx)
+                t0c = time.perf_counter()                                     # the oracle's own work: staging, pileup, text (not the numpy selection)
+                oe.begin_region(0, sp - 1, sp, ref); oe.push_reads(sel)
+                oe.end_region(); want = oe.format_region("chrS"); oe.clear_indel_queue(); tcpu += time.perf_counter() - t0c; oev += oe.counts()[0]
                 d = int(i) * 384 + 170 - sp
                 got = eng.format_window("chrS", sp - 1 + d, sp + d, d)
                 assert got == want, "site %d (position %d): the planner's line differs from the oracle's" % (i, sp)
             oe.close()
             validated = {"sites_checked": int(len(pick)), "site_lines_byte_exact": True}
-            cpu = {"value": round(oev / (time.perf_counter() - t0c), 1), "unit": "pileup base-events/s", "cores": 1, "kind": "port",
-                   "sample": "%d of the %d sites, one oracle region per site (fetch of the overlapping reads included)" % (len(pick), len(sites))}
+            cpu = {"value": round(oev / max(tcpu, 1e-9), 1), "unit": "pileup base-events/s", "cores": 1, "kind": "port", "sites_per_s": round(len(pick) / max(tcpu, 1e-9), 1),
+                   "sample": "%d of the %d sites, one oracle region per site (staging, pileup and text; the reads handed over already decoded)" % (len(pick), len(sites))}
         elif args.cpu_sample_mbp > 0:
             import parity
             subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
