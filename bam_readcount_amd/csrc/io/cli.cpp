@@ -726,7 +726,9 @@ int main(int argc, char** argv) {
     {
         int64_t widest = 0; for (const Work& w : items) if (w.kind == 0) widest = std::max<int64_t>(widest, std::min<int64_t>(w.end - w.beg0, (int64_t)c.opt.chunk_bp));
         const bool dev_text = !(getenv("BRC_DEVICE_TEXT") && atoi(getenv("BRC_DEVICE_TEXT")) == 0);
-        if (dev_text && widest >= 100000) {
+        // (not with -p: several libraries mean deep data, which the engine routes to the host formatter as a rule — gigabytes
+        // pinned for nothing would only compete with the staging allocations of the first piece)
+        if (dev_text && widest >= 100000 && !o.per_lib && !(getenv("BRC_PIN_AHEAD") && atoi(getenv("BRC_PIN_AHEAD")) == 0)) {
             const int64_t bytes = widest * (int64_t)(o.per_lib ? std::max<size_t>(c.libs.size(), 1) : 1) * 400;
             pin_ahead = std::thread([&c, eng_ready, bytes]() { if (eng_ready.get() == 0) brc_set_option(c.eng, BRC_OPT_EXPECT_TEXT, bytes); });
         }
