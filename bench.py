@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--contig-mbp", type=float, default=50.0, help="weak/sites: contig per GPU; strong: the whole contig")
     ap.add_argument("--sites", type=int, default=100000, help="--mode sites: lines of the site list (all ranks together)")
     ap.add_argument("--cpu-sample-mbp", type=float, default=8.0, help="prefix timed with the 1-thread CPU oracle and used for validation (0 = skip)")
+    ap.add_argument("--cpu-ref-mbp", type=float, default=0.5, help="prefix timed with the reference-compiled library oracle/_ref (0 = skip)")
     ap.add_argument("--cpu-all-cores", type=int, default=-1, help="oracle processes of the all-cores baseline (-1: min(usable CPUs, 64); 0 = skip)")
     ap.add_argument("--e2e-mbp", type=float, default=30.0, help="contig of the end-to-end command-line run (0 = skip)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r02_traffic.json"))
@@ -296,6 +297,25 @@ def main():
             cpu = {"value": round(oev / tc, 1), "unit": "pileup base-events/s", "cores": 1, "kind": "port",
                    "sample": "first %.2f Mbp of the same contig (%d events, %.1f s), C oracle incl. its text formatting, 1 thread of %d host cores"
                              % (send / 1e6, oev, tc, ncpu)}
+            # the reference's OWN code (fetch_func / pileup_func / BasicStat / IndelQueue compiled unmodified over the htslib shim,
+            # oracle/_ref — prebuilt, it travels with the snapshot) on a smaller prefix: std::map + stringstream per position and a
+            # text-encoded tag parsed per event make it several times slower than the C restatement
+            ref_so = os.path.join(ROOT, "oracle", "_ref", "libbamrc_ref.so")
+            if os.path.exists(ref_so) and args.cpu_ref_mbp > 0:
+                rsend = int(min(args.cpu_ref_mbp * 1e6 * (0.15 if per_lib else 1.0), send))
+                rsub = capi.select_reads(arrs, capi.fetch_overlapping(arrs, ends, -1, rsend))
+                o2 = capi.Engine(oracle, lib_names=names, **opts)
+                o2.begin_region(0, 0, rsend, ref); o2.push_reads(rsub); o2.end_region(); want_t = o2.format_region_np("chrS").copy(); rev, _ = o2.counts(); o2.close()      # (a view of the engine's buffer: copy before closing)
+                rl = capi.Library(ref_so)
+                re_ = capi.Engine(rl, lib_names=names, **opts)
+                re_.begin_region(0, 0, rsend, ref); re_.push_reads(rsub)
+                t0 = time.perf_counter(); re_.upload(); re_.compute(); tr = time.perf_counter() - t0
+                re_.fetch_result(); got_t = re_.format_region_np("chrS")
+                assert len(got_t) == len(want_t) and np.array_equal(got_t, want_t), "the reference-compiled library and the oracle print different text"
+                re_.close()
+                cpu["reference_compiled"] = {"value": round(rev / tr, 1), "unit": "pileup base-events/s", "cores": 1, "kind": "reference",
+                                             "sample": "first %.2f Mbp of the same contig (%d events, %.1f s): bam-readcount's own fetch_func / pileup_func / BasicStat / IndelQueue sources "
+                                                       "compiled unmodified over the samtools/htslib shim of oracle/ref_shim, text identical to the oracle's" % (rsend / 1e6, rev, tr)}
             if nworkers:
                 # all cores: one oracle process per core, each on its own contig of the same data model; started only now —
                 # nothing else of this benchmark runs while they do
