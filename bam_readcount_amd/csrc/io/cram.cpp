@@ -211,6 +211,18 @@ struct CramReader::Impl {
     bool rn_preserved = true, ap_delta = true; uint8_t sm[5] = {0, 0, 0, 0, 0};
     std::vector<std::vector<int32_t> > td;      // tag dictionary: per line the tag keys (tag0<<16|tag1<<8|type)
 
+    // containers of the file, found by one walk over their headers
+    struct Cont { int32_t ref, start, span, nrec, len; off_t body_at; };
+    std::vector<Cont> table; bool table_built = false;
+
+    // step over a block without decompressing it
+    bool skip_block(Cur& c) {
+        (void)c.u8(); (void)c.u8(); (void)c.itf8();
+        const int32_t cs = c.itf8(); (void)c.itf8();
+        if (c.bad || cs < 0 || c.p + cs + 4 > c.e) { err = "truncated CRAM block"; return false; }
+        c.p += cs + 4;
+        return true;
+    }
     bool read_block(Cur& c, Block* b) {
         const uint8_t* const b0 = c.p;
         b->method = c.u8(); b->type = c.u8(); b->id = c.itf8();
@@ -453,30 +465,40 @@ bool CramReader::open(const std::string& path, Fasta* fasta) {
 bool CramReader::fetch_impl(int tid, int64_t beg, int64_t end, void (*thunk)(void*, const BamRecord&), void* ctx) {
     Impl& d = *d_;
     if (beg < 0) beg = 0;
-    fseeko(d.f, d.data_start, SEEK_SET);
-    for (;;) {
-        int32_t len, ref, start, span, nrec, nblocks; std::vector<int32_t> land;
-        if (!read_container_header(d.f, &len, &ref, &start, &span, &nrec, &nblocks, &land)) break;
-        const off_t body_at = ftello(d.f);
-        const bool eof_marker = ref == -1 && nrec == 0;
-        const bool may = !eof_marker && nrec > 0 && (ref == -2 || (ref == tid && (int64_t)start - 1 < end && (int64_t)start - 1 + span > beg));
-        if (may) {
-            std::vector<uint8_t> body((size_t)len);
-            if (fread(body.data(), 1, body.size(), d.f) != body.size()) { d.err = "truncated CRAM container"; return false; }
-            Cur c; c.p = body.data(); c.e = c.p + body.size();
-            Block ch; if (!d.read_block(c, &ch) || ch.type != 1 || !d.parse_comp_header(ch)) { if (d.err.empty()) d.err = "bad CRAM compression header"; return false; }
-            while (c.p < c.e) {
-                Block sh; if (!d.read_block(c, &sh)) return false;
-                if (sh.type != 2) { d.err = "expected a CRAM slice header"; return false; }
-                Cur s; s.p = sh.data.data(); s.e = s.p + sh.data.size();
-                const int32_t sref = s.itf8(), sstart = s.itf8(); (void)s.itf8(); const int32_t snrec = s.itf8(); (void)s.ltf8(); const int32_t snb = s.itf8();
-                d.ext.clear();
-                for (int i = 0; i < snb; ++i) { Block b; if (!d.read_block(c, &b)) return false; if (b.type == 5) d.core = b; else d.ext[b.id] = b; }
-                auto cb = [&](const BamRecord& r) { thunk(ctx, r); };
-                if (!d.decode_slice(sref, sstart, snrec, tid, beg, end, cb)) return false;
-            }
+    // The container headers are walked ONCE (reference id, start, span, where the body lies): later queries — a site list is
+    // one query per line — go straight to the containers that can overlap.  (A .crai would give the same table without the walk.)
+    if (!d.table_built) {
+        fseeko(d.f, d.data_start, SEEK_SET);
+        for (;;) {
+            int32_t len, ref, start, span, nrec, nblocks; std::vector<int32_t> land;
+            if (!read_container_header(d.f, &len, &ref, &start, &span, &nrec, &nblocks, &land)) break;
+            Impl::Cont ct; ct.ref = ref; ct.start = start; ct.span = span; ct.nrec = nrec; ct.len = len; ct.body_at = ftello(d.f);
+            if (!(ref == -1 && nrec == 0) && nrec > 0) d.table.push_back(ct);          // (not the EOF marker / empty containers)
+            if (fseeko(d.f, ct.body_at + len, SEEK_SET) != 0) break;
         }
-        if (fseeko(d.f, body_at + len, SEEK_SET) != 0) break;
+        d.table_built = true;
+    }
+    std::vector<uint8_t> body;
+    for (const Impl::Cont& ct : d.table) {
+        const bool may = ct.ref == -2 || (ct.ref == tid && (int64_t)ct.start - 1 < end && (int64_t)ct.start - 1 + ct.span > beg);
+        if (!may) continue;
+        body.resize((size_t)ct.len);
+        if (fseeko(d.f, ct.body_at, SEEK_SET) != 0 || fread(body.data(), 1, body.size(), d.f) != body.size()) { d.err = "truncated CRAM container"; return false; }
+        Cur c; c.p = body.data(); c.e = c.p + body.size();
+        Block ch; if (!d.read_block(c, &ch) || ch.type != 1 || !d.parse_comp_header(ch)) { if (d.err.empty()) d.err = "bad CRAM compression header"; return false; }
+        while (c.p < c.e) {
+            Block sh; if (!d.read_block(c, &sh)) return false;
+            if (sh.type != 2) { d.err = "expected a CRAM slice header"; return false; }
+            Cur s; s.p = sh.data.data(); s.e = s.p + sh.data.size();
+            const int32_t sref = s.itf8(), sstart = s.itf8(); const int32_t sspan = s.itf8(); const int32_t snrec = s.itf8(); (void)s.ltf8(); const int32_t snb = s.itf8();
+            d.ext.clear();
+            // a single-reference slice that cannot overlap is skipped without inflating its blocks
+            const bool slice_may = sref == -2 || sref < 0 || (sref == tid && (int64_t)sstart - 1 < end && (int64_t)sstart - 1 + sspan > beg);
+            if (!slice_may) { for (int i = 0; i < snb; ++i) if (!d.skip_block(c)) return false; continue; }
+            for (int i = 0; i < snb; ++i) { Block b; if (!d.read_block(c, &b)) return false; if (b.type == 5) d.core = b; else d.ext[b.id] = b; }
+            auto cb = [&](const BamRecord& r) { thunk(ctx, r); };
+            if (!d.decode_slice(sref, sstart, snrec, tid, beg, end, cb)) return false;
+        }
     }
     return true;
 }
