@@ -463,22 +463,25 @@ static int run_site_batch(Ctx& c, const std::vector<Site>& sites) {
         BamReader rd;
         if (!rd.open(c.opt.bam)) { failed = 1; return; }
         for (;;) {
-            const size_t i = next.fetch_add(1);
-            if (i >= n) break;
-            const Site& st = sites[i];
-            int64_t l = st.beg0 > 0 ? st.beg0 - 1 : 0, r = st.end;
-            if (!rd.fetch(c.idx, st.tid, st.beg0 - 1, st.end, [&](const BamRecord& rec) {
-                    parts[i].add(rec, c.opt.per_lib ? lib_index(c, rec) : 0);
-                    if (rec.pos < l) l = rec.pos;
-                    const int64_t e = rec.endpos(); if (e > r) r = e;
-                })) failed = 1;
-            lo[i] = l; hi[i] = r + 64;      // room for deletion alleles read from the reference past the last read
+            // (runs of consecutive lines per thread: neighbouring sites of a sorted list share their BGZF blocks)
+            const size_t i0 = next.fetch_add(16);
+            if (i0 >= n) break;
+            for (size_t i = i0; i < std::min(n, i0 + 16); ++i) {
+                const Site& st = sites[i];
+                int64_t l = st.beg0 > 0 ? st.beg0 - 1 : 0, r = st.end;
+                if (!rd.fetch(c.idx, st.tid, st.beg0 - 1, st.end, [&](const BamRecord& rec) {
+                        parts[i].add(rec, c.opt.per_lib ? lib_index(c, rec) : 0);
+                        if (rec.pos < l) l = rec.pos;
+                        const int64_t e = rec.endpos(); if (e > r) r = e;
+                    })) failed = 1;
+                lo[i] = l; hi[i] = r + 64;      // room for deletion alleles read from the reference past the last read
+            }
         }
     };
     unsigned nthr = effective_cpus(); if (nthr > 64) nthr = 64;
     if (const char* t = getenv("BRC_FETCH_THREADS")) { const int v = atoi(t); if (v > 0) nthr = (unsigned)v; }
     std::vector<std::thread> th;
-    for (unsigned k = 1; k < nthr && k < n; ++k) th.emplace_back(work);
+    for (unsigned k = 1; k < nthr && (size_t)k * 16 < n; ++k) th.emplace_back(work);
     work();
     for (std::thread& t : th) t.join();
     if (failed) { c.complain("bam-readcount: read error while fetching sites\n"); return 1; }
