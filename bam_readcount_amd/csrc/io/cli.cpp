@@ -459,29 +459,45 @@ static int run_site_batch(Ctx& c, const std::vector<Site>& sites) {
     for (Batcher& b : parts) b.keep_names = c.opt.max_warnings != 0;
     std::vector<int64_t> lo(n), hi(n);
     std::atomic<size_t> next(0); std::atomic<int> failed(0);
+    // Clusters of consecutive lines that lie close together (same contig, ascending, within 64 kb): ONE indexed fetch per
+    // cluster, every record handed to the lines it overlaps with exactly samfetch's test.  An index points at 16-kb
+    // windows, so a line-by-line fetch decodes its window's reads over and over — with one site per kb, sixteen times.
+    std::vector<std::pair<size_t, size_t> > clusters;
+    for (size_t i0 = 0; i0 < n;) {
+        size_t i1 = i0 + 1;
+        while (i1 < n && i1 - i0 < 256 && sites[i1].tid == sites[i0].tid && sites[i1].beg0 >= sites[i1 - 1].beg0 && sites[i1].beg0 - sites[i0].beg0 <= 65536) ++i1;
+        clusters.push_back(std::make_pair(i0, i1));
+        i0 = i1;
+    }
     auto work = [&]() {
         BamReader rd;
         if (!rd.open(c.opt.bam)) { failed = 1; return; }
         for (;;) {
-            // (runs of consecutive lines per thread: neighbouring sites of a sorted list share their BGZF blocks)
-            const size_t i0 = next.fetch_add(16);
-            if (i0 >= n) break;
-            for (size_t i = i0; i < std::min(n, i0 + 16); ++i) {
-                const Site& st = sites[i];
-                int64_t l = st.beg0 > 0 ? st.beg0 - 1 : 0, r = st.end;
-                if (!rd.fetch(c.idx, st.tid, st.beg0 - 1, st.end, [&](const BamRecord& rec) {
-                        parts[i].add(rec, c.opt.per_lib ? lib_index(c, rec) : 0);
-                        if (rec.pos < l) l = rec.pos;
-                        const int64_t e = rec.endpos(); if (e > r) r = e;
-                    })) failed = 1;
-                lo[i] = l; hi[i] = r + 64;      // room for deletion alleles read from the reference past the last read
-            }
+            const size_t ci = next.fetch_add(1);
+            if (ci >= clusters.size()) break;
+            const size_t i0 = clusters[ci].first, i1 = clusters[ci].second;
+            int64_t cend = 0;
+            for (size_t i = i0; i < i1; ++i) { lo[i] = sites[i].beg0 > 0 ? sites[i].beg0 - 1 : 0; hi[i] = sites[i].end; cend = std::max(cend, sites[i].end); }
+            size_t jlo = i0;                       // lines before it end at or before every coming record's start (lines are < 1 kb wide)
+            if (!rd.fetch(c.idx, sites[i0].tid, sites[i0].beg0 - 1, cend, [&](const BamRecord& rec) {
+                    const int64_t rend = rec.endpos();
+                    while (jlo < i1 && sites[jlo].beg0 + 1000 <= rec.pos) ++jlo;
+                    for (size_t j = jlo; j < i1 && sites[j].beg0 - 1 < rend; ++j) {
+                        const Site& st = sites[j];
+                        const int64_t qb = st.beg0 - 1 < 0 ? 0 : st.beg0 - 1;                  // samfetch: beg clamped at 0, pos < end && endpos > beg
+                        if (st.end <= qb || rec.pos >= st.end || rend <= qb) continue;
+                        parts[j].add(rec, c.opt.per_lib ? lib_index(c, rec) : 0);
+                        if (rec.pos < lo[j]) lo[j] = rec.pos;
+                        if (rend > hi[j]) hi[j] = rend;
+                    }
+                })) failed = 1;
+            for (size_t i = i0; i < i1; ++i) hi[i] += 64;      // room for deletion alleles read from the reference past the last read
         }
     };
     unsigned nthr = effective_cpus(); if (nthr > 64) nthr = 64;
     if (const char* t = getenv("BRC_FETCH_THREADS")) { const int v = atoi(t); if (v > 0) nthr = (unsigned)v; }
     std::vector<std::thread> th;
-    for (unsigned k = 1; k < nthr && (size_t)k * 16 < n; ++k) th.emplace_back(work);
+    for (unsigned k = 1; k < nthr && (size_t)k < clusters.size(); ++k) th.emplace_back(work);
     work();
     for (std::thread& t : th) t.join();
     if (failed) { c.complain("bam-readcount: read error while fetching sites\n"); return 1; }
