@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--contig-mbp", type=float, default=50.0, help="weak/sites: contig per GPU; strong: the whole contig")
     ap.add_argument("--sites", type=int, default=100000, help="--mode sites: lines of the site list (all ranks together)")
     ap.add_argument("--cpu-sample-mbp", type=float, default=8.0, help="prefix timed with the 1-thread CPU oracle and used for validation (0 = skip)")
+    ap.add_argument("--allow-large", action="store_true", help="--mode strong: accept more than 12.5 Mbp of 200x data per rank")
     ap.add_argument("--cpu-ref-mbp", type=float, default=0.5, help="prefix timed with the reference-compiled library oracle/_ref (0 = skip)")
     ap.add_argument("--cpu-all-cores", type=int, default=-1, help="oracle processes of the all-cores baseline (-1: min(usable CPUs, 64); 0 = skip)")
     ap.add_argument("--e2e-mbp", type=float, default=30.0, help="contig of the end-to-end command-line run (0 = skip)")
@@ -154,6 +155,11 @@ def main():
 
     total_len = int(args.contig_mbp * 1e6)
     contig_len = total_len // world if args.mode == "strong" else total_len
+    if args.mode == "strong" and contig_len > 12_500_000 and not args.allow_large:
+        # (one rank would stage 200x over %d Mbp: tens of GB of pinned host memory and minutes of set-up; measured here: the
+        # per-GPU shape of the 8-GPU configuration, 6.25 Mbp)
+        raise SystemExit("--mode strong with %d rank(s) puts %.1f Mbp of 200x data (%.0f M reads) on one GPU: use --gpus 4 / 8, a smaller --contig-mbp "
+                         "(6.25 = the per-GPU shape of BASELINE config 5), or --allow-large" % (world, contig_len / 1e6, contig_len * 200 / 150 / 1e6))
     t0 = time.time()
     ref, arrs = synthgen.generate(contig_len, config, seed=1 + 1000 * rank)
     t_gen = time.time() - t0
