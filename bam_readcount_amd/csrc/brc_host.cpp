@@ -686,10 +686,14 @@ static bool format_range(const brc_engine* e, const brc_result* r, const char* c
         for (int l = 0; l < Lp; ++l) {
             const std::deque<QEnt>& q = queue[(size_t)l];
             if (q.empty() || r->ncol[(int64_t)l * S + k] == 0) continue;
+            // exactly IndelQueue::process: stale entries are dropped from the FRONT only, then the run of entries due here
+            // is taken — an entry behind one that is due later (or behind a stale one that follows a due one) stays
+            bool taking = false;
             for (const QEnt& x : q) {
-                if (x.tid != tid || x.pos < (uint32_t)pos) continue;                      // (stale: dropped below)
-                if (x.pos != (uint32_t)pos) break;
-                depth += x.st.i[I_N];
+                const bool stale = x.tid != tid || x.pos < (uint32_t)pos;
+                if (!taking && stale) continue;
+                if (x.tid != tid || x.pos != (uint32_t)pos) break;
+                taking = true; depth += x.st.i[I_N];
             }
         }
         const size_t line_start = out.n;

@@ -486,3 +486,41 @@ def test_hip_warning_text_equals_reference_compiled(hip_lib, ref_lib, case):
     for max_w in (1, -1):
         want = warnings_per_region(ref_lib, arrs, WARN_REGIONS, ref, names, max_w, case["opts"])
         assert warnings_per_region(hip_lib, arrs, WARN_REGIONS, ref, names, max_w, case["opts"]) == want
+
+
+def test_pending_deletion_blocks_the_queue_like_the_reference(oracle_lib, sim_lib, ref_lib):
+    """IndelQueue::process only ever looks at the FRONT of its queue (IndelQueue.cpp:3-15).  Regions given on the command line
+    are not separated by a clear (:641-657), so a deletion left pending at the end of one region (due at a position the next
+    region never reaches) blocks every deletion queued behind it: the second region prints none of its deletions, and when a
+    third region finally reaches the pending position, one entry is printed, the stale ones behind it are dropped only at
+    the NEXT position, and the second copy queued by the third region itself stays stuck.  All host routes of the product
+    (dense planes, compact planes, device-side text) must reproduce that, depth column included."""
+    rng = np.random.default_rng(7)
+    ref = synth.make_ref(rng, 2000)
+    arrs = synth.make_batch(11, ref, 900, style="simple", region=(600, 1500), read_len=(80, 100), n_libs=2)
+    arrs = synth.pile_indels(arrs, 1499, seed=1, frac=0.5)        # deletions behind position 1499: queued for 1500, outside the first region
+    arrs = synth.pile_indels(arrs, 799, seed=2, frac=0.5)
+    regions = [(1400, 1500), (700, 900), (1490, 1510)]
+    for kw in (dict(), dict(per_lib=True, lib_names=["libA", "libB"])):
+        want, _ = parity.run_engine(ref_lib, arrs, regions, ref=ref, clear_queue=False, **kw)
+        line801 = [l for l in want.split(b"\n") if l.startswith(b"chrS\t801\t")][0]
+        assert b"\t-" not in line801                                  # the second region's deletions are stuck behind the pending one
+        assert parity.run_engine(oracle_lib, arrs, regions, ref=ref, clear_queue=False, **kw)[0] == want
+        for route in (dict(), dict(text_only=True), dict(device_text="chrS")):
+            got, _ = parity.run_engine(sim_lib, arrs, regions, ref=ref, clear_queue=False, **route, **kw)
+            assert got == want, (kw, route)
+
+
+@pytest.mark.gpu
+def test_pending_deletion_blocks_the_queue_like_the_reference_gpu(hip_lib, ref_lib):
+    """The same scenario through the product library on the GPU (all three text routes)."""
+    rng = np.random.default_rng(7)
+    ref = synth.make_ref(rng, 2000)
+    arrs = synth.make_batch(11, ref, 900, style="simple", region=(600, 1500), read_len=(80, 100), n_libs=2)
+    arrs = synth.pile_indels(synth.pile_indels(arrs, 1499, seed=1, frac=0.5), 799, seed=2, frac=0.5)
+    regions = [(1400, 1500), (700, 900), (1490, 1510)]
+    for kw in (dict(), dict(per_lib=True, lib_names=["libA", "libB"])):
+        want, _ = parity.run_engine(ref_lib, arrs, regions, ref=ref, clear_queue=False, **kw)
+        for route in (dict(), dict(text_only=True), dict(device_text="chrS")):
+            got, _ = parity.run_engine(hip_lib, arrs, regions, ref=ref, clear_queue=False, **route, **kw)
+            assert got == want, (kw, route)
