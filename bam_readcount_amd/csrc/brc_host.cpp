@@ -929,6 +929,10 @@ static int format_chunks(brc_engine* e, const brc_result* r, const char* chrom, 
     if (CH < 2048) CH = 2048;
     if (CH > (1 << 16)) CH = 1 << 16;
     if (const char* t = getenv("BRC_FORMAT_CHUNK")) { const long long v = atoll(t); if (v > 0) CH = v; }   // test knob
+    // Chunks after the first start from the deletions their previous position queued: right as long as nothing older sits in
+    // the queues.  An entry a previous region left pending for a position still ahead blocks everything queued behind it
+    // (IndelQueue::process looks at the front only) — then the region is assembled in one piece, in order.
+    for (const std::deque<QEnt>& q : e->queue) if (!q.empty()) { CH = std::max<int64_t>(P, 1); break; }
     const int64_t nch = std::max<int64_t>((P + CH - 1) / CH, 1);
     while (e->fparts.size() < (size_t)nch) e->fparts.emplace_back();
     std::vector<TextBuf>& parts = e->fparts;

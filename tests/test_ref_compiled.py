@@ -509,6 +509,14 @@ def test_pending_deletion_blocks_the_queue_like_the_reference(oracle_lib, sim_li
         for route in (dict(), dict(text_only=True), dict(device_text="chrS")):
             got, _ = parity.run_engine(sim_lib, arrs, regions, ref=ref, clear_queue=False, **route, **kw)
             assert got == want, (kw, route)
+        # the pooled formatter cuts a region into chunks of positions: with something pending it must not
+        os.environ["BRC_FORMAT_CHUNK"] = "16"; os.environ["BRC_FORMAT_THREADS"] = "4"
+        try:
+            for route in (dict(), dict(text_only=True)):
+                got, _ = parity.run_engine(sim_lib, arrs, regions, ref=ref, clear_queue=False, **route, **kw)
+                assert got == want, (kw, route, "chunked")
+        finally:
+            del os.environ["BRC_FORMAT_CHUNK"]; del os.environ["BRC_FORMAT_THREADS"]
 
 
 @pytest.mark.gpu
