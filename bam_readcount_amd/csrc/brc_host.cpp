@@ -267,6 +267,7 @@ struct brc_engine {
     // formatter reads the compact slot planes; third-allele events are aggregated into a sparse (position, library,
     // bucket)-sorted table instead
     bool text_only = false;
+    bool continues = false, warn_skip_lead = false; // BRC_OPT_CONTINUES_PREVIOUS (1: both; 2: the warnings only)
     bool device_text = false; std::string chrom;   // BRC_OPT_DEVICE_TEXT / brc_set_chrom
     bool text_result = false;                       // the last fetched result is device text (no planes on the host)
     bool text_computed = false; int text_slot_computed = 0, text_slot = 0;   // device text started by the last brc_compute / fetched
@@ -350,6 +351,7 @@ int brc_set_option(brc_engine* e, int option, int64_t value) {
         case BRC_OPT_EXPECT_READS: e->hint_reads = value > 0 ? (size_t)value : 0; return BRC_OK;
         case BRC_OPT_EXPECT_BASES: e->hint_bases = value > 0 ? (size_t)value : 0; return BRC_OK;
         case BRC_OPT_DEVICE_TEXT: e->device_text = value != 0; return BRC_OK;
+        case BRC_OPT_CONTINUES_PREVIOUS: e->continues = value == 1; e->warn_skip_lead = value == 1 || value == 2; return BRC_OK;
         case BRC_OPT_EXPECT_TEXT: { if (value <= 0) return BRC_OK; const int rc = e->be->reserve_text((size_t)value); return rc ? fail(e, rc, e->be->last_error()) : BRC_OK; }
         default: return fail(e, BRC_E_ARG, "unknown engine option");
     }
@@ -814,7 +816,9 @@ static int format_device_text(brc_engine* e, const brc_result* r) {
         const int32_t pos = r->pos0 + (int32_t)k;
         while (ii < r->n_indel && r->indel[ii].pos < pos) ++ii;
         while (xi < e->xagg.size() && (int64_t)(e->xagg[xi].key >> 16) < k) ++xi;
-        if (ht.off[k + 1] == ht.off[k]) {                          // no line: no pileup callback here, nothing is queued or processed
+        if (ht.off[k + 1] == ht.off[k] || (k == 0 && e->continues && r->pos0 < r->beg0)) {
+            // no line: no pileup callback here, nothing is queued or processed — nor at the lead position of a region that
+            // continues the previous one (it was that region's last position)
             while (ii < r->n_indel && r->indel[ii].pos == pos) ++ii;
             continue;
         }
@@ -938,8 +942,10 @@ static int format_chunks(brc_engine* e, const brc_result* r, const char* chrom, 
     std::vector<TextBuf>& parts = e->fparts;
     std::vector<std::vector<std::deque<QEnt> > > qs((size_t)nch);
     std::atomic<int> nomem(0);
+    // a region that continues the previous one does not process its lead position again (BRC_OPT_CONTINUES_PREVIOUS)
+    const int64_t kfirst = (e->continues && P > 0 && r->pos0 < r->beg0) ? 1 : 0;
     parallel_for(nch, nthr, [&](int64_t c) {
-        const int64_t k0 = c * CH, k1 = std::min<int64_t>(P, k0 + CH);
+        const int64_t k0 = std::max<int64_t>(c * CH, c == 0 ? kfirst : 0), k1 = std::min<int64_t>(P, c * CH + CH);
         bool ok = true;
         try {
             if (c == 0) qs[0] = e->queue;
@@ -1183,7 +1189,9 @@ static int warnings_impl(brc_engine* e, const char* chrom, int64_t wbeg0, int64_
 
 int brc_region_warnings(brc_engine* e, const char* chrom, int64_t cap, const char** events, size_t* events_len) {
     if (!e) return BRC_E_ARG;
-    return warnings_impl(e, chrom, e->g.beg0, e->g.end, true, cap, events, events_len);
+    // (BRC_OPT_CONTINUES_PREVIOUS: the lead position was the last position of the region before this one, which has
+    // reported that position's events already)
+    return warnings_impl(e, chrom, (int64_t)e->g.beg0 + (e->warn_skip_lead ? 1 : 0), e->g.end, true, cap, events, events_len);
 }
 int brc_window_warnings(brc_engine* e, int32_t vbeg0, int32_t vend, int64_t cap, const char** events, size_t* events_len) {
     return warnings_impl(e, "", vbeg0, vend, false, cap, events, events_len);

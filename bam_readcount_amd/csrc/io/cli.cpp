@@ -340,7 +340,8 @@ static void fetch_chunk(Ctx& c, int tid, int64_t a, int64_t b, Fetched& out) {
 
 // one reporting window [beg0,end) on tid: the body of the site-list / region loops (:588-605, :649-656)
 // keep_queue: the first piece keeps the deletions the previous command-line region left pending (like the reference, :641-657)
-static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode, bool keep_queue = true) {
+// inner_piece: (several engines) this window is a piece of a longer region whose previous piece ran elsewhere
+static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode, bool keep_queue = true, bool inner_piece = false) {
     const BamHeader& h = c.header();
     if (c.have_fa && tid != c.ref_tid) {
         if (!c.fa.fetch(h.names[(size_t)tid], &c.ref)) c.ref.clear();
@@ -417,7 +418,11 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
             // an internal piece boundary is not a region boundary: the deletions left pending by the previous piece start at
             // its last position, which is this piece's lead position and queues them again — drop the leftovers (the FIRST
             // piece keeps whatever the previous command-line region left, like the reference, :641-657)
-            const bool clear_first = a > beg0 || !keep_queue;
+            const bool clear_first = a == beg0 && !keep_queue;
+            // a piece after the first continues the piece before it on this engine: its lead position is not processed again
+            // and the deletion queues carry over.  (Set between the download of this piece and the download of the next:
+            // the formatter thread and the warnings of THIS piece are its only readers.)
+            brc_set_option(c.eng, BRC_OPT_CONTINUES_PREVIOUS, a > beg0 ? 1 : (inner_piece ? 2 : 0));
             const char* chrom = h.names[(size_t)tid].c_str();
             fmt_rc = 0;
             fmt = std::thread([&c, &R, chrom, clear_first, &fmt_rc, &fmt_s]() {
@@ -429,7 +434,10 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
                 fmt_s = now_s() - f0;
             });
             // (the warnings read the staged reads of this piece: before the next brc_begin_region)
-            if (c.opt.max_warnings != 0) { const char* ev = ""; size_t evn = 0; if (brc_region_warnings(c.eng, chrom, c.opt.max_warnings, &ev, &evn) == 0) c.warn_events(ev, evn); }
+            if (c.opt.max_warnings != 0) {
+                const char* ev = ""; size_t evn = 0;
+                if (brc_region_warnings(c.eng, chrom, c.opt.max_warnings, &ev, &evn) == 0) c.warn_events(ev, evn);
+            }
             for (int w = 0; w < BRC_N_WARN; ++w) c.warn[w] += R.warn[w];
         }
         if (rc) { join_fmt(); c.complain(std::string("bam-readcount: engine error: ") + brc_strerror(rc) + " (" + brc_last_error(c.eng) + ")\n"); return 1; }
@@ -587,8 +595,8 @@ static bool parse_region(const BamHeader& h, const std::string& s, int* tid, int
 #include <mutex>
 
 struct Work {
-    int kind = 0;                     // 0: region piece, 1: site-list batch
-    int tid = 0; int64_t beg0 = 0, end = 0; bool site_mode = false, keep_queue = false;
+    int kind = 0;                     // 0: region piece, 1: site-list batch, 2: an error that ends the run, 3: a message (stderr) in file order
+    int tid = 0; int64_t beg0 = 0, end = 0; bool site_mode = false, keep_queue = false, inner_piece = false;
     std::vector<Site> sites;
     int engine = 0;
     std::string out, err, wev; int rc = 0; bool done = false;
@@ -597,7 +605,7 @@ struct Work {
 
 static int run_item(Ctx& c, Work& w) {
     if (w.kind == 1) return run_site_batch(c, w.sites);
-    return run_region(c, w.tid, w.beg0, w.end, w.site_mode, w.keep_queue);
+    return run_region(c, w.tid, w.beg0, w.end, w.site_mode, w.keep_queue, w.inner_piece);
 }
 
 static bool open_inputs(Ctx& c, bool quiet) {
@@ -654,6 +662,10 @@ int main(int argc, char** argv) {
         const std::vector<int> one = devices;
         for (long long k = 1; k < K; ++k) devices.insert(devices.end(), one.begin(), one.end());
     }
+    // Deletions left pending by one command-line region reach into the next (the reference does not clear its queue there,
+    // :641-657) and can block its deletions from the first position to the last: such runs keep every piece on one engine,
+    // in order.  (One region — a chromosome — and site lists spread over the engines.)
+    if (o.site_list.empty() && o.regions.size() > 1) devices.resize(1);
     size_t N = devices.size();
     // The engine (HIP runtime start, streams) is created on a thread of its own while this one reads the index and the site
     // list and — inside the first work item — the reference and the first reads; whoever needs the engine waits for it.
@@ -685,6 +697,7 @@ int main(int argc, char** argv) {
             const int64_t b = std::min<int64_t>(a + step, end);
             Work w; w.kind = 0; w.tid = tid; w.beg0 = a; w.end = b; w.site_mode = site_mode && b >= end;
             w.keep_queue = first && !site_mode;       // a -l line starts from an empty queue (:605 cleared it after the previous line)
+            w.inner_piece = !first;
             items.push_back(std::move(w));
             first = false; a = b;
         } while (a < end);
@@ -702,8 +715,10 @@ int main(int argc, char** argv) {
             char name[4096]; int beg, end;
             if (sscanf(line, "%4095s %d %d", name, &beg, &end) != 3) continue;
             auto it = c.header().name2tid.find(name);
-            if (it == c.header().name2tid.end()) {                                   // :580-582 (printed when the line is read, like the reference)
-                fprintf(stderr, "%s not found in bam file. Region %s %i %i skipped.\n", name, name, beg, end); continue;
+            if (it == c.header().name2tid.end()) {                                   // :580-582 — printed when the reference's loop reaches the line,
+                flush();                                                             // i.e. behind the warnings of the lines before it: a work item of its own
+                char msg[8300]; snprintf(msg, sizeof msg, "%s not found in bam file. Region %s %i %i skipped.\n", name, name, beg, end);
+                Work w; w.kind = 3; w.err = msg; items.push_back(std::move(w)); continue;
             }
             if (beg < 1) beg = 1;
             // (windows near the end of a contig run on their own: fetch_func's "Request for position" lines carry real coordinates)
@@ -757,6 +772,7 @@ int main(int argc, char** argv) {
     if (N == 1) {
         for (Work& w : items) {
             if (w.kind == 2) { fputs(w.err.c_str(), stderr); ret = 1; break; }
+            if (w.kind == 3) { fflush(stdout); fputs(w.err.c_str(), stderr); continue; }
             if ((ret = run_item(c, w))) break;
         }
     } else {
@@ -798,7 +814,7 @@ int main(int argc, char** argv) {
                     if (abort_all) return;
                 }
                 int r = w.rc;
-                if (w.kind != 2) {
+                if (w.kind != 2 && w.kind != 3) {
                     wc->out_buf = &w.out; wc->err_buf = &w.err; wc->wev_buf = &w.wev;
                     // (a piece is formatted by exactly one brc_format_region call: its text can stay where it is)
                     const bool zc = w.kind == 0 && w.end - w.beg0 <= (int64_t)c.opt.chunk_bp;

@@ -203,6 +203,16 @@ void brc_destroy(brc_engine*);
  *                      option may be set from another thread while the first region is being staged — pinning hundreds of
  *                      megabytes takes as long as decoding the first reads) */
 #define BRC_OPT_EXPECT_TEXT 5
+/*   BRC_OPT_CONTINUES_PREVIOUS  1: the next region continues the previous region of this engine (same contig, its beg0 == the
+ *                      previous end) — a caller cutting a long region into abutting pieces.  Its lead position beg0-1 was the
+ *                      previous piece's last position and is not processed again: no deletions are queued twice, the queues
+ *                      (with whatever an earlier region left pending, which can block them — IndelQueue::process looks at the
+ *                      front only) carry over untouched, and brc_region_warnings leaves that position's events out.  Without
+ *                      it a caller has to call brc_clear_indel_queue before every piece but the first, which
+ *                      is exact only when nothing older is pending.
+ *                      2: the piece before this one ran on ANOTHER engine: the queues start empty here and the lead position
+ *                      queues its deletions as usual, only brc_region_warnings leaves its events out. */
+#define BRC_OPT_CONTINUES_PREVIOUS 6
 int  brc_set_option(brc_engine*, int option, int64_t value);
 /* Target name printed in column 1 of the following regions' lines (BRC_OPT_DEVICE_TEXT: the text is written at
  * brc_fetch_result time, before brc_format_region names the contig); copied. */

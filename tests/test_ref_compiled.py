@@ -568,3 +568,86 @@ def test_random_scenarios_equal_reference_compiled(oracle_lib, sim_lib, ref_lib,
         for lib, route in ((oracle_lib, {}), (sim_lib, {}), (sim_lib, dict(text_only=True)), (sim_lib, dict(device_text="chrS"))):
             got, _ = parity.run_engine(lib, arrs, regions, ref=ref, clear_queue=clear, **route, **kw)
             assert got == want, (seed, style, kw, regions, clear, route)
+
+
+def _random_cli_case(seed, d):
+    """A random two-contig BAM (+ .bai, FASTA) and a random bam-readcount command line over it; returns (reference options,
+    drop-in extras, positional arguments, environment of the drop-in)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bamio
+    from test_cli import _write_fasta
+    rng = np.random.default_rng(seed)
+    L0 = int(rng.integers(800, 6000)); L1 = int(rng.integers(500, 3000))
+    refs = [synth.make_ref(rng, L0 + 600), synth.make_ref(rng, L1 + 600)]      # (longer than any read reaches)
+    nl = int(rng.choice([1, 2, 3]))
+    parts = [synth.make_batch(seed * 2 + 1, refs[0], int(rng.integers(100, 1500)), style=str(rng.choice(["simple", "indel", "wild", "mixed"])), n_libs=nl, region=(0, L0), p_nolib=float(rng.choice([0, 0.03]))),
+             synth.make_batch(seed * 2 + 2, refs[1], int(rng.integers(50, 600)), style=str(rng.choice(["simple", "indel", "mixed"])), n_libs=nl, region=(0, L1))]
+    arrs = {}
+    for k in ("pos", "flag", "mapq", "lib", "l_qseq", "n_cigar", "nm", "sm", "tags"):
+        arrs[k] = np.concatenate([p[k] for p in parts])
+    for arena, off in (("cigar", "cigar_off"), ("seq4", "seq_off"), ("qual", "qual_off")):
+        arrs[arena] = np.concatenate([p[arena] for p in parts]); arrs[off] = np.concatenate([parts[0][off], parts[1][off] + np.uint64(parts[0][arena].size)])
+    tids = np.concatenate([np.zeros(len(parts[0]["pos"]), int), np.ones(len(parts[1]["pos"]), int)])
+    rg_ids = ["rg%d" % i for i in range(nl)]
+    rgs = [rg_ids[int(l)] if l >= 0 else None for l in arrs["lib"]]
+    bamio.write_bam(os.path.join(d, "x.bam"), [("chrA", L0 + 600), ("chrB", L1 + 600)], arrs, tids, rg_of_read=rgs,
+                    rg_lines=["@RG\tID:%s\tLB:lib%c\tSM:s" % (r, 65 + i) for i, r in enumerate(rg_ids)], block_bytes=int(rng.choice([3000, 20000])))
+    _write_fasta(os.path.join(d, "r.fa"), [("chrA", refs[0]), ("chrB", refs[1])])
+    opts = []
+    if rng.random() < 0.5: opts += ["-q", str(int(rng.choice([1, 10, 30])))]
+    if rng.random() < 0.5: opts += ["-b", str(int(rng.choice([5, 13, 25])))]
+    if rng.random() < 0.4: opts += ["-p"]
+    if rng.random() < 0.4: opts += ["-i"]
+    if rng.random() < 0.15: opts += ["-d", str(int(rng.choice([2, 10])))]
+    opts += ["-w", str(int(rng.choice([0, 1, 3, -1]))), "-f", "r.fa"]          # (without -f the reference dereferences a null pointer)
+
+    def region():
+        c = str(rng.choice(["chrA", "chrB"])); Lc = L0 if c == "chrA" else L1
+        k = rng.random()
+        if k < 0.2: return c
+        a = int(rng.integers(1, Lc))
+        return "%s:%d" % (c, a) if k < 0.35 else "%s:%d-%d" % (c, a, a + int(rng.choice([0, 1, 20, 300, Lc])))
+    if rng.random() < 0.5:
+        args = ["x.bam"] + [region() for _ in range(int(rng.integers(1, 5)))]
+    else:
+        lines = []
+        for _ in range(int(rng.integers(1, 40))):
+            c = "chrZ" if rng.random() < 0.05 else str(rng.choice(["chrA", "chrB"]))
+            Lc = L0 if c == "chrA" else L1; a = int(rng.integers(1, Lc)); lines.append("%s\t%d\t%d\n" % (c, a, a + int(rng.choice([0, 0, 0, 1, 30, 400]))))
+        if rng.random() < 0.5: lines.sort(key=lambda t: (t.split("\t")[0], int(t.split("\t")[1])))
+        open(os.path.join(d, "s.txt"), "w").write("".join(lines)); args = ["-l", "s.txt", "x.bam"]
+    extra = []
+    if rng.random() < 0.5: extra += ["--brc-chunk", str(int(rng.choice([64, 333, 5000])))]
+    if rng.random() < 0.3: extra += ["--brc-gpus", str(int(rng.choice([2, 3])))]
+    if rng.random() < 0.2: extra += ["--brc-plan", str(int(rng.choice([0, 3])))]
+    env = dict(os.environ, BRC_DEVICE_TEXT_MAX_SHARE=str(rng.choice(["100", "0.06"])))
+    if rng.random() < 0.3:
+        env["BRC_FETCH_STRIPE_MIN"] = "1"; env["BRC_FETCH_THREADS"] = str(int(rng.choice([2, 5])))
+    return opts, extra, args, env
+
+
+def _cli_fuzz(cli, ref_lib, tmp_path, seeds):
+    for seed in seeds:
+        d = tmp_path / ("s%d" % seed); d.mkdir()
+        opts, extra, args, env = _random_cli_case(seed, str(d))
+        a = subprocess.run([REF_CLI] + opts + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        b = subprocess.run([cli] + opts + extra + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert (a.returncode, a.stdout == b.stdout, a.stderr == b.stderr) == (b.returncode, True, True), (seed, opts, extra, args)
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_cli_random_command_lines_equal_reference_main(ref_lib, tmp_path, block):
+    """Differential fuzz of the whole command line against the reference's own main(): random BAMs (all CIGAR operators, reads
+    without library / tags), options, regions in any order or -l lists (unsorted, unknown contigs, wide lines), warning caps —
+    and, on the drop-in's side, random piece sizes, engine counts, planner settings, striped fetches and text routes.
+    stdout, stderr and the exit code must be the reference's."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    from test_cli import SIM_CLI
+    _cli_fuzz(SIM_CLI, ref_lib, tmp_path, range(block * 10, block * 10 + 10))
+
+
+@pytest.mark.gpu
+def test_cli_random_command_lines_equal_reference_main_gpu(ref_lib, tmp_path):
+    from test_cli import HIP_CLI
+    _cli_fuzz(HIP_CLI, ref_lib, tmp_path, range(100, 112))
