@@ -627,10 +627,12 @@ def _random_cli_case(seed, d):
     return opts, extra, args, env
 
 
-def _cli_fuzz(cli, ref_lib, tmp_path, seeds):
+def _cli_fuzz(cli, ref_lib, tmp_path, seeds, one_device=False):
     for seed in seeds:
         d = tmp_path / ("s%d" % seed); d.mkdir()
         opts, extra, args, env = _random_cli_case(seed, str(d))
+        if one_device and "--brc-gpus" in extra:          # the GPU box has one device: several engines on it
+            i = extra.index("--brc-gpus"); env["BRC_DEVICES"] = ",".join(["0"] * int(extra[i + 1])); del extra[i:i + 2]
         a = subprocess.run([REF_CLI] + opts + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         b = subprocess.run([cli] + opts + extra + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         assert (a.returncode, a.stdout == b.stdout, a.stderr == b.stderr) == (b.returncode, True, True), (seed, opts, extra, args)
@@ -650,4 +652,4 @@ def test_cli_random_command_lines_equal_reference_main(ref_lib, tmp_path, block)
 @pytest.mark.gpu
 def test_cli_random_command_lines_equal_reference_main_gpu(ref_lib, tmp_path):
     from test_cli import HIP_CLI
-    _cli_fuzz(HIP_CLI, ref_lib, tmp_path, range(100, 112))
+    _cli_fuzz(HIP_CLI, ref_lib, tmp_path, range(100, 112), one_device=True)
