@@ -579,7 +579,7 @@ def _random_cli_case(seed, d):
     from test_cli import _write_fasta
     rng = np.random.default_rng(seed)
     L0 = int(rng.integers(800, 6000)); L1 = int(rng.integers(500, 3000))
-    refs = [synth.make_ref(rng, L0 + 600), synth.make_ref(rng, L1 + 600)]      # (longer than any read reaches)
+    refs = [synth.make_ref(rng, L0 + 600, weird=float(rng.choice([0, 0.03]))), synth.make_ref(rng, L1 + 600)]      # (longer than any read reaches)
     nl = int(rng.choice([1, 2, 3]))
     parts = [synth.make_batch(seed * 2 + 1, refs[0], int(rng.integers(100, 1500)), style=str(rng.choice(["simple", "indel", "wild", "mixed"])), n_libs=nl, region=(0, L0), p_nolib=float(rng.choice([0, 0.03]))),
              synth.make_batch(seed * 2 + 2, refs[1], int(rng.integers(50, 600)), style=str(rng.choice(["simple", "indel", "mixed"])), n_libs=nl, region=(0, L1))]
@@ -592,7 +592,8 @@ def _random_cli_case(seed, d):
     rg_ids = ["rg%d" % i for i in range(nl)]
     rgs = [rg_ids[int(l)] if l >= 0 else None for l in arrs["lib"]]
     bamio.write_bam(os.path.join(d, "x.bam"), [("chrA", L0 + 600), ("chrB", L1 + 600)], arrs, tids, rg_of_read=rgs,
-                    rg_lines=["@RG\tID:%s\tLB:lib%c\tSM:s" % (r, 65 + i) for i, r in enumerate(rg_ids)], block_bytes=int(rng.choice([3000, 20000])))
+                    rg_lines=["@RG\tID:%s\tLB:lib%c\tSM:s" % (r, 65 + i) for i, r in enumerate(rg_ids)], block_bytes=int(rng.choice([3000, 20000])),
+                    int_types=[str(t) for t in rng.choice(list("cCsSiI"), len(arrs["pos"]))])
     _write_fasta(os.path.join(d, "r.fa"), [("chrA", refs[0]), ("chrB", refs[1])])
     opts = []
     if rng.random() < 0.5: opts += ["-q", str(int(rng.choice([1, 10, 30])))]

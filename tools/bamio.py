@@ -121,7 +121,16 @@ def _bgzf_block(payload):
     return hdr + c + struct.pack("<II", zlib.crc32(payload) & 0xffffffff, len(payload))
 
 
-def write_bam(path, contigs, arrs, tids, rg_of_read=None, rg_lines=(), qnames=None, block_bytes=20000, long_cigar=(), csi=None):
+def _int_tag(tag, v, ty):
+    """An integer aux field in one of BAM's six integer types (the smallest that holds v when ty is None)."""
+    fmt = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I"}
+    lim = {"c": (-128, 127), "C": (0, 255), "s": (-32768, 32767), "S": (0, 65535), "i": (-2**31, 2**31 - 1), "I": (0, 2**32 - 1)}
+    if ty is None or not (lim[ty][0] <= v <= lim[ty][1]):
+        ty = "i"
+    return tag + ty.encode() + struct.pack(fmt[ty], v)
+
+
+def write_bam(path, contigs, arrs, tids, rg_of_read=None, rg_lines=(), qnames=None, block_bytes=20000, long_cigar=(), csi=None, int_types=None):
     """contigs: [(name, length)]; arrs: brc_read_batch arrays (coordinate-sorted per contig); tids: contig index per
     read (non-decreasing).  Writes path and path + '.bai' — or, with csi=(min_shift, depth), path + '.csi' (CSIv1: BGZF-
     compressed, bins of that geometry with a left offset each, no linear index).  Aux: NM:i / SM:i when the tags bits say so, RG:Z."""
@@ -152,8 +161,9 @@ def write_bam(path, contigs, arrs, tids, rg_of_read=None, rg_lines=(), qnames=No
         end = pos + (rl if (nc and not flag & 4) else 1)
         qn = (qnames[i] if qnames is not None else "r%d" % i).encode() + b"\0"
         aux = b""
-        if int(arrs["tags"][i]) & 1: aux += b"NMi" + struct.pack("<i", int(arrs["nm"][i]))
-        if int(arrs["tags"][i]) & 2: aux += b"SMi" + struct.pack("<i", int(arrs["sm"][i]))
+        # (int_types: per read the type letter of its NM / SM fields — c C s S i I — for readers that must take all six)
+        if int(arrs["tags"][i]) & 1: aux += _int_tag(b"NM", int(arrs["nm"][i]), int_types[i] if int_types is not None else "i")
+        if int(arrs["tags"][i]) & 2: aux += _int_tag(b"SM", int(arrs["sm"][i]), int_types[i] if int_types is not None else "i")
         if rg_of_read is not None and rg_of_read[i] is not None: aux += b"RGZ" + rg_of_read[i].encode() + b"\0"
         if i in long_cigar:      # SAMv1 4.2.2: the real operators travel in CG:B,I behind the placeholder <l_seq>S<span>N
             aux += b"CGBI" + struct.pack("<I", nc) + b"".join(struct.pack("<I", int(c)) for c in cig)
