@@ -717,15 +717,15 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
             count_if(a.depth, m_p);                                                            /* mapq_n (:312) */         \
             if (!(fl & PF_NB)) {                                                               /* :343 with -i */          \
                 const uint32_t b = S.w & 0xffu;                                                                           \
-                float ts3p, tq2; double tsev;                                                                             \
-                if (__builtin_expect((fl & PF_TABLE) != 0u, 1)) {                                                         \
-                    /* q2 == tp, or no Q2 position: then +0.0f, the identity on these sums */                            \
-                    ts3p = S.t; tsev = S.sev; tq2 = __uint_as_float(__float_as_uint(S.t) & ((fl & PF_Q2OK) ? 0xffffffffu : 0u)); \
-                } else {                                                                                                  \
+                /* the terms live in the stage's own registers: a piece without PF_TABLE overwrites them (no copies on the   \
+                   common path); q2 == tp, or no Q2 position: then +0.0f, the identity on these sums */                  \
+                float tq2 = __uint_as_float(__float_as_uint(S.t) & ((fl & PF_Q2OK) ? 0xffffffffu : 0u));                  \
+                if (__builtin_expect((fl & PF_TABLE) == 0u, 0)) {                                                         \
                     PieceHot H; BRC_LD_DIV(H, R, m)                                                                       \
                     const EvTerms t = piece_terms_div(H, (int)((uint32_t)lane + (uint32_t)S.s_c));                        \
-                    ts3p = t.s3p; tq2 = t.q2; tsev = t.sev;                                                               \
+                    S.t = t.s3p; tq2 = t.q2; S.sev = t.sev;                                                               \
                 }                                                                                                         \
+                const float ts3p = S.t; const double tsev = S.sev;                                                        \
                 const uint64_t m_dom = m_p & __builtin_amdgcn_ballot_w64(b == a.dom_b);                                   \
                 if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(m_dom), 1)) {                                    \
                     a.dom.w1 += R.f[5]; a.dom.w2 += R.f[6]; a.dom.w3 += R.f[7]; a.dom.sw += S.w;                          \
