@@ -342,7 +342,9 @@ struct CramReader::Impl {
             else if (cf & 4) { int32_t nf; if (!geti("NF", &nf)) return false; }
             int32_t tl; if (!geti("TL", &tl)) return false;
             std::vector<uint8_t> aux;
+            bool has_nm = false; uint32_t nm = 0;
             if (tl >= 0 && (size_t)tl < td.size()) for (int32_t key : td[(size_t)tl]) {
+                if ((key >> 8) == (('N' << 8) | 'M')) has_nm = true;
                 auto it = tagenc.find(key); if (it == tagenc.end()) { err = "CRAM tag encoding missing"; return false; }
                 if (!dec_bytes(it->second, &tmp)) return false;
                 aux.push_back((uint8_t)(key >> 16)); aux.push_back((uint8_t)(key >> 8)); aux.push_back((uint8_t)key);
@@ -355,6 +357,7 @@ struct CramReader::Impl {
                 if (ri != ref_tid) { if (!fa || !fa->fetch(hdr.names[(size_t)ri], &ref)) { err = "CRAM needs the reference FASTA (-f) to reconstruct reads"; return false; } ref_tid = ri; }
                 int32_t fn; if (!geti("FN", &fn)) return false;
                 int64_t refp = (int64_t)ap - 1; int sp = 1, prev = 0;
+                auto ref_at = [&](int64_t x) { return (x >= 0 && x < (int64_t)ref.size()) ? (char)toupper((unsigned char)ref[(size_t)x]) : 'N'; };
                 auto copy_ref = [&](int len) { for (int i = 0; i < len; ++i) { const int64_t x = refp + i; seq[(size_t)(sp - 1 + i)] = (x >= 0 && x < (int64_t)ref.size()) ? (char)toupper((unsigned char)ref[(size_t)x]) : 'N'; } };
                 for (int fi = 0; fi < fn; ++fi) {
                     uint8_t fc; int32_t fp; if (!getb("FC", &fc) || !geti("FP", &fp)) return false;
@@ -362,16 +365,22 @@ struct CramReader::Impl {
                     if (pos > sp) { const int l = pos - sp; copy_ref(l); push_cigar(cg, 0, (uint32_t)l); refp += l; sp = pos; }
                     uint8_t b1; int32_t iv;
                     switch (fc) {
-                        case 'X': if (!getb("BS", &b1)) return false; seq[(size_t)(sp - 1)] = substitute((refp >= 0 && refp < (int64_t)ref.size()) ? ref[(size_t)refp] : 'N', b1); push_cigar(cg, 0, 1); ++refp; ++sp; break;
-                        case 'I': if (!geta("IN", &tmp)) return false; for (size_t i = 0; i < tmp.size(); ++i) seq[(size_t)(sp - 1) + i] = (char)tmp[i]; push_cigar(cg, 1, (uint32_t)tmp.size()); sp += (int)tmp.size(); break;
-                        case 'i': if (!getb("BA", &b1)) return false; seq[(size_t)(sp - 1)] = (char)b1; push_cigar(cg, 1, 1); ++sp; break;
+                        case 'X': if (!getb("BS", &b1)) return false; seq[(size_t)(sp - 1)] = substitute((refp >= 0 && refp < (int64_t)ref.size()) ? ref[(size_t)refp] : 'N', b1); push_cigar(cg, 0, 1); ++refp; ++sp; ++nm; break;
+                        case 'I': if (!geta("IN", &tmp)) return false; for (size_t i = 0; i < tmp.size(); ++i) seq[(size_t)(sp - 1) + i] = (char)tmp[i]; push_cigar(cg, 1, (uint32_t)tmp.size()); sp += (int)tmp.size(); nm += (uint32_t)tmp.size(); break;
+                        case 'i': if (!getb("BA", &b1)) return false; seq[(size_t)(sp - 1)] = (char)b1; push_cigar(cg, 1, 1); ++sp; ++nm; break;
                         case 'S': if (!geta("SC", &tmp)) return false; for (size_t i = 0; i < tmp.size(); ++i) seq[(size_t)(sp - 1) + i] = (char)tmp[i]; push_cigar(cg, 4, (uint32_t)tmp.size()); sp += (int)tmp.size(); break;
-                        case 'D': if (!geti("DL", &iv)) return false; push_cigar(cg, 2, (uint32_t)iv); refp += iv; break;
+                        case 'D': if (!geti("DL", &iv)) return false; push_cigar(cg, 2, (uint32_t)iv);
+                                  nm += refp + iv <= (int64_t)ref.size() ? (uint32_t)iv : (uint32_t)std::max<int64_t>((int64_t)ref.size() - refp, 0);
+                                  refp += iv; break;
                         case 'N': if (!geti("RS", &iv)) return false; push_cigar(cg, 3, (uint32_t)iv); refp += iv; break;
                         case 'H': if (!geti("HC", &iv)) return false; push_cigar(cg, 5, (uint32_t)iv); break;
                         case 'P': if (!geti("PD", &iv)) return false; push_cigar(cg, 6, (uint32_t)iv); break;
-                        case 'B': { uint8_t q; if (!getb("BA", &b1) || !getb("QS", &q)) return false; seq[(size_t)(sp - 1)] = (char)b1; qual[(size_t)(sp - 1)] = q; push_cigar(cg, 0, 1); ++refp; ++sp; break; }
-                        case 'b': if (!geta("BB", &tmp)) return false; for (size_t i = 0; i < tmp.size(); ++i) seq[(size_t)(sp - 1) + i] = (char)tmp[i]; push_cigar(cg, 0, (uint32_t)tmp.size()); refp += (int64_t)tmp.size(); sp += (int)tmp.size(); break;
+                        case 'B': { uint8_t q; if (!getb("BA", &b1) || !getb("QS", &q)) return false; seq[(size_t)(sp - 1)] = (char)b1; qual[(size_t)(sp - 1)] = q; push_cigar(cg, 0, 1);
+                                    if (ref_at(refp) != (char)b1) ++nm;
+                                    ++refp; ++sp; break; }
+                        case 'b': if (!geta("BB", &tmp)) return false;
+                                  for (size_t i = 0; i < tmp.size(); ++i) { seq[(size_t)(sp - 1) + i] = (char)tmp[i]; if (ref_at(refp + (int64_t)i) != (char)tmp[i]) ++nm; }
+                                  push_cigar(cg, 0, (uint32_t)tmp.size()); refp += (int64_t)tmp.size(); sp += (int)tmp.size(); break;
                         case 'Q': { uint8_t q; if (!getb("QS", &q)) return false; qual[(size_t)(pos - 1)] = q; break; }
                         case 'q': if (!geta("QQ", &tmp)) return false; for (size_t i = 0; i < tmp.size(); ++i) qual[(size_t)(pos - 1) + i] = tmp[i]; break;
                         default: err = "unknown CRAM feature code"; return false;
@@ -380,6 +389,10 @@ struct CramReader::Impl {
                 if (sp <= rl) { const int l = rl - sp + 1; copy_ref(l); push_cigar(cg, 0, (uint32_t)l); }
                 if (!geti("MQ", &mq)) return false;
                 if (cf & 1) for (int i = 0; i < rl; ++i) if (!getb("QS", &qual[(size_t)i])) return false;
+                // htslib regenerates NM (and MD, which this path never reads) for a mapped record that was stored without
+                // it — samtools drops both tags when it writes CRAM (cram_decode.c cram_decode_seq, decode_md = 1 by default):
+                // substitutions, inserted and deleted bases, and literal bases that differ from the reference
+                if (!has_nm && !(cf & 8) && ri >= 0) { aux.push_back('N'); aux.push_back('M'); aux.push_back('I'); for (int k = 0; k < 4; ++k) aux.push_back((uint8_t)(nm >> (8 * k))); }
             } else {
                 for (int i = 0; i < rl; ++i) { uint8_t b; if (!getb("BA", &b)) return false; seq[(size_t)i] = (char)b; }
                 if (cf & 1) for (int i = 0; i < rl; ++i) if (!getb("QS", &qual[(size_t)i])) return false;

@@ -135,7 +135,8 @@ def main():
               "twolib.sorted.cram", "twolib.sorted.cram.crai", "rand1k.fa", "rand1k.fa.fai"):
         shutil.copyfile(os.path.join(REF, f), os.path.join(OUT, f))
 
-    # twolib.sorted.cram: 4 reads 60M, flag 0, MAPQ 60, starts 0/60/120/180, perfect match, QUAL 0xFF, no NM/SM
+    # twolib.sorted.cram: 4 reads 60M, flag 0, MAPQ 60, starts 0/60/120/180, perfect match, QUAL 0xFF, no NM/SM stored:
+    # htslib's decoder regenerates NM (= 0 here) for a mapped record stored without it (cram_decode.c cram_decode_seq)
     fa = "".join(l.strip() for l in open(os.path.join(REF, "rand1k.fa")) if not l.startswith(">"))
     assert len(fa) == 1000
     code = {c: i for i, c in enumerate(NT16)}
@@ -145,7 +146,7 @@ def main():
         nib = [code[c] for c in s]
         seq4 = np.array([(nib[j] << 4) | nib[j + 1] for j in range(0, 60, 2)], np.uint8)
         trecs.append(dict(tid=0, pos=i * 60, mapq=60, flag=0, l_seq=60, qname=name, cigar=np.array([60 << 4], np.uint32),
-                          seq4=seq4, qual=np.full(60, 255, np.uint8), aux={"RG": ("Z", lb)}))
+                          seq4=seq4, qual=np.full(60, 255, np.uint8), aux={"RG": ("Z", lb), "NM": ("I", 0)}))
     tl = ["reads1_lb", "reads2_lb"]
     ta = batch_arrays(trecs, {x: x for x in tl}, tl)
     np.savez_compressed(os.path.join(OUT, "twolib.npz"), ref_start=np.int64(0), ref_slice=np.frombuffer(fa.encode(), np.uint8),
