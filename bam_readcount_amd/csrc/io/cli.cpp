@@ -566,22 +566,89 @@ static int run_site_batch(Ctx& c, const std::vector<Site>& sites) {
     return 0;
 }
 
-// "chr", "chr:beg", "chr:beg-end" (1-based, commas allowed) -> tid, 0-based beg, end      (bam_parse_region, :644)
-static bool parse_region(const BamHeader& h, const std::string& s, int* tid, int64_t* beg, int64_t* end) {
-    std::string t; for (char ch : s) if (ch != ',') t.push_back(ch);
-    auto it = h.name2tid.find(t);
-    size_t colon = t.rfind(':');
-    if (it != h.name2tid.end()) { *tid = it->second; *beg = 0; *end = INT_MAX; return true; }
-    if (colon == std::string::npos) return false;
-    it = h.name2tid.find(t.substr(0, colon));
+// A command-line region as samtools-1.10's legacy bam_parse_region reads it (bamreadcount.cpp:644; bam.c: hts_parse_reg, and
+// when that fails the whole string as a contig name): the name ends at the LAST colon; numbers go through
+// hts_parse_decimal (leading white space, sign, thousands commas, fraction, exponent, k/M/G suffix; stderr notes for a
+// discarded fraction and for trailing characters); "chr:beg" runs to the end, beg <= 0 means 1, an interval that is empty
+// or past INT_MAX is no region.  Returns tid, 0-based beg, end.
+static long long parse_decimal_like_htslib(const char* str, const char** strend, std::string* log) {
+    auto push = [](long long v, char ch) { const int d = ch - '0'; return v > (LLONG_MAX - d) / 10 ? LLONG_MAX : 10 * v + d; };
+    long long n = 0; int decimals = 0, e = 0, lost = 0; char sign = '+', esign = '+';
+    while (*str == ' ' || (*str >= '\t' && *str <= '\r')) ++str;
+    const char* q = str;
+    if (*q == '+' || *q == '-') sign = *q++;
+    while (*q) { if (*q >= '0' && *q <= '9') n = push(n, *q++); else if (*q == ',') ++q; else break; }
+    if (*q == '.') { ++q; while (*q >= '0' && *q <= '9') { ++decimals; n = push(n, *q++); } }
+    switch (*q) {
+        case 'e': case 'E':
+            ++q; if (*q == '+' || *q == '-') esign = *q++;
+            while (*q >= '0' && *q <= '9') e = (int)push(e, *q++);
+            if (esign == '-') e = -e;
+            break;
+        case 'k': case 'K': e += 3; ++q; break;
+        case 'm': case 'M': e += 6; ++q; break;
+        case 'g': case 'G': e += 9; ++q; break;
+    }
+    e -= decimals;
+    while (e > 0) { n *= 10; --e; }
+    while (e < 0) { lost += (int)(n % 10); n /= 10; ++e; }
+    if (lost > 0) *log += "[W::hts_parse_decimal] Discarding fractional part of " + std::string(str, q) + "\n";
+    if (strend) *strend = q;
+    else if (*q) *log += "[W::hts_parse_decimal] Ignoring unknown characters after " + std::string(str, q) + "[" + q + "]\n";
+    return sign == '+' ? n : -n;
+}
+
+static bool parse_region(const BamHeader& h, const std::string& s, int* tid, int64_t* beg, int64_t* end, std::string* log) {
+    // (log: what htslib writes to stderr while it parses — the caller prints it when the reference would reach this region)
+    const size_t colon = s.rfind(':');
+    bool ok = true;                                                 // parsable as a region
+    long long b = 0, e = 0;
+    if (colon == std::string::npos) { b = 0; e = LLONG_MAX; }
+    else {
+        const char* hyphen = nullptr;
+        b = parse_decimal_like_htslib(s.c_str() + colon + 1, &hyphen, log) - 1;
+        if (b < 0) b = 0;
+        if (*hyphen == '\0') e = LLONG_MAX;
+        else if (*hyphen == '-') e = parse_decimal_like_htslib(hyphen + 1, nullptr, log);
+        else ok = false;
+        if (ok && b >= e) ok = false;
+    }
+    // hts_parse_reg narrows hts_parse_reg64's positions to int whatever that returned
+    if (b > INT_MAX) { *log += "[E::hts_parse_reg] Position " + std::to_string(b) + " too large\n"; ok = false; }
+    else if (e > INT_MAX) { if (e == LLONG_MAX) e = INT_MAX; else { *log += "[E::hts_parse_reg] Position " + std::to_string(e) + " too large\n"; ok = false; } }
+    size_t name_lim = colon == std::string::npos ? s.size() : colon;
+    if (!ok) { name_lim = s.size(); b = 0; e = INT_MAX; }            // ... but possibly a contig named "foo:a"
+    auto it = h.name2tid.find(s.substr(0, name_lim));
     if (it == h.name2tid.end()) return false;
-    *tid = it->second;
-    const std::string r = t.substr(colon + 1);
-    char* e = nullptr;
-    const long long b = strtoll(r.c_str(), &e, 10);
-    *beg = b > 0 ? b - 1 : 0; *end = INT_MAX;
-    if (*e == '-') { const long long x = strtoll(e + 1, &e, 10); *end = x; }
-    return *beg < *end;
+    *tid = it->second; *beg = b; *end = e;
+    return true;
+}
+
+// One line of the site list as `std::stringstream ss(line); ss >> ref_name >> beg >> end` reads it (bamreadcount.cpp:574-577):
+// fields separated by any white space, the numbers as the stream's num_get takes them — optional sign, decimal digits, stop
+// at the first other character; no digit, or a value outside int, fails the extraction and the line is skipped.
+static bool parse_site_line(const char* p, size_t n, std::string* name, int* beg, int* end) {
+    const char* e = p + n;
+    if (n && e[-1] == '\n') --e;                                   // (getline drops the delimiter; a '\r' stays and is white space)
+    auto space = [](char ch) { return ch == ' ' || (ch >= '\t' && ch <= '\r'); };
+    auto skip = [&]() { while (p < e && space(*p)) ++p; };
+    skip();
+    const char* b = p;
+    while (p < e && !space(*p)) ++p;
+    if (p == b) return false;
+    name->assign(b, p);
+    auto integer = [&](int* out) {
+        skip();
+        bool neg = false;
+        if (p < e && (*p == '+' || *p == '-')) { neg = *p == '-'; ++p; }
+        const char* d = p; long long v = 0; bool over = false;
+        while (p < e && *p >= '0' && *p <= '9') { if (v < (1ll << 40)) v = v * 10 + (*p - '0'); else over = true; ++p; }
+        if (p == d) return false;
+        if (neg) v = -v;
+        if (over || v > 2147483647ll || v < -2147483648ll) return false;
+        *out = (int)v; return true;
+    };
+    return integer(beg) && integer(end);
 }
 
 // ---------------------------------------------------------------- work items and engines
@@ -710,16 +777,19 @@ int main(int argc, char** argv) {
         const bool plan = o.plan_sites > 0 && o.max_cnt >= 1000000 && !c.is_cram;
         Work pend; pend.kind = 1; int64_t pend_bp = 0;
         auto flush = [&]() { if (!pend.sites.empty()) { items.push_back(std::move(pend)); pend = Work(); pend.kind = 1; pend_bp = 0; } };
-        char line[65536];
-        while (fgets(line, sizeof line, fp)) {                                       // ss >> ref_name >> beg >> end (:574-577)
-            char name[4096]; int beg, end;
-            if (sscanf(line, "%4095s %d %d", name, &beg, &end) != 3) continue;
+        char* line = nullptr; size_t line_cap = 0; ssize_t line_len;
+        while ((line_len = getline(&line, &line_cap, fp)) >= 0) {                   // getline + ss >> ref_name >> beg >> end (:574-577)
+            std::string name; int beg, end;
+            if (!parse_site_line(line, (size_t)line_len, &name, &beg, &end)) continue;
             auto it = c.header().name2tid.find(name);
             if (it == c.header().name2tid.end()) {                                   // :580-582 — printed when the reference's loop reaches the line,
                 flush();                                                             // i.e. behind the warnings of the lines before it: a work item of its own
-                char msg[8300]; snprintf(msg, sizeof msg, "%s not found in bam file. Region %s %i %i skipped.\n", name, name, beg, end);
-                Work w; w.kind = 3; w.err = msg; items.push_back(std::move(w)); continue;
+                Work w; w.kind = 3; w.err = name + " not found in bam file. Region " + name + " " + std::to_string(beg) + " " + std::to_string(end) + " skipped.\n";
+                items.push_back(std::move(w)); continue;
             }
+            // pileup_func works on [beg - 2, end) in 0-based terms (:268 takes the position before the first printed one for
+            // its deletions): a line whose end lies before that touches nothing
+            if ((int64_t)end < (int64_t)beg - 1) continue;
             if (beg < 1) beg = 1;
             // (windows near the end of a contig run on their own: fetch_func's "Request for position" lines carry real coordinates)
             if (plan && (int64_t)end - beg < 1000 && (int64_t)end + 100000 < (int64_t)c.header().lengths[(size_t)it->second]) {
@@ -734,14 +804,16 @@ int main(int argc, char** argv) {
             add_region(it->second, (int64_t)beg - 1, end, true);
         }
         flush();
+        free(line);
         fclose(fp);
     } else if (!o.regions.empty()) {
         if (!c.is_cram && !c.idx.load(o.bam)) { fprintf(stderr, "BAM indexing file is not available.\n"); return 1; }                  // :637-640
         for (const std::string& r : o.regions) {
-            int tid; int64_t beg, end;
-            if (!parse_region(c.header(), r, &tid, &beg, &end)) {                    // :645-648: the regions before it have been printed
-                Work w; w.kind = 2; w.err = "Invalid region " + r + "\n"; w.rc = 1; items.push_back(std::move(w)); break;
+            int tid; int64_t beg, end; std::string log;
+            if (!parse_region(c.header(), r, &tid, &beg, &end, &log)) {              // :645-648: the regions before it have been printed
+                Work w; w.kind = 2; w.err = log + "Invalid region " + r + "\n"; w.rc = 1; items.push_back(std::move(w)); break;
             }
+            if (!log.empty()) { Work w; w.kind = 3; w.err = log; items.push_back(std::move(w)); }
             add_region(tid, beg, end, false);
         }
     } else {
@@ -781,7 +853,7 @@ int main(int argc, char** argv) {
         for (Work& w : items) {
             if (w.kind == 0 && w.keep_queue && last_engine >= 0) w.engine = last_engine;
             else w.engine = (int)(rr++ % N);
-            last_engine = w.engine;
+            if (w.kind == 0) last_engine = w.engine;
         }
         std::vector<std::unique_ptr<Ctx> > ctxs(N);
         std::mutex mu; std::condition_variable cv;

@@ -343,30 +343,70 @@ extern "C" int sampileup(samfile_t*, int, bam_pileup_f, void*) {
     return -1;
 }
 
-/* samtools legacy bam_parse_region -> hts_parse_reg: "chr", "chr:beg", "chr:beg-end"; commas ignored; 1-based inclusive
- * begin becomes 0-based; a bare name covers [0, INT_MAX) */
-extern "C" int bam_parse_region(bam_header_t* header, const char* str, int* ref_id, int* begin, int* end) {
-    std::string s;
-    for (const char* p = str; *p; ++p) if (*p != ',' && !isspace((unsigned char)*p)) s += *p;
-    const brcio::BamHeader* h = (const brcio::BamHeader*)header->shim;
-    *ref_id = -1; *begin = 0; *end = INT_MAX;
-    std::string name = s; long long b = 0, e = INT_MAX;
-    const size_t colon = s.rfind(':');
-    std::map<std::string, int>::const_iterator it = h->name2tid.find(s);
-    if (it == h->name2tid.end() && colon != std::string::npos) {
-        name = s.substr(0, colon);
-        const std::string rng = s.substr(colon + 1);
-        char* q = 0;
-        b = strtoll(rng.c_str(), &q, 10);
-        if (b > 0) --b; else b = 0;
-        if (*q == '-') { e = strtoll(q + 1, &q, 10); if (e <= 0) e = INT_MAX; }
-        else if (q != rng.c_str()) e = INT_MAX;
-        it = h->name2tid.find(name);
+/* htslib-1.10 hts_parse_decimal (hts.c), with HTS_PARSE_THOUSANDS_SEP: white space, sign, digits and commas, fraction,
+ * exponent or k/M/G suffix; hts_log warnings (stderr at the default log level) for a discarded fraction and, when the caller
+ * does not take the end pointer, for characters left over. */
+static long long shim_parse_decimal(const char* str, char** strend) {
+    long long n = 0; int decimals = 0, e = 0, lost = 0; char sign = '+', esign = '+';
+    while (isspace((unsigned char)*str)) str++;
+    const char* s = str;
+    if (*s == '+' || *s == '-') sign = *s++;
+    while (*s) {
+        if (isdigit((unsigned char)*s)) { const int d = *s++ - '0'; n = n > (LLONG_MAX - d) / 10 ? LLONG_MAX : 10 * n + d; }
+        else if (*s == ',') s++;
+        else break;
     }
-    if (it == h->name2tid.end()) return -1;
-    if (b > e) return -1;
-    *ref_id = it->second; *begin = (int)b; *end = (int)(e > INT_MAX ? INT_MAX : e);
-    return 0;
+    if (*s == '.') { s++; while (isdigit((unsigned char)*s)) { const int d = *s++ - '0'; decimals++; n = n > (LLONG_MAX - d) / 10 ? LLONG_MAX : 10 * n + d; } }
+    switch (*s) {
+        case 'e': case 'E':
+            s++; if (*s == '+' || *s == '-') esign = *s++;
+            while (isdigit((unsigned char)*s)) e = 10 * e + (*s++ - '0');
+            if (esign == '-') e = -e;
+            break;
+        case 'k': case 'K': e += 3; s++; break;
+        case 'm': case 'M': e += 6; s++; break;
+        case 'g': case 'G': e += 9; s++; break;
+    }
+    e -= decimals;
+    while (e > 0) n *= 10, e--;
+    while (e < 0) lost += (int)(n % 10), n /= 10, e++;
+    if (lost > 0) fprintf(stderr, "[W::hts_parse_decimal] Discarding fractional part of %.*s\n", (int)(s - str), str);
+    if (strend) *strend = (char*)s;
+    else if (*s) fprintf(stderr, "[W::hts_parse_decimal] Ignoring unknown characters after %.*s[%s]\n", (int)(s - str), str, s);
+    return sign == '+' ? n : -n;
+}
+
+/* samtools-1.10 legacy bam_parse_region (bam.c) over htslib-1.10 hts_parse_reg / hts_parse_reg64: the name ends at the last
+ * colon; "chr" covers [0, INT_MAX), "chr:beg" runs to the end; an interval that does not parse, is empty or lies past
+ * INT_MAX makes the whole string the name. */
+extern "C" int bam_parse_region(bam_header_t* header, const char* str, int* ref_id, int* begin, int* end) {
+    const brcio::BamHeader* h = (const brcio::BamHeader*)header->shim;
+    const char* name_lim = 0;
+    long long b = 0, e = 0;
+    const char* colon = strrchr(str, ':');
+    if (!colon) { b = 0; e = LLONG_MAX; name_lim = str + strlen(str); }
+    else {
+        char* hyphen = 0;
+        b = shim_parse_decimal(colon + 1, &hyphen) - 1;
+        if (b < 0) b = 0;
+        name_lim = colon;
+        if (*hyphen == '\0') e = LLONG_MAX;
+        else if (*hyphen == '-') e = shim_parse_decimal(hyphen + 1, 0);
+        else name_lim = 0;
+        if (name_lim && b >= e) name_lim = 0;
+    }
+    if (b > INT_MAX) { fprintf(stderr, "[E::hts_parse_reg] Position %lld too large\n", b); name_lim = 0; }
+    else if (e > INT_MAX) {
+        if (e == LLONG_MAX) e = INT_MAX;
+        else { fprintf(stderr, "[E::hts_parse_reg] Position %lld too large\n", e); name_lim = 0; }
+    }
+    *begin = (int)b; *end = (int)e;
+    std::map<std::string, int>::const_iterator it;
+    if (name_lim) it = h->name2tid.find(std::string(str, name_lim));
+    else { it = h->name2tid.find(str); *begin = 0; *end = INT_MAX; }
+    *ref_id = it == h->name2tid.end() ? -1 : it->second;
+    if (*ref_id == -1) return -1;
+    return *begin <= *end ? 0 : -1;
 }
 
 /* samtools legacy bam_get_library: LB of the @RG line named by the read's RG:Z tag; NULL when either is missing */

@@ -639,6 +639,54 @@ def _cli_fuzz(cli, ref_lib, tmp_path, seeds, one_device=False):
         assert (a.returncode, a.stdout == b.stdout, a.stderr == b.stderr) == (b.returncode, True, True), (seed, opts, extra, args)
 
 
+def _weird_site_line(rng):
+    c = str(rng.choice(["chrA", "chrB", "chrZ", "", "chrA ", "*"]))
+    a = int(rng.integers(1, 900)); b = a + int(rng.choice([0, 1, 5, 50]))
+    forms = ["%s\t%d\t%d" % (c, a, b), "%s %d %d" % (c, a, b), "%s\t%d\t%d\textra\tcols" % (c, a, b), "%s\t%d\t%d\r" % (c, a, b),
+             "%s\t%d" % (c, a), "%s" % c, "", "\t\t", "%s\t%d\t%d" % (c, b + 3, a), "%s\t%d\t%d" % (c, a + 1, a - 1), "%s\t0\t%d" % (c, b), "%s\t-5\t%d" % (c, b),
+             "%s\t%d\t-1" % (c, a), "%s\t%d.5\t%d" % (c, a, b), "%s\t1e2\t%d" % (c, b), "%s\tx\t%d" % (c, b), "%s\t%d\ty" % (c, a), "%s\t+%d\t%d" % (c, a, b),
+             "%s\t%d\t99999999999" % (c, a), "%s\t99999999999\t%d" % (c, b), "%s\t%d\t%d" % (c, a, 2**31 - 1), "%s\t%d\t%d" % (c, a, 2**31),
+             "  %s\t%d\t%d" % (c, a, b), "%s\t\t%d\t%d" % (c, a, b), "#%s\t%d\t%d" % (c, a, b), "%s\t0x10\t%d" % (c, b), "%s\t010\t%d" % (c, b),
+             "%s\t%d\t%d abc" % (c, a, b), "%s\t%d\t%dabc" % (c, a, b), "%s\t%d,000\t%d" % (c, a, b), "%s\t%d-%d" % (c, a, b)]
+    return forms[int(rng.integers(0, len(forms)))]
+
+
+def _weird_region(rng):
+    c = str(rng.choice(["chrA", "chrB", "chrZ", "", "chrA ", "*", "chra"]))
+    a = int(rng.integers(1, 900)); b = a + int(rng.choice([0, 1, 5, 50]))
+    forms = ["%s:%d-%d" % (c, a, b), "%s" % c, "%s:" % c, "%s:%d" % (c, a), "%s:%d-" % (c, a), "%s:-%d" % (c, b), "%s:%d-%d" % (c, b + 2, a),
+             "%s:%d-%d" % (c, a, a), "%s:0-%d" % (c, b), "%s:1,0%02d-2,000" % (c, a % 100), "%s:abc" % c, "%s:%d-%d-%d" % (c, a, b, b + 5),
+             "%s:1e2-%d" % (c, b), " %s:%d-%d" % (c, a, b), "%s:%d - %d" % (c, a, b), "%s:%d-%d " % (c, a, b), "%s:%d-99999999999" % (c, a),
+             "%s:99999999999-%d" % (c, b), "%s:%d-2147483647" % (c, a), "%s:%d-2147483648" % (c, a), "%s:+%d-%d" % (c, a, b), "%s:%d.5-%d" % (c, a, b),
+             "%s:%d-%dx" % (c, a, b), "%s:-" % c, "%s::%d-%d" % (c, a, b), ":%d-%d" % (a, b), "%s:%d--%d" % (c, a, b), "%s:0" % c, "%s:0-0" % c, "%s:1-1" % c,
+             "%s: %d- %d" % (c, a, b), "%s:0.%dk-1k" % (c, a % 10), "%s:1K" % c]
+    return forms[int(rng.integers(0, len(forms)))]
+
+
+def test_cli_malformed_site_lines_and_regions_equal_reference_main(ref_lib, tmp_path):
+    """The reference reads a site-list line with `stringstream >> name >> int >> int` (bamreadcount.cpp:574-577: any white
+    space, signs, a number cut at the first other character, overflow = no line) and works on [beg - 2, end) (:268); a
+    command-line region goes through samtools' bam_parse_region (:644; restated in oracle/ref_shim/shim_hts.cpp from
+    htslib-1.10's hts_parse_reg / hts_parse_decimal: last colon, k/M/G, fractions, notes on stderr).  Malformed, reversed,
+    overflowing and unknown-contig input: stdout, stderr and the exit code of the drop-in are the reference's."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    from test_cli import SIM_CLI
+    d = tmp_path / "case"; d.mkdir()
+    _random_cli_case(4242, str(d))
+    rng = np.random.default_rng(11)
+    for it in range(120):
+        o = ["-w", "2", "-f", "r.fa"] + (["-p"] if rng.random() < 0.3 else [])
+        if it % 2 == 0:
+            txt = "\n".join(_weird_site_line(rng) for _ in range(int(rng.integers(1, 12)))) + ("" if rng.random() < 0.3 else "\n")
+            open(d / "w.txt", "w", newline="").write(txt)
+            args = ["-l", "w.txt", "x.bam"]
+        else:
+            txt = None; args = ["x.bam"] + [_weird_region(rng) for _ in range(int(rng.integers(1, 4)))]
+        a = subprocess.run([REF_CLI] + o + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        b = subprocess.run([SIM_CLI] + o + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert (a.returncode, a.stdout == b.stdout, a.stderr == b.stderr) == (b.returncode, True, True), (it, txt, args)
+
+
 @pytest.mark.parametrize("block", range(3))
 def test_cli_random_command_lines_equal_reference_main(ref_lib, tmp_path, block):
     """Differential fuzz of the whole command line against the reference's own main(): random BAMs (all CIGAR operators, reads
