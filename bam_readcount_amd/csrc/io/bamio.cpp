@@ -195,6 +195,47 @@ std::vector<std::string> BamHeader::libraries() const {
     return std::vector<std::string>(s.begin(), s.end());
 }
 
+// The two ways the reference looks at @RG lines:
+//  * per read, samtools-1.10's legacy bam_get_library (bamreadcount.cpp:280): the first @RG line of the header text with an
+//    ID and an LB whose ID equals the read's RG:Z — the scan takes the LAST "ID:" / "LB:" that follow a tab, and only
+//    accepts an ID that is itself followed by a tab (an ID at the end of its line never matches); LB is cut at 1023 bytes;
+//  * once, find_library_names (:92-111) for the "Expect library" lines: every tag of every @RG line EXCEPT THE FIRST
+//    (`while (tag->next) { tag = tag->next; ...`) that starts with "LB", so an LB written first is not announced and a
+//    second LB on a line is.
+void BamHeader::parse_read_groups() {
+    rg2lb.clear(); expected.clear();
+    std::set<std::string> exp;
+    size_t p = 0;
+    while (p < text.size()) {
+        size_t e = text.find('\n', p); if (e == std::string::npos) e = text.size();
+        if (text.compare(p, 3, "@RG") == 0) {
+            size_t id = std::string::npos, lb = std::string::npos; char last = '\t';
+            for (size_t q = p + 4; q < e; ++q) {
+                if (last == '\t') { if (text.compare(q, 3, "LB:") == 0) lb = q + 3; else if (text.compare(q, 3, "ID:") == 0) id = q + 3; }
+                last = text[q];
+            }
+            if (id != std::string::npos && lb != std::string::npos) {
+                const size_t ie = text.find('\t', id);
+                if (ie != std::string::npos && ie < e) {
+                    size_t le = lb; while (le < e && text[le] != '\t') ++le;
+                    const std::string key = text.substr(id, ie - id);
+                    if (!rg2lb.count(key)) rg2lb[key] = text.substr(lb, std::min<size_t>(le - lb, 1023));
+                }
+            }
+            size_t le = e; if (le > p && text[le - 1] == '\r') --le;
+            bool first = true;
+            for (size_t q = p + 3; q < le;) {
+                if (text[q] == '\t') { ++q; continue; }
+                size_t t = text.find('\t', q); if (t == std::string::npos || t > le) t = le;
+                if (!first && t - q >= 2 && text.compare(q, 2, "LB") == 0) exp.insert(t - q > 3 ? text.substr(q + 3, t - q - 3) : std::string());
+                first = false; q = t;
+            }
+        }
+        p = e + 1;
+    }
+    expected.assign(exp.begin(), exp.end());
+}
+
 bool BamReader::open(const std::string& path) {
     if (!bg_.open(path)) { err_ = bg_.error(); return false; }
     uint8_t m[8];
@@ -215,25 +256,7 @@ bool BamReader::open(const std::string& path) {
         hdr_.name2tid[name] = (int)hdr_.names.size();
         hdr_.names.push_back(name); hdr_.lengths.push_back((int32_t)rd32(b4));
     }
-    // @RG lines: ID -> LB
-    size_t p = 0;
-    while (p < hdr_.text.size()) {
-        size_t e = hdr_.text.find('\n', p); if (e == std::string::npos) e = hdr_.text.size();
-        const std::string line = hdr_.text.substr(p, e - p);
-        if (line.compare(0, 3, "@RG") == 0) {
-            std::string id, lb; bool has_lb = false;
-            size_t q = 3;
-            while (q < line.size()) {
-                size_t t = line.find('\t', q + 1); if (t == std::string::npos) t = line.size();
-                const std::string f = line.substr(q + 1, t - q - 1);
-                if (f.compare(0, 3, "ID:") == 0) id = f.substr(3);
-                if (f.compare(0, 3, "LB:") == 0) { lb = f.substr(3); has_lb = true; }
-                q = t;
-            }
-            if (!id.empty() && has_lb) hdr_.rg2lb[id] = lb;
-        }
-        p = e + 1;
-    }
+    hdr_.parse_read_groups();
     return true;
 }
 

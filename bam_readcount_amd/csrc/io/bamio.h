@@ -69,8 +69,10 @@ struct BamHeader {
     std::vector<std::string> names;
     std::vector<int32_t> lengths;
     std::map<std::string, int> name2tid;
-    std::map<std::string, std::string> rg2lb;      // @RG ID -> LB (only RG lines that carry an LB)
-    std::vector<std::string> libraries() const;    // sorted unique LB values (find_library_names, bamreadcount.cpp:92-111)
+    std::map<std::string, std::string> rg2lb;      // read group -> library as bam_get_library resolves it (bamreadcount.cpp:280)
+    std::vector<std::string> expected;             // what find_library_names collects (:92-111), sorted: the "Expect library" lines
+    std::vector<std::string> libraries() const;    // sorted unique libraries a read can resolve to
+    void parse_read_groups();                      // fills rg2lb and expected from text
 };
 
 struct Chunk { uint64_t beg, end; };

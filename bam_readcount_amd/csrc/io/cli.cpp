@@ -713,7 +713,7 @@ int main(int argc, char** argv) {
     const double t_start = now_s();
     if (!open_inputs(c, false)) return 1;
     const double t_inputs = now_s();
-    for (const std::string& l : c.libs) fprintf(stderr, "Expect library: %s in BAM\n", l.c_str());                                         // :526-529
+    for (const std::string& l : c.header().expected) fprintf(stderr, "Expect library: %s in BAM\n", l.c_str());                                         // :526-529
     if (o.distribution) { fprintf(stderr, "Not currently supporting distributions\n"); return 1; }                                          // :367 (the reference throws)
     // -d below any real depth changes which reads bam_plp_push keeps, and that depends on everything buffered before:
     // no internal pieces then (the planner is off for the same reason)

@@ -469,9 +469,10 @@ bool CramReader::open(const std::string& path, Fasta* fasta) {
         const std::string line = d.hdr.text.substr(p, e - p);
         auto field = [&](const char* key) { const std::string k = std::string("\t") + key + ":"; const size_t q = line.find(k); if (q == std::string::npos) return std::string(); size_t t = line.find('\t', q + 1); return line.substr(q + k.size(), (t == std::string::npos ? line.size() : t) - q - k.size()); };
         if (line.compare(0, 3, "@SQ") == 0) { const std::string n = field("SN"); d.hdr.name2tid[n] = (int)d.hdr.names.size(); d.hdr.names.push_back(n); d.hdr.lengths.push_back(atoi(field("LN").c_str())); }
-        if (line.compare(0, 3, "@RG") == 0) { const std::string id = field("ID"); d.rg_ids.push_back(id); if (line.find("\tLB:") != std::string::npos) d.hdr.rg2lb[id] = field("LB"); }
+        if (line.compare(0, 3, "@RG") == 0) d.rg_ids.push_back(field("ID"));
         p = e + 1;
     }
+    d.hdr.parse_read_groups();
     return true;
 }
 

@@ -63,6 +63,7 @@ struct brc_engine {
     samfile_t in;
     bam_hdr_t hdr;
     brcio::BamHeader shim_hdr;
+    std::string hdr_text;          // header text for bam_get_library (one @RG line per library)
     std::vector<char*> target_names;
     // region
     bool in_region = false; int32_t tid = 0, beg0 = 0, end = 0; const char* ref = 0; int64_t ref_len = 0;
@@ -96,7 +97,9 @@ int brc_create(const brc_config* cfg, brc_engine** out) {
     e->d.per_lib = cfg->per_lib != 0; e->d.insertion_centric = cfg->insertion_centric != 0;
     e->d.indel_queue_map = indel_queue_map_t();
     memset(&e->in, 0, sizeof e->in); memset(&e->hdr, 0, sizeof e->hdr);
-    for (size_t l = 0; l < e->lib_names.size(); ++l) { char rg[32]; snprintf(rg, sizeof rg, "rg%d", (int)l); e->shim_hdr.rg2lb[rg] = e->lib_names[l]; }
+    // bam_get_library scans the header text: one @RG line per library of the batch interface (read i of library l carries RG:Z:rg<l>)
+    for (size_t l = 0; l < e->lib_names.size(); ++l) e->hdr_text += "@RG\tID:rg" + std::to_string(l) + "\tLB:" + e->lib_names[l] + "\n";
+    e->hdr.text = &e->hdr_text[0]; e->hdr.l_text = e->hdr_text.size();
     e->hdr.shim = &e->shim_hdr;
     e->in.header = &e->hdr;
     e->d.in = &e->in;

@@ -409,16 +409,39 @@ extern "C" int bam_parse_region(bam_header_t* header, const char* str, int* ref_
     return *begin <= *end ? 0 : -1;
 }
 
-/* samtools legacy bam_get_library: LB of the @RG line named by the read's RG:Z tag; NULL when either is missing */
+/* samtools-1.10 legacy bam_get_library (bam.c), restated: scan the header TEXT for the first @RG line that has an ID and an
+ * LB and whose ID is the read's RG:Z — the last "ID:" / "LB:" after a tab count, the ID must be followed by a tab, the LB is
+ * copied (at most 1023 bytes) into a static buffer */
 extern "C" const char* bam_get_library(bam_header_t* header, const bam1_t* b) {
-    static std::string buf;      // the legacy API returns a static buffer too
-    const uint8_t* rg = bam_aux_get(b, "RG");
-    if (!rg || *rg != 'Z') return 0;
-    const brcio::BamHeader* h = (const brcio::BamHeader*)header->shim;
-    std::map<std::string, std::string>::const_iterator it = h->rg2lb.find((const char*)(rg + 1));
-    if (it == h->rg2lb.end()) return 0;
-    buf = it->second;
-    return buf.c_str();
+    const char* rg = (const char*)bam_aux_get(b, "RG");
+    const char* cp = header->text;
+    if (!rg || !cp) return 0;
+    rg++;
+    while (*cp) {
+        const char *ID = 0, *LB = 0;
+        char last = '\t';
+        if (strncmp(cp, "@RG", 3) != 0) {
+            while (*cp && *cp != '\n') cp++;
+            if (*cp) cp++;
+            continue;
+        }
+        cp += 4;
+        while (*cp && *cp != '\n') {
+            if (last == '\t') {
+                if (strncmp(cp, "LB:", 3) == 0) LB = cp + 3;
+                else if (strncmp(cp, "ID:", 3) == 0) ID = cp + 3;
+            }
+            last = *cp++;
+        }
+        if (!ID || !LB) continue;
+        if (strncmp(rg, ID, strlen(rg)) != 0 || ID[strlen(rg)] != '\t') continue;
+        static char LB_text[1024];
+        for (cp = LB; *cp && *cp != '\t' && *cp != '\n'; cp++) {}
+        const size_t n = (size_t)(cp - LB) < 1023 ? (size_t)(cp - LB) : 1023;
+        strncpy(LB_text, LB, n); LB_text[n] = 0;
+        return LB_text;
+    }
+    return 0;
 }
 
 /* sam_hdr_parse, reduced to what find_library_names walks: every @RG line as a linked list of its tags in file order */

@@ -687,6 +687,47 @@ def test_cli_malformed_site_lines_and_regions_equal_reference_main(ref_lib, tmp_
         assert (a.returncode, a.stdout == b.stdout, a.stderr == b.stderr) == (b.returncode, True, True), (it, txt, args)
 
 
+def test_cli_read_group_header_quirks_equal_reference_main(ref_lib, tmp_path):
+    """@RG lines as the reference sees them: find_library_names (bamreadcount.cpp:92-111) skips the first tag of every line
+    and takes every later "LB" one (its "Expect library" lines); per read, samtools' bam_get_library (:280, restated in the
+    shim from bam.c) wants an ID that is followed by a tab and takes the last LB of the first matching line.  LB written
+    first, twice, empty or missing, duplicate IDs, reads naming an unknown group, a comment that mentions LB."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bamio
+    from test_cli import SIM_CLI, _write_fasta
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    for seed in range(24):
+        rng = np.random.default_rng(seed)
+        d = tmp_path / ("h%d" % seed); d.mkdir()
+        L = 1200
+        ref = synth.make_ref(rng, L + 600)
+        arrs = synth.make_batch(seed, ref, 250, style="mixed", n_libs=3, region=(0, L), p_nolib=0.05)
+        ids = ["rg0", "rg1", "rg2"]
+
+        def rgline(i):
+            k = rng.random(); lb = str(rng.choice(["libA", "libB", "libC", "", "lib A", "LB"]))
+            if k < 0.15: return "@RG\tLB:%s\tID:%s" % (lb, ids[i])
+            if k < 0.30: return "@RG\tID:%s\tSM:s" % ids[i]
+            if k < 0.40: return "@RG\tID:%s\tLB:%s\tLB:other" % (ids[i], lb)
+            if k < 0.50: return "@RG\tID:%s\tPL:x\tLB:%s\tSM:s" % (ids[i], lb)
+            if k < 0.55: return "@RG\tSM:s\tID:%s\tLB:%s" % (ids[i], lb)
+            return "@RG\tID:%s\tLB:%s\tSM:s" % (ids[i], lb)
+        lines = [rgline(i) for i in range(3)]
+        if rng.random() < 0.2: lines.append("@RG\tID:rg0\tLB:dup")
+        if rng.random() < 0.2: lines = lines[:2]
+        if rng.random() < 0.1: lines = []
+        if rng.random() < 0.3: lines.insert(0, "@CO\tsome comment LB:fake")
+        rgs = [ids[int(l)] if l >= 0 else None for l in arrs["lib"]]
+        bamio.write_bam(str(d / "x.bam"), [("chrA", L + 600)], arrs, np.zeros(len(arrs["pos"]), int), rg_of_read=rgs, rg_lines=lines)
+        _write_fasta(d / "r.fa", [("chrA", ref)])
+        for o in (["-p"], [], ["-p", "-i"]):
+            args = ["-w", "2", "-f", "r.fa"] + o + ["x.bam", "chrA:100-400"]
+            a = subprocess.run([REF_CLI] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            b = subprocess.run([SIM_CLI] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert (a.returncode, a.stdout == b.stdout, a.stderr == b.stderr) == (b.returncode, True, True), (seed, o, lines)
+
+
 @pytest.mark.parametrize("block", range(3))
 def test_cli_random_command_lines_equal_reference_main(ref_lib, tmp_path, block):
     """Differential fuzz of the whole command line against the reference's own main(): random BAMs (all CIGAR operators, reads
