@@ -352,6 +352,7 @@ int brc_set_option(brc_engine* e, int option, int64_t value) {
         case BRC_OPT_EXPECT_BASES: e->hint_bases = value > 0 ? (size_t)value : 0; return BRC_OK;
         case BRC_OPT_DEVICE_TEXT: e->device_text = value != 0; return BRC_OK;
         case BRC_OPT_CONTINUES_PREVIOUS: e->continues = value == 1; e->warn_skip_lead = value == 1 || value == 2; return BRC_OK;
+        case BRC_OPT_MAX_COUNT: if (value < INT32_MIN || value > INT32_MAX) return fail(e, BRC_E_ARG, "max count out of range"); e->cfg.max_cnt = (int32_t)value; return BRC_OK;
         case BRC_OPT_EXPECT_TEXT: { if (value <= 0) return BRC_OK; const int rc = e->be->reserve_text((size_t)value); return rc ? fail(e, rc, e->be->last_error()) : BRC_OK; }
         default: return fail(e, BRC_E_ARG, "unknown engine option");
     }

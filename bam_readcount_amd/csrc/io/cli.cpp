@@ -34,6 +34,7 @@ using namespace brcio;
 
 struct Options {
     bool help = false, version = false, per_lib = false, insertion_centric = false, distribution = false;
+    unsigned seen = 0;                 // options given so far
     int min_mapq = 0, min_bq = 0, max_cnt = 10000000;
     long long max_warnings = -1;
     std::string site_list, fasta, bam;
@@ -82,6 +83,10 @@ static bool apply(Options& o, const OptSpec& sp, const std::string& v, std::stri
         if (errno || e == v.c_str() || *e) { *err = "the argument ('" + v + "') for option '--" + sp.l + "' is invalid"; return false; }
         *out = x; return true;
     };
+    // (boost::program_options: none of the reference's options is composing — a second occurrence is an error, :463)
+    const unsigned bit = 1u << (unsigned)(&sp - kSpecs);
+    if (o.seen & bit) { *err = std::string("option '--") + sp.l + "' cannot be specified more than once"; return false; }
+    o.seen |= bit;
     long long x = 0;
     switch (sp.s) {
         case 'h': o.help = true; return true;
@@ -700,6 +705,7 @@ static int make_engine(Ctx& c, int device) {
     cfg.ref_len_check = (!o.site_list.empty() && c.have_fa) ? 1 : 0;                                                                        // :594-600
     const int rc = brc_create(&cfg, &c.eng);
     if (rc == 0) brc_set_option(c.eng, BRC_OPT_TEXT_ONLY, 1);      // the command line only prints: no dense planes on the host
+    if (rc == 0 && o.max_cnt <= 0) brc_set_option(c.eng, BRC_OPT_MAX_COUNT, o.max_cnt);   // -d 0 / -d -3 reach the iterator as they are (:592,:651)
     return rc;
 }
 

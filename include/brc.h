@@ -213,6 +213,10 @@ void brc_destroy(brc_engine*);
  *                      2: the piece before this one ran on ANOTHER engine: the queues start empty here and the lead position
  *                      queues its deletions as usual, only brc_region_warnings leaves its events out. */
 #define BRC_OPT_CONTINUES_PREVIOUS 6
+/*   BRC_OPT_MAX_COUNT  the pileup's max-count exactly as given (-d, :440/:592/:651 bam_plp_set_maxcnt): brc_config.max_cnt
+ *   treats values <= 0 as "the default"; the reference hands them to the iterator, whose drop rule `count > maxcnt` then holds
+ *   for every read that starts where the previous one did.  Set before the next region's reads are pushed. */
+#define BRC_OPT_MAX_COUNT 7
 int  brc_set_option(brc_engine*, int option, int64_t value);
 /* Target name printed in column 1 of the following regions' lines (BRC_OPT_DEVICE_TEXT: the text is written at
  * brc_fetch_result time, before brc_format_region names the contig); copied. */

@@ -561,7 +561,10 @@ int brc_format_region_parts(brc_engine* e, const brc_result* r, const char* chro
 }
 
 /* the oracle always builds the dense planes; the option only changes how the product lays its result out */
-int brc_set_option(brc_engine* e, int option, int64_t value) { (void)value; return (e && option >= BRC_OPT_TEXT_ONLY && option <= BRC_OPT_CONTINUES_PREVIOUS) ? BRC_OK : BRC_E_ARG; }
+int brc_set_option(brc_engine* e, int option, int64_t value) {
+    if (e && option == BRC_OPT_MAX_COUNT) { e->cfg.max_cnt = (int32_t)value; return BRC_OK; }      /* the iterator's maxcnt as given, <= 0 included */
+    return (e && option >= BRC_OPT_TEXT_ONLY && option <= BRC_OPT_CONTINUES_PREVIOUS) ? BRC_OK : BRC_E_ARG;
+}
 int brc_set_chrom(brc_engine* e, const char* chrom) { return (e && chrom) ? BRC_OK : BRC_E_ARG; }
 
 int brc_create(const brc_config* cfg, brc_engine** out) {

@@ -676,6 +676,7 @@ def test_cli_malformed_site_lines_and_regions_equal_reference_main(ref_lib, tmp_
     rng = np.random.default_rng(11)
     for it in range(120):
         o = ["-w", "2", "-f", "r.fa"] + (["-p"] if rng.random() < 0.3 else [])
+        if rng.random() < 0.2: o += ["-d", str(int(rng.choice([0, -3, 1])))]       # (:592,:651 hand any value to the iterator)
         if it % 2 == 0:
             txt = "\n".join(_weird_site_line(rng) for _ in range(int(rng.integers(1, 12)))) + ("" if rng.random() < 0.3 else "\n")
             open(d / "w.txt", "w", newline="").write(txt)
