@@ -570,6 +570,53 @@ def test_random_scenarios_equal_reference_compiled(oracle_lib, sim_lib, ref_lib,
             assert got == want, (seed, style, kw, regions, clear, route)
 
 
+def _extreme_case(seed):
+    """Reads with values at the edges of their BAM fields: base qualities 0 / 93 / 255, MAPQ 0 / 255, NM / SM of any int32
+    (negative too), proper pairs without SM, long reads (2 kb, many operators), thresholds that sit on those edges."""
+    rng = np.random.default_rng(seed)
+    RL = int(rng.integers(300, 1500))
+    ref = synth.make_ref(rng, RL + 3000, weird=float(rng.choice([0, 0.02])))
+    n_libs = int(rng.choice([1, 2]))
+    long_reads = rng.random() < 0.3
+    arrs = synth.make_batch(seed + 7000, ref, int(rng.integers(30, 300)), style=str(rng.choice(["simple", "indel", "wild", "mixed"])), n_libs=n_libs,
+                            read_len=(200, 2000) if long_reads else (20, 150), region=(0, RL))
+    n = len(arrs["pos"]); q = arrs["qual"]
+    if rng.random() < 0.5:
+        idx = rng.integers(0, len(q), max(1, len(q) // 10)); q[idx] = rng.choice([0, 1, 2, 93, 94, 127, 128, 200, 254, 255], len(idx)).astype(q.dtype)
+    if rng.random() < 0.5:
+        idx = rng.integers(0, n, max(1, n // 5)); arrs["mapq"][idx] = rng.choice([0, 1, 254, 255], len(idx)).astype(arrs["mapq"].dtype)
+    if rng.random() < 0.5:
+        idx = rng.integers(0, n, max(1, n // 5)); arrs["nm"][idx] = rng.choice([0, 1, 255, 256, 65535, 70000, 2**31 - 1, -1, -5], len(idx)).astype(arrs["nm"].dtype)
+    if rng.random() < 0.5:
+        idx = rng.integers(0, n, max(1, n // 5)); arrs["sm"][idx] = rng.choice([0, 255, 256, 100000, 2**31 - 1, -1], len(idx)).astype(arrs["sm"].dtype)
+    if rng.random() < 0.3:
+        arrs["flag"][rng.integers(0, n, max(1, n // 3))] |= 2
+    kw = dict(min_mapq=int(rng.choice([0, 1, 255])), min_bq=int(rng.choice([0, 2, 94, 255])), insertion_centric=bool(rng.random() < 0.4))
+    if rng.random() < 0.4:
+        kw.update(per_lib=True, lib_names=["lib%c" % (65 + i) for i in range(n_libs)])
+    a0 = int(rng.integers(0, RL))
+    return ref, arrs, [(0, RL + 50), (a0, a0 + 300)], kw
+
+
+def _extreme_check(lib, ref_lib, seeds, oracle_lib=None):
+    for seed in seeds:
+        ref, arrs, regions, kw = _extreme_case(seed)
+        want, _ = parity.run_engine(ref_lib, arrs, regions, ref=ref, clear_queue=False, **kw)
+        routes = [(lib, {}), (lib, dict(text_only=True)), (lib, dict(device_text="chrS"))] + ([(oracle_lib, {})] if oracle_lib is not None else [])
+        for l, route in routes:
+            got, _ = parity.run_engine(l, arrs, regions, ref=ref, clear_queue=False, **route, **kw)
+            assert got == want, (seed, kw, route)
+
+
+def test_extreme_field_values_equal_reference_compiled(oracle_lib, sim_lib, ref_lib):
+    _extreme_check(sim_lib, ref_lib, range(24), oracle_lib)
+
+
+@pytest.mark.gpu
+def test_extreme_field_values_equal_reference_compiled_gpu(hip_lib, ref_lib):
+    _extreme_check(hip_lib, ref_lib, range(100, 112))
+
+
 def _random_cli_case(seed, d):
     """A random two-contig BAM (+ .bai, FASTA) and a random bam-readcount command line over it; returns (reference options,
     drop-in extras, positional arguments, environment of the drop-in)."""
