@@ -135,7 +135,7 @@ static bool parse_args(int argc, char** argv, Options& o, std::string* err) {
         }
         for (size_t k = 1; k < a.size(); ++k) {              // short options, sticky
             const OptSpec* hit = nullptr;
-            for (const OptSpec& sp : kSpecs) if (sp.s > 2 && sp.s == a[k]) hit = &sp;
+            for (const OptSpec& sp : kSpecs) if (sp.s >= 'A' && sp.s == a[k]) hit = &sp;      // (codes below 'A' name the long-only --brc-* options)
             if (!hit) { *err = std::string("unrecognised option '-") + a[k] + "'"; return false; }
             if (hit->takes_value) {
                 std::string v = a.substr(k + 1);
