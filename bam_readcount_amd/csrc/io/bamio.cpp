@@ -416,10 +416,10 @@ bool Fasta::open(const std::string& path) {
     path_ = path;
     FILE* f = fopen((path + ".fai").c_str(), "r");
     if (!f) { err_ = "cannot open " + path + ".fai"; return false; }
-    char name[4096]; long long len, off; int lb, lw;
+    char name[4096]; long long len, off, lb, lw;                     // (a contig written on one line: its width can pass 2^31)
     char line[8192];
     while (fgets(line, sizeof line, f)) {
-        if (sscanf(line, "%4095s %lld %lld %d %d", name, &len, &off, &lb, &lw) == 5) { Ent e; e.len = len; e.off = off; e.linebases = lb; e.linewidth = lw; idx_[name] = e; }
+        if (sscanf(line, "%4095s %lld %lld %lld %lld", name, &len, &off, &lb, &lw) == 5 && lb > 0 && lw >= lb) { Ent e; e.len = len; e.off = off; e.linebases = lb; e.linewidth = lw; idx_[name] = e; }
     }
     fclose(f);
     FILE* g = fopen(path.c_str(), "rb");

@@ -138,7 +138,7 @@ class Fasta {
     const std::string& error() const { return err_; }
 
   private:
-    struct Ent { int64_t len, off; int linebases, linewidth; };
+    struct Ent { int64_t len, off, linebases, linewidth; };
     std::map<std::string, Ent> idx_;
     std::string path_, err_;
 };

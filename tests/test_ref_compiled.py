@@ -570,6 +570,37 @@ def test_random_scenarios_equal_reference_compiled(oracle_lib, sim_lib, ref_lib,
             assert got == want, (seed, style, kw, regions, clear, route)
 
 
+def test_cli_coordinates_beyond_the_bai_limit_equal_reference_main(ref_lib, tmp_path):
+    """Reads past 2^29 on a contig that needs a CSI index (depth 6): regions, a bare start and a site list print what the
+    reference's main() prints."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bamio
+    from test_cli import SIM_CLI
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    d = tmp_path
+    OFF = (1 << 29) + 1000; CL = OFF + 5000
+    rng = np.random.default_rng(1)
+    small = synth.make_ref(rng, 3600)
+    arrs = synth.make_batch(5, small, 400, style="mixed", n_libs=2, region=(0, 3000))
+    arrs["pos"] = (arrs["pos"].astype(np.int64) + OFF).astype(arrs["pos"].dtype)
+    rgs = [["rg0", "rg1"][int(l)] if l >= 0 else None for l in arrs["lib"]]
+    bamio.write_bam(str(d / "x.bam"), [("chrBig", CL)], arrs, np.zeros(len(arrs["pos"]), int), rg_of_read=rgs,
+                    rg_lines=["@RG\tID:rg0\tLB:libA\tSM:s", "@RG\tID:rg1\tLB:libB\tSM:s"], csi=(14, 6))
+    with open(d / "r.fa", "wb") as f:                     # one line: N up to the reads, the reads' reference, N to the end
+        f.write(b">chrBig\n"); left = OFF; chunk = b"N" * (1 << 22)
+        while left > 0:
+            f.write(chunk[:min(left, len(chunk))]); left -= min(left, len(chunk))
+        f.write(bytes(small)); f.write(b"N" * (CL - OFF - len(small))); f.write(b"\n")
+    open(d / "r.fa.fai", "w").write("chrBig\t%d\t8\t%d\t%d\n" % (CL, CL, CL + 1))
+    open(d / "s.txt", "w").write("".join("chrBig\t%d\t%d\n" % (OFF + x, OFF + x + 2) for x in (5, 900, 901, 2500)))
+    for args in (["x.bam", "chrBig:%d-%d" % (OFF + 100, OFF + 600)], ["-p", "x.bam", "chrBig:%d" % (OFF + 2000)], ["-l", "s.txt", "x.bam"]):
+        a = subprocess.run([REF_CLI, "-w", "1", "-f", "r.fa"] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        b = subprocess.run([SIM_CLI, "-w", "1", "-f", "r.fa"] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert (a.returncode, a.stdout == b.stdout, a.stderr == b.stderr) == (b.returncode, True, True), args
+        assert a.returncode == 0 and a.stdout.count(b"\n") >= 12
+
+
 def _extreme_case(seed):
     """Reads with values at the edges of their BAM fields: base qualities 0 / 93 / 255, MAPQ 0 / 255, NM / SM of any int32
     (negative too), proper pairs without SM, long reads (2 kb, many operators), thresholds that sit on those edges."""

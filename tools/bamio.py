@@ -171,7 +171,7 @@ def write_bam(path, contigs, arrs, tids, rg_of_read=None, rg_lines=(), qnames=No
         seq = bytes(arrs["seq4"][int(arrs["seq_off"][i]):int(arrs["seq_off"][i]) + (L + 1) // 2])
         qual = bytes(arrs["qual"][int(arrs["qual_off"][i]):int(arrs["qual_off"][i]) + L])
         b = _reg2bin(pos, end)
-        body = struct.pack("<iiBBHHHiiii", tid, pos, len(qn), int(arrs["mapq"][i]), b, nc, flag, L, -1, -1, 0) + qn + \
+        body = struct.pack("<iiBBHHHiiii", tid, pos, len(qn), int(arrs["mapq"][i]), b & 0xffff, nc, flag, L, -1, -1, 0) + qn + \
             b"".join(struct.pack("<I", int(c)) for c in cig) + seq + qual + aux
         cur.extend(struct.pack("<i", len(body)) + body)
         v1 = (coff << 16) | len(cur)
