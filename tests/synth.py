@@ -13,8 +13,41 @@ def make_ref(rng, length, weird=0.0):
     return ref
 
 
+def dense_cigar(rng, L):
+    """Long-read style: match runs of about a dozen bases separated by 1-3 base insertions / deletions, now and then a
+    reference skip; consumes exactly L query bases."""
+    ops = []; rem = L
+    if rng.random() < 0.3 and rem > 30:
+        s = int(rng.integers(1, 25)); ops.append((4, s)); rem -= s
+    while rem > 0:
+        m = min(rem, int(rng.geometric(0.08))); ops.append((0, m)); rem -= m
+        if rem <= 1:
+            if rem == 1: ops.append((0, 1)); rem = 0
+            break
+        k = rng.random()
+        if k < 0.45:
+            i = min(rem - 1, int(rng.integers(1, 4))); ops.append((1, i)); rem -= i
+        elif k < 0.9:
+            ops.append((2, int(rng.integers(1, 4))))
+        else:
+            ops.append((3, int(rng.integers(5, 200))))
+    out = []
+    for o, l in ops:
+        if out and out[-1][0] == o: out[-1] = (o, out[-1][1] + l)
+        else: out.append((o, l))
+    if out[-1][0] != 0:                     # end on a match: take the base from an earlier run
+        out.append((0, 1))
+        for i, (o, l) in enumerate(out[:-1]):
+            if o == 0 and l > 1:
+                out[i] = (o, l - 1); break
+    assert sum(l for o, l in out if o in (0, 1, 4)) == L
+    return out
+
+
 def random_cigar(rng, L, style):
-    """Return list of (op,len) consuming exactly L query bases.  style: 'simple' | 'indel' | 'wild'."""
+    """Return list of (op,len) consuming exactly L query bases.  style: 'simple' | 'indel' | 'wild' | 'dense'."""
+    if style == "dense" and L >= 8:
+        return dense_cigar(rng, L)
     if style == "simple" or L < 8:
         return [(0, L)]
     ops = []

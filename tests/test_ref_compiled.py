@@ -601,6 +601,35 @@ def test_cli_coordinates_beyond_the_bai_limit_equal_reference_main(ref_lib, tmp_
         assert a.returncode == 0 and a.stdout.count(b"\n") >= 12
 
 
+def _long_read_check(lib, ref_lib, seeds):
+    """Reads of 3-20 kb with an insertion or deletion every dozen bases (a thousand and more CIGAR operators each, skips
+    of up to 200 bases): one region over everything and a narrow one inside."""
+    for seed in seeds:
+        rng = np.random.default_rng(seed)
+        RL = 30000
+        ref = synth.make_ref(rng, RL + 45000)
+        n_libs = int(rng.choice([1, 2]))
+        arrs = synth.make_batch(seed + 9000, ref, int(rng.integers(10, 30)), style="dense", n_libs=n_libs, read_len=(3000, 20000), region=(0, RL))
+        assert len(arrs["cigar"]) > 200 * len(arrs["pos"])
+        kw = dict(min_bq=int(rng.choice([0, 10])), insertion_centric=bool(rng.random() < 0.5))
+        if rng.random() < 0.5:
+            kw.update(per_lib=True, lib_names=["lib%c" % (65 + i) for i in range(n_libs)])
+        regions = [(0, RL + 25000), (12000, 12800)]
+        want, _ = parity.run_engine(ref_lib, arrs, regions, ref=ref, clear_queue=False, **kw)
+        for route in (dict(), dict(text_only=True), dict(device_text="chrS")):
+            got, _ = parity.run_engine(lib, arrs, regions, ref=ref, clear_queue=False, **route, **kw)
+            assert got == want, (seed, kw, route)
+
+
+def test_long_dense_indel_reads_equal_reference_compiled(sim_lib, ref_lib):
+    _long_read_check(sim_lib, ref_lib, range(2))
+
+
+@pytest.mark.gpu
+def test_long_dense_indel_reads_equal_reference_compiled_gpu(hip_lib, ref_lib):
+    _long_read_check(hip_lib, ref_lib, range(10, 13))
+
+
 def _extreme_case(seed):
     """Reads with values at the edges of their BAM fields: base qualities 0 / 93 / 255, MAPQ 0 / 255, NM / SM of any int32
     (negative too), proper pairs without SM, long reads (2 kb, many operators), thresholds that sit on those edges."""
