@@ -145,7 +145,7 @@ class Fasta {
 
 // ---------------------------------------------------------------- CRAM 3.0 (minimal, cram.cpp)
 // The reference reads CRAM through htslib's samopen (bamreadcount.cpp:411, test-data/twolib.sorted.cram); this reader
-// covers reference-based CRAM 3.0 (raw / gzip / rANS 4x8 / bzip2 / lzma blocks).  Records come out in BAM layout, mapped
+// covers CRAM 3.0 — external, embedded or no reference; raw / gzip / rANS 4x8 / bzip2 / lzma blocks.  Records come out in BAM layout, mapped
 // ones with the NM tag htslib's decoder generates when the file does not store it.
 class CramReader {
   public:

@@ -208,7 +208,10 @@ struct CramReader::Impl {
     // per-slice decode state
     std::map<int, Block> ext; Block core; BitReader br;
     std::map<std::string, Enc> ds; std::map<int32_t, Enc> tagenc;
-    bool rn_preserved = true, ap_delta = true; uint8_t sm[5] = {0, 0, 0, 0, 0};
+    bool rn_preserved = true, ap_delta = true, ref_required = true; uint8_t sm[5] = {0, 0, 0, 0, 0};
+    // the reference of the slice being decoded: the contig loaded from the FASTA, or the slice's embedded reference block
+    // (its first base is the slice's alignment start), or none (RR = 0: every base is stored as a feature)
+    const uint8_t* emb_ref = nullptr; int64_t emb_start0 = 0, emb_len = 0;
     std::vector<std::vector<int32_t> > td;      // tag dictionary: per line the tag keys (tag0<<16|tag1<<8|type)
 
     // containers of the file, found by one walk over their headers
@@ -287,7 +290,7 @@ struct CramReader::Impl {
     bool geta(const char* k, std::vector<uint8_t>* v) { const Enc* e = series(k); if (!e) { err = std::string("CRAM data series ") + k + " missing"; return false; } return dec_bytes(*e, v); }
 
     bool parse_comp_header(const Block& b) {
-        ds.clear(); tagenc.clear(); td.clear(); rn_preserved = true; ap_delta = true;
+        ds.clear(); tagenc.clear(); td.clear(); rn_preserved = true; ap_delta = true; ref_required = true;
         Cur c; c.p = b.data.data(); c.e = c.p + b.data.size();
         { const int32_t sz = c.itf8(); Cur m; m.p = c.p; m.e = c.p + sz; c.p += sz;
           const int n = m.itf8();
@@ -295,7 +298,7 @@ struct CramReader::Impl {
               const char k0 = (char)m.u8(), k1 = (char)m.u8();
               if (k0 == 'R' && k1 == 'N') rn_preserved = m.u8() != 0;
               else if (k0 == 'A' && k1 == 'P') ap_delta = m.u8() != 0;
-              else if (k0 == 'R' && k1 == 'R') (void)m.u8();
+              else if (k0 == 'R' && k1 == 'R') ref_required = m.u8() != 0;
               else if (k0 == 'S' && k1 == 'M') for (int j = 0; j < 5; ++j) sm[j] = m.u8();
               else if (k0 == 'T' && k1 == 'D') { const int32_t l = m.itf8(); const uint8_t* t = m.p; m.p += l;
                   std::vector<int32_t> line; for (int32_t o = 0; o < l;) { if (t[o] == 0) { td.push_back(line); line.clear(); ++o; } else { line.push_back((t[o] << 16) | (t[o + 1] << 8) | t[o + 2]); o += 3; } } }
@@ -354,23 +357,31 @@ struct CramReader::Impl {
             std::string seq((size_t)std::max(rl, 0), 'N'); std::vector<uint8_t> qual((size_t)std::max(rl, 0), 0xff); std::vector<uint32_t> cg;
             int32_t mq = 0;
             if (!(bf & 4)) {
-                if (ri != ref_tid) { if (!fa || !fa->fetch(hdr.names[(size_t)ri], &ref)) { err = "CRAM needs the reference FASTA (-f) to reconstruct reads"; return false; } ref_tid = ri; }
+                const bool have_ref = emb_ref != nullptr || ref_required;              // htslib: s->ref
+                if (!emb_ref && ref_required && ri != ref_tid) { if (!fa || !fa->fetch(hdr.names[(size_t)ri], &ref)) { err = "CRAM needs the reference FASTA (-f) to reconstruct reads"; return false; } ref_tid = ri; }
+                // raw reference character at 0-based x ('N' outside what is known)
+                auto ref_raw = [&](int64_t x) -> char {
+                    if (emb_ref) { const int64_t k = x - emb_start0; return (k >= 0 && k < emb_len) ? (char)emb_ref[k] : 'N'; }
+                    if (!ref_required) return 'N';
+                    return (x >= 0 && x < (int64_t)ref.size()) ? ref[(size_t)x] : 'N';
+                };
+                const int64_t ref_end = emb_ref ? emb_start0 + emb_len : (ref_required ? (int64_t)ref.size() : 0);
                 int32_t fn; if (!geti("FN", &fn)) return false;
                 int64_t refp = (int64_t)ap - 1; int sp = 1, prev = 0;
-                auto ref_at = [&](int64_t x) { return (x >= 0 && x < (int64_t)ref.size()) ? (char)toupper((unsigned char)ref[(size_t)x]) : 'N'; };
-                auto copy_ref = [&](int len) { for (int i = 0; i < len; ++i) { const int64_t x = refp + i; seq[(size_t)(sp - 1 + i)] = (x >= 0 && x < (int64_t)ref.size()) ? (char)toupper((unsigned char)ref[(size_t)x]) : 'N'; } };
+                auto ref_at = [&](int64_t x) { return (char)toupper((unsigned char)ref_raw(x)); };
+                auto copy_ref = [&](int len) { for (int i = 0; i < len; ++i) seq[(size_t)(sp - 1 + i)] = ref_at(refp + i); };
                 for (int fi = 0; fi < fn; ++fi) {
                     uint8_t fc; int32_t fp; if (!getb("FC", &fc) || !geti("FP", &fp)) return false;
                     const int pos = prev + fp; prev = pos;
                     if (pos > sp) { const int l = pos - sp; copy_ref(l); push_cigar(cg, 0, (uint32_t)l); refp += l; sp = pos; }
                     uint8_t b1; int32_t iv;
                     switch (fc) {
-                        case 'X': if (!getb("BS", &b1)) return false; seq[(size_t)(sp - 1)] = substitute((refp >= 0 && refp < (int64_t)ref.size()) ? ref[(size_t)refp] : 'N', b1); push_cigar(cg, 0, 1); ++refp; ++sp; ++nm; break;
+                        case 'X': if (!getb("BS", &b1)) return false; seq[(size_t)(sp - 1)] = substitute(ref_raw(refp), b1); push_cigar(cg, 0, 1); ++refp; ++sp; ++nm; break;
                         case 'I': if (!geta("IN", &tmp)) return false; for (size_t i = 0; i < tmp.size(); ++i) seq[(size_t)(sp - 1) + i] = (char)tmp[i]; push_cigar(cg, 1, (uint32_t)tmp.size()); sp += (int)tmp.size(); nm += (uint32_t)tmp.size(); break;
                         case 'i': if (!getb("BA", &b1)) return false; seq[(size_t)(sp - 1)] = (char)b1; push_cigar(cg, 1, 1); ++sp; ++nm; break;
                         case 'S': if (!geta("SC", &tmp)) return false; for (size_t i = 0; i < tmp.size(); ++i) seq[(size_t)(sp - 1) + i] = (char)tmp[i]; push_cigar(cg, 4, (uint32_t)tmp.size()); sp += (int)tmp.size(); break;
                         case 'D': if (!geti("DL", &iv)) return false; push_cigar(cg, 2, (uint32_t)iv);
-                                  nm += refp + iv <= (int64_t)ref.size() ? (uint32_t)iv : (uint32_t)std::max<int64_t>((int64_t)ref.size() - refp, 0);
+                                  nm += refp + iv <= ref_end ? (uint32_t)iv : (uint32_t)std::max<int64_t>(ref_end - refp, 0);
                                   refp += iv; break;
                         case 'N': if (!geti("RS", &iv)) return false; push_cigar(cg, 3, (uint32_t)iv); refp += iv; break;
                         case 'H': if (!geti("HC", &iv)) return false; push_cigar(cg, 5, (uint32_t)iv); break;
@@ -392,7 +403,7 @@ struct CramReader::Impl {
                 // htslib regenerates NM (and MD, which this path never reads) for a mapped record that was stored without
                 // it — samtools drops both tags when it writes CRAM (cram_decode.c cram_decode_seq, decode_md = 1 by default):
                 // substitutions, inserted and deleted bases, and literal bases that differ from the reference
-                if (!has_nm && !(cf & 8) && ri >= 0) { aux.push_back('N'); aux.push_back('M'); aux.push_back('I'); for (int k = 0; k < 4; ++k) aux.push_back((uint8_t)(nm >> (8 * k))); }
+                if (!has_nm && !(cf & 8) && ri >= 0 && have_ref) { aux.push_back('N'); aux.push_back('M'); aux.push_back('I'); for (int k = 0; k < 4; ++k) aux.push_back((uint8_t)(nm >> (8 * k))); }
             } else {
                 for (int i = 0; i < rl; ++i) { uint8_t b; if (!getb("BA", &b)) return false; seq[(size_t)i] = (char)b; }
                 if (cf & 1) for (int i = 0; i < rl; ++i) if (!getb("QS", &qual[(size_t)i])) return false;
@@ -510,6 +521,15 @@ bool CramReader::fetch_impl(int tid, int64_t beg, int64_t end, void (*thunk)(voi
             const bool slice_may = sref == -2 || sref < 0 || (sref == tid && (int64_t)sstart - 1 < end && (int64_t)sstart - 1 + sspan > beg);
             if (!slice_may) { for (int i = 0; i < snb; ++i) if (!d.skip_block(c)) return false; continue; }
             for (int i = 0; i < snb; ++i) { Block b; if (!d.read_block(c, &b)) return false; if (b.type == 5) d.core = b; else d.ext[b.id] = b; }
+            // (slice header, continued: the block content ids, then the id of an embedded reference block or -1)
+            { const int32_t ncid = s.itf8(); for (int32_t i = 0; i < ncid; ++i) (void)s.itf8(); }
+            const int32_t emb = s.bad ? -1 : s.itf8();
+            d.emb_ref = nullptr; d.emb_len = 0;
+            if (!s.bad && emb >= 0) {
+                auto it = d.ext.find(emb);
+                if (it == d.ext.end()) { d.err = "CRAM slice names an embedded reference block it does not have"; return false; }
+                d.emb_ref = it->second.data.data(); d.emb_len = (int64_t)it->second.data.size(); d.emb_start0 = (int64_t)sstart - 1;
+            }
             auto cb = [&](const BamRecord& r) { thunk(ctx, r); };
             if (!d.decode_slice(sref, sstart, snrec, tid, beg, end, cb)) return false;
         }

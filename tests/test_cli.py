@@ -145,6 +145,18 @@ def synthetic_bam(tmp_path_factory):
     cramio.write_cram(str(d / "syn_rans.cram"), [("chrA", 5000), ("chrB", 3000)], arrs, tids, refs, rg_of_read=rgs,
                       rg_lines=["@RG\tID:rgA1\tLB:libA\tSM:s", "@RG\tID:rgB1\tLB:libB\tSM:s"], per_container=310,
                       methods=(4, 5, 0, 1, 2, 3, 5), int_codecs=True)
+    # embedded reference slices, and a reference-less file (RR = 0, every base a feature): neither needs the FASTA to rebuild
+    # its reads — syn_alt.fa differs from the reference they were written against at every 50th base
+    cramio.write_cram(str(d / "syn_emb.cram"), [("chrA", 5000), ("chrB", 3000)], arrs, tids, refs, rg_of_read=rgs,
+                      rg_lines=["@RG\tID:rgA1\tLB:libA\tSM:s", "@RG\tID:rgB1\tLB:libB\tSM:s"], per_container=280, embed_ref=True)
+    cramio.write_cram(str(d / "syn_noref.cram"), [("chrA", 5000), ("chrB", 3000)], arrs, tids, refs, rg_of_read=rgs,
+                      rg_lines=["@RG\tID:rgA1\tLB:libA\tSM:s", "@RG\tID:rgB1\tLB:libB\tSM:s"], per_container=280, no_ref=True)
+    bamio.write_bam(str(d / "syn_m_nonm.bam"), [("chrA", 5000), ("chrB", 3000)], dict(norm, tags=arrs["tags"], nm=arrs["nm"]), tids, rg_of_read=rgs,
+                    rg_lines=["@RG\tID:rgA1\tLB:libA\tSM:s", "@RG\tID:rgB1\tLB:libB\tSM:s"], block_bytes=6000)
+    alt = [r.copy() for r in refs]
+    for r in alt:
+        r[::50] = np.frombuffer(bytes({65: 67, 67: 71, 71: 84, 84: 65}.get(int(b) & ~32, 65) for b in r[::50]), np.uint8)
+    _write_fasta(d / "syn_alt.fa", [("chrA", alt[0]), ("chrB", alt[1])])
     return d
 
 
@@ -354,6 +366,34 @@ def test_cli_cram_reader_equals_bam_reader_cpu(synthetic_bam):
     a = subprocess.run([SIM_CLI, "-w", "0", "-f", "syn.fa", "-p", "-l", sl, "--brc-plan", "0", "syn_m.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     b = subprocess.run([SIM_CLI, "-w", "0", "-f", "syn.fa", "-p", "-l", sl, "syn.cram"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and a.stdout.count(b"\n") > 60
+
+
+def _cram_embedded_and_reference_less(cli, d):
+    regs = ["chrA:1-5000", "chrB", "chrA:2400-2450"]
+    # (the container that holds the end of chrA and the start of chrB is a multi-reference slice: those cannot embed a
+    # reference and are rebuilt from the FASTA like any other — the embedded-reference comparison stays clear of it)
+    eregs = ["chrA:1-4200", "chrB:1300-3000", "chrA:2400-2450"]
+    for extra in ([], ["-p", "-i"]):
+        # embedded reference: the reads come back as written even under another FASTA, NM generated from the embedded bases
+        a = subprocess.run([cli, "-w", "3", "-f", "syn_alt.fa"] + extra + ["syn_m.bam"] + eregs, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        b = subprocess.run([cli, "-w", "3", "-f", "syn_alt.fa"] + extra + ["syn_emb.cram"] + eregs, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
+        assert a.stdout.count(b"\n") > 5000 and a.stdout == b.stdout and a.stderr == b.stderr, extra
+        # ... which matters: rebuilt from the other FASTA the reads would differ
+        c = subprocess.run([cli, "-w", "3", "-f", "syn_alt.fa"] + extra + ["syn.cram"] + eregs, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert c.returncode == 0 and c.stdout != a.stdout
+        # no reference required: same reads, and no NM is made up for the records stored without one (htslib: no s->ref)
+        a = subprocess.run([cli, "-w", "3", "-f", "syn_alt.fa"] + extra + ["syn_m_nonm.bam"] + regs, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        b = subprocess.run([cli, "-w", "3", "-f", "syn_alt.fa"] + extra + ["syn_noref.cram"] + regs, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
+        assert a.stdout == b.stdout and a.stderr == b.stderr and b"NM tag" in b.stderr, extra
+
+
+def test_cli_cram_embedded_reference_and_reference_less_cpu(synthetic_bam):
+    """CRAM slices that carry their own reference (slice header: embedded reference block id) and files written without one
+    (preservation map RR = 0) decode without consulting the FASTA."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    _cram_embedded_and_reference_less(SIM_CLI, synthetic_bam)
 
 
 def test_cli_cram_rans_bzip2_lzma_blocks_equal_bam_reader_cpu(synthetic_bam):

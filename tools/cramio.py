@@ -252,8 +252,12 @@ IDS = dict(RI=1, RL=2, AP=3, RG=4, RN=5, MF=6, NS=7, NP=8, TS=9, NF=10, FN=11, F
            HC=20, PD=21, BA=22, QS=23, BB=24, BBL=25, QQ=26)
 
 
-def write_cram(path, contigs, arrs, tids, refs, rg_of_read=None, rg_lines=(), qnames=None, per_container=300, methods=(0, 1), int_codecs=False):
-    """contigs [(name, len)], arrs = brc_read_batch arrays, tids = contig per read, refs = list of uint8 reference arrays."""
+def write_cram(path, contigs, arrs, tids, refs, rg_of_read=None, rg_lines=(), qnames=None, per_container=300, methods=(0, 1), int_codecs=False,
+               embed_ref=False, no_ref=False):
+    """contigs [(name, len)], arrs = brc_read_batch arrays, tids = contig per read, refs = list of uint8 reference arrays.
+    embed_ref: every single-reference slice carries its stretch of the reference as an external block (slice header field
+    "embedded reference bases block content id"); no_ref: RR = 0 in the preservation map and every aligned base stored as
+    a 'b' feature (what samtools writes with no_ref=1)."""
     text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % c for c in contigs) + "".join(l + "\n" for l in rg_lines)
     rg_ids = [dict(f.split(":", 1) for f in l.split("\t")[1:])["ID"] for l in rg_lines]
     out = bytearray(b"CRAM" + bytes([3, 0]) + b"brc-test-cram".ljust(20, b"\0"))
@@ -306,7 +310,9 @@ def write_cram(path, contigs, arrs, tids, refs, rg_of_read=None, rg_lines=(), qn
                 ref = refs[tid]; feats = []; rp = pos; sp = 1
                 for c in cig:
                     op, ln = c & 15, c >> 4
-                    if op in (0, 7, 8):
+                    if op in (0, 7, 8) and no_ref:
+                        feats.append((sp, "b", seq[sp - 1:sp - 1 + ln])); rp += ln; sp += ln
+                    elif op in (0, 7, 8):
                         for j in range(ln):
                             rb = chr(ref[rp + j]).upper() if 0 <= rp + j < len(ref) else "N"
                             b = seq[sp - 1 + j]
@@ -328,6 +334,7 @@ def write_cram(path, contigs, arrs, tids, refs, rg_of_read=None, rg_lines=(), qn
                     if fc == "X": ext["BS"].append(v)
                     elif fc == "B": ext["BA"] += v[0].encode(); ext["QS"].append(v[1])
                     elif fc == "i": ext["BA"] += v.encode()
+                    elif fc == "b": ext["BBL"] += itf8(len(v)); ext["BB"] += v.encode()
                     elif fc == "I": ext["INL"] += itf8(len(v)); ext["IN"] += v.encode()
                     elif fc == "S": ext["SC"] += v.encode() + b"\0"
                     elif fc == "D":
@@ -343,7 +350,7 @@ def write_cram(path, contigs, arrs, tids, refs, rg_of_read=None, rg_lines=(), qn
                 max_end = max(max_end, pos + 1)
         # ---- compression header
         td = b"".join(l + b"\0" for l in td_lines)
-        pres = [b"RN" + b"\1", b"AP" + (b"\0" if multi else b"\1"), b"RR" + b"\1", b"SM" + sm_bytes(), b"TD" + itf8(len(td)) + td]
+        pres = [b"RN" + b"\1", b"AP" + (b"\0" if multi else b"\1"), b"RR" + (b"\0" if no_ref else b"\1"), b"SM" + sm_bytes(), b"TD" + itf8(len(td)) + td]
         pm = itf8(len(pres)) + b"".join(pres)
         dse = {"BF": enc(3, itf8(len(border)) + b"".join(itf8(s) for s in border) + itf8(len(border)) + b"".join(itf8(blens[s]) for s in border)),
                "CF": e_huff1(1), "MQ": e_beta(3, 9), "RN": e_stop(0, IDS["RN"]), "SC": e_stop(0, IDS["SC"]),
@@ -367,8 +374,14 @@ def write_cram(path, contigs, arrs, tids, refs, rg_of_read=None, rg_lines=(), qn
         sref = -2 if multi else ctids[0]
         sstart = 0 if multi else first_pos; sspan = 0 if multi else max_end - first_pos + 1
         ids = [IDS[k] for k in sorted(IDS, key=lambda kk: IDS[kk]) if ext[k]] + ([tl_ids] if len(td_lines) > 1 else []) + list(tag_blocks)
+        emb_id = -1
+        if embed_ref and not multi:
+            emb_id = 99
+            r0 = refs[ctids[0]]
+            stretch = bytes(r0[sstart - 1:sstart - 1 + sspan]) + b"N" * max(0, sstart - 1 + sspan - len(r0))
+            eblocks.append(block(methods[0], 4, emb_id, stretch)); ids.append(emb_id)
         sh = itf8(sref) + itf8(sstart) + itf8(sspan) + itf8(len(idx)) + ltf8(c0) + itf8(1 + len(eblocks)) + itf8(len(ids)) + \
-            b"".join(itf8(x) for x in ids) + itf8(-1) + bytes(16)
+            b"".join(itf8(x) for x in ids) + itf8(emb_id) + bytes(16)
         blocks = [ch, block(0, 2, 0, sh), block(methods[-1] if len(methods) > 2 else 0, 5, 0, bytes(core.out))] + eblocks
         out += container(sref, sstart, sspan, len(idx), blocks, [len(ch)])
     out += bytes.fromhex("0f000000ffffffff0fe0454f460000000001000 5bdd94f0001000606010001000100ee63014b".replace(" ", ""))
