@@ -215,8 +215,11 @@ struct CramReader::Impl {
     std::vector<std::vector<int32_t> > td;      // tag dictionary: per line the tag keys (tag0<<16|tag1<<8|type)
 
     // containers of the file, found by one walk over their headers
-    struct Cont { int32_t ref, start, span, nrec, len; off_t body_at; };
+    // containers of the file: from the .crai when there is one (header_at known, the header itself read on first use), else
+    // from one walk over the container headers
+    struct Cont { int32_t ref, start, span, nrec, len; off_t body_at; off_t header_at; bool loaded; };
     std::vector<Cont> table; bool table_built = false;
+    std::string path;
 
     // step over a block without decompressing it
     bool skip_block(Cur& c) {
@@ -323,6 +326,36 @@ struct CramReader::Impl {
     static void push_cigar(std::vector<uint32_t>& cg, uint32_t op, uint32_t len) {
         if (!len) return;
         if (!cg.empty() && (cg.back() & 15u) == op) cg.back() += len << 4; else cg.push_back((len << 4) | op);
+    }
+
+    // <cram>.crai (gzip text, one line per slice and reference: seq id, alignment start, span, container offset, slice offset,
+    // slice size): one table entry per container, spanning its lines; several references in it = a multi-reference container
+    bool load_crai() {
+        gzFile z = gzopen((path + ".crai").c_str(), "rb");
+        if (!z) return false;
+        std::string text; char buf[65536]; int n;
+        while ((n = gzread(z, buf, sizeof buf)) > 0) text.append(buf, (size_t)n);
+        gzclose(z);
+        std::map<long long, Cont> by_off;
+        size_t p = 0; bool any = false;
+        while (p < text.size()) {
+            size_t e = text.find('\n', p); if (e == std::string::npos) e = text.size();
+            long long sid, st, sp, coff, soff, ssz;
+            if (sscanf(text.substr(p, e - p).c_str(), "%lld %lld %lld %lld %lld %lld", &sid, &st, &sp, &coff, &soff, &ssz) == 6) {
+                any = true;
+                auto it = by_off.find(coff);
+                if (it == by_off.end()) { Cont c; c.ref = (int32_t)sid; c.start = (int32_t)st; c.span = (int32_t)sp; c.nrec = 0; c.len = 0; c.body_at = 0; c.header_at = (off_t)coff; c.loaded = false; by_off[coff] = c; }
+                else {
+                    Cont& c = it->second;
+                    if (c.ref != (int32_t)sid) c.ref = -2;
+                    else { const long long a = std::min<long long>(c.start, st), b = std::max<long long>((long long)c.start + c.span, st + sp); c.start = (int32_t)a; c.span = (int32_t)(b - a); }
+                }
+            }
+            p = e + 1;
+        }
+        if (!any) return false;
+        for (auto& kv : by_off) if (kv.second.ref != -1) table.push_back(kv.second);     // (unmapped-only containers are never asked for)
+        return true;
     }
 
     // decode the records of one slice; cb(record) for those overlapping [beg,end) on tid
@@ -440,7 +473,9 @@ bool CramReader::is_cram(const std::string& path) {
     return n == 4 && memcmp(m, "CRAM", 4) == 0;
 }
 
-static bool read_container_header(FILE* f, int32_t* length, int32_t* ref, int32_t* start, int32_t* span, int32_t* nrec, int32_t* nblocks, std::vector<int32_t>* land) {
+// *bad (when given): set when bytes were there but are not a container header (its CRC32 does not match), left alone at the
+// end of the file
+static bool read_container_header(FILE* f, int32_t* length, int32_t* ref, int32_t* start, int32_t* span, int32_t* nrec, int32_t* nblocks, std::vector<int32_t>* land, bool* bad = nullptr) {
     uint8_t buf[1024];
     const off_t at = ftello(f);
     const size_t got = fread(buf, 1, sizeof buf, f);
@@ -448,9 +483,11 @@ static bool read_container_header(FILE* f, int32_t* length, int32_t* ref, int32_
     Cur c; c.p = buf; c.e = buf + got;
     *length = c.i32(); *ref = c.itf8(); *start = c.itf8(); *span = c.itf8(); *nrec = c.itf8();
     (void)c.ltf8(); (void)c.ltf8(); *nblocks = c.itf8();
-    const int nl = c.itf8(); land->clear(); for (int i = 0; i < nl; ++i) land->push_back(c.itf8());
-    c.p += 4;                                   // crc32
-    if (c.bad) return false;
+    const int nl = c.itf8(); land->clear(); for (int i = 0; i < nl && !c.bad; ++i) land->push_back(c.itf8());
+    if (c.bad || c.p + 4 > c.e) { if (bad) *bad = true; return false; }
+    uint32_t want = 0; for (int k = 0; k < 4; ++k) want |= (uint32_t)c.p[k] << (8 * k);
+    if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), buf, (uInt)(c.p - buf)) != want) { if (bad) *bad = true; return false; }
+    c.p += 4;
     fseeko(f, at + (off_t)(c.p - buf), SEEK_SET);
     return true;
 }
@@ -460,6 +497,7 @@ bool CramReader::open(const std::string& path, Fasta* fasta) {
     d.fa = fasta;
     d.f = fopen(path.c_str(), "rb");
     if (!d.f) { d.err = "cannot open " + path; return false; }
+    d.path = path;
     uint8_t def[26];
     if (fread(def, 1, 26, d.f) != 26 || memcmp(def, "CRAM", 4) != 0) { d.err = "not a CRAM file"; return false; }
     if (def[4] != 3) { d.err = "only CRAM 3.x is supported by the minimal reader"; return false; }
@@ -493,20 +531,32 @@ bool CramReader::fetch_impl(int tid, int64_t beg, int64_t end, void (*thunk)(voi
     // The container headers are walked ONCE (reference id, start, span, where the body lies): later queries — a site list is
     // one query per line — go straight to the containers that can overlap.  (A .crai would give the same table without the walk.)
     if (!d.table_built) {
-        fseeko(d.f, d.data_start, SEEK_SET);
-        for (;;) {
-            int32_t len, ref, start, span, nrec, nblocks; std::vector<int32_t> land;
-            if (!read_container_header(d.f, &len, &ref, &start, &span, &nrec, &nblocks, &land)) break;
-            Impl::Cont ct; ct.ref = ref; ct.start = start; ct.span = span; ct.nrec = nrec; ct.len = len; ct.body_at = ftello(d.f);
-            if (!(ref == -1 && nrec == 0) && nrec > 0) d.table.push_back(ct);          // (not the EOF marker / empty containers)
-            if (fseeko(d.f, ct.body_at + len, SEEK_SET) != 0) break;
+        if (!d.load_crai()) {
+            fseeko(d.f, d.data_start, SEEK_SET);
+            for (;;) {
+                int32_t len, ref, start, span, nrec, nblocks; std::vector<int32_t> land;
+                const off_t at = ftello(d.f);
+                bool bad = false;
+                if (!read_container_header(d.f, &len, &ref, &start, &span, &nrec, &nblocks, &land, &bad)) {
+                    if (bad) { d.err = "CRAM container header CRC32 mismatch"; return false; }
+                    break;
+                }
+                Impl::Cont ct; ct.ref = ref; ct.start = start; ct.span = span; ct.nrec = nrec; ct.len = len; ct.body_at = ftello(d.f); ct.header_at = at; ct.loaded = true;
+                if (!(ref == -1 && nrec == 0) && nrec > 0) d.table.push_back(ct);          // (not the EOF marker / empty containers)
+                if (fseeko(d.f, ct.body_at + len, SEEK_SET) != 0) break;
+            }
         }
         d.table_built = true;
     }
     std::vector<uint8_t> body;
-    for (const Impl::Cont& ct : d.table) {
+    for (Impl::Cont& ct : d.table) {
         const bool may = ct.ref == -2 || (ct.ref == tid && (int64_t)ct.start - 1 < end && (int64_t)ct.start - 1 + ct.span > beg);
         if (!may) continue;
+        if (!ct.loaded) {                                                         // an index entry: now read the container's header
+            int32_t ref, start, span, nblocks; std::vector<int32_t> land;
+            if (fseeko(d.f, ct.header_at, SEEK_SET) != 0 || !read_container_header(d.f, &ct.len, &ref, &start, &span, &ct.nrec, &nblocks, &land)) { d.err = "the .crai index points at something that is not a CRAM container"; return false; }
+            ct.body_at = ftello(d.f); ct.loaded = true;
+        }
         body.resize((size_t)ct.len);
         if (fseeko(d.f, ct.body_at, SEEK_SET) != 0 || fread(body.data(), 1, body.size(), d.f) != body.size()) { d.err = "truncated CRAM container"; return false; }
         Cur c; c.p = body.data(); c.e = c.p + body.size();

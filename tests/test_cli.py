@@ -148,7 +148,7 @@ def synthetic_bam(tmp_path_factory):
     # embedded reference slices, and a reference-less file (RR = 0, every base a feature): neither needs the FASTA to rebuild
     # its reads — syn_alt.fa differs from the reference they were written against at every 50th base
     cramio.write_cram(str(d / "syn_emb.cram"), [("chrA", 5000), ("chrB", 3000)], arrs, tids, refs, rg_of_read=rgs,
-                      rg_lines=["@RG\tID:rgA1\tLB:libA\tSM:s", "@RG\tID:rgB1\tLB:libB\tSM:s"], per_container=280, embed_ref=True)
+                      rg_lines=["@RG\tID:rgA1\tLB:libA\tSM:s", "@RG\tID:rgB1\tLB:libB\tSM:s"], per_container=280, embed_ref=True, write_crai=True)
     cramio.write_cram(str(d / "syn_noref.cram"), [("chrA", 5000), ("chrB", 3000)], arrs, tids, refs, rg_of_read=rgs,
                       rg_lines=["@RG\tID:rgA1\tLB:libA\tSM:s", "@RG\tID:rgB1\tLB:libB\tSM:s"], per_container=280, no_ref=True)
     bamio.write_bam(str(d / "syn_m_nonm.bam"), [("chrA", 5000), ("chrB", 3000)], dict(norm, tags=arrs["tags"], nm=arrs["nm"]), tids, rg_of_read=rgs,
@@ -366,6 +366,64 @@ def test_cli_cram_reader_equals_bam_reader_cpu(synthetic_bam):
     a = subprocess.run([SIM_CLI, "-w", "0", "-f", "syn.fa", "-p", "-l", sl, "--brc-plan", "0", "syn_m.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     b = subprocess.run([SIM_CLI, "-w", "0", "-f", "syn.fa", "-p", "-l", sl, "syn.cram"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and a.stdout.count(b"\n") > 60
+
+
+def test_cli_cram_index_cpu(synthetic_bam, tmp_path):
+    """A .crai next to the CRAM replaces the walk over the container headers: same text with it; an index that leaves out
+    the containers of one contig makes that contig's reads invisible (so it is the index that is used); an index that
+    points into the middle of a container is refused (container header CRC32)."""
+    import gzip, shutil
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    d = synthetic_bam
+    for f in ("syn.cram", "syn.fa", "syn.fa.fai"):
+        shutil.copy(d / f, tmp_path / f)
+    regs = ["chrA:1-5000", "chrB", "chrA:2400-2450"]
+    run = lambda: subprocess.run([SIM_CLI, "-w", "0", "-p", "-f", "syn.fa", "syn.cram"] + regs, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    want = run()
+    assert want.returncode == 0 and want.stdout.count(b"\n") > 7000
+    # the index of this very file: re-create the CRAM with the writer's .crai (same bytes, plus the index)
+    # walk the container headers here to write the index by hand: (ref, start, span, offset) of every data container
+    import struct
+    raw = open(tmp_path / "syn.cram", "rb").read()
+    def itf8(b, o):
+        v = b[o]
+        if v < 0x80: return v, o + 1
+        if v < 0xc0: return ((v & 0x3f) << 8) | b[o + 1], o + 2
+        if v < 0xe0: return ((v & 0x1f) << 16) | (b[o + 1] << 8) | b[o + 2], o + 3
+        if v < 0xf0: return ((v & 0x0f) << 24) | (b[o + 1] << 16) | (b[o + 2] << 8) | b[o + 3], o + 4
+        x = ((v & 0x0f) << 28) | (b[o + 1] << 20) | (b[o + 2] << 12) | (b[o + 3] << 4) | (b[o + 4] & 0x0f)
+        return x - (1 << 32) if x & (1 << 31) else x, o + 5
+    def ltf8_skip(b, o):
+        v = b[o]; n = 0
+        while n < 8 and (v << n) & 0x80: n += 1
+        return o + 1 + n
+    o = 26; first = True; conts = []
+    while o < len(raw):
+        at = o
+        ln = struct.unpack_from("<i", raw, o)[0]; o += 4
+        ref, o = itf8(raw, o); st, o = itf8(raw, o); sp, o = itf8(raw, o); nrec, o = itf8(raw, o)
+        o = ltf8_skip(raw, o); o = ltf8_skip(raw, o)
+        nb, o = itf8(raw, o); nl, o = itf8(raw, o)
+        for _ in range(nl): _, o = itf8(raw, o)
+        o += 4 + ln
+        if not first and nrec > 0: conts.append((ref, st, sp, at))
+        first = False
+    assert len(conts) > 4
+    def write_index(entries):
+        txt = ""
+        for ref, st, sp, at in entries:
+            if ref == -2: txt += "0\t1\t5000\t%d\t0\t0\n1\t1\t3000\t%d\t0\t0\n" % (at, at)
+            else: txt += "%d\t%d\t%d\t%d\t0\t0\n" % (ref, st, sp, at)
+        gzip.open(tmp_path / "syn.cram.crai", "wb").write(txt.encode())
+    write_index(conts)
+    got = run()
+    assert got.returncode == 0 and got.stdout == want.stdout
+    write_index([c for c in conts if c[0] == 0])                                  # no chrB (and no multi-reference) container
+    got = run()
+    assert got.returncode == 0 and got.stdout != want.stdout and b"chrB\t2000\t" not in got.stdout and b"chrA\t2000\t" in got.stdout
+    write_index([(r, s0, sp, at + 7) for r, s0, sp, at in conts])
+    got = run()
+    assert got.returncode != 0 and b"crai" in got.stderr
 
 
 def _cram_embedded_and_reference_less(cli, d):

@@ -253,7 +253,7 @@ IDS = dict(RI=1, RL=2, AP=3, RG=4, RN=5, MF=6, NS=7, NP=8, TS=9, NF=10, FN=11, F
 
 
 def write_cram(path, contigs, arrs, tids, refs, rg_of_read=None, rg_lines=(), qnames=None, per_container=300, methods=(0, 1), int_codecs=False,
-               embed_ref=False, no_ref=False):
+               embed_ref=False, no_ref=False, write_crai=False):
     """contigs [(name, len)], arrs = brc_read_batch arrays, tids = contig per read, refs = list of uint8 reference arrays.
     embed_ref: every single-reference slice carries its stretch of the reference as an external block (slice header field
     "embedded reference bases block content id"); no_ref: RR = 0 in the preservation map and every aligned base stored as
@@ -269,6 +269,7 @@ def write_cram(path, contigs, arrs, tids, refs, rg_of_read=None, rg_lines=(), qn
         return h + struct.pack("<I", zlib.crc32(h)) + body
 
     out += container(0, 0, 0, 0, [block(0, 0, 0, struct.pack("<i", len(text)) + text.encode())], [0])
+    crai = []                                                                    # lines of the .crai index
     n = len(arrs["pos"])
     for c0 in range(0, n, per_container):
         idx = range(c0, min(n, c0 + per_container))
@@ -281,6 +282,7 @@ def write_cram(path, contigs, arrs, tids, refs, rg_of_read=None, rg_lines=(), qn
         blens = huffman_lengths(flags); border, bcodes = canonical(blens)
         first_pos = int(arrs["pos"][c0]) + 1
         last_ap = first_pos; max_end = first_pos
+        extent = {}                                                              # tid -> [first start (1-based), last end] of this container
         for i in idx:
             L = int(arrs["l_qseq"][i]); nc = int(arrs["n_cigar"][i]); pos = int(arrs["pos"][i]); tid = int(tids[i]); flag = int(arrs["flag"][i])
             cig = [int(x) for x in arrs["cigar"][int(arrs["cigar_off"][i]):int(arrs["cigar_off"][i]) + nc]]
@@ -306,6 +308,7 @@ def write_cram(path, contigs, arrs, tids, refs, rg_of_read=None, rg_lines=(), qn
             for k, v in tl:
                 key = (k[0] << 16) | (k[1] << 8) | k[2]
                 tag_blocks.setdefault(key, bytearray()); tag_blocks[key] += bytes([v]) if k[2:] == b"C" else struct.pack("<i", v)
+            ex = extent.setdefault(tid, [pos + 1, pos + 1]); ex[0] = min(ex[0], pos + 1)
             if not flag & 4:
                 ref = refs[tid]; feats = []; rp = pos; sp = 1
                 for c in cig:
@@ -327,7 +330,7 @@ def write_cram(path, contigs, arrs, tids, refs, rg_of_read=None, rg_lines=(), qn
                     elif op == 3: feats.append((sp, "N", ln)); rp += ln
                     elif op == 5: feats.append((sp, "H", ln))
                     elif op == 6: feats.append((sp, "P", ln))
-                max_end = max(max_end, rp)
+                max_end = max(max_end, rp); ex[1] = max(ex[1], rp)
                 ext["FN"] += itf8(len(feats)); prev = 0
                 for fp, fc, v in feats:
                     ext["FC"] += fc.encode(); ext["FP"] += itf8(fp - prev); prev = fp
@@ -383,6 +386,12 @@ def write_cram(path, contigs, arrs, tids, refs, rg_of_read=None, rg_lines=(), qn
         sh = itf8(sref) + itf8(sstart) + itf8(sspan) + itf8(len(idx)) + ltf8(c0) + itf8(1 + len(eblocks)) + itf8(len(ids)) + \
             b"".join(itf8(x) for x in ids) + itf8(emb_id) + bytes(16)
         blocks = [ch, block(0, 2, 0, sh), block(methods[-1] if len(methods) > 2 else 0, 5, 0, bytes(core.out))] + eblocks
-        out += container(sref, sstart, sspan, len(idx), blocks, [len(ch)])
+        cbytes = container(sref, sstart, sspan, len(idx), blocks, [len(ch)])
+        for t in sorted(extent):
+            crai.append("%d\t%d\t%d\t%d\t%d\t%d\n" % (t, extent[t][0], extent[t][1] - extent[t][0] + 1, len(out), len(ch), len(cbytes) - len(ch)))
+        out += cbytes
     out += bytes.fromhex("0f000000ffffffff0fe0454f460000000001000 5bdd94f0001000606010001000100ee63014b".replace(" ", ""))
     open(path, "wb").write(bytes(out))
+    if write_crai:
+        import gzip
+        gzip.open(path + ".crai", "wb").write("".join(crai).encode())
