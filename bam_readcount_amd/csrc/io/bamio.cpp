@@ -412,10 +412,51 @@ std::vector<Chunk> BamIndex::query(int tid, int64_t beg, int64_t end) const {
 
 // ---------------------------------------------------------------- FASTA
 
+// The index htslib's fai_load builds when <fasta>.fai is missing (faidx.c fai_build_core): name = the header line up to the
+// first white space, length, offset of the first base, bases and bytes per line; every line of a sequence but its last must
+// have the same length.  Written next to the FASTA like htslib does; when that is not possible the index is only kept in
+// memory (htslib would give up the reference).
+bool Fasta::build_index() {
+    FILE* g = fopen(path_.c_str(), "rb");
+    if (!g) { err_ = "cannot open " + path_; return false; }
+    std::vector<std::pair<std::string, Ent> > order;
+    char* line = nullptr; size_t cap = 0; ssize_t n; int64_t off = 0;
+    bool have = false, last_short = false; std::string name; Ent cur{0, 0, 0, 0};
+    auto close_seq = [&]() { if (have) order.emplace_back(name, cur); };
+    while ((n = getline(&line, &cap, g)) >= 0) {
+        if (n > 0 && line[0] == '>') {
+            close_seq();
+            size_t k = 1; while (k < (size_t)n && !isspace((unsigned char)line[k])) ++k;
+            name.assign(line + 1, k - 1); cur = Ent{0, off + n, 0, 0}; have = true; last_short = false;
+        } else if (have) {
+            int64_t bases = 0; for (ssize_t i = 0; i < n; ++i) if (isgraph((unsigned char)line[i])) ++bases;
+            if (bases || n > 1) {
+                if (last_short && bases) { err_ = "different line length in sequence '" + name + "' of " + path_; free(line); fclose(g); return false; }
+                if (cur.linebases == 0) { cur.linebases = bases; cur.linewidth = n; }
+                else if (bases != cur.linebases || n != cur.linewidth) {
+                    if (bases > cur.linebases) { err_ = "different line length in sequence '" + name + "' of " + path_; free(line); fclose(g); return false; }
+                    last_short = true;
+                }
+                cur.len += bases;
+            }
+        }
+        off += n;
+    }
+    close_seq();
+    free(line); fclose(g);
+    if (order.empty()) { err_ = "no sequence in " + path_; return false; }
+    for (auto& kv : order) { if (kv.second.linebases == 0) { kv.second.linebases = 1; kv.second.linewidth = 1; } if (!idx_.count(kv.first)) idx_[kv.first] = kv.second; }
+    if (FILE* w = fopen((path_ + ".fai").c_str(), "w")) {
+        for (const auto& kv : order) fprintf(w, "%s\t%lld\t%lld\t%lld\t%lld\n", kv.first.c_str(), (long long)kv.second.len, (long long)kv.second.off, (long long)kv.second.linebases, (long long)kv.second.linewidth);
+        fclose(w);
+    }
+    return true;
+}
+
 bool Fasta::open(const std::string& path) {
     path_ = path;
     FILE* f = fopen((path + ".fai").c_str(), "r");
-    if (!f) { err_ = "cannot open " + path + ".fai"; return false; }
+    if (!f) return build_index();                                    // (fai_load / samfaipath build it, bamreadcount.cpp:501-506)
     char name[4096]; long long len, off, lb, lw;                     // (a contig written on one line: its width can pass 2^31)
     char line[8192];
     while (fgets(line, sizeof line, f)) {

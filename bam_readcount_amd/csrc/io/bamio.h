@@ -132,13 +132,14 @@ class BamReader {
 // ---------------------------------------------------------------- FASTA + .fai
 class Fasta {
   public:
-    bool open(const std::string& path);            // needs <path>.fai
+    bool open(const std::string& path);            // reads <path>.fai, or builds (and writes) it like fai_load does
     // whole contig, raw characters (case preserved), like fai_fetch(fai, name, &len)
     bool fetch(const std::string& name, std::string* seq);
     const std::string& error() const { return err_; }
 
   private:
     struct Ent { int64_t len, off, linebases, linewidth; };
+    bool build_index();
     std::map<std::string, Ent> idx_;
     std::string path_, err_;
 };

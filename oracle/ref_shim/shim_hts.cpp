@@ -306,8 +306,10 @@ extern "C" char* samfaipath(const char* fn_ref) {
     if (!fn_ref) return 0;
     std::string p = std::string(fn_ref) + ".fai";
     FILE* f = fopen(p.c_str(), "rb");
-    if (!f) { fprintf(stderr, "[shim samfaipath] %s not found (the shim does not build indexes)\n", p.c_str()); return 0; }
-    fclose(f);
+    if (!f) {   // samtools' samfaipath builds the index (fai_build) when it is missing and the FASTA is readable
+        brcio::Fasta fa;
+        if (!fa.open(fn_ref)) { fprintf(stderr, "[samfaipath] fail to build FASTA index.\n"); return 0; }
+    } else fclose(f);
     return strdup(p.c_str());
 }
 extern "C" hts_idx_t* sam_index_load3(htsFile* fp, const char* fn, const char*, int) {

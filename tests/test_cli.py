@@ -368,6 +368,30 @@ def test_cli_cram_reader_equals_bam_reader_cpu(synthetic_bam):
     assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and a.stdout.count(b"\n") > 60
 
 
+def test_cli_builds_a_missing_fasta_index(synthetic_bam, tmp_path):
+    """htslib's fai_load / samtools' samfaipath build <fasta>.fai when it is missing (bamreadcount.cpp:501-506): so does the
+    drop-in — the same index (wrapped lines, a short last line, a header with a description), the same text."""
+    import shutil
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    d = synthetic_bam
+    for f in ("syn.bam", "syn.bam.bai", "syn.fa"):
+        shutil.copy(d / f, tmp_path / f)
+    fa = open(tmp_path / "syn.fa", "rb").read().replace(b">chrA\n", b">chrA some description\n")
+    open(tmp_path / "syn.fa", "wb").write(fa)
+    args = ["-w", "0", "-p", "-f", "syn.fa", "syn.bam", "chrA:4900-5000", "chrB:1-80"]
+    want = subprocess.run([SIM_CLI] + ["-w", "0", "-p", "-f", str(d / "syn.fa"), "syn.bam", "chrA:4900-5000", "chrB:1-80"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    got = subprocess.run([SIM_CLI] + args, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert got.returncode == 0 and want.returncode == 0 and got.stdout == want.stdout and got.stdout.count(b"\n") > 150
+    built = open(tmp_path / "syn.fa.fai").read().split("\n"); orig = open(d / "syn.fa.fai").read().split("\n")
+    shift = len(b" some description")
+    assert built[0] == "chrA\t5000\t%d\t60\t61" % (6 + shift) and [l.split("\t")[:2] + l.split("\t")[3:] for l in built] == [l.split("\t")[:2] + l.split("\t")[3:] for l in orig]
+    assert int(built[1].split("\t")[2]) == int(orig[1].split("\t")[2]) + shift
+    # uneven lines inside a sequence are refused, as by fai_build
+    open(tmp_path / "bad.fa", "wb").write(b">x\nACGT\nAC\nACGT\n")
+    bad = subprocess.run([SIM_CLI, "-f", "bad.fa", "syn.bam", "chrA:1-2"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert bad.returncode != 0 and not os.path.exists(tmp_path / "bad.fa.fai")
+
+
 def test_cli_cram_index_cpu(synthetic_bam, tmp_path):
     """A .crai next to the CRAM replaces the walk over the container headers: same text with it; an index that leaves out
     the containers of one contig makes that contig's reads invisible (so it is the index that is used); an index that
