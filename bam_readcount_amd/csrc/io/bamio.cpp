@@ -475,10 +475,15 @@ bool Fasta::fetch(const std::string& name, std::string* seq) {
     const Ent& e = it->second;
     FILE* f = fopen(path_.c_str(), "rb");
     if (!f) { err_ = "cannot open " + path_; return false; }
+    // an index entry must fit the file it describes (a damaged or foreign .fai must not turn into a huge allocation)
+    fseeko(f, 0, SEEK_END); const int64_t fsize = (int64_t)ftello(f);
+    if (e.len < 0 || e.off < 0 || e.linebases <= 0 || e.linewidth < e.linebases || e.off > fsize || e.len > fsize - e.off) {
+        fclose(f); err_ = "the FASTA index entry of " + name + " does not fit " + path_; return false;
+    }
     seq->clear(); seq->reserve((size_t)e.len);
     if (fseeko(f, (off_t)e.off, SEEK_SET) != 0) { fclose(f); err_ = "seek failed"; return false; }
     const int64_t nlines = (e.len + e.linebases - 1) / e.linebases;
-    const size_t raw = (size_t)(nlines * e.linewidth);
+    const size_t raw = (size_t)std::min<__int128>((__int128)nlines * e.linewidth, (__int128)(fsize - e.off));
     std::vector<char> buf(raw + 1);
     const size_t got = fread(buf.data(), 1, raw, f);
     fclose(f);

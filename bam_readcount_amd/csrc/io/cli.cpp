@@ -349,7 +349,7 @@ static void fetch_chunk(Ctx& c, int tid, int64_t a, int64_t b, Fetched& out) {
 static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode, bool keep_queue = true, bool inner_piece = false) {
     const BamHeader& h = c.header();
     if (c.have_fa && tid != c.ref_tid) {
-        if (!c.fa.fetch(h.names[(size_t)tid], &c.ref)) c.ref.clear();
+        if (!c.fa.fetch(h.names[(size_t)tid], &c.ref)) { c.ref.clear(); fprintf(stderr, "bam-readcount: %s: no reference bases for %s\n", c.fa.error().c_str(), h.names[(size_t)tid].c_str()); }   // (the reference dereferences a null pointer here)
         c.ref_tid = tid;
     }
     const char* ref = c.have_fa && !c.ref.empty() ? c.ref.data() : nullptr;
@@ -530,7 +530,10 @@ static int run_site_batch(Ctx& c, const std::vector<Site>& sites) {
         for (size_t i = i0; i < i1; ++i) {
             const Site& st = sites[i];
             if (c.have_fa) {
-                if (st.tid != c.ref_tid) { if (!c.fa.fetch(h.names[(size_t)st.tid], &c.ref)) c.ref.clear(); c.ref_tid = st.tid; }
+                if (st.tid != c.ref_tid) {
+                    if (!c.fa.fetch(h.names[(size_t)st.tid], &c.ref)) { c.ref.clear(); fprintf(stderr, "bam-readcount: %s: no reference bases for %s\n", c.fa.error().c_str(), h.names[(size_t)st.tid].c_str()); }
+                    c.ref_tid = st.tid;
+                }
                 // past the contig: the annotator stops at the terminating NUL (x == len, :151) but merely skips positions
                 // x > len (site-list mode, :144-148); 'N' reproduces the skip (it never counts as a mismatch, :152)
                 const int64_t clen = (int64_t)c.ref.size();
