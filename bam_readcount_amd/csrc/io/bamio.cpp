@@ -271,7 +271,7 @@ bool BamReader::next(BamRecord* r) {
     r->mtid = (int32_t)rd32(h + 24); r->mpos = (int32_t)rd32(h + 28); r->tlen = (int32_t)rd32(h + 32);
     r->data.resize(bs - 32);
     if (bs > 32 && !bg_.read(r->data.data(), bs - 32)) { err_ = "truncated BAM record"; return false; }
-    if ((size_t)r->l_qname + 4u * r->n_cigar + (size_t)((r->l_seq + 1) / 2) + (size_t)r->l_seq > r->data.size() || r->l_seq < 0) { err_ = "corrupt BAM record"; return false; }
+    if (r->l_seq < 0 || (uint64_t)r->l_qname + 4ull * r->n_cigar + ((uint64_t)r->l_seq + 1) / 2 + (uint64_t)r->l_seq > r->data.size()) { err_ = "corrupt BAM record"; return false; }
     // Long CIGARs (SAMv1 4.2.2): more than 65535 operators are stored in the CG:B,I tag behind the placeholder <l_seq>S<span>N;
     // put the real operators in place (htslib's bam_tag2cigar does the same when it reads the record)
     if (r->n_cigar == 2) {

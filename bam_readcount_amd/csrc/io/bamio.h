@@ -54,7 +54,7 @@ struct BamRecord {
     const char* qname() const { return (const char*)data.data(); }
     const uint32_t* cigar() const { return (const uint32_t*)(data.data() + l_qname); }
     const uint8_t* seq() const { return data.data() + l_qname + 4u * n_cigar; }
-    const uint8_t* qual() const { return seq() + (l_seq + 1) / 2; }
+    const uint8_t* qual() const { return seq() + ((int64_t)l_seq + 1) / 2; }
     const uint8_t* aux() const { return qual() + l_seq; }
     size_t aux_len() const { return data.size() - (size_t)(aux() - data.data()); }
     int32_t endpos() const;          // bam_endpos

@@ -169,7 +169,7 @@ struct Batcher {
         if (r.aux_int("NM", &vnm)) t |= BRC_TAG_NM;      // bam_aux_get + bam_aux2i (BasicStat.cpp:94-96)
         if (r.aux_int("SM", &vsm)) t |= BRC_TAG_SM;      // (BasicStat.cpp:79-81)
         nm.push_back(vnm); sm.push_back(vsm); tags.push_back(t);
-        if (keep_names) { name_off.push_back(names.size()); const char* q = r.qname(); names.insert(names.end(), q, q + strlen(q) + 1); }
+        if (keep_names) { name_off.push_back(names.size()); const char* q = r.qname(); const size_t ql = strnlen(q, r.l_qname); names.insert(names.end(), q, q + ql); names.push_back(0); }   // (a record whose name lacks its NUL stays inside the record)
     }
     brc_read_batch view() const {
         brc_read_batch v; memset(&v, 0, sizeof v);
