@@ -60,35 +60,36 @@ struct Enc {            // one data-series / tag encoding
 
 struct BitReader { const uint8_t* p = nullptr; size_t n = 0, bit = 0;
     int get() { if ((bit >> 3) >= n) return 0; const int b = (p[bit >> 3] >> (7 - (bit & 7))) & 1; ++bit; return b; }
-    uint32_t bits(int k) { uint32_t v = 0; for (int i = 0; i < k; ++i) v = (v << 1) | (uint32_t)get(); return v; }
+    uint32_t bits(int k) { uint32_t v = 0; for (int i = 0; i < k && i < 32; ++i) v = (v << 1) | (uint32_t)get(); return v; }
 };
 
 bool parse_enc(Cur& c, Enc* e, std::string* err) {
     e->codec = c.itf8();
     const int32_t plen = c.itf8();
+    if (c.bad || plen < 0 || plen > c.e - c.p) { *err = "truncated CRAM encoding"; return false; }
     Cur q; q.p = c.p; q.e = c.p + plen; c.p += plen;
-    if (c.p > c.e) { *err = "truncated CRAM encoding"; return false; }
     switch (e->codec) {
         case 0: return true;
-        case 1: e->ext_id = q.itf8(); return true;
+        case 1: e->ext_id = q.itf8(); return !q.bad;
         case 3: {
-            const int na = q.itf8(); for (int i = 0; i < na; ++i) e->sym.push_back(q.itf8());
-            const int nl = q.itf8(); for (int i = 0; i < nl; ++i) e->len.push_back(q.itf8());
-            if (na != nl) { *err = "bad HUFFMAN encoding"; return false; }
+            const int na = q.itf8(); for (int i = 0; i < na && !q.bad; ++i) e->sym.push_back(q.itf8());
+            const int nl = q.itf8(); for (int i = 0; i < nl && !q.bad; ++i) e->len.push_back(q.itf8());
+            if (q.bad || na != nl || na < 0) { *err = "bad HUFFMAN encoding"; return false; }
+            for (int32_t l : e->len) if (l < 0 || l > 32) { *err = "bad HUFFMAN code length"; return false; }
             // canonical code assignment: sort by (length, symbol)
             std::vector<int> ord((size_t)na); for (int i = 0; i < na; ++i) ord[(size_t)i] = i;
             std::sort(ord.begin(), ord.end(), [&](int a, int b) { return e->len[(size_t)a] != e->len[(size_t)b] ? e->len[(size_t)a] < e->len[(size_t)b] : e->sym[(size_t)a] < e->sym[(size_t)b]; });
             std::vector<int32_t> s2, l2; for (int i : ord) { s2.push_back(e->sym[(size_t)i]); l2.push_back(e->len[(size_t)i]); }
             e->sym = s2; e->len = l2; e->code.assign((size_t)na, 0);
             uint32_t code = 0; int prev = na ? e->len[0] : 0;
-            for (int i = 0; i < na; ++i) { code <<= (e->len[(size_t)i] - prev); prev = e->len[(size_t)i]; e->code[(size_t)i] = code++; }
+            for (int i = 0; i < na; ++i) { const int sh = e->len[(size_t)i] - prev; code = sh >= 32 ? 0u : code << sh; prev = e->len[(size_t)i]; e->code[(size_t)i] = code++; }
             return true;
         }
         case 4: { e->sub.resize(2); return parse_enc(q, &e->sub[0], err) && parse_enc(q, &e->sub[1], err); }
-        case 5: e->stop = q.u8(); e->ext_id = q.itf8(); return true;
-        case 6: e->beta_off = q.itf8(); e->beta_bits = q.itf8(); return true;
-        case 7: e->beta_off = q.itf8(); e->beta_bits = q.itf8(); return true;     // SUBEXP: offset, k
-        case 9: e->beta_off = q.itf8(); return true;                              // GAMMA: offset
+        case 5: e->stop = q.u8(); e->ext_id = q.itf8(); return !q.bad;
+        case 6: e->beta_off = q.itf8(); e->beta_bits = q.itf8(); if (q.bad || e->beta_bits < 0 || e->beta_bits > 32) { *err = "bad BETA encoding"; return false; } return true;
+        case 7: e->beta_off = q.itf8(); e->beta_bits = q.itf8(); if (q.bad || e->beta_bits < 0 || e->beta_bits > 30) { *err = "bad SUBEXP encoding"; return false; } return true;     // SUBEXP: offset, k
+        case 9: e->beta_off = q.itf8(); return !q.bad;                            // GAMMA: offset
         default: *err = "CRAM codec " + std::to_string(e->codec) + " not supported by the minimal reader"; return false;
     }
 }
@@ -262,12 +263,13 @@ struct CramReader::Impl {
                       *out = c.itf8(); it->second.pos = (size_t)(c.p - it->second.data.data()); return !c.bad; }
             case 3: { if (e.sym.size() == 1 && e.len[0] == 0) { *out = e.sym[0]; return true; }
                       uint32_t code = 0; int l = 0; size_t i = 0;
-                      while (i < e.sym.size()) { while (l < e.len[i]) { code = (code << 1) | (uint32_t)br.get(); ++l; }
+                      while (i < e.sym.size()) { while (l < e.len[i]) { if ((br.bit >> 3) >= br.n) { err = "CRAM core block exhausted"; return false; } code = (code << 1) | (uint32_t)br.get(); ++l; }
                           for (; i < e.sym.size() && e.len[i] == l; ++i) if (e.code[i] == code) { *out = e.sym[i]; return true; } }
                       err = "bad CRAM Huffman code"; return false; }
             case 6: *out = (int32_t)br.bits(e.beta_bits) - e.beta_off; return true;
             case 7: { int i = 0; while (br.get() == 1 && i < 32) ++i;                     // SUBEXP: i ones, a zero, then i ? i + k - 1 : k bits
                       const int tail = i ? i + e.beta_bits - 1 : e.beta_bits;
+                      if (tail > 31) { err = "bad CRAM SUBEXP value"; return false; }
                       uint32_t v = br.bits(tail); if (i) v += 1u << tail;
                       *out = (int32_t)v - e.beta_off; return true; }
             case 9: { int nz = 0; while (br.get() == 0 && nz < 31) { ++nz; if ((br.bit >> 3) >= br.n) { err = "CRAM core block exhausted"; return false; } }   // GAMMA: nz zeros, a one, nz bits
@@ -295,23 +297,31 @@ struct CramReader::Impl {
     bool parse_comp_header(const Block& b) {
         ds.clear(); tagenc.clear(); td.clear(); rn_preserved = true; ap_delta = true; ref_required = true;
         Cur c; c.p = b.data.data(); c.e = c.p + b.data.size();
-        { const int32_t sz = c.itf8(); Cur m; m.p = c.p; m.e = c.p + sz; c.p += sz;
+        auto sub = [&](Cur* m) {                                  // a size-prefixed map inside the header block
+            const int32_t sz = c.itf8();
+            if (c.bad || sz < 0 || sz > c.e - c.p) { err = "truncated CRAM compression header"; return false; }
+            m->p = c.p; m->e = c.p + sz; c.p += sz; return true;
+        };
+        { Cur m; if (!sub(&m)) return false;
           const int n = m.itf8();
-          for (int i = 0; i < n; ++i) {
+          for (int i = 0; i < n && !m.bad; ++i) {
               const char k0 = (char)m.u8(), k1 = (char)m.u8();
               if (k0 == 'R' && k1 == 'N') rn_preserved = m.u8() != 0;
               else if (k0 == 'A' && k1 == 'P') ap_delta = m.u8() != 0;
               else if (k0 == 'R' && k1 == 'R') ref_required = m.u8() != 0;
               else if (k0 == 'S' && k1 == 'M') for (int j = 0; j < 5; ++j) sm[j] = m.u8();
-              else if (k0 == 'T' && k1 == 'D') { const int32_t l = m.itf8(); const uint8_t* t = m.p; m.p += l;
-                  std::vector<int32_t> line; for (int32_t o = 0; o < l;) { if (t[o] == 0) { td.push_back(line); line.clear(); ++o; } else { line.push_back((t[o] << 16) | (t[o + 1] << 8) | t[o + 2]); o += 3; } } }
-              else { err = "unknown CRAM preservation key"; return false; } } }
-        { const int32_t sz = c.itf8(); Cur m; m.p = c.p; m.e = c.p + sz; c.p += sz;
+              else if (k0 == 'T' && k1 == 'D') { const int32_t l = m.itf8();
+                  if (m.bad || l < 0 || l > m.e - m.p) { err = "truncated CRAM tag dictionary"; return false; }
+                  const uint8_t* t = m.p; m.p += l;
+                  std::vector<int32_t> line; for (int32_t o = 0; o < l;) { if (t[o] == 0) { td.push_back(line); line.clear(); ++o; } else { if (o + 3 > l) { err = "truncated CRAM tag dictionary"; return false; } line.push_back((t[o] << 16) | (t[o + 1] << 8) | t[o + 2]); o += 3; } } }
+              else { err = "unknown CRAM preservation key"; return false; } }
+          if (m.bad) { err = "truncated CRAM preservation map"; return false; } }
+        { Cur m; if (!sub(&m)) return false;
           const int n = m.itf8();
-          for (int i = 0; i < n; ++i) { std::string k; k.push_back((char)m.u8()); k.push_back((char)m.u8()); Enc e; if (!parse_enc(m, &e, &err)) return false; ds[k] = e; } }
-        { const int32_t sz = c.itf8(); Cur m; m.p = c.p; m.e = c.p + sz; c.p += sz;
+          for (int i = 0; i < n; ++i) { std::string k; k.push_back((char)m.u8()); k.push_back((char)m.u8()); if (m.bad) { err = "truncated CRAM data series map"; return false; } Enc e; if (!parse_enc(m, &e, &err)) return false; ds[k] = e; } }
+        { Cur m; if (!sub(&m)) return false;
           const int n = m.itf8();
-          for (int i = 0; i < n; ++i) { const int32_t key = m.itf8(); Enc e; if (!parse_enc(m, &e, &err)) return false; tagenc[key] = e; } }
+          for (int i = 0; i < n; ++i) { const int32_t key = m.itf8(); if (m.bad) { err = "truncated CRAM tag encoding map"; return false; } Enc e; if (!parse_enc(m, &e, &err)) return false; tagenc[key] = e; } }
         return !c.bad;
     }
 
@@ -370,6 +380,7 @@ struct CramReader::Impl {
             if (!geti("BF", &bf) || !geti("CF", &cf)) return false;
             if (slice_ref == -2 && !geti("RI", &ri)) return false;
             if (!geti("RL", &rl) || !geti("AP", &ap) || !geti("RG", &rg)) return false;
+            if (rl < 0 || rl > (1 << 28) || (ri < 0 && !(bf & 4)) || ri >= (int32_t)hdr.names.size()) { err = "corrupt CRAM record"; return false; }
             if (ap_delta) { ap += last_ap; last_ap = ap; }
             std::vector<uint8_t> name, tmp;
             if (rn_preserved && !geta("RN", &name)) return false;
@@ -403,30 +414,40 @@ struct CramReader::Impl {
                 int64_t refp = (int64_t)ap - 1; int sp = 1, prev = 0;
                 auto ref_at = [&](int64_t x) { return (char)toupper((unsigned char)ref_raw(x)); };
                 auto copy_ref = [&](int len) { for (int i = 0; i < len; ++i) seq[(size_t)(sp - 1 + i)] = ref_at(refp + i); };
+                // every feature must stay inside the read (positions are 1-based; a clip or pad may sit at rl + 1)
+                auto bad_record = [&]() { err = "corrupt CRAM record (a read feature outside its read)"; return false; };
+                auto room = [&](int64_t at1, int64_t n) { return at1 >= 1 && n >= 0 && at1 - 1 + n <= (int64_t)rl; };
                 for (int fi = 0; fi < fn; ++fi) {
                     uint8_t fc; int32_t fp; if (!getb("FC", &fc) || !geti("FP", &fp)) return false;
-                    const int pos = prev + fp; prev = pos;
+                    const int64_t pos64 = (int64_t)prev + fp;
+                    if (pos64 < 1 || pos64 > (int64_t)rl + 1) return bad_record();
+                    const int pos = (int)pos64; prev = pos;
                     if (pos > sp) { const int l = pos - sp; copy_ref(l); push_cigar(cg, 0, (uint32_t)l); refp += l; sp = pos; }
-                    uint8_t b1; int32_t iv;
+                    uint8_t b1; int32_t iv = 0;
+                    switch (fc) {
+                        case 'X': case 'i': case 'B': if (!room(sp, 1)) return bad_record(); break;
+                        case 'Q': if (!room(pos, 1)) return bad_record(); break;
+                        default: break;
+                    }
                     switch (fc) {
                         case 'X': if (!getb("BS", &b1)) return false; seq[(size_t)(sp - 1)] = substitute(ref_raw(refp), b1); push_cigar(cg, 0, 1); ++refp; ++sp; ++nm; break;
-                        case 'I': if (!geta("IN", &tmp)) return false; for (size_t i = 0; i < tmp.size(); ++i) seq[(size_t)(sp - 1) + i] = (char)tmp[i]; push_cigar(cg, 1, (uint32_t)tmp.size()); sp += (int)tmp.size(); nm += (uint32_t)tmp.size(); break;
+                        case 'I': if (!geta("IN", &tmp)) return false; if (!room(sp, (int64_t)tmp.size())) return bad_record(); for (size_t i = 0; i < tmp.size(); ++i) seq[(size_t)(sp - 1) + i] = (char)tmp[i]; push_cigar(cg, 1, (uint32_t)tmp.size()); sp += (int)tmp.size(); nm += (uint32_t)tmp.size(); break;
                         case 'i': if (!getb("BA", &b1)) return false; seq[(size_t)(sp - 1)] = (char)b1; push_cigar(cg, 1, 1); ++sp; ++nm; break;
-                        case 'S': if (!geta("SC", &tmp)) return false; for (size_t i = 0; i < tmp.size(); ++i) seq[(size_t)(sp - 1) + i] = (char)tmp[i]; push_cigar(cg, 4, (uint32_t)tmp.size()); sp += (int)tmp.size(); break;
-                        case 'D': if (!geti("DL", &iv)) return false; push_cigar(cg, 2, (uint32_t)iv);
+                        case 'S': if (!geta("SC", &tmp)) return false; if (!room(sp, (int64_t)tmp.size())) return bad_record(); for (size_t i = 0; i < tmp.size(); ++i) seq[(size_t)(sp - 1) + i] = (char)tmp[i]; push_cigar(cg, 4, (uint32_t)tmp.size()); sp += (int)tmp.size(); break;
+                        case 'D': if (!geti("DL", &iv)) return false; if (iv < 0 || iv >= (1 << 28)) return bad_record(); push_cigar(cg, 2, (uint32_t)iv);
                                   nm += refp + iv <= ref_end ? (uint32_t)iv : (uint32_t)std::max<int64_t>(ref_end - refp, 0);
                                   refp += iv; break;
-                        case 'N': if (!geti("RS", &iv)) return false; push_cigar(cg, 3, (uint32_t)iv); refp += iv; break;
-                        case 'H': if (!geti("HC", &iv)) return false; push_cigar(cg, 5, (uint32_t)iv); break;
-                        case 'P': if (!geti("PD", &iv)) return false; push_cigar(cg, 6, (uint32_t)iv); break;
+                        case 'N': if (!geti("RS", &iv)) return false; if (iv < 0 || iv >= (1 << 28)) return bad_record(); push_cigar(cg, 3, (uint32_t)iv); refp += iv; break;
+                        case 'H': if (!geti("HC", &iv)) return false; if (iv < 0 || iv >= (1 << 28)) return bad_record(); push_cigar(cg, 5, (uint32_t)iv); break;
+                        case 'P': if (!geti("PD", &iv)) return false; if (iv < 0 || iv >= (1 << 28)) return bad_record(); push_cigar(cg, 6, (uint32_t)iv); break;
                         case 'B': { uint8_t q; if (!getb("BA", &b1) || !getb("QS", &q)) return false; seq[(size_t)(sp - 1)] = (char)b1; qual[(size_t)(sp - 1)] = q; push_cigar(cg, 0, 1);
                                     if (ref_at(refp) != (char)b1) ++nm;
                                     ++refp; ++sp; break; }
-                        case 'b': if (!geta("BB", &tmp)) return false;
+                        case 'b': if (!geta("BB", &tmp)) return false; if (!room(sp, (int64_t)tmp.size())) return bad_record();
                                   for (size_t i = 0; i < tmp.size(); ++i) { seq[(size_t)(sp - 1) + i] = (char)tmp[i]; if (ref_at(refp + (int64_t)i) != (char)tmp[i]) ++nm; }
                                   push_cigar(cg, 0, (uint32_t)tmp.size()); refp += (int64_t)tmp.size(); sp += (int)tmp.size(); break;
                         case 'Q': { uint8_t q; if (!getb("QS", &q)) return false; qual[(size_t)(pos - 1)] = q; break; }
-                        case 'q': if (!geta("QQ", &tmp)) return false; for (size_t i = 0; i < tmp.size(); ++i) qual[(size_t)(pos - 1) + i] = tmp[i]; break;
+                        case 'q': if (!geta("QQ", &tmp)) return false; if (!room(pos, (int64_t)tmp.size())) return bad_record(); for (size_t i = 0; i < tmp.size(); ++i) qual[(size_t)(pos - 1) + i] = tmp[i]; break;
                         default: err = "unknown CRAM feature code"; return false;
                     }
                 }
