@@ -450,6 +450,40 @@ def test_cli_cram_index_cpu(synthetic_bam, tmp_path):
     assert got.returncode != 0 and b"crai" in got.stderr
 
 
+def test_cli_cram_with_damaged_contents_is_refused(synthetic_bam, tmp_path):
+    """Blocks whose CRC32 is right but whose contents are not: read features that point outside their read, a truncated tag
+    dictionary, code lengths no Huffman code has — an error message and a non-zero exit code, no output for the damaged part."""
+    import sys, shutil
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import cramio
+    import synth
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    d = synthetic_bam
+    for f in ("syn.fa", "syn.fa.fai"):
+        shutil.copy(d / f, tmp_path / f)
+    ref = np.frombuffer(open(d / "syn.fa", "rb").read().split(b">")[1].split(b"\n", 1)[1].replace(b"\n", b""), np.uint8)
+    arrs = synth.make_batch(31, ref, 300, style="mixed", n_libs=2)
+    rgs = [["rgA1", "rgB1"][int(l)] if l >= 0 else None for l in arrs["lib"]]
+    orig = cramio.block
+    def damaged(which):
+        def blk(method, ctype, cid, data):
+            data = bytearray(data)
+            if which == "features" and ctype == 4 and cid == cramio.IDS["FP"] and len(data) > 8: data[5] = 0x7f; data[6] = 0x7f
+            if which == "dictionary" and ctype == 1 and len(data) > 12: data = data[:len(data) // 2]
+            if which == "lengths" and ctype == 4 and cid == cramio.IDS["RL"] and len(data) > 4: data[0:5] = b"\xff\xff\xff\xff\x0f"
+            return orig(method, ctype, cid, bytes(data))
+        return blk
+    try:
+        for which in ("features", "dictionary", "lengths"):
+            cramio.block = damaged(which)
+            cramio.write_cram(str(tmp_path / "bad.cram"), [("chrA", 5000)], arrs, np.zeros(len(arrs["pos"]), int), [ref], rg_of_read=rgs,
+                              rg_lines=["@RG\tID:rgA1\tLB:libA\tSM:s", "@RG\tID:rgB1\tLB:libB\tSM:s"], per_container=400)
+            p = subprocess.run([SIM_CLI, "-w", "0", "-f", "syn.fa", "bad.cram", "chrA"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert p.returncode == 1 and b"CRAM" in p.stderr and p.stdout == b"", (which, p.returncode, p.stderr[-200:])
+    finally:
+        cramio.block = orig
+
+
 def _cram_embedded_and_reference_less(cli, d):
     regs = ["chrA:1-5000", "chrB", "chrA:2400-2450"]
     # (the container that holds the end of chrA and the start of chrB is a multi-reference slice: those cannot embed a
