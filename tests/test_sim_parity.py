@@ -204,3 +204,32 @@ def test_sim_sequenceless_secondary_read(sim_lib, oracle_lib):
         text, _ = parity.compare_libs(sim_lib, oracle_lib, arrs, [(0, 600)], ref=ref, **kw)
         got, _ = parity.run_engine(sim_lib, arrs, [(0, 600)], ref=ref, device_text="chrS", **kw)
         assert got == text and b"\t421\t" in text
+
+
+def test_push_reads_refuses_inconsistent_records(sim_lib):
+    """The staging code is the last stop before the kernels index a read's rows: a CIGAR that walks more or fewer query bases
+    than the record has, offsets outside the arenas and unsorted reads are errors, not work."""
+    from bam_readcount_amd import capi
+    rng = np.random.default_rng(1)
+    ref = synth.make_ref(rng, 600)
+    good = synth.make_batch(3, ref, 20, style="indel")
+
+    def refused(arrs, what):
+        eng = capi.Engine(sim_lib)
+        eng.begin_region(0, 0, 500, ref)
+        with pytest.raises(capi.BrcError) as ei:
+            eng.push_reads(arrs)
+        assert what in str(ei.value), str(ei.value)
+        eng.close()
+    bad = {k: v.copy() for k, v in good.items()}
+    bad["l_qseq"][5] += 3
+    refused(bad, "CIGAR and sequence length disagree")
+    bad = {k: v.copy() for k, v in good.items()}
+    bad["cigar"][int(bad["cigar_off"][7])] += 2 << 4
+    refused(bad, "CIGAR and sequence length disagree")
+    bad = {k: v.copy() for k, v in good.items()}
+    bad["pos"][9] = bad["pos"][3] - 1 if bad["pos"][3] > 0 else 0; bad["pos"][10] = bad["pos"][9] - 1 if bad["pos"][9] > 0 else -1
+    refused(bad, "coordinate-sorted")
+    bad = {k: v.copy() for k, v in good.items()}
+    bad["qual_off"][19] = np.uint64(len(bad["qual"]))
+    refused(bad, "outside the batch arenas")
