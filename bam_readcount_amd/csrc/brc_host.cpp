@@ -440,11 +440,15 @@ int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
         const int32_t rlen = cigar_rlen(s.cigar.p + s.cig_off.p[r], nc, &s.n_indel_ops);
         // A record whose CIGAR walks more (or fewer) query bases than it has would send the kernels outside the read's
         // quality / base rows (htslib indexes the record's memory just the same: undefined there, refused here).
-        // Sequence-less records (l_qseq == 0, SEQ "*") are exempt: they only ever reach a column as dropped secondaries.
+        // Sequence-less records (l_qseq == 0, SEQ "*") pass when pileup_func drops them anyway (secondary alignments).
         if (s.l_qseq.p[r] > 0 && nc > 0) {
             int64_t ql = 0;
             for (uint32_t k = 0; k < nc; ++k) { const uint32_t op = s.cigar.p[s.cig_off.p[r] + k] & 0xfu; if (op == CMATCH || op == CINS || op == CSOFT_CLIP || op == CEQUAL || op == CDIFF) ql += s.cigar.p[s.cig_off.p[r] + k] >> 4; }
             if (ql != s.l_qseq.p[r]) return fail(e, BRC_E_ARG, "a read's CIGAR and sequence length disagree");
+        } else if (s.l_qseq.p[r] == 0 && nc > 0 && !(fl & (FUNMAP | BRC_NOCOUNT_MASK))) {
+            // (SEQ "*" on a record that pileup_func would count: the reference takes its bases from whatever follows the
+            // empty sequence in the record)
+            return fail(e, BRC_E_ARG, "a read without sequence would be counted");
         }
         const int32_t end = (!(fl & FUNMAP) && nc > 0) ? pos + rlen : pos + 1;           // bam_endpos
         if (rlen > s.max_span) s.max_span = rlen;

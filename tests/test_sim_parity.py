@@ -233,3 +233,6 @@ def test_push_reads_refuses_inconsistent_records(sim_lib):
     bad = {k: v.copy() for k, v in good.items()}
     bad["qual_off"][19] = np.uint64(len(bad["qual"]))
     refused(bad, "outside the batch arenas")
+    bad = {k: v.copy() for k, v in good.items()}
+    bad["l_qseq"][4] = 0; bad["flag"][4] = 16
+    refused(bad, "without sequence")
