@@ -370,14 +370,15 @@ int brc_begin_region(brc_engine* e, int32_t tid, int32_t beg0, int32_t end, cons
     return BRC_OK;
 }
 
+// reference length of a CIGAR; -1 when it does not fit 31 bits (a damaged record: positions are int32 everywhere, as in the reference)
 static inline int32_t cigar_rlen(const uint32_t* cig, uint32_t nc, uint64_t* n_indel_ops) {
-    int32_t l = 0;
+    int64_t l = 0;
     for (uint32_t k = 0; k < nc; ++k) {
         const uint32_t op = cig[k] & 0xfu;
-        if (is_refop(op)) l += (int32_t)(cig[k] >> 4);
+        if (is_refop(op)) l += (int64_t)(cig[k] >> 4);
         if (op == CINS || op == CDEL || op == CPAD) ++*n_indel_ops;
     }
-    return l;
+    return l > INT32_MAX ? -1 : (int32_t)l;
 }
 
 int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
@@ -438,6 +439,7 @@ int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
         e->last_pos = pos;
         uint16_t fl = (uint16_t)(s.flag.p[r] & 0x7fffu);
         const int32_t rlen = cigar_rlen(s.cigar.p + s.cig_off.p[r], nc, &s.n_indel_ops);
+        if (rlen < 0 || (int64_t)s.pos.p[r] + rlen > (int64_t)INT32_MAX) return fail(e, BRC_E_ARG, "a read ends beyond the last 32-bit position");
         // A record whose CIGAR walks more (or fewer) query bases than it has would send the kernels outside the read's
         // quality / base rows (htslib indexes the record's memory just the same: undefined there, refused here).
         // Sequence-less records (l_qseq == 0, SEQ "*") pass when pileup_func drops them anyway (secondary alignments).
