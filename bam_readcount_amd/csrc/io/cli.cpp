@@ -260,7 +260,7 @@ static void write_parts(const char* const* parts, const size_t* lens, size_t n) 
 struct Ctx {
     double t_fetch = 0, t_engine = 0, t_format = 0, t_write = 0;   // BRC_CLI_TIMING=1 prints them on stderr
     Options opt; BamReader bam; BamIndex idx; Fasta fa; bool have_fa = false;
-    CramReader cram; bool is_cram = false;          // minimal CRAM 3.0 input (cram.cpp); region queries scan container headers
+    CramReader cram; bool is_cram = false;          // CRAM 3.0 input (cram.cpp); region queries go through the .crai or one walk over the container headers
     const BamHeader& header() const { return is_cram ? cram.header() : bam.header(); }
     brc_engine* eng = nullptr;
     std::vector<std::string> libs;

@@ -9,8 +9,11 @@
 // frequency tables and the four interleaved states), bzip2 and lzma (through the system's libbz2 / liblzma, looked up at
 // run time: the image has the shared objects but no headers); every block's CRC32 is checked.  Integer codecs GAMMA and
 // SUBEXP are decoded too; GOLOMB / GOLOMB_RICE (no known writer) are reported as unsupported.  Records come out as
-// BAM-layout BamRecords (bamio.h) so the CLI's batcher is unchanged.  Region queries scan the container headers (ref id,
-// start, span); the .crai is not needed.
+// BAM-layout BamRecords (bamio.h) so the CLI's batcher is unchanged — mapped ones with the NM tag htslib's decoder generates
+// when none is stored.  The reference of a slice comes from the FASTA, from the slice's embedded reference block, or from
+// nowhere (RR = 0).  Region queries use the .crai when there is one, else one walk over the container headers (ref id,
+// start, span; CRC32 checked).  Everything a file says about lengths and positions is bounded before it is used: a block
+// with a valid CRC32 and damaged contents ends in an error, not in memory it does not own (tools/fuzz/cram_contents.py).
 #include <dlfcn.h>
 #include <string.h>
 #include <zlib.h>
