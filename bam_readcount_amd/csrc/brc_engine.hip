@@ -681,7 +681,10 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                     (void __attribute__((address_space(3)))*)(rows_base + (hoff)), 16, 0, 0);                             \
             }                                                                                                             \
         }
-        // scalar loads of the record at rp (issued HERE), and the wait that makes them usable
+        // scalar loads of the record at rp (issued HERE), and the wait that makes them usable.  The compiler believes R is
+        // written when the first statement ends: this is only sound while it never moves or spills R between the two
+        // statements — true at this kernel's register budget (88 SGPRs, nothing of R0..R2 goes to VGPR lanes; the GPU
+        // parity tests would show it at once), NOT true at 8 waves per SIMD (tools/experiments/README.md).
 #define BRC_LD_REC(R, rp) asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x20" : "=&s"(R.f), "=&s"(R.g) : "s"(rp));
 #define BRC_WAIT_REC(R) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R.f), "+s"(R.g));
         // the division constants of piece m (dwords 10-15 of its record) by scalar loads, on demand: only pieces without PF_TABLE
