@@ -348,8 +348,9 @@ int brc_set_option(brc_engine* e, int option, int64_t value) {
     if (!e) return BRC_E_ARG;
     switch (option) {
         case BRC_OPT_TEXT_ONLY: e->text_only = value != 0; return BRC_OK;
-        case BRC_OPT_EXPECT_READS: e->hint_reads = value > 0 ? (size_t)value : 0; return BRC_OK;
-        case BRC_OPT_EXPECT_BASES: e->hint_bases = value > 0 ? (size_t)value : 0; return BRC_OK;
+        // (hints size the staging buffers ahead of the pushes: a wild value must not become a wild allocation)
+        case BRC_OPT_EXPECT_READS: e->hint_reads = value > 0 ? (size_t)std::min<int64_t>(value, (int64_t)1 << 31) : 0; return BRC_OK;
+        case BRC_OPT_EXPECT_BASES: e->hint_bases = value > 0 ? (size_t)std::min<int64_t>(value, (int64_t)1 << 36) : 0; return BRC_OK;
         case BRC_OPT_DEVICE_TEXT: e->device_text = value != 0; return BRC_OK;
         case BRC_OPT_CONTINUES_PREVIOUS: e->continues = value == 1; e->warn_skip_lead = value == 1 || value == 2; return BRC_OK;
         case BRC_OPT_MAX_COUNT: if (value < INT32_MIN || value > INT32_MAX) return fail(e, BRC_E_ARG, "max count out of range"); e->cfg.max_cnt = (int32_t)value; return BRC_OK;
@@ -1035,7 +1036,8 @@ int brc_format_region_parts(brc_engine* e, const brc_result* r, const char* chro
 
 int brc_format_window(brc_engine* e, const brc_result* r, const char* chrom, int32_t vbeg0, int32_t vend, int32_t delta,
                       const char** text, size_t* text_len) {
-    if (!e || !r || !chrom || !text || vend < vbeg0) return BRC_E_ARG;
+    if (!e || !r || !chrom || !text) return BRC_E_ARG;
+    if (vend < vbeg0) return fail(e, BRC_E_ARG, "brc_format_window: the window ends before it begins");
     if ((size_t)r->n_lib != e->queue.size()) return fail(e, BRC_E_ARG, "result does not belong to this engine");
     if (r->ncol == NULL) return fail(e, BRC_E_ARG, "brc_format_window needs planes: switch BRC_OPT_DEVICE_TEXT off for regions cut into windows");
     if (r->istat == NULL && (!e->text_only || r->ncol != e->hp.ncol)) return fail(e, BRC_E_ARG, "a text-only result can only be formatted before the next download");
