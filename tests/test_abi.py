@@ -46,3 +46,36 @@ def test_oracle_is_not_linked_into_product():
     assert "oracle" not in out.lower()
     ldd = subprocess.check_output(["ldd", capi.PRODUCT_LIB]).decode()
     assert "oracle" not in ldd and "brc_sim" not in ldd
+
+
+def test_kernel_register_budget():
+    """k_pileup2's design point is read off the built library (no GPU): 72 VGPRs = 7 waves per SIMD, a few bytes of scratch
+    (outside the piece loop), and an SGPR budget at which the record sets of its inline-assembly scalar loads are never
+    spilled (brc_engine.hip, BRC_LD_REC; tools/experiments/README.md shows what happens at 72 SGPRs)."""
+    import re, struct
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        pytest.skip("no llvm-readelf")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bam_readcount_amd", "csrc")])
+    data = open(capi.PRODUCT_LIB, "rb").read()
+    i = data.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    assert i >= 0
+    n = struct.unpack_from("<Q", data, i + 24)[0]; o = i + 32; blob = None
+    for _ in range(n):
+        off, size, tl = struct.unpack_from("<QQQ", data, o); o += 24
+        triple = data[o:o + tl].decode(); o += tl
+        if "gfx950" in triple:
+            blob = data[i + off:i + off + size]
+    assert blob is not None, "no gfx950 code object in the product library"
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".elf") as f:
+        f.write(blob); f.flush()
+        notes = subprocess.check_output([readelf, "--notes", f.name]).decode()
+    kern = {}
+    for m in re.finditer(r"\.name:\s+(\S+)(.*?)\.wavefront_size", notes, re.S):
+        body = m.group(2)
+        kern[m.group(1)] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, body).group(1)) for k in ("private_segment_fixed_size", "sgpr_count", "vgpr_count")}
+    pile = next(v for k, v in kern.items() if "k_pileup2" in k)
+    ann = next(v for k, v in kern.items() if "k_annotate_groups" in k)
+    assert pile["vgpr_count"] <= 72 and pile["private_segment_fixed_size"] <= 16 and pile["sgpr_count"] >= 90, pile
+    assert ann["private_segment_fixed_size"] == 0 and ann["vgpr_count"] <= 80, ann
