@@ -425,7 +425,7 @@ int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
     const int32_t maxcnt = e->cfg.max_cnt;
     for (size_t i = 0; i < n; ++i) {
         const size_t r = n0 + i;
-        const uint32_t nc = s.n_cigar.p[r];
+        uint32_t nc = s.n_cigar.p[r];
         if (b->cigar_off[i] + nc > b->n_cigar_total || b->qual_off[i] + (uint64_t)(s.l_qseq.p[r] > 0 ? s.l_qseq.p[r] : 0) > b->qual_bytes ||
             b->seq_off[i] + (uint64_t)((s.l_qseq.p[r] + 1) / 2) > b->seq_bytes || s.l_qseq.p[r] < 0)
             return fail(e, BRC_E_ARG, "read offsets outside the batch arenas");
@@ -439,16 +439,23 @@ int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
         if (pos < e->last_pos) return fail(e, BRC_E_ARG, "reads are not coordinate-sorted");
         e->last_pos = pos;
         uint16_t fl = (uint16_t)(s.flag.p[r] & 0x7fffu);
-        const int32_t rlen = cigar_rlen(s.cigar.p + s.cig_off.p[r], nc, &s.n_indel_ops);
-        if (rlen < 0 || (int64_t)s.pos.p[r] + rlen > (int64_t)INT32_MAX) return fail(e, BRC_E_ARG, "a read ends beyond the last 32-bit position");
-        // A record whose CIGAR walks more (or fewer) query bases than it has would send the kernels outside the read's
-        // quality / base rows (htslib indexes the record's memory just the same: undefined there, refused here).
-        // Sequence-less records (l_qseq == 0, SEQ "*") pass when pileup_func drops them anyway (secondary alignments).
+        // A record whose CIGAR walks more (or fewer) query bases than it has would send the annotator outside the read's
+        // quality / base rows (htslib indexes the record's memory just the same: undefined there).  Mapped: refused.
+        // Unmapped (some aligners leave the mate's CIGAR on such records; they never reach a column): the CIGAR is dropped.
         if (s.l_qseq.p[r] > 0 && nc > 0) {
             int64_t ql = 0;
             for (uint32_t k = 0; k < nc; ++k) { const uint32_t op = s.cigar.p[s.cig_off.p[r] + k] & 0xfu; if (op == CMATCH || op == CINS || op == CSOFT_CLIP || op == CEQUAL || op == CDIFF) ql += s.cigar.p[s.cig_off.p[r] + k] >> 4; }
-            if (ql != s.l_qseq.p[r]) return fail(e, BRC_E_ARG, "a read's CIGAR and sequence length disagree");
-        } else if (s.l_qseq.p[r] == 0 && nc > 0 && !(fl & (FUNMAP | BRC_NOCOUNT_MASK))) {
+            if (ql != s.l_qseq.p[r]) {
+                if (!(fl & FUNMAP)) return fail(e, BRC_E_ARG, "a read's CIGAR and sequence length disagree");
+                nc = 0; s.n_cigar.p[r] = 0;
+            }
+        }
+        const int32_t rlen = cigar_rlen(s.cigar.p + s.cig_off.p[r], nc, &s.n_indel_ops);
+        if (rlen < 0 || (int64_t)s.pos.p[r] + rlen > (int64_t)INT32_MAX) {
+            if (!(fl & FUNMAP)) return fail(e, BRC_E_ARG, "a read ends beyond the last 32-bit position");
+            nc = 0; s.n_cigar.p[r] = 0;
+        }
+        if (s.l_qseq.p[r] == 0 && nc > 0 && !(fl & (FUNMAP | BRC_NOCOUNT_MASK))) {
             // (SEQ "*" on a record that pileup_func would count: the reference takes its bases from whatever follows the
             // empty sequence in the record)
             return fail(e, BRC_E_ARG, "a read without sequence would be counted");

@@ -236,3 +236,8 @@ def test_push_reads_refuses_inconsistent_records(sim_lib):
     bad = {k: v.copy() for k, v in good.items()}
     bad["l_qseq"][4] = 0; bad["flag"][4] = 16
     refused(bad, "without sequence")
+    # ... but not when the record is unmapped: it never reaches a column, whatever CIGAR an aligner left on it
+    ok = {k: v.copy() for k, v in good.items()}
+    ok["cigar"][int(ok["cigar_off"][7])] += 2 << 4; ok["flag"][7] |= 4
+    eng = capi.Engine(sim_lib)
+    eng.begin_region(0, 0, 500, ref); eng.push_reads(ok); eng.end_region(); eng.close()
