@@ -45,9 +45,11 @@ def test_hip_twolib_cram_fixture(hip_lib, oracle_lib, twolib):
     assert len(lines) == 11
     assert lines[0].startswith("rand1k\t50\tA\t1\treads1_lb\t{") and lines[0].endswith("\t}")
     assert "A:1:60.00:255.00:60.00:1:0:0.37:0.00:0.00:1:0.15:60.00:0.15" in lines[0]
-    # 12 NM-missing warnings: the 11 reported positions plus the lead position beg-1, which pileup_func also
-    # processes (bamreadcount.cpp:269) — SURVEY.md's derived "11" overlooked it; oracle and engine agree on 12
-    assert res[0].warn[1] == 12
+    # NM-missing warnings (BasicStat.cpp:100): one per counted event of a read without NM — the 11 reported positions plus
+    # the lead position beg-1, which pileup_func also processes (bamreadcount.cpp:269).  The fixture carries the NM that
+    # htslib's CRAM decoder regenerates (tools/make_fixtures.py), so the expected count follows the fixture's tag bits.
+    has_nm = bool(twolib["tags"][0] & 1)
+    assert res[0].warn[1] == (0 if has_nm else 12)
 
 
 @pytest.mark.parametrize("case", FUZZ, ids=lambda c: "seed%d-%s" % (c["seed"], c["style"]))
