@@ -221,6 +221,11 @@ BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i, uint16_t
         if (stop) continue;     // rlen (the pileup's view of the read) still needs the remaining ops
         if (op == CMATCH) {
             int j = 0;
+            // a record stored without its sequence (SEQ '*', l_qseq == 0: secondary alignments of minimap2 / bwa) still has a
+            // CIGAR; it is never counted (brc_push_reads accepts it only with a no-count flag), so nothing below is ever
+            // used — and its base / quality bytes do not exist: walking them would read the neighbouring records' bytes or
+            // past the end of the arenas.  Only the cursors move.
+            if (L == 0) j = len;
             for (; j < len; ++j) {
                 const int cur = read_position + j;
                 const int64_t refpos = reference_position + j;

@@ -382,8 +382,20 @@ static inline int32_t cigar_rlen(const uint32_t* cig, uint32_t nc, uint64_t* n_i
     return l > INT32_MAX ? -1 : (int32_t)l;
 }
 
+static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touched);
+
+// A refused batch leaves the staging arrays half appended (per-read arrays and arenas grow before a record is found bad),
+// so the region cannot take further batches: it is abandoned — every later push / upload on it fails with "outside an open
+// region" until the caller opens the next one with brc_begin_region (which resets the staging).
 int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
     if (!e || !b) return BRC_E_ARG;
+    bool touched = false;
+    const int rc = push_reads_staged(e, b, &touched);
+    if (rc != BRC_OK && touched) e->state = 0;
+    return rc;
+}
+
+static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touched) {
     if (e->state != 1) return fail(e, BRC_E_ARG, "brc_push_reads outside an open region");
     if (b->n_reads < 0) return fail(e, BRC_E_ARG, "negative n_reads");
     if (e->cfg.per_lib && !b->lib && b->n_reads) return fail(e, BRC_E_ARG, "per-library mode needs brc_read_batch.lib");
@@ -402,6 +414,7 @@ int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
                    s.qual.reserve(hb) && s.seq4.reserve(hb / 2 + hr);
         if (!okh) return fail(e, BRC_E_NOMEM, "host staging allocation failed");
     }
+    *touched = true;
     bool ok = s.pos.append(b->pos, n) && s.flag.append(b->flag, n) && s.mapq.append(b->mapq, n) && s.l_qseq.append(b->l_qseq, n) &&
               s.n_cigar.append(b->n_cigar, n) && s.cig_off.append(b->cigar_off, n) && s.seq_off.append(b->seq_off, n) &&
               s.qual_off.append(b->qual_off, n) && s.cigar.append(b->cigar, b->n_cigar_total) &&

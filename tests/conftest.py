@@ -42,6 +42,18 @@ def hip_lib():
     return capi.load_product()
 
 
+@pytest.fixture(scope="session", params=["sim", pytest.param("hip", marks=pytest.mark.gpu)])
+def dev_lib(request):
+    """The device algorithm behind the C-ABI, twice: [hip] = the product library on the GPU (gpu-marked: the parity tests
+    proper), [sim] = the same test body against the CPU lane simulator, so that the CPU suite executes every assertion a
+    GPU test makes (a stale literal cannot hide until the GPU box runs it)."""
+    from bam_readcount_amd import capi
+    if request.param == "hip":
+        return capi.load_product()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    return capi.Library(os.path.join(ROOT, "tests", "sim", "libbrc_sim.so"))
+
+
 def load_fixture(name):
     z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
     arrs = {k: z[k] for k in z.files}

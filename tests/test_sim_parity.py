@@ -1,6 +1,7 @@
 """CPU-only checks of the DEVICE algorithm (bam_readcount_amd/csrc/brc_core.h run lane-by-lane by tests/sim)
-and the host formatter against the oracle and the reference goldens.  The GPU parity tests (test_gpu_parity.py)
-repeat these through the HIP library."""
+and the host formatter against the oracle.  The parity tests proper live in test_gpu_parity.py, whose every body runs
+twice — [sim] here on the CPU, [hip] on the GPU (conftest.py: dev_lib); this file keeps what only the simulator can do
+(host formatter internals, staging refusals) and the shared FUZZ table."""
 import os
 import subprocess
 
@@ -12,25 +13,6 @@ from conftest import ROOT
 import parity
 import synth
 from test_oracle_golden import CASES, golden, run_case
-
-
-@pytest.mark.parametrize("name,opts,bad_rg", CASES)
-def test_sim_matches_reference_goldens(sim_lib, test_bam, name, opts, bad_rg):
-    text, _ = run_case(sim_lib, test_bam, opts, bad_rg)
-    assert text == golden(name)
-
-
-def test_sim_full_window_of_test_bam_equals_oracle(sim_lib, oracle_lib, test_bam):
-    # 21:10402737-10405248 -> 796 emitted lines, sum of depths 96243
-    names = [str(s) for s in test_bam["lib_names"]]
-    for per_lib in (False, True):
-        for ic in (False, True):
-            text, res = parity.compare_libs(sim_lib, oracle_lib, test_bam, [(10402736, 10405248)], tid=20, chrom="21",
-                                            ref=test_bam["ref"], lib_names=names if per_lib else (), per_lib=per_lib,
-                                            insertion_centric=ic)
-            lines = text.decode().splitlines()
-            assert len(lines) == 796
-            assert sum(int(l.split("\t")[3]) for l in lines) == 96243
 
 
 FUZZ = [
@@ -47,44 +29,11 @@ FUZZ = [
 ]
 
 
-@pytest.mark.parametrize("case", FUZZ, ids=lambda c: "seed%d-%s" % (c["seed"], c["style"]))
-def test_sim_fuzz_equals_oracle(sim_lib, oracle_lib, case):
-    rng = np.random.default_rng(case["seed"])
-    ref = synth.make_ref(rng, 3000, weird=case.get("weird", 0.0))
-    n_libs = case.get("n_libs", 1)
-    arrs = synth.make_batch(case["seed"] + 100, ref, case["n"], style=case["style"], n_libs=n_libs,
-                            p_nolib=case.get("p_nolib", 0.0))
-    names = ["lib%c" % (65 + i) for i in range(n_libs)] if case["opts"].get("per_lib") else ()
-    regions = [(0, 3000), (100, 101), (700, 1500), (2990, 3200), (1500, 1500)]
-    nolib = case.get("p_nolib", 0.0) > 0
-    parity.compare_libs(sim_lib, oracle_lib, arrs, regions, ref=ref, lib_names=names, check_warn=not nolib, **case["opts"])
-
-
 def test_sim_without_reference(sim_lib, oracle_lib):
     rng = np.random.default_rng(77)
     ref = synth.make_ref(rng, 1000)
     arrs = synth.make_batch(78, ref, 150, style="indel")
     parity.compare_libs(sim_lib, oracle_lib, arrs, [(0, 1000)], ref=None)
-
-
-def test_sim_empty_and_ragged(sim_lib, oracle_lib):
-    rng = np.random.default_rng(5)
-    ref = synth.make_ref(rng, 500)
-    arrs = synth.make_batch(6, ref, 40, style="indel", region=(200, 300))
-    # empty region (no reads overlap), region before/after all reads, single base, zero reads pushed
-    text, res = parity.compare_libs(sim_lib, oracle_lib, arrs, [(0, 50), (480, 500), (250, 251), (0, 500)], ref=ref)
-    assert res[0].n_pos == 0
-    empty = capi.select_reads(arrs, [])
-    parity.compare_libs(sim_lib, oracle_lib, empty, [(0, 100)], ref=ref)
-
-
-def test_sim_max_count(sim_lib, oracle_lib):
-    rng = np.random.default_rng(11)
-    ref = synth.make_ref(rng, 400)
-    arrs = synth.make_batch(12, ref, 300, style="simple", region=(100, 110), read_len=(50, 60))
-    arrs["pos"] = np.sort(np.where(np.arange(300) % 3 == 0, 100, arrs["pos"])).astype(np.int32)
-    for d in (1, 5, 40):
-        parity.compare_libs(sim_lib, oracle_lib, arrs, [(90, 200)], ref=ref, max_cnt=d)
 
 
 def test_fmt_f2_matches_printf(sim_lib):
@@ -119,39 +68,6 @@ def test_threaded_formatter_chunk_boundaries(sim_lib, oracle_lib, monkeypatch):
         assert got == want, (chunk, threads)
 
 
-KNOBS = [{"BRC_NO_TABLE": "1"}, {"BRC_FLUSH_K": "3"}, {"BRC_PACK_LIM": "255", "BRC_FLUSH_K": "9"}, {"BRC_FORCE_DOM": "0"},
-         {"BRC_FORCE_DOM": "3", "BRC_FLUSH_K": "1"}, {"BRC_FORCE_DOM": "5", "BRC_PACK_LIM": "255"}]
-
-
-@pytest.mark.parametrize("env", KNOBS, ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()))
-def test_sim_rare_device_paths(sim_lib, oracle_lib, monkeypatch, env):
-    """The rarely taken paths of the piece walk, forced by test knobs (see tests/test_gpu_parity.py::test_hip_rare_device_paths)."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    rng = np.random.default_rng(99)
-    ref = synth.make_ref(rng, 3000, weird=0.01)
-    arrs = synth.make_batch(199, ref, 700, style="mixed", n_libs=3, p_nolib=0.02)
-    names = ["libA", "libB", "libC"]
-    parity.compare_libs(sim_lib, oracle_lib, arrs, [(0, 3000), (1200, 1300)], ref=ref, lib_names=names, per_lib=True, check_warn=False)
-    parity.compare_libs(sim_lib, oracle_lib, arrs, [(0, 3000)], ref=ref, min_mapq=5, min_bq=10, insertion_centric=True)
-    deep = synth.make_batch(299, ref, 2500, style="mixed", region=(900, 1400), read_len=(100, 150))
-    parity.compare_libs(sim_lib, oracle_lib, deep, [(800, 1600)], ref=ref)
-
-
-@pytest.mark.parametrize("case", FUZZ, ids=lambda c: "seed%d-%s" % (c["seed"], c["style"]))
-def test_sim_device_text_equals_oracle_on_every_fuzz_family(sim_lib, oracle_lib, case):
-    """Device-side text through the same regions as test_sim_fuzz_equals_oracle, deletion queues carried across regions
-    (no clear between them, like regions given on the command line) and cleared (site-list mode)."""
-    rng = np.random.default_rng(case["seed"])
-    ref = synth.make_ref(rng, 3000, weird=case.get("weird", 0.0))
-    n_libs = case.get("n_libs", 1)
-    arrs = synth.make_batch(case["seed"] + 100, ref, case["n"], style=case["style"], n_libs=n_libs, p_nolib=case.get("p_nolib", 0.0))
-    names = ["lib%c" % (65 + i) for i in range(n_libs)] if case["opts"].get("per_lib") else ()
-    regions = [(0, 3000), (100, 101), (700, 1500), (1500, 1501), (1501, 2200), (2990, 3200), (1500, 1500), (5, 900)]
-    for clear in (True, False):
-        want, _ = parity.run_engine(oracle_lib, arrs, regions, ref=ref, lib_names=names, clear_queue=clear, **case["opts"])
-        got, _ = parity.run_engine(sim_lib, arrs, regions, ref=ref, lib_names=names, clear_queue=clear, device_text="chrS", **case["opts"])
-        assert got == want, clear
 
 
 @pytest.mark.parametrize("case", [FUZZ[2], FUZZ[4], FUZZ[6], FUZZ[7]], ids=lambda c: "seed%d-%s" % (c["seed"], c["style"]))
@@ -194,18 +110,6 @@ def test_sim_deep_indel_key_equals_oracle(sim_lib, oracle_lib):
         assert max(int(d["i"][0]) for d in res[0].indels) > 100
 
 
-def test_sim_sequenceless_secondary_read(sim_lib, oracle_lib):
-    """A secondary alignment stored without its sequence (SEQ '*', l_qseq 0) but with a CIGAR: in the columns, never counted."""
-    rng = np.random.default_rng(1)
-    ref = synth.make_ref(rng, 600)
-    arrs = synth.add_sequenceless_secondary(synth.make_batch(5, ref, 60, style="simple", region=(100, 300)), 200)
-    arrs = synth.add_sequenceless_secondary(arrs, 420, span=30)            # beyond every other read: positions that print only because of it
-    for kw in (dict(), dict(min_mapq=10, min_bq=5), dict(per_lib=True, lib_names=["libA"])):
-        text, _ = parity.compare_libs(sim_lib, oracle_lib, arrs, [(0, 600)], ref=ref, **kw)
-        got, _ = parity.run_engine(sim_lib, arrs, [(0, 600)], ref=ref, device_text="chrS", **kw)
-        assert got == text and b"\t421\t" in text
-
-
 def test_push_reads_refuses_inconsistent_records(sim_lib):
     """The staging code is the last stop before the kernels index a read's rows: a CIGAR that walks more or fewer query bases
     than the record has, offsets outside the arenas and unsorted reads are errors, not work."""
@@ -220,7 +124,16 @@ def test_push_reads_refuses_inconsistent_records(sim_lib):
         with pytest.raises(capi.BrcError) as ei:
             eng.push_reads(arrs)
         assert what in str(ei.value), str(ei.value)
+        # the refused batch abandons the region (its staging is half appended): a later batch is not taken on top of it ...
+        with pytest.raises(capi.BrcError) as ei:
+            eng.push_reads(good)
+        assert "outside an open region" in str(ei.value)
+        # ... and the next region of the same engine starts clean
+        eng.begin_region(0, 0, 500, ref); eng.push_reads(good); again = eng.end_region()
+        assert again.n_events == clean.n_events and np.array_equal(again.istat, clean.istat)
         eng.close()
+    eng = capi.Engine(sim_lib)
+    eng.begin_region(0, 0, 500, ref); eng.push_reads(good); clean = eng.end_region(); eng.close()
     bad = {k: v.copy() for k, v in good.items()}
     bad["l_qseq"][5] += 3
     refused(bad, "CIGAR and sequence length disagree")
