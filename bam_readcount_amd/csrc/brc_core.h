@@ -15,8 +15,9 @@
 //                                                   tile, in stream order = pileup column order; BasicStat::process_read
 //                                                   per event into two register-resident buckets with packed integers
 //                                                   (BasicStat.cpp:28-107, bamreadcount.cpp:276-348)
-//   KI  reduce_indel_key  one lane per (pos,lib) : ordered reduction of that key's indel events into
-//                                                   per-allele BasicStats (bamreadcount.cpp:315-342)
+//   KI  reduce_indel_bucket one lane per (tile,lib): the bucket's indel events sorted by (position, library, read), every
+//                                                   key's run folded in column order into per-allele BasicStats
+//                                                   (bamreadcount.cpp:315-342)
 #ifndef BRC_CORE_H
 #define BRC_CORE_H
 
@@ -81,6 +82,7 @@ struct DevIn {
     // (rows are padded to multiples of 8 elements so every row is 16-byte aligned: KB bulk-loads row windows as uint4)
     const uint16_t* bq;
     const uint64_t* bq_row;  // [n_reads] host-computed prefix sums of roundup8(l_qseq)
+    const uint32_t* iev_off; // [n_reads] host-computed: first slot of the read in the raw indel-event list (one slot per I/D/P operator)
     const struct RcpPair* rcp;   // [n_reads], device-produced by K1
 };
 
@@ -715,28 +717,25 @@ BRC_HD bool same_allele(const DevIn& in, const DRead* reads, const IndelEv& a, c
     return true;
 }
 
-// KI: ordered reduction of the n events of one (position, library) key.  ev[0..n) hold the key's events in
-// arbitrary order; they are first sorted by read index (= pileup column order), then folded into out[0..na)
-// (one IndelOut per distinct allele, first-seen order).  Returns na.  w_sm/w_nm: warning counts.
-BRC_HD int reduce_indel_key(const DevCfg& c, const DevIn& in, const DRead* reads, IndelEv* ev, int n, int32_t pos, int lib,
-                            IndelOut* out, uint32_t& w_sm, uint32_t& w_nm) {
-    (void)c;
+// Order of the indel events inside a bucket: by key (position, library), then by read index (= pileup column order; a read
+// has at most one event per key, so there are no ties).
+BRC_HD bool iev_before(const IndelEv& a, const IndelEv& b) { return a.key_lo < b.key_lo || (a.key_lo == b.key_lo && a.read < b.read); }
+BRC_HD void sort_indel_events(IndelEv* ev, int n) {
     if (n <= 48) {
-        for (int i = 1; i < n; ++i) {                                   // insertion sort by read index: n is tiny as a rule
+        for (int i = 1; i < n; ++i) {                                   // insertion sort: n is tiny as a rule
             const IndelEv t = ev[i]; int j = i - 1;
-            while (j >= 0 && ev[j].read > t.read) { ev[j + 1] = ev[j]; --j; }
+            while (j >= 0 && iev_before(t, ev[j])) { ev[j + 1] = ev[j]; --j; }
             ev[j + 1] = t;
         }
     } else {
-        // deep targeted data can put thousands of reads on one indel: heapsort (in place, n log n moves; a read has one
-        // event per key, so no ties)
+        // deep targeted data can put thousands of reads on one indel: heapsort (in place, n log n moves)
         auto sift = [&](int root, int end) {
             const IndelEv t = ev[root];
             for (;;) {
                 int ch = 2 * root + 1;
                 if (ch >= end) break;
-                if (ch + 1 < end && ev[ch + 1].read > ev[ch].read) ++ch;
-                if (ev[ch].read <= t.read) break;
+                if (ch + 1 < end && iev_before(ev[ch], ev[ch + 1])) ++ch;
+                if (!iev_before(t, ev[ch])) break;
                 ev[root] = ev[ch]; root = ch;
             }
             ev[root] = t;
@@ -744,6 +743,13 @@ BRC_HD int reduce_indel_key(const DevCfg& c, const DevIn& in, const DRead* reads
         for (int i = n / 2 - 1; i >= 0; --i) sift(i, n);
         for (int e2 = n - 1; e2 > 0; --e2) { const IndelEv t = ev[0]; ev[0] = ev[e2]; ev[e2] = t; sift(0, e2); }
     }
+}
+
+// KI: ordered reduction of the n events of one (position, library) key, already in read order (= pileup column order): folded
+// into out[0..na) (one IndelOut per distinct allele, first-seen order).  Returns na.  w_sm/w_nm: warning counts.
+BRC_HD int fold_indel_key(const DevCfg& c, const DevIn& in, const DRead* reads, const IndelEv* ev, int n, int32_t pos, int lib,
+                          IndelOut* out, uint32_t& w_sm, uint32_t& w_nm) {
+    (void)c;
     int na = 0;
     for (int i = 0; i < n; ++i) {
         const IndelEv e = ev[i];
@@ -774,20 +780,26 @@ BRC_HD int reduce_indel_key(const DevCfg& c, const DevIn& in, const DRead* reads
     return na;
 }
 
-// ---------------------------------------------------------------- tile -> read range
-
-// Tile t covers plane indices [t*TILE, t*TILE+TILE).  lo = first read whose running-max end exceeds the tile's
-// first position (no earlier read can cover any of its positions); hi = first read starting after its last one.
-BRC_HD void tile_range(const DevCfg& c, const int32_t* prefmax_end, const DRead* reads, int64_t t, uint32_t& lo, uint32_t& hi) {
-    const int64_t p0 = (int64_t)c.pos0 + t * TILE;
-    const int64_t p1 = p0 + TILE - 1;
-    int64_t a = 0, b = c.n_reads;
-    while (a < b) { const int64_t m = (a + b) >> 1; if ((int64_t)prefmax_end[m] > p0) b = m; else a = m + 1; }
-    lo = (uint32_t)a;
-    a = lo; b = c.n_reads;
-    while (a < b) { const int64_t m = (a + b) >> 1; if ((int64_t)reads[m].pos > p1) b = m; else a = m + 1; }
-    hi = (uint32_t)a;
+// The indel side path works on BUCKETS of events: bucket = (64-position tile, library), the events of a region's reads
+// scattered into them in any order (k_indel_scatter).  One lane reduces one bucket: sort by (key, read), fold every key's
+// run into out[run start ..] (one slot per event: a key's alleles take the first na slots of its run, the others get
+// len = 0), skipping the keys of positions abandoned for a library-less read (bamreadcount.cpp:281-284).
+BRC_HD void reduce_indel_bucket(const DevCfg& c, const DevIn& in, const DRead* reads, IndelEv* ev, int n, const uint32_t* unavail,
+                                IndelOut* out, uint32_t& w_sm, uint32_t& w_nm) {
+    sort_indel_events(ev, n);
+    for (int i = 0; i < n;) {
+        int j = i + 1;
+        while (j < n && ev[j].key_lo == ev[i].key_lo) ++j;
+        const int64_t k = (int64_t)ev[i].key_lo / c.Lp; const int lib = (int)((int64_t)ev[i].key_lo % c.Lp);
+        int na = 0;
+        if (!(c.per_lib && unavail[k] != NONE32))
+            na = fold_indel_key(c, in, reads, ev + i, j - i, (int32_t)(c.pos0 + k), lib, out + i, w_sm, w_nm);
+        for (int q = i + na; q < j; ++q) out[q].len = 0;
+        i = j;
+    }
 }
+// bucket of an event key (key = plane index * Lp + library)
+BRC_HD uint32_t indel_bucket(const DevCfg& c, uint32_t key) { return (uint32_t)(((int64_t)key / c.Lp / TILE) * c.Lp + (int64_t)key % c.Lp); }
 
 // ================================================================ device-side text (the "on device" option)
 //

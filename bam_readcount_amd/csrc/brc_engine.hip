@@ -5,10 +5,11 @@
 //   k_refcode       reference characters -> 4-bit codes
 //   k_annotate_groups  K1: fetch_func's Zm integers per read (8 bases per lane, byte-parallel), the event-word stream
 //                   (quality << 8 | bucket per base) and the read's PIECES (walk_pieces): 64-B hot + 32-B cold records in
-//                   library-major slots; also counts each read's indel events per (position, library) key
+//                   library-major slots; also writes each read's indel events to its slots of the raw event list and counts
+//                   them per (tile, library) bucket
 //   k_unavail       -p only: first library-less read of every column (those positions are abandoned, :281-284)
 //   k_scan_*        3-phase scans: running max of piece reaches per library (tile lower bounds), exclusive sum of
-//                   indel-event counts (per-key offsets)
+//                   indel-event counts (per-bucket offsets)
 //   k_tiles         [lo,hi) piece range of every 64-position tile of a library, one coalesced pass over its pieces
 //   k_pileup2       THE hot kernel: one wave per (tile, library), lane == reference position, wave-uniform walk over the
 //                   tile's pieces in column order: piece records by scalar loads, event-word windows staged into LDS by
@@ -16,7 +17,8 @@
 //                   coalesced 256-B plane stores.  Integer/byte work, HBM-bound: no MFMA by design.
 //   k_xev_compact   the 1024 third-allele sub-lists (one atomic cursor each) -> one list
 //   k_finalize      emitted-position count + per-tile partial counters
-//   k_indel_fill / k_indel_reduce   indel side path (<1 % of events): keyed fill, ordered per-key reduction
+//   k_indel_scatter / k_indel_reduce   indel side path (<1 % of events), sparse: raw events -> (tile, library) buckets,
+//                   one lane per bucket sorts by (position, library, read) and folds every key in column order
 //   k_text_len / k_text_write   BRC_OPT_DEVICE_TEXT: the lines pileup_func prints, written from the compact result
 //                   (brc_core.h: text_line): byte lengths -> exclusive scan -> bytes
 //
@@ -48,6 +50,18 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+
+// sum over the 64 lanes of a 32-bit value, result in every lane's return value (wave-uniform): six adds on the DPP
+// network (quad swaps, mirrors inside a row of 16, row broadcasts) instead of six ds_bpermute round trips
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);    // row_half_mirror
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true);    // row_mirror: every lane holds its row's sum
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // ---------------------------------------------------------------- K1
@@ -110,7 +124,7 @@ __device__ __forceinline__ uint32_t nzb7(uint32_t x) { return x + 0x7f7f7f7fu; }
 #endif
 __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, DevIn in, DRead* __restrict__ reads, const uint32_t* __restrict__ piece_off,
                                                          PieceHot* __restrict__ hot, PieceCold* __restrict__ cold, int32_t* __restrict__ key, int32_t* __restrict__ reach,
-                                                         uint16_t* __restrict__ bq, uint32_t* __restrict__ indel_cnt,
+                                                         uint16_t* __restrict__ bq, IndelEv* __restrict__ ev_raw, uint32_t* __restrict__ bucket_cnt,
                                                          const uint32_t* __restrict__ cigar_ro, const uint8_t* __restrict__ qual_ro,
                                                          const uint8_t* __restrict__ seq_ro, const uint8_t* __restrict__ refcode) {
     struct WaveLds { AnnPar par[64]; int32_t lo[64], hi[64]; uint32_t sum[64]; uint32_t redo[64]; uint32_t G[64]; uint8_t mark[64]; };
@@ -131,7 +145,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
     const uint64_t qoff = in.qual_off[my], soff = in.seq_off[my], brow = in.bq_row[my];
     const uint32_t coff = (uint32_t)in.cig_off[my];
     int32_t rlen = 0; int clipped = L, left_clip = 0, right_clip = L; int64_t tot_d = 0, tot_is = 0;
-    uint32_t cig0 = 0;
+    uint32_t cig0 = 0, n_idp = 0;                     // n_idp: I / D / P operators = the read's slots in the raw indel-event list
     CigShape shape;
     int n_m = 0; int32_t m1lo = 0, m1hi = 0, m2lo = 0, m2hi = 0; int64_t d1 = 0, d2 = 0;
     {
@@ -142,6 +156,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
             const uint32_t op = cg & 0xfu; const int len = (int)(cg >> 4);
             shape_add(shape, op, len);
             if (is_refop(op)) rlen += len;
+            if (op == CINS || op == CDEL || op == CPAD) ++n_idp;
             if (op == CDEL || op == CREF_SKIP) tot_d += len;
             if (op == CINS || op == CSOFT_CLIP) tot_is += len;
             if (op == CSOFT_CLIP) { clipped -= len; if (k == 0) left_clip += len; else right_clip -= len; }
@@ -388,9 +403,17 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
             hot[slot] = h; cold[slot] = cd; key[slot] = pos; reach[slot] = rs + ext; ++slot;
         });
     }
-    if (indel_cnt && !simple) {
+    if (ev_raw && n_idp) {
+        // indel events of this read (bamreadcount.cpp:315-342), written to the read's own slots of the raw list (the host
+        // counted one slot per I / D / P operator: no cursor, no atomics on the list) and counted per (tile, library) bucket;
+        // slots the read does not use are marked empty
         const int lib = (int)((r.misc >> 16) & 0xffu) - 1;
-        enumerate_indels(c, in, r, qual_ro + qoff, [&](int32_t p, int, int) { atomicAdd(&indel_cnt[(int64_t)(p - c.pos0) * c.Lp + lib], 1u); });
+        IndelEv* slot = ev_raw + in.iev_off[my]; uint32_t used = 0;
+        enumerate_indels(c, in, r, qual_ro + qoff, [&](int32_t p, int qpos, int len) {
+            IndelEv e; e.read = (uint32_t)my; e.qpos = qpos; e.len = len; e.key_lo = (uint32_t)((int64_t)(p - c.pos0) * c.Lp + lib);   // (keys fit 32 bits: checked at upload)
+            if (used < n_idp) { slot[used++] = e; atomicAdd(&bucket_cnt[indel_bucket(c, e.key_lo)], 1u); }
+        });
+        for (; used < n_idp; ++used) slot[used].key_lo = NONE32;
     }
 }
 
@@ -603,7 +626,8 @@ struct PRec { u32x8 f; u32x2 g; };
 #endif
 __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_eu(BRC_WAVES_PER_EU, BRC_WAVES_PER_EU))) void k_pileup2(DevCfg c, DevIn in, const uint4* __restrict__ hot4, const PieceCold* __restrict__ cold,
                                                                const uint2* __restrict__ rng, int64_t ntiles, Planes pl, uint4* __restrict__ tile_ctr,
-                                                               const uint16_t* __restrict__ bq_ro, const uint32_t* __restrict__ unavail_ro) {
+                                                               const uint16_t* __restrict__ bq_ro, const uint32_t* __restrict__ unavail_ro,
+                                                               const uint8_t* __restrict__ refcode) {
     // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch order); give every XCD one contiguous
     // run of tiles so neighbouring tiles, which share most of their pieces, hit the same 4-MiB L2.
     const uint32_t nbk = gridDim.x;           // multiple of 8
@@ -643,7 +667,16 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
     const int32_t p0 = (int32_t)(c.pos0 + tile * TILE);                     // first position of the tile (scalar)
 
     LaneAcc2 a;
-    lane2_init(a, c.force_dom >= 0 ? (uint32_t)c.force_dom : (valid ? dominant_bucket(c, in, p) : 1u));
+    {
+        // dominant bucket = the bucket of the position's reference base (dominant_bucket, brc_core.h), from the 4-bit codes
+        // k_refcode wrote for K1 (padded with code 15 on both sides; a NUL character has code 15 in its low nibble too)
+        uint32_t dom = 1u;
+        if (c.has_ref && valid) {
+            const int64_t ri = (int64_t)p - c.ref_lo;
+            dom = (ri >= -(int64_t)REFCODE_PAD && ri < c.ref_hi - c.ref_lo + (int64_t)REFCODE_PAD) ? canon_bucket(refcode[ri] & 15u) : 5u;
+        }
+        lane2_init(a, c.force_dom >= 0 ? (uint32_t)c.force_dom : dom);
+    }
     bool flushed = false;                                                   // (scalar) the slot planes of this tile hold partial integer sums
     unsigned long long wsm_tot = 0, wnm_tot = 0;                            // (scalar) warnings moved out of the lanes at flushes
 
@@ -782,7 +815,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
 #define BRC_FLUSH()                                                                                                     \
         {                                                                                                                 \
             if (valid) lane2_flush(c, pl, lib, kk, a, flushed);                                                           \
-            wsm_tot += wave_sum_u64(valid ? (a.ww & 0xffffu) : 0u); wnm_tot += wave_sum_u64(valid ? (a.ww >> 16) : 0u); a.ww = 0u; \
+            wsm_tot += wave_sum_u32(valid ? (a.ww & 0xffffu) : 0u); wnm_tot += wave_sum_u32(valid ? (a.ww >> 16) : 0u); a.ww = 0u; \
             flushed = true; since_flush = 0;                                                                              \
         }
         // between half-batches: drain the queue (the event words of this half-batch are still staged in ring half hoff),
@@ -883,30 +916,55 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
 #undef BRC_STAGE
 #undef BRC_LD_TAB
     }
-    // ---- end of the tile: registers -> the two slots of every position (coalesced: lane == position)
+    // ---- end of the tile: registers -> the two slots of every position (coalesced: lane == position).  Every plane address
+    // is a wave-uniform base in a scalar register pair + the lane's byte offset, one VGPR for all 29 stores; the bases advance
+    // by scalar adds.  (Inline assembly: left to the optimiser, the lane offset is folded into ONE 64-bit vector address and
+    // the other 28 are derived from it with a 64-bit vector add each.)
     if (inreg && c.variant != 1) {
         const int64_t P = c.PS;
-        pl.ncol[(int64_t)lib * P + k] = a.ncol;                            // (dead lanes accumulated nothing: zeros)
-        pl.depth[(int64_t)lib * P + k] = a.depth;
-        pl.slotid[(int64_t)lib * P + k] = a.dom_b | (a.alt_b << 8);
+        const int64_t tb = tile * TILE;                                    // (scalar) plane index of lane 0
+        const uint32_t loff = (uint32_t)lane << 2;
+#define BRC_ST(base, val) asm volatile("global_store_dword %0, %1, %2" :: "v"(loff), "v"(val), "s"(base) : "memory")
+        const uint32_t sid = a.dom_b | (a.alt_b << 8);
+        { const uint32_t* q = pl.ncol + (int64_t)lib * P + tb; BRC_ST(q, a.ncol); }       // (dead lanes accumulated nothing: zeros)
+        { const uint32_t* q = pl.depth + (int64_t)lib * P + tb; BRC_ST(q, a.depth); }
+        { const uint32_t* q = pl.slotid + (int64_t)lib * P + tb; BRC_ST(q, sid); }
         uint32_t dv[NI], av[NI];
         pack_unpack(a.dom, a.dom_b, dv); pack_unpack(a.alt, a.alt_b, av);
-        uint32_t* i0 = slot_i(c, pl, lib, 0u, k); uint32_t* i1 = slot_i(c, pl, lib, 1u, k);
-        float* f0 = slot_f(c, pl, lib, 0u, k); float* f1 = slot_f(c, pl, lib, 1u, k);
-        const bool add = flushed && !dead;                                 // (uniform but for dead lanes) earlier flushes of this tile
+        uint32_t* i0 = slot_i(c, pl, lib, 0u, tb); uint32_t* i1 = slot_i(c, pl, lib, 1u, tb);
+        if (__builtin_expect(flushed, 0)) {
+            // (wave-uniform) earlier flushes of this tile left partial integer sums in the planes; dead lanes never flush
 #pragma unroll
-        for (int f = 0; f < NI; ++f) {
-            i0[(int64_t)f * P] = dv[f] + (add ? i0[(int64_t)f * P] : 0u);
-            i1[(int64_t)f * P] = av[f] + (add ? i1[(int64_t)f * P] : 0u);
+            for (int f = 0; f < NI; ++f) {
+                const uint32_t x0 = i0[(int64_t)f * P + lane], x1 = i1[(int64_t)f * P + lane];
+                dv[f] += dead ? 0u : x0; av[f] += dead ? 0u : x1;
+            }
         }
+        {
+            const uint32_t* q0 = i0; const uint32_t* q1 = i1;
 #pragma unroll
-        for (int f = 0; f < NF; ++f) { f0[(int64_t)f * P] = a.dom.f[f]; f1[(int64_t)f * P] = a.alt.f[f]; }
+            for (int f = 0; f < NI; ++f) { BRC_ST(q0, dv[f]); BRC_ST(q1, av[f]); q0 += P; q1 += P; }
+            const float* g0 = slot_f(c, pl, lib, 0u, tb); const float* g1 = slot_f(c, pl, lib, 1u, tb);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) { BRC_ST(g0, a.dom.f[f]); BRC_ST(g1, a.alt.f[f]); g0 += P; g1 += P; }
+        }
+#undef BRC_ST
     }
-    unsigned long long ev = (valid && p >= c.beg0) ? a.ncol : 0u;
-    unsigned long long wsm = valid ? (a.ww & 0xffffu) : 0u, wnm = valid ? (a.ww >> 16) : 0u, wl = (dead && lib == 0) ? 1u : 0u;
-    ev = wave_sum_u64(ev); wsm = wave_sum_u64(wsm) + wsm_tot; wnm = wave_sum_u64(wnm) + wnm_tot; wl = wave_sum_u64(wl);
-    // per-(tile, library) partials; k_finalize sums them (a single-address atomic per wave costs ~12 ns x 780 k waves)
-    if (lane == 0) tile_ctr[(int64_t)lib * ntiles + tile] = make_uint4((uint32_t)ev, (uint32_t)wsm, (uint32_t)wnm, (uint32_t)wl);
+    // per-(tile, library) partials; k_finalize sums them (a single-address atomic per wave costs ~12 ns x 780 k waves):
+    // events (columns of the reporting window), the lanes' warning counters, abandoned positions, and — when there is one
+    // library — the emitted positions (with several, a position prints if ANY library's column is non-empty: k_finalize
+    // looks at the ncol planes then)
+    const bool rep = valid && p >= c.beg0;
+    const uint32_t ev_lo = wave_sum_u32(rep ? (a.ncol & 0xffffu) : 0u);
+    const uint64_t m_big = __builtin_amdgcn_ballot_w64(rep && (a.ncol >> 16) != 0u);
+    unsigned long long ev = ev_lo;
+    if (__builtin_expect(m_big != 0ull, 0)) ev += (unsigned long long)wave_sum_u32(rep ? (a.ncol >> 16) : 0u) << 16;
+    const unsigned long long wsm = wave_sum_u32(valid ? (a.ww & 0xffffu) : 0u) + wsm_tot, wnm = wave_sum_u32(valid ? (a.ww >> 16) : 0u) + wnm_tot;
+    const uint32_t wl = lib == 0 ? (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(dead)) : 0u;
+    const uint32_t npos = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(rep && a.ncol != 0u));
+    // (ev of one tile: 64 lanes x a column count; the 32-bit slot holds it up to 67 M reads deep — deeper, it saturates the
+    // warning slots first: all four are summed in 64 bits by k_finalize, a tile's share travels in 32)
+    if (lane == 0) tile_ctr[(int64_t)lib * ntiles + tile] = make_uint4((uint32_t)ev, (uint32_t)wsm, (uint32_t)wnm, wl | (npos << 8));
 }
 
 template <int NV>
@@ -919,13 +977,16 @@ __device__ __forceinline__ void block_sum_u64(unsigned long long (&v)[NV], unsig
     if (threadIdx.x == 0) for (int i = 0; i < NV; ++i) { unsigned long long t = 0; for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += sh[k * NV + i]; v[i] = t; }
 }
 
-// emitted-position count + sum of the per-tile partials; grid-stride, one set of atomics per work-group
+// sum of the per-(tile, library) partials of k_pileup2 (events, warnings, abandoned positions, and with one library the
+// emitted positions); with several libraries the emitted positions are counted here from the ncol planes (a position
+// prints if any library's column is non-empty).  Grid-stride, per-block partials.
 __global__ __launch_bounds__(256) void k_finalize(DevCfg c, const uint32_t* __restrict__ ncol, const uint4* __restrict__ tile_ctr,
                                                   int64_t n_tile_ctr, unsigned long long* __restrict__ part) {
     __shared__ unsigned long long sh[4 * 5];
     unsigned long long v[5] = {0, 0, 0, 0, 0};   // positions, events, w_sm, w_nm, w_lib
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     // four positions per thread and load (the plane stride PS is a multiple of 64, the planes are 16-byte aligned)
+    if (c.Lp > 1)
     for (int64_t k4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; k4 < c.P; k4 += stride * 4) {
         uint4 tot = make_uint4(0u, 0u, 0u, 0u);
         for (int l = 0; l < c.Lp; ++l) { const uint4 x = *reinterpret_cast<const uint4*>(ncol + (int64_t)l * c.PS + k4); tot.x |= x.x; tot.y |= x.y; tot.z |= x.z; tot.w |= x.w; }
@@ -935,7 +996,8 @@ __global__ __launch_bounds__(256) void k_finalize(DevCfg c, const uint32_t* __re
     }
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_tile_ctr; t += stride) {
         const uint4 x = tile_ctr[t];
-        v[1] += x.x; v[2] += x.y; v[3] += x.z; v[4] += x.w;
+        v[1] += x.x; v[2] += x.y; v[3] += x.z; v[4] += x.w & 0xffu;
+        if (c.Lp == 1) v[0] += x.w >> 8;
     }
     block_sum_u64<5>(v, sh);
     // per-block partials, summed by k_finalize_sum: thousands of atomics on one cache line cost ~12 ns each
@@ -992,19 +1054,15 @@ __global__ __launch_bounds__(256) void k_text_write(DevCfg c, DevIn in, Planes p
     (void)text_line(c, in, pl, t, k, text + off[k]);
 }
 
-__global__ __launch_bounds__(256) void k_indel_fill(DevCfg c, DevIn in, const DRead* __restrict__ reads, uint32_t* __restrict__ cursor,
-                                                    IndelEv* __restrict__ ev) {
+// raw indel events (K1: one slot per I / D / P operator, unused ones marked NONE32) -> their (tile, library) buckets;
+// cursor[] holds the buckets' start offsets (exclusive scan of K1's counts) and ends up at their ends
+__global__ __launch_bounds__(256) void k_indel_scatter(DevCfg c, const IndelEv* __restrict__ raw, int64_t n_raw, uint32_t* __restrict__ cursor,
+                                                       IndelEv* __restrict__ ev) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= c.n_reads) return;
-    if (in.n_cigar[i] < 2u) return;                   // an indel needs an M operator next to an I / D: skip without touching the record
-    const DRead r = reads[i];
-    const int lib = (int)((r.misc >> 16) & 0xffu) - 1;
-    enumerate_indels(c, in, r, in.qual + in.qual_off[i], [&](int32_t p, int qpos, int len) {
-        const int64_t key = (int64_t)(p - c.pos0) * c.Lp + lib;
-        const uint32_t slot = atomicAdd(&cursor[key], 1u);
-        IndelEv e; e.read = (uint32_t)i; e.qpos = qpos; e.len = len; e.key_lo = (uint32_t)key;   // (keys fit 32 bits: checked at upload)
-        ev[slot] = e;
-    });
+    if (i >= n_raw) return;
+    const IndelEv e = raw[i];
+    if (e.key_lo == NONE32) return;
+    ev[atomicAdd(&cursor[indel_bucket(c, e.key_lo)], 1u)] = e;
 }
 
 // -p: reads without a library abandon every position they cover (bamreadcount.cpp:281-284).  unavail[k] = index of the
@@ -1022,32 +1080,24 @@ __global__ __launch_bounds__(256) void k_unavail(DevCfg c, DevIn in, uint32_t* _
     for (int64_t k = k0; k < k1; ++k) atomicMin(&unavail[k], (uint32_t)i);
 }
 
-// cursor[key] has been advanced by k_indel_fill to the END of the key's events, which sit in consecutive slots.  One lane
-// per SLOT: the lane of a key's first slot reduces the key (the count plane is never scanned: keys with events are a few
-// in ten thousand).  A key's reduced alleles are written to out[start .. start+na); unused slots get len = 0.
+// cursor[b] has been advanced by k_indel_scatter to the END of bucket b's events, which sit in consecutive slots
+// [end - cnt[b], end).  One lane per bucket (buckets with events are a few in a hundred): reduce_indel_bucket sorts the
+// bucket and folds every key; a key's alleles are written to the first slots of its run in out[], unused slots get len = 0.
 __global__ __launch_bounds__(256) void k_indel_reduce(DevCfg c, DevIn in, const DRead* __restrict__ reads, const uint32_t* __restrict__ cnt,
-                                                      const uint32_t* __restrict__ cursor, IndelEv* __restrict__ ev,
+                                                      const uint32_t* __restrict__ cursor, int64_t n_buckets, IndelEv* __restrict__ ev,
                                                       const uint32_t* __restrict__ unavail, IndelOut* __restrict__ out,
                                                       Counters* __restrict__ ctr) {
     __shared__ unsigned long long sh[4 * 2];
     unsigned long long w[2] = {0, 0};
-    const int64_t nkeys = c.P * c.Lp;
-    const uint32_t nslots = nkeys > 0 ? cursor[nkeys - 1] : 0u;          // total number of event slots
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctr->n_indel_slots = nslots;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctr->n_indel_slots = n_buckets > 0 ? cursor[n_buckets - 1] : 0u;   // total number of event slots
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)nslots; i += stride) {
-        const uint32_t key = ev[i].key_lo;
-        if (i > 0 && ev[i - 1].key_lo == key) continue;                 // not the first slot of its key
-        const int n = (int)cnt[key];
-        const int64_t k = (int64_t)key / c.Lp; const int lib = (int)((int64_t)key % c.Lp);
-        const uint32_t start = (uint32_t)i;
-        int na = 0;
-        if (!(c.per_lib && unavail[k] != NONE32)) {                     // else: position abandoned (bamreadcount.cpp:281-284)
-            uint32_t wsm = 0, wnm = 0;
-            na = reduce_indel_key(c, in, reads, ev + start, n, (int32_t)(c.pos0 + k), lib, out + start, wsm, wnm);
-            w[0] += wsm; w[1] += wnm;
-        }
-        for (int j = na; j < n; ++j) out[start + j].len = 0;
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_buckets; b += stride) {
+        const uint32_t n = cnt[b];
+        if (!n) continue;
+        const uint32_t start = cursor[b] - n;
+        uint32_t wsm = 0, wnm = 0;
+        reduce_indel_bucket(c, in, reads, ev + start, (int)n, unavail, out + start, wsm, wnm);
+        w[0] += wsm; w[1] += wnm;
     }
     block_sum_u64<2>(w, sh);
     if (threadIdx.x == 0) {
@@ -1097,7 +1147,7 @@ class HipBackend : public Backend {
     std::vector<int64_t> lib_base;      // first piece of every library's stream (Lp + 1 entries)
     // device buffers
     DBuf d_pos, d_flag, d_mapq, d_lib, d_lq, d_nc, d_co, d_so, d_qo, d_nm, d_sm, d_tags, d_cigar, d_seq, d_qual, d_ref, d_refcode;
-    DBuf d_bq, d_bqrow, d_pieceoff, d_hot, d_cold, d_key, d_reach, d_reads, d_prefmax, d_agg, d_rng, d_ncol, d_depth, d_slotid, d_si, d_sf, d_xev, d_xevc, d_xevn, d_unavail, d_cnt, d_cursor, d_ev, d_iout, d_ctr, d_tilectr, d_part;
+    DBuf d_bq, d_bqrow, d_pieceoff, d_hot, d_cold, d_key, d_reach, d_reads, d_prefmax, d_agg, d_rng, d_ncol, d_depth, d_slotid, d_si, d_sf, d_xev, d_xevc, d_xevn, d_unavail, d_cnt, d_cursor, d_ev, d_evraw, d_ievoff, d_iout, d_ctr, d_tilectr, d_part;
     DBuf d_tlen, d_toff, d_text, d_tctx;
     // device-side text, downloaded (pinned) on its own stream into one of two host buffers
     HBuf<char> h_text[2]; HBuf<uint32_t> h_toff[2]; HBuf<uint32_t> h_total;
@@ -1145,7 +1195,7 @@ class HipBackend : public Backend {
         (void)hipSetDevice(device);
         DBuf* all[] = {&d_pos, &d_flag, &d_mapq, &d_lib, &d_lq, &d_nc, &d_co, &d_so, &d_qo, &d_nm, &d_sm, &d_tags, &d_cigar, &d_seq, &d_qual,
                        &d_ref, &d_refcode, &d_bq, &d_bqrow, &d_pieceoff, &d_hot, &d_cold, &d_key, &d_reach, &d_reads, &d_prefmax, &d_agg, &d_rng, &d_ncol, &d_depth, &d_slotid, &d_si, &d_sf, &d_xev, &d_xevc, &d_xevn, &d_unavail, &d_cnt,
-                       &d_cursor, &d_ev, &d_iout, &d_ctr, &d_tilectr, &d_part, &d_tlen, &d_toff, &d_text, &d_tctx};
+                       &d_cursor, &d_ev, &d_evraw, &d_ievoff, &d_iout, &d_ctr, &d_tilectr, &d_part, &d_tlen, &d_toff, &d_text, &d_tctx};
         for (DBuf* b : all) b->release();
         for (int i = 0; i < 2; ++i) { h_text[i].destroy(); h_toff[i].destroy(); if (ev_text[i]) (void)hipEventDestroy(ev_text[i]); }
         h_total.destroy();
@@ -1212,7 +1262,7 @@ class HipBackend : public Backend {
         const size_t P = (size_t)c.PS, Lp = (size_t)c.Lp;   // allocation sizes use the padded stride
         ntiles = (c.P + TILE - 1) / TILE;
         n_indel_cap = c.has_ref ? s.n_indel_ops : 0;
-        if (n_indel_cap && (uint64_t)c.P * (uint64_t)c.Lp >= 0xffffffffull) { err = "region too large: (positions x libraries) must stay below 2^32"; return BRC_E_ARG; }
+        if (n_indel_cap && ((uint64_t)c.P * (uint64_t)c.Lp >= 0xffffffffull || n_indel_cap >= 0xfffffff0ull)) { err = "region too large: (positions x libraries) and the indel operators must stay below 2^32"; return BRC_E_ARG; }
         const size_t nagg = std::max<size_t>((std::max<size_t>(np, P * Lp) + SCAN_CHUNK - 1) / SCAN_CHUNK, 1);
         HIPCHK(d_reads.ensure((n + 1) * sizeof(DRead))); HIPCHK(d_prefmax.ensure((np + 16) * 4));
         HIPCHK(d_agg.ensure(nagg * 4 + 16)); HIPCHK(d_agg2.ensure(nagg * 4 + 16)); HIPCHK(d_rng.ensure(((size_t)ntiles * Lp + 1) * sizeof(uint2)));
@@ -1229,8 +1279,14 @@ class HipBackend : public Backend {
         HIPCHK(d_xevn.ensure((size_t)XEV_SHARDS * XEV_CTR_STRIDE * 4));
         HIPCHK(d_part.ensure(4096 * 5 * sizeof(unsigned long long)));
         HIPCHK(d_ctr.ensure(sizeof(Counters))); HIPCHK(d_tilectr.ensure(((size_t)ntiles * Lp + 1) * sizeof(uint4)));
+        in.iev_off = nullptr;
         if (n_indel_cap) {
-            HIPCHK(d_cnt.ensure(Lp * P * 4 + 16)); HIPCHK(d_cursor.ensure(Lp * P * 4 + 16));
+            // indel side path: raw events (one slot per I / D / P operator, at host-computed per-read offsets), their counts
+            // per (tile, library) bucket, the bucketed events and the reduced alleles
+            const size_t nbk = (size_t)ntiles * Lp;
+            if ((rc = up(d_ievoff, s.iev_off, n))) return rc;
+            in.iev_off = (const uint32_t*)d_ievoff.p;
+            HIPCHK(d_cnt.ensure(nbk * 4 + 16)); HIPCHK(d_cursor.ensure(nbk * 4 + 16)); HIPCHK(d_evraw.ensure((n_indel_cap + 1) * sizeof(IndelEv)));
             HIPCHK(d_ev.ensure((n_indel_cap + 1) * sizeof(IndelEv))); HIPCHK(d_iout.ensure((n_indel_cap + 1) * sizeof(IndelOut)));
         }
         HIPCHK(hipStreamSynchronize(stream));
@@ -1260,7 +1316,8 @@ class HipBackend : public Backend {
         HIPCHK(hipMemsetAsync(ctr, 0, sizeof(Counters), stream));
         HIPCHK(hipMemsetAsync(d_xevn.p, 0, (size_t)XEV_SHARDS * XEV_CTR_STRIDE * 4, stream));
         const bool indels = n_indel_cap > 0 && P > 0 && n > 0;
-        if (indels) HIPCHK(hipMemsetAsync(d_cnt.p, 0, (size_t)(Lp * P) * 4, stream));
+        const int64_t n_buckets = ntiles * Lp;          // indel buckets: (tile, library)
+        if (indels) HIPCHK(hipMemsetAsync(d_cnt.p, 0, (size_t)n_buckets * 4, stream));
         Planes pl = {(uint32_t*)d_ncol.p, (uint32_t*)d_depth.p, (uint32_t*)d_slotid.p, (uint32_t*)d_si.p, (float*)d_sf.p, (uint32_t*)d_unavail.p,
                      (XEv*)d_xev.p, (uint32_t*)d_xevn.p, (uint32_t)xev_cap, (uint32_t)XEV_SHARDS};
         pl_last = pl;
@@ -1272,7 +1329,7 @@ class HipBackend : public Backend {
                 hipLaunchKernelGGL(k_refcode, dim3((unsigned)(((rl + 2 * REFCODE_PAD + 15) / 16 + 255) / 256)), dim3(256), 0, stream, in.ref, (uint8_t*)d_refcode.p, rl);
             hipLaunchKernelGGL(k_annotate_groups, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (const uint32_t*)d_pieceoff.p,
                                (PieceHot*)d_hot.p, (PieceCold*)d_cold.p, (int32_t*)d_key.p, (int32_t*)d_reach.p,
-                               (uint16_t*)in.bq, indels ? (uint32_t*)d_cnt.p : (uint32_t*)nullptr,
+                               (uint16_t*)in.bq, indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p,
                                in.cigar, in.qual, in.seq4, (const uint8_t*)d_refcode.p + REFCODE_PAD);
             if (c.per_lib) {
                 HIPCHK(hipMemsetAsync(d_unavail.p, 0xff, (size_t)c.PS * 4, stream));
@@ -1288,12 +1345,13 @@ class HipBackend : public Backend {
         auto launch_indel = [&](hipStream_t si, DBuf& scratch) -> int {
             HIPCHK(hipEventRecord(ev_indel[0], si));
             int r2;
-            if ((r2 = scan_on<OpSumU32, false>((const uint32_t*)d_cnt.p, (uint32_t*)d_cursor.p, (int64_t)Lp * P, si, scratch))) return r2;
+            if ((r2 = scan_on<OpSumU32, false>((const uint32_t*)d_cnt.p, (uint32_t*)d_cursor.p, n_buckets, si, scratch))) return r2;
             HIPCHK(hipEventRecord(ev_indel[1], si));
-            hipLaunchKernelGGL(k_indel_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, si, c, in, reads, (uint32_t*)d_cursor.p, (IndelEv*)d_ev.p);
+            hipLaunchKernelGGL(k_indel_scatter, dim3((unsigned)((n_indel_cap + 255) / 256)), dim3(256), 0, si, c, (const IndelEv*)d_evraw.p, (int64_t)n_indel_cap,
+                               (uint32_t*)d_cursor.p, (IndelEv*)d_ev.p);
             HIPCHK(hipEventRecord(ev_indel[2], si));
-            hipLaunchKernelGGL(k_indel_reduce, dim3((unsigned)std::min<int64_t>(((int64_t)n_indel_cap + 255) / 256 + 1, 4096)), dim3(256), 0, si, c, in, reads,
-                               (const uint32_t*)d_cnt.p, (const uint32_t*)d_cursor.p, (IndelEv*)d_ev.p, (const uint32_t*)d_unavail.p,
+            hipLaunchKernelGGL(k_indel_reduce, dim3((unsigned)std::min<int64_t>((n_buckets + 255) / 256, 4096)), dim3(256), 0, si, c, in, reads,
+                               (const uint32_t*)d_cnt.p, (const uint32_t*)d_cursor.p, n_buckets, (IndelEv*)d_ev.p, (const uint32_t*)d_unavail.p,
                                (IndelOut*)d_iout.p, ctr);
             HIPCHK(hipEventRecord(ev_indel[3], si));
             return BRC_OK;
@@ -1321,13 +1379,14 @@ class HipBackend : public Backend {
             // profiling knob: unused dynamic LDS lowers the number of resident waves (occupancy sweeps)
             static const unsigned dyn_lds = getenv("BRC_PILEUP_LDS_PAD") ? (unsigned)atoi(getenv("BRC_PILEUP_LDS_PAD")) : 0u;
             hipLaunchKernelGGL(k_pileup2, dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), dyn_lds, stream, c, in, (const uint4*)d_hot.p, (const PieceCold*)d_cold.p,
-                               (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.bq, (const uint32_t*)d_unavail.p);
+                               (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.bq, (const uint32_t*)d_unavail.p,
+                               (const uint8_t*)d_refcode.p + REFCODE_PAD);
             hipLaunchKernelGGL(k_xev_compact, dim3((unsigned)XEV_SHARDS), dim3(256), 0, stream, (const XEv*)d_xev.p, (const uint32_t*)d_xevn.p, (uint32_t)xev_cap,
                                (uint32_t)XEV_SHARDS, (XEv*)d_xevc.p, ctr);
         }
         HIPCHK(hipEventRecord(evt[T_COUNT], stream));
         if (P > 0) {
-            const unsigned nb = (unsigned)std::min<int64_t>((P / 4 + 255) / 256 + 1, 4096);
+            const unsigned nb = (unsigned)std::min<int64_t>(((Lp > 1 ? P / 4 : ntiles) + 255) / 256 + 1, Lp > 1 ? 4096 : 256);
             hipLaunchKernelGGL(k_finalize, dim3(nb), dim3(256), 0, stream, c, (const uint32_t*)d_ncol.p, (const uint4*)d_tilectr.p, (int64_t)ntiles * Lp,
                                (unsigned long long*)d_part.p);
             hipLaunchKernelGGL(k_finalize_sum, dim3(1), dim3(256), 0, stream, (const unsigned long long*)d_part.p, (int)nb, ctr);

@@ -64,18 +64,18 @@ static void parallel_for(int64_t n, unsigned nthr, F fn) {
 
 void Staged::init(const HostAlloc* A) {
     pos.A = A; flag.A = A; mapq.A = A; lib.A = A; l_qseq.A = A; n_cigar.A = A; cig_off.A = A; seq_off.A = A; qual_off.A = A;
-    nm.A = A; sm.A = A; tags.A = A; cigar.A = A; seq4.A = A; qual.A = A; bq_row.A = A; piece_cnt.A = A; piece_off.A = A; qnames.A = A; qname_off.A = A;
+    nm.A = A; sm.A = A; tags.A = A; cigar.A = A; seq4.A = A; qual.A = A; bq_row.A = A; piece_cnt.A = A; piece_off.A = A; iev_off.A = A; qnames.A = A; qname_off.A = A;
 }
 void Staged::clear() {
     pos.clear(); flag.clear(); mapq.clear(); lib.clear(); l_qseq.clear(); n_cigar.clear(); cig_off.clear(); seq_off.clear();
     qual_off.clear(); nm.clear(); sm.clear(); tags.clear(); cigar.clear(); seq4.clear(); qual.clear(); bq_row.clear();
     bq_elems = 0; memset(len_hist, 0, sizeof len_hist); n = 0; min_pos = 0; max_end = 0; n_indel_ops = 0;
-    piece_cnt.clear(); piece_off.clear(); lib_base.clear(); n_pieces = 0; max_lqseq = 0; max_span = 0; qnames.clear(); qname_off.clear();
+    piece_cnt.clear(); piece_off.clear(); iev_off.clear(); lib_base.clear(); n_pieces = 0; max_lqseq = 0; max_span = 0; qnames.clear(); qname_off.clear();
 }
 void Staged::destroy() {
     pos.destroy(); flag.destroy(); mapq.destroy(); lib.destroy(); l_qseq.destroy(); n_cigar.destroy(); cig_off.destroy();
     seq_off.destroy(); qual_off.destroy(); nm.destroy(); sm.destroy(); tags.destroy(); cigar.destroy(); seq4.destroy(); qual.destroy(); bq_row.destroy();
-    piece_cnt.destroy(); piece_off.destroy(); qnames.destroy(); qname_off.destroy();
+    piece_cnt.destroy(); piece_off.destroy(); iev_off.destroy(); qnames.destroy(); qname_off.destroy();
 }
 // library-major slots: all pieces of library 0 in file order, then library 1, ... (one stream without -p)
 void Staged::layout_pieces(int Lp, bool per_lib) {
@@ -409,7 +409,7 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
     if (e->hint_reads > n0 + n || e->hint_bases > qb + b->qual_bytes) {
         const size_t hr = std::max(e->hint_reads, n0 + n) + 16, hb = std::max<size_t>(e->hint_bases, qb + b->qual_bytes) + 16;
         bool okh = s.pos.reserve(hr) && s.flag.reserve(hr) && s.mapq.reserve(hr) && s.l_qseq.reserve(hr) && s.n_cigar.reserve(hr) && s.cig_off.reserve(hr) &&
-                   s.seq_off.reserve(hr) && s.qual_off.reserve(hr) && s.bq_row.reserve(hr) && s.piece_cnt.reserve(hr) && s.piece_off.reserve(hr) && s.lib.reserve(hr) &&
+                   s.seq_off.reserve(hr) && s.qual_off.reserve(hr) && s.bq_row.reserve(hr) && s.piece_cnt.reserve(hr) && s.piece_off.reserve(hr) && s.iev_off.reserve(hr) && s.lib.reserve(hr) &&
                    s.nm.reserve(hr) && s.sm.reserve(hr) && s.tags.reserve(hr) && s.qname_off.reserve(hr) && s.cigar.reserve(hr + hr / 4) &&
                    s.qual.reserve(hb) && s.seq4.reserve(hb / 2 + hr);
         if (!okh) return fail(e, BRC_E_NOMEM, "host staging allocation failed");
@@ -419,7 +419,7 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
               s.n_cigar.append(b->n_cigar, n) && s.cig_off.append(b->cigar_off, n) && s.seq_off.append(b->seq_off, n) &&
               s.qual_off.append(b->qual_off, n) && s.cigar.append(b->cigar, b->n_cigar_total) &&
               s.seq4.append(b->seq4, b->seq_bytes) && s.qual.append(b->qual, b->qual_bytes) &&
-              s.bq_row.reserve(n0 + n + 16) && s.piece_cnt.reserve(n0 + n + 16) && s.piece_off.reserve(n0 + n + 16) && s.lib.reserve(n0 + n + 16) && s.nm.reserve(n0 + n + 16) && s.sm.reserve(n0 + n + 16) && s.tags.reserve(n0 + n + 16);
+              s.bq_row.reserve(n0 + n + 16) && s.piece_cnt.reserve(n0 + n + 16) && s.piece_off.reserve(n0 + n + 16) && s.iev_off.reserve(n0 + n + 16) && s.lib.reserve(n0 + n + 16) && s.nm.reserve(n0 + n + 16) && s.sm.reserve(n0 + n + 16) && s.tags.reserve(n0 + n + 16);
     if (!ok) return fail(e, BRC_E_NOMEM, "host staging allocation failed");
     if (!s.qname_off.reserve(n0 + n + 16)) return fail(e, BRC_E_NOMEM, "host staging allocation failed");
     for (size_t i = 0; i < n; ++i) {
@@ -434,7 +434,7 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
         s.sm.p[n0 + i] = b->sm ? b->sm[i] : 0;
         s.tags.p[n0 + i] = b->tags ? b->tags[i] : 0;
     }
-    s.lib.n = s.nm.n = s.sm.n = s.tags.n = s.bq_row.n = s.piece_cnt.n = n0 + n;
+    s.lib.n = s.nm.n = s.sm.n = s.tags.n = s.bq_row.n = s.piece_cnt.n = s.iev_off.n = n0 + n;
     const int32_t maxcnt = e->cfg.max_cnt;
     for (size_t i = 0; i < n; ++i) {
         const size_t r = n0 + i;
@@ -463,11 +463,14 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
                 nc = 0; s.n_cigar.p[r] = 0;
             }
         }
-        const int32_t rlen = cigar_rlen(s.cigar.p + s.cig_off.p[r], nc, &s.n_indel_ops);
+        uint64_t idp = 0;                                     // I / D / P operators of the CIGAR the device will see
+        const int32_t rlen = cigar_rlen(s.cigar.p + s.cig_off.p[r], nc, &idp);
         if (rlen < 0 || (int64_t)s.pos.p[r] + rlen > (int64_t)INT32_MAX) {
             if (!(fl & FUNMAP)) return fail(e, BRC_E_ARG, "a read ends beyond the last 32-bit position");
-            nc = 0; s.n_cigar.p[r] = 0;
+            nc = 0; s.n_cigar.p[r] = 0; idp = 0;
         }
+        // the read's slots in the raw indel-event list (K1 writes every one of them: an event or an empty mark)
+        s.iev_off.p[r] = (uint32_t)s.n_indel_ops; s.n_indel_ops += idp;
         if (s.l_qseq.p[r] == 0 && nc > 0 && !(fl & (FUNMAP | BRC_NOCOUNT_MASK))) {
             // (SEQ "*" on a record that pileup_func would count: the reference takes its bases from whatever follows the
             // empty sequence in the record)

@@ -62,6 +62,7 @@ struct Staged {
     // read's first piece) and lib_base (first slot of every library's stream, Lp + 1 entries) at upload
     HBuf<char> qnames; HBuf<uint64_t> qname_off;   // read names when the caller gave them (warning text only); qname_off[i] = ~0 without
     HBuf<uint32_t> piece_cnt, piece_off;
+    HBuf<uint32_t> iev_off;             // per read: its first slot in the raw indel-event list (one slot per I / D / P operator; n_indel_ops in all)
     std::vector<int64_t> lib_base;
     int64_t n_pieces = 0;
     int32_t max_lqseq = 0;
@@ -71,7 +72,7 @@ struct Staged {
     int32_t modal_len() const { uint32_t best = 0; int32_t arg = 0; for (int l = 1; l <= TABLE_MAX; ++l) if (len_hist[l] > best) { best = len_hist[l]; arg = l; } return arg; }
     int64_t n = 0;
     int64_t min_pos = 0, max_end = 0;   // extent of reads that enter the pileup
-    uint64_t n_indel_ops = 0;           // upper bound on indel events (I/D/P operators)
+    uint64_t n_indel_ops = 0;           // I / D / P operators of all reads = slots of the raw indel-event list (an upper bound on the events)
     void init(const HostAlloc* A);
     void clear();
     void destroy();

@@ -172,33 +172,42 @@ class SimBackend : public Backend {
             uint32_t tot = 0; for (int l = 0; l < Lp; ++l) tot += ncol[(size_t)(l * PS + k)];
             if (tot) n_positions++;
         }
-        // indel events: count -> scan -> fill -> reduce
-        std::vector<uint32_t> cnt((size_t)(P * Lp) + 1, 0), off((size_t)(P * Lp) + 1, 0);
-        for (int64_t i = 0; i < n; ++i) {
-            const DRead& rd = reads[(size_t)i]; const int lib = (int)((rd.misc >> 16) & 0xffu) - 1;
-            enumerate_indels(c, in, rd, in.qual + in.qual_off[i], [&](int32_t p, int, int) { cnt[(size_t)((int64_t)(p - c.pos0) * Lp + lib)]++; });
-        }
-        uint32_t run = 0;
-        for (size_t k = 0; k < cnt.size(); ++k) { off[k] = run; run += cnt[k]; }
-        std::vector<IndelEv> ev(run + 1); std::vector<uint32_t> cur(off);
-        for (int64_t i = n - 1; i >= 0; --i) {   // reversed on purpose: the reduction must not depend on fill order
-            const DRead& rd = reads[(size_t)i]; const int lib = (int)((rd.misc >> 16) & 0xffu) - 1;
-            enumerate_indels(c, in, rd, in.qual + in.qual_off[i], [&](int32_t p, int qpos, int len) {
-                IndelEv e; e.read = (uint32_t)i; e.qpos = qpos; e.len = len; e.key_lo = 0;
-                ev[cur[(size_t)((int64_t)(p - c.pos0) * Lp + lib)]++] = e;
-            });
-        }
+        // indel side path, in the kernels' structure: K1 writes every read's events to its own slots of the raw list (one slot
+        // per I / D / P operator, unused ones marked empty) and counts them per (tile, library) bucket; scan; scatter; one
+        // reduce_indel_bucket per bucket
         iout.clear();
-        std::vector<IndelOut> tmp;
-        for (int64_t key2 = 0; key2 < P * Lp; ++key2) {
-            const int nk = (int)cnt[(size_t)key2]; if (!nk) continue;
-            const int64_t k = key2 / Lp; const int lib = (int)(key2 % Lp);
-            if (c.per_lib && unavail[(size_t)k] != NONE32) continue;                                  // position abandoned
-            tmp.resize((size_t)nk);
-            uint32_t wsm = 0, wnm = 0;
-            const int na = reduce_indel_key(c, in, reads.data(), ev.data() + off[(size_t)key2], nk, (int32_t)(c.pos0 + k), lib, tmp.data(), wsm, wnm);
-            warn[BRC_W_SM_MISSING] += wsm; warn[BRC_W_NM_MISSING] += wnm;
-            for (int a = 0; a < na; ++a) iout.push_back(tmp[(size_t)a]);
+        if (c.has_ref && P > 0 && n > 0) {
+            const int64_t nbk = ntiles * Lp;
+            std::vector<IndelEv> raw((size_t)st->n_indel_ops + 1);
+            std::vector<uint32_t> cnt((size_t)nbk + 1, 0), off((size_t)nbk + 1, 0);
+            for (int64_t i = 0; i < n; ++i) {
+                const DRead& rd = reads[(size_t)i]; const int lib = (int)((rd.misc >> 16) & 0xffu) - 1;
+                uint32_t n_idp = 0;
+                for (uint32_t k = 0; k < in.n_cigar[i]; ++k) { const uint32_t op = in.cigar[in.cig_off[i] + k] & 0xfu; if (op == CINS || op == CDEL || op == CPAD) ++n_idp; }
+                const uint64_t next = i + 1 < n ? st->iev_off.p[i + 1] : st->n_indel_ops;
+                if (next - st->iev_off.p[i] != n_idp) { err = "raw indel slots of the host and of K1 differ"; return BRC_E_ARG; }
+                IndelEv* slot = raw.data() + st->iev_off.p[i]; uint32_t used = 0;
+                enumerate_indels(c, in, rd, in.qual + in.qual_off[i], [&](int32_t p, int qpos, int len) {
+                    IndelEv e; e.read = (uint32_t)i; e.qpos = qpos; e.len = len; e.key_lo = (uint32_t)((int64_t)(p - c.pos0) * Lp + lib);
+                    if (used < n_idp) { slot[used++] = e; cnt[indel_bucket(c, e.key_lo)]++; }
+                });
+                for (; used < n_idp; ++used) slot[used].key_lo = NONE32;
+            }
+            uint32_t run = 0;
+            for (int64_t b = 0; b < nbk; ++b) { off[(size_t)b] = run; run += cnt[(size_t)b]; }
+            std::vector<IndelEv> ev(run + 1); std::vector<uint32_t> cur(off);
+            for (int64_t j = (int64_t)st->n_indel_ops - 1; j >= 0; --j) {   // reversed on purpose: the reduction must not depend on scatter order
+                const IndelEv& e = raw[(size_t)j];
+                if (e.key_lo != NONE32) ev[cur[indel_bucket(c, e.key_lo)]++] = e;
+            }
+            std::vector<IndelOut> tmp(run + 1);
+            for (int64_t b = 0; b < nbk; ++b) {
+                const uint32_t nk = cnt[(size_t)b]; if (!nk) continue;
+                uint32_t wsm = 0, wnm = 0;
+                reduce_indel_bucket(c, in, reads.data(), ev.data() + off[(size_t)b], (int)nk, unavail.data(), tmp.data() + off[(size_t)b], wsm, wnm);
+                warn[BRC_W_SM_MISSING] += wsm; warn[BRC_W_NM_MISSING] += wnm;
+            }
+            for (uint32_t j = 0; j < run; ++j) if (tmp[j].len != 0) iout.push_back(tmp[j]);
         }
         return BRC_OK;
     }

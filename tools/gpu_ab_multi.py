@@ -72,10 +72,11 @@ def main():
                 acc /= args.steps
                 eng.close()
                 ix = lambda k: kn.index(k) if k in kn else 0
-                times[name].append((acc[ix("k_pileup")], acc[ix("k_annotate")], acc.sum()))
+                times[name].append((acc[ix("k_pileup")], acc[ix("k_annotate")], _tot if False else acc.sum()) + tuple(acc))
         for name, _ in libs:
             t = np.array(times[name])
             print("%s %-10s pileup %s  median %.4f  annotate %.4f  all %.4f" % (shape, name, " ".join("%.4f" % x for x in t[:, 0]), np.median(t[:, 0]), np.median(t[:, 1]), np.median(t[:, 2])), flush=True)
+            print("%s %-10s slots %s" % (shape, name, " ".join("%s=%.3f" % (k.replace("k_", ""), v) for k, v in zip(libs[0][1].kernel_names(), np.median(t[:, 3:], axis=0)) if k)), flush=True)
 
 
 if __name__ == "__main__":
