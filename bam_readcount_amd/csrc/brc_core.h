@@ -65,6 +65,7 @@ struct DevCfg {
     int64_t n_reads;
     int32_t table_len;      // L0: modal read length of the region (host); reads with l_qseq == clipped == L0 take their terms from tables
     int32_t variant;        // 0 in production; >0 = profiling ablations selected by BRC_PILEUP_VARIANT (see brc_engine.hip)
+    int32_t ann_variant;    // 0 in production; >0 = profiling ablations of K1 selected by BRC_ANN_VARIANT (wrong results, timing only)
     int32_t force_dom;      // test knob (BRC_FORCE_DOM): -1, or the bucket every lane treats as dominant (stresses the alternate / third-allele paths)
     int64_t n_pieces;       // pieces of all libraries (KB v2)
     int32_t flush_k;        // K: pieces a lane may accumulate in its packed integer registers between two flushes (1..127)
@@ -790,7 +791,7 @@ BRC_HD void reduce_indel_bucket(const DevCfg& c, const DevIn& in, const DRead* r
     for (int i = 0; i < n;) {
         int j = i + 1;
         while (j < n && ev[j].key_lo == ev[i].key_lo) ++j;
-        const int64_t k = (int64_t)ev[i].key_lo / c.Lp; const int lib = (int)((int64_t)ev[i].key_lo % c.Lp);
+        const uint32_t k = c.Lp == 1 ? ev[i].key_lo : ev[i].key_lo / (uint32_t)c.Lp; const int lib = (int)(ev[i].key_lo - k * (uint32_t)c.Lp);
         int na = 0;
         if (!(c.per_lib && unavail[k] != NONE32))
             na = fold_indel_key(c, in, reads, ev + i, j - i, (int32_t)(c.pos0 + k), lib, out + i, w_sm, w_nm);
@@ -798,8 +799,13 @@ BRC_HD void reduce_indel_bucket(const DevCfg& c, const DevIn& in, const DRead* r
         i = j;
     }
 }
-// bucket of an event key (key = plane index * Lp + library)
-BRC_HD uint32_t indel_bucket(const DevCfg& c, uint32_t key) { return (uint32_t)(((int64_t)key / c.Lp / TILE) * c.Lp + (int64_t)key % c.Lp); }
+// bucket of an event: (tile of the plane index, library); from a key (= plane index * Lp + library) with 32-bit divisions
+BRC_HD uint32_t indel_bucket_of(const DevCfg& c, uint32_t k, uint32_t lib) { return (k / (uint32_t)TILE) * (uint32_t)c.Lp + lib; }
+BRC_HD uint32_t indel_bucket(const DevCfg& c, uint32_t key) {
+    if (c.Lp == 1) return key / (uint32_t)TILE;
+    const uint32_t k = key / (uint32_t)c.Lp;
+    return indel_bucket_of(c, k, key - k * (uint32_t)c.Lp);
+}
 
 // ================================================================ device-side text (the "on device" option)
 //

@@ -64,6 +64,10 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// the value of the lane below / above (lane 0 / lane 63 get 0): one DPP move on the gfx9 wave-shift network
+__device__ __forceinline__ int lane_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }   // wave_shr:1
+__device__ __forceinline__ int lane_shl1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }   // wave_shl:1
+
 // ---------------------------------------------------------------- K1
 
 // Reference characters -> 4-bit base codes, once per region (the annotator compares codes, bamreadcount.cpp:149-152).
@@ -106,13 +110,14 @@ __global__ __launch_bounds__(256) void k_refcode(const char* __restrict__ ref, u
 //                          and their parameters go to LDS; reads with more than two M operators, reads overhanging the
 //                          reference (the annotator's break/continue quirks) and runs without a reference are left to
 //                          the serial annotate_read() in phase C;
-//   phase B (lane = group) 64 groups per pass.  lane -> read through a per-pass marker row in LDS (ballot + mbcnt);
-//                          base codes vs reference codes, "=ACGTN" buckets and the quality != 2 test are byte-parallel;
-//                          mismatch qualities: runs of read-adjacent mismatches contribute their maximum (:152-172,199) —
-//                          a lone mismatch inside its group is added directly, anything else (two mismatches in a group,
-//                          a run crossing a group or pass boundary) goes through a lane-serial walk + neighbour links;
-//                          results are accumulated per read in LDS (sum, first/last quality != 2);
-//   phase C (lane = read)  three-prime / Q2 logic, DRead + float constants, indel-event counting.
+//   phase B (lane = group) 64 groups per pass.  lane -> read through one LDS word per pass (reads starting inside the pass
+//                          set the bit of their first lane; mbcnt); base codes vs reference codes and the "=ACGTN" buckets
+//                          are byte-parallel; mismatch qualities: runs of read-adjacent mismatches contribute their
+//                          maximum (:152-172,199) — a lone mismatch inside its group is added directly, anything else (two
+//                          mismatches in a group, a run crossing a group or pass boundary) goes through a lane-serial
+//                          walk + neighbour links (DPP lane shifts); sums are accumulated per read in LDS;
+//   phase C (lane = read)  the quality != 2 scan from the read's 3' end (:201-238; 8 bases per load, as a rule one load),
+//                          three-prime / Q2 logic, DRead + float constants, the pieces, the indel events.
 struct AnnPar { uint4 a, b, c; };    // a = {L, qrel, srel, brow.lo}  b = {S, m1lo, m1hi, d1}  c = {m2lo, m2hi, d2, brow.hi}
 
 __device__ __forceinline__ uint32_t nzb7(uint32_t x) { return x + 0x7f7f7f7fu; }   // bytes <= 0x7f: bit 7 of a byte <=> byte != 0
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
                                                          uint16_t* __restrict__ bq, IndelEv* __restrict__ ev_raw, uint32_t* __restrict__ bucket_cnt,
                                                          const uint32_t* __restrict__ cigar_ro, const uint8_t* __restrict__ qual_ro,
                                                          const uint8_t* __restrict__ seq_ro, const uint8_t* __restrict__ refcode) {
-    struct WaveLds { AnnPar par[64]; int32_t lo[64], hi[64]; uint32_t sum[64]; uint32_t redo[64]; uint32_t G[64]; uint8_t mark[64]; };
+    struct WaveLds { AnnPar par[64]; uint32_t sum[64]; uint32_t redo[64]; uint32_t G[64]; unsigned long long mark; };
     __shared__ WaveLds lds_all[4];
     const int lane = threadIdx.x & 63;
     const uint32_t wv = __builtin_amdgcn_readfirstlane((uint32_t)threadIdx.x >> 6);
@@ -183,6 +188,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
     const uint64_t qbase = __builtin_amdgcn_readfirstlane((uint32_t)qoff) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(qoff >> 32)) << 32);
     const uint64_t sbase = __builtin_amdgcn_readfirstlane((uint32_t)soff) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(soff >> 32)) << 32);
     uint32_t T = 0;
+    if (c.ann_variant == 5) return;
     if (nd) {
         if (work_me) {
             AnnPar p;
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
             W.par[rank] = p;
             W.G[rank] = ((uint32_t)L + 7u) >> 3;
         }
-        W.lo[lane] = INT32_MAX; W.hi[lane] = -1; W.sum[lane] = 0u; W.redo[lane] = 0u;
+        W.sum[lane] = 0u; W.redo[lane] = 0u;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");               // lanes read each other's LDS records below
         // exclusive prefix sum of the group counts over the dense reads
         const uint32_t g_me = lane < nd ? W.G[lane] : 0u;
@@ -209,33 +215,54 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
         // ---- phase B
         int jbefore = -1;                          // last dense read that starts before the pass
         bool carry_open = false; uint32_t carry_t = 0; int carry_jr = -1;    // mismatch run open at the end of the previous pass
-        bool carry_nz = false;                                              // previous pass's last lane saw a quality != 2 (same read)
         const int64_t ref_n = c.ref_hi - c.ref_lo;
-        for (uint32_t base = 0; base < T; base += 64u) {
-            // lane -> dense read: reads starting inside the pass mark their first lane
-            // (volatile: the lanes talk to each other through this row; without it the compiler forwards a lane's own store)
-            volatile uint8_t* mark = W.mark;
-            mark[lane] = 0;
-            { const uint32_t d = S_me - base; if (lane < nd && g_me && d < 64u) mark[d] = 1; }
-            const unsigned long long M = __ballot(mark[lane] != 0);
+        const uint8_t* const qwave = qual_ro + qbase; const uint8_t* const swave = seq_ro + sbase; const uint8_t* const refpad = refcode - REFCODE_PAD;
+        // Software pipeline, one pass deep: the loads of pass p + 1 (lane -> read mapping through LDS, then QUAL / SEQ /
+        // reference codes from HBM) are issued before pass p is worked on, so a wave's memory round trips overlap its own
+        // arithmetic instead of standing between two passes.
+        struct Fetch { int jr; int32_t b; uint2 Q; uint32_t S; uint2 R1; };
+        auto fetch = [&](uint32_t base) -> Fetch {
+            Fetch F;
+            // lane -> dense read: reads starting inside the pass set the bit of their first lane in one LDS word (the LDS
+            // operations of a wave execute in issue order: clear, ORs, read)
+            if (lane == 0) __hip_atomic_store(&W.mark, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            { const uint32_t d = S_me - base; if (lane < nd && g_me && d < 64u) __hip_atomic_fetch_or(&W.mark, 1ull << d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            unsigned long long M = __hip_atomic_load(&W.mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            M = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)M) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(M >> 32)) << 32);
             const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0u));
-            const int jr = jbefore + below + (int)((M >> lane) & 1ull);
+            F.jr = jbefore + below + (int)((M >> lane) & 1ull);
             jbefore += __builtin_popcountll(M);
+            const uint32_t G = base + (uint32_t)lane;
+            const uint4 Pa = W.par[F.jr].a, Pb = W.par[F.jr].b;
+            F.b = G < T ? (int32_t)((G - Pb.x) << 3) : 0;               // idle lanes of the last pass stay inside their read
+            // (wave-uniform base + 32-bit lane offset: the scalar-base addressing form, no 64-bit vector arithmetic)
+            __builtin_memcpy(&F.Q, qwave + (uint32_t)(Pa.y + (uint32_t)F.b), 8);
+            __builtin_memcpy(&F.S, swave + (uint32_t)(Pa.z + ((uint32_t)F.b >> 1)), 4);
+            // reference codes under the first M operator (a window outside the slice: any in-bounds window, its bytes are masked)
+            int64_t r1off = (int64_t)F.b + (int32_t)Pb.w;
+            if (r1off < -8 || r1off > ref_n) r1off = 0;
+            __builtin_memcpy(&F.R1, refpad + (uint32_t)((int32_t)r1off + REFCODE_PAD), 8);
+            return F;
+        };
+        if (c.ann_variant == 3) T = 0;
+        Fetch Fn = fetch(0u);
+        for (uint32_t base = 0; base < T; base += 64u) {
+            const Fetch F = Fn;
+            if (base + 64u < T) Fn = fetch(base + 64u);
+            const int jr = F.jr;
             const uint32_t G = base + (uint32_t)lane;
             const bool act = G < T;
             const AnnPar P = W.par[jr];
-            const uint32_t gi = G - P.b.x;
-            const int32_t b = act ? (int32_t)(gi << 3) : 0;          // idle lanes of the last pass stay inside their read
+
+            const int32_t b = F.b;
             const int32_t Lr = (int32_t)P.a.x;
             const int nv = act ? (Lr - b < 8 ? Lr - b : 8) : 0;              // valid bases of the group (1..8)
-            // ---- loads (unaligned 8 / 4 / 8 bytes)
-            uint2 Q; uint32_t S; uint2 R1;
-            __builtin_memcpy(&Q, qual_ro + qbase + P.a.y + (uint32_t)b, 8);
-            __builtin_memcpy(&S, seq_ro + sbase + P.a.z + ((uint32_t)b >> 1), 4);
+            const uint2 Q = F.Q; const uint32_t S = F.S; const uint2 R1 = F.R1;
             // flags of the bases inside the first / second M operator, as bit 7 of each byte
             const unsigned long long vflags = (nv >= 8 ? ~0ull : ((1ull << (8 * nv)) - 1ull)) & 0x8080808080808080ull;
             unsigned long long f1 = vflags, f2 = 0ull;
-            int64_t r1off = (int64_t)b + (int32_t)P.b.w;
             const bool plain = (int32_t)P.b.y == 0 && (int32_t)P.b.z == Lr;       // one M operator over the whole read
             if (__ballot(act && !plain)) {
                 const int lo1 = (int32_t)P.b.y - b, hi1 = (int32_t)P.b.z - b;     // first M operator, group-relative
@@ -247,8 +274,6 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
                 const unsigned long long below_e2 = e2 >= 8 ? ~0ull : ((1ull << (8 * e2)) - 1ull), below_a2 = a2 >= 8 ? ~0ull : ((1ull << (8 * a2)) - 1ull);
                 f2 = vflags & below_e2 & ~below_a2;
             }
-            if (!f1 || r1off < -8 || r1off > ref_n) r1off = 0;                // nothing to compare: any in-bounds window
-            __builtin_memcpy(&R1, refcode + r1off, 8);
             // ---- base codes of the 8 bases in read order: N.x = bases 0..3, N.y = bases 4..7 (one per byte)
             const uint32_t Ev = (S >> 4) & 0x0f0f0f0fu, Od = S & 0x0f0f0f0fu;
             uint2 N;
@@ -265,7 +290,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
             if (__ballot(f2 != 0ull)) {                                       // bases of a second M operator (after an indel)
                 int64_t r2off = (int64_t)b + (int32_t)P.c.z;
                 if (!f2 || r2off < -8 || r2off > ref_n) r2off = 0;
-                uint2 R2; __builtin_memcpy(&R2, refcode + r2off, 8);
+                uint2 R2; __builtin_memcpy(&R2, refpad + (uint32_t)((int32_t)r2off + REFCODE_PAD), 8);
                 const uint32_t rx = R2.x & 0x0f0f0f0fu, ry = R2.y & 0x0f0f0f0fu;
                 mm.x |= nzb7(N.x ^ rx) & nzb7(rx ^ 0x0f0f0f0fu) & nzb7(N.x) & (uint32_t)f2;
                 mm.y |= nzb7(N.y ^ ry) & nzb7(ry ^ 0x0f0f0f0fu) & nzb7(N.y) & (uint32_t)(f2 >> 32);
@@ -282,32 +307,18 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
                 Bk.x = (hx & mx) | (lx & ~mx); Bk.y = (hy & my2) | (ly & ~my2);
             }
             // ---- the event words for KB: quality << 8 | bucket per base; the row is padded to 8 elements
-            if (act) {
+            if (act && c.ann_variant != 1) {
                 uint4 out;
                 out.x = __builtin_amdgcn_perm(Bk.x, Q.x, 0x01050004u); out.y = __builtin_amdgcn_perm(Bk.x, Q.x, 0x03070206u);
                 out.z = __builtin_amdgcn_perm(Bk.y, Q.y, 0x01050004u); out.w = __builtin_amdgcn_perm(Bk.y, Q.y, 0x03070206u);
                 __builtin_memcpy(bq + ((((uint64_t)P.c.w) << 32) | (uint64_t)P.a.w) + (uint32_t)b, &out, 16);
-            }
-            // ---- first / last base with quality != 2 (:201-238)
-            uint2 nz;
-            { const uint32_t x = Q.x ^ 0x02020202u, y = Q.y ^ 0x02020202u;
-              nz.x = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & (uint32_t)vflags; nz.y = (((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y) & (uint32_t)(vflags >> 32); }
-            const bool has_nz = (nz.x | nz.y) != 0u;
-            {
-                // only the ends of lane runs with such a base touch the per-read slots (no same-address pile-ups)
-                const int pj = __shfl_up(jr, 1, 64), nj = __shfl_down(jr, 1, 64);
-                const int pn = __shfl_up(has_nz ? 1 : 0, 1, 64), nn = __shfl_down(has_nz ? 1 : 0, 1, 64);
-                const bool prev_same_nz = lane ? (pj == jr && pn != 0) : (carry_nz && carry_jr == jr);
-                const bool next_same_nz = lane < 63 && nj == jr && nn != 0;
-                if (has_nz && !prev_same_nz) atomicMin(&W.lo[jr], b + (nz.x ? (__builtin_ctz(nz.x) >> 3) : 4 + (__builtin_ctz(nz.y) >> 3)));
-                if (has_nz && !next_same_nz) atomicMax(&W.hi[jr], b + (nz.y ? 4 + ((31 - __builtin_clz(nz.y)) >> 3) : ((31 - __builtin_clz(nz.x)) >> 3)));
             }
             if (nul & 0x80808080u) atomicOr(&W.redo[jr], 1u);                           // a NUL reference character under an M base
             // ---- mismatch qualities
             const bool has_mm = (mm.x | mm.y) != 0u;
             const int nbits = __builtin_popcount(mm.x) + __builtin_popcount(mm.y);
             const bool bit0 = (mm.x & 0x80u) != 0u, bit7 = (mm.y & 0x80000000u) != 0u;
-            const int pjr = __shfl_up(jr, 1, 64); const int pb7 = __shfl_up(bit7 ? 1 : 0, 1, 64);
+            const int pjr = lane_shr1(jr); const int pb7 = lane_shr1(bit7 ? 1 : 0);
             const bool link = bit0 && (lane ? (pjr == jr && pb7 != 0) : (carry_open && carry_jr == jr));
             // a run left open by the previous pass that does not continue into lane 0 ended there
             if (carry_open && lane == 0 && !link) atomicAdd(&W.sum[carry_jr], carry_t);
@@ -335,15 +346,15 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
                     // propagate through lanes that are one run from end to end
                     uint32_t t = t_own;
                     for (;;) {
-                        uint32_t pt = (uint32_t)__shfl_up((int)t, 1, 64);
+                        uint32_t pt = (uint32_t)lane_shr1((int)t);
                         if (lane == 0) pt = carry_t;
                         const uint32_t nt = (full && link) ? (t_own > pt ? t_own : pt) : t_own;
                         const bool ch = nt != t; t = nt;
                         if (!__ballot(ch)) break;
                     }
-                    uint32_t pt = (uint32_t)__shfl_up((int)t, 1, 64);
+                    uint32_t pt = (uint32_t)lane_shr1((int)t);
                     if (lane == 0) pt = carry_t;
-                    const int nlink = __shfl_down(link ? 1 : 0, 1, 64);       // does the next lane continue my tail run?
+                    const int nlink = lane_shl1(link ? 1 : 0);       // does the next lane continue my tail run?
                     uint32_t add = 0u; { bool open = link; uint32_t cur = link ? pt : 0u;
                         _Pragma("unroll") for (int k = 0; k < 8; ++k) { const bool m = (m64 >> (8 * k + 7)) & 1ull; const uint32_t qv = (uint32_t)(q64 >> (8 * k)) & 0xffu;
                             if (m) { cur = open ? (cur > qv ? cur : qv) : qv; open = true; } else { if (open) add += cur; open = false; } }
@@ -355,18 +366,38 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
             // carries into the next pass (from lane 63)
             carry_open = __builtin_amdgcn_readlane((bit7 && act) ? 1 : 0, 63) != 0;
             carry_t = (uint32_t)__builtin_amdgcn_readlane((int)t_out, 63);
-            carry_nz = __builtin_amdgcn_readlane(has_nz ? 1 : 0, 63) != 0;
             carry_jr = __builtin_amdgcn_readlane(jr, 63);
         }
         if (carry_open && lane == 0) atomicAdd(&W.sum[carry_jr], carry_t);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
     // ---- phase C
-    if (!have) return;
+    if (!have || c.ann_variant == 4) return;
     DRead r;
     bool serial = fallback;
     uint32_t my_sum = 0; int my_hi = -1, my_lo = -1;
-    if (work_me) { my_sum = W.sum[rank]; my_hi = W.hi[rank]; my_lo = W.lo[rank]; if (my_lo == INT32_MAX) my_lo = -1; if (W.redo[rank]) serial = true; }
+    if (work_me && W.redo[rank]) serial = true;
+    if (work_me && !serial) {
+        my_sum = W.sum[rank];
+        // first / last base with quality != 2, whichever the strand needs (:201-238): a scan from the read's 3' end, 8 bases
+        // per load (as a rule the first load decides)
+        const uint8_t* q = qual_ro + qoff;
+        if (flag & FREVERSE) {
+            for (int k = 0; k < L && my_lo < 0; k += 8) {
+                unsigned long long w; const int nv = L - k < 8 ? L - k : 8;
+                if (nv == 8) __builtin_memcpy(&w, q + k, 8); else { w = 0x0202020202020202ull; for (int j = 0; j < nv; ++j) w = (w & ~(0xffull << (8 * j))) | ((unsigned long long)q[k + j] << (8 * j)); }
+                const unsigned long long x = w ^ 0x0202020202020202ull;                    // zero bytes: quality 2
+                if (x) my_lo = k + (__builtin_ctzll(x) >> 3);
+            }
+        } else {
+            for (int k = L; k > 0 && my_hi < 0; k -= 8) {
+                unsigned long long w; const int lo8 = k - 8;
+                if (lo8 >= 0) __builtin_memcpy(&w, q + lo8, 8); else { w = 0x0202020202020202ull; for (int j = 0; j < k; ++j) w = (w & ~(0xffull << (8 * (j - lo8)))) | ((unsigned long long)q[j] << (8 * (j - lo8))); }
+                const unsigned long long x = w ^ 0x0202020202020202ull;
+                if (x) my_hi = lo8 + ((63 - __builtin_clzll(x)) >> 3);
+            }
+        }
+    }
     if (serial) {
         r = annotate_read(c, in, my, bq);
     } else {
@@ -400,7 +431,8 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
         walk_pieces(c.insertion_centric != 0, enters && !nolib, rc.counts, pos, cigar_ro + coff, nc, [&](int32_t rs, int32_t len, int32_t ext, int qoff, bool nb) {
             PieceHot h; PieceCold cd;
             make_piece(c, rc, rs, len, ext, qoff, nb, h, cd);
-            hot[slot] = h; cold[slot] = cd; key[slot] = pos; reach[slot] = rs + ext; ++slot;
+            if (c.ann_variant != 2) { hot[slot] = h; cold[slot] = cd; key[slot] = pos; reach[slot] = rs + ext; }
+            ++slot;
         });
     }
     if (ev_raw && n_idp) {
@@ -411,7 +443,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
         IndelEv* slot = ev_raw + in.iev_off[my]; uint32_t used = 0;
         enumerate_indels(c, in, r, qual_ro + qoff, [&](int32_t p, int qpos, int len) {
             IndelEv e; e.read = (uint32_t)my; e.qpos = qpos; e.len = len; e.key_lo = (uint32_t)((int64_t)(p - c.pos0) * c.Lp + lib);   // (keys fit 32 bits: checked at upload)
-            if (used < n_idp) { slot[used++] = e; atomicAdd(&bucket_cnt[indel_bucket(c, e.key_lo)], 1u); }
+            if (used < n_idp) { slot[used++] = e; atomicAdd(&bucket_cnt[indel_bucket_of(c, (uint32_t)(p - c.pos0), (uint32_t)lib)], 1u); }
         });
         for (; used < n_idp; ++used) slot[used].key_lo = NONE32;
     }
@@ -1232,6 +1264,7 @@ class HipBackend : public Backend {
         choose_pack(s.max_lqseq, getenv("BRC_FLUSH_K") ? atoi(getenv("BRC_FLUSH_K")) : 0, getenv("BRC_PACK_LIM") ? atoi(getenv("BRC_PACK_LIM")) : 0, c.flush_k, c.pack_lim);
         c.force_dom = getenv("BRC_FORCE_DOM") ? atoi(getenv("BRC_FORCE_DOM")) : -1;
         c.variant = getenv("BRC_PILEUP_VARIANT") ? atoi(getenv("BRC_PILEUP_VARIANT")) : 0;
+        c.ann_variant = getenv("BRC_ANN_VARIANT") ? atoi(getenv("BRC_ANN_VARIANT")) : 0;
         const size_t n = (size_t)s.n;
         int rc;
         if ((rc = up(d_pos, s.pos, n)) || (rc = up(d_flag, s.flag, n)) || (rc = up(d_mapq, s.mapq, n)) || (rc = up(d_lib, s.lib, n)) ||
@@ -1526,6 +1559,12 @@ class HipBackend : public Backend {
 };
 
 Backend* make_backend(const brc_config& cfg, int* errc) {
+    // Engines are created one at a time, process-wide: the command line creates its engines on worker threads, and the first
+    // calls into the HIP runtime (device initialisation, code-object load at the first launch) from several threads at once
+    // crashed a run in a dozen on the GPU boxes (SIGSEGV before the first line of output).  The later, per-engine work
+    // (streams, uploads, launches) runs concurrently as before.
+    static std::mutex create_mu;
+    std::lock_guard<std::mutex> create_lock(create_mu);
     HipBackend* b = new (std::nothrow) HipBackend();
     if (!b) { *errc = BRC_E_NOMEM; return nullptr; }
     const int rc = b->init(cfg.device);

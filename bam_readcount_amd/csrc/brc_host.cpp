@@ -26,9 +26,7 @@ namespace brc {
 // CPUs this process may really use at once: the affinity mask, capped by a cgroup CPU quota (cpu.max / cfs_quota_us).
 // Pools sized by hardware_concurrency() on a 256-thread host inside a 16-CPU container burn the quota in a fraction of
 // every scheduling period and are throttled for the rest of it.
-unsigned effective_cpus() {
-    static unsigned cached = 0;
-    if (cached) return cached;
+static unsigned probe_cpus() {
     unsigned n = std::thread::hardware_concurrency(); if (n == 0) n = 1;
     double quota = 0;
     if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                        // cgroup v2: "<quota|max> <period>"
@@ -43,8 +41,9 @@ unsigned effective_cpus() {
     }
     if (quota > 0 && quota < (double)n) n = (unsigned)(quota + 0.999);
     if (n < 1) n = 1;
-    return cached = n;
+    return n;
 }
+unsigned effective_cpus() { static const unsigned cached = probe_cpus(); return cached; }   // (initialised once, thread-safe)
 
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 

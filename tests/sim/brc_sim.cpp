@@ -189,7 +189,7 @@ class SimBackend : public Backend {
                 IndelEv* slot = raw.data() + st->iev_off.p[i]; uint32_t used = 0;
                 enumerate_indels(c, in, rd, in.qual + in.qual_off[i], [&](int32_t p, int qpos, int len) {
                     IndelEv e; e.read = (uint32_t)i; e.qpos = qpos; e.len = len; e.key_lo = (uint32_t)((int64_t)(p - c.pos0) * Lp + lib);
-                    if (used < n_idp) { slot[used++] = e; cnt[indel_bucket(c, e.key_lo)]++; }
+                    if (used < n_idp) { slot[used++] = e; cnt[indel_bucket_of(c, (uint32_t)(p - c.pos0), (uint32_t)lib)]++; }
                 });
                 for (; used < n_idp; ++used) slot[used].key_lo = NONE32;
             }

@@ -1,0 +1,6 @@
+#!/bin/bash
+# timing-only ablations of K1 (BRC_ANN_VARIANT) / k_pileup2 (BRC_PILEUP_VARIANT): kernel times of the default bench shape
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; mkdir -p gpurun_out/r03
+for v in ${ANN:-0 1 2 3 4 5}; do
+  BRC_ANN_VARIANT=$v timeout 300 python bench.py --steps 6 --warmup 1 --cpu-sample-mbp 0 --e2e-mbp 0 ${BENCH_ARGS:-} 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('ann_variant $v', d['ms_per_step'], d['roofline']['kernel_ms'])"
+done | tee gpurun_out/r03/variants_${1:-x}.log
