@@ -396,37 +396,47 @@ BRC_HD uint32_t dominant_bucket(const DevCfg& c, const DevIn& in, int64_t p) {
 // Pieces of a read are adjacent and reads keep their file order, so every bucket still sees its events in pileup-column
 // order.  In per-library mode (-p) the pieces are laid out library-major (all pieces of library 0 in file order, then
 // library 1, ...): a (tile, library) wave walks only its own library's stream.
-enum { PF_TABLE = 1,    // event terms come from the quotient tables (l_qseq == clipped == table_len, left_clip == 0, q2 in {tp, none})
+enum PieceFlag { PF_TABLE = 1,    // event terms come from the quotient tables (l_qseq == clipped == table_len, left_clip == 0, q2 in {tp, none})
        PF_Q2OK = 2, PF_NB = 4,
        PF_HUGE = 8,     // a per-read integer does not fit its packed field: w2/w3 carry only the mapping quality, the rest is added by drain_int()
        PF_SMW = 16, PF_NMW = 32, PF_REV = 64 };
 // an event word w passes the base-quality test (:288) iff w >= piece_thr(c)  (0x10000: no 16-bit word reaches it)
 BRC_HD uint32_t piece_thr(const DevCfg& c) { return (uint32_t)(c.min_bq < 0 ? 0 : (c.min_bq > 256 ? 256 : c.min_bq)) << 8; }
 
-// hot half (64 bytes): dwords 0-9 are what the read loop needs of every piece (scalar loads x8 + x2, two pieces ahead);
-// dwords 10-15 only pieces whose event terms are divided out (no PF_TABLE)
-struct alignas(64) PieceHot {
+// One piece record, 48 bytes.  Dwords 0-9 are what the read loop of k_pileup2 needs of every piece (scalar loads x8 + x2, two
+// pieces ahead); bytes 32-47 = {ww, a, bq_off} are the one 16-byte word the staging lanes load.
+struct alignas(16) Piece {
     int32_t rs;            // reference position of the first base
-    int32_t a;             // rs - query offset: the lane on position p sees query base p - a
     int32_t len;           // events: positions [rs, rs + len); every piece with len > 0 belongs to a read that counts
     int32_t ext;           // column: positions [rs, rs + ext), ext >= len
     uint32_t tp_flags;     // bits 0-23: three_prime_index * 4 (byte offset into the float quotient table); 24-31: PF_*
     uint32_t w1, w2, w3;   // packed integer addends: three 10-bit counters 1 | rev << 10 | q2ok << 20;  mapq | sse << 16;  zm_sum | clipped << 16
     float snm;             // NM / (float)clipped_length, 0 when NM is missing
     uint32_t ww;           // per-lane (not per-bucket) warning counters: SM-missing | NM-missing << 16 (process_read warnings, BasicStat.cpp:85,100)
-    float rcpL, Lf, rcpC, center;   // exact-division constants
-    int32_t left, q2;
-};
-// cold half: staging, the drain paths and the indel reduction
-struct alignas(32) PieceCold {
+    int32_t a;             // rs - query offset: the lane on position p sees query base p - a
     uint64_t bq_off;       // first element of the read's row in the event-word stream
-    int32_t a;             // copy of PieceHot::a (staging reads {bq_off, a} with one 16-byte load)
-    uint32_t read;         // region-wide read index (push order)
-    uint32_t zm_raw, sse_raw, mapq;
-    int32_t clipped;
 };
-BRC_HD uint32_t piece_flags(const PieceHot& h) { return h.tp_flags >> 24; }
-BRC_HD int piece_tp(const PieceHot& h) { return (int)((h.tp_flags & 0xffffffu) >> 2); }
+// What only the rare paths need, 32 bytes: the exact-division constants of pieces whose event terms are divided out (no
+// PF_TABLE) and the raw integers of pieces whose packed addends left them out (PF_HUGE), and of any piece that leaves a
+// third-allele event.  K1 WRITES it only for pieces without PF_TABLE or with PF_HUGE; for all others (93 % at 30x) the
+// record is derived from the piece itself (piece_rare_of): l_qseq == clipped_length == table_len, no left clip, q2 in {tp, none}.
+struct alignas(32) PieceRare {
+    float rcpL, Lf, rcpC, center;   // correctly rounded 1 / (float)l_qseq, (float)l_qseq, 1 / center, center = (float)clipped_length / 2
+    int32_t left, q2;
+    uint32_t zm_raw, sse_raw;
+};
+BRC_HD uint32_t piece_flags(const Piece& h) { return h.tp_flags >> 24; }
+BRC_HD int piece_tp(const Piece& h) { return (int)((h.tp_flags & 0xffffffu) >> 2); }
+BRC_HD bool piece_has_rare(uint32_t fl) { return (fl & PF_TABLE) == 0u || (fl & PF_HUGE) != 0u; }
+BRC_HD PieceRare piece_rare_of(const DevCfg& c, const Piece& h) {       // for pieces with PF_TABLE and without PF_HUGE
+    PieceRare r;
+    r.Lf = (float)c.table_len; r.center = (float)c.table_len * 0.5f; r.rcpL = 1.0f / r.Lf; r.rcpC = 1.0f / r.center;
+    r.left = 0; r.q2 = (piece_flags(h) & PF_Q2OK) ? piece_tp(h) : -1;
+    r.zm_raw = h.w3 & 0xffffu; r.sse_raw = h.w2 >> 16;
+    return r;
+}
+BRC_HD uint32_t piece_mapq(const Piece& h) { return h.w2 & 0xffffu; }                          // (w2 = mapq | sse << 16, or mapq alone: PF_HUGE)
+BRC_HD uint32_t piece_clipped(const PieceRare& r) { return (uint32_t)(r.center * 2.0f); }     // exact: clipped_length < 2^22
 
 // what K1 knows about a read once it is annotated
 struct ReadConst {
@@ -505,7 +515,7 @@ BRC_HD bool read_enters(uint32_t flag, const uint32_t* cig, uint32_t nc) {
     return true;
 }
 
-BRC_HD void make_piece(const DevCfg& c, const ReadConst& r, int32_t rs, int32_t len, int32_t ext, int qoff, bool nb, PieceHot& h, PieceCold& cold) {
+BRC_HD void make_piece(const DevCfg& c, const ReadConst& r, int32_t rs, int32_t len, int32_t ext, int qoff, bool nb, Piece& h, PieceRare& rare) {
     h.rs = rs; h.a = rs - qoff; h.len = len; h.ext = ext;
     uint32_t fl = r.flags;
     const bool q2ok = (fl & PF_Q2OK) != 0;
@@ -520,24 +530,26 @@ BRC_HD void make_piece(const DevCfg& c, const ReadConst& r, int32_t rs, int32_t 
     h.w3 = huge ? 0u : (r.zm | ((uint32_t)r.clipped << 16));
     h.snm = r.snm;
     h.ww = ((fl & PF_SMW) ? 1u : 0u) | ((fl & PF_NMW) ? (1u << 16) : 0u);
-    h.Lf = (float)r.l_qseq; h.center = (float)r.clipped * 0.5f; h.rcpL = 1.0f / h.Lf; h.rcpC = 1.0f / h.center;
-    h.left = r.left; h.q2 = r.q2;
-    cold.bq_off = r.bq_off; cold.a = h.a; cold.read = r.read; cold.zm_raw = r.zm; cold.sse_raw = r.sse; cold.mapq = r.mapq;
-    cold.clipped = r.clipped;
+    h.bq_off = r.bq_off;
+    // (the rare record is stored only when piece_has_rare(flags): the two divisions are skipped with it)
+    if (piece_has_rare(fl)) {
+        rare.Lf = (float)r.l_qseq; rare.center = (float)r.clipped * 0.5f; rare.rcpL = 1.0f / rare.Lf; rare.rcpC = 1.0f / rare.center;
+        rare.left = r.left; rare.q2 = r.q2; rare.zm_raw = r.zm; rare.sse_raw = r.sse;
+    }
 }
 
 // event terms of a piece at query position qpos by exact division (any read) ...
-BRC_HD EvTerms piece_terms_div(const PieceHot& h, int qpos) {
-    EvTerms t; const int tp = piece_tp(h);
-    t.q2 = (piece_flags(h) & PF_Q2OK) ? div_rcp((float)BRC_ABSDIFF(qpos, h.q2), h.Lf, h.rcpL) : 0.0f;
-    t.s3p = div_rcp((float)BRC_ABSDIFF(qpos, tp), h.Lf, h.rcpL);
-    float d = (float)(qpos - h.left) - h.center;
+BRC_HD EvTerms piece_terms_div(uint32_t tp_flags, const PieceRare& r, int qpos) {
+    EvTerms t; const int tp = (int)((tp_flags & 0xffffffu) >> 2);
+    t.q2 = ((tp_flags >> 24) & PF_Q2OK) ? div_rcp((float)BRC_ABSDIFF(qpos, r.q2), r.Lf, r.rcpL) : 0.0f;
+    t.s3p = div_rcp((float)BRC_ABSDIFF(qpos, tp), r.Lf, r.rcpL);
+    float d = (float)(qpos - r.left) - r.center;
     d = d < 0.0f ? -d : d;
-    t.sev = 1.0 - (double)div_rcp(d, h.center, h.rcpC);
+    t.sev = 1.0 - (double)div_rcp(d, r.center, r.rcpC);
     return t;
 }
 // ... and from the quotient tables (PF_TABLE): one float look-up serves both distances (q2 == tp or no q2)
-BRC_HD EvTerms piece_terms_tab(const PieceHot& h, const TermTab& tt, int table_len, int qpos) {
+BRC_HD EvTerms piece_terms_tab(const Piece& h, const TermTab& tt, int table_len, int qpos) {
     EvTerms t;
     t.s3p = tt.q[absdiff_u((uint32_t)qpos, (uint32_t)piece_tp(h))];
     t.q2 = (piece_flags(h) & PF_Q2OK) ? t.s3p : 0.0f;
@@ -551,7 +563,7 @@ BRC_HD EvTerms piece_terms_tab(const PieceHot& h, const TermTab& tt, int table_l
 // order-sensitive float sums.
 struct PackAcc { uint32_t w1, w2, w3, sw; float f[NF]; };
 BRC_HD void pack_init(PackAcc& a) { a.w1 = a.w2 = a.w3 = a.sw = 0; for (int f = 0; f < NF; ++f) a.f[f] = 0.0f; }
-BRC_HD void pack_event(PackAcc& a, const PieceHot& h, const EvTerms& t, uint32_t word) {
+BRC_HD void pack_event(PackAcc& a, const Piece& h, const EvTerms& t, uint32_t word) {
     a.w1 += h.w1; a.w2 += h.w2; a.w3 += h.w3; a.sw += word;
     a.f[F_SQ2] += t.q2; a.f[F_S3P] += t.s3p;
     a.f[F_SEV] = (float)((double)a.f[F_SEV] + t.sev);
@@ -616,21 +628,21 @@ BRC_HD void lane2_flush(const DevCfg& c, const Planes& pl, int lib, int64_t k, L
     flush_slot(c, pl, lib, k, a.alt, 1u, a.alt_b, live);
 }
 // one event of a third (fourth, ...) base at this position: its raw addends, for the list
-BRC_HD XEv make_xev(int lib, int64_t k, const PieceHot& h, const PieceCold& cold, int qpos, uint32_t word) {
+BRC_HD XEv make_xev(int lib, int64_t k, const Piece& h, const PieceRare& rare, int qpos, uint32_t word) {
     XEv e;
     const uint32_t fl = piece_flags(h);
-    const EvTerms t = piece_terms_div(h, qpos);
+    const EvTerms t = piece_terms_div(h.tp_flags, rare, qpos);
     e.k = (uint32_t)k; e.lib_b = ((uint32_t)lib << 8) | (word & 0xffu);
-    e.mapq = cold.mapq; e.sse = cold.sse_raw; e.zm = cold.zm_raw; e.clip = (uint32_t)cold.clipped;
+    e.mapq = piece_mapq(h); e.sse = rare.sse_raw; e.zm = rare.zm_raw; e.clip = piece_clipped(rare);
     e.qf = (word >> 8) | ((fl & PF_REV) ? 0x100u : 0u) | ((fl & PF_Q2OK) ? 0x200u : 0u);
     e.fq2 = t.q2; e.fs3p = t.s3p; e.fsnm = h.snm; e.sev = t.sev;
     return e;
 }
 // the integers of a PF_HUGE piece that its packed addends left out, for a lane whose event went to `slot` (the slot planes
 // are live: the caller flushed)
-BRC_HD void drain_int(const DevCfg& c, const Planes& pl, int lib, int64_t k, const PieceCold& cold, uint32_t slot) {
+BRC_HD void drain_int(const DevCfg& c, const Planes& pl, int lib, int64_t k, const PieceRare& rare, uint32_t slot) {
     uint32_t* ip = slot_i(c, pl, lib, slot, k);
-    ip[(int64_t)I_SSE * c.PS] += cold.sse_raw; ip[(int64_t)I_SMMQ * c.PS] += cold.zm_raw; ip[(int64_t)I_SCLIP * c.PS] += (uint32_t)cold.clipped;
+    ip[(int64_t)I_SSE * c.PS] += rare.sse_raw; ip[(int64_t)I_SMMQ * c.PS] += rare.zm_raw; ip[(int64_t)I_SCLIP * c.PS] += piece_clipped(rare);
 }
 // end of the tile (reference statement; the kernel stores the same values with coalesced selects)
 BRC_HD void lane2_store(const DevCfg& c, const Planes& pl, int lib, int64_t k, LaneAcc2& a, bool dead, bool live) {

@@ -4,7 +4,7 @@
 // device-written text on a third; see DESIGN.md for layouts and rooflines):
 //   k_refcode       reference characters -> 4-bit codes
 //   k_annotate_groups  K1: fetch_func's Zm integers per read (8 bases per lane, byte-parallel), the event-word stream
-//                   (quality << 8 | bucket per base) and the read's PIECES (walk_pieces): 64-B hot + 32-B cold records in
+//                   (quality << 8 | bucket per base) and the read's PIECES (walk_pieces): 48-B records (+ a 32-B rare record for the few that need one) in
 //                   library-major slots; also writes each read's indel events to its slots of the raw event list and counts
 //                   them per (tile, library) bucket
 //   k_unavail       -p only: first library-less read of every column (those positions are abandoned, :281-284)
@@ -128,7 +128,7 @@ __device__ __forceinline__ uint32_t nzb7(uint32_t x) { return x + 0x7f7f7f7fu; }
 #define BRC_ANN_OCC
 #endif
 __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, DevIn in, DRead* __restrict__ reads, const uint32_t* __restrict__ piece_off,
-                                                         PieceHot* __restrict__ hot, PieceCold* __restrict__ cold, int32_t* __restrict__ key, int32_t* __restrict__ reach,
+                                                         Piece* __restrict__ pieces, PieceRare* __restrict__ rare, int32_t* __restrict__ key, int32_t* __restrict__ reach,
                                                          uint16_t* __restrict__ bq, IndelEv* __restrict__ ev_raw, uint32_t* __restrict__ bucket_cnt,
                                                          const uint32_t* __restrict__ cigar_ro, const uint8_t* __restrict__ qual_ro,
                                                          const uint8_t* __restrict__ seq_ro, const uint8_t* __restrict__ refcode) {
@@ -429,9 +429,9 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
         const ReadConst rc = read_const(c, r, (uint32_t)my);
         uint32_t slot = piece_off[my];
         walk_pieces(c.insertion_centric != 0, enters && !nolib, rc.counts, pos, cigar_ro + coff, nc, [&](int32_t rs, int32_t len, int32_t ext, int qoff, bool nb) {
-            PieceHot h; PieceCold cd;
-            make_piece(c, rc, rs, len, ext, qoff, nb, h, cd);
-            if (c.ann_variant != 2) { hot[slot] = h; cold[slot] = cd; key[slot] = pos; reach[slot] = rs + ext; }
+            Piece h; PieceRare rr;
+            make_piece(c, rc, rs, len, ext, qoff, nb, h, rr);
+            if (c.ann_variant != 2) { pieces[slot] = h; if (piece_has_rare(piece_flags(h))) rare[slot] = rr; key[slot] = pos; reach[slot] = rs + ext; }
             ++slot;
         });
     }
@@ -632,7 +632,7 @@ static_assert(HALF % 3 == 0, "the piece-record registers rotate with period 3");
 
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-// dwords 0-9 of a PieceHot in scalar registers: f = {rs, a, len, ext, tp_flags, w1, w2, w3}, g = {snm, ww}
+// dwords 0-9 of a Piece in scalar registers: f = {rs, len, ext, tp_flags, w1, w2, w3, snm}, g = {ww, a}
 struct PRec { u32x8 f; u32x2 g; };
 
 // One wave = one (64-position tile, library); lane == position.  The wave walks the tile's pieces [lo, hi) of its library
@@ -643,7 +643,7 @@ struct PRec { u32x8 f; u32x2 g; };
 //    the matching s_waitcnt names the registers, which orders every use behind it;
 //  * event words: the 72-element window of each piece's row that this tile can touch is copied by ONE direct-to-LDS
 //    instruction per half-batch (global_load_lds_dwordx4: lane = row * 9 + chunk, no VGPR round trip) into a two-half
-//    ring; the copy of half-batch h + 2 is issued when h is done, its addresses come from a 16-byte cold-record load
+//    ring; the copy of half-batch h + 2 is issued when h is done, its addresses come from a 16-byte load of the pieces' {ww, a, bq_off} words
 //    issued one half-batch earlier;
 //  * one pipeline step = probe of piece j + 1 (coverage ballots, event word and table look-ups: LDS reads only) and
 //    accumulate of piece j (quality / bucket ballots, one exec region with the 10 adds of the dominant bucket, a usually
@@ -656,7 +656,7 @@ struct PRec { u32x8 f; u32x2 g; };
 #ifndef BRC_WAVES_PER_EU
 #define BRC_WAVES_PER_EU 7      // 72 VGPRs: 16 values spill into the rare paths (measured: 6 waves 3.92 ms, 7 waves 3.78 ms, 8 waves 5.6 ms — spills reach the loop)
 #endif
-__global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_eu(BRC_WAVES_PER_EU, BRC_WAVES_PER_EU))) void k_pileup2(DevCfg c, DevIn in, const uint4* __restrict__ hot4, const PieceCold* __restrict__ cold,
+__global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_eu(BRC_WAVES_PER_EU, BRC_WAVES_PER_EU))) void k_pileup2(DevCfg c, DevIn in, const uint4* __restrict__ pieces4, const PieceRare* __restrict__ rare,
                                                                const uint2* __restrict__ rng, int64_t ntiles, Planes pl, uint4* __restrict__ tile_ctr,
                                                                const uint16_t* __restrict__ bq_ro, const uint32_t* __restrict__ unavail_ro,
                                                                const uint8_t* __restrict__ refcode) {
@@ -732,15 +732,15 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         // ... and, by the first lane of every row, one dword of its hot record: nothing uses the value — the load pulls the
         // record's cache line into L2 a half-batch before the scalar loads of the read loop ask for it (their own look-ahead
         // of two pieces covers an L2 hit, not an HBM miss)
-#define BRC_LD_TAB(T, b0) { const uint32_t mi = (b0) + srow < hi ? (b0) + srow : hi - 1u; T = *reinterpret_cast<const uint4*>(cold + mi); \
-                            asm volatile("" :: "v"(pf)); if (schunk == 0u) pf = hot4[(size_t)mi * 4u].x; }
+#define BRC_LD_TAB(T, b0) { const uint32_t mi = (b0) + srow < hi ? (b0) + srow : hi - 1u; T = pieces4[(size_t)mi * 3u + 2u];   /* {ww, a, bq_off} */ \
+                            asm volatile("" :: "v"(pf)); if (schunk == 0u) pf = pieces4[(size_t)mi * 3u].x; }
         // window copy of the half-batch starting at piece b0 into the ring half at byte offset hoff: element window
         // [ws, ws + 72) of the row, ws = floor8(p0 - a) (may start before the row: the event-word stream is padded)
 #define BRC_STAGE(T, b0, hoff)                                                                                           \
         {                                                                                                                 \
             if (slane && (b0) + srow < hi) {                                                                              \
-                const int64_t boff = (int64_t)(((uint64_t)T.y << 32) | T.x);                                              \
-                const int32_t ws = (p0 - (int32_t)T.z) & ~7;                                                              \
+                const int64_t boff = (int64_t)(((uint64_t)T.w << 32) | T.z);                                              \
+                const int32_t ws = (p0 - (int32_t)T.y) & ~7;                                                              \
                 const uint16_t* src = bq_ro + (boff + ws) + 8u * schunk;                                                  \
                 __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,                      \
                     (void __attribute__((address_space(3)))*)(rows_base + (hoff)), 16, 0, 0);                             \
@@ -752,14 +752,14 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         // parity tests would show it at once), NOT true at 8 waves per SIMD (tools/experiments/README.md).
 #define BRC_LD_REC(R, rp) asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x20" : "=&s"(R.f), "=&s"(R.g) : "s"(rp));
 #define BRC_WAIT_REC(R) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R.f), "+s"(R.g));
-        // the division constants of piece m (dwords 10-15 of its record) by scalar loads, on demand: only pieces without PF_TABLE
+        // the division constants of piece m (its rare record) by scalar loads, on demand: only pieces without PF_TABLE
 #define BRC_LD_DIV(H, R, m)                                                                                             \
         {                                                                                                                 \
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));                                                   \
-            u32x4 dA; u32x2 dB; const char* dp = reinterpret_cast<const char*>(hot4) + (size_t)(m) * 64u;                 \
-            asm volatile("s_load_dwordx4 %0, %2, 0x28\n\ts_load_dwordx2 %1, %2, 0x38\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dA), "=&s"(dB) : "s"(dp)); \
-            H.tp_flags = R.f[4]; H.rcpL = __uint_as_float(dA[0]); H.Lf = __uint_as_float(dA[1]); H.rcpC = __uint_as_float(dA[2]);  \
-            H.center = __uint_as_float(dA[3]); H.left = (int32_t)dB[0]; H.q2 = (int32_t)dB[1];                            \
+            u32x4 dA; u32x2 dB; const char* dp = reinterpret_cast<const char*>(rare) + (size_t)(m) * 32u;                 \
+            asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x10\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dA), "=&s"(dB) : "s"(dp)); \
+            H.rcpL = __uint_as_float(dA[0]); H.Lf = __uint_as_float(dA[1]); H.rcpC = __uint_as_float(dA[2]);              \
+            H.center = __uint_as_float(dA[3]); H.left = (int32_t)dB[0]; H.q2 = (int32_t)dB[1]; H.zm_raw = 0u; H.sse_raw = 0u; \
         }
         struct Stage { uint32_t w; float t; double sev; uint64_t m_in, m_cov; int32_t s_c; };
         // PROBE of the piece in R, staged in the ring row at byte offset roff: coverage ballots and three LDS reads whose
@@ -767,19 +767,19 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         // look-ups are issued for every piece; a piece without PF_TABLE ignores them and divides in its accumulate stage.
 #define BRC_PROBE(R, roff, S)                                                                                           \
         {                                                                                                                 \
-            const int32_t s_d = p0 - (int32_t)R.f[0]; S.s_c = p0 - (int32_t)R.f[1];                                       \
+            const int32_t s_d = p0 - (int32_t)R.f[0]; S.s_c = p0 - (int32_t)R.g[1];                                       \
             const uint32_t d = lanev + (uint32_t)s_d;                                                                     \
-            S.m_cov = __builtin_amdgcn_ballot_w64(d < R.f[3]);   /* counted in the accumulate stage: a probe may run past the tile's last piece */ \
-            S.m_in = __builtin_amdgcn_ballot_w64(d < R.f[2]);                                                             \
+            S.m_cov = __builtin_amdgcn_ballot_w64(d < R.f[2]);   /* counted in the accumulate stage: a probe may run past the tile's last piece */ \
+            S.m_in = __builtin_amdgcn_ballot_w64(d < R.f[1]);                                                             \
             const uint32_t off = (uint32_t)(roff) + 2u * ((uint32_t)S.s_c & 7u);                                          \
             S.w = (uint32_t)*reinterpret_cast<const uint16_t*>(rows_base + (((uint32_t)lane << 1) + off));                                  \
-            S.t = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds.q) + sad_u32(((uint32_t)lane << 2) + 4u * (uint32_t)S.s_c, R.f[4] & 0xffffffu)); \
+            S.t = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds.q) + sad_u32(((uint32_t)lane << 2) + 4u * (uint32_t)S.s_c, R.f[3] & 0xffffffu)); \
             S.sev = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds.e) + sad_u32(((uint32_t)lane << 4) + 16u * (uint32_t)S.s_c, L0 << 3)); \
         }
         // ACC of the piece in R (S = its probe results), piece index m
 #define BRC_ACC(R, S, m)                                                                                                \
         {                                                                                                                 \
-            const uint32_t fl = R.f[4] >> 24;                                                                             \
+            const uint32_t fl = R.f[3] >> 24;                                                                             \
             count_if(a.ncol, S.m_cov);                                                         /* lib_counts[library] (:286) */ \
             const uint64_t m_p = S.m_in & __builtin_amdgcn_ballot_w64(S.w >= thr0);           /* :288 */                  \
             count_if(a.depth, m_p);                                                            /* mapq_n (:312) */         \
@@ -789,17 +789,17 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                    common path); q2 == tp, or no Q2 position: then +0.0f, the identity on these sums */                  \
                 float tq2 = __uint_as_float(__float_as_uint(S.t) & ((fl & PF_Q2OK) ? 0xffffffffu : 0u));                  \
                 if (__builtin_expect((fl & PF_TABLE) == 0u, 0)) {                                                         \
-                    PieceHot H; BRC_LD_DIV(H, R, m)                                                                       \
-                    const EvTerms t = piece_terms_div(H, (int)((uint32_t)lane + (uint32_t)S.s_c));                        \
+                    PieceRare H; BRC_LD_DIV(H, R, m)                                                                      \
+                    const EvTerms t = piece_terms_div(R.f[3], H, (int)((uint32_t)lane + (uint32_t)S.s_c));                \
                     S.t = t.s3p; tq2 = t.q2; S.sev = t.sev;                                                               \
                 }                                                                                                         \
                 const float ts3p = S.t; const double tsev = S.sev;                                                        \
                 const uint64_t m_dom = m_p & __builtin_amdgcn_ballot_w64(b == a.dom_b);                                   \
                 if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(m_dom), 1)) {                                    \
-                    a.dom.w1 += R.f[5]; a.dom.w2 += R.f[6]; a.dom.w3 += R.f[7]; a.dom.sw += S.w;                          \
+                    a.dom.w1 += R.f[4]; a.dom.w2 += R.f[5]; a.dom.w3 += R.f[6]; a.dom.sw += S.w;                          \
                     fadd_v(a.dom.f[F_SQ2], tq2); fadd_v(a.dom.f[F_S3P], ts3p);                                            \
                     fadd_through_double(a.dom.f[F_SEV], tsev);                                                            \
-                    fadd_s(a.dom.f[F_SNM], __uint_as_float(R.g[0])); a.ww += R.g[1];                                      \
+                    fadd_s(a.dom.f[F_SNM], __uint_as_float(R.f[7])); a.ww += R.g[0];                                      \
                 }                                                                                                         \
                 const uint64_t m_rest = m_p & ~m_dom;                                                                     \
                 uint64_t m_ovf = 0;                                                                                       \
@@ -809,12 +809,12 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                         const bool take_alt = a.alt_b == NB_NONE || a.alt_b == b;                                         \
                         if (take_alt) {                                                                                   \
                             a.alt_b = b;                                                                                  \
-                            a.alt.w1 += R.f[5]; a.alt.w2 += R.f[6]; a.alt.w3 += R.f[7]; a.alt.sw += S.w;                  \
+                            a.alt.w1 += R.f[4]; a.alt.w2 += R.f[5]; a.alt.w3 += R.f[6]; a.alt.sw += S.w;                  \
                             fadd_v(a.alt.f[F_SQ2], tq2); fadd_v(a.alt.f[F_S3P], ts3p);                                    \
                             fadd_through_double(a.alt.f[F_SEV], tsev);                                                    \
-                            fadd_s(a.alt.f[F_SNM], __uint_as_float(R.g[0]));                                              \
+                            fadd_s(a.alt.f[F_SNM], __uint_as_float(R.f[7]));                                              \
                         }                                                                                                 \
-                        a.ww += R.g[1];                        /* alternate and third alleles alike */                    \
+                        a.ww += R.g[0];                        /* alternate and third alleles alike */                    \
                         ovf = !take_alt;                                                                                  \
                     }                                                                                                     \
                     m_ovf = __builtin_amdgcn_ballot_w64(ovf);                                                             \
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         // accumulated.
 #define BRC_STEP(J, RC, RN, RL, SC, SN, G)                                                                              \
         if ((J) == 0 || (J) < nb) {                                                                                       \
-            /* the last step probes the first row of the OTHER ring half: its copy (and the cold-record load behind it)  \
+            /* the last step probes the first row of the OTHER ring half: its copy (and the record load behind it)       \
                was issued at the previous half-batch boundary */                                                         \
             if ((J) == HALF - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
             /* record RN was requested a whole step ago, the LDS results of the previous probe likewise */               \
@@ -862,20 +862,21 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                     const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane(queue[e].piece), kind = (uint32_t)__builtin_amdgcn_readfirstlane(queue[e].kind); \
                     /* (readfirstlane returns int: without the casts a set bit 31 of the low half would sign-extend) */  \
                     const uint64_t mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(queue[e].mhi) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(queue[e].mlo); \
-                    PieceHot H; PieceCold CD;                                                                             \
-                    {   /* both records into scalar registers */                                                         \
+                    Piece H; PieceRare RR;                                                                                \
+                    {   /* the piece into scalar registers; its rare record likewise when K1 stored one, derived otherwise */ \
                         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));                                       \
-                        u32x8 hf; u32x2 hg; u32x4 dA; u32x2 dB; u32x4 cd;                                                 \
-                        const char* hp = reinterpret_cast<const char*>(hot4) + (size_t)m * 64u;                           \
-                        const char* cp = reinterpret_cast<const char*>(cold) + (size_t)m * 32u;                           \
-                        asm volatile("s_load_dwordx8 %0, %5, 0x0\n\ts_load_dwordx2 %1, %5, 0x20\n\ts_load_dwordx4 %2, %5, 0x28\n\t" \
-                                     "s_load_dwordx2 %3, %5, 0x38\n\ts_load_dwordx4 %4, %6, 0x10\n\ts_waitcnt lgkmcnt(0)"   \
-                                     : "=&s"(hf), "=&s"(hg), "=&s"(dA), "=&s"(dB), "=&s"(cd) : "s"(hp), "s"(cp));         \
-                        H.rs = (int32_t)hf[0]; H.a = (int32_t)hf[1]; H.len = (int32_t)hf[2]; H.ext = (int32_t)hf[3]; H.tp_flags = hf[4]; \
-                        H.w1 = hf[5]; H.w2 = hf[6]; H.w3 = hf[7]; H.snm = __uint_as_float(hg[0]); H.ww = hg[1];          \
-                        H.rcpL = __uint_as_float(dA[0]); H.Lf = __uint_as_float(dA[1]); H.rcpC = __uint_as_float(dA[2]); H.center = __uint_as_float(dA[3]); \
-                        H.left = (int32_t)dB[0]; H.q2 = (int32_t)dB[1];                                                   \
-                        CD.bq_off = 0; CD.a = H.a; CD.read = 0; CD.zm_raw = cd[0]; CD.sse_raw = cd[1]; CD.mapq = cd[2]; CD.clipped = (int32_t)cd[3]; \
+                        u32x8 hf; u32x4 hg;                                                                               \
+                        const char* hp = reinterpret_cast<const char*>(pieces4) + (size_t)m * 48u;                        \
+                        asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(hf), "=&s"(hg) : "s"(hp)); \
+                        H.rs = (int32_t)hf[0]; H.len = (int32_t)hf[1]; H.ext = (int32_t)hf[2]; H.tp_flags = hf[3];       \
+                        H.w1 = hf[4]; H.w2 = hf[5]; H.w3 = hf[6]; H.snm = __uint_as_float(hf[7]); H.ww = hg[0]; H.a = (int32_t)hg[1]; \
+                        H.bq_off = 0;                                                                                     \
+                        if (piece_has_rare(H.tp_flags >> 24)) {                                                           \
+                            u32x8 rf; const char* rp = reinterpret_cast<const char*>(rare) + (size_t)m * 32u;             \
+                            asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(rf) : "s"(rp));    \
+                            RR.rcpL = __uint_as_float(rf[0]); RR.Lf = __uint_as_float(rf[1]); RR.rcpC = __uint_as_float(rf[2]); RR.center = __uint_as_float(rf[3]); \
+                            RR.left = (int32_t)rf[4]; RR.q2 = (int32_t)rf[5]; RR.zm_raw = rf[6]; RR.sse_raw = rf[7];      \
+                        } else RR = piece_rare_of(c, H);                                                                  \
                     }                                                                                                     \
                     if (kind == 1u && !flushed) {              /* huge integers go straight to the slot planes: make them live */ \
                         BRC_FLUSH()                                                                                       \
@@ -890,8 +891,8 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                         at0 = (uint32_t)__builtin_amdgcn_readfirstlane(at0);                                              \
                         const uint64_t below = mask & ((1ull << lane) - 1ull);                                            \
                         const uint32_t at = at0 + (uint32_t)__builtin_popcountll(below);                                  \
-                        if (mine && at < pl.xev_cap) pl.xev[(size_t)xshard * pl.xev_cap + at] = make_xev(lib, kk, H, CD, lane + s_c, w); \
-                    } else if (mine) drain_int(c, pl, lib, kk, CD, (w & 0xffu) == a.dom_b ? 0u : 1u);                     \
+                        if (mine && at < pl.xev_cap) pl.xev[(size_t)xshard * pl.xev_cap + at] = make_xev(lib, kk, H, RR, lane + s_c, w); \
+                    } else if (mine) drain_int(c, pl, lib, kk, RR, (w & 0xffu) == a.dom_b ? 0u : 1u);                     \
                 }                                                                                                         \
                 qn = 0;                                                                                                   \
             }                                                                                                             \
@@ -912,10 +913,10 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         if (c.variant != 7) BRC_STAGE(T, lo + (uint32_t)HALF, (uint32_t)HOFF_X)
         BRC_LD_TAB(T, lo + 2u * (uint32_t)HALF)
         PRec R0, R1, R2;
-        const char* recp = reinterpret_cast<const char*>(hot4) + (size_t)lo * 64u;   // (scalar) next record to request
-        const uint32_t recstep = c.variant == 10 ? 0u : 64u;                   // (profiling: 10 = every scalar load hits the same line)
-        BRC_LD_REC(R0, recp) recp += 64;
-        BRC_LD_REC(R1, recp) recp += 64;
+        const char* recp = reinterpret_cast<const char*>(pieces4) + (size_t)lo * 48u;   // (scalar) next record to request
+        const uint32_t recstep = c.variant == 10 ? 0u : 48u;                   // (profiling: 10 = every scalar load hits the same line)
+        BRC_LD_REC(R0, recp) recp += 48;
+        BRC_LD_REC(R1, recp) recp += 48;
         R2 = R1;
         Stage S0, S1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // first two half-batches staged (tile prologue)
@@ -1179,7 +1180,7 @@ class HipBackend : public Backend {
     std::vector<int64_t> lib_base;      // first piece of every library's stream (Lp + 1 entries)
     // device buffers
     DBuf d_pos, d_flag, d_mapq, d_lib, d_lq, d_nc, d_co, d_so, d_qo, d_nm, d_sm, d_tags, d_cigar, d_seq, d_qual, d_ref, d_refcode;
-    DBuf d_bq, d_bqrow, d_pieceoff, d_hot, d_cold, d_key, d_reach, d_reads, d_prefmax, d_agg, d_rng, d_ncol, d_depth, d_slotid, d_si, d_sf, d_xev, d_xevc, d_xevn, d_unavail, d_cnt, d_cursor, d_ev, d_evraw, d_ievoff, d_iout, d_ctr, d_tilectr, d_part;
+    DBuf d_bq, d_bqrow, d_pieceoff, d_pieces, d_rare, d_key, d_reach, d_reads, d_prefmax, d_agg, d_rng, d_ncol, d_depth, d_slotid, d_si, d_sf, d_xev, d_xevc, d_xevn, d_unavail, d_cnt, d_cursor, d_ev, d_evraw, d_ievoff, d_iout, d_ctr, d_tilectr, d_part;
     DBuf d_tlen, d_toff, d_text, d_tctx;
     // device-side text, downloaded (pinned) on its own stream into one of two host buffers
     HBuf<char> h_text[2]; HBuf<uint32_t> h_toff[2]; HBuf<uint32_t> h_total;
@@ -1226,7 +1227,7 @@ class HipBackend : public Backend {
     ~HipBackend() override {
         (void)hipSetDevice(device);
         DBuf* all[] = {&d_pos, &d_flag, &d_mapq, &d_lib, &d_lq, &d_nc, &d_co, &d_so, &d_qo, &d_nm, &d_sm, &d_tags, &d_cigar, &d_seq, &d_qual,
-                       &d_ref, &d_refcode, &d_bq, &d_bqrow, &d_pieceoff, &d_hot, &d_cold, &d_key, &d_reach, &d_reads, &d_prefmax, &d_agg, &d_rng, &d_ncol, &d_depth, &d_slotid, &d_si, &d_sf, &d_xev, &d_xevc, &d_xevn, &d_unavail, &d_cnt,
+                       &d_ref, &d_refcode, &d_bq, &d_bqrow, &d_pieceoff, &d_pieces, &d_rare, &d_key, &d_reach, &d_reads, &d_prefmax, &d_agg, &d_rng, &d_ncol, &d_depth, &d_slotid, &d_si, &d_sf, &d_xev, &d_xevc, &d_xevn, &d_unavail, &d_cnt,
                        &d_cursor, &d_ev, &d_evraw, &d_ievoff, &d_iout, &d_ctr, &d_tilectr, &d_part, &d_tlen, &d_toff, &d_text, &d_tctx};
         for (DBuf* b : all) b->release();
         for (int i = 0; i < 2; ++i) { h_text[i].destroy(); h_toff[i].destroy(); if (ev_text[i]) (void)hipEventDestroy(ev_text[i]); }
@@ -1289,7 +1290,7 @@ class HipBackend : public Backend {
         in.bq_row = (const uint64_t*)d_bqrow.p;
         in.rcp = nullptr;
         const size_t np = (size_t)c.n_pieces;
-        HIPCHK(d_hot.ensure((np + 2) * sizeof(PieceHot))); HIPCHK(d_cold.ensure((np + 2) * sizeof(PieceCold)));
+        HIPCHK(d_pieces.ensure((np + 4) * sizeof(Piece))); HIPCHK(d_rare.ensure((np + 2) * sizeof(PieceRare)));      // (the read loop requests records up to two past the last)
         HIPCHK(d_key.ensure((np + 16) * 4)); HIPCHK(d_reach.ensure((np + 16) * 4));
         // outputs / scratch
         const size_t P = (size_t)c.PS, Lp = (size_t)c.Lp;   // allocation sizes use the padded stride
@@ -1361,7 +1362,7 @@ class HipBackend : public Backend {
             if (c.has_ref)
                 hipLaunchKernelGGL(k_refcode, dim3((unsigned)(((rl + 2 * REFCODE_PAD + 15) / 16 + 255) / 256)), dim3(256), 0, stream, in.ref, (uint8_t*)d_refcode.p, rl);
             hipLaunchKernelGGL(k_annotate_groups, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (const uint32_t*)d_pieceoff.p,
-                               (PieceHot*)d_hot.p, (PieceCold*)d_cold.p, (int32_t*)d_key.p, (int32_t*)d_reach.p,
+                               (Piece*)d_pieces.p, (PieceRare*)d_rare.p, (int32_t*)d_key.p, (int32_t*)d_reach.p,
                                (uint16_t*)in.bq, indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p,
                                in.cigar, in.qual, in.seq4, (const uint8_t*)d_refcode.p + REFCODE_PAD);
             if (c.per_lib) {
@@ -1411,7 +1412,7 @@ class HipBackend : public Backend {
             nwg = (nwg + 7u) & ~7u;
             // profiling knob: unused dynamic LDS lowers the number of resident waves (occupancy sweeps)
             static const unsigned dyn_lds = getenv("BRC_PILEUP_LDS_PAD") ? (unsigned)atoi(getenv("BRC_PILEUP_LDS_PAD")) : 0u;
-            hipLaunchKernelGGL(k_pileup2, dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), dyn_lds, stream, c, in, (const uint4*)d_hot.p, (const PieceCold*)d_cold.p,
+            hipLaunchKernelGGL(k_pileup2, dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), dyn_lds, stream, c, in, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p,
                                (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.bq, (const uint32_t*)d_unavail.p,
                                (const uint8_t*)d_refcode.p + REFCODE_PAD);
             hipLaunchKernelGGL(k_xev_compact, dim3((unsigned)XEV_SHARDS), dim3(256), 0, stream, (const XEv*)d_xev.p, (const uint32_t*)d_xevn.p, (uint32_t)xev_cap,

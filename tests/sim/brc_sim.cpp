@@ -23,7 +23,9 @@ class SimBackend : public Backend {
     DevCfg c; DevIn in; std::string err;
     const Staged* st = nullptr;
     std::vector<DRead> reads; std::vector<uint16_t> bq; size_t bq_n = 0; std::vector<float> tq; std::vector<double> te;
-    std::vector<PieceHot> hot; std::vector<PieceCold> cold; std::vector<int32_t> key, reach, prefmax;
+    std::vector<Piece> hot; std::vector<PieceRare> rare; std::vector<int32_t> key, reach, prefmax;
+    // the rare record of piece m: stored by K1 only when piece_has_rare(flags), derived from the piece otherwise
+    PieceRare rare_of(uint32_t m) const { return piece_has_rare(piece_flags(hot[m])) ? rare[m] : piece_rare_of(c, hot[m]); }
     std::vector<uint32_t> ncol, depth, slotid, si, unavail; std::vector<float> sf; std::vector<XEv> xev; uint32_t xev_n = 0;
     std::vector<IndelOut> iout;
     uint64_t n_events = 0, n_positions = 0, warn[BRC_N_WARN] = {0, 0, 0, 0};
@@ -69,7 +71,7 @@ class SimBackend : public Backend {
         for (uint32_t base = lo; base < hi; base += HALF) {
             const uint32_t nb = hi - base < (uint32_t)HALF ? hi - base : (uint32_t)HALF;
             for (uint32_t m = base; m < base + nb; ++m) {
-                const PieceHot& h = hot[m]; const PieceCold& cd = cold[m];
+                const Piece& h = hot[m];
                 const uint32_t fl = piece_flags(h);
                 QEnt full, ints; full.piece = ints.piece = m; full.kind = 0; ints.kind = 1; bool any_full = false, any_int = false;
                 for (int l = 0; l < TILE; ++l) {
@@ -79,11 +81,11 @@ class SimBackend : public Backend {
                     if (d < (uint32_t)h.ext) a[l].ncol++;                                             // lib_counts[library] (:286)
                     if (!(d < (uint32_t)h.len)) continue;
                     const int qpos = p[l] - h.a;
-                    const uint32_t w = bq[cd.bq_off + (uint64_t)qpos];
+                    const uint32_t w = bq[h.bq_off + (uint64_t)qpos];
                     if (w < thr) continue;                                                            // :288
                     a[l].depth++;                                                                     // mapq_n (:312)
                     if (fl & PF_NB) continue;                                                         // :343 with -i
-                    const EvTerms t = (fl & PF_TABLE) ? piece_terms_tab(h, tt, c.table_len, qpos) : piece_terms_div(h, qpos);
+                    const EvTerms t = (fl & PF_TABLE) ? piece_terms_tab(h, tt, c.table_len, qpos) : piece_terms_div(h.tp_flags, rare[m], qpos);
                     const uint32_t b = w & 0xffu;
                     a[l].ww += h.ww;
                     if (b == a[l].dom_b) { pack_event(a[l].dom, h, t, w); if (fl & PF_HUGE) { ints.lane[l] = true; any_int = true; } }
@@ -97,7 +99,7 @@ class SimBackend : public Backend {
             // between half-batches: drain the queue (the event words of this half-batch are still staged), flush when the
             // packed fields could overflow during the next half-batch
             for (const QEnt& e : queue) {
-                const PieceHot& h = hot[e.piece]; const PieceCold& cd = cold[e.piece];
+                const Piece& h = hot[e.piece]; const PieceRare rr = rare_of(e.piece);
                 if (e.kind == 1 && !flushed) {                                                        // huge integers go straight to the slot planes: make them live
                     for (int l = 0; l < TILE; ++l) if (valid[l]) lane2_flush(c, pl, lib, kk[l], a[l], false);
                     flushed = true; since_flush = 0;
@@ -105,9 +107,9 @@ class SimBackend : public Backend {
                 for (int l = 0; l < TILE; ++l) {
                     if (!e.lane[l]) continue;
                     const int qpos = p[l] - h.a;
-                    const uint32_t w = bq[cd.bq_off + (uint64_t)qpos];
-                    if (e.kind == 0) { const XEv x = make_xev(lib, kk[l], h, cd, qpos, w); const uint32_t at = (*pl.xev_n)++; if (at < pl.xev_cap) pl.xev[at] = x; }
-                    else drain_int(c, pl, lib, kk[l], cd, (w & 0xffu) == a[l].dom_b ? 0u : 1u);
+                    const uint32_t w = bq[h.bq_off + (uint64_t)qpos];
+                    if (e.kind == 0) { const XEv x = make_xev(lib, kk[l], h, rr, qpos, w); const uint32_t at = (*pl.xev_n)++; if (at < pl.xev_cap) pl.xev[at] = x; }
+                    else drain_int(c, pl, lib, kk[l], rr, (w & 0xffu) == a[l].dom_b ? 0u : 1u);
                 }
             }
             queue.clear();
@@ -130,7 +132,8 @@ class SimBackend : public Backend {
         const int64_t n = c.n_reads, P = c.P, PS = c.PS; const int Lp = c.Lp;
         const int64_t np = c.n_pieces;
         reads.resize((size_t)n); bq.assign(bq_n + 1, 0); in.bq = bq.data();
-        hot.assign((size_t)np + 1, PieceHot()); cold.assign((size_t)np + 1, PieceCold()); key.assign((size_t)np + 1, 0); reach.assign((size_t)np + 1, 0); prefmax.assign((size_t)np + 1, 0);
+        hot.assign((size_t)np + 1, Piece()); { PieceRare poison; memset(&poison, 0xff, sizeof poison); rare.assign((size_t)np + 1, poison); }   // (a rare record nobody wrote must not be read)
+        key.assign((size_t)np + 1, 0); reach.assign((size_t)np + 1, 0); prefmax.assign((size_t)np + 1, 0);
         unavail.assign((size_t)PS, NONE32);
         for (int64_t i = 0; i < n; ++i) {                                                             // K1
             const DRead rd = reads[(size_t)i] = annotate_read(c, in, i, bq.data());
@@ -142,7 +145,8 @@ class SimBackend : public Backend {
             const ReadConst rc = read_const(c, rd, (uint32_t)i);
             uint32_t slot = st->piece_off.p[i], cnt = 0;
             walk_pieces(c.insertion_centric != 0, enters && !nolib, rc.counts, rd.pos, cg, in.n_cigar[i], [&](int32_t rs, int32_t len, int32_t ext, int qoff, bool nb) {
-                make_piece(c, rc, rs, len, ext, qoff, nb, hot[slot], cold[slot]);
+                PieceRare rr; make_piece(c, rc, rs, len, ext, qoff, nb, hot[slot], rr);
+                if (piece_has_rare(piece_flags(hot[slot]))) rare[slot] = rr;
                 key[slot] = rd.pos; reach[slot] = rs + ext; ++slot; ++cnt;
             });
             if (cnt != st->piece_cnt.p[i]) { err = "piece count of the host and of K1 differ"; return BRC_E_ARG; }
