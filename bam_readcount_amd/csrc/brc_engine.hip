@@ -666,9 +666,11 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
     const uint32_t per = nbk >> 3;
     const uint32_t wg = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
     //   q[n] = (float)n / (float)L0 for 0 <= n <= L0 (see piece_terms_tab);   e[n] = 1.0 - (double)q[n]
+    //   The q entries stand 16 bytes apart and the e entries 8: both look-ups of a probe, q[|qpos - tp|] and e[|2 qpos - L0|],
+    //   then have byte offsets |16 lane + const| — ONE lane register (16 lane + bias) and one v_sad_u32 each.
     struct QEnt { uint32_t piece, kind, mlo, mhi; };
     struct Lds {
-        float q[TABLE_MAX + 4];
+        alignas(16) float q16[(TABLE_MAX + 2) * 4];
         double e[TABLE_MAX + 2];
         alignas(16) uint4 rows[PILEUP_WAVES][2 * HALF][WIN_U4];
         QEnt queue[PILEUP_WAVES][QCAP];
@@ -678,7 +680,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         const float l0 = (float)c.table_len;
         for (int n = threadIdx.x; n <= c.table_len; n += PILEUP_WAVES * 64) {
             const float qv = (float)n / l0;
-            lds.q[n] = qv; lds.e[n] = 1.0 - (double)qv;
+            lds.q16[4 * n] = qv; lds.e[n] = 1.0 - (double)qv;
         }
         __syncthreads();
     }
@@ -716,6 +718,14 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         // lanes past the region's last position stand far left of every piece: no coverage test is ever true for them
         // (d = 2^31 + lane + p0 - rs >= 2^31 - (rs - p0) >= ext for every piece, because rs + ext <= 2^31 - 1 and p0 >= 0)
         const uint32_t lanev = valid ? (uint32_t)lane : (0x80000000u | (uint32_t)lane);
+        // 16 lane + bias: the lane side of both table addresses (the bias keeps the scalar side, bias - 16 (s_c - tp) and
+        // bias - (16 s_c - 8 L0), positive: |s_c| < 2^22 + 64)
+        enum : uint32_t { LBIAS = 1u << 28 };
+        const uint32_t lane16b = ((uint32_t)lane << 4) + (uint32_t)LBIAS;
+        // (the rare paths below recompute the lane index and the plane index instead of keeping them alive across the read loop:
+        // every register that stays live there pushes a value of the alternate-bucket path into scratch)
+#define BRC_LANE() ((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))
+#define BRC_KK() (valid ? tile * TILE + BRC_LANE() : (int64_t)0)
         const uint32_t L0 = (uint32_t)c.table_len;
         const uint32_t thr0 = piece_thr(c);
         char* const rows_base = reinterpret_cast<char*>(&lds.rows[wv][0][0]);
@@ -746,12 +756,21 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                     (void __attribute__((address_space(3)))*)(rows_base + (hoff)), 16, 0, 0);                             \
             }                                                                                                             \
         }
-        // scalar loads of the record at rp (issued HERE), and the wait that makes them usable.  The compiler believes R is
-        // written when the first statement ends: this is only sound while it never moves or spills R between the two
-        // statements — true at this kernel's register budget (88 SGPRs, nothing of R0..R2 goes to VGPR lanes; the GPU
-        // parity tests would show it at once), NOT true at 8 waves per SIMD (tools/experiments/README.md).
-#define BRC_LD_REC(R, rp) asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x20" : "=&s"(R.f), "=&s"(R.g) : "s"(rp));
-#define BRC_WAIT_REC(R) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R.f), "+s"(R.g));
+        // Scalar loads of the record at rp (issued HERE, two pieces ahead), and the wait that makes them usable.  The three
+        // record sets live in FIXED scalar registers, named in the constraints of both statements: the load writes exactly the
+        // registers the wait hands over, nothing is copied in between.  What the compiler does with them between the two
+        // statements is not left to belief: tools/check_isa.py walks the control-flow graph of the built kernel from every
+        // such load to the first s_waitcnt lgkmcnt(0) on every path and fails the build if any instruction on the way reads
+        // or writes one of the registers in flight (bam_readcount_amd/csrc/Makefile runs it; tests/test_abi.py repeats it
+        // for builds at 6, 7 and 8 waves per SIMD).
+#define BRC_F_R0 "{s[56:63]}"
+#define BRC_G_R0 "{s[64:65]}"
+#define BRC_F_R1 "{s[68:75]}"
+#define BRC_G_R1 "{s[66:67]}"
+#define BRC_F_R2 "{s[76:83]}"
+#define BRC_G_R2 "{s[84:85]}"
+#define BRC_LD_REC(R, rp) asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x20" : "=" BRC_F_##R (R.f), "=" BRC_G_##R (R.g) : "s"(rp));
+#define BRC_WAIT_REC(R) asm volatile("s_waitcnt lgkmcnt(0)" : "+" BRC_F_##R (R.f), "+" BRC_G_##R (R.g));
         // the division constants of piece m (its rare record) by scalar loads, on demand: only pieces without PF_TABLE
 #define BRC_LD_DIV(H, R, m)                                                                                             \
         {                                                                                                                 \
@@ -773,8 +792,9 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
             S.m_in = __builtin_amdgcn_ballot_w64(d < R.f[1]);                                                             \
             const uint32_t off = (uint32_t)(roff) + 2u * ((uint32_t)S.s_c & 7u);                                          \
             S.w = (uint32_t)*reinterpret_cast<const uint16_t*>(rows_base + (((uint32_t)lane << 1) + off));                                  \
-            S.t = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds.q) + sad_u32(((uint32_t)lane << 2) + 4u * (uint32_t)S.s_c, R.f[3] & 0xffffffu)); \
-            S.sev = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds.e) + sad_u32(((uint32_t)lane << 4) + 16u * (uint32_t)S.s_c, L0 << 3)); \
+            const uint32_t s_c16 = (uint32_t)S.s_c << 4;                                      /* (scalar) */              \
+            S.t = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds.q16) + sad_u32(lane16b, (uint32_t)LBIAS + ((R.f[3] & 0xffffffu) << 2) - s_c16)); \
+            S.sev = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds.e) + sad_u32(lane16b, (uint32_t)LBIAS + (L0 << 3) - s_c16)); \
         }
         // ACC of the piece in R (S = its probe results), piece index m
 #define BRC_ACC(R, S, m)                                                                                                \
@@ -790,7 +810,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                 float tq2 = __uint_as_float(__float_as_uint(S.t) & ((fl & PF_Q2OK) ? 0xffffffffu : 0u));                  \
                 if (__builtin_expect((fl & PF_TABLE) == 0u, 0)) {                                                         \
                     PieceRare H; BRC_LD_DIV(H, R, m)                                                                      \
-                    const EvTerms t = piece_terms_div(R.f[3], H, (int)((uint32_t)lane + (uint32_t)S.s_c));                \
+                    const EvTerms t = piece_terms_div(R.f[3], H, (int)((uint32_t)BRC_LANE() + (uint32_t)S.s_c));          \
                     S.t = t.s3p; tq2 = t.q2; S.sev = t.sev;                                                               \
                 }                                                                                                         \
                 const float ts3p = S.t; const double tsev = S.sev;                                                        \
@@ -818,11 +838,11 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                         ovf = !take_alt;                                                                                  \
                     }                                                                                                     \
                     m_ovf = __builtin_amdgcn_ballot_w64(ovf);                                                             \
-                    if (m_ovf) { if (lane == 0) { QEnt e; e.piece = (m); e.kind = 0u; e.mlo = (uint32_t)m_ovf; e.mhi = (uint32_t)(m_ovf >> 32); queue[qn] = e; } ++qn; } \
+                    if (m_ovf) { if (BRC_LANE() == 0) { QEnt e; e.piece = (m); e.kind = 0u; e.mlo = (uint32_t)m_ovf; e.mhi = (uint32_t)(m_ovf >> 32); queue[qn] = e; } ++qn; } \
                 }                                                                                                         \
                 if (__builtin_expect((fl & PF_HUGE) != 0u, 0)) {                                                          \
                     const uint64_t m_int = m_p & ~m_ovf;                                                                  \
-                    if (m_int) { if (lane == 0) { QEnt e; e.piece = (m); e.kind = 1u; e.mlo = (uint32_t)m_int; e.mhi = (uint32_t)(m_int >> 32); queue[qn] = e; } ++qn; } \
+                    if (m_int) { if (BRC_LANE() == 0) { QEnt e; e.piece = (m); e.kind = 1u; e.mlo = (uint32_t)m_int; e.mhi = (uint32_t)(m_int >> 32); queue[qn] = e; } ++qn; } \
                 }                                                                                                         \
             }                                                                                                             \
         }
@@ -846,7 +866,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         // packed integers -> slot planes; the 16-bit warning counters of the lanes move to the wave's totals
 #define BRC_FLUSH()                                                                                                     \
         {                                                                                                                 \
-            if (valid) lane2_flush(c, pl, lib, kk, a, flushed);                                                           \
+            if (valid) lane2_flush(c, pl, lib, BRC_KK(), a, flushed);                                                     \
             wsm_tot += wave_sum_u32(valid ? (a.ww & 0xffffu) : 0u); wnm_tot += wave_sum_u32(valid ? (a.ww >> 16) : 0u); a.ww = 0u; \
             flushed = true; since_flush = 0;                                                                              \
         }
@@ -881,18 +901,19 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                     if (kind == 1u && !flushed) {              /* huge integers go straight to the slot planes: make them live */ \
                         BRC_FLUSH()                                                                                       \
                     }                                                                                                     \
-                    const bool mine = ((mask >> lane) & 1ull) != 0ull;                                                    \
+                    const int lr = BRC_LANE(); const int64_t kr = BRC_KK();                                               \
+                    const bool mine = ((mask >> lr) & 1ull) != 0ull;                                                      \
                     const int32_t s_c = p0 - H.a;                                                                         \
                     const uint32_t off = hoff + (m - base) * (uint32_t)ROW_BYTES + 2u * ((uint32_t)s_c & 7u);             \
-                    const uint32_t w = (uint32_t)*reinterpret_cast<const uint16_t*>(rows_base + off + 2u * (uint32_t)lane); \
+                    const uint32_t w = (uint32_t)*reinterpret_cast<const uint16_t*>(rows_base + off + 2u * (uint32_t)lr);  \
                     if (kind == 0u) {                          /* third alleles: raw addends to the list, in piece order */ \
                         uint32_t at0 = 0;                                                                                 \
-                        if (lane == 0 && c.variant != 11) at0 = atomicAdd(pl.xev_n + (size_t)xshard * XEV_CTR_STRIDE, (uint32_t)__builtin_popcountll(mask)); /* (11: profiling, no list cursor) */ \
+                        if (lr == 0 && c.variant != 11) at0 = atomicAdd(pl.xev_n + (size_t)xshard * XEV_CTR_STRIDE, (uint32_t)__builtin_popcountll(mask)); /* (11: profiling, no list cursor) */ \
                         at0 = (uint32_t)__builtin_amdgcn_readfirstlane(at0);                                              \
-                        const uint64_t below = mask & ((1ull << lane) - 1ull);                                            \
+                        const uint64_t below = mask & ((1ull << lr) - 1ull);                                              \
                         const uint32_t at = at0 + (uint32_t)__builtin_popcountll(below);                                  \
-                        if (mine && at < pl.xev_cap) pl.xev[(size_t)xshard * pl.xev_cap + at] = make_xev(lib, kk, H, RR, lane + s_c, w); \
-                    } else if (mine) drain_int(c, pl, lib, kk, RR, (w & 0xffu) == a.dom_b ? 0u : 1u);                     \
+                        if (mine && at < pl.xev_cap) pl.xev[(size_t)xshard * pl.xev_cap + at] = make_xev(lib, kr, H, RR, lr + s_c, w); \
+                    } else if (mine) drain_int(c, pl, lib, kr, RR, (w & 0xffu) == a.dom_b ? 0u : 1u);                     \
                 }                                                                                                         \
                 qn = 0;                                                                                                   \
             }                                                                                                             \
@@ -917,7 +938,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         const uint32_t recstep = c.variant == 10 ? 0u : 48u;                   // (profiling: 10 = every scalar load hits the same line)
         BRC_LD_REC(R0, recp) recp += 48;
         BRC_LD_REC(R1, recp) recp += 48;
-        R2 = R1;
+        asm volatile("" : "=" BRC_F_R2 (R2.f), "=" BRC_G_R2 (R2.g));             // (defined before its first wait: whatever the registers hold; not a copy of a set in flight)
         Stage S0, S1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // first two half-batches staged (tile prologue)
         BRC_WAIT_REC(R0)
@@ -936,14 +957,22 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
             BRC_STEP(5, R2, R0, R1, S1, S0, true)
             BRC_BOUNDARY(nb)
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R0.f), "+s"(R0.g), "+s"(R1.f), "+s"(R1.g), "+s"(R2.f), "+s"(R2.g));   // no scalar load may outlive its registers
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+" BRC_F_R0 (R0.f), "+" BRC_G_R0 (R0.g), "+" BRC_F_R1 (R1.f), "+" BRC_G_R1 (R1.g), "+" BRC_F_R2 (R2.f), "+" BRC_G_R2 (R2.g));   // no scalar load may outlive its registers
         asm volatile("" :: "v"(pf));
 #undef BRC_BOUNDARY
+#undef BRC_KK
+#undef BRC_LANE
 #undef BRC_FLUSH
 #undef BRC_STEP
 #undef BRC_ACC
 #undef BRC_PROBE
 #undef BRC_WAIT_REC
+#undef BRC_F_R0
+#undef BRC_G_R0
+#undef BRC_F_R1
+#undef BRC_G_R1
+#undef BRC_F_R2
+#undef BRC_G_R2
 #undef BRC_LD_DIV
 #undef BRC_LD_REC
 #undef BRC_STAGE
@@ -953,10 +982,11 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
     // is a wave-uniform base in a scalar register pair + the lane's byte offset, one VGPR for all 29 stores; the bases advance
     // by scalar adds.  (Inline assembly: left to the optimiser, the lane offset is folded into ONE 64-bit vector address and
     // the other 28 are derived from it with a 64-bit vector add each.)
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // (the lane index again: see above)
     if (inreg && c.variant != 1) {
         const int64_t P = c.PS;
         const int64_t tb = tile * TILE;                                    // (scalar) plane index of lane 0
-        const uint32_t loff = (uint32_t)lane << 2;
+        const uint32_t loff = (uint32_t)lane_e << 2;
 #define BRC_ST(base, val) asm volatile("global_store_dword %0, %1, %2" :: "v"(loff), "v"(val), "s"(base) : "memory")
         const uint32_t sid = a.dom_b | (a.alt_b << 8);
         { const uint32_t* q = pl.ncol + (int64_t)lib * P + tb; BRC_ST(q, a.ncol); }       // (dead lanes accumulated nothing: zeros)
@@ -969,7 +999,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
             // (wave-uniform) earlier flushes of this tile left partial integer sums in the planes; dead lanes never flush
 #pragma unroll
             for (int f = 0; f < NI; ++f) {
-                const uint32_t x0 = i0[(int64_t)f * P + lane], x1 = i1[(int64_t)f * P + lane];
+                const uint32_t x0 = i0[(int64_t)f * P + lane_e], x1 = i1[(int64_t)f * P + lane_e];
                 dv[f] += dead ? 0u : x0; av[f] += dead ? 0u : x1;
             }
         }
@@ -987,7 +1017,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
     // events (columns of the reporting window), the lanes' warning counters, abandoned positions, and — when there is one
     // library — the emitted positions (with several, a position prints if ANY library's column is non-empty: k_finalize
     // looks at the ncol planes then)
-    const bool rep = valid && p >= c.beg0;
+    const bool rep = valid && (int32_t)(c.pos0 + tile * TILE + lane_e) >= c.beg0;
     const uint32_t ev_lo = wave_sum_u32(rep ? (a.ncol & 0xffffu) : 0u);
     const uint64_t m_big = __builtin_amdgcn_ballot_w64(rep && (a.ncol >> 16) != 0u);
     unsigned long long ev = ev_lo;
@@ -997,7 +1027,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
     const uint32_t npos = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(rep && a.ncol != 0u));
     // (ev of one tile: 64 lanes x a column count; the 32-bit slot holds it up to 67 M reads deep — deeper, it saturates the
     // warning slots first: all four are summed in 64 bits by k_finalize, a tile's share travels in 32)
-    if (lane == 0) tile_ctr[(int64_t)lib * ntiles + tile] = make_uint4((uint32_t)ev, (uint32_t)wsm, (uint32_t)wnm, wl | (npos << 8));
+    if (lane_e == 0) tile_ctr[(int64_t)lib * ntiles + tile] = make_uint4((uint32_t)ev, (uint32_t)wsm, (uint32_t)wnm, wl | (npos << 8));
 }
 
 template <int NV>

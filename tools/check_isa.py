@@ -1,32 +1,140 @@
 #!/usr/bin/env python3
-"""Register budget of k_pileup2 from the compiler's assembly (no GPU needed): VGPRs, SGPRs, scratch bytes, and how many
-scratch and SGPR-spill (v_writelane / v_readlane) operations sit from the piece loop on.  The kernel's scalar-load scheme
-(brc_engine.hip, BRC_LD_REC / BRC_WAIT_REC) and its 7 waves per SIMD depend on that budget: 72 VGPRs, 88 SGPRs, scratch
-only outside the loop.  Whether a build is also CORRECT is for the -m gpu parity tests to say (tools/experiments/README.md
-has a build that fits 64 registers and is wrong).
+"""Static checks of k_pileup2's machine code (no GPU needed), run by bam_readcount_amd/csrc/Makefile after every build of
+the engine and by tests/test_abi.py for builds at 6, 7 and 8 waves per SIMD.
 
-    python tools/check_isa.py [extra hipcc flags, e.g. -DBRC_WAVES_PER_EU=8]
+1. Register budget: VGPRs, SGPRs, scratch bytes; scratch and SGPR-spill (v_writelane / v_readlane) operations from the
+   piece loop on (printed; --max-vgpr / --max-scratch turn them into failures).
+
+2. SOUNDNESS OF THE EARLY SCALAR LOADS.  k_pileup2 issues the scalar loads of a piece record two pieces ahead of its use
+   (brc_engine.hip, BRC_LD_REC) and waits for them in a later inline-assembly statement (BRC_WAIT_REC); the record sets live
+   in fixed scalar registers named in the constraints of both statements.  The compiler knows nothing about the time in
+   between, so this script checks it on the code the compiler actually produced: it builds the control-flow graph of the
+   kernel and walks it from every inline-assembly s_load_dword* to the first `s_waitcnt lgkmcnt(0)` on EVERY path; an
+   instruction on the way that reads or writes one of the destination registers (a copy, a spill to a VGPR lane, a reuse
+   as a temporary, another load into them) is an error.  Exit status 1 and a listing of the offending paths.
+
+    python tools/check_isa.py [--quiet] [--max-vgpr N] [--max-scratch BYTES] [extra hipcc flags, e.g. -DBRC_WAVES_PER_EU=8]
 """
-import os, re, subprocess, sys
+import os
+import re
+import subprocess
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "bam_readcount_amd", "csrc", "brc_engine.hip")
 
 
+def sregs(text):
+    """scalar registers named in an operand string"""
+    out = set()
+    for m in re.finditer(r"\bs\[(\d+):(\d+)\]", text):
+        out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in re.finditer(r"\bs(\d+)\b", text):
+        out.add(int(m.group(1)))
+    return out
+
+
+def parse(body):
+    """instructions [(text, in_asm)], label -> instruction index"""
+    ins = []; labels = {}; in_asm = False
+    for l in body:
+        s = l.split(";")[0].strip() if not l.strip().startswith(";;#") else l.strip()
+        if s.startswith(";;#ASMSTART"): in_asm = True; continue
+        if s.startswith(";;#ASMEND"): in_asm = False; continue
+        if not s or s.startswith("."):
+            m = re.match(r"^(\.LBB\d+_\d+):", s)
+            if m: labels[m.group(1)] = len(ins)
+            continue
+        if s.endswith(":"):
+            continue
+        ins.append((s, in_asm))
+    return ins, labels
+
+
+def successors(ins, labels, i):
+    s = ins[i][0]; op = s.split()[0]
+    if op in ("s_endpgm",):
+        return []
+    if op == "s_branch":
+        return [labels[s.split()[1]]]
+    if op.startswith("s_cbranch"):
+        return [labels[s.split()[1]]] + ([i + 1] if i + 1 < len(ins) else [])
+    return [i + 1] if i + 1 < len(ins) else []
+
+
+def waits_lgkm0(s):
+    return s.startswith("s_waitcnt") and re.search(r"lgkmcnt\(0\)", s) is not None
+
+
+def check_loads(ins, labels):
+    errors = []; nloads = 0
+    for i, (s, in_asm) in enumerate(ins):
+        if not (in_asm and s.startswith("s_load_dword")):
+            continue
+        nloads += 1
+        dest = sregs(s.split(",")[0])
+        # the statement's own companion loads (same asm block) write other registers; start behind this instruction
+        seen = set(); stack = [(j, (i,)) for j in successors(ins, labels, i)]
+        while stack:
+            j, path = stack.pop()
+            if j in seen:
+                continue
+            seen.add(j)
+            t = ins[j][0]
+            if waits_lgkm0(t):
+                continue
+            ops = t.split(None, 1)[1] if " " in t else ""
+            if t.split()[0] == "s_endpgm":
+                errors.append("load at #%d `%s`: a path reaches s_endpgm without s_waitcnt lgkmcnt(0)" % (i, s)); continue
+            hit = dest & sregs(ops)
+            if hit and not t.startswith(("s_branch", "s_cbranch")):
+                errors.append("load at #%d `%s`: register(s) %s touched before the wait by #%d `%s`" % (i, s, sorted(hit), j, t))
+                continue
+            for k in successors(ins, labels, j):
+                stack.append((k, path))
+    return nloads, errors
+
+
 def main():
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-O3", "-std=c++17", "-ffp-contract=off"] + sys.argv[1:] + [SRC, "-o", "-"]
+    args = sys.argv[1:]; quiet = False; max_vgpr = None; max_scratch = None; extra = []
+    while args:
+        a = args.pop(0)
+        if a == "--quiet": quiet = True
+        elif a == "--max-vgpr": max_vgpr = int(args.pop(0))
+        elif a == "--max-scratch": max_scratch = int(args.pop(0))
+        else: extra.append(a)
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-O3", "-std=c++17", "-ffp-contract=off"] + extra + [SRC, "-o", "-"]
     asm = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
     lines = asm.split("\n")
     start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN3brc9k_pileup2.*:", l))
     end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
-    body = lines[start:end]
+    body = lines[start + 1:end]
     meta = {k: int(re.search(r"k_pileup2\S*\.%s, (\d+)" % k, asm).group(1)) for k in ("num_vgpr", "numbered_sgpr", "private_seg_size")}
     loop = [i for i, l in enumerate(body) if "Loop Header: Depth=1" in l]
     tail = body[loop[-1]:] if loop else body
     count = lambda pred: sum(1 for l in tail if pred(l.strip()))
-    print("k_pileup2: %(num_vgpr)d VGPRs, %(numbered_sgpr)d SGPRs, %(private_seg_size)d bytes of scratch per lane" % meta)
-    print("from the piece loop on: %d VALU, %d SALU, %d scratch, %d v_writelane / v_readlane instructions (static counts)" % (
-        count(lambda l: l.startswith("v_")), count(lambda l: l.startswith("s_")), count(lambda l: l.startswith("scratch_")),
-        count(lambda l: l.startswith("v_writelane") or l.startswith("v_readlane"))))
+    if not quiet:
+        print("k_pileup2: %(num_vgpr)d VGPRs, %(numbered_sgpr)d SGPRs, %(private_seg_size)d bytes of scratch per lane" % meta)
+        print("from the piece loop on: %d VALU, %d SALU, %d scratch, %d v_writelane / v_readlane instructions (static counts)" % (
+            count(lambda l: l.startswith("v_")), count(lambda l: l.startswith("s_")), count(lambda l: l.startswith("scratch_")),
+            count(lambda l: l.startswith("v_writelane") or l.startswith("v_readlane"))))
+    ins, labels = parse(body)
+    nloads, errors = check_loads(ins, labels)
+    rc = 0
+    if nloads < 6:
+        print("check_isa: expected the read loop's inline-assembly scalar loads, found %d" % nloads); rc = 1
+    if errors:
+        print("check_isa: UNSOUND early scalar loads in k_pileup2 (%d):" % len(errors))
+        for e in errors[:20]:
+            print("  " + e)
+        rc = 1
+    elif not quiet:
+        print("early scalar loads: %d inline-assembly loads, no instruction touches their registers before the wait on any path" % nloads)
+    if max_vgpr is not None and meta["num_vgpr"] > max_vgpr:
+        print("check_isa: %d VGPRs > %d" % (meta["num_vgpr"], max_vgpr)); rc = 1
+    if max_scratch is not None and meta["private_seg_size"] > max_scratch:
+        print("check_isa: %d bytes of scratch > %d" % (meta["private_seg_size"], max_scratch)); rc = 1
+    sys.exit(rc)
 
 
 if __name__ == "__main__":
