@@ -113,15 +113,24 @@ def main():
     ap.add_argument("--cpu-ref-mbp", type=float, default=0.5, help="prefix timed with the reference-compiled library oracle/_ref (0 = skip)")
     ap.add_argument("--cpu-all-cores", type=int, default=-1, help="oracle processes of the all-cores baseline (-1: min(usable CPUs, 64); 0 = skip)")
     ap.add_argument("--e2e-mbp", type=float, default=30.0, help="contig of the end-to-end command-line run (0 = skip)")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r02_traffic.json"))
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r03_traffic.json"))
+    ap.add_argument("--other-configs", type=int, default=-1, help="1: also run BASELINE config 4 (--mode sites) and the per-GPU shape of config 5 (--mode strong --contig-mbp 6.25) "
+                    "in sub-processes and put their lines under other_configs (-1: yes on the default single-GPU config-3 run, no otherwise)")
     ap.add_argument("--cpu-worker", nargs=3, default=None, help=argparse.SUPPRESS)
+    # test infrastructure (tests/test_bench_multirank.py): the rank arithmetic of this script — who owns which interval / slice of
+    # the site list, the reductions of the metrics line — executed on CPUs: gloo instead of RCCL, and the C-ABI served by the CPU
+    # lane simulator named here.  The line it prints says so ("dry_run") and carries no throughput.
+    ap.add_argument("--dry-run-lib", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--as-rank", type=int, default=None, help=argparse.SUPPRESS)     # with --as-world: one rank's share, without a launcher
+    ap.add_argument("--as-world", type=int, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
         return cpu_worker(int(args.cpu_worker[0]), float(args.cpu_worker[1]), args.cpu_worker[2])
     config = args.config or ("tumor200x" if args.mode == "strong" else "wgs30x")
 
     # ---- N > 1 without a launcher: become `python -m torch.distributed.run ... bench.py <same arguments>`
-    if args.gpus > 1 and "RANK" not in os.environ:
+    dry = args.dry_run_lib is not None
+    if args.gpus > 1 and "RANK" not in os.environ and args.as_rank is None:
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
@@ -133,22 +142,32 @@ def main():
     from bam_readcount_amd import capi
 
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    emulated = args.as_rank is not None
+    if emulated:                                     # (dry run only) the share of rank --as-rank of --as-world, on its own
+        if not dry:
+            raise SystemExit("--as-rank is part of the dry run (--dry-run-lib)")
+        rank, world = args.as_rank, int(args.as_world or args.gpus)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
-    torch.cuda.set_device(local_rank)
+    if not dry:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+        torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    tdev = "cpu" if dry else "cuda"
+    if world > 1 and not emulated:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
 
     ncpu = os.cpu_count() or 1
     ncpu_eff = effective_cpus()
     nworkers = (min(ncpu_eff, 64) if args.cpu_all_cores < 0 else args.cpu_all_cores) if (rank == 0 and world == 1 and args.cpu_sample_mbp > 0) else 0
 
-    hip = capi.load_product()
+    hip = capi.Library(os.path.abspath(args.dry_run_lib)) if dry else capi.load_product()
     per_lib = config == "tumor200x"
     names = ["lib%d" % i for i in range(synthgen.CONFIGS[config]["n_libs"])] if per_lib else ()
     opts = dict(min_mapq=20, min_bq=13) if not per_lib else dict(min_mapq=0, min_bq=0, per_lib=True, insertion_centric=True)
@@ -182,21 +201,21 @@ def main():
     t_up = time.time() - t0
 
     def sync_all():
-        torch.cuda.synchronize()
+        if not dry: torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry: torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         eng.compute()
-    kernel_names = hip.kernel_names()
+    kernel_names = hip.kernel_names() if not dry else ["k_pileup"]
     k_pile = kernel_names.index("k_pileup")
     kms = np.zeros(len(kernel_names))
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ms, _tot = eng.compute()                  # launches the pipeline on the engine stream and waits for it
-        kms += np.array(ms)
+        if not dry: kms += np.array(ms)
     sync_all()
     dt = time.perf_counter() - t0
     kms /= max(args.steps, 1)
@@ -206,12 +225,22 @@ def main():
 
     tmax, ev_total, pos_total = dt, n_events, n_positions
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        c = torch.tensor([n_events, n_positions], dtype=torch.int64, device="cuda")
+        c = torch.tensor([n_events, n_positions], dtype=torch.int64, device=tdev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)   # the only collective: 16 bytes of counters for the metrics line
         tmax, ev_total, pos_total = float(t.item()), int(c[0].item()), int(c[1].item())
 
+    if dry:
+        # the dry run ends here: what every rank (or the emulated one) owned, and — on rank 0 — the reduced totals
+        if rank == 0 or emulated:
+            print(json.dumps({"dry_run": "rank arithmetic only (gloo, %s)" % hip.kind(), "value": None, "n_gpus": world, "rank": rank, "mode": args.mode,
+                              "events_per_step": int(ev_total), "positions_per_step": int(pos_total), "own_events": int(n_events), "own_positions": int(n_positions),
+                              "reads_per_gpu": int(len(region_reads["pos"]))}))
+        eng.close()
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if rank == 0:
         ms_per_step = tmax / args.steps * 1e3
         value = ev_total * args.steps / tmax
@@ -227,6 +256,9 @@ def main():
             if tj and abs(float(tj.get("contig_mbp", 50.0)) - contig_len / 1e6) < 1e-6:       # the passes measured exactly this workload
                 traffic = tj.get("k_pileup_hbm_bytes_per_launch")
                 traffic_src = "%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not measured in this run" % os.path.relpath(args.traffic_json, ROOT)
+        # what THIS design must move per step at the least: the inputs once, the reference once, the compact result once
+        # (116 B per position and library; SURVEY 8d's figure above credits the dense 312 B the kernel does not write)
+        compact = b_in + b_ref + 116 * int(eng_positions) * res_libs
         roof = {"bound": "hbm", "kernel": "k_pileup2", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_copy_rate": round(achieved / HBM_COPY_GBS, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
@@ -234,6 +266,9 @@ def main():
                 "frac_of_peak_by_traffic": round(traffic / (kms[k_pile] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (traffic and kms[k_pile] > 0) else None,
                 "algorithmic_bytes_per_launch": alg, "bytes_per_event": round(alg / max(eng_events, 1), 3),
                 "compact_result_bytes_per_launch": 116 * int(eng_positions) * res_libs,
+                "compulsory_bytes_compact": compact,
+                "kernel_frac_by_compulsory_bytes_compact": round(compact / (kms[k_pile] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kms[k_pile] > 0 else None,
+                "whole_step_frac_by_compulsory_bytes_compact": round(compact / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if world == 1 else None,
                 "whole_step_frac": round(alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if world == 1 else None,
                 "kernel_ms": {k: round(float(v), 4) for k, v in zip(kernel_names, kms) if k}}
 
@@ -368,6 +403,28 @@ def main():
             import shutil
             shutil.rmtree(d, ignore_errors=True)
 
+        # ---- the other timed BASELINE configurations, each a sub-process of this script with a short timed region; their
+        # own validation (config 4: 400 sites against one oracle region per site; config-5 shape: planes + text of a prefix
+        # against the oracle) runs inside them
+        other = None
+        want_other = args.other_configs == 1 or (args.other_configs < 0 and world == 1 and args.mode == "weak" and config == "wgs30x" and abs(args.contig_mbp - 50.0) < 1e-9 and args.cpu_sample_mbp > 0)
+        if want_other:
+            eng.close(); eng = None                              # (the sub-processes get the GPU and the host memory to themselves)
+            other = {}
+            subs = {"config4_sites": ["--mode", "sites"],
+                    "config5_per_gpu_shape": ["--mode", "strong", "--contig-mbp", "6.25"]}
+            for key, extra in subs.items():
+                cmd = [sys.executable, os.path.abspath(__file__)] + extra + ["--steps", "60", "--warmup", "5", "--cpu-all-cores", "0", "--cpu-ref-mbp", "0", "--e2e-mbp", "0", "--other-configs", "0"]
+                try:
+                    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                    sub = json.loads([l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1])
+                    other[key] = {"value": sub["value"], "unit": sub["unit"], "ms_per_step": sub["ms_per_step"], "steps": sub["steps"], "positions_per_s": sub["positions_per_s"],
+                                  "workload": sub["config"]["workload"], "events_per_step": sub["config"]["events_per_step"], "positions_per_step": sub["config"]["positions_per_step"],
+                                  "kernel_ms": sub["roofline"]["kernel_ms"], "frac": sub["roofline"]["frac"], "achieved_GBs": sub["roofline"]["achieved"],
+                                  "kernel_frac_by_compulsory_bytes_compact": sub["roofline"].get("kernel_frac_by_compulsory_bytes_compact"),
+                                  "whole_step_frac": sub["roofline"]["whole_step_frac"], "validated": sub["validated"], "cpu_baseline": sub["cpu_baseline"]}
+                except Exception as ex:                                      # noqa: BLE001 — reported, never hidden
+                    other[key] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         what = {"weak": "synthetic 30x WGS, 150bp reads, 1 contig %.0f Mbp per GPU, -q20 -b13" % (contig_len / 1e6),
                 "strong": "synthetic 200x tumor 4 libraries, 150bp reads, -p -i, 1 contig %.0f Mbp cut into %d intervals" % (total_len / 1e6, world),
                 "sites": "-l site list of %d single-base sites in file order over %d synthetic 30x contigs of %.0f Mbp (genome scaled from 3.1 Gbp), -q20 -b13, cut into %d slices"
@@ -381,11 +438,12 @@ def main():
             "config": {"workload": what, "mode": args.mode, "reads_per_gpu": int(len(region_reads["pos"])),
                        "events_per_step": int(ev_total), "positions_per_step": int(pos_total), "parallelism": "interval-shard x%d" % world},
             "positions_per_s": round(pos_total * args.steps / tmax, 1),
-            "roofline": roof, "cpu_baseline": cpu, "e2e": e2e, "validated": validated,
+            "roofline": roof, "cpu_baseline": cpu, "e2e": e2e, "validated": validated, "other_configs": other,
             "host": {"gen_s": round(t_gen, 2), "push_s": round(t_push, 2), "upload_s": round(t_up, 2), "timed_s": round(tmax, 3)},
         }
         print(json.dumps(line))
-    eng.close()
+    if eng is not None:
+        eng.close()
     if dist is not None:
         dist.destroy_process_group()
 
