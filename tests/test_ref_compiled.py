@@ -21,6 +21,7 @@ import numpy as np
 import pytest
 
 from bam_readcount_amd import capi
+from test_cli import synthetic_bam  # noqa: F401  (fixture)
 from conftest import GOLDEN, ROOT
 import parity
 import synth
@@ -64,6 +65,55 @@ def test_reference_main_reproduces_its_goldens(ref_lib, workdir):
         assert rc == 0, err
         assert out == open(os.path.join(GOLDEN, exp), "rb").read(), (exp, bam, extra, how)
         assert "Minimum mapping quality is set to 0" in err
+
+
+# ---------------------------------------------------------------- INTEGRATION.md section 2, compiled and run
+# oracle/ref_shim/ref_bound.cpp: the reference's own main() with fetch_func / the plbuf calls bound to the brc C-ABI —
+# option parsing, file opening, the site-list and region loops, messages and exit codes are the reference's; everything
+# fetch_func, pileup_func, BasicStat and IndelQueue did happens behind include/brc.h (libbrc_sim.so here, libbrc_hip.so on the GPU).
+
+BOUND_SIM = os.path.join(REF_DIR, "bam-readcount-bound-sim")
+BOUND_HIP = os.path.join(REF_DIR, "bam-readcount-bound-hip")
+
+
+def _bound_main_check(exe, workdir, synthetic_bam):
+    from test_cli import RUNS, run_cli
+    assert os.path.exists(exe), "oracle/_ref is built by oracle/ref_shim/Makefile where the reference checkout exists and travels prebuilt"
+    # the reference's six integration commands: its goldens, and stdout + stderr + exit code of the reference-compiled main()
+    for w in ("1", "3", "-1", "0"):
+        for exp, bam, extra, how in RUNS:
+            tail = ["-l", "site_list", bam] if how == "list" else [bam, "21:10402985-10402985", "21:10405200-10405200"]
+            want = subprocess.run([REF_CLI, "-w", w] + extra + ["-f", "ref.fa"] + tail, cwd=workdir, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            got = subprocess.run([exe, "-w", w] + extra + ["-f", "ref.fa"] + tail, cwd=workdir, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert got.stdout == open(os.path.join(GOLDEN, exp), "rb").read(), (exp, bam, extra, how)
+            assert (got.returncode, got.stdout) == (want.returncode, want.stdout), got.stderr[-500:]
+            assert got.stderr == want.stderr, (w, bam, extra, how)
+    # synthetic reads with every CIGAR operator, two libraries, regions in any order (deletions pending across them), a
+    # site list with duplicate and overlapping lines, an unknown contig, no reference.  (Regions keep clear of the reads that
+    # hang over a contig's end: past it the reference's annotator reads unowned memory, bamreadcount.cpp:149 — DESIGN.md.)
+    d = synthetic_bam
+    open(d / "sites_bound.txt", "w").write("chrA\t100\t160\nchrB\t5\t900\nchrA\t100\t160\nnochr\t1\t2\nchrA\t3390\t3400\nchrA\t130\t400\nbad line\n")
+    for args in (["-f", "syn.fa", "syn.bam", "chrA:1-2000", "chrA:2001-3500", "chrB:1-1200", "chrA:100-100"],
+                 ["-p", "-i", "-q", "10", "-b", "5", "-f", "syn.fa", "syn.bam", "chrB:1-1500", "chrA:1-3000"],
+                 ["-w", "2", "-p", "-f", "syn.fa", "-l", "sites_bound.txt", "syn.bam"],
+                 ["-w", "0", "-i", "-d", "30", "-f", "syn.fa", "-l", "sites_bound.txt", "syn.bam"],
+                 ["-f", "syn.fa", "syn.bam", "chrA:1-50", "nochr:1-2", "chrB:1-5"]):
+        want = subprocess.run([REF_CLI] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        got = subprocess.run([exe] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert (got.returncode, got.stdout) == (want.returncode, want.stdout), (args, got.stderr[-500:])
+        assert got.stderr == want.stderr, args
+        assert want.returncode == 1 or want.stdout.count(b"\n") > 50
+
+
+def test_reference_main_bound_to_the_c_abi_cpu(ref_lib, workdir, synthetic_bam):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    _bound_main_check(BOUND_SIM, workdir, synthetic_bam)
+
+
+@pytest.mark.gpu
+def test_reference_main_bound_to_the_c_abi_gpu(ref_lib, workdir, synthetic_bam):
+    """The same binding linked to libbrc_hip.so: the reference's main() driving the MI355X engine."""
+    _bound_main_check(BOUND_HIP, workdir, synthetic_bam)
 
 
 # ---------------------------------------------------------------- oracle text == reference-compiled text
