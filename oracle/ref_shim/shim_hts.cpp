@@ -9,8 +9,13 @@
  *     control flow as published (lazy node removal, max_pos gating, max-count rule on mp->cnt), while the per-entry
  *     CIGAR resolution is written STATELESSLY (a pure function of (cigar, pos)) as a second formulation next to
  *     the stateful cursor of oracle/brc_oracle.c;
- *   - samopen / samfetch / sam_index_load3 / fai_* sit on this repository's own BGZF/BAM/BAI/CRAM/FASTA readers
- *     (bam_readcount_amd/csrc/io/bamio.*), used here purely as a file-format library.
+ *   - samopen / samfetch / sam_index_load3 / fai_* for BAM and FASTA input sit on a SECOND, independent decoder written here
+ *     (IndepBam / IndepFasta below: whole-file BGZF inflate with zlib, sequential record scan, no index arithmetic) — so the
+ *     differential tests of the drop-in command line against the reference's main() also cover the product's own reader
+ *     stack (bam_readcount_amd/csrc/io/bamio.*: BGZF blocks, BAI / CSI bins and linear index, striped fetches, CG-tag CIGARs,
+ *     .fai arithmetic) instead of sharing its bugs.  CRAM input still goes through the product's CRAM decoder (cram.o) —
+ *     the one reader both sides share; BRC_SHIM_PRODUCT_READER=1 routes BAM / FASTA through the product's readers as well
+ *     (A/B of the two decoders).
  */
 #include <limits.h>
 #include <stdio.h>
@@ -232,17 +237,159 @@ extern "C" int bam_plbuf_push(const bam1_t* b, bam_plbuf_t* buf) {
     return 0;
 }
 
-/* ---------------------------------------------------------------- header, files, index (on bamio) */
+/* ---------------------------------------------------------------- the independent BAM / FASTA decoder */
+#include <zlib.h>
+
+static bool product_reader() { static const bool v = getenv("BRC_SHIM_PRODUCT_READER") && atoi(getenv("BRC_SHIM_PRODUCT_READER")) != 0; return v; }
+
+struct IndepRec { int32_t tid, pos, l_seq, mtid, mpos, tlen, end; uint16_t flag, bin; uint32_t n_cigar; uint8_t mapq; uint32_t l_qname; std::vector<uint8_t> data; };
+
+struct IndepBam {
+    std::string text; std::vector<std::string> names; std::vector<int32_t> lengths;
+    std::vector<IndepRec> recs;
+    static uint32_t u32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+    static uint16_t u16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+    // SAMv1 4.1: a BGZF file is a series of gzip members with a 'BC' extra subfield holding the member's size - 1
+    static bool inflate_all(const std::vector<uint8_t>& in, std::vector<uint8_t>* out) {
+        size_t at = 0;
+        while (at < in.size()) {
+            if (in.size() - at < 18 || in[at] != 31 || in[at + 1] != 139 || in[at + 2] != 8 || !(in[at + 3] & 4)) return false;
+            const uint32_t xlen = u16(&in[at + 10]); size_t x = at + 12; const size_t xend = x + xlen; int64_t bsize = -1;
+            if (xend > in.size()) return false;
+            while (x + 4 <= xend) { const uint32_t slen = u16(&in[x + 2]); if (in[x] == 'B' && in[x + 1] == 'C' && slen == 2 && x + 6 <= xend) bsize = u16(&in[x + 4]); x += 4 + slen; }
+            if (bsize < 0 || at + (size_t)bsize + 1 > in.size() || (size_t)bsize + 1 < 12 + xlen + 8) return false;
+            const size_t cbeg = xend, cend = at + (size_t)bsize + 1 - 8;
+            const uint32_t isize = u32(&in[cend + 4]);
+            const size_t o = out->size(); out->resize(o + isize);
+            if (isize) {
+                z_stream zs; memset(&zs, 0, sizeof zs);
+                if (inflateInit2(&zs, -15) != Z_OK) return false;
+                zs.next_in = const_cast<Bytef*>(&in[cbeg]); zs.avail_in = (uInt)(cend - cbeg); zs.next_out = &(*out)[o]; zs.avail_out = isize;
+                const int r = inflate(&zs, Z_FINISH); inflateEnd(&zs);
+                if (r != Z_STREAM_END || zs.avail_out != 0) return false;
+                if (crc32(crc32(0L, Z_NULL, 0), &(*out)[o], isize) != u32(&in[cend])) return false;
+            }
+            at += (size_t)bsize + 1;
+        }
+        return true;
+    }
+    // bam_endpos: pos + reference length of the CIGAR; pos + 1 for unmapped records and records without one
+    static int32_t endpos(const IndepRec& r) {
+        if ((r.flag & 4) || r.n_cigar == 0) return r.pos + 1;
+        int64_t l = 0; const uint8_t* c = r.data.data() + r.l_qname;
+        for (uint32_t k = 0; k < r.n_cigar; ++k) { const uint32_t v = u32(c + 4 * k), op = v & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) l += v >> 4; }
+        return l ? (int32_t)(r.pos + l) : r.pos + 1;
+    }
+    // SAMv1 4.2.2: a CIGAR of more than 65535 operators is stored in the CG:B,I tag behind a placeholder <l_seq>S<ref>N;
+    // htslib 1.10 (bam_tag2cigar) moves it back into place and drops the tag
+    static void splice_cg(IndepRec& r) {
+        if (r.n_cigar != 2 || r.tid < 0 || r.pos < 0) return;
+        const uint8_t* c = r.data.data() + r.l_qname;
+        const uint32_t c0 = u32(c);
+        if ((c0 & 15) != 4 || (int32_t)(c0 >> 4) != r.l_seq) return;
+        const size_t aux0 = r.l_qname + 4u * r.n_cigar + ((size_t)r.l_seq + 1) / 2 + (size_t)r.l_seq;
+        size_t a = aux0;
+        while (a + 3 <= r.data.size()) {
+            const uint8_t* t = &r.data[a]; const char ty = (char)t[2]; size_t len;
+            if (ty == 'A' || ty == 'c' || ty == 'C') len = 1; else if (ty == 's' || ty == 'S') len = 2; else if (ty == 'i' || ty == 'I' || ty == 'f') len = 4;
+            else if (ty == 'Z' || ty == 'H') { len = 0; while (a + 3 + len < r.data.size() && t[3 + len]) ++len; ++len; }
+            else if (ty == 'B') { if (a + 8 > r.data.size()) return; const char st = (char)t[3]; const uint32_t n = u32(t + 4); const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4; len = 5 + (size_t)n * es; }
+            else return;
+            if (a + 3 + len > r.data.size()) return;
+            if (t[0] == 'C' && t[1] == 'G' && ty == 'B' && (char)t[3] == 'I') {
+                const uint32_t n = u32(t + 4);
+                if (n == 0) return;
+                std::vector<uint8_t> d(r.data.begin(), r.data.begin() + r.l_qname);
+                d.insert(d.end(), t + 8, t + 8 + 4u * (size_t)n);                                                  // the real CIGAR
+                d.insert(d.end(), r.data.begin() + r.l_qname + 4u * r.n_cigar, r.data.begin() + a);                // seq, qual, aux before CG
+                d.insert(d.end(), r.data.begin() + a + 3 + len, r.data.end());                                     // aux behind CG
+                r.data.swap(d); r.n_cigar = n;
+                return;
+            }
+            a += 3 + len;
+        }
+    }
+    bool open(const char* fn) {
+        FILE* f = fopen(fn, "rb");
+        if (!f) return false;
+        std::vector<uint8_t> raw; uint8_t buf[1 << 16]; size_t n;
+        while ((n = fread(buf, 1, sizeof buf, f)) > 0) raw.insert(raw.end(), buf, buf + n);
+        fclose(f);
+        std::vector<uint8_t> u;
+        if (!inflate_all(raw, &u)) return false;
+        if (u.size() < 12 || memcmp(u.data(), "BAM\1", 4) != 0) return false;
+        size_t at = 4; const uint32_t l_text = u32(&u[at]); at += 4;
+        if (at + l_text + 4 > u.size()) return false;
+        text.assign((const char*)&u[at], l_text); { const size_t z = text.find('\0'); if (z != std::string::npos) text.resize(z); }
+        at += l_text;
+        const uint32_t n_ref = u32(&u[at]); at += 4;
+        for (uint32_t i = 0; i < n_ref; ++i) {
+            if (at + 4 > u.size()) return false;
+            const uint32_t ln = u32(&u[at]); at += 4;
+            if (at + ln + 4 > u.size() || ln == 0) return false;
+            names.push_back(std::string((const char*)&u[at], ln - 1)); at += ln;
+            lengths.push_back((int32_t)u32(&u[at])); at += 4;
+        }
+        while (at + 4 <= u.size()) {
+            const uint32_t bs = u32(&u[at]); at += 4;
+            if (bs < 32 || at + bs > u.size()) return false;                 // a truncated record is an error, like the product's reader says
+            const uint8_t* p = &u[at]; IndepRec r;
+            r.tid = (int32_t)u32(p); r.pos = (int32_t)u32(p + 4); r.l_qname = p[8]; r.mapq = p[9]; r.bin = u16(p + 10); r.n_cigar = u16(p + 12); r.flag = u16(p + 14);
+            r.l_seq = (int32_t)u32(p + 16); r.mtid = (int32_t)u32(p + 20); r.mpos = (int32_t)u32(p + 24); r.tlen = (int32_t)u32(p + 28);
+            if (r.l_seq < 0 || 32 + (uint64_t)r.l_qname + 4ull * r.n_cigar + ((uint64_t)r.l_seq + 1) / 2 + (uint64_t)r.l_seq > bs) return false;
+            r.data.assign(p + 32, p + bs);
+            splice_cg(r);
+            r.end = endpos(r);
+            recs.push_back(r); at += bs;
+        }
+        return at == u.size();
+    }
+    // the records an indexed fetch of [beg, end) on tid returns: file order, pos < end, endpos > beg
+    template <class F> void fetch(int tid, int beg, int end, F f) const {
+        for (size_t i = 0; i < recs.size(); ++i) { const IndepRec& r = recs[i]; if (r.tid == tid && r.pos < end && r.end > beg) f(r); }
+    }
+};
+
+// FASTA through its .fai (name, length, offset, line bases, line bytes)
+struct IndepFasta {
+    std::string path; std::map<std::string, std::vector<long long> > ent;
+    bool open(const char* fn) {
+        path = fn;
+        FILE* f = fopen((path + ".fai").c_str(), "r");
+        if (!f) return false;
+        char name[4096]; long long a, b, c, d;
+        while (fscanf(f, "%4095s %lld %lld %lld %lld", name, &a, &b, &c, &d) == 5) { std::vector<long long> v; v.push_back(a); v.push_back(b); v.push_back(c); v.push_back(d); if (!ent.count(name)) ent[name] = v; }
+        fclose(f);
+        return true;
+    }
+    bool fetch(const char* name, std::string* seq) const {
+        std::map<std::string, std::vector<long long> >::const_iterator it = ent.find(name);
+        if (it == ent.end()) return false;
+        const long long len = it->second[0], off = it->second[1], lb = it->second[2], lw = it->second[3];
+        if (lb <= 0 || lw < lb) return false;
+        FILE* f = fopen(path.c_str(), "rb");
+        if (!f) return false;
+        seq->clear(); seq->reserve((size_t)len);
+        if (fseek(f, (long)off, SEEK_SET) != 0) { fclose(f); return false; }
+        int ch;
+        while ((long long)seq->size() < len && (ch = fgetc(f)) != EOF) if (ch > ' ') seq->push_back((char)ch);     // (faidx keeps every graphic character)
+        fclose(f);
+        return (long long)seq->size() == len;
+    }
+};
+
+/* ---------------------------------------------------------------- header, files, index */
 
 struct htsFile {
     std::string path, fai_path;
     bool is_cram = false, opened = false;
-    brcio::BamReader bam;
+    brcio::BamReader bam;            // (BRC_SHIM_PRODUCT_READER=1 only)
+    IndepBam ibam;
     brcio::CramReader* cram = 0;
     brcio::Fasta fasta;
 };
 struct hts_idx_t { brcio::BamIndex idx; bool none = false; };
-struct faidx_shim_t { brcio::Fasta fa; };
+struct faidx_shim_t { brcio::Fasta fa; IndepFasta ifa; };
 
 static bam_hdr_t* make_header(const brcio::BamHeader& h) {
     bam_hdr_t* o = (bam_hdr_t*)calloc(1, sizeof(bam_hdr_t));
@@ -282,7 +429,13 @@ extern "C" samfile_t* samopen(const char* fn, const char* mode, const void*) {
     fp->file = new htsFile();
     fp->file->path = fn;
     fp->file->is_cram = brcio::CramReader::is_cram(fn);
-    if (!fp->file->is_cram) {
+    if (!fp->file->is_cram && !product_reader()) {
+        if (!fp->file->ibam.open(fn)) { delete fp->file; free(fp); return 0; }
+        fp->file->opened = true;
+        brcio::BamHeader h; h.text = fp->file->ibam.text; h.names = fp->file->ibam.names; h.lengths = fp->file->ibam.lengths;    // (a plain record of what was read)
+        for (size_t i = 0; i < h.names.size(); ++i) if (!h.name2tid.count(h.names[i])) h.name2tid[h.names[i]] = (int)i;
+        fp->header = make_header(h);
+    } else if (!fp->file->is_cram) {
         if (!fp->file->bam.open(fn)) { delete fp->file; free(fp); return 0; }
         fp->file->opened = true;
         fp->header = make_header(fp->file->bam.header());
@@ -315,6 +468,14 @@ extern "C" char* samfaipath(const char* fn_ref) {
 extern "C" hts_idx_t* sam_index_load3(htsFile* fp, const char* fn, const char*, int) {
     hts_idx_t* x = new hts_idx_t();
     if (fp->is_cram) { x->none = true; return x; }      // the CRAM reader scans its own container index
+    if (!product_reader()) {
+        // the independent reader scans the records: the index only has to EXIST (main() reports its absence, :583,:637)
+        const std::string b = fn; x->none = true;
+        const char* tries[] = {".bai", ".csi"};
+        for (int k = 0; k < 2; ++k) { FILE* f = fopen((b + tries[k]).c_str(), "rb"); if (f) { fclose(f); return x; } }
+        if (b.size() > 4 && b.compare(b.size() - 4, 4, ".bam") == 0) { FILE* f = fopen((b.substr(0, b.size() - 4) + ".bai").c_str(), "rb"); if (f) { fclose(f); return x; } }
+        delete x; return 0;
+    }
     if (!x->idx.load(fn)) { delete x; return 0; }
     return x;
 }
@@ -334,9 +495,17 @@ extern "C" int samfetch(samfile_t* fp, const hts_idx_t* idx, int tid, int beg, i
     if (!ensure_open(fp)) return -1;
     bam1_t b; memset(&b, 0, sizeof b);
     auto cb = [&](const brcio::BamRecord& r) { to_bam1(r, &b); func(&b, data); };
-    bool ok;
+    bool ok = true;
     if (fp->file->is_cram) ok = fp->file->cram->fetch(tid, beg, end, cb);
-    else ok = fp->file->bam.fetch(idx->idx, tid, beg, end, cb);
+    else if (product_reader()) ok = fp->file->bam.fetch(idx->idx, tid, beg, end, cb);
+    else fp->file->ibam.fetch(tid, beg < 0 ? 0 : beg, end, [&](const IndepRec& r) {
+        memset(&b.core, 0, sizeof b.core);
+        b.core.pos = r.pos; b.core.tid = r.tid; b.core.bin = r.bin; b.core.qual = r.mapq; b.core.flag = r.flag;
+        b.core.l_qname = (uint16_t)r.l_qname; b.core.n_cigar = r.n_cigar; b.core.l_qseq = r.l_seq; b.core.mtid = r.mtid; b.core.mpos = r.mpos; b.core.isize = r.tlen;
+        if (b.m_data < r.data.size() + 64) { b.m_data = (uint32_t)r.data.size() + 64; b.data = (uint8_t*)realloc(b.data, b.m_data); }
+        memcpy(b.data, r.data.data(), r.data.size()); b.l_data = (int)r.data.size();
+        func(&b, data);
+    });
     free(b.data);
     return ok ? 0 : -1;
 }
@@ -483,13 +652,13 @@ extern "C" sam_hdr_t* sam_hdr_parse(size_t l_text, const char* text) {
 /* ---------------------------------------------------------------- faidx */
 extern "C" faidx_t* fai_load(const char* fn) {
     faidx_shim_t* f = new faidx_shim_t();
-    if (!f->fa.open(fn)) { delete f; return 0; }
+    if (product_reader() ? !f->fa.open(fn) : !f->ifa.open(fn)) { delete f; return 0; }
     return f;
 }
 extern "C" void fai_destroy(faidx_t* fai) { delete fai; }
 extern "C" char* fai_fetch(const faidx_t* fai, const char* reg, int* len) {
     std::string seq;
-    if (!const_cast<faidx_shim_t*>(fai)->fa.fetch(reg, &seq)) { *len = -2; return 0; }
+    if (product_reader() ? !const_cast<faidx_shim_t*>(fai)->fa.fetch(reg, &seq) : !fai->ifa.fetch(reg, &seq)) { *len = -2; return 0; }
     char* s = (char*)malloc(seq.size() + 1);
     memcpy(s, seq.data(), seq.size()); s[seq.size()] = 0;
     *len = (int)seq.size();
