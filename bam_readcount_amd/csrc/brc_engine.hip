@@ -6,7 +6,7 @@
 //   k_annotate_groups  K1: fetch_func's Zm integers per read (8 bases per lane, byte-parallel), the event-word stream
 //                   (quality << 8 | bucket per base) and the read's PIECES (walk_pieces): 48-B records (+ a 32-B rare record for the few that need one) in
 //                   library-major slots; also writes each read's indel events to its slots of the raw event list and counts
-//                   them per (tile, library) bucket
+//                   them per (16 positions, library) bucket
 //   k_unavail       -p only: first library-less read of every column (those positions are abandoned, :281-284)
 //   k_scan_*        3-phase scans: running max of piece reaches per library (tile lower bounds), exclusive sum of
 //                   indel-event counts (per-bucket offsets)
@@ -17,7 +17,7 @@
 //                   coalesced 256-B plane stores.  Integer/byte work, HBM-bound: no MFMA by design.
 //   k_xev_compact   the 1024 third-allele sub-lists (one atomic cursor each) -> one list
 //   k_finalize      emitted-position count + per-tile partial counters
-//   k_indel_scatter / k_indel_reduce   indel side path (<1 % of events), sparse: raw events -> (tile, library) buckets,
+//   k_indel_scatter / k_indel_reduce   indel side path (<1 % of events), sparse: raw events -> (16 positions, library) buckets,
 //                   one lane per bucket sorts by (position, library, read) and folds every key in column order
 //   k_text_len / k_text_write   BRC_OPT_DEVICE_TEXT: the lines pileup_func prints, written from the compact result
 //                   (brc_core.h: text_line): byte lengths -> exclusive scan -> bytes
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
     }
     if (ev_raw && n_idp) {
         // indel events of this read (bamreadcount.cpp:315-342), written to the read's own slots of the raw list (the host
-        // counted one slot per I / D / P operator: no cursor, no atomics on the list) and counted per (tile, library) bucket;
+        // counted one slot per I / D / P operator: no cursor, no atomics on the list) and counted per (IBUCKET positions, library) bucket;
         // slots the read does not use are marked empty
         const int lib = (int)((r.misc >> 16) & 0xffu) - 1;
         IndelEv* slot = ev_raw + in.iev_off[my]; uint32_t used = 0;
@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(256) void k_text_write(DevCfg c, DevIn in, Planes p
     (void)text_line(c, in, pl, t, k, text + off[k]);
 }
 
-// raw indel events (K1: one slot per I / D / P operator, unused ones marked NONE32) -> their (tile, library) buckets;
+// raw indel events (K1: one slot per I / D / P operator, unused ones marked NONE32) -> their (IBUCKET positions, library) buckets;
 // cursor[] holds the buckets' start offsets (exclusive scan of K1's counts) and ends up at their ends
 __global__ __launch_bounds__(256) void k_indel_scatter(DevCfg c, const IndelEv* __restrict__ raw, int64_t n_raw, uint32_t* __restrict__ cursor,
                                                        IndelEv* __restrict__ ev) {
@@ -1346,8 +1346,8 @@ class HipBackend : public Backend {
         in.iev_off = nullptr;
         if (n_indel_cap) {
             // indel side path: raw events (one slot per I / D / P operator, at host-computed per-read offsets), their counts
-            // per (tile, library) bucket, the bucketed events and the reduced alleles
-            const size_t nbk = (size_t)ntiles * Lp;
+            // per (IBUCKET positions, library) bucket, the bucketed events and the reduced alleles
+            const size_t nbk = (size_t)indel_buckets(c);
             if ((rc = up(d_ievoff, s.iev_off, n))) return rc;
             in.iev_off = (const uint32_t*)d_ievoff.p;
             HIPCHK(d_cnt.ensure(nbk * 4 + 16)); HIPCHK(d_cursor.ensure(nbk * 4 + 16)); HIPCHK(d_evraw.ensure((n_indel_cap + 1) * sizeof(IndelEv)));
@@ -1380,7 +1380,7 @@ class HipBackend : public Backend {
         HIPCHK(hipMemsetAsync(ctr, 0, sizeof(Counters), stream));
         HIPCHK(hipMemsetAsync(d_xevn.p, 0, (size_t)XEV_SHARDS * XEV_CTR_STRIDE * 4, stream));
         const bool indels = n_indel_cap > 0 && P > 0 && n > 0;
-        const int64_t n_buckets = ntiles * Lp;          // indel buckets: (tile, library)
+        const int64_t n_buckets = indel_buckets(c);     // indel buckets: (IBUCKET positions, library)
         if (indels) HIPCHK(hipMemsetAsync(d_cnt.p, 0, (size_t)n_buckets * 4, stream));
         Planes pl = {(uint32_t*)d_ncol.p, (uint32_t*)d_depth.p, (uint32_t*)d_slotid.p, (uint32_t*)d_si.p, (float*)d_sf.p, (uint32_t*)d_unavail.p,
                      (XEv*)d_xev.p, (uint32_t*)d_xevn.p, (uint32_t)xev_cap, (uint32_t)XEV_SHARDS};
@@ -1590,10 +1590,10 @@ class HipBackend : public Backend {
 };
 
 Backend* make_backend(const brc_config& cfg, int* errc) {
-    // Engines are created one at a time, process-wide: the command line creates its engines on worker threads, and the first
-    // calls into the HIP runtime (device initialisation, code-object load at the first launch) from several threads at once
-    // crashed a run in a dozen on the GPU boxes (SIGSEGV before the first line of output).  The later, per-engine work
-    // (streams, uploads, launches) runs concurrently as before.
+    // Engines are created one at a time, process-wide: the first calls into the HIP runtime (device initialisation, code-object
+    // load at the first launch) need not meet each other on several threads.  The later, per-engine work (streams, uploads,
+    // launches) runs concurrently.  (Callers: the HIP runtime reads the environment while it starts — never setenv() in a
+    // process that is creating an engine; see BRC_OPT_FORMAT_THREADS.)
     static std::mutex create_mu;
     std::lock_guard<std::mutex> create_lock(create_mu);
     HipBackend* b = new (std::nothrow) HipBackend();

@@ -251,6 +251,7 @@ struct brc_engine {
     Staged st;
     Geometry g;
     int state = 0;   // 0 idle, 1 region open, 2 uploaded, 3 computed, 4 fetched
+    unsigned format_threads = 0;   // BRC_OPT_FORMAT_THREADS (0: effective_cpus())
     std::string err;
     // bam_plp_push max-count emulation
     int64_t accepted = 0, n_ext = 0; int32_t last_acc_pos = 0; int32_t last_pos = 0;
@@ -352,6 +353,7 @@ int brc_set_option(brc_engine* e, int option, int64_t value) {
         case BRC_OPT_EXPECT_BASES: e->hint_bases = value > 0 ? (size_t)std::min<int64_t>(value, (int64_t)1 << 36) : 0; return BRC_OK;
         case BRC_OPT_DEVICE_TEXT: e->device_text = value != 0; return BRC_OK;
         case BRC_OPT_CONTINUES_PREVIOUS: e->continues = value == 1; e->warn_skip_lead = value == 1 || value == 2; return BRC_OK;
+        case BRC_OPT_FORMAT_THREADS: e->format_threads = value > 0 ? (unsigned)std::min<int64_t>(value, 1024) : 0u; return BRC_OK;
         case BRC_OPT_MAX_COUNT: if (value < INT32_MIN || value > INT32_MAX) return fail(e, BRC_E_ARG, "max count out of range"); e->cfg.max_cnt = (int32_t)value; return BRC_OK;
         case BRC_OPT_EXPECT_TEXT: { if (value <= 0) return BRC_OK; const int rc = e->be->reserve_text((size_t)value); return rc ? fail(e, rc, e->be->last_error()) : BRC_OK; }
         default: return fail(e, BRC_E_ARG, "unknown engine option");
@@ -965,7 +967,8 @@ static int format_chunks(brc_engine* e, const brc_result* r, const char* chrom, 
     if (r->ncol == NULL) return fail(e, BRC_E_ARG, "this result carries device text only");
     if (r->istat == NULL && (!e->text_only || r->ncol != e->hp.ncol)) return fail(e, BRC_E_ARG, "a text-only result can only be formatted before the next download");
     unsigned nthr = effective_cpus(); if (nthr > 64) nthr = 64;
-    if (const char* t = getenv("BRC_FORMAT_THREADS")) { const int v = atoi(t); if (v > 0) nthr = (unsigned)v; }
+    if (e->format_threads) nthr = e->format_threads;
+    if (const char* t = getenv("BRC_FORMAT_THREADS")) { const int v = atoi(t); if (v > 0) nthr = (unsigned)v; }   // (test knob: wins over the option)
     // about four chunks per thread, 2048 .. 65536 positions each (a 1-Mbp piece in 64-Ki chunks keeps only 15 threads busy)
     int64_t CH = P / (4 * (int64_t)nthr);
     if (CH < 2048) CH = 2048;

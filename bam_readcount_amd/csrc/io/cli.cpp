@@ -193,6 +193,7 @@ static double now_s() { return std::chrono::duration<double>(std::chrono::steady
 // CPUs this process may really use at once: hardware threads capped by a cgroup CPU quota (a container with 16 CPUs of
 // quota on a 256-thread host is throttled for most of every period if its pools are sized by the hardware)
 static unsigned g_engines = 1;            // engines of this process (they share the CPUs)
+static std::atomic<unsigned> g_format_threads{0};   // formatter threads per engine when several engines share the process (0: the engine's default)
 static unsigned effective_cpus() {
     static unsigned cached = 0;
     if (cached) return cached;
@@ -708,6 +709,7 @@ static int make_engine(Ctx& c, int device) {
     cfg.ref_len_check = (!o.site_list.empty() && c.have_fa) ? 1 : 0;                                                                        // :594-600
     const int rc = brc_create(&cfg, &c.eng);
     if (rc == 0) brc_set_option(c.eng, BRC_OPT_TEXT_ONLY, 1);      // the command line only prints: no dense planes on the host
+    if (rc == 0 && g_format_threads.load()) brc_set_option(c.eng, BRC_OPT_FORMAT_THREADS, (int64_t)g_format_threads.load());
     if (rc == 0 && o.max_cnt <= 0) brc_set_option(c.eng, BRC_OPT_MAX_COUNT, o.max_cnt);   // -d 0 / -d -3 reach the iterator as they are (:592,:651)
     return rc;
 }
@@ -715,6 +717,7 @@ static int make_engine(Ctx& c, int device) {
 // A crash must not be silent: frames of the faulting thread (module + offset: `addr2line -e <module> <offset>` resolves
 // them) go to stderr before the default action takes the process down.
 #include <execinfo.h>
+#include <fcntl.h>
 #include <signal.h>
 static void crash_handler(int sig) {
     void* frames[64];
@@ -722,6 +725,11 @@ static void crash_handler(int sig) {
     static const char msg[] = "bam-readcount: fatal signal, backtrace of the faulting thread:\n";
     if (write(2, msg, sizeof msg - 1) < 0) {}
     backtrace_symbols_fd(frames, n, 2);
+    if (const char* dir = getenv("BRC_CRASH_DIR")) {       // (test harnesses: the same frames into a file of their own)
+        char path[512]; snprintf(path, sizeof path, "%s/brc_crash_%d.txt", dir, (int)getpid());
+        const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fd >= 0) { backtrace_symbols_fd(frames, n, fd); close(fd); }
+    }
     signal(sig, SIG_DFL); raise(sig);
 }
 
@@ -767,6 +775,8 @@ int main(int argc, char** argv) {
     auto wait_engine = [&]() -> bool {
         const int r = eng_ready.get();
         if (r && !eng_reported) { eng_reported = true; fprintf(stderr, "bam-readcount: cannot create the MI355X engine: %s\n", brc_strerror(r)); }
+        // (engine 0 was created before the number of engines was known)
+        if (r == 0 && g_format_threads.load()) brc_set_option(c.eng, BRC_OPT_FORMAT_THREADS, (int64_t)g_format_threads.load());
         return r == 0;
     };
     c.need_engine = wait_engine;
@@ -849,7 +859,10 @@ int main(int argc, char** argv) {
     if (items.size() < N) N = std::max<size_t>(items.size(), 1);      // engines without work are never created
     if (N > 1) {    // the engines share this process's CPUs: each gets its part of the decode and formatter pools
         g_engines = (unsigned)N;
-        if (!getenv("BRC_FORMAT_THREADS")) { const unsigned ft = std::max(2u, effective_cpus() / (unsigned)N); setenv("BRC_FORMAT_THREADS", std::to_string(ft).c_str(), 1); }
+        // (told to every engine with BRC_OPT_FORMAT_THREADS in make_engine — never through setenv(): the engine-creation
+        // threads are inside the HIP runtime by now, which reads the environment while it starts, and getenv() racing a
+        // setenv() that reallocates `environ` was a rare SIGSEGV before the first line of output)
+        g_format_threads = std::max(2u, effective_cpus() / (unsigned)N);
     }
     // pin the text buffers of a long region's pieces while the first reads are being decoded
     std::thread pin_ahead;

@@ -217,6 +217,11 @@ void brc_destroy(brc_engine*);
  *   treats values <= 0 as "the default"; the reference hands them to the iterator, whose drop rule `count > maxcnt` then holds
  *   for every read that starts where the previous one did.  Set before the next region's reads are pushed. */
 #define BRC_OPT_MAX_COUNT 7
+/*   BRC_OPT_FORMAT_THREADS  threads of this engine's host formatter pool (0: its share of the CPUs the process may use, the
+ *                      default).  A caller that runs several engines in one process divides the CPUs among them with this
+ *                      option — not through the environment: setenv() in a process whose other threads are inside the HIP
+ *                      runtime (which reads the environment while it starts) is a data race. */
+#define BRC_OPT_FORMAT_THREADS 8
 int  brc_set_option(brc_engine*, int option, int64_t value);
 /* Target name printed in column 1 of the following regions' lines (BRC_OPT_DEVICE_TEXT: the text is written at
  * brc_fetch_result time, before brc_format_region names the contig); copied. */

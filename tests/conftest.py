@@ -12,6 +12,7 @@ os.environ.setdefault("BRC_DEVICE_TEXT_MAX_SHARE", "100")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))       # synthgen, bamio, cramio (test / bench infrastructure)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 

@@ -181,7 +181,7 @@ class SimBackend : public Backend {
         // reduce_indel_bucket per bucket
         iout.clear();
         if (c.has_ref && P > 0 && n > 0) {
-            const int64_t nbk = ntiles * Lp;
+            const int64_t nbk = indel_buckets(c);
             std::vector<IndelEv> raw((size_t)st->n_indel_ops + 1);
             std::vector<uint32_t> cnt((size_t)nbk + 1, 0), off((size_t)nbk + 1, 0);
             for (int64_t i = 0; i < n; ++i) {
