@@ -65,6 +65,7 @@ struct DevCfg {
     int64_t n_reads;
     int32_t table_len;      // L0: modal read length of the region (host); reads with l_qseq == clipped == L0 take their terms from tables
     int32_t variant;        // 0 in production; >0 = profiling ablations selected by BRC_PILEUP_VARIANT (see brc_engine.hip)
+    int32_t ibucket_shift;  // log2 of the positions per indel bucket (indel_bucket_shift)
     int32_t ann_variant;    // 0 in production; >0 = profiling ablations of K1 selected by BRC_ANN_VARIANT (wrong results, timing only)
     int32_t force_dom;      // test knob (BRC_FORCE_DOM): -1, or the bucket every lane treats as dominant (stresses the alternate / third-allele paths)
     int64_t n_pieces;       // pieces of all libraries (KB v2)
@@ -793,7 +794,7 @@ BRC_HD int fold_indel_key(const DevCfg& c, const DevIn& in, const DRead* reads, 
     return na;
 }
 
-// The indel side path works on BUCKETS of events: bucket = (IBUCKET consecutive positions, library), the events of a region's reads
+// The indel side path works on BUCKETS of events: bucket = (16 or 64 consecutive positions, library), the events of a region's reads
 // scattered into them in any order (k_indel_scatter).  One lane reduces one bucket: sort by (key, read), fold every key's
 // run into out[run start ..] (one slot per event: a key's alleles take the first na slots of its run, the others get
 // len = 0), skipping the keys of positions abandoned for a library-less read (bamreadcount.cpp:281-284).
@@ -812,11 +813,14 @@ BRC_HD void reduce_indel_bucket(const DevCfg& c, const DevIn& in, const DRead* r
     }
 }
 // bucket of an event: (tile of the plane index, library); from a key (= plane index * Lp + library) with 32-bit divisions
-enum { IBUCKET = 16 };          // positions per indel bucket: small buckets = many short per-lane sorts instead of a few long ones (200x, 10 % indel reads)
-BRC_HD int64_t indel_buckets(const DevCfg& c) { return ((c.P + IBUCKET - 1) / IBUCKET) * c.Lp; }
-BRC_HD uint32_t indel_bucket_of(const DevCfg& c, uint32_t k, uint32_t lib) { return (k / (uint32_t)IBUCKET) * (uint32_t)c.Lp + lib; }
+// positions per indel bucket = 1 << DevCfg.ibucket_shift, chosen per region (indel_bucket_shift): 64 where events are sparse
+// (30x: one bucket in four holds an event — fewer buckets to scan), 16 where they are dense (200x with 10 % indel reads: many
+// short per-lane sorts instead of a few long ones)
+BRC_HD int32_t indel_bucket_shift(uint64_t n_indel_ops, int64_t P, int Lp) { return (P > 0 && n_indel_ops * 64ull >= (uint64_t)P * (uint64_t)Lp) ? 4 : 6; }
+BRC_HD int64_t indel_buckets(const DevCfg& c) { return ((c.P + ((int64_t)1 << c.ibucket_shift) - 1) >> c.ibucket_shift) * c.Lp; }
+BRC_HD uint32_t indel_bucket_of(const DevCfg& c, uint32_t k, uint32_t lib) { return (k >> c.ibucket_shift) * (uint32_t)c.Lp + lib; }
 BRC_HD uint32_t indel_bucket(const DevCfg& c, uint32_t key) {
-    if (c.Lp == 1) return key / (uint32_t)IBUCKET;
+    if (c.Lp == 1) return key >> c.ibucket_shift;
     const uint32_t k = key / (uint32_t)c.Lp;
     return indel_bucket_of(c, k, key - k * (uint32_t)c.Lp);
 }

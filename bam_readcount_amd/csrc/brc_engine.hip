@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
     }
     if (ev_raw && n_idp) {
         // indel events of this read (bamreadcount.cpp:315-342), written to the read's own slots of the raw list (the host
-        // counted one slot per I / D / P operator: no cursor, no atomics on the list) and counted per (IBUCKET positions, library) bucket;
+        // counted one slot per I / D / P operator: no cursor, no atomics on the list) and counted per (16 or 64 positions, library) bucket;
         // slots the read does not use are marked empty
         const int lib = (int)((r.misc >> 16) & 0xffu) - 1;
         IndelEv* slot = ev_raw + in.iev_off[my]; uint32_t used = 0;
@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(256) void k_text_write(DevCfg c, DevIn in, Planes p
     (void)text_line(c, in, pl, t, k, text + off[k]);
 }
 
-// raw indel events (K1: one slot per I / D / P operator, unused ones marked NONE32) -> their (IBUCKET positions, library) buckets;
+// raw indel events (K1: one slot per I / D / P operator, unused ones marked NONE32) -> their (16 or 64 positions, library) buckets;
 // cursor[] holds the buckets' start offsets (exclusive scan of K1's counts) and ends up at their ends
 __global__ __launch_bounds__(256) void k_indel_scatter(DevCfg c, const IndelEv* __restrict__ raw, int64_t n_raw, uint32_t* __restrict__ cursor,
                                                        IndelEv* __restrict__ ev) {
@@ -1291,6 +1291,7 @@ class HipBackend : public Backend {
         c.beg0 = g.beg0; c.end = g.end; c.pos0 = g.pos0; c.P = g.P; c.PS = g.PS; c.ref_lo = g.ref_lo; c.ref_hi = g.ref_hi; c.ref_len = g.ref_len;
         c.n_reads = s.n; c.table_len = getenv("BRC_NO_TABLE") ? 0 : s.modal_len();
         c.n_pieces = s.n_pieces; lib_base = s.lib_base;
+        c.ibucket_shift = getenv("BRC_IBUCKET_SHIFT") ? atoi(getenv("BRC_IBUCKET_SHIFT")) : indel_bucket_shift(s.n_indel_ops, c.P, c.Lp);   // (the knob: tests run both sizes)
         // test knobs (tests/test_gpu_parity.py): small K -> flushes, small limit -> PF_HUGE, forced dominant bucket -> third alleles
         choose_pack(s.max_lqseq, getenv("BRC_FLUSH_K") ? atoi(getenv("BRC_FLUSH_K")) : 0, getenv("BRC_PACK_LIM") ? atoi(getenv("BRC_PACK_LIM")) : 0, c.flush_k, c.pack_lim);
         c.force_dom = getenv("BRC_FORCE_DOM") ? atoi(getenv("BRC_FORCE_DOM")) : -1;
@@ -1346,7 +1347,7 @@ class HipBackend : public Backend {
         in.iev_off = nullptr;
         if (n_indel_cap) {
             // indel side path: raw events (one slot per I / D / P operator, at host-computed per-read offsets), their counts
-            // per (IBUCKET positions, library) bucket, the bucketed events and the reduced alleles
+            // per (16 or 64 positions, library) bucket, the bucketed events and the reduced alleles
             const size_t nbk = (size_t)indel_buckets(c);
             if ((rc = up(d_ievoff, s.iev_off, n))) return rc;
             in.iev_off = (const uint32_t*)d_ievoff.p;
@@ -1380,7 +1381,7 @@ class HipBackend : public Backend {
         HIPCHK(hipMemsetAsync(ctr, 0, sizeof(Counters), stream));
         HIPCHK(hipMemsetAsync(d_xevn.p, 0, (size_t)XEV_SHARDS * XEV_CTR_STRIDE * 4, stream));
         const bool indels = n_indel_cap > 0 && P > 0 && n > 0;
-        const int64_t n_buckets = indel_buckets(c);     // indel buckets: (IBUCKET positions, library)
+        const int64_t n_buckets = indel_buckets(c);     // indel buckets: (16 or 64 positions, library)
         if (indels) HIPCHK(hipMemsetAsync(d_cnt.p, 0, (size_t)n_buckets * 4, stream));
         Planes pl = {(uint32_t*)d_ncol.p, (uint32_t*)d_depth.p, (uint32_t*)d_slotid.p, (uint32_t*)d_si.p, (float*)d_sf.p, (uint32_t*)d_unavail.p,
                      (XEv*)d_xev.p, (uint32_t*)d_xevn.p, (uint32_t)xev_cap, (uint32_t)XEV_SHARDS};

@@ -41,6 +41,7 @@ class SimBackend : public Backend {
         c.beg0 = g.beg0; c.end = g.end; c.pos0 = g.pos0; c.P = g.P; c.PS = g.PS; c.ref_lo = g.ref_lo; c.ref_hi = g.ref_hi; c.ref_len = g.ref_len;
         c.n_reads = s.n; c.table_len = getenv("BRC_NO_TABLE") ? 0 : s.modal_len(); c.n_pieces = s.n_pieces;
         c.force_dom = getenv("BRC_FORCE_DOM") ? atoi(getenv("BRC_FORCE_DOM")) : -1;
+        c.ibucket_shift = getenv("BRC_IBUCKET_SHIFT") ? atoi(getenv("BRC_IBUCKET_SHIFT")) : indel_bucket_shift(s.n_indel_ops, c.P, c.Lp);
         choose_pack(s.max_lqseq, getenv("BRC_FLUSH_K") ? atoi(getenv("BRC_FLUSH_K")) : 0, getenv("BRC_PACK_LIM") ? atoi(getenv("BRC_PACK_LIM")) : 0, c.flush_k, c.pack_lim);
         tq.assign((size_t)TABLE_MAX + 2, 0.0f); te.assign((size_t)TABLE_MAX + 2, 0.0);
         for (int k = 0; k <= c.table_len; ++k) { tq[(size_t)k] = (float)k / (float)c.table_len; te[(size_t)k] = 1.0 - (double)tq[(size_t)k]; }

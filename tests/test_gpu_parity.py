@@ -195,8 +195,11 @@ def test_hip_device_text_equals_oracle_on_every_fuzz_family(dev_lib, oracle_lib,
         assert got == want, clear
 
 
-def test_hip_deep_indel_key_equals_oracle(dev_lib, oracle_lib):
-    """k_indel_reduce with hundreds (and, at 6000 reads, thousands) of events on one (position, library) key."""
+@pytest.mark.parametrize("shift", ["4", "6", "0"])
+def test_hip_deep_indel_key_equals_oracle(dev_lib, oracle_lib, monkeypatch, shift):
+    """k_indel_reduce with hundreds (and, at 6000 reads, thousands) of events on one (position, library) key; every bucket size
+    the engine chooses from (16 / 64 positions) and single-position buckets."""
+    monkeypatch.setenv("BRC_IBUCKET_SHIFT", shift)
     rng = np.random.default_rng(41)
     ref = synth.make_ref(rng, 600)
     for n in (700, 6000):
