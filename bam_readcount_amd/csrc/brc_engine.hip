@@ -185,8 +185,10 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
     const unsigned long long work = __ballot(work_me);
     const int nd = __builtin_popcountll(work);                               // dense reads of this wave
     const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(work >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)work, 0u));
-    const uint64_t qbase = __builtin_amdgcn_readfirstlane((uint32_t)qoff) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(qoff >> 32)) << 32);
-    const uint64_t sbase = __builtin_amdgcn_readfirstlane((uint32_t)soff) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(soff >> 32)) << 32);
+    // (readfirstlane returns int: without the uint32_t casts a low half with bit 31 set sign-extends into the high half — arenas
+    // beyond 2 GB then read 4 GB below their rows; tests/test_gpu_parity.py::test_hip_arena_offsets_beyond_2_gib)
+    const uint64_t qbase = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)qoff) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(qoff >> 32)) << 32);
+    const uint64_t sbase = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)soff) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(soff >> 32)) << 32);
     uint32_t T = 0;
     if (c.ann_variant == 5) return;
     if (nd) {

@@ -174,9 +174,9 @@ def main():
 
     total_len = int(args.contig_mbp * 1e6)
     contig_len = total_len // world if args.mode == "strong" else total_len
-    if args.mode == "strong" and contig_len > 12_500_000 and not args.allow_large:
-        # (one rank would stage 200x over %d Mbp: tens of GB of pinned host memory and minutes of set-up; measured here: the
-        # per-GPU shape of the 8-GPU configuration, 6.25 Mbp)
+    if args.mode == "strong" and contig_len > 50_000_000 and not args.allow_large:
+        # (BASELINE config 5 itself — 50 Mbp at 200x, 67 M reads, 21 GB of pinned staging, 80 GB of HBM — runs on one GPU in
+        # 13 s all told, 36 ms per step; anything larger wants --allow-large)
         raise SystemExit("--mode strong with %d rank(s) puts %.1f Mbp of 200x data (%.0f M reads) on one GPU: use --gpus 4 / 8, a smaller --contig-mbp "
                          "(6.25 = the per-GPU shape of BASELINE config 5), or --allow-large" % (world, contig_len / 1e6, contig_len * 200 / 150 / 1e6))
     t0 = time.time()
@@ -412,9 +412,12 @@ def main():
             eng.close(); eng = None                              # (the sub-processes get the GPU and the host memory to themselves)
             other = {}
             subs = {"config4_sites": ["--mode", "sites"],
-                    "config5_per_gpu_shape": ["--mode", "strong", "--contig-mbp", "6.25"]}
+                    "config5_per_gpu_shape": ["--mode", "strong", "--contig-mbp", "6.25"],
+                    # config 5 whole on ONE GPU (50 Mbp, 200x, 4 libraries: 67 M reads, 10 G events per step); validated by event
+                    # conservation only — the oracle check of this data model is the per-GPU shape's
+                    "config5_full_one_gpu": ["--mode", "strong", "--contig-mbp", "50", "--cpu-sample-mbp", "0", "--steps", "10", "--warmup", "2"]}
             for key, extra in subs.items():
-                cmd = [sys.executable, os.path.abspath(__file__)] + extra + ["--steps", "60", "--warmup", "5", "--cpu-all-cores", "0", "--cpu-ref-mbp", "0", "--e2e-mbp", "0", "--other-configs", "0"]
+                cmd = [sys.executable, os.path.abspath(__file__), "--steps", "60", "--warmup", "5", "--cpu-all-cores", "0", "--cpu-ref-mbp", "0", "--e2e-mbp", "0", "--other-configs", "0"] + extra
                 try:
                     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
                     sub = json.loads([l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1])

@@ -219,3 +219,31 @@ def test_hip_sequenceless_secondary_read(dev_lib, oracle_lib):
         text, _ = parity.compare_libs(dev_lib, oracle_lib, arrs, [(0, 600)], ref=ref, **kw)
         got, _ = parity.run_engine(dev_lib, arrs, [(0, 600)], ref=ref, device_text="chrS", **kw)
         assert got == text and b"\t421\t" in text
+
+
+def test_hip_arena_offsets_beyond_2_gib(dev_lib, oracle_lib):
+    """Offsets into the QUAL / SEQ arenas of a batch are 64-bit (include/brc.h): a region of more than 14 M 150-bp reads has
+    rows beyond 2 GiB, one of more than 28 M beyond 4 GiB.  A few hundred reads whose rows sit around the 2^31 and 2^32 marks of
+    (mostly empty) arenas: K1 assembles wave-uniform 64-bit bases from two 32-bit halves — a sign-extended low half read 4 GiB
+    below the rows until round 3 (silently wrong, or a memory fault once the arenas pass 4 GiB)."""
+    rng = np.random.default_rng(23)
+    ref = synth.make_ref(rng, 4000)
+    arrs = synth.make_batch(123, ref, 600, style="mixed", read_len=(100, 150))
+    n = len(arrs["pos"])
+    big = {k: v for k, v in arrs.items()}
+    # row i of the new arenas: the first third below 2^31, the second third straddling and above it, the last third above 2^32
+    marks = np.where(np.arange(n) < n // 3, (1 << 31) - 40_000, np.where(np.arange(n) < 2 * n // 3, (1 << 31) - 600, (1 << 32) - 300)).astype(np.int64)
+    qlen = arrs["l_qseq"].astype(np.int64); slen = (qlen + 1) // 2
+    # consecutive rows inside each third (arena order = read order, as a reader would lay them out)
+    qoff = np.zeros(n, np.int64); soff = np.zeros(n, np.int64)
+    for third in (slice(0, n // 3), slice(n // 3, 2 * n // 3), slice(2 * n // 3, n)):
+        qoff[third] = marks[third] + np.concatenate([[0], np.cumsum(qlen[third])[:-1]])
+        soff[third] = marks[third] + np.concatenate([[0], np.cumsum(slen[third])[:-1]])
+    qual = np.zeros(int(qoff[-1] + qlen[-1]) + 64, np.uint8); seq4 = np.zeros(int(soff[-1] + slen[-1]) + 64, np.uint8)
+    for i in range(n):
+        o = int(arrs["qual_off"][i]); qual[qoff[i]:qoff[i] + qlen[i]] = arrs["qual"][o:o + qlen[i]]
+        o = int(arrs["seq_off"][i]); seq4[soff[i]:soff[i] + slen[i]] = arrs["seq4"][o:o + slen[i]]
+    big["qual"] = qual; big["seq4"] = seq4; big["qual_off"] = qoff.astype(np.uint64); big["seq_off"] = soff.astype(np.uint64)
+    want, _ = parity.run_engine(oracle_lib, arrs, [(0, 4000)], ref=ref, min_mapq=5, min_bq=10)          # (the small arenas: the oracle's answer)
+    got, res = parity.run_engine(dev_lib, big, [(0, 4000)], ref=ref, min_mapq=5, min_bq=10)
+    assert got == want and want.count(b"\n") > 3000
