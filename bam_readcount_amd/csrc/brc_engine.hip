@@ -8,9 +8,10 @@
 //                   library-major slots; also writes each read's indel events to its slots of the raw event list and counts
 //                   them per (16 positions, library) bucket
 //   k_unavail       -p only: first library-less read of every column (those positions are abandoned, :281-284)
-//   k_scan_*        3-phase scans: running max of piece reaches per library (tile lower bounds), exclusive sum of
-//                   indel-event counts (per-bucket offsets)
-//   k_tiles         [lo,hi) piece range of every 64-position tile of a library, one coalesced pass over its pieces
+//   k_reach_blockmax / k_scan_aggregates / k_tiles_all   [lo,hi) piece range of every (64-position tile, library): running
+//                   maximum of the piece reaches (library << 32 | reach: one scan for all libraries), then one coalesced
+//                   pass over the pieces — piece r owns the tiles whose lo is r and those whose hi is r + 1
+//   k_scan_*        3-phase exclusive sum of the indel-event counts (per-bucket offsets), of the text line lengths
 //   k_pileup2       THE hot kernel: one wave per (tile, library), lane == reference position, wave-uniform walk over the
 //                   tile's pieces in column order: piece records by scalar loads, event-word windows staged into LDS by
 //                   direct-to-LDS loads, three packed integer accumulators + 4 order-preserving fp32 sums per bucket,
@@ -128,7 +129,7 @@ __device__ __forceinline__ uint32_t nzb7(uint32_t x) { return x + 0x7f7f7f7fu; }
 #define BRC_ANN_OCC
 #endif
 __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, DevIn in, DRead* __restrict__ reads, const uint32_t* __restrict__ piece_off,
-                                                         Piece* __restrict__ pieces, PieceRare* __restrict__ rare, int32_t* __restrict__ key, int32_t* __restrict__ reach,
+                                                         Piece* __restrict__ pieces, PieceRare* __restrict__ rare, int2* __restrict__ keyreach,
                                                          uint16_t* __restrict__ bq, IndelEv* __restrict__ ev_raw, uint32_t* __restrict__ bucket_cnt,
                                                          const uint32_t* __restrict__ cigar_ro, const uint8_t* __restrict__ qual_ro,
                                                          const uint8_t* __restrict__ seq_ro, const uint8_t* __restrict__ refcode) {
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
         walk_pieces(c.insertion_centric != 0, enters && !nolib, rc.counts, pos, cigar_ro + coff, nc, [&](int32_t rs, int32_t len, int32_t ext, int qoff, bool nb) {
             Piece h; PieceRare rr;
             make_piece(c, rc, rs, len, ext, qoff, nb, h, rr);
-            if (c.ann_variant != 2) { pieces[slot] = h; if (piece_has_rare(piece_flags(h))) rare[slot] = rr; key[slot] = pos; reach[slot] = rs + ext; }
+            if (c.ann_variant != 2) { pieces[slot] = h; if (piece_has_rare(piece_flags(h))) rare[slot] = rr; keyreach[slot] = make_int2(pos, rs + ext); }
             ++slot;
         });
     }
@@ -455,7 +456,6 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
 
 enum { SCAN_T = 256, SCAN_ITEMS = 16, SCAN_CHUNK = SCAN_T * SCAN_ITEMS };
 
-struct OpMaxI32 { typedef int32_t T; static __device__ __forceinline__ T id() { return INT32_MIN; } static __device__ __forceinline__ T op(T a, T b) { return a > b ? a : b; } };
 struct OpSumU32 { typedef uint32_t T; static __device__ __forceinline__ T id() { return 0u; } static __device__ __forceinline__ T op(T a, T b) { return a + b; } };
 
 template <class Op>
@@ -576,29 +576,106 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_apply(const typename Op::T* __r
 // (key[r] <= p1 < key[r+1]) — usually none or one of each; the last piece also covers the tiles past the data.
 __device__ __forceinline__ int64_t tiles_ceil_div64(int64_t x) { return x <= 0 ? 0 : (x + (TILE - 1)) / TILE; }
 
-__global__ __launch_bounds__(256) void k_tiles(DevCfg c, const int32_t* __restrict__ prefmax, const int32_t* __restrict__ key,
-                                               int64_t s0, int64_t n, int64_t ntiles, uint2* __restrict__ rng) {
-    // piece stream [s0, s0 + n) of one library; prefmax = running max of the pieces' reaches inside the stream, key = start
-    // of each piece's read (non-decreasing); rng = this library's row of tile ranges (absolute piece indices)
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    prefmax += s0; key += s0;
-    uint32_t* out = reinterpret_cast<uint32_t*>(rng);
-    // lo: tiles t with prefmax[r-1] <= p0(t) < prefmax[r]
-    {
-        int64_t t0 = r ? tiles_ceil_div64((int64_t)prefmax[r - 1] - c.pos0) : 0;
-        int64_t t1 = tiles_ceil_div64((int64_t)prefmax[r] - c.pos0);
-        if (t1 > ntiles) t1 = ntiles;
-        for (int64_t t = t0; t < t1; ++t) out[2 * t] = (uint32_t)(s0 + r);
-        if (r == n - 1) for (int64_t t = t1 > t0 ? t1 : t0; t < ntiles; ++t) out[2 * t] = (uint32_t)(s0 + n);
+// All libraries in three launches (reduce, scan of the block aggregates, k_tiles_all), without materialising the running maxima.  The piece streams are library-major, so the library of a piece
+// never decreases along the array: the running maximum of (library << 32 | reach) IS the running maximum of the reaches
+// inside the current library (anything from an earlier library is smaller).  keyreach[m] = {start of the piece's read, reach}.
+struct OpMaxU64 { typedef unsigned long long T; static __device__ __forceinline__ T id() { return 0ull; } static __device__ __forceinline__ T op(T a, T b) { return a > b ? a : b; } };
+enum { TR_T = 256, TR_ITEMS = 4, TR_CHUNK = TR_T * TR_ITEMS };    // a thread owns 4 consecutive pieces (two 16-byte loads), a block 1024
+__device__ __forceinline__ int lib_of_slot(const int64_t* __restrict__ lib_base, int Lp, int64_t r, int l) { while (l + 1 < Lp && r >= lib_base[l + 1]) ++l; return l; }
+__device__ __forceinline__ unsigned long long shfl_up_u64(unsigned long long v, int d) {
+    return ((unsigned long long)(uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, 64) << 32) | (uint32_t)__shfl_up((int)(uint32_t)v, d, 64);
+}
+// the thread's 4 {key, reach} pairs (+ the next piece's key), zero past the end
+__device__ __forceinline__ void load_keyreach4(const int2* __restrict__ keyreach, int64_t b, int64_t n, int2 (&kr)[TR_ITEMS + 1]) {
+    if (b + TR_ITEMS <= n) {
+        const uint4 x = *reinterpret_cast<const uint4*>(keyreach + b), y = *reinterpret_cast<const uint4*>(keyreach + b + 2);
+        kr[0] = make_int2((int)x.x, (int)x.y); kr[1] = make_int2((int)x.z, (int)x.w); kr[2] = make_int2((int)y.x, (int)y.y); kr[3] = make_int2((int)y.z, (int)y.w);
+    } else {
+#pragma unroll
+        for (int j = 0; j < TR_ITEMS; ++j) kr[j] = b + j < n ? keyreach[b + j] : make_int2(0, 0);
     }
-    // hi: tiles t with key[r] <= p1(t) < key[r+1]      (p1(t) >= x  <=>  t >= ceil((x - pos0 - 63) / 64))
+    kr[TR_ITEMS] = b + TR_ITEMS < n ? keyreach[b + TR_ITEMS] : make_int2(0, 0);
+}
+
+__global__ __launch_bounds__(TR_T) void k_reach_blockmax(const int2* __restrict__ keyreach, int64_t n, const int64_t* __restrict__ lib_base, int Lp,
+                                                         unsigned long long* __restrict__ agg) {
+    __shared__ unsigned long long sh[TR_T / 64];
+    const int64_t b = (int64_t)blockIdx.x * TR_CHUNK + (int64_t)threadIdx.x * TR_ITEMS;
+    unsigned long long v = 0ull;
+    if (b < n) {
+        int2 kr[TR_ITEMS + 1]; load_keyreach4(keyreach, b, n, kr);
+        int l = lib_of_slot(lib_base, Lp, b, 0);
+#pragma unroll
+        for (int j = 0; j < TR_ITEMS; ++j) if (b + j < n) {
+            l = lib_of_slot(lib_base, Lp, b + j, l);
+            const unsigned long long x = ((unsigned long long)(uint32_t)l << 32) | (uint32_t)kr[j].y;                 // (reaches are positions: non-negative)
+            v = x > v ? x : v;
+        }
+    }
+    v = block_reduce<OpMaxU64>(v, sh);
+    if (threadIdx.x == 0) agg[blockIdx.x] = v;
+}
+
+__global__ __launch_bounds__(TR_T) void k_tiles_all(DevCfg c, const int2* __restrict__ keyreach, int64_t n, const int64_t* __restrict__ lib_base, int Lp,
+                                                    const unsigned long long* __restrict__ agg, int64_t ntiles, uint2* __restrict__ rng) {
+    __shared__ unsigned long long sh[TR_T / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t b = (int64_t)blockIdx.x * TR_CHUNK + (int64_t)threadIdx.x * TR_ITEMS;
+    int2 kr[TR_ITEMS + 1]; int lib[TR_ITEMS];
+    load_keyreach4(keyreach, b, n, kr);
+    unsigned long long tot = 0ull;
     {
-        int64_t t0 = tiles_ceil_div64((int64_t)key[r] - c.pos0 - (TILE - 1));
-        int64_t t1 = r + 1 < n ? tiles_ceil_div64((int64_t)key[r + 1] - c.pos0 - (TILE - 1)) : ntiles;
-        if (t1 > ntiles) t1 = ntiles;
-        if (r == 0) for (int64_t t = 0; t < t0 && t < ntiles; ++t) out[2 * t + 1] = (uint32_t)s0;
-        for (int64_t t = t0; t < t1; ++t) out[2 * t + 1] = (uint32_t)(s0 + r + 1);
+        int l = b < n ? lib_of_slot(lib_base, Lp, b, 0) : 0;
+#pragma unroll
+        for (int j = 0; j < TR_ITEMS; ++j) {
+            if (b + j < n) {
+                l = lib_of_slot(lib_base, Lp, b + j, l);
+                const unsigned long long x = ((unsigned long long)(uint32_t)l << 32) | (uint32_t)kr[j].y;
+                tot = x > tot ? x : tot;
+            }
+            lib[j] = l;
+        }
+    }
+    // exclusive running maximum in front of this thread's first piece: the blocks before (agg, already scanned), the waves
+    // of this block before, the lanes of this wave before
+    unsigned long long incl = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long u = shfl_up_u64(incl, d); if (lane >= d && u > incl) incl = u; }
+    if (lane == 63) sh[wv] = incl;
+    __syncthreads();
+    unsigned long long run = agg[blockIdx.x];
+    for (int w = 0; w < wv; ++w) { const unsigned long long u = sh[w]; run = u > run ? u : run; }
+    { const unsigned long long u = shfl_up_u64(incl, 1); if (lane && u > run) run = u; }
+    uint32_t* out = reinterpret_cast<uint32_t*>(rng);
+#pragma unroll
+    for (int j = 0; j < TR_ITEMS; ++j) {
+        const int64_t r = b + j;
+        if (r >= n) break;
+        const int l = lib[j];
+        const int64_t s0 = lib_base[l], s1 = lib_base[l + 1];
+        uint32_t* row = out + 2 * (int64_t)l * ntiles;
+        const unsigned long long x = ((unsigned long long)(uint32_t)l << 32) | (uint32_t)kr[j].y;
+        // lo: tiles t with prefmax[r-1] <= p0(t) < prefmax[r]   (no earlier piece in this library: from tile 0)
+        {
+            const bool have_prev = (int)(run >> 32) == l && r > s0;
+            const int64_t prev = have_prev ? (int64_t)(int32_t)(uint32_t)run : INT32_MIN;
+            const unsigned long long cur64 = x > run ? x : run;
+            const int64_t cur = (int64_t)(int32_t)(uint32_t)cur64;
+            int64_t t0 = have_prev ? tiles_ceil_div64(prev - c.pos0) : 0;
+            int64_t t1 = tiles_ceil_div64(cur - c.pos0);
+            if (t1 > ntiles) t1 = ntiles;
+            for (int64_t t = t0; t < t1; ++t) row[2 * t] = (uint32_t)r;
+            if (r == s1 - 1) for (int64_t t = t1 > t0 ? t1 : t0; t < ntiles; ++t) row[2 * t] = (uint32_t)s1;
+            run = cur64;
+        }
+        // hi: tiles t with key[r] <= p1(t) < key[r+1]      (p1(t) >= x  <=>  t >= ceil((x - pos0 - 63) / 64))
+        {
+            int64_t t0 = tiles_ceil_div64((int64_t)kr[j].x - c.pos0 - (TILE - 1));
+            int64_t t1 = r + 1 < s1 ? tiles_ceil_div64((int64_t)kr[j + 1].x - c.pos0 - (TILE - 1)) : ntiles;
+            if (t1 > ntiles) t1 = ntiles;
+            if (r == s0) for (int64_t t = 0; t < t0 && t < ntiles; ++t) row[2 * t + 1] = (uint32_t)s0;
+            for (int64_t t = t0; t < t1; ++t) row[2 * t + 1] = (uint32_t)(r + 1);
+        }
     }
 }
 
@@ -1212,7 +1289,7 @@ class HipBackend : public Backend {
     std::vector<int64_t> lib_base;      // first piece of every library's stream (Lp + 1 entries)
     // device buffers
     DBuf d_pos, d_flag, d_mapq, d_lib, d_lq, d_nc, d_co, d_so, d_qo, d_nm, d_sm, d_tags, d_cigar, d_seq, d_qual, d_ref, d_refcode;
-    DBuf d_bq, d_bqrow, d_pieceoff, d_pieces, d_rare, d_key, d_reach, d_reads, d_prefmax, d_agg, d_rng, d_ncol, d_depth, d_slotid, d_si, d_sf, d_xev, d_xevc, d_xevn, d_unavail, d_cnt, d_cursor, d_ev, d_evraw, d_ievoff, d_iout, d_ctr, d_tilectr, d_part;
+    DBuf d_bq, d_bqrow, d_pieceoff, d_pieces, d_rare, d_keyreach, d_libbase, d_reads, d_agg, d_rng, d_ncol, d_depth, d_slotid, d_si, d_sf, d_xev, d_xevc, d_xevn, d_unavail, d_cnt, d_cursor, d_ev, d_evraw, d_ievoff, d_iout, d_ctr, d_tilectr, d_part;
     DBuf d_tlen, d_toff, d_text, d_tctx;
     // device-side text, downloaded (pinned) on its own stream into one of two host buffers
     HBuf<char> h_text[2]; HBuf<uint32_t> h_toff[2]; HBuf<uint32_t> h_total;
@@ -1259,7 +1336,7 @@ class HipBackend : public Backend {
     ~HipBackend() override {
         (void)hipSetDevice(device);
         DBuf* all[] = {&d_pos, &d_flag, &d_mapq, &d_lib, &d_lq, &d_nc, &d_co, &d_so, &d_qo, &d_nm, &d_sm, &d_tags, &d_cigar, &d_seq, &d_qual,
-                       &d_ref, &d_refcode, &d_bq, &d_bqrow, &d_pieceoff, &d_pieces, &d_rare, &d_key, &d_reach, &d_reads, &d_prefmax, &d_agg, &d_rng, &d_ncol, &d_depth, &d_slotid, &d_si, &d_sf, &d_xev, &d_xevc, &d_xevn, &d_unavail, &d_cnt,
+                       &d_ref, &d_refcode, &d_bq, &d_bqrow, &d_pieceoff, &d_pieces, &d_rare, &d_keyreach, &d_libbase, &d_reads, &d_agg, &d_rng, &d_ncol, &d_depth, &d_slotid, &d_si, &d_sf, &d_xev, &d_xevc, &d_xevn, &d_unavail, &d_cnt,
                        &d_cursor, &d_ev, &d_evraw, &d_ievoff, &d_iout, &d_ctr, &d_tilectr, &d_part, &d_tlen, &d_toff, &d_text, &d_tctx};
         for (DBuf* b : all) b->release();
         for (int i = 0; i < 2; ++i) { h_text[i].destroy(); h_toff[i].destroy(); if (ev_text[i]) (void)hipEventDestroy(ev_text[i]); }
@@ -1324,15 +1401,17 @@ class HipBackend : public Backend {
         in.rcp = nullptr;
         const size_t np = (size_t)c.n_pieces;
         HIPCHK(d_pieces.ensure((np + 4) * sizeof(Piece))); HIPCHK(d_rare.ensure((np + 2) * sizeof(PieceRare)));      // (the read loop requests records up to two past the last)
-        HIPCHK(d_key.ensure((np + 16) * 4)); HIPCHK(d_reach.ensure((np + 16) * 4));
+        HIPCHK(d_keyreach.ensure((np + 16) * sizeof(int2)));
+        HIPCHK(d_libbase.ensure((lib_base.size() + 1) * sizeof(int64_t)));
+        if (!lib_base.empty()) HIPCHK(hipMemcpyAsync(d_libbase.p, lib_base.data(), lib_base.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
         // outputs / scratch
         const size_t P = (size_t)c.PS, Lp = (size_t)c.Lp;   // allocation sizes use the padded stride
         ntiles = (c.P + TILE - 1) / TILE;
         n_indel_cap = c.has_ref ? s.n_indel_ops : 0;
         if (n_indel_cap && ((uint64_t)c.P * (uint64_t)c.Lp >= 0xffffffffull || n_indel_cap >= 0xfffffff0ull)) { err = "region too large: (positions x libraries) and the indel operators must stay below 2^32"; return BRC_E_ARG; }
-        const size_t nagg = std::max<size_t>((std::max<size_t>(np, P * Lp) + SCAN_CHUNK - 1) / SCAN_CHUNK, 1);
-        HIPCHK(d_reads.ensure((n + 1) * sizeof(DRead))); HIPCHK(d_prefmax.ensure((np + 16) * 4));
-        HIPCHK(d_agg.ensure(nagg * 4 + 16)); HIPCHK(d_agg2.ensure(nagg * 4 + 16)); HIPCHK(d_rng.ensure(((size_t)ntiles * Lp + 1) * sizeof(uint2)));
+        const size_t nagg = std::max<size_t>(std::max<size_t>((std::max<size_t>(np, P * Lp) + SCAN_CHUNK - 1) / SCAN_CHUNK, (np + TR_CHUNK - 1) / TR_CHUNK), 1);
+        HIPCHK(d_reads.ensure((n + 1) * sizeof(DRead)));
+        HIPCHK(d_agg.ensure(nagg * 8 + 16)); HIPCHK(d_agg2.ensure(nagg * 4 + 16)); HIPCHK(d_rng.ensure(((size_t)ntiles * Lp + 1) * sizeof(uint2)));
         HIPCHK(d_ncol.ensure(Lp * P * 4 + 16)); HIPCHK(d_depth.ensure(Lp * P * 4 + 16)); HIPCHK(d_unavail.ensure(P * 4 + 16));
         HIPCHK(d_slotid.ensure(Lp * P * 4 + 16)); HIPCHK(d_si.ensure(Lp * 2 * NI * P * 4 + 16)); HIPCHK(d_sf.ensure(Lp * 2 * NF * P * 4 + 16));
         // third-allele lists: XEV_SHARDS sub-lists; about one piece in 25 leaves an event at 30-50x, capacity for twice that,
@@ -1395,7 +1474,7 @@ class HipBackend : public Backend {
             if (c.has_ref)
                 hipLaunchKernelGGL(k_refcode, dim3((unsigned)(((rl + 2 * REFCODE_PAD + 15) / 16 + 255) / 256)), dim3(256), 0, stream, in.ref, (uint8_t*)d_refcode.p, rl);
             hipLaunchKernelGGL(k_annotate_groups, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (const uint32_t*)d_pieceoff.p,
-                               (Piece*)d_pieces.p, (PieceRare*)d_rare.p, (int32_t*)d_key.p, (int32_t*)d_reach.p,
+                               (Piece*)d_pieces.p, (PieceRare*)d_rare.p, (int2*)d_keyreach.p,
                                (uint16_t*)in.bq, indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p,
                                in.cigar, in.qual, in.seq4, (const uint8_t*)d_refcode.p + REFCODE_PAD);
             if (c.per_lib) {
@@ -1427,18 +1506,20 @@ class HipBackend : public Backend {
             HIPCHK(hipStreamWaitEvent(stream3, evt[T_SCAN_ENDS], 0));
             if ((rc = launch_indel(stream3, d_agg2))) return rc;
         }
-        // per library: running max of the piece reaches of its stream, then the piece range of every tile
-        for (int l = 0; l < Lp; ++l) {
-            const int64_t s0 = lib_base[(size_t)l], ns = lib_base[(size_t)l + 1] - s0;
-            if ((rc = scan<OpMaxI32, true>((const int32_t*)d_reach.p + s0, (int32_t*)d_prefmax.p + s0, ns))) return rc;
+        // the piece range of every (tile, library): running maximum of the piece reaches (block aggregates, their scan), then
+        // one pass over the pieces of all libraries
+        const int64_t np_all = c.n_pieces;
+        const int64_t trb = (np_all + TR_CHUNK - 1) / TR_CHUNK;
+        if (np_all > 0 && ntiles > 0) {
+            hipLaunchKernelGGL(k_reach_blockmax, dim3((unsigned)trb), dim3(TR_T), 0, stream, (const int2*)d_keyreach.p, np_all, (const int64_t*)d_libbase.p, Lp, (unsigned long long*)d_agg.p);
+            hipLaunchKernelGGL((k_scan_aggregates<OpMaxU64>), dim3(1), dim3(1024), 0, stream, (unsigned long long*)d_agg.p, trb);
         }
         HIPCHK(hipEventRecord(evt[T_TILES], stream));
-        for (int l = 0; l < Lp && ntiles > 0; ++l) {
-            const int64_t s0 = lib_base[(size_t)l], ns = lib_base[(size_t)l + 1] - s0;
-            uint2* row = (uint2*)d_rng.p + (int64_t)l * ntiles;
-            if (ns == 0) HIPCHK(hipMemsetAsync(row, 0, (size_t)ntiles * sizeof(uint2), stream));
-            else hipLaunchKernelGGL(k_tiles, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, c, (const int32_t*)d_prefmax.p, (const int32_t*)d_key.p, s0, ns, ntiles, row);
-        }
+        for (int l = 0; l < Lp && ntiles > 0; ++l)        // (a library without pieces: empty ranges)
+            if (lib_base[(size_t)l + 1] == lib_base[(size_t)l]) HIPCHK(hipMemsetAsync((uint2*)d_rng.p + (int64_t)l * ntiles, 0, (size_t)ntiles * sizeof(uint2), stream));
+        if (np_all > 0 && ntiles > 0)
+            hipLaunchKernelGGL(k_tiles_all, dim3((unsigned)trb), dim3(TR_T), 0, stream, c, (const int2*)d_keyreach.p, np_all, (const int64_t*)d_libbase.p, Lp,
+                               (const unsigned long long*)d_agg.p, ntiles, (uint2*)d_rng.p);
         HIPCHK(hipEventRecord(evt[T_PILEUP], stream));
         if (ntiles > 0) {
             unsigned nwg = (unsigned)((ntiles + PILEUP_WAVES - 1) / PILEUP_WAVES);
