@@ -584,6 +584,36 @@ def test_pending_deletion_blocks_the_queue_like_the_reference_gpu(hip_lib, ref_l
             assert got == want, (kw, route)
 
 
+def random_scenario(seed, big=False):
+    """One scenario of the engine-level differential fuzz (also driven from tools/gpu_soak.py with other seeds; big: deeper
+    piles and longer reads, so that flushes of the packed registers and many half-batches per tile happen without knobs)."""
+    rng = np.random.default_rng(seed)
+    RL = int(rng.integers(400, 2500))
+    ref = synth.make_ref(rng, RL + (1400 if big else 600), weird=float(rng.choice([0, 0, 0.02])))
+    n_libs = int(rng.choice([1, 1, 2, 3]))
+    style = str(rng.choice(["simple", "indel", "wild", "mixed"]))
+    n_reads = int(rng.integers(50, 700)) if not big else int(rng.integers(2000, 9000))
+    max_len = int(rng.integers(40, 160)) if not big else int(rng.integers(100, 900))
+    arrs = synth.make_batch(seed + 1000, ref, n_reads, style=style, n_libs=n_libs, p_nolib=float(rng.choice([0, 0, 0.05])),
+                            read_len=(20, max_len), region=(0, RL))
+    if rng.random() < 0.4:
+        arrs = synth.pile_indels(arrs, int(rng.integers(50, RL - 50)), seed=seed, frac=0.5)
+    regions = []
+    for _ in range(int(rng.integers(1, 7))):
+        a = int(rng.integers(0, RL)); b = a + int(rng.choice([0, 1, 2, 17, 200, RL]))
+        regions.append((a, min(b, RL + 100)))
+    if rng.random() < 0.3:
+        regions.append((regions[0][1], regions[0][1] + 50))
+    per_lib = bool(rng.random() < 0.4)
+    kw = dict(min_mapq=int(rng.choice([0, 0, 10, 30])), min_bq=int(rng.choice([0, 0, 13, 25])), insertion_centric=bool(rng.random() < 0.4))
+    if rng.random() < 0.15:
+        kw["max_cnt"] = int(rng.choice([1, 3, 10]))
+    if per_lib:
+        kw.update(per_lib=True, lib_names=["lib%c" % (65 + i) for i in range(n_libs)])
+    clear = bool(rng.random() < 0.5)
+    return ref, arrs, regions, kw, clear, style
+
+
 @pytest.mark.parametrize("block", range(4))
 def test_random_scenarios_equal_reference_compiled(oracle_lib, sim_lib, ref_lib, block):
     """Differential fuzz against the reference's own code: random data styles, libraries, option sets (-q -b -i -p -d), lists of
@@ -592,28 +622,7 @@ def test_random_scenarios_equal_reference_compiled(oracle_lib, sim_lib, ref_lib,
     reference-compiled library prints.  (The reference string is longer than any read reaches: past its end the reference
     reads out of bounds, see DESIGN.md.)"""
     for seed in range(block * 12, block * 12 + 12):
-        rng = np.random.default_rng(seed)
-        RL = int(rng.integers(400, 2500))
-        ref = synth.make_ref(rng, RL + 600, weird=float(rng.choice([0, 0, 0.02])))
-        n_libs = int(rng.choice([1, 1, 2, 3]))
-        style = str(rng.choice(["simple", "indel", "wild", "mixed"]))
-        arrs = synth.make_batch(seed + 1000, ref, int(rng.integers(50, 700)), style=style, n_libs=n_libs, p_nolib=float(rng.choice([0, 0, 0.05])),
-                                read_len=(20, int(rng.integers(40, 160))), region=(0, RL))
-        if rng.random() < 0.4:
-            arrs = synth.pile_indels(arrs, int(rng.integers(50, RL - 50)), seed=seed, frac=0.5)
-        regions = []
-        for _ in range(int(rng.integers(1, 7))):
-            a = int(rng.integers(0, RL)); b = a + int(rng.choice([0, 1, 2, 17, 200, RL]))
-            regions.append((a, min(b, RL + 100)))
-        if rng.random() < 0.3:
-            regions.append((regions[0][1], regions[0][1] + 50))
-        per_lib = bool(rng.random() < 0.4)
-        kw = dict(min_mapq=int(rng.choice([0, 0, 10, 30])), min_bq=int(rng.choice([0, 0, 13, 25])), insertion_centric=bool(rng.random() < 0.4))
-        if rng.random() < 0.15:
-            kw["max_cnt"] = int(rng.choice([1, 3, 10]))
-        if per_lib:
-            kw.update(per_lib=True, lib_names=["lib%c" % (65 + i) for i in range(n_libs)])
-        clear = bool(rng.random() < 0.5)
+        ref, arrs, regions, kw, clear, style = random_scenario(seed)
         want, _ = parity.run_engine(ref_lib, arrs, regions, ref=ref, clear_queue=clear, **kw)
         for lib, route in ((oracle_lib, {}), (sim_lib, {}), (sim_lib, dict(text_only=True)), (sim_lib, dict(device_text="chrS"))):
             got, _ = parity.run_engine(lib, arrs, regions, ref=ref, clear_queue=clear, **route, **kw)
