@@ -102,3 +102,46 @@ def test_an_unsound_build_is_refused():
     if r.returncode == 1:
         m = subprocess.run(["make", "-s", "-B", "-n", "-C", os.path.join(ROOT, "bam_readcount_amd", "csrc"), "brc_engine.o", "EXTRA=-DBRC_WAVES_PER_EU=8"], stdout=subprocess.PIPE)
         assert b"check_isa.py" in m.stdout          # the gate is part of the object's recipe
+
+
+def test_isa_checker_follows_every_path():
+    """The checker itself, on hand-written instruction lists: a register of an early load touched on the fall-through path, on
+    a branch target only, inside a loop body, and not at all."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_isa
+
+    def errors(text):
+        ins, labels = check_isa.parse(text.strip("\n").split("\n"))
+        return check_isa.check_loads(ins, labels)
+
+    sound = """
+	;;#ASMSTART
+	s_load_dwordx8 s[56:63], s[4:5], 0x0
+	s_load_dwordx2 s[64:65], s[4:5], 0x20
+	;;#ASMEND
+	s_add_u32 s4, s4, 48
+	v_add_u32_e32 v1, s70, v2
+	s_cbranch_scc1 .LBB9_2
+	v_mov_b32_e32 v3, s71
+.LBB9_2:
+	;;#ASMSTART
+	s_waitcnt lgkmcnt(0)
+	;;#ASMEND
+	v_add_u32_e32 v1, s56, v2
+	s_endpgm
+"""
+    n, errs = errors(sound)
+    assert n == 2 and errs == []
+    # a copy of a register in flight on the fall-through path
+    n, errs = errors(sound.replace("v_mov_b32_e32 v3, s71", "s_mov_b64 s[36:37], s[58:59]"))
+    assert len(errs) == 1 and "s_mov_b64" in errs[0] and "[58, 59]" in errs[0]
+    # ... only behind a taken branch (an out-of-line block that rejoins before the wait)
+    far = sound.replace("s_cbranch_scc1 .LBB9_2", "s_cbranch_scc1 .LBB9_7").replace("	s_endpgm", "	s_endpgm\n.LBB9_7:\n	v_writelane_b32 v62, s64, 3\n	s_branch .LBB9_2")
+    n, errs = errors(far)
+    assert len(errs) == 1 and "v_writelane_b32" in errs[0]
+    # ... a second load into the same set before the first one's wait
+    n, errs = errors(sound.replace("s_add_u32 s4, s4, 48", ";;#ASMSTART\n	s_load_dwordx8 s[56:63], s[4:5], 0x30\n	;;#ASMEND"))
+    assert any("s_load_dwordx8 s[56:63], s[4:5], 0x30" in e for e in errs)
+    # ... a path that never waits
+    n, errs = errors(sound.replace("	;;#ASMSTART\n	s_waitcnt lgkmcnt(0)\n	;;#ASMEND\n", ""))
+    assert any("s_endpgm" in e or "touched" in e for e in errs)
