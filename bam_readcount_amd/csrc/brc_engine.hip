@@ -128,6 +128,7 @@ __device__ __forceinline__ uint32_t nzb7(uint32_t x) { return x + 0x7f7f7f7fu; }
 #else
 #define BRC_ANN_OCC
 #endif
+template <bool one_stream>     // the event-word rows and the pieces of consecutive reads are consecutive in memory (no per-library layout)
 __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, DevIn in, DRead* __restrict__ reads, const uint32_t* __restrict__ piece_off,
                                                          Piece* __restrict__ pieces, PieceRare* __restrict__ rare, int2* __restrict__ keyreach,
                                                          uint16_t* __restrict__ bq, IndelEv* __restrict__ ev_raw, uint32_t* __restrict__ bucket_cnt,
@@ -314,7 +315,13 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
                 uint4 out;
                 out.x = __builtin_amdgcn_perm(Bk.x, Q.x, 0x01050004u); out.y = __builtin_amdgcn_perm(Bk.x, Q.x, 0x03070206u);
                 out.z = __builtin_amdgcn_perm(Bk.y, Q.y, 0x01050004u); out.w = __builtin_amdgcn_perm(Bk.y, Q.y, 0x03070206u);
-                __builtin_memcpy(bq + ((((uint64_t)P.c.w) << 32) | (uint64_t)P.a.w) + (uint32_t)b, &out, 16);
+                // (rows are 16-byte aligned; written once here, read by k_pileup2 a kernel later.  With ONE stream of rows — no
+                // per-library layout — the wave's stores run on through memory and the non-temporal hint pays: K1 -5 %, and -8 %
+                // with the piece records likewise; with four library-major streams it costs 2-8 %: measured, profiles/r03_ab_09)
+                typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+                u32x4s* dst = reinterpret_cast<u32x4s*>(bq + ((((uint64_t)P.c.w) << 32) | (uint64_t)P.a.w) + (uint32_t)b);
+                const u32x4s val = {out.x, out.y, out.z, out.w};
+                if (one_stream) __builtin_nontemporal_store(val, dst); else *dst = val;
             }
             if (nul & 0x80808080u) atomicOr(&W.redo[jr], 1u);                           // a NUL reference character under an M base
             // ---- mismatch qualities
@@ -434,7 +441,14 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
         walk_pieces(c.insertion_centric != 0, enters && !nolib, rc.counts, pos, cigar_ro + coff, nc, [&](int32_t rs, int32_t len, int32_t ext, int qoff, bool nb) {
             Piece h; PieceRare rr;
             make_piece(c, rc, rs, len, ext, qoff, nb, h, rr);
-            if (c.ann_variant != 2) { pieces[slot] = h; if (piece_has_rare(piece_flags(h))) rare[slot] = rr; keyreach[slot] = make_int2(pos, rs + ext); }
+            if (c.ann_variant != 2) {
+                typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+                const u32x4s* hs = reinterpret_cast<const u32x4s*>(&h); u32x4s* hd = reinterpret_cast<u32x4s*>(pieces + slot);
+                if (one_stream) { __builtin_nontemporal_store(hs[0], hd); __builtin_nontemporal_store(hs[1], hd + 1); __builtin_nontemporal_store(hs[2], hd + 2); }
+                else pieces[slot] = h;
+                if (piece_has_rare(piece_flags(h))) rare[slot] = rr;
+                keyreach[slot] = make_int2(pos, rs + ext);
+            }
             ++slot;
         });
     }
@@ -1473,10 +1487,17 @@ class HipBackend : public Backend {
             const int64_t rl = c.ref_hi - c.ref_lo;
             if (c.has_ref)
                 hipLaunchKernelGGL(k_refcode, dim3((unsigned)(((rl + 2 * REFCODE_PAD + 15) / 16 + 255) / 256)), dim3(256), 0, stream, in.ref, (uint8_t*)d_refcode.p, rl);
-            hipLaunchKernelGGL(k_annotate_groups, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (const uint32_t*)d_pieceoff.p,
-                               (Piece*)d_pieces.p, (PieceRare*)d_rare.p, (int2*)d_keyreach.p,
-                               (uint16_t*)in.bq, indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p,
-                               in.cigar, in.qual, in.seq4, (const uint8_t*)d_refcode.p + REFCODE_PAD);
+            if (Lp == 1) {
+                hipLaunchKernelGGL((k_annotate_groups<true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (const uint32_t*)d_pieceoff.p,
+                                   (Piece*)d_pieces.p, (PieceRare*)d_rare.p, (int2*)d_keyreach.p,
+                                   (uint16_t*)in.bq, indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p,
+                                   in.cigar, in.qual, in.seq4, (const uint8_t*)d_refcode.p + REFCODE_PAD);
+            } else {
+                hipLaunchKernelGGL((k_annotate_groups<false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (const uint32_t*)d_pieceoff.p,
+                                   (Piece*)d_pieces.p, (PieceRare*)d_rare.p, (int2*)d_keyreach.p,
+                                   (uint16_t*)in.bq, indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p,
+                                   in.cigar, in.qual, in.seq4, (const uint8_t*)d_refcode.p + REFCODE_PAD);
+            }
             if (c.per_lib) {
                 HIPCHK(hipMemsetAsync(d_unavail.p, 0xff, (size_t)c.PS * 4, stream));
                 hipLaunchKernelGGL(k_unavail, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (uint32_t*)d_unavail.p);
