@@ -241,7 +241,8 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
             const uint32_t G = base + (uint32_t)lane;
             const uint4 Pa = W.par[F.jr].a, Pb = W.par[F.jr].b;
             F.b = G < T ? (int32_t)((G - Pb.x) << 3) : 0;               // idle lanes of the last pass stay inside their read
-            // (wave-uniform base + 32-bit lane offset: the scalar-base addressing form, no 64-bit vector arithmetic)
+            // (wave-uniform base + 32-bit lane offset: the scalar-base addressing form, no 64-bit vector arithmetic.  Non-temporal
+            // LOADS of QUAL / SEQ — read exactly once — were measured: K1 +6 %)
             __builtin_memcpy(&F.Q, qwave + (uint32_t)(Pa.y + (uint32_t)F.b), 8);
             __builtin_memcpy(&F.S, swave + (uint32_t)(Pa.z + ((uint32_t)F.b >> 1)), 4);
             // reference codes under the first M operator (a window outside the slice: any in-bounds window, its bytes are masked)
@@ -1080,7 +1081,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         const int64_t P = c.PS;
         const int64_t tb = tile * TILE;                                    // (scalar) plane index of lane 0
         const uint32_t loff = (uint32_t)lane_e << 2;
-#define BRC_ST(base, val) asm volatile("global_store_dword %0, %1, %2" :: "v"(loff), "v"(val), "s"(base) : "memory")
+#define BRC_ST(base, val) asm volatile("global_store_dword %0, %1, %2 nt" :: "v"(loff), "v"(val), "s"(base) : "memory")   /* (written once per step, read by nobody on the device: streaming) */
         const uint32_t sid = a.dom_b | (a.alt_b << 8);
         { const uint32_t* q = pl.ncol + (int64_t)lib * P + tb; BRC_ST(q, a.ncol); }       // (dead lanes accumulated nothing: zeros)
         { const uint32_t* q = pl.depth + (int64_t)lib * P + tb; BRC_ST(q, a.depth); }
