@@ -336,7 +336,10 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
             const unsigned long long any_mm = __ballot(has_mm);
             uint32_t t_out = 0u;                                              // maximum of the run still open at the lane's last base
             if (any_mm) {
-                const unsigned long long hard = __ballot(has_mm && (nbits > 1 || link || bit7));
+                // a mismatch on a group's last base is part of a longer run only if the NEXT lane links to it (lane 63: the next
+                // pass decides): anything else stands alone (30 % of the passes took the lane-serial walk for that bit alone)
+                const int nlink = lane_shl1(link ? 1 : 0);
+                const unsigned long long hard = __ballot(has_mm && (nbits > 1 || link || (bit7 && (lane == 63 || nlink != 0))));
                 if (!hard) {
                     // every mismatch stands alone inside its group: its quality is the run maximum
                     if (has_mm) {
@@ -365,7 +368,6 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
                     }
                     uint32_t pt = (uint32_t)lane_shr1((int)t);
                     if (lane == 0) pt = carry_t;
-                    const int nlink = lane_shl1(link ? 1 : 0);       // does the next lane continue my tail run?
                     uint32_t add = 0u; { bool open = link; uint32_t cur = link ? pt : 0u;
                         _Pragma("unroll") for (int k = 0; k < 8; ++k) { const bool m = (m64 >> (8 * k + 7)) & 1ull; const uint32_t qv = (uint32_t)(q64 >> (8 * k)) & 0xffu;
                             if (m) { cur = open ? (cur > qv ? cur : qv) : qv; open = true; } else { if (open) add += cur; open = false; } }
@@ -747,6 +749,9 @@ struct PRec { u32x8 f; u32x2 g; };
 //    planes every K pieces (K = 127 for short reads) and at the end of the tile;
 //  * third alleles (a lane keeps its reference base and the first other base in registers) and PF_HUGE integers are
 //    queued and drained into the planes between half-batches, in piece order.
+#ifndef BRC_EXP
+#define BRC_EXP 0               // compile-time experiments of tools/experiments/README.md (0 = the product)
+#endif
 #ifndef BRC_WAVES_PER_EU
 #define BRC_WAVES_PER_EU 7      // 72 VGPRs: 16 values spill into the rare paths (measured: 6 waves 3.92 ms, 7 waves 3.78 ms, 8 waves 5.6 ms — spills reach the loop)
 #endif
@@ -887,17 +892,52 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
             const uint32_t off = (uint32_t)(roff) + 2u * ((uint32_t)S.s_c & 7u);                                          \
             S.w = (uint32_t)*reinterpret_cast<const uint16_t*>(rows_base + (((uint32_t)lane << 1) + off));                                  \
             const uint32_t s_c16 = (uint32_t)S.s_c << 4;                                      /* (scalar) */              \
+            if (BRC_EXP == 2) { S.t = 0.5f; S.sev = 0.25; } else {     /* (2: timing only, no table look-ups) */                 \
             S.t = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds.q16) + sad_u32(lane16b, (uint32_t)LBIAS + ((R.f[3] & 0xffffffu) << 2) - s_c16)); \
-            S.sev = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds.e) + sad_u32(lane16b, (uint32_t)LBIAS + (L0 << 3) - s_c16)); \
+            S.sev = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds.e) + sad_u32(lane16b, (uint32_t)LBIAS + (L0 << 3) - s_c16)); } \
         }
+        // the 10 adds of the dominant bucket, in the lanes of m_dom
+#if BRC_EXP == 5
+        // (experiment: ONE assembly statement, accumulators updated in place under an exec mask set and restored inside it)
+#define BRC_DOM_REGION(R, S, m_dom, tq2, ts3p, tsev)                                                                    \
+                {                                                                                                         \
+                    double dtmp; uint64_t sv;                                                                             \
+                    asm("s_and_saveexec_b64 %[sv], %[m]\n\t"                                                              \
+                        "v_add_u32_e32 %[w1], %[a1], %[w1]\n\tv_add_u32_e32 %[w2], %[a2], %[w2]\n\tv_add_u32_e32 %[w3], %[a3], %[w3]\n\t" \
+                        "v_add_u32_e32 %[sw], %[w], %[sw]\n\t"                                                            \
+                        "v_add_f32_e32 %[q2], %[q2], %[tq]\n\tv_add_f32_e32 %[s3], %[s3], %[t3]\n\t"                       \
+                        "v_cvt_f64_f32_e32 %[tmp], %[sev]\n\tv_add_f64 %[tmp], %[tmp], %[ts]\n\tv_cvt_f32_f64_e32 %[sev], %[tmp]\n\t" \
+                        "v_add_f32_e32 %[snm], %[an], %[snm]\n\tv_add_u32_e32 %[ww], %[aw], %[ww]\n\t"                      \
+                        "s_mov_b64 exec, %[sv]"                                                                           \
+                        : [w1] "+v"(a.dom.w1), [w2] "+v"(a.dom.w2), [w3] "+v"(a.dom.w3), [sw] "+v"(a.dom.sw),           \
+                          [q2] "+v"(a.dom.f[F_SQ2]), [s3] "+v"(a.dom.f[F_S3P]), [sev] "+v"(a.dom.f[F_SEV]), [snm] "+v"(a.dom.f[F_SNM]), \
+                          [ww] "+v"(a.ww), [tmp] "=&v"(dtmp), [sv] "=&s"(sv)                                             \
+                        : [m] "s"(m_dom), [a1] "s"(R.f[4]), [a2] "s"(R.f[5]), [a3] "s"(R.f[6]), [an] "s"(R.f[7]), [aw] "s"(R.g[0]), \
+                          [w] "v"(S.w), [tq] "v"(tq2), [t3] "v"(ts3p), [ts] "v"(tsev) : "scc");                          \
+                }
+#else
+#define BRC_DOM_REGION(R, S, m_dom, tq2, ts3p, tsev)                                                                    \
+                if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(m_dom), 1)) {                                    \
+                    a.dom.w1 += R.f[4]; a.dom.w2 += R.f[5]; a.dom.w3 += R.f[6]; a.dom.sw += S.w;                          \
+                    fadd_v(a.dom.f[F_SQ2], tq2); fadd_v(a.dom.f[F_S3P], ts3p);                                            \
+                    BRC_SEV_ADD(a.dom.f[F_SEV], tsev);                                                                    \
+                    fadd_s(a.dom.f[F_SNM], __uint_as_float(R.f[7])); a.ww += R.g[0];                                      \
+                }
+#endif
+#if BRC_EXP == 1      // (timing only, wrong sums: the event-location sum without its three double-precision instructions)
+#define BRC_SEV_ADD(acc, x) acc += (float)__double2hiint(x)
+#else
+#define BRC_SEV_ADD(acc, x) fadd_through_double(acc, x)
+#endif
         // ACC of the piece in R (S = its probe results), piece index m
 #define BRC_ACC(R, S, m)                                                                                                \
         {                                                                                                                 \
-            const uint32_t fl = R.f[3] >> 24;                                                                             \
+            const uint32_t fl = BRC_EXP == 6 ? (uint32_t)(PF_TABLE | PF_Q2OK) : BRC_EXP == 7 ? ((R.f[3] >> 24) | (uint32_t)PF_TABLE) :   \
+                                BRC_EXP == 8 ? ((R.f[3] >> 24) & ~(uint32_t)(PF_NB | PF_HUGE)) : R.f[3] >> 24;   /* (6, 7, 8: timing only, flag tests folded away) */ \
             count_if(a.ncol, S.m_cov);                                                         /* lib_counts[library] (:286) */ \
             const uint64_t m_p = S.m_in & __builtin_amdgcn_ballot_w64(S.w >= thr0);           /* :288 */                  \
             count_if(a.depth, m_p);                                                            /* mapq_n (:312) */         \
-            if (!(fl & PF_NB)) {                                                               /* :343 with -i */          \
+            if (BRC_EXP != 3 && !(fl & PF_NB)) {                                               /* :343 with -i  (3: timing only, probe and counters alone) */ \
                 const uint32_t b = S.w & 0xffu;                                                                           \
                 /* the terms live in the stage's own registers: a piece without PF_TABLE overwrites them (no copies on the   \
                    common path); q2 == tp, or no Q2 position: then +0.0f, the identity on these sums */                  \
@@ -909,12 +949,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                 }                                                                                                         \
                 const float ts3p = S.t; const double tsev = S.sev;                                                        \
                 const uint64_t m_dom = m_p & __builtin_amdgcn_ballot_w64(b == a.dom_b);                                   \
-                if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(m_dom), 1)) {                                    \
-                    a.dom.w1 += R.f[4]; a.dom.w2 += R.f[5]; a.dom.w3 += R.f[6]; a.dom.sw += S.w;                          \
-                    fadd_v(a.dom.f[F_SQ2], tq2); fadd_v(a.dom.f[F_S3P], ts3p);                                            \
-                    fadd_through_double(a.dom.f[F_SEV], tsev);                                                            \
-                    fadd_s(a.dom.f[F_SNM], __uint_as_float(R.f[7])); a.ww += R.g[0];                                      \
-                }                                                                                                         \
+                BRC_DOM_REGION(R, S, m_dom, tq2, ts3p, tsev)                                                              \
                 const uint64_t m_rest = m_p & ~m_dom;                                                                     \
                 uint64_t m_ovf = 0;                                                                                       \
                 if (__builtin_expect(m_rest != 0ull, 0)) {                                                                \
@@ -1059,6 +1094,8 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
 #undef BRC_FLUSH
 #undef BRC_STEP
 #undef BRC_ACC
+#undef BRC_DOM_REGION
+#undef BRC_SEV_ADD
 #undef BRC_PROBE
 #undef BRC_WAIT_REC
 #undef BRC_F_R0
