@@ -813,7 +813,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
     bool flushed = false;                                                   // (scalar) the slot planes of this tile hold partial integer sums
     unsigned long long wsm_tot = 0, wnm_tot = 0;                            // (scalar) warnings moved out of the lanes at flushes
 
-    if (lo < hi && c.variant != 4 && c.variant != 14) {            // (variant: profiling ablations, BRC_PILEUP_VARIANT — 4: no piece loop, 1: no plane stores, 5: one half-batch only)
+    if (lo < hi && c.variant != 4) {            // (variant: profiling ablations, BRC_PILEUP_VARIANT — 4: no piece loop, 1: no plane stores, 5: one half-batch only)
         // lanes past the region's last position stand far left of every piece: no coverage test is ever true for them
         // (d = 2^31 + lane + p0 - rs >= 2^31 - (rs - p0) >= ext for every piece, because rs + ext <= 2^31 - 1 and p0 >= 0)
         const uint32_t lanev = valid ? (uint32_t)lane : (0x80000000u | (uint32_t)lane);
@@ -1058,9 +1058,9 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         enum { HOFF_X = HALF * ROW_BYTES };                                    // byte offset of the second ring half
         uint4 T; uint32_t pf = 0;
         BRC_LD_TAB(T, lo)
-        if (c.variant != 7 && c.variant != 12) BRC_STAGE(T, lo, 0u)
+        if (c.variant != 7) BRC_STAGE(T, lo, 0u)
         BRC_LD_TAB(T, lo + (uint32_t)HALF)
-        if (c.variant != 7 && c.variant != 12) BRC_STAGE(T, lo + (uint32_t)HALF, (uint32_t)HOFF_X)
+        if (c.variant != 7) BRC_STAGE(T, lo + (uint32_t)HALF, (uint32_t)HOFF_X)
         BRC_LD_TAB(T, lo + 2u * (uint32_t)HALF)
         PRec R0, R1, R2;
         const char* recp = reinterpret_cast<const char*>(pieces4) + (size_t)lo * 48u;   // (scalar) next record to request
@@ -1074,7 +1074,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         BRC_PROBE(R0, 0u, S0)
         S1 = S0;
         uint32_t hoff = 0;                                                     // byte offset of the current ring half
-        uint32_t base = (c.variant == 6 || c.variant == 7 || c.variant == 12 || c.variant == 13) ? hi : lo;   // (6: prologue only; 7: without its window copies; 12 = 7 + 1, 13 = 6 + 1, 14 = 4 + 1)
+        uint32_t base = (c.variant == 6 || c.variant == 7) ? hi : lo;
         for (; base < hi; base += (uint32_t)HALF, hoff ^= (uint32_t)HOFF_X) {
             const uint32_t nb = (hi - base) < (uint32_t)HALF ? (hi - base) : (uint32_t)HALF;
             if (c.variant == 5 && base != lo) continue;
@@ -1114,7 +1114,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
     // by scalar adds.  (Inline assembly: left to the optimiser, the lane offset is folded into ONE 64-bit vector address and
     // the other 28 are derived from it with a 64-bit vector add each.)
     const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // (the lane index again: see above)
-    if (inreg && c.variant != 1 && c.variant != 12 && c.variant != 13 && c.variant != 14) {
+    if (inreg && c.variant != 1) {
         const int64_t P = c.PS;
         const int64_t tb = tile * TILE;                                    // (scalar) plane index of lane 0
         const uint32_t loff = (uint32_t)lane_e << 2;
