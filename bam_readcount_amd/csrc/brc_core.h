@@ -410,7 +410,8 @@ struct alignas(16) Piece {
     int32_t rs;            // reference position of the first base
     int32_t len;           // events: positions [rs, rs + len); every piece with len > 0 belongs to a read that counts
     int32_t ext;           // column: positions [rs, rs + ext), ext >= len
-    uint32_t tp_flags;     // bits 0-23: three_prime_index * 4 (byte offset into the float quotient table); 24-31: PF_*
+    uint32_t tp_flags;     // bits 24-31: PF_*; bits 0-23: with PF_TABLE 16 * three_prime_index - 8 * table_len (signed: the byte distance between the
+                           // two table addresses of a probe, so that the second is one scalar add away from the first), else three_prime_index
     uint32_t w1, w2, w3;   // packed integer addends: three 10-bit counters 1 | rev << 10 | q2ok << 20;  mapq | sse << 16;  zm_sum | clipped << 16
     float snm;             // NM / (float)clipped_length, 0 when NM is missing
     uint32_t ww;           // per-lane (not per-bucket) warning counters: SM-missing | NM-missing << 16 (process_read warnings, BasicStat.cpp:85,100)
@@ -427,12 +428,16 @@ struct alignas(32) PieceRare {
     uint32_t zm_raw, sse_raw;
 };
 BRC_HD uint32_t piece_flags(const Piece& h) { return h.tp_flags >> 24; }
-BRC_HD int piece_tp(const Piece& h) { return (int)((h.tp_flags & 0xffffffu) >> 2); }
+BRC_HD int32_t piece_tp_field(uint32_t tp_flags) { return (int32_t)(tp_flags << 8) >> 8; }       // (sign-extended)
+BRC_HD int piece_tp_of(uint32_t tp_flags, int table_len) {
+    return ((tp_flags >> 24) & PF_TABLE) ? (piece_tp_field(tp_flags) + 8 * table_len) >> 4 : (int)(tp_flags & 0xffffffu);
+}
+BRC_HD int piece_tp(const DevCfg& c, const Piece& h) { return piece_tp_of(h.tp_flags, c.table_len); }
 BRC_HD bool piece_has_rare(uint32_t fl) { return (fl & PF_TABLE) == 0u || (fl & PF_HUGE) != 0u; }
 BRC_HD PieceRare piece_rare_of(const DevCfg& c, const Piece& h) {       // for pieces with PF_TABLE and without PF_HUGE
     PieceRare r;
     r.Lf = (float)c.table_len; r.center = (float)c.table_len * 0.5f; r.rcpL = 1.0f / r.Lf; r.rcpC = 1.0f / r.center;
-    r.left = 0; r.q2 = (piece_flags(h) & PF_Q2OK) ? piece_tp(h) : -1;
+    r.left = 0; r.q2 = (piece_flags(h) & PF_Q2OK) ? piece_tp(c, h) : -1;
     r.zm_raw = h.w3 & 0xffffu; r.sse_raw = h.w2 >> 16;
     return r;
 }
@@ -525,7 +530,7 @@ BRC_HD void make_piece(const DevCfg& c, const ReadConst& r, int32_t rs, int32_t 
     if (nb) fl |= PF_NB;
     const bool huge = r.zm > c.pack_lim || r.sse > c.pack_lim || (uint32_t)r.clipped > c.pack_lim;
     if (huge) fl |= PF_HUGE;
-    h.tp_flags = (((uint32_t)r.tp << 2) & 0xffffffu) | (fl << 24);      // l_qseq < 2^22 is checked at push
+    h.tp_flags = (((fl & PF_TABLE) ? (uint32_t)(16 * r.tp - 8 * c.table_len) : (uint32_t)r.tp) & 0xffffffu) | (fl << 24);      // l_qseq < 2^22 is checked at push
     h.w1 = 1u | ((fl & PF_REV) ? (1u << 10) : 0u) | (q2ok ? (1u << 20) : 0u);
     h.w2 = r.mapq | (huge ? 0u : (r.sse << 16));
     h.w3 = huge ? 0u : (r.zm | ((uint32_t)r.clipped << 16));
@@ -540,9 +545,9 @@ BRC_HD void make_piece(const DevCfg& c, const ReadConst& r, int32_t rs, int32_t 
 }
 
 // event terms of a piece at query position qpos by exact division (any read) ...
-BRC_HD EvTerms piece_terms_div(uint32_t tp_flags, const PieceRare& r, int qpos) {
-    EvTerms t; const int tp = (int)((tp_flags & 0xffffffu) >> 2);
-    t.q2 = ((tp_flags >> 24) & PF_Q2OK) ? div_rcp((float)BRC_ABSDIFF(qpos, r.q2), r.Lf, r.rcpL) : 0.0f;
+BRC_HD EvTerms piece_terms_div(uint32_t fl, int tp, const PieceRare& r, int qpos) {
+    EvTerms t;
+    t.q2 = (fl & PF_Q2OK) ? div_rcp((float)BRC_ABSDIFF(qpos, r.q2), r.Lf, r.rcpL) : 0.0f;
     t.s3p = div_rcp((float)BRC_ABSDIFF(qpos, tp), r.Lf, r.rcpL);
     float d = (float)(qpos - r.left) - r.center;
     d = d < 0.0f ? -d : d;
@@ -552,7 +557,7 @@ BRC_HD EvTerms piece_terms_div(uint32_t tp_flags, const PieceRare& r, int qpos) 
 // ... and from the quotient tables (PF_TABLE): one float look-up serves both distances (q2 == tp or no q2)
 BRC_HD EvTerms piece_terms_tab(const Piece& h, const TermTab& tt, int table_len, int qpos) {
     EvTerms t;
-    t.s3p = tt.q[absdiff_u((uint32_t)qpos, (uint32_t)piece_tp(h))];
+    t.s3p = tt.q[absdiff_u((uint32_t)qpos, (uint32_t)piece_tp_of(h.tp_flags, table_len))];
     t.q2 = (piece_flags(h) & PF_Q2OK) ? t.s3p : 0.0f;
     t.sev = tt.e[absdiff_u(2u * (uint32_t)qpos, (uint32_t)table_len)];
     return t;
@@ -629,10 +634,10 @@ BRC_HD void lane2_flush(const DevCfg& c, const Planes& pl, int lib, int64_t k, L
     flush_slot(c, pl, lib, k, a.alt, 1u, a.alt_b, live);
 }
 // one event of a third (fourth, ...) base at this position: its raw addends, for the list
-BRC_HD XEv make_xev(int lib, int64_t k, const Piece& h, const PieceRare& rare, int qpos, uint32_t word) {
+BRC_HD XEv make_xev(const DevCfg& c, int lib, int64_t k, const Piece& h, const PieceRare& rare, int qpos, uint32_t word) {
     XEv e;
     const uint32_t fl = piece_flags(h);
-    const EvTerms t = piece_terms_div(h.tp_flags, rare, qpos);
+    const EvTerms t = piece_terms_div(fl, piece_tp(c, h), rare, qpos);
     e.k = (uint32_t)k; e.lib_b = ((uint32_t)lib << 8) | (word & 0xffu);
     e.mapq = piece_mapq(h); e.sse = rare.sse_raw; e.zm = rare.zm_raw; e.clip = piece_clipped(rare);
     e.qf = (word >> 8) | ((fl & PF_REV) ? 0x100u : 0u) | ((fl & PF_Q2OK) ? 0x200u : 0u);

@@ -826,6 +826,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
 #define BRC_LANE() ((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))
 #define BRC_KK() (valid ? tile * TILE + BRC_LANE() : (int64_t)0)
         const uint32_t L0 = (uint32_t)c.table_len;
+        const uint32_t cb = (uint32_t)LBIAS + (L0 << 3);
         const uint32_t thr0 = piece_thr(c);
         char* const rows_base = reinterpret_cast<char*>(&lds.rows[wv][0][0]);
         QEnt* const queue = lds.queue[wv];
@@ -891,10 +892,11 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
             S.m_in = __builtin_amdgcn_ballot_w64(d < R.f[1]);                                                             \
             const uint32_t off = (uint32_t)(roff) + 2u * ((uint32_t)S.s_c & 7u);                                          \
             S.w = (uint32_t)*reinterpret_cast<const uint16_t*>(rows_base + (((uint32_t)lane << 1) + off));                                  \
-            const uint32_t s_c16 = (uint32_t)S.s_c << 4;                                      /* (scalar) */              \
+            /* (scalar) the lane-independent side of both table addresses: the second is the record's signed distance away from the first */ \
+            const uint32_t eoff = cb - ((uint32_t)S.s_c << 4), qoff16 = eoff + (uint32_t)piece_tp_field(R.f[3]);          \
             if (BRC_EXP == 2) { S.t = 0.5f; S.sev = 0.25; } else {     /* (2: timing only, no table look-ups) */                 \
-            S.t = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds.q16) + sad_u32(lane16b, (uint32_t)LBIAS + ((R.f[3] & 0xffffffu) << 2) - s_c16)); \
-            S.sev = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds.e) + sad_u32(lane16b, (uint32_t)LBIAS + (L0 << 3) - s_c16)); } \
+            S.t = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds.q16) + sad_u32(lane16b, qoff16));       \
+            S.sev = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds.e) + sad_u32(lane16b, eoff)); }      \
         }
         // the 10 adds of the dominant bucket, in the lanes of m_dom
 #if BRC_EXP == 5
@@ -940,11 +942,12 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
             if (BRC_EXP != 3 && !(fl & PF_NB)) {                                               /* :343 with -i  (3: timing only, probe and counters alone) */ \
                 const uint32_t b = S.w & 0xffu;                                                                           \
                 /* the terms live in the stage's own registers: a piece without PF_TABLE overwrites them (no copies on the   \
-                   common path); q2 == tp, or no Q2 position: then +0.0f, the identity on these sums */                  \
-                float tq2 = __uint_as_float(__float_as_uint(S.t) & ((fl & PF_Q2OK) ? 0xffffffffu : 0u));                  \
+                   common path); q2 == tp, or no Q2 position (every reverse read without a Q2 run): then +0.0f, the identity  \
+                   on these sums — the flag bit spread over a scalar register masks the look-up */                        \
+                float tq2 = __uint_as_float(__float_as_uint(S.t) & (uint32_t)((int32_t)(R.f[3] << 6) >> 31));           \
                 if (__builtin_expect((fl & PF_TABLE) == 0u, 0)) {                                                         \
                     PieceRare H; BRC_LD_DIV(H, R, m)                                                                      \
-                    const EvTerms t = piece_terms_div(R.f[3], H, (int)((uint32_t)BRC_LANE() + (uint32_t)S.s_c));          \
+                    const EvTerms t = piece_terms_div(fl, (int)(R.f[3] & 0xffffffu), H, (int)((uint32_t)BRC_LANE() + (uint32_t)S.s_c));          \
                     S.t = t.s3p; tq2 = t.q2; S.sev = t.sev;                                                               \
                 }                                                                                                         \
                 const float ts3p = S.t; const double tsev = S.sev;                                                        \
@@ -1041,7 +1044,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                         at0 = (uint32_t)__builtin_amdgcn_readfirstlane(at0);                                              \
                         const uint64_t below = mask & ((1ull << lr) - 1ull);                                              \
                         const uint32_t at = at0 + (uint32_t)__builtin_popcountll(below);                                  \
-                        if (mine && at < pl.xev_cap) pl.xev[(size_t)xshard * pl.xev_cap + at] = make_xev(lib, kr, H, RR, lr + s_c, w); \
+                        if (mine && at < pl.xev_cap) pl.xev[(size_t)xshard * pl.xev_cap + at] = make_xev(c, lib, kr, H, RR, lr + s_c, w); \
                     } else if (mine) drain_int(c, pl, lib, kr, RR, (w & 0xffu) == a.dom_b ? 0u : 1u);                     \
                 }                                                                                                         \
                 qn = 0;                                                                                                   \

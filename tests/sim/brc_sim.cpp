@@ -86,7 +86,7 @@ class SimBackend : public Backend {
                     if (w < thr) continue;                                                            // :288
                     a[l].depth++;                                                                     // mapq_n (:312)
                     if (fl & PF_NB) continue;                                                         // :343 with -i
-                    const EvTerms t = (fl & PF_TABLE) ? piece_terms_tab(h, tt, c.table_len, qpos) : piece_terms_div(h.tp_flags, rare[m], qpos);
+                    const EvTerms t = (fl & PF_TABLE) ? piece_terms_tab(h, tt, c.table_len, qpos) : piece_terms_div(fl, piece_tp(c, h), rare[m], qpos);
                     const uint32_t b = w & 0xffu;
                     a[l].ww += h.ww;
                     if (b == a[l].dom_b) { pack_event(a[l].dom, h, t, w); if (fl & PF_HUGE) { ints.lane[l] = true; any_int = true; } }
@@ -109,7 +109,7 @@ class SimBackend : public Backend {
                     if (!e.lane[l]) continue;
                     const int qpos = p[l] - h.a;
                     const uint32_t w = bq[h.bq_off + (uint64_t)qpos];
-                    if (e.kind == 0) { const XEv x = make_xev(lib, kk[l], h, rr, qpos, w); const uint32_t at = (*pl.xev_n)++; if (at < pl.xev_cap) pl.xev[at] = x; }
+                    if (e.kind == 0) { const XEv x = make_xev(c, lib, kk[l], h, rr, qpos, w); const uint32_t at = (*pl.xev_n)++; if (at < pl.xev_cap) pl.xev[at] = x; }
                     else drain_int(c, pl, lib, kk[l], rr, (w & 0xffu) == a[l].dom_b ? 0u : 1u);
                 }
             }
