@@ -400,7 +400,10 @@ BRC_HD uint32_t dominant_bucket(const DevCfg& c, const DevIn& in, int64_t p) {
 enum PieceFlag { PF_TABLE = 1,    // event terms come from the quotient tables (l_qseq == clipped == table_len, left_clip == 0, q2 in {tp, none})
        PF_Q2OK = 2, PF_NB = 4,
        PF_HUGE = 8,     // a per-read integer does not fit its packed field: w2/w3 carry only the mapping quality, the rest is added by drain_int()
-       PF_SMW = 16, PF_NMW = 32, PF_REV = 64 };
+       PF_SMW = 16, PF_NMW = 32, PF_REV = 64,
+       PF_TABQ = 128 };  // no PF_TABLE only because the read is soft-clipped (l_qseq == table_len, left_clip < 512, q2 in {tp, none}, no PF_HUGE): the two
+                         // distances still come from the quotient table, the event location is divided out in the lane — from clipped_length (w3)
+                         // and left_clip (the record's tp field), without the piece's rare record
 // an event word w passes the base-quality test (:288) iff w >= piece_thr(c)  (0x10000: no 16-bit word reaches it)
 BRC_HD uint32_t piece_thr(const DevCfg& c) { return (uint32_t)(c.min_bq < 0 ? 0 : (c.min_bq > 256 ? 256 : c.min_bq)) << 8; }
 
@@ -410,8 +413,9 @@ struct alignas(16) Piece {
     int32_t rs;            // reference position of the first base
     int32_t len;           // events: positions [rs, rs + len); every piece with len > 0 belongs to a read that counts
     int32_t ext;           // column: positions [rs, rs + ext), ext >= len
-    uint32_t tp_flags;     // bits 24-31: PF_*; bits 0-23: with PF_TABLE 16 * three_prime_index - 8 * table_len (signed: the byte distance between the
-                           // two table addresses of a probe, so that the second is one scalar add away from the first), else three_prime_index
+    uint32_t tp_flags;     // bits 24-31: PF_*; bits 0-23: with PF_TABLE / PF_TABQ bits 0-14 = 16 * three_prime_index - 8 * table_len (signed: the byte distance
+                           // between the two table addresses of a probe, so that the second is one scalar add away from the first) and bits 15-23 =
+                           // left_clip; else three_prime_index
     uint32_t w1, w2, w3;   // packed integer addends: three 10-bit counters 1 | rev << 10 | q2ok << 20;  mapq | sse << 16;  zm_sum | clipped << 16
     float snm;             // NM / (float)clipped_length, 0 when NM is missing
     uint32_t ww;           // per-lane (not per-bucket) warning counters: SM-missing | NM-missing << 16 (process_read warnings, BasicStat.cpp:85,100)
@@ -428,9 +432,16 @@ struct alignas(32) PieceRare {
     uint32_t zm_raw, sse_raw;
 };
 BRC_HD uint32_t piece_flags(const Piece& h) { return h.tp_flags >> 24; }
-BRC_HD int32_t piece_tp_field(uint32_t tp_flags) { return (int32_t)(tp_flags << 8) >> 8; }       // (sign-extended)
+BRC_HD int32_t piece_tp_field(uint32_t tp_flags) { return (int32_t)(tp_flags << 17) >> 17; }     // (bits 0-14, sign-extended)
+BRC_HD int piece_left_field(uint32_t tp_flags) { return (int)((tp_flags >> 15) & 0x1ffu); }
 BRC_HD int piece_tp_of(uint32_t tp_flags, int table_len) {
-    return ((tp_flags >> 24) & PF_TABLE) ? (piece_tp_field(tp_flags) + 8 * table_len) >> 4 : (int)(tp_flags & 0xffffffu);
+    return ((tp_flags >> 24) & (PF_TABLE | PF_TABQ)) ? (piece_tp_field(tp_flags) + 8 * table_len) >> 4 : (int)(tp_flags & 0xffffffu);
+}
+// the event-location term of a PF_TABQ piece at query position qpos: |(qpos - left) - cl/2| / (cl/2) is the correctly rounded quotient of the
+// rational |2 (qpos - left) - cl| / cl — the same float whichever pair of exactly represented operands is divided (BasicStat.cpp:69-70)
+BRC_HD double tabq_sev(int qpos, int left, uint32_t clipped) {
+    const int n = 2 * (qpos - left) - (int)clipped;
+    return 1.0 - (double)((float)(n < 0 ? -n : n) / (float)clipped);
 }
 BRC_HD int piece_tp(const DevCfg& c, const Piece& h) { return piece_tp_of(h.tp_flags, c.table_len); }
 BRC_HD bool piece_has_rare(uint32_t fl) { return (fl & PF_TABLE) == 0u || (fl & PF_HUGE) != 0u; }
@@ -530,7 +541,9 @@ BRC_HD void make_piece(const DevCfg& c, const ReadConst& r, int32_t rs, int32_t 
     if (nb) fl |= PF_NB;
     const bool huge = r.zm > c.pack_lim || r.sse > c.pack_lim || (uint32_t)r.clipped > c.pack_lim;
     if (huge) fl |= PF_HUGE;
-    h.tp_flags = (((fl & PF_TABLE) ? (uint32_t)(16 * r.tp - 8 * c.table_len) : (uint32_t)r.tp) & 0xffffffu) | (fl << 24);      // l_qseq < 2^22 is checked at push
+    if (!(fl & PF_TABLE) && !huge && c.table_len > 0 && r.l_qseq == c.table_len && r.clipped > 0 && r.left >= 0 && r.left < 512 &&
+        r.tp >= 0 && r.tp <= c.table_len && (!q2ok || r.q2 == r.tp)) fl |= PF_TABQ;
+    h.tp_flags = ((fl & (PF_TABLE | PF_TABQ)) ? (((uint32_t)(16 * r.tp - 8 * c.table_len) & 0x7fffu) | ((uint32_t)r.left << 15)) : ((uint32_t)r.tp & 0xffffffu)) | (fl << 24);      // l_qseq < 2^22 is checked at push
     h.w1 = 1u | ((fl & PF_REV) ? (1u << 10) : 0u) | (q2ok ? (1u << 20) : 0u);
     h.w2 = r.mapq | (huge ? 0u : (r.sse << 16));
     h.w3 = huge ? 0u : (r.zm | ((uint32_t)r.clipped << 16));

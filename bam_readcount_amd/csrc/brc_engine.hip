@@ -946,9 +946,13 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                    on these sums — the flag bit spread over a scalar register masks the look-up */                        \
                 float tq2 = __uint_as_float(__float_as_uint(S.t) & (uint32_t)((int32_t)(R.f[3] << 6) >> 31));           \
                 if (__builtin_expect((fl & PF_TABLE) == 0u, 0)) {                                                         \
-                    PieceRare H; BRC_LD_DIV(H, R, m)                                                                      \
-                    const EvTerms t = piece_terms_div(fl, (int)(R.f[3] & 0xffffffu), H, (int)((uint32_t)BRC_LANE() + (uint32_t)S.s_c));          \
-                    S.t = t.s3p; tq2 = t.q2; S.sev = t.sev;                                                               \
+                    if (fl & PF_TABQ) {                    /* soft-clipped: only the event location differs, and it needs no rare record */ \
+                        S.sev = tabq_sev((int)((uint32_t)BRC_LANE() + (uint32_t)S.s_c), piece_left_field(R.f[3]), R.f[6] >> 16); \
+                    } else {                                                                                              \
+                        PieceRare H; BRC_LD_DIV(H, R, m)                                                                  \
+                        const EvTerms t = piece_terms_div(fl, (int)(R.f[3] & 0xffffffu), H, (int)((uint32_t)BRC_LANE() + (uint32_t)S.s_c));      \
+                        S.t = t.s3p; tq2 = t.q2; S.sev = t.sev;                                                           \
+                    }                                                                                                     \
                 }                                                                                                         \
                 const float ts3p = S.t; const double tsev = S.sev;                                                        \
                 const uint64_t m_dom = m_p & __builtin_amdgcn_ballot_w64(b == a.dom_b);                                   \
