@@ -538,7 +538,7 @@ BRC_HD void make_piece(const DevCfg& c, const ReadConst& r, int32_t rs, int32_t 
     const bool q2ok = (fl & PF_Q2OK) != 0;
     if (c.table_len > 0 && r.l_qseq == c.table_len && r.clipped == c.table_len && r.left == 0 && r.tp >= 0 && r.tp <= c.table_len &&
         (!q2ok || r.q2 == r.tp)) fl |= PF_TABLE;
-    if (nb) fl |= PF_NB;
+    if (nb) fl = (fl | PF_NB) & ~(uint32_t)PF_TABLE;      // (k_pileup2 finds the unusual pieces behind ONE test: no PF_TABLE)
     const bool huge = r.zm > c.pack_lim || r.sse > c.pack_lim || (uint32_t)r.clipped > c.pack_lim;
     if (huge) fl |= PF_HUGE;
     if (!(fl & PF_TABLE) && !huge && c.table_len > 0 && r.l_qseq == c.table_len && r.clipped > 0 && r.left >= 0 && r.left < 512 &&

@@ -939,14 +939,16 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
             count_if(a.ncol, S.m_cov);                                                         /* lib_counts[library] (:286) */ \
             const uint64_t m_p = S.m_in & __builtin_amdgcn_ballot_w64(S.w >= thr0);           /* :288 */                  \
             count_if(a.depth, m_p);                                                            /* mapq_n (:312) */         \
-            if (BRC_EXP != 3 && !(fl & PF_NB)) {                                               /* :343 with -i  (3: timing only, probe and counters alone) */ \
+            if (BRC_EXP != 3) {                                                                /* (3: timing only, probe and counters alone) */ \
                 const uint32_t b = S.w & 0xffu;                                                                           \
+                uint64_t m_b = m_p;                            /* lanes whose event goes to a base bucket */               \
                 /* the terms live in the stage's own registers: a piece without PF_TABLE overwrites them (no copies on the   \
                    common path); q2 == tp, or no Q2 position (every reverse read without a Q2 run): then +0.0f, the identity  \
                    on these sums — the flag bit spread over a scalar register masks the look-up */                        \
                 float tq2 = __uint_as_float(__float_as_uint(S.t) & (uint32_t)((int32_t)(R.f[3] << 6) >> 31));           \
                 if (__builtin_expect((fl & PF_TABLE) == 0u, 0)) {                                                         \
-                    if (fl & PF_TABQ) {                    /* soft-clipped: only the event location differs, and it needs no rare record */ \
+                    if (fl & PF_NB) m_b = 0ull;            /* :343 with -i: counted in the depth, in no bucket (make_piece leaves such a piece without PF_TABLE) */ \
+                    else if (fl & PF_TABQ) {               /* soft-clipped: only the event location differs, and it needs no rare record */ \
                         S.sev = tabq_sev((int)((uint32_t)BRC_LANE() + (uint32_t)S.s_c), piece_left_field(R.f[3]), R.f[6] >> 16); \
                     } else {                                                                                              \
                         PieceRare H; BRC_LD_DIV(H, R, m)                                                                  \
@@ -955,9 +957,9 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                     }                                                                                                     \
                 }                                                                                                         \
                 const float ts3p = S.t; const double tsev = S.sev;                                                        \
-                const uint64_t m_dom = m_p & __builtin_amdgcn_ballot_w64(b == a.dom_b);                                   \
+                const uint64_t m_dom = m_b & __builtin_amdgcn_ballot_w64(b == a.dom_b);                                   \
                 BRC_DOM_REGION(R, S, m_dom, tq2, ts3p, tsev)                                                              \
-                const uint64_t m_rest = m_p & ~m_dom;                                                                     \
+                const uint64_t m_rest = m_b & ~m_dom;                                                                     \
                 uint64_t m_ovf = 0;                                                                                       \
                 if (__builtin_expect(m_rest != 0ull, 0)) {                                                                \
                     bool ovf = false;                                                                                     \
@@ -977,7 +979,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                     if (m_ovf) { if (BRC_LANE() == 0) { QEnt e; e.piece = (m); e.kind = 0u; e.mlo = (uint32_t)m_ovf; e.mhi = (uint32_t)(m_ovf >> 32); queue[qn] = e; } ++qn; } \
                 }                                                                                                         \
                 if (__builtin_expect((fl & PF_HUGE) != 0u, 0)) {                                                          \
-                    const uint64_t m_int = m_p & ~m_ovf;                                                                  \
+                    const uint64_t m_int = m_b & ~m_ovf;                                                                  \
                     if (m_int) { if (BRC_LANE() == 0) { QEnt e; e.piece = (m); e.kind = 1u; e.mlo = (uint32_t)m_int; e.mhi = (uint32_t)(m_int >> 32); queue[qn] = e; } ++qn; } \
                 }                                                                                                         \
             }                                                                                                             \
