@@ -401,9 +401,9 @@ enum PieceFlag { PF_TABLE = 1,    // event terms come from the quotient tables (
        PF_Q2OK = 2, PF_NB = 4,
        PF_HUGE = 8,     // a per-read integer does not fit its packed field: w2/w3 carry only the mapping quality, the rest is added by drain_int()
        PF_SMW = 16, PF_NMW = 32, PF_REV = 64,
-       PF_TABQ = 128 };  // no PF_TABLE only because the read is soft-clipped (l_qseq == table_len, left_clip < 512, q2 in {tp, none}, no PF_HUGE): the two
+       PF_TABQ = 128 };  // without PF_HUGE: no PF_TABLE only because the read is soft-clipped (l_qseq == table_len, left_clip < 512, q2 in {tp, none}, no PF_HUGE): the two
                          // distances still come from the quotient table, the event location is divided out in the lane — from clipped_length (w3)
-                         // and left_clip (the record's tp field), without the piece's rare record
+                         // and left_clip (the record's tp field), without the piece's rare record.  With PF_HUGE: a table piece (all terms from the tables)
 // an event word w passes the base-quality test (:288) iff w >= piece_thr(c)  (0x10000: no 16-bit word reaches it)
 BRC_HD uint32_t piece_thr(const DevCfg& c) { return (uint32_t)(c.min_bq < 0 ? 0 : (c.min_bq > 256 ? 256 : c.min_bq)) << 8; }
 
@@ -538,10 +538,12 @@ BRC_HD void make_piece(const DevCfg& c, const ReadConst& r, int32_t rs, int32_t 
     const bool q2ok = (fl & PF_Q2OK) != 0;
     if (c.table_len > 0 && r.l_qseq == c.table_len && r.clipped == c.table_len && r.left == 0 && r.tp >= 0 && r.tp <= c.table_len &&
         (!q2ok || r.q2 == r.tp)) fl |= PF_TABLE;
-    if (nb) fl = (fl | PF_NB) & ~(uint32_t)PF_TABLE;      // (k_pileup2 finds the unusual pieces behind ONE test: no PF_TABLE)
+    // k_pileup2 finds every unusual piece behind ONE test, "no PF_TABLE": -i's one-base pieces, and pieces with huge integers —
+    // those keep PF_TABQ as the mark of "all three terms from the tables" when they were table pieces
+    if (nb) fl = (fl | PF_NB) & ~(uint32_t)PF_TABLE;
     const bool huge = r.zm > c.pack_lim || r.sse > c.pack_lim || (uint32_t)r.clipped > c.pack_lim;
-    if (huge) fl |= PF_HUGE;
-    if (!(fl & PF_TABLE) && !huge && c.table_len > 0 && r.l_qseq == c.table_len && r.clipped > 0 && r.left >= 0 && r.left < 512 &&
+    if (huge) fl = (fl & PF_TABLE) ? ((fl & ~(uint32_t)PF_TABLE) | PF_HUGE | PF_TABQ) : (fl | PF_HUGE);
+    if (!(fl & (PF_TABLE | PF_TABQ)) && !nb && !huge && c.table_len > 0 && r.l_qseq == c.table_len && r.clipped > 0 && r.left >= 0 && r.left < 512 &&
         r.tp >= 0 && r.tp <= c.table_len && (!q2ok || r.q2 == r.tp)) fl |= PF_TABQ;
     h.tp_flags = ((fl & (PF_TABLE | PF_TABQ)) ? (((uint32_t)(16 * r.tp - 8 * c.table_len) & 0x7fffu) | ((uint32_t)r.left << 15)) : ((uint32_t)r.tp & 0xffffffu)) | (fl << 24);      // l_qseq < 2^22 is checked at push
     h.w1 = 1u | ((fl & PF_REV) ? (1u << 10) : 0u) | (q2ok ? (1u << 20) : 0u);

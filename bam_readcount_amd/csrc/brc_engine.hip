@@ -946,21 +946,30 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                    common path); q2 == tp, or no Q2 position (every reverse read without a Q2 run): then +0.0f, the identity  \
                    on these sums — the flag bit spread over a scalar register masks the look-up */                        \
                 float tq2 = __uint_as_float(__float_as_uint(S.t) & (uint32_t)((int32_t)(R.f[3] << 6) >> 31));           \
-                if (__builtin_expect((fl & PF_TABLE) == 0u, 0)) {                                                         \
-                    if (fl & PF_NB) m_b = 0ull;            /* :343 with -i: counted in the depth, in no bucket (make_piece leaves such a piece without PF_TABLE) */ \
-                    else if (fl & PF_TABQ) {               /* soft-clipped: only the event location differs, and it needs no rare record */ \
-                        S.sev = tabq_sev((int)((uint32_t)BRC_LANE() + (uint32_t)S.s_c), piece_left_field(R.f[3]), R.f[6] >> 16); \
-                    } else {                                                                                              \
-                        PieceRare H; BRC_LD_DIV(H, R, m)                                                                  \
-                        const EvTerms t = piece_terms_div(fl, (int)(R.f[3] & 0xffffffu), H, (int)((uint32_t)BRC_LANE() + (uint32_t)S.s_c));      \
-                        S.t = t.s3p; tq2 = t.q2; S.sev = t.sev;                                                           \
+                if (__builtin_expect((fl & PF_TABLE) == 0u, 0)) {      /* every unusual piece (make_piece) */                 \
+                    if (fl & PF_NB) m_b = 0ull;            /* :343 with -i: counted in the depth, in no bucket */            \
+                    else {                                                                                                \
+                        if ((fl & (PF_TABQ | PF_HUGE)) == PF_TABQ) {   /* soft-clipped: only the event location differs, and it needs no rare record */ \
+                            S.sev = tabq_sev((int)((uint32_t)BRC_LANE() + (uint32_t)S.s_c), piece_left_field(R.f[3]), R.f[6] >> 16); \
+                        } else if (!(fl & PF_TABQ)) {                                                                     \
+                            PieceRare H; BRC_LD_DIV(H, R, m)                                                              \
+                            const EvTerms t = piece_terms_div(fl, (int)(R.f[3] & 0xffffffu), H, (int)((uint32_t)BRC_LANE() + (uint32_t)S.s_c));  \
+                            S.t = t.s3p; tq2 = t.q2; S.sev = t.sev;                                                       \
+                        }                                                                                                 \
+                        if (fl & PF_HUGE) {                                                                               \
+                            /* the integers the packed addends left out are added at the next boundary, to the lanes whose event goes   \
+                               to one of the two slots: every lane of m_b but those that will overflow to the third-allele list —   \
+                               known before the adds, a lane's alternate bucket changes only by its own event */              \
+                            const bool ovf_l = b != a.dom_b && a.alt_b != NB_NONE && a.alt_b != b;                         \
+                            const uint64_t m_int = m_b & ~__builtin_amdgcn_ballot_w64(ovf_l);                             \
+                            if (m_int) { if (BRC_LANE() == 0) { QEnt e; e.piece = (m); e.kind = 1u; e.mlo = (uint32_t)m_int; e.mhi = (uint32_t)(m_int >> 32); queue[qn] = e; } ++qn; } \
+                        }                                                                                                 \
                     }                                                                                                     \
                 }                                                                                                         \
                 const float ts3p = S.t; const double tsev = S.sev;                                                        \
                 const uint64_t m_dom = m_b & __builtin_amdgcn_ballot_w64(b == a.dom_b);                                   \
                 BRC_DOM_REGION(R, S, m_dom, tq2, ts3p, tsev)                                                              \
                 const uint64_t m_rest = m_b & ~m_dom;                                                                     \
-                uint64_t m_ovf = 0;                                                                                       \
                 if (__builtin_expect(m_rest != 0ull, 0)) {                                                                \
                     bool ovf = false;                                                                                     \
                     if (__builtin_amdgcn_inverse_ballot_w64(m_rest)) {                                                    \
@@ -975,12 +984,8 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                         a.ww += R.g[0];                        /* alternate and third alleles alike */                    \
                         ovf = !take_alt;                                                                                  \
                     }                                                                                                     \
-                    m_ovf = __builtin_amdgcn_ballot_w64(ovf);                                                             \
+                    const uint64_t m_ovf = __builtin_amdgcn_ballot_w64(ovf);                                              \
                     if (m_ovf) { if (BRC_LANE() == 0) { QEnt e; e.piece = (m); e.kind = 0u; e.mlo = (uint32_t)m_ovf; e.mhi = (uint32_t)(m_ovf >> 32); queue[qn] = e; } ++qn; } \
-                }                                                                                                         \
-                if (__builtin_expect((fl & PF_HUGE) != 0u, 0)) {                                                          \
-                    const uint64_t m_int = m_b & ~m_ovf;                                                                  \
-                    if (m_int) { if (BRC_LANE() == 0) { QEnt e; e.piece = (m); e.kind = 1u; e.mlo = (uint32_t)m_int; e.mhi = (uint32_t)(m_int >> 32); queue[qn] = e; } ++qn; } \
                 }                                                                                                         \
             }                                                                                                             \
         }

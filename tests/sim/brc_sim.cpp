@@ -87,7 +87,7 @@ class SimBackend : public Backend {
                     a[l].depth++;                                                                     // mapq_n (:312)
                     if (fl & PF_NB) continue;                                                         // :343 with -i
                     EvTerms t = (fl & (PF_TABLE | PF_TABQ)) ? piece_terms_tab(h, tt, c.table_len, qpos) : piece_terms_div(fl, piece_tp(c, h), rare[m], qpos);
-                    if (fl & PF_TABQ) t.sev = tabq_sev(qpos, piece_left_field(h.tp_flags), h.w3 >> 16);       // (as k_pileup2 does: no rare record)
+                    if ((fl & PF_TABQ) && !(fl & PF_HUGE)) t.sev = tabq_sev(qpos, piece_left_field(h.tp_flags), h.w3 >> 16);       // (as k_pileup2 does: no rare record)
                     const uint32_t b = w & 0xffu;
                     a[l].ww += h.ww;
                     if (b == a[l].dom_b) { pack_event(a[l].dom, h, t, w); if (fl & PF_HUGE) { ints.lane[l] = true; any_int = true; } }
