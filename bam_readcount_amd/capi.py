@@ -20,7 +20,7 @@ F_NAMES = ["sev", "sq2", "snm", "s3p"]
 EXPORTS = [
     "brc_strerror", "brc_last_error", "brc_kernel_name", "brc_engine_kind", "brc_create", "brc_destroy",
     "brc_begin_region", "brc_push_reads", "brc_upload", "brc_compute", "brc_fetch_result", "brc_end_region",
-    "brc_clear_indel_queue", "brc_region_counts", "brc_format_region", "brc_format_window", "brc_region_warnings", "brc_window_warnings", "brc_warnings_text", "brc_set_option", "brc_format_region_parts", "brc_set_chrom",
+    "brc_clear_indel_queue", "brc_region_counts", "brc_format_region", "brc_format_window", "brc_region_windows", "brc_region_warnings", "brc_window_warnings", "brc_warnings_text", "brc_set_option", "brc_format_region_parts", "brc_set_chrom",
 ]
 
 
@@ -101,6 +101,8 @@ class Library:
         if hasattr(L, "brc_window_warnings"):
             L.brc_window_warnings.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
         L.brc_format_window.argtypes = [C.c_void_p, C.POINTER(Result), C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
+        if hasattr(L, "brc_region_windows"):
+            L.brc_region_windows.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int64]
 
     def kind(self):
         return self.lib.brc_engine_kind().decode()
@@ -351,6 +353,17 @@ def _format_window(self, chrom, vbeg0, vend, delta):
 
 
 Engine.format_window = _format_window
+
+
+def _region_windows(self, vbeg0, vend):
+    """Announce the only windows [vbeg0[i], vend[i]) of the open region that will be formatted (site-list planner): the engine
+    piles up only the tiles they touch."""
+    b = np.ascontiguousarray(vbeg0, np.int32); e = np.ascontiguousarray(vend, np.int32)
+    assert b.shape == e.shape and b.ndim == 1
+    self._check(self.L.lib.brc_region_windows(self.h, b.ctypes.data_as(C.POINTER(C.c_int32)), e.ctypes.data_as(C.POINTER(C.c_int32)), b.size))
+
+
+Engine.region_windows = _region_windows
 
 
 def fetch_overlapping(arrs, ends, lo, hi):

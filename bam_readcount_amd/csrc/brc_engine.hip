@@ -696,6 +696,13 @@ __global__ __launch_bounds__(TR_T) void k_tiles_all(DevCfg c, const int2* __rest
     }
 }
 
+// brc_region_windows: tiles no announced window touches get an empty piece range — k_pileup2 then leaves their planes empty
+__global__ __launch_bounds__(256) void k_mask_tiles(const uint8_t* __restrict__ wanted, int64_t ntiles, int Lp, uint2* __restrict__ rng) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= ntiles * Lp) return;
+    if (!wanted[i % ntiles]) rng[i] = make_uint2(0u, 0u);
+}
+
 // ---------------------------------------------------------------- KB: pileup + BasicStat accumulation (the hot kernel)
 
 // |a - b| of two unsigned values in one instruction (LLVM does not form v_sad_u32 from max - min)
@@ -1355,6 +1362,7 @@ class HipBackend : public Backend {
     std::vector<int64_t> lib_base;      // first piece of every library's stream (Lp + 1 entries)
     // device buffers
     DBuf d_pos, d_flag, d_mapq, d_lib, d_lq, d_nc, d_co, d_so, d_qo, d_nm, d_sm, d_tags, d_cigar, d_seq, d_qual, d_ref, d_refcode;
+    std::vector<uint8_t> h_wanted; bool has_wanted = false; DBuf d_wanted;      // brc_region_windows (kept alive for the asynchronous copy)
     DBuf d_bq, d_bqrow, d_pieceoff, d_pieces, d_rare, d_keyreach, d_libbase, d_reads, d_agg, d_rng, d_ncol, d_depth, d_slotid, d_si, d_sf, d_xev, d_xevc, d_xevn, d_unavail, d_cnt, d_cursor, d_ev, d_evraw, d_ievoff, d_iout, d_ctr, d_tilectr, d_part;
     DBuf d_tlen, d_toff, d_text, d_tctx;
     // device-side text, downloaded (pinned) on its own stream into one of two host buffers
@@ -1403,7 +1411,7 @@ class HipBackend : public Backend {
         (void)hipSetDevice(device);
         DBuf* all[] = {&d_pos, &d_flag, &d_mapq, &d_lib, &d_lq, &d_nc, &d_co, &d_so, &d_qo, &d_nm, &d_sm, &d_tags, &d_cigar, &d_seq, &d_qual,
                        &d_ref, &d_refcode, &d_bq, &d_bqrow, &d_pieceoff, &d_pieces, &d_rare, &d_keyreach, &d_libbase, &d_reads, &d_agg, &d_rng, &d_ncol, &d_depth, &d_slotid, &d_si, &d_sf, &d_xev, &d_xevc, &d_xevn, &d_unavail, &d_cnt,
-                       &d_cursor, &d_ev, &d_evraw, &d_ievoff, &d_iout, &d_ctr, &d_tilectr, &d_part, &d_tlen, &d_toff, &d_text, &d_tctx};
+                       &d_cursor, &d_ev, &d_evraw, &d_ievoff, &d_iout, &d_ctr, &d_tilectr, &d_part, &d_tlen, &d_toff, &d_text, &d_tctx, &d_wanted};
         for (DBuf* b : all) b->release();
         for (int i = 0; i < 2; ++i) { h_text[i].destroy(); h_toff[i].destroy(); if (ev_text[i]) (void)hipEventDestroy(ev_text[i]); }
         h_total.destroy();
@@ -1474,6 +1482,8 @@ class HipBackend : public Backend {
         const size_t P = (size_t)c.PS, Lp = (size_t)c.Lp;   // allocation sizes use the padded stride
         ntiles = (c.P + TILE - 1) / TILE;
         n_indel_cap = c.has_ref ? s.n_indel_ops : 0;
+        h_wanted = s.wanted_tiles(c.pos0, c.P); has_wanted = !h_wanted.empty();
+        if (has_wanted) { HIPCHK(d_wanted.ensure(h_wanted.size() + 16)); HIPCHK(hipMemcpyAsync(d_wanted.p, h_wanted.data(), h_wanted.size(), hipMemcpyHostToDevice, stream)); }
         if (n_indel_cap && ((uint64_t)c.P * (uint64_t)c.Lp >= 0xffffffffull || n_indel_cap >= 0xfffffff0ull)) { err = "region too large: (positions x libraries) and the indel operators must stay below 2^32"; return BRC_E_ARG; }
         const size_t nagg = std::max<size_t>(std::max<size_t>((std::max<size_t>(np, P * Lp) + SCAN_CHUNK - 1) / SCAN_CHUNK, (np + TR_CHUNK - 1) / TR_CHUNK), 1);
         HIPCHK(d_reads.ensure((n + 1) * sizeof(DRead)));
@@ -1593,6 +1603,8 @@ class HipBackend : public Backend {
         if (np_all > 0 && ntiles > 0)
             hipLaunchKernelGGL(k_tiles_all, dim3((unsigned)trb), dim3(TR_T), 0, stream, c, (const int2*)d_keyreach.p, np_all, (const int64_t*)d_libbase.p, Lp,
                                (const unsigned long long*)d_agg.p, ntiles, (uint2*)d_rng.p);
+        if (has_wanted && ntiles > 0)
+            hipLaunchKernelGGL(k_mask_tiles, dim3((unsigned)((ntiles * Lp + 255) / 256)), dim3(256), 0, stream, (const uint8_t*)d_wanted.p, ntiles, Lp, (uint2*)d_rng.p);
         HIPCHK(hipEventRecord(evt[T_PILEUP], stream));
         if (ntiles > 0) {
             unsigned nwg = (unsigned)((ntiles + PILEUP_WAVES - 1) / PILEUP_WAVES);

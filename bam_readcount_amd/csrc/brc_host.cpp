@@ -70,6 +70,20 @@ void Staged::clear() {
     qual_off.clear(); nm.clear(); sm.clear(); tags.clear(); cigar.clear(); seq4.clear(); qual.clear(); bq_row.clear();
     bq_elems = 0; memset(len_hist, 0, sizeof len_hist); n = 0; min_pos = 0; max_end = 0; n_indel_ops = 0;
     piece_cnt.clear(); piece_off.clear(); iev_off.clear(); lib_base.clear(); n_pieces = 0; max_lqseq = 0; max_span = 0; qnames.clear(); qname_off.clear();
+    win_beg.clear(); win_end.clear();
+}
+std::vector<uint8_t> Staged::wanted_tiles(int32_t pos0, int64_t P) const {
+    std::vector<uint8_t> w;
+    if (win_beg.empty() || P <= 0) return w;
+    const int64_t nt = (P + TILE - 1) / TILE;
+    w.assign((size_t)nt, 0);
+    for (size_t i = 0; i < win_beg.size(); ++i) {
+        int64_t k0 = (int64_t)win_beg[i] - 1 - pos0, k1 = (int64_t)win_end[i] - pos0;      // plane indices of [beg - 1, end), as brc_format_window cuts them
+        if (k0 < 0) k0 = 0;
+        if (k1 > P) k1 = P;
+        for (int64_t t = k0 / TILE; k1 > k0 && t <= (k1 - 1) / TILE; ++t) w[(size_t)t] = 1;
+    }
+    return w;
 }
 void Staged::destroy() {
     pos.destroy(); flag.destroy(); mapq.destroy(); lib.destroy(); l_qseq.destroy(); n_cigar.destroy(); cig_off.destroy();
@@ -1056,6 +1070,14 @@ int brc_format_region_parts(brc_engine* e, const brc_result* r, const char* chro
     for (int64_t c = 0; c < nch; ++c) { e->part_ptr[(size_t)c] = e->fparts[(size_t)c].p ? e->fparts[(size_t)c].p : ""; e->part_len[(size_t)c] = e->fparts[(size_t)c].n; }
     *parts = e->part_ptr.data(); *part_lens = e->part_len.data(); *n_parts = (size_t)nch;
     e->t_format += now_s() - t_in;
+    return BRC_OK;
+}
+
+int brc_region_windows(brc_engine* e, const int32_t* vbeg0, const int32_t* vend, int64_t n) {
+    if (!e || n < 0 || (n > 0 && (!vbeg0 || !vend))) return BRC_E_ARG;
+    if (e->state != 1) return fail(e, BRC_E_ARG, "brc_region_windows: between brc_begin_region and brc_end_region");
+    for (int64_t i = 0; i < n; ++i) if (vend[i] < vbeg0[i]) return fail(e, BRC_E_ARG, "brc_region_windows: a window ends before it begins");
+    try { e->st.win_beg.assign(vbeg0, vbeg0 + n); e->st.win_end.assign(vend, vend + n); } catch (...) { e->st.win_beg.clear(); e->st.win_end.clear(); return fail(e, BRC_E_NOMEM, "host allocation failed"); }
     return BRC_OK;
 }
 

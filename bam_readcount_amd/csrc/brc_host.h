@@ -73,6 +73,9 @@ struct Staged {
     int64_t n = 0;
     int64_t min_pos = 0, max_end = 0;   // extent of reads that enter the pileup
     uint64_t n_indel_ops = 0;           // I / D / P operators of all reads = slots of the raw indel-event list (an upper bound on the events)
+    std::vector<int32_t> win_beg, win_end;   // brc_region_windows: the only windows [beg - 1, end) of the region anybody will format (empty: all of it)
+    // 1 per 64-position tile of the planes [pos0, pos0 + P) that a window touches (empty vector: no hint, every tile is wanted)
+    std::vector<uint8_t> wanted_tiles(int32_t pos0, int64_t P) const;
     void init(const HostAlloc* A);
     void clear();
     void destroy();

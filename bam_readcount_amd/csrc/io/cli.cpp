@@ -558,6 +558,11 @@ static int run_site_batch(Ctx& c, const std::vector<Site>& sites) {
         int rc = brc_begin_region(c.eng, 0, 1, (int32_t)V, c.have_fa ? vref.data() : nullptr, V);
         const brc_read_batch v = all.view();
         if (!rc) rc = brc_push_reads(c.eng, &v);
+        if (!rc) {         // only the lines' own positions are ever formatted: the engine need not pile up the rest of their reads' extent
+            std::vector<int32_t> wb, we;
+            for (size_t i = i0; i < i1; ++i) { wb.push_back((int32_t)(sites[i].beg0 + delta[i])); we.push_back((int32_t)(sites[i].end + delta[i])); }
+            rc = brc_region_windows(c.eng, wb.data(), we.data(), (int64_t)wb.size());
+        }
         brc_result res;
         if (!rc) rc = brc_end_region(c.eng, &res);
         if (rc) { c.complain(std::string("bam-readcount: engine error: ") + brc_strerror(rc) + " (" + brc_last_error(c.eng) + ")\n"); return 1; }

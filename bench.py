@@ -195,6 +195,10 @@ def main():
     t0 = time.time()
     eng.begin_region(0, 0, region_len, region_ref)
     eng.push_reads(region_reads)
+    if args.mode == "sites" and not os.environ.get("BRC_BENCH_NO_WINDOWS"):
+        # the planner announces the lines it is going to cut out (brc_region_windows): only their tiles are piled up
+        vb = np.arange(len(sites), dtype=np.int64) * 384 + 170 - 1
+        eng.region_windows(vb.astype(np.int32), (vb + 1).astype(np.int32))
     t_push = time.time() - t0
     t0 = time.time()
     eng.upload()                                  # inputs resident in HBM from here on

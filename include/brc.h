@@ -282,6 +282,16 @@ int  brc_format_region_parts(brc_engine*, const brc_result*, const char* chrom,
  */
 int  brc_format_window(brc_engine*, const brc_result*, const char* chrom, int32_t vbeg0, int32_t vend, int32_t delta,
                        const char** text, size_t* text_len);
+/*
+ * ... and the hint that makes such a shared region cheap: the windows the caller is going to format.  The reference piles up
+ * nothing outside a -l line — every line is its own fetch + pileup (bamreadcount.cpp:574-607), and pileup_func returns at
+ * once for positions outside [beg - 1, end) (:269) — while a window laid on a shared axis brings the whole extent of its
+ * reads with it (the annotator needs the reference under every base of a read, :139-174).  With the hint the engine piles
+ * up only the 64-position tiles that a window [vbeg0[i] - 1, vend[i]) touches; the planes of every other tile come back
+ * EMPTY (no column).  Only brc_format_window / brc_window_warnings of the announced windows are meaningful on such a
+ * region.  Call between brc_begin_region and brc_end_region; the next brc_begin_region forgets the windows.
+ */
+int  brc_region_windows(brc_engine*, const int32_t* vbeg0, const int32_t* vend, int64_t n);
 
 /*
  * The stderr side of the path: what ReadWarnings::warn (src/lib/bamrc/ReadWarnings.hpp:39-50) would be called with while the

@@ -783,6 +783,11 @@ int brc_format_window(brc_engine* e, const brc_result* res, const char* chrom, i
     return BRC_E_ARG;
 }
 
+int brc_region_windows(brc_engine* e, const int32_t* vbeg0, const int32_t* vend, int64_t n) {
+    (void)e; (void)vbeg0; (void)vend; (void)n;
+    return BRC_E_ARG;
+}
+
 /* the events recorded by the last brc_compute (the oracle records while it piles up: at most BRC_ORACLE_WARN_CAP, default 64,
  * per type — `cap` can only shorten that); chrom replaces the placeholder of the "B" lines */
 int brc_region_warnings(brc_engine* e, const char* chrom, int64_t cap, const char** events, size_t* events_len) {

@@ -162,12 +162,14 @@ class SimBackend : public Backend {
         Planes pl = {ncol.data(), depth.data(), slotid.data(), si.data(), sf.data(), unavail.data(), xev.data(), &xev_n, (uint32_t)xev.size(), 1u};
         n_events = n_positions = 0; memset(warn, 0, sizeof warn);
         const int64_t ntiles = (P + TILE - 1) / TILE;
+        const std::vector<uint8_t> wanted = st->wanted_tiles(c.pos0, c.P);
         for (int l = 0; l < Lp; ++l) {
             const int64_t s0 = st->lib_base[(size_t)l], s1 = st->lib_base[(size_t)l + 1];
             int32_t m = INT32_MIN;
             for (int64_t i = s0; i < s1; ++i) { if (reach[(size_t)i] > m) m = reach[(size_t)i]; prefmax[(size_t)i] = m; }
             for (int64_t tl = 0; tl < ntiles; ++tl) {                                                 // KB
                 uint32_t lo, hi; tile_range2(c, prefmax.data(), key.data(), s0, s1, tl, lo, hi);
+                if (!wanted.empty() && !wanted[(size_t)tl]) lo = hi = 0;                              // brc_region_windows (k_mask_tiles)
                 pileup_tile(pl, l, tl, lo, hi);
             }
         }

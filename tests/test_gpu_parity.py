@@ -247,3 +247,41 @@ def test_hip_arena_offsets_beyond_2_gib(dev_lib, oracle_lib):
     want, _ = parity.run_engine(oracle_lib, arrs, [(0, 4000)], ref=ref, min_mapq=5, min_bq=10)          # (the small arenas: the oracle's answer)
     got, res = parity.run_engine(dev_lib, big, [(0, 4000)], ref=ref, min_mapq=5, min_bq=10)
     assert got == want and want.count(b"\n") > 3000
+
+
+@pytest.mark.parametrize("case", [c for c in FUZZ if c["style"] in ("indel", "mixed", "clip")][:3] or FUZZ[:3], ids=lambda c: "seed%d-%s" % (c["seed"], c["style"]))
+def test_hip_announced_windows_equal_the_whole_region(dev_lib, case):
+    """brc_region_windows (the site-list planner's hint): every announced window prints what it prints without the hint —
+    deletion carry from its lead position included — and tiles no window touches come back empty."""
+    rng = np.random.default_rng(case["seed"])
+    ref = synth.make_ref(rng, 3000, weird=case.get("weird", 0.0))
+    n_libs = case.get("n_libs", 1)
+    arrs = synth.make_batch(case["seed"] + 100, ref, case["n"], style=case["style"], n_libs=n_libs, p_nolib=case.get("p_nolib", 0.0))
+    names = ["lib%c" % (65 + i) for i in range(n_libs)] if case["opts"].get("per_lib") else ()
+    # single sites, a window over a tile boundary, overlapping and duplicate windows, the region's first and last positions
+    wins = [(0, 1), (5, 6), (63, 65), (64, 65), (127, 129), (700, 760), (730, 731), (730, 731), (1500, 1501), (2047, 2048), (2999, 3000), (2900, 3000)]
+    eng = capi.Engine(dev_lib, lib_names=names, **case["opts"])
+
+    def run(hint):
+        eng.begin_region(0, 0, 3000, ref); eng.push_reads(arrs)
+        if hint:
+            eng.region_windows(np.array([w[0] for w in wins], np.int32), np.array([w[1] for w in wins], np.int32))
+        res = eng.end_region()
+        return [eng.format_window("chrS", b, e, 0) for b, e in wins], res.ncol.copy(), int(res.pos0), int(res.n_pos)
+
+    want, ncol_all, pos0, n_pos = run(False)
+    got, ncol_hint, pos0_h, n_pos_h = run(True)
+    assert got == want and sum(len(t) for t in want) > 0 and (pos0_h, n_pos_h) == (pos0, n_pos)
+    wanted = np.zeros((n_pos + 63) // 64, bool)                      # tiles of the planes [pos0, pos0 + n_pos)
+    for b, e in wins:
+        k0, k1 = max(b - 1 - pos0, 0), min(e - pos0, n_pos)
+        if k1 > k0:
+            wanted[k0 // 64:(k1 - 1) // 64 + 1] = True
+    per_pos = np.repeat(wanted, 64)[:n_pos]
+    assert not ncol_hint[..., ~per_pos].any()                       # nothing piled up outside the announced tiles
+    np.testing.assert_array_equal(ncol_hint[..., per_pos], ncol_all[..., per_pos])
+    assert ncol_all[..., ~per_pos].any()
+    # the hint does not outlive its region
+    eng.begin_region(0, 0, 3000, ref); eng.push_reads(arrs)
+    np.testing.assert_array_equal(eng.end_region().ncol, ncol_all)
+    eng.close()
