@@ -29,6 +29,11 @@
 #else
 #define BRC_HD static inline __attribute__((always_inline))
 #endif
+#if defined(__HIPCC__)
+#define BRC_HDM __host__ __device__ __forceinline__        // (member functions)
+#else
+#define BRC_HDM inline __attribute__((always_inline))
+#endif
 
 namespace brc {
 
@@ -475,43 +480,51 @@ BRC_HD ReadConst read_const(const DevCfg& c, const DRead& rd, uint32_t read_inde
 }
 
 // does the base in front of CIGAR operator k+1.. see an insertion (resolve_cigar2's peek: I, or P ... I)?
-BRC_HD bool peek_insertion(const uint32_t* cig, uint32_t nc, uint32_t k) {
+// (the walks over a read's operators take them through an accessor cig(k): a pointer on the host, in the simulator and in the serial
+// device paths; K1's phase C hands over the first operators in registers — every cig[k] from memory is a dependent round trip for
+// the whole wave there)
+struct CigPtr { const uint32_t* p; BRC_HDM uint32_t operator()(uint32_t k) const { return p[k]; } };
+template <class C>
+BRC_HD bool peek_insertion_at(const C& cig, uint32_t nc, uint32_t k) {
     if (k + 1 >= nc) return false;
-    const uint32_t op2 = cig[k + 1] & 0xfu;
-    if (op2 == CINS) return (cig[k + 1] >> 4) > 0;
+    const uint32_t c1 = cig(k + 1);
+    const uint32_t op2 = c1 & 0xfu;
+    if (op2 == CINS) return (c1 >> 4) > 0;
     if (op2 == CPAD && k + 2 < nc) {
         int l3 = 0;
         for (uint32_t kk = k + 2; kk < nc; ++kk) {
-            const uint32_t o = cig[kk] & 0xfu;
-            if (o == CINS) l3 += (int)(cig[kk] >> 4);
+            const uint32_t ck = cig(kk);
+            const uint32_t o = ck & 0xfu;
+            if (o == CINS) l3 += (int)(ck >> 4);
             else if (o == CDEL || o == CMATCH || o == CREF_SKIP || o == CEQUAL || o == CDIFF) break;
         }
         return l3 > 0;
     }
     return false;
 }
+BRC_HD bool peek_insertion(const uint32_t* cig, uint32_t nc, uint32_t k) { CigPtr a; a.p = cig; return peek_insertion_at(a, nc, k); }
 
 // THE piece decomposition (host: counting at push time; K1: emission; the two must agree, so both call this).
 // f(rs, len, ext, qoff, nb).  `entered`: the read enters pileup columns at all (not dropped at push, has a usable CIGAR).
-template <class F>
-BRC_HD void walk_pieces(bool insertion_centric, bool entered, bool counts, int32_t pos, const uint32_t* cig, uint32_t nc, F f) {
+template <class C, class F>
+BRC_HD void walk_pieces_at(bool insertion_centric, bool entered, bool counts, int32_t pos, const C& cig, uint32_t nc, F f) {
     if (!entered) return;
     int32_t x = pos; int y = 0;
     if (!counts) {
         int32_t rlen = 0;
-        for (uint32_t k = 0; k < nc; ++k) if (is_refop(cig[k] & 0xfu)) rlen += (int32_t)(cig[k] >> 4);
+        for (uint32_t k = 0; k < nc; ++k) { const uint32_t ck = cig(k); if (is_refop(ck & 0xfu)) rlen += (int32_t)(ck >> 4); }
         if (rlen > 0) f(pos, 0, rlen, 0, false);
         return;
     }
     bool have = false; int32_t crs = 0, clen = 0; int cq = 0; bool cnb = false;
     for (uint32_t k = 0; k < nc; ++k) {
-        const uint32_t op = cig[k] & 0xfu; const int32_t len = (int32_t)(cig[k] >> 4);
+        const uint32_t ck = cig(k); const uint32_t op = ck & 0xfu; const int32_t len = (int32_t)(ck >> 4);
         if (is_mop(op)) {
             if (len > 0) {
                 if (have) f(crs, clen, x - crs, cq, cnb);
                 else if (x > pos) f(pos, 0, x - pos, 0, false);              // leading deletion / skip: column only
                 have = true;
-                if (insertion_centric && peek_insertion(cig, nc, k)) {
+                if (insertion_centric && peek_insertion_at(cig, nc, k)) {
                     if (len > 1) f(x, len - 1, len - 1, y, false);
                     crs = x + len - 1; clen = 1; cq = y + len - 1; cnb = true;
                 } else { crs = x; clen = len; cq = y; cnb = false; }
@@ -522,6 +535,11 @@ BRC_HD void walk_pieces(bool insertion_centric, bool entered, bool counts, int32
     }
     if (have) f(crs, clen, x - crs, cq, cnb);
     else if (x > pos) f(pos, 0, x - pos, 0, false);
+}
+
+template <class F>
+BRC_HD void walk_pieces(bool insertion_centric, bool entered, bool counts, int32_t pos, const uint32_t* cig, uint32_t nc, F f) {
+    CigPtr a; a.p = cig; walk_pieces_at(insertion_centric, entered, counts, pos, a, nc, f);
 }
 
 // does a read enter pileup columns?  (bam_plp_push drop rules + a CIGAR resolve_cigar2 can stand on)
@@ -698,26 +716,26 @@ BRC_HD void tile_range2(const DevCfg& c, const int32_t* prefmax_reach, const int
 // (bamreadcount.cpp:288-342): last base of an M/=/X operator followed by I, D or P..I, inside the processing
 // window [beg0-1,end), passing the MAPQ / base-quality filters.
 // qual_row = the read's QUAL bytes (in.qual + qual_off[read])
-template <class F>
-BRC_HD void enumerate_indels(const DevCfg& c, const DevIn& in, const DRead& rd, const uint8_t* qual_row, F emit) {
+template <class C, class F>
+BRC_HD void enumerate_indels_at(const DevCfg& c, const C& cig, const DRead& rd, const uint8_t* qual_row, F emit) {
     if (rd.end <= rd.pos || (rd.misc & M_SIMPLE) || !c.has_ref) return;
     if (((rd.misc >> 16) & 0xffu) == 0) return;                         // library unavailable: position is abandoned
     if ((int)((rd.misc >> 8) & 0xffu) < c.min_mapq || (rd.misc & M_NOCOUNT)) return;
-    const uint32_t* cig = in.cigar + rd.cig_off; const uint32_t nc = rd.n_cigar;
+    const uint32_t nc = rd.n_cigar;
     int32_t x = rd.pos; int y = 0;
     for (uint32_t k = 0; k < nc; ++k) {
-        const uint32_t op = cig[k] & 0xfu; const int len = (int)(cig[k] >> 4);
+        const uint32_t ck = cig(k); const uint32_t op = ck & 0xfu; const int len = (int)(ck >> 4);
         if (is_refop(op)) {
             if (is_mop(op) && len > 0 && k + 1 < nc) {
-                const uint32_t op2 = cig[k + 1] & 0xfu; const int l2 = (int)(cig[k + 1] >> 4);
+                const uint32_t c1 = cig(k + 1); const uint32_t op2 = c1 & 0xfu; const int l2 = (int)(c1 >> 4);
                 int indel = 0;
                 if (op2 == CDEL) indel = -l2;
                 else if (op2 == CINS) indel = l2;
                 else if (op2 == CPAD && k + 2 < nc) {
                     int l3 = 0;
                     for (uint32_t kk = k + 2; kk < nc; ++kk) {
-                        const uint32_t o = cig[kk] & 0xfu;
-                        if (o == CINS) l3 += (int)(cig[kk] >> 4);
+                        const uint32_t ck2 = cig(kk); const uint32_t o = ck2 & 0xfu;
+                        if (o == CINS) l3 += (int)(ck2 >> 4);
                         else if (o == CDEL || o == CMATCH || o == CREF_SKIP || o == CEQUAL || o == CDIFF) break;
                     }
                     if (l3 > 0) indel = l3;
@@ -734,6 +752,11 @@ BRC_HD void enumerate_indels(const DevCfg& c, const DevIn& in, const DRead& rd, 
             if (is_mop(op)) y += len;
         } else if (op == CINS || op == CSOFT_CLIP) y += len;
     }
+}
+
+template <class F>
+BRC_HD void enumerate_indels(const DevCfg& c, const DevIn& in, const DRead& rd, const uint8_t* qual_row, F emit) {
+    CigPtr a; a.p = in.cigar + rd.cig_off; enumerate_indels_at(c, a, rd, qual_row, emit);
 }
 
 // Same allele?  Deletions: same length (the allele text is the reference, identical for equal length);

@@ -436,12 +436,20 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
         r.zm_sum = my_sum; r.sse_add = sse; r.snm_add = snm; r.clipped_dup = clipped;
     }
     if (nc >= 2u) reads[my] = r;          // only the indel side path reads these records, and only for reads with an indel operator
+    // The read's first three operators in registers for the two walks below (three independent loads, issued together; the
+    // first operator is still there from phase A): each cig[k] from memory inside a walk is a dependent round trip for the whole wave.
+    struct CigRegs {
+        uint32_t c0, c1, c2; const uint32_t* p;
+        __device__ __forceinline__ uint32_t operator()(uint32_t k) const { return k == 0u ? c0 : k == 1u ? c1 : k == 2u ? c2 : p[k]; }
+    } cigr;
+    cigr.p = cigar_ro + coff; cigr.c0 = cig0;
+    cigr.c1 = nc > 1u ? cigr.p[1] : 0u; cigr.c2 = nc > 2u ? cigr.p[2] : 0u;
     {   // the read's pieces (the host counted them with the same walk_pieces: piece_off[] are their slots)
         const bool nolib = c.per_lib && in.lib[my] < 0;
         const bool enters = r.end > r.pos && pos >= 0;
         const ReadConst rc = read_const(c, r, (uint32_t)my);
         uint32_t slot = piece_off[my];
-        walk_pieces(c.insertion_centric != 0, enters && !nolib, rc.counts, pos, cigar_ro + coff, nc, [&](int32_t rs, int32_t len, int32_t ext, int qoff, bool nb) {
+        walk_pieces_at(c.insertion_centric != 0, enters && !nolib, rc.counts, pos, cigr, nc, [&](int32_t rs, int32_t len, int32_t ext, int qoff, bool nb) {
             Piece h; PieceRare rr;
             make_piece(c, rc, rs, len, ext, qoff, nb, h, rr);
             if (c.ann_variant != 2) {
@@ -461,7 +469,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
         // slots the read does not use are marked empty
         const int lib = (int)((r.misc >> 16) & 0xffu) - 1;
         IndelEv* slot = ev_raw + in.iev_off[my]; uint32_t used = 0;
-        enumerate_indels(c, in, r, qual_ro + qoff, [&](int32_t p, int qpos, int len) {
+        enumerate_indels_at(c, cigr, r, qual_ro + qoff, [&](int32_t p, int qpos, int len) {
             IndelEv e; e.read = (uint32_t)my; e.qpos = qpos; e.len = len; e.key_lo = (uint32_t)((int64_t)(p - c.pos0) * c.Lp + lib);   // (keys fit 32 bits: checked at upload)
             if (used < n_idp) { slot[used++] = e; atomicAdd(&bucket_cnt[indel_bucket_of(c, (uint32_t)(p - c.pos0), (uint32_t)lib)], 1u); }
         });
