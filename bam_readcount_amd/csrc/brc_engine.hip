@@ -386,6 +386,16 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
     }
     // ---- phase C
     if (!have || c.ann_variant == 4) return;
+    // everything phase C reads from memory whose address is known by now, requested together (each load left to the place of its
+    // use is one more dependent round trip for the wave: lane = read here, nothing else hides it)
+    const uint32_t mapq_l = in.mapq[my], tags_l = in.tags[my];
+
+    const int lib_l = c.per_lib ? (int)in.lib[my] : 0;
+
+    const uint32_t cig1_l = nc > 1u ? cigar_ro[coff + 1u] : 0u, cig2_l = nc > 2u ? cigar_ro[coff + 2u] : 0u;
+    const bool q2_pre = work_me && L >= 8;             // the 8 qualities at the read's 3' end: as a rule all the Q2 scan needs
+    unsigned long long q2_w0 = 0ull;
+    if (q2_pre) __builtin_memcpy(&q2_w0, qual_ro + qoff + ((flag & FREVERSE) ? 0 : L - 8), 8);
     DRead r;
     bool serial = fallback;
     uint32_t my_sum = 0; int my_hi = -1, my_lo = -1;
@@ -398,14 +408,14 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
         if (flag & FREVERSE) {
             for (int k = 0; k < L && my_lo < 0; k += 8) {
                 unsigned long long w; const int nv = L - k < 8 ? L - k : 8;
-                if (nv == 8) __builtin_memcpy(&w, q + k, 8); else { w = 0x0202020202020202ull; for (int j = 0; j < nv; ++j) w = (w & ~(0xffull << (8 * j))) | ((unsigned long long)q[k + j] << (8 * j)); }
+                if (k == 0 && q2_pre) w = q2_w0; else if (nv == 8) __builtin_memcpy(&w, q + k, 8); else { w = 0x0202020202020202ull; for (int j = 0; j < nv; ++j) w = (w & ~(0xffull << (8 * j))) | ((unsigned long long)q[k + j] << (8 * j)); }
                 const unsigned long long x = w ^ 0x0202020202020202ull;                    // zero bytes: quality 2
                 if (x) my_lo = k + (__builtin_ctzll(x) >> 3);
             }
         } else {
             for (int k = L; k > 0 && my_hi < 0; k -= 8) {
                 unsigned long long w; const int lo8 = k - 8;
-                if (lo8 >= 0) __builtin_memcpy(&w, q + lo8, 8); else { w = 0x0202020202020202ull; for (int j = 0; j < k; ++j) w = (w & ~(0xffull << (8 * (j - lo8)))) | ((unsigned long long)q[j] << (8 * (j - lo8))); }
+                if (k == L && q2_pre) w = q2_w0; else if (lo8 >= 0) __builtin_memcpy(&w, q + lo8, 8); else { w = 0x0202020202020202ull; for (int j = 0; j < k; ++j) w = (w & ~(0xffull << (8 * (j - lo8)))) | ((unsigned long long)q[j] << (8 * (j - lo8))); }
                 const unsigned long long x = w ^ 0x0202020202020202ull;
                 if (x) my_hi = lo8 + ((63 - __builtin_clzll(x)) >> 3);
             }
@@ -418,10 +428,10 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
         int tp, q2;
         if (rev) { tp = 0; if (tp < left_clip) tp = left_clip; q2 = my_lo >= 0 ? my_lo - 1 : -1; if (tp < q2) tp = q2; }
         else { tp = L - 1; if (tp > right_clip) tp = right_clip; q2 = my_hi >= 0 ? my_hi - 1 : -1; if (tp > q2 && q2 != -1) tp = q2; }
-        const uint32_t mapq = in.mapq[my]; const uint32_t tags = in.tags[my];
+        const uint32_t mapq = mapq_l; const uint32_t tags = tags_l;
         r.pos = pos; r.end = dropped ? pos : pos + rlen;
         r.cig_off = coff; r.n_cigar = nc; r.bq_off = brow;
-        const int lib = c.per_lib ? (int)in.lib[my] : 0;
+        const int lib = lib_l;
         uint32_t misc = (mapq << 8) | ((uint32_t)((lib + 1) & 0xff) << 16);
         if (rev) misc |= M_REV;
         if (flag & BRC_NOCOUNT_MASK) misc |= M_NOCOUNT;
@@ -436,16 +446,16 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
         r.zm_sum = my_sum; r.sse_add = sse; r.snm_add = snm; r.clipped_dup = clipped;
     }
     if (nc >= 2u) reads[my] = r;          // only the indel side path reads these records, and only for reads with an indel operator
-    // The read's first three operators in registers for the two walks below (three independent loads, issued together; the
+    // The read's first three operators in registers for the two walks below (loaded at the start of the phase; the
     // first operator is still there from phase A): each cig[k] from memory inside a walk is a dependent round trip for the whole wave.
     struct CigRegs {
         uint32_t c0, c1, c2; const uint32_t* p;
         __device__ __forceinline__ uint32_t operator()(uint32_t k) const { return k == 0u ? c0 : k == 1u ? c1 : k == 2u ? c2 : p[k]; }
     } cigr;
     cigr.p = cigar_ro + coff; cigr.c0 = cig0;
-    cigr.c1 = nc > 1u ? cigr.p[1] : 0u; cigr.c2 = nc > 2u ? cigr.p[2] : 0u;
+    cigr.c1 = cig1_l; cigr.c2 = cig2_l;
     {   // the read's pieces (the host counted them with the same walk_pieces: piece_off[] are their slots)
-        const bool nolib = c.per_lib && in.lib[my] < 0;
+        const bool nolib = c.per_lib && lib_l < 0;
         const bool enters = r.end > r.pos && pos >= 0;
         const ReadConst rc = read_const(c, r, (uint32_t)my);
         uint32_t slot = piece_off[my];
