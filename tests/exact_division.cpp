@@ -21,6 +21,17 @@ int main() {
             if (k >= 0 && k < cl) { const unsigned m = brc::absdiff_u(2u * (unsigned)k, (unsigned)cl); if (bits(d / c) != bits((float)m / (float)cl)) ++bad; }
         }
     }
+    for (int cl = 1; cl <= 512; ++cl) {                     // the event-location term of a soft-clipped read as k_pileup2 divides it out (PF_TABQ)
+        const float c = (float)cl * 0.5f;
+        const int lefts[4] = {0, 1, 37, 511};
+        for (int li = 0; li < 4; ++li)
+            for (int k = 0; k < cl; ++k, ++tot) {
+                float d = (float)k - c; d = d < 0 ? -d : d;
+                const double want = 1.0 - (double)(d / c);                 // event_terms (BasicStat.cpp:69-70)
+                const double got = brc::tabq_sev(lefts[li] + k, lefts[li], (uint32_t)cl);
+                if (memcmp(&want, &got, 8) != 0) ++bad;
+            }
+    }
     srand(7);
     for (long it = 0; it < 20000000; ++it, ++tot) {         // long reads, sampled
         const int L = 1 + rand() % 3000000, n = rand() % (L + 1);
