@@ -251,6 +251,8 @@ def main():
         res_libs = len(names) if per_lib else 1
         # ---- roofline of the dominant kernel
         eng_events, eng_positions = eng.counts()
+        if args.mode == "sites":
+            eng_positions = n_positions          # SURVEY 8d's B_out counts the lines printed: the requested sites, not what their tiles hold besides
         b_in, b_ref, b_out = synthgen.algorithmic_bytes(region_reads, eng_positions, res_libs, 0, ref_positions=region_len)
         alg = b_in + b_ref + b_out
         achieved = alg / (kms[k_pile] * 1e-3) / 1e9 if kms[k_pile] > 0 else 0.0
