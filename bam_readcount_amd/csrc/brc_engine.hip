@@ -714,11 +714,20 @@ __global__ __launch_bounds__(TR_T) void k_tiles_all(DevCfg c, const int2* __rest
     }
 }
 
-// brc_region_windows: tiles no announced window touches get an empty piece range — k_pileup2 then leaves their planes empty
-__global__ __launch_bounds__(256) void k_mask_tiles(const uint8_t* __restrict__ wanted, int64_t ntiles, int Lp, uint2* __restrict__ rng) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= ntiles * Lp) return;
-    if (!wanted[i % ntiles]) rng[i] = make_uint2(0u, 0u);
+// brc_region_windows: tiles no announced window touches are not piled up.  This kernel leaves their columns empty (no column, no
+// depth, no slot: what the host reads first of a position) and marks their piece range lo > hi, at which k_pileup2 returns at once —
+// without it the pileup kernel would spend most of a site list's time storing zeros for the 300-odd positions a line's reads
+// cover around the one or two the line asked for.
+__global__ __launch_bounds__(256) void k_mask_tiles(const uint8_t* __restrict__ wanted, int64_t ntiles, int Lp, int64_t P, int64_t PS, uint2* __restrict__ rng,
+                                                    uint32_t* __restrict__ ncol, uint32_t* __restrict__ depth, uint32_t* __restrict__ slotid, uint4* __restrict__ tile_ctr) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;           // (library, tile, lane)
+    const int64_t lt = i >> 6; const int lane = (int)(i & 63);
+    if (lt >= ntiles * Lp) return;
+    const int64_t tile = lt % ntiles, lib = lt / ntiles;
+    if (wanted[tile]) return;
+    const int64_t k = tile * TILE + lane;
+    if (k < P) { ncol[lib * PS + k] = 0u; depth[lib * PS + k] = 0u; slotid[lib * PS + k] = (uint32_t)NB_NONE | ((uint32_t)NB_NONE << 8); }
+    if (lane == 0) { rng[lt] = make_uint2(1u, 0u); tile_ctr[lt] = make_uint4(0u, 0u, 0u, 0u); }
 }
 
 // ---------------------------------------------------------------- KB: pileup + BasicStat accumulation (the hot kernel)
@@ -780,6 +789,8 @@ struct PRec { u32x8 f; u32x2 g; };
 #ifndef BRC_WAVES_PER_EU
 #define BRC_WAVES_PER_EU 7      // 72 VGPRs: 16 values spill into the rare paths (measured: 6 waves 3.92 ms, 7 waves 3.78 ms, 8 waves 5.6 ms — spills reach the loop)
 #endif
+template <bool WINDOWS>      // brc_region_windows is in force: tiles whose range k_mask_tiles marked lo > hi are skipped (an instantiation of its own: the
+                             // common one stays the code that was measured — one more branch at its head moved its register allocation and cost 2.4 %)
 __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_eu(BRC_WAVES_PER_EU, BRC_WAVES_PER_EU))) void k_pileup2(DevCfg c, DevIn in, const uint4* __restrict__ pieces4, const PieceRare* __restrict__ rare,
                                                                const uint2* __restrict__ rng, int64_t ntiles, Planes pl, uint4* __restrict__ tile_ctr,
                                                                const uint16_t* __restrict__ bq_ro, const uint32_t* __restrict__ unavail_ro,
@@ -815,6 +826,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
     const int lib = blockIdx.y;
     const uint2 r2 = rng[(int64_t)lib * ntiles + tile];
     const uint32_t lo = __builtin_amdgcn_readfirstlane(r2.x), hi = __builtin_amdgcn_readfirstlane(r2.y);
+    if (WINDOWS && lo > hi) return;           // (a tile nobody asked for: k_mask_tiles has emptied its columns)
     const int64_t k = tile * TILE + lane;
     const bool inreg = k < c.P;
     const int64_t kk = inreg ? k : 0;
@@ -1622,16 +1634,23 @@ class HipBackend : public Backend {
             hipLaunchKernelGGL(k_tiles_all, dim3((unsigned)trb), dim3(TR_T), 0, stream, c, (const int2*)d_keyreach.p, np_all, (const int64_t*)d_libbase.p, Lp,
                                (const unsigned long long*)d_agg.p, ntiles, (uint2*)d_rng.p);
         if (has_wanted && ntiles > 0)
-            hipLaunchKernelGGL(k_mask_tiles, dim3((unsigned)((ntiles * Lp + 255) / 256)), dim3(256), 0, stream, (const uint8_t*)d_wanted.p, ntiles, Lp, (uint2*)d_rng.p);
+            hipLaunchKernelGGL(k_mask_tiles, dim3((unsigned)((ntiles * Lp * 64 + 255) / 256)), dim3(256), 0, stream, (const uint8_t*)d_wanted.p, ntiles, Lp, (int64_t)c.P, (int64_t)c.PS, (uint2*)d_rng.p,
+                               (uint32_t*)d_ncol.p, (uint32_t*)d_depth.p, (uint32_t*)d_slotid.p, (uint4*)d_tilectr.p);
         HIPCHK(hipEventRecord(evt[T_PILEUP], stream));
         if (ntiles > 0) {
             unsigned nwg = (unsigned)((ntiles + PILEUP_WAVES - 1) / PILEUP_WAVES);
             nwg = (nwg + 7u) & ~7u;
             // profiling knob: unused dynamic LDS lowers the number of resident waves (occupancy sweeps)
             static const unsigned dyn_lds = getenv("BRC_PILEUP_LDS_PAD") ? (unsigned)atoi(getenv("BRC_PILEUP_LDS_PAD")) : 0u;
-            hipLaunchKernelGGL(k_pileup2, dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), dyn_lds, stream, c, in, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p,
+if (has_wanted) {
+                            hipLaunchKernelGGL((k_pileup2<true>), dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), dyn_lds, stream, c, in, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p,
                                (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.bq, (const uint32_t*)d_unavail.p,
                                (const uint8_t*)d_refcode.p + REFCODE_PAD);
+            } else {
+                            hipLaunchKernelGGL((k_pileup2<false>), dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), dyn_lds, stream, c, in, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p,
+                               (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.bq, (const uint32_t*)d_unavail.p,
+                               (const uint8_t*)d_refcode.p + REFCODE_PAD);
+            }
             hipLaunchKernelGGL(k_xev_compact, dim3((unsigned)XEV_SHARDS), dim3(256), 0, stream, (const XEv*)d_xev.p, (const uint32_t*)d_xevn.p, (uint32_t)xev_cap,
                                (uint32_t)XEV_SHARDS, (XEv*)d_xevc.p, ctr);
         }

@@ -106,34 +106,40 @@ def main():
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-O3", "-std=c++17", "-ffp-contract=off"] + extra + [SRC, "-o", "-"]
     asm = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
     lines = asm.split("\n")
-    start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN3brc9k_pileup2.*:", l))
-    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
-    body = lines[start + 1:end]
-    meta = {k: int(re.search(r"k_pileup2\S*\.%s, (\d+)" % k, asm).group(1)) for k in ("num_vgpr", "numbered_sgpr", "private_seg_size")}
-    loop = [i for i, l in enumerate(body) if "Loop Header: Depth=1" in l]
-    tail = body[loop[-1]:] if loop else body
-    count = lambda pred: sum(1 for l in tail if pred(l.strip()))
-    if not quiet:
-        print("k_pileup2: %(num_vgpr)d VGPRs, %(numbered_sgpr)d SGPRs, %(private_seg_size)d bytes of scratch per lane" % meta)
-        print("from the piece loop on: %d VALU, %d SALU, %d scratch, %d v_writelane / v_readlane instructions (static counts)" % (
-            count(lambda l: l.startswith("v_")), count(lambda l: l.startswith("s_")), count(lambda l: l.startswith("scratch_")),
-            count(lambda l: l.startswith("v_writelane") or l.startswith("v_readlane"))))
-    ins, labels = parse(body)
-    nloads, errors = check_loads(ins, labels)
+    # every instantiation of the kernel (k_pileup2<false>: the common one; k_pileup2<true>: with brc_region_windows in force)
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN3brc9k_pileup2\S*:", l)]
+    if not starts:
+        print("check_isa: no k_pileup2 in the assembly"); sys.exit(1)
     rc = 0
-    if nloads < 6:
-        print("check_isa: expected the read loop's inline-assembly scalar loads, found %d" % nloads); rc = 1
-    if errors:
-        print("check_isa: UNSOUND early scalar loads in k_pileup2 (%d):" % len(errors))
-        for e in errors[:20]:
-            print("  " + e)
-        rc = 1
-    elif not quiet:
-        print("early scalar loads: %d inline-assembly loads, no instruction touches their registers before the wait on any path" % nloads)
-    if max_vgpr is not None and meta["num_vgpr"] > max_vgpr:
-        print("check_isa: %d VGPRs > %d" % (meta["num_vgpr"], max_vgpr)); rc = 1
-    if max_scratch is not None and meta["private_seg_size"] > max_scratch:
-        print("check_isa: %d bytes of scratch > %d" % (meta["private_seg_size"], max_scratch)); rc = 1
+    for start in starts:
+        sym = re.match(r"^(_ZN3brc9k_pileup2[^\s:]*):", lines[start]).group(1)
+        tag = "k_pileup2<true>" if "ILb1E" in sym else "k_pileup2<false>" if "ILb0E" in sym else "k_pileup2"
+        end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+        body = lines[start + 1:end]
+        meta = {k: int(re.search(r"%s\.%s, (\d+)" % (re.escape(sym), k), asm).group(1)) for k in ("num_vgpr", "numbered_sgpr", "private_seg_size")}
+        loop = [i for i, l in enumerate(body) if "Loop Header: Depth=1" in l]
+        tail = body[loop[-1]:] if loop else body
+        count = lambda pred: sum(1 for l in tail if pred(l.strip()))
+        if not quiet:
+            print("%s: %d VGPRs, %d SGPRs, %d bytes of scratch per lane" % (tag, meta["num_vgpr"], meta["numbered_sgpr"], meta["private_seg_size"]))
+            print("from the piece loop on: %d VALU, %d SALU, %d scratch, %d v_writelane / v_readlane instructions (static counts)" % (
+                count(lambda l: l.startswith("v_")), count(lambda l: l.startswith("s_")), count(lambda l: l.startswith("scratch_")),
+                count(lambda l: l.startswith("v_writelane") or l.startswith("v_readlane"))))
+        ins, labels = parse(body)
+        nloads, errors = check_loads(ins, labels)
+        if nloads < 6:
+            print("check_isa: %s: expected the read loop's inline-assembly scalar loads, found %d" % (tag, nloads)); rc = 1
+        if errors:
+            print("check_isa: UNSOUND early scalar loads in %s (%d):" % (tag, len(errors)))
+            for e in errors[:20]:
+                print("  " + e)
+            rc = 1
+        elif not quiet:
+            print("early scalar loads: %d inline-assembly loads, no instruction touches their registers before the wait on any path" % nloads)
+        if max_vgpr is not None and meta["num_vgpr"] > max_vgpr:
+            print("check_isa: %s: %d VGPRs > %d" % (tag, meta["num_vgpr"], max_vgpr)); rc = 1
+        if max_scratch is not None and meta["private_seg_size"] > max_scratch:
+            print("check_isa: %s: %d bytes of scratch > %d" % (tag, meta["private_seg_size"], max_scratch)); rc = 1
     sys.exit(rc)
 
 

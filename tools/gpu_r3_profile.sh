@@ -28,7 +28,7 @@ for cfg in ("wgs30x", "tumor200x"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(O, "pmc_%s_*_raw.csv" % cfg)):
         for r in csv.DictReader(open(f)):
-            acc[r["Kernel_Name"].split("(")[0].split("::")[-1]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            acc[r["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out[cfg] = {k: {c: round(sum(v) / len(v)) for c, v in d.items()} for k, d in acc.items()}
     p = out[cfg].get("k_pileup2", {})
     if "FETCH_SIZE" in p and "WRITE_SIZE" in p:
