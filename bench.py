@@ -96,7 +96,8 @@ def site_batch(np, capi, arrs, ref, sites, window=384, lead=170):
     # unit of work: reads covering the reported position s - 1 itself (the fetch also returns reads that only
     # cover the lead position s - 2)
     events = int(((pos[ridx] <= sites[sidx] - 1) & (ends[ridx] > sites[sidx] - 1)).sum())
-    return sub, vref, events
+    vbeg0 = np.arange(len(sites), dtype=np.int64) * window + lead - 1          # the lines themselves on the virtual axis: [vbeg0, vbeg0 + 1)
+    return sub, vref, events, vbeg0
 
 
 def main():
@@ -188,7 +189,7 @@ def main():
     if args.mode == "sites":
         n_mine = args.sites // world + (1 if rank < args.sites % world else 0)
         sites = np.sort(np.random.default_rng(3 + rank).integers(200, contig_len - 200, n_mine))      # 1-based site == 0-based end
-        sub, vref, site_events = site_batch(np, capi, arrs, ref, sites)
+        sub, vref, site_events, site_vbeg0 = site_batch(np, capi, arrs, ref, sites)
         region_len, region_ref, region_reads = len(vref), vref, sub
     else:
         region_len, region_ref, region_reads = contig_len, ref, arrs
@@ -197,8 +198,7 @@ def main():
     eng.push_reads(region_reads)
     if args.mode == "sites" and not os.environ.get("BRC_BENCH_NO_WINDOWS"):
         # the planner announces the lines it is going to cut out (brc_region_windows): only their tiles are piled up
-        vb = np.arange(len(sites), dtype=np.int64) * 384 + 170 - 1
-        eng.region_windows(vb.astype(np.int32), (vb + 1).astype(np.int32))
+        eng.region_windows(site_vbeg0.astype(np.int32), (site_vbeg0 + 1).astype(np.int32))
     t_push = time.time() - t0
     t0 = time.time()
     eng.upload()                                  # inputs resident in HBM from here on
@@ -302,7 +302,7 @@ def main():
                 t0c = time.perf_counter()                                     # the oracle's own work: staging, pileup, text (not the numpy selection)
                 oe.begin_region(0, sp - 1, sp, ref); oe.push_reads(sel)
                 oe.end_region(); want = oe.format_region("chrS"); oe.clear_indel_queue(); tcpu += time.perf_counter() - t0c; oev += oe.counts()[0]
-                d = int(i) * 384 + 170 - sp
+                d = int(site_vbeg0[i]) + 1 - sp
                 got = eng.format_window("chrS", sp - 1 + d, sp + d, d)
                 assert got == want, "site %d (position %d): the planner's line differs from the oracle's" % (i, sp)
             oe.close()
