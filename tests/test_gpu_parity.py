@@ -285,3 +285,29 @@ def test_hip_announced_windows_equal_the_whole_region(dev_lib, case):
     eng.begin_region(0, 0, 3000, ref); eng.push_reads(arrs)
     np.testing.assert_array_equal(eng.end_region().ncol, ncol_all)
     eng.close()
+
+
+def test_hip_region_windows_argument_handling(dev_lib):
+    """brc_region_windows: only inside an open region, windows must not end before they begin, windows outside the planes are
+    clipped away, n = 0 withdraws the hint."""
+    rng = np.random.default_rng(7)
+    ref = synth.make_ref(rng, 2000)
+    arrs = synth.make_batch(107, ref, 300, style="mixed")
+    eng = capi.Engine(dev_lib, min_mapq=0, min_bq=0)
+    with pytest.raises(capi.BrcError):
+        eng.region_windows(np.array([5], np.int32), np.array([6], np.int32))            # no open region
+    eng.begin_region(0, 0, 2000, ref); eng.push_reads(arrs)
+    with pytest.raises(capi.BrcError):
+        eng.region_windows(np.array([10], np.int32), np.array([9], np.int32))           # ends before it begins
+    eng.region_windows(np.array([100], np.int32), np.array([101], np.int32))
+    eng.region_windows(np.zeros(0, np.int32), np.zeros(0, np.int32))                    # withdrawn: everything is piled up
+    whole = eng.end_region(); ncol_all = whole.ncol.copy(); text_all = eng.format_window("chrS", 100, 101, 0)
+    assert ncol_all.any()
+    eng.begin_region(0, 0, 2000, ref); eng.push_reads(arrs)
+    eng.region_windows(np.array([-500, 100, 1_000_000], np.int32), np.array([-400, 101, 1_000_001], np.int32))   # two of them miss the planes
+    res = eng.end_region()
+    assert eng.format_window("chrS", 100, 101, 0) == text_all
+    k = 100 - 1 - int(res.pos0)
+    keep = np.zeros(int(res.n_pos), bool); keep[(k // 64) * 64:((100 - int(res.pos0) - 1) // 64 + 1) * 64] = True
+    assert not res.ncol[..., ~keep].any() and np.array_equal(res.ncol[..., keep], ncol_all[..., keep])
+    eng.close()
