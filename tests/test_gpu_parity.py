@@ -311,3 +311,29 @@ def test_hip_region_windows_argument_handling(dev_lib):
     keep = np.zeros(int(res.n_pos), bool); keep[(k // 64) * 64:((100 - int(res.pos0) - 1) // 64 + 1) * 64] = True
     assert not res.ncol[..., ~keep].any() and np.array_equal(res.ncol[..., keep], ncol_all[..., keep])
     eng.close()
+
+
+@pytest.mark.parametrize("env", [{}, {"BRC_PACK_LIM": "90"}, {"BRC_PACK_LIM": "90", "BRC_FLUSH_K": "5"}, {"BRC_FORCE_DOM": "3", "BRC_PACK_LIM": "90"}],
+                         ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()) or "default")
+def test_hip_table_piece_flag_combinations(dev_lib, oracle_lib, monkeypatch, env):
+    """Reads of ONE length, so that nearly every piece is a table piece of k_pileup2 — and then every way of not being one behind
+    the kernel's single flag test: soft-clipped reads (PF_TABQ: the event location divided out in the lane), -i's one-base pieces
+    (PF_NB), pieces with huge integers (PF_HUGE, forced by a small packing limit: both a former table piece and a soft-clipped
+    one), reads without a Q2 position, other lengths (rare record + exact divisions).  Same bits as the oracle."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(41)
+    ref = synth.make_ref(rng, 4000, weird=0.01)
+    same = synth.make_batch(411, ref, 900, read_len=(100, 100), style="mixed", n_libs=2, p_nolib=0.01, p_q2tail=0.4, mismatch=0.04)
+    other = synth.make_batch(412, ref, 60, read_len=(40, 140), style="mixed", n_libs=2)
+    both = {}                                                     # the two batches as one, in coordinate order
+    for k in ("pos", "flag", "mapq", "lib", "l_qseq", "n_cigar", "nm", "sm", "tags", "cigar", "seq4", "qual"):
+        both[k] = np.concatenate([np.asarray(same[k]), np.asarray(other[k])])
+    for k, arena in (("cigar_off", "cigar"), ("seq_off", "seq4"), ("qual_off", "qual")):
+        both[k] = np.concatenate([np.asarray(same[k]), np.asarray(other[k]) + np.uint64(len(same[arena]))])
+    arrs = capi.select_reads(both, np.argsort(both["pos"], kind="stable"))
+    names = ["libA", "libB"]
+    parity.compare_libs(dev_lib, oracle_lib, arrs, [(0, 4000), (2000, 2001)], ref=ref, lib_names=names, per_lib=True, insertion_centric=True, check_warn=False)
+    parity.compare_libs(dev_lib, oracle_lib, arrs, [(0, 4000)], ref=ref, min_mapq=10, min_bq=12)
+    deep = synth.make_batch(413, ref, 2500, read_len=(100, 100), style="mixed", region=(1500, 1900), mismatch=0.03)        # ~600x of one length
+    parity.compare_libs(dev_lib, oracle_lib, deep, [(1400, 2100)], ref=ref, insertion_centric=True)
