@@ -69,9 +69,9 @@ struct DevCfg {
     int64_t ref_len;        // contig length (positions >= ref_len read as NUL)
     int64_t n_reads;
     int32_t table_len;      // L0: modal read length of the region (host); reads with l_qseq == clipped == L0 take their terms from tables
-    int32_t variant;        // 0 in production; >0 = profiling ablations selected by BRC_PILEUP_VARIANT (see brc_engine.hip)
+    int32_t variant;        // always 0 in the product; experiment builds (-DBRC_EXP_KNOBS) put BRC_PILEUP_VARIANT here (see brc_engine.hip)
     int32_t ibucket_shift;  // log2 of the positions per indel bucket (indel_bucket_shift)
-    int32_t ann_variant;    // 0 in production; >0 = profiling ablations of K1 selected by BRC_ANN_VARIANT (wrong results, timing only)
+    int32_t ann_variant;    // always 0 in the product; experiment builds: BRC_ANN_VARIANT (ablations of K1: wrong results, timing only)
     int32_t force_dom;      // test knob (BRC_FORCE_DOM): -1, or the bucket every lane treats as dominant (stresses the alternate / third-allele paths)
     int64_t n_pieces;       // pieces of all libraries (KB v2)
     int32_t flush_k;        // K: pieces a lane may accumulate in its packed integer registers between two flushes (1..127)

@@ -45,6 +45,18 @@ struct Counters {
     unsigned int xev_max, pad_;          // fullest sub-list's cursor (above its capacity: grow and compute again)
 };
 
+// Profiling ablations that switch parts of the kernels off (wrong results, timing only) exist only in experiment builds
+// (tools/build_variant.sh passes -DBRC_EXP_KNOBS; such a library then reads BRC_PILEUP_VARIANT / BRC_ANN_VARIANT).  In the product
+// both tests are the constant `false`: the shipped library contains neither the code nor the names of the knobs
+// (tests/test_abi.py::test_product_ignores_ablation_environment).
+#ifdef BRC_EXP_KNOBS
+#define BRC_PVAR(n) (c.variant == (n))
+#define BRC_AVAR(n) (c.ann_variant == (n))
+#else
+#define BRC_PVAR(n) false
+#define BRC_AVAR(n) false
+#endif
+
 // ---------------------------------------------------------------- wave helpers (wave64)
 
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
@@ -63,6 +75,16 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// minimum over the 64 lanes of a 64-bit value, wave-uniform (scalar registers)
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t u = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64) << 32) | (uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)v, o, 64);
+        v = u < v ? u : v;
+    }
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
 }
 
 // the value of the lane below / above (lane 0 / lane 63 get 0): one DPP move on the gfx9 wave-shift network
@@ -133,7 +155,8 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
                                                          Piece* __restrict__ pieces, PieceRare* __restrict__ rare, int2* __restrict__ keyreach,
                                                          uint16_t* __restrict__ bq, IndelEv* __restrict__ ev_raw, uint32_t* __restrict__ bucket_cnt,
                                                          const uint32_t* __restrict__ cigar_ro, const uint8_t* __restrict__ qual_ro,
-                                                         const uint8_t* __restrict__ seq_ro, const uint8_t* __restrict__ refcode) {
+                                                         const uint8_t* __restrict__ seq_ro, const uint8_t* __restrict__ refcode,
+                                                         const uint8_t* __restrict__ wanted /* brc_region_windows: 1 per announced tile, or null */) {
     struct WaveLds { AnnPar par[64]; uint32_t sum[64]; uint32_t redo[64]; uint32_t G[64]; unsigned long long mark; };
     __shared__ WaveLds lds_all[4];
     const int lane = threadIdx.x & 63;
@@ -181,18 +204,21 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
     if (nc == 1 && !is_mop(cig0 & 0xfu)) dropped = true;
     // query ranges are clamped to the read (malformed CIGARs), reference offsets must fit the 32-bit slice index
     if (m1hi > L) m1hi = L; if (m2hi > L) m2hi = L; if (m1lo > m1hi) m1lo = m1hi; if (m2lo > m2hi) m2lo = m2hi;
+    // The per-base pass addresses QUAL / SEQ as a wave-uniform 64-bit base + a 32-bit lane offset.  The base is the SMALLEST
+    // offset of the wave's reads (a batch may lay its rows out in any order — brc.h only asks for offsets inside the arenas —
+    // so lane 0's row need not be the first); a read whose row starts 4 GiB or more above it takes the serial path, which
+    // addresses with 64 bits.  (readfirstlane returns int: without the uint32_t casts a low half with bit 31 set sign-extends into
+    // the high half — arenas beyond 2 GB then read 4 GB below their rows; tests/test_gpu_parity.py::test_hip_arena_offsets_beyond_2_gib)
+    const uint64_t qbase = wave_min_u64(qoff), sbase = wave_min_u64(soff);
     const bool fallback = !c.has_ref || pos < 0 || (int64_t)pos + rlen > c.ref_len || n_m > 2 ||
-                          d1 < -(int64_t)L || d2 < -(int64_t)L || d1 > 0x7fff0000ll || d2 > 0x7fff0000ll;
+                          d1 < -(int64_t)L || d2 < -(int64_t)L || d1 > 0x7fff0000ll || d2 > 0x7fff0000ll ||
+                          qoff - qbase > 0xff000000ull || soff - sbase > 0xff000000ull;
     const bool work_me = have && !dropped && !fallback && L > 0;
     const unsigned long long work = __ballot(work_me);
     const int nd = __builtin_popcountll(work);                               // dense reads of this wave
     const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(work >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)work, 0u));
-    // (readfirstlane returns int: without the uint32_t casts a low half with bit 31 set sign-extends into the high half — arenas
-    // beyond 2 GB then read 4 GB below their rows; tests/test_gpu_parity.py::test_hip_arena_offsets_beyond_2_gib)
-    const uint64_t qbase = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)qoff) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(qoff >> 32)) << 32);
-    const uint64_t sbase = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)soff) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(soff >> 32)) << 32);
     uint32_t T = 0;
-    if (c.ann_variant == 5) return;
+    if (BRC_AVAR(5)) return;
     if (nd) {
         if (work_me) {
             AnnPar p;
@@ -251,7 +277,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
             __builtin_memcpy(&F.R1, refpad + (uint32_t)((int32_t)r1off + REFCODE_PAD), 8);
             return F;
         };
-        if (c.ann_variant == 3) T = 0;
+        if (BRC_AVAR(3)) T = 0;
         Fetch Fn = fetch(0u);
         for (uint32_t base = 0; base < T; base += 64u) {
             const Fetch F = Fn;
@@ -312,7 +338,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
                 Bk.x = (hx & mx) | (lx & ~mx); Bk.y = (hy & my2) | (ly & ~my2);
             }
             // ---- the event words for KB: quality << 8 | bucket per base; the row is padded to 8 elements
-            if (act && c.ann_variant != 1) {
+            if (act && !BRC_AVAR(1)) {
                 uint4 out;
                 out.x = __builtin_amdgcn_perm(Bk.x, Q.x, 0x01050004u); out.y = __builtin_amdgcn_perm(Bk.x, Q.x, 0x03070206u);
                 out.z = __builtin_amdgcn_perm(Bk.y, Q.y, 0x01050004u); out.w = __builtin_amdgcn_perm(Bk.y, Q.y, 0x03070206u);
@@ -385,7 +411,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
     // ---- phase C
-    if (!have || c.ann_variant == 4) return;
+    if (!have || BRC_AVAR(4)) return;
     // everything phase C reads from memory whose address is known by now, requested together (each load left to the place of its
     // use is one more dependent round trip for the wave: lane = read here, nothing else hides it)
     const uint32_t mapq_l = in.mapq[my], tags_l = in.tags[my];
@@ -462,7 +488,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
         walk_pieces_at(c.insertion_centric != 0, enters && !nolib, rc.counts, pos, cigr, nc, [&](int32_t rs, int32_t len, int32_t ext, int qoff, bool nb) {
             Piece h; PieceRare rr;
             make_piece(c, rc, rs, len, ext, qoff, nb, h, rr);
-            if (c.ann_variant != 2) {
+            if (!BRC_AVAR(2)) {
                 typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
                 const u32x4s* hs = reinterpret_cast<const u32x4s*>(&h); u32x4s* hd = reinterpret_cast<u32x4s*>(pieces + slot);
                 if (one_stream) { __builtin_nontemporal_store(hs[0], hd); __builtin_nontemporal_store(hs[1], hd + 1); __builtin_nontemporal_store(hs[2], hd + 2); }
@@ -481,6 +507,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
         IndelEv* slot = ev_raw + in.iev_off[my]; uint32_t used = 0;
         enumerate_indels_at(c, cigr, r, qual_ro + qoff, [&](int32_t p, int qpos, int len) {
             IndelEv e; e.read = (uint32_t)my; e.qpos = qpos; e.len = len; e.key_lo = (uint32_t)((int64_t)(p - c.pos0) * c.Lp + lib);   // (keys fit 32 bits: checked at upload)
+            if (wanted && !wanted[(uint32_t)(p - c.pos0) >> 6]) return;       // a tile no announced window touches comes back empty: no indel alleles either
             if (used < n_idp) { slot[used++] = e; atomicAdd(&bucket_cnt[indel_bucket_of(c, (uint32_t)(p - c.pos0), (uint32_t)lib)], 1u); }
         });
         for (; used < n_idp; ++used) slot[used].key_lo = NONE32;
@@ -786,6 +813,7 @@ struct PRec { u32x8 f; u32x2 g; };
 #ifndef BRC_EXP
 #define BRC_EXP 0               // compile-time experiments of tools/experiments/README.md (0 = the product)
 #endif
+
 #ifndef BRC_WAVES_PER_EU
 #define BRC_WAVES_PER_EU 7      // 72 VGPRs: 16 values spill into the rare paths (measured: 6 waves 3.92 ms, 7 waves 3.78 ms, 8 waves 5.6 ms — spills reach the loop)
 #endif
@@ -850,7 +878,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
     bool flushed = false;                                                   // (scalar) the slot planes of this tile hold partial integer sums
     unsigned long long wsm_tot = 0, wnm_tot = 0;                            // (scalar) warnings moved out of the lanes at flushes
 
-    if (lo < hi && c.variant != 4) {            // (variant: profiling ablations, BRC_PILEUP_VARIANT — 4: no piece loop, 1: no plane stores, 5: one half-batch only)
+    if (lo < hi && !BRC_PVAR(4)) {            // (variant: profiling ablations, BRC_PILEUP_VARIANT — 4: no piece loop, 1: no plane stores, 5: one half-batch only)
         // lanes past the region's last position stand far left of every piece: no coverage test is ever true for them
         // (d = 2^31 + lane + p0 - rs >= 2^31 - (rs - p0) >= ext for every piece, because rs + ext <= 2^31 - 1 and p0 >= 0)
         const uint32_t lanev = valid ? (uint32_t)lane : (0x80000000u | (uint32_t)lane);
@@ -1091,7 +1119,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                     const uint32_t w = (uint32_t)*reinterpret_cast<const uint16_t*>(rows_base + off + 2u * (uint32_t)lr);  \
                     if (kind == 0u) {                          /* third alleles: raw addends to the list, in piece order */ \
                         uint32_t at0 = 0;                                                                                 \
-                        if (lr == 0 && c.variant != 11) at0 = atomicAdd(pl.xev_n + (size_t)xshard * XEV_CTR_STRIDE, (uint32_t)__builtin_popcountll(mask)); /* (11: profiling, no list cursor) */ \
+                        if (lr == 0 && !BRC_PVAR(11)) at0 = atomicAdd(pl.xev_n + (size_t)xshard * XEV_CTR_STRIDE, (uint32_t)__builtin_popcountll(mask)); /* (11: profiling, no list cursor) */ \
                         at0 = (uint32_t)__builtin_amdgcn_readfirstlane(at0);                                              \
                         const uint64_t below = mask & ((1ull << lr) - 1ull);                                              \
                         const uint32_t at = at0 + (uint32_t)__builtin_popcountll(below);                                  \
@@ -1112,13 +1140,13 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         enum { HOFF_X = HALF * ROW_BYTES };                                    // byte offset of the second ring half
         uint4 T; uint32_t pf = 0;
         BRC_LD_TAB(T, lo)
-        if (c.variant != 7) BRC_STAGE(T, lo, 0u)
+        if (!BRC_PVAR(7)) BRC_STAGE(T, lo, 0u)
         BRC_LD_TAB(T, lo + (uint32_t)HALF)
-        if (c.variant != 7) BRC_STAGE(T, lo + (uint32_t)HALF, (uint32_t)HOFF_X)
+        if (!BRC_PVAR(7)) BRC_STAGE(T, lo + (uint32_t)HALF, (uint32_t)HOFF_X)
         BRC_LD_TAB(T, lo + 2u * (uint32_t)HALF)
         PRec R0, R1, R2;
         const char* recp = reinterpret_cast<const char*>(pieces4) + (size_t)lo * 48u;   // (scalar) next record to request
-        const uint32_t recstep = c.variant == 10 ? 0u : 48u;                   // (profiling: 10 = every scalar load hits the same line)
+        const uint32_t recstep = BRC_PVAR(10) ? 0u : 48u;                   // (profiling: 10 = every scalar load hits the same line)
         BRC_LD_REC(R0, recp) recp += 48;
         BRC_LD_REC(R1, recp) recp += 48;
         asm volatile("" : "=" BRC_F_R2 (R2.f), "=" BRC_G_R2 (R2.g));             // (defined before its first wait: whatever the registers hold; not a copy of a set in flight)
@@ -1128,10 +1156,10 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         BRC_PROBE(R0, 0u, S0)
         S1 = S0;
         uint32_t hoff = 0;                                                     // byte offset of the current ring half
-        uint32_t base = (c.variant == 6 || c.variant == 7) ? hi : lo;
+        uint32_t base = (BRC_PVAR(6) || BRC_PVAR(7)) ? hi : lo;
         for (; base < hi; base += (uint32_t)HALF, hoff ^= (uint32_t)HOFF_X) {
             const uint32_t nb = (hi - base) < (uint32_t)HALF ? (hi - base) : (uint32_t)HALF;
-            if (c.variant == 5 && base != lo) continue;
+            if (BRC_PVAR(5) && base != lo) continue;
             BRC_STEP(0, R0, R1, R2, S0, S1, true)
             BRC_STEP(1, R1, R2, R0, S1, S0, true)
             BRC_STEP(2, R2, R0, R1, S0, S1, true)
@@ -1168,7 +1196,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
     // by scalar adds.  (Inline assembly: left to the optimiser, the lane offset is folded into ONE 64-bit vector address and
     // the other 28 are derived from it with a 64-bit vector add each.)
     const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // (the lane index again: see above)
-    if (inreg && c.variant != 1) {
+    if (inreg && !BRC_PVAR(1)) {
         const int64_t P = c.PS;
         const int64_t tb = tile * TILE;                                    // (scalar) plane index of lane 0
         const uint32_t loff = (uint32_t)lane_e << 2;
@@ -1477,12 +1505,15 @@ class HipBackend : public Backend {
         c.beg0 = g.beg0; c.end = g.end; c.pos0 = g.pos0; c.P = g.P; c.PS = g.PS; c.ref_lo = g.ref_lo; c.ref_hi = g.ref_hi; c.ref_len = g.ref_len;
         c.n_reads = s.n; c.table_len = getenv("BRC_NO_TABLE") ? 0 : s.modal_len();
         c.n_pieces = s.n_pieces; lib_base = s.lib_base;
-        c.ibucket_shift = getenv("BRC_IBUCKET_SHIFT") ? atoi(getenv("BRC_IBUCKET_SHIFT")) : indel_bucket_shift(s.n_indel_ops, c.P, c.Lp);   // (the knob: tests run both sizes)
+        c.ibucket_shift = indel_bucket_shift(s.n_indel_ops, c.P, c.Lp);
+        if (const char* ib = getenv("BRC_IBUCKET_SHIFT")) { const int v = atoi(ib); if (v == 4 || v == 6) c.ibucket_shift = v; }   // (test knob: both supported sizes; anything else is ignored)
         // test knobs (tests/test_gpu_parity.py): small K -> flushes, small limit -> PF_HUGE, forced dominant bucket -> third alleles
         choose_pack(s.max_lqseq, getenv("BRC_FLUSH_K") ? atoi(getenv("BRC_FLUSH_K")) : 0, getenv("BRC_PACK_LIM") ? atoi(getenv("BRC_PACK_LIM")) : 0, c.flush_k, c.pack_lim);
         c.force_dom = getenv("BRC_FORCE_DOM") ? atoi(getenv("BRC_FORCE_DOM")) : -1;
+#ifdef BRC_EXP_KNOBS
         c.variant = getenv("BRC_PILEUP_VARIANT") ? atoi(getenv("BRC_PILEUP_VARIANT")) : 0;
         c.ann_variant = getenv("BRC_ANN_VARIANT") ? atoi(getenv("BRC_ANN_VARIANT")) : 0;
+#endif
         const size_t n = (size_t)s.n;
         int rc;
         if ((rc = up(d_pos, s.pos, n)) || (rc = up(d_flag, s.flag, n)) || (rc = up(d_mapq, s.mapq, n)) || (rc = up(d_lib, s.lib, n)) ||
@@ -1586,12 +1617,12 @@ class HipBackend : public Backend {
                 hipLaunchKernelGGL((k_annotate_groups<true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (const uint32_t*)d_pieceoff.p,
                                    (Piece*)d_pieces.p, (PieceRare*)d_rare.p, (int2*)d_keyreach.p,
                                    (uint16_t*)in.bq, indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p,
-                                   in.cigar, in.qual, in.seq4, (const uint8_t*)d_refcode.p + REFCODE_PAD);
+                                   in.cigar, in.qual, in.seq4, (const uint8_t*)d_refcode.p + REFCODE_PAD, has_wanted ? (const uint8_t*)d_wanted.p : (const uint8_t*)nullptr);
             } else {
                 hipLaunchKernelGGL((k_annotate_groups<false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (const uint32_t*)d_pieceoff.p,
                                    (Piece*)d_pieces.p, (PieceRare*)d_rare.p, (int2*)d_keyreach.p,
                                    (uint16_t*)in.bq, indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p,
-                                   in.cigar, in.qual, in.seq4, (const uint8_t*)d_refcode.p + REFCODE_PAD);
+                                   in.cigar, in.qual, in.seq4, (const uint8_t*)d_refcode.p + REFCODE_PAD, has_wanted ? (const uint8_t*)d_wanted.p : (const uint8_t*)nullptr);
             }
             if (c.per_lib) {
                 HIPCHK(hipMemsetAsync(d_unavail.p, 0xff, (size_t)c.PS * 4, stream));
@@ -1603,7 +1634,11 @@ class HipBackend : public Backend {
         // on a stream of its own under the pileup kernel (BRC_INDEL_OVERLAP=1) — measured: the step does not get shorter, the
         // two only share the machine (k_pileup2 3.75 -> 3.95 ms, step 6.2 ms either way) — so by default it follows the
         // pileup on the main stream.
+#ifdef BRC_EXP_KNOBS
         static const bool indel_overlap = getenv("BRC_INDEL_OVERLAP") && atoi(getenv("BRC_INDEL_OVERLAP")) != 0;
+#else
+        const bool indel_overlap = false;
+#endif
         auto launch_indel = [&](hipStream_t si, DBuf& scratch) -> int {
             HIPCHK(hipEventRecord(ev_indel[0], si));
             int r2;
@@ -1644,7 +1679,11 @@ class HipBackend : public Backend {
             unsigned nwg = (unsigned)((ntiles + PILEUP_WAVES - 1) / PILEUP_WAVES);
             nwg = (nwg + 7u) & ~7u;
             // profiling knob: unused dynamic LDS lowers the number of resident waves (occupancy sweeps)
+#ifdef BRC_EXP_KNOBS
             static const unsigned dyn_lds = getenv("BRC_PILEUP_LDS_PAD") ? (unsigned)atoi(getenv("BRC_PILEUP_LDS_PAD")) : 0u;
+#else
+            const unsigned dyn_lds = 0u;
+#endif
 if (has_wanted) {
                             hipLaunchKernelGGL((k_pileup2<true>), dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), dyn_lds, stream, c, in, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p,
                                (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.bq, (const uint32_t*)d_unavail.p,

@@ -195,22 +195,24 @@ static double now_s() { return std::chrono::duration<double>(std::chrono::steady
 static unsigned g_engines = 1;            // engines of this process (they share the CPUs)
 static std::atomic<unsigned> g_format_threads{0};   // formatter threads per engine when several engines share the process (0: the engine's default)
 static unsigned effective_cpus() {
-    static unsigned cached = 0;
-    if (cached) return cached;
-    unsigned n = std::thread::hardware_concurrency(); if (n == 0) n = 1;
-    double quota = 0;
-    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-        char q[64]; long long per = 0;
-        if (fscanf(f, "%63s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) quota = atof(q) / (double)per;
-        fclose(f);
-    } else {
-        long long q = -1, per = 0;
-        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &q) != 1) q = -1; fclose(g); }
-        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &per) != 1) per = 0; fclose(g); }
-        if (q > 0 && per > 0) quota = (double)q / (double)per;
-    }
-    if (quota > 0 && quota < (double)n) n = (unsigned)(quota + 0.999);
-    return cached = (n < 1 ? 1 : n);
+    // (worker threads call this: a function-local static is initialised once, thread-safely)
+    static const unsigned cached = []() -> unsigned {
+        unsigned n = std::thread::hardware_concurrency(); if (n == 0) n = 1;
+        double quota = 0;
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64]; long long per = 0;
+            if (fscanf(f, "%63s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) quota = atof(q) / (double)per;
+            fclose(f);
+        } else {
+            long long q = -1, per = 0;
+            if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &q) != 1) q = -1; fclose(g); }
+            if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &per) != 1) per = 0; fclose(g); }
+            if (q > 0 && per > 0) quota = (double)q / (double)per;
+        }
+        if (quota > 0 && quota < (double)n) n = (unsigned)(quota + 0.999);
+        return n < 1 ? 1u : n;
+    }();
+    return cached;
 }
 
 // ReadWarnings::warn (src/lib/bamrc/ReadWarnings.hpp:39-50) over a tagged event stream of the engine (brc_region_warnings)
@@ -780,8 +782,6 @@ int main(int argc, char** argv) {
     auto wait_engine = [&]() -> bool {
         const int r = eng_ready.get();
         if (r && !eng_reported) { eng_reported = true; fprintf(stderr, "bam-readcount: cannot create the MI355X engine: %s\n", brc_strerror(r)); }
-        // (engine 0 was created before the number of engines was known)
-        if (r == 0 && g_format_threads.load()) brc_set_option(c.eng, BRC_OPT_FORMAT_THREADS, (int64_t)g_format_threads.load());
         return r == 0;
     };
     c.need_engine = wait_engine;
@@ -868,6 +868,9 @@ int main(int argc, char** argv) {
         // threads are inside the HIP runtime by now, which reads the environment while it starts, and getenv() racing a
         // setenv() that reallocates `environ` was a rare SIGSEGV before the first line of output)
         g_format_threads = std::max(2u, effective_cpus() / (unsigned)N);
+        // engine 0 was created before the number of engines was known: it is told its share here, explicitly (the other
+        // engines get theirs in make_engine) — not as a side effect of whoever waits for it next
+        if (eng_ready.get() == 0) brc_set_option(c.eng, BRC_OPT_FORMAT_THREADS, (int64_t)g_format_threads.load());
     }
     // pin the text buffers of a long region's pieces while the first reads are being decoded
     std::thread pin_ahead;

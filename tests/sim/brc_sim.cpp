@@ -41,7 +41,8 @@ class SimBackend : public Backend {
         c.beg0 = g.beg0; c.end = g.end; c.pos0 = g.pos0; c.P = g.P; c.PS = g.PS; c.ref_lo = g.ref_lo; c.ref_hi = g.ref_hi; c.ref_len = g.ref_len;
         c.n_reads = s.n; c.table_len = getenv("BRC_NO_TABLE") ? 0 : s.modal_len(); c.n_pieces = s.n_pieces;
         c.force_dom = getenv("BRC_FORCE_DOM") ? atoi(getenv("BRC_FORCE_DOM")) : -1;
-        c.ibucket_shift = getenv("BRC_IBUCKET_SHIFT") ? atoi(getenv("BRC_IBUCKET_SHIFT")) : indel_bucket_shift(s.n_indel_ops, c.P, c.Lp);
+        c.ibucket_shift = indel_bucket_shift(s.n_indel_ops, c.P, c.Lp);
+        if (const char* ib = getenv("BRC_IBUCKET_SHIFT")) { const int v = atoi(ib); if (v == 4 || v == 6) c.ibucket_shift = v; }   // (as the HIP backend: the two supported sizes)
         choose_pack(s.max_lqseq, getenv("BRC_FLUSH_K") ? atoi(getenv("BRC_FLUSH_K")) : 0, getenv("BRC_PACK_LIM") ? atoi(getenv("BRC_PACK_LIM")) : 0, c.flush_k, c.pack_lim);
         tq.assign((size_t)TABLE_MAX + 2, 0.0f); te.assign((size_t)TABLE_MAX + 2, 0.0);
         for (int k = 0; k <= c.table_len; ++k) { tq[(size_t)k] = (float)k / (float)c.table_len; te[(size_t)k] = 1.0 - (double)tq[(size_t)k]; }
@@ -169,7 +170,13 @@ class SimBackend : public Backend {
             for (int64_t i = s0; i < s1; ++i) { if (reach[(size_t)i] > m) m = reach[(size_t)i]; prefmax[(size_t)i] = m; }
             for (int64_t tl = 0; tl < ntiles; ++tl) {                                                 // KB
                 uint32_t lo, hi; tile_range2(c, prefmax.data(), key.data(), s0, s1, tl, lo, hi);
-                if (!wanted.empty() && !wanted[(size_t)tl]) lo = hi = 0;                              // brc_region_windows (k_mask_tiles)
+                if (!wanted.empty() && !wanted[(size_t)tl]) {
+                    // brc_region_windows: exactly what k_mask_tiles leaves of a tile nobody announced — no column, no depth, no slot;
+                    // its statistics planes are never written (and must never be read: they keep their poison here)
+                    for (int ln = 0; ln < TILE; ++ln) { const int64_t k = tl * TILE + ln; if (k >= P) break;
+                        ncol[(size_t)(l * PS + k)] = 0; depth[(size_t)(l * PS + k)] = 0; slotid[(size_t)(l * PS + k)] = (uint32_t)NB_NONE | ((uint32_t)NB_NONE << 8); }
+                    continue;
+                }
                 pileup_tile(pl, l, tl, lo, hi);
             }
         }
@@ -197,6 +204,7 @@ class SimBackend : public Backend {
                 IndelEv* slot = raw.data() + st->iev_off.p[i]; uint32_t used = 0;
                 enumerate_indels(c, in, rd, in.qual + in.qual_off[i], [&](int32_t p, int qpos, int len) {
                     IndelEv e; e.read = (uint32_t)i; e.qpos = qpos; e.len = len; e.key_lo = (uint32_t)((int64_t)(p - c.pos0) * Lp + lib);
+                    if (!wanted.empty() && !wanted[(size_t)((uint32_t)(p - c.pos0) >> 6)]) return;     // (as K1: no indel alleles outside the announced tiles)
                     if (used < n_idp) { slot[used++] = e; cnt[indel_bucket_of(c, (uint32_t)(p - c.pos0), (uint32_t)lib)]++; }
                 });
                 for (; used < n_idp; ++used) slot[used].key_lo = NONE32;

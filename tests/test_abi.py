@@ -49,6 +49,20 @@ def test_oracle_is_not_linked_into_product():
     assert "oracle" not in ldd and "brc_sim" not in ldd
 
 
+def test_product_contains_no_ablation_knobs():
+    """The timing-only ablations of the two big kernels (BRC_PILEUP_VARIANT / BRC_ANN_VARIANT: parts of the kernels switched
+    off, wrong results) and the other profiling knobs exist only in experiment builds (-DBRC_EXP_KNOBS, tools/build_variant.sh):
+    the shipped library does not even contain their names, so no inherited environment variable can change what it computes
+    (the GPU half: tests/test_gpu_parity.py::test_product_ignores_ablation_environment)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bam_readcount_amd", "csrc")])
+    blob = open(capi.PRODUCT_LIB, "rb").read()
+    for knob in (b"BRC_PILEUP_VARIANT", b"BRC_ANN_VARIANT", b"BRC_PILEUP_LDS_PAD", b"BRC_INDEL_OVERLAP"):
+        assert knob not in blob, knob
+    src = open(os.path.join(ROOT, "bam_readcount_amd", "csrc", "brc_engine.hip")).read()
+    assert "c.variant ==" not in src.replace("#define BRC_PVAR(n) (c.variant == (n))", "")
+    assert "c.ann_variant ==" not in src.replace("#define BRC_AVAR(n) (c.ann_variant == (n))", "")
+
+
 def test_kernel_register_budget():
     """k_pileup2's design point is read off the built library (no GPU): at most 72 VGPRs = 7 waves per SIMD and no scratch."""
     import re, struct

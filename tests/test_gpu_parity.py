@@ -108,6 +108,51 @@ def test_hip_rare_device_paths(dev_lib, oracle_lib, monkeypatch, env):
     parity.compare_libs(dev_lib, oracle_lib, deep, [(800, 1600)], ref=ref)
 
 
+def test_product_ignores_ablation_environment(dev_lib, oracle_lib, monkeypatch):
+    """An inherited BRC_PILEUP_VARIANT / BRC_ANN_VARIANT (the profiling ablations of experiment builds: kernels with parts
+    switched off) must not change what the product computes: same bits as the oracle with every one of them set."""
+    rng = np.random.default_rng(41)
+    ref = synth.make_ref(rng, 4000, weird=0.01)
+    arrs = synth.make_batch(241, ref, 900, style="mixed")
+    for pv, av in (("4", "3"), ("1", "1"), ("6", "5"), ("11", "2")):
+        monkeypatch.setenv("BRC_PILEUP_VARIANT", pv); monkeypatch.setenv("BRC_ANN_VARIANT", av)
+        monkeypatch.setenv("BRC_IBUCKET_SHIFT", "40")          # (an unsupported bucket size is ignored, not used as a shift count)
+        parity.compare_libs(dev_lib, oracle_lib, arrs, [(0, 4000), (1000, 1100)], ref=ref, min_mapq=5, min_bq=10)
+
+
+def shuffled_arenas(arrs, seed):
+    """The same reads with their QUAL / SEQ / CIGAR rows laid out in a random order inside the arenas (legal: brc.h asks for
+    offsets inside the arenas, not for increasing ones), with gaps between the rows."""
+    rng = np.random.default_rng(seed)
+    n = len(arrs["pos"]); order = rng.permutation(n)
+    out = dict(arrs)
+    lq = np.asarray(arrs["l_qseq"]).astype(np.int64); nc = np.asarray(arrs["n_cigar"]).astype(np.int64)
+    for arena, off_name, lens in (("qual", "qual_off", lq), ("seq4", "seq_off", (lq + 1) // 2), ("cigar", "cigar_off", nc)):
+        src = np.asarray(arrs[arena]); offs = np.asarray(arrs[off_name]).astype(np.int64)
+        gaps = rng.integers(0, 5, n)
+        new_off = np.zeros(n, np.int64); at = int(rng.integers(0, 9))
+        for r in order:
+            new_off[r] = at; at += int(lens[r]) + int(gaps[r])
+        dst = np.full(at + 8, 7 if arena != "cigar" else 0, src.dtype)
+        for r in range(n):
+            dst[new_off[r]:new_off[r] + lens[r]] = src[offs[r]:offs[r] + lens[r]]
+        out[arena] = dst; out[off_name] = new_off.astype(np.uint64)
+    return out
+
+
+def test_hip_rows_in_any_arena_order(dev_lib, oracle_lib):
+    """K1's per-base pass addresses a wave's QUAL / SEQ rows as wave-uniform base + 32-bit lane offset: the base must be the
+    smallest offset of the wave's reads, not lane 0's (rows laid out in any order inside the batch arenas)."""
+    rng = np.random.default_rng(17)
+    ref = synth.make_ref(rng, 5000, weird=0.01)
+    arrs = synth.make_batch(317, ref, 1500, style="mixed", mismatch=0.1, p_q2tail=0.3)
+    sh = shuffled_arenas(arrs, 5)
+    want_t, want_r = parity.run_engine(oracle_lib, arrs, [(0, 5000)], ref=ref)
+    got_t, got_r = parity.run_engine(dev_lib, sh, [(0, 5000)], ref=ref)
+    parity.assert_results_equal(got_r[0], want_r[0], "shuffled arenas")
+    assert got_t == want_t
+
+
 def test_hip_edge_cases(dev_lib, oracle_lib):
     rng = np.random.default_rng(5)
     ref = synth.make_ref(rng, 500)

@@ -14,6 +14,9 @@ the engine and by tests/test_abi.py for builds at 6, 7 and 8 waves per SIMD.
    as a temporary, another load into them) is an error.  Exit status 1 and a listing of the offending paths.
 
     python tools/check_isa.py [--quiet] [--max-vgpr N] [--max-scratch BYTES] [extra hipcc flags, e.g. -DBRC_WAVES_PER_EU=8]
+    python tools/check_isa.py --asm FILE.s [--arch gfx950]     the assembly a build left behind (hipcc -save-temps=obj: the
+                                                               Makefile checks the very compile whose object it ships)
+Without --asm the script compiles the source itself with $HIPCC (default /opt/rocm/bin/hipcc), --arch and the product's flags.
 """
 import os
 import re
@@ -96,15 +99,25 @@ def check_loads(ins, labels):
 
 
 def main():
-    args = sys.argv[1:]; quiet = False; max_vgpr = None; max_scratch = None; extra = []
+    args = sys.argv[1:]; quiet = False; max_vgpr = None; max_scratch = None; extra = []; asm_file = None; arch = "gfx950"
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     while args:
         a = args.pop(0)
         if a == "--quiet": quiet = True
         elif a == "--max-vgpr": max_vgpr = int(args.pop(0))
         elif a == "--max-scratch": max_scratch = int(args.pop(0))
+        elif a == "--asm": asm_file = args.pop(0)
+        elif a == "--arch": arch = args.pop(0)
+        elif a == "--hipcc": hipcc = args.pop(0)
         else: extra.append(a)
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-O3", "-std=c++17", "-ffp-contract=off"] + extra + [SRC, "-o", "-"]
-    asm = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
+    if asm_file:
+        asm = open(asm_file).read()
+        m = re.search(r'\.amdgcn_target\s+"[^"]*--(gfx[0-9a-f]+)', asm)
+        if not m or m.group(1) != arch:
+            print("check_isa: %s was built for %s, not for %s" % (asm_file, m.group(1) if m else "an unknown target", arch)); sys.exit(1)
+    else:
+        cmd = [hipcc, "--offload-arch=" + arch, "--cuda-device-only", "-S", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"] + extra + [SRC, "-o", "-"]
+        asm = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
     lines = asm.split("\n")
     # every instantiation of the kernel (k_pileup2<false>: the common one; k_pileup2<true>: with brc_region_windows in force)
     starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN3brc9k_pileup2\S*:", l)]
