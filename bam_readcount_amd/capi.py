@@ -20,7 +20,7 @@ F_NAMES = ["sev", "sq2", "snm", "s3p"]
 EXPORTS = [
     "brc_strerror", "brc_last_error", "brc_kernel_name", "brc_engine_kind", "brc_create", "brc_destroy",
     "brc_begin_region", "brc_push_reads", "brc_upload", "brc_compute", "brc_fetch_result", "brc_end_region",
-    "brc_clear_indel_queue", "brc_region_counts", "brc_format_region", "brc_format_window", "brc_region_windows", "brc_region_warnings", "brc_window_warnings", "brc_warnings_text", "brc_set_option", "brc_format_region_parts", "brc_set_chrom",
+    "brc_clear_indel_queue", "brc_region_counts", "brc_format_region", "brc_format_window", "brc_region_windows", "brc_region_warnings", "brc_window_warnings", "brc_warnings_text", "brc_set_option", "brc_format_region_parts", "brc_set_chrom", "brc_fetch_window",
 ]
 
 
@@ -92,6 +92,8 @@ class Library:
         L.brc_compute.argtypes = [C.c_void_p, C.POINTER(Timing)]
         L.brc_fetch_result.argtypes = [C.c_void_p, C.POINTER(Result)]
         L.brc_end_region.argtypes = [C.c_void_p, C.POINTER(Result)]
+        if hasattr(L, "brc_fetch_window"):
+            L.brc_fetch_window.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(Result)]
         L.brc_clear_indel_queue.argtypes = [C.c_void_p]
         L.brc_region_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.brc_format_region.argtypes = [C.c_void_p, C.POINTER(Result), C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
@@ -283,6 +285,12 @@ class Engine:
 
     def fetch_result(self):
         self._check(self.L.lib.brc_fetch_result(self.h, C.byref(self._res)))
+        return RegionResult(self._res)
+
+    def fetch_window(self, beg0, end):
+        """The window [beg0, end) of the last computed region as a stand-alone result (include/brc.h: brc_fetch_window); it
+        becomes the engine's current result: format_region() prints it."""
+        self._check(self.L.lib.brc_fetch_window(self.h, beg0, end, C.byref(self._res)))
         return RegionResult(self._res)
 
     def end_region(self):

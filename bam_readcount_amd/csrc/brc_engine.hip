@@ -1482,6 +1482,7 @@ class HipBackend : public Backend {
         if (stream3) (void)hipStreamDestroy(stream3);
         d_agg2.release();
         h_ncol.destroy(); h_depth.destroy(); h_slotid.destroy(); h_si.destroy(); h_unavail.destroy(); h_sf.destroy(); h_iout.destroy(); h_xev.destroy();
+        if (w_init) { w_ncol.destroy(); w_depth.destroy(); w_slotid.destroy(); w_si.destroy(); w_unavail.destroy(); w_sf.destroy(); }
         if (have_events) for (int i = 0; i <= T_N; ++i) (void)hipEventDestroy(evt[i]);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -1599,6 +1600,7 @@ class HipBackend : public Backend {
         const int64_t n = c.n_reads, P = c.P; const int Lp = c.Lp;
         int rc;
         Counters* ctr = (Counters*)d_ctr.p;
+        lists_host = false;
         HIPCHK(hipMemsetAsync(ctr, 0, sizeof(Counters), stream));
         HIPCHK(hipMemsetAsync(d_xevn.p, 0, (size_t)XEV_SHARDS * XEV_CTR_STRIDE * 4, stream));
         const bool indels = n_indel_cap > 0 && P > 0 && n > 0;
@@ -1785,6 +1787,43 @@ if (has_wanted) {
         return BRC_OK;
     }
 
+    // brc_fetch_window: the compact planes of plane indices [k0, k0 + n) -> pinned window buffers (strided copies: a plane
+    // row of n elements out of every PS), the region's two lists whole (downloaded once per computed region)
+    HBuf<uint32_t> w_ncol, w_depth, w_slotid, w_si, w_unavail; HBuf<float> w_sf; bool w_init = false;
+    bool lists_host = false;             // h_xev / h_iout / iout_compact hold the lists of the last compute
+    int fetch_window(int64_t k0, int64_t n, HostPlanes* out, int64_t* stride) override {
+        HIPCHK(hipSetDevice(device));
+        if (!computed) { err = "not computed"; return BRC_E_ARG; }
+        if (k0 < 0 || n < 0 || k0 + n > c.P) { err = "window outside the planes"; return BRC_E_ARG; }
+        if (!w_init) { w_ncol.A = w_depth.A = w_slotid.A = w_si.A = w_unavail.A = &kPinned; w_sf.A = &kPinned; w_init = true; }
+        const size_t WS = (size_t)((n + 63) & ~(int64_t)63), Lp = (size_t)c.Lp, PS = (size_t)c.PS;
+        if (!w_ncol.reserve(Lp * WS + 4) || !w_depth.reserve(Lp * WS + 4) || !w_slotid.reserve(Lp * WS + 4) || !w_unavail.reserve(WS + 4) ||
+            !w_si.reserve(Lp * 2 * NI * WS + 4) || !w_sf.reserve(Lp * 2 * NF * WS + 4)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }
+        if (n) {
+            const size_t wb = (size_t)n * 4;
+            HIPCHK(hipMemcpy2DAsync(w_ncol.p, WS * 4, (const uint32_t*)d_ncol.p + k0, PS * 4, wb, Lp, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpy2DAsync(w_depth.p, WS * 4, (const uint32_t*)d_depth.p + k0, PS * 4, wb, Lp, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpy2DAsync(w_slotid.p, WS * 4, (const uint32_t*)d_slotid.p + k0, PS * 4, wb, Lp, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpy2DAsync(w_si.p, WS * 4, (const uint32_t*)d_si.p + k0, PS * 4, wb, Lp * 2 * NI, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpy2DAsync(w_sf.p, WS * 4, (const float*)d_sf.p + k0, PS * 4, wb, Lp * 2 * NF, hipMemcpyDeviceToHost, stream));
+            if (c.per_lib) HIPCHK(hipMemcpyAsync(w_unavail.p, (const uint32_t*)d_unavail.p + k0, wb, hipMemcpyDeviceToHost, stream));
+        }
+        if (!lists_host) {
+            const int rc = enqueue_lists(); if (rc) return rc;
+            lists_enqueued = false;
+            HIPCHK(hipStreamSynchronize(stream));
+            iout_compact.clear();
+            for (size_t i = 0; i < (size_t)h_ctr.n_indel_slots; ++i) if (h_iout.p[i].len != 0) iout_compact.push_back(h_iout.p[i]);
+            lists_host = true;
+        } else HIPCHK(hipStreamSynchronize(stream));
+        *out = HostPlanes();
+        out->ncol = w_ncol.p; out->depth = w_depth.p; out->slotid = w_slotid.p; out->si = w_si.p; out->sf = w_sf.p; out->unavail = w_unavail.p;
+        out->xev = h_xev.p; out->n_xev = h_ctr.n_xev;
+        out->indel = iout_compact.data(); out->n_indel = (int64_t)iout_compact.size();
+        out->n_events = h_ctr.n_events; out->n_positions = h_ctr.n_positions;
+        *stride = (int64_t)WS;
+        return BRC_OK;
+    }
     // the two small lists (third-allele events, indel buckets) -> pinned host memory.  With device-side text they are
     // requested BEFORE the text: the DMA engine serves copies in order, and the caller needs the lists first.
     bool lists_enqueued = false;
@@ -1827,6 +1866,7 @@ if (has_wanted) {
         HIPCHK(hipStreamSynchronize(stream));
         iout_compact.clear();
         for (size_t i = 0; i < ns; ++i) if (h_iout.p[i].len != 0) iout_compact.push_back(h_iout.p[i]);
+        lists_host = true;
         out->ncol = h_ncol.p; out->depth = h_depth.p; out->slotid = h_slotid.p; out->si = h_si.p; out->sf = h_sf.p; out->unavail = h_unavail.p;
         out->xev = h_xev.p; out->n_xev = nx;
         out->indel = iout_compact.data(); out->n_indel = (int64_t)iout_compact.size();

@@ -277,6 +277,9 @@ struct brc_engine {
     std::vector<brc_indel> indels;
     std::string alleles;
     std::vector<char> refbase;
+    // brc_fetch_window: the dense result of one window of the computed region (buffers of its own: a fetched whole-region result stays valid)
+    uint32_t* win_i = nullptr; float* win_f = nullptr; size_t win_cap = 0;
+    std::vector<brc_indel> win_indels; std::string win_alleles; std::vector<char> win_refbase; std::vector<XEv> win_xev; std::vector<IndelOut> win_iout;
     // BRC_OPT_TEXT_ONLY: the caller only formats (brc_format_region / brc_format_window): no dense planes are built, the
     // formatter reads the compact slot planes; third-allele events are aggregated into a sparse (position, library,
     // bucket)-sorted table instead
@@ -304,6 +307,43 @@ struct brc_engine {
 };
 
 static int fail(brc_engine* e, int code, const char* msg) { e->err = msg; return code; }
+
+// allele text + std::map<std::string,BasicStat> iteration order (bamreadcount.cpp:323-342, 389-401): the device's reduced indel
+// buckets -> the ABI's list, sorted by (position, library, allele text bytewise)
+static void assemble_indels(const brc_engine* e, const IndelOut* list, int64_t n, std::vector<brc_indel>& out, std::string& alleles) {
+    const Geometry& g = e->g; const Staged& s = e->st;
+    std::vector<std::string> txt((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        const IndelOut& o = list[i];
+        std::string& a = txt[(size_t)i];
+        if (o.len > 0) {
+            a.push_back('+');
+            const uint8_t* seq = s.seq4.p + s.seq_off.p[o.rep_read];
+            const int32_t L = s.l_qseq.p[o.rep_read];
+            for (int j = 0; j < o.len; ++j) { const int q = o.rep_qpos + 1 + j; a.push_back(q < L ? "=ACGTN"[canon_bucket(seqi(seq, q))] : 'N'); }
+        } else {
+            a.push_back('-');
+            for (int j = 0; j < -o.len; ++j) { const int64_t p = (int64_t)o.pos + 1 + j; a.push_back((g.ref && p < g.ref_len && g.ref[p]) ? g.ref[p] : 'N'); }
+        }
+    }
+    std::vector<uint32_t> ord((size_t)n);
+    for (size_t i = 0; i < ord.size(); ++i) ord[i] = (uint32_t)i;
+    std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) {
+        const IndelOut& a = list[x]; const IndelOut& b = list[y];
+        if (a.pos != b.pos) return a.pos < b.pos;
+        if (a.lib != b.lib) return a.lib < b.lib;
+        return txt[x] < txt[y];
+    });
+    out.resize(ord.size()); alleles.clear();
+    for (size_t i = 0; i < ord.size(); ++i) {
+        const IndelOut& o = list[ord[i]]; brc_indel& d = out[i];
+        d.pos = o.pos; d.lib = o.lib; d.len = o.len; d.rep_read = o.rep_read; d.rep_qpos = o.rep_qpos;
+        d.allele_off = (uint32_t)alleles.size(); d.allele_len = (uint32_t)txt[ord[i]].size();
+        alleles += txt[ord[i]];
+        for (int f = 0; f < BRC_NI; ++f) d.stat.i[f] = o.i[f];
+        for (int f = 0; f < BRC_NF; ++f) d.stat.f[f] = o.f[f];
+    }
+}
 
 extern "C" {
 
@@ -348,7 +388,7 @@ void brc_destroy(brc_engine* e) {
                 (long long)e->n_regions, e->t_push, e->t_upload, e->t_compute, e->t_d2h, e->t_post, e->t_format, e->t_textwait, (unsigned long long)e->n_xev_total, (unsigned long long)e->n_indel_total);
     e->st.destroy();
     delete e->be;
-    free(e->dense_i); free(e->dense_f); free(e->tbuf);
+    free(e->dense_i); free(e->dense_f); free(e->tbuf); free(e->win_i); free(e->win_f);
     delete e;
 }
 
@@ -590,7 +630,7 @@ int brc_fetch_result(brc_engine* e, brc_result* out) {
     if (rc) return fail(e, rc, e->be->last_error());
     const double t_dl = now_s(); e->t_d2h += t_dl - t_in;
     e->n_xev_total += e->hp.n_xev; e->n_indel_total += (uint64_t)e->hp.n_indel;
-    const Geometry& g = e->g; const Staged& s = e->st; const HostPlanes& hp = e->hp;
+    const Geometry& g = e->g; const HostPlanes& hp = e->hp;
     // column 3: raw reference character (bamreadcount.cpp:353)
     e->refbase.resize((size_t)g.P + 1);
     if (!e->text_result) {
@@ -599,38 +639,7 @@ int brc_fetch_result(brc_engine* e, brc_result* out) {
         for (int64_t k = 0; k < have; ++k) if (!e->refbase[(size_t)k]) e->refbase[(size_t)k] = 'N';
         if (g.P > have) memset(e->refbase.data() + have, 'N', (size_t)(g.P - have));
     }
-    // allele text + std::map<std::string,BasicStat> iteration order (bamreadcount.cpp:323-342, 389-401)
-    std::vector<std::string> txt((size_t)hp.n_indel);
-    for (int64_t i = 0; i < hp.n_indel; ++i) {
-        const IndelOut& o = hp.indel[i];
-        std::string& a = txt[(size_t)i];
-        if (o.len > 0) {
-            a.push_back('+');
-            const uint8_t* seq = s.seq4.p + s.seq_off.p[o.rep_read];
-            const int32_t L = s.l_qseq.p[o.rep_read];
-            for (int j = 0; j < o.len; ++j) { const int q = o.rep_qpos + 1 + j; a.push_back(q < L ? "=ACGTN"[canon_bucket(seqi(seq, q))] : 'N'); }
-        } else {
-            a.push_back('-');
-            for (int j = 0; j < -o.len; ++j) { const int64_t p = (int64_t)o.pos + 1 + j; a.push_back((g.ref && p < g.ref_len && g.ref[p]) ? g.ref[p] : 'N'); }
-        }
-    }
-    std::vector<uint32_t> ord((size_t)hp.n_indel);
-    for (size_t i = 0; i < ord.size(); ++i) ord[i] = (uint32_t)i;
-    std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) {
-        const IndelOut& a = hp.indel[x]; const IndelOut& b = hp.indel[y];
-        if (a.pos != b.pos) return a.pos < b.pos;
-        if (a.lib != b.lib) return a.lib < b.lib;
-        return txt[x] < txt[y];
-    });
-    e->indels.resize(ord.size()); e->alleles.clear();
-    for (size_t i = 0; i < ord.size(); ++i) {
-        const IndelOut& o = hp.indel[ord[i]]; brc_indel& d = e->indels[i];
-        d.pos = o.pos; d.lib = o.lib; d.len = o.len; d.rep_read = o.rep_read; d.rep_qpos = o.rep_qpos;
-        d.allele_off = (uint32_t)e->alleles.size(); d.allele_len = (uint32_t)txt[ord[i]].size();
-        e->alleles += txt[ord[i]];
-        for (int f = 0; f < BRC_NI; ++f) d.stat.i[f] = o.i[f];
-        for (int f = 0; f < BRC_NF; ++f) d.stat.f[f] = o.f[f];
-    }
+    assemble_indels(e, hp.indel, hp.n_indel, e->indels, e->alleles);
     memset(out, 0, sizeof *out);
     out->tid = g.tid; out->beg0 = g.beg0; out->end = g.end; out->pos0 = g.pos0; out->n_pos = g.P; out->stride = g.PS; out->n_lib = g.Lp;
     if (e->text_only) {
@@ -675,6 +684,59 @@ int brc_fetch_result(brc_engine* e, brc_result* out) {
     out->n_events = hp.n_events;
     for (int w = 0; w < BRC_N_WARN; ++w) out->warn[w] = hp.warn[w];
     e->state = 4; e->t_post += now_s() - t_dl;
+    return BRC_OK;
+}
+
+int brc_fetch_window(brc_engine* e, int32_t beg0, int32_t end, brc_result* out) {
+    if (!e || !out) return BRC_E_ARG;
+    if (e->state < 3) return fail(e, BRC_E_ARG, "brc_fetch_window before brc_compute");
+    const Geometry& g = e->g;
+    if (beg0 < g.beg0 || end > g.end || end < beg0) return fail(e, BRC_E_ARG, "brc_fetch_window: the window must lie inside the computed region");
+    // plane indices of [beg0 - 1, end) clipped to the planes (the lead position only when the region processed it)
+    int64_t k0 = (int64_t)(beg0 > 0 ? beg0 - 1 : 0) - g.pos0, k1 = (int64_t)end - g.pos0;
+    if (k0 < 0) k0 = 0;
+    if (k1 > g.P) k1 = g.P;
+    if (k1 < k0) k1 = k0;
+    const int64_t n = k1 - k0;
+    HostPlanes hw; int64_t WS = 0;
+    int rc = e->be->fetch_window(k0, n, &hw, &WS);
+    if (rc) return fail(e, rc, e->be->last_error());
+    const int32_t wpos0 = (int32_t)(g.pos0 + k0);
+    // the two lists cover the whole region: keep the window's entries (third-allele events re-based to the window's planes)
+    e->win_xev.clear(); e->win_iout.clear();
+    for (uint64_t i = 0; i < hw.n_xev; ++i) { const XEv& x = hw.xev[i]; if ((int64_t)x.k >= k0 && (int64_t)x.k < k1) { XEv y = x; y.k = (uint32_t)((int64_t)x.k - k0); e->win_xev.push_back(y); } }
+    for (int64_t i = 0; i < hw.n_indel; ++i) { const IndelOut& o = hw.indel[i]; if (o.pos >= wpos0 && (int64_t)o.pos < (int64_t)wpos0 + n) e->win_iout.push_back(o); }
+    hw.xev = e->win_xev.data(); hw.n_xev = e->win_xev.size();
+    assemble_indels(e, e->win_iout.data(), (int64_t)e->win_iout.size(), e->win_indels, e->win_alleles);
+    const size_t need = (size_t)g.Lp * NBUCKET * (size_t)WS + 16;
+    if (need > e->win_cap) {
+        free(e->win_i); free(e->win_f);
+        e->win_i = (uint32_t*)malloc(need * NI * 4); e->win_f = (float*)malloc(need * NF * 4); e->win_cap = need;
+        if (!e->win_i || !e->win_f) { e->win_cap = 0; return fail(e, BRC_E_NOMEM, "host allocation of the dense planes failed"); }
+    }
+    expand_slots(hw, g.Lp, n, WS, e->win_i, e->win_f);
+    e->win_refbase.resize((size_t)n + 1);
+    {
+        const int64_t have = g.ref ? std::max<int64_t>(0, std::min<int64_t>(n, g.ref_len - wpos0)) : 0;
+        if (have) memcpy(e->win_refbase.data(), g.ref + wpos0, (size_t)have);
+        for (int64_t k = 0; k < have; ++k) if (!e->win_refbase[(size_t)k]) e->win_refbase[(size_t)k] = 'N';
+        if (n > have) memset(e->win_refbase.data() + have, 'N', (size_t)(n - have));
+    }
+    memset(out, 0, sizeof *out);
+    out->tid = g.tid; out->beg0 = beg0; out->end = end; out->pos0 = wpos0; out->n_pos = n; out->stride = WS; out->n_lib = g.Lp;
+    out->ncol = hw.ncol; out->depth = hw.depth; out->istat = e->win_i; out->fstat = e->win_f;
+    out->unavail = e->cfg.per_lib ? hw.unavail : NULL;
+    out->refbase = e->win_refbase.data();
+    out->n_indel = (int64_t)e->win_indels.size(); out->indel = e->win_indels.data();
+    out->alleles = e->win_alleles.data(); out->alleles_len = e->win_alleles.size();
+    // events of the window: its pileup columns inside [beg0, end), abandoned positions left out as the device counts them
+    uint64_t ev = 0;
+    for (int l = 0; l < g.Lp; ++l) for (int64_t k = 0; k < n; ++k) {
+        if ((int64_t)wpos0 + k < (int64_t)beg0) continue;
+        if (e->cfg.per_lib && hw.unavail && hw.unavail[k] != 0xFFFFFFFFu) continue;
+        ev += hw.ncol[(int64_t)l * WS + k];
+    }
+    out->n_events = ev;
     return BRC_OK;
 }
 

@@ -111,6 +111,8 @@ class Backend {
     virtual int upload(const brc_config& cfg, const Staged& s, Geometry& g) = 0;         // staging -> device; sets g.PS
     virtual int compute(brc_timing* t) = 0;                                              // whole pipeline, waits
     virtual int fetch(HostPlanes* out, bool planes) = 0;                                 // device -> host: counters, third-allele and indel lists, and (planes) the slot planes
+    // the slot planes of plane indices [k0, k0 + n) only (host planes `*stride` elements apart), and the region's two lists whole
+    virtual int fetch_window(int64_t k0, int64_t n, HostPlanes* out, int64_t* stride) = 0;
     // device-side text of the computed region: text_begin launches the line kernels and starts the download (the device
     // buffers of the region stay untouched until it is done: same stream), text_wait waits for it
     // (two host buffers: `slot` names the one this region's text goes to — the text of the region before may still be

@@ -19,11 +19,13 @@ under a launcher.  Extra objects on the JSON line:
   roofline      k_pileup2 (dominant kernel): algorithmic bytes per launch (B_in + B_ref + B_out, dense 312 B per
                 position and library) / its average duration measured with HIP events on the engine's stream, against the
                 8 TB/s HBM peak and the 6.29 TB/s measured copy rate; the bytes the kernel really writes (compact planes)
-  cpu_baseline  the C oracle (CPU restatement of the reference semantics): 1 thread like the reference, and all cores
-                (one oracle process per core, each on its own contig of the same data model, after the timed region)
+  cpu_baseline  the C oracle (CPU restatement of the reference semantics): 1 thread like the reference on a prefix, the reference's own
+                sources compiled over a shim (oracle/_ref) on a smaller prefix, and all cores = the whole-region validation below
   e2e           the drop-in command line on a generated BAM + BAI -> /dev/null (BAM decode, PCIe, formatting included)
-  validated     the HIP planes / text of a prefix of the timed contig equal the oracle's, and the event count of the timed
-                full-size run equals the sum of the reads' in-window spans
+  validated     full_contig: the result of the TIMED region — every position of it — equals the oracle's: the region is cut into
+                windows, the oracle computes each as a region of its own on all usable cores (tools/fullcheck.py), the HIP side
+                reads the same windows back with brc_fetch_window; planes bit for bit, indel lists, text byte for byte (digests).
+                Besides: planes / text / device-side text of a prefix, and event count == sum of the reads' in-window spans
 """
 import argparse
 import json
@@ -60,23 +62,6 @@ def effective_cpus():
     return n
 
 
-def cpu_worker(seed, mbp, config):
-    """One oracle process of the all-cores baseline: its own slice of the data model; prints events and seconds."""
-    import synthgen
-    from bam_readcount_amd import capi
-    n = int(mbp * 1e6)
-    ref, arrs = synthgen.generate(n, config, seed=seed, n_chunks=1)
-    oracle = capi.Library(os.path.join(ROOT, "oracle", "libbrc_oracle.so"))
-    per_lib = config == "tumor200x"
-    names = ["lib%d" % i for i in range(synthgen.CONFIGS[config]["n_libs"])] if per_lib else ()
-    opts = dict(min_mapq=20, min_bq=13) if not per_lib else dict(per_lib=True, insertion_centric=True)
-    e = capi.Engine(oracle, lib_names=names, **opts)
-    e.begin_region(0, 0, n, ref); e.push_reads(arrs)
-    t0 = time.perf_counter(); e.upload(); e.compute(); dt = time.perf_counter() - t0
-    ev, _ = e.counts(); e.close()
-    print(json.dumps({"events": ev, "seconds": dt}))
-
-
 def site_batch(np, capi, arrs, ref, sites, window=384, lead=170):
     """The CLI planner's layout for single-base -l lines: site i's reads (those samfetch would return for [s-2, s)) and its
     reference slice are translated to virtual positions [i * window, (i + 1) * window)."""
@@ -100,24 +85,32 @@ def site_batch(np, capi, arrs, ref, sites, window=384, lead=170):
     return sub, vref, events, vbeg0
 
 
+def fullcheck_window_reads(capi, arrs, ends, pos64, a, b):
+    """reads samfetch would return for [a - 1, b) (tools/fullcheck.py: window_reads; reads here are at most 1 kb long)"""
+    import fullcheck
+    return fullcheck.window_reads(capi, arrs, ends, pos64, 1000, a, b)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300, help="timed steps (300 x ~7 ms: a timed region above 2 s)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--mode", default="weak", choices=["weak", "strong", "sites"])
-    ap.add_argument("--config", default=None, choices=["wgs30x", "tumor200x"], help="data model (default: wgs30x; tumor200x for --mode strong)")
+    ap.add_argument("--config", default=None, choices=["wgs30x", "tumor200x", "wgs30x_mixed"], help="data model (default: wgs30x; tumor200x for --mode strong; wgs30x_mixed: config 3 with 30 %% of the reads trimmed to U[100,149] and 10 %% 250 bases long)")
     ap.add_argument("--contig-mbp", type=float, default=50.0, help="weak/sites: contig per GPU; strong: the whole contig")
     ap.add_argument("--sites", type=int, default=100000, help="--mode sites: lines of the site list (all ranks together)")
     ap.add_argument("--cpu-sample-mbp", type=float, default=8.0, help="prefix timed with the 1-thread CPU oracle and used for validation (0 = skip)")
     ap.add_argument("--allow-large", action="store_true", help="--mode strong: accept more than 12.5 Mbp of 200x data per rank")
     ap.add_argument("--cpu-ref-mbp", type=float, default=0.5, help="prefix timed with the reference-compiled library oracle/_ref (0 = skip)")
-    ap.add_argument("--cpu-all-cores", type=int, default=-1, help="oracle processes of the all-cores baseline (-1: min(usable CPUs, 64); 0 = skip)")
+    ap.add_argument("--cpu-all-cores", type=int, default=-1, help="oracle processes of the whole-region validation = the all-cores CPU baseline (-1: min(usable CPUs, 64); 0 = skip both)")
+    ap.add_argument("--full-check", type=int, default=-1, help="validate the WHOLE timed region against the oracle on all cores, window by window (brc_fetch_window): -1 = on a 1-GPU run "
+                    "of --mode weak / strong with a CPU sample, 2 = planes only (no text: config 5 whole prints 72 GB), 0 = off")
     ap.add_argument("--e2e-mbp", type=float, default=30.0, help="contig of the end-to-end command-line run (0 = skip)")
+    ap.add_argument("--abi-mbp", type=float, default=10.0, help="prefix run through the C-ABI from host batches to host text (abi_roundtrip; 0 = skip)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r03_traffic.json"))
     ap.add_argument("--other-configs", type=int, default=-1, help="1: also run BASELINE config 4 (--mode sites) and the per-GPU shape of config 5 (--mode strong --contig-mbp 6.25) "
                     "in sub-processes and put their lines under other_configs (-1: yes on the default single-GPU config-3 run, no otherwise)")
-    ap.add_argument("--cpu-worker", nargs=3, default=None, help=argparse.SUPPRESS)
     # test infrastructure (tests/test_bench_multirank.py): the rank arithmetic of this script — who owns which interval / slice of
     # the site list, the reductions of the metrics line — executed on CPUs: gloo instead of RCCL, and the C-ABI served by the CPU
     # lane simulator named here.  The line it prints says so ("dry_run") and carries no throughput.
@@ -125,8 +118,6 @@ def main():
     ap.add_argument("--as-rank", type=int, default=None, help=argparse.SUPPRESS)     # with --as-world: one rank's share, without a launcher
     ap.add_argument("--as-world", type=int, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
-    if args.cpu_worker:
-        return cpu_worker(int(args.cpu_worker[0]), float(args.cpu_worker[1]), args.cpu_worker[2])
     config = args.config or ("tumor200x" if args.mode == "strong" else "wgs30x")
 
     # ---- N > 1 without a launcher: become `python -m torch.distributed.run ... bench.py <same arguments>`
@@ -150,25 +141,10 @@ def main():
         rank, world = args.as_rank, int(args.as_world or args.gpus)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not dry:
-        if not torch.cuda.is_available():
-            raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
-        torch.cuda.set_device(local_rank)
-    dist = None
-    tdev = "cpu" if dry else "cuda"
-    if world > 1 and not emulated:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if dry:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
-
     ncpu = os.cpu_count() or 1
     ncpu_eff = effective_cpus()
     nworkers = (min(ncpu_eff, 64) if args.cpu_all_cores < 0 else args.cpu_all_cores) if (rank == 0 and world == 1 and args.cpu_sample_mbp > 0) else 0
 
-    hip = capi.Library(os.path.abspath(args.dry_run_lib)) if dry else capi.load_product()
     per_lib = config == "tumor200x"
     names = ["lib%d" % i for i in range(synthgen.CONFIGS[config]["n_libs"])] if per_lib else ()
     opts = dict(min_mapq=20, min_bq=13) if not per_lib else dict(min_mapq=0, min_bq=0, per_lib=True, insertion_centric=True)
@@ -183,6 +159,30 @@ def main():
     t0 = time.time()
     ref, arrs = synthgen.generate(contig_len, config, seed=1 + 1000 * rank)
     t_gen = time.time() - t0
+    # The oracle processes of the whole-region validation are forked HERE — before this process touches the GPU (a process
+    # that has initialised the HIP runtime must not fork); they inherit the reads and sleep until the timed region is over.
+    pool = None
+    full_check = args.full_check if args.full_check >= 0 else (1 if (world == 1 and not dry and args.mode != "sites" and args.cpu_sample_mbp > 0 and nworkers > 0) else 0)
+    if full_check and rank == 0 and world == 1 and not dry and args.mode != "sites":
+        import fullcheck
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+        pool = fullcheck.OraclePool(max(nworkers, 1), ref, arrs, names, opts, capi)
+
+    if not dry:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+        torch.cuda.set_device(local_rank)
+    dist = None
+    tdev = "cpu" if dry else "cuda"
+    if world > 1 and not emulated:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+
+    hip = capi.Library(os.path.abspath(args.dry_run_lib)) if dry else capi.load_product()
     # (sites mode: the result is only ever cut into lines — no dense planes on the host)
     eng = capi.Engine(hip, lib_names=names, device=local_rank, text_only=(args.mode == "sites"), **opts)
     site_events = 0
@@ -228,18 +228,28 @@ def main():
         n_events, n_positions = site_events, len(sites)      # the unit of work counts the requested sites only
 
     tmax, ev_total, pos_total = dt, n_events, n_positions
+    # device memory this rank's engine holds (inputs, intermediates, result planes): what an 8-GPU run must fit per GPU
+    hbm_used = 0
+    if not dry:
+        free_b, total_b = torch.cuda.mem_get_info(local_rank); hbm_used = int(total_b - free_b)
+    per_rank = [{"rank": rank, "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 4), "events": int(n_events), "positions": int(n_positions), "hbm_bytes": hbm_used}]
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         c = torch.tensor([n_events, n_positions], dtype=torch.int64, device=tdev)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)   # the only collective: 16 bytes of counters for the metrics line
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)   # the only collectives: 16 bytes of counters for the metrics line ...
         tmax, ev_total, pos_total = float(t.item()), int(c[0].item()), int(c[1].item())
+        # ... and every rank's own clock, share and memory (32 bytes each), so that the line of an N-GPU run describes itself
+        mine = torch.tensor([dt, float(n_events), float(n_positions), float(hbm_used)], dtype=torch.float64, device=tdev)
+        each = [torch.zeros(4, dtype=torch.float64, device=tdev) for _ in range(world)]
+        dist.all_gather(each, mine)
+        per_rank = [{"rank": r, "ms_per_step": round(float(x[0]) / max(args.steps, 1) * 1e3, 4), "events": int(x[1]), "positions": int(x[2]), "hbm_bytes": int(x[3])} for r, x in enumerate(each)]
 
     if dry:
         # the dry run ends here: what every rank (or the emulated one) owned, and — on rank 0 — the reduced totals
         if rank == 0 or emulated:
             print(json.dumps({"dry_run": "rank arithmetic only (gloo, %s)" % hip.kind(), "value": None, "n_gpus": world, "rank": rank, "mode": args.mode,
-                              "events_per_step": int(ev_total), "positions_per_step": int(pos_total), "own_events": int(n_events), "own_positions": int(n_positions),
+                              "events_per_step": int(ev_total), "positions_per_step": int(pos_total), "own_events": int(n_events), "own_positions": int(n_positions), "per_rank": per_rank,
                               "reads_per_gpu": int(len(region_reads["pos"]))}))
         eng.close()
         if dist is not None:
@@ -363,17 +373,21 @@ def main():
                 cpu["reference_compiled"] = {"value": round(rev / tr, 1), "unit": "pileup base-events/s", "cores": 1, "kind": "reference",
                                              "sample": "first %.2f Mbp of the same contig (%d events, %.1f s): bam-readcount's own fetch_func / pileup_func / BasicStat / IndelQueue sources "
                                                        "compiled unmodified over the samtools/htslib shim of oracle/ref_shim, text identical to the oracle's" % (rsend / 1e6, rev, tr)}
-            if nworkers:
-                # all cores: one oracle process per core, each on its own contig of the same data model; started only now —
-                # nothing else of this benchmark runs while they do
-                per = 1.0 if config == "wgs30x" else 0.15                        # ~2 s of oracle work per process
-                cpu_procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(1000 + w), str(per), config],
-                                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for w in range(nworkers)]
-                outs = [json.loads(p.communicate()[0].decode().strip().splitlines()[-1]) for p in cpu_procs]
-                cpu["all_cores"] = {"value": round(sum(o["events"] for o in outs) / max(o["seconds"] for o in outs), 1), "cores": len(outs),
-                                    "sample": "%d oracle processes at once (the CPUs this container may use: %d hardware threads, cgroup quota %d), each on its own %.2f-Mbp contig of the same data model (%d events in all, slowest %.1f s)"
-                                              % (len(outs), ncpu, ncpu_eff, 1.0 if config == "wgs30x" else 0.15, sum(o["events"] for o in outs), max(o["seconds"] for o in outs))}
-
+            if pool is not None:
+                # ---- the WHOLE timed region against the oracle on all usable cores: the oracle computes every window as a region of
+                # its own (reads fetched the reference's way), the HIP side reads the same windows back from the result of the timed
+                # region (brc_fetch_window, no second computation); digests of every plane, of the indel list and of the text
+                import fullcheck
+                depth = 200.0 / 30.0 if per_lib else 1.0
+                nwin = max(3 * len(pool.procs), int(contig_len * depth / 1.0e6))
+                full = fullcheck.check_region(pool, eng, parity, fullcheck.windows_of(0, contig_len, nwin), want_events=eng_events, with_text=(full_check != 2))
+                validated = dict(validated or {}, **full)
+                oc = full["oracle_cpu_seconds"]; npr = full["oracle_processes"]
+                cpu["all_cores"] = {"value": round(full["events"] / max(oc["pileup"] / npr, 1e-9), 1), "cores": npr,
+                                    "value_incl_text": round(full["events"] / max((oc["pileup"] + oc["text"]) / npr, 1e-9), 1),
+                                    "sample": "the whole timed region (%d events) as %d abutting oracle regions on %d processes at once (the CPUs this container may use: %d hardware threads, "
+                                              "cgroup quota %d): events / (summed oracle pileup seconds / processes); the same run is the whole-region validation"
+                                              % (full["events"], full["windows"], npr, ncpu, ncpu_eff)}
         # ---- end to end through the drop-in command line (BAM decode + PCIe + text)
         e2e = None
         if args.e2e_mbp > 0 and world == 1 and os.path.exists(CLI):
@@ -409,6 +423,33 @@ def main():
             import shutil
             shutil.rmtree(d, ignore_errors=True)
 
+        # ---- the engine apart from the BAM decoder: decoded batches in host memory -> text in host memory through the C-ABI
+        # (begin -> push -> upload -> compute -> device-side text -> download -> the host's line patches), piece by piece on ONE
+        # engine, nothing overlapped (the command line overlaps decode, engine and formatting of consecutive pieces on threads)
+        abi = None
+        if args.abi_mbp > 0 and world == 1 and args.mode == "weak" and not per_lib:
+            piece = 2_000_000; alen = int(min(args.abi_mbp * 1e6, contig_len))
+            cuts = [(a, min(a + piece, alen)) for a in range(0, alen, piece)]
+            pos64 = arrs["pos"].astype(np.int64)
+            batches = [capi.select_reads(arrs, fullcheck_window_reads(capi, arrs, ends, pos64, a, b)) for a, b in cuts]      # (untimed: the caller's decoded reads)
+            ha = capi.Engine(hip, device=local_rank, device_text="chrS", **opts)
+            def abi_pass():
+                tb = 0; ev = 0
+                for (a, b), sub in zip(cuts, batches):
+                    ha.begin_region(0, a, b, ref); ha.push_reads(sub); ha.end_region()
+                    if a > 0: ha.clear_indel_queue()
+                    tb += len(ha.format_region_np("chrS")); ev += ha.counts()[0]
+                return tb, ev
+            abi_pass()                                                  # (first pass: pinned buffers are allocated)
+            t0a = time.perf_counter(); tb, eva = abi_pass(); ta = time.perf_counter() - t0a
+            ha.close()
+            in_bytes = int(sum(synthgen.algorithmic_bytes(bt, 0, 1, 0, ref_positions=0)[0] for bt in batches))
+            abi = {"value": round(eva / ta, 1), "unit": "pileup base-events/s", "seconds": round(ta, 3), "events": int(eva), "pieces": len(cuts),
+                   "h2d_bytes": in_bytes, "d2h_text_bytes": int(tb), "pcie_GBs": round((in_bytes + tb) / ta / 1e9, 2),
+                   "what": "first %.0f Mbp of the timed contig through the C-ABI from decoded host batches to host text: brc_begin_region, brc_push_reads (staging copy into pinned "
+                           "memory), brc_end_region (H2D, kernels, device-side text, D2H), brc_format_region (the host's line patches), %d pieces of 2 Mbp one after the other on one "
+                           "engine, nothing overlapped, second pass timed" % (alen / 1e6, len(cuts))}
+
         # ---- the other timed BASELINE configurations, each a sub-process of this script with a short timed region; their
         # own validation (config 4: 400 sites against one oracle region per site; config-5 shape: planes + text of a prefix
         # against the oracle) runs inside them
@@ -419,13 +460,16 @@ def main():
             other = {}
             subs = {"config4_sites": ["--mode", "sites"],
                     "config5_per_gpu_shape": ["--mode", "strong", "--contig-mbp", "6.25"],
-                    # config 5 whole on ONE GPU (50 Mbp, 200x, 4 libraries: 67 M reads, 10 G events per step); validated by event
-                    # conservation only — the oracle check of this data model is the per-GPU shape's
-                    "config5_full_one_gpu": ["--mode", "strong", "--contig-mbp", "50", "--cpu-sample-mbp", "0", "--steps", "10", "--warmup", "2"]}
+                    # config 3's data model with mixed read lengths (30 % trimmed to U[100,149], 10 % 250 bases): what the one-modal-length
+                    # fast path of k_pileup2 costs on reads of other lengths
+                    "mixed_lengths": ["--mode", "weak", "--config", "wgs30x_mixed"],
+                    # config 5 whole on ONE GPU (50 Mbp, 200x, 4 libraries: 67 M reads, 10 G events per step); every position of it
+                    # against the oracle on all cores too — planes only: its text would be 72 GB
+                    "config5_full_one_gpu": ["--mode", "strong", "--contig-mbp", "50", "--full-check", "2", "--steps", "10", "--warmup", "2"]}
             for key, extra in subs.items():
-                cmd = [sys.executable, os.path.abspath(__file__), "--steps", "60", "--warmup", "5", "--cpu-all-cores", "0", "--cpu-ref-mbp", "0", "--e2e-mbp", "0", "--other-configs", "0"] + extra
+                cmd = [sys.executable, os.path.abspath(__file__), "--steps", "60", "--warmup", "5", "--cpu-ref-mbp", "0", "--e2e-mbp", "0", "--abi-mbp", "0", "--other-configs", "0"] + extra
                 try:
-                    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
                     sub = json.loads([l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1])
                     other[key] = {"value": sub["value"], "unit": sub["unit"], "ms_per_step": sub["ms_per_step"], "steps": sub["steps"], "positions_per_s": sub["positions_per_s"],
                                   "workload": sub["config"]["workload"], "events_per_step": sub["config"]["events_per_step"], "positions_per_step": sub["config"]["positions_per_step"],
@@ -438,6 +482,8 @@ def main():
                 "strong": "synthetic 200x tumor 4 libraries, 150bp reads, -p -i, 1 contig %.0f Mbp cut into %d intervals" % (total_len / 1e6, world),
                 "sites": "-l site list of %d single-base sites in file order over %d synthetic 30x contigs of %.0f Mbp (genome scaled from 3.1 Gbp), -q20 -b13, cut into %d slices"
                          % (args.sites, world, contig_len / 1e6, world)}[args.mode]
+        if config == "wgs30x_mixed":
+            what = "synthetic 30x WGS, MIXED read lengths (60 %% 150 bp, 30 %% trimmed to U[100,149], 10 %% 250 bp), 1 contig %.0f Mbp per GPU, -q20 -b13" % (contig_len / 1e6)
         if config == "tumor200x" and args.mode == "weak":
             what = "synthetic 200x tumor 4 libraries, 150bp reads, -p -i, 1 contig %.2f Mbp per GPU" % (contig_len / 1e6)
         line = {
@@ -447,7 +493,8 @@ def main():
             "config": {"workload": what, "mode": args.mode, "reads_per_gpu": int(len(region_reads["pos"])),
                        "events_per_step": int(ev_total), "positions_per_step": int(pos_total), "parallelism": "interval-shard x%d" % world},
             "positions_per_s": round(pos_total * args.steps / tmax, 1),
-            "roofline": roof, "cpu_baseline": cpu, "e2e": e2e, "validated": validated, "other_configs": other,
+            "per_rank": per_rank, "per_gpu_value": round(value / world, 1),
+            "roofline": roof, "cpu_baseline": cpu, "e2e": e2e, "abi_roundtrip": abi, "validated": validated, "other_configs": other,
             "host": {"gen_s": round(t_gen, 2), "push_s": round(t_push, 2), "upload_s": round(t_up, 2), "timed_s": round(tmax, 3)},
         }
         print(json.dumps(line))

@@ -248,6 +248,22 @@ int  brc_upload(brc_engine*);
 int  brc_compute(brc_engine*, brc_timing* timing /* may be NULL */);
 int  brc_fetch_result(brc_engine*, brc_result* out);
 
+/*
+ * A window of the last computed region, as the stand-alone region [beg0, end) would have returned it — without computing again and
+ * without the whole region's dense planes on the host: a caller that wants the statistics of a region far larger than 312 bytes per
+ * position and library of host memory allow (a 50-Mbp contig with four libraries is 62 GB dense, 23 GB in the engine's compact form
+ * on the device) walks it window by window; only the window's compact planes cross PCIe.  [beg0, end) must lie inside the computed
+ * region; the planes cover [max(beg0 - 1, 0), end) clipped to the region's planes (index 0 is the window's lead position, see
+ * brc_result).  `out` is a complete brc_result with a stride of its own (engine-owned arrays, valid until the next brc_fetch_window
+ * / brc_begin_region of this engine; a result of brc_fetch_result stays valid beside it); brc_format_region accepts it — windows
+ * formatted one after the other, in order, print the region's text, and after brc_clear_indel_queue a window prints exactly what
+ * the reference prints for a -l line [beg0 + 1, end] (bamreadcount.cpp:574-607).  n_events counts the window's columns inside
+ * [beg0, end); warn[] is a whole-region quantity and comes back zero.  Callable any number of times between brc_compute and the
+ * next brc_begin_region, before or after brc_fetch_result (not with BRC_OPT_DEVICE_TEXT regions whose planes the text replaced: it
+ * reads the device planes, which stay in place).
+ */
+int  brc_fetch_window(brc_engine*, int32_t beg0, int32_t end, brc_result* out);
+
 /* Forget deletions queued for pos+1 (d.indel_queue_map.clear(), bamreadcount.cpp:605: after every -l line,
  * NOT between command-line regions).  The queue lives in the host-side assembler (brc_format_region). */
 int  brc_clear_indel_queue(brc_engine*);

@@ -45,3 +45,16 @@ def compare_libs(lib_a, lib_b, arrs, regions, check_warn=True, **kw):
             assert x.warn[:3] == y.warn[:3], "warn counts region %d: %r vs %r" % (i, x.warn, y.warn)
     assert ta == tb, "text differs"
     return ta, resa
+
+
+def slice_result(r, lo, hi):
+    """planes of the positions [lo, hi) of a RegionResult (positions outside its planes: no reads, zeros), indel list likewise"""
+    n = hi - lo
+    def cut(a):
+        out = np.zeros(a.shape[:-1] + (n,), a.dtype)
+        a0, a1 = max(lo, r.pos0), min(hi, r.pos0 + r.n_pos)
+        if a1 > a0:
+            out[..., a0 - lo:a1 - lo] = a[..., a0 - r.pos0:a1 - r.pos0]
+        return out
+    ind = [(x["pos"], x["lib"], x["len"], x["allele"], x["i"].tobytes(), x["f"].tobytes()) for x in r.indels if lo <= x["pos"] < hi]
+    return cut(r.ncol), cut(r.depth), cut(r.istat), cut(r.fstat).view(np.uint32), ind

@@ -257,6 +257,23 @@ class SimBackend : public Backend {
         memcpy(out->warn, warn, sizeof warn);
         return BRC_OK;
     }
+    std::vector<uint32_t> w_ncol, w_depth, w_slotid, w_si, w_unavail; std::vector<float> w_sf;
+    int fetch_window(int64_t k0, int64_t n, HostPlanes* out, int64_t* stride) override {
+        if (!have_pl || k0 < 0 || n < 0 || k0 + n > c.P) return BRC_E_ARG;
+        const int64_t WS = n + 5, PS = c.PS; const int Lp = c.Lp;      // (an odd stride of its own)
+        auto cut = [&](const auto& src, auto& dst, int64_t planes) {
+            dst.assign((size_t)(planes * WS), 0);
+            for (int64_t pl = 0; pl < planes; ++pl) for (int64_t k = 0; k < n; ++k) dst[(size_t)(pl * WS + k)] = src[(size_t)(pl * PS + k0 + k)];
+        };
+        cut(ncol, w_ncol, Lp); cut(depth, w_depth, Lp); cut(slotid, w_slotid, Lp); cut(si, w_si, (int64_t)Lp * 2 * NI); cut(sf, w_sf, (int64_t)Lp * 2 * NF); cut(unavail, w_unavail, 1);
+        h_xev = xev; h_iout = iout;
+        *out = HostPlanes();
+        out->ncol = w_ncol.data(); out->depth = w_depth.data(); out->slotid = w_slotid.data(); out->si = w_si.data(); out->sf = w_sf.data(); out->unavail = w_unavail.data();
+        out->xev = h_xev.data(); out->n_xev = xev_n; out->indel = h_iout.data(); out->n_indel = (int64_t)h_iout.size();
+        out->n_events = n_events; out->n_positions = n_positions;
+        *stride = WS;
+        return BRC_OK;
+    }
     int counts(uint64_t* e, uint64_t* p) override { if (e) *e = n_events; if (p) *p = n_positions; return BRC_OK; }
 };
 

@@ -25,6 +25,28 @@ def line_of(out):
     return json.loads([l for l in out.decode().splitlines() if l.startswith("{")][-1])
 
 
+@pytest.mark.parametrize("mode,world", [("strong", 4), ("sites", 8)])
+def test_more_ranks_describe_themselves(mode, world):
+    """world 4 and 8 (the driver's scaling run goes to 8): the line carries every rank's own clock, share and memory, the
+    shares add up to the totals, and the partition is the documented one."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    small = {"strong": ["--mode", "strong", "--contig-mbp", "0.016"], "sites": ["--mode", "sites", "--contig-mbp", "0.03", "--sites", "203"]}[mode]
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + small + COMMON, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
+    assert run.returncode == 0, run.stderr.decode()[-2000:]
+    total = line_of(run.stdout)
+    pr = total["per_rank"]
+    assert total["n_gpus"] == world and [x["rank"] for x in pr] == list(range(world))
+    assert sum(x["events"] for x in pr) == total["events_per_step"] > 0 and sum(x["positions"] for x in pr) == total["positions_per_step"]
+    if mode == "sites":
+        assert total["positions_per_step"] == 203 and sorted(x["positions"] for x in pr) == sorted([203 // world + (1 if r < 203 % world else 0) for r in range(world)])
+    else:
+        for x in pr:
+            assert 3_500 < x["positions"] <= 4_000           # 16 kb cut into 4 intervals
+
+
 @pytest.mark.parametrize("mode", sorted(MODES))
 def test_two_ranks_reduce_what_each_rank_owns(mode):
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])

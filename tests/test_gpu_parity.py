@@ -120,6 +120,51 @@ def test_product_ignores_ablation_environment(dev_lib, oracle_lib, monkeypatch):
         parity.compare_libs(dev_lib, oracle_lib, arrs, [(0, 4000), (1000, 1100)], ref=ref, min_mapq=5, min_bq=10)
 
 
+@pytest.mark.parametrize("per_lib", [False, True])
+def test_hip_fetch_window_equals_the_stand_alone_region(dev_lib, oracle_lib, per_lib):
+    """brc_fetch_window: windows of a computed region come back as the stand-alone regions would (oracle: one region per window,
+    reads fetched the reference's way), planes bit for bit and — formatted after a queue reset — byte for byte; windows formatted
+    in order without resets print the whole region's text; a whole-region fetch stays valid beside them."""
+    rng = np.random.default_rng(23)
+    ref = synth.make_ref(rng, 6000, weird=0.01)
+    arrs = synth.make_batch(523, ref, 2500, style="mixed", n_libs=3 if per_lib else 1, p_nolib=0.01 if per_lib else 0.0, mismatch=0.05)
+    names = ["libA", "libB", "libC"] if per_lib else ()
+    opts = dict(per_lib=per_lib, insertion_centric=per_lib, min_mapq=5, min_bq=10)
+    eng = capi.Engine(dev_lib, lib_names=names, **opts)
+    oe = capi.Engine(oracle_lib, lib_names=names, **opts)
+    ends = capi.read_ends(arrs)
+    eng.begin_region(0, 100, 5900, ref); eng.push_reads(capi.select_reads(arrs, capi.fetch_overlapping(arrs, ends, 99, 5900)))
+    eng.upload(); eng.compute()
+    whole = eng.fetch_result(); whole_text = eng.format_region("chrS"); eng.clear_indel_queue()
+    cuts = [100, 101, 164, 1000, 1001, 2500, 4097, 5900]
+    in_order = b""
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        w = eng.fetch_window(a, b)
+        in_order += eng.format_region("chrS")
+        assert (w.beg0, w.end, w.pos0) == (a, b, max(a - 1, whole.pos0)) and w.pos0 + w.n_pos == min(b, whole.pos0 + whole.n_pos)
+        for x, y in zip(parity.slice_result(w, a - 1, b), parity.slice_result(whole, a - 1, b)):
+            assert (x == y) if isinstance(x, list) else np.array_equal(x, y)
+    assert in_order == whole_text
+    eng.clear_indel_queue()
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        oe.begin_region(0, a, b, ref); oe.push_reads(capi.select_reads(arrs, capi.fetch_overlapping(arrs, ends, a - 1, b)))
+        want = oe.end_region(); want_text = oe.format_region("chrS"); oe.clear_indel_queue()
+        got = eng.fetch_window(a, b); got_text = eng.format_region("chrS"); eng.clear_indel_queue()
+        for x, y in zip(parity.slice_result(got, a - 1, b), parity.slice_result(want, a - 1, b)):
+            assert (x == y) if isinstance(x, list) else np.array_equal(x, y)
+        assert got_text == want_text and got.n_events == want.n_events
+        if per_lib:
+            g_un = np.full(b - a + 1, 0xFFFFFFFF, np.uint32); w_un = g_un.copy()
+            g_un[got.pos0 - (a - 1):got.pos0 - (a - 1) + got.n_pos] = got.unavail != 0xFFFFFFFF; w_un[want.pos0 - (a - 1):want.pos0 - (a - 1) + want.n_pos] = want.unavail != 0xFFFFFFFF
+            assert np.array_equal(g_un, w_un)
+    # argument handling
+    with pytest.raises(capi.BrcError):
+        eng.fetch_window(50, 200)
+    with pytest.raises(capi.BrcError):
+        eng.fetch_window(200, 6000)
+    eng.close(); oe.close()
+
+
 def shuffled_arenas(arrs, seed):
     """The same reads with their QUAL / SEQ / CIGAR rows laid out in a random order inside the arenas (legal: brc.h asks for
     offsets inside the arenas, not for increasing ones), with gaps between the rows."""

@@ -26,6 +26,11 @@ typedef struct {
     double p_sub, p_clip, p_ins, p_del;
     int32_t indel_max;
     int32_t n_chunks;      /* generation chunks (fixed by the caller so that output is thread-count independent) */
+    /* mixed read lengths (adapter-trimmed / two run types in one file): a read is trimmed to U[trim_min, read_len - 1] with
+     * probability p_trim, is long_len bases long with probability p_long, read_len otherwise.  Both 0: every read read_len
+     * (and no extra draw: the fixed-length configurations generate the bytes they always did). */
+    double p_trim, p_long;
+    int32_t trim_min, long_len;
 } synth_params;
 
 typedef struct { uint64_t s[4]; } rng_t;
@@ -74,20 +79,22 @@ static void build_qtab(void) {
 }
 
 /* Arrays are caller-allocated: per-read arrays [n_reads]; cigar [3*n_reads] (stride 3 per read);
- * seq4 [n_reads * ceil(L/2)]; qual [n_reads * L]. */
+ * seq4 [n_reads * ceil(Lmax/2)]; qual [n_reads * Lmax], Lmax = max(read_len, long_len when p_long > 0): rows at a fixed stride. */
 int synth_reads(const synth_params* P, const uint8_t* ref, int32_t* pos, uint16_t* flag, uint8_t* mapq, int16_t* lib, int32_t* l_qseq,
                 uint32_t* n_cigar, uint64_t* cig_off, uint64_t* seq_off, uint64_t* qual_off, int32_t* nm, int32_t* sm, uint8_t* tags,
                 uint32_t* cigar, uint8_t* seq4, uint8_t* qual) {
-    const int L = P->read_len, SB = (L + 1) / 2;
+    const int mixed = (P->p_trim > 0 || P->p_long > 0);
+    const int Lmax = (P->p_long > 0 && P->long_len > P->read_len) ? P->long_len : P->read_len, SB = (Lmax + 1) / 2;
     const int nch = P->n_chunks > 0 ? P->n_chunks : 64;
-    if (L < 30 || L > 1000 || P->contig_len < 4 * L) return -1;
+    if (P->read_len < 30 || Lmax > 1000 || P->contig_len < 4 * Lmax) return -1;
+    if (mixed && (P->trim_min < 30 || P->trim_min >= P->read_len || (P->p_long > 0 && P->long_len < 30))) return -1;
     build_qtab();
     const double lg1mp = P->p_sub > 0 ? log(1.0 - P->p_sub) : 0.0;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int c = 0; c < nch; ++c) {
         rng_t r; rng_seed(&r, P->seed, (uint64_t)c + 1000003u);
         const int64_t r0 = P->n_reads * c / nch, r1 = P->n_reads * (c + 1) / nch;
-        const int64_t span = P->contig_len - L - 2 * P->indel_max - 1;
+        const int64_t span = P->contig_len - Lmax - 2 * P->indel_max - 1;
         const int64_t p0 = span * c / nch, p1 = span * (c + 1) / nch;
         for (int64_t i = r0; i < r1; ++i) pos[i] = (int32_t)(p0 + (int64_t)(rng_u01(&r) * (double)(p1 - p0)));
         qsort(pos + r0, (size_t)(r1 - r0), sizeof(int32_t), cmp_i32);
@@ -101,8 +108,10 @@ int synth_reads(const synth_params* P, const uint8_t* ref, int32_t* pos, uint16_
             flag[i] = f;
             mapq[i] = (rng_u01(&r) < 0.9) ? 60 : (uint8_t)rng_below(&r, 60);
             lib[i] = (int16_t)(P->n_libs > 1 ? rng_below(&r, (uint32_t)P->n_libs) : 0);
+            int L = P->read_len;
+            if (mixed) { const double ul = rng_u01(&r); if (ul < P->p_trim) L = P->trim_min + (int)rng_below(&r, (uint32_t)(P->read_len - P->trim_min)); else if (ul < P->p_trim + P->p_long) L = P->long_len; }
             l_qseq[i] = L;
-            cig_off[i] = (uint64_t)i * 3; seq_off[i] = (uint64_t)i * SB; qual_off[i] = (uint64_t)i * L;
+            cig_off[i] = (uint64_t)i * 3; seq_off[i] = (uint64_t)i * SB; qual_off[i] = (uint64_t)i * Lmax;
             uint32_t* cg = cigar + i * 3;
             /* CIGAR */
             const double uc = rng_u01(&r);
@@ -144,7 +153,7 @@ int synth_reads(const synth_params* P, const uint8_t* ref, int32_t* pos, uint16_
             for (int j = 0; j + 1 < L; j += 2) s4[j >> 1] = (uint8_t)((codes[j] << 4) | codes[j + 1]);
             if (L & 1) s4[L >> 1] = (uint8_t)(codes[L - 1] << 4);
             /* qualities */
-            uint8_t* qq = qual + (uint64_t)i * L;
+            uint8_t* qq = qual + (uint64_t)i * Lmax;
             for (int j = 0; j < L; j += 5) {
                 uint64_t x = rng_next(&r);
                 for (int k = 0; k < 5 && j + k < L; ++k, x >>= 12) qq[j + k] = QTAB[x & 4095];

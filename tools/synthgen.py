@@ -12,7 +12,7 @@ LIB = os.path.join(HERE, "libsynth.so")
 class Params(C.Structure):
     _fields_ = [("contig_len", C.c_int64), ("n_reads", C.c_int64), ("read_len", C.c_int32), ("n_libs", C.c_int32),
                 ("seed", C.c_uint64), ("p_sub", C.c_double), ("p_clip", C.c_double), ("p_ins", C.c_double), ("p_del", C.c_double),
-                ("indel_max", C.c_int32), ("n_chunks", C.c_int32)]
+                ("indel_max", C.c_int32), ("n_chunks", C.c_int32), ("p_trim", C.c_double), ("p_long", C.c_double), ("trim_min", C.c_int32), ("long_len", C.c_int32)]
 
 
 def build():
@@ -65,6 +65,10 @@ CONFIGS = {
     "wgs30x": dict(depth=30.0, read_len=150, n_libs=1, p_sub=0.005, p_clip=0.05, p_ins=0.01, p_del=0.01, indel_max=3),
     # config 5: 200x tumour, 4 libraries, 10 % of reads carry one I or D of length U[1,10]
     "tumor200x": dict(depth=200.0, read_len=150, n_libs=4, p_sub=0.005, p_clip=0.05, p_ins=0.05, p_del=0.05, indel_max=10),
+    # config 3's model with mixed read lengths (adapter-trimmed reads, two run types in one file): 30 % of the reads trimmed to
+    # U[100, 149] bases, 10 % are 250 bases long, the rest 150; the number of reads keeps the depth at 30x
+    "wgs30x_mixed": dict(depth=30.0, read_len=150, n_libs=1, p_sub=0.005, p_clip=0.05, p_ins=0.01, p_del=0.01, indel_max=3,
+                         p_trim=0.3, p_long=0.1, trim_min=100, long_len=250),
 }
 
 
@@ -72,7 +76,11 @@ def generate(contig_len, config="wgs30x", seed=1, n_chunks=64):
     """Returns (ref uint8[contig_len], arrays dict in brc_read_batch layout)."""
     cfg = CONFIGS[config]
     L = cfg["read_len"]
-    n = int(round(contig_len * cfg["depth"] / L))
+    p_trim, p_long = cfg.get("p_trim", 0.0), cfg.get("p_long", 0.0)
+    trim_min, long_len = cfg.get("trim_min", 0), cfg.get("long_len", 0)
+    mean_len = L * (1.0 - p_trim - p_long) + p_trim * (trim_min + L - 1) / 2.0 + p_long * long_len
+    n = int(round(contig_len * cfg["depth"] / mean_len))
+    L = max(L, long_len if p_long > 0 else 0)           # row stride of the arenas
     ref = np.empty(contig_len, np.uint8)
     lib().synth_ref(ref.ctypes.data_as(C.c_void_p), C.c_int64(contig_len), C.c_uint64(seed))
     a = dict(pos=np.empty(n, np.int32), flag=np.empty(n, np.uint16), mapq=np.empty(n, np.uint8), lib=np.empty(n, np.int16),
@@ -80,7 +88,8 @@ def generate(contig_len, config="wgs30x", seed=1, n_chunks=64):
              seq_off=np.empty(n, np.uint64), qual_off=np.empty(n, np.uint64), nm=np.empty(n, np.int32), sm=np.empty(n, np.int32),
              tags=np.empty(n, np.uint8), cigar=np.empty(3 * n, np.uint32), seq4=np.empty(n * ((L + 1) // 2), np.uint8),
              qual=np.empty(n * L, np.uint8))
-    p = Params(contig_len, n, L, cfg["n_libs"], seed + 1, cfg["p_sub"], cfg["p_clip"], cfg["p_ins"], cfg["p_del"], cfg["indel_max"], n_chunks)
+    p = Params(contig_len, n, cfg["read_len"], cfg["n_libs"], seed + 1, cfg["p_sub"], cfg["p_clip"], cfg["p_ins"], cfg["p_del"], cfg["indel_max"], n_chunks,
+               p_trim, p_long, trim_min, long_len)
     order = ["pos", "flag", "mapq", "lib", "l_qseq", "n_cigar", "cigar_off", "seq_off", "qual_off", "nm", "sm", "tags", "cigar", "seq4", "qual"]
     rc = lib().synth_reads(C.byref(p), ref.ctypes.data_as(C.c_void_p), *[a[k].ctypes.data_as(C.c_void_p) for k in order])
     if rc != 0:
