@@ -20,7 +20,7 @@ F_NAMES = ["sev", "sq2", "snm", "s3p"]
 EXPORTS = [
     "brc_strerror", "brc_last_error", "brc_kernel_name", "brc_engine_kind", "brc_create", "brc_destroy",
     "brc_begin_region", "brc_push_reads", "brc_upload", "brc_compute", "brc_fetch_result", "brc_end_region",
-    "brc_clear_indel_queue", "brc_region_counts", "brc_format_region", "brc_format_window", "brc_region_windows", "brc_region_warnings", "brc_window_warnings", "brc_warnings_text", "brc_set_option", "brc_format_region_parts", "brc_set_chrom", "brc_fetch_window",
+    "brc_clear_indel_queue", "brc_region_counts", "brc_format_region", "brc_format_window", "brc_region_windows", "brc_region_warnings", "brc_window_warnings", "brc_warnings_text", "brc_set_option", "brc_format_region_parts", "brc_set_chrom", "brc_fetch_window", "brc_compute_n",
 ]
 
 
@@ -90,6 +90,8 @@ class Library:
         L.brc_push_reads.argtypes = [C.c_void_p, C.POINTER(ReadBatch)]
         L.brc_upload.argtypes = [C.c_void_p]
         L.brc_compute.argtypes = [C.c_void_p, C.POINTER(Timing)]
+        if hasattr(L, "brc_compute_n"):
+            L.brc_compute_n.argtypes = [C.c_void_p, C.c_int32, C.POINTER(Timing)]
         L.brc_fetch_result.argtypes = [C.c_void_p, C.POINTER(Result)]
         L.brc_end_region.argtypes = [C.c_void_p, C.POINTER(Result)]
         if hasattr(L, "brc_fetch_window"):
@@ -281,6 +283,12 @@ class Engine:
     def compute(self):
         t = Timing()
         self._check(self.L.lib.brc_compute(self.h, C.byref(t)))
+        return [float(x) for x in t.ms], float(t.total_ms)
+
+    def compute_n(self, n):
+        """n passes queued back to back, one wait (include/brc.h: brc_compute_n); per-kernel ms averaged over the passes"""
+        t = Timing()
+        self._check(self.L.lib.brc_compute_n(self.h, n, C.byref(t)))
         return [float(x) for x in t.ms], float(t.total_ms)
 
     def fetch_result(self):

@@ -1416,7 +1416,12 @@ class HipBackend : public Backend {
     std::string err;
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t evt[T_N + 1];
+    // one set of timing events per pass in flight: brc_compute uses set 0, brc_compute_n a ring of them (passes queued back to
+    // back record into sets of their own, read after the one wait at the end of a batch)
+    enum { EV_RING = 32 };
+    struct EvSet { hipEvent_t evt[T_N + 1]; hipEvent_t ev_indel[4]; };
+    std::vector<EvSet> evsets;
+    hipEvent_t* evt = nullptr;           // the current pass's sets (point into evsets)
     bool have_events = false;
     DevCfg c; DevIn in;
     int64_t ntiles = 0; uint64_t n_indel_cap = 0;
@@ -1429,7 +1434,7 @@ class HipBackend : public Backend {
     // device-side text, downloaded (pinned) on its own stream into one of two host buffers
     HBuf<char> h_text[2]; HBuf<uint32_t> h_toff[2]; HBuf<uint32_t> h_total;
     hipStream_t stream2 = nullptr; hipEvent_t ev_text[2] = {nullptr, nullptr}, ev_lines = nullptr;
-    hipStream_t stream3 = nullptr; hipEvent_t ev_indel[4] = {nullptr, nullptr, nullptr, nullptr}; DBuf d_agg2;   // the indel side path's stream
+    hipStream_t stream3 = nullptr; hipEvent_t* ev_indel = nullptr; DBuf d_agg2;   // the indel side path's stream
     bool text_started[2] = {false, false}; uint64_t text_total[2] = {0, 0}; int64_t text_n[2] = {0, 0}; int text_slot = 0;
     Planes pl_last;                      // the planes of the last compute
     // host result buffers (pinned)
@@ -1455,11 +1460,9 @@ class HipBackend : public Backend {
         device = dev;
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        for (int i = 0; i <= T_N; ++i) HIPCHK(hipEventCreate(&evt[i]));
-        have_events = true;
+        { const int rc0 = ensure_evsets(1); if (rc0) return rc0; }
         HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&stream3, hipStreamNonBlocking));
-        for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&ev_indel[i]));
         hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, stream);
         HIPCHK(hipStreamSynchronize(stream));
         for (int i = 0; i < 2; ++i) { HIPCHK(hipEventCreateWithFlags(&ev_text[i], hipEventDisableTiming)); h_text[i].A = &kPinned; h_toff[i].A = &kPinned; }
@@ -1478,13 +1481,22 @@ class HipBackend : public Backend {
         h_total.destroy();
         if (ev_lines) (void)hipEventDestroy(ev_lines);
         if (stream2) (void)hipStreamDestroy(stream2);
-        for (int i = 0; i < 4; ++i) if (ev_indel[i]) (void)hipEventDestroy(ev_indel[i]);
         if (stream3) (void)hipStreamDestroy(stream3);
         d_agg2.release();
         h_ncol.destroy(); h_depth.destroy(); h_slotid.destroy(); h_si.destroy(); h_unavail.destroy(); h_sf.destroy(); h_iout.destroy(); h_xev.destroy();
         if (w_init) { w_ncol.destroy(); w_depth.destroy(); w_slotid.destroy(); w_si.destroy(); w_unavail.destroy(); w_sf.destroy(); }
-        if (have_events) for (int i = 0; i <= T_N; ++i) (void)hipEventDestroy(evt[i]);
+        for (EvSet& es : evsets) { for (int i = 0; i <= T_N; ++i) if (es.evt[i]) (void)hipEventDestroy(es.evt[i]); for (int i = 0; i < 4; ++i) if (es.ev_indel[i]) (void)hipEventDestroy(es.ev_indel[i]); }
         if (stream) (void)hipStreamDestroy(stream);
+    }
+    int ensure_evsets(size_t n) {
+        while (evsets.size() < n) {
+            EvSet es; memset(&es, 0, sizeof es);
+            evsets.push_back(es);
+            for (int i = 0; i <= T_N; ++i) HIPCHK(hipEventCreate(&evsets.back().evt[i]));
+            for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&evsets.back().ev_indel[i]));
+        }
+        evt = evsets[0].evt; ev_indel = evsets[0].ev_indel; have_events = true;
+        return BRC_OK;
     }
     const HostAlloc* host_alloc() override { return &kPinned; }
     const char* last_error() const override { return err.c_str(); }
@@ -1595,8 +1607,9 @@ class HipBackend : public Backend {
         return BRC_OK;
     }
 
-    int compute(brc_timing* t) override {
-        HIPCHK(hipSetDevice(device));
+    // One pass of the whole pipeline, queued on the engine's stream; its timing events go to event set `set`.
+    int enqueue_pass(size_t set) {
+        evt = evsets[set].evt; ev_indel = evsets[set].ev_indel;
         const int64_t n = c.n_reads, P = c.P; const int Lp = c.Lp;
         int rc;
         Counters* ctr = (Counters*)d_ctr.p;
@@ -1711,19 +1724,60 @@ if (has_wanted) {
         if (indels && indel_overlap) HIPCHK(hipStreamWaitEvent(stream, ev_indel[3], 0));
         HIPCHK(hipEventRecord(evt[T_N], stream));
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(&h_ctr, ctr, sizeof(Counters), hipMemcpyDeviceToHost, stream));
+        return BRC_OK;
+    }
+    // the counters of the last queued pass -> host, wait; 1 = a third-allele sub-list was too short (lists grown: compute again)
+    int finish_passes(bool* again) {
+        HIPCHK(hipMemcpyAsync(&h_ctr, d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
-        if ((size_t)h_ctr.xev_max > xev_cap) {        // a third-allele sub-list was too short: grow them and compute again
+        *again = false;
+        if ((size_t)h_ctr.xev_max > xev_cap) {
             xev_cap = (size_t)h_ctr.xev_max * 2;
             HIPCHK(d_xev.ensure(((size_t)XEV_SHARDS * xev_cap + 1) * sizeof(XEv))); HIPCHK(d_xevc.ensure(((size_t)XEV_SHARDS * xev_cap + 1) * sizeof(XEv)));
-            return compute(t);
+            *again = true;
         }
-        if (t) {
-            memset(t, 0, sizeof *t);
-            for (int i = 0; i < T_INDEL_SCAN; ++i) HIPCHK(hipEventElapsedTime(&t->ms[i], evt[i], evt[i + 1]));
-            if (indels) for (int i = 0; i < 3; ++i) HIPCHK(hipEventElapsedTime(&t->ms[T_INDEL_SCAN + i], ev_indel[i], ev_indel[i + 1]));
-            HIPCHK(hipEventElapsedTime(&t->total_ms, evt[0], evt[T_N]));
+        return BRC_OK;
+    }
+    // adds the per-kernel times of the pass recorded in event set `set` to t (slots and total)
+    int add_timing(size_t set, brc_timing* t) {
+        const bool indels = n_indel_cap > 0 && c.P > 0 && c.n_reads > 0;
+        const EvSet& es = evsets[set]; float ms = 0;
+        for (int i = 0; i < T_INDEL_SCAN; ++i) { HIPCHK(hipEventElapsedTime(&ms, es.evt[i], es.evt[i + 1])); t->ms[i] += ms; }
+        if (indels) for (int i = 0; i < 3; ++i) { HIPCHK(hipEventElapsedTime(&ms, es.ev_indel[i], es.ev_indel[i + 1])); t->ms[T_INDEL_SCAN + i] += ms; }
+        HIPCHK(hipEventElapsedTime(&ms, es.evt[0], es.evt[T_N])); t->total_ms += ms;
+        return BRC_OK;
+    }
+    int compute(brc_timing* t) override {
+        HIPCHK(hipSetDevice(device));
+        for (;;) {
+            int rc = enqueue_pass(0); if (rc) return rc;
+            bool again = false;
+            if ((rc = finish_passes(&again))) return rc;
+            if (!again) break;                           // (a third-allele sub-list was too short: the lists were grown, compute again)
         }
+        if (t) { memset(t, 0, sizeof *t); const int rc = add_timing(0, t); if (rc) return rc; }
+        computed = true;
+        return BRC_OK;
+    }
+    // n passes over the uploaded region queued back to back, ONE wait per ring of event sets: between two passes the device
+    // never waits for the host (submission of pass k + 1 runs under the kernels of pass k).  t: per-kernel times averaged over
+    // the passes; total_ms: the passes' own first-launch-to-last-completion spans, averaged.
+    int compute_n(int n, brc_timing* t) override {
+        HIPCHK(hipSetDevice(device));
+        if (n <= 0) return BRC_OK;
+        int rc = ensure_evsets((size_t)std::min<int>(n, EV_RING)); if (rc) return rc;
+        brc_timing acc; memset(&acc, 0, sizeof acc);
+        int done = 0;
+        while (done < n) {
+            const int k = std::min<int>(n - done, EV_RING);
+            for (int i = 0; i < k; ++i) if ((rc = enqueue_pass((size_t)i))) return rc;
+            bool again = false;
+            if ((rc = finish_passes(&again))) return rc;
+            if (again) continue;                         // (lists grown: this ring's passes are repeated)
+            if (t) for (int i = 0; i < k; ++i) if ((rc = add_timing((size_t)i, &acc))) return rc;
+            done += k;
+        }
+        if (t) { for (int i = 0; i < BRC_NKERNEL; ++i) t->ms[i] = acc.ms[i] / (float)n; t->total_ms = acc.total_ms / (float)n; }
         computed = true;
         return BRC_OK;
     }

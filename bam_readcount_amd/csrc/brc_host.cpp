@@ -595,11 +595,17 @@ int brc_upload(brc_engine* e) {
     return BRC_OK;
 }
 
-int brc_compute(brc_engine* e, brc_timing* t) {
+static int compute_passes(brc_engine* e, int32_t n, brc_timing* t);
+int brc_compute(brc_engine* e, brc_timing* t) { return compute_passes(e, 0, t); }
+int brc_compute_n(brc_engine* e, int32_t n, brc_timing* t) {
+    if (n < 1) return e ? fail(e, BRC_E_ARG, "brc_compute_n: at least one pass") : BRC_E_ARG;
+    return compute_passes(e, n, t);
+}
+static int compute_passes(brc_engine* e, int32_t n, brc_timing* t) {
     if (!e) return BRC_E_ARG;
     if (e->state < 2) return fail(e, BRC_E_ARG, "brc_compute before brc_upload");
     const double t_in = now_s();
-    int rc = e->be->compute(t);
+    int rc = n > 0 ? e->be->compute_n(n, t) : e->be->compute(t);
     if (rc) return fail(e, rc, e->be->last_error());
     // device-side text: the line kernels and the download start as soon as the region is computed (lines above 4 GiB per
     // region would overflow the 32-bit offsets: such regions are formatted on the host)

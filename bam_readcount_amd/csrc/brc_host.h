@@ -110,6 +110,13 @@ class Backend {
     virtual const HostAlloc* host_alloc() = 0;
     virtual int upload(const brc_config& cfg, const Staged& s, Geometry& g) = 0;         // staging -> device; sets g.PS
     virtual int compute(brc_timing* t) = 0;                                              // whole pipeline, waits
+    // n passes queued back to back with one wait (default: n waits); t = per-kernel times averaged over the passes
+    virtual int compute_n(int n, brc_timing* t) {
+        brc_timing acc; memset(&acc, 0, sizeof acc);
+        for (int i = 0; i < n; ++i) { brc_timing one; memset(&one, 0, sizeof one); const int rc = compute(&one); if (rc) return rc; for (int k = 0; k < BRC_NKERNEL; ++k) acc.ms[k] += one.ms[k]; acc.total_ms += one.total_ms; }
+        if (t && n > 0) { for (int k = 0; k < BRC_NKERNEL; ++k) t->ms[k] = acc.ms[k] / (float)n; t->total_ms = acc.total_ms / (float)n; }
+        return BRC_OK;
+    }
     virtual int fetch(HostPlanes* out, bool planes) = 0;                                 // device -> host: counters, third-allele and indel lists, and (planes) the slot planes
     // the slot planes of plane indices [k0, k0 + n) only (host planes `*stride` elements apart), and the region's two lists whole
     virtual int fetch_window(int64_t k0, int64_t n, HostPlanes* out, int64_t* stride) = 0;

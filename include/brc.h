@@ -247,6 +247,11 @@ int  brc_push_reads(brc_engine*, const brc_read_batch*);
 int  brc_upload(brc_engine*);
 int  brc_compute(brc_engine*, brc_timing* timing /* may be NULL */);
 int  brc_fetch_result(brc_engine*, brc_result* out);
+/* n passes of brc_compute over the uploaded region, queued back to back on the engine's stream with ONE wait at the end: between
+ * two passes the device never waits for the host (a caller that keeps a region resident and runs it repeatedly — the benchmark's
+ * timed steps; the state afterwards is that of one brc_compute).  timing (may be NULL): per-kernel times averaged over the
+ * passes, from HIP events of every pass; total_ms = the passes' own spans (first launch to last completion), averaged. */
+int  brc_compute_n(brc_engine*, int32_t n, brc_timing* timing);
 
 /*
  * A window of the last computed region, as the stand-alone region [beg0, end) would have returned it — without computing again and

@@ -165,6 +165,29 @@ def test_hip_fetch_window_equals_the_stand_alone_region(dev_lib, oracle_lib, per
     eng.close(); oe.close()
 
 
+def test_hip_passes_back_to_back_leave_the_result_of_one(dev_lib, oracle_lib, monkeypatch):
+    """brc_compute_n: passes queued without a host wait in between (more of them than the engine has event sets; with a tiny
+    third-allele list: the grow-and-repeat path inside a batch) leave exactly the result of one brc_compute."""
+    rng = np.random.default_rng(61)
+    ref = synth.make_ref(rng, 4000, weird=0.01)
+    arrs = synth.make_batch(261, ref, 1200, style="mixed", mismatch=0.2)
+    want_t, want_r = parity.run_engine(oracle_lib, arrs, [(0, 4000)], ref=ref, min_bq=10)
+    for env in ({}, {"BRC_XEV_CAP": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = capi.Engine(dev_lib, min_bq=10)
+        eng.begin_region(0, 0, 4000, ref); eng.push_reads(arrs); eng.upload()
+        ms, tot = eng.compute_n(70)
+        assert len(ms) == 8 and tot >= 0
+        got = eng.fetch_result()
+        parity.assert_results_equal(got, want_r[0], "after 70 passes")
+        assert eng.format_region("chrS") == want_t
+        eng.compute_n(1); parity.assert_results_equal(eng.fetch_result(), want_r[0], "after one more")
+        with pytest.raises(capi.BrcError):
+            eng.compute_n(0)
+        eng.close()
+
+
 def shuffled_arenas(arrs, seed):
     """The same reads with their QUAL / SEQ / CIGAR rows laid out in a random order inside the arenas (legal: brc.h asks for
     offsets inside the arenas, not for increasing ones), with gaps between the rows."""
