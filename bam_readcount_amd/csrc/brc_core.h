@@ -58,6 +58,9 @@ enum { A_SMQ = 0, A_SSE, A_PLUS, A_MINUS, A_NQ2, A_SMMQ, A_SCLIP, A_SBQ, NACC_I 
 
 static const uint32_t NONE32 = 0xFFFFFFFFu;
 static const int TILE = 64;   // positions per wave = lanes per wavefront on gfx950
+// brc_region_windows: a tile's entry in the wanted table — TILE_UNWANTED, or first lane | last lane << 8 of what the windows ask for
+enum { TILE_UNWANTED = 0xffff };
+BRC_HD bool tile_wants(uint32_t w, uint32_t lane) { return w != (uint32_t)TILE_UNWANTED && lane >= (w & 0xffu) && lane <= (w >> 8); }
 
 struct DevCfg {
     int32_t min_mapq, min_bq, per_lib, insertion_centric, Lp, ref_len_check, has_ref;
@@ -84,11 +87,16 @@ struct DevIn {
     const uint32_t* n_cigar; const uint64_t* cig_off; const uint64_t* seq_off; const uint64_t* qual_off;
     const int32_t* nm; const int32_t* sm; const uint8_t* tags;
     const uint32_t* cigar; const uint8_t* seq4; const uint8_t* qual; const char* ref;
-    // device-produced by K1: per base  quality << 8 | bucket("=ACGTN") (the "event word": `word >= min_bq << 8` is the
-    // base-quality test of bamreadcount.cpp:288 without unpacking); read i's row starts at element bq_row[i]
-    // (rows are padded to multiples of 8 elements so every row is 16-byte aligned: KB bulk-loads row windows as uint4)
-    const uint16_t* bq;
-    const uint64_t* bq_row;  // [n_reads] host-computed prefix sums of roundup8(l_qseq)
+    // device-produced by K1: ONE BYTE per base, the "event byte" (see eb_make below): quality << 2 | base index (A C G T = 0..3)
+    // — `byte >= min_bq << 2` is the base-quality test of bamreadcount.cpp:288 without unpacking, `byte & 3` against the lane's
+    // reference base says "the reference base's bucket".  Read i's row starts at element bq_row[i] (rows are padded to multiples
+    // of 16 elements so every row is 16-byte aligned: KB copies row windows into LDS 16 bytes at a time).  The few bases a byte
+    // cannot describe (quality 0 or above 62, an N or '=' base) carry an ESCAPE byte that still answers the quality test, and
+    // their full word quality << 8 | bucket("=ACGTN") is in `bqw` at the same element index (written for those 8-base groups
+    // only); the pieces of such a read are marked PF_WIDE.
+    const uint8_t* eb;
+    const uint16_t* bqw;
+    const uint64_t* bq_row;  // [n_reads] host-computed prefix sums of roundup16(l_qseq)
     const uint32_t* iev_off; // [n_reads] host-computed: first slot of the read in the raw indel-event list (one slot per I/D/P operator)
     const struct RcpPair* rcp;   // [n_reads], device-produced by K1
 };
@@ -196,10 +204,37 @@ BRC_HD uint32_t ref_at(const DevCfg& c, const char* ref, int64_t p) {
     return (p >= 0 && p < c.ref_len && p >= c.ref_lo && p < c.ref_hi) ? (uint32_t)(uint8_t)ref[p - c.ref_lo] : 0u;
 }
 
+// ---------------------------------------------------------------- the event byte
+//
+//   byte = q << 2 | i         1 <= q <= 62: the base quality;  i = 0..3: the base is A C G T (bucket i + 1)
+//   byte = 63 << 2 / 0        ESCAPE (quality 0 or >= 63, or an N / '=' base): 63 << 2 when the base passes the base-quality
+//                             filter (q >= -b), 0 when it does not — so `byte >= piece_thr` is the filter for every byte; the
+//                             truth is in DevIn.bqw
+// Nothing in a byte depends on the reference: K1 writes it for every base alike (the indel side path compares inserted bases
+// through the same bytes, same_allele).  A lane compares `byte & 3` with the index of its reference base (dom_index; 4 and 5
+// for a reference base that is not A C G T: no byte matches).  Events of an N / '=' base are rare and never enter a lane's two
+// slots: they go to the third-allele list whatever the slots hold ("exotic").
+// The accumulators add event VALUES q << 2 | i with the full quality (up to 255): every event of a slot has the slot's index,
+// so the slot's base-quality sum is (sum - count * i) >> 2 — no unpacking per event.
+enum { EB_ESC = 63 };
+BRC_HD bool bucket_acgt(uint32_t b) { return b - 1u < 4u; }
+BRC_HD uint32_t eb_index(uint32_t b) { return bucket_acgt(b) ? b - 1u : 0u; }              // the index an event VALUE of bucket b carries
+BRC_HD uint32_t dom_index(uint32_t dom_b) { return bucket_acgt(dom_b) ? dom_b - 1u : (dom_b == 5u ? 4u : 5u); }   // what a lane compares `byte & 3` with
+BRC_HD uint32_t dom_bucket_of_index(uint32_t di) { return di < 4u ? di + 1u : (di == 4u ? 5u : 0u); }
+BRC_HD bool eb_is_escape(uint32_t byte) { const uint32_t q6 = byte >> 2; return q6 == 0u || q6 == (uint32_t)EB_ESC; }
+BRC_HD uint32_t eb_min_bq(int32_t min_bq) { return (uint32_t)(min_bq < 0 ? 0 : (min_bq > EB_ESC ? EB_ESC : min_bq)); }
+// the byte of a base; esc: it is an escape (the caller stores the wide word of its 8-base group too)
+BRC_HD uint32_t eb_make(int32_t min_bq, uint32_t q, uint32_t b, bool& esc) {
+    esc = q == 0u || q >= (uint32_t)EB_ESC || !bucket_acgt(b);
+    if (!esc) return (q << 2) | (b - 1u);
+    return (int32_t)q >= min_bq ? ((uint32_t)EB_ESC << 2) : 0u;
+}
+
 // ---------------------------------------------------------------- K1: per-read annotation (fetch_func)
 
 // Restates bamreadcount.cpp:114-256 for read i and packs everything KB needs into a DRead.
-BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i, uint16_t* bq_out) {
+// `wide`: the read has a base its event byte cannot describe (its pieces are marked PF_WIDE)
+BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i, uint8_t* eb_out, uint16_t* bqw_out, bool& wide) {
     DRead r;
     const int32_t pos = in.pos[i];
     const uint32_t flag = in.flag[i];
@@ -285,8 +320,21 @@ BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i, uint16_t
     r.cig_off = (uint32_t)in.cig_off[i];
     r.n_cigar = nc;
     r.bq_off = in.bq_row[i];
-    // per-base stream for KB: quality | bucket << 8
-    for (int j = 0; j < L; ++j) bq_out[in.bq_row[i] + (uint64_t)j] = (uint16_t)((qual[j] << 8) | canon_bucket(seqi(seq, j)));
+    // per-base stream for KB: the event bytes; an escape byte brings the whole 8-base group's words into the wide stream (as
+    // the group form of K1 writes them)
+    wide = false;
+    {
+        const uint64_t row = in.bq_row[i];
+        for (int j = 0; j < L; ++j) {
+            bool esc;
+            eb_out[row + (uint64_t)j] = (uint8_t)eb_make(c.min_bq, qual[j], canon_bucket(seqi(seq, j)), esc);
+            if (esc) {
+                wide = true;
+                const int g0 = j & ~7;
+                for (int t = g0; t < g0 + 8 && t < L; ++t) bqw_out[row + (uint64_t)t] = (uint16_t)((qual[t] << 8) | canon_bucket(seqi(seq, t)));
+            }
+        }
+    }
     const int lib = c.per_lib ? (int)in.lib[i] : 0;
     uint32_t misc = (mapq << 8) | ((uint32_t)((lib + 1) & 0xff) << 16);
     if (rev) misc |= M_REV;
@@ -382,8 +430,10 @@ enum { NB_NONE = 7 };      // "no alternate bucket yet"
 #define BRC_UNROLL _Pragma("GCC unroll 16")
 #endif
 
-// dominant bucket of position p: the bucket of its reference base ('A' when there is no reference)
+// dominant bucket of position p: the bucket of its reference base ('A' when there is no reference); BRC_FORCE_DOM (test
+// knob) names one bucket for every position
 BRC_HD uint32_t dominant_bucket(const DevCfg& c, const DevIn& in, int64_t p) {
+    if (c.force_dom >= 0) return (uint32_t)c.force_dom;
     if (!c.has_ref) return 1u;
     return canon_bucket(nt16_of_char(ref_at(c, in.ref, p)));
 }
@@ -405,12 +455,16 @@ BRC_HD uint32_t dominant_bucket(const DevCfg& c, const DevIn& in, int64_t p) {
 enum PieceFlag { PF_TABLE = 1,    // event terms come from the quotient tables (l_qseq == clipped == table_len, left_clip == 0, q2 in {tp, none})
        PF_Q2OK = 2, PF_NB = 4,
        PF_HUGE = 8,     // a per-read integer does not fit its packed field: w2/w3 carry only the mapping quality, the rest is added by drain_int()
-       PF_SMW = 16, PF_NMW = 32, PF_REV = 64,
-       PF_TABQ = 128 };  // without PF_HUGE: no PF_TABLE only because the read is soft-clipped (l_qseq == table_len, left_clip < 512, q2 in {tp, none}, no PF_HUGE): the two
+       PF_WIDE = 16,    // the read has escape bytes in its row (never with PF_TABLE): lanes that meet one take quality and bucket from DevIn.bqw; an N / '=' base goes to the third-allele list
+       PF_DIV = 32,     // a read of another length (<= 255 bases; q2 in {tp, none}; no PF_TABLE / PF_TABQ / PF_HUGE): the event terms are divided out in the
+                        // lane from the record itself — its tp field holds three_prime_index | l_qseq << 8 | left_clip << 16 — without the rare record
+       PF_REV = 64,
+       PF_TABQ = 128,
+       PF_SMW = 256, PF_NMW = 512 };   // (ReadConst.flags only: the record's flag byte has no room for them, its ww field carries them)  // without PF_HUGE: no PF_TABLE only because the read is soft-clipped (l_qseq == table_len, left_clip < 512, q2 in {tp, none}, no PF_HUGE): the two
                          // distances still come from the quotient table, the event location is divided out in the lane — from clipped_length (w3)
                          // and left_clip (the record's tp field), without the piece's rare record.  With PF_HUGE: a table piece (all terms from the tables)
-// an event word w passes the base-quality test (:288) iff w >= piece_thr(c)  (0x10000: no 16-bit word reaches it)
-BRC_HD uint32_t piece_thr(const DevCfg& c) { return (uint32_t)(c.min_bq < 0 ? 0 : (c.min_bq > 256 ? 256 : c.min_bq)) << 8; }
+// an event byte w passes the base-quality test (:288) iff w >= piece_thr(c)  (-b above 62: only escape bytes of passing bases reach it)
+BRC_HD uint32_t piece_thr(const DevCfg& c) { return eb_min_bq(c.min_bq) << 2; }
 
 // One piece record, 48 bytes.  Dwords 0-9 are what the read loop of k_pileup2 needs of every piece (scalar loads x8 + x2, two
 // pieces ahead); bytes 32-47 = {ww, a, bq_off} are the one 16-byte word the staging lanes load.
@@ -440,7 +494,8 @@ BRC_HD uint32_t piece_flags(const Piece& h) { return h.tp_flags >> 24; }
 BRC_HD int32_t piece_tp_field(uint32_t tp_flags) { return (int32_t)(tp_flags << 17) >> 17; }     // (bits 0-14, sign-extended)
 BRC_HD int piece_left_field(uint32_t tp_flags) { return (int)((tp_flags >> 15) & 0x1ffu); }
 BRC_HD int piece_tp_of(uint32_t tp_flags, int table_len) {
-    return ((tp_flags >> 24) & (PF_TABLE | PF_TABQ)) ? (piece_tp_field(tp_flags) + 8 * table_len) >> 4 : (int)(tp_flags & 0xffffffu);
+    const uint32_t fl = tp_flags >> 24;
+    return (fl & (PF_TABLE | PF_TABQ)) ? (piece_tp_field(tp_flags) + 8 * table_len) >> 4 : (fl & PF_DIV) ? (int)(tp_flags & 0xffu) : (int)(tp_flags & 0xffffffu);
 }
 // the event-location term of a PF_TABQ piece at query position qpos: |(qpos - left) - cl/2| / (cl/2) is the correctly rounded quotient of the
 // rational |2 (qpos - left) - cl| / cl — the same float whichever pair of exactly represented operands is divided (BasicStat.cpp:69-70)
@@ -463,17 +518,17 @@ BRC_HD uint32_t piece_clipped(const PieceRare& r) { return (uint32_t)(r.center *
 // what K1 knows about a read once it is annotated
 struct ReadConst {
     int32_t pos, l_qseq, clipped, left, tp, q2;
-    uint32_t flags;        // PF_REV | PF_Q2OK | PF_SMW | PF_NMW
+    uint32_t flags;        // PF_REV | PF_Q2OK | PF_SMW | PF_NMW | PF_WIDE
     uint32_t mapq, zm, sse;
     float snm;
     uint64_t bq_off; uint32_t read;
     bool counts;           // MAPQ >= -q and no SECONDARY/QCFAIL/DUP flag
 };
 
-BRC_HD ReadConst read_const(const DevCfg& c, const DRead& rd, uint32_t read_index) {
+BRC_HD ReadConst read_const(const DevCfg& c, const DRead& rd, uint32_t read_index, bool wide) {
     ReadConst rc;
     rc.pos = rd.pos; rc.l_qseq = rd.l_qseq; rc.clipped = rd.clipped; rc.left = rd.left; rc.tp = rd.tp; rc.q2 = rd.q2;
-    rc.flags = ((rd.misc & M_REV) ? (uint32_t)PF_REV : 0u) | ((rd.misc & M_Q2OK) ? (uint32_t)PF_Q2OK : 0u) | ((rd.misc & M_SMW) ? (uint32_t)PF_SMW : 0u) | ((rd.misc & M_NMW) ? (uint32_t)PF_NMW : 0u);
+    rc.flags = ((rd.misc & M_REV) ? (uint32_t)PF_REV : 0u) | ((rd.misc & M_Q2OK) ? (uint32_t)PF_Q2OK : 0u) | ((rd.misc & M_SMW) ? (uint32_t)PF_SMW : 0u) | ((rd.misc & M_NMW) ? (uint32_t)PF_NMW : 0u) | (wide ? (uint32_t)PF_WIDE : 0u);
     rc.mapq = (rd.misc >> 8) & 0xffu; rc.zm = rd.zm_sum; rc.sse = rd.sse_add; rc.snm = rd.snm_add; rc.bq_off = rd.bq_off; rc.read = read_index;
     rc.counts = (int)rc.mapq >= c.min_mapq && !(rd.misc & M_NOCOUNT);
     return rc;
@@ -556,6 +611,9 @@ BRC_HD void make_piece(const DevCfg& c, const ReadConst& r, int32_t rs, int32_t 
     const bool q2ok = (fl & PF_Q2OK) != 0;
     if (c.table_len > 0 && r.l_qseq == c.table_len && r.clipped == c.table_len && r.left == 0 && r.tp >= 0 && r.tp <= c.table_len &&
         (!q2ok || r.q2 == r.tp)) fl |= PF_TABLE;
+    // a wide read's pieces sit behind the same test; one that would have been a table piece keeps "every term from the table" as
+    // PF_TABQ (no clip: the in-lane event location of the PF_TABQ path is the table's value)
+    if ((fl & PF_WIDE) && (fl & PF_TABLE)) fl = (fl & ~(uint32_t)PF_TABLE) | PF_TABQ;
     // k_pileup2 finds every unusual piece behind ONE test, "no PF_TABLE": -i's one-base pieces, and pieces with huge integers —
     // those keep PF_TABQ as the mark of "all three terms from the tables" when they were table pieces
     if (nb) fl = (fl | PF_NB) & ~(uint32_t)PF_TABLE;
@@ -563,7 +621,10 @@ BRC_HD void make_piece(const DevCfg& c, const ReadConst& r, int32_t rs, int32_t 
     if (huge) fl = (fl & PF_TABLE) ? ((fl & ~(uint32_t)PF_TABLE) | PF_HUGE | PF_TABQ) : (fl | PF_HUGE);
     if (!(fl & (PF_TABLE | PF_TABQ)) && !nb && !huge && c.table_len > 0 && r.l_qseq == c.table_len && r.clipped > 0 && r.left >= 0 && r.left < 512 &&
         r.tp >= 0 && r.tp <= c.table_len && (!q2ok || r.q2 == r.tp)) fl |= PF_TABQ;
-    h.tp_flags = ((fl & (PF_TABLE | PF_TABQ)) ? (((uint32_t)(16 * r.tp - 8 * c.table_len) & 0x7fffu) | ((uint32_t)r.left << 15)) : ((uint32_t)r.tp & 0xffffffu)) | (fl << 24);      // l_qseq < 2^22 is checked at push
+    if (!(fl & (PF_TABLE | PF_TABQ | PF_NB)) && !huge && r.l_qseq > 0 && r.l_qseq <= 255 && r.clipped > 0 && r.left >= 0 && r.left <= 255 && r.tp >= 0 && r.tp <= 255 &&
+        (!q2ok || r.q2 == r.tp)) fl |= PF_DIV;
+    h.tp_flags = ((fl & (PF_TABLE | PF_TABQ)) ? (((uint32_t)(16 * r.tp - 8 * c.table_len) & 0x7fffu) | ((uint32_t)r.left << 15)) :
+                  (fl & PF_DIV) ? ((uint32_t)r.tp | ((uint32_t)r.l_qseq << 8) | ((uint32_t)r.left << 16)) : ((uint32_t)r.tp & 0xffffffu)) | ((fl & 0xffu) << 24);      // l_qseq < 2^22 is checked at push
     h.w1 = 1u | ((fl & PF_REV) ? (1u << 10) : 0u) | (q2ok ? (1u << 20) : 0u);
     h.w2 = r.mapq | (huge ? 0u : (r.sse << 16));
     h.w3 = huge ? 0u : (r.zm | ((uint32_t)r.clipped << 16));
@@ -587,6 +648,19 @@ BRC_HD EvTerms piece_terms_div(uint32_t fl, int tp, const PieceRare& r, int qpos
     t.sev = 1.0 - (double)div_rcp(d, r.center, r.rcpC);
     return t;
 }
+// ... a PF_DIV piece's from its own record (tp | l_qseq << 8 | left_clip << 16 in the tp field, clipped_length in w3): the
+// reference's own expressions, BasicStat.cpp:60-70 (fp32 division: correctly rounded on the device too; q2 == tp or no q2)
+BRC_HD EvTerms piece_terms_inlane(uint32_t fl, uint32_t tp_flags, uint32_t w3, int qpos) {
+    EvTerms t;
+    const int tp = (int)(tp_flags & 0xffu), left = (int)((tp_flags >> 16) & 0xffu);
+    const float Lf = (float)((tp_flags >> 8) & 0xffu), center = (float)(w3 >> 16) * 0.5f;
+    t.s3p = (float)BRC_ABSDIFF(qpos, tp) / Lf;
+    t.q2 = (fl & PF_Q2OK) ? t.s3p : 0.0f;
+    float d = (float)(qpos - left) - center;
+    d = d < 0.0f ? -d : d;
+    t.sev = 1.0 - (double)(d / center);
+    return t;
+}
 // ... and from the quotient tables (PF_TABLE): one float look-up serves both distances (q2 == tp or no q2)
 BRC_HD EvTerms piece_terms_tab(const Piece& h, const TermTab& tt, int table_len, int qpos) {
     EvTerms t;
@@ -597,8 +671,8 @@ BRC_HD EvTerms piece_terms_tab(const Piece& h, const TermTab& tt, int table_len,
 }
 
 // One bucket of a lane between two flushes: three packed integer registers (w1: three 10-bit counters; w2, w3: two 16-bit
-// sums each, which bound K: 255 x K and clipped_length x K must stay below 2^16), the sum of the EVENT WORDS (quality << 8 | bucket: every event of a slot
-// has the slot's bucket, so the base-quality sum is (sum - count * bucket) >> 8 — no unpacking per event) and the four
+// sums each, which bound K: 255 x K and clipped_length x K must stay below 2^16), the sum of the EVENT VALUES (quality << 2 | code: every event of a slot
+// has the slot's code, so the base-quality sum is (sum - count * code) >> 2 — no unpacking per event) and the four
 // order-sensitive float sums.
 struct PackAcc { uint32_t w1, w2, w3, sw; float f[NF]; };
 BRC_HD void pack_init(PackAcc& a) { a.w1 = a.w2 = a.w3 = a.sw = 0; for (int f = 0; f < NF; ++f) a.f[f] = 0.0f; }
@@ -608,11 +682,11 @@ BRC_HD void pack_event(PackAcc& a, const Piece& h, const EvTerms& t, uint32_t wo
     a.f[F_SEV] = (float)((double)a.f[F_SEV] + t.sev);
     a.f[F_SNM] += h.snm;
 }
-// the nine integer plane values held by a PackAcc whose events all carry bucket b (I_* order)
+// the nine integer plane values held by a PackAcc whose events all carry index b (I_* order)
 BRC_HD void pack_unpack(const PackAcc& a, uint32_t b, uint32_t* v) {
     const uint32_t n = a.w1 & 0x3ffu, minus = (a.w1 >> 10) & 0x3ffu;
     v[I_N] = n; v[I_SMQ] = a.w2 & 0xffffu; v[I_SSE] = a.w2 >> 16; v[I_PLUS] = n - minus; v[I_MINUS] = minus;
-    v[I_NQ2] = a.w1 >> 20; v[I_SMMQ] = a.w3 & 0xffffu; v[I_SCLIP] = a.w3 >> 16; v[I_SBQ] = (a.sw - n * b) >> 8;
+    v[I_NQ2] = a.w1 >> 20; v[I_SMMQ] = a.w3 & 0xffffu; v[I_SCLIP] = a.w3 >> 16; v[I_SBQ] = (a.sw - n * b) >> 2;
 }
 
 // K (pieces between two flushes of a lane's packed integers) and the per-read limit of a 16-bit field: clipped_length of
@@ -627,7 +701,10 @@ BRC_HD void choose_pack(int32_t max_lqseq, int32_t k_override, int32_t lim_overr
 }
 
 // Per-lane state of KB v2.
-enum { HALF = 6 };          // pieces per staging half-batch (6 rows x 9 chunks = 54 lanes of one direct-to-LDS instruction; a multiple of 3,
+#ifndef BRC_HALF
+#define BRC_HALF 12
+#endif
+enum { HALF = BRC_HALF };   // pieces per staging half-batch (12 rows x 5 chunks of 16 event bytes = 60 lanes of one direct-to-LDS instruction; a multiple of 3,
                             // the rotation period of the piece-record registers); queue drains and flushes happen between half-batches
 struct LaneAcc2 {
     PackAcc dom, alt;
@@ -651,10 +728,10 @@ BRC_HD uint32_t pack_field(const PackAcc& a, uint32_t b, int f) {
     const uint32_t n = a.w1 & 0x3ffu, minus = (a.w1 >> 10) & 0x3ffu;
     uint32_t v = n;                                            // I_N
     v = f == I_SMQ ? (a.w2 & 0xffffu) : v; v = f == I_SSE ? (a.w2 >> 16) : v; v = f == I_PLUS ? n - minus : v; v = f == I_MINUS ? minus : v;
-    v = f == I_NQ2 ? (a.w1 >> 20) : v; v = f == I_SMMQ ? (a.w3 & 0xffffu) : v; v = f == I_SCLIP ? (a.w3 >> 16) : v; v = f == I_SBQ ? ((a.sw - n * b) >> 8) : v;
+    v = f == I_NQ2 ? (a.w1 >> 20) : v; v = f == I_SMMQ ? (a.w3 & 0xffffu) : v; v = f == I_SCLIP ? (a.w3 >> 16) : v; v = f == I_SBQ ? ((a.sw - n * b) >> 2) : v;
     return v;
 }
-// packed registers -> the integer planes of one slot (adds when the tile has flushed before), registers reset; b = the slot's bucket
+// packed registers -> the integer planes of one slot (adds when the tile has flushed before), registers reset; b = the slot's index (eb_index)
 BRC_HD void flush_slot(const DevCfg& c, const Planes& pl, int lib, int64_t k, PackAcc& a, uint32_t slot, uint32_t b, bool live) {
     uint32_t* ip = slot_i(c, pl, lib, slot, k);
     BRC_NOUNROLL
@@ -663,17 +740,17 @@ BRC_HD void flush_slot(const DevCfg& c, const Planes& pl, int lib, int64_t k, Pa
 }
 // `live`: the tile has flushed before (wave-uniform)
 BRC_HD void lane2_flush(const DevCfg& c, const Planes& pl, int lib, int64_t k, LaneAcc2& a, bool live) {
-    flush_slot(c, pl, lib, k, a.dom, 0u, a.dom_b, live);
-    flush_slot(c, pl, lib, k, a.alt, 1u, a.alt_b, live);
+    flush_slot(c, pl, lib, k, a.dom, 0u, eb_index(a.dom_b), live);
+    flush_slot(c, pl, lib, k, a.alt, 1u, eb_index(a.alt_b), live);                 // (no alternate yet: nothing to unpack)
 }
 // one event of a third (fourth, ...) base at this position: its raw addends, for the list
-BRC_HD XEv make_xev(const DevCfg& c, int lib, int64_t k, const Piece& h, const PieceRare& rare, int qpos, uint32_t word) {
+BRC_HD XEv make_xev(const DevCfg& c, int lib, int64_t k, const Piece& h, const PieceRare& rare, int qpos, uint32_t q, uint32_t b) {
     XEv e;
     const uint32_t fl = piece_flags(h);
     const EvTerms t = piece_terms_div(fl, piece_tp(c, h), rare, qpos);
-    e.k = (uint32_t)k; e.lib_b = ((uint32_t)lib << 8) | (word & 0xffu);
+    e.k = (uint32_t)k; e.lib_b = ((uint32_t)lib << 8) | b;
     e.mapq = piece_mapq(h); e.sse = rare.sse_raw; e.zm = rare.zm_raw; e.clip = piece_clipped(rare);
-    e.qf = (word >> 8) | ((fl & PF_REV) ? 0x100u : 0u) | ((fl & PF_Q2OK) ? 0x200u : 0u);
+    e.qf = q | ((fl & PF_REV) ? 0x100u : 0u) | ((fl & PF_Q2OK) ? 0x200u : 0u);
     e.fq2 = t.q2; e.fs3p = t.s3p; e.fsnm = h.snm; e.sev = t.sev;
     return e;
 }
@@ -693,7 +770,7 @@ BRC_HD void lane2_store(const DevCfg& c, const Planes& pl, int lib, int64_t k, L
         PackAcc& r = sl ? a.alt : a.dom;
         float* fp = slot_f(c, pl, lib, sl, k);
         for (int f = 0; f < NF; ++f) fp[(int64_t)f * P] = dead ? 0.0f : r.f[f];
-        flush_slot(c, pl, lib, k, r, sl, sl ? a.alt_b : a.dom_b, live);
+        flush_slot(c, pl, lib, k, r, sl, eb_index(sl ? a.alt_b : a.dom_b), live);
         if (dead) { uint32_t* ip = slot_i(c, pl, lib, sl, k); for (int f = 0; f < NI; ++f) ip[(int64_t)f * P] = 0u; }
     }
 }
@@ -759,6 +836,8 @@ BRC_HD void enumerate_indels(const DevCfg& c, const DevIn& in, const DRead& rd, 
     CigPtr a; a.p = in.cigar + rd.cig_off; enumerate_indels_at(c, a, rd, qual_row, emit);
 }
 
+// bucket of the base at element e of the event-byte stream (an escape byte: from the wide stream)
+BRC_HD uint32_t base_bucket(const DevIn& in, uint64_t e) { const uint32_t w = in.eb[e]; return eb_is_escape(w) ? (uint32_t)(in.bqw[e] & 0xffu) : (w & 3u) + 1u; }
 // Same allele?  Deletions: same length (the allele text is the reference, identical for equal length);
 // insertions: same canonical ("=ACGTN") inserted bases (bamreadcount.cpp:324-338).
 BRC_HD bool same_allele(const DevIn& in, const DRead* reads, const IndelEv& a, const IndelEv& b) {
@@ -767,8 +846,8 @@ BRC_HD bool same_allele(const DevIn& in, const DRead* reads, const IndelEv& a, c
     const DRead& ra = reads[a.read]; const DRead& rb = reads[b.read];
     for (int j = 0; j < a.len; ++j) {
         const int qa = a.qpos + 1 + j, qb = b.qpos + 1 + j;
-        const uint32_t ca = qa < ra.l_qseq ? (uint32_t)(in.bq[ra.bq_off + (uint64_t)qa] & 0xffu) : 5u;
-        const uint32_t cb = qb < rb.l_qseq ? (uint32_t)(in.bq[rb.bq_off + (uint64_t)qb] & 0xffu) : 5u;
+        const uint32_t ca = qa < ra.l_qseq ? base_bucket(in, ra.bq_off + (uint64_t)qa) : 5u;
+        const uint32_t cb = qb < rb.l_qseq ? base_bucket(in, rb.bq_off + (uint64_t)qb) : 5u;
         if (ca != cb) return false;
     }
     return true;

@@ -145,19 +145,27 @@ struct AnnPar { uint4 a, b, c; };    // a = {L, qrel, srel, brow.lo}  b = {S, m1
 
 __device__ __forceinline__ uint32_t nzb7(uint32_t x) { return x + 0x7f7f7f7fu; }   // bytes <= 0x7f: bit 7 of a byte <=> byte != 0
 
-#ifdef BRC_ANN_WAVES_PER_EU
-#define BRC_ANN_OCC __attribute__((amdgpu_waves_per_eu(BRC_ANN_WAVES_PER_EU, BRC_ANN_WAVES_PER_EU)))
+// K1 at six waves per SIMD (80 VGPRs): left alone the allocator takes 88 — five waves — for three values that live from phase A
+// to phase C across the whole per-base pass; at 80 they are spilled ONCE before the pass loop and reloaded after it (six scratch
+// instructions per wave, none inside a loop: tests/test_abi.py::test_kernel_register_budget).  0 = the allocator's own choice.
+#ifndef BRC_ANN_WAVES_PER_EU
+#define BRC_ANN_WAVES_PER_EU 6
+#endif
+// (The per-library instantiation keeps the allocator's five waves: at six it spills inside the operator walks of phase C, and its
+// time did not move with the occupancy — profiles/r04_ab_*.)
+#if BRC_ANN_WAVES_PER_EU > 0
+#define BRC_ANN_OCC __attribute__((amdgpu_waves_per_eu(one_stream ? BRC_ANN_WAVES_PER_EU : 5, one_stream ? BRC_ANN_WAVES_PER_EU : 5)))
 #else
 #define BRC_ANN_OCC
 #endif
 template <bool one_stream>     // the event-word rows and the pieces of consecutive reads are consecutive in memory (no per-library layout)
 __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, DevIn in, DRead* __restrict__ reads, const uint32_t* __restrict__ piece_off,
                                                          Piece* __restrict__ pieces, PieceRare* __restrict__ rare, int2* __restrict__ keyreach,
-                                                         uint16_t* __restrict__ bq, IndelEv* __restrict__ ev_raw, uint32_t* __restrict__ bucket_cnt,
+                                                         uint8_t* __restrict__ eb, uint16_t* __restrict__ bqw, IndelEv* __restrict__ ev_raw, uint32_t* __restrict__ bucket_cnt,
                                                          const uint32_t* __restrict__ cigar_ro, const uint8_t* __restrict__ qual_ro,
                                                          const uint8_t* __restrict__ seq_ro, const uint8_t* __restrict__ refcode,
-                                                         const uint8_t* __restrict__ wanted /* brc_region_windows: 1 per announced tile, or null */) {
-    struct WaveLds { AnnPar par[64]; uint32_t sum[64]; uint32_t redo[64]; uint32_t G[64]; unsigned long long mark; };
+                                                         const uint16_t* __restrict__ wanted /* brc_region_windows: the wanted lanes of every tile, or null */) {
+    struct WaveLds { AnnPar par[64]; uint32_t sum[64]; uint32_t redo[64]; uint32_t wide[64]; uint32_t G[64]; unsigned long long mark; };
     __shared__ WaveLds lds_all[4];
     const int lane = threadIdx.x & 63;
     const uint32_t wv = __builtin_amdgcn_readfirstlane((uint32_t)threadIdx.x >> 6);
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
             W.par[rank] = p;
             W.G[rank] = ((uint32_t)L + 7u) >> 3;
         }
-        W.sum[lane] = 0u; W.redo[lane] = 0u;
+        W.sum[lane] = 0u; W.redo[lane] = 0u; W.wide[lane] = 0u;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");               // lanes read each other's LDS records below
         // exclusive prefix sum of the group counts over the dense reads
         const uint32_t g_me = lane < nd ? W.G[lane] : 0u;
@@ -327,27 +335,58 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
                 mm.y |= nzb7(N.y ^ ry) & nzb7(ry ^ 0x0f0f0f0fu) & nzb7(N.y) & (uint32_t)(f2 >> 32);
                 nul |= (R2.x & (uint32_t)f2) | (R2.y & (uint32_t)(f2 >> 32));
             }
-            // ---- "=ACGTN" buckets (canon_bucket) per byte: codes 0..7 and 8..15 through two byte tables
-            uint2 Bk;
-            {
-                const uint32_t sx = N.x & 0x07070707u, sy = N.y & 0x07070707u;
-                const uint32_t lx = __builtin_amdgcn_perm(0x05050503u, 0x05020100u, sx), ly = __builtin_amdgcn_perm(0x05050503u, 0x05020100u, sy);
-                const uint32_t hx = __builtin_amdgcn_perm(0x05050505u, 0x05050504u, sx), hy = __builtin_amdgcn_perm(0x05050505u, 0x05050504u, sy);
-                const uint32_t gx = (N.x + 0x78787878u) & 0x80808080u, gy = (N.y + 0x78787878u) & 0x80808080u;   // code >= 8
-                const uint32_t mx = (gx - (gx >> 7)) | gx, my2 = (gy - (gy >> 7)) | gy;                             // 0xff per such byte
-                Bk.x = (hx & mx) | (lx & ~mx); Bk.y = (hy & my2) | (ly & ~my2);
-            }
-            // ---- the event words for KB: quality << 8 | bucket per base; the row is padded to 8 elements
+            // ---- the event bytes for KB (brc_core.h: eb_make), 8 per lane: quality << 2 | base index (A C G T = 0..3); the row is
+            // padded to 16 elements.  Base codes -> index or "not A C G T" (bit 7) through two byte tables (codes 0..7 and 8..15).
             if (act && !BRC_AVAR(1)) {
-                uint4 out;
-                out.x = __builtin_amdgcn_perm(Bk.x, Q.x, 0x01050004u); out.y = __builtin_amdgcn_perm(Bk.x, Q.x, 0x03070206u);
-                out.z = __builtin_amdgcn_perm(Bk.y, Q.y, 0x01050004u); out.w = __builtin_amdgcn_perm(Bk.y, Q.y, 0x03070206u);
+                auto index_of = [](uint32_t codes) -> uint32_t {
+                    const uint32_t sx = codes & 0x07070707u;
+                    const uint32_t lx = __builtin_amdgcn_perm(0x80808002u, 0x80010080u, sx), hx = __builtin_amdgcn_perm(0x80808080u, 0x80808003u, sx);
+                    const uint32_t gx = (codes + 0x78787878u) & 0x80808080u;                                       // code >= 8
+                    const uint32_t mx = (gx - (gx >> 7)) | gx;                                                     // 0xff per such byte
+                    return (hx & mx) | (lx & ~mx);
+                };
+                auto ev_bytes = [](uint32_t Qd, uint32_t Id, uint32_t valid7, uint32_t& esc7) -> uint32_t {
+                    const uint32_t qlo = Qd & 0x7f7f7f7fu, qhi = Qd & 0x80808080u;
+                    const uint32_t q0 = ~(nzb7(qlo) | qhi), q63 = (qlo + 0x41414141u) | qhi;                       // (bit 7 of each byte)
+                    esc7 = (Id | q0 | q63) & valid7;
+                    return ((Qd & 0x3f3f3f3fu) << 2) | (Id & 0x03030303u);
+                };
+                uint32_t ex, ey;
+                uint2 E; E.x = ev_bytes(Q.x, index_of(N.x), (uint32_t)vflags, ex); E.y = ev_bytes(Q.y, index_of(N.y), (uint32_t)(vflags >> 32), ey);
+                if (ex | ey) {
+                    // escapes (a quality of 0 or above 62, an N or '=' base): the byte only answers the base-quality filter; the
+                    // group's full words quality << 8 | bucket go to the wide stream and the read's pieces are marked PF_WIDE
+                    auto buckets_of = [](uint32_t codes) -> uint32_t {
+                        const uint32_t sx = codes & 0x07070707u;
+                        const uint32_t lx = __builtin_amdgcn_perm(0x05050503u, 0x05020100u, sx), hx = __builtin_amdgcn_perm(0x05050505u, 0x05050504u, sx);
+                        const uint32_t gx = (codes + 0x78787878u) & 0x80808080u;
+                        const uint32_t mx = (gx - (gx >> 7)) | gx;
+                        return (hx & mx) | (lx & ~mx);
+                    };
+                    const uint32_t Bx = buckets_of(N.x), By = buckets_of(N.y);
+                    // escape byte = 63 << 2 where the base passes -b, 0 where it does not: bytewise q >= min_bq (both sides split into
+                    // their low seven bits and bit 7)
+                    const uint32_t mq = (uint32_t)(c.min_bq < 0 ? 0 : (c.min_bq > 255 ? 255 : c.min_bq)) * 0x01010101u;
+                    const uint32_t none = c.min_bq > 255 ? 0u : 0xffffffffu;                                   // (-b above 255: nothing passes)
+                    auto ge7 = [](uint32_t x, uint32_t y) -> uint32_t {                                          // bit 7 of each byte: x >= y
+                        const uint32_t t = ((x | 0x80808080u) - (y & 0x7f7f7f7fu));                              // bit 7: low seven bits of x >= those of y
+                        return ((x & ~y) | (~(x ^ y) & t)) & 0x80808080u;
+                    };
+                    const uint32_t px = ((ge7(Q.x, mq) & none) >> 7) * 0xffu, py = ((ge7(Q.y, mq) & none) >> 7) * 0xffu;
+                    const uint32_t mx2 = (ex >> 7) * 0xffu, my3 = (ey >> 7) * 0xffu;
+                    E.x = (E.x & ~mx2) | (mx2 & px & 0xfcfcfcfcu); E.y = (E.y & ~my3) | (my3 & py & 0xfcfcfcfcu);
+                    uint4 out;
+                    out.x = __builtin_amdgcn_perm(Q.x, Bx, 0x05010400u); out.y = __builtin_amdgcn_perm(Q.x, Bx, 0x07030602u);
+                    out.z = __builtin_amdgcn_perm(Q.y, By, 0x05010400u); out.w = __builtin_amdgcn_perm(Q.y, By, 0x07030602u);
+                    *reinterpret_cast<uint4*>(bqw + ((((uint64_t)P.c.w) << 32) | (uint64_t)P.a.w) + (uint32_t)b) = out;
+                    atomicOr(&W.wide[jr], 1u);
+                }
                 // (rows are 16-byte aligned; written once here, read by k_pileup2 a kernel later.  With ONE stream of rows — no
-                // per-library layout — the wave's stores run on through memory and the non-temporal hint pays: K1 -5 %, and -8 %
-                // with the piece records likewise; with four library-major streams it costs 2-8 %: measured, profiles/r03_ab_09)
-                typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
-                u32x4s* dst = reinterpret_cast<u32x4s*>(bq + ((((uint64_t)P.c.w) << 32) | (uint64_t)P.a.w) + (uint32_t)b);
-                const u32x4s val = {out.x, out.y, out.z, out.w};
+                // per-library layout — the wave's stores run on through memory and the non-temporal hint pays; with four
+                // library-major streams it costs 2-8 %: measured, profiles/r03_ab_09)
+                typedef uint32_t u32x2s __attribute__((ext_vector_type(2)));
+                u32x2s* dst = reinterpret_cast<u32x2s*>(eb + ((((uint64_t)P.c.w) << 32) | (uint64_t)P.a.w) + (uint32_t)b);
+                const u32x2s val = {E.x, E.y};
                 if (one_stream) __builtin_nontemporal_store(val, dst); else *dst = val;
             }
             if (nul & 0x80808080u) atomicOr(&W.redo[jr], 1u);                           // a NUL reference character under an M base
@@ -424,6 +463,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
     if (q2_pre) __builtin_memcpy(&q2_w0, qual_ro + qoff + ((flag & FREVERSE) ? 0 : L - 8), 8);
     DRead r;
     bool serial = fallback;
+    bool wide = work_me && W.wide[rank] != 0u;        // an escape byte in the read's row
     uint32_t my_sum = 0; int my_hi = -1, my_lo = -1;
     if (work_me && W.redo[rank]) serial = true;
     if (work_me && !serial) {
@@ -448,7 +488,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
         }
     }
     if (serial) {
-        r = annotate_read(c, in, my, bq);
+        r = annotate_read(c, in, my, eb, bqw, wide);
     } else {
         const bool rev = (flag & FREVERSE) != 0;
         int tp, q2;
@@ -483,7 +523,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
     {   // the read's pieces (the host counted them with the same walk_pieces: piece_off[] are their slots)
         const bool nolib = c.per_lib && lib_l < 0;
         const bool enters = r.end > r.pos && pos >= 0;
-        const ReadConst rc = read_const(c, r, (uint32_t)my);
+        const ReadConst rc = read_const(c, r, (uint32_t)my, wide);
         uint32_t slot = piece_off[my];
         walk_pieces_at(c.insertion_centric != 0, enters && !nolib, rc.counts, pos, cigr, nc, [&](int32_t rs, int32_t len, int32_t ext, int qoff, bool nb) {
             Piece h; PieceRare rr;
@@ -507,7 +547,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
         IndelEv* slot = ev_raw + in.iev_off[my]; uint32_t used = 0;
         enumerate_indels_at(c, cigr, r, qual_ro + qoff, [&](int32_t p, int qpos, int len) {
             IndelEv e; e.read = (uint32_t)my; e.qpos = qpos; e.len = len; e.key_lo = (uint32_t)((int64_t)(p - c.pos0) * c.Lp + lib);   // (keys fit 32 bits: checked at upload)
-            if (wanted && !wanted[(uint32_t)(p - c.pos0) >> 6]) return;       // a tile no announced window touches comes back empty: no indel alleles either
+            if (wanted && !tile_wants(wanted[(uint32_t)(p - c.pos0) >> 6], (uint32_t)(p - c.pos0) & 63u)) return;       // what no announced window touches comes back empty: no indel alleles either
             if (used < n_idp) { slot[used++] = e; atomicAdd(&bucket_cnt[indel_bucket_of(c, (uint32_t)(p - c.pos0), (uint32_t)lib)], 1u); }
         });
         for (; used < n_idp; ++used) slot[used].key_lo = NONE32;
@@ -745,13 +785,27 @@ __global__ __launch_bounds__(TR_T) void k_tiles_all(DevCfg c, const int2* __rest
 // depth, no slot: what the host reads first of a position) and marks their piece range lo > hi, at which k_pileup2 returns at once —
 // without it the pileup kernel would spend most of a site list's time storing zeros for the 300-odd positions a line's reads
 // cover around the one or two the line asked for.
-__global__ __launch_bounds__(256) void k_mask_tiles(const uint8_t* __restrict__ wanted, int64_t ntiles, int Lp, int64_t P, int64_t PS, uint2* __restrict__ rng,
-                                                    uint32_t* __restrict__ ncol, uint32_t* __restrict__ depth, uint32_t* __restrict__ slotid, uint4* __restrict__ tile_ctr) {
+__global__ __launch_bounds__(256) void k_mask_tiles(const uint16_t* __restrict__ wanted, int64_t ntiles, int Lp, int32_t pos0, int64_t P, int64_t PS, uint2* __restrict__ rng,
+                                                    const int2* __restrict__ keyreach, uint32_t* __restrict__ ncol, uint32_t* __restrict__ depth, uint32_t* __restrict__ slotid,
+                                                    uint4* __restrict__ tile_ctr) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;           // (library, tile, lane)
     const int64_t lt = i >> 6; const int lane = (int)(i & 63);
     if (lt >= ntiles * Lp) return;
     const int64_t tile = lt % ntiles, lib = lt / ntiles;
-    if (wanted[tile]) return;
+    const uint32_t w = wanted[tile];
+    if (w != (uint32_t)TILE_UNWANTED) {
+        // an announced tile is piled up for the lanes [w0, w1] its windows ask for (the other lanes behave like lanes outside the
+        // region): pieces that cannot reach them are trimmed off both ends of its range — a line's window is one or two positions
+        // wide, the tile around it holds a third more pieces than cover those (keyreach = {start of the piece's read, end of its column})
+        if (lane == 0) {
+            uint2 r = rng[lt];
+            const int64_t p0w = (int64_t)pos0 + tile * TILE + (w & 0xffu), p1w = (int64_t)pos0 + tile * TILE + (w >> 8);
+            while (r.x < r.y && (int64_t)keyreach[r.x].y <= p0w) ++r.x;
+            while (r.y > r.x && (int64_t)keyreach[r.y - 1].x > p1w) --r.y;
+            rng[lt] = r;
+        }
+        return;
+    }
     const int64_t k = tile * TILE + lane;
     if (k < P) { ncol[lib * PS + k] = 0u; depth[lib * PS + k] = 0u; slotid[lib * PS + k] = (uint32_t)NB_NONE | ((uint32_t)NB_NONE << 8); }
     if (lane == 0) { rng[lt] = make_uint2(1u, 0u); tile_ctr[lt] = make_uint4(0u, 0u, 0u, 0u); }
@@ -781,9 +835,9 @@ __device__ __forceinline__ void fadd_through_double(float& acc, double x) {
 }
 
 enum { PILEUP_WAVES = 4 };   // 256 threads: 4 consecutive tiles (256 positions) per workgroup
-enum { WIN_U4 = 9 };         // event-word window of a staged piece: 9 x 16 B = 72 elements >= 64 tile positions + 7 of alignment
+enum { WIN_U4 = 5 };         // event-byte window of a staged piece: 5 x 16 B = 80 elements >= 64 tile positions + 15 of alignment
 enum { ROW_BYTES = WIN_U4 * 16 };
-enum { QCAP = 2 * HALF + 2 };   // deferred entries of one half-batch: at most a third-allele and a huge-integer entry per piece
+enum { QCAP = 3 * HALF + 2 };   // deferred entries of one half-batch: at most a third-allele, an unnameable-bucket and a huge-integer entry per piece
 static_assert(HALF * WIN_U4 <= 64, "one direct-to-LDS instruction stages a half-batch");
 static_assert(HALF % 3 == 0, "the piece-record registers rotate with period 3");
 
@@ -821,8 +875,8 @@ template <bool WINDOWS>      // brc_region_windows is in force: tiles whose rang
                              // common one stays the code that was measured — one more branch at its head moved its register allocation and cost 2.4 %)
 __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_eu(BRC_WAVES_PER_EU, BRC_WAVES_PER_EU))) void k_pileup2(DevCfg c, DevIn in, const uint4* __restrict__ pieces4, const PieceRare* __restrict__ rare,
                                                                const uint2* __restrict__ rng, int64_t ntiles, Planes pl, uint4* __restrict__ tile_ctr,
-                                                               const uint16_t* __restrict__ bq_ro, const uint32_t* __restrict__ unavail_ro,
-                                                               const uint8_t* __restrict__ refcode) {
+                                                               const uint8_t* __restrict__ eb_ro, const uint16_t* __restrict__ bqw_ro, const uint32_t* __restrict__ unavail_ro,
+                                                               const uint8_t* __restrict__ refcode, const uint16_t* __restrict__ wanted_ro) {
     // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch order); give every XCD one contiguous
     // run of tiles so neighbouring tiles, which share most of their pieces, hit the same 4-MiB L2.
     const uint32_t nbk = gridDim.x;           // multiple of 8
@@ -860,7 +914,9 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
     const int64_t kk = inreg ? k : 0;
     // a position abandoned for a library-less read (:281-284) accumulates nothing: it behaves like a lane outside the region
     const bool dead = c.per_lib && inreg && unavail_ro[kk] != NONE32;
-    const bool valid = inreg && !dead;
+    // (brc_region_windows: the lanes no window asks for behave like lanes outside the region — k_mask_tiles has trimmed the tile's
+    // piece range to what reaches the others)
+    const bool valid = inreg && !dead && (!WINDOWS || tile_wants(wanted_ro[tile], (uint32_t)lane));
     const int32_t p = (int32_t)(c.pos0 + k);
     const int32_t p0 = (int32_t)(c.pos0 + tile * TILE);                     // first position of the tile (scalar)
 
@@ -875,6 +931,10 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         }
         lane2_init(a, c.force_dom >= 0 ? (uint32_t)c.force_dom : dom);
     }
+    // what `event byte & 3` is compared with (4, 5: no byte matches).  The lane keeps THIS across the read loop; the bucket
+    // itself is recomputed from it where a rare path or the tile's end needs it (one register, not two, live in the loop)
+    const uint32_t dom_i = dom_index(a.dom_b);
+#define BRC_DOM_B() dom_bucket_of_index(dom_i)
     bool flushed = false;                                                   // (scalar) the slot planes of this tile hold partial integer sums
     unsigned long long wsm_tot = 0, wnm_tot = 0;                            // (scalar) warnings moved out of the lanes at flushes
 
@@ -910,13 +970,13 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
 #define BRC_LD_TAB(T, b0) { const uint32_t mi = (b0) + srow < hi ? (b0) + srow : hi - 1u; T = pieces4[(size_t)mi * 3u + 2u];   /* {ww, a, bq_off} */ \
                             asm volatile("" :: "v"(pf)); if (schunk == 0u) pf = pieces4[(size_t)mi * 3u].x; }
         // window copy of the half-batch starting at piece b0 into the ring half at byte offset hoff: element window
-        // [ws, ws + 72) of the row, ws = floor8(p0 - a) (may start before the row: the event-word stream is padded)
+        // [ws, ws + 80) of the row, ws = floor16(p0 - a) (may start before the row: the event-byte stream is padded)
 #define BRC_STAGE(T, b0, hoff)                                                                                           \
         {                                                                                                                 \
             if (slane && (b0) + srow < hi) {                                                                              \
                 const int64_t boff = (int64_t)(((uint64_t)T.w << 32) | T.z);                                              \
-                const int32_t ws = (p0 - (int32_t)T.y) & ~7;                                                              \
-                const uint16_t* src = bq_ro + (boff + ws) + 8u * schunk;                                                  \
+                const int32_t ws = (p0 - (int32_t)T.y) & ~15;                                                             \
+                const uint8_t* src = eb_ro + (boff + ws) + 16u * schunk;                                                  \
                 __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,                      \
                     (void __attribute__((address_space(3)))*)(rows_base + (hoff)), 16, 0, 0);                             \
             }                                                                                                             \
@@ -936,7 +996,10 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
 #define BRC_G_R2 "{s[84:85]}"
 #define BRC_LD_REC(R, rp) asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x20" : "=" BRC_F_##R (R.f), "=" BRC_G_##R (R.g) : "s"(rp));
 #define BRC_WAIT_REC(R) asm volatile("s_waitcnt lgkmcnt(0)" : "+" BRC_F_##R (R.f), "+" BRC_G_##R (R.g));
-        // the division constants of piece m (its rare record) by scalar loads, on demand: only pieces without PF_TABLE
+        // the division constants of piece m (its rare record) by scalar loads, on demand: only the few pieces that neither look
+        // their terms up nor divide them out from their own record (PF_DIV) — reads longer than 255 bases, a Q2 position of its own.
+        // (The wait below also waits for the record loads just issued: a synchronous round trip.  It used to be the price of EVERY
+        // read of another length than the region's modal one.)
 #define BRC_LD_DIV(H, R, m)                                                                                             \
         {                                                                                                                 \
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));                                                   \
@@ -955,8 +1018,8 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
             const uint32_t d = lanev + (uint32_t)s_d;                                                                     \
             S.m_cov = __builtin_amdgcn_ballot_w64(d < R.f[2]);   /* counted in the accumulate stage: a probe may run past the tile's last piece */ \
             S.m_in = __builtin_amdgcn_ballot_w64(d < R.f[1]);                                                             \
-            const uint32_t off = (uint32_t)(roff) + 2u * ((uint32_t)S.s_c & 7u);                                          \
-            S.w = (uint32_t)*reinterpret_cast<const uint16_t*>(rows_base + (((uint32_t)lane << 1) + off));                                  \
+            const uint32_t off = (uint32_t)(roff) + ((uint32_t)S.s_c & 15u);                                              \
+            S.w = (uint32_t)*reinterpret_cast<const uint8_t*>(rows_base + ((uint32_t)lane + off));                        \
             /* (scalar) the lane-independent side of both table addresses: the second is the record's signed distance away from the first */ \
             const uint32_t eoff = cb - ((uint32_t)S.s_c << 4), qoff16 = eoff + (uint32_t)piece_tp_field(R.f[3]);          \
             if (BRC_EXP == 2) { S.t = 0.5f; S.sev = 0.25; } else {     /* (2: timing only, no table look-ups) */                 \
@@ -1000,15 +1063,17 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
 #define BRC_SEV_ADD(acc, x) fadd_through_double(acc, x)
 #endif
         // ACC of the piece in R (S = its probe results), piece index m
+        // (the entry's kind is materialised by an instruction of its own: left to the allocator, the two constants live in a
+        // register pair across the whole read loop and are spilled to scratch around every push)
+#define BRC_QPUSH(mm, kd, mask) { if (BRC_LANE() == 0) { uint32_t kq; asm volatile("v_mov_b32 %0, %1" : "=v"(kq) : "n"(kd)); QEnt e; e.piece = (mm); e.kind = kq; e.mlo = (uint32_t)(mask); e.mhi = (uint32_t)((mask) >> 32); queue[qn] = e; } ++qn; }
 #define BRC_ACC(R, S, m)                                                                                                \
         {                                                                                                                 \
             const uint32_t fl = BRC_EXP == 6 ? (uint32_t)(PF_TABLE | PF_Q2OK) : BRC_EXP == 7 ? ((R.f[3] >> 24) | (uint32_t)PF_TABLE) :   \
                                 BRC_EXP == 8 ? ((R.f[3] >> 24) & ~(uint32_t)(PF_NB | PF_HUGE)) : R.f[3] >> 24;   /* (6, 7, 8: timing only, flag tests folded away) */ \
             count_if(a.ncol, S.m_cov);                                                         /* lib_counts[library] (:286) */ \
-            const uint64_t m_p = S.m_in & __builtin_amdgcn_ballot_w64(S.w >= thr0);           /* :288 */                  \
+            const uint64_t m_p = S.m_in & __builtin_amdgcn_ballot_w64(S.w >= thr0);           /* :288 (escape bytes answer it too) */ \
             count_if(a.depth, m_p);                                                            /* mapq_n (:312) */         \
             if (BRC_EXP != 3) {                                                                /* (3: timing only, probe and counters alone) */ \
-                const uint32_t b = S.w & 0xffu;                                                                           \
                 uint64_t m_b = m_p;                            /* lanes whose event goes to a base bucket */               \
                 /* the terms live in the stage's own registers: a piece without PF_TABLE overwrites them (no copies on the   \
                    common path); q2 == tp, or no Q2 position (every reverse read without a Q2 run): then +0.0f, the identity  \
@@ -1017,8 +1082,31 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                 if (__builtin_expect((fl & PF_TABLE) == 0u, 0)) {      /* every unusual piece (make_piece) */                 \
                     if (fl & PF_NB) m_b = 0ull;            /* :343 with -i: counted in the depth, in no bucket */            \
                     else {                                                                                                \
+                        if (fl & PF_WIDE) {                                                                               \
+                            /* a wide read: lanes that meet an escape byte take quality and bucket from the wide stream; an N / '='   \
+                               base goes to the third-allele list whatever the lane's slots hold */                       \
+                            const uint64_t m_esc = m_b & __builtin_amdgcn_ballot_w64(eb_is_escape(S.w));                  \
+                            if (m_esc) {                                                                                  \
+                                u32x2 bo; const char* bp = reinterpret_cast<const char*>(pieces4) + (size_t)(m) * 48u;    \
+                                asm volatile("s_load_dwordx2 %0, %1, 0x28\n\ts_waitcnt lgkmcnt(0)" : "=&s"(bo) : "s"(bp)); \
+                                /* (scalar base + 32-bit lane offset: no 64-bit vector address in this rare path's register budget) */ \
+                                const uint16_t* wrow = bqw_ro + (int64_t)(((uint64_t)bo[1] << 32) | bo[0]);               \
+                                bool exo = false;                                                                         \
+                                if (__builtin_amdgcn_inverse_ballot_w64(m_esc)) {                                         \
+                                    uint32_t w16; const uint32_t wv = ((uint32_t)BRC_LANE() + (uint32_t)S.s_c) << 1;      \
+                                    asm volatile("global_load_ushort %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(w16) : "v"(wv), "s"(wrow) : "memory"); \
+                                    exo = !bucket_acgt(w16 & 0xffu);                                                      \
+                                    if (exo) a.ww += R.g[0]; else S.w = ((w16 >> 8) << 2) | ((w16 & 0xffu) - 1u);         \
+                                }                                                                                         \
+                                const uint64_t m_exo = __builtin_amdgcn_ballot_w64(exo);                                  \
+                                if (m_exo) { BRC_QPUSH((m), 0u, m_exo) m_b &= ~m_exo; }                                   \
+                            }                                                                                             \
+                        }                                                                                                 \
                         if ((fl & (PF_TABQ | PF_HUGE)) == PF_TABQ) {   /* soft-clipped: only the event location differs, and it needs no rare record */ \
                             S.sev = tabq_sev((int)((uint32_t)BRC_LANE() + (uint32_t)S.s_c), piece_left_field(R.f[3]), R.f[6] >> 16); \
+                        } else if (fl & PF_DIV) {      /* another read length: the terms divided out in the lane, from the record itself */ \
+                            const EvTerms t = piece_terms_inlane(fl, R.f[3], R.f[6], (int)((uint32_t)BRC_LANE() + (uint32_t)S.s_c)); \
+                            S.t = t.s3p; tq2 = t.q2; S.sev = t.sev;                                                       \
                         } else if (!(fl & PF_TABQ)) {                                                                     \
                             PieceRare H; BRC_LD_DIV(H, R, m)                                                              \
                             const EvTerms t = piece_terms_div(fl, (int)(R.f[3] & 0xffffffu), H, (int)((uint32_t)BRC_LANE() + (uint32_t)S.s_c));  \
@@ -1028,19 +1116,21 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                             /* the integers the packed addends left out are added at the next boundary, to the lanes whose event goes   \
                                to one of the two slots: every lane of m_b but those that will overflow to the third-allele list —   \
                                known before the adds, a lane's alternate bucket changes only by its own event */              \
-                            const bool ovf_l = b != a.dom_b && a.alt_b != NB_NONE && a.alt_b != b;                         \
+                            const uint32_t bh = (S.w & 3u) + 1u;                                                          \
+                            const bool ovf_l = bh != BRC_DOM_B() && a.alt_b != NB_NONE && a.alt_b != bh;                   \
                             const uint64_t m_int = m_b & ~__builtin_amdgcn_ballot_w64(ovf_l);                             \
-                            if (m_int) { if (BRC_LANE() == 0) { QEnt e; e.piece = (m); e.kind = 1u; e.mlo = (uint32_t)m_int; e.mhi = (uint32_t)(m_int >> 32); queue[qn] = e; } ++qn; } \
+                            if (m_int) BRC_QPUSH((m), 1u, m_int)                                                          \
                         }                                                                                                 \
                     }                                                                                                     \
                 }                                                                                                         \
                 const float ts3p = S.t; const double tsev = S.sev;                                                        \
-                const uint64_t m_dom = m_b & __builtin_amdgcn_ballot_w64(b == a.dom_b);                                   \
+                const uint64_t m_dom = m_b & __builtin_amdgcn_ballot_w64((S.w & 3u) == dom_i);  /* the base of the reference */ \
                 BRC_DOM_REGION(R, S, m_dom, tq2, ts3p, tsev)                                                              \
                 const uint64_t m_rest = m_b & ~m_dom;                                                                     \
                 if (__builtin_expect(m_rest != 0ull, 0)) {                                                                \
                     bool ovf = false;                                                                                     \
                     if (__builtin_amdgcn_inverse_ballot_w64(m_rest)) {                                                    \
+                        const uint32_t b = (S.w & 3u) + 1u;                                                               \
                         const bool take_alt = a.alt_b == NB_NONE || a.alt_b == b;                                         \
                         if (take_alt) {                                                                                   \
                             a.alt_b = b;                                                                                  \
@@ -1053,7 +1143,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                         ovf = !take_alt;                                                                                  \
                     }                                                                                                     \
                     const uint64_t m_ovf = __builtin_amdgcn_ballot_w64(ovf);                                              \
-                    if (m_ovf) { if (BRC_LANE() == 0) { QEnt e; e.piece = (m); e.kind = 0u; e.mlo = (uint32_t)m_ovf; e.mhi = (uint32_t)(m_ovf >> 32); queue[qn] = e; } ++qn; } \
+                    if (m_ovf) BRC_QPUSH((m), 0u, m_ovf)                                                                  \
                 }                                                                                                         \
             }                                                                                                             \
         }
@@ -1077,6 +1167,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         // packed integers -> slot planes; the 16-bit warning counters of the lanes move to the wave's totals
 #define BRC_FLUSH()                                                                                                     \
         {                                                                                                                 \
+            a.dom_b = BRC_DOM_B();                                                                                        \
             if (valid) lane2_flush(c, pl, lib, BRC_KK(), a, flushed);                                                     \
             wsm_tot += wave_sum_u32(valid ? (a.ww & 0xffffu) : 0u); wnm_tot += wave_sum_u32(valid ? (a.ww >> 16) : 0u); a.ww = 0u; \
             flushed = true; since_flush = 0;                                                                              \
@@ -1101,7 +1192,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                         asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(hf), "=&s"(hg) : "s"(hp)); \
                         H.rs = (int32_t)hf[0]; H.len = (int32_t)hf[1]; H.ext = (int32_t)hf[2]; H.tp_flags = hf[3];       \
                         H.w1 = hf[4]; H.w2 = hf[5]; H.w3 = hf[6]; H.snm = __uint_as_float(hf[7]); H.ww = hg[0]; H.a = (int32_t)hg[1]; \
-                        H.bq_off = 0;                                                                                     \
+                        H.bq_off = ((uint64_t)hg[3] << 32) | hg[2];                                                       \
                         if (piece_has_rare(H.tp_flags >> 24)) {                                                           \
                             u32x8 rf; const char* rp = reinterpret_cast<const char*>(rare) + (size_t)m * 32u;             \
                             asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(rf) : "s"(rp));    \
@@ -1115,16 +1206,21 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                     const int lr = BRC_LANE(); const int64_t kr = BRC_KK();                                               \
                     const bool mine = ((mask >> lr) & 1ull) != 0ull;                                                      \
                     const int32_t s_c = p0 - H.a;                                                                         \
-                    const uint32_t off = hoff + (m - base) * (uint32_t)ROW_BYTES + 2u * ((uint32_t)s_c & 7u);             \
-                    const uint32_t w = (uint32_t)*reinterpret_cast<const uint16_t*>(rows_base + off + 2u * (uint32_t)lr);  \
+                    const uint32_t off = hoff + (m - base) * (uint32_t)ROW_BYTES + ((uint32_t)s_c & 15u);                 \
+                    const uint32_t w = (uint32_t)*reinterpret_cast<const uint8_t*>(rows_base + off + (uint32_t)lr);        \
+                    /* the lane's quality and bucket: from its event byte, or — an escape byte of a wide read — from the wide stream */ \
+                    uint32_t eq = w >> 2, ebk = (w & 3u) + 1u;                                                            \
+                    if (((H.tp_flags >> 24) & PF_WIDE) && mine && eb_is_escape(w)) {                                      \
+                        const uint32_t w16 = bqw_ro[(int64_t)H.bq_off + (int64_t)(lr + s_c)]; eq = w16 >> 8; ebk = w16 & 0xffu; \
+                    }                                                                                                     \
                     if (kind == 0u) {                          /* third alleles: raw addends to the list, in piece order */ \
                         uint32_t at0 = 0;                                                                                 \
                         if (lr == 0 && !BRC_PVAR(11)) at0 = atomicAdd(pl.xev_n + (size_t)xshard * XEV_CTR_STRIDE, (uint32_t)__builtin_popcountll(mask)); /* (11: profiling, no list cursor) */ \
                         at0 = (uint32_t)__builtin_amdgcn_readfirstlane(at0);                                              \
                         const uint64_t below = mask & ((1ull << lr) - 1ull);                                              \
                         const uint32_t at = at0 + (uint32_t)__builtin_popcountll(below);                                  \
-                        if (mine && at < pl.xev_cap) pl.xev[(size_t)xshard * pl.xev_cap + at] = make_xev(c, lib, kr, H, RR, lr + s_c, w); \
-                    } else if (mine) drain_int(c, pl, lib, kr, RR, (w & 0xffu) == a.dom_b ? 0u : 1u);                     \
+                        if (mine && at < pl.xev_cap) pl.xev[(size_t)xshard * pl.xev_cap + at] = make_xev(c, lib, kr, H, RR, lr + s_c, eq, ebk); \
+                    } else if (mine) drain_int(c, pl, lib, kr, RR, ebk == BRC_DOM_B() ? 0u : 1u);                         \
                 }                                                                                                         \
                 qn = 0;                                                                                                   \
             }                                                                                                             \
@@ -1166,6 +1262,14 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
             BRC_STEP(3, R0, R1, R2, S1, S0, true)
             BRC_STEP(4, R1, R2, R0, S0, S1, true)
             BRC_STEP(5, R2, R0, R1, S1, S0, true)
+#if BRC_HALF == 12
+            BRC_STEP(6, R0, R1, R2, S0, S1, true)
+            BRC_STEP(7, R1, R2, R0, S1, S0, true)
+            BRC_STEP(8, R2, R0, R1, S0, S1, true)
+            BRC_STEP(9, R0, R1, R2, S1, S0, true)
+            BRC_STEP(10, R1, R2, R0, S0, S1, true)
+            BRC_STEP(11, R2, R0, R1, S1, S0, true)
+#endif
             BRC_BOUNDARY(nb)
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+" BRC_F_R0 (R0.f), "+" BRC_G_R0 (R0.g), "+" BRC_F_R1 (R1.f), "+" BRC_G_R1 (R1.g), "+" BRC_F_R2 (R2.f), "+" BRC_G_R2 (R2.g));   // no scalar load may outlive its registers
@@ -1176,6 +1280,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
 #undef BRC_FLUSH
 #undef BRC_STEP
 #undef BRC_ACC
+#undef BRC_QPUSH
 #undef BRC_DOM_REGION
 #undef BRC_SEV_ADD
 #undef BRC_PROBE
@@ -1201,12 +1306,13 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         const int64_t tb = tile * TILE;                                    // (scalar) plane index of lane 0
         const uint32_t loff = (uint32_t)lane_e << 2;
 #define BRC_ST(base, val) asm volatile("global_store_dword %0, %1, %2 nt" :: "v"(loff), "v"(val), "s"(base) : "memory")   /* (written once per step, read by nobody on the device: streaming) */
+        a.dom_b = BRC_DOM_B();
         const uint32_t sid = a.dom_b | (a.alt_b << 8);
         { const uint32_t* q = pl.ncol + (int64_t)lib * P + tb; BRC_ST(q, a.ncol); }       // (dead lanes accumulated nothing: zeros)
         { const uint32_t* q = pl.depth + (int64_t)lib * P + tb; BRC_ST(q, a.depth); }
         { const uint32_t* q = pl.slotid + (int64_t)lib * P + tb; BRC_ST(q, sid); }
         uint32_t dv[NI], av[NI];
-        pack_unpack(a.dom, a.dom_b, dv); pack_unpack(a.alt, a.alt_b, av);
+        pack_unpack(a.dom, eb_index(a.dom_b), dv); pack_unpack(a.alt, eb_index(a.alt_b), av);     // (the slots' base indices; no alternate yet: all zeros)
         uint32_t* i0 = slot_i(c, pl, lib, 0u, tb); uint32_t* i1 = slot_i(c, pl, lib, 1u, tb);
         if (__builtin_expect(flushed, 0)) {
             // (wave-uniform) earlier flushes of this tile left partial integer sums in the planes; dead lanes never flush
@@ -1226,6 +1332,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         }
 #undef BRC_ST
     }
+#undef BRC_DOM_B
     // per-(tile, library) partials; k_finalize sums them (a single-address atomic per wave costs ~12 ns x 780 k waves):
     // events (columns of the reporting window), the lanes' warning counters, abandoned positions, and — when there is one
     // library — the emitted positions (with several, a position prints if ANY library's column is non-empty: k_finalize
@@ -1428,8 +1535,8 @@ class HipBackend : public Backend {
     std::vector<int64_t> lib_base;      // first piece of every library's stream (Lp + 1 entries)
     // device buffers
     DBuf d_pos, d_flag, d_mapq, d_lib, d_lq, d_nc, d_co, d_so, d_qo, d_nm, d_sm, d_tags, d_cigar, d_seq, d_qual, d_ref, d_refcode;
-    std::vector<uint8_t> h_wanted; bool has_wanted = false; DBuf d_wanted;      // brc_region_windows (kept alive for the asynchronous copy)
-    DBuf d_bq, d_bqrow, d_pieceoff, d_pieces, d_rare, d_keyreach, d_libbase, d_reads, d_agg, d_rng, d_ncol, d_depth, d_slotid, d_si, d_sf, d_xev, d_xevc, d_xevn, d_unavail, d_cnt, d_cursor, d_ev, d_evraw, d_ievoff, d_iout, d_ctr, d_tilectr, d_part;
+    std::vector<uint16_t> h_wanted; bool has_wanted = false; DBuf d_wanted;      // brc_region_windows (kept alive for the asynchronous copy)
+    DBuf d_bq, d_bqw, d_bqrow, d_pieceoff, d_pieces, d_rare, d_keyreach, d_libbase, d_reads, d_agg, d_rng, d_ncol, d_depth, d_slotid, d_si, d_sf, d_xev, d_xevc, d_xevn, d_unavail, d_cnt, d_cursor, d_ev, d_evraw, d_ievoff, d_iout, d_ctr, d_tilectr, d_part;
     DBuf d_tlen, d_toff, d_text, d_tctx;
     // device-side text, downloaded (pinned) on its own stream into one of two host buffers
     HBuf<char> h_text[2]; HBuf<uint32_t> h_toff[2]; HBuf<uint32_t> h_total;
@@ -1474,7 +1581,7 @@ class HipBackend : public Backend {
     ~HipBackend() override {
         (void)hipSetDevice(device);
         DBuf* all[] = {&d_pos, &d_flag, &d_mapq, &d_lib, &d_lq, &d_nc, &d_co, &d_so, &d_qo, &d_nm, &d_sm, &d_tags, &d_cigar, &d_seq, &d_qual,
-                       &d_ref, &d_refcode, &d_bq, &d_bqrow, &d_pieceoff, &d_pieces, &d_rare, &d_keyreach, &d_libbase, &d_reads, &d_agg, &d_rng, &d_ncol, &d_depth, &d_slotid, &d_si, &d_sf, &d_xev, &d_xevc, &d_xevn, &d_unavail, &d_cnt,
+                       &d_ref, &d_refcode, &d_bq, &d_bqw, &d_bqrow, &d_pieceoff, &d_pieces, &d_rare, &d_keyreach, &d_libbase, &d_reads, &d_agg, &d_rng, &d_ncol, &d_depth, &d_slotid, &d_si, &d_sf, &d_xev, &d_xevc, &d_xevn, &d_unavail, &d_cnt,
                        &d_cursor, &d_ev, &d_evraw, &d_ievoff, &d_iout, &d_ctr, &d_tilectr, &d_part, &d_tlen, &d_toff, &d_text, &d_tctx, &d_wanted};
         for (DBuf* b : all) b->release();
         for (int i = 0; i < 2; ++i) { h_text[i].destroy(); h_toff[i].destroy(); if (ev_text[i]) (void)hipEventDestroy(ev_text[i]); }
@@ -1544,9 +1651,12 @@ class HipBackend : public Backend {
         in.tags = (const uint8_t*)d_tags.p; in.cigar = (const uint32_t*)d_cigar.p; in.seq4 = (const uint8_t*)d_seq.p; in.qual = (const uint8_t*)d_qual.p;
         in.ref = (const char*)d_ref.p;
         // event-word stream, padded on both sides: a staged window starts up to 71 elements before / ends after a row
+        // (the wide stream — full words of the few 8-base groups with an escape byte — is indexed like the bytes; it is
+        // allocated whole and touched only where K1 writes such a group)
         enum { BQ_PAD = 128 };
-        HIPCHK(d_bq.ensure((s.bq_elems + BQ_PAD + 512) * sizeof(uint16_t)));
-        in.bq = (const uint16_t*)d_bq.p + BQ_PAD;
+        HIPCHK(d_bq.ensure(s.bq_elems + BQ_PAD + 512));
+        HIPCHK(d_bqw.ensure((s.bq_elems + 16) * sizeof(uint16_t)));
+        in.eb = (const uint8_t*)d_bq.p + BQ_PAD; in.bqw = (const uint16_t*)d_bqw.p;
         if ((rc = up(d_bqrow, s.bq_row, n)) || (rc = up(d_pieceoff, s.piece_off, n))) return rc;
         in.bq_row = (const uint64_t*)d_bqrow.p;
         in.rcp = nullptr;
@@ -1560,7 +1670,7 @@ class HipBackend : public Backend {
         ntiles = (c.P + TILE - 1) / TILE;
         n_indel_cap = c.has_ref ? s.n_indel_ops : 0;
         h_wanted = s.wanted_tiles(c.pos0, c.P); has_wanted = !h_wanted.empty();
-        if (has_wanted) { HIPCHK(d_wanted.ensure(h_wanted.size() + 16)); HIPCHK(hipMemcpyAsync(d_wanted.p, h_wanted.data(), h_wanted.size(), hipMemcpyHostToDevice, stream)); }
+        if (has_wanted) { HIPCHK(d_wanted.ensure(h_wanted.size() * 2 + 16)); HIPCHK(hipMemcpyAsync(d_wanted.p, h_wanted.data(), h_wanted.size() * 2, hipMemcpyHostToDevice, stream)); }
         if (n_indel_cap && ((uint64_t)c.P * (uint64_t)c.Lp >= 0xffffffffull || n_indel_cap >= 0xfffffff0ull)) { err = "region too large: (positions x libraries) and the indel operators must stay below 2^32"; return BRC_E_ARG; }
         const size_t nagg = std::max<size_t>(std::max<size_t>((std::max<size_t>(np, P * Lp) + SCAN_CHUNK - 1) / SCAN_CHUNK, (np + TR_CHUNK - 1) / TR_CHUNK), 1);
         HIPCHK(d_reads.ensure((n + 1) * sizeof(DRead)));
@@ -1631,13 +1741,13 @@ class HipBackend : public Backend {
             if (Lp == 1) {
                 hipLaunchKernelGGL((k_annotate_groups<true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (const uint32_t*)d_pieceoff.p,
                                    (Piece*)d_pieces.p, (PieceRare*)d_rare.p, (int2*)d_keyreach.p,
-                                   (uint16_t*)in.bq, indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p,
-                                   in.cigar, in.qual, in.seq4, (const uint8_t*)d_refcode.p + REFCODE_PAD, has_wanted ? (const uint8_t*)d_wanted.p : (const uint8_t*)nullptr);
+                                   (uint8_t*)in.eb, (uint16_t*)in.bqw, indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p,
+                                   in.cigar, in.qual, in.seq4, (const uint8_t*)d_refcode.p + REFCODE_PAD, has_wanted ? (const uint16_t*)d_wanted.p : (const uint16_t*)nullptr);
             } else {
                 hipLaunchKernelGGL((k_annotate_groups<false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (const uint32_t*)d_pieceoff.p,
                                    (Piece*)d_pieces.p, (PieceRare*)d_rare.p, (int2*)d_keyreach.p,
-                                   (uint16_t*)in.bq, indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p,
-                                   in.cigar, in.qual, in.seq4, (const uint8_t*)d_refcode.p + REFCODE_PAD, has_wanted ? (const uint8_t*)d_wanted.p : (const uint8_t*)nullptr);
+                                   (uint8_t*)in.eb, (uint16_t*)in.bqw, indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p,
+                                   in.cigar, in.qual, in.seq4, (const uint8_t*)d_refcode.p + REFCODE_PAD, has_wanted ? (const uint16_t*)d_wanted.p : (const uint16_t*)nullptr);
             }
             if (c.per_lib) {
                 HIPCHK(hipMemsetAsync(d_unavail.p, 0xff, (size_t)c.PS * 4, stream));
@@ -1687,8 +1797,8 @@ class HipBackend : public Backend {
             hipLaunchKernelGGL(k_tiles_all, dim3((unsigned)trb), dim3(TR_T), 0, stream, c, (const int2*)d_keyreach.p, np_all, (const int64_t*)d_libbase.p, Lp,
                                (const unsigned long long*)d_agg.p, ntiles, (uint2*)d_rng.p);
         if (has_wanted && ntiles > 0)
-            hipLaunchKernelGGL(k_mask_tiles, dim3((unsigned)((ntiles * Lp * 64 + 255) / 256)), dim3(256), 0, stream, (const uint8_t*)d_wanted.p, ntiles, Lp, (int64_t)c.P, (int64_t)c.PS, (uint2*)d_rng.p,
-                               (uint32_t*)d_ncol.p, (uint32_t*)d_depth.p, (uint32_t*)d_slotid.p, (uint4*)d_tilectr.p);
+            hipLaunchKernelGGL(k_mask_tiles, dim3((unsigned)((ntiles * Lp * 64 + 255) / 256)), dim3(256), 0, stream, (const uint16_t*)d_wanted.p, ntiles, Lp, c.pos0, (int64_t)c.P, (int64_t)c.PS, (uint2*)d_rng.p,
+                               (const int2*)d_keyreach.p, (uint32_t*)d_ncol.p, (uint32_t*)d_depth.p, (uint32_t*)d_slotid.p, (uint4*)d_tilectr.p);
         HIPCHK(hipEventRecord(evt[T_PILEUP], stream));
         if (ntiles > 0) {
             unsigned nwg = (unsigned)((ntiles + PILEUP_WAVES - 1) / PILEUP_WAVES);
@@ -1701,12 +1811,12 @@ class HipBackend : public Backend {
 #endif
 if (has_wanted) {
                             hipLaunchKernelGGL((k_pileup2<true>), dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), dyn_lds, stream, c, in, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p,
-                               (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.bq, (const uint32_t*)d_unavail.p,
-                               (const uint8_t*)d_refcode.p + REFCODE_PAD);
+                               (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.eb, in.bqw, (const uint32_t*)d_unavail.p,
+                               (const uint8_t*)d_refcode.p + REFCODE_PAD, (const uint16_t*)d_wanted.p);
             } else {
                             hipLaunchKernelGGL((k_pileup2<false>), dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), dyn_lds, stream, c, in, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p,
-                               (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.bq, (const uint32_t*)d_unavail.p,
-                               (const uint8_t*)d_refcode.p + REFCODE_PAD);
+                               (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.eb, in.bqw, (const uint32_t*)d_unavail.p,
+                               (const uint8_t*)d_refcode.p + REFCODE_PAD, (const uint16_t*)d_wanted.p);
             }
             hipLaunchKernelGGL(k_xev_compact, dim3((unsigned)XEV_SHARDS), dim3(256), 0, stream, (const XEv*)d_xev.p, (const uint32_t*)d_xevn.p, (uint32_t)xev_cap,
                                (uint32_t)XEV_SHARDS, (XEv*)d_xevc.p, ctr);

@@ -72,16 +72,21 @@ void Staged::clear() {
     piece_cnt.clear(); piece_off.clear(); iev_off.clear(); lib_base.clear(); n_pieces = 0; max_lqseq = 0; max_span = 0; qnames.clear(); qname_off.clear();
     win_beg.clear(); win_end.clear();
 }
-std::vector<uint8_t> Staged::wanted_tiles(int32_t pos0, int64_t P) const {
-    std::vector<uint8_t> w;
+std::vector<uint16_t> Staged::wanted_tiles(int32_t pos0, int64_t P) const {
+    std::vector<uint16_t> w;
     if (win_beg.empty() || P <= 0) return w;
     const int64_t nt = (P + TILE - 1) / TILE;
-    w.assign((size_t)nt, 0);
+    w.assign((size_t)nt, (uint16_t)TILE_UNWANTED);
     for (size_t i = 0; i < win_beg.size(); ++i) {
         int64_t k0 = (int64_t)win_beg[i] - 1 - pos0, k1 = (int64_t)win_end[i] - pos0;      // plane indices of [beg - 1, end), as brc_format_window cuts them
         if (k0 < 0) k0 = 0;
         if (k1 > P) k1 = P;
-        for (int64_t t = k0 / TILE; k1 > k0 && t <= (k1 - 1) / TILE; ++t) w[(size_t)t] = 1;
+        for (int64_t t = k0 / TILE; k1 > k0 && t <= (k1 - 1) / TILE; ++t) {
+            const uint32_t a = (uint32_t)std::max<int64_t>(k0 - t * TILE, 0), b = (uint32_t)std::min<int64_t>(k1 - 1 - t * TILE, TILE - 1);
+            uint16_t& x = w[(size_t)t];
+            if (x == (uint16_t)TILE_UNWANTED) x = (uint16_t)(a | (b << 8));
+            else x = (uint16_t)(std::min<uint32_t>(x & 0xffu, a) | (std::max<uint32_t>(x >> 8, b) << 8));
+        }
     }
     return w;
 }
@@ -499,7 +504,7 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
             return fail(e, BRC_E_ARG, "read offsets outside the batch arenas");
         if (e->cfg.per_lib && s.lib.p[r] >= e->g.Lp) return fail(e, BRC_E_ARG, "library index out of range");
         s.cig_off.p[r] += cb; s.seq_off.p[r] += sb; s.qual_off.p[r] += qb;
-        s.bq_row.p[r] = s.bq_elems; s.bq_elems += ((uint64_t)s.l_qseq.p[r] + 7u) & ~(uint64_t)7u;
+        s.bq_row.p[r] = s.bq_elems; s.bq_elems += ((uint64_t)s.l_qseq.p[r] + 15u) & ~(uint64_t)15u;
         if (s.l_qseq.p[r] <= TABLE_MAX) s.len_hist[s.l_qseq.p[r]]++;
         if (s.l_qseq.p[r] >= (1 << 22)) return fail(e, BRC_E_LIMIT, "reads of 4 Mbases and more are not supported");
         if (s.l_qseq.p[r] > s.max_lqseq) s.max_lqseq = s.l_qseq.p[r];
@@ -834,10 +839,11 @@ static bool format_range(const brc_engine* e, const brc_result* r, const char* c
                 const uint32_t sid = hp.slotid[(int64_t)l * S + k];
                 const uint32_t b0 = sid & 0xffu, b1 = (sid >> 8) & 0xffu;
                 for (uint32_t b = 0; b < (uint32_t)BRC_NBUCKET; ++b) {
+                    // a bucket's events sit in ONE place: the slot that names it, or the third-allele table — also for a bucket a slot
+                    // names: the events of an N / '=' base never enter the slots, not even where N is the reference's own bucket
                     const int sl = b == b0 ? 0 : (b == b1 ? 1 : -1);
-                    if (sl >= 0) {
-                        const uint32_t* ip = hp.si + (((int64_t)l * 2 + sl) * NI) * S + k;
-                        if (ip[(int64_t)I_N * S] == 0) { memcpy(w, zero[b], ZERO_LEN + 3); w += ZERO_LEN + 3; continue; }
+                    const uint32_t* ip = sl >= 0 ? hp.si + (((int64_t)l * 2 + sl) * NI) * S + k : nullptr;
+                    if (ip && ip[(int64_t)I_N * S] != 0) {
                         const float* fp = hp.sf + (((int64_t)l * 2 + sl) * NF) * S + k;
                         for (int f = 0; f < BRC_NI; ++f) si[f] = ip[(int64_t)f * S];
                         for (int f = 0; f < BRC_NF; ++f) sf[f] = fp[(int64_t)f * S];

@@ -56,8 +56,8 @@ struct Staged {
     HBuf<int32_t> pos; HBuf<uint16_t> flag; HBuf<uint8_t> mapq; HBuf<int16_t> lib; HBuf<int32_t> l_qseq;
     HBuf<uint32_t> n_cigar; HBuf<uint64_t> cig_off, seq_off, qual_off; HBuf<int32_t> nm, sm; HBuf<uint8_t> tags;
     HBuf<uint32_t> cigar; HBuf<uint8_t> seq4, qual;
-    HBuf<uint64_t> bq_row;              // per read: first element of its 16-byte-aligned row in the device bq stream
-    uint64_t bq_elems = 0;              // total elements of the bq stream (sum of roundup8(l_qseq))
+    HBuf<uint64_t> bq_row;              // per read: first element of its 16-byte-aligned row in the device's event-byte stream
+    uint64_t bq_elems = 0;              // total elements of the event-byte stream (sum of roundup16(l_qseq))
     // KB v2: pieces (walk_pieces in brc_core.h).  piece_cnt is filled at push time; piece_off (library-major slot of a
     // read's first piece) and lib_base (first slot of every library's stream, Lp + 1 entries) at upload
     HBuf<char> qnames; HBuf<uint64_t> qname_off;   // read names when the caller gave them (warning text only); qname_off[i] = ~0 without
@@ -74,8 +74,9 @@ struct Staged {
     int64_t min_pos = 0, max_end = 0;   // extent of reads that enter the pileup
     uint64_t n_indel_ops = 0;           // I / D / P operators of all reads = slots of the raw indel-event list (an upper bound on the events)
     std::vector<int32_t> win_beg, win_end;   // brc_region_windows: the only windows [beg - 1, end) of the region anybody will format (empty: all of it)
-    // 1 per 64-position tile of the planes [pos0, pos0 + P) that a window touches (empty vector: no hint, every tile is wanted)
-    std::vector<uint8_t> wanted_tiles(int32_t pos0, int64_t P) const;
+    // per 64-position tile of the planes [pos0, pos0 + P): TILE_UNWANTED, or the first and last lane any window [beg - 1, end) asks
+    // for (lo | hi << 8) — the tile is piled up for those lanes only (empty vector: no hint, everything is wanted)
+    std::vector<uint16_t> wanted_tiles(int32_t pos0, int64_t P) const;
     void init(const HostAlloc* A);
     void clear();
     void destroy();

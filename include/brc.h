@@ -308,10 +308,11 @@ int  brc_format_window(brc_engine*, const brc_result*, const char* chrom, int32_
  * nothing outside a -l line — every line is its own fetch + pileup (bamreadcount.cpp:574-607), and pileup_func returns at
  * once for positions outside [beg - 1, end) (:269) — while a window laid on a shared axis brings the whole extent of its
  * reads with it (the annotator needs the reference under every base of a read, :139-174).  With the hint the engine piles
- * up only the 64-position tiles that a window [vbeg0[i] - 1, vend[i]) touches; every other tile comes back EMPTY (no
- * column, no depth, all-zero dense planes, no indel buckets: its statistics are not computed at all).  Only brc_format_window /
- * brc_window_warnings of the announced windows are meaningful on such a region; brc_region_counts, brc_result.n_events and
- * brc_result.warn[] then cover the announced tiles only (positions of an announced tile outside every window included).  Call between brc_begin_region and brc_end_region; n = 0 withdraws the hint, the next
+ * up only the positions a window [vbeg0[i] - 1, vend[i]) asks for (per 64-position tile: from the first to the last such
+ * position, with the reads that reach them); everything else comes back EMPTY (no column, no depth, all-zero dense planes, no
+ * indel buckets: its statistics are not computed at all).  Only brc_format_window / brc_window_warnings of the announced
+ * windows are meaningful on such a region; brc_region_counts, brc_result.n_events and brc_result.warn[] then cover those
+ * positions only.  Call between brc_begin_region and brc_end_region; n = 0 withdraws the hint, the next
  * brc_begin_region forgets it.
  */
 int  brc_region_windows(brc_engine*, const int32_t* vbeg0, const int32_t* vend, int64_t n);

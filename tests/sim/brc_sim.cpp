@@ -22,7 +22,7 @@ static const HostAlloc kAlloc = {sim_alloc, sim_release};
 class SimBackend : public Backend {
     DevCfg c; DevIn in; std::string err;
     const Staged* st = nullptr;
-    std::vector<DRead> reads; std::vector<uint16_t> bq; size_t bq_n = 0; std::vector<float> tq; std::vector<double> te;
+    std::vector<DRead> reads; std::vector<uint8_t> eb; std::vector<uint16_t> bqw; size_t bq_n = 0; std::vector<float> tq; std::vector<double> te;
     std::vector<Piece> hot; std::vector<PieceRare> rare; std::vector<int32_t> key, reach, prefmax;
     // the rare record of piece m: stored by K1 only when piece_has_rare(flags), derived from the piece otherwise
     PieceRare rare_of(uint32_t m) const { return piece_has_rare(piece_flags(hot[m])) ? rare[m] : piece_rare_of(c, hot[m]); }
@@ -49,20 +49,20 @@ class SimBackend : public Backend {
         in.pos = s.pos.p; in.flag = s.flag.p; in.mapq = s.mapq.p; in.lib = s.lib.p; in.l_qseq = s.l_qseq.p; in.n_cigar = s.n_cigar.p;
         in.cig_off = s.cig_off.p; in.seq_off = s.seq_off.p; in.qual_off = s.qual_off.p; in.nm = s.nm.p; in.sm = s.sm.p; in.tags = s.tags.p;
         in.cigar = s.cigar.p; in.seq4 = s.seq4.p; in.qual = s.qual.p; in.ref = g.ref ? g.ref + g.ref_lo : nullptr;
-        bq_n = s.bq_elems; in.bq = nullptr; in.bq_row = s.bq_row.p;
+        bq_n = s.bq_elems; in.eb = nullptr; in.bqw = nullptr; in.bq_row = s.bq_row.p;
         st = &s;
         return BRC_OK;
     }
 
+    uint32_t tile_want = 0u | (63u << 8);     // brc_region_windows: the lanes of the current tile that a window asks for
     // one (tile, library) wave of KB
     void pileup_tile(const Planes& pl, int lib, int64_t tl, uint32_t lo, uint32_t hi) {
         LaneAcc2 a[TILE]; bool valid[TILE], inreg[TILE]; int32_t p[TILE]; int64_t kk[TILE];
         for (int l = 0; l < TILE; ++l) {
             kk[l] = tl * TILE + l; inreg[l] = kk[l] < c.P; p[l] = (int32_t)(c.pos0 + kk[l]);
             // a position abandoned for a library-less read (:281-284) accumulates nothing: it behaves like a lane outside the region
-            valid[l] = inreg[l] && !(c.per_lib && unavail[(size_t)kk[l]] != NONE32);
-            uint32_t dom = valid[l] ? dominant_bucket(c, in, p[l]) : 1u;
-            if (c.force_dom >= 0) dom = (uint32_t)c.force_dom;
+            valid[l] = inreg[l] && !(c.per_lib && unavail[(size_t)kk[l]] != NONE32) && tile_wants(tile_want, (uint32_t)l);
+            const uint32_t dom = valid[l] ? dominant_bucket(c, in, p[l]) : 1u;
             lane2_init(a[l], dom);
         }
         TermTab tt; tt.q = tq.data(); tt.e = te.data();
@@ -83,13 +83,20 @@ class SimBackend : public Backend {
                     if (d < (uint32_t)h.ext) a[l].ncol++;                                             // lib_counts[library] (:286)
                     if (!(d < (uint32_t)h.len)) continue;
                     const int qpos = p[l] - h.a;
-                    const uint32_t w = bq[h.bq_off + (uint64_t)qpos];
+                    uint32_t w = eb[h.bq_off + (uint64_t)qpos];
                     if (w < thr) continue;                                                            // :288
                     a[l].depth++;                                                                     // mapq_n (:312)
                     if (fl & PF_NB) continue;                                                         // :343 with -i
-                    EvTerms t = (fl & (PF_TABLE | PF_TABQ)) ? piece_terms_tab(h, tt, c.table_len, qpos) : piece_terms_div(fl, piece_tp(c, h), rare[m], qpos);
+                    // a wide read's escape bytes: quality and bucket from the wide stream; an N / '=' base goes to the third-allele list
+                    // whatever the slots hold
+                    if ((fl & PF_WIDE) && eb_is_escape(w)) {
+                        const uint32_t w16 = bqw[h.bq_off + (uint64_t)qpos];
+                        if (!bucket_acgt(w16 & 0xffu)) { a[l].ww += h.ww; full.lane[l] = true; any_full = true; continue; }
+                        w = ((w16 >> 8) << 2) | ((w16 & 0xffu) - 1u);
+                    }
+                    EvTerms t = (fl & (PF_TABLE | PF_TABQ)) ? piece_terms_tab(h, tt, c.table_len, qpos) : (fl & PF_DIV) ? piece_terms_inlane(fl, h.tp_flags, h.w3, qpos) : piece_terms_div(fl, piece_tp(c, h), rare[m], qpos);
                     if ((fl & PF_TABQ) && !(fl & PF_HUGE)) t.sev = tabq_sev(qpos, piece_left_field(h.tp_flags), h.w3 >> 16);       // (as k_pileup2 does: no rare record)
-                    const uint32_t b = w & 0xffu;
+                    const uint32_t b = (w & 3u) + 1u;
                     a[l].ww += h.ww;
                     if (b == a[l].dom_b) { pack_event(a[l].dom, h, t, w); if (fl & PF_HUGE) { ints.lane[l] = true; any_int = true; } }
                     else if (a[l].alt_b == NB_NONE || a[l].alt_b == b) { a[l].alt_b = b; pack_event(a[l].alt, h, t, w); if (fl & PF_HUGE) { ints.lane[l] = true; any_int = true; } }
@@ -110,9 +117,11 @@ class SimBackend : public Backend {
                 for (int l = 0; l < TILE; ++l) {
                     if (!e.lane[l]) continue;
                     const int qpos = p[l] - h.a;
-                    const uint32_t w = bq[h.bq_off + (uint64_t)qpos];
-                    if (e.kind == 0) { const XEv x = make_xev(c, lib, kk[l], h, rr, qpos, w); const uint32_t at = (*pl.xev_n)++; if (at < pl.xev_cap) pl.xev[at] = x; }
-                    else drain_int(c, pl, lib, kk[l], rr, (w & 0xffu) == a[l].dom_b ? 0u : 1u);
+                    const uint32_t w = eb[h.bq_off + (uint64_t)qpos];
+                    uint32_t q = w >> 2, b = (w & 3u) + 1u;
+                    if ((piece_flags(h) & PF_WIDE) && eb_is_escape(w)) { const uint32_t w16 = bqw[h.bq_off + (uint64_t)qpos]; q = w16 >> 8; b = w16 & 0xffu; }
+                    if (e.kind == 0) { const XEv x = make_xev(c, lib, kk[l], h, rr, qpos, q, b); const uint32_t at = (*pl.xev_n)++; if (at < pl.xev_cap) pl.xev[at] = x; }
+                    else drain_int(c, pl, lib, kk[l], rr, b == a[l].dom_b ? 0u : 1u);
                 }
             }
             queue.clear();
@@ -134,18 +143,19 @@ class SimBackend : public Backend {
         if (t) memset(t, 0, sizeof *t);
         const int64_t n = c.n_reads, P = c.P, PS = c.PS; const int Lp = c.Lp;
         const int64_t np = c.n_pieces;
-        reads.resize((size_t)n); bq.assign(bq_n + 1, 0); in.bq = bq.data();
+        reads.resize((size_t)n); eb.assign(bq_n + 1, 0); bqw.assign(bq_n + 1, 0xdeadu); in.eb = eb.data(); in.bqw = bqw.data();       // (wide words nobody wrote must not be read)
         hot.assign((size_t)np + 1, Piece()); { PieceRare poison; memset(&poison, 0xff, sizeof poison); rare.assign((size_t)np + 1, poison); }   // (a rare record nobody wrote must not be read)
         key.assign((size_t)np + 1, 0); reach.assign((size_t)np + 1, 0); prefmax.assign((size_t)np + 1, 0);
         unavail.assign((size_t)PS, NONE32);
         for (int64_t i = 0; i < n; ++i) {                                                             // K1
-            const DRead rd = reads[(size_t)i] = annotate_read(c, in, i, bq.data());
+            bool wide = false;
+            const DRead rd = reads[(size_t)i] = annotate_read(c, in, i, eb.data(), bqw.data(), wide);
             const uint32_t* cg = in.cigar + in.cig_off[i];
             const bool nolib = c.per_lib && in.lib[i] < 0;
             const bool enters = read_enters(in.flag[i], cg, in.n_cigar[i]) && in.pos[i] >= 0;
             if (enters && nolib)                                                                       // k_unavail: first library-less read of every column (:281-284)
                 for (int64_t q = rd.pos; q < rd.end; ++q) { const int64_t k = q - c.pos0; if (k >= 0 && k < P && unavail[(size_t)k] > (uint32_t)i) unavail[(size_t)k] = (uint32_t)i; }
-            const ReadConst rc = read_const(c, rd, (uint32_t)i);
+            const ReadConst rc = read_const(c, rd, (uint32_t)i, wide);
             uint32_t slot = st->piece_off.p[i], cnt = 0;
             walk_pieces(c.insertion_centric != 0, enters && !nolib, rc.counts, rd.pos, cg, in.n_cigar[i], [&](int32_t rs, int32_t len, int32_t ext, int qoff, bool nb) {
                 PieceRare rr; make_piece(c, rc, rs, len, ext, qoff, nb, hot[slot], rr);
@@ -163,20 +173,29 @@ class SimBackend : public Backend {
         Planes pl = {ncol.data(), depth.data(), slotid.data(), si.data(), sf.data(), unavail.data(), xev.data(), &xev_n, (uint32_t)xev.size(), 1u};
         n_events = n_positions = 0; memset(warn, 0, sizeof warn);
         const int64_t ntiles = (P + TILE - 1) / TILE;
-        const std::vector<uint8_t> wanted = st->wanted_tiles(c.pos0, c.P);
+        const std::vector<uint16_t> wanted = st->wanted_tiles(c.pos0, c.P);
         for (int l = 0; l < Lp; ++l) {
             const int64_t s0 = st->lib_base[(size_t)l], s1 = st->lib_base[(size_t)l + 1];
             int32_t m = INT32_MIN;
             for (int64_t i = s0; i < s1; ++i) { if (reach[(size_t)i] > m) m = reach[(size_t)i]; prefmax[(size_t)i] = m; }
             for (int64_t tl = 0; tl < ntiles; ++tl) {                                                 // KB
                 uint32_t lo, hi; tile_range2(c, prefmax.data(), key.data(), s0, s1, tl, lo, hi);
-                if (!wanted.empty() && !wanted[(size_t)tl]) {
+                if (!wanted.empty() && wanted[(size_t)tl] == (uint16_t)TILE_UNWANTED) {
                     // brc_region_windows: exactly what k_mask_tiles leaves of a tile nobody announced — no column, no depth, no slot;
                     // its statistics planes are never written (and must never be read: they keep their poison here)
                     for (int ln = 0; ln < TILE; ++ln) { const int64_t k = tl * TILE + ln; if (k >= P) break;
                         ncol[(size_t)(l * PS + k)] = 0; depth[(size_t)(l * PS + k)] = 0; slotid[(size_t)(l * PS + k)] = (uint32_t)NB_NONE | ((uint32_t)NB_NONE << 8); }
                     continue;
                 }
+                if (!wanted.empty()) {
+                    // an announced tile is piled up for the lanes its windows ask for: pieces that cannot reach them are trimmed off
+                    // both ends of its range (k_mask_tiles), the other lanes behave like lanes outside the region
+                    const uint32_t w = wanted[(size_t)tl];
+                    const int64_t p0w = (int64_t)c.pos0 + tl * TILE + (w & 0xffu), p1w = (int64_t)c.pos0 + tl * TILE + (w >> 8);
+                    while (lo < hi && (int64_t)reach[lo] <= p0w) ++lo;
+                    while (hi > lo && (int64_t)key[hi - 1] > p1w) --hi;
+                    tile_want = w;
+                } else tile_want = 0u | (63u << 8);
                 pileup_tile(pl, l, tl, lo, hi);
             }
         }
@@ -204,7 +223,7 @@ class SimBackend : public Backend {
                 IndelEv* slot = raw.data() + st->iev_off.p[i]; uint32_t used = 0;
                 enumerate_indels(c, in, rd, in.qual + in.qual_off[i], [&](int32_t p, int qpos, int len) {
                     IndelEv e; e.read = (uint32_t)i; e.qpos = qpos; e.len = len; e.key_lo = (uint32_t)((int64_t)(p - c.pos0) * Lp + lib);
-                    if (!wanted.empty() && !wanted[(size_t)((uint32_t)(p - c.pos0) >> 6)]) return;     // (as K1: no indel alleles outside the announced tiles)
+                    if (!wanted.empty() && !tile_wants(wanted[(size_t)((uint32_t)(p - c.pos0) >> 6)], (uint32_t)(p - c.pos0) & 63u)) return;     // (as K1: no indel alleles outside the announced windows)
                     if (used < n_idp) { slot[used++] = e; cnt[indel_bucket_of(c, (uint32_t)(p - c.pos0), (uint32_t)lib)]++; }
                 });
                 for (; used < n_idp; ++used) slot[used].key_lo = NONE32;

@@ -91,10 +91,33 @@ def test_kernel_register_budget():
     piles = [v for k, v in kern.items() if "k_pileup2" in k]           # both instantiations (with / without brc_region_windows)
     anns = [v for k, v in kern.items() if "k_annotate_groups" in k]
     assert len(piles) == 2 and len(anns) == 2, sorted(kern)
+    # k_pileup2: 7 waves per SIMD; a few values may be spilled around its rare paths (the drain of queued third-allele / huge-integer
+    # entries between half-batches), never in a step: tools/check_isa.py counts the scratch instructions from the piece loop on
     for pile in piles:
-        assert pile["vgpr_count"] <= 72 and pile["private_segment_fixed_size"] == 0, pile
-    for ann in anns:
-        assert ann["private_segment_fixed_size"] == 0 and ann["vgpr_count"] <= 80, ann
+        assert pile["vgpr_count"] <= 72 and pile["private_segment_fixed_size"] <= 16, pile
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_isa.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()
+    for m in re.finditer(r"from the piece loop on: \d+ VALU, \d+ SALU, (\d+) scratch", r.stdout.decode()):
+        assert int(m.group(1)) <= 8, r.stdout.decode()
+    # K1: 6 waves per SIMD (80 VGPRs); three values that live from its first to its last phase are spilled once around the
+    # per-base pass (no scratch instruction inside a loop: checked on the assembly below)
+    # (the per-library instantiation stays at the allocator's five waves, without scratch)
+    ann_by = {("ILb1E" in k): v for k, v in kern.items() if "k_annotate_groups" in k}
+    assert ann_by[True]["private_segment_fixed_size"] <= 64 and ann_by[True]["vgpr_count"] <= 80, ann_by[True]
+    assert ann_by[False]["private_segment_fixed_size"] == 0 and ann_by[False]["vgpr_count"] <= 96, ann_by[False]
+    asm = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                          os.path.join(ROOT, "bam_readcount_amd", "csrc", "brc_engine.hip"), "-o", "-"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode().split("\n")
+    starts = [i for i, l in enumerate(asm) if re.match(r"^_ZN3brc17k_annotate_groups\S*:", l)]
+    assert len(starts) == 2
+    for st in starts:
+        in_loop = False; n_scratch = 0
+        for l in asm[st:next(i for i in range(st, len(asm)) if asm[i].startswith(".Lfunc_end"))]:
+            if re.match(r"^\.LBB|^; %bb", l):
+                in_loop = "in Loop:" in l or "Loop Header" in l
+            if l.strip().startswith("scratch_"):
+                n_scratch += 1
+                assert not in_loop, "K1 spills inside a loop: " + l
+        assert n_scratch <= 12
 
 
 @pytest.mark.parametrize("waves", [7, 6])
@@ -104,7 +127,7 @@ def test_early_scalar_loads_are_sound_in_the_machine_code(waves):
     control-flow graph of the compiled kernel from every such load to the first s_waitcnt lgkmcnt(0) on every path and
     fails if an instruction on the way reads or writes a register in flight.  The product's build (7 waves per SIMD; the
     Makefile runs the same check before it compiles the object) and a 6-wave build must pass."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_isa.py"), "--max-vgpr", "72", "--max-scratch", "0", "-DBRC_WAVES_PER_EU=%d" % waves],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_isa.py"), "--max-vgpr", {7: "72", 6: "84"}[waves], "--max-scratch", "16", "-DBRC_WAVES_PER_EU=%d" % waves],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode()
     assert b"no instruction touches their registers before the wait on any path" in r.stdout

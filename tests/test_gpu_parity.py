@@ -188,6 +188,30 @@ def test_hip_passes_back_to_back_leave_the_result_of_one(dev_lib, oracle_lib, mo
         eng.close()
 
 
+@pytest.mark.parametrize("min_bq", [0, 13, 63, 64, 200])
+def test_hip_escape_bytes_and_the_wide_stream(dev_lib, oracle_lib, min_bq):
+    """The event byte holds qualities 1..62 and buckets nameable relative to the reference base's; everything else is an escape
+    byte + a word in the wide stream + PF_WIDE pieces: qualities 0 and 63..255, N / '=' bases off the reference's bucket, any
+    mismatch over a reference base that is not A C G T (those events go to the third-allele list).  Base-quality thresholds
+    below, at and above the byte's range."""
+    rng = np.random.default_rng(71)
+    ref = synth.make_ref(rng, 4000, weird=0.03)
+    arrs = synth.make_batch(271, ref, 1500, style="mixed", mismatch=0.05, n_libs=2)
+    q = arrs["qual"].copy(); r = np.random.default_rng(5)
+    pick = r.random(q.size)
+    q[pick < 0.02] = 0; q[(pick >= 0.02) & (pick < 0.04)] = 63; q[(pick >= 0.04) & (pick < 0.06)] = r.integers(64, 256, int(((pick >= 0.04) & (pick < 0.06)).sum())); q[(pick >= 0.06) & (pick < 0.07)] = 62; q[(pick >= 0.07) & (pick < 0.08)] = 1
+    arrs["qual"] = q
+    s4 = arrs["seq4"].copy(); pk = r.random(s4.size)
+    s4[pk < 0.01] = (s4[pk < 0.01] & 0x0f) | 0xf0            # N in the high nibble
+    s4[(pk >= 0.01) & (pk < 0.02)] &= 0xf0                  # '=' in the low nibble
+    s4[(pk >= 0.02) & (pk < 0.025)] = 0x5a                  # IUPAC codes (bucket N)
+    arrs["seq4"] = s4
+    names = ["libA", "libB"]
+    parity.compare_libs(dev_lib, oracle_lib, arrs, [(0, 4000), (2000, 2100)], ref=ref, min_bq=min_bq, lib_names=names, per_lib=True, insertion_centric=True)
+    parity.compare_libs(dev_lib, oracle_lib, arrs, [(0, 4000)], ref=ref, min_bq=min_bq, min_mapq=3)
+    parity.compare_libs(dev_lib, oracle_lib, arrs, [(0, 4000)], ref=None, min_bq=min_bq)
+
+
 def shuffled_arenas(arrs, seed):
     """The same reads with their QUAL / SEQ / CIGAR rows laid out in a random order inside the arenas (legal: brc.h asks for
     offsets inside the arenas, not for increasing ones), with gaps between the rows."""
@@ -385,13 +409,17 @@ def test_hip_announced_windows_equal_the_whole_region(dev_lib, case):
     want, ncol_all, pos0, n_pos = run(False)
     got, ncol_hint, pos0_h, n_pos_h = run(True)
     assert got == want and sum(len(t) for t in want) > 0 and (pos0_h, n_pos_h) == (pos0, n_pos)
-    wanted = np.zeros((n_pos + 63) // 64, bool)                      # tiles of the planes [pos0, pos0 + n_pos)
+    # what is piled up: per 64-position tile of the planes [pos0, pos0 + n_pos), from the first to the last position a window
+    # [b - 1, e) asks for
+    nt = (n_pos + 63) // 64
+    lo = np.full(nt, 64, np.int64); hi = np.full(nt, -1, np.int64)
     for b, e in wins:
         k0, k1 = max(b - 1 - pos0, 0), min(e - pos0, n_pos)
-        if k1 > k0:
-            wanted[k0 // 64:(k1 - 1) // 64 + 1] = True
-    per_pos = np.repeat(wanted, 64)[:n_pos]
-    assert not ncol_hint[..., ~per_pos].any()                       # nothing piled up outside the announced tiles
+        for t in range(k0 // 64, (k1 - 1) // 64 + 1 if k1 > k0 else 0):
+            lo[t] = min(lo[t], max(k0 - 64 * t, 0)); hi[t] = max(hi[t], min(k1 - 1 - 64 * t, 63))
+    lane = np.arange(nt * 64) % 64
+    per_pos = ((lane >= np.repeat(lo, 64)) & (lane <= np.repeat(hi, 64)))[:n_pos]
+    assert not ncol_hint[..., ~per_pos].any()                       # nothing piled up outside
     np.testing.assert_array_equal(ncol_hint[..., per_pos], ncol_all[..., per_pos])
     assert ncol_all[..., ~per_pos].any()
     # the hint does not outlive its region
@@ -421,7 +449,7 @@ def test_hip_region_windows_argument_handling(dev_lib):
     res = eng.end_region()
     assert eng.format_window("chrS", 100, 101, 0) == text_all
     k = 100 - 1 - int(res.pos0)
-    keep = np.zeros(int(res.n_pos), bool); keep[(k // 64) * 64:((100 - int(res.pos0) - 1) // 64 + 1) * 64] = True
+    keep = np.zeros(int(res.n_pos), bool); keep[k:k + 2] = True                            # the window's lead position and the position itself
     assert not res.ncol[..., ~keep].any() and np.array_equal(res.ncol[..., keep], ncol_all[..., keep])
     eng.close()
 

@@ -42,7 +42,7 @@ def main():
     assert torch.cuda.is_available() or os.environ.get("BRC_AB_NO_GPU")
     libs = [(os.path.basename(p).replace("libbrc_hip", "").replace(".so", "").strip("_") or "default", capi.Library(os.path.abspath(p))) for p in args.libs]
     for shape in args.shapes.split(","):
-        config = "tumor200x" if shape == "tumor" else "wgs30x"
+        config = {"tumor": "tumor200x", "mixed": "wgs30x_mixed"}.get(shape, "wgs30x")
         per_lib = config == "tumor200x"
         names = ["lib%d" % i for i in range(synthgen.CONFIGS[config]["n_libs"])] if per_lib else ()
         opts = dict(min_mapq=20, min_bq=13) if not per_lib else dict(min_mapq=0, min_bq=0, per_lib=True, insertion_centric=True)

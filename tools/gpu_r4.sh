@@ -7,6 +7,7 @@ for what in "$@"; do
     suitex) ( time timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -40 ) > $out/pytest_gpu_$tag.log 2>&1 ;;
     bench) ( time timeout 1500 python bench.py --steps 20 --warmup 5 ) > $out/bench_$tag.log 2> $out/bench_$tag.err ;;
     bench300) ( time timeout 1500 python bench.py ) > $out/bench300_$tag.log 2> $out/bench300_$tag.err ;;
+    ab) ( time timeout 1200 python tools/gpu_ab_multi.py --libs $AB_LIBS --reps ${AB_REPS:-3} --shapes ${AB_SHAPES:-tumor,wgs} ) > $out/ab_$tag.log 2>&1 ;;
     quick) ( time timeout 900 python bench.py --steps 20 --warmup 5 --other-configs 0 --e2e-mbp 0 ) > $out/quick_$tag.log 2> $out/quick_$tag.err ;;
   esac
 done
