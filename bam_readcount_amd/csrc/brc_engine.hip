@@ -781,34 +781,23 @@ __global__ __launch_bounds__(TR_T) void k_tiles_all(DevCfg c, const int2* __rest
     }
 }
 
-// brc_region_windows: tiles no announced window touches are not piled up.  This kernel leaves their columns empty (no column, no
-// depth, no slot: what the host reads first of a position) and marks their piece range lo > hi, at which k_pileup2 returns at once —
-// without it the pileup kernel would spend most of a site list's time storing zeros for the 300-odd positions a line's reads
-// cover around the one or two the line asked for.
-__global__ __launch_bounds__(256) void k_mask_tiles(const uint16_t* __restrict__ wanted, int64_t ntiles, int Lp, int32_t pos0, int64_t P, int64_t PS, uint2* __restrict__ rng,
-                                                    const int2* __restrict__ keyreach, uint32_t* __restrict__ ncol, uint32_t* __restrict__ depth, uint32_t* __restrict__ slotid,
-                                                    uint4* __restrict__ tile_ctr) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;           // (library, tile, lane)
-    const int64_t lt = i >> 6; const int lane = (int)(i & 63);
-    if (lt >= ntiles * Lp) return;
-    const int64_t tile = lt % ntiles, lib = lt / ntiles;
+// brc_region_windows: only what an announced window asks for is piled up.  The host hands over the LIST of announced tiles
+// (k_pileup2<true> is launched over that list: a site list touches a quarter of the tiles its reads span) and, per tile, the
+// first and last lane a window asks for; everything else of the planes is emptied once, when the region is uploaded — no
+// kernel of the pass writes there.  This kernel trims every announced tile's piece range to the pieces that can reach its
+// wanted lanes: a line's window is one or two positions wide, the tile around it holds a third more pieces than cover those
+// (keyreach = {start of the piece's read, end of its column}).
+__global__ __launch_bounds__(256) void k_narrow_tiles(const uint16_t* __restrict__ wanted, const uint32_t* __restrict__ tile_list, int64_t n_listed, int64_t ntiles, int Lp, int32_t pos0,
+                                                      uint2* __restrict__ rng, const int2* __restrict__ keyreach) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;           // (library, listed tile)
+    if (i >= n_listed * Lp) return;
+    const int64_t tile = tile_list[i % n_listed], lib = i / n_listed;
     const uint32_t w = wanted[tile];
-    if (w != (uint32_t)TILE_UNWANTED) {
-        // an announced tile is piled up for the lanes [w0, w1] its windows ask for (the other lanes behave like lanes outside the
-        // region): pieces that cannot reach them are trimmed off both ends of its range — a line's window is one or two positions
-        // wide, the tile around it holds a third more pieces than cover those (keyreach = {start of the piece's read, end of its column})
-        if (lane == 0) {
-            uint2 r = rng[lt];
-            const int64_t p0w = (int64_t)pos0 + tile * TILE + (w & 0xffu), p1w = (int64_t)pos0 + tile * TILE + (w >> 8);
-            while (r.x < r.y && (int64_t)keyreach[r.x].y <= p0w) ++r.x;
-            while (r.y > r.x && (int64_t)keyreach[r.y - 1].x > p1w) --r.y;
-            rng[lt] = r;
-        }
-        return;
-    }
-    const int64_t k = tile * TILE + lane;
-    if (k < P) { ncol[lib * PS + k] = 0u; depth[lib * PS + k] = 0u; slotid[lib * PS + k] = (uint32_t)NB_NONE | ((uint32_t)NB_NONE << 8); }
-    if (lane == 0) { rng[lt] = make_uint2(1u, 0u); tile_ctr[lt] = make_uint4(0u, 0u, 0u, 0u); }
+    uint2 r = rng[lib * ntiles + tile];
+    const int64_t p0w = (int64_t)pos0 + tile * TILE + (w & 0xffu), p1w = (int64_t)pos0 + tile * TILE + (w >> 8);
+    while (r.x < r.y && (int64_t)keyreach[r.x].y <= p0w) ++r.x;
+    while (r.y > r.x && (int64_t)keyreach[r.y - 1].x > p1w) --r.y;
+    rng[lib * ntiles + tile] = r;
 }
 
 // ---------------------------------------------------------------- KB: pileup + BasicStat accumulation (the hot kernel)
@@ -876,7 +865,8 @@ template <bool WINDOWS>      // brc_region_windows is in force: tiles whose rang
 __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_eu(BRC_WAVES_PER_EU, BRC_WAVES_PER_EU))) void k_pileup2(DevCfg c, DevIn in, const uint4* __restrict__ pieces4, const PieceRare* __restrict__ rare,
                                                                const uint2* __restrict__ rng, int64_t ntiles, Planes pl, uint4* __restrict__ tile_ctr,
                                                                const uint8_t* __restrict__ eb_ro, const uint16_t* __restrict__ bqw_ro, const uint32_t* __restrict__ unavail_ro,
-                                                               const uint8_t* __restrict__ refcode, const uint16_t* __restrict__ wanted_ro) {
+                                                               const uint8_t* __restrict__ refcode, const uint16_t* __restrict__ wanted_ro,
+                                                               const uint32_t* __restrict__ tile_list, int64_t n_listed) {
     // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch order); give every XCD one contiguous
     // run of tiles so neighbouring tiles, which share most of their pieces, hit the same 4-MiB L2.
     const uint32_t nbk = gridDim.x;           // multiple of 8
@@ -903,18 +893,19 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
     }
     const int lane = threadIdx.x & 63;
     const uint32_t wv = __builtin_amdgcn_readfirstlane((uint32_t)threadIdx.x >> 6);   // wave of the workgroup (scalar)
-    const int64_t tile = (int64_t)wg * PILEUP_WAVES + wv;
-    if (tile >= ntiles) return;
+    // (brc_region_windows: the launch covers the list of announced tiles, not the region)
+    const int64_t slot = (int64_t)wg * PILEUP_WAVES + wv;
+    if (slot >= (WINDOWS ? n_listed : ntiles)) return;
+    const int64_t tile = WINDOWS ? (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)tile_list[slot]) : slot;
     const int lib = blockIdx.y;
     const uint2 r2 = rng[(int64_t)lib * ntiles + tile];
     const uint32_t lo = __builtin_amdgcn_readfirstlane(r2.x), hi = __builtin_amdgcn_readfirstlane(r2.y);
-    if (WINDOWS && lo > hi) return;           // (a tile nobody asked for: k_mask_tiles has emptied its columns)
     const int64_t k = tile * TILE + lane;
     const bool inreg = k < c.P;
     const int64_t kk = inreg ? k : 0;
     // a position abandoned for a library-less read (:281-284) accumulates nothing: it behaves like a lane outside the region
     const bool dead = c.per_lib && inreg && unavail_ro[kk] != NONE32;
-    // (brc_region_windows: the lanes no window asks for behave like lanes outside the region — k_mask_tiles has trimmed the tile's
+    // (brc_region_windows: the lanes no window asks for behave like lanes outside the region — k_narrow_tiles has trimmed the tile's
     // piece range to what reaches the others)
     const bool valid = inreg && !dead && (!WINDOWS || tile_wants(wanted_ro[tile], (uint32_t)lane));
     const int32_t p = (int32_t)(c.pos0 + k);
@@ -1535,7 +1526,7 @@ class HipBackend : public Backend {
     std::vector<int64_t> lib_base;      // first piece of every library's stream (Lp + 1 entries)
     // device buffers
     DBuf d_pos, d_flag, d_mapq, d_lib, d_lq, d_nc, d_co, d_so, d_qo, d_nm, d_sm, d_tags, d_cigar, d_seq, d_qual, d_ref, d_refcode;
-    std::vector<uint16_t> h_wanted; bool has_wanted = false; DBuf d_wanted;      // brc_region_windows (kept alive for the asynchronous copy)
+    std::vector<uint16_t> h_wanted; bool has_wanted = false; DBuf d_wanted; std::vector<uint32_t> h_tilelist; DBuf d_tilelist;      // brc_region_windows (kept alive for the asynchronous copy)
     DBuf d_bq, d_bqw, d_bqrow, d_pieceoff, d_pieces, d_rare, d_keyreach, d_libbase, d_reads, d_agg, d_rng, d_ncol, d_depth, d_slotid, d_si, d_sf, d_xev, d_xevc, d_xevn, d_unavail, d_cnt, d_cursor, d_ev, d_evraw, d_ievoff, d_iout, d_ctr, d_tilectr, d_part;
     DBuf d_tlen, d_toff, d_text, d_tctx;
     // device-side text, downloaded (pinned) on its own stream into one of two host buffers
@@ -1582,7 +1573,7 @@ class HipBackend : public Backend {
         (void)hipSetDevice(device);
         DBuf* all[] = {&d_pos, &d_flag, &d_mapq, &d_lib, &d_lq, &d_nc, &d_co, &d_so, &d_qo, &d_nm, &d_sm, &d_tags, &d_cigar, &d_seq, &d_qual,
                        &d_ref, &d_refcode, &d_bq, &d_bqw, &d_bqrow, &d_pieceoff, &d_pieces, &d_rare, &d_keyreach, &d_libbase, &d_reads, &d_agg, &d_rng, &d_ncol, &d_depth, &d_slotid, &d_si, &d_sf, &d_xev, &d_xevc, &d_xevn, &d_unavail, &d_cnt,
-                       &d_cursor, &d_ev, &d_evraw, &d_ievoff, &d_iout, &d_ctr, &d_tilectr, &d_part, &d_tlen, &d_toff, &d_text, &d_tctx, &d_wanted};
+                       &d_cursor, &d_ev, &d_evraw, &d_ievoff, &d_iout, &d_ctr, &d_tilectr, &d_part, &d_tlen, &d_toff, &d_text, &d_tctx, &d_wanted, &d_tilelist};
         for (DBuf* b : all) b->release();
         for (int i = 0; i < 2; ++i) { h_text[i].destroy(); h_toff[i].destroy(); if (ev_text[i]) (void)hipEventDestroy(ev_text[i]); }
         h_total.destroy();
@@ -1670,7 +1661,13 @@ class HipBackend : public Backend {
         ntiles = (c.P + TILE - 1) / TILE;
         n_indel_cap = c.has_ref ? s.n_indel_ops : 0;
         h_wanted = s.wanted_tiles(c.pos0, c.P); has_wanted = !h_wanted.empty();
-        if (has_wanted) { HIPCHK(d_wanted.ensure(h_wanted.size() * 2 + 16)); HIPCHK(hipMemcpyAsync(d_wanted.p, h_wanted.data(), h_wanted.size() * 2, hipMemcpyHostToDevice, stream)); }
+        h_tilelist.clear();
+        if (has_wanted) {
+            HIPCHK(d_wanted.ensure(h_wanted.size() * 2 + 16)); HIPCHK(hipMemcpyAsync(d_wanted.p, h_wanted.data(), h_wanted.size() * 2, hipMemcpyHostToDevice, stream));
+            for (size_t t = 0; t < h_wanted.size(); ++t) if (h_wanted[t] != (uint16_t)TILE_UNWANTED) h_tilelist.push_back((uint32_t)t);
+            HIPCHK(d_tilelist.ensure(h_tilelist.size() * 4 + 16));
+            if (!h_tilelist.empty()) HIPCHK(hipMemcpyAsync(d_tilelist.p, h_tilelist.data(), h_tilelist.size() * 4, hipMemcpyHostToDevice, stream));
+        }
         if (n_indel_cap && ((uint64_t)c.P * (uint64_t)c.Lp >= 0xffffffffull || n_indel_cap >= 0xfffffff0ull)) { err = "region too large: (positions x libraries) and the indel operators must stay below 2^32"; return BRC_E_ARG; }
         const size_t nagg = std::max<size_t>(std::max<size_t>((std::max<size_t>(np, P * Lp) + SCAN_CHUNK - 1) / SCAN_CHUNK, (np + TR_CHUNK - 1) / TR_CHUNK), 1);
         HIPCHK(d_reads.ensure((n + 1) * sizeof(DRead)));
@@ -1697,6 +1694,13 @@ class HipBackend : public Backend {
             in.iev_off = (const uint32_t*)d_ievoff.p;
             HIPCHK(d_cnt.ensure(nbk * 4 + 16)); HIPCHK(d_cursor.ensure(nbk * 4 + 16)); HIPCHK(d_evraw.ensure((n_indel_cap + 1) * sizeof(IndelEv)));
             HIPCHK(d_ev.ensure((n_indel_cap + 1) * sizeof(IndelEv))); HIPCHK(d_iout.ensure((n_indel_cap + 1) * sizeof(IndelOut)));
+        }
+        if (has_wanted && P) {
+            // brc_region_windows: what no window asks for comes back empty — written here, ONCE per uploaded region: the passes
+            // over it only touch the announced tiles (their columns, their counters)
+            HIPCHK(hipMemsetAsync(d_ncol.p, 0, Lp * P * 4, stream)); HIPCHK(hipMemsetAsync(d_depth.p, 0, Lp * P * 4, stream));
+            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)d_slotid.p, (int)((uint32_t)NB_NONE | ((uint32_t)NB_NONE << 8)), Lp * P, stream));
+            HIPCHK(hipMemsetAsync(d_tilectr.p, 0, (size_t)ntiles * Lp * sizeof(uint4), stream));
         }
         HIPCHK(hipStreamSynchronize(stream));
         return BRC_OK;
@@ -1796,12 +1800,13 @@ class HipBackend : public Backend {
         if (np_all > 0 && ntiles > 0)
             hipLaunchKernelGGL(k_tiles_all, dim3((unsigned)trb), dim3(TR_T), 0, stream, c, (const int2*)d_keyreach.p, np_all, (const int64_t*)d_libbase.p, Lp,
                                (const unsigned long long*)d_agg.p, ntiles, (uint2*)d_rng.p);
-        if (has_wanted && ntiles > 0)
-            hipLaunchKernelGGL(k_mask_tiles, dim3((unsigned)((ntiles * Lp * 64 + 255) / 256)), dim3(256), 0, stream, (const uint16_t*)d_wanted.p, ntiles, Lp, c.pos0, (int64_t)c.P, (int64_t)c.PS, (uint2*)d_rng.p,
-                               (const int2*)d_keyreach.p, (uint32_t*)d_ncol.p, (uint32_t*)d_depth.p, (uint32_t*)d_slotid.p, (uint4*)d_tilectr.p);
+        const int64_t n_listed = (int64_t)h_tilelist.size();
+        if (has_wanted && n_listed > 0)
+            hipLaunchKernelGGL(k_narrow_tiles, dim3((unsigned)((n_listed * Lp + 255) / 256)), dim3(256), 0, stream, (const uint16_t*)d_wanted.p, (const uint32_t*)d_tilelist.p, n_listed, ntiles, Lp, c.pos0,
+                               (uint2*)d_rng.p, (const int2*)d_keyreach.p);
         HIPCHK(hipEventRecord(evt[T_PILEUP], stream));
         if (ntiles > 0) {
-            unsigned nwg = (unsigned)((ntiles + PILEUP_WAVES - 1) / PILEUP_WAVES);
+            unsigned nwg = (unsigned)(((has_wanted ? n_listed : ntiles) + PILEUP_WAVES - 1) / PILEUP_WAVES);
             nwg = (nwg + 7u) & ~7u;
             // profiling knob: unused dynamic LDS lowers the number of resident waves (occupancy sweeps)
 #ifdef BRC_EXP_KNOBS
@@ -1809,14 +1814,15 @@ class HipBackend : public Backend {
 #else
             const unsigned dyn_lds = 0u;
 #endif
-if (has_wanted) {
+            if (has_wanted) {
+                if (n_listed > 0)
                             hipLaunchKernelGGL((k_pileup2<true>), dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), dyn_lds, stream, c, in, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p,
                                (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.eb, in.bqw, (const uint32_t*)d_unavail.p,
-                               (const uint8_t*)d_refcode.p + REFCODE_PAD, (const uint16_t*)d_wanted.p);
+                               (const uint8_t*)d_refcode.p + REFCODE_PAD, (const uint16_t*)d_wanted.p, (const uint32_t*)d_tilelist.p, n_listed);
             } else {
                             hipLaunchKernelGGL((k_pileup2<false>), dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), dyn_lds, stream, c, in, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p,
                                (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.eb, in.bqw, (const uint32_t*)d_unavail.p,
-                               (const uint8_t*)d_refcode.p + REFCODE_PAD, (const uint16_t*)d_wanted.p);
+                               (const uint8_t*)d_refcode.p + REFCODE_PAD, (const uint16_t*)d_wanted.p, (const uint32_t*)d_tilelist.p, n_listed);
             }
             hipLaunchKernelGGL(k_xev_compact, dim3((unsigned)XEV_SHARDS), dim3(256), 0, stream, (const XEv*)d_xev.p, (const uint32_t*)d_xevn.p, (uint32_t)xev_cap,
                                (uint32_t)XEV_SHARDS, (XEv*)d_xevc.p, ctr);

@@ -110,6 +110,53 @@ def test_sim_deep_indel_key_equals_oracle(sim_lib, oracle_lib):
         assert max(int(d["i"][0]) for d in res[0].indels) > 100
 
 
+def test_large_batches_are_staged_on_several_threads_like_on_one(sim_lib, oracle_lib):
+    """brc_push_reads takes batches of 32 768 reads and more through a pool of threads (per-chunk sums, a scan, offsets): the
+    staging — rows of the event-byte stream, indel slots, pieces, extent, histogram — and the first error in file order must be
+    those of the one-thread pass (BRC_OPT_FORMAT_THREADS = 1 caps the pool at one thread: the serial pass)."""
+    import sys
+    from bam_readcount_amd import capi
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synthgen
+    import parity
+    ref, arrs = synthgen.generate(120_000, "tumor200x", seed=21, n_chunks=4)          # 160 000 reads, 10 % with an indel
+    assert len(arrs["pos"]) >= 100_000
+    names = ["lib%d" % i for i in range(4)]
+
+    def run(threads, batch):
+        eng = capi.Engine(sim_lib, per_lib=True, insertion_centric=True, lib_names=names)
+        if threads:
+            sim_lib.lib.brc_set_option(eng.h, 8, threads)
+        try:
+            eng.begin_region(0, 0, 120_000, ref); eng.push_reads(batch)
+            r = eng.end_region(); return r, eng.format_region("chrS")
+        finally:
+            eng.close()
+    r1, t1 = run(1, arrs); r8, t8 = run(0, arrs)
+    parity.assert_results_equal(r8, r1, "pooled vs one-thread staging"); assert t8 == t1
+    # two batches: the second continues the first one's running sums
+    half = len(arrs["pos"]) // 2
+    eng = capi.Engine(sim_lib, per_lib=True, insertion_centric=True, lib_names=names)
+    eng.begin_region(0, 0, 120_000, ref); eng.push_reads(capi.select_reads(arrs, np.arange(half))); eng.push_reads(capi.select_reads(arrs, np.arange(half, len(arrs["pos"]))))
+    parity.assert_results_equal(eng.end_region(), r1, "two pooled batches"); assert eng.format_region("chrS") == t1; eng.close()
+    # the first bad record in file order decides the error, whichever chunk meets one first
+    for where, field, what in ((90_001, "l_qseq", "CIGAR and sequence length disagree"), (40_000, "pos", "not coordinate-sorted"), (150_000, "lib", "library index out of range")):
+        bad = {k: (v.copy() if v is not None else None) for k, v in arrs.items()}
+        bad["l_qseq"][120_000] += 1                                             # a later bad record that must not win
+        if field == "l_qseq": bad["l_qseq"][where] += 2
+        elif field == "pos": bad["pos"][where] = bad["pos"][where - 1] - 5
+        else: bad["lib"][where] = 9; bad["l_qseq"][120_000] -= 1
+        for threads in (1, 0):
+            eng = capi.Engine(sim_lib, per_lib=True, insertion_centric=True, lib_names=names)
+            if threads: sim_lib.lib.brc_set_option(eng.h, 8, threads)
+            eng.begin_region(0, 0, 120_000, ref)
+            with pytest.raises(capi.BrcError) as ei:
+                eng.push_reads(bad)
+            assert what in str(ei.value), (where, threads, str(ei.value))
+            eng.close()
+
+
 def test_push_reads_refuses_inconsistent_records(sim_lib):
     """The staging code is the last stop before the kernels index a read's rows: a CIGAR that walks more or fewer query bases
     than the record has, offsets outside the arenas and unsorted reads are errors, not work."""
