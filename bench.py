@@ -108,7 +108,7 @@ def main():
                     "of --mode weak / strong with a CPU sample, 2 = planes only (no text: config 5 whole prints 72 GB), 0 = off")
     ap.add_argument("--e2e-mbp", type=float, default=30.0, help="contig of the end-to-end command-line run (0 = skip)")
     ap.add_argument("--abi-mbp", type=float, default=10.0, help="prefix run through the C-ABI from host batches to host text (abi_roundtrip; 0 = skip)")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r03_traffic.json"))
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r04_traffic.json"))
     ap.add_argument("--other-configs", type=int, default=-1, help="1: also run BASELINE config 4 (--mode sites) and the per-GPU shape of config 5 (--mode strong --contig-mbp 6.25) "
                     "in sub-processes and put their lines under other_configs (-1: yes on the default single-GPU config-3 run, no otherwise)")
     # test infrastructure (tests/test_bench_multirank.py): the rank arithmetic of this script — who owns which interval / slice of

@@ -9,7 +9,7 @@ for cfg in wgs30x tumor200x; do
   if [ $cfg = wgs30x ]; then A="--mode weak"; else A="--mode strong --contig-mbp 6.25"; fi
   timeout 600 python bench.py --steps 100 --warmup 5 $Q --other-configs 0 $A 2>/dev/null | grep '^{' > $O/bench_line_$cfg.json
   rm -rf /tmp/prof_$cfg
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$cfg -o trace -- python "$OLDPWD/bench.py" --steps 5 --warmup 1 $Q $A ) > $O/rocprof_$cfg.log 2>&1
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$cfg -o trace -- python "$OLDPWD/bench.py" --steps 20 --warmup 5 $Q --other-configs 0 $A ) > $O/rocprof_$cfg.log 2>&1
   f=$(find /tmp/prof_$cfg -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/rocprofv3_kernel_stats_$cfg.csv
   for set in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq1:SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "sq2:SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM_WR"; do
     name=${set%%:*}; ctrs=${set#*:}
