@@ -272,6 +272,26 @@ def main():
             if tj and abs(float(tj.get("contig_mbp", 50.0)) - contig_len / 1e6) < 1e-6:       # the passes measured exactly this workload
                 traffic = tj.get("k_pileup_hbm_bytes_per_launch")
                 traffic_src = "%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not measured in this run" % os.path.relpath(args.traffic_json, ROOT)
+        # The roofline that really binds the kernel: vector-instruction issue.  From the committed PMC passes of this workload at the
+        # shipped kernel (profiles/r04_pmc_summary.json, not measured in this run): a wave64 VALU instruction occupies its SIMD for 4
+        # cycles, so SQ_INSTS_VALU x 4 / 1024 SIMDs = the cycles every SIMD spends issuing vector instructions, against the kernel's
+        # own busy cycles (SQ_BUSY_CYCLES is summed over the chip's 32 shader engines; its quotient by the duration is the clock the
+        # kernel really ran at, below the 2.4 GHz peak).
+        issue = None
+        pmc_json = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
+        if traffic is not None and os.path.exists(pmc_json):
+            pm = json.load(open(pmc_json)).get(config, {})
+            def issue_of(name):
+                k = pm.get(name)
+                if not k or not k.get("SQ_BUSY_CYCLES"):
+                    return None
+                busy = k["SQ_BUSY_CYCLES"] / 32.0
+                return {"valu_insts_per_launch": int(k["SQ_INSTS_VALU"]), "salu_insts_per_launch": int(k["SQ_INSTS_SALU"]),
+                        "valu_issue_cycles_per_simd": round(k["SQ_INSTS_VALU"] * 4 / 1024.0), "busy_cycles": round(busy),
+                        "valu_issue_frac": round(k["SQ_INSTS_VALU"] * 4 / 1024.0 / busy, 4), "salu_issue_frac": round(k["SQ_INSTS_SALU"] * 4 / 1024.0 / busy, 4),
+                        "lane_utilisation": round(k["SQ_THREAD_CYCLES_VALU"] / (64.0 * k["SQ_INSTS_VALU"]), 4) if k.get("SQ_THREAD_CYCLES_VALU") else None}
+            issue = {"k_pileup2": issue_of("k_pileup2"), "k_annotate_groups": issue_of("k_annotate_groups"),
+                     "source": "profiles/r04_pmc_summary.json: separate rocprofv3 --pmc passes of this workload at the shipped kernels, not measured in this run"}
         # what THIS design must move per step at the least: the inputs once, the reference once, the compact result once
         # (116 B per position and library; SURVEY 8d's figure above credits the dense 312 B the kernel does not write)
         compact = b_in + b_ref + 116 * int(eng_positions) * res_libs
@@ -286,6 +306,7 @@ def main():
                 "kernel_frac_by_compulsory_bytes_compact": round(compact / (kms[k_pile] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kms[k_pile] > 0 else None,
                 "whole_step_frac_by_compulsory_bytes_compact": round(compact / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if world == 1 else None,
                 "whole_step_frac": round(alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if world == 1 else None,
+                "instruction_issue": issue,
                 "kernel_ms": {k: round(float(v), 4) for k, v in zip(kernel_names, kms) if k}}
 
         # ---- validation + 1-thread CPU baseline on a prefix of the timed contig
