@@ -1044,9 +1044,10 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                     BRC_SEV_ADD(a.dom.f[F_SEV], tsev);                                                                    \
                     fadd_s(a.dom.f[F_SNM], __uint_as_float(R.f[7])); a.ww += R.g[0];                                      \
                 }                                                                                                         \
-                /* (no instruction: naming the two sums here keeps each in ONE register across the join — left alone, the allocator   \
-                   computes them into temporaries inside the region and copies them back, two moves per step: -0.7 %, measured) */ \
-                asm volatile("" : "+v"(a.dom.f[F_SEV]), "+v"(a.dom.f[F_SQ2]));
+                /* (no instruction: naming the four sums here keeps each in ONE register across the join — left alone, the allocator   \
+                   computes them into temporaries inside the region and copies them back, or packs two of the adds into a v_pk_add_f32   \
+                   with a move in front and a 64-bit move behind: the region is 11 vector instructions with the four named, 12-13 without) */ \
+                asm volatile("" : "+v"(a.dom.f[F_SEV]), "+v"(a.dom.f[F_SQ2]), "+v"(a.dom.f[F_S3P]), "+v"(a.dom.f[F_SNM]));
 #endif
 #if BRC_EXP == 1      // (timing only, wrong sums: the event-location sum without its three double-precision instructions)
 #define BRC_SEV_ADD(acc, x) acc += (float)__double2hiint(x)
