@@ -854,6 +854,7 @@ int brc_fetch_window(brc_engine* e, int32_t beg0, int32_t end, brc_result* out) 
     // plane indices of [beg0 - 1, end) clipped to the planes (the lead position only when the region processed it)
     int64_t k0 = (int64_t)(beg0 > 0 ? beg0 - 1 : 0) - g.pos0, k1 = (int64_t)end - g.pos0;
     if (k0 < 0) k0 = 0;
+    if (k0 > g.P) k0 = g.P;                                  // (a window behind the reads' extent: no planes, an empty result)
     if (k1 > g.P) k1 = g.P;
     if (k1 < k0) k1 = k0;
     const int64_t n = k1 - k0;

@@ -261,8 +261,10 @@ int  brc_compute_n(brc_engine*, int32_t n, brc_timing* timing);
  * region; the planes cover [max(beg0 - 1, 0), end) clipped to the region's planes (index 0 is the window's lead position, see
  * brc_result).  `out` is a complete brc_result with a stride of its own (engine-owned arrays, valid until the next brc_fetch_window
  * / brc_begin_region of this engine; a result of brc_fetch_result stays valid beside it); brc_format_region accepts it — windows
- * formatted one after the other, in order, print the region's text, and after brc_clear_indel_queue a window prints exactly what
- * the reference prints for a -l line [beg0 + 1, end] (bamreadcount.cpp:574-607).  n_events counts the window's columns inside
+ * formatted one after the other, in order, with BRC_OPT_CONTINUES_PREVIOUS = 1 for every window but the first (a window's lead
+ * position was the last position of the window before: it is not processed again), print the region's text; and after
+ * brc_clear_indel_queue (option 0) a window prints exactly what the reference prints for a -l line [beg0 + 1, end]
+ * (bamreadcount.cpp:574-607).  A window behind the extent of the region's reads comes back without positions.  n_events counts the window's columns inside
  * [beg0, end); warn[] is a whole-region quantity and comes back zero.  Callable any number of times between brc_compute and the
  * next brc_begin_region, before or after brc_fetch_result (not with BRC_OPT_DEVICE_TEXT regions whose planes the text replaced: it
  * reads the device planes, which stay in place).

@@ -138,13 +138,16 @@ def test_hip_fetch_window_equals_the_stand_alone_region(dev_lib, oracle_lib, per
     whole = eng.fetch_result(); whole_text = eng.format_region("chrS"); eng.clear_indel_queue()
     cuts = [100, 101, 164, 1000, 1001, 2500, 4097, 5900]
     in_order = b""
-    for a, b in zip(cuts[:-1], cuts[1:]):
+    for wi, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        dev_lib.lib.brc_set_option(eng.h, 6, 1 if wi else 0)       # BRC_OPT_CONTINUES_PREVIOUS: a window's lead position was the last one of the window before
         w = eng.fetch_window(a, b)
         in_order += eng.format_region("chrS")
         assert (w.beg0, w.end, w.pos0) == (a, b, max(a - 1, whole.pos0)) and w.pos0 + w.n_pos == min(b, whole.pos0 + whole.n_pos)
         for x, y in zip(parity.slice_result(w, a - 1, b), parity.slice_result(whole, a - 1, b)):
             assert (x == y) if isinstance(x, list) else np.array_equal(x, y)
     assert in_order == whole_text
+    dev_lib.lib.brc_set_option(eng.h, 6, 0)
+    assert eng.fetch_window(5800, 5900).n_pos >= 0                     # (a window that may lie behind the reads' extent: empty, not an error)
     eng.clear_indel_queue()
     for a, b in zip(cuts[:-1], cuts[1:]):
         oe.begin_region(0, a, b, ref); oe.push_reads(capi.select_reads(arrs, capi.fetch_overlapping(arrs, ends, a - 1, b)))
