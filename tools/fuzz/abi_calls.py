@@ -15,6 +15,7 @@ random.seed(int(sys.argv[2]))
 rng = np.random.default_rng(1)
 ref = synth.make_ref(rng, 1500)
 batches = [synth.make_batch(s, ref, 120, style=st, n_libs=2) for s, st in ((1, "mixed"), (2, "wild"), (3, "indel"))]
+big = synth.make_batch(9, ref, 40000, style="mixed", n_libs=2, read_len=(20, 40))
 errs = {}
 for it in range(int(sys.argv[3])):
     per_lib = random.random() < 0.5
@@ -24,7 +25,8 @@ for it in range(int(sys.argv[3])):
     except capi.BrcError as e:
         errs[str(e)[:40]] = errs.get(str(e)[:40], 0) + 1; continue
     for step in range(random.randint(3, 25)):
-        op = random.choice(["begin", "push", "upload", "compute", "fetch", "end", "format", "clear", "counts", "warn", "opt", "chrom", "window"])
+        op = random.choice(["begin", "push", "upload", "compute", "fetch", "end", "format", "clear", "counts", "warn", "opt", "chrom", "window",
+                            "compute_n", "fetch_window", "windows", "bigpush"])
         try:
             if op == "begin":
                 a = random.randint(0, 1200); eng.begin_region(0, a, a + random.choice([0, 1, 50, 700]), ref if random.random() < 0.9 else None)
@@ -39,6 +41,12 @@ for it in range(int(sys.argv[3])):
             elif op == "warn": capi._region_warnings(eng, "chrS") if hasattr(capi, "_region_warnings") else None
             elif op == "opt": lib.lib.brc_set_option(eng.h, random.randint(0, 9), random.choice([0, 1, 2, -1, 10**12]))
             elif op == "chrom": lib.lib.brc_set_chrom(eng.h, random.choice([b"chrS", b"", None]))
+            elif op == "compute_n": eng.compute_n(random.choice([-1, 0, 1, 3, 40]))
+            elif op == "fetch_window": a = random.randint(0, 1400); eng.fetch_window(a, a + random.choice([-3, 0, 1, 64, 65, 900]))
+            elif op == "windows":
+                k = random.randint(0, 6); wb = np.array([random.randint(-50, 1600) for _ in range(k)], np.int32)
+                eng.region_windows(wb, wb + np.array([random.choice([0, 1, 2, 70, 400]) for _ in range(k)], np.int32))
+            elif op == "bigpush": eng.push_reads(big)              # (above the staging pool's threshold)
             elif op == "window": capi._format_window(eng, "chrS", random.randint(0, 500), random.randint(0, 900), random.randint(-5, 5))
         except capi.BrcError as e:
             k = str(e)[:60]; errs[k] = errs.get(k, 0) + 1
