@@ -412,6 +412,14 @@ BRC_HD float div_rcp(float a, float b, float y) {
 // |a - b| for two non-negative ints
 BRC_HD uint32_t absdiff_u(uint32_t a, uint32_t b) { return (a > b ? a : b) - (a < b ? a : b); }
 #define BRC_ABSDIFF(a, b) ((int)absdiff_u((uint32_t)(a), (uint32_t)(b)))
+// (|lane value - wave-uniform value| of unsigned operands: one v_sad_u32 on the device — LLVM does not form it from max - min)
+BRC_HD uint32_t absdiff_vs(uint32_t a, uint32_t b_uniform) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t d; asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "s"(b_uniform)); return d;
+#else
+    return absdiff_u(a, b_uniform);
+#endif
+}
 
 // Quotient tables for reads with l_qseq == clipped_length == L0 (DevCfg.table_len): every division of the event terms is
 // then n / L0 with an integer 0 <= n <= L0:  |qpos-q2| / L,  |qpos-tp| / L  and  |(qpos-left) - cl/2| / (cl/2) = |2(qpos-left) - cl| / cl.
@@ -497,11 +505,29 @@ BRC_HD int piece_tp_of(uint32_t tp_flags, int table_len) {
     const uint32_t fl = tp_flags >> 24;
     return (fl & (PF_TABLE | PF_TABQ)) ? (piece_tp_field(tp_flags) + 8 * table_len) >> 4 : (fl & PF_DIV) ? (int)(tp_flags & 0xffu) : (int)(tp_flags & 0xffffffu);
 }
+// n / m for small non-negative integers held in floats (n < 2^12, 0 < m < 2^10), correctly rounded.  On the device: the hardware's
+// approximate reciprocal (v_rcp_f32, 1 ulp), one multiply, two FMAs — q0 = n*y, e = n - q0*m (exact in one FMA), q = RN(q0 + e*y).
+// The error y carries into e*y is some 2^-46 of the quotient, and a quotient of such integers is either a float (then e*y lands on
+// it) or at least 2^-35 of itself away from every midpoint between two floats (|n/m - M| >= 1/(m 2^s) for a 25-bit M = Mint/2^s):
+// the last rounding cannot go the other way.  The engine checks the whole domain against the compiler's IEEE division when it is
+// created (k_divcheck in brc_engine.hip) and refuses to come up otherwise; tests/exact_division.cpp walks the same sequence over the
+// domain with RN(1/m) and every reciprocal up to 2 ulp away from it.
+// On the host (simulator): `/`.
+BRC_HD float div_small(float n, float m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float y = __builtin_amdgcn_rcpf(m);
+    const float q = n * y;
+    const float e = __builtin_fmaf(-q, m, n);
+    return __builtin_fmaf(e, y, q);
+#else
+    return n / m;
+#endif
+}
+enum { DIV_SMALL_N = 4096, DIV_SMALL_M = 1024 };    // the domain k_divcheck covers: numerators below / denominators below
 // the event-location term of a PF_TABQ piece at query position qpos: |(qpos - left) - cl/2| / (cl/2) is the correctly rounded quotient of the
 // rational |2 (qpos - left) - cl| / cl — the same float whichever pair of exactly represented operands is divided (BasicStat.cpp:69-70)
 BRC_HD double tabq_sev(int qpos, int left, uint32_t clipped) {
-    const int n = 2 * (qpos - left) - (int)clipped;
-    return 1.0 - (double)((float)(n < 0 ? -n : n) / (float)clipped);
+    return 1.0 - (double)div_small((float)absdiff_vs(2u * (uint32_t)qpos, 2u * (uint32_t)left + clipped), (float)clipped);   // (left < 512, clipped <= table_len <= 512: make_piece)
 }
 BRC_HD int piece_tp(const DevCfg& c, const Piece& h) { return piece_tp_of(h.tp_flags, c.table_len); }
 BRC_HD bool piece_has_rare(uint32_t fl) { return (fl & PF_TABLE) == 0u || (fl & PF_HUGE) != 0u; }
@@ -649,16 +675,15 @@ BRC_HD EvTerms piece_terms_div(uint32_t fl, int tp, const PieceRare& r, int qpos
     return t;
 }
 // ... a PF_DIV piece's from its own record (tp | l_qseq << 8 | left_clip << 16 in the tp field, clipped_length in w3): the
-// reference's own expressions, BasicStat.cpp:60-70 (fp32 division: correctly rounded on the device too; q2 == tp or no q2)
-BRC_HD EvTerms piece_terms_inlane(uint32_t fl, uint32_t tp_flags, uint32_t w3, int qpos) {
+// reference's expressions, BasicStat.cpp:60-70, with both sides of the second quotient doubled — |(qpos - left) - clipped/2| /
+// (clipped/2) = |2 (qpos - left) - clipped| / clipped as real numbers, so the correctly rounded quotients are the same float —
+// which makes every operand a small integer (q2 == tp or no q2; l_qseq, left, tp <= 255 and 0 < clipped <= l_qseq: make_piece)
+BRC_HD EvTerms piece_terms_inlane(uint32_t fl, uint32_t tp_flags, uint32_t w3, uint32_t qpos) {
     EvTerms t;
-    const int tp = (int)(tp_flags & 0xffu), left = (int)((tp_flags >> 16) & 0xffu);
-    const float Lf = (float)((tp_flags >> 8) & 0xffu), center = (float)(w3 >> 16) * 0.5f;
-    t.s3p = (float)BRC_ABSDIFF(qpos, tp) / Lf;
+    const uint32_t tp = tp_flags & 0xffu, left = (tp_flags >> 16) & 0xffu, cl = w3 >> 16;
+    t.s3p = div_small((float)absdiff_vs(qpos, tp), (float)((tp_flags >> 8) & 0xffu));
     t.q2 = (fl & PF_Q2OK) ? t.s3p : 0.0f;
-    float d = (float)(qpos - left) - center;
-    d = d < 0.0f ? -d : d;
-    t.sev = 1.0 - (double)(d / center);
+    t.sev = 1.0 - (double)div_small((float)absdiff_vs(2u * qpos, 2u * left + cl), (float)cl);     // |2 (qpos - left) - cl|
     return t;
 }
 // ... and from the quotient tables (PF_TABLE): one float look-up serves both distances (q2 == tp or no q2)

@@ -98,7 +98,15 @@ __device__ __forceinline__ int lane_shl1(int v) { return __builtin_amdgcn_update
 // REFCODE_PAD bytes of padding (code 15) on both sides: an 8-byte window may start before / end after the slice.
 enum { REFCODE_PAD = 16 };
 // (launched once when an engine is created: the code object is loaded then, not inside the first region)
-__global__ void k_warm() {}
+// First launch of an engine (loads the code object) and the proof obligation of div_small (brc_core.h): every quotient of the
+// domain against the compiler's correctly rounded division, bit for bit, on THIS device.
+__global__ void k_divcheck(uint32_t* __restrict__ bad) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = i / DIV_SMALL_M, m = i % DIV_SMALL_M;
+    if (n >= DIV_SMALL_N || m == 0u) return;
+    const float q = div_small((float)n, (float)m), want = (float)n / (float)m;
+    if (__float_as_uint(q) != __float_as_uint(want)) atomicAdd(bad, 1u);
+}
 __global__ __launch_bounds__(256) void k_refcode(const char* __restrict__ ref, uint8_t* __restrict__ code, int64_t n) {
     // 16 codes per thread; `code` (padded buffer) is 16-byte aligned and REFCODE_PAD == 16, so chunk i of the output
     // holds the codes of ref[16 i - 16 .. 16 i)
@@ -1071,7 +1079,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                    common path); q2 == tp, or no Q2 position (every reverse read without a Q2 run): then +0.0f, the identity  \
                    on these sums — the flag bit spread over a scalar register masks the look-up */                        \
                 float tq2 = __uint_as_float(__float_as_uint(S.t) & (uint32_t)((int32_t)(R.f[3] << 6) >> 31));           \
-                if (__builtin_expect((fl & PF_TABLE) == 0u, 0)) {      /* every unusual piece (make_piece) */                 \
+                if (__builtin_expect((fl & PF_TABLE) == 0u, 0) && m_p != 0ull) {   /* every unusual piece (make_piece) with an event in this tile */ \
                     if (fl & PF_NB) m_b = 0ull;            /* :343 with -i: counted in the depth, in no bucket */            \
                     else {                                                                                                \
                         if (fl & PF_WIDE) {                                                                               \
@@ -1097,7 +1105,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                         if ((fl & (PF_TABQ | PF_HUGE)) == PF_TABQ) {   /* soft-clipped: only the event location differs, and it needs no rare record */ \
                             S.sev = tabq_sev((int)((uint32_t)BRC_LANE() + (uint32_t)S.s_c), piece_left_field(R.f[3]), R.f[6] >> 16); \
                         } else if (fl & PF_DIV) {      /* another read length: the terms divided out in the lane, from the record itself */ \
-                            const EvTerms t = piece_terms_inlane(fl, R.f[3], R.f[6], (int)((uint32_t)BRC_LANE() + (uint32_t)S.s_c)); \
+                            const EvTerms t = piece_terms_inlane(fl, R.f[3], R.f[6], (uint32_t)BRC_LANE() + (uint32_t)S.s_c); \
                             S.t = t.s3p; tq2 = t.q2; S.sev = t.sev;                                                       \
                         } else if (!(fl & PF_TABQ)) {                                                                     \
                             PieceRare H; BRC_LD_DIV(H, R, m)                                                              \
@@ -1562,8 +1570,16 @@ class HipBackend : public Backend {
         { const int rc0 = ensure_evsets(1); if (rc0) return rc0; }
         HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&stream3, hipStreamNonBlocking));
-        hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, stream);
-        HIPCHK(hipStreamSynchronize(stream));
+        {
+            uint32_t* d_bad = nullptr; uint32_t bad = 0;
+            HIPCHK(hipMalloc(&d_bad, sizeof(uint32_t)));
+            HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(uint32_t), stream));
+            hipLaunchKernelGGL(k_divcheck, dim3((DIV_SMALL_N * DIV_SMALL_M + 255) / 256), dim3(256), 0, stream, d_bad);
+            HIPCHK(hipMemcpyAsync(&bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            (void)hipFree(d_bad);
+            if (bad) { err = "this device's reciprocal does not give correctly rounded small-integer quotients (div_small self-check failed)"; return BRC_E_HIP; }
+        }
         for (int i = 0; i < 2; ++i) { HIPCHK(hipEventCreateWithFlags(&ev_text[i], hipEventDisableTiming)); h_text[i].A = &kPinned; h_toff[i].A = &kPinned; }
         HIPCHK(hipEventCreateWithFlags(&ev_lines, hipEventDisableTiming));
         h_total.A = &kPinned;

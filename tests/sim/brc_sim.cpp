@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <string>
+#include <map>
 #include <vector>
 
 #include "../../bam_readcount_amd/csrc/brc_host.h"
@@ -54,6 +55,7 @@ class SimBackend : public Backend {
         return BRC_OK;
     }
 
+    bool stats_on = false; uint64_t stat_steps = 0, stat_dead = 0;      // BRC_SIM_PIECE_STATS: piece-steps, and those whose piece does not touch the tile
     uint32_t tile_want = 0u | (63u << 8);     // brc_region_windows: the lanes of the current tile that a window asks for
     // one (tile, library) wave of KB
     void pileup_tile(const Planes& pl, int lib, int64_t tl, uint32_t lo, uint32_t hi) {
@@ -76,6 +78,7 @@ class SimBackend : public Backend {
                 const Piece& h = hot[m];
                 const uint32_t fl = piece_flags(h);
                 QEnt full, ints; full.piece = ints.piece = m; full.kind = 0; ints.kind = 1; bool any_full = false, any_int = false;
+                if (stats_on) { const int64_t t0 = c.pos0 + tl * TILE; ++stat_steps; if (!((int64_t)h.rs < t0 + TILE && (int64_t)h.rs + h.ext > t0)) ++stat_dead; }
                 for (int l = 0; l < TILE; ++l) {
                     full.lane[l] = ints.lane[l] = false;
                     if (!valid[l]) continue;
@@ -164,6 +167,12 @@ class SimBackend : public Backend {
             });
             if (cnt != st->piece_cnt.p[i]) { err = "piece count of the host and of K1 differ"; return BRC_E_ARG; }
         }
+        stats_on = getenv("BRC_SIM_PIECE_STATS") != nullptr; stat_steps = stat_dead = 0;
+        if (getenv("BRC_SIM_PIECE_STATS")) {      // (diagnostics: how many pieces of each flag combination a data set produces)
+            std::map<uint32_t, uint64_t> hist;
+            for (int64_t m = 0; m < np; ++m) hist[piece_flags(hot[(size_t)m])]++;
+            for (const auto& kv : hist) fprintf(stderr, "piece flags 0x%03x: %llu (%.2f %%)\n", kv.first, (unsigned long long)kv.second, 100.0 * (double)kv.second / (double)np);
+        }
         ncol.assign((size_t)(Lp * PS), 0); depth.assign((size_t)(Lp * PS), 0); slotid.assign((size_t)(Lp * PS), 0xdeadbeefu);
         si.assign((size_t)(Lp * 2 * NI * PS), 0xdeadbeefu); sf.assign((size_t)(Lp * 2 * NF * PS), -1.0f);   // KB must write every plane element
         const char* xc = getenv("BRC_XEV_CAP");                                                            // (test knob: a tiny list exercises the grow-and-recompute path)
@@ -244,6 +253,8 @@ class SimBackend : public Backend {
             }
             for (uint32_t j = 0; j < run; ++j) if (tmp[j].len != 0) iout.push_back(tmp[j]);
         }
+        if (stats_on) fprintf(stderr, "piece-steps %llu, of them %llu (%.2f %%) of a piece that does not touch the tile; %.1f events per step\n", (unsigned long long)stat_steps,
+                              (unsigned long long)stat_dead, 100.0 * (double)stat_dead / (double)(stat_steps ? stat_steps : 1), (double)n_events / (double)(stat_steps ? stat_steps : 1));
         return BRC_OK;
     }
     // "download": like the HIP backend, the host view is a copy — upload / compute of the next region may run while the

@@ -43,6 +43,12 @@ def main():
     libs = [(os.path.basename(p).replace("libbrc_hip", "").replace(".so", "").strip("_") or "default", capi.Library(os.path.abspath(p))) for p in args.libs]
     for shape in args.shapes.split(","):
         config = {"tumor": "tumor200x", "mixed": "wgs30x_mixed"}.get(shape, "wgs30x")
+        # "wgs_notable": config 3 with the quotient tables switched off (BRC_NO_TABLE, read at upload): every piece takes the
+        # path of a read of another length — what that path costs per piece, measured directly
+        if shape.endswith("_notable"):
+            os.environ["BRC_NO_TABLE"] = "1"
+        else:
+            os.environ.pop("BRC_NO_TABLE", None)
         per_lib = config == "tumor200x"
         names = ["lib%d" % i for i in range(synthgen.CONFIGS[config]["n_libs"])] if per_lib else ()
         opts = dict(min_mapq=20, min_bq=13) if not per_lib else dict(min_mapq=0, min_bq=0, per_lib=True, insertion_centric=True)
