@@ -487,7 +487,7 @@ struct alignas(16) Piece {
     float snm;             // NM / (float)clipped_length, 0 when NM is missing
     uint32_t ww;           // per-lane (not per-bucket) warning counters: SM-missing | NM-missing << 16 (process_read warnings, BasicStat.cpp:85,100)
     int32_t a;             // rs - query offset: the lane on position p sees query base p - a
-    uint64_t bq_off;       // first element of the read's row in the event-word stream
+    uint64_t bq_off;       // first element of the read's row in the event-byte stream
 };
 // What only the rare paths need, 32 bytes: the exact-division constants of pieces whose event terms are divided out (no
 // PF_TABLE) and the raw integers of pieces whose packed addends left them out (PF_HUGE), and of any piece that leaves a

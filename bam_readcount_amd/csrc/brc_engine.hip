@@ -3,8 +3,8 @@
 // Kernels (per region; the main pipeline on one engine-owned stream, the indel side path on a second one, the download of
 // device-written text on a third; see DESIGN.md for layouts and rooflines):
 //   k_refcode       reference characters -> 4-bit codes
-//   k_annotate_groups  K1: fetch_func's Zm integers per read (8 bases per lane, byte-parallel), the event-word stream
-//                   (quality << 8 | bucket per base) and the read's PIECES (walk_pieces): 48-B records (+ a 32-B rare record for the few that need one) in
+//   k_annotate_groups  K1: fetch_func's Zm integers per read (8 bases per lane, byte-parallel), the event-BYTE stream
+//                   (quality << 2 | base index per base; brc_core.h: eb_make — plus the sparse wide stream for escapes) and the read's PIECES (walk_pieces): 48-B records (+ a 32-B rare record for the few that need one) in
 //                   library-major slots; also writes each read's indel events to its slots of the raw event list and counts
 //                   them per (16 positions, library) bucket
 //   k_unavail       -p only: first library-less read of every column (those positions are abandoned, :281-284)
@@ -13,7 +13,7 @@
 //                   pass over the pieces — piece r owns the tiles whose lo is r and those whose hi is r + 1
 //   k_scan_*        3-phase exclusive sum of the indel-event counts (per-bucket offsets), of the text line lengths
 //   k_pileup2       THE hot kernel: one wave per (tile, library), lane == reference position, wave-uniform walk over the
-//                   tile's pieces in column order: piece records by scalar loads, event-word windows staged into LDS by
+//                   tile's pieces in column order: piece records by scalar loads, event-byte windows staged into LDS by
 //                   direct-to-LDS loads, three packed integer accumulators + 4 order-preserving fp32 sums per bucket,
 //                   coalesced 256-B plane stores.  Integer/byte work, HBM-bound: no MFMA by design.
 //   k_xev_compact   the 1024 third-allele sub-lists (one atomic cursor each) -> one list
@@ -167,7 +167,7 @@ __device__ __forceinline__ uint32_t nzb7(uint32_t x) { return x + 0x7f7f7f7fu; }
 #else
 #define BRC_ANN_OCC
 #endif
-template <bool one_stream>     // the event-word rows and the pieces of consecutive reads are consecutive in memory (no per-library layout)
+template <bool one_stream>     // the event-byte rows and the pieces of consecutive reads are consecutive in memory (no per-library layout)
 __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, DevIn in, DRead* __restrict__ reads, const uint32_t* __restrict__ piece_off,
                                                          Piece* __restrict__ pieces, PieceRare* __restrict__ rare, int2* __restrict__ keyreach,
                                                          uint8_t* __restrict__ eb, uint16_t* __restrict__ bqw, IndelEv* __restrict__ ev_raw, uint32_t* __restrict__ bucket_cnt,
@@ -850,15 +850,15 @@ struct PRec { u32x8 f; u32x2 g; };
 //    scalar register sets — everything wave-uniform (positions, lengths, packed addends) lives in SGPRs.  The loads are
 //    inline assembly so that they are issued exactly there (the scheduler sinks compiler-visible loads to their first use);
 //    the matching s_waitcnt names the registers, which orders every use behind it;
-//  * event words: the 72-element window of each piece's row that this tile can touch is copied by ONE direct-to-LDS
-//    instruction per half-batch (global_load_lds_dwordx4: lane = row * 9 + chunk, no VGPR round trip) into a two-half
+//  * event bytes: the 80-byte window of each piece's row that this tile can touch is copied by ONE direct-to-LDS
+//    instruction per half-batch of 12 pieces (global_load_lds_dwordx4: lane = row * 5 + chunk, no VGPR round trip) into a two-half
 //    ring; the copy of half-batch h + 2 is issued when h is done, its addresses come from a 16-byte load of the pieces' {ww, a, bq_off} words
 //    issued one half-batch earlier;
-//  * one pipeline step = probe of piece j + 1 (coverage ballots, event word and table look-ups: LDS reads only) and
+//  * one pipeline step = probe of piece j + 1 (coverage ballots, event byte and table look-ups: LDS reads only) and
 //    accumulate of piece j (quality / bucket ballots, one exec region with the 10 adds of the dominant bucket, a usually
 //    skipped one for everything else); lane conditions are 64-bit masks in scalar registers;
 //  * per bucket a lane holds three PACKED integer registers (three 10-bit counters; mapq | sse; zm | clipped), the sum of
-//    its event words (= 256 x base-quality sum + count x bucket) and the four fp32 sums; the integers are flushed to the
+//    its event bytes (= 4 x base-quality sum + count x base index) and the four fp32 sums; the integers are flushed to the
 //    planes every K pieces (K = 127 for short reads) and at the end of the tile;
 //  * third alleles (a lane keeps its reference base and the first other base in registers) and PF_HUGE integers are
 //    queued and drained into the planes between half-batches, in piece order.
@@ -1173,7 +1173,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
             wsm_tot += wave_sum_u32(valid ? (a.ww & 0xffffu) : 0u); wnm_tot += wave_sum_u32(valid ? (a.ww >> 16) : 0u); a.ww = 0u; \
             flushed = true; since_flush = 0;                                                                              \
         }
-        // between half-batches: drain the queue (the event words of this half-batch are still staged in ring half hoff),
+        // between half-batches: drain the queue (the event bytes of this half-batch are still staged in ring half hoff),
         // flush when the packed fields could overflow during the next half-batch, then reuse the ring half just processed
         // (every LDS read of it has returned after the lgkmcnt wait): copy half-batch base + 2 HALF into it and request
         // the addresses of the one after
@@ -1667,7 +1667,7 @@ class HipBackend : public Backend {
         in.seq_off = (const uint64_t*)d_so.p; in.qual_off = (const uint64_t*)d_qo.p; in.nm = (const int32_t*)d_nm.p; in.sm = (const int32_t*)d_sm.p;
         in.tags = (const uint8_t*)d_tags.p; in.cigar = (const uint32_t*)d_cigar.p; in.seq4 = (const uint8_t*)d_seq.p; in.qual = (const uint8_t*)d_qual.p;
         in.ref = (const char*)d_ref.p;
-        // event-word stream, padded on both sides: a staged window starts up to 71 elements before / ends after a row
+        // event-byte stream, padded on both sides: a staged window starts up to 79 elements before / ends after a row
         // (the wide stream — full words of the few 8-base groups with an escape byte — is indexed like the bytes; it is
         // allocated whole and touched only where K1 writes such a group)
         enum { BQ_PAD = 128 };

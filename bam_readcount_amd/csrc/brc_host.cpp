@@ -140,7 +140,7 @@ void Staged::layout_pieces(int Lp, bool per_lib) {
         if (!piece_cnt.p[i]) { piece_off.p[i] = 0; continue; }
         piece_off.p[i] = (uint32_t)cur[(size_t)l]; cur[(size_t)l] += piece_cnt.p[i];
     }
-    // event-word rows, library-major as well: the pieces a (tile, library) wave stages one after the other then lie one
+    // event-byte rows, library-major as well: the pieces a (tile, library) wave stages one after the other then lie one
     // after the other in the stream (reads without a library, which have no pieces, go last).  Without -p this is the
     // file order brc_push_reads already assigned.
     if (per_lib && Lp > 1) {

@@ -177,6 +177,10 @@ const char* brc_last_error(const brc_engine*);
 const char* brc_kernel_name(int k);     /* name of timing slot k, NULL if unused */
 const char* brc_engine_kind(void);      /* "hip-gfx950" for the product library, "oracle-c" for oracle/ */
 
+/* brc_create: BRC_E_NODEVICE without a HIP device (there is no CPU fallback).  The HIP engine's first launch is a self-check of the
+ * one place where it leans on an approximate instruction — the small-integer quotients of reads of another length than the region's
+ * modal one (hardware reciprocal + multiply + two FMAs, brc_core.h: div_small) are compared with IEEE division over their whole
+ * domain, bit for bit; a device that disagrees anywhere is refused with BRC_E_HIP instead of being trusted. */
 int  brc_create(const brc_config* cfg, brc_engine** out);
 void brc_destroy(brc_engine*);
 

@@ -109,7 +109,7 @@ class SimBackend : public Backend {
                 if (any_int) queue.push_back(ints);
             }
             since_flush += (int)nb;
-            // between half-batches: drain the queue (the event words of this half-batch are still staged), flush when the
+            // between half-batches: drain the queue (the event bytes of this half-batch are still staged), flush when the
             // packed fields could overflow during the next half-batch
             for (const QEnt& e : queue) {
                 const Piece& h = hot[e.piece]; const PieceRare rr = rare_of(e.piece);
