@@ -715,21 +715,27 @@ BRC_HD void pack_unpack(const PackAcc& a, uint32_t b, uint32_t* v) {
 }
 
 // K (pieces between two flushes of a lane's packed integers) and the per-read limit of a 16-bit field: clipped_length of
-// every read must fit, so long reads get a small K
+// every read must fit, so long reads get a small K.  A flush can only happen BETWEEN half-batches (HALF pieces), so up to
+// max(K, HALF) pieces are summed into a field before it is emptied: the limit follows that count, not K — with K < HALF (reads of
+// more than 65535 / HALF = 5461 bases in the batch) a piece whose clipped length, mismatch-quality sum or single-ended mapping quality
+// exceeds it takes the PF_HUGE path (make_piece), and the lanes flush at every boundary.  (Until round 4's end the limit was 65535 / K:
+// twelve 20-kb reads in one half-batch overflowed the 16-bit sums — no test had a read longer than 900 bases;
+// tests/test_gpu_parity.py::test_hip_long_reads.)
 // (the overrides are test knobs: a small K exercises the flushes, a small limit the PF_HUGE path)
+#ifndef BRC_HALF
+#define BRC_HALF 12
+#endif
+enum { HALF = BRC_HALF };
 BRC_HD void choose_pack(int32_t max_lqseq, int32_t k_override, int32_t lim_override, int32_t& K, uint32_t& lim) {
     int32_t m = max_lqseq < 255 ? 255 : max_lqseq;
     K = 65535 / m; if (K > 127) K = 127; if (K < 1) K = 1;
     if (k_override > 0 && k_override < K) K = k_override;
-    lim = 65535u / (uint32_t)K;
+    lim = 65535u / (uint32_t)(K > (int32_t)HALF ? K : (int32_t)HALF);
     if (lim_override >= 255 && (uint32_t)lim_override < lim) lim = (uint32_t)lim_override;    // >= 255: a mapping quality always fits
 }
 
 // Per-lane state of KB v2.
-#ifndef BRC_HALF
-#define BRC_HALF 12
-#endif
-enum { HALF = BRC_HALF };   // pieces per staging half-batch (12 rows x 5 chunks of 16 event bytes = 60 lanes of one direct-to-LDS instruction; a multiple of 3,
+// (HALF, defined above choose_pack:) pieces per staging half-batch (12 rows x 5 chunks of 16 event bytes = 60 lanes of one direct-to-LDS instruction; a multiple of 3,
                             // the rotation period of the piece-record registers); queue drains and flushes happen between half-batches
 struct LaneAcc2 {
     PackAcc dom, alt;

@@ -481,3 +481,46 @@ def test_hip_table_piece_flag_combinations(dev_lib, oracle_lib, monkeypatch, env
     parity.compare_libs(dev_lib, oracle_lib, arrs, [(0, 4000)], ref=ref, min_mapq=10, min_bq=12)
     deep = synth.make_batch(413, ref, 2500, read_len=(100, 100), style="mixed", region=(1500, 1900), mismatch=0.03)        # ~600x of one length
     parity.compare_libs(dev_lib, oracle_lib, deep, [(1400, 2100)], ref=ref, insertion_centric=True)
+
+
+@pytest.mark.parametrize("offset", [1_073_000_000, 2_147_000_000], ids=["above_2^30", "end_of_int32"])
+def test_hip_coordinates_up_to_the_end_of_int32(dev_lib, oracle_lib, offset):
+    """The same reads at the far end of the longest contig the formats allow (positions are int32 in BAM and in the reference's
+    pileup_data_t, bamreadcount.cpp:52-66): every position-derived quantity of the device path — tile starts, the lanes of a tile
+    past the region (a bias of 2^31 on their coordinate), slice offsets into the reference, indel keys — must behave at 2.147 G as
+    it does near 0.  Mixed read lengths and indels: tables, in-lane division and the indel side path all run."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import synthgen
+    n = 60_000
+    small, arrs = synthgen.generate(n, "wgs30x_mixed", seed=11)
+    L = min(offset + n, 2**31 - 1)
+    ref = np.full(L, ord("N"), np.uint8); ref[offset:] = small[:L - offset]
+    moved = dict(arrs); moved["pos"] = (np.asarray(arrs["pos"]).astype(np.int64) + offset).astype(np.int32)
+    moved = capi.select_reads(moved, np.nonzero(capi.read_ends(moved).astype(np.int64) <= L)[0])
+    near = capi.select_reads(arrs, np.nonzero(capi.read_ends(arrs).astype(np.int64) <= L - offset)[0])
+    regions = [(offset + 100, L - 1), (offset + 5_000, offset + 5_001), (L - 300, L)]
+    text_far, res_far = parity.compare_libs(dev_lib, oracle_lib, moved, regions, ref=ref, min_mapq=20, min_bq=13)
+    # ... and the far result is the near one moved: same counts, same statistics, coordinates aside
+    text_near, res_near = parity.compare_libs(dev_lib, oracle_lib, near, [(a - offset, b - offset) for a, b in regions], ref=small[:L - offset], min_mapq=20, min_bq=13)
+    assert sum(r.n_events for r in res_far) == sum(r.n_events for r in res_near) > 1_000_000
+    far_lines, near_lines = text_far.decode().splitlines(), text_near.decode().splitlines()
+    assert len(far_lines) == len(near_lines)
+    for a, b in zip(far_lines[::97], near_lines[::97]):
+        fa, fb = a.split("\t"), b.split("\t")
+        assert int(fa[1]) - offset == int(fb[1]) and fa[2:] == fb[2:]
+
+
+@pytest.mark.parametrize("style,read_len,n", [("simple", (5400, 5600), 160), ("wild", (3000, 20000), 120), ("mixed", (100, 7000), 500)],
+                         ids=["around_the_16_bit_limit", "20_kb_reads", "short_and_long_mixed"])
+def test_hip_long_reads(dev_lib, oracle_lib, style, read_len, n):
+    """Reads of thousands of bases (PacBio / ONT alignments): a lane's packed 16-bit sums (clipped length, mismatch-quality sum,
+    single-ended mapping quality) are emptied between half-batches of twelve pieces only, so whatever does not fit twelve times
+    must take the PF_HUGE path (brc_core.h: choose_pack).  Until the end of round 4 the limit followed K instead: with reads above
+    5461 bases the sums of a half-batch overflowed into their neighbours — found by exactly this comparison."""
+    rng = np.random.default_rng(3)
+    ref = synth.make_ref(rng, 80_000)
+    arrs = synth.make_batch(5, ref, n, read_len=read_len, style=style, region=(0, 60_000))
+    for kw in (dict(min_mapq=0, min_bq=0), dict(min_mapq=20, min_bq=13, insertion_centric=True)):
+        _, res = parity.compare_libs(dev_lib, oracle_lib, arrs, [(1000, 75_000)], ref=ref, **kw)
+        assert sum(r.n_events for r in res) > 200_000

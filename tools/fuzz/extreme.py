@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Differential fuzz at the EDGES of the parameter space (test infrastructure): the product's device functions (CPU lane simulator by
+default, or the HIP library with --hip on a GPU box) against the C oracle on scenarios the suite's families do not reach — reads
+of tens of kilobases, piles thousands deep at one position, a dozen libraries, base-quality and mapping-quality thresholds at
+and beyond their ranges, tiny -d.  Planes, indel buckets, warning counters and text must be identical.
+
+    python tools/fuzz/extreme.py [--first 0] [--count 200] [--hip]
+
+Found with it: the 16-bit packed sums overflowing on reads above 5461 bases (brc_core.h: choose_pack)."""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from bam_readcount_amd import capi
+import parity
+import synth
+
+
+def scenario(seed):
+    rng = np.random.default_rng(seed)
+    kind = str(rng.choice(["long", "deep", "libs", "thresholds", "tiny", "mixed_len", "dense_indel"]))
+    RL = int(rng.integers(2_000, 40_000)) if kind == "long" else int(rng.integers(300, 4_000))
+    n_libs = int(rng.integers(4, 13)) if kind == "libs" else int(rng.choice([1, 1, 2, 4]))
+    style = str(rng.choice(["simple", "indel", "wild", "mixed", "clip"] if kind != "dense_indel" else ["wild", "indel"]))
+    if kind == "long":
+        hi = int(rng.choice([6_000, 12_000, 30_000])); read_len = (int(rng.integers(50, hi)), hi); n_reads = int(rng.integers(20, 200))
+    elif kind == "deep":
+        read_len = (int(rng.integers(20, 100)), int(rng.integers(100, 300))); n_reads = int(rng.integers(4_000, 15_000)); RL = int(rng.integers(150, 600))
+    elif kind == "tiny":
+        read_len = (1, int(rng.integers(1, 12))); n_reads = int(rng.integers(50, 3_000))
+    elif kind == "mixed_len":
+        read_len = (int(rng.integers(1, 60)), int(rng.choice([255, 256, 257, 511, 512, 513, 700]))); n_reads = int(rng.integers(300, 3_000))
+    else:
+        read_len = (20, int(rng.integers(40, 400))); n_reads = int(rng.integers(100, 2_500))
+    ref = synth.make_ref(rng, RL + read_len[1] + 200, weird=float(rng.choice([0, 0, 0.02, 0.2])))
+    arrs = synth.make_batch(seed + 77, ref, n_reads, style=style, n_libs=n_libs, p_nolib=float(rng.choice([0, 0, 0.05, 0.5])), read_len=read_len,
+                            region=(0, RL), mismatch=float(rng.choice([0.0, 0.02, 0.02, 0.3, 0.9])), p_q2tail=float(rng.choice([0.0, 0.3, 0.9])),
+                            p_nonm=float(rng.choice([0.0, 0.1, 1.0])), p_sm=float(rng.choice([0.0, 0.5, 1.0])), p_flagdrop=float(rng.choice([0.0, 0.02, 0.4])))
+    if rng.random() < 0.4:
+        arrs = synth.pile_indels(arrs, int(rng.integers(10, max(RL - 10, 11))), seed=seed, frac=float(rng.choice([0.2, 0.9])))
+    regions = []
+    for _ in range(int(rng.integers(1, 5))):
+        a = int(rng.integers(0, RL)); b = a + int(rng.choice([0, 1, 2, 63, 64, 65, 200, RL]))
+        regions.append((a, min(b, RL + 100)))
+    kw = dict(min_mapq=int(rng.choice([0, 0, 1, 20, 60, 254, 255, 256])), min_bq=int(rng.choice([0, 0, 1, 2, 3, 13, 40, 62, 63, 64, 93, 255, 300])),
+              insertion_centric=bool(rng.random() < 0.4))
+    if rng.random() < 0.25:
+        kw["max_cnt"] = int(rng.choice([1, 2, 5, 50, 1000]))
+    if rng.random() < 0.5:
+        kw.update(per_lib=True, lib_names=["lib%d" % i for i in range(n_libs)])
+    return kind, style, ref, arrs, regions, kw, bool(rng.random() < 0.5)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--first", type=int, default=0); ap.add_argument("--count", type=int, default=200); ap.add_argument("--hip", action="store_true")
+    a = ap.parse_args()
+    dev = capi.load_product() if a.hip else capi.Library(os.path.join(ROOT, "tests", "sim", "libbrc_sim.so"))
+    oracle = capi.Library(os.path.join(ROOT, "oracle", "libbrc_oracle.so"))
+    bad = 0; t0 = time.time(); ev = 0
+    for seed in range(a.first, a.first + a.count):
+        kind, style, ref, arrs, regions, kw, clear = scenario(seed)
+        try:
+            check_warn = not (kw.get("per_lib") and any(int(l) < 0 for l in arrs["lib"]))
+            _, res = parity.compare_libs(dev, oracle, arrs, regions, ref=ref, clear_queue=clear, check_warn=check_warn, **kw)
+            ev += sum(r.n_events for r in res)
+            for route in (dict(text_only=True), dict(device_text="chrS")):
+                want, _ = parity.run_engine(oracle, arrs, regions, ref=ref, clear_queue=clear, **kw)
+                got, _ = parity.run_engine(dev, arrs, regions, ref=ref, clear_queue=clear, **route, **kw)
+                assert got == want, "text differs (route %r)" % (route,)
+        except Exception as ex:                                   # noqa: BLE001 — every failure is reported, the run goes on
+            bad += 1
+            print("FAIL seed %d kind %s style %s kw %r regions %r: %s: %s" % (seed, kind, style, {k: v for k, v in kw.items() if k != "lib_names"}, regions, type(ex).__name__, str(ex)[:300].replace("\n", " ")), flush=True)
+    print("extreme fuzz: %d scenarios from seed %d, %d events, %d failures, %.1f s" % (a.count, a.first, ev, bad, time.time() - t0), flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
