@@ -20,11 +20,74 @@ import parity
 import synth
 
 
+def spliced_cigar(rng, L, style):
+    """RNA-seq-like and structural-variant-like alignments: introns (N) of 50 bases to 100 kb, deletions and insertions of tens to
+    hundreds of bases, soft clips of up to half the read, hard clips"""
+    if L < 12:
+        return [(0, L)]
+    ops = []; rem = L
+    if rng.random() < 0.2:
+        ops.append((5, int(rng.integers(1, 200))))
+    if rng.random() < 0.3:
+        c = int(rng.integers(1, max(2, rem // 2))); ops.append((4, c)); rem -= c
+    tail = 0
+    if rng.random() < 0.3 and rem > 8:
+        tail = int(rng.integers(1, max(2, rem // 2))); rem -= tail
+    nseg = int(rng.integers(1, 5))
+    while True:
+        if nseg <= 1 or rem < 4:
+            ops.append((0, rem)); rem = 0
+            break
+        m = int(rng.integers(1, rem - 1)); ops.append((0, m)); rem -= m
+        r = rng.random()
+        if r < 0.5:
+            ops.append((3, int(np.exp(rng.uniform(np.log(50), np.log(100_000))))))
+        elif r < 0.75:
+            ops.append((2, int(rng.integers(20, 600))))
+        elif rem > 3:
+            k = int(rng.integers(1, min(120, rem - 1))); ops.append((1, k)); rem -= k
+        nseg -= 1
+    if ops[-1][0] != 0:
+        ops.append((0, 1))
+        for i, (o, l) in enumerate(ops[:-1]):
+            if o == 0 and l > 1:
+                ops[i] = (o, l - 1); break
+        else:
+            ops.pop()
+    if tail:
+        ops.append((4, tail))
+    out = []
+    for o, l in ops:
+        if out and out[-1][0] == o:
+            out[-1] = (o, out[-1][1] + l)
+        else:
+            out.append((o, l))
+    assert sum(l for o, l in out if o in (0, 1, 4)) == L, out
+    return out
+
+
 def scenario(seed):
     rng = np.random.default_rng(seed)
-    kind = str(rng.choice(["long", "deep", "libs", "thresholds", "tiny", "mixed_len", "dense_indel"]))
+    kind = str(rng.choice(["long", "deep", "libs", "thresholds", "tiny", "mixed_len", "dense_indel", "spliced", "spliced"]))
+    if kind == "spliced":
+        RL = int(rng.integers(150_000, 400_000))
+        ref = synth.make_ref(rng, RL + 450_000, weird=float(rng.choice([0, 0.02])))
+        n_libs = int(rng.choice([1, 2, 4])); read_len = (int(rng.integers(12, 100)), int(rng.choice([100, 150, 250, 600])))
+        saved = synth.random_cigar; synth.random_cigar = spliced_cigar
+        try:
+            arrs = synth.make_batch(seed + 77, ref, int(rng.integers(200, 2_500)), style="indel", n_libs=n_libs, read_len=read_len, region=(0, RL),
+                                    p_nolib=float(rng.choice([0, 0.05])), mismatch=float(rng.choice([0.0, 0.02, 0.3])))
+        finally:
+            synth.random_cigar = saved
+        regions = []
+        for _ in range(int(rng.integers(1, 4))):
+            a = int(rng.integers(0, RL)); regions.append((a, min(a + int(rng.choice([1, 64, 5_000, 120_000, RL])), RL + 400_000)))
+        kw = dict(min_mapq=int(rng.choice([0, 20])), min_bq=int(rng.choice([0, 13])), insertion_centric=bool(rng.random() < 0.4))
+        if rng.random() < 0.5:
+            kw.update(per_lib=True, lib_names=["lib%d" % i for i in range(n_libs)])
+        return kind, "spliced", ref, arrs, regions, kw, bool(rng.random() < 0.5)
     RL = int(rng.integers(2_000, 40_000)) if kind == "long" else int(rng.integers(300, 4_000))
-    n_libs = int(rng.integers(4, 13)) if kind == "libs" else int(rng.choice([1, 1, 2, 4]))
+    n_libs = int(rng.choice([5, 12, 64, 254])) if kind == "libs" else int(rng.choice([1, 1, 2, 4]))
     style = str(rng.choice(["simple", "indel", "wild", "mixed", "clip"] if kind != "dense_indel" else ["wild", "indel"]))
     if kind == "long":
         hi = int(rng.choice([6_000, 12_000, 30_000])); read_len = (int(rng.integers(50, hi)), hi); n_reads = int(rng.integers(20, 200))
