@@ -78,7 +78,8 @@ struct DevCfg {
     int32_t force_dom;      // test knob (BRC_FORCE_DOM): -1, or the bucket every lane treats as dominant (stresses the alternate / third-allele paths)
     int64_t n_pieces;       // pieces of all libraries (KB v2)
     int32_t flush_k;        // K: pieces a lane may accumulate in its packed integer registers between two flushes (1..127)
-    uint32_t pack_lim;      // 65535 / K: largest per-read value a 16-bit packed field can take (PF_HUGE above it)
+    uint32_t pack_lim;      // 65535 / max(K, HALF): largest per-read value a 16-bit packed field can take (PF_HUGE above it)
+    int32_t max_lqseq;      // longest read of the batch (k_pileup2: a staged window further from its row than that belongs to a piece that only SPANS the tile)
 };
 
 // Region inputs exactly as brc_read_batch lays them out (uploaded as-is; offsets rebased per region).

@@ -963,6 +963,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         // ---- staging: lane -> (row, chunk) of a half-batch
         const uint32_t srow = (uint32_t)lane / (uint32_t)WIN_U4, schunk = (uint32_t)lane % (uint32_t)WIN_U4;
         const bool slane = lane < HALF * WIN_U4;
+        const uint32_t win_span = (uint32_t)c.max_lqseq + 96u + 16u;          // legitimate window starts: -95 .. max_lqseq + 15 (rows are padded to 16)
         // {bq_off, a} of piece b0 + srow (clamped): what the window copy of that row needs
         // ... and, by the first lane of every row, one dword of its hot record: nothing uses the value — the load pulls the
         // record's cache line into L2 a half-batch before the scalar loads of the read loop ask for it (their own look-ahead
@@ -975,7 +976,11 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         {                                                                                                                 \
             if (slane && (b0) + srow < hi) {                                                                              \
                 const int64_t boff = (int64_t)(((uint64_t)T.w << 32) | T.z);                                              \
-                const int32_t ws = (p0 - (int32_t)T.y) & ~15;                                                             \
+                int32_t ws = (p0 - (int32_t)T.y) & ~15;                                                                   \
+                /* a piece that only SPANS the tile (an intron, a long deletion: ext >> len) or does not touch it at all has its  \
+                   window anywhere — 100 kb from its row, before the stream or past its end; no lane will read the copy: take    \
+                   the row's first bytes instead (round 4: a memory fault on spliced alignments, tools/fuzz/extreme.py) */      \
+                if ((uint32_t)(ws + 96) > win_span) ws = 0;                                                               \
                 const uint8_t* src = eb_ro + (boff + ws) + 16u * schunk;                                                  \
                 __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,                      \
                     (void __attribute__((address_space(3)))*)(rows_base + (hoff)), 16, 0, 0);                             \
@@ -1641,7 +1646,7 @@ class HipBackend : public Backend {
         g.PS = (g.P + 63) & ~(int64_t)63;
         c.beg0 = g.beg0; c.end = g.end; c.pos0 = g.pos0; c.P = g.P; c.PS = g.PS; c.ref_lo = g.ref_lo; c.ref_hi = g.ref_hi; c.ref_len = g.ref_len;
         c.n_reads = s.n; c.table_len = getenv("BRC_NO_TABLE") ? 0 : s.modal_len();
-        c.n_pieces = s.n_pieces; lib_base = s.lib_base;
+        c.n_pieces = s.n_pieces; lib_base = s.lib_base; c.max_lqseq = s.max_lqseq;
         c.ibucket_shift = indel_bucket_shift(s.n_indel_ops, c.P, c.Lp);
         if (const char* ib = getenv("BRC_IBUCKET_SHIFT")) { const int v = atoi(ib); if (v == 4 || v == 6) c.ibucket_shift = v; }   // (test knob: both supported sizes; anything else is ignored)
         // test knobs (tests/test_gpu_parity.py): small K -> flushes, small limit -> PF_HUGE, forced dominant bucket -> third alleles

@@ -524,3 +524,26 @@ def test_hip_long_reads(dev_lib, oracle_lib, style, read_len, n):
     for kw in (dict(min_mapq=0, min_bq=0), dict(min_mapq=20, min_bq=13, insertion_centric=True)):
         _, res = parity.compare_libs(dev_lib, oracle_lib, arrs, [(1000, 75_000)], ref=ref, **kw)
         assert sum(r.n_events for r in res) > 200_000
+
+
+@pytest.mark.parametrize("seed", [60030, 20040])
+def test_hip_spliced_and_structural_alignments(dev_lib, oracle_lib, seed):
+    """Introns of up to 100 kb (N), deletions and insertions of hundreds of bases, soft clips of half a read: a piece then SPANS
+    tiles it has no base in (ext >> len), and the window of its event bytes such a tile would stage lies 100 kb from the read's row —
+    before the stream or past its end.  k_pileup2 staged it anyway (nobody reads the copy) and faulted on the address; the
+    window now falls back to the row's first bytes (found by tools/fuzz/extreme.py on the GPU: the simulator has no staging)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz"))
+    import extreme
+    import zlib
+    rng = np.random.default_rng(seed)
+    while True:                      # (the first seed at or after `seed` whose scenario is of the spliced kind)
+        kind, style, ref, arrs, regions, kw, clear = extreme.scenario(seed)
+        if kind == "spliced":
+            break
+        seed += 1
+    check_warn = not (kw.get("per_lib") and any(int(l) < 0 for l in arrs["lib"]))
+    text, res = parity.compare_libs(dev_lib, oracle_lib, arrs, regions, ref=ref, clear_queue=clear, check_warn=check_warn, **kw)
+    assert sum(r.n_events for r in res) > 0
+    got, _ = parity.run_engine(dev_lib, arrs, regions, ref=ref, clear_queue=clear, device_text="chrS", **kw)
+    assert zlib.crc32(got) == zlib.crc32(text)

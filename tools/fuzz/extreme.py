@@ -120,13 +120,15 @@ def scenario(seed):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--first", type=int, default=0); ap.add_argument("--count", type=int, default=200); ap.add_argument("--hip", action="store_true")
+    ap.add_argument("--first", type=int, default=0); ap.add_argument("--count", type=int, default=200); ap.add_argument("--hip", action="store_true"); ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args()
     dev = capi.load_product() if a.hip else capi.Library(os.path.join(ROOT, "tests", "sim", "libbrc_sim.so"))
     oracle = capi.Library(os.path.join(ROOT, "oracle", "libbrc_oracle.so"))
     bad = 0; t0 = time.time(); ev = 0
     for seed in range(a.first, a.first + a.count):
         kind, style, ref, arrs, regions, kw, clear = scenario(seed)
+        if a.verbose:
+            print("seed %d kind %s style %s reads %d kw %r regions %r" % (seed, kind, style, len(arrs["pos"]), {k: v for k, v in kw.items() if k != "lib_names"}, regions), flush=True)
         try:
             check_warn = not (kw.get("per_lib") and any(int(l) < 0 for l in arrs["lib"]))
             _, res = parity.compare_libs(dev, oracle, arrs, regions, ref=ref, clear_queue=clear, check_warn=check_warn, **kw)
