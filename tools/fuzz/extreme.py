@@ -118,6 +118,46 @@ def scenario(seed):
     return kind, style, ref, arrs, regions, kw, bool(rng.random() < 0.5)
 
 
+def api_routes(dev, oracle, seed, ref, arrs, regions, kw):
+    """the first region of some size again through the other entry points: reads pushed in several batches, passes queued back to back
+    (brc_compute_n), windows of the resident result (brc_fetch_window) against slices of the whole, announced windows
+    (brc_region_windows) against the unhinted engine"""
+    rr = np.random.default_rng(seed + 5)
+    big = [r for r in regions if r[1] - r[0] >= 4]
+    if not big:
+        return
+    b0, e0 = big[0]
+    ends = capi.read_ends(arrs)
+    idx = capi.fetch_overlapping(arrs, ends, b0 - 1, e0)
+    sub = capi.select_reads(arrs, idx)
+    want, _ = parity.run_engine(oracle, sub, [(b0, e0)], ref=ref, **kw)
+    eng = capi.Engine(dev, **kw)
+    eng.begin_region(0, b0, e0, ref)
+    n = len(idx); cuts = sorted(set([0, n] + [int(x) for x in rr.integers(0, n + 1, int(rr.integers(0, 4)))]))
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        eng.push_reads(capi.select_reads(sub, np.arange(a, b)))
+    eng.upload(); eng.compute_n(int(rr.integers(1, 4)))
+    whole = eng.fetch_result(); whole_text = eng.format_region("chrS"); eng.clear_indel_queue()
+    assert whole_text == want, "reads pushed in %d batches: text differs from the oracle's" % (len(cuts) - 1)
+    wc = sorted(set([b0, e0] + [int(x) for x in rr.integers(b0, e0 + 1, 4)]))
+    joined = b""
+    for wi, (wa, wb) in enumerate(zip(wc[:-1], wc[1:])):
+        dev.lib.brc_set_option(eng.h, 6, 1 if wi else 0)          # BRC_OPT_CONTINUES_PREVIOUS
+        w = eng.fetch_window(wa, wb); joined += eng.format_region("chrS")
+        for x, y in zip(parity.slice_result(w, wa - 1, wb), parity.slice_result(whole, wa - 1, wb)):
+            assert (x == y) if isinstance(x, list) else np.array_equal(x, y), "fetch_window [%d,%d) differs from the whole result" % (wa, wb)
+    assert joined == whole_text, "windows formatted in order differ from the region's text"
+    dev.lib.brc_set_option(eng.h, 6, 0); eng.close()
+    wins = sorted((int(x), int(x) + int(rr.choice([1, 1, 2, 64, 70, 300]))) for x in rr.integers(b0, max(e0 - 1, b0 + 1), int(rr.integers(1, 9))))
+    wins = [(x, min(y, e0)) for x, y in wins if x < e0]
+    e1 = capi.Engine(dev, text_only=True, **kw); e2 = capi.Engine(dev, text_only=True, **kw)
+    e1.begin_region(0, b0, e0, ref); e1.push_reads(sub); e1.end_region()
+    e2.begin_region(0, b0, e0, ref); e2.push_reads(sub); e2.region_windows(np.array([w[0] for w in wins], np.int32), np.array([w[1] for w in wins], np.int32)); e2.end_region()
+    for wa, wb in wins:
+        assert e1.format_window("chrS", wa, wb, 0) == e2.format_window("chrS", wa, wb, 0), "announced window [%d,%d) differs" % (wa, wb)
+    e1.close(); e2.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--first", type=int, default=0); ap.add_argument("--count", type=int, default=200); ap.add_argument("--hip", action="store_true"); ap.add_argument("--verbose", action="store_true")
@@ -137,6 +177,7 @@ def main():
                 want, _ = parity.run_engine(oracle, arrs, regions, ref=ref, clear_queue=clear, **kw)
                 got, _ = parity.run_engine(dev, arrs, regions, ref=ref, clear_queue=clear, **route, **kw)
                 assert got == want, "text differs (route %r)" % (route,)
+            api_routes(dev, oracle, seed, ref, arrs, regions, kw)
         except Exception as ex:                                   # noqa: BLE001 — every failure is reported, the run goes on
             bad += 1
             print("FAIL seed %d kind %s style %s kw %r regions %r: %s: %s" % (seed, kind, style, {k: v for k, v in kw.items() if k != "lib_names"}, regions, type(ex).__name__, str(ex)[:300].replace("\n", " ")), flush=True)
