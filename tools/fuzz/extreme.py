@@ -4,7 +4,7 @@ default, or the HIP library with --hip on a GPU box) against the C oracle on sce
 of tens of kilobases, piles thousands deep at one position, a dozen libraries, base-quality and mapping-quality thresholds at
 and beyond their ranges, tiny -d.  Planes, indel buckets, warning counters and text must be identical.
 
-    python tools/fuzz/extreme.py [--first 0] [--count 200] [--hip]
+    python tools/fuzz/extreme.py [--first 0] [--count 200] [--hip] [--ref]
 
 Found with it: the 16-bit packed sums overflowing on reads above 5461 bases (brc_core.h: choose_pack)."""
 import argparse
@@ -161,9 +161,14 @@ def api_routes(dev, oracle, seed, ref, arrs, regions, kw):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--first", type=int, default=0); ap.add_argument("--count", type=int, default=200); ap.add_argument("--hip", action="store_true"); ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--ref", action="store_true", help="also: the oracle's text against the reference's own sources compiled over the htslib shim (oracle/_ref; skips the deep piles, its std::map per position is slow there)")
     a = ap.parse_args()
     dev = capi.load_product() if a.hip else capi.Library(os.path.join(ROOT, "tests", "sim", "libbrc_sim.so"))
     oracle = capi.Library(os.path.join(ROOT, "oracle", "libbrc_oracle.so"))
+    ref_lib = None
+    if a.ref:
+        from test_ref_compiled import REF_LIB
+        ref_lib = capi.Library(REF_LIB)
     bad = 0; t0 = time.time(); ev = 0
     for seed in range(a.first, a.first + a.count):
         kind, style, ref, arrs, regions, kw, clear = scenario(seed)
@@ -178,6 +183,10 @@ def main():
                 got, _ = parity.run_engine(dev, arrs, regions, ref=ref, clear_queue=clear, **route, **kw)
                 assert got == want, "text differs (route %r)" % (route,)
             api_routes(dev, oracle, seed, ref, arrs, regions, kw)
+            if ref_lib is not None and kind != "deep":
+                want, _ = parity.run_engine(ref_lib, arrs, regions, ref=ref, clear_queue=clear, **kw)
+                got, _ = parity.run_engine(oracle, arrs, regions, ref=ref, clear_queue=clear, **kw)
+                assert got == want, "the oracle's text differs from the reference-compiled library's"
         except Exception as ex:                                   # noqa: BLE001 — every failure is reported, the run goes on
             bad += 1
             print("FAIL seed %d kind %s style %s kw %r regions %r: %s: %s" % (seed, kind, style, {k: v for k, v in kw.items() if k != "lib_names"}, regions, type(ex).__name__, str(ex)[:300].replace("\n", " ")), flush=True)
