@@ -416,6 +416,12 @@ const char* brc_engine_kind(void) { return backend_kind(); }
 int brc_create(const brc_config* cfg, brc_engine** out) {
     if (!cfg || !out || cfg->abi_version != BRC_ABI_VERSION) return BRC_E_ARG;
     if (cfg->per_lib && (cfg->n_libs < 0 || (cfg->n_libs > 0 && !cfg->lib_names) || cfg->n_libs > 254)) return BRC_E_ARG;   // library index + 1 travels in 8 bits of the device read record
+    // brc.h asks for bytewise-sorted, distinct names: the reference keeps its libraries in a std::map keyed by name (:273) and prints
+    // them in that order (:360); names in another order would print in another order — refused instead of printed differently
+    if (cfg->per_lib) for (int i = 0; i < cfg->n_libs; ++i) {
+        if (!cfg->lib_names[i]) return BRC_E_ARG;
+        if (i && strcmp(cfg->lib_names[i - 1], cfg->lib_names[i]) >= 0) return BRC_E_ARG;
+    }
     brc_engine* e = new (std::nothrow) brc_engine();
     if (!e) return BRC_E_NOMEM;
     e->cfg = *cfg;

@@ -87,7 +87,7 @@ typedef struct brc_config {
     int32_t per_lib;            /* -p  (:444) */
     int32_t insertion_centric;  /* -i  (:446) */
     int32_t n_libs;             /* number of library names (per_lib only) */
-    const char* const* lib_names; /* bytewise-sorted library names (std::map order, :273,360); copied */
+    const char* const* lib_names; /* bytewise-sorted, distinct library names (std::map order, :273,360); copied; brc_create returns BRC_E_ARG for any other order */
     int32_t device;             /* HIP device ordinal */
     int32_t ref_len_check;      /* 1 in site-list mode: fetch_data_t.ref_len != 0 (:594-600,144-148) */
 } brc_config;

@@ -201,3 +201,17 @@ def test_push_reads_refuses_inconsistent_records(sim_lib):
     ok["cigar"][int(ok["cigar_off"][7])] += 2 << 4; ok["flag"][7] |= 4
     eng = capi.Engine(sim_lib)
     eng.begin_region(0, 0, 500, ref); eng.push_reads(ok); eng.end_region(); eng.close()
+
+
+def test_library_names_must_come_in_the_reference_s_order(sim_lib):
+    """brc.h: library names bytewise-sorted and distinct — the order of the reference's std::map (bamreadcount.cpp:273), in which
+    it prints them (:360).  "lib10" sorts before "lib2": a caller numbering its libraries would print them in another order than
+    the reference; brc_create refuses such a list instead (found when tools/fuzz/extreme.py compared 254 numbered libraries with
+    the reference-compiled library)."""
+    import pytest
+    from bam_readcount_amd import capi
+    capi.Engine(sim_lib, per_lib=True, lib_names=["lib10", "lib2"]).close()
+    capi.Engine(sim_lib, per_lib=True, lib_names=["", "A", "a"]).close()
+    for names in (["lib2", "lib10"], ["b", "a"], ["same", "same"]):
+        with pytest.raises(capi.BrcError):
+            capi.Engine(sim_lib, per_lib=True, lib_names=names)

@@ -84,7 +84,7 @@ def scenario(seed):
             a = int(rng.integers(0, RL)); regions.append((a, min(a + int(rng.choice([1, 64, 5_000, 120_000, RL])), RL + 400_000)))
         kw = dict(min_mapq=int(rng.choice([0, 20])), min_bq=int(rng.choice([0, 13])), insertion_centric=bool(rng.random() < 0.4))
         if rng.random() < 0.5:
-            kw.update(per_lib=True, lib_names=["lib%d" % i for i in range(n_libs)])
+            kw.update(per_lib=True, lib_names=["lib%03d" % i for i in range(n_libs)])
         return kind, "spliced", ref, arrs, regions, kw, bool(rng.random() < 0.5)
     RL = int(rng.integers(2_000, 40_000)) if kind == "long" else int(rng.integers(300, 4_000))
     n_libs = int(rng.choice([5, 12, 64, 254])) if kind == "libs" else int(rng.choice([1, 1, 2, 4]))
@@ -114,7 +114,7 @@ def scenario(seed):
     if rng.random() < 0.25:
         kw["max_cnt"] = int(rng.choice([1, 2, 5, 50, 1000]))
     if rng.random() < 0.5:
-        kw.update(per_lib=True, lib_names=["lib%d" % i for i in range(n_libs)])
+        kw.update(per_lib=True, lib_names=["lib%03d" % i for i in range(n_libs)])
     return kind, style, ref, arrs, regions, kw, bool(rng.random() < 0.5)
 
 
@@ -158,6 +158,26 @@ def api_routes(dev, oracle, seed, ref, arrs, regions, kw):
     e1.close(); e2.close()
 
 
+def mutate_fields(seed, arrs):
+    """qualities at the edges of the event byte (0, 1, 2, 62, 63, 64, 93, 255; whole reads of 255 = a '*' quality string), NM / SM
+    values at the edges of their types — in place, on a copy"""
+    rng = np.random.default_rng(seed + 31)
+    arrs = dict(arrs)
+    if rng.random() < 0.6 and len(arrs["qual"]):
+        q = arrs["qual"].copy(); p = float(rng.choice([0.001, 0.05, 0.5]))
+        hit = rng.random(len(q)) < p
+        q[hit] = rng.choice(np.array([0, 1, 2, 3, 61, 62, 63, 64, 93, 127, 128, 200, 254, 255], np.uint8), int(hit.sum()))
+        if rng.random() < 0.3:
+            for r in rng.integers(0, len(arrs["pos"]), max(1, len(arrs["pos"]) // 20)):
+                o = int(arrs["qual_off"][r]); q[o:o + int(arrs["l_qseq"][r])] = 255
+        arrs["qual"] = q
+    n = len(arrs["pos"])
+    if rng.random() < 0.3 and n:
+        nm = arrs["nm"].copy(); idx = rng.integers(0, n, max(1, n // 5)); nm[idx] = rng.choice([0, 1, 255, 256, 65535, 70000, 2**31 - 1, -1, -5], len(idx)).astype(nm.dtype); arrs["nm"] = nm
+        sm = arrs["sm"].copy(); idx = rng.integers(0, n, max(1, n // 5)); sm[idx] = rng.choice([0, 255, 256, 100000, 2**31 - 1, -1], len(idx)).astype(sm.dtype); arrs["sm"] = sm
+    return arrs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--first", type=int, default=0); ap.add_argument("--count", type=int, default=200); ap.add_argument("--hip", action="store_true"); ap.add_argument("--verbose", action="store_true")
@@ -172,6 +192,7 @@ def main():
     bad = 0; t0 = time.time(); ev = 0
     for seed in range(a.first, a.first + a.count):
         kind, style, ref, arrs, regions, kw, clear = scenario(seed)
+        arrs = mutate_fields(seed, arrs)
         if a.verbose:
             print("seed %d kind %s style %s reads %d kw %r regions %r" % (seed, kind, style, len(arrs["pos"]), {k: v for k, v in kw.items() if k != "lib_names"}, regions), flush=True)
         try:
