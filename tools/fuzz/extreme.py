@@ -180,10 +180,10 @@ def mutate_fields(seed, arrs):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--first", type=int, default=0); ap.add_argument("--count", type=int, default=200); ap.add_argument("--hip", action="store_true"); ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--first", type=int, default=0); ap.add_argument("--count", type=int, default=200); ap.add_argument("--hip", action="store_true"); ap.add_argument("--verbose", action="store_true"); ap.add_argument("--sim", default=None, help="another build of the simulator library (a sanitizer build: run under LD_PRELOAD of libasan / libubsan)")
     ap.add_argument("--ref", action="store_true", help="also: the oracle's text against the reference's own sources compiled over the htslib shim (oracle/_ref; skips the deep piles, its std::map per position is slow there)")
     a = ap.parse_args()
-    dev = capi.load_product() if a.hip else capi.Library(os.path.join(ROOT, "tests", "sim", "libbrc_sim.so"))
+    dev = capi.load_product() if a.hip else capi.Library(a.sim or os.path.join(ROOT, "tests", "sim", "libbrc_sim.so"))
     oracle = capi.Library(os.path.join(ROOT, "oracle", "libbrc_oracle.so"))
     ref_lib = None
     if a.ref:
