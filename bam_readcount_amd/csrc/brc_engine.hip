@@ -1437,6 +1437,14 @@ __global__ __launch_bounds__(256) void k_text_len(DevCfg c, DevIn in, Planes pl,
     if (k > c.P) return;
     len[k] = k < c.P ? text_line(c, in, pl, t, k, nullptr) : 0u;        // (entry P: the scan turns it into the total)
 }
+// the true total of the line lengths, in 64 bits (the offsets are 32-bit: a region whose text would pass 4 GiB must not be written)
+__global__ __launch_bounds__(256) void k_text_total(const uint32_t* __restrict__ len, int64_t n, unsigned long long* __restrict__ total) {
+    unsigned long long v = 0ull;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) v += len[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (unsigned long long)__shfl_xor((long long)v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(total, v);
+}
 __global__ __launch_bounds__(256) void k_text_write(DevCfg c, DevIn in, Planes pl, TextCtx t, const uint32_t* __restrict__ off, char* __restrict__ text) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= c.P || off[k + 1] == off[k]) return;
@@ -1550,7 +1558,7 @@ class HipBackend : public Backend {
     DBuf d_pos, d_flag, d_mapq, d_lib, d_lq, d_nc, d_co, d_so, d_qo, d_nm, d_sm, d_tags, d_cigar, d_seq, d_qual, d_ref, d_refcode;
     std::vector<uint16_t> h_wanted; bool has_wanted = false; DBuf d_wanted; std::vector<uint32_t> h_tilelist; DBuf d_tilelist;      // brc_region_windows (kept alive for the asynchronous copy)
     DBuf d_bq, d_bqw, d_bqrow, d_pieceoff, d_pieces, d_rare, d_keyreach, d_libbase, d_reads, d_agg, d_rng, d_ncol, d_depth, d_slotid, d_si, d_sf, d_xev, d_xevc, d_xevn, d_unavail, d_cnt, d_cursor, d_ev, d_evraw, d_ievoff, d_iout, d_ctr, d_tilectr, d_part;
-    DBuf d_tlen, d_toff, d_text, d_tctx;
+    DBuf d_tlen, d_toff, d_text, d_tctx, d_total64;
     // device-side text, downloaded (pinned) on its own stream into one of two host buffers
     HBuf<char> h_text[2]; HBuf<uint32_t> h_toff[2]; HBuf<uint32_t> h_total;
     hipStream_t stream2 = nullptr; hipEvent_t ev_text[2] = {nullptr, nullptr}, ev_lines = nullptr;
@@ -1604,7 +1612,7 @@ class HipBackend : public Backend {
         if (getenv("BRC_ENGINE_TIMING")) fprintf(stderr, "device buffers: %llu (re)allocations, %.3f s\n", (unsigned long long)g_dev_allocs, g_dev_alloc_s);
         DBuf* all[] = {&d_pos, &d_flag, &d_mapq, &d_lib, &d_lq, &d_nc, &d_co, &d_so, &d_qo, &d_nm, &d_sm, &d_tags, &d_cigar, &d_seq, &d_qual,
                        &d_ref, &d_refcode, &d_bq, &d_bqw, &d_bqrow, &d_pieceoff, &d_pieces, &d_rare, &d_keyreach, &d_libbase, &d_reads, &d_agg, &d_rng, &d_ncol, &d_depth, &d_slotid, &d_si, &d_sf, &d_xev, &d_xevc, &d_xevn, &d_unavail, &d_cnt,
-                       &d_cursor, &d_ev, &d_evraw, &d_ievoff, &d_iout, &d_ctr, &d_tilectr, &d_part, &d_tlen, &d_toff, &d_text, &d_tctx, &d_wanted, &d_tilelist};
+                       &d_cursor, &d_ev, &d_evraw, &d_ievoff, &d_iout, &d_ctr, &d_tilectr, &d_part, &d_tlen, &d_toff, &d_text, &d_tctx, &d_total64, &d_wanted, &d_tilelist};
         for (DBuf* b : all) b->release();
         for (int i = 0; i < 2; ++i) { h_text[i].destroy(); h_toff[i].destroy(); if (ev_text[i]) (void)hipEventDestroy(ev_text[i]); }
         h_total.destroy();
@@ -1936,7 +1944,7 @@ class HipBackend : public Backend {
         const int slot = (text_slot ^= 1); *slot_out = slot;
         text_started[slot] = true; text_total[slot] = 0; text_n[slot] = P;
         { const int rc0 = enqueue_lists(); if (rc0) return rc0; }
-        if (!h_toff[slot].reserve((size_t)P + 4) || !h_total.reserve(4)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }
+        if (!h_toff[slot].reserve((size_t)P + 4) || !h_total.reserve(8)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }
         if (P == 0) { h_toff[slot].p[0] = 0; HIPCHK(hipEventRecord(ev_text[slot], stream)); return BRC_OK; }
         // column 1 and the library names, behind the offsets of the names
         std::vector<int32_t> loff((size_t)c.Lp + 1, 0); std::string bytes = chrom;
@@ -1953,9 +1961,18 @@ class HipBackend : public Backend {
         hipLaunchKernelGGL(k_text_len, dim3(nb), dim3(256), 0, stream, c, in, pl_last, t, (uint32_t*)d_tlen.p);
         int rc;
         if ((rc = scan<OpSumU32, false>((const uint32_t*)d_tlen.p, (uint32_t*)d_toff.p, P + 1))) return rc;
+        // the 32-bit total, and the true one: the caller's estimate of the text size (brc_host.cpp) does not know the lengths of the
+        // library names or of sums at the far end of int32 — a region whose lines pass 4 GiB is handed back for the host formatter
+        HIPCHK(d_total64.ensure(16)); HIPCHK(hipMemsetAsync(d_total64.p, 0, 8, stream));
+        hipLaunchKernelGGL(k_text_total, dim3((unsigned)std::min<int64_t>((P + 255) / 256, 1024)), dim3(256), 0, stream, (const uint32_t*)d_tlen.p, P, (unsigned long long*)d_total64.p);
         HIPCHK(hipMemcpyAsync(h_total.p, (const uint32_t*)d_toff.p + P, 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(h_total.p + 2, d_total64.p, 8, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));                                  // (also covers the local `ctx`)
         const uint64_t total = h_total.p[0];
+        { uint64_t t64; memcpy(&t64, h_total.p + 2, 8);
+          // (BRC_DEVICE_TEXT_LIMIT: test knob, a lower limit — the route changes, the text does not)
+          const uint64_t limit = getenv("BRC_DEVICE_TEXT_LIMIT") ? strtoull(getenv("BRC_DEVICE_TEXT_LIMIT"), nullptr, 10) : ~0ull;
+          if (t64 != total || t64 > limit) { text_started[slot] = false; text_slot ^= 1; return BRC_TEXT_TOO_LONG; } }
         text_total[slot] = total;
         std::lock_guard<std::mutex> lk(text_mu);
         HIPCHK(d_text.ensure((size_t)total + 64));

@@ -779,7 +779,8 @@ static int compute_passes(brc_engine* e, int32_t n, brc_timing* t) {
     }
     if (e->text_computed) {
         rc = e->be->text_begin(e->chrom, e->libs, &e->text_slot_computed);
-        if (rc) return fail(e, rc, e->be->last_error());
+        if (rc == BRC_TEXT_TOO_LONG) e->text_computed = false;          // (the estimate above was too low: long library names, sums at the far end of int32)
+        else if (rc) return fail(e, rc, e->be->last_error());
     }
     e->state = 3; e->t_compute += now_s() - t_in;
     return BRC_OK;

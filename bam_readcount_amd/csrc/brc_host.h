@@ -105,6 +105,8 @@ struct HostPlanes {
 // for positions that print nothing; n + 1 offsets.
 struct HostText { const char* text = nullptr; const uint32_t* off = nullptr; uint64_t total = 0; int64_t n = 0; };
 
+enum { BRC_TEXT_TOO_LONG = 1000 };      // Backend::text_begin only (not an ABI code)
+
 class Backend {
   public:
     virtual ~Backend() {}
@@ -125,6 +127,8 @@ class Backend {
     // buffers of the region stay untouched until it is done: same stream), text_wait waits for it
     // (two host buffers: `slot` names the one this region's text goes to — the text of the region before may still be
     // in the writer's hands while the next region's download is already running)
+    // (BRC_TEXT_TOO_LONG: the region's lines would pass the 4 GiB its 32-bit offsets can address — nothing was started, the caller
+    // formats this region on the host)
     virtual int text_begin(const std::string& chrom, const std::vector<std::string>& libs, int* slot) = 0;
     virtual int text_wait(int slot, HostText* out) = 0;
     virtual int reserve_text(size_t) { return BRC_OK; }

@@ -269,7 +269,10 @@ class SimBackend : public Backend {
         if (c.per_lib) for (int l = 0; l < c.Lp; ++l) { loff[(size_t)l] = (int32_t)names.size(); if ((size_t)l < libs.size()) names += libs[(size_t)l]; loff[(size_t)l + 1] = (int32_t)names.size(); }
         TextCtx t; t.chrom = chrom.data(); t.chrom_len = (int32_t)chrom.size(); t.lib_names = names.data(); t.lib_off = loff.data();
         t_off.assign((size_t)c.P + 1, 0);
-        for (int64_t k = 0; k < c.P; ++k) t_off[(size_t)k + 1] = t_off[(size_t)k] + text_line(c, in, pl_last, t, k, nullptr);
+        uint64_t total64 = 0;
+        for (int64_t k = 0; k < c.P; ++k) { const uint32_t n = text_line(c, in, pl_last, t, k, nullptr); t_off[(size_t)k + 1] = t_off[(size_t)k] + n; total64 += n; }
+        const uint64_t limit = getenv("BRC_DEVICE_TEXT_LIMIT") ? strtoull(getenv("BRC_DEVICE_TEXT_LIMIT"), nullptr, 10) : ~0ull;     // (test knob, as in the HIP backend)
+        if (total64 != (uint64_t)t_off[(size_t)c.P] || total64 > limit) { t_slot ^= 1; return BRC_TEXT_TOO_LONG; }     // (as the HIP backend: 32-bit offsets cannot address it)
         t_text.assign((size_t)t_off[(size_t)c.P] + 1, 0);
         for (int64_t k = 0; k < c.P; ++k) if (t_off[(size_t)k + 1] > t_off[(size_t)k]) (void)text_line(c, in, pl_last, t, k, t_text.data() + t_off[(size_t)k]);
         return BRC_OK;

@@ -547,3 +547,23 @@ def test_hip_spliced_and_structural_alignments(dev_lib, oracle_lib, seed):
     assert sum(r.n_events for r in res) > 0
     got, _ = parity.run_engine(dev_lib, arrs, regions, ref=ref, clear_queue=clear, device_text="chrS", **kw)
     assert zlib.crc32(got) == zlib.crc32(text)
+
+
+def test_hip_device_text_hands_a_region_back_when_its_lines_do_not_fit(dev_lib, oracle_lib, monkeypatch):
+    """The device writes a region's lines behind 32-bit offsets.  Whether they fit is estimated before the line kernels run
+    (brc_host.cpp: 700 bytes per position and library) — an estimate that knows neither the lengths of the library names nor sums at
+    the far end of int32 — and CHECKED after the length pass: the true 64-bit total against the 32-bit one.  A region that does
+    not fit is formatted on the host instead; the text is the same.  (BRC_DEVICE_TEXT_LIMIT lowers the limit for the test: the
+    real one needs 4 GiB of text.)"""
+    ref, arrs = synth.make_ref(np.random.default_rng(5), 3000), None
+    arrs = synth.make_batch(9, ref, 900, style="mixed", n_libs=2, region=(0, 2400))
+    kw = dict(per_lib=True, lib_names=["L" * 500, "M" * 900], min_mapq=0, min_bq=0)
+    want, _ = parity.run_engine(oracle_lib, arrs, [(10, 2300), (2300, 2350)], ref=ref, **kw)
+    assert len(want) > 1_000_000
+    for limit in ("100", "1500000", None):
+        if limit is None:
+            monkeypatch.delenv("BRC_DEVICE_TEXT_LIMIT", raising=False)
+        else:
+            monkeypatch.setenv("BRC_DEVICE_TEXT_LIMIT", limit)
+        got, _ = parity.run_engine(dev_lib, arrs, [(10, 2300), (2300, 2350)], ref=ref, device_text="chrS", **kw)
+        assert got == want, limit
