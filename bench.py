@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300, help="timed steps (300 x ~7 ms: a timed region above 2 s)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--mode", default="weak", choices=["weak", "strong", "sites"])
-    ap.add_argument("--config", default=None, choices=["wgs30x", "tumor200x", "wgs30x_mixed"], help="data model (default: wgs30x; tumor200x for --mode strong; wgs30x_mixed: config 3 with 30 %% of the reads trimmed to U[100,149] and 10 %% 250 bases long)")
+    ap.add_argument("--config", default=None, choices=["wgs30x", "tumor200x", "wgs30x_mixed", "long10k"], help="data model (default: wgs30x; tumor200x for --mode strong; wgs30x_mixed: config 3 with 30 %% of the reads trimmed to U[100,149] and 10 %% 250 bases long; long10k: 10-kb reads at 30x, a functional and throughput point outside BASELINE's configurations)")
     ap.add_argument("--contig-mbp", type=float, default=50.0, help="weak/sites: contig per GPU; strong: the whole contig")
     ap.add_argument("--sites", type=int, default=100000, help="--mode sites: lines of the site list (all ranks together)")
     ap.add_argument("--cpu-sample-mbp", type=float, default=8.0, help="prefix timed with the 1-thread CPU oracle and used for validation (0 = skip)")
@@ -505,6 +505,8 @@ def main():
                          % (args.sites, world, contig_len / 1e6, world)}[args.mode]
         if config == "wgs30x_mixed":
             what = "synthetic 30x WGS, MIXED read lengths (60 %% 150 bp, 30 %% trimmed to U[100,149], 10 %% 250 bp), 1 contig %.0f Mbp per GPU, -q20 -b13" % (contig_len / 1e6)
+        if config == "long10k":
+            what = "synthetic 30x, 10-kb reads (30 %% with an insertion, 30 %% with a deletion), 1 contig %.0f Mbp per GPU, -q20 -b13 — not one of BASELINE's configurations" % (contig_len / 1e6)
         if config == "tumor200x" and args.mode == "weak":
             what = "synthetic 200x tumor 4 libraries, 150bp reads, -p -i, 1 contig %.2f Mbp per GPU" % (contig_len / 1e6)
         line = {

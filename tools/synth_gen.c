@@ -86,7 +86,7 @@ int synth_reads(const synth_params* P, const uint8_t* ref, int32_t* pos, uint16_
     const int mixed = (P->p_trim > 0 || P->p_long > 0);
     const int Lmax = (P->p_long > 0 && P->long_len > P->read_len) ? P->long_len : P->read_len, SB = (Lmax + 1) / 2;
     const int nch = P->n_chunks > 0 ? P->n_chunks : 64;
-    if (P->read_len < 30 || Lmax > 1000 || P->contig_len < 4 * Lmax) return -1;
+    if (P->read_len < 30 || Lmax > 100000 || P->contig_len < 4 * Lmax) return -1;
     if (mixed && (P->trim_min < 30 || P->trim_min >= P->read_len || (P->p_long > 0 && P->long_len < 30))) return -1;
     build_qtab();
     const double lg1mp = P->p_sub > 0 ? log(1.0 - P->p_sub) : 0.0;
@@ -98,7 +98,7 @@ int synth_reads(const synth_params* P, const uint8_t* ref, int32_t* pos, uint16_
         const int64_t p0 = span * c / nch, p1 = span * (c + 1) / nch;
         for (int64_t i = r0; i < r1; ++i) pos[i] = (int32_t)(p0 + (int64_t)(rng_u01(&r) * (double)(p1 - p0)));
         qsort(pos + r0, (size_t)(r1 - r0), sizeof(int32_t), cmp_i32);
-        uint8_t codes[1024];
+        uint8_t* codes = (uint8_t*)malloc((size_t)Lmax + 64);     /* (reads of up to 100 kb: not on the stack) */
         for (int64_t i = r0; i < r1; ++i) {
             const int rev = (int)(rng_next(&r) >> 63);
             const double uf = rng_u01(&r);
@@ -168,6 +168,7 @@ int synth_reads(const synth_params* P, const uint8_t* ref, int32_t* pos, uint16_
             if (rng_next(&r) >> 63) { t |= 2; sm[i] = mapq[i]; } else sm[i] = 0;
             tags[i] = t;
         }
+        free(codes);
     }
     return 0;
 }

@@ -67,6 +67,9 @@ CONFIGS = {
     "tumor200x": dict(depth=200.0, read_len=150, n_libs=4, p_sub=0.005, p_clip=0.05, p_ins=0.05, p_del=0.05, indel_max=10),
     # config 3's model with mixed read lengths (adapter-trimmed reads, two run types in one file): 30 % of the reads trimmed to
     # U[100, 149] bases, 10 % are 250 bases long, the rest 150; the number of reads keeps the depth at 30x
+    # long reads (PacBio-HiFi-like lengths; the generator's indel model stays per read): every piece is above the 16-bit packing limit
+    # and takes the PF_HUGE path — a functional check and a throughput point, not one of BASELINE's configurations
+    "long10k": dict(depth=30.0, read_len=10000, n_libs=1, p_sub=0.005, p_clip=0.05, p_ins=0.3, p_del=0.3, indel_max=3),
     "wgs30x_mixed": dict(depth=30.0, read_len=150, n_libs=1, p_sub=0.005, p_clip=0.05, p_ins=0.01, p_del=0.01, indel_max=3,
                          p_trim=0.3, p_long=0.1, trim_min=100, long_len=250),
 }
