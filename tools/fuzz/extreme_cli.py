@@ -35,6 +35,8 @@ while done+bad<want_n:
         if "max_cnt" in kw: o+=["-d",str(kw["max_cnt"])]
         regs=["chrA:%d-%d"%(a+1,max(b,a+1)) for a,b in regions]
         extra=["--brc-chunk",str(int(rng.choice([64,333,5000,100000])))]
+        if rng.random()<0.5: extra+=["--brc-gpus",str(int(rng.choice([2,3])))]          # (several engines take the pieces in turn)
+        if rng.random()<0.3: extra+=["--brc-plan",str(int(rng.choice([0,3])))]
         if rng.random()<0.5:
             open(os.path.join(d,"s.txt"),"w").write("".join("chrA\t%d\t%d\n"%(a+1,max(b,a+1)) for a,b in regions)); args=["-l","s.txt","x.bam"]
         else: args=["x.bam"]+regs
