@@ -25,6 +25,7 @@
 //
 // There is no CPU fallback here: without a HIP device make_backend() fails with BRC_E_NODEVICE.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <chrono>
 
 #include <stdio.h>
@@ -1513,13 +1514,13 @@ static void* pinned_alloc(size_t n) {
 static void pinned_release(void* p) { (void)hipHostFree(p); }
 static const HostAlloc kPinned = {pinned_alloc, pinned_release};
 
-static uint64_t g_dev_allocs = 0; static double g_dev_alloc_s = 0.0;     // BRC_ENGINE_TIMING: (re)allocations of device buffers and the time they took
+static std::atomic<uint64_t> g_dev_allocs{0}, g_dev_alloc_ns{0};     // BRC_ENGINE_TIMING: (re)allocations of device buffers and the time they took (several engines allocate from their own threads)
 struct DBuf {
     void* p = nullptr; size_t cap = 0;
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
         struct Tm { std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-                    ~Tm() { g_dev_alloc_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); ++g_dev_allocs; } } tm_;
+                    ~Tm() { g_dev_alloc_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); ++g_dev_allocs; } } tm_;
         // a FIRST allocation takes an eighth more than asked (the 18 GB of a config-5 contig must not be padded by half); a buffer that has to
         // grow again belongs to a run of regions of fluctuating size (the command line's 1-Mbp pieces): half more, so that the run settles
         // after a few pieces instead of paying hipFree (a device-wide synchronisation) + hipMalloc for 40-odd buffers on every new maximum
@@ -1609,7 +1610,7 @@ class HipBackend : public Backend {
     }
     ~HipBackend() override {
         (void)hipSetDevice(device);
-        if (getenv("BRC_ENGINE_TIMING")) fprintf(stderr, "device buffers: %llu (re)allocations, %.3f s\n", (unsigned long long)g_dev_allocs, g_dev_alloc_s);
+        if (getenv("BRC_ENGINE_TIMING")) fprintf(stderr, "device buffers: %llu (re)allocations, %.3f s\n", (unsigned long long)g_dev_allocs.load(), (double)g_dev_alloc_ns.load() * 1e-9);
         DBuf* all[] = {&d_pos, &d_flag, &d_mapq, &d_lib, &d_lq, &d_nc, &d_co, &d_so, &d_qo, &d_nm, &d_sm, &d_tags, &d_cigar, &d_seq, &d_qual,
                        &d_ref, &d_refcode, &d_bq, &d_bqw, &d_bqrow, &d_pieceoff, &d_pieces, &d_rare, &d_keyreach, &d_libbase, &d_reads, &d_agg, &d_rng, &d_ncol, &d_depth, &d_slotid, &d_si, &d_sf, &d_xev, &d_xevc, &d_xevn, &d_unavail, &d_cnt,
                        &d_cursor, &d_ev, &d_evraw, &d_ievoff, &d_iout, &d_ctr, &d_tilectr, &d_part, &d_tlen, &d_toff, &d_text, &d_tctx, &d_total64, &d_wanted, &d_tilelist};
