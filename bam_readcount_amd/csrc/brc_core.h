@@ -735,6 +735,21 @@ BRC_HD void choose_pack(int32_t max_lqseq, int32_t k_override, int32_t lim_overr
     if (lim_override >= 255 && (uint32_t)lim_override < lim) lim = (uint32_t)lim_override;    // >= 255: a mapping quality always fits
 }
 
+// The event-byte stream on the device is padded: EB_PAD_FRONT bytes before its first row, EB_PAD_BACK + (the batch's longest read) behind
+// its last.  A tile stages, for every piece of its range, the 80-byte window [ws, ws + 80) of the piece's row that its 64 positions can
+// touch, ws = floor16(p0 - a) — up to 79 bytes before the row, up to 79 + 15 past it.  A piece that only SPANS the tile (an intron, a long
+// deletion) or does not touch it has its window anywhere — 100 kb off the row — and nobody reads the copy: a window further from the row's
+// start than the longest read of the batch takes the row's first bytes instead; what is left — a SHORT read's window up to a long read's
+// length past its own row, when both are in the batch — is what the back pad is sized for.
+// (k_pileup2's BRC_STAGE states the same two lines in place; the simulator checks with this function that every window the device
+// would copy lies inside the padded stream — the fault on spliced alignments of round 4 was invisible to it before.)
+enum { EB_PAD_FRONT = 128, EB_PAD_BACK = 512, EB_WINDOW = 80 };
+BRC_HD int32_t stage_window_start(int32_t p0, int32_t a, int32_t max_lqseq) {
+    int32_t ws = (p0 - a) & ~15;
+    if ((uint32_t)(ws + 96) > (uint32_t)max_lqseq + 96u + 16u) ws = 0;
+    return ws;
+}
+
 // Per-lane state of KB v2.
 // (HALF, defined above choose_pack:) pieces per staging half-batch (12 rows x 5 chunks of 16 event bytes = 60 lanes of one direct-to-LDS instruction; a multiple of 3,
                             // the rotation period of the piece-record registers); queue drains and flushes happen between half-batches

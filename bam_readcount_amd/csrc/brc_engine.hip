@@ -1684,8 +1684,8 @@ class HipBackend : public Backend {
         // event-byte stream, padded on both sides: a staged window starts up to 79 elements before / ends after a row
         // (the wide stream — full words of the few 8-base groups with an escape byte — is indexed like the bytes; it is
         // allocated whole and touched only where K1 writes such a group)
-        enum { BQ_PAD = 128 };
-        HIPCHK(d_bq.ensure(s.bq_elems + BQ_PAD + 512));
+        enum { BQ_PAD = EB_PAD_FRONT };
+        HIPCHK(d_bq.ensure(s.bq_elems + BQ_PAD + EB_PAD_BACK + (size_t)std::max<int32_t>(s.max_lqseq, 0)));     // (brc_core.h: stage_window_start — a staged window ends at most that far past the stream)
         HIPCHK(d_bqw.ensure((s.bq_elems + 16) * sizeof(uint16_t)));
         in.eb = (const uint8_t*)d_bq.p + BQ_PAD; in.bqw = (const uint16_t*)d_bqw.p;
         if ((rc = up(d_bqrow, s.bq_row, n)) || (rc = up(d_pieceoff, s.piece_off, n))) return rc;

@@ -40,7 +40,7 @@ class SimBackend : public Backend {
         c.min_mapq = cfg.min_mapq; c.min_bq = cfg.min_bq; c.per_lib = cfg.per_lib; c.insertion_centric = cfg.insertion_centric;
         c.Lp = g.Lp; c.ref_len_check = cfg.ref_len_check; c.has_ref = g.ref != nullptr;
         c.beg0 = g.beg0; c.end = g.end; c.pos0 = g.pos0; c.P = g.P; c.PS = g.PS; c.ref_lo = g.ref_lo; c.ref_hi = g.ref_hi; c.ref_len = g.ref_len;
-        c.n_reads = s.n; c.table_len = getenv("BRC_NO_TABLE") ? 0 : s.modal_len(); c.n_pieces = s.n_pieces;
+        c.n_reads = s.n; c.table_len = getenv("BRC_NO_TABLE") ? 0 : s.modal_len(); c.n_pieces = s.n_pieces; c.max_lqseq = s.max_lqseq;
         c.force_dom = getenv("BRC_FORCE_DOM") ? atoi(getenv("BRC_FORCE_DOM")) : -1;
         c.ibucket_shift = indel_bucket_shift(s.n_indel_ops, c.P, c.Lp);
         if (const char* ib = getenv("BRC_IBUCKET_SHIFT")) { const int v = atoi(ib); if (v == 4 || v == 6) c.ibucket_shift = v; }   // (as the HIP backend: the two supported sizes)
@@ -55,6 +55,7 @@ class SimBackend : public Backend {
         return BRC_OK;
     }
 
+    bool stage_fault = false;            // a staged window outside the padded event-byte stream: the device would fault (checked at the end of compute)
     bool stats_on = false; uint64_t stat_steps = 0, stat_dead = 0;      // BRC_SIM_PIECE_STATS: piece-steps, and those whose piece does not touch the tile
     uint32_t tile_want = 0u | (63u << 8);     // brc_region_windows: the lanes of the current tile that a window asks for
     // one (tile, library) wave of KB
@@ -78,6 +79,11 @@ class SimBackend : public Backend {
                 const Piece& h = hot[m];
                 const uint32_t fl = piece_flags(h);
                 QEnt full, ints; full.piece = ints.piece = m; full.kind = 0; ints.kind = 1; bool any_full = false, any_int = false;
+                {   // the window of this piece's event bytes the device would stage for this tile must lie inside the padded stream
+                    const int32_t p0w = (int32_t)(c.pos0 + tl * TILE);
+                    const int64_t w0 = (int64_t)h.bq_off + stage_window_start(p0w, h.a, c.max_lqseq);
+                    if (w0 < -(int64_t)EB_PAD_FRONT || w0 + EB_WINDOW > (int64_t)bq_n + EB_PAD_BACK + c.max_lqseq) stage_fault = true;     // (the HIP backend's allocation)
+                }
                 if (stats_on) { const int64_t t0 = c.pos0 + tl * TILE; ++stat_steps; if (!((int64_t)h.rs < t0 + TILE && (int64_t)h.rs + h.ext > t0)) ++stat_dead; }
                 for (int l = 0; l < TILE; ++l) {
                     full.lane[l] = ints.lane[l] = false;
@@ -253,6 +259,7 @@ class SimBackend : public Backend {
             }
             for (uint32_t j = 0; j < run; ++j) if (tmp[j].len != 0) iout.push_back(tmp[j]);
         }
+        if (stage_fault) { stage_fault = false; err = "a tile would stage a window of event bytes outside the padded stream (k_pileup2: BRC_STAGE)"; return BRC_E_HIP; }
         if (stats_on) fprintf(stderr, "piece-steps %llu, of them %llu (%.2f %%) of a piece that does not touch the tile; %.1f events per step\n", (unsigned long long)stat_steps,
                               (unsigned long long)stat_dead, 100.0 * (double)stat_dead / (double)(stat_steps ? stat_steps : 1), (double)n_events / (double)(stat_steps ? stat_steps : 1));
         return BRC_OK;
