@@ -262,6 +262,7 @@ static void write_parts(const char* const* parts, const size_t* lens, size_t n) 
 
 struct Ctx {
     double t_fetch = 0, t_engine = 0, t_format = 0, t_write = 0;   // BRC_CLI_TIMING=1 prints them on stderr
+    double t_site_fetch = 0, t_site_fetch_threads = 0, t_site_layout = 0, t_site_engine = 0, t_site_format = 0; uint64_t n_site_lines = 0, n_site_clusters = 0, n_site_reads = 0, n_site_batches = 0;   // the site-list planner's own account
     Options opt; BamReader bam; BamIndex idx; Fasta fa; bool have_fa = false;
     CramReader cram; bool is_cram = false;          // CRAM 3.0 input (cram.cpp); region queries go through the .crai or one walk over the container headers
     const BamHeader& header() const { return is_cram ? cram.header() : bam.header(); }
@@ -468,20 +469,30 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
 
 struct Site { int tid; int64_t beg0, end; };
 
-static int run_site_batch(Ctx& c, const std::vector<Site>& sites) {
+// the indexed fetches of one batch of lines: every line's own reads (exactly what samfetch would hand over for [beg0 - 1, end))
+// and the extent they span.  Reads only what never changes while the run lasts (options, index, header, libraries), so the
+// fetch of the NEXT batch runs on threads of its own while this batch is laid out, computed and printed.
+struct SiteFetch { std::vector<Batcher> parts; std::vector<int64_t> lo, hi; bool ok = true; size_t n_clusters = 0; double seconds = 0; };
+
+static void fetch_site_batch(const Ctx& c, const std::vector<Site>& sites, SiteFetch& F) {
+    const double ts0 = now_s();
     const size_t n = sites.size();
-    const BamHeader& h = c.header();
-    std::vector<Batcher> parts(n);
+    std::vector<Batcher>& parts = F.parts; parts.clear(); parts.resize(n);
     for (Batcher& b : parts) b.keep_names = c.opt.max_warnings != 0;
-    std::vector<int64_t> lo(n), hi(n);
+    std::vector<int64_t>& lo = F.lo; std::vector<int64_t>& hi = F.hi; lo.assign(n, 0); hi.assign(n, 0);
     std::atomic<size_t> next(0); std::atomic<int> failed(0);
-    // Clusters of consecutive lines that lie close together (same contig, ascending, within 64 kb): ONE indexed fetch per
-    // cluster, every record handed to the lines it overlaps with exactly samfetch's test.  An index points at 16-kb
-    // windows, so a line-by-line fetch decodes its window's reads over and over — with one site per kb, sixteen times.
+    // Clusters of consecutive lines that one indexed fetch serves at no extra cost: an index points at 16-kb windows (the
+    // linear index; a CSI's finest bins), so a fetch for line k decodes its window from the window's first record up to the
+    // line.  A following line in the SAME window (ascending, same contig) would decode the same records again — with one site
+    // per kb, sixteen times — so it joins the cluster and every record is handed to the lines it overlaps with exactly
+    // samfetch's test.  A line in a LATER window starts a cluster of its own: one fetch over both would also decode
+    // everything between them (at the 31-kb spacing of a whole-genome SNV list that was three times the bytes).
     std::vector<std::pair<size_t, size_t> > clusters;
     for (size_t i0 = 0; i0 < n;) {
         size_t i1 = i0 + 1;
-        while (i1 < n && i1 - i0 < 256 && sites[i1].tid == sites[i0].tid && sites[i1].beg0 >= sites[i1 - 1].beg0 && sites[i1].beg0 - sites[i0].beg0 <= 65536) ++i1;
+        int64_t reach = sites[i0].end;                     // the cluster's fetch decodes up to here anyway
+        while (i1 < n && i1 - i0 < 256 && sites[i1].tid == sites[i0].tid && sites[i1].beg0 >= sites[i1 - 1].beg0 && sites[i1].beg0 - sites[i0].beg0 <= 65536 &&
+               (((sites[i1].beg0 > 0 ? sites[i1].beg0 - 1 : 0) >> 14) <= (reach >> 14) || sites[i1].beg0 - reach <= 2048)) { reach = std::max(reach, sites[i1].end); ++i1; }
         clusters.push_back(std::make_pair(i0, i1));
         i0 = i1;
     }
@@ -516,7 +527,18 @@ static int run_site_batch(Ctx& c, const std::vector<Site>& sites) {
     for (unsigned k = 1; k < nthr && (size_t)k < clusters.size(); ++k) th.emplace_back(work);
     work();
     for (std::thread& t : th) t.join();
-    if (failed) { c.complain("bam-readcount: read error while fetching sites\n"); return 1; }
+    F.ok = !failed; F.n_clusters = clusters.size(); F.seconds = now_s() - ts0;
+}
+
+// pre: the batch's reads when they were fetched ahead (one engine: the main loop overlaps the next batch's fetch with this batch)
+static int run_site_batch(Ctx& c, const std::vector<Site>& sites, SiteFetch* pre = nullptr) {
+    const size_t n = sites.size();
+    const BamHeader& h = c.header();
+    SiteFetch own;
+    if (!pre) { const double w0 = now_s(); fetch_site_batch(c, sites, own); pre = &own; c.t_site_fetch += now_s() - w0; }
+    if (!pre->ok) { c.complain("bam-readcount: read error while fetching sites\n"); return 1; }
+    std::vector<Batcher>& parts = pre->parts; const std::vector<int64_t>& lo = pre->lo; const std::vector<int64_t>& hi = pre->hi;
+    c.t_site_fetch_threads += pre->seconds; c.n_site_lines += n; c.n_site_clusters += pre->n_clusters;
     // Virtual layout, in sub-batches: the engine keeps planes for every virtual position, and a window's extent is known
     // only now (it includes the overhang of its reads — with long reads far more than the line asked for), so the batch is
     // cut wherever the axis would outgrow the chunk size.  A window wider than that runs alone.
@@ -524,12 +546,13 @@ static int run_site_batch(Ctx& c, const std::vector<Site>& sites) {
     const int64_t vmax = vmax_env > 0 ? vmax_env : std::max<int64_t>(4 * c.opt.chunk_bp, 1 << 20);
     std::vector<int64_t> delta(n);
     for (size_t i0 = 0; i0 < n;) {
+        const double tl0 = now_s();
         int64_t V = 1; size_t i1 = i0;
         while (i1 < n && (i1 == i0 || V + (hi[i1] - lo[i1]) + 1 <= vmax)) { delta[i1] = V - lo[i1]; V += (hi[i1] - lo[i1]) + 1; ++i1; }
         if (V >= (int64_t)INT_MAX - 64) { c.complain("bam-readcount: a site-list window is too wide for the planner; rerun with --brc-plan 0\n"); return 1; }
         std::string vref;
         if (c.have_fa) vref.assign((size_t)V + 1, '\0');
-        Batcher all;
+        size_t nr = 0, nq = 0;
         for (size_t i = i0; i < i1; ++i) {
             const Site& st = sites[i];
             if (c.have_fa) {
@@ -540,26 +563,26 @@ static int run_site_batch(Ctx& c, const std::vector<Site>& sites) {
                 // past the contig: the annotator stops at the terminating NUL (x == len, :151) but merely skips positions
                 // x > len (site-list mode, :144-148); 'N' reproduces the skip (it never counts as a mismatch, :152)
                 const int64_t clen = (int64_t)c.ref.size();
-                for (int64_t x = lo[i]; x < hi[i]; ++x)
-                    if (x >= 0) vref[(size_t)(x + delta[i])] = x < clen ? c.ref[(size_t)x] : (x == clen ? '\0' : 'N');
+                const int64_t x0 = std::max<int64_t>(lo[i], 0), x1 = hi[i];
+                const int64_t xin = std::min(x1, clen);                    // [x0, xin): inside the contig, copied as they are
+                if (xin > x0) memcpy(&vref[(size_t)(x0 + delta[i])], c.ref.data() + x0, (size_t)(xin - x0));
+                for (int64_t x = std::max(x0, clen); x < x1; ++x) vref[(size_t)(x + delta[i])] = x == clen ? '\0' : 'N';
             }
-            const Batcher& b = parts[i];
-            const uint64_t cb = all.cigar.size(), sb = all.seq4.size(), qb = all.qual.size();
-            for (size_t k = 0; k < b.pos.size(); ++k) {
-                all.pos.push_back((int32_t)(b.pos[k] + delta[i])); all.flag.push_back(b.flag[k]); all.mapq.push_back(b.mapq[k]); all.lib.push_back(b.lib[k]);
-                all.l_qseq.push_back(b.l_qseq[k]); all.n_cigar.push_back(b.n_cigar[k]); all.nm.push_back(b.nm[k]); all.sm.push_back(b.sm[k]); all.tags.push_back(b.tags[k]);
-                all.cig_off.push_back(b.cig_off[k] + cb); all.seq_off.push_back(b.seq_off[k] + sb); all.qual_off.push_back(b.qual_off[k] + qb);
-            }
-            { const size_t nb0 = all.names.size(); for (size_t k = 0; k < b.name_off.size(); ++k) all.name_off.push_back(b.name_off[k] + nb0); all.names.insert(all.names.end(), b.names.begin(), b.names.end()); }
-            all.cigar.insert(all.cigar.end(), b.cigar.begin(), b.cigar.end());
-            all.seq4.insert(all.seq4.end(), b.seq4.begin(), b.seq4.end());
-            all.qual.insert(all.qual.end(), b.qual.begin(), b.qual.end());
+            // the line's reads move to its window of the virtual axis where they are (no second copy of the batch)
+            Batcher& b = parts[i];
+            for (size_t k = 0; k < b.pos.size(); ++k) b.pos[k] = (int32_t)(b.pos[k] + delta[i]);
+            nr += b.pos.size(); nq += b.qual.size();
         }
+        const double te0 = now_s(); c.t_site_layout += te0 - tl0; c.n_site_reads += nr; ++c.n_site_batches;
         if (c.need_engine && !c.need_engine()) return 1;
         brc_set_option(c.eng, BRC_OPT_DEVICE_TEXT, 0);           // windows are cut out of shared planes on the host
         int rc = brc_begin_region(c.eng, 0, 1, (int32_t)V, c.have_fa ? vref.data() : nullptr, V);
-        const brc_read_batch v = all.view();
-        if (!rc) rc = brc_push_reads(c.eng, &v);
+        brc_set_option(c.eng, BRC_OPT_EXPECT_READS, (int64_t)(nr + 16)); brc_set_option(c.eng, BRC_OPT_EXPECT_BASES, (int64_t)(nq + 16));
+        for (size_t i = i0; i < i1 && !rc; ++i) {                // window by window, in axis order (= coordinate order)
+            if (parts[i].pos.empty()) continue;
+            const brc_read_batch v = parts[i].view();
+            rc = brc_push_reads(c.eng, &v);
+        }
         if (!rc) {         // only the lines' own positions are ever formatted: the engine need not pile up the rest of their reads' extent
             std::vector<int32_t> wb, we;
             for (size_t i = i0; i < i1; ++i) { wb.push_back((int32_t)(sites[i].beg0 + delta[i])); we.push_back((int32_t)(sites[i].end + delta[i])); }
@@ -568,6 +591,7 @@ static int run_site_batch(Ctx& c, const std::vector<Site>& sites) {
         brc_result res;
         if (!rc) rc = brc_end_region(c.eng, &res);
         if (rc) { c.complain(std::string("bam-readcount: engine error: ") + brc_strerror(rc) + " (" + brc_last_error(c.eng) + ")\n"); return 1; }
+        const double tf0 = now_s(); c.t_site_engine += tf0 - te0;
         for (size_t i = i0; i < i1; ++i) {
             const Site& st = sites[i];
             const char* text = ""; size_t len = 0;
@@ -577,6 +601,7 @@ static int run_site_batch(Ctx& c, const std::vector<Site>& sites) {
             if (c.opt.max_warnings != 0) { const char* ev = ""; size_t evn = 0; if (brc_window_warnings(c.eng, (int32_t)(st.beg0 + delta[i]), (int32_t)(st.end + delta[i]), c.opt.max_warnings, &ev, &evn) == 0) c.warn_events(ev, evn); }
         }
         for (int w = 0; w < BRC_N_WARN; ++w) c.warn[w] += res.warn[w];
+        c.t_site_format += now_s() - tf0;
         i0 = i1;
     }
     return 0;
@@ -887,9 +912,29 @@ int main(int argc, char** argv) {
     struct JoinPin { std::thread& t; ~JoinPin() { if (t.joinable()) t.join(); } } join_pin{pin_ahead};
     const bool clean_exit = getenv("BRC_CLEAN_EXIT") != nullptr || getenv("BRC_ENGINE_TIMING") != nullptr;
     if (N == 1) {
-        for (Work& w : items) {
+        // site-list batches: the reads of batch k + 1 are fetched and decoded (a pool of BAM handles) while batch k is laid out,
+        // computed and printed
+        std::unique_ptr<SiteFetch> ahead_f; std::thread ahead_t; size_t ahead_i = (size_t)-1;
+        struct JoinAhead { std::thread& t; ~JoinAhead() { if (t.joinable()) t.join(); } } join_ahead{ahead_t};
+        static const bool site_ahead = !(getenv("BRC_SITE_AHEAD") && atoi(getenv("BRC_SITE_AHEAD")) == 0);
+        for (size_t i = 0; i < items.size(); ++i) {
+            Work& w = items[i];
             if (w.kind == 2) { fputs(w.err.c_str(), stderr); ret = 1; break; }
             if (w.kind == 3) { fflush(stdout); fputs(w.err.c_str(), stderr); continue; }
+            if (w.kind == 1 && site_ahead) {
+                std::unique_ptr<SiteFetch> cur;
+                const double w0 = now_s();
+                if (ahead_i == i) { ahead_t.join(); cur = std::move(ahead_f); }
+                else { cur.reset(new SiteFetch()); fetch_site_batch(c, w.sites, *cur); }
+                c.t_site_fetch += now_s() - w0;
+                if (i + 1 < items.size() && items[i + 1].kind == 1) {
+                    ahead_f.reset(new SiteFetch()); ahead_i = i + 1;
+                    SiteFetch* fp = ahead_f.get(); const std::vector<Site>* sp = &items[i + 1].sites; const Ctx* cp = &c;
+                    ahead_t = std::thread([cp, sp, fp]() { fetch_site_batch(*cp, *sp, *fp); });
+                }
+                if ((ret = run_site_batch(c, w.sites, cur.get()))) break;
+                continue;
+            }
             if ((ret = run_item(c, w))) break;
         }
     } else {
@@ -982,6 +1027,9 @@ int main(int argc, char** argv) {
     }
     if (getenv("BRC_CLI_TIMING")) fprintf(stderr, "startup: open inputs %.3f s, create engine %.3f s\n", t_inputs - t_start, t_engine0 - t_inputs);
     if (getenv("BRC_CLI_TIMING")) fprintf(stderr, "timing: fetch+decode %.3f s, engine (push, upload, kernels, download) %.3f s, format %.3f s, write %.3f s\n", c.t_fetch, c.t_engine, c.t_format, c.t_write);
+    if (getenv("BRC_CLI_TIMING") && c.n_site_lines)
+        fprintf(stderr, "sites: %llu lines in %llu clusters, %llu engine regions of %llu reads all told: waiting for indexed fetch + decode %.3f s (the fetches themselves, next batch behind the current one: %.3f s), layout on the virtual axis %.3f s, engine (push, upload, kernels, download) %.3f s, cutting the lines out + writing %.3f s\n",
+                (unsigned long long)c.n_site_lines, (unsigned long long)c.n_site_clusters, (unsigned long long)c.n_site_batches, (unsigned long long)c.n_site_reads, c.t_site_fetch, c.t_site_fetch_threads, c.t_site_layout, c.t_site_engine, c.t_site_format);
     // Everything has been written.  Unpinning and freeing gigabytes of staging and the HIP runtime's own teardown only delay
     // the exit of a process that is done: leave them to the operating system (BRC_CLEAN_EXIT=1 keeps the orderly path).
     fflush(stdout); fflush(stderr);

@@ -114,6 +114,10 @@ def main():
     # test infrastructure (tests/test_bench_multirank.py): the rank arithmetic of this script — who owns which interval / slice of
     # the site list, the reductions of the metrics line — executed on CPUs: gloo instead of RCCL, and the C-ABI served by the CPU
     # lane simulator named here.  The line it prints says so ("dry_run") and carries no throughput.
+    ap.add_argument("--force-dist", action="store_true", help="run the N > 1 branch even with one rank: init_process_group(nccl = RCCL), the barriers, both all-reduces, the all-gathers and the "
+                    "destroy — so that the first time RCCL sees this code is not an 8-GPU run (tests/test_bench_dist_gpu.py)")
+    ap.add_argument("--rank-check-mbp", type=float, default=1.5, help="every rank validates this prefix of ITS OWN interval against the oracle after the timed region (an N-rank run, or --force-dist; "
+                    "sites mode: 100 of the rank's own sites); 0 = skip")
     ap.add_argument("--dry-run-lib", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--as-rank", type=int, default=None, help=argparse.SUPPRESS)     # with --as-world: one rank's share, without a launcher
     ap.add_argument("--as-world", type=int, default=None, help=argparse.SUPPRESS)
@@ -174,9 +178,12 @@ def main():
         torch.cuda.set_device(local_rank)
     dist = None
     tdev = "cpu" if dry else "cuda"
-    if world > 1 and not emulated:
+    if (world > 1 or args.force_dist) and not emulated:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "RANK" not in os.environ:                  # --force-dist without a launcher: a group of one
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); os.environ.setdefault("MASTER_PORT", str(s.getsockname()[1])); s.close()
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local_rank))
         if dry:
             dist.init_process_group("gloo")
         else:
@@ -245,15 +252,73 @@ def main():
         dist.all_gather(each, mine)
         per_rank = [{"rank": r, "ms_per_step": round(float(x[0]) / max(args.steps, 1) * 1e3, 4), "events": int(x[1]), "positions": int(x[2]), "hbm_bytes": int(x[3])} for r, x in enumerate(each)]
 
+    # ---- every rank validates a prefix of ITS OWN interval (its own sites) against the oracle, one thread, after the timed region:
+    # a wrong result on rank 5 of an 8-GPU run must not print a healthy line.  The verdicts are MIN-reduced.
+    rank_check = None
+    if (dist is not None or emulated) and args.rank_check_mbp > 0:
+        rank_check = {"ok": 1, "events": 0, "what": "", "error": None}
+        try:
+            import parity
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+            oracle_r = capi.Library(os.path.join(ROOT, "oracle", "libbrc_oracle.so"))
+            ends_r = capi.read_ends(arrs)
+            oe = capi.Engine(oracle_r, lib_names=names, **opts)
+            if args.mode == "sites":
+                eng.fetch_result()
+                pick = np.unique(np.linspace(0, len(sites) - 1, min(100, len(sites))).astype(np.int64)); pos64 = arrs["pos"].astype(np.int64)
+                for i in pick:
+                    sp = int(sites[i])
+                    lo_i = int(np.searchsorted(pos64, sp - 2 - 1000, side="left")); hi_i = int(np.searchsorted(pos64, sp, side="left"))
+                    idx = lo_i + np.nonzero(ends_r[lo_i:hi_i] > max(sp - 2, 0))[0]
+                    oe.begin_region(0, sp - 1, sp, ref); oe.push_reads(capi.select_reads(arrs, idx)); oe.end_region()
+                    want = oe.format_region("chrS"); oe.clear_indel_queue(); rank_check["events"] += oe.counts()[0]
+                    d = int(site_vbeg0[i]) + 1 - sp
+                    if eng.format_window("chrS", sp - 1 + d, sp + d, d) != want:
+                        raise AssertionError("site %d (position %d): the planner's line differs from the oracle's" % (i, sp))
+                rank_check["what"] = "%d of this rank's %d sites, line by line" % (len(pick), len(sites))
+            else:
+                vlen = int(min(args.rank_check_mbp * 1e6 * (0.15 if per_lib else 1.0), contig_len))
+                oe.begin_region(0, 0, vlen, ref); oe.push_reads(capi.select_reads(arrs, capi.fetch_overlapping(arrs, ends_r, -1, vlen)))
+                ores = oe.end_region(); otext = oe.format_region_np("chrS").copy()
+                eng.clear_indel_queue()
+                hres = eng.fetch_window(0, vlen); htext = eng.format_region_np("chrS"); eng.clear_indel_queue()      # the TIMED region's own result
+                parity.assert_results_equal(hres, ores, "rank %d prefix" % rank)
+                if not (len(htext) == len(otext) and np.array_equal(htext, otext)):
+                    raise AssertionError("text of the HIP engine and of the oracle differ")
+                rank_check["events"] = int(ores.n_events)
+                rank_check["what"] = "planes bit for bit + text of [0, %d) of this rank's interval, read back from the timed region (brc_fetch_window)" % vlen
+            oe.close()
+        except Exception as ex:                                  # noqa: BLE001 — reduced and reported; raising here would hang the other ranks
+            rank_check["ok"] = 0; rank_check["error"] = "%s: %s" % (type(ex).__name__, str(ex)[:300])
+        per_rank_checks = [rank_check]
+        if dist is not None:
+            okt = torch.tensor([rank_check["ok"]], dtype=torch.int64, device=tdev)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            mine_v = torch.tensor([rank_check["ok"], rank_check["events"]], dtype=torch.int64, device=tdev)
+            each_v = [torch.zeros(2, dtype=torch.int64, device=tdev) for _ in range(world)]
+            dist.all_gather(each_v, mine_v)
+            for r, x in enumerate(each_v):
+                per_rank[r]["validated_ok"] = bool(int(x[0])); per_rank[r]["validated_events"] = int(x[1])
+            all_ok = bool(int(okt.item()))
+        else:
+            per_rank[0]["validated_ok"] = bool(rank_check["ok"]); per_rank[0]["validated_events"] = rank_check["events"]
+            all_ok = bool(rank_check["ok"])
+        rank_check["all_ranks_ok"] = all_ok
+        if not rank_check["ok"]:
+            sys.stderr.write("bench.py: rank %d: validation of its own interval FAILED: %s\n" % (rank, rank_check["error"]))
+
     if dry:
         # the dry run ends here: what every rank (or the emulated one) owned, and — on rank 0 — the reduced totals
         if rank == 0 or emulated:
             print(json.dumps({"dry_run": "rank arithmetic only (gloo, %s)" % hip.kind(), "value": None, "n_gpus": world, "rank": rank, "mode": args.mode,
                               "events_per_step": int(ev_total), "positions_per_step": int(pos_total), "own_events": int(n_events), "own_positions": int(n_positions), "per_rank": per_rank,
-                              "reads_per_gpu": int(len(region_reads["pos"]))}))
+                              "reads_per_gpu": int(len(region_reads["pos"])),
+                              "validated": None if rank_check is None else {"all_ranks_ok": rank_check["all_ranks_ok"], "own": rank_check["what"], "own_error": rank_check["error"]}}))
         eng.close()
         if dist is not None:
             dist.destroy_process_group()
+        if rank_check is not None and not rank_check["all_ranks_ok"]:
+            raise SystemExit(3)
         return
     if rank == 0:
         ms_per_step = tmax / args.steps * 1e3
@@ -509,6 +574,9 @@ def main():
             what = "synthetic 30x, 10-kb reads (30 %% with an insertion, 30 %% with a deletion), 1 contig %.0f Mbp per GPU, -q20 -b13 — not one of BASELINE's configurations" % (contig_len / 1e6)
         if config == "tumor200x" and args.mode == "weak":
             what = "synthetic 200x tumor 4 libraries, 150bp reads, -p -i, 1 contig %.2f Mbp per GPU" % (contig_len / 1e6)
+        if rank_check is not None:
+            validated = dict(validated or {}, all_ranks_ok=rank_check["all_ranks_ok"], per_rank_check=rank_check["what"], rank0_error=rank_check["error"],
+                             distributed_backend=(dist.get_backend() if dist is not None else None))
         line = {
             "metric": "pileup base-events/sec", "value": round(value, 1), "unit": "events/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
@@ -525,6 +593,8 @@ def main():
         eng.close()
     if dist is not None:
         dist.destroy_process_group()
+    if rank_check is not None and not rank_check["all_ranks_ok"]:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -33,20 +33,72 @@ def build_bamwrite():
     return BAMLIB
 
 
-def write_bam(path, contig, contig_len, arrs, n_libs=1, block_bytes=60000, level=1):
-    """Fast single-contig BAM + BAI of a brc_read_batch (tools/bam_write.c); libraries become @RG rg<k> with LB lib<k>."""
-    L = C.CDLL(build_bamwrite())
-    text = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:%s\tLN:%d\n" % (contig, contig_len)
+_ORDER = [("pos", np.int32), ("flag", np.uint16), ("mapq", np.uint8), ("lib", np.int16), ("l_qseq", np.int32), ("n_cigar", np.uint32),
+          ("cigar_off", np.uint64), ("seq_off", np.uint64), ("qual_off", np.uint64), ("nm", np.int32), ("sm", np.int32), ("tags", np.uint8),
+          ("cigar", np.uint32), ("seq4", np.uint8), ("qual", np.uint8)]
+
+
+def header_text(contigs, n_libs=1, rgs_per_lib=1):
+    """@HD / @SQ / @RG lines: read group rg<l * rgs_per_lib + j> belongs to library lib<l>."""
+    text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (nm, ln) for nm, ln in contigs)
     if n_libs > 1:
-        text += "".join("@RG\tID:rg%d\tLB:lib%d\tSM:s\n" % (k, k) for k in range(n_libs))
-    order = [("pos", np.int32), ("flag", np.uint16), ("mapq", np.uint8), ("lib", np.int16), ("l_qseq", np.int32), ("n_cigar", np.uint32),
-             ("cigar_off", np.uint64), ("seq_off", np.uint64), ("qual_off", np.uint64), ("nm", np.int32), ("sm", np.int32), ("tags", np.uint8),
-             ("cigar", np.uint32), ("seq4", np.uint8), ("qual", np.uint8)]
-    keep = [np.ascontiguousarray(arrs[k], dt) for k, dt in order]
-    rc = L.brc_write_bam(path.encode(), text.encode(), contig.encode(), C.c_int32(contig_len), C.c_int64(len(arrs["pos"])), C.c_int32(n_libs),
-                         *[a.ctypes.data_as(C.c_void_p) for a in keep], C.c_int32(block_bytes), C.c_int32(level))
-    if rc != 0:
-        raise RuntimeError("brc_write_bam failed: %d" % rc)
+        text += "".join("@RG\tID:rg%d\tLB:lib%d\tSM:s\n" % (k, k // rgs_per_lib) for k in range(n_libs * rgs_per_lib))
+    return text
+
+
+class BamWriter:
+    """Multi-contig BAM + BAI written contig by contig (tools/bam_write.c): add(tid, arrays) in @SQ order, then close()."""
+
+    def __init__(self, path, contigs, n_libs=1, rgs_per_lib=1, block_bytes=60000, level=1):
+        self.L = C.CDLL(build_bamwrite())
+        self.L.brc_bamw_open.restype = C.c_void_p
+        names = (C.c_char_p * len(contigs))(*[nm.encode() for nm, _ in contigs])
+        lens = (C.c_int32 * len(contigs))(*[int(ln) for _, ln in contigs])
+        self.n_libs, self.rgs = n_libs, rgs_per_lib
+        self.h = self.L.brc_bamw_open(path.encode(), header_text(contigs, n_libs, rgs_per_lib).encode(), C.c_int32(len(contigs)), names, lens,
+                                      C.c_int32(block_bytes), C.c_int32(level))
+        if not self.h:
+            raise RuntimeError("cannot create %s" % path)
+
+    def add(self, tid, arrs):
+        keep = [np.ascontiguousarray(arrs[k], dt) for k, dt in _ORDER]
+        rc = self.L.brc_bamw_add(C.c_void_p(self.h), C.c_int32(tid), C.c_int64(len(arrs["pos"])), C.c_int32(self.n_libs), C.c_int32(self.rgs),
+                                 *[a.ctypes.data_as(C.c_void_p) for a in keep])
+        if rc != 0:
+            raise RuntimeError("brc_bamw_add failed: %d" % rc)
+
+    def close(self):
+        if self.h:
+            rc = self.L.brc_bamw_close(C.c_void_p(self.h)); self.h = None
+            if rc != 0:
+                raise RuntimeError("brc_bamw_close failed: %d" % rc)
+
+
+def write_bam(path, contig, contig_len, arrs, n_libs=1, block_bytes=60000, level=1, rgs_per_lib=1):
+    """Fast single-contig BAM + BAI of a brc_read_batch (tools/bam_write.c); libraries become @RG rg<k> with LB lib<k // rgs_per_lib>."""
+    w = BamWriter(path, [(contig, contig_len)], n_libs, rgs_per_lib, block_bytes, level)
+    w.add(0, arrs)
+    w.close()
+
+
+def write_fasta(path, contigs_with_ref, width=60):
+    """FASTA + .fai of [(name, uint8 array)]"""
+    fai = []
+    with open(path, "wb") as f:
+        off = 0
+        for name, ref in contigs_with_ref:
+            head = b">" + name.encode() + b"\n"
+            f.write(head); off += len(head)
+            n = len(ref); rows = (n + width - 1) // width
+            pad = np.full(rows * width, 10, np.uint8); pad[:n] = ref
+            body = np.concatenate([pad.reshape(rows, width), np.full((rows, 1), 10, np.uint8)], axis=1).reshape(-1)
+            # (the last line is short: drop its padding newlines but one)
+            last = n - (rows - 1) * width
+            body = body[:(rows - 1) * (width + 1) + last + 1].copy(); body[-1] = 10
+            f.write(body.tobytes())
+            fai.append("%s\t%d\t%d\t%d\t%d\n" % (name, n, off, width, width + 1))
+            off += len(body)
+    open(path + ".fai", "w").write("".join(fai))
 
 
 _lib = None
