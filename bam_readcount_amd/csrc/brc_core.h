@@ -80,7 +80,55 @@ struct DevCfg {
     int32_t flush_k;        // K: pieces a lane may accumulate in its packed integer registers between two flushes (1..127)
     uint32_t pack_lim;      // 65535 / max(K, HALF): largest per-read value a 16-bit packed field can take (PF_HUGE above it)
     int32_t max_lqseq;      // longest read of the batch (k_pileup2: a staged window further from its row than that belongs to a piece that only SPANS the tile)
+#ifdef BRC_CHECKED
+    void* chk;              // (bounds-checked fuzzing build only) the engine's ChkState in device memory
+#endif
 };
+
+// ---------------------------------------------------------------- the bounds-checked instantiation (-DBRC_CHECKED)
+//
+// csrc/Makefile builds libbrc_hip_checked.so from the same sources with -DBRC_CHECKED (a fuzzing build: never shipped, never
+// loaded by the product's callers).  In it every data-dependent device address of K1 and of k_pileup2 — the staged event-byte
+// windows, the scalar record loads two pieces ahead, rare records, wide-stream words, QUAL / SEQ / reference-code / CIGAR
+// windows, the event-byte and wide rows K1 writes, piece / key slots, plane, queue and list stores — is compared with the
+// extent its buffer was ALLOCATED FOR (the bytes the host asked for, not the rounded-up capacity).  A violation is counted,
+// the first one is recorded {kernel, site, buffer, address, bytes, unit = tile or read, piece}, and the access is redirected to
+// the buffer's first bytes; the host reads the record back after every pass and fails the call with it.  (No s_trap: a trapped
+// queue takes the record with it, and on a shared pool the box.)  Everywhere else BRC_CK is the pointer itself.
+enum ChkBuf { CB_CIGAR = 0, CB_SEQ, CB_QUAL, CB_REFCODE, CB_EB, CB_BQW, CB_PIECES, CB_RARE, CB_KEYREACH, CB_READS, CB_EVRAW, CB_CNT, CB_WANTED, CB_RNG,
+              CB_UNAVAIL, CB_TILELIST, CB_NCOL, CB_DEPTH, CB_SLOTID, CB_SI, CB_SF, CB_XEV, CB_XEVN, CB_TILECTR, CB_LDS_ROWS, CB_LDS_QUEUE, CB_N };
+enum ChkKernel { CK_ANNOTATE = 1, CK_PILEUP = 2 };
+struct ChkExt { uint64_t lo, hi; };
+struct ChkState { ChkExt ext[CB_N]; uint32_t count, kernel, site, buf; uint64_t addr, bytes; int64_t unit, piece; };
+#if defined(BRC_CHECKED) && defined(__HIPCC__)
+__host__ __device__ __forceinline__ uint64_t chk_range(void* state, uint32_t kernel, uint32_t site, uint32_t buf, uint64_t addr, uint64_t bytes, int64_t unit, int64_t piece) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    ChkState* st = (ChkState*)state;
+    const uint64_t lo = st->ext[buf].lo, hi = st->ext[buf].hi;
+    if (addr >= lo && addr + bytes <= hi && addr + bytes >= addr) return addr;
+    if (atomicAdd(&st->count, 1u) == 0u) { st->kernel = kernel; st->site = site; st->buf = buf; st->addr = addr; st->bytes = bytes; st->unit = unit; st->piece = piece; }
+    return lo;
+#else
+    (void)state; (void)kernel; (void)site; (void)buf; (void)bytes; (void)unit; (void)piece;
+    return addr;
+#endif
+}
+// pointer form: p itself when [p, p + bytes) lies inside buffer BUF, the buffer's start otherwise (recorded)
+#define BRC_CK(c, K, SITE, BUF, p, bytes, unit, piece) ((decltype((p) + 0))brc::chk_range((c).chk, (K), (SITE), (BUF), (uint64_t)(p), (uint64_t)(bytes), (int64_t)(unit), (int64_t)(piece)))
+// index form (LDS arrays, counters): idx itself when idx < n, 0 otherwise (recorded with the index as the address)
+#define BRC_CKI(c, K, SITE, BUF, idx, n, unit, piece) ((uint64_t)(idx) < (uint64_t)(n) ? (idx) : (brc::chk_fail_index((c).chk, (K), (SITE), (BUF), (uint64_t)(idx), (uint64_t)(n), (int64_t)(unit), (int64_t)(piece)), (decltype((idx) + 0))0))
+__host__ __device__ __forceinline__ void chk_fail_index(void* state, uint32_t kernel, uint32_t site, uint32_t buf, uint64_t idx, uint64_t n, int64_t unit, int64_t piece) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    ChkState* st = (ChkState*)state;
+    if (atomicAdd(&st->count, 1u) == 0u) { st->kernel = kernel; st->site = site; st->buf = buf; st->addr = idx; st->bytes = n; st->unit = unit; st->piece = piece; }
+#else
+    (void)state; (void)kernel; (void)site; (void)buf; (void)idx; (void)n; (void)unit; (void)piece;
+#endif
+}
+#else
+#define BRC_CK(c, K, SITE, BUF, p, bytes, unit, piece) (p)
+#define BRC_CKI(c, K, SITE, BUF, idx, n, unit, piece) (idx)
+#endif
 
 // Region inputs exactly as brc_read_batch lays them out (uploaded as-is; offsets rebased per region).
 struct DevIn {
@@ -241,11 +289,14 @@ BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i, uint8_t*
     const uint32_t flag = in.flag[i];
     const int32_t L = in.l_qseq[i];
     const uint32_t nc = in.n_cigar[i];
-    const uint32_t* cig = in.cigar + in.cig_off[i];
-    const uint8_t* seq = in.seq4 + in.seq_off[i];
-    const uint8_t* qual = in.qual + in.qual_off[i];
+    const uint32_t* cig = BRC_CK(c, CK_ANNOTATE, 20, CB_CIGAR, in.cigar + in.cig_off[i], 4ull * nc, i, -1);
+    const uint8_t* seq = BRC_CK(c, CK_ANNOTATE, 21, CB_SEQ, in.seq4 + in.seq_off[i], (uint64_t)((L + 1) / 2), i, -1);
+    const uint8_t* qual = BRC_CK(c, CK_ANNOTATE, 22, CB_QUAL, in.qual + in.qual_off[i], (uint64_t)(L > 0 ? L : 0), i, -1);
     const uint32_t mapq = in.mapq[i];
     const uint32_t tags = in.tags[i];
+    // (the rows this read writes: its event bytes, and — where an escape byte needs them — the wide words of whole 8-base groups)
+    (void)BRC_CK(c, CK_ANNOTATE, 23, CB_EB, eb_out + in.bq_row[i], (uint64_t)(L > 0 ? L : 0), i, -1);
+    (void)BRC_CK(c, CK_ANNOTATE, 24, CB_BQW, bqw_out + in.bq_row[i], 2ull * (uint64_t)(L > 0 ? L : 0), i, -1);
 
     uint32_t sum = 0;
     int left_clip = 0, clipped = L, right_clip = L;
@@ -744,6 +795,13 @@ BRC_HD void choose_pack(int32_t max_lqseq, int32_t k_override, int32_t lim_overr
 // (k_pileup2's BRC_STAGE states the same two lines in place; the simulator checks with this function that every window the device
 // would copy lies inside the padded stream — the fault on spliced alignments of round 4 was invisible to it before.)
 enum { EB_PAD_FRONT = 128, EB_PAD_BACK = 512, EB_WINDOW = 80 };
+// what the comments above promise, checked where the constants are defined: a window starts at most 95 bytes before a row (the
+// test below lets ws in [-96, max_lqseq + 16]; floor16 keeps it >= -80 for a piece that touches the tile) — inside the front pad;
+// a window that survives the test ends at most max_lqseq + 16 + 80 past the row's START, and the stream is allocated with
+// EB_PAD_BACK + max_lqseq behind its last row: 96 <= EB_PAD_BACK.  (brc_upload repeats the run-time half on its own numbers.)
+static_assert(EB_PAD_FRONT >= 96 + 16, "a staged window may start 96 bytes before the stream's first row");
+static_assert(EB_PAD_BACK >= 16 + EB_WINDOW + 16, "a staged window of the last row ends inside the back pad");
+static_assert(EB_WINDOW == 80 && TILE + 15 < EB_WINDOW, "64 tile positions + 15 bytes of alignment fit a window");
 BRC_HD int32_t stage_window_start(int32_t p0, int32_t a, int32_t max_lqseq) {
     int32_t ws = (p0 - a) & ~15;
     if ((uint32_t)(ws + 96) > (uint32_t)max_lqseq + 96u + 16u) ws = 0;
@@ -780,7 +838,7 @@ BRC_HD uint32_t pack_field(const PackAcc& a, uint32_t b, int f) {
 }
 // packed registers -> the integer planes of one slot (adds when the tile has flushed before), registers reset; b = the slot's index (eb_index)
 BRC_HD void flush_slot(const DevCfg& c, const Planes& pl, int lib, int64_t k, PackAcc& a, uint32_t slot, uint32_t b, bool live) {
-    uint32_t* ip = slot_i(c, pl, lib, slot, k);
+    uint32_t* ip = BRC_CK(c, CK_PILEUP, 40, CB_SI, slot_i(c, pl, lib, slot, k), ((uint64_t)(NI - 1) * (uint64_t)c.PS + 1u) * 4u, k, -1);
     BRC_NOUNROLL
     for (int f = 0; f < NI; ++f) { const uint32_t v = pack_field(a, b, f); ip[(int64_t)f * c.PS] = v + (live ? ip[(int64_t)f * c.PS] : 0u); }
     a.w1 = a.w2 = a.w3 = a.sw = 0;
@@ -804,7 +862,7 @@ BRC_HD XEv make_xev(const DevCfg& c, int lib, int64_t k, const Piece& h, const P
 // the integers of a PF_HUGE piece that its packed addends left out, for a lane whose event went to `slot` (the slot planes
 // are live: the caller flushed)
 BRC_HD void drain_int(const DevCfg& c, const Planes& pl, int lib, int64_t k, const PieceRare& rare, uint32_t slot) {
-    uint32_t* ip = slot_i(c, pl, lib, slot, k);
+    uint32_t* ip = BRC_CK(c, CK_PILEUP, 41, CB_SI, slot_i(c, pl, lib, slot, k), ((uint64_t)(NI - 1) * (uint64_t)c.PS + 1u) * 4u, k, -1);
     ip[(int64_t)I_SSE * c.PS] += rare.sse_raw; ip[(int64_t)I_SMMQ * c.PS] += rare.zm_raw; ip[(int64_t)I_SCLIP * c.PS] += piece_clipped(rare);
 }
 // end of the tile (reference statement; the kernel stores the same values with coalesced selects)

@@ -61,6 +61,19 @@ struct Counters {
 
 // ---------------------------------------------------------------- wave helpers (wave64)
 
+// BRC_CKS: BRC_CK for an address that feeds a scalar load (inline assembly, "s" constraint).  The checked pointer comes out of a
+// per-lane comparison, so the compiler keeps it in vector registers: it is made wave-uniform again (it is: every lane checked
+// the same address).  Outside the checked build: the pointer itself.
+#ifdef BRC_CHECKED
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const uint64_t v = (uint64_t)p;
+    return (const char*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
+}
+#define BRC_CKS(c, K, SITE, BUF, p, bytes, unit, piece) uniform_ptr(BRC_CK(c, K, SITE, BUF, p, bytes, unit, piece))
+#else
+#define BRC_CKS(c, K, SITE, BUF, p, bytes, unit, piece) (p)
+#endif
+
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -198,8 +211,14 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
     int n_m = 0; int32_t m1lo = 0, m1hi = 0, m2lo = 0, m2hi = 0; int64_t d1 = 0, d2 = 0;
     {
         int rs = 0; int64_t x = pos;                     // the annotator's read / reference cursors (bamreadcount.cpp:133-198)
+#ifdef BRC_CHECKED
+        const uint32_t* const cig_row = BRC_CK(c, CK_ANNOTATE, 1, CB_CIGAR, cigar_ro + coff, 4ull * nc, my, -1);
+#define BRC_CIG_AT(k) cig_row[k]
+#else
+#define BRC_CIG_AT(k) cigar_ro[coff + (k)]
+#endif
         for (uint32_t k = 0; k < nc; ++k) {
-            const uint32_t cg = cigar_ro[coff + k];
+            const uint32_t cg = BRC_CIG_AT(k);
             if (k == 0) cig0 = cg;
             const uint32_t op = cg & 0xfu; const int len = (int)(cg >> 4);
             shape_add(shape, op, len);
@@ -215,6 +234,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
             } else if (op == CDEL || op == CREF_SKIP) x += len;
             else if (op == CINS || op == CSOFT_CLIP) rs += len;
         }
+#undef BRC_CIG_AT
     }
     const bool simple = nc == 1 && (cig0 & 0xfu) == CMATCH;
     bool dropped = (flag & BRC_PUSH_MASK) != 0;
@@ -287,12 +307,12 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
             F.b = G < T ? (int32_t)((G - Pb.x) << 3) : 0;               // idle lanes of the last pass stay inside their read
             // (wave-uniform base + 32-bit lane offset: the scalar-base addressing form, no 64-bit vector arithmetic.  Non-temporal
             // LOADS of QUAL / SEQ — read exactly once — were measured: K1 +6 %)
-            __builtin_memcpy(&F.Q, qwave + (uint32_t)(Pa.y + (uint32_t)F.b), 8);
-            __builtin_memcpy(&F.S, swave + (uint32_t)(Pa.z + ((uint32_t)F.b >> 1)), 4);
+            __builtin_memcpy(&F.Q, BRC_CK(c, CK_ANNOTATE, 2, CB_QUAL, qwave + (uint32_t)(Pa.y + (uint32_t)F.b), 8, rb + F.jr, F.b), 8);
+            __builtin_memcpy(&F.S, BRC_CK(c, CK_ANNOTATE, 3, CB_SEQ, swave + (uint32_t)(Pa.z + ((uint32_t)F.b >> 1)), 4, rb + F.jr, F.b), 4);
             // reference codes under the first M operator (a window outside the slice: any in-bounds window, its bytes are masked)
             int64_t r1off = (int64_t)F.b + (int32_t)Pb.w;
             if (r1off < -8 || r1off > ref_n) r1off = 0;
-            __builtin_memcpy(&F.R1, refpad + (uint32_t)((int32_t)r1off + REFCODE_PAD), 8);
+            __builtin_memcpy(&F.R1, BRC_CK(c, CK_ANNOTATE, 4, CB_REFCODE, refpad + (uint32_t)((int32_t)r1off + REFCODE_PAD), 8, rb + F.jr, F.b), 8);
             return F;
         };
         if (BRC_AVAR(3)) T = 0;
@@ -339,7 +359,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
             if (__ballot(f2 != 0ull)) {                                       // bases of a second M operator (after an indel)
                 int64_t r2off = (int64_t)b + (int32_t)P.c.z;
                 if (!f2 || r2off < -8 || r2off > ref_n) r2off = 0;
-                uint2 R2; __builtin_memcpy(&R2, refpad + (uint32_t)((int32_t)r2off + REFCODE_PAD), 8);
+                uint2 R2; __builtin_memcpy(&R2, BRC_CK(c, CK_ANNOTATE, 5, CB_REFCODE, refpad + (uint32_t)((int32_t)r2off + REFCODE_PAD), 8, rb + jr, b), 8);
                 const uint32_t rx = R2.x & 0x0f0f0f0fu, ry = R2.y & 0x0f0f0f0fu;
                 mm.x |= nzb7(N.x ^ rx) & nzb7(rx ^ 0x0f0f0f0fu) & nzb7(N.x) & (uint32_t)f2;
                 mm.y |= nzb7(N.y ^ ry) & nzb7(ry ^ 0x0f0f0f0fu) & nzb7(N.y) & (uint32_t)(f2 >> 32);
@@ -388,14 +408,14 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
                     uint4 out;
                     out.x = __builtin_amdgcn_perm(Q.x, Bx, 0x05010400u); out.y = __builtin_amdgcn_perm(Q.x, Bx, 0x07030602u);
                     out.z = __builtin_amdgcn_perm(Q.y, By, 0x05010400u); out.w = __builtin_amdgcn_perm(Q.y, By, 0x07030602u);
-                    *reinterpret_cast<uint4*>(bqw + ((((uint64_t)P.c.w) << 32) | (uint64_t)P.a.w) + (uint32_t)b) = out;
+                    *reinterpret_cast<uint4*>(BRC_CK(c, CK_ANNOTATE, 6, CB_BQW, bqw + ((((uint64_t)P.c.w) << 32) | (uint64_t)P.a.w) + (uint32_t)b, 16, rb + jr, b)) = out;
                     atomicOr(&W.wide[jr], 1u);
                 }
                 // (rows are 16-byte aligned; written once here, read by k_pileup2 a kernel later.  With ONE stream of rows — no
                 // per-library layout — the wave's stores run on through memory and the non-temporal hint pays; with four
                 // library-major streams it costs 2-8 %: measured, profiles/r03_ab_09)
                 typedef uint32_t u32x2s __attribute__((ext_vector_type(2)));
-                u32x2s* dst = reinterpret_cast<u32x2s*>(eb + ((((uint64_t)P.c.w) << 32) | (uint64_t)P.a.w) + (uint32_t)b);
+                u32x2s* dst = reinterpret_cast<u32x2s*>(BRC_CK(c, CK_ANNOTATE, 7, CB_EB, eb + ((((uint64_t)P.c.w) << 32) | (uint64_t)P.a.w) + (uint32_t)b, 8, rb + jr, b));
                 const u32x2s val = {E.x, E.y};
                 if (one_stream) __builtin_nontemporal_store(val, dst); else *dst = val;
             }
@@ -470,7 +490,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
     const uint32_t cig1_l = nc > 1u ? cigar_ro[coff + 1u] : 0u, cig2_l = nc > 2u ? cigar_ro[coff + 2u] : 0u;
     const bool q2_pre = work_me && L >= 8;             // the 8 qualities at the read's 3' end: as a rule all the Q2 scan needs
     unsigned long long q2_w0 = 0ull;
-    if (q2_pre) __builtin_memcpy(&q2_w0, qual_ro + qoff + ((flag & FREVERSE) ? 0 : L - 8), 8);
+    if (q2_pre) __builtin_memcpy(&q2_w0, BRC_CK(c, CK_ANNOTATE, 8, CB_QUAL, qual_ro + qoff + ((flag & FREVERSE) ? 0 : L - 8), 8, my, -1), 8);
     DRead r;
     bool serial = fallback;
     bool wide = work_me && W.wide[rank] != 0u;        // an escape byte in the read's row
@@ -480,7 +500,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
         my_sum = W.sum[rank];
         // first / last base with quality != 2, whichever the strand needs (:201-238): a scan from the read's 3' end, 8 bases
         // per load (as a rule the first load decides)
-        const uint8_t* q = qual_ro + qoff;
+        const uint8_t* q = BRC_CK(c, CK_ANNOTATE, 9, CB_QUAL, qual_ro + qoff, (uint64_t)L, my, -1);       // (the scan below stays inside [0, L))
         if (flag & FREVERSE) {
             for (int k = 0; k < L && my_lo < 0; k += 8) {
                 unsigned long long w; const int nv = L - k < 8 ? L - k : 8;
@@ -521,14 +541,14 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
         r.misc = finish_misc(misc, c.table_len > 0 && L == c.table_len && clipped == L, shape_clipm(shape, nc, left_clip)); r.l_qseq = L; r.q2 = q2; r.tp = tp; r.left = left_clip; r.clipped = clipped;
         r.zm_sum = my_sum; r.sse_add = sse; r.snm_add = snm; r.clipped_dup = clipped;
     }
-    if (nc >= 2u) reads[my] = r;          // only the indel side path reads these records, and only for reads with an indel operator
+    if (nc >= 2u) *BRC_CK(c, CK_ANNOTATE, 10, CB_READS, reads + my, sizeof(DRead), my, -1) = r;          // only the indel side path reads these records, and only for reads with an indel operator
     // The read's first three operators in registers for the two walks below (loaded at the start of the phase; the
     // first operator is still there from phase A): each cig[k] from memory inside a walk is a dependent round trip for the whole wave.
     struct CigRegs {
         uint32_t c0, c1, c2; const uint32_t* p;
         __device__ __forceinline__ uint32_t operator()(uint32_t k) const { return k == 0u ? c0 : k == 1u ? c1 : k == 2u ? c2 : p[k]; }
     } cigr;
-    cigr.p = cigar_ro + coff; cigr.c0 = cig0;
+    cigr.p = BRC_CK(c, CK_ANNOTATE, 11, CB_CIGAR, cigar_ro + coff, 4ull * nc, my, -1); cigr.c0 = cig0;
     cigr.c1 = cig1_l; cigr.c2 = cig2_l;
     {   // the read's pieces (the host counted them with the same walk_pieces: piece_off[] are their slots)
         const bool nolib = c.per_lib && lib_l < 0;
@@ -540,11 +560,12 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
             make_piece(c, rc, rs, len, ext, qoff, nb, h, rr);
             if (!BRC_AVAR(2)) {
                 typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
-                const u32x4s* hs = reinterpret_cast<const u32x4s*>(&h); u32x4s* hd = reinterpret_cast<u32x4s*>(pieces + slot);
+                Piece* const pdst = BRC_CK(c, CK_ANNOTATE, 12, CB_PIECES, pieces + slot, sizeof(Piece), my, slot);
+                const u32x4s* hs = reinterpret_cast<const u32x4s*>(&h); u32x4s* hd = reinterpret_cast<u32x4s*>(pdst);
                 if (one_stream) { __builtin_nontemporal_store(hs[0], hd); __builtin_nontemporal_store(hs[1], hd + 1); __builtin_nontemporal_store(hs[2], hd + 2); }
-                else pieces[slot] = h;
-                if (piece_has_rare(piece_flags(h))) rare[slot] = rr;
-                keyreach[slot] = make_int2(pos, rs + ext);
+                else *pdst = h;
+                if (piece_has_rare(piece_flags(h))) *BRC_CK(c, CK_ANNOTATE, 13, CB_RARE, rare + slot, sizeof(PieceRare), my, slot) = rr;
+                *BRC_CK(c, CK_ANNOTATE, 14, CB_KEYREACH, keyreach + slot, sizeof(int2), my, slot) = make_int2(pos, rs + ext);
             }
             ++slot;
         });
@@ -554,11 +575,11 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
         // counted one slot per I / D / P operator: no cursor, no atomics on the list) and counted per (16 or 64 positions, library) bucket;
         // slots the read does not use are marked empty
         const int lib = (int)((r.misc >> 16) & 0xffu) - 1;
-        IndelEv* slot = ev_raw + in.iev_off[my]; uint32_t used = 0;
+        IndelEv* slot = BRC_CK(c, CK_ANNOTATE, 15, CB_EVRAW, ev_raw + in.iev_off[my], sizeof(IndelEv) * (uint64_t)n_idp, my, -1); uint32_t used = 0;
         enumerate_indels_at(c, cigr, r, qual_ro + qoff, [&](int32_t p, int qpos, int len) {
             IndelEv e; e.read = (uint32_t)my; e.qpos = qpos; e.len = len; e.key_lo = (uint32_t)((int64_t)(p - c.pos0) * c.Lp + lib);   // (keys fit 32 bits: checked at upload)
-            if (wanted && !tile_wants(wanted[(uint32_t)(p - c.pos0) >> 6], (uint32_t)(p - c.pos0) & 63u)) return;       // what no announced window touches comes back empty: no indel alleles either
-            if (used < n_idp) { slot[used++] = e; atomicAdd(&bucket_cnt[indel_bucket_of(c, (uint32_t)(p - c.pos0), (uint32_t)lib)], 1u); }
+            if (wanted && !tile_wants(*BRC_CK(c, CK_ANNOTATE, 16, CB_WANTED, wanted + ((uint32_t)(p - c.pos0) >> 6), 2, my, p), (uint32_t)(p - c.pos0) & 63u)) return;       // what no announced window touches comes back empty: no indel alleles either
+            if (used < n_idp) { slot[used++] = e; atomicAdd(BRC_CK(c, CK_ANNOTATE, 17, CB_CNT, bucket_cnt + indel_bucket_of(c, (uint32_t)(p - c.pos0), (uint32_t)lib), 4, my, p), 1u); }
         });
         for (; used < n_idp; ++used) slot[used].key_lo = NONE32;
     }
@@ -846,7 +867,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 struct PRec { u32x8 f; u32x2 g; };
 
 // One wave = one (64-position tile, library); lane == position.  The wave walks the tile's pieces [lo, hi) of its library
-// in stream (= pileup column) order, in half-batches of HALF = 6:
+// in stream (= pileup column) order, in half-batches of HALF = 12 (brc_core.h: BRC_HALF):
 //  * piece records: the 40 bytes every piece needs arrive by two scalar loads, two pieces ahead, rotating through three
 //    scalar register sets — everything wave-uniform (positions, lengths, packed addends) lives in SGPRs.  The loads are
 //    inline assembly so that they are issued exactly there (the scheduler sinks compiler-visible loads to their first use);
@@ -906,18 +927,18 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
     // (brc_region_windows: the launch covers the list of announced tiles, not the region)
     const int64_t slot = (int64_t)wg * PILEUP_WAVES + wv;
     if (slot >= (WINDOWS ? n_listed : ntiles)) return;
-    const int64_t tile = WINDOWS ? (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)tile_list[slot]) : slot;
+    const int64_t tile = WINDOWS ? (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)*BRC_CK(c, CK_PILEUP, 1, CB_TILELIST, tile_list + slot, 4, slot, -1)) : slot;
     const int lib = blockIdx.y;
-    const uint2 r2 = rng[(int64_t)lib * ntiles + tile];
+    const uint2 r2 = *BRC_CK(c, CK_PILEUP, 2, CB_RNG, rng + ((int64_t)lib * ntiles + tile), sizeof(uint2), tile, -1);
     const uint32_t lo = __builtin_amdgcn_readfirstlane(r2.x), hi = __builtin_amdgcn_readfirstlane(r2.y);
     const int64_t k = tile * TILE + lane;
     const bool inreg = k < c.P;
     const int64_t kk = inreg ? k : 0;
     // a position abandoned for a library-less read (:281-284) accumulates nothing: it behaves like a lane outside the region
-    const bool dead = c.per_lib && inreg && unavail_ro[kk] != NONE32;
+    const bool dead = c.per_lib && inreg && *BRC_CK(c, CK_PILEUP, 3, CB_UNAVAIL, unavail_ro + kk, 4, tile, -1) != NONE32;
     // (brc_region_windows: the lanes no window asks for behave like lanes outside the region — k_narrow_tiles has trimmed the tile's
     // piece range to what reaches the others)
-    const bool valid = inreg && !dead && (!WINDOWS || tile_wants(wanted_ro[tile], (uint32_t)lane));
+    const bool valid = inreg && !dead && (!WINDOWS || tile_wants(*BRC_CK(c, CK_PILEUP, 4, CB_WANTED, wanted_ro + tile, 2, tile, -1), (uint32_t)lane));
     const int32_t p = (int32_t)(c.pos0 + k);
     const int32_t p0 = (int32_t)(c.pos0 + tile * TILE);                     // first position of the tile (scalar)
 
@@ -928,7 +949,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         uint32_t dom = 1u;
         if (c.has_ref && valid) {
             const int64_t ri = (int64_t)p - c.ref_lo;
-            dom = (ri >= -(int64_t)REFCODE_PAD && ri < c.ref_hi - c.ref_lo + (int64_t)REFCODE_PAD) ? canon_bucket(refcode[ri] & 15u) : 5u;
+            dom = (ri >= -(int64_t)REFCODE_PAD && ri < c.ref_hi - c.ref_lo + (int64_t)REFCODE_PAD) ? canon_bucket(*BRC_CK(c, CK_PILEUP, 5, CB_REFCODE, refcode + ri, 1, tile, -1) & 15u) : 5u;
         }
         lane2_init(a, c.force_dom >= 0 ? (uint32_t)c.force_dom : dom);
     }
@@ -969,8 +990,8 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         // ... and, by the first lane of every row, one dword of its hot record: nothing uses the value — the load pulls the
         // record's cache line into L2 a half-batch before the scalar loads of the read loop ask for it (their own look-ahead
         // of two pieces covers an L2 hit, not an HBM miss)
-#define BRC_LD_TAB(T, b0) { const uint32_t mi = (b0) + srow < hi ? (b0) + srow : hi - 1u; T = pieces4[(size_t)mi * 3u + 2u];   /* {ww, a, bq_off} */ \
-                            asm volatile("" :: "v"(pf)); if (schunk == 0u) pf = pieces4[(size_t)mi * 3u].x; }
+#define BRC_LD_TAB(T, b0) { const uint32_t mi = (b0) + srow < hi ? (b0) + srow : hi - 1u; T = *BRC_CK(c, CK_PILEUP, 6, CB_PIECES, pieces4 + ((size_t)mi * 3u + 2u), 16, tile, mi);   /* {ww, a, bq_off} */ \
+                            asm volatile("" :: "v"(pf)); if (schunk == 0u) pf = BRC_CK(c, CK_PILEUP, 7, CB_PIECES, pieces4 + (size_t)mi * 3u, 16, tile, mi)->x; }
         // window copy of the half-batch starting at piece b0 into the ring half at byte offset hoff: element window
         // [ws, ws + 80) of the row, ws = floor16(p0 - a) (may start before the row: the event-byte stream is padded)
 #define BRC_STAGE(T, b0, hoff)                                                                                           \
@@ -982,7 +1003,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                    window anywhere — 100 kb from its row, before the stream or past its end; no lane will read the copy: take    \
                    the row's first bytes instead (round 4: a memory fault on spliced alignments, tools/fuzz/extreme.py) */      \
                 if ((uint32_t)(ws + 96) > win_span) ws = 0;                                                               \
-                const uint8_t* src = eb_ro + (boff + ws) + 16u * schunk;                                                  \
+                const uint8_t* src = BRC_CK(c, CK_PILEUP, 8, CB_EB, eb_ro + (boff + ws) + 16u * schunk, 16, tile, (b0) + srow);   \
                 __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,                      \
                     (void __attribute__((address_space(3)))*)(rows_base + (hoff)), 16, 0, 0);                             \
             }                                                                                                             \
@@ -1000,7 +1021,14 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
 #define BRC_G_R1 "{s[66:67]}"
 #define BRC_F_R2 "{s[76:83]}"
 #define BRC_G_R2 "{s[84:85]}"
+#ifdef BRC_CHECKED
+        // (checked build: the address is compared first, and the load waits for itself — the registers are valid when the statement
+        // ends, so this build does not depend on what the compiler does between a load and its wait and needs no ISA check)
+#define BRC_LD_REC(R, rp) { const char* rpc = BRC_CKS(c, CK_PILEUP, 9, CB_PIECES, (rp), 40, tile, ((rp) - reinterpret_cast<const char*>(pieces4)) / 48); \
+                            asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=" BRC_F_##R (R.f), "=" BRC_G_##R (R.g) : "s"(rpc)); }
+#else
 #define BRC_LD_REC(R, rp) asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x20" : "=" BRC_F_##R (R.f), "=" BRC_G_##R (R.g) : "s"(rp));
+#endif
 #define BRC_WAIT_REC(R) asm volatile("s_waitcnt lgkmcnt(0)" : "+" BRC_F_##R (R.f), "+" BRC_G_##R (R.g));
         // the division constants of piece m (its rare record) by scalar loads, on demand: only the few pieces that neither look
         // their terms up nor divide them out from their own record (PF_DIV) — reads longer than 255 bases, a Q2 position of its own.
@@ -1009,7 +1037,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
 #define BRC_LD_DIV(H, R, m)                                                                                             \
         {                                                                                                                 \
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));                                                   \
-            u32x4 dA; u32x2 dB; const char* dp = reinterpret_cast<const char*>(rare) + (size_t)(m) * 32u;                 \
+            u32x4 dA; u32x2 dB; const char* dp = BRC_CKS(c, CK_PILEUP, 10, CB_RARE, reinterpret_cast<const char*>(rare) + (size_t)(m) * 32u, 24, tile, (m)); \
             asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x10\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dA), "=&s"(dB) : "s"(dp)); \
             H.rcpL = __uint_as_float(dA[0]); H.Lf = __uint_as_float(dA[1]); H.rcpC = __uint_as_float(dA[2]);              \
             H.center = __uint_as_float(dA[3]); H.left = (int32_t)dB[0]; H.q2 = (int32_t)dB[1]; H.zm_raw = 0u; H.sse_raw = 0u; \
@@ -1025,7 +1053,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
             S.m_cov = __builtin_amdgcn_ballot_w64(d < R.f[2]);   /* counted in the accumulate stage: a probe may run past the tile's last piece */ \
             S.m_in = __builtin_amdgcn_ballot_w64(d < R.f[1]);                                                             \
             const uint32_t off = (uint32_t)(roff) + ((uint32_t)S.s_c & 15u);                                              \
-            S.w = (uint32_t)*reinterpret_cast<const uint8_t*>(rows_base + ((uint32_t)lane + off));                        \
+            S.w = (uint32_t)*reinterpret_cast<const uint8_t*>(rows_base + BRC_CKI(c, CK_PILEUP, 11, CB_LDS_ROWS, (uint32_t)lane + off, 2u * HALF * ROW_BYTES, tile, -1)); \
             /* (scalar) the lane-independent side of both table addresses: the second is the record's signed distance away from the first */ \
             const uint32_t eoff = cb - ((uint32_t)S.s_c << 4), qoff16 = eoff + (uint32_t)piece_tp_field(R.f[3]);          \
             if (BRC_EXP == 2) { S.t = 0.5f; S.sev = 0.25; } else {     /* (2: timing only, no table look-ups) */                 \
@@ -1072,7 +1100,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         // ACC of the piece in R (S = its probe results), piece index m
         // (the entry's kind is materialised by an instruction of its own: left to the allocator, the two constants live in a
         // register pair across the whole read loop and are spilled to scratch around every push)
-#define BRC_QPUSH(mm, kd, mask) { if (BRC_LANE() == 0) { uint32_t kq; asm volatile("v_mov_b32 %0, %1" : "=v"(kq) : "n"(kd)); QEnt e; e.piece = (mm); e.kind = kq; e.mlo = (uint32_t)(mask); e.mhi = (uint32_t)((mask) >> 32); queue[qn] = e; } ++qn; }
+#define BRC_QPUSH(mm, kd, mask) { if (BRC_LANE() == 0) { uint32_t kq; asm volatile("v_mov_b32 %0, %1" : "=v"(kq) : "n"(kd)); QEnt e; e.piece = (mm); e.kind = kq; e.mlo = (uint32_t)(mask); e.mhi = (uint32_t)((mask) >> 32); queue[BRC_CKI(c, CK_PILEUP, 12, CB_LDS_QUEUE, qn, (uint32_t)QCAP, tile, (mm))] = e; } ++qn; }
 #define BRC_ACC(R, S, m)                                                                                                \
         {                                                                                                                 \
             const uint32_t fl = BRC_EXP == 6 ? (uint32_t)(PF_TABLE | PF_Q2OK) : BRC_EXP == 7 ? ((R.f[3] >> 24) | (uint32_t)PF_TABLE) :   \
@@ -1094,13 +1122,14 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                                base goes to the third-allele list whatever the lane's slots hold */                       \
                             const uint64_t m_esc = m_b & __builtin_amdgcn_ballot_w64(eb_is_escape(S.w));                  \
                             if (m_esc) {                                                                                  \
-                                u32x2 bo; const char* bp = reinterpret_cast<const char*>(pieces4) + (size_t)(m) * 48u;    \
+                                u32x2 bo; const char* bp = BRC_CKS(c, CK_PILEUP, 13, CB_PIECES, reinterpret_cast<const char*>(pieces4) + (size_t)(m) * 48u, 48, tile, (m)); \
                                 asm volatile("s_load_dwordx2 %0, %1, 0x28\n\ts_waitcnt lgkmcnt(0)" : "=&s"(bo) : "s"(bp)); \
                                 /* (scalar base + 32-bit lane offset: no 64-bit vector address in this rare path's register budget) */ \
                                 const uint16_t* wrow = bqw_ro + (int64_t)(((uint64_t)bo[1] << 32) | bo[0]);               \
                                 bool exo = false;                                                                         \
                                 if (__builtin_amdgcn_inverse_ballot_w64(m_esc)) {                                         \
                                     uint32_t w16; const uint32_t wv = ((uint32_t)BRC_LANE() + (uint32_t)S.s_c) << 1;      \
+                                    (void)BRC_CK(c, CK_PILEUP, 14, CB_BQW, reinterpret_cast<const char*>(wrow) + wv, 2, tile, (m)); \
                                     asm volatile("global_load_ushort %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(w16) : "v"(wv), "s"(wrow) : "memory"); \
                                     exo = !bucket_acgt(w16 & 0xffu);                                                      \
                                     if (exo) a.ww += R.g[0]; else S.w = ((w16 >> 8) << 2) | ((w16 & 0xffu) - 1u);         \
@@ -1188,6 +1217,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
             since_flush += (int32_t)(nbv);                                                                                \
             if (__builtin_expect(qn != 0u, 0)) {                                                                          \
                 for (uint32_t e = 0; e < qn; ++e) {                                                                       \
+                    (void)BRC_CKI(c, CK_PILEUP, 21, CB_LDS_QUEUE, e, (uint32_t)QCAP, tile, -1);                           \
                     const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane(queue[e].piece), kind = (uint32_t)__builtin_amdgcn_readfirstlane(queue[e].kind); \
                     /* (readfirstlane returns int: without the casts a set bit 31 of the low half would sign-extend) */  \
                     const uint64_t mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(queue[e].mhi) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(queue[e].mlo); \
@@ -1195,13 +1225,13 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                     {   /* the piece into scalar registers; its rare record likewise when K1 stored one, derived otherwise */ \
                         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));                                       \
                         u32x8 hf; u32x4 hg;                                                                               \
-                        const char* hp = reinterpret_cast<const char*>(pieces4) + (size_t)m * 48u;                        \
+                        const char* hp = BRC_CKS(c, CK_PILEUP, 15, CB_PIECES, reinterpret_cast<const char*>(pieces4) + (size_t)m * 48u, 48, tile, m); \
                         asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(hf), "=&s"(hg) : "s"(hp)); \
                         H.rs = (int32_t)hf[0]; H.len = (int32_t)hf[1]; H.ext = (int32_t)hf[2]; H.tp_flags = hf[3];       \
                         H.w1 = hf[4]; H.w2 = hf[5]; H.w3 = hf[6]; H.snm = __uint_as_float(hf[7]); H.ww = hg[0]; H.a = (int32_t)hg[1]; \
                         H.bq_off = ((uint64_t)hg[3] << 32) | hg[2];                                                       \
                         if (piece_has_rare(H.tp_flags >> 24)) {                                                           \
-                            u32x8 rf; const char* rp = reinterpret_cast<const char*>(rare) + (size_t)m * 32u;             \
+                            u32x8 rf; const char* rp = BRC_CKS(c, CK_PILEUP, 16, CB_RARE, reinterpret_cast<const char*>(rare) + (size_t)m * 32u, 32, tile, m); \
                             asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(rf) : "s"(rp));    \
                             RR.rcpL = __uint_as_float(rf[0]); RR.Lf = __uint_as_float(rf[1]); RR.rcpC = __uint_as_float(rf[2]); RR.center = __uint_as_float(rf[3]); \
                             RR.left = (int32_t)rf[4]; RR.q2 = (int32_t)rf[5]; RR.zm_raw = rf[6]; RR.sse_raw = rf[7];      \
@@ -1214,19 +1244,19 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                     const bool mine = ((mask >> lr) & 1ull) != 0ull;                                                      \
                     const int32_t s_c = p0 - H.a;                                                                         \
                     const uint32_t off = hoff + (m - base) * (uint32_t)ROW_BYTES + ((uint32_t)s_c & 15u);                 \
-                    const uint32_t w = (uint32_t)*reinterpret_cast<const uint8_t*>(rows_base + off + (uint32_t)lr);        \
+                    const uint32_t w = (uint32_t)*reinterpret_cast<const uint8_t*>(rows_base + BRC_CKI(c, CK_PILEUP, 17, CB_LDS_ROWS, off + (uint32_t)lr, 2u * HALF * ROW_BYTES, tile, m)); \
                     /* the lane's quality and bucket: from its event byte, or — an escape byte of a wide read — from the wide stream */ \
                     uint32_t eq = w >> 2, ebk = (w & 3u) + 1u;                                                            \
                     if (((H.tp_flags >> 24) & PF_WIDE) && mine && eb_is_escape(w)) {                                      \
-                        const uint32_t w16 = bqw_ro[(int64_t)H.bq_off + (int64_t)(lr + s_c)]; eq = w16 >> 8; ebk = w16 & 0xffu; \
+                        const uint32_t w16 = *BRC_CK(c, CK_PILEUP, 18, CB_BQW, bqw_ro + ((int64_t)H.bq_off + (int64_t)(lr + s_c)), 2, tile, m); eq = w16 >> 8; ebk = w16 & 0xffu; \
                     }                                                                                                     \
                     if (kind == 0u) {                          /* third alleles: raw addends to the list, in piece order */ \
                         uint32_t at0 = 0;                                                                                 \
-                        if (lr == 0 && !BRC_PVAR(11)) at0 = atomicAdd(pl.xev_n + (size_t)xshard * XEV_CTR_STRIDE, (uint32_t)__builtin_popcountll(mask)); /* (11: profiling, no list cursor) */ \
+                        if (lr == 0 && !BRC_PVAR(11)) at0 = atomicAdd(BRC_CK(c, CK_PILEUP, 19, CB_XEVN, pl.xev_n + (size_t)xshard * XEV_CTR_STRIDE, 4, tile, m), (uint32_t)__builtin_popcountll(mask)); /* (11: profiling, no list cursor) */ \
                         at0 = (uint32_t)__builtin_amdgcn_readfirstlane(at0);                                              \
                         const uint64_t below = mask & ((1ull << lr) - 1ull);                                              \
                         const uint32_t at = at0 + (uint32_t)__builtin_popcountll(below);                                  \
-                        if (mine && at < pl.xev_cap) pl.xev[(size_t)xshard * pl.xev_cap + at] = make_xev(c, lib, kr, H, RR, lr + s_c, eq, ebk); \
+                        if (mine && at < pl.xev_cap) *BRC_CK(c, CK_PILEUP, 20, CB_XEV, pl.xev + ((size_t)xshard * pl.xev_cap + at), sizeof(XEv), tile, m) = make_xev(c, lib, kr, H, RR, lr + s_c, eq, ebk); \
                     } else if (mine) drain_int(c, pl, lib, kr, RR, ebk == BRC_DOM_B() ? 0u : 1u);                         \
                 }                                                                                                         \
                 qn = 0;                                                                                                   \
@@ -1315,12 +1345,15 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
 #define BRC_ST(base, val) asm volatile("global_store_dword %0, %1, %2 nt" :: "v"(loff), "v"(val), "s"(base) : "memory")   /* (written once per step, read by nobody on the device: streaming) */
         a.dom_b = BRC_DOM_B();
         const uint32_t sid = a.dom_b | (a.alt_b << 8);
-        { const uint32_t* q = pl.ncol + (int64_t)lib * P + tb; BRC_ST(q, a.ncol); }       // (dead lanes accumulated nothing: zeros)
-        { const uint32_t* q = pl.depth + (int64_t)lib * P + tb; BRC_ST(q, a.depth); }
-        { const uint32_t* q = pl.slotid + (int64_t)lib * P + tb; BRC_ST(q, sid); }
+        // (checked build: the wave's 256-byte segment of every plane — stores are coalesced, lane == position, so the segment of
+        // the tile is what each of the 29 store instructions may touch)
+        { const uint32_t* q = (const uint32_t*)BRC_CKS(c, CK_PILEUP, 22, CB_NCOL, reinterpret_cast<const char*>(pl.ncol + (int64_t)lib * P + tb), 256, tile, -1); BRC_ST(q, a.ncol); }       // (dead lanes accumulated nothing: zeros)
+        { const uint32_t* q = (const uint32_t*)BRC_CKS(c, CK_PILEUP, 23, CB_DEPTH, reinterpret_cast<const char*>(pl.depth + (int64_t)lib * P + tb), 256, tile, -1); BRC_ST(q, a.depth); }
+        { const uint32_t* q = (const uint32_t*)BRC_CKS(c, CK_PILEUP, 24, CB_SLOTID, reinterpret_cast<const char*>(pl.slotid + (int64_t)lib * P + tb), 256, tile, -1); BRC_ST(q, sid); }
         uint32_t dv[NI], av[NI];
         pack_unpack(a.dom, eb_index(a.dom_b), dv); pack_unpack(a.alt, eb_index(a.alt_b), av);     // (the slots' base indices; no alternate yet: all zeros)
-        uint32_t* i0 = slot_i(c, pl, lib, 0u, tb); uint32_t* i1 = slot_i(c, pl, lib, 1u, tb);
+        uint32_t* i0 = (uint32_t*)BRC_CKS(c, CK_PILEUP, 25, CB_SI, reinterpret_cast<const char*>(slot_i(c, pl, lib, 0u, tb)), ((uint64_t)(NI - 1) * (uint64_t)P + 64u) * 4u, tile, -1);
+        uint32_t* i1 = (uint32_t*)BRC_CKS(c, CK_PILEUP, 26, CB_SI, reinterpret_cast<const char*>(slot_i(c, pl, lib, 1u, tb)), ((uint64_t)(NI - 1) * (uint64_t)P + 64u) * 4u, tile, -1);
         if (__builtin_expect(flushed, 0)) {
             // (wave-uniform) earlier flushes of this tile left partial integer sums in the planes; dead lanes never flush
 #pragma unroll
@@ -1333,7 +1366,8 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
             const uint32_t* q0 = i0; const uint32_t* q1 = i1;
 #pragma unroll
             for (int f = 0; f < NI; ++f) { BRC_ST(q0, dv[f]); BRC_ST(q1, av[f]); q0 += P; q1 += P; }
-            const float* g0 = slot_f(c, pl, lib, 0u, tb); const float* g1 = slot_f(c, pl, lib, 1u, tb);
+            const float* g0 = (const float*)BRC_CKS(c, CK_PILEUP, 27, CB_SF, reinterpret_cast<const char*>(slot_f(c, pl, lib, 0u, tb)), ((uint64_t)(NF - 1) * (uint64_t)P + 64u) * 4u, tile, -1);
+            const float* g1 = (const float*)BRC_CKS(c, CK_PILEUP, 28, CB_SF, reinterpret_cast<const char*>(slot_f(c, pl, lib, 1u, tb)), ((uint64_t)(NF - 1) * (uint64_t)P + 64u) * 4u, tile, -1);
 #pragma unroll
             for (int f = 0; f < NF; ++f) { BRC_ST(g0, a.dom.f[f]); BRC_ST(g1, a.alt.f[f]); g0 += P; g1 += P; }
         }
@@ -1354,7 +1388,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
     const uint32_t npos = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(rep && a.ncol != 0u));
     // (ev of one tile: 64 lanes x a column count; the 32-bit slot holds it up to 67 M reads deep — deeper, it saturates the
     // warning slots first: all four are summed in 64 bits by k_finalize, a tile's share travels in 32)
-    if (lane_e == 0) tile_ctr[(int64_t)lib * ntiles + tile] = make_uint4((uint32_t)ev, (uint32_t)wsm, (uint32_t)wnm, wl | (npos << 8));
+    if (lane_e == 0) *BRC_CK(c, CK_PILEUP, 29, CB_TILECTR, tile_ctr + ((int64_t)lib * ntiles + tile), sizeof(uint4), tile, -1) = make_uint4((uint32_t)ev, (uint32_t)wsm, (uint32_t)wnm, wl | (npos << 8));
 }
 
 template <int NV>
@@ -1517,7 +1551,9 @@ static const HostAlloc kPinned = {pinned_alloc, pinned_release};
 static std::atomic<uint64_t> g_dev_allocs{0}, g_dev_alloc_ns{0};     // BRC_ENGINE_TIMING: (re)allocations of device buffers and the time they took (several engines allocate from their own threads)
 struct DBuf {
     void* p = nullptr; size_t cap = 0;
+    size_t req = 0;      // the bytes the last ensure() asked for: the extent the kernels may touch (the checked build compares addresses with it, not with the rounded-up capacity)
     hipError_t ensure(size_t bytes) {
+        req = bytes;
         if (bytes <= cap) return hipSuccess;
         struct Tm { std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
                     ~Tm() { g_dev_alloc_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); ++g_dev_allocs; } } tm_;
@@ -1573,6 +1609,35 @@ class HipBackend : public Backend {
     std::vector<IndelOut> iout_compact;
     Counters h_ctr;
     bool computed = false;
+#ifdef BRC_CHECKED
+    // the bounds-checked build: extents of every buffer K1 and k_pileup2 address (what the host asked for), uploaded in front of
+    // every pass; the fault record is read back behind it (finish_passes)
+    DBuf d_chk; ChkState h_chk;
+    void chk_fill() {
+        memset(&h_chk, 0, sizeof h_chk);
+        auto set = [&](int b, const DBuf& d) { h_chk.ext[b].lo = (uint64_t)d.p; h_chk.ext[b].hi = (uint64_t)d.p + d.req; };
+        set(CB_CIGAR, d_cigar); set(CB_SEQ, d_seq); set(CB_QUAL, d_qual); set(CB_REFCODE, d_refcode); set(CB_EB, d_bq); set(CB_BQW, d_bqw);
+        set(CB_PIECES, d_pieces); set(CB_RARE, d_rare); set(CB_KEYREACH, d_keyreach); set(CB_READS, d_reads); set(CB_EVRAW, d_evraw); set(CB_CNT, d_cnt);
+        set(CB_WANTED, d_wanted); set(CB_RNG, d_rng); set(CB_UNAVAIL, d_unavail); set(CB_TILELIST, d_tilelist); set(CB_NCOL, d_ncol); set(CB_DEPTH, d_depth);
+        set(CB_SLOTID, d_slotid); set(CB_SI, d_si); set(CB_SF, d_sf); set(CB_XEV, d_xev); set(CB_XEVN, d_xevn); set(CB_TILECTR, d_tilectr);
+        // (self-test of the checker, tests/test_checked_build.py: BRC_CHECKED_SHRINK=<buffer index>:<bytes> takes bytes off a buffer's end)
+        if (const char* sh = getenv("BRC_CHECKED_SHRINK")) { const int b = atoi(sh); const char* cpos = strchr(sh, ':'); if (b >= 0 && b < CB_N && cpos) { const uint64_t by = strtoull(cpos + 1, nullptr, 10); ChkExt& x = h_chk.ext[b]; x.hi = x.hi - x.lo > by ? x.hi - by : x.lo; } }
+    }
+    int chk_report() {
+        if (hipMemcpy(&h_chk, d_chk.p, sizeof h_chk, hipMemcpyDeviceToHost) != hipSuccess) { err = "checked build: cannot read the fault record"; return BRC_E_HIP; }
+        if (!h_chk.count) return BRC_OK;
+        static const char* const kBuf[CB_N] = {"cigar", "seq4", "qual", "refcode", "event bytes", "wide words", "pieces", "rare records", "keyreach", "reads", "raw indel events", "indel bucket counts",
+                                               "wanted lanes", "tile ranges", "unavail", "tile list", "ncol", "depth", "slotid", "integer slot planes", "float slot planes", "third-allele lists",
+                                               "third-allele cursors", "tile counters", "LDS rows", "LDS queue"};
+        char b[512];
+        snprintf(b, sizeof b, "BRC_CHECKED: %u out-of-bounds device access(es); first: kernel %s, site %u, buffer '%s' [0x%llx, 0x%llx), address 0x%llx + %llu bytes (offset %lld), %s %lld, piece %lld",
+                 h_chk.count, h_chk.kernel == CK_ANNOTATE ? "k_annotate_groups" : "k_pileup2", h_chk.site, h_chk.buf < CB_N ? kBuf[h_chk.buf] : "?",
+                 (unsigned long long)h_chk.ext[h_chk.buf < CB_N ? h_chk.buf : 0].lo, (unsigned long long)h_chk.ext[h_chk.buf < CB_N ? h_chk.buf : 0].hi, (unsigned long long)h_chk.addr,
+                 (unsigned long long)h_chk.bytes, (long long)(h_chk.addr - h_chk.ext[h_chk.buf < CB_N ? h_chk.buf : 0].lo), h_chk.kernel == CK_ANNOTATE ? "read" : "tile", (long long)h_chk.unit, (long long)h_chk.piece);
+        err = b; fprintf(stderr, "%s\n", b);
+        return BRC_E_HIP;
+    }
+#endif
 
     int hip_fail(hipError_t e, const char* what) {
         char b[512];
@@ -1615,6 +1680,9 @@ class HipBackend : public Backend {
                        &d_ref, &d_refcode, &d_bq, &d_bqw, &d_bqrow, &d_pieceoff, &d_pieces, &d_rare, &d_keyreach, &d_libbase, &d_reads, &d_agg, &d_rng, &d_ncol, &d_depth, &d_slotid, &d_si, &d_sf, &d_xev, &d_xevc, &d_xevn, &d_unavail, &d_cnt,
                        &d_cursor, &d_ev, &d_evraw, &d_ievoff, &d_iout, &d_ctr, &d_tilectr, &d_part, &d_tlen, &d_toff, &d_text, &d_tctx, &d_total64, &d_wanted, &d_tilelist};
         for (DBuf* b : all) b->release();
+#ifdef BRC_CHECKED
+        d_chk.release();
+#endif
         for (int i = 0; i < 2; ++i) { h_text[i].destroy(); h_toff[i].destroy(); if (ev_text[i]) (void)hipEventDestroy(ev_text[i]); }
         h_total.destroy();
         if (ev_lines) (void)hipEventDestroy(ev_lines);
@@ -1661,6 +1729,9 @@ class HipBackend : public Backend {
         // test knobs (tests/test_gpu_parity.py): small K -> flushes, small limit -> PF_HUGE, forced dominant bucket -> third alleles
         choose_pack(s.max_lqseq, getenv("BRC_FLUSH_K") ? atoi(getenv("BRC_FLUSH_K")) : 0, getenv("BRC_PACK_LIM") ? atoi(getenv("BRC_PACK_LIM")) : 0, c.flush_k, c.pack_lim);
         c.force_dom = getenv("BRC_FORCE_DOM") ? atoi(getenv("BRC_FORCE_DOM")) : -1;
+#ifdef BRC_CHECKED
+        HIPCHK(d_chk.ensure(sizeof(ChkState))); c.chk = d_chk.p;
+#endif
 #ifdef BRC_EXP_KNOBS
         c.variant = getenv("BRC_PILEUP_VARIANT") ? atoi(getenv("BRC_PILEUP_VARIANT")) : 0;
         c.ann_variant = getenv("BRC_ANN_VARIANT") ? atoi(getenv("BRC_ANN_VARIANT")) : 0;
@@ -1773,6 +1844,9 @@ class HipBackend : public Backend {
         const bool indels = n_indel_cap > 0 && P > 0 && n > 0;
         const int64_t n_buckets = indel_buckets(c);     // indel buckets: (16 or 64 positions, library)
         if (indels) HIPCHK(hipMemsetAsync(d_cnt.p, 0, (size_t)n_buckets * 4, stream));
+#ifdef BRC_CHECKED
+        if (set == 0) { chk_fill(); HIPCHK(hipMemcpyAsync(d_chk.p, &h_chk, sizeof h_chk, hipMemcpyHostToDevice, stream)); HIPCHK(hipStreamSynchronize(stream)); }   // (faults of a ring of passes accumulate in one record)
+#endif
         Planes pl = {(uint32_t*)d_ncol.p, (uint32_t*)d_depth.p, (uint32_t*)d_slotid.p, (uint32_t*)d_si.p, (float*)d_sf.p, (uint32_t*)d_unavail.p,
                      (XEv*)d_xev.p, (uint32_t*)d_xevn.p, (uint32_t)xev_cap, (uint32_t)XEV_SHARDS};
         pl_last = pl;
@@ -1887,6 +1961,9 @@ class HipBackend : public Backend {
         HIPCHK(hipMemcpyAsync(&h_ctr, d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         *again = false;
+#ifdef BRC_CHECKED
+        { const int rcc = chk_report(); if (rcc) return rcc; }
+#endif
         if ((size_t)h_ctr.xev_max > xev_cap) {
             xev_cap = (size_t)h_ctr.xev_max * 2;
             HIPCHK(d_xev.ensure(((size_t)XEV_SHARDS * xev_cap + 1) * sizeof(XEv))); HIPCHK(d_xevc.ensure(((size_t)XEV_SHARDS * xev_cap + 1) * sizeof(XEv)));
@@ -2113,7 +2190,11 @@ Backend* make_backend(const brc_config& cfg, int* errc) {
     *errc = BRC_OK;
     return b;
 }
+#ifdef BRC_CHECKED
+const char* backend_kind() { return "hip-gfx950-checked"; }
+#else
 const char* backend_kind() { return "hip-gfx950"; }
+#endif
 const char* backend_kernel_name(int k) { return (k >= 0 && k < T_N) ? kKernelNames[k] : nullptr; }
 
 }  // namespace brc

@@ -27,8 +27,14 @@ def bin_events(arrs, length, bin_size=BIN):
     linear-index / chunk sizes or a coverage prepass"): every read adds its reference span to the windows it overlaps.
     Returns the cumulative events at every window edge (len = n_bins + 1), so any interval's weight is a difference."""
     nb = int((length + bin_size - 1) // bin_size)
-    pos = np.clip(np.asarray(arrs["pos"]).astype(np.int64), 0, length)
-    end = np.clip(capi.read_ends(arrs), 0, length)
+    # reads that never enter a column weigh nothing (unmapped, no position); a record at or past the contig's end — legal in
+    # a BAM whose header understates a length — is clipped INTO the last window (pos == length would index one window past it)
+    pos_all = np.asarray(arrs["pos"]).astype(np.int64)
+    live = (pos_all >= 0) & ((np.asarray(arrs["flag"]).astype(np.int64) & 4) == 0) if "flag" in arrs else (pos_all >= 0)
+    pos = np.clip(pos_all, 0, max(length - 1, 0))[live]
+    end = np.clip(capi.read_ends(arrs)[live], pos, length)
+    if nb == 0:
+        return np.zeros(1, np.float64)
     # coverage as a difference array on base resolution would be length-sized; per window: spans split at window edges
     cum = np.zeros(nb + 1, np.float64)
     b0 = pos // bin_size; b1 = np.maximum(end - 1, pos) // bin_size

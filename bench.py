@@ -22,6 +22,9 @@ under a launcher.  Extra objects on the JSON line:
   cpu_baseline  the C oracle (CPU restatement of the reference semantics): 1 thread like the reference on a prefix, the reference's own
                 sources compiled over a shim (oracle/_ref) on a smaller prefix, and all cores = the whole-region validation below
   e2e           the drop-in command line on a generated BAM + BAI -> /dev/null (BAM decode, PCIe, formatting included)
+  e2e_sites     BASELINE config 4 end to end: `bam-readcount -l sites` over a generated 8-contig 30x BAM + BAI, sites at BASELINE's
+  e2e_tumor     spacing in file order; config 5 end to end: `-p -i` on a 200x / 4-library / 8-read-group BAM.  Both validated against
+                the reference's own main() (oracle/_ref/bam-readcount-ref) — tools/e2e_configs.py
   validated     full_contig: the result of the TIMED region — every position of it — equals the oracle's: the region is cut into
                 windows, the oracle computes each as a region of its own on all usable cores (tools/fullcheck.py), the HIP side
                 reads the same windows back with brc_fetch_window; planes bit for bit, indel lists, text byte for byte (digests).
@@ -107,6 +110,9 @@ def main():
     ap.add_argument("--full-check", type=int, default=-1, help="validate the WHOLE timed region against the oracle on all cores, window by window (brc_fetch_window): -1 = on a 1-GPU run "
                     "of --mode weak / strong with a CPU sample, 2 = planes only (no text: config 5 whole prints 72 GB), 0 = off")
     ap.add_argument("--e2e-mbp", type=float, default=30.0, help="contig of the end-to-end command-line run (0 = skip)")
+    ap.add_argument("--e2e-configs", type=int, default=-1, help="BASELINE configs 4 and 5 END TO END through the drop-in command line on generated multi-contig BAM + BAI files "
+                    "(tools/e2e_configs.py; e2e_sites / e2e_tumor on the line): -1 = on the default single-GPU config-3 run, 1 = yes, 0 = no")
+    ap.add_argument("--e2e-sites-mbp", type=float, default=25.0, help="e2e_sites: length of each of its 8 contigs")
     ap.add_argument("--abi-mbp", type=float, default=10.0, help="prefix run through the C-ABI from host batches to host text (abi_roundtrip; 0 = skip)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r04_traffic.json"))
     ap.add_argument("--other-configs", type=int, default=-1, help="1: also run BASELINE config 4 (--mode sites) and the per-GPU shape of config 5 (--mode strong --contig-mbp 6.25) "
@@ -564,6 +570,21 @@ def main():
                                   "whole_step_frac": sub["roofline"]["whole_step_frac"], "validated": sub["validated"], "cpu_baseline": sub["cpu_baseline"]}
                 except Exception as ex:                                      # noqa: BLE001 — reported, never hidden
                     other[key] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        # ---- BASELINE configs 4 and 5 through the drop-in CLI itself: multi-contig BAM + BAI, the reference's own -l loop and -p -i
+        # lookups (tools/e2e_configs.py validates against oracle/_ref/bam-readcount-ref, the reference's own main())
+        e2e_sites = e2e_tumor = None
+        if (args.e2e_configs == 1 or (args.e2e_configs < 0 and want_other)) and world == 1 and os.path.exists(CLI):
+            tool = os.path.join(ROOT, "tools", "e2e_configs.py")
+            def e2e_leg(extra):
+                try:
+                    out = subprocess.run([sys.executable, tool] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+                    if out.returncode != 0:
+                        return {"error": out.stderr.decode(errors="replace")[-600:]}
+                    return json.loads(out.stdout.decode().strip().splitlines()[-1])
+                except Exception as ex:                                  # noqa: BLE001 — reported, never hidden
+                    return {"error": "%s: %s" % (type(ex).__name__, ex)}
+            e2e_sites = e2e_leg(["--leg", "sites", "--contigs", "8", "--contig-mbp", str(args.e2e_sites_mbp), "--check-lines", "1000"])
+            e2e_tumor = e2e_leg(["--leg", "tumor", "--contig-mbp", "6.25", "--check-mbp", "1.0"])
         what = {"weak": "synthetic 30x WGS, 150bp reads, 1 contig %.0f Mbp per GPU, -q20 -b13" % (contig_len / 1e6),
                 "strong": "synthetic 200x tumor 4 libraries, 150bp reads, -p -i, 1 contig %.0f Mbp cut into %d intervals" % (total_len / 1e6, world),
                 "sites": "-l site list of %d single-base sites in file order over %d synthetic 30x contigs of %.0f Mbp (genome scaled from 3.1 Gbp), -q20 -b13, cut into %d slices"
@@ -585,7 +606,7 @@ def main():
                        "events_per_step": int(ev_total), "positions_per_step": int(pos_total), "parallelism": "interval-shard x%d" % world},
             "positions_per_s": round(pos_total * args.steps / tmax, 1),
             "per_rank": per_rank, "per_gpu_value": round(value / world, 1),
-            "roofline": roof, "cpu_baseline": cpu, "e2e": e2e, "abi_roundtrip": abi, "validated": validated, "other_configs": other,
+            "roofline": roof, "cpu_baseline": cpu, "e2e": e2e, "e2e_sites": e2e_sites, "e2e_tumor": e2e_tumor, "abi_roundtrip": abi, "validated": validated, "other_configs": other,
             "host": {"gen_s": round(t_gen, 2), "push_s": round(t_push, 2), "upload_s": round(t_up, 2), "timed_s": round(tmax, 3)},
         }
         print(json.dumps(line))

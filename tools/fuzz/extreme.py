@@ -4,7 +4,7 @@ default, or the HIP library with --hip on a GPU box) against the C oracle on sce
 of tens of kilobases, piles thousands deep at one position, a dozen libraries, base-quality and mapping-quality thresholds at
 and beyond their ranges, tiny -d.  Planes, indel buckets, warning counters and text must be identical.
 
-    python tools/fuzz/extreme.py [--first 0] [--count 200] [--hip] [--ref]
+    python tools/fuzz/extreme.py [--first 0] [--count 200] [--hip | --lib libbrc_hip_checked.so] [--ref]
 
 Found with it: the 16-bit packed sums overflowing on reads above 5461 bases (brc_core.h: choose_pack)."""
 import argparse
@@ -182,8 +182,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--first", type=int, default=0); ap.add_argument("--count", type=int, default=200); ap.add_argument("--hip", action="store_true"); ap.add_argument("--verbose", action="store_true"); ap.add_argument("--sim", default=None, help="another build of the simulator library (a sanitizer build: run under LD_PRELOAD of libasan / libubsan)")
     ap.add_argument("--ref", action="store_true", help="also: the oracle's text against the reference's own sources compiled over the htslib shim (oracle/_ref; skips the deep piles, its std::map per position is slow there)")
+    ap.add_argument("--lib", default=None, help="another build of the HIP library on the GPU box: bam_readcount_amd/csrc/libbrc_hip_checked.so, the bounds-checked instantiation "
+                    "(make -C bam_readcount_amd/csrc checked) — an out-of-bounds device address fails the scenario with its fault record")
     a = ap.parse_args()
-    dev = capi.load_product() if a.hip else capi.Library(a.sim or os.path.join(ROOT, "tests", "sim", "libbrc_sim.so"))
+    dev = capi.Library(os.path.abspath(a.lib)) if a.lib else capi.load_product() if a.hip else capi.Library(a.sim or os.path.join(ROOT, "tests", "sim", "libbrc_sim.so"))
     oracle = capi.Library(os.path.join(ROOT, "oracle", "libbrc_oracle.so"))
     ref_lib = None
     if a.ref:
