@@ -114,9 +114,17 @@ __host__ __device__ __forceinline__ uint64_t chk_range(void* state, uint32_t ker
 #endif
 }
 // pointer form: p itself when [p, p + bytes) lies inside buffer BUF, the buffer's start otherwise (recorded)
-#define BRC_CK(c, K, SITE, BUF, p, bytes, unit, piece) ((decltype((p) + 0))brc::chk_range((c).chk, (K), (SITE), (BUF), (uint64_t)(p), (uint64_t)(bytes), (int64_t)(unit), (int64_t)(piece)))
+// (BRC_CHK_MASK_A / _P: compile-time masks of the sites of K1 / k_pileup2 that are checked — all of them unless a debugging build narrows them)
+#ifndef BRC_CHK_MASK_A
+#define BRC_CHK_MASK_A 0xffffffffffffffffull
+#endif
+#ifndef BRC_CHK_MASK_P
+#define BRC_CHK_MASK_P 0xffffffffffffffffull
+#endif
+#define BRC_CHK_ON(K, SITE) (((((K) == brc::CK_ANNOTATE) ? (BRC_CHK_MASK_A) : (BRC_CHK_MASK_P)) >> (SITE)) & 1ull)
+#define BRC_CK(c, K, SITE, BUF, p, bytes, unit, piece) (BRC_CHK_ON(K, SITE) ? (decltype((p) + 0))brc::chk_range((c).chk, (K), (SITE), (BUF), (uint64_t)(p), (uint64_t)(bytes), (int64_t)(unit), (int64_t)(piece)) : (decltype((p) + 0))(p))
 // index form (LDS arrays, counters): idx itself when idx < n, 0 otherwise (recorded with the index as the address)
-#define BRC_CKI(c, K, SITE, BUF, idx, n, unit, piece) ((uint64_t)(idx) < (uint64_t)(n) ? (idx) : (brc::chk_fail_index((c).chk, (K), (SITE), (BUF), (uint64_t)(idx), (uint64_t)(n), (int64_t)(unit), (int64_t)(piece)), (decltype((idx) + 0))0))
+#define BRC_CKI(c, K, SITE, BUF, idx, n, unit, piece) ((!BRC_CHK_ON(K, SITE) || (uint64_t)(idx) < (uint64_t)(n)) ? (idx) : (brc::chk_fail_index((c).chk, (K), (SITE), (BUF), (uint64_t)(idx), (uint64_t)(n), (int64_t)(unit), (int64_t)(piece)), (decltype((idx) + 0))0))
 __host__ __device__ __forceinline__ void chk_fail_index(void* state, uint32_t kernel, uint32_t site, uint32_t buf, uint64_t idx, uint64_t n, int64_t unit, int64_t piece) {
 #if defined(__HIP_DEVICE_COMPILE__)
     ChkState* st = (ChkState*)state;

@@ -1342,7 +1342,13 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         const int64_t P = c.PS;
         const int64_t tb = tile * TILE;                                    // (scalar) plane index of lane 0
         const uint32_t loff = (uint32_t)lane_e << 2;
+#ifdef BRC_CHECKED
+        // (checked build: the plane bases come out of v_readfirstlane — uniform_ptr — and a VMEM instruction that reads an SGPR a VALU
+        // instruction wrote needs five wait states in between; the compiler's hazard recogniser cannot see into the assembly statement)
+#define BRC_ST(base, val) asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 nt" :: "v"(loff), "v"(val), "s"(base) : "memory")
+#else
 #define BRC_ST(base, val) asm volatile("global_store_dword %0, %1, %2 nt" :: "v"(loff), "v"(val), "s"(base) : "memory")   /* (written once per step, read by nobody on the device: streaming) */
+#endif
         a.dom_b = BRC_DOM_B();
         const uint32_t sid = a.dom_b | (a.alt_b << 8);
         // (checked build: the wave's 256-byte segment of every plane — stores are coalesced, lane == position, so the segment of
