@@ -1130,7 +1130,9 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                                 if (__builtin_amdgcn_inverse_ballot_w64(m_esc)) {                                         \
                                     uint32_t w16; const uint32_t wv = ((uint32_t)BRC_LANE() + (uint32_t)S.s_c) << 1;      \
                                     (void)BRC_CK(c, CK_PILEUP, 14, CB_BQW, reinterpret_cast<const char*>(wrow) + wv, 2, tile, (m)); \
-                                    asm volatile("global_load_ushort %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(w16) : "v"(wv), "s"(wrow) : "memory"); \
+                                    /* (s_nop 4: a VMEM instruction that reads an SGPR a VALU instruction wrote — a v_readlane that restores a spilled pair — needs \
+                                       five wait states, and the compiler's hazard recogniser does not look into an assembly statement) */ \
+                                    asm volatile("s_nop 4\n\tglobal_load_ushort %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(w16) : "v"(wv), "s"(wrow) : "memory"); \
                                     exo = !bucket_acgt(w16 & 0xffu);                                                      \
                                     if (exo) a.ww += R.g[0]; else S.w = ((w16 >> 8) << 2) | ((w16 & 0xffu) - 1u);         \
                                 }                                                                                         \
@@ -1728,13 +1730,13 @@ class HipBackend : public Backend {
         c.Lp = g.Lp; c.ref_len_check = cfg.ref_len_check; c.has_ref = g.ref != nullptr;
         g.PS = (g.P + 63) & ~(int64_t)63;
         c.beg0 = g.beg0; c.end = g.end; c.pos0 = g.pos0; c.P = g.P; c.PS = g.PS; c.ref_lo = g.ref_lo; c.ref_hi = g.ref_hi; c.ref_len = g.ref_len;
-        c.n_reads = s.n; c.table_len = getenv("BRC_NO_TABLE") ? 0 : s.modal_len();
+        c.n_reads = s.n; c.table_len = test_knob(TK_NO_TABLE) ? 0 : s.modal_len();
         c.n_pieces = s.n_pieces; lib_base = s.lib_base; c.max_lqseq = s.max_lqseq;
         c.ibucket_shift = indel_bucket_shift(s.n_indel_ops, c.P, c.Lp);
-        if (const char* ib = getenv("BRC_IBUCKET_SHIFT")) { const int v = atoi(ib); if (v == 4 || v == 6) c.ibucket_shift = v; }   // (test knob: both supported sizes; anything else is ignored)
-        // test knobs (tests/test_gpu_parity.py): small K -> flushes, small limit -> PF_HUGE, forced dominant bucket -> third alleles
-        choose_pack(s.max_lqseq, getenv("BRC_FLUSH_K") ? atoi(getenv("BRC_FLUSH_K")) : 0, getenv("BRC_PACK_LIM") ? atoi(getenv("BRC_PACK_LIM")) : 0, c.flush_k, c.pack_lim);
-        c.force_dom = getenv("BRC_FORCE_DOM") ? atoi(getenv("BRC_FORCE_DOM")) : -1;
+        if (const char* ib = test_knob(TK_IBUCKET_SHIFT)) { const int v = atoi(ib); if (v == 4 || v == 6) c.ibucket_shift = v; }   // (test knob: both supported sizes; anything else is ignored)
+        // test knobs (brc_host.h: TestKnob — the constant nullptr in the product): small K -> flushes, small limit -> PF_HUGE, forced dominant bucket -> third alleles
+        choose_pack(s.max_lqseq, test_knob(TK_FLUSH_K) ? atoi(test_knob(TK_FLUSH_K)) : 0, test_knob(TK_PACK_LIM) ? atoi(test_knob(TK_PACK_LIM)) : 0, c.flush_k, c.pack_lim);
+        c.force_dom = test_knob(TK_FORCE_DOM) ? atoi(test_knob(TK_FORCE_DOM)) : -1;
 #ifdef BRC_CHECKED
         HIPCHK(d_chk.ensure(sizeof(ChkState))); c.chk = d_chk.p;
 #endif
@@ -1794,7 +1796,7 @@ class HipBackend : public Backend {
         // third-allele lists: XEV_SHARDS sub-lists; about one piece in 25 leaves an event at 30-50x, capacity for twice that,
         // spread evenly (the grow-and-recompute path covers the rest)
         {
-            const char* xc = getenv("BRC_XEV_CAP");           // (test knob: tiny lists exercise the grow-and-recompute path)
+            const char* xc = test_knob(TK_XEV_CAP);           // (test knob: tiny lists exercise the grow-and-recompute path)
             const size_t want = xc ? (size_t)std::max(atoi(xc), 1) : std::max<size_t>(256, np / 8 / XEV_SHARDS);
             if (want > xev_cap) xev_cap = want;
         }
@@ -2054,8 +2056,8 @@ class HipBackend : public Backend {
         HIPCHK(hipStreamSynchronize(stream));                                  // (also covers the local `ctx`)
         const uint64_t total = h_total.p[0];
         { uint64_t t64; memcpy(&t64, h_total.p + 2, 8);
-          // (BRC_DEVICE_TEXT_LIMIT: test knob, a lower limit — the route changes, the text does not)
-          const uint64_t limit = getenv("BRC_DEVICE_TEXT_LIMIT") ? strtoull(getenv("BRC_DEVICE_TEXT_LIMIT"), nullptr, 10) : ~0ull;
+          // (TK_DEVICE_TEXT_LIMIT: test knob, a lower limit — the route changes, the text does not)
+          const uint64_t limit = test_knob(TK_DEVICE_TEXT_LIMIT) ? strtoull(test_knob(TK_DEVICE_TEXT_LIMIT), nullptr, 10) : ~0ull;
           if (t64 != total || t64 > limit) { text_started[slot] = false; text_slot ^= 1; return BRC_TEXT_TOO_LONG; } }
         text_total[slot] = total;
         std::lock_guard<std::mutex> lk(text_mu);

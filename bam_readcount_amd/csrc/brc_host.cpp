@@ -80,7 +80,9 @@ class Pool {
         }
     }
   public:
-    explicit Pool(unsigned n) { for (unsigned t = 0; t < n; ++t) th.emplace_back([this] { worker(); }); }
+    // (thread creation can fail — std::system_error under a thread limit: the pool then runs with the workers it got, none in the
+    // worst case; an exception leaving the constructor with started threads in `th` would end in std::terminate)
+    explicit Pool(unsigned n) { try { th.reserve(n); for (unsigned t = 0; t < n; ++t) th.emplace_back([this] { worker(); }); } catch (...) {} }
     ~Pool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv_go.notify_all(); for (std::thread& t : th) t.join(); }
     unsigned size() const { return (unsigned)th.size() + 1; }
     template <class F> void run(int64_t n, F fn) {
@@ -503,7 +505,13 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
 int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
     if (!e || !b) return BRC_E_ARG;
     bool touched = false;
-    const int rc = push_reads_staged(e, b, &touched);
+    int rc;
+    // no exception crosses the C boundary: the parallel staging path allocates (per-chunk tables, the job's std::function), and a C
+    // caller would see std::terminate
+    try { rc = push_reads_staged(e, b, &touched); }
+    catch (const std::bad_alloc&) { touched = true; rc = fail(e, BRC_E_NOMEM, "host allocation failed while staging reads"); }
+    catch (const std::exception& ex) { touched = true; rc = fail(e, BRC_E_NOMEM, ex.what()); }
+    catch (...) { touched = true; rc = fail(e, BRC_E_NOMEM, "unexpected failure while staging reads"); }
     if (rc != BRC_OK && touched) e->state = 0;
     return rc;
 }
@@ -1212,12 +1220,12 @@ static int format_chunks(brc_engine* e, const brc_result* r, const char* chrom, 
     if (r->istat == NULL && (!e->text_only || r->ncol != e->hp.ncol)) return fail(e, BRC_E_ARG, "a text-only result can only be formatted before the next download");
     unsigned nthr = effective_cpus(); if (nthr > 64) nthr = 64;
     if (e->format_threads) nthr = e->format_threads;
-    if (const char* t = getenv("BRC_FORMAT_THREADS")) { const int v = atoi(t); if (v > 0) nthr = (unsigned)v; }   // (test knob: wins over the option)
+    if (const char* t = test_knob(TK_FORMAT_THREADS)) { const int v = atoi(t); if (v > 0) nthr = (unsigned)v; }   // (test knob: wins over the option)
     // about four chunks per thread, 2048 .. 65536 positions each (a 1-Mbp piece in 64-Ki chunks keeps only 15 threads busy)
     int64_t CH = P / (4 * (int64_t)nthr);
     if (CH < 2048) CH = 2048;
     if (CH > (1 << 16)) CH = 1 << 16;
-    if (const char* t = getenv("BRC_FORMAT_CHUNK")) { const long long v = atoll(t); if (v > 0) CH = v; }   // test knob
+    if (const char* t = test_knob(TK_FORMAT_CHUNK)) { const long long v = atoll(t); if (v > 0) CH = v; }   // test knob
     // Chunks after the first start from the deletions their previous position queued: right as long as nothing older sits in
     // the queues.  An entry a previous region left pending for a position still ahead blocks everything queued behind it
     // (IndelQueue::process looks at the front only) — then the region is assembled in one piece, in order.

@@ -148,6 +148,15 @@ void expand_slots(const HostPlanes& hp, int Lp, int64_t P, int64_t PS, uint32_t*
 // CPUs the process may use at once (affinity, cgroup quota): sizes the host-side thread pools
 unsigned effective_cpus();
 
+// Test knobs (tests/test_gpu_parity.py: small K -> flushes, a small packing limit -> PF_HUGE, a forced dominant bucket -> third
+// alleles, tiny third-allele lists -> grow and recompute, no quotient tables, either indel bucket size, a low device-text limit).
+// They change which device path runs, never a result — and they exist only in libbrc_hip_testknobs.so (brc_knobs.cpp compiled
+// with -DBRC_TEST_KNOBS, which maps an index to an environment variable): in the product test_knob() is the constant nullptr and
+// the library contains neither the names nor a getenv for them (tests/test_abi.py) — an inherited BRC_NO_TABLE=1 cannot turn the
+// shipped kernel into its slow path without a word.
+enum TestKnob { TK_NO_TABLE = 0, TK_FLUSH_K, TK_PACK_LIM, TK_FORCE_DOM, TK_IBUCKET_SHIFT, TK_XEV_CAP, TK_DEVICE_TEXT_LIMIT, TK_FORMAT_THREADS, TK_FORMAT_CHUNK, TK_N };
+const char* test_knob(int which);
+
 // exact "%.2f" of a float (== iostream fixed/setprecision(2), BasicStat.cpp:116); returns bytes written
 int fmt_f2(char* out, float v);
 int fmt_u32(char* out, uint32_t v);

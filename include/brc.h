@@ -41,7 +41,9 @@ extern "C" {
 #define BRC_E_NODEVICE   -2   /* no HIP device / kernels unavailable: the engine never falls back to CPU */
 #define BRC_E_HIP        -3   /* HIP runtime error (see brc_last_error) */
 #define BRC_E_NOMEM      -4
-#define BRC_E_LIMIT      -5   /* region / batch exceeds an engine limit (see brc_limits) */
+#define BRC_E_LIMIT      -5   /* region / batch exceeds an engine limit: 2^32 - 16 reads, CIGAR operators or read segments per region; reads of
+                                 2^22 bases and more; (positions x libraries) and the indel operators of a region below 2^32 when a reference
+                                 is given (brc_last_error names the one that was hit) — split the region */
 
 /* number of base buckets per (position, library): "=ACGTN"  (bamreadcount.cpp:34-39) */
 #define BRC_NBUCKET 6

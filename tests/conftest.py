@@ -55,6 +55,22 @@ def dev_lib(request):
     return capi.Library(os.path.join(ROOT, "tests", "sim", "libbrc_sim.so"))
 
 
+@pytest.fixture(scope="session", params=["sim", pytest.param("hip", marks=pytest.mark.gpu)])
+def knob_lib(request):
+    """For the tests that steer the device paths with the TEST KNOBS (BRC_FLUSH_K, BRC_PACK_LIM, BRC_FORCE_DOM, BRC_XEV_CAP, BRC_NO_TABLE,
+    BRC_IBUCKET_SHIFT, BRC_DEVICE_TEXT_LIMIT): [hip] = libbrc_hip_testknobs.so — the product's own objects (the same kernels, the same host
+    code) linked with brc_knobs.cpp -DBRC_TEST_KNOBS; the product library itself does not read them (tests/test_abi.py).  [sim]: the
+    simulator reads them itself."""
+    from bam_readcount_amd import capi
+    if request.param == "hip":
+        path = os.path.join(ROOT, "bam_readcount_amd", "csrc", "libbrc_hip_testknobs.so")
+        if not os.path.exists(path):
+            raise RuntimeError("libbrc_hip_testknobs.so is not built (make -C bam_readcount_amd/csrc)")
+        return capi.Library(path)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    return capi.Library(os.path.join(ROOT, "tests", "sim", "libbrc_sim.so"))
+
+
 def load_fixture(name):
     z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
     arrs = {k: z[k] for k in z.files}

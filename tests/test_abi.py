@@ -58,6 +58,18 @@ def test_product_contains_no_ablation_knobs():
     blob = open(capi.PRODUCT_LIB, "rb").read()
     for knob in (b"BRC_PILEUP_VARIANT", b"BRC_ANN_VARIANT", b"BRC_PILEUP_LDS_PAD", b"BRC_INDEL_OVERLAP"):
         assert knob not in blob, knob
+    # ... and the TEST knobs (result-neutral, but they choose the device path: an inherited BRC_NO_TABLE=1 would turn the shipped kernel
+    # into its slow path without a word) exist only in libbrc_hip_testknobs.so — the same objects linked with brc_knobs.cpp -DBRC_TEST_KNOBS
+    knobs = (b"BRC_NO_TABLE", b"BRC_FLUSH_K", b"BRC_PACK_LIM", b"BRC_FORCE_DOM", b"BRC_IBUCKET_SHIFT", b"BRC_XEV_CAP", b"BRC_DEVICE_TEXT_LIMIT", b"BRC_FORMAT_THREADS", b"BRC_FORMAT_CHUNK")
+    for knob in knobs:
+        assert knob not in blob, knob
+    tk = open(os.path.join(os.path.dirname(capi.PRODUCT_LIB), "libbrc_hip_testknobs.so"), "rb").read()
+    for knob in knobs:
+        assert knob in tk, knob
+    for name in ("brc_engine.hip", "brc_host.cpp"):
+        text = open(os.path.join(ROOT, "bam_readcount_amd", "csrc", name)).read()
+        for knob in knobs:
+            assert ('getenv("%s")' % knob.decode()) not in text, (name, knob)
     src = open(os.path.join(ROOT, "bam_readcount_amd", "csrc", "brc_engine.hip")).read()
     assert "c.variant ==" not in src.replace("#define BRC_PVAR(n) (c.variant == (n))", "")
     assert "c.ann_variant ==" not in src.replace("#define BRC_AVAR(n) (c.ann_variant == (n))", "")

@@ -91,7 +91,7 @@ KNOBS = [{"BRC_NO_TABLE": "1"}, {"BRC_FLUSH_K": "3"}, {"BRC_PACK_LIM": "255", "B
 
 
 @pytest.mark.parametrize("env", KNOBS, ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()))
-def test_hip_rare_device_paths(dev_lib, oracle_lib, monkeypatch, env):
+def test_hip_rare_device_paths(knob_lib, oracle_lib, monkeypatch, env):
     """Paths of k_pileup2 that ordinary data takes for a few events only, forced for all of them by test knobs: event terms by
     exact reciprocal division (BRC_NO_TABLE), flushes of the packed integer registers every K pieces (BRC_FLUSH_K), PF_HUGE
     pieces whose integers are drained (BRC_PACK_LIM), third-allele queue + live planes at the final store (BRC_FORCE_DOM
@@ -102,10 +102,10 @@ def test_hip_rare_device_paths(dev_lib, oracle_lib, monkeypatch, env):
     ref = synth.make_ref(rng, 3000, weird=0.01)
     arrs = synth.make_batch(199, ref, 700, style="mixed", n_libs=3, p_nolib=0.02)
     names = ["libA", "libB", "libC"]
-    parity.compare_libs(dev_lib, oracle_lib, arrs, [(0, 3000), (1200, 1300)], ref=ref, lib_names=names, per_lib=True, check_warn=False)
-    parity.compare_libs(dev_lib, oracle_lib, arrs, [(0, 3000)], ref=ref, min_mapq=5, min_bq=10, insertion_centric=True)
+    parity.compare_libs(knob_lib, oracle_lib, arrs, [(0, 3000), (1200, 1300)], ref=ref, lib_names=names, per_lib=True, check_warn=False)
+    parity.compare_libs(knob_lib, oracle_lib, arrs, [(0, 3000)], ref=ref, min_mapq=5, min_bq=10, insertion_centric=True)
     deep = synth.make_batch(299, ref, 2500, style="mixed", region=(900, 1400), read_len=(100, 150))       # ~600x: many half-batches per tile
-    parity.compare_libs(dev_lib, oracle_lib, deep, [(800, 1600)], ref=ref)
+    parity.compare_libs(knob_lib, oracle_lib, deep, [(800, 1600)], ref=ref)
 
 
 def test_product_ignores_ablation_environment(dev_lib, oracle_lib, monkeypatch):
@@ -168,7 +168,7 @@ def test_hip_fetch_window_equals_the_stand_alone_region(dev_lib, oracle_lib, per
     eng.close(); oe.close()
 
 
-def test_hip_passes_back_to_back_leave_the_result_of_one(dev_lib, oracle_lib, monkeypatch):
+def test_hip_passes_back_to_back_leave_the_result_of_one(knob_lib, oracle_lib, monkeypatch):
     """brc_compute_n: passes queued without a host wait in between (more of them than the engine has event sets; with a tiny
     third-allele list: the grow-and-repeat path inside a batch) leave exactly the result of one brc_compute."""
     rng = np.random.default_rng(61)
@@ -178,7 +178,7 @@ def test_hip_passes_back_to_back_leave_the_result_of_one(dev_lib, oracle_lib, mo
     for env in ({}, {"BRC_XEV_CAP": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        eng = capi.Engine(dev_lib, min_bq=10)
+        eng = capi.Engine(knob_lib, min_bq=10)
         eng.begin_region(0, 0, 4000, ref); eng.push_reads(arrs); eng.upload()
         ms, tot = eng.compute_n(70)
         assert len(ms) == 8 and tot >= 0
@@ -336,7 +336,7 @@ def test_hip_device_text_equals_oracle_on_every_fuzz_family(dev_lib, oracle_lib,
 
 
 @pytest.mark.parametrize("shift", ["4", "6", "0"])
-def test_hip_deep_indel_key_equals_oracle(dev_lib, oracle_lib, monkeypatch, shift):
+def test_hip_deep_indel_key_equals_oracle(knob_lib, oracle_lib, monkeypatch, shift):
     """k_indel_reduce with hundreds (and, at 6000 reads, thousands) of events on one (position, library) key; every bucket size
     the engine chooses from (16 / 64 positions) and single-position buckets."""
     monkeypatch.setenv("BRC_IBUCKET_SHIFT", shift)
@@ -345,7 +345,7 @@ def test_hip_deep_indel_key_equals_oracle(dev_lib, oracle_lib, monkeypatch, shif
     for n in (700, 6000):
         arrs = synth.pile_indels(synth.make_batch(141, ref, n, style="simple", region=(215, 262), read_len=(80, 100), n_libs=2), 270, seed=3)
         for kw in (dict(), dict(per_lib=True, insertion_centric=True, lib_names=["libA", "libB"])):
-            text, res = parity.compare_libs(dev_lib, oracle_lib, arrs, [(0, 600)], ref=ref, **kw)
+            text, res = parity.compare_libs(knob_lib, oracle_lib, arrs, [(0, 600)], ref=ref, **kw)
             assert max(int(d["i"][0]) for d in res[0].indels) > n // 8
 
 
@@ -459,7 +459,7 @@ def test_hip_region_windows_argument_handling(dev_lib):
 
 @pytest.mark.parametrize("env", [{}, {"BRC_PACK_LIM": "90"}, {"BRC_PACK_LIM": "90", "BRC_FLUSH_K": "5"}, {"BRC_FORCE_DOM": "3", "BRC_PACK_LIM": "90"}],
                          ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()) or "default")
-def test_hip_table_piece_flag_combinations(dev_lib, oracle_lib, monkeypatch, env):
+def test_hip_table_piece_flag_combinations(knob_lib, oracle_lib, monkeypatch, env):
     """Reads of ONE length, so that nearly every piece is a table piece of k_pileup2 — and then every way of not being one behind
     the kernel's single flag test: soft-clipped reads (PF_TABQ: the event location divided out in the lane), -i's one-base pieces
     (PF_NB), pieces with huge integers (PF_HUGE, forced by a small packing limit: both a former table piece and a soft-clipped
@@ -477,10 +477,10 @@ def test_hip_table_piece_flag_combinations(dev_lib, oracle_lib, monkeypatch, env
         both[k] = np.concatenate([np.asarray(same[k]), np.asarray(other[k]) + np.uint64(len(same[arena]))])
     arrs = capi.select_reads(both, np.argsort(both["pos"], kind="stable"))
     names = ["libA", "libB"]
-    parity.compare_libs(dev_lib, oracle_lib, arrs, [(0, 4000), (2000, 2001)], ref=ref, lib_names=names, per_lib=True, insertion_centric=True, check_warn=False)
-    parity.compare_libs(dev_lib, oracle_lib, arrs, [(0, 4000)], ref=ref, min_mapq=10, min_bq=12)
+    parity.compare_libs(knob_lib, oracle_lib, arrs, [(0, 4000), (2000, 2001)], ref=ref, lib_names=names, per_lib=True, insertion_centric=True, check_warn=False)
+    parity.compare_libs(knob_lib, oracle_lib, arrs, [(0, 4000)], ref=ref, min_mapq=10, min_bq=12)
     deep = synth.make_batch(413, ref, 2500, read_len=(100, 100), style="mixed", region=(1500, 1900), mismatch=0.03)        # ~600x of one length
-    parity.compare_libs(dev_lib, oracle_lib, deep, [(1400, 2100)], ref=ref, insertion_centric=True)
+    parity.compare_libs(knob_lib, oracle_lib, deep, [(1400, 2100)], ref=ref, insertion_centric=True)
 
 
 @pytest.mark.parametrize("offset", [1_073_000_000, 2_147_000_000], ids=["above_2^30", "end_of_int32"])
@@ -549,7 +549,7 @@ def test_hip_spliced_and_structural_alignments(dev_lib, oracle_lib, seed):
     assert zlib.crc32(got) == zlib.crc32(text)
 
 
-def test_hip_device_text_hands_a_region_back_when_its_lines_do_not_fit(dev_lib, oracle_lib, monkeypatch):
+def test_hip_device_text_hands_a_region_back_when_its_lines_do_not_fit(knob_lib, oracle_lib, monkeypatch):
     """The device writes a region's lines behind 32-bit offsets.  Whether they fit is estimated before the line kernels run
     (brc_host.cpp: 700 bytes per position and library) — an estimate that knows neither the lengths of the library names nor sums at
     the far end of int32 — and CHECKED after the length pass: the true 64-bit total against the 32-bit one.  A region that does
@@ -565,5 +565,5 @@ def test_hip_device_text_hands_a_region_back_when_its_lines_do_not_fit(dev_lib, 
             monkeypatch.delenv("BRC_DEVICE_TEXT_LIMIT", raising=False)
         else:
             monkeypatch.setenv("BRC_DEVICE_TEXT_LIMIT", limit)
-        got, _ = parity.run_engine(dev_lib, arrs, [(10, 2300), (2300, 2350)], ref=ref, device_text="chrS", **kw)
+        got, _ = parity.run_engine(knob_lib, arrs, [(10, 2300), (2300, 2350)], ref=ref, device_text="chrS", **kw)
         assert got == want, limit

@@ -13,6 +13,14 @@ the engine and by tests/test_abi.py for builds at 6, 7 and 8 waves per SIMD.
    instruction on the way that reads or writes one of the destination registers (a copy, a spill to a VGPR lane, a reuse
    as a temporary, another load into them) is an error.  Exit status 1 and a listing of the offending paths.
 
+3. VALU-WRITTEN SGPR READ BY AN INLINE-ASSEMBLY VMEM INSTRUCTION.  On gfx9 a vector memory instruction that reads an SGPR which a
+   VALU instruction wrote (v_readlane / v_readfirstlane — e.g. the restore of a spilled scalar pair — or a v_cmp into a pair) needs
+   five wait states in between.  The compiler inserts them for its own instructions; it does not look into an assembly statement.
+   k_pileup2 stores its planes and loads wide words with scalar-base VMEM instructions written in assembly: this walks the control-flow
+   graph BACKWARDS from each of them and fails if a VALU write of one of its scalar operands can be fewer than five wait states away
+   (s_nop N counts N + 1).  Found in round 5 on the bounds-checked build, whose checked plane bases come out of v_readfirstlane: the
+   stores went to half-updated addresses.
+
     python tools/check_isa.py [--quiet] [--max-vgpr N] [--max-scratch BYTES] [extra hipcc flags, e.g. -DBRC_WAVES_PER_EU=8]
     python tools/check_isa.py --asm FILE.s [--arch gfx950]     the assembly a build left behind (hipcc -save-temps=obj: the
                                                                Makefile checks the very compile whose object it ships)
@@ -98,6 +106,49 @@ def check_loads(ins, labels):
     return nloads, errors
 
 
+VALU_SGPR_WRITERS = ("v_readlane_b32", "v_readfirstlane_b32", "v_cmp", "v_add_co", "v_addc_co", "v_sub_co", "v_subb_co", "v_div_scale", "v_mad_u64_u32", "v_mad_i64_i32")
+
+
+def check_vmem_sgpr_hazard(ins, labels):
+    """inline-assembly global_* / buffer_* / flat_* / scratch_* instructions whose scalar operands a VALU instruction may have written
+    fewer than five wait states earlier, on any path"""
+    preds = {}
+    for i in range(len(ins)):
+        for j in successors(ins, labels, i):
+            preds.setdefault(j, []).append(i)
+    errors = []; n = 0
+    for i, (s, in_asm) in enumerate(ins):
+        if not (in_asm and s.split()[0].startswith(("global_", "buffer_", "flat_", "scratch_"))):
+            continue
+        n += 1
+        used = sregs(s.split(None, 1)[1] if " " in s else "")
+        if not used:
+            continue
+        # wait states already provided by s_nop instructions of the same statement in front of it are counted by the walk
+        stack = [(j, 0) for j in preds.get(i, [])]; seen = {}
+        while stack:
+            j, w = stack.pop()
+            if w >= 5 or seen.get(j, 99) <= w:
+                continue
+            seen[j] = w
+            t = ins[j][0]; op = t.split()[0]
+            m = re.match(r"s_nop (\d+)", t)
+            if m:
+                w2 = w + int(m.group(1)) + 1
+            else:
+                if op.startswith(VALU_SGPR_WRITERS):
+                    dest = sregs(t.split(None, 1)[1].split(",")[0]) if " " in t else set()
+                    if op.startswith(("v_add_co", "v_addc_co", "v_sub_co", "v_subb_co", "v_div_scale", "v_mad_u64", "v_mad_i64")):
+                        dest = sregs(t.split(None, 1)[1].split(",")[1]) if t.count(",") >= 1 else set()      # (the carry-out pair is the second operand)
+                    if dest & used:
+                        errors.append("`%s` (#%d) reads %s, written by `%s` (#%d) only %d wait state(s) before" % (s, i, sorted(dest & used), t, j, w))
+                        continue
+                w2 = w + 1
+            for k in preds.get(j, []):
+                stack.append((k, w2))
+    return n, errors
+
+
 def main():
     args = sys.argv[1:]; quiet = False; max_vgpr = None; max_scratch = None; extra = []; asm_file = None; arch = "gfx950"
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -149,6 +200,14 @@ def main():
             rc = 1
         elif not quiet:
             print("early scalar loads: %d inline-assembly loads, no instruction touches their registers before the wait on any path" % nloads)
+        nvm, herr = check_vmem_sgpr_hazard(ins, labels)
+        if herr:
+            print("check_isa: %s: VALU-written SGPR read by an inline-assembly VMEM instruction without five wait states (%d):" % (tag, len(herr)))
+            for e in herr[:20]:
+                print("  " + e)
+            rc = 1
+        elif not quiet:
+            print("inline-assembly VMEM instructions: %d, none reads an SGPR a VALU instruction wrote within five wait states" % nvm)
         if max_vgpr is not None and meta["num_vgpr"] > max_vgpr:
             print("check_isa: %s: %d VGPRs > %d" % (tag, meta["num_vgpr"], max_vgpr)); rc = 1
         if max_scratch is not None and meta["private_seg_size"] > max_scratch:

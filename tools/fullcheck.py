@@ -99,8 +99,20 @@ class OraclePool:
 
     def collect(self):
         out = {}
+        import queue as _queue
         for _ in range(self.n_tasks):
-            d = self.result_q.get()
+            # a worker killed from outside (the OOM killer, a crash inside the oracle library) posts nothing: do not wait for it forever
+            while True:
+                try:
+                    d = self.result_q.get(timeout=5.0); break
+                except _queue.Empty:
+                    dead = [(p.pid, p.exitcode) for p in self.procs if not p.is_alive() and p.exitcode not in (0, None)]
+                    if dead:
+                        self.close()
+                        raise RuntimeError("oracle worker(s) died without a result (pid, exit code): %r" % (dead,))
+                    if not any(p.is_alive() for p in self.procs) and self.result_q.empty():
+                        self.close()
+                        raise RuntimeError("every oracle worker has exited and %d window(s) are still missing" % (self.n_tasks - len(out)))
             if "error" in d:
                 self.close()
                 raise RuntimeError("oracle worker failed: " + d["error"])
