@@ -72,13 +72,26 @@ struct DevCfg {
     int64_t ref_len;        // contig length (positions >= ref_len read as NUL)
     int64_t n_reads;
     int32_t table_len;      // L0: modal read length of the region (host); reads with l_qseq == clipped == L0 take their terms from tables
-    int32_t variant;        // always 0 in the product; experiment builds (-DBRC_EXP_KNOBS) put BRC_PILEUP_VARIANT here (see brc_engine.hip)
+    // (the layout of the packed sums, choose_pack, lives in the two slots the experiment builds' ablation knobs use: the structure — the first
+    // kernel argument of both big kernels — keeps its size and the offsets of everything behind it; a structure 8 bytes longer cost
+    // k_pileup2 1.5 % on every shape, tools/experiments/README.md)
+#ifdef BRC_EXP_KNOBS
+    int32_t variant;        // experiment builds (-DBRC_EXP_KNOBS): BRC_PILEUP_VARIANT (see brc_engine.hip)
+    int32_t pack_shift;
+#else
+    int32_t pack_shift;     // bits of the narrow packed fields: 16 (reads up to 5461 bases) or 12 (longer reads: 20 bits for the wide fields) — choose_pack
+#endif
     int32_t ibucket_shift;  // log2 of the positions per indel bucket (indel_bucket_shift)
-    int32_t ann_variant;    // always 0 in the product; experiment builds: BRC_ANN_VARIANT (ablations of K1: wrong results, timing only)
+#ifdef BRC_EXP_KNOBS
+    int32_t ann_variant;    // experiment builds: BRC_ANN_VARIANT (ablations of K1: wrong results, timing only)
+    uint32_t pack_lim_lo;
+#else
+    uint32_t pack_lim_lo;   // largest per-read value of a NARROW packed field (mapping quality, single-ended mapping quality): (2^pack_shift - 1) / max(K, HALF), never below 255
+#endif
     int32_t force_dom;      // test knob (BRC_FORCE_DOM): -1, or the bucket every lane treats as dominant (stresses the alternate / third-allele paths)
     int64_t n_pieces;       // pieces of all libraries (KB v2)
     int32_t flush_k;        // K: pieces a lane may accumulate in its packed integer registers between two flushes (1..127)
-    uint32_t pack_lim;      // 65535 / max(K, HALF): largest per-read value a 16-bit packed field can take (PF_HUGE above it)
+    uint32_t pack_lim;      // largest per-read value of a WIDE packed field (mismatch-quality sum, clipped length): (2^(32 - pack_shift) - 1) / max(K, HALF); PF_HUGE above it
     int32_t max_lqseq;      // longest read of the batch (k_pileup2: a staged window further from its row than that belongs to a piece that only SPANS the tile)
 #ifdef BRC_CHECKED
     void* chk;              // (bounds-checked fuzzing build only) the engine's ChkState in device memory
@@ -543,7 +556,7 @@ struct alignas(16) Piece {
     uint32_t tp_flags;     // bits 24-31: PF_*; bits 0-23: with PF_TABLE / PF_TABQ bits 0-14 = 16 * three_prime_index - 8 * table_len (signed: the byte distance
                            // between the two table addresses of a probe, so that the second is one scalar add away from the first) and bits 15-23 =
                            // left_clip; else three_prime_index
-    uint32_t w1, w2, w3;   // packed integer addends: three 10-bit counters 1 | rev << 10 | q2ok << 20;  mapq | sse << 16;  zm_sum | clipped << 16
+    uint32_t w1, w2, w3;   // packed integer addends: three 10-bit counters 1 | rev << 10 | q2ok << 20;  mapq | sse << 16;  zm_sum | clipped << 16 — or, in a region with long reads (DevCfg.pack_shift 12), mapq | zm_sum << 12;  sse | clipped << 12
     float snm;             // NM / (float)clipped_length, 0 when NM is missing
     uint32_t ww;           // per-lane (not per-bucket) warning counters: SM-missing | NM-missing << 16 (process_read warnings, BasicStat.cpp:85,100)
     int32_t a;             // rs - query offset: the lane on position p sees query base p - a
@@ -591,14 +604,17 @@ BRC_HD double tabq_sev(int qpos, int left, uint32_t clipped) {
 }
 BRC_HD int piece_tp(const DevCfg& c, const Piece& h) { return piece_tp_of(h.tp_flags, c.table_len); }
 BRC_HD bool piece_has_rare(uint32_t fl) { return (fl & PF_TABLE) == 0u || (fl & PF_HUGE) != 0u; }
-BRC_HD PieceRare piece_rare_of(const DevCfg& c, const Piece& h) {       // for pieces with PF_TABLE and without PF_HUGE
+// (sh: DevCfg.pack_shift — k_pileup2 hands over its template constant; -1: take it from the structure)
+BRC_HD PieceRare piece_rare_of(const DevCfg& c, const Piece& h, int sh = -1) {       // for pieces with PF_TABLE and without PF_HUGE
+    if (sh < 0) sh = c.pack_shift;
     PieceRare r;
     r.Lf = (float)c.table_len; r.center = (float)c.table_len * 0.5f; r.rcpL = 1.0f / r.Lf; r.rcpC = 1.0f / r.center;
     r.left = 0; r.q2 = (piece_flags(h) & PF_Q2OK) ? piece_tp(c, h) : -1;
-    r.zm_raw = h.w3 & 0xffffu; r.sse_raw = h.w2 >> 16;
+    if (sh == 16) { r.zm_raw = h.w3 & 0xffffu; r.sse_raw = h.w2 >> 16; }
+    else { r.zm_raw = h.w2 >> sh; r.sse_raw = h.w3 & ((1u << sh) - 1u); }
     return r;
 }
-BRC_HD uint32_t piece_mapq(const Piece& h) { return h.w2 & 0xffffu; }                          // (w2 = mapq | sse << 16, or mapq alone: PF_HUGE)
+BRC_HD uint32_t piece_mapq(int sh, const Piece& h) { return h.w2 & ((1u << sh) - 1u); }    // (w2 = mapq | zm << s, or mapq alone: PF_HUGE)
 BRC_HD uint32_t piece_clipped(const PieceRare& r) { return (uint32_t)(r.center * 2.0f); }     // exact: clipped_length < 2^22
 
 // what K1 knows about a read once it is annotated
@@ -691,7 +707,9 @@ BRC_HD bool read_enters(uint32_t flag, const uint32_t* cig, uint32_t nc) {
     return true;
 }
 
-BRC_HD void make_piece(const DevCfg& c, const ReadConst& r, int32_t rs, int32_t len, int32_t ext, int qoff, bool nb, Piece& h, PieceRare& rare) {
+// (sh = DevCfg.pack_shift, handed over separately: K1 is instantiated per layout, so the shifts of its common instantiation are
+// immediates — as a run-time value they cost it the registers that keep its piece walk free of spills)
+BRC_HD void make_piece(const DevCfg& c, const ReadConst& r, int32_t rs, int32_t len, int32_t ext, int qoff, bool nb, Piece& h, PieceRare& rare, const int sh) {
     h.rs = rs; h.a = rs - qoff; h.len = len; h.ext = ext;
     uint32_t fl = r.flags;
     const bool q2ok = (fl & PF_Q2OK) != 0;
@@ -703,7 +721,7 @@ BRC_HD void make_piece(const DevCfg& c, const ReadConst& r, int32_t rs, int32_t 
     // k_pileup2 finds every unusual piece behind ONE test, "no PF_TABLE": -i's one-base pieces, and pieces with huge integers —
     // those keep PF_TABQ as the mark of "all three terms from the tables" when they were table pieces
     if (nb) fl = (fl | PF_NB) & ~(uint32_t)PF_TABLE;
-    const bool huge = r.zm > c.pack_lim || r.sse > c.pack_lim || (uint32_t)r.clipped > c.pack_lim;
+    const bool huge = r.zm > c.pack_lim || r.sse > (sh == 16 ? c.pack_lim : c.pack_lim_lo) || (uint32_t)r.clipped > c.pack_lim;   // (16 + 16 bits: one limit)
     if (huge) fl = (fl & PF_TABLE) ? ((fl & ~(uint32_t)PF_TABLE) | PF_HUGE | PF_TABQ) : (fl | PF_HUGE);
     if (!(fl & (PF_TABLE | PF_TABQ)) && !nb && !huge && c.table_len > 0 && r.l_qseq == c.table_len && r.clipped > 0 && r.left >= 0 && r.left < 512 &&
         r.tp >= 0 && r.tp <= c.table_len && (!q2ok || r.q2 == r.tp)) fl |= PF_TABQ;
@@ -712,8 +730,8 @@ BRC_HD void make_piece(const DevCfg& c, const ReadConst& r, int32_t rs, int32_t 
     h.tp_flags = ((fl & (PF_TABLE | PF_TABQ)) ? (((uint32_t)(16 * r.tp - 8 * c.table_len) & 0x7fffu) | ((uint32_t)r.left << 15)) :
                   (fl & PF_DIV) ? ((uint32_t)r.tp | ((uint32_t)r.l_qseq << 8) | ((uint32_t)r.left << 16)) : ((uint32_t)r.tp & 0xffffffu)) | ((fl & 0xffu) << 24);      // l_qseq < 2^22 is checked at push
     h.w1 = 1u | ((fl & PF_REV) ? (1u << 10) : 0u) | (q2ok ? (1u << 20) : 0u);
-    h.w2 = r.mapq | (huge ? 0u : (r.sse << 16));
-    h.w3 = huge ? 0u : (r.zm | ((uint32_t)r.clipped << 16));
+    if (sh == 16) { h.w2 = r.mapq | (huge ? 0u : (r.sse << 16)); h.w3 = huge ? 0u : (r.zm | ((uint32_t)r.clipped << 16)); }             // 16 + 16: mapq | sse, zm | clipped
+    else { h.w2 = r.mapq | (huge ? 0u : (r.zm << sh)); h.w3 = huge ? 0u : (r.sse | ((uint32_t)r.clipped << sh)); }                     // 12 + 20: mapq | zm, sse | clipped
     h.snm = r.snm;
     h.ww = ((fl & PF_SMW) ? 1u : 0u) | ((fl & PF_NMW) ? (1u << 16) : 0u);
     h.bq_off = r.bq_off;
@@ -738,9 +756,9 @@ BRC_HD EvTerms piece_terms_div(uint32_t fl, int tp, const PieceRare& r, int qpos
 // reference's expressions, BasicStat.cpp:60-70, with both sides of the second quotient doubled — |(qpos - left) - clipped/2| /
 // (clipped/2) = |2 (qpos - left) - clipped| / clipped as real numbers, so the correctly rounded quotients are the same float —
 // which makes every operand a small integer (q2 == tp or no q2; l_qseq, left, tp <= 255 and 0 < clipped <= l_qseq: make_piece)
-BRC_HD EvTerms piece_terms_inlane(uint32_t fl, uint32_t tp_flags, uint32_t w3, uint32_t qpos) {
+BRC_HD EvTerms piece_terms_inlane(uint32_t fl, uint32_t tp_flags, uint32_t cl /* clipped_length: w3 >> pack_shift */, uint32_t qpos) {
     EvTerms t;
-    const uint32_t tp = tp_flags & 0xffu, left = (tp_flags >> 16) & 0xffu, cl = w3 >> 16;
+    const uint32_t tp = tp_flags & 0xffu, left = (tp_flags >> 16) & 0xffu;
     t.s3p = div_small((float)absdiff_vs(qpos, tp), (float)((tp_flags >> 8) & 0xffu));
     t.q2 = (fl & PF_Q2OK) ? t.s3p : 0.0f;
     t.sev = 1.0 - (double)div_small((float)absdiff_vs(2u * qpos, 2u * left + cl), (float)cl);     // |2 (qpos - left) - cl|
@@ -755,8 +773,8 @@ BRC_HD EvTerms piece_terms_tab(const Piece& h, const TermTab& tt, int table_len,
     return t;
 }
 
-// One bucket of a lane between two flushes: three packed integer registers (w1: three 10-bit counters; w2, w3: two 16-bit
-// sums each, which bound K: 255 x K and clipped_length x K must stay below 2^16), the sum of the EVENT VALUES (quality << 2 | code: every event of a slot
+// One bucket of a lane between two flushes: three packed integer registers (w1: three 10-bit counters; w2, w3: a narrow and a wide
+// sum each, whose widths and the K they bound choose_pack picks per region), the sum of the EVENT VALUES (quality << 2 | code: every event of a slot
 // has the slot's code, so the base-quality sum is (sum - count * code) >> 2 — no unpacking per event) and the four
 // order-sensitive float sums.
 struct PackAcc { uint32_t w1, w2, w3, sw; float f[NF]; };
@@ -768,30 +786,42 @@ BRC_HD void pack_event(PackAcc& a, const Piece& h, const EvTerms& t, uint32_t wo
     a.f[F_SNM] += h.snm;
 }
 // the nine integer plane values held by a PackAcc whose events all carry index b (I_* order)
-BRC_HD void pack_unpack(const PackAcc& a, uint32_t b, uint32_t* v) {
-    const uint32_t n = a.w1 & 0x3ffu, minus = (a.w1 >> 10) & 0x3ffu;
-    v[I_N] = n; v[I_SMQ] = a.w2 & 0xffffu; v[I_SSE] = a.w2 >> 16; v[I_PLUS] = n - minus; v[I_MINUS] = minus;
-    v[I_NQ2] = a.w1 >> 20; v[I_SMMQ] = a.w3 & 0xffffu; v[I_SCLIP] = a.w3 >> 16; v[I_SBQ] = (a.sw - n * b) >> 2;
+BRC_HD void pack_unpack(const PackAcc& a, uint32_t b, uint32_t sh /* DevCfg.pack_shift */, uint32_t* v) {
+    const uint32_t n = a.w1 & 0x3ffu, minus = (a.w1 >> 10) & 0x3ffu, lo = (1u << sh) - 1u;
+    v[I_N] = n; v[I_SMQ] = a.w2 & lo; v[I_PLUS] = n - minus; v[I_MINUS] = minus;
+    v[I_NQ2] = a.w1 >> 20; v[I_SCLIP] = a.w3 >> sh; v[I_SBQ] = (a.sw - n * b) >> 2;
+    if (sh == 16) { v[I_SSE] = a.w2 >> 16; v[I_SMMQ] = a.w3 & 0xffffu; } else { v[I_SMMQ] = a.w2 >> sh; v[I_SSE] = a.w3 & lo; }
 }
 
-// K (pieces between two flushes of a lane's packed integers) and the per-read limit of a 16-bit field: clipped_length of
-// every read must fit, so long reads get a small K.  A flush can only happen BETWEEN half-batches (HALF pieces), so up to
-// max(K, HALF) pieces are summed into a field before it is emptied: the limit follows that count, not K — with K < HALF (reads of
-// more than 65535 / HALF = 5461 bases in the batch) a piece whose clipped length, mismatch-quality sum or single-ended mapping quality
-// exceeds it takes the PF_HUGE path (make_piece), and the lanes flush at every boundary.  (Until round 4's end the limit was 65535 / K:
-// twelve 20-kb reads in one half-batch overflowed the 16-bit sums — no test had a read longer than 900 bases;
-// tests/test_gpu_parity.py::test_hip_long_reads.)
+// The packed sums of a lane, their widths and their limits.  w2 and w3 each hold a NARROW and a WIDE sum: mapping quality | mismatch-
+// quality sum, single-ended mapping quality | clipped length, the narrow one in the low `shift` bits.  K = pieces between two
+// flushes; a flush can only happen BETWEEN half-batches (HALF pieces), so up to max(K, HALF) pieces are summed into a field before it is
+// emptied, and a per-read value above (field maximum) / max(K, HALF) sends its piece down the PF_HUGE path (make_piece).
+//   reads up to 5461 bases (65535 / HALF):  16 + 16 bits, K = 65535 / longest read, at most 127 — every field holds K reads' worth;
+//   longer reads:                           12 + 20 bits, K = (2^20 - 1) / longest read, at most 16 (255 x 16 < 2^12: a mapping quality
+//                                           always fits); clipped lengths and mismatch-quality sums up to 87 381 stay packed.
+// Both big kernels are instantiated per layout (template parameter SH), the host launches the instantiation of the region's
+// DevCfg.pack_shift: the short-read instantiations keep their shifts as immediates and are, instruction for instruction, the kernels that
+// were measured before the second layout existed (tools/isa_diff.py).
+// (Until round 4's end the limit was 65535 / K whatever HALF: twelve 20-kb reads in one half-batch overflowed the 16-bit sums — no test
+// had a read longer than 900 bases; tests/test_gpu_parity.py::test_hip_long_reads.  The 12 + 20 layout took long reads off the
+// PF_HUGE path: 10-kb reads ran k_pileup2 at 4.9x the time per event of 150-base reads.)
 // (the overrides are test knobs: a small K exercises the flushes, a small limit the PF_HUGE path)
 #ifndef BRC_HALF
 #define BRC_HALF 12
 #endif
 enum { HALF = BRC_HALF };
-BRC_HD void choose_pack(int32_t max_lqseq, int32_t k_override, int32_t lim_override, int32_t& K, uint32_t& lim) {
-    int32_t m = max_lqseq < 255 ? 255 : max_lqseq;
-    K = 65535 / m; if (K > 127) K = 127; if (K < 1) K = 1;
+BRC_HD void choose_pack(int32_t max_lqseq, int32_t k_override, int32_t lim_override, int32_t& K, uint32_t& lim, uint32_t& lim_lo, int32_t& shift) {
+    const int32_t m = max_lqseq < 255 ? 255 : max_lqseq;
+    if ((int64_t)m * HALF <= 65535) { shift = 16; K = 65535 / m; if (K > 127) K = 127; }
+    else { shift = 12; K = (int32_t)(((1u << 20) - 1u) / (uint32_t)m); if (K > 16) K = 16; }
+    if (K < 1) K = 1;
     if (k_override > 0 && k_override < K) K = k_override;
-    lim = 65535u / (uint32_t)(K > (int32_t)HALF ? K : (int32_t)HALF);
+    const uint32_t keff = (uint32_t)(K > (int32_t)HALF ? K : (int32_t)HALF);
+    lim = ((shift == 16 ? 0xffffu : 0xfffffu)) / keff;
+    lim_lo = ((1u << shift) - 1u) / keff;                                                       // >= 255 by construction (keff <= 127 resp. 16)
     if (lim_override >= 255 && (uint32_t)lim_override < lim) lim = (uint32_t)lim_override;    // >= 255: a mapping quality always fits
+    if (lim_override >= 255 && (uint32_t)lim_override < lim_lo) lim_lo = (uint32_t)lim_override;
 }
 
 // The event-byte stream on the device is padded: EB_PAD_FRONT bytes before its first row, EB_PAD_BACK + (the batch's longest read) behind
@@ -837,32 +867,35 @@ BRC_HD float* slot_f(const DevCfg& c, const Planes& pl, int lib, uint32_t slot, 
 #else
 #define BRC_NOUNROLL _Pragma("GCC unroll 1")
 #endif
-BRC_HD uint32_t pack_field(const PackAcc& a, uint32_t b, int f) {
-    const uint32_t n = a.w1 & 0x3ffu, minus = (a.w1 >> 10) & 0x3ffu;
+BRC_HD uint32_t pack_field(const PackAcc& a, uint32_t b, uint32_t sh, int f) {
+    const uint32_t n = a.w1 & 0x3ffu, minus = (a.w1 >> 10) & 0x3ffu, lo = (1u << sh) - 1u;
     uint32_t v = n;                                            // I_N
-    v = f == I_SMQ ? (a.w2 & 0xffffu) : v; v = f == I_SSE ? (a.w2 >> 16) : v; v = f == I_PLUS ? n - minus : v; v = f == I_MINUS ? minus : v;
-    v = f == I_NQ2 ? (a.w1 >> 20) : v; v = f == I_SMMQ ? (a.w3 & 0xffffu) : v; v = f == I_SCLIP ? (a.w3 >> 16) : v; v = f == I_SBQ ? ((a.sw - n * b) >> 2) : v;
+    const uint32_t w2hi = a.w2 >> sh, w3lo = a.w3 & lo;
+    v = f == I_SMQ ? (a.w2 & lo) : v; v = f == I_SSE ? (sh == 16 ? w2hi : w3lo) : v; v = f == I_PLUS ? n - minus : v; v = f == I_MINUS ? minus : v;
+    v = f == I_NQ2 ? (a.w1 >> 20) : v; v = f == I_SMMQ ? (sh == 16 ? w3lo : w2hi) : v; v = f == I_SCLIP ? (a.w3 >> sh) : v; v = f == I_SBQ ? ((a.sw - n * b) >> 2) : v;
     return v;
 }
 // packed registers -> the integer planes of one slot (adds when the tile has flushed before), registers reset; b = the slot's index (eb_index)
-BRC_HD void flush_slot(const DevCfg& c, const Planes& pl, int lib, int64_t k, PackAcc& a, uint32_t slot, uint32_t b, bool live) {
+BRC_HD void flush_slot(const DevCfg& c, const Planes& pl, int lib, int64_t k, PackAcc& a, uint32_t slot, uint32_t b, bool live, int sh = -1) {
+    if (sh < 0) sh = c.pack_shift;
     uint32_t* ip = BRC_CK(c, CK_PILEUP, 40, CB_SI, slot_i(c, pl, lib, slot, k), ((uint64_t)(NI - 1) * (uint64_t)c.PS + 1u) * 4u, k, -1);
     BRC_NOUNROLL
-    for (int f = 0; f < NI; ++f) { const uint32_t v = pack_field(a, b, f); ip[(int64_t)f * c.PS] = v + (live ? ip[(int64_t)f * c.PS] : 0u); }
+    for (int f = 0; f < NI; ++f) { const uint32_t v = pack_field(a, b, (uint32_t)sh, f); ip[(int64_t)f * c.PS] = v + (live ? ip[(int64_t)f * c.PS] : 0u); }
     a.w1 = a.w2 = a.w3 = a.sw = 0;
 }
 // `live`: the tile has flushed before (wave-uniform)
-BRC_HD void lane2_flush(const DevCfg& c, const Planes& pl, int lib, int64_t k, LaneAcc2& a, bool live) {
-    flush_slot(c, pl, lib, k, a.dom, 0u, eb_index(a.dom_b), live);
-    flush_slot(c, pl, lib, k, a.alt, 1u, eb_index(a.alt_b), live);                 // (no alternate yet: nothing to unpack)
+BRC_HD void lane2_flush(const DevCfg& c, const Planes& pl, int lib, int64_t k, LaneAcc2& a, bool live, int sh = -1) {
+    flush_slot(c, pl, lib, k, a.dom, 0u, eb_index(a.dom_b), live, sh);
+    flush_slot(c, pl, lib, k, a.alt, 1u, eb_index(a.alt_b), live, sh);                 // (no alternate yet: nothing to unpack)
 }
 // one event of a third (fourth, ...) base at this position: its raw addends, for the list
-BRC_HD XEv make_xev(const DevCfg& c, int lib, int64_t k, const Piece& h, const PieceRare& rare, int qpos, uint32_t q, uint32_t b) {
+BRC_HD XEv make_xev(const DevCfg& c, int lib, int64_t k, const Piece& h, const PieceRare& rare, int qpos, uint32_t q, uint32_t b, int sh = -1) {
+    if (sh < 0) sh = c.pack_shift;
     XEv e;
     const uint32_t fl = piece_flags(h);
     const EvTerms t = piece_terms_div(fl, piece_tp(c, h), rare, qpos);
     e.k = (uint32_t)k; e.lib_b = ((uint32_t)lib << 8) | b;
-    e.mapq = piece_mapq(h); e.sse = rare.sse_raw; e.zm = rare.zm_raw; e.clip = piece_clipped(rare);
+    e.mapq = piece_mapq(sh, h); e.sse = rare.sse_raw; e.zm = rare.zm_raw; e.clip = piece_clipped(rare);
     e.qf = q | ((fl & PF_REV) ? 0x100u : 0u) | ((fl & PF_Q2OK) ? 0x200u : 0u);
     e.fq2 = t.q2; e.fs3p = t.s3p; e.fsnm = h.snm; e.sev = t.sev;
     return e;

@@ -181,13 +181,14 @@ __device__ __forceinline__ uint32_t nzb7(uint32_t x) { return x + 0x7f7f7f7fu; }
 #else
 #define BRC_ANN_OCC
 #endif
-template <bool one_stream>     // the event-byte rows and the pieces of consecutive reads are consecutive in memory (no per-library layout)
+template <bool one_stream, int SH>     // one_stream: the event-byte rows and the pieces of consecutive reads are consecutive in memory (no per-library layout); SH: DevCfg.pack_shift
 __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, DevIn in, DRead* __restrict__ reads, const uint32_t* __restrict__ piece_off,
                                                          Piece* __restrict__ pieces, PieceRare* __restrict__ rare, int2* __restrict__ keyreach,
                                                          uint8_t* __restrict__ eb, uint16_t* __restrict__ bqw, IndelEv* __restrict__ ev_raw, uint32_t* __restrict__ bucket_cnt,
                                                          const uint32_t* __restrict__ cigar_ro, const uint8_t* __restrict__ qual_ro,
                                                          const uint8_t* __restrict__ seq_ro, const uint8_t* __restrict__ refcode,
                                                          const uint16_t* __restrict__ wanted /* brc_region_windows: the wanted lanes of every tile, or null */) {
+    c.pack_shift = SH;
     struct WaveLds { AnnPar par[64]; uint32_t sum[64]; uint32_t redo[64]; uint32_t wide[64]; uint32_t G[64]; unsigned long long mark; };
     __shared__ WaveLds lds_all[4];
     const int lane = threadIdx.x & 63;
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
         uint32_t slot = piece_off[my];
         walk_pieces_at(c.insertion_centric != 0, enters && !nolib, rc.counts, pos, cigr, nc, [&](int32_t rs, int32_t len, int32_t ext, int qoff, bool nb) {
             Piece h; PieceRare rr;
-            make_piece(c, rc, rs, len, ext, qoff, nb, h, rr);
+            make_piece(c, rc, rs, len, ext, qoff, nb, h, rr, SH);
             if (!BRC_AVAR(2)) {
                 typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
                 Piece* const pdst = BRC_CK(c, CK_ANNOTATE, 12, CB_PIECES, pieces + slot, sizeof(Piece), my, slot);
@@ -891,13 +892,17 @@ struct PRec { u32x8 f; u32x2 g; };
 #ifndef BRC_WAVES_PER_EU
 #define BRC_WAVES_PER_EU 7      // 72 VGPRs: 16 values spill into the rare paths (measured: 6 waves 3.92 ms, 7 waves 3.78 ms, 8 waves 5.6 ms — spills reach the loop)
 #endif
-template <bool WINDOWS>      // brc_region_windows is in force: tiles whose range k_mask_tiles marked lo > hi are skipped (an instantiation of its own: the
+template <bool WINDOWS, int SH>      // SH: DevCfg.pack_shift as a compile-time constant (the layout of the packed sums, choose_pack: the instantiation of
+                             // short-read regions keeps its shifts as immediates — the code that was measured); WINDOWS: brc_region_windows is in force: tiles whose range k_mask_tiles marked lo > hi are skipped (an instantiation of its own: the
                              // common one stays the code that was measured — one more branch at its head moved its register allocation and cost 2.4 %)
 __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_eu(BRC_WAVES_PER_EU, BRC_WAVES_PER_EU))) void k_pileup2(DevCfg c, DevIn in, const uint4* __restrict__ pieces4, const PieceRare* __restrict__ rare,
                                                                const uint2* __restrict__ rng, int64_t ntiles, Planes pl, uint4* __restrict__ tile_ctr,
                                                                const uint8_t* __restrict__ eb_ro, const uint16_t* __restrict__ bqw_ro, const uint32_t* __restrict__ unavail_ro,
                                                                const uint8_t* __restrict__ refcode, const uint16_t* __restrict__ wanted_ro,
                                                                const uint32_t* __restrict__ tile_list, int64_t n_listed) {
+    // (the host launches the instantiation of DevCfg.pack_shift; the structure itself is left alone — assigning the constant to its field
+    // moved the kernel's argument loads and, with them, its register allocation: the SH = 16 instantiation must stay, instruction for
+    // instruction, the kernel that was measured — the few helpers that need the shift get it as an argument)
     // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch order); give every XCD one contiguous
     // run of tiles so neighbouring tiles, which share most of their pieces, hit the same 4-MiB L2.
     const uint32_t nbk = gridDim.x;           // multiple of 8
@@ -975,6 +980,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         const uint32_t L0 = (uint32_t)c.table_len;
         const uint32_t cb = (uint32_t)LBIAS + (L0 << 3);
         const uint32_t thr0 = piece_thr(c);
+        constexpr uint32_t pack_sh = (uint32_t)SH;                                // (the clipped length of a piece: its w3 above the narrow field)
         char* const rows_base = reinterpret_cast<char*>(&lds.rows[wv][0][0]);
         QEnt* const queue = lds.queue[wv];
         // sub-list of this workgroup's third-allele events: workgroups in flight on an XCD are consecutive, so their
@@ -1141,9 +1147,9 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                             }                                                                                             \
                         }                                                                                                 \
                         if ((fl & (PF_TABQ | PF_HUGE)) == PF_TABQ) {   /* soft-clipped: only the event location differs, and it needs no rare record */ \
-                            S.sev = tabq_sev((int)((uint32_t)BRC_LANE() + (uint32_t)S.s_c), piece_left_field(R.f[3]), R.f[6] >> 16); \
+                            S.sev = tabq_sev((int)((uint32_t)BRC_LANE() + (uint32_t)S.s_c), piece_left_field(R.f[3]), R.f[6] >> pack_sh); \
                         } else if (fl & PF_DIV) {      /* another read length: the terms divided out in the lane, from the record itself */ \
-                            const EvTerms t = piece_terms_inlane(fl, R.f[3], R.f[6], (uint32_t)BRC_LANE() + (uint32_t)S.s_c); \
+                            const EvTerms t = piece_terms_inlane(fl, R.f[3], R.f[6] >> pack_sh, (uint32_t)BRC_LANE() + (uint32_t)S.s_c); \
                             S.t = t.s3p; tq2 = t.q2; S.sev = t.sev;                                                       \
                         } else if (!(fl & PF_TABQ)) {                                                                     \
                             PieceRare H; BRC_LD_DIV(H, R, m)                                                              \
@@ -1206,7 +1212,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
 #define BRC_FLUSH()                                                                                                     \
         {                                                                                                                 \
             a.dom_b = BRC_DOM_B();                                                                                        \
-            if (valid) lane2_flush(c, pl, lib, BRC_KK(), a, flushed);                                                     \
+            if (valid) lane2_flush(c, pl, lib, BRC_KK(), a, flushed, SH);                                                     \
             wsm_tot += wave_sum_u32(valid ? (a.ww & 0xffffu) : 0u); wnm_tot += wave_sum_u32(valid ? (a.ww >> 16) : 0u); a.ww = 0u; \
             flushed = true; since_flush = 0;                                                                              \
         }
@@ -1237,7 +1243,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                             asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(rf) : "s"(rp));    \
                             RR.rcpL = __uint_as_float(rf[0]); RR.Lf = __uint_as_float(rf[1]); RR.rcpC = __uint_as_float(rf[2]); RR.center = __uint_as_float(rf[3]); \
                             RR.left = (int32_t)rf[4]; RR.q2 = (int32_t)rf[5]; RR.zm_raw = rf[6]; RR.sse_raw = rf[7];      \
-                        } else RR = piece_rare_of(c, H);                                                                  \
+                        } else RR = piece_rare_of(c, H, SH);                                                                  \
                     }                                                                                                     \
                     if (kind == 1u && !flushed) {              /* huge integers go straight to the slot planes: make them live */ \
                         BRC_FLUSH()                                                                                       \
@@ -1258,7 +1264,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                         at0 = (uint32_t)__builtin_amdgcn_readfirstlane(at0);                                              \
                         const uint64_t below = mask & ((1ull << lr) - 1ull);                                              \
                         const uint32_t at = at0 + (uint32_t)__builtin_popcountll(below);                                  \
-                        if (mine && at < pl.xev_cap) *BRC_CK(c, CK_PILEUP, 20, CB_XEV, pl.xev + ((size_t)xshard * pl.xev_cap + at), sizeof(XEv), tile, m) = make_xev(c, lib, kr, H, RR, lr + s_c, eq, ebk); \
+                        if (mine && at < pl.xev_cap) *BRC_CK(c, CK_PILEUP, 20, CB_XEV, pl.xev + ((size_t)xshard * pl.xev_cap + at), sizeof(XEv), tile, m) = make_xev(c, lib, kr, H, RR, lr + s_c, eq, ebk, SH); \
                     } else if (mine) drain_int(c, pl, lib, kr, RR, ebk == BRC_DOM_B() ? 0u : 1u);                         \
                 }                                                                                                         \
                 qn = 0;                                                                                                   \
@@ -1359,7 +1365,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         { const uint32_t* q = (const uint32_t*)BRC_CKS(c, CK_PILEUP, 23, CB_DEPTH, reinterpret_cast<const char*>(pl.depth + (int64_t)lib * P + tb), 256, tile, -1); BRC_ST(q, a.depth); }
         { const uint32_t* q = (const uint32_t*)BRC_CKS(c, CK_PILEUP, 24, CB_SLOTID, reinterpret_cast<const char*>(pl.slotid + (int64_t)lib * P + tb), 256, tile, -1); BRC_ST(q, sid); }
         uint32_t dv[NI], av[NI];
-        pack_unpack(a.dom, eb_index(a.dom_b), dv); pack_unpack(a.alt, eb_index(a.alt_b), av);     // (the slots' base indices; no alternate yet: all zeros)
+        pack_unpack(a.dom, eb_index(a.dom_b), (uint32_t)SH, dv); pack_unpack(a.alt, eb_index(a.alt_b), (uint32_t)SH, av);     // (the slots' base indices; no alternate yet: all zeros)
         uint32_t* i0 = (uint32_t*)BRC_CKS(c, CK_PILEUP, 25, CB_SI, reinterpret_cast<const char*>(slot_i(c, pl, lib, 0u, tb)), ((uint64_t)(NI - 1) * (uint64_t)P + 64u) * 4u, tile, -1);
         uint32_t* i1 = (uint32_t*)BRC_CKS(c, CK_PILEUP, 26, CB_SI, reinterpret_cast<const char*>(slot_i(c, pl, lib, 1u, tb)), ((uint64_t)(NI - 1) * (uint64_t)P + 64u) * 4u, tile, -1);
         if (__builtin_expect(flushed, 0)) {
@@ -1735,7 +1741,7 @@ class HipBackend : public Backend {
         c.ibucket_shift = indel_bucket_shift(s.n_indel_ops, c.P, c.Lp);
         if (const char* ib = test_knob(TK_IBUCKET_SHIFT)) { const int v = atoi(ib); if (v == 4 || v == 6) c.ibucket_shift = v; }   // (test knob: both supported sizes; anything else is ignored)
         // test knobs (brc_host.h: TestKnob — the constant nullptr in the product): small K -> flushes, small limit -> PF_HUGE, forced dominant bucket -> third alleles
-        choose_pack(s.max_lqseq, test_knob(TK_FLUSH_K) ? atoi(test_knob(TK_FLUSH_K)) : 0, test_knob(TK_PACK_LIM) ? atoi(test_knob(TK_PACK_LIM)) : 0, c.flush_k, c.pack_lim);
+        choose_pack(s.max_lqseq, test_knob(TK_FLUSH_K) ? atoi(test_knob(TK_FLUSH_K)) : 0, test_knob(TK_PACK_LIM) ? atoi(test_knob(TK_PACK_LIM)) : 0, c.flush_k, c.pack_lim, c.pack_lim_lo, c.pack_shift);
         c.force_dom = test_knob(TK_FORCE_DOM) ? atoi(test_knob(TK_FORCE_DOM)) : -1;
 #ifdef BRC_CHECKED
         HIPCHK(d_chk.ensure(sizeof(ChkState))); c.chk = d_chk.p;
@@ -1864,16 +1870,14 @@ class HipBackend : public Backend {
             const int64_t rl = c.ref_hi - c.ref_lo;
             if (c.has_ref)
                 hipLaunchKernelGGL(k_refcode, dim3((unsigned)(((rl + 2 * REFCODE_PAD + 15) / 16 + 255) / 256)), dim3(256), 0, stream, in.ref, (uint8_t*)d_refcode.p, rl);
-            if (Lp == 1) {
-                hipLaunchKernelGGL((k_annotate_groups<true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (const uint32_t*)d_pieceoff.p,
-                                   (Piece*)d_pieces.p, (PieceRare*)d_rare.p, (int2*)d_keyreach.p,
-                                   (uint8_t*)in.eb, (uint16_t*)in.bqw, indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p,
-                                   in.cigar, in.qual, in.seq4, (const uint8_t*)d_refcode.p + REFCODE_PAD, has_wanted ? (const uint16_t*)d_wanted.p : (const uint16_t*)nullptr);
-            } else {
-                hipLaunchKernelGGL((k_annotate_groups<false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (const uint32_t*)d_pieceoff.p,
-                                   (Piece*)d_pieces.p, (PieceRare*)d_rare.p, (int2*)d_keyreach.p,
-                                   (uint8_t*)in.eb, (uint16_t*)in.bqw, indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p,
-                                   in.cigar, in.qual, in.seq4, (const uint8_t*)d_refcode.p + REFCODE_PAD, has_wanted ? (const uint16_t*)d_wanted.p : (const uint16_t*)nullptr);
+            {   // K1: one instantiation per (row layout, width of the narrow packed fields — choose_pack)
+#define BRC_LAUNCH_K1(OS, SH) hipLaunchKernelGGL((k_annotate_groups<OS, SH>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (const uint32_t*)d_pieceoff.p, \
+                                   (Piece*)d_pieces.p, (PieceRare*)d_rare.p, (int2*)d_keyreach.p,                                                                               \
+                                   (uint8_t*)in.eb, (uint16_t*)in.bqw, indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p,                                    \
+                                   in.cigar, in.qual, in.seq4, (const uint8_t*)d_refcode.p + REFCODE_PAD, has_wanted ? (const uint16_t*)d_wanted.p : (const uint16_t*)nullptr)
+                if (Lp == 1) { if (c.pack_shift == 16) BRC_LAUNCH_K1(true, 16); else BRC_LAUNCH_K1(true, 12); }
+                else { if (c.pack_shift == 16) BRC_LAUNCH_K1(false, 16); else BRC_LAUNCH_K1(false, 12); }
+#undef BRC_LAUNCH_K1
             }
             if (c.per_lib) {
                 HIPCHK(hipMemsetAsync(d_unavail.p, 0xff, (size_t)c.PS * 4, stream));
@@ -1936,16 +1940,12 @@ class HipBackend : public Backend {
 #else
             const unsigned dyn_lds = 0u;
 #endif
-            if (has_wanted) {
-                if (n_listed > 0)
-                            hipLaunchKernelGGL((k_pileup2<true>), dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), dyn_lds, stream, c, in, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p,
-                               (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.eb, in.bqw, (const uint32_t*)d_unavail.p,
-                               (const uint8_t*)d_refcode.p + REFCODE_PAD, (const uint16_t*)d_wanted.p, (const uint32_t*)d_tilelist.p, n_listed);
-            } else {
-                            hipLaunchKernelGGL((k_pileup2<false>), dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), dyn_lds, stream, c, in, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p,
-                               (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.eb, in.bqw, (const uint32_t*)d_unavail.p,
-                               (const uint8_t*)d_refcode.p + REFCODE_PAD, (const uint16_t*)d_wanted.p, (const uint32_t*)d_tilelist.p, n_listed);
-            }
+#define BRC_LAUNCH_KP(W, SH) hipLaunchKernelGGL((k_pileup2<W, SH>), dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), dyn_lds, stream, c, in, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p, \
+                               (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.eb, in.bqw, (const uint32_t*)d_unavail.p,                                                     \
+                               (const uint8_t*)d_refcode.p + REFCODE_PAD, (const uint16_t*)d_wanted.p, (const uint32_t*)d_tilelist.p, n_listed)
+            if (has_wanted) { if (n_listed > 0) { if (c.pack_shift == 16) BRC_LAUNCH_KP(true, 16); else BRC_LAUNCH_KP(true, 12); } }
+            else { if (c.pack_shift == 16) BRC_LAUNCH_KP(false, 16); else BRC_LAUNCH_KP(false, 12); }
+#undef BRC_LAUNCH_KP
             hipLaunchKernelGGL(k_xev_compact, dim3((unsigned)XEV_SHARDS), dim3(256), 0, stream, (const XEv*)d_xev.p, (const uint32_t*)d_xevn.p, (uint32_t)xev_cap,
                                (uint32_t)XEV_SHARDS, (XEv*)d_xevc.p, ctr);
         }

@@ -52,7 +52,7 @@ int main() {
             for (int left = 0; left + cl <= L; left += 3)
                 for (int tp = 0; tp < L; tp += 11)
                     for (int qpos = 0; qpos < L; ++qpos, ++tot) {
-                        const brc::EvTerms t = brc::piece_terms_inlane(brc::PF_Q2OK, (uint32_t)tp | ((uint32_t)L << 8) | ((uint32_t)left << 16), (uint32_t)cl << 16, (uint32_t)qpos);
+                        const brc::EvTerms t = brc::piece_terms_inlane(brc::PF_Q2OK, (uint32_t)tp | ((uint32_t)L << 8) | ((uint32_t)left << 16), (uint32_t)cl, (uint32_t)qpos);
                         const float center = (float)cl * 0.5f; float d = (float)(qpos - left) - center; d = d < 0 ? -d : d;
                         const float s3p = (float)(qpos > tp ? qpos - tp : tp - qpos) / (float)L; const double sev = 1.0 - (double)(d / center);
                         if (bits(t.s3p) != bits(s3p) || bits(t.q2) != bits(s3p) || memcmp(&sev, &t.sev, 8) != 0) ++bad;

@@ -44,7 +44,7 @@ class SimBackend : public Backend {
         c.force_dom = getenv("BRC_FORCE_DOM") ? atoi(getenv("BRC_FORCE_DOM")) : -1;
         c.ibucket_shift = indel_bucket_shift(s.n_indel_ops, c.P, c.Lp);
         if (const char* ib = getenv("BRC_IBUCKET_SHIFT")) { const int v = atoi(ib); if (v == 4 || v == 6) c.ibucket_shift = v; }   // (as the HIP backend: the two supported sizes)
-        choose_pack(s.max_lqseq, getenv("BRC_FLUSH_K") ? atoi(getenv("BRC_FLUSH_K")) : 0, getenv("BRC_PACK_LIM") ? atoi(getenv("BRC_PACK_LIM")) : 0, c.flush_k, c.pack_lim);
+        choose_pack(s.max_lqseq, getenv("BRC_FLUSH_K") ? atoi(getenv("BRC_FLUSH_K")) : 0, getenv("BRC_PACK_LIM") ? atoi(getenv("BRC_PACK_LIM")) : 0, c.flush_k, c.pack_lim, c.pack_lim_lo, c.pack_shift);
         tq.assign((size_t)TABLE_MAX + 2, 0.0f); te.assign((size_t)TABLE_MAX + 2, 0.0);
         for (int k = 0; k <= c.table_len; ++k) { tq[(size_t)k] = (float)k / (float)c.table_len; te[(size_t)k] = 1.0 - (double)tq[(size_t)k]; }
         in.pos = s.pos.p; in.flag = s.flag.p; in.mapq = s.mapq.p; in.lib = s.lib.p; in.l_qseq = s.l_qseq.p; in.n_cigar = s.n_cigar.p;
@@ -103,8 +103,8 @@ class SimBackend : public Backend {
                         if (!bucket_acgt(w16 & 0xffu)) { a[l].ww += h.ww; full.lane[l] = true; any_full = true; continue; }
                         w = ((w16 >> 8) << 2) | ((w16 & 0xffu) - 1u);
                     }
-                    EvTerms t = (fl & (PF_TABLE | PF_TABQ)) ? piece_terms_tab(h, tt, c.table_len, qpos) : (fl & PF_DIV) ? piece_terms_inlane(fl, h.tp_flags, h.w3, qpos) : piece_terms_div(fl, piece_tp(c, h), rare[m], qpos);
-                    if ((fl & PF_TABQ) && !(fl & PF_HUGE)) t.sev = tabq_sev(qpos, piece_left_field(h.tp_flags), h.w3 >> 16);       // (as k_pileup2 does: no rare record)
+                    EvTerms t = (fl & (PF_TABLE | PF_TABQ)) ? piece_terms_tab(h, tt, c.table_len, qpos) : (fl & PF_DIV) ? piece_terms_inlane(fl, h.tp_flags, h.w3 >> c.pack_shift, qpos) : piece_terms_div(fl, piece_tp(c, h), rare[m], qpos);
+                    if ((fl & PF_TABQ) && !(fl & PF_HUGE)) t.sev = tabq_sev(qpos, piece_left_field(h.tp_flags), h.w3 >> c.pack_shift);       // (as k_pileup2 does: no rare record)
                     const uint32_t b = (w & 3u) + 1u;
                     a[l].ww += h.ww;
                     if (b == a[l].dom_b) { pack_event(a[l].dom, h, t, w); if (fl & PF_HUGE) { ints.lane[l] = true; any_int = true; } }
@@ -167,7 +167,7 @@ class SimBackend : public Backend {
             const ReadConst rc = read_const(c, rd, (uint32_t)i, wide);
             uint32_t slot = st->piece_off.p[i], cnt = 0;
             walk_pieces(c.insertion_centric != 0, enters && !nolib, rc.counts, rd.pos, cg, in.n_cigar[i], [&](int32_t rs, int32_t len, int32_t ext, int qoff, bool nb) {
-                PieceRare rr; make_piece(c, rc, rs, len, ext, qoff, nb, hot[slot], rr);
+                PieceRare rr; make_piece(c, rc, rs, len, ext, qoff, nb, hot[slot], rr, c.pack_shift);
                 if (piece_has_rare(piece_flags(hot[slot]))) rare[slot] = rr;
                 key[slot] = rd.pos; reach[slot] = rs + ext; ++slot; ++cnt;
             });

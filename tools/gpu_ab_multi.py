@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--wgs-mbp", type=float, default=50.0)
     ap.add_argument("--tumor-mbp", type=float, default=6.25)
+    ap.add_argument("--long-mbp", type=float, default=20.0)
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -42,7 +43,7 @@ def main():
     assert torch.cuda.is_available() or os.environ.get("BRC_AB_NO_GPU")
     libs = [(os.path.basename(p).replace("libbrc_hip", "").replace(".so", "").strip("_") or "default", capi.Library(os.path.abspath(p))) for p in args.libs]
     for shape in args.shapes.split(","):
-        config = {"tumor": "tumor200x", "mixed": "wgs30x_mixed"}.get(shape, "wgs30x")
+        config = {"tumor": "tumor200x", "mixed": "wgs30x_mixed", "long": "long10k"}.get(shape, "wgs30x")
         # "wgs_notable": config 3 with the quotient tables switched off (BRC_NO_TABLE, read at upload): every piece takes the
         # path of a read of another length — what that path costs per piece, measured directly
         if shape.endswith("_notable"):
@@ -63,7 +64,7 @@ def main():
                 want = d
             print("%s check %-10s %s %s" % (shape, name, d, "ok" if d == want else "DIFFERENT"), flush=True)
         # ---- timings
-        n = int((args.tumor_mbp if per_lib else args.wgs_mbp) * 1e6)
+        n = int((args.tumor_mbp if per_lib else args.long_mbp if shape == "long" else args.wgs_mbp) * 1e6)
         ref, arrs = synthgen.generate(n, config, seed=1)
         times = {name: [] for name, _ in libs}
         for rep in range(args.reps):
