@@ -2,7 +2,11 @@
 #include "bamio.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <stdlib.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <string.h>
 #include <zlib.h>
 
@@ -499,6 +503,47 @@ bool Fasta::fetch(const std::string& name, std::string* seq) {
     }
     seq->resize((size_t)done);
     return true;
+}
+
+Fasta::~Fasta() { if (map_) munmap((void*)map_, (size_t)map_len_); }
+
+int64_t Fasta::read_range(const std::string& name, int64_t beg, int64_t n, char* dst, int64_t* contig_len) {
+    auto it = idx_.find(name);
+    if (it == idx_.end()) { err_ = "sequence " + name + " not in FASTA index"; return -1; }
+    const Ent& e = it->second;
+    if (!map_tried_) {
+        map_tried_ = true;
+        const int fd = ::open(path_.c_str(), O_RDONLY);
+        if (fd >= 0) {
+            struct stat st;
+            if (fstat(fd, &st) == 0 && st.st_size > 0) {
+                void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m != MAP_FAILED) { map_ = (const char*)m; map_len_ = (int64_t)st.st_size; }
+            }
+            ::close(fd);
+        }
+    }
+    if (!map_) { err_ = "cannot map " + path_; return -1; }
+    // the same entry checks as fetch(); the length fetch() would return: the index's, cut where the file ends
+    if (e.len < 0 || e.off < 0 || e.linebases <= 0 || e.linewidth < e.linebases || e.off > map_len_ || e.len > map_len_ - e.off) { err_ = "the FASTA index entry of " + name + " does not fit " + path_; return -1; }
+    int64_t have = e.len;
+    {   // bases actually present: whole lines of linebases, the last line as far as the file goes
+        const int64_t avail = map_len_ - e.off;
+        const int64_t full = avail / e.linewidth, rest = std::min<int64_t>(avail - full * e.linewidth, e.linebases);
+        have = std::min<int64_t>(e.len, full * e.linebases + rest);
+    }
+    if (contig_len) *contig_len = have;
+    if (beg < 0) beg = 0;
+    if (beg >= have || n <= 0) return 0;
+    if (n > have - beg) n = have - beg;
+    int64_t done = 0;
+    while (done < n) {
+        const int64_t x = beg + done, line = x / e.linebases, col = x % e.linebases;
+        const int64_t k = std::min<int64_t>(e.linebases - col, n - done);
+        memcpy(dst + done, map_ + e.off + line * e.linewidth + col, (size_t)k);
+        done += k;
+    }
+    return done;
 }
 
 }  // namespace brcio

@@ -135,6 +135,13 @@ class Fasta {
     bool open(const std::string& path);            // reads <path>.fai, or builds (and writes) it like fai_load does
     // whole contig, raw characters (case preserved), like fai_fetch(fai, name, &len)
     bool fetch(const std::string& name, std::string* seq);
+    // Bases [beg, beg + n) of a contig as raw characters, WITHOUT loading the contig (the file is mapped once): the site-list
+    // planner needs a few hundred bases around each -l line, and a whole-genome list visits every contig — fai_fetch of 24
+    // chromosomes for 100 000 one-base windows was a sixth of the run.  Returns the bases copied (fewer where the contig — or the
+    // file behind a longer index entry — ends), -1 for an unknown contig or an unreadable file; *contig_len = the length a whole
+    // fetch() would return.
+    int64_t read_range(const std::string& name, int64_t beg, int64_t n, char* dst, int64_t* contig_len);
+    ~Fasta();
     const std::string& error() const { return err_; }
 
   private:
@@ -142,6 +149,7 @@ class Fasta {
     bool build_index();
     std::map<std::string, Ent> idx_;
     std::string path_, err_;
+    const char* map_ = nullptr; int64_t map_len_ = 0; bool map_tried_ = false;      // read_range: the file, mapped read-only
 };
 
 // ---------------------------------------------------------------- CRAM 3.0 (minimal, cram.cpp)

@@ -556,16 +556,22 @@ static int run_site_batch(Ctx& c, const std::vector<Site>& sites, SiteFetch* pre
         for (size_t i = i0; i < i1; ++i) {
             const Site& st = sites[i];
             if (c.have_fa) {
-                if (st.tid != c.ref_tid) {
-                    if (!c.fa.fetch(h.names[(size_t)st.tid], &c.ref)) { c.ref.clear(); fprintf(stderr, "bam-readcount: %s: no reference bases for %s\n", c.fa.error().c_str(), h.names[(size_t)st.tid].c_str()); }
-                    c.ref_tid = st.tid;
-                }
-                // past the contig: the annotator stops at the terminating NUL (x == len, :151) but merely skips positions
-                // x > len (site-list mode, :144-148); 'N' reproduces the skip (it never counts as a mismatch, :152)
-                const int64_t clen = (int64_t)c.ref.size();
+                // The window's slice of the reference, read straight out of the mapped FASTA (Fasta::read_range): a whole-genome list
+                // visits every contig, and loading each one whole (fai_fetch, as the reference does per -l line's contig) was a sixth of
+                // the run.  Past the contig: the annotator stops at the terminating NUL (x == len, :151) but merely skips positions
+                // x > len (site-list mode, :144-148); 'N' reproduces the skip (it never counts as a mismatch, :152).
                 const int64_t x0 = std::max<int64_t>(lo[i], 0), x1 = hi[i];
-                const int64_t xin = std::min(x1, clen);                    // [x0, xin): inside the contig, copied as they are
-                if (xin > x0) memcpy(&vref[(size_t)(x0 + delta[i])], c.ref.data() + x0, (size_t)(xin - x0));
+                int64_t clen = 0;
+                int64_t got = x1 > x0 ? c.fa.read_range(h.names[(size_t)st.tid], x0, x1 - x0, &vref[(size_t)(x0 + delta[i])], &clen) : 0;
+                if (got < 0) {         // (no mapping / unknown contig: the whole contig, as before)
+                    if (st.tid != c.ref_tid) {
+                        if (!c.fa.fetch(h.names[(size_t)st.tid], &c.ref)) { c.ref.clear(); fprintf(stderr, "bam-readcount: %s: no reference bases for %s\n", c.fa.error().c_str(), h.names[(size_t)st.tid].c_str()); }
+                        c.ref_tid = st.tid;
+                    }
+                    clen = (int64_t)c.ref.size();
+                    const int64_t xin = std::min(x1, clen);
+                    if (xin > x0) memcpy(&vref[(size_t)(x0 + delta[i])], c.ref.data() + x0, (size_t)(xin - x0));
+                }
                 for (int64_t x = std::max(x0, clen); x < x1; ++x) vref[(size_t)(x + delta[i])] = x == clen ? '\0' : 'N';
             }
             // the line's reads move to its window of the virtual axis where they are (no second copy of the batch)
