@@ -20,7 +20,7 @@ F_NAMES = ["sev", "sq2", "snm", "s3p"]
 EXPORTS = [
     "brc_strerror", "brc_last_error", "brc_kernel_name", "brc_engine_kind", "brc_create", "brc_destroy",
     "brc_begin_region", "brc_push_reads", "brc_upload", "brc_compute", "brc_fetch_result", "brc_end_region",
-    "brc_clear_indel_queue", "brc_region_counts", "brc_format_region", "brc_format_window", "brc_region_windows", "brc_region_warnings", "brc_window_warnings", "brc_warnings_text", "brc_set_option", "brc_format_region_parts", "brc_set_chrom", "brc_fetch_window", "brc_compute_n",
+    "brc_clear_indel_queue", "brc_region_counts", "brc_format_region", "brc_format_window", "brc_region_windows", "brc_region_warnings", "brc_window_warnings", "brc_warnings_text", "brc_set_option", "brc_format_region_parts", "brc_set_chrom", "brc_fetch_window", "brc_compute_n", "brc_host_alloc", "brc_host_free", "brc_push_reads_pinned",
 ]
 
 
@@ -88,6 +88,10 @@ class Library:
             L.brc_set_chrom.argtypes = [C.c_void_p, C.c_char_p]
         L.brc_begin_region.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]
         L.brc_push_reads.argtypes = [C.c_void_p, C.POINTER(ReadBatch)]
+        if hasattr(L, "brc_push_reads_pinned"):   # (zero-copy feed: the engine libraries; the checkers only copy)
+            L.brc_push_reads_pinned.argtypes = [C.c_void_p, C.POINTER(ReadBatch)]
+            L.brc_host_alloc.restype = C.c_void_p; L.brc_host_alloc.argtypes = [C.c_size_t]
+            L.brc_host_free.restype = None; L.brc_host_free.argtypes = [C.c_void_p]
         L.brc_upload.argtypes = [C.c_void_p]
         L.brc_compute.argtypes = [C.c_void_p, C.POINTER(Timing)]
         if hasattr(L, "brc_compute_n"):
@@ -244,6 +248,7 @@ class Engine:
             self._check(lib.lib.brc_set_chrom(self.h, device_text.encode()))
         self._ref = None
         self._res = Result()
+        self._pinned = []           # brc_host_alloc buffers of the current region (push_reads_pinned)
 
     def _check(self, rc, create=False):
         if rc != 0:
@@ -256,6 +261,7 @@ class Engine:
         if self.h:
             self.L.lib.brc_destroy(self.h)
             self.h = C.c_void_p()
+            self._free_pinned()
 
     def __del__(self):
         try:
@@ -265,6 +271,7 @@ class Engine:
 
     def begin_region(self, tid, beg0, end, ref):
         """ref: None or contiguous uint8 numpy array / bytes holding the whole contig."""
+        self._free_pinned()                           # (the previous region's adopted arenas: the engine is done with them now)
         if ref is None:
             self._ref = None
             self._check(self.L.lib.brc_begin_region(self.h, tid, beg0, end, None, 0))
@@ -276,6 +283,28 @@ class Engine:
         b, keep = make_batch(arrs)
         self._check(self.L.lib.brc_push_reads(self.h, C.byref(b)))
         del keep
+
+    def push_reads_pinned(self, arrs):
+        """brc_push_reads_pinned: seq4 / qual are first copied into brc_host_alloc memory (what a decoder would have written there
+        itself), which this object keeps alive until the next begin_region / close — the engine reads them in place."""
+        lib = self.L.lib
+        pinned = {}
+        for k in ("seq4", "qual"):
+            a = np.ascontiguousarray(arrs[k], np.uint8)
+            p = lib.brc_host_alloc(max(a.size, 1))
+            if not p:
+                raise BrcError("brc_host_alloc failed")
+            C.memmove(p, a.ctypes.data, a.size)
+            buf = np.ctypeslib.as_array((C.c_uint8 * max(a.size, 1)).from_address(p))[:a.size]
+            self._pinned.append(p); pinned[k] = buf
+        b, keep = make_batch(dict(arrs, **pinned))
+        self._check(lib.brc_push_reads_pinned(self.h, C.byref(b)))
+        del keep
+
+    def _free_pinned(self):
+        for p in self._pinned:
+            self.L.lib.brc_host_free(p)
+        self._pinned = []
 
     def upload(self):
         self._check(self.L.lib.brc_upload(self.h))

@@ -1728,6 +1728,15 @@ class HipBackend : public Backend {
         return BRC_OK;
     }
 
+    // SEQ / QUAL: from the staging copy, or — brc_push_reads_pinned — segment by segment from the caller's page-locked buffers
+    int up_arena(DBuf& d, const HBuf<uint8_t>& h, const std::vector<Staged::Seg>& segs, uint64_t total) {
+        if (segs.empty()) return up(d, h, h.n);
+        HIPCHK(d.ensure((size_t)total + 16));
+        for (const Staged::Seg& g : segs) if (g.n) HIPCHK(hipMemcpyAsync((uint8_t*)d.p + g.off, g.p, (size_t)g.n, hipMemcpyHostToDevice, stream));
+        return BRC_OK;
+    }
+    bool adopts_arenas() const override { return true; }
+
     int upload(const brc_config& cfg, const Staged& s, Geometry& g) override {
         HIPCHK(hipSetDevice(device));
         computed = false;
@@ -1755,7 +1764,7 @@ class HipBackend : public Backend {
         if ((rc = up(d_pos, s.pos, n)) || (rc = up(d_flag, s.flag, n)) || (rc = up(d_mapq, s.mapq, n)) || (rc = up(d_lib, s.lib, n)) ||
             (rc = up(d_lq, s.l_qseq, n)) || (rc = up(d_nc, s.n_cigar, n)) || (rc = up(d_co, s.cig_off, n)) || (rc = up(d_so, s.seq_off, n)) ||
             (rc = up(d_qo, s.qual_off, n)) || (rc = up(d_nm, s.nm, n)) || (rc = up(d_sm, s.sm, n)) || (rc = up(d_tags, s.tags, n)) ||
-            (rc = up(d_cigar, s.cigar, s.cigar.n)) || (rc = up(d_seq, s.seq4, s.seq4.n)) || (rc = up(d_qual, s.qual, s.qual.n)))
+            (rc = up(d_cigar, s.cigar, s.cigar.n)) || (rc = up_arena(d_seq, s.seq4, s.seq_seg, s.seq_total)) || (rc = up_arena(d_qual, s.qual, s.qual_seg, s.qual_total)))
             return rc;
         const size_t rl = (size_t)(g.ref_hi - g.ref_lo);
         HIPCHK(d_ref.ensure(rl + 16));
@@ -2180,6 +2189,14 @@ class HipBackend : public Backend {
         return BRC_OK;
     }
 };
+
+// brc_host_alloc: page-locked memory every device context of the process can copy from (the engines of one process may sit on several GPUs)
+void* backend_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) return nullptr;
+    return p;
+}
+void backend_host_free(void* p) { (void)hipHostFree(p); }
 
 Backend* make_backend(const brc_config& cfg, int* errc) {
     // Engines are created one at a time, process-wide: the first calls into the HIP runtime (device initialisation, code-object

@@ -103,6 +103,7 @@ void Staged::clear() {
     pos.clear(); flag.clear(); mapq.clear(); lib.clear(); l_qseq.clear(); n_cigar.clear(); cig_off.clear(); seq_off.clear();
     qual_off.clear(); nm.clear(); sm.clear(); tags.clear(); cigar.clear(); seq4.clear(); qual.clear(); bq_row.clear();
     bq_elems = 0; memset(len_hist, 0, sizeof len_hist); n = 0; min_pos = 0; max_end = 0; n_indel_ops = 0;
+    seq_seg.clear(); qual_seg.clear(); seq_total = 0; qual_total = 0;
     piece_cnt.clear(); piece_off.clear(); iev_off.clear(); lib_base.clear(); n_pieces = 0; max_lqseq = 0; max_span = 0; qnames.clear(); qname_off.clear();
     win_beg.clear(); win_end.clear();
 }
@@ -371,7 +372,7 @@ static void assemble_indels(const brc_engine* e, const IndelOut* list, int64_t n
         std::string& a = txt[(size_t)i];
         if (o.len > 0) {
             a.push_back('+');
-            const uint8_t* seq = s.seq4.p + s.seq_off.p[o.rep_read];
+            const uint8_t* seq = s.seq_at(s.seq_off.p[o.rep_read]);
             const int32_t L = s.l_qseq.p[o.rep_read];
             for (int j = 0; j < o.len; ++j) { const int q = o.rep_qpos + 1 + j; a.push_back(q < L ? "=ACGTN"[canon_bucket(seqi(seq, q))] : 'N'); }
         } else {
@@ -497,18 +498,23 @@ static inline int32_t cigar_rlen(const uint32_t* cig, uint32_t nc, uint64_t* n_i
     return l > INT32_MAX ? -1 : (int32_t)l;
 }
 
-static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touched);
+static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touched, bool pinned);
 
 // A refused batch leaves the staging arrays half appended (per-read arrays and arenas grow before a record is found bad),
 // so the region cannot take further batches: it is abandoned — every later push / upload on it fails with "outside an open
 // region" until the caller opens the next one with brc_begin_region (which resets the staging).
-int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
+void* brc_host_alloc(size_t bytes) { return backend_host_alloc(bytes); }
+void brc_host_free(void* p) { if (p) backend_host_free(p); }
+static int push_reads_any(brc_engine* e, const brc_read_batch* b, bool pinned);
+int brc_push_reads(brc_engine* e, const brc_read_batch* b) { return push_reads_any(e, b, false); }
+int brc_push_reads_pinned(brc_engine* e, const brc_read_batch* b) { return push_reads_any(e, b, true); }
+static int push_reads_any(brc_engine* e, const brc_read_batch* b, bool pinned) {
     if (!e || !b) return BRC_E_ARG;
     bool touched = false;
     int rc;
     // no exception crosses the C boundary: the parallel staging path allocates (per-chunk tables, the job's std::function), and a C
     // caller would see std::terminate
-    try { rc = push_reads_staged(e, b, &touched); }
+    try { rc = push_reads_staged(e, b, &touched, pinned); }
     catch (const std::bad_alloc&) { touched = true; rc = fail(e, BRC_E_NOMEM, "host allocation failed while staging reads"); }
     catch (const std::exception& ex) { touched = true; rc = fail(e, BRC_E_NOMEM, ex.what()); }
     catch (...) { touched = true; rc = fail(e, BRC_E_NOMEM, "unexpected failure while staging reads"); }
@@ -516,7 +522,7 @@ int brc_push_reads(brc_engine* e, const brc_read_batch* b) {
     return rc;
 }
 
-static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touched) {
+static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touched, bool pinned) {
     if (e->state != 1) return fail(e, BRC_E_ARG, "brc_push_reads outside an open region");
     if (b->n_reads < 0) return fail(e, BRC_E_ARG, "negative n_reads");
     if (e->cfg.per_lib && !b->lib && b->n_reads) return fail(e, BRC_E_ARG, "per-library mode needs brc_read_batch.lib");
@@ -526,13 +532,16 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
     const size_t n = (size_t)b->n_reads, n0 = (size_t)s.n;
     if ((uint64_t)s.n + n >= 0xFFFFFFF0ull || s.cigar.n + b->n_cigar_total >= 0xFFFFFFF0ull)
         return fail(e, BRC_E_LIMIT, "more than 2^32 reads or CIGAR operators in one region: split the region");
-    const uint64_t cb = s.cigar.n, sb = s.seq4.n, qb = s.qual.n;
+    // adopted arenas (brc_push_reads_pinned on a backend that uploads them in place): the region's first push decides for the region
+    const bool adopt = pinned && e->be->adopts_arenas();
+    if (s.n > 0 && adopt != s.adopted() && (s.seq_total || s.qual_total)) return fail(e, BRC_E_ARG, "a region takes brc_push_reads or brc_push_reads_pinned, not both");
+    const uint64_t cb = s.cigar.n, sb = s.seq_total, qb = s.qual_total;
     if (e->hint_reads > n0 + n || e->hint_bases > qb + b->qual_bytes) {
         const size_t hr = std::max(e->hint_reads, n0 + n) + 16, hb = std::max<size_t>(e->hint_bases, qb + b->qual_bytes) + 16;
         bool okh = s.pos.reserve(hr) && s.flag.reserve(hr) && s.mapq.reserve(hr) && s.l_qseq.reserve(hr) && s.n_cigar.reserve(hr) && s.cig_off.reserve(hr) &&
                    s.seq_off.reserve(hr) && s.qual_off.reserve(hr) && s.bq_row.reserve(hr) && s.piece_cnt.reserve(hr) && s.piece_off.reserve(hr) && s.iev_off.reserve(hr) && s.lib.reserve(hr) &&
                    s.nm.reserve(hr) && s.sm.reserve(hr) && s.tags.reserve(hr) && s.qname_off.reserve(hr) && s.cigar.reserve(hr + hr / 4) &&
-                   s.qual.reserve(hb) && s.seq4.reserve(hb / 2 + hr);
+                   (adopt || (s.qual.reserve(hb) && s.seq4.reserve(hb / 2 + hr)));
         if (!okh) return fail(e, BRC_E_NOMEM, "host staging allocation failed");
     }
     // the staging stage's threads (a share of the CPUs the process may use; BRC_OPT_FORMAT_THREADS caps it like the formatter's)
@@ -545,9 +554,14 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
     bool ok = s.pos.append(b->pos, n) && s.flag.append(b->flag, n) && s.mapq.append(b->mapq, n) && s.l_qseq.append(b->l_qseq, n) &&
               s.n_cigar.append(b->n_cigar, n) && s.cig_off.append(b->cigar_off, n) && s.seq_off.append(b->seq_off, n) &&
               s.qual_off.append(b->qual_off, n) && s.cigar.append(b->cigar, b->n_cigar_total) &&
-              append_big(pool, s.seq4, b->seq4, b->seq_bytes) && append_big(pool, s.qual, b->qual, b->qual_bytes) &&
+              (adopt || (append_big(pool, s.seq4, b->seq4, b->seq_bytes) && append_big(pool, s.qual, b->qual, b->qual_bytes))) &&
               s.bq_row.reserve(n0 + n + 16) && s.piece_cnt.reserve(n0 + n + 16) && s.piece_off.reserve(n0 + n + 16) && s.iev_off.reserve(n0 + n + 16) && s.lib.reserve(n0 + n + 16) && s.nm.reserve(n0 + n + 16) && s.sm.reserve(n0 + n + 16) && s.tags.reserve(n0 + n + 16);
     if (!ok) return fail(e, BRC_E_NOMEM, "host staging allocation failed");
+    if (adopt) {
+        if (b->seq_bytes) { Staged::Seg g; g.p = b->seq4; g.off = sb; g.n = b->seq_bytes; s.seq_seg.push_back(g); }
+        if (b->qual_bytes) { Staged::Seg g; g.p = b->qual; g.off = qb; g.n = b->qual_bytes; s.qual_seg.push_back(g); }
+    }
+    s.seq_total = sb + b->seq_bytes; s.qual_total = qb + b->qual_bytes;
     if (!s.qname_off.reserve(n0 + n + 16)) return fail(e, BRC_E_NOMEM, "host staging allocation failed");
     for (size_t i = 0; i < n; ++i) {
         uint64_t off = ~0ull;
@@ -1465,7 +1479,7 @@ static int warnings_impl(brc_engine* e, const char* chrom, int64_t wbeg0, int64_
                     if (r.lib_less) { emit(BRC_W_LIB_UNAVAILABLE, r.i); break; }                            // :281-284
                     const WEv ev = resolve_at(s.cigar.p + s.cig_off.p[r.i], s.n_cigar.p[r.i], r.pos, (int32_t)p);
                     if (!ev.in_col || ev.is_del) continue;
-                    if ((int)s.mapq.p[r.i] < cfg.min_mapq || ev.qpos >= s.l_qseq.p[r.i] || (int)s.qual.p[s.qual_off.p[r.i] + (uint64_t)ev.qpos] < cfg.min_bq) continue;   // :288
+                    if ((int)s.mapq.p[r.i] < cfg.min_mapq || ev.qpos >= s.l_qseq.p[r.i] || (int)s.qual_at(s.qual_off.p[r.i] + (uint64_t)ev.qpos)[0] < cfg.min_bq) continue;   // :288
                     if (s.flag.p[r.i] & BRC_NOCOUNT_MASK) continue;                                         // :295-310
                     const int calls = ((ev.indel != 0 && g.ref) ? 1 : 0) + ((ev.indel < 1 || !cfg.insertion_centric) ? 1 : 0);   // :315-346
                     for (int c2 = 0; c2 < calls; ++c2) {                                                    // BasicStat::process_read

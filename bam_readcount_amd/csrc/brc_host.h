@@ -56,6 +56,20 @@ struct Staged {
     HBuf<int32_t> pos; HBuf<uint16_t> flag; HBuf<uint8_t> mapq; HBuf<int16_t> lib; HBuf<int32_t> l_qseq;
     HBuf<uint32_t> n_cigar; HBuf<uint64_t> cig_off, seq_off, qual_off; HBuf<int32_t> nm, sm; HBuf<uint8_t> tags;
     HBuf<uint32_t> cigar; HBuf<uint8_t> seq4, qual;
+    // brc_push_reads_pinned: arenas the caller keeps in page-locked memory of its own — logical bytes [off, off + n) of seq4 / qual live at
+    // p (nothing is copied into the HBufs above, which stay empty for such a region); seq_total / qual_total are the arenas' logical
+    // lengths in either case (what the next batch's offsets are rebased by, what the device buffers are sized for)
+    struct Seg { const uint8_t* p; uint64_t off, n; };
+    std::vector<Seg> seq_seg, qual_seg;
+    uint64_t seq_total = 0, qual_total = 0;
+    bool adopted() const { return !seq_seg.empty() || !qual_seg.empty(); }
+    static const uint8_t* seg_at(const std::vector<Seg>& v, uint64_t off) {
+        size_t lo = 0, hi = v.size();                              // last segment whose off <= the wanted offset
+        while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (v[mid].off <= off) lo = mid; else hi = mid; }
+        return v[lo].p + (off - v[lo].off);
+    }
+    const uint8_t* seq_at(uint64_t off) const { return seq_seg.empty() ? seq4.p + off : seg_at(seq_seg, off); }
+    const uint8_t* qual_at(uint64_t off) const { return qual_seg.empty() ? qual.p + off : seg_at(qual_seg, off); }
     HBuf<uint64_t> bq_row;              // per read: first element of its 16-byte-aligned row in the device's event-byte stream
     uint64_t bq_elems = 0;              // total elements of the event-byte stream (sum of roundup16(l_qseq))
     // KB v2: pieces (walk_pieces in brc_core.h).  piece_cnt is filled at push time; piece_off (library-major slot of a
@@ -111,6 +125,9 @@ class Backend {
   public:
     virtual ~Backend() {}
     virtual const HostAlloc* host_alloc() = 0;
+    // the backend uploads adopted arenas (Staged::seq_seg / qual_seg) from where they lie; false: brc_push_reads_pinned copies like
+    // brc_push_reads (the CPU lane simulator, whose "device" pointers ARE the staging arrays)
+    virtual bool adopts_arenas() const { return false; }
     virtual int upload(const brc_config& cfg, const Staged& s, Geometry& g) = 0;         // staging -> device; sets g.PS
     virtual int compute(brc_timing* t) = 0;                                              // whole pipeline, waits
     // n passes queued back to back with one wait (default: n waits); t = per-kernel times averaged over the passes
@@ -139,6 +156,8 @@ class Backend {
 
 // Provided by exactly one translation unit per library: brc_engine.hip (product) or tests/sim/brc_sim.cpp.
 Backend* make_backend(const brc_config& cfg, int* err);
+void* backend_host_alloc(size_t bytes);          // brc_host_alloc / brc_host_free
+void backend_host_free(void* p);
 const char* backend_kind();
 const char* backend_kernel_name(int k);
 

@@ -150,14 +150,42 @@ static bool parse_args(int argc, char** argv, Options& o, std::string* err) {
     return true;
 }
 
+// The two big arenas of a batch (SEQ, QUAL: 225 of the ~290 bytes of a 150-base read) can live in page-locked memory
+// (brc_host_alloc): the engine then uploads them from where the decoder wrote them (brc_push_reads_pinned) instead of copying them
+// into its own staging first — the copy was the longest stage of the engine thread.  A stateful allocator: `pinned` chooses.
+#include <new>
+template <class T> struct ArenaAlloc {
+    typedef T value_type; typedef std::true_type propagate_on_container_copy_assignment; typedef std::true_type propagate_on_container_move_assignment; typedef std::true_type propagate_on_container_swap;
+    bool pinned = false;
+    ArenaAlloc() {}
+    explicit ArenaAlloc(bool p) : pinned(p) {}
+    template <class U> ArenaAlloc(const ArenaAlloc<U>& o) : pinned(o.pinned) {}
+    T* allocate(size_t n) { void* p = pinned ? brc_host_alloc(n * sizeof(T)) : malloc(n * sizeof(T)); if (!p) throw std::bad_alloc(); return (T*)p; }
+    void deallocate(T* p, size_t) { if (pinned) brc_host_free(p); else free(p); }
+    template <class U> bool operator==(const ArenaAlloc<U>& o) const { return pinned == o.pinned; }
+    template <class U> bool operator!=(const ArenaAlloc<U>& o) const { return pinned != o.pinned; }
+};
+typedef std::vector<uint8_t, ArenaAlloc<uint8_t> > ArenaVec;
+
 // SoA batch in the brc_read_batch layout
 struct Batcher {
     std::vector<int32_t> pos, l_qseq, nm, sm; std::vector<uint16_t> flag; std::vector<uint8_t> mapq, tags;
     std::vector<int16_t> lib; std::vector<uint32_t> n_cigar, cigar; std::vector<uint64_t> cig_off, seq_off, qual_off;
-    std::vector<uint8_t> seq4, qual;
+    ArenaVec seq4, qual;
+    bool pinned = false; size_t seen_seq = 0, seen_qual = 0;       // arenas in page-locked memory; the largest fills seen so far (what a pinned arena is sized by)
+    // from now on this batch's arenas are page-locked, with room for what it held before and a quarter more (an allocation of
+    // page-locked memory costs milliseconds: once per buffer, not once per growth step)
+    void use_pinned() {
+        if (pinned) return;
+        try {
+            ArenaVec s2{ArenaAlloc<uint8_t>(true)}, q2{ArenaAlloc<uint8_t>(true)};
+            s2.reserve(seen_seq + seen_seq / 4 + 4096); q2.reserve(seen_qual + seen_qual / 4 + 4096);
+            seq4.swap(s2); qual.swap(q2); pinned = true;
+        } catch (...) { pinned = false; }                            // (no page-locked memory to be had: the copying path stays)
+    }
     std::vector<char> names; std::vector<size_t> name_off; mutable std::vector<const char*> name_ptr;   // read names (warning text)
     bool keep_names = true;           // -w 0: no warning text will ever be printed
-    void clear() { names.clear(); name_off.clear(); pos.clear(); l_qseq.clear(); nm.clear(); sm.clear(); flag.clear(); mapq.clear(); tags.clear(); lib.clear(); n_cigar.clear(); cigar.clear(); cig_off.clear(); seq_off.clear(); qual_off.clear(); seq4.clear(); qual.clear(); }
+    void clear() { seen_seq = std::max(seen_seq, seq4.size()); seen_qual = std::max(seen_qual, qual.size()); names.clear(); name_off.clear(); pos.clear(); l_qseq.clear(); nm.clear(); sm.clear(); flag.clear(); mapq.clear(); tags.clear(); lib.clear(); n_cigar.clear(); cigar.clear(); cig_off.clear(); seq_off.clear(); qual_off.clear(); seq4.clear(); qual.clear(); }
     void add(const BamRecord& r, int lib_index) {
         pos.push_back(r.pos); flag.push_back(r.flag); mapq.push_back(r.mapq); l_qseq.push_back(r.l_seq); n_cigar.push_back(r.n_cigar);
         lib.push_back((int16_t)lib_index);
@@ -311,7 +339,7 @@ static int lib_index(const Ctx& c, const BamRecord& r) {      // bam_get_library
 // Reads of one chunk [a-1, b) (the reference's own fetch rule, :602), decoded by a pool of BAM handles: the chunk is cut
 // by read START position into K stripes; stripe i keeps the records whose pos lies in its stripe (stripe 0 also the reads
 // that start before the chunk), so the stripes concatenated are exactly the single-handle fetch, in file order.
-struct Fetched { std::vector<Batcher> parts; bool ok = true; std::string err;
+struct Fetched { std::vector<Batcher> parts; bool ok = true; std::string err; unsigned uses = 0; bool allow_pinned = false;
                  std::vector<std::unique_ptr<BamReader> > pool; };   // the BAM handles of this buffer's stripes (fetches of different buffers run side by side)
 
 static void fetch_chunk(Ctx& c, int tid, int64_t a, int64_t b, Fetched& out) {
@@ -326,6 +354,10 @@ static void fetch_chunk(Ctx& c, int tid, int64_t a, int64_t b, Fetched& out) {
     }
     if (out.parts.size() < K) out.parts.resize(K);
     for (Batcher& p : out.parts) { p.clear(); p.keep_names = c.opt.max_warnings != 0; }
+    // a buffer that has been through one piece knows its sizes: from its second piece on its arenas are page-locked and the engine
+    // uploads them in place (run_region: brc_push_reads_pinned)
+    static const bool zero_copy = !(getenv("BRC_ZERO_COPY") && atoi(getenv("BRC_ZERO_COPY")) == 0);
+    if (zero_copy && out.allow_pinned && out.uses++ > 0) for (Batcher& p : out.parts) if (p.seen_qual) p.use_pinned();
     if (c.is_cram) {
         auto add = [&](const BamRecord& r) { out.parts[0].add(r, c.opt.per_lib ? lib_index(c, r) : 0); };
         if (!c.cram.fetch(tid, a - 1, b, add)) { out.ok = false; out.err = c.cram.error(); }
@@ -368,6 +400,7 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
     // (the CRAM reader is one handle: one fetch at a time)
     const int ahead = c.is_cram ? 1 : (ahead_env > 0 ? ahead_env : 2);
     std::vector<Fetched> bufs((size_t)ahead + 1); std::vector<std::thread> fth((size_t)ahead + 1);
+    for (Fetched& f : bufs) f.allow_pinned = npieces > (int64_t)ahead + 1;        // (only a run of pieces reuses its buffers)
     auto start_fetch = [&](int64_t j) {
         if (j >= npieces) return;
         const size_t slot = (size_t)(j % (ahead + 1));
@@ -394,12 +427,14 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
         const int64_t b = std::min<int64_t>(a + chunk, end);
         const size_t cur = (size_t)(j % (ahead + 1));
         { const double w0 = now_s(); if (fth[cur].joinable()) fth[cur].join(); c.t_fetch += now_s() - w0; }   // only what the background fetch did not hide
-        start_fetch(j + ahead);                          // into the buffer piece j - 1 has left
         Fetched& F = bufs[cur];
         if (!F.ok) { join_fmt(); c.complain("bam-readcount: read error: " + F.err + "\n"); return 1; }
         double t1 = now_s();
         if (c.need_engine && !c.need_engine()) { join_fmt(); return 1; }
         rc = brc_begin_region(c.eng, tid, (int32_t)a, (int32_t)b, ref, (int64_t)c.ref.size());
+        // (behind brc_begin_region: the buffer piece j - 1 has left may hold arenas the engine adopted — brc_push_reads_pinned —
+        // which stay the engine's to read until this call)
+        start_fetch(j + ahead);
         // the lines of a region piece are written on the GPU and come back as text (BRC_DEVICE_TEXT=0: host formatter)
         static const bool dev_text = !(getenv("BRC_DEVICE_TEXT") && atoi(getenv("BRC_DEVICE_TEXT")) == 0);
         brc_set_option(c.eng, BRC_OPT_DEVICE_TEXT, dev_text ? 1 : 0);
@@ -408,10 +443,12 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
             size_t nr = 0, nq = 0; for (const Batcher& part : F.parts) { nr += part.pos.size(); nq += part.qual.size(); }
             brc_set_option(c.eng, BRC_OPT_EXPECT_READS, (int64_t)(nr + nr / 8)); brc_set_option(c.eng, BRC_OPT_EXPECT_BASES, (int64_t)(nq + nq / 8));
         }
+        bool all_pinned = true;
+        for (const Batcher& part : F.parts) if (!part.pos.empty() && !part.pinned) all_pinned = false;
         for (const Batcher& part : F.parts) {
             if (rc || part.pos.empty()) continue;
             const brc_read_batch v = part.view();
-            rc = brc_push_reads(c.eng, &v);
+            rc = all_pinned ? brc_push_reads_pinned(c.eng, &v) : brc_push_reads(c.eng, &v);
         }
         if (!rc) rc = brc_upload(c.eng);
         if (!rc) rc = brc_compute(c.eng, nullptr);

@@ -246,6 +246,22 @@ int  brc_begin_region(brc_engine*, int32_t tid, int32_t beg0, int32_t end, const
  * brc_push_reads / brc_upload calls fail until the next brc_begin_region. */
 int  brc_push_reads(brc_engine*, const brc_read_batch*);
 
+/* Zero-copy feed of the two big arenas (round 5).  brc_push_reads copies every array of a batch into the engine's page-locked staging; two
+ * of them — seq4 and qual, 225 of the ~290 bytes of a 150-base read — are only ever uploaded and, rarely, read back on the host (the
+ * inserted bases of an indel allele, a warning line's quality test).  A caller that DECODES INTO page-locked memory itself (the BAM / CRAM
+ * reader of the command line: the north_star's "decoded read records are batched into pinned host buffers and hipMemcpyAsync'd") hands
+ * those two arenas over instead: brc_upload copies them to the device from where they lie.
+ *   brc_host_alloc / brc_host_free   page-locked host memory any engine of this process can upload from (hipHostMalloc, portable; usable
+ *                      before an engine exists — the first call starts the HIP runtime, which engine creation would do anyway).  NULL when it
+ *                      cannot be had.
+ *   brc_push_reads_pinned   brc_push_reads, except that batch->seq4 and batch->qual MUST point into brc_host_alloc memory and stay the
+ *                      caller's: unchanged and valid until the next brc_begin_region (or brc_destroy) of this engine — the engine reads
+ *                      them at brc_upload, brc_fetch_result (allele text) and brc_region_warnings.  Everything else of the batch is copied
+ *                      as usual.  A region takes either kind of push, not both (BRC_E_ARG otherwise); results are identical. */
+void* brc_host_alloc(size_t bytes);
+void  brc_host_free(void* p);
+int   brc_push_reads_pinned(brc_engine*, const brc_read_batch*);
+
 /* Split form of brc_end_region, used by the benchmark to keep inputs/outputs resident in HBM:
  *   brc_upload   : staging -> HBM (async on the engine stream, then waits)
  *   brc_compute  : launch the whole device pipeline on the engine stream and wait; repeatable

@@ -317,6 +317,9 @@ class SimBackend : public Backend {
     int counts(uint64_t* e, uint64_t* p) override { if (e) *e = n_events; if (p) *p = n_positions; return BRC_OK; }
 };
 
+void* backend_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }      // (no device: plain memory; pushes copy, Backend::adopts_arenas)
+void backend_host_free(void* p) { free(p); }
+
 Backend* make_backend(const brc_config&, int* err) { *err = BRC_OK; return new SimBackend(); }
 const char* backend_kind() { return "sim-cpu"; }
 const char* backend_kernel_name(int) { return nullptr; }

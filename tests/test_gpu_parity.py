@@ -567,3 +567,36 @@ def test_hip_device_text_hands_a_region_back_when_its_lines_do_not_fit(knob_lib,
             monkeypatch.setenv("BRC_DEVICE_TEXT_LIMIT", limit)
         got, _ = parity.run_engine(knob_lib, arrs, [(10, 2300), (2300, 2350)], ref=ref, device_text="chrS", **kw)
         assert got == want, limit
+
+
+@pytest.mark.parametrize("per_lib", [False, True])
+def test_hip_adopted_arenas_equal_copied_ones(dev_lib, oracle_lib, per_lib):
+    """brc_push_reads_pinned (include/brc.h, the zero-copy feed): SEQ / QUAL stay in the caller's page-locked memory, the engine uploads them
+    from there segment by segment and reads them again for the allele text and the warning lines — planes, indel alleles, text and warnings
+    of a region pushed that way in several batches equal the copied region's and the oracle's; the two kinds do not mix in one region."""
+    rng = np.random.default_rng(77)
+    ref = synth.make_ref(rng, 5000, weird=0.01)
+    arrs = synth.make_batch(78, ref, 1500, style="indel", n_libs=3 if per_lib else 1)
+    names = ["a", "b", "c"] if per_lib else ()
+    opts = dict(per_lib=per_lib, insertion_centric=True, min_bq=5)
+    want_text, want = parity.run_engine(oracle_lib, arrs, [(0, 5000)], ref=ref, lib_names=names, **opts)
+    n = len(arrs["pos"]); cuts = [0, n // 4, n // 4, n // 2, n]             # (an empty batch among them)
+    eng = capi.Engine(dev_lib, lib_names=names, **opts)
+    eng.begin_region(0, 0, 5000, ref)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        eng.push_reads_pinned(capi.select_reads(arrs, np.arange(a, b)))
+    got = eng.end_region()
+    parity.assert_results_equal(got, want[0], "adopted arenas")
+    assert eng.format_region("chrS") == want_text
+    w_ad = capi._region_warnings(eng, "chrS") if hasattr(capi, "_region_warnings") else None
+    # the same engine, next region, copied this time; then a region that tries both kinds
+    eng.begin_region(0, 0, 5000, ref); eng.push_reads(arrs)
+    got2 = eng.end_region()
+    parity.assert_results_equal(got2, want[0], "copied arenas")
+    if w_ad is not None:
+        assert capi._region_warnings(eng, "chrS") == w_ad
+    if dev_lib.kind().startswith("hip"):
+        eng.begin_region(0, 0, 5000, ref); eng.push_reads(capi.select_reads(arrs, np.arange(0, 10)))
+        with pytest.raises(capi.BrcError):
+            eng.push_reads_pinned(capi.select_reads(arrs, np.arange(10, 20)))
+    eng.close()
