@@ -547,7 +547,7 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
     // the staging stage's threads (a share of the CPUs the process may use; BRC_OPT_FORMAT_THREADS caps it like the formatter's)
     unsigned pthr = effective_cpus(); if (pthr > 8) pthr = 8;
     if (e->format_threads && e->format_threads < pthr) pthr = e->format_threads;
-    const bool par = n >= 32768 && pthr > 1;
+    const bool par = n >= 8192 && pthr > 1;      // (a stripe of a 1-Mbp piece is 17 000 reads: with the arenas adopted, the per-read pass is what is left of a push)
     if (par && !e->pool) e->pool = new (std::nothrow) Pool(pthr - 1);
     Pool* const pool = par ? e->pool : nullptr;
     *touched = true;
