@@ -114,7 +114,7 @@ def main():
                     "(tools/e2e_configs.py; e2e_sites / e2e_tumor on the line): -1 = on the default single-GPU config-3 run, 1 = yes, 0 = no")
     ap.add_argument("--e2e-sites-mbp", type=float, default=25.0, help="e2e_sites: length of each of its 8 contigs")
     ap.add_argument("--abi-mbp", type=float, default=10.0, help="prefix run through the C-ABI from host batches to host text (abi_roundtrip; 0 = skip)")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r04_traffic.json"))
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r05_traffic.json"))
     ap.add_argument("--other-configs", type=int, default=-1, help="1: also run BASELINE config 4 (--mode sites) and the per-GPU shape of config 5 (--mode strong --contig-mbp 6.25) "
                     "in sub-processes and put their lines under other_configs (-1: yes on the default single-GPU config-3 run, no otherwise)")
     # test infrastructure (tests/test_bench_multirank.py): the rank arithmetic of this script — who owns which interval / slice of
@@ -344,12 +344,12 @@ def main():
                 traffic = tj.get("k_pileup_hbm_bytes_per_launch")
                 traffic_src = "%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not measured in this run" % os.path.relpath(args.traffic_json, ROOT)
         # The roofline that really binds the kernel: vector-instruction issue.  From the committed PMC passes of this workload at the
-        # shipped kernel (profiles/r04_pmc_summary.json, not measured in this run): a wave64 VALU instruction occupies its SIMD for 4
+        # shipped kernel (profiles/r05_pmc_summary.json, not measured in this run): a wave64 VALU instruction occupies its SIMD for 4
         # cycles, so SQ_INSTS_VALU x 4 / 1024 SIMDs = the cycles every SIMD spends issuing vector instructions, against the kernel's
         # own busy cycles (SQ_BUSY_CYCLES is summed over the chip's 32 shader engines; its quotient by the duration is the clock the
         # kernel really ran at, below the 2.4 GHz peak).
         issue = None
-        pmc_json = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
+        pmc_json = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")
         if traffic is not None and os.path.exists(pmc_json):
             pm = json.load(open(pmc_json)).get(config, {})
             def issue_of(name):
@@ -362,7 +362,7 @@ def main():
                         "valu_issue_frac": round(k["SQ_INSTS_VALU"] * 4 / 1024.0 / busy, 4), "salu_issue_frac": round(k["SQ_INSTS_SALU"] * 4 / 1024.0 / busy, 4),
                         "lane_utilisation": round(k["SQ_THREAD_CYCLES_VALU"] / (64.0 * k["SQ_INSTS_VALU"]), 4) if k.get("SQ_THREAD_CYCLES_VALU") else None}
             issue = {"k_pileup2": issue_of("k_pileup2"), "k_annotate_groups": issue_of("k_annotate_groups"),
-                     "source": "profiles/r04_pmc_summary.json: separate rocprofv3 --pmc passes of this workload at the shipped kernels, not measured in this run"}
+                     "source": "profiles/r05_pmc_summary.json: separate rocprofv3 --pmc passes of this workload at the shipped kernels, not measured in this run"}
         # what THIS design must move per step at the least: the inputs once, the reference once, the compact result once
         # (116 B per position and library; SURVEY 8d's figure above credits the dense 312 B the kernel does not write)
         compact = b_in + b_ref + 116 * int(eng_positions) * res_libs

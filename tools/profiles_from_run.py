@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r04prof")
 tag = sys.argv[2] if len(sys.argv) > 2 else "r04"
 P = os.path.join(ROOT, "profiles")
-HOW = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/gpu_r4_profile.sh, at the shipped round-4 kernels), "
+HOW = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/gpu_rNN_profile.sh, at the shipped kernels of that round), "
        "per k_pileup2 launch; bytes = FETCH_SIZE x 1024 x 2 (gfx950: wide streaming reads are tallied at half their size, "
        "/opt/skills/guides/MI355X_MICROARCH.md; an upper bound here, the scalar record loads are not wide) + WRITE_SIZE x 1024")
 summary = json.load(open(os.path.join(src, "pmc_summary.json")))
