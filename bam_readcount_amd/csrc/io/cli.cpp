@@ -160,8 +160,16 @@ template <class T> struct ArenaAlloc {
     ArenaAlloc() {}
     explicit ArenaAlloc(bool p) : pinned(p) {}
     template <class U> ArenaAlloc(const ArenaAlloc<U>& o) : pinned(o.pinned) {}
-    T* allocate(size_t n) { void* p = pinned ? brc_host_alloc(n * sizeof(T)) : malloc(n * sizeof(T)); if (!p) throw std::bad_alloc(); return (T*)p; }
-    void deallocate(T* p, size_t) { if (pinned) brc_host_free(p); else free(p); }
+    // (a 16-byte header in front of every block says where it came from: when no more page-locked memory can be had a block comes from the
+    // heap instead of failing the decode thread — hipMemcpyAsync takes pageable memory too, only slower)
+    T* allocate(size_t n) {
+        char* p = pinned ? (char*)brc_host_alloc(n * sizeof(T) + 16) : nullptr; uint64_t tag = 1;
+        if (!p) { p = (char*)malloc(n * sizeof(T) + 16); tag = 0; }
+        if (!p) throw std::bad_alloc();
+        memcpy(p, &tag, sizeof tag);
+        return (T*)(p + 16);
+    }
+    void deallocate(T* q, size_t) { char* p = (char*)q - 16; uint64_t tag; memcpy(&tag, p, sizeof tag); if (tag) brc_host_free(p); else free(p); }
     template <class U> bool operator==(const ArenaAlloc<U>& o) const { return pinned == o.pinned; }
     template <class U> bool operator!=(const ArenaAlloc<U>& o) const { return pinned != o.pinned; }
 };
