@@ -20,7 +20,7 @@ F_NAMES = ["sev", "sq2", "snm", "s3p"]
 EXPORTS = [
     "brc_strerror", "brc_last_error", "brc_kernel_name", "brc_engine_kind", "brc_create", "brc_destroy",
     "brc_begin_region", "brc_push_reads", "brc_upload", "brc_compute", "brc_fetch_result", "brc_end_region",
-    "brc_clear_indel_queue", "brc_region_counts", "brc_format_region", "brc_format_window", "brc_region_windows", "brc_region_warnings", "brc_window_warnings", "brc_warnings_text", "brc_set_option", "brc_format_region_parts", "brc_set_chrom", "brc_fetch_window", "brc_compute_n", "brc_host_alloc", "brc_host_free", "brc_push_reads_pinned",
+    "brc_clear_indel_queue", "brc_region_counts", "brc_format_region", "brc_format_window", "brc_region_windows", "brc_region_warnings", "brc_window_warnings", "brc_warnings_text", "brc_set_option", "brc_format_region_parts", "brc_set_chrom", "brc_fetch_window", "brc_compute_n", "brc_host_alloc", "brc_host_free", "brc_push_reads_pinned", "brc_region_piece_steps",
 ]
 
 
@@ -92,6 +92,8 @@ class Library:
             L.brc_push_reads_pinned.argtypes = [C.c_void_p, C.POINTER(ReadBatch)]
             L.brc_host_alloc.restype = C.c_void_p; L.brc_host_alloc.argtypes = [C.c_size_t]
             L.brc_host_free.restype = None; L.brc_host_free.argtypes = [C.c_void_p]
+        if hasattr(L, "brc_region_piece_steps"):
+            L.brc_region_piece_steps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.brc_upload.argtypes = [C.c_void_p]
         L.brc_compute.argtypes = [C.c_void_p, C.POINTER(Timing)]
         if hasattr(L, "brc_compute_n"):
@@ -337,6 +339,12 @@ class Engine:
     def counts(self):
         a, b = C.c_uint64(), C.c_uint64()
         self._check(self.L.lib.brc_region_counts(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def piece_steps(self):
+        """(ranged, walked) piece-steps of the last compute (brc_region_piece_steps); (0, 0) when the region was not compacted"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self.L.lib.brc_region_piece_steps(self.h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
     def clear_indel_queue(self):

@@ -109,7 +109,8 @@ struct DevCfg {
 // the buffer's first bytes; the host reads the record back after every pass and fails the call with it.  (No s_trap: a trapped
 // queue takes the record with it, and on a shared pool the box.)  Everywhere else BRC_CK is the pointer itself.
 enum ChkBuf { CB_CIGAR = 0, CB_SEQ, CB_QUAL, CB_REFCODE, CB_EB, CB_BQW, CB_PIECES, CB_RARE, CB_KEYREACH, CB_READS, CB_EVRAW, CB_CNT, CB_WANTED, CB_RNG,
-              CB_UNAVAIL, CB_TILELIST, CB_NCOL, CB_DEPTH, CB_SLOTID, CB_SI, CB_SF, CB_XEV, CB_XEVN, CB_TILECTR, CB_LDS_ROWS, CB_LDS_QUEUE, CB_N };
+              CB_UNAVAIL, CB_TILELIST, CB_NCOL, CB_DEPTH, CB_SLOTID, CB_SI, CB_SF, CB_XEV, CB_XEVN, CB_TILECTR, CB_LDS_ROWS, CB_LDS_QUEUE,
+              CB_KP_PIECES, CB_KP_RARE, CB_KP_RNG /* what k_pileup2 reads: K1's stream and ranges, or the compacted ones */, CB_N };
 enum ChkKernel { CK_ANNOTATE = 1, CK_PILEUP = 2 };
 struct ChkExt { uint64_t lo, hi; };
 struct ChkState { ChkExt ext[CB_N]; uint32_t count, kernel, site, buf; uint64_t addr, bytes; int64_t unit, piece; };

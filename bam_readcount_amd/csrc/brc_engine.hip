@@ -832,6 +832,45 @@ __global__ __launch_bounds__(256) void k_narrow_tiles(const uint16_t* __restrict
     rng[lib * ntiles + tile] = r;
 }
 
+// Tile compaction for reads with MANY operators (round 5).  A tile's pieces are a contiguous range of the stream in read order, and ALL
+// pieces of every read that overlaps the tile lie in it: a 10-kb read with an operator every 15 bases has 700 pieces, five of which
+// touch a given tile — k_pileup2 would spend 98 % of its piece-steps (40 vector instructions each) on pieces that are not there.  For
+// regions whose reads average more than a dozen pieces the range of every (tile, library) is first COMPACTED: one wave walks it 64
+// pieces at a time (a 16-byte load and two compares per piece instead of a pipeline step), keeps those whose column extent
+// [rs, rs + ext) meets the tile, in stream order (ballot + prefix count: the order the fp32 sums need), and copies their records —
+// hot and rare — into a tile-major stream of their own.  k_pileup2 then runs unchanged over that stream and its ranges.
+// COUNT: the live pieces per (tile, library) (+ the two totals of brc_region_piece_steps); else: the copy, to cmp_off[] (exclusive scan).
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_compact_tiles(DevCfg c, const uint4* __restrict__ pieces4, const PieceRare* __restrict__ rare, const uint2* __restrict__ rng,
+                                                        int64_t ntiles, uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cmp_off, uint4* __restrict__ out4,
+                                                        PieceRare* __restrict__ out_rare, uint2* __restrict__ out_rng, unsigned long long* __restrict__ totals) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const int lib = blockIdx.y;
+    const int64_t slot = (int64_t)lib * ntiles + tile;
+    const uint2 r = rng[slot];
+    const int64_t p0 = (int64_t)c.pos0 + tile * TILE, p1 = p0 + TILE;
+    uint32_t run = COUNT ? 0u : cmp_off[slot];
+    const uint32_t first = run;
+    for (uint32_t base = r.x; base < r.y; base += 64u) {
+        const uint32_t m = base + (uint32_t)lane;
+        bool live = false; uint4 h0 = make_uint4(0u, 0u, 0u, 0u);
+        if (m < r.y) { h0 = pieces4[(size_t)m * 3u]; live = (int64_t)(int32_t)h0.x < p1 && (int64_t)(int32_t)h0.x + (int64_t)(int32_t)h0.z > p0; }      // {rs, len, ext, tp|flags}
+        const unsigned long long mask = __ballot(live);
+        if (!COUNT && live) {
+            const uint32_t at = run + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            out4[(size_t)at * 3u] = h0; out4[(size_t)at * 3u + 1u] = pieces4[(size_t)m * 3u + 1u]; out4[(size_t)at * 3u + 2u] = pieces4[(size_t)m * 3u + 2u];
+            if (piece_has_rare(h0.w >> 24)) out_rare[at] = rare[m];
+        }
+        run += (uint32_t)__builtin_popcountll(mask);
+    }
+    if (lane == 0) {
+        if (COUNT) { cnt[slot] = run; atomicAdd(&totals[0], (unsigned long long)(r.y - r.x)); atomicAdd(&totals[1], (unsigned long long)run); }
+        else out_rng[slot] = make_uint2(first, run);
+    }
+}
+
 // ---------------------------------------------------------------- KB: pileup + BasicStat accumulation (the hot kernel)
 
 // |a - b| of two unsigned values in one instruction (LLVM does not form v_sad_u32 from max - min)
@@ -934,7 +973,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
     if (slot >= (WINDOWS ? n_listed : ntiles)) return;
     const int64_t tile = WINDOWS ? (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)*BRC_CK(c, CK_PILEUP, 1, CB_TILELIST, tile_list + slot, 4, slot, -1)) : slot;
     const int lib = blockIdx.y;
-    const uint2 r2 = *BRC_CK(c, CK_PILEUP, 2, CB_RNG, rng + ((int64_t)lib * ntiles + tile), sizeof(uint2), tile, -1);
+    const uint2 r2 = *BRC_CK(c, CK_PILEUP, 2, CB_KP_RNG, rng + ((int64_t)lib * ntiles + tile), sizeof(uint2), tile, -1);
     const uint32_t lo = __builtin_amdgcn_readfirstlane(r2.x), hi = __builtin_amdgcn_readfirstlane(r2.y);
     const int64_t k = tile * TILE + lane;
     const bool inreg = k < c.P;
@@ -996,8 +1035,8 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
         // ... and, by the first lane of every row, one dword of its hot record: nothing uses the value — the load pulls the
         // record's cache line into L2 a half-batch before the scalar loads of the read loop ask for it (their own look-ahead
         // of two pieces covers an L2 hit, not an HBM miss)
-#define BRC_LD_TAB(T, b0) { const uint32_t mi = (b0) + srow < hi ? (b0) + srow : hi - 1u; T = *BRC_CK(c, CK_PILEUP, 6, CB_PIECES, pieces4 + ((size_t)mi * 3u + 2u), 16, tile, mi);   /* {ww, a, bq_off} */ \
-                            asm volatile("" :: "v"(pf)); if (schunk == 0u) pf = BRC_CK(c, CK_PILEUP, 7, CB_PIECES, pieces4 + (size_t)mi * 3u, 16, tile, mi)->x; }
+#define BRC_LD_TAB(T, b0) { const uint32_t mi = (b0) + srow < hi ? (b0) + srow : hi - 1u; T = *BRC_CK(c, CK_PILEUP, 6, CB_KP_PIECES, pieces4 + ((size_t)mi * 3u + 2u), 16, tile, mi);   /* {ww, a, bq_off} */ \
+                            asm volatile("" :: "v"(pf)); if (schunk == 0u) pf = BRC_CK(c, CK_PILEUP, 7, CB_KP_PIECES, pieces4 + (size_t)mi * 3u, 16, tile, mi)->x; }
         // window copy of the half-batch starting at piece b0 into the ring half at byte offset hoff: element window
         // [ws, ws + 80) of the row, ws = floor16(p0 - a) (may start before the row: the event-byte stream is padded)
 #define BRC_STAGE(T, b0, hoff)                                                                                           \
@@ -1030,7 +1069,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
 #ifdef BRC_CHECKED
         // (checked build: the address is compared first, and the load waits for itself — the registers are valid when the statement
         // ends, so this build does not depend on what the compiler does between a load and its wait and needs no ISA check)
-#define BRC_LD_REC(R, rp) { const char* rpc = BRC_CKS(c, CK_PILEUP, 9, CB_PIECES, (rp), 40, tile, ((rp) - reinterpret_cast<const char*>(pieces4)) / 48); \
+#define BRC_LD_REC(R, rp) { const char* rpc = BRC_CKS(c, CK_PILEUP, 9, CB_KP_PIECES, (rp), 40, tile, ((rp) - reinterpret_cast<const char*>(pieces4)) / 48); \
                             asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=" BRC_F_##R (R.f), "=" BRC_G_##R (R.g) : "s"(rpc)); }
 #else
 #define BRC_LD_REC(R, rp) asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x20" : "=" BRC_F_##R (R.f), "=" BRC_G_##R (R.g) : "s"(rp));
@@ -1043,7 +1082,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
 #define BRC_LD_DIV(H, R, m)                                                                                             \
         {                                                                                                                 \
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));                                                   \
-            u32x4 dA; u32x2 dB; const char* dp = BRC_CKS(c, CK_PILEUP, 10, CB_RARE, reinterpret_cast<const char*>(rare) + (size_t)(m) * 32u, 24, tile, (m)); \
+            u32x4 dA; u32x2 dB; const char* dp = BRC_CKS(c, CK_PILEUP, 10, CB_KP_RARE, reinterpret_cast<const char*>(rare) + (size_t)(m) * 32u, 24, tile, (m)); \
             asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x10\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dA), "=&s"(dB) : "s"(dp)); \
             H.rcpL = __uint_as_float(dA[0]); H.Lf = __uint_as_float(dA[1]); H.rcpC = __uint_as_float(dA[2]);              \
             H.center = __uint_as_float(dA[3]); H.left = (int32_t)dB[0]; H.q2 = (int32_t)dB[1]; H.zm_raw = 0u; H.sse_raw = 0u; \
@@ -1128,7 +1167,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                                base goes to the third-allele list whatever the lane's slots hold */                       \
                             const uint64_t m_esc = m_b & __builtin_amdgcn_ballot_w64(eb_is_escape(S.w));                  \
                             if (m_esc) {                                                                                  \
-                                u32x2 bo; const char* bp = BRC_CKS(c, CK_PILEUP, 13, CB_PIECES, reinterpret_cast<const char*>(pieces4) + (size_t)(m) * 48u, 48, tile, (m)); \
+                                u32x2 bo; const char* bp = BRC_CKS(c, CK_PILEUP, 13, CB_KP_PIECES, reinterpret_cast<const char*>(pieces4) + (size_t)(m) * 48u, 48, tile, (m)); \
                                 asm volatile("s_load_dwordx2 %0, %1, 0x28\n\ts_waitcnt lgkmcnt(0)" : "=&s"(bo) : "s"(bp)); \
                                 /* (scalar base + 32-bit lane offset: no 64-bit vector address in this rare path's register budget) */ \
                                 const uint16_t* wrow = bqw_ro + (int64_t)(((uint64_t)bo[1] << 32) | bo[0]);               \
@@ -1233,13 +1272,13 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                     {   /* the piece into scalar registers; its rare record likewise when K1 stored one, derived otherwise */ \
                         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));                                       \
                         u32x8 hf; u32x4 hg;                                                                               \
-                        const char* hp = BRC_CKS(c, CK_PILEUP, 15, CB_PIECES, reinterpret_cast<const char*>(pieces4) + (size_t)m * 48u, 48, tile, m); \
+                        const char* hp = BRC_CKS(c, CK_PILEUP, 15, CB_KP_PIECES, reinterpret_cast<const char*>(pieces4) + (size_t)m * 48u, 48, tile, m); \
                         asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(hf), "=&s"(hg) : "s"(hp)); \
                         H.rs = (int32_t)hf[0]; H.len = (int32_t)hf[1]; H.ext = (int32_t)hf[2]; H.tp_flags = hf[3];       \
                         H.w1 = hf[4]; H.w2 = hf[5]; H.w3 = hf[6]; H.snm = __uint_as_float(hf[7]); H.ww = hg[0]; H.a = (int32_t)hg[1]; \
                         H.bq_off = ((uint64_t)hg[3] << 32) | hg[2];                                                       \
                         if (piece_has_rare(H.tp_flags >> 24)) {                                                           \
-                            u32x8 rf; const char* rp = BRC_CKS(c, CK_PILEUP, 16, CB_RARE, reinterpret_cast<const char*>(rare) + (size_t)m * 32u, 32, tile, m); \
+                            u32x8 rf; const char* rp = BRC_CKS(c, CK_PILEUP, 16, CB_KP_RARE, reinterpret_cast<const char*>(rare) + (size_t)m * 32u, 32, tile, m); \
                             asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(rf) : "s"(rp));    \
                             RR.rcpL = __uint_as_float(rf[0]); RR.Lf = __uint_as_float(rf[1]); RR.rcpC = __uint_as_float(rf[2]); RR.center = __uint_as_float(rf[3]); \
                             RR.left = (int32_t)rf[4]; RR.q2 = (int32_t)rf[5]; RR.zm_raw = rf[6]; RR.sse_raw = rf[7];      \
@@ -1616,6 +1655,11 @@ class HipBackend : public Backend {
     hipStream_t stream3 = nullptr; hipEvent_t* ev_indel = nullptr; DBuf d_agg2;   // the indel side path's stream
     bool text_started[2] = {false, false}; uint64_t text_total[2] = {0, 0}; int64_t text_n[2] = {0, 0}; int text_slot = 0;
     Planes pl_last;                      // the planes of the last compute
+    // tile compaction (k_compact_tiles): on for regions whose reads average more than COMPACT_PIECES_PER_READ pieces
+    enum { COMPACT_PIECES_PER_READ = 12 };
+    bool compact_on = false; uint64_t compact_total = 0; bool compact_sized = false;
+    unsigned long long h_steps[2] = {0, 0};   // piece-steps of the last pass: what the tile ranges hold / what k_pileup2 walked (brc_region_piece_steps)
+    DBuf d_ccnt, d_coff, d_cpieces, d_crare, d_crng, d_ctot;
     // host result buffers (pinned)
     HBuf<uint32_t> h_ncol, h_depth, h_slotid, h_si, h_unavail; HBuf<float> h_sf; HBuf<IndelOut> h_iout; HBuf<XEv> h_xev;
     size_t xev_cap = 0;                  // entries per sub-list
@@ -1634,6 +1678,9 @@ class HipBackend : public Backend {
         set(CB_PIECES, d_pieces); set(CB_RARE, d_rare); set(CB_KEYREACH, d_keyreach); set(CB_READS, d_reads); set(CB_EVRAW, d_evraw); set(CB_CNT, d_cnt);
         set(CB_WANTED, d_wanted); set(CB_RNG, d_rng); set(CB_UNAVAIL, d_unavail); set(CB_TILELIST, d_tilelist); set(CB_NCOL, d_ncol); set(CB_DEPTH, d_depth);
         set(CB_SLOTID, d_slotid); set(CB_SI, d_si); set(CB_SF, d_sf); set(CB_XEV, d_xev); set(CB_XEVN, d_xevn); set(CB_TILECTR, d_tilectr);
+        // what k_pileup2 reads its records and ranges from: K1's stream, or the compacted one (k_compact_tiles)
+        const bool cz = compact_on && compact_sized;
+        set(CB_KP_PIECES, cz ? d_cpieces : d_pieces); set(CB_KP_RARE, cz ? d_crare : d_rare); set(CB_KP_RNG, cz ? d_crng : d_rng);
         // (self-test of the checker, tests/test_checked_build.py: BRC_CHECKED_SHRINK=<buffer index>:<bytes> takes bytes off a buffer's end)
         if (const char* sh = getenv("BRC_CHECKED_SHRINK")) { const int b = atoi(sh); const char* cpos = strchr(sh, ':'); if (b >= 0 && b < CB_N && cpos) { const uint64_t by = strtoull(cpos + 1, nullptr, 10); ChkExt& x = h_chk.ext[b]; x.hi = x.hi - x.lo > by ? x.hi - by : x.lo; } }
     }
@@ -1642,7 +1689,7 @@ class HipBackend : public Backend {
         if (!h_chk.count) return BRC_OK;
         static const char* const kBuf[CB_N] = {"cigar", "seq4", "qual", "refcode", "event bytes", "wide words", "pieces", "rare records", "keyreach", "reads", "raw indel events", "indel bucket counts",
                                                "wanted lanes", "tile ranges", "unavail", "tile list", "ncol", "depth", "slotid", "integer slot planes", "float slot planes", "third-allele lists",
-                                               "third-allele cursors", "tile counters", "LDS rows", "LDS queue"};
+                                               "third-allele cursors", "tile counters", "LDS rows", "LDS queue", "pieces (pileup)", "rare records (pileup)", "tile ranges (pileup)"};
         char b[512];
         snprintf(b, sizeof b, "BRC_CHECKED: %u out-of-bounds device access(es); first: kernel %s, site %u, buffer '%s' [0x%llx, 0x%llx), address 0x%llx + %llu bytes (offset %lld), %s %lld, piece %lld",
                  h_chk.count, h_chk.kernel == CK_ANNOTATE ? "k_annotate_groups" : "k_pileup2", h_chk.site, h_chk.buf < CB_N ? kBuf[h_chk.buf] : "?",
@@ -1694,6 +1741,7 @@ class HipBackend : public Backend {
                        &d_ref, &d_refcode, &d_bq, &d_bqw, &d_bqrow, &d_pieceoff, &d_pieces, &d_rare, &d_keyreach, &d_libbase, &d_reads, &d_agg, &d_rng, &d_ncol, &d_depth, &d_slotid, &d_si, &d_sf, &d_xev, &d_xevc, &d_xevn, &d_unavail, &d_cnt,
                        &d_cursor, &d_ev, &d_evraw, &d_ievoff, &d_iout, &d_ctr, &d_tilectr, &d_part, &d_tlen, &d_toff, &d_text, &d_tctx, &d_total64, &d_wanted, &d_tilelist};
         for (DBuf* b : all) b->release();
+        d_ccnt.release(); d_coff.release(); d_cpieces.release(); d_crare.release(); d_crng.release(); d_ctot.release();
 #ifdef BRC_CHECKED
         d_chk.release();
 #endif
@@ -1759,6 +1807,10 @@ class HipBackend : public Backend {
         c.variant = getenv("BRC_PILEUP_VARIANT") ? atoi(getenv("BRC_PILEUP_VARIANT")) : 0;
         c.ann_variant = getenv("BRC_ANN_VARIANT") ? atoi(getenv("BRC_ANN_VARIANT")) : 0;
 #endif
+        // reads with many operators: compact every tile's piece range before the pileup (k_compact_tiles); TK_COMPACT: 1 forces it, 0 forbids
+        compact_on = s.n > 0 && s.n_pieces > (int64_t)COMPACT_PIECES_PER_READ * s.n;
+        if (const char* ck = test_knob(TK_COMPACT)) compact_on = atoi(ck) != 0 && s.n_pieces > 0;
+        compact_sized = false; compact_total = 0; h_steps[0] = h_steps[1] = 0;
         const size_t n = (size_t)s.n;
         int rc;
         if ((rc = up(d_pos, s.pos, n)) || (rc = up(d_flag, s.flag, n)) || (rc = up(d_mapq, s.mapq, n)) || (rc = up(d_lib, s.lib, n)) ||
@@ -1939,6 +1991,37 @@ class HipBackend : public Backend {
         if (has_wanted && n_listed > 0)
             hipLaunchKernelGGL(k_narrow_tiles, dim3((unsigned)((n_listed * Lp + 255) / 256)), dim3(256), 0, stream, (const uint16_t*)d_wanted.p, (const uint32_t*)d_tilelist.p, n_listed, ntiles, Lp, c.pos0,
                                (uint2*)d_rng.p, (const int2*)d_keyreach.p);
+        const uint4* kp_pieces = (const uint4*)d_pieces.p; const PieceRare* kp_rare = (const PieceRare*)d_rare.p; const uint2* kp_rng = (const uint2*)d_rng.p;
+        if (compact_on && ntiles > 0 && np_all > 0) {
+            // count the live pieces of every (tile, library), scan, (first pass of the region: size the compacted stream — one wait), copy
+            const size_t nslot = (size_t)ntiles * (size_t)Lp;
+            HIPCHK(d_ccnt.ensure((nslot + 2) * 4)); HIPCHK(d_coff.ensure((nslot + 2) * 4)); HIPCHK(d_crng.ensure((nslot + 1) * sizeof(uint2))); HIPCHK(d_ctot.ensure(16));
+            HIPCHK(hipMemsetAsync(d_ctot.p, 0, 16, stream));
+            HIPCHK(hipMemsetAsync((uint32_t*)d_ccnt.p + nslot, 0, 4, stream));
+            const dim3 cg((unsigned)((ntiles + 3) / 4), (unsigned)Lp);
+            hipLaunchKernelGGL((k_compact_tiles<true>), cg, dim3(256), 0, stream, c, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p, (const uint2*)d_rng.p, ntiles,
+                               (uint32_t*)d_ccnt.p, (const uint32_t*)nullptr, (uint4*)nullptr, (PieceRare*)nullptr, (uint2*)nullptr, (unsigned long long*)d_ctot.p);
+            if ((rc = scan<OpSumU32, false>((const uint32_t*)d_ccnt.p, (uint32_t*)d_coff.p, (int64_t)nslot + 1))) return rc;
+            if (!compact_sized) {
+                uint32_t tot = 0;
+                HIPCHK(hipMemcpyAsync(&tot, (const uint32_t*)d_coff.p + nslot, 4, hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipMemcpyAsync(h_steps, d_ctot.p, 16, hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+                compact_total = tot; compact_sized = true;
+                HIPCHK(d_cpieces.ensure(((size_t)compact_total + 4) * sizeof(Piece))); HIPCHK(d_crare.ensure(((size_t)compact_total + 2) * sizeof(PieceRare)));
+            }
+            hipLaunchKernelGGL((k_compact_tiles<false>), cg, dim3(256), 0, stream, c, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p, (const uint2*)d_rng.p, ntiles,
+                               (uint32_t*)d_ccnt.p, (const uint32_t*)d_coff.p, (uint4*)d_cpieces.p, (PieceRare*)d_crare.p, (uint2*)d_crng.p, (unsigned long long*)d_ctot.p);
+            kp_pieces = (const uint4*)d_cpieces.p; kp_rare = (const PieceRare*)d_crare.p; kp_rng = (const uint2*)d_crng.p;
+#ifdef BRC_CHECKED
+            {   // (the compacted stream exists now: its extents replace K1's for the pileup's sites; the fault count so far is kept)
+                HIPCHK(hipStreamSynchronize(stream));
+                ChkState seen; HIPCHK(hipMemcpy(&seen, d_chk.p, sizeof seen, hipMemcpyDeviceToHost));
+                chk_fill(); ChkState upd = h_chk; upd.count = seen.count; upd.kernel = seen.kernel; upd.site = seen.site; upd.buf = seen.buf; upd.addr = seen.addr; upd.bytes = seen.bytes; upd.unit = seen.unit; upd.piece = seen.piece;
+                HIPCHK(hipMemcpy(d_chk.p, &upd, sizeof upd, hipMemcpyHostToDevice));
+            }
+#endif
+        }
         HIPCHK(hipEventRecord(evt[T_PILEUP], stream));
         if (ntiles > 0) {
             unsigned nwg = (unsigned)(((has_wanted ? n_listed : ntiles) + PILEUP_WAVES - 1) / PILEUP_WAVES);
@@ -1949,8 +2032,8 @@ class HipBackend : public Backend {
 #else
             const unsigned dyn_lds = 0u;
 #endif
-#define BRC_LAUNCH_KP(W, SH) hipLaunchKernelGGL((k_pileup2<W, SH>), dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), dyn_lds, stream, c, in, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p, \
-                               (const uint2*)d_rng.p, ntiles, pl, (uint4*)d_tilectr.p, in.eb, in.bqw, (const uint32_t*)d_unavail.p,                                                     \
+#define BRC_LAUNCH_KP(W, SH) hipLaunchKernelGGL((k_pileup2<W, SH>), dim3(nwg, (unsigned)Lp), dim3(PILEUP_WAVES * 64), dyn_lds, stream, c, in, kp_pieces, kp_rare, \
+                               kp_rng, ntiles, pl, (uint4*)d_tilectr.p, in.eb, in.bqw, (const uint32_t*)d_unavail.p,                                                     \
                                (const uint8_t*)d_refcode.p + REFCODE_PAD, (const uint16_t*)d_wanted.p, (const uint32_t*)d_tilelist.p, n_listed)
             if (has_wanted) { if (n_listed > 0) { if (c.pack_shift == 16) BRC_LAUNCH_KP(true, 16); else BRC_LAUNCH_KP(true, 12); } }
             else { if (c.pack_shift == 16) BRC_LAUNCH_KP(false, 16); else BRC_LAUNCH_KP(false, 12); }
@@ -2093,6 +2176,7 @@ class HipBackend : public Backend {
         return BRC_OK;
     }
 
+    void piece_steps(uint64_t* ranged, uint64_t* walked) override { *ranged = compact_on ? h_steps[0] : 0; *walked = compact_on ? h_steps[1] : 0; }
     int counts(uint64_t* e, uint64_t* p) override {
         if (!computed) { err = "not computed"; return BRC_E_ARG; }
         if (e) *e = h_ctr.n_events;

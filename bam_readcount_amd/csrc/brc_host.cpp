@@ -945,6 +945,13 @@ int brc_region_counts(brc_engine* e, uint64_t* n_events, uint64_t* n_positions) 
     return BRC_OK;
 }
 
+int brc_region_piece_steps(brc_engine* e, uint64_t* ranged, uint64_t* walked) {
+    if (!e || !ranged || !walked) return BRC_E_ARG;
+    if (e->state < 3) return fail(e, BRC_E_ARG, "brc_region_piece_steps before brc_compute");
+    e->be->piece_steps(ranged, walked);
+    return BRC_OK;
+}
+
 int brc_clear_indel_queue(brc_engine* e) {
     if (!e) return BRC_E_ARG;
     for (size_t l = 0; l < e->queue.size(); ++l) e->queue[l].clear();

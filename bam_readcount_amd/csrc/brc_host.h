@@ -151,6 +151,8 @@ class Backend {
     virtual int reserve_text(size_t) { return BRC_OK; }
     virtual void list_sizes(uint64_t* n_xev, uint64_t* n_indel_slots) { *n_xev = 0; *n_indel_slots = 0; }   // of the last compute                                  // room for the text of coming regions (optional)
     virtual int counts(uint64_t* n_events, uint64_t* n_positions) = 0;
+    // piece-steps of the last compute: what the tile ranges hold / what the pileup kernel walked (0, 0: not counted — no compaction ran)
+    virtual void piece_steps(uint64_t* ranged, uint64_t* walked) { *ranged = 0; *walked = 0; }
     virtual const char* last_error() const = 0;
 };
 
@@ -173,7 +175,7 @@ unsigned effective_cpus();
 // with -DBRC_TEST_KNOBS, which maps an index to an environment variable): in the product test_knob() is the constant nullptr and
 // the library contains neither the names nor a getenv for them (tests/test_abi.py) — an inherited BRC_NO_TABLE=1 cannot turn the
 // shipped kernel into its slow path without a word.
-enum TestKnob { TK_NO_TABLE = 0, TK_FLUSH_K, TK_PACK_LIM, TK_FORCE_DOM, TK_IBUCKET_SHIFT, TK_XEV_CAP, TK_DEVICE_TEXT_LIMIT, TK_FORMAT_THREADS, TK_FORMAT_CHUNK, TK_N };
+enum TestKnob { TK_NO_TABLE = 0, TK_FLUSH_K, TK_PACK_LIM, TK_FORCE_DOM, TK_IBUCKET_SHIFT, TK_XEV_CAP, TK_DEVICE_TEXT_LIMIT, TK_FORMAT_THREADS, TK_FORMAT_CHUNK, TK_COMPACT, TK_N };
 const char* test_knob(int which);
 
 // exact "%.2f" of a float (== iostream fixed/setprecision(2), BasicStat.cpp:116); returns bytes written

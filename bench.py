@@ -89,9 +89,9 @@ def site_batch(np, capi, arrs, ref, sites, window=384, lead=170):
 
 
 def fullcheck_window_reads(capi, arrs, ends, pos64, a, b):
-    """reads samfetch would return for [a - 1, b) (tools/fullcheck.py: window_reads; reads here are at most 1 kb long)"""
+    """reads samfetch would return for [a - 1, b) (tools/fullcheck.py: window_reads)"""
     import fullcheck
-    return fullcheck.window_reads(capi, arrs, ends, pos64, 1000, a, b)
+    return fullcheck.window_reads(capi, arrs, ends, pos64, int((ends - pos64).max()) if len(pos64) else 0, a, b)
 
 
 def main():
@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300, help="timed steps (300 x ~7 ms: a timed region above 2 s)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--mode", default="weak", choices=["weak", "strong", "sites"])
-    ap.add_argument("--config", default=None, choices=["wgs30x", "tumor200x", "wgs30x_mixed", "long10k"], help="data model (default: wgs30x; tumor200x for --mode strong; wgs30x_mixed: config 3 with 30 %% of the reads trimmed to U[100,149] and 10 %% 250 bases long; long10k: 10-kb reads at 30x, a functional and throughput point outside BASELINE's configurations)")
+    ap.add_argument("--config", default=None, choices=["wgs30x", "tumor200x", "wgs30x_mixed", "long10k", "ont"], help="data model (default: wgs30x; tumor200x for --mode strong; wgs30x_mixed: config 3 with 30 %% of the reads trimmed to U[100,149] and 10 %% 250 bases long; long10k: 10-kb reads at 30x; ont: 3-10-kb reads with an insertion or deletion every ~15 bases at 30x (use --contig-mbp 20) — functional and throughput points outside BASELINE's configurations)")
     ap.add_argument("--contig-mbp", type=float, default=50.0, help="weak/sites: contig per GPU; strong: the whole contig")
     ap.add_argument("--sites", type=int, default=100000, help="--mode sites: lines of the site list (all ranks together)")
     ap.add_argument("--cpu-sample-mbp", type=float, default=8.0, help="prefix timed with the 1-thread CPU oracle and used for validation (0 = skip)")
@@ -167,7 +167,7 @@ def main():
         raise SystemExit("--mode strong with %d rank(s) puts %.1f Mbp of 200x data (%.0f M reads) on one GPU: use --gpus 4 / 8, a smaller --contig-mbp "
                          "(6.25 = the per-GPU shape of BASELINE config 5), or --allow-large" % (world, contig_len / 1e6, contig_len * 200 / 150 / 1e6))
     t0 = time.time()
-    ref, arrs = synthgen.generate(contig_len, config, seed=1 + 1000 * rank)
+    ref, arrs = synthgen.generate_dense(contig_len, "ont", seed=1 + 1000 * rank) if config == "ont" else synthgen.generate(contig_len, config, seed=1 + 1000 * rank)
     t_gen = time.time() - t0
     # The oracle processes of the whole-region validation are forked HERE — before this process touches the GPU (a process
     # that has initialised the HIP runtime must not fork); they inherit the reads and sleep until the timed region is over.
@@ -237,6 +237,9 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     n_events, n_positions = eng.counts()
+    # (regions of reads with many CIGAR segments: the tile ranges are compacted before the pileup — what they held, what was walked)
+    ps = eng.piece_steps() if hasattr(eng.L.lib, "brc_region_piece_steps") else (0, 0)
+    piece_steps = {"in_tile_ranges": ps[0], "walked": ps[1], "dead_share_without_compaction": round(1.0 - ps[1] / ps[0], 4)} if ps[0] else None
     if args.mode == "sites":
         n_events, n_positions = site_events, len(sites)      # the unit of work counts the requested sites only
 
@@ -593,6 +596,8 @@ def main():
             what = "synthetic 30x WGS, MIXED read lengths (60 %% 150 bp, 30 %% trimmed to U[100,149], 10 %% 250 bp), 1 contig %.0f Mbp per GPU, -q20 -b13" % (contig_len / 1e6)
         if config == "long10k":
             what = "synthetic 30x, 10-kb reads (30 %% with an insertion, 30 %% with a deletion), 1 contig %.0f Mbp per GPU, -q20 -b13 — not one of BASELINE's configurations" % (contig_len / 1e6)
+        if config == "ont":
+            what = "synthetic 30x, 3-10-kb reads with an insertion or a deletion every ~15 bases (%.0f CIGAR operators per read; ONT / CLR-like), 1 contig %.0f Mbp per GPU, -q20 -b13 — not one of BASELINE's configurations" % (float(arrs["n_cigar"].mean()), contig_len / 1e6)
         if config == "tumor200x" and args.mode == "weak":
             what = "synthetic 200x tumor 4 libraries, 150bp reads, -p -i, 1 contig %.2f Mbp per GPU" % (contig_len / 1e6)
         if rank_check is not None:
@@ -602,7 +607,7 @@ def main():
             "metric": "pileup base-events/sec", "value": round(value, 1), "unit": "events/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak" if args.mode == "weak" else "strong", "vs_baseline": None, "dtype": "u32+f32", "data": "synthetic",
-            "config": {"workload": what, "mode": args.mode, "reads_per_gpu": int(len(region_reads["pos"])),
+            "config": {"workload": what, "mode": args.mode, "reads_per_gpu": int(len(region_reads["pos"])), "piece_steps": piece_steps,
                        "events_per_step": int(ev_total), "positions_per_step": int(pos_total), "parallelism": "interval-shard x%d" % world},
             "positions_per_s": round(pos_total * args.steps / tmax, 1),
             "per_rank": per_rank, "per_gpu_value": round(value / world, 1),

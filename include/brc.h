@@ -303,6 +303,11 @@ int  brc_end_region(brc_engine*, brc_result* out);
 /* Number of pileup base-events / emitted positions of the last compute without downloading planes. */
 int  brc_region_counts(brc_engine*, uint64_t* n_events, uint64_t* n_positions);
 
+/* Piece-steps of the last compute, for regions whose tile ranges were compacted (reads averaging more than a dozen CIGAR segments — ONT /
+ * CLR-like alignments: see DESIGN.md): `ranged` = the pieces the tiles' contiguous ranges hold (what the pileup kernel would have walked),
+ * `walked` = the pieces that touch their tile (what it walked).  Both 0 when the region was not compacted. */
+int  brc_region_piece_steps(brc_engine*, uint64_t* ranged, uint64_t* walked);
+
 /*
  * Host-side record assembly for the last fetched region: produces the reference's exact stdout text
  * ("chr\tpos\tref\tdepth\t..." lines, one per emitted position) in an engine-owned buffer that stays

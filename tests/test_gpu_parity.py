@@ -600,3 +600,56 @@ def test_hip_adopted_arenas_equal_copied_ones(dev_lib, oracle_lib, per_lib):
         with pytest.raises(capi.BrcError):
             eng.push_reads_pinned(capi.select_reads(arrs, np.arange(10, 20)))
     eng.close()
+
+
+@pytest.mark.parametrize("case", FUZZ, ids=lambda c: "seed%d-%s" % (c["seed"], c["style"]))
+def test_hip_compacted_tile_ranges_equal_oracle_on_every_fuzz_family(knob_lib, oracle_lib, monkeypatch, case):
+    """k_compact_tiles (regions whose reads average more than a dozen pieces: the pieces of a tile's range that do not touch the tile are
+    dropped before the pileup, in stream order) forced on for every fuzz family — planes, indel lists, text, device-side text and a window
+    read back from the computed region equal the oracle's.  (BRC_COMPACT_TILES exists in the test-knobs library only; [sim]: the
+    simulator has no compaction — it checks the body itself.)"""
+    monkeypatch.setenv("BRC_COMPACT_TILES", "1")
+    rng = np.random.default_rng(case["seed"])
+    ref = synth.make_ref(rng, 3000, weird=case.get("weird", 0.0))
+    n_libs = case.get("n_libs", 1)
+    arrs = synth.make_batch(case["seed"] + 100, ref, case["n"], style=case["style"], n_libs=n_libs, p_nolib=case.get("p_nolib", 0.0))
+    names = ["lib%c" % (65 + i) for i in range(n_libs)] if case["opts"].get("per_lib") else ()
+    regions = [(0, 3000), (100, 101), (700, 1500), (2990, 3200)]
+    nolib = case.get("p_nolib", 0.0) > 0
+    want, _ = parity.compare_libs(knob_lib, oracle_lib, arrs, regions, ref=ref, lib_names=names, check_warn=not nolib, **case["opts"])
+    got, _ = parity.run_engine(knob_lib, arrs, regions, ref=ref, lib_names=names, device_text="chrS", **case["opts"])
+    assert got == want
+
+
+def test_hip_reads_with_an_operator_every_few_bases(dev_lib, knob_lib, oracle_lib, monkeypatch):
+    """ONT / CLR-like alignments (tools/synth_gen.c: synth_reads_dense — 3-10-kb reads, an insertion or a deletion every ~15 bases, 800
+    operators per read): the PRODUCT library compacts their tile ranges by itself (more than a dozen pieces per read), reports how many
+    piece-steps that saved, and equals the oracle — as does the same region with compaction forbidden, and through brc_compute_n /
+    brc_fetch_window / announced windows."""
+    import synthgen
+    n = 120_000
+    ref, arrs = synthgen.generate_dense(n, "ont", seed=11, n_chunks=2)
+    assert float(arrs["n_cigar"].mean()) > 400
+    opts = dict(min_mapq=20, min_bq=13)
+    want_text, want = parity.run_engine(oracle_lib, arrs, [(500, 90_000)], ref=ref, **opts)
+    eng = capi.Engine(dev_lib, **opts)
+    eng.begin_region(0, 500, 90_000, ref); eng.push_reads(arrs); eng.upload()
+    eng.compute_n(2)
+    got = eng.fetch_result()
+    parity.assert_results_equal(got, want[0], "dense operators, compacted")
+    assert eng.format_region("chrS") == want_text
+    if dev_lib.kind().startswith("hip"):
+        ranged, walked = eng.piece_steps()
+        assert 0 < walked < 0.2 * ranged, (ranged, walked)          # four fifths and more of the ranges' pieces do not touch their tile
+    eng.clear_indel_queue()
+    w = eng.fetch_window(30_000, 31_000)
+    o2 = capi.Engine(oracle_lib, **opts)
+    ends = capi.read_ends(arrs)
+    o2.begin_region(0, 30_000, 31_000, ref); o2.push_reads(capi.select_reads(arrs, capi.fetch_overlapping(arrs, ends, 29_999, 31_000)))
+    parity.assert_results_equal(w, o2.end_region(), "window of the compacted region"); o2.close()
+    eng.close()
+    # compaction forbidden (test-knobs library): the same bits, the slow way
+    monkeypatch.setenv("BRC_COMPACT_TILES", "0")
+    t2, r2 = parity.run_engine(knob_lib, arrs, [(500, 20_000)], ref=ref, **opts)
+    t3, r3 = parity.run_engine(oracle_lib, arrs, [(500, 20_000)], ref=ref, **opts)
+    parity.assert_results_equal(r2[0], r3[0], "dense operators, not compacted"); assert t2 == t3

@@ -172,3 +172,94 @@ int synth_reads(const synth_params* P, const uint8_t* ref, int32_t* pos, uint16_
     }
     return 0;
 }
+
+/*
+ * Long reads with an operator every few bases (ONT / PacBio-CLR-like alignments): read lengths U[len_min, len_max], the CIGAR alternates
+ * M segments of 1 + Geometric(mean op_gap) bases with an insertion or a deletion (50 / 50) of U[1, indel_max] bases until the read is
+ * used up; 5 % of the reads start or end with a soft clip U[1, 200].  Everything else as in synth_reads (flags, MAPQ, qualities, SM,
+ * substitutions at p_sub, NM = mismatches + indel bases).  Arrays are caller-allocated with fixed strides: cigar [n_reads * cig_stride],
+ * seq4 [n_reads * ceil(len_max / 2)], qual [n_reads * len_max]; cig_off / seq_off / qual_off are set to the strided rows and n_cigar to
+ * the operators used (the Python wrapper packs the CIGARs).  A read whose operators would pass cig_stride - 2 ends with one M.
+ */
+int synth_reads_dense(const synth_params* P, int32_t len_min, int32_t len_max, double op_gap, int32_t cig_stride, const uint8_t* ref,
+                      int32_t* pos, uint16_t* flag, uint8_t* mapq, int16_t* lib, int32_t* l_qseq, uint32_t* n_cigar, uint64_t* cig_off, uint64_t* seq_off,
+                      uint64_t* qual_off, int32_t* nm, int32_t* sm, uint8_t* tags, uint32_t* cigar, uint8_t* seq4, uint8_t* qual) {
+    const int Lmax = len_max, SB = (Lmax + 1) / 2;
+    const int nch = P->n_chunks > 0 ? P->n_chunks : 64;
+    if (len_min < 64 || len_max < len_min || len_max > 100000 || cig_stride < 8 || op_gap < 2.0 || P->contig_len < 6 * (int64_t)Lmax) return -1;
+    build_qtab();
+    const double lg1mp = P->p_sub > 0 ? log(1.0 - P->p_sub) : 0.0, lgap = log(1.0 - 1.0 / op_gap);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int c = 0; c < nch; ++c) {
+        rng_t r; rng_seed(&r, P->seed, (uint64_t)c + 2000003u);
+        const int64_t r0 = P->n_reads * c / nch, r1 = P->n_reads * (c + 1) / nch;
+        const int64_t span = P->contig_len - 2 * (int64_t)Lmax - 1;            /* (deletions make a read's reference span longer than its length) */
+        const int64_t p0 = span * c / nch, p1 = span * (c + 1) / nch;
+        for (int64_t i = r0; i < r1; ++i) pos[i] = (int32_t)(p0 + (int64_t)(rng_u01(&r) * (double)(p1 - p0)));
+        qsort(pos + r0, (size_t)(r1 - r0), sizeof(int32_t), cmp_i32);
+        uint8_t* codes = (uint8_t*)malloc((size_t)Lmax + 64);
+        uint8_t* aligned = (uint8_t*)malloc((size_t)Lmax + 64);
+        for (int64_t i = r0; i < r1; ++i) {
+            const int rev = (int)(rng_next(&r) >> 63);
+            flag[i] = rev ? 16 : 0;
+            mapq[i] = (rng_u01(&r) < 0.9) ? 60 : (uint8_t)rng_below(&r, 60);
+            lib[i] = (int16_t)(P->n_libs > 1 ? rng_below(&r, (uint32_t)P->n_libs) : 0);
+            const int L = len_min + (int)rng_below(&r, (uint32_t)(len_max - len_min + 1));
+            l_qseq[i] = L;
+            cig_off[i] = (uint64_t)i * (uint64_t)cig_stride; seq_off[i] = (uint64_t)i * SB; qual_off[i] = (uint64_t)i * Lmax;
+            uint32_t* cg = cigar + (uint64_t)i * (uint64_t)cig_stride;
+            int ncg = 0, used = 0, nmv = 0;
+            int64_t rp = pos[i];
+            int clipL = 0, clipR = 0;
+            if (rng_u01(&r) < 0.05) { const int s = 1 + (int)rng_below(&r, 200); if (rng_next(&r) >> 63) clipL = s; else clipR = s; }
+            if (clipL) { cg[ncg++] = ((uint32_t)clipL << 4) | 4; for (int j = 0; j < clipL; ++j) { codes[used + j] = (uint8_t)(1u << rng_below(&r, 4)); aligned[used + j] = 0; } used += clipL; }
+            const int body_end = L - clipR;
+            while (used < body_end) {
+                int m = 1 + (int)floor(log(1.0 - rng_u01(&r)) / lgap);
+                if (m > body_end - used || ncg >= cig_stride - 3) m = body_end - used;
+                if (rp + m >= P->contig_len) m = body_end - used;                  /* (cannot happen with the span above; keeps rp inside the contig in any case) */
+                cg[ncg++] = ((uint32_t)m << 4) | 0;
+                for (int j = 0; j < m; ++j) { codes[used + j] = code_of(ref[rp + j]); aligned[used + j] = 1; }
+                used += m; rp += m;
+                if (used >= body_end) break;
+                const int k = 1 + (int)rng_below(&r, (uint32_t)P->indel_max);
+                if ((rng_next(&r) >> 63) && body_end - used > k) {                      /* insertion (never the read's last operator before a clip) */
+                    cg[ncg++] = ((uint32_t)k << 4) | 1;
+                    for (int j = 0; j < k; ++j) { codes[used + j] = (uint8_t)(1u << rng_below(&r, 4)); aligned[used + j] = 0; }
+                    used += k; nmv += k;
+                } else { cg[ncg++] = ((uint32_t)k << 4) | 2; rp += k; nmv += k; }
+            }
+            if ((cg[ncg - 1] & 15u) != 0u) { /* ends on an indel: give it a last aligned base by shortening nothing — turn the operator into M of the next base */
+                if ((cg[ncg - 1] & 15u) == 2u) { rp -= (int64_t)(cg[ncg - 1] >> 4); nmv -= (int)(cg[ncg - 1] >> 4); --ncg; }   /* a trailing deletion is dropped */
+            }
+            if (clipR) { cg[ncg++] = ((uint32_t)clipR << 4) | 4; for (int j = 0; j < clipR; ++j) { codes[used + j] = (uint8_t)(1u << rng_below(&r, 4)); aligned[used + j] = 0; } used += clipR; }
+            for (int k = ncg; k < cig_stride && k < ncg + 2; ++k) cg[k] = 0;
+            n_cigar[i] = (uint32_t)ncg;
+            if (P->p_sub > 0) {
+                int q = (int)floor(log(1.0 - rng_u01(&r)) / lg1mp);
+                while (q < L) {
+                    const uint8_t old = codes[q];
+                    uint8_t nw = (uint8_t)(1u << rng_below(&r, 4));
+                    if (nw == old) nw = (uint8_t)(old == 8 ? 1 : old << 1);
+                    codes[q] = nw;
+                    if (aligned[q]) nmv++;
+                    q += 1 + (int)floor(log(1.0 - rng_u01(&r)) / lg1mp);
+                }
+            }
+            uint8_t* s4 = seq4 + (uint64_t)i * SB;
+            for (int j = 0; j + 1 < L; j += 2) s4[j >> 1] = (uint8_t)((codes[j] << 4) | codes[j + 1]);
+            if (L & 1) s4[L >> 1] = (uint8_t)(codes[L - 1] << 4);
+            uint8_t* qq = qual + (uint64_t)i * Lmax;
+            for (int j = 0; j < L; j += 5) {
+                uint64_t x = rng_next(&r);
+                for (int k = 0; k < 5 && j + k < L; ++k, x >>= 12) qq[j + k] = QTAB[x & 4095];
+            }
+            nm[i] = nmv;
+            uint8_t t = 1;
+            if (rng_next(&r) >> 63) { t |= 2; sm[i] = mapq[i]; } else sm[i] = 0;
+            tags[i] = t;
+        }
+        free(codes); free(aligned);
+    }
+    return 0;
+}

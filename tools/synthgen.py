@@ -152,6 +152,38 @@ def generate(contig_len, config="wgs30x", seed=1, n_chunks=64):
     return ref, a
 
 
+# reads with an operator every ~15 bases (ONT / CLR-like alignments): 3-10 kb, 30x — the regime the tile compaction exists for
+DENSE = {"ont": dict(depth=30.0, len_min=3000, len_max=10000, op_gap=15.0, indel_max=3, p_sub=0.01, n_libs=1)}
+
+
+def generate_dense(contig_len, config="ont", seed=1, n_chunks=64):
+    """(ref, arrays) like generate(), from tools/synth_gen.c: synth_reads_dense; CIGARs packed (cigar_off = running sum of n_cigar)."""
+    cfg = DENSE[config]
+    lmin, lmax = cfg["len_min"], cfg["len_max"]
+    n = int(round(contig_len * cfg["depth"] / ((lmin + lmax) / 2.0)))
+    stride = int(2.5 * lmax / cfg["op_gap"]) + 16
+    ref = np.empty(contig_len, np.uint8)
+    lib().synth_ref(ref.ctypes.data_as(C.c_void_p), C.c_int64(contig_len), C.c_uint64(seed))
+    a = dict(pos=np.empty(n, np.int32), flag=np.empty(n, np.uint16), mapq=np.empty(n, np.uint8), lib=np.empty(n, np.int16),
+             l_qseq=np.empty(n, np.int32), n_cigar=np.empty(n, np.uint32), cigar_off=np.empty(n, np.uint64),
+             seq_off=np.empty(n, np.uint64), qual_off=np.empty(n, np.uint64), nm=np.empty(n, np.int32), sm=np.empty(n, np.int32),
+             tags=np.empty(n, np.uint8), cigar=np.zeros(n * stride, np.uint32), seq4=np.empty(n * ((lmax + 1) // 2), np.uint8),
+             qual=np.empty(n * lmax, np.uint8))
+    p = Params(contig_len, n, lmax, cfg["n_libs"], seed + 1, cfg["p_sub"], 0.0, 0.0, 0.0, cfg["indel_max"], n_chunks, 0.0, 0.0, 0, 0)
+    order = ["pos", "flag", "mapq", "lib", "l_qseq", "n_cigar", "cigar_off", "seq_off", "qual_off", "nm", "sm", "tags", "cigar", "seq4", "qual"]
+    L = lib(); L.synth_reads_dense.argtypes = None
+    rc = L.synth_reads_dense(C.byref(p), C.c_int32(lmin), C.c_int32(lmax), C.c_double(cfg["op_gap"]), C.c_int32(stride), ref.ctypes.data_as(C.c_void_p),
+                             *[a[k].ctypes.data_as(C.c_void_p) for k in order])
+    if rc != 0:
+        raise RuntimeError("synth_reads_dense failed: %d" % rc)
+    # pack the CIGARs: row i keeps its first n_cigar[i] operators
+    nc = a["n_cigar"].astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(nc)])
+    idx = np.repeat(np.arange(n, dtype=np.int64) * stride, nc) + (np.arange(int(off[-1]), dtype=np.int64) - np.repeat(off[:-1], nc))
+    a["cigar"] = a["cigar"][idx].copy(); a["cigar_off"] = off[:-1].astype(np.uint64)
+    return ref, a
+
+
 def algorithmic_bytes(arrs, n_positions, n_libs_printed, n_indel_buckets=0, ref_positions=None):
     """B_in + B_ref + B_out (compulsory HBM traffic of the path, implementation independent)."""
     L = arrs["l_qseq"].astype(np.int64)
