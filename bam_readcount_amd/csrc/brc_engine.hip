@@ -44,7 +44,7 @@ namespace brc {
 struct Counters {
     unsigned long long n_events, n_positions, w_sm, w_nm, w_lib;
     unsigned int n_indel_slots, n_xev;   // n_xev: third-allele events in the compacted list
-    unsigned int xev_max, pad_;          // fullest sub-list's cursor (above its capacity: grow and compute again)
+    unsigned int xev_max, n_wave_reads;  // fullest sub-list's cursor (above its capacity: grow and compute again); reads K1 left to k_annotate_wave
 };
 
 // Profiling ablations that switch parts of the kernels off (wrong results, timing only) exist only in experiment builds
@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void k_refcode(const char* __restrict__ ref, u
 //                          walk + neighbour links (DPP lane shifts); sums are accumulated per read in LDS;
 //   phase C (lane = read)  the quality != 2 scan from the read's 3' end (:201-238; 8 bases per load, as a rule one load),
 //                          three-prime / Q2 logic, DRead + float constants, the pieces, the indel events.
+enum { AW_MCAP = 1024 };             // M operators of a read the wave form (k_annotate_wave, below) holds in LDS
 struct AnnPar { uint4 a, b, c; };    // a = {L, qrel, srel, brow.lo}  b = {S, m1lo, m1hi, d1}  c = {m2lo, m2hi, d2, brow.hi}
 
 __device__ __forceinline__ uint32_t nzb7(uint32_t x) { return x + 0x7f7f7f7fu; }   // bytes <= 0x7f: bit 7 of a byte <=> byte != 0
@@ -583,6 +584,276 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
             if (used < n_idp) { slot[used++] = e; atomicAdd(BRC_CK(c, CK_ANNOTATE, 17, CB_CNT, bucket_cnt + indel_bucket_of(c, (uint32_t)(p - c.pos0), (uint32_t)lib), 4, my, p), 1u); }
         });
         for (; used < n_idp; ++used) slot[used].key_lo = NONE32;
+    }
+}
+
+// K1w, wave form: ONE WAVE PER READ, for the reads K1 would hand to the serial annotate_read() only because their CIGAR has more
+// than two M operators (long reads with an indel every few bases — ONT / CLR / HiFi — and the few short reads with several
+// indels).  There a lane of K1 walks one read base by base and operator by operator, every step a dependent round trip for its
+// whole wave: 35-46 ms for ANY region of 3-10-kb reads with ~800 operators each, whatever its size.  Here the lanes of a wave
+// share one read:
+//   pass 1 (lane = operator)   running read / reference cursors by wave prefix sums; the M operators go to an LDS list
+//                              {query start, reference start, length | "an insertion follows"}; clips and totals; the read's
+//                              indel events (enumerate_indels_at, restated per operator) into its slots of the raw list;
+//   pass 2 (lane = base)       operator of the base by binary search in the LDS list (64-entry window that moves with the
+//                              pass), reference code, mismatch flag (:152), event byte + wide words (eb_make), the
+//                              quality != 2 scan (:201-238), mismatch-run maxima (:152-172,199) by a segmented max-scan over the lanes
+//                              with a carry between passes;
+//   pass 3 (lane = M operator) the pieces (walk_pieces_at, restated per M operator: the next operator's reference start is
+//                              the neighbour's list entry) through make_piece.
+// K1 picks the reads (phase A knows everything the choice needs) and appends them to `wave_list`; this kernel is a fixed grid
+// whose waves take list entries round robin — no host round trip for the count.  A read with a NUL reference character under
+// an M base (the annotator's break, :151) is re-annotated by annotate_read() on one lane; pieces and indel events do not
+// depend on it.  Eligible: mapped-and-pushed reads with bases, inside the reference, 3..AW_MCAP M operators, no P / = / X
+// operator and no empty M operator (those keep the serial path, as do reads with more M operators than the list holds).
+__device__ __forceinline__ uint32_t mbcnt64(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+// Which reads take the wave form: lane = read.  K1 itself is not touched by the choice — a changed K1 is another register allocation, and
+// its 80-register budget holds by a hair (tests/test_abi.py) —: it is launched with a COPY of the operator counts in which the chosen
+// reads have none, and for a read without operators K1 writes nothing at all (no record, no pieces, no indel slots, no event bytes).
+__global__ __launch_bounds__(256) void k_pick_wave(DevCfg c, DevIn in, uint32_t* __restrict__ n_cigar_k1, uint32_t* __restrict__ wave_list, unsigned int* __restrict__ wave_n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool pick = false; uint32_t nc_me = 0u;
+    if (i < c.n_reads) {
+        const uint32_t nc = in.n_cigar[i]; nc_me = nc;
+        const int32_t pos = in.pos[i], L = in.l_qseq[i];
+        if (nc >= 5u && L > 0 && pos >= 0 && c.has_ref && !(in.flag[i] & BRC_PUSH_MASK)) {       // (three M operators take at least five)
+            const uint32_t* cig = BRC_CK(c, CK_ANNOTATE, 44, CB_CIGAR, in.cigar + in.cig_off[i], 4ull * nc, i, -1);
+            int64_t rlen = 0; uint32_t n_m = 0; bool irregular = false;
+            for (uint32_t k = 0; k < nc; ++k) {
+                const uint32_t cg = cig[k], op = cg & 0xfu, len = cg >> 4;
+                if (op > (uint32_t)CHARD_CLIP || (op == CMATCH && len == 0u)) irregular = true;  // P, =, X, unknown codes, an empty M: the serial path restates those
+                if (op == CMATCH) ++n_m;
+                if (is_refop(op)) rlen += len;
+            }
+            pick = !irregular && n_m > 2u && n_m <= (uint32_t)AW_MCAP && (int64_t)pos + rlen <= c.ref_len && rlen < 0x7fffffffll;
+        }
+    }
+    const unsigned long long pm = __ballot(pick);
+    if (pm) {
+        const int lane = threadIdx.x & 63;
+        uint32_t base = 0u;
+        if (lane == __builtin_ctzll(pm)) base = atomicAdd(wave_n, (unsigned int)__builtin_popcountll(pm));
+        base = (uint32_t)__shfl((int)base, __builtin_ctzll(pm), 64);
+        if (pick) wave_list[base + mbcnt64(pm)] = (uint32_t)i;
+    }
+    if (i < c.n_reads) n_cigar_k1[i] = pick ? 0u : nc_me;
+}
+__device__ __forceinline__ int32_t wave_incl_sum(int32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(v, d, 64); if (lane >= d) v += o; }
+    return v;
+}
+template <int SH>
+__global__ __launch_bounds__(256) void k_annotate_wave(DevCfg c, DevIn in, const uint32_t* __restrict__ wave_list, const unsigned int* __restrict__ wave_n,
+                                                       DRead* __restrict__ reads, const uint32_t* __restrict__ piece_off,
+                                                       Piece* __restrict__ pieces, PieceRare* __restrict__ rare, int2* __restrict__ keyreach,
+                                                       uint8_t* __restrict__ eb, uint16_t* __restrict__ bqw, IndelEv* __restrict__ ev_raw, uint32_t* __restrict__ bucket_cnt,
+                                                       const uint8_t* __restrict__ refcode, const uint16_t* __restrict__ wanted) {
+    c.pack_shift = SH;
+    struct WaveLds { int32_t y[AW_MCAP]; int32_t x[AW_MCAP]; uint32_t lw[AW_MCAP]; DRead r; uint32_t wide; };
+    __shared__ WaveLds lds_all[4];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    WaveLds& W = lds_all[wv];
+    const uint32_t n_list = *wave_n;
+    const uint32_t nwaves = gridDim.x * 4u;
+    const int64_t ref_n = c.ref_hi - c.ref_lo;
+    for (uint32_t li = blockIdx.x * 4u + wv; li < n_list; li += nwaves) {
+        const int64_t my = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)wave_list[li]);
+        const int32_t pos = __builtin_amdgcn_readfirstlane(in.pos[my]);
+        const uint32_t flag = (uint32_t)__builtin_amdgcn_readfirstlane((int)in.flag[my]);
+        const int32_t L = __builtin_amdgcn_readfirstlane(in.l_qseq[my]);
+        const uint32_t nc = (uint32_t)__builtin_amdgcn_readfirstlane((int)in.n_cigar[my]);
+        const uint32_t mapq = (uint32_t)__builtin_amdgcn_readfirstlane((int)in.mapq[my]);
+        const uint32_t tags = (uint32_t)__builtin_amdgcn_readfirstlane((int)in.tags[my]);
+        const int lib = c.per_lib ? __builtin_amdgcn_readfirstlane((int)in.lib[my]) : 0;
+        const uint64_t qoff = in.qual_off[my], soff = in.seq_off[my], brow = in.bq_row[my];
+        const uint32_t coff = (uint32_t)in.cig_off[my];
+        const uint32_t* const cig = BRC_CK(c, CK_ANNOTATE, 30, CB_CIGAR, in.cigar + coff, 4ull * nc, my, -1);
+        const uint8_t* const qual = BRC_CK(c, CK_ANNOTATE, 31, CB_QUAL, in.qual + qoff, (uint64_t)L, my, -1);
+        const uint8_t* const seq = BRC_CK(c, CK_ANNOTATE, 32, CB_SEQ, in.seq4 + soff, (uint64_t)((L + 1) / 2), my, -1);
+        uint8_t* const eb_row = BRC_CK(c, CK_ANNOTATE, 33, CB_EB, eb + brow, (uint64_t)L, my, -1);
+        uint16_t* const bqw_row = BRC_CK(c, CK_ANNOTATE, 34, CB_BQW, bqw + brow, 2ull * (uint64_t)L, my, -1);
+        const bool nocount = (flag & BRC_NOCOUNT_MASK) != 0u;
+        const bool ev_on = ev_raw && !(c.per_lib && lib < 0) && (int)mapq >= c.min_mapq && !nocount;
+        IndelEv* const ev_slots = ev_raw ? ev_raw + in.iev_off[my] : nullptr;
+
+        // ---- pass 1: lane = operator
+        int32_t xc = pos, yc = 0; uint32_t mc = 0u, used = 0u, n_idp = 0u;
+        uint32_t s_part = 0u, d_part = 0u, i_part = 0u; int32_t left_clip = 0;
+        for (uint32_t kb = 0; kb < nc; kb += 64u) {
+            const uint32_t k = kb + (uint32_t)lane; const bool on = k < nc;
+            const uint32_t cg = on ? cig[k] : 0u, c1 = k + 1u < nc ? cig[k + 1u] : 0u;
+            const uint32_t op = on ? (cg & 0xfu) : (uint32_t)CHARD_CLIP; const int32_t len = (int32_t)(cg >> 4);
+            const bool isM = op == CMATCH, isI = op == CINS, isD = op == CDEL, isN = op == CREF_SKIP, isS = op == CSOFT_CLIP;
+            const int32_t ql = (isM || isI || isS) ? len : 0, rl = (isM || isD || isN) ? len : 0;
+            const int32_t qi = wave_incl_sum(ql, lane), ri = wave_incl_sum(rl, lane);
+            const int32_t y = yc + qi - ql, x = xc + ri - rl;
+            if (isS) { s_part += (uint32_t)len; if (k == 0u) left_clip = len; }
+            if (isD || isN) d_part += (uint32_t)len;
+            if (isI || isS) i_part += (uint32_t)len;
+            const unsigned long long mb = __ballot(isM);
+            if (isM) {
+                const uint32_t mr = mc + mbcnt64(mb);                                   // (K1 sends only reads with at most AW_MCAP M operators)
+                if (mr < (uint32_t)AW_MCAP) { W.y[mr] = y; W.x[mr] = x; W.lw[mr] = (uint32_t)len | (((c1 & 0xfu) == CINS && (c1 >> 4) > 0u) ? 0x80000000u : 0u); }
+            }
+            mc += (uint32_t)__builtin_popcountll(mb);
+            n_idp += (uint32_t)__builtin_popcountll(__ballot(isI || isD));
+            if (ev_on) {
+                // (bamreadcount.cpp:288-342, as enumerate_indels_at: the last base of an M operator followed by D or I, inside the
+                // processing window, passing -b)
+                int32_t indel = 0;
+                if (isM && k + 1u < nc) { const uint32_t op2 = c1 & 0xfu; const int32_t l2 = (int32_t)(c1 >> 4); if (op2 == CDEL) indel = -l2; else if (op2 == CINS) indel = l2; }
+                const int32_t p = x + len - 1; const int32_t qp = y + len - 1;
+                bool emit = false;
+                if (indel != 0 && p >= c.beg0 - 1 && p < c.end && p >= c.pos0 && (int64_t)p < (int64_t)c.pos0 + c.P) {
+                    emit = (int)qual[qp] >= c.min_bq;
+                    if (emit && wanted && !tile_wants(*BRC_CK(c, CK_ANNOTATE, 35, CB_WANTED, wanted + ((uint32_t)(p - c.pos0) >> 6), 2, my, p), (uint32_t)(p - c.pos0) & 63u)) emit = false;
+                }
+                const unsigned long long em = __ballot(emit);
+                if (emit) {
+                    IndelEv e; e.read = (uint32_t)my; e.qpos = qp; e.len = indel; e.key_lo = (uint32_t)((int64_t)(p - c.pos0) * c.Lp + lib);
+                    *BRC_CK(c, CK_ANNOTATE, 36, CB_EVRAW, ev_slots + used + mbcnt64(em), sizeof(IndelEv), my, p) = e;
+                    atomicAdd(BRC_CK(c, CK_ANNOTATE, 37, CB_CNT, bucket_cnt + indel_bucket_of(c, (uint32_t)(p - c.pos0), (uint32_t)lib), 4, my, p), 1u);
+                }
+                used += (uint32_t)__builtin_popcountll(em);
+            }
+            yc += __builtin_amdgcn_readlane(qi, 63); xc += __builtin_amdgcn_readlane(ri, 63);
+        }
+        if (ev_raw) for (uint32_t u = used + (uint32_t)lane; u < n_idp; u += 64u) BRC_CK(c, CK_ANNOTATE, 38, CB_EVRAW, ev_slots + u, sizeof(IndelEv), my, -1)->key_lo = NONE32;
+        const int32_t rlen = xc - pos;
+        const uint32_t s_tot = wave_sum_u32(s_part), tot_d = wave_sum_u32(d_part), tot_is = wave_sum_u32(i_part);
+        left_clip = __builtin_amdgcn_readfirstlane(left_clip);
+        const int32_t clipped = L - (int32_t)s_tot;
+        const int32_t right_clip = L - ((int32_t)s_tot - left_clip);
+        const uint32_t nm_ops = mc < (uint32_t)AW_MCAP ? mc : (uint32_t)AW_MCAP;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                       // the list is read by other lanes below
+
+        // ---- pass 2: lane = base
+        uint32_t sum_part = 0u; bool carry_open = false; uint32_t carry_t = 0u;
+        int32_t my_lo = -1, my_hi = -1; bool wide = false, redo = false;
+        uint32_t mlo = 0u;                                                            // M operators starting at or before the pass's first base, less one window
+        for (int32_t jb = 0; jb < L; jb += 64) {
+            const int32_t j = jb + lane; const bool valid = j < L;
+            const int32_t jc = valid ? j : L - 1;
+            const uint32_t q = qual[jc];
+            const uint32_t nib = (seq[jc >> 1] >> ((~jc & 1) << 2)) & 0xfu;
+            // number of list entries with query start <= j (entries are sorted; at most 64 start inside a pass)
+            uint32_t cnt = mlo;
+#pragma unroll
+            for (uint32_t st = 64u; st > 0u; st >>= 1) { const uint32_t t = cnt + st; if (t <= nm_ops && W.y[t - 1u] <= jc) cnt = t; }
+            mlo = (uint32_t)__builtin_amdgcn_readlane((int)cnt, 0);                   // (every later base has at least lane 0's count)
+            bool in_m = false; uint32_t rcode = 0x0fu;
+            if (cnt > 0u) {
+                const uint32_t m = cnt - 1u; const int32_t y0 = W.y[m]; const int32_t ln = (int32_t)(W.lw[m] & 0x7fffffffu);
+                if (valid && jc - y0 < ln) {
+                    in_m = true;
+                    const int64_t ri = (int64_t)W.x[m] - c.ref_lo + (jc - y0);
+                    if (ri < 0 || ri >= ref_n) rcode = 0x8fu;                         // outside the uploaded slice: ref_at() gives 0 there — the serial path decides
+                    else rcode = *BRC_CK(c, CK_ANNOTATE, 39, CB_REFCODE, refcode + ri, 1, my, jc);
+                }
+            }
+            if (__ballot(in_m && (rcode & 0x80u))) redo = true;
+            const uint32_t refb = rcode & 0xfu;
+            const bool mm = in_m && nib != refb && refb != 15u && nib != 0u;          // :152
+            // event byte (+ the wide words of 8-base groups that hold an escape)
+            bool esc; const uint32_t bucket = canon_bucket(nib);
+            const uint32_t byte = eb_make(c.min_bq, q, bucket, esc);
+            if (valid) eb_row[j] = (uint8_t)byte;
+            unsigned long long eg = __ballot(esc && valid);
+            if (eg) {
+                wide = true;
+                eg |= eg >> 4; eg |= eg >> 2; eg |= eg >> 1; eg &= 0x0101010101010101ull; eg *= 0xffull;      // every lane of a group with an escape
+                if (valid && ((eg >> lane) & 1ull)) bqw_row[j] = (uint16_t)((q << 8) | bucket);
+            }
+            // first / last base with quality != 2
+            const unsigned long long nz = __ballot(valid && q != 2u);
+            if (nz) { if (my_lo < 0) my_lo = jb + __builtin_ctzll(nz); my_hi = jb + 63 - __builtin_clzll(nz); }
+            // mismatch qualities: every run of read-adjacent mismatches adds its maximum
+            const unsigned long long M = __ballot(mm);
+            if (carry_open && !(M & 1ull)) { if (lane == 0) sum_part += carry_t; carry_open = false; }
+            if (M) {
+                const unsigned long long zb = ~M & ((2ull << lane) - 1ull);           // lanes <= mine without a mismatch
+                const int start = zb ? 64 - __builtin_clzll(zb) : 0;                  // first lane of my run (if I am in one)
+                uint32_t v = mm ? q : 0u;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64); if (lane - d >= start) v = v > o ? v : o; }
+                if (mm && start == 0 && carry_open) v = v > carry_t ? v : carry_t;
+                const bool last = mm && lane < 63 && !((M >> (lane + 1)) & 1ull);
+                if (last) sum_part += v;
+                carry_open = (M >> 63) != 0ull;
+                carry_t = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+            }
+        }
+        if (carry_open && lane == 0) sum_part += carry_t;
+        const uint32_t zm_sum = wave_sum_u32(sum_part);
+
+        // ---- the read's record (as K1's phase C) — or, for a read with a NUL reference character under an M base, annotate_read()
+        if (lane == 0) {
+            DRead r0; bool w0 = wide;
+            if (redo) r0 = annotate_read(c, in, my, eb, bqw, w0);
+            else {
+                const bool rev = (flag & FREVERSE) != 0;
+                int tp, q2;
+                if (rev) { tp = 0; if (tp < left_clip) tp = left_clip; q2 = my_lo >= 0 ? my_lo - 1 : -1; if (tp < q2) tp = q2; }
+                else { tp = L - 1; if (tp > right_clip) tp = right_clip; q2 = my_hi >= 0 ? my_hi - 1 : -1; if (tp > q2 && q2 != -1) tp = q2; }
+                r0.pos = pos; r0.end = pos + rlen; r0.cig_off = coff; r0.n_cigar = nc; r0.bq_off = brow;
+                uint32_t misc = (mapq << 8) | ((uint32_t)((lib + 1) & 0xff) << 16);
+                if (rev) misc |= M_REV;
+                if (nocount) misc |= M_NOCOUNT;
+                if (q2 > -1) misc |= M_Q2OK;
+                if ((uint64_t)tot_d + (uint64_t)tot_is <= (uint64_t)STAGE_SLACK) misc |= M_STAGED | (tot_d << 24);
+                uint32_t sse;
+                if (flag & FPROPER_PAIR) { if (tags & 2u) sse = (uint32_t)in.sm[my]; else { sse = 0; misc |= M_SMW; } } else sse = mapq;
+                float snm = 0.0f;
+                if (tags & 1u) snm = (float)in.nm[my] / (float)clipped; else misc |= M_NMW;
+                r0.misc = finish_misc(misc, c.table_len > 0 && L == c.table_len && clipped == L, false); r0.l_qseq = L; r0.q2 = q2; r0.tp = tp; r0.left = left_clip; r0.clipped = clipped;
+                r0.zm_sum = zm_sum; r0.sse_add = sse; r0.snm_add = snm; r0.clipped_dup = clipped;
+            }
+            W.r = r0; W.wide = w0 ? 1u : 0u;
+            *BRC_CK(c, CK_ANNOTATE, 40, CB_READS, reads + my, sizeof(DRead), my, -1) = r0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const DRead r = W.r;
+        const ReadConst rc = read_const(c, r, (uint32_t)my, W.wide != 0u);
+
+        // ---- pass 3: lane = M operator: the pieces (walk_pieces_at; the host counted them with it: piece_off[] are their slots)
+        const bool entered = r.end > r.pos && !(c.per_lib && lib < 0);
+        const uint32_t slot0 = piece_off[my];
+        auto put_piece = [&](uint32_t slot, int32_t rs, int32_t len, int32_t ext, int qo, bool nb) {
+            Piece h; PieceRare rr;
+            make_piece(c, rc, rs, len, ext, qo, nb, h, rr, SH);
+            *BRC_CK(c, CK_ANNOTATE, 41, CB_PIECES, pieces + slot, sizeof(Piece), my, slot) = h;
+            if (piece_has_rare(piece_flags(h))) *BRC_CK(c, CK_ANNOTATE, 42, CB_RARE, rare + slot, sizeof(PieceRare), my, slot) = rr;
+            *BRC_CK(c, CK_ANNOTATE, 43, CB_KEYREACH, keyreach + slot, sizeof(int2), my, slot) = make_int2(pos, rs + ext);
+        };
+        if (entered && !rc.counts) { if (lane == 0 && rlen > 0) put_piece(slot0, pos, 0, rlen, 0, false); }
+        else if (entered) {
+            const int32_t x_first = W.x[0];
+            uint32_t ord = 0u;
+            if (x_first > pos) { if (lane == 0) put_piece(slot0, pos, 0, x_first - pos, 0, false); ord = 1u; }     // leading deletion / skip: column only
+            const bool ic = c.insertion_centric != 0;
+            for (uint32_t mb0 = 0; mb0 < nm_ops; mb0 += 64u) {
+                const uint32_t m = mb0 + (uint32_t)lane; const bool on = m < nm_ops;
+                const uint32_t mi = on ? m : 0u;
+                const int32_t x = W.x[mi], y = W.y[mi]; const uint32_t lw = W.lw[mi];
+                const int32_t len = (int32_t)(lw & 0x7fffffffu);
+                const int32_t xnext = mi + 1u < nm_ops ? W.x[mi + 1u] : pos + rlen;
+                const bool split = ic && (lw >> 31) != 0u;
+                const int32_t cnt = on ? ((split && len > 1) ? 2 : 1) : 0;
+                const int32_t ci = wave_incl_sum(cnt, lane);
+                uint32_t slot = slot0 + ord + (uint32_t)(ci - cnt);
+                if (on) {
+                    if (!split) put_piece(slot, x, len, xnext - x, y, false);
+                    else {
+                        if (len > 1) { put_piece(slot, x, len - 1, len - 1, y, false); ++slot; }
+                        put_piece(slot, x + len - 1, 1, xnext - (x + len - 1), y + len - 1, true);
+                    }
+                }
+                ord += (uint32_t)__builtin_amdgcn_readlane(ci, 63);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                       // the next read reuses the list
     }
 }
 
@@ -1647,7 +1918,7 @@ class HipBackend : public Backend {
     // device buffers
     DBuf d_pos, d_flag, d_mapq, d_lib, d_lq, d_nc, d_co, d_so, d_qo, d_nm, d_sm, d_tags, d_cigar, d_seq, d_qual, d_ref, d_refcode;
     std::vector<uint16_t> h_wanted; bool has_wanted = false; DBuf d_wanted; std::vector<uint32_t> h_tilelist; DBuf d_tilelist;      // brc_region_windows (kept alive for the asynchronous copy)
-    DBuf d_bq, d_bqw, d_bqrow, d_pieceoff, d_pieces, d_rare, d_keyreach, d_libbase, d_reads, d_agg, d_rng, d_ncol, d_depth, d_slotid, d_si, d_sf, d_xev, d_xevc, d_xevn, d_unavail, d_cnt, d_cursor, d_ev, d_evraw, d_ievoff, d_iout, d_ctr, d_tilectr, d_part;
+    DBuf d_bq, d_bqw, d_bqrow, d_pieceoff, d_pieces, d_rare, d_keyreach, d_libbase, d_reads, d_agg, d_rng, d_ncol, d_depth, d_slotid, d_si, d_sf, d_xev, d_xevc, d_xevn, d_unavail, d_cnt, d_cursor, d_ev, d_evraw, d_ievoff, d_iout, d_ctr, d_tilectr, d_part, d_wavelist, d_nc_k1;
     DBuf d_tlen, d_toff, d_text, d_tctx, d_total64;
     // device-side text, downloaded (pinned) on its own stream into one of two host buffers
     HBuf<char> h_text[2]; HBuf<uint32_t> h_toff[2]; HBuf<uint32_t> h_total;
@@ -1658,6 +1929,8 @@ class HipBackend : public Backend {
     // tile compaction (k_compact_tiles): on for regions whose reads average more than COMPACT_PIECES_PER_READ pieces
     enum { COMPACT_PIECES_PER_READ = 12 };
     bool compact_on = false; uint64_t compact_total = 0; bool compact_sized = false;
+    bool wave_on = false;                      // this region's reads with more than two M operators go to k_annotate_wave
+    enum { WAVE_FORM_BLOCKS = 768 };           // its fixed grid: 3 blocks of 4 waves per CU (48 KB of LDS each)
     unsigned long long h_steps[2] = {0, 0};   // piece-steps of the last pass: what the tile ranges hold / what k_pileup2 walked (brc_region_piece_steps)
     DBuf d_ccnt, d_coff, d_cpieces, d_crare, d_crng, d_ctot;
     // host result buffers (pinned)
@@ -1739,7 +2012,7 @@ class HipBackend : public Backend {
         if (getenv("BRC_ENGINE_TIMING")) fprintf(stderr, "device buffers: %llu (re)allocations, %.3f s\n", (unsigned long long)g_dev_allocs.load(), (double)g_dev_alloc_ns.load() * 1e-9);
         DBuf* all[] = {&d_pos, &d_flag, &d_mapq, &d_lib, &d_lq, &d_nc, &d_co, &d_so, &d_qo, &d_nm, &d_sm, &d_tags, &d_cigar, &d_seq, &d_qual,
                        &d_ref, &d_refcode, &d_bq, &d_bqw, &d_bqrow, &d_pieceoff, &d_pieces, &d_rare, &d_keyreach, &d_libbase, &d_reads, &d_agg, &d_rng, &d_ncol, &d_depth, &d_slotid, &d_si, &d_sf, &d_xev, &d_xevc, &d_xevn, &d_unavail, &d_cnt,
-                       &d_cursor, &d_ev, &d_evraw, &d_ievoff, &d_iout, &d_ctr, &d_tilectr, &d_part, &d_tlen, &d_toff, &d_text, &d_tctx, &d_total64, &d_wanted, &d_tilelist};
+                       &d_cursor, &d_ev, &d_evraw, &d_ievoff, &d_iout, &d_ctr, &d_tilectr, &d_part, &d_tlen, &d_toff, &d_text, &d_tctx, &d_total64, &d_wanted, &d_tilelist, &d_wavelist, &d_nc_k1};
         for (DBuf* b : all) b->release();
         d_ccnt.release(); d_coff.release(); d_cpieces.release(); d_crare.release(); d_crng.release(); d_ctot.release();
 #ifdef BRC_CHECKED
@@ -1840,6 +2113,10 @@ class HipBackend : public Backend {
         const size_t np = (size_t)c.n_pieces;
         HIPCHK(d_pieces.ensure((np + 4) * sizeof(Piece))); HIPCHK(d_rare.ensure((np + 2) * sizeof(PieceRare)));      // (the read loop requests records up to two past the last)
         HIPCHK(d_keyreach.ensure((np + 16) * sizeof(int2)));
+        // reads with more than two M operators are annotated a wave per read (k_annotate_wave); TK_WAVE_FORM=0 keeps them on K1's serial path
+        wave_on = n > 0 && c.has_ref && s.max_ncigar >= 5;                          // (three M operators take at least five operators)
+        if (const char* wk = test_knob(TK_WAVE_FORM)) wave_on = wave_on && atoi(wk) != 0;
+        if (wave_on) { HIPCHK(d_wavelist.ensure(((size_t)n + 16) * sizeof(uint32_t))); HIPCHK(d_nc_k1.ensure(((size_t)n + 16) * sizeof(uint32_t))); }
         HIPCHK(d_libbase.ensure((lib_base.size() + 1) * sizeof(int64_t)));
         if (!lib_base.empty()) HIPCHK(hipMemcpyAsync(d_libbase.p, lib_base.data(), lib_base.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
         // outputs / scratch
@@ -1931,14 +2208,29 @@ class HipBackend : public Backend {
             const int64_t rl = c.ref_hi - c.ref_lo;
             if (c.has_ref)
                 hipLaunchKernelGGL(k_refcode, dim3((unsigned)(((rl + 2 * REFCODE_PAD + 15) / 16 + 255) / 256)), dim3(256), 0, stream, in.ref, (uint8_t*)d_refcode.p, rl);
+            DevIn in_k1 = in;
+            if (wave_on) {   // reads with more than two M operators: listed for k_annotate_wave, without operators in K1's copy of the counts
+                hipLaunchKernelGGL(k_pick_wave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (uint32_t*)d_nc_k1.p, (uint32_t*)d_wavelist.p, &ctr->n_wave_reads);
+                in_k1.n_cigar = (const uint32_t*)d_nc_k1.p;
+            }
             {   // K1: one instantiation per (row layout, width of the narrow packed fields — choose_pack)
-#define BRC_LAUNCH_K1(OS, SH) hipLaunchKernelGGL((k_annotate_groups<OS, SH>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (DRead*)d_reads.p, (const uint32_t*)d_pieceoff.p, \
+#define BRC_LAUNCH_K1(OS, SH) hipLaunchKernelGGL((k_annotate_groups<OS, SH>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in_k1, (DRead*)d_reads.p, (const uint32_t*)d_pieceoff.p, \
                                    (Piece*)d_pieces.p, (PieceRare*)d_rare.p, (int2*)d_keyreach.p,                                                                               \
                                    (uint8_t*)in.eb, (uint16_t*)in.bqw, indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p,                                    \
                                    in.cigar, in.qual, in.seq4, (const uint8_t*)d_refcode.p + REFCODE_PAD, has_wanted ? (const uint16_t*)d_wanted.p : (const uint16_t*)nullptr)
                 if (Lp == 1) { if (c.pack_shift == 16) BRC_LAUNCH_K1(true, 16); else BRC_LAUNCH_K1(true, 12); }
                 else { if (c.pack_shift == 16) BRC_LAUNCH_K1(false, 16); else BRC_LAUNCH_K1(false, 12); }
 #undef BRC_LAUNCH_K1
+                if (wave_on) {
+                    // the reads K1 left to the wave form (their number stays on the device: a fixed grid takes them round robin)
+                    const unsigned nb = (unsigned)std::min<int64_t>((n + 3) / 4, (int64_t)WAVE_FORM_BLOCKS);
+#define BRC_LAUNCH_K1W(SH) hipLaunchKernelGGL((k_annotate_wave<SH>), dim3(nb), dim3(256), 0, stream, c, in, (const uint32_t*)d_wavelist.p, (const unsigned int*)&ctr->n_wave_reads,     \
+                                   (DRead*)d_reads.p, (const uint32_t*)d_pieceoff.p, (Piece*)d_pieces.p, (PieceRare*)d_rare.p, (int2*)d_keyreach.p,                                   \
+                                   (uint8_t*)in.eb, (uint16_t*)in.bqw, indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p,                                          \
+                                   (const uint8_t*)d_refcode.p + REFCODE_PAD, has_wanted ? (const uint16_t*)d_wanted.p : (const uint16_t*)nullptr)
+                    if (c.pack_shift == 16) BRC_LAUNCH_K1W(16); else BRC_LAUNCH_K1W(12);
+#undef BRC_LAUNCH_K1W
+                }
             }
             if (c.per_lib) {
                 HIPCHK(hipMemsetAsync(d_unavail.p, 0xff, (size_t)c.PS * 4, stream));

@@ -104,7 +104,7 @@ void Staged::clear() {
     qual_off.clear(); nm.clear(); sm.clear(); tags.clear(); cigar.clear(); seq4.clear(); qual.clear(); bq_row.clear();
     bq_elems = 0; memset(len_hist, 0, sizeof len_hist); n = 0; min_pos = 0; max_end = 0; n_indel_ops = 0;
     seq_seg.clear(); qual_seg.clear(); seq_total = 0; qual_total = 0;
-    piece_cnt.clear(); piece_off.clear(); iev_off.clear(); lib_base.clear(); n_pieces = 0; max_lqseq = 0; max_span = 0; qnames.clear(); qname_off.clear();
+    piece_cnt.clear(); piece_off.clear(); iev_off.clear(); lib_base.clear(); n_pieces = 0; max_lqseq = 0; max_ncigar = 0; max_span = 0; qnames.clear(); qname_off.clear();
     win_beg.clear(); win_end.clear();
 }
 std::vector<uint16_t> Staged::wanted_tiles(int32_t pos0, int64_t P) const {
@@ -505,6 +505,10 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
 // region" until the caller opens the next one with brc_begin_region (which resets the staging).
 void* brc_host_alloc(size_t bytes) { return backend_host_alloc(bytes); }
 void brc_host_free(void* p) { if (p) backend_host_free(p); }
+// A mapped read with an M / = / X operator of length zero: htslib's resolve_cigar2 steps ONTO such an operator without asking whether the
+// position lies inside it (it reports the column as a match at the operator's query offset and the deletion behind it one column late) —
+// the pieces of walk_pieces() cannot say that, and no aligner writes such records.  Refused, loudly, rather than counted differently.
+static const char* const kEmptyM = "a mapped read has an M/=/X CIGAR operator of length zero";
 static int push_reads_any(brc_engine* e, const brc_read_batch* b, bool pinned);
 int brc_push_reads(brc_engine* e, const brc_read_batch* b) { return push_reads_any(e, b, false); }
 int brc_push_reads_pinned(brc_engine* e, const brc_read_batch* b) { return push_reads_any(e, b, true); }
@@ -557,6 +561,7 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
               (adopt || (append_big(pool, s.seq4, b->seq4, b->seq_bytes) && append_big(pool, s.qual, b->qual, b->qual_bytes))) &&
               s.bq_row.reserve(n0 + n + 16) && s.piece_cnt.reserve(n0 + n + 16) && s.piece_off.reserve(n0 + n + 16) && s.iev_off.reserve(n0 + n + 16) && s.lib.reserve(n0 + n + 16) && s.nm.reserve(n0 + n + 16) && s.sm.reserve(n0 + n + 16) && s.tags.reserve(n0 + n + 16);
     if (!ok) return fail(e, BRC_E_NOMEM, "host staging allocation failed");
+    { uint32_t mx = s.max_ncigar; for (size_t i = 0; i < n; ++i) mx = b->n_cigar[i] > mx ? b->n_cigar[i] : mx; s.max_ncigar = mx; }   // (the engine's wave-form annotator is for reads with five operators and more)
     if (adopt) {
         if (b->seq_bytes) { Staged::Seg g; g.p = b->seq4; g.off = sb; g.n = b->seq_bytes; s.seq_seg.push_back(g); }
         if (b->qual_bytes) { Staged::Seg g; g.p = b->qual; g.off = qb; g.n = b->qual_bytes; s.qual_seg.push_back(g); }
@@ -613,12 +618,12 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
                 if (pos < prev) { bad(i, BRC_E_ARG, "reads are not coordinate-sorted"); break; }
                 const uint16_t fl = (uint16_t)(s.flag.p[r] & 0x7fffu);
                 if (s.l_qseq.p[r] > 0 && nc > 0) {
-                    int64_t ql = 0;
-                    for (uint32_t k = 0; k < nc; ++k) { const uint32_t op = s.cigar.p[s.cig_off.p[r] + k] & 0xfu; if (op == CMATCH || op == CINS || op == CSOFT_CLIP || op == CEQUAL || op == CDIFF) ql += s.cigar.p[s.cig_off.p[r] + k] >> 4; }
+                    int64_t ql = 0; bool empty_m = false;
+                    for (uint32_t k = 0; k < nc; ++k) { const uint32_t cg = s.cigar.p[s.cig_off.p[r] + k], op = cg & 0xfu; if (op == CMATCH || op == CINS || op == CSOFT_CLIP || op == CEQUAL || op == CDIFF) ql += cg >> 4; if (is_mop(op) && (cg >> 4) == 0u) empty_m = true; }
                     if (ql != s.l_qseq.p[r]) {
                         if (!(fl & FUNMAP)) { bad(i, BRC_E_ARG, "a read's CIGAR and sequence length disagree"); break; }
                         nc = 0; s.n_cigar.p[r] = 0;
-                    }
+                    } else if (empty_m && !(fl & FUNMAP)) { bad(i, BRC_E_ARG, kEmptyM); break; }
                 }
                 uint64_t idp = 0;
                 const int32_t rlen = cigar_rlen(s.cigar.p + s.cig_off.p[r], nc, &idp);
@@ -692,12 +697,12 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
         // quality / base rows (htslib indexes the record's memory just the same: undefined there).  Mapped: refused.
         // Unmapped (some aligners leave the mate's CIGAR on such records; they never reach a column): the CIGAR is dropped.
         if (s.l_qseq.p[r] > 0 && nc > 0) {
-            int64_t ql = 0;
-            for (uint32_t k = 0; k < nc; ++k) { const uint32_t op = s.cigar.p[s.cig_off.p[r] + k] & 0xfu; if (op == CMATCH || op == CINS || op == CSOFT_CLIP || op == CEQUAL || op == CDIFF) ql += s.cigar.p[s.cig_off.p[r] + k] >> 4; }
+            int64_t ql = 0; bool empty_m = false;
+            for (uint32_t k = 0; k < nc; ++k) { const uint32_t cg = s.cigar.p[s.cig_off.p[r] + k], op = cg & 0xfu; if (op == CMATCH || op == CINS || op == CSOFT_CLIP || op == CEQUAL || op == CDIFF) ql += cg >> 4; if (is_mop(op) && (cg >> 4) == 0u) empty_m = true; }
             if (ql != s.l_qseq.p[r]) {
                 if (!(fl & FUNMAP)) return fail(e, BRC_E_ARG, "a read's CIGAR and sequence length disagree");
                 nc = 0; s.n_cigar.p[r] = 0;
-            }
+            } else if (empty_m && !(fl & FUNMAP)) return fail(e, BRC_E_ARG, kEmptyM);
         }
         uint64_t idp = 0;                                     // I / D / P operators of the CIGAR the device will see
         const int32_t rlen = cigar_rlen(s.cigar.p + s.cig_off.p[r], nc, &idp);

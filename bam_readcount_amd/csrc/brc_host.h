@@ -80,6 +80,7 @@ struct Staged {
     std::vector<int64_t> lib_base;
     int64_t n_pieces = 0;
     int32_t max_lqseq = 0;
+    uint32_t max_ncigar = 0;        // most CIGAR operators of a staged read
     int64_t max_span = 0;               // longest reference span of a pushed read
     void layout_pieces(int Lp, bool per_lib);
     uint32_t len_hist[TABLE_MAX + 1] = {0};   // histogram of l_qseq <= TABLE_MAX (modal length -> DevCfg.table_len)
@@ -175,7 +176,7 @@ unsigned effective_cpus();
 // with -DBRC_TEST_KNOBS, which maps an index to an environment variable): in the product test_knob() is the constant nullptr and
 // the library contains neither the names nor a getenv for them (tests/test_abi.py) — an inherited BRC_NO_TABLE=1 cannot turn the
 // shipped kernel into its slow path without a word.
-enum TestKnob { TK_NO_TABLE = 0, TK_FLUSH_K, TK_PACK_LIM, TK_FORCE_DOM, TK_IBUCKET_SHIFT, TK_XEV_CAP, TK_DEVICE_TEXT_LIMIT, TK_FORMAT_THREADS, TK_FORMAT_CHUNK, TK_COMPACT, TK_N };
+enum TestKnob { TK_NO_TABLE = 0, TK_FLUSH_K, TK_PACK_LIM, TK_FORCE_DOM, TK_IBUCKET_SHIFT, TK_XEV_CAP, TK_DEVICE_TEXT_LIMIT, TK_FORMAT_THREADS, TK_FORMAT_CHUNK, TK_COMPACT, TK_WAVE_FORM, TK_N };
 const char* test_knob(int which);
 
 // exact "%.2f" of a float (== iostream fixed/setprecision(2), BasicStat.cpp:116); returns bytes written

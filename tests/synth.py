@@ -44,10 +44,64 @@ def dense_cigar(rng, L):
     return out
 
 
+def many_cigar(rng, L):
+    """Reads with MANY operators of every regular kind, for the wave-form annotator (k_annotate_wave): match runs of a few bases (now and
+    then one base, now and then a hundred) between insertions, deletions, skips, a deletion followed by an insertion and the reverse;
+    hard / soft clips at either end, an insertion or a deletion as the first aligned operator.  Consumes exactly L query bases."""
+    ops = []; rem = L
+    if rng.random() < 0.2: ops.append((5, int(rng.integers(1, 9))))
+    if rng.random() < 0.4 and rem > 40:
+        s = int(rng.integers(1, 30)); ops.append((4, s)); rem -= s
+    tail = 0
+    if rng.random() < 0.4 and rem > 40:
+        tail = int(rng.integers(1, 30)); rem -= tail
+    r = rng.random()
+    if r < 0.1 and rem > 10:
+        i = int(rng.integers(1, 4)); ops.append((1, i)); rem -= i                  # insertion before the first match
+    elif r < 0.2:
+        ops.append((2, int(rng.integers(1, 5))))                                   # deletion before the first match: a column-only piece
+    mean = float(rng.choice([2.0, 6.0, 15.0]))
+    while rem > 0:
+        m = int(rng.geometric(1.0 / mean)) if rng.random() > 0.03 else int(rng.integers(60, 200))
+        m = max(1, min(rem, m)); ops.append((0, m)); rem -= m
+        if rem <= 1:
+            if rem == 1: ops.append((0, 1)); rem = 0
+            break
+        k = rng.random()
+        if k < 0.35:
+            i = min(rem - 1, int(rng.integers(1, 4))); ops.append((1, i)); rem -= i
+        elif k < 0.7:
+            ops.append((2, int(rng.integers(1, 4))))
+        elif k < 0.78:
+            ops.append((3, int(rng.integers(5, 120))))
+        elif k < 0.9:
+            ops.append((2, int(rng.integers(1, 3)))); i = min(rem - 1, int(rng.integers(1, 3))); ops.append((1, i)); rem -= i   # D then I
+        else:
+            i = min(rem - 1, int(rng.integers(1, 3))); ops.append((1, i)); rem -= i; ops.append((2, int(rng.integers(1, 3))))   # I then D
+    out = []
+    for o, l in ops:
+        if out and out[-1][0] == o: out[-1] = (o, out[-1][1] + l)
+        else: out.append((o, l))
+    if out[-1][0] != 0:                     # end on a match: take the base from an earlier run
+        out.append((0, 1))
+        for i, (o, l) in enumerate(out[:-1]):
+            if o == 0 and l > 1:
+                out[i] = (o, l - 1); break
+        else:
+            out.pop()
+            while out and out[-1][0] != 0: o, l = out.pop(); tail += l if o == 1 else 0
+    if tail: out.append((4, tail))
+    if rng.random() < 0.2: out.append((5, int(rng.integers(1, 9))))
+    assert sum(l for o, l in out if o in (0, 1, 4)) == L, (out, L)
+    return out
+
+
 def random_cigar(rng, L, style):
-    """Return list of (op,len) consuming exactly L query bases.  style: 'simple' | 'indel' | 'wild' | 'dense'."""
+    """Return list of (op,len) consuming exactly L query bases.  style: 'simple' | 'indel' | 'wild' | 'dense' | 'many'."""
     if style == "dense" and L >= 8:
         return dense_cigar(rng, L)
+    if style == "many" and L >= 60:
+        return many_cigar(rng, L)
     if style == "simple" or L < 8:
         return [(0, L)]
     ops = []
@@ -212,3 +266,62 @@ def add_sequenceless_secondary(arrs, pos, span=50):
         a[k] = np.insert(a[k], i, v).astype(a[k].dtype)
     a["cigar"] = np.append(a["cigar"], np.uint32((span << 4) | 0)).astype(np.uint32)
     return a
+
+
+# reads with MANY operators (many_cigar): the GPU suite runs them through the wave-form annotator (k_annotate_wave)
+MANY_OPS = [
+    dict(seed=31, n=120, opts=dict()),
+    dict(seed=32, n=120, opts=dict(min_mapq=20, min_bq=13)),
+    dict(seed=33, n=150, opts=dict(insertion_centric=True)),
+    dict(seed=34, n=150, opts=dict(per_lib=True, insertion_centric=True, min_bq=5), n_libs=3, p_nolib=0.05),
+    dict(seed=35, n=120, opts=dict(min_bq=30), weird=0.1),
+    dict(seed=36, n=100, opts=dict(per_lib=True), n_libs=2, nul=True),     # NUL characters inside the reference text (no FASTA has them: wave form against K1's serial walk)
+]
+
+
+def many_ops_inputs(case):
+    """inputs of one MANY_OPS case: reference (IUPAC / lower-case / NUL characters on request), a batch of
+    100-1200-base reads in the many_cigar style, library names, regions, whether library-less reads are in it"""
+    rng = np.random.default_rng(case["seed"])
+    ref = make_ref(rng, 4000, weird=case.get("weird", 0.0))
+    if case.get("nul"):
+        ref = ref.copy(); ref[rng.integers(0, len(ref), 12)] = 0
+    n_libs = case.get("n_libs", 1)
+    arrs = make_batch(case["seed"] + 100, ref, case["n"], style="many", read_len=(100, 1200), n_libs=n_libs, p_nolib=case.get("p_nolib", 0.0), p_iupac_read=0.01)
+    assert int(arrs["n_cigar"].max()) > 128                      # more operators than lanes: the passes carry their cursors
+    names = ["lib%c" % (65 + i) for i in range(n_libs)] if case["opts"].get("per_lib") else ()
+    return ref, arrs, names, [(0, 4000), (100, 101), (700, 1500), (3990, 4300)], case.get("p_nolib", 0.0) > 0
+
+
+def operator_limit_reads():
+    """Six hand-made reads around the wave form's limits: 1024 / 1025 / 1500 M operators, a P operator, = and X operators, and a plain
+    seven-operator read."""
+    rng = np.random.default_rng(41)
+    ref = make_ref(rng, 6000)
+    def read(pos, ops):
+        L = sum(l for o, l in ops if o in (0, 1, 4, 7, 8))
+        return pos, ops, rng.choice([1, 2, 4, 8], size=L).astype(np.uint8), rng.integers(3, 41, L).astype(np.uint8)
+    def alternating(n_m, gap_op):                                 # n_m one- or two-base matches separated by one-base operators
+        ops = []
+        for k in range(n_m):
+            ops.append((0, 1 + (k & 1)))
+            if k + 1 < n_m: ops.append((gap_op if k % 3 else 2, 1))
+        return ops
+    rows = [read(10, alternating(1024, 1)), read(20, alternating(1025, 1)), read(30, alternating(1500, 2)),
+            read(40, [(0, 5), (6, 1), (1, 2), (0, 7), (2, 1), (0, 9), (1, 1), (0, 4)]),          # P
+            read(50, [(7, 5), (1, 2), (0, 7), (2, 1), (8, 3), (0, 9), (1, 1), (0, 4)]),          # = and X
+            read(70, [(0, 5), (1, 2), (0, 7), (2, 1), (0, 9), (1, 1), (0, 4)])]
+    a = dict(pos=[], flag=[], mapq=[], lib=[], l_qseq=[], n_cigar=[], cigar_off=[], seq_off=[], qual_off=[], nm=[], sm=[], tags=[])
+    cig, seqs, quals = [], [], []; so = qo = 0
+    for pos, ops, seq, q in rows:
+        L = len(seq)
+        a["pos"].append(pos); a["flag"].append(0); a["mapq"].append(60); a["lib"].append(0); a["l_qseq"].append(L); a["n_cigar"].append(len(ops))
+        a["cigar_off"].append(len(cig)); a["seq_off"].append(so); a["qual_off"].append(qo); a["nm"].append(3); a["sm"].append(0); a["tags"].append(1)
+        cig += [(l << 4) | o for o, l in ops]
+        s4 = np.append(seq, 0) if L & 1 else seq
+        seqs.append(((s4[0::2] << 4) | s4[1::2]).astype(np.uint8)); so += (L + 1) // 2
+        quals.append(q); qo += L
+    dt = dict(pos=np.int32, flag=np.uint16, mapq=np.uint8, lib=np.int16, l_qseq=np.int32, n_cigar=np.uint32, cigar_off=np.uint64, seq_off=np.uint64, qual_off=np.uint64, nm=np.int32, sm=np.int32, tags=np.uint8)
+    a = {k: np.array(v, dt[k]) for k, v in a.items()}
+    a["cigar"] = np.array(cig, np.uint32); a["seq4"] = np.concatenate(seqs); a["qual"] = np.concatenate(quals)
+    return ref, a

@@ -16,6 +16,7 @@ import parity
 import synth
 from test_oracle_golden import CASES, golden, run_case
 from test_sim_parity import FUZZ
+from synth import MANY_OPS
 
 
 
@@ -619,6 +620,41 @@ def test_hip_compacted_tile_ranges_equal_oracle_on_every_fuzz_family(knob_lib, o
     want, _ = parity.compare_libs(knob_lib, oracle_lib, arrs, regions, ref=ref, lib_names=names, check_warn=not nolib, **case["opts"])
     got, _ = parity.run_engine(knob_lib, arrs, regions, ref=ref, lib_names=names, device_text="chrS", **case["opts"])
     assert got == want
+
+
+@pytest.mark.parametrize("case", MANY_OPS, ids=lambda c: "seed%d" % c["seed"])
+def test_hip_wave_form_annotator_on_reads_with_many_operators(dev_lib, knob_lib, oracle_lib, monkeypatch, case):
+    """k_annotate_wave (one wave per read, for reads with more than two M operators): 100-1200-base reads with up to several hundred
+    operators of every regular kind (tests/synth.py: many_cigar — one-base and hundred-base match runs, I / D / N, D then I, I then D,
+    hard and soft clips at both ends, an insertion or a deletion in front of the first match), quality-2 tails, N bases, escapes; with
+    -i, per library (with library-less reads), over IUPAC / lower-case reference characters and over NUL characters in the reference
+    (the annotator's break, :151: the wave re-annotates such a read on one lane).  Planes, indel lists, text, device text and windows
+    equal the oracle's; the test-knobs library with the wave form switched off (K1's serial walk) gives the same bytes.  ([sim]: the
+    simulator has no wave form — the same inputs through the serial annotator and the shared host code.)"""
+    ref, arrs, names, regions, nolib = synth.many_ops_inputs(case)
+    if case.get("nul"):
+        # (NUL characters INSIDE a reference text are no input a FASTA can produce — the oracle's C strings end there —: the wave form's
+        # re-annotation of such reads is held against K1's serial walk instead)
+        want, res = parity.run_engine(dev_lib, arrs, regions, ref=ref, lib_names=names, **case["opts"])
+        monkeypatch.setenv("BRC_WAVE_FORM", "0")
+        off, res_off = parity.run_engine(knob_lib, arrs, regions, ref=ref, lib_names=names, **case["opts"])
+        for a, b in zip(res, res_off): parity.assert_results_equal(a, b, "NUL reference characters")
+        assert off == want
+        return
+    want, _ = parity.compare_libs(dev_lib, oracle_lib, arrs, regions, ref=ref, lib_names=names, check_warn=not nolib, **case["opts"])
+    got, _ = parity.run_engine(dev_lib, arrs, regions, ref=ref, lib_names=names, device_text="chrS", **case["opts"])
+    assert got == want
+    monkeypatch.setenv("BRC_WAVE_FORM", "0")
+    off, _ = parity.run_engine(knob_lib, arrs, regions, ref=ref, lib_names=names, **case["opts"])
+    assert off == want
+
+
+def test_hip_wave_form_operator_count_limits(dev_lib, oracle_lib):
+    """The wave form holds at most 1024 M operators of a read in LDS: a read with exactly that many takes it, one with more (and reads
+    with P, = or X operators) keep K1's serial walk — side by side in one region, all equal to the oracle.  [sim]: the serial walk."""
+    ref, arrs = synth.operator_limit_reads()
+    for opts in (dict(), dict(insertion_centric=True, min_bq=10)):
+        parity.compare_libs(dev_lib, oracle_lib, arrs, [(0, 6000), (900, 1100)], ref=ref, **opts)
 
 
 def test_hip_reads_with_an_operator_every_few_bases(dev_lib, knob_lib, oracle_lib, monkeypatch):

@@ -28,7 +28,6 @@ FUZZ = [
     dict(seed=10, style="indel", n=50, opts=dict()),
 ]
 
-
 def test_sim_without_reference(sim_lib, oracle_lib):
     rng = np.random.default_rng(77)
     ref = synth.make_ref(rng, 1000)
@@ -187,6 +186,14 @@ def test_push_reads_refuses_inconsistent_records(sim_lib):
     bad = {k: v.copy() for k, v in good.items()}
     bad["cigar"][int(bad["cigar_off"][7])] += 2 << 4
     refused(bad, "CIGAR and sequence length disagree")
+    # an M operator of length zero (htslib's resolve_cigar2 steps ONTO it and reports its column as a match, the deletion behind it one
+    # column late — no aligner writes it, and the engine's pieces cannot say it): refused
+    bad = {k: v.copy() for k, v in good.items()}
+    i6 = int(np.flatnonzero(good["n_cigar"] >= 3)[0]); c0 = int(bad["cigar_off"][i6])
+    assert (int(bad["cigar"][c0]) & 15) == 0 and (int(bad["cigar"][c0 + 2]) & 15) == 0
+    moved = int(bad["cigar"][c0 + 2]) >> 4
+    bad["cigar"][c0] = np.uint32(int(bad["cigar"][c0]) + (moved << 4)); bad["cigar"][c0 + 2] = np.uint32(0)
+    refused(bad, "operator of length zero")
     bad = {k: v.copy() for k, v in good.items()}
     bad["pos"][9] = bad["pos"][3] - 1 if bad["pos"][3] > 0 else 0; bad["pos"][10] = bad["pos"][9] - 1 if bad["pos"][9] > 0 else -1
     refused(bad, "coordinate-sorted")
