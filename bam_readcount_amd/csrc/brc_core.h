@@ -1085,7 +1085,13 @@ BRC_HD void reduce_indel_bucket(const DevCfg& c, const DevIn& in, const DRead* r
 // positions per indel bucket = 1 << DevCfg.ibucket_shift, chosen per region (indel_bucket_shift): 64 where events are sparse
 // (30x: one bucket in four holds an event — fewer buckets to scan), 16 where they are dense (200x with 10 % indel reads: many
 // short per-lane sorts instead of a few long ones)
-BRC_HD int32_t indel_bucket_shift(uint64_t n_indel_ops, int64_t P, int Lp) { return (P > 0 && n_indel_ops * 64ull >= (uint64_t)P * (uint64_t)Lp) ? 4 : 6; }
+// — and 4 where there is an indel operator for every other position and more (long reads with an operator every ~15 bases at 30x: two events
+// per position; 16-position buckets gave every lane 32 events to sort and fold, 13.9 ms of a 54-ms step)
+BRC_HD int32_t indel_bucket_shift(uint64_t n_indel_ops, int64_t P, int Lp) {
+    if (P <= 0) return 6;
+    const uint64_t cells = (uint64_t)P * (uint64_t)Lp;
+    return n_indel_ops * 2ull >= cells ? 2 : n_indel_ops * 64ull >= cells ? 4 : 6;
+}
 BRC_HD int64_t indel_buckets(const DevCfg& c) { return ((c.P + ((int64_t)1 << c.ibucket_shift) - 1) >> c.ibucket_shift) * c.Lp; }
 BRC_HD uint32_t indel_bucket_of(const DevCfg& c, uint32_t k, uint32_t lib) { return (k >> c.ibucket_shift) * (uint32_t)c.Lp + lib; }
 BRC_HD uint32_t indel_bucket(const DevCfg& c, uint32_t key) {

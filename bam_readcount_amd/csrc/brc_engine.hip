@@ -1142,6 +1142,77 @@ __global__ __launch_bounds__(256) void k_compact_tiles(DevCfg c, const uint4* __
     }
 }
 
+// The same compaction READ-WISE (one library: the slots of consecutive reads are consecutive, piece_off[] is their prefix sum): the
+// pieces of one read are sorted by their reference start and their column extents follow each other without gaps or overlaps, so the
+// pieces of a read that touch a tile are ONE run of its slots — found by a binary search (first piece whose extent ends behind the tile's
+// first position), a handful of steps forward to its end.  A lane takes one read of the tile's range: ~40 reads x (9 + 5) 16-byte loads
+// per tile instead of the ~15 000 a walk over the whole range takes when every read has 400 pieces.  (With several libraries the slots
+// are library-major and piece_off[] is not monotone: k_compact_tiles serves those.)
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_compact_reads(DevCfg c, const uint4* __restrict__ pieces4, const PieceRare* __restrict__ rare, const uint2* __restrict__ rng,
+                                                        const uint32_t* __restrict__ piece_off, int64_t ntiles, uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cmp_off,
+                                                        uint4* __restrict__ out4, PieceRare* __restrict__ out_rare, uint2* __restrict__ out_rng, unsigned long long* __restrict__ totals) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const uint2 r = rng[tile];
+    const int64_t p0 = (int64_t)c.pos0 + tile * TILE, p1 = p0 + TILE;
+    uint32_t run = COUNT ? 0u : cmp_off[tile];
+    const uint32_t first = run;
+    if (r.x < r.y) {
+        const uint32_t n = (uint32_t)c.n_reads;
+        // reads whose slots start at or before r.x (64-ary search: piece_off[] is non-decreasing); the last of them holds slot r.x
+        uint32_t lo_i = 0u, len = n;
+        while (len > 0u) {
+            const uint32_t stride = (len + 63u) >> 6;
+            uint32_t idx = lo_i + ((uint32_t)lane + 1u) * stride - 1u; const uint32_t last = lo_i + len - 1u;
+            if (idx > last) idx = last;
+            const uint32_t k = (uint32_t)__builtin_popcountll(__ballot(piece_off[idx] <= r.x));
+            const uint32_t nlo = lo_i + k * stride;
+            if (k == 64u || nlo > last) { lo_i = last + 1u; break; }
+            const uint32_t nlen = (stride < last + 1u - nlo ? stride : last + 1u - nlo);
+            lo_i = nlo; len = nlen - 1u;                                  // (the last element of block k is above r.x)
+        }
+        const uint32_t r_first = lo_i > 0u ? lo_i - 1u : 0u;
+        for (uint32_t rb = r_first; rb < n; rb += 64u) {
+            const uint32_t rd = rb + (uint32_t)lane;
+            uint32_t a = 0u, b = 0u;
+            if (rd < n) { a = piece_off[rd]; b = rd + 1u < n ? piece_off[rd + 1u] : (uint32_t)c.n_pieces; }
+            const bool inside = rd < n && a < r.y;
+            if (!__ballot(inside)) break;
+            if (a < r.x) a = r.x; if (b > r.y) b = r.y;
+            uint32_t m = a, nlive = 0u;
+            if (inside && a < b) {
+                // first slot of [a, b) whose extent ends behind p0
+                uint32_t lo = a, hi = b;
+                while (lo < hi) {
+                    const uint32_t mid = lo + ((hi - lo) >> 1);
+                    const uint4 h = pieces4[(size_t)mid * 3u];
+                    if ((int64_t)(int32_t)h.x + (int64_t)(int32_t)h.z > p0) hi = mid; else lo = mid + 1u;
+                }
+                m = lo;
+                for (uint32_t q = m; q < b; ++q) { const uint4 h = pieces4[(size_t)q * 3u]; if ((int64_t)(int32_t)h.x >= p1) break; ++nlive; }
+            }
+            uint32_t incl = nlive;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+            if (!COUNT) {
+                uint32_t at = run + incl - nlive;
+                for (uint32_t q = m; q < m + nlive; ++q, ++at) {
+                    const uint4 h0 = pieces4[(size_t)q * 3u];
+                    out4[(size_t)at * 3u] = h0; out4[(size_t)at * 3u + 1u] = pieces4[(size_t)q * 3u + 1u]; out4[(size_t)at * 3u + 2u] = pieces4[(size_t)q * 3u + 2u];
+                    if (piece_has_rare(h0.w >> 24)) out_rare[at] = rare[q];
+                }
+            }
+            run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+    }
+    if (lane == 0) {
+        if (COUNT) { cnt[tile] = run; atomicAdd(&totals[0], (unsigned long long)(r.y - r.x)); atomicAdd(&totals[1], (unsigned long long)run); }
+        else out_rng[tile] = make_uint2(first, run);
+    }
+}
+
 // ---------------------------------------------------------------- KB: pileup + BasicStat accumulation (the hot kernel)
 
 // |a - b| of two unsigned values in one instruction (LLVM does not form v_sad_u32 from max - min)
@@ -2069,7 +2140,7 @@ class HipBackend : public Backend {
         c.n_reads = s.n; c.table_len = test_knob(TK_NO_TABLE) ? 0 : s.modal_len();
         c.n_pieces = s.n_pieces; lib_base = s.lib_base; c.max_lqseq = s.max_lqseq;
         c.ibucket_shift = indel_bucket_shift(s.n_indel_ops, c.P, c.Lp);
-        if (const char* ib = test_knob(TK_IBUCKET_SHIFT)) { const int v = atoi(ib); if (v == 4 || v == 6) c.ibucket_shift = v; }   // (test knob: both supported sizes; anything else is ignored)
+        if (const char* ib = test_knob(TK_IBUCKET_SHIFT)) { const int v = atoi(ib); if (v == 2 || v == 4 || v == 6) c.ibucket_shift = v; }   // (test knob: the supported sizes; anything else is ignored)
         // test knobs (brc_host.h: TestKnob — the constant nullptr in the product): small K -> flushes, small limit -> PF_HUGE, forced dominant bucket -> third alleles
         choose_pack(s.max_lqseq, test_knob(TK_FLUSH_K) ? atoi(test_knob(TK_FLUSH_K)) : 0, test_knob(TK_PACK_LIM) ? atoi(test_knob(TK_PACK_LIM)) : 0, c.flush_k, c.pack_lim, c.pack_lim_lo, c.pack_shift);
         c.force_dom = test_knob(TK_FORCE_DOM) ? atoi(test_knob(TK_FORCE_DOM)) : -1;
@@ -2291,6 +2362,12 @@ class HipBackend : public Backend {
             HIPCHK(hipMemsetAsync(d_ctot.p, 0, 16, stream));
             HIPCHK(hipMemsetAsync((uint32_t*)d_ccnt.p + nslot, 0, 4, stream));
             const dim3 cg((unsigned)((ntiles + 3) / 4), (unsigned)Lp);
+            // (one library: read-wise, a binary search per read instead of a walk over the whole range; TK_COMPACT=2 keeps the walk)
+            const bool by_read = Lp == 1 && !(test_knob(TK_COMPACT) && atoi(test_knob(TK_COMPACT)) == 2);
+            if (by_read)
+                hipLaunchKernelGGL((k_compact_reads<true>), cg, dim3(256), 0, stream, c, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p, (const uint2*)d_rng.p, (const uint32_t*)d_pieceoff.p, ntiles,
+                                   (uint32_t*)d_ccnt.p, (const uint32_t*)nullptr, (uint4*)nullptr, (PieceRare*)nullptr, (uint2*)nullptr, (unsigned long long*)d_ctot.p);
+            else
             hipLaunchKernelGGL((k_compact_tiles<true>), cg, dim3(256), 0, stream, c, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p, (const uint2*)d_rng.p, ntiles,
                                (uint32_t*)d_ccnt.p, (const uint32_t*)nullptr, (uint4*)nullptr, (PieceRare*)nullptr, (uint2*)nullptr, (unsigned long long*)d_ctot.p);
             if ((rc = scan<OpSumU32, false>((const uint32_t*)d_ccnt.p, (uint32_t*)d_coff.p, (int64_t)nslot + 1))) return rc;
@@ -2302,6 +2379,10 @@ class HipBackend : public Backend {
                 compact_total = tot; compact_sized = true;
                 HIPCHK(d_cpieces.ensure(((size_t)compact_total + 4) * sizeof(Piece))); HIPCHK(d_crare.ensure(((size_t)compact_total + 2) * sizeof(PieceRare)));
             }
+            if (by_read)
+                hipLaunchKernelGGL((k_compact_reads<false>), cg, dim3(256), 0, stream, c, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p, (const uint2*)d_rng.p, (const uint32_t*)d_pieceoff.p, ntiles,
+                                   (uint32_t*)d_ccnt.p, (const uint32_t*)d_coff.p, (uint4*)d_cpieces.p, (PieceRare*)d_crare.p, (uint2*)d_crng.p, (unsigned long long*)d_ctot.p);
+            else
             hipLaunchKernelGGL((k_compact_tiles<false>), cg, dim3(256), 0, stream, c, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p, (const uint2*)d_rng.p, ntiles,
                                (uint32_t*)d_ccnt.p, (const uint32_t*)d_coff.p, (uint4*)d_cpieces.p, (PieceRare*)d_crare.p, (uint2*)d_crng.p, (unsigned long long*)d_ctot.p);
             kp_pieces = (const uint4*)d_cpieces.p; kp_rare = (const PieceRare*)d_crare.p; kp_rng = (const uint2*)d_crng.p;

@@ -140,7 +140,9 @@ void Staged::layout_pieces(int Lp, bool per_lib) {
     piece_off.n = (size_t)n;
     for (int64_t i = 0; i < n; ++i) {
         const int l = per_lib ? (int)lib.p[i] : 0;
-        if (!piece_cnt.p[i]) { piece_off.p[i] = 0; continue; }
+        // (a read without pieces takes the running slot of its library — of library 0 when it has none —: with one library piece_off[]
+        // is then the non-decreasing prefix sum the read-wise tile compaction searches, k_compact_reads)
+        if (!piece_cnt.p[i]) { piece_off.p[i] = (uint32_t)cur[(size_t)((l >= 0 && l < Lp) ? l : 0)]; continue; }
         piece_off.p[i] = (uint32_t)cur[(size_t)l]; cur[(size_t)l] += piece_cnt.p[i];
     }
     // event-byte rows, library-major as well: the pieces a (tile, library) wave stages one after the other then lie one

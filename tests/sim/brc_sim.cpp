@@ -43,7 +43,7 @@ class SimBackend : public Backend {
         c.n_reads = s.n; c.table_len = getenv("BRC_NO_TABLE") ? 0 : s.modal_len(); c.n_pieces = s.n_pieces; c.max_lqseq = s.max_lqseq;
         c.force_dom = getenv("BRC_FORCE_DOM") ? atoi(getenv("BRC_FORCE_DOM")) : -1;
         c.ibucket_shift = indel_bucket_shift(s.n_indel_ops, c.P, c.Lp);
-        if (const char* ib = getenv("BRC_IBUCKET_SHIFT")) { const int v = atoi(ib); if (v == 4 || v == 6) c.ibucket_shift = v; }   // (as the HIP backend: the two supported sizes)
+        if (const char* ib = getenv("BRC_IBUCKET_SHIFT")) { const int v = atoi(ib); if (v == 2 || v == 4 || v == 6) c.ibucket_shift = v; }   // (as the HIP backend: the supported sizes)
         choose_pack(s.max_lqseq, getenv("BRC_FLUSH_K") ? atoi(getenv("BRC_FLUSH_K")) : 0, getenv("BRC_PACK_LIM") ? atoi(getenv("BRC_PACK_LIM")) : 0, c.flush_k, c.pack_lim, c.pack_lim_lo, c.pack_shift);
         tq.assign((size_t)TABLE_MAX + 2, 0.0f); te.assign((size_t)TABLE_MAX + 2, 0.0);
         for (int k = 0; k <= c.table_len; ++k) { tq[(size_t)k] = (float)k / (float)c.table_len; te[(size_t)k] = 1.0 - (double)tq[(size_t)k]; }

@@ -336,10 +336,10 @@ def test_hip_device_text_equals_oracle_on_every_fuzz_family(dev_lib, oracle_lib,
         assert got == want, clear
 
 
-@pytest.mark.parametrize("shift", ["4", "6", "0"])
+@pytest.mark.parametrize("shift", ["2", "4", "6", "0"])
 def test_hip_deep_indel_key_equals_oracle(knob_lib, oracle_lib, monkeypatch, shift):
     """k_indel_reduce with hundreds (and, at 6000 reads, thousands) of events on one (position, library) key; every bucket size
-    the engine chooses from (16 / 64 positions) and single-position buckets."""
+    the engine chooses from (4 / 16 / 64 positions; "0": an unsupported value, ignored)."""
     monkeypatch.setenv("BRC_IBUCKET_SHIFT", shift)
     rng = np.random.default_rng(41)
     ref = synth.make_ref(rng, 600)
@@ -689,3 +689,15 @@ def test_hip_reads_with_an_operator_every_few_bases(dev_lib, knob_lib, oracle_li
     t2, r2 = parity.run_engine(knob_lib, arrs, [(500, 20_000)], ref=ref, **opts)
     t3, r3 = parity.run_engine(oracle_lib, arrs, [(500, 20_000)], ref=ref, **opts)
     parity.assert_results_equal(r2[0], r3[0], "dense operators, not compacted"); assert t2 == t3
+    # compacted by the walk over whole ranges (k_compact_tiles: what several libraries use) instead of read-wise (k_compact_reads)
+    monkeypatch.setenv("BRC_COMPACT_TILES", "2")
+    t4, r4 = parity.run_engine(knob_lib, arrs, [(500, 20_000)], ref=ref, **opts)
+    parity.assert_results_equal(r4[0], r3[0], "dense operators, compacted by the range walk"); assert t4 == t3
+    # several libraries (library-major slots: the range walk) with library-less reads among them
+    monkeypatch.delenv("BRC_COMPACT_TILES")
+    lib2 = dict(arrs); rng = np.random.default_rng(5)
+    lib2["lib"] = np.where(rng.random(len(arrs["pos"])) < 0.03, -1, rng.integers(0, 3, len(arrs["pos"]))).astype(np.int16)
+    parity.compare_libs(dev_lib, oracle_lib, lib2, [(500, 20_000)], ref=ref, lib_names=["libA", "libB", "libC"], check_warn=False, per_lib=True, **opts)
+    # one library with -p and library-less reads (their slots are the running ones: piece_off[] stays non-decreasing for the read-wise search)
+    lib1 = dict(arrs); lib1["lib"] = np.where(rng.random(len(arrs["pos"])) < 0.1, -1, 0).astype(np.int16)
+    parity.compare_libs(dev_lib, oracle_lib, lib1, [(500, 20_000)], ref=ref, lib_names=["libA"], check_warn=False, per_lib=True, **opts)
