@@ -1143,22 +1143,33 @@ __global__ __launch_bounds__(256) void k_compact_tiles(DevCfg c, const uint4* __
 }
 
 // The same compaction READ-WISE (one library: the slots of consecutive reads are consecutive, piece_off[] is their prefix sum): the
-// pieces of one read are sorted by their reference start and their column extents follow each other without gaps or overlaps, so the
-// pieces of a read that touch a tile are ONE run of its slots — found by a binary search (first piece whose extent ends behind the tile's
-// first position), a handful of steps forward to its end.  A lane takes one read of the tile's range: ~40 reads x (9 + 5) 16-byte loads
-// per tile instead of the ~15 000 a walk over the whole range takes when every read has 400 pieces.  (With several libraries the slots
-// are library-major and piece_off[] is not monotone: k_compact_tiles serves those.)
-template <bool COUNT>
+// pieces of one read are sorted by their reference start and their column extents follow each other without gaps or overlaps (piece q
+// starts where piece q - 1 of its read ends, a read's first piece at the read's position), so the pieces of a read that touch a tile are
+// ONE run of its slots — found by a binary search over keyreach[] = {read position, end of the piece's extent} (8 bytes per piece: the
+// last levels of a search share a cache line; the 48-byte records are read only to be copied), a handful of steps forward to the run's
+// end.  A lane takes one read of the tile's range: ~40 reads x ~14 probes per tile instead of the ~15 000 records a walk over the whole
+// range reads when every read has 400 pieces.  The tiles' sizes come from a pass over the PIECES (k_count_piece_tiles: every piece adds
+// one to each tile its extent meets — an upper bound where announced windows narrowed a tile's range), so the search runs once.
+// (With several libraries the slots are library-major and piece_off[] is not monotone: k_compact_tiles serves those.)
+__global__ __launch_bounds__(256) void k_count_piece_tiles(DevCfg c, const uint4* __restrict__ pieces4, int64_t n_pieces, uint32_t* __restrict__ cnt) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_pieces) return;
+    const uint4 h = pieces4[(size_t)q * 3u];                                                 // {rs, len, ext, tp|flags}
+    int64_t k0 = (int64_t)(int32_t)h.x - c.pos0, k1 = k0 + (int64_t)(int32_t)h.z - 1;
+    if (k1 < 0 || k0 >= c.P || k1 < k0) return;
+    if (k0 < 0) k0 = 0; if (k1 > c.P - 1) k1 = c.P - 1;
+    for (int64_t t = k0 >> 6; t <= (k1 >> 6); ++t) atomicAdd(&cnt[t], 1u);
+}
 __global__ __launch_bounds__(256) void k_compact_reads(DevCfg c, const uint4* __restrict__ pieces4, const PieceRare* __restrict__ rare, const uint2* __restrict__ rng,
-                                                        const uint32_t* __restrict__ piece_off, int64_t ntiles, uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cmp_off,
+                                                        const uint32_t* __restrict__ piece_off, const int2* __restrict__ keyreach, int64_t ntiles, const uint32_t* __restrict__ cmp_off,
                                                         uint4* __restrict__ out4, PieceRare* __restrict__ out_rare, uint2* __restrict__ out_rng, unsigned long long* __restrict__ totals) {
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile >= ntiles) return;
     const uint2 r = rng[tile];
     const int64_t p0 = (int64_t)c.pos0 + tile * TILE, p1 = p0 + TILE;
-    uint32_t run = COUNT ? 0u : cmp_off[tile];
-    const uint32_t first = run;
+    const uint32_t first = cmp_off[tile];
+    uint32_t run = first;
     if (r.x < r.y) {
         const uint32_t n = (uint32_t)c.n_reads;
         // reads whose slots start at or before r.x (64-ary search: piece_off[] is non-decreasing); the last of them holds slot r.x
@@ -1176,40 +1187,41 @@ __global__ __launch_bounds__(256) void k_compact_reads(DevCfg c, const uint4* __
         const uint32_t r_first = lo_i > 0u ? lo_i - 1u : 0u;
         for (uint32_t rb = r_first; rb < n; rb += 64u) {
             const uint32_t rd = rb + (uint32_t)lane;
-            uint32_t a = 0u, b = 0u;
-            if (rd < n) { a = piece_off[rd]; b = rd + 1u < n ? piece_off[rd + 1u] : (uint32_t)c.n_pieces; }
-            const bool inside = rd < n && a < r.y;
+            uint32_t a0 = 0u, b = 0u;
+            if (rd < n) { a0 = piece_off[rd]; b = rd + 1u < n ? piece_off[rd + 1u] : (uint32_t)c.n_pieces; }
+            const bool inside = rd < n && a0 < r.y;
             if (!__ballot(inside)) break;
-            if (a < r.x) a = r.x; if (b > r.y) b = r.y;
+            uint32_t a = a0 < r.x ? r.x : a0; if (b > r.y) b = r.y;
             uint32_t m = a, nlive = 0u;
             if (inside && a < b) {
                 // first slot of [a, b) whose extent ends behind p0
                 uint32_t lo = a, hi = b;
                 while (lo < hi) {
                     const uint32_t mid = lo + ((hi - lo) >> 1);
-                    const uint4 h = pieces4[(size_t)mid * 3u];
-                    if ((int64_t)(int32_t)h.x + (int64_t)(int32_t)h.z > p0) hi = mid; else lo = mid + 1u;
+                    if ((int64_t)keyreach[mid].y > p0) hi = mid; else lo = mid + 1u;
                 }
                 m = lo;
-                for (uint32_t q = m; q < b; ++q) { const uint4 h = pieces4[(size_t)q * 3u]; if ((int64_t)(int32_t)h.x >= p1) break; ++nlive; }
+                if (m < b) {
+                    // its start: the read's position for the read's first slot, the end of the slot before it otherwise
+                    int64_t rs = m == a0 ? (int64_t)keyreach[m].x : (int64_t)keyreach[m - 1u].y;
+                    for (uint32_t q = m; q < b && rs < p1; ++q) { ++nlive; rs = (int64_t)keyreach[q].y; }
+                }
             }
             uint32_t incl = nlive;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
-            if (!COUNT) {
-                uint32_t at = run + incl - nlive;
-                for (uint32_t q = m; q < m + nlive; ++q, ++at) {
-                    const uint4 h0 = pieces4[(size_t)q * 3u];
-                    out4[(size_t)at * 3u] = h0; out4[(size_t)at * 3u + 1u] = pieces4[(size_t)q * 3u + 1u]; out4[(size_t)at * 3u + 2u] = pieces4[(size_t)q * 3u + 2u];
-                    if (piece_has_rare(h0.w >> 24)) out_rare[at] = rare[q];
-                }
+            uint32_t at = run + incl - nlive;
+            for (uint32_t q = m; q < m + nlive; ++q, ++at) {
+                const uint4 h0 = pieces4[(size_t)q * 3u];
+                out4[(size_t)at * 3u] = h0; out4[(size_t)at * 3u + 1u] = pieces4[(size_t)q * 3u + 1u]; out4[(size_t)at * 3u + 2u] = pieces4[(size_t)q * 3u + 2u];
+                if (piece_has_rare(h0.w >> 24)) out_rare[at] = rare[q];
             }
             run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
     }
     if (lane == 0) {
-        if (COUNT) { cnt[tile] = run; atomicAdd(&totals[0], (unsigned long long)(r.y - r.x)); atomicAdd(&totals[1], (unsigned long long)run); }
-        else out_rng[tile] = make_uint2(first, run);
+        out_rng[tile] = make_uint2(first, run);
+        atomicAdd(&totals[0], (unsigned long long)(r.y - r.x)); atomicAdd(&totals[1], (unsigned long long)(run - first));
     }
 }
 
@@ -2364,13 +2376,15 @@ class HipBackend : public Backend {
             const dim3 cg((unsigned)((ntiles + 3) / 4), (unsigned)Lp);
             // (one library: read-wise, a binary search per read instead of a walk over the whole range; TK_COMPACT=2 keeps the walk)
             const bool by_read = Lp == 1 && !(test_knob(TK_COMPACT) && atoi(test_knob(TK_COMPACT)) == 2);
-            if (by_read)
-                hipLaunchKernelGGL((k_compact_reads<true>), cg, dim3(256), 0, stream, c, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p, (const uint2*)d_rng.p, (const uint32_t*)d_pieceoff.p, ntiles,
-                                   (uint32_t*)d_ccnt.p, (const uint32_t*)nullptr, (uint4*)nullptr, (PieceRare*)nullptr, (uint2*)nullptr, (unsigned long long*)d_ctot.p);
+            if (by_read) {
+                HIPCHK(hipMemsetAsync(d_ccnt.p, 0, nslot * 4, stream));
+                hipLaunchKernelGGL(k_count_piece_tiles, dim3((unsigned)((np_all + 255) / 256)), dim3(256), 0, stream, c, (const uint4*)d_pieces.p, np_all, (uint32_t*)d_ccnt.p);
+            }
             else
             hipLaunchKernelGGL((k_compact_tiles<true>), cg, dim3(256), 0, stream, c, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p, (const uint2*)d_rng.p, ntiles,
                                (uint32_t*)d_ccnt.p, (const uint32_t*)nullptr, (uint4*)nullptr, (PieceRare*)nullptr, (uint2*)nullptr, (unsigned long long*)d_ctot.p);
             if ((rc = scan<OpSumU32, false>((const uint32_t*)d_ccnt.p, (uint32_t*)d_coff.p, (int64_t)nslot + 1))) return rc;
+            const bool first_pass = !compact_sized;
             if (!compact_sized) {
                 uint32_t tot = 0;
                 HIPCHK(hipMemcpyAsync(&tot, (const uint32_t*)d_coff.p + nslot, 4, hipMemcpyDeviceToHost, stream));
@@ -2380,11 +2394,15 @@ class HipBackend : public Backend {
                 HIPCHK(d_cpieces.ensure(((size_t)compact_total + 4) * sizeof(Piece))); HIPCHK(d_crare.ensure(((size_t)compact_total + 2) * sizeof(PieceRare)));
             }
             if (by_read)
-                hipLaunchKernelGGL((k_compact_reads<false>), cg, dim3(256), 0, stream, c, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p, (const uint2*)d_rng.p, (const uint32_t*)d_pieceoff.p, ntiles,
-                                   (uint32_t*)d_ccnt.p, (const uint32_t*)d_coff.p, (uint4*)d_cpieces.p, (PieceRare*)d_crare.p, (uint2*)d_crng.p, (unsigned long long*)d_ctot.p);
+                hipLaunchKernelGGL(k_compact_reads, cg, dim3(256), 0, stream, c, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p, (const uint2*)d_rng.p, (const uint32_t*)d_pieceoff.p, (const int2*)d_keyreach.p, ntiles,
+                                   (const uint32_t*)d_coff.p, (uint4*)d_cpieces.p, (PieceRare*)d_crare.p, (uint2*)d_crng.p, (unsigned long long*)d_ctot.p);
             else
             hipLaunchKernelGGL((k_compact_tiles<false>), cg, dim3(256), 0, stream, c, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p, (const uint2*)d_rng.p, ntiles,
                                (uint32_t*)d_ccnt.p, (const uint32_t*)d_coff.p, (uint4*)d_cpieces.p, (PieceRare*)d_crare.p, (uint2*)d_crng.p, (unsigned long long*)d_ctot.p);
+            if (by_read && first_pass) {   // (the read-wise copy adds up the piece-steps itself: brc_region_piece_steps reads them after the region's first pass)
+                HIPCHK(hipMemcpyAsync(h_steps, d_ctot.p, 16, hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+            }
             kp_pieces = (const uint4*)d_cpieces.p; kp_rare = (const PieceRare*)d_crare.p; kp_rng = (const uint2*)d_crng.p;
 #ifdef BRC_CHECKED
             {   // (the compacted stream exists now: its extents replace K1's for the pileup's sites; the fault count so far is kept)
