@@ -1168,8 +1168,10 @@ __global__ __launch_bounds__(256) void k_compact_reads(DevCfg c, const uint4* __
     if (tile >= ntiles) return;
     const uint2 r = rng[tile];
     const int64_t p0 = (int64_t)c.pos0 + tile * TILE, p1 = p0 + TILE;
-    const uint32_t first = cmp_off[tile];
+    const uint32_t first = cmp_off[tile], limit = cmp_off[tile + 1];
     uint32_t run = first;
+    __shared__ uint32_t src_all[4][64];
+    uint32_t* const src = src_all[threadIdx.x >> 6];
     if (r.x < r.y) {
         const uint32_t n = (uint32_t)c.n_reads;
         // reads whose slots start at or before r.x (64-ary search: piece_off[] is non-decreasing); the last of them holds slot r.x
@@ -1210,13 +1212,23 @@ __global__ __launch_bounds__(256) void k_compact_reads(DevCfg c, const uint4* __
             uint32_t incl = nlive;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
-            uint32_t at = run + incl - nlive;
-            for (uint32_t q = m; q < m + nlive; ++q, ++at) {
-                const uint4 h0 = pieces4[(size_t)q * 3u];
-                out4[(size_t)at * 3u] = h0; out4[(size_t)at * 3u + 1u] = pieces4[(size_t)q * 3u + 1u]; out4[(size_t)at * 3u + 2u] = pieces4[(size_t)q * 3u + 2u];
-                if (piece_has_rare(h0.w >> 24)) out_rare[at] = rare[q];
+            // copy: consecutive lanes take consecutive OUTPUT slots (64 records = 3 KB of contiguous stores per round; the sources are
+            // runs of a read's consecutive slots) — the owners publish the source slot of every output of the round through LDS
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63), excl = incl - nlive;
+            for (uint32_t j0 = 0u; j0 < total; j0 += 64u) {
+                for (uint32_t i = 0u; i < nlive; ++i) { const uint32_t o = excl + i - j0; if (o < 64u) src[o] = m + i; }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                const uint32_t at = run + j0 + (uint32_t)lane;
+                if (j0 + (uint32_t)lane < total && at < limit) {            // (limit: the tile's block, sized by k_count_piece_tiles from the same extents)
+                    const uint32_t q = src[lane];
+                    const uint4 h0 = pieces4[(size_t)q * 3u];
+                    out4[(size_t)at * 3u] = h0; out4[(size_t)at * 3u + 1u] = pieces4[(size_t)q * 3u + 1u]; out4[(size_t)at * 3u + 2u] = pieces4[(size_t)q * 3u + 2u];
+                    if (piece_has_rare(h0.w >> 24)) out_rare[at] = rare[q];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             }
-            run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            run += total;
+            if (run > limit) run = limit;
         }
     }
     if (lane == 0) {
