@@ -1167,9 +1167,10 @@ __global__ __launch_bounds__(256) void k_compact_reads(DevCfg c, const uint4* __
     const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile >= ntiles) return;
     const uint2 r = rng[tile];
-    const int64_t p0 = (int64_t)c.pos0 + tile * TILE, p1 = p0 + TILE;
+    // (the region's last tile ends with the region: k_count_piece_tiles does not count a piece that starts behind the last position)
+    const int64_t p0 = (int64_t)c.pos0 + tile * TILE, p1 = p0 + TILE < (int64_t)c.pos0 + c.P ? p0 + TILE : (int64_t)c.pos0 + c.P;
     const uint32_t first = cmp_off[tile], limit = cmp_off[tile + 1];
-    uint32_t run = first;
+    uint32_t run = first; bool over = false;       // over: more live pieces than the tile's block holds (never: the host fails the call if it happens)
     __shared__ uint32_t src_all[4][64];
     uint32_t* const src = src_all[threadIdx.x >> 6];
     if (r.x < r.y) {
@@ -1228,12 +1229,13 @@ __global__ __launch_bounds__(256) void k_compact_reads(DevCfg c, const uint4* __
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             }
             run += total;
-            if (run > limit) run = limit;
+            if (run > limit) { over = true; run = limit; }
         }
     }
     if (lane == 0) {
         out_rng[tile] = make_uint2(first, run);
         atomicAdd(&totals[0], (unsigned long long)(r.y - r.x)); atomicAdd(&totals[1], (unsigned long long)(run - first));
+        if (over) atomicAdd(&totals[2], 1ull);
     }
 }
 
@@ -2026,7 +2028,7 @@ class HipBackend : public Backend {
     bool compact_on = false; uint64_t compact_total = 0; bool compact_sized = false;
     bool wave_on = false;                      // this region's reads with more than two M operators go to k_annotate_wave
     enum { WAVE_FORM_BLOCKS = 768 };           // its fixed grid: 3 blocks of 4 waves per CU (48 KB of LDS each)
-    unsigned long long h_steps[2] = {0, 0};   // piece-steps of the last pass: what the tile ranges hold / what k_pileup2 walked (brc_region_piece_steps)
+    unsigned long long h_steps[3] = {0, 0, 0};   // piece-steps of the last pass: what the tile ranges hold / what k_pileup2 walked (brc_region_piece_steps)
     DBuf d_ccnt, d_coff, d_cpieces, d_crare, d_crng, d_ctot;
     // host result buffers (pinned)
     HBuf<uint32_t> h_ncol, h_depth, h_slotid, h_si, h_unavail; HBuf<float> h_sf; HBuf<IndelOut> h_iout; HBuf<XEv> h_xev;
@@ -2178,7 +2180,7 @@ class HipBackend : public Backend {
         // reads with many operators: compact every tile's piece range before the pileup (k_compact_tiles); TK_COMPACT: 1 forces it, 0 forbids
         compact_on = s.n > 0 && s.n_pieces > (int64_t)COMPACT_PIECES_PER_READ * s.n;
         if (const char* ck = test_knob(TK_COMPACT)) compact_on = atoi(ck) != 0 && s.n_pieces > 0;
-        compact_sized = false; compact_total = 0; h_steps[0] = h_steps[1] = 0;
+        compact_sized = false; compact_total = 0; h_steps[0] = h_steps[1] = h_steps[2] = 0;
         const size_t n = (size_t)s.n;
         int rc;
         if ((rc = up(d_pos, s.pos, n)) || (rc = up(d_flag, s.flag, n)) || (rc = up(d_mapq, s.mapq, n)) || (rc = up(d_lib, s.lib, n)) ||
@@ -2382,8 +2384,8 @@ class HipBackend : public Backend {
         if (compact_on && ntiles > 0 && np_all > 0) {
             // count the live pieces of every (tile, library), scan, (first pass of the region: size the compacted stream — one wait), copy
             const size_t nslot = (size_t)ntiles * (size_t)Lp;
-            HIPCHK(d_ccnt.ensure((nslot + 2) * 4)); HIPCHK(d_coff.ensure((nslot + 2) * 4)); HIPCHK(d_crng.ensure((nslot + 1) * sizeof(uint2))); HIPCHK(d_ctot.ensure(16));
-            HIPCHK(hipMemsetAsync(d_ctot.p, 0, 16, stream));
+            HIPCHK(d_ccnt.ensure((nslot + 2) * 4)); HIPCHK(d_coff.ensure((nslot + 2) * 4)); HIPCHK(d_crng.ensure((nslot + 1) * sizeof(uint2))); HIPCHK(d_ctot.ensure(24));
+            HIPCHK(hipMemsetAsync(d_ctot.p, 0, 24, stream));
             HIPCHK(hipMemsetAsync((uint32_t*)d_ccnt.p + nslot, 0, 4, stream));
             const dim3 cg((unsigned)((ntiles + 3) / 4), (unsigned)Lp);
             // (one library: read-wise, a binary search per read instead of a walk over the whole range; TK_COMPACT=2 keeps the walk)
@@ -2412,8 +2414,9 @@ class HipBackend : public Backend {
             hipLaunchKernelGGL((k_compact_tiles<false>), cg, dim3(256), 0, stream, c, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p, (const uint2*)d_rng.p, ntiles,
                                (uint32_t*)d_ccnt.p, (const uint32_t*)d_coff.p, (uint4*)d_cpieces.p, (PieceRare*)d_crare.p, (uint2*)d_crng.p, (unsigned long long*)d_ctot.p);
             if (by_read && first_pass) {   // (the read-wise copy adds up the piece-steps itself: brc_region_piece_steps reads them after the region's first pass)
-                HIPCHK(hipMemcpyAsync(h_steps, d_ctot.p, 16, hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipMemcpyAsync(h_steps, d_ctot.p, 24, hipMemcpyDeviceToHost, stream));
                 HIPCHK(hipStreamSynchronize(stream));
+                if (h_steps[2]) { err = "tile compaction: a tile holds more live read segments than the pass over the segments counted for it"; return BRC_E_HIP; }
             }
             kp_pieces = (const uint4*)d_cpieces.p; kp_rare = (const PieceRare*)d_crare.p; kp_rng = (const uint2*)d_crng.p;
 #ifdef BRC_CHECKED

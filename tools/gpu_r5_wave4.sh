@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5: coalesced copy of the read-wise compaction — parity, the `ont` model validated whole, then the extreme fuzz on the bounds-checked
-# library at HEAD (wave-form annotator, tile compaction and 4-position indel buckets included)
+# library
 cd "$(dirname "$0")/.." && mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_checked_build.py --maxfail 6 -q -m gpu -k "operator_every or compacted or wave_form or extreme_scenarios or announced" 2>&1 | tail -6
@@ -14,4 +14,4 @@ try:
 except Exception as ex:
     print("no line:", ex)
 PY
-timeout ${FUZZ_TIMEOUT:-900} python tools/fuzz/extreme.py --lib bam_readcount_amd/csrc/libbrc_hip_checked.so --first ${FUZZ_FIRST:-9000} --count ${FUZZ_COUNT:-400} > gpurun_out/r05_extreme_fuzz_checked_build_3.log 2>&1; echo "fuzz rc $?"; tail -5 gpurun_out/r05_extreme_fuzz_checked_build_3.log
+
