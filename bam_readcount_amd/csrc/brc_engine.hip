@@ -45,6 +45,7 @@ struct Counters {
     unsigned long long n_events, n_positions, w_sm, w_nm, w_lib;
     unsigned int n_indel_slots, n_xev;   // n_xev: third-allele events in the compacted list
     unsigned int xev_max, n_wave_reads;  // fullest sub-list's cursor (above its capacity: grow and compute again); reads K1 left to k_annotate_wave
+    unsigned int n_wave_big, pad2_;      // ... those of them with more than AW_MCAP M operators (the one-wave-per-workgroup instantiation)
 };
 
 // Profiling ablations that switch parts of the kernels off (wrong results, timing only) exist only in experiment builds
@@ -164,7 +165,8 @@ __global__ __launch_bounds__(256) void k_refcode(const char* __restrict__ ref, u
 //                          walk + neighbour links (DPP lane shifts); sums are accumulated per read in LDS;
 //   phase C (lane = read)  the quality != 2 scan from the read's 3' end (:201-238; 8 bases per load, as a rule one load),
 //                          three-prime / Q2 logic, DRead + float constants, the pieces, the indel events.
-enum { AW_MCAP = 1024 };             // M operators of a read the wave form (k_annotate_wave, below) holds in LDS
+enum { AW_MCAP = 1024,               // M operators of a read the wave form (k_annotate_wave, below) holds in LDS: four waves per workgroup ...
+       AW_MCAP_BIG = 5120 };         // ... and one wave per workgroup (60 KB: reads of ~150 kb with an operator every 15 bases)
 struct AnnPar { uint4 a, b, c; };    // a = {L, qrel, srel, brow.lo}  b = {S, m1lo, m1hi, d1}  c = {m2lo, m2hi, d2, brow.hi}
 
 __device__ __forceinline__ uint32_t nzb7(uint32_t x) { return x + 0x7f7f7f7fu; }   // bytes <= 0x7f: bit 7 of a byte <=> byte != 0
@@ -604,15 +606,18 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
 // K1 picks the reads (phase A knows everything the choice needs) and appends them to `wave_list`; this kernel is a fixed grid
 // whose waves take list entries round robin — no host round trip for the count.  A read with a NUL reference character under
 // an M base (the annotator's break, :151) is re-annotated by annotate_read() on one lane; pieces and indel events do not
-// depend on it.  Eligible: mapped-and-pushed reads with bases, inside the reference, 3..AW_MCAP M operators, no P / = / X
+// depend on it.  Eligible: mapped-and-pushed reads with bases, inside the reference, 3..AW_MCAP_BIG M operators (two instantiations:
+// up to AW_MCAP with four waves per workgroup, above it one wave per workgroup with a list five times as long), no P / = / X
 // operator and no empty M operator (those keep the serial path, as do reads with more M operators than the list holds).
 __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 // Which reads take the wave form: lane = read.  K1 itself is not touched by the choice — a changed K1 is another register allocation, and
 // its 80-register budget holds by a hair (tests/test_abi.py) —: it is launched with a COPY of the operator counts in which the chosen
 // reads have none, and for a read without operators K1 writes nothing at all (no record, no pieces, no indel slots, no event bytes).
-__global__ __launch_bounds__(256) void k_pick_wave(DevCfg c, DevIn in, uint32_t* __restrict__ n_cigar_k1, uint32_t* __restrict__ wave_list, unsigned int* __restrict__ wave_n) {
+// (wave_list: the reads of the four-wave instantiation from the front, those of the one-wave instantiation from the back, list_cap - 1 downwards)
+__global__ __launch_bounds__(256) void k_pick_wave(DevCfg c, DevIn in, uint32_t* __restrict__ n_cigar_k1, uint32_t* __restrict__ wave_list, uint32_t list_cap,
+                                                   unsigned int* __restrict__ wave_n, unsigned int* __restrict__ wave_n_big) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool pick = false; uint32_t nc_me = 0u;
+    bool pick = false, big = false; uint32_t nc_me = 0u;
     if (i < c.n_reads) {
         const uint32_t nc = in.n_cigar[i]; nc_me = nc;
         const int32_t pos = in.pos[i], L = in.l_qseq[i];
@@ -625,16 +630,23 @@ __global__ __launch_bounds__(256) void k_pick_wave(DevCfg c, DevIn in, uint32_t*
                 if (op == CMATCH) ++n_m;
                 if (is_refop(op)) rlen += len;
             }
-            pick = !irregular && n_m > 2u && n_m <= (uint32_t)AW_MCAP && (int64_t)pos + rlen <= c.ref_len && rlen < 0x7fffffffll;
+            pick = !irregular && n_m > 2u && n_m <= (uint32_t)AW_MCAP_BIG && (int64_t)pos + rlen <= c.ref_len && rlen < 0x7fffffffll;
+            big = pick && n_m > (uint32_t)AW_MCAP;
         }
     }
-    const unsigned long long pm = __ballot(pick);
+    const int lane = threadIdx.x & 63;
+    const unsigned long long pm = __ballot(pick && !big), pb = __ballot(big);
     if (pm) {
-        const int lane = threadIdx.x & 63;
         uint32_t base = 0u;
         if (lane == __builtin_ctzll(pm)) base = atomicAdd(wave_n, (unsigned int)__builtin_popcountll(pm));
         base = (uint32_t)__shfl((int)base, __builtin_ctzll(pm), 64);
-        if (pick) wave_list[base + mbcnt64(pm)] = (uint32_t)i;
+        if (pick && !big) wave_list[base + mbcnt64(pm)] = (uint32_t)i;
+    }
+    if (pb) {
+        uint32_t base = 0u;
+        if (lane == __builtin_ctzll(pb)) base = atomicAdd(wave_n_big, (unsigned int)__builtin_popcountll(pb));
+        base = (uint32_t)__shfl((int)base, __builtin_ctzll(pb), 64);
+        if (big) wave_list[list_cap - 1u - (base + mbcnt64(pb))] = (uint32_t)i;
     }
     if (i < c.n_reads) n_cigar_k1[i] = pick ? 0u : nc_me;
 }
@@ -643,23 +655,23 @@ __device__ __forceinline__ int32_t wave_incl_sum(int32_t v, int lane) {
     for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(v, d, 64); if (lane >= d) v += o; }
     return v;
 }
-template <int SH>
-__global__ __launch_bounds__(256) void k_annotate_wave(DevCfg c, DevIn in, const uint32_t* __restrict__ wave_list, const unsigned int* __restrict__ wave_n,
+template <int SH, int MCAP, int WAVES>      // MCAP: M operators the LDS list holds; WAVES per workgroup (AW_MCAP x 4, or AW_MCAP_BIG x 1); list_step: +1 / -1 (the big reads are listed from the back)
+__global__ __launch_bounds__(WAVES * 64) void k_annotate_wave(DevCfg c, DevIn in, const uint32_t* __restrict__ wave_list, int list_step, const unsigned int* __restrict__ wave_n,
                                                        DRead* __restrict__ reads, const uint32_t* __restrict__ piece_off,
                                                        Piece* __restrict__ pieces, PieceRare* __restrict__ rare, int2* __restrict__ keyreach,
                                                        uint8_t* __restrict__ eb, uint16_t* __restrict__ bqw, IndelEv* __restrict__ ev_raw, uint32_t* __restrict__ bucket_cnt,
                                                        const uint8_t* __restrict__ refcode, const uint16_t* __restrict__ wanted) {
     c.pack_shift = SH;
-    struct WaveLds { int32_t y[AW_MCAP]; int32_t x[AW_MCAP]; uint32_t lw[AW_MCAP]; DRead r; uint32_t wide; };
-    __shared__ WaveLds lds_all[4];
+    struct WaveLds { int32_t y[MCAP]; int32_t x[MCAP]; uint32_t lw[MCAP]; DRead r; uint32_t wide; };
+    __shared__ WaveLds lds_all[WAVES];
     const int lane = threadIdx.x & 63;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     WaveLds& W = lds_all[wv];
     const uint32_t n_list = *wave_n;
-    const uint32_t nwaves = gridDim.x * 4u;
+    const uint32_t nwaves = gridDim.x * (uint32_t)WAVES;
     const int64_t ref_n = c.ref_hi - c.ref_lo;
-    for (uint32_t li = blockIdx.x * 4u + wv; li < n_list; li += nwaves) {
-        const int64_t my = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)wave_list[li]);
+    for (uint32_t li = blockIdx.x * (uint32_t)WAVES + wv; li < n_list; li += nwaves) {
+        const int64_t my = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)wave_list[(int64_t)list_step * (int64_t)li]);
         const int32_t pos = __builtin_amdgcn_readfirstlane(in.pos[my]);
         const uint32_t flag = (uint32_t)__builtin_amdgcn_readfirstlane((int)in.flag[my]);
         const int32_t L = __builtin_amdgcn_readfirstlane(in.l_qseq[my]);
@@ -694,8 +706,8 @@ __global__ __launch_bounds__(256) void k_annotate_wave(DevCfg c, DevIn in, const
             if (isI || isS) i_part += (uint32_t)len;
             const unsigned long long mb = __ballot(isM);
             if (isM) {
-                const uint32_t mr = mc + mbcnt64(mb);                                   // (K1 sends only reads with at most AW_MCAP M operators)
-                if (mr < (uint32_t)AW_MCAP) { W.y[mr] = y; W.x[mr] = x; W.lw[mr] = (uint32_t)len | (((c1 & 0xfu) == CINS && (c1 >> 4) > 0u) ? 0x80000000u : 0u); }
+                const uint32_t mr = mc + mbcnt64(mb);                                   // (k_pick_wave lists only reads with at most MCAP M operators)
+                if (mr < (uint32_t)MCAP) { W.y[mr] = y; W.x[mr] = x; W.lw[mr] = (uint32_t)len | (((c1 & 0xfu) == CINS && (c1 >> 4) > 0u) ? 0x80000000u : 0u); }
             }
             mc += (uint32_t)__builtin_popcountll(mb);
             n_idp += (uint32_t)__builtin_popcountll(__ballot(isI || isD));
@@ -726,7 +738,7 @@ __global__ __launch_bounds__(256) void k_annotate_wave(DevCfg c, DevIn in, const
         left_clip = __builtin_amdgcn_readfirstlane(left_clip);
         const int32_t clipped = L - (int32_t)s_tot;
         const int32_t right_clip = L - ((int32_t)s_tot - left_clip);
-        const uint32_t nm_ops = mc < (uint32_t)AW_MCAP ? mc : (uint32_t)AW_MCAP;
+        const uint32_t nm_ops = mc < (uint32_t)MCAP ? mc : (uint32_t)MCAP;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                       // the list is read by other lanes below
 
         // ---- pass 2: lane = base
@@ -2027,7 +2039,9 @@ class HipBackend : public Backend {
     enum { COMPACT_PIECES_PER_READ = 12 };
     bool compact_on = false; uint64_t compact_total = 0; bool compact_sized = false;
     bool wave_on = false;                      // this region's reads with more than two M operators go to k_annotate_wave
-    enum { WAVE_FORM_BLOCKS = 768 };           // its fixed grid: 3 blocks of 4 waves per CU (48 KB of LDS each)
+    bool wave_big = false;                     // ... and some may have more than AW_MCAP M operators (a read with more than 2 AW_MCAP operators exists)
+    enum { WAVE_FORM_BLOCKS = 768,             // its fixed grid: 3 blocks of 4 waves per CU (48 KB of LDS each)
+           WAVE_FORM_BLOCKS_BIG = 512 };       // the one-wave instantiation: 2 blocks per CU (60 KB of LDS each)
     unsigned long long h_steps[3] = {0, 0, 0};   // piece-steps of the last pass: what the tile ranges hold / what k_pileup2 walked (brc_region_piece_steps)
     DBuf d_ccnt, d_coff, d_cpieces, d_crare, d_crng, d_ctot;
     // host result buffers (pinned)
@@ -2213,6 +2227,7 @@ class HipBackend : public Backend {
         // reads with more than two M operators are annotated a wave per read (k_annotate_wave); TK_WAVE_FORM=0 keeps them on K1's serial path
         wave_on = n > 0 && c.has_ref && s.max_ncigar >= 5;                          // (three M operators take at least five operators)
         if (const char* wk = test_knob(TK_WAVE_FORM)) wave_on = wave_on && atoi(wk) != 0;
+        wave_big = wave_on && s.max_ncigar > 2u * (uint32_t)AW_MCAP;
         if (wave_on) { HIPCHK(d_wavelist.ensure(((size_t)n + 16) * sizeof(uint32_t))); HIPCHK(d_nc_k1.ensure(((size_t)n + 16) * sizeof(uint32_t))); }
         HIPCHK(d_libbase.ensure((lib_base.size() + 1) * sizeof(int64_t)));
         if (!lib_base.empty()) HIPCHK(hipMemcpyAsync(d_libbase.p, lib_base.data(), lib_base.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
@@ -2307,7 +2322,7 @@ class HipBackend : public Backend {
                 hipLaunchKernelGGL(k_refcode, dim3((unsigned)(((rl + 2 * REFCODE_PAD + 15) / 16 + 255) / 256)), dim3(256), 0, stream, in.ref, (uint8_t*)d_refcode.p, rl);
             DevIn in_k1 = in;
             if (wave_on) {   // reads with more than two M operators: listed for k_annotate_wave, without operators in K1's copy of the counts
-                hipLaunchKernelGGL(k_pick_wave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (uint32_t*)d_nc_k1.p, (uint32_t*)d_wavelist.p, &ctr->n_wave_reads);
+                hipLaunchKernelGGL(k_pick_wave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (uint32_t*)d_nc_k1.p, (uint32_t*)d_wavelist.p, (uint32_t)n, &ctr->n_wave_reads, &ctr->n_wave_big);
                 in_k1.n_cigar = (const uint32_t*)d_nc_k1.p;
             }
             {   // K1: one instantiation per (row layout, width of the narrow packed fields — choose_pack)
@@ -2321,11 +2336,16 @@ class HipBackend : public Backend {
                 if (wave_on) {
                     // the reads K1 left to the wave form (their number stays on the device: a fixed grid takes them round robin)
                     const unsigned nb = (unsigned)std::min<int64_t>((n + 3) / 4, (int64_t)WAVE_FORM_BLOCKS);
-#define BRC_LAUNCH_K1W(SH) hipLaunchKernelGGL((k_annotate_wave<SH>), dim3(nb), dim3(256), 0, stream, c, in, (const uint32_t*)d_wavelist.p, (const unsigned int*)&ctr->n_wave_reads,     \
+#define BRC_LAUNCH_K1W(SH, MCAP, WAVES, GRID, LIST, STEP, COUNT) hipLaunchKernelGGL((k_annotate_wave<SH, MCAP, WAVES>), dim3(GRID), dim3(WAVES * 64), 0, stream, c, in, LIST, STEP, (const unsigned int*)(COUNT),     \
                                    (DRead*)d_reads.p, (const uint32_t*)d_pieceoff.p, (Piece*)d_pieces.p, (PieceRare*)d_rare.p, (int2*)d_keyreach.p,                                   \
                                    (uint8_t*)in.eb, (uint16_t*)in.bqw, indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p,                                          \
                                    (const uint8_t*)d_refcode.p + REFCODE_PAD, has_wanted ? (const uint16_t*)d_wanted.p : (const uint16_t*)nullptr)
-                    if (c.pack_shift == 16) BRC_LAUNCH_K1W(16); else BRC_LAUNCH_K1W(12);
+                    const uint32_t* const wl = (const uint32_t*)d_wavelist.p;
+                    if (c.pack_shift == 16) BRC_LAUNCH_K1W(16, AW_MCAP, 4, nb, wl, 1, &ctr->n_wave_reads); else BRC_LAUNCH_K1W(12, AW_MCAP, 4, nb, wl, 1, &ctr->n_wave_reads);
+                    if (wave_big) {     // reads with more than AW_MCAP M operators (more than 2 * AW_MCAP operators): one wave per workgroup, listed from the back
+                        const unsigned nbb = (unsigned)std::min<int64_t>(n, (int64_t)WAVE_FORM_BLOCKS_BIG);
+                        if (c.pack_shift == 16) BRC_LAUNCH_K1W(16, AW_MCAP_BIG, 1, nbb, wl + (n - 1), -1, &ctr->n_wave_big); else BRC_LAUNCH_K1W(12, AW_MCAP_BIG, 1, nbb, wl + (n - 1), -1, &ctr->n_wave_big);
+                    }
 #undef BRC_LAUNCH_K1W
                 }
             }
