@@ -68,7 +68,10 @@ def spliced_cigar(rng, L, style):
 
 def scenario(seed):
     rng = np.random.default_rng(seed)
-    kind = str(rng.choice(["long", "deep", "libs", "thresholds", "tiny", "mixed_len", "dense_indel", "spliced", "spliced"]))
+    kinds = ["long", "deep", "libs", "thresholds", "tiny", "mixed_len", "dense_indel", "spliced", "spliced"]
+    if seed >= 20_000:          # (seeds below keep the scenarios of the earlier logs) reads with hundreds to thousands of operators: wave-form annotator, tile compaction
+        kinds += ["many_ops", "many_ops", "many_ops"]
+    kind = str(rng.choice(kinds))
     if kind == "spliced":
         RL = int(rng.integers(150_000, 400_000))
         ref = synth.make_ref(rng, RL + 450_000, weird=float(rng.choice([0, 0.02])))
@@ -86,10 +89,12 @@ def scenario(seed):
         if rng.random() < 0.5:
             kw.update(per_lib=True, lib_names=["lib%03d" % i for i in range(n_libs)])
         return kind, "spliced", ref, arrs, regions, kw, bool(rng.random() < 0.5)
-    RL = int(rng.integers(2_000, 40_000)) if kind == "long" else int(rng.integers(300, 4_000))
+    RL = int(rng.integers(2_000, 40_000)) if kind in ("long", "many_ops") else int(rng.integers(300, 4_000))
     n_libs = int(rng.choice([5, 12, 64, 254])) if kind == "libs" else int(rng.choice([1, 1, 2, 4]))
     style = str(rng.choice(["simple", "indel", "wild", "mixed", "clip"] if kind != "dense_indel" else ["wild", "indel"]))
-    if kind == "long":
+    if kind == "many_ops":
+        style = "many"; hi = int(rng.choice([400, 1_500, 6_000, 20_000])); read_len = (int(rng.integers(60, min(hi, 3_000))), hi); n_reads = int(rng.integers(20, 400 if hi < 6_000 else 80))
+    elif kind == "long":
         hi = int(rng.choice([6_000, 12_000, 30_000])); read_len = (int(rng.integers(50, hi)), hi); n_reads = int(rng.integers(20, 200))
     elif kind == "deep":
         read_len = (int(rng.integers(20, 100)), int(rng.integers(100, 300))); n_reads = int(rng.integers(4_000, 15_000)); RL = int(rng.integers(150, 600))
