@@ -172,6 +172,9 @@ class CramReader {
         return fetch_impl(tid, beg, end, [](void* c, const BamRecord& r) { (*(F*)c)(r); }, &cb);
     }
     const std::string& error() const;
+    // The bases of contig `tid`, already loaded by the caller and alive until the next call of this function: used instead of a copy of
+    // the reader's own (several readers decoding stripes of one region side by side would each load the whole contig).  nullptr: none.
+    void share_reference(int tid, const std::string* bases);
 
   private:
     struct Impl;

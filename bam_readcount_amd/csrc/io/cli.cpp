@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <functional>
 #include <future>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -348,14 +349,16 @@ static int lib_index(const Ctx& c, const BamRecord& r) {      // bam_get_library
 // by read START position into K stripes; stripe i keeps the records whose pos lies in its stripe (stripe 0 also the reads
 // that start before the chunk), so the stripes concatenated are exactly the single-handle fetch, in file order.
 struct Fetched { std::vector<Batcher> parts; bool ok = true; std::string err; unsigned uses = 0; bool allow_pinned = false;
-                 std::vector<std::unique_ptr<BamReader> > pool; };   // the BAM handles of this buffer's stripes (fetches of different buffers run side by side)
+                 std::vector<std::unique_ptr<BamReader> > pool;      // the BAM handles of this buffer's stripes (fetches of different buffers run side by side)
+                 std::vector<std::unique_ptr<CramReader> > cram_pool; };   // ... or its CRAM readers
 
+static long long stripe_min_bp() { static const long long v = getenv("BRC_FETCH_STRIPE_MIN") ? atoll(getenv("BRC_FETCH_STRIPE_MIN")) : 65536; return v; }   // (tests force small chunks into stripes)
 static void fetch_chunk(Ctx& c, int tid, int64_t a, int64_t b, Fetched& out) {
     out.ok = true; out.err.clear();
     const int64_t q0 = a - 1 < 0 ? 0 : a - 1;
     unsigned K = 1;
-    static const long long stripe_min = getenv("BRC_FETCH_STRIPE_MIN") ? atoll(getenv("BRC_FETCH_STRIPE_MIN")) : 65536;   // (tests force small chunks into stripes)
-    if (!c.is_cram && b - q0 >= stripe_min) {
+    const long long stripe_min = stripe_min_bp();
+    if (b - q0 >= stripe_min) {
         K = effective_cpus() * 3 / 4 / g_engines; if (K < 2) K = 2; if (K > 32) K = 32;
         if (const char* t = getenv("BRC_FETCH_THREADS")) { const int v = atoi(t); if (v > 0) K = (unsigned)v; }
         if ((int64_t)K > b - q0) K = (unsigned)(b - q0);          // every stripe at least one position wide (stripe 0 must contain q0)
@@ -366,9 +369,34 @@ static void fetch_chunk(Ctx& c, int tid, int64_t a, int64_t b, Fetched& out) {
     // uploads them in place (run_region: brc_push_reads_pinned)
     static const bool zero_copy = !(getenv("BRC_ZERO_COPY") && atoi(getenv("BRC_ZERO_COPY")) == 0);
     if (zero_copy && out.allow_pinned && out.uses++ > 0) for (Batcher& p : out.parts) if (p.seen_qual) p.use_pinned();
-    if (c.is_cram) {
+    if (c.is_cram && K == 1) {
         auto add = [&](const BamRecord& r) { out.parts[0].add(r, c.opt.per_lib ? lib_index(c, r) : 0); };
         if (!c.cram.fetch(tid, a - 1, b, add)) { out.ok = false; out.err = c.cram.error(); }
+        return;
+    }
+    if (c.is_cram) {
+        // stripes of a CRAM piece: a reader of its own per stripe (a stripe decodes the slices that overlap it — a slice that straddles a
+        // stripe boundary twice — and keeps the records that START in it); the contig's bases, which run_region holds, are shared
+        while (out.cram_pool.size() < K) {
+            out.cram_pool.emplace_back(new CramReader());
+            if (!out.cram_pool.back()->open(c.opt.bam, c.have_fa ? &c.fa : nullptr)) { out.ok = false; out.err = out.cram_pool.back()->error(); return; }
+        }
+        const bool share = c.have_fa && c.ref_tid == tid && !c.ref.empty();
+        std::atomic<int> failed(0); std::mutex em;
+        auto work = [&](unsigned i) {
+            const int64_t s0 = q0 + (b - q0) * (int64_t)i / (int64_t)K, s1 = q0 + (b - q0) * (int64_t)(i + 1) / (int64_t)K;
+            CramReader& rd = *out.cram_pool[i];
+            rd.share_reference(tid, share ? &c.ref : nullptr);
+            if (!rd.fetch(tid, i == 0 ? a - 1 : s0, s1, [&](const BamRecord& r) {
+                    if (r.pos >= s1 || (i > 0 && r.pos < s0)) return;
+                    out.parts[i].add(r, c.opt.per_lib ? lib_index(c, r) : 0);
+                })) { failed = 1; std::lock_guard<std::mutex> g(em); if (out.err.empty()) out.err = rd.error(); }
+        };
+        std::vector<std::thread> th;
+        for (unsigned i = 1; i < K; ++i) th.emplace_back(work, i);
+        work(0);
+        for (std::thread& t : th) t.join();
+        if (failed) out.ok = false;
         return;
     }
     while (out.pool.size() < K) { out.pool.emplace_back(new BamReader()); if (!out.pool.back()->open(c.opt.bam)) { out.ok = false; out.err = "cannot reopen " + c.opt.bam; return; } }
@@ -405,8 +433,8 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
     const int64_t chunk = (int64_t)c.opt.chunk_bp;
     const int64_t npieces = std::max<int64_t>(1, (end - beg0 + chunk - 1) / chunk);
     static const int ahead_env = getenv("BRC_FETCH_AHEAD") ? atoi(getenv("BRC_FETCH_AHEAD")) : 0;
-    // (the CRAM reader is one handle: one fetch at a time)
-    const int ahead = c.is_cram ? 1 : (ahead_env > 0 ? ahead_env : 2);
+    // (a CRAM piece that is too short for stripes goes through the context's one reader: one fetch at a time)
+    const int ahead = (c.is_cram && chunk < stripe_min_bp()) ? 1 : (ahead_env > 0 ? ahead_env : 2);
     std::vector<Fetched> bufs((size_t)ahead + 1); std::vector<std::thread> fth((size_t)ahead + 1);
     for (Fetched& f : bufs) f.allow_pinned = npieces > (int64_t)ahead + 1;        // (only a run of pieces reuses its buffers)
     auto start_fetch = [&](int64_t j) {

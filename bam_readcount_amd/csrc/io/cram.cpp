@@ -59,6 +59,7 @@ struct Enc {            // one data-series / tag encoding
     std::vector<uint32_t> code;      // canonical codes matching sym/len (sorted)
     int beta_off = 0, beta_bits = 0;     // BETA; GAMMA: offset; SUBEXP: offset, k
     std::vector<Enc> sub;            // BYTE_ARRAY_LEN: [0] lengths, [1] values
+    Block* blk = nullptr;            // EXTERNAL / BYTE_ARRAY_STOP: the slice's block with this content id (bound once per slice: bind_blocks)
 };
 
 struct BitReader { const uint8_t* p = nullptr; size_t n = 0, bit = 0;
@@ -208,6 +209,7 @@ struct CramReader::Impl {
     Fasta* fa = nullptr;
     std::string err;
     int ref_tid = -1; std::string ref;
+    int shared_tid = -1; const std::string* shared_ref = nullptr;   // CramReader::share_reference
     off_t data_start = 0;
     // per-slice decode state
     std::map<int, Block> ext; Block core; BitReader br;
@@ -261,9 +263,9 @@ struct CramReader::Impl {
     // ---- decoders
     bool dec_int(const Enc& e, int32_t* out) {
         switch (e.codec) {
-            case 1: { auto it = ext.find(e.ext_id); if (it == ext.end()) { err = "missing CRAM external block"; return false; }
-                      Cur c; c.p = it->second.data.data() + it->second.pos; c.e = it->second.data.data() + it->second.data.size();
-                      *out = c.itf8(); it->second.pos = (size_t)(c.p - it->second.data.data()); return !c.bad; }
+            case 1: { Block* const b = e.blk; if (!b) { err = "missing CRAM external block"; return false; }
+                      Cur c; c.p = b->data.data() + b->pos; c.e = b->data.data() + b->data.size();
+                      *out = c.itf8(); b->pos = (size_t)(c.p - b->data.data()); return !c.bad; }
             case 3: { if (e.sym.size() == 1 && e.len[0] == 0) { *out = e.sym[0]; return true; }
                       uint32_t code = 0; int l = 0; size_t i = 0;
                       while (i < e.sym.size()) { while (l < e.len[i]) { if ((br.bit >> 3) >= br.n) { err = "CRAM core block exhausted"; return false; } code = (code << 1) | (uint32_t)br.get(); ++l; }
@@ -281,20 +283,43 @@ struct CramReader::Impl {
         }
     }
     bool dec_byte(const Enc& e, uint8_t* out) {
-        if (e.codec == 1) { auto it = ext.find(e.ext_id); if (it == ext.end() || it->second.pos >= it->second.data.size()) { err = "CRAM external block exhausted"; return false; }
-            *out = it->second.data[it->second.pos++]; return true; }
+        if (e.codec == 1) { Block* const b = e.blk; if (!b || b->pos >= b->data.size()) { err = "CRAM external block exhausted"; return false; }
+            *out = b->data[b->pos++]; return true; }
         int32_t v; if (!dec_int(e, &v)) return false; *out = (uint8_t)v; return true;
     }
     bool dec_bytes(const Enc& e, std::vector<uint8_t>* out) {
         out->clear();
-        if (e.codec == 5) { auto it = ext.find(e.ext_id); if (it == ext.end()) { err = "missing CRAM external block"; return false; }
-            Block& b = it->second; while (b.pos < b.data.size() && b.data[b.pos] != e.stop) out->push_back(b.data[b.pos++]); if (b.pos < b.data.size()) ++b.pos; return true; }
-        if (e.codec == 4) { int32_t n; if (!dec_int(e.sub[0], &n)) return false; for (int i = 0; i < n; ++i) { uint8_t v; if (!dec_byte(e.sub[1], &v)) return false; out->push_back(v); } return true; }
+        if (e.codec == 5) { if (!e.blk) { err = "missing CRAM external block"; return false; }
+            Block& b = *e.blk; const uint8_t* const p0 = b.data.data() + b.pos; const size_t left = b.data.size() - b.pos;
+            const uint8_t* const q = (const uint8_t*)memchr(p0, e.stop, left); const size_t n = q ? (size_t)(q - p0) : left;
+            out->assign(p0, p0 + n); b.pos += n + (q ? 1u : 0u); return true; }
+        if (e.codec == 4) { int32_t n; if (!dec_int(e.sub[0], &n)) return false; if (n < 0) { err = "corrupt CRAM byte array length"; return false; }
+            const Enc& v = e.sub[1];
+            if (v.codec == 1 && v.blk && v.blk->data.size() - v.blk->pos >= (size_t)n) { out->assign(v.blk->data.data() + v.blk->pos, v.blk->data.data() + v.blk->pos + n); v.blk->pos += (size_t)n; return true; }
+            for (int i = 0; i < n; ++i) { uint8_t b1; if (!dec_byte(v, &b1)) return false; out->push_back(b1); } return true; }
         err = "CRAM byte-array codec " + std::to_string(e.codec) + " not supported"; return false;
     }
-    const Enc* series(const char* k) { auto it = ds.find(k); return it == ds.end() ? nullptr : &it->second; }
+    // The per-value path: a data series is found through a table indexed by its two-letter key (rebuilt per compression header), an
+    // encoding's external block through a pointer bound once per slice — a map lookup with a string key per value made every read cost
+    // 10 us (150 qualities alone are 150 values)
+    std::vector<const Enc*> fast = std::vector<const Enc*>(65536, nullptr);
+    const Enc* series(const char* k) const { return fast[((size_t)(uint8_t)k[0] << 8) | (size_t)(uint8_t)k[1]]; }
+    void bind_enc(Enc& e) {
+        e.blk = nullptr;
+        if (e.codec == 1 || e.codec == 5) { auto it = ext.find(e.ext_id); if (it != ext.end()) e.blk = &it->second; }
+        for (Enc& s : e.sub) bind_enc(s);
+    }
+    void bind_blocks() { for (auto& kv : ds) bind_enc(kv.second); for (auto& kv : tagenc) bind_enc(kv.second); }
+    void index_series() { std::fill(fast.begin(), fast.end(), (const Enc*)nullptr); for (auto& kv : ds) if (kv.first.size() == 2) fast[((size_t)(uint8_t)kv.first[0] << 8) | (size_t)(uint8_t)kv.first[1]] = &kv.second; }
     bool geti(const char* k, int32_t* v) { const Enc* e = series(k); if (!e) { err = std::string("CRAM data series ") + k + " missing"; return false; } return dec_int(*e, v); }
     bool getb(const char* k, uint8_t* v) { const Enc* e = series(k); if (!e) { err = std::string("CRAM data series ") + k + " missing"; return false; } return dec_byte(*e, v); }
+    // n values of a byte series at once (the quality array of a record): straight out of the block when the series is EXTERNAL
+    bool getn(const char* k, uint8_t* dst, int n) {
+        const Enc* e = series(k); if (!e) { err = std::string("CRAM data series ") + k + " missing"; return false; }
+        if (e->codec == 1 && e->blk && n >= 0 && e->blk->data.size() - e->blk->pos >= (size_t)n) { memcpy(dst, e->blk->data.data() + e->blk->pos, (size_t)n); e->blk->pos += (size_t)n; return true; }
+        for (int i = 0; i < n; ++i) if (!dec_byte(*e, dst + i)) return false;
+        return true;
+    }
     bool geta(const char* k, std::vector<uint8_t>* v) { const Enc* e = series(k); if (!e) { err = std::string("CRAM data series ") + k + " missing"; return false; } return dec_bytes(*e, v); }
 
     bool parse_comp_header(const Block& b) {
@@ -325,6 +350,7 @@ struct CramReader::Impl {
         { Cur m; if (!sub(&m)) return false;
           const int n = m.itf8();
           for (int i = 0; i < n; ++i) { const int32_t key = m.itf8(); if (m.bad) { err = "truncated CRAM tag encoding map"; return false; } Enc e; if (!parse_enc(m, &e, &err)) return false; tagenc[key] = e; } }
+        index_series();
         return !c.bad;
     }
 
@@ -376,8 +402,9 @@ struct CramReader::Impl {
     bool decode_slice(int slice_ref, int slice_start, int nrec, int tid, int64_t beg, int64_t end, F& cb) {
         br.p = core.data.data(); br.n = core.data.size(); br.bit = 0;
         int32_t last_ap = slice_start;
-        static const uint8_t nt16[256] = {0};
-        (void)nt16;
+        // (buffers of the record loop: cleared, not reallocated, per record)
+        std::vector<uint8_t> name, tmp, aux, qual; std::string seq; std::vector<uint32_t> cg; BamRecord rec;
+        static const struct Nt16 { uint8_t t[256]; Nt16() { memset(t, 15, sizeof t); const char* codes = "=ACMGRSVTWYHKDBN"; for (int i = 0; i < 16; ++i) { t[(uint8_t)codes[i]] = (uint8_t)i; t[(uint8_t)tolower(codes[i])] = (uint8_t)i; } } } nt16;
         for (int r = 0; r < nrec; ++r) {
             int32_t bf, cf, ri = slice_ref, rl, ap, rg;
             if (!geti("BF", &bf) || !geti("CF", &cf)) return false;
@@ -385,13 +412,13 @@ struct CramReader::Impl {
             if (!geti("RL", &rl) || !geti("AP", &ap) || !geti("RG", &rg)) return false;
             if (rl < 0 || rl > (1 << 28) || (ri < 0 && !(bf & 4)) || ri >= (int32_t)hdr.names.size()) { err = "corrupt CRAM record"; return false; }
             if (ap_delta) { ap += last_ap; last_ap = ap; }
-            std::vector<uint8_t> name, tmp;
+            name.clear(); tmp.clear();
             if (rn_preserved && !geta("RN", &name)) return false;
             if (cf & 2) { int32_t mf, ns, np, ts; if (!geti("MF", &mf)) return false; if (!rn_preserved && !geta("RN", &name)) return false;
                           if (!geti("NS", &ns) || !geti("NP", &np) || !geti("TS", &ts)) return false; }
             else if (cf & 4) { int32_t nf; if (!geti("NF", &nf)) return false; }
             int32_t tl; if (!geti("TL", &tl)) return false;
-            std::vector<uint8_t> aux;
+            aux.clear();
             bool has_nm = false; uint32_t nm = 0;
             if (tl >= 0 && (size_t)tl < td.size()) for (int32_t key : td[(size_t)tl]) {
                 if ((key >> 8) == (('N' << 8) | 'M')) has_nm = true;
@@ -401,18 +428,20 @@ struct CramReader::Impl {
                 aux.insert(aux.end(), tmp.begin(), tmp.end());
             }
             if (rg >= 0 && (size_t)rg < rg_ids.size()) { aux.push_back('R'); aux.push_back('G'); aux.push_back('Z'); aux.insert(aux.end(), rg_ids[(size_t)rg].begin(), rg_ids[(size_t)rg].end()); aux.push_back(0); }
-            std::string seq((size_t)std::max(rl, 0), 'N'); std::vector<uint8_t> qual((size_t)std::max(rl, 0), 0xff); std::vector<uint32_t> cg;
+            seq.assign((size_t)std::max(rl, 0), 'N'); qual.assign((size_t)std::max(rl, 0), 0xff); cg.clear();
             int32_t mq = 0;
             if (!(bf & 4)) {
                 const bool have_ref = emb_ref != nullptr || ref_required;              // htslib: s->ref
-                if (!emb_ref && ref_required && ri != ref_tid) { if (!fa || !fa->fetch(hdr.names[(size_t)ri], &ref)) { err = "CRAM needs the reference FASTA (-f) to reconstruct reads"; return false; } ref_tid = ri; }
+                const bool use_shared = shared_ref && ri == shared_tid;
+                if (!emb_ref && ref_required && !use_shared && ri != ref_tid) { if (!fa || !fa->fetch(hdr.names[(size_t)ri], &ref)) { err = "CRAM needs the reference FASTA (-f) to reconstruct reads"; return false; } ref_tid = ri; }
+                const std::string& R = use_shared ? *shared_ref : ref;
                 // raw reference character at 0-based x ('N' outside what is known)
                 auto ref_raw = [&](int64_t x) -> char {
                     if (emb_ref) { const int64_t k = x - emb_start0; return (k >= 0 && k < emb_len) ? (char)emb_ref[k] : 'N'; }
                     if (!ref_required) return 'N';
-                    return (x >= 0 && x < (int64_t)ref.size()) ? ref[(size_t)x] : 'N';
+                    return (x >= 0 && x < (int64_t)R.size()) ? R[(size_t)x] : 'N';
                 };
-                const int64_t ref_end = emb_ref ? emb_start0 + emb_len : (ref_required ? (int64_t)ref.size() : 0);
+                const int64_t ref_end = emb_ref ? emb_start0 + emb_len : (ref_required ? (int64_t)R.size() : 0);
                 int32_t fn; if (!geti("FN", &fn)) return false;
                 int64_t refp = (int64_t)ap - 1; int sp = 1, prev = 0;
                 auto ref_at = [&](int64_t x) { return (char)toupper((unsigned char)ref_raw(x)); };
@@ -456,26 +485,25 @@ struct CramReader::Impl {
                 }
                 if (sp <= rl) { const int l = rl - sp + 1; copy_ref(l); push_cigar(cg, 0, (uint32_t)l); }
                 if (!geti("MQ", &mq)) return false;
-                if (cf & 1) for (int i = 0; i < rl; ++i) if (!getb("QS", &qual[(size_t)i])) return false;
+                if ((cf & 1) && !getn("QS", qual.data(), rl)) return false;
                 // htslib regenerates NM (and MD, which this path never reads) for a mapped record that was stored without
                 // it — samtools drops both tags when it writes CRAM (cram_decode.c cram_decode_seq, decode_md = 1 by default):
                 // substitutions, inserted and deleted bases, and literal bases that differ from the reference
                 if (!has_nm && !(cf & 8) && ri >= 0 && have_ref) { aux.push_back('N'); aux.push_back('M'); aux.push_back('I'); for (int k = 0; k < 4; ++k) aux.push_back((uint8_t)(nm >> (8 * k))); }
             } else {
-                for (int i = 0; i < rl; ++i) { uint8_t b; if (!getb("BA", &b)) return false; seq[(size_t)i] = (char)b; }
-                if (cf & 1) for (int i = 0; i < rl; ++i) if (!getb("QS", &qual[(size_t)i])) return false;
+                if (!getn("BA", reinterpret_cast<uint8_t*>(&seq[0]), rl)) return false;
+                if ((cf & 1) && !getn("QS", qual.data(), rl)) return false;
             }
             // ---- BAM-layout record
-            BamRecord rec;
             rec.tid = ri; rec.pos = ap - 1; rec.mapq = (uint8_t)mq; rec.flag = (uint16_t)bf; rec.l_seq = rl; rec.n_cigar = (uint32_t)cg.size();
             if (name.empty()) { const std::string gen = "cram" + std::to_string(r); name.assign(gen.begin(), gen.end()); }
             rec.l_qname = (uint32_t)name.size() + 1;
+            rec.data.clear();
+            rec.data.reserve(name.size() + 1 + 4 * cg.size() + (size_t)(rl + 1) / 2 + qual.size() + aux.size());
             rec.data.assign(name.begin(), name.end()); rec.data.push_back(0);
             for (uint32_t v : cg) for (int k = 0; k < 4; ++k) rec.data.push_back((uint8_t)(v >> (8 * k)));
-            static const char* codes = "=ACMGRSVTWYHKDBN";
             for (int i = 0; i < rl; i += 2) {
-                auto code_of = [&](char ch) { const char* q = strchr(codes, toupper((unsigned char)ch)); return (uint8_t)(q ? q - codes : 15); };
-                const uint8_t hi = code_of(seq[(size_t)i]), lo = i + 1 < rl ? code_of(seq[(size_t)i + 1]) : 0;
+                const uint8_t hi = nt16.t[(uint8_t)seq[(size_t)i]], lo = i + 1 < rl ? nt16.t[(uint8_t)seq[(size_t)i + 1]] : 0;
                 rec.data.push_back((uint8_t)((hi << 4) | lo));
             }
             rec.data.insert(rec.data.end(), qual.begin(), qual.end());
@@ -490,6 +518,7 @@ CramReader::CramReader() : d_(new Impl) {}
 CramReader::~CramReader() { if (d_->f) fclose(d_->f); delete d_; }
 const BamHeader& CramReader::header() const { return d_->hdr; }
 const std::string& CramReader::error() const { return d_->err; }
+void CramReader::share_reference(int tid, const std::string* bases) { d_->shared_tid = bases ? tid : -1; d_->shared_ref = bases; }
 
 bool CramReader::is_cram(const std::string& path) {
     FILE* f = fopen(path.c_str(), "rb"); if (!f) return false;
@@ -594,7 +623,8 @@ bool CramReader::fetch_impl(int tid, int64_t beg, int64_t end, void (*thunk)(voi
             // a single-reference slice that cannot overlap is skipped without inflating its blocks
             const bool slice_may = sref == -2 || sref < 0 || (sref == tid && (int64_t)sstart - 1 < end && (int64_t)sstart - 1 + sspan > beg);
             if (!slice_may) { for (int i = 0; i < snb; ++i) if (!d.skip_block(c)) return false; continue; }
-            for (int i = 0; i < snb; ++i) { Block b; if (!d.read_block(c, &b)) return false; if (b.type == 5) d.core = b; else d.ext[b.id] = b; }
+            for (int i = 0; i < snb; ++i) { Block b; if (!d.read_block(c, &b)) return false; if (b.type == 5) d.core = std::move(b); else d.ext[b.id] = std::move(b); }
+            d.bind_blocks();
             // (slice header, continued: the block content ids, then the id of an embedded reference block or -1)
             { const int32_t ncid = s.itf8(); for (int32_t i = 0; i < ncid; ++i) (void)s.itf8(); }
             const int32_t emb = s.bad ? -1 : s.itf8();

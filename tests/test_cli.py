@@ -611,6 +611,24 @@ def test_rans_encoder_round_trip_sizes():
                 assert cramio.rans_decode(comp) == data, (order, n, kind)
 
 
+def test_cli_striped_cram_fetch_equals_single_reader_cpu(synthetic_bam):
+    """CRAM pieces are decoded in stripes too (round 5): one CramReader per stripe, each decoding the slices that overlap its stripe and
+    keeping the records that start in it, the contig's bases shared — forced onto small regions with odd thread counts and chunk sizes,
+    over the multi-container CRAM with a multi-reference slice: the text of the one-reader route (and of the BAM)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    d = synthetic_bam
+    for extra in ([], ["-p", "-i"]):
+        base = [SIM_CLI, "-w", "0", "-f", "syn.fa"] + extra + ["syn.cram", "chrA", "chrB:100-2900", "chrA:4990-5000"]
+        want = subprocess.run(base, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, BRC_FETCH_STRIPE_MIN="1000000000"))
+        bam = subprocess.run([SIM_CLI, "-w", "0", "-f", "syn.fa"] + extra + ["syn_m.bam", "chrA", "chrB:100-2900", "chrA:4990-5000"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert want.returncode == 0 and want.stdout.count(b"\n") > 7000 and want.stdout == bam.stdout
+        for threads, chunk in ((3, "700"), (7, "1000000"), (16, "64"), (2, "5000")):
+            env = dict(os.environ, BRC_FETCH_STRIPE_MIN="1", BRC_FETCH_THREADS=str(threads))
+            got = subprocess.run(base[:1] + ["--brc-chunk", chunk] + base[1:], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            assert got.returncode == 0, got.stderr
+            assert got.stdout == want.stdout and got.stderr == want.stderr, (extra, threads, chunk)
+
+
 def test_cli_striped_parallel_fetch_equals_single_handle_cpu(synthetic_bam, workdir):
     """Long chunks are decoded by several BAM handles in stripes of read start positions while the previous chunk is on
     the engine; forced here onto small regions (BRC_FETCH_STRIPE_MIN) with odd thread counts and chunk sizes."""
