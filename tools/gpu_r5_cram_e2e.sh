@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 5: the drop-in command line on CRAM input against the same reads as BAM (15 Mbp at 30x, 3 M reads; the CRAM was written by
-# tools/cramio.py in the build container — gpurun_in/, not in the repository: tools/gpu_r5_cram_e2e.sh regenerates it with `python gen.py 15`)
+# tools/cramio.py in the build container, 5 minutes of Python, into gpurun_in/ — git-ignored, but it travels to the GPU box:
+# `mkdir -p gpurun_in && cd gpurun_in && python ../tools/cram_e2e_gen.py 15 && rm syn.bam syn.bam.bai`; remove it afterwards, 300 MB are pushed with every call)
 cd "$(dirname "$0")/.." && mkdir -p gpurun_out
 export TMPDIR=/tmp
 python - 2>&1 <<'PY' | tee gpurun_out/r05_e2e_cram.log
