@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void k_refcode(const char* __restrict__ ref, u
 //   phase C (lane = read)  the quality != 2 scan from the read's 3' end (:201-238; 8 bases per load, as a rule one load),
 //                          three-prime / Q2 logic, DRead + float constants, the pieces, the indel events.
 enum { AW_MCAP = 1024,               // M operators of a read the wave form (k_annotate_wave, below) holds in LDS: four waves per workgroup ...
-       AW_MCAP_BIG = 5120 };         // ... and one wave per workgroup (60 KB: reads of ~150 kb with an operator every 15 bases)
+       AW_MCAP_BIG = 5120 };         // ... and one wave per workgroup (60 KB: reads of ~80 kb with a match run of 15 bases between two operators)
 struct AnnPar { uint4 a, b, c; };    // a = {L, qrel, srel, brow.lo}  b = {S, m1lo, m1hi, d1}  c = {m2lo, m2hi, d2, brow.hi}
 
 __device__ __forceinline__ uint32_t nzb7(uint32_t x) { return x + 0x7f7f7f7fu; }   // bytes <= 0x7f: bit 7 of a byte <=> byte != 0

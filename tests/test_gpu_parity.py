@@ -651,7 +651,7 @@ def test_hip_wave_form_annotator_on_reads_with_many_operators(dev_lib, knob_lib,
 
 def test_hip_wave_form_operator_count_limits(dev_lib, oracle_lib):
     """The wave form holds the M operators of a read in LDS: up to 1024 with four waves per workgroup, up to 5120 with one (reads of
-    ~150 kb at an operator every 15 bases); a read with more, and reads with P, = or X operators, keep K1's serial walk — side by side in
+    ~80 kb with a match run of ~15 bases between operators); a read with more, and reads with P, = or X operators, keep K1's serial walk — side by side in
     one region, all equal to the oracle.  [sim]: the serial walk."""
     ref, arrs = synth.operator_limit_reads()
     for opts in (dict(), dict(insertion_centric=True, min_bq=10)):
