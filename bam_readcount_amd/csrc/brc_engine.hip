@@ -45,7 +45,7 @@ struct Counters {
     unsigned long long n_events, n_positions, w_sm, w_nm, w_lib;
     unsigned int n_indel_slots, n_xev;   // n_xev: third-allele events in the compacted list
     unsigned int xev_max, n_wave_reads;  // fullest sub-list's cursor (above its capacity: grow and compute again); reads K1 left to k_annotate_wave
-    unsigned int n_wave_big, pad2_;      // ... those of them with more than AW_MCAP M operators (the one-wave-per-workgroup instantiation)
+    unsigned int n_wave_big, n_wave_huge;   // ... those of them with more than AW_MCAP / AW_MCAP_BIG M operators (the one-wave-per-workgroup instantiations)
 };
 
 // Profiling ablations that switch parts of the kernels off (wrong results, timing only) exist only in experiment builds
@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void k_refcode(const char* __restrict__ ref, u
 //   phase C (lane = read)  the quality != 2 scan from the read's 3' end (:201-238; 8 bases per load, as a rule one load),
 //                          three-prime / Q2 logic, DRead + float constants, the pieces, the indel events.
 enum { AW_MCAP = 1024,               // M operators of a read the wave form (k_annotate_wave, below) holds in LDS: four waves per workgroup ...
-       AW_MCAP_BIG = 5120 };         // ... and one wave per workgroup (60 KB: reads of ~80 kb with a match run of 15 bases between two operators)
+       AW_MCAP_BIG = 5120,           // ... and one wave per workgroup (60 KB: reads of ~80 kb with a match run of 15 bases between two operators)
+       AW_MCAP_HUGE = 13500 };       // ... and one wave per CU (158 of gfx950's 160 KB of LDS: reads of ~210 kb)
 struct AnnPar { uint4 a, b, c; };    // a = {L, qrel, srel, brow.lo}  b = {S, m1lo, m1hi, d1}  c = {m2lo, m2hi, d2, brow.hi}
 
 __device__ __forceinline__ uint32_t nzb7(uint32_t x) { return x + 0x7f7f7f7fu; }   // bytes <= 0x7f: bit 7 of a byte <=> byte != 0
@@ -606,18 +607,19 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
 // K1 picks the reads (phase A knows everything the choice needs) and appends them to `wave_list`; this kernel is a fixed grid
 // whose waves take list entries round robin — no host round trip for the count.  A read with a NUL reference character under
 // an M base (the annotator's break, :151) is re-annotated by annotate_read() on one lane; pieces and indel events do not
-// depend on it.  Eligible: mapped-and-pushed reads with bases, inside the reference, 3..AW_MCAP_BIG M operators (two instantiations:
-// up to AW_MCAP with four waves per workgroup, above it one wave per workgroup with a list five times as long), no P / = / X
+// depend on it.  Eligible: mapped-and-pushed reads with bases, inside the reference, 3..AW_MCAP_HUGE M operators (three instantiations:
+// up to AW_MCAP with four waves per workgroup, up to AW_MCAP_BIG one wave per workgroup, above it one wave per CU), no P / = / X
 // operator and no empty M operator (those keep the serial path, as do reads with more M operators than the list holds).
 __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 // Which reads take the wave form: lane = read.  K1 itself is not touched by the choice — a changed K1 is another register allocation, and
 // its 80-register budget holds by a hair (tests/test_abi.py) —: it is launched with a COPY of the operator counts in which the chosen
 // reads have none, and for a read without operators K1 writes nothing at all (no record, no pieces, no indel slots, no event bytes).
-// (wave_list: the reads of the four-wave instantiation from the front, those of the one-wave instantiation from the back, list_cap - 1 downwards)
+// (wave_list: the reads of the four-wave instantiation from the front, those of the one-wave instantiation from the back, list_cap - 1 downwards;
+// those of the one-wave-per-CU instantiation in a second list behind it, from list_cap + 16 on)
 __global__ __launch_bounds__(256) void k_pick_wave(DevCfg c, DevIn in, uint32_t* __restrict__ n_cigar_k1, uint32_t* __restrict__ wave_list, uint32_t list_cap,
-                                                   unsigned int* __restrict__ wave_n, unsigned int* __restrict__ wave_n_big) {
+                                                   unsigned int* __restrict__ wave_n, unsigned int* __restrict__ wave_n_big, unsigned int* __restrict__ wave_n_huge) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool pick = false, big = false; uint32_t nc_me = 0u;
+    bool pick = false, big = false, huge = false; uint32_t nc_me = 0u;
     if (i < c.n_reads) {
         const uint32_t nc = in.n_cigar[i]; nc_me = nc;
         const int32_t pos = in.pos[i], L = in.l_qseq[i];
@@ -630,17 +632,24 @@ __global__ __launch_bounds__(256) void k_pick_wave(DevCfg c, DevIn in, uint32_t*
                 if (op == CMATCH) ++n_m;
                 if (is_refop(op)) rlen += len;
             }
-            pick = !irregular && n_m > 2u && n_m <= (uint32_t)AW_MCAP_BIG && (int64_t)pos + rlen <= c.ref_len && rlen < 0x7fffffffll;
-            big = pick && n_m > (uint32_t)AW_MCAP;
+            pick = !irregular && n_m > 2u && n_m <= (uint32_t)AW_MCAP_HUGE && (int64_t)pos + rlen <= c.ref_len && rlen < 0x7fffffffll;
+            huge = pick && n_m > (uint32_t)AW_MCAP_BIG;
+            big = pick && !huge && n_m > (uint32_t)AW_MCAP;
         }
     }
     const int lane = threadIdx.x & 63;
-    const unsigned long long pm = __ballot(pick && !big), pb = __ballot(big);
+    const unsigned long long pm = __ballot(pick && !big && !huge), pb = __ballot(big), ph = __ballot(huge);
+    if (ph) {
+        uint32_t base = 0u;
+        if (lane == __builtin_ctzll(ph)) base = atomicAdd(wave_n_huge, (unsigned int)__builtin_popcountll(ph));
+        base = (uint32_t)__shfl((int)base, __builtin_ctzll(ph), 64);
+        if (huge) wave_list[list_cap + 16u + base + mbcnt64(ph)] = (uint32_t)i;
+    }
     if (pm) {
         uint32_t base = 0u;
         if (lane == __builtin_ctzll(pm)) base = atomicAdd(wave_n, (unsigned int)__builtin_popcountll(pm));
         base = (uint32_t)__shfl((int)base, __builtin_ctzll(pm), 64);
-        if (pick && !big) wave_list[base + mbcnt64(pm)] = (uint32_t)i;
+        if (pick && !big && !huge) wave_list[base + mbcnt64(pm)] = (uint32_t)i;
     }
     if (pb) {
         uint32_t base = 0u;
@@ -2041,7 +2050,9 @@ class HipBackend : public Backend {
     bool wave_on = false;                      // this region's reads with more than two M operators go to k_annotate_wave
     bool wave_big = false;                     // ... and some may have more than AW_MCAP M operators (a read with more than 2 AW_MCAP operators exists)
     enum { WAVE_FORM_BLOCKS = 768,             // its fixed grid: 3 blocks of 4 waves per CU (48 KB of LDS each)
-           WAVE_FORM_BLOCKS_BIG = 512 };       // the one-wave instantiation: 2 blocks per CU (60 KB of LDS each)
+           WAVE_FORM_BLOCKS_BIG = 512,         // the one-wave instantiation: 2 blocks per CU (60 KB of LDS each)
+           WAVE_FORM_BLOCKS_HUGE = 256 };      // one block per CU (158 KB of LDS)
+    bool wave_huge = false;                    // ... or more than AW_MCAP_BIG
     unsigned long long h_steps[3] = {0, 0, 0};   // piece-steps of the last pass: what the tile ranges hold / what k_pileup2 walked (brc_region_piece_steps)
     DBuf d_ccnt, d_coff, d_cpieces, d_crare, d_crng, d_ctot;
     // host result buffers (pinned)
@@ -2228,7 +2239,8 @@ class HipBackend : public Backend {
         wave_on = n > 0 && c.has_ref && s.max_ncigar >= 5;                          // (three M operators take at least five operators)
         if (const char* wk = test_knob(TK_WAVE_FORM)) wave_on = wave_on && atoi(wk) != 0;
         wave_big = wave_on && s.max_ncigar > 2u * (uint32_t)AW_MCAP;
-        if (wave_on) { HIPCHK(d_wavelist.ensure(((size_t)n + 16) * sizeof(uint32_t))); HIPCHK(d_nc_k1.ensure(((size_t)n + 16) * sizeof(uint32_t))); }
+        wave_huge = wave_on && s.max_ncigar > 2u * (uint32_t)AW_MCAP_BIG;
+        if (wave_on) { HIPCHK(d_wavelist.ensure((2 * (size_t)n + 48) * sizeof(uint32_t))); HIPCHK(d_nc_k1.ensure(((size_t)n + 16) * sizeof(uint32_t))); }
         HIPCHK(d_libbase.ensure((lib_base.size() + 1) * sizeof(int64_t)));
         if (!lib_base.empty()) HIPCHK(hipMemcpyAsync(d_libbase.p, lib_base.data(), lib_base.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
         // outputs / scratch
@@ -2322,7 +2334,7 @@ class HipBackend : public Backend {
                 hipLaunchKernelGGL(k_refcode, dim3((unsigned)(((rl + 2 * REFCODE_PAD + 15) / 16 + 255) / 256)), dim3(256), 0, stream, in.ref, (uint8_t*)d_refcode.p, rl);
             DevIn in_k1 = in;
             if (wave_on) {   // reads with more than two M operators: listed for k_annotate_wave, without operators in K1's copy of the counts
-                hipLaunchKernelGGL(k_pick_wave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (uint32_t*)d_nc_k1.p, (uint32_t*)d_wavelist.p, (uint32_t)n, &ctr->n_wave_reads, &ctr->n_wave_big);
+                hipLaunchKernelGGL(k_pick_wave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (uint32_t*)d_nc_k1.p, (uint32_t*)d_wavelist.p, (uint32_t)n, &ctr->n_wave_reads, &ctr->n_wave_big, &ctr->n_wave_huge);
                 in_k1.n_cigar = (const uint32_t*)d_nc_k1.p;
             }
             {   // K1: one instantiation per (row layout, width of the narrow packed fields — choose_pack)
@@ -2345,6 +2357,10 @@ class HipBackend : public Backend {
                     if (wave_big) {     // reads with more than AW_MCAP M operators (more than 2 * AW_MCAP operators): one wave per workgroup, listed from the back
                         const unsigned nbb = (unsigned)std::min<int64_t>(n, (int64_t)WAVE_FORM_BLOCKS_BIG);
                         if (c.pack_shift == 16) BRC_LAUNCH_K1W(16, AW_MCAP_BIG, 1, nbb, wl + (n - 1), -1, &ctr->n_wave_big); else BRC_LAUNCH_K1W(12, AW_MCAP_BIG, 1, nbb, wl + (n - 1), -1, &ctr->n_wave_big);
+                    }
+                    if (wave_huge) {    // more than AW_MCAP_BIG M operators: one wave per CU (its list fills the CU's LDS), second list
+                        const unsigned nbh = (unsigned)std::min<int64_t>(n, (int64_t)WAVE_FORM_BLOCKS_HUGE);
+                        if (c.pack_shift == 16) BRC_LAUNCH_K1W(16, AW_MCAP_HUGE, 1, nbh, wl + (n + 16), 1, &ctr->n_wave_huge); else BRC_LAUNCH_K1W(12, AW_MCAP_HUGE, 1, nbh, wl + (n + 16), 1, &ctr->n_wave_huge);
                     }
 #undef BRC_LAUNCH_K1W
                 }

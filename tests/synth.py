@@ -294,10 +294,11 @@ def many_ops_inputs(case):
 
 
 def operator_limit_reads():
-    """Hand-made reads around the wave form's limits: 1024 M operators (the four-wave instantiation's last), 1025 / 1500 / 5120 (the
-    one-wave instantiation), 5121 (K1's serial walk), a P operator, = and X operators, and a plain seven-operator read."""
+    """Hand-made reads around the wave form's limits: 1024 M operators (the four-wave instantiation's last), 1025 / 1500 / 5120 (one
+    wave per workgroup), 5121 / 13500 (one wave per CU), 13501 (K1's serial walk), a P operator, = and X operators, and a plain
+    seven-operator read."""
     rng = np.random.default_rng(41)
-    ref = make_ref(rng, 30000)
+    ref = make_ref(rng, 40000)
     def read(pos, ops):
         L = sum(l for o, l in ops if o in (0, 1, 4, 7, 8))
         return pos, ops, rng.choice([1, 2, 4, 8], size=L).astype(np.uint8), rng.integers(3, 41, L).astype(np.uint8)
@@ -307,7 +308,7 @@ def operator_limit_reads():
             ops.append((0, 1 + (k & 1)))
             if k + 1 < n_m: ops.append((gap_op if k % 3 else 2, 1))
         return ops
-    rows = [read(10, alternating(1024, 1)), read(20, alternating(1025, 1)), read(30, alternating(1500, 2)), read(35, alternating(5120, 1)), read(37, alternating(5121, 2)),
+    rows = [read(10, alternating(1024, 1)), read(20, alternating(1025, 1)), read(30, alternating(1500, 2)), read(35, alternating(5120, 1)), read(37, alternating(5121, 2)), read(38, alternating(13500, 1)), read(39, alternating(13501, 1)),
             read(40, [(0, 5), (6, 1), (1, 2), (0, 7), (2, 1), (0, 9), (1, 1), (0, 4)]),          # P
             read(50, [(7, 5), (1, 2), (0, 7), (2, 1), (8, 3), (0, 9), (1, 1), (0, 4)]),          # = and X
             read(70, [(0, 5), (1, 2), (0, 7), (2, 1), (0, 9), (1, 1), (0, 4)])]
