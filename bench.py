@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300, help="timed steps (300 x ~7 ms: a timed region above 2 s)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--mode", default="weak", choices=["weak", "strong", "sites"])
-    ap.add_argument("--config", default=None, choices=["wgs30x", "tumor200x", "wgs30x_mixed", "long10k", "ont", "ont_ul"], help="data model (default: wgs30x; tumor200x for --mode strong; wgs30x_mixed: config 3 with 30 %% of the reads trimmed to U[100,149] and 10 %% 250 bases long; long10k: 10-kb reads at 30x; ont: 3-10-kb reads with an insertion or deletion every ~15 bases at 30x (use --contig-mbp 20); ont_ul: the same with 30-70-kb reads — functional and throughput points outside BASELINE's configurations)")
+    ap.add_argument("--config", default=None, choices=["wgs30x", "tumor200x", "wgs30x_mixed", "long10k", "ont", "ont_ul"], help="data model (default: wgs30x; tumor200x for --mode strong; wgs30x_mixed: config 3 with 30 %% of the reads trimmed to U[100,149] and 10 %% 250 bases long; long10k: 10-kb reads at 30x; ont: 3-10-kb reads with an insertion or deletion every ~15 bases at 30x (use --contig-mbp 20); ont_ul: the same with 30-100-kb reads — functional and throughput points outside BASELINE's configurations)")
     ap.add_argument("--contig-mbp", type=float, default=50.0, help="weak/sites: contig per GPU; strong: the whole contig")
     ap.add_argument("--sites", type=int, default=100000, help="--mode sites: lines of the site list (all ranks together)")
     ap.add_argument("--cpu-sample-mbp", type=float, default=8.0, help="prefix timed with the 1-thread CPU oracle and used for validation (0 = skip)")
@@ -597,7 +597,7 @@ def main():
         if config == "long10k":
             what = "synthetic 30x, 10-kb reads (30 %% with an insertion, 30 %% with a deletion), 1 contig %.0f Mbp per GPU, -q20 -b13 — not one of BASELINE's configurations" % (contig_len / 1e6)
         if config in ("ont", "ont_ul"):
-            what = "synthetic 30x, %s reads with an insertion or a deletion every ~15 bases (%.0f CIGAR operators per read; ONT / CLR-like), 1 contig %.0f Mbp per GPU, -q20 -b13 — not one of BASELINE's configurations" % ("3-10-kb" if config == "ont" else "30-70-kb", float(arrs["n_cigar"].mean()), contig_len / 1e6)
+            what = "synthetic 30x, %s reads with an insertion or a deletion every ~15 bases (%.0f CIGAR operators per read; ONT / CLR-like), 1 contig %.0f Mbp per GPU, -q20 -b13 — not one of BASELINE's configurations" % ("3-10-kb" if config == "ont" else "30-100-kb", float(arrs["n_cigar"].mean()), contig_len / 1e6)
         if config == "tumor200x" and args.mode == "weak":
             what = "synthetic 200x tumor 4 libraries, 150bp reads, -p -i, 1 contig %.2f Mbp per GPU" % (contig_len / 1e6)
         if rank_check is not None:

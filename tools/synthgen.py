@@ -154,8 +154,8 @@ def generate(contig_len, config="wgs30x", seed=1, n_chunks=64):
 
 # reads with an operator every ~15 bases (ONT / CLR-like alignments): 3-10 kb, 30x — the regime the tile compaction exists for
 DENSE = {"ont": dict(depth=30.0, len_min=3000, len_max=10000, op_gap=15.0, indel_max=3, p_sub=0.01, n_libs=1),
-         # ultra-long reads: 30-70 kb, 2 000-4 700 M operators each (the wave-form annotator's one-wave-per-workgroup instantiation)
-         "ont_ul": dict(depth=30.0, len_min=30000, len_max=70000, op_gap=15.0, indel_max=3, p_sub=0.01, n_libs=1)}
+         # ultra-long reads: 30-100 kb, 2 000-6 600 M operators each (the wave-form annotator's one-wave-per-workgroup and one-wave-per-CU instantiations)
+         "ont_ul": dict(depth=30.0, len_min=30000, len_max=100000, op_gap=15.0, indel_max=3, p_sub=0.01, n_libs=1)}
 
 
 def generate_dense(contig_len, config="ont", seed=1, n_chunks=64):
