@@ -181,9 +181,10 @@ bool rans_decode(const uint8_t* in, size_t n, size_t expect, std::vector<uint8_t
 // public API, resolved with dlopen on first use)
 bool bz2_decode(const uint8_t* in, size_t n, std::vector<uint8_t>* out, std::string* err) {
     typedef int (*Fn)(char*, unsigned*, char*, unsigned, int, int);
-    static Fn fn = nullptr; static bool tried = false;
-    if (!tried) { tried = true; void* h = dlopen("libbz2.so.1.0", RTLD_NOW); if (!h) h = dlopen("libbz2.so.1", RTLD_NOW); if (!h) h = dlopen("libbz2.so", RTLD_NOW);
-                  if (h) fn = (Fn)dlsym(h, "BZ2_bzBuffToBuffDecompress"); }
+    // (looked up once, by whichever thread comes first — several readers decode stripes of one piece side by side: a function-local
+    // static's initialisation is the lock)
+    static const Fn fn = []() -> Fn { void* h = dlopen("libbz2.so.1.0", RTLD_NOW); if (!h) h = dlopen("libbz2.so.1", RTLD_NOW); if (!h) h = dlopen("libbz2.so", RTLD_NOW);
+                                      return h ? (Fn)dlsym(h, "BZ2_bzBuffToBuffDecompress") : (Fn)nullptr; }();
     if (!fn) { *err = "CRAM bzip2 block: libbz2 is not available on this system"; return false; }
     unsigned len = (unsigned)out->size();
     if (fn((char*)out->data(), &len, (char*)in, (unsigned)n, 0, 0) != 0 || len != out->size()) { *err = "CRAM bzip2 block decompression failed"; return false; }
@@ -191,9 +192,8 @@ bool bz2_decode(const uint8_t* in, size_t n, std::vector<uint8_t>* out, std::str
 }
 bool lzma_decode(const uint8_t* in, size_t n, std::vector<uint8_t>* out, std::string* err) {
     typedef int (*Fn)(uint64_t*, uint32_t, const void*, const uint8_t*, size_t*, size_t, uint8_t*, size_t*, size_t);
-    static Fn fn = nullptr; static bool tried = false;
-    if (!tried) { tried = true; void* h = dlopen("liblzma.so.5", RTLD_NOW); if (!h) h = dlopen("liblzma.so", RTLD_NOW);
-                  if (h) fn = (Fn)dlsym(h, "lzma_stream_buffer_decode"); }
+    static const Fn fn = []() -> Fn { void* h = dlopen("liblzma.so.5", RTLD_NOW); if (!h) h = dlopen("liblzma.so", RTLD_NOW);
+                                      return h ? (Fn)dlsym(h, "lzma_stream_buffer_decode") : (Fn)nullptr; }();
     if (!fn) { *err = "CRAM lzma block: liblzma is not available on this system"; return false; }
     uint64_t memlimit = UINT64_MAX; size_t ip = 0, op = 0;
     if (fn(&memlimit, 0, nullptr, in, &ip, n, out->data(), &op, out->size()) != 0 || op != out->size()) { *err = "CRAM lzma block decompression failed"; return false; }

@@ -627,6 +627,14 @@ def test_cli_striped_cram_fetch_equals_single_reader_cpu(synthetic_bam):
             got = subprocess.run(base[:1] + ["--brc-chunk", chunk] + base[1:], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
             assert got.returncode == 0, got.stderr
             assert got.stdout == want.stdout and got.stderr == want.stderr, (extra, threads, chunk)
+    # the other CRAM files of the fixture — every block method and integer codec, embedded reference slices found through a .crai, a
+    # reference-less file — in stripes against one reader
+    for f in ("syn_rans.cram", "syn_emb.cram", "syn_noref.cram"):
+        base = [SIM_CLI, "-w", "0", "-p", "-f", "syn.fa", f, "chrA", "chrB:100-2900"]
+        want = subprocess.run(base, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, BRC_FETCH_STRIPE_MIN="1000000000"))
+        got = subprocess.run(base[:1] + ["--brc-chunk", "900"] + base[1:], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, BRC_FETCH_STRIPE_MIN="1", BRC_FETCH_THREADS="5"))
+        assert want.returncode == 0 and got.returncode == 0 and want.stdout.count(b"\n") > 6000, (f, want.stderr, got.stderr)
+        assert got.stdout == want.stdout and got.stderr == want.stderr, f
 
 
 def test_cli_striped_parallel_fetch_equals_single_handle_cpu(synthetic_bam, workdir):
