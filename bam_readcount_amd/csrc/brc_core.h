@@ -812,6 +812,7 @@ BRC_HD void pack_unpack(const PackAcc& a, uint32_t b, uint32_t sh /* DevCfg.pack
 #define BRC_HALF 12
 #endif
 enum { HALF = BRC_HALF };
+static_assert(255 * HALF < (1 << 12), "a half-batch of mapping qualities of 255 must fit the 12-bit narrow field (choose_pack: lim_lo >= 255)");
 BRC_HD void choose_pack(int32_t max_lqseq, int32_t k_override, int32_t lim_override, int32_t& K, uint32_t& lim, uint32_t& lim_lo, int32_t& shift) {
     const int32_t m = max_lqseq < 255 ? 255 : max_lqseq;
     if ((int64_t)m * HALF <= 65535) { shift = 16; K = 65535 / m; if (K > 127) K = 127; }

@@ -2048,7 +2048,7 @@ class HipBackend : public Backend {
     enum { COMPACT_PIECES_PER_READ = 12 };
     bool compact_on = false; uint64_t compact_total = 0; bool compact_sized = false;
     bool wave_on = false;                      // this region's reads with more than two M operators go to k_annotate_wave
-    bool wave_big = false;                     // ... and some may have more than AW_MCAP M operators (a read with more than 2 AW_MCAP operators exists)
+    bool wave_big = false;                     // ... and some may have more than AW_MCAP M operators (a read with more than AW_MCAP operators exists)
     enum { WAVE_FORM_BLOCKS = 768,             // its fixed grid: 3 blocks of 4 waves per CU (48 KB of LDS each)
            WAVE_FORM_BLOCKS_BIG = 512,         // the one-wave instantiation: 2 blocks per CU (60 KB of LDS each)
            WAVE_FORM_BLOCKS_HUGE = 256 };      // one block per CU (158 KB of LDS)
@@ -2238,8 +2238,11 @@ class HipBackend : public Backend {
         // reads with more than two M operators are annotated a wave per read (k_annotate_wave); TK_WAVE_FORM=0 keeps them on K1's serial path
         wave_on = n > 0 && c.has_ref && s.max_ncigar >= 5;                          // (three M operators take at least five operators)
         if (const char* wk = test_knob(TK_WAVE_FORM)) wave_on = wave_on && atoi(wk) != 0;
-        wave_big = wave_on && s.max_ncigar > 2u * (uint32_t)AW_MCAP;
-        wave_huge = wave_on && s.max_ncigar > 2u * (uint32_t)AW_MCAP_BIG;
+        // (k_pick_wave sorts the reads by their count of M operators, which the host does not keep: a read can have that many only with at
+        // least as many operators — adjacent M operators are legal —, so the operator count decides which instantiations are launched; one
+        // whose list stays empty costs a launch)
+        wave_big = wave_on && s.max_ncigar > (uint32_t)AW_MCAP;
+        wave_huge = wave_on && s.max_ncigar > (uint32_t)AW_MCAP_BIG;
         if (wave_on) { HIPCHK(d_wavelist.ensure((2 * (size_t)n + 48) * sizeof(uint32_t))); HIPCHK(d_nc_k1.ensure(((size_t)n + 16) * sizeof(uint32_t))); }
         HIPCHK(d_libbase.ensure((lib_base.size() + 1) * sizeof(int64_t)));
         if (!lib_base.empty()) HIPCHK(hipMemcpyAsync(d_libbase.p, lib_base.data(), lib_base.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));

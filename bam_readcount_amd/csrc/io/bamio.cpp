@@ -370,6 +370,46 @@ bool BamIndex::load_csi(const std::string& path) {
     return true;
 }
 
+double BamIndex::span_bytes(int tid, int64_t beg, int64_t end) const {
+    if (tid < 0 || (size_t)tid >= refs_.size()) return -1.0;
+    const Ref& r = refs_[(size_t)tid];
+    if (!r.woff_built) {
+        // compressed file offset of the first record overlapping every window (virtual offset >> 16); windows without one (zero in
+        // older BAI files, no bin in a CSI) take the next window's; one more edge behind the last window, a window's worth further
+        std::vector<uint64_t> lin;
+        if (!csi_) lin = r.linear;
+        else {
+            const uint32_t leaf0 = (uint32_t)(((1ull << (3 * depth_)) - 1) / 7);
+            for (const auto& kv : r.loffset) if (kv.first >= leaf0 && kv.first - leaf0 < (1u << 24)) { const size_t w = (size_t)(kv.first - leaf0); if (lin.size() <= w) lin.resize(w + 1, 0); lin[w] = kv.second; }
+        }
+        std::vector<double>& o = r.woff; o.clear();
+        if (!lin.empty()) {
+            o.resize(lin.size() + 1);
+            uint64_t next = 0; bool have = false;
+            for (size_t i = lin.size(); i-- > 0;) { if (lin[i]) { next = lin[i]; have = true; } o[i] = have ? (double)(next >> 16) : -1.0; }
+            double last = 0; for (size_t i = 0; i < lin.size(); ++i) if (o[i] >= 0) last = o[i];
+            for (size_t i = 0; i < lin.size(); ++i) if (o[i] < 0) o[i] = last;                   // (trailing windows without records)
+            for (size_t i = 1; i < lin.size(); ++i) if (o[i] < o[i - 1]) o[i] = o[i - 1];           // monotone (an index written out of order)
+            const double step = lin.size() > 1 ? (o[lin.size() - 1] - o[0]) / (double)(lin.size() - 1) : 65536.0;
+            o[lin.size()] = o[lin.size() - 1] + (step > 0 ? step : 0);
+        }
+        r.woff_built = true;
+    }
+    const std::vector<double>& o = r.woff;
+    if (o.size() < 2) return -1.0;
+    const int shift = csi_ ? min_shift_ : 14;
+    auto at = [&](int64_t x) {
+        if (x < 0) x = 0;
+        const int64_t nw = (int64_t)o.size() - 1;
+        const int64_t w = x >> shift;
+        if (w >= nw) return o[(size_t)nw];
+        const double f = (double)(x - (w << shift)) / (double)(1ll << shift);
+        return o[(size_t)w] + (o[(size_t)w + 1] - o[(size_t)w]) * f;
+    };
+    const double v = at(end) - at(beg);
+    return v > 0 ? v : 0.0;
+}
+
 std::vector<Chunk> BamIndex::query(int tid, int64_t beg, int64_t end) const {
     std::vector<Chunk> out;
     if (tid < 0 || (size_t)tid >= refs_.size() || end <= beg) return out;

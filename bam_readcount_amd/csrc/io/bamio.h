@@ -82,10 +82,16 @@ class BamIndex {
     bool load(const std::string& bam_path);        // <bam>.bai, <bam minus .bam>.bai, then <bam>.csi (SAMv1 5.2 / CSIv1)
     // chunks (virtual offset ranges) that may hold records overlapping [beg,end) on tid, merged and sorted
     std::vector<Chunk> query(int tid, int64_t beg, int64_t end) const;
+    // Estimated compressed bytes of the records that START in [beg, end) of tid: differences of the file offsets the index keeps per
+    // window (BAI: the 16-kb linear index; CSI: the left offsets of its finest bins), linear inside a window.  What a caller that has
+    // nothing but the index can balance work by ("balanced by estimated event count — BAI linear-index / chunk sizes").
+    // < 0: the index holds no such offsets for this contig.
+    double span_bytes(int tid, int64_t beg, int64_t end) const;
     const std::string& error() const { return err_; }
 
   private:
-    struct Ref { std::map<uint32_t, std::vector<Chunk> > bins; std::vector<uint64_t> linear; std::map<uint32_t, uint64_t> loffset; };
+    struct Ref { std::map<uint32_t, std::vector<Chunk> > bins; std::vector<uint64_t> linear; std::map<uint32_t, uint64_t> loffset;
+                 mutable std::vector<double> woff; mutable bool woff_built = false; };      // span_bytes: compressed offset at every window edge (built on first use)
     bool load_csi(const std::string& path);
     std::vector<Ref> refs_;
     int min_shift_ = 14, depth_ = 5;               // BAI's fixed binning; a CSI file carries its own

@@ -14,6 +14,11 @@
 // pieces, site-list batches — are dealt out in file order and their text is written in file order).  Every engine
 // pipelines consecutive pieces: piece k is formatted and written while piece k+1 is staged and on the GPU and piece k+2
 // is being decoded.
+//
+// --brc-ranks N (one rank per GPU): the command line becomes N PROCESSES, started before any of them has touched
+// the HIP runtime; rank r binds to GPU devices[r] and to its share of the CPUs, takes a contiguous, event-weighted slice of the
+// work list IN FILE ORDER (the rule of shard.partition; weights from the index's file offsets, BamIndex::span_bytes) and prints
+// it; the coordinating process writes the ranks' text and stderr in rank order — see "ranks" below.
 #include <errno.h>
 #include <limits.h>
 #include <stdio.h>
@@ -44,6 +49,9 @@ struct Options {
     long long plan_sites = 4096;    // site-list planner: -l lines batched per engine pass (0 = one pass per line): --brc-plan
     long long gpus = 1;             // GPUs: --brc-gpus
     long long streams = 0;          // engines per GPU (0: one; every engine already overlaps decode | GPU | format of consecutive pieces): --brc-streams
+    long long ranks = 0;            // processes, one per GPU: --brc-ranks (BRC_RANKS)
+    std::string rank_of;            // "r:N": this process IS rank r of N (what the coordinating process starts its children with): --brc-rank-of
+    std::string tmpdir;             // where the ranks behind the first keep their text until its turn comes: --brc-tmpdir (TMPDIR, /tmp)
 };
 
 static const char* kUsage =
@@ -76,6 +84,7 @@ static const OptSpec kSpecs[] = {
     {'h', "help", false}, {'v', "version", false}, {'q', "min-mapping-quality", true}, {'b', "min-base-quality", true},
     {'d', "max-count", true}, {'l', "site-list", true}, {'f', "reference-fasta", true}, {'D', "print-individual-mapq", true},
     {'p', "per-library", false}, {'w', "max-warnings", true}, {'i', "insertion-centric", false}, {0, "brc-chunk", true}, {1, "brc-plan", true}, {2, "brc-gpus", true}, {3, "brc-streams", true},
+    {4, "brc-ranks", true}, {5, "brc-rank-of", true}, {6, "brc-tmpdir", true},
 };
 
 static bool apply(Options& o, const OptSpec& sp, const std::string& v, std::string* err) {
@@ -104,6 +113,9 @@ static bool apply(Options& o, const OptSpec& sp, const std::string& v, std::stri
         case 1: if (!to_ll(&x)) return false; o.plan_sites = x; return true;
         case 2: if (!to_ll(&x)) return false; o.gpus = x; return true;
         case 3: if (!to_ll(&x)) return false; o.streams = x; return true;
+        case 4: if (!to_ll(&x)) return false; o.ranks = x; return true;
+        case 5: o.rank_of = v; return true;
+        case 6: o.tmpdir = v; return true;
         default: if (!to_ll(&x)) return false; o.chunk_bp = x; return true;
     }
 }
@@ -230,6 +242,8 @@ static double now_s() { return std::chrono::duration<double>(std::chrono::steady
 // CPUs this process may really use at once: hardware threads capped by a cgroup CPU quota (a container with 16 CPUs of
 // quota on a 256-thread host is throttled for most of every period if its pools are sized by the hardware)
 static unsigned g_engines = 1;            // engines of this process (they share the CPUs)
+static unsigned g_ranks = 1;              // --brc-ranks: processes side by side on this node; each sizes its pools by its share of the CPUs (set before the first effective_cpus())
+static int g_rank = -1;                   // this process's rank (-1: not one of a group)
 static std::atomic<unsigned> g_format_threads{0};   // formatter threads per engine when several engines share the process (0: the engine's default)
 static unsigned effective_cpus() {
     // (worker threads call this: a function-local static is initialised once, thread-safely)
@@ -247,6 +261,7 @@ static unsigned effective_cpus() {
             if (q > 0 && per > 0) quota = (double)q / (double)per;
         }
         if (quota > 0 && quota < (double)n) n = (unsigned)(quota + 0.999);
+        if (g_ranks > 1) n = (n + g_ranks - 1) / g_ranks;              // one rank's share
         return n < 1 ? 1u : n;
     }();
     return cached;
@@ -297,6 +312,11 @@ static void write_parts(const char* const* parts, const size_t* lens, size_t n) 
     }
 }
 
+// Reads of one chunk [a-1, b) (the reference's own fetch rule, :602), decoded by a pool of BAM handles: see fetch_chunk
+struct Fetched { std::vector<Batcher> parts; bool ok = true; std::string err; unsigned uses = 0; bool allow_pinned = false;
+                 std::vector<std::unique_ptr<BamReader> > pool;      // the BAM handles of this buffer's stripes (fetches of different buffers run side by side)
+                 std::vector<std::unique_ptr<CramReader> > cram_pool; };   // ... or its CRAM readers
+
 struct Ctx {
     double t_fetch = 0, t_engine = 0, t_format = 0, t_write = 0;   // BRC_CLI_TIMING=1 prints them on stderr
     double t_site_fetch = 0, t_site_fetch_threads = 0, t_site_layout = 0, t_site_engine = 0, t_site_format = 0; uint64_t n_site_lines = 0, n_site_clusters = 0, n_site_reads = 0, n_site_batches = 0;   // the site-list planner's own account
@@ -313,9 +333,17 @@ struct Ctx {
     std::string* out_buf = nullptr; std::string* err_buf = nullptr;
     std::string* wev_buf = nullptr;       // tagged warning events of the item (several engines) — else they are printed at once
     int64_t wcount[BRC_N_WARN] = {0, 0, 0, 0};   // ReadWarnings' counters (the main context's are the global ones)
+    // a rank behind the first: its warning events travel to the coordinating process as they are, one per stderr line behind a
+    // 0x01 byte — ReadWarnings' counters are global (-w caps every type across the whole run), so the process that sees the
+    // ranks' streams in file order applies them
+    bool tag_warnings = false;
     void warn_events(const char* ev, size_t n) {
         if (!n) return;
         if (wev_buf) { wev_buf->append(ev, n); return; }
+        if (tag_warnings) {
+            for (size_t i = 0; i < n;) { size_t j = i; while (j < n && ev[j] != '\n') ++j; fputc(1, stderr); fwrite(ev + i, 1, j - i, stderr); fputc('\n', stderr); i = j + 1; }
+            return;
+        }
         print_warn_events(ev, n, opt.max_warnings, wcount, stderr);
     }
     void emit(const char* t, size_t n) { if (!n) return; if (out_buf) out_buf->append(t, n); else fwrite(t, 1, n, stdout); }
@@ -332,7 +360,11 @@ struct Ctx {
     }
     // several engines: the reads of this engine's next piece, fetched while the current piece is on the GPU / being formatted
     struct Prefetch { bool valid = false; int tid = 0; int64_t a = 0, b = 0; } pf;
-    std::unique_ptr<struct Fetched> pf_buf;
+    std::unique_ptr<Fetched> pf_buf;
+    // run_region's fetch buffers.  They outlive the call: the engine may still hold pointers into the page-locked arenas of the last piece
+    // it adopted (brc_push_reads_pinned: valid until the next brc_begin_region or brc_destroy, include/brc.h), and the next region finds
+    // its handles open and its arenas pinned
+    std::vector<Fetched> bufs;
     void complain(const std::string& m) { if (err_buf) err_buf->append(m); else fputs(m.c_str(), stderr); }
 };
 
@@ -348,9 +380,6 @@ static int lib_index(const Ctx& c, const BamRecord& r) {      // bam_get_library
 // Reads of one chunk [a-1, b) (the reference's own fetch rule, :602), decoded by a pool of BAM handles: the chunk is cut
 // by read START position into K stripes; stripe i keeps the records whose pos lies in its stripe (stripe 0 also the reads
 // that start before the chunk), so the stripes concatenated are exactly the single-handle fetch, in file order.
-struct Fetched { std::vector<Batcher> parts; bool ok = true; std::string err; unsigned uses = 0; bool allow_pinned = false;
-                 std::vector<std::unique_ptr<BamReader> > pool;      // the BAM handles of this buffer's stripes (fetches of different buffers run side by side)
-                 std::vector<std::unique_ptr<CramReader> > cram_pool; };   // ... or its CRAM readers
 
 static long long stripe_min_bp() { static const long long v = getenv("BRC_FETCH_STRIPE_MIN") ? atoll(getenv("BRC_FETCH_STRIPE_MIN")) : 65536; return v; }   // (tests force small chunks into stripes)
 static void fetch_chunk(Ctx& c, int tid, int64_t a, int64_t b, Fetched& out) {
@@ -369,12 +398,8 @@ static void fetch_chunk(Ctx& c, int tid, int64_t a, int64_t b, Fetched& out) {
     // uploads them in place (run_region: brc_push_reads_pinned)
     static const bool zero_copy = !(getenv("BRC_ZERO_COPY") && atoi(getenv("BRC_ZERO_COPY")) == 0);
     if (zero_copy && out.allow_pinned && out.uses++ > 0) for (Batcher& p : out.parts) if (p.seen_qual) p.use_pinned();
-    if (c.is_cram && K == 1) {
-        auto add = [&](const BamRecord& r) { out.parts[0].add(r, c.opt.per_lib ? lib_index(c, r) : 0); };
-        if (!c.cram.fetch(tid, a - 1, b, add)) { out.ok = false; out.err = c.cram.error(); }
-        return;
-    }
     if (c.is_cram) {
+        // (also a piece too short for stripes, K == 1: a reader of this BUFFER, never the context's one — two pieces are fetched side by side)
         // stripes of a CRAM piece: a reader of its own per stripe (a stripe decodes the slices that overlap it — a slice that straddles a
         // stripe boundary twice — and keeps the records that START in it); the contig's bases, which run_region holds, are shared
         while (out.cram_pool.size() < K) {
@@ -433,10 +458,10 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
     const int64_t chunk = (int64_t)c.opt.chunk_bp;
     const int64_t npieces = std::max<int64_t>(1, (end - beg0 + chunk - 1) / chunk);
     static const int ahead_env = getenv("BRC_FETCH_AHEAD") ? atoi(getenv("BRC_FETCH_AHEAD")) : 0;
-    // (a CRAM piece that is too short for stripes goes through the context's one reader: one fetch at a time)
-    const int ahead = (c.is_cram && chunk < stripe_min_bp()) ? 1 : (ahead_env > 0 ? ahead_env : 2);
-    std::vector<Fetched> bufs((size_t)ahead + 1); std::vector<std::thread> fth((size_t)ahead + 1);
-    for (Fetched& f : bufs) f.allow_pinned = npieces > (int64_t)ahead + 1;        // (only a run of pieces reuses its buffers)
+    const int ahead = ahead_env > 0 ? ahead_env : 2;
+    std::vector<Fetched>& bufs = c.bufs; if (bufs.size() < (size_t)ahead + 1) bufs.resize((size_t)ahead + 1);
+    std::vector<std::thread> fth((size_t)ahead + 1);
+    for (Fetched& f : bufs) { if (npieces > (int64_t)ahead + 1) f.allow_pinned = true; }        // (only a run of pieces reuses its buffers)
     auto start_fetch = [&](int64_t j) {
         if (j >= npieces) return;
         const size_t slot = (size_t)(j % (ahead + 1));
@@ -844,28 +869,253 @@ static void crash_handler(int sig) {
     signal(sig, SIG_DFL); raise(sig);
 }
 
+// ---------------------------------------------------------------- ranks: one process per GPU
+// `bam-readcount --brc-ranks N ...` (or BRC_RANKS=N): this process becomes the COORDINATOR.  It never touches the HIP runtime: it
+// starts N copies of itself (`--brc-rank-of r:N`), each a fresh process that binds to one GPU (BRC_DEVICES=a,b,.. names them, default
+// 0..N-1; the child sees only its own through HIP_VISIBLE_DEVICES) and to its share of the CPUs, builds the same work list from the
+// same files, cuts it — in FILE ORDER — into N contiguous slices of near-equal estimated work (the index's file offsets per 16-kb
+// window: BamIndex::span_bytes) and runs its own slice exactly like a single process would.  No data-path exchange: a line depends on
+// nothing but the reads over its position (and the position before it, which every piece fetches itself, bamreadcount.cpp:602);
+// overlapping and repeated -l lines are printed as often as the list names them (:574-608), the deletion queue is cleared per line
+// (:605).  Rank 0 writes to this process's stdout and stderr directly; the ranks behind it write into unlinked temporary files
+// (--brc-tmpdir, TMPDIR, /tmp) which the coordinator copies to stdout in rank order, following rank r's file while it is still being
+// written once the ranks before it are done (stdout /dev/null: they write there themselves).  stderr of those ranks arrives line by
+// line, warning events tagged so that ReadWarnings' -w counters run over the whole run in file order.  A rank that fails ends the run
+// where the reference would have stopped: the text of the ranks before it is out, the ranks behind it are stopped and their text dropped.
+// Several command-line regions in one run stay one process: a deletion left pending by one region can hold back the deletions of every
+// region behind it (the reference does not clear its queue there, :641-657), which only a process that has seen them all can know.
+#include <sys/stat.h>
+#include <sys/sysmacros.h>
+#include <sys/sendfile.h>
+#include <sys/wait.h>
+#include <sched.h>
+
+static bool parse_rank_of(const std::string& v, int* r, int* n) {
+    const size_t c = v.find(':');
+    if (c == std::string::npos) return false;
+    char* e = nullptr; const long a = strtol(v.c_str(), &e, 10); if (e != v.c_str() + c) return false;
+    const long b = strtol(v.c_str() + c + 1, &e, 10); if (*e || e == v.c_str() + c + 1) return false;
+    if (b < 1 || b > 4096 || a < 0 || a >= b) return false;
+    *r = (int)a; *n = (int)b; return true;
+}
+
+static bool write_all(int fd, const char* p, size_t n) {
+    while (n) { const ssize_t w = write(fd, p, n); if (w < 0) { if (errno == EINTR || errno == EAGAIN) continue; return false; } p += w; n -= (size_t)w; }
+    return true;
+}
+
+static int coordinate(int argc, char** argv, const Options& o, int N) {
+    const double t0 = now_s();
+    // GPUs of the ranks
+    std::vector<int> devs;
+    if (const char* dv = getenv("BRC_DEVICES")) { for (const char* q = dv; *q;) { devs.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q) ++q; } }
+    if (devs.empty()) for (int g = 0; g < N; ++g) devs.push_back(g);
+    std::vector<std::string> visible;               // the caller's own HIP_VISIBLE_DEVICES: rank r's GPU is the devs[r]-th entry of it
+    if (const char* hv = getenv("HIP_VISIBLE_DEVICES")) { std::string cur; for (const char* q = hv;; ++q) { if (*q == ',' || !*q) { visible.push_back(cur); cur.clear(); if (!*q) break; } else cur.push_back(*q); } }
+    const bool narrow = !(getenv("BRC_RANK_NARROW") && atoi(getenv("BRC_RANK_NARROW")) == 0);
+    struct stat st; const bool to_null = fstat(1, &st) == 0 && S_ISCHR(st.st_mode) && major(st.st_rdev) == 1 && minor(st.st_rdev) == 3;
+    std::string tdir = !o.tmpdir.empty() ? o.tmpdir : (getenv("TMPDIR") && *getenv("TMPDIR") ? getenv("TMPDIR") : "/tmp");
+    auto tmpfd = [&]() -> int {
+        std::string path = tdir + "/brc_rank_XXXXXX";
+        std::vector<char> b(path.begin(), path.end()); b.push_back(0);
+        const int fd = mkstemp(b.data());
+        if (fd >= 0) unlink(b.data());
+        return fd;
+    };
+    struct Child { pid_t pid = -1; int out = -1, err = -1, status = -1; bool reaped = false; int wstatus = 0; };
+    std::vector<Child> ch((size_t)N);
+    fflush(stdout); fflush(stderr);
+    for (int r = 0; r < N; ++r) {
+        Child& c = ch[(size_t)r];
+        int sp[2];
+        if (pipe(sp) != 0) { fprintf(stderr, "bam-readcount: cannot create a pipe for rank %d: %s\n", r, strerror(errno)); return 1; }
+        if (r > 0) {
+            if (!to_null) { c.out = tmpfd(); if (c.out < 0) { fprintf(stderr, "bam-readcount: cannot create a temporary file in %s for the text of rank %d: %s (--brc-tmpdir)\n", tdir.c_str(), r, strerror(errno)); return 1; } }
+            c.err = tmpfd(); if (c.err < 0) { fprintf(stderr, "bam-readcount: cannot create a temporary file in %s: %s (--brc-tmpdir)\n", tdir.c_str(), strerror(errno)); return 1; }
+        }
+        const pid_t pid = fork();
+        if (pid < 0) { fprintf(stderr, "bam-readcount: cannot start rank %d: %s\n", r, strerror(errno)); return 1; }
+        if (pid == 0) {
+            // the child: its text and stderr where the coordinator will look for them, its GPU, then a fresh image of this program
+            close(sp[0]);
+            if (r > 0) {
+                if (c.out >= 0) dup2(c.out, 1);
+                dup2(c.err, 2);
+            }
+            for (int k = 0; k < r; ++k) { if (ch[(size_t)k].status >= 0) close(ch[(size_t)k].status); }
+            const int dev = devs[(size_t)r % devs.size()];
+            char b[64];
+            if (narrow) {
+                if (!visible.empty()) { if ((size_t)dev < visible.size()) setenv("HIP_VISIBLE_DEVICES", visible[(size_t)dev].c_str(), 1); }
+                else { snprintf(b, sizeof b, "%d", dev); setenv("HIP_VISIBLE_DEVICES", b, 1); }
+                setenv("BRC_DEVICE", "0", 1);
+            } else { snprintf(b, sizeof b, "%d", dev); setenv("BRC_DEVICE", b, 1); }
+            unsetenv("BRC_DEVICES"); unsetenv("BRC_RANKS");
+            snprintf(b, sizeof b, "%d", sp[1]); setenv("BRC_RANK_STATUS_FD", b, 1);
+            std::vector<char*> av;
+            av.push_back(argv[0]);
+            std::string ro = "--brc-rank-of=" + std::to_string(r) + ":" + std::to_string(N);
+            av.push_back(&ro[0]);
+            for (int i = 1; i < argc; ++i) av.push_back(argv[i]);
+            av.push_back(nullptr);
+            execv("/proc/self/exe", av.data());
+            execvp(argv[0], av.data());
+            fprintf(stderr, "bam-readcount: cannot start rank %d: %s\n", r, strerror(errno));
+            _exit(127);
+        }
+        close(sp[1]);
+        c.pid = pid; c.status = sp[0];
+    }
+    auto reap = [&](Child& c, bool block) {
+        if (c.reaped) return true;
+        const pid_t w = waitpid(c.pid, &c.wstatus, block ? 0 : WNOHANG);
+        if (w == c.pid) c.reaped = true;
+        return c.reaped;
+    };
+    int ret = 0;
+    int64_t gcount[BRC_N_WARN] = {0, 0, 0, 0};
+    std::vector<double> secs((size_t)N, 0.0); std::vector<double> done_at((size_t)N, 0.0);
+    std::vector<char> buf((size_t)1 << 20);
+    const bool timing = getenv("BRC_CLI_TIMING") != nullptr;
+    for (int r = 0; r < N && !ret; ++r) {
+        Child& c = ch[(size_t)r];
+        if (r > 0 && c.out >= 0) {
+            // follow the rank's text: copy what is there, look whether the rank is done, copy the rest
+            off_t off = 0; bool use_sendfile = true;
+            for (;;) {
+                const bool finished = reap(c, false);
+                struct stat fs; if (fstat(c.out, &fs) != 0) break;
+                bool moved = false;
+                while (off < fs.st_size) {
+                    ssize_t w = -1;
+                    if (use_sendfile) { w = sendfile(1, c.out, &off, (size_t)std::min<off_t>(fs.st_size - off, (off_t)1 << 30)); if (w < 0 && (errno == EINVAL || errno == ENOSYS)) use_sendfile = false; else if (w < 0 && (errno == EINTR || errno == EAGAIN)) continue; else if (w < 0) { off = fs.st_size; break; } }
+                    if (!use_sendfile) {
+                        const ssize_t g = pread(c.out, buf.data(), (size_t)std::min<off_t>(fs.st_size - off, (off_t)buf.size()), off);
+                        if (g <= 0) { if (g < 0 && errno == EINTR) continue; off = fs.st_size; break; }
+                        if (!write_all(1, buf.data(), (size_t)g)) { off = fs.st_size; break; }     // (a closed pipe: like the reference, carry on silently)
+                        off += g;
+                    }
+                    moved = true;
+                }
+                if (finished) { struct stat f2; if (fstat(c.out, &f2) == 0 && f2.st_size > off) continue; break; }
+                if (!moved) usleep(500);
+            }
+        }
+        reap(c, true);
+        done_at[(size_t)r] = now_s() - t0;
+        // what the rank said when it ended: exit code, ReadWarnings' counters (rank 0 printed its own warnings), seconds
+        int rc = WIFEXITED(c.wstatus) ? WEXITSTATUS(c.wstatus) : 1;
+        {
+            std::string sline; char b[256]; ssize_t g;
+            while ((g = read(c.status, b, sizeof b)) > 0 || (g < 0 && errno == EINTR)) if (g > 0) sline.append(b, (size_t)g);
+            long long w[BRC_N_WARN] = {0, 0, 0, 0}; int src = 1; double s = 0;
+            if (sscanf(sline.c_str(), "%d %lld %lld %lld %lld %lf", &src, &w[0], &w[1], &w[2], &w[3], &s) == 6) { secs[(size_t)r] = s; if (r == 0) for (int k = 0; k < BRC_N_WARN; ++k) gcount[k] = w[k]; if (src && !rc) rc = src; }
+            else if (!rc) rc = 1;           // (a rank that ended without a word did not end well)
+        }
+        if (r > 0) {
+            // its stderr, in order: plain lines as they are, tagged warning events through the run's counters
+            fflush(stdout);
+            std::string all; ssize_t g; off_t eo = 0;
+            while ((g = pread(c.err, buf.data(), buf.size(), eo)) > 0 || (g < 0 && errno == EINTR)) if (g > 0) { all.append(buf.data(), (size_t)g); eo += g; }
+            for (size_t i = 0; i < all.size();) {
+                size_t j = i; while (j < all.size() && all[j] != '\n') ++j;
+                if (all[i] == 1) { std::string ev(all, i + 1, j - (i + 1)); ev.push_back('\n'); print_warn_events(ev.data(), ev.size(), o.max_warnings, gcount, stderr); }
+                else { fwrite(all.data() + i, 1, j - i, stderr); if (j < all.size()) fputc('\n', stderr); }
+                i = j + 1;
+            }
+        }
+        if (rc) ret = WIFSIGNALED(c.wstatus) ? 1 : (rc == 127 ? 1 : rc);
+        if (WIFSIGNALED(c.wstatus)) fprintf(stderr, "bam-readcount: rank %d ended on signal %d\n", r, WTERMSIG(c.wstatus));
+    }
+    // a failed run: the ranks behind the failure are stopped, their text is dropped
+    for (Child& c : ch) if (!c.reaped) { kill(c.pid, SIGTERM); }
+    for (Child& c : ch) reap(c, true);
+    if (timing) {
+        fprintf(stderr, "ranks: %d processes", N);
+        for (int r = 0; r < N; ++r) fprintf(stderr, "%s rank %d: %.3f s (its text was out after %.3f s)", r ? ";" : ":", r, secs[(size_t)r], done_at[(size_t)r]);
+        fprintf(stderr, "; all told %.3f s\n", now_s() - t0);
+    }
+    fflush(stdout); fflush(stderr);
+    return ret;
+}
+
+// the slice of `atoms` that rank r of n owns: contiguous, order-preserving, balanced by weight — shard.partition's rule (the atom that
+// crosses the r-th boundary goes to whichever side leaves the smaller excess)
+static void rank_slice(const std::vector<double>& w, int r, int n, size_t* lo, size_t* hi) {
+    const size_t m = w.size();
+    std::vector<double> cum(m); double t = 0; for (size_t i = 0; i < m; ++i) { t += w[i] > 1e-9 ? w[i] : 1e-9; cum[i] = t; }
+    size_t start = 0, stop = 0;
+    for (int k = 0; k <= r; ++k) {
+        start = stop;
+        if (k + 1 < n) {
+            const double target = t * (double)(k + 1) / (double)n;
+            stop = (size_t)(std::upper_bound(cum.begin(), cum.end(), target) - cum.begin());
+            if (stop < m && stop >= start && (cum[stop] - target) < (target - (stop > 0 ? cum[stop - 1] : 0.0))) ++stop;
+        } else stop = m;
+        if (stop < start) stop = start;
+        if (stop > m) stop = m;
+    }
+    *lo = start; *hi = stop;
+}
+
 int main(int argc, char** argv) {
     { struct sigaction sa; memset(&sa, 0, sizeof sa); sa.sa_handler = crash_handler; sigemptyset(&sa.sa_mask); sa.sa_flags = SA_RESETHAND;
       sigaction(SIGSEGV, &sa, nullptr); sigaction(SIGBUS, &sa, nullptr); sigaction(SIGABRT, &sa, nullptr); sigaction(SIGFPE, &sa, nullptr); }
     Ctx c; std::string err;
     if (!parse_args(argc, argv, c.opt, &err)) { fprintf(stderr, "bam-readcount: %s\n", err.c_str()); return 1; }
     const Options& o = c.opt;
-    if (o.version) { printf("bam-readcount version: 1.0.1-mi355x (engine %s, abi %d)\n", brc_engine_kind(), BRC_ABI_VERSION); return 1; }   // :467-470
-    if (o.help || o.bam.empty()) { fputs(kUsage, stdout); fputs("\n", stdout); return 1; }                                                   // :472-475
-    fprintf(stderr, "Minimum mapping quality is set to %d\n", o.min_mapq);                                                                 // :477
+    // ---- ranks: this process is one of a group, or starts one
+    int my_rank = -1, n_ranks = 1;
+    if (!o.rank_of.empty()) {
+        if (!parse_rank_of(o.rank_of, &my_rank, &n_ranks)) { fprintf(stderr, "bam-readcount: the argument ('%s') for option '--brc-rank-of' is invalid\n", o.rank_of.c_str()); return 1; }
+        g_ranks = (unsigned)n_ranks; g_rank = my_rank;
+        // this rank's share of the CPUs, as a contiguous slice of the ones the group may use (BRC_RANK_AFFINITY=0: left to the scheduler)
+        if (n_ranks > 1 && !(getenv("BRC_RANK_AFFINITY") && atoi(getenv("BRC_RANK_AFFINITY")) == 0)) {
+            cpu_set_t all; CPU_ZERO(&all);
+            if (sched_getaffinity(0, sizeof all, &all) == 0) {
+                std::vector<int> cpus; for (int k = 0; k < CPU_SETSIZE; ++k) if (CPU_ISSET(k, &all)) cpus.push_back(k);
+                if ((int)cpus.size() >= n_ranks) {
+                    cpu_set_t mine; CPU_ZERO(&mine);
+                    const size_t a = cpus.size() * (size_t)my_rank / (size_t)n_ranks, b = cpus.size() * (size_t)(my_rank + 1) / (size_t)n_ranks;
+                    for (size_t k = a; k < b; ++k) CPU_SET(cpus[k], &mine);
+                    (void)sched_setaffinity(0, sizeof mine, &mine);
+                }
+            }
+        }
+    }
+    const bool lead = my_rank <= 0;                 // the process whose informational lines reach the caller (a single process, or rank 0)
+    const int status_fd = getenv("BRC_RANK_STATUS_FD") ? atoi(getenv("BRC_RANK_STATUS_FD")) : -1;
     const double t_start = now_s();
-    if (!open_inputs(c, false)) return 1;
+    auto leave = [&](int rc) {                      // a rank tells the coordinator how it ended (exit code, ReadWarnings' counters, seconds)
+        if (my_rank >= 0 && status_fd >= 0) {
+            char b[256]; const int n = snprintf(b, sizeof b, "%d %lld %lld %lld %lld %.6f\n", rc, (long long)c.wcount[0], (long long)c.wcount[1], (long long)c.wcount[2], (long long)c.wcount[3], now_s() - t_start);
+            fflush(stdout); fflush(stderr);
+            write_all(status_fd, b, (size_t)n);
+        }
+        return rc;
+    };
+    if (o.version) { if (lead) printf("bam-readcount version: 1.0.1-mi355x (engine %s, abi %d)\n", brc_engine_kind(), BRC_ABI_VERSION); return leave(1); }   // :467-470
+    if (o.help || o.bam.empty()) { if (lead) { fputs(kUsage, stdout); fputs("\n", stdout); } return leave(1); }                                                   // :472-475
+    {
+        const long long want = o.ranks > 0 ? o.ranks : (getenv("BRC_RANKS") ? atoll(getenv("BRC_RANKS")) : 0);
+        // (several command-line regions: one process — see "ranks" above; -D ends the run before any work)
+        if (my_rank < 0 && want > 1 && !o.distribution && (!o.site_list.empty() || o.regions.size() == 1)) return coordinate(argc, argv, o, (int)std::min<long long>(want, 4096));
+    }
+    c.tag_warnings = my_rank > 0;
+    if (lead) fprintf(stderr, "Minimum mapping quality is set to %d\n", o.min_mapq);                                                                 // :477
+    if (!open_inputs(c, !lead)) return leave(1);
     const double t_inputs = now_s();
-    for (const std::string& l : c.header().expected) fprintf(stderr, "Expect library: %s in BAM\n", l.c_str());                                         // :526-529
-    if (o.distribution) { fprintf(stderr, "Not currently supporting distributions\n"); return 1; }                                          // :367 (the reference throws)
+    if (lead) for (const std::string& l : c.header().expected) fprintf(stderr, "Expect library: %s in BAM\n", l.c_str());                                         // :526-529
+    if (o.distribution) { if (lead) fprintf(stderr, "Not currently supporting distributions\n"); return leave(1); }                                          // :367 (the reference throws)
     // -d below any real depth changes which reads bam_plp_push keeps, and that depends on everything buffered before:
     // no internal pieces then (the planner is off for the same reason)
     if (o.max_cnt < 1000000) c.opt.chunk_bp = (long long)INT_MAX;
     // devices: BRC_DEVICES=0,2,3 or --brc-gpus N (devices 0..N-1); BRC_DEVICE=k for a single engine
     std::vector<int> devices;
-    if (const char* dv = getenv("BRC_DEVICES")) { for (const char* q = dv; *q;) { devices.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q) ++q; } }
+    if (my_rank < 0) if (const char* dv = getenv("BRC_DEVICES")) { for (const char* q = dv; *q;) { devices.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q) ++q; } }
+    if (my_rank >= 0) devices.push_back(getenv("BRC_DEVICE") ? atoi(getenv("BRC_DEVICE")) : 0);       // one rank, one GPU
     if (devices.empty()) for (long long g = 0; g < std::max<long long>(o.gpus, 1); ++g) devices.push_back((o.gpus <= 1 && getenv("BRC_DEVICE")) ? atoi(getenv("BRC_DEVICE")) : (int)g);
-    {   // K engines per GPU, GPU-major round robin (engine i -> GPU i mod #GPUs)
+    if (my_rank < 0) {   // K engines per GPU, GPU-major round robin (engine i -> GPU i mod #GPUs)
         long long K = o.streams > 0 ? o.streams : (getenv("BRC_STREAMS") ? atoll(getenv("BRC_STREAMS")) : 1);
         if (K < 1) K = 1;
         if (o.max_cnt < 1000000) K = 1;                  // (no internal pieces then)
@@ -892,6 +1142,11 @@ int main(int argc, char** argv) {
     struct JoinEng { std::thread& t; ~JoinEng() { if (t.joinable()) t.join(); } } join_eng{eng_thread};
 
     // ---- the work items, in file order
+    // (a rank of a group first lists ATOMS — one -l line, or one 64-kb piece of a region / wide line, each with a weight —, takes its
+    // slice of them and joins what lies side by side in it back into batches and regions: see below)
+    const bool atoms = my_rank >= 0 && n_ranks > 1;
+    // (64 kb: four windows of the index; BRC_RANK_CUT: tests cut their kilobase contigs finer)
+    const int64_t rank_cut = o.max_cnt < 1000000 ? (int64_t)INT_MAX : (getenv("BRC_RANK_CUT") && atoll(getenv("BRC_RANK_CUT")) > 0 ? (int64_t)atoll(getenv("BRC_RANK_CUT")) : (int64_t)65536);
     std::vector<Work> items;
     int ret = 0;
     auto add_region = [&](int tid, int64_t beg0, int64_t end, bool site_mode) {
@@ -900,11 +1155,12 @@ int main(int argc, char** argv) {
         const BamHeader& h = c.header();
         if (end > (int64_t)h.lengths[(size_t)tid] + 1000) end = (int64_t)h.lengths[(size_t)tid] + 1000;
         if (end < beg0) end = beg0;
-        const int64_t step = N > 1 ? (int64_t)c.opt.chunk_bp : (int64_t)INT_MAX;
+        const int64_t step = atoms ? rank_cut : (N > 1 ? (int64_t)c.opt.chunk_bp : (int64_t)INT_MAX);
         bool first = true;
         int64_t a = beg0;
         do {
-            const int64_t b = std::min<int64_t>(a + step, end);
+            // (atoms end on multiples of the cut: the index's windows, what the weights are known by)
+            const int64_t b = std::min<int64_t>(atoms && step < (int64_t)INT_MAX ? (a / step + 1) * step : a + step, end);
             Work w; w.kind = 0; w.tid = tid; w.beg0 = a; w.end = b; w.site_mode = site_mode && b >= end;
             w.keep_queue = first && !site_mode;       // a -l line starts from an empty queue (:605 cleared it after the previous line)
             w.inner_piece = !first;
@@ -914,8 +1170,8 @@ int main(int argc, char** argv) {
     };
     if (!o.site_list.empty()) {
         FILE* fp = fopen(o.site_list.c_str(), "r");
-        if (!fp) { fprintf(stderr, "Failed to open region list file: %s\n", o.site_list.c_str()); return 1; }            // :535-538
-        if (!c.is_cram && !c.idx.load(o.bam)) { fprintf(stderr, "BAM indexing file is not available.\n"); return 1; }                  // :548-551
+        if (!fp) { if (lead) fprintf(stderr, "Failed to open region list file: %s\n", o.site_list.c_str()); return leave(1); }            // :535-538
+        if (!c.is_cram && !c.idx.load(o.bam)) { if (lead) fprintf(stderr, "BAM indexing file is not available.\n"); return leave(1); }                  // :548-551
         // the planner needs -d to be out of play (its drop rule depends on what else is buffered) and narrow lines
         const bool plan = o.plan_sites > 0 && o.max_cnt >= 1000000 && !c.is_cram;
         Work pend; pend.kind = 1; int64_t pend_bp = 0;
@@ -940,7 +1196,7 @@ int main(int argc, char** argv) {
                 const int64_t clen = (int64_t)c.header().lengths[(size_t)st.tid];
                 if (st.end > clen + 1000) st.end = std::max<int64_t>(clen + 1000, st.beg0);
                 pend.sites.push_back(st); pend_bp += (st.end - st.beg0) + 600;
-                if ((long long)pend.sites.size() >= o.plan_sites || pend_bp > 4 * (int64_t)c.opt.chunk_bp) flush();
+                if (atoms || (long long)pend.sites.size() >= o.plan_sites || pend_bp > 4 * (int64_t)c.opt.chunk_bp) flush();
                 continue;
             }
             flush();
@@ -950,7 +1206,7 @@ int main(int argc, char** argv) {
         free(line);
         fclose(fp);
     } else if (!o.regions.empty()) {
-        if (!c.is_cram && !c.idx.load(o.bam)) { fprintf(stderr, "BAM indexing file is not available.\n"); return 1; }                  // :637-640
+        if (!c.is_cram && !c.idx.load(o.bam)) { if (lead) fprintf(stderr, "BAM indexing file is not available.\n"); return leave(1); }                  // :637-640
         for (const std::string& r : o.regions) {
             int tid; int64_t beg, end; std::string log;
             if (!parse_region(c.header(), r, &tid, &beg, &end, &log)) {              // :645-648: the regions before it have been printed
@@ -960,9 +1216,50 @@ int main(int argc, char** argv) {
             add_region(tid, beg, end, false);
         }
     } else {
-        fprintf(stderr, "bam-readcount: give a region or a site list (-l); the reference's whole-file mode skips its per-read "
-                        "pre-processing (bamreadcount.cpp:624 FIXME) and is not reproduced\n");
-        return 1;
+        if (lead) fprintf(stderr, "bam-readcount: give a region or a site list (-l); the reference's whole-file mode skips its per-read "
+                                  "pre-processing (bamreadcount.cpp:624 FIXME) and is not reproduced\n");
+        return leave(1);
+    }
+
+    if (atoms) {
+        // ---- this rank's slice of the atoms, in file order, by estimated work: the compressed bytes the index places under an atom —
+        // for a -l line, what its indexed fetch decodes: from the start of its 16-kb window to the line (bamio.h: span_bytes)
+        std::vector<double> w(items.size(), 0.0); bool known = !c.is_cram;
+        for (size_t i = 0; i < items.size() && known; ++i) {
+            const Work& a = items[i];
+            if (a.kind == 0) { w[i] = c.idx.span_bytes(a.tid, std::max<int64_t>(a.beg0 - 1, 0), std::max<int64_t>(a.end, a.beg0)); if (w[i] < 0) known = false; w[i] += 64.0; }
+            else if (a.kind == 1) { const Site& s = a.sites[0]; w[i] = c.idx.span_bytes(s.tid, (std::max<int64_t>(s.beg0 - 1, 0) >> 14) << 14, std::max<int64_t>(s.end, s.beg0)); if (w[i] < 0) known = false; w[i] += 2048.0; }
+        }
+        if (!known) for (size_t i = 0; i < items.size(); ++i) { const Work& a = items[i]; w[i] = a.kind == 0 ? (double)(a.end - a.beg0) + 1.0 : (a.kind == 1 ? 1000.0 : 0.0); }   // (no offsets to weigh by: positions)
+        size_t lo = 0, hi = 0;
+        rank_slice(w, my_rank, n_ranks, &lo, &hi);
+        // an error item ends the run where the reference's loop would have stopped: the rank that owns it reports it, the ranks behind
+        // it have nothing to do (the coordinator drops whatever they print)
+        std::vector<Work> mine;
+        for (size_t i = lo; i < hi; ++i) {
+            Work& a = items[i];
+            if (!mine.empty()) {
+                Work& p = mine.back();
+                if (a.kind == 1 && p.kind == 1 && (long long)p.sites.size() < std::max<long long>(o.plan_sites, 1)) {
+                    int64_t bp = 0; for (const Site& s : p.sites) bp += (s.end - s.beg0) + 600;
+                    if (bp <= 4 * (int64_t)c.opt.chunk_bp) { p.sites.push_back(a.sites[0]); continue; }
+                }
+                if (a.kind == 0 && p.kind == 0 && a.inner_piece && a.tid == p.tid && a.beg0 == p.end && !p.site_mode) { p.end = a.end; p.site_mode = a.site_mode; continue; }
+            }
+            mine.push_back(std::move(a));
+        }
+        if (getenv("BRC_CLI_TIMING")) {
+            double wm = 0, wt = 0; for (size_t i = 0; i < w.size(); ++i) { wt += w[i]; if (i >= lo && i < hi) wm += w[i]; }
+            fprintf(stderr, "rank %d of %d: atoms [%zu, %zu) of %zu, %.4f of the estimated work (%s), %zu work items\n", my_rank, n_ranks, lo, hi, items.size(), wt > 0 ? wm / wt : 0.0, known ? "index offsets" : "positions", mine.size());
+        }
+        items.swap(mine);
+        N = 1;
+        // a rank's part of a region is a fraction of it: pieces small enough that the rank's decode | GPU | format pipeline still has a
+        // few of them to overlap (a part of one piece would run its three stages one after the other)
+        if (o.max_cnt >= 1000000) {
+            int64_t widest = 0; for (const Work& w2 : items) if (w2.kind == 0) widest = std::max<int64_t>(widest, w2.end - w2.beg0);
+            if (widest > 0 && widest < 4 * (int64_t)c.opt.chunk_bp) c.opt.chunk_bp = std::min<long long>(c.opt.chunk_bp, std::max<long long>(131072, ((widest / 4 + 65535) / 65536) * 65536));
+        }
     }
 
     if (items.size() < N) N = std::max<size_t>(items.size(), 1);      // engines without work are never created
@@ -975,15 +1272,16 @@ int main(int argc, char** argv) {
         // engine 0 was created before the number of engines was known: it is told its share here, explicitly (the other
         // engines get theirs in make_engine) — not as a side effect of whoever waits for it next
         if (eng_ready.get() == 0) brc_set_option(c.eng, BRC_OPT_FORMAT_THREADS, (int64_t)g_format_threads.load());
+    } else if (g_ranks > 1) {
+        // a rank among others on this node: the engine's own pools (staging, formatter) get this rank's share of the CPUs too
+        if (eng_ready.get() == 0) brc_set_option(c.eng, BRC_OPT_FORMAT_THREADS, (int64_t)std::max(2u, effective_cpus()));
     }
     // pin the text buffers of a long region's pieces while the first reads are being decoded
     std::thread pin_ahead;
     {
         int64_t widest = 0; for (const Work& w : items) if (w.kind == 0) widest = std::max<int64_t>(widest, std::min<int64_t>(w.end - w.beg0, (int64_t)c.opt.chunk_bp));
         const bool dev_text = !(getenv("BRC_DEVICE_TEXT") && atoi(getenv("BRC_DEVICE_TEXT")) == 0);
-        // (not with -p: several libraries mean deep data, which the engine routes to the host formatter as a rule — gigabytes
-        // pinned for nothing would only compete with the staging allocations of the first piece)
-        if (dev_text && widest >= 100000 && !o.per_lib && !(getenv("BRC_PIN_AHEAD") && atoi(getenv("BRC_PIN_AHEAD")) == 0)) {
+        if (dev_text && widest >= 100000 && !(getenv("BRC_PIN_AHEAD") && atoi(getenv("BRC_PIN_AHEAD")) == 0)) {
             const int64_t bytes = widest * (int64_t)(o.per_lib ? std::max<size_t>(c.libs.size(), 1) : 1) * 400;
             pin_ahead = std::thread([&c, eng_ready, bytes]() { if (eng_ready.get() == 0) brc_set_option(c.eng, BRC_OPT_EXPECT_TEXT, bytes); });
         }
@@ -998,7 +1296,7 @@ int main(int argc, char** argv) {
         static const bool site_ahead = !(getenv("BRC_SITE_AHEAD") && atoi(getenv("BRC_SITE_AHEAD")) == 0);
         for (size_t i = 0; i < items.size(); ++i) {
             Work& w = items[i];
-            if (w.kind == 2) { fputs(w.err.c_str(), stderr); ret = 1; break; }
+            if (w.kind == 2) { fflush(stdout); fputs(w.err.c_str(), stderr); ret = 1; break; }
             if (w.kind == 3) { fflush(stdout); fputs(w.err.c_str(), stderr); continue; }
             if (w.kind == 1 && site_ahead) {
                 std::unique_ptr<SiteFetch> cur;
@@ -1104,14 +1402,16 @@ int main(int argc, char** argv) {
         for (size_t g = 1; g < N; ++g) if (ctxs[g]) { for (int w = 0; w < BRC_N_WARN; ++w) c.warn[w] += ctxs[g]->warn[w]; if (ctxs[g]->eng && clean_exit) brc_destroy(ctxs[g]->eng); }
         if (!clean_exit) for (auto& p : ctxs) (void)p.release();
     }
-    if (getenv("BRC_CLI_TIMING")) fprintf(stderr, "startup: open inputs %.3f s, create engine %.3f s\n", t_inputs - t_start, t_engine0 - t_inputs);
-    if (getenv("BRC_CLI_TIMING")) fprintf(stderr, "timing: fetch+decode %.3f s, engine (push, upload, kernels, download) %.3f s, format %.3f s, write %.3f s\n", c.t_fetch, c.t_engine, c.t_format, c.t_write);
+    const std::string who = my_rank >= 0 ? "rank " + std::to_string(my_rank) + ": " : std::string();
+    if (getenv("BRC_CLI_TIMING")) fprintf(stderr, "%sstartup: open inputs %.3f s, create engine %.3f s\n", who.c_str(), t_inputs - t_start, t_engine0 - t_inputs);
+    if (getenv("BRC_CLI_TIMING")) fprintf(stderr, "%stiming: fetch+decode %.3f s, engine (push, upload, kernels, download) %.3f s, format %.3f s, write %.3f s\n", who.c_str(), c.t_fetch, c.t_engine, c.t_format, c.t_write);
     if (getenv("BRC_CLI_TIMING") && c.n_site_lines)
-        fprintf(stderr, "sites: %llu lines in %llu clusters, %llu engine regions of %llu reads all told: waiting for indexed fetch + decode %.3f s (the fetches themselves, next batch behind the current one: %.3f s), layout on the virtual axis %.3f s, engine (push, upload, kernels, download) %.3f s, cutting the lines out + writing %.3f s\n",
-                (unsigned long long)c.n_site_lines, (unsigned long long)c.n_site_clusters, (unsigned long long)c.n_site_batches, (unsigned long long)c.n_site_reads, c.t_site_fetch, c.t_site_fetch_threads, c.t_site_layout, c.t_site_engine, c.t_site_format);
+        fprintf(stderr, "%ssites: %llu lines in %llu clusters, %llu engine regions of %llu reads all told: waiting for indexed fetch + decode %.3f s (the fetches themselves, next batch behind the current one: %.3f s), layout on the virtual axis %.3f s, engine (push, upload, kernels, download) %.3f s, cutting the lines out + writing %.3f s\n",
+                who.c_str(), (unsigned long long)c.n_site_lines, (unsigned long long)c.n_site_clusters, (unsigned long long)c.n_site_batches, (unsigned long long)c.n_site_reads, c.t_site_fetch, c.t_site_fetch_threads, c.t_site_layout, c.t_site_engine, c.t_site_format);
     // Everything has been written.  Unpinning and freeing gigabytes of staging and the HIP runtime's own teardown only delay
     // the exit of a process that is done: leave them to the operating system (BRC_CLEAN_EXIT=1 keeps the orderly path).
     fflush(stdout); fflush(stderr);
+    leave(ret);
     if (!clean_exit) _exit(ret);
     if (wait_engine()) brc_destroy(c.eng);
     return ret;

@@ -315,6 +315,7 @@ struct CramReader::Impl {
     bool getb(const char* k, uint8_t* v) { const Enc* e = series(k); if (!e) { err = std::string("CRAM data series ") + k + " missing"; return false; } return dec_byte(*e, v); }
     // n values of a byte series at once (the quality array of a record): straight out of the block when the series is EXTERNAL
     bool getn(const char* k, uint8_t* dst, int n) {
+        if (n <= 0) return true;                                   // (an empty read never looks its series up: a header without BA / QS decodes it)
         const Enc* e = series(k); if (!e) { err = std::string("CRAM data series ") + k + " missing"; return false; }
         if (e->codec == 1 && e->blk && n >= 0 && e->blk->data.size() - e->blk->pos >= (size_t)n) { memcpy(dst, e->blk->data.data() + e->blk->pos, (size_t)n); e->blk->pos += (size_t)n; return true; }
         for (int i = 0; i < n; ++i) if (!dec_byte(*e, dst + i)) return false;

@@ -25,6 +25,9 @@ under a launcher.  Extra objects on the JSON line:
   e2e_sites     BASELINE config 4 end to end: `bam-readcount -l sites` over a generated 8-contig 30x BAM + BAI, sites at BASELINE's
   e2e_tumor     spacing in file order; config 5 end to end: `-p -i` on a 200x / 4-library / 8-read-group BAM.  Both validated against
                 the reference's own main() (oracle/_ref/bam-readcount-ref) — tools/e2e_configs.py
+  e2e_sharded   the same two commands as N processes, one rank per GPU (`bam-readcount --brc-ranks N`: contiguous event-weighted slices
+                of the work list in file order, text in rank order): seconds, aggregate events/s, every rank's own seconds and share,
+                speed-up and efficiency against the one-process run, the whole output byte-identical to it.  --gpus 1: two ranks on GPU 0
   validated     full_contig: the result of the TIMED region — every position of it — equals the oracle's: the region is cut into
                 windows, the oracle computes each as a region of its own on all usable cores (tools/fullcheck.py), the HIP side
                 reads the same windows back with brc_fetch_window; planes bit for bit, indel lists, text byte for byte (digests).
@@ -575,19 +578,31 @@ def main():
                     other[key] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         # ---- BASELINE configs 4 and 5 through the drop-in CLI itself: multi-contig BAM + BAI, the reference's own -l loop and -p -i
         # lookups (tools/e2e_configs.py validates against oracle/_ref/bam-readcount-ref, the reference's own main())
-        e2e_sites = e2e_tumor = None
-        if (args.e2e_configs == 1 or (args.e2e_configs < 0 and want_other)) and world == 1 and os.path.exists(CLI):
+        e2e_sites = e2e_tumor = None; e2e_sharded = None
+        dist_backend = dist.get_backend() if dist is not None else None
+        want_e2e = (args.e2e_configs == 1 or (args.e2e_configs < 0 and (want_other or (world > 1 and args.mode == "weak" and config == "wgs30x")))) and os.path.exists(CLI) and not args.force_dist
+        if want_e2e and world > 1:
+            # an N-rank run: the other ranks are done (their engines close, their processes end) — the drop-in's own one-rank-per-GPU
+            # launcher gets the node's GPUs to itself; nothing below is a collective
+            if eng is not None:
+                eng.close(); eng = None
+            dist.destroy_process_group(); dist = None
+        if want_e2e:
             tool = os.path.join(ROOT, "tools", "e2e_configs.py")
+            # the drop-in as N processes, one per GPU (cli.cpp: --brc-ranks): on a one-GPU run two ranks share GPU 0 (what separate
+            # processes do to the host-bound command line); on an N-GPU run rank r owns GPU r — strong scaling of configs 4 and 5 end to end
+            rk = ["--ranks", str(world), "--rank-devices", ",".join(str(i) for i in range(world))] if world > 1 else ["--ranks", "2", "--rank-devices", "0,0"]
             def e2e_leg(extra):
                 try:
-                    out = subprocess.run([sys.executable, tool] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+                    out = subprocess.run([sys.executable, tool] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
                     if out.returncode != 0:
                         return {"error": out.stderr.decode(errors="replace")[-600:]}
                     return json.loads(out.stdout.decode().strip().splitlines()[-1])
                 except Exception as ex:                                  # noqa: BLE001 — reported, never hidden
                     return {"error": "%s: %s" % (type(ex).__name__, ex)}
-            e2e_sites = e2e_leg(["--leg", "sites", "--contigs", "8", "--contig-mbp", str(args.e2e_sites_mbp), "--check-lines", "1000"])
-            e2e_tumor = e2e_leg(["--leg", "tumor", "--contig-mbp", "6.25", "--check-mbp", "1.0"])
+            e2e_sites = e2e_leg(["--leg", "sites", "--contigs", "8", "--contig-mbp", str(args.e2e_sites_mbp), "--check-lines", "1000"] + rk)
+            e2e_tumor = e2e_leg(["--leg", "tumor", "--contig-mbp", str(6.25 * min(world, 4)), "--check-mbp", "1.0"] + rk)
+            e2e_sharded = {"sites": e2e_sites.pop("sharded", None) if isinstance(e2e_sites, dict) else None, "tumor": e2e_tumor.pop("sharded", None) if isinstance(e2e_tumor, dict) else None}
         what = {"weak": "synthetic 30x WGS, 150bp reads, 1 contig %.0f Mbp per GPU, -q20 -b13" % (contig_len / 1e6),
                 "strong": "synthetic 200x tumor 4 libraries, 150bp reads, -p -i, 1 contig %.0f Mbp cut into %d intervals" % (total_len / 1e6, world),
                 "sites": "-l site list of %d single-base sites in file order over %d synthetic 30x contigs of %.0f Mbp (genome scaled from 3.1 Gbp), -q20 -b13, cut into %d slices"
@@ -602,7 +617,7 @@ def main():
             what = "synthetic 200x tumor 4 libraries, 150bp reads, -p -i, 1 contig %.2f Mbp per GPU" % (contig_len / 1e6)
         if rank_check is not None:
             validated = dict(validated or {}, all_ranks_ok=rank_check["all_ranks_ok"], per_rank_check=rank_check["what"], rank0_error=rank_check["error"],
-                             distributed_backend=(dist.get_backend() if dist is not None else None))
+                             distributed_backend=dist_backend)
         line = {
             "metric": "pileup base-events/sec", "value": round(value, 1), "unit": "events/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
@@ -611,7 +626,7 @@ def main():
                        "events_per_step": int(ev_total), "positions_per_step": int(pos_total), "parallelism": "interval-shard x%d" % world},
             "positions_per_s": round(pos_total * args.steps / tmax, 1),
             "per_rank": per_rank, "per_gpu_value": round(value / world, 1),
-            "roofline": roof, "cpu_baseline": cpu, "e2e": e2e, "e2e_sites": e2e_sites, "e2e_tumor": e2e_tumor, "abi_roundtrip": abi, "validated": validated, "other_configs": other,
+            "roofline": roof, "cpu_baseline": cpu, "e2e": e2e, "e2e_sites": e2e_sites, "e2e_tumor": e2e_tumor, "e2e_sharded": e2e_sharded, "abi_roundtrip": abi, "validated": validated, "other_configs": other,
             "host": {"gen_s": round(t_gen, 2), "push_s": round(t_push, 2), "upload_s": round(t_up, 2), "timed_s": round(tmax, 3)},
         }
         print(json.dumps(line))

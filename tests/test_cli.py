@@ -655,3 +655,62 @@ def test_cli_striped_parallel_fetch_equals_single_handle_cpu(synthetic_bam, work
     rc, out, _ = run_cli(SIM_CLI, workdir, "test.bam", ["-i", "-p"], "list") if False else (0, None, None)
     p = subprocess.run([SIM_CLI, "-w", "1", "-i", "-p", "-f", "ref.fa", "-l", "site_list", "--brc-plan", "0", "test.bam"], cwd=workdir, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     assert p.returncode == 0 and p.stdout == exp
+
+
+def _ranks_check(cli, d, devices=None):
+    """--brc-ranks N (one process per GPU): N processes, each with a contiguous event-weighted slice of the work list in file order, must
+    print — stdout, stderr (the -w cap runs over the whole list) and exit code — exactly what one process prints: regions cut inside
+    deletions, site lists with duplicate / overlapping / unsorted lines and lines on unknown contigs, per-library and insertion-centric
+    modes; a bad region ends the run where one process would have stopped."""
+    rng = np.random.default_rng(12)
+    sites = [("chrA", int(p), int(p)) for p in rng.integers(1, 5000, 300)] + [("chrB", 10, 2500), ("chrA", 300, 2900), ("chrB", 5, 5), ("chrA", 100, 100), ("chrA", 100, 100), ("chrA", 90, 130)]
+    order = rng.permutation(len(sites)); sites = [sites[i] for i in order]
+    sites.insert(40, ("nochr", 5, 9)); sites.insert(200, ("chrZ", 1, 1))
+    sl = _sites_file(d, "sites_ranks.txt", sites)
+    runs = [["-w", "0", "-f", "syn.fa", "syn.bam", "chrA"],
+            ["-w", "7", "-p", "-i", "-f", "syn.fa", "syn_m_nonm.bam", "chrA:200-4800"],
+            ["-w", "0", "-q", "10", "-b", "5", "-f", "syn.fa", "-l", sl, "--brc-plan", "16", "syn.bam"],
+            ["-w", "5", "-p", "-f", "syn.fa", "-l", sl, "syn_m_nonm.bam"],
+            ["-w", "-1", "-f", "syn.fa", "-l", sl, "--brc-plan", "0", "syn_m_nonm.bam"],
+            ["-w", "0", "-d", "30", "-f", "syn.fa", "-l", sl, "syn.bam"]]
+    env1 = dict(os.environ); env1.pop("BRC_DEVICES", None); env1.pop("BRC_RANKS", None)
+    for args in runs:
+        one = subprocess.run([cli, "--brc-chunk", "333"] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env1)
+        assert one.returncode == 0 and one.stdout.count(b"\n") > 500, one.stderr
+        for n in (2, 3, 4):
+            env = dict(env1, BRC_RANK_CUT="257")
+            if devices is not None:
+                env["BRC_DEVICES"] = ",".join([str(devices)] * n)
+            many = subprocess.run([cli, "--brc-chunk", "333", "--brc-ranks", str(n)] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            assert many.returncode == 0, many.stderr
+            assert many.stdout == one.stdout, (args, n)
+            assert many.stderr == one.stderr, (args, n, many.stderr[-2000:], one.stderr[-2000:])
+    # several command-line regions stay one process (a pending deletion can hold back every region behind it); BRC_RANKS asks like the option
+    args = ["-w", "0", "-f", "syn.fa", "syn.bam", "chrA:1-2000", "chrA:2001-5000", "chrB"]
+    one = subprocess.run([cli] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env1)
+    env = dict(env1, BRC_RANKS="3")
+    if devices is not None:
+        env["BRC_DEVICES"] = ",".join([str(devices)] * 3)
+    many = subprocess.run([cli] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert many.returncode == 0 and many.stdout == one.stdout and many.stderr == one.stderr
+    # /dev/null as stdout: the ranks write there themselves; the stage account names every rank and its share of the estimated work
+    with open(os.devnull, "wb") as dn:
+        t = subprocess.run([cli, "--brc-ranks", "2", "-w", "0", "-f", "syn.fa", "syn.bam", "chrA"], cwd=d, stdout=dn, stderr=subprocess.PIPE, env=dict(env, BRC_CLI_TIMING="1", BRC_RANK_CUT="257"))
+    assert t.returncode == 0 and b"rank 0 of 2" in t.stderr and b"rank 1 of 2" in t.stderr and b"ranks: 2 processes" in t.stderr, t.stderr
+    # errors: an unknown contig in the region ends the run with the reference's message, once; a BAM that cannot be opened likewise
+    bad = subprocess.run([cli, "--brc-ranks", "2", "-f", "syn.fa", "syn.bam", "nochr:1-2"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert bad.returncode == 1 and bad.stderr.count(b"Invalid region nochr:1-2") == 1 and bad.stdout == b""
+    bad = subprocess.run([cli, "--brc-ranks", "3", "-f", "syn.fa", "missing.bam", "chrA"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    one = subprocess.run([cli, "-f", "syn.fa", "missing.bam", "chrA"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env1)
+    assert bad.returncode == one.returncode == 1 and bad.stderr == one.stderr and bad.stdout == b""
+
+
+def test_cli_ranks_equal_single_process_cpu(synthetic_bam):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sim")])
+    _ranks_check(SIM_CLI, synthetic_bam)
+
+
+@pytest.mark.gpu
+def test_cli_ranks_equal_single_process_gpu(synthetic_bam):
+    """world 2, 3 and 4 on ONE GPU (BRC_DEVICES=0,0,..): every rank a process of its own with its own HIP context"""
+    _ranks_check(CLI, synthetic_bam, devices=0)

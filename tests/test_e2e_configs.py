@@ -37,6 +37,12 @@ def check_sites(cli):
     # many small planner batches: the fetch of batch k + 1 runs behind batch k (cli.cpp: fetch_site_batch); same text, same checks
     k = leg(cli, "--leg", "sites", "--contigs", "5", "--contig-mbp", "0.3", "--sites", "400", "--check-lines", "150", "--", "--brc-plan", "37")
     assert k["validated"]["byte_exact_vs_reference_main"] and k["validated"]["full_output_md5"] == v["full_output_md5"]
+    # one process per GPU (--brc-ranks; here: three ranks, on a GPU box all on device 0): every rank's slice of the list, in file order,
+    # is what one process prints for it — the whole output byte for byte —, and the slices are balanced by the index's offsets
+    r = leg(cli, "--leg", "sites", "--contigs", "5", "--contig-mbp", "0.3", "--sites", "400", "--check-lines", "150", "--ranks", "3", "--rank-devices", "0,0,0")
+    sh = r["sharded"]
+    assert r["validated"]["full_output_md5"] == v["full_output_md5"] and sh["whole_output_byte_identical_to_one_process"] and sh["output_lines"] == r["printed_lines"]
+    assert len(sh["per_rank"]) == 3 and all(0.2 < pr["share_of_estimated_work"] < 0.47 and pr["weights"] == "index offsets" for pr in sh["per_rank"])
 
 
 def check_tumor(cli):
@@ -44,6 +50,10 @@ def check_tumor(cli):
     v = j["validated"]
     assert v["byte_exact_vs_reference_main"] and v["full_line_count_equals_covered_positions"] and v["text_bytes_checked"] > 10_000_000
     assert j["events"] > 9_000_000
+    r = leg(cli, "--leg", "tumor", "--contig-mbp", "0.3", "--check-mbp", "0.01", "--ranks", "2", "--rank-devices", "0,0")
+    sh = r["sharded"]
+    assert sh["whole_output_byte_identical_to_one_process"] and sh["output_lines"] == r["printed_lines"] and len(sh["per_rank"]) == 2
+    assert all(0.35 < pr["share_of_estimated_work"] < 0.65 for pr in sh["per_rank"])
 
 
 @needs_ref

@@ -791,6 +791,10 @@ def _random_cli_case(seed, d):
     env = dict(os.environ, BRC_DEVICE_TEXT_MAX_SHARE=str(rng.choice(["100", "0.06"])))
     if rng.random() < 0.3:
         env["BRC_FETCH_STRIPE_MIN"] = "1"; env["BRC_FETCH_THREADS"] = str(int(rng.choice([2, 5])))
+    # one process per GPU (--brc-ranks; a random stream of its own: the cases of the seeds above stay what they were)
+    rng2 = np.random.default_rng(seed + 777777)
+    if "--brc-gpus" not in extra and rng2.random() < 0.3:
+        extra += ["--brc-ranks", str(int(rng2.choice([2, 3])))]; env["BRC_RANK_CUT"] = str(int(rng2.choice([97, 500, 65536])))
     return opts, extra, args, env
 
 
@@ -800,6 +804,8 @@ def _cli_fuzz(cli, ref_lib, tmp_path, seeds, one_device=False):
         opts, extra, args, env = _random_cli_case(seed, str(d))
         if one_device and "--brc-gpus" in extra:          # the GPU box has one device: several engines on it
             i = extra.index("--brc-gpus"); env["BRC_DEVICES"] = ",".join(["0"] * int(extra[i + 1])); del extra[i:i + 2]
+        if one_device and "--brc-ranks" in extra:         # ... or several processes, each with a context of its own on it
+            env["BRC_DEVICES"] = ",".join(["0"] * int(extra[extra.index("--brc-ranks") + 1]))
         a = subprocess.run([REF_CLI] + opts + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         b = subprocess.run([cli] + opts + extra + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         assert (a.returncode, a.stdout == b.stdout, a.stderr == b.stderr) == (b.returncode, True, True), (seed, opts, extra, args)

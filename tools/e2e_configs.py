@@ -107,6 +107,67 @@ def timed_to_devnull(cmd, cwd, reps):
     return best, stages
 
 
+def digest_of_stdout(cmd, cwd, env=None):
+    """xxh3-128 digest, byte and line count of a command's stdout, streamed (config 5's text is gigabytes)"""
+    import xxhash
+    h = xxhash.xxh3_128(); nb = 0; nl = 0
+    p = subprocess.Popen(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, bufsize=0)
+    import threading
+    err = []
+    t = threading.Thread(target=lambda: err.append(p.stderr.read())); t.start()
+    while True:
+        b = p.stdout.read(1 << 24)
+        if not b:
+            break
+        h.update(b); nb += len(b); nl += b.count(b"\n")
+    p.wait(); t.join()
+    return p.returncode, h.hexdigest(), nb, nl, (err[0] if err else b"").decode(errors="replace")
+
+
+def sharded(args, d, cmd, events, one_seconds):
+    """The same command as N processes, one per GPU (--brc-ranks N: contiguous event-weighted slices of the work list in file order,
+    text in rank order): best of --reps to /dev/null with the coordinator's account of every rank, and the whole output — every rank's
+    slice — compared with the one-process output byte for byte (digests, streamed)."""
+    if args.ranks < 2:
+        return None
+    env = dict(os.environ, BRC_CLI_TIMING="1")
+    if args.rank_devices:
+        env["BRC_DEVICES"] = args.rank_devices
+    rcmd = [cmd[0], "--brc-ranks", str(args.ranks)] + cmd[1:]
+    best = None; acct = None
+    for _ in range(args.reps):
+        with open(os.devnull, "wb") as dn:
+            t, rc, err = run(rcmd, d, dn, env)
+        if rc != 0:
+            raise SystemExit("command failed (%d): %s\n%s" % (rc, " ".join(rcmd), err[-2000:]))
+        if best is None or t < best:
+            best = t; acct = [l for l in err.splitlines() if l.startswith(("ranks:", "rank "))]
+    rc1, h1, nb1, nl1, e1 = digest_of_stdout(cmd, d)
+    rcn, hn, nbn, nln, en = digest_of_stdout(rcmd, d, env)
+    assert rc1 == 0 and rcn == 0, (e1[-1000:], en[-1000:])
+    assert (h1, nb1, nl1) == (hn, nbn, nln), "the output of %d ranks differs from the one-process output (%d vs %d bytes, %d vs %d lines)" % (args.ranks, nbn, nb1, nln, nl1)
+    per_rank = []
+    for l in acct:
+        if l.startswith("ranks:"):
+            import re
+            per_rank = [{"rank": int(a), "seconds": float(b), "text_out_after_s": float(c)} for a, b, c in re.findall(r"rank (\d+): ([0-9.]+) s \(its text was out after ([0-9.]+) s\)", l)]
+    shares = {}
+    for l in acct:
+        if l.startswith("rank ") and " of the estimated work" in l:
+            import re
+            m = re.match(r"rank (\d+) of \d+: atoms \[(\d+), (\d+)\) of (\d+), ([0-9.]+) of the estimated work \(([^)]*)\)", l)
+            if m:
+                shares[int(m.group(1))] = {"atoms": [int(m.group(2)), int(m.group(3))], "of": int(m.group(4)), "share_of_estimated_work": float(m.group(5)), "weights": m.group(6)}
+    for pr in per_rank:
+        pr.update(shares.get(pr["rank"], {}))
+    return {"ranks": args.ranks, "devices": args.rank_devices or ",".join(str(i) for i in range(args.ranks)), "seconds": round(best, 3), "value": round(events / best, 1), "unit": "pileup base-events/s",
+            "one_process_seconds": round(one_seconds, 3), "speedup_vs_one_process": round(one_seconds / best, 3), "efficiency": round(one_seconds / best / args.ranks, 3),
+            "per_rank": per_rank, "whole_output_byte_identical_to_one_process": True, "output_bytes": nbn, "output_lines": nln, "output_xxh3_128": hn,
+            "what": "the same command as %d processes (--brc-ranks %d, GPUs %s): one rank per GPU started before HIP initialisation, contiguous slices of the work list in file order weighted by the "
+                    "index's file offsets, text written in rank order; strong scaling end to end (decode, PCIe, kernels, text) against the one-process run above"
+                    % (args.ranks, args.ranks, args.rank_devices or "0..%d" % (args.ranks - 1))}
+
+
 def is_subsequence(sub_lines, full_lines):
     it = iter(full_lines)
     return all(any(x == y for y in it) for x in sub_lines)
@@ -169,7 +230,8 @@ def leg_sites(args, d):
     sub_lines = got.split(b"\n")[:-1]
     assert is_subsequence(sub_lines, full), "the sub-list's lines are not found in order in the full run's output"
     ref_events = events * len(sub) / max(len(lines), 1)
-    return {"what": "config 4 through the drop-in CLI: bam-readcount -w0 -q20 -b13 -f g.fa -l sites g.bam > /dev/null; %d contigs x %.1f Mbp = %.0f Mbp at 30x (%d reads; genome scaled 1:%.1f "
+    sh = sharded(args, d, base + ["sites", "g.bam"] + args.cli_extra, events, best)
+    return {"sharded": sh, "what": "config 4 through the drop-in CLI: bam-readcount -w0 -q20 -b13 -f g.fa -l sites g.bam > /dev/null; %d contigs x %.1f Mbp = %.0f Mbp at 30x (%d reads; genome scaled 1:%.1f "
                     "against BASELINE's 24 contigs / 3.1 Gbp), %d site-list lines at BASELINE's spacing of one site per %.0f kb over all contigs in file order "
                     "(every 199th line twice, every 199th followed by a 20-base line over it, every 331st followed by an earlier line again, out of order)"
                     % (args.contigs, args.contig_mbp, total / 1e6, n_reads, GENOME_BP / total, len(lines), total / max(n_sites, 1) / 1e3),
@@ -231,7 +293,8 @@ def leg_tumor(args, d):
             nbytes += len(want)
         assert g.read(1) == b"", "the drop-in printed more than the reference for chr2:1-%d" % cb
     ref_events = int(cov2[:cb].sum(dtype=np.int64))
-    return {"what": "config 5 through the drop-in CLI: bam-readcount -w0 -p -i -f g.fa g.bam chr2 > /dev/null; chr2 = %.2f Mbp at 200x, 4 libraries / 8 read groups, 10 %% indel reads "
+    sh = sharded(args, d, base + ["chr2"] + args.cli_extra, events, best)
+    return {"sharded": sh, "what": "config 5 through the drop-in CLI: bam-readcount -w0 -p -i -f g.fa g.bam chr2 > /dev/null; chr2 = %.2f Mbp at 200x, 4 libraries / 8 read groups, 10 %% indel reads "
                     "(BASELINE: 50 Mbp over 8 GPUs = 6.25 Mbp per GPU), inside a 3-contig BAM of %d reads" % (args.contig_mbp, n_reads),
             "seconds": round(best, 3), "value": round(events / best, 1), "unit": "pileup base-events/s", "events": events, "positions_per_s": round(want_lines / best, 1),
             "printed_lines": want_lines, "stages": stages, "bam_bytes": os.path.getsize(os.path.join(d, "g.bam")), "generate_seconds": round(t_gen, 1),
@@ -255,6 +318,8 @@ def main():
                     help="how the reference-compiled main() reads the BAM (oracle/ref_shim/shim_hts.cpp): 'independent' = the shim's own reader, which loads every record of the file "
                          "and ignores the index (a second BAM decoder, fine for megabytes); 'indexed' = the repository's BGZF/BAM/BAI reader under the reference's samfetch "
                          "(BRC_SHIM_PRODUCT_READER=1); auto: independent below 200 MB of BAM")
+    ap.add_argument("--ranks", type=int, default=0, help="also run the leg's command as this many processes, one per GPU (--brc-ranks), timed and compared byte for byte with the one-process output ('sharded' in the result)")
+    ap.add_argument("--rank-devices", default=None, help="BRC_DEVICES of the ranks run (e.g. 0,0: two ranks on one GPU); default: GPUs 0..ranks-1")
     ap.add_argument("--keep", default=None, help="work in this directory and keep the files")
     ap.add_argument("cli_extra", nargs="*", help="extra arguments for the drop-in (after --)")
     args = ap.parse_args()
