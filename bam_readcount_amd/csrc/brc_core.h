@@ -248,6 +248,38 @@ struct Planes {
     uint32_t xev_shards;   // power of two (1 in the CPU simulator)
 };
 
+// Third-allele events folded ON THE DEVICE (round 6; until then the host added them up): one record per (position, library, bucket) that
+// has such events, its 13 sums accumulated in list order = pileup-column order (every event of a position sits in ONE sub-list, in append
+// order, and the compaction keeps that order) — BasicStat::process_read's work (BasicStat.cpp:28-107) for the few events that found both of
+// their position's slots taken.  The records of one (64-position tile, library) lie together, sorted by (position, bucket): a lane that
+// writes a position's line, and the host that expands the slots to the ABI's dense planes, find a bucket's sums in ONE place — the slot that
+// names the bucket, or this table.
+struct alignas(16) XAgg { uint32_t k; uint32_t lib_b; uint32_t i[NI]; float f[NF]; uint32_t pad; };     // 64 bytes
+static_assert(sizeof(XAgg) == 64, "XAgg is copied to the host as it is");
+// fold of ONE (tile, library) bucket: idx[0..n) = the bucket's events as indices into the compacted list `list`, in any order;
+// sorted here by (position, bucket, index) — insertion sort: a bucket holds a handful —, every run folded in index order into
+// out[0..).  Returns the number of records.
+BRC_HD int fold_xev_bucket(const XEv* list, uint32_t* idx, int n, XAgg* out) {
+    auto key = [&](uint32_t i) -> uint64_t { const XEv& e = list[i]; return ((uint64_t)(e.k & 63u) << 40) | ((uint64_t)(e.lib_b & 0xffu) << 32) | (uint64_t)i; };      // (one tile: the position's lane orders it)
+    for (int a = 1; a < n; ++a) { const uint32_t t = idx[a]; const uint64_t kt = key(t); int b = a - 1; while (b >= 0 && key(idx[b]) > kt) { idx[b + 1] = idx[b]; --b; } idx[b + 1] = t; }
+    int no = 0;
+    for (int a = 0; a < n; ++a) {
+        const XEv& e = list[idx[a]];
+        if (no == 0 || out[no - 1].k != e.k || out[no - 1].lib_b != e.lib_b) {
+            XAgg& o = out[no++]; o.k = e.k; o.lib_b = e.lib_b; o.pad = 0u;
+            for (int f = 0; f < NI; ++f) o.i[f] = 0u;
+            for (int f = 0; f < NF; ++f) o.f[f] = 0.0f;
+        }
+        XAgg& o = out[no - 1];
+        const uint32_t rev = (e.qf >> 8) & 1u;
+        o.i[I_N] += 1u; o.i[I_SMQ] += e.mapq; o.i[I_SSE] += e.sse; o.i[I_PLUS] += 1u - rev; o.i[I_MINUS] += rev;
+        o.i[I_NQ2] += (e.qf >> 9) & 1u; o.i[I_SMMQ] += e.zm; o.i[I_SCLIP] += e.clip; o.i[I_SBQ] += e.qf & 0xffu;
+        o.f[F_SQ2] += e.fq2; o.f[F_S3P] += e.fs3p; o.f[F_SNM] += e.fsnm;
+        o.f[F_SEV] = (float)((double)o.f[F_SEV] + e.sev);                    // through double, like BasicStat.cpp:69-70
+    }
+    return no;
+}
+
 // ---------------------------------------------------------------- small tables as packed constants
 
 // htslib seq_nt16_table (IUPAC char -> 4-bit code; '=' 0; '0'..'3' 1,2,4,8; everything else 15), bamreadcount.cpp:149
@@ -1104,14 +1136,27 @@ BRC_HD uint32_t indel_bucket(const DevCfg& c, uint32_t key) {
 // ================================================================ device-side text (the "on device" option)
 //
 // The line pileup_func prints for one position (bamreadcount.cpp:351-416 with operator<<(BasicStat), BasicStat.cpp:110-159),
-// written straight from the compact result: chrom, 1-based position, reference character, depth, and per library present in
-// the column its six base buckets.  What a lane cannot know stays with the host, which rewrites those few lines
-// (brc_host.cpp: patch_lines): indel buckets (their alleles are ordered as strings on the host), the deletions queued for
-// pos + 1 with their depth increment (IndelQueue.cpp:3-15), and buckets of a third base (they live in the event list).
+// written straight from the device's own results: chrom, 1-based position, reference character, depth, and per library present in
+// the column its six base buckets (the two slots + the folded third-allele table), the insertion alleles of the position in the
+// order std::map<std::string, BasicStat> iterates them (:389-401) and the deletion alleles the position BEFORE it queued for this
+// one (:391-396 with IndelQueue::process, IndelQueue.cpp:3-15), whose read counts join the depth column (:415).  Round 6: until then
+// a lane left indel buckets, queued deletions and third bases to the host, which rewrote those lines one by one — every line of deep,
+// indel-rich data (BASELINE config 5).
+// What a lane cannot know is what an EARLIER region left in the host's deletion queues (the reference does not clear them between
+// command-line regions, :641-657: a deletion left pending can be printed a second time, or hold back everything queued behind it):
+// the lines assume queues that hold nothing but what the position before queued — true inside a region that started from empty
+// queues or continues the piece before it (BRC_OPT_CONTINUES_PREVIOUS) —, and the host, which knows its queues, rewrites the indel
+// entries of a region that started otherwise (brc_host.cpp: format_device_text).
 // Two passes over the same code: lengths (w == nullptr), an exclusive scan, then the bytes.
 struct TextCtx {
     const char* chrom; int32_t chrom_len;
     const char* lib_names; const int32_t* lib_off;      // library l's name: lib_names[lib_off[l] .. lib_off[l + 1])
+};
+// the two side tables of a computed region as a lane finds them
+struct TextAux {
+    const XAgg* xagg; const uint32_t* xagg_end; const uint32_t* xagg_cnt;      // records of (tile, library) bucket b = tile * Lp + library: [xagg_end[b] - xagg_cnt[b], xagg_end[b]); nullptr: none
+    const IndelOut* iout; const uint32_t* ib_end; const uint32_t* ib_cnt;      // reduced indel buckets: slots [ib_end[b] - ib_cnt[b], ib_end[b]) of bucket b = indel_bucket_of(c, k, library); unused slots have len == 0
+    const DRead* reads;                                                       // (an insertion allele's bases: the event bytes of its first read)
 };
 struct TextSink { char* w; uint32_t n; };
 BRC_HD void ts_put(TextSink& s, char ch) { if (s.w) s.w[s.n] = ch; ++s.n; }
@@ -1135,12 +1180,13 @@ BRC_HD void ts_f2(TextSink& s, float v) {
     const int fr = (int)(u % 100);
     ts_put(s, '.'); ts_put(s, (char)('0' + fr / 10)); ts_put(s, (char)('0' + fr % 10));
 }
-// operator<<(ostream&, BasicStat) for a base bucket with at least one read (BasicStat.cpp:110-140)
-BRC_HD void ts_stat(TextSink& s, const uint32_t* si, const float* sf) {
+// operator<<(ostream&, BasicStat) for a bucket with at least one read (BasicStat.cpp:110-140); is_indel: the base-quality field reads 0.00 (:123)
+BRC_HD void ts_stat(TextSink& s, const uint32_t* si, const float* sf, bool is_indel = false) {
     const float c = (float)si[I_N];
     ts_u32(s, si[I_N]); ts_put(s, ':');
     ts_f2(s, (float)si[I_SMQ] / c); ts_put(s, ':');
-    ts_f2(s, (float)si[I_SBQ] / c); ts_put(s, ':');
+    if (is_indel) { ts_put(s, '0'); ts_put(s, '.'); ts_put(s, '0'); ts_put(s, '0'); } else ts_f2(s, (float)si[I_SBQ] / c);
+    ts_put(s, ':');
     ts_f2(s, (float)si[I_SSE] / c); ts_put(s, ':');
     ts_u32(s, si[I_PLUS]); ts_put(s, ':');
     ts_u32(s, si[I_MINUS]); ts_put(s, ':');
@@ -1153,15 +1199,76 @@ BRC_HD void ts_stat(TextSink& s, const uint32_t* si, const float* sf) {
     ts_f2(s, (float)si[I_SCLIP] / c); ts_put(s, ':');
     ts_f2(s, sf[F_S3P] / c);
 }
+// character j of an indel bucket's allele text behind its sign (bamreadcount.cpp:324-338): an inserted base as "=ACGTN"[canonical code]
+// ('N' past the read's end), a deleted one as the reference's raw character ('N' where there is none)
+BRC_HD char allele_char(const DevCfg& c, const DevIn& in, const TextAux& ax, const IndelOut& o, int j) {
+    if (o.len > 0) {
+        const DRead& rd = ax.reads[o.rep_read];
+        const int q = o.rep_qpos + 1 + j;
+        const char bases[] = "=ACGTN";
+        return q < rd.l_qseq ? bases[base_bucket(in, rd.bq_off + (uint64_t)q)] : 'N';
+    }
+    const uint32_t rc = ref_at(c, in.ref, (int64_t)o.pos + 1 + j);
+    return rc ? (char)rc : 'N';
+}
+// a < b as std::string compares "+ACG" / "-TT" (the order of std::map<std::string, BasicStat>, :389): '+' before '-', then bytewise, a
+// prefix before the longer text.  (Deletions at one position are prefixes of one another: the shorter first.)
+BRC_HD bool allele_before(const DevCfg& c, const DevIn& in, const TextAux& ax, const IndelOut& a, const IndelOut& b) {
+    if ((a.len > 0) != (b.len > 0)) return a.len > 0;
+    const int la = iabs(a.len), lb = iabs(b.len);
+    if (a.len < 0) return la < lb;
+    const int n = la < lb ? la : lb;
+    for (int j = 0; j < n; ++j) { const char ca = allele_char(c, in, ax, a, j), cb = allele_char(c, in, ax, b, j); if (ca != cb) return (unsigned char)ca < (unsigned char)cb; }
+    return la < lb;
+}
+// the slots of the indel bucket that holds key (plane index k, library l)
+BRC_HD void indel_slots(const DevCfg& c, const TextAux& ax, int64_t k, int l, uint32_t& s0, uint32_t& s1) {
+    s0 = s1 = 0u;
+    if (!ax.iout) return;
+    const uint32_t b = indel_bucket_of(c, (uint32_t)k, (uint32_t)l);
+    s1 = ax.ib_end[b]; s0 = s1 - ax.ib_cnt[b];
+}
+// The alleles of key (k, l) with want_ins ? len > 0 : len < 0, in allele order: one "\t<allele>:<stat>" each.  Returns the sum of their read counts.
+// (No array of them: the next one to print is found by a pass over the bucket's few slots — the smallest allele behind the one printed last.)
+BRC_HD uint32_t ts_indels(TextSink& s, const DevCfg& c, const DevIn& in, const TextAux& ax, int64_t k, int l, bool want_ins, bool print) {
+    uint32_t s0, s1; indel_slots(c, ax, k, l, s0, s1);
+    const int32_t pos = (int32_t)(c.pos0 + k);
+    uint32_t nsum = 0; int64_t last = -1;
+    for (;;) {
+        int64_t best = -1;
+        for (uint32_t i = s0; i < s1; ++i) {
+            const IndelOut& o = ax.iout[i];
+            if (o.len == 0 || o.pos != pos || (o.len > 0) != want_ins) continue;
+            if (last >= 0 && ((int64_t)i == last || !allele_before(c, in, ax, ax.iout[last], o))) continue;       // not behind the last one printed
+            if (best < 0 || allele_before(c, in, ax, o, ax.iout[best])) best = (int64_t)i;
+        }
+        if (best < 0) break;
+        const IndelOut& o = ax.iout[best];
+        nsum += o.i[I_N];
+        if (print) {
+            ts_put(s, '\t'); ts_put(s, o.len > 0 ? '+' : '-');
+            const int n = iabs(o.len);
+            for (int j = 0; j < n; ++j) ts_put(s, allele_char(c, in, ax, o, j));
+            ts_put(s, ':');
+            ts_stat(s, o.i, o.f, true);
+        }
+        last = best;
+    }
+    return nsum;
+}
 // The line of plane index k, or nothing (returns 0) when no read covers the position / the position was abandoned (:281-284).
 // Lines are produced for every index, the lead position included (the host needs its shape; it does not print it).
-BRC_HD uint32_t text_line(const DevCfg& c, const DevIn& in, const Planes& pl, const TextCtx& t, int64_t k, char* w) {
+BRC_HD uint32_t text_line(const DevCfg& c, const DevIn& in, const Planes& pl, const TextCtx& t, const TextAux& ax, int64_t k, char* w) {
     if (c.per_lib && pl.unavail[k] != NONE32) return 0u;
     uint32_t tot = 0, depth = 0;
     for (int l = 0; l < c.Lp; ++l) { tot += pl.ncol[(int64_t)l * c.PS + k]; depth += pl.depth[(int64_t)l * c.PS + k]; }
     if (tot == 0) return 0u;
     TextSink s; s.w = w; s.n = 0;
     const int64_t p = (int64_t)c.pos0 + k;
+    // the deletions position k - 1 queued are due here, for the libraries present in this column (IndelQueue.cpp:3-15; an abandoned
+    // position queued nothing: its keys were never reduced)
+    const bool prev = ax.iout != nullptr && k > 0;
+    if (prev) for (int l = 0; l < c.Lp; ++l) if (pl.ncol[(int64_t)l * c.PS + k] != 0) depth += ts_indels(s, c, in, ax, k - 1, l, false, false);
     ts_bytes(s, t.chrom, t.chrom_len); ts_put(s, '\t');
     ts_u32(s, (uint32_t)(p + 1)); ts_put(s, '\t');
     { const uint32_t rc = c.has_ref ? ref_at(c, in.ref, p) : 0u; ts_put(s, rc ? (char)rc : 'N'); }                 // :353
@@ -1169,11 +1276,16 @@ BRC_HD uint32_t text_line(const DevCfg& c, const DevIn& in, const Planes& pl, co
     ts_u32(s, depth);
     const char zero[] = "0:0.00:0.00:0.00:0:0:0.00:0.00:0.00:0:0.00:0.00:0.00";
     const char bases[] = "=ACGTN";
+    const int64_t tile = k >> 6;
     for (int l = 0; l < c.Lp; ++l) {
         if (pl.ncol[(int64_t)l * c.PS + k] == 0) continue;                                                             // :286,360
         if (c.per_lib) { ts_put(s, '\t'); ts_bytes(s, t.lib_names + t.lib_off[l], t.lib_off[l + 1] - t.lib_off[l]); ts_put(s, '\t'); ts_put(s, '{'); }
         const uint32_t sid = pl.slotid[(int64_t)l * c.PS + k];
         const uint32_t b0 = sid & 0xffu, b1 = (sid >> 8) & 0xffu;
+        // third-allele records of this (tile, library): a bucket's sums sit in ONE place — the slot that names it, or here (also for a
+        // bucket a slot names: the events of an N / '=' base never enter the slots)
+        uint32_t x0 = 0u, x1 = 0u;
+        if (ax.xagg) { const int64_t xb = tile * c.Lp + l; x1 = ax.xagg_end[xb]; x0 = x1 - ax.xagg_cnt[xb]; }
         for (uint32_t b = 0; b < (uint32_t)NBUCKET; ++b) {
             ts_put(s, '\t'); ts_put(s, bases[b]); ts_put(s, ':');
             const int sl = b == b0 ? 0 : (b == b1 ? 1 : -1);
@@ -1188,8 +1300,14 @@ BRC_HD uint32_t text_line(const DevCfg& c, const DevIn& in, const Planes& pl, co
                     for (int f = 0; f < NF; ++f) sf[f] = fp[(int64_t)f * c.PS];
                 }
             }
+            if (!si[I_N]) for (uint32_t x = x0; x < x1; ++x) {
+                const XAgg& a = ax.xagg[x];
+                if (a.k == (uint32_t)k && (a.lib_b & 0xffu) == b) { for (int f = 0; f < NI; ++f) si[f] = a.i[f]; for (int f = 0; f < NF; ++f) sf[f] = a.f[f]; break; }
+            }
             if (si[I_N]) ts_stat(s, si, sf); else ts_bytes(s, zero, (int)sizeof(zero) - 1);
         }
+        if (ax.iout) (void)ts_indels(s, c, in, ax, k, l, true, true);                                                  // insertions: printed now (:399)
+        if (prev) (void)ts_indels(s, c, in, ax, k - 1, l, false, true);                                                // deletions queued by the position before (:391-396, IndelQueue.cpp:9-12)
         if (c.per_lib) { ts_put(s, '\t'); ts_put(s, '}'); }
     }
     ts_put(s, '\n');

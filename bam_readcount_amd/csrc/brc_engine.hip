@@ -1883,9 +1883,10 @@ __global__ __launch_bounds__(256) void k_finalize_sum(const unsigned long long* 
 // ---------------------------------------------------------------- indel side path
 
 // Third-allele sub-lists -> one list (sub-list order; the events of one position all sit in one sub-list, in append
-// order, which is all the host needs): block s copies its entries behind those of the sub-lists before it.
+// order, which is all their fold needs): block s copies its entries behind those of the sub-lists before it, and counts them per
+// (64-position tile, library) bucket for the fold below.
 __global__ __launch_bounds__(256) void k_xev_compact(const XEv* __restrict__ lists, const uint32_t* __restrict__ cursors, uint32_t cap, uint32_t shards,
-                                                    XEv* __restrict__ out, Counters* __restrict__ ctr) {
+                                                    XEv* __restrict__ out, Counters* __restrict__ ctr, uint32_t* __restrict__ bucket_cnt, int Lp) {
     __shared__ unsigned long long sh[4];
     const uint32_t s = blockIdx.x;
     unsigned long long before = 0; uint32_t mx = 0;
@@ -1902,17 +1903,59 @@ __global__ __launch_bounds__(256) void k_xev_compact(const XEv* __restrict__ lis
     const unsigned long long off = sh[0] + sh[1] + sh[2] + sh[3];
     const uint32_t mine = cursors[(size_t)s * XEV_CTR_STRIDE], n = mine < cap ? mine : cap;
     const uint4* src = reinterpret_cast<const uint4*>(lists + (size_t)s * cap); uint4* dst = reinterpret_cast<uint4*>(out + off);
-    for (uint32_t i = threadIdx.x; i < n * 3u; i += 256) dst[i] = src[i];                 // 48-byte entries as 3 x 16 bytes
+    for (uint32_t i = threadIdx.x; i < n * 3u; i += 256) {                 // 48-byte entries as 3 x 16 bytes
+        const uint4 v = src[i]; dst[i] = v;
+        if (i % 3u == 0u) atomicAdd(bucket_cnt + ((size_t)(v.x >> 6) * (size_t)Lp + (size_t)(v.y >> 8)), 1u);      // (first 16 bytes of an entry: k, library << 8 | bucket)
+    }
     if (s == shards - 1 && threadIdx.x == 0) ctr->n_xev = (unsigned int)(off + n);
     if (s == 0 && (threadIdx.x & 63) == 0) atomicMax(&ctr->xev_max, mx);
+}
+// ... the compacted events' indices into their buckets (cursor[] = the exclusive scan of the counts, advanced to the buckets' ends) ...
+__global__ __launch_bounds__(256) void k_xev_scatter(const XEv* __restrict__ list, const Counters* __restrict__ ctr, uint32_t* __restrict__ cursor, uint32_t* __restrict__ idx, int Lp) {
+    const uint32_t n = ctr->n_xev;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const XEv& e = list[i];
+        idx[atomicAdd(cursor + ((size_t)(e.k >> 6) * (size_t)Lp + (size_t)(e.lib_b >> 8)), 1u)] = i;
+    }
+}
+// ... and the fold (brc_core.h: fold_xev_bucket), one lane per bucket that holds events: BasicStat::process_read's sums (BasicStat.cpp:28-107)
+// of the events that found both slots of their position taken, in column order.  A bucket's records take the first slots of its run in
+// out[]; end[] / cnt[] are rewritten to name them ([end - cnt, end)), the run's other slots are marked unused (k = NONE32).
+__global__ __launch_bounds__(256) void k_xev_fold(const XEv* __restrict__ list, uint32_t* __restrict__ cnt, uint32_t* __restrict__ end, int64_t n_buckets, uint32_t* __restrict__ idx, XAgg* __restrict__ out) {
+    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < n_buckets; b += (int64_t)gridDim.x * 256) {
+        const uint32_t n = cnt[b];
+        if (!n) continue;
+        const uint32_t start = end[b] - n;
+        const int nd = fold_xev_bucket(list, idx + start, (int)n, out + start);
+        for (uint32_t j = (uint32_t)nd; j < n; ++j) out[start + j].k = NONE32;
+        cnt[b] = (uint32_t)nd; end[b] = start + (uint32_t)nd;
+    }
+}
+// The last plane index at which every library was processed (a non-empty, not abandoned column: the positions pileup_func's loop body ran
+// for that library, :360): what the host needs to know which deletions a region leaves queued behind it (brc_host.cpp: format_device_text).
+// One block per library, from the back; NONE32: never.
+__global__ __launch_bounds__(256) void k_last_processed(DevCfg c, const uint32_t* __restrict__ ncol, const uint32_t* __restrict__ unavail, uint32_t* __restrict__ last) {
+    __shared__ uint32_t best;
+    const int l = blockIdx.x;
+    if (threadIdx.x == 0) best = 0u;                                          // (plane index + 1; 0: none yet)
+    __syncthreads();
+    for (int64_t hi = c.P; hi > 0; hi -= 256) {
+        const int64_t k = hi - 1 - (int64_t)threadIdx.x;
+        if (k >= 0 && ncol[(int64_t)l * c.PS + k] != 0u && !(c.per_lib && unavail[k] != NONE32)) atomicMax(&best, (uint32_t)k + 1u);
+        __syncthreads();
+        const uint32_t seen = best;
+        __syncthreads();
+        if (seen) break;
+    }
+    if (threadIdx.x == 0) last[l] = best ? best - 1u : NONE32;
 }
 
 // Device-side text (brc_core.h: text_line): byte length of every position's line, then — after an exclusive scan — the bytes.
 // One lane per position; a lane's stores walk its own line, neighbouring lanes write neighbouring lines.
-__global__ __launch_bounds__(256) void k_text_len(DevCfg c, DevIn in, Planes pl, TextCtx t, uint32_t* __restrict__ len) {
+__global__ __launch_bounds__(256) void k_text_len(DevCfg c, DevIn in, Planes pl, TextCtx t, TextAux ax, uint32_t* __restrict__ len) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k > c.P) return;
-    len[k] = k < c.P ? text_line(c, in, pl, t, k, nullptr) : 0u;        // (entry P: the scan turns it into the total)
+    len[k] = k < c.P ? text_line(c, in, pl, t, ax, k, nullptr) : 0u;        // (entry P: the scan turns it into the total)
 }
 // the true total of the line lengths, in 64 bits (the offsets are 32-bit: a region whose text would pass 4 GiB must not be written)
 __global__ __launch_bounds__(256) void k_text_total(const uint32_t* __restrict__ len, int64_t n, unsigned long long* __restrict__ total) {
@@ -1922,10 +1965,10 @@ __global__ __launch_bounds__(256) void k_text_total(const uint32_t* __restrict__
     for (int o = 32; o > 0; o >>= 1) v += (unsigned long long)__shfl_xor((long long)v, o, 64);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(total, v);
 }
-__global__ __launch_bounds__(256) void k_text_write(DevCfg c, DevIn in, Planes pl, TextCtx t, const uint32_t* __restrict__ off, char* __restrict__ text) {
+__global__ __launch_bounds__(256) void k_text_write(DevCfg c, DevIn in, Planes pl, TextCtx t, TextAux ax, const uint32_t* __restrict__ off, char* __restrict__ text) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= c.P || off[k + 1] == off[k]) return;
-    (void)text_line(c, in, pl, t, k, text + off[k]);
+    (void)text_line(c, in, pl, t, ax, k, text + off[k]);
 }
 
 // raw indel events (K1: one slot per I / D / P operator, unused ones marked NONE32) -> their (16 or 64 positions, library) buckets;
@@ -2037,7 +2080,8 @@ class HipBackend : public Backend {
     DBuf d_pos, d_flag, d_mapq, d_lib, d_lq, d_nc, d_co, d_so, d_qo, d_nm, d_sm, d_tags, d_cigar, d_seq, d_qual, d_ref, d_refcode;
     std::vector<uint16_t> h_wanted; bool has_wanted = false; DBuf d_wanted; std::vector<uint32_t> h_tilelist; DBuf d_tilelist;      // brc_region_windows (kept alive for the asynchronous copy)
     DBuf d_bq, d_bqw, d_bqrow, d_pieceoff, d_pieces, d_rare, d_keyreach, d_libbase, d_reads, d_agg, d_rng, d_ncol, d_depth, d_slotid, d_si, d_sf, d_xev, d_xevc, d_xevn, d_unavail, d_cnt, d_cursor, d_ev, d_evraw, d_ievoff, d_iout, d_ctr, d_tilectr, d_part, d_wavelist, d_nc_k1;
-    DBuf d_tlen, d_toff, d_text, d_tctx, d_total64;
+    DBuf d_tlen, d_toff, d_text, d_tctx, d_total64, d_lastproc;
+    DBuf d_xcnt, d_xend, d_xidx, d_xagg;   // the third-allele fold: events per (tile, library) bucket, the buckets' ends, the events' indices by bucket, the folded records
     // device-side text, downloaded (pinned) on its own stream into one of two host buffers
     HBuf<char> h_text[2]; HBuf<uint32_t> h_toff[2]; HBuf<uint32_t> h_total;
     hipStream_t stream2 = nullptr; hipEvent_t ev_text[2] = {nullptr, nullptr}, ev_lines = nullptr;
@@ -2056,7 +2100,8 @@ class HipBackend : public Backend {
     unsigned long long h_steps[3] = {0, 0, 0};   // piece-steps of the last pass: what the tile ranges hold / what k_pileup2 walked (brc_region_piece_steps)
     DBuf d_ccnt, d_coff, d_cpieces, d_crare, d_crng, d_ctot;
     // host result buffers (pinned)
-    HBuf<uint32_t> h_ncol, h_depth, h_slotid, h_si, h_unavail; HBuf<float> h_sf; HBuf<IndelOut> h_iout; HBuf<XEv> h_xev;
+    HBuf<uint32_t> h_ncol, h_depth, h_slotid, h_si, h_unavail; HBuf<float> h_sf; HBuf<IndelOut> h_iout; HBuf<XAgg> h_xagg; HBuf<uint32_t> h_lastproc[2];
+    std::vector<XAgg> xagg_compact;
     size_t xev_cap = 0;                  // entries per sub-list
     enum { XEV_SHARDS = 1024 };
     std::vector<IndelOut> iout_compact;
@@ -2126,7 +2171,7 @@ class HipBackend : public Backend {
         for (int i = 0; i < 2; ++i) { HIPCHK(hipEventCreateWithFlags(&ev_text[i], hipEventDisableTiming)); h_text[i].A = &kPinned; h_toff[i].A = &kPinned; }
         HIPCHK(hipEventCreateWithFlags(&ev_lines, hipEventDisableTiming));
         h_total.A = &kPinned;
-        h_ncol.A = h_depth.A = h_slotid.A = h_si.A = h_unavail.A = &kPinned; h_sf.A = &kPinned; h_iout.A = &kPinned; h_xev.A = &kPinned;
+        h_ncol.A = h_depth.A = h_slotid.A = h_si.A = h_unavail.A = &kPinned; h_sf.A = &kPinned; h_iout.A = &kPinned; h_xagg.A = &kPinned; h_lastproc[0].A = h_lastproc[1].A = &kPinned;
         return BRC_OK;
     }
     ~HipBackend() override {
@@ -2134,7 +2179,7 @@ class HipBackend : public Backend {
         if (getenv("BRC_ENGINE_TIMING")) fprintf(stderr, "device buffers: %llu (re)allocations, %.3f s\n", (unsigned long long)g_dev_allocs.load(), (double)g_dev_alloc_ns.load() * 1e-9);
         DBuf* all[] = {&d_pos, &d_flag, &d_mapq, &d_lib, &d_lq, &d_nc, &d_co, &d_so, &d_qo, &d_nm, &d_sm, &d_tags, &d_cigar, &d_seq, &d_qual,
                        &d_ref, &d_refcode, &d_bq, &d_bqw, &d_bqrow, &d_pieceoff, &d_pieces, &d_rare, &d_keyreach, &d_libbase, &d_reads, &d_agg, &d_rng, &d_ncol, &d_depth, &d_slotid, &d_si, &d_sf, &d_xev, &d_xevc, &d_xevn, &d_unavail, &d_cnt,
-                       &d_cursor, &d_ev, &d_evraw, &d_ievoff, &d_iout, &d_ctr, &d_tilectr, &d_part, &d_tlen, &d_toff, &d_text, &d_tctx, &d_total64, &d_wanted, &d_tilelist, &d_wavelist, &d_nc_k1};
+                       &d_cursor, &d_ev, &d_evraw, &d_ievoff, &d_iout, &d_ctr, &d_tilectr, &d_part, &d_tlen, &d_toff, &d_text, &d_tctx, &d_total64, &d_lastproc, &d_xcnt, &d_xend, &d_xidx, &d_xagg, &d_wanted, &d_tilelist, &d_wavelist, &d_nc_k1};
         for (DBuf* b : all) b->release();
         d_ccnt.release(); d_coff.release(); d_cpieces.release(); d_crare.release(); d_crng.release(); d_ctot.release();
 #ifdef BRC_CHECKED
@@ -2146,7 +2191,7 @@ class HipBackend : public Backend {
         if (stream2) (void)hipStreamDestroy(stream2);
         if (stream3) (void)hipStreamDestroy(stream3);
         d_agg2.release();
-        h_ncol.destroy(); h_depth.destroy(); h_slotid.destroy(); h_si.destroy(); h_unavail.destroy(); h_sf.destroy(); h_iout.destroy(); h_xev.destroy();
+        h_ncol.destroy(); h_depth.destroy(); h_slotid.destroy(); h_si.destroy(); h_unavail.destroy(); h_sf.destroy(); h_iout.destroy(); h_xagg.destroy(); h_lastproc[0].destroy(); h_lastproc[1].destroy();
         if (w_init) { w_ncol.destroy(); w_depth.destroy(); w_slotid.destroy(); w_si.destroy(); w_unavail.destroy(); w_sf.destroy(); }
         for (EvSet& es : evsets) { for (int i = 0; i <= T_N; ++i) if (es.evt[i]) (void)hipEventDestroy(es.evt[i]); for (int i = 0; i < 4; ++i) if (es.ev_indel[i]) (void)hipEventDestroy(es.ev_indel[i]); }
         if (stream) (void)hipStreamDestroy(stream);
@@ -2273,6 +2318,8 @@ class HipBackend : public Backend {
         }
         HIPCHK(d_xev.ensure(((size_t)XEV_SHARDS * xev_cap + 1) * sizeof(XEv))); HIPCHK(d_xevc.ensure(((size_t)XEV_SHARDS * xev_cap + 1) * sizeof(XEv)));
         HIPCHK(d_xevn.ensure((size_t)XEV_SHARDS * XEV_CTR_STRIDE * 4));
+        HIPCHK(d_xidx.ensure(((size_t)XEV_SHARDS * xev_cap + 1) * 4)); HIPCHK(d_xagg.ensure(((size_t)XEV_SHARDS * xev_cap + 1) * sizeof(XAgg)));
+        HIPCHK(d_xcnt.ensure(((size_t)ntiles * Lp + 2) * 4)); HIPCHK(d_xend.ensure(((size_t)ntiles * Lp + 2) * 4));
         HIPCHK(d_part.ensure(4096 * 5 * sizeof(unsigned long long)));
         HIPCHK(d_ctr.ensure(sizeof(Counters))); HIPCHK(d_tilectr.ensure(((size_t)ntiles * Lp + 1) * sizeof(uint4)));
         in.iev_off = nullptr;
@@ -2483,8 +2530,16 @@ class HipBackend : public Backend {
             if (has_wanted) { if (n_listed > 0) { if (c.pack_shift == 16) BRC_LAUNCH_KP(true, 16); else BRC_LAUNCH_KP(true, 12); } }
             else { if (c.pack_shift == 16) BRC_LAUNCH_KP(false, 16); else BRC_LAUNCH_KP(false, 12); }
 #undef BRC_LAUNCH_KP
+            // third-allele events: one list, then their fold per (position, library, bucket) in column order — the rest of
+            // BasicStat::process_read's accumulation (the host did this until round 6)
+            const int64_t nxb = ntiles * Lp;
+            HIPCHK(hipMemsetAsync(d_xcnt.p, 0, (size_t)nxb * 4, stream));
             hipLaunchKernelGGL(k_xev_compact, dim3((unsigned)XEV_SHARDS), dim3(256), 0, stream, (const XEv*)d_xev.p, (const uint32_t*)d_xevn.p, (uint32_t)xev_cap,
-                               (uint32_t)XEV_SHARDS, (XEv*)d_xevc.p, ctr);
+                               (uint32_t)XEV_SHARDS, (XEv*)d_xevc.p, ctr, (uint32_t*)d_xcnt.p, Lp);
+            if ((rc = scan<OpSumU32, false>((const uint32_t*)d_xcnt.p, (uint32_t*)d_xend.p, nxb))) return rc;
+            hipLaunchKernelGGL(k_xev_scatter, dim3(256), dim3(256), 0, stream, (const XEv*)d_xevc.p, (const Counters*)ctr, (uint32_t*)d_xend.p, (uint32_t*)d_xidx.p, Lp);
+            hipLaunchKernelGGL(k_xev_fold, dim3((unsigned)std::min<int64_t>((nxb + 255) / 256, 2048)), dim3(256), 0, stream, (const XEv*)d_xevc.p, (uint32_t*)d_xcnt.p, (uint32_t*)d_xend.p, nxb,
+                               (uint32_t*)d_xidx.p, (XAgg*)d_xagg.p);
         }
         HIPCHK(hipEventRecord(evt[T_COUNT], stream));
         if (P > 0) {
@@ -2512,6 +2567,7 @@ class HipBackend : public Backend {
         if ((size_t)h_ctr.xev_max > xev_cap) {
             xev_cap = (size_t)h_ctr.xev_max * 2;
             HIPCHK(d_xev.ensure(((size_t)XEV_SHARDS * xev_cap + 1) * sizeof(XEv))); HIPCHK(d_xevc.ensure(((size_t)XEV_SHARDS * xev_cap + 1) * sizeof(XEv)));
+            HIPCHK(d_xidx.ensure(((size_t)XEV_SHARDS * xev_cap + 1) * 4)); HIPCHK(d_xagg.ensure(((size_t)XEV_SHARDS * xev_cap + 1) * sizeof(XAgg)));
             *again = true;
         }
         return BRC_OK;
@@ -2567,7 +2623,8 @@ class HipBackend : public Backend {
         const int slot = (text_slot ^= 1); *slot_out = slot;
         text_started[slot] = true; text_total[slot] = 0; text_n[slot] = P;
         { const int rc0 = enqueue_lists(); if (rc0) return rc0; }
-        if (!h_toff[slot].reserve((size_t)P + 4) || !h_total.reserve(8)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }
+        if (!h_toff[slot].reserve((size_t)P + 4) || !h_total.reserve(8) || !h_lastproc[slot].reserve((size_t)c.Lp + 4)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }
+        for (int l = 0; l < c.Lp; ++l) h_lastproc[slot].p[l] = NONE32;
         if (P == 0) { h_toff[slot].p[0] = 0; HIPCHK(hipEventRecord(ev_text[slot], stream)); return BRC_OK; }
         // column 1 and the library names, behind the offsets of the names
         std::vector<int32_t> loff((size_t)c.Lp + 1, 0); std::string bytes = chrom;
@@ -2581,7 +2638,11 @@ class HipBackend : public Backend {
         HIPCHK(hipMemcpyAsync(d_tctx.p, ctx.data(), ctx.size(), hipMemcpyHostToDevice, stream));
         TextCtx t; t.lib_off = (const int32_t*)d_tctx.p; t.chrom = (const char*)d_tctx.p + ob; t.chrom_len = (int32_t)chrom.size(); t.lib_names = t.chrom;
         const unsigned nb = (unsigned)((P + 1 + 255) / 256);
-        hipLaunchKernelGGL(k_text_len, dim3(nb), dim3(256), 0, stream, c, in, pl_last, t, (uint32_t*)d_tlen.p);
+        const bool indels = n_indel_cap > 0 && c.P > 0 && c.n_reads > 0;
+        TextAux ax; memset(&ax, 0, sizeof ax);
+        ax.xagg = (const XAgg*)d_xagg.p; ax.xagg_end = (const uint32_t*)d_xend.p; ax.xagg_cnt = (const uint32_t*)d_xcnt.p;
+        if (indels) { ax.iout = (const IndelOut*)d_iout.p; ax.ib_end = (const uint32_t*)d_cursor.p; ax.ib_cnt = (const uint32_t*)d_cnt.p; ax.reads = (const DRead*)d_reads.p; }
+        hipLaunchKernelGGL(k_text_len, dim3(nb), dim3(256), 0, stream, c, in, pl_last, t, ax, (uint32_t*)d_tlen.p);
         int rc;
         if ((rc = scan<OpSumU32, false>((const uint32_t*)d_tlen.p, (uint32_t*)d_toff.p, P + 1))) return rc;
         // the 32-bit total, and the true one: the caller's estimate of the text size (brc_host.cpp) does not know the lengths of the
@@ -2600,12 +2661,16 @@ class HipBackend : public Backend {
         std::lock_guard<std::mutex> lk(text_mu);
         HIPCHK(d_text.ensure((size_t)total + 64));
         if (!h_text[slot].reserve((size_t)total + 64)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }
-        hipLaunchKernelGGL(k_text_write, dim3(nb), dim3(256), 0, stream, c, in, pl_last, t, (const uint32_t*)d_toff.p, (char*)d_text.p);
+        hipLaunchKernelGGL(k_text_write, dim3(nb), dim3(256), 0, stream, c, in, pl_last, t, ax, (const uint32_t*)d_toff.p, (char*)d_text.p);
+        // the last position every library was processed at: the host's account of what the region leaves in the deletion queues
+        HIPCHK(d_lastproc.ensure((size_t)c.Lp * 4 + 16));
+        hipLaunchKernelGGL(k_last_processed, dim3((unsigned)c.Lp), dim3(256), 0, stream, c, (const uint32_t*)d_ncol.p, (const uint32_t*)d_unavail.p, (uint32_t*)d_lastproc.p);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ev_lines, stream));
         // the copies run on their own stream: uploads and kernels of the next region do not queue behind 300 MB of text
         HIPCHK(hipStreamWaitEvent(stream2, ev_lines, 0));
         HIPCHK(hipMemcpyAsync(h_toff[slot].p, d_toff.p, ((size_t)P + 1) * 4, hipMemcpyDeviceToHost, stream2));
+        HIPCHK(hipMemcpyAsync(h_lastproc[slot].p, d_lastproc.p, (size_t)c.Lp * 4, hipMemcpyDeviceToHost, stream2));
         if (total) HIPCHK(hipMemcpyAsync(h_text[slot].p, d_text.p, (size_t)total, hipMemcpyDeviceToHost, stream2));
         HIPCHK(hipEventRecord(ev_text[slot], stream2));
         // ... but the next region's kernels overwrite d_toff / d_text / the planes only after the copies (d_text is rewritten
@@ -2617,7 +2682,7 @@ class HipBackend : public Backend {
         slot &= 1;
         if (!text_started[slot]) { err = "no device text was started"; return BRC_E_ARG; }
         HIPCHK(hipEventSynchronize(ev_text[slot]));
-        out->text = h_text[slot].p; out->off = h_toff[slot].p; out->total = text_total[slot]; out->n = text_n[slot];
+        out->text = h_text[slot].p; out->off = h_toff[slot].p; out->total = text_total[slot]; out->n = text_n[slot]; out->last_processed = h_lastproc[slot].p;
         return BRC_OK;
     }
 
@@ -2656,11 +2721,13 @@ class HipBackend : public Backend {
             HIPCHK(hipStreamSynchronize(stream));
             iout_compact.clear();
             for (size_t i = 0; i < (size_t)h_ctr.n_indel_slots; ++i) if (h_iout.p[i].len != 0) iout_compact.push_back(h_iout.p[i]);
+            xagg_compact.clear();
+            for (size_t i = 0; i < (size_t)h_ctr.n_xev; ++i) if (h_xagg.p[i].k != NONE32) xagg_compact.push_back(h_xagg.p[i]);
             lists_host = true;
         } else HIPCHK(hipStreamSynchronize(stream));
         *out = HostPlanes();
         out->ncol = w_ncol.p; out->depth = w_depth.p; out->slotid = w_slotid.p; out->si = w_si.p; out->sf = w_sf.p; out->unavail = w_unavail.p;
-        out->xev = h_xev.p; out->n_xev = h_ctr.n_xev;
+        out->xagg = xagg_compact.data(); out->n_xagg = xagg_compact.size();
         out->indel = iout_compact.data(); out->n_indel = (int64_t)iout_compact.size();
         out->n_events = h_ctr.n_events; out->n_positions = h_ctr.n_positions;
         *stride = (int64_t)WS;
@@ -2671,8 +2738,8 @@ class HipBackend : public Backend {
     bool lists_enqueued = false;
     int enqueue_lists() {
         const size_t nx = h_ctr.n_xev, ns = h_ctr.n_indel_slots;
-        if (!h_xev.reserve(nx + 4) || !h_iout.reserve(ns + 4)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }
-        if (nx) HIPCHK(hipMemcpyAsync(h_xev.p, d_xevc.p, nx * sizeof(XEv), hipMemcpyDeviceToHost, stream));
+        if (!h_xagg.reserve(nx + 4) || !h_iout.reserve(ns + 4)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }
+        if (nx) HIPCHK(hipMemcpyAsync(h_xagg.p, d_xagg.p, nx * sizeof(XAgg), hipMemcpyDeviceToHost, stream));        // (a record per event at the most; unused slots are marked)
         if (ns) HIPCHK(hipMemcpyAsync(h_iout.p, d_iout.p, ns * sizeof(IndelOut), hipMemcpyDeviceToHost, stream));
         lists_enqueued = true;
         return BRC_OK;
@@ -2693,7 +2760,7 @@ class HipBackend : public Backend {
         const size_t P = planes ? (size_t)c.PS : 0, Lp = (size_t)c.Lp;   // planes are copied with their padded stride
         const size_t nx = h_ctr.n_xev;
         if (!h_ncol.reserve(Lp * P + 4) || !h_depth.reserve(Lp * P + 4) || !h_slotid.reserve(Lp * P + 4) || !h_unavail.reserve(P + 4) ||
-            !h_si.reserve(Lp * 2 * NI * P + 4) || !h_sf.reserve(Lp * 2 * NF * P + 4) || !h_xev.reserve(nx + 4)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }
+            !h_si.reserve(Lp * 2 * NI * P + 4) || !h_sf.reserve(Lp * 2 * NF * P + 4)) { err = "pinned host allocation failed"; return BRC_E_NOMEM; }
         if (P) {
             HIPCHK(hipMemcpyAsync(h_ncol.p, d_ncol.p, Lp * P * 4, hipMemcpyDeviceToHost, stream));
             HIPCHK(hipMemcpyAsync(h_depth.p, d_depth.p, Lp * P * 4, hipMemcpyDeviceToHost, stream));
@@ -2708,9 +2775,11 @@ class HipBackend : public Backend {
         HIPCHK(hipStreamSynchronize(stream));
         iout_compact.clear();
         for (size_t i = 0; i < ns; ++i) if (h_iout.p[i].len != 0) iout_compact.push_back(h_iout.p[i]);
+        xagg_compact.clear();
+        for (size_t i = 0; i < nx; ++i) if (h_xagg.p[i].k != NONE32) xagg_compact.push_back(h_xagg.p[i]);
         lists_host = true;
         out->ncol = h_ncol.p; out->depth = h_depth.p; out->slotid = h_slotid.p; out->si = h_si.p; out->sf = h_sf.p; out->unavail = h_unavail.p;
-        out->xev = h_xev.p; out->n_xev = nx;
+        out->xagg = xagg_compact.data(); out->n_xagg = xagg_compact.size();
         out->indel = iout_compact.data(); out->n_indel = (int64_t)iout_compact.size();
         out->n_events = h_ctr.n_events; out->n_positions = h_ctr.n_positions;
         out->warn[BRC_W_SM_MISSING] = h_ctr.w_sm; out->warn[BRC_W_NM_MISSING] = h_ctr.w_nm; out->warn[BRC_W_ZM_MISSING] = 0;

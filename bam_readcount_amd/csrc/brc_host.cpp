@@ -231,17 +231,15 @@ void expand_slots(const HostPlanes& hp, int Lp, int64_t P, int64_t PS, uint32_t*
     for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
     work();
     for (auto& t : th) t.join();
-    // third-allele events, in list order (= pileup-column order of every bucket they touch)
-    for (uint64_t i = 0; i < hp.n_xev; ++i) {
-        const XEv& e = hp.xev[i];
-        const int64_t l = e.lib_b >> 8; const uint32_t b = e.lib_b & 0xffu; const int64_t k = e.k;
+    // third-allele buckets: their sums were folded on the device (brc_core.h: fold_xev_bucket); a bucket's sums sit in ONE place — the
+    // slot that names it, or this table (also for a bucket a slot names: the events of an N / '=' base never enter the slots)
+    for (uint64_t i = 0; i < hp.n_xagg; ++i) {
+        const XAgg& a = hp.xagg[i];
+        const int64_t l = a.lib_b >> 8; const uint32_t b = a.lib_b & 0xffu; const int64_t k = a.k;
         if (l >= Lp || b >= (uint32_t)NBUCKET || k >= P) continue;
         uint32_t* ip = istat + ((l * NBUCKET + b) * NI) * PS + k; float* fp = fstat + ((l * NBUCKET + b) * NF) * PS + k;
-        const uint32_t rev = (e.qf >> 8) & 1u;
-        ip[I_N * PS] += 1u; ip[I_SMQ * PS] += e.mapq; ip[I_SSE * PS] += e.sse; ip[I_PLUS * PS] += 1u - rev; ip[I_MINUS * PS] += rev;
-        ip[I_NQ2 * PS] += (e.qf >> 9) & 1u; ip[I_SMMQ * PS] += e.zm; ip[I_SCLIP * PS] += e.clip; ip[I_SBQ * PS] += e.qf & 0xffu;
-        fp[F_SQ2 * PS] += e.fq2; fp[F_S3P * PS] += e.fs3p; fp[F_SNM * PS] += e.fsnm;
-        fp[F_SEV * PS] = (float)((double)fp[F_SEV * PS] + e.sev);
+        for (int f = 0; f < NI; ++f) ip[(int64_t)f * PS] = a.i[f];
+        for (int f = 0; f < NF; ++f) fp[(int64_t)f * PS] = a.f[f];
     }
 }
 
@@ -298,7 +296,7 @@ struct TextBuf {
 using namespace brc;
 
 struct QEnt { uint32_t tid, pos; brc_stat st; std::string allele; };
-struct XAgg { uint64_t key; brc_stat st; };      // key = k << 16 | library << 8 | bucket
+struct XKey { uint64_t key; brc_stat st; };      // a third-allele bucket for the host formatter's merge: key = k << 16 | library << 8 | bucket
 
 struct brc_engine {
     brc_config cfg;
@@ -322,7 +320,7 @@ struct brc_engine {
     std::vector<char> refbase;
     // brc_fetch_window: the dense result of one window of the computed region (buffers of its own: a fetched whole-region result stays valid)
     uint32_t* win_i = nullptr; float* win_f = nullptr; size_t win_cap = 0;
-    std::vector<brc_indel> win_indels; std::string win_alleles; std::vector<char> win_refbase; std::vector<XEv> win_xev; std::vector<IndelOut> win_iout;
+    std::vector<brc_indel> win_indels; std::string win_alleles; std::vector<char> win_refbase; std::vector<XAgg> win_xagg; std::vector<IndelOut> win_iout;
     // BRC_OPT_TEXT_ONLY: the caller only formats (brc_format_region / brc_format_window): no dense planes are built, the
     // formatter reads the compact slot planes; third-allele events are aggregated into a sparse (position, library,
     // bucket)-sorted table instead
@@ -331,10 +329,16 @@ struct brc_engine {
     bool device_text = false; std::string chrom;   // BRC_OPT_DEVICE_TEXT / brc_set_chrom
     bool text_result = false;                       // the last fetched result is device text (no planes on the host)
     bool text_computed = false; int text_slot_computed = 0, text_slot = 0;   // device text started by the last brc_compute / fetched
+    // a text result and the host's deletion queues (prepare_text_queues / format_device_text): per library the deletion buckets at the
+    // library's last position that has any, as the queue entries they would be; and — only when the queues were not empty when the
+    // result was fetched — every deletion bucket of the region, sorted by (position, library, length)
+    struct DelEnt { int32_t pos, lib, len; brc_stat st; std::string allele; };
+    std::vector<std::vector<QEnt> > tail_dels; std::vector<int64_t> tail_pos;
+    std::vector<DelEnt> dels; bool have_dels = false;
     TextBuf pbuf;                                   // the lines the host rewrote
     struct Patch { int64_t k; size_t off, len; };
     std::vector<Patch> patches;
-    std::vector<XAgg> xagg;
+    std::vector<XKey> xagg;
     size_t hint_reads = 0, hint_bases = 0;          // BRC_OPT_EXPECT_*: staging is sized once instead of grown batch by batch
     // formatter state: the text of the last call (one contiguous buffer, capacity kept across calls), the per-chunk
     // buffers the threads format into (kept too: a fresh 300-MB buffer per piece costs more in page faults than the text)
@@ -398,6 +402,44 @@ static void assemble_indels(const brc_engine* e, const IndelOut* list, int64_t n
         alleles += txt[ord[i]];
         for (int f = 0; f < BRC_NI; ++f) d.stat.i[f] = o.i[f];
         for (int f = 0; f < BRC_NF; ++f) d.stat.f[f] = o.f[f];
+    }
+}
+
+// A text result (BRC_OPT_DEVICE_TEXT): the device wrote the indel entries of every line itself, assuming deletion queues that hold nothing but
+// what the position before queued.  What is left for the host is the queues' own life ACROSS regions (the reference never clears them
+// between command-line regions, bamreadcount.cpp:641-657): which deletions this region leaves pending — those queued at the last position a
+// library was processed at (IndelQueue.cpp:3-15: an entry lives until the library's next processed position) — and, when the region did
+// not start from clean queues, the true entries of its lines (format_device_text rewrites them).  Runs inside brc_fetch_result: the
+// reference bases (deletion alleles are the reference's characters, :331-338) are the caller's only until that call returns, and the
+// region before has been formatted by then (include/brc.h, threads), so the queues are what this region will find.
+static std::string deletion_allele(const Geometry& g, const IndelOut& o) {
+    std::string a; a.push_back('-');
+    for (int j = 0; j < -o.len; ++j) { const int64_t p = (int64_t)o.pos + 1 + j; a.push_back((g.ref && p < g.ref_len && g.ref[p]) ? g.ref[p] : 'N'); }
+    return a;
+}
+static void prepare_text_queues(brc_engine* e) {
+    const Geometry& g = e->g; const HostPlanes& hp = e->hp; const int Lp = g.Lp;
+    e->tail_dels.assign((size_t)Lp, std::vector<QEnt>()); e->tail_pos.assign((size_t)Lp, INT64_MIN);
+    for (int64_t i = 0; i < hp.n_indel; ++i) { const IndelOut& o = hp.indel[i]; if (o.len < 0 && o.lib >= 0 && o.lib < Lp && (int64_t)o.pos > e->tail_pos[(size_t)o.lib]) e->tail_pos[(size_t)o.lib] = o.pos; }
+    auto stat_of = [](const IndelOut& o) { brc_stat st; for (int f = 0; f < BRC_NI; ++f) st.i[f] = o.i[f]; for (int f = 0; f < BRC_NF; ++f) st.f[f] = o.f[f]; return st; };
+    for (int64_t i = 0; i < hp.n_indel; ++i) {
+        const IndelOut& o = hp.indel[i];
+        if (o.len >= 0 || o.lib < 0 || o.lib >= Lp || (int64_t)o.pos != e->tail_pos[(size_t)o.lib]) continue;
+        QEnt q; q.tid = (uint32_t)g.tid; q.pos = (uint32_t)o.pos + 1u; q.st = stat_of(o); q.allele = deletion_allele(g, o);
+        e->tail_dels[(size_t)o.lib].push_back(q);
+    }
+    // (deletions at one position are prefixes of one another: allele order = by length, what std::map<std::string, ...> gives, :389)
+    for (std::vector<QEnt>& v : e->tail_dels) std::sort(v.begin(), v.end(), [](const QEnt& a, const QEnt& b) { return a.allele.size() < b.allele.size(); });
+    bool busy = false; for (const std::deque<QEnt>& q : e->queue) if (!q.empty()) busy = true;
+    e->dels.clear(); e->have_dels = busy;
+    if (busy) {
+        for (int64_t i = 0; i < hp.n_indel; ++i) {
+            const IndelOut& o = hp.indel[i];
+            if (o.len >= 0) continue;
+            brc_engine::DelEnt d; d.pos = o.pos; d.lib = o.lib; d.len = o.len; d.st = stat_of(o); d.allele = deletion_allele(g, o);
+            e->dels.push_back(std::move(d));
+        }
+        std::sort(e->dels.begin(), e->dels.end(), [](const brc_engine::DelEnt& a, const brc_engine::DelEnt& b) { return a.pos != b.pos ? a.pos < b.pos : (a.lib != b.lib ? a.lib < b.lib : a.len > b.len); });
     }
 }
 
@@ -797,15 +839,10 @@ static int compute_passes(brc_engine* e, int32_t n, brc_timing* t) {
     if (rc) return fail(e, rc, e->be->last_error());
     // device-side text: the line kernels and the download start as soon as the region is computed (lines above 4 GiB per
     // region would overflow the 32-bit offsets: such regions are formatted on the host)
+    // (indel entries are part of the lines now: their share of the estimate comes from the list sizes of this pass)
+    uint64_t nx_ = 0, ni_ = 0; e->be->list_sizes(&nx_, &ni_);
     e->text_computed = e->text_only && e->device_text && !e->chrom.empty() &&
-                       (double)e->g.P * (double)e->g.Lp * 700.0 + 64.0 * (double)e->g.P < 4.0e9;
-    if (e->text_computed) {
-        // the host rewrites the lines with indel buckets (and the line after a deletion) or a third base one by one: where
-        // those are a large share of the region (deep, indel-rich data) the pooled host formatter is the faster route
-        uint64_t nx = 0, ni = 0; e->be->list_sizes(&nx, &ni);
-        static const double max_share = getenv("BRC_DEVICE_TEXT_MAX_SHARE") ? atof(getenv("BRC_DEVICE_TEXT_MAX_SHARE")) : 0.06;
-        if ((double)nx + 2.0 * (double)ni > max_share * (double)std::max<int64_t>(e->g.P, 1)) e->text_computed = false;
-    }
+                       (double)e->g.P * (double)e->g.Lp * 700.0 + 64.0 * (double)e->g.P + 2.0 * (double)ni_ * (700.0 + (double)e->st.max_span) < 4.0e9;
     if (e->text_computed) {
         rc = e->be->text_begin(e->chrom, e->libs, &e->text_slot_computed);
         if (rc == BRC_TEXT_TOO_LONG) e->text_computed = false;          // (the estimate above was too low: long library names, sums at the far end of int32)
@@ -824,7 +861,7 @@ int brc_fetch_result(brc_engine* e, brc_result* out) {
     int rc = e->be->fetch(&e->hp, !e->text_result);
     if (rc) return fail(e, rc, e->be->last_error());
     const double t_dl = now_s(); e->t_d2h += t_dl - t_in;
-    e->n_xev_total += e->hp.n_xev; e->n_indel_total += (uint64_t)e->hp.n_indel;
+    e->n_xev_total += e->hp.n_xagg; e->n_indel_total += (uint64_t)e->hp.n_indel;
     const Geometry& g = e->g; const HostPlanes& hp = e->hp;
     // column 3: raw reference character (bamreadcount.cpp:353)
     e->refbase.resize((size_t)g.P + 1);
@@ -834,30 +871,24 @@ int brc_fetch_result(brc_engine* e, brc_result* out) {
         for (int64_t k = 0; k < have; ++k) if (!e->refbase[(size_t)k]) e->refbase[(size_t)k] = 'N';
         if (g.P > have) memset(e->refbase.data() + have, 'N', (size_t)(g.P - have));
     }
-    assemble_indels(e, hp.indel, hp.n_indel, e->indels, e->alleles);
+    // a text result leaves the indel buckets to the device's lines; the host keeps what its deletion queues need (prepare_text_queues)
+    if (e->text_result) { e->indels.clear(); e->alleles.clear(); prepare_text_queues(e); }
+    else assemble_indels(e, hp.indel, hp.n_indel, e->indels, e->alleles);
     memset(out, 0, sizeof *out);
     out->tid = g.tid; out->beg0 = g.beg0; out->end = g.end; out->pos0 = g.pos0; out->n_pos = g.P; out->stride = g.PS; out->n_lib = g.Lp;
-    if (e->text_only) {
-        // third-allele events -> one brc_stat per (position, library, bucket), accumulated in list order (= the pileup-column
-        // order of every bucket they touch); sorted by position for the formatter's merge
-        std::vector<std::pair<uint64_t, uint32_t> > ord2((size_t)hp.n_xev);
-        for (uint64_t i = 0; i < hp.n_xev; ++i) {
-            const XEv& x = hp.xev[i];
-            ord2[(size_t)i] = std::make_pair(((uint64_t)x.k << 16) | (uint64_t)(x.lib_b & 0xffffu), (uint32_t)i);
-        }
-        std::stable_sort(ord2.begin(), ord2.end(), [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& b) { return a.first < b.first; });
-        e->xagg.clear();
-        for (const auto& kv : ord2) {
-            const XEv& x = hp.xev[kv.second];
+    if (e->text_result) {
+    } else if (e->text_only) {
+        // third-allele buckets -> sorted by (position, library, bucket) for the formatter's merge (the device groups them by tile and library)
+        e->xagg.clear(); e->xagg.reserve((size_t)hp.n_xagg);
+        for (uint64_t i = 0; i < hp.n_xagg; ++i) {
+            const XAgg& x = hp.xagg[i];
             if ((int64_t)(x.lib_b >> 8) >= g.Lp || (x.lib_b & 0xffu) >= (uint32_t)NBUCKET || (int64_t)x.k >= g.P) continue;
-            if (e->xagg.empty() || e->xagg.back().key != kv.first) { XAgg a; a.key = kv.first; memset(&a.st, 0, sizeof a.st); e->xagg.push_back(a); }
-            brc_stat& t = e->xagg.back().st;
-            const uint32_t rev = (x.qf >> 8) & 1u;
-            t.i[I_N] += 1u; t.i[I_SMQ] += x.mapq; t.i[I_SSE] += x.sse; t.i[I_PLUS] += 1u - rev; t.i[I_MINUS] += rev;
-            t.i[I_NQ2] += (x.qf >> 9) & 1u; t.i[I_SMMQ] += x.zm; t.i[I_SCLIP] += x.clip; t.i[I_SBQ] += x.qf & 0xffu;
-            t.f[F_SQ2] += x.fq2; t.f[F_S3P] += x.fs3p; t.f[F_SNM] += x.fsnm;
-            t.f[F_SEV] = (float)((double)t.f[F_SEV] + x.sev);
+            XKey a; a.key = ((uint64_t)x.k << 16) | (uint64_t)(x.lib_b & 0xffffu);
+            for (int f = 0; f < BRC_NI; ++f) a.st.i[f] = x.i[f];
+            for (int f = 0; f < BRC_NF; ++f) a.st.f[f] = x.f[f];
+            e->xagg.push_back(a);
         }
+        std::sort(e->xagg.begin(), e->xagg.end(), [](const XKey& a, const XKey& b) { return a.key < b.key; });
     } else {
         const size_t need = (size_t)g.Lp * NBUCKET * (size_t)g.PS + 16;
         if (need > e->dense_cap) {
@@ -899,10 +930,10 @@ int brc_fetch_window(brc_engine* e, int32_t beg0, int32_t end, brc_result* out) 
     if (rc) return fail(e, rc, e->be->last_error());
     const int32_t wpos0 = (int32_t)(g.pos0 + k0);
     // the two lists cover the whole region: keep the window's entries (third-allele events re-based to the window's planes)
-    e->win_xev.clear(); e->win_iout.clear();
-    for (uint64_t i = 0; i < hw.n_xev; ++i) { const XEv& x = hw.xev[i]; if ((int64_t)x.k >= k0 && (int64_t)x.k < k1) { XEv y = x; y.k = (uint32_t)((int64_t)x.k - k0); e->win_xev.push_back(y); } }
+    e->win_xagg.clear(); e->win_iout.clear();
+    for (uint64_t i = 0; i < hw.n_xagg; ++i) { const XAgg& x = hw.xagg[i]; if ((int64_t)x.k >= k0 && (int64_t)x.k < k1) { XAgg y = x; y.k = (uint32_t)((int64_t)x.k - k0); e->win_xagg.push_back(y); } }
     for (int64_t i = 0; i < hw.n_indel; ++i) { const IndelOut& o = hw.indel[i]; if (o.pos >= wpos0 && (int64_t)o.pos < (int64_t)wpos0 + n) e->win_iout.push_back(o); }
-    hw.xev = e->win_xev.data(); hw.n_xev = e->win_xev.size();
+    hw.xagg = e->win_xagg.data(); hw.n_xagg = e->win_xagg.size();
     assemble_indels(e, e->win_iout.data(), (int64_t)e->win_iout.size(), e->win_indels, e->win_alleles);
     const size_t need = (size_t)g.Lp * NBUCKET * (size_t)WS + 16;
     if (need > e->win_cap) {
@@ -992,7 +1023,7 @@ static bool format_range(const brc_engine* e, const brc_result* r, const char* c
     const bool compact = r->istat == NULL;
     const HostPlanes& hp = e->hp;
     size_t xi = 0;
-    if (compact) xi = (size_t)(std::lower_bound(e->xagg.begin(), e->xagg.end(), (uint64_t)k0 << 16, [](const XAgg& a, uint64_t key) { return a.key < key; }) - e->xagg.begin());
+    if (compact) xi = (size_t)(std::lower_bound(e->xagg.begin(), e->xagg.end(), (uint64_t)k0 << 16, [](const XKey& a, uint64_t key) { return a.key < key; }) - e->xagg.begin());
     const uint32_t tid = (uint32_t)r->tid;
     for (int64_t k = k0; k < k1; ++k) {
         const int32_t pos = r->pos0 + (int32_t)k;
@@ -1114,32 +1145,48 @@ static int format_device_text(brc_engine* e, const brc_result* r) {
     const uint32_t tid = (uint32_t)r->tid;
     e->pbuf.clear(); e->patches.clear();
     std::vector<std::deque<QEnt> >& queue = e->queue;
-    int64_t ii = 0; size_t xi = 0;
+    const bool lead = P > 0 && r->pos0 < r->beg0;                   // plane index 0 is the lead position: never printed
+    // ---- did the region start from the queues its lines assume?  Empty ones — or, for a region that continues the piece before it, nothing
+    // but what that piece's last position (this region's lead position) queued: the device queued the same again
+    bool busy = false, expected = true;
+    for (const std::deque<QEnt>& q : queue) for (const QEnt& x : q) { busy = true; if (!(e->continues && lead && x.tid == tid && x.pos == (uint32_t)r->beg0)) expected = false; }
+    if (!busy || expected) {
+        e->part_ptr.clear(); e->part_len.clear();
+        const uint64_t cur = lead ? ht.off[1] : 0;
+        if (P > 0 && ht.total > cur) { e->part_ptr.push_back(ht.text + cur); e->part_len.push_back((size_t)(ht.total - cur)); }
+        // what the region leaves pending: per library the deletions of its last processed position (a library that was never processed
+        // keeps what it had)
+        for (int l = 0; l < Lp; ++l) {
+            const uint32_t lp = ht.last_processed ? ht.last_processed[l] : NONE32;
+            if (lp == NONE32) continue;
+            std::deque<QEnt>& q = queue[(size_t)l]; q.clear();
+            if ((size_t)l < e->tail_pos.size() && e->tail_pos[(size_t)l] == (int64_t)r->pos0 + (int64_t)lp) for (const QEnt& x : e->tail_dels[(size_t)l]) q.push_back(x);
+        }
+        return BRC_OK;
+    }
+    // ---- queues that hold something else (a deletion an earlier command-line region left pending, :641-657): the deletion entries of the
+    // lines are rewritten with IndelQueue::process's own rules (IndelQueue.cpp:3-15) — entries stuck behind a later-due front entry included.
+    // Every line is a candidate while a queue is not empty (process() runs at every printed position).
+    if (!e->have_dels) return fail(e, BRC_E_ARG, "a text result must be formatted after the region before it (the deletion queues changed behind its back)");
+    const std::vector<brc_engine::DelEnt>& dels = e->dels;
+    size_t di = 0;
     auto queues_busy = [&]() { for (const std::deque<QEnt>& q : queue) if (!q.empty()) return true; return false; };
     char nb[STAT_MAX + 64];
     int64_t k = -1;
-    // the lines to rewrite are scattered over text that just arrived by DMA (not in any cache): pull the next few in early
-    int64_t la_i = 0; size_t la_x = 0;
-    auto prefetch_line = [&](int64_t kk) { if (kk >= 0 && kk < P) { const char* q = ht.text + ht.off[kk]; for (int o = 0; o < 448; o += 64) __builtin_prefetch(q + o); } };
     for (;;) {
-        for (la_i = std::max(la_i, ii); la_i < r->n_indel && la_i < ii + 12; ++la_i) { const int64_t kk = (int64_t)r->indel[la_i].pos - r->pos0; prefetch_line(kk); prefetch_line(kk + 1); }
-        for (la_x = std::max(la_x, xi); la_x < e->xagg.size() && la_x < xi + 12; ++la_x) prefetch_line((int64_t)(e->xagg[la_x].key >> 16));
-        while (ii < r->n_indel && (int64_t)r->indel[ii].pos - r->pos0 <= k) ++ii;       // behind the last line looked at
-        while (xi < e->xagg.size() && (int64_t)(e->xagg[xi].key >> 16) <= k) ++xi;
+        while (di < dels.size() && (int64_t)dels[di].pos - r->pos0 <= k) ++di;           // behind the last line looked at
         int64_t kc = INT64_MAX;
-        if (ii < r->n_indel) kc = std::min<int64_t>(kc, (int64_t)r->indel[ii].pos - r->pos0);
-        if (xi < e->xagg.size()) kc = std::min<int64_t>(kc, (int64_t)(e->xagg[xi].key >> 16));
+        if (di < dels.size()) kc = std::min<int64_t>(kc, (int64_t)dels[di].pos - r->pos0);
         if (queues_busy()) { int64_t j = k + 1; while (j < P && ht.off[j + 1] == ht.off[j]) ++j; if (j < P) kc = std::min(kc, j); }
         if (kc == INT64_MAX || kc >= P) break;
         if (kc <= k) kc = k + 1;                                   // (defensive: cursors always move forward)
         k = kc;
         const int32_t pos = r->pos0 + (int32_t)k;
-        while (ii < r->n_indel && r->indel[ii].pos < pos) ++ii;
-        while (xi < e->xagg.size() && (int64_t)(e->xagg[xi].key >> 16) < k) ++xi;
-        if (ht.off[k + 1] == ht.off[k] || (k == 0 && e->continues && r->pos0 < r->beg0)) {
+        while (di < dels.size() && dels[di].pos < pos) ++di;
+        if (ht.off[k + 1] == ht.off[k] || (k == 0 && e->continues && lead)) {
             // no line: no pileup callback here, nothing is queued or processed — nor at the lead position of a region that
             // continues the previous one (it was that region's last position)
-            while (ii < r->n_indel && r->indel[ii].pos == pos) ++ii;
+            while (di < dels.size() && dels[di].pos == pos) ++di;
             continue;
         }
         const char* L0 = ht.text + ht.off[k]; const char* const L1 = ht.text + ht.off[k + 1] - 1;    // [L0, L1): the line without its newline
@@ -1155,9 +1202,9 @@ static int format_device_text(brc_engine* e, const brc_result* r) {
         char* w0 = e->pbuf.room(cap_need);
         if (!w0) return fail(e, BRC_E_NOMEM, "host allocation of the text buffers failed");
         size_t wn = pre + 10;                                      // bytes used behind w0 (body starts here)
-        bool changed = false; uint32_t extra = 0;
+        bool changed = false; uint32_t extra = 0, dev_extra = 0;
         auto put = [&](const char* src, size_t len) -> bool {
-            if (wn + len + 64 > cap_need) {                        // indel entries make a line longer than the device's
+            if (wn + len + 64 > cap_need) {                        // queued entries can make a line longer than the device's
                 cap_need = wn + len + 4096;
                 if (!e->pbuf.room(cap_need)) return false;
                 w0 = e->pbuf.p + base;
@@ -1165,19 +1212,20 @@ static int format_device_text(brc_engine* e, const brc_result* r) {
             memcpy(w0 + wn, src, len); wn += len;
             return true;
         };
-        auto bucket_tokens = [&](int l) -> bool {
-            const bool any = xi < e->xagg.size() && (int64_t)(e->xagg[xi].key >> 16) == k;
-            for (int b = 0; b < BRC_NBUCKET; ++b) {                // p at '\t' of "\tX:stat"
+        // the tokens of one library's block: six buckets and the insertion entries as they are; the device's deletion entries are dropped
+        // (their read counts leave the depth)
+        auto block_tokens = [&](const char* end) -> bool {
+            int tok = 0;
+            while (p < end) {
                 const char* t0 = p;
-                const char* t1 = (const char*)memchr(p + 1, '\t', (size_t)(L1 - p - 1));
-                p = t1 ? t1 : L1;
-                const XAgg* xa = nullptr;
-                if (any) for (size_t x = xi; x < e->xagg.size() && (int64_t)(e->xagg[x].key >> 16) == k; ++x)
-                    if ((e->xagg[x].key & 0xffffu) == (((uint64_t)l << 8) | (uint64_t)b)) { xa = &e->xagg[x]; break; }
-                if (!xa) { if (!put(t0, (size_t)(p - t0))) return false; continue; }
-                char* w = fmt_stat(nb, xa->st.i, xa->st.f, false);
-                if (!put(t0, 3) || !put(nb, (size_t)(w - nb))) return false;       // "\tX:" + the bucket's text
-                changed = true;
+                const char* t1 = (const char*)memchr(p + 1, '\t', (size_t)(end - p - 1));
+                p = t1 ? t1 : end;
+                if (tok >= BRC_NBUCKET && t0[1] == '-') {
+                    const char* c = (const char*)memchr(t0, ':', (size_t)(p - t0)); uint32_t n = 0;
+                    if (c) for (++c; c < p && *c >= '0' && *c <= '9'; ++c) n = n * 10u + (uint32_t)(*c - '0');
+                    dev_extra += n; changed = true;
+                } else if (!put(t0, (size_t)(p - t0))) return false;
+                ++tok;
             }
             return true;
         };
@@ -1187,14 +1235,10 @@ static int format_device_text(brc_engine* e, const brc_result* r) {
                 changed = true;
                 return put("\t", 1) && put(allele, alen) && put(":", 1) && put(nb, (size_t)(w - nb));
             };
-            while (ii < r->n_indel && r->indel[ii].pos == pos && r->indel[ii].lib < l) ++ii;
-            for (; ii < r->n_indel && r->indel[ii].pos == pos && r->indel[ii].lib == l; ++ii) {
-                const brc_indel& d = r->indel[ii];
-                if (d.len < 0) {                                                          // :391-396
-                    QEnt q; q.tid = tid; q.pos = (uint32_t)pos + 1; q.st = d.stat;
-                    q.allele.assign(r->alleles + d.allele_off, d.allele_len);
-                    queue[(size_t)l].push_back(q);
-                } else if (!entry(r->alleles + d.allele_off, d.allele_len, d.stat.i, d.stat.f)) return false;   // :399
+            while (di < dels.size() && dels[di].pos == pos && dels[di].lib < l) ++di;
+            for (; di < dels.size() && dels[di].pos == pos && dels[di].lib == l; ++di) {          // :391-396
+                QEnt q; q.tid = tid; q.pos = (uint32_t)pos + 1; q.st = dels[di].st; q.allele = dels[di].allele;
+                queue[(size_t)l].push_back(q);
             }
             std::deque<QEnt>& q = queue[(size_t)l];                                       // IndelQueue::process
             while (!q.empty() && ((q.front().tid == tid && q.front().pos < (uint32_t)pos) || q.front().tid != tid)) q.pop_front();
@@ -1206,22 +1250,25 @@ static int format_device_text(brc_engine* e, const brc_result* r) {
             return true;
         };
         bool ok = true;
-        if (!per_lib) ok = bucket_tokens(0) && lib_tail(0);
+        if (!per_lib) ok = block_tokens(L1) && lib_tail(0);
         else {
-            while (ok && p < L1) {                                 // "\tname\t{" six buckets "\t}"
+            while (ok && p < L1) {                                 // "\tname\t{" six buckets, indel entries, "\t}"
                 const char* t0 = p; ++p; const char* n0 = p; while (p < L1 && *p != '\t') ++p;
                 int l = -1; for (int x = 0; x < Lp; ++x) if (e->libs[(size_t)x].size() == (size_t)(p - n0) && memcmp(e->libs[(size_t)x].data(), n0, (size_t)(p - n0)) == 0) { l = x; break; }
                 p += 2;                                            // "\t{"
                 if (l < 0 || p > L1) return fail(e, BRC_E_ARG, "device text: unknown library block");
-                ok = put(t0, (size_t)(p - t0)) && bucket_tokens(l) && lib_tail(l) && put(p, 2);
-                p += 2;                                            // "\t}"
+                // the block's end: the "\t}" in front of the next block's "\tname\t{" or of the line's end (a closing brace is a token of its own)
+                const char* be = p;
+                for (;;) { const char* t = (const char*)memchr(be + 1, '\t', (size_t)(L1 - be - 1)); if (be + 2 == (t ? t : L1) && be[1] == '}') break; if (!t) return fail(e, BRC_E_ARG, "device text: a library block without its end"); be = t; }
+                ok = put(t0, (size_t)(p - t0)) && block_tokens(be) && lib_tail(l) && put(be, 2);
+                p = be + 2;
             }
         }
         if (!ok) return fail(e, BRC_E_NOMEM, "host allocation of the text buffers failed");
-        while (ii < r->n_indel && r->indel[ii].pos == pos) ++ii;   // (indel entries of libraries without a block cannot exist)
+        while (di < dels.size() && dels[di].pos == pos) ++di;      // (deletion entries of libraries without a block cannot exist)
         if (!changed) continue;                                    // (nothing was committed: pbuf.n is unchanged)
         w0[wn++] = '\n';
-        char dg[16]; const int nd = fmt_u32(dg, depth + extra);
+        char dg[16]; const int nd = fmt_u32(dg, depth - dev_extra + extra);
         char* line = w0 + 10 - nd;                                 // prefix + depth right in front of the body
         memmove(line, L0, pre); memcpy(line + pre, dg, (size_t)nd);
         brc_engine::Patch pt; pt.k = k; pt.off = base + (size_t)(10 - nd); pt.len = wn - (size_t)(10 - nd);
@@ -1230,10 +1277,10 @@ static int format_device_text(brc_engine* e, const brc_result* r) {
     }
     // parts: device text between the rewritten lines; the lead position (index 0 when pos0 < beg0) is never printed
     e->part_ptr.clear(); e->part_len.clear();
-    uint64_t cur = (P > 0 && r->pos0 < r->beg0) ? ht.off[1] : 0;
+    uint64_t cur = lead ? ht.off[1] : 0;
     for (const brc_engine::Patch& pt : e->patches) {
-        if (pt.k == 0 && r->pos0 < r->beg0) continue;
-        if (ht.off[pt.k] > cur) { e->part_ptr.push_back(ht.text + cur); e->part_len.push_back((size_t)(ht.off[pt.k] - cur)); }
+        if (pt.k == 0 && lead) continue;
+        if (ht.off[pt.k] > cur) { e->part_ptr.push_back(ht.text + cur); e->part_len.push_back((size_t)(ht.total - cur) < (size_t)(ht.off[pt.k] - cur) ? (size_t)(ht.total - cur) : (size_t)(ht.off[pt.k] - cur)); }
         e->part_ptr.push_back(e->pbuf.p + pt.off); e->part_len.push_back(pt.len);
         cur = ht.off[pt.k + 1];
     }

@@ -105,12 +105,12 @@ struct Geometry {
     int64_t ref_lo = 0, ref_hi = 0;     // slice of the contig the device needs
 };
 
-// Host view of the device results after fetch: the compact slot planes + third-allele events (struct Planes, brc_core.h);
+// Host view of the device results after fetch: the compact slot planes + the folded third-allele records (struct Planes, XAgg, brc_core.h);
 // brc_fetch_result expands them to the ABI's dense planes (expand_slots).
 struct HostPlanes {
     uint32_t *ncol = nullptr, *depth = nullptr, *slotid = nullptr, *si = nullptr, *unavail = nullptr;
     float* sf = nullptr;
-    const XEv* xev = nullptr; uint64_t n_xev = 0;
+    const XAgg* xagg = nullptr; uint64_t n_xagg = 0;       // third-allele records, folded on the device: one per (position, library, bucket), grouped by (64-position tile, library)
     const IndelOut* indel = nullptr; int64_t n_indel = 0;
     uint64_t n_events = 0, n_positions = 0;
     uint64_t warn[BRC_N_WARN] = {0, 0, 0, 0};
@@ -118,7 +118,8 @@ struct HostPlanes {
 
 // The region's text as the device wrote it (BRC_OPT_DEVICE_TEXT): line of plane index k = text[off[k] .. off[k + 1]), empty
 // for positions that print nothing; n + 1 offsets.
-struct HostText { const char* text = nullptr; const uint32_t* off = nullptr; uint64_t total = 0; int64_t n = 0; };
+struct HostText { const char* text = nullptr; const uint32_t* off = nullptr; uint64_t total = 0; int64_t n = 0;
+                  const uint32_t* last_processed = nullptr; };      // [Lp] the last plane index every library was processed at (NONE32: never)
 
 enum { BRC_TEXT_TOO_LONG = 1000 };      // Backend::text_begin only (not an ABI code)
 

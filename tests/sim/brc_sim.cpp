@@ -29,6 +29,9 @@ class SimBackend : public Backend {
     PieceRare rare_of(uint32_t m) const { return piece_has_rare(piece_flags(hot[m])) ? rare[m] : piece_rare_of(c, hot[m]); }
     std::vector<uint32_t> ncol, depth, slotid, si, unavail; std::vector<float> sf; std::vector<XEv> xev; uint32_t xev_n = 0;
     std::vector<IndelOut> iout;
+    // the side tables a text lane reads (brc_core.h: TextAux), in the kernels' layout: folded third-allele records per (tile, library) bucket,
+    // reduced indel buckets in their slots
+    std::vector<XAgg> xagg, xagg_list; std::vector<uint32_t> xagg_end, xagg_cnt; std::vector<IndelOut> ib_slots; std::vector<uint32_t> ib_end, ib_cnt; bool have_indel_tables = false;
     uint64_t n_events = 0, n_positions = 0, warn[BRC_N_WARN] = {0, 0, 0, 0};
 
   public:
@@ -216,6 +219,21 @@ class SimBackend : public Backend {
         }
         if (xev_n > xev.size()) { xev.resize((size_t)xev_n * 2); goto again; }                                 // the list was too short: grow, compute again
         pl_last = pl; have_pl = true;
+        {   // k_xev_compact's count / scan / k_xev_scatter / k_xev_fold: the events of every (tile, library) bucket folded in list order
+            const int64_t nxb = ntiles * Lp;
+            std::vector<uint32_t> cnt((size_t)nxb + 1, 0), off((size_t)nxb + 1, 0);
+            for (uint32_t i = 0; i < xev_n; ++i) cnt[(size_t)((int64_t)(xev[i].k >> 6) * Lp + (xev[i].lib_b >> 8))]++;
+            uint32_t run = 0; for (int64_t b = 0; b < nxb; ++b) { off[(size_t)b] = run; run += cnt[(size_t)b]; }
+            std::vector<uint32_t> idx(run + 1), cur(off);
+            for (int64_t i = (int64_t)xev_n - 1; i >= 0; --i) idx[cur[(size_t)((int64_t)(xev[(size_t)i].k >> 6) * Lp + (xev[(size_t)i].lib_b >> 8))]++] = (uint32_t)i;    // reversed on purpose: the fold must not depend on scatter order
+            xagg.assign(run + 1, XAgg()); xagg_end.assign((size_t)nxb + 1, 0); xagg_cnt.assign((size_t)nxb + 1, 0); xagg_list.clear();
+            for (int64_t b = 0; b < nxb; ++b) {
+                const uint32_t nk = cnt[(size_t)b]; if (!nk) { xagg_end[(size_t)b] = off[(size_t)b]; continue; }
+                const int nd = fold_xev_bucket(xev.data(), idx.data() + off[(size_t)b], (int)nk, xagg.data() + off[(size_t)b]);
+                xagg_cnt[(size_t)b] = (uint32_t)nd; xagg_end[(size_t)b] = off[(size_t)b] + (uint32_t)nd;
+                for (int j = 0; j < nd; ++j) xagg_list.push_back(xagg[off[(size_t)b] + (size_t)j]);
+            }
+        }
         for (int64_t k = 0; k < P; ++k) {
             if (c.pos0 + k < c.beg0) continue;
             uint32_t tot = 0; for (int l = 0; l < Lp; ++l) tot += ncol[(size_t)(l * PS + k)];
@@ -224,7 +242,7 @@ class SimBackend : public Backend {
         // indel side path, in the kernels' structure: K1 writes every read's events to its own slots of the raw list (one slot
         // per I / D / P operator, unused ones marked empty) and counts them per (tile, library) bucket; scan; scatter; one
         // reduce_indel_bucket per bucket
-        iout.clear();
+        iout.clear(); have_indel_tables = false;
         if (c.has_ref && P > 0 && n > 0) {
             const int64_t nbk = indel_buckets(c);
             std::vector<IndelEv> raw((size_t)st->n_indel_ops + 1);
@@ -258,6 +276,8 @@ class SimBackend : public Backend {
                 warn[BRC_W_SM_MISSING] += wsm; warn[BRC_W_NM_MISSING] += wnm;
             }
             for (uint32_t j = 0; j < run; ++j) if (tmp[j].len != 0) iout.push_back(tmp[j]);
+            ib_slots = tmp; ib_cnt = cnt; ib_end.assign((size_t)nbk + 1, 0); for (int64_t b = 0; b < nbk; ++b) ib_end[(size_t)b] = off[(size_t)b] + cnt[(size_t)b];
+            have_indel_tables = true;
         }
         if (stage_fault) { stage_fault = false; err = "a tile would stage a window of event bytes outside the padded stream (k_pileup2: BRC_STAGE)"; return BRC_E_HIP; }
         if (stats_on) fprintf(stderr, "piece-steps %llu, of them %llu (%.2f %%) of a piece that does not touch the tile; %.1f events per step\n", (unsigned long long)stat_steps,
@@ -266,8 +286,8 @@ class SimBackend : public Backend {
     }
     // "download": like the HIP backend, the host view is a copy — upload / compute of the next region may run while the
     // previous result is still being formatted (include/brc.h, threads)
-    std::vector<uint32_t> h_ncol, h_depth, h_slotid, h_si, h_unavail; std::vector<float> h_sf; std::vector<XEv> h_xev; std::vector<IndelOut> h_iout;
-    std::vector<char> t_text2[2]; std::vector<uint32_t> t_off2[2]; int t_slot = 0; Planes pl_last; bool have_pl = false;
+    std::vector<uint32_t> h_ncol, h_depth, h_slotid, h_si, h_unavail; std::vector<float> h_sf; std::vector<XAgg> h_xagg; std::vector<IndelOut> h_iout;
+    std::vector<char> t_text2[2]; std::vector<uint32_t> t_off2[2], t_last[2]; int t_slot = 0; Planes pl_last; bool have_pl = false;
     int text_begin(const std::string& chrom, const std::vector<std::string>& libs, int* slot) override {
         if (!have_pl) return BRC_E_ARG;
         t_slot ^= 1; *slot = t_slot;
@@ -275,24 +295,29 @@ class SimBackend : public Backend {
         std::vector<int32_t> loff((size_t)c.Lp + 1, 0); std::string names;
         if (c.per_lib) for (int l = 0; l < c.Lp; ++l) { loff[(size_t)l] = (int32_t)names.size(); if ((size_t)l < libs.size()) names += libs[(size_t)l]; loff[(size_t)l + 1] = (int32_t)names.size(); }
         TextCtx t; t.chrom = chrom.data(); t.chrom_len = (int32_t)chrom.size(); t.lib_names = names.data(); t.lib_off = loff.data();
+        TextAux ax; memset(&ax, 0, sizeof ax);
+        ax.xagg = xagg.data(); ax.xagg_end = xagg_end.data(); ax.xagg_cnt = xagg_cnt.data();
+        if (have_indel_tables) { ax.iout = ib_slots.data(); ax.ib_end = ib_end.data(); ax.ib_cnt = ib_cnt.data(); ax.reads = reads.data(); }
+        t_last[t_slot].assign((size_t)c.Lp, NONE32);
+        for (int l = 0; l < c.Lp; ++l) for (int64_t k = c.P - 1; k >= 0; --k) if (ncol[(size_t)(l * c.PS + k)] != 0 && !(c.per_lib && unavail[(size_t)k] != NONE32)) { t_last[t_slot][(size_t)l] = (uint32_t)k; break; }     // k_last_processed
         t_off.assign((size_t)c.P + 1, 0);
         uint64_t total64 = 0;
-        for (int64_t k = 0; k < c.P; ++k) { const uint32_t n = text_line(c, in, pl_last, t, k, nullptr); t_off[(size_t)k + 1] = t_off[(size_t)k] + n; total64 += n; }
+        for (int64_t k = 0; k < c.P; ++k) { const uint32_t n = text_line(c, in, pl_last, t, ax, k, nullptr); t_off[(size_t)k + 1] = t_off[(size_t)k] + n; total64 += n; }
         const uint64_t limit = getenv("BRC_DEVICE_TEXT_LIMIT") ? strtoull(getenv("BRC_DEVICE_TEXT_LIMIT"), nullptr, 10) : ~0ull;     // (test knob, as in the HIP backend)
         if (total64 != (uint64_t)t_off[(size_t)c.P] || total64 > limit) { t_slot ^= 1; return BRC_TEXT_TOO_LONG; }     // (as the HIP backend: 32-bit offsets cannot address it)
         t_text.assign((size_t)t_off[(size_t)c.P] + 1, 0);
-        for (int64_t k = 0; k < c.P; ++k) if (t_off[(size_t)k + 1] > t_off[(size_t)k]) (void)text_line(c, in, pl_last, t, k, t_text.data() + t_off[(size_t)k]);
+        for (int64_t k = 0; k < c.P; ++k) if (t_off[(size_t)k + 1] > t_off[(size_t)k]) (void)text_line(c, in, pl_last, t, ax, k, t_text.data() + t_off[(size_t)k]);
         return BRC_OK;
     }
     void list_sizes(uint64_t* nx, uint64_t* ni) override { *nx = xev_n; *ni = iout.size(); }
     int text_wait(int slot, HostText* out) override {
         const std::vector<char>& t_text = t_text2[slot & 1]; const std::vector<uint32_t>& t_off = t_off2[slot & 1];
-        out->text = t_text.data(); out->off = t_off.data(); out->total = t_off.empty() ? 0 : t_off.back(); out->n = (int64_t)t_off.size() - 1; return BRC_OK;
+        out->text = t_text.data(); out->off = t_off.data(); out->total = t_off.empty() ? 0 : t_off.back(); out->n = (int64_t)t_off.size() - 1; out->last_processed = t_last[slot & 1].data(); return BRC_OK;
     }
     int fetch(HostPlanes* out, bool) override {
-        h_ncol = ncol; h_depth = depth; h_slotid = slotid; h_si = si; h_unavail = unavail; h_sf = sf; h_xev = xev; h_iout = iout;
+        h_ncol = ncol; h_depth = depth; h_slotid = slotid; h_si = si; h_unavail = unavail; h_sf = sf; h_xagg = xagg_list; h_iout = iout;
         out->ncol = h_ncol.data(); out->depth = h_depth.data(); out->slotid = h_slotid.data(); out->si = h_si.data(); out->sf = h_sf.data(); out->unavail = h_unavail.data();
-        out->xev = h_xev.data(); out->n_xev = xev_n;
+        out->xagg = h_xagg.data(); out->n_xagg = h_xagg.size();
         out->indel = h_iout.data(); out->n_indel = (int64_t)h_iout.size(); out->n_events = n_events; out->n_positions = n_positions;
         memcpy(out->warn, warn, sizeof warn);
         return BRC_OK;
@@ -306,10 +331,10 @@ class SimBackend : public Backend {
             for (int64_t pl = 0; pl < planes; ++pl) for (int64_t k = 0; k < n; ++k) dst[(size_t)(pl * WS + k)] = src[(size_t)(pl * PS + k0 + k)];
         };
         cut(ncol, w_ncol, Lp); cut(depth, w_depth, Lp); cut(slotid, w_slotid, Lp); cut(si, w_si, (int64_t)Lp * 2 * NI); cut(sf, w_sf, (int64_t)Lp * 2 * NF); cut(unavail, w_unavail, 1);
-        h_xev = xev; h_iout = iout;
+        h_xagg = xagg_list; h_iout = iout;
         *out = HostPlanes();
         out->ncol = w_ncol.data(); out->depth = w_depth.data(); out->slotid = w_slotid.data(); out->si = w_si.data(); out->sf = w_sf.data(); out->unavail = w_unavail.data();
-        out->xev = h_xev.data(); out->n_xev = xev_n; out->indel = h_iout.data(); out->n_indel = (int64_t)h_iout.size();
+        out->xagg = h_xagg.data(); out->n_xagg = h_xagg.size(); out->indel = h_iout.data(); out->n_indel = (int64_t)h_iout.size();
         out->n_events = n_events; out->n_positions = n_positions;
         *stride = WS;
         return BRC_OK;

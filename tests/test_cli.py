@@ -713,4 +713,4 @@ def test_cli_ranks_equal_single_process_cpu(synthetic_bam):
 @pytest.mark.gpu
 def test_cli_ranks_equal_single_process_gpu(synthetic_bam):
     """world 2, 3 and 4 on ONE GPU (BRC_DEVICES=0,0,..): every rank a process of its own with its own HIP context"""
-    _ranks_check(CLI, synthetic_bam, devices=0)
+    _ranks_check(HIP_CLI, synthetic_bam, devices=0)
