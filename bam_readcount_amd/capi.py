@@ -456,3 +456,28 @@ def run_regions(engine, arrs, regions, tid, chrom, ref, clear_queue=True):
         if clear_queue:
             engine.clear_indel_queue()
     return text, results
+
+
+def kernel_object_hash(path=None):
+    """sha256 (first 16 hex digits) of the DEVICE code of a built library: its `.hip_fatbin` section — the gfx950 code object hipcc embeds,
+    which changes when a kernel changes and only then (host-side edits leave it alone).  bench.py stamps the PMC passes under profiles/ with
+    it: counters measured on other kernels than the loaded ones are not reported.  None: no such section (the oracle, the simulator)."""
+    import hashlib
+    import struct
+    path = path or PRODUCT_LIB
+    with open(path, "rb") as f:
+        d = f.read()
+    if d[:4] != b"\x7fELF" or d[4] != 2:
+        return None
+    shoff, = struct.unpack_from("<Q", d, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", d, 0x3A)
+    def sh(i):
+        name, typ, flags, addr, off, size = struct.unpack_from("<IIQQQQ", d, shoff + i * shentsize)
+        return name, off, size
+    _, stroff, strsize = sh(shstrndx)
+    for i in range(shnum):
+        name, off, size = sh(i)
+        end = d.index(b"\0", stroff + name)
+        if d[stroff + name:end] == b".hip_fatbin":
+            return hashlib.sha256(d[off:off + size]).hexdigest()[:16]
+    return None

@@ -727,8 +727,90 @@ BRC_HD void walk_pieces_at(bool insertion_centric, bool entered, bool counts, in
     else if (x > pos) f(pos, 0, x - pos, 0, false);
 }
 
+// ---------------------------------------------------------------- CIGARs with an M / = / X operator of length zero
+//
+// htslib-1.10's resolve_cigar2 keeps a cursor (operator k, its reference start x, the query offset y) per buffered read and moves it by ONE
+// reference-consuming operator whenever the column has passed the current one — without asking whether the column lies inside the operator it
+// lands on.  Every aligner's CIGAR has operators of positive length and the question never arises; on an operator of length zero the cursor
+// stands for one column: the column is reported as a match at the operator's query offset, whatever follows is seen one column late, and a
+// deletion behind it is never announced (its "last base of the operator before" test looks at the empty operator).  The formulas of
+// walk_pieces_at / enumerate_indels_at — which compute every segment from the operators' lengths — cannot say that; such reads (round 6: until
+// then refused at push) take the cursor itself, column by column: exact, one lane per read, and rare enough not to matter.
+// (Restated from the published algorithm, htslib sam.c; the oracle's resolve_cigar2 and the shim's are the two other statements of it.)
+struct CigCursor { int32_t k, x; int y; };
+BRC_HD bool has_empty_mop(const uint32_t* cig, uint32_t nc) { for (uint32_t k = 0; k < nc; ++k) if (is_mop(cig[k] & 0xfu) && (cig[k] >> 4) == 0u) return true; return false; }
+// the pileup entry of a read at column `col` (called for every column from the read's start on, ascending); false: not in the column
+BRC_HD bool cursor_resolve(const uint32_t* cig, uint32_t nc, int32_t rpos, int32_t col, CigCursor& s, int& qpos, bool& is_del, int& indel) {
+    const int32_t n = (int32_t)nc;
+    if (s.k == -1) {
+        qpos = 0;
+        if (n == 1) { if (is_mop(cig[0] & 0xfu)) { s.k = 0; s.x = rpos; s.y = 0; } }
+        else {
+            int32_t k = 0; s.x = rpos; s.y = 0;
+            for (; k < n; ++k) { const uint32_t op = cig[k] & 0xfu; if (is_refop(op)) break; else if (op == CINS || op == CSOFT_CLIP) s.y += (int)(cig[k] >> 4); }
+            s.k = k;
+        }
+        if (s.k < 0 || s.k >= n) return false;
+    } else {
+        const int32_t l = (int32_t)(cig[s.k] >> 4);
+        if (col - s.x >= l) {
+            if (s.k + 1 >= n) return false;
+            const bool cur_m = is_mop(cig[s.k] & 0xfu);
+            if (is_refop(cig[s.k + 1] & 0xfu)) { if (cur_m) s.y += l; s.x += l; ++s.k; }
+            else {
+                if (cur_m) s.y += l;
+                s.x += l;
+                int32_t k = s.k + 1;
+                for (; k < n; ++k) { const uint32_t op = cig[k] & 0xfu; if (is_refop(op)) break; else if (op == CINS || op == CSOFT_CLIP) s.y += (int)(cig[k] >> 4); }
+                s.k = k;
+            }
+            if (s.k >= n) return false;
+        }
+    }
+    const uint32_t op = cig[s.k] & 0xfu; const int32_t l = (int32_t)(cig[s.k] >> 4);
+    is_del = false; indel = 0;
+    if (s.x + l - 1 == col && s.k + 1 < n) {
+        const uint32_t op2 = cig[s.k + 1] & 0xfu; const int l2 = (int)(cig[s.k + 1] >> 4);
+        if (op2 == CDEL) indel = -l2;
+        else if (op2 == CINS) indel = l2;
+        else if (op2 == CPAD && s.k + 2 < n) {
+            int l3 = 0;
+            for (int32_t kk = s.k + 2; kk < n; ++kk) { const uint32_t o = cig[kk] & 0xfu; if (o == CINS) l3 += (int)(cig[kk] >> 4); else if (is_refop(o)) break; }
+            if (l3 > 0) indel = l3;
+        }
+    }
+    if (is_mop(op)) qpos = s.y + (col - s.x);
+    else if (op == CDEL || op == CREF_SKIP) { is_del = true; qpos = s.y; }
+    return true;
+}
+// walk_pieces_at for such a read: the segments the cursor's columns form
+template <class F>
+BRC_HD void walk_pieces_cursor(bool insertion_centric, bool entered, bool counts, int32_t pos, const uint32_t* cig, uint32_t nc, F f) {
+    if (!entered) return;
+    int32_t rlen = 0;
+    for (uint32_t k = 0; k < nc; ++k) if (is_refop(cig[k] & 0xfu)) rlen += (int32_t)(cig[k] >> 4);
+    if (!counts) { if (rlen > 0) f(pos, 0, rlen, 0, false); return; }
+    CigCursor s; s.k = -1; s.x = pos; s.y = 0;
+    bool have = false; int32_t crs = 0, clen = 0; int cq = 0; bool cnb = false;
+    int32_t col = pos, last_in = pos;           // last_in: one past the last column the read was seen in
+    for (; col < pos + rlen; ++col) {
+        int qpos = 0, indel = 0; bool is_del = false;
+        if (!cursor_resolve(cig, nc, pos, col, s, qpos, is_del, indel)) continue;      // (the cursor has run out of operators: nothing behind this column either)
+        last_in = col + 1;
+        if (is_del) continue;
+        const bool nb = insertion_centric && indel > 0;                                  // :343: counted in the depth, in no base bucket
+        if (have && !cnb && !nb && col == crs + clen && qpos == cq + clen) { ++clen; continue; }
+        if (have) f(crs, clen, col - crs, cq, cnb);
+        else if (col > pos) f(pos, 0, col - pos, 0, false);                              // leading deletion / skip: column only
+        have = true; crs = col; clen = 1; cq = qpos; cnb = nb;
+    }
+    if (have) f(crs, clen, last_in - crs, cq, cnb);
+    else if (last_in > pos) f(pos, 0, last_in - pos, 0, false);
+}
+
 template <class F>
 BRC_HD void walk_pieces(bool insertion_centric, bool entered, bool counts, int32_t pos, const uint32_t* cig, uint32_t nc, F f) {
+    if (has_empty_mop(cig, nc)) { walk_pieces_cursor(insertion_centric, entered, counts, pos, cig, nc, f); return; }
     CigPtr a; a.p = cig; walk_pieces_at(insertion_centric, entered, counts, pos, a, nc, f);
 }
 
@@ -1011,8 +1093,23 @@ BRC_HD void enumerate_indels_at(const DevCfg& c, const C& cig, const DRead& rd, 
     }
 }
 
+// ... for a read with an empty M / = / X operator: the indel announcements of the cursor's own columns (see cursor_resolve)
+template <class F>
+BRC_HD void enumerate_indels_cursor(const DevCfg& c, const uint32_t* cig, const DRead& rd, const uint8_t* qual_row, F emit) {
+    if (rd.end <= rd.pos || (rd.misc & M_SIMPLE) || !c.has_ref) return;
+    if (((rd.misc >> 16) & 0xffu) == 0) return;
+    if ((int)((rd.misc >> 8) & 0xffu) < c.min_mapq || (rd.misc & M_NOCOUNT)) return;
+    CigCursor s; s.k = -1; s.x = rd.pos; s.y = 0;
+    for (int32_t col = rd.pos; col < rd.end; ++col) {
+        int qpos = 0, indel = 0; bool is_del = false;
+        if (!cursor_resolve(cig, rd.n_cigar, rd.pos, col, s, qpos, is_del, indel)) continue;
+        if (is_del || indel == 0) continue;
+        if (col >= c.beg0 - 1 && col < c.end && col >= c.pos0 && (int64_t)col < (int64_t)c.pos0 + c.P && qpos < rd.l_qseq && (int)qual_row[qpos] >= c.min_bq) emit(col, qpos, indel);
+    }
+}
 template <class F>
 BRC_HD void enumerate_indels(const DevCfg& c, const DevIn& in, const DRead& rd, const uint8_t* qual_row, F emit) {
+    if (has_empty_mop(in.cigar + rd.cig_off, rd.n_cigar)) { enumerate_indels_cursor(c, in.cigar + rd.cig_off, rd, qual_row, emit); return; }
     CigPtr a; a.p = in.cigar + rd.cig_off; enumerate_indels_at(c, a, rd, qual_row, emit);
 }
 

@@ -46,6 +46,7 @@ struct Counters {
     unsigned int n_indel_slots, n_xev;   // n_xev: third-allele events in the compacted list
     unsigned int xev_max, n_wave_reads;  // fullest sub-list's cursor (above its capacity: grow and compute again); reads K1 left to k_annotate_wave
     unsigned int n_wave_big, n_wave_huge;   // ... those of them with more than AW_MCAP / AW_MCAP_BIG M operators (the one-wave-per-workgroup instantiations)
+    unsigned int n_literal, pad_;            // reads with an empty M / = / X operator: piled up by the iterator's own cursor (k_annotate_cursor)
 };
 
 // Profiling ablations that switch parts of the kernels off (wrong results, timing only) exist only in experiment builds
@@ -617,13 +618,16 @@ __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m) { return __bui
 // (wave_list: the reads of the four-wave instantiation from the front, those of the one-wave instantiation from the back, list_cap - 1 downwards;
 // those of the one-wave-per-CU instantiation in a second list behind it, from list_cap + 16 on)
 __global__ __launch_bounds__(256) void k_pick_wave(DevCfg c, DevIn in, uint32_t* __restrict__ n_cigar_k1, uint32_t* __restrict__ wave_list, uint32_t list_cap,
-                                                   unsigned int* __restrict__ wave_n, unsigned int* __restrict__ wave_n_big, unsigned int* __restrict__ wave_n_huge) {
+                                                   unsigned int* __restrict__ wave_n, unsigned int* __restrict__ wave_n_big, unsigned int* __restrict__ wave_n_huge,
+                                                   int wave_on, int cursor_on, unsigned int* __restrict__ cursor_n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool pick = false, big = false, huge = false; uint32_t nc_me = 0u;
+    bool pick = false, big = false, huge = false, lit = false; uint32_t nc_me = 0u;
     if (i < c.n_reads) {
         const uint32_t nc = in.n_cigar[i]; nc_me = nc;
         const int32_t pos = in.pos[i], L = in.l_qseq[i];
-        if (nc >= 5u && L > 0 && pos >= 0 && c.has_ref && !(in.flag[i] & BRC_PUSH_MASK)) {       // (three M operators take at least five)
+        // a mapped read with an M / = / X operator of length zero (the host saw one in this region): third list, k_annotate_cursor
+        if (cursor_on && nc > 0u && !(in.flag[i] & FUNMAP)) lit = has_empty_mop(BRC_CK(c, CK_ANNOTATE, 45, CB_CIGAR, in.cigar + in.cig_off[i], 4ull * nc, i, -1), nc);
+        if (!lit && wave_on && nc >= 5u && L > 0 && pos >= 0 && c.has_ref && !(in.flag[i] & BRC_PUSH_MASK)) {       // (three M operators take at least five)
             const uint32_t* cig = BRC_CK(c, CK_ANNOTATE, 44, CB_CIGAR, in.cigar + in.cig_off[i], 4ull * nc, i, -1);
             int64_t rlen = 0; uint32_t n_m = 0; bool irregular = false;
             for (uint32_t k = 0; k < nc; ++k) {
@@ -657,7 +661,59 @@ __global__ __launch_bounds__(256) void k_pick_wave(DevCfg c, DevIn in, uint32_t*
         base = (uint32_t)__shfl((int)base, __builtin_ctzll(pb), 64);
         if (big) wave_list[list_cap - 1u - (base + mbcnt64(pb))] = (uint32_t)i;
     }
-    if (i < c.n_reads) n_cigar_k1[i] = pick ? 0u : nc_me;
+    const unsigned long long pl = __ballot(lit);
+    if (pl) {
+        uint32_t base = 0u;
+        if (lane == __builtin_ctzll(pl)) base = atomicAdd(cursor_n, (unsigned int)__builtin_popcountll(pl));
+        base = (uint32_t)__shfl((int)base, __builtin_ctzll(pl), 64);
+        if (lit) wave_list[2u * list_cap + 32u + base + mbcnt64(pl)] = (uint32_t)i;
+    }
+    if (i < c.n_reads) n_cigar_k1[i] = (pick || lit) ? 0u : nc_me;
+}
+// Reads with an empty M / = / X operator (brc_core.h: cursor_resolve): one lane per read — fetch_func's annotation by annotate_read() (the
+// annotator walks the CIGAR operator by operator: an empty operator is an empty loop, bamreadcount.cpp:133-197), the read's segments and indel
+// events by the iterator's own cursor, column by column (walk_pieces / enumerate_indels switch to it).  Exact and slow; no aligner writes such
+// records, the reference piles them up all the same.
+template <int SH>
+__global__ __launch_bounds__(64) void k_annotate_cursor(DevCfg c, DevIn in, const uint32_t* __restrict__ list, const unsigned int* __restrict__ list_n,
+                                                        DRead* __restrict__ reads, const uint32_t* __restrict__ piece_off, Piece* __restrict__ pieces, PieceRare* __restrict__ rare,
+                                                        int2* __restrict__ keyreach, uint8_t* __restrict__ eb, uint16_t* __restrict__ bqw, IndelEv* __restrict__ ev_raw,
+                                                        uint32_t* __restrict__ bucket_cnt, const uint16_t* __restrict__ wanted) {
+    c.pack_shift = SH;
+    const uint32_t n = *list_n;
+    for (uint32_t li = blockIdx.x * 64u + threadIdx.x; li < n; li += gridDim.x * 64u) {
+        const int64_t my = (int64_t)list[li];
+        bool wide = false;
+        const DRead r = annotate_read(c, in, my, eb, bqw, wide);
+        *BRC_CK(c, CK_ANNOTATE, 46, CB_READS, reads + my, sizeof(DRead), my, -1) = r;
+        const uint32_t nc = in.n_cigar[my]; const uint32_t* cig = in.cigar + in.cig_off[my];
+        const int lib = c.per_lib ? (int)in.lib[my] : 0;
+        const bool nolib = c.per_lib && lib < 0;
+        const bool enters = r.end > r.pos && r.pos >= 0;
+        const ReadConst rc = read_const(c, r, (uint32_t)my, wide);
+        uint32_t slot = piece_off[my];
+        walk_pieces(c.insertion_centric != 0, enters && !nolib, rc.counts, r.pos, cig, nc, [&](int32_t rs, int32_t len, int32_t ext, int qoff, bool nb) {
+            Piece h; PieceRare rr;
+            make_piece(c, rc, rs, len, ext, qoff, nb, h, rr, SH);
+            *BRC_CK(c, CK_ANNOTATE, 47, CB_PIECES, pieces + slot, sizeof(Piece), my, slot) = h;
+            if (piece_has_rare(piece_flags(h))) *BRC_CK(c, CK_ANNOTATE, 48, CB_RARE, rare + slot, sizeof(PieceRare), my, slot) = rr;
+            *BRC_CK(c, CK_ANNOTATE, 49, CB_KEYREACH, keyreach + slot, sizeof(int2), my, slot) = make_int2(r.pos, rs + ext);
+            ++slot;
+        });
+        if (ev_raw) {
+            uint32_t n_idp = 0;
+            for (uint32_t k = 0; k < nc; ++k) { const uint32_t op = cig[k] & 0xfu; if (op == CINS || op == CDEL || op == CPAD) ++n_idp; }
+            if (n_idp) {
+                IndelEv* es = BRC_CK(c, CK_ANNOTATE, 50, CB_EVRAW, ev_raw + in.iev_off[my], sizeof(IndelEv) * (uint64_t)n_idp, my, -1); uint32_t used = 0;
+                enumerate_indels(c, in, r, in.qual + in.qual_off[my], [&](int32_t p, int qpos, int len) {
+                    IndelEv e; e.read = (uint32_t)my; e.qpos = qpos; e.len = len; e.key_lo = (uint32_t)((int64_t)(p - c.pos0) * c.Lp + lib);
+                    if (wanted && !tile_wants(wanted[(uint32_t)(p - c.pos0) >> 6], (uint32_t)(p - c.pos0) & 63u)) return;
+                    if (used < n_idp) { es[used++] = e; atomicAdd(bucket_cnt + indel_bucket_of(c, (uint32_t)(p - c.pos0), (uint32_t)lib), 1u); }
+                });
+                for (; used < n_idp; ++used) es[used].key_lo = NONE32;
+            }
+        }
+    }
 }
 __device__ __forceinline__ int32_t wave_incl_sum(int32_t v, int lane) {
 #pragma unroll
@@ -2097,6 +2153,7 @@ class HipBackend : public Backend {
            WAVE_FORM_BLOCKS_BIG = 512,         // the one-wave instantiation: 2 blocks per CU (60 KB of LDS each)
            WAVE_FORM_BLOCKS_HUGE = 256 };      // one block per CU (158 KB of LDS)
     bool wave_huge = false;                    // ... or more than AW_MCAP_BIG
+    bool cursor_on = false;                    // a read with an empty M / = / X operator was staged: k_pick_wave lists such reads for k_annotate_cursor
     unsigned long long h_steps[3] = {0, 0, 0};   // piece-steps of the last pass: what the tile ranges hold / what k_pileup2 walked (brc_region_piece_steps)
     DBuf d_ccnt, d_coff, d_cpieces, d_crare, d_crng, d_ctot;
     // host result buffers (pinned)
@@ -2288,7 +2345,8 @@ class HipBackend : public Backend {
         // whose list stays empty costs a launch)
         wave_big = wave_on && s.max_ncigar > (uint32_t)AW_MCAP;
         wave_huge = wave_on && s.max_ncigar > (uint32_t)AW_MCAP_BIG;
-        if (wave_on) { HIPCHK(d_wavelist.ensure((2 * (size_t)n + 48) * sizeof(uint32_t))); HIPCHK(d_nc_k1.ensure(((size_t)n + 16) * sizeof(uint32_t))); }
+        cursor_on = n > 0 && s.has_empty_m;
+        if (wave_on || cursor_on) { HIPCHK(d_wavelist.ensure((3 * (size_t)n + 64) * sizeof(uint32_t))); HIPCHK(d_nc_k1.ensure(((size_t)n + 16) * sizeof(uint32_t))); }
         HIPCHK(d_libbase.ensure((lib_base.size() + 1) * sizeof(int64_t)));
         if (!lib_base.empty()) HIPCHK(hipMemcpyAsync(d_libbase.p, lib_base.data(), lib_base.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
         // outputs / scratch
@@ -2383,8 +2441,9 @@ class HipBackend : public Backend {
             if (c.has_ref)
                 hipLaunchKernelGGL(k_refcode, dim3((unsigned)(((rl + 2 * REFCODE_PAD + 15) / 16 + 255) / 256)), dim3(256), 0, stream, in.ref, (uint8_t*)d_refcode.p, rl);
             DevIn in_k1 = in;
-            if (wave_on) {   // reads with more than two M operators: listed for k_annotate_wave, without operators in K1's copy of the counts
-                hipLaunchKernelGGL(k_pick_wave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (uint32_t*)d_nc_k1.p, (uint32_t*)d_wavelist.p, (uint32_t)n, &ctr->n_wave_reads, &ctr->n_wave_big, &ctr->n_wave_huge);
+            if (wave_on || cursor_on) {   // reads with more than two M operators: listed for k_annotate_wave, without operators in K1's copy of the counts (reads with an empty M / = / X operator: for k_annotate_cursor)
+                hipLaunchKernelGGL(k_pick_wave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (uint32_t*)d_nc_k1.p, (uint32_t*)d_wavelist.p, (uint32_t)n, &ctr->n_wave_reads, &ctr->n_wave_big, &ctr->n_wave_huge,
+                                   wave_on ? 1 : 0, cursor_on ? 1 : 0, &ctr->n_literal);
                 in_k1.n_cigar = (const uint32_t*)d_nc_k1.p;
             }
             {   // K1: one instantiation per (row layout, width of the narrow packed fields — choose_pack)
@@ -2413,6 +2472,14 @@ class HipBackend : public Backend {
                         if (c.pack_shift == 16) BRC_LAUNCH_K1W(16, AW_MCAP_HUGE, 1, nbh, wl + (n + 16), 1, &ctr->n_wave_huge); else BRC_LAUNCH_K1W(12, AW_MCAP_HUGE, 1, nbh, wl + (n + 16), 1, &ctr->n_wave_huge);
                     }
 #undef BRC_LAUNCH_K1W
+                }
+                if (cursor_on) {
+                    const unsigned nbc = (unsigned)std::min<int64_t>((n + 63) / 64, 1024);
+#define BRC_LAUNCH_K1C(SH) hipLaunchKernelGGL((k_annotate_cursor<SH>), dim3(nbc), dim3(64), 0, stream, c, in, (const uint32_t*)d_wavelist.p + (2 * (size_t)n + 32), (const unsigned int*)&ctr->n_literal,    \
+                                   (DRead*)d_reads.p, (const uint32_t*)d_pieceoff.p, (Piece*)d_pieces.p, (PieceRare*)d_rare.p, (int2*)d_keyreach.p, (uint8_t*)in.eb, (uint16_t*)in.bqw,                     \
+                                   indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p, has_wanted ? (const uint16_t*)d_wanted.p : (const uint16_t*)nullptr)
+                    if (c.pack_shift == 16) BRC_LAUNCH_K1C(16); else BRC_LAUNCH_K1C(12);
+#undef BRC_LAUNCH_K1C
                 }
             }
             if (c.per_lib) {

@@ -104,7 +104,7 @@ void Staged::clear() {
     qual_off.clear(); nm.clear(); sm.clear(); tags.clear(); cigar.clear(); seq4.clear(); qual.clear(); bq_row.clear();
     bq_elems = 0; memset(len_hist, 0, sizeof len_hist); n = 0; min_pos = 0; max_end = 0; n_indel_ops = 0;
     seq_seg.clear(); qual_seg.clear(); seq_total = 0; qual_total = 0;
-    piece_cnt.clear(); piece_off.clear(); iev_off.clear(); lib_base.clear(); n_pieces = 0; max_lqseq = 0; max_ncigar = 0; max_span = 0; qnames.clear(); qname_off.clear();
+    piece_cnt.clear(); piece_off.clear(); iev_off.clear(); lib_base.clear(); n_pieces = 0; max_lqseq = 0; max_ncigar = 0; has_empty_m = false; max_span = 0; qnames.clear(); qname_off.clear();
     win_beg.clear(); win_end.clear();
 }
 std::vector<uint16_t> Staged::wanted_tiles(int32_t pos0, int64_t P) const {
@@ -550,9 +550,11 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
 void* brc_host_alloc(size_t bytes) { return backend_host_alloc(bytes); }
 void brc_host_free(void* p) { if (p) backend_host_free(p); }
 // A mapped read with an M / = / X operator of length zero: htslib's resolve_cigar2 steps ONTO such an operator without asking whether the
-// position lies inside it (it reports the column as a match at the operator's query offset and the deletion behind it one column late) —
-// the pieces of walk_pieces() cannot say that, and no aligner writes such records.  Refused, loudly, rather than counted differently.
-static const char* const kEmptyM = "a mapped read has an M/=/X CIGAR operator of length zero";
+// position lies inside it (it reports the column as a match at the operator's query offset and the deletion behind it one column late).
+// Round 6: such reads are piled up by the cursor itself (brc_core.h: cursor_resolve — walk_pieces / enumerate_indels switch to it).  What
+// stays refused is the one case in which the reference reads memory behind the read: an empty operator reported at the query offset
+// l_qseq (every base of the read already consumed before it).
+static const char* const kEmptyM = "a mapped read has an empty M/=/X CIGAR operator behind its last base (the reference would read past the read's qualities)";
 static int push_reads_any(brc_engine* e, const brc_read_batch* b, bool pinned);
 int brc_push_reads(brc_engine* e, const brc_read_batch* b) { return push_reads_any(e, b, false); }
 int brc_push_reads_pinned(brc_engine* e, const brc_read_batch* b) { return push_reads_any(e, b, true); }
@@ -636,7 +638,7 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
     if (pool && e->accepted + (int64_t)n < (int64_t)maxcnt && !e->heap_built) {
         struct Chunk {
             uint64_t bq = 0, idp = 0, np = 0; int32_t max_lq = 0; int64_t max_span = 0; int64_t min_pos = INT64_MAX, max_end = INT64_MIN, n_ext = 0, acc = 0;
-            int32_t last_acc_pos = 0; int err = 0; const char* msg = nullptr; size_t err_at = 0; uint32_t hist[TABLE_MAX + 1];
+            int32_t last_acc_pos = 0; int err = 0; const char* msg = nullptr; size_t err_at = 0; uint32_t hist[TABLE_MAX + 1]; bool empty_m = false;
         };
         const size_t CH = (n + (size_t)pool->size() * 4 - 1) / ((size_t)pool->size() * 4);
         const size_t nch = (n + CH - 1) / CH;
@@ -667,7 +669,7 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
                     if (ql != s.l_qseq.p[r]) {
                         if (!(fl & FUNMAP)) { bad(i, BRC_E_ARG, "a read's CIGAR and sequence length disagree"); break; }
                         nc = 0; s.n_cigar.p[r] = 0;
-                    } else if (empty_m && !(fl & FUNMAP)) { bad(i, BRC_E_ARG, kEmptyM); break; }
+                    } else if (empty_m && !(fl & FUNMAP)) C.empty_m = true;
                 }
                 uint64_t idp = 0;
                 const int32_t rlen = cigar_rlen(s.cigar.p + s.cig_off.p[r], nc, &idp);
@@ -685,8 +687,10 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
                 const uint32_t* cg = s.cigar.p + s.cig_off.p[r];
                 const bool entered = read_enters(fl, cg, nc) && pos >= 0 && !(e->cfg.per_lib && s.lib.p[r] < 0);
                 const bool counts = (int)s.mapq.p[r] >= e->cfg.min_mapq && !(fl & BRC_NOCOUNT_MASK);
-                uint32_t np = 0;
-                walk_pieces(e->cfg.insertion_centric != 0, entered, counts, pos, cg, nc, [&](int32_t, int32_t, int32_t, int, bool) { ++np; });
+                uint32_t np = 0; bool past = false;
+                const int32_t lq = s.l_qseq.p[r];
+                walk_pieces(e->cfg.insertion_centric != 0, entered, counts, pos, cg, nc, [&](int32_t, int32_t len, int32_t, int qoff, bool) { ++np; if (len > 0 && qoff + len > lq) past = true; });
+                if (past) { bad(i, BRC_E_ARG, kEmptyM); break; }
                 s.piece_cnt.p[r] = np; C.np += np;
             }
         });
@@ -707,6 +711,7 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
                 e->n_ext += C.n_ext;
             }
             if (C.acc) { e->accepted += C.acc; e->last_acc_pos = C.last_acc_pos; }
+            if (C.empty_m) s.has_empty_m = true;
         }
         pool->run((int64_t)nch, [&](int64_t ci) {
             uint64_t bq = bq0[(size_t)ci], idp = idp0[(size_t)ci];
@@ -746,7 +751,7 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
             if (ql != s.l_qseq.p[r]) {
                 if (!(fl & FUNMAP)) return fail(e, BRC_E_ARG, "a read's CIGAR and sequence length disagree");
                 nc = 0; s.n_cigar.p[r] = 0;
-            } else if (empty_m && !(fl & FUNMAP)) return fail(e, BRC_E_ARG, kEmptyM);
+            } else if (empty_m && !(fl & FUNMAP)) s.has_empty_m = true;
         }
         uint64_t idp = 0;                                     // I / D / P operators of the CIGAR the device will see
         const int32_t rlen = cigar_rlen(s.cigar.p + s.cig_off.p[r], nc, &idp);
@@ -794,8 +799,10 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
             const uint32_t* cg = s.cigar.p + s.cig_off.p[r];
             const bool entered = read_enters(fl, cg, nc) && pos >= 0 && !(e->cfg.per_lib && s.lib.p[r] < 0);
             const bool counts = (int)s.mapq.p[r] >= e->cfg.min_mapq && !(fl & BRC_NOCOUNT_MASK);
-            uint32_t np = 0;
-            walk_pieces(e->cfg.insertion_centric != 0, entered, counts, pos, cg, nc, [&](int32_t, int32_t, int32_t, int, bool) { ++np; });
+            uint32_t np = 0; bool past = false;
+            const int32_t lq = s.l_qseq.p[r];
+            walk_pieces(e->cfg.insertion_centric != 0, entered, counts, pos, cg, nc, [&](int32_t, int32_t len, int32_t, int qoff, bool) { ++np; if (len > 0 && qoff + len > lq) past = true; });
+            if (past) return fail(e, BRC_E_ARG, kEmptyM);
             s.piece_cnt.p[r] = np;
             if ((uint64_t)(s.n_pieces += np) >= 0xFFFFFFF0ull) return fail(e, BRC_E_LIMIT, "more than 2^32 read segments in one region: split the region");
         }
@@ -1428,6 +1435,11 @@ struct WEv { int qpos, indel; bool in_col, is_del; };
 // htslib's resolve_cigar2 as a pure function of (read, position): what the pileup entry of read r at p looks like
 WEv resolve_at(const uint32_t* cig, uint32_t nc, int32_t pos, int32_t p) {
     WEv e; e.qpos = 0; e.indel = 0; e.in_col = false; e.is_del = false;
+    if (has_empty_mop(cig, nc)) {        // (an empty M / = / X operator: the iterator's own cursor, column by column from the read's start — brc_core.h)
+        CigCursor s; s.k = -1; s.x = pos; s.y = 0;
+        for (int32_t col = pos; col <= p; ++col) { int q = 0, ind = 0; bool del = false; const bool in = cursor_resolve(cig, nc, pos, col, s, q, del, ind); if (col == p) { e.in_col = in; e.is_del = del; e.qpos = q; e.indel = ind; } }
+        return e;
+    }
     int32_t x = pos; int y = 0;
     for (uint32_t k = 0; k < nc; ++k) {
         const uint32_t op = cig[k] & 0xfu; const int len = (int)(cig[k] >> 4);

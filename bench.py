@@ -16,9 +16,9 @@ max-over-ranks step time.
 
 `--gpus N` with N > 1 re-executes itself under torch.distributed.run (one rank per GPU, RCCL) unless it already runs
 under a launcher.  Extra objects on the JSON line:
-  roofline      k_pileup2 (dominant kernel): algorithmic bytes per launch (B_in + B_ref + B_out, dense 312 B per
-                position and library) / its average duration measured with HIP events on the engine's stream, against the
-                8 TB/s HBM peak and the 6.29 TB/s measured copy rate; the bytes the kernel really writes (compact planes)
+  roofline      SURVEY 8d's algorithmic bytes (B_in + B_ref + B_out, dense 312 B per position and library) over the WHOLE device step
+                (HIP events on the engine's stream), against the 8 TB/s HBM peak; per_kernel: each of the two big kernels against its OWN
+                bytes and against its PMC traffic (profiles/r06_traffic.json, reported only when stamped with the loaded kernel object)
   cpu_baseline  the C oracle (CPU restatement of the reference semantics): 1 thread like the reference on a prefix, the reference's own
                 sources compiled over a shim (oracle/_ref) on a smaller prefix, and all cores = the whole-region validation below
   e2e           the drop-in command line on a generated BAM + BAI -> /dev/null (BAM decode, PCIe, formatting included)
@@ -91,6 +91,11 @@ def site_batch(np, capi, arrs, ref, sites, window=384, lead=170):
     return sub, vref, events, vbeg0
 
 
+def eb_positions_padded(n):
+    """plane stride of the engine: positions rounded up to 64 (every plane store of a wave is one aligned 256-byte segment)"""
+    return (int(n) + 63) & ~63
+
+
 def fullcheck_window_reads(capi, arrs, ends, pos64, a, b):
     """reads samfetch would return for [a - 1, b) (tools/fullcheck.py: window_reads)"""
     import fullcheck
@@ -117,7 +122,7 @@ def main():
                     "(tools/e2e_configs.py; e2e_sites / e2e_tumor on the line): -1 = on the default single-GPU config-3 run, 1 = yes, 0 = no")
     ap.add_argument("--e2e-sites-mbp", type=float, default=25.0, help="e2e_sites: length of each of its 8 contigs")
     ap.add_argument("--abi-mbp", type=float, default=10.0, help="prefix run through the C-ABI from host batches to host text (abi_roundtrip; 0 = skip)")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r05_traffic.json"))
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r06_traffic.json"), help="PMC passes of the big kernels (FETCH_SIZE / WRITE_SIZE per launch), stamped with the kernel object they ran on; <same name with pmc_summary> holds the SQ counters")
     ap.add_argument("--other-configs", type=int, default=-1, help="1: also run BASELINE config 4 (--mode sites) and the per-GPU shape of config 5 (--mode strong --contig-mbp 6.25) "
                     "in sub-processes and put their lines under other_configs (-1: yes on the default single-GPU config-3 run, no otherwise)")
     # test infrastructure (tests/test_bench_multirank.py): the rank arithmetic of this script — who owns which interval / slice of
@@ -342,21 +347,51 @@ def main():
             eng_positions = n_positions          # SURVEY 8d's B_out counts the lines printed: the requested sites, not what their tiles hold besides
         b_in, b_ref, b_out = synthgen.algorithmic_bytes(region_reads, eng_positions, res_libs, 0, ref_positions=region_len)
         alg = b_in + b_ref + b_out
-        achieved = alg / (kms[k_pile] * 1e-3) / 1e9 if kms[k_pile] > 0 else 0.0
-        traffic = None; traffic_src = None
-        if os.path.exists(args.traffic_json) and args.mode != "sites" and world == 1:
-            tj = json.load(open(args.traffic_json)).get(config)
-            if tj and abs(float(tj.get("contig_mbp", 50.0)) - contig_len / 1e6) < 1e-6:       # the passes measured exactly this workload
-                traffic = tj.get("k_pileup_hbm_bytes_per_launch")
-                traffic_src = "%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not measured in this run" % os.path.relpath(args.traffic_json, ROOT)
-        # The roofline that really binds the kernel: vector-instruction issue.  From the committed PMC passes of this workload at the
-        # shipped kernel (profiles/r05_pmc_summary.json, not measured in this run): a wave64 VALU instruction occupies its SIMD for 4
-        # cycles, so SQ_INSTS_VALU x 4 / 1024 SIMDs = the cycles every SIMD spends issuing vector instructions, against the kernel's
-        # own busy cycles (SQ_BUSY_CYCLES is summed over the chip's 32 shader engines; its quotient by the duration is the clock the
-        # kernel really ran at, below the 2.4 GHz peak).
+        step_s = ms_per_step * 1e-3
+        # ---- what each of the two big kernels must move by ITS OWN account (this design's traffic, not SURVEY 8d's):
+        #   K1 (k_annotate_groups + k_refcode + k_annotate_wave): the reads once (8d's B_in), the reference once; out: one event byte per base
+        #       (rows padded to 16), a 48-byte record + 8 bytes of (start, reach) per read segment, a 64-byte record per read
+        #   k_pileup2: every event byte once, a 48-byte segment record per (segment, 64-position tile it touches), one reference code per
+        #       position, a tile range per (tile, library); out: the compact result, 116 bytes per (position, library)
+        # (read segments from the CIGARs: one per M / = / X operator of a read; -i's one-base segments and the single segment of a read that
+        # cannot count are not modelled: an estimate, within a percent on these data models)
+        Lq = region_reads["l_qseq"].astype(np.int64); cig = region_reads["cigar"]; opc = cig & 15
+        n_seg = int(np.count_nonzero((opc == 0) | (opc == 7) | (opc == 8)))
+        rends = capi.read_ends(region_reads); rpos = region_reads["pos"].astype(np.int64)
+        seg_tiles = int((((rends - 1) >> 6) - (rpos >> 6) + 1).clip(min=0).sum()) + max(n_seg - len(rpos), 0)      # (a read's segments share its tiles; every further segment: one more)
+        eb_bytes = int(((Lq + 15) & ~15).sum())
+        own = {"k_annotate": {"in": int(b_in + b_ref), "out": int(eb_bytes + 56 * n_seg + 64 * len(rpos))},
+               "k_pileup": {"in": int(Lq.sum() + 48 * seg_tiles + region_len + 8 * ((region_len + 63) // 64) * res_libs), "out": 116 * int(eb_positions_padded(region_len)) * res_libs}}
+        traffic_json = args.traffic_json if os.path.exists(args.traffic_json) else None
+        tj = None; traffic_src = None; kobj = capi.kernel_object_hash(hip.path)
+        if traffic_json and args.mode != "sites" and world == 1:
+            tj = json.load(open(traffic_json)).get(config)
+            if tj and abs(float(tj.get("contig_mbp", 50.0)) - contig_len / 1e6) >= 1e-6:
+                tj = None                                                # (the passes measured another workload)
+            if tj and tj.get("kernel_object_sha256_16") != kobj:
+                traffic_src = "%s holds PMC passes of kernel object %s; the loaded library's is %s: counters of other kernels are not reported (repeat tools/gpu_r6_profile.sh)" % (
+                    os.path.relpath(traffic_json, ROOT), tj.get("kernel_object_sha256_16"), kobj)
+                tj = None
+            elif tj:
+                traffic_src = "%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload on kernel object %s (= the loaded library's), not measured in this run" % (os.path.relpath(traffic_json, ROOT), kobj)
+        def kernel_entry(slot, name):
+            ms = float(kms[kernel_names.index(slot)]); ob = own[slot]; tot = ob["in"] + ob["out"]
+            tr = (tj or {}).get(name, {}).get("hbm_bytes_per_launch") if tj else None
+            return {"ms": round(ms, 4), "own_bytes_in": ob["in"], "own_bytes_out": ob["out"],
+                    "achieved_GBs_by_own_bytes": round(tot / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+                    "frac_by_own_bytes": round(tot / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None,
+                    "traffic": tr, "traffic_GBs": round(tr / (ms * 1e-3) / 1e9, 1) if (tr and ms > 0) else None,
+                    "frac_by_traffic": round(tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (tr and ms > 0) else None,
+                    "traffic_over_own_bytes": round(tr / tot, 3) if tr else None}
+        per_kernel = {"k_annotate_groups": kernel_entry("k_annotate", "k_annotate_groups"), "k_pileup2": kernel_entry("k_pileup", "k_pileup2")}
+        step_traffic = (tj or {}).get("step_hbm_bytes") if tj else None
+        # The roofline that really binds the two kernels: vector-instruction issue.  From the committed PMC passes of this workload at the
+        # loaded kernels (not measured in this run): a wave64 VALU instruction occupies its SIMD for 4 cycles, so SQ_INSTS_VALU x 4 / 1024
+        # SIMDs = the cycles every SIMD spends issuing vector instructions, against the kernel's own busy cycles (SQ_BUSY_CYCLES is summed
+        # over the chip's 32 shader engines; its quotient by the duration is the clock the kernel really ran at, below the 2.4 GHz peak).
         issue = None
-        pmc_json = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")
-        if traffic is not None and os.path.exists(pmc_json):
+        pmc_json = os.path.join(os.path.dirname(traffic_json), os.path.basename(traffic_json).replace("traffic", "pmc_summary")) if traffic_json else None
+        if tj is not None and pmc_json and os.path.exists(pmc_json):
             pm = json.load(open(pmc_json)).get(config, {})
             def issue_of(name):
                 k = pm.get(name)
@@ -368,22 +403,22 @@ def main():
                         "valu_issue_frac": round(k["SQ_INSTS_VALU"] * 4 / 1024.0 / busy, 4), "salu_issue_frac": round(k["SQ_INSTS_SALU"] * 4 / 1024.0 / busy, 4),
                         "lane_utilisation": round(k["SQ_THREAD_CYCLES_VALU"] / (64.0 * k["SQ_INSTS_VALU"]), 4) if k.get("SQ_THREAD_CYCLES_VALU") else None}
             issue = {"k_pileup2": issue_of("k_pileup2"), "k_annotate_groups": issue_of("k_annotate_groups"),
-                     "source": "profiles/r05_pmc_summary.json: separate rocprofv3 --pmc passes of this workload at the shipped kernels, not measured in this run"}
-        # what THIS design must move per step at the least: the inputs once, the reference once, the compact result once
-        # (116 B per position and library; SURVEY 8d's figure above credits the dense 312 B the kernel does not write)
-        compact = b_in + b_ref + 116 * int(eng_positions) * res_libs
-        roof = {"bound": "hbm", "kernel": "k_pileup2", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_copy_rate": round(achieved / HBM_COPY_GBS, 4),
-                "traffic": traffic, "traffic_source": traffic_src,
-                "traffic_GBs": round(traffic / (kms[k_pile] * 1e-3) / 1e9, 1) if (traffic and kms[k_pile] > 0) else None,
-                "frac_of_peak_by_traffic": round(traffic / (kms[k_pile] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (traffic and kms[k_pile] > 0) else None,
-                "algorithmic_bytes_per_launch": alg, "bytes_per_event": round(alg / max(eng_events, 1), 3),
-                "compact_result_bytes_per_launch": 116 * int(eng_positions) * res_libs,
-                "compulsory_bytes_compact": compact,
-                "kernel_frac_by_compulsory_bytes_compact": round(compact / (kms[k_pile] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kms[k_pile] > 0 else None,
-                "whole_step_frac_by_compulsory_bytes_compact": round(compact / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if world == 1 else None,
-                "whole_step_frac": round(alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if world == 1 else None,
+                     "source": "%s: separate rocprofv3 --pmc passes of this workload on kernel object %s, not measured in this run" % (os.path.relpath(pmc_json, ROOT), kobj)}
+        # HEADLINE: SURVEY 8d's algorithmic bytes (the reads once, the reference once, the DENSE 312-byte result per position and library — what
+        # any implementation of the path must move) over the WHOLE device step — annotation, scans, pileup, third-allele fold, indel path —,
+        # HIP events on the engine's stream.  No single kernel is charged with bytes another kernel moves.
+        roof = {"bound": "hbm", "kernel": "the whole device step (k_annotate_groups -> scans -> k_pileup2 -> third-allele fold -> indel path); k_pileup2 is the longest of its kernels",
+                "achieved": round(alg / step_s / 1e9, 1) if world == 1 else round(alg / (float(sum(kms)) * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(alg / step_s / 1e9 / HBM_PEAK_GBS, 4) if world == 1 else round(alg / (float(sum(kms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "frac_of_measured_copy_rate": round(alg / step_s / 1e9 / HBM_COPY_GBS, 4) if world == 1 else None,
+                "traffic": step_traffic, "traffic_source": traffic_src, "kernel_object_sha256_16": kobj,
+                "traffic_GBs": round(step_traffic / step_s / 1e9, 1) if (step_traffic and world == 1) else None,
+                "frac_of_peak_by_traffic": round(step_traffic / step_s / 1e9 / HBM_PEAK_GBS, 4) if (step_traffic and world == 1) else None,
+                "algorithmic_bytes_per_step": alg, "bytes_per_event": round(alg / max(eng_events, 1), 3),
+                "step_ms": round(ms_per_step, 4) if world == 1 else round(float(sum(kms)), 4),
+                "per_kernel": per_kernel,
                 "instruction_issue": issue,
+                "in_step_since_round_6": "the fold of third-allele events into their buckets (k_xev_scatter / k_xev_fold: the last accumulation the host did)",
                 "kernel_ms": {k: round(float(v), 4) for k, v in zip(kernel_names, kms) if k}}
 
         # ---- validation + 1-thread CPU baseline on a prefix of the timed contig
@@ -572,8 +607,7 @@ def main():
                     other[key] = {"value": sub["value"], "unit": sub["unit"], "ms_per_step": sub["ms_per_step"], "steps": sub["steps"], "positions_per_s": sub["positions_per_s"],
                                   "workload": sub["config"]["workload"], "events_per_step": sub["config"]["events_per_step"], "positions_per_step": sub["config"]["positions_per_step"],
                                   "kernel_ms": sub["roofline"]["kernel_ms"], "frac": sub["roofline"]["frac"], "achieved_GBs": sub["roofline"]["achieved"],
-                                  "kernel_frac_by_compulsory_bytes_compact": sub["roofline"].get("kernel_frac_by_compulsory_bytes_compact"),
-                                  "whole_step_frac": sub["roofline"]["whole_step_frac"], "validated": sub["validated"], "cpu_baseline": sub["cpu_baseline"]}
+                                  "per_kernel": sub["roofline"]["per_kernel"], "validated": sub["validated"], "cpu_baseline": sub["cpu_baseline"]}
                 except Exception as ex:                                      # noqa: BLE001 — reported, never hidden
                     other[key] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         # ---- BASELINE configs 4 and 5 through the drop-in CLI itself: multi-contig BAM + BAI, the reference's own -l loop and -p -i

@@ -242,9 +242,10 @@ int  brc_begin_region(brc_engine*, int32_t tid, int32_t beg0, int32_t end, const
  * The engine copies what it needs into pinned staging before returning.  BRC_E_ARG for records the kernels could not index
  * safely: offsets outside the batch arenas, reads out of order, a mapped record's CIGAR whose query-consuming operators (M I S = X) do
  * not add up to l_qseq (an UNMAPPED record with such a CIGAR is taken without it: it never reaches a column), a record without sequence (l_qseq == 0) that is neither unmapped nor secondary / QC-fail / duplicate, a
- * library index outside the configured ones, a mapped record with an M / = / X operator of length zero (htslib's resolve_cigar2 steps
- * ONTO such an operator and reports its column as a match, the deletion behind it one column late: nothing the engine's read segments can
- * express, and nothing an aligner writes).  A refused batch ABANDONS the region (its staging is half appended): further
+ * library index outside the configured ones, a mapped record whose CIGAR has an EMPTY M / = / X operator behind the read's last base (the
+ * reference reads past the read's qualities there).  Every other M / = / X operator of length zero is accepted (round 6): htslib's
+ * resolve_cigar2 steps ONTO such an operator for one column — reported as a match at the operator's query offset, whatever follows seen one
+ * column late — and such reads are piled up by that cursor itself, column by column (brc_core.h: cursor_resolve); no aligner writes them. A refused batch ABANDONS the region (its staging is half appended): further
  * brc_push_reads / brc_upload calls fail until the next brc_begin_region. */
 int  brc_push_reads(brc_engine*, const brc_read_batch*);
 

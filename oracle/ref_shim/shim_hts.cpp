@@ -116,44 +116,53 @@ static hts_pos_t shim_endpos(const bam1_t* b) {   // bam_endpos: rlen 0 (or unma
     return b->core.pos + (l ? l : 1);
 }
 
-/* resolve_cigar2 as a pure function of the position: which operator holds `pos`, the query offset there, and what the
- * last reference base of an operator sees ahead (D -> -len, I -> +len, P...I -> +sum of I).  Returns false when no
- * reference-consuming operator covers pos. */
-static bool resolve_stateless(const bam1_t* b, hts_pos_t pos, bam_pileup1_t* p) {
+/* resolve_cigar2 (htslib 1.10 sam.c, restated from its published algorithm): every buffered read keeps a cursor — the reference-consuming
+ * operator it stands on (k), that operator's reference start (x) and the query offset there (y) — which moves on by ONE such operator when
+ * the column has passed the current one.  For CIGARs whose operators all have a positive length this is the same as asking which operator
+ * holds the column (what this file did until round 6); on an M / = / X operator of length zero the cursor stands for one column, reports it
+ * as a match at the operator's query offset, and sees what follows one column late.  Returns false when the read has no entry in the column. */
+struct PlpCursor { int k = -1; hts_pos_t x = 0; int y = 0; };
+static bool resolve_cursor(const bam1_t* b, hts_pos_t pos, PlpCursor* s, bam_pileup1_t* p) {
     const uint32_t* c = bam1_cigar(b); const int n = (int)b->core.n_cigar;
-    hts_pos_t x = b->core.pos; int y = 0;
-    if (n == 1 && !mop(c[0] & 0xf)) return false;    // htslib asserts here; nothing to stand on
-    for (int k = 0; k < n; ++k) {
-        const int op = c[k] & 0xf, l = c[k] >> 4;
-        if (refop(op)) {
-            if (pos >= x && pos < x + l) {
-                p->is_del = p->is_refskip = 0; p->indel = 0;
-                if (mop(op)) p->qpos = y + (int)(pos - x);
-                else { p->is_del = 1; p->qpos = y; p->is_refskip = (op == BAM_CREF_SKIP); }
-                if (pos == x + l - 1 && k + 1 < n) {
-                    const int op2 = c[k + 1] & 0xf, l2 = c[k + 1] >> 4;
-                    if (op2 == BAM_CDEL) p->indel = -l2;
-                    else if (op2 == BAM_CINS) p->indel = l2;
-                    else if (op2 == BAM_CPAD && k + 2 < n) {
-                        int l3 = 0;
-                        for (int j = k + 2; j < n; ++j) {
-                            const int o = c[j] & 0xf;
-                            if (o == BAM_CINS) l3 += c[j] >> 4;
-                            else if (o == BAM_CDEL || o == BAM_CMATCH || o == BAM_CREF_SKIP || o == BAM_CEQUAL || o == BAM_CDIFF) break;
-                        }
-                        if (l3 > 0) p->indel = l3;
-                    }
-                }
-                return true;
-            }
-            x += l;
-            if (mop(op)) y += l;
-        } else if (op == BAM_CINS || op == BAM_CSOFT_CLIP) y += l;
+    if (s->k == -1) {                                   /* first column of the read */
+        p->qpos = 0;
+        if (n == 1) { if (mop(c[0] & 0xf)) { s->k = 0; s->x = b->core.pos; s->y = 0; } }
+        else {
+            int k = 0; s->x = b->core.pos; s->y = 0;
+            for (; k < n; ++k) { const int op = c[k] & 0xf; if (refop(op)) break; if (op == BAM_CINS || op == BAM_CSOFT_CLIP) s->y += c[k] >> 4; }
+            s->k = k;
+        }
+        if (s->k < 0 || s->k >= n) return false;        /* htslib asserts here; nothing to stand on */
+    } else {
+        const int l = c[s->k] >> 4;
+        if (pos - s->x >= l) {                          /* the column has left the operator: on to the next reference-consuming one */
+            if (s->k + 1 >= n) return false;
+            if (mop(c[s->k] & 0xf)) s->y += l;
+            s->x += l;
+            int k = s->k + 1;
+            for (; k < n; ++k) { const int op = c[k] & 0xf; if (refop(op)) break; if (op == BAM_CINS || op == BAM_CSOFT_CLIP) s->y += c[k] >> 4; }
+            s->k = k;
+            if (s->k >= n) return false;
+        }
     }
-    return false;
+    const int op = c[s->k] & 0xf, l = c[s->k] >> 4;
+    p->is_del = p->is_refskip = 0; p->indel = 0;
+    if (s->x + l - 1 == pos && s->k + 1 < n) {          /* the operator's last reference base looks ahead */
+        const int op2 = c[s->k + 1] & 0xf, l2 = c[s->k + 1] >> 4;
+        if (op2 == BAM_CDEL) p->indel = -l2;
+        else if (op2 == BAM_CINS) p->indel = l2;
+        else if (op2 == BAM_CPAD && s->k + 2 < n) {
+            int l3 = 0;
+            for (int j = s->k + 2; j < n; ++j) { const int o = c[j] & 0xf; if (o == BAM_CINS) l3 += c[j] >> 4; else if (refop(o)) break; }
+            if (l3 > 0) p->indel = l3;
+        }
+    }
+    if (mop(op)) p->qpos = s->y + (int)(pos - s->x);
+    else { p->is_del = 1; p->qpos = s->y; p->is_refskip = (op == BAM_CREF_SKIP); }
+    return true;
 }
 
-struct PlpNode { bam1_t b; hts_pos_t beg, end; };
+struct PlpNode { bam1_t b; hts_pos_t beg, end; PlpCursor cur; };
 struct __bam_plp_t {
     std::vector<PlpNode*> list;          // head..tail (without htslib's spare tail node)
     std::vector<bam_pileup1_t> plp;
@@ -194,7 +203,7 @@ static const bam_pileup1_t* plp_next(bam_plp_t it, int* tid, int* pos, int* n_ou
             if (p->b.core.tid == it->tid && p->beg <= it->pos) {
                 bam_pileup1_t e; memset(&e, 0, sizeof e);
                 e.b = &p->b;
-                if (resolve_stateless(&p->b, it->pos, &e)) {
+                if (resolve_cursor(&p->b, it->pos, &p->cur, &e)) {
                     e.is_head = (it->pos == p->beg); e.is_tail = (it->pos == p->end - 1);
                     it->plp.push_back(e); ++n_plp;
                 }

@@ -326,3 +326,28 @@ def operator_limit_reads():
     a = {k: np.array(v, dt[k]) for k, v in a.items()}
     a["cigar"] = np.array(cig, np.uint32); a["seq4"] = np.concatenate(seqs); a["qual"] = np.concatenate(quals)
     return ref, a
+
+
+def inject_empty_mops(arrs, seed=0, frac=0.5):
+    """Round 6: a copy of a batch in which `frac` of the mapped reads with a CIGAR get one to three M / = / X operators of LENGTH ZERO at
+    random places (in front of a deletion, behind one, between two matches, as the first operator, ...) — htslib's cursor steps onto such an
+    operator for one column (brc_core.h: cursor_resolve).  Never as the last reference-consuming operator behind the read's last base (the
+    reference reads past the read's qualities there: the engine refuses that one case)."""
+    rng = np.random.default_rng(seed)
+    n = len(arrs["pos"])
+    new_cig = []; new_off = np.zeros(n, np.uint64); new_nc = np.zeros(n, np.uint32)
+    for i in range(n):
+        nc = int(arrs["n_cigar"][i]); off = int(arrs["cigar_off"][i])
+        ops = [int(c) for c in arrs["cigar"][off:off + nc]]
+        if nc > 0 and not (int(arrs["flag"][i]) & 4) and rng.random() < frac:
+            # (positions in front of the last query-consuming match: the cursor never reports an empty operator at query offset l_qseq)
+            qcons = [k for k, c in enumerate(ops) if (c & 15) in (0, 7, 8) and (c >> 4) > 0]
+            if qcons:
+                for _ in range(int(rng.integers(1, 4))):
+                    at = int(rng.integers(0, qcons[-1] + 1))
+                    ops.insert(at, int(rng.choice([0, 0, 7, 8])))            # length zero: the operator code alone
+                    qcons = [k for k, c in enumerate(ops) if (c & 15) in (0, 7, 8) and (c >> 4) > 0]
+        new_off[i] = len(new_cig); new_nc[i] = len(ops); new_cig.extend(ops)
+    out = {k: v.copy() for k, v in arrs.items()}
+    out["cigar"] = np.array(new_cig, np.uint32); out["cigar_off"] = new_off; out["n_cigar"] = new_nc
+    return out

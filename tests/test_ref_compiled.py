@@ -916,3 +916,33 @@ def test_cli_random_command_lines_equal_reference_main(ref_lib, tmp_path, block)
 def test_cli_random_command_lines_equal_reference_main_gpu(ref_lib, tmp_path):
     from test_cli import HIP_CLI
     _cli_fuzz(HIP_CLI, ref_lib, tmp_path, range(100, 112), one_device=True)
+
+
+def _empty_mop_case():
+    rng = np.random.default_rng(5)
+    ref = synth.make_ref(rng, 3000, weird=0.01)
+    base = synth.make_batch(21, ref, 400, read_len=(40, 160), style="indel", n_libs=2)
+    return ref, synth.inject_empty_mops(base, seed=3, frac=0.6)
+
+
+def test_empty_m_operators_equal_the_reference_s_own_sources(oracle_lib, sim_lib, ref_lib):
+    """CIGARs with M / = / X operators of length zero (round 6: piled up by the iterator's cursor instead of refused): the reference's own
+    fetch_func / pileup_func over the shim's pileup iterator against the oracle and every text route of the device algorithm."""
+    ref, arrs = _empty_mop_case()
+    regions = [(0, 3000), (700, 900)]
+    for kw in (dict(), dict(insertion_centric=True, min_mapq=10, min_bq=8), dict(per_lib=True, lib_names=["libA", "libB"], insertion_centric=True)):
+        want, _ = parity.run_engine(ref_lib, arrs, regions, ref=ref, **kw)
+        assert parity.run_engine(oracle_lib, arrs, regions, ref=ref, **kw)[0] == want, kw
+        for route in (dict(), dict(text_only=True), dict(device_text="chrS")):
+            assert parity.run_engine(sim_lib, arrs, regions, ref=ref, **route, **kw)[0] == want, (kw, route)
+
+
+@pytest.mark.gpu
+def test_empty_m_operators_equal_the_reference_s_own_sources_gpu(hip_lib, oracle_lib, ref_lib):
+    ref, arrs = _empty_mop_case()
+    regions = [(0, 3000), (700, 900)]
+    for kw in (dict(), dict(insertion_centric=True, min_mapq=10, min_bq=8), dict(per_lib=True, lib_names=["libA", "libB"], insertion_centric=True)):
+        want, _ = parity.run_engine(ref_lib, arrs, regions, ref=ref, **kw)
+        for route in (dict(), dict(text_only=True), dict(device_text="chrS")):
+            assert parity.run_engine(hip_lib, arrs, regions, ref=ref, **route, **kw)[0] == want, (kw, route)
+    parity.compare_libs(hip_lib, oracle_lib, arrs, regions, ref=ref)

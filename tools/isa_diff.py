@@ -20,7 +20,8 @@ def kernels(path):
             t = l.strip()
             if not t or t.startswith(';') or t.startswith('.'):
                 continue
-            out[cur].append(re.sub(r'\s*;.*$', '', t))
+            # (basic-block labels carry the function's ordinal in the file: a kernel added in front renumbers them)
+            out[cur].append(re.sub(r'\.LBB\d+_', '.LBB_', re.sub(r'\s*;.*$', '', t)))
     return out
 
 
