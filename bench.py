@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300, help="timed steps (300 x ~7 ms: a timed region above 2 s)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--mode", default="weak", choices=["weak", "strong", "sites"])
-    ap.add_argument("--config", default=None, choices=["wgs30x", "tumor200x", "wgs30x_mixed", "long10k", "ont", "ont_ul"], help="data model (default: wgs30x; tumor200x for --mode strong; wgs30x_mixed: config 3 with 30 %% of the reads trimmed to U[100,149] and 10 %% 250 bases long; long10k: 10-kb reads at 30x; ont: 3-10-kb reads with an insertion or deletion every ~15 bases at 30x (use --contig-mbp 20); ont_ul: the same with 30-100-kb reads — functional and throughput points outside BASELINE's configurations)")
+    ap.add_argument("--config", default=None, choices=["wgs30x", "tumor200x", "wgs30x_mixed", "novaseq", "long10k", "ont", "ont_ul"], help="data model (default: wgs30x; tumor200x for --mode strong; wgs30x_mixed: config 3 with 30 %% of the reads trimmed to U[100,149] and 10 %% 250 bases long; long10k: 10-kb reads at 30x; ont: 3-10-kb reads with an insertion or deletion every ~15 bases at 30x (use --contig-mbp 20); ont_ul: the same with 30-100-kb reads — functional and throughput points outside BASELINE's configurations)")
     ap.add_argument("--contig-mbp", type=float, default=50.0, help="weak/sites: contig per GPU; strong: the whole contig")
     ap.add_argument("--sites", type=int, default=100000, help="--mode sites: lines of the site list (all ranks together)")
     ap.add_argument("--cpu-sample-mbp", type=float, default=8.0, help="prefix timed with the 1-thread CPU oracle and used for validation (0 = skip)")
@@ -596,6 +596,9 @@ def main():
                     # config 3's data model with mixed read lengths (30 % trimmed to U[100,149], 10 % 250 bases): what the one-modal-length
                     # fast path of k_pileup2 costs on reads of other lengths
                     "mixed_lengths": ["--mode", "weak", "--config", "wgs30x_mixed"],
+                    # NovaSeq-like records: 151 bases, binned qualities, a quarter of the reads adapter-trimmed, 10 % soft clips, duplicates,
+                    # secondary / supplementary records, MAPQ-0 multimappers (tools/synthgen.py: "novaseq")
+                    "novaseq": ["--mode", "weak", "--config", "novaseq"],
                     # config 5 whole on ONE GPU (50 Mbp, 200x, 4 libraries: 67 M reads, 10 G events per step); every position of it
                     # against the oracle on all cores too — planes only: its text would be 72 GB
                     "config5_full_one_gpu": ["--mode", "strong", "--contig-mbp", "50", "--full-check", "2", "--steps", "10", "--warmup", "2"]}
@@ -643,6 +646,8 @@ def main():
                          % (args.sites, world, contig_len / 1e6, world)}[args.mode]
         if config == "wgs30x_mixed":
             what = "synthetic 30x WGS, MIXED read lengths (60 %% 150 bp, 30 %% trimmed to U[100,149], 10 %% 250 bp), 1 contig %.0f Mbp per GPU, -q20 -b13" % (contig_len / 1e6)
+        if config == "novaseq":
+            what = "synthetic 30x, NovaSeq-like reads (151 bp; quality bins 2 / 12 / 23 / 37; 25 %% adapter-trimmed to U[35,150]; 10 %% soft-clipped; 8 %% duplicates, 1 %% secondary, 1 %% supplementary; 5 %% MAPQ 0), 1 contig %.0f Mbp per GPU, -q20 -b13 — not one of BASELINE's configurations" % (contig_len / 1e6)
         if config == "long10k":
             what = "synthetic 30x, 10-kb reads (30 %% with an insertion, 30 %% with a deletion), 1 contig %.0f Mbp per GPU, -q20 -b13 — not one of BASELINE's configurations" % (contig_len / 1e6)
         if config in ("ont", "ont_ul"):

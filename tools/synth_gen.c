@@ -31,6 +31,11 @@ typedef struct {
      * (and no extra draw: the fixed-length configurations generate the bytes they always did). */
     double p_trim, p_long;
     int32_t trim_min, long_len;
+    /* NovaSeq-like records (round 6, the "novaseq" model): qual_bins != 0 -> qualities from the four RTA3 bins {2, 12, 23, 37} (2 %, 6 %, 12 %,
+     * 80 %; the 3' Q2 run stays); p_dup / p_sec / p_supp: duplicate (0x400), secondary (0x100) and supplementary (0x800) records; p_mapq0:
+     * multimappers with MAPQ 0.  All 0: the records the other models always had (and no extra draw). */
+    int32_t qual_bins;
+    double p_dup, p_sec, p_supp, p_mapq0;
 } synth_params;
 
 typedef struct { uint64_t s[4]; } rng_t;
@@ -105,8 +110,11 @@ int synth_reads(const synth_params* P, const uint8_t* ref, int32_t* pos, uint16_
             uint16_t f;
             if (uf < 0.98) { const int first = (int)(rng_next(&r) >> 63); f = rev ? (first ? 83 : 147) : (first ? 99 : 163); }
             else { static const uint16_t odd[4] = {65, 129, 121, 73}; f = odd[rng_below(&r, 4)]; if (rev) f |= 16; else f &= (uint16_t)~16u; }
+            const int nova = P->qual_bins != 0 || P->p_dup > 0 || P->p_sec > 0 || P->p_supp > 0 || P->p_mapq0 > 0;
+            if (nova) { const double ux = rng_u01(&r); if (ux < P->p_dup) f |= 0x400; else if (ux < P->p_dup + P->p_sec) f |= 0x100; else if (ux < P->p_dup + P->p_sec + P->p_supp) f |= 0x800; }
             flag[i] = f;
             mapq[i] = (rng_u01(&r) < 0.9) ? 60 : (uint8_t)rng_below(&r, 60);
+            if (nova && rng_u01(&r) < P->p_mapq0) mapq[i] = 0;
             lib[i] = (int16_t)(P->n_libs > 1 ? rng_below(&r, (uint32_t)P->n_libs) : 0);
             int L = P->read_len;
             if (mixed) { const double ul = rng_u01(&r); if (ul < P->p_trim) L = P->trim_min + (int)rng_below(&r, (uint32_t)(P->read_len - P->trim_min)); else if (ul < P->p_trim + P->p_long) L = P->long_len; }
@@ -154,6 +162,12 @@ int synth_reads(const synth_params* P, const uint8_t* ref, int32_t* pos, uint16_
             if (L & 1) s4[L >> 1] = (uint8_t)(codes[L - 1] << 4);
             /* qualities */
             uint8_t* qq = qual + (uint64_t)i * Lmax;
+            if (P->qual_bins) {
+                for (int j = 0; j < L; j += 8) {
+                    uint64_t x = rng_next(&r);
+                    for (int k = 0; k < 8 && j + k < L; ++k, x >>= 8) { const unsigned u = (unsigned)(x & 255); qq[j + k] = u < 5 ? 2 : u < 20 ? 12 : u < 51 ? 23 : 37; }
+                }
+            } else
             for (int j = 0; j < L; j += 5) {
                 uint64_t x = rng_next(&r);
                 for (int k = 0; k < 5 && j + k < L; ++k, x >>= 12) qq[j + k] = QTAB[x & 4095];

@@ -12,7 +12,8 @@ LIB = os.path.join(HERE, "libsynth.so")
 class Params(C.Structure):
     _fields_ = [("contig_len", C.c_int64), ("n_reads", C.c_int64), ("read_len", C.c_int32), ("n_libs", C.c_int32),
                 ("seed", C.c_uint64), ("p_sub", C.c_double), ("p_clip", C.c_double), ("p_ins", C.c_double), ("p_del", C.c_double),
-                ("indel_max", C.c_int32), ("n_chunks", C.c_int32), ("p_trim", C.c_double), ("p_long", C.c_double), ("trim_min", C.c_int32), ("long_len", C.c_int32)]
+                ("indel_max", C.c_int32), ("n_chunks", C.c_int32), ("p_trim", C.c_double), ("p_long", C.c_double), ("trim_min", C.c_int32), ("long_len", C.c_int32),
+                ("qual_bins", C.c_int32), ("p_dup", C.c_double), ("p_sec", C.c_double), ("p_supp", C.c_double), ("p_mapq0", C.c_double)]
 
 
 def build():
@@ -124,6 +125,11 @@ CONFIGS = {
     "long10k": dict(depth=30.0, read_len=10000, n_libs=1, p_sub=0.005, p_clip=0.05, p_ins=0.3, p_del=0.3, indel_max=3),
     "wgs30x_mixed": dict(depth=30.0, read_len=150, n_libs=1, p_sub=0.005, p_clip=0.05, p_ins=0.01, p_del=0.01, indel_max=3,
                          p_trim=0.3, p_long=0.1, trim_min=100, long_len=250),
+    # NovaSeq-like short reads (round 6): 151 bases, the four RTA3 quality bins {2, 12, 23, 37}, a quarter of the reads adapter-trimmed to
+    # U[35, 150] bases, 10 % soft-clipped, 8 % duplicates / 1 % secondary / 1 % supplementary records, 5 % MAPQ-0 multimappers: the shape of
+    # real Illumina data that the one-modal-length fast path of k_pileup2 meets (uniform 150-base reads are its best case)
+    "novaseq": dict(depth=30.0, read_len=151, n_libs=1, p_sub=0.005, p_clip=0.10, p_ins=0.01, p_del=0.01, indel_max=3,
+                    p_trim=0.25, p_long=0.0, trim_min=35, long_len=0, qual_bins=1, p_dup=0.08, p_sec=0.01, p_supp=0.01, p_mapq0=0.05),
 }
 
 
@@ -144,7 +150,7 @@ def generate(contig_len, config="wgs30x", seed=1, n_chunks=64):
              tags=np.empty(n, np.uint8), cigar=np.empty(3 * n, np.uint32), seq4=np.empty(n * ((L + 1) // 2), np.uint8),
              qual=np.empty(n * L, np.uint8))
     p = Params(contig_len, n, cfg["read_len"], cfg["n_libs"], seed + 1, cfg["p_sub"], cfg["p_clip"], cfg["p_ins"], cfg["p_del"], cfg["indel_max"], n_chunks,
-               p_trim, p_long, trim_min, long_len)
+               p_trim, p_long, trim_min, long_len, cfg.get("qual_bins", 0), cfg.get("p_dup", 0.0), cfg.get("p_sec", 0.0), cfg.get("p_supp", 0.0), cfg.get("p_mapq0", 0.0))
     order = ["pos", "flag", "mapq", "lib", "l_qseq", "n_cigar", "cigar_off", "seq_off", "qual_off", "nm", "sm", "tags", "cigar", "seq4", "qual"]
     rc = lib().synth_reads(C.byref(p), ref.ctypes.data_as(C.c_void_p), *[a[k].ctypes.data_as(C.c_void_p) for k in order])
     if rc != 0:
@@ -171,7 +177,7 @@ def generate_dense(contig_len, config="ont", seed=1, n_chunks=64):
              seq_off=np.empty(n, np.uint64), qual_off=np.empty(n, np.uint64), nm=np.empty(n, np.int32), sm=np.empty(n, np.int32),
              tags=np.empty(n, np.uint8), cigar=np.zeros(n * stride, np.uint32), seq4=np.empty(n * ((lmax + 1) // 2), np.uint8),
              qual=np.empty(n * lmax, np.uint8))
-    p = Params(contig_len, n, lmax, cfg["n_libs"], seed + 1, cfg["p_sub"], 0.0, 0.0, 0.0, cfg["indel_max"], n_chunks, 0.0, 0.0, 0, 0)
+    p = Params(contig_len, n, lmax, cfg["n_libs"], seed + 1, cfg["p_sub"], 0.0, 0.0, 0.0, cfg["indel_max"], n_chunks, 0.0, 0.0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0)
     order = ["pos", "flag", "mapq", "lib", "l_qseq", "n_cigar", "cigar_off", "seq_off", "qual_off", "nm", "sm", "tags", "cigar", "seq4", "qual"]
     L = lib(); L.synth_reads_dense.argtypes = None
     rc = L.synth_reads_dense(C.byref(p), C.c_int32(lmin), C.c_int32(lmax), C.c_double(cfg["op_gap"]), C.c_int32(stride), ref.ctypes.data_as(C.c_void_p),
