@@ -46,7 +46,8 @@ struct Counters {
     unsigned int n_indel_slots, n_xev;   // n_xev: third-allele events in the compacted list
     unsigned int xev_max, n_wave_reads;  // fullest sub-list's cursor (above its capacity: grow and compute again); reads K1 left to k_annotate_wave
     unsigned int n_wave_big, n_wave_huge;   // ... those of them with more than AW_MCAP / AW_MCAP_BIG M operators (the one-wave-per-workgroup instantiations)
-    unsigned int n_literal, pad_;            // reads with an empty M / = / X operator: piled up by the iterator's own cursor (k_annotate_cursor)
+    unsigned int n_literal, n_wave_eqx;      // reads with an empty M / = / X operator: piled up by the iterator's own cursor (k_annotate_cursor); wave-form reads with = / X operators ...
+    unsigned int n_wave_eqx_big, pad_;       // ... those of them with more than AW_MCAP_EQX match operators
 };
 
 // Profiling ablations that switch parts of the kernels off (wrong results, timing only) exist only in experiment builds
@@ -168,7 +169,9 @@ __global__ __launch_bounds__(256) void k_refcode(const char* __restrict__ ref, u
 //                          three-prime / Q2 logic, DRead + float constants, the pieces, the indel events.
 enum { AW_MCAP = 1024,               // M operators of a read the wave form (k_annotate_wave, below) holds in LDS: four waves per workgroup ...
        AW_MCAP_BIG = 5120,           // ... and one wave per workgroup (60 KB: reads of ~80 kb with a match run of 15 bases between two operators)
-       AW_MCAP_HUGE = 13500 };       // ... and one wave per CU (158 of gfx950's 160 KB of LDS: reads of ~210 kb)
+       AW_MCAP_HUGE = 13500,         // ... and one wave per CU (158 of gfx950's 160 KB of LDS: reads of ~210 kb)
+       // reads with = / X operators (pbmm2, minimap2 --eqx): the list keeps a fourth word per entry — the ANNOTATOR's query offset, see k_annotate_wave
+       AW_MCAP_EQX = 768, AW_MCAP_EQX_BIG = 3840 };
 struct AnnPar { uint4 a, b, c; };    // a = {L, qrel, srel, brow.lo}  b = {S, m1lo, m1hi, d1}  c = {m2lo, m2hi, d2, brow.hi}
 
 __device__ __forceinline__ uint32_t nzb7(uint32_t x) { return x + 0x7f7f7f7fu; }   // bytes <= 0x7f: bit 7 of a byte <=> byte != 0
@@ -619,26 +622,35 @@ __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m) { return __bui
 // those of the one-wave-per-CU instantiation in a second list behind it, from list_cap + 16 on)
 __global__ __launch_bounds__(256) void k_pick_wave(DevCfg c, DevIn in, uint32_t* __restrict__ n_cigar_k1, uint32_t* __restrict__ wave_list, uint32_t list_cap,
                                                    unsigned int* __restrict__ wave_n, unsigned int* __restrict__ wave_n_big, unsigned int* __restrict__ wave_n_huge,
-                                                   int wave_on, int cursor_on, unsigned int* __restrict__ cursor_n) {
+                                                   int wave_on, int cursor_on, unsigned int* __restrict__ cursor_n,
+                                                   unsigned int* __restrict__ wave_n_eqx, unsigned int* __restrict__ wave_n_eqx_big) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool pick = false, big = false, huge = false, lit = false; uint32_t nc_me = 0u;
+    bool pick = false, big = false, huge = false, lit = false, eqx = false, eqx_big = false; uint32_t nc_me = 0u;
     if (i < c.n_reads) {
         const uint32_t nc = in.n_cigar[i]; nc_me = nc;
         const int32_t pos = in.pos[i], L = in.l_qseq[i];
         // a mapped read with an M / = / X operator of length zero (the host saw one in this region): third list, k_annotate_cursor
         if (cursor_on && nc > 0u && !(in.flag[i] & FUNMAP)) lit = has_empty_mop(BRC_CK(c, CK_ANNOTATE, 45, CB_CIGAR, in.cigar + in.cig_off[i], 4ull * nc, i, -1), nc);
-        if (!lit && wave_on && nc >= 5u && L > 0 && pos >= 0 && c.has_ref && !(in.flag[i] & BRC_PUSH_MASK)) {       // (three M operators take at least five)
+        if (!lit && wave_on && nc >= 3u && L > 0 && pos >= 0 && c.has_ref && !(in.flag[i] & BRC_PUSH_MASK)) {       // (three match operators: five operators with M alone, three with = / X)
             const uint32_t* cig = BRC_CK(c, CK_ANNOTATE, 44, CB_CIGAR, in.cigar + in.cig_off[i], 4ull * nc, i, -1);
-            int64_t rlen = 0; uint32_t n_m = 0; bool irregular = false;
+            int64_t rlen = 0; uint32_t n_m = 0, n_ml = 0; bool irregular = false, has_eqx = false;
             for (uint32_t k = 0; k < nc; ++k) {
                 const uint32_t cg = cig[k], op = cg & 0xfu, len = cg >> 4;
-                if (op > (uint32_t)CHARD_CLIP || (op == CMATCH && len == 0u)) irregular = true;  // P, =, X, unknown codes, an empty M: the serial path restates those
+                if (op == (uint32_t)CPAD || op > (uint32_t)CDIFF || (is_mop(op) && len == 0u)) irregular = true;  // P, unknown codes, an empty match operator: the serial path (or the cursor) restates those
                 if (op == CMATCH) ++n_m;
+                if (op == CEQUAL || op == CDIFF) has_eqx = true;
+                if (is_mop(op)) ++n_ml;
                 if (is_refop(op)) rlen += len;
             }
-            pick = !irregular && n_m > 2u && n_m <= (uint32_t)AW_MCAP_HUGE && (int64_t)pos + rlen <= c.ref_len && rlen < 0x7fffffffll;
-            huge = pick && n_m > (uint32_t)AW_MCAP_BIG;
-            big = pick && !huge && n_m > (uint32_t)AW_MCAP;
+            const bool fits = !irregular && (int64_t)pos + rlen <= c.ref_len && rlen < 0x7fffffffll;
+            if (has_eqx) {          // = / X beside anything: the instantiation that keeps the annotator's own cursors (k_annotate_wave<.., EQX>)
+                eqx = fits && n_ml > 2u && n_ml <= (uint32_t)AW_MCAP_EQX_BIG;
+                eqx_big = eqx && n_ml > (uint32_t)AW_MCAP_EQX;
+            } else {
+                pick = fits && n_m > 2u && n_m <= (uint32_t)AW_MCAP_HUGE;
+                huge = pick && n_m > (uint32_t)AW_MCAP_BIG;
+                big = pick && !huge && n_m > (uint32_t)AW_MCAP;
+            }
         }
     }
     const int lane = threadIdx.x & 63;
@@ -668,7 +680,20 @@ __global__ __launch_bounds__(256) void k_pick_wave(DevCfg c, DevIn in, uint32_t*
         base = (uint32_t)__shfl((int)base, __builtin_ctzll(pl), 64);
         if (lit) wave_list[2u * list_cap + 32u + base + mbcnt64(pl)] = (uint32_t)i;
     }
-    if (i < c.n_reads) n_cigar_k1[i] = (pick || lit) ? 0u : nc_me;
+    const unsigned long long pe = __ballot(eqx && !eqx_big), peb = __ballot(eqx_big);
+    if (pe) {
+        uint32_t base = 0u;
+        if (lane == __builtin_ctzll(pe)) base = atomicAdd(wave_n_eqx, (unsigned int)__builtin_popcountll(pe));
+        base = (uint32_t)__shfl((int)base, __builtin_ctzll(pe), 64);
+        if (eqx && !eqx_big) wave_list[3u * list_cap + 48u + base + mbcnt64(pe)] = (uint32_t)i;
+    }
+    if (peb) {
+        uint32_t base = 0u;
+        if (lane == __builtin_ctzll(peb)) base = atomicAdd(wave_n_eqx_big, (unsigned int)__builtin_popcountll(peb));
+        base = (uint32_t)__shfl((int)base, __builtin_ctzll(peb), 64);
+        if (eqx_big) wave_list[4u * list_cap + 47u - (base + mbcnt64(peb))] = (uint32_t)i;
+    }
+    if (i < c.n_reads) n_cigar_k1[i] = (pick || lit || eqx) ? 0u : nc_me;
 }
 // Reads with an empty M / = / X operator (brc_core.h: cursor_resolve): one lane per read — fetch_func's annotation by annotate_read() (the
 // annotator walks the CIGAR operator by operator: an empty operator is an empty loop, bamreadcount.cpp:133-197), the read's segments and indel
@@ -720,14 +745,20 @@ __device__ __forceinline__ int32_t wave_incl_sum(int32_t v, int lane) {
     for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(v, d, 64); if (lane >= d) v += o; }
     return v;
 }
-template <int SH, int MCAP, int WAVES>      // MCAP: M operators the LDS list holds; WAVES per workgroup (AW_MCAP x 4, or AW_MCAP_BIG x 1); list_step: +1 / -1 (the big reads are listed from the back)
+// EQX: reads with = / X operators.  fetch_func's operator loop has no branch for them (bamreadcount.cpp:133-197): NEITHER of its cursors moves,
+// so the M operators behind them are compared at the annotator's own query / reference offsets — the true ones less the = / X bases before —,
+// while the pileup iterator treats = and X like M.  The list then holds every match operator (M, =, X) with its TRUE offsets (the segments of
+// pass 3), the annotator's query offset beside it (its reference offset is the true one less the same difference), and a bit that says "M":
+// pass 2 finds a base's operator by the annotator's offsets and only an M operator makes it a compared base.
+template <int SH, int MCAP, int WAVES, bool EQX = false>      // MCAP: match operators the LDS list holds; WAVES per workgroup (AW_MCAP x 4, or AW_MCAP_BIG x 1); list_step: +1 / -1 (the big reads are listed from the back)
 __global__ __launch_bounds__(WAVES * 64) void k_annotate_wave(DevCfg c, DevIn in, const uint32_t* __restrict__ wave_list, int list_step, const unsigned int* __restrict__ wave_n,
                                                        DRead* __restrict__ reads, const uint32_t* __restrict__ piece_off,
                                                        Piece* __restrict__ pieces, PieceRare* __restrict__ rare, int2* __restrict__ keyreach,
                                                        uint8_t* __restrict__ eb, uint16_t* __restrict__ bqw, IndelEv* __restrict__ ev_raw, uint32_t* __restrict__ bucket_cnt,
                                                        const uint8_t* __restrict__ refcode, const uint16_t* __restrict__ wanted) {
     c.pack_shift = SH;
-    struct WaveLds { int32_t y[MCAP]; int32_t x[MCAP]; uint32_t lw[MCAP]; DRead r; uint32_t wide; };
+    struct WaveLds { int32_t y[MCAP]; int32_t x[MCAP]; uint32_t lw[MCAP]; int32_t ya[EQX ? MCAP : 1]; DRead r; uint32_t wide; };
+    constexpr uint32_t LW_LEN = EQX ? 0x0fffffffu : 0x7fffffffu, LW_M = 1u << 30;      // (a CIGAR length has 28 bits)
     __shared__ WaveLds lds_all[WAVES];
     const int lane = threadIdx.x & 63;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -756,23 +787,29 @@ __global__ __launch_bounds__(WAVES * 64) void k_annotate_wave(DevCfg c, DevIn in
         IndelEv* const ev_slots = ev_raw ? ev_raw + in.iev_off[my] : nullptr;
 
         // ---- pass 1: lane = operator
-        int32_t xc = pos, yc = 0; uint32_t mc = 0u, used = 0u, n_idp = 0u;
+        int32_t xc = pos, yc = 0, ec = 0; uint32_t mc = 0u, used = 0u, n_idp = 0u;         // ec: = / X bases so far (the annotator's cursors lag by them)
         uint32_t s_part = 0u, d_part = 0u, i_part = 0u; int32_t left_clip = 0;
         for (uint32_t kb = 0; kb < nc; kb += 64u) {
             const uint32_t k = kb + (uint32_t)lane; const bool on = k < nc;
             const uint32_t cg = on ? cig[k] : 0u, c1 = k + 1u < nc ? cig[k + 1u] : 0u;
             const uint32_t op = on ? (cg & 0xfu) : (uint32_t)CHARD_CLIP; const int32_t len = (int32_t)(cg >> 4);
-            const bool isM = op == CMATCH, isI = op == CINS, isD = op == CDEL, isN = op == CREF_SKIP, isS = op == CSOFT_CLIP;
+            const bool isE = EQX && (op == CEQUAL || op == CDIFF);
+            const bool isM = op == CMATCH || isE, isI = op == CINS, isD = op == CDEL, isN = op == CREF_SKIP, isS = op == CSOFT_CLIP;      // (isM: a match operator of the iterator's)
             const int32_t ql = (isM || isI || isS) ? len : 0, rl = (isM || isD || isN) ? len : 0;
             const int32_t qi = wave_incl_sum(ql, lane), ri = wave_incl_sum(rl, lane);
             const int32_t y = yc + qi - ql, x = xc + ri - rl;
+            int32_t e_before = 0;
+            if (EQX) { const int32_t el = isE ? len : 0; const int32_t ei = wave_incl_sum(el, lane); e_before = ec + ei - el; ec += __builtin_amdgcn_readlane(ei, 63); }
             if (isS) { s_part += (uint32_t)len; if (k == 0u) left_clip = len; }
             if (isD || isN) d_part += (uint32_t)len;
             if (isI || isS) i_part += (uint32_t)len;
             const unsigned long long mb = __ballot(isM);
             if (isM) {
                 const uint32_t mr = mc + mbcnt64(mb);                                   // (k_pick_wave lists only reads with at most MCAP M operators)
-                if (mr < (uint32_t)MCAP) { W.y[mr] = y; W.x[mr] = x; W.lw[mr] = (uint32_t)len | (((c1 & 0xfu) == CINS && (c1 >> 4) > 0u) ? 0x80000000u : 0u); }
+                if (mr < (uint32_t)MCAP) {
+                    W.y[mr] = y; W.x[mr] = x; W.lw[mr] = (uint32_t)len | (((c1 & 0xfu) == CINS && (c1 >> 4) > 0u) ? 0x80000000u : 0u) | ((EQX && !isE) ? LW_M : 0u);
+                    if (EQX) W.ya[mr] = y - e_before;
+                }
             }
             mc += (uint32_t)__builtin_popcountll(mb);
             n_idp += (uint32_t)__builtin_popcountll(__ballot(isI || isD));
@@ -816,16 +853,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_annotate_wave(DevCfg c, DevIn in
             const uint32_t q = qual[jc];
             const uint32_t nib = (seq[jc >> 1] >> ((~jc & 1) << 2)) & 0xfu;
             // number of list entries with query start <= j (entries are sorted; at most 64 start inside a pass)
-            uint32_t cnt = mlo;
+            // (EQX: an = / X entry takes no query base of the annotator's — any number of entries may share an offset —: the whole list is searched)
+            uint32_t cnt = EQX ? 0u : mlo;
 #pragma unroll
-            for (uint32_t st = 64u; st > 0u; st >>= 1) { const uint32_t t = cnt + st; if (t <= nm_ops && W.y[t - 1u] <= jc) cnt = t; }
+            for (uint32_t st = EQX ? 4096u : 64u; st > 0u; st >>= 1) { const uint32_t t = cnt + st; if (t <= nm_ops && (EQX ? W.ya[t - 1u] : W.y[t - 1u]) <= jc) cnt = t; }
             mlo = (uint32_t)__builtin_amdgcn_readlane((int)cnt, 0);                   // (every later base has at least lane 0's count)
             bool in_m = false; uint32_t rcode = 0x0fu;
             if (cnt > 0u) {
-                const uint32_t m = cnt - 1u; const int32_t y0 = W.y[m]; const int32_t ln = (int32_t)(W.lw[m] & 0x7fffffffu);
+                const uint32_t m = cnt - 1u; const int32_t y0 = EQX ? W.ya[m] : W.y[m];
+                const uint32_t lwm = W.lw[m];
+                const int32_t ln = (!EQX || (lwm & LW_M)) ? (int32_t)(lwm & LW_LEN) : 0;       // (an = / X operator compares nothing)
                 if (valid && jc - y0 < ln) {
                     in_m = true;
-                    const int64_t ri = (int64_t)W.x[m] - c.ref_lo + (jc - y0);
+                    const int64_t ri = (int64_t)W.x[m] - (EQX ? (int64_t)(W.y[m] - y0) : 0) - c.ref_lo + (jc - y0);
                     if (ri < 0 || ri >= ref_n) rcode = 0x8fu;                         // outside the uploaded slice: ref_at() gives 0 there — the serial path decides
                     else rcode = *BRC_CK(c, CK_ANNOTATE, 39, CB_REFCODE, refcode + ri, 1, my, jc);
                 }
@@ -914,7 +954,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_annotate_wave(DevCfg c, DevIn in
                 const uint32_t m = mb0 + (uint32_t)lane; const bool on = m < nm_ops;
                 const uint32_t mi = on ? m : 0u;
                 const int32_t x = W.x[mi], y = W.y[mi]; const uint32_t lw = W.lw[mi];
-                const int32_t len = (int32_t)(lw & 0x7fffffffu);
+                const int32_t len = (int32_t)(lw & LW_LEN);
                 const int32_t xnext = mi + 1u < nm_ops ? W.x[mi + 1u] : pos + rlen;
                 const bool split = ic && (lw >> 31) != 0u;
                 const int32_t cnt = on ? ((split && len > 1) ? 2 : 1) : 0;
@@ -2153,6 +2193,7 @@ class HipBackend : public Backend {
            WAVE_FORM_BLOCKS_BIG = 512,         // the one-wave instantiation: 2 blocks per CU (60 KB of LDS each)
            WAVE_FORM_BLOCKS_HUGE = 256 };      // one block per CU (158 KB of LDS)
     bool wave_huge = false;                    // ... or more than AW_MCAP_BIG
+    bool wave_eqx = false; uint32_t s_max_ncigar = 0;   // reads with = / X operators exist: the EQX instantiations are launched too
     bool cursor_on = false;                    // a read with an empty M / = / X operator was staged: k_pick_wave lists such reads for k_annotate_cursor
     unsigned long long h_steps[3] = {0, 0, 0};   // piece-steps of the last pass: what the tile ranges hold / what k_pileup2 walked (brc_region_piece_steps)
     DBuf d_ccnt, d_coff, d_cpieces, d_crare, d_crng, d_ctot;
@@ -2338,15 +2379,17 @@ class HipBackend : public Backend {
         HIPCHK(d_pieces.ensure((np + 4) * sizeof(Piece))); HIPCHK(d_rare.ensure((np + 2) * sizeof(PieceRare)));      // (the read loop requests records up to two past the last)
         HIPCHK(d_keyreach.ensure((np + 16) * sizeof(int2)));
         // reads with more than two M operators are annotated a wave per read (k_annotate_wave); TK_WAVE_FORM=0 keeps them on K1's serial path
-        wave_on = n > 0 && c.has_ref && s.max_ncigar >= 5;                          // (three M operators take at least five operators)
-        if (const char* wk = test_knob(TK_WAVE_FORM)) wave_on = wave_on && atoi(wk) != 0;
+        wave_eqx = n > 0 && c.has_ref && s.has_eqx && s.max_ncigar >= 3;            // (= / X operators: three match operators take three operators)
+        wave_on = n > 0 && c.has_ref && (s.max_ncigar >= 5 || wave_eqx);            // (three M operators take at least five operators)
+        s_max_ncigar = s.max_ncigar;
+        if (const char* wk = test_knob(TK_WAVE_FORM)) { wave_on = wave_on && atoi(wk) != 0; wave_eqx = wave_eqx && wave_on; }
         // (k_pick_wave sorts the reads by their count of M operators, which the host does not keep: a read can have that many only with at
         // least as many operators — adjacent M operators are legal —, so the operator count decides which instantiations are launched; one
         // whose list stays empty costs a launch)
         wave_big = wave_on && s.max_ncigar > (uint32_t)AW_MCAP;
         wave_huge = wave_on && s.max_ncigar > (uint32_t)AW_MCAP_BIG;
         cursor_on = n > 0 && s.has_empty_m;
-        if (wave_on || cursor_on) { HIPCHK(d_wavelist.ensure((3 * (size_t)n + 64) * sizeof(uint32_t))); HIPCHK(d_nc_k1.ensure(((size_t)n + 16) * sizeof(uint32_t))); }
+        if (wave_on || cursor_on) { HIPCHK(d_wavelist.ensure((4 * (size_t)n + 96) * sizeof(uint32_t))); HIPCHK(d_nc_k1.ensure(((size_t)n + 16) * sizeof(uint32_t))); }
         HIPCHK(d_libbase.ensure((lib_base.size() + 1) * sizeof(int64_t)));
         if (!lib_base.empty()) HIPCHK(hipMemcpyAsync(d_libbase.p, lib_base.data(), lib_base.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
         // outputs / scratch
@@ -2443,7 +2486,7 @@ class HipBackend : public Backend {
             DevIn in_k1 = in;
             if (wave_on || cursor_on) {   // reads with more than two M operators: listed for k_annotate_wave, without operators in K1's copy of the counts (reads with an empty M / = / X operator: for k_annotate_cursor)
                 hipLaunchKernelGGL(k_pick_wave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (uint32_t*)d_nc_k1.p, (uint32_t*)d_wavelist.p, (uint32_t)n, &ctr->n_wave_reads, &ctr->n_wave_big, &ctr->n_wave_huge,
-                                   wave_on ? 1 : 0, cursor_on ? 1 : 0, &ctr->n_literal);
+                                   wave_on ? 1 : 0, cursor_on ? 1 : 0, &ctr->n_literal, &ctr->n_wave_eqx, &ctr->n_wave_eqx_big);
                 in_k1.n_cigar = (const uint32_t*)d_nc_k1.p;
             }
             {   // K1: one instantiation per (row layout, width of the narrow packed fields — choose_pack)
@@ -2466,6 +2509,18 @@ class HipBackend : public Backend {
                     if (wave_big) {     // reads with more than AW_MCAP M operators (more than 2 * AW_MCAP operators): one wave per workgroup, listed from the back
                         const unsigned nbb = (unsigned)std::min<int64_t>(n, (int64_t)WAVE_FORM_BLOCKS_BIG);
                         if (c.pack_shift == 16) BRC_LAUNCH_K1W(16, AW_MCAP_BIG, 1, nbb, wl + (n - 1), -1, &ctr->n_wave_big); else BRC_LAUNCH_K1W(12, AW_MCAP_BIG, 1, nbb, wl + (n - 1), -1, &ctr->n_wave_big);
+                    }
+                    if (wave_eqx) {     // reads with = / X operators: the instantiations that keep the annotator's own cursors; fourth list, the longer ones from its back
+#define BRC_LAUNCH_K1E(SH, MCAP, WAVES, GRID, LIST, STEP, COUNT) hipLaunchKernelGGL((k_annotate_wave<SH, MCAP, WAVES, true>), dim3(GRID), dim3(WAVES * 64), 0, stream, c, in, LIST, STEP, (const unsigned int*)(COUNT),     \
+                                   (DRead*)d_reads.p, (const uint32_t*)d_pieceoff.p, (Piece*)d_pieces.p, (PieceRare*)d_rare.p, (int2*)d_keyreach.p,                                   \
+                                   (uint8_t*)in.eb, (uint16_t*)in.bqw, indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p,                                          \
+                                   (const uint8_t*)d_refcode.p + REFCODE_PAD, has_wanted ? (const uint16_t*)d_wanted.p : (const uint16_t*)nullptr)
+                        if (c.pack_shift == 16) BRC_LAUNCH_K1E(16, AW_MCAP_EQX, 4, nb, wl + (3 * n + 48), 1, &ctr->n_wave_eqx); else BRC_LAUNCH_K1E(12, AW_MCAP_EQX, 4, nb, wl + (3 * n + 48), 1, &ctr->n_wave_eqx);
+                        if (s_max_ncigar > (uint32_t)AW_MCAP_EQX) {
+                            const unsigned nbe = (unsigned)std::min<int64_t>(n, (int64_t)WAVE_FORM_BLOCKS_BIG);
+                            if (c.pack_shift == 16) BRC_LAUNCH_K1E(16, AW_MCAP_EQX_BIG, 1, nbe, wl + (4 * n + 47), -1, &ctr->n_wave_eqx_big); else BRC_LAUNCH_K1E(12, AW_MCAP_EQX_BIG, 1, nbe, wl + (4 * n + 47), -1, &ctr->n_wave_eqx_big);
+                        }
+#undef BRC_LAUNCH_K1E
                     }
                     if (wave_huge) {    // more than AW_MCAP_BIG M operators: one wave per CU (its list fills the CU's LDS), second list
                         const unsigned nbh = (unsigned)std::min<int64_t>(n, (int64_t)WAVE_FORM_BLOCKS_HUGE);

@@ -104,7 +104,7 @@ void Staged::clear() {
     qual_off.clear(); nm.clear(); sm.clear(); tags.clear(); cigar.clear(); seq4.clear(); qual.clear(); bq_row.clear();
     bq_elems = 0; memset(len_hist, 0, sizeof len_hist); n = 0; min_pos = 0; max_end = 0; n_indel_ops = 0;
     seq_seg.clear(); qual_seg.clear(); seq_total = 0; qual_total = 0;
-    piece_cnt.clear(); piece_off.clear(); iev_off.clear(); lib_base.clear(); n_pieces = 0; max_lqseq = 0; max_ncigar = 0; has_empty_m = false; max_span = 0; qnames.clear(); qname_off.clear();
+    piece_cnt.clear(); piece_off.clear(); iev_off.clear(); lib_base.clear(); n_pieces = 0; max_lqseq = 0; max_ncigar = 0; has_empty_m = false; has_eqx = false; max_span = 0; qnames.clear(); qname_off.clear();
     win_beg.clear(); win_end.clear();
 }
 std::vector<uint16_t> Staged::wanted_tiles(int32_t pos0, int64_t P) const {
@@ -638,7 +638,7 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
     if (pool && e->accepted + (int64_t)n < (int64_t)maxcnt && !e->heap_built) {
         struct Chunk {
             uint64_t bq = 0, idp = 0, np = 0; int32_t max_lq = 0; int64_t max_span = 0; int64_t min_pos = INT64_MAX, max_end = INT64_MIN, n_ext = 0, acc = 0;
-            int32_t last_acc_pos = 0; int err = 0; const char* msg = nullptr; size_t err_at = 0; uint32_t hist[TABLE_MAX + 1]; bool empty_m = false;
+            int32_t last_acc_pos = 0; int err = 0; const char* msg = nullptr; size_t err_at = 0; uint32_t hist[TABLE_MAX + 1]; bool empty_m = false, eqx = false;
         };
         const size_t CH = (n + (size_t)pool->size() * 4 - 1) / ((size_t)pool->size() * 4);
         const size_t nch = (n + CH - 1) / CH;
@@ -664,12 +664,13 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
                 if (pos < prev) { bad(i, BRC_E_ARG, "reads are not coordinate-sorted"); break; }
                 const uint16_t fl = (uint16_t)(s.flag.p[r] & 0x7fffu);
                 if (s.l_qseq.p[r] > 0 && nc > 0) {
-                    int64_t ql = 0; bool empty_m = false;
-                    for (uint32_t k = 0; k < nc; ++k) { const uint32_t cg = s.cigar.p[s.cig_off.p[r] + k], op = cg & 0xfu; if (op == CMATCH || op == CINS || op == CSOFT_CLIP || op == CEQUAL || op == CDIFF) ql += cg >> 4; if (is_mop(op) && (cg >> 4) == 0u) empty_m = true; }
+                    int64_t ql = 0; bool empty_m = false, eqx = false;
+                    for (uint32_t k = 0; k < nc; ++k) { const uint32_t cg = s.cigar.p[s.cig_off.p[r] + k], op = cg & 0xfu; if (op == CMATCH || op == CINS || op == CSOFT_CLIP || op == CEQUAL || op == CDIFF) ql += cg >> 4; if (is_mop(op) && (cg >> 4) == 0u) empty_m = true; if (op == CEQUAL || op == CDIFF) eqx = true; }
                     if (ql != s.l_qseq.p[r]) {
                         if (!(fl & FUNMAP)) { bad(i, BRC_E_ARG, "a read's CIGAR and sequence length disagree"); break; }
                         nc = 0; s.n_cigar.p[r] = 0;
                     } else if (empty_m && !(fl & FUNMAP)) C.empty_m = true;
+                    if (eqx) C.eqx = true;
                 }
                 uint64_t idp = 0;
                 const int32_t rlen = cigar_rlen(s.cigar.p + s.cig_off.p[r], nc, &idp);
@@ -712,6 +713,7 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
             }
             if (C.acc) { e->accepted += C.acc; e->last_acc_pos = C.last_acc_pos; }
             if (C.empty_m) s.has_empty_m = true;
+            if (C.eqx) s.has_eqx = true;
         }
         pool->run((int64_t)nch, [&](int64_t ci) {
             uint64_t bq = bq0[(size_t)ci], idp = idp0[(size_t)ci];
@@ -746,12 +748,13 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
         // quality / base rows (htslib indexes the record's memory just the same: undefined there).  Mapped: refused.
         // Unmapped (some aligners leave the mate's CIGAR on such records; they never reach a column): the CIGAR is dropped.
         if (s.l_qseq.p[r] > 0 && nc > 0) {
-            int64_t ql = 0; bool empty_m = false;
-            for (uint32_t k = 0; k < nc; ++k) { const uint32_t cg = s.cigar.p[s.cig_off.p[r] + k], op = cg & 0xfu; if (op == CMATCH || op == CINS || op == CSOFT_CLIP || op == CEQUAL || op == CDIFF) ql += cg >> 4; if (is_mop(op) && (cg >> 4) == 0u) empty_m = true; }
+            int64_t ql = 0; bool empty_m = false, eqx = false;
+            for (uint32_t k = 0; k < nc; ++k) { const uint32_t cg = s.cigar.p[s.cig_off.p[r] + k], op = cg & 0xfu; if (op == CMATCH || op == CINS || op == CSOFT_CLIP || op == CEQUAL || op == CDIFF) ql += cg >> 4; if (is_mop(op) && (cg >> 4) == 0u) empty_m = true; if (op == CEQUAL || op == CDIFF) eqx = true; }
             if (ql != s.l_qseq.p[r]) {
                 if (!(fl & FUNMAP)) return fail(e, BRC_E_ARG, "a read's CIGAR and sequence length disagree");
                 nc = 0; s.n_cigar.p[r] = 0;
             } else if (empty_m && !(fl & FUNMAP)) s.has_empty_m = true;
+            if (eqx) s.has_eqx = true;
         }
         uint64_t idp = 0;                                     // I / D / P operators of the CIGAR the device will see
         const int32_t rlen = cigar_rlen(s.cigar.p + s.cig_off.p[r], nc, &idp);

@@ -81,6 +81,7 @@ struct Staged {
     int64_t n_pieces = 0;
     int32_t max_lqseq = 0;
     uint32_t max_ncigar = 0;        // most CIGAR operators of a staged read
+    bool has_eqx = false;           // a read with an = or X operator was staged (the wave-form annotator's EQX instantiations)
     bool has_empty_m = false;       // a mapped read with an M / = / X operator of length zero was staged (brc_core.h: cursor_resolve)
     int64_t max_span = 0;               // longest reference span of a pushed read
     void layout_pieces(int Lp, bool per_lib);

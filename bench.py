@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300, help="timed steps (300 x ~7 ms: a timed region above 2 s)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--mode", default="weak", choices=["weak", "strong", "sites"])
-    ap.add_argument("--config", default=None, choices=["wgs30x", "tumor200x", "wgs30x_mixed", "novaseq", "long10k", "ont", "ont_ul"], help="data model (default: wgs30x; tumor200x for --mode strong; wgs30x_mixed: config 3 with 30 %% of the reads trimmed to U[100,149] and 10 %% 250 bases long; long10k: 10-kb reads at 30x; ont: 3-10-kb reads with an insertion or deletion every ~15 bases at 30x (use --contig-mbp 20); ont_ul: the same with 30-100-kb reads — functional and throughput points outside BASELINE's configurations)")
+    ap.add_argument("--config", default=None, choices=["wgs30x", "tumor200x", "wgs30x_mixed", "novaseq", "long10k", "ont", "ont_ul", "hifi_eqx"], help="data model (default: wgs30x; tumor200x for --mode strong; wgs30x_mixed: config 3 with 30 %% of the reads trimmed to U[100,149] and 10 %% 250 bases long; long10k: 10-kb reads at 30x; ont: 3-10-kb reads with an insertion or deletion every ~15 bases at 30x (use --contig-mbp 20); ont_ul: the same with 30-100-kb reads — functional and throughput points outside BASELINE's configurations)")
     ap.add_argument("--contig-mbp", type=float, default=50.0, help="weak/sites: contig per GPU; strong: the whole contig")
     ap.add_argument("--sites", type=int, default=100000, help="--mode sites: lines of the site list (all ranks together)")
     ap.add_argument("--cpu-sample-mbp", type=float, default=8.0, help="prefix timed with the 1-thread CPU oracle and used for validation (0 = skip)")
@@ -175,7 +175,7 @@ def main():
         raise SystemExit("--mode strong with %d rank(s) puts %.1f Mbp of 200x data (%.0f M reads) on one GPU: use --gpus 4 / 8, a smaller --contig-mbp "
                          "(6.25 = the per-GPU shape of BASELINE config 5), or --allow-large" % (world, contig_len / 1e6, contig_len * 200 / 150 / 1e6))
     t0 = time.time()
-    ref, arrs = synthgen.generate_dense(contig_len, config, seed=1 + 1000 * rank) if config in ("ont", "ont_ul") else synthgen.generate(contig_len, config, seed=1 + 1000 * rank)
+    ref, arrs = synthgen.generate_dense(contig_len, config, seed=1 + 1000 * rank) if config in synthgen.DENSE else synthgen.generate(contig_len, config, seed=1 + 1000 * rank)
     t_gen = time.time() - t0
     # The oracle processes of the whole-region validation are forked HERE — before this process touches the GPU (a process
     # that has initialised the HIP runtime must not fork); they inherit the reads and sleep until the timed region is over.
@@ -650,6 +650,8 @@ def main():
             what = "synthetic 30x, NovaSeq-like reads (151 bp; quality bins 2 / 12 / 23 / 37; 25 %% adapter-trimmed to U[35,150]; 10 %% soft-clipped; 8 %% duplicates, 1 %% secondary, 1 %% supplementary; 5 %% MAPQ 0), 1 contig %.0f Mbp per GPU, -q20 -b13 — not one of BASELINE's configurations" % (contig_len / 1e6)
         if config == "long10k":
             what = "synthetic 30x, 10-kb reads (30 %% with an insertion, 30 %% with a deletion), 1 contig %.0f Mbp per GPU, -q20 -b13 — not one of BASELINE's configurations" % (contig_len / 1e6)
+        if config == "hifi_eqx":
+            what = "synthetic 30x, 10-20-kb reads aligned with --eqx (match runs as = and X, no M operator; an insertion or a deletion every ~150 bases, a substitution every ~300: %.0f CIGAR operators per read; HiFi / pbmm2-like), 1 contig %.0f Mbp per GPU, -q20 -b13 — not one of BASELINE's configurations" % (float(arrs["n_cigar"].mean()), contig_len / 1e6)
         if config in ("ont", "ont_ul"):
             what = "synthetic 30x, %s reads with an insertion or a deletion every ~15 bases (%.0f CIGAR operators per read; ONT / CLR-like), 1 contig %.0f Mbp per GPU, -q20 -b13 — not one of BASELINE's configurations" % ("3-10-kb" if config == "ont" else "30-100-kb", float(arrs["n_cigar"].mean()), contig_len / 1e6)
         if config == "tumor200x" and args.mode == "weak":

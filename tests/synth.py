@@ -351,3 +351,34 @@ def inject_empty_mops(arrs, seed=0, frac=0.5):
     out = {k: v.copy() for k, v in arrs.items()}
     out["cigar"] = np.array(new_cig, np.uint32); out["cigar_off"] = new_off; out["n_cigar"] = new_nc
     return out
+
+
+def eqx_cigars(arrs, seed=0, frac=0.8, keep_m=0.3):
+    """Round 6: a copy of a batch in which `frac` of the reads have their M operators cut into runs of = and X (pbmm2 / minimap2 --eqx write
+    such CIGARs) — with probability keep_m a piece stays an M, so that = / X stand BESIDE M operators: fetch_func moves neither of its cursors
+    on = / X (bamreadcount.cpp:133-197) and compares the M operators behind them at lagging offsets, the iterator treats all three alike."""
+    rng = np.random.default_rng(seed)
+    n = len(arrs["pos"])
+    new_cig = []; new_off = np.zeros(n, np.uint64); new_nc = np.zeros(n, np.uint32)
+    for i in range(n):
+        nc = int(arrs["n_cigar"][i]); off = int(arrs["cigar_off"][i])
+        ops = [int(c) for c in arrs["cigar"][off:off + nc]]
+        out = []
+        if rng.random() < frac:
+            for c in ops:
+                op, ln = c & 15, c >> 4
+                if op != 0 or ln < 1:
+                    out.append(c); continue
+                rem = ln
+                while rem > 0:
+                    run = min(rem, int(rng.geometric(0.08)))
+                    o = 0 if rng.random() < keep_m else (7 if rng.random() < 0.85 else 8)
+                    if out and (out[-1] & 15) == o and o != 0: out[-1] += run << 4
+                    else: out.append((run << 4) | o)
+                    rem -= run
+        else:
+            out = ops
+        new_off[i] = len(new_cig); new_nc[i] = len(out); new_cig.extend(out)
+    res = {k: v.copy() for k, v in arrs.items()}
+    res["cigar"] = np.array(new_cig, np.uint32); res["cigar_off"] = new_off; res["n_cigar"] = new_nc
+    return res

@@ -649,6 +649,25 @@ def test_hip_wave_form_annotator_on_reads_with_many_operators(dev_lib, knob_lib,
     assert off == want
 
 
+def test_hip_wave_form_annotator_on_reads_with_eqx_operators(dev_lib, knob_lib, oracle_lib, monkeypatch):
+    """= / X operators (pbmm2, minimap2 --eqx) beside M operators, in reads with many operators: fetch_func moves NEITHER of its cursors on
+    = and X (bamreadcount.cpp:133-197) — the M operators behind them are compared at lagging offsets, pure = / X reads compare nothing —
+    while the pileup iterator treats = and X like M.  Round 6: such reads take the wave form's EQX instantiations (k_annotate_wave<.., true>:
+    the list keeps the annotator's own query offset beside the true one) instead of K1's one-lane walk.  Planes, indel lists, text and
+    device text equal the oracle's; the wave form switched off (serial walk) gives the same bytes.  [sim]: the serial annotator."""
+    for case in (dict(seed=3, opts=dict(min_mapq=10, min_bq=8)), dict(seed=4, opts=dict(insertion_centric=True, per_lib=True), n_libs=3), dict(seed=5, opts=dict(), keep_m=0.0)):
+        ref, arrs, names, regions, nolib = synth.many_ops_inputs(dict(seed=case["seed"], n=300, opts=case["opts"], n_libs=case.get("n_libs", 1)))
+        arrs = synth.eqx_cigars(arrs, seed=case["seed"], frac=0.8, keep_m=case.get("keep_m", 0.3))
+        assert int(((arrs["cigar"] & 15) >= 7).sum()) > 1000
+        want, _ = parity.compare_libs(dev_lib, oracle_lib, arrs, regions, ref=ref, lib_names=names, check_warn=not nolib, **case["opts"])
+        got, _ = parity.run_engine(dev_lib, arrs, regions, ref=ref, lib_names=names, device_text="chrS", **case["opts"])
+        assert got == want
+        monkeypatch.setenv("BRC_WAVE_FORM", "0")
+        off, _ = parity.run_engine(knob_lib, arrs, regions, ref=ref, lib_names=names, **case["opts"])
+        monkeypatch.delenv("BRC_WAVE_FORM")
+        assert off == want
+
+
 def test_hip_wave_form_operator_count_limits(dev_lib, oracle_lib):
     """The wave form holds the M operators of a read in LDS: up to 1024 with four waves per workgroup, up to 5120 with one (reads of
     ~80 kb with a match run of ~15 bases between operators), up to 13 500 with one wave per CU (158 of the CU's 160 KB: ~210 kb); a read

@@ -36,6 +36,9 @@ typedef struct {
      * multimappers with MAPQ 0.  All 0: the records the other models always had (and no extra draw). */
     int32_t qual_bins;
     double p_dup, p_sec, p_supp, p_mapq0;
+    /* synth_reads_dense: eqx != 0 -> the M operators are written as runs of = and X (pbmm2 / minimap2 --eqx: X where the read's base differs
+     * from the reference's) */
+    int32_t eqx;
 } synth_params;
 
 typedef struct { uint64_t s[4]; } rng_t;
@@ -259,6 +262,27 @@ int synth_reads_dense(const synth_params* P, int32_t len_min, int32_t len_max, d
                     if (aligned[q]) nmv++;
                     q += 1 + (int)floor(log(1.0 - rng_u01(&r)) / lg1mp);
                 }
+            }
+            if (P->eqx) {
+                /* every M operator becomes runs of = (the base equals the reference's) and X (it differs); the row holds cig_stride operators */
+                uint32_t* tmp = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)cig_stride);
+                int no = 0, q = 0; int64_t rq = pos[i]; int full = 0;
+                for (int k = 0; k < ncg && !full; ++k) {
+                    const int op = (int)(cg[k] & 15u), len = (int)(cg[k] >> 4);
+                    if (op != 0) { if (no >= cig_stride - 1) { full = 1; break; } tmp[no++] = cg[k]; if (op == 1 || op == 4) q += len; else if (op == 2) rq += len; continue; }
+                    int j = 0;
+                    while (j < len) {
+                        const int eq = codes[q + j] == code_of(ref[rq + j]);
+                        int e = j + 1;
+                        while (e < len && (codes[q + e] == code_of(ref[rq + e])) == eq) ++e;
+                        if (no >= cig_stride - 1) { full = 1; break; }
+                        tmp[no++] = ((uint32_t)(e - j) << 4) | (eq ? 7u : 8u);
+                        j = e;
+                    }
+                    q += len; rq += len;
+                }
+                if (!full) { for (int k = 0; k < no; ++k) cg[k] = tmp[k]; ncg = no; for (int k = ncg; k < cig_stride && k < ncg + 2; ++k) cg[k] = 0; n_cigar[i] = (uint32_t)ncg; }     /* (a row too short for the runs keeps its M operators) */
+                free(tmp);
             }
             uint8_t* s4 = seq4 + (uint64_t)i * SB;
             for (int j = 0; j + 1 < L; j += 2) s4[j >> 1] = (uint8_t)((codes[j] << 4) | codes[j + 1]);

@@ -13,7 +13,7 @@ class Params(C.Structure):
     _fields_ = [("contig_len", C.c_int64), ("n_reads", C.c_int64), ("read_len", C.c_int32), ("n_libs", C.c_int32),
                 ("seed", C.c_uint64), ("p_sub", C.c_double), ("p_clip", C.c_double), ("p_ins", C.c_double), ("p_del", C.c_double),
                 ("indel_max", C.c_int32), ("n_chunks", C.c_int32), ("p_trim", C.c_double), ("p_long", C.c_double), ("trim_min", C.c_int32), ("long_len", C.c_int32),
-                ("qual_bins", C.c_int32), ("p_dup", C.c_double), ("p_sec", C.c_double), ("p_supp", C.c_double), ("p_mapq0", C.c_double)]
+                ("qual_bins", C.c_int32), ("p_dup", C.c_double), ("p_sec", C.c_double), ("p_supp", C.c_double), ("p_mapq0", C.c_double), ("eqx", C.c_int32)]
 
 
 def build():
@@ -150,7 +150,7 @@ def generate(contig_len, config="wgs30x", seed=1, n_chunks=64):
              tags=np.empty(n, np.uint8), cigar=np.empty(3 * n, np.uint32), seq4=np.empty(n * ((L + 1) // 2), np.uint8),
              qual=np.empty(n * L, np.uint8))
     p = Params(contig_len, n, cfg["read_len"], cfg["n_libs"], seed + 1, cfg["p_sub"], cfg["p_clip"], cfg["p_ins"], cfg["p_del"], cfg["indel_max"], n_chunks,
-               p_trim, p_long, trim_min, long_len, cfg.get("qual_bins", 0), cfg.get("p_dup", 0.0), cfg.get("p_sec", 0.0), cfg.get("p_supp", 0.0), cfg.get("p_mapq0", 0.0))
+               p_trim, p_long, trim_min, long_len, cfg.get("qual_bins", 0), cfg.get("p_dup", 0.0), cfg.get("p_sec", 0.0), cfg.get("p_supp", 0.0), cfg.get("p_mapq0", 0.0), 0)
     order = ["pos", "flag", "mapq", "lib", "l_qseq", "n_cigar", "cigar_off", "seq_off", "qual_off", "nm", "sm", "tags", "cigar", "seq4", "qual"]
     rc = lib().synth_reads(C.byref(p), ref.ctypes.data_as(C.c_void_p), *[a[k].ctypes.data_as(C.c_void_p) for k in order])
     if rc != 0:
@@ -161,7 +161,10 @@ def generate(contig_len, config="wgs30x", seed=1, n_chunks=64):
 # reads with an operator every ~15 bases (ONT / CLR-like alignments): 3-10 kb, 30x — the regime the tile compaction exists for
 DENSE = {"ont": dict(depth=30.0, len_min=3000, len_max=10000, op_gap=15.0, indel_max=3, p_sub=0.01, n_libs=1),
          # ultra-long reads: 30-100 kb, 2 000-6 600 M operators each (the wave-form annotator's one-wave-per-workgroup and one-wave-per-CU instantiations)
-         "ont_ul": dict(depth=30.0, len_min=30000, len_max=100000, op_gap=15.0, indel_max=3, p_sub=0.01, n_libs=1)}
+         "ont_ul": dict(depth=30.0, len_min=30000, len_max=100000, op_gap=15.0, indel_max=3, p_sub=0.01, n_libs=1),
+         # HiFi reads aligned with --eqx (pbmm2, minimap2 --eqx; round 6): 10-20 kb, an insertion or a deletion every ~150 bases, a substitution
+         # every ~300, the match runs written as = and X — no M operator at all: fetch_func compares nothing (bamreadcount.cpp:133-197)
+         "hifi_eqx": dict(depth=30.0, len_min=10000, len_max=20000, op_gap=150.0, indel_max=3, p_sub=0.0033, n_libs=1, eqx=1)}
 
 
 def generate_dense(contig_len, config="ont", seed=1, n_chunks=64):
@@ -169,7 +172,7 @@ def generate_dense(contig_len, config="ont", seed=1, n_chunks=64):
     cfg = DENSE[config]
     lmin, lmax = cfg["len_min"], cfg["len_max"]
     n = int(round(contig_len * cfg["depth"] / ((lmin + lmax) / 2.0)))
-    stride = int(2.5 * lmax / cfg["op_gap"]) + 16
+    stride = int(2.5 * lmax / cfg["op_gap"]) + 16 + (int(4.0 * cfg["p_sub"] * lmax) + 64 if cfg.get("eqx") else 0)
     ref = np.empty(contig_len, np.uint8)
     lib().synth_ref(ref.ctypes.data_as(C.c_void_p), C.c_int64(contig_len), C.c_uint64(seed))
     a = dict(pos=np.empty(n, np.int32), flag=np.empty(n, np.uint16), mapq=np.empty(n, np.uint8), lib=np.empty(n, np.int16),
@@ -177,7 +180,7 @@ def generate_dense(contig_len, config="ont", seed=1, n_chunks=64):
              seq_off=np.empty(n, np.uint64), qual_off=np.empty(n, np.uint64), nm=np.empty(n, np.int32), sm=np.empty(n, np.int32),
              tags=np.empty(n, np.uint8), cigar=np.zeros(n * stride, np.uint32), seq4=np.empty(n * ((lmax + 1) // 2), np.uint8),
              qual=np.empty(n * lmax, np.uint8))
-    p = Params(contig_len, n, lmax, cfg["n_libs"], seed + 1, cfg["p_sub"], 0.0, 0.0, 0.0, cfg["indel_max"], n_chunks, 0.0, 0.0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0)
+    p = Params(contig_len, n, lmax, cfg["n_libs"], seed + 1, cfg["p_sub"], 0.0, 0.0, 0.0, cfg["indel_max"], n_chunks, 0.0, 0.0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, cfg.get("eqx", 0))
     order = ["pos", "flag", "mapq", "lib", "l_qseq", "n_cigar", "cigar_off", "seq_off", "qual_off", "nm", "sm", "tags", "cigar", "seq4", "qual"]
     L = lib(); L.synth_reads_dense.argtypes = None
     rc = L.synth_reads_dense(C.byref(p), C.c_int32(lmin), C.c_int32(lmax), C.c_double(cfg["op_gap"]), C.c_int32(stride), ref.ctypes.data_as(C.c_void_p),
