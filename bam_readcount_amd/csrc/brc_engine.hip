@@ -2153,7 +2153,7 @@ struct DBuf {
 };
 
 enum { T_ANNOTATE = 0, T_SCAN_ENDS, T_TILES, T_PILEUP, T_COUNT, T_INDEL_SCAN, T_INDEL_FILL, T_INDEL_REDUCE, T_N };
-static const char* kKernelNames[BRC_NKERNEL] = {"k_annotate", "k_scan_ends", "k_tiles", "k_pileup", "k_finalize",
+static const char* kKernelNames[BRC_NKERNEL] = {"k_annotate", "k_scan_ends", "k_tiles", "k_pileup", "k_xev_fold+finalize",
                                                 "k_scan_indel", "k_indel_fill", "k_indel_reduce"};
 
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { return hip_fail(_e, #x); } } while (0)
@@ -2652,8 +2652,11 @@ class HipBackend : public Backend {
             if (has_wanted) { if (n_listed > 0) { if (c.pack_shift == 16) BRC_LAUNCH_KP(true, 16); else BRC_LAUNCH_KP(true, 12); } }
             else { if (c.pack_shift == 16) BRC_LAUNCH_KP(false, 16); else BRC_LAUNCH_KP(false, 12); }
 #undef BRC_LAUNCH_KP
+        }
+        HIPCHK(hipEventRecord(evt[T_COUNT], stream));      // (the k_pileup slot is k_pileup2 alone: what rocprofv3's average for the kernel must agree with)
+        if (ntiles > 0) {
             // third-allele events: one list, then their fold per (position, library, bucket) in column order — the rest of
-            // BasicStat::process_read's accumulation (the host did this until round 6)
+            // BasicStat::process_read's accumulation (the host did this until round 6); timed with the counters below
             const int64_t nxb = ntiles * Lp;
             HIPCHK(hipMemsetAsync(d_xcnt.p, 0, (size_t)nxb * 4, stream));
             hipLaunchKernelGGL(k_xev_compact, dim3((unsigned)XEV_SHARDS), dim3(256), 0, stream, (const XEv*)d_xev.p, (const uint32_t*)d_xevn.p, (uint32_t)xev_cap,
@@ -2663,7 +2666,6 @@ class HipBackend : public Backend {
             hipLaunchKernelGGL(k_xev_fold, dim3((unsigned)std::min<int64_t>((nxb + 255) / 256, 2048)), dim3(256), 0, stream, (const XEv*)d_xevc.p, (uint32_t*)d_xcnt.p, (uint32_t*)d_xend.p, nxb,
                                (uint32_t*)d_xidx.p, (XAgg*)d_xagg.p);
         }
-        HIPCHK(hipEventRecord(evt[T_COUNT], stream));
         if (P > 0) {
             const unsigned nb = (unsigned)std::min<int64_t>(((Lp > 1 ? P / 4 : ntiles) + 255) / 256 + 1, Lp > 1 ? 4096 : 256);
             hipLaunchKernelGGL(k_finalize, dim3(nb), dim3(256), 0, stream, c, (const uint32_t*)d_ncol.p, (const uint4*)d_tilectr.p, (int64_t)ntiles * Lp,

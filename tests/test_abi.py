@@ -203,3 +203,19 @@ def test_isa_checker_follows_every_path():
     # ... a path that never waits
     n, errs = errors(sound.replace("	;;#ASMSTART\n	s_waitcnt lgkmcnt(0)\n	;;#ASMEND\n", ""))
     assert any("s_endpgm" in e or "touched" in e for e in errs)
+
+
+def test_committed_pmc_passes_belong_to_the_built_kernels():
+    """bench.py reports the counters of profiles/r06_traffic.json / r06_pmc_summary.json (separate rocprofv3 --pmc passes) only when they
+    were measured on the kernel object the loaded library carries (capi.kernel_object_hash: sha256 of its .hip_fatbin section).  A kernel
+    edit without new passes would make the bench line drop its traffic fields: this test says so at commit time."""
+    import json
+    from bam_readcount_amd import capi
+    kobj = capi.kernel_object_hash()
+    assert kobj and len(kobj) == 16
+    assert capi.kernel_object_hash(os.path.join(ROOT, "bam_readcount_amd", "csrc", "libbrc_hip_testknobs.so")) == kobj      # the same objects
+    assert capi.kernel_object_hash(os.path.join(ROOT, "oracle", "libbrc_oracle.so")) is None
+    for name in ("r06_traffic.json", "r06_pmc_summary.json"):
+        j = json.load(open(os.path.join(ROOT, "profiles", name)))
+        for cfg in ("wgs30x", "tumor200x"):
+            assert j[cfg]["kernel_object_sha256_16"] == kobj, "%s [%s] was measured on kernel object %s, the build is %s: repeat tools/gpu_r6_profile.sh" % (name, cfg, j[cfg]["kernel_object_sha256_16"], kobj)
