@@ -889,6 +889,7 @@ static void crash_handler(int sig) {
 #include <sys/sendfile.h>
 #include <sys/wait.h>
 #include <sched.h>
+#include <poll.h>
 
 static bool parse_rank_of(const std::string& v, int* r, int* n) {
     const size_t c = v.find(':');
@@ -977,13 +978,34 @@ static int coordinate(int argc, char** argv, const Options& o, int N) {
     std::vector<double> secs((size_t)N, 0.0); std::vector<double> done_at((size_t)N, 0.0);
     std::vector<char> buf((size_t)1 << 20);
     const bool timing = getenv("BRC_CLI_TIMING") != nullptr;
+    // A rank is DONE when it has written its last word to the status pipe (it flushes its text and its stderr first) — or when the pipe
+    // closes without one (it died).  The process itself may take a good while longer to disappear: a rank that printed gigabytes holds as
+    // many gigabytes of page-locked buffers, which the kernel unpins at exit (0.5-0.7 s for BASELINE config 5's share) — nothing this run has
+    // to wait for: the coordinator goes on to the next rank's text, and leaves when the last rank is done.
+    std::vector<std::string> status_line((size_t)N); std::vector<bool> status_eof((size_t)N, false);
+    auto poll_status = [&](int r, int timeout_ms) -> bool {         // true: rank r has said its last word (or will never)
+        Child& c = ch[(size_t)r];
+        if (status_eof[(size_t)r]) return true;
+        for (;;) {
+            struct pollfd pf; pf.fd = c.status; pf.events = POLLIN; pf.revents = 0;
+            const int pr = poll(&pf, 1, timeout_ms);
+            if (pr < 0 && errno == EINTR) continue;
+            if (pr <= 0) return false;
+            char b[256]; const ssize_t g = read(c.status, b, sizeof b);
+            if (g < 0 && (errno == EINTR || errno == EAGAIN)) continue;
+            if (g <= 0) { status_eof[(size_t)r] = true; return true; }
+            status_line[(size_t)r].append(b, (size_t)g);
+            if (status_line[(size_t)r].find('\n') != std::string::npos) { status_eof[(size_t)r] = true; return true; }
+            timeout_ms = 0;
+        }
+    };
     for (int r = 0; r < N && !ret; ++r) {
         Child& c = ch[(size_t)r];
         if (r > 0 && c.out >= 0) {
             // follow the rank's text: copy what is there, look whether the rank is done, copy the rest
             off_t off = 0; bool use_sendfile = true;
             for (;;) {
-                const bool finished = reap(c, false);
+                const bool finished = poll_status(r, 0);
                 struct stat fs; if (fstat(c.out, &fs) != 0) break;
                 bool moved = false;
                 while (off < fs.st_size) {
@@ -998,19 +1020,18 @@ static int coordinate(int argc, char** argv, const Options& o, int N) {
                     moved = true;
                 }
                 if (finished) { struct stat f2; if (fstat(c.out, &f2) == 0 && f2.st_size > off) continue; break; }
-                if (!moved) usleep(500);
+                if (!moved) poll_status(r, 1);
             }
         }
-        reap(c, true);
+        while (!poll_status(r, 1000)) {}
         done_at[(size_t)r] = now_s() - t0;
         // what the rank said when it ended: exit code, ReadWarnings' counters (rank 0 printed its own warnings), seconds
-        int rc = WIFEXITED(c.wstatus) ? WEXITSTATUS(c.wstatus) : 1;
+        int rc = 0;
         {
-            std::string sline; char b[256]; ssize_t g;
-            while ((g = read(c.status, b, sizeof b)) > 0 || (g < 0 && errno == EINTR)) if (g > 0) sline.append(b, (size_t)g);
+            const std::string& sline = status_line[(size_t)r];
             long long w[BRC_N_WARN] = {0, 0, 0, 0}; int src = 1; double s = 0;
-            if (sscanf(sline.c_str(), "%d %lld %lld %lld %lld %lf", &src, &w[0], &w[1], &w[2], &w[3], &s) == 6) { secs[(size_t)r] = s; if (r == 0) for (int k = 0; k < BRC_N_WARN; ++k) gcount[k] = w[k]; if (src && !rc) rc = src; }
-            else if (!rc) rc = 1;           // (a rank that ended without a word did not end well)
+            if (sscanf(sline.c_str(), "%d %lld %lld %lld %lld %lf", &src, &w[0], &w[1], &w[2], &w[3], &s) == 6) { secs[(size_t)r] = s; if (r == 0) for (int k = 0; k < BRC_N_WARN; ++k) gcount[k] = w[k]; rc = src; }
+            else { reap(c, true); rc = WIFEXITED(c.wstatus) && WEXITSTATUS(c.wstatus) ? WEXITSTATUS(c.wstatus) : 1; }           // (a rank that ended without a word did not end well: wait for it, say how it went)
         }
         if (r > 0) {
             // its stderr, in order: plain lines as they are, tagged warning events through the run's counters
@@ -1024,12 +1045,12 @@ static int coordinate(int argc, char** argv, const Options& o, int N) {
                 i = j + 1;
             }
         }
-        if (rc) ret = WIFSIGNALED(c.wstatus) ? 1 : (rc == 127 ? 1 : rc);
-        if (WIFSIGNALED(c.wstatus)) fprintf(stderr, "bam-readcount: rank %d ended on signal %d\n", r, WTERMSIG(c.wstatus));
+        if (rc) ret = rc == 127 ? 1 : rc;
+        if (c.reaped && WIFSIGNALED(c.wstatus)) { ret = 1; fprintf(stderr, "bam-readcount: rank %d ended on signal %d\n", r, WTERMSIG(c.wstatus)); }
     }
-    // a failed run: the ranks behind the failure are stopped, their text is dropped
-    for (Child& c : ch) if (!c.reaped) { kill(c.pid, SIGTERM); }
-    for (Child& c : ch) reap(c, true);
+    // a failed run: the ranks behind the failure are stopped, their text is dropped.  (Ranks that are done are not waited for: see above.)
+    if (ret) { for (int r = 0; r < N; ++r) if (!ch[(size_t)r].reaped && !status_eof[(size_t)r]) kill(ch[(size_t)r].pid, SIGTERM); }
+    for (Child& c : ch) reap(c, false);
     if (timing) {
         fprintf(stderr, "ranks: %d processes", N);
         for (int r = 0; r < N; ++r) fprintf(stderr, "%s rank %d: %.3f s (its text was out after %.3f s)", r ? ";" : ":", r, secs[(size_t)r], done_at[(size_t)r]);
@@ -1412,6 +1433,9 @@ int main(int argc, char** argv) {
     // the exit of a process that is done: leave them to the operating system (BRC_CLEAN_EXIT=1 keeps the orderly path).
     fflush(stdout); fflush(stderr);
     leave(ret);
+    // (a rank: whoever reads the run's stdout / stderr through a pipe sees its end when the last holder lets go — now, not when the kernel has
+    // unpinned this process's gigabytes)
+    if (my_rank >= 0 && !clean_exit) { close(1); close(2); }
     if (!clean_exit) _exit(ret);
     if (wait_engine()) brc_destroy(c.eng);
     return ret;

@@ -198,12 +198,18 @@ void brc_destroy(brc_engine*);
 #define BRC_OPT_EXPECT_READS 2
 #define BRC_OPT_EXPECT_BASES 3
 /*   BRC_OPT_DEVICE_TEXT  1 (with BRC_OPT_TEXT_ONLY and a column-1 name set by brc_set_chrom): the lines of the following regions
- *                      are written on the GPU from the compact result and downloaded as text; brc_fetch_result downloads
- *                      no planes at all (brc_result.ncol / depth / istat / fstat / refbase are NULL), brc_format_region[_parts]
- *                      only rewrites the few lines the device cannot finish (indel buckets, deletions queued for pos+1,
- *                      buckets of a third base).  Such a result must be formatted, and the returned text consumed, before
- *                      the next brc_fetch_result of this engine; brc_format_window needs planes and refuses it.  Regions
- *                      whose text could exceed 4 GiB fall back to the host formatter by themselves. */
+ *                      are written on the GPU and downloaded as text — round 6: the WHOLE lines, indel buckets (in the order of the
+ *                      reference's std::map, :389-401), the deletions the position before queued (IndelQueue.cpp:3-15) and buckets of a
+ *                      third base included.  brc_fetch_result downloads no planes at all (brc_result.ncol / depth / istat / fstat /
+ *                      refbase are NULL) and assembles no indel list (n_indel = 0: the lines carry the entries).  What
+ *                      brc_format_region[_parts] still does is keep the deletion queues across regions: a region that starts from
+ *                      empty queues, or continues the piece before it (BRC_OPT_CONTINUES_PREVIOUS = 1, set before the region is
+ *                      formatted), is printed as it arrived; a region that finds something else pending — a deletion an earlier
+ *                      command-line region left behind, :641-657 — has the deletion entries of its lines rewritten by
+ *                      IndelQueue::process's own rules.  Such a result must be FETCHED after the region before it has been formatted
+ *                      (the threads rule above) and formatted, and the returned text consumed, before the next brc_fetch_result of this
+ *                      engine; brc_format_window needs planes and refuses it.  Regions whose text could exceed 4 GiB fall back to the
+ *                      host formatter by themselves. */
 #define BRC_OPT_DEVICE_TEXT 4
 /*   BRC_OPT_EXPECT_TEXT  bytes of text a coming region will print: the two pinned text buffers are allocated now (this one
  *                      option may be set from another thread while the first region is being staged — pinning hundreds of
