@@ -46,6 +46,7 @@ struct Options {
     std::string site_list, fasta, bam;
     std::vector<std::string> regions;
     long long chunk_bp = 1000000;   // engine-side tiling of long regions (not a reference option): --brc-chunk
+    bool chunk_given = false;       // ... given on the command line (else: sized by the data under a region, run_region: auto_chunk)
     long long plan_sites = 4096;    // site-list planner: -l lines batched per engine pass (0 = one pass per line): --brc-plan
     long long gpus = 1;             // GPUs: --brc-gpus
     long long streams = 0;          // engines per GPU (0: one; every engine already overlaps decode | GPU | format of consecutive pieces): --brc-streams
@@ -116,7 +117,7 @@ static bool apply(Options& o, const OptSpec& sp, const std::string& v, std::stri
         case 4: if (!to_ll(&x)) return false; o.ranks = x; return true;
         case 5: o.rank_of = v; return true;
         case 6: o.tmpdir = v; return true;
-        default: if (!to_ll(&x)) return false; o.chunk_bp = x; return true;
+        default: if (!to_ll(&x)) return false; o.chunk_bp = x; o.chunk_given = true; return true;
     }
 }
 
@@ -443,6 +444,25 @@ static void fetch_chunk(Ctx& c, int tid, int64_t a, int64_t b, Fetched& out) {
 // one reporting window [beg0,end) on tid: the body of the site-list / region loops (:588-605, :649-656)
 // keep_queue: the first piece keeps the deletions the previous command-line region left pending (like the reference, :641-657)
 // inner_piece: (several engines) this window is a piece of a longer region whose previous piece ran elsewhere
+// The piece a long region is cut into, when the command line does not say (--brc-chunk): by the DATA under it, not by positions — about
+// 26 MB of compressed records (200 000 reads of 150 bases), weighed by the index's file offsets (BamIndex::span_bytes): 1 Mbp of a 30x
+// genome, 125 kb of a 200x tumour.  A piece sizes everything that is page-locked (decode arenas, staging, two text buffers — 1.4 GB per
+// Mbp with four libraries) and the latency of the three-stage pipeline's first piece: BASELINE config 5 end to end went from 1.7 s at the
+// fixed 1 Mbp to 0.93 s at 125 kb on the same box (profiles/r06_e2e_tumor_chunk_sweep.log), a third of it process exit (the kernel unpins
+// what was pinned).  Multiples of 64 kb; never above the 1 Mbp that suits shallow data.
+static int64_t auto_chunk(const Ctx& c, int tid, int64_t beg0, int64_t end) {
+    const int64_t max_chunk = (int64_t)c.opt.chunk_bp;
+    if (c.opt.chunk_given || c.is_cram || end - beg0 < 2 * 65536 || c.opt.max_cnt < 1000000) return max_chunk;
+    static const double target = getenv("BRC_CHUNK_BYTES") && atof(getenv("BRC_CHUNK_BYTES")) > 0 ? atof(getenv("BRC_CHUNK_BYTES")) : 26.0e6;
+    const double bytes = c.idx.span_bytes(tid, beg0, end);
+    if (bytes <= 0) return max_chunk;
+    const double per_bp = bytes / (double)(end - beg0);
+    int64_t ch = (int64_t)(target / per_bp);
+    ch = ((ch + 65535) / 65536) * 65536;
+    if (ch < 65536) ch = 65536;
+    return ch < max_chunk ? ch : max_chunk;
+}
+
 static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode, bool keep_queue = true, bool inner_piece = false) {
     const BamHeader& h = c.header();
     if (c.have_fa && tid != c.ref_tid) {
@@ -455,7 +475,7 @@ static int run_region(Ctx& c, int tid, int64_t beg0, int64_t end, bool site_mode
     // long regions are cut into abutting pieces; each piece fetches one base early exactly like the reference (:602).
     // The next `ahead` pieces are fetched and decoded in the background (each by its own pool of striped BAM handles)
     // while the current one is on the GPU / being formatted: decoding is the slowest of the three stages.
-    const int64_t chunk = (int64_t)c.opt.chunk_bp;
+    const int64_t chunk = auto_chunk(c, tid, beg0, end);
     const int64_t npieces = std::max<int64_t>(1, (end - beg0 + chunk - 1) / chunk);
     static const int ahead_env = getenv("BRC_FETCH_AHEAD") ? atoi(getenv("BRC_FETCH_AHEAD")) : 0;
     const int ahead = ahead_env > 0 ? ahead_env : 2;
@@ -1286,6 +1306,7 @@ int main(int argc, char** argv) {
     if (items.size() < N) N = std::max<size_t>(items.size(), 1);      // engines without work are never created
     if (N > 1) {    // the engines share this process's CPUs: each gets its part of the decode and formatter pools
         g_engines = (unsigned)N;
+        c.opt.chunk_given = true;        // (the items ARE the pieces here: one brc_format_region per item, whose text stays in its engine's buffer)
         // (told to every engine with BRC_OPT_FORMAT_THREADS in make_engine — never through setenv(): the engine-creation
         // threads are inside the HIP runtime by now, which reads the environment while it starts, and getenv() racing a
         // setenv() that reallocates `environ` was a rare SIGSEGV before the first line of output)
@@ -1300,7 +1321,7 @@ int main(int argc, char** argv) {
     // pin the text buffers of a long region's pieces while the first reads are being decoded
     std::thread pin_ahead;
     {
-        int64_t widest = 0; for (const Work& w : items) if (w.kind == 0) widest = std::max<int64_t>(widest, std::min<int64_t>(w.end - w.beg0, (int64_t)c.opt.chunk_bp));
+        int64_t widest = 0; for (const Work& w : items) if (w.kind == 0) widest = std::max<int64_t>(widest, std::min<int64_t>(w.end - w.beg0, auto_chunk(c, w.tid, w.beg0, w.end)));
         const bool dev_text = !(getenv("BRC_DEVICE_TEXT") && atoi(getenv("BRC_DEVICE_TEXT")) == 0);
         if (dev_text && widest >= 100000 && !(getenv("BRC_PIN_AHEAD") && atoi(getenv("BRC_PIN_AHEAD")) == 0)) {
             const int64_t bytes = widest * (int64_t)(o.per_lib ? std::max<size_t>(c.libs.size(), 1) : 1) * 400;
