@@ -328,25 +328,60 @@ def operator_limit_reads():
     return ref, a
 
 
+def cursor_columns(pos, ops):
+    """htslib's resolve_cigar2 as the iterator runs it (a cursor per read, moved by ONE reference-consuming operator when the column has left
+    the current one): per column of [pos, bam_endpos) None (not in the column), ("M", qpos) or ("D", qpos).  ops: [(op, len)].  Test-side
+    restatement of brc_core.h: cursor_resolve, used to keep generated CIGARs inside the reads they belong to."""
+    n = len(ops); k = -1; x = pos; y = 0; out = []
+    refop = (0, 2, 3, 7, 8); mop = (0, 7, 8)
+    def skip(kk, yy):
+        while kk < n:
+            o, l = ops[kk]
+            if o in refop: break
+            if o in (1, 4): yy += l
+            kk += 1
+        return kk, yy
+    rlen = sum(l for o, l in ops if o in refop)
+    for col in range(pos, pos + rlen):
+        if k == -1:
+            if n == 1:
+                if ops[0][0] in mop: k, x, y = 0, pos, 0
+            else:
+                x, y = pos, 0; k, y = skip(0, 0)
+            if k < 0 or k >= n: out.append(None); continue
+        else:
+            l = ops[k][1]
+            if col - x >= l:
+                if k + 1 >= n: out.append(None); continue
+                if ops[k][0] in mop: y += l
+                x += l
+                k, y = skip(k + 1, y)
+                if k >= n: out.append(None); continue
+        o, l = ops[k]
+        out.append(("M", y + (col - x)) if o in mop else ("D", y))
+    return out
+
+
 def inject_empty_mops(arrs, seed=0, frac=0.5):
     """Round 6: a copy of a batch in which `frac` of the mapped reads with a CIGAR get one to three M / = / X operators of LENGTH ZERO at
-    random places (in front of a deletion, behind one, between two matches, as the first operator, ...) — htslib's cursor steps onto such an
-    operator for one column (brc_core.h: cursor_resolve).  Never as the last reference-consuming operator behind the read's last base (the
-    reference reads past the read's qualities there: the engine refuses that one case)."""
+    random places (in front of a deletion, behind one, between two matches, as the first operator, several in a row, ...) — htslib's cursor
+    steps onto such an operator for one column (brc_core.h: cursor_resolve).  Only sets of empty operators whose columns stay inside the
+    read's bases are kept (an empty operator reported at or past query offset l_qseq makes the reference read past the read's qualities:
+    the engine refuses that case, tests/test_sim_parity.py)."""
     rng = np.random.default_rng(seed)
     n = len(arrs["pos"])
     new_cig = []; new_off = np.zeros(n, np.uint64); new_nc = np.zeros(n, np.uint32)
     for i in range(n):
         nc = int(arrs["n_cigar"][i]); off = int(arrs["cigar_off"][i])
         ops = [int(c) for c in arrs["cigar"][off:off + nc]]
-        if nc > 0 and not (int(arrs["flag"][i]) & 4) and rng.random() < frac:
-            # (positions in front of the last query-consuming match: the cursor never reports an empty operator at query offset l_qseq)
-            qcons = [k for k, c in enumerate(ops) if (c & 15) in (0, 7, 8) and (c >> 4) > 0]
-            if qcons:
+        if nc > 0 and not (int(arrs["flag"][i]) & 4) and int(arrs["l_qseq"][i]) > 0 and rng.random() < frac:
+            for _ in range(4):                                   # (a few tries per read)
+                cand = list(ops)
                 for _ in range(int(rng.integers(1, 4))):
-                    at = int(rng.integers(0, qcons[-1] + 1))
-                    ops.insert(at, int(rng.choice([0, 0, 7, 8])))            # length zero: the operator code alone
-                    qcons = [k for k, c in enumerate(ops) if (c & 15) in (0, 7, 8) and (c >> 4) > 0]
+                    cand.insert(int(rng.integers(0, len(cand) + 1)), int(rng.choice([0, 0, 7, 8])))      # length zero: the operator code alone
+                cols = cursor_columns(int(arrs["pos"][i]), [(c & 15, c >> 4) for c in cand])
+                if all(c is None or c[1] < int(arrs["l_qseq"][i]) for c in cols):
+                    ops = cand; break
         new_off[i] = len(new_cig); new_nc[i] = len(ops); new_cig.extend(ops)
     out = {k: v.copy() for k, v in arrs.items()}
     out["cigar"] = np.array(new_cig, np.uint32); out["cigar_off"] = new_off; out["n_cigar"] = new_nc

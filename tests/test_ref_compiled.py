@@ -611,6 +611,14 @@ def random_scenario(seed, big=False):
     if per_lib:
         kw.update(per_lib=True, lib_names=["lib%c" % (65 + i) for i in range(n_libs)])
     clear = bool(rng.random() < 0.5)
+    # round 6, a random stream of its own (the scenarios of the seeds above stay what they were): = / X operators beside M, and M / = / X
+    # operators of length zero (the iterator's cursor), on some scenarios
+    rng2 = np.random.default_rng(seed + 555555)
+    u = rng2.random()
+    if u < 0.15:
+        arrs = synth.eqx_cigars(arrs, seed=seed, frac=0.7, keep_m=float(rng2.choice([0.0, 0.3])))
+    elif u < 0.27:
+        arrs = synth.inject_empty_mops(arrs, seed=seed, frac=0.5)
     return ref, arrs, regions, kw, clear, style
 
 

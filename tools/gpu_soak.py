@@ -5,7 +5,6 @@ indel buckets / warning counters against the oracle.  Prints one line per failur
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
-os.environ.setdefault("BRC_DEVICE_TEXT_MAX_SHARE", "100")
 import numpy as np
 from bam_readcount_amd import capi
 import parity
