@@ -132,6 +132,7 @@ def main():
                     "destroy — so that the first time RCCL sees this code is not an 8-GPU run (tests/test_bench_dist_gpu.py)")
     ap.add_argument("--rank-check-mbp", type=float, default=1.5, help="every rank validates this prefix of ITS OWN interval against the oracle after the timed region (an N-rank run, or --force-dist; "
                     "sites mode: 100 of the rank's own sites); 0 = skip")
+    ap.add_argument("--e2e-tumor-mbp", type=float, default=0.0, help="e2e_tumor: the region's contig (0: 6.25 Mbp per rank, at most 25)")
     ap.add_argument("--dry-run-lib", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--as-rank", type=int, default=None, help=argparse.SUPPRESS)     # with --as-world: one rank's share, without a launcher
     ap.add_argument("--as-world", type=int, default=None, help=argparse.SUPPRESS)
@@ -186,19 +187,25 @@ def main():
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
         pool = fullcheck.OraclePool(max(nworkers, 1), ref, arrs, names, opts, capi)
 
+    # test infrastructure (tests/test_dist_gpu.py): BRC_BENCH_SHARE_GPU0=1 puts EVERY rank's engine on GPU 0 and the process group on gloo —
+    # a real N > 1 run of this script (both all-reduces, the gathers, every rank's own validation, the e2e_sharded legs with one process
+    # per rank) on a box with one GPU; RCCL itself refuses two ranks on one device, and is covered at world 1 (--force-dist).  The line says so.
+    share_gpu0 = os.environ.get("BRC_BENCH_SHARE_GPU0") == "1" and not dry
+    if share_gpu0:
+        local_rank = 0
     if not dry:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
         torch.cuda.set_device(local_rank)
     dist = None
-    tdev = "cpu" if dry else "cuda"
+    tdev = "cpu" if (dry or share_gpu0) else "cuda"
     if (world > 1 or args.force_dist) and not emulated:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "RANK" not in os.environ:                  # --force-dist without a launcher: a group of one
             s = socket.socket(); s.bind(("127.0.0.1", 0)); os.environ.setdefault("MASTER_PORT", str(s.getsockname()[1])); s.close()
             os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local_rank))
-        if dry:
+        if dry or share_gpu0:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
@@ -628,7 +635,7 @@ def main():
             tool = os.path.join(ROOT, "tools", "e2e_configs.py")
             # the drop-in as N processes, one per GPU (cli.cpp: --brc-ranks): on a one-GPU run two ranks share GPU 0 (what separate
             # processes do to the host-bound command line); on an N-GPU run rank r owns GPU r — strong scaling of configs 4 and 5 end to end
-            rk = ["--ranks", str(world), "--rank-devices", ",".join(str(i) for i in range(world))] if world > 1 else ["--ranks", "2", "--rank-devices", "0,0"]
+            rk = ["--ranks", str(world), "--rank-devices", ",".join("0" if share_gpu0 else str(i) for i in range(world))] if world > 1 else ["--ranks", "2", "--rank-devices", "0,0"]
             def e2e_leg(extra):
                 try:
                     out = subprocess.run([sys.executable, tool] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
@@ -638,7 +645,7 @@ def main():
                 except Exception as ex:                                  # noqa: BLE001 — reported, never hidden
                     return {"error": "%s: %s" % (type(ex).__name__, ex)}
             e2e_sites = e2e_leg(["--leg", "sites", "--contigs", "8", "--contig-mbp", str(args.e2e_sites_mbp), "--check-lines", "1000"] + rk)
-            e2e_tumor = e2e_leg(["--leg", "tumor", "--contig-mbp", str(6.25 * min(world, 4)), "--check-mbp", "1.0"] + rk)
+            e2e_tumor = e2e_leg(["--leg", "tumor", "--contig-mbp", str(args.e2e_tumor_mbp if args.e2e_tumor_mbp > 0 else 6.25 * min(world, 4)), "--check-mbp", str(min(1.0, args.e2e_tumor_mbp / 4) if args.e2e_tumor_mbp > 0 else 1.0)] + rk)
             e2e_sharded = {"sites": e2e_sites.pop("sharded", None) if isinstance(e2e_sites, dict) else None, "tumor": e2e_tumor.pop("sharded", None) if isinstance(e2e_tumor, dict) else None}
         what = {"weak": "synthetic 30x WGS, 150bp reads, 1 contig %.0f Mbp per GPU, -q20 -b13" % (contig_len / 1e6),
                 "strong": "synthetic 200x tumor 4 libraries, 150bp reads, -p -i, 1 contig %.0f Mbp cut into %d intervals" % (total_len / 1e6, world),
@@ -662,7 +669,7 @@ def main():
         line = {
             "metric": "pileup base-events/sec", "value": round(value, 1), "unit": "events/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak" if args.mode == "weak" else "strong", "vs_baseline": None, "dtype": "u32+f32", "data": "synthetic",
+            "scaling": "weak" if args.mode == "weak" else "strong", "vs_baseline": None, "dtype": "u32+f32", "data": "synthetic" + (" (TEST RUN: every rank on GPU 0, process group on gloo — BRC_BENCH_SHARE_GPU0)" if share_gpu0 else ""),
             "config": {"workload": what, "mode": args.mode, "reads_per_gpu": int(len(region_reads["pos"])), "piece_steps": piece_steps,
                        "events_per_step": int(ev_total), "positions_per_step": int(pos_total), "parallelism": "interval-shard x%d" % world},
             "positions_per_s": round(pos_total * args.steps / tmax, 1),

@@ -84,3 +84,23 @@ def test_run_sharded_and_gather_text_on_rccl_world1(tmp_path):
     assert run.returncode == 0, run.stderr.decode()[-3000:]
     got = open(out).read().split()
     assert got[0] == "ok" and int(got[1]) > 0 and int(got[2]) > 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_run_the_whole_n_rank_flow():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, two ranks), on the ONE GPU of a test box: BRC_BENCH_SHARE_GPU0=1
+    puts both engines on GPU 0 and the process group on gloo (RCCL refuses two ranks on one device; it is covered at world 1 above).
+    Everything else is the N > 1 run: max-over-ranks clock, summed counters, per-rank table, every rank validating its own interval, and —
+    round 6 — rank 0's e2e_sharded legs: configs 4 and 5 through `bam-readcount --brc-ranks 2`, whole output byte-identical to one process."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BRC_BENCH_SHARE_GPU0="1")
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "weak", "--contig-mbp", "2", "--steps", "3", "--warmup", "1", "--cpu-sample-mbp", "0", "--e2e-mbp", "0",
+                          "--abi-mbp", "0", "--other-configs", "0", "--e2e-configs", "1", "--e2e-sites-mbp", "1", "--e2e-tumor-mbp", "0.4"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=1500)
+    assert run.returncode == 0, run.stderr.decode()[-3000:]
+    line = json.loads([l for l in run.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and len(line["per_rank"]) == 2 and line["validated"]["all_ranks_ok"] is True
+    assert line["config"]["events_per_step"] == sum(p["events"] for p in line["per_rank"]) and all(p["validated_ok"] for p in line["per_rank"])
+    sh = line["e2e_sharded"]
+    for leg in ("sites", "tumor"):
+        assert sh[leg] is not None and sh[leg]["ranks"] == 2 and sh[leg]["whole_output_byte_identical_to_one_process"] and len(sh[leg]["per_rank"]) == 2, (leg, line.get("e2e_" + leg))
