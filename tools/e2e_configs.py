@@ -209,6 +209,8 @@ def leg_sites(args, d):
     # ---- the reference's own main() on blocks of consecutive lines spread over the list
     blk = 25; nblk = max(1, -(-args.check_lines // blk)); starts = np.unique(np.linspace(0, max(len(lines) - blk, 0), nblk).astype(int))
     sub = [lines[i] for s in starts for i in range(s, min(s + blk, len(lines)))]
+    if nblk * blk >= len(lines):
+        sub = list(lines)                      # (a list shorter than what is asked for: all of it — overlapping blocks would repeat lines out of order)
     nproc = max(1, min(args.procs, len(sub) // 20 + 1)); parts = [sub[i * len(sub) // nproc:(i + 1) * len(sub) // nproc] for i in range(nproc)]
     for i, part in enumerate(parts):
         open(os.path.join(d, "sub%d" % i), "w").write("".join("%s\t%d\t%d\n" % (contigs[t][0], b, e) for t, b, e in part))
