@@ -671,7 +671,8 @@ def test_hip_wave_form_annotator_on_reads_with_eqx_operators(dev_lib, knob_lib, 
 def test_hip_wave_form_operator_count_limits(dev_lib, oracle_lib):
     """The wave form holds the M operators of a read in LDS: up to 1024 with four waves per workgroup, up to 5120 with one (reads of
     ~80 kb with a match run of ~15 bases between operators), up to 13 500 with one wave per CU (158 of the CU's 160 KB: ~210 kb); a read
-    with more, and reads with P, = or X operators, keep K1's serial walk — side by side in one region, all equal to the oracle.
+    with more, and reads with P operators, keep K1's serial walk (= / X: the EQX instantiations, round 6) — side by side in one region, all
+    equal to the oracle.
     [sim]: the serial walk."""
     ref, arrs = synth.operator_limit_reads()
     for opts in (dict(), dict(insertion_centric=True, min_bq=10)):
