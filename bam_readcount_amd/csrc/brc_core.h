@@ -163,8 +163,13 @@ struct DevIn {
     // reference base says "the reference base's bucket".  Read i's row starts at element bq_row[i] (rows are padded to multiples
     // of 16 elements so every row is 16-byte aligned: KB copies row windows into LDS 16 bytes at a time).  The few bases a byte
     // cannot describe (quality 0 or above 62, an N or '=' base) carry an ESCAPE byte that still answers the quality test, and
-    // their full word quality << 8 | bucket("=ACGTN") is in `bqw` at the same element index (written for those 8-base groups
-    // only); the pieces of such a read are marked PF_WIDE.
+    // their full word quality << 8 | bucket("=ACGTN") is in the WIDE stream `bqw` (written for those 8-base groups only); the
+    // pieces of such a read are marked PF_WIDE.  The wide stream is SPARSE: a row (as long as the read's byte row) exists only
+    // for the reads the host found an escape base in when they were pushed (Staged.wide: eb_make's predicate, which asks
+    // nothing of the reference or of -b).  The buffer `bqw` starts with a table of one u32 per 16 elements of the byte stream:
+    // the entry of the chunk a read's byte row starts with holds where its wide row starts, in units of 16 elements from
+    // `bqw` itself (wide_base below: one pointer serves the table and the rows).  Entries of reads without a wide row are
+    // never read.
     const uint8_t* eb;
     const uint16_t* bqw;
     const uint64_t* bq_row;  // [n_reads] host-computed prefix sums of roundup16(l_qseq)
@@ -175,6 +180,9 @@ struct DevIn {
 // per-read float constants written by K1 next to each DRead (one 16-byte scalar load in KB): correctly rounded
 // reciprocals 1/(float)l_qseq and 1/((float)clipped_length/2), and the two denominators themselves
 struct RcpPair { float rcpL, rcpC, Lf, center; };
+
+// first element of the wide row of the read whose event-byte row starts at element `row` (DevIn.bqw)
+BRC_HD uint64_t wide_base(const uint16_t* bqw, uint64_t row) { return (uint64_t)reinterpret_cast<const uint32_t*>(bqw)[row >> 4] << 4; }
 
 // Packed per-read record written by K1 and read with ONE scalar load (s_load_dwordx16) by KB: 64 bytes.
 enum { M_REV = 1, M_Q2OK = 2, M_SMW = 4, M_NMW = 8, M_SIMPLE = 16,
@@ -350,7 +358,6 @@ BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i, uint8_t*
     const uint32_t tags = in.tags[i];
     // (the rows this read writes: its event bytes, and — where an escape byte needs them — the wide words of whole 8-base groups)
     (void)BRC_CK(c, CK_ANNOTATE, 23, CB_EB, eb_out + in.bq_row[i], (uint64_t)(L > 0 ? L : 0), i, -1);
-    (void)BRC_CK(c, CK_ANNOTATE, 24, CB_BQW, bqw_out + in.bq_row[i], 2ull * (uint64_t)(L > 0 ? L : 0), i, -1);
 
     uint32_t sum = 0;
     int left_clip = 0, clipped = L, right_clip = L;
@@ -426,8 +433,7 @@ BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i, uint8_t*
     r.cig_off = (uint32_t)in.cig_off[i];
     r.n_cigar = nc;
     r.bq_off = in.bq_row[i];
-    // per-base stream for KB: the event bytes; an escape byte brings the whole 8-base group's words into the wide stream (as
-    // the group form of K1 writes them)
+    // per-base stream for KB: the event bytes; an escape byte brings the whole 8-base group's words into the wide stream
     wide = false;
     {
         const uint64_t row = in.bq_row[i];
@@ -436,8 +442,11 @@ BRC_HD DRead annotate_read(const DevCfg& c, const DevIn& in, int64_t i, uint8_t*
             eb_out[row + (uint64_t)j] = (uint8_t)eb_make(c.min_bq, qual[j], canon_bucket(seqi(seq, j)), esc);
             if (esc) {
                 wide = true;
-                const int g0 = j & ~7;
-                for (int t = g0; t < g0 + 8 && t < L; ++t) bqw_out[row + (uint64_t)t] = (uint16_t)((qual[t] << 8) | canon_bucket(seqi(seq, t)));
+                if (bqw_out) {                  // (the device's kernels pass none: k_wide_rows writes the words of every read the host found an escape in)
+                    const int g0 = j & ~7;
+                    uint16_t* const wrow = bqw_out + wide_base(bqw_out, row);
+                    for (int t = g0; t < g0 + 8 && t < L; ++t) wrow[t] = (uint16_t)((qual[t] << 8) | canon_bucket(seqi(seq, t)));
+                }
             }
         }
     }
@@ -1114,7 +1123,7 @@ BRC_HD void enumerate_indels(const DevCfg& c, const DevIn& in, const DRead& rd, 
 }
 
 // bucket of the base at element e of the event-byte stream (an escape byte: from the wide stream)
-BRC_HD uint32_t base_bucket(const DevIn& in, uint64_t e) { const uint32_t w = in.eb[e]; return eb_is_escape(w) ? (uint32_t)(in.bqw[e] & 0xffu) : (w & 3u) + 1u; }
+BRC_HD uint32_t base_bucket(const DevIn& in, uint64_t row, uint64_t q) { const uint32_t w = in.eb[row + q]; return eb_is_escape(w) ? (uint32_t)(in.bqw[wide_base(in.bqw, row) + q] & 0xffu) : (w & 3u) + 1u; }
 // Same allele?  Deletions: same length (the allele text is the reference, identical for equal length);
 // insertions: same canonical ("=ACGTN") inserted bases (bamreadcount.cpp:324-338).
 BRC_HD bool same_allele(const DevIn& in, const DRead* reads, const IndelEv& a, const IndelEv& b) {
@@ -1123,8 +1132,8 @@ BRC_HD bool same_allele(const DevIn& in, const DRead* reads, const IndelEv& a, c
     const DRead& ra = reads[a.read]; const DRead& rb = reads[b.read];
     for (int j = 0; j < a.len; ++j) {
         const int qa = a.qpos + 1 + j, qb = b.qpos + 1 + j;
-        const uint32_t ca = qa < ra.l_qseq ? base_bucket(in, ra.bq_off + (uint64_t)qa) : 5u;
-        const uint32_t cb = qb < rb.l_qseq ? base_bucket(in, rb.bq_off + (uint64_t)qb) : 5u;
+        const uint32_t ca = qa < ra.l_qseq ? base_bucket(in, ra.bq_off, (uint64_t)qa) : 5u;
+        const uint32_t cb = qb < rb.l_qseq ? base_bucket(in, rb.bq_off, (uint64_t)qb) : 5u;
         if (ca != cb) return false;
     }
     return true;
@@ -1303,7 +1312,7 @@ BRC_HD char allele_char(const DevCfg& c, const DevIn& in, const TextAux& ax, con
         const DRead& rd = ax.reads[o.rep_read];
         const int q = o.rep_qpos + 1 + j;
         const char bases[] = "=ACGTN";
-        return q < rd.l_qseq ? bases[base_bucket(in, rd.bq_off + (uint64_t)q)] : 'N';
+        return q < rd.l_qseq ? bases[base_bucket(in, rd.bq_off, (uint64_t)q)] : 'N';
     }
     const uint32_t rc = ref_at(c, in.ref, (int64_t)o.pos + 1 + j);
     return rc ? (char)rc : 'N';

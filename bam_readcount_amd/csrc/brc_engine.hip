@@ -192,7 +192,7 @@ __device__ __forceinline__ uint32_t nzb7(uint32_t x) { return x + 0x7f7f7f7fu; }
 template <bool one_stream, int SH>     // one_stream: the event-byte rows and the pieces of consecutive reads are consecutive in memory (no per-library layout); SH: DevCfg.pack_shift
 __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, DevIn in, DRead* __restrict__ reads, const uint32_t* __restrict__ piece_off,
                                                          Piece* __restrict__ pieces, PieceRare* __restrict__ rare, int2* __restrict__ keyreach,
-                                                         uint8_t* __restrict__ eb, uint16_t* __restrict__ bqw, IndelEv* __restrict__ ev_raw, uint32_t* __restrict__ bucket_cnt,
+                                                         uint8_t* __restrict__ eb, IndelEv* __restrict__ ev_raw, uint32_t* __restrict__ bucket_cnt,
                                                          const uint32_t* __restrict__ cigar_ro, const uint8_t* __restrict__ qual_ro,
                                                          const uint8_t* __restrict__ seq_ro, const uint8_t* __restrict__ refcode,
                                                          const uint16_t* __restrict__ wanted /* brc_region_windows: the wanted lanes of every tile, or null */) {
@@ -394,15 +394,8 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
                 uint2 E; E.x = ev_bytes(Q.x, index_of(N.x), (uint32_t)vflags, ex); E.y = ev_bytes(Q.y, index_of(N.y), (uint32_t)(vflags >> 32), ey);
                 if (ex | ey) {
                     // escapes (a quality of 0 or above 62, an N or '=' base): the byte only answers the base-quality filter; the
-                    // group's full words quality << 8 | bucket go to the wide stream and the read's pieces are marked PF_WIDE
-                    auto buckets_of = [](uint32_t codes) -> uint32_t {
-                        const uint32_t sx = codes & 0x07070707u;
-                        const uint32_t lx = __builtin_amdgcn_perm(0x05050503u, 0x05020100u, sx), hx = __builtin_amdgcn_perm(0x05050505u, 0x05050504u, sx);
-                        const uint32_t gx = (codes + 0x78787878u) & 0x80808080u;
-                        const uint32_t mx = (gx - (gx >> 7)) | gx;
-                        return (hx & mx) | (lx & ~mx);
-                    };
-                    const uint32_t Bx = buckets_of(N.x), By = buckets_of(N.y);
+                    // read's pieces are marked PF_WIDE, and its full words quality << 8 | bucket are in the wide stream (k_wide_rows
+                    // wrote them: the host found the read when it was pushed)
                     // escape byte = 63 << 2 where the base passes -b, 0 where it does not: bytewise q >= min_bq (both sides split into
                     // their low seven bits and bit 7)
                     const uint32_t mq = (uint32_t)(c.min_bq < 0 ? 0 : (c.min_bq > 255 ? 255 : c.min_bq)) * 0x01010101u;
@@ -414,10 +407,6 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
                     const uint32_t px = ((ge7(Q.x, mq) & none) >> 7) * 0xffu, py = ((ge7(Q.y, mq) & none) >> 7) * 0xffu;
                     const uint32_t mx2 = (ex >> 7) * 0xffu, my3 = (ey >> 7) * 0xffu;
                     E.x = (E.x & ~mx2) | (mx2 & px & 0xfcfcfcfcu); E.y = (E.y & ~my3) | (my3 & py & 0xfcfcfcfcu);
-                    uint4 out;
-                    out.x = __builtin_amdgcn_perm(Q.x, Bx, 0x05010400u); out.y = __builtin_amdgcn_perm(Q.x, Bx, 0x07030602u);
-                    out.z = __builtin_amdgcn_perm(Q.y, By, 0x05010400u); out.w = __builtin_amdgcn_perm(Q.y, By, 0x07030602u);
-                    *reinterpret_cast<uint4*>(BRC_CK(c, CK_ANNOTATE, 6, CB_BQW, bqw + ((((uint64_t)P.c.w) << 32) | (uint64_t)P.a.w) + (uint32_t)b, 16, rb + jr, b)) = out;
                     atomicOr(&W.wide[jr], 1u);
                 }
                 // (rows are 16-byte aligned; written once here, read by k_pileup2 a kernel later.  With ONE stream of rows — no
@@ -527,7 +516,7 @@ __global__ __launch_bounds__(256) BRC_ANN_OCC void k_annotate_groups(DevCfg c, D
         }
     }
     if (serial) {
-        r = annotate_read(c, in, my, eb, bqw, wide);
+        r = annotate_read(c, in, my, eb, nullptr, wide);
     } else {
         const bool rev = (flag & FREVERSE) != 0;
         int tp, q2;
@@ -620,6 +609,22 @@ __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m) { return __bui
 // reads have none, and for a read without operators K1 writes nothing at all (no record, no pieces, no indel slots, no event bytes).
 // (wave_list: the reads of the four-wave instantiation from the front, those of the one-wave instantiation from the back, list_cap - 1 downwards;
 // those of the one-wave-per-CU instantiation in a second list behind it, from list_cap + 16 on)
+// The sparse wide stream (DevIn.bqw), ONE WAVE PER READ the host found an escape base in (Staged::wide_layout: the read, where its wide
+// row starts in units of 16 elements): the table entry of the chunk its byte row starts with, then the words quality << 8 | bucket of
+// all its bases.  K1 — whatever its form — only marks such a read's pieces PF_WIDE.
+__global__ __launch_bounds__(256) void k_wide_rows(DevCfg c, DevIn in, const uint2* __restrict__ pairs, uint32_t n, uint16_t* __restrict__ bqw) {
+    const uint32_t w = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    if (w >= n) return;
+    const uint2 p = pairs[w];
+    const int64_t i = (int64_t)p.x;
+    const int32_t L = in.l_qseq[i];
+    if (lane == 0u) *BRC_CK(c, CK_ANNOTATE, 51, CB_BQW, reinterpret_cast<uint32_t*>(bqw) + (in.bq_row[i] >> 4), 4, i, -1) = p.y;
+    const uint8_t* const qual = BRC_CK(c, CK_ANNOTATE, 52, CB_QUAL, in.qual + in.qual_off[i], (uint64_t)L, i, -1);
+    const uint8_t* const seq = BRC_CK(c, CK_ANNOTATE, 53, CB_SEQ, in.seq4 + in.seq_off[i], (uint64_t)((L + 1) / 2), i, -1);
+    uint16_t* const row = BRC_CK(c, CK_ANNOTATE, 54, CB_BQW, bqw + ((uint64_t)p.y << 4), 2ull * (uint64_t)L, i, -1);
+    for (int32_t j = (int32_t)lane; j < L; j += 64) row[j] = (uint16_t)(((uint32_t)qual[j] << 8) | canon_bucket(seqi(seq, j)));
+}
+
 __global__ __launch_bounds__(256) void k_pick_wave(DevCfg c, DevIn in, uint32_t* __restrict__ n_cigar_k1, uint32_t* __restrict__ wave_list, uint32_t list_cap,
                                                    unsigned int* __restrict__ wave_n, unsigned int* __restrict__ wave_n_big, unsigned int* __restrict__ wave_n_huge,
                                                    int wave_on, int cursor_on, unsigned int* __restrict__ cursor_n,
@@ -702,14 +707,14 @@ __global__ __launch_bounds__(256) void k_pick_wave(DevCfg c, DevIn in, uint32_t*
 template <int SH>
 __global__ __launch_bounds__(64) void k_annotate_cursor(DevCfg c, DevIn in, const uint32_t* __restrict__ list, const unsigned int* __restrict__ list_n,
                                                         DRead* __restrict__ reads, const uint32_t* __restrict__ piece_off, Piece* __restrict__ pieces, PieceRare* __restrict__ rare,
-                                                        int2* __restrict__ keyreach, uint8_t* __restrict__ eb, uint16_t* __restrict__ bqw, IndelEv* __restrict__ ev_raw,
+                                                        int2* __restrict__ keyreach, uint8_t* __restrict__ eb, IndelEv* __restrict__ ev_raw,
                                                         uint32_t* __restrict__ bucket_cnt, const uint16_t* __restrict__ wanted) {
     c.pack_shift = SH;
     const uint32_t n = *list_n;
     for (uint32_t li = blockIdx.x * 64u + threadIdx.x; li < n; li += gridDim.x * 64u) {
         const int64_t my = (int64_t)list[li];
         bool wide = false;
-        const DRead r = annotate_read(c, in, my, eb, bqw, wide);
+        const DRead r = annotate_read(c, in, my, eb, nullptr, wide);
         *BRC_CK(c, CK_ANNOTATE, 46, CB_READS, reads + my, sizeof(DRead), my, -1) = r;
         const uint32_t nc = in.n_cigar[my]; const uint32_t* cig = in.cigar + in.cig_off[my];
         const int lib = c.per_lib ? (int)in.lib[my] : 0;
@@ -754,7 +759,7 @@ template <int SH, int MCAP, int WAVES, bool EQX = false>      // MCAP: match ope
 __global__ __launch_bounds__(WAVES * 64) void k_annotate_wave(DevCfg c, DevIn in, const uint32_t* __restrict__ wave_list, int list_step, const unsigned int* __restrict__ wave_n,
                                                        DRead* __restrict__ reads, const uint32_t* __restrict__ piece_off,
                                                        Piece* __restrict__ pieces, PieceRare* __restrict__ rare, int2* __restrict__ keyreach,
-                                                       uint8_t* __restrict__ eb, uint16_t* __restrict__ bqw, IndelEv* __restrict__ ev_raw, uint32_t* __restrict__ bucket_cnt,
+                                                       uint8_t* __restrict__ eb, IndelEv* __restrict__ ev_raw, uint32_t* __restrict__ bucket_cnt,
                                                        const uint8_t* __restrict__ refcode, const uint16_t* __restrict__ wanted) {
     c.pack_shift = SH;
     struct WaveLds { int32_t y[MCAP]; int32_t x[MCAP]; uint32_t lw[MCAP]; int32_t ya[EQX ? MCAP : 1]; DRead r; uint32_t wide; };
@@ -781,7 +786,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_annotate_wave(DevCfg c, DevIn in
         const uint8_t* const qual = BRC_CK(c, CK_ANNOTATE, 31, CB_QUAL, in.qual + qoff, (uint64_t)L, my, -1);
         const uint8_t* const seq = BRC_CK(c, CK_ANNOTATE, 32, CB_SEQ, in.seq4 + soff, (uint64_t)((L + 1) / 2), my, -1);
         uint8_t* const eb_row = BRC_CK(c, CK_ANNOTATE, 33, CB_EB, eb + brow, (uint64_t)L, my, -1);
-        uint16_t* const bqw_row = BRC_CK(c, CK_ANNOTATE, 34, CB_BQW, bqw + brow, 2ull * (uint64_t)L, my, -1);
         const bool nocount = (flag & BRC_NOCOUNT_MASK) != 0u;
         const bool ev_on = ev_raw && !(c.per_lib && lib < 0) && (int)mapq >= c.min_mapq && !nocount;
         IndelEv* const ev_slots = ev_raw ? ev_raw + in.iev_off[my] : nullptr;
@@ -873,16 +877,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_annotate_wave(DevCfg c, DevIn in
             if (__ballot(in_m && (rcode & 0x80u))) redo = true;
             const uint32_t refb = rcode & 0xfu;
             const bool mm = in_m && nib != refb && refb != 15u && nib != 0u;          // :152
-            // event byte (+ the wide words of 8-base groups that hold an escape)
+            // event byte
             bool esc; const uint32_t bucket = canon_bucket(nib);
             const uint32_t byte = eb_make(c.min_bq, q, bucket, esc);
             if (valid) eb_row[j] = (uint8_t)byte;
-            unsigned long long eg = __ballot(esc && valid);
-            if (eg) {
-                wide = true;
-                eg |= eg >> 4; eg |= eg >> 2; eg |= eg >> 1; eg &= 0x0101010101010101ull; eg *= 0xffull;      // every lane of a group with an escape
-                if (valid && ((eg >> lane) & 1ull)) bqw_row[j] = (uint16_t)((q << 8) | bucket);
-            }
+            if (__ballot(esc && valid)) wide = true;                                  // (its words are in the wide stream: k_wide_rows)
             // first / last base with quality != 2
             const unsigned long long nz = __ballot(valid && q != 2u);
             if (nz) { if (my_lo < 0) my_lo = jb + __builtin_ctzll(nz); my_hi = jb + 63 - __builtin_clzll(nz); }
@@ -908,7 +907,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_annotate_wave(DevCfg c, DevIn in
         // ---- the read's record (as K1's phase C) — or, for a read with a NUL reference character under an M base, annotate_read()
         if (lane == 0) {
             DRead r0; bool w0 = wide;
-            if (redo) r0 = annotate_read(c, in, my, eb, bqw, w0);
+            if (redo) r0 = annotate_read(c, in, my, eb, nullptr, w0);
             else {
                 const bool rev = (flag & FREVERSE) != 0;
                 int tp, q2;
@@ -1654,15 +1653,14 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                             if (m_esc) {                                                                                  \
                                 u32x2 bo; const char* bp = BRC_CKS(c, CK_PILEUP, 13, CB_KP_PIECES, reinterpret_cast<const char*>(pieces4) + (size_t)(m) * 48u, 48, tile, (m)); \
                                 asm volatile("s_load_dwordx2 %0, %1, 0x28\n\ts_waitcnt lgkmcnt(0)" : "=&s"(bo) : "s"(bp)); \
-                                /* (scalar base + 32-bit lane offset: no 64-bit vector address in this rare path's register budget) */ \
-                                const uint16_t* wrow = bqw_ro + (int64_t)(((uint64_t)bo[1] << 32) | bo[0]);               \
+                                /* (the read's wide row: where it starts, in units of 16 elements, is in the table at the head of the stream — \
+                                   wide_base; its entry is 4 x (bq_off / 16) bytes in.  Both loads are the lanes' own: the row's address in \
+                                   vector registers costs this rare path nothing, in scalar ones it cost the whole kernel 40 spills) */ \
+                                const uint32_t toff = (bo[0] >> 2) | (bo[1] << 30);                                       \
                                 bool exo = false;                                                                         \
                                 if (__builtin_amdgcn_inverse_ballot_w64(m_esc)) {                                         \
-                                    uint32_t w16; const uint32_t wv = ((uint32_t)BRC_LANE() + (uint32_t)S.s_c) << 1;      \
-                                    (void)BRC_CK(c, CK_PILEUP, 14, CB_BQW, reinterpret_cast<const char*>(wrow) + wv, 2, tile, (m)); \
-                                    /* (s_nop 4: a VMEM instruction that reads an SGPR a VALU instruction wrote — a v_readlane that restores a spilled pair — needs \
-                                       five wait states, and the compiler's hazard recogniser does not look into an assembly statement) */ \
-                                    asm volatile("s_nop 4\n\tglobal_load_ushort %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(w16) : "v"(wv), "s"(wrow) : "memory"); \
+                                    const uint32_t w16v = *BRC_CK(c, CK_PILEUP, 42, CB_BQW, reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(bqw_ro) + toff), 4, tile, (m)); \
+                                    const uint32_t w16 = *BRC_CK(c, CK_PILEUP, 14, CB_BQW, bqw_ro + (((uint64_t)w16v << 4) + ((uint32_t)BRC_LANE() + (uint32_t)S.s_c)), 2, tile, (m)); \
                                     exo = !bucket_acgt(w16 & 0xffu);                                                      \
                                     if (exo) a.ww += R.g[0]; else S.w = ((w16 >> 8) << 2) | ((w16 & 0xffu) - 1u);         \
                                 }                                                                                         \
@@ -1780,7 +1778,7 @@ __global__ __launch_bounds__(PILEUP_WAVES * 64) __attribute__((amdgpu_waves_per_
                     /* the lane's quality and bucket: from its event byte, or — an escape byte of a wide read — from the wide stream */ \
                     uint32_t eq = w >> 2, ebk = (w & 3u) + 1u;                                                            \
                     if (((H.tp_flags >> 24) & PF_WIDE) && mine && eb_is_escape(w)) {                                      \
-                        const uint32_t w16 = *BRC_CK(c, CK_PILEUP, 18, CB_BQW, bqw_ro + ((int64_t)H.bq_off + (int64_t)(lr + s_c)), 2, tile, m); eq = w16 >> 8; ebk = w16 & 0xffu; \
+                        const uint32_t w16 = *BRC_CK(c, CK_PILEUP, 18, CB_BQW, bqw_ro + ((int64_t)wide_base(bqw_ro, H.bq_off) + (int64_t)(lr + s_c)), 2, tile, m); eq = w16 >> 8; ebk = w16 & 0xffu; \
                     }                                                                                                     \
                     if (kind == 0u) {                          /* third alleles: raw addends to the list, in piece order */ \
                         uint32_t at0 = 0;                                                                                 \
@@ -2175,6 +2173,8 @@ class HipBackend : public Backend {
     // device buffers
     DBuf d_pos, d_flag, d_mapq, d_lib, d_lq, d_nc, d_co, d_so, d_qo, d_nm, d_sm, d_tags, d_cigar, d_seq, d_qual, d_ref, d_refcode;
     std::vector<uint16_t> h_wanted; bool has_wanted = false; DBuf d_wanted; std::vector<uint32_t> h_tilelist; DBuf d_tilelist;      // brc_region_windows (kept alive for the asynchronous copy)
+    std::vector<Staged::WidePair> h_wpairs;
+    DBuf d_wpairs;
     DBuf d_bq, d_bqw, d_bqrow, d_pieceoff, d_pieces, d_rare, d_keyreach, d_libbase, d_reads, d_agg, d_rng, d_ncol, d_depth, d_slotid, d_si, d_sf, d_xev, d_xevc, d_xevn, d_unavail, d_cnt, d_cursor, d_ev, d_evraw, d_ievoff, d_iout, d_ctr, d_tilectr, d_part, d_wavelist, d_nc_k1;
     DBuf d_tlen, d_toff, d_text, d_tctx, d_total64, d_lastproc;
     DBuf d_xcnt, d_xend, d_xidx, d_xagg;   // the third-allele fold: events per (tile, library) bucket, the buckets' ends, the events' indices by bucket, the folded records
@@ -2277,7 +2277,7 @@ class HipBackend : public Backend {
         if (getenv("BRC_ENGINE_TIMING")) fprintf(stderr, "device buffers: %llu (re)allocations, %.3f s\n", (unsigned long long)g_dev_allocs.load(), (double)g_dev_alloc_ns.load() * 1e-9);
         DBuf* all[] = {&d_pos, &d_flag, &d_mapq, &d_lib, &d_lq, &d_nc, &d_co, &d_so, &d_qo, &d_nm, &d_sm, &d_tags, &d_cigar, &d_seq, &d_qual,
                        &d_ref, &d_refcode, &d_bq, &d_bqw, &d_bqrow, &d_pieceoff, &d_pieces, &d_rare, &d_keyreach, &d_libbase, &d_reads, &d_agg, &d_rng, &d_ncol, &d_depth, &d_slotid, &d_si, &d_sf, &d_xev, &d_xevc, &d_xevn, &d_unavail, &d_cnt,
-                       &d_cursor, &d_ev, &d_evraw, &d_ievoff, &d_iout, &d_ctr, &d_tilectr, &d_part, &d_tlen, &d_toff, &d_text, &d_tctx, &d_total64, &d_lastproc, &d_xcnt, &d_xend, &d_xidx, &d_xagg, &d_wanted, &d_tilelist, &d_wavelist, &d_nc_k1};
+                       &d_cursor, &d_ev, &d_evraw, &d_ievoff, &d_iout, &d_ctr, &d_tilectr, &d_part, &d_tlen, &d_toff, &d_text, &d_tctx, &d_total64, &d_lastproc, &d_xcnt, &d_xend, &d_xidx, &d_xagg, &d_wanted, &d_tilelist, &d_wavelist, &d_nc_k1, &d_wpairs};
         for (DBuf* b : all) b->release();
         d_ccnt.release(); d_coff.release(); d_cpieces.release(); d_crare.release(); d_crng.release(); d_ctot.release();
 #ifdef BRC_CHECKED
@@ -2366,12 +2366,26 @@ class HipBackend : public Backend {
         in.tags = (const uint8_t*)d_tags.p; in.cigar = (const uint32_t*)d_cigar.p; in.seq4 = (const uint8_t*)d_seq.p; in.qual = (const uint8_t*)d_qual.p;
         in.ref = (const char*)d_ref.p;
         // event-byte stream, padded on both sides: a staged window starts up to 79 elements before / ends after a row
-        // (the wide stream — full words of the few 8-base groups with an escape byte — is indexed like the bytes; it is
-        // allocated whole and touched only where K1 writes such a group)
+        // (the wide stream — full words of the few 8-base groups with an escape byte — has rows for the reads the host found such
+        // a base in: DevIn.bqw)
         enum { BQ_PAD = EB_PAD_FRONT };
         HIPCHK(d_bq.ensure(s.bq_elems + BQ_PAD + EB_PAD_BACK + (size_t)std::max<int32_t>(s.max_lqseq, 0)));     // (brc_core.h: stage_window_start — a staged window ends at most that far past the stream)
-        HIPCHK(d_bqw.ensure((s.bq_elems + 16) * sizeof(uint16_t)));
-        in.eb = (const uint8_t*)d_bq.p + BQ_PAD; in.bqw = (const uint16_t*)d_bqw.p;
+        {   // the sparse wide stream: [table: one u32 per 16 elements of the byte stream][rows of the wide reads] (brc_core.h: DevIn.bqw)
+            if (s.bq_elems >> 34) { err = "region too large: 2^34 bases and more"; return BRC_E_LIMIT; }      // (k_pileup2 reaches a table entry through a 32-bit byte offset)
+            const size_t tab_bytes = ((((size_t)(s.bq_elems >> 4) + 2) * 4) + 255) & ~(size_t)255;
+            const uint64_t wq_elems = s.wide_layout(h_wpairs, (uint32_t)(tab_bytes / 32));
+            if ((tab_bytes / 32 + (wq_elems >> 4)) >> 32) { err = "region too large: 2^36 bases of reads with escape bases"; return BRC_E_LIMIT; }
+            HIPCHK(d_bqw.ensure(tab_bytes + ((size_t)wq_elems + 16) * sizeof(uint16_t)));
+            in.bqw = (const uint16_t*)d_bqw.p;
+#ifdef BRC_CHECKED
+            HIPCHK(hipMemsetAsync(d_bqw.p, 0xff, tab_bytes, stream));        // (an entry nobody set points far outside the stream)
+#endif
+            if (!h_wpairs.empty()) {
+                HIPCHK(d_wpairs.ensure(h_wpairs.size() * sizeof(Staged::WidePair)));
+                HIPCHK(hipMemcpyAsync(d_wpairs.p, h_wpairs.data(), h_wpairs.size() * sizeof(Staged::WidePair), hipMemcpyHostToDevice, stream));
+            }
+        }
+        in.eb = (const uint8_t*)d_bq.p + BQ_PAD;
         if ((rc = up(d_bqrow, s.bq_row, n)) || (rc = up(d_pieceoff, s.piece_off, n))) return rc;
         in.bq_row = (const uint64_t*)d_bqrow.p;
         in.rcp = nullptr;
@@ -2483,6 +2497,8 @@ class HipBackend : public Backend {
             const int64_t rl = c.ref_hi - c.ref_lo;
             if (c.has_ref)
                 hipLaunchKernelGGL(k_refcode, dim3((unsigned)(((rl + 2 * REFCODE_PAD + 15) / 16 + 255) / 256)), dim3(256), 0, stream, in.ref, (uint8_t*)d_refcode.p, rl);
+            if (!h_wpairs.empty())        // the wide rows of the reads the host found an escape base in
+                hipLaunchKernelGGL(k_wide_rows, dim3((unsigned)((h_wpairs.size() + 3) / 4)), dim3(256), 0, stream, c, in, (const uint2*)d_wpairs.p, (uint32_t)h_wpairs.size(), (uint16_t*)in.bqw);
             DevIn in_k1 = in;
             if (wave_on || cursor_on) {   // reads with more than two M operators: listed for k_annotate_wave, without operators in K1's copy of the counts (reads with an empty M / = / X operator: for k_annotate_cursor)
                 hipLaunchKernelGGL(k_pick_wave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (uint32_t*)d_nc_k1.p, (uint32_t*)d_wavelist.p, (uint32_t)n, &ctr->n_wave_reads, &ctr->n_wave_big, &ctr->n_wave_huge,
@@ -2492,7 +2508,7 @@ class HipBackend : public Backend {
             {   // K1: one instantiation per (row layout, width of the narrow packed fields — choose_pack)
 #define BRC_LAUNCH_K1(OS, SH) hipLaunchKernelGGL((k_annotate_groups<OS, SH>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in_k1, (DRead*)d_reads.p, (const uint32_t*)d_pieceoff.p, \
                                    (Piece*)d_pieces.p, (PieceRare*)d_rare.p, (int2*)d_keyreach.p,                                                                               \
-                                   (uint8_t*)in.eb, (uint16_t*)in.bqw, indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p,                                    \
+                                   (uint8_t*)in.eb, indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p,                                    \
                                    in.cigar, in.qual, in.seq4, (const uint8_t*)d_refcode.p + REFCODE_PAD, has_wanted ? (const uint16_t*)d_wanted.p : (const uint16_t*)nullptr)
                 if (Lp == 1) { if (c.pack_shift == 16) BRC_LAUNCH_K1(true, 16); else BRC_LAUNCH_K1(true, 12); }
                 else { if (c.pack_shift == 16) BRC_LAUNCH_K1(false, 16); else BRC_LAUNCH_K1(false, 12); }
@@ -2502,7 +2518,7 @@ class HipBackend : public Backend {
                     const unsigned nb = (unsigned)std::min<int64_t>((n + 3) / 4, (int64_t)WAVE_FORM_BLOCKS);
 #define BRC_LAUNCH_K1W(SH, MCAP, WAVES, GRID, LIST, STEP, COUNT) hipLaunchKernelGGL((k_annotate_wave<SH, MCAP, WAVES>), dim3(GRID), dim3(WAVES * 64), 0, stream, c, in, LIST, STEP, (const unsigned int*)(COUNT),     \
                                    (DRead*)d_reads.p, (const uint32_t*)d_pieceoff.p, (Piece*)d_pieces.p, (PieceRare*)d_rare.p, (int2*)d_keyreach.p,                                   \
-                                   (uint8_t*)in.eb, (uint16_t*)in.bqw, indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p,                                          \
+                                   (uint8_t*)in.eb, indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p,                                          \
                                    (const uint8_t*)d_refcode.p + REFCODE_PAD, has_wanted ? (const uint16_t*)d_wanted.p : (const uint16_t*)nullptr)
                     const uint32_t* const wl = (const uint32_t*)d_wavelist.p;
                     if (c.pack_shift == 16) BRC_LAUNCH_K1W(16, AW_MCAP, 4, nb, wl, 1, &ctr->n_wave_reads); else BRC_LAUNCH_K1W(12, AW_MCAP, 4, nb, wl, 1, &ctr->n_wave_reads);
@@ -2513,7 +2529,7 @@ class HipBackend : public Backend {
                     if (wave_eqx) {     // reads with = / X operators: the instantiations that keep the annotator's own cursors; fourth list, the longer ones from its back
 #define BRC_LAUNCH_K1E(SH, MCAP, WAVES, GRID, LIST, STEP, COUNT) hipLaunchKernelGGL((k_annotate_wave<SH, MCAP, WAVES, true>), dim3(GRID), dim3(WAVES * 64), 0, stream, c, in, LIST, STEP, (const unsigned int*)(COUNT),     \
                                    (DRead*)d_reads.p, (const uint32_t*)d_pieceoff.p, (Piece*)d_pieces.p, (PieceRare*)d_rare.p, (int2*)d_keyreach.p,                                   \
-                                   (uint8_t*)in.eb, (uint16_t*)in.bqw, indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p,                                          \
+                                   (uint8_t*)in.eb, indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p,                                          \
                                    (const uint8_t*)d_refcode.p + REFCODE_PAD, has_wanted ? (const uint16_t*)d_wanted.p : (const uint16_t*)nullptr)
                         if (c.pack_shift == 16) BRC_LAUNCH_K1E(16, AW_MCAP_EQX, 4, nb, wl + (3 * n + 48), 1, &ctr->n_wave_eqx); else BRC_LAUNCH_K1E(12, AW_MCAP_EQX, 4, nb, wl + (3 * n + 48), 1, &ctr->n_wave_eqx);
                         if (s_max_ncigar > (uint32_t)AW_MCAP_EQX) {
@@ -2531,7 +2547,7 @@ class HipBackend : public Backend {
                 if (cursor_on) {
                     const unsigned nbc = (unsigned)std::min<int64_t>((n + 63) / 64, 1024);
 #define BRC_LAUNCH_K1C(SH) hipLaunchKernelGGL((k_annotate_cursor<SH>), dim3(nbc), dim3(64), 0, stream, c, in, (const uint32_t*)d_wavelist.p + (2 * (size_t)n + 32), (const unsigned int*)&ctr->n_literal,    \
-                                   (DRead*)d_reads.p, (const uint32_t*)d_pieceoff.p, (Piece*)d_pieces.p, (PieceRare*)d_rare.p, (int2*)d_keyreach.p, (uint8_t*)in.eb, (uint16_t*)in.bqw,                     \
+                                   (DRead*)d_reads.p, (const uint32_t*)d_pieceoff.p, (Piece*)d_pieces.p, (PieceRare*)d_rare.p, (int2*)d_keyreach.p, (uint8_t*)in.eb,                     \
                                    indels ? (IndelEv*)d_evraw.p : (IndelEv*)nullptr, (uint32_t*)d_cnt.p, has_wanted ? (const uint16_t*)d_wanted.p : (const uint16_t*)nullptr)
                     if (c.pack_shift == 16) BRC_LAUNCH_K1C(16); else BRC_LAUNCH_K1C(12);
 #undef BRC_LAUNCH_K1C

@@ -97,11 +97,11 @@ class Pool {
 
 void Staged::init(const HostAlloc* A) {
     pos.A = A; flag.A = A; mapq.A = A; lib.A = A; l_qseq.A = A; n_cigar.A = A; cig_off.A = A; seq_off.A = A; qual_off.A = A;
-    nm.A = A; sm.A = A; tags.A = A; cigar.A = A; seq4.A = A; qual.A = A; bq_row.A = A; piece_cnt.A = A; piece_off.A = A; iev_off.A = A; qnames.A = A; qname_off.A = A;
+    nm.A = A; sm.A = A; tags.A = A; cigar.A = A; seq4.A = A; qual.A = A; bq_row.A = A; wide.A = A; piece_cnt.A = A; piece_off.A = A; iev_off.A = A; qnames.A = A; qname_off.A = A;
 }
 void Staged::clear() {
     pos.clear(); flag.clear(); mapq.clear(); lib.clear(); l_qseq.clear(); n_cigar.clear(); cig_off.clear(); seq_off.clear();
-    qual_off.clear(); nm.clear(); sm.clear(); tags.clear(); cigar.clear(); seq4.clear(); qual.clear(); bq_row.clear();
+    qual_off.clear(); nm.clear(); sm.clear(); tags.clear(); cigar.clear(); seq4.clear(); qual.clear(); bq_row.clear(); wide.clear();
     bq_elems = 0; memset(len_hist, 0, sizeof len_hist); n = 0; min_pos = 0; max_end = 0; n_indel_ops = 0;
     seq_seg.clear(); qual_seg.clear(); seq_total = 0; qual_total = 0;
     piece_cnt.clear(); piece_off.clear(); iev_off.clear(); lib_base.clear(); n_pieces = 0; max_lqseq = 0; max_ncigar = 0; has_empty_m = false; has_eqx = false; max_span = 0; qnames.clear(); qname_off.clear();
@@ -127,7 +127,7 @@ std::vector<uint16_t> Staged::wanted_tiles(int32_t pos0, int64_t P) const {
 }
 void Staged::destroy() {
     pos.destroy(); flag.destroy(); mapq.destroy(); lib.destroy(); l_qseq.destroy(); n_cigar.destroy(); cig_off.destroy();
-    seq_off.destroy(); qual_off.destroy(); nm.destroy(); sm.destroy(); tags.destroy(); cigar.destroy(); seq4.destroy(); qual.destroy(); bq_row.destroy();
+    seq_off.destroy(); qual_off.destroy(); nm.destroy(); sm.destroy(); tags.destroy(); cigar.destroy(); seq4.destroy(); qual.destroy(); bq_row.destroy(); wide.destroy();
     piece_cnt.destroy(); piece_off.destroy(); iev_off.destroy(); qnames.destroy(); qname_off.destroy();
 }
 // library-major slots: all pieces of library 0 in file order, then library 1, ... (one stream without -p)
@@ -151,10 +151,45 @@ void Staged::layout_pieces(int Lp, bool per_lib) {
     if (per_lib && Lp > 1) {
         std::vector<uint64_t> rows((size_t)Lp + 2, 0);
         auto slot = [&](int64_t i) { const int l = (int)lib.p[i]; return (size_t)((l >= 0 && l < Lp) ? l : Lp); };
-        for (int64_t i = 0; i < n; ++i) rows[slot(i) + 1] += ((uint64_t)l_qseq.p[i] + 7u) & ~(uint64_t)7u;
+        for (int64_t i = 0; i < n; ++i) rows[slot(i) + 1] += ((uint64_t)l_qseq.p[i] + 15u) & ~(uint64_t)15u;
         for (int l = 0; l <= Lp; ++l) rows[(size_t)l + 1] += rows[(size_t)l];
-        for (int64_t i = 0; i < n; ++i) { const size_t k = slot(i); bq_row.p[i] = rows[k]; rows[k] += ((uint64_t)l_qseq.p[i] + 7u) & ~(uint64_t)7u; }
+        for (int64_t i = 0; i < n; ++i) { const size_t k = slot(i); bq_row.p[i] = rows[k]; rows[k] += ((uint64_t)l_qseq.p[i] + 15u) & ~(uint64_t)15u; }
     }
+}
+uint64_t Staged::wide_layout(std::vector<WidePair>& pairs, uint32_t first16) const {
+    pairs.clear();
+    uint64_t w = 0;
+    for (int64_t i = 0; i < n; ++i) if (wide.p[i]) {
+        WidePair x; x.read = (uint32_t)i; x.w16 = first16 + (uint32_t)(w >> 4);
+        pairs.push_back(x); w += ((uint64_t)l_qseq.p[i] + 15u) & ~(uint64_t)15u;
+    }
+    return w;
+}
+// eb_make's escape predicate (brc_core.h) over a read's bytes as they were pushed: a quality of 0 or above 62, a base code
+// that is not one of A C G T.  Eight qualities / sixteen base codes at a time.
+static bool read_has_escape(const uint8_t* qual, const uint8_t* seq4, int32_t L) {
+    if (L <= 0) return false;
+    const uint64_t K01 = 0x0101010101010101ull, K80 = 0x8080808080808080ull, K7F = 0x7f7f7f7f7f7f7f7full;
+    int32_t j = 0;
+    for (; j + 8 <= L; j += 8) {
+        uint64_t x; memcpy(&x, qual + j, 8);
+        const uint64_t zero = (x - K01) & ~x & K80;                                  // some byte is 0
+        const uint64_t big = (((x & K7F) + (uint64_t)(128 - EB_ESC) * K01) | x) & K80;   // some byte is >= 63
+        if (zero | big) return true;
+    }
+    for (; j < L; ++j) if ((uint8_t)(qual[j] - 1u) >= (uint8_t)(EB_ESC - 1)) return true;
+    const int32_t nb = L / 2;                                                       // whole bytes: two base codes each
+    const uint64_t K11 = 0x1111111111111111ull, K88 = 0x8888888888888888ull;
+    int32_t t = 0;
+    for (; t + 8 <= nb; t += 8) {
+        uint64_t x; memcpy(&x, seq4 + t, 8);
+        if ((x - K11) & ~x & K88) return true;                                      // some code is 0 ('=')
+        if (x & (x - K11)) return true;                                             // (no borrows now) some code has two bits and more
+    }
+    auto bad = [](uint32_t n) { return n == 0u || (n & (n - 1u)) != 0u; };
+    for (; t < nb; ++t) if (bad(seq4[t] >> 4) || bad(seq4[t] & 15u)) return true;
+    if ((L & 1) && bad(seq4[nb] >> 4)) return true;
+    return false;
 }
 
 // two decimal digits at a time
@@ -589,7 +624,7 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
     if (e->hint_reads > n0 + n || e->hint_bases > qb + b->qual_bytes) {
         const size_t hr = std::max(e->hint_reads, n0 + n) + 16, hb = std::max<size_t>(e->hint_bases, qb + b->qual_bytes) + 16;
         bool okh = s.pos.reserve(hr) && s.flag.reserve(hr) && s.mapq.reserve(hr) && s.l_qseq.reserve(hr) && s.n_cigar.reserve(hr) && s.cig_off.reserve(hr) &&
-                   s.seq_off.reserve(hr) && s.qual_off.reserve(hr) && s.bq_row.reserve(hr) && s.piece_cnt.reserve(hr) && s.piece_off.reserve(hr) && s.iev_off.reserve(hr) && s.lib.reserve(hr) &&
+                   s.seq_off.reserve(hr) && s.qual_off.reserve(hr) && s.bq_row.reserve(hr) && s.wide.reserve(hr) && s.piece_cnt.reserve(hr) && s.piece_off.reserve(hr) && s.iev_off.reserve(hr) && s.lib.reserve(hr) &&
                    s.nm.reserve(hr) && s.sm.reserve(hr) && s.tags.reserve(hr) && s.qname_off.reserve(hr) && s.cigar.reserve(hr + hr / 4) &&
                    (adopt || (s.qual.reserve(hb) && s.seq4.reserve(hb / 2 + hr)));
         if (!okh) return fail(e, BRC_E_NOMEM, "host staging allocation failed");
@@ -605,7 +640,7 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
               s.n_cigar.append(b->n_cigar, n) && s.cig_off.append(b->cigar_off, n) && s.seq_off.append(b->seq_off, n) &&
               s.qual_off.append(b->qual_off, n) && s.cigar.append(b->cigar, b->n_cigar_total) &&
               (adopt || (append_big(pool, s.seq4, b->seq4, b->seq_bytes) && append_big(pool, s.qual, b->qual, b->qual_bytes))) &&
-              s.bq_row.reserve(n0 + n + 16) && s.piece_cnt.reserve(n0 + n + 16) && s.piece_off.reserve(n0 + n + 16) && s.iev_off.reserve(n0 + n + 16) && s.lib.reserve(n0 + n + 16) && s.nm.reserve(n0 + n + 16) && s.sm.reserve(n0 + n + 16) && s.tags.reserve(n0 + n + 16);
+              s.bq_row.reserve(n0 + n + 16) && s.wide.reserve(n0 + n + 16) && s.piece_cnt.reserve(n0 + n + 16) && s.piece_off.reserve(n0 + n + 16) && s.iev_off.reserve(n0 + n + 16) && s.lib.reserve(n0 + n + 16) && s.nm.reserve(n0 + n + 16) && s.sm.reserve(n0 + n + 16) && s.tags.reserve(n0 + n + 16);
     if (!ok) return fail(e, BRC_E_NOMEM, "host staging allocation failed");
     { uint32_t mx = s.max_ncigar; for (size_t i = 0; i < n; ++i) mx = b->n_cigar[i] > mx ? b->n_cigar[i] : mx; s.max_ncigar = mx; }   // (the engine's wave-form annotator is for reads with five operators and more)
     if (adopt) {
@@ -626,7 +661,7 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
         s.sm.p[n0 + i] = b->sm ? b->sm[i] : 0;
         s.tags.p[n0 + i] = b->tags ? b->tags[i] : 0;
     }
-    s.lib.n = s.nm.n = s.sm.n = s.tags.n = s.bq_row.n = s.piece_cnt.n = s.iev_off.n = n0 + n;
+    s.lib.n = s.nm.n = s.sm.n = s.tags.n = s.bq_row.n = s.wide.n = s.piece_cnt.n = s.iev_off.n = n0 + n;
     const int32_t maxcnt = e->cfg.max_cnt;
     // ---- large batches: the per-read pass on several threads.  Everything a read contributes to a running quantity — its row
     // in the event-byte stream, its slots in the raw indel list, its pieces, the region's extent, the length histogram — is a
@@ -693,6 +728,7 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
                 walk_pieces(e->cfg.insertion_centric != 0, entered, counts, pos, cg, nc, [&](int32_t, int32_t len, int32_t, int qoff, bool) { ++np; if (len > 0 && qoff + len > lq) past = true; });
                 if (past) { bad(i, BRC_E_ARG, kEmptyM); break; }
                 s.piece_cnt.p[r] = np; C.np += np;
+                s.wide.p[r] = read_has_escape(b->qual + b->qual_off[i], b->seq4 + b->seq_off[i], lq) ? 1 : 0;
             }
         });
         for (size_t ci = 0; ci < nch; ++ci) if (ch[ci].err) return fail(e, ch[ci].err, ch[ci].msg);      // (chunks are in file order: the first bad record's message)
@@ -808,6 +844,7 @@ static int push_reads_staged(brc_engine* e, const brc_read_batch* b, bool* touch
             if (past) return fail(e, BRC_E_ARG, kEmptyM);
             s.piece_cnt.p[r] = np;
             if ((uint64_t)(s.n_pieces += np) >= 0xFFFFFFF0ull) return fail(e, BRC_E_LIMIT, "more than 2^32 read segments in one region: split the region");
+            s.wide.p[r] = read_has_escape(b->qual + b->qual_off[i], b->seq4 + b->seq_off[i], lq) ? 1 : 0;
         }
     }
     s.n += (int64_t)n;

@@ -72,6 +72,13 @@ struct Staged {
     const uint8_t* qual_at(uint64_t off) const { return qual_seg.empty() ? qual.p + off : seg_at(qual_seg, off); }
     HBuf<uint64_t> bq_row;              // per read: first element of its 16-byte-aligned row in the device's event-byte stream
     uint64_t bq_elems = 0;              // total elements of the event-byte stream (sum of roundup16(l_qseq))
+    // the sparse wide stream (brc_core.h: DevIn.bqw): wide[i] != 0 when read i has a base its event byte cannot describe
+    // (read_has_escape at push: eb_make's predicate on the bytes the device will see) — only those reads get a wide row.
+    // wide_layout: one pair per such read, in file order — (the read, first16 + its wide row's start / 16: the table in front of the
+    // rows takes first16 units of 16 elements); returns the elements of all wide rows.
+    HBuf<uint8_t> wide;
+    struct WidePair { uint32_t read, w16; };
+    uint64_t wide_layout(std::vector<WidePair>& pairs, uint32_t first16) const;
     // KB v2: pieces (walk_pieces in brc_core.h).  piece_cnt is filled at push time; piece_off (library-major slot of a
     // read's first piece) and lib_base (first slot of every library's stream, Lp + 1 entries) at upload
     HBuf<char> qnames; HBuf<uint64_t> qname_off;   // read names when the caller gave them (warning text only); qname_off[i] = ~0 without

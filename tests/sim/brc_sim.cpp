@@ -23,7 +23,8 @@ static const HostAlloc kAlloc = {sim_alloc, sim_release};
 class SimBackend : public Backend {
     DevCfg c; DevIn in; std::string err;
     const Staged* st = nullptr;
-    std::vector<DRead> reads; std::vector<uint8_t> eb; std::vector<uint16_t> bqw; size_t bq_n = 0; std::vector<float> tq; std::vector<double> te;
+    std::vector<DRead> reads; std::vector<uint8_t> eb; std::vector<uint32_t> wbuf; size_t bq_n = 0;      // wbuf: the sparse wide stream, table then rows (DevIn.bqw)
+     std::vector<float> tq; std::vector<double> te;
     std::vector<Piece> hot; std::vector<PieceRare> rare; std::vector<int32_t> key, reach, prefmax;
     // the rare record of piece m: stored by K1 only when piece_has_rare(flags), derived from the piece otherwise
     PieceRare rare_of(uint32_t m) const { return piece_has_rare(piece_flags(hot[m])) ? rare[m] : piece_rare_of(c, hot[m]); }
@@ -102,7 +103,7 @@ class SimBackend : public Backend {
                     // a wide read's escape bytes: quality and bucket from the wide stream; an N / '=' base goes to the third-allele list
                     // whatever the slots hold
                     if ((fl & PF_WIDE) && eb_is_escape(w)) {
-                        const uint32_t w16 = bqw[h.bq_off + (uint64_t)qpos];
+                        const uint32_t w16 = in.bqw[wide_base(in.bqw, h.bq_off) + (uint64_t)qpos];
                         if (!bucket_acgt(w16 & 0xffu)) { a[l].ww += h.ww; full.lane[l] = true; any_full = true; continue; }
                         w = ((w16 >> 8) << 2) | ((w16 & 0xffu) - 1u);
                     }
@@ -131,7 +132,7 @@ class SimBackend : public Backend {
                     const int qpos = p[l] - h.a;
                     const uint32_t w = eb[h.bq_off + (uint64_t)qpos];
                     uint32_t q = w >> 2, b = (w & 3u) + 1u;
-                    if ((piece_flags(h) & PF_WIDE) && eb_is_escape(w)) { const uint32_t w16 = bqw[h.bq_off + (uint64_t)qpos]; q = w16 >> 8; b = w16 & 0xffu; }
+                    if ((piece_flags(h) & PF_WIDE) && eb_is_escape(w)) { const uint32_t w16 = in.bqw[wide_base(in.bqw, h.bq_off) + (uint64_t)qpos]; q = w16 >> 8; b = w16 & 0xffu; }
                     if (e.kind == 0) { const XEv x = make_xev(c, lib, kk[l], h, rr, qpos, q, b); const uint32_t at = (*pl.xev_n)++; if (at < pl.xev_cap) pl.xev[at] = x; }
                     else drain_int(c, pl, lib, kk[l], rr, b == a[l].dom_b ? 0u : 1u);
                 }
@@ -155,13 +156,23 @@ class SimBackend : public Backend {
         if (t) memset(t, 0, sizeof *t);
         const int64_t n = c.n_reads, P = c.P, PS = c.PS; const int Lp = c.Lp;
         const int64_t np = c.n_pieces;
-        reads.resize((size_t)n); eb.assign(bq_n + 1, 0); bqw.assign(bq_n + 1, 0xdeadu); in.eb = eb.data(); in.bqw = bqw.data();       // (wide words nobody wrote must not be read)
+        reads.resize((size_t)n); eb.assign(bq_n + 1, 0); in.eb = eb.data();
+        {   // table entries nobody set point far outside the rows; wide words nobody wrote must not be read
+            const size_t tab = (((bq_n >> 4) + 2) + 7) & ~(size_t)7;                  // u32 entries: a multiple of 16 elements
+            std::vector<Staged::WidePair> pairs; const uint64_t wq = st->wide_layout(pairs, (uint32_t)(tab / 8));
+            wbuf.assign(tab + (size_t)(wq / 2) + 8, 0xdeaddeadu);
+            for (size_t k = 0; k < tab; ++k) wbuf[k] = 0xffffffffu;
+            for (const Staged::WidePair& x : pairs) wbuf[(size_t)(st->bq_row.p[x.read] >> 4)] = x.w16;      // (a wide read has bases: no other read's row starts in its first chunk)
+            in.bqw = reinterpret_cast<const uint16_t*>(wbuf.data());
+        }
+        uint16_t* const bqw_w = const_cast<uint16_t*>(in.bqw);
         hot.assign((size_t)np + 1, Piece()); { PieceRare poison; memset(&poison, 0xff, sizeof poison); rare.assign((size_t)np + 1, poison); }   // (a rare record nobody wrote must not be read)
         key.assign((size_t)np + 1, 0); reach.assign((size_t)np + 1, 0); prefmax.assign((size_t)np + 1, 0);
         unavail.assign((size_t)PS, NONE32);
         for (int64_t i = 0; i < n; ++i) {                                                             // K1
             bool wide = false;
-            const DRead rd = reads[(size_t)i] = annotate_read(c, in, i, eb.data(), bqw.data(), wide);
+            const DRead rd = reads[(size_t)i] = annotate_read(c, in, i, eb.data(), bqw_w, wide);
+            if (wide != (st->wide.p[i] != 0)) { err = "the host's scan for escape bases and K1 differ"; return BRC_E_ARG; }
             const uint32_t* cg = in.cigar + in.cig_off[i];
             const bool nolib = c.per_lib && in.lib[i] < 0;
             const bool enters = read_enters(in.flag[i], cg, in.n_cigar[i]) && in.pos[i] >= 0;

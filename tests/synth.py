@@ -417,3 +417,26 @@ def eqx_cigars(arrs, seed=0, frac=0.8, keep_m=0.3):
     res = {k: v.copy() for k, v in arrs.items()}
     res["cigar"] = np.array(new_cig, np.uint32); res["cigar_off"] = new_off; res["n_cigar"] = new_nc
     return res
+
+
+def one_special_byte_per_read(arrs, rng):
+    """Three reads in four get ONE special byte (in place): a quality next to the event byte's range (0, 1, 62, 63, 64, 127, 128, 255), a
+    base code 0..15, or both at the same offset — any offset, the last base of the read one time in seven.  All other qualities are
+    clipped into 3..45.  Returns a lower bound of the reads that now hold an escape base."""
+    q = arrs["qual"].copy(); s4 = arrs["seq4"].copy()
+    q[:] = np.clip(q, 3, 45)
+    n_wide = 0
+    for r in range(len(arrs["pos"])):
+        L = int(arrs["l_qseq"][r]); kind = r % 4
+        if L == 0 or kind == 0:
+            continue
+        at = int(rng.integers(0, L)) if r % 7 else L - 1
+        if kind in (1, 3):
+            v = int(rng.choice([0, 1, 62, 63, 64, 127, 128, 255])); q[int(arrs["qual_off"][r]) + at] = v
+            n_wide += v == 0 or v >= 63
+        if kind in (2, 3):
+            code = int(rng.integers(0, 16)); b = int(arrs["seq_off"][r]) + at // 2
+            s4[b] = (s4[b] & 0x0f) | (code << 4) if at % 2 == 0 else (s4[b] & 0xf0) | code
+            n_wide += code not in (1, 2, 4, 8) and kind == 2
+    arrs["qual"] = q; arrs["seq4"] = s4
+    return n_wide

@@ -216,6 +216,24 @@ def test_hip_escape_bytes_and_the_wide_stream(dev_lib, oracle_lib, min_bq):
     parity.compare_libs(dev_lib, oracle_lib, arrs, [(0, 4000)], ref=None, min_bq=min_bq)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_reads", [1500, 9000])
+def test_hip_sparse_wide_stream_rows_of_exactly_the_reads_with_an_escape(dev_lib, oracle_lib, n_reads):
+    """The wide stream has rows only for the reads brc_push_reads found an escape base in (k_wide_rows writes them, K1 marks the
+    pieces PF_WIDE from its own look at the bases): one special byte per read at any offset — tests/test_sim_parity.py's case on the
+    device; a read the host missed would read words nobody wrote."""
+    rng = np.random.default_rng(97)
+    ref = synth.make_ref(rng, 3000)
+    arrs = synth.make_batch(197, ref, n_reads, style="simple", read_len=(1, 70), mismatch=0.02, p_iupac_read=0.0, p_q2tail=0.0)
+    assert synth.one_special_byte_per_read(arrs, rng) > n_reads // 8
+    parity.compare_libs(dev_lib, oracle_lib, arrs, [(0, 3000)], ref=ref, min_bq=0)
+    parity.compare_libs(dev_lib, oracle_lib, arrs, [(0, 3000)], ref=None, min_bq=20, insertion_centric=True)
+    names = ["libA", "libB", "libC"]
+    arrs3 = synth.make_batch(198, ref, n_reads, style="mixed", read_len=(1, 70), n_libs=3, p_iupac_read=0.0)
+    synth.one_special_byte_per_read(arrs3, rng)
+    parity.compare_libs(dev_lib, oracle_lib, arrs3, [(0, 3000), (1000, 1100)], ref=ref, min_bq=13, lib_names=names, per_lib=True)
+
+
 def shuffled_arenas(arrs, seed):
     """The same reads with their QUAL / SEQ / CIGAR rows laid out in a random order inside the arenas (legal: brc.h asks for
     offsets inside the arenas, not for increasing ones), with gaps between the rows."""

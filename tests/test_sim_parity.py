@@ -242,3 +242,23 @@ def test_empty_m_operators_are_piled_up_like_the_iterator_does(sim_lib, oracle_l
     for route in (dict(text_only=True), dict(device_text="chrS")):
         got, _ = parity.run_engine(sim_lib, arrs, [(0, 3000)], ref=ref, lib_names=names, **dict(opts, **route))
         assert got == want, route
+
+
+@pytest.mark.parametrize("n_reads", [1500, 9000])
+def test_host_scan_for_escape_bases_is_k1_s_predicate(sim_lib, oracle_lib, n_reads):
+    """The wide stream is sparse: only the reads brc_push_reads finds an escape base in (eight qualities / sixteen base codes
+    per step, tails byte by byte) get a wide row, and K1 must mark exactly those reads' pieces PF_WIDE — the CPU twin compares the two
+    for every read.  Reads of 1..70 bases with ONE special byte each: every quality next to the event byte's range (0, 1, 62, 63,
+    64, 127, 128, 255), every base code 0..15, at any offset — word boundaries, the last base of reads of odd length.  9000 reads:
+    the batch is staged by the pool (one thread below 8192 reads)."""
+    rng = np.random.default_rng(97)
+    ref = synth.make_ref(rng, 3000)
+    arrs = synth.make_batch(197, ref, n_reads, style="simple", read_len=(1, 70), mismatch=0.02, p_iupac_read=0.0, p_q2tail=0.0)
+    n_wide = synth.one_special_byte_per_read(arrs, rng)
+    assert n_wide > n_reads // 8
+    parity.compare_libs(sim_lib, oracle_lib, arrs, [(0, 3000)], ref=ref, min_bq=0)
+    parity.compare_libs(sim_lib, oracle_lib, arrs, [(0, 3000)], ref=None, min_bq=20, insertion_centric=True)
+    if n_reads < 8192:            # library-major rows (-p): wide reads of three libraries
+        arrs3 = synth.make_batch(198, ref, n_reads, style="mixed", read_len=(1, 70), n_libs=3, p_iupac_read=0.0)
+        synth.one_special_byte_per_read(arrs3, rng)
+        parity.compare_libs(sim_lib, oracle_lib, arrs3, [(0, 3000), (1000, 1100)], ref=ref, min_bq=13, lib_names=["libA", "libB", "libC"], per_lib=True)
