@@ -369,6 +369,12 @@ def main():
         eb_bytes = int(((Lq + 15) & ~15).sum())
         own = {"k_annotate": {"in": int(b_in + b_ref), "out": int(eb_bytes + 56 * n_seg + 64 * len(rpos))},
                "k_pileup": {"in": int(Lq.sum() + 48 * seg_tiles + region_len + 8 * ((region_len + 63) // 64) * res_libs), "out": 116 * int(eb_positions_padded(region_len)) * res_libs}}
+        if args.mode == "sites" and not os.environ.get("BRC_BENCH_NO_WINDOWS"):
+            # k_pileup2 piles up only the tiles the announced windows [site - 1, site] touch: per such tile the records of the reads over it
+            # (48 bytes each) and their event bytes inside the tile (at most 64), its reference codes and range; out: the tile's compact result
+            wt = np.unique(np.concatenate([(site_vbeg0.astype(np.int64) - 1).clip(min=0) >> 6, site_vbeg0.astype(np.int64) >> 6]))
+            over = np.searchsorted(rpos, (wt + 1) << 6, "left") - np.searchsorted(np.sort(rends), wt << 6, "right")
+            own["k_pileup"] = {"in": int((48 + 64) * int(over.clip(min=0).sum()) + (64 + 8 * res_libs) * len(wt)), "out": 116 * 64 * len(wt) * res_libs}
         traffic_json = args.traffic_json if os.path.exists(args.traffic_json) else None
         tj = None; traffic_src = None; kobj = capi.kernel_object_hash(hip.path)
         if traffic_json and args.mode != "sites" and world == 1:
