@@ -28,7 +28,7 @@ def test_whole_region_check_against_the_oracle_pool(sim_lib, oracle_lib, config,
     eng.begin_region(0, 0, n, ref); eng.push_reads(arrs); eng.upload(); eng.compute()
     ev, _ = eng.counts()
     out = fullcheck.check_region(pool, eng, parity, fullcheck.windows_of(0, n, 7), want_events=ev, with_text=text)
-    assert out["full_contig"] and out["events"] == ev and out["windows"] == 7 and out["text_byte_exact"] == text
+    assert out["full_contig"] and out["events"] == ev and out["windows"] == 7 and (out["text_byte_exact"] is True if text else ("text_byte_exact" not in out and "not formatted" in out["whole_region_text"]))
     assert (out["text_bytes"] > 0) == text
     eng.close()
 

@@ -161,7 +161,7 @@ def check_region(pool, eng, parity, windows, want_events=None, with_text=True):
     pile = sum(d["pileup_s"] for d in want.values()); text_s = sum(d["text_s"] for d in want.values())
     return {"full_contig": True, "windows": len(windows), "events": int(events), "lines": int(sum(d["lines"] for d in got.values())),
             "text_bytes": int(sum(d["text_bytes"] for d in got.values())), "indel_buckets": int(sum(d["n_indel"] for d in got.values())),
-            "planes_bit_exact": True, "text_byte_exact": bool(with_text), "digest": "xxh3_128 per window of ncol / depth / dense istat / dense fstat bits / indel list / text",
+            "planes_bit_exact": True, **({"text_byte_exact": True} if with_text else {"whole_region_text": "not formatted (planes, indel lists and event counts of every window are compared; the text of the prefix is: text_byte_exact)"}), "digest": "xxh3_128 per window of ncol / depth / dense istat / dense fstat bits / indel list / text",
             "text_digest_of_digests": h.hexdigest(), "seconds": round(wall, 2), "hip_side_seconds": round(t_hip, 2),
             "oracle_cpu_seconds": {"pileup": round(pile, 2), "text": round(text_s, 2), "select": round(sum(d["select_s"] for d in want.values()), 2),
                                    "digest": round(sum(d["digest_s"] for d in want.values()), 2)},
