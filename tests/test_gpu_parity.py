@@ -693,7 +693,7 @@ def test_hip_wave_form_operator_count_limits(dev_lib, oracle_lib):
     equal to the oracle.
     [sim]: the serial walk."""
     ref, arrs = synth.operator_limit_reads()
-    for opts in (dict(), dict(insertion_centric=True, min_bq=10)):
+    for opts in (dict(), dict(insertion_centric=True, min_bq=10))[:2 if dev_lib.kind().startswith("hip") else 1]:      # (the CPU twin: one pass)
         parity.compare_libs(dev_lib, oracle_lib, arrs, [(0, 40000), (900, 1100)], ref=ref, **opts)
 
 
@@ -704,8 +704,8 @@ def test_hip_reads_with_an_operator_every_few_bases(dev_lib, knob_lib, oracle_li
     brc_fetch_window / announced windows."""
     import synthgen
     hip = dev_lib.kind().startswith("hip")
-    n = 120_000 if hip else 72_000              # (the lane simulator walks every tile's whole piece range: a smaller region on CPUs)
-    hi = 90_000 if hip else 45_000
+    n = 120_000 if hip else 48_000              # (the lane simulator walks every tile's whole piece range: a smaller region on CPUs)
+    hi = 90_000 if hip else 36_000
     ref, arrs = synthgen.generate_dense(n, "ont", seed=11, n_chunks=2)
     assert float(arrs["n_cigar"].mean()) > 400
     opts = dict(min_mapq=20, min_bq=13)

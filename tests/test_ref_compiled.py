@@ -689,7 +689,7 @@ def _long_read_check(lib, ref_lib, seeds):
 
 
 def test_long_dense_indel_reads_equal_reference_compiled(sim_lib, ref_lib):
-    _long_read_check(sim_lib, ref_lib, range(2))
+    _long_read_check(sim_lib, ref_lib, range(1))
 
 
 @pytest.mark.gpu
