@@ -704,8 +704,8 @@ def test_hip_reads_with_an_operator_every_few_bases(dev_lib, knob_lib, oracle_li
     brc_fetch_window / announced windows."""
     import synthgen
     hip = dev_lib.kind().startswith("hip")
-    n = 120_000 if hip else 48_000              # (the lane simulator walks every tile's whole piece range: a smaller region on CPUs)
-    hi = 90_000 if hip else 36_000
+    n = 120_000 if hip else 60_000              # (the lane simulator walks every tile's whole piece range: a smaller region on CPUs)
+    hi = 90_000 if hip else 32_000
     ref, arrs = synthgen.generate_dense(n, "ont", seed=11, n_chunks=2)
     assert float(arrs["n_cigar"].mean()) > 400
     opts = dict(min_mapq=20, min_bq=13)
