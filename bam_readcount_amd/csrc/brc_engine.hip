@@ -1276,83 +1276,114 @@ __global__ __launch_bounds__(256) void k_count_piece_tiles(DevCfg c, const uint4
     if (k0 < 0) k0 = 0; if (k1 > c.P - 1) k1 = c.P - 1;
     for (int64_t t = k0 >> 6; t <= (k1 >> 6); ++t) atomicAdd(&cnt[t], 1u);
 }
+enum { CR_GROUP = 8 };       // consecutive tiles a wave of k_compact_reads takes: a read's binary search is paid once per group, a tile's run is a few steps behind the last one's
 __global__ __launch_bounds__(256) void k_compact_reads(DevCfg c, const uint4* __restrict__ pieces4, const PieceRare* __restrict__ rare, const uint2* __restrict__ rng,
                                                         const uint32_t* __restrict__ piece_off, const int2* __restrict__ keyreach, int64_t ntiles, const uint32_t* __restrict__ cmp_off,
                                                         uint4* __restrict__ out4, PieceRare* __restrict__ out_rare, uint2* __restrict__ out_rng, unsigned long long* __restrict__ totals) {
     const int lane = threadIdx.x & 63;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= ntiles) return;
-    const uint2 r = rng[tile];
-    // (the region's last tile ends with the region: k_count_piece_tiles does not count a piece that starts behind the last position)
-    const int64_t p0 = (int64_t)c.pos0 + tile * TILE, p1 = p0 + TILE < (int64_t)c.pos0 + c.P ? p0 + TILE : (int64_t)c.pos0 + c.P;
-    const uint32_t first = cmp_off[tile], limit = cmp_off[tile + 1];
-    uint32_t run = first; bool over = false;       // over: more live pieces than the tile's block holds (never: the host fails the call if it happens)
+    const int64_t tile0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * CR_GROUP;
+    if (tile0 >= ntiles) return;
+    const int ng = (int)(ntiles - tile0 < CR_GROUP ? ntiles - tile0 : CR_GROUP);
     __shared__ uint32_t src_all[4][64];
+    __shared__ uint32_t run_all[4][CR_GROUP];
     uint32_t* const src = src_all[threadIdx.x >> 6];
-    if (r.x < r.y) {
+    uint32_t* const runs = run_all[threadIdx.x >> 6];
+    // the group's tiles: their ranges of the stream (k_tiles_all / k_narrow_tiles) and their blocks of the compacted stream
+    uint2 r_me = make_uint2(0u, 0u);
+    if (lane < ng) { r_me = rng[tile0 + lane]; runs[lane] = cmp_off[tile0 + lane]; }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const bool some = lane < ng && r_me.x < r_me.y;
+    uint32_t gx = some ? r_me.x : 0xffffffffu, gy = some ? r_me.y : 0u;
+#pragma unroll
+    for (int d = 1; d < CR_GROUP; d <<= 1) { const uint32_t ox = (uint32_t)__shfl_xor((int)gx, d, 64), oy = (uint32_t)__shfl_xor((int)gy, d, 64); gx = ox < gx ? ox : gx; gy = oy > gy ? oy : gy; }
+    gx = (uint32_t)__builtin_amdgcn_readfirstlane((int)gx); gy = (uint32_t)__builtin_amdgcn_readfirstlane((int)gy);
+    bool over = false;       // over: more live pieces than a tile's block holds (never: the host fails the call if it happens)
+    if (gx < gy) {
         const uint32_t n = (uint32_t)c.n_reads;
-        // reads whose slots start at or before r.x (64-ary search: piece_off[] is non-decreasing); the last of them holds slot r.x
+        // reads whose slots start at or before gx (64-ary search: piece_off[] is non-decreasing); the last of them holds slot gx
         uint32_t lo_i = 0u, len = n;
         while (len > 0u) {
             const uint32_t stride = (len + 63u) >> 6;
             uint32_t idx = lo_i + ((uint32_t)lane + 1u) * stride - 1u; const uint32_t last = lo_i + len - 1u;
             if (idx > last) idx = last;
-            const uint32_t k = (uint32_t)__builtin_popcountll(__ballot(piece_off[idx] <= r.x));
+            const uint32_t k = (uint32_t)__builtin_popcountll(__ballot(piece_off[idx] <= gx));
             const uint32_t nlo = lo_i + k * stride;
             if (k == 64u || nlo > last) { lo_i = last + 1u; break; }
             const uint32_t nlen = (stride < last + 1u - nlo ? stride : last + 1u - nlo);
-            lo_i = nlo; len = nlen - 1u;                                  // (the last element of block k is above r.x)
+            lo_i = nlo; len = nlen - 1u;                                  // (the last element of block k is above gx)
         }
         const uint32_t r_first = lo_i > 0u ? lo_i - 1u : 0u;
         for (uint32_t rb = r_first; rb < n; rb += 64u) {
             const uint32_t rd = rb + (uint32_t)lane;
-            uint32_t a0 = 0u, b = 0u;
-            if (rd < n) { a0 = piece_off[rd]; b = rd + 1u < n ? piece_off[rd + 1u] : (uint32_t)c.n_pieces; }
-            const bool inside = rd < n && a0 < r.y;
-            if (!__ballot(inside)) break;
-            uint32_t a = a0 < r.x ? r.x : a0; if (b > r.y) b = r.y;
-            uint32_t m = a, nlive = 0u;
-            if (inside && a < b) {
-                // first slot of [a, b) whose extent ends behind p0
-                uint32_t lo = a, hi = b;
-                while (lo < hi) {
-                    const uint32_t mid = lo + ((hi - lo) >> 1);
-                    if ((int64_t)keyreach[mid].y > p0) hi = mid; else lo = mid + 1u;
+            uint32_t a0 = 0u, b0 = 0u;
+            if (rd < n) { a0 = piece_off[rd]; b0 = rd + 1u < n ? piece_off[rd + 1u] : (uint32_t)c.n_pieces; }
+            if (!__ballot(rd < n && a0 < gy)) break;
+            uint32_t cur = 0u; bool searched = false;          // cur: every slot of the read before it ends at or before the current tile's first position
+            for (int g = 0; g < ng; ++g) {
+                const int64_t tile = tile0 + g;
+                const uint2 r = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)r_me.x, g), (uint32_t)__builtin_amdgcn_readlane((int)r_me.y, g));
+                if (r.x >= r.y) continue;
+                // (the region's last tile ends with the region: k_count_piece_tiles does not count a piece that starts behind the last position)
+                const int64_t p0 = (int64_t)c.pos0 + tile * TILE, p1 = p0 + TILE < (int64_t)c.pos0 + c.P ? p0 + TILE : (int64_t)c.pos0 + c.P;
+                const bool inside = rd < n && a0 < r.y;
+                if (!__ballot(inside)) continue;
+                const uint32_t a = a0 < r.x ? r.x : a0, b = b0 > r.y ? r.y : b0;
+                uint32_t m = a, nlive = 0u;
+                if (inside && a < b) {
+                    if (!searched) {
+                        // first slot of [a, b) whose extent ends behind p0
+                        uint32_t lo = a, hi = b;
+                        while (lo < hi) {
+                            const uint32_t mid = lo + ((hi - lo) >> 1);
+                            if ((int64_t)keyreach[mid].y > p0) hi = mid; else lo = mid + 1u;
+                        }
+                        cur = lo; searched = true;
+                    } else {
+                        if (cur < a) cur = a;
+                        while (cur < b && (int64_t)keyreach[cur].y <= p0) ++cur;
+                    }
+                    m = cur < b ? cur : b;
+                    if (m < b) {
+                        // its start: the read's position for the read's first slot, the end of the slot before it otherwise
+                        int64_t rs = m == a0 ? (int64_t)keyreach[m].x : (int64_t)keyreach[m - 1u].y;
+                        for (uint32_t q = m; q < b && rs < p1; ++q) { ++nlive; rs = (int64_t)keyreach[q].y; }
+                    }
                 }
-                m = lo;
-                if (m < b) {
-                    // its start: the read's position for the read's first slot, the end of the slot before it otherwise
-                    int64_t rs = m == a0 ? (int64_t)keyreach[m].x : (int64_t)keyreach[m - 1u].y;
-                    for (uint32_t q = m; q < b && rs < p1; ++q) { ++nlive; rs = (int64_t)keyreach[q].y; }
-                }
-            }
-            uint32_t incl = nlive;
+                uint32_t incl = nlive;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
-            // copy: consecutive lanes take consecutive OUTPUT slots (64 records = 3 KB of contiguous stores per round; the sources are
-            // runs of a read's consecutive slots) — the owners publish the source slot of every output of the round through LDS
-            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63), excl = incl - nlive;
-            for (uint32_t j0 = 0u; j0 < total; j0 += 64u) {
-                for (uint32_t i = 0u; i < nlive; ++i) { const uint32_t o = excl + i - j0; if (o < 64u) src[o] = m + i; }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                const uint32_t at = run + j0 + (uint32_t)lane;
-                if (j0 + (uint32_t)lane < total && at < limit) {            // (limit: the tile's block, sized by k_count_piece_tiles from the same extents)
-                    const uint32_t q = src[lane];
-                    const uint4 h0 = pieces4[(size_t)q * 3u];
-                    out4[(size_t)at * 3u] = h0; out4[(size_t)at * 3u + 1u] = pieces4[(size_t)q * 3u + 1u]; out4[(size_t)at * 3u + 2u] = pieces4[(size_t)q * 3u + 2u];
-                    if (piece_has_rare(h0.w >> 24)) out_rare[at] = rare[q];
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+                // copy: consecutive lanes take consecutive OUTPUT slots (64 records = 3 KB of contiguous stores per round; the sources are
+                // runs of a read's consecutive slots) — the owners publish the source slot of every output of the round through LDS
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63), excl = incl - nlive;
+                if (!total) continue;
+                const uint32_t limit = cmp_off[tile + 1];                 // (the tile's block, sized by k_count_piece_tiles from the same extents)
+                uint32_t run = runs[g];
+                for (uint32_t j0 = 0u; j0 < total; j0 += 64u) {
+                    for (uint32_t i = 0u; i < nlive; ++i) { const uint32_t o = excl + i - j0; if (o < 64u) src[o] = m + i; }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    const uint32_t at = run + j0 + (uint32_t)lane;
+                    if (j0 + (uint32_t)lane < total && at < limit) {
+                        const uint32_t q = src[lane];
+                        const uint4 h0 = pieces4[(size_t)q * 3u];
+                        out4[(size_t)at * 3u] = h0; out4[(size_t)at * 3u + 1u] = pieces4[(size_t)q * 3u + 1u]; out4[(size_t)at * 3u + 2u] = pieces4[(size_t)q * 3u + 2u];
+                        if (piece_has_rare(h0.w >> 24)) out_rare[at] = rare[q];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 }
+                run += total;
+                if (run > limit) { over = true; run = limit; }
+                if (lane == 0) runs[g] = run;
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             }
-            run += total;
-            if (run > limit) { over = true; run = limit; }
         }
     }
-    if (lane == 0) {
-        out_rng[tile] = make_uint2(first, run);
-        atomicAdd(&totals[0], (unsigned long long)(r.y - r.x)); atomicAdd(&totals[1], (unsigned long long)(run - first));
-        if (over) atomicAdd(&totals[2], 1ull);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (lane < ng) {
+        const uint32_t first = cmp_off[tile0 + lane];
+        out_rng[tile0 + lane] = make_uint2(first, runs[lane]);
+        atomicAdd(&totals[0], (unsigned long long)(r_me.x < r_me.y ? r_me.y - r_me.x : 0u)); atomicAdd(&totals[1], (unsigned long long)(runs[lane] - first));
     }
+    if (lane == 0 && over) atomicAdd(&totals[2], 1ull);
 }
 
 // ---------------------------------------------------------------- KB: pileup + BasicStat accumulation (the hot kernel)
@@ -2632,7 +2663,7 @@ class HipBackend : public Backend {
                 HIPCHK(d_cpieces.ensure(((size_t)compact_total + 4) * sizeof(Piece))); HIPCHK(d_crare.ensure(((size_t)compact_total + 2) * sizeof(PieceRare)));
             }
             if (by_read)
-                hipLaunchKernelGGL(k_compact_reads, cg, dim3(256), 0, stream, c, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p, (const uint2*)d_rng.p, (const uint32_t*)d_pieceoff.p, (const int2*)d_keyreach.p, ntiles,
+                hipLaunchKernelGGL(k_compact_reads, dim3((unsigned)((ntiles + 4 * CR_GROUP - 1) / (4 * CR_GROUP))), dim3(256), 0, stream, c, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p, (const uint2*)d_rng.p, (const uint32_t*)d_pieceoff.p, (const int2*)d_keyreach.p, ntiles,
                                    (const uint32_t*)d_coff.p, (uint4*)d_cpieces.p, (PieceRare*)d_crare.p, (uint2*)d_crng.p, (unsigned long long*)d_ctot.p);
             else
             hipLaunchKernelGGL((k_compact_tiles<false>), cg, dim3(256), 0, stream, c, (const uint4*)d_pieces.p, (const PieceRare*)d_rare.p, (const uint2*)d_rng.p, ntiles,
