@@ -450,6 +450,41 @@ def test_hip_announced_windows_equal_the_whole_region(dev_lib, case):
     eng.close()
 
 
+@pytest.mark.gpu
+def test_hip_announced_windows_on_a_compacted_region(hip_lib, oracle_lib):
+    """The site-list planner's windows over reads with an operator every few bases: k_narrow_tiles cuts every wanted tile's range to its
+    wanted lanes (a tile's range may then START behind its neighbour's), k_compact_reads takes eight consecutive tiles per wave and
+    carries a read's position from one tile to the next.  Every window prints what the whole region prints for it, and what the oracle
+    prints for a region of its own over the same reads."""
+    import synthgen
+    ref, arrs = synthgen.generate_dense(60_000, "ont", seed=23, n_chunks=2)
+    opts = dict(min_mapq=20, min_bq=13)
+    rng = np.random.default_rng(5)
+    starts = np.sort(rng.integers(600, 59_000, 70))
+    wins = [(int(b), int(b) + int(rng.choice([1, 1, 1, 2, 30, 64, 200]))) for b in starts] + [(30_000, 30_001), (30_000, 30_001), (30_063, 30_066), (30_064, 30_065), (30_127, 30_129)]
+    eng = capi.Engine(hip_lib, **opts)
+
+    def run(hint):
+        eng.begin_region(0, 0, 60_000, ref); eng.push_reads(arrs)
+        if hint:
+            eng.region_windows(np.array([w[0] for w in wins], np.int32), np.array([w[1] for w in wins], np.int32))
+        res = eng.end_region()
+        assert eng.piece_steps()[0] > 0                       # the region was compacted
+        return [eng.format_window("chrS", b, e, 0) for b, e in wins], res.ncol.copy()
+
+    want, ncol_all = run(False)
+    got, ncol_hint = run(True)
+    assert got == want and sum(len(t) > 0 for t in want) > len(want) * 3 // 4
+    assert int(ncol_hint.sum()) < int(ncol_all.sum()) // 2
+    ends = capi.read_ends(arrs)
+    for b, e in wins[::9]:
+        o = capi.Engine(oracle_lib, **opts)
+        o.begin_region(0, b, e, ref); o.push_reads(capi.select_reads(arrs, capi.fetch_overlapping(arrs, ends, b - 1, e))); o.end_region()
+        assert o.format_region("chrS") == want[wins.index((b, e))], (b, e)
+        o.close()
+    eng.close()
+
+
 def test_hip_region_windows_argument_handling(dev_lib):
     """brc_region_windows: only inside an open region, windows must not end before they begin, windows outside the planes are
     clipped away, n = 0 withdraws the hint."""
