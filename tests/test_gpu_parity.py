@@ -325,6 +325,24 @@ def test_hip_wgs_sample_equals_oracle_and_full_size_properties(dev_lib, oracle_l
     eng.close()
 
 
+def test_hip_every_read_has_a_wide_row(dev_lib, oracle_lib):
+    """HiFi-like qualities on the config-3 and config-5 data models: base qualities up to 93, so that nearly every read has a base the
+    event byte cannot describe — every read gets a row in the sparse wide stream (k_wide_rows), every piece is PF_WIDE, and the lanes
+    take quality and bucket from the words.  Planes, indel buckets and all three text routes against the oracle."""
+    import synthgen
+    hip = dev_lib.kind().startswith("hip")
+    n = 400_000 if hip else 60_000
+    for config, kw in (("wgs30x", dict(min_mapq=20, min_bq=13)), ("tumor200x", dict(per_lib=True, insertion_centric=True, lib_names=["libA", "libB", "libC", "libD"], min_bq=70))):
+        m = n if config == "wgs30x" else n // 8
+        ref, arrs = synthgen.generate(m, config, seed=17, n_chunks=4)
+        q = arrs["qual"].astype(np.int32) + 52; q[::7] = 0; q[3::11] = 63; arrs["qual"] = np.minimum(q, 93).astype(np.uint8)
+        regions = [(0, m), (m // 2, m // 2 + 1)]
+        text, _ = parity.compare_libs(dev_lib, oracle_lib, arrs, regions, ref=ref, **kw)
+        for route in (dict(text_only=True), dict(device_text="chrS")):
+            got, _ = parity.run_engine(dev_lib, arrs, regions, ref=ref, **route, **kw)
+            assert got == text
+
+
 def test_hip_text_only_engine_prints_the_same(dev_lib, oracle_lib):
     """BRC_OPT_TEXT_ONLY (the command line's setting): the formatter reads the compact device result directly."""
     import synthgen
