@@ -609,20 +609,56 @@ __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m) { return __bui
 // reads have none, and for a read without operators K1 writes nothing at all (no record, no pieces, no indel slots, no event bytes).
 // (wave_list: the reads of the four-wave instantiation from the front, those of the one-wave instantiation from the back, list_cap - 1 downwards;
 // those of the one-wave-per-CU instantiation in a second list behind it, from list_cap + 16 on)
-// The sparse wide stream (DevIn.bqw), ONE WAVE PER READ the host found an escape base in (Staged::wide_layout: the read, where its wide
-// row starts in units of 16 elements): the table entry of the chunk its byte row starts with, then the words quality << 8 | bucket of
-// all its bases.  K1 — whatever its form — only marks such a read's pieces PF_WIDE.
-__global__ __launch_bounds__(256) void k_wide_rows(DevCfg c, DevIn in, const uint2* __restrict__ pairs, uint32_t n, uint16_t* __restrict__ bqw) {
-    const uint32_t w = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
-    if (w >= n) return;
-    const uint2 p = pairs[w];
-    const int64_t i = (int64_t)p.x;
-    const int32_t L = in.l_qseq[i];
-    if (lane == 0u) *BRC_CK(c, CK_ANNOTATE, 51, CB_BQW, reinterpret_cast<uint32_t*>(bqw) + (in.bq_row[i] >> 4), 4, i, -1) = p.y;
-    const uint8_t* const qual = BRC_CK(c, CK_ANNOTATE, 52, CB_QUAL, in.qual + in.qual_off[i], (uint64_t)L, i, -1);
-    const uint8_t* const seq = BRC_CK(c, CK_ANNOTATE, 53, CB_SEQ, in.seq4 + in.seq_off[i], (uint64_t)((L + 1) / 2), i, -1);
-    uint16_t* const row = BRC_CK(c, CK_ANNOTATE, 54, CB_BQW, bqw + ((uint64_t)p.y << 4), 2ull * (uint64_t)L, i, -1);
-    for (int32_t j = (int32_t)lane; j < L; j += 64) row[j] = (uint16_t)(((uint32_t)qual[j] << 8) | canon_bucket(seqi(seq, j)));
+// The sparse wide stream (DevIn.bqw) of the reads the host found an escape base in (Staged::wide_layout: the read, where its wide row
+// starts in units of 16 elements — ascending in the list): the table entry of the chunk a read's byte row starts with, then the words
+// quality << 8 | bucket of all its bases.  K1 — whatever its form — only marks such a read's pieces PF_WIDE.  A wave takes 64
+// consecutive reads of the list and walks THEIR ROWS' 16-element chunks, a lane per chunk (short reads — every read of a run with
+// qualities above 62 — fill the lanes like long ones; a wave per read took 3.5 ms for ten million 150-base reads): the chunk's owner by
+// a search over the lanes' row starts, 16 qualities and 8 bytes of base codes in, two 16-byte stores out.
+__global__ __launch_bounds__(256) void k_wide_rows(DevCfg c, DevIn in, const uint2* __restrict__ pairs, uint32_t n, uint16_t* __restrict__ bqw) {      // gridDim.y: waves that share a group's chunks (long reads)
+    struct Par { uint32_t w16, L; uint64_t qoff, soff; };
+    __shared__ Par par_all[4][64];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t first = (blockIdx.x * 4u + wv) * 64u;
+    if (first >= n) return;
+    Par* const par = par_all[wv];
+    const uint32_t nr = n - first < 64u ? n - first : 64u;
+    uint32_t w16_me = 0xffffffffu, cnt_me = 0u;
+    if (lane < nr) {
+        const uint2 p = pairs[first + lane];
+        const int64_t i = (int64_t)p.x;
+        const int32_t L = in.l_qseq[i];
+        if (blockIdx.y == 0) *BRC_CK(c, CK_ANNOTATE, 51, CB_BQW, reinterpret_cast<uint32_t*>(bqw) + (in.bq_row[i] >> 4), 4, i, -1) = p.y;
+        Par q; q.w16 = p.y; q.L = (uint32_t)L; q.qoff = in.qual_off[i]; q.soff = in.seq_off[i];
+        par[lane] = q;
+        w16_me = p.y; cnt_me = ((uint32_t)L + 15u) >> 4;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w16_me);
+    const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)(w16_me + cnt_me), (int)(nr - 1u));      // (rows follow each other in list order)
+    for (uint32_t cb = c0 + 64u * blockIdx.y; cb < c1; cb += 64u * gridDim.y) {
+        const uint32_t ch = cb + lane;
+        uint32_t idx = 0u;                                   // the last lane whose row starts at or before the chunk (every lane takes part in the shuffles: a lane that has left reads as 0)
+#pragma unroll
+        for (uint32_t st = 32u; st; st >>= 1) { const uint32_t cand = idx + st; const uint32_t v = (uint32_t)__shfl((int)w16_me, (int)(cand & 63u), 64); if (cand < 64u && v <= ch) idx = cand; }
+        if (ch >= c1) continue;
+        const Par q = par[idx];
+        const uint32_t j0 = (ch - q.w16) << 4;
+        if (j0 >= q.L) continue;
+        uint4 Q; uint2 S;
+        __builtin_memcpy(&Q, BRC_CK(c, CK_ANNOTATE, 52, CB_QUAL, in.qual + q.qoff + j0, 16, (int64_t)pairs[first + idx].x, (int32_t)j0), 16);       // (the arenas are padded by 16 bytes: a row's last chunk may read past its read)
+        __builtin_memcpy(&S, BRC_CK(c, CK_ANNOTATE, 53, CB_SEQ, in.seq4 + q.soff + (j0 >> 1), 8, (int64_t)pairs[first + idx].x, (int32_t)j0), 8);
+        const uint32_t qd[4] = {Q.x, Q.y, Q.z, Q.w}; const uint32_t sd[2] = {S.x, S.y};
+        uint32_t out[8];
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) {
+            const uint32_t sb = (sd[k >> 3] >> (((k >> 1) & 3) << 3)) & 0xffu;           // the byte with bases k (high nibble) and k + 1
+            const uint32_t q0 = (qd[k >> 2] >> ((k & 3) << 3)) & 0xffu, q1 = (qd[(k + 1) >> 2] >> (((k + 1) & 3) << 3)) & 0xffu;
+            out[k >> 1] = ((q0 << 8) | canon_bucket(sb >> 4)) | (((q1 << 8) | canon_bucket(sb & 15u)) << 16);
+        }
+        uint4* const dst = reinterpret_cast<uint4*>(BRC_CK(c, CK_ANNOTATE, 54, CB_BQW, bqw + ((uint64_t)ch << 4), 32, (int64_t)pairs[first + idx].x, (int32_t)j0));
+        dst[0] = make_uint4(out[0], out[1], out[2], out[3]); dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_pick_wave(DevCfg c, DevIn in, uint32_t* __restrict__ n_cigar_k1, uint32_t* __restrict__ wave_list, uint32_t list_cap,
@@ -2204,7 +2240,7 @@ class HipBackend : public Backend {
     // device buffers
     DBuf d_pos, d_flag, d_mapq, d_lib, d_lq, d_nc, d_co, d_so, d_qo, d_nm, d_sm, d_tags, d_cigar, d_seq, d_qual, d_ref, d_refcode;
     std::vector<uint16_t> h_wanted; bool has_wanted = false; DBuf d_wanted; std::vector<uint32_t> h_tilelist; DBuf d_tilelist;      // brc_region_windows (kept alive for the asynchronous copy)
-    std::vector<Staged::WidePair> h_wpairs;
+    std::vector<Staged::WidePair> h_wpairs; unsigned wide_slices = 1;
     DBuf d_wpairs;
     DBuf d_bq, d_bqw, d_bqrow, d_pieceoff, d_pieces, d_rare, d_keyreach, d_libbase, d_reads, d_agg, d_rng, d_ncol, d_depth, d_slotid, d_si, d_sf, d_xev, d_xevc, d_xevn, d_unavail, d_cnt, d_cursor, d_ev, d_evraw, d_ievoff, d_iout, d_ctr, d_tilectr, d_part, d_wavelist, d_nc_k1;
     DBuf d_tlen, d_toff, d_text, d_tctx, d_total64, d_lastproc;
@@ -2405,6 +2441,10 @@ class HipBackend : public Backend {
             if (s.bq_elems >> 34) { err = "region too large: 2^34 bases and more"; return BRC_E_LIMIT; }      // (k_pileup2 reaches a table entry through a 32-bit byte offset)
             const size_t tab_bytes = ((((size_t)(s.bq_elems >> 4) + 2) * 4) + 255) & ~(size_t)255;
             const uint64_t wq_elems = s.wide_layout(h_wpairs, (uint32_t)(tab_bytes / 32));
+            {   // k_wide_rows: a wave per 64 listed reads and slice of their rows' chunks — 512 chunks (eight rounds) per wave and more
+                const uint64_t groups = (h_wpairs.size() + 63) / 64, per_group = groups ? (wq_elems >> 4) / groups : 0;
+                wide_slices = (unsigned)std::min<uint64_t>(std::max<uint64_t>(per_group / 512, 1), 64);
+            }
             if ((tab_bytes / 32 + (wq_elems >> 4)) >> 32) { err = "region too large: 2^36 bases of reads with escape bases"; return BRC_E_LIMIT; }
             HIPCHK(d_bqw.ensure(tab_bytes + ((size_t)wq_elems + 16) * sizeof(uint16_t)));
             in.bqw = (const uint16_t*)d_bqw.p;
@@ -2529,7 +2569,7 @@ class HipBackend : public Backend {
             if (c.has_ref)
                 hipLaunchKernelGGL(k_refcode, dim3((unsigned)(((rl + 2 * REFCODE_PAD + 15) / 16 + 255) / 256)), dim3(256), 0, stream, in.ref, (uint8_t*)d_refcode.p, rl);
             if (!h_wpairs.empty())        // the wide rows of the reads the host found an escape base in
-                hipLaunchKernelGGL(k_wide_rows, dim3((unsigned)((h_wpairs.size() + 3) / 4)), dim3(256), 0, stream, c, in, (const uint2*)d_wpairs.p, (uint32_t)h_wpairs.size(), (uint16_t*)in.bqw);
+                hipLaunchKernelGGL(k_wide_rows, dim3((unsigned)((h_wpairs.size() + 255) / 256), wide_slices), dim3(256), 0, stream, c, in, (const uint2*)d_wpairs.p, (uint32_t)h_wpairs.size(), (uint16_t*)in.bqw);
             DevIn in_k1 = in;
             if (wave_on || cursor_on) {   // reads with more than two M operators: listed for k_annotate_wave, without operators in K1's copy of the counts (reads with an empty M / = / X operator: for k_annotate_cursor)
                 hipLaunchKernelGGL(k_pick_wave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (uint32_t*)d_nc_k1.p, (uint32_t*)d_wavelist.p, (uint32_t)n, &ctr->n_wave_reads, &ctr->n_wave_big, &ctr->n_wave_huge,

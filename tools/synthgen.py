@@ -133,6 +133,15 @@ CONFIGS = {
 }
 
 
+def _hifi_qualities(a):
+    """BRC_SYNTH_QUAL_SHIFT=n (measurements only): every base quality raised by n, capped at 93 — PacBio-HiFi-like values, above the 62 an
+    event byte holds: every read then has a row in the wide stream and every lane takes the escape path."""
+    sh = int(os.environ.get("BRC_SYNTH_QUAL_SHIFT", "0") or 0)
+    if sh:
+        a["qual"] = np.minimum(a["qual"].astype(np.int32) + sh, 93).astype(np.uint8)
+    return a
+
+
 def generate(contig_len, config="wgs30x", seed=1, n_chunks=64):
     """Returns (ref uint8[contig_len], arrays dict in brc_read_batch layout)."""
     cfg = CONFIGS[config]
@@ -155,7 +164,7 @@ def generate(contig_len, config="wgs30x", seed=1, n_chunks=64):
     rc = lib().synth_reads(C.byref(p), ref.ctypes.data_as(C.c_void_p), *[a[k].ctypes.data_as(C.c_void_p) for k in order])
     if rc != 0:
         raise RuntimeError("synth_reads failed: %d" % rc)
-    return ref, a
+    return ref, _hifi_qualities(a)
 
 
 # reads with an operator every ~15 bases (ONT / CLR-like alignments): 3-10 kb, 30x — the regime the tile compaction exists for
@@ -192,7 +201,7 @@ def generate_dense(contig_len, config="ont", seed=1, n_chunks=64):
     off = np.concatenate([[0], np.cumsum(nc)])
     idx = np.repeat(np.arange(n, dtype=np.int64) * stride, nc) + (np.arange(int(off[-1]), dtype=np.int64) - np.repeat(off[:-1], nc))
     a["cigar"] = a["cigar"][idx].copy(); a["cigar_off"] = off[:-1].astype(np.uint64)
-    return ref, a
+    return ref, _hifi_qualities(a)
 
 
 def algorithmic_bytes(arrs, n_positions, n_libs_printed, n_indel_buckets=0, ref_positions=None):
