@@ -2240,7 +2240,7 @@ class HipBackend : public Backend {
     // device buffers
     DBuf d_pos, d_flag, d_mapq, d_lib, d_lq, d_nc, d_co, d_so, d_qo, d_nm, d_sm, d_tags, d_cigar, d_seq, d_qual, d_ref, d_refcode;
     std::vector<uint16_t> h_wanted; bool has_wanted = false; DBuf d_wanted; std::vector<uint32_t> h_tilelist; DBuf d_tilelist;      // brc_region_windows (kept alive for the asynchronous copy)
-    std::vector<Staged::WidePair> h_wpairs; unsigned wide_slices = 1;
+    HBuf<Staged::WidePair> h_wpairs; unsigned wide_slices = 1;      // (page-locked: the list is every read of a run with HiFi qualities)
     DBuf d_wpairs;
     DBuf d_bq, d_bqw, d_bqrow, d_pieceoff, d_pieces, d_rare, d_keyreach, d_libbase, d_reads, d_agg, d_rng, d_ncol, d_depth, d_slotid, d_si, d_sf, d_xev, d_xevc, d_xevn, d_unavail, d_cnt, d_cursor, d_ev, d_evraw, d_ievoff, d_iout, d_ctr, d_tilectr, d_part, d_wavelist, d_nc_k1;
     DBuf d_tlen, d_toff, d_text, d_tctx, d_total64, d_lastproc;
@@ -2336,7 +2336,7 @@ class HipBackend : public Backend {
         for (int i = 0; i < 2; ++i) { HIPCHK(hipEventCreateWithFlags(&ev_text[i], hipEventDisableTiming)); h_text[i].A = &kPinned; h_toff[i].A = &kPinned; }
         HIPCHK(hipEventCreateWithFlags(&ev_lines, hipEventDisableTiming));
         h_total.A = &kPinned;
-        h_ncol.A = h_depth.A = h_slotid.A = h_si.A = h_unavail.A = &kPinned; h_sf.A = &kPinned; h_iout.A = &kPinned; h_xagg.A = &kPinned; h_lastproc[0].A = h_lastproc[1].A = &kPinned;
+        h_ncol.A = h_depth.A = h_slotid.A = h_si.A = h_unavail.A = &kPinned; h_sf.A = &kPinned; h_iout.A = &kPinned; h_xagg.A = &kPinned; h_wpairs.A = &kPinned; h_lastproc[0].A = h_lastproc[1].A = &kPinned;
         return BRC_OK;
     }
     ~HipBackend() override {
@@ -2356,7 +2356,7 @@ class HipBackend : public Backend {
         if (stream2) (void)hipStreamDestroy(stream2);
         if (stream3) (void)hipStreamDestroy(stream3);
         d_agg2.release();
-        h_ncol.destroy(); h_depth.destroy(); h_slotid.destroy(); h_si.destroy(); h_unavail.destroy(); h_sf.destroy(); h_iout.destroy(); h_xagg.destroy(); h_lastproc[0].destroy(); h_lastproc[1].destroy();
+        h_ncol.destroy(); h_depth.destroy(); h_slotid.destroy(); h_si.destroy(); h_unavail.destroy(); h_sf.destroy(); h_iout.destroy(); h_xagg.destroy(); h_wpairs.destroy(); h_lastproc[0].destroy(); h_lastproc[1].destroy();
         if (w_init) { w_ncol.destroy(); w_depth.destroy(); w_slotid.destroy(); w_si.destroy(); w_unavail.destroy(); w_sf.destroy(); }
         for (EvSet& es : evsets) { for (int i = 0; i <= T_N; ++i) if (es.evt[i]) (void)hipEventDestroy(es.evt[i]); for (int i = 0; i < 4; ++i) if (es.ev_indel[i]) (void)hipEventDestroy(es.ev_indel[i]); }
         if (stream) (void)hipStreamDestroy(stream);
@@ -2440,9 +2440,11 @@ class HipBackend : public Backend {
         {   // the sparse wide stream: [table: one u32 per 16 elements of the byte stream][rows of the wide reads] (brc_core.h: DevIn.bqw)
             if (s.bq_elems >> 34) { err = "region too large: 2^34 bases and more"; return BRC_E_LIMIT; }      // (k_pileup2 reaches a table entry through a 32-bit byte offset)
             const size_t tab_bytes = ((((size_t)(s.bq_elems >> 4) + 2) * 4) + 255) & ~(size_t)255;
-            const uint64_t wq_elems = s.wide_layout(h_wpairs, (uint32_t)(tab_bytes / 32));
+            h_wpairs.clear();
+            { const size_t nw = s.n_wide(); if (!h_wpairs.reserve(nw + 1)) { err = "host allocation failed (wide-stream list)"; return BRC_E_NOMEM; } h_wpairs.n = nw; }
+            const uint64_t wq_elems = s.wide_layout(h_wpairs.p, (uint32_t)(tab_bytes / 32));
             {   // k_wide_rows: a wave per 64 listed reads and slice of their rows' chunks — 512 chunks (eight rounds) per wave and more
-                const uint64_t groups = (h_wpairs.size() + 63) / 64, per_group = groups ? (wq_elems >> 4) / groups : 0;
+                const uint64_t groups = (h_wpairs.n + 63) / 64, per_group = groups ? (wq_elems >> 4) / groups : 0;
                 wide_slices = (unsigned)std::min<uint64_t>(std::max<uint64_t>(per_group / 512, 1), 64);
             }
             if ((tab_bytes / 32 + (wq_elems >> 4)) >> 32) { err = "region too large: 2^36 bases of reads with escape bases"; return BRC_E_LIMIT; }
@@ -2451,9 +2453,9 @@ class HipBackend : public Backend {
 #ifdef BRC_CHECKED
             HIPCHK(hipMemsetAsync(d_bqw.p, 0xff, tab_bytes, stream));        // (an entry nobody set points far outside the stream)
 #endif
-            if (!h_wpairs.empty()) {
-                HIPCHK(d_wpairs.ensure(h_wpairs.size() * sizeof(Staged::WidePair)));
-                HIPCHK(hipMemcpyAsync(d_wpairs.p, h_wpairs.data(), h_wpairs.size() * sizeof(Staged::WidePair), hipMemcpyHostToDevice, stream));
+            if (h_wpairs.n) {
+                HIPCHK(d_wpairs.ensure(h_wpairs.n * sizeof(Staged::WidePair)));
+                HIPCHK(hipMemcpyAsync(d_wpairs.p, h_wpairs.p, h_wpairs.n * sizeof(Staged::WidePair), hipMemcpyHostToDevice, stream));
             }
         }
         in.eb = (const uint8_t*)d_bq.p + BQ_PAD;
@@ -2568,8 +2570,8 @@ class HipBackend : public Backend {
             const int64_t rl = c.ref_hi - c.ref_lo;
             if (c.has_ref)
                 hipLaunchKernelGGL(k_refcode, dim3((unsigned)(((rl + 2 * REFCODE_PAD + 15) / 16 + 255) / 256)), dim3(256), 0, stream, in.ref, (uint8_t*)d_refcode.p, rl);
-            if (!h_wpairs.empty())        // the wide rows of the reads the host found an escape base in
-                hipLaunchKernelGGL(k_wide_rows, dim3((unsigned)((h_wpairs.size() + 255) / 256), wide_slices), dim3(256), 0, stream, c, in, (const uint2*)d_wpairs.p, (uint32_t)h_wpairs.size(), (uint16_t*)in.bqw);
+            if (h_wpairs.n)        // the wide rows of the reads the host found an escape base in
+                hipLaunchKernelGGL(k_wide_rows, dim3((unsigned)((h_wpairs.n + 255) / 256), wide_slices), dim3(256), 0, stream, c, in, (const uint2*)d_wpairs.p, (uint32_t)h_wpairs.n, (uint16_t*)in.bqw);
             DevIn in_k1 = in;
             if (wave_on || cursor_on) {   // reads with more than two M operators: listed for k_annotate_wave, without operators in K1's copy of the counts (reads with an empty M / = / X operator: for k_annotate_cursor)
                 hipLaunchKernelGGL(k_pick_wave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c, in, (uint32_t*)d_nc_k1.p, (uint32_t*)d_wavelist.p, (uint32_t)n, &ctr->n_wave_reads, &ctr->n_wave_big, &ctr->n_wave_huge,

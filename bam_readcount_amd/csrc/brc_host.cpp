@@ -159,12 +159,11 @@ void Staged::layout_pieces(int Lp, bool per_lib) {
         for (int64_t i = 0; i < n; ++i) { const size_t k = slot(i); bq_row.p[i] = rows[k]; rows[k] += ((uint64_t)l_qseq.p[i] + 15u) & ~(uint64_t)15u; }
     }
 }
-uint64_t Staged::wide_layout(std::vector<WidePair>& pairs, uint32_t first16) const {
-    pairs.clear();
-    uint64_t w = 0;
+uint64_t Staged::wide_layout(WidePair* pairs, uint32_t first16) const {
+    uint64_t w = 0; size_t k = 0;
     for (int64_t i = 0; i < n; ++i) if (wide.p[i]) {
-        WidePair x; x.read = (uint32_t)i; x.w16 = first16 + (uint32_t)(w >> 4);
-        pairs.push_back(x); w += ((uint64_t)l_qseq.p[i] + 15u) & ~(uint64_t)15u;
+        if (pairs) { WidePair x; x.read = (uint32_t)i; x.w16 = first16 + (uint32_t)(w >> 4); pairs[k++] = x; }
+        w += ((uint64_t)l_qseq.p[i] + 15u) & ~(uint64_t)15u;
     }
     return w;
 }

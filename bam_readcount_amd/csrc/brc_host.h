@@ -78,7 +78,8 @@ struct Staged {
     // rows takes first16 units of 16 elements); returns the elements of all wide rows.
     HBuf<uint8_t> wide;
     struct WidePair { uint32_t read, w16; };
-    uint64_t wide_layout(std::vector<WidePair>& pairs, uint32_t first16) const;
+    uint64_t wide_layout(WidePair* pairs /* n_wide() of them; nullptr: only the sum */, uint32_t first16) const;
+    size_t n_wide() const { size_t k = 0; for (int64_t i = 0; i < n; ++i) k += wide.p[i] != 0; return k; }
     // KB v2: pieces (walk_pieces in brc_core.h).  piece_cnt is filled at push time; piece_off (library-major slot of a
     // read's first piece) and lib_base (first slot of every library's stream, Lp + 1 entries) at upload
     HBuf<char> qnames; HBuf<uint64_t> qname_off;   // read names when the caller gave them (warning text only); qname_off[i] = ~0 without

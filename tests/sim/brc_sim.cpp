@@ -159,7 +159,7 @@ class SimBackend : public Backend {
         reads.resize((size_t)n); eb.assign(bq_n + 1, 0); in.eb = eb.data();
         {   // table entries nobody set point far outside the rows; wide words nobody wrote must not be read
             const size_t tab = (((bq_n >> 4) + 2) + 7) & ~(size_t)7;                  // u32 entries: a multiple of 16 elements
-            std::vector<Staged::WidePair> pairs; const uint64_t wq = st->wide_layout(pairs, (uint32_t)(tab / 8));
+            std::vector<Staged::WidePair> pairs(st->n_wide()); const uint64_t wq = st->wide_layout(pairs.data(), (uint32_t)(tab / 8));
             wbuf.assign(tab + (size_t)(wq / 2) + 8, 0xdeaddeadu);
             for (size_t k = 0; k < tab; ++k) wbuf[k] = 0xffffffffu;
             for (const Staged::WidePair& x : pairs) wbuf[(size_t)(st->bq_row.p[x.read] >> 4)] = x.w16;      // (a wide read has bases: no other read's row starts in its first chunk)
